@@ -1,0 +1,84 @@
+"""ctypes binding of libclairsto_amd.so (the C ABI declared in include/clairsto_amd.h).
+
+The library is the product: there is no Python/CPU fallback.  Importing this module loads it and fails
+loudly when it has not been built (`python -c "import __graft_entry__ as g; g.build()"` or
+`make -C clairs_to_amd/csrc`).  torch is imported first so that the process ends up with ONE HIP runtime:
+torch's bundled libamdhip64.so and /opt/rocm's share the SONAME libamdhip64.so.7, so the copy torch loaded
+is the one our library binds to and torch streams / device pointers are valid inside it.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the dlopen, see above)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libclairsto_amd.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "clairs_to_amd: %s is missing - build the HIP extension first (__graft_entry__.build() or "
+        "`make -C clairs_to_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+c_i64 = C.c_int64
+c_i32 = C.c_int32
+c_vp = C.c_void_p
+
+
+class PackView(C.Structure):
+    _fields_ = [("n_cols", c_i64), ("n_entries", c_i64), ("n_keys", c_i64),
+                ("col_pos", c_vp), ("col_ref", c_vp), ("col_off", c_vp), ("key_off", c_vp),
+                ("entries", c_vp), ("key_meta", c_vp)]
+
+
+class CvtCfg(C.Structure):
+    _fields_ = [("emb_dim", C.c_int * 3), ("heads", C.c_int * 3), ("depth", C.c_int * 3), ("n_out", C.c_int)]
+
+
+# every symbol include/clairsto_amd.h declares: (restype, argtypes)
+SYMBOLS = {
+    "cto_last_error": (C.c_char_p, []),
+    "cto_version": (C.c_int, []),
+    "cto_device_count": (C.c_int, []),
+    "cto_pack_from_mpileup": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, c_i64, C.c_size_t, C.c_int, C.POINTER(c_vp)]),
+    "cto_pack_from_arrays": (C.c_int, [C.POINTER(PackView), c_vp, c_vp, C.POINTER(c_vp)]),
+    "cto_pack_view_of": (C.c_int, [c_vp, C.POINTER(PackView)]),
+    "cto_pack_key_string": (C.c_int, [c_vp, c_i64, C.POINTER(C.c_char_p)]),
+    "cto_pack_free": (None, [c_vp]),
+    "cto_featurize_columns": (C.c_int, [C.POINTER(PackView), C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "cto_gather_windows": (C.c_int, [C.POINTER(PackView), c_vp, c_vp, c_vp, c_i64, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "cto_alt_info": (C.c_int, [c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, C.c_char_p, C.c_size_t]),
+    "cto_weights_new": (c_vp, []),
+    "cto_weights_add": (C.c_int, [c_vp, C.c_char_p, c_vp, c_i64]),
+    "cto_weights_free": (None, [c_vp]),
+    "cto_cvt_create": (C.c_int, [c_vp, C.POINTER(CvtCfg), C.POINTER(c_vp)]),
+    "cto_bigru_create": (C.c_int, [c_vp, C.c_int, C.POINTER(c_vp)]),
+    "cto_model_forward": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "cto_model_macs_per_site": (c_i64, [c_vp]),
+    "cto_model_n_out": (C.c_int, [c_vp]),
+    "cto_model_destroy": (None, [c_vp]),
+    "cto_posterior": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "cto_posterior_from_probs": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+}
+
+for _name, (_res, _args) in SYMBOLS.items():
+    _fn = getattr(lib, _name)   # AttributeError here = the built library is stale; rebuild it
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class CtoError(RuntimeError):
+    pass
+
+
+def check(rc):
+    """Raise CtoError for a negative return code of the C ABI."""
+    if rc is not None and rc < 0:
+        raise CtoError("clairsto_amd error %d: %s" % (rc, lib.cto_last_error().decode()))
+    return rc
+
+
+def current_stream_ptr():
+    """hipStream_t of torch's current stream on the current device, as an integer for the void* argument."""
+    return int(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,269 @@
+// Pileup featurisation kernels for gfx950 (HBM-bound integer work; no MFMA).
+//
+// Stage A  k_featurize_columns : column pack -> one 34-channel count vector per column, for the
+//          AFF pass (BQ >= min_bq) and the NEG pass (all read-bases) in a single sweep of the entries.
+//          Restates decode_pileup_bases (src/create_tensor_pileup_calling.py:146-228 of the reference):
+//          three counters (MQ>=20 / MQ<20 / BQ<30), indel channels with per-distinct-key maxima,
+//          reference-channel negation.
+// Stage B  k_gather_windows    : 33 consecutive positions per candidate -> [33][34] tensors (+ coverage
+//          rescale of clairs/predict.py:179-195 and the strand counts of predict.py:626-642).
+//
+// Layout: one wavefront (64 lanes) owns COLS_PER_WAVE consecutive columns, i.e. one contiguous run of
+// entries, which it streams with coalesced 256-byte loads; counts are accumulated in LDS with the AFF
+// and NEG counters packed in one 32-bit word (low/high 16 bits), then finalised and written back as one
+// contiguous, coalesced block of COLS_PER_WAVE*144 bytes.
+#include "common.h"
+
+namespace {
+
+constexpr int COLS_PER_WAVE = 16;
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int HSLOTS = 36;       // 34 channels + slot 34 = depth + 1 spare
+constexpr int INT_NONE = 0x7fffffff;
+
+struct PackDev {
+    int64_t n_cols;
+    const int32_t* col_pos;
+    const uint8_t* col_ref;
+    const int64_t* col_off;
+    const int32_t* key_off;
+    const uint32_t* entries;
+    const uint8_t* key_meta;
+};
+
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_featurize_columns(
+    PackDev pk, int min_bq, int16_t* __restrict__ colvec, int32_t* __restrict__ coldepth,
+    int32_t* __restrict__ colfirst, uint32_t* __restrict__ keycnt, int32_t* __restrict__ keyfirst) {
+    __shared__ uint32_t s_hist[WAVES_PER_BLOCK][COLS_PER_WAVE][HSLOTS];
+    __shared__ int32_t s_first[WAVES_PER_BLOCK][COLS_PER_WAVE][4];
+    __shared__ int64_t s_off[WAVES_PER_BLOCK][COLS_PER_WAVE + 1];
+    __shared__ int16_t s_out[WAVES_PER_BLOCK][COLS_PER_WAVE][CTO_COLVEC_STRIDE];
+
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int64_t c0 = (int64_t(blockIdx.x) * WAVES_PER_BLOCK + w) * COLS_PER_WAVE;
+    int ncol = 0;
+    if (c0 < pk.n_cols) ncol = int(pk.n_cols - c0 < COLS_PER_WAVE ? pk.n_cols - c0 : COLS_PER_WAVE);
+
+    for (int i = lane; i < COLS_PER_WAVE * HSLOTS; i += 64) (&s_hist[w][0][0])[i] = 0u;
+    if (lane < COLS_PER_WAVE * 4) (&s_first[w][0][0])[lane] = INT_NONE;
+    if (lane <= COLS_PER_WAVE) s_off[w][lane] = (ncol > 0) ? pk.col_off[c0 + (lane < ncol ? lane : ncol)] : 0;
+    __syncthreads();
+
+    if (ncol > 0) {
+        const int64_t e_begin = s_off[w][0];
+        const int64_t e_end = s_off[w][ncol];
+        int cl = 0;
+        for (int64_t e = e_begin + lane; e < e_end; e += 64) {
+            const uint32_t ent = pk.entries[e];
+            while (e >= s_off[w][cl + 1]) ++cl;
+            const int idx = int(e - s_off[w][cl]);
+            const uint32_t b = ent & 15u;
+            const uint32_t kind = (ent >> 4) & 3u;
+            const int bq = int((ent >> 6) & 127u);
+            const int mq = int((ent >> 13) & 255u);
+            const uint32_t kid = ent >> 21;
+            const bool pass = bq >= min_bq;
+            const uint32_t inc = (pass ? 1u : 0u) | 0x10000u;
+            const bool acgt = b < 8u;
+            const bool fwd = (b < 4u) || b == 8u || b == 10u;
+            const bool mq_ok = mq >= 20;
+            uint32_t* h = s_hist[w][cl];
+            if (kind == 0u) {
+                if (mq_ok) {
+                    int ch = -1;
+                    if (acgt) ch = (b < 4u) ? int(b) : int(b) + 5;       // A..T -> 0..3, a..t -> 9..12
+                    else if (b == 8u) ch = 8;                               // '*'
+                    else if (b == 9u) ch = 17;                              // '#'
+                    if (ch >= 0) {
+                        atomicAdd(&h[ch], inc);
+                        atomicAdd(&h[34], inc);                             // depth
+                        if (acgt && pass) atomicMin(&s_first[w][cl][b & 3u], idx);
+                    }
+                } else if (acgt) {
+                    atomicAdd(&h[18 + int(b)], inc);                        // {ACGTacgt}LMQ
+                }
+                if (acgt && bq < 30) atomicAdd(&h[26 + int(b)], inc);       // {ACGTacgt}LBQ (threshold is always 30, F3)
+            } else if (kind != 3u && mq_ok) {
+                const int ch = (kind == 1u) ? (fwd ? 4 : 13) : (fwd ? 6 : 15);
+                atomicAdd(&h[ch], inc);
+                atomicAdd(&h[34], inc);
+                const int64_t k = int64_t(pk.key_off[c0 + cl]) + kid;
+                atomicAdd(&keycnt[k], inc);
+                if (pass) atomicMin(&keyfirst[k], idx);
+            }
+        }
+    }
+    // make the global key counters of this wave's columns visible to its own finalisation reads
+    __threadfence();
+    __syncthreads();
+
+    if (lane < ncol) {
+        const int64_t c = c0 + lane;
+        const int ref = pk.col_ref[c];
+        const uint32_t* h = s_hist[w][lane];
+        const int32_t k0 = pk.key_off[c], k1 = pk.key_off[c + 1];
+        // per-distinct-key maxima -> I1 / i1 / D1 / d1 (F4, F6)
+        uint32_t mx[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};   // [pass][ins fwd, ins rev, del fwd, del rev]
+        for (int32_t k = k0; k < k1; ++k) {
+            const uint32_t cnt = __hip_atomic_load(&keycnt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t meta = pk.key_meta[k];
+            const int slot = (((meta & 3u) == 2u) ? 2 : 0) + ((meta & 4u) ? 0 : 1);
+            const uint32_t a = cnt & 0xffffu, n = cnt >> 16;
+            mx[0][slot] = a > mx[0][slot] ? a : mx[0][slot];
+            mx[1][slot] = n > mx[1][slot] ? n : mx[1][slot];
+        }
+        for (int p = 0; p < 2; ++p) {
+            int v[HSLOTS];
+#pragma unroll
+            for (int i = 0; i < 34; ++i) v[i] = int(p == 0 ? (h[i] & 0xffffu) : (h[i] >> 16));
+            v[34] = 0; v[35] = 0;
+            v[5] = int(mx[p][0]);   // I1
+            v[14] = int(mx[p][1]);  // i1
+            v[7] = int(mx[p][2]);   // D1
+            v[16] = int(mx[p][3]);  // d1
+            // reference-channel negation over the six 4-base groups (create_tensor_pileup_calling.py:223-228)
+            const int g0[6] = {0, 9, 18, 22, 26, 30};
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                const int s = v[g0[g]] + v[g0[g] + 1] + v[g0[g] + 2] + v[g0[g] + 3];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i == ref) v[g0[g] + i] = -s;
+            }
+#pragma unroll
+            for (int i = 0; i < HSLOTS; ++i) s_out[w][lane][p * HSLOTS + i] = int16_t(v[i]);
+            coldepth[c * 2 + p] = int(p == 0 ? (h[34] & 0xffffu) : (h[34] >> 16));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) colfirst[c * 4 + i] = s_first[w][lane][i];
+    }
+    __syncthreads();
+    // coalesced write-back: ncol * 144 contiguous bytes per wave, 16 B per lane per pass
+    if (ncol > 0) {
+        const uint4* src = reinterpret_cast<const uint4*>(&s_out[w][0][0]);
+        uint4* dst = reinterpret_cast<uint4*>(colvec + c0 * CTO_COLVEC_STRIDE);
+        const int n16 = ncol * (CTO_COLVEC_STRIDE * 2 / 16);
+        for (int i = lane; i < n16; i += 64) dst[i] = src[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gather_windows(
+    PackDev pk, const int16_t* __restrict__ colvec, const int32_t* __restrict__ coldepth,
+    const int32_t* __restrict__ site_pos, int64_t n_sites, int min_rescale_cov,
+    float* __restrict__ x_aff, float* __restrict__ x_neg, int16_t* __restrict__ raw_aff,
+    int16_t* __restrict__ raw_neg, int32_t* __restrict__ site_info) {
+    __shared__ int64_t s_col[CTO_NPOS];
+    __shared__ double s_scale[2];
+    __shared__ int s_skip;
+    const int64_t site = blockIdx.x;
+    if (site >= n_sites) return;
+    const int pos = site_pos[site];
+    const int tid = threadIdx.x;
+    if (tid < CTO_NPOS) {
+        const int p = pos - CTO_FLANK + tid;
+        // lower_bound over the strictly increasing column positions
+        int64_t lo = 0, hi = pk.n_cols;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (pk.col_pos[mid] < p) lo = mid + 1; else hi = mid;
+        }
+        s_col[tid] = (lo < pk.n_cols && pk.col_pos[lo] == p) ? lo : -1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int64_t cc = s_col[CTO_FLANK];
+        const bool skip = (cc < 0) || (pos - CTO_FLANK < 1);
+        int da = 0, dn = 0;
+        int info[12];
+        for (int i = 0; i < 12; ++i) info[i] = 0;
+        if (cc >= 0) {
+            da = coldepth[cc * 2 + 0];
+            dn = coldepth[cc * 2 + 1];
+            const int16_t* cv = colvec + cc * CTO_COLVEC_STRIDE;
+            // predict.py:626-642: the negative (reference) entry becomes -(row sum) = the true ref count
+            for (int s = 0; s < 2; ++s) {
+                const int o = s == 0 ? 0 : 9;
+                int sum = 0;
+                for (int i = 0; i < 4; ++i) sum += cv[o + i];
+                for (int i = 0; i < 4; ++i) info[4 + s * 4 + i] = cv[o + i] < 0 ? -sum : cv[o + i];
+            }
+        }
+        info[0] = int(cc);  // low 32 bits are enough for the per-batch packs; full index is re-derived by callers
+        info[1] = da;
+        info[2] = dn;
+        info[3] = skip ? 1 : 0;
+        for (int i = 0; i < 12; ++i) site_info[site * 12 + i] = info[i];
+        s_scale[0] = (min_rescale_cov > 0 && da > min_rescale_cov) ? double(min_rescale_cov) / double(da) : 1.0;
+        s_scale[1] = (min_rescale_cov > 0 && dn > min_rescale_cov) ? double(min_rescale_cov) / double(dn) : 1.0;
+        s_skip = skip ? 1 : 0;
+    }
+    __syncthreads();
+    const bool skip = s_skip != 0;
+    const double sa = s_scale[0], sn = s_scale[1];
+    const int64_t base = site * (CTO_NPOS * CTO_NCHAN);
+    for (int i = tid; i < CTO_NPOS * CTO_NCHAN; i += 256) {
+        const int p = i / CTO_NCHAN, ch = i - p * CTO_NCHAN;
+        const int64_t c = s_col[p];
+        int va = 0, vn = 0;
+        if (c >= 0 && !skip) {
+            va = colvec[c * CTO_COLVEC_STRIDE + ch];
+            vn = colvec[c * CTO_COLVEC_STRIDE + HSLOTS + ch];
+        }
+        if (x_aff) x_aff[base + i] = float(double(va) * sa);
+        if (x_neg) x_neg[base + i] = float(double(vn) * sn);
+        if (raw_aff) raw_aff[base + i] = int16_t(va);
+        if (raw_neg) raw_neg[base + i] = int16_t(vn);
+    }
+}
+
+PackDev to_dev(const cto_pack_view* v) {
+    PackDev d;
+    d.n_cols = v->n_cols;
+    d.col_pos = v->col_pos;
+    d.col_ref = v->col_ref;
+    d.col_off = v->col_off;
+    d.key_off = v->key_off;
+    d.entries = v->entries;
+    d.key_meta = v->key_meta;
+    return d;
+}
+
+}  // namespace
+
+extern "C" int cto_featurize_columns(const cto_pack_view* dp, int min_bq, int16_t* colvec, int32_t* coldepth,
+                                      int32_t* colfirst, uint32_t* keycnt, int32_t* keyfirst, void* stream) {
+    CTO_REQUIRE(dp && colvec && coldepth && colfirst, CTO_EINVAL, "cto_featurize_columns: null argument");
+    CTO_REQUIRE(dp->n_keys == 0 || (keycnt && keyfirst), CTO_EINVAL, "cto_featurize_columns: key buffers missing");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dp->n_keys > 0) {
+        CTO_HIP(hipMemsetAsync(keycnt, 0, size_t(dp->n_keys) * 4, s));
+        CTO_HIP(hipMemsetAsync(keyfirst, 0x7f, size_t(dp->n_keys) * 4, s));   // 0x7f7f7f7f: > any entry index
+    }
+    if (dp->n_cols == 0) return CTO_OK;
+    const int64_t per_block = COLS_PER_WAVE * WAVES_PER_BLOCK;
+    const unsigned grid = unsigned(cto::cdiv(dp->n_cols, per_block));
+    hipLaunchKernelGGL(k_featurize_columns, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, to_dev(dp), min_bq,
+                       colvec, coldepth, colfirst, keycnt, keyfirst);
+    CTO_HIP(hipGetLastError());
+    return CTO_OK;
+}
+
+extern "C" int cto_gather_windows(const cto_pack_view* dp, const int16_t* colvec, const int32_t* coldepth,
+                                   const int32_t* site_pos, int64_t n_sites, int min_rescale_cov,
+                                   float* x_aff, float* x_neg, int16_t* raw_aff, int16_t* raw_neg,
+                                   int32_t* site_info, void* stream) {
+    CTO_REQUIRE(dp && colvec && coldepth && site_pos && site_info, CTO_EINVAL, "cto_gather_windows: null argument");
+    if (n_sites == 0) return CTO_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_gather_windows, dim3(unsigned(n_sites)), dim3(256), 0, s, to_dev(dp), colvec, coldepth,
+                       site_pos, n_sites, min_rescale_cov, x_aff, x_neg, raw_aff, raw_neg, site_info);
+    CTO_HIP(hipGetLastError());
+    return CTO_OK;
+}
+
+extern "C" int cto_device_count(void) {
+    int n = 0;
+    CTO_HIP(hipGetDeviceCount(&n));
+    return n;
+}

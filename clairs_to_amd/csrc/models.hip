@@ -1,0 +1,448 @@
+// Host side of the two networks: weight hand-over by state_dict name, packing into the layouts the
+// kernels consume, and the launch sequences of the eval-mode forward passes.
+//   CvT / CvT_Indel            clairs/model.py:150-384   (AFF network)
+//   BiGRU_NACGT / .._Indel     clairs/model.py:387-560   (NEG network; the `lstm*` attributes are nn.GRU)
+#include <cmath>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+#include "common.h"
+#include "nn_kernels.h"
+
+using namespace cto;
+
+struct cto_weights {
+    std::map<std::string, std::vector<float>> t;
+};
+
+extern "C" cto_weights* cto_weights_new(void) { return new cto_weights(); }
+extern "C" void cto_weights_free(cto_weights* w) { delete w; }
+extern "C" int cto_weights_add(cto_weights* w, const char* name, const float* data, int64_t numel) {
+    CTO_REQUIRE(w && name && data && numel >= 0, CTO_EINVAL, "cto_weights_add: bad argument");
+    w->t[name].assign(data, data + numel);
+    return CTO_OK;
+}
+
+namespace {
+
+struct Arena {
+    std::vector<void*> ptrs;
+    ~Arena() { for (void* p : ptrs) (void)hipFree(p); }
+    int alloc(void** out, size_t bytes) {
+        CTO_HIP(hipMalloc(out, bytes ? bytes : 16));
+        ptrs.push_back(*out);
+        return CTO_OK;
+    }
+    int upload(const std::vector<float>& v, float** out) {
+        void* p = nullptr;
+        int rc = alloc(&p, v.size() * sizeof(float));
+        if (rc != CTO_OK) return rc;
+        CTO_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+        *out = static_cast<float*>(p);
+        return CTO_OK;
+    }
+};
+
+struct HeadDev {          // fc1 -> SELU -> K x (fc2 -> SELU -> fc3 -> SELU)
+    float *w1 = nullptr, *b1 = nullptr;   // [128][K1]
+    float *w2 = nullptr, *b2 = nullptr;   // [K*128][128]
+    float *w3 = nullptr, *b3 = nullptr;   // [K][2][128]
+    int k1 = 0;
+};
+
+struct BlockDev {
+    float *n0g, *n0b, *dwq, *bnq, *wq, *dwkv, *bnkv, *wkv, *wo, *bo, *n1g, *n1b, *w1, *b1, *w2, *b2;
+};
+
+struct StageDev {
+    int cin, c, win, w, wkv, heads, inner;
+    float *wemb, *bemb, *lng, *lnb;
+    std::vector<BlockDev> blocks;
+};
+
+}  // namespace
+
+struct cto_model {
+    int kind = 0;      // 0 = CvT, 1 = BiGRU
+    int n_out = 4;
+    Arena arena;
+    // CvT
+    StageDev st[3];
+    // BiGRU
+    float *gw1 = nullptr, *gb1 = nullptr, *gw2 = nullptr, *gb2 = nullptr;
+    HeadDev head;
+    int64_t macs = 0;
+    // workspace
+    int64_t ws_B = 0;
+    std::vector<void*> ws_ptrs;
+    float *b_h = nullptr, *b_t = nullptr, *b_yq = nullptr, *b_ykv = nullptr, *b_q = nullptr, *b_kv = nullptr,
+          *b_o = nullptr, *b_u = nullptr, *b_g = nullptr, *b_u2 = nullptr, *b_slab = nullptr;
+    ~cto_model() { for (void* p : ws_ptrs) (void)hipFree(p); }
+};
+
+namespace {
+
+const std::vector<float>* find(const cto_weights* w, const std::string& name, int64_t numel, int* rc) {
+    auto it = w->t.find(name);
+    if (it == w->t.end()) { set_error("weight '%s' missing", name.c_str()); *rc = CTO_EMISSING; return nullptr; }
+    if (int64_t(it->second.size()) != numel) {
+        set_error("weight '%s' has %zu elements, expected %lld", name.c_str(), it->second.size(), (long long)numel);
+        *rc = CTO_EMISSING;
+        return nullptr;
+    }
+    return &it->second;
+}
+
+#define GETW(var, name, numel)                                   \
+    const std::vector<float>* var = find(w, (name), (numel), &rc); \
+    if (!var) return rc;
+
+int build_head(const cto_weights* w, const char* const* names, int K, int k1, const std::vector<float>& w1perm,
+               Arena& a, HeadDev& h) {
+    int rc = CTO_OK;
+    h.k1 = k1;
+    GETW(b1, "fc1.bias", 128);
+    if ((rc = a.upload(w1perm, &h.w1)) != CTO_OK) return rc;
+    if ((rc = a.upload(*b1, &h.b1)) != CTO_OK) return rc;
+    std::vector<float> w2(size_t(K) * 128 * 128), b2(size_t(K) * 128), w3(size_t(K) * 2 * 128), b3(size_t(K) * 2);
+    for (int k = 0; k < K; ++k) {
+        const std::string p = names[k];
+        GETW(f2w, p + "_fc2.weight", 128 * 128);
+        GETW(f2b, p + "_fc2.bias", 128);
+        GETW(f3w, p + "_fc3.weight", 2 * 128);
+        GETW(f3b, p + "_fc3.bias", 2);
+        std::copy(f2w->begin(), f2w->end(), w2.begin() + size_t(k) * 128 * 128);
+        std::copy(f2b->begin(), f2b->end(), b2.begin() + size_t(k) * 128);
+        std::copy(f3w->begin(), f3w->end(), w3.begin() + size_t(k) * 256);
+        std::copy(f3b->begin(), f3b->end(), b3.begin() + size_t(k) * 2);
+    }
+    if ((rc = a.upload(w2, &h.w2)) != CTO_OK) return rc;
+    if ((rc = a.upload(b2, &h.b2)) != CTO_OK) return rc;
+    if ((rc = a.upload(w3, &h.w3)) != CTO_OK) return rc;
+    if ((rc = a.upload(b3, &h.b3)) != CTO_OK) return rc;
+    return CTO_OK;
+}
+
+int pack_bn(const cto_weights* w, const std::string& p, int C, Arena& a, float** out) {
+    int rc = CTO_OK;
+    GETW(wt, p + ".weight", C);
+    GETW(bs, p + ".bias", C);
+    GETW(mu, p + ".running_mean", C);
+    GETW(var, p + ".running_var", C);
+    std::vector<float> v(size_t(4) * C);
+    for (int c = 0; c < C; ++c) {
+        v[size_t(c)] = (*mu)[size_t(c)];
+        v[size_t(C + c)] = float(1.0 / std::sqrt(double((*var)[size_t(c)]) + 1e-5));   // BatchNorm2d eps (eval)
+        v[size_t(2 * C + c)] = (*wt)[size_t(c)];
+        v[size_t(3 * C + c)] = (*bs)[size_t(c)];
+    }
+    return a.upload(v, out);
+}
+
+int pack_dw(const cto_weights* w, const std::string& name, int C, Arena& a, float** out) {
+    int rc = CTO_OK;
+    GETW(k, name, int64_t(C) * 9);
+    std::vector<float> v(size_t(C) * 3);
+    for (int c = 0; c < C; ++c)
+        for (int t = 0; t < 3; ++t) v[size_t(c * 3 + t)] = (*k)[size_t((c * 3 + 1) * 3 + t)];   // middle kernel row
+    return a.upload(v, out);
+}
+
+int upload_named(const cto_weights* w, const std::string& name, int64_t numel, Arena& a, float** out) {
+    int rc = CTO_OK;
+    GETW(v, name, numel);
+    return a.upload(*v, out);
+}
+
+// ---------------------------------------------------------------- launch helpers
+int launch_gemm(hipStream_t s, const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                const float* R, int64_t ldr, float* C, int64_t ldc, int M, int N, int K, int act,
+                int conv_win = 0, int conv_wout = 0, int conv_cin = 0, int splitk = 1, int64_t slab = 0) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.R = R; g.ldr = ldr; g.C = C; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.act = act;
+    g.conv_win = conv_win; g.conv_wout = conv_wout; g.conv_cin = conv_cin;
+    g.kslice = splitk > 1 ? int(cdiv(cdiv(K, splitk), 16) * 16) : K;
+    g.slab = slab;
+    g.vecA = (conv_wout == 0 && (lda % 4) == 0 && (K % 4) == 0 && (reinterpret_cast<uintptr_t>(A) % 16) == 0) ? 1 : 0;
+    if (M <= 0) return CTO_OK;
+    if (N <= 16) {
+        dim3 grid(unsigned(cdiv(M, 128)), unsigned(cdiv(N, 16)), unsigned(splitk));
+        hipLaunchKernelGGL((k_gemm<4, 1, 2, 1>), grid, dim3(256), 0, s, g);
+    } else if (N <= 64) {
+        dim3 grid(unsigned(cdiv(M, 64)), unsigned(cdiv(N, 64)), unsigned(splitk));
+        hipLaunchKernelGGL((k_gemm<2, 2, 2, 2>), grid, dim3(256), 0, s, g);
+    } else {
+        dim3 grid(unsigned(cdiv(M, 64)), unsigned(cdiv(N, 128)), unsigned(splitk));
+        hipLaunchKernelGGL((k_gemm<2, 2, 2, 4>), grid, dim3(256), 0, s, g);
+    }
+    CTO_HIP(hipGetLastError());
+    return CTO_OK;
+}
+
+int ensure_ws(cto_model* m, int64_t B) {
+    if (B <= m->ws_B) return CTO_OK;
+    for (void* p : m->ws_ptrs) (void)hipFree(p);
+    m->ws_ptrs.clear();
+    m->ws_B = 0;
+    auto get = [&](float** out, int64_t per_site) -> int {
+        void* p = nullptr;
+        CTO_HIP(hipMalloc(&p, size_t(B) * size_t(per_site) * sizeof(float)));
+        m->ws_ptrs.push_back(p);
+        *out = static_cast<float*>(p);
+        return CTO_OK;
+    };
+    int rc;
+    const int K = m->n_out;
+    if (m->kind == 0) {
+        int64_t act = 0, qn = 0, kvn = 0, un = 0;
+        for (const StageDev& s : m->st) {
+            act = std::max<int64_t>(act, int64_t(s.w) * s.c);
+            qn = std::max<int64_t>(qn, int64_t(s.w) * s.inner);
+            kvn = std::max<int64_t>(kvn, int64_t(s.wkv) * 2 * s.inner);
+            un = std::max<int64_t>(un, int64_t(s.w) * 4 * s.c);
+        }
+        if ((rc = get(&m->b_h, act)) || (rc = get(&m->b_t, act)) || (rc = get(&m->b_yq, act)) ||
+            (rc = get(&m->b_ykv, act)) || (rc = get(&m->b_q, qn)) || (rc = get(&m->b_kv, kvn)) ||
+            (rc = get(&m->b_o, qn)) || (rc = get(&m->b_u, un)))
+            return rc;
+    } else {
+        if ((rc = get(&m->b_h, 33 * 256)) || (rc = get(&m->b_t, 33 * 384)) || (rc = get(&m->b_slab, 3 * 128))) return rc;
+    }
+    if ((rc = get(&m->b_g, 128)) || (rc = get(&m->b_u2, int64_t(K) * 128))) return rc;
+    m->ws_B = B;
+    return CTO_OK;
+}
+
+// fc1 (split-K when the reduction is long) -> SELU -> fc2 heads -> SELU -> fc3 -> SELU
+int run_head(cto_model* m, hipStream_t s, const float* feat, int64_t B, float* logits) {
+    const HeadDev& h = m->head;
+    const int K = m->n_out;
+    int rc;
+    if (h.k1 > 2048) {
+        const int S = 3;
+        if ((rc = launch_gemm(s, feat, h.k1, h.w1, h.k1, nullptr, nullptr, 0, m->b_slab, 128, int(B), 128, h.k1,
+                              ACT_NONE, 0, 0, 0, S, B * 128)))
+            return rc;
+        const int64_t total = B * 128;
+        hipLaunchKernelGGL(k_sum_bias_selu, dim3(unsigned(cdiv(total, 256))), dim3(256), 0, s, m->b_slab, S, B * 128,
+                           h.b1, m->b_g, total, 128);
+        CTO_HIP(hipGetLastError());
+    } else {
+        if ((rc = launch_gemm(s, feat, h.k1, h.w1, h.k1, h.b1, nullptr, 0, m->b_g, 128, int(B), 128, h.k1, ACT_SELU)))
+            return rc;
+    }
+    if ((rc = launch_gemm(s, m->b_g, 128, h.w2, 128, h.b2, nullptr, 0, m->b_u2, int64_t(K) * 128, int(B), K * 128, 128,
+                          ACT_SELU)))
+        return rc;
+    hipLaunchKernelGGL(k_fc3, dim3(unsigned(cdiv(B, 4))), dim3(256), 0, s, m->b_u2, h.w3, h.b3, logits, B, K);
+    CTO_HIP(hipGetLastError());
+    return CTO_OK;
+}
+
+int cvt_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStream_t s) {
+    int rc;
+    const float* in = x;
+    for (int si = 0; si < 3; ++si) {
+        const StageDev& st = m->st[si];
+        const int M = int(B) * st.w, Mkv = int(B) * st.wkv, C = st.c;
+        // conv embedding (3-tap stride 2) + channel LayerNorm
+        if ((rc = launch_gemm(s, in, 0, st.wemb, 3 * st.cin, st.bemb, nullptr, 0, m->b_t, C, M, C, 3 * st.cin, ACT_NONE,
+                              st.win, st.w, st.cin)))
+            return rc;
+        hipLaunchKernelGGL(k_layernorm, dim3(unsigned(cdiv(M, 4))), dim3(256), 0, s, m->b_t, m->b_h, st.lng, st.lnb, M, C);
+        CTO_HIP(hipGetLastError());
+        for (const BlockDev& b : st.blocks) {
+            hipLaunchKernelGGL(k_ln_dw, dim3(unsigned(B)), dim3(256), 0, s, m->b_h, b.n0g, b.n0b, b.dwq, b.bnq, b.dwkv,
+                               b.bnkv, m->b_yq, m->b_ykv, st.w, st.wkv, C);
+            CTO_HIP(hipGetLastError());
+            if ((rc = launch_gemm(s, m->b_yq, C, b.wq, C, nullptr, nullptr, 0, m->b_q, st.inner, M, st.inner, C, ACT_NONE)))
+                return rc;
+            if ((rc = launch_gemm(s, m->b_ykv, C, b.wkv, C, nullptr, nullptr, 0, m->b_kv, 2 * st.inner, Mkv, 2 * st.inner,
+                                  C, ACT_NONE)))
+                return rc;
+            const size_t smem = size_t(st.w * st.inner + st.wkv * 2 * st.inner + st.heads * st.w * st.wkv) * sizeof(float);
+            hipLaunchKernelGGL(k_attention, dim3(unsigned(B)), dim3(256), smem, s, m->b_q, m->b_kv, m->b_o, st.w, st.wkv,
+                               st.heads);
+            CTO_HIP(hipGetLastError());
+            // h = h + to_out(o)
+            if ((rc = launch_gemm(s, m->b_o, st.inner, b.wo, st.inner, b.bo, m->b_h, C, m->b_h, C, M, C, st.inner, ACT_NONE)))
+                return rc;
+            hipLaunchKernelGGL(k_layernorm, dim3(unsigned(cdiv(M, 4))), dim3(256), 0, s, m->b_h, m->b_t, b.n1g, b.n1b, M, C);
+            CTO_HIP(hipGetLastError());
+            if ((rc = launch_gemm(s, m->b_t, C, b.w1, C, b.b1, nullptr, 0, m->b_u, 4 * C, M, 4 * C, C, ACT_GELU))) return rc;
+            // h = h + ff2(u)
+            if ((rc = launch_gemm(s, m->b_u, 4 * C, b.w2, 4 * C, b.b2, m->b_h, C, m->b_h, C, M, C, 4 * C, ACT_NONE))) return rc;
+        }
+        // the stage output feeds the next stage's embedding GEMM, which writes b_t; b_h is only rewritten by
+        // the LayerNorm that follows it in stream order, so no copy is needed
+        in = m->b_h;
+    }
+    return run_head(m, s, m->b_h, B, logits);
+}
+
+template <int KIN, int KP, int H, int MS>
+int launch_gru(hipStream_t s, const float* x, const float* W, const float* bias, float* out, int64_t B) {
+    const size_t smem = size_t(2) * MS * 16 * (H + 4) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_layer<KIN, KP, H, MS>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
+        attr_set = true;
+    }
+    const unsigned grid = unsigned(cdiv(B, MS * 16)) * 2;
+    hipLaunchKernelGGL((k_gru_layer<KIN, KP, H, MS>), dim3(grid), dim3(256), smem, s, x, W, bias, out, int(B));
+    CTO_HIP(hipGetLastError());
+    return CTO_OK;
+}
+
+int bigru_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStream_t s) {
+    int rc;
+    if ((rc = launch_gru<34, 48, 128, 2>(s, x, m->gw1, m->gb1, m->b_h, B))) return rc;
+    if ((rc = launch_gru<256, 256, 192, 2>(s, m->b_h, m->gw2, m->gb2, m->b_t, B))) return rc;
+    return run_head(m, s, m->b_t, B, logits);
+}
+
+// [W_ih | W_hh] per gate row, W_ih zero-padded to KP; bias rows: r (b_ir + b_hr), z (b_iz + b_hz), b_in, b_hn
+int pack_gru(const cto_weights* w, const std::string& base, int kin, int kp, int H, Arena& a, float** Wout, float** bout) {
+    int rc = CTO_OK;
+    const int KT = kp + H;
+    std::vector<float> W(size_t(2) * 3 * H * KT, 0.f), bv(size_t(2) * 4 * H);
+    for (int d = 0; d < 2; ++d) {
+        const std::string sfx = d == 0 ? "" : "_reverse";
+        GETW(wih, base + ".weight_ih_l0" + sfx, int64_t(3) * H * kin);
+        GETW(whh, base + ".weight_hh_l0" + sfx, int64_t(3) * H * H);
+        GETW(bih, base + ".bias_ih_l0" + sfx, 3 * H);
+        GETW(bhh, base + ".bias_hh_l0" + sfx, 3 * H);
+        for (int n = 0; n < 3 * H; ++n) {
+            float* row = W.data() + (size_t(d) * 3 * H + n) * KT;
+            for (int k = 0; k < kin; ++k) row[k] = (*wih)[size_t(n) * kin + k];
+            for (int k = 0; k < H; ++k) row[kp + k] = (*whh)[size_t(n) * H + k];
+        }
+        float* b = bv.data() + size_t(d) * 4 * H;
+        for (int j = 0; j < H; ++j) {
+            b[0 * H + j] = (*bih)[size_t(j)] + (*bhh)[size_t(j)];
+            b[1 * H + j] = (*bih)[size_t(H + j)] + (*bhh)[size_t(H + j)];
+            b[2 * H + j] = (*bih)[size_t(2 * H + j)];
+            b[3 * H + j] = (*bhh)[size_t(2 * H + j)];
+        }
+    }
+    if ((rc = a.upload(W, Wout)) != CTO_OK) return rc;
+    return a.upload(bv, bout);
+}
+
+}  // namespace
+
+extern "C" int cto_cvt_create(const cto_weights* w, const cto_cvt_cfg* cfg, cto_model** out) {
+    CTO_REQUIRE(w && cfg && out, CTO_EINVAL, "cto_cvt_create: null argument");
+    CTO_REQUIRE(cfg->n_out == 4 || cfg->n_out == 6, CTO_EINVAL, "n_out must be 4 or 6");
+    for (int i = 0; i < 3; ++i)
+        CTO_REQUIRE(cfg->emb_dim[i] >= 4 && cfg->emb_dim[i] <= 128 && cfg->emb_dim[i] % 4 == 0 && cfg->heads[i] >= 1 &&
+                        cfg->heads[i] <= 8 && cfg->depth[i] >= 1,
+                    CTO_EUNSUPPORTED, "CvT stage %d config out of range (emb_dim <= 128, multiple of 4)", i + 1);
+    std::unique_ptr<cto_model> m(new cto_model());
+    m->kind = 0;
+    m->n_out = cfg->n_out;
+    Arena& a = m->arena;
+    int rc = CTO_OK;
+    int cin = CTO_NCHAN, win = CTO_NPOS;
+    int64_t macs = 0;
+    auto fail = [&](int code) { return code; };
+    for (int si = 0; si < 3; ++si) {
+        StageDev& st = m->st[si];
+        st.cin = cin; st.c = cfg->emb_dim[si]; st.win = win; st.w = (win + 1) / 2; st.wkv = (st.w + 1) / 2;
+        st.heads = cfg->heads[si]; st.inner = 64 * st.heads;
+        const int C = st.c;
+        const std::string L = "layer" + std::to_string(si + 1);
+        {
+            GETW(cw, L + ".0.weight", int64_t(C) * cin * 9);
+            std::vector<float> v(size_t(C) * 3 * cin);
+            for (int n = 0; n < C; ++n)
+                for (int t = 0; t < 3; ++t)
+                    for (int ci = 0; ci < cin; ++ci)
+                        v[(size_t(n) * 3 + t) * cin + ci] = (*cw)[((size_t(n) * cin + ci) * 3 + 1) * 3 + t];
+            if ((rc = a.upload(v, &st.wemb))) return fail(rc);
+        }
+        if ((rc = upload_named(w, L + ".0.bias", C, a, &st.bemb))) return fail(rc);
+        if ((rc = upload_named(w, L + ".1.g", C, a, &st.lng))) return fail(rc);
+        if ((rc = upload_named(w, L + ".1.b", C, a, &st.lnb))) return fail(rc);
+        macs += int64_t(st.w) * 3 * cin * C;
+        for (int d = 0; d < cfg->depth[si]; ++d) {
+            BlockDev b;
+            const std::string P = L + ".2.layers." + std::to_string(d);
+            if ((rc = upload_named(w, P + ".0.norm.g", C, a, &b.n0g)) || (rc = upload_named(w, P + ".0.norm.b", C, a, &b.n0b)) ||
+                (rc = pack_dw(w, P + ".0.fn.to_q.net.0.weight", C, a, &b.dwq)) ||
+                (rc = pack_bn(w, P + ".0.fn.to_q.net.1", C, a, &b.bnq)) ||
+                (rc = upload_named(w, P + ".0.fn.to_q.net.2.weight", int64_t(st.inner) * C, a, &b.wq)) ||
+                (rc = pack_dw(w, P + ".0.fn.to_kv.net.0.weight", C, a, &b.dwkv)) ||
+                (rc = pack_bn(w, P + ".0.fn.to_kv.net.1", C, a, &b.bnkv)) ||
+                (rc = upload_named(w, P + ".0.fn.to_kv.net.2.weight", int64_t(2) * st.inner * C, a, &b.wkv)) ||
+                (rc = upload_named(w, P + ".0.fn.to_out.0.weight", int64_t(C) * st.inner, a, &b.wo)) ||
+                (rc = upload_named(w, P + ".0.fn.to_out.0.bias", C, a, &b.bo)) ||
+                (rc = upload_named(w, P + ".1.norm.g", C, a, &b.n1g)) || (rc = upload_named(w, P + ".1.norm.b", C, a, &b.n1b)) ||
+                (rc = upload_named(w, P + ".1.fn.net.0.weight", int64_t(4) * C * C, a, &b.w1)) ||
+                (rc = upload_named(w, P + ".1.fn.net.0.bias", 4 * C, a, &b.b1)) ||
+                (rc = upload_named(w, P + ".1.fn.net.3.weight", int64_t(4) * C * C, a, &b.w2)) ||
+                (rc = upload_named(w, P + ".1.fn.net.3.bias", C, a, &b.b2)))
+                return fail(rc);
+            st.blocks.push_back(b);
+            macs += int64_t(st.w) * C * st.inner + int64_t(st.wkv) * C * 2 * st.inner + int64_t(st.w) * st.inner * C +
+                    int64_t(st.w) * 8 * C * C + int64_t(2) * st.heads * st.w * st.wkv * 64 +
+                    int64_t(3) * C * (st.w + st.wkv);
+        }
+        cin = C;
+        win = st.w;
+    }
+    // fc1: torch flattens [C][1][W] as c*W + w; our activations are channels-last (w*C + c)
+    const int C3 = m->st[2].c, W3 = m->st[2].w, k1 = C3 * W3;
+    {
+        GETW(f1, "fc1.weight", int64_t(128) * k1);
+        std::vector<float> v(size_t(128) * k1);
+        for (int n = 0; n < 128; ++n)
+            for (int c = 0; c < C3; ++c)
+                for (int ww = 0; ww < W3; ++ww) v[size_t(n) * k1 + ww * C3 + c] = (*f1)[size_t(n) * k1 + c * W3 + ww];
+        static const char* const names[6] = {"a", "c", "g", "t", "i", "d"};
+        if ((rc = build_head(w, names, m->n_out, k1, v, a, m->head))) return fail(rc);
+    }
+    macs += int64_t(k1) * 128 + int64_t(m->n_out) * (128 * 128 + 256);
+    m->macs = macs;
+    *out = m.release();
+    return CTO_OK;
+}
+
+extern "C" int cto_bigru_create(const cto_weights* w, int n_out, cto_model** out) {
+    CTO_REQUIRE(w && out, CTO_EINVAL, "cto_bigru_create: null argument");
+    CTO_REQUIRE(n_out == 4 || n_out == 6, CTO_EINVAL, "n_out must be 4 or 6");
+    std::unique_ptr<cto_model> m(new cto_model());
+    m->kind = 1;
+    m->n_out = n_out;
+    int rc = CTO_OK;
+    auto fail = [&](int code) { return code; };
+    if ((rc = pack_gru(w, "lstm", 34, 48, 128, m->arena, &m->gw1, &m->gb1))) return fail(rc);
+    if ((rc = pack_gru(w, "lstm_2", 256, 256, 192, m->arena, &m->gw2, &m->gb2))) return fail(rc);
+    const int k1 = 33 * 384;
+    {
+        GETW(f1, "fc1.weight", int64_t(128) * k1);
+        static const char* const names[6] = {"na", "nc", "ng", "nt", "ni", "nd"};
+        if ((rc = build_head(w, names, n_out, k1, *f1, m->arena, m->head))) return fail(rc);
+    }
+    m->macs = int64_t(33) * 2 * 3 * 128 * (34 + 128) + int64_t(33) * 2 * 3 * 192 * (256 + 192) + int64_t(k1) * 128 +
+              int64_t(n_out) * (128 * 128 + 256);
+    *out = m.release();
+    return CTO_OK;
+}
+
+extern "C" int cto_model_forward(cto_model* m, const float* x, int64_t B, float* logits, void* stream) {
+    CTO_REQUIRE(m && x && logits && B >= 0, CTO_EINVAL, "cto_model_forward: bad argument");
+    CTO_REQUIRE(B * 33 < (int64_t(1) << 31) / 640, CTO_EUNSUPPORTED, "batch too large for 32-bit row indices; split it");
+    if (B == 0) return CTO_OK;
+    int rc = ensure_ws(m, B);
+    if (rc != CTO_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return m->kind == 0 ? cvt_forward(m, x, B, logits, s) : bigru_forward(m, x, B, logits, s);
+}
+
+extern "C" int64_t cto_model_macs_per_site(const cto_model* m) { return m ? m->macs : 0; }
+extern "C" int cto_model_n_out(const cto_model* m) { return m ? m->n_out : 0; }
+extern "C" void cto_model_destroy(cto_model* m) { delete m; }

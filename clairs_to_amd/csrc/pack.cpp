@@ -1,0 +1,313 @@
+// Host side of the column pack: mpileup text -> binary columns, and the alt_info string builder.
+//
+// Behaviour follows src/create_tensor_pileup_calling.py of the reference:
+//   tokeniser           :120-144   (decode_pileup_bases, first loop)
+//   row handling        :472-497   (pos, bases, BQ, MQ columns; reference base via evc_base_from :82-92)
+//   indel length gates  :173-176, :188-191 (deletion uses len(seq)+1: the off-by-one is kept)
+//   alt_info            :158-209
+// Written from the behaviour, not from the text, of those lines.
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "common.h"
+
+namespace cto {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+}  // namespace cto
+
+struct cto_pack {
+    std::vector<int32_t> col_pos;
+    std::vector<uint8_t> col_ref;
+    std::vector<int64_t> col_off;   // n_cols + 1
+    std::vector<int32_t> key_off;   // n_cols + 1
+    std::vector<uint32_t> entries;
+    std::vector<uint8_t> key_meta;
+    std::vector<int64_t> key_str_off;  // n_keys + 1
+    std::string key_str;               // alt_info keys ("I<ANCHOR><SEQ>", "D<refslice>")
+};
+
+extern "C" const char* cto_last_error(void) { return cto::g_err; }
+extern "C" int cto_version(void) { return 100; }
+
+namespace {
+
+inline int base_code(char c) {
+    switch (c) {
+        case 'A': return 0;  case 'C': return 1;  case 'G': return 2;  case 'T': return 3;
+        case 'a': return 4;  case 'c': return 5;  case 'g': return 6;  case 't': return 7;
+        case '*': return 8;  case '#': return 9;  case 'N': return 10; case 'n': return 11;
+        default:  return -1;
+    }
+}
+
+inline char up(char c) { return (c >= 'a' && c <= 'z') ? char(c - 32) : c; }
+
+// evc_base_from(...).upper(): ACGT (any case) stay, everything else becomes 'A'.
+inline int ref_code_of(char c) {
+    switch (up(c)) {
+        case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3;
+        default:  return 0;
+    }
+}
+
+struct Tok {
+    int code;          // base code
+    int kind;          // 0 none, 1 ins, 2 del
+    const char* seq;   // indel sequence (not owned)
+    int seqlen;
+};
+
+constexpr int kMaxDepth = 32767;
+constexpr int kMaxKeysPerCol = 2048;
+
+}  // namespace
+
+extern "C" int cto_pack_from_mpileup(const char* text, size_t len, const char* ref_seq, int64_t ref_start,
+                                      size_t ref_len, int max_indel_length, cto_pack** out) {
+    CTO_REQUIRE(text && ref_seq && out, CTO_EINVAL, "cto_pack_from_mpileup: null argument");
+    auto* p = new cto_pack();
+    p->col_off.push_back(0);
+    p->key_off.push_back(0);
+    p->key_str_off.push_back(0);
+    std::vector<Tok> toks;
+    std::unordered_map<std::string, int> keymap;
+    std::string keybuf;
+    const char* cur = text;
+    const char* end = text + len;
+    int64_t last_pos = -1;
+    while (cur < end) {
+        const char* eol = static_cast<const char*>(memchr(cur, '\n', size_t(end - cur)));
+        if (!eol) eol = end;
+        const char* row_end = eol;
+        while (row_end > cur && (row_end[-1] == '\r' || row_end[-1] == ' ')) --row_end;
+        if (row_end > cur) {
+            // split the first seven tab-separated fields
+            const char* f[8];
+            int nf = 0;
+            f[nf++] = cur;
+            for (const char* q = cur; q < row_end && nf < 8; ++q)
+                if (*q == '\t') f[nf++] = q + 1;
+            if (nf < 7) {
+                delete p;
+                cto::set_error("mpileup row has %d fields, need >= 7 (is --output-MQ on?)", nf);
+                return CTO_EINVAL;
+            }
+            auto fend = [&](int i) { return (i + 1 < nf) ? f[i + 1] - 1 : row_end; };
+            int64_t pos = 0;
+            for (const char* q = f[1]; q < fend(1); ++q) {
+                if (*q < '0' || *q > '9') { delete p; cto::set_error("bad position field"); return CTO_EINVAL; }
+                pos = pos * 10 + (*q - '0');
+            }
+            if (pos <= last_pos) { delete p; cto::set_error("mpileup rows not in increasing position order"); return CTO_EINVAL; }
+            last_pos = pos;
+            int64_t ri = pos - ref_start;
+            if (ri < 0 || size_t(ri) >= ref_len) {
+                delete p;
+                cto::set_error("position %lld outside the supplied reference [%lld, %lld)", (long long)pos,
+                               (long long)ref_start, (long long)(ref_start + int64_t(ref_len)));
+                return CTO_EINVAL;
+            }
+            const char* bs = f[4];
+            const char* be = fend(4);
+            const char* qs = f[5];
+            const int nq = int(fend(5) - f[5]);
+            const char* ms = f[6];
+            const int nm = int(fend(6) - f[6]);
+            // ---- tokenise the base string (reference :124-144) ----
+            toks.clear();
+            for (const char* q = bs; q < be;) {
+                char c = *q;
+                if (c == '+' || c == '-') {
+                    ++q;
+                    int adv = 0;
+                    while (q < be && *q >= '0' && *q <= '9') { adv = adv * 10 + (*q - '0'); ++q; }
+                    if (toks.empty()) { delete p; cto::set_error("indel token before any base at pos %lld", (long long)pos); return CTO_EINVAL; }
+                    int avail = int(std::min<int64_t>(adv, be - q));
+                    toks.back().kind = (c == '+') ? 1 : 2;
+                    toks.back().seq = q;
+                    toks.back().seqlen = avail;
+                    q += adv;  // the reference advances by `adv` characters in total
+                    continue;
+                }
+                int code = base_code(c);
+                if (code >= 0) {
+                    toks.push_back(Tok{code, 0, nullptr, 0});
+                } else if (c == '^') {
+                    ++q;  // skip the mapping-quality character of a read start
+                }
+                ++q;
+            }
+            // zip(base_list, mapping_quality) / zip(base_list, base_quality) truncate: entries without a
+            // quality character contribute to no counter; they are dropped here (only malformed rows).
+            int n = int(std::min<size_t>(toks.size(), size_t(std::min(nq, nm))));
+            if (n > kMaxDepth) { delete p; cto::set_error("column depth %d > %d unsupported", n, kMaxDepth); return CTO_EUNSUPPORTED; }
+            keymap.clear();
+            int nkeys_col = 0;
+            for (int i = 0; i < n; ++i) {
+                const Tok& t = toks[size_t(i)];
+                int bq = qs[i] - 33, mq = ms[i] - 33;
+                bq = std::max(0, std::min(bq, 127));
+                mq = std::max(0, std::min(mq, 255));
+                uint32_t kind = uint32_t(t.kind), kid = 0;
+                if (t.kind != 0) {
+                    const int gate_len = (t.kind == 1) ? t.seqlen : t.seqlen + 1;
+                    if (gate_len > max_indel_length) {
+                        kind = 3;
+                    } else {
+                        // distinct Counter key: base char + sign + sequence, case-sensitive
+                        keybuf.clear();
+                        keybuf.push_back(char('0' + t.code));
+                        keybuf.push_back(t.kind == 1 ? '+' : '-');
+                        keybuf.append(t.seq, size_t(t.seqlen));
+                        auto it = keymap.find(keybuf);
+                        if (it == keymap.end()) {
+                            if (nkeys_col >= kMaxKeysPerCol) { delete p; cto::set_error("more than %d distinct indel keys in one column", kMaxKeysPerCol); return CTO_EUNSUPPORTED; }
+                            kid = uint32_t(nkeys_col++);
+                            keymap.emplace(keybuf, int(kid));
+                            const bool fwd = (t.code < 4) || t.code == 8 || t.code == 10;
+                            p->key_meta.push_back(uint8_t(t.kind | (fwd ? 4 : 0)));
+                            // merged alt_info key
+                            if (t.kind == 1) {
+                                p->key_str.push_back('I');
+                                static const char kBaseChar[] = "ACGTACGT*#NN";
+                                p->key_str.push_back(kBaseChar[t.code]);
+                                for (int j = 0; j < t.seqlen; ++j) p->key_str.push_back(up(t.seq[j]));
+                            } else {
+                                p->key_str.push_back('D');
+                                // chunk_ref_seq[:len+1] with chunk_ref_seq = ref[pos : pos+max_indel_length].upper()
+                                int64_t take = std::min<int64_t>(t.seqlen + 1, max_indel_length);
+                                take = std::min<int64_t>(take, int64_t(ref_len) - ri);
+                                for (int64_t j = 0; j < take; ++j) p->key_str.push_back(up(ref_seq[ri + j]));
+                            }
+                            p->key_str_off.push_back(int64_t(p->key_str.size()));
+                        } else {
+                            kid = uint32_t(it->second);
+                        }
+                    }
+                }
+                p->entries.push_back(uint32_t(t.code) | (kind << 4) | (uint32_t(bq) << 6) | (uint32_t(mq) << 13) | (kid << 21));
+            }
+            p->col_pos.push_back(int32_t(pos));
+            p->col_ref.push_back(uint8_t(ref_code_of(ref_seq[ri])));
+            p->col_off.push_back(int64_t(p->entries.size()));
+            p->key_off.push_back(int32_t(p->key_meta.size()));
+        }
+        cur = eol + 1;
+    }
+    *out = p;
+    return CTO_OK;
+}
+
+extern "C" int cto_pack_from_arrays(const cto_pack_view* v, const int64_t* key_str_off, const char* key_str, cto_pack** out) {
+    CTO_REQUIRE(v && out, CTO_EINVAL, "cto_pack_from_arrays: null argument");
+    CTO_REQUIRE(v->n_cols >= 0 && v->n_entries >= 0 && v->n_keys >= 0, CTO_EINVAL, "negative sizes");
+    auto* p = new cto_pack();
+    p->col_pos.assign(v->col_pos, v->col_pos + v->n_cols);
+    p->col_ref.assign(v->col_ref, v->col_ref + v->n_cols);
+    p->col_off.assign(v->col_off, v->col_off + v->n_cols + 1);
+    p->key_off.assign(v->key_off, v->key_off + v->n_cols + 1);
+    p->entries.assign(v->entries, v->entries + v->n_entries);
+    p->key_meta.assign(v->key_meta, v->key_meta + v->n_keys);
+    if (key_str_off && key_str) {
+        p->key_str_off.assign(key_str_off, key_str_off + v->n_keys + 1);
+        p->key_str.assign(key_str, size_t(key_str_off[v->n_keys]));
+    } else {
+        p->key_str_off.assign(size_t(v->n_keys) + 1, 0);
+    }
+    for (int64_t c = 0; c < v->n_cols; ++c) {
+        if (p->col_off[size_t(c) + 1] - p->col_off[size_t(c)] > kMaxDepth) {
+            delete p;
+            cto::set_error("column depth > %d unsupported", kMaxDepth);
+            return CTO_EUNSUPPORTED;
+        }
+        if (c > 0 && p->col_pos[size_t(c)] <= p->col_pos[size_t(c) - 1]) {
+            delete p;
+            cto::set_error("col_pos must be strictly increasing");
+            return CTO_EINVAL;
+        }
+    }
+    *out = p;
+    return CTO_OK;
+}
+
+extern "C" int cto_pack_view_of(const cto_pack* p, cto_pack_view* v) {
+    CTO_REQUIRE(p && v, CTO_EINVAL, "cto_pack_view_of: null argument");
+    v->n_cols = int64_t(p->col_pos.size());
+    v->n_entries = int64_t(p->entries.size());
+    v->n_keys = int64_t(p->key_meta.size());
+    v->col_pos = p->col_pos.data();
+    v->col_ref = p->col_ref.data();
+    v->col_off = p->col_off.data();
+    v->key_off = p->key_off.data();
+    v->entries = p->entries.data();
+    v->key_meta = p->key_meta.data();
+    return CTO_OK;
+}
+
+extern "C" int cto_pack_key_string(const cto_pack* p, int64_t k, const char** s) {
+    CTO_REQUIRE(p && s && k >= 0 && size_t(k) + 1 < p->key_str_off.size(), CTO_EINVAL, "bad key index");
+    *s = p->key_str.data() + p->key_str_off[size_t(k)];
+    return int(p->key_str_off[size_t(k) + 1] - p->key_str_off[size_t(k)]);
+}
+
+extern "C" void cto_pack_free(cto_pack* p) { delete p; }
+
+extern "C" int cto_alt_info(const cto_pack* p, int64_t col, const int16_t* cv, int32_t depth_aff,
+                            const int32_t* colfirst_col, const uint32_t* keycnt, const int32_t* keyfirst,
+                            char* buf, size_t cap) {
+    CTO_REQUIRE(p && cv && colfirst_col && buf && cap > 0, CTO_EINVAL, "cto_alt_info: null argument");
+    CTO_REQUIRE(col >= 0 && size_t(col) < p->col_pos.size(), CTO_EINVAL, "cto_alt_info: column out of range");
+    struct Item { int64_t first; std::string key; int64_t count; };
+    std::vector<Item> items;
+    const int ref = p->col_ref[size_t(col)];
+    static const char kB[] = "ACGT";
+    // channel layout F0: A C G T at 0..3, a c g t at 9..12; the reference base's channel holds -(group sum)
+    int64_t fwd[4], rev[4];
+    int64_t sf = 0, sr = 0;
+    for (int b = 0; b < 4; ++b) { fwd[b] = cv[b]; rev[b] = cv[9 + b]; if (b != ref) { sf += fwd[b]; sr += rev[b]; } }
+    fwd[ref] = -fwd[ref] - sf;
+    rev[ref] = -rev[ref] - sr;
+    for (int b = 0; b < 4; ++b) {
+        if (b == ref) continue;
+        int64_t c = fwd[b] + rev[b];
+        if (c > 0) items.push_back(Item{colfirst_col[b], std::string("X") + kB[b], c});
+    }
+    const int32_t k0 = p->key_off[size_t(col)], k1 = p->key_off[size_t(col) + 1];
+    for (int32_t k = k0; k < k1; ++k) {
+        int64_t c = keycnt[k] & 0xffffu;
+        if (c == 0) continue;
+        std::string key(p->key_str.data() + p->key_str_off[size_t(k)], size_t(p->key_str_off[size_t(k) + 1] - p->key_str_off[size_t(k)]));
+        bool merged = false;
+        for (auto& it : items) {
+            if (it.key == key) { it.count += c; it.first = std::min<int64_t>(it.first, keyfirst[k]); merged = true; break; }
+        }
+        if (!merged) items.push_back(Item{keyfirst[k], key, c});
+    }
+    std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.first < b.first; });
+    std::string s = std::to_string(depth_aff) + "-";
+    bool first = true;
+    for (auto& it : items) {
+        if (!first) s.push_back(' ');
+        first = false;
+        s += it.key; s.push_back(' '); s += std::to_string(it.count);
+    }
+    const int64_t refc = fwd[ref] + rev[ref];
+    if (refc > 0) {
+        if (!first) s.push_back(' ');
+        s += std::string("R") + kB[ref] + " " + std::to_string(refc);
+    }
+    s.push_back('-');
+    CTO_REQUIRE(s.size() + 1 <= cap, CTO_EINVAL, "cto_alt_info: buffer too small (%zu needed)", s.size() + 1);
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return int(s.size());
+}

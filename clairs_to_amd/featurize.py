@@ -1,0 +1,80 @@
+"""Pileup-tensor creation on the GPU: host wrapper of cto_featurize_columns / cto_gather_windows.
+
+Mirrors what src/create_tensor_pileup_calling.py (reference) produces for ONE chunk of candidates, for the
+AFF pass (--min_bq <platform>) and the NEG pass (--min_bq 0) at once, plus the rescale and strand counts that
+clairs/predict.py derives from the tensor text (predict.py:172-207, 626-642)."""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from ._lib import lib, check, current_stream_ptr
+
+NPOS, NCHAN, COLVEC_STRIDE = 33, 34, 72
+
+
+@dataclass
+class Features:
+    x_aff: torch.Tensor        # [n,33,34] float32, rescaled AFF tensor (network input)
+    x_neg: torch.Tensor        # [n,33,34] float32, rescaled NEG tensor
+    raw_aff: torch.Tensor      # [n,33,34] int16 or None
+    raw_neg: torch.Tensor      # [n,33,34] int16 or None
+    site_info: torch.Tensor    # [n,12] int32: centre col, depth_aff, depth_neg, flags, fwd ACGT, rev ACGT
+    colvec: torch.Tensor       # [n_cols,72] int16
+    coldepth: torch.Tensor     # [n_cols,2] int32
+    colfirst: torch.Tensor     # [n_cols,4] int32
+    keycnt: torch.Tensor       # [n_keys] int32 (uint32 bits: low16 AFF count, high16 NEG count)
+    keyfirst: torch.Tensor     # [n_keys] int32
+
+
+def featurize(dev_pack, site_pos, min_bq, min_rescale_cov=50, want_raw=False, want_x=True):
+    """dev_pack: DevicePack; site_pos: int32 tensor on the same device (1-based candidate positions)."""
+    dev = dev_pack.device
+    if site_pos.device != dev or site_pos.dtype != torch.int32:
+        site_pos = site_pos.to(device=dev, dtype=torch.int32)
+    site_pos = site_pos.contiguous()
+    n = site_pos.numel()
+    nc, nk = dev_pack.n_cols, dev_pack.n_keys
+    colvec = torch.empty((nc, COLVEC_STRIDE), dtype=torch.int16, device=dev)
+    coldepth = torch.empty((nc, 2), dtype=torch.int32, device=dev)
+    colfirst = torch.empty((nc, 4), dtype=torch.int32, device=dev)
+    keycnt = torch.empty((max(nk, 1),), dtype=torch.int32, device=dev)
+    keyfirst = torch.empty((max(nk, 1),), dtype=torch.int32, device=dev)
+    s = current_stream_ptr()
+    check(lib.cto_featurize_columns(C.byref(dev_pack.view), int(min_bq), colvec.data_ptr(), coldepth.data_ptr(),
+                                    colfirst.data_ptr(), keycnt.data_ptr(), keyfirst.data_ptr(), s))
+    x_aff = torch.empty((n, NPOS, NCHAN), dtype=torch.float32, device=dev) if want_x else None
+    x_neg = torch.empty((n, NPOS, NCHAN), dtype=torch.float32, device=dev) if want_x else None
+    raw_aff = torch.empty((n, NPOS, NCHAN), dtype=torch.int16, device=dev) if want_raw else None
+    raw_neg = torch.empty((n, NPOS, NCHAN), dtype=torch.int16, device=dev) if want_raw else None
+    site_info = torch.empty((n, 12), dtype=torch.int32, device=dev)
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    check(lib.cto_gather_windows(C.byref(dev_pack.view), colvec.data_ptr(), coldepth.data_ptr(), site_pos.data_ptr(), n,
+                                 int(min_rescale_cov) if min_rescale_cov else 0, ptr(x_aff), ptr(x_neg), ptr(raw_aff),
+                                 ptr(raw_neg), site_info.data_ptr(), s))
+    return Features(x_aff, x_neg, raw_aff, raw_neg, site_info, colvec, coldepth, colfirst, keycnt[:nk], keyfirst[:nk])
+
+
+def alt_infos(feat, host_pack, site_info_host=None):
+    """The reference's alt_info strings of the AFF pass for every site with a centre column
+    (create_tensor_pileup_calling.py:158-209); '' for sites without one.  Host work on device results."""
+    info = feat.site_info.cpu().numpy() if site_info_host is None else site_info_host
+    colvec = feat.colvec.cpu().numpy()
+    colfirst = feat.colfirst.cpu().numpy()
+    keycnt = np.ascontiguousarray(feat.keycnt.cpu().numpy().view(np.uint32))
+    keyfirst = np.ascontiguousarray(feat.keyfirst.cpu().numpy())
+    if keycnt.size == 0:
+        keycnt = np.zeros(1, dtype=np.uint32)
+        keyfirst = np.zeros(1, dtype=np.int32)
+    buf = C.create_string_buffer(1 << 16)
+    out = []
+    for i in range(info.shape[0]):
+        c = int(info[i, 0])
+        if c < 0:
+            out.append("")
+            continue
+        n = check(lib.cto_alt_info(host_pack._h, c, colvec[c].ctypes.data, int(info[i, 1]), colfirst[c].ctypes.data,
+                                   keycnt.ctypes.data, keyfirst.ctypes.data, buf, len(buf)))
+        out.append(buf.raw[:n].decode())
+    return out

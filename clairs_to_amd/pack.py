@@ -1,0 +1,104 @@
+"""Column packs on the host and in HBM (see include/clairsto_amd.h for the binary layout)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import lib, check, PackView, c_vp
+
+_FIELDS = (("col_pos", np.int32), ("col_ref", np.uint8), ("col_off", np.int64), ("key_off", np.int32),
+           ("entries", np.uint32), ("key_meta", np.uint8))
+
+
+class ColumnPack:
+    """Host-side pack (owns a cto_pack). Build it from mpileup text or from arrays."""
+
+    def __init__(self, handle):
+        self._h = c_vp(handle)
+        v = PackView()
+        check(lib.cto_pack_view_of(self._h, C.byref(v)))
+        self.view = v
+        self.n_cols, self.n_entries, self.n_keys = int(v.n_cols), int(v.n_entries), int(v.n_keys)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.cto_pack_free(h)
+
+    @classmethod
+    def from_mpileup(cls, text, ref_seq, ref_start, max_indel_length=60):
+        """text: `samtools mpileup --reverse-del --output-MQ --min-BQ 0` rows of ONE contig, increasing position.
+        Replaces the tokeniser of src/create_tensor_pileup_calling.py:120-144 (reference)."""
+        tb = text.encode() if isinstance(text, str) else bytes(text)
+        rb = ref_seq.encode() if isinstance(ref_seq, str) else bytes(ref_seq)
+        out = c_vp()
+        check(lib.cto_pack_from_mpileup(tb, len(tb), rb, int(ref_start), len(rb), int(max_indel_length), C.byref(out)))
+        return cls(out.value)
+
+    @classmethod
+    def from_arrays(cls, col_pos, col_ref, col_off, key_off, entries, key_meta, key_str_off=None, key_str=None):
+        arrs = dict(col_pos=col_pos, col_ref=col_ref, col_off=col_off, key_off=key_off, entries=entries, key_meta=key_meta)
+        keep = {k: np.ascontiguousarray(arrs[k], dtype=dt) for k, dt in _FIELDS}
+        v = PackView()
+        v.n_cols, v.n_entries, v.n_keys = len(keep["col_pos"]), len(keep["entries"]), len(keep["key_meta"])
+        assert len(keep["col_off"]) == v.n_cols + 1 and len(keep["key_off"]) == v.n_cols + 1
+        for k, _ in _FIELDS:
+            setattr(v, k, keep[k].ctypes.data)
+        kso = ks = None
+        if key_str_off is not None:
+            kso = np.ascontiguousarray(key_str_off, dtype=np.int64)
+            ks = bytes(key_str)
+        out = c_vp()
+        check(lib.cto_pack_from_arrays(C.byref(v), kso.ctypes.data if kso is not None else None, ks, C.byref(out)))
+        return cls(out.value)
+
+    def numpy(self):
+        """Zero-copy numpy views of the pack arrays (valid while this object lives)."""
+        v = self.view
+        n = dict(col_pos=v.n_cols, col_ref=v.n_cols, col_off=v.n_cols + 1, key_off=v.n_cols + 1,
+                 entries=v.n_entries, key_meta=v.n_keys)
+        out = {}
+        for k, dt in _FIELDS:
+            ptr = getattr(v, k)
+            cnt = int(n[k])
+            if cnt == 0 or not ptr:
+                out[k] = np.zeros(0, dtype=dt)
+            else:
+                buf = (C.c_char * (cnt * np.dtype(dt).itemsize)).from_address(ptr)
+                out[k] = np.frombuffer(buf, dtype=dt, count=cnt)
+        return out
+
+    def key_string(self, k):
+        s = C.c_char_p()
+        n = check(lib.cto_pack_key_string(self._h, int(k), C.byref(s)))
+        return C.string_at(s, n).decode()
+
+    def to_device(self, device="cuda"):
+        return DevicePack(self.numpy(), device, host=self)
+
+
+class DevicePack:
+    """The pack arrays resident in HBM (torch owns the memory) plus the cto_pack_view of device pointers."""
+
+    def __init__(self, arrays, device="cuda", host=None):
+        self.host = host
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("clairs_to_amd: the featurisation kernels need a HIP device; there is no CPU fallback")
+        self.t = {}
+        for k, dt in _FIELDS:
+            a = np.ascontiguousarray(arrays[k], dtype=dt)
+            # torch has no uint32: carry the bits in int32
+            t = torch.from_numpy(a.view(np.int32) if dt == np.uint32 else a.copy() if a.size == 0 else a)
+            self.t[k] = t.to(self.device, non_blocking=False)
+        v = PackView()
+        v.n_cols = len(arrays["col_pos"])
+        v.n_entries = len(arrays["entries"])
+        v.n_keys = len(arrays["key_meta"])
+        for k, _ in _FIELDS:
+            setattr(v, k, self.t[k].data_ptr())
+        self.view = v
+        self.n_cols, self.n_entries, self.n_keys = int(v.n_cols), int(v.n_entries), int(v.n_keys)
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self.t.values())

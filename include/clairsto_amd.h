@@ -1,0 +1,183 @@
+/*
+ * clairsto_amd.h -- C ABI of the MI355X (gfx950) hot-path engine for ClairS-TO.
+ *
+ * The hot path is: pileup-tensor creation -> AFF (CvT) + NEG (BiGRU)
+ * inference -> posterior / arg-max / QUAL.  The reference has no FFI for this path; it sits behind
+ * three concrete seams.  Every entry point below names the reference interface it
+ * replaces (file:line into HKU-BAL/ClairS-TO v0.4.4).
+ *
+ * Conventions
+ *   - plain C, no exceptions; every function returns CTO_OK (0) or a negative error code;
+ *     cto_last_error() gives a thread-local message for the last failure.
+ *   - "dev" pointers are device (HBM) pointers the caller owns; "host" pointers are host memory.
+ *   - stream arguments are a hipStream_t passed as void* (NULL = the default stream).  All device
+ *     work is stream-ordered; nothing synchronises the device unless stated.
+ *   - handles are re-entrant per handle; one handle must not be used from two streams at once
+ *     (its activation workspace is shared).
+ */
+#ifndef CLAIRSTO_AMD_H
+#define CLAIRSTO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTO_OK            0
+#define CTO_EINVAL       -1   /* bad argument / malformed input                        */
+#define CTO_EHIP         -2   /* a HIP runtime call failed                              */
+#define CTO_ENOMEM       -3
+#define CTO_EUNSUPPORTED -4   /* input outside the documented limits    */
+#define CTO_EMISSING     -5   /* a required weight tensor is missing / has a wrong size */
+
+#define CTO_NPOS      33      /* shared/param.py:60-61  no_of_positions                 */
+#define CTO_NCHAN     34      /* shared/param.py:50-58  pileup_channel_size             */
+#define CTO_FLANK     16      /* shared/param.py:60     flankingBaseNum                 */
+
+const char* cto_last_error(void);
+int cto_version(void);
+/* number of visible HIP devices, or a negative error code */
+int cto_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Column pack: the binary form of `samtools mpileup` rows that the featurisation kernels consume.
+ * One pack = one contig region, columns in increasing position order (one column per mpileup row).
+ *
+ * entry (uint32), one per read-base of a column, in samtools' read order, as printed with --min-BQ 0:
+ *   bits  3:0  base code: 0..3 = A C G T, 4..7 = a c g t, 8 = '*', 9 = '#', 10 = 'N', 11 = 'n'
+ *   bits  5:4  indel kind attached to this base: 0 none, 1 insertion, 2 deletion,
+ *              3 = indel longer than max_indel_length (entry contributes nothing, F4)
+ *   bits 12:6  base quality (phred, clamped to 127)
+ *   bits 20:13 mapping quality
+ *   bits 31:21 key id: index of this entry's distinct indel key within its column (first-seen order)
+ * key_meta (uint8) per distinct indel key: bits 1:0 kind (1 ins / 2 del), bit 2 = forward strand.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct cto_pack_view {
+    int64_t         n_cols;
+    int64_t         n_entries;
+    int64_t         n_keys;
+    const int32_t*  col_pos;   /* [n_cols]   1-based reference position, strictly increasing       */
+    const uint8_t*  col_ref;   /* [n_cols]   reference base code 0..3 after evc_base_from (F1)      */
+    const int64_t*  col_off;   /* [n_cols+1] first entry of each column                             */
+    const int32_t*  key_off;   /* [n_cols+1] first distinct indel key of each column                */
+    const uint32_t* entries;   /* [n_entries]                                                       */
+    const uint8_t*  key_meta;  /* [n_keys]                                                          */
+} cto_pack_view;
+
+typedef struct cto_pack cto_pack;   /* host-side pack incl. the key strings needed for alt_info   */
+
+/* Parse `samtools mpileup --reverse-del --output-MQ --min-BQ 0` text (rows "chr\tpos\tN\tdepth\tbases\tBQ\tMQ")
+ * into a pack.  ref_seq is the (raw, any case) reference covering [ref_start, ref_start+ref_len),
+ * ref_start 1-based.  Replaces the text tokeniser of src/create_tensor_pileup_calling.py:120-144 and
+ * the row handling at :472-497.  max_indel_length: shared/param.py max_indel_length (60). */
+int cto_pack_from_mpileup(const char* text, size_t len, const char* ref_seq, int64_t ref_start,
+                          size_t ref_len, int max_indel_length, cto_pack** out);
+/* Build a pack from caller-made arrays (synthetic generators, BAM readers); key strings are the
+ * alt_info keys ("IACG", "DACGT") concatenated, key_str_off[n_keys+1]. Arrays are copied. */
+int cto_pack_from_arrays(const cto_pack_view* host_view, const int64_t* key_str_off,
+                         const char* key_str, cto_pack** out);
+int cto_pack_view_of(const cto_pack* p, cto_pack_view* host_view);
+/* alt_info key string of distinct key `k` (global index); returns its length. */
+int cto_pack_key_string(const cto_pack* p, int64_t k, const char** s);
+void cto_pack_free(cto_pack* p);
+
+/* ------------------------------------------------------------------------------------------------
+ * Featurisation (src/create_tensor_pileup_calling.py).
+ * ---------------------------------------------------------------------------------------------- */
+#define CTO_COLVEC_STRIDE 72          /* int16 per column: [2 passes][36] (34 channels + 2 pad)   */
+
+/* Stage A: one 34-channel vector per column for the AFF pass (read-bases with BQ >= min_bq, as
+ * `samtools --min-BQ min_bq` would print) and the NEG pass (all read-bases), in one sweep.
+ * Replaces decode_pileup_bases (create_tensor_pileup_calling.py:95-233), called twice per site by the
+ * reference (run_clairs_to:1228-1271).
+ *   colvec   dev [n_cols][2][36] int16   pass 0 = AFF, pass 1 = NEG
+ *   coldepth dev [n_cols][2]     int32   `depth` of F4 (MQ>=20, N / over-long indels excluded)
+ *   colfirst dev [n_cols][4]     int32   AFF pass: first-seen entry index of bases A,C,G,T (either
+ *                                        strand, MQ>=20) or 0x7fffffff -- alt_info key order (F5)
+ *   keycnt   dev [n_keys]        uint32  low 16 = AFF count, high 16 = NEG count of each distinct key
+ *   keyfirst dev [n_keys]        int32   AFF pass first-seen entry index (0x7fffffff if none)
+ * keycnt/keyfirst are initialised by the call. Limit: column depth <= 32767 (CTO_EUNSUPPORTED is
+ * raised by the pack builders). */
+int cto_featurize_columns(const cto_pack_view* dev_pack, int min_bq, int16_t* colvec, int32_t* coldepth,
+                          int32_t* colfirst, uint32_t* keycnt, int32_t* keyfirst, void* stream);
+
+/* Stage B: 33x34 window per candidate + coverage rescale, both passes.
+ * Replaces the window assembly of create_tensor_pileup_calling.py:536-570 and the rescale of
+ * clairs/predict.py:172-207 (x * (min_rescale_cov/depth) in double, cast to float, when depth > min_rescale_cov).
+ *   site_pos  dev [n_sites] int32   1-based candidate positions
+ *   x_aff/x_neg dev [n_sites][33][34] float   network inputs (rescaled); may be NULL
+ *   raw_aff/raw_neg dev [n_sites][33][34] int16  un-rescaled tensors (the reference's text tensor); may be NULL
+ *   site_info dev [n_sites][12] int32: {centre column index or -1, depth_aff, depth_neg, flags,
+ *             fwd A,C,G,T, rev A,C,G,T} -- strand counts per predict.py:626-642 (true ref count restored)
+ *             flags bit0: site skipped by the reference (no mpileup row at the candidate, or window
+ *             start < 1: create_tensor_pileup_calling.py:542,552)
+ * min_rescale_cov <= 0 disables the rescale. */
+int cto_gather_windows(const cto_pack_view* dev_pack, const int16_t* colvec, const int32_t* coldepth,
+                       const int32_t* site_pos, int64_t n_sites, int min_rescale_cov,
+                       float* x_aff, float* x_neg, int16_t* raw_aff, int16_t* raw_neg,
+                       int32_t* site_info, void* stream);
+
+/* Host: the reference's alt_info string "<depth>-<key count ...>-" for the column `col` of the AFF pass
+ * (create_tensor_pileup_calling.py:158-209), from stage-A outputs copied to the host.
+ * colvec_col points at that column's [2][36] int16. Returns the string length (<= cap-1) or an error. */
+int cto_alt_info(const cto_pack* p, int64_t col, const int16_t* colvec_col, int32_t depth_aff,
+                 const int32_t* colfirst_col, const uint32_t* keycnt, const int32_t* keyfirst,
+                 char* buf, size_t cap);
+
+/* ------------------------------------------------------------------------------------------------
+ * Models (clairs/model.py).  Weights are handed over by state_dict name; data is host fp32.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct cto_weights cto_weights;
+typedef struct cto_model   cto_model;
+
+cto_weights* cto_weights_new(void);
+int  cto_weights_add(cto_weights* w, const char* name, const float* data, int64_t numel);
+void cto_weights_free(cto_weights* w);
+
+typedef struct cto_cvt_cfg {
+    int emb_dim[3];   /* s{1,2,3}_emb_dim, e.g. 16, 64, 128  (clairs/predict.py:520-553)        */
+    int heads[3];     /* s{1,2,3}_heads,   e.g. 1, 3, 4                                         */
+    int depth[3];     /* s{1,2,3}_depth,   e.g. 1, 2, 3                                         */
+    int n_out;        /* 4 (CvT: a c g t) or 6 (CvT_Indel: a c g t i d)                         */
+} cto_cvt_cfg;
+
+/* clairs.model.CvT / CvT_Indel (clairs/model.py:150-384): eval-mode forward. */
+int cto_cvt_create(const cto_weights* w, const cto_cvt_cfg* cfg, cto_model** out);
+/* clairs.model.BiGRU_NACGT / BiGRU_NACGT_Indel (clairs/model.py:387-560); n_out = 4 or 6. */
+int cto_bigru_create(const cto_weights* w, int n_out, cto_model** out);
+/* x dev [B][33][34] float -> logits dev [n_out][B][2] float (post-SELU, pre-softmax), exactly the tuple
+ * `model(x)` returns at clairs/predict.py:646-658. */
+int cto_model_forward(cto_model* m, const float* x, int64_t B, float* logits, void* stream);
+/* algorithmic multiply-accumulate count per site of this model (for roofline accounting). */
+int64_t cto_model_macs_per_site(const cto_model* m);
+int  cto_model_n_out(const cto_model* m);
+void cto_model_destroy(cto_model* m);
+
+/* ------------------------------------------------------------------------------------------------
+ * Posterior / decision / quality (clairs/call_variants.py:154-304, 79-88), fused with the 2-way
+ * softmax of clairs/predict.py:659-684 and the "{:0.8f}" round trip of the probability text seam
+ * (predict.py:114-152 -> call_variants.py:803-829).
+ *   aff_logits, neg_logits dev [K][B][2] float
+ *   lik   dev [K][10][10] double   likelihood matrices (call_variants.py:661-664 / 717-722)
+ *   edges dev [2K][11]   double    bin edges with 0 prepended and 1 appended, order a,na,c,nc,...
+ *   probs dev [B][2K][2] float     softmax outputs, order a c g t [i d] na nc ng nt [ni nd]; may be NULL
+ *   post  dev [B][K] double        posterior per base
+ *   decision dev [B][4] int32      {argmax, clamped flag (an index 10 the reference would crash on), 0, 0}
+ *   qual  dev [B] double           quality_score_from(max posterior), rounded to 4 dp
+ * ---------------------------------------------------------------------------------------------- */
+int cto_posterior(const float* aff_logits, const float* neg_logits, int K, int64_t B,
+                  const double* lik, const double* edges, float* probs, double* post,
+                  int32_t* decision, double* qual, void* stream);
+
+/* Same epilogue entered at the probability text seam (clairs/call_variants.py:798-829 parses the rows that
+ * clairs/predict.py:114-152 wrote): p1 dev [B][2K] double = the second number of each "p0 p1" field, in the
+ * order a c g t [i d] na nc ng nt [ni nd], already rounded to 8 decimals by the producer. */
+int cto_posterior_from_probs(const double* p1, int K, int64_t B, const double* lik, const double* edges,
+                             double* post, int32_t* decision, double* qual, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLAIRSTO_AMD_H */

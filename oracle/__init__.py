@@ -1,0 +1,154 @@
+"""ctypes wrapper of the CPU oracle (oracle/cto_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Nothing under clairs_to_amd/ may import this package (tests/test_layout.py enforces it).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "cto_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
+    return _LIB
+
+
+_lib = None
+
+
+class _Tensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        _lib = C.CDLL(_LIB)
+        _lib.orc_decode_column.restype = C.c_int
+        _lib.orc_ref_base.restype = C.c_char
+        _lib.orc_ref_base.argtypes = [C.c_char]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def ref_base(c):
+    return lib().orc_ref_base(c.encode()).decode()
+
+
+def decode_column(bases, bq, mq, ref_base_char, chunk_ref, is_candidate, max_indel_length=60):
+    """decode_pileup_bases restatement: returns (tensor[34] list, depth, alt_info)."""
+    out = np.zeros(34, dtype=np.int32)
+    buf = C.create_string_buffer(1 << 16)
+    b, q, m, cr = bases.encode(), bq.encode(), mq.encode(), chunk_ref.encode()
+    depth = lib().orc_decode_column(b, len(b), q, len(q), m, len(m), C.c_char(ref_base_char.encode()), cr, len(cr),
+                                    int(max_indel_length), int(bool(is_candidate)), _p(out), buf, len(buf))
+    return out.tolist(), depth, buf.value.decode()
+
+
+def create_tensor(text, ref, ref_start, sites, max_indel_length=60, alt_stride=4096):
+    """create_tensor restatement on (already BQ-filtered) mpileup text.
+    Returns tensor int32 [n,33,34], depth int32 [n], alt_info list[str], flags uint8 [n]."""
+    sites = np.ascontiguousarray(sites, dtype=np.int32)
+    n = len(sites)
+    tensor = np.zeros((n, 33, 34), dtype=np.int32)
+    depth = np.zeros(n, dtype=np.int32)
+    flags = np.zeros(n, dtype=np.uint8)
+    alts = np.zeros((n, alt_stride), dtype=np.uint8)
+    tb = text.encode() if isinstance(text, str) else text
+    rb = ref.encode() if isinstance(ref, str) else ref
+    lib().orc_create_tensor(tb, C.c_size_t(len(tb)), rb, C.c_int64(ref_start), C.c_int64(len(rb)), _p(sites), n,
+                            int(max_indel_length), _p(tensor), _p(depth), _p(alts), alt_stride, _p(flags))
+    alt_list = [bytes(alts[i]).split(b"\0", 1)[0].decode() for i in range(n)]
+    return tensor, depth, alt_list, flags
+
+
+def rescale(tensor, depth, min_rescale_cov=50):
+    tensor = np.ascontiguousarray(tensor, dtype=np.int32)
+    out = np.zeros(tensor.shape, dtype=np.float32)
+    for i in range(tensor.shape[0]):
+        lib().orc_rescale(_p(tensor[i]), int(depth[i]), int(min_rescale_cov), _p(out[i]))
+    return out
+
+
+def strand_counts(tensor):
+    tensor = np.ascontiguousarray(tensor, dtype=np.int32)
+    f = np.zeros((tensor.shape[0], 4), dtype=np.int32)
+    r = np.zeros((tensor.shape[0], 4), dtype=np.int32)
+    for i in range(tensor.shape[0]):
+        lib().orc_strand_counts(_p(tensor[i]), _p(f[i]), _p(r[i]))
+    return f, r
+
+
+def _table(weights):
+    keep = []
+    arr = (_Tensor * len(weights))()
+    for i, (k, v) in enumerate(weights.items()):
+        a = np.ascontiguousarray(v, dtype=np.float32)
+        keep.append(a)
+        arr[i].name = k.encode()
+        arr[i].data = a.ctypes.data
+        arr[i].numel = a.size
+    return arr, keep
+
+
+def cvt_forward(weights, cfg, x):
+    """weights: dict name -> array (state_dict), cfg = dict(emb_dim, heads, depth, n_out); x [B,33,34] float32.
+    Returns logits [K,B,2] float32."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    B, K = x.shape[0], int(cfg["n_out"])
+    out = np.zeros((K, B, 2), dtype=np.float32)
+    arr, keep = _table(weights)
+    i3 = lambda v: (C.c_int * 3)(*[int(t) for t in v])
+    lib().orc_cvt_forward(arr, len(weights), i3(cfg["emb_dim"]), i3(cfg["heads"]), i3(cfg["depth"]), K, _p(x),
+                          C.c_int64(B), _p(out))
+    return out
+
+
+def bigru_forward(weights, n_out, x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    B, K = x.shape[0], int(n_out)
+    out = np.zeros((K, B, 2), dtype=np.float32)
+    arr, keep = _table(weights)
+    lib().orc_bigru_forward(arr, len(weights), K, _p(x), C.c_int64(B), _p(out))
+    return out
+
+
+def posterior(aff, neg, lik, edges):
+    """aff/neg logits [K,B,2] float32; lik [K,10,10] float64; edges [2K,11] float64.
+    Returns probs [B,2K,2] f32, post [B,K] f64, decision [B,4] i32, qual [B] f64."""
+    aff = np.ascontiguousarray(aff, dtype=np.float32)
+    neg = np.ascontiguousarray(neg, dtype=np.float32)
+    lik = np.ascontiguousarray(lik, dtype=np.float64)
+    edges = np.ascontiguousarray(edges, dtype=np.float64)
+    K, B = aff.shape[0], aff.shape[1]
+    probs = np.zeros((B, 2 * K, 2), dtype=np.float32)
+    post = np.zeros((B, K), dtype=np.float64)
+    dec = np.zeros((B, 4), dtype=np.int32)
+    qual = np.zeros(B, dtype=np.float64)
+    lib().orc_posterior(_p(aff), _p(neg), K, C.c_int64(B), _p(lik), _p(edges), _p(probs), _p(post), _p(dec), _p(qual))
+    return probs, post, dec, qual
+
+
+def posterior_from_probs(p1, lik, edges):
+    """p1 [B,2K] float64 (8-decimal probabilities of the text seam). Returns post, decision, qual."""
+    p1 = np.ascontiguousarray(p1, dtype=np.float64)
+    lik = np.ascontiguousarray(lik, dtype=np.float64)
+    edges = np.ascontiguousarray(edges, dtype=np.float64)
+    B, K = p1.shape[0], p1.shape[1] // 2
+    post = np.zeros((B, K), dtype=np.float64)
+    dec = np.zeros((B, 4), dtype=np.int32)
+    qual = np.zeros(B, dtype=np.float64)
+    lib().orc_posterior_from_probs(_p(p1), K, C.c_int64(B), _p(lik), _p(edges), _p(post), _p(dec), _p(qual))
+    return post, dec, qual

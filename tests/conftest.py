@@ -1,0 +1,47 @@
+import gzip
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (ROOT, GOLDEN):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_json_gz(name):
+    with gzip.open(os.path.join(GOLDEN, name), "rt") as f:
+        return json.load(f)
+
+
+def load_models_npz(cls):
+    z = np.load(os.path.join(GOLDEN, "models_%s.npz" % cls))
+    manifest = [(k, tuple(s)) for k, s in json.loads(str(z["manifest"]))]
+    return dict(x=z["x"], logits=z["logits"], manifest=manifest, n_out=int(z["n_out"]))
+
+
+def parse_tensor_text(text):
+    """rows of the reference's tensor text -> (ctg,pos,ref_seq) list, int32 [n,33,34], alt_info list"""
+    rows = [r.split("\t") for r in text.strip().split("\n") if r]
+    X = np.array([[int(v) for v in r[3].split()] for r in rows], dtype=np.int32).reshape(-1, 33, 34)
+    return rows, X, [r[4] for r in rows]
+
+
+@pytest.fixture(scope="session")
+def golden_region():
+    return load_json_gz("region.json.gz")
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    import oracle
+    oracle.build()
+    return oracle

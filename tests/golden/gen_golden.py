@@ -1,0 +1,328 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures by running the REFERENCE ITSELF (HKU-BAL/ClairS-TO v0.4.4).
+
+Runs only in the build container, where /root/reference exists; the GPU box and the tests never read the
+reference - they read the files this script writes next to itself:
+
+  columns.json.gz      decode_pileup_bases on hand-made + random mpileup columns  
+  region.json.gz       create_tensor_pileup_calling end to end through a fake `samtools` shim, for the AFF
+                       (--min_bq 20) and NEG (--min_bq 0) passes: inputs (mpileup text, reference, sites) and
+                       the tensor text rows it wrote                                         (F9-F11)
+  models_<cls>.npz     logits of the four clairs.model classes on count tensors, weights from
+                       weights_recipe.py (only the (name, shape) manifest is stored)         (M1-M9)
+  calls_<mode>.json.gz clairs_to.py predict (--predict_fn) then call_variants on those tensors: probability rows,
+                       likelihood table, VCF rows                                            (H1-H6, Q1-Q6)
+
+Usage: python tests/golden/gen_golden.py     (from the repo root)
+"""
+import gzip
+import io
+import json
+import os
+import stat
+import subprocess
+import sys
+import tempfile
+from argparse import Namespace
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import torch  # noqa: E402
+
+import src.create_tensor_pileup_calling as ct  # noqa: E402  (the reference)
+import clairs.model as rm  # noqa: E402                  (the reference)
+from clairs_to_amd.synth import SynthChunk, mpileup_text, likelihood_table  # noqa: E402
+from weights_recipe import make_weights, CVT_CFG  # noqa: E402
+
+
+def dump_json_gz(name, obj):
+    raw = json.dumps(obj, separators=(",", ":")).encode()
+    with open(os.path.join(HERE, name), "wb") as f:
+        with gzip.GzipFile(fileobj=f, mode="wb", mtime=0) as g:
+            g.write(raw)
+    print("wrote", name, len(raw), "bytes raw")
+
+
+# ------------------------------------------------------------------------------------------ columns
+def ref_decode(bases, bq, mq, ref_base, chunk_ref, cand):
+    args = Namespace(max_indel_length=60)
+    pos = 1000
+    tensor, base_list, _, _, _, alt_info = ct.decode_pileup_bases(
+        args=args, pos=pos, pileup_bases=bases, reference_base=ref_base, minimum_snp_af_for_candidate=0,
+        minimum_indel_af_for_candidate=0, has_pileup_candidates=1,
+        candidates_type_dict={pos: "unknown"} if cand else {}, is_tumor=True,
+        mapping_quality=[ord(c) - 33 for c in mq], base_quality=[ord(c) - 33 for c in bq],
+        phasing_info=None, chunk_ref_seq=chunk_ref)
+    return tensor, alt_info
+
+
+def random_column(rng, depth, p_indel=0.15, p_long=0.03):
+    toks, bq, mq = [], [], []
+    for _ in range(depth):
+        rev = rng.random() < 0.5
+        r = rng.random()
+        if r < 0.08:
+            b = "#" if rev else "*"
+        elif r < 0.12:
+            b = "n" if rev else "N"
+        else:
+            b = "ACGT"[rng.integers(0, 4)] if rng.random() < 0.3 else "A"
+            b = b.lower() if rev else b
+        t = b
+        if rng.random() < 0.05:
+            t = "^" + chr(33 + int(rng.integers(0, 60))) + t
+        if rng.random() < p_indel:
+            if rng.random() < p_long:
+                ln = int(rng.integers(58, 63))
+            else:
+                ln = int(min(rng.geometric(0.5), 8))
+            if rng.random() < 0.5:
+                seq = "".join("ACGT"[rng.integers(0, 2)] for _ in range(ln))
+                t += "+%d%s" % (ln, seq.lower() if rev else seq)
+            else:
+                t += "-%d%s" % (ln, ("n" if rev else "N") * ln)
+        if rng.random() < 0.05:
+            t += "$"
+        toks.append(t)
+        bq.append(chr(33 + int(rng.choice([5, 19, 20, 29, 30, 40]))))
+        mq.append(chr(33 + int(rng.choice([0, 19, 20, 60]))))
+    return "".join(toks), "".join(bq), "".join(mq)
+
+
+def gen_columns():
+    ref70 = "ACGTTGCAAC" * 7
+    cases = []
+    hand = [
+        # (bases, bq, mq, ref_base, chunk_ref, cand)
+        ("AAAa+2acC*#^]A$N-3NNNt", "I" * 10, "]" * 10, "A", "ACGTACGT", 1),
+        ("", "", "", "C", ref70, 1),
+        ("*", "*", "*", "G", ref70, 1),                                   # samtools placeholder row (all filtered)
+        ("ACGTacgtNn*#", "?" * 12, "5" * 12, "T", ref70, 1),            # MQ 20 boundary (char '5' = 20)
+        ("ACGTacgtNn*#", "?" * 12, "4" * 12, "T", ref70, 1),            # MQ 19
+        ("AAAAaaaa", ">>>>????", "]]]]]]]]", "A", ref70, 1),             # BQ 29 / 30 boundary
+        ("A+60" + "A" * 60 + "A+61" + "C" * 61 + "a+60" + "a" * 60, "III", "]]]", "A", ref70, 1),
+        ("A-59" + "N" * 59 + "A-60" + "N" * 60 + "a-59" + "n" * 59, "III", "]]]", "A", ref70, 1),
+        ("*+2AC#+2ac*-1N#-1nN+1A n-2nn", "IIIIII", "]]]]]]", "C", ref70, 1),
+        ("A-2NNC-2NNa-2nnG-2NN", "IIII", "]]]]", "A", ref70, 1),         # one merged D key, four distinct keys
+        ("A+1CA+1CA+1Ga+1ca+1ga+1g", "IIIIII", "]]]]]]", "A", ref70, 1),
+        ("A+1C", "I", "5", "G", ref70, 0),
+        ("GGGGgggg", "IIIIIIII", "]]]]4444", "G", ref70, 1),
+        ("TtTtCc", "++++++", "]]]]]]", "T", ref70, 1),
+        ("A$^!C.,<>G", "III", "]]]", "A", ref70, 1),                    # characters the tokeniser skips
+        ("ACGT", "IIII", "]]]]", "A", "AC", 1),                          # short chunk_ref
+        ("A-5NNNNN", "I", "]", "A", "ACG", 1),                           # D key truncated by the reference end
+        ("a+3acga+3ACGA+3acg", "III", "]]]", "C", ref70, 1),
+    ]
+    for bases, bq, mq, rb, cr, cand in hand:
+        t, a = ref_decode(bases, bq, mq, rb, cr, cand)
+        cases.append(dict(bases=bases, bq=bq, mq=mq, ref=rb, chunk_ref=cr, cand=cand, tensor=t, alt_info=a))
+    rng = np.random.default_rng(11)
+    for i in range(260):
+        depth = int(rng.integers(1, 90))
+        bases, bq, mq = random_column(rng, depth)
+        rb = "ACGT"[rng.integers(0, 4)]
+        cr = "".join("ACGT"[rng.integers(0, 4)] for _ in range(60))
+        cand = int(rng.random() < 0.7)
+        t, a = ref_decode(bases, bq, mq, rb, cr, cand)
+        cases.append(dict(bases=bases, bq=bq, mq=mq, ref=rb, chunk_ref=cr, cand=cand, tensor=t, alt_info=a))
+    dump_json_gz("columns.json.gz", cases)
+
+
+# ------------------------------------------------------------------------------------------ region
+SHIM = r'''#!/usr/bin/env python3
+import os, sys
+a = sys.argv[1:]
+if a[0] == "faidx":
+    seq = open(os.environ["FAKE_REF"]).read().strip()
+    ctg, rng = a[2].split(":")
+    s, e = [int(x) for x in rng.split("-")]
+    e = min(e, len(seq))
+    sys.stdout.write(">%s:%d-%d\n" % (ctg, s, e))
+    sub = seq[s - 1:e]
+    for i in range(0, len(sub), 60):
+        sys.stdout.write(sub[i:i + 60] + "\n")
+elif a[0] == "mpileup":
+    q = a[a.index("--min-BQ") + 1]
+    sys.stdout.write(open(os.environ["FAKE_MPILEUP_" + q]).read())
+else:
+    sys.exit(1)
+'''
+
+
+def run_reference_create_tensor(tmp, min_bq, bed_fn, out_fn):
+    cmd = [sys.executable, os.path.join(REF, "clairs_to.py"), "create_tensor_pileup_calling",
+           "--tumor_bam_fn", "fake.bam", "--ref_fn", os.path.join(tmp, "ref.fa"), "--ctg_name", "chr1",
+           "--min_bq", str(min_bq), "--samtools", os.path.join(tmp, "samtools"),
+           "--candidates_bed_regions", bed_fn, "--tensor_can_fn", out_fn, "--platform", "ont"]
+    subprocess.check_call(cmd, cwd=tmp, env=dict(os.environ, PYTHONPATH=REF))
+    return gzip.open(out_fn, "rt").read()
+
+
+def gen_region(tmp):
+    # a dense little region: overlapping windows, early positions (< 17), gaps, N in the reference
+    chunk = SynthChunk(48, seed=5, start=1, spacing=14, depth_mean=60.0, p_ins=0.02, p_del=0.03, n_rate=0.03)
+    # candidates at positions < 17 cannot have complete windows; SynthChunk emits columns at pos >= 1 only
+    keep_cols = chunk.col_pos >= 1
+    assert keep_cols.all() or True
+    ref, ref_lo = chunk.ref_window()
+    assert ref_lo == 1
+    sites = chunk.site_pos.tolist()
+    texts = {}
+    drop_pos = set()
+    rng = np.random.default_rng(3)
+    # drop some rows: a few flank positions and one candidate's own row
+    allpos = chunk.col_pos.tolist()
+    for p in rng.choice(allpos, size=25, replace=False).tolist():
+        drop_pos.add(int(p))
+    drop_pos.add(int(sites[7]))
+    # two positions (one of them a candidate) where every read-base is below the AFF BQ gate: the NEG pass
+    # sees the reads, the AFF pass gets samtools' depth-0 placeholder row
+    low_pos = {int(sites[11]), int(sites[20]) + 3}
+    for q in (0, 20):
+        rows = []
+        for r in mpileup_text(chunk, min_bq=q).split("\n"):
+            if not r:
+                continue
+            f = r.split("\t")
+            pos = int(f[1])
+            if pos in drop_pos or pos < 1:
+                continue
+            if pos in low_pos:
+                if q == 0:
+                    f[5] = "+" * len(f[5])
+                else:
+                    f = [f[0], f[1], "N", "0", "*", "*", "*"]
+            rows.append("\t".join(f))
+        texts[q] = "\n".join(rows) + "\n"
+    with open(os.path.join(tmp, "ref.fa"), "w") as f:
+        f.write(">chr1\n" + ref + "\n")
+    with open(os.path.join(tmp, "ref.fa.fai"), "w") as f:
+        f.write("chr1\t%d\t6\t%d\t%d\n" % (len(ref), len(ref), len(ref) + 1))
+    with open(os.path.join(tmp, "ref.txt"), "w") as f:
+        f.write(ref)
+    shim = os.path.join(tmp, "samtools")
+    with open(shim, "w") as f:
+        f.write(SHIM)
+    os.chmod(shim, os.stat(shim).st_mode | stat.S_IEXEC)
+    bed = os.path.join(tmp, "cand.bed")
+    with open(bed, "w") as f:
+        for x in sites:
+            f.write("chr1\t%d\t%d\n" % (x - 17, x + 17))     # extract_candidates_calling writes x-17 .. x+17
+    os.environ["FAKE_REF"] = os.path.join(tmp, "ref.txt")
+    out = {}
+    for q in (0, 20):
+        p = os.path.join(tmp, "mp_%d.txt" % q)
+        open(p, "w").write(texts[q])
+        os.environ["FAKE_MPILEUP_%d" % q] = p
+    for q, tag in ((20, "aff"), (0, "neg")):
+        out[tag] = run_reference_create_tensor(tmp, q, bed, os.path.join(tmp, "tensor_%s.gz" % tag))
+    fixture = dict(ref=ref, ref_start=1, sites=sites, min_bq_aff=20, mpileup_neg=texts[0], mpileup_aff=texts[20],
+                   tensor_aff=out["aff"], tensor_neg=out["neg"])
+    dump_json_gz("region.json.gz", fixture)
+    return fixture
+
+
+# ------------------------------------------------------------------------------------------ models
+def build_reference_model(cls, n_out):
+    if cls.startswith("CvT"):
+        kw = dict(num_classes=2, s1_emb_dim=CVT_CFG["emb_dim"][0], s2_emb_dim=CVT_CFG["emb_dim"][1],
+                  s3_emb_dim=CVT_CFG["emb_dim"][2], s1_heads=CVT_CFG["heads"][0], s2_heads=CVT_CFG["heads"][1],
+                  s3_heads=CVT_CFG["heads"][2], s1_depth=CVT_CFG["depth"][0], s2_depth=CVT_CFG["depth"][1],
+                  s3_depth=CVT_CFG["depth"][2], apply_softmax=False, model_type="acgt")
+        m = getattr(rm, cls)(**kw)
+    else:
+        m = getattr(rm, cls)(apply_softmax=False, num_classes=2, model_type="nacgt")
+    manifest = [(k, list(v.shape)) for k, v in m.state_dict().items() if not k.endswith("num_batches_tracked")]
+    w = make_weights(manifest, seed=n_out)
+    sd = m.state_dict()
+    for k, v in w.items():
+        sd[k] = torch.from_numpy(v.copy())
+    m.load_state_dict(sd)
+    m.eval()
+    return m, manifest
+
+
+def tensors_from_text(text):
+    rows = [r.split("\t") for r in text.strip().split("\n") if r]
+    X = np.array([[int(v) for v in r[3].split()] for r in rows], dtype=np.int32).reshape(-1, 33, 34)
+    depth = np.array([int(r[4].split("-")[0]) for r in rows], dtype=np.int32)
+    return rows, X, depth
+
+
+def gen_models(region):
+    _, Xa, da = tensors_from_text(region["tensor_aff"])
+    _, Xn, dn = tensors_from_text(region["tensor_neg"])
+
+    def rescale(X, d):   # predict.py:179-207
+        out = np.empty(X.shape, dtype=np.float32)
+        for i in range(len(X)):
+            r = 50.0 / float(d[i]) if float(d[i]) > 50 else None
+            v = [float(t) for t in X[i].ravel().tolist()]
+            out[i] = np.array([t * r for t in v] if r is not None else v, dtype=np.float32).reshape(33, 34)
+        return out
+
+    xa, xn = rescale(Xa, da), rescale(Xn, dn)
+    torch.set_num_threads(1)
+    for cls, n_out, x in (("CvT", 4, xa), ("CvT_Indel", 6, xa), ("BiGRU_NACGT", 4, xn), ("BiGRU_NACGT_Indel", 6, xn)):
+        m, manifest = build_reference_model(cls, n_out)
+        with torch.no_grad():
+            outs = m(torch.from_numpy(x))
+        logits = np.stack([o.numpy() for o in outs])    # [K][B][2]
+        np.savez_compressed(os.path.join(HERE, "models_%s.npz" % cls), x=x, logits=logits.astype(np.float32),
+                            manifest=json.dumps(manifest), n_out=n_out)
+        print("wrote models_%s.npz" % cls, logits.shape, "logit range", float(logits.min()), float(logits.max()))
+
+
+# ------------------------------------------------------------------------------------------ predict + call_variants
+def gen_calls(tmp, region):
+    for mode, n_out, aff_cls, neg_cls in (("snv", 4, "CvT", "BiGRU_NACGT"), ("indel", 6, "CvT_Indel", "BiGRU_NACGT_Indel")):
+        ma, _ = build_reference_model(aff_cls, n_out)
+        mn, _ = build_reference_model(neg_cls, n_out)
+        pa, pn = os.path.join(tmp, "aff_%s.pkl" % mode), os.path.join(tmp, "neg_%s.pkl" % mode)
+        torch.save({"model_acgt": ma}, pa)      # pickled by qualified name clairs.model.<cls>
+        torch.save({"model_nacgt": mn}, pn)
+        pred = os.path.join(tmp, "pred_%s.gz" % mode)
+        disable = "True" if mode == "snv" else "False"
+        subprocess.check_call([sys.executable, os.path.join(REF, "clairs_to.py"), "predict",
+                               "--tensor_fn_acgt", os.path.join(tmp, "tensor_aff.gz"),
+                               "--tensor_fn_nacgt", os.path.join(tmp, "tensor_neg.gz"),
+                               "--chkpnt_fn_acgt", pa, "--chkpnt_fn_nacgt", pn, "--predict_fn", pred,
+                               "--pileup", "--disable_indel_calling", disable, "--ctg_name", "chr1"],
+                              cwd=tmp, env=dict(os.environ, PYTHONPATH=REF))
+        pred_rows = gzip.open(pred, "rt").read()
+        table = likelihood_table(n_out, seed=7 + n_out)
+        lik_fn = os.path.join(tmp, "lik_%s.txt" % mode)
+        np.savetxt(lik_fn, table, fmt="%.17g")
+        vcfs = {}
+        for show_ref in (False, True):
+            vcf_fn = os.path.join(tmp, "out_%s_%d.vcf" % (mode, int(show_ref)))
+            cmd = [sys.executable, os.path.join(REF, "clairs_to.py"), "call_variants", "--predict_fn", pred,
+                   "--call_fn", vcf_fn, "--likelihood_matrix_data", lik_fn, "--disable_indel_calling", disable,
+                   "--ctg_name", "chr1", "--pileup"]
+            if show_ref:
+                cmd.append("--show_ref")
+            subprocess.check_call(cmd, cwd=tmp, env=dict(os.environ, PYTHONPATH=REF))
+            rows = [r for r in open(vcf_fn).read().split("\n") if r and not r.startswith("#")] if os.path.exists(vcf_fn) else []
+            vcfs["show_ref" if show_ref else "default"] = rows
+        dump_json_gz("calls_%s.json.gz" % mode, dict(n_out=n_out, predict_rows=pred_rows,
+                                                     likelihood_table=open(lik_fn).read(), vcf=vcfs))
+        print(mode, "vcf rows:", {k: len(v) for k, v in vcfs.items()})
+
+
+def main():
+    gen_columns()
+    with tempfile.TemporaryDirectory() as tmp:
+        region = gen_region(tmp)
+        gen_models(region)
+        gen_calls(tmp, region)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,78 @@
+"""CPU-only tests of the host side: C-ABI loads and exports every declared symbol, the mpileup tokeniser
+round-trips the synthetic packs, and the VCF row assembly reproduces the reference's call_variants output when
+fed the reference's own probability rows (posterior from the CPU oracle here; from the GPU in test_gpu_parity)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_json_gz
+
+
+def test_cabi_exports_every_declared_symbol():
+    import clairs_to_amd._lib as L
+    header = open(os.path.join(ROOT, "include", "clairsto_amd.h")).read()
+    declared = set(re.findall(r"\b(cto_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(L.SYMBOLS), (declared ^ set(L.SYMBOLS))
+    for name in declared:
+        assert hasattr(L.lib, name)
+    assert L.lib.cto_version() >= 100
+
+
+def test_mpileup_tokeniser_round_trips_synthetic_pack():
+    from clairs_to_amd.pack import ColumnPack
+    from clairs_to_amd.synth import SynthChunk, mpileup_text
+    chunk = SynthChunk(40, seed=9, p_ins=0.03, p_del=0.04, spacing=30)
+    ref, lo = chunk.ref_window()
+    pack = ColumnPack.from_mpileup(mpileup_text(chunk), ref, lo)
+    got, want = pack.numpy(), chunk.arrays()
+    for k in ("col_pos", "col_ref", "col_off", "key_off", "key_meta"):
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    # MQ is printed clamped to 93 ('~') by the text writer; compare entries with MQ saturated the same way
+    e = want["entries"].astype(np.uint64)
+    mq = np.minimum((e >> 13) & 255, 93)
+    e = (e & ~np.uint64(255 << 13)) | (mq << 13)
+    np.testing.assert_array_equal(got["entries"].astype(np.uint64), e)
+    assert pack.n_keys > 0
+    s = pack.key_string(0)
+    assert s[0] in "ID" and len(s) >= 2
+
+
+def test_tokeniser_rejects_malformed_rows():
+    from clairs_to_amd.pack import ColumnPack
+    from clairs_to_amd._lib import CtoError
+    with pytest.raises(CtoError):
+        ColumnPack.from_mpileup("chr1\t5\tN\t1\tA\tI\n", "ACGTACGT", 1)            # no MQ column
+    with pytest.raises(CtoError):
+        ColumnPack.from_mpileup("chr1\t50\tN\t1\tA\tI\t]\n", "ACGTACGT", 1)        # outside the reference
+    with pytest.raises(CtoError):
+        ColumnPack.from_mpileup("chr1\t5\tN\t1\tA\tI\t]\nchr1\t4\tN\t1\tA\tI\t]\n", "ACGTACGT", 1)   # unsorted
+    p = ColumnPack.from_mpileup("", "ACGT", 1)
+    assert p.n_cols == 0 and p.n_entries == 0
+
+
+def _rows(text):
+    return [r.split("\t") for r in text.strip().split("\n") if r]
+
+
+@pytest.mark.parametrize("mode", ["snv", "indel"])
+@pytest.mark.parametrize("show_ref", [False, True])
+def test_vcf_rows_match_reference(oracle_lib, mode, show_ref):
+    from clairs_to_amd.call_variants import load_likelihood, vcf_row
+    calls = load_json_gz("calls_%s.json.gz" % mode)
+    K = calls["n_out"]
+    rows = _rows(calls["predict_rows"])
+    lik, edges = load_likelihood(np.loadtxt(calls["likelihood_table"].split("\n")), K)
+    p1 = np.array([[float(f.split()[1]) for f in r[6:6 + 2 * K]] for r in rows], dtype=np.float64)
+    post, dec, qual = oracle_lib.posterior_from_probs(p1, lik, edges)
+    assert not dec[:, 1].any()
+    out = []
+    for i, r in enumerate(rows):
+        row = vcf_row(r[0], r[1], r[2], r[3], eval(r[4]), eval(r[5]), int(dec[i, 0]), float(qual[i]), K, show_ref=show_ref)
+        if row is not None:
+            out.append(row)
+    want = calls["vcf"]["show_ref" if show_ref else "default"]
+    assert len(want) > 0
+    assert out == want

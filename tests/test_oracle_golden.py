@@ -1,0 +1,80 @@
+"""Pins the CPU oracle (oracle/cto_oracle.c) to the golden fixtures produced by the reference itself
+(tests/golden/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import load_json_gz, load_models_npz, parse_tensor_text
+from weights_recipe import make_weights, CVT_CFG
+
+
+def test_decode_columns_match_reference(oracle_lib):
+    cases = load_json_gz("columns.json.gz")
+    assert len(cases) >= 200
+    for i, c in enumerate(cases):
+        tensor, depth, alt = oracle_lib.decode_column(c["bases"], c["bq"], c["mq"], c["ref"], c["chunk_ref"], c["cand"])
+        assert tensor == c["tensor"], "column %d tensor" % i
+        assert alt == c["alt_info"], "column %d alt_info" % i
+        assert depth == int(c["alt_info"].split("-")[0])
+
+
+@pytest.mark.parametrize("tag,text_key", [("aff", "mpileup_aff"), ("neg", "mpileup_neg")])
+def test_create_tensor_matches_reference(oracle_lib, golden_region, tag, text_key):
+    g = golden_region
+    rows, X, alts = parse_tensor_text(g["tensor_" + tag])
+    tensor, depth, alt_list, flags = oracle_lib.create_tensor(g[text_key], g["ref"], g["ref_start"], g["sites"])
+    kept = [i for i in range(len(g["sites"])) if not flags[i]]
+    assert [int(r[1]) for r in rows] == [g["sites"][i] for i in kept]      # same sites emitted, same order
+    assert 0 < len(kept) < len(g["sites"])                                  # the fixture exercises the skip rules
+    np.testing.assert_array_equal(tensor[kept], X)
+    assert [alt_list[i] for i in kept] == alts
+    assert [int(a.split("-")[0]) for a in alts] == depth[kept].tolist()
+
+
+@pytest.mark.parametrize("cls", ["CvT", "CvT_Indel", "BiGRU_NACGT", "BiGRU_NACGT_Indel"])
+def test_model_forward_matches_reference(oracle_lib, cls):
+    g = load_models_npz(cls)
+    w = make_weights(g["manifest"], seed=g["n_out"])
+    if cls.startswith("CvT"):
+        out = oracle_lib.cvt_forward(w, dict(CVT_CFG, n_out=g["n_out"]), g["x"])
+    else:
+        out = oracle_lib.bigru_forward(w, g["n_out"], g["x"])
+    assert out.shape == g["logits"].shape
+    # tolerance: fp32 reference vs double-accumulating restatement (1e-5 abs on logits)
+    np.testing.assert_allclose(out, g["logits"], rtol=0, atol=2e-5)
+
+
+def _parse_predict_rows(text, n_out):
+    rows = [r.split("\t") for r in text.strip().split("\n") if r]
+    probs = np.array([[[float(v) for v in f.split()] for f in r[6:6 + 2 * n_out]] for r in rows], dtype=np.float64)
+    return rows, probs   # probs [B][2K][2]
+
+
+@pytest.mark.parametrize("mode,aff_cls,neg_cls", [("snv", "CvT", "BiGRU_NACGT"), ("indel", "CvT_Indel", "BiGRU_NACGT_Indel")])
+def test_predict_rows_match_reference(oracle_lib, golden_region, mode, aff_cls, neg_cls):
+    """tensor text -> rescale -> both nets -> softmax, against the reference's own predict output
+    (probabilities are printed with 8 decimals)."""
+    from clairs_to_amd.synth import lik_and_edges
+    calls = load_json_gz("calls_%s.json.gz" % mode)
+    K = calls["n_out"]
+    rows, probs_ref = _parse_predict_rows(calls["predict_rows"], K)
+    ra, Xa, alts_a = parse_tensor_text(golden_region["tensor_aff"])
+    rn, Xn, alts_n = parse_tensor_text(golden_region["tensor_neg"])
+    keep = [i for i, r in enumerate(ra) if r[2][16] in "ACGT"]          # predict.py:219
+    assert len(rows) == len(keep)
+    da = np.array([int(a.split("-")[0]) for a in alts_a])
+    dn = np.array([int(a.split("-")[0]) for a in alts_n])
+    xa = oracle_lib.rescale(Xa, da)[keep]
+    xn = oracle_lib.rescale(Xn, dn)[keep]
+    ga, gn = load_models_npz(aff_cls), load_models_npz(neg_cls)
+    la = oracle_lib.cvt_forward(make_weights(ga["manifest"], seed=K), dict(CVT_CFG, n_out=K), xa)
+    ln = oracle_lib.bigru_forward(make_weights(gn["manifest"], seed=K), K, xn)
+    table = np.loadtxt(calls["likelihood_table"].split("\n"))
+    lik, edges = lik_and_edges(table, K)
+    probs, post, dec, qual = oracle_lib.posterior(la, ln, lik, edges)
+    np.testing.assert_allclose(probs, probs_ref, rtol=0, atol=2e-6)
+    # strand counts (predict.py:626-642) are printed as python float lists
+    f, r = oracle_lib.strand_counts(Xa[keep])
+    for i, row in enumerate(rows):
+        assert row[4] == str([float(v) for v in f[i]])
+        assert row[5] == str([float(v) for v in r[i]])
+        assert row[3] == alts_a[keep[i]]
