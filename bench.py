@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: candidate sites/s for pileup-tensor creation + AFF + NEG inference + posterior.
+
+One "step" = one pass of the whole hot path over one 4096-site chunk of the ONT 50x synthetic SNV job
+(BASELINE.json configs[1]: "ONT 50x synthetic BAM, 1M candidate SNV sites, batch=4096, 1xMI355X"); the
+column packs of the chunks are resident in HBM before the timed region starts.  With N > 1 ranks
+(torch.distributed over RCCL, one rank per GPU) every rank processes its own chunks (sites shard with no
+cross-site dependence) and the per-site probabilities are gathered over xGMI each step.
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events around the dominant kernel
+(the BiGRU layer-2 recurrent kernel), `cpu_baseline` times the CPU oracle on a bounded sample of the same
+workload on the host cores of this box.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BATCH = 4096
+N_OUT = 4
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+
+
+def cpu_baseline(chunk, models, lik, edges, min_bq, n_sample, budget_s=25.0):
+    """CPU oracle (scalar C port of the reference path, OpenMP over sites) on the first n_sample sites."""
+    import numpy as np
+    import oracle
+    from clairs_to_amd.synth import mpileup_text
+    oracle.build()
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    sites = chunk.site_pos[:n_sample]
+    last_col = int(np.searchsorted(chunk.col_pos, int(sites[-1]) + 17, side="right"))
+    ref, lo = chunk.ref_window()
+    texts = {q: mpileup_text(chunk, q, col_range=(0, last_col)) for q in (min_bq, 0)}      # untimed input prep
+    cfg = dict(emb_dim=(16, 64, 128), heads=(1, 3, 4), depth=(1, 2, 3), n_out=N_OUT)
+    t0 = time.perf_counter()
+    ta, da, _, _ = oracle.create_tensor(texts[min_bq], ref, lo, sites)
+    tn, dn, _, _ = oracle.create_tensor(texts[0], ref, lo, sites)
+    xa, xn = oracle.rescale(ta, da), oracle.rescale(tn, dn)
+    la = oracle.cvt_forward(models["aff_weights"], cfg, xa)
+    ln = oracle.bigru_forward(models["neg_weights"], N_OUT, xn)
+    probs, post, dec, qual = oracle.posterior(la, ln, lik, edges)
+    dt = time.perf_counter() - t0
+    return dict(value=round(len(sites) / dt, 2), unit="sites/s", cores=cores, kind="port",
+                sample="%d sites of the same synthetic chunk (mpileup text of both passes -> tensors -> CvT + BiGRU -> "
+                       "posterior), CPU oracle oracle/cto_oracle.c, OpenMP over sites, %.1f s" % (len(sites), dt)), probs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pool", type=int, default=4, help="distinct synthetic chunks resident in HBM per rank")
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=768)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from clairs_to_amd._lib import lib, check
+    from clairs_to_amd.engine import Engine, synthetic_models
+    from clairs_to_amd.synth import SynthChunk, likelihood_table, lik_and_edges
+    import ctypes as C
+
+    min_bq = 20                                              # ONT sup models: shared/param.py min_bq_dict
+    models = synthetic_models(N_OUT, seed=0)
+    lik, edges = lik_and_edges(likelihood_table(N_OUT), N_OUT)
+    eng = Engine(models["aff"], models["neg"], lik, edges, min_bq=min_bq, device=dev)
+
+    # ---- synthetic job: `pool` chunks per rank, packs resident in HBM ----
+    chunks, packs, sites = [], [], []
+    for i in range(args.pool):
+        ch = SynthChunk(args.batch, seed=20260928 + 1000 * rank + i, start=100000 + (rank * args.pool + i) * 2000000)
+        chunks.append(ch)
+        packs.append(eng.upload(ch.arrays()))
+        sites.append(torch.from_numpy(ch.site_pos).to(dev))
+    pack_bytes = sum(p.nbytes() for p in packs) / len(packs)
+    gather_buf = torch.empty((world, args.batch, 2 * N_OUT, 2), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step(i):
+        out = eng.run_device(packs[i % args.pool], sites[i % args.pool])
+        if world > 1:
+            dist.all_gather_into_tensor(gather_buf, out["probs"])     # per-site outputs to every rank over xGMI
+        return out
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    check(lib.cto_model_profile(eng.h_neg, 1))
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    check(lib.cto_model_profile(eng.h_neg, 0))
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline of the dominant kernel (BiGRU layer-2 recurrent kernel), live HIP-event timing ----
+    mean_ms, macs = C.c_double(0.0), C.c_int64(0)
+    n_meas = check(lib.cto_model_profile_read(eng.h_neg, C.byref(mean_ms), C.byref(macs)))
+    flops_per_launch = 2.0 * macs.value * args.batch
+    achieved = flops_per_launch / (mean_ms.value * 1e-3) / 1e12 if n_meas > 0 and mean_ms.value > 0 else 0.0
+
+    if rank == 0:
+        sites_total = world * args.steps * args.batch
+        res = {
+            "metric": "candidate sites/sec (pileup-tensor + AFF/NEG inference) at 1/2/4/8 MI355X",
+            "value": round(sites_total / dt, 1), "unit": "sites/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ONT 50x synthetic pileups, SNV (K=4), 1M-site job cut into %d-site chunks "
+                                   "(BASELINE.json configs[1]); step = featurize(AFF+NEG) + CvT + BiGRU + posterior on one chunk"
+                                   % args.batch,
+                       "batch": args.batch, "chunks_resident_per_gpu": args.pool, "min_bq_aff": min_bq,
+                       "pack_bytes_per_chunk": int(pack_bytes),
+                       "parallelism": "sites sharded, 1 rank/GPU" + (", all_gather of per-site probabilities (RCCL)" if world > 1 else ""),
+                       "weights": "seeded random init (no pretrained weights offline)"},
+            "roofline": {"bound": "mfma", "kernel": "k_gru_layer<256,256,192,2> (BiGRU layer 2, both directions)",
+                         "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "launch_ms": round(mean_ms.value, 4), "launches_measured": int(n_meas),
+                         "flops_per_launch": flops_per_launch},
+            "end_to_end_tflops": round(2.0 * eng.macs_per_site * sites_total / dt / 1e12, 3),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, probs_cpu = cpu_baseline(chunks[0], models, lik, edges, min_bq, min(args.cpu_sample, args.batch))
+            res["cpu_baseline"] = cb
+            got = eng.run_device(packs[0], sites[0])["probs"][: probs_cpu.shape[0]].cpu().numpy()
+            res["parity_max_abs_dP_vs_cpu_sample"] = float(np.abs(got - probs_cpu).max())
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

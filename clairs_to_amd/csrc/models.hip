@@ -76,9 +76,16 @@ struct cto_model {
     // workspace
     int64_t ws_B = 0;
     std::vector<void*> ws_ptrs;
+    // live kernel timing (cto_model_profile)
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+    int64_t prof_macs = 0;
     float *b_h = nullptr, *b_t = nullptr, *b_yq = nullptr, *b_ykv = nullptr, *b_q = nullptr, *b_kv = nullptr,
           *b_o = nullptr, *b_u = nullptr, *b_g = nullptr, *b_u2 = nullptr, *b_slab = nullptr;
-    ~cto_model() { for (void* p : ws_ptrs) (void)hipFree(p); }
+    ~cto_model() {
+        for (void* p : ws_ptrs) (void)hipFree(p);
+        for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    }
 };
 
 namespace {
@@ -297,10 +304,23 @@ int launch_gru(hipStream_t s, const float* x, const float* W, const float* bias,
     return CTO_OK;
 }
 
+int prof_begin(cto_model* m, hipStream_t s, hipEvent_t* e0, hipEvent_t* e1) {
+    CTO_HIP(hipEventCreate(e0));
+    CTO_HIP(hipEventCreate(e1));
+    CTO_HIP(hipEventRecord(*e0, s));
+    return CTO_OK;
+}
+
 int bigru_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStream_t s) {
     int rc;
     if ((rc = launch_gru<34, 48, 128, 2>(s, x, m->gw1, m->gb1, m->b_h, B))) return rc;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (m->prof && (rc = prof_begin(m, s, &e0, &e1))) return rc;
     if ((rc = launch_gru<256, 256, 192, 2>(s, m->b_h, m->gw2, m->gb2, m->b_t, B))) return rc;
+    if (m->prof) {
+        CTO_HIP(hipEventRecord(e1, s));
+        m->prof_ev.emplace_back(e0, e1);
+    }
     return run_head(m, s, m->b_t, B, logits);
 }
 
@@ -440,7 +460,42 @@ extern "C" int cto_model_forward(cto_model* m, const float* x, int64_t B, float*
     int rc = ensure_ws(m, B);
     if (rc != CTO_OK) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return m->kind == 0 ? cvt_forward(m, x, B, logits, s) : bigru_forward(m, x, B, logits, s);
+    if (m->kind == 1) return bigru_forward(m, x, B, logits, s);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (m->prof && (rc = prof_begin(m, s, &e0, &e1))) return rc;
+    rc = cvt_forward(m, x, B, logits, s);
+    if (m->prof && rc == CTO_OK) {
+        CTO_HIP(hipEventRecord(e1, s));
+        m->prof_ev.emplace_back(e0, e1);
+    }
+    return rc;
+}
+
+extern "C" int cto_model_profile(cto_model* m, int enable) {
+    CTO_REQUIRE(m, CTO_EINVAL, "cto_model_profile: null model");
+    m->prof = enable != 0;
+    // per-site MACs of the measured kernel: BiGRU layer 2 (both directions), or the whole CvT
+    m->prof_macs = m->kind == 1 ? int64_t(33) * 2 * 3 * 192 * (256 + 192) : m->macs;
+    return CTO_OK;
+}
+
+extern "C" int cto_model_profile_read(cto_model* m, double* mean_ms, int64_t* macs_per_site) {
+    CTO_REQUIRE(m && mean_ms && macs_per_site, CTO_EINVAL, "cto_model_profile_read: null argument");
+    double sum = 0.0;
+    int n = 0;
+    for (auto& e : m->prof_ev) {
+        CTO_HIP(hipEventSynchronize(e.second));
+        float ms = 0.f;
+        CTO_HIP(hipEventElapsedTime(&ms, e.first, e.second));
+        sum += ms;
+        ++n;
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    m->prof_ev.clear();
+    *mean_ms = n ? sum / n : 0.0;
+    *macs_per_site = m->prof_macs;
+    return n;
 }
 
 extern "C" int64_t cto_model_macs_per_site(const cto_model* m) { return m ? m->macs : 0; }

@@ -1,0 +1,117 @@
+"""End-to-end hot path for one GPU: column pack -> pileup tensors -> AFF + NEG networks -> posterior.
+
+This is what replaces STEP 2a-2d / 6-1..6-3 of run_clairs_to (reference: run_clairs_to:1228-1308, 1562-1647)
+for one chunk of candidate sites.  Everything between the pack upload and the posterior stays in HBM:
+no text tensors, no gzip pipes, no host round trips.  The AFF and NEG networks are independent given the two
+tensors, so they run on two HIP streams.
+"""
+import numpy as np
+import torch
+
+from ._lib import lib, check, c_vp
+from .call_variants import Posterior
+from .featurize import featurize
+from .nn_shims import CvT, CvT_Indel, BiGRU_NACGT, BiGRU_NACGT_Indel
+from .pack import DevicePack
+
+CVT_PREDICT_CFG = dict(s1_emb_dim=16, s2_emb_dim=64, s3_emb_dim=128, s1_heads=1, s2_heads=3, s3_heads=4,
+                       s1_depth=1, s2_depth=2, s3_depth=3)        # clairs/predict.py:520-553
+
+
+def random_state_dict(module, seed=0, head_gain=2.0):
+    """Seeded synthetic weights (no pretrained weights exist offline): uniform with fan-in scaling so that
+    activations stay O(1); BatchNorm statistics randomised.  Returns dict name -> float32 numpy array."""
+    import zlib
+    out = {}
+    for name, t in module.state_dict().items():
+        if name.endswith("num_batches_tracked"):
+            continue
+        shape = tuple(t.shape)
+        r = np.random.default_rng([zlib.crc32(name.encode()) & 0xffffffff, seed])
+        if name.endswith("running_var"):
+            a = r.uniform(0.5, 1.5, size=shape)
+        elif name.endswith("running_mean"):
+            a = r.uniform(-0.2, 0.2, size=shape)
+        elif name.endswith(".g") or ".net.1.weight" in name:
+            a = r.uniform(0.8, 1.2, size=shape)
+        elif name.endswith(".b") or name.endswith("bias") or "bias_" in name:
+            a = r.uniform(-0.1, 0.1, size=shape)
+        else:
+            fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+            if len(shape) == 4 and shape[1] == 1:
+                fan_in = 3
+            elif len(shape) == 4 and shape[2] == 3:
+                fan_in = shape[1] * 3
+            bound = (3.0 / fan_in) ** 0.5
+            if "_fc3" in name:
+                bound *= head_gain
+            if name.startswith("layer1.0.") or name.startswith("lstm.weight_ih"):
+                bound *= 0.05
+            a = r.uniform(-bound, bound, size=shape)
+        out[name] = a.astype(np.float32)
+    return out
+
+
+def synthetic_models(n_out=4, seed=0):
+    """Random-init AFF/NEG modules of the reference architecture (predict.py configuration)."""
+    aff_cls, neg_cls = (CvT, BiGRU_NACGT) if n_out == 4 else (CvT_Indel, BiGRU_NACGT_Indel)
+    aff = aff_cls(model_type="acgt", **CVT_PREDICT_CFG).eval()
+    neg = neg_cls(model_type="nacgt").eval()
+    out = {}
+    for tag, m in (("aff", aff), ("neg", neg)):
+        w = random_state_dict(m, seed=seed + n_out)
+        sd = m.state_dict()
+        for k, v in w.items():
+            sd[k] = torch.from_numpy(v)
+        m.load_state_dict(sd)
+        out[tag] = m
+        out[tag + "_weights"] = w
+    return out
+
+
+class Engine:
+    """One GPU's worth of the hot path.  aff/neg: nn_shims modules (or anything exposing `_handle()`)."""
+
+    def __init__(self, aff, neg, lik, edges, min_bq=20, min_rescale_cov=50, device="cuda", two_streams=True):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("clairs_to_amd.Engine needs a HIP device; there is no CPU fallback")
+        self.aff, self.neg = aff, neg
+        self.K = len(aff._heads_out)
+        assert len(neg._heads_out) == self.K
+        self.min_bq, self.min_rescale_cov = int(min_bq), int(min_rescale_cov)
+        with torch.cuda.device(self.device):
+            self.h_aff, self.h_neg = aff._handle(), neg._handle()
+            self.posterior = Posterior(lik, edges, self.device)
+            self.s_neg = torch.cuda.Stream(self.device) if two_streams else None
+        self.macs_per_site = int(lib.cto_model_macs_per_site(self.h_aff)) + int(lib.cto_model_macs_per_site(self.h_neg))
+
+    def upload(self, arrays):
+        return DevicePack(arrays, self.device)
+
+    def run_device(self, dev_pack, site_pos_dev, want_raw=False):
+        """All inputs already resident in HBM. Returns device tensors."""
+        with torch.cuda.device(self.device):
+            feat = featurize(dev_pack, site_pos_dev, self.min_bq, self.min_rescale_cov, want_raw=want_raw)
+            B, K = site_pos_dev.numel(), self.K
+            la = torch.empty((K, B, 2), dtype=torch.float32, device=self.device)
+            ln = torch.empty((K, B, 2), dtype=torch.float32, device=self.device)
+            main = torch.cuda.current_stream()
+            if self.s_neg is not None:
+                self.s_neg.wait_stream(main)
+                check(lib.cto_model_forward(self.h_neg, feat.x_neg.data_ptr(), B, ln.data_ptr(), int(self.s_neg.cuda_stream)))
+                check(lib.cto_model_forward(self.h_aff, feat.x_aff.data_ptr(), B, la.data_ptr(), int(main.cuda_stream)))
+                main.wait_stream(self.s_neg)
+                feat.x_neg.record_stream(self.s_neg)
+                ln.record_stream(self.s_neg)
+            else:
+                check(lib.cto_model_forward(self.h_neg, feat.x_neg.data_ptr(), B, ln.data_ptr(), int(main.cuda_stream)))
+                check(lib.cto_model_forward(self.h_aff, feat.x_aff.data_ptr(), B, la.data_ptr(), int(main.cuda_stream)))
+            out = self.posterior(la, ln)
+        out.update(aff_logits=la, neg_logits=ln, site_info=feat.site_info, features=feat)
+        return out
+
+    def run_chunk(self, arrays, site_pos):
+        dp = self.upload(arrays)
+        sp = torch.as_tensor(np.ascontiguousarray(site_pos, dtype=np.int32)).to(self.device)
+        return self.run_device(dp, sp)

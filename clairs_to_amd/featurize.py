@@ -36,9 +36,9 @@ def featurize(dev_pack, site_pos, min_bq, min_rescale_cov=50, want_raw=False, wa
     site_pos = site_pos.contiguous()
     n = site_pos.numel()
     nc, nk = dev_pack.n_cols, dev_pack.n_keys
-    colvec = torch.empty((nc, COLVEC_STRIDE), dtype=torch.int16, device=dev)
-    coldepth = torch.empty((nc, 2), dtype=torch.int32, device=dev)
-    colfirst = torch.empty((nc, 4), dtype=torch.int32, device=dev)
+    colvec = torch.empty((max(nc, 1), COLVEC_STRIDE), dtype=torch.int16, device=dev)   # never a null pointer
+    coldepth = torch.empty((max(nc, 1), 2), dtype=torch.int32, device=dev)
+    colfirst = torch.empty((max(nc, 1), 4), dtype=torch.int32, device=dev)
     keycnt = torch.empty((max(nk, 1),), dtype=torch.int32, device=dev)
     keyfirst = torch.empty((max(nk, 1),), dtype=torch.int32, device=dev)
     s = current_stream_ptr()
@@ -53,7 +53,7 @@ def featurize(dev_pack, site_pos, min_bq, min_rescale_cov=50, want_raw=False, wa
     check(lib.cto_gather_windows(C.byref(dev_pack.view), colvec.data_ptr(), coldepth.data_ptr(), site_pos.data_ptr(), n,
                                  int(min_rescale_cov) if min_rescale_cov else 0, ptr(x_aff), ptr(x_neg), ptr(raw_aff),
                                  ptr(raw_neg), site_info.data_ptr(), s))
-    return Features(x_aff, x_neg, raw_aff, raw_neg, site_info, colvec, coldepth, colfirst, keycnt[:nk], keyfirst[:nk])
+    return Features(x_aff, x_neg, raw_aff, raw_neg, site_info, colvec[:nc], coldepth[:nc], colfirst[:nc], keycnt[:nk], keyfirst[:nk])
 
 
 def alt_infos(feat, host_pack, site_info_host=None):

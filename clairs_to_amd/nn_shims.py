@@ -128,6 +128,8 @@ class _HipNet(nn.Module):
             raise ValueError("expected [B,%d,%d], got %s" % (NPOS, NCHAN, tuple(x.shape)))
         x = x.to(torch.float32).contiguous()
         out = torch.empty((len(self._heads_out), x.shape[0], 2), dtype=torch.float32, device=x.device)
+        if x.shape[0] == 0:
+            return out
         with torch.cuda.device(x.device):
             check(lib.cto_model_forward(self._handle(), x.data_ptr(), x.shape[0], out.data_ptr(), current_stream_ptr()))
         return out

@@ -154,6 +154,13 @@ int cto_model_forward(cto_model* m, const float* x, int64_t B, float* logits, vo
 int64_t cto_model_macs_per_site(const cto_model* m);
 int  cto_model_n_out(const cto_model* m);
 void cto_model_destroy(cto_model* m);
+/* Live kernel timing for roofline accounting: when enabled, the dominant kernel of the model (BiGRU: the
+ * layer-2 recurrent kernel; CvT: the whole forward) is bracketed by HIP events on the launch stream.
+ * cto_model_profile_read waits for the recorded events, returns the number of launches measured since the
+ * last read, writes their mean duration in milliseconds and the algorithmic multiply-accumulates of ONE site
+ * in that kernel (launch MACs = per-site MACs x batch). */
+int cto_model_profile(cto_model* m, int enable);
+int cto_model_profile_read(cto_model* m, double* mean_ms, int64_t* macs_per_site);
 
 /* ------------------------------------------------------------------------------------------------
  * Posterior / decision / quality (clairs/call_variants.py:154-304, 79-88), fused with the 2-way

@@ -1,0 +1,178 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path through the C ABI against
+(a) the golden fixtures produced by the reference and (b) the CPU oracle on seeded synthetic inputs."""
+import numpy as np
+import pytest
+
+from conftest import load_json_gz, load_models_npz, parse_tensor_text
+from weights_recipe import make_weights, CVT_CFG
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _featurize_text(text, ref, ref_start, sites, min_bq, dev, rescale=50):
+    import torch
+    from clairs_to_amd.pack import ColumnPack
+    from clairs_to_amd.featurize import featurize, alt_infos
+    pack = ColumnPack.from_mpileup(text, ref, ref_start)
+    dp = pack.to_device(dev)
+    feat = featurize(dp, torch.tensor(sites, dtype=torch.int32, device=dev), min_bq, rescale, want_raw=True)
+    torch.cuda.synchronize()
+    return pack, feat, alt_infos(feat, pack)
+
+
+def test_featurize_matches_reference_region(dev, golden_region):
+    """mpileup text (NEG pass, --min-BQ 0) -> pack -> HIP: both tensors, depths, alt_info and skip rules must equal
+    what the reference's create_tensor_pileup_calling wrote for its two passes (bit-exact)."""
+    g = golden_region
+    pack, feat, alts = _featurize_text(g["mpileup_neg"], g["ref"], g["ref_start"], g["sites"], g["min_bq_aff"], dev)
+    info = feat.site_info.cpu().numpy()
+    kept = np.nonzero(info[:, 3] == 0)[0]
+    for tag, raw, dcol in (("aff", feat.raw_aff, 1), ("neg", feat.raw_neg, 2)):
+        rows, X, alt_ref = parse_tensor_text(g["tensor_" + tag])
+        assert [int(r[1]) for r in rows] == [g["sites"][i] for i in kept]
+        np.testing.assert_array_equal(raw.cpu().numpy()[kept].astype(np.int32), X)
+        assert info[kept, dcol].tolist() == [int(a.split("-")[0]) for a in alt_ref]
+        if tag == "aff":
+            assert [alts[i] for i in kept] == alt_ref
+
+
+def test_featurize_matches_oracle_synthetic(dev, oracle_lib):
+    """Seeded synthetic chunk generated directly as a pack (the bench generator) vs the oracle run on the
+    equivalent mpileup text of each pass; includes the rescaled fp32 network inputs and strand counts."""
+    import torch
+    from clairs_to_amd.pack import DevicePack
+    from clairs_to_amd.featurize import featurize
+    from clairs_to_amd.synth import SynthChunk, mpileup_text
+    chunk = SynthChunk(300, seed=123, spacing=40, p_ins=0.01, p_del=0.02, depth_mean=70.0)
+    ref, lo = chunk.ref_window()
+    dp = DevicePack(chunk.arrays(), dev)
+    feat = featurize(dp, torch.from_numpy(chunk.site_pos).to(dev), 20, 50, want_raw=True)
+    torch.cuda.synchronize()
+    info = feat.site_info.cpu().numpy()
+    for q, raw, x, dcol in ((20, feat.raw_aff, feat.x_aff, 1), (0, feat.raw_neg, feat.x_neg, 2)):
+        t, depth, _, flags = oracle_lib.create_tensor(mpileup_text(chunk, min_bq=q), ref, lo, chunk.site_pos)
+        np.testing.assert_array_equal(info[:, 3] & 1, flags)
+        np.testing.assert_array_equal(raw.cpu().numpy().astype(np.int32), t)
+        np.testing.assert_array_equal(info[:, dcol], depth)
+        np.testing.assert_array_equal(x.cpu().numpy(), oracle_lib.rescale(t, depth))      # bit-exact fp32
+        if q == 20:
+            f, r = oracle_lib.strand_counts(t)
+            np.testing.assert_array_equal(info[:, 4:8], f)
+            np.testing.assert_array_equal(info[:, 8:12], r)
+
+
+def test_featurize_empty_and_ragged(dev):
+    import torch
+    from clairs_to_amd.pack import ColumnPack
+    from clairs_to_amd.featurize import featurize
+    # empty pack, sites without any row
+    pack = ColumnPack.from_mpileup("", "ACGT" * 50, 1)
+    feat = featurize(pack.to_device(dev), torch.tensor([50, 60], dtype=torch.int32, device=dev), 20, 50, want_raw=True)
+    torch.cuda.synchronize()
+    assert feat.site_info.cpu().numpy()[:, 3].tolist() == [1, 1]
+    assert int(feat.raw_aff.abs().sum()) == 0
+    # a single deep column (several 64-entry chunks in one wave) and an empty column
+    text = "chr1\t40\tN\t300\t" + "A" * 150 + "c" * 150 + "\t" + "I" * 300 + "\t" + "]" * 300 + "\n" + \
+           "chr1\t41\tN\t0\t*\t*\t*\n"
+    pack = ColumnPack.from_mpileup(text, "ACGT" * 50, 1)
+    feat = featurize(pack.to_device(dev), torch.tensor([40], dtype=torch.int32, device=dev), 20, 0, want_raw=True)
+    torch.cuda.synchronize()
+    raw = feat.raw_aff.cpu().numpy()[0]
+    ref40 = ("ACGT" * 50)[39]          # 'T'
+    assert ref40 == "T"
+    assert raw[16, 0] == 150 and raw[16, 10] == 150 and raw[16, 3] == -150 and raw[16, 12] == -150
+    assert feat.site_info.cpu().numpy()[0, 1] == 300
+
+
+@pytest.mark.parametrize("cls", ["CvT", "CvT_Indel", "BiGRU_NACGT", "BiGRU_NACGT_Indel"])
+def test_models_match_reference_logits(dev, cls):
+    """HIP forward vs the logits the reference's own modules produced (fp32 CPU torch); bar 1e-4 (north_star)."""
+    import torch
+    from clairs_to_amd.nn_shims import from_state_dict
+    g = load_models_npz(cls)
+    m = from_state_dict(cls, make_weights(g["manifest"], seed=g["n_out"]))
+    out = m(torch.from_numpy(g["x"]).to(dev))
+    assert isinstance(out, tuple) and len(out) == g["n_out"] and tuple(out[0].shape) == (g["x"].shape[0], 2)
+    got = torch.stack(out).cpu().numpy()
+    np.testing.assert_allclose(got, g["logits"], rtol=0, atol=1e-4)
+    p_got = torch.softmax(torch.stack(out), dim=-1).cpu().numpy()
+    p_ref = torch.softmax(torch.from_numpy(g["logits"]), dim=-1).numpy()
+    assert np.abs(p_got - p_ref).max() < 1e-4
+
+
+@pytest.mark.parametrize("cls,B", [("CvT", 700), ("BiGRU_NACGT_Indel", 333)])
+def test_models_match_oracle_ragged_batch(dev, oracle_lib, cls, B):
+    """Batch sizes that are not multiples of any tile, inputs with realistic count statistics."""
+    import torch
+    from clairs_to_amd.nn_shims import from_state_dict
+    g = load_models_npz(cls)
+    w = make_weights(g["manifest"], seed=g["n_out"])
+    rng = np.random.default_rng(5)
+    x = g["x"][rng.integers(0, g["x"].shape[0], size=B)] * rng.uniform(0.5, 1.5, size=(B, 1, 1)).astype(np.float32)
+    m = from_state_dict(cls, w)
+    got = torch.stack(m(torch.from_numpy(x).to(dev))).cpu().numpy()
+    if cls.startswith("CvT"):
+        want = oracle_lib.cvt_forward(w, dict(CVT_CFG, n_out=g["n_out"]), x)
+    else:
+        want = oracle_lib.bigru_forward(w, g["n_out"], x)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-4)
+    assert m.logits(torch.zeros((0, 33, 34), device=dev)).shape == (g["n_out"], 0, 2)
+
+
+def test_model_rejects_cpu_input():
+    import torch
+    from clairs_to_amd.nn_shims import from_state_dict
+    g = load_models_npz("BiGRU_NACGT")
+    m = from_state_dict("BiGRU_NACGT", make_weights(g["manifest"], seed=4))
+    with pytest.raises(RuntimeError):
+        m(torch.zeros((1, 33, 34)))
+
+
+@pytest.mark.parametrize("K", [4, 6])
+def test_posterior_matches_oracle(dev, oracle_lib, K):
+    import torch
+    from clairs_to_amd.call_variants import Posterior
+    from clairs_to_amd.synth import likelihood_table, lik_and_edges
+    rng = np.random.default_rng(K)
+    B = 5000
+    aff = rng.normal(0, 3, size=(K, B, 2)).astype(np.float32)
+    neg = rng.normal(0, 3, size=(K, B, 2)).astype(np.float32)
+    aff[0, :5] = [[-30, 30], [30, -30], [0, 0], [-1.7, 20], [20, -1.7]]        # saturating probabilities
+    lik, edges = lik_and_edges(likelihood_table(K), K)
+    post = Posterior(lik, edges, dev)
+    out = post(torch.from_numpy(aff).to(dev), torch.from_numpy(neg).to(dev))
+    probs, p, dec, qual = oracle_lib.posterior(aff, neg, lik, edges)
+    np.testing.assert_allclose(out["probs"].cpu().numpy(), probs, rtol=0, atol=2e-7)
+    # feed the device its own 8-decimal probabilities through the text-seam entry: must equal the oracle bit for bit
+    p8 = np.round(probs[:, :, 1].astype(np.float64) * 1e8) / 1e8
+    o2 = post.from_probs(torch.from_numpy(p8).to(dev))
+    p_o, d_o, q_o = oracle_lib.posterior_from_probs(p8, lik, edges)
+    np.testing.assert_array_equal(o2["post"].cpu().numpy(), p_o)
+    np.testing.assert_array_equal(o2["decision"].cpu().numpy(), d_o)
+    np.testing.assert_allclose(o2["qual"].cpu().numpy(), q_o, rtol=0, atol=1.01e-4)
+    assert d_o[:, 1].sum() > 0          # the clamp (reference IndexError) case is exercised
+
+
+@pytest.mark.parametrize("mode", ["snv", "indel"])
+def test_vcf_rows_from_gpu_posterior(dev, mode):
+    """probability rows of the reference -> GPU posterior -> host row assembly == reference VCF rows."""
+    import torch
+    from clairs_to_amd.call_variants import Posterior, load_likelihood, vcf_row
+    calls = load_json_gz("calls_%s.json.gz" % mode)
+    K = calls["n_out"]
+    rows = [r.split("\t") for r in calls["predict_rows"].strip().split("\n") if r]
+    lik, edges = load_likelihood(np.loadtxt(calls["likelihood_table"].split("\n")), K)
+    p1 = np.array([[float(f.split()[1]) for f in r[6:6 + 2 * K]] for r in rows], dtype=np.float64)
+    o = Posterior(lik, edges, dev).from_probs(torch.from_numpy(p1).to(dev))
+    dec, qual = o["decision"].cpu().numpy(), o["qual"].cpu().numpy()
+    for show_ref in (False, True):
+        out = [vcf_row(r[0], r[1], r[2], r[3], eval(r[4]), eval(r[5]), int(dec[i, 0]), float(qual[i]), K, show_ref=show_ref)
+               for i, r in enumerate(rows)]
+        assert [x for x in out if x is not None] == calls["vcf"]["show_ref" if show_ref else "default"]
