@@ -215,7 +215,7 @@ int ensure_ws(cto_model* m, int64_t B) {
             (rc = get(&m->b_o, qn)) || (rc = get(&m->b_u, un)))
             return rc;
     } else {
-        if ((rc = get(&m->b_h, 33 * 256)) || (rc = get(&m->b_t, 33 * 384)) || (rc = get(&m->b_slab, 3 * 128))) return rc;
+        if ((rc = get(&m->b_h, 33 * 256)) || (rc = get(&m->b_slab, 2 * 128))) return rc;
     }
     if ((rc = get(&m->b_g, 128)) || (rc = get(&m->b_u2, int64_t(K) * 128))) return rc;
     m->ws_B = B;
@@ -227,11 +227,9 @@ int run_head(cto_model* m, hipStream_t s, const float* feat, int64_t B, float* l
     const HeadDev& h = m->head;
     const int K = m->n_out;
     int rc;
-    if (h.k1 > 2048) {
-        const int S = 3;
-        if ((rc = launch_gemm(s, feat, h.k1, h.w1, h.k1, nullptr, nullptr, 0, m->b_slab, 128, int(B), 128, h.k1,
-                              ACT_NONE, 0, 0, 0, S, B * 128)))
-            return rc;
+    if (feat == nullptr) {
+        // BiGRU: fc1 was accumulated inside the layer-2 recurrent kernel, one slab per direction
+        const int S = 2;
         const int64_t total = B * 128;
         hipLaunchKernelGGL(k_sum_bias_selu, dim3(unsigned(cdiv(total, 256))), dim3(256), 0, s, m->b_slab, S, B * 128,
                            h.b1, m->b_g, total, 128);
@@ -289,17 +287,19 @@ int cvt_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStrea
     return run_head(m, s, m->b_h, B, logits);
 }
 
-template <int KIN, int KP, int H, int MS>
-int launch_gru(hipStream_t s, const float* x, const float* W, const float* bias, float* out, int64_t B) {
+template <int KIN, int KP, int H, int MS, bool FUSE>
+int launch_gru(hipStream_t s, const float* x, const float* W, const float* bias, float* out, const float* fc1w,
+               float* fc1_part, int64_t B) {
     const size_t smem = size_t(2) * MS * 16 * (H + 4) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_layer<KIN, KP, H, MS>),
+        CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_layer<KIN, KP, H, MS, FUSE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
         attr_set = true;
     }
     const unsigned grid = unsigned(cdiv(B, MS * 16)) * 2;
-    hipLaunchKernelGGL((k_gru_layer<KIN, KP, H, MS>), dim3(grid), dim3(256), smem, s, x, W, bias, out, int(B));
+    hipLaunchKernelGGL((k_gru_layer<KIN, KP, H, MS, FUSE>), dim3(grid), dim3(256), smem, s, x, W, bias, out, fc1w, fc1_part,
+                       int(B));
     CTO_HIP(hipGetLastError());
     return CTO_OK;
 }
@@ -313,15 +313,16 @@ int prof_begin(cto_model* m, hipStream_t s, hipEvent_t* e0, hipEvent_t* e1) {
 
 int bigru_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStream_t s) {
     int rc;
-    if ((rc = launch_gru<34, 48, 128, 2>(s, x, m->gw1, m->gb1, m->b_h, B))) return rc;
+    if ((rc = launch_gru<34, 48, 128, 2, false>(s, x, m->gw1, m->gb1, m->b_h, nullptr, nullptr, B))) return rc;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (m->prof && (rc = prof_begin(m, s, &e0, &e1))) return rc;
-    if ((rc = launch_gru<256, 256, 192, 2>(s, m->b_h, m->gw2, m->gb2, m->b_t, B))) return rc;
+    // layer 2 with the head's fc1 folded in: writes one partial [B][128] slab per direction into b_slab
+    if ((rc = launch_gru<256, 256, 192, 2, true>(s, m->b_h, m->gw2, m->gb2, nullptr, m->head.w1, m->b_slab, B))) return rc;
     if (m->prof) {
         CTO_HIP(hipEventRecord(e1, s));
         m->prof_ev.emplace_back(e0, e1);
     }
-    return run_head(m, s, m->b_t, B, logits);
+    return run_head(m, s, nullptr, B, logits);
 }
 
 // [W_ih | W_hh] per gate row, W_ih zero-padded to KP; bias rows: r (b_ir + b_hr), z (b_iz + b_hz), b_in, b_hn
@@ -474,8 +475,8 @@ extern "C" int cto_model_forward(cto_model* m, const float* x, int64_t B, float*
 extern "C" int cto_model_profile(cto_model* m, int enable) {
     CTO_REQUIRE(m, CTO_EINVAL, "cto_model_profile: null model");
     m->prof = enable != 0;
-    // per-site MACs of the measured kernel: BiGRU layer 2 (both directions), or the whole CvT
-    m->prof_macs = m->kind == 1 ? int64_t(33) * 2 * 3 * 192 * (256 + 192) : m->macs;
+    // per-site MACs of the measured kernel: BiGRU layer 2 (both directions) incl. the fused fc1, or the whole CvT
+    m->prof_macs = m->kind == 1 ? int64_t(33) * 2 * 3 * 192 * (256 + 192) + int64_t(33) * 384 * 128 : m->macs;
     return CTO_OK;
 }
 

@@ -349,11 +349,23 @@ __global__ __launch_bounds__(256) void k_fc3(const float* __restrict__ u, const 
 //             h_{t-1} from a double-buffered LDS tile [MS*16][H] that all waves rewrite each step.
 // B operands (weights) stream from L2 as one 16-byte load per lane per (gate, 16-wide k chunk); they
 //             are shared by the MS row-subtiles.  One barrier per time step.
+// The K loop is fully unrolled and software-pipelined by hand: the operands of chunk c+1 (and, at the
+// end of a step, of chunk 0 of the next step) are requested before the MFMAs of chunk c, so the matrix
+// pipe never waits on an L2 round trip except right after the barrier (LDS reads only).
+// FUSE_FC1 (layer 2): the head's fc1 (clairs/model.py:445-448, K = 33*384) is accumulated on the fly -
+// the h_{t-1} fragments already in registers for the recurrence are multiplied with the matching
+// 192-column slice of fc1.weight - and written as one partial [B][128] slab per direction, so the
+// [B][33][384] layer output never goes to HBM.
 // --------------------------------------------------------------------------------------------
-template <int KIN, int KP, int H, int MS>
+__device__ __forceinline__ float fast_sigmoid(float x) { return __fdividef(1.0f, 1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - __fdividef(2.0f, 1.0f + __expf(2.0f * x)); }
+
+template <int KIN, int KP, int H, int MS, bool FUSE_FC1>
 __global__ __launch_bounds__(256) void k_gru_layer(const float* __restrict__ x, const float* __restrict__ Wcat,
-                                                   const float* __restrict__ bias, float* __restrict__ out, int B) {
-    constexpr int NB = H / 64, T = 33, KT = KP + H, HS = H + 4;
+                                                   const float* __restrict__ bias, float* __restrict__ out,
+                                                   const float* __restrict__ fc1w, float* __restrict__ fc1_part, int B) {
+    constexpr int NB = H / 64, T = 33, KT = KP + H, HS = H + 4, NX = KP / 16, NH = H / 16, NC = NX + NH;
+    constexpr int FC1_K = T * 2 * H;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* hbuf = smem;   // [2][MS*16][HS]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -362,6 +374,8 @@ __global__ __launch_bounds__(256) void k_gru_layer(const float* __restrict__ x, 
     const int site0 = (blockIdx.x >> 1) * MS * 16;
     const float* Wd = Wcat + int64_t(dir) * 3 * H * KT;
     const float* bd = bias + dir * 4 * H;
+
+    for (int i = threadIdx.x; i < MS * 16 * HS; i += 256) hbuf[i] = 0.f;   // h_{-1} = 0
 
     float bia[NB][4];
     const float* wrow[NB][3];
@@ -373,6 +387,11 @@ __global__ __launch_bounds__(256) void k_gru_layer(const float* __restrict__ x, 
 #pragma unroll
         for (int q = 0; q < 3; ++q) wrow[nb][q] = Wd + int64_t(q * H + hcol) * KT + 4 * kg;
     }
+    const float* frow[2] = {nullptr, nullptr};
+    if constexpr (FUSE_FC1) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) frow[nt] = fc1w + int64_t(wave * 32 + nt * 16 + j) * FC1_K + dir * H + 4 * kg;
+    }
     float hprev[MS][NB][4];
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms)
@@ -380,14 +399,72 @@ __global__ __launch_bounds__(256) void k_gru_layer(const float* __restrict__ x, 
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) hprev[ms][nb][r] = 0.f;
-
-    int arow[MS];   // site whose A row this lane feeds (may be >= B: zero rows)
+    f32x4 accf[MS][2];
 #pragma unroll
-    for (int ms = 0; ms < MS; ++ms) arow[ms] = site0 + ms * 16 + j;
+    for (int ms = 0; ms < MS; ++ms) { accf[ms][0] = f32x4{0.f, 0.f, 0.f, 0.f}; accf[ms][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const float* xrow[MS];   // x row of the site this lane feeds, nullptr for rows past the batch (zero rows)
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+        const int site = site0 + ms * 16 + j;
+        xrow[ms] = site < B ? x + int64_t(site) * T * KIN + 4 * kg : nullptr;
+    }
+
+    float4 Bq[2][NB][3], Fq[2][2], Aq[2][MS];
+
+    int opq = 0;
+    auto load_B = [&](int buf, int c) {   // weights of k chunk c (x chunks first, then h chunks)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) Bq[buf][nb][q] = *reinterpret_cast<const float4*>(wrow[nb][q] + c * 16 + opq);
+    };
+    auto load_F = [&](int buf, int kh, int tprev) {
+        if constexpr (FUSE_FC1) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                Fq[buf][nt] = *reinterpret_cast<const float4*>(frow[nt] + tprev * (2 * H) + kh * 16);
+        }
+    };
+    auto load_Ax = [&](int buf, int c, int t) {
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (xrow[ms]) {
+                const float* xr = xrow[ms] + t * KIN + c * 16;
+                if constexpr (KIN % 4 == 0) {
+                    a = *reinterpret_cast<const float4*>(xr);
+                } else {
+                    const int k = c * 16 + 4 * kg;
+                    a.x = k + 0 < KIN ? xr[0] : 0.f;
+                    a.y = k + 1 < KIN ? xr[1] : 0.f;
+                    a.z = k + 2 < KIN ? xr[2] : 0.f;
+                    a.w = k + 3 < KIN ? xr[3] : 0.f;
+                }
+            }
+            Aq[buf][ms] = a;
+        }
+    };
+    auto load_Ah = [&](int buf, int kh, const float* hc) {
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+            Aq[buf][ms] = *reinterpret_cast<const float4*>(hc + (ms * 16 + j) * HS + kh * 16 + 4 * kg);
+    };
+
+    // prologue: operands of chunk 0 of step 0
+    load_B(0, 0);
+    load_Ax(0, 0, dir == 0 ? 0 : T - 1);
 
     for (int step = 0; step < T; ++step) {
         const int t = dir == 0 ? step : T - 1 - step;
-        const int cur = step & 1, nxt = cur ^ 1;
+        const int tnext = dir == 0 ? t + 1 : t - 1;                          // valid while step + 1 < T
+        const int tprev = step == 0 ? t : (dir == 0 ? t - 1 : t + 1);        // step 0: h = 0, any valid slice will do
+        const int cur_h = step & 1;
+        const float* hc = hbuf + cur_h * (MS * 16 * HS);
+        // The weight addresses do not depend on `step`; without this the compiler hoists all K chunks of weight
+        // loads out of the time loop (hundreds of registers, spills).  An opaque zero keeps them per-step.
+        opq = 0;
+        asm volatile("" : "+v"(opq));
         f32x4 ar[MS][NB], az[MS][NB], ain[MS][NB], ahn[MS][NB];
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
@@ -398,82 +475,79 @@ __global__ __launch_bounds__(256) void k_gru_layer(const float* __restrict__ x, 
                 ain[ms][nb] = f32x4{bia[nb][2], bia[nb][2], bia[nb][2], bia[nb][2]};
                 ahn[ms][nb] = f32x4{bia[nb][3], bia[nb][3], bia[nb][3], bia[nb][3]};
             }
-        // ---- x part: independent of h, runs ahead of the barrier ----
-#pragma unroll 2
-        for (int kc = 0; kc < KP / 16; ++kc) {
-            float4 a[MS];
 #pragma unroll
-            for (int ms = 0; ms < MS; ++ms) {
-                a[ms] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (arow[ms] < B) {
-                    const float* xr = x + (int64_t(arow[ms]) * T + t) * KIN + kc * 16 + 4 * kg;
-                    if constexpr (KIN % 4 == 0) {
-                        a[ms] = *reinterpret_cast<const float4*>(xr);
-                    } else {
-                        const int k = kc * 16 + 4 * kg;
-                        a[ms].x = k + 0 < KIN ? xr[0] : 0.f;
-                        a[ms].y = k + 1 < KIN ? xr[1] : 0.f;
-                        a[ms].z = k + 2 < KIN ? xr[2] : 0.f;
-                        a[ms].w = k + 3 < KIN ? xr[3] : 0.f;
-                    }
-                }
+        for (int c = 0; c < NC; ++c) {
+            const int cur = c & 1, nxt = cur ^ 1;
+            if (c == NX) {
+                __syncthreads();            // h_{t-1}, written by all waves during the previous step, is complete
+                load_Ah(cur, 0, hc);
+                load_F(cur, 0, tprev);
             }
+            // ---- request the operands of the next chunk before computing this one ----
+            if (c + 1 < NC) {
+                load_B(nxt, c + 1);
+                if (c + 1 < NX) load_Ax(nxt, c + 1, t);
+                else if (c + 1 > NX) { load_Ah(nxt, c + 1 - NX, hc); load_F(nxt, c + 1 - NX, tprev); }
+            } else if (step + 1 < T) {
+                load_B(nxt, 0);
+                load_Ax(nxt, 0, tnext);
+            }
+            // ---- MFMAs of chunk c ----
+            const bool xpart = c < NX;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const float4 br = *reinterpret_cast<const float4*>(wrow[nb][0] + kc * 16);
-                const float4 bz = *reinterpret_cast<const float4*>(wrow[nb][1] + kc * 16);
-                const float4 bn = *reinterpret_cast<const float4*>(wrow[nb][2] + kc * 16);
+                const float4 br = Bq[cur][nb][0], bz = Bq[cur][nb][1], bn = Bq[cur][nb][2];
 #pragma unroll
                 for (int ms = 0; ms < MS; ++ms) {
-                    ar[ms][nb] = mfma16(a[ms].x, br.x, ar[ms][nb]);
-                    az[ms][nb] = mfma16(a[ms].x, bz.x, az[ms][nb]);
-                    ain[ms][nb] = mfma16(a[ms].x, bn.x, ain[ms][nb]);
-                    ar[ms][nb] = mfma16(a[ms].y, br.y, ar[ms][nb]);
-                    az[ms][nb] = mfma16(a[ms].y, bz.y, az[ms][nb]);
-                    ain[ms][nb] = mfma16(a[ms].y, bn.y, ain[ms][nb]);
-                    ar[ms][nb] = mfma16(a[ms].z, br.z, ar[ms][nb]);
-                    az[ms][nb] = mfma16(a[ms].z, bz.z, az[ms][nb]);
-                    ain[ms][nb] = mfma16(a[ms].z, bn.z, ain[ms][nb]);
-                    ar[ms][nb] = mfma16(a[ms].w, br.w, ar[ms][nb]);
-                    az[ms][nb] = mfma16(a[ms].w, bz.w, az[ms][nb]);
-                    ain[ms][nb] = mfma16(a[ms].w, bn.w, ain[ms][nb]);
-                }
-            }
-        }
-        __syncthreads();   // h_{t-1} (written by all waves in the previous step) is complete
-        if (step > 0) {    // h_{-1} = 0: the h part contributes nothing at the first step
-            const float* hc = hbuf + cur * (MS * 16 * HS);
-#pragma unroll 2
-            for (int kc = 0; kc < H / 16; ++kc) {
-                float4 a[MS];
-#pragma unroll
-                for (int ms = 0; ms < MS; ++ms)
-                    a[ms] = *reinterpret_cast<const float4*>(hc + (ms * 16 + j) * HS + kc * 16 + 4 * kg);
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const float4 br = *reinterpret_cast<const float4*>(wrow[nb][0] + KP + kc * 16);
-                    const float4 bz = *reinterpret_cast<const float4*>(wrow[nb][1] + KP + kc * 16);
-                    const float4 bn = *reinterpret_cast<const float4*>(wrow[nb][2] + KP + kc * 16);
-#pragma unroll
-                    for (int ms = 0; ms < MS; ++ms) {
-                        ar[ms][nb] = mfma16(a[ms].x, br.x, ar[ms][nb]);
-                        az[ms][nb] = mfma16(a[ms].x, bz.x, az[ms][nb]);
-                        ahn[ms][nb] = mfma16(a[ms].x, bn.x, ahn[ms][nb]);
-                        ar[ms][nb] = mfma16(a[ms].y, br.y, ar[ms][nb]);
-                        az[ms][nb] = mfma16(a[ms].y, bz.y, az[ms][nb]);
-                        ahn[ms][nb] = mfma16(a[ms].y, bn.y, ahn[ms][nb]);
-                        ar[ms][nb] = mfma16(a[ms].z, br.z, ar[ms][nb]);
-                        az[ms][nb] = mfma16(a[ms].z, bz.z, az[ms][nb]);
-                        ahn[ms][nb] = mfma16(a[ms].z, bn.z, ahn[ms][nb]);
-                        ar[ms][nb] = mfma16(a[ms].w, br.w, ar[ms][nb]);
-                        az[ms][nb] = mfma16(a[ms].w, bz.w, az[ms][nb]);
-                        ahn[ms][nb] = mfma16(a[ms].w, bn.w, ahn[ms][nb]);
+                    const float4 a = Aq[cur][ms];
+                    ar[ms][nb] = mfma16(a.x, br.x, ar[ms][nb]);
+                    az[ms][nb] = mfma16(a.x, bz.x, az[ms][nb]);
+                    ar[ms][nb] = mfma16(a.y, br.y, ar[ms][nb]);
+                    az[ms][nb] = mfma16(a.y, bz.y, az[ms][nb]);
+                    ar[ms][nb] = mfma16(a.z, br.z, ar[ms][nb]);
+                    az[ms][nb] = mfma16(a.z, bz.z, az[ms][nb]);
+                    ar[ms][nb] = mfma16(a.w, br.w, ar[ms][nb]);
+                    az[ms][nb] = mfma16(a.w, bz.w, az[ms][nb]);
+                    if (xpart) {
+                        ain[ms][nb] = mfma16(a.x, bn.x, ain[ms][nb]);
+                        ain[ms][nb] = mfma16(a.y, bn.y, ain[ms][nb]);
+                        ain[ms][nb] = mfma16(a.z, bn.z, ain[ms][nb]);
+                        ain[ms][nb] = mfma16(a.w, bn.w, ain[ms][nb]);
+                    } else {
+                        ahn[ms][nb] = mfma16(a.x, bn.x, ahn[ms][nb]);
+                        ahn[ms][nb] = mfma16(a.y, bn.y, ahn[ms][nb]);
+                        ahn[ms][nb] = mfma16(a.z, bn.z, ahn[ms][nb]);
+                        ahn[ms][nb] = mfma16(a.w, bn.w, ahn[ms][nb]);
                     }
                 }
             }
+            if constexpr (FUSE_FC1) {
+                if (!xpart) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int ms = 0; ms < MS; ++ms) {
+                            const float4 a = Aq[cur][ms], f = Fq[cur][nt];
+                            accf[ms][nt] = mfma16(a.x, f.x, accf[ms][nt]);
+                            accf[ms][nt] = mfma16(a.y, f.y, accf[ms][nt]);
+                            accf[ms][nt] = mfma16(a.z, f.z, accf[ms][nt]);
+                            accf[ms][nt] = mfma16(a.w, f.w, accf[ms][nt]);
+                        }
+                }
+            }
+            // keep the hand-made pipeline: nothing (in particular no later prefetch) moves across a chunk boundary
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr ((NC & 1) != 0) {   // odd chunk count: next step's chunk 0 landed in buffer 1, it is read from 0
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) Bq[0][nb][q] = Bq[1][nb][q];
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms) Aq[0][ms] = Aq[1][ms];
         }
         // ---- gates + state update (lane-local), publish h_t ----
-        float* hn = hbuf + nxt * (MS * 16 * HS);
+        float* hn = hbuf + (cur_h ^ 1) * (MS * 16 * HS);
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
@@ -481,17 +555,50 @@ __global__ __launch_bounds__(256) void k_gru_layer(const float* __restrict__ x, 
                 const int hcol = (wave * NB + nb) * 16 + j;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float rg = sigmoid_f(ar[ms][nb][r]);
-                    const float zg = sigmoid_f(az[ms][nb][r]);
-                    const float ng = tanhf(ain[ms][nb][r] + rg * ahn[ms][nb][r]);
-                    const float hv = (1.0f - zg) * ng + zg * hprev[ms][nb][r];
+                    const float rg = fast_sigmoid(ar[ms][nb][r]);
+                    const float zg = fast_sigmoid(az[ms][nb][r]);
+                    const float ng = fast_tanh(ain[ms][nb][r] + rg * ahn[ms][nb][r]);
+                    const float hv = ng + zg * (hprev[ms][nb][r] - ng);      // (1 - z) * n + z * h
                     hprev[ms][nb][r] = hv;
                     const int row = ms * 16 + kg * 4 + r;
                     hn[row * HS + hcol] = hv;
-                    const int site = site0 + row;
-                    if (site < B) out[(int64_t(site) * T + t) * (2 * H) + dir * H + hcol] = hv;
+                    if constexpr (!FUSE_FC1) {
+                        const int site = site0 + row;
+                        if (site < B) out[(int64_t(site) * T + t) * (2 * H) + dir * H + hcol] = hv;
+                    }
                 }
             }
+    }
+    if constexpr (FUSE_FC1) {
+        // fc1 contribution of the last state h_{T-1 (fwd) / 0 (bwd)}, then one partial slab per direction
+        __syncthreads();
+        const float* hl = hbuf + (T & 1) * (MS * 16 * HS);
+        const int tl = dir == 0 ? T - 1 : 0;
+#pragma unroll
+        for (int kh = 0; kh < NH; ++kh) {
+            load_Ah(0, kh, hl);
+            load_F(0, kh, tl);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int ms = 0; ms < MS; ++ms) {
+                    const float4 a = Aq[0][ms], f = Fq[0][nt];
+                    accf[ms][nt] = mfma16(a.x, f.x, accf[ms][nt]);
+                    accf[ms][nt] = mfma16(a.y, f.y, accf[ms][nt]);
+                    accf[ms][nt] = mfma16(a.z, f.z, accf[ms][nt]);
+                    accf[ms][nt] = mfma16(a.w, f.w, accf[ms][nt]);
+                }
+        }
+        float* part = fc1_part + int64_t(dir) * B * 128;
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int site = site0 + ms * 16 + kg * 4 + r;
+                    if (site < B) part[int64_t(site) * 128 + wave * 32 + nt * 16 + j] = accf[ms][nt][r];
+                }
     }
 }
 

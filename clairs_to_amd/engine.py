@@ -72,7 +72,7 @@ def synthetic_models(n_out=4, seed=0):
 class Engine:
     """One GPU's worth of the hot path.  aff/neg: nn_shims modules (or anything exposing `_handle()`)."""
 
-    def __init__(self, aff, neg, lik, edges, min_bq=20, min_rescale_cov=50, device="cuda", two_streams=True):
+    def __init__(self, aff, neg, lik, edges, min_bq=20, min_rescale_cov=50, device="cuda", two_streams=False):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("clairs_to_amd.Engine needs a HIP device; there is no CPU fallback")

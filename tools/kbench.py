@@ -49,6 +49,14 @@ def main():
     res["neg_ms"] = timeit(lambda: check(lib.cto_model_forward(eng.h_neg, feat.x_neg.data_ptr(), B, ln.data_ptr(), s)), a.reps)
     res["post_ms"] = timeit(lambda: eng.posterior(la, ln), a.reps)
     res["all_ms"] = timeit(lambda: eng.run_device(dp, sp), a.reps)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.reps):
+        eng.run_device(dp, sp)
+    res["all_host_issue_ms"] = (time.perf_counter() - t0) / a.reps * 1e3
+    torch.cuda.synchronize()
+    eng1 = Engine(models["aff"], models["neg"], lik, edges, device=dev, two_streams=False)
+    res["all_1stream_ms"] = timeit(lambda: eng1.run_device(dp, sp), a.reps)
     gf_aff = 2e-9 * lib.cto_model_macs_per_site(eng.h_aff) * B
     gf_neg = 2e-9 * lib.cto_model_macs_per_site(eng.h_neg) * B
     res["aff_tflops"] = gf_aff / res["aff_ms"]
