@@ -1,0 +1,17 @@
+"""`python -m clairs_to_amd <submodule> ...` - same dispatch style as the reference's clairs_to.py:84-107 for the
+three hot-path sub-modules this package replaces."""
+import importlib
+import sys
+
+SUBMODULES = ("create_tensor_pileup_calling", "predict", "call_variants")
+
+
+def main():
+    if len(sys.argv) < 2 or sys.argv[1] not in SUBMODULES:
+        sys.exit("usage: python -m clairs_to_amd {%s} [options]" % "|".join(SUBMODULES))
+    name = sys.argv.pop(1)
+    importlib.import_module("clairs_to_amd." + name).main()
+
+
+if __name__ == "__main__":
+    main()

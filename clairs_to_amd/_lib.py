@@ -48,7 +48,7 @@ SYMBOLS = {
     "cto_pack_free": (None, [c_vp]),
     "cto_featurize_columns": (C.c_int, [C.POINTER(PackView), C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "cto_gather_windows": (C.c_int, [C.POINTER(PackView), c_vp, c_vp, c_vp, c_i64, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "cto_alt_info": (C.c_int, [c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, C.c_char_p, C.c_size_t]),
+    "cto_alt_info": (C.c_int, [c_vp, c_i64, C.c_int, c_vp, c_i32, c_vp, c_vp, c_vp, C.c_char_p, C.c_size_t]),
     "cto_weights_new": (c_vp, []),
     "cto_weights_add": (C.c_int, [c_vp, C.c_char_p, c_vp, c_i64]),
     "cto_weights_free": (None, [c_vp]),
@@ -61,6 +61,7 @@ SYMBOLS = {
     "cto_model_profile": (C.c_int, [c_vp, C.c_int]),
     "cto_model_profile_read": (C.c_int, [c_vp, C.POINTER(C.c_double), C.POINTER(c_i64)]),
     "cto_posterior": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "cto_softmax_probs": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, c_vp, c_vp]),
     "cto_posterior_from_probs": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
 }
 

@@ -139,3 +139,89 @@ def vcf_row(chrom, pos, ref_base, alt_info, fwd, rev, argmax, qual, n_out, show_
     return "%s\t%d\t.\t%s\t%s\t%.4f\t%s\t%s\tGT:GQ:DP:AF:AD:AU:CU:GU:TU\t%s:%d:%d:%.4f:%s:%d:%d:%d:%d" % (
         chrom, int(pos), ref, alt, qual, flt, info, gt, int(float(qual)), depth, af_out, ad,
         f[0] + r[0], f[1] + r[1], f[2] + r[2], f[3] + r[3])
+
+
+VCF_HEADER = """##fileformat=VCFv4.2
+##source=clairs_to_amd
+##FILTER=<ID=PASS,Description="All filters passed">
+##FILTER=<ID=LowQual,Description="Low quality variant">
+##FILTER=<ID=RefCall,Description="Reference call">
+##INFO=<ID=FAU,Number=1,Type=Integer,Description="Forward-strand A count in the tumor BAM">
+##INFO=<ID=FCU,Number=1,Type=Integer,Description="Forward-strand C count in the tumor BAM">
+##INFO=<ID=FGU,Number=1,Type=Integer,Description="Forward-strand G count in the tumor BAM">
+##INFO=<ID=FTU,Number=1,Type=Integer,Description="Forward-strand T count in the tumor BAM">
+##INFO=<ID=RAU,Number=1,Type=Integer,Description="Reverse-strand A count in the tumor BAM">
+##INFO=<ID=RCU,Number=1,Type=Integer,Description="Reverse-strand C count in the tumor BAM">
+##INFO=<ID=RGU,Number=1,Type=Integer,Description="Reverse-strand G count in the tumor BAM">
+##INFO=<ID=RTU,Number=1,Type=Integer,Description="Reverse-strand T count in the tumor BAM">
+##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">
+##FORMAT=<ID=GQ,Number=1,Type=Integer,Description="Genotype quality">
+##FORMAT=<ID=DP,Number=1,Type=Integer,Description="Read depth">
+##FORMAT=<ID=AF,Number=1,Type=Float,Description="Estimated allele frequency">
+##FORMAT=<ID=AD,Number=R,Type=Integer,Description="Allelic depths (ref, alt)">
+##FORMAT=<ID=AU,Number=1,Type=Integer,Description="A count in the tumor BAM">
+##FORMAT=<ID=CU,Number=1,Type=Integer,Description="C count in the tumor BAM">
+##FORMAT=<ID=GU,Number=1,Type=Integer,Description="G count in the tumor BAM">
+##FORMAT=<ID=TU,Number=1,Type=Integer,Description="T count in the tumor BAM">
+"""
+
+
+def call_variants_from_probability(args, device="cuda"):
+    """`clairs_to.py call_variants` counterpart: probability text rows in, VCF out (call_variants.py:620-867)."""
+    import ast
+    import gzip
+    import os
+    import sys
+    if not torch.cuda.is_available():
+        sys.exit("[ERROR] clairs_to_amd call_variants needs a HIP device; there is no CPU fallback")
+    K = 4 if args.disable_indel_calling else 6
+    lik, edges = load_likelihood(args.likelihood_matrix_data, K)
+    post = Posterior(lik, edges, device)
+    with open(args.predict_fn, "rb") as f:
+        gz = f.read(2) == b"\x1f\x8b"
+    rows = []
+    with (gzip.open(args.predict_fn, "rt") if gz else open(args.predict_fn)) as f:
+        for row in f:
+            c = row.rstrip().split("\t")
+            if len(c) >= 6 + 2 * K:
+                rows.append(c)
+    n_rows = 0
+    os.makedirs(os.path.dirname(os.path.abspath(args.call_fn)), exist_ok=True)
+    with open(args.call_fn, "w") as out:
+        out.write(VCF_HEADER + "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n" % args.sample_name)
+        if rows:
+            p1 = np.array([[float(f.split()[1]) for f in r[6:6 + 2 * K]] for r in rows], dtype=np.float64)
+            o = post.from_probs(torch.from_numpy(p1).to(device))
+            dec, qual = o["decision"].cpu().numpy(), o["qual"].cpu().numpy()
+            for i, r in enumerate(rows):
+                if dec[i, 1]:
+                    print("[WARNING] %s:%s probability 1.00000000 falls outside the likelihood bins (the reference "
+                          "raises IndexError here); clamped" % (r[0], r[1]), file=sys.stderr)
+                line = vcf_row(r[0], r[1], r[2], r[3], ast.literal_eval(r[4]), ast.literal_eval(r[5]), int(dec[i, 0]),
+                               float(qual[i]), K, show_ref=args.show_ref, qual_pass=args.qual)
+                if line is not None:
+                    out.write(line + "\n")
+                    n_rows += 1
+    if n_rows == 0:
+        os.remove(args.call_fn)       # the reference removes VCFs without records (call_variants.py:859-867)
+    return n_rows
+
+
+def main():
+    from argparse import ArgumentParser
+    p = ArgumentParser(description="Call variants from probability rows (GPU posterior)")
+    p.add_argument("--platform", type=str, default="ont")
+    p.add_argument("--call_fn", type=str, required=True)
+    p.add_argument("--predict_fn", type=str, required=True)
+    p.add_argument("--likelihood_matrix_data", type=str, required=True)
+    p.add_argument("--ctg_name", type=str, default=None)
+    p.add_argument("--sample_name", type=str, default="SAMPLE")
+    p.add_argument("--qual", type=int, default=0)
+    p.add_argument("--show_ref", action="store_true")
+    p.add_argument("--disable_indel_calling", type=lambda v: str(v).lower() in ("yes", "true", "t", "y", "1"), default=False)
+    p.add_argument("--pileup", action="store_true")
+    call_variants_from_probability(p.parse_args())
+
+
+if __name__ == "__main__":
+    main()

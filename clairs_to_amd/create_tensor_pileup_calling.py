@@ -1,0 +1,108 @@
+"""Drop-in counterpart of `clairs_to.py create_tensor_pileup_calling` (reference: src/create_tensor_pileup_calling.py,
+invoked twice per chunk at run_clairs_to:1228-1271) with the featurisation on the GPU.
+
+Same tensor text out (7 tab-separated fields per site, create_tensor_pileup_calling.py:561-569).  The pileup comes
+either from `--mpileup_fn` (text made by `samtools mpileup --reverse-del --output-MQ --min-MQ 0 --min-BQ 0 ...`) or,
+when samtools exists, from the BAM with the reference's own command line except `--min-BQ 0`: the per-base BQ gate
+of the AFF pass is applied inside the kernel, so ONE pileup serves both passes (`--tensor_can_fn_neg`)."""
+import gzip
+import shlex
+import subprocess
+import sys
+from argparse import ArgumentParser
+
+import numpy as np
+import torch
+
+from .fasta import read_region
+from .featurize import featurize, alt_infos
+from .pack import ColumnPack
+
+FLANK, NPOS, MAX_INDEL, EXPAND_REF = 16, 33, 60, 1000        # shared/param.py:60,61,114,101
+
+
+def read_candidates(bed_fn, ctg_name):
+    """BED rows `ctg x-17 x+17 [type]` -> sorted centres, types, (ctg_start, ctg_end) as at :347-370."""
+    opener = gzip.open if bed_fn.endswith(".gz") else open
+    centres, ctg_start, ctg_end = {}, float("inf"), 0
+    with opener(bed_fn, "rt") as f:
+        for row in f:
+            c = row.rstrip().split("\t")
+            if len(c) < 3 or c[0] != ctg_name:
+                continue
+            position, end = int(c[1]) + 1, int(c[2]) + 1
+            ctg_start, ctg_end = min(position, ctg_start), max(end, ctg_end)
+            centre = end - FLANK - 2 if position < 1 else position + (end - position) // 2 - 1
+            centres[centre] = c[3] if len(c) == 4 else "unknown"
+    return centres, ctg_start, ctg_end
+
+
+def create_tensor(args, device="cuda"):
+    centres, ctg_start, ctg_end = read_candidates(args.candidates_bed_regions, args.ctg_name)
+    if not centres:
+        print("[INFO] {} Tensors generated: 0".format(args.ctg_name))
+        return 0
+    sites = sorted(centres)
+    ref_start = max(1, ctg_start - EXPAND_REF)
+    ref = read_region(args.ref_fn, args.ctg_name, ref_start, ctg_end + EXPAND_REF)
+    if not ref:
+        sys.exit("[ERROR] Failed to load reference sequence from file ({}).".format(args.ref_fn))
+    if args.mpileup_fn:
+        opener = gzip.open if args.mpileup_fn.endswith(".gz") else open
+        with opener(args.mpileup_fn, "rb") as f:
+            text = f.read()
+    else:
+        ext_s, ext_e = max(1, ctg_start - NPOS), ctg_end + NPOS
+        cmd = "{} mpileup --reverse-del --output-MQ -r {}:{}-{} --min-MQ 0 --min-BQ 0 -l {} --excl-flags 2316".format(
+            args.samtools, args.ctg_name, ext_s, ext_e, args.candidates_bed_regions)
+        if args.max_depth is not None:
+            cmd += " --max-depth {}".format(args.max_depth)
+        text = subprocess.run(shlex.split(cmd) + [args.tumor_bam_fn], stdout=subprocess.PIPE, check=True).stdout
+    max_indel = MAX_INDEL if args.max_indel_length is None else args.max_indel_length
+    pack = ColumnPack.from_mpileup(text, ref, ref_start, max_indel)
+    dp = pack.to_device(device)
+    feat = featurize(dp, torch.tensor(sites, dtype=torch.int32, device=device), args.min_bq, 0, want_raw=True, want_x=False)
+    torch.cuda.synchronize()
+    info = feat.site_info.cpu().numpy()
+    outs = [(args.tensor_can_fn, feat.raw_aff, 1)]
+    if args.tensor_can_fn_neg:
+        outs.append((args.tensor_can_fn_neg, feat.raw_neg, 2))
+    alts_aff = alt_infos(feat, pack, info)
+    n_written = 0
+    for fn, raw, dcol in outs:
+        raw = raw.cpu().numpy()
+        alts = alts_aff if dcol == 1 else alt_infos(feat, pack, info, pass_idx=1)
+        n_written = 0
+        with (gzip.open(fn, "wt") if fn != "PIPE" else sys.stdout) as out:
+            for i, pos in enumerate(sites):
+                if info[i, 3] & 1:
+                    continue
+                o = pos - ref_start
+                ref_seq = ref[o - FLANK: o + FLANK + 1]
+                out.write("%s\t%d\t%s\t%s\t%s\t%s\t%s\n" % (
+                    args.ctg_name, pos, ref_seq, " ".join("%d" % v for v in raw[i].ravel()), alts[i], centres[pos],
+                    ref_seq[FLANK]))
+                n_written += 1
+    print("[INFO] {} Tensors generated: {}".format(args.ctg_name, n_written))
+    return n_written
+
+
+def main():
+    p = ArgumentParser(description="Generate tumor pileup tensors for calling (GPU featurisation)")
+    p.add_argument("--platform", type=str, default="ont")
+    p.add_argument("--tumor_bam_fn", type=str, default=None)
+    p.add_argument("--mpileup_fn", type=str, default=None, help="samtools mpileup text (--min-BQ 0) instead of a BAM")
+    p.add_argument("--ref_fn", type=str, required=True)
+    p.add_argument("--tensor_can_fn", type=str, default="PIPE")
+    p.add_argument("--tensor_can_fn_neg", type=str, default=None, help="also write the --min_bq 0 (NEG) tensor")
+    p.add_argument("--ctg_name", type=str, required=True)
+    p.add_argument("--samtools", type=str, default="samtools")
+    p.add_argument("--min_bq", type=int, default=0)
+    p.add_argument("--max_depth", type=int, default=None)
+    p.add_argument("--max_indel_length", type=int, default=None)
+    p.add_argument("--candidates_bed_regions", type=str, required=True)
+    create_tensor(p.parse_args())
+
+
+if __name__ == "__main__":
+    main()

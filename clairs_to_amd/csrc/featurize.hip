@@ -35,7 +35,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_featurize_columns(
     PackDev pk, int min_bq, int16_t* __restrict__ colvec, int32_t* __restrict__ coldepth,
     int32_t* __restrict__ colfirst, uint32_t* __restrict__ keycnt, int32_t* __restrict__ keyfirst) {
     __shared__ uint32_t s_hist[WAVES_PER_BLOCK][COLS_PER_WAVE][HSLOTS];
-    __shared__ int32_t s_first[WAVES_PER_BLOCK][COLS_PER_WAVE][4];
+    __shared__ int32_t s_first[WAVES_PER_BLOCK][COLS_PER_WAVE][8];   // [pass][A,C,G,T]
     __shared__ int64_t s_off[WAVES_PER_BLOCK][COLS_PER_WAVE + 1];
     __shared__ int16_t s_out[WAVES_PER_BLOCK][COLS_PER_WAVE][CTO_COLVEC_STRIDE];
 
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_featurize_columns(
     if (c0 < pk.n_cols) ncol = int(pk.n_cols - c0 < COLS_PER_WAVE ? pk.n_cols - c0 : COLS_PER_WAVE);
 
     for (int i = lane; i < COLS_PER_WAVE * HSLOTS; i += 64) (&s_hist[w][0][0])[i] = 0u;
-    if (lane < COLS_PER_WAVE * 4) (&s_first[w][0][0])[lane] = INT_NONE;
+    for (int i = lane; i < COLS_PER_WAVE * 8; i += 64) (&s_first[w][0][0])[i] = INT_NONE;
     if (lane <= COLS_PER_WAVE) s_off[w][lane] = (ncol > 0) ? pk.col_off[c0 + (lane < ncol ? lane : ncol)] : 0;
     __syncthreads();
 
@@ -78,7 +78,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_featurize_columns(
                     if (ch >= 0) {
                         atomicAdd(&h[ch], inc);
                         atomicAdd(&h[34], inc);                             // depth
-                        if (acgt && pass) atomicMin(&s_first[w][cl][b & 3u], idx);
+                        if (acgt) {
+                            atomicMin(&s_first[w][cl][4 + (b & 3u)], idx);
+                            if (pass) atomicMin(&s_first[w][cl][b & 3u], idx);
+                        }
                     }
                 } else if (acgt) {
                     atomicAdd(&h[18 + int(b)], inc);                        // {ACGTacgt}LMQ
@@ -90,7 +93,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_featurize_columns(
                 atomicAdd(&h[34], inc);
                 const int64_t k = int64_t(pk.key_off[c0 + cl]) + kid;
                 atomicAdd(&keycnt[k], inc);
-                if (pass) atomicMin(&keyfirst[k], idx);
+                atomicMin(&keyfirst[2 * k + 1], idx);
+                if (pass) atomicMin(&keyfirst[2 * k], idx);
             }
         }
     }
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_featurize_columns(
             coldepth[c * 2 + p] = int(p == 0 ? (h[34] & 0xffffu) : (h[34] >> 16));
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) colfirst[c * 4 + i] = s_first[w][lane][i];
+        for (int i = 0; i < 8; ++i) colfirst[c * 8 + i] = s_first[w][lane][i];
     }
     __syncthreads();
     // coalesced write-back: ncol * 144 contiguous bytes per wave, 16 B per lane per pass
@@ -238,7 +242,7 @@ extern "C" int cto_featurize_columns(const cto_pack_view* dp, int min_bq, int16_
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dp->n_keys > 0) {
         CTO_HIP(hipMemsetAsync(keycnt, 0, size_t(dp->n_keys) * 4, s));
-        CTO_HIP(hipMemsetAsync(keyfirst, 0x7f, size_t(dp->n_keys) * 4, s));   // 0x7f7f7f7f: > any entry index
+        CTO_HIP(hipMemsetAsync(keyfirst, 0x7f, size_t(dp->n_keys) * 8, s));   // 0x7f7f7f7f: > any entry index
     }
     if (dp->n_cols == 0) return CTO_OK;
     const int64_t per_block = COLS_PER_WAVE * WAVES_PER_BLOCK;

@@ -262,11 +262,14 @@ extern "C" int cto_pack_key_string(const cto_pack* p, int64_t k, const char** s)
 
 extern "C" void cto_pack_free(cto_pack* p) { delete p; }
 
-extern "C" int cto_alt_info(const cto_pack* p, int64_t col, const int16_t* cv, int32_t depth_aff,
+extern "C" int cto_alt_info(const cto_pack* p, int64_t col, int pass, const int16_t* cv, int32_t depth_aff,
                             const int32_t* colfirst_col, const uint32_t* keycnt, const int32_t* keyfirst,
                             char* buf, size_t cap) {
     CTO_REQUIRE(p && cv && colfirst_col && buf && cap > 0, CTO_EINVAL, "cto_alt_info: null argument");
     CTO_REQUIRE(col >= 0 && size_t(col) < p->col_pos.size(), CTO_EINVAL, "cto_alt_info: column out of range");
+    CTO_REQUIRE(pass == 0 || pass == 1, CTO_EINVAL, "cto_alt_info: pass must be 0 (AFF) or 1 (NEG)");
+    cv += pass * 36;
+    colfirst_col += pass * 4;
     struct Item { int64_t first; std::string key; int64_t count; };
     std::vector<Item> items;
     const int ref = p->col_ref[size_t(col)];
@@ -284,14 +287,14 @@ extern "C" int cto_alt_info(const cto_pack* p, int64_t col, const int16_t* cv, i
     }
     const int32_t k0 = p->key_off[size_t(col)], k1 = p->key_off[size_t(col) + 1];
     for (int32_t k = k0; k < k1; ++k) {
-        int64_t c = keycnt[k] & 0xffffu;
+        int64_t c = pass == 0 ? (keycnt[k] & 0xffffu) : (keycnt[k] >> 16);
         if (c == 0) continue;
         std::string key(p->key_str.data() + p->key_str_off[size_t(k)], size_t(p->key_str_off[size_t(k) + 1] - p->key_str_off[size_t(k)]));
         bool merged = false;
         for (auto& it : items) {
-            if (it.key == key) { it.count += c; it.first = std::min<int64_t>(it.first, keyfirst[k]); merged = true; break; }
+            if (it.key == key) { it.count += c; it.first = std::min<int64_t>(it.first, keyfirst[2 * k + pass]); merged = true; break; }
         }
-        if (!merged) items.push_back(Item{keyfirst[k], key, c});
+        if (!merged) items.push_back(Item{keyfirst[2 * k + pass], key, c});
     }
     std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.first < b.first; });
     std::string s = std::to_string(depth_aff) + "-";

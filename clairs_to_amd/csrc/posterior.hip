@@ -86,7 +86,28 @@ __global__ __launch_bounds__(256) void k_posterior(const float* __restrict__ aff
     qual[b] = rint(q * 1e4) / 1e4;
 }
 
+__global__ __launch_bounds__(256) void k_softmax_probs(const float* __restrict__ aff, const float* __restrict__ neg, int K,
+                                                       int64_t B, float* __restrict__ probs) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;   // one (site, head) pair per thread
+    if (i >= B * 2 * K) return;
+    const int64_t b = i / (2 * K);
+    const int k = int(i - b * 2 * K);
+    const float* o = (k < K ? aff + (int64_t(k) * B + b) * 2 : neg + (int64_t(k - K) * B + b) * 2);
+    probs[i * 2 + 0] = softmax_p0(o);
+    probs[i * 2 + 1] = softmax_p1(o);
+}
+
 }  // namespace
+
+extern "C" int cto_softmax_probs(const float* aff_logits, const float* neg_logits, int K, int64_t B, float* probs, void* stream) {
+    CTO_REQUIRE(aff_logits && neg_logits && probs, CTO_EINVAL, "cto_softmax_probs: null argument");
+    CTO_REQUIRE(K == 4 || K == 6, CTO_EINVAL, "K must be 4 or 6");
+    if (B == 0) return CTO_OK;
+    hipLaunchKernelGGL(k_softmax_probs, dim3(unsigned(cto::cdiv(B * 2 * K, 256))), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), aff_logits, neg_logits, K, B, probs);
+    CTO_HIP(hipGetLastError());
+    return CTO_OK;
+}
 
 extern "C" int cto_posterior(const float* aff_logits, const float* neg_logits, int K, int64_t B, const double* lik,
                              const double* edges, float* probs, double* post, int32_t* decision, double* qual,

@@ -23,9 +23,9 @@ class Features:
     site_info: torch.Tensor    # [n,12] int32: centre col, depth_aff, depth_neg, flags, fwd ACGT, rev ACGT
     colvec: torch.Tensor       # [n_cols,72] int16
     coldepth: torch.Tensor     # [n_cols,2] int32
-    colfirst: torch.Tensor     # [n_cols,4] int32
+    colfirst: torch.Tensor     # [n_cols,8] int32 ([pass][A,C,G,T])
     keycnt: torch.Tensor       # [n_keys] int32 (uint32 bits: low16 AFF count, high16 NEG count)
-    keyfirst: torch.Tensor     # [n_keys] int32
+    keyfirst: torch.Tensor     # [n_keys,2] int32 (per pass)
 
 
 def featurize(dev_pack, site_pos, min_bq, min_rescale_cov=50, want_raw=False, want_x=True):
@@ -38,9 +38,9 @@ def featurize(dev_pack, site_pos, min_bq, min_rescale_cov=50, want_raw=False, wa
     nc, nk = dev_pack.n_cols, dev_pack.n_keys
     colvec = torch.empty((max(nc, 1), COLVEC_STRIDE), dtype=torch.int16, device=dev)   # never a null pointer
     coldepth = torch.empty((max(nc, 1), 2), dtype=torch.int32, device=dev)
-    colfirst = torch.empty((max(nc, 1), 4), dtype=torch.int32, device=dev)
+    colfirst = torch.empty((max(nc, 1), 8), dtype=torch.int32, device=dev)
     keycnt = torch.empty((max(nk, 1),), dtype=torch.int32, device=dev)
-    keyfirst = torch.empty((max(nk, 1),), dtype=torch.int32, device=dev)
+    keyfirst = torch.empty((max(nk, 1), 2), dtype=torch.int32, device=dev)
     s = current_stream_ptr()
     check(lib.cto_featurize_columns(C.byref(dev_pack.view), int(min_bq), colvec.data_ptr(), coldepth.data_ptr(),
                                     colfirst.data_ptr(), keycnt.data_ptr(), keyfirst.data_ptr(), s))
@@ -56,8 +56,8 @@ def featurize(dev_pack, site_pos, min_bq, min_rescale_cov=50, want_raw=False, wa
     return Features(x_aff, x_neg, raw_aff, raw_neg, site_info, colvec[:nc], coldepth[:nc], colfirst[:nc], keycnt[:nk], keyfirst[:nk])
 
 
-def alt_infos(feat, host_pack, site_info_host=None):
-    """The reference's alt_info strings of the AFF pass for every site with a centre column
+def alt_infos(feat, host_pack, site_info_host=None, pass_idx=0):
+    """The reference's alt_info strings of pass `pass_idx` (0 = AFF, 1 = NEG) for every site with a centre column
     (create_tensor_pileup_calling.py:158-209); '' for sites without one.  Host work on device results."""
     info = feat.site_info.cpu().numpy() if site_info_host is None else site_info_host
     colvec = feat.colvec.cpu().numpy()
@@ -66,7 +66,7 @@ def alt_infos(feat, host_pack, site_info_host=None):
     keyfirst = np.ascontiguousarray(feat.keyfirst.cpu().numpy())
     if keycnt.size == 0:
         keycnt = np.zeros(1, dtype=np.uint32)
-        keyfirst = np.zeros(1, dtype=np.int32)
+        keyfirst = np.zeros((1, 2), dtype=np.int32)
     buf = C.create_string_buffer(1 << 16)
     out = []
     for i in range(info.shape[0]):
@@ -74,7 +74,7 @@ def alt_infos(feat, host_pack, site_info_host=None):
         if c < 0:
             out.append("")
             continue
-        n = check(lib.cto_alt_info(host_pack._h, c, colvec[c].ctypes.data, int(info[i, 1]), colfirst[c].ctypes.data,
-                                   keycnt.ctypes.data, keyfirst.ctypes.data, buf, len(buf)))
+        n = check(lib.cto_alt_info(host_pack._h, c, int(pass_idx), colvec[c].ctypes.data, int(info[i, 1 + pass_idx]),
+                                   colfirst[c].ctypes.data, keycnt.ctypes.data, keyfirst.ctypes.data, buf, len(buf)))
         out.append(buf.raw[:n].decode())
     return out

@@ -94,10 +94,10 @@ void cto_pack_free(cto_pack* p);
  * reference (run_clairs_to:1228-1271).
  *   colvec   dev [n_cols][2][36] int16   pass 0 = AFF, pass 1 = NEG
  *   coldepth dev [n_cols][2]     int32   `depth` of F4 (MQ>=20, N / over-long indels excluded)
- *   colfirst dev [n_cols][4]     int32   AFF pass: first-seen entry index of bases A,C,G,T (either
+ *   colfirst dev [n_cols][2][4]  int32   per pass: first-seen entry index of bases A,C,G,T (either
  *                                        strand, MQ>=20) or 0x7fffffff -- alt_info key order (F5)
  *   keycnt   dev [n_keys]        uint32  low 16 = AFF count, high 16 = NEG count of each distinct key
- *   keyfirst dev [n_keys]        int32   AFF pass first-seen entry index (0x7fffffff if none)
+ *   keyfirst dev [n_keys][2]     int32   per pass first-seen entry index (>= 0x7f7f7f7f if none)
  * keycnt/keyfirst are initialised by the call. Limit: column depth <= 32767 (CTO_EUNSUPPORTED is
  * raised by the pack builders). */
 int cto_featurize_columns(const cto_pack_view* dev_pack, int min_bq, int16_t* colvec, int32_t* coldepth,
@@ -119,10 +119,11 @@ int cto_gather_windows(const cto_pack_view* dev_pack, const int16_t* colvec, con
                        float* x_aff, float* x_neg, int16_t* raw_aff, int16_t* raw_neg,
                        int32_t* site_info, void* stream);
 
-/* Host: the reference's alt_info string "<depth>-<key count ...>-" for the column `col` of the AFF pass
- * (create_tensor_pileup_calling.py:158-209), from stage-A outputs copied to the host.
- * colvec_col points at that column's [2][36] int16. Returns the string length (<= cap-1) or an error. */
-int cto_alt_info(const cto_pack* p, int64_t col, const int16_t* colvec_col, int32_t depth_aff,
+/* Host: the reference's alt_info string "<depth>-<key count ...>-" for the column `col` of pass `pass`
+ * (0 = AFF, 1 = NEG; create_tensor_pileup_calling.py:158-209), from stage-A outputs copied to the host.
+ * colvec_col / colfirst_col point at that column's [2][36] int16 / [2][4] int32; keycnt / keyfirst are the whole
+ * arrays.  Returns the string length (<= cap-1) or an error. */
+int cto_alt_info(const cto_pack* p, int64_t col, int pass, const int16_t* colvec_col, int32_t depth,
                  const int32_t* colfirst_col, const uint32_t* keycnt, const int32_t* keyfirst,
                  char* buf, size_t cap);
 
@@ -177,6 +178,10 @@ int cto_model_profile_read(cto_model* m, double* mean_ms, int64_t* macs_per_site
 int cto_posterior(const float* aff_logits, const float* neg_logits, int K, int64_t B,
                   const double* lik, const double* edges, float* probs, double* post,
                   int32_t* decision, double* qual, void* stream);
+
+/* Only the 2-way softmax of clairs/predict.py:659-684: probs dev [B][2K][2] in the order the probability text
+ * rows use (a c g t [i d] na nc ng nt [ni nd]). */
+int cto_softmax_probs(const float* aff_logits, const float* neg_logits, int K, int64_t B, float* probs, void* stream);
 
 /* Same epilogue entered at the probability text seam (clairs/call_variants.py:798-829 parses the rows that
  * clairs/predict.py:114-152 wrote): p1 dev [B][2K] double = the second number of each "p0 p1" field, in the

@@ -1,0 +1,94 @@
+"""GPU tests of the three drop-in sub-modules at their text seams, against the reference's own files."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_json_gz, load_models_npz
+from weights_recipe import make_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_region(tmp_path, g):
+    ref = g["ref"]
+    fa = tmp_path / "ref.fa"
+    fa.write_text(">chr1\n" + "\n".join(ref[i:i + 60] for i in range(0, len(ref), 60)) + "\n")
+    (tmp_path / "ref.fa.fai").write_text("chr1\t%d\t6\t60\t61\n" % len(ref))
+    bed = tmp_path / "cand.bed"
+    bed.write_text("".join("chr1\t%d\t%d\n" % (x - 17, x + 17) for x in g["sites"]))
+    mp = tmp_path / "mp.txt"
+    mp.write_text(g["mpileup_neg"])
+    return str(fa), str(bed), str(mp)
+
+
+def test_create_tensor_cli_matches_reference_text(tmp_path, golden_region):
+    from argparse import Namespace
+    from clairs_to_amd.create_tensor_pileup_calling import create_tensor
+    fa, bed, mp = _write_region(tmp_path, golden_region)
+    aff, neg = str(tmp_path / "aff.gz"), str(tmp_path / "neg.gz")
+    args = Namespace(candidates_bed_regions=bed, ctg_name="chr1", ref_fn=fa, mpileup_fn=mp, samtools="samtools",
+                     tumor_bam_fn=None, max_depth=None, max_indel_length=None, min_bq=20, tensor_can_fn=aff,
+                     tensor_can_fn_neg=neg, platform="ont")
+    create_tensor(args)
+    assert gzip.open(aff, "rt").read() == golden_region["tensor_aff"]
+    assert gzip.open(neg, "rt").read() == golden_region["tensor_neg"]
+
+
+@pytest.mark.parametrize("mode,aff_cls,neg_cls", [("snv", "CvT", "BiGRU_NACGT"), ("indel", "CvT_Indel", "BiGRU_NACGT_Indel")])
+def test_predict_and_call_variants_cli(tmp_path, golden_region, mode, aff_cls, neg_cls):
+    import torch
+    from argparse import Namespace
+    from clairs_to_amd import nn_shims
+    from clairs_to_amd.predict import predict
+    from clairs_to_amd.call_variants import call_variants_from_probability
+    calls = load_json_gz("calls_%s.json.gz" % mode)
+    K = calls["n_out"]
+    for tag in ("aff", "neg"):
+        with gzip.open(tmp_path / ("t_%s.gz" % tag), "wt") as f:
+            f.write(golden_region["tensor_" + tag])
+    # checkpoints pickled under the reference's qualified names (clairs.model.<cls>), as its releases are
+    nn_shims.install_reference_aliases()
+    paths = {}
+    for key, cls in (("model_acgt", aff_cls), ("model_nacgt", neg_cls)):
+        g = load_models_npz(cls)
+        m = nn_shims.from_state_dict(cls, make_weights(g["manifest"], seed=K))
+        klasses = [c for c in type(m).__mro__ if c.__module__ == nn_shims.__name__]
+        saved = {c: c.__module__ for c in klasses}
+        try:
+            for c in vars(nn_shims).values():
+                if isinstance(c, type) and c.__module__ == nn_shims.__name__:
+                    saved[c] = c.__module__
+                    c.__module__ = "clairs.model"
+            paths[key] = str(tmp_path / (key + ".pkl"))
+            torch.save({key: m}, paths[key])
+        finally:
+            for c, mod in saved.items():
+                c.__module__ = mod
+    pred = str(tmp_path / "pred.gz")
+    args = Namespace(tensor_fn_acgt=str(tmp_path / "t_aff.gz"), tensor_fn_nacgt=str(tmp_path / "t_neg.gz"),
+                     chkpnt_fn_acgt=paths["model_acgt"], chkpnt_fn_nacgt=paths["model_nacgt"], predict_fn=pred,
+                     ctg_name="chr1", min_rescale_cov=50, disable_indel_calling=(mode == "snv"), use_gpu=True, pileup=True)
+    n = predict(args)
+    got = [r.split("\t") for r in gzip.open(pred, "rt").read().split("\n") if r]
+    want = [r.split("\t") for r in calls["predict_rows"].split("\n") if r]
+    assert n == len(want) == len(got)
+    for a, b in zip(got, want):
+        assert a[:6] == b[:6] and len(a) == len(b)
+        pa = np.array([[float(v) for v in f.split()] for f in a[6:6 + 2 * K]])
+        pb = np.array([[float(v) for v in f.split()] for f in b[6:6 + 2 * K]])
+        assert np.abs(pa - pb).max() < 1e-4          # north_star tolerance on probabilities
+    # call_variants on the REFERENCE's probability rows: VCF records must be byte-identical
+    ref_pred = str(tmp_path / "ref_pred.gz")
+    with gzip.open(ref_pred, "wt") as f:
+        f.write(calls["predict_rows"])
+    lik = str(tmp_path / "lik.txt")
+    open(lik, "w").write(calls["likelihood_table"])
+    for show_ref in (False, True):
+        vcf = str(tmp_path / ("out_%d.vcf" % show_ref))
+        call_variants_from_probability(Namespace(call_fn=vcf, predict_fn=ref_pred, likelihood_matrix_data=lik, ctg_name="chr1",
+                                                 sample_name="SAMPLE", qual=0, show_ref=show_ref,
+                                                 disable_indel_calling=(mode == "snv"), pileup=True, platform="ont"))
+        rows = [r for r in open(vcf).read().split("\n") if r and not r.startswith("#")]
+        assert rows == calls["vcf"]["show_ref" if show_ref else "default"]

@@ -41,6 +41,10 @@ def test_featurize_matches_reference_region(dev, golden_region):
         assert info[kept, dcol].tolist() == [int(a.split("-")[0]) for a in alt_ref]
         if tag == "aff":
             assert [alts[i] for i in kept] == alt_ref
+        else:
+            from clairs_to_amd.featurize import alt_infos
+            alts_neg = alt_infos(feat, pack, info, pass_idx=1)
+            assert [alts_neg[i] for i in kept] == alt_ref
 
 
 def test_featurize_matches_oracle_synthetic(dev, oracle_lib):
