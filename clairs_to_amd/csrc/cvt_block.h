@@ -1,0 +1,409 @@
+// Fused CvT transformer block (clairs/model.py:134-147: x = attn(x) + x; x = ff(x) + x) for gfx950.
+//
+// One workgroup (4 waves) owns TS sites = R = TS*W activation rows of C channels and keeps the residual
+// stream, every intermediate (LayerNorm output, depth-wise conv outputs, per-head q/k/v, attention output,
+// FFN hidden chunk) in LDS; only the weights stream in (from L2, straight into MFMA B registers) and only
+// the updated residual stream goes back to HBM.  The unfused path spends ~8 launches and ~10 HBM round
+// trips per block on the same work.
+//
+//   phase 0  h tile -> LDS
+//   phase 1  y  = LN(h; norm0)                              (model.py:57-76, wave reduction per row)
+//   phase 2  yq = BN(DW_s1(y)) in place, ykv = BN(DW_s2(y)) (model.py:91-100, 112-113)
+//   phase 3  per head: q_h, k_h, v_h (MFMA) -> LDS; softmax(q_h k_h^T / 8) v_h per site (VALU, <= 9x5
+//            scores); out-projection accumulated over heads in registers (MFMA, K = 64 per head)
+//   phase 4  h += to_out(o) + bias
+//   phase 5  y  = LN(h; norm1)
+//   phase 6  per 128-wide chunk of the 4C hidden units: u = GELU(y W1^T + b1) -> LDS, acc += u W2^T
+//   phase 7  h += acc + b2 -> HBM
+//
+// GEMMs: fp32 MFMA 16x16x4; A fragments from LDS (ds_read_b128 = four k-steps), B fragments from global
+// (one 16-byte load per lane per n-tile per 16-wide k chunk, prefetched two chunks ahead); the 4 waves split
+// N, every wave sweeps all M tiles so each weight fragment is reused MT (= 5) times.
+#pragma once
+#include <type_traits>
+#include "nn_kernels.h"
+
+namespace cto {
+
+struct CvtBlockParams {
+    const float *n0g, *n0b, *dwq, *bnq, *wq, *dwkv, *bnkv, *wkv, *wo, *bo, *n1g, *n1b, *w1, *b1, *w2, *b2;
+};
+
+// The first two 16-wide k chunks of a GEMM's weights, requested early (before the barriers / VALU phases that
+// precede the GEMM) so that the matrix pipe does not start every GEMM with an exposed L2 round trip.
+template <int NTW>
+struct BPre {
+    float4 b0[NTW], b1[NTW];
+};
+template <int NTW, int KCH>
+__device__ __forceinline__ BPre<NTW> prefetch_b(const float* const (&wrow)[NTW]) {
+    BPre<NTW> p;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        p.b0[nt] = *reinterpret_cast<const float4*>(wrow[nt]);
+        p.b1[nt] = KCH > 1 ? *reinterpret_cast<const float4*>(wrow[nt] + 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return p;
+}
+
+// acc[mt][nt] += A[mt*16 .. +16][0 .. KCH*16) * W[n-tile rows][same k];  wrow[nt] already points at
+// W[(n0 + nt*16 + j)][4*kg].  A rows are `lda` floats apart in LDS.  `pre` holds chunks 0 and 1.
+template <int MT, int NTW, int KCH>
+__device__ __forceinline__ void gemm_lds(const float* __restrict__ A, int lda, const float* const (&wrow)[NTW],
+                                         const BPre<NTW>& pre, f32x4 (&acc)[MT][NTW], int j, int kg) {
+    float4 Bq[3][NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) { Bq[0][nt] = pre.b0[nt]; Bq[1][nt] = pre.b1[nt]; }
+    float4 a[2][MT];     // A fragments are fetched one chunk ahead too (LDS latency is exposed with 1 wave per SIMD)
+    const float* Arow = A + j * lda + 4 * kg;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[0][mt] = *reinterpret_cast<const float4*>(Arow + mt * 16 * lda);
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) {
+        if (c + 2 < KCH) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) Bq[(c + 2) % 3][nt] = *reinterpret_cast<const float4*>(wrow[nt] + (c + 2) * 16);
+        }
+        if (c + 1 < KCH) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[(c + 1) & 1][mt] = *reinterpret_cast<const float4*>(Arow + mt * 16 * lda + (c + 1) * 16);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const float4 b = Bq[c % 3][nt];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float4 av = a[c & 1][mt];
+                acc[mt][nt] = mfma16(av.x, b.x, acc[mt][nt]);
+                acc[mt][nt] = mfma16(av.y, b.y, acc[mt][nt]);
+                acc[mt][nt] = mfma16(av.z, b.z, acc[mt][nt]);
+                acc[mt][nt] = mfma16(av.w, b.w, acc[mt][nt]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int C, int W, int WKV, int TS>
+struct CvtBlockGeom {
+    static constexpr int R = TS * W, RKV = TS * WKV;
+    static constexpr int MT = (R + 15) / 16, MTKV = (RKV + 15) / 16;
+    static constexpr int RS = C + 4, QS = 68, HC = 128, US = HC + 4;
+    static constexpr int OFF_H = 0;
+    static constexpr int OFF_Y = OFF_H + MT * 16 * RS;
+    static constexpr int OFF_YKV = OFF_Y + MT * 16 * RS;
+    static constexpr int OFF_Q = OFF_YKV + MTKV * 16 * RS;
+    static constexpr int OFF_K = OFF_Q + MT * 16 * QS;
+    static constexpr int OFF_V = OFF_K + MTKV * 16 * QS;
+    static constexpr int OFF_P = OFF_V + MTKV * 16 * QS;
+    static constexpr int SCRATCH = OFF_P - OFF_YKV;            // ykv|q|k|v region, re-used for the FFN hidden chunk
+    static constexpr int U_FLOATS = MT * 16 * US;
+    static constexpr int TOTAL = OFF_P + TS * W * WKV + (U_FLOATS > SCRATCH ? U_FLOATS - SCRATCH : 0);
+    static constexpr size_t LDS_BYTES = size_t(TOTAL) * sizeof(float);
+};
+
+// 8 waves per workgroup (two per SIMD): waves 0-3 and 4-7 split the M tiles of every GEMM between them (the
+// n-tile owner is wave & 3), so one wave's LDS / L2 waits and VALU phases overlap the other's MFMAs.
+constexpr int CVT_BLOCK_THREADS = 512;
+
+template <int C, int W, int WKV, int TS>
+__global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restrict__ h, CvtBlockParams p, int heads, int B) {
+    using G = CvtBlockGeom<C, W, WKV, TS>;
+    constexpr int NT = CVT_BLOCK_THREADS, NWV = NT / 64;
+    constexpr int R = G::R, RKV = G::RKV, MT = G::MT, MTKV = G::MTKV, RS = G::RS, QS = G::QS, HC = G::HC, US = G::US;
+    constexpr int MT0 = (MT + 1) / 2, MT1 = MT - MT0, MK0 = (MTKV + 1) / 2, MK1 = MTKV - MK0;
+    constexpr int NTC = C / 64;          // n-tiles per wave when the output is C wide
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sh = smem + G::OFF_H;
+    float* sy = smem + G::OFF_Y;
+    float* sykv = smem + G::OFF_YKV;
+    float* sq = smem + G::OFF_Q;
+    float* sk = smem + G::OFF_K;
+    float* sv = smem + G::OFF_V;
+    float* sp = smem + G::OFF_P;
+    float* su = smem + G::OFF_YKV;       // alias: FFN hidden chunk [MT*16][US]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
+    const int wn = wave & 3, mh = wave >> 2;                   // n-tile owner, M half
+    const int mbase = mh ? MT0 : 0, mcount = mh ? MT1 : MT0;   // this wave's m-tiles of [R]-row operands
+    const int kbase = mh ? MK0 : 0, kcount = mh ? MK1 : MK0;   // ... of [RKV]-row operands
+    const int site0 = blockIdx.x * TS;
+    const int nsite = min(TS, B - site0);
+    const int rows_valid = nsite * W;
+    const int inner = heads * 64;
+    float* hg = h + int64_t(site0) * W * C;
+
+    // GEMM over this wave's M half; accumulators are sized for the larger half
+    auto gemm_r = [&](auto ntw_tag, auto kch_tag, const float* A, int lda, const auto& wr, const auto& pre, auto& acc) {
+        constexpr int NTW = decltype(ntw_tag)::value, KCH = decltype(kch_tag)::value;
+        if (mh == 0) {
+            gemm_lds<MT0, NTW, KCH>(A, lda, wr, pre, acc, j, kg);
+        } else if constexpr (MT1 > 0) {
+            f32x4 (&a1)[MT1][NTW] = reinterpret_cast<f32x4 (&)[MT1][NTW]>(acc);
+            gemm_lds<MT1, NTW, KCH>(A + MT0 * 16 * lda, lda, wr, pre, a1, j, kg);
+        }
+    };
+    auto gemm_kv = [&](auto kch_tag, const float* A, int lda, const auto& wr, const auto& pre, auto& acc) {
+        constexpr int KCH = decltype(kch_tag)::value;
+        if (mh == 0) {
+            gemm_lds<MK0, 2, KCH>(A, lda, wr, pre, acc, j, kg);
+        } else if constexpr (MK1 > 0) {
+            f32x4 (&a1)[MK1][2] = reinterpret_cast<f32x4 (&)[MK1][2]>(acc);
+            gemm_lds<MK1, 2, KCH>(A + MK0 * 16 * lda, lda, wr, pre, a1, j, kg);
+        }
+    };
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using INTC = std::integral_constant<int, NTC>;
+    using KC = std::integral_constant<int, C / 16>;
+    using K4 = std::integral_constant<int, 4>;
+    using KH = std::integral_constant<int, HC / 16>;
+
+    // ---- phase 0: residual stream tile -> LDS (pad rows zero) ----
+    for (int i = tid; i < MT * 16 * (C / 4); i += NT) {
+        const int r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < rows_valid) v = *reinterpret_cast<const float4*>(hg + r * C + c4);
+        *reinterpret_cast<float4*>(sh + r * RS + c4) = v;
+    }
+    for (int i = tid; i < (MTKV * 16 - RKV) * RS; i += NT) sykv[RKV * RS + i] = 0.f;
+    __syncthreads();
+
+    auto layer_norm = [&](const float* g, const float* b) {   // sh -> sy, one wave per row
+        const float g0 = lane < C ? g[lane] : 0.f, g1 = lane + 64 < C ? g[lane + 64] : 0.f;
+        const float b0 = lane < C ? b[lane] : 0.f, b1 = lane + 64 < C ? b[lane + 64] : 0.f;
+        for (int r = wave; r < MT * 16; r += NWV) {
+            const float* xr = sh + r * RS;
+            const float v0 = lane < C ? xr[lane] : 0.f, v1 = lane + 64 < C ? xr[lane + 64] : 0.f;
+            const float mean = wave_sum(v0 + v1) / float(C);
+            const float d0 = lane < C ? v0 - mean : 0.f, d1 = lane + 64 < C ? v1 - mean : 0.f;
+            const float var = wave_sum(d0 * d0 + d1 * d1) / float(C);
+            const float inv = 1.0f / (sqrtf(var) + 1e-5f);
+            if (lane < C) sy[r * RS + lane] = d0 * inv * g0 + b0;
+            if (lane + 64 < C) sy[r * RS + lane + 64] = d1 * inv * g1 + b1;
+        }
+    };
+
+    // ---- phase 1 ----
+    layer_norm(p.n0g, p.n0b);
+    __syncthreads();
+
+    // ---- phase 2: depth-wise 3-tap conv + BatchNorm; q path in place, kv path (stride 2) to sykv ----
+    {
+        static_assert(NT % C == 0, "column mapping assumes C divides the block size");
+        const int c = tid % C;                 // every column this thread handles has the same channel
+        const float q0 = p.dwq[c * 3], q1 = p.dwq[c * 3 + 1], q2 = p.dwq[c * 3 + 2];
+        const float k0 = p.dwkv[c * 3], k1 = p.dwkv[c * 3 + 1], k2 = p.dwkv[c * 3 + 2];
+        const float qm = p.bnq[c], qi = p.bnq[C + c], qw = p.bnq[2 * C + c], qb = p.bnq[3 * C + c];
+        const float km = p.bnkv[c], ki = p.bnkv[C + c], kw = p.bnkv[2 * C + c], kb = p.bnkv[3 * C + c];
+        for (int s = tid / C; s < TS; s += NT / C) {
+            float y[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) y[w] = sy[(s * W + w) * RS + c];
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const float l = w > 0 ? y[w - 1] : 0.f, r = w + 1 < W ? y[w + 1] : 0.f;
+                const float d = q0 * l + q1 * y[w] + q2 * r;
+                sy[(s * W + w) * RS + c] = (d - qm) * qi * qw + qb;
+            }
+#pragma unroll
+            for (int wo = 0; wo < WKV; ++wo) {
+                const int w = 2 * wo;
+                const float l = w > 0 ? y[w - 1] : 0.f, r = w + 1 < W ? y[w + 1] : 0.f;
+                const float d = k0 * l + k1 * y[w] + k2 * r;
+                sykv[(s * WKV + wo) * RS + c] = (d - km) * ki * kw + kb;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: attention, head by head; out-projection accumulates in registers ----
+    f32x4 acc_o[MT0][NTC];
+#pragma unroll
+    for (int mt = 0; mt < MT0; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) acc_o[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto q_rows = [&](int hh, const float* (&wr)[1]) { wr[0] = p.wq + int64_t(hh * 64 + wn * 16 + j) * C + 4 * kg; };
+    auto kv_rows = [&](int hh, const float* (&wr)[2]) {
+        wr[0] = p.wkv + int64_t(hh * 64 + wn * 16 + j) * C + 4 * kg;
+        wr[1] = p.wkv + int64_t(inner + hh * 64 + wn * 16 + j) * C + 4 * kg;
+    };
+    auto o_rows = [&](int hh, const float* (&wr)[NTC]) {
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) wr[nt] = p.wo + int64_t((wn * NTC + nt) * 16 + j) * inner + hh * 64 + 4 * kg;
+    };
+    auto w1_rows = [&](int cc, const float* (&wr)[2]) {
+        wr[0] = p.w1 + int64_t(cc * HC + wn * 32 + j) * C + 4 * kg;
+        wr[1] = p.w1 + int64_t(cc * HC + wn * 32 + 16 + j) * C + 4 * kg;
+    };
+    auto w2_rows = [&](int cc, const float* (&wr)[NTC]) {
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) wr[nt] = p.w2 + int64_t((wn * NTC + nt) * 16 + j) * (4 * C) + cc * HC + 4 * kg;
+    };
+
+    const float* wq_r[1];
+    q_rows(0, wq_r);
+    BPre<1> pre_q = prefetch_b<1, C / 16>(wq_r);
+    for (int hh = 0; hh < heads; ++hh) {
+        const float* wkv_r[2];
+        kv_rows(hh, wkv_r);
+        const BPre<2> pre_kv = prefetch_b<2, C / 16>(wkv_r);
+        {   // q_h : [R][64], this wave's 16 columns of its M half
+            f32x4 aq[MT0][1];
+#pragma unroll
+            for (int mt = 0; mt < MT0; ++mt) aq[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm_r(I1{}, KC{}, sy, RS, wq_r, pre_q, aq);
+#pragma unroll
+            for (int mt = 0; mt < MT0; ++mt)
+                if (mt < mcount) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sq[((mbase + mt) * 16 + 4 * kg + r) * QS + wn * 16 + j] = aq[mt][0][r];
+                }
+        }
+        const float* wo_r[NTC];
+        o_rows(hh, wo_r);
+        const BPre<NTC> pre_o = prefetch_b<NTC, 4>(wo_r);
+        {   // k_h, v_h : [RKV][64]
+            f32x4 akv[MK0][2];
+#pragma unroll
+            for (int mt = 0; mt < MK0; ++mt) { akv[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; akv[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            gemm_kv(KC{}, sykv, RS, wkv_r, pre_kv, akv);
+#pragma unroll
+            for (int mt = 0; mt < MK0; ++mt)
+                if (mt < kcount) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sk[((kbase + mt) * 16 + 4 * kg + r) * QS + wn * 16 + j] = akv[mt][0][r];
+                        sv[((kbase + mt) * 16 + 4 * kg + r) * QS + wn * 16 + j] = akv[mt][1][r];
+                    }
+                }
+        }
+        __syncthreads();
+        // scores = q k^T / 8 per site (model.py:126; dim_head = 64)
+        for (int t = tid; t < TS * W * WKV; t += NT) {
+            const int s = t / (W * WKV), rem = t - s * (W * WKV), i = rem / WKV, jj = rem - i * WKV;
+            const float4* qv = reinterpret_cast<const float4*>(sq + (s * W + i) * QS);
+            const float4* kv = reinterpret_cast<const float4*>(sk + (s * WKV + jj) * QS);
+            float acc = 0.f;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) {
+                const float4 a = qv[d], b = kv[d];
+                acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+            }
+            sp[t] = acc * 0.125f;
+        }
+        __syncthreads();
+        for (int t = tid; t < TS * W; t += NT) {
+            float* row = sp + t * WKV;
+            float mx = row[0];
+#pragma unroll
+            for (int jj = 1; jj < WKV; ++jj) mx = fmaxf(mx, row[jj]);
+            float e[WKV], sum = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < WKV; ++jj) { e[jj] = expf(row[jj] - mx); sum += e[jj]; }
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int jj = 0; jj < WKV; ++jj) row[jj] = e[jj] * inv;
+        }
+        __syncthreads();
+        // o_h = P v_h, overwrites q_h
+        for (int t = tid; t < R * 16; t += NT) {
+            const int row = t >> 4, d4 = (t & 15) * 4, s = row / W;
+            const float* pr = sp + row * WKV;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int jj = 0; jj < WKV; ++jj) {
+                const float pj = pr[jj];
+                const float4 vv = *reinterpret_cast<const float4*>(sv + (s * WKV + jj) * QS + d4);
+                o.x = fmaf(pj, vv.x, o.x); o.y = fmaf(pj, vv.y, o.y); o.z = fmaf(pj, vv.z, o.z); o.w = fmaf(pj, vv.w, o.w);
+            }
+            *reinterpret_cast<float4*>(sq + row * QS + d4) = o;
+        }
+        if (hh + 1 < heads) {        // next head's q weights fly under the barrier and the out-projection
+            q_rows(hh + 1, wq_r);
+            pre_q = prefetch_b<1, C / 16>(wq_r);
+        }
+        __syncthreads();
+        gemm_r(INTC{}, K4{}, sq, QS, wo_r, pre_o, acc_o);   // acc_o += o_h Wo[:, hh*64 .. +64]^T
+        __syncthreads();   // sq / sk / sv are rewritten by the next head
+    }
+
+    // first FFN weights are requested before the residual update and the second LayerNorm
+    const float* w1_r[2];
+    w1_rows(0, w1_r);
+    BPre<2> pre_w1 = prefetch_b<2, C / 16>(w1_r);
+
+    // ---- phase 4: h += to_out(o) + bias ----
+#pragma unroll
+    for (int nt = 0; nt < NTC; ++nt) {
+        const int col = (wn * NTC + nt) * 16 + j;
+        const float bv = p.bo[col];
+#pragma unroll
+        for (int mt = 0; mt < MT0; ++mt)
+            if (mt < mcount) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sh[((mbase + mt) * 16 + 4 * kg + r) * RS + col] += acc_o[mt][nt][r] + bv;
+            }
+    }
+    __syncthreads();
+
+    // ---- phase 5 ----
+    layer_norm(p.n1g, p.n1b);
+    __syncthreads();
+
+    // ---- phase 6: feed-forward, hidden units in chunks of HC ----
+    f32x4 acc_f[MT0][NTC];
+#pragma unroll
+    for (int mt = 0; mt < MT0; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) acc_f[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int cc = 0; cc < 4 * C / HC; ++cc) {
+        const float* w2_r[NTC];
+        w2_rows(cc, w2_r);
+        const BPre<NTC> pre_w2 = prefetch_b<NTC, HC / 16>(w2_r);
+        {
+            f32x4 au[MT0][2];
+#pragma unroll
+            for (int mt = 0; mt < MT0; ++mt) { au[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; au[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            gemm_r(I2{}, KC{}, sy, RS, w1_r, pre_w1, au);
+            const int n0 = cc * HC + wn * 32;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const float bv = p.b1[n0 + nt * 16 + j];
+#pragma unroll
+                for (int mt = 0; mt < MT0; ++mt)
+                    if (mt < mcount) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            su[((mbase + mt) * 16 + 4 * kg + r) * US + wn * 32 + nt * 16 + j] = gelu_f(au[mt][nt][r] + bv);
+                    }
+            }
+        }
+        if (cc + 1 < 4 * C / HC) {
+            w1_rows(cc + 1, w1_r);
+            pre_w1 = prefetch_b<2, C / 16>(w1_r);
+        }
+        __syncthreads();
+        gemm_r(INTC{}, KH{}, su, US, w2_r, pre_w2, acc_f);
+        __syncthreads();   // su is rewritten by the next chunk
+    }
+
+    // ---- phase 7: h += ff(y) + bias -> HBM ----
+#pragma unroll
+    for (int nt = 0; nt < NTC; ++nt) {
+        const int col = (wn * NTC + nt) * 16 + j;
+        const float bv = p.b2[col];
+#pragma unroll
+        for (int mt = 0; mt < MT0; ++mt)
+            if (mt < mcount) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = (mbase + mt) * 16 + 4 * kg + r;
+                    if (row < rows_valid) hg[row * C + col] = sh[row * RS + col] + acc_f[mt][nt][r] + bv;
+                }
+            }
+    }
+}
+
+}  // namespace cto

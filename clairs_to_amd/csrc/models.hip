@@ -3,12 +3,14 @@
 //   CvT / CvT_Indel            clairs/model.py:150-384   (AFF network)
 //   BiGRU_NACGT / .._Indel     clairs/model.py:387-560   (NEG network; the `lstm*` attributes are nn.GRU)
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <string>
 #include <vector>
 #include "common.h"
 #include "nn_kernels.h"
+#include "cvt_block.h"
 
 using namespace cto;
 
@@ -76,6 +78,7 @@ struct cto_model {
     // workspace
     int64_t ws_B = 0;
     std::vector<void*> ws_ptrs;
+    bool fuse_blocks = true;   // CvT: fused transformer-block kernel where the stage geometry allows (CTO_CVT_UNFUSED=1 disables)
     // live kernel timing (cto_model_profile)
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
@@ -212,7 +215,7 @@ int ensure_ws(cto_model* m, int64_t B) {
         }
         if ((rc = get(&m->b_h, act)) || (rc = get(&m->b_t, act)) || (rc = get(&m->b_yq, act)) ||
             (rc = get(&m->b_ykv, act)) || (rc = get(&m->b_q, qn)) || (rc = get(&m->b_kv, kvn)) ||
-            (rc = get(&m->b_o, qn)) || (rc = get(&m->b_u, un)))
+            (rc = get(&m->b_o, qn)) || (rc = get(&m->b_u, un)) || (rc = get(&m->b_slab, 4 * 128)))
             return rc;
     } else {
         if ((rc = get(&m->b_h, 33 * 256)) || (rc = get(&m->b_slab, 2 * 128))) return rc;
@@ -235,8 +238,15 @@ int run_head(cto_model* m, hipStream_t s, const float* feat, int64_t B, float* l
                            h.b1, m->b_g, total, 128);
         CTO_HIP(hipGetLastError());
     } else {
-        if ((rc = launch_gemm(s, feat, h.k1, h.w1, h.k1, h.b1, nullptr, 0, m->b_g, 128, int(B), 128, h.k1, ACT_SELU)))
+        // CvT: fc1 has M = B rows and only N = 128 columns; split K four ways so that the launch fills the chip
+        const int S = 4;
+        if ((rc = launch_gemm(s, feat, h.k1, h.w1, h.k1, nullptr, nullptr, 0, m->b_slab, 128, int(B), 128, h.k1, ACT_NONE,
+                              0, 0, 0, S, B * 128)))
             return rc;
+        const int64_t total = B * 128;
+        hipLaunchKernelGGL(k_sum_bias_selu, dim3(unsigned(cdiv(total, 256))), dim3(256), 0, s, m->b_slab, S, B * 128,
+                           h.b1, m->b_g, total, 128);
+        CTO_HIP(hipGetLastError());
     }
     if ((rc = launch_gemm(s, m->b_g, 128, h.w2, 128, h.b2, nullptr, 0, m->b_u2, int64_t(K) * 128, int(B), K * 128, 128,
                           ACT_SELU)))
@@ -244,6 +254,31 @@ int run_head(cto_model* m, hipStream_t s, const float* feat, int64_t B, float* l
     hipLaunchKernelGGL(k_fc3, dim3(unsigned(cdiv(B, 4))), dim3(256), 0, s, m->b_u2, h.w3, h.b3, logits, B, K);
     CTO_HIP(hipGetLastError());
     return CTO_OK;
+}
+
+template <int C, int W, int WKV, int TS>
+int launch_cvt_block(hipStream_t s, float* h, const BlockDev& b, int heads, int64_t B) {
+    using G = CvtBlockGeom<C, W, WKV, TS>;
+    static_assert(G::LDS_BYTES <= 160 * 1024, "fused CvT block does not fit the 160 KB LDS of a gfx950 CU");
+    static bool attr_set = false;
+    if (!attr_set) {
+        CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cvt_block<C, W, WKV, TS>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES)));
+        attr_set = true;
+    }
+    CvtBlockParams p{b.n0g, b.n0b, b.dwq, b.bnq, b.wq, b.dwkv, b.bnkv, b.wkv, b.wo, b.bo, b.n1g, b.n1b, b.w1, b.b1, b.w2, b.b2};
+    hipLaunchKernelGGL((k_cvt_block<C, W, WKV, TS>), dim3(unsigned(cdiv(B, TS))), dim3(CVT_BLOCK_THREADS), G::LDS_BYTES, s, h, p, heads, int(B));
+    CTO_HIP(hipGetLastError());
+    return CTO_OK;
+}
+
+// fused transformer block when the stage geometry has an instantiation; returns 1 if it ran, 0 if not, < 0 on error
+int try_fused_block(hipStream_t s, const StageDev& st, const BlockDev& b, float* h, int64_t B) {
+    int rc = CTO_OK;
+    if (st.c == 128 && st.w == 5 && st.wkv == 3) rc = launch_cvt_block<128, 5, 3, 16>(s, h, b, st.heads, B);
+    else if (st.c == 64 && st.w == 9 && st.wkv == 5) rc = launch_cvt_block<64, 9, 5, 8>(s, h, b, st.heads, B);
+    else return 0;
+    return rc == CTO_OK ? 1 : rc;
 }
 
 int cvt_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStream_t s) {
@@ -259,6 +294,11 @@ int cvt_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStrea
         hipLaunchKernelGGL(k_layernorm, dim3(unsigned(cdiv(M, 4))), dim3(256), 0, s, m->b_t, m->b_h, st.lng, st.lnb, M, C);
         CTO_HIP(hipGetLastError());
         for (const BlockDev& b : st.blocks) {
+            if (m->fuse_blocks) {
+                const int fr = try_fused_block(s, st, b, m->b_h, B);
+                if (fr < 0) return fr;
+                if (fr == 1) continue;
+            }
             hipLaunchKernelGGL(k_ln_dw, dim3(unsigned(B)), dim3(256), 0, s, m->b_h, b.n0g, b.n0b, b.dwq, b.bnq, b.dwkv,
                                b.bnkv, m->b_yq, m->b_ykv, st.w, st.wkv, C);
             CTO_HIP(hipGetLastError());
@@ -428,6 +468,7 @@ extern "C" int cto_cvt_create(const cto_weights* w, const cto_cvt_cfg* cfg, cto_
     }
     macs += int64_t(k1) * 128 + int64_t(m->n_out) * (128 * 128 + 256);
     m->macs = macs;
+    if (const char* e = getenv("CTO_CVT_UNFUSED")) m->fuse_blocks = !(e[0] == '1');
     *out = m.release();
     return CTO_OK;
 }
