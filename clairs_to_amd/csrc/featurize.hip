@@ -31,12 +31,17 @@ struct PackDev {
     const uint8_t* key_meta;
 };
 
+constexpr int KCAP = 128;   // distinct indel keys of one wave's 16 columns held in LDS; beyond that: global atomics
+
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_featurize_columns(
     PackDev pk, int min_bq, int16_t* __restrict__ colvec, int32_t* __restrict__ coldepth,
     int32_t* __restrict__ colfirst, uint32_t* __restrict__ keycnt, int32_t* __restrict__ keyfirst) {
     __shared__ uint32_t s_hist[WAVES_PER_BLOCK][COLS_PER_WAVE][HSLOTS];
     __shared__ int32_t s_first[WAVES_PER_BLOCK][COLS_PER_WAVE][8];   // [pass][A,C,G,T]
     __shared__ int64_t s_off[WAVES_PER_BLOCK][COLS_PER_WAVE + 1];
+    __shared__ int32_t s_koff[WAVES_PER_BLOCK][COLS_PER_WAVE + 1];
+    __shared__ uint32_t s_kcnt[WAVES_PER_BLOCK][KCAP];
+    __shared__ int32_t s_kfirst[WAVES_PER_BLOCK][KCAP][2];
     __shared__ int16_t s_out[WAVES_PER_BLOCK][COLS_PER_WAVE][CTO_COLVEC_STRIDE];
 
     const int lane = threadIdx.x & 63;
@@ -47,15 +52,26 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_featurize_columns(
 
     for (int i = lane; i < COLS_PER_WAVE * HSLOTS; i += 64) (&s_hist[w][0][0])[i] = 0u;
     for (int i = lane; i < COLS_PER_WAVE * 8; i += 64) (&s_first[w][0][0])[i] = INT_NONE;
-    if (lane <= COLS_PER_WAVE) s_off[w][lane] = (ncol > 0) ? pk.col_off[c0 + (lane < ncol ? lane : ncol)] : 0;
+    for (int i = lane; i < KCAP; i += 64) { s_kcnt[w][i] = 0u; s_kfirst[w][i][0] = INT_NONE; s_kfirst[w][i][1] = INT_NONE; }
+    if (lane <= COLS_PER_WAVE) {
+        const int64_t ci = c0 + (lane < ncol ? lane : ncol);
+        s_off[w][lane] = (ncol > 0) ? pk.col_off[ci] : 0;
+        s_koff[w][lane] = (ncol > 0) ? pk.key_off[ci] : 0;
+    }
     __syncthreads();
+    const int kbase = s_koff[w][0];
+    const int nkeys_w = s_koff[w][ncol] - kbase;
+    const bool keys_in_lds = nkeys_w <= KCAP;     // wave-uniform
 
     if (ncol > 0) {
         const int64_t e_begin = s_off[w][0];
         const int64_t e_end = s_off[w][ncol];
         int cl = 0;
-        for (int64_t e = e_begin + lane; e < e_end; e += 64) {
-            const uint32_t ent = pk.entries[e];
+        int64_t e = e_begin + lane;
+        uint32_t ent = e < e_end ? pk.entries[e] : 0u;
+        while (e < e_end) {
+            const int64_t en = e + 64;
+            const uint32_t ent_next = en < e_end ? pk.entries[en] : 0u;   // next load flies under this iteration's atomics
             while (e >= s_off[w][cl + 1]) ++cl;
             const int idx = int(e - s_off[w][cl]);
             const uint32_t b = ent & 15u;
@@ -91,56 +107,83 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_featurize_columns(
                 const int ch = (kind == 1u) ? (fwd ? 4 : 13) : (fwd ? 6 : 15);
                 atomicAdd(&h[ch], inc);
                 atomicAdd(&h[34], inc);
-                const int64_t k = int64_t(pk.key_off[c0 + cl]) + kid;
-                atomicAdd(&keycnt[k], inc);
-                atomicMin(&keyfirst[2 * k + 1], idx);
-                if (pass) atomicMin(&keyfirst[2 * k], idx);
+                const int kl = s_koff[w][cl] - kbase + int(kid);
+                if (keys_in_lds) {
+                    atomicAdd(&s_kcnt[w][kl], inc);
+                    atomicMin(&s_kfirst[w][kl][1], idx);
+                    if (pass) atomicMin(&s_kfirst[w][kl][0], idx);
+                } else {
+                    const int64_t k = int64_t(kbase) + kl;
+                    atomicAdd(&keycnt[k], inc);
+                    atomicMin(&keyfirst[2 * k + 1], idx);
+                    if (pass) atomicMin(&keyfirst[2 * k], idx);
+                }
             }
+            e = en;
+            ent = ent_next;
         }
     }
-    // make the global key counters of this wave's columns visible to its own finalisation reads
-    __threadfence();
+    if (!keys_in_lds) __threadfence();   // rare: make this wave's global key counters visible to its finalisation reads
     __syncthreads();
 
-    if (lane < ncol) {
-        const int64_t c = c0 + lane;
-        const int ref = pk.col_ref[c];
-        const uint32_t* h = s_hist[w][lane];
-        const int32_t k0 = pk.key_off[c], k1 = pk.key_off[c + 1];
-        // per-distinct-key maxima -> I1 / i1 / D1 / d1 (F4, F6)
-        uint32_t mx[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};   // [pass][ins fwd, ins rev, del fwd, del rev]
-        for (int32_t k = k0; k < k1; ++k) {
-            const uint32_t cnt = __hip_atomic_load(&keycnt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t meta = pk.key_meta[k];
-            const int slot = (((meta & 3u) == 2u) ? 2 : 0) + ((meta & 4u) ? 0 : 1);
-            const uint32_t a = cnt & 0xffffu, n = cnt >> 16;
-            mx[0][slot] = a > mx[0][slot] ? a : mx[0][slot];
-            mx[1][slot] = n > mx[1][slot] ? n : mx[1][slot];
-        }
-        for (int p = 0; p < 2; ++p) {
-            int v[HSLOTS];
-#pragma unroll
-            for (int i = 0; i < 34; ++i) v[i] = int(p == 0 ? (h[i] & 0xffffu) : (h[i] >> 16));
-            v[34] = 0; v[35] = 0;
-            v[5] = int(mx[p][0]);   // I1
-            v[14] = int(mx[p][1]);  // i1
-            v[7] = int(mx[p][2]);   // D1
-            v[16] = int(mx[p][3]);  // d1
-            // reference-channel negation over the six 4-base groups (create_tensor_pileup_calling.py:223-228)
-            const int g0[6] = {0, 9, 18, 22, 26, 30};
-#pragma unroll
-            for (int g = 0; g < 6; ++g) {
-                const int s = v[g0[g]] + v[g0[g] + 1] + v[g0[g] + 2] + v[g0[g] + 3];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i == ref) v[g0[g] + i] = -s;
+    // ---- finalise: 4 lanes per column, each owns a run of channels that contains whole 4-base groups ----
+    {
+        const int col = lane >> 2, part = lane & 3;
+        if (col < ncol) {
+            const int64_t c = c0 + col;
+            const int ref = pk.col_ref[c];
+            const uint32_t* h = s_hist[w][col];
+            const int ch0 = part == 0 ? 0 : (part == 1 ? 9 : (part == 2 ? 18 : 26));
+            const int nch = part < 2 ? 9 : 8;
+            // per-distinct-key maxima -> I1 / D1 (part 0, forward) and i1 / d1 (part 1, reverse)   (F4, F6)
+            uint32_t mx[2][2] = {{0u, 0u}, {0u, 0u}};   // [pass][ins, del]
+            if (part < 2) {
+                const int k0 = s_koff[w][col] - kbase, k1 = s_koff[w][col + 1] - kbase;
+                for (int k = k0; k < k1; ++k) {
+                    const uint32_t cnt = keys_in_lds ? s_kcnt[w][k]
+                                                     : __hip_atomic_load(&keycnt[kbase + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t meta = pk.key_meta[kbase + k];
+                    const bool kfwd = (meta & 4u) != 0u;
+                    if (kfwd != (part == 0)) continue;
+                    const int slot = ((meta & 3u) == 2u) ? 1 : 0;
+                    const uint32_t a = cnt & 0xffffu, n = cnt >> 16;
+                    mx[0][slot] = a > mx[0][slot] ? a : mx[0][slot];
+                    mx[1][slot] = n > mx[1][slot] ? n : mx[1][slot];
+                }
             }
 #pragma unroll
-            for (int i = 0; i < HSLOTS; ++i) s_out[w][lane][p * HSLOTS + i] = int16_t(v[i]);
-            coldepth[c * 2 + p] = int(p == 0 ? (h[34] & 0xffffu) : (h[34] >> 16));
-        }
+            for (int p = 0; p < 2; ++p) {
+                int v[9];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) colfirst[c * 8 + i] = s_first[w][lane][i];
+                for (int i = 0; i < 9; ++i) v[i] = i < nch ? int(p == 0 ? (h[ch0 + i] & 0xffffu) : (h[ch0 + i] >> 16)) : 0;
+                if (part < 2) { v[5] = int(mx[p][0]); v[7] = int(mx[p][1]); }       // I1 / D1 (or i1 / d1)
+                // reference-channel negation of each whole 4-base group in this run (create_tensor_pileup_calling.py:223-228)
+                const int ngroups = part < 2 ? 1 : 2;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    if (g < ngroups) {
+                        const int s4 = v[g * 4] + v[g * 4 + 1] + v[g * 4 + 2] + v[g * 4 + 3];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (i == ref) v[g * 4 + i] = -s4;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 9; ++i)
+                    if (i < nch) s_out[w][col][p * HSLOTS + ch0 + i] = int16_t(v[i]);
+                if (part == 3) { s_out[w][col][p * HSLOTS + 34] = 0; s_out[w][col][p * HSLOTS + 35] = 0; }
+                if (part == 0) coldepth[c * 2 + p] = int(p == 0 ? (h[34] & 0xffffu) : (h[34] >> 16));
+            }
+            colfirst[c * 8 + part * 2 + 0] = s_first[w][col][part * 2 + 0];
+            colfirst[c * 8 + part * 2 + 1] = s_first[w][col][part * 2 + 1];
+        }
+    }
+    if (keys_in_lds) {
+        for (int k = lane; k < nkeys_w; k += 64) {
+            keycnt[kbase + k] = s_kcnt[w][k];
+            keyfirst[2 * (int64_t(kbase) + k) + 0] = s_kfirst[w][k][0];
+            keyfirst[2 * (int64_t(kbase) + k) + 1] = s_kfirst[w][k][1];
+        }
     }
     __syncthreads();
     // coalesced write-back: ncol * 144 contiguous bytes per wave, 16 B per lane per pass

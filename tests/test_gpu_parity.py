@@ -47,14 +47,19 @@ def test_featurize_matches_reference_region(dev, golden_region):
             assert [alts_neg[i] for i in kept] == alt_ref
 
 
-def test_featurize_matches_oracle_synthetic(dev, oracle_lib):
+@pytest.mark.parametrize("p_ins,p_del,n_sites", [(0.01, 0.02, 300), (0.25, 0.25, 60)])
+def test_featurize_matches_oracle_synthetic(dev, oracle_lib, p_ins, p_del, n_sites):
     """Seeded synthetic chunk generated directly as a pack (the bench generator) vs the oracle run on the
-    equivalent mpileup text of each pass; includes the rescaled fp32 network inputs and strand counts."""
+    equivalent mpileup text of each pass; includes the rescaled fp32 network inputs and strand counts.
+    The second case has so many distinct indel keys per column that the kernel's LDS key table overflows and the
+    global-atomic path runs."""
     import torch
     from clairs_to_amd.pack import DevicePack
     from clairs_to_amd.featurize import featurize
     from clairs_to_amd.synth import SynthChunk, mpileup_text
-    chunk = SynthChunk(300, seed=123, spacing=40, p_ins=0.01, p_del=0.02, depth_mean=70.0)
+    chunk = SynthChunk(n_sites, seed=123, spacing=40, p_ins=p_ins, p_del=p_del, depth_mean=70.0)
+    if p_ins > 0.1:
+        assert np.diff(chunk.key_off[::16]).max() > 128
     ref, lo = chunk.ref_window()
     dp = DevicePack(chunk.arrays(), dev)
     feat = featurize(dp, torch.from_numpy(chunk.site_pos).to(dev), 20, 50, want_raw=True)
