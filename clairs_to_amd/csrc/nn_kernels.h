@@ -360,22 +360,27 @@ __global__ __launch_bounds__(256) void k_fc3(const float* __restrict__ u, const 
 __device__ __forceinline__ float fast_sigmoid(float x) { return __fdividef(1.0f, 1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - __fdividef(2.0f, 1.0f + __expf(2.0f * x)); }
 
-template <int KIN, int KP, int H, int MS, bool FUSE_FC1>
-__global__ __launch_bounds__(256) void k_gru_layer(const float* __restrict__ x, const float* __restrict__ Wcat,
+// MS = 16-row sub-tiles per wave, MH = wave groups along M: the block has 4*MH waves and owns MH*MS*16 sites.
+// With MH = 2 every SIMD hosts two waves of the same workgroup, so one wave's gate arithmetic / barrier wait
+// is covered by the other's MFMAs.
+template <int KIN, int KP, int H, int MS, int MH, bool FUSE_FC1>
+__global__ __launch_bounds__(256 * MH) void k_gru_layer(const float* __restrict__ x, const float* __restrict__ Wcat,
                                                    const float* __restrict__ bias, float* __restrict__ out,
                                                    const float* __restrict__ fc1w, float* __restrict__ fc1_part, int B) {
     constexpr int NB = H / 64, T = 33, KT = KP + H, HS = H + 4, NX = KP / 16, NH = H / 16, NC = NX + NH;
     constexpr int FC1_K = T * 2 * H;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* hbuf = smem;   // [2][MS*16][HS]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int TILE = MH * MS * 16, NTHR = 256 * MH;
+    float* hbuf = smem;   // [2][TILE][HS]
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, mh = threadIdx.x >> 8;
+    const int rb = mh * MS * 16;          // first tile row of this wave
     const int j = lane & 15, kg = lane >> 4;
     const int dir = blockIdx.x & 1;
-    const int site0 = (blockIdx.x >> 1) * MS * 16;
+    const int site0 = (blockIdx.x >> 1) * TILE;
     const float* Wd = Wcat + int64_t(dir) * 3 * H * KT;
     const float* bd = bias + dir * 4 * H;
 
-    for (int i = threadIdx.x; i < MS * 16 * HS; i += 256) hbuf[i] = 0.f;   // h_{-1} = 0
+    for (int i = threadIdx.x; i < TILE * HS; i += NTHR) hbuf[i] = 0.f;   // h_{-1} = 0
 
     float bia[NB][4];
     const float* wrow[NB][3];
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(256) void k_gru_layer(const float* __restrict__ x, 
     const float* xrow[MS];   // x row of the site this lane feeds, nullptr for rows past the batch (zero rows)
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
-        const int site = site0 + ms * 16 + j;
+        const int site = site0 + rb + ms * 16 + j;
         xrow[ms] = site < B ? x + int64_t(site) * T * KIN + 4 * kg : nullptr;
     }
 
@@ -448,7 +453,7 @@ __global__ __launch_bounds__(256) void k_gru_layer(const float* __restrict__ x, 
     auto load_Ah = [&](int buf, int kh, const float* hc) {
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
-            Aq[buf][ms] = *reinterpret_cast<const float4*>(hc + (ms * 16 + j) * HS + kh * 16 + 4 * kg);
+            Aq[buf][ms] = *reinterpret_cast<const float4*>(hc + (rb + ms * 16 + j) * HS + kh * 16 + 4 * kg);
     };
 
     // prologue: operands of chunk 0 of step 0
@@ -460,7 +465,7 @@ __global__ __launch_bounds__(256) void k_gru_layer(const float* __restrict__ x, 
         const int tnext = dir == 0 ? t + 1 : t - 1;                          // valid while step + 1 < T
         const int tprev = step == 0 ? t : (dir == 0 ? t - 1 : t + 1);        // step 0: h = 0, any valid slice will do
         const int cur_h = step & 1;
-        const float* hc = hbuf + cur_h * (MS * 16 * HS);
+        const float* hc = hbuf + cur_h * (TILE * HS);
         // The weight addresses do not depend on `step`; without this the compiler hoists all K chunks of weight
         // loads out of the time loop (hundreds of registers, spills).  An opaque zero keeps them per-step.
         opq = 0;
@@ -547,7 +552,7 @@ __global__ __launch_bounds__(256) void k_gru_layer(const float* __restrict__ x, 
             for (int ms = 0; ms < MS; ++ms) Aq[0][ms] = Aq[1][ms];
         }
         // ---- gates + state update (lane-local), publish h_t ----
-        float* hn = hbuf + (cur_h ^ 1) * (MS * 16 * HS);
+        float* hn = hbuf + (cur_h ^ 1) * (TILE * HS);
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
@@ -560,7 +565,7 @@ __global__ __launch_bounds__(256) void k_gru_layer(const float* __restrict__ x, 
                     const float ng = fast_tanh(ain[ms][nb][r] + rg * ahn[ms][nb][r]);
                     const float hv = ng + zg * (hprev[ms][nb][r] - ng);      // (1 - z) * n + z * h
                     hprev[ms][nb][r] = hv;
-                    const int row = ms * 16 + kg * 4 + r;
+                    const int row = rb + ms * 16 + kg * 4 + r;
                     hn[row * HS + hcol] = hv;
                     if constexpr (!FUSE_FC1) {
                         const int site = site0 + row;
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(256) void k_gru_layer(const float* __restrict__ x, 
     if constexpr (FUSE_FC1) {
         // fc1 contribution of the last state h_{T-1 (fwd) / 0 (bwd)}, then one partial slab per direction
         __syncthreads();
-        const float* hl = hbuf + (T & 1) * (MS * 16 * HS);
+        const float* hl = hbuf + (T & 1) * (TILE * HS);
         const int tl = dir == 0 ? T - 1 : 0;
 #pragma unroll
         for (int kh = 0; kh < NH; ++kh) {
@@ -596,7 +601,7 @@ __global__ __launch_bounds__(256) void k_gru_layer(const float* __restrict__ x, 
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int site = site0 + ms * 16 + kg * 4 + r;
+                    const int site = site0 + rb + ms * 16 + kg * 4 + r;
                     if (site < B) part[int64_t(site) * 128 + wave * 32 + nt * 16 + j] = accf[ms][nt][r];
                 }
     }
