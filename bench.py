@@ -26,30 +26,51 @@ N_OUT = 4
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 
 
-def cpu_baseline(chunk, models, lik, edges, min_bq, n_sample, budget_s=25.0):
-    """CPU oracle (scalar C port of the reference path, OpenMP over sites) on the first n_sample sites."""
+def pmc_traffic(batch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
+    profiles/round1_b_pmc_hbm_traffic.json, collected at batch 4096); None for any other batch."""
+    fn = os.path.join(ROOT, "profiles", "round1_b_pmc_hbm_traffic.json")
+    if batch != 4096 or not os.path.exists(fn):
+        return None
+    k = json.load(open(fn))["kernels"]
+    for name, v in k.items():
+        if "k_gru_layer<256" in name:
+            return int((v["FETCH_SIZE_KB_mean_per_launch"] + v["WRITE_SIZE_KB_mean_per_launch"]) * 1024)
+    return None
+
+
+def cpu_baseline(chunks, models, lik, edges, min_bq, n_sample, budget_s=12.0):
+    """CPU oracle (scalar C port of the reference path, OpenMP over sites) on a bounded sample of the same job:
+    the first n_sample sites of as many resident chunks as fit in ~budget_s seconds (at least one)."""
     import numpy as np
     import oracle
-    from clairs_to_amd.synth import mpileup_text
     oracle.build()
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    sites = chunk.site_pos[:n_sample]
-    last_col = int(np.searchsorted(chunk.col_pos, int(sites[-1]) + 17, side="right"))
-    ref, lo = chunk.ref_window()
-    texts = {q: mpileup_text(chunk, q, col_range=(0, last_col)) for q in (min_bq, 0)}      # untimed input prep
     cfg = dict(emb_dim=(16, 64, 128), heads=(1, 3, 4), depth=(1, 2, 3), n_out=N_OUT)
-    t0 = time.perf_counter()
-    ta, da, _, _ = oracle.create_tensor(texts[min_bq], ref, lo, sites)
-    tn, dn, _, _ = oracle.create_tensor(texts[0], ref, lo, sites)
-    xa, xn = oracle.rescale(ta, da), oracle.rescale(tn, dn)
-    la = oracle.cvt_forward(models["aff_weights"], cfg, xa)
-    ln = oracle.bigru_forward(models["neg_weights"], N_OUT, xn)
-    probs, post, dec, qual = oracle.posterior(la, ln, lik, edges)
-    dt = time.perf_counter() - t0
-    return dict(value=round(len(sites) / dt, 2), unit="sites/s", cores=cores, kind="port",
-                sample="%d sites of the same synthetic chunk (mpileup text of both passes -> tensors -> CvT + BiGRU -> "
-                       "posterior), CPU oracle oracle/cto_oracle.c, OpenMP over sites, %.1f s" % (len(sites), dt)), probs
+    total_sites, total_t, first_probs = 0, 0.0, None
+    for chunk in chunks:
+        sites = chunk.site_pos[:n_sample]
+        last_col = int(np.searchsorted(chunk.col_pos, int(sites[-1]) + 17, side="right"))
+        ref, lo = chunk.ref_window()
+        texts = {q: oracle.synth_mpileup_text(chunk, q, (0, last_col)) for q in (min_bq, 0)}      # untimed input prep
+        t0 = time.perf_counter()
+        ta, da, _, _ = oracle.create_tensor(texts[min_bq], ref, lo, sites)
+        tn, dn, _, _ = oracle.create_tensor(texts[0], ref, lo, sites)
+        xa, xn = oracle.rescale(ta, da), oracle.rescale(tn, dn)
+        la = oracle.cvt_forward(models["aff_weights"], cfg, xa)
+        ln = oracle.bigru_forward(models["neg_weights"], N_OUT, xn)
+        probs, post, dec, qual = oracle.posterior(la, ln, lik, edges)
+        total_t += time.perf_counter() - t0
+        total_sites += len(sites)
+        if first_probs is None:
+            first_probs = probs
+        if total_t >= budget_s:
+            break
+    return dict(value=round(total_sites / total_t, 2), unit="sites/s", cores=cores, kind="port",
+                sample="%d sites of the same synthetic chunks (mpileup text of both passes -> tensors -> CvT + BiGRU -> "
+                       "posterior), CPU oracle oracle/cto_oracle.c, OpenMP over sites for the networks (tensor creation "
+                       "serial), %.1f s" % (total_sites, total_t)), first_probs
 
 
 def main():
@@ -60,7 +81,7 @@ def main():
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic chunks resident in HBM per rank")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=768)
+    ap.add_argument("--cpu-sample", type=int, default=4096)
     args = ap.parse_args()
 
     import numpy as np
@@ -145,15 +166,16 @@ def main():
                        "pack_bytes_per_chunk": int(pack_bytes),
                        "parallelism": "sites sharded, 1 rank/GPU" + (", all_gather of per-site probabilities (RCCL)" if world > 1 else ""),
                        "weights": "seeded random init (no pretrained weights offline)"},
-            "roofline": {"bound": "mfma", "kernel": "k_gru_layer<256,256,192,2> (BiGRU layer 2, both directions)",
+            "roofline": {"bound": "mfma", "kernel": "k_gru_layer<256,256,192,2,1,true> (BiGRU layer 2 + fused fc1, both directions)",
                          "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(args.batch),
+                         "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/round1_b_pmc_hbm_traffic.json)",
                          "launch_ms": round(mean_ms.value, 4), "launches_measured": int(n_meas),
                          "flops_per_launch": flops_per_launch},
             "end_to_end_tflops": round(2.0 * eng.macs_per_site * sites_total / dt / 1e12, 3),
         }
         if world == 1 and not args.no_cpu_baseline:
-            cb, probs_cpu = cpu_baseline(chunks[0], models, lik, edges, min_bq, min(args.cpu_sample, args.batch))
+            cb, probs_cpu = cpu_baseline(chunks, models, lik, edges, min_bq, min(args.cpu_sample, args.batch))
             res["cpu_baseline"] = cb
             got = eng.run_device(packs[0], sites[0])["probs"][: probs_cpu.shape[0]].cpu().numpy()
             res["parity_max_abs_dP_vs_cpu_sample"] = float(np.abs(got - probs_cpu).max())

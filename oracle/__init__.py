@@ -152,3 +152,19 @@ def posterior_from_probs(p1, lik, edges):
     qual = np.zeros(B, dtype=np.float64)
     lib().orc_posterior_from_probs(_p(p1), K, C.c_int64(B), _p(lik), _p(edges), _p(post), _p(dec), _p(qual))
     return post, dec, qual
+
+
+def synth_mpileup_text(chunk, min_bq=0, col_range=None):
+    """Fast (C) equivalent of clairs_to_amd.synth.mpileup_text for a SynthChunk; returns bytes."""
+    c0, c1 = col_range if col_range else (0, chunk.col_pos.size)
+    n_ent = int(chunk.col_off[c1] - chunk.col_off[c0])
+    cap = n_ent * 90 + (c1 - c0) * 64 + 1024
+    buf = np.empty(cap, dtype=np.uint8)
+    a = lambda v, dt: np.ascontiguousarray(v, dtype=dt)
+    arrs = [a(chunk.col_pos, np.int32), a(chunk.col_off, np.int64), a(chunk.entries, np.uint32), a(chunk._okind, np.uint8),
+            a(chunk._ilen, np.int32), a(chunk._ivar, np.int32)]
+    f = lib().orc_pack_to_mpileup
+    f.restype = C.c_int64
+    n = f(*[_p(x) for x in arrs], C.c_int64(c0), C.c_int64(c1), int(min_bq), _p(buf), C.c_int64(cap))
+    assert n >= 0
+    return buf[:n].tobytes()

@@ -78,3 +78,12 @@ def test_predict_rows_match_reference(oracle_lib, golden_region, mode, aff_cls, 
         assert row[4] == str([float(v) for v in f[i]])
         assert row[5] == str([float(v) for v in r[i]])
         assert row[3] == alts_a[keep[i]]
+
+
+def test_c_text_writer_equals_python_writer(oracle_lib):
+    """the C pack->mpileup-text helper used for cpu_baseline samples must render exactly what synth.mpileup_text does"""
+    from clairs_to_amd.synth import SynthChunk, mpileup_text
+    chunk = SynthChunk(25, seed=77, p_ins=0.05, p_del=0.05, spacing=20)
+    for q in (0, 20, 45):
+        assert oracle_lib.synth_mpileup_text(chunk, q).decode() == mpileup_text(chunk, q)
+    assert oracle_lib.synth_mpileup_text(chunk, 0, (3, 9)).decode() == mpileup_text(chunk, 0, col_range=(3, 9))
