@@ -39,14 +39,32 @@ def pmc_traffic(batch):
     return None
 
 
+def usable_cores():
+    """Cores this process may really use: affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = max(1, min(n, int(q / p_ + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(chunks, models, lik, edges, min_bq, n_sample, budget_s=12.0):
     """CPU oracle (scalar C port of the reference path, OpenMP over sites) on a bounded sample of the same job:
     the first n_sample sites of as many resident chunks as fit in ~budget_s seconds (at least one)."""
     import numpy as np
     import oracle
     oracle.build()
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    cores = usable_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     cfg = dict(emb_dim=(16, 64, 128), heads=(1, 3, 4), depth=(1, 2, 3), n_out=N_OUT)
     total_sites, total_t, first_probs = 0, 0.0, None
     for chunk in chunks:

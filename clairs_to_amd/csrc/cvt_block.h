@@ -88,7 +88,7 @@ template <int C, int W, int WKV, int TS>
 struct CvtBlockGeom {
     static constexpr int R = TS * W, RKV = TS * WKV;
     static constexpr int MT = (R + 15) / 16, MTKV = (RKV + 15) / 16;
-    static constexpr int RS = C + 4, QS = 68, HC = 128, US = HC + 4;
+    static constexpr int RS = C + 4, QS = 68, HC = (4 * C < 128 ? 4 * C : 128), US = HC + 4;
     static constexpr int OFF_H = 0;
     static constexpr int OFF_Y = OFF_H + MT * 16 * RS;
     static constexpr int OFF_YKV = OFF_Y + MT * 16 * RS;
@@ -112,7 +112,9 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
     constexpr int NT = CVT_BLOCK_THREADS, NWV = NT / 64;
     constexpr int R = G::R, RKV = G::RKV, MT = G::MT, MTKV = G::MTKV, RS = G::RS, QS = G::QS, HC = G::HC, US = G::US;
     constexpr int MT0 = (MT + 1) / 2, MT1 = MT - MT0, MK0 = (MTKV + 1) / 2, MK1 = MTKV - MK0;
-    constexpr int NTC = C / 64;          // n-tiles per wave when the output is C wide
+    constexpr int NTC = C >= 64 ? C / 64 : 1;   // n-tiles per wave when the output is C wide
+    constexpr int NTF = HC / 64;                // n-tiles per wave of one FFN hidden chunk
+    static_assert(C % 16 == 0 && HC % 64 == 0, "channel count must be a multiple of 16");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sh = smem + G::OFF_H;
     float* sy = smem + G::OFF_Y;
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
     const int wn = wave & 3, mh = wave >> 2;                   // n-tile owner, M half
+    const bool own_c = (wn * NTC * 16) < C;                    // C < 64: only some waves own columns of a C-wide output
     const int mbase = mh ? MT0 : 0, mcount = mh ? MT1 : MT0;   // this wave's m-tiles of [R]-row operands
     const int kbase = mh ? MK0 : 0, kcount = mh ? MK1 : MK0;   // ... of [RKV]-row operands
     const int site0 = blockIdx.x * TS;
@@ -153,8 +156,8 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
         }
     };
     using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
     using INTC = std::integral_constant<int, NTC>;
+    using INTF = std::integral_constant<int, NTF>;
     using KC = std::integral_constant<int, C / 16>;
     using K4 = std::integral_constant<int, 4>;
     using KH = std::integral_constant<int, HC / 16>;
@@ -231,15 +234,15 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
     };
     auto o_rows = [&](int hh, const float* (&wr)[NTC]) {
 #pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) wr[nt] = p.wo + int64_t((wn * NTC + nt) * 16 + j) * inner + hh * 64 + 4 * kg;
+        for (int nt = 0; nt < NTC; ++nt) wr[nt] = p.wo + int64_t(own_c ? (wn * NTC + nt) * 16 + j : j) * inner + hh * 64 + 4 * kg;
     };
-    auto w1_rows = [&](int cc, const float* (&wr)[2]) {
-        wr[0] = p.w1 + int64_t(cc * HC + wn * 32 + j) * C + 4 * kg;
-        wr[1] = p.w1 + int64_t(cc * HC + wn * 32 + 16 + j) * C + 4 * kg;
+    auto w1_rows = [&](int cc, const float* (&wr)[NTF]) {
+#pragma unroll
+        for (int nt = 0; nt < NTF; ++nt) wr[nt] = p.w1 + int64_t(cc * HC + (wn * NTF + nt) * 16 + j) * C + 4 * kg;
     };
     auto w2_rows = [&](int cc, const float* (&wr)[NTC]) {
 #pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) wr[nt] = p.w2 + int64_t((wn * NTC + nt) * 16 + j) * (4 * C) + cc * HC + 4 * kg;
+        for (int nt = 0; nt < NTC; ++nt) wr[nt] = p.w2 + int64_t(own_c ? (wn * NTC + nt) * 16 + j : j) * (4 * C) + cc * HC + 4 * kg;
     };
 
     const float* wq_r[1];
@@ -325,18 +328,19 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
             pre_q = prefetch_b<1, C / 16>(wq_r);
         }
         __syncthreads();
-        gemm_r(INTC{}, K4{}, sq, QS, wo_r, pre_o, acc_o);   // acc_o += o_h Wo[:, hh*64 .. +64]^T
+        if (own_c) gemm_r(INTC{}, K4{}, sq, QS, wo_r, pre_o, acc_o);   // acc_o += o_h Wo[:, hh*64 .. +64]^T
         __syncthreads();   // sq / sk / sv are rewritten by the next head
     }
 
     // first FFN weights are requested before the residual update and the second LayerNorm
-    const float* w1_r[2];
+    const float* w1_r[NTF];
     w1_rows(0, w1_r);
-    BPre<2> pre_w1 = prefetch_b<2, C / 16>(w1_r);
+    BPre<NTF> pre_w1 = prefetch_b<NTF, C / 16>(w1_r);
 
     // ---- phase 4: h += to_out(o) + bias ----
 #pragma unroll
     for (int nt = 0; nt < NTC; ++nt) {
+        if (!own_c) break;
         const int col = (wn * NTC + nt) * 16 + j;
         const float bv = p.bo[col];
 #pragma unroll
@@ -363,35 +367,38 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
         w2_rows(cc, w2_r);
         const BPre<NTC> pre_w2 = prefetch_b<NTC, HC / 16>(w2_r);
         {
-            f32x4 au[MT0][2];
+            f32x4 au[MT0][NTF];
 #pragma unroll
-            for (int mt = 0; mt < MT0; ++mt) { au[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; au[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-            gemm_r(I2{}, KC{}, sy, RS, w1_r, pre_w1, au);
-            const int n0 = cc * HC + wn * 32;
+            for (int mt = 0; mt < MT0; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+                for (int nt = 0; nt < NTF; ++nt) au[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm_r(INTF{}, KC{}, sy, RS, w1_r, pre_w1, au);
+            const int n0 = cc * HC + wn * NTF * 16;
+#pragma unroll
+            for (int nt = 0; nt < NTF; ++nt) {
                 const float bv = p.b1[n0 + nt * 16 + j];
 #pragma unroll
                 for (int mt = 0; mt < MT0; ++mt)
                     if (mt < mcount) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            su[((mbase + mt) * 16 + 4 * kg + r) * US + wn * 32 + nt * 16 + j] = gelu_f(au[mt][nt][r] + bv);
+                            su[((mbase + mt) * 16 + 4 * kg + r) * US + (wn * NTF + nt) * 16 + j] = gelu_f(au[mt][nt][r] + bv);
                     }
             }
         }
         if (cc + 1 < 4 * C / HC) {
             w1_rows(cc + 1, w1_r);
-            pre_w1 = prefetch_b<2, C / 16>(w1_r);
+            pre_w1 = prefetch_b<NTF, C / 16>(w1_r);
         }
         __syncthreads();
-        gemm_r(INTC{}, KH{}, su, US, w2_r, pre_w2, acc_f);
+        if (own_c) gemm_r(INTC{}, KH{}, su, US, w2_r, pre_w2, acc_f);
         __syncthreads();   // su is rewritten by the next chunk
     }
 
     // ---- phase 7: h += ff(y) + bias -> HBM ----
 #pragma unroll
     for (int nt = 0; nt < NTC; ++nt) {
+        if (!own_c) break;
         const int col = (wn * NTC + nt) * 16 + j;
         const float bv = p.b2[col];
 #pragma unroll

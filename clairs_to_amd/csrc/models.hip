@@ -277,6 +277,8 @@ int try_fused_block(hipStream_t s, const StageDev& st, const BlockDev& b, float*
     int rc = CTO_OK;
     if (st.c == 128 && st.w == 5 && st.wkv == 3) rc = launch_cvt_block<128, 5, 3, 16>(s, h, b, st.heads, B);
     else if (st.c == 64 && st.w == 9 && st.wkv == 5) rc = launch_cvt_block<64, 9, 5, 8>(s, h, b, st.heads, B);
+    else if (st.c == 16 && st.w == 17 && st.wkv == 9) rc = launch_cvt_block<16, 17, 9, 8>(s, h, b, st.heads, B);
+    else if (st.c == 32 && st.w == 17 && st.wkv == 9) rc = launch_cvt_block<32, 17, 9, 8>(s, h, b, st.heads, B);
     else return 0;
     return rc == CTO_OK ? 1 : rc;
 }

@@ -135,6 +135,27 @@ def test_models_match_oracle_ragged_batch(dev, oracle_lib, cls, B):
     assert m.logits(torch.zeros((0, 33, 34), device=dev)).shape == (g["n_out"], 0, 2)
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_cvt_constructor_default_config_matches_oracle(dev, oracle_lib, fused, monkeypatch):
+    """clairs/model.py:153-177 defaults (emb 32/64/128, heads 1/3/6, depth 1/2/10) - the shipped SNV pickles may use
+    them; exercises the C=32 stage-1 and heads=6 stage-3 instantiations of the fused block kernel, and the unfused
+    kernel sequence (CTO_CVT_UNFUSED=1) on the same weights."""
+    import torch
+    from clairs_to_amd.nn_shims import CvT
+    from clairs_to_amd.engine import random_state_dict
+    monkeypatch.setenv("CTO_CVT_UNFUSED", "0" if fused == "1" else "1")
+    m = CvT(model_type="acgt").eval()
+    w = random_state_dict(m, seed=11)
+    sd = m.state_dict()
+    for k, v in w.items():
+        sd[k] = torch.from_numpy(v)
+    m.load_state_dict(sd)
+    x = load_models_npz("CvT")["x"][:37]
+    got = m.logits(torch.from_numpy(x).to(dev)).cpu().numpy()
+    want = oracle_lib.cvt_forward(w, dict(emb_dim=(32, 64, 128), heads=(1, 3, 6), depth=(1, 2, 10), n_out=4), x)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-4)
+
+
 def test_model_rejects_cpu_input():
     import torch
     from clairs_to_amd.nn_shims import from_state_dict
