@@ -1,9 +1,9 @@
 """`python -m clairs_to_amd <submodule> ...` - same dispatch style as the reference's clairs_to.py:84-107 for the
-three hot-path sub-modules this package replaces."""
+hot-path sub-modules this package replaces."""
 import importlib
 import sys
 
-SUBMODULES = ("create_tensor_pileup_calling", "predict", "call_variants")
+SUBMODULES = ("extract_candidates_calling", "create_tensor_pileup_calling", "predict", "call_variants")
 
 
 def main():

@@ -29,7 +29,7 @@ c_vp = C.c_void_p
 class PackView(C.Structure):
     _fields_ = [("n_cols", c_i64), ("n_entries", c_i64), ("n_keys", c_i64),
                 ("col_pos", c_vp), ("col_ref", c_vp), ("col_off", c_vp), ("key_off", c_vp),
-                ("entries", c_vp), ("key_meta", c_vp)]
+                ("entries", c_vp), ("key_meta", c_vp), ("key_group", c_vp)]
 
 
 class CvtCfg(C.Structure):
@@ -48,6 +48,8 @@ SYMBOLS = {
     "cto_pack_free": (None, [c_vp]),
     "cto_featurize_columns": (C.c_int, [C.POINTER(PackView), C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "cto_gather_windows": (C.c_int, [C.POINTER(PackView), c_vp, c_vp, c_vp, c_i64, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "cto_extract_candidates": (C.c_int, [C.POINTER(PackView), C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
+                                         C.c_int, c_vp, c_vp, c_vp]),
     "cto_alt_info": (C.c_int, [c_vp, c_i64, C.c_int, c_vp, c_i32, c_vp, c_vp, c_vp, C.c_char_p, C.c_size_t]),
     "cto_weights_new": (c_vp, []),
     "cto_weights_add": (C.c_int, [c_vp, C.c_char_p, c_vp, c_i64]),

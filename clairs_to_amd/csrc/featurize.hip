@@ -29,6 +29,7 @@ struct PackDev {
     const int32_t* key_off;
     const uint32_t* entries;
     const uint8_t* key_meta;
+    const int32_t* key_group;
 };
 
 constexpr int KCAP = 128;   // distinct indel keys of one wave's 16 columns held in LDS; beyond that: global atomics
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_featurize_columns(
         const int col = lane >> 2, part = lane & 3;
         if (col < ncol) {
             const int64_t c = c0 + col;
-            const int ref = pk.col_ref[c];
+            const int ref = pk.col_ref[c] & 3;
             const uint32_t* h = s_hist[w][col];
             const int ch0 = part == 0 ? 0 : (part == 1 ? 9 : (part == 2 ? 18 : 26));
             const int nch = part < 2 ? 9 : 8;
@@ -273,6 +274,7 @@ PackDev to_dev(const cto_pack_view* v) {
     d.key_off = v->key_off;
     d.entries = v->entries;
     d.key_meta = v->key_meta;
+    d.key_group = v->key_group;
     return d;
 }
 

@@ -32,6 +32,7 @@ struct cto_pack {
     std::vector<int32_t> key_off;   // n_cols + 1
     std::vector<uint32_t> entries;
     std::vector<uint8_t> key_meta;
+    std::vector<int32_t> key_group;
     std::vector<int64_t> key_str_off;  // n_keys + 1
     std::string key_str;               // alt_info keys ("I<ANCHOR><SEQ>", "D<refslice>")
 };
@@ -80,8 +81,8 @@ extern "C" int cto_pack_from_mpileup(const char* text, size_t len, const char* r
     p->key_off.push_back(0);
     p->key_str_off.push_back(0);
     std::vector<Tok> toks;
-    std::unordered_map<std::string, int> keymap;
-    std::string keybuf;
+    std::unordered_map<std::string, int> keymap, groupmap;
+    std::string keybuf, groupbuf;
     const char* cur = text;
     const char* end = text + len;
     int64_t last_pos = -1;
@@ -152,6 +153,7 @@ extern "C" int cto_pack_from_mpileup(const char* text, size_t len, const char* r
             int n = int(std::min<size_t>(toks.size(), size_t(std::min(nq, nm))));
             if (n > kMaxDepth) { delete p; cto::set_error("column depth %d > %d unsupported", n, kMaxDepth); return CTO_EUNSUPPORTED; }
             keymap.clear();
+            groupmap.clear();
             int nkeys_col = 0;
             for (int i = 0; i < n; ++i) {
                 const Tok& t = toks[size_t(i)];
@@ -161,9 +163,9 @@ extern "C" int cto_pack_from_mpileup(const char* text, size_t len, const char* r
                 uint32_t kind = uint32_t(t.kind), kid = 0;
                 if (t.kind != 0) {
                     const int gate_len = (t.kind == 1) ? t.seqlen : t.seqlen + 1;
-                    if (gate_len > max_indel_length) {
-                        kind = 3;
-                    } else {
+                    const bool overlong = gate_len > max_indel_length;
+                    if (overlong) kind = 3;
+                    {
                         // distinct Counter key: base char + sign + sequence, case-sensitive
                         keybuf.clear();
                         keybuf.push_back(char('0' + t.code));
@@ -175,7 +177,21 @@ extern "C" int cto_pack_from_mpileup(const char* text, size_t len, const char* r
                             kid = uint32_t(nkeys_col++);
                             keymap.emplace(keybuf, int(kid));
                             const bool fwd = (t.code < 4) || t.code == 8 || t.code == 10;
-                            p->key_meta.push_back(uint8_t(t.kind | (fwd ? 4 : 0)));
+                            p->key_meta.push_back(uint8_t(t.kind | (fwd ? 4 : 0) | (overlong ? 8 : 0)));
+                            // merged allele for candidate extraction: insertions by upper-cased anchor + sequence,
+                            // deletions by length (extract_candidates_calling.py:118-126)
+                            groupbuf.clear();
+                            if (t.kind == 1) {
+                                static const char kAnchor[] = "ACGTACGT*#NN";
+                                groupbuf.push_back('I');
+                                groupbuf.push_back(kAnchor[t.code]);
+                                for (int j = 0; j < t.seqlen; ++j) groupbuf.push_back(up(t.seq[j]));
+                            } else {
+                                groupbuf = "D" + std::to_string(t.seqlen);
+                            }
+                            auto gi = groupmap.find(groupbuf);
+                            if (gi == groupmap.end()) gi = groupmap.emplace(groupbuf, int(groupmap.size())).first;
+                            p->key_group.push_back(int32_t(gi->second));
                             // merged alt_info key
                             if (t.kind == 1) {
                                 p->key_str.push_back('I');
@@ -198,7 +214,11 @@ extern "C" int cto_pack_from_mpileup(const char* text, size_t len, const char* r
                 p->entries.push_back(uint32_t(t.code) | (kind << 4) | (uint32_t(bq) << 6) | (uint32_t(mq) << 13) | (kid << 21));
             }
             p->col_pos.push_back(int32_t(pos));
-            p->col_ref.push_back(uint8_t(ref_code_of(ref_seq[ri])));
+            {
+                const char ru = up(ref_seq[ri]);
+                const bool acgt = ru == 'A' || ru == 'C' || ru == 'G' || ru == 'T';
+                p->col_ref.push_back(uint8_t(ref_code_of(ref_seq[ri]) | (acgt ? 0 : 0x80)));
+            }
             p->col_off.push_back(int64_t(p->entries.size()));
             p->key_off.push_back(int32_t(p->key_meta.size()));
         }
@@ -218,6 +238,8 @@ extern "C" int cto_pack_from_arrays(const cto_pack_view* v, const int64_t* key_s
     p->key_off.assign(v->key_off, v->key_off + v->n_cols + 1);
     p->entries.assign(v->entries, v->entries + v->n_entries);
     p->key_meta.assign(v->key_meta, v->key_meta + v->n_keys);
+    if (v->key_group) p->key_group.assign(v->key_group, v->key_group + v->n_keys);
+    else p->key_group.assign(size_t(v->n_keys), 0);
     if (key_str_off && key_str) {
         p->key_str_off.assign(key_str_off, key_str_off + v->n_keys + 1);
         p->key_str.assign(key_str, size_t(key_str_off[v->n_keys]));
@@ -251,6 +273,7 @@ extern "C" int cto_pack_view_of(const cto_pack* p, cto_pack_view* v) {
     v->key_off = p->key_off.data();
     v->entries = p->entries.data();
     v->key_meta = p->key_meta.data();
+    v->key_group = p->key_group.data();
     return CTO_OK;
 }
 
@@ -272,7 +295,7 @@ extern "C" int cto_alt_info(const cto_pack* p, int64_t col, int pass, const int1
     colfirst_col += pass * 4;
     struct Item { int64_t first; std::string key; int64_t count; };
     std::vector<Item> items;
-    const int ref = p->col_ref[size_t(col)];
+    const int ref = p->col_ref[size_t(col)] & 3;
     static const char kB[] = "ACGT";
     // channel layout F0: A C G T at 0..3, a c g t at 9..12; the reference base's channel holds -(group sum)
     int64_t fwd[4], rev[4];

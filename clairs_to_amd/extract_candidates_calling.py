@@ -1,0 +1,99 @@
+"""Candidate extraction on the GPU: counterpart of `clairs_to.py extract_candidates_calling`
+(reference: src/extract_candidates_calling.py, STEP 1 of run_clairs_to:1194-1226).
+
+`extract_candidates()` runs the gates on a column pack that is already in HBM - the same pack tensor creation uses, so
+candidate sites become an internal product of the engine (one pileup instead of three).  `main()` mirrors the CLI at
+its file seam: it writes the `<ctg>.<chunk>_<i>_<n>_snv` / `_indel` BED chunk files (<= 10 000 windows
+`x-17 .. x+17` each) and the `SNV_CANDIDATES_FILE_*` list the next step reads."""
+import ctypes as C
+import gzip
+import os
+from argparse import ArgumentParser
+
+import numpy as np
+import torch
+
+from ._lib import lib, check, current_stream_ptr
+from .fasta import read_region
+from .pack import ColumnPack
+
+SPLIT_BED_SIZE, FLANK, EXPAND_REF = 10000, 16, 1000       # shared/param.py:21, 60, 101
+
+
+def extract_candidates(dev_pack, min_bq, min_mq=20, snv_min_af=0.05, indel_min_af=0.05, min_coverage=4, alt_base_num=3,
+                       select_indel=True):
+    """-> (flags uint8 [n_cols]: bit0 SNV candidate, bit1 indel candidate, bit2 pass_af; depth int32 [n_cols])."""
+    n = max(dev_pack.n_cols, 1)
+    flags = torch.zeros((n,), dtype=torch.uint8, device=dev_pack.device)
+    depth = torch.zeros((n,), dtype=torch.int32, device=dev_pack.device)
+    with torch.cuda.device(dev_pack.device):
+        check(lib.cto_extract_candidates(C.byref(dev_pack.view), int(min_mq), int(min_bq), float(snv_min_af),
+                                         float(indel_min_af), float(min_coverage), int(alt_base_num), int(bool(select_indel)),
+                                         flags.data_ptr(), depth.data_ptr(), current_stream_ptr()))
+    return flags[:dev_pack.n_cols], depth[:dev_pack.n_cols]
+
+
+def candidate_positions(dev_pack, flags, bit=1):
+    """Sorted 1-based positions of the columns whose flag has `bit` set (device tensor, int32)."""
+    idx = torch.nonzero((flags & bit) != 0).flatten()
+    return dev_pack.t["col_pos"][idx]
+
+
+def write_bed_chunks(folder, ctg, chunk_id, positions, suffix, list_prefix):
+    """The chunk files of extract_candidates_calling.py:450-488."""
+    if not len(positions):
+        return []
+    os.makedirs(folder, exist_ok=True)
+    n_regions = -(-len(positions) // SPLIT_BED_SIZE)
+    paths = []
+    for i in range(n_regions):
+        part = positions[i * SPLIT_BED_SIZE:(i + 1) * SPLIT_BED_SIZE]
+        path = os.path.join(folder, "{}.{}_{}_{}_{}".format(ctg, chunk_id, i, n_regions, suffix))
+        with open(path, "w") as f:
+            f.write("\n".join("\t".join([ctg, str(max(x - FLANK - 1, 1)), str(x + FLANK + 1)]) for x in part) + "\n")
+        paths.append(path)
+    with open(os.path.join(folder, "{}_{}_{}".format(list_prefix, ctg, chunk_id)), "w") as f:
+        f.write("\n".join(paths) + "\n")
+    return paths
+
+
+def main():
+    p = ArgumentParser(description="Extract candidate sites from a pileup (GPU gates)")
+    p.add_argument("--platform", type=str, default="ont")
+    p.add_argument("--candidates_folder", type=str, required=True)
+    p.add_argument("--mpileup_fn", type=str, required=True, help="samtools mpileup --reverse-del --output-MQ --min-MQ 0 --min-BQ 0 text")
+    p.add_argument("--ref_fn", type=str, required=True)
+    p.add_argument("--ctg_name", type=str, required=True)
+    p.add_argument("--chunk_id", type=int, default=None)
+    p.add_argument("--snv_min_af", type=float, default=0.05)
+    p.add_argument("--indel_min_af", type=float, default=1.0)
+    p.add_argument("--min_coverage", type=float, default=4)
+    p.add_argument("--min_mq", type=int, default=20)
+    p.add_argument("--min_bq", type=int, default=0)
+    p.add_argument("--alternative_base_num", type=int, default=3)
+    p.add_argument("--select_indel_candidates", type=lambda v: str(v).lower() in ("yes", "true", "t", "y", "1"), default=False)
+    a = p.parse_args()
+    opener = gzip.open if a.mpileup_fn.endswith(".gz") else open
+    with opener(a.mpileup_fn, "rb") as f:
+        text = f.read()
+    first = int(text.split(b"\t", 2)[1])
+    last = int(text.rstrip(b"\n").rsplit(b"\n", 1)[-1].split(b"\t", 2)[1])
+    ref_start = max(1, first - EXPAND_REF)
+    ref = read_region(a.ref_fn, a.ctg_name, ref_start, last + EXPAND_REF)
+    pack = ColumnPack.from_mpileup(text, ref, ref_start)
+    dp = pack.to_device("cuda")
+    flags, _ = extract_candidates(dp, a.min_bq, a.min_mq, a.snv_min_af, a.indel_min_af, a.min_coverage,
+                                  a.alternative_base_num, a.select_indel_candidates)
+    snv = candidate_positions(dp, flags, 1).cpu().tolist()
+    indel = candidate_positions(dp, flags, 2).cpu().tolist() if a.select_indel_candidates else []
+    write_bed_chunks(a.candidates_folder, a.ctg_name, a.chunk_id, snv, "snv", "SNV_CANDIDATES_FILE")
+    write_bed_chunks(a.candidates_folder, a.ctg_name, a.chunk_id, indel, "indel", "INDEL_CANDIDATES_FILE")
+    if a.select_indel_candidates:
+        print("[INFO] {} chunk {}: Total SNV candidates found: {}, total Indel candidates found: {}".format(
+            a.ctg_name, a.chunk_id, len(snv), len(indel)))
+    else:
+        print("[INFO] {} chunk {}: Total SNV candidates found: {}".format(a.ctg_name, a.chunk_id, len(snv)))
+
+
+if __name__ == "__main__":
+    main()

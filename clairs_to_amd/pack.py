@@ -7,7 +7,7 @@ import torch
 from ._lib import lib, check, PackView, c_vp
 
 _FIELDS = (("col_pos", np.int32), ("col_ref", np.uint8), ("col_off", np.int64), ("key_off", np.int32),
-           ("entries", np.uint32), ("key_meta", np.uint8))
+           ("entries", np.uint32), ("key_meta", np.uint8), ("key_group", np.int32))
 
 
 class ColumnPack:
@@ -36,8 +36,12 @@ class ColumnPack:
         return cls(out.value)
 
     @classmethod
-    def from_arrays(cls, col_pos, col_ref, col_off, key_off, entries, key_meta, key_str_off=None, key_str=None):
-        arrs = dict(col_pos=col_pos, col_ref=col_ref, col_off=col_off, key_off=key_off, entries=entries, key_meta=key_meta)
+    def from_arrays(cls, col_pos, col_ref, col_off, key_off, entries, key_meta, key_group=None, key_str_off=None,
+                    key_str=None):
+        if key_group is None:
+            key_group = np.zeros(len(key_meta), dtype=np.int32)
+        arrs = dict(col_pos=col_pos, col_ref=col_ref, col_off=col_off, key_off=key_off, entries=entries, key_meta=key_meta,
+                    key_group=key_group)
         keep = {k: np.ascontiguousarray(arrs[k], dtype=dt) for k, dt in _FIELDS}
         v = PackView()
         v.n_cols, v.n_entries, v.n_keys = len(keep["col_pos"]), len(keep["entries"]), len(keep["key_meta"])
@@ -56,7 +60,7 @@ class ColumnPack:
         """Zero-copy numpy views of the pack arrays (valid while this object lives)."""
         v = self.view
         n = dict(col_pos=v.n_cols, col_ref=v.n_cols, col_off=v.n_cols + 1, key_off=v.n_cols + 1,
-                 entries=v.n_entries, key_meta=v.n_keys)
+                 entries=v.n_entries, key_meta=v.n_keys, key_group=v.n_keys)
         out = {}
         for k, dt in _FIELDS:
             ptr = getattr(v, k)

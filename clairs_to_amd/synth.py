@@ -36,7 +36,7 @@ class SynthChunk:
         ref = rng.integers(0, 4, size=n_cols).astype(np.uint8)
         is_n = rng.random(n_cols) < n_rate
         self.col_ref_char = np.where(is_n, ord("N"), np.frombuffer(b"ACGT", dtype=np.uint8)[ref]).astype(np.uint8)
-        self.col_ref = np.where(is_n, 0, ref).astype(np.uint8)      # evc_base_from: N -> A
+        self.col_ref = np.where(is_n, 0x80, ref).astype(np.uint8)   # evc_base_from: N -> A (code 0); bit 7 = raw base not ACGT
         depth = np.clip(rng.poisson(depth_mean, size=n_cols), 4, 200).astype(np.int64)
         self.col_off = np.concatenate([[0], np.cumsum(depth)]).astype(np.int64)
         n_ent = int(self.col_off[-1])
@@ -45,11 +45,11 @@ class SynthChunk:
         centre = np.searchsorted(col_pos, self.site_pos.astype(np.int64))
         alt_af = np.zeros(n_cols)
         alt_af[centre] = rng.uniform(0.05, 0.6, size=n_sites)
-        alt_base = ((self.col_ref.astype(np.int64) + rng.integers(1, 4, size=n_cols)) % 4).astype(np.uint8)
+        alt_base = (((self.col_ref & 3).astype(np.int64) + rng.integers(1, 4, size=n_cols)) % 4).astype(np.uint8)
         # per read-base draws
         rev = rng.random(n_ent) < 0.5
         u = rng.random(n_ent)
-        base = self.col_ref[col_of].astype(np.int64)
+        base = (self.col_ref[col_of] & 3).astype(np.int64)
         mism = u < p_mismatch
         base = np.where(mism, (base + rng.integers(1, 4, size=n_ent)) % 4, base)
         is_alt = rng.random(n_ent) < alt_af[col_of]
@@ -66,9 +66,11 @@ class SynthChunk:
         bq = np.clip(np.rint(rng.normal(bq_mean, bq_sd, size=n_ent)), 1, 50).astype(np.uint32)
         mq = np.where(rng.random(n_ent) < 0.93, 60, rng.integers(0, 60, size=n_ent)).astype(np.uint32)
         # ---- distinct indel keys per column, ids in first-seen order ----
-        idx = np.nonzero((kind == 1) | (kind == 2))[0]
-        kcode = (kind[idx].astype(np.int64) << 40) | (code[idx].astype(np.int64) << 32) | (ilen[idx] << 8) | \
-            np.where(kind[idx] == 1, ivar[idx], 0)
+        # (over-long indels keep a key: tensor creation ignores them, candidate extraction does not)
+        okind = self._okind.astype(np.int64)
+        idx = np.nonzero(okind > 0)[0]
+        kcode = (okind[idx] << 40) | (code[idx].astype(np.int64) << 32) | (ilen[idx] << 8) | \
+            np.where(okind[idx] == 1, ivar[idx], 0)
         gkey = (col_of[idx] << 44) | kcode            # (column, key) identity; kcode < 2^43
         uniq, first_pos, inv = np.unique(gkey, return_index=True, return_inverse=True)
         first_ent = idx[first_pos]                       # entry index of each key's first occurrence
@@ -84,9 +86,22 @@ class SynthChunk:
         k_kind = (kc_sorted >> 40).astype(np.uint8)
         k_code = ((kc_sorted >> 32) & 0xff).astype(np.uint8)
         fwd = (k_code < 4) | (k_code == 8) | (k_code == 10)
-        self.key_meta = (k_kind | (fwd.astype(np.uint8) << 2)).astype(np.uint8)
         self.key_len = ((kc_sorted >> 8) & 0xffffff).astype(np.int32)
         self.key_var = (kc_sorted & 0xff).astype(np.int32)
+        k_gate = np.where(k_kind == 1, self.key_len, self.key_len + 1)
+        self.key_meta = (k_kind | (fwd.astype(np.uint8) << 2) | ((k_gate > max_indel_length).astype(np.uint8) << 3)).astype(np.uint8)
+        # merged allele for candidate extraction: insertions by (upper-cased anchor, sequence), deletions by length
+        anchor = np.where(k_code < 8, k_code % 4, np.where(k_code == 8, 8, np.where(k_code == 9, 9, 10))).astype(np.int64)
+        gcode = np.where(k_kind == 1, (np.int64(1) << 40) | (anchor << 32) | (self.key_len.astype(np.int64) << 8) | self.key_var,
+                         (np.int64(2) << 40) | (self.key_len.astype(np.int64) << 8))
+        gkey2 = (key_col.astype(np.int64) << 44) | gcode
+        gu, gfirst, ginv = np.unique(gkey2, return_index=True, return_inverse=True)
+        gorder = np.argsort(gfirst, kind="stable")          # groups in first-seen (= key) order, column-major
+        grank = np.empty_like(gorder)
+        grank[gorder] = np.arange(gorder.size)
+        gcol = (gu >> 44)[gorder]
+        goff = np.searchsorted(gcol, np.arange(n_cols + 1))
+        self.key_group = (grank[ginv] - goff[key_col]).astype(np.int32)
         assert n_keys == 0 or kid.max() < 2048
         self.entries = (code | (kind << 4) | (bq << 6) | (mq << 13) | (kid << 21)).astype(np.uint32)
         # over-long indels keep their length so the text writer can print them
@@ -97,7 +112,7 @@ class SynthChunk:
     # ---- numpy views in the cto_pack_view layout ----
     def arrays(self):
         return dict(col_pos=self.col_pos, col_ref=self.col_ref, col_off=self.col_off, key_off=self.key_off,
-                    entries=self.entries, key_meta=self.key_meta)
+                    entries=self.entries, key_meta=self.key_meta, key_group=self.key_group)
 
     def ref_window(self):
         """(ref_seq, ref_start): a reference string covering every column +- 100 bp; gaps are 'A'."""
@@ -119,16 +134,21 @@ def _ins_seq(length, var, lower):
     return s.lower() if lower else s
 
 
-def mpileup_text(chunk, min_bq=0, ctg="chr1", col_range=None):
-    """`samtools mpileup --reverse-del --output-MQ --min-BQ min_bq` text of a SynthChunk (Python loop: small n)."""
+def mpileup_text(chunk, min_bq=0, ctg="chr1", col_range=None, min_mq=0, with_mq=True):
+    """`samtools mpileup --reverse-del [--output-MQ] --min-MQ min_mq --min-BQ min_bq` text of a SynthChunk (Python
+    loop: small n).  with_mq=False drops the MQ column (candidate extraction runs samtools without --output-MQ);
+    positions whose reads are all below min_mq print no row (the read-level filter removes them from the pileup)."""
     rows = []
     c0, c1 = col_range if col_range else (0, chunk.col_pos.size)
     ent, off = chunk.entries, chunk.col_off
     for c in range(c0, c1):
-        toks, bqs, mqs = [], [], []
+        toks, bqs, mqs, n_reads = [], [], [], 0
         for e in range(int(off[c]), int(off[c + 1])):
             x = int(ent[e])
             code, kind, bq, mq = x & 15, (x >> 4) & 3, (x >> 6) & 127, (x >> 13) & 255
+            if mq < min_mq:
+                continue
+            n_reads += 1
             if bq < min_bq:
                 continue
             t = BASE_CHARS[code]
@@ -143,10 +163,13 @@ def mpileup_text(chunk, min_bq=0, ctg="chr1", col_range=None):
             bqs.append(chr(bq + 33))
             mqs.append(chr(min(mq, 93) + 33))
         n = len(toks)
+        if n_reads == 0:
+            continue
+        tail = ("\t" + ("".join(mqs) if n else "*")) if with_mq else ""
         if n == 0:   # samtools prints placeholders when every base was filtered (bam_plcmd.c)
-            rows.append("%s\t%d\tN\t0\t*\t*\t*" % (ctg, int(chunk.col_pos[c])))
+            rows.append("%s\t%d\tN\t0\t*\t*%s" % (ctg, int(chunk.col_pos[c]), tail))
         else:
-            rows.append("%s\t%d\tN\t%d\t%s\t%s\t%s" % (ctg, int(chunk.col_pos[c]), n, "".join(toks), "".join(bqs), "".join(mqs)))
+            rows.append("%s\t%d\tN\t%d\t%s\t%s%s" % (ctg, int(chunk.col_pos[c]), n, "".join(toks), "".join(bqs), tail))
     return "\n".join(rows) + "\n"
 
 

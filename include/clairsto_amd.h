@@ -48,22 +48,31 @@ int cto_device_count(void);
  * entry (uint32), one per read-base of a column, in samtools' read order, as printed with --min-BQ 0:
  *   bits  3:0  base code: 0..3 = A C G T, 4..7 = a c g t, 8 = '*', 9 = '#', 10 = 'N', 11 = 'n'
  *   bits  5:4  indel kind attached to this base: 0 none, 1 insertion, 2 deletion,
- *              3 = indel longer than max_indel_length (entry contributes nothing, F4)
+ *              3 = indel longer than max_indel_length (contributes nothing to the tensors, F4; still
+ *                  carries its key id for candidate extraction, which has no length gate)
  *   bits 12:6  base quality (phred, clamped to 127)
  *   bits 20:13 mapping quality
  *   bits 31:21 key id: index of this entry's distinct indel key within its column (first-seen order)
- * key_meta (uint8) per distinct indel key: bits 1:0 kind (1 ins / 2 del), bit 2 = forward strand.
+ * key_meta (uint8) per distinct indel key: bits 1:0 kind (1 ins / 2 del), bit 2 = forward strand,
+ *   bit 3 = longer than max_indel_length.
+ * key_group (int32) per distinct key: index, within its column, of the strand-/anchor-case-merged allele the
+ *   key belongs to for candidate extraction (insertions: anchor + sequence upper-cased; deletions: length),
+ *   src/extract_candidates_calling.py:118-126.
+ * col_ref bit 7 is set when the raw reference base is not A/C/G/T (such rows are skipped by candidate
+ *   extraction, extract_candidates_calling.py:329-331, but not by tensor creation).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct cto_pack_view {
     int64_t         n_cols;
     int64_t         n_entries;
     int64_t         n_keys;
     const int32_t*  col_pos;   /* [n_cols]   1-based reference position, strictly increasing       */
-    const uint8_t*  col_ref;   /* [n_cols]   reference base code 0..3 after evc_base_from (F1)      */
+    const uint8_t*  col_ref;   /* [n_cols]   bits 1:0 reference base code after evc_base_from (F1);
+                                             bit 7: raw reference base is not A/C/G/T               */
     const int64_t*  col_off;   /* [n_cols+1] first entry of each column                             */
     const int32_t*  key_off;   /* [n_cols+1] first distinct indel key of each column                */
     const uint32_t* entries;   /* [n_entries]                                                       */
     const uint8_t*  key_meta;  /* [n_keys]                                                          */
+    const int32_t*  key_group; /* [n_keys]                                                          */
 } cto_pack_view;
 
 typedef struct cto_pack cto_pack;   /* host-side pack incl. the key strings needed for alt_info   */
@@ -118,6 +127,16 @@ int cto_gather_windows(const cto_pack_view* dev_pack, const int16_t* colvec, con
                        const int32_t* site_pos, int64_t n_sites, int min_rescale_cov,
                        float* x_aff, float* x_neg, int16_t* raw_aff, int16_t* raw_neg,
                        int32_t* site_info, void* stream);
+
+/* Candidate extraction (src/extract_candidates_calling.py:55-169, 322-372) on the same pack: read-bases with
+ * MQ >= min_mq and BQ >= min_bq (what `samtools mpileup --min-MQ --min-BQ` would print) are counted per column,
+ *   depth = bases in ACGTacgt*#;  pass_depth = depth > min_coverage;
+ *   pass_snv   = some non-reference base with count / depth >= snv_min_af and count >= alt_base_num;
+ *   pass_indel = (select_indel) some merged indel allele with count / depth >= indel_min_af and count >= alt_base_num;
+ * flags dev [n_cols] uint8: bit0 SNV candidate, bit1 indel candidate, bit2 pass_af; depth dev [n_cols] int32. */
+int cto_extract_candidates(const cto_pack_view* dev_pack, int min_mq, int min_bq, double snv_min_af,
+                           double indel_min_af, double min_coverage, int alt_base_num, int select_indel,
+                           uint8_t* flags, int32_t* depth, void* stream);
 
 /* Host: the reference's alt_info string "<depth>-<key count ...>-" for the column `col` of pass `pass`
  * (0 = AFF, 1 = NEG; create_tensor_pileup_calling.py:158-209), from stage-A outputs copied to the host.

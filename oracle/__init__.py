@@ -154,7 +154,7 @@ def posterior_from_probs(p1, lik, edges):
     return post, dec, qual
 
 
-def synth_mpileup_text(chunk, min_bq=0, col_range=None):
+def synth_mpileup_text(chunk, min_bq=0, col_range=None, min_mq=0, with_mq=True):
     """Fast (C) equivalent of clairs_to_amd.synth.mpileup_text for a SynthChunk; returns bytes."""
     c0, c1 = col_range if col_range else (0, chunk.col_pos.size)
     n_ent = int(chunk.col_off[c1] - chunk.col_off[c0])
@@ -165,6 +165,25 @@ def synth_mpileup_text(chunk, min_bq=0, col_range=None):
             a(chunk._ilen, np.int32), a(chunk._ivar, np.int32)]
     f = lib().orc_pack_to_mpileup
     f.restype = C.c_int64
-    n = f(*[_p(x) for x in arrs], C.c_int64(c0), C.c_int64(c1), int(min_bq), _p(buf), C.c_int64(cap))
+    n = f(*[_p(x) for x in arrs], C.c_int64(c0), C.c_int64(c1), int(min_bq), int(min_mq), int(bool(with_mq)), _p(buf),
+          C.c_int64(cap))
     assert n >= 0
     return buf[:n].tobytes()
+
+
+def extract_candidates(text, ref, ref_start, snv_min_af=0.05, indel_min_af=0.05, min_coverage=4, alt_base_num=3,
+                       select_indel=True):
+    """extract_candidates_calling restatement on `samtools mpileup --min-MQ 20 --min-BQ q` text (6 columns).
+    Returns pos int32 [n_rows], flags uint8 [n_rows] (bit0 SNV, bit1 indel, bit2 pass_af), depth int32 [n_rows]."""
+    tb = text.encode() if isinstance(text, str) else text
+    rb = ref.encode() if isinstance(ref, str) else ref
+    cap = tb.count(b"\n") + 1
+    pos = np.zeros(cap, dtype=np.int32)
+    flags = np.zeros(cap, dtype=np.uint8)
+    depth = np.zeros(cap, dtype=np.int32)
+    f = lib().orc_extract_candidates
+    f.restype = C.c_int64
+    n = f(tb, C.c_size_t(len(tb)), rb, C.c_int64(ref_start), C.c_int64(len(rb)), C.c_double(min_coverage),
+          C.c_double(snv_min_af), C.c_double(indel_min_af), int(alt_base_num), int(bool(select_indel)), _p(pos), _p(flags),
+          _p(depth), C.c_int64(cap))
+    return pos[:n], flags[:n], depth[:n]

@@ -10,6 +10,7 @@ reference - they read the files this script writes next to itself:
                        the tensor text rows it wrote                                         (F9-F11)
   models_<cls>.npz     logits of the four clairs.model classes on count tensors, weights from
                        weights_recipe.py (only the (name, shape) manifest is stored)         (M1-M9)
+  extract.json.gz      extract_candidates_calling through the shim: pileup text in, SNV / indel candidate positions out
   calls_<mode>.json.gz clairs_to.py predict (--predict_fn) then call_variants on those tensors: probability rows,
                        likelihood table, VCF rows                                            (H1-H6, Q1-Q6)
 
@@ -316,12 +317,64 @@ def gen_calls(tmp, region):
         print(mode, "vcf rows:", {k: len(v) for k, v in vcfs.items()})
 
 
+# ------------------------------------------------------------------------------------------ candidate extraction
+def gen_extract(tmp):
+    """extract_candidates_calling through the shim: `samtools mpileup --min-MQ 20 --min-BQ 20` text in,
+    SNV / indel candidate BED chunk files out."""
+    chunk = SynthChunk(70, seed=21, start=2000, spacing=30, depth_mean=14.0, p_mismatch=0.03, p_ins=0.03, p_del=0.04,
+                       n_rate=0.03)
+    ref, ref_lo = chunk.ref_window()
+    full_ref = "A" * (ref_lo - 1) + ref                     # the shim serves a contig that starts at position 1
+    text6 = mpileup_text(chunk, min_bq=20, min_mq=20, with_mq=False)
+    d = os.path.join(tmp, "extract")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "ref.fa"), "w") as f:
+        f.write(">chr1\n" + full_ref + "\n")
+    with open(os.path.join(d, "ref.fa.fai"), "w") as f:
+        f.write("chr1\t%d\t6\t%d\t%d\n" % (len(full_ref), len(full_ref), len(full_ref) + 1))
+    open(os.path.join(d, "ref.txt"), "w").write(full_ref)
+    shim = os.path.join(d, "samtools")
+    open(shim, "w").write(SHIM)
+    os.chmod(shim, os.stat(shim).st_mode | stat.S_IEXEC)
+    open(os.path.join(d, "mp.txt"), "w").write(text6)
+    env = dict(os.environ, PYTHONPATH=REF, FAKE_REF=os.path.join(d, "ref.txt"), FAKE_MPILEUP_20=os.path.join(d, "mp.txt"))
+    params = dict(snv_min_af=0.05, indel_min_af=0.05, min_coverage=4, min_bq=20, min_mq=20, alt_base_num=3)
+    ctg_start, ctg_end = int(chunk.col_pos[0]), int(chunk.col_pos[-1])
+    out_dir = os.path.join(d, "candidates")
+    subprocess.check_call([sys.executable, os.path.join(REF, "clairs_to.py"), "extract_candidates_calling",
+                           "--tumor_bam_fn", "fake.bam", "--ref_fn", os.path.join(d, "ref.fa"), "--samtools", shim,
+                           "--snv_min_af", str(params["snv_min_af"]), "--indel_min_af", str(params["indel_min_af"]),
+                           "--ctg_name", "chr1", "--ctg_start", str(ctg_start), "--ctg_end", str(ctg_end),
+                           "--platform", "ont", "--min_coverage", str(params["min_coverage"]), "--min_bq", "20",
+                           "--select_indel_candidates", "True", "--candidates_folder", out_dir, "--output_depth", "True"],
+                          cwd=d, env=env)
+
+    def centres(suffix):
+        out = []
+        for fn in sorted(os.listdir(out_dir)):
+            if fn.endswith(suffix) and fn.startswith("chr1."):
+                for row in open(os.path.join(out_dir, fn)):
+                    c = row.split("\t")
+                    if len(c) >= 3:
+                        out.append(int(c[2]) - 17)             # rows are ctg, max(x-17, 1), x+17
+        return out
+    fixture = dict(ref=ref, ref_start=ref_lo, params=params, mpileup_extract=text6, mpileup_neg=mpileup_text(chunk, 0),
+                   snv=centres("_snv"), indel=centres("_indel"))
+    print("extract: rows", text6.count("\n"), "snv", len(fixture["snv"]), "indel", len(fixture["indel"]))
+    dump_json_gz("extract.json.gz", fixture)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "extract":
+        with tempfile.TemporaryDirectory() as tmp:
+            gen_extract(tmp)
+        return
     gen_columns()
     with tempfile.TemporaryDirectory() as tmp:
         region = gen_region(tmp)
         gen_models(region)
         gen_calls(tmp, region)
+        gen_extract(tmp)
 
 
 if __name__ == "__main__":

@@ -206,3 +206,36 @@ def test_vcf_rows_from_gpu_posterior(dev, mode):
         out = [vcf_row(r[0], r[1], r[2], r[3], eval(r[4]), eval(r[5]), int(dec[i, 0]), float(qual[i]), K, show_ref=show_ref)
                for i, r in enumerate(rows)]
         assert [x for x in out if x is not None] == calls["vcf"]["show_ref" if show_ref else "default"]
+
+
+def test_extract_candidates_match_reference_and_oracle(dev, oracle_lib):
+    """GPU gates on the column pack vs (a) the candidate files the reference wrote, (b) the oracle on a bigger chunk,
+    including a chunk whose merged-allele table overflows LDS."""
+    import torch
+    from clairs_to_amd.pack import ColumnPack, DevicePack
+    from clairs_to_amd.extract_candidates_calling import extract_candidates, candidate_positions
+    from clairs_to_amd.synth import SynthChunk
+    g = load_json_gz("extract.json.gz")
+    pr = g["params"]
+    pack = ColumnPack.from_mpileup(g["mpileup_neg"], g["ref"], g["ref_start"])
+    dp = pack.to_device(dev)
+    flags, depth = extract_candidates(dp, pr["min_bq"], pr["min_mq"], pr["snv_min_af"], pr["indel_min_af"], pr["min_coverage"],
+                                      pr["alt_base_num"], True)
+    assert candidate_positions(dp, flags, 1).cpu().tolist() == g["snv"]
+    assert candidate_positions(dp, flags, 2).cpu().tolist() == g["indel"]
+    for kw, n in ((dict(p_mismatch=0.03, p_ins=0.02, p_del=0.03, depth_mean=30.0), 400),
+                  (dict(p_ins=0.25, p_del=0.25, depth_mean=60.0), 60)):
+        chunk = SynthChunk(n, seed=5, spacing=25, n_rate=0.02, **kw)
+        ref, lo = chunk.ref_window()
+        dp = DevicePack(chunk.arrays(), dev)
+        flags, depth = extract_candidates(dp, 20, 20, 0.05, 0.05, 4, 3, True)
+        text6 = oracle_lib.synth_mpileup_text(chunk, 20, None, 20, False)
+        pos, fl, dep = oracle_lib.extract_candidates(text6, ref, lo, 0.05, 0.05, 4, 3, True)
+        got_f, got_d = flags.cpu().numpy(), depth.cpu().numpy()
+        cols = np.searchsorted(chunk.col_pos, pos)                 # rows exist only where some read passes the MQ gate
+        np.testing.assert_array_equal(got_f[cols], fl)
+        np.testing.assert_array_equal(got_d[cols], dep)
+        mask = np.ones(chunk.col_pos.size, bool)
+        mask[cols] = False
+        assert not got_f[mask].any()
+        assert (fl & 1).sum() > 0

@@ -28,7 +28,7 @@ def test_mpileup_tokeniser_round_trips_synthetic_pack():
     ref, lo = chunk.ref_window()
     pack = ColumnPack.from_mpileup(mpileup_text(chunk), ref, lo)
     got, want = pack.numpy(), chunk.arrays()
-    for k in ("col_pos", "col_ref", "col_off", "key_off", "key_meta"):
+    for k in ("col_pos", "col_ref", "col_off", "key_off", "key_meta", "key_group"):
         np.testing.assert_array_equal(got[k], want[k], err_msg=k)
     # MQ is printed clamped to 93 ('~') by the text writer; compare entries with MQ saturated the same way
     e = want["entries"].astype(np.uint64)

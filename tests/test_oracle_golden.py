@@ -87,3 +87,15 @@ def test_c_text_writer_equals_python_writer(oracle_lib):
     for q in (0, 20, 45):
         assert oracle_lib.synth_mpileup_text(chunk, q).decode() == mpileup_text(chunk, q)
     assert oracle_lib.synth_mpileup_text(chunk, 0, (3, 9)).decode() == mpileup_text(chunk, 0, col_range=(3, 9))
+    assert oracle_lib.synth_mpileup_text(chunk, 20, None, 20, False).decode() == mpileup_text(chunk, 20, min_mq=20, with_mq=False)
+
+
+def test_extract_candidates_match_reference(oracle_lib):
+    """the reference's own extract_candidates_calling output (SNV / indel candidate BED files) vs the restatement"""
+    g = load_json_gz("extract.json.gz")
+    pr = g["params"]
+    pos, flags, depth = oracle_lib.extract_candidates(g["mpileup_extract"], g["ref"], g["ref_start"], pr["snv_min_af"],
+                                                      pr["indel_min_af"], pr["min_coverage"], pr["alt_base_num"], True)
+    assert pos[(flags & 1) != 0].tolist() == g["snv"] and len(g["snv"]) > 10
+    assert pos[(flags & 2) != 0].tolist() == g["indel"] and len(g["indel"]) > 0
+    assert ((flags & 4) != 0).sum() >= len(g["snv"])
