@@ -68,16 +68,20 @@ __device__ __forceinline__ void gemm_lds(const float* __restrict__ A, int lda, c
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a[(c + 1) & 1][mt] = *reinterpret_cast<const float4*>(Arow + mt * 16 * lda + (c + 1) * 16);
         }
+        // k-step outermost, tiles innermost: consecutive MFMAs never hit the same accumulator (dependent latency 40 cycles
+        // vs issue interval 32 for v_mfma_f32_16x16x4_f32)
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const float4 b = Bq[c % 3][nt];
+        for (int e = 0; e < 4; ++e) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const float4 av = a[c & 1][mt];
-                acc[mt][nt] = mfma16(av.x, b.x, acc[mt][nt]);
-                acc[mt][nt] = mfma16(av.y, b.y, acc[mt][nt]);
-                acc[mt][nt] = mfma16(av.z, b.z, acc[mt][nt]);
-                acc[mt][nt] = mfma16(av.w, b.w, acc[mt][nt]);
+            for (int nt = 0; nt < NTW; ++nt) {
+                const float4 b4 = Bq[c % 3][nt];
+                const float bv = e == 0 ? b4.x : (e == 1 ? b4.y : (e == 2 ? b4.z : b4.w));
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float4 a4 = a[c & 1][mt];
+                    const float av = e == 0 ? a4.x : (e == 1 ? a4.y : (e == 2 ? a4.z : a4.w));
+                    acc[mt][nt] = mfma16(av, bv, acc[mt][nt]);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);

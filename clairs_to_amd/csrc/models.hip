@@ -332,7 +332,7 @@ int cvt_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStrea
 template <int KIN, int KP, int H, int MS, int MH, bool FUSE>
 int launch_gru(hipStream_t s, const float* x, const float* W, const float* bias, float* out, const float* fc1w,
                float* fc1_part, int64_t B) {
-    const size_t smem = size_t(2) * MH * MS * 16 * (H + 4) * sizeof(float);
+    const size_t smem = size_t(2) * MH * MS * 16 * ((H + 4) + (KP + 4)) * sizeof(float);   // h tiles + x tiles
     static bool attr_set = false;
     if (!attr_set) {
         CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_layer<KIN, KP, H, MS, MH, FUSE>),

@@ -345,7 +345,9 @@ __global__ __launch_bounds__(256) void k_fc3(const float* __restrict__ u, const 
 // (= [W_ih | W_hh] per gate row, W_ih zero-padded to KP) with fp32 MFMA:
 //     r, z : one accumulator over the whole K;   n : separate accumulators for the x part (gi_n) and
 //     the h part (gh_n) because n = tanh(gi_n + r * gh_n).
-// A operands: x_t straight from global memory (independent of the recurrence, so prefetchable),
+// A operands: x_t from a double-buffered LDS tile that the whole block fills one step ahead (loads issued at the start
+//             of step t for step t+1, written to LDS just before the barrier of step t: the HBM latency of the
+//             activations - which every one of the 4 waves needs in full - is paid once per step, off the MFMA path),
 //             h_{t-1} from a double-buffered LDS tile [MS*16][H] that all waves rewrite each step.
 // B operands (weights) stream from L2 as one 16-byte load per lane per (gate, 16-wide k chunk); they
 //             are shared by the MS row-subtiles.  One barrier per time step.
@@ -371,7 +373,12 @@ __global__ __launch_bounds__(256 * MH) void k_gru_layer(const float* __restrict_
     constexpr int FC1_K = T * 2 * H;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TILE = MH * MS * 16, NTHR = 256 * MH;
-    float* hbuf = smem;   // [2][TILE][HS]
+    constexpr int XS = KP + 4;                                    // row stride of the x tile (16-byte aligned rows)
+    constexpr bool XV = (KIN % 4 == 0);                           // stage x as float4 (else scalars)
+    constexpr int XQ = XV ? TILE * (KIN / 4) : TILE * KIN;        // staging units per step
+    constexpr int XPER = (XQ + NTHR - 1) / NTHR;
+    float* hbuf = smem;                       // [2][TILE][HS]
+    float* xbuf = smem + 2 * TILE * HS;       // [2][TILE][XS]
     const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, mh = threadIdx.x >> 8;
     const int rb = mh * MS * 16;          // first tile row of this wave
     const int j = lane & 15, kg = lane >> 4;
@@ -381,6 +388,7 @@ __global__ __launch_bounds__(256 * MH) void k_gru_layer(const float* __restrict_
     const float* bd = bias + dir * 4 * H;
 
     for (int i = threadIdx.x; i < TILE * HS; i += NTHR) hbuf[i] = 0.f;   // h_{-1} = 0
+    for (int i = threadIdx.x; i < 2 * TILE * XS; i += NTHR) xbuf[i] = 0.f;   // K padding and rows past the batch stay 0
 
     float bia[NB][4];
     const float* wrow[NB][3];
@@ -408,12 +416,41 @@ __global__ __launch_bounds__(256 * MH) void k_gru_layer(const float* __restrict_
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms) { accf[ms][0] = f32x4{0.f, 0.f, 0.f, 0.f}; accf[ms][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    const float* xrow[MS];   // x row of the site this lane feeds, nullptr for rows past the batch (zero rows)
+    // x staging: unit u of the tile = (row, 4-float group) or (row, scalar); global -> registers -> LDS
+    float4 xstage[XPER];
+    auto x_fetch = [&](int t) {
 #pragma unroll
-    for (int ms = 0; ms < MS; ++ms) {
-        const int site = site0 + rb + ms * 16 + j;
-        xrow[ms] = site < B ? x + int64_t(site) * T * KIN + 4 * kg : nullptr;
-    }
+        for (int q = 0; q < XPER; ++q) {
+            const int u = threadIdx.x + q * NTHR;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u < XQ) {
+                if constexpr (XV) {
+                    const int row = u / (KIN / 4), c4 = (u - row * (KIN / 4)) * 4;
+                    if (site0 + row < B) v = *reinterpret_cast<const float4*>(x + (int64_t(site0 + row) * T + t) * KIN + c4);
+                } else {
+                    const int row = u / KIN, c = u - row * KIN;
+                    if (site0 + row < B) v.x = x[(int64_t(site0 + row) * T + t) * KIN + c];
+                }
+            }
+            xstage[q] = v;
+        }
+    };
+    auto x_commit = [&](int buf) {
+        float* xb = xbuf + buf * (TILE * XS);
+#pragma unroll
+        for (int q = 0; q < XPER; ++q) {
+            const int u = threadIdx.x + q * NTHR;
+            if (u < XQ) {
+                if constexpr (XV) {
+                    const int row = u / (KIN / 4), c4 = (u - row * (KIN / 4)) * 4;
+                    *reinterpret_cast<float4*>(xb + row * XS + c4) = xstage[q];
+                } else {
+                    const int row = u / KIN, c = u - row * KIN;
+                    xb[row * XS + c] = xstage[q].x;
+                }
+            }
+        }
+    };
 
     float4 Bq[2][NB][3], Fq[2][2], Aq[2][MS];
 
@@ -431,24 +468,10 @@ __global__ __launch_bounds__(256 * MH) void k_gru_layer(const float* __restrict_
                 Fq[buf][nt] = *reinterpret_cast<const float4*>(frow[nt] + tprev * (2 * H) + kh * 16);
         }
     };
-    auto load_Ax = [&](int buf, int c, int t) {
+    auto load_Ax = [&](int buf, int c, const float* xc) {
 #pragma unroll
-        for (int ms = 0; ms < MS; ++ms) {
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (xrow[ms]) {
-                const float* xr = xrow[ms] + t * KIN + c * 16;
-                if constexpr (KIN % 4 == 0) {
-                    a = *reinterpret_cast<const float4*>(xr);
-                } else {
-                    const int k = c * 16 + 4 * kg;
-                    a.x = k + 0 < KIN ? xr[0] : 0.f;
-                    a.y = k + 1 < KIN ? xr[1] : 0.f;
-                    a.z = k + 2 < KIN ? xr[2] : 0.f;
-                    a.w = k + 3 < KIN ? xr[3] : 0.f;
-                }
-            }
-            Aq[buf][ms] = a;
-        }
+        for (int ms = 0; ms < MS; ++ms)
+            Aq[buf][ms] = *reinterpret_cast<const float4*>(xc + (rb + ms * 16 + j) * XS + c * 16 + 4 * kg);
     };
     auto load_Ah = [&](int buf, int kh, const float* hc) {
 #pragma unroll
@@ -456,9 +479,13 @@ __global__ __launch_bounds__(256 * MH) void k_gru_layer(const float* __restrict_
             Aq[buf][ms] = *reinterpret_cast<const float4*>(hc + (rb + ms * 16 + j) * HS + kh * 16 + 4 * kg);
     };
 
-    // prologue: operands of chunk 0 of step 0
+    // prologue: x tile of step 0 into LDS, weights of chunk 0
+    x_fetch(dir == 0 ? 0 : T - 1);
+    __syncthreads();              // the zero fill above is complete
+    x_commit(0);
     load_B(0, 0);
-    load_Ax(0, 0, dir == 0 ? 0 : T - 1);
+    __syncthreads();
+    load_Ax(0, 0, xbuf);
 
     for (int step = 0; step < T; ++step) {
         const int t = dir == 0 ? step : T - 1 - step;
@@ -466,6 +493,8 @@ __global__ __launch_bounds__(256 * MH) void k_gru_layer(const float* __restrict_
         const int tprev = step == 0 ? t : (dir == 0 ? t - 1 : t + 1);        // step 0: h = 0, any valid slice will do
         const int cur_h = step & 1;
         const float* hc = hbuf + cur_h * (TILE * HS);
+        const float* xc = xbuf + cur_h * (TILE * XS);             // x_t (filled during the previous step)
+        const float* xn = xbuf + (cur_h ^ 1) * (TILE * XS);       // x_{t+1} (filled during this step)
         // The weight addresses do not depend on `step`; without this the compiler hoists all K chunks of weight
         // loads out of the time loop (hundreds of registers, spills).  An opaque zero keeps them per-step.
         opq = 0;
@@ -483,61 +512,56 @@ __global__ __launch_bounds__(256 * MH) void k_gru_layer(const float* __restrict_
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int cur = c & 1, nxt = cur ^ 1;
+            if (c == 0 && step + 1 < T) x_fetch(tnext);   // next step's activations: in flight under this step's x part
             if (c == NX) {
-                __syncthreads();            // h_{t-1}, written by all waves during the previous step, is complete
+                if (step + 1 < T) x_commit(cur_h ^ 1);
+                __syncthreads();            // h_{t-1} (written during the previous step) and x_{t+1} are complete
                 load_Ah(cur, 0, hc);
                 load_F(cur, 0, tprev);
             }
             // ---- request the operands of the next chunk before computing this one ----
             if (c + 1 < NC) {
                 load_B(nxt, c + 1);
-                if (c + 1 < NX) load_Ax(nxt, c + 1, t);
+                if (c + 1 < NX) load_Ax(nxt, c + 1, xc);
                 else if (c + 1 > NX) { load_Ah(nxt, c + 1 - NX, hc); load_F(nxt, c + 1 - NX, tprev); }
             } else if (step + 1 < T) {
                 load_B(nxt, 0);
-                load_Ax(nxt, 0, tnext);
+                load_Ax(nxt, 0, xn);
             }
             // ---- MFMAs of chunk c ----
+            // k-step outermost, accumulators innermost: consecutive MFMAs never share an accumulator, so the 40-cycle
+            // dependent latency of v_mfma_f32_16x16x4_f32 (issue interval 32) is never exposed.
             const bool xpart = c < NX;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const float4 br = Bq[cur][nb][0], bz = Bq[cur][nb][1], bn = Bq[cur][nb][2];
+                const float brv[4] = {br.x, br.y, br.z, br.w}, bzv[4] = {bz.x, bz.y, bz.z, bz.w}, bnv[4] = {bn.x, bn.y, bn.z, bn.w};
 #pragma unroll
-                for (int ms = 0; ms < MS; ++ms) {
-                    const float4 a = Aq[cur][ms];
-                    ar[ms][nb] = mfma16(a.x, br.x, ar[ms][nb]);
-                    az[ms][nb] = mfma16(a.x, bz.x, az[ms][nb]);
-                    ar[ms][nb] = mfma16(a.y, br.y, ar[ms][nb]);
-                    az[ms][nb] = mfma16(a.y, bz.y, az[ms][nb]);
-                    ar[ms][nb] = mfma16(a.z, br.z, ar[ms][nb]);
-                    az[ms][nb] = mfma16(a.z, bz.z, az[ms][nb]);
-                    ar[ms][nb] = mfma16(a.w, br.w, ar[ms][nb]);
-                    az[ms][nb] = mfma16(a.w, bz.w, az[ms][nb]);
-                    if (xpart) {
-                        ain[ms][nb] = mfma16(a.x, bn.x, ain[ms][nb]);
-                        ain[ms][nb] = mfma16(a.y, bn.y, ain[ms][nb]);
-                        ain[ms][nb] = mfma16(a.z, bn.z, ain[ms][nb]);
-                        ain[ms][nb] = mfma16(a.w, bn.w, ain[ms][nb]);
-                    } else {
-                        ahn[ms][nb] = mfma16(a.x, bn.x, ahn[ms][nb]);
-                        ahn[ms][nb] = mfma16(a.y, bn.y, ahn[ms][nb]);
-                        ahn[ms][nb] = mfma16(a.z, bn.z, ahn[ms][nb]);
-                        ahn[ms][nb] = mfma16(a.w, bn.w, ahn[ms][nb]);
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int ms = 0; ms < MS; ++ms) {
+                        const float4 a4 = Aq[cur][ms];
+                        const float av = e == 0 ? a4.x : (e == 1 ? a4.y : (e == 2 ? a4.z : a4.w));
+                        ar[ms][nb] = mfma16(av, brv[e], ar[ms][nb]);
+                        az[ms][nb] = mfma16(av, bzv[e], az[ms][nb]);
+                        if (xpart) ain[ms][nb] = mfma16(av, bnv[e], ain[ms][nb]);
+                        else ahn[ms][nb] = mfma16(av, bnv[e], ahn[ms][nb]);
                     }
                 }
             }
             if constexpr (FUSE_FC1) {
                 if (!xpart) {
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
+                    for (int e = 0; e < 4; ++e)
 #pragma unroll
-                        for (int ms = 0; ms < MS; ++ms) {
-                            const float4 a = Aq[cur][ms], f = Fq[cur][nt];
-                            accf[ms][nt] = mfma16(a.x, f.x, accf[ms][nt]);
-                            accf[ms][nt] = mfma16(a.y, f.y, accf[ms][nt]);
-                            accf[ms][nt] = mfma16(a.z, f.z, accf[ms][nt]);
-                            accf[ms][nt] = mfma16(a.w, f.w, accf[ms][nt]);
-                        }
+                        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                            for (int ms = 0; ms < MS; ++ms) {
+                                const float4 a4 = Aq[cur][ms], f4 = Fq[cur][nt];
+                                const float av = e == 0 ? a4.x : (e == 1 ? a4.y : (e == 2 ? a4.z : a4.w));
+                                const float fv = e == 0 ? f4.x : (e == 1 ? f4.y : (e == 2 ? f4.z : f4.w));
+                                accf[ms][nt] = mfma16(av, fv, accf[ms][nt]);
+                            }
                 }
             }
             // keep the hand-made pipeline: nothing (in particular no later prefetch) moves across a chunk boundary

@@ -111,6 +111,14 @@ class Engine:
         out.update(aff_logits=la, neg_logits=ln, site_info=feat.site_info, features=feat)
         return out
 
+    def run_region(self, dev_pack, snv_min_af=0.05, min_coverage=4, alt_base_num=3, min_mq=20):
+        """Candidates as an internal product: extract SNV candidates from the pack (STEP 1 of the reference), then run the
+        hot path on them (STEP 2) without leaving HBM.  Returns (site_pos, outputs)."""
+        from .extract_candidates_calling import extract_candidates, candidate_positions
+        flags, _ = extract_candidates(dev_pack, self.min_bq, min_mq, snv_min_af, 1.0, min_coverage, alt_base_num, False)
+        sites = candidate_positions(dev_pack, flags, 1)
+        return sites, self.run_device(dev_pack, sites)
+
     def run_chunk(self, arrays, site_pos):
         dp = self.upload(arrays)
         sp = torch.as_tensor(np.ascontiguousarray(site_pos, dtype=np.int32)).to(self.device)

@@ -47,6 +47,8 @@ def main():
     res["featurize_ms"] = timeit(lambda: featurize(dp, sp, 20, 50), a.reps)
     res["aff_ms"] = timeit(lambda: check(lib.cto_model_forward(eng.h_aff, feat.x_aff.data_ptr(), B, la.data_ptr(), s)), a.reps)
     res["neg_ms"] = timeit(lambda: check(lib.cto_model_forward(eng.h_neg, feat.x_neg.data_ptr(), B, ln.data_ptr(), s)), a.reps)
+    from clairs_to_amd.extract_candidates_calling import extract_candidates
+    res["extract_ms"] = timeit(lambda: extract_candidates(dp, 20), a.reps)
     res["post_ms"] = timeit(lambda: eng.posterior(la, ln), a.reps)
     res["all_ms"] = timeit(lambda: eng.run_device(dp, sp), a.reps)
     torch.cuda.synchronize()
