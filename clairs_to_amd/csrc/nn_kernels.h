@@ -25,7 +25,19 @@ __device__ __forceinline__ float selu_f(float x) {
     const float alpha = 1.6732632423543772848170429916717f;
     return x > 0.f ? scale * x : scale * alpha * expm1f(x);
 }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU (nn.GELU() default).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 round-off class):
+// libm's erff costs ~45 VALU per call and the FFN epilogues evaluate it 160 times per lane per transformer block.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float r = 1.0f - p * t * __expf(-ax * ax);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SELU = 2 };
@@ -359,8 +371,10 @@ __global__ __launch_bounds__(256) void k_fc3(const float* __restrict__ u, const 
 // 192-column slice of fc1.weight - and written as one partial [B][128] slab per direction, so the
 // [B][33][384] layer output never goes to HBM.
 // --------------------------------------------------------------------------------------------
-__device__ __forceinline__ float fast_sigmoid(float x) { return __fdividef(1.0f, 1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - __fdividef(2.0f, 1.0f + __expf(2.0f * x)); }
+// v_exp_f32 / v_rcp_f32 (1 ulp each): `__fdividef` expands to the full IEEE division sequence (div_scale, fma chain,
+// div_fmas, div_fixup: ~10 VALU) - three of those per state element were 40 % of the kernel's non-MFMA instructions.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 // MS = 16-row sub-tiles per wave, MH = wave groups along M: the block has 4*MH waves and owns MH*MS*16 sites.
 // With MH = 2 every SIMD hosts two waves of the same workgroup, so one wave's gate arithmetic / barrier wait
