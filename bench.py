@@ -28,7 +28,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32
 
 def pmc_traffic(batch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
-    profiles/round1_b_pmc_hbm_traffic.json, collected at batch 4096); None for any other batch."""
+    profiles/round1_d_pmc_hbm_traffic.json, collected at batch 4096); None for any other batch."""
     fn = os.path.join(ROOT, "profiles", "round1_b_pmc_hbm_traffic.json")
     if batch != 4096 or not os.path.exists(fn):
         return None
@@ -187,7 +187,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "k_gru_layer<256,256,192,2,1,true> (BiGRU layer 2 + fused fc1, both directions)",
                          "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(args.batch),
-                         "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/round1_b_pmc_hbm_traffic.json)",
+                         "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/round1_d_pmc_hbm_traffic.json)",
                          "launch_ms": round(mean_ms.value, 4), "launches_measured": int(n_meas),
                          "flops_per_launch": flops_per_launch},
             "end_to_end_tflops": round(2.0 * eng.macs_per_site * sites_total / dt / 1e12, 3),
