@@ -8,6 +8,8 @@
 // Written from the behaviour, not from the text, of those lines.
 #include <algorithm>
 #include <cstring>
+#include <memory>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -71,12 +73,22 @@ struct Tok {
 constexpr int kMaxDepth = 32767;
 constexpr int kMaxKeysPerCol = 2048;
 
+void set_err(std::string* err, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    *err = buf;
+}
+
 }  // namespace
 
-extern "C" int cto_pack_from_mpileup(const char* text, size_t len, const char* ref_seq, int64_t ref_start,
-                                      size_t ref_len, int max_indel_length, cto_pack** out) {
-    CTO_REQUIRE(text && ref_seq && out, CTO_EINVAL, "cto_pack_from_mpileup: null argument");
-    auto* p = new cto_pack();
+namespace {
+
+// Parses the rows in [text, text + len) into `p` (offsets local to p).  Thread-safe: no shared state.
+int parse_rows(const char* text, size_t len, const char* ref_seq, int64_t ref_start, size_t ref_len, int max_indel_length,
+               cto_pack* p, std::string* err) {
     p->col_off.push_back(0);
     p->key_off.push_back(0);
     p->key_str_off.push_back(0);
@@ -99,22 +111,20 @@ extern "C" int cto_pack_from_mpileup(const char* text, size_t len, const char* r
             for (const char* q = cur; q < row_end && nf < 8; ++q)
                 if (*q == '\t') f[nf++] = q + 1;
             if (nf < 7) {
-                delete p;
-                cto::set_error("mpileup row has %d fields, need >= 7 (is --output-MQ on?)", nf);
+                set_err(err, "mpileup row has %d fields, need >= 7 (is --output-MQ on?)", nf);
                 return CTO_EINVAL;
             }
             auto fend = [&](int i) { return (i + 1 < nf) ? f[i + 1] - 1 : row_end; };
             int64_t pos = 0;
             for (const char* q = f[1]; q < fend(1); ++q) {
-                if (*q < '0' || *q > '9') { delete p; cto::set_error("bad position field"); return CTO_EINVAL; }
+                if (*q < '0' || *q > '9') { set_err(err, "bad position field"); return CTO_EINVAL; }
                 pos = pos * 10 + (*q - '0');
             }
-            if (pos <= last_pos) { delete p; cto::set_error("mpileup rows not in increasing position order"); return CTO_EINVAL; }
+            if (pos <= last_pos) { set_err(err, "mpileup rows not in increasing position order"); return CTO_EINVAL; }
             last_pos = pos;
             int64_t ri = pos - ref_start;
             if (ri < 0 || size_t(ri) >= ref_len) {
-                delete p;
-                cto::set_error("position %lld outside the supplied reference [%lld, %lld)", (long long)pos,
+                set_err(err, "position %lld outside the supplied reference [%lld, %lld)", (long long)pos,
                                (long long)ref_start, (long long)(ref_start + int64_t(ref_len)));
                 return CTO_EINVAL;
             }
@@ -132,7 +142,7 @@ extern "C" int cto_pack_from_mpileup(const char* text, size_t len, const char* r
                     ++q;
                     int adv = 0;
                     while (q < be && *q >= '0' && *q <= '9') { adv = adv * 10 + (*q - '0'); ++q; }
-                    if (toks.empty()) { delete p; cto::set_error("indel token before any base at pos %lld", (long long)pos); return CTO_EINVAL; }
+                    if (toks.empty()) { set_err(err, "indel token before any base at pos %lld", (long long)pos); return CTO_EINVAL; }
                     int avail = int(std::min<int64_t>(adv, be - q));
                     toks.back().kind = (c == '+') ? 1 : 2;
                     toks.back().seq = q;
@@ -151,7 +161,7 @@ extern "C" int cto_pack_from_mpileup(const char* text, size_t len, const char* r
             // zip(base_list, mapping_quality) / zip(base_list, base_quality) truncate: entries without a
             // quality character contribute to no counter; they are dropped here (only malformed rows).
             int n = int(std::min<size_t>(toks.size(), size_t(std::min(nq, nm))));
-            if (n > kMaxDepth) { delete p; cto::set_error("column depth %d > %d unsupported", n, kMaxDepth); return CTO_EUNSUPPORTED; }
+            if (n > kMaxDepth) { set_err(err, "column depth %d > %d unsupported", n, kMaxDepth); return CTO_EUNSUPPORTED; }
             keymap.clear();
             groupmap.clear();
             int nkeys_col = 0;
@@ -173,7 +183,7 @@ extern "C" int cto_pack_from_mpileup(const char* text, size_t len, const char* r
                         keybuf.append(t.seq, size_t(t.seqlen));
                         auto it = keymap.find(keybuf);
                         if (it == keymap.end()) {
-                            if (nkeys_col >= kMaxKeysPerCol) { delete p; cto::set_error("more than %d distinct indel keys in one column", kMaxKeysPerCol); return CTO_EUNSUPPORTED; }
+                            if (nkeys_col >= kMaxKeysPerCol) { set_err(err, "more than %d distinct indel keys in one column", kMaxKeysPerCol); return CTO_EUNSUPPORTED; }
                             kid = uint32_t(nkeys_col++);
                             keymap.emplace(keybuf, int(kid));
                             const bool fwd = (t.code < 4) || t.code == 8 || t.code == 10;
@@ -224,7 +234,63 @@ extern "C" int cto_pack_from_mpileup(const char* text, size_t len, const char* r
         }
         cur = eol + 1;
     }
-    *out = p;
+    return CTO_OK;
+}
+
+}  // namespace
+
+extern "C" int cto_pack_from_mpileup(const char* text, size_t len, const char* ref_seq, int64_t ref_start,
+                                      size_t ref_len, int max_indel_length, cto_pack** out) {
+    CTO_REQUIRE(text && ref_seq && out, CTO_EINVAL, "cto_pack_from_mpileup: null argument");
+    // rows are independent: split the text at line boundaries and tokenise the pieces on several host threads
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = std::max(1u, std::min(nt, 16u));
+    if (len < (size_t(1) << 22)) nt = 1;
+    std::vector<size_t> cut(nt + 1, len);
+    cut[0] = 0;
+    for (unsigned t = 1; t < nt; ++t) {
+        size_t pos = len / nt * t;
+        const char* nl = static_cast<const char*>(memchr(text + pos, '\n', len - pos));
+        cut[t] = nl ? size_t(nl - text) + 1 : len;
+    }
+    std::vector<std::unique_ptr<cto_pack>> parts(nt);
+    std::vector<int> rcs(nt, CTO_OK);
+    std::vector<std::string> errs(nt);
+    auto work = [&](unsigned t) {
+        parts[t].reset(new cto_pack());
+        rcs[t] = parse_rows(text + cut[t], cut[t + 1] - cut[t], ref_seq, ref_start, ref_len, max_indel_length, parts[t].get(), &errs[t]);
+    };
+    if (nt == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, t);
+        for (auto& x : th) x.join();
+    }
+    for (unsigned t = 0; t < nt; ++t)
+        if (rcs[t] != CTO_OK) { cto::set_error("%s", errs[t].c_str()); return rcs[t]; }
+    std::unique_ptr<cto_pack> p(parts[0].release());
+    for (unsigned t = 1; t < nt; ++t) {
+        const cto_pack& q = *parts[t];
+        if (q.col_pos.empty()) continue;
+        if (!p->col_pos.empty() && q.col_pos.front() <= p->col_pos.back()) {
+            cto::set_error("mpileup rows not in increasing position order");
+            return CTO_EINVAL;
+        }
+        const int64_t e0 = p->col_off.back(), s0 = p->key_str_off.back();
+        const int32_t k0 = p->key_off.back();
+        p->col_pos.insert(p->col_pos.end(), q.col_pos.begin(), q.col_pos.end());
+        p->col_ref.insert(p->col_ref.end(), q.col_ref.begin(), q.col_ref.end());
+        for (size_t i = 1; i < q.col_off.size(); ++i) p->col_off.push_back(q.col_off[i] + e0);
+        for (size_t i = 1; i < q.key_off.size(); ++i) p->key_off.push_back(q.key_off[i] + k0);
+        p->entries.insert(p->entries.end(), q.entries.begin(), q.entries.end());
+        p->key_meta.insert(p->key_meta.end(), q.key_meta.begin(), q.key_meta.end());
+        p->key_group.insert(p->key_group.end(), q.key_group.begin(), q.key_group.end());
+        for (size_t i = 1; i < q.key_str_off.size(); ++i) p->key_str_off.push_back(q.key_str_off[i] + s0);
+        p->key_str += q.key_str;
+        parts[t].reset();
+    }
+    *out = p.release();
     return CTO_OK;
 }
 
