@@ -239,3 +239,64 @@ def test_extract_candidates_match_reference_and_oracle(dev, oracle_lib):
         mask[cols] = False
         assert not got_f[mask].any()
         assert (fl & 1).sum() > 0
+
+
+def test_full_chunk_properties(dev):
+    """Size-independent properties at the bench's full chunk size (4096 sites, ~6.5 M read-bases):
+    (1) batch invariance - a site's outputs do not depend on which other sites share its launch (bit-exact),
+    (2) the NEG pass sees a superset of the AFF pass's read-bases, so |NEG count| >= |AFF count| everywhere,
+    (3) min_bq = 0 makes the two passes identical (the Illumina `ln -sf` of run_clairs_to:1248-1252),
+    (4) the epilogue entered at the text seam with its own 8-decimal probabilities reproduces itself."""
+    import torch
+    from clairs_to_amd.engine import Engine, synthetic_models
+    from clairs_to_amd.featurize import featurize
+    from clairs_to_amd.synth import SynthChunk, likelihood_table, lik_and_edges
+    ch = SynthChunk(4096, seed=20260928)
+    models = synthetic_models(4)
+    lik, edges = lik_and_edges(likelihood_table(4), 4)
+    eng = Engine(models["aff"], models["neg"], lik, edges, min_bq=20, device=dev)
+    dp = eng.upload(ch.arrays())
+    sp = torch.from_numpy(ch.site_pos).to(dev)
+    full = eng.run_device(dp, sp, want_raw=True)
+    torch.cuda.synchronize()
+    # (1) odd-sized sub-batches
+    cuts = [0, 1, 34, 1000, 2049, 4096]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        part = eng.run_device(dp, sp[a:b])
+        for k in ("aff_logits", "neg_logits"):
+            assert torch.equal(part[k], full[k][:, a:b]), (k, a, b)
+        for k in ("probs", "post", "decision", "qual"):
+            assert torch.equal(part[k], full[k][a:b]), (k, a, b)
+    # (2)
+    f = full["features"]
+    assert bool((f.raw_neg.abs() >= f.raw_aff.abs()).all())
+    info = f.site_info
+    assert bool((info[:, 2] >= info[:, 1]).all()) and int(info[:, 3].sum()) == 0
+    # (3)
+    f0 = featurize(dp, sp, 0, 50, want_raw=True)
+    assert torch.equal(f0.raw_aff, f0.raw_neg) and torch.equal(f0.x_aff, f0.x_neg)
+    assert torch.equal(f0.raw_neg, f.raw_neg)
+    # (4)
+    p8 = np.round(full["probs"][:, :, 1].cpu().numpy().astype(np.float64) * 1e8) / 1e8    # IEEE division on the host
+    again = eng.posterior.from_probs(torch.from_numpy(np.ascontiguousarray(p8)).to(dev))
+    assert torch.equal(again["post"], full["post"]) and torch.equal(again["decision"], full["decision"])
+    assert torch.equal(again["qual"], full["qual"])
+
+
+def test_c_abi_error_codes(dev):
+    """the C ABI reports errors by code + message, never by crashing"""
+    import ctypes as C
+    import torch
+    from clairs_to_amd._lib import lib, CvtCfg, c_vp
+    w = c_vp(lib.cto_weights_new())
+    out = c_vp()
+    assert lib.cto_bigru_create(w, 4, C.byref(out)) == -5 and b"missing" in lib.cto_last_error()       # CTO_EMISSING
+    assert lib.cto_bigru_create(w, 5, C.byref(out)) == -1                                                # CTO_EINVAL
+    cfg = CvtCfg()
+    cfg.emb_dim[:] = [16, 64, 256]
+    cfg.heads[:] = [1, 3, 4]
+    cfg.depth[:] = [1, 2, 3]
+    cfg.n_out = 4
+    assert lib.cto_cvt_create(w, C.byref(cfg), C.byref(out)) == -4                                       # CTO_EUNSUPPORTED
+    lib.cto_weights_free(w)
+    assert lib.cto_posterior(None, None, 4, 1, None, None, None, None, None, None, None) == -1
