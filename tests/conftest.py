@@ -15,6 +15,12 @@ for p in (ROOT, GOLDEN):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the built libraries are git-ignored: a fresh checkout builds them before the first test imports the package
+    import subprocess
+    if not os.path.exists(os.path.join(ROOT, "clairs_to_amd", "libclairsto_amd.so")):
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "clairs_to_amd", "csrc")])
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
 
 
 def load_json_gz(name):
