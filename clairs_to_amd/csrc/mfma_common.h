@@ -1,0 +1,44 @@
+// MFMA / activation primitives shared by the network kernels (gfx950 / CDNA4).
+//
+// All dense contractions run on the exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32: fp32 in, fp32
+// accumulate, bit-equal to an fmaf chain), because the parity bar is 1e-4 on probabilities and bf16/fp16
+// inputs miss it.  Wave = 64 lanes; one MFMA computes a 16x16 tile over k = 4:
+//     lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15],
+//     lane l receives  D[row = 4 * (l >> 4) + r][col = l & 15] in register r = 0..3.
+// Every weight matrix is consumed in PyTorch's native Linear layout W[n][k] (k contiguous), so
+// C[m][n] = sum_k A[m][k] * W[n][k] needs no transposition: lane l reads W[n0 + (l & 15)][k0 + (l >> 4)].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cto {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ---- activations (clairs/model.py: nn.SELU, nn.GELU() exact-erf form) ----
+__device__ __forceinline__ float selu_f(float x) {
+    const float scale = 1.0507009873554804934193349852946f;
+    const float alpha = 1.6732632423543772848170429916717f;
+    return x > 0.f ? scale * x : scale * alpha * expm1f(x);
+}
+// exact-erf GELU (nn.GELU() default).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 round-off class):
+// libm's erff costs ~45 VALU per call and the FFN epilogues evaluate it 160 times per lane per transformer block.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float r = 1.0f - p * t * __expf(-ax * ax);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+
+}  // namespace cto
