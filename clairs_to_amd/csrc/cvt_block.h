@@ -27,6 +27,7 @@ namespace cto {
 
 struct CvtBlockParams {
     const float *n0g, *n0b, *dwq, *bnq, *wq, *dwkv, *bnkv, *wkv, *wo, *bo, *n1g, *n1b, *w1, *b1, *w2, *b2;
+    long long* prof;   // debug: phase time stamps (s_memtime) of workgroup 0 / thread 0 when non-null (CTO_BLOCK_PROF=1)
 };
 
 // The first two 16-wide k chunks of a GEMM's weights, requested early (before the barriers / VALU phases that
@@ -139,6 +140,9 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
     const int rows_valid = nsite * W;
     const int inner = heads * 64;
     float* hg = h + int64_t(site0) * W * C;
+    int nstamp = 0;
+    auto stamp = [&]() { if (p.prof && blockIdx.x == 0 && tid == 0) p.prof[nstamp++] = clock64(); };
+    stamp();
 
     // GEMM over this wave's M half; accumulators are sized for the larger half
     auto gemm_r = [&](auto ntw_tag, auto kch_tag, const float* A, int lda, const auto& wr, const auto& pre, auto& acc) {
@@ -176,24 +180,40 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
     for (int i = tid; i < (MTKV * 16 - RKV) * RS; i += NT) sykv[RKV * RS + i] = 0.f;
     __syncthreads();
 
-    auto layer_norm = [&](const float* g, const float* b) {   // sh -> sy, one wave per row
-        const float g0 = lane < C ? g[lane] : 0.f, g1 = lane + 64 < C ? g[lane + 64] : 0.f;
-        const float b0 = lane < C ? b[lane] : 0.f, b1 = lane + 64 < C ? b[lane + 64] : 0.f;
-        for (int r = wave; r < MT * 16; r += NWV) {
-            const float* xr = sh + r * RS;
-            const float v0 = lane < C ? xr[lane] : 0.f, v1 = lane + 64 < C ? xr[lane + 64] : 0.f;
-            const float mean = wave_sum(v0 + v1) / float(C);
-            const float d0 = lane < C ? v0 - mean : 0.f, d1 = lane + 64 < C ? v1 - mean : 0.f;
-            const float var = wave_sum(d0 * d0 + d1 * d1) / float(C);
-            const float inv = 1.0f / (sqrtf(var) + 1e-5f);
-            if (lane < C) sy[r * RS + lane] = d0 * inv * g0 + b0;
-            if (lane + 64 < C) sy[r * RS + lane + 64] = d1 * inv * g1 + b1;
+    // Channel LayerNorm sh -> sy.  16 lanes per row (4 rows per wave at a time), each lane owning C/16 contiguous
+    // channels: the row reductions are 4 DPP steps inside a 16-lane row instead of 6 cross-lane permutes through the
+    // LDS crossbar - the wave-per-row version spent 12.5 k cycles per LayerNorm (10 % of a stage-3 block).
+    auto layer_norm = [&](const float* g, const float* b) {
+        constexpr int CPL = C / 16;
+        const int l16 = lane & 15, grp = lane >> 4;
+        float gv[CPL], bv[CPL];
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) { gv[i] = g[l16 * CPL + i]; bv[i] = b[l16 * CPL + i]; }
+        for (int r = wave * 4 + grp; r < MT * 16; r += NWV * 4) {
+            const float* xr = sh + r * RS + l16 * CPL;
+            float v[CPL], sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) { v[i] = xr[i]; sum += v[i]; }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+            const float mean = sum / float(C);
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) { v[i] -= mean; sq += v[i] * v[i]; }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 16);
+            const float inv = 1.0f / (sqrtf(sq / float(C)) + 1e-5f);
+            float* yr = sy + r * RS + l16 * CPL;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) yr[i] = v[i] * inv * gv[i] + bv[i];
         }
     };
 
+    stamp();
     // ---- phase 1 ----
     layer_norm(p.n0g, p.n0b);
     __syncthreads();
+    stamp();
 
     // ---- phase 2: depth-wise 3-tap conv + BatchNorm; q path in place, kv path (stride 2) to sykv ----
     {
@@ -224,6 +244,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
     }
     __syncthreads();
 
+    stamp();
     // ---- phase 3: attention, head by head; out-projection accumulates in registers ----
     f32x4 acc_o[MT0][NTC];
 #pragma unroll
@@ -287,6 +308,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
                 }
         }
         __syncthreads();
+        stamp();
         // scores = q k^T / 8 per site (model.py:126; dim_head = 64)
         for (int t = tid; t < TS * W * WKV; t += NT) {
             const int s = t / (W * WKV), rem = t - s * (W * WKV), i = rem / WKV, jj = rem - i * WKV;
@@ -332,8 +354,10 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
             pre_q = prefetch_b<1, C / 16>(wq_r);
         }
         __syncthreads();
+        stamp();
         if (own_c) gemm_r(INTC{}, K4{}, sq, QS, wo_r, pre_o, acc_o);   // acc_o += o_h Wo[:, hh*64 .. +64]^T
         __syncthreads();   // sq / sk / sv are rewritten by the next head
+        stamp();
     }
 
     // first FFN weights are requested before the residual update and the second LayerNorm
@@ -356,9 +380,11 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
     }
     __syncthreads();
 
+    stamp();
     // ---- phase 5 ----
     layer_norm(p.n1g, p.n1b);
     __syncthreads();
+    stamp();
 
     // ---- phase 6: feed-forward, hidden units in chunks of HC ----
     f32x4 acc_f[MT0][NTC];
@@ -397,6 +423,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
         __syncthreads();
         if (own_c) gemm_r(INTC{}, KH{}, su, US, w2_r, pre_w2, acc_f);
         __syncthreads();   // su is rewritten by the next chunk
+        stamp();
     }
 
     // ---- phase 7: h += ff(y) + bias -> HBM ----
@@ -415,6 +442,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
                 }
             }
     }
+    stamp();
 }
 
 }  // namespace cto

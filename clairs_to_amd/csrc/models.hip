@@ -273,9 +273,22 @@ int launch_cvt_block(hipStream_t s, float* h, const BlockDev& b, int heads, int6
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES)));
         attr_set = true;
     }
-    CvtBlockParams p{b.n0g, b.n0b, b.dwq, b.bnq, b.wq, b.dwkv, b.bnkv, b.wkv, b.wo, b.bo, b.n1g, b.n1b, b.w1, b.b1, b.w2, b.b2};
+    static long long* prof_buf = nullptr;
+    static const bool prof_on = [] { const char* e = getenv("CTO_BLOCK_PROF"); return e && e[0] == '1'; }();
+    if (prof_on && !prof_buf) CTO_HIP(hipMalloc(reinterpret_cast<void**>(&prof_buf), 256 * sizeof(long long)));
+    if (prof_on) CTO_HIP(hipMemsetAsync(prof_buf, 0, 256 * sizeof(long long), s));
+    CvtBlockParams p{b.n0g, b.n0b, b.dwq, b.bnq, b.wq, b.dwkv, b.bnkv, b.wkv, b.wo, b.bo, b.n1g, b.n1b, b.w1, b.b1, b.w2, b.b2,
+                     prof_on ? prof_buf : nullptr};
     hipLaunchKernelGGL((k_cvt_block<C, W, WKV, TS>), dim3(unsigned(cdiv(B, TS))), dim3(CVT_BLOCK_THREADS), G::LDS_BYTES, s, h, p, heads, int(B));
     CTO_HIP(hipGetLastError());
+    if (prof_on) {   // debug aid: phase time stamps of workgroup 0 (cycles since the kernel's first stamp)
+        long long hst[256];
+        CTO_HIP(hipStreamSynchronize(s));
+        CTO_HIP(hipMemcpy(hst, prof_buf, sizeof(hst), hipMemcpyDeviceToHost));
+        fprintf(stderr, "k_cvt_block<%d,%d,%d,%d> stamps:", C, W, WKV, TS);
+        for (int i = 1; i < 256 && hst[i]; ++i) fprintf(stderr, " %lld", hst[i] - hst[i - 1]);
+        fprintf(stderr, "\n");
+    }
     return CTO_OK;
 }
 
