@@ -29,7 +29,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32
 def pmc_traffic(batch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
     profiles/round1_d_pmc_hbm_traffic.json, collected at batch 4096); None for any other batch."""
-    fn = os.path.join(ROOT, "profiles", "round1_b_pmc_hbm_traffic.json")
+    fn = os.path.join(ROOT, "profiles", "round1_d_pmc_hbm_traffic.json")
     if batch != 4096 or not os.path.exists(fn):
         return None
     k = json.load(open(fn))["kernels"]

@@ -119,7 +119,7 @@ class Engine:
         sites = candidate_positions(dev_pack, flags, 1)
         return sites, self.run_device(dev_pack, sites)
 
-    def run_chunk(self, arrays, site_pos):
+    def run_chunk(self, arrays, site_pos, want_raw=False):
         dp = self.upload(arrays)
         sp = torch.as_tensor(np.ascontiguousarray(site_pos, dtype=np.int32)).to(self.device)
-        return self.run_device(dp, sp)
+        return self.run_device(dp, sp, want_raw=want_raw)

@@ -15,12 +15,25 @@ import numpy as np
 
 BASE_CHARS = "ACGTacgt*#Nn"
 
+# Generator presets of SURVEY.md 8(d) + the per-platform --min_bq of the AFF pass (shared/param.py:34 min_bq_dict) and
+# the indel candidate threshold (shared/param.py:23, run_clairs_to ONT override 0.1).
+PLATFORMS = {
+    "ont": dict(seed=20260928, min_bq=20, indel_min_af=0.1, generator=dict(depth_mean=50.0)),
+    "ilmn": dict(seed=20260930, min_bq=0, indel_min_af=0.05,
+                 generator=dict(depth_mean=50.0, p_ins=0.0005, p_del=0.0005,
+                                bq_model=("discrete", (11, 25, 37), (0.05, 0.15, 0.80)))),
+    "hifi": dict(seed=20261001, min_bq=0, indel_min_af=0.05,
+                 generator=dict(depth_mean=75.0, p_ins=0.002, p_del=0.002, bq_model=("uniform", 20, 93))),
+}
+
 
 class SynthChunk:
     """One chunk of `n_sites` candidates on a private stretch of the contig."""
 
     def __init__(self, n_sites, seed=20260928, depth_mean=50.0, start=100000, spacing=250, max_indel_length=60,
-                 p_mismatch=0.01, p_star=0.01, p_ins=0.004, p_del=0.006, bq_mean=28.0, bq_sd=8.0, n_rate=0.001):
+                 p_mismatch=0.01, p_star=0.01, p_ins=0.004, p_del=0.006, bq_mean=28.0, bq_sd=8.0, n_rate=0.001,
+                 bq_model=None):
+        """bq_model: None -> round(N(bq_mean, bq_sd)) in [1, 50]; ("discrete", values, probs); ("uniform", lo, hi)."""
         rng = np.random.default_rng(seed)
         self.max_indel_length = max_indel_length
         # candidate positions: sorted, mean distance `spacing`, minimum distance 1 (windows may overlap)
@@ -63,7 +76,15 @@ class SynthChunk:
         self._okind = kind.astype(np.uint8)               # indel kind before the over-long gate (text writer)
         gate = np.where(kind == 1, ilen, ilen + 1)
         kind = np.where((kind > 0) & (gate > max_indel_length), 3, kind).astype(np.uint32)
-        bq = np.clip(np.rint(rng.normal(bq_mean, bq_sd, size=n_ent)), 1, 50).astype(np.uint32)
+        if bq_model is None:
+            bq = np.clip(np.rint(rng.normal(bq_mean, bq_sd, size=n_ent)), 1, 50).astype(np.uint32)
+        elif bq_model[0] == "discrete":
+            bq = rng.choice(np.asarray(bq_model[1]), size=n_ent, p=np.asarray(bq_model[2])).astype(np.uint32)
+        elif bq_model[0] == "uniform":
+            bq = rng.integers(int(bq_model[1]), int(bq_model[2]) + 1, size=n_ent).astype(np.uint32)
+        else:
+            raise ValueError("unknown bq_model %r" % (bq_model,))
+        assert bq.max(initial=0) < 128
         mq = np.where(rng.random(n_ent) < 0.93, 60, rng.integers(0, 60, size=n_ent)).astype(np.uint32)
         # ---- distinct indel keys per column, ids in first-seen order ----
         # (over-long indels keep a key: tensor creation ignores them, candidate extraction does not)
@@ -108,6 +129,13 @@ class SynthChunk:
         self._ilen = ilen.astype(np.int32)
         self._ivar = ivar.astype(np.int32)
         self.n_sites = n_sites
+
+    @classmethod
+    def for_platform(cls, platform, n_sites, seed=None, **kw):
+        """The generator presets of SURVEY.md 8(d): 'ont' (config 2/3), 'ilmn' (config 4), 'hifi' (config 5)."""
+        cfg = dict(PLATFORMS[platform]["generator"])
+        cfg.update(kw)
+        return cls(n_sites, seed=PLATFORMS[platform]["seed"] if seed is None else seed, **cfg)
 
     # ---- numpy views in the cto_pack_view layout ----
     def arrays(self):

@@ -283,6 +283,48 @@ def test_full_chunk_properties(dev):
     assert torch.equal(again["qual"], full["qual"])
 
 
+@pytest.mark.parametrize("platform", ["ont", "ilmn", "hifi"])
+@pytest.mark.parametrize("K", [4, 6])
+def test_platform_configs_end_to_end(dev, oracle_lib, platform, K):
+    """BASELINE.json configs 2/4/5 as parity cases (SURVEY.md 8d generator presets): ONT 50x (min_bq 20), Illumina 50x
+    (min_bq 0: NEG tensor == AFF tensor, three-valued BQ) and HiFi 75x (most sites rescaled by 50/depth, BQ up to 93), each with
+    the SNV (K=4) and the indel (K=6) model pair: whole engine vs the oracle run on the equivalent mpileup text of each pass."""
+    import torch
+    import oracle
+    from clairs_to_amd.engine import Engine, synthetic_models
+    from clairs_to_amd.synth import SynthChunk, PLATFORMS, mpileup_text, likelihood_table, lik_and_edges
+    min_bq = PLATFORMS[platform]["min_bq"]
+    chunk = SynthChunk.for_platform(platform, 160, spacing=60)
+    models = synthetic_models(K)
+    lik, edges = lik_and_edges(likelihood_table(K), K)
+    eng = Engine(models["aff"], models["neg"], lik, edges, min_bq=min_bq, device=dev)
+    res = eng.run_chunk(chunk.arrays(), chunk.site_pos, want_raw=True)
+    torch.cuda.synchronize()
+    ref, lo = chunk.ref_window()
+    ta, da, _, _ = oracle.create_tensor(mpileup_text(chunk, min_bq), ref, lo, chunk.site_pos)
+    tn, dn, _, _ = oracle.create_tensor(mpileup_text(chunk, 0), ref, lo, chunk.site_pos)
+    f = res["features"]
+    np.testing.assert_array_equal(f.raw_aff.cpu().numpy().astype(np.int32).reshape(ta.shape), ta)
+    np.testing.assert_array_equal(f.raw_neg.cpu().numpy().astype(np.int32).reshape(tn.shape), tn)
+    info = f.site_info.cpu().numpy()
+    assert info[:, 1].tolist() == da.tolist() and info[:, 2].tolist() == dn.tolist()
+    if platform == "hifi":
+        assert (da > 50).mean() > 0.9                     # the rescale branch is the common case here
+    xa, xn = oracle.rescale(ta, da), oracle.rescale(tn, dn)
+    np.testing.assert_array_equal(f.x_aff.cpu().numpy().reshape(xa.shape), xa)
+    np.testing.assert_array_equal(f.x_neg.cpu().numpy().reshape(xn.shape), xn)
+    la = oracle.cvt_forward(models["aff_weights"], dict(CVT_CFG, n_out=K), xa)
+    ln = oracle.bigru_forward(models["neg_weights"], K, xn)
+    probs, post, dec, qual = oracle.posterior(la, ln, lik, edges)
+    assert np.abs(res["probs"].cpu().numpy() - probs).max() < 1e-4          # north_star tolerance
+    # the epilogue itself is exact: the oracle fed with the device's own 8-decimal probabilities reproduces it bit for bit
+    p8 = np.round(res["probs"][:, :, 1].cpu().numpy().astype(np.float64) * 1e8) / 1e8
+    post2, dec2, qual2 = oracle.posterior_from_probs(p8, lik, edges)
+    np.testing.assert_array_equal(res["post"].cpu().numpy(), post2)
+    np.testing.assert_array_equal(res["decision"].cpu().numpy(), dec2)
+    np.testing.assert_array_equal(res["qual"].cpu().numpy(), qual2)
+
+
 def test_c_abi_error_codes(dev):
     """the C ABI reports errors by code + message, never by crashing"""
     import ctypes as C

@@ -11,7 +11,7 @@ import torch  # noqa: E402
 from clairs_to_amd._lib import lib, check  # noqa: E402
 from clairs_to_amd.engine import Engine, synthetic_models  # noqa: E402
 from clairs_to_amd.featurize import featurize  # noqa: E402
-from clairs_to_amd.synth import SynthChunk, likelihood_table, lik_and_edges  # noqa: E402
+from clairs_to_amd.synth import SynthChunk, PLATFORMS, likelihood_table, lik_and_edges  # noqa: E402
 
 
 def timeit(fn, reps):
@@ -29,13 +29,14 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--n-out", type=int, default=4)
+    ap.add_argument("--platform", default="ont", choices=["ont", "ilmn", "hifi"], help="generator preset (SURVEY 8d)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     K = a.n_out
     models = synthetic_models(K)
     lik, edges = lik_and_edges(likelihood_table(K), K)
-    eng = Engine(models["aff"], models["neg"], lik, edges, device=dev)
-    ch = SynthChunk(a.batch, seed=1)
+    eng = Engine(models["aff"], models["neg"], lik, edges, min_bq=PLATFORMS[a.platform]["min_bq"], device=dev)
+    ch = SynthChunk.for_platform(a.platform, a.batch, seed=1)
     dp = eng.upload(ch.arrays())
     sp = torch.from_numpy(ch.site_pos).to(dev)
     feat = featurize(dp, sp, 20, 50)
@@ -57,7 +58,7 @@ def main():
         eng.run_device(dp, sp)
     res["all_host_issue_ms"] = (time.perf_counter() - t0) / a.reps * 1e3
     torch.cuda.synchronize()
-    eng1 = Engine(models["aff"], models["neg"], lik, edges, device=dev, two_streams=False)
+    eng1 = Engine(models["aff"], models["neg"], lik, edges, min_bq=PLATFORMS[a.platform]["min_bq"], device=dev, two_streams=False)
     res["all_1stream_ms"] = timeit(lambda: eng1.run_device(dp, sp), a.reps)
     gf_aff = 2e-9 * lib.cto_model_macs_per_site(eng.h_aff) * B
     gf_neg = 2e-9 * lib.cto_model_macs_per_site(eng.h_neg) * B
