@@ -89,6 +89,84 @@ __device__ __forceinline__ void gemm_lds(const float* __restrict__ A, int lda, c
     }
 }
 
+// ---- classifier tail shared by both networks (clairs/model.py:245-261, 451-467): K heads of fc2 (128 -> 128) -> SELU ->
+// fc3 (128 -> 2) -> SELU on a 16-site tile whose SELU(fc1) activations sit in LDS.  8 waves; wave w owns hidden units
+// [16w, 16w+16) of every head, two heads per pass (two independent accumulators keep the matrix pipe at issue rate).
+struct HeadTailParams {
+    const float *w2, *b2;   // [K*128][128], [K*128]
+    const float *w3, *b3;   // [K][2][128], [K][2]
+    float* logits;          // [K][B][2]
+    int K;
+};
+constexpr int HEAD_T1S = 132;                       // LDS row stride of the fc1 activations [16][128]
+__host__ __device__ constexpr int head_t2s(int K) { return K * 128 + 4; }
+__host__ __device__ constexpr int head_lds_floats(int K) { return 16 * HEAD_T1S + 16 * head_t2s(K); }
+
+// t1: [16][HEAD_T1S] (in), t2: [16][head_t2s(K)] scratch.  All 512 threads call; ends without a barrier.
+__device__ __forceinline__ void head_tail(const float* t1, float* t2, const HeadTailParams& hp, int64_t B, int64_t site0,
+                                          int nsite) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
+    const int K = hp.K, T2S = head_t2s(K);
+    for (int h0 = 0; h0 < K; h0 += 2) {
+        const float* wr[2];
+        wr[0] = hp.w2 + int64_t(h0 * 128 + wave * 16 + j) * 128 + 4 * kg;
+        wr[1] = wr[0] + 128 * 128;
+        const BPre<2> pre = prefetch_b<2, 8>(wr);
+        f32x4 acc[1][2] = {{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}};
+        gemm_lds<1, 2, 8>(t1, HEAD_T1S, wr, pre, acc, j, kg);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int col = (h0 + q) * 128 + wave * 16 + j;
+            const float bv = hp.b2[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t2[(4 * kg + r) * T2S + col] = selu_f(acc[0][q][r] + bv);
+        }
+    }
+    __syncthreads();
+    // fc3: 16 sites x K heads x 2 outputs, four lanes per dot product of length 128
+    const int part = tid & 3;
+    for (int idx = tid >> 2; idx < 16 * K * 2; idx += blockDim.x >> 2) {
+        const int site = idx / (2 * K), rem = idx - site * 2 * K, hh = rem >> 1, o = rem & 1;
+        const float4* u = reinterpret_cast<const float4*>(t2 + site * T2S + hh * 128 + part * 32);
+        const float4* w = reinterpret_cast<const float4*>(hp.w3 + (hh * 2 + o) * 128 + part * 32);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 a = u[i], b = w[i];
+            sum = fmaf(a.x, b.x, sum); sum = fmaf(a.y, b.y, sum); sum = fmaf(a.z, b.z, sum); sum = fmaf(a.w, b.w, sum);
+        }
+        sum += __shfl_xor(sum, 1, 4);
+        sum += __shfl_xor(sum, 2, 4);
+        if (part == 0 && site < nsite) hp.logits[(int64_t(hh) * B + site0 + site) * 2 + o] = selu_f(sum + hp.b3[hh * 2 + o]);
+    }
+}
+
+// Stand-alone classifier tail for fc1 partial sums that already sit in HBM (BiGRU: one slab per direction from the fused
+// layer-2 kernel; unfused CvT path: split-K slabs): t1 = SELU(sum_z slab_z + b1), then head_tail.
+__global__ __launch_bounds__(512) void k_head(const float* __restrict__ slabs, int S, int64_t slab_stride,
+                                              const float* __restrict__ b1, HeadTailParams hp, int64_t B) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* t1 = smem;
+    float* t2 = smem + 16 * HEAD_T1S;
+    const int64_t site0 = int64_t(blockIdx.x) * 16;
+    const int nsite = int(min(int64_t(16), B - site0));
+    {
+        const int site = threadIdx.x >> 5, c4 = (threadIdx.x & 31) * 4;     // 512 threads = 16 sites x 32 float4
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (site < nsite) {
+            for (int z = 0; z < S; ++z) {
+                const float4 a = *reinterpret_cast<const float4*>(slabs + z * slab_stride + (site0 + site) * 128 + c4);
+                v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+            }
+        }
+        const float4 bb = *reinterpret_cast<const float4*>(b1 + c4);
+        *reinterpret_cast<float4*>(t1 + site * HEAD_T1S + c4) =
+            make_float4(selu_f(v.x + bb.x), selu_f(v.y + bb.y), selu_f(v.z + bb.z), selu_f(v.w + bb.w));
+    }
+    __syncthreads();
+    head_tail(t1, t2, hp, B, site0, nsite);
+}
+
 template <int C, int W, int WKV, int TS>
 struct CvtBlockGeom {
     static constexpr int R = TS * W, RKV = TS * WKV;

@@ -233,34 +233,33 @@ int ensure_ws(cto_model* m, int64_t B) {
 }
 
 // fc1 (split-K when the reduction is long) -> SELU -> fc2 heads -> SELU -> fc3 -> SELU
-int run_head(cto_model* m, hipStream_t s, const float* feat, int64_t B, float* logits) {
+int launch_head(cto_model* m, hipStream_t s, const float* slabs, int S, int64_t B, float* logits) {
     const HeadDev& h = m->head;
     const int K = m->n_out;
-    int rc;
-    if (feat == nullptr) {
-        // BiGRU: fc1 was accumulated inside the layer-2 recurrent kernel, one slab per direction
-        const int S = 2;
-        const int64_t total = B * 128;
-        hipLaunchKernelGGL(k_sum_bias_selu, dim3(unsigned(cdiv(total, 256))), dim3(256), 0, s, m->b_slab, S, B * 128,
-                           h.b1, m->b_g, total, 128);
-        CTO_HIP(hipGetLastError());
-    } else {
-        // CvT: fc1 has M = B rows and only N = 128 columns; split K four ways so that the launch fills the chip
-        const int S = 4;
-        if ((rc = launch_gemm(s, feat, h.k1, h.w1, h.k1, nullptr, nullptr, 0, m->b_slab, 128, int(B), 128, h.k1, ACT_NONE,
-                              0, 0, 0, S, B * 128)))
-            return rc;
-        const int64_t total = B * 128;
-        hipLaunchKernelGGL(k_sum_bias_selu, dim3(unsigned(cdiv(total, 256))), dim3(256), 0, s, m->b_slab, S, B * 128,
-                           h.b1, m->b_g, total, 128);
-        CTO_HIP(hipGetLastError());
+    const size_t smem = size_t(head_lds_floats(K)) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    int(head_lds_floats(6) * sizeof(float))));
+        attr_set = true;
     }
-    if ((rc = launch_gemm(s, m->b_g, 128, h.w2, 128, h.b2, nullptr, 0, m->b_u2, int64_t(K) * 128, int(B), K * 128, 128,
-                          ACT_SELU)))
-        return rc;
-    hipLaunchKernelGGL(k_fc3, dim3(unsigned(cdiv(B, 4))), dim3(256), 0, s, m->b_u2, h.w3, h.b3, logits, B, K);
+    HeadTailParams hp{h.w2, h.b2, h.w3, h.b3, logits, K};
+    hipLaunchKernelGGL(k_head, dim3(unsigned(cdiv(B, 16))), dim3(512), smem, s, slabs, S, B * 128, h.b1, hp, B);
     CTO_HIP(hipGetLastError());
     return CTO_OK;
+}
+
+int run_head(cto_model* m, hipStream_t s, const float* feat, int64_t B, float* logits) {
+    const HeadDev& h = m->head;
+    int rc;
+    if (feat == nullptr)   // BiGRU: fc1 was accumulated inside the layer-2 recurrent kernel, one slab per direction
+        return launch_head(m, s, m->b_slab, 2, B, logits);
+    // CvT (unfused tail): fc1 has M = B rows and only N = 128 columns; split K four ways so that the launch fills the chip
+    const int S = 4;
+    if ((rc = launch_gemm(s, feat, h.k1, h.w1, h.k1, nullptr, nullptr, 0, m->b_slab, 128, int(B), 128, h.k1, ACT_NONE,
+                          0, 0, 0, S, B * 128)))
+        return rc;
+    return launch_head(m, s, m->b_slab, S, B, logits);
 }
 
 template <int C, int W, int WKV, int TS>
