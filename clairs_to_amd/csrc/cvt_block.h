@@ -28,6 +28,10 @@ namespace cto {
 struct CvtBlockParams {
     const float *n0g, *n0b, *dwq, *bnq, *wq, *dwkv, *bnkv, *wkv, *wo, *bo, *n1g, *n1b, *w1, *b1, *w2, *b2;
     long long* prof;   // debug: phase time stamps (s_memtime) of workgroup 0 / thread 0 when non-null (CTO_BLOCK_PROF=1)
+    // first block of a stage (CIN > 0): the stage's conv embedding + LayerNorm run here instead of reading h
+    const float *xin, *wembp, *bemb, *lng, *lnb;   // x [B][2W-1][CIN]; wembp [C][KCHE*16] (positions padded to PS)
+    // last block of the network (HEAD): fc1 + classifier tail run here instead of writing h
+    const float *w1p, *b1h;                        // fc1 [128][KCH1*16] over the LDS image of h (rows padded to RS)
 };
 
 // The first two 16-wide k chunks of a GEMM's weights, requested early (before the barriers / VALU phases that
@@ -167,6 +171,11 @@ __global__ __launch_bounds__(512) void k_head(const float* __restrict__ slabs, i
     head_tail(t1, t2, hp, B, site0, nsite);
 }
 
+// LDS position stride of the stage input [site][2W][PS] for the in-block conv embedding: >= CIN, multiple of 4 (float4
+// A fragments) and = 4 mod 16, so that the im2col row stride 2*PS is = 8 mod 32 banks (4-way instead of 16-way conflicts).
+__host__ __device__ constexpr int emb_ps(int cin) { return cin > 0 ? ((cin - 4 + 15) / 16) * 16 + 4 : 0; }
+__host__ __device__ constexpr int emb_kch(int cin) { return (3 * emb_ps(cin) + 15) / 16; }
+
 template <int C, int W, int WKV, int TS>
 struct CvtBlockGeom {
     static constexpr int R = TS * W, RKV = TS * WKV;
@@ -183,15 +192,21 @@ struct CvtBlockGeom {
     static constexpr int U_FLOATS = MT * 16 * US;
     static constexpr int TOTAL = OFF_P + TS * W * WKV + (U_FLOATS > SCRATCH ? U_FLOATS - SCRATCH : 0);
     static constexpr size_t LDS_BYTES = size_t(TOTAL) * sizeof(float);
+    static constexpr int ALIAS = TOTAL - OFF_Y;                // everything but the residual stream is free in phases 0 and 8
+    static constexpr int KCH1 = (W * RS + 15) / 16;            // fc1 over the LDS image of one site's [W][RS] rows
+    static constexpr int emb_floats(int cin) { return (MT * 32 + 4) * emb_ps(cin); }
 };
 
 // 8 waves per workgroup (two per SIMD): waves 0-3 and 4-7 split the M tiles of every GEMM between them (the
 // n-tile owner is wave & 3), so one wave's LDS / L2 waits and VALU phases overlap the other's MFMAs.
 constexpr int CVT_BLOCK_THREADS = 512;
 
-template <int C, int W, int WKV, int TS>
-__global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restrict__ h, CvtBlockParams p, int heads, int B) {
+template <int C, int W, int WKV, int TS, int CIN, bool HEAD>
+__global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restrict__ h, CvtBlockParams p, HeadTailParams hp,
+                                                                 int heads, int B) {
     using G = CvtBlockGeom<C, W, WKV, TS>;
+    static_assert(CIN == 0 || G::emb_floats(CIN) <= G::ALIAS, "stage input tile does not fit the free LDS");
+    static_assert(!HEAD || (TS == 16 && 64 + head_lds_floats(6) <= G::ALIAS), "classifier tail needs a 16-site tile");
     constexpr int NT = CVT_BLOCK_THREADS, NWV = NT / 64;
     constexpr int R = G::R, RKV = G::RKV, MT = G::MT, MTKV = G::MTKV, RS = G::RS, QS = G::QS, HC = G::HC, US = G::US;
     constexpr int MT0 = (MT + 1) / 2, MT1 = MT - MT0, MK0 = (MTKV + 1) / 2, MK1 = MTKV - MK0;
@@ -248,27 +263,53 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
     using K4 = std::integral_constant<int, 4>;
     using KH = std::integral_constant<int, HC / 16>;
 
-    // ---- phase 0: residual stream tile -> LDS (pad rows zero) ----
-    for (int i = tid; i < MT * 16 * (C / 4); i += NT) {
-        const int r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < rows_valid) v = *reinterpret_cast<const float4*>(hg + r * C + c4);
-        *reinterpret_cast<float4*>(sh + r * RS + c4) = v;
+    // ---- phase 0: residual stream tile -> LDS (pad rows zero); first block of a stage: stage input -> LDS instead ----
+    if constexpr (HEAD) {   // fc1 sweeps the LDS image of h including the 4 pad columns of every row (zero weights): keep them finite
+        for (int i = tid; i < MT * 16; i += NT) *reinterpret_cast<float4*>(sh + i * RS + C) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int i = tid; i < (MTKV * 16 - RKV) * RS; i += NT) sykv[RKV * RS + i] = 0.f;
+    if constexpr (CIN == 0) {
+        for (int i = tid; i < MT * 16 * (C / 4); i += NT) {
+            const int r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < rows_valid) v = *reinterpret_cast<const float4*>(hg + r * C + c4);
+            *reinterpret_cast<float4*>(sh + r * RS + c4) = v;
+        }
+        for (int i = tid; i < (MTKV * 16 - RKV) * RS; i += NT) sykv[RKV * RS + i] = 0.f;
+    } else {
+        // x tile as [site][2W positions][PS]: slot 0 of a site is the conv's left zero pad, the next site's slot 0 doubles as
+        // this site's right pad, so the im2col row of output (site, wo) is the contiguous run starting at row*2*PS
+        constexpr int WIN = 2 * W - 1, PS = emb_ps(CIN), NPOS = MT * 32 + 4, VW = (CIN % 4 == 0) ? 4 : 2, SLOTS = PS / VW;
+        static_assert(CIN % 2 == 0, "stage input channels must be even");
+        float* sin = smem + G::OFF_Y;
+        const float* xg = p.xin + int64_t(site0) * WIN * CIN;
+        for (int i = tid; i < NPOS * SLOTS; i += NT) {
+            const int pp = i / SLOTS, c = (i - pp * SLOTS) * VW;
+            const int s = pp / (2 * W), pos = pp - s * 2 * W - 1;
+            const bool ok = pos >= 0 && s < nsite && c < CIN;
+            if constexpr (VW == 4) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) v = *reinterpret_cast<const float4*>(xg + (s * WIN + pos) * CIN + c);
+                *reinterpret_cast<float4*>(sin + pp * PS + c) = v;
+            } else {
+                float2 v = make_float2(0.f, 0.f);
+                if (ok) v = *reinterpret_cast<const float2*>(xg + (s * WIN + pos) * CIN + c);
+                *reinterpret_cast<float2*>(sin + pp * PS + c) = v;
+            }
+        }
+    }
     __syncthreads();
 
     // Channel LayerNorm sh -> sy.  16 lanes per row (4 rows per wave at a time), each lane owning C/16 contiguous
     // channels: the row reductions are 4 DPP steps inside a 16-lane row instead of 6 cross-lane permutes through the
     // LDS crossbar - the wave-per-row version spent 12.5 k cycles per LayerNorm (10 % of a stage-3 block).
-    auto layer_norm = [&](const float* g, const float* b) {
+    auto layer_norm = [&](const float* src, float* dst, const float* g, const float* b) {
         constexpr int CPL = C / 16;
         const int l16 = lane & 15, grp = lane >> 4;
         float gv[CPL], bv[CPL];
 #pragma unroll
         for (int i = 0; i < CPL; ++i) { gv[i] = g[l16 * CPL + i]; bv[i] = b[l16 * CPL + i]; }
         for (int r = wave * 4 + grp; r < MT * 16; r += NWV * 4) {
-            const float* xr = sh + r * RS + l16 * CPL;
+            const float* xr = src + r * RS + l16 * CPL;
             float v[CPL], sum = 0.f;
 #pragma unroll
             for (int i = 0; i < CPL; ++i) { v[i] = xr[i]; sum += v[i]; }
@@ -281,15 +322,46 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 16);
             const float inv = 1.0f / (sqrtf(sq / float(C)) + 1e-5f);
-            float* yr = sy + r * RS + l16 * CPL;
+            float* yr = dst + r * RS + l16 * CPL;
 #pragma unroll
             for (int i = 0; i < CPL; ++i) yr[i] = v[i] * inv * gv[i] + bv[i];
         }
     };
 
+    if constexpr (CIN > 0) {
+        // conv embedding (model.py:195, only the middle kernel row is live) + bias, then the stage's channel LayerNorm
+        constexpr int PS = emb_ps(CIN), KE = emb_kch(CIN);
+        const float* we_r[NTC];
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) we_r[nt] = p.wembp + int64_t(own_c ? (wn * NTC + nt) * 16 + j : j) * (KE * 16) + 4 * kg;
+        const BPre<NTC> pre_e = prefetch_b<NTC, KE>(we_r);
+        f32x4 acc_e[MT0][NTC];
+#pragma unroll
+        for (int mt = 0; mt < MT0; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTC; ++nt) acc_e[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (own_c) gemm_r(INTC{}, std::integral_constant<int, KE>{}, smem + G::OFF_Y, 2 * PS, we_r, pre_e, acc_e);
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) {
+            if (!own_c) break;
+            const int col = (wn * NTC + nt) * 16 + j;
+            const float bv = p.bemb[col];
+#pragma unroll
+            for (int mt = 0; mt < MT0; ++mt)
+                if (mt < mcount) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sh[((mbase + mt) * 16 + 4 * kg + r) * RS + col] = acc_e[mt][nt][r] + bv;
+                }
+        }
+        __syncthreads();
+        for (int i = tid; i < (MTKV * 16 - RKV) * RS; i += NT) sykv[RKV * RS + i] = 0.f;
+        layer_norm(sh, sh, p.lng, p.lnb);
+        __syncthreads();
+    }
+
     stamp();
     // ---- phase 1 ----
-    layer_norm(p.n0g, p.n0b);
+    layer_norm(sh, sy, p.n0g, p.n0b);
     __syncthreads();
     stamp();
 
@@ -460,7 +532,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
 
     stamp();
     // ---- phase 5 ----
-    layer_norm(p.n1g, p.n1b);
+    layer_norm(sh, sy, p.n1g, p.n1b);
     __syncthreads();
     stamp();
 
@@ -504,7 +576,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
         stamp();
     }
 
-    // ---- phase 7: h += ff(y) + bias -> HBM ----
+    // ---- phase 7: h += ff(y) + bias -> HBM (last block of the network: -> LDS, the classifier consumes it there) ----
 #pragma unroll
     for (int nt = 0; nt < NTC; ++nt) {
         if (!own_c) break;
@@ -516,9 +588,30 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = (mbase + mt) * 16 + 4 * kg + r;
-                    if (row < rows_valid) hg[row * C + col] = sh[row * RS + col] + acc_f[mt][nt][r] + bv;
+                    const float v = sh[row * RS + col] + acc_f[mt][nt][r] + bv;
+                    if constexpr (HEAD) sh[row * RS + col] = v;
+                    else if (row < rows_valid) hg[row * C + col] = v;
                 }
             }
+    }
+    if constexpr (HEAD) {
+        // ---- phase 8: fc1 over the flattened [W][C] features of each site (model.py:239-247; torch's c*W + w order is folded
+        // into w1p, whose k axis follows the LDS image w*RS + c with zero weights on the pad columns), SELU, classifier tail
+        constexpr int K1 = G::KCH1;
+        float* t1 = smem + G::OFF_Y + 64;       // the last site's k run ends up to 12 floats past its rows
+        float* t2 = t1 + 16 * HEAD_T1S;
+        const float* w1_r1[1] = {p.w1p + int64_t(wave * 16 + j) * (K1 * 16) + 4 * kg};
+        const BPre<1> pre1 = prefetch_b<1, K1>(w1_r1);
+        __syncthreads();
+        stamp();
+        f32x4 a1[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
+        gemm_lds<1, 1, K1>(sh, W * RS, w1_r1, pre1, a1, j, kg);
+        const float bv = p.b1h[wave * 16 + j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t1[(4 * kg + r) * HEAD_T1S + wave * 16 + j] = selu_f(a1[0][0][r] + bv);
+        __syncthreads();
+        stamp();
+        head_tail(t1, t2, hp, B, site0, nsite);
     }
     stamp();
 }

@@ -55,6 +55,7 @@ struct Arena {
 
 struct HeadDev {          // fc1 -> SELU -> K x (fc2 -> SELU -> fc3 -> SELU)
     float *w1 = nullptr, *b1 = nullptr;   // [128][K1]
+    float* w1p = nullptr;                 // CvT: fc1 over the LDS image of the last block's tile ([128][KCH1*16]), or null
     float *w2 = nullptr, *b2 = nullptr;   // [K*128][128]
     float *w3 = nullptr, *b3 = nullptr;   // [K][2][128]
     int k1 = 0;
@@ -67,6 +68,7 @@ struct BlockDev {
 struct StageDev {
     int cin, c, win, w, wkv, heads, inner;
     float *wemb, *bemb, *lng, *lnb;
+    float* wembp = nullptr;       // wemb re-laid for the in-block embedding: [C][emb_kch(cin)*16], positions padded to emb_ps(cin)
     std::vector<BlockDev> blocks;
 };
 
@@ -91,7 +93,7 @@ struct cto_model {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
     int64_t prof_macs = 0;
     float *b_h = nullptr, *b_t = nullptr, *b_yq = nullptr, *b_ykv = nullptr, *b_q = nullptr, *b_kv = nullptr,
-          *b_o = nullptr, *b_u = nullptr, *b_g = nullptr, *b_u2 = nullptr, *b_slab = nullptr;
+          *b_o = nullptr, *b_u = nullptr, *b_slab = nullptr, *b_h2 = nullptr;
     ~cto_model() {
         for (void* p : ws_ptrs) (void)hipFree(p);
         for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -211,7 +213,6 @@ int ensure_ws(cto_model* m, int64_t B) {
         return CTO_OK;
     };
     int rc;
-    const int K = m->n_out;
     if (m->kind == 0) {
         int64_t act = 0, qn = 0, kvn = 0, un = 0;
         for (const StageDev& s : m->st) {
@@ -220,14 +221,13 @@ int ensure_ws(cto_model* m, int64_t B) {
             kvn = std::max<int64_t>(kvn, int64_t(s.wkv) * 2 * s.inner);
             un = std::max<int64_t>(un, int64_t(s.w) * 4 * s.c);
         }
-        if ((rc = get(&m->b_h, act)) || (rc = get(&m->b_t, act)) || (rc = get(&m->b_yq, act)) ||
+        if ((rc = get(&m->b_h, act)) || (rc = get(&m->b_h2, act)) || (rc = get(&m->b_t, act)) || (rc = get(&m->b_yq, act)) ||
             (rc = get(&m->b_ykv, act)) || (rc = get(&m->b_q, qn)) || (rc = get(&m->b_kv, kvn)) ||
             (rc = get(&m->b_o, qn)) || (rc = get(&m->b_u, un)) || (rc = get(&m->b_slab, 4 * 128)))
             return rc;
     } else {
         if ((rc = get(&m->b_h, 33 * 256)) || (rc = get(&m->b_slab, 2 * 128))) return rc;
     }
-    if ((rc = get(&m->b_g, 128)) || (rc = get(&m->b_u2, int64_t(K) * 128))) return rc;
     m->ws_B = B;
     return CTO_OK;
 }
@@ -262,13 +262,21 @@ int run_head(cto_model* m, hipStream_t s, const float* feat, int64_t B, float* l
     return launch_head(m, s, m->b_slab, S, B, logits);
 }
 
-template <int C, int W, int WKV, int TS>
-int launch_cvt_block(hipStream_t s, float* h, const BlockDev& b, int heads, int64_t B) {
+struct BlockExtra {            // what the first / last block of the network additionally needs
+    const float* xin = nullptr;          // stage input when the embedding runs in the block
+    const StageDev* st = nullptr;
+    const HeadDev* head = nullptr;       // classifier when the tail runs in the block
+    float* logits = nullptr;
+    int n_out = 0;
+};
+
+template <int C, int W, int WKV, int TS, int CIN, bool HEAD>
+int launch_cvt_block(hipStream_t s, float* h, const BlockDev& b, int heads, int64_t B, const BlockExtra& ex) {
     using G = CvtBlockGeom<C, W, WKV, TS>;
     static_assert(G::LDS_BYTES <= 160 * 1024, "fused CvT block does not fit the 160 KB LDS of a gfx950 CU");
     static bool attr_set = false;
     if (!attr_set) {
-        CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cvt_block<C, W, WKV, TS>),
+        CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cvt_block<C, W, WKV, TS, CIN, HEAD>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES)));
         attr_set = true;
     }
@@ -277,27 +285,56 @@ int launch_cvt_block(hipStream_t s, float* h, const BlockDev& b, int heads, int6
     if (prof_on && !prof_buf) CTO_HIP(hipMalloc(reinterpret_cast<void**>(&prof_buf), 256 * sizeof(long long)));
     if (prof_on) CTO_HIP(hipMemsetAsync(prof_buf, 0, 256 * sizeof(long long), s));
     CvtBlockParams p{b.n0g, b.n0b, b.dwq, b.bnq, b.wq, b.dwkv, b.bnkv, b.wkv, b.wo, b.bo, b.n1g, b.n1b, b.w1, b.b1, b.w2, b.b2,
-                     prof_on ? prof_buf : nullptr};
-    hipLaunchKernelGGL((k_cvt_block<C, W, WKV, TS>), dim3(unsigned(cdiv(B, TS))), dim3(CVT_BLOCK_THREADS), G::LDS_BYTES, s, h, p, heads, int(B));
+                     prof_on ? prof_buf : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    HeadTailParams hp{};
+    if (CIN > 0) { p.xin = ex.xin; p.wembp = ex.st->wembp; p.bemb = ex.st->bemb; p.lng = ex.st->lng; p.lnb = ex.st->lnb; }
+    if (HEAD) {
+        p.w1p = ex.head->w1p; p.b1h = ex.head->b1;
+        hp = HeadTailParams{ex.head->w2, ex.head->b2, ex.head->w3, ex.head->b3, ex.logits, ex.n_out};
+    }
+    hipLaunchKernelGGL((k_cvt_block<C, W, WKV, TS, CIN, HEAD>), dim3(unsigned(cdiv(B, TS))), dim3(CVT_BLOCK_THREADS), G::LDS_BYTES,
+                       s, h, p, hp, heads, int(B));
     CTO_HIP(hipGetLastError());
     if (prof_on) {   // debug aid: phase time stamps of workgroup 0 (cycles since the kernel's first stamp)
         long long hst[256];
         CTO_HIP(hipStreamSynchronize(s));
         CTO_HIP(hipMemcpy(hst, prof_buf, sizeof(hst), hipMemcpyDeviceToHost));
-        fprintf(stderr, "k_cvt_block<%d,%d,%d,%d> stamps:", C, W, WKV, TS);
+        fprintf(stderr, "k_cvt_block<%d,%d,%d,%d,%d,%d> stamps:", C, W, WKV, TS, CIN, int(HEAD));
         for (int i = 1; i < 256 && hst[i]; ++i) fprintf(stderr, " %lld", hst[i] - hst[i - 1]);
         fprintf(stderr, "\n");
     }
     return CTO_OK;
 }
 
+// The instantiated geometries: (C, W, WKV) -> sites per workgroup and the stage-input channel count whose embedding
+// can run inside the stage's first block.
+template <int C, int W, int WKV, int TS, int CIN>
+int dispatch_block(hipStream_t s, float* h, const BlockDev& b, int heads, int64_t B, const BlockExtra& ex, bool embed, bool head) {
+    if constexpr (TS == 16) {
+        if (head) return embed ? launch_cvt_block<C, W, WKV, TS, CIN, true>(s, h, b, heads, B, ex)
+                               : launch_cvt_block<C, W, WKV, TS, 0, true>(s, h, b, heads, B, ex);
+    }
+    return embed ? launch_cvt_block<C, W, WKV, TS, CIN, false>(s, h, b, heads, B, ex)
+                 : launch_cvt_block<C, W, WKV, TS, 0, false>(s, h, b, heads, B, ex);
+}
+struct FusedGeom { int c, w, wkv, ts, cin; };
+const FusedGeom* fused_geom(const StageDev& st) {
+    static const FusedGeom G[4] = {{128, 5, 3, 16, 64}, {64, 9, 5, 8, 16}, {16, 17, 9, 8, 34}, {32, 17, 9, 8, 34}};
+    for (const FusedGeom& g : G)
+        if (st.c == g.c && st.w == g.w && st.wkv == g.wkv) return &g;
+    return nullptr;
+}
+bool can_fuse_embed(const StageDev& st) { const FusedGeom* g = fused_geom(st); return g && g->cin == st.cin && st.wembp; }
+bool can_fuse_head(const StageDev& st, const HeadDev& hd) { const FusedGeom* g = fused_geom(st); return g && g->ts == 16 && hd.w1p; }
+
 // fused transformer block when the stage geometry has an instantiation; returns 1 if it ran, 0 if not, < 0 on error
-int try_fused_block(hipStream_t s, const StageDev& st, const BlockDev& b, float* h, int64_t B) {
+int try_fused_block(hipStream_t s, const StageDev& st, const BlockDev& b, float* h, int64_t B, const BlockExtra& ex, bool embed,
+                    bool head) {
     int rc = CTO_OK;
-    if (st.c == 128 && st.w == 5 && st.wkv == 3) rc = launch_cvt_block<128, 5, 3, 16>(s, h, b, st.heads, B);
-    else if (st.c == 64 && st.w == 9 && st.wkv == 5) rc = launch_cvt_block<64, 9, 5, 8>(s, h, b, st.heads, B);
-    else if (st.c == 16 && st.w == 17 && st.wkv == 9) rc = launch_cvt_block<16, 17, 9, 8>(s, h, b, st.heads, B);
-    else if (st.c == 32 && st.w == 17 && st.wkv == 9) rc = launch_cvt_block<32, 17, 9, 8>(s, h, b, st.heads, B);
+    if (st.c == 128 && st.w == 5 && st.wkv == 3) rc = dispatch_block<128, 5, 3, 16, 64>(s, h, b, st.heads, B, ex, embed, head);
+    else if (st.c == 64 && st.w == 9 && st.wkv == 5) rc = dispatch_block<64, 9, 5, 8, 16>(s, h, b, st.heads, B, ex, embed, head);
+    else if (st.c == 16 && st.w == 17 && st.wkv == 9) rc = dispatch_block<16, 17, 9, 8, 34>(s, h, b, st.heads, B, ex, embed, head);
+    else if (st.c == 32 && st.w == 17 && st.wkv == 9) rc = dispatch_block<32, 17, 9, 8, 34>(s, h, b, st.heads, B, ex, embed, head);
     else return 0;
     return rc == CTO_OK ? 1 : rc;
 }
@@ -308,19 +345,36 @@ int cvt_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStrea
     for (int si = 0; si < 3; ++si) {
         const StageDev& st = m->st[si];
         const int M = int(B) * st.w, Mkv = int(B) * st.wkv, C = st.c;
-        // conv embedding (3-tap stride 2) + channel LayerNorm
-        if ((rc = launch_gemm(s, in, 0, st.wemb, 3 * st.cin, st.bemb, nullptr, 0, m->b_t, C, M, C, 3 * st.cin, ACT_NONE,
-                              st.win, st.w, st.cin)))
-            return rc;
-        hipLaunchKernelGGL(k_layernorm, dim3(unsigned(cdiv(M, 4))), dim3(256), 0, s, m->b_t, m->b_h, st.lng, st.lnb, M, C);
-        CTO_HIP(hipGetLastError());
-        for (const BlockDev& b : st.blocks) {
+        // The stage's residual stream alternates between two buffers: with the embedding inside the first block, that block
+        // reads the previous stage's output (another per-site layout) while other workgroups already write this stage's.
+        float* hbuf = (si & 1) ? m->b_h2 : m->b_h;
+        // conv embedding (3-tap stride 2) + channel LayerNorm: inside the stage's first block when that is fused
+        static const bool no_embed = [] { const char* e = getenv("CTO_CVT_NO_EMBED_FUSE"); return e && e[0] == '1'; }();
+        static const bool no_head = [] { const char* e = getenv("CTO_CVT_NO_HEAD_FUSE"); return e && e[0] == '1'; }();
+        const bool embed_in_block = m->fuse_blocks && !no_embed && can_fuse_embed(st);
+        if (!embed_in_block) {
+            if ((rc = launch_gemm(s, in, 0, st.wemb, 3 * st.cin, st.bemb, nullptr, 0, m->b_t, C, M, C, 3 * st.cin, ACT_NONE,
+                                  st.win, st.w, st.cin)))
+                return rc;
+            hipLaunchKernelGGL(k_layernorm, dim3(unsigned(cdiv(M, 4))), dim3(256), 0, s, m->b_t, hbuf, st.lng, st.lnb, M, C);
+            CTO_HIP(hipGetLastError());
+        }
+        for (size_t bi = 0; bi < st.blocks.size(); ++bi) {
+            const BlockDev& b = st.blocks[bi];
             if (m->fuse_blocks) {
-                const int fr = try_fused_block(s, st, b, m->b_h, B);
+                BlockExtra ex;
+                const bool embed = embed_in_block && bi == 0;
+                const bool head = !no_head && si == 2 && bi + 1 == st.blocks.size() && can_fuse_head(st, m->head);
+                ex.xin = in; ex.st = &st; ex.head = &m->head; ex.logits = logits; ex.n_out = m->n_out;
+                const int fr = try_fused_block(s, st, b, hbuf, B, ex, embed, head);
                 if (fr < 0) return fr;
-                if (fr == 1) continue;
+                if (fr == 1) {
+                    if (head) return CTO_OK;
+                    continue;
+                }
             }
-            hipLaunchKernelGGL(k_ln_dw, dim3(unsigned(B)), dim3(256), 0, s, m->b_h, b.n0g, b.n0b, b.dwq, b.bnq, b.dwkv,
+            float* h = hbuf;
+            hipLaunchKernelGGL(k_ln_dw, dim3(unsigned(B)), dim3(256), 0, s, h, b.n0g, b.n0b, b.dwq, b.bnq, b.dwkv,
                                b.bnkv, m->b_yq, m->b_ykv, st.w, st.wkv, C);
             CTO_HIP(hipGetLastError());
             if ((rc = launch_gemm(s, m->b_yq, C, b.wq, C, nullptr, nullptr, 0, m->b_q, st.inner, M, st.inner, C, ACT_NONE)))
@@ -333,19 +387,17 @@ int cvt_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStrea
                                st.heads);
             CTO_HIP(hipGetLastError());
             // h = h + to_out(o)
-            if ((rc = launch_gemm(s, m->b_o, st.inner, b.wo, st.inner, b.bo, m->b_h, C, m->b_h, C, M, C, st.inner, ACT_NONE)))
+            if ((rc = launch_gemm(s, m->b_o, st.inner, b.wo, st.inner, b.bo, h, C, h, C, M, C, st.inner, ACT_NONE)))
                 return rc;
-            hipLaunchKernelGGL(k_layernorm, dim3(unsigned(cdiv(M, 4))), dim3(256), 0, s, m->b_h, m->b_t, b.n1g, b.n1b, M, C);
+            hipLaunchKernelGGL(k_layernorm, dim3(unsigned(cdiv(M, 4))), dim3(256), 0, s, h, m->b_t, b.n1g, b.n1b, M, C);
             CTO_HIP(hipGetLastError());
             if ((rc = launch_gemm(s, m->b_t, C, b.w1, C, b.b1, nullptr, 0, m->b_u, 4 * C, M, 4 * C, C, ACT_GELU))) return rc;
             // h = h + ff2(u)
-            if ((rc = launch_gemm(s, m->b_u, 4 * C, b.w2, 4 * C, b.b2, m->b_h, C, m->b_h, C, M, C, 4 * C, ACT_NONE))) return rc;
+            if ((rc = launch_gemm(s, m->b_u, 4 * C, b.w2, 4 * C, b.b2, h, C, h, C, M, C, 4 * C, ACT_NONE))) return rc;
         }
-        // the stage output feeds the next stage's embedding GEMM, which writes b_t; b_h is only rewritten by
-        // the LayerNorm that follows it in stream order, so no copy is needed
-        in = m->b_h;
+        in = hbuf;
     }
-    return run_head(m, s, m->b_h, B, logits);
+    return run_head(m, s, in, B, logits);
 }
 
 int prof_begin(cto_model* m, hipStream_t s, hipEvent_t* e0, hipEvent_t* e1) {
@@ -428,6 +480,13 @@ extern "C" int cto_cvt_create(const cto_weights* w, const cto_cvt_cfg* cfg, cto_
                     for (int ci = 0; ci < cin; ++ci)
                         v[(size_t(n) * 3 + t) * cin + ci] = (*cw)[((size_t(n) * cin + ci) * 3 + 1) * 3 + t];
             if ((rc = a.upload(v, &st.wemb))) return fail(rc);
+            // the same taps re-laid for the in-block embedding: k = t * PS + ci, zero elsewhere
+            const int PS = emb_ps(cin), KP = emb_kch(cin) * 16;
+            std::vector<float> vp(size_t(C) * KP, 0.f);
+            for (int n = 0; n < C; ++n)
+                for (int t = 0; t < 3; ++t)
+                    for (int ci = 0; ci < cin; ++ci) vp[size_t(n) * KP + t * PS + ci] = v[(size_t(n) * 3 + t) * cin + ci];
+            if ((rc = a.upload(vp, &st.wembp))) return fail(rc);
         }
         if ((rc = upload_named(w, L + ".0.bias", C, a, &st.bemb))) return fail(rc);
         if ((rc = upload_named(w, L + ".1.g", C, a, &st.lng))) return fail(rc);
@@ -469,6 +528,15 @@ extern "C" int cto_cvt_create(const cto_weights* w, const cto_cvt_cfg* cfg, cto_
                 for (int ww = 0; ww < W3; ++ww) v[size_t(n) * k1 + ww * C3 + c] = (*f1)[size_t(n) * k1 + c * W3 + ww];
         static const char* const names[6] = {"a", "c", "g", "t", "i", "d"};
         if ((rc = build_head(w, names, m->n_out, k1, v, a, m->head))) return fail(rc);
+        if (C3 == 128 && W3 == 5) {      // fc1 over the LDS image of the last block's tile: k = w * RS + c
+            using G = CvtBlockGeom<128, 5, 3, 16>;
+            const int KP = G::KCH1 * 16;
+            std::vector<float> vp(size_t(128) * KP, 0.f);
+            for (int n = 0; n < 128; ++n)
+                for (int ww = 0; ww < W3; ++ww)
+                    for (int c = 0; c < C3; ++c) vp[size_t(n) * KP + ww * G::RS + c] = v[size_t(n) * k1 + ww * C3 + c];
+            if ((rc = a.upload(vp, &m->head.w1p))) return fail(rc);
+        }
     }
     macs += int64_t(k1) * 128 + int64_t(m->n_out) * (128 * 128 + 256);
     m->macs = macs;
