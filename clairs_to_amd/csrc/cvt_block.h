@@ -93,6 +93,58 @@ __device__ __forceinline__ void gemm_lds(const float* __restrict__ A, int lda, c
     }
 }
 
+// One 16-row m-tile (the classifier GEMMs: 16 sites per workgroup): weights are used once, so the loop is bound by
+// the L2 round trip, not by the matrix pipe, unless many loads are in flight - DEPTH 16-wide k chunks per n-tile are
+// requested at a time, one group ahead of the MFMAs; even / odd chunks alternate between two accumulator sets.
+template <int NTW, int DEPTH>
+struct BGroup {
+    float4 b[DEPTH][NTW];
+};
+template <int NTW, int KCH, int DEPTH>
+__device__ __forceinline__ void load_group(BGroup<NTW, DEPTH>& g, const float* const (&wrow)[NTW], int c0) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+            if (c0 + d < KCH) g.b[d][nt] = *reinterpret_cast<const float4*>(wrow[nt] + (c0 + d) * 16);
+}
+template <int NTW, int KCH, int DEPTH>
+__device__ __forceinline__ void mfma_group(const BGroup<NTW, DEPTH>& g, const float* Arow, int c0, f32x4 (&acc)[2][NTW]) {
+    float4 a[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (c0 + d < KCH) a[d] = *reinterpret_cast<const float4*>(Arow + (c0 + d) * 16);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        if (c0 + d >= KCH) break;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float av = e == 0 ? a[d].x : (e == 1 ? a[d].y : (e == 2 ? a[d].z : a[d].w));
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const float4 b4 = g.b[d][nt];
+                const float bv = e == 0 ? b4.x : (e == 1 ? b4.y : (e == 2 ? b4.z : b4.w));
+                acc[d & 1][nt] = mfma16(av, bv, acc[d & 1][nt]);
+            }
+        }
+    }
+}
+template <int NTW, int KCH, int DEPTH>
+__device__ __forceinline__ void gemm_m1(const float* __restrict__ A, int lda, const float* const (&wrow)[NTW],
+                                        const BGroup<NTW, DEPTH>& first, f32x4 (&acc)[2][NTW], int j, int kg) {
+    constexpr int NG = (KCH + DEPTH - 1) / DEPTH;
+    const float* Arow = A + j * lda + 4 * kg;
+    BGroup<NTW, DEPTH> g[2];
+    g[0] = first;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        if (i + 1 < NG) load_group<NTW, KCH, DEPTH>(g[(i + 1) & 1], wrow, (i + 1) * DEPTH);
+        __builtin_amdgcn_sched_barrier(0);      // keep the next group's loads ahead of this group's MFMAs
+        mfma_group<NTW, KCH, DEPTH>(g[i & 1], Arow, i * DEPTH, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // ---- classifier tail shared by both networks (clairs/model.py:245-261, 451-467): K heads of fc2 (128 -> 128) -> SELU ->
 // fc3 (128 -> 2) -> SELU on a 16-site tile whose SELU(fc1) activations sit in LDS.  8 waves; wave w owns hidden units
 // [16w, 16w+16) of every head, two heads per pass (two independent accumulators keep the matrix pipe at issue rate).
@@ -107,23 +159,38 @@ __host__ __device__ constexpr int head_t2s(int K) { return K * 128 + 4; }
 __host__ __device__ constexpr int head_lds_floats(int K) { return 16 * HEAD_T1S + 16 * head_t2s(K); }
 
 // t1: [16][HEAD_T1S] (in), t2: [16][head_t2s(K)] scratch.  All 512 threads call; ends without a barrier.
-__device__ __forceinline__ void head_tail(const float* t1, float* t2, const HeadTailParams& hp, int64_t B, int64_t site0,
-                                          int nsite) {
+template <int K>
+__device__ __forceinline__ void head_tail_k(const float* t1, float* t2, const HeadTailParams& hp, int64_t B, int64_t site0,
+                                            int nsite) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
-    const int K = hp.K, T2S = head_t2s(K);
-    for (int h0 = 0; h0 < K; h0 += 2) {
-        const float* wr[2];
-        wr[0] = hp.w2 + int64_t(h0 * 128 + wave * 16 + j) * 128 + 4 * kg;
-        wr[1] = wr[0] + 128 * 128;
-        const BPre<2> pre = prefetch_b<2, 8>(wr);
-        f32x4 acc[1][2] = {{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}};
-        gemm_lds<1, 2, 8>(t1, HEAD_T1S, wr, pre, acc, j, kg);
+    constexpr int T2S = head_t2s(K);
+    static_assert(K % 2 == 0, "heads are processed in pairs");
+    const float* wr[2];
+    wr[0] = hp.w2 + int64_t(wave * 16 + j) * 128 + 4 * kg;
+    wr[1] = wr[0] + 128 * 128;
+    BGroup<2, 8> g[2];
+    load_group<2, 8, 8>(g[0], wr, 0);
+    const float* Arow = t1 + j * HEAD_T1S + 4 * kg;
+#pragma unroll
+    for (int pi = 0; pi < K / 2; ++pi) {
+        if (pi + 1 < K / 2) {        // the next pair of heads' weights fly under this pair's MFMAs
+            const float* wn[2] = {wr[0] + (pi + 1) * 2 * 128 * 128, wr[1] + (pi + 1) * 2 * 128 * 128};
+            load_group<2, 8, 8>(g[(pi + 1) & 1], wn, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[a][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mfma_group<2, 8, 8>(g[pi & 1], Arow, 0, acc);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int col = (h0 + q) * 128 + wave * 16 + j;
+            const int col = (pi * 2 + q) * 128 + wave * 16 + j;
             const float bv = hp.b2[col];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) t2[(4 * kg + r) * T2S + col] = selu_f(acc[0][q][r] + bv);
+            for (int r = 0; r < 4; ++r) t2[(4 * kg + r) * T2S + col] = selu_fast(acc[0][q][r] + acc[1][q][r] + bv);
         }
     }
     __syncthreads();
@@ -143,6 +210,11 @@ __device__ __forceinline__ void head_tail(const float* t1, float* t2, const Head
         sum += __shfl_xor(sum, 2, 4);
         if (part == 0 && site < nsite) hp.logits[(int64_t(hh) * B + site0 + site) * 2 + o] = selu_f(sum + hp.b3[hh * 2 + o]);
     }
+}
+__device__ __forceinline__ void head_tail(const float* t1, float* t2, const HeadTailParams& hp, int64_t B, int64_t site0,
+                                          int nsite) {
+    if (hp.K == 4) head_tail_k<4>(t1, t2, hp, B, site0, nsite);
+    else head_tail_k<6>(t1, t2, hp, B, site0, nsite);
 }
 
 // Stand-alone classifier tail for fc1 partial sums that already sit in HBM (BiGRU: one slab per direction from the fused
@@ -165,7 +237,7 @@ __global__ __launch_bounds__(512) void k_head(const float* __restrict__ slabs, i
         }
         const float4 bb = *reinterpret_cast<const float4*>(b1 + c4);
         *reinterpret_cast<float4*>(t1 + site * HEAD_T1S + c4) =
-            make_float4(selu_f(v.x + bb.x), selu_f(v.y + bb.y), selu_f(v.z + bb.z), selu_f(v.w + bb.w));
+            make_float4(selu_fast(v.x + bb.x), selu_fast(v.y + bb.y), selu_fast(v.z + bb.z), selu_fast(v.w + bb.w));
     }
     __syncthreads();
     head_tail(t1, t2, hp, B, site0, nsite);
@@ -601,14 +673,15 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
         float* t1 = smem + G::OFF_Y + 64;       // the last site's k run ends up to 12 floats past its rows
         float* t2 = t1 + 16 * HEAD_T1S;
         const float* w1_r1[1] = {p.w1p + int64_t(wave * 16 + j) * (K1 * 16) + 4 * kg};
-        const BPre<1> pre1 = prefetch_b<1, K1>(w1_r1);
+        BGroup<1, 7> g0;
+        load_group<1, K1, 7>(g0, w1_r1, 0);
         __syncthreads();
         stamp();
-        f32x4 a1[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
-        gemm_lds<1, 1, K1>(sh, W * RS, w1_r1, pre1, a1, j, kg);
+        f32x4 a1[2][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}, {f32x4{0.f, 0.f, 0.f, 0.f}}};
+        gemm_m1<1, K1, 7>(sh, W * RS, w1_r1, g0, a1, j, kg);
         const float bv = p.b1h[wave * 16 + j];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) t1[(4 * kg + r) * HEAD_T1S + wave * 16 + j] = selu_f(a1[0][0][r] + bv);
+        for (int r = 0; r < 4; ++r) t1[(4 * kg + r) * HEAD_T1S + wave * 16 + j] = selu_fast(a1[0][0][r] + a1[1][0][r] + bv);
         __syncthreads();
         stamp();
         head_tail(t1, t2, hp, B, site0, nsite);

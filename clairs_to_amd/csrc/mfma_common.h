@@ -25,6 +25,14 @@ __device__ __forceinline__ float selu_f(float x) {
     const float alpha = 1.6732632423543772848170429916717f;
     return x > 0.f ? scale * x : scale * alpha * expm1f(x);
 }
+// branch-free SELU for MFMA epilogues: exp(x) - 1 by the hardware exponential; the cancellation near 0 costs at most one
+// ulp of 1.0 (6e-8 absolute), far inside the 1e-4 parity bar, and there is no libm expm1f call (branches, ~50 VALU) per element
+__device__ __forceinline__ float selu_fast(float x) {
+    const float scale = 1.0507009873554804934193349852946f;
+    const float alpha = 1.6732632423543772848170429916717f;
+    const float neg = scale * alpha * (__expf(fminf(x, 0.f)) - 1.0f);
+    return x > 0.f ? scale * x : neg;
+}
 // exact-erf GELU (nn.GELU() default).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 round-off class):
 // libm's erff costs ~45 VALU per call and the FFN epilogues evaluate it 160 times per lane per transformer block.
 __device__ __forceinline__ float erf_as(float x) {
