@@ -3,13 +3,17 @@ hot-path sub-modules this package replaces."""
 import importlib
 import sys
 
-SUBMODULES = ("extract_candidates_calling", "create_tensor_pileup_calling", "predict", "call_variants")
+SUBMODULES = ("extract_candidates_calling", "create_tensor_pileup_calling", "predict", "call_variants", "sort_vcf",
+              "postprocess_vcf")
 
 
 def main():
     if len(sys.argv) < 2 or sys.argv[1] not in SUBMODULES:
         sys.exit("usage: python -m clairs_to_amd {%s} [options]" % "|".join(SUBMODULES))
     name = sys.argv.pop(1)
+    if name in ("sort_vcf", "postprocess_vcf"):          # the host-side tail lives in one module
+        mod = importlib.import_module("clairs_to_amd.postprocess_vcf")
+        return getattr(mod, name + "_main")()
     importlib.import_module("clairs_to_amd." + name).main()
 
 

@@ -145,7 +145,9 @@ VCF_HEADER = """##fileformat=VCFv4.2
 ##source=clairs_to_amd
 ##FILTER=<ID=PASS,Description="All filters passed">
 ##FILTER=<ID=LowQual,Description="Low quality variant">
+##FILTER=<ID=NonSomatic,Description="Tagged as non-somatic by a panel of normals (set downstream, kept by postprocess_vcf)">
 ##FILTER=<ID=RefCall,Description="Reference call">
+##INFO=<ID=H,Number=0,Type=Flag,Description="Phaseable: variant seen on one haplotype only (set downstream, read by postprocess_vcf)">
 ##INFO=<ID=FAU,Number=1,Type=Integer,Description="Forward-strand A count in the tumor BAM">
 ##INFO=<ID=FCU,Number=1,Type=Integer,Description="Forward-strand C count in the tumor BAM">
 ##INFO=<ID=FGU,Number=1,Type=Integer,Description="Forward-strand G count in the tumor BAM">
@@ -162,8 +164,10 @@ VCF_HEADER = """##fileformat=VCFv4.2
 ##FORMAT=<ID=AU,Number=1,Type=Integer,Description="A count in the tumor BAM">
 ##FORMAT=<ID=CU,Number=1,Type=Integer,Description="C count in the tumor BAM">
 ##FORMAT=<ID=GU,Number=1,Type=Integer,Description="G count in the tumor BAM">
-##FORMAT=<ID=TU,Number=1,Type=Integer,Description="T count in the tumor BAM">
+##FORMAT=<ID=TU,Number=1,Type=Integer,Description="Count of T in the tumor BAM">
 """
+# The TU line is byte-identical to the reference's (shared/vcf.py): its postprocess_vcf cuts the header after exactly this
+# line (src/postprocess_vcf.py:165-166), so a VCF written here stays a valid input of the reference's own tail.
 
 
 def call_variants_from_probability(args, device="cuda"):

@@ -364,7 +364,89 @@ def gen_extract(tmp):
     dump_json_gz("extract.json.gz", fixture)
 
 
+# ------------------------------------------------------------------------------------------ sort_vcf + postprocess_vcf
+def gen_post(tmp):
+    """reference `sort_vcf` and `postprocess_vcf` on chunk VCFs made of the call_variants records of
+    calls_snv.json.gz, re-labelled over several contigs and salted with the record kinds the gates distinguish
+    (phaseable `H` INFO, NonSomatic / LowQual filters, low QUAL, low AF)."""
+    import random
+    calls = json.load(gzip.open(os.path.join(HERE, "calls_snv.json.gz"), "rt"))
+    rows = calls["vcf"]["show_ref"]
+    sys.path.insert(0, REF)
+    from shared.vcf import vcf_header
+    rnd = random.Random(11)
+    contigs = ["chr1", "chr11", "chr2", "chrX", "scaffold_7"]
+    d = os.path.join(tmp, "post")
+    os.makedirs(os.path.join(d, "vcf_output"), exist_ok=True)
+    chunks = {}
+    for ci, ctg in enumerate(contigs):
+        for part in range(2):
+            recs = []
+            for r in rows[part::2]:
+                c = r.split("\t")
+                c[0] = ctg
+                c[1] = str(int(c[1]) + 1000 * ci)
+                u = rnd.random()
+                if c[6] == "PASS":
+                    if u < 0.25:
+                        c[7] += ";H"
+                    if rnd.random() < 0.3:
+                        c[5] = "%.4f" % rnd.uniform(0.5, 14.0)
+                    if rnd.random() < 0.15:
+                        c[6] = "NonSomatic"
+                    elif rnd.random() < 0.1:
+                        c[6] = "LowQual"
+                recs.append("\t".join(c))
+            rnd.shuffle(recs)
+            head = vcf_header + "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSAMPLE\n"
+            fn = "p_%s.%d_2.vcf" % (ctg, part + 1)
+            chunks[fn] = head + "".join(x + "\n" for x in recs)
+            open(os.path.join(d, "vcf_output", fn), "w").write(chunks[fn])
+    order = ["chrX", "scaffold_7", "chr2", "chr11", "chr1", "chr5"]       # chr5 has no files
+    open(os.path.join(d, "CONTIGS"), "w").write("".join(c + "\n" for c in order))
+    fai = "".join("%s\t%d\t6\t60\t61\n" % (c, 100000 + i) for i, c in enumerate(["chr1", "chr2", "chr5", "chr11", "chrX", "scaffold_7"]))
+    open(os.path.join(d, "ref.fa.fai"), "w").write(fai)
+    open(os.path.join(d, "ref.fa"), "w").write(">x\nA\n")
+    open(os.path.join(d, "CMD"), "w").write("run_clairs_to --synthetic fixture\n")
+    env = dict(os.environ, PYTHONPATH=REF)
+    merged = os.path.join(d, "merged.vcf")
+    subprocess.check_call([sys.executable, os.path.join(REF, "clairs_to.py"), "sort_vcf", "--input_dir", os.path.join(d, "vcf_output"),
+                           "--vcf_fn_prefix", "p_", "--vcf_fn_suffix", ".vcf", "--output_fn", merged, "--sample_name", "SAMPLE",
+                           "--ref_fn", os.path.join(d, "ref.fa"), "--contigs_fn", os.path.join(d, "CONTIGS")], cwd=d, env=env)
+    empty = os.path.join(d, "empty.vcf")
+    subprocess.check_call([sys.executable, os.path.join(REF, "clairs_to.py"), "sort_vcf", "--input_dir", os.path.join(d, "vcf_output"),
+                           "--vcf_fn_prefix", "nothing_", "--output_fn", empty, "--sample_name", "S2",
+                           "--ref_fn", os.path.join(d, "ref.fa"), "--contigs_fn", os.path.join(d, "CONTIGS")], cwd=d, env=env)
+    cases = []
+    for opts in ({"platform": "ont"}, {"platform": "ilmn"}, {"platform": "hifi", "qual": 20.0, "af": 0.3},
+                 {"platform": "ont", "qual_cutoff_phaseable_region": 5.0, "qual_cutoff_unphaseable_region": 30.0,
+                  "cmdline": True, "ref_fn": True},
+                 {"platform": "ilmn", "max_qual_filter_pileup_calls": 12.0, "af": 0.35},
+                 {"platform": "ont", "max_qual_filter_pileup_calls": 25.0}):
+        out = os.path.join(d, "final_%d.vcf" % len(cases))
+        cmd = [sys.executable, os.path.join(REF, "clairs_to.py"), "postprocess_vcf", "--pileup_vcf_fn", merged, "--output_fn", out,
+               "--compress_vcf", "False", "--sample_name", "SAMPLE", "--platform", opts["platform"]]
+        for k in ("qual", "af", "qual_cutoff_phaseable_region", "qual_cutoff_unphaseable_region", "max_qual_filter_pileup_calls"):
+            if k in opts:
+                cmd += ["--" + k, str(opts[k])]
+        if opts.get("cmdline"):
+            cmd += ["--cmdline", os.path.join(d, "CMD")]
+        if opts.get("ref_fn"):
+            cmd += ["--ref_fn", os.path.join(d, "ref.fa")]
+        subprocess.check_call(cmd, cwd=d, env=env)
+        cases.append(dict(opts=opts, out=open(out).read()))
+    fixture = dict(chunks=chunks, contigs_order=order, fai=fai, cmd=open(os.path.join(d, "CMD")).read(),
+                   merged=open(merged).read(), empty=open(empty).read(), cases=cases)
+    print("post: merged records", sum(1 for r in fixture["merged"].split("\n") if r and r[0] != "#"),
+          "case records", [sum(1 for r in c["out"].split("\n") if r and r[0] != "#") for c in cases])
+    dump_json_gz("post.json.gz", fixture)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "post":
+        with tempfile.TemporaryDirectory() as tmp:
+            gen_post(tmp)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "extract":
         with tempfile.TemporaryDirectory() as tmp:
             gen_extract(tmp)
@@ -375,6 +457,7 @@ def main():
         gen_models(region)
         gen_calls(tmp, region)
         gen_extract(tmp)
+        gen_post(tmp)
 
 
 if __name__ == "__main__":

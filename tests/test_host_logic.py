@@ -76,3 +76,41 @@ def test_vcf_rows_match_reference(oracle_lib, mode, show_ref):
     want = calls["vcf"]["show_ref" if show_ref else "default"]
     assert len(want) > 0
     assert out == want
+
+
+def test_sort_and_postprocess_vcf_match_reference(tmp_path):
+    """chunk VCF merge + QUAL/AF gates byte-identical to the reference's sort_vcf / postprocess_vcf outputs
+    (tests/golden/post.json.gz: several contigs incl. a chr1/chr11 name clash, `H` records, NonSomatic / LowQual, 6 option sets)."""
+    from clairs_to_amd.postprocess_vcf import sort_vcf_main, postprocess_vcf_main
+    g = load_json_gz("post.json.gz")
+    d = tmp_path / "vcf_output"
+    d.mkdir()
+    for fn, text in g["chunks"].items():
+        (d / fn).write_text(text)
+    (tmp_path / "CONTIGS").write_text("".join(c + "\n" for c in g["contigs_order"]))
+    (tmp_path / "ref.fa.fai").write_text(g["fai"])
+    (tmp_path / "CMD").write_text(g["cmd"])
+    merged = tmp_path / "merged.vcf"
+    base = ["--input_dir", str(d), "--ref_fn", str(tmp_path / "ref.fa"), "--contigs_fn", str(tmp_path / "CONTIGS")]
+    n = sort_vcf_main(base + ["--vcf_fn_prefix", "p_", "--output_fn", str(merged)])
+    assert merged.read_text() == g["merged"] and n == sum(1 for r in g["merged"].split("\n") if r and r[0] != "#")
+    empty = tmp_path / "empty.vcf"
+    assert sort_vcf_main(base + ["--vcf_fn_prefix", "nothing_", "--output_fn", str(empty), "--sample_name", "S2"]) == 0
+    # no records: a bare header (own meta lines, so compare the parts both sides must agree on) without a trailing newline
+    from clairs_to_amd.call_variants import VCF_HEADER
+    tail = [r for r in g["empty"].split("\n") if r.startswith("##contig") or r.startswith("#CHROM")]
+    assert empty.read_text() == VCF_HEADER + "\n".join(tail)
+    assert [r for r in VCF_HEADER.split("\n") if "ID=TU," in r] == [r for r in g["empty"].split("\n") if "FORMAT=<ID=TU," in r]
+    for i, case in enumerate(g["cases"]):
+        o = case["opts"]
+        out = tmp_path / ("final_%d.vcf" % i)
+        argv = ["--pileup_vcf_fn", str(merged), "--output_fn", str(out), "--platform", o["platform"]]
+        for k in ("qual", "af", "qual_cutoff_phaseable_region", "qual_cutoff_unphaseable_region", "max_qual_filter_pileup_calls"):
+            if k in o:
+                argv += ["--" + k, str(o[k])]
+        if o.get("cmdline"):
+            argv += ["--cmdline", str(tmp_path / "CMD")]
+        if o.get("ref_fn"):
+            argv += ["--ref_fn", str(tmp_path / "ref.fa")]
+        postprocess_vcf_main(argv)
+        assert out.read_text() == case["out"], o
