@@ -3,8 +3,8 @@ hot-path sub-modules this package replaces."""
 import importlib
 import sys
 
-SUBMODULES = ("extract_candidates_calling", "create_tensor_pileup_calling", "predict", "call_variants", "sort_vcf",
-              "postprocess_vcf")
+SUBMODULES = ("extract_candidates_calling", "create_tensor_pileup_calling", "predict", "call_variants", "pileup_call",
+              "sort_vcf", "postprocess_vcf")
 
 
 def main():

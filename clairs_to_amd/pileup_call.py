@@ -1,0 +1,136 @@
+"""One invocation per candidate chunk: BED chunk + BAM (or mpileup text) + checkpoints + likelihood table -> `p_<chunk>.vcf`.
+
+Replaces the four commands the reference orchestrator runs per chunk (run_clairs_to:1228-1308 / 1562-1647:
+`create_tensor_pileup_calling --min_bq <platform>`, the same with `--min_bq 0`, `predict --pileup`, `call_variants`) with a
+single pass that never leaves HBM between the pileup pack and the decision: no tensor text, no probability text.
+The options are the union of those four commands' options under their reference names; `--predict_fn` / `--tensor_can_fn*`
+remain available as debugging taps and produce exactly what the separate mirrors write.
+
+The result is the same VCF the chained mirrors (and the reference) produce: the epilogue kernel rounds probabilities to
+the 8 decimals of the text seam before the table look-up (csrc/posterior.hip), strand counts and depths come from the AFF
+pass (predict.py:614, 689), rows whose centre reference base is not ACGT are dropped (predict.py:228), sites without an
+mpileup row at the candidate are skipped (create_tensor_pileup_calling.py:552).
+"""
+import gzip
+import os
+import shlex
+import subprocess
+import sys
+from argparse import ArgumentParser
+
+import numpy as np
+import torch
+
+from .call_variants import IUPAC_TO_ACGT, VCF_HEADER, load_likelihood, vcf_row
+from .create_tensor_pileup_calling import EXPAND_REF, FLANK, MAX_INDEL, NPOS, read_candidates
+from .engine import Engine
+from .fasta import read_region
+from .featurize import alt_infos
+from .pack import ColumnPack
+from .predict import load_models, str2bool
+from .synth import PLATFORMS
+
+
+def mpileup_text_of(args, ctg_start, ctg_end):
+    """The NEG-pass pileup (`--min-BQ 0`) serves both passes: the AFF pass's base-quality gate runs on the device."""
+    if args.mpileup_fn:
+        opener = gzip.open if args.mpileup_fn.endswith(".gz") else open
+        with opener(args.mpileup_fn, "rb") as f:
+            return f.read()
+    ext_s, ext_e = max(1, ctg_start - NPOS), ctg_end + NPOS
+    cmd = "{} mpileup --reverse-del --output-MQ -r {}:{}-{} --min-MQ 0 --min-BQ 0 -l {} --excl-flags 2316".format(
+        args.samtools, args.ctg_name, ext_s, ext_e, args.candidates_bed_regions)
+    if args.max_depth is not None:
+        cmd += " --max-depth {}".format(args.max_depth)
+    return subprocess.run(shlex.split(cmd) + [args.tumor_bam_fn], stdout=subprocess.PIPE, check=True).stdout
+
+
+def pileup_call(args, device="cuda"):
+    if not torch.cuda.is_available():
+        sys.exit("[ERROR] clairs_to_amd pileup_call needs a HIP device; there is no CPU fallback")
+    K = 4 if args.disable_indel_calling else 6
+    centres, ctg_start, ctg_end = read_candidates(args.candidates_bed_regions, args.ctg_name)
+    if not centres:
+        print("[INFO] {} total processed positions: 0".format(args.ctg_name), file=sys.stderr)
+        return 0
+    sites = sorted(centres)
+    ref_start = max(1, ctg_start - EXPAND_REF)
+    ref = read_region(args.ref_fn, args.ctg_name, ref_start, ctg_end + EXPAND_REF)
+    if not ref:
+        sys.exit("[ERROR] Failed to load reference sequence from file ({}).".format(args.ref_fn))
+    min_bq = args.min_bq if args.min_bq is not None else PLATFORMS.get(args.platform, PLATFORMS["ont"])["min_bq"]
+    aff, neg = load_models(args, device)
+    lik, edges = load_likelihood(args.likelihood_matrix_data, K)
+    eng = Engine(aff, neg, lik, edges, min_bq=min_bq, min_rescale_cov=args.min_rescale_cov, device=device)
+    max_indel = MAX_INDEL if args.max_indel_length is None else args.max_indel_length
+    pack = ColumnPack.from_mpileup(mpileup_text_of(args, ctg_start, ctg_end), ref, ref_start, max_indel)
+    dp = pack.to_device(device)
+    res = eng.run_device(dp, torch.tensor(sites, dtype=torch.int32, device=device))
+    torch.cuda.synchronize()
+    feat = res["features"]
+    info = feat.site_info.cpu().numpy()
+    alts = alt_infos(feat, pack, info)
+    dec, qual = res["decision"].cpu().numpy(), res["qual"].cpu().numpy()
+    probs = res["probs"].cpu().numpy() if args.predict_fn else None
+    n_rows = n_sites = 0
+    pred = gzip.open(args.predict_fn, "wt") if args.predict_fn else None
+    os.makedirs(os.path.dirname(os.path.abspath(args.call_fn)), exist_ok=True)
+    with open(args.call_fn, "w") as out:
+        out.write(VCF_HEADER + "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n" % args.sample_name)
+        for i, pos in enumerate(sites):
+            if info[i, 3] & 1:
+                continue
+            centre = ref[pos - ref_start]
+            if centre not in "ACGT":
+                continue
+            n_sites += 1
+            ref_base = IUPAC_TO_ACGT[centre.upper()]
+            fwd, rev = [float(v) for v in info[i, 4:8]], [float(v) for v in info[i, 8:12]]
+            if pred is not None:
+                fields = [args.ctg_name, str(pos), ref_base, alts[i], str(fwd), str(rev)]
+                fields += [" ".join("{:0.8f}".format(x) for x in probs[i, k]) for k in range(2 * K)]
+                pred.write("\t".join(fields) + ("\t\n" if K == 4 else "\n"))
+            if dec[i, 1]:
+                print("[WARNING] %s:%d probability 1.00000000 falls outside the likelihood bins (the reference raises "
+                      "IndexError here); clamped" % (args.ctg_name, pos), file=sys.stderr)
+            line = vcf_row(args.ctg_name, str(pos), ref_base, alts[i], fwd, rev, int(dec[i, 0]), float(qual[i]), K,
+                           show_ref=args.show_ref, qual_pass=args.qual)
+            if line is not None:
+                out.write(line + "\n")
+                n_rows += 1
+    if pred is not None:
+        pred.close()
+    if n_rows == 0:
+        os.remove(args.call_fn)            # the reference removes VCFs without records (call_variants.py:859-867)
+    print("[INFO] {} total processed positions: {}".format(args.ctg_name, n_sites), file=sys.stderr)
+    return n_rows
+
+
+def main():
+    p = ArgumentParser(description="Pileup calling of one candidate chunk on the GPU: BED + BAM/mpileup -> VCF")
+    p.add_argument("--platform", type=str, default="ont")
+    p.add_argument("--tumor_bam_fn", type=str, default=None)
+    p.add_argument("--mpileup_fn", type=str, default=None, help="samtools mpileup text (--min-BQ 0) instead of a BAM")
+    p.add_argument("--ref_fn", type=str, required=True)
+    p.add_argument("--ctg_name", type=str, required=True)
+    p.add_argument("--samtools", type=str, default="samtools")
+    p.add_argument("--min_bq", type=int, default=None, help="AFF-pass base quality gate (default: the platform's)")
+    p.add_argument("--max_depth", type=int, default=None)
+    p.add_argument("--max_indel_length", type=int, default=None)
+    p.add_argument("--candidates_bed_regions", type=str, required=True)
+    p.add_argument("--chkpnt_fn_acgt", type=str, required=True)
+    p.add_argument("--chkpnt_fn_nacgt", type=str, required=True)
+    p.add_argument("--min_rescale_cov", type=int, default=50)
+    p.add_argument("--disable_indel_calling", type=str2bool, default=False)
+    p.add_argument("--likelihood_matrix_data", type=str, required=True)
+    p.add_argument("--call_fn", type=str, required=True)
+    p.add_argument("--predict_fn", type=str, default=None, help="also write the probability rows (debugging tap)")
+    p.add_argument("--sample_name", type=str, default="SAMPLE")
+    p.add_argument("--show_ref", action="store_true")
+    p.add_argument("--qual", type=int, default=0)
+    p.add_argument("--pileup", action="store_true")
+    pileup_call(p.parse_args())
+
+
+if __name__ == "__main__":
+    main()

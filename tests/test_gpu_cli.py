@@ -23,6 +23,29 @@ def _write_region(tmp_path, g):
     return str(fa), str(bed), str(mp)
 
 
+def _pickle_models(tmp_path, aff_cls, neg_cls, K):
+    """checkpoints pickled under the reference's qualified names (clairs.model.<cls>), as its releases are"""
+    import torch
+    from clairs_to_amd import nn_shims
+    nn_shims.install_reference_aliases()
+    paths = {}
+    for key, cls in (("model_acgt", aff_cls), ("model_nacgt", neg_cls)):
+        g = load_models_npz(cls)
+        m = nn_shims.from_state_dict(cls, make_weights(g["manifest"], seed=K))
+        saved = {}
+        try:
+            for c in vars(nn_shims).values():
+                if isinstance(c, type) and c.__module__ == nn_shims.__name__:
+                    saved[c] = c.__module__
+                    c.__module__ = "clairs.model"
+            paths[key] = str(tmp_path / (key + ".pkl"))
+            torch.save({key: m}, paths[key])
+        finally:
+            for c, mod in saved.items():
+                c.__module__ = mod
+    return paths
+
+
 def test_create_tensor_cli_matches_reference_text(tmp_path, golden_region):
     from argparse import Namespace
     from clairs_to_amd.create_tensor_pileup_calling import create_tensor
@@ -48,24 +71,7 @@ def test_predict_and_call_variants_cli(tmp_path, golden_region, mode, aff_cls, n
     for tag in ("aff", "neg"):
         with gzip.open(tmp_path / ("t_%s.gz" % tag), "wt") as f:
             f.write(golden_region["tensor_" + tag])
-    # checkpoints pickled under the reference's qualified names (clairs.model.<cls>), as its releases are
-    nn_shims.install_reference_aliases()
-    paths = {}
-    for key, cls in (("model_acgt", aff_cls), ("model_nacgt", neg_cls)):
-        g = load_models_npz(cls)
-        m = nn_shims.from_state_dict(cls, make_weights(g["manifest"], seed=K))
-        klasses = [c for c in type(m).__mro__ if c.__module__ == nn_shims.__name__]
-        saved = {c: c.__module__ for c in klasses}
-        try:
-            for c in vars(nn_shims).values():
-                if isinstance(c, type) and c.__module__ == nn_shims.__name__:
-                    saved[c] = c.__module__
-                    c.__module__ = "clairs.model"
-            paths[key] = str(tmp_path / (key + ".pkl"))
-            torch.save({key: m}, paths[key])
-        finally:
-            for c, mod in saved.items():
-                c.__module__ = mod
+    paths = _pickle_models(tmp_path, aff_cls, neg_cls, K)
     pred = str(tmp_path / "pred.gz")
     args = Namespace(tensor_fn_acgt=str(tmp_path / "t_aff.gz"), tensor_fn_nacgt=str(tmp_path / "t_neg.gz"),
                      chkpnt_fn_acgt=paths["model_acgt"], chkpnt_fn_nacgt=paths["model_nacgt"], predict_fn=pred,
@@ -92,3 +98,39 @@ def test_predict_and_call_variants_cli(tmp_path, golden_region, mode, aff_cls, n
                                                  disable_indel_calling=(mode == "snv"), pileup=True, platform="ont"))
         rows = [r for r in open(vcf).read().split("\n") if r and not r.startswith("#")]
         assert rows == calls["vcf"]["show_ref" if show_ref else "default"]
+
+
+@pytest.mark.parametrize("mode,aff_cls,neg_cls", [("snv", "CvT", "BiGRU_NACGT"), ("indel", "CvT_Indel", "BiGRU_NACGT_Indel")])
+def test_pileup_call_one_invocation(tmp_path, golden_region, mode, aff_cls, neg_cls):
+    """The whole-chunk driver (BED + mpileup text + pickled checkpoints + likelihood table -> VCF, nothing but HBM in
+    between) against the VCF the REFERENCE wrote through its four commands: same records, field for field; QUAL / GQ may
+    move in the last digit because the probabilities differ by < 1e-4 before the 8-decimal rounding."""
+    from argparse import Namespace
+    from clairs_to_amd.pileup_call import pileup_call
+    calls = load_json_gz("calls_%s.json.gz" % mode)
+    K = calls["n_out"]
+    fa, bed, mp = _write_region(tmp_path, golden_region)
+    paths = _pickle_models(tmp_path, aff_cls, neg_cls, K)
+    lik = str(tmp_path / "lik.txt")
+    open(lik, "w").write(calls["likelihood_table"])
+    for show_ref in (False, True):
+        vcf, pred = str(tmp_path / ("one_%d.vcf" % show_ref)), str(tmp_path / ("pred_%d.gz" % show_ref))
+        n = pileup_call(Namespace(platform="ont", tumor_bam_fn=None, mpileup_fn=mp, ref_fn=fa, ctg_name="chr1", samtools="samtools",
+                                  min_bq=golden_region["min_bq_aff"], max_depth=None, max_indel_length=None,
+                                  candidates_bed_regions=bed, chkpnt_fn_acgt=paths["model_acgt"],
+                                  chkpnt_fn_nacgt=paths["model_nacgt"], min_rescale_cov=50, disable_indel_calling=(mode == "snv"),
+                                  likelihood_matrix_data=lik, call_fn=vcf, predict_fn=pred, sample_name="SAMPLE",
+                                  show_ref=show_ref, qual=0, pileup=True))
+        want = calls["vcf"]["show_ref" if show_ref else "default"]
+        got = [r for r in open(vcf).read().split("\n") if r and not r.startswith("#")] if n else []
+        assert n == len(want) == len(got)
+        for a, b in zip(got, want):
+            a, b = a.split("\t"), b.split("\t")
+            assert a[:5] == b[:5] and a[6:9] == b[6:9]
+            assert abs(float(a[5]) - float(b[5])) < 0.02
+            fa_, fb_ = a[9].split(":"), b[9].split(":")
+            assert fa_[0] == fb_[0] and fa_[2:] == fb_[2:] and abs(int(fa_[1]) - int(fb_[1])) <= 1
+        # the debugging tap writes the same rows as the predict mirror / the reference (non-probability fields identical)
+        rows = [r.split("\t") for r in gzip.open(pred, "rt").read().split("\n") if r]
+        ref_rows = [r.split("\t") for r in calls["predict_rows"].split("\n") if r]
+        assert [r[:6] for r in rows] == [r[:6] for r in ref_rows]
