@@ -1,5 +1,6 @@
 // BiGRU recurrent kernel (template only: safe to include from several translation units).
 #pragma once
+#include <type_traits>
 #include "mfma_common.h"
 
 namespace cto {
@@ -40,7 +41,7 @@ template <int KIN, int KP, int H, int MS, int MH, bool FUSE_FC1>
 __global__ __launch_bounds__(256 * MH) void k_gru_layer(const float* __restrict__ x, const float* __restrict__ Wcat,
                                                    const float* __restrict__ bias, float* __restrict__ out,
                                                    const float* __restrict__ fc1w, float* __restrict__ fc1_part, int B) {
-    constexpr int NB = H / 64, T = 33, KT = KP + H, HS = H + 4, NX = KP / 16, NH = H / 16, NC = NX + NH;
+    constexpr int NB = H / 64, T = 33, KT = KP + H + GRU_WPAD, HS = H + 4, NX = KP / 16, NH = H / 16, NC = NX + NH;
     constexpr int FC1_K = T * 2 * H;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TILE = MH * MS * 16, NTHR = 256 * MH;
@@ -297,6 +298,321 @@ __global__ __launch_bounds__(256 * MH) void k_gru_layer(const float* __restrict_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int site = site0 + rb + ms * 16 + kg * 4 + r;
+                    if (site < B) part[int64_t(site) * 128 + wave * 32 + nt * 16 + j] = accf[ms][nt][r];
+                }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Rotated schedule of the same recurrence (one wave per SIMD, MH = 1): the x part of step t+1 does not depend on
+// h_t, so it is computed *after* the h part of step t, in the same instruction stream as the gate arithmetic of
+// step t - the VALU / transcendental work of the gates (and the publication of h_t) then runs in the shadow of
+// MFMAs instead of leaving the matrix pipe idle between the last chunk of a step and the barrier.
+//     prologue : x_0, x_1 -> LDS;  (r, z, n_x) <- bias + x_0 W_ih^T
+//     step t   : barrier;  fetch x_{t+2};  (r, z, n_h) += h_{t-1} W_hh^T  [+ fused fc1 on h_{t-1}];
+//                (r', z', n_x') <- bias + x_{t+1} W_ih^T  interleaved with  gates(t) -> h_t -> LDS;  commit x_{t+2}
+// Chunk sequence inside a step: h chunks NX..NC-1, then x chunks 0..NX-1 of the next step.
+// --------------------------------------------------------------------------------------------
+#ifdef CTO_GRU_CLOCKS
+__device__ long long g_gru_clk[8];
+#endif
+template <int KIN, int KP, int H, int MS, bool FUSE_FC1>
+__global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__ x, const float* __restrict__ Wcat,
+                                                       const float* __restrict__ bias, float* __restrict__ out,
+                                                       const float* __restrict__ fc1w, float* __restrict__ fc1_part, int B) {
+    constexpr int NB = H / 64, T = 33, KT = KP + H + GRU_WPAD, HS = H + 4, NX = KP / 16, NH = H / 16, NC = NX + NH, NP = MS * NB;
+    constexpr int FC1_K = T * 2 * H;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TILE = MS * 16, NTHR = 256;
+    constexpr int XS = KP + 4;
+    constexpr bool XV = (KIN % 4 == 0);
+    constexpr int XQ = XV ? TILE * (KIN / 4) : TILE * KIN;
+    constexpr int XPER = (XQ + NTHR - 1) / NTHR;
+    float* hbuf = smem;                       // [2][TILE][HS]
+    float* xbuf = smem + 2 * TILE * HS;       // [2][TILE][XS]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kg = lane >> 4;
+    const int dir = blockIdx.x & 1;
+    const int site0 = (blockIdx.x >> 1) * TILE;
+    const float* Wd = Wcat + int64_t(dir) * 3 * H * KT;
+    const float* bd = bias + dir * 4 * H;
+    auto t_of = [&](int step) { return dir == 0 ? step : T - 1 - step; };
+#ifdef CTO_GRU_CLOCKS
+    const long long c0 = clock64(), w0 = wall_clock64();
+#endif
+
+    for (int i = threadIdx.x; i < TILE * HS; i += NTHR) hbuf[i] = 0.f;       // h_{-1} = 0
+    for (int i = threadIdx.x; i < 2 * TILE * XS; i += NTHR) xbuf[i] = 0.f;   // K padding and rows past the batch stay 0
+
+    float bia[NB][4];
+    const float* wrow[NB][3];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int hcol = (wave * NB + nb) * 16 + j;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bia[nb][q] = bd[q * H + hcol];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) wrow[nb][q] = Wd + int64_t(q * H + hcol) * KT + 4 * kg;
+    }
+    const float* frow[2] = {nullptr, nullptr};
+    if constexpr (FUSE_FC1) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) frow[nt] = fc1w + int64_t(wave * 32 + nt * 16 + j) * FC1_K + dir * H + 4 * kg;
+    }
+    float hprev[MS][NB][4];
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hprev[ms][nb][r] = 0.f;
+    f32x4 accf[MS][2];
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) { accf[ms][0] = f32x4{0.f, 0.f, 0.f, 0.f}; accf[ms][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    float4 xstage[XPER];
+    auto x_fetch = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < XPER; ++q) {
+            const int u = threadIdx.x + q * NTHR;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u < XQ) {
+                if constexpr (XV) {
+                    const int row = u / (KIN / 4), c4 = (u - row * (KIN / 4)) * 4;
+                    if (site0 + row < B) v = *reinterpret_cast<const float4*>(x + (int64_t(site0 + row) * T + t) * KIN + c4);
+                } else {
+                    const int row = u / KIN, c = u - row * KIN;
+                    if (site0 + row < B) v.x = x[(int64_t(site0 + row) * T + t) * KIN + c];
+                }
+            }
+            xstage[q] = v;
+        }
+    };
+    auto x_commit = [&](int buf) {
+        float* xb = xbuf + buf * (TILE * XS);
+#pragma unroll
+        for (int q = 0; q < XPER; ++q) {
+            const int u = threadIdx.x + q * NTHR;
+            if (u < XQ) {
+                if constexpr (XV) {
+                    const int row = u / (KIN / 4), c4 = (u - row * (KIN / 4)) * 4;
+                    *reinterpret_cast<float4*>(xb + row * XS + c4) = xstage[q];
+                } else {
+                    const int row = u / KIN, c = u - row * KIN;
+                    xb[row * XS + c] = xstage[q].x;
+                }
+            }
+        }
+    };
+
+    float4 Bq[2][NB][3], Fq[2][2], Aq[2][MS];
+    int opq = 0;
+    auto load_B = [&](int buf, int c) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) Bq[buf][nb][q] = *reinterpret_cast<const float4*>(wrow[nb][q] + c * 16 + opq);
+    };
+    auto load_F = [&](int buf, int kh, int tprev) {
+        if constexpr (FUSE_FC1) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                Fq[buf][nt] = *reinterpret_cast<const float4*>(frow[nt] + tprev * (2 * H) + kh * 16);
+        }
+    };
+    auto load_Ax = [&](int buf, int c, const float* xc) {
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+            Aq[buf][ms] = *reinterpret_cast<const float4*>(xc + (ms * 16 + j) * XS + c * 16 + 4 * kg);
+    };
+    auto load_Ah = [&](int buf, int kh, const float* hc) {
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+            Aq[buf][ms] = *reinterpret_cast<const float4*>(hc + (ms * 16 + j) * HS + kh * 16 + 4 * kg);
+    };
+
+    f32x4 ar[MS][NB], az[MS][NB], ain[MS][NB], ahn[MS][NB];     // gates of the current step
+    f32x4 nr[MS][NB], nz[MS][NB], nn[MS][NB];                   // x part of the next step, in the making
+    auto init_x = [&](f32x4 (&r_)[MS][NB], f32x4 (&z_)[MS][NB], f32x4 (&n_)[MS][NB]) {
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                r_[ms][nb] = f32x4{bia[nb][0], bia[nb][0], bia[nb][0], bia[nb][0]};
+                z_[ms][nb] = f32x4{bia[nb][1], bia[nb][1], bia[nb][1], bia[nb][1]};
+                n_[ms][nb] = f32x4{bia[nb][2], bia[nb][2], bia[nb][2], bia[nb][2]};
+            }
+    };
+    // one 16-wide k chunk: three gate accumulators per (ms, nb)
+    auto mfma_chunk = [&](int cur, f32x4 (&r_)[MS][NB], f32x4 (&z_)[MS][NB], f32x4 (&n_)[MS][NB]) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const float4 br = Bq[cur][nb][0], bz = Bq[cur][nb][1], bn = Bq[cur][nb][2];
+            const float brv[4] = {br.x, br.y, br.z, br.w}, bzv[4] = {bz.x, bz.y, bz.z, bz.w}, bnv[4] = {bn.x, bn.y, bn.z, bn.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int ms = 0; ms < MS; ++ms) {
+                    const float4 a4 = Aq[cur][ms];
+                    const float av = e == 0 ? a4.x : (e == 1 ? a4.y : (e == 2 ? a4.z : a4.w));
+                    r_[ms][nb] = mfma16(av, brv[e], r_[ms][nb]);
+                    z_[ms][nb] = mfma16(av, bzv[e], z_[ms][nb]);
+                    n_[ms][nb] = mfma16(av, bnv[e], n_[ms][nb]);
+                }
+            }
+        }
+    };
+    auto fc1_chunk = [&](int cur) {
+        if constexpr (FUSE_FC1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int ms = 0; ms < MS; ++ms) {
+                        const float4 a4 = Aq[cur][ms], f4 = Fq[cur][nt];
+                        const float av = e == 0 ? a4.x : (e == 1 ? a4.y : (e == 2 ? a4.z : a4.w));
+                        const float fv = e == 0 ? f4.x : (e == 1 ? f4.y : (e == 2 ? f4.z : f4.w));
+                        accf[ms][nt] = mfma16(av, fv, accf[ms][nt]);
+                    }
+        }
+    };
+    // gates + state update of one (ms, nb) pair (lane-local), publish that slice of h_t
+    auto gate_pair = [&](int ms, int nb, float* hn, int t) {
+        const int hcol = (wave * NB + nb) * 16 + j;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float rg = fast_sigmoid(ar[ms][nb][r]);
+            const float zg = fast_sigmoid(az[ms][nb][r]);
+            const float ng = fast_tanh(ain[ms][nb][r] + rg * ahn[ms][nb][r]);
+            const float hv = ng + zg * (hprev[ms][nb][r] - ng);      // (1 - z) * n + z * h
+            hprev[ms][nb][r] = hv;
+            const int row = ms * 16 + kg * 4 + r;
+            hn[row * HS + hcol] = hv;
+            if constexpr (!FUSE_FC1) {
+                const int site = site0 + row;
+                if (site < B) out[(int64_t(site) * T + t) * (2 * H) + dir * H + hcol] = hv;
+            }
+        }
+    };
+
+    // ---- prologue ----
+    constexpr int P0 = NX & 1;          // buffer parity such that the weights of the first h chunk land in buffer 0
+    x_fetch(t_of(0));
+    __syncthreads();                    // zero fill complete
+    x_commit(0);
+    x_fetch(t_of(1));
+    x_commit(1);
+    load_B(P0, 0);
+    __syncthreads();
+    load_Ax(P0, 0, xbuf);
+    init_x(ar, az, ain);
+#pragma unroll
+    for (int c = 0; c < NX; ++c) {
+        const int cur = (c + P0) & 1, nxt = cur ^ 1;
+        if (c + 1 < NX) { load_B(nxt, c + 1); load_Ax(nxt, c + 1, xbuf); }
+        else { load_B(nxt, NX); load_F(0, 0, t_of(0)); }
+        mfma_chunk(cur, ar, az, ain);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    auto step_body = [&](int step, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const int t = t_of(step);
+        const int tprev = step == 0 ? t : t_of(step - 1);          // step 0: h = 0, any valid slice will do
+        static_assert(!FUSE_FC1 || (NC % 2 == 0), "the fc1 prefetch across the step boundary assumes an even chunk count");
+        const int cur_h = step & 1;
+        const float* hc = hbuf + cur_h * (TILE * HS);
+        float* hn = hbuf + (cur_h ^ 1) * (TILE * HS);
+        const float* xnx = xbuf + ((step + 1) & 1) * (TILE * XS);   // x_{t+1}
+        opq = 0;
+        asm volatile("" : "+v"(opq));      // keeps the (step-invariant) weight loads inside the time loop
+        __syncthreads();                   // h_{t-1} and x_{t+1} are complete
+        if (step + 2 < T) x_fetch(t_of(step + 2));
+        load_Ah(0, 0, hc);
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) ahn[ms][nb] = f32x4{bia[nb][3], bia[nb][3], bia[nb][3], bia[nb][3]};
+        if constexpr (!LAST) init_x(nr, nz, nn);
+#pragma unroll
+        for (int sq = 0; sq < (LAST ? NH : NC); ++sq) {
+            const int cur = sq & 1, nxt = cur ^ 1;
+            // ---- request the operands of the next chunk in the sequence ----
+            if (sq + 1 < NH) {
+                load_B(nxt, NX + sq + 1);
+                load_Ah(nxt, sq + 1, hc);
+                load_F(nxt, sq + 1, tprev);
+            } else if (!LAST) {
+                if (sq + 1 < NC) { load_B(nxt, sq + 1 - NH); load_Ax(nxt, sq + 1 - NH, xnx); }
+                else { load_B(nxt, NX); load_F(0, 0, t); }     // first h chunk of the next step (its fc1 slice is that of h_t)
+            }
+            if (sq < NH) {
+                mfma_chunk(cur, ar, az, ahn);
+                fc1_chunk(cur);
+            } else {
+                mfma_chunk(cur, nr, nz, nn);
+                // gate arithmetic of step t, spread over the x chunks of step t+1
+#pragma unroll
+                for (int pq = 0; pq < NP; ++pq)
+                    if ((pq * NX) / NP == sq - NH) gate_pair(pq / NB, pq % NB, hn, t);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (LAST) {
+#pragma unroll
+            for (int pq = 0; pq < NP; ++pq) gate_pair(pq / NB, pq % NB, hn, t);
+        } else {
+            if (step + 2 < T) x_commit(step & 1);          // x_{t+2} replaces x_t
+            if constexpr ((NC & 1) != 0) {   // odd chunk count: the next step's first weights landed in buffer 1
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) Bq[0][nb][q] = Bq[1][nb][q];
+            }
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) { ar[ms][nb] = nr[ms][nb]; az[ms][nb] = nz[ms][nb]; ain[ms][nb] = nn[ms][nb]; }
+        }
+    };
+    for (int step = 0; step + 1 < T; ++step) step_body(step, std::false_type{});
+    step_body(T - 1, std::true_type{});
+#ifdef CTO_GRU_CLOCKS
+    if (blockIdx.x == 7 && threadIdx.x == 0) {
+        const int o = FUSE_FC1 ? 4 : 0;
+        g_gru_clk[o] = clock64() - c0; g_gru_clk[o + 1] = wall_clock64() - w0;
+    }
+#endif
+
+    if constexpr (FUSE_FC1) {
+        // fc1 contribution of the last state, then one partial slab per direction
+        __syncthreads();
+        const float* hl = hbuf + (T & 1) * (TILE * HS);
+        const int tl = t_of(T - 1);
+#pragma unroll
+        for (int kh = 0; kh < NH; ++kh) {
+            load_Ah(0, kh, hl);
+            load_F(0, kh, tl);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int ms = 0; ms < MS; ++ms) {
+                    const float4 a = Aq[0][ms], f = Fq[0][nt];
+                    accf[ms][nt] = mfma16(a.x, f.x, accf[ms][nt]);
+                    accf[ms][nt] = mfma16(a.y, f.y, accf[ms][nt]);
+                    accf[ms][nt] = mfma16(a.z, f.z, accf[ms][nt]);
+                    accf[ms][nt] = mfma16(a.w, f.w, accf[ms][nt]);
+                }
+        }
+        float* part = fc1_part + int64_t(dir) * B * 128;
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int site = site0 + ms * 16 + kg * 4 + r;
                     if (site < B) part[int64_t(site) * 128 + wave * 32 + nt * 16 + j] = accf[ms][nt][r];
                 }
     }

@@ -15,6 +15,12 @@ namespace cto {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+// Row padding (floats) of the packed GRU weight matrices [3H][KP + H + pad]: see gru_kernel.h
+#ifndef CTO_GRU_WPAD
+#define CTO_GRU_WPAD 32
+#endif
+constexpr int GRU_WPAD = CTO_GRU_WPAD;
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

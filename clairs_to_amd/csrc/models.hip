@@ -424,7 +424,7 @@ int bigru_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStr
 // [W_ih | W_hh] per gate row, W_ih zero-padded to KP; bias rows: r (b_ir + b_hr), z (b_iz + b_hz), b_in, b_hn
 int pack_gru(const cto_weights* w, const std::string& base, int kin, int kp, int H, Arena& a, float** Wout, float** bout) {
     int rc = CTO_OK;
-    const int KT = kp + H;
+    const int KT = kp + H + GRU_WPAD;
     std::vector<float> W(size_t(2) * 3 * H * KT, 0.f), bv(size_t(2) * 4 * H);
     for (int d = 0; d < 2; ++d) {
         const std::string sfx = d == 0 ? "" : "_reverse";
