@@ -28,13 +28,13 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32
 
 def pmc_traffic(batch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
-    profiles/round1_d_pmc_hbm_traffic.json, collected at batch 4096); None for any other batch."""
-    fn = os.path.join(ROOT, "profiles", "round1_d_pmc_hbm_traffic.json")
+    profiles/round1_f_pmc_hbm_traffic.json, collected at batch 4096); None for any other batch."""
+    fn = os.path.join(ROOT, "profiles", "round1_f_pmc_hbm_traffic.json")
     if batch != 4096 or not os.path.exists(fn):
         return None
     k = json.load(open(fn))["kernels"]
     for name, v in k.items():
-        if "k_gru_layer<256" in name:
+        if "k_gru_layer" in name and "<256" in name:
             return int((v["FETCH_SIZE_KB_mean_per_launch"] + v["WRITE_SIZE_KB_mean_per_launch"]) * 1024)
     return None
 
@@ -184,10 +184,10 @@ def main():
                        "pack_bytes_per_chunk": int(pack_bytes),
                        "parallelism": "sites sharded, 1 rank/GPU" + (", all_gather of per-site probabilities (RCCL)" if world > 1 else ""),
                        "weights": "seeded random init (no pretrained weights offline)"},
-            "roofline": {"bound": "mfma", "kernel": "k_gru_layer<256,256,192,2,1,true> (BiGRU layer 2 + fused fc1, both directions)",
+            "roofline": {"bound": "mfma", "kernel": "k_gru_layer_rot<256,256,192,2,true> (BiGRU layer 2 + fused fc1, both directions)",
                          "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(args.batch),
-                         "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/round1_d_pmc_hbm_traffic.json)",
+                         "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/round1_f_pmc_hbm_traffic.json)",
                          "launch_ms": round(mean_ms.value, 4), "launches_measured": int(n_meas),
                          "flops_per_launch": flops_per_launch},
             "end_to_end_tflops": round(2.0 * eng.macs_per_site * sites_total / dt / 1e12, 3),

@@ -1,3 +1,5 @@
+"""Average shader clock during the BiGRU kernels (s_memtime / s_memrealtime).  Needs a library built with
+   make -C clairs_to_amd/csrc clean all CXXFLAGS="... -DCTO_GRU_CLOCKS" (debug probe, compiled out by default)."""
 import os, sys, ctypes as C
 sys.path.insert(0, os.getcwd())
 import torch, numpy as np

@@ -1,0 +1,67 @@
+"""Digest of a tools/collect_profiles.sh run -> the small files kept under profiles/ (run on either box)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def find(d, suffix):
+    fs = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+    return fs[0] if fs else None
+
+
+def main():
+    out, tag = sys.argv[1], sys.argv[2]
+    dst = os.path.join(out, "digest")
+    os.makedirs(dst, exist_ok=True)
+    for name in ("default", "short"):
+        st = find(os.path.join(out, name), "kernel_stats.csv")
+        if st:
+            open(os.path.join(dst, "round1_%s_%s_bench_kernel_stats.csv" % (tag, name)), "w").write(open(st).read())
+        js = os.path.join(out, name + "_bench.json")
+        if os.path.exists(js):
+            lines = [l for l in open(js).read().split("\n") if l.startswith("{")]
+            if lines:
+                open(os.path.join(dst, "round1_%s_%s_bench.json" % (tag, name)), "w").write(lines[-1] + "\n")
+    # one step's launch timeline from the short run's kernel trace
+    tr = find(os.path.join(out, "short"), "kernel_trace.csv")
+    if tr:
+        rows = list(csv.DictReader(open(tr)))
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        names = [r["Kernel_Name"] for r in rows]
+        # last occurrence of the first kernel of a step (featurize) marks the last step
+        starts = [i for i, n in enumerate(names) if "k_featurize_columns" in n]
+        if len(starts) >= 2:
+            a, b = starts[-2], starts[-1]
+            t0 = int(rows[a]["Start_Timestamp"])
+            with open(os.path.join(dst, "round1_%s_step_timeline.txt" % tag), "w") as f:
+                f.write("# one step of bench.py (launch order): start us, duration us, kernel\n")
+                for r in rows[a:b]:
+                    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+                    f.write("%9.1f %9.1f  %s\n" % ((s - t0) / 1e3, (e - s) / 1e3, r["Kernel_Name"][:120]))
+    # PMC passes
+    kern = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        fn = find(os.path.join(out, "pmc_" + c), "counter_collection.csv")
+        if not fn:
+            continue
+        acc = {}
+        for r in csv.DictReader(open(fn)):
+            if r["Counter_Name"] != c:
+                continue
+            acc.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            d = kern.setdefault(k, {})
+            d[c + "_KB_mean_per_launch"] = round(sum(v) / len(v), 1)
+            d["launches"] = len(v)
+    if kern:
+        note = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 3 "
+                "--warmup 1 --no-cpu-baseline`, batch 4096; raw counter values in KB (calibrated 1.0x on known byte counts of "
+                "these access patterns, see profiles/README.md).")
+        json.dump(dict(note=note, kernels=kern), open(os.path.join(dst, "round1_%s_pmc_hbm_traffic.json" % tag), "w"), indent=1)
+    print("digest:", sorted(os.listdir(dst)))
+
+
+if __name__ == "__main__":
+    main()
