@@ -7,6 +7,8 @@
 //   alt_info            :158-209
 // Written from the behaviour, not from the text, of those lines.
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <thread>
@@ -89,10 +91,17 @@ namespace {
 // Parses the rows in [text, text + len) into `p` (offsets local to p).  Thread-safe: no shared state.
 int parse_rows(const char* text, size_t len, const char* ref_seq, int64_t ref_start, size_t ref_len, int max_indel_length,
                cto_pack* p, std::string* err) {
+    // one read-base is >= 3 characters of a row (base, BQ, MQ), one row >= ~40: reserve once instead of growing
+    p->entries.reserve(len / 3 + 16);
+    p->col_pos.reserve(len / 40 + 16);
+    p->col_ref.reserve(len / 40 + 16);
+    p->col_off.reserve(len / 40 + 17);
+    p->key_off.reserve(len / 40 + 17);
     p->col_off.push_back(0);
     p->key_off.push_back(0);
     p->key_str_off.push_back(0);
     std::vector<Tok> toks;
+    toks.reserve(1024);
     std::unordered_map<std::string, int> keymap, groupmap;
     std::string keybuf, groupbuf;
     const char* cur = text;
@@ -244,7 +253,8 @@ extern "C" int cto_pack_from_mpileup(const char* text, size_t len, const char* r
     CTO_REQUIRE(text && ref_seq && out, CTO_EINVAL, "cto_pack_from_mpileup: null argument");
     // rows are independent: split the text at line boundaries and tokenise the pieces on several host threads
     unsigned nt = std::thread::hardware_concurrency();
-    nt = std::max(1u, std::min(nt, 16u));
+    nt = std::max(1u, std::min(nt, 32u));     // scales to ~3.9 GB/s of text at 32 threads (tools/tokenise_bench.py)
+    if (const char* e = getenv("CTO_PACK_THREADS")) nt = std::max(1u, std::min(unsigned(atoi(e)), 64u));
     if (len < (size_t(1) << 22)) nt = 1;
     std::vector<size_t> cut(nt + 1, len);
     cut[0] = 0;
@@ -260,6 +270,8 @@ extern "C" int cto_pack_from_mpileup(const char* text, size_t len, const char* r
         parts[t].reset(new cto_pack());
         rcs[t] = parse_rows(text + cut[t], cut[t + 1] - cut[t], ref_seq, ref_start, ref_len, max_indel_length, parts[t].get(), &errs[t]);
     };
+    const bool timing = getenv("CTO_PACK_TIMING") != nullptr;
+    const auto T0 = std::chrono::steady_clock::now();
     if (nt == 1) {
         work(0);
     } else {
@@ -267,6 +279,7 @@ extern "C" int cto_pack_from_mpileup(const char* text, size_t len, const char* r
         for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, t);
         for (auto& x : th) x.join();
     }
+    const auto T1 = std::chrono::steady_clock::now();
     for (unsigned t = 0; t < nt; ++t)
         if (rcs[t] != CTO_OK) { cto::set_error("%s", errs[t].c_str()); return rcs[t]; }
     std::unique_ptr<cto_pack> p(parts[0].release());
@@ -290,6 +303,10 @@ extern "C" int cto_pack_from_mpileup(const char* text, size_t len, const char* r
         p->key_str += q.key_str;
         parts[t].reset();
     }
+    if (timing)
+        fprintf(stderr, "cto_pack_from_mpileup: %u threads, parse %.1f ms, merge %.1f ms\n", nt,
+                std::chrono::duration<double, std::milli>(T1 - T0).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T1).count());
     *out = p.release();
     return CTO_OK;
 }

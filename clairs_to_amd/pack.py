@@ -81,8 +81,20 @@ class ColumnPack:
         return DevicePack(self.numpy(), device, host=self)
 
 
+def pin_arrays(arrays):
+    """Copies of the pack arrays in page-locked host memory (torch tensors), for asynchronous uploads.  A producer that
+    fills such buffers directly (instead of copying into them) gets the PCIe transfer fully off the critical path."""
+    out = {}
+    for k, dt in _FIELDS:
+        a = np.ascontiguousarray(arrays[k], dtype=dt)
+        t = torch.from_numpy(a.view(np.int32) if dt == np.uint32 else a.copy() if a.size == 0 else a)
+        out[k] = t.pin_memory()
+    return out
+
+
 class DevicePack:
-    """The pack arrays resident in HBM (torch owns the memory) plus the cto_pack_view of device pointers."""
+    """The pack arrays resident in HBM (torch owns the memory) plus the cto_pack_view of device pointers.
+    arrays: numpy arrays (synchronous upload) or the pinned tensors of `pin_arrays` (asynchronous, on the current stream)."""
 
     def __init__(self, arrays, device="cuda", host=None):
         self.host = host
@@ -91,6 +103,9 @@ class DevicePack:
             raise RuntimeError("clairs_to_amd: the featurisation kernels need a HIP device; there is no CPU fallback")
         self.t = {}
         for k, dt in _FIELDS:
+            if isinstance(arrays[k], torch.Tensor):
+                self.t[k] = arrays[k].to(self.device, non_blocking=True)
+                continue
             a = np.ascontiguousarray(arrays[k], dtype=dt)
             # torch has no uint32: carry the bits in int32
             t = torch.from_numpy(a.view(np.int32) if dt == np.uint32 else a.copy() if a.size == 0 else a)

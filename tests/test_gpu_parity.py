@@ -342,3 +342,27 @@ def test_c_abi_error_codes(dev):
     assert lib.cto_cvt_create(w, C.byref(cfg), C.byref(out)) == -4                                       # CTO_EUNSUPPORTED
     lib.cto_weights_free(w)
     assert lib.cto_posterior(None, None, 4, 1, None, None, None, None, None, None, None) == -1
+
+
+def test_run_stream_matches_run_device(dev):
+    """Host buffers in / host results out with uploads on a copy stream: same numbers as the resident path, chunk order kept,
+    pageable and pinned inputs alike."""
+    import torch
+    from clairs_to_amd.engine import Engine, synthetic_models
+    from clairs_to_amd.pack import pin_arrays
+    from clairs_to_amd.synth import SynthChunk, likelihood_table, lik_and_edges
+    models = synthetic_models(4)
+    lik, edges = lik_and_edges(likelihood_table(4), 4)
+    eng = Engine(models["aff"], models["neg"], lik, edges, min_bq=20, device=dev)
+    chunks = [SynthChunk(n, seed=40 + i) for i, n in enumerate((300, 17, 512, 64, 129))]
+    want = []
+    for ch in chunks:
+        r = eng.run_chunk(ch.arrays(), ch.site_pos)
+        want.append({k: r[k].cpu().numpy() for k in ("probs", "post", "decision", "qual")})
+    for pinned in (False, True):
+        feed = ((pin_arrays(ch.arrays()) if pinned else ch.arrays(), ch.site_pos) for ch in chunks)
+        got = list(eng.run_stream(feed, depth=2))
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            for k in w:
+                np.testing.assert_array_equal(g[k], w[k])

@@ -66,6 +66,17 @@ def main():
     res["neg_tflops"] = gf_neg / res["neg_ms"]
     res["all_tflops"] = (gf_aff + gf_neg) / res["all_ms"]
     res["sites_per_s"] = B / res["all_ms"] * 1e3
+    # PCIe-inclusive: host packs in, host results out (Engine.run_stream), pageable vs pinned host buffers
+    from clairs_to_amd.pack import pin_arrays
+    n_chunks = max(8, a.reps)
+    for tag, arrs in (("pageable", ch.arrays()), ("pinned", pin_arrays(ch.arrays()))):
+        for _ in eng.run_stream(((arrs, ch.site_pos) for _ in range(3))):
+            pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = sum(1 for _ in eng.run_stream(((arrs, ch.site_pos) for _ in range(n_chunks))))
+        dt = time.perf_counter() - t0
+        res["pcie_%s_sites_per_s" % tag] = n * B / dt
     print({k: round(v, 4) for k, v in res.items()})
 
 
