@@ -112,10 +112,14 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # test hooks (never set by the driver): run several ranks on ONE GPU over gloo to exercise the multi-rank code path
+    backend = os.environ.get("CTO_BENCH_BACKEND", "nccl")
+    if "CTO_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["CTO_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(backend, device_id=dev) if backend == "nccl" else dist.init_process_group(backend)
 
     from clairs_to_amd._lib import lib, check
     from clairs_to_amd.engine import Engine, synthetic_models
@@ -135,15 +139,25 @@ def main():
         packs.append(eng.upload(ch.arrays()))
         sites.append(torch.from_numpy(ch.site_pos).to(dev))
     pack_bytes = sum(p.nbytes() for p in packs) / len(packs)
-    gather_buf = torch.empty((world, args.batch, 2 * N_OUT, 2), dtype=torch.float32, device=dev) if world > 1 else None
+    # per-site outputs go to every rank over xGMI (262 KB per rank and step).  The gather is asynchronous and double-buffered:
+    # it runs on RCCL's stream under the next step's kernels and is only waited for when its buffer comes up for reuse.
+    gather_buf = [torch.empty((world * args.batch, 2 * N_OUT, 2), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None   # rank-major = genomic order
+    pending = [None, None]
 
     def step(i):
         out = eng.run_device(packs[i % args.pool], sites[i % args.pool])
         if world > 1:
-            dist.all_gather_into_tensor(gather_buf, out["probs"])     # per-site outputs to every rank over xGMI
+            if pending[i & 1] is not None:
+                pending[i & 1][0].wait()
+            pending[i & 1] = (dist.all_gather_into_tensor(gather_buf[i & 1], out["probs"], async_op=True), out["probs"])
         return out
 
     def sync():
+        if world > 1:
+            for k in (0, 1):
+                if pending[k] is not None:
+                    pending[k][0].wait()
+                    pending[k] = None
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
