@@ -311,6 +311,30 @@ extern "C" int cto_gather_windows(const cto_pack_view* dp, const int16_t* colvec
     return CTO_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(1024) void k_poison_lds() {
+    extern __shared__ unsigned int lds_all[];
+    for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 1024) lds_all[i] = 0x7fa00000u + unsigned(i & 0xffff);   // NaN payloads
+    __syncthreads();
+    if (lds_all[threadIdx.x] == 1u) __builtin_trap();    // keeps the stores alive
+}
+}  // namespace
+
+extern "C" int cto_debug_poison_lds(void* stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_poison_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    int dev = 0, cus = 0;
+    CTO_HIP(hipGetDevice(&dev));
+    CTO_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    // one 160 KB workgroup occupies a whole CU; a few rounds make sure every CU is visited
+    hipLaunchKernelGGL(k_poison_lds, dim3(unsigned(cus) * 4), dim3(1024), 160 * 1024, static_cast<hipStream_t>(stream));
+    CTO_HIP(hipGetLastError());
+    return CTO_OK;
+}
+
 extern "C" int cto_device_count(void) {
     int n = 0;
     CTO_HIP(hipGetDeviceCount(&n));

@@ -87,7 +87,10 @@ struct cto_model {
     // workspace
     int64_t ws_B = 0;
     std::vector<void*> ws_ptrs;
-    bool fuse_blocks = true;   // CvT: fused transformer-block kernel where the stage geometry allows (CTO_CVT_UNFUSED=1 disables)
+    // CvT fusion levels, read from the environment when the model is created (debugging / A-B testing):
+    bool fuse_blocks = true;   // fused transformer-block kernel where the stage geometry allows (CTO_CVT_UNFUSED=1 disables)
+    bool fuse_embed = true;    // stage embedding + LayerNorm inside the stage's first block (CTO_CVT_NO_EMBED_FUSE=1 disables)
+    bool fuse_head = true;     // fc1 + classifier tail inside the network's last block (CTO_CVT_NO_HEAD_FUSE=1 disables)
     // live kernel timing (cto_model_profile)
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
@@ -349,9 +352,7 @@ int cvt_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStrea
         // reads the previous stage's output (another per-site layout) while other workgroups already write this stage's.
         float* hbuf = (si & 1) ? m->b_h2 : m->b_h;
         // conv embedding (3-tap stride 2) + channel LayerNorm: inside the stage's first block when that is fused
-        static const bool no_embed = [] { const char* e = getenv("CTO_CVT_NO_EMBED_FUSE"); return e && e[0] == '1'; }();
-        static const bool no_head = [] { const char* e = getenv("CTO_CVT_NO_HEAD_FUSE"); return e && e[0] == '1'; }();
-        const bool embed_in_block = m->fuse_blocks && !no_embed && can_fuse_embed(st);
+        const bool embed_in_block = m->fuse_blocks && m->fuse_embed && can_fuse_embed(st);
         if (!embed_in_block) {
             if ((rc = launch_gemm(s, in, 0, st.wemb, 3 * st.cin, st.bemb, nullptr, 0, m->b_t, C, M, C, 3 * st.cin, ACT_NONE,
                                   st.win, st.w, st.cin)))
@@ -364,7 +365,7 @@ int cvt_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStrea
             if (m->fuse_blocks) {
                 BlockExtra ex;
                 const bool embed = embed_in_block && bi == 0;
-                const bool head = !no_head && si == 2 && bi + 1 == st.blocks.size() && can_fuse_head(st, m->head);
+                const bool head = m->fuse_head && si == 2 && bi + 1 == st.blocks.size() && can_fuse_head(st, m->head);
                 ex.xin = in; ex.st = &st; ex.head = &m->head; ex.logits = logits; ex.n_out = m->n_out;
                 const int fr = try_fused_block(s, st, b, hbuf, B, ex, embed, head);
                 if (fr < 0) return fr;
@@ -541,6 +542,8 @@ extern "C" int cto_cvt_create(const cto_weights* w, const cto_cvt_cfg* cfg, cto_
     macs += int64_t(k1) * 128 + int64_t(m->n_out) * (128 * 128 + 256);
     m->macs = macs;
     if (const char* e = getenv("CTO_CVT_UNFUSED")) m->fuse_blocks = !(e[0] == '1');
+    if (const char* e = getenv("CTO_CVT_NO_EMBED_FUSE")) m->fuse_embed = !(e[0] == '1');
+    if (const char* e = getenv("CTO_CVT_NO_HEAD_FUSE")) m->fuse_head = !(e[0] == '1');
     *out = m.release();
     return CTO_OK;
 }

@@ -283,33 +283,4 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ q, 
     }
 }
 
-// g[b][n] = SELU(sum_s slabs[s][b][n] + bias[n])  -- closes the split-K fc1 of the BiGRU head
-__global__ __launch_bounds__(256) void k_sum_bias_selu(const float* __restrict__ slabs, int S, int64_t slab,
-                                                       const float* __restrict__ bias, float* __restrict__ out,
-                                                       int64_t total, int N) {
-    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (i >= total) return;
-    float s = 0.f;
-    for (int z = 0; z < S; ++z) s += slabs[z * slab + i];
-    out[i] = selu_f(s + bias[i % N]);
-}
-
-// out[k][b][c] = SELU(sum_j u[b][k*128 + j] * W3[k][c][j] + b3[k][c])   (x_fc3 heads, clairs/model.py:250-253)
-__global__ __launch_bounds__(256) void k_fc3(const float* __restrict__ u, const float* __restrict__ W3,
-                                             const float* __restrict__ b3, float* __restrict__ out, int64_t B, int K) {
-    const int64_t b = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (b >= B) return;
-    for (int k = 0; k < K; ++k) {
-        const float* ur = u + (b * K + k) * 128;
-        const float u0 = ur[lane], u1 = ur[lane + 64];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const float* wr = W3 + (k * 2 + c) * 128;
-            const float s = wave_sum(u0 * wr[lane] + u1 * wr[lane + 64]);
-            if (lane == 0) out[(int64_t(k) * B + b) * 2 + c] = selu_f(s + b3[k * 2 + c]);
-        }
-    }
-}
-
 }  // namespace cto

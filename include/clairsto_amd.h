@@ -40,6 +40,10 @@ const char* cto_last_error(void);
 int cto_version(void);
 /* number of visible HIP devices, or a negative error code */
 int cto_device_count(void);
+/* Test aid: fills the LDS of every compute unit of the current device with signalling-NaN bit patterns (stream-ordered).
+ * Kernels that read LDS they did not write (e.g. padding columns multiplied by zero weights) then fail parity tests
+ * deterministically instead of depending on what the previous kernel left behind.  No reference counterpart. */
+int cto_debug_poison_lds(void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Column pack: the binary form of `samtools mpileup` rows that the featurisation kernels consume.

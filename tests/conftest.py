@@ -51,3 +51,15 @@ def oracle_lib():
     import oracle
     oracle.build()
     return oracle
+
+
+@pytest.fixture(autouse=True)
+def _poisoned_lds(request):
+    """Every GPU test starts on LDS full of NaN patterns (cto_debug_poison_lds): results must not depend on what an
+    earlier kernel left in shared memory."""
+    if request.node.get_closest_marker("gpu") is not None:
+        import torch
+        if torch.cuda.is_available():
+            from clairs_to_amd._lib import lib, check, current_stream_ptr
+            check(lib.cto_debug_poison_lds(current_stream_ptr()))
+    yield

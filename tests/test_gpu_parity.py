@@ -366,3 +366,46 @@ def test_run_stream_matches_run_device(dev):
         for g, w in zip(got, want):
             for k in w:
                 np.testing.assert_array_equal(g[k], w[k])
+
+
+@pytest.mark.parametrize("env", [{}, {"CTO_CVT_NO_EMBED_FUSE": "1"}, {"CTO_CVT_NO_HEAD_FUSE": "1"},
+                                 {"CTO_CVT_NO_EMBED_FUSE": "1", "CTO_CVT_NO_HEAD_FUSE": "1"}, {"CTO_CVT_UNFUSED": "1"}])
+@pytest.mark.parametrize("cls,K", [("CvT", 4), ("CvT_Indel", 6)])
+def test_cvt_fusion_levels_on_poisoned_lds(dev, oracle_lib, monkeypatch, env, cls, K):
+    """Every fusion level of the CvT (embedding in the first block, classifier in the last block, fused blocks only, fully
+    unfused) against the oracle, each forward preceded by a launch that fills every CU's LDS with NaN patterns: padding that is
+    only ever multiplied by zero weights must still be initialised."""
+    import torch
+    import oracle
+    from clairs_to_amd import nn_shims
+    from clairs_to_amd._lib import lib, check, current_stream_ptr
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    g = load_models_npz(cls)
+    w = make_weights(g["manifest"], seed=3)
+    m = nn_shims.from_state_dict(cls, w).to(dev)
+    rng = np.random.default_rng(5)
+    for B in (1, 16, 37, 300):
+        x = (rng.integers(-60, 60, size=(B, 33, 34)) * rng.random((B, 1, 1))).astype(np.float32)
+        check(lib.cto_debug_poison_lds(current_stream_ptr()))
+        got = m.logits(torch.from_numpy(x).to(dev)).cpu().numpy()
+        ref = oracle.cvt_forward(w, dict(CVT_CFG, n_out=K), x)
+        assert np.isfinite(got).all() and np.abs(got - ref).max() < 1e-4, (env, B)
+
+
+@pytest.mark.parametrize("cls,K", [("BiGRU_NACGT", 4), ("BiGRU_NACGT_Indel", 6)])
+def test_bigru_on_poisoned_lds(dev, oracle_lib, cls, K):
+    import torch
+    import oracle
+    from clairs_to_amd import nn_shims
+    from clairs_to_amd._lib import lib, check, current_stream_ptr
+    g = load_models_npz(cls)
+    w = make_weights(g["manifest"], seed=3)
+    m = nn_shims.from_state_dict(cls, w).to(dev)
+    rng = np.random.default_rng(6)
+    for B in (1, 33, 200):
+        x = (rng.integers(-60, 60, size=(B, 33, 34)) * rng.random((B, 1, 1))).astype(np.float32)
+        check(lib.cto_debug_poison_lds(current_stream_ptr()))
+        got = m.logits(torch.from_numpy(x).to(dev)).cpu().numpy()
+        ref = oracle.bigru_forward(w, K, x)
+        assert np.isfinite(got).all() and np.abs(got - ref).max() < 1e-4, B
