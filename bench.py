@@ -39,6 +39,17 @@ def pmc_traffic(batch):
     return None
 
 
+def pmc_traffic_featurize(batch):
+    fn = os.path.join(ROOT, "profiles", "round1_f_pmc_hbm_traffic.json")
+    if batch != 4096 or not os.path.exists(fn):
+        return None
+    tot = 0
+    for name, v in json.load(open(fn))["kernels"].items():
+        if "k_featurize_columns" in name or "k_gather_windows" in name:
+            tot += int((v["FETCH_SIZE_KB_mean_per_launch"] + v["WRITE_SIZE_KB_mean_per_launch"]) * 1024)
+    return tot or None
+
+
 def usable_cores():
     """Cores this process may really use: affinity mask, capped by the cgroup CPU quota when there is one."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -184,6 +195,21 @@ def main():
     flops_per_launch = 2.0 * macs.value * args.batch
     achieved = flops_per_launch / (mean_ms.value * 1e-3) / 1e12 if n_meas > 0 and mean_ms.value > 0 else 0.0
 
+    # ---- secondary roofline: pileup-tensor creation (HBM-bound stage), timed on its own after the timed region ----
+    from clairs_to_amd.featurize import featurize
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for i in range(2):
+        featurize(packs[i % args.pool], sites[i % args.pool], min_bq, 50)
+    ev[0].record()
+    n_feat = 8
+    for i in range(n_feat):
+        featurize(packs[i % args.pool], sites[i % args.pool], min_bq, 50)
+    ev[1].record()
+    torch.cuda.synchronize()
+    feat_ms = ev[0].elapsed_time(ev[1]) / n_feat
+    # algorithmic bytes: the pack once (4 B per read-base + column tables) + two fp32 [33][34] tensors per site
+    feat_bytes = pack_bytes + 2 * 33 * 34 * 4 * args.batch
+
     if rank == 0:
         sites_total = world * args.steps * args.batch
         res = {
@@ -204,6 +230,11 @@ def main():
                          "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/round1_f_pmc_hbm_traffic.json)",
                          "launch_ms": round(mean_ms.value, 4), "launches_measured": int(n_meas),
                          "flops_per_launch": flops_per_launch},
+            "roofline_tensor_creation": {"bound": "hbm", "kernel": "k_featurize_columns + k_gather_windows (both passes, rescale fused)",
+                                         "achieved": round(feat_bytes / (feat_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                         "frac": round(feat_bytes / (feat_ms * 1e-3) / 1e9 / 8000.0, 4), "launch_ms": round(feat_ms, 4),
+                                         "bytes_per_launch": int(feat_bytes), "traffic": pmc_traffic_featurize(args.batch),
+                                         "note": "LDS-atomic bound (about 50 read-bases of a column hit the same counter), not bandwidth bound; 5 % of the step"},
             "end_to_end_tflops": round(2.0 * eng.macs_per_site * sites_total / dt / 1e12, 3),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -20,6 +20,7 @@ constexpr int COLS_PER_WAVE = 16;
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int HSLOTS = 36;       // 34 channels + slot 34 = depth + 1 spare
 constexpr int INT_NONE = 0x7fffffff;
+constexpr int KFIRST_CAP = 256;  // distinct indel keys of one candidate column tracked in LDS by the window kernel
 
 struct PackDev {
     int64_t n_cols;
@@ -33,16 +34,15 @@ struct PackDev {
 };
 
 constexpr int KCAP = 128;   // distinct indel keys of one wave's 16 columns held in LDS; beyond that: global atomics
+constexpr int NCOPY = 4;    // privatised histograms per wave (copy = lane & 3): the ~50 read-bases of a column mostly
+                            // hit the same one or two counters, so a 64-lane LDS atomic would serialise ~25-fold
 
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_featurize_columns(
-    PackDev pk, int min_bq, int16_t* __restrict__ colvec, int32_t* __restrict__ coldepth,
-    int32_t* __restrict__ colfirst, uint32_t* __restrict__ keycnt, int32_t* __restrict__ keyfirst) {
-    __shared__ uint32_t s_hist[WAVES_PER_BLOCK][COLS_PER_WAVE][HSLOTS];
-    __shared__ int32_t s_first[WAVES_PER_BLOCK][COLS_PER_WAVE][8];   // [pass][A,C,G,T]
+    PackDev pk, int min_bq, int16_t* __restrict__ colvec, int32_t* __restrict__ coldepth, uint32_t* __restrict__ keycnt) {
+    __shared__ uint32_t s_hist[WAVES_PER_BLOCK][NCOPY][COLS_PER_WAVE][HSLOTS];
     __shared__ int64_t s_off[WAVES_PER_BLOCK][COLS_PER_WAVE + 1];
     __shared__ int32_t s_koff[WAVES_PER_BLOCK][COLS_PER_WAVE + 1];
     __shared__ uint32_t s_kcnt[WAVES_PER_BLOCK][KCAP];
-    __shared__ int32_t s_kfirst[WAVES_PER_BLOCK][KCAP][2];
     __shared__ int16_t s_out[WAVES_PER_BLOCK][COLS_PER_WAVE][CTO_COLVEC_STRIDE];
 
     const int lane = threadIdx.x & 63;
@@ -51,9 +51,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_featurize_columns(
     int ncol = 0;
     if (c0 < pk.n_cols) ncol = int(pk.n_cols - c0 < COLS_PER_WAVE ? pk.n_cols - c0 : COLS_PER_WAVE);
 
-    for (int i = lane; i < COLS_PER_WAVE * HSLOTS; i += 64) (&s_hist[w][0][0])[i] = 0u;
-    for (int i = lane; i < COLS_PER_WAVE * 8; i += 64) (&s_first[w][0][0])[i] = INT_NONE;
-    for (int i = lane; i < KCAP; i += 64) { s_kcnt[w][i] = 0u; s_kfirst[w][i][0] = INT_NONE; s_kfirst[w][i][1] = INT_NONE; }
+    for (int i = lane; i < NCOPY * COLS_PER_WAVE * HSLOTS; i += 64) (&s_hist[w][0][0][0])[i] = 0u;
+    for (int i = lane; i < KCAP; i += 64) s_kcnt[w][i] = 0u;
     if (lane <= COLS_PER_WAVE) {
         const int64_t ci = c0 + (lane < ncol ? lane : ncol);
         s_off[w][lane] = (ncol > 0) ? pk.col_off[ci] : 0;
@@ -63,6 +62,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_featurize_columns(
     const int kbase = s_koff[w][0];
     const int nkeys_w = s_koff[w][ncol] - kbase;
     const bool keys_in_lds = nkeys_w <= KCAP;     // wave-uniform
+    if (!keys_in_lds) {
+        // rare: the wave's keys do not fit its LDS table; it owns their global counters exclusively, zeroes them itself
+        for (int k = lane; k < nkeys_w; k += 64) keycnt[kbase + k] = 0u;
+        __threadfence();
+    }
 
     if (ncol > 0) {
         const int64_t e_begin = s_off[w][0];
@@ -70,11 +74,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_featurize_columns(
         int cl = 0;
         int64_t e = e_begin + lane;
         uint32_t ent = e < e_end ? pk.entries[e] : 0u;
+        uint32_t (*hc)[HSLOTS] = s_hist[w][lane & (NCOPY - 1)];
         while (e < e_end) {
             const int64_t en = e + 64;
             const uint32_t ent_next = en < e_end ? pk.entries[en] : 0u;   // next load flies under this iteration's atomics
             while (e >= s_off[w][cl + 1]) ++cl;
-            const int idx = int(e - s_off[w][cl]);
             const uint32_t b = ent & 15u;
             const uint32_t kind = (ent >> 4) & 3u;
             const int bq = int((ent >> 6) & 127u);
@@ -85,21 +89,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_featurize_columns(
             const bool acgt = b < 8u;
             const bool fwd = (b < 4u) || b == 8u || b == 10u;
             const bool mq_ok = mq >= 20;
-            uint32_t* h = s_hist[w][cl];
+            uint32_t* h = hc[cl];
             if (kind == 0u) {
                 if (mq_ok) {
                     int ch = -1;
                     if (acgt) ch = (b < 4u) ? int(b) : int(b) + 5;       // A..T -> 0..3, a..t -> 9..12
                     else if (b == 8u) ch = 8;                               // '*'
                     else if (b == 9u) ch = 17;                              // '#'
-                    if (ch >= 0) {
-                        atomicAdd(&h[ch], inc);
-                        atomicAdd(&h[34], inc);                             // depth
-                        if (acgt) {
-                            atomicMin(&s_first[w][cl][4 + (b & 3u)], idx);
-                            if (pass) atomicMin(&s_first[w][cl][b & 3u], idx);
-                        }
-                    }
+                    if (ch >= 0) atomicAdd(&h[ch], inc);                    // `depth` is the sum of these channels (finalise)
                 } else if (acgt) {
                     atomicAdd(&h[18 + int(b)], inc);                        // {ACGTacgt}LMQ
                 }
@@ -107,18 +104,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_featurize_columns(
             } else if (kind != 3u && mq_ok) {
                 const int ch = (kind == 1u) ? (fwd ? 4 : 13) : (fwd ? 6 : 15);
                 atomicAdd(&h[ch], inc);
-                atomicAdd(&h[34], inc);
                 const int kl = s_koff[w][cl] - kbase + int(kid);
-                if (keys_in_lds) {
-                    atomicAdd(&s_kcnt[w][kl], inc);
-                    atomicMin(&s_kfirst[w][kl][1], idx);
-                    if (pass) atomicMin(&s_kfirst[w][kl][0], idx);
-                } else {
-                    const int64_t k = int64_t(kbase) + kl;
-                    atomicAdd(&keycnt[k], inc);
-                    atomicMin(&keyfirst[2 * k + 1], idx);
-                    if (pass) atomicMin(&keyfirst[2 * k], idx);
-                }
+                if (keys_in_lds) atomicAdd(&s_kcnt[w][kl], inc);
+                else atomicAdd(&keycnt[int64_t(kbase) + kl], inc);
             }
             e = en;
             ent = ent_next;
@@ -130,61 +118,68 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_featurize_columns(
     // ---- finalise: 4 lanes per column, each owns a run of channels that contains whole 4-base groups ----
     {
         const int col = lane >> 2, part = lane & 3;
-        if (col < ncol) {
-            const int64_t c = c0 + col;
-            const int ref = pk.col_ref[c] & 3;
-            const uint32_t* h = s_hist[w][col];
-            const int ch0 = part == 0 ? 0 : (part == 1 ? 9 : (part == 2 ? 18 : 26));
-            const int nch = part < 2 ? 9 : 8;
-            // per-distinct-key maxima -> I1 / D1 (part 0, forward) and i1 / d1 (part 1, reverse)   (F4, F6)
-            uint32_t mx[2][2] = {{0u, 0u}, {0u, 0u}};   // [pass][ins, del]
-            if (part < 2) {
-                const int k0 = s_koff[w][col] - kbase, k1 = s_koff[w][col + 1] - kbase;
-                for (int k = k0; k < k1; ++k) {
-                    const uint32_t cnt = keys_in_lds ? s_kcnt[w][k]
-                                                     : __hip_atomic_load(&keycnt[kbase + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint32_t meta = pk.key_meta[kbase + k];
-                    const bool kfwd = (meta & 4u) != 0u;
-                    if (kfwd != (part == 0)) continue;
-                    const int slot = ((meta & 3u) == 2u) ? 1 : 0;
-                    const uint32_t a = cnt & 0xffffu, n = cnt >> 16;
-                    mx[0][slot] = a > mx[0][slot] ? a : mx[0][slot];
-                    mx[1][slot] = n > mx[1][slot] ? n : mx[1][slot];
+        const bool live = col < ncol;
+        const int64_t c = c0 + (live ? col : 0);
+        const int ref = live ? (pk.col_ref[c] & 3) : 0;
+        const int ch0 = part == 0 ? 0 : (part == 1 ? 9 : (part == 2 ? 18 : 26));
+        const int nch = part < 2 ? 9 : 8;
+        // per-distinct-key maxima -> I1 / D1 (part 0, forward) and i1 / d1 (part 1, reverse)   (F4, F6)
+        uint32_t mx[2][2] = {{0u, 0u}, {0u, 0u}};   // [pass][ins, del]
+        if (live && part < 2) {
+            const int k0 = s_koff[w][col] - kbase, k1 = s_koff[w][col + 1] - kbase;
+            for (int k = k0; k < k1; ++k) {
+                const uint32_t cnt = keys_in_lds ? s_kcnt[w][k]
+                                                 : __hip_atomic_load(&keycnt[kbase + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t meta = pk.key_meta[kbase + k];
+                const bool kfwd = (meta & 4u) != 0u;
+                if (kfwd != (part == 0)) continue;
+                const int slot = ((meta & 3u) == 2u) ? 1 : 0;
+                const uint32_t a = cnt & 0xffffu, n = cnt >> 16;
+                mx[0][slot] = a > mx[0][slot] ? a : mx[0][slot];
+                mx[1][slot] = n > mx[1][slot] ? n : mx[1][slot];
+            }
+        }
+        uint32_t hsum[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            uint32_t t = 0u;
+            if (live && i < nch) {
+#pragma unroll
+                for (int q = 0; q < NCOPY; ++q) t += s_hist[w][q][col][ch0 + i];
+            }
+            hsum[i] = t;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            int v[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) v[i] = int(p == 0 ? (hsum[i] & 0xffffu) : (hsum[i] >> 16));
+            // depth (F4): bases, '*' / '#', insertions and deletions with MQ >= 20 = channels 0-4, 6, 8 of each strand's run
+            int dpart = part < 2 ? v[0] + v[1] + v[2] + v[3] + v[4] + v[6] + v[8] : 0;
+            dpart += __shfl_xor(dpart, 1);          // part 0 + part 1 (adjacent lanes)
+            if (part < 2) { v[5] = int(mx[p][0]); v[7] = int(mx[p][1]); }       // I1 / D1 (or i1 / d1)
+            // reference-channel negation of each whole 4-base group in this run (create_tensor_pileup_calling.py:223-228)
+            const int ngroups = part < 2 ? 1 : 2;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                if (g < ngroups) {
+                    const int s4 = v[g * 4] + v[g * 4 + 1] + v[g * 4 + 2] + v[g * 4 + 3];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (i == ref) v[g * 4 + i] = -s4;
                 }
             }
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                int v[9];
-#pragma unroll
-                for (int i = 0; i < 9; ++i) v[i] = i < nch ? int(p == 0 ? (h[ch0 + i] & 0xffffu) : (h[ch0 + i] >> 16)) : 0;
-                if (part < 2) { v[5] = int(mx[p][0]); v[7] = int(mx[p][1]); }       // I1 / D1 (or i1 / d1)
-                // reference-channel negation of each whole 4-base group in this run (create_tensor_pileup_calling.py:223-228)
-                const int ngroups = part < 2 ? 1 : 2;
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    if (g < ngroups) {
-                        const int s4 = v[g * 4] + v[g * 4 + 1] + v[g * 4 + 2] + v[g * 4 + 3];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (i == ref) v[g * 4 + i] = -s4;
-                    }
-                }
+            if (live) {
 #pragma unroll
                 for (int i = 0; i < 9; ++i)
                     if (i < nch) s_out[w][col][p * HSLOTS + ch0 + i] = int16_t(v[i]);
                 if (part == 3) { s_out[w][col][p * HSLOTS + 34] = 0; s_out[w][col][p * HSLOTS + 35] = 0; }
-                if (part == 0) coldepth[c * 2 + p] = int(p == 0 ? (h[34] & 0xffffu) : (h[34] >> 16));
+                if (part == 0) coldepth[c * 2 + p] = dpart;
             }
-            colfirst[c * 8 + part * 2 + 0] = s_first[w][col][part * 2 + 0];
-            colfirst[c * 8 + part * 2 + 1] = s_first[w][col][part * 2 + 1];
         }
     }
     if (keys_in_lds) {
-        for (int k = lane; k < nkeys_w; k += 64) {
-            keycnt[kbase + k] = s_kcnt[w][k];
-            keyfirst[2 * (int64_t(kbase) + k) + 0] = s_kfirst[w][k][0];
-            keyfirst[2 * (int64_t(kbase) + k) + 1] = s_kfirst[w][k][1];
-        }
+        for (int k = lane; k < nkeys_w; k += 64) keycnt[kbase + k] = s_kcnt[w][k];
     }
     __syncthreads();
     // coalesced write-back: ncol * 144 contiguous bytes per wave, 16 B per lane per pass
@@ -200,10 +195,13 @@ __global__ __launch_bounds__(256) void k_gather_windows(
     PackDev pk, const int16_t* __restrict__ colvec, const int32_t* __restrict__ coldepth,
     const int32_t* __restrict__ site_pos, int64_t n_sites, int min_rescale_cov,
     float* __restrict__ x_aff, float* __restrict__ x_neg, int16_t* __restrict__ raw_aff,
-    int16_t* __restrict__ raw_neg, int32_t* __restrict__ site_info) {
+    int16_t* __restrict__ raw_neg, int32_t* __restrict__ site_info, int min_bq, int32_t* __restrict__ sitefirst,
+    int32_t* __restrict__ keyfirst) {
     __shared__ int64_t s_col[CTO_NPOS];
     __shared__ double s_scale[2];
     __shared__ int s_skip;
+    __shared__ int32_t s_first[8];                 // [pass][A,C,G,T]
+    __shared__ int32_t s_kfirst[KFIRST_CAP][2];
     const int64_t site = blockIdx.x;
     if (site >= n_sites) return;
     const int pos = site_pos[site];
@@ -247,6 +245,46 @@ __global__ __launch_bounds__(256) void k_gather_windows(
         s_skip = skip ? 1 : 0;
     }
     __syncthreads();
+    // ---- first-seen order of the alleles at the candidate column (alt_info key order, F5): only candidates need it, so it
+    // is computed here from the centre column's ~50 entries instead of with atomics on every column of the pack ----
+    if (sitefirst) {
+        const int64_t cc = s_col[CTO_FLANK];
+        const int64_t e0 = cc >= 0 ? pk.col_off[cc] : 0, e1 = cc >= 0 ? pk.col_off[cc + 1] : 0;
+        const int k0 = cc >= 0 ? pk.key_off[cc] : 0, nk = cc >= 0 ? pk.key_off[cc + 1] - k0 : 0;
+        const int nk_lds = nk < KFIRST_CAP ? nk : KFIRST_CAP;
+        if (tid < 8) s_first[tid] = INT_NONE;
+        for (int k = tid; k < nk_lds; k += 256) { s_kfirst[k][0] = INT_NONE; s_kfirst[k][1] = INT_NONE; }
+        if (keyfirst)
+            for (int k = KFIRST_CAP + tid; k < nk; k += 256) { keyfirst[2 * int64_t(k0 + k)] = INT_NONE; keyfirst[2 * int64_t(k0 + k) + 1] = INT_NONE; }
+        if (nk > KFIRST_CAP) __threadfence();       // block-uniform and rare: more distinct keys in one column than the LDS table holds
+        __syncthreads();
+        for (int64_t e = e0 + tid; e < e1; e += 256) {
+            const uint32_t ent = pk.entries[e];
+            const uint32_t b = ent & 15u, kind = (ent >> 4) & 3u;
+            const bool pass = int((ent >> 6) & 127u) >= min_bq, mq_ok = int((ent >> 13) & 255u) >= 20;
+            const int idx = int(e - e0);
+            if (!mq_ok) continue;
+            if (kind == 0u) {
+                if (b < 8u) {
+                    atomicMin(&s_first[4 + (b & 3u)], idx);
+                    if (pass) atomicMin(&s_first[b & 3u], idx);
+                }
+            } else if (kind != 3u && keyfirst) {
+                const int k = int(ent >> 21);
+                if (k < KFIRST_CAP) {
+                    atomicMin(&s_kfirst[k][1], idx);
+                    if (pass) atomicMin(&s_kfirst[k][0], idx);
+                } else {
+                    atomicMin(&keyfirst[2 * int64_t(k0 + k) + 1], idx);
+                    if (pass) atomicMin(&keyfirst[2 * int64_t(k0 + k)], idx);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 8) sitefirst[site * 8 + tid] = s_first[tid];
+        if (keyfirst)
+            for (int k = tid; k < nk_lds; k += 256) { keyfirst[2 * int64_t(k0 + k)] = s_kfirst[k][0]; keyfirst[2 * int64_t(k0 + k) + 1] = s_kfirst[k][1]; }
+    }
     const bool skip = s_skip != 0;
     const double sa = s_scale[0], sn = s_scale[1];
     const int64_t base = site * (CTO_NPOS * CTO_NCHAN);
@@ -281,32 +319,29 @@ PackDev to_dev(const cto_pack_view* v) {
 }  // namespace
 
 extern "C" int cto_featurize_columns(const cto_pack_view* dp, int min_bq, int16_t* colvec, int32_t* coldepth,
-                                      int32_t* colfirst, uint32_t* keycnt, int32_t* keyfirst, void* stream) {
-    CTO_REQUIRE(dp && colvec && coldepth && colfirst, CTO_EINVAL, "cto_featurize_columns: null argument");
-    CTO_REQUIRE(dp->n_keys == 0 || (keycnt && keyfirst), CTO_EINVAL, "cto_featurize_columns: key buffers missing");
+                                      uint32_t* keycnt, void* stream) {
+    CTO_REQUIRE(dp && colvec && coldepth, CTO_EINVAL, "cto_featurize_columns: null argument");
+    CTO_REQUIRE(dp->n_keys == 0 || keycnt, CTO_EINVAL, "cto_featurize_columns: key buffer missing");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dp->n_keys > 0) {
-        CTO_HIP(hipMemsetAsync(keycnt, 0, size_t(dp->n_keys) * 4, s));
-        CTO_HIP(hipMemsetAsync(keyfirst, 0x7f, size_t(dp->n_keys) * 8, s));   // 0x7f7f7f7f: > any entry index
-    }
     if (dp->n_cols == 0) return CTO_OK;
     const int64_t per_block = COLS_PER_WAVE * WAVES_PER_BLOCK;
     const unsigned grid = unsigned(cto::cdiv(dp->n_cols, per_block));
-    hipLaunchKernelGGL(k_featurize_columns, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, to_dev(dp), min_bq,
-                       colvec, coldepth, colfirst, keycnt, keyfirst);
+    hipLaunchKernelGGL(k_featurize_columns, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, to_dev(dp), min_bq, colvec, coldepth,
+                       keycnt);
     CTO_HIP(hipGetLastError());
     return CTO_OK;
 }
 
 extern "C" int cto_gather_windows(const cto_pack_view* dp, const int16_t* colvec, const int32_t* coldepth,
-                                   const int32_t* site_pos, int64_t n_sites, int min_rescale_cov,
+                                   const int32_t* site_pos, int64_t n_sites, int min_bq, int min_rescale_cov,
                                    float* x_aff, float* x_neg, int16_t* raw_aff, int16_t* raw_neg,
-                                   int32_t* site_info, void* stream) {
+                                   int32_t* site_info, int32_t* sitefirst, int32_t* keyfirst, void* stream) {
     CTO_REQUIRE(dp && colvec && coldepth && site_pos && site_info, CTO_EINVAL, "cto_gather_windows: null argument");
     if (n_sites == 0) return CTO_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(k_gather_windows, dim3(unsigned(n_sites)), dim3(256), 0, s, to_dev(dp), colvec, coldepth,
-                       site_pos, n_sites, min_rescale_cov, x_aff, x_neg, raw_aff, raw_neg, site_info);
+                       site_pos, n_sites, min_rescale_cov, x_aff, x_neg, raw_aff, raw_neg, site_info, min_bq, sitefirst,
+                       dp->n_keys > 0 ? keyfirst : nullptr);
     CTO_HIP(hipGetLastError());
     return CTO_OK;
 }

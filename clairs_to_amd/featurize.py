@@ -23,9 +23,9 @@ class Features:
     site_info: torch.Tensor    # [n,12] int32: centre col, depth_aff, depth_neg, flags, fwd ACGT, rev ACGT
     colvec: torch.Tensor       # [n_cols,72] int16
     coldepth: torch.Tensor     # [n_cols,2] int32
-    colfirst: torch.Tensor     # [n_cols,8] int32 ([pass][A,C,G,T])
+    sitefirst: torch.Tensor    # [n,8] int32 ([pass][A,C,G,T]) first-seen entry index within the candidate column
     keycnt: torch.Tensor       # [n_keys] int32 (uint32 bits: low16 AFF count, high16 NEG count)
-    keyfirst: torch.Tensor     # [n_keys,2] int32 (per pass)
+    keyfirst: torch.Tensor     # [n_keys,2] int32 (per pass; defined for the keys of candidate columns only)
 
 
 def featurize(dev_pack, site_pos, min_bq, min_rescale_cov=50, want_raw=False, want_x=True):
@@ -38,22 +38,22 @@ def featurize(dev_pack, site_pos, min_bq, min_rescale_cov=50, want_raw=False, wa
     nc, nk = dev_pack.n_cols, dev_pack.n_keys
     colvec = torch.empty((max(nc, 1), COLVEC_STRIDE), dtype=torch.int16, device=dev)   # never a null pointer
     coldepth = torch.empty((max(nc, 1), 2), dtype=torch.int32, device=dev)
-    colfirst = torch.empty((max(nc, 1), 8), dtype=torch.int32, device=dev)
     keycnt = torch.empty((max(nk, 1),), dtype=torch.int32, device=dev)
     keyfirst = torch.empty((max(nk, 1), 2), dtype=torch.int32, device=dev)
     s = current_stream_ptr()
     check(lib.cto_featurize_columns(C.byref(dev_pack.view), int(min_bq), colvec.data_ptr(), coldepth.data_ptr(),
-                                    colfirst.data_ptr(), keycnt.data_ptr(), keyfirst.data_ptr(), s))
+                                    keycnt.data_ptr(), s))
     x_aff = torch.empty((n, NPOS, NCHAN), dtype=torch.float32, device=dev) if want_x else None
     x_neg = torch.empty((n, NPOS, NCHAN), dtype=torch.float32, device=dev) if want_x else None
     raw_aff = torch.empty((n, NPOS, NCHAN), dtype=torch.int16, device=dev) if want_raw else None
     raw_neg = torch.empty((n, NPOS, NCHAN), dtype=torch.int16, device=dev) if want_raw else None
     site_info = torch.empty((n, 12), dtype=torch.int32, device=dev)
+    sitefirst = torch.empty((max(n, 1), 8), dtype=torch.int32, device=dev)
     ptr = lambda t: t.data_ptr() if t is not None else None
     check(lib.cto_gather_windows(C.byref(dev_pack.view), colvec.data_ptr(), coldepth.data_ptr(), site_pos.data_ptr(), n,
-                                 int(min_rescale_cov) if min_rescale_cov else 0, ptr(x_aff), ptr(x_neg), ptr(raw_aff),
-                                 ptr(raw_neg), site_info.data_ptr(), s))
-    return Features(x_aff, x_neg, raw_aff, raw_neg, site_info, colvec[:nc], coldepth[:nc], colfirst[:nc], keycnt[:nk], keyfirst[:nk])
+                                 int(min_bq), int(min_rescale_cov) if min_rescale_cov else 0, ptr(x_aff), ptr(x_neg), ptr(raw_aff),
+                                 ptr(raw_neg), site_info.data_ptr(), sitefirst.data_ptr(), keyfirst.data_ptr(), s))
+    return Features(x_aff, x_neg, raw_aff, raw_neg, site_info, colvec[:nc], coldepth[:nc], sitefirst[:n], keycnt[:nk], keyfirst[:nk])
 
 
 def alt_infos(feat, host_pack, site_info_host=None, pass_idx=0):
@@ -61,7 +61,7 @@ def alt_infos(feat, host_pack, site_info_host=None, pass_idx=0):
     (create_tensor_pileup_calling.py:158-209); '' for sites without one.  Host work on device results."""
     info = feat.site_info.cpu().numpy() if site_info_host is None else site_info_host
     colvec = feat.colvec.cpu().numpy()
-    colfirst = feat.colfirst.cpu().numpy()
+    sitefirst = np.ascontiguousarray(feat.sitefirst.cpu().numpy())
     keycnt = np.ascontiguousarray(feat.keycnt.cpu().numpy().view(np.uint32))
     keyfirst = np.ascontiguousarray(feat.keyfirst.cpu().numpy())
     if keycnt.size == 0:
@@ -75,6 +75,6 @@ def alt_infos(feat, host_pack, site_info_host=None, pass_idx=0):
             out.append("")
             continue
         n = check(lib.cto_alt_info(host_pack._h, c, int(pass_idx), colvec[c].ctypes.data, int(info[i, 1 + pass_idx]),
-                                   colfirst[c].ctypes.data, keycnt.ctypes.data, keyfirst.ctypes.data, buf, len(buf)))
+                                   sitefirst[i].ctypes.data, keycnt.ctypes.data, keyfirst.ctypes.data, buf, len(buf)))
         out.append(buf.raw[:n].decode())
     return out

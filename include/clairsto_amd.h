@@ -107,14 +107,11 @@ void cto_pack_free(cto_pack* p);
  * reference (run_clairs_to:1228-1271).
  *   colvec   dev [n_cols][2][36] int16   pass 0 = AFF, pass 1 = NEG
  *   coldepth dev [n_cols][2]     int32   `depth` of F4 (MQ>=20, N / over-long indels excluded)
- *   colfirst dev [n_cols][2][4]  int32   per pass: first-seen entry index of bases A,C,G,T (either
- *                                        strand, MQ>=20) or 0x7fffffff -- alt_info key order (F5)
- *   keycnt   dev [n_keys]        uint32  low 16 = AFF count, high 16 = NEG count of each distinct key
- *   keyfirst dev [n_keys][2]     int32   per pass first-seen entry index (>= 0x7f7f7f7f if none)
- * keycnt/keyfirst are initialised by the call. Limit: column depth <= 32767 (CTO_EUNSUPPORTED is
- * raised by the pack builders). */
+ *   keycnt   dev [n_keys]        uint32  low 16 = AFF count, high 16 = NEG count of each distinct key (written by the
+ *                                        call, no initialisation needed)
+ * Limit: column depth <= 32767 (CTO_EUNSUPPORTED is raised by the pack builders). */
 int cto_featurize_columns(const cto_pack_view* dev_pack, int min_bq, int16_t* colvec, int32_t* coldepth,
-                          int32_t* colfirst, uint32_t* keycnt, int32_t* keyfirst, void* stream);
+                          uint32_t* keycnt, void* stream);
 
 /* Stage B: 33x34 window per candidate + coverage rescale, both passes.
  * Replaces the window assembly of create_tensor_pileup_calling.py:536-570 and the rescale of
@@ -126,11 +123,15 @@ int cto_featurize_columns(const cto_pack_view* dev_pack, int min_bq, int16_t* co
  *             fwd A,C,G,T, rev A,C,G,T} -- strand counts per predict.py:626-642 (true ref count restored)
  *             flags bit0: site skipped by the reference (no mpileup row at the candidate, or window
  *             start < 1: create_tensor_pileup_calling.py:542,552)
- * min_rescale_cov <= 0 disables the rescale. */
+ *   sitefirst dev [n_sites][2][4] int32  per pass: first-seen entry index, within the candidate's own column, of bases
+ *             A,C,G,T (either strand, MQ>=20) or 0x7fffffff -- the alt_info key order (F5); may be NULL
+ *   keyfirst  dev [n_keys][2]     int32  per pass first-seen entry index of each distinct indel key OF THE CANDIDATE COLUMNS
+ *             (0x7fffffff if none; entries of other columns are left untouched); may be NULL
+ * min_bq is the AFF pass's gate (as in cto_featurize_columns); min_rescale_cov <= 0 disables the rescale. */
 int cto_gather_windows(const cto_pack_view* dev_pack, const int16_t* colvec, const int32_t* coldepth,
-                       const int32_t* site_pos, int64_t n_sites, int min_rescale_cov,
+                       const int32_t* site_pos, int64_t n_sites, int min_bq, int min_rescale_cov,
                        float* x_aff, float* x_neg, int16_t* raw_aff, int16_t* raw_neg,
-                       int32_t* site_info, void* stream);
+                       int32_t* site_info, int32_t* sitefirst, int32_t* keyfirst, void* stream);
 
 /* Candidate extraction (src/extract_candidates_calling.py:55-169, 322-372) on the same pack: read-bases with
  * MQ >= min_mq and BQ >= min_bq (what `samtools mpileup --min-MQ --min-BQ` would print) are counted per column,
@@ -144,7 +145,7 @@ int cto_extract_candidates(const cto_pack_view* dev_pack, int min_mq, int min_bq
 
 /* Host: the reference's alt_info string "<depth>-<key count ...>-" for the column `col` of pass `pass`
  * (0 = AFF, 1 = NEG; create_tensor_pileup_calling.py:158-209), from stage-A outputs copied to the host.
- * colvec_col / colfirst_col point at that column's [2][36] int16 / [2][4] int32; keycnt / keyfirst are the whole
+ * colvec_col points at that column's [2][36] int16, colfirst_col at the site's [2][4] int32 row of `sitefirst`; keycnt / keyfirst are the whole
  * arrays.  Returns the string length (<= cap-1) or an error. */
 int cto_alt_info(const cto_pack* p, int64_t col, int pass, const int16_t* colvec_col, int32_t depth,
                  const int32_t* colfirst_col, const uint32_t* keycnt, const int32_t* keyfirst,
