@@ -16,7 +16,13 @@
 
 namespace {
 
-constexpr int COLS_PER_WAVE = 16;
+#ifndef CTO_FEAT_COLS
+#define CTO_FEAT_COLS 8
+#endif
+#ifndef CTO_FEAT_NCOPY
+#define CTO_FEAT_NCOPY 2
+#endif
+constexpr int COLS_PER_WAVE = CTO_FEAT_COLS;
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int HSLOTS = 36;       // 34 channels + slot 34 = depth + 1 spare
 constexpr int INT_NONE = 0x7fffffff;
@@ -34,7 +40,7 @@ struct PackDev {
 };
 
 constexpr int KCAP = 128;   // distinct indel keys of one wave's 16 columns held in LDS; beyond that: global atomics
-constexpr int NCOPY = 4;    // privatised histograms per wave (copy = lane & 3): the ~50 read-bases of a column mostly
+constexpr int NCOPY = CTO_FEAT_NCOPY;    // privatised histograms per wave (copy = lane & 3): the ~50 read-bases of a column mostly
                             // hit the same one or two counters, so a 64-lane LDS atomic would serialise ~25-fold
 
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_featurize_columns(
@@ -191,7 +197,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_featurize_columns(
     }
 }
 
-__global__ __launch_bounds__(256) void k_gather_windows(
+#ifndef CTO_GATHER_THREADS
+#define CTO_GATHER_THREADS 128
+#endif
+constexpr int GT = CTO_GATHER_THREADS;
+__global__ __launch_bounds__(GT) void k_gather_windows(
     PackDev pk, const int16_t* __restrict__ colvec, const int32_t* __restrict__ coldepth,
     const int32_t* __restrict__ site_pos, int64_t n_sites, int min_rescale_cov,
     float* __restrict__ x_aff, float* __restrict__ x_neg, int16_t* __restrict__ raw_aff,
@@ -206,15 +216,37 @@ __global__ __launch_bounds__(256) void k_gather_windows(
     if (site >= n_sites) return;
     const int pos = site_pos[site];
     const int tid = threadIdx.x;
-    if (tid < CTO_NPOS) {
-        const int p = pos - CTO_FLANK + tid;
-        // lower_bound over the strictly increasing column positions
+    // Column of every window position: one binary search for the centre (lower_bound over the strictly increasing
+    // column positions), then the neighbours are probed at centre +- d - windows are almost always runs of consecutive
+    // columns - with a short local search as the fallback; 17 dependent L2 round trips per position were the kernel's latency.
+    __shared__ int64_t s_lb;
+    if (tid == 0) {
         int64_t lo = 0, hi = pk.n_cols;
         while (lo < hi) {
             const int64_t mid = (lo + hi) >> 1;
-            if (pk.col_pos[mid] < p) lo = mid + 1; else hi = mid;
+            if (pk.col_pos[mid] < pos) lo = mid + 1; else hi = mid;
         }
-        s_col[tid] = (lo < pk.n_cols && pk.col_pos[lo] == p) ? lo : -1;
+        s_lb = lo;
+    }
+    __syncthreads();
+    if (tid < CTO_NPOS) {
+        const int p = pos - CTO_FLANK + tid;
+        const int64_t g = s_lb + (tid - CTO_FLANK);
+        int64_t found = -1;
+        if (g >= 0 && g < pk.n_cols && pk.col_pos[g] == p) {
+            found = g;
+        } else {
+            // any column with position p lies within CTO_NPOS columns of the centre's lower bound
+            int64_t lo = s_lb - CTO_NPOS, hi = s_lb + CTO_NPOS;
+            lo = lo < 0 ? 0 : lo;
+            hi = hi > pk.n_cols ? pk.n_cols : hi;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (pk.col_pos[mid] < p) lo = mid + 1; else hi = mid;
+            }
+            if (lo < pk.n_cols && pk.col_pos[lo] == p) found = lo;
+        }
+        s_col[tid] = found;
     }
     __syncthreads();
     if (tid == 0) {
@@ -253,12 +285,12 @@ __global__ __launch_bounds__(256) void k_gather_windows(
         const int k0 = cc >= 0 ? pk.key_off[cc] : 0, nk = cc >= 0 ? pk.key_off[cc + 1] - k0 : 0;
         const int nk_lds = nk < KFIRST_CAP ? nk : KFIRST_CAP;
         if (tid < 8) s_first[tid] = INT_NONE;
-        for (int k = tid; k < nk_lds; k += 256) { s_kfirst[k][0] = INT_NONE; s_kfirst[k][1] = INT_NONE; }
+        for (int k = tid; k < nk_lds; k += GT) { s_kfirst[k][0] = INT_NONE; s_kfirst[k][1] = INT_NONE; }
         if (keyfirst)
-            for (int k = KFIRST_CAP + tid; k < nk; k += 256) { keyfirst[2 * int64_t(k0 + k)] = INT_NONE; keyfirst[2 * int64_t(k0 + k) + 1] = INT_NONE; }
+            for (int k = KFIRST_CAP + tid; k < nk; k += GT) { keyfirst[2 * int64_t(k0 + k)] = INT_NONE; keyfirst[2 * int64_t(k0 + k) + 1] = INT_NONE; }
         if (nk > KFIRST_CAP) __threadfence();       // block-uniform and rare: more distinct keys in one column than the LDS table holds
         __syncthreads();
-        for (int64_t e = e0 + tid; e < e1; e += 256) {
+        for (int64_t e = e0 + tid; e < e1; e += GT) {
             const uint32_t ent = pk.entries[e];
             const uint32_t b = ent & 15u, kind = (ent >> 4) & 3u;
             const bool pass = int((ent >> 6) & 127u) >= min_bq, mq_ok = int((ent >> 13) & 255u) >= 20;
@@ -283,12 +315,12 @@ __global__ __launch_bounds__(256) void k_gather_windows(
         __syncthreads();
         if (tid < 8) sitefirst[site * 8 + tid] = s_first[tid];
         if (keyfirst)
-            for (int k = tid; k < nk_lds; k += 256) { keyfirst[2 * int64_t(k0 + k)] = s_kfirst[k][0]; keyfirst[2 * int64_t(k0 + k) + 1] = s_kfirst[k][1]; }
+            for (int k = tid; k < nk_lds; k += GT) { keyfirst[2 * int64_t(k0 + k)] = s_kfirst[k][0]; keyfirst[2 * int64_t(k0 + k) + 1] = s_kfirst[k][1]; }
     }
     const bool skip = s_skip != 0;
     const double sa = s_scale[0], sn = s_scale[1];
     const int64_t base = site * (CTO_NPOS * CTO_NCHAN);
-    for (int i = tid; i < CTO_NPOS * CTO_NCHAN; i += 256) {
+    for (int i = tid; i < CTO_NPOS * CTO_NCHAN; i += GT) {
         const int p = i / CTO_NCHAN, ch = i - p * CTO_NCHAN;
         const int64_t c = s_col[p];
         int va = 0, vn = 0;
@@ -339,7 +371,7 @@ extern "C" int cto_gather_windows(const cto_pack_view* dp, const int16_t* colvec
     CTO_REQUIRE(dp && colvec && coldepth && site_pos && site_info, CTO_EINVAL, "cto_gather_windows: null argument");
     if (n_sites == 0) return CTO_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(k_gather_windows, dim3(unsigned(n_sites)), dim3(256), 0, s, to_dev(dp), colvec, coldepth,
+    hipLaunchKernelGGL(k_gather_windows, dim3(unsigned(n_sites)), dim3(GT), 0, s, to_dev(dp), colvec, coldepth,
                        site_pos, n_sites, min_rescale_cov, x_aff, x_neg, raw_aff, raw_neg, site_info, min_bq, sitefirst,
                        dp->n_keys > 0 ? keyfirst : nullptr);
     CTO_HIP(hipGetLastError());
