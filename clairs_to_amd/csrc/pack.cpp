@@ -16,6 +16,7 @@
 #include <unordered_map>
 #include <vector>
 #include "common.h"
+#include "pack_internal.h"
 
 namespace cto {
 
@@ -29,51 +30,10 @@ void set_error(const char* fmt, ...) {
 
 }  // namespace cto
 
-struct cto_pack {
-    std::vector<int32_t> col_pos;
-    std::vector<uint8_t> col_ref;
-    std::vector<int64_t> col_off;   // n_cols + 1
-    std::vector<int32_t> key_off;   // n_cols + 1
-    std::vector<uint32_t> entries;
-    std::vector<uint8_t> key_meta;
-    std::vector<int32_t> key_group;
-    std::vector<int64_t> key_str_off;  // n_keys + 1
-    std::string key_str;               // alt_info keys ("I<ANCHOR><SEQ>", "D<refslice>")
-};
-
 extern "C" const char* cto_last_error(void) { return cto::g_err; }
 extern "C" int cto_version(void) { return 100; }
 
-namespace {
-
-inline int base_code(char c) {
-    switch (c) {
-        case 'A': return 0;  case 'C': return 1;  case 'G': return 2;  case 'T': return 3;
-        case 'a': return 4;  case 'c': return 5;  case 'g': return 6;  case 't': return 7;
-        case '*': return 8;  case '#': return 9;  case 'N': return 10; case 'n': return 11;
-        default:  return -1;
-    }
-}
-
-inline char up(char c) { return (c >= 'a' && c <= 'z') ? char(c - 32) : c; }
-
-// evc_base_from(...).upper(): ACGT (any case) stay, everything else becomes 'A'.
-inline int ref_code_of(char c) {
-    switch (up(c)) {
-        case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3;
-        default:  return 0;
-    }
-}
-
-struct Tok {
-    int code;          // base code
-    int kind;          // 0 none, 1 ins, 2 del
-    const char* seq;   // indel sequence (not owned)
-    int seqlen;
-};
-
-constexpr int kMaxDepth = 32767;
-constexpr int kMaxKeysPerCol = 2048;
+namespace cto {
 
 void set_err(std::string* err, const char* fmt, ...) {
     char buf[512];
@@ -84,7 +44,93 @@ void set_err(std::string* err, const char* fmt, ...) {
     *err = buf;
 }
 
-}  // namespace
+void pack_begin(cto_pack* p, size_t entries_hint, size_t cols_hint) {
+    p->entries.reserve(entries_hint);
+    p->col_pos.reserve(cols_hint);
+    p->col_ref.reserve(cols_hint);
+    p->col_off.reserve(cols_hint + 1);
+    p->key_off.reserve(cols_hint + 1);
+    p->col_off.push_back(0);
+    p->key_off.push_back(0);
+    p->key_str_off.push_back(0);
+}
+
+int append_column(cto_pack* p, ColumnScratch& sc, int64_t pos, int64_t ri, const char* ref_seq, size_t ref_len,
+                  int max_indel_length, const Tok* toks, int n, std::string* err) {
+    if (n > kMaxDepth) { set_err(err, "column depth %d > %d unsupported", n, kMaxDepth); return CTO_EUNSUPPORTED; }
+    sc.keymap.clear();
+    sc.groupmap.clear();
+    std::string& keybuf = sc.keybuf;
+    std::string& groupbuf = sc.groupbuf;
+    int nkeys_col = 0;
+    for (int i = 0; i < n; ++i) {
+        const Tok& t = toks[i];
+        const int bq = std::max(0, std::min(t.bq, 127));
+        const int mq = std::max(0, std::min(t.mq, 255));
+        uint32_t kind = uint32_t(t.kind), kid = 0;
+        if (t.kind != 0) {
+            const int gate_len = (t.kind == 1) ? t.seqlen : t.seqlen + 1;
+            const bool overlong = gate_len > max_indel_length;
+            if (overlong) kind = 3;
+            // distinct Counter key: base char + sign + sequence, case-sensitive
+            keybuf.clear();
+            keybuf.push_back(char('0' + t.code));
+            keybuf.push_back(t.kind == 1 ? '+' : '-');
+            keybuf.append(t.seq, size_t(t.seqlen));
+            auto it = sc.keymap.find(keybuf);
+            if (it == sc.keymap.end()) {
+                if (nkeys_col >= kMaxKeysPerCol) { set_err(err, "more than %d distinct indel keys in one column", kMaxKeysPerCol); return CTO_EUNSUPPORTED; }
+                kid = uint32_t(nkeys_col++);
+                sc.keymap.emplace(keybuf, int(kid));
+                const bool fwd = (t.code < 4) || t.code == 8 || t.code == 10;
+                p->key_meta.push_back(uint8_t(t.kind | (fwd ? 4 : 0) | (overlong ? 8 : 0)));
+                // merged allele for candidate extraction: insertions by upper-cased anchor + sequence,
+                // deletions by length (extract_candidates_calling.py:118-126)
+                static const char kAnchor[] = "ACGTACGT*#NN";
+                groupbuf.clear();
+                if (t.kind == 1) {
+                    groupbuf.push_back('I');
+                    groupbuf.push_back(kAnchor[t.code]);
+                    for (int j = 0; j < t.seqlen; ++j) groupbuf.push_back(up(t.seq[j]));
+                } else {
+                    groupbuf = "D" + std::to_string(t.seqlen);
+                }
+                auto gi = sc.groupmap.find(groupbuf);
+                if (gi == sc.groupmap.end()) gi = sc.groupmap.emplace(groupbuf, int(sc.groupmap.size())).first;
+                p->key_group.push_back(int32_t(gi->second));
+                // merged alt_info key
+                if (t.kind == 1) {
+                    p->key_str.push_back('I');
+                    p->key_str.push_back(kAnchor[t.code]);
+                    for (int j = 0; j < t.seqlen; ++j) p->key_str.push_back(up(t.seq[j]));
+                } else {
+                    p->key_str.push_back('D');
+                    // chunk_ref_seq[:len+1] with chunk_ref_seq = ref[pos : pos+max_indel_length].upper()
+                    int64_t take = std::min<int64_t>(t.seqlen + 1, max_indel_length);
+                    take = std::min<int64_t>(take, int64_t(ref_len) - ri);
+                    for (int64_t j = 0; j < take; ++j) p->key_str.push_back(up(ref_seq[ri + j]));
+                }
+                p->key_str_off.push_back(int64_t(p->key_str.size()));
+            } else {
+                kid = uint32_t(it->second);
+            }
+        }
+        p->entries.push_back(uint32_t(t.code) | (kind << 4) | (uint32_t(bq) << 6) | (uint32_t(mq) << 13) | (kid << 21));
+    }
+    p->col_pos.push_back(int32_t(pos));
+    {
+        const char ru = up(ref_seq[ri]);
+        const bool acgt = ru == 'A' || ru == 'C' || ru == 'G' || ru == 'T';
+        p->col_ref.push_back(uint8_t(ref_code_of(ref_seq[ri]) | (acgt ? 0 : 0x80)));
+    }
+    p->col_off.push_back(int64_t(p->entries.size()));
+    p->key_off.push_back(int32_t(p->key_meta.size()));
+    return CTO_OK;
+}
+
+}  // namespace cto
+
+using namespace cto;
 
 namespace {
 
@@ -92,18 +138,10 @@ namespace {
 int parse_rows(const char* text, size_t len, const char* ref_seq, int64_t ref_start, size_t ref_len, int max_indel_length,
                cto_pack* p, std::string* err) {
     // one read-base is >= 3 characters of a row (base, BQ, MQ), one row >= ~40: reserve once instead of growing
-    p->entries.reserve(len / 3 + 16);
-    p->col_pos.reserve(len / 40 + 16);
-    p->col_ref.reserve(len / 40 + 16);
-    p->col_off.reserve(len / 40 + 17);
-    p->key_off.reserve(len / 40 + 17);
-    p->col_off.push_back(0);
-    p->key_off.push_back(0);
-    p->key_str_off.push_back(0);
+    pack_begin(p, len / 3 + 16, len / 40 + 16);
     std::vector<Tok> toks;
     toks.reserve(1024);
-    std::unordered_map<std::string, int> keymap, groupmap;
-    std::string keybuf, groupbuf;
+    ColumnScratch sc;
     const char* cur = text;
     const char* end = text + len;
     int64_t last_pos = -1;
@@ -161,7 +199,7 @@ int parse_rows(const char* text, size_t len, const char* ref_seq, int64_t ref_st
                 }
                 int code = base_code(c);
                 if (code >= 0) {
-                    toks.push_back(Tok{code, 0, nullptr, 0});
+                    toks.push_back(Tok{code, 0, nullptr, 0, 0, 0});
                 } else if (c == '^') {
                     ++q;  // skip the mapping-quality character of a read start
                 }
@@ -169,77 +207,10 @@ int parse_rows(const char* text, size_t len, const char* ref_seq, int64_t ref_st
             }
             // zip(base_list, mapping_quality) / zip(base_list, base_quality) truncate: entries without a
             // quality character contribute to no counter; they are dropped here (only malformed rows).
-            int n = int(std::min<size_t>(toks.size(), size_t(std::min(nq, nm))));
-            if (n > kMaxDepth) { set_err(err, "column depth %d > %d unsupported", n, kMaxDepth); return CTO_EUNSUPPORTED; }
-            keymap.clear();
-            groupmap.clear();
-            int nkeys_col = 0;
-            for (int i = 0; i < n; ++i) {
-                const Tok& t = toks[size_t(i)];
-                int bq = qs[i] - 33, mq = ms[i] - 33;
-                bq = std::max(0, std::min(bq, 127));
-                mq = std::max(0, std::min(mq, 255));
-                uint32_t kind = uint32_t(t.kind), kid = 0;
-                if (t.kind != 0) {
-                    const int gate_len = (t.kind == 1) ? t.seqlen : t.seqlen + 1;
-                    const bool overlong = gate_len > max_indel_length;
-                    if (overlong) kind = 3;
-                    {
-                        // distinct Counter key: base char + sign + sequence, case-sensitive
-                        keybuf.clear();
-                        keybuf.push_back(char('0' + t.code));
-                        keybuf.push_back(t.kind == 1 ? '+' : '-');
-                        keybuf.append(t.seq, size_t(t.seqlen));
-                        auto it = keymap.find(keybuf);
-                        if (it == keymap.end()) {
-                            if (nkeys_col >= kMaxKeysPerCol) { set_err(err, "more than %d distinct indel keys in one column", kMaxKeysPerCol); return CTO_EUNSUPPORTED; }
-                            kid = uint32_t(nkeys_col++);
-                            keymap.emplace(keybuf, int(kid));
-                            const bool fwd = (t.code < 4) || t.code == 8 || t.code == 10;
-                            p->key_meta.push_back(uint8_t(t.kind | (fwd ? 4 : 0) | (overlong ? 8 : 0)));
-                            // merged allele for candidate extraction: insertions by upper-cased anchor + sequence,
-                            // deletions by length (extract_candidates_calling.py:118-126)
-                            groupbuf.clear();
-                            if (t.kind == 1) {
-                                static const char kAnchor[] = "ACGTACGT*#NN";
-                                groupbuf.push_back('I');
-                                groupbuf.push_back(kAnchor[t.code]);
-                                for (int j = 0; j < t.seqlen; ++j) groupbuf.push_back(up(t.seq[j]));
-                            } else {
-                                groupbuf = "D" + std::to_string(t.seqlen);
-                            }
-                            auto gi = groupmap.find(groupbuf);
-                            if (gi == groupmap.end()) gi = groupmap.emplace(groupbuf, int(groupmap.size())).first;
-                            p->key_group.push_back(int32_t(gi->second));
-                            // merged alt_info key
-                            if (t.kind == 1) {
-                                p->key_str.push_back('I');
-                                static const char kBaseChar[] = "ACGTACGT*#NN";
-                                p->key_str.push_back(kBaseChar[t.code]);
-                                for (int j = 0; j < t.seqlen; ++j) p->key_str.push_back(up(t.seq[j]));
-                            } else {
-                                p->key_str.push_back('D');
-                                // chunk_ref_seq[:len+1] with chunk_ref_seq = ref[pos : pos+max_indel_length].upper()
-                                int64_t take = std::min<int64_t>(t.seqlen + 1, max_indel_length);
-                                take = std::min<int64_t>(take, int64_t(ref_len) - ri);
-                                for (int64_t j = 0; j < take; ++j) p->key_str.push_back(up(ref_seq[ri + j]));
-                            }
-                            p->key_str_off.push_back(int64_t(p->key_str.size()));
-                        } else {
-                            kid = uint32_t(it->second);
-                        }
-                    }
-                }
-                p->entries.push_back(uint32_t(t.code) | (kind << 4) | (uint32_t(bq) << 6) | (uint32_t(mq) << 13) | (kid << 21));
-            }
-            p->col_pos.push_back(int32_t(pos));
-            {
-                const char ru = up(ref_seq[ri]);
-                const bool acgt = ru == 'A' || ru == 'C' || ru == 'G' || ru == 'T';
-                p->col_ref.push_back(uint8_t(ref_code_of(ref_seq[ri]) | (acgt ? 0 : 0x80)));
-            }
-            p->col_off.push_back(int64_t(p->entries.size()));
-            p->key_off.push_back(int32_t(p->key_meta.size()));
+            const int n = int(std::min<size_t>(toks.size(), size_t(std::min(nq, nm))));
+            for (int i = 0; i < n; ++i) { toks[size_t(i)].bq = qs[i] - 33; toks[size_t(i)].mq = ms[i] - 33; }
+            const int rc = append_column(p, sc, pos, ri, ref_seq, ref_len, max_indel_length, toks.data(), n, err);
+            if (rc != CTO_OK) return rc;
         }
         cur = eol + 1;
     }

@@ -1,0 +1,67 @@
+// Internals shared by the two pack producers (mpileup text: pack.cpp, BAM: bam.cpp): the pack object and the per-column
+// appender that turns a column's read-bases into entries + distinct indel keys.
+#pragma once
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "common.h"
+
+struct cto_pack {
+    std::vector<int32_t> col_pos;
+    std::vector<uint8_t> col_ref;
+    std::vector<int64_t> col_off;   // n_cols + 1
+    std::vector<int32_t> key_off;   // n_cols + 1
+    std::vector<uint32_t> entries;
+    std::vector<uint8_t> key_meta;
+    std::vector<int32_t> key_group;
+    std::vector<int64_t> key_str_off;  // n_keys + 1
+    std::string key_str;               // alt_info keys ("I<ANCHOR><SEQ>", "D<refslice>")
+};
+
+
+namespace cto {
+
+inline char up(char c) { return (c >= 'a' && c <= 'z') ? char(c - 32) : c; }
+
+inline int base_code(char c) {
+    switch (c) {
+        case 'A': return 0;  case 'C': return 1;  case 'G': return 2;  case 'T': return 3;
+        case 'a': return 4;  case 'c': return 5;  case 'g': return 6;  case 't': return 7;
+        case '*': return 8;  case '#': return 9;  case 'N': return 10; case 'n': return 11;
+        default:  return -1;
+    }
+}
+
+// evc_base_from(...).upper(): ACGT (any case) stay, everything else becomes 'A'.
+inline int ref_code_of(char c) {
+    switch (up(c)) {
+        case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3;
+        default:  return 0;
+    }
+}
+
+struct Tok {
+    int code;          // base code
+    int kind;          // 0 none, 1 ins, 2 del
+    const char* seq;   // indel sequence as mpileup prints it (not owned): inserted bases in the strand's case, N/n for deletions
+    int seqlen;
+    int bq, mq;        // phred values
+};
+
+constexpr int kMaxDepth = 32767;
+constexpr int kMaxKeysPerCol = 2048;
+
+struct ColumnScratch {
+    std::unordered_map<std::string, int> keymap, groupmap;
+    std::string keybuf, groupbuf;
+};
+
+void set_err(std::string* err, const char* fmt, ...);
+void pack_begin(cto_pack* p, size_t entries_hint, size_t cols_hint);
+// Appends one column (position `pos`, reference index ri = pos - ref_start) made of toks[0..n)
+int append_column(cto_pack* p, ColumnScratch& sc, int64_t pos, int64_t ri, const char* ref_seq, size_t ref_len,
+                  int max_indel_length, const Tok* toks, int n, std::string* err);
+
+}  // namespace cto
