@@ -37,6 +37,39 @@ def read_candidates(bed_fn, ctg_name):
     return centres, ctg_start, ctg_end
 
 
+def read_bed_intervals(bed_fn, ctg_name):
+    """The BED rows of `ctg_name` as 0-based [begin, end) intervals (what `samtools mpileup -l` restricts positions to)."""
+    opener = gzip.open if bed_fn.endswith(".gz") else open
+    out = []
+    with opener(bed_fn, "rt") as f:
+        for row in f:
+            c = row.rstrip().split("\t")
+            if len(c) >= 3 and c[0] == ctg_name:
+                out.append((max(0, int(c[1])), int(c[2])))
+    return out
+
+
+def load_pack(args, ref, ref_start, ctg_start, ctg_end, max_indel):
+    """The chunk's column pack from (in this order) `--mpileup_fn` text, the native BAM reader (`--bam_reader native`,
+    csrc/bam.cpp, parity unpinned) or `samtools mpileup` run exactly as the reference runs it except for `--min-BQ 0`
+    (create_tensor_pileup_calling.py:426-446): one pileup serves the AFF and the NEG pass."""
+    if getattr(args, "mpileup_fn", None):
+        opener = gzip.open if args.mpileup_fn.endswith(".gz") else open
+        with opener(args.mpileup_fn, "rb") as f:
+            return ColumnPack.from_mpileup(f.read(), ref, ref_start, max_indel)
+    ext_s, ext_e = max(1, ctg_start - NPOS), ctg_end + NPOS
+    if getattr(args, "bam_reader", "samtools") == "native":
+        return ColumnPack.from_bam(args.tumor_bam_fn, args.ctg_name, ext_s, ext_e, ref, ref_start,
+                                   bed=read_bed_intervals(args.candidates_bed_regions, args.ctg_name),
+                                   max_depth=args.max_depth if args.max_depth is not None else 8000, max_indel_length=max_indel)
+    cmd = "{} mpileup --reverse-del --output-MQ -r {}:{}-{} --min-MQ 0 --min-BQ 0 -l {} --excl-flags 2316".format(
+        args.samtools, args.ctg_name, ext_s, ext_e, args.candidates_bed_regions)
+    if args.max_depth is not None:
+        cmd += " --max-depth {}".format(args.max_depth)
+    text = subprocess.run(shlex.split(cmd) + [args.tumor_bam_fn], stdout=subprocess.PIPE, check=True).stdout
+    return ColumnPack.from_mpileup(text, ref, ref_start, max_indel)
+
+
 def create_tensor(args, device="cuda"):
     centres, ctg_start, ctg_end = read_candidates(args.candidates_bed_regions, args.ctg_name)
     if not centres:
@@ -47,19 +80,8 @@ def create_tensor(args, device="cuda"):
     ref = read_region(args.ref_fn, args.ctg_name, ref_start, ctg_end + EXPAND_REF)
     if not ref:
         sys.exit("[ERROR] Failed to load reference sequence from file ({}).".format(args.ref_fn))
-    if args.mpileup_fn:
-        opener = gzip.open if args.mpileup_fn.endswith(".gz") else open
-        with opener(args.mpileup_fn, "rb") as f:
-            text = f.read()
-    else:
-        ext_s, ext_e = max(1, ctg_start - NPOS), ctg_end + NPOS
-        cmd = "{} mpileup --reverse-del --output-MQ -r {}:{}-{} --min-MQ 0 --min-BQ 0 -l {} --excl-flags 2316".format(
-            args.samtools, args.ctg_name, ext_s, ext_e, args.candidates_bed_regions)
-        if args.max_depth is not None:
-            cmd += " --max-depth {}".format(args.max_depth)
-        text = subprocess.run(shlex.split(cmd) + [args.tumor_bam_fn], stdout=subprocess.PIPE, check=True).stdout
     max_indel = MAX_INDEL if args.max_indel_length is None else args.max_indel_length
-    pack = ColumnPack.from_mpileup(text, ref, ref_start, max_indel)
+    pack = load_pack(args, ref, ref_start, ctg_start, ctg_end, max_indel)
     dp = pack.to_device(device)
     feat = featurize(dp, torch.tensor(sites, dtype=torch.int32, device=device), args.min_bq, 0, want_raw=True, want_x=False)
     torch.cuda.synchronize()
@@ -97,6 +119,8 @@ def main():
     p.add_argument("--tensor_can_fn_neg", type=str, default=None, help="also write the --min_bq 0 (NEG) tensor")
     p.add_argument("--ctg_name", type=str, required=True)
     p.add_argument("--samtools", type=str, default="samtools")
+    p.add_argument("--bam_reader", type=str, default="samtools", choices=["samtools", "native"],
+                   help="'native': built-in BAM + BAI reader instead of a samtools subprocess (parity unpinned, see csrc/bam.cpp)")
     p.add_argument("--min_bq", type=int, default=0)
     p.add_argument("--max_depth", type=int, default=None)
     p.add_argument("--max_indel_length", type=int, default=None)

@@ -1,0 +1,504 @@
+// BAM -> column pack producer: what `samtools mpileup --reverse-del --output-MQ -r ctg:s-e --min-MQ 0
+// --min-BQ 0 -l <bed> --excl-flags 2316 [--max-depth N]` followed by the text tokeniser would yield, without the text.
+//
+// PARITY UNPINNED: neither samtools nor htslib exists on the build or GPU boxes, so this reader is validated only against
+// an independent restatement of the pileup rules below on BAM files written by the test-suite itself
+// (tests/bamutil.py, tests/test_bam_reader.py).  The drivers keep `samtools mpileup` as their default producer.
+//
+// Pileup rules implemented (SAM/BAM specification v1 sections 4.2, 5.1-5.3 for the formats; samtools-mpileup(1) and
+// SURVEY.md Appendix B for the column semantics):
+//   * a record is used if it is mapped to the region's reference, (flag & excl_flags) == 0, MAPQ >= min_mq, has a CIGAR
+//     and SEQ, and - as mpileup does without -A - is not an "orphan" (PAIRED set without PROPER_PAIR);
+//   * reads enter a column in file order (= coordinate order, ties by file position);
+//   * M / = / X : one read-base per reference position, base letter upper case on the forward strand, lower case on the
+//     reverse strand ('=' resolves to the reference base), BQ = QUAL at that query position;
+//   * D : placeholder '*' (forward) / '#' (reverse, --reverse-del) at every deleted position, carrying the BQ of the
+//     query base that follows the deletion (0 past the end of the read);
+//   * the last aligned base before an I (or D) carries the indel: inserted bases in the strand's case, or len x 'N'/'n'
+//     for a deletion (no -f: deleted bases print as N); an insertion that is not preceded by an aligned base of the
+//     same read (start of read, after a clip / skip / deletion) is not reported;
+//   * N (reference skip) contributes nothing (samtools prints '>' / '<', which the reference's decoder ignores);
+//   * S / H / P consume as the specification says and contribute nothing;
+//   * MQ and BQ are capped at 93, the largest value mpileup's phred+33 characters can carry;
+//   * a read is dropped when `max_depth` reads are already active at its start (htslib's per-file maxcnt);
+//   * rows exist only for positions covered by >= 1 read-base or placeholder, inside [start, end] and inside the BED
+//     intervals when given.
+// Not implemented (documented deviations): mate-overlap quality adjustment (mpileup without -x; paired-end short reads
+// only), BAQ (needs -f, which the reference does not pass), CRAM, multi-file input.
+#include <dlfcn.h>
+#include <zlib.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <deque>
+#include <memory>
+
+#include "pack_internal.h"
+
+using namespace cto;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ BGZF
+// libdeflate inflates BGZF blocks 2-3x faster than zlib.  Its headers are not installed here, only the runtime library, so
+// the three entry points of its stable v1 ABI are resolved with dlopen; zlib remains the fallback.
+struct LibDeflate {
+    void* h = nullptr;
+    void* (*alloc)() = nullptr;
+    int (*inflate)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+    void (*release)(void*) = nullptr;
+    LibDeflate() {
+        if (getenv("CTO_NO_LIBDEFLATE")) return;
+        for (const char* name : {"libdeflate.so.0", "libdeflate.so"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+        }
+        if (!h) return;
+        alloc = reinterpret_cast<void* (*)()>(dlsym(h, "libdeflate_alloc_decompressor"));
+        inflate = reinterpret_cast<int (*)(void*, const void*, size_t, void*, size_t, size_t*)>(dlsym(h, "libdeflate_deflate_decompress"));
+        release = reinterpret_cast<void (*)(void*)>(dlsym(h, "libdeflate_free_decompressor"));
+        if (!alloc || !inflate || !release) { alloc = nullptr; inflate = nullptr; release = nullptr; }
+    }
+    bool ok() const { return inflate != nullptr; }
+};
+const LibDeflate& libdeflate() {
+    static const LibDeflate ld;
+    return ld;
+}
+
+struct Bgzf {
+    FILE* f = nullptr;
+    std::vector<uint8_t> comp, block;   // compressed / inflated current block
+    int64_t block_coffset = -1;         // file offset of the current block
+    int64_t next_coffset = 0;           // file offset of the block after it
+    size_t upos = 0;                    // read position inside `block`
+    int64_t file_pos = -1;              // where the FILE's cursor stands, when known
+    z_stream zs;
+    bool zs_init = false;
+    void* ld = nullptr;                 // libdeflate decompressor when available
+    std::string err;
+
+    ~Bgzf() {
+        if (zs_init) inflateEnd(&zs);
+        if (ld) libdeflate().release(ld);
+        if (f) fclose(f);
+    }
+    bool open(const char* path) {
+        f = fopen(path, "rb");
+        if (!f) { err = std::string("cannot open ") + path; return false; }
+        setvbuf(f, nullptr, _IOFBF, 1 << 20);
+        file_pos = 0;
+        memset(&zs, 0, sizeof(zs));
+        if (inflateInit2(&zs, -15) != Z_OK) { err = "inflateInit2 failed"; return false; }
+        zs_init = true;
+        if (libdeflate().ok()) ld = libdeflate().alloc();
+        return true;
+    }
+    // loads the block that starts at file offset `coff`; false at EOF (err stays empty) or on error
+    bool load(int64_t coff) {
+        if (coff != file_pos && fseeko(f, off_t(coff), SEEK_SET) != 0) { err = "seek failed"; return false; }   // sequential reads keep the stdio buffer
+        file_pos = -1;
+        uint8_t h[18];
+        const size_t got = fread(h, 1, 18, f);
+        if (got == 0) return false;   // clean EOF
+        if (got != 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { err = "not a BGZF block header"; return false; }
+        const int xlen = h[10] | (h[11] << 8);
+        // the BC subfield is normally first; scan the extra field in general
+        std::vector<uint8_t> extra(size_t(xlen), 0);
+        memcpy(extra.data(), h + 12, std::min<size_t>(6, size_t(xlen)));
+        if (xlen > 6 && fread(extra.data() + 6, 1, size_t(xlen - 6), f) != size_t(xlen - 6)) { err = "truncated BGZF extra field"; return false; }
+        int bsize = -1;
+        for (int i = 0; i + 4 <= xlen;) {
+            const int slen = extra[size_t(i) + 2] | (extra[size_t(i) + 3] << 8);
+            if (extra[size_t(i)] == 'B' && extra[size_t(i) + 1] == 'C' && slen == 2 && i + 6 <= xlen)
+                bsize = (extra[size_t(i) + 4] | (extra[size_t(i) + 5] << 8)) + 1;
+            i += 4 + slen;
+        }
+        if (bsize < 0) { err = "BGZF block without BC subfield"; return false; }
+        const int cdata = bsize - xlen - 12 - 8;     // deflate payload; then CRC32 + ISIZE
+        if (cdata < 0) { err = "bad BGZF block size"; return false; }
+        comp.resize(size_t(cdata) + 8);
+        if (xlen <= 6) {                              // part of the payload may already sit in h[]
+            const int have = 6 - xlen;                // bytes of h beyond the extra field
+            memcpy(comp.data(), h + 12 + xlen, size_t(have));
+            if (fread(comp.data() + have, 1, comp.size() - size_t(have), f) != comp.size() - size_t(have)) { err = "truncated BGZF block"; return false; }
+        } else if (fread(comp.data(), 1, comp.size(), f) != comp.size()) { err = "truncated BGZF block"; return false; }
+        const uint8_t* tail = comp.data() + cdata;
+        const uint32_t isize = uint32_t(tail[4]) | (uint32_t(tail[5]) << 8) | (uint32_t(tail[6]) << 16) | (uint32_t(tail[7]) << 24);
+        block.resize(isize);
+        if (isize && ld) {
+            size_t got_out = 0;
+            if (libdeflate().inflate(ld, comp.data(), size_t(cdata), block.data(), isize, &got_out) != 0 || got_out != isize) {
+                err = "inflate failed";
+                return false;
+            }
+        } else if (isize) {
+            inflateReset(&zs);
+            zs.next_in = comp.data();
+            zs.avail_in = uInt(cdata);
+            zs.next_out = block.data();
+            zs.avail_out = uInt(isize);
+            const int rc = inflate(&zs, Z_FINISH);
+            if (rc != Z_STREAM_END || zs.avail_out != 0) { err = "inflate failed"; return false; }
+        }
+        block_coffset = coff;
+        next_coffset = coff + bsize;
+        file_pos = next_coffset;
+        upos = 0;
+        return true;
+    }
+    bool seek(uint64_t voff) {
+        const int64_t coff = int64_t(voff >> 16);
+        if (coff != block_coffset && !load(coff)) return false;
+        upos = size_t(voff & 0xffff);
+        return upos <= block.size();
+    }
+    // virtual offset of the next byte; the end of a block is reported as the start of the next one, as index chunks do
+    uint64_t tell() const {
+        if (block_coffset >= 0 && upos >= block.size()) return uint64_t(next_coffset) << 16;
+        return (uint64_t(block_coffset) << 16) | uint64_t(upos);
+    }
+    // reads exactly n bytes across block boundaries; false at EOF / error
+    bool read(void* dst, size_t n) {
+        uint8_t* d = static_cast<uint8_t*>(dst);
+        while (n > 0) {
+            if (block_coffset < 0 || upos >= block.size()) {
+                if (!load(block_coffset < 0 ? 0 : next_coffset)) return false;
+                if (block.empty()) continue;          // empty blocks (e.g. the EOF marker) are skipped
+            }
+            const size_t take = std::min(n, block.size() - upos);
+            memcpy(d, block.data() + upos, take);
+            upos += take;
+            d += take;
+            n -= take;
+        }
+        return true;
+    }
+};
+
+inline int32_t le32(const uint8_t* p) { return int32_t(uint32_t(p[0]) | (uint32_t(p[1]) << 8) | (uint32_t(p[2]) << 16) | (uint32_t(p[3]) << 24)); }
+inline uint64_t le64(const uint8_t* p) { return uint64_t(uint32_t(le32(p))) | (uint64_t(uint32_t(le32(p + 4))) << 32); }
+
+// ------------------------------------------------------------------------------------------------ BAI
+struct Chunk { uint64_t beg, end; };
+
+// bins that may hold alignments overlapping [beg, end) (0-based), SAM specification section 5.3
+void reg2bins(int64_t beg, int64_t end, std::vector<uint32_t>* bins) {
+    --end;
+    bins->push_back(0);
+    for (int k = 1 + int(beg >> 26); k <= 1 + int(end >> 26); ++k) bins->push_back(uint32_t(k));
+    for (int k = 9 + int(beg >> 23); k <= 9 + int(end >> 23); ++k) bins->push_back(uint32_t(k));
+    for (int k = 73 + int(beg >> 20); k <= 73 + int(end >> 20); ++k) bins->push_back(uint32_t(k));
+    for (int k = 585 + int(beg >> 17); k <= 585 + int(end >> 17); ++k) bins->push_back(uint32_t(k));
+    for (int k = 4681 + int(beg >> 14); k <= 4681 + int(end >> 14); ++k) bins->push_back(uint32_t(k));
+}
+
+// chunks of reference `tid` that may overlap [beg, end), merged and sorted; false on a malformed index
+bool bai_query(const char* path, int tid, int64_t beg, int64_t end, std::vector<Chunk>* out, std::string* err) {
+    FILE* f = fopen(path, "rb");
+    if (!f) { *err = std::string("cannot open index ") + path; return false; }
+    std::vector<uint8_t> buf;
+    fseeko(f, 0, SEEK_END);
+    const off_t sz = ftello(f);
+    fseeko(f, 0, SEEK_SET);
+    buf.resize(size_t(sz));
+    const bool ok = fread(buf.data(), 1, buf.size(), f) == buf.size();
+    fclose(f);
+    if (!ok || buf.size() < 8 || memcmp(buf.data(), "BAI\1", 4) != 0) { *err = "not a BAI index"; return false; }
+    size_t o = 4;
+    auto need = [&](size_t n) { return o + n <= buf.size(); };
+    const int n_ref = le32(buf.data() + o); o += 4;
+    if (tid < 0 || tid >= n_ref) { *err = "reference not in the index"; return false; }
+    std::vector<uint32_t> want;
+    reg2bins(beg, end, &want);
+    std::sort(want.begin(), want.end());
+    std::vector<Chunk> chunks;
+    uint64_t min_off = 0;
+    for (int r = 0; r <= tid; ++r) {
+        if (!need(4)) { *err = "truncated BAI"; return false; }
+        const int n_bin = le32(buf.data() + o); o += 4;
+        for (int b = 0; b < n_bin; ++b) {
+            if (!need(8)) { *err = "truncated BAI"; return false; }
+            const uint32_t bin = uint32_t(le32(buf.data() + o));
+            const int n_chunk = le32(buf.data() + o + 4);
+            o += 8;
+            if (!need(size_t(n_chunk) * 16)) { *err = "truncated BAI"; return false; }
+            if (r == tid && bin != 37450 && std::binary_search(want.begin(), want.end(), bin))
+                for (int c = 0; c < n_chunk; ++c) chunks.push_back(Chunk{le64(buf.data() + o + size_t(c) * 16), le64(buf.data() + o + size_t(c) * 16 + 8)});
+            o += size_t(n_chunk) * 16;
+        }
+        if (!need(4)) { *err = "truncated BAI"; return false; }
+        const int n_intv = le32(buf.data() + o); o += 4;
+        if (!need(size_t(n_intv) * 8)) { *err = "truncated BAI"; return false; }
+        if (r == tid && n_intv > 0) {
+            const int64_t w = std::min<int64_t>(beg >> 14, n_intv - 1);
+            min_off = le64(buf.data() + o + size_t(w) * 8);
+        }
+        o += size_t(n_intv) * 8;
+    }
+    std::sort(chunks.begin(), chunks.end(), [](const Chunk& a, const Chunk& b) { return a.beg < b.beg; });
+    for (const Chunk& c : chunks) {
+        if (c.end <= min_off) continue;                       // entirely before the first alignment that can overlap
+        Chunk d{std::max(c.beg, min_off), c.end};
+        if (!out->empty() && d.beg <= out->back().end) out->back().end = std::max(out->back().end, d.end);
+        else out->push_back(d);
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ records + pileup
+struct Read {
+    int32_t pos = 0;            // 0-based leftmost
+    int32_t end = 0;            // 0-based exclusive reference end
+    uint8_t mapq = 0;
+    bool rev = false;
+    std::vector<uint32_t> cigar;
+    std::vector<uint8_t> raw;   // packed SEQ (4 bits per base) followed by QUAL, as in the record: decoded on demand, since a
+                                // BED-restricted pileup touches a small part of a long read
+    int32_t l_seq = 0;
+    bool no_qual = false;
+    int base4(int q) const { return (raw[size_t(q >> 1)] >> ((~q & 1) << 2)) & 15; }
+    int bq(int q) const { return (no_qual || q >= l_seq) ? 0 : std::min(int(raw[size_t((l_seq + 1) / 2 + q)]), 93); }
+    // cursor: CIGAR op index, offset inside it, reference / query positions at the start of the op
+    size_t op = 0;
+    int32_t op_ref = 0, op_q = 0;
+};
+
+const char kNt16[] = "=ACMGRSVTWYHKDBN";
+
+struct Producer {
+    cto_pack* p;
+    ColumnScratch sc;
+    const char* ref_seq;
+    int64_t ref_start;
+    size_t ref_len;
+    int max_indel;
+    std::vector<Tok> toks;
+    std::deque<std::string> arena;      // inserted sequences of the current column (Tok::seq points into these)
+    std::string nbuf_up, nbuf_lo;       // runs of 'N' / 'n' for deletion keys
+    std::string err;
+
+    // advances the read's cursor to reference position `rpos` (0-based) and appends its contribution to the column
+    void emit(Read& r, int32_t rpos) {
+        while (r.op < r.cigar.size()) {
+            const uint32_t c = r.cigar[r.op];
+            const int len = int(c >> 4), opc = int(c & 15);
+            const bool cons_ref = opc == 0 || opc == 2 || opc == 3 || opc == 7 || opc == 8;
+            const bool cons_q = opc == 0 || opc == 1 || opc == 4 || opc == 7 || opc == 8;
+            if (cons_ref && rpos < r.op_ref + len) break;
+            if (cons_ref) r.op_ref += len;
+            if (cons_q) r.op_q += len;
+            ++r.op;
+        }
+        if (r.op >= r.cigar.size()) return;
+        const uint32_t c = r.cigar[r.op];
+        const int len = int(c >> 4), opc = int(c & 15);
+        const int off = rpos - r.op_ref;
+        if (opc == 3) return;                                  // N: reference skip, nothing in the pack
+        Tok t{0, 0, nullptr, 0, 0, std::min(int(r.mapq), 93)};      // mpileup prints min(MAPQ, 93) + 33, likewise for BQ
+        if (opc == 2) {                                        // D: placeholder
+            t.code = r.rev ? 9 : 8;
+            t.bq = r.bq(r.op_q);
+            toks.push_back(t);
+            return;
+        }
+        // aligned base
+        const int q = r.op_q + off;
+        char b = kNt16[r.base4(q)];
+        if (b == '=') {
+            const int64_t ri = int64_t(rpos) + 1 - ref_start;
+            b = (ri >= 0 && size_t(ri) < ref_len) ? up(ref_seq[ri]) : 'N';
+        }
+        if (b != 'A' && b != 'C' && b != 'G' && b != 'T') b = 'N';      // mpileup prints IUPAC codes; the decoder ignores all but ACGTN
+        int code = base_code(b);
+        if (r.rev) code += (code < 4) ? 4 : 1;                 // A..T -> a..t, N -> n
+        t.code = code;
+        t.bq = r.bq(q);
+        if (off == len - 1) {                                  // last base of the op: does an indel follow?
+            size_t nx = r.op + 1;
+            while (nx < r.cigar.size() && (r.cigar[nx] & 15) == 6) ++nx;    // P
+            if (nx < r.cigar.size()) {
+                const int nop = int(r.cigar[nx] & 15), nlen = int(r.cigar[nx] >> 4);
+                if (nop == 1) {
+                    arena.emplace_back();
+                    std::string& s = arena.back();
+                    for (int i = 0; i < nlen; ++i) {
+                        char ib = kNt16[r.base4(q + 1 + i)];
+                        if (ib == '=') ib = 'N';
+                        s.push_back(r.rev ? char(ib | 0x20) : ib);
+                    }
+                    t.kind = 1;
+                    t.seq = s.data();
+                    t.seqlen = nlen;
+                } else if (nop == 2) {
+                    std::string& nb = r.rev ? nbuf_lo : nbuf_up;
+                    if (int(nb.size()) < nlen) nb.assign(size_t(nlen), r.rev ? 'n' : 'N');
+                    t.kind = 2;
+                    t.seq = nb.data();
+                    t.seqlen = nlen;
+                }
+            }
+        }
+        toks.push_back(t);
+    }
+};
+
+bool in_bed(const int64_t* bed, int64_t n_bed, int64_t pos1, int64_t* cursor) {
+    if (!bed) return true;
+    const int64_t p0 = pos1 - 1;
+    while (*cursor < n_bed && bed[2 * *cursor + 1] <= p0) ++*cursor;     // intervals sorted by start, merged by the caller
+    return *cursor < n_bed && bed[2 * *cursor] <= p0;
+}
+
+}  // namespace
+
+extern "C" int cto_pack_from_bam(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
+                                  const int64_t* bed, int64_t n_bed, const char* ref_seq, int64_t ref_start, size_t ref_len,
+                                  int excl_flags, int min_mq, int max_depth, int max_indel_length, cto_pack** out) {
+    CTO_REQUIRE(bam_path && ctg_name && ref_seq && out, CTO_EINVAL, "cto_pack_from_bam: null argument");
+    CTO_REQUIRE(start >= 1 && end >= start, CTO_EINVAL, "cto_pack_from_bam: bad region %lld-%lld", (long long)start, (long long)end);
+    CTO_REQUIRE(n_bed == 0 || bed, CTO_EINVAL, "cto_pack_from_bam: bed intervals missing");
+    for (int64_t i = 1; i < n_bed; ++i)
+        CTO_REQUIRE(bed[2 * i] >= bed[2 * i - 1], CTO_EINVAL, "cto_pack_from_bam: bed intervals must be sorted and non-overlapping");
+    Bgzf bz;
+    CTO_REQUIRE(bz.open(bam_path), CTO_EINVAL, "cto_pack_from_bam: %s", bz.err.c_str());
+    // ---- header ----
+    uint8_t h4[4];
+    CTO_REQUIRE(bz.read(h4, 4) && memcmp(h4, "BAM\1", 4) == 0, CTO_EINVAL, "cto_pack_from_bam: %s is not a BAM file%s%s", bam_path,
+                bz.err.empty() ? "" : ": ", bz.err.c_str());
+    CTO_REQUIRE(bz.read(h4, 4), CTO_EINVAL, "cto_pack_from_bam: truncated header");
+    {
+        std::vector<uint8_t> text(size_t(le32(h4)));
+        CTO_REQUIRE(text.empty() || bz.read(text.data(), text.size()), CTO_EINVAL, "cto_pack_from_bam: truncated header text");
+    }
+    CTO_REQUIRE(bz.read(h4, 4), CTO_EINVAL, "cto_pack_from_bam: truncated header");
+    const int n_ref = le32(h4);
+    int tid = -1;
+    for (int r = 0; r < n_ref; ++r) {
+        CTO_REQUIRE(bz.read(h4, 4), CTO_EINVAL, "cto_pack_from_bam: truncated reference list");
+        std::vector<char> name(size_t(le32(h4)));
+        CTO_REQUIRE(bz.read(name.data(), name.size()) && bz.read(h4, 4), CTO_EINVAL, "cto_pack_from_bam: truncated reference list");
+        if (tid < 0 && !name.empty() && strcmp(name.data(), ctg_name) == 0) tid = r;
+    }
+    CTO_REQUIRE(tid >= 0, CTO_EINVAL, "cto_pack_from_bam: contig %s not in the BAM header", ctg_name);
+    // ---- index ----
+    std::vector<Chunk> chunks;
+    {
+        std::string err, idx = bai_path ? std::string(bai_path) : std::string(bam_path) + ".bai";
+        CTO_REQUIRE(bai_query(idx.c_str(), tid, start - 1, end, &chunks, &err), CTO_EINVAL, "cto_pack_from_bam: %s", err.c_str());
+    }
+    std::unique_ptr<cto_pack> pk(new cto_pack());
+    pack_begin(pk.get(), 1 << 16, 1 << 10);
+    Producer pr;
+    pr.p = pk.get();
+    pr.ref_seq = ref_seq;
+    pr.ref_start = ref_start;
+    pr.ref_len = ref_len;
+    pr.max_indel = max_indel_length;
+
+    std::deque<Read> active;
+    int64_t next_col = start;            // next 1-based position to emit
+    int64_t bed_cursor = 0;
+    const int64_t beg0 = start - 1, end0 = end;   // 0-based half-open region
+    auto flush_until = [&](int64_t limit1) -> int {   // emit columns next_col .. limit1 (1-based, inclusive)
+        for (; next_col <= limit1; ++next_col) {
+            while (!active.empty() && active.front().end <= next_col - 1) active.pop_front();
+            if (active.empty()) { next_col = limit1 + 1; break; }       // nothing can cover the positions up to the limit
+            if (!in_bed(bed, n_bed, next_col, &bed_cursor)) continue;
+            pr.toks.clear();
+            pr.arena.clear();
+            const int32_t rpos = int32_t(next_col - 1);
+            size_t dead = 0;
+            for (Read& r : active) {
+                if (r.pos <= rpos && rpos < r.end) pr.emit(r, rpos);
+                else dead += r.end <= rpos;
+            }
+            if (dead > 32 && dead * 2 > active.size())       // finished reads parked behind a long one: compact, keeping file order
+                active.erase(std::remove_if(active.begin(), active.end(), [&](const Read& r) { return r.end <= rpos; }), active.end());
+            if (pr.toks.empty()) continue;
+            const int64_t ri = next_col - ref_start;
+            if (ri < 0 || size_t(ri) >= ref_len) {
+                set_error("cto_pack_from_bam: position %lld outside the supplied reference", (long long)next_col);
+                return CTO_EINVAL;
+            }
+            const int rc = append_column(pr.p, pr.sc, next_col, ri, ref_seq, ref_len, max_indel_length, pr.toks.data(),
+                                         int(pr.toks.size()), &pr.err);
+            if (rc != CTO_OK) { set_error("%s", pr.err.c_str()); return rc; }
+        }
+        return CTO_OK;
+    };
+    // Reads are NOT removed from `active` in end order (a deque in file order, popped only from the front): a long read
+    // at the front keeps shorter finished ones behind it alive, which only costs the bounds check in the loop above.
+    std::vector<uint8_t> rec;
+    bool done = false;
+    const bool timing = getenv("CTO_PACK_TIMING") != nullptr;
+    double t_flush = 0.0, t_read = 0.0;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    for (size_t ci = 0; ci < chunks.size() && !done; ++ci) {
+        CTO_REQUIRE(bz.seek(chunks[ci].beg), CTO_EINVAL, "cto_pack_from_bam: seek into BAM failed: %s", bz.err.c_str());
+        while (bz.tell() < chunks[ci].end) {
+            const double tr0 = timing ? now() : 0.0;
+            if (!bz.read(h4, 4)) { CTO_REQUIRE(bz.err.empty(), CTO_EINVAL, "cto_pack_from_bam: %s", bz.err.c_str()); done = true; break; }
+            const int bsz = le32(h4);
+            CTO_REQUIRE(bsz >= 32, CTO_EINVAL, "cto_pack_from_bam: bad alignment block size %d", bsz);
+            rec.resize(size_t(bsz));
+            CTO_REQUIRE(bz.read(rec.data(), rec.size()), CTO_EINVAL, "cto_pack_from_bam: truncated alignment record");
+            if (timing) t_read += now() - tr0;
+            const uint8_t* b = rec.data();
+            const int rtid = le32(b), pos = le32(b + 4);
+            const int l_name = b[8], mapq = b[9];
+            const int n_cig = b[12] | (b[13] << 8), flag = b[14] | (b[15] << 8);
+            const int l_seq = le32(b + 16);
+            if (rtid != tid) { if (rtid > tid || rtid < 0) { done = true; break; } continue; }
+            if (pos >= end0) { done = true; break; }
+            if ((flag & excl_flags) || (flag & 4) || mapq < min_mq || n_cig == 0 || l_seq == 0) continue;
+            if ((flag & 1) && !(flag & 2)) continue;           // orphan (mpileup without -A)
+            const size_t need = 32 + size_t(l_name) + size_t(n_cig) * 4 + size_t((l_seq + 1) / 2) + size_t(l_seq);
+            CTO_REQUIRE(need <= rec.size(), CTO_EINVAL, "cto_pack_from_bam: alignment record shorter than its fields");
+            const uint8_t* cg = b + 32 + l_name;
+            const uint8_t* sq = cg + size_t(n_cig) * 4;
+            const uint8_t* ql = sq + (l_seq + 1) / 2;
+            Read r;
+            r.pos = pos;
+            r.mapq = uint8_t(mapq);
+            r.rev = (flag & 16) != 0;
+            r.cigar.resize(size_t(n_cig));
+            int32_t rlen = 0, qlen = 0;
+            for (int i = 0; i < n_cig; ++i) {
+                const uint32_t c = uint32_t(le32(cg + i * 4));
+                r.cigar[size_t(i)] = c;
+                const int opc = int(c & 15), len = int(c >> 4);
+                if (opc == 0 || opc == 2 || opc == 3 || opc == 7 || opc == 8) rlen += len;
+                if (opc == 0 || opc == 1 || opc == 4 || opc == 7 || opc == 8) qlen += len;
+            }
+            if (qlen != l_seq || rlen == 0) continue;          // inconsistent or reference-less record
+            r.end = pos + rlen;
+            if (r.end <= beg0) continue;
+            r.op_ref = pos;
+            r.l_seq = l_seq;
+            r.raw.assign(sq, ql + l_seq);
+            r.no_qual = ql[0] == 0xff;                                                             // QUAL absent
+            // columns strictly before this read's start are final
+            const double tf0 = timing ? now() : 0.0;
+            const int rcf = flush_until(std::min<int64_t>(pos, end));     // columns at 1-based positions <= pos (0-based start) are final
+            if (rcf != CTO_OK) return rcf;
+            if (timing) t_flush += now() - tf0;
+            if (max_depth > 0) {
+                int live = 0;
+                for (const Read& a : active) live += a.end > pos;
+                if (live >= max_depth) continue;
+            }
+            active.push_back(std::move(r));
+        }
+    }
+    const double tf1 = timing ? now() : 0.0;
+    const int rcf = flush_until(end);
+    if (rcf != CTO_OK) return rcf;
+    if (timing)
+        fprintf(stderr, "cto_pack_from_bam: total %.1f ms: read+inflate %.1f, pileup %.1f (libdeflate %d)\n", now() - t_begin, t_read,
+                t_flush + now() - tf1, int(libdeflate().ok()));
+    *out = pk.release();
+    return CTO_OK;
+}

@@ -36,6 +36,29 @@ class ColumnPack:
         return cls(out.value)
 
     @classmethod
+    def from_bam(cls, bam_fn, ctg_name, start, end, ref_seq, ref_start, bed=None, bai_fn=None, excl_flags=2316, min_mq=0,
+                 max_depth=8000, max_indel_length=60):
+        """The pack of `samtools mpileup -r ctg:start-end --min-BQ 0 ...` on `bam_fn`, without samtools (cto_pack_from_bam;
+        PARITY UNPINNED, see csrc/bam.cpp).  bed: iterable of 0-based [begin, end) intervals restricting the positions."""
+        rb = ref_seq.encode() if isinstance(ref_seq, str) else bytes(ref_seq)
+        iv = None
+        if bed is not None:
+            iv = sorted((int(a), int(b)) for a, b in bed)
+            merged = []
+            for a, b in iv:
+                if merged and a <= merged[-1][1]:
+                    merged[-1][1] = max(merged[-1][1], b)
+                else:
+                    merged.append([a, b])
+            iv = np.ascontiguousarray(np.array(merged, dtype=np.int64).reshape(-1, 2))
+        out = c_vp()
+        check(lib.cto_pack_from_bam(str(bam_fn).encode(), str(bai_fn).encode() if bai_fn else None, ctg_name.encode(), int(start),
+                                    int(end), iv.ctypes.data if iv is not None and len(iv) else None, len(iv) if iv is not None else 0,
+                                    rb, int(ref_start), len(rb), int(excl_flags), int(min_mq), int(max_depth), int(max_indel_length),
+                                    C.byref(out)))
+        return cls(out.value)
+
+    @classmethod
     def from_arrays(cls, col_pos, col_ref, col_off, key_off, entries, key_meta, key_group=None, key_str_off=None,
                     key_str=None):
         if key_group is None:

@@ -13,8 +13,6 @@ mpileup row at the candidate are skipped (create_tensor_pileup_calling.py:552).
 """
 import gzip
 import os
-import shlex
-import subprocess
 import sys
 from argparse import ArgumentParser
 
@@ -22,27 +20,12 @@ import numpy as np
 import torch
 
 from .call_variants import IUPAC_TO_ACGT, VCF_HEADER, load_likelihood, vcf_row
-from .create_tensor_pileup_calling import EXPAND_REF, FLANK, MAX_INDEL, NPOS, read_candidates
+from .create_tensor_pileup_calling import EXPAND_REF, MAX_INDEL, load_pack, read_candidates
 from .engine import Engine
 from .fasta import read_region
 from .featurize import alt_infos
-from .pack import ColumnPack
 from .predict import load_models, str2bool
 from .synth import PLATFORMS
-
-
-def mpileup_text_of(args, ctg_start, ctg_end):
-    """The NEG-pass pileup (`--min-BQ 0`) serves both passes: the AFF pass's base-quality gate runs on the device."""
-    if args.mpileup_fn:
-        opener = gzip.open if args.mpileup_fn.endswith(".gz") else open
-        with opener(args.mpileup_fn, "rb") as f:
-            return f.read()
-    ext_s, ext_e = max(1, ctg_start - NPOS), ctg_end + NPOS
-    cmd = "{} mpileup --reverse-del --output-MQ -r {}:{}-{} --min-MQ 0 --min-BQ 0 -l {} --excl-flags 2316".format(
-        args.samtools, args.ctg_name, ext_s, ext_e, args.candidates_bed_regions)
-    if args.max_depth is not None:
-        cmd += " --max-depth {}".format(args.max_depth)
-    return subprocess.run(shlex.split(cmd) + [args.tumor_bam_fn], stdout=subprocess.PIPE, check=True).stdout
 
 
 def pileup_call(args, device="cuda"):
@@ -63,7 +46,7 @@ def pileup_call(args, device="cuda"):
     lik, edges = load_likelihood(args.likelihood_matrix_data, K)
     eng = Engine(aff, neg, lik, edges, min_bq=min_bq, min_rescale_cov=args.min_rescale_cov, device=device)
     max_indel = MAX_INDEL if args.max_indel_length is None else args.max_indel_length
-    pack = ColumnPack.from_mpileup(mpileup_text_of(args, ctg_start, ctg_end), ref, ref_start, max_indel)
+    pack = load_pack(args, ref, ref_start, ctg_start, ctg_end, max_indel)
     dp = pack.to_device(device)
     res = eng.run_device(dp, torch.tensor(sites, dtype=torch.int32, device=device))
     torch.cuda.synchronize()
@@ -114,6 +97,8 @@ def main():
     p.add_argument("--ref_fn", type=str, required=True)
     p.add_argument("--ctg_name", type=str, required=True)
     p.add_argument("--samtools", type=str, default="samtools")
+    p.add_argument("--bam_reader", type=str, default="samtools", choices=["samtools", "native"],
+                   help="'native': built-in BAM + BAI reader instead of a samtools subprocess (parity unpinned, see csrc/bam.cpp)")
     p.add_argument("--min_bq", type=int, default=None, help="AFF-pass base quality gate (default: the platform's)")
     p.add_argument("--max_depth", type=int, default=None)
     p.add_argument("--max_indel_length", type=int, default=None)

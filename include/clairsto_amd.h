@@ -87,6 +87,15 @@ typedef struct cto_pack cto_pack;   /* host-side pack incl. the key strings need
  * the row handling at :472-497.  max_indel_length: shared/param.py max_indel_length (60). */
 int cto_pack_from_mpileup(const char* text, size_t len, const char* ref_seq, int64_t ref_start,
                           size_t ref_len, int max_indel_length, cto_pack** out);
+/* BAM -> pack without the mpileup text: the columns `samtools mpileup --reverse-del --output-MQ
+ * -r ctg:start-end --min-MQ <min_mq> --min-BQ 0 [-l bed] --excl-flags <excl_flags> [--max-depth N]` would print
+ * (create_tensor_pileup_calling.py:426-446 runs that command), tokenised as cto_pack_from_mpileup would.  Needs the
+ * BAM's .bai index (bai_path NULL = bam_path + ".bai").  start/end are 1-based inclusive; bed = n_bed sorted,
+ * non-overlapping [begin, end) pairs in 0-based BED coordinates, or NULL.  PARITY UNPINNED against samtools (absent
+ * from both boxes); rules and known deviations are listed at the top of csrc/bam.cpp. */
+int cto_pack_from_bam(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
+                      const int64_t* bed, int64_t n_bed, const char* ref_seq, int64_t ref_start, size_t ref_len,
+                      int excl_flags, int min_mq, int max_depth, int max_indel_length, cto_pack** out);
 /* Build a pack from caller-made arrays (synthetic generators, BAM readers); key strings are the
  * alt_info keys ("IACG", "DACGT") concatenated, key_str_off[n_keys+1]. Arrays are copied. */
 int cto_pack_from_arrays(const cto_pack_view* host_view, const int64_t* key_str_off,

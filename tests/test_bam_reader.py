@@ -1,0 +1,122 @@
+"""BAM -> pack producer (csrc/bam.cpp) against an independent naive pileup of the same rules, on BAM + BAI
+files written by tests/bamutil.py.  PARITY UNPINNED against samtools (absent from both boxes): this pins the reader to
+the documented rules and to the text tokeniser, nothing more."""
+import numpy as np
+import pytest
+
+from bamutil import write_bam, mpileup_rows, ref_len_of
+
+
+def _random_reads(rng, n, ref_lens, paired_frac=0.0, weird=True):
+    reads = []
+    for i in range(n):
+        ref = int(rng.integers(0, len(ref_lens)))
+        L = ref_lens[ref]
+        pos = int(rng.integers(0, L - 450))
+        cigar = []
+        if rng.random() < 0.3:
+            cigar.append(("H" if rng.random() < 0.3 else "S", int(rng.integers(1, 12))))
+        if weird and rng.random() < 0.05:
+            cigar.append(("I", int(rng.integers(1, 4))))              # insertion before any aligned base
+        nblk = int(rng.integers(1, 6))
+        for b in range(nblk):
+            cigar.append((str(rng.choice(list("MMMM=X"))), int(rng.integers(1, 70))))
+            if b + 1 < nblk:
+                u = rng.random()
+                if u < 0.4:
+                    cigar.append(("I", int(rng.integers(1, 70 if rng.random() < 0.1 else 6))))
+                elif u < 0.8:
+                    cigar.append(("D", int(rng.integers(1, 70 if rng.random() < 0.1 else 6))))
+                    if weird and rng.random() < 0.1:
+                        cigar.append(("I", int(rng.integers(1, 3))))  # insertion right after a deletion
+                elif u < 0.9:
+                    cigar.append(("N", int(rng.integers(1, 30))))
+                elif weird:
+                    cigar.append(("P", 1))
+                    cigar.append(("I", 2))
+                else:
+                    cigar.append(("D", 1))
+        if rng.random() < 0.3:
+            cigar.append(("S", int(rng.integers(1, 12))))
+        # merge accidental adjacent equal ops is not needed for validity; query length from the CIGAR
+        qlen = sum(n for op, n in cigar if op in "MIS=X")
+        seq = "".join(rng.choice(list("ACGTACGTACGTN=RY"), size=qlen))
+        qual = None if rng.random() < 0.03 else [int(q) for q in rng.integers(0, 100, size=qlen)]
+        flag = 0
+        if rng.random() < 0.5:
+            flag |= 16
+        u = rng.random()
+        if u < 0.04:
+            flag |= 256
+        elif u < 0.08:
+            flag |= 2048
+        elif u < 0.10:
+            flag |= 1024                                                # duplicates are kept by --excl-flags 2316
+        if rng.random() < paired_frac:
+            flag |= 1 | (2 if rng.random() < 0.8 else 0) | (8 if rng.random() < 0.1 else 0)
+        mapq = int(rng.choice([0, 3, 19, 20, 60, 60, 60, 120, 255]))
+        reads.append(dict(name="r%d" % i, flag=flag, ref=ref, pos=pos, mapq=mapq, cigar=cigar, seq=seq, qual=qual))
+    reads.sort(key=lambda r: (r["ref"], r["pos"]))
+    return reads
+
+
+def _pack_arrays(pack):
+    a = {k: v.copy() for k, v in pack.numpy().items()}
+    a["keys"] = [pack.key_string(k) for k in range(pack.n_keys)]
+    return a
+
+
+def _assert_same(a, b):
+    for k in ("col_pos", "col_ref", "col_off", "key_off", "entries", "key_meta", "key_group"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert a["keys"] == b["keys"]
+
+
+@pytest.mark.parametrize("seed,paired", [(1, 0.0), (2, 0.5), (3, 0.0)])
+def test_pack_from_bam_matches_naive_pileup(tmp_path, seed, paired):
+    from clairs_to_amd.pack import ColumnPack
+    rng = np.random.default_rng(seed)
+    ref_lens = [40000, 3000]
+    refs = [("chrA", ref_lens[0]), ("chrB", ref_lens[1])]
+    ref_seqs = ["".join(rng.choice(list("ACGTN"), p=[.24, .24, .24, .24, .04], size=L)) for L in ref_lens]
+    reads = _random_reads(rng, 900, ref_lens, paired_frac=paired)
+    # a deep spot, to exercise max_depth
+    for i in range(40):
+        reads.append(dict(name="d%d" % i, flag=16 * (i & 1), ref=0, pos=20000 + (i % 3), mapq=60, cigar=[("M", 30)],
+                          seq="ACGT" * 7 + "AC", qual=[30] * 30))
+    reads.sort(key=lambda r: (r["ref"], r["pos"]))
+    bam = str(tmp_path / "t.bam")
+    write_bam(bam, refs, reads, block_payload=1500 if seed != 3 else 60000)
+    cases = [(0, 1, ref_lens[0], None, 8000), (0, 5000, 9000, None, 8000), (0, 16380, 16400, None, 8000),
+             (0, 19990, 20040, None, 10), (1, 1, ref_lens[1], None, 8000), (1, 700, 2400, [(650, 720), (900, 934), (2000, 2500)], 8000),
+             (0, 39000, 40000, [(38990, 39010)], 8000)]
+    for ref_i, start, end, bed, max_depth in cases:
+        name = refs[ref_i][0]
+        text = mpileup_rows(reads, ref_i, name, start, end, bed=bed, max_depth=max_depth, ref_seq=ref_seqs[ref_i], ref_start=1)
+        want = ColumnPack.from_mpileup(text, ref_seqs[ref_i], 1)
+        got = ColumnPack.from_bam(bam, name, start, end, ref_seqs[ref_i], 1, bed=bed, max_depth=max_depth)
+        assert want.n_cols > 0 or (start, end) == (16380, 16400)
+        _assert_same(_pack_arrays(got), _pack_arrays(want))
+
+
+def test_pack_from_bam_errors(tmp_path):
+    from clairs_to_amd.pack import ColumnPack
+    from clairs_to_amd._lib import CtoError
+    refs = [("chrA", 1000)]
+    reads = [dict(name="a", flag=0, ref=0, pos=10, mapq=60, cigar=[("M", 20)], seq="A" * 20, qual=[20] * 20)]
+    bam = str(tmp_path / "e.bam")
+    write_bam(bam, refs, reads)
+    ref = "A" * 1000
+    with pytest.raises(CtoError):
+        ColumnPack.from_bam(bam, "chrZ", 1, 100, ref, 1)              # unknown contig
+    with pytest.raises(CtoError):
+        ColumnPack.from_bam(str(tmp_path / "missing.bam"), "chrA", 1, 100, ref, 1)
+    with pytest.raises(CtoError):
+        ColumnPack.from_bam(bam, "chrA", 1, 100, ref, 1, bai_fn=str(tmp_path / "nope.bai"))
+    (tmp_path / "junk.bam").write_bytes(b"not a bam at all, definitely" * 10)
+    with pytest.raises(CtoError):
+        ColumnPack.from_bam(str(tmp_path / "junk.bam"), "chrA", 1, 100, ref, 1, bai_fn=bam + ".bai")
+    with pytest.raises(CtoError):
+        ColumnPack.from_bam(bam, "chrA", 1, 100, ref[:5], 1)          # reference too short for the covered positions
+    p = ColumnPack.from_bam(bam, "chrA", 500, 600, ref, 1)            # nothing there: an empty pack, not an error
+    assert p.n_cols == 0 and p.n_entries == 0

@@ -154,3 +154,75 @@ def test_bench_multi_rank_code_path(tmp_path):
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 3 and res["value"] > 0 and res["scaling"] == "weak"
     assert res["roofline"]["frac"] > 0 and "cpu_baseline" not in res
+
+
+def test_pileup_call_bam_readers_agree(tmp_path):
+    """One chunk called three ways - native BAM + BAI reader, `samtools mpileup` subprocess (a shim that prints the naive
+    pileup of the same BAM, as the real tool is absent here) and pre-made mpileup text - must give the same VCF bytes."""
+    import stat
+    from argparse import Namespace
+    from bamutil import write_bam, mpileup_rows
+    from clairs_to_amd.pileup_call import pileup_call
+    from clairs_to_amd.synth import likelihood_table
+    rng = np.random.default_rng(17)
+    L = 6000
+    ref = "".join(rng.choice(list("ACGT"), size=L))
+    reads = []
+    for i in range(700):
+        pos = int(rng.integers(0, L - 700))
+        n = int(rng.integers(300, 650))
+        seq, cigar, q, rp = [], [], [], pos
+        while n > 0:
+            m = int(min(n, rng.integers(20, 120)))
+            seg = list(ref[rp:rp + m])
+            for k in range(m):
+                if rng.random() < 0.03:
+                    seg[k] = "ACGT"[(("ACGT".index(seg[k])) + int(rng.integers(1, 4))) % 4]
+            seq += seg
+            cigar.append(("M", m))
+            rp += m
+            n -= m
+            if n > 0:
+                u = rng.random()
+                if u < 0.3:
+                    k = int(rng.integers(1, 5))
+                    seq += list(rng.choice(list("ACGT"), size=k))
+                    cigar.append(("I", k))
+                elif u < 0.6:
+                    k = int(rng.integers(1, 5))
+                    cigar.append(("D", k))
+                    rp += k
+        reads.append(dict(name="r%d" % i, flag=16 * int(rng.random() < 0.5), ref=0, pos=pos, mapq=int(rng.choice([60, 60, 60, 10])),
+                          cigar=cigar, seq="".join(seq), qual=[int(v) for v in np.clip(rng.normal(28, 8, size=len(seq)), 1, 50)]))
+    reads.sort(key=lambda r: r["pos"])
+    bam = str(tmp_path / "t.bam")
+    write_bam(bam, [("chr1", L)], reads)
+    fa = tmp_path / "ref.fa"
+    fa.write_text(">chr1\n" + "\n".join(ref[i:i + 60] for i in range(0, L, 60)) + "\n")
+    (tmp_path / "ref.fa.fai").write_text("chr1\t%d\t6\t60\t61\n" % L)
+    sites = list(range(900, 5100, 37))
+    bed = tmp_path / "cand.bed"
+    bed.write_text("".join("chr1\t%d\t%d\n" % (x - 17, x + 17) for x in sites))
+    ext_s, ext_e = min(sites) - 16 - 33, max(sites) + 18 + 33
+    text = mpileup_rows(reads, 0, "chr1", ext_s, ext_e, bed=[(x - 17, x + 17) for x in sites])
+    mp = tmp_path / "mp.txt"
+    mp.write_text(text)
+    shim = tmp_path / "samtools"
+    shim.write_text("#!/bin/sh\n# stands in for `samtools mpileup ...` (absent here): prints the prepared pileup\ncat %s\n" % mp)
+    shim.chmod(shim.stat().st_mode | stat.S_IEXEC)
+    paths = _pickle_models(tmp_path, "CvT", "BiGRU_NACGT", 4)
+    lik = tmp_path / "lik.txt"
+    np.savetxt(lik, likelihood_table(4, seed=11), fmt="%.17g")
+    out = {}
+    for tag, kw in (("native", dict(bam_reader="native", tumor_bam_fn=bam, mpileup_fn=None)),
+                    ("shim", dict(bam_reader="samtools", tumor_bam_fn=bam, mpileup_fn=None)),
+                    ("text", dict(bam_reader="samtools", tumor_bam_fn=None, mpileup_fn=str(mp)))):
+        vcf = str(tmp_path / (tag + ".vcf"))
+        n = pileup_call(Namespace(platform="ont", ref_fn=str(fa), ctg_name="chr1", samtools=str(shim), min_bq=None, max_depth=None,
+                                  max_indel_length=None, candidates_bed_regions=str(bed), chkpnt_fn_acgt=paths["model_acgt"],
+                                  chkpnt_fn_nacgt=paths["model_nacgt"], min_rescale_cov=50, disable_indel_calling=True,
+                                  likelihood_matrix_data=str(lik), call_fn=vcf, predict_fn=None, sample_name="SAMPLE", show_ref=True,
+                                  qual=0, pileup=True, **kw))
+        assert n > 50
+        out[tag] = open(vcf).read()
+    assert out["native"] == out["text"] == out["shim"]
