@@ -3,7 +3,7 @@ hot-path sub-modules this package replaces."""
 import importlib
 import sys
 
-SUBMODULES = ("extract_candidates_calling", "create_tensor_pileup_calling", "predict", "call_variants", "pileup_call",
+SUBMODULES = ("extract_candidates_calling", "create_tensor_pileup_calling", "predict", "call_variants", "pileup_call", "call_chunks",
               "sort_vcf", "postprocess_vcf")
 
 

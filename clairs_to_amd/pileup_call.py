@@ -28,10 +28,21 @@ from .predict import load_models, str2bool
 from .synth import PLATFORMS
 
 
-def pileup_call(args, device="cuda"):
+def make_engine(args, device="cuda"):
+    """Checkpoints + likelihood table -> Engine (done once per process; chunks re-use it)."""
     if not torch.cuda.is_available():
         sys.exit("[ERROR] clairs_to_amd pileup_call needs a HIP device; there is no CPU fallback")
     K = 4 if args.disable_indel_calling else 6
+    min_bq = args.min_bq if args.min_bq is not None else PLATFORMS.get(args.platform, PLATFORMS["ont"])["min_bq"]
+    aff, neg = load_models(args, device)
+    lik, edges = load_likelihood(args.likelihood_matrix_data, K)
+    return Engine(aff, neg, lik, edges, min_bq=min_bq, min_rescale_cov=args.min_rescale_cov, device=device)
+
+
+def pileup_call(args, device="cuda", engine=None):
+    eng = engine if engine is not None else make_engine(args, device)
+    device = eng.device
+    K = eng.K
     centres, ctg_start, ctg_end = read_candidates(args.candidates_bed_regions, args.ctg_name)
     if not centres:
         print("[INFO] {} total processed positions: 0".format(args.ctg_name), file=sys.stderr)
@@ -41,10 +52,6 @@ def pileup_call(args, device="cuda"):
     ref = read_region(args.ref_fn, args.ctg_name, ref_start, ctg_end + EXPAND_REF)
     if not ref:
         sys.exit("[ERROR] Failed to load reference sequence from file ({}).".format(args.ref_fn))
-    min_bq = args.min_bq if args.min_bq is not None else PLATFORMS.get(args.platform, PLATFORMS["ont"])["min_bq"]
-    aff, neg = load_models(args, device)
-    lik, edges = load_likelihood(args.likelihood_matrix_data, K)
-    eng = Engine(aff, neg, lik, edges, min_bq=min_bq, min_rescale_cov=args.min_rescale_cov, device=device)
     max_indel = MAX_INDEL if args.max_indel_length is None else args.max_indel_length
     pack = load_pack(args, ref, ref_start, ctg_start, ctg_end, max_indel)
     dp = pack.to_device(device)
@@ -89,31 +96,35 @@ def pileup_call(args, device="cuda"):
     return n_rows
 
 
-def main():
-    p = ArgumentParser(description="Pileup calling of one candidate chunk on the GPU: BED + BAM/mpileup -> VCF")
+def add_common_arguments(p):
     p.add_argument("--platform", type=str, default="ont")
     p.add_argument("--tumor_bam_fn", type=str, default=None)
-    p.add_argument("--mpileup_fn", type=str, default=None, help="samtools mpileup text (--min-BQ 0) instead of a BAM")
     p.add_argument("--ref_fn", type=str, required=True)
-    p.add_argument("--ctg_name", type=str, required=True)
     p.add_argument("--samtools", type=str, default="samtools")
     p.add_argument("--bam_reader", type=str, default="samtools", choices=["samtools", "native"],
                    help="'native': built-in BAM + BAI reader instead of a samtools subprocess (parity unpinned, see csrc/bam.cpp)")
     p.add_argument("--min_bq", type=int, default=None, help="AFF-pass base quality gate (default: the platform's)")
     p.add_argument("--max_depth", type=int, default=None)
     p.add_argument("--max_indel_length", type=int, default=None)
-    p.add_argument("--candidates_bed_regions", type=str, required=True)
     p.add_argument("--chkpnt_fn_acgt", type=str, required=True)
     p.add_argument("--chkpnt_fn_nacgt", type=str, required=True)
     p.add_argument("--min_rescale_cov", type=int, default=50)
     p.add_argument("--disable_indel_calling", type=str2bool, default=False)
     p.add_argument("--likelihood_matrix_data", type=str, required=True)
-    p.add_argument("--call_fn", type=str, required=True)
-    p.add_argument("--predict_fn", type=str, default=None, help="also write the probability rows (debugging tap)")
     p.add_argument("--sample_name", type=str, default="SAMPLE")
     p.add_argument("--show_ref", action="store_true")
     p.add_argument("--qual", type=int, default=0)
     p.add_argument("--pileup", action="store_true")
+
+
+def main():
+    p = ArgumentParser(description="Pileup calling of one candidate chunk on the GPU: BED + BAM/mpileup -> VCF")
+    add_common_arguments(p)
+    p.add_argument("--mpileup_fn", type=str, default=None, help="samtools mpileup text (--min-BQ 0) instead of a BAM")
+    p.add_argument("--ctg_name", type=str, required=True)
+    p.add_argument("--candidates_bed_regions", type=str, required=True)
+    p.add_argument("--call_fn", type=str, required=True)
+    p.add_argument("--predict_fn", type=str, default=None, help="also write the probability rows (debugging tap)")
     pileup_call(p.parse_args())
 
 

@@ -156,9 +156,9 @@ def test_bench_multi_rank_code_path(tmp_path):
     assert res["roofline"]["frac"] > 0 and "cpu_baseline" not in res
 
 
-def test_pileup_call_bam_readers_agree(tmp_path):
-    """One chunk called three ways - native BAM + BAI reader, `samtools mpileup` subprocess (a shim that prints the naive
-    pileup of the same BAM, as the real tool is absent here) and pre-made mpileup text - must give the same VCF bytes."""
+def _bam_scenario(tmp_path):
+    """A 6 kb contig, 700 synthetic long reads with substitutions and indels (BAM + BAI), candidates every 37 bp, the naive
+    pileup text of their windows and a `samtools` shim that prints it."""
     import stat
     from argparse import Namespace
     from bamutil import write_bam, mpileup_rows
@@ -210,19 +210,80 @@ def test_pileup_call_bam_readers_agree(tmp_path):
     shim = tmp_path / "samtools"
     shim.write_text("#!/bin/sh\n# stands in for `samtools mpileup ...` (absent here): prints the prepared pileup\ncat %s\n" % mp)
     shim.chmod(shim.stat().st_mode | stat.S_IEXEC)
+    return dict(bam=bam, fa=str(fa), bed=str(bed), mp=str(mp), shim=str(shim), sites=sites, L=L)
+
+
+def test_pileup_call_bam_readers_agree(tmp_path):
+    """One chunk called three ways - native BAM + BAI reader, `samtools mpileup` subprocess (a shim that prints the naive
+    pileup of the same BAM, as the real tool is absent here) and pre-made mpileup text - must give the same VCF bytes."""
+    import numpy as np
+    from argparse import Namespace
+    from clairs_to_amd.pileup_call import pileup_call
+    from clairs_to_amd.synth import likelihood_table
+    sc = _bam_scenario(tmp_path)
+    bam, fa, bed, mp, shim = sc["bam"], sc["fa"], sc["bed"], sc["mp"], sc["shim"]
     paths = _pickle_models(tmp_path, "CvT", "BiGRU_NACGT", 4)
     lik = tmp_path / "lik.txt"
     np.savetxt(lik, likelihood_table(4, seed=11), fmt="%.17g")
     out = {}
     for tag, kw in (("native", dict(bam_reader="native", tumor_bam_fn=bam, mpileup_fn=None)),
                     ("shim", dict(bam_reader="samtools", tumor_bam_fn=bam, mpileup_fn=None)),
-                    ("text", dict(bam_reader="samtools", tumor_bam_fn=None, mpileup_fn=str(mp)))):
+                    ("text", dict(bam_reader="samtools", tumor_bam_fn=None, mpileup_fn=mp))):
         vcf = str(tmp_path / (tag + ".vcf"))
-        n = pileup_call(Namespace(platform="ont", ref_fn=str(fa), ctg_name="chr1", samtools=str(shim), min_bq=None, max_depth=None,
-                                  max_indel_length=None, candidates_bed_regions=str(bed), chkpnt_fn_acgt=paths["model_acgt"],
+        n = pileup_call(Namespace(platform="ont", ref_fn=fa, ctg_name="chr1", samtools=shim, min_bq=None, max_depth=None,
+                                  max_indel_length=None, candidates_bed_regions=bed, chkpnt_fn_acgt=paths["model_acgt"],
                                   chkpnt_fn_nacgt=paths["model_nacgt"], min_rescale_cov=50, disable_indel_calling=True,
                                   likelihood_matrix_data=str(lik), call_fn=vcf, predict_fn=None, sample_name="SAMPLE", show_ref=True,
                                   qual=0, pileup=True, **kw))
         assert n > 50
         out[tag] = open(vcf).read()
     assert out["native"] == out["text"] == out["shim"]
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_call_chunks_matches_single_call(tmp_path, world):
+    """The chunk-list driver (one process per GPU; here 1 process, then 2 ranks sharing this box's GPU) writes the same
+    records, chunk by chunk and merged, as one pileup_call over all candidates."""
+    import subprocess
+    import sys
+    from argparse import Namespace
+    from conftest import ROOT
+    from clairs_to_amd.pileup_call import pileup_call
+    from clairs_to_amd.synth import likelihood_table
+    sc = _bam_scenario(tmp_path)
+    paths = _pickle_models(tmp_path, "CvT", "BiGRU_NACGT", 4)
+    lik = tmp_path / "lik.txt"
+    np.savetxt(lik, likelihood_table(4, seed=11), fmt="%.17g")
+    sites = sc["sites"]
+    cdir = tmp_path / "candidates"
+    cdir.mkdir()
+    names = []
+    for i in range(3):
+        part = sites[i * len(sites) // 3:(i + 1) * len(sites) // 3]
+        fn = cdir / ("chr1.%d_3_snv" % (i + 1))
+        fn.write_text("".join("chr1\t%d\t%d\n" % (x - 17, x + 17) for x in part))
+        names.append(str(fn))
+    (tmp_path / "CANDIDATES_FILES").write_text("".join(n + "\n" for n in names))
+    common = ["--platform", "ont", "--tumor_bam_fn", sc["bam"], "--ref_fn", sc["fa"], "--bam_reader", "native", "--chkpnt_fn_acgt",
+              paths["model_acgt"], "--chkpnt_fn_nacgt", paths["model_nacgt"], "--disable_indel_calling", "True",
+              "--likelihood_matrix_data", str(lik), "--show_ref"]
+    out_dir, merged, final = tmp_path / "vcf_output", tmp_path / "merged.vcf", tmp_path / "final.vcf"
+    cmd = ["-m", "clairs_to_amd", "call_chunks", "--chunk_list", str(tmp_path / "CANDIDATES_FILES"), "--output_dir", str(out_dir),
+           "--merged_vcf_fn", str(merged), "--final_vcf_fn", str(final)] + common
+    if world == 1:
+        full = [sys.executable] + cmd
+    else:
+        full = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29544"] + cmd
+    r = subprocess.run(full, cwd=ROOT, capture_output=True, text=True, timeout=280, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    one = tmp_path / "one.vcf"
+    pileup_call(Namespace(platform="ont", ref_fn=sc["fa"], ctg_name="chr1", samtools="samtools", bam_reader="native", tumor_bam_fn=sc["bam"],
+                          mpileup_fn=None, min_bq=None, max_depth=None, max_indel_length=None, candidates_bed_regions=sc["bed"],
+                          chkpnt_fn_acgt=paths["model_acgt"], chkpnt_fn_nacgt=paths["model_nacgt"], min_rescale_cov=50,
+                          disable_indel_calling=True, likelihood_matrix_data=str(lik), call_fn=str(one), predict_fn=None,
+                          sample_name="SAMPLE", show_ref=True, qual=0, pileup=True))
+    rec = lambda fn: [l for l in open(fn).read().split("\n") if l and not l.startswith("#")]
+    assert rec(merged) == rec(one) and len(rec(one)) > 50
+    assert sorted(os.listdir(out_dir)) == ["p_chr1.%d_3_snv.vcf" % (i + 1) for i in range(3)]
+    assert 0 < len(rec(final)) <= len(rec(merged))      # postprocess drops PASS records under the platform's AF cut-off
