@@ -32,8 +32,9 @@ def main():
         names = [r["Kernel_Name"] for r in rows]
         # last occurrence of the first kernel of a step (featurize) marks the last step
         starts = [i for i, n in enumerate(names) if "k_featurize_columns" in n]
-        if len(starts) >= 2:
-            a, b = starts[-2], starts[-1]
+        full = [(a, b) for a, b in zip(starts[:-1], starts[1:]) if b - a >= 10]    # whole steps, not the featurize-only tail
+        if full:
+            a, b = full[-1]
             t0 = int(rows[a]["Start_Timestamp"])
             with open(os.path.join(dst, "round1_%s_step_timeline.txt" % tag), "w") as f:
                 f.write("# one step of bench.py (launch order): start us, duration us, kernel\n")
