@@ -557,6 +557,24 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
                 for (int pq = 0; pq < NP; ++pq)
                     if ((pq * NX) / NP == sq - NH) gate_pair(pq / NB, pq % NB, hn, t);
             }
+            // Spread the next chunk's operand requests (NB*3 weight loads, MS LDS reads, 2 fc1 loads) between the MFMAs instead of
+            // issuing them as one burst at the top of the chunk: the wave issues in order, so a burst of ~12 memory instructions
+            // with their address arithmetic leaves the matrix pipe idle for ~10 % of every chunk.
+#ifndef CTO_GRU_IL
+#define CTO_GRU_IL 5
+#endif
+#ifndef CTO_GRU_NO_INTERLEAVE
+#pragma unroll
+            for (int g = 0; g < NB * 3 + 2; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, CTO_GRU_IL, 0);      // MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
+            }
+#pragma unroll
+            for (int g = 0; g < MS; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, CTO_GRU_IL, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (LAST) {
