@@ -444,13 +444,18 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
             }
     };
     // one 16-wide k chunk: three gate accumulators per (ms, nb)
-    auto mfma_chunk = [&](int cur, f32x4 (&r_)[MS][NB], f32x4 (&z_)[MS][NB], f32x4 (&n_)[MS][NB]) {
+    // k-steps of the last x chunk that hold real input channels: K is zero-padded from KIN to KP (layer 1: 34 -> 48) and
+    // element e of lane group kg is k = 16 c + 4 kg + e, so with r = KIN - 16 (NX - 1) real channels in the last chunk only
+    // the k-steps e < min(4, r) touch any of them (layer 1: r = 2, two of the four k-steps)
+    constexpr int NE_LAST = (KIN - 16 * (NX - 1)) < 4 ? (KIN - 16 * (NX - 1)) : 4;
+    auto mfma_chunk = [&](int cur, f32x4 (&r_)[MS][NB], f32x4 (&z_)[MS][NB], f32x4 (&n_)[MS][NB], int ne = 4) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const float4 br = Bq[cur][nb][0], bz = Bq[cur][nb][1], bn = Bq[cur][nb][2];
             const float brv[4] = {br.x, br.y, br.z, br.w}, bzv[4] = {bz.x, bz.y, bz.z, bz.w}, bnv[4] = {bn.x, bn.y, bn.z, bn.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                if (e >= ne) break;
 #pragma unroll
                 for (int ms = 0; ms < MS; ++ms) {
                     const float4 a4 = Aq[cur][ms];
@@ -512,7 +517,7 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
         const int cur = (c + P0) & 1, nxt = cur ^ 1;
         if (c + 1 < NX) { load_B(nxt, c + 1); load_Ax(nxt, c + 1, xbuf); }
         else { load_B(nxt, NX); load_F(0, 0, t_of(0)); }
-        mfma_chunk(cur, ar, az, ain);
+        mfma_chunk(cur, ar, az, ain, c == NX - 1 ? NE_LAST : 4);
         __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -551,7 +556,7 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
                 mfma_chunk(cur, ar, az, ahn);
                 fc1_chunk(cur);
             } else {
-                mfma_chunk(cur, nr, nz, nn);
+                mfma_chunk(cur, nr, nz, nn, sq - NH == NX - 1 ? NE_LAST : 4);
                 // gate arithmetic of step t, spread over the x chunks of step t+1
 #pragma unroll
                 for (int pq = 0; pq < NP; ++pq)
