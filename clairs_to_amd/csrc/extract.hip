@@ -111,8 +111,10 @@ __global__ __launch_bounds__(64 * XWAVES) void k_extract_candidates(
 }
 
 // scratch for the overflow path lives in the library (grown on demand, per process / device)
+// merged-allele counters, grown on demand; one process drives one GPU, so one buffer per process
 uint32_t* g_scratch = nullptr;
 int64_t g_scratch_n = 0;
+int g_scratch_dev = -1;
 
 }  // namespace
 
@@ -122,6 +124,11 @@ extern "C" int cto_extract_candidates(const cto_pack_view* dp, int min_mq, int m
     CTO_REQUIRE(dp && flags && depth, CTO_EINVAL, "cto_extract_candidates: null argument");
     if (dp->n_cols == 0) return CTO_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    {
+        int dev = -1;
+        CTO_HIP(hipGetDevice(&dev));
+        if (dev != g_scratch_dev) { g_scratch = nullptr; g_scratch_n = 0; g_scratch_dev = dev; }   // another device became current: start over there
+    }
     if (dp->n_keys > g_scratch_n) {
         if (g_scratch) (void)hipFree(g_scratch);
         g_scratch_n = dp->n_keys + dp->n_keys / 4 + 1024;

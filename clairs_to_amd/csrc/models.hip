@@ -75,6 +75,7 @@ struct StageDev {
 }  // namespace
 
 struct cto_model {
+    int device = -1;   // HIP device the weights and workspaces live on (the device that was current at creation)
     int kind = 0;      // 0 = CvT, 1 = BiGRU
     int n_out = 4;
     Arena arena;
@@ -460,6 +461,7 @@ extern "C" int cto_cvt_create(const cto_weights* w, const cto_cvt_cfg* cfg, cto_
                         cfg->heads[i] <= 8 && cfg->depth[i] >= 1,
                     CTO_EUNSUPPORTED, "CvT stage %d config out of range (emb_dim <= 128, multiple of 4)", i + 1);
     std::unique_ptr<cto_model> m(new cto_model());
+    CTO_HIP(hipGetDevice(&m->device));
     m->kind = 0;
     m->n_out = cfg->n_out;
     Arena& a = m->arena;
@@ -552,6 +554,7 @@ extern "C" int cto_bigru_create(const cto_weights* w, int n_out, cto_model** out
     CTO_REQUIRE(w && out, CTO_EINVAL, "cto_bigru_create: null argument");
     CTO_REQUIRE(n_out == 4 || n_out == 6, CTO_EINVAL, "n_out must be 4 or 6");
     std::unique_ptr<cto_model> m(new cto_model());
+    CTO_HIP(hipGetDevice(&m->device));
     m->kind = 1;
     m->n_out = n_out;
     int rc = CTO_OK;
@@ -574,6 +577,12 @@ extern "C" int cto_model_forward(cto_model* m, const float* x, int64_t B, float*
     CTO_REQUIRE(m && x && logits && B >= 0, CTO_EINVAL, "cto_model_forward: bad argument");
     CTO_REQUIRE(B * 33 < (int64_t(1) << 31) / 640, CTO_EUNSUPPORTED, "batch too large for 32-bit row indices; split it");
     if (B == 0) return CTO_OK;
+    {
+        int dev = -1;
+        CTO_HIP(hipGetDevice(&dev));
+        CTO_REQUIRE(dev == m->device, CTO_EINVAL, "cto_model_forward: model lives on device %d but device %d is current (one process per GPU)",
+                    m->device, dev);
+    }
     int rc = ensure_ws(m, B);
     if (rc != CTO_OK) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
