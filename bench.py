@@ -28,8 +28,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32
 
 def pmc_traffic(batch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
-    profiles/round1_g_pmc_hbm_traffic.json, collected at batch 4096); None for any other batch."""
-    fn = os.path.join(ROOT, "profiles", "round1_g_pmc_hbm_traffic.json")
+    profiles/round1_h_pmc_hbm_traffic.json, collected at batch 4096); None for any other batch."""
+    fn = os.path.join(ROOT, "profiles", "round1_h_pmc_hbm_traffic.json")
     if batch != 4096 or not os.path.exists(fn):
         return None
     k = json.load(open(fn))["kernels"]
@@ -40,7 +40,7 @@ def pmc_traffic(batch):
 
 
 def pmc_traffic_featurize(batch):
-    fn = os.path.join(ROOT, "profiles", "round1_g_pmc_hbm_traffic.json")
+    fn = os.path.join(ROOT, "profiles", "round1_h_pmc_hbm_traffic.json")
     if batch != 4096 or not os.path.exists(fn):
         return None
     tot = 0
@@ -227,7 +227,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "k_gru_layer_rot<256,256,192,2,true> (BiGRU layer 2 + fused fc1, both directions)",
                          "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(args.batch),
-                         "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/round1_g_pmc_hbm_traffic.json)",
+                         "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/round1_h_pmc_hbm_traffic.json)",
                          "launch_ms": round(mean_ms.value, 4), "launches_measured": int(n_meas),
                          "flops_per_launch": flops_per_launch},
             "roofline_tensor_creation": {"bound": "hbm", "kernel": "k_featurize_columns + k_gather_windows (both passes, rescale fused)",
