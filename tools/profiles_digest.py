@@ -61,6 +61,35 @@ def main():
                 "--warmup 1 --no-cpu-baseline`, batch 4096; raw counter values in KB (calibrated 1.0x on known byte counts of "
                 "these access patterns, see profiles/README.md).")
         json.dump(dict(note=note, kernels=kern), open(os.path.join(dst, "round1_%s_pmc_hbm_traffic.json" % tag), "w"), indent=1)
+    # matrix-pipe occupancy per kernel
+    vals = {}
+    for d in glob.glob(os.path.join(out, "pmc_SQ_*")) + glob.glob(os.path.join(out, "pmc_GRBM*")):
+        fn = find(d, "counter_collection.csv")
+        if not fn or not os.path.isdir(d):
+            continue
+        for r in csv.DictReader(open(fn)):
+            vals.setdefault(r["Kernel_Name"], {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    mf = {}
+    for k, v in vals.items():
+        if "SQ_INSTS_MFMA" not in v or "SQ_WAVE_CYCLES" not in v:
+            continue
+        n_mfma = sum(v["SQ_INSTS_MFMA"]) / len(v["SQ_INSTS_MFMA"])
+        wave_q = sum(v["SQ_WAVE_CYCLES"]) / len(v["SQ_WAVE_CYCLES"])
+        if n_mfma <= 0:
+            continue
+        e = dict(SQ_INSTS_MFMA=round(n_mfma), SQ_WAVE_CYCLES_quad=round(wave_q),
+                 mfma_issue_cycles_over_wave_cycles=round(n_mfma * 32.0 / (wave_q * 4.0), 4))
+        for c in ("SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
+            if c in v:
+                e[c] = round(sum(v[c]) / len(v[c]))
+        mf[k] = e
+    if mf:
+        note = ("rocprofv3 --kernel-trace --pmc passes (SQ_INSTS_MFMA SQ_WAVE_CYCLES; SQ_BUSY_CYCLES GRBM_GUI_ACTIVE) over `python bench.py "
+                "--steps 3 --warmup 1 --no-cpu-baseline`.  v_mfma_f32_16x16x4_f32 occupies its SIMD's matrix pipe for 32 cycles; "
+                "SQ_WAVE_CYCLES counts quad-cycles summed over waves, so mfma_issue_cycles_over_wave_cycles = 32 N_mfma / (4 SQ_WAVE_CYCLES) "
+                "is the matrix-pipe occupancy seen by a wave (with two waves per SIMD, as in k_cvt_block, the pipe's own occupancy is "
+                "up to twice that).")
+        json.dump(dict(note=note, kernels=mf), open(os.path.join(dst, "round1_%s_pmc_mfma.json" % tag), "w"), indent=1)
     print("digest:", sorted(os.listdir(dst)))
 
 
