@@ -494,10 +494,20 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
             hprev[ms][nb][r] = hv;
             const int row = ms * 16 + kg * 4 + r;
             hn[row * HS + hcol] = hv;
-            if constexpr (!FUSE_FC1) {
-                const int site = site0 + row;
-                if (site < B) out[(int64_t(site) * T + t) * (2 * H) + dir * H + hcol] = hv;
-            }
+        }
+    };
+    // Layer output (not fused with fc1): h_t leaves for HBM one step later, as whole 16-byte pieces of its LDS tile - four
+    // coalesced stores per lane spread over the next step's h part instead of 16 scalar stores with their address arithmetic
+    // in the middle of the gate code (the x part of layer 1 is only 144 MFMAs long and could not hide them).
+    constexpr int OPER = (TILE * (H / 4) + NTHR - 1) / NTHR;
+    auto store_tile = [&](const float* tile, int tt) {
+#pragma unroll
+        for (int q = 0; q < OPER; ++q) {
+            const int u = threadIdx.x + q * NTHR;
+            const int row = u / (H / 4), c4 = (u - row * (H / 4)) * 4;
+            if (u < TILE * (H / 4) && site0 + row < B)
+                *reinterpret_cast<float4*>(out + (int64_t(site0 + row) * T + tt) * (2 * H) + dir * H + c4) =
+                    *reinterpret_cast<const float4*>(tile + row * HS + c4);
         }
     };
 
@@ -553,6 +563,9 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
                 else { load_B(nxt, NX); load_F(0, 0, t); }     // first h chunk of the next step (its fc1 slice is that of h_t)
             }
             if (sq < NH) {
+                if constexpr (!FUSE_FC1) {
+                    if (sq == 1 && step > 0) store_tile(hc, tprev);
+                }
                 mfma_chunk(cur, ar, az, ahn);
                 fc1_chunk(cur);
             } else {
@@ -579,6 +592,15 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
                 __builtin_amdgcn_sched_group_barrier(0x008, CTO_GRU_IL, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
             }
+            if (!FUSE_FC1 && sq == 1) {
+#pragma unroll
+                for (int g = 0; g < OPER; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // tile piece from LDS
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);  // ... to HBM
+                }
+            }
 #endif
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -601,6 +623,10 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
     };
     for (int step = 0; step + 1 < T; ++step) step_body(step, std::false_type{});
     step_body(T - 1, std::true_type{});
+    if constexpr (!FUSE_FC1) {
+        __syncthreads();                                  // h_{T-1} is complete in LDS
+        store_tile(hbuf + (T & 1) * (TILE * HS), t_of(T - 1));
+    }
 #ifdef CTO_GRU_CLOCKS
     if (blockIdx.x == 7 && threadIdx.x == 0) {
         const int o = FUSE_FC1 ? 4 : 0;
