@@ -325,8 +325,8 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TILE = MS * 16, NTHR = 256;
     constexpr int XS = KP + 4;
-    constexpr bool XV = (KIN % 4 == 0);
-    constexpr int XQ = XV ? TILE * (KIN / 4) : TILE * KIN;
+    constexpr int XW = (KIN % 4 == 0) ? 4 : ((KIN % 2 == 0) ? 2 : 1);    // floats per staging unit (layer 1: 34 channels -> float2)
+    constexpr int XQ = TILE * (KIN / XW);
     constexpr int XPER = (XQ + NTHR - 1) / NTHR;
     float* hbuf = smem;                       // [2][TILE][HS]
     float* xbuf = smem + 2 * TILE * HS;       // [2][TILE][XS]
@@ -376,14 +376,12 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
         for (int q = 0; q < XPER; ++q) {
             const int u = threadIdx.x + q * NTHR;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (u < XQ) {
-                if constexpr (XV) {
-                    const int row = u / (KIN / 4), c4 = (u - row * (KIN / 4)) * 4;
-                    if (site0 + row < B) v = *reinterpret_cast<const float4*>(x + (int64_t(site0 + row) * T + t) * KIN + c4);
-                } else {
-                    const int row = u / KIN, c = u - row * KIN;
-                    if (site0 + row < B) v.x = x[(int64_t(site0 + row) * T + t) * KIN + c];
-                }
+            const int row = u / (KIN / XW), c = (u - row * (KIN / XW)) * XW;
+            if (u < XQ && site0 + row < B) {
+                const float* src = x + (int64_t(site0 + row) * T + t) * KIN + c;     // (site, t) rows are KIN floats: XW-aligned
+                if constexpr (XW == 4) v = *reinterpret_cast<const float4*>(src);
+                else if constexpr (XW == 2) { const float2 w2 = *reinterpret_cast<const float2*>(src); v.x = w2.x; v.y = w2.y; }
+                else v.x = *src;
             }
             xstage[q] = v;
         }
@@ -393,14 +391,12 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
 #pragma unroll
         for (int q = 0; q < XPER; ++q) {
             const int u = threadIdx.x + q * NTHR;
+            const int row = u / (KIN / XW), c = (u - row * (KIN / XW)) * XW;
             if (u < XQ) {
-                if constexpr (XV) {
-                    const int row = u / (KIN / 4), c4 = (u - row * (KIN / 4)) * 4;
-                    *reinterpret_cast<float4*>(xb + row * XS + c4) = xstage[q];
-                } else {
-                    const int row = u / KIN, c = u - row * KIN;
-                    xb[row * XS + c] = xstage[q].x;
-                }
+                float* dst = xb + row * XS + c;
+                if constexpr (XW == 4) *reinterpret_cast<float4*>(dst) = xstage[q];
+                else if constexpr (XW == 2) *reinterpret_cast<float2*>(dst) = make_float2(xstage[q].x, xstage[q].y);
+                else *dst = xstage[q].x;
             }
         }
     };
