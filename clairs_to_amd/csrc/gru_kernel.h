@@ -40,7 +40,8 @@ __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __bui
 template <int KIN, int KP, int H, int MS, int MH, bool FUSE_FC1>
 __global__ __launch_bounds__(256 * MH) void k_gru_layer(const float* __restrict__ x, const float* __restrict__ Wcat,
                                                    const float* __restrict__ bias, float* __restrict__ out,
-                                                   const float* __restrict__ fc1w, float* __restrict__ fc1_part, int B) {
+                                                   const float* __restrict__ fc1w, float* __restrict__ fc1_part, int B, int site_begin,
+                                                       int site_end) {
     constexpr int NB = H / 64, T = 33, KT = KP + H + GRU_WPAD, HS = H + 4, NX = KP / 16, NH = H / 16, NC = NX + NH;
     constexpr int FC1_K = T * 2 * H;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -55,7 +56,8 @@ __global__ __launch_bounds__(256 * MH) void k_gru_layer(const float* __restrict_
     const int rb = mh * MS * 16;          // first tile row of this wave
     const int j = lane & 15, kg = lane >> 4;
     const int dir = blockIdx.x & 1;
-    const int site0 = (blockIdx.x >> 1) * TILE;
+    // the launch covers sites [site_begin, site_end) of a batch of B (sub-ranges let the host mix tile heights, see gru.hip)
+    const int site0 = site_begin + (blockIdx.x >> 1) * TILE;
     const float* Wd = Wcat + int64_t(dir) * 3 * H * KT;
     const float* bd = bias + dir * 4 * H;
 
@@ -98,10 +100,10 @@ __global__ __launch_bounds__(256 * MH) void k_gru_layer(const float* __restrict_
             if (u < XQ) {
                 if constexpr (XV) {
                     const int row = u / (KIN / 4), c4 = (u - row * (KIN / 4)) * 4;
-                    if (site0 + row < B) v = *reinterpret_cast<const float4*>(x + (int64_t(site0 + row) * T + t) * KIN + c4);
+                    if (site0 + row < site_end) v = *reinterpret_cast<const float4*>(x + (int64_t(site0 + row) * T + t) * KIN + c4);
                 } else {
                     const int row = u / KIN, c = u - row * KIN;
-                    if (site0 + row < B) v.x = x[(int64_t(site0 + row) * T + t) * KIN + c];
+                    if (site0 + row < site_end) v.x = x[(int64_t(site0 + row) * T + t) * KIN + c];
                 }
             }
             xstage[q] = v;
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(256 * MH) void k_gru_layer(const float* __restrict_
                     hn[row * HS + hcol] = hv;
                     if constexpr (!FUSE_FC1) {
                         const int site = site0 + row;
-                        if (site < B) out[(int64_t(site) * T + t) * (2 * H) + dir * H + hcol] = hv;
+                        if (site < site_end) out[(int64_t(site) * T + t) * (2 * H) + dir * H + hcol] = hv;
                     }
                 }
             }
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256 * MH) void k_gru_layer(const float* __restrict_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int site = site0 + rb + ms * 16 + kg * 4 + r;
-                    if (site < B) part[int64_t(site) * 128 + wave * 32 + nt * 16 + j] = accf[ms][nt][r];
+                    if (site < site_end) part[int64_t(site) * 128 + wave * 32 + nt * 16 + j] = accf[ms][nt][r];
                 }
     }
 }
@@ -319,7 +321,8 @@ __device__ long long g_gru_clk[8];
 template <int KIN, int KP, int H, int MS, bool FUSE_FC1>
 __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__ x, const float* __restrict__ Wcat,
                                                        const float* __restrict__ bias, float* __restrict__ out,
-                                                       const float* __restrict__ fc1w, float* __restrict__ fc1_part, int B) {
+                                                       const float* __restrict__ fc1w, float* __restrict__ fc1_part, int B, int site_begin,
+                                                       int site_end) {
     constexpr int NB = H / 64, T = 33, KT = KP + H + GRU_WPAD, HS = H + 4, NX = KP / 16, NH = H / 16, NC = NX + NH, NP = MS * NB;
     constexpr int FC1_K = T * 2 * H;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -333,7 +336,8 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kg = lane >> 4;
     const int dir = blockIdx.x & 1;
-    const int site0 = (blockIdx.x >> 1) * TILE;
+    // the launch covers sites [site_begin, site_end) of a batch of B (sub-ranges let the host mix tile heights, see gru.hip)
+    const int site0 = site_begin + (blockIdx.x >> 1) * TILE;
     const float* Wd = Wcat + int64_t(dir) * 3 * H * KT;
     const float* bd = bias + dir * 4 * H;
     auto t_of = [&](int step) { return dir == 0 ? step : T - 1 - step; };
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
             const int u = threadIdx.x + q * NTHR;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const int row = u / (KIN / XW), c = (u - row * (KIN / XW)) * XW;
-            if (u < XQ && site0 + row < B) {
+            if (u < XQ && site0 + row < site_end) {
                 const float* src = x + (int64_t(site0 + row) * T + t) * KIN + c;     // (site, t) rows are KIN floats: XW-aligned
                 if constexpr (XW == 4) v = *reinterpret_cast<const float4*>(src);
                 else if constexpr (XW == 2) { const float2 w2 = *reinterpret_cast<const float2*>(src); v.x = w2.x; v.y = w2.y; }
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
         for (int q = 0; q < OPER; ++q) {
             const int u = threadIdx.x + q * NTHR;
             const int row = u / (H / 4), c4 = (u - row * (H / 4)) * 4;
-            if (u < TILE * (H / 4) && site0 + row < B)
+            if (u < TILE * (H / 4) && site0 + row < site_end)
                 *reinterpret_cast<float4*>(out + (int64_t(site0 + row) * T + tt) * (2 * H) + dir * H + c4) =
                     *reinterpret_cast<const float4*>(tile + row * HS + c4);
         }
@@ -658,7 +662,7 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int site = site0 + ms * 16 + kg * 4 + r;
-                    if (site < B) part[int64_t(site) * 128 + wave * 32 + nt * 16 + j] = accf[ms][nt][r];
+                    if (site < site_end) part[int64_t(site) * 128 + wave * 32 + nt * 16 + j] = accf[ms][nt][r];
                 }
     }
 }
