@@ -383,8 +383,18 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
         for (int r = wave * 4 + grp; r < MT * 16; r += NWV * 4) {
             const float* xr = src + r * RS + l16 * CPL;
             float v[CPL], sum = 0.f;
+            if constexpr (CPL % 4 == 0) {
 #pragma unroll
-            for (int i = 0; i < CPL; ++i) { v[i] = xr[i]; sum += v[i]; }
+                for (int i = 0; i < CPL; i += 4) {
+                    const float4 q = *reinterpret_cast<const float4*>(xr + i);
+                    v[i] = q.x; v[i + 1] = q.y; v[i + 2] = q.z; v[i + 3] = q.w;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) v[i] = xr[i];
+            }
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) sum += v[i];
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
             const float mean = sum / float(C);
@@ -395,8 +405,15 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
             for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 16);
             const float inv = 1.0f / (sqrtf(sq / float(C)) + 1e-5f);
             float* yr = dst + r * RS + l16 * CPL;
+            if constexpr (CPL % 4 == 0) {
 #pragma unroll
-            for (int i = 0; i < CPL; ++i) yr[i] = v[i] * inv * gv[i] + bv[i];
+                for (int i = 0; i < CPL; i += 4)
+                    *reinterpret_cast<float4*>(yr + i) = make_float4(v[i] * inv * gv[i] + bv[i], v[i + 1] * inv * gv[i + 1] + bv[i + 1],
+                                                                     v[i + 2] * inv * gv[i + 2] + bv[i + 2], v[i + 3] * inv * gv[i + 3] + bv[i + 3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) yr[i] = v[i] * inv * gv[i] + bv[i];
+            }
         }
     };
 
@@ -648,7 +665,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
         stamp();
     }
 
-    // ---- phase 7: h += ff(y) + bias -> HBM (last block of the network: -> LDS, the classifier consumes it there) ----
+    // ---- phase 7: h += ff(y) + bias in LDS, then -> HBM (last block of the network: the classifier consumes it in LDS) ----
 #pragma unroll
     for (int nt = 0; nt < NTC; ++nt) {
         if (!own_c) break;
@@ -660,11 +677,16 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = (mbase + mt) * 16 + 4 * kg + r;
-                    const float v = sh[row * RS + col] + acc_f[mt][nt][r] + bv;
-                    if constexpr (HEAD) sh[row * RS + col] = v;
-                    else if (row < rows_valid) hg[row * C + col] = v;
+                    sh[row * RS + col] += acc_f[mt][nt][r] + bv;     // the tile leaves through LDS: 16-byte coalesced stores below
                 }
             }
+    }
+    if constexpr (!HEAD) {
+        __syncthreads();
+        for (int i = tid; i < rows_valid * (C / 4); i += NT) {
+            const int r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
+            *reinterpret_cast<float4*>(hg + r * C + c4) = *reinterpret_cast<const float4*>(sh + r * RS + c4);
+        }
     }
     if constexpr (HEAD) {
         // ---- phase 8: fc1 over the flattened [W][C] features of each site (model.py:239-247; torch's c*W + w order is folded
