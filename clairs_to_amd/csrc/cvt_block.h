@@ -340,11 +340,17 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
         for (int i = tid; i < MT * 16; i += NT) *reinterpret_cast<float4*>(sh + i * RS + C) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if constexpr (CIN == 0) {
-        for (int i = tid; i < MT * 16 * (C / 4); i += NT) {
-            const int r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < rows_valid) v = *reinterpret_cast<const float4*>(hg + r * C + c4);
-            *reinterpret_cast<float4*>(sh + r * RS + c4) = v;
+        constexpr int NIT = (MT * 16 * (C / 4) + NT - 1) / NT;
+        float4 stage[NIT];
+#pragma unroll
+        for (int q = 0; q < NIT; ++q) {
+            const int i = tid + q * NT, r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
+            stage[q] = (i < MT * 16 * (C / 4) && r < rows_valid) ? *reinterpret_cast<const float4*>(hg + r * C + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < NIT; ++q) {
+            const int i = tid + q * NT, r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
+            if (i < MT * 16 * (C / 4)) *reinterpret_cast<float4*>(sh + r * RS + c4) = stage[q];
         }
         for (int i = tid; i < (MTKV * 16 - RKV) * RS; i += NT) sykv[RKV * RS + i] = 0.f;
     } else {
@@ -354,18 +360,30 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
         static_assert(CIN % 2 == 0, "stage input channels must be even");
         float* sin = smem + G::OFF_Y;
         const float* xg = p.xin + int64_t(site0) * WIN * CIN;
-        for (int i = tid; i < NPOS * SLOTS; i += NT) {
+        // all of a thread's pieces are requested before the first one is written to LDS: one HBM round trip, not one per piece
+        constexpr int NIT = (NPOS * SLOTS + NT - 1) / NT;
+        float4 stage[NIT];
+#pragma unroll
+        for (int q = 0; q < NIT; ++q) {
+            const int i = tid + q * NT;
             const int pp = i / SLOTS, c = (i - pp * SLOTS) * VW;
             const int s = pp / (2 * W), pos = pp - s * 2 * W - 1;
-            const bool ok = pos >= 0 && s < nsite && c < CIN;
-            if constexpr (VW == 4) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) v = *reinterpret_cast<const float4*>(xg + (s * WIN + pos) * CIN + c);
-                *reinterpret_cast<float4*>(sin + pp * PS + c) = v;
-            } else {
-                float2 v = make_float2(0.f, 0.f);
-                if (ok) v = *reinterpret_cast<const float2*>(xg + (s * WIN + pos) * CIN + c);
-                *reinterpret_cast<float2*>(sin + pp * PS + c) = v;
+            const bool ok = i < NPOS * SLOTS && pos >= 0 && s < nsite && c < CIN;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                const float* src = xg + (s * WIN + pos) * CIN + c;
+                if constexpr (VW == 4) v = *reinterpret_cast<const float4*>(src);
+                else { const float2 w2 = *reinterpret_cast<const float2*>(src); v.x = w2.x; v.y = w2.y; }
+            }
+            stage[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < NIT; ++q) {
+            const int i = tid + q * NT;
+            const int pp = i / SLOTS, c = (i - pp * SLOTS) * VW;
+            if (i < NPOS * SLOTS) {
+                if constexpr (VW == 4) *reinterpret_cast<float4*>(sin + pp * PS + c) = stage[q];
+                else *reinterpret_cast<float2*>(sin + pp * PS + c) = make_float2(stage[q].x, stage[q].y);
             }
         }
     }
