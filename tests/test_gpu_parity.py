@@ -409,3 +409,54 @@ def test_bigru_on_poisoned_lds(dev, oracle_lib, cls, K):
         got = m.logits(torch.from_numpy(x).to(dev)).cpu().numpy()
         ref = oracle.bigru_forward(w, K, x)
         assert np.isfinite(got).all() and np.abs(got - ref).max() < 1e-4, B
+
+
+def test_featurize_matches_reference_edge_columns(dev):
+    """Every golden column of tests/golden/columns.json.gz (the reference's decode_pileup_bases on hand-made and random
+    columns: 59/60-base deletions, 60/61-base insertions, `*+` / `#+`, N reference, `^x`, `$`, MQ 19/20, BQ 29/30 ...)
+    through tokeniser -> pack -> HIP kernels: the 34 channels, the depth and the alt_info string must be the reference's."""
+    import torch
+    from clairs_to_amd.pack import ColumnPack
+    from clairs_to_amd.featurize import featurize, alt_infos
+    cases = load_json_gz("columns.json.gz")
+    checked = skipped = 0
+    for i, c in enumerate(cases):
+        n_tok = sum(1 for ch in _strip_indels(c["bases"]) if ch in "ACGTNacgtn*#")
+        if not (n_tok == len(c["bq"]) == len(c["mq"])):
+            skipped += 1                   # malformed rows: documented deviation (DESIGN.md section 4, item 2)
+            continue
+        text = "chr1\t1000\tN\t%d\t%s\t%s\t%s\n" % (n_tok, c["bases"], c["bq"], c["mq"])
+        pack = ColumnPack.from_mpileup(text, c["chunk_ref"], 1000)
+        # the fixture draws the reference base and the 60-base reference slice independently (decode_pileup_bases takes both):
+        # the slice goes in as the reference sequence (deletion keys), the base is patched into the pack (channel negation)
+        pack.numpy()["col_ref"][0] = "ACGT".index(c["ref"])
+        feat = featurize(pack.to_device(dev), torch.tensor([1000], dtype=torch.int32, device=dev), 0, 0, want_raw=True, want_x=False)
+        info = feat.site_info.cpu().numpy()
+        got = feat.raw_neg.cpu().numpy()[0, 16].astype(int).tolist()
+        assert got == c["tensor"], "column %d: %r" % (i, c["bases"])
+        assert feat.raw_aff.cpu().numpy()[0, 16].astype(int).tolist() == c["tensor"]        # min_bq 0: both passes agree
+        assert int(info[0, 2]) == int(c["alt_info"].split("-")[0]) if c["alt_info"] else True
+        if c["cand"] and c["alt_info"]:
+            assert alt_infos(feat, pack, info, pass_idx=1)[0] == c["alt_info"], "column %d alt_info" % i
+        checked += 1
+    assert checked >= 200 and skipped <= len(cases) // 5
+
+
+def _strip_indels(bases):
+    """mpileup base string without the `+n<seq>` / `-n<seq>` runs and without the character after `^`."""
+    out, i = [], 0
+    while i < len(bases):
+        ch = bases[i]
+        if ch in "+-":
+            j = i + 1
+            n = 0
+            while j < len(bases) and bases[j].isdigit():
+                n = n * 10 + int(bases[j])
+                j += 1
+            i = j + n
+        elif ch == "^":
+            i += 2
+        else:
+            out.append(ch)
+            i += 1
+    return "".join(out)
