@@ -4,13 +4,13 @@
 // its depth and some non-reference allele pass the AF / read-count gates (decode_pileup_bases :55-169, the
 // candidate sets at :352-372).  Here the same gates run on the pack that tensor creation consumes, so a BAM is
 // piled up ONCE for extraction, the AFF tensor and the NEG tensor.  HBM-bound integer work, same shape as
-// k_featurize_columns: one wave per 16 consecutive columns, counters in LDS, per-allele (merged key) counts in an
+// k_featurize_columns: one wave per 8 consecutive columns, counters in LDS, per-allele (merged key) counts in an
 // LDS table with a global-atomic overflow path.
 #include "common.h"
 
 namespace {
 
-constexpr int XCOLS = 16, XWAVES = 4, GCAP = 128;
+constexpr int XCOLS = 8, XWAVES = 4, GCAP = 128, XCOPY = 2;    // same tiling as k_featurize_columns: short waves, two counter copies
 
 struct XPack {
     int64_t n_cols;
@@ -25,7 +25,7 @@ struct XPack {
 __global__ __launch_bounds__(64 * XWAVES) void k_extract_candidates(
     XPack pk, int min_mq, int min_bq, double snv_min_af, double indel_min_af, double min_coverage, int alt_base_num,
     int select_indel, uint32_t* __restrict__ gscratch, uint8_t* __restrict__ flags, int32_t* __restrict__ depth_out) {
-    __shared__ uint32_t s_cnt[XWAVES][XCOLS][12];     // depth, all-base ACGT (4), pure-base ACGT (4)
+    __shared__ uint32_t s_cnt[XWAVES][XCOPY][XCOLS][12];     // '*' / '#' placeholders, all-base ACGT (4), pure-base ACGT (4)
     __shared__ int64_t s_off[XWAVES][XCOLS + 1];
     __shared__ int32_t s_koff[XWAVES][XCOLS + 1];
     __shared__ uint32_t s_g[XWAVES][GCAP];            // merged-allele counts, indexed like the wave's keys
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(64 * XWAVES) void k_extract_candidates(
     const int64_t c0 = (int64_t(blockIdx.x) * XWAVES + w) * XCOLS;
     int ncol = 0;
     if (c0 < pk.n_cols) ncol = int(pk.n_cols - c0 < XCOLS ? pk.n_cols - c0 : XCOLS);
-    for (int i = lane; i < XCOLS * 12; i += 64) (&s_cnt[w][0][0])[i] = 0u;
+    for (int i = lane; i < XCOPY * XCOLS * 12; i += 64) (&s_cnt[w][0][0][0])[i] = 0u;
     for (int i = lane; i < GCAP; i += 64) s_g[w][i] = 0u;
     if (lane <= XCOLS) {
         const int64_t ci = c0 + (lane < ncol ? lane : ncol);
@@ -44,6 +44,10 @@ __global__ __launch_bounds__(64 * XWAVES) void k_extract_candidates(
     const int kbase = s_koff[w][0];
     const int nkeys_w = s_koff[w][ncol] - kbase;
     const bool in_lds = nkeys_w <= GCAP;
+    if (!in_lds) {      // rare: the wave owns this slice of the global scratch exclusively and zeroes it itself
+        for (int k = lane; k < nkeys_w; k += 64) gscratch[kbase + k] = 0u;
+        __threadfence();
+    }
     if (ncol > 0) {
         const int64_t e_end = s_off[w][ncol];
         int cl = 0;
@@ -56,9 +60,8 @@ __global__ __launch_bounds__(64 * XWAVES) void k_extract_candidates(
             const uint32_t b = ent & 15u, kind = (ent >> 4) & 3u, kid = ent >> 21;
             const int bq = int((ent >> 6) & 127u), mq = int((ent >> 13) & 255u);
             if (mq >= min_mq && bq >= min_bq) {       // what samtools --min-MQ / --min-BQ leaves in the column
-                uint32_t* c = s_cnt[w][cl];
-                if (b < 8u) {
-                    atomicAdd(&c[0], 1u);
+                uint32_t* c = s_cnt[w][lane & (XCOPY - 1)][cl];
+                if (b < 8u) {                                        // depth = bases + placeholders, summed at the end
                     atomicAdd(&c[1 + (b & 3u)], 1u);                 // pileup_dict[base] counts indel carriers too (:111-113)
                     if (kind == 0u) atomicAdd(&c[5 + (b & 3u)], 1u); // alt_dict single-base keys (:102)
                 } else if (b == 8u || b == 9u) {
@@ -79,10 +82,14 @@ __global__ __launch_bounds__(64 * XWAVES) void k_extract_candidates(
     __syncthreads();
     if (lane < ncol) {
         const int64_t c = c0 + lane;
-        const uint32_t* cn = s_cnt[w][lane];
+        uint32_t cn[12];
+        for (int i = 0; i < 12; ++i) {
+            cn[i] = 0u;
+            for (int q = 0; q < XCOPY; ++q) cn[i] += s_cnt[w][q][lane][i];
+        }
         const int ref = pk.col_ref[c] & 3;
         const bool ref_ok = (pk.col_ref[c] & 0x80) == 0;     // rows whose reference base is not ACGT are skipped (:329-331)
-        const int depth = int(cn[0]);
+        const int depth = int(cn[0] + cn[1] + cn[2] + cn[3] + cn[4]);
         const double den = depth > 0 ? double(depth) : 1.0;
         bool pass_snv = false, has_alt_base = false, pass_indel = false;
         for (int b = 0; b < 4; ++b) {
@@ -134,7 +141,6 @@ extern "C" int cto_extract_candidates(const cto_pack_view* dp, int min_mq, int m
         g_scratch_n = dp->n_keys + dp->n_keys / 4 + 1024;
         CTO_HIP(hipMalloc(reinterpret_cast<void**>(&g_scratch), size_t(g_scratch_n) * 4));
     }
-    if (dp->n_keys > 0) CTO_HIP(hipMemsetAsync(g_scratch, 0, size_t(dp->n_keys) * 4, s));
     XPack pk{dp->n_cols, dp->col_ref, dp->col_off, dp->key_off, dp->entries, dp->key_meta, dp->key_group};
     const unsigned grid = unsigned(cto::cdiv(dp->n_cols, XCOLS * XWAVES));
     hipLaunchKernelGGL(k_extract_candidates, dim3(grid), dim3(64 * XWAVES), 0, s, pk, min_mq, min_bq, snv_min_af,
