@@ -1,24 +1,27 @@
 // Fused CvT transformer block (clairs/model.py:134-147: x = attn(x) + x; x = ff(x) + x) for gfx950.
 //
-// One workgroup (4 waves) owns TS sites = R = TS*W activation rows of C channels and keeps the residual
-// stream, every intermediate (LayerNorm output, depth-wise conv outputs, per-head q/k/v, attention output,
-// FFN hidden chunk) in LDS; only the weights stream in (from L2, straight into MFMA B registers) and only
-// the updated residual stream goes back to HBM.  The unfused path spends ~8 launches and ~10 HBM round
-// trips per block on the same work.
+// One workgroup (8 waves, two per SIMD) owns TS sites = R = TS*W activation rows of C channels and keeps the
+// residual stream, every intermediate (LayerNorm output, depth-wise conv outputs, per-head q/k/v, attention
+// output, FFN hidden chunk) in LDS; only the weights stream in (from L2, straight into MFMA B registers) and only
+// the updated residual stream goes back to HBM.  The unfused path spends ~8 launches and ~10 HBM round trips per
+// block on the same work.
 //
-//   phase 0  h tile -> LDS
-//   phase 1  y  = LN(h; norm0)                              (model.py:57-76, wave reduction per row)
+//   phase 0  h tile -> LDS                                  (CIN > 0, first block of a stage: the stage input tile instead,
+//                                                            then the stride-2 conv embedding as an im2col GEMM + LayerNorm)
+//   phase 1  y  = LN(h; norm0)                              (model.py:57-76; 16 lanes per row, DPP row reductions)
 //   phase 2  yq = BN(DW_s1(y)) in place, ykv = BN(DW_s2(y)) (model.py:91-100, 112-113)
 //   phase 3  per head: q_h, k_h, v_h (MFMA) -> LDS; softmax(q_h k_h^T / 8) v_h per site (VALU, <= 9x5
 //            scores); out-projection accumulated over heads in registers (MFMA, K = 64 per head)
 //   phase 4  h += to_out(o) + bias
 //   phase 5  y  = LN(h; norm1)
 //   phase 6  per 128-wide chunk of the 4C hidden units: u = GELU(y W1^T + b1) -> LDS, acc += u W2^T
-//   phase 7  h += acc + b2 -> HBM
+//   phase 7  h += acc + b2 in LDS, then coalesced 16-byte stores to HBM
+//   phase 8  (HEAD, last block of the network) fc1 over the LDS image of the tile -> SELU -> K x (fc2, fc3) instead of the store
 //
 // GEMMs: fp32 MFMA 16x16x4; A fragments from LDS (ds_read_b128 = four k-steps), B fragments from global
-// (one 16-byte load per lane per n-tile per 16-wide k chunk, prefetched two chunks ahead); the 4 waves split
-// N, every wave sweeps all M tiles so each weight fragment is reused MT (= 5) times.
+// (one 16-byte load per lane per n-tile per 16-wide k chunk, prefetched two chunks ahead); waves 0-3 / 4-7 split the
+// M tiles, wave & 3 owns the n-tiles, so each weight fragment is reused for 2-3 m-tiles and one wave's waits and VALU
+// epilogues overlap the other's MFMAs on the same SIMD.
 #pragma once
 #include <type_traits>
 #include "nn_kernels.h"
