@@ -57,13 +57,61 @@ def write_bed_chunks(folder, ctg, chunk_id, positions, suffix, list_prefix):
     return paths
 
 
+def pack_of_region(a):
+    """The MQ- and BQ-unfiltered pack of the chunk (the gates run on the device): pre-made text, the native BAM reader, or
+    `samtools mpileup` - the reference's own command (extract_candidates_calling.py:298-309) but with `--min-MQ 0 --min-BQ 0
+    --output-MQ` so that the same pack also serves tensor creation."""
+    import shlex
+    import subprocess
+    if a.mpileup_fn:
+        opener = gzip.open if a.mpileup_fn.endswith(".gz") else open
+        with opener(a.mpileup_fn, "rb") as f:
+            text = f.read()
+        first = int(text.split(b"\t", 2)[1])
+        last = int(text.rstrip(b"\n").rsplit(b"\n", 1)[-1].split(b"\t", 2)[1])
+        ref_start = max(1, first - EXPAND_REF)
+        ref = read_region(a.ref_fn, a.ctg_name, ref_start, last + EXPAND_REF)
+        return ColumnPack.from_mpileup(text, ref, ref_start)
+    if a.ctg_start is None or a.ctg_end is None:
+        raise SystemExit("[ERROR] --ctg_start / --ctg_end are required with --tumor_bam_fn")
+    ref_start = max(1, a.ctg_start - EXPAND_REF)
+    ref = read_region(a.ref_fn, a.ctg_name, ref_start, a.ctg_end + EXPAND_REF)
+    if a.bam_reader == "native":
+        return ColumnPack.from_bam(a.tumor_bam_fn, a.ctg_name, a.ctg_start, a.ctg_end, ref, ref_start,
+                                   max_depth=a.max_depth if a.max_depth is not None else 8000)
+    cmd = "{} mpileup --reverse-del --output-MQ -r {}:{}-{} --min-MQ 0 --min-BQ 0 --excl-flags 2316".format(
+        a.samtools, a.ctg_name, a.ctg_start, a.ctg_end)
+    if a.max_depth is not None:
+        cmd += " --max-depth {}".format(a.max_depth)
+    text = subprocess.run(shlex.split(cmd) + [a.tumor_bam_fn], stdout=subprocess.PIPE, check=True).stdout
+    return ColumnPack.from_mpileup(text, ref, ref_start)
+
+
+def extract_to_files(a, device="cuda"):
+    pack = pack_of_region(a)
+    dp = pack.to_device(device)
+    flags, _ = extract_candidates(dp, a.min_bq, a.min_mq, a.snv_min_af, a.indel_min_af, a.min_coverage,
+                                  a.alternative_base_num, a.select_indel_candidates)
+    snv = candidate_positions(dp, flags, 1).cpu().tolist()
+    indel = candidate_positions(dp, flags, 2).cpu().tolist() if a.select_indel_candidates else []
+    write_bed_chunks(a.candidates_folder, a.ctg_name, a.chunk_id, snv, "snv", "SNV_CANDIDATES_FILE")
+    write_bed_chunks(a.candidates_folder, a.ctg_name, a.chunk_id, indel, "indel", "INDEL_CANDIDATES_FILE")
+    return snv, indel
+
+
 def main():
     p = ArgumentParser(description="Extract candidate sites from a pileup (GPU gates)")
     p.add_argument("--platform", type=str, default="ont")
     p.add_argument("--candidates_folder", type=str, required=True)
-    p.add_argument("--mpileup_fn", type=str, required=True, help="samtools mpileup --reverse-del --output-MQ --min-MQ 0 --min-BQ 0 text")
+    p.add_argument("--mpileup_fn", type=str, default=None, help="samtools mpileup --reverse-del --output-MQ --min-MQ 0 --min-BQ 0 text")
+    p.add_argument("--tumor_bam_fn", type=str, default=None)
+    p.add_argument("--samtools", type=str, default="samtools")
+    p.add_argument("--bam_reader", type=str, default="samtools", choices=["samtools", "native"])
+    p.add_argument("--max_depth", type=int, default=None)
     p.add_argument("--ref_fn", type=str, required=True)
     p.add_argument("--ctg_name", type=str, required=True)
+    p.add_argument("--ctg_start", type=int, default=None)
+    p.add_argument("--ctg_end", type=int, default=None)
     p.add_argument("--chunk_id", type=int, default=None)
     p.add_argument("--snv_min_af", type=float, default=0.05)
     p.add_argument("--indel_min_af", type=float, default=1.0)
@@ -73,26 +121,9 @@ def main():
     p.add_argument("--alternative_base_num", type=int, default=3)
     p.add_argument("--select_indel_candidates", type=lambda v: str(v).lower() in ("yes", "true", "t", "y", "1"), default=False)
     a = p.parse_args()
-    opener = gzip.open if a.mpileup_fn.endswith(".gz") else open
-    with opener(a.mpileup_fn, "rb") as f:
-        text = f.read()
-    first = int(text.split(b"\t", 2)[1])
-    last = int(text.rstrip(b"\n").rsplit(b"\n", 1)[-1].split(b"\t", 2)[1])
-    ref_start = max(1, first - EXPAND_REF)
-    ref = read_region(a.ref_fn, a.ctg_name, ref_start, last + EXPAND_REF)
-    pack = ColumnPack.from_mpileup(text, ref, ref_start)
-    dp = pack.to_device("cuda")
-    flags, _ = extract_candidates(dp, a.min_bq, a.min_mq, a.snv_min_af, a.indel_min_af, a.min_coverage,
-                                  a.alternative_base_num, a.select_indel_candidates)
-    snv = candidate_positions(dp, flags, 1).cpu().tolist()
-    indel = candidate_positions(dp, flags, 2).cpu().tolist() if a.select_indel_candidates else []
-    write_bed_chunks(a.candidates_folder, a.ctg_name, a.chunk_id, snv, "snv", "SNV_CANDIDATES_FILE")
-    write_bed_chunks(a.candidates_folder, a.ctg_name, a.chunk_id, indel, "indel", "INDEL_CANDIDATES_FILE")
-    if a.select_indel_candidates:
-        print("[INFO] {} chunk {}: Total SNV candidates found: {}, total Indel candidates found: {}".format(
-            a.ctg_name, a.chunk_id, len(snv), len(indel)))
-    else:
-        print("[INFO] {} chunk {}: Total SNV candidates found: {}".format(a.ctg_name, a.chunk_id, len(snv)))
+    if not a.mpileup_fn and not a.tumor_bam_fn:
+        raise SystemExit("[ERROR] one of --mpileup_fn / --tumor_bam_fn is required")
+    extract_to_files(a)
 
 
 if __name__ == "__main__":

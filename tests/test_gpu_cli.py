@@ -197,6 +197,8 @@ def _bam_scenario(tmp_path):
     reads.sort(key=lambda r: r["pos"])
     bam = str(tmp_path / "t.bam")
     write_bam(bam, [("chr1", L)], reads)
+    import pickle
+    pickle.dump(reads, open(tmp_path / "reads.pkl", "wb"))
     fa = tmp_path / "ref.fa"
     fa.write_text(">chr1\n" + "\n".join(ref[i:i + 60] for i in range(0, L, 60)) + "\n")
     (tmp_path / "ref.fa.fai").write_text("chr1\t%d\t6\t60\t61\n" % L)
@@ -287,3 +289,50 @@ def test_call_chunks_matches_single_call(tmp_path, world):
     assert rec(merged) == rec(one) and len(rec(one)) > 50
     assert sorted(os.listdir(out_dir)) == ["p_chr1.%d_3_snv.vcf" % (i + 1) for i in range(3)]
     assert 0 < len(rec(final)) <= len(rec(merged))      # postprocess drops PASS records under the platform's AF cut-off
+
+
+def test_extract_cli_writes_reference_bed_chunks(tmp_path):
+    """extract_candidates_calling at its file seam: the BED chunk files (x-17 .. x+17 windows) and the list file, from the
+    golden fixture's pileup, must name exactly the candidates of the reference's own files; the native BAM reader and the
+    text path agree on a synthetic BAM."""
+    from argparse import Namespace
+    from clairs_to_amd.extract_candidates_calling import extract_to_files
+    g = load_json_gz("extract.json.gz")
+    pr = g["params"]
+    ref = "A" * (g["ref_start"] - 1) + g["ref"]
+    fa = tmp_path / "ref.fa"
+    fa.write_text(">chr1\n" + "\n".join(ref[i:i + 60] for i in range(0, len(ref), 60)) + "\n")
+    (tmp_path / "ref.fa.fai").write_text("chr1\t%d\t6\t60\t61\n" % len(ref))
+    mp = tmp_path / "mp.txt"
+    mp.write_text(g["mpileup_neg"])
+    common = dict(platform="ont", ref_fn=str(fa), ctg_name="chr1", chunk_id=1, snv_min_af=pr["snv_min_af"],
+                  indel_min_af=pr["indel_min_af"], min_coverage=pr["min_coverage"], min_mq=pr["min_mq"], min_bq=pr["min_bq"],
+                  alternative_base_num=pr["alt_base_num"], select_indel_candidates=True, samtools="samtools", max_depth=None)
+    out = tmp_path / "cand"
+    snv, indel = extract_to_files(Namespace(candidates_folder=str(out), mpileup_fn=str(mp), tumor_bam_fn=None, bam_reader="samtools",
+                                            ctg_start=None, ctg_end=None, **common))
+    assert snv == g["snv"] and indel == g["indel"]
+
+    def centres(suffix):
+        xs = []
+        for fn in sorted(os.listdir(out)):
+            if fn.endswith(suffix) and fn.startswith("chr1."):
+                for row in open(out / fn):
+                    c = row.split("\t")
+                    xs.append(int(c[2]) - 17)
+        return xs
+    assert centres("_snv") == g["snv"] and centres("_indel") == g["indel"]
+    assert open(out / "SNV_CANDIDATES_FILE_chr1_1").read().split() == [str(out / "chr1.1_0_1_snv")]
+    # BAM path: native reader vs the text of the naive pileup of the same BAM
+    from bamutil import mpileup_rows
+    sc = _bam_scenario(tmp_path)
+    L = sc["L"]
+    got = extract_to_files(Namespace(candidates_folder=str(tmp_path / "c_native"), mpileup_fn=None, tumor_bam_fn=sc["bam"],
+                                     bam_reader="native", ctg_start=200, ctg_end=L - 200, **dict(common, ref_fn=sc["fa"])))
+    import pickle
+    reads = pickle.load(open(tmp_path / "reads.pkl", "rb"))
+    txt = tmp_path / "region.txt"
+    txt.write_text(mpileup_rows(reads, 0, "chr1", 200, L - 200))
+    want = extract_to_files(Namespace(candidates_folder=str(tmp_path / "c_text"), mpileup_fn=str(txt), tumor_bam_fn=None,
+                                      bam_reader="samtools", ctg_start=None, ctg_end=None, **dict(common, ref_fn=sc["fa"])))
+    assert got == want and len(got[0]) > 20
