@@ -464,10 +464,40 @@ extern "C" int cto_pack_from_bam(const char* bam_path, const char* bai_path, con
             r.pos = pos;
             r.mapq = uint8_t(mapq);
             r.rev = (flag & 16) != 0;
-            r.cigar.resize(size_t(n_cig));
+            // CIGARs with more than 65535 operations (ultra-long reads) live in the CG:B,I tag; the CIGAR field then holds the
+            // placeholder <l_seq>S<ref_len>N (SAM specification, section 4.2.2)
+            int n_ops = n_cig;
+            const uint8_t* ops = cg;
+            if (n_cig == 2 && (le32(cg) & 15) == 4 && int(uint32_t(le32(cg)) >> 4) == l_seq && (le32(cg + 4) & 15) == 3) {
+                const uint8_t* aux = ql + l_seq;
+                const uint8_t* aend = rec.data() + rec.size();
+                while (aux + 3 <= aend) {
+                    const char t0 = char(aux[0]), t1 = char(aux[1]), ty = char(aux[2]);
+                    aux += 3;
+                    size_t skip = 0;
+                    if (ty == 'A' || ty == 'c' || ty == 'C') skip = 1;
+                    else if (ty == 's' || ty == 'S') skip = 2;
+                    else if (ty == 'i' || ty == 'I' || ty == 'f') skip = 4;
+                    else if (ty == 'Z' || ty == 'H') { while (aux + skip < aend && aux[skip]) ++skip; ++skip; }
+                    else if (ty == 'B') {
+                        if (aux + 5 > aend) break;
+                        const char sub = char(aux[0]);
+                        const uint32_t cnt = uint32_t(le32(aux + 1));
+                        const size_t esz = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                        if (t0 == 'C' && t1 == 'G' && sub == 'I' && aux + 5 + size_t(cnt) * 4 <= aend) {
+                            n_ops = int(cnt);
+                            ops = aux + 5;
+                            break;
+                        }
+                        skip = 5 + size_t(cnt) * esz;
+                    } else break;                                   // unknown type: stop scanning
+                    aux += skip;
+                }
+            }
+            r.cigar.resize(size_t(n_ops));
             int32_t rlen = 0, qlen = 0;
-            for (int i = 0; i < n_cig; ++i) {
-                const uint32_t c = uint32_t(le32(cg + i * 4));
+            for (int i = 0; i < n_ops; ++i) {
+                const uint32_t c = uint32_t(le32(ops + i * 4));
                 r.cigar[size_t(i)] = c;
                 const int opc = int(c & 15), len = int(c >> 4);
                 if (opc == 0 || opc == 2 || opc == 3 || opc == 7 || opc == 8) rlen += len;

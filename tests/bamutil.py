@@ -43,16 +43,26 @@ def _record(read, tid):
     seq, qual = read["seq"], read["qual"]
     pos = read["pos"]
     end = pos + max(1, ref_len_of(cigar))
-    body = struct.pack("<iiBBHHHiiii", tid, pos, len(name), read["mapq"], reg2bin(pos, end), len(cigar), read["flag"],
-                       len(seq), -1, -1, 0)
+    body = struct.pack("<iiBBHHHiiii", tid, pos, len(name), read["mapq"], reg2bin(pos, end), 2 if read.get("cg_tag") else len(cigar),
+                       read["flag"], len(seq), -1, -1, 0)
     body += name
-    for op, n in cigar:
-        body += struct.pack("<I", (n << 4) | CIGAR_OPS.index(op))
+    real = b"".join(struct.pack("<I", (n << 4) | CIGAR_OPS.index(op)) for op, n in cigar)
+    if read.get("cg_tag"):
+        # long-CIGAR convention (SAM spec 4.2.2): placeholder <l_seq>S<ref_len>N in the CIGAR field, the real one in CG:B,I
+        body_cigar = struct.pack("<II", (len(seq) << 4) | 4, (max(1, ref_len_of(cigar)) << 4) | 3)
+    else:
+        body_cigar = real
+    body += body_cigar
     codes = [NT16.index(c) for c in seq]
     if len(codes) & 1:
         codes.append(0)
     body += bytes((codes[i] << 4) | codes[i + 1] for i in range(0, len(codes), 2))
     body += bytes(qual if qual is not None else [0xff] * len(seq))
+    # a few auxiliary fields of every kind the reader has to skip over
+    body += b"NMi" + struct.pack("<i", 3) + b"XAZ" + b"chr9,+1,5M;" + b"\0" + b"xsA" + b"+" + b"mlBC" + struct.pack("<I", 3) + bytes([1, 2, 3])
+    if read.get("cg_tag"):
+        body += b"CGBI" + struct.pack("<I", len(cigar)) + real
+    body += b"ASs" + struct.pack("<h", -7)
     return struct.pack("<i", len(body)) + body
 
 

@@ -55,7 +55,8 @@ def _random_reads(rng, n, ref_lens, paired_frac=0.0, weird=True):
         if rng.random() < paired_frac:
             flag |= 1 | (2 if rng.random() < 0.8 else 0) | (8 if rng.random() < 0.1 else 0)
         mapq = int(rng.choice([0, 3, 19, 20, 60, 60, 60, 120, 255]))
-        reads.append(dict(name="r%d" % i, flag=flag, ref=ref, pos=pos, mapq=mapq, cigar=cigar, seq=seq, qual=qual))
+        reads.append(dict(name="r%d" % i, flag=flag, ref=ref, pos=pos, mapq=mapq, cigar=cigar, seq=seq, qual=qual,
+                          cg_tag=bool(rng.random() < 0.1)))               # some CIGARs travel in the CG tag
     reads.sort(key=lambda r: (r["ref"], r["pos"]))
     return reads
 
@@ -90,13 +91,15 @@ def test_pack_from_bam_matches_naive_pileup(tmp_path, seed, paired):
     cases = [(0, 1, ref_lens[0], None, 8000), (0, 5000, 9000, None, 8000), (0, 16380, 16400, None, 8000),
              (0, 19990, 20040, None, 10), (1, 1, ref_lens[1], None, 8000), (1, 700, 2400, [(650, 720), (900, 934), (2000, 2500)], 8000),
              (0, 39000, 40000, [(38990, 39010)], 8000)]
+    nonempty = 0
     for ref_i, start, end, bed, max_depth in cases:
         name = refs[ref_i][0]
         text = mpileup_rows(reads, ref_i, name, start, end, bed=bed, max_depth=max_depth, ref_seq=ref_seqs[ref_i], ref_start=1)
         want = ColumnPack.from_mpileup(text, ref_seqs[ref_i], 1)
         got = ColumnPack.from_bam(bam, name, start, end, ref_seqs[ref_i], 1, bed=bed, max_depth=max_depth)
-        assert want.n_cols > 0 or (start, end) == (16380, 16400)
         _assert_same(_pack_arrays(got), _pack_arrays(want))
+        nonempty += want.n_cols > 0
+    assert nonempty >= 5
 
 
 def test_pack_from_bam_errors(tmp_path):
