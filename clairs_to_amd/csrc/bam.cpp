@@ -126,6 +126,7 @@ struct Bgzf {
         } else if (fread(comp.data(), 1, comp.size(), f) != comp.size()) { err = "truncated BGZF block"; return false; }
         const uint8_t* tail = comp.data() + cdata;
         const uint32_t isize = uint32_t(tail[4]) | (uint32_t(tail[5]) << 8) | (uint32_t(tail[6]) << 16) | (uint32_t(tail[7]) << 24);
+        if (isize > 65536) { err = "BGZF block claims more than 64 KiB of data"; return false; }     // the format's limit
         block.resize(isize);
         if (isize && ld) {
             size_t got_out = 0;
@@ -218,11 +219,13 @@ bool bai_query(const char* path, int tid, int64_t beg, int64_t end, std::vector<
     for (int r = 0; r <= tid; ++r) {
         if (!need(4)) { *err = "truncated BAI"; return false; }
         const int n_bin = le32(buf.data() + o); o += 4;
+        if (n_bin < 0) { *err = "malformed BAI"; return false; }
         for (int b = 0; b < n_bin; ++b) {
             if (!need(8)) { *err = "truncated BAI"; return false; }
             const uint32_t bin = uint32_t(le32(buf.data() + o));
             const int n_chunk = le32(buf.data() + o + 4);
             o += 8;
+            if (n_chunk < 0) { *err = "malformed BAI"; return false; }
             if (!need(size_t(n_chunk) * 16)) { *err = "truncated BAI"; return false; }
             if (r == tid && bin != 37450 && std::binary_search(want.begin(), want.end(), bin))
                 for (int c = 0; c < n_chunk; ++c) chunks.push_back(Chunk{le64(buf.data() + o + size_t(c) * 16), le64(buf.data() + o + size_t(c) * 16 + 8)});
@@ -230,6 +233,7 @@ bool bai_query(const char* path, int tid, int64_t beg, int64_t end, std::vector<
         }
         if (!need(4)) { *err = "truncated BAI"; return false; }
         const int n_intv = le32(buf.data() + o); o += 4;
+        if (n_intv < 0) { *err = "malformed BAI"; return false; }
         if (!need(size_t(n_intv) * 8)) { *err = "truncated BAI"; return false; }
         if (r == tid && n_intv > 0) {
             const int64_t w = std::min<int64_t>(beg >> 14, n_intv - 1);
@@ -369,17 +373,21 @@ extern "C" int cto_pack_from_bam(const char* bam_path, const char* bai_path, con
                 bz.err.empty() ? "" : ": ", bz.err.c_str());
     CTO_REQUIRE(bz.read(h4, 4), CTO_EINVAL, "cto_pack_from_bam: truncated header");
     {
+        CTO_REQUIRE(le32(h4) >= 0 && le32(h4) <= (1 << 28), CTO_EINVAL, "cto_pack_from_bam: bad header text length");
         std::vector<uint8_t> text(size_t(le32(h4)));
         CTO_REQUIRE(text.empty() || bz.read(text.data(), text.size()), CTO_EINVAL, "cto_pack_from_bam: truncated header text");
     }
     CTO_REQUIRE(bz.read(h4, 4), CTO_EINVAL, "cto_pack_from_bam: truncated header");
     const int n_ref = le32(h4);
+    CTO_REQUIRE(n_ref >= 0, CTO_EINVAL, "cto_pack_from_bam: bad reference count");
     int tid = -1;
     for (int r = 0; r < n_ref; ++r) {
         CTO_REQUIRE(bz.read(h4, 4), CTO_EINVAL, "cto_pack_from_bam: truncated reference list");
+        CTO_REQUIRE(le32(h4) > 0 && le32(h4) <= 65536, CTO_EINVAL, "cto_pack_from_bam: bad reference name length");
         std::vector<char> name(size_t(le32(h4)));
         CTO_REQUIRE(bz.read(name.data(), name.size()) && bz.read(h4, 4), CTO_EINVAL, "cto_pack_from_bam: truncated reference list");
-        if (tid < 0 && !name.empty() && strcmp(name.data(), ctg_name) == 0) tid = r;
+        name.back() = 0;
+        if (tid < 0 && strcmp(name.data(), ctg_name) == 0) tid = r;
     }
     CTO_REQUIRE(tid >= 0, CTO_EINVAL, "cto_pack_from_bam: contig %s not in the BAM header", ctg_name);
     // ---- index ----
@@ -442,7 +450,7 @@ extern "C" int cto_pack_from_bam(const char* bam_path, const char* bai_path, con
             const double tr0 = timing ? now() : 0.0;
             if (!bz.read(h4, 4)) { CTO_REQUIRE(bz.err.empty(), CTO_EINVAL, "cto_pack_from_bam: %s", bz.err.c_str()); done = true; break; }
             const int bsz = le32(h4);
-            CTO_REQUIRE(bsz >= 32, CTO_EINVAL, "cto_pack_from_bam: bad alignment block size %d", bsz);
+            CTO_REQUIRE(bsz >= 32 && bsz <= (1 << 28), CTO_EINVAL, "cto_pack_from_bam: bad alignment block size %d", bsz);
             rec.resize(size_t(bsz));
             CTO_REQUIRE(bz.read(rec.data(), rec.size()), CTO_EINVAL, "cto_pack_from_bam: truncated alignment record");
             if (timing) t_read += now() - tr0;
@@ -453,7 +461,7 @@ extern "C" int cto_pack_from_bam(const char* bam_path, const char* bai_path, con
             const int l_seq = le32(b + 16);
             if (rtid != tid) { if (rtid > tid || rtid < 0) { done = true; break; } continue; }
             if (pos >= end0) { done = true; break; }
-            if ((flag & excl_flags) || (flag & 4) || mapq < min_mq || n_cig == 0 || l_seq == 0) continue;
+            if ((flag & excl_flags) || (flag & 4) || mapq < min_mq || n_cig == 0 || l_seq <= 0 || pos < 0) continue;
             if ((flag & 1) && !(flag & 2)) continue;           // orphan (mpileup without -A)
             const size_t need = 32 + size_t(l_name) + size_t(n_cig) * 4 + size_t((l_seq + 1) / 2) + size_t(l_seq);
             CTO_REQUIRE(need <= rec.size(), CTO_EINVAL, "cto_pack_from_bam: alignment record shorter than its fields");

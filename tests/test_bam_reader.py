@@ -123,3 +123,49 @@ def test_pack_from_bam_errors(tmp_path):
         ColumnPack.from_bam(bam, "chrA", 1, 100, ref[:5], 1)          # reference too short for the covered positions
     p = ColumnPack.from_bam(bam, "chrA", 500, 600, ref, 1)            # nothing there: an empty pack, not an error
     assert p.n_cols == 0 and p.n_entries == 0
+
+
+def test_producers_survive_corrupt_input(tmp_path):
+    """Neither pack producer may crash on damaged input: every call returns a pack or raises CtoError.  200 random byte
+    flips / truncations of a valid BAM, of its index and of a valid mpileup text."""
+    from clairs_to_amd.pack import ColumnPack
+    from clairs_to_amd._lib import CtoError
+    rng = np.random.default_rng(99)
+    ref_lens = [5000]
+    reads = _random_reads(rng, 120, ref_lens)
+    bam = str(tmp_path / "ok.bam")
+    write_bam(bam, [("chrA", 5000)], reads, block_payload=900)
+    ref = "".join(rng.choice(list("ACGT"), size=5000))
+    good_bam, good_bai = open(bam, "rb").read(), open(bam + ".bai", "rb").read()
+    text = mpileup_rows(reads, 0, "chrA", 1, 5000).encode()
+
+    def damage(b):
+        b = bytearray(b)
+        mode = rng.integers(0, 3)
+        if mode == 0 and len(b) > 10:
+            del b[int(rng.integers(1, len(b))):]
+        elif mode == 1:
+            for _ in range(int(rng.integers(1, 8))):
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        else:
+            i = int(rng.integers(0, len(b)))
+            b[i:i] = bytes(rng.integers(0, 256, size=int(rng.integers(1, 40)), dtype=np.uint8))
+        return bytes(b)
+    outcomes = {"ok": 0, "err": 0}
+    for it in range(200):
+        which = it % 3
+        try:
+            if which == 0:
+                p = tmp_path / "bad.bam"
+                p.write_bytes(damage(good_bam))
+                (tmp_path / "bad.bam.bai").write_bytes(good_bai)
+                ColumnPack.from_bam(str(p), "chrA", 1, 5000, ref, 1)
+            elif which == 1:
+                (tmp_path / "bad2.bai").write_bytes(damage(good_bai))
+                ColumnPack.from_bam(bam, "chrA", 1, 5000, ref, 1, bai_fn=str(tmp_path / "bad2.bai"))
+            else:
+                ColumnPack.from_mpileup(damage(text), ref, 1)
+            outcomes["ok"] += 1
+        except CtoError:
+            outcomes["err"] += 1
+    assert outcomes["ok"] + outcomes["err"] == 200 and outcomes["err"] > 20
