@@ -48,8 +48,8 @@ __device__ __forceinline__ BPre<NTW> prefetch_b(const float* const (&wrow)[NTW])
     BPre<NTW> p;
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
-        p.b0[nt] = *reinterpret_cast<const float4*>(wrow[nt]);
-        p.b1[nt] = KCH > 1 ? *reinterpret_cast<const float4*>(wrow[nt] + 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+        p.b0[nt] = ldg4(wrow[nt]);
+        p.b1[nt] = KCH > 1 ? ldg4(wrow[nt] + 16) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     return p;
 }
@@ -70,12 +70,16 @@ __device__ __forceinline__ void gemm_lds(const float* __restrict__ A, int lda, c
     for (int c = 0; c < KCH; ++c) {
         if (c + 2 < KCH) {
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) Bq[(c + 2) % 3][nt] = *reinterpret_cast<const float4*>(wrow[nt] + (c + 2) * 16);
+            for (int nt = 0; nt < NTW; ++nt) Bq[(c + 2) % 3][nt] = ldg4(wrow[nt] + (c + 2) * 16);
         }
         if (c + 1 < KCH) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a[(c + 1) & 1][mt] = *reinterpret_cast<const float4*>(Arow + mt * 16 * lda + (c + 1) * 16);
         }
+        // Without this fence the scheduler sinks the operand requests above to the END of the chunk (nothing here needs them),
+        // i.e. right in front of the s_waitcnt of the chunk that does: the "prefetch" then exposes a full LDS / L2 round trip
+        // per chunk.  Requests first, then this chunk's MFMAs; the other wave of the SIMD covers the short issue burst.
+        __builtin_amdgcn_sched_barrier(0);
         // k-step outermost, tiles innermost: consecutive MFMAs never hit the same accumulator (dependent latency 40 cycles
         // vs issue interval 32 for v_mfma_f32_16x16x4_f32)
 #pragma unroll
@@ -109,7 +113,7 @@ __device__ __forceinline__ void load_group(BGroup<NTW, DEPTH>& g, const float* c
     for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
-            if (c0 + d < KCH) g.b[d][nt] = *reinterpret_cast<const float4*>(wrow[nt] + (c0 + d) * 16);
+            if (c0 + d < KCH) g.b[d][nt] = ldg4(wrow[nt] + (c0 + d) * 16);
 }
 template <int NTW, int KCH, int DEPTH>
 __device__ __forceinline__ void mfma_group(const BGroup<NTW, DEPTH>& g, const float* Arow, int c0, f32x4 (&acc)[2][NTW]) {
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     // Channel LayerNorm sh -> sy.  16 lanes per row (4 rows per wave at a time), each lane owning C/16 contiguous
     // channels: the row reductions are 4 DPP steps inside a 16-lane row instead of 6 cross-lane permutes through the
@@ -463,16 +467,16 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
                     for (int r = 0; r < 4; ++r) sh[((mbase + mt) * 16 + 4 * kg + r) * RS + col] = acc_e[mt][nt][r] + bv;
                 }
         }
-        __syncthreads();
+        lds_barrier();
         for (int i = tid; i < (MTKV * 16 - RKV) * RS; i += NT) sykv[RKV * RS + i] = 0.f;
         layer_norm(sh, sh, p.lng, p.lnb);
-        __syncthreads();
+        lds_barrier();
     }
 
     stamp();
     // ---- phase 1 ----
     layer_norm(sh, sy, p.n0g, p.n0b);
-    __syncthreads();
+    lds_barrier();
     stamp();
 
     // ---- phase 2: depth-wise 3-tap conv + BatchNorm; q path in place, kv path (stride 2) to sykv ----
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     stamp();
     // ---- phase 3: attention, head by head; out-projection accumulates in registers ----
@@ -567,7 +571,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
                     }
                 }
         }
-        __syncthreads();
+        lds_barrier();
         stamp();
         // scores = q k^T / 8 per site (model.py:126; dim_head = 64)
         for (int t = tid; t < TS * W * WKV; t += NT) {
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
             }
             sp[t] = acc * 0.125f;
         }
-        __syncthreads();
+        lds_barrier();
         for (int t = tid; t < TS * W; t += NT) {
             float* row = sp + t * WKV;
             float mx = row[0];
@@ -595,7 +599,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
 #pragma unroll
             for (int jj = 0; jj < WKV; ++jj) row[jj] = e[jj] * inv;
         }
-        __syncthreads();
+        lds_barrier();
         // o_h = P v_h, overwrites q_h
         for (int t = tid; t < R * 16; t += NT) {
             const int row = t >> 4, d4 = (t & 15) * 4, s = row / W;
@@ -613,10 +617,10 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
             q_rows(hh + 1, wq_r);
             pre_q = prefetch_b<1, C / 16>(wq_r);
         }
-        __syncthreads();
+        lds_barrier();
         stamp();
         if (own_c) gemm_r(INTC{}, K4{}, sq, QS, wo_r, pre_o, acc_o);   // acc_o += o_h Wo[:, hh*64 .. +64]^T
-        __syncthreads();   // sq / sk / sv are rewritten by the next head
+        lds_barrier();   // sq / sk / sv are rewritten by the next head
         stamp();
     }
 
@@ -638,12 +642,12 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
                 for (int r = 0; r < 4; ++r) sh[((mbase + mt) * 16 + 4 * kg + r) * RS + col] += acc_o[mt][nt][r] + bv;
             }
     }
-    __syncthreads();
+    lds_barrier();
 
     stamp();
     // ---- phase 5 ----
     layer_norm(sh, sy, p.n1g, p.n1b);
-    __syncthreads();
+    lds_barrier();
     stamp();
 
     // ---- phase 6: feed-forward, hidden units in chunks of HC ----
@@ -680,9 +684,9 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
             w1_rows(cc + 1, w1_r);
             pre_w1 = prefetch_b<NTF, C / 16>(w1_r);
         }
-        __syncthreads();
+        lds_barrier();
         if (own_c) gemm_r(INTC{}, KH{}, su, US, w2_r, pre_w2, acc_f);
-        __syncthreads();   // su is rewritten by the next chunk
+        lds_barrier();   // su is rewritten by the next chunk
         stamp();
     }
 
@@ -703,7 +707,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
             }
     }
     if constexpr (!HEAD) {
-        __syncthreads();
+        lds_barrier();
         for (int i = tid; i < rows_valid * (C / 4); i += NT) {
             const int r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
             *reinterpret_cast<float4*>(hg + r * C + c4) = *reinterpret_cast<const float4*>(sh + r * RS + c4);
@@ -718,14 +722,14 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
         const float* w1_r1[1] = {p.w1p + int64_t(wave * 16 + j) * (K1 * 16) + 4 * kg};
         BGroup<1, 7> g0;
         load_group<1, K1, 7>(g0, w1_r1, 0);
-        __syncthreads();
+        lds_barrier();
         stamp();
         f32x4 a1[2][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}, {f32x4{0.f, 0.f, 0.f, 0.f}}};
         gemm_m1<1, K1, 7>(sh, W * RS, w1_r1, g0, a1, j, kg);
         const float bv = p.b1h[wave * 16 + j];
 #pragma unroll
         for (int r = 0; r < 4; ++r) t1[(4 * kg + r) * HEAD_T1S + wave * 16 + j] = selu_fast(a1[0][0][r] + a1[1][0][r] + bv);
-        __syncthreads();
+        lds_barrier();
         stamp();
         head_tail(t1, t2, hp, B, site0, nsite);
     }

@@ -21,6 +21,21 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 #endif
 constexpr int GRU_WPAD = CTO_GRU_WPAD;
 
+// Workgroup barrier for LDS-only hand-offs.  `__syncthreads()` is a workgroup-scope release/acquire fence: it drains EVERY
+// outstanding memory operation (s_waitcnt vmcnt(0) lgkmcnt(0)) before s_barrier, so weight fragments that were requested to
+// "fly under the barrier" are waited for right there - one exposed L2 round trip per barrier.  Waves of these kernels only talk
+// through LDS, for which completing the LDS operations (lgkmcnt) is sufficient; register-destined global loads stay in flight.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// 16-byte weight load with the global address space spelled out.  Pointers that reach a loop through arrays / lambdas can lose
+// it, and the compiler then emits flat_load, which counts on vmcnt AND lgkmcnt: every s_waitcnt for an LDS read then also waits
+// for the weight prefetches in flight (seen in one k_cvt_block instantiation: lgkmcnt(0) before every chunk's MFMAs).
+__device__ __forceinline__ float4 ldg4(const float* p) {
+    typedef const __attribute__((address_space(1))) f32x4* gptr;
+    const f32x4 v = *reinterpret_cast<gptr>(reinterpret_cast<uintptr_t>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
