@@ -289,8 +289,13 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
     constexpr int NT = CVT_BLOCK_THREADS, NWV = NT / 64;
     constexpr int R = G::R, RKV = G::RKV, MT = G::MT, MTKV = G::MTKV, RS = G::RS, QS = G::QS, HC = G::HC, US = G::US;
     constexpr int MT0 = (MT + 1) / 2, MT1 = MT - MT0, MK0 = (MTKV + 1) / 2, MK1 = MTKV - MK0;
-    constexpr int NTC = C >= 64 ? C / 64 : 1;   // n-tiles per wave when the output is C wide
-    constexpr int NTF = HC / 64;                // n-tiles per wave of one FFN hidden chunk
+    // C = 128: every 128-wide output (k|v of a head, out-projection, both FFN GEMMs, the stage embedding) has exactly 8 n-tiles -
+    // one per wave, all m-tiles each.  The waves are then balanced (the M split gives waves 0-3 three m-tiles and waves 4-7 two,
+    // so half of the workgroup idled a third of every GEMM phase) and a wave requests one weight fragment per chunk, not two.
+    constexpr bool NSPLIT = (C == 128);
+    constexpr int NTC = NSPLIT ? 1 : (C >= 64 ? C / 64 : 1);   // n-tiles per wave when the output is C wide
+    constexpr int NTF = NSPLIT ? 1 : HC / 64;                  // n-tiles per wave of one FFN hidden chunk
+    constexpr int MTC = NSPLIT ? MT : (MT + 1) / 2;            // m-tiles a wave holds of such an output
     static_assert(C % 16 == 0 && HC % 64 == 0, "channel count must be a multiple of 16");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sh = smem + G::OFF_H;
@@ -304,8 +309,11 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
     const int wn = wave & 3, mh = wave >> 2;                   // n-tile owner, M half
-    const bool own_c = (wn * NTC * 16) < C;                    // C < 64: only some waves own columns of a C-wide output
-    const int mbase = mh ? MT0 : 0, mcount = mh ? MT1 : MT0;   // this wave's m-tiles of [R]-row operands
+    const bool own_c = NSPLIT || (wn * NTC * 16) < C;          // C < 64: only some waves own columns of a C-wide output
+    const int mbase = mh ? MT0 : 0, mcount = mh ? MT1 : MT0;   // this wave's m-tiles of [R]-row operands (M split)
+    const int ctile0 = NSPLIT ? wave : wn * NTC;               // first column tile of a C-wide output
+    const int ftile0 = NSPLIT ? wave : wn * NTF;               // ... of an FFN hidden chunk
+    const int mbaseC = NSPLIT ? 0 : mbase, mcountC = NSPLIT ? MT : mcount;
     const int kbase = mh ? MK0 : 0, kcount = mh ? MK1 : MK0;   // ... of [RKV]-row operands
     const int site0 = blockIdx.x * TS;
     const int nsite = min(TS, B - site0);
@@ -334,6 +342,11 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
             f32x4 (&a1)[MK1][2] = reinterpret_cast<f32x4 (&)[MK1][2]>(acc);
             gemm_lds<MK1, 2, KCH>(A + MK0 * 16 * lda, lda, wr, pre, a1, j, kg);
         }
+    };
+    auto gemm_c = [&](auto ntw_tag, auto kch_tag, const float* A, int lda, const auto& wr, const auto& pre, auto& acc) {
+        constexpr int NTW = decltype(ntw_tag)::value, KCH = decltype(kch_tag)::value;
+        if constexpr (NSPLIT) gemm_lds<MT, NTW, KCH>(A, lda, wr, pre, acc, j, kg);
+        else gemm_r(ntw_tag, kch_tag, A, lda, wr, pre, acc);
     };
     using I1 = std::integral_constant<int, 1>;
     using INTC = std::integral_constant<int, NTC>;
@@ -447,24 +460,24 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
         constexpr int PS = emb_ps(CIN), KE = emb_kch(CIN);
         const float* we_r[NTC];
 #pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) we_r[nt] = p.wembp + int64_t(own_c ? (wn * NTC + nt) * 16 + j : j) * (KE * 16) + 4 * kg;
+        for (int nt = 0; nt < NTC; ++nt) we_r[nt] = p.wembp + int64_t(own_c ? (ctile0 + nt) * 16 + j : j) * (KE * 16) + 4 * kg;
         const BPre<NTC> pre_e = prefetch_b<NTC, KE>(we_r);
-        f32x4 acc_e[MT0][NTC];
+        f32x4 acc_e[MTC][NTC];
 #pragma unroll
-        for (int mt = 0; mt < MT0; ++mt)
+        for (int mt = 0; mt < MTC; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTC; ++nt) acc_e[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (own_c) gemm_r(INTC{}, std::integral_constant<int, KE>{}, smem + G::OFF_Y, 2 * PS, we_r, pre_e, acc_e);
+        if (own_c) gemm_c(INTC{}, std::integral_constant<int, KE>{}, smem + G::OFF_Y, 2 * PS, we_r, pre_e, acc_e);
 #pragma unroll
         for (int nt = 0; nt < NTC; ++nt) {
             if (!own_c) break;
-            const int col = (wn * NTC + nt) * 16 + j;
+            const int col = (ctile0 + nt) * 16 + j;
             const float bv = p.bemb[col];
 #pragma unroll
-            for (int mt = 0; mt < MT0; ++mt)
-                if (mt < mcount) {
+            for (int mt = 0; mt < MTC; ++mt)
+                if (mt < mcountC) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sh[((mbase + mt) * 16 + 4 * kg + r) * RS + col] = acc_e[mt][nt][r] + bv;
+                    for (int r = 0; r < 4; ++r) sh[((mbaseC + mt) * 16 + 4 * kg + r) * RS + col] = acc_e[mt][nt][r] + bv;
                 }
         }
         lds_barrier();
@@ -510,9 +523,9 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
 
     stamp();
     // ---- phase 3: attention, head by head; out-projection accumulates in registers ----
-    f32x4 acc_o[MT0][NTC];
+    f32x4 acc_o[MTC][NTC];
 #pragma unroll
-    for (int mt = 0; mt < MT0; ++mt)
+    for (int mt = 0; mt < MTC; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NTC; ++nt) acc_o[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -523,15 +536,15 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
     };
     auto o_rows = [&](int hh, const float* (&wr)[NTC]) {
 #pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) wr[nt] = p.wo + int64_t(own_c ? (wn * NTC + nt) * 16 + j : j) * inner + hh * 64 + 4 * kg;
+        for (int nt = 0; nt < NTC; ++nt) wr[nt] = p.wo + int64_t(own_c ? (ctile0 + nt) * 16 + j : j) * inner + hh * 64 + 4 * kg;
     };
     auto w1_rows = [&](int cc, const float* (&wr)[NTF]) {
 #pragma unroll
-        for (int nt = 0; nt < NTF; ++nt) wr[nt] = p.w1 + int64_t(cc * HC + (wn * NTF + nt) * 16 + j) * C + 4 * kg;
+        for (int nt = 0; nt < NTF; ++nt) wr[nt] = p.w1 + int64_t(cc * HC + (ftile0 + nt) * 16 + j) * C + 4 * kg;
     };
     auto w2_rows = [&](int cc, const float* (&wr)[NTC]) {
 #pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) wr[nt] = p.w2 + int64_t(own_c ? (wn * NTC + nt) * 16 + j : j) * (4 * C) + cc * HC + 4 * kg;
+        for (int nt = 0; nt < NTC; ++nt) wr[nt] = p.w2 + int64_t(own_c ? (ctile0 + nt) * 16 + j : j) * (4 * C) + cc * HC + 4 * kg;
     };
 
     const float* wq_r[1];
@@ -540,7 +553,12 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
     for (int hh = 0; hh < heads; ++hh) {
         const float* wkv_r[2];
         kv_rows(hh, wkv_r);
-        const BPre<2> pre_kv = prefetch_b<2, C / 16>(wkv_r);
+        // NSPLIT: wave w computes one of the 8 n-tiles of [k_h | v_h] (w < 4: k columns 16 w.., else v columns 16 (w - 4)..)
+        const float* wkv1_r[1] = {p.wkv + int64_t((wave < 4 ? 0 : inner) + hh * 64 + wn * 16 + j) * C + 4 * kg};
+        BPre<2> pre_kv;
+        BPre<1> pre_kv1;
+        if constexpr (NSPLIT) pre_kv1 = prefetch_b<1, C / 16>(wkv1_r);
+        else pre_kv = prefetch_b<2, C / 16>(wkv_r);
         {   // q_h : [R][64], this wave's 16 columns of its M half
             f32x4 aq[MT0][1];
 #pragma unroll
@@ -556,7 +574,17 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
         const float* wo_r[NTC];
         o_rows(hh, wo_r);
         const BPre<NTC> pre_o = prefetch_b<NTC, 4>(wo_r);
-        {   // k_h, v_h : [RKV][64]
+        if constexpr (NSPLIT) {   // k_h, v_h : [RKV][64] each, one n-tile of the pair per wave, all m-tiles
+            f32x4 akv1[MTKV][1];
+#pragma unroll
+            for (int mt = 0; mt < MTKV; ++mt) akv1[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm_lds<MTKV, 1, C / 16>(sykv, RS, wkv1_r, pre_kv1, akv1, j, kg);
+            float* dst = wave < 4 ? sk : sv;
+#pragma unroll
+            for (int mt = 0; mt < MTKV; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(mt * 16 + 4 * kg + r) * QS + wn * 16 + j] = akv1[mt][0][r];
+        } else {   // k_h, v_h : [RKV][64], M split
             f32x4 akv[MK0][2];
 #pragma unroll
             for (int mt = 0; mt < MK0; ++mt) { akv[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; akv[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -619,7 +647,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
         }
         lds_barrier();
         stamp();
-        if (own_c) gemm_r(INTC{}, K4{}, sq, QS, wo_r, pre_o, acc_o);   // acc_o += o_h Wo[:, hh*64 .. +64]^T
+        if (own_c) gemm_c(INTC{}, K4{}, sq, QS, wo_r, pre_o, acc_o);   // acc_o += o_h Wo[:, hh*64 .. +64]^T
         lds_barrier();   // sq / sk / sv are rewritten by the next head
         stamp();
     }
@@ -633,13 +661,13 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
 #pragma unroll
     for (int nt = 0; nt < NTC; ++nt) {
         if (!own_c) break;
-        const int col = (wn * NTC + nt) * 16 + j;
+        const int col = (ctile0 + nt) * 16 + j;
         const float bv = p.bo[col];
 #pragma unroll
-        for (int mt = 0; mt < MT0; ++mt)
-            if (mt < mcount) {
+        for (int mt = 0; mt < MTC; ++mt)
+            if (mt < mcountC) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sh[((mbase + mt) * 16 + 4 * kg + r) * RS + col] += acc_o[mt][nt][r] + bv;
+                for (int r = 0; r < 4; ++r) sh[((mbaseC + mt) * 16 + 4 * kg + r) * RS + col] += acc_o[mt][nt][r] + bv;
             }
     }
     lds_barrier();
@@ -651,9 +679,9 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
     stamp();
 
     // ---- phase 6: feed-forward, hidden units in chunks of HC ----
-    f32x4 acc_f[MT0][NTC];
+    f32x4 acc_f[MTC][NTC];
 #pragma unroll
-    for (int mt = 0; mt < MT0; ++mt)
+    for (int mt = 0; mt < MTC; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NTC; ++nt) acc_f[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int cc = 0; cc < 4 * C / HC; ++cc) {
@@ -661,22 +689,22 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
         w2_rows(cc, w2_r);
         const BPre<NTC> pre_w2 = prefetch_b<NTC, HC / 16>(w2_r);
         {
-            f32x4 au[MT0][NTF];
+            f32x4 au[MTC][NTF];
 #pragma unroll
-            for (int mt = 0; mt < MT0; ++mt)
+            for (int mt = 0; mt < MTC; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NTF; ++nt) au[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gemm_r(INTF{}, KC{}, sy, RS, w1_r, pre_w1, au);
-            const int n0 = cc * HC + wn * NTF * 16;
+            gemm_c(INTF{}, KC{}, sy, RS, w1_r, pre_w1, au);
+            const int n0 = cc * HC + ftile0 * 16;
 #pragma unroll
             for (int nt = 0; nt < NTF; ++nt) {
                 const float bv = p.b1[n0 + nt * 16 + j];
 #pragma unroll
-                for (int mt = 0; mt < MT0; ++mt)
-                    if (mt < mcount) {
+                for (int mt = 0; mt < MTC; ++mt)
+                    if (mt < mcountC) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            su[((mbase + mt) * 16 + 4 * kg + r) * US + (wn * NTF + nt) * 16 + j] = gelu_f(au[mt][nt][r] + bv);
+                            su[((mbaseC + mt) * 16 + 4 * kg + r) * US + (ftile0 + nt) * 16 + j] = gelu_f(au[mt][nt][r] + bv);
                     }
             }
         }
@@ -685,7 +713,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
             pre_w1 = prefetch_b<NTF, C / 16>(w1_r);
         }
         lds_barrier();
-        if (own_c) gemm_r(INTC{}, KH{}, su, US, w2_r, pre_w2, acc_f);
+        if (own_c) gemm_c(INTC{}, KH{}, su, US, w2_r, pre_w2, acc_f);
         lds_barrier();   // su is rewritten by the next chunk
         stamp();
     }
@@ -694,14 +722,14 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
 #pragma unroll
     for (int nt = 0; nt < NTC; ++nt) {
         if (!own_c) break;
-        const int col = (wn * NTC + nt) * 16 + j;
+        const int col = (ctile0 + nt) * 16 + j;
         const float bv = p.b2[col];
 #pragma unroll
-        for (int mt = 0; mt < MT0; ++mt)
-            if (mt < mcount) {
+        for (int mt = 0; mt < MTC; ++mt)
+            if (mt < mcountC) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = (mbase + mt) * 16 + 4 * kg + r;
+                    const int row = (mbaseC + mt) * 16 + 4 * kg + r;
                     sh[row * RS + col] += acc_f[mt][nt][r] + bv;     // the tile leaves through LDS: 16-byte coalesced stores below
                 }
             }
