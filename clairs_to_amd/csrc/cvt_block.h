@@ -288,13 +288,15 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
     static_assert(!HEAD || (TS == 16 && 64 + head_lds_floats(6) <= G::ALIAS), "classifier tail needs a 16-site tile");
     constexpr int NT = CVT_BLOCK_THREADS, NWV = NT / 64;
     constexpr int R = G::R, RKV = G::RKV, MT = G::MT, MTKV = G::MTKV, RS = G::RS, QS = G::QS, HC = G::HC, US = G::US;
-    constexpr int MT0 = (MT + 1) / 2, MT1 = MT - MT0, MK0 = (MTKV + 1) / 2, MK1 = MTKV - MK0;
+    constexpr int MT0 = (MT + 1) / 2, MT1 = MT - MT0;
     // C = 128: every 128-wide output (k|v of a head, out-projection, both FFN GEMMs, the stage embedding) has exactly 8 n-tiles -
     // one per wave, all m-tiles each.  The waves are then balanced (the M split gives waves 0-3 three m-tiles and waves 4-7 two,
     // so half of the workgroup idled a third of every GEMM phase) and a wave requests one weight fragment per chunk, not two.
     constexpr bool NSPLIT = (C == 128);
     constexpr int NTC = NSPLIT ? 1 : (C >= 64 ? C / 64 : 1);   // n-tiles per wave when the output is C wide
-    constexpr int NTF = NSPLIT ? 1 : HC / 64;                  // n-tiles per wave of one FFN hidden chunk
+    constexpr bool NSPLIT_F = (HC == 128);                     // the same for a 128-wide FFN hidden chunk (any C >= 32)
+    constexpr int NTF = NSPLIT_F ? 1 : HC / 64;                // n-tiles per wave of one FFN hidden chunk
+    constexpr int MTF = NSPLIT_F ? MT : (MT + 1) / 2;
     constexpr int MTC = NSPLIT ? MT : (MT + 1) / 2;            // m-tiles a wave holds of such an output
     static_assert(C % 16 == 0 && HC % 64 == 0, "channel count must be a multiple of 16");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -312,9 +314,9 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
     const bool own_c = NSPLIT || (wn * NTC * 16) < C;          // C < 64: only some waves own columns of a C-wide output
     const int mbase = mh ? MT0 : 0, mcount = mh ? MT1 : MT0;   // this wave's m-tiles of [R]-row operands (M split)
     const int ctile0 = NSPLIT ? wave : wn * NTC;               // first column tile of a C-wide output
-    const int ftile0 = NSPLIT ? wave : wn * NTF;               // ... of an FFN hidden chunk
+    const int ftile0 = NSPLIT_F ? wave : wn * NTF;             // ... of an FFN hidden chunk
+    const int mbaseF = NSPLIT_F ? 0 : mbase, mcountF = NSPLIT_F ? MT : mcount;
     const int mbaseC = NSPLIT ? 0 : mbase, mcountC = NSPLIT ? MT : mcount;
-    const int kbase = mh ? MK0 : 0, kcount = mh ? MK1 : MK0;   // ... of [RKV]-row operands
     const int site0 = blockIdx.x * TS;
     const int nsite = min(TS, B - site0);
     const int rows_valid = nsite * W;
@@ -334,18 +336,14 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
             gemm_lds<MT1, NTW, KCH>(A + MT0 * 16 * lda, lda, wr, pre, a1, j, kg);
         }
     };
-    auto gemm_kv = [&](auto kch_tag, const float* A, int lda, const auto& wr, const auto& pre, auto& acc) {
-        constexpr int KCH = decltype(kch_tag)::value;
-        if (mh == 0) {
-            gemm_lds<MK0, 2, KCH>(A, lda, wr, pre, acc, j, kg);
-        } else if constexpr (MK1 > 0) {
-            f32x4 (&a1)[MK1][2] = reinterpret_cast<f32x4 (&)[MK1][2]>(acc);
-            gemm_lds<MK1, 2, KCH>(A + MK0 * 16 * lda, lda, wr, pre, a1, j, kg);
-        }
-    };
     auto gemm_c = [&](auto ntw_tag, auto kch_tag, const float* A, int lda, const auto& wr, const auto& pre, auto& acc) {
         constexpr int NTW = decltype(ntw_tag)::value, KCH = decltype(kch_tag)::value;
         if constexpr (NSPLIT) gemm_lds<MT, NTW, KCH>(A, lda, wr, pre, acc, j, kg);
+        else gemm_r(ntw_tag, kch_tag, A, lda, wr, pre, acc);
+    };
+    auto gemm_f = [&](auto ntw_tag, auto kch_tag, const float* A, int lda, const auto& wr, const auto& pre, auto& acc) {
+        constexpr int NTW = decltype(ntw_tag)::value, KCH = decltype(kch_tag)::value;
+        if constexpr (NSPLIT_F) gemm_lds<MT, NTW, KCH>(A, lda, wr, pre, acc, j, kg);
         else gemm_r(ntw_tag, kch_tag, A, lda, wr, pre, acc);
     };
     using I1 = std::integral_constant<int, 1>;
@@ -530,10 +528,6 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
         for (int nt = 0; nt < NTC; ++nt) acc_o[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto q_rows = [&](int hh, const float* (&wr)[1]) { wr[0] = p.wq + int64_t(hh * 64 + wn * 16 + j) * C + 4 * kg; };
-    auto kv_rows = [&](int hh, const float* (&wr)[2]) {
-        wr[0] = p.wkv + int64_t(hh * 64 + wn * 16 + j) * C + 4 * kg;
-        wr[1] = p.wkv + int64_t(inner + hh * 64 + wn * 16 + j) * C + 4 * kg;
-    };
     auto o_rows = [&](int hh, const float* (&wr)[NTC]) {
 #pragma unroll
         for (int nt = 0; nt < NTC; ++nt) wr[nt] = p.wo + int64_t(own_c ? (ctile0 + nt) * 16 + j : j) * inner + hh * 64 + 4 * kg;
@@ -551,14 +545,10 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
     q_rows(0, wq_r);
     BPre<1> pre_q = prefetch_b<1, C / 16>(wq_r);
     for (int hh = 0; hh < heads; ++hh) {
-        const float* wkv_r[2];
-        kv_rows(hh, wkv_r);
-        // NSPLIT: wave w computes one of the 8 n-tiles of [k_h | v_h] (w < 4: k columns 16 w.., else v columns 16 (w - 4)..)
+        // [k_h | v_h] is 128 wide for every stage: wave w computes one of its 8 n-tiles (w < 4: k columns 16 w.., else v columns
+        // 16 (w - 4)..) for all m-tiles
         const float* wkv1_r[1] = {p.wkv + int64_t((wave < 4 ? 0 : inner) + hh * 64 + wn * 16 + j) * C + 4 * kg};
-        BPre<2> pre_kv;
-        BPre<1> pre_kv1;
-        if constexpr (NSPLIT) pre_kv1 = prefetch_b<1, C / 16>(wkv1_r);
-        else pre_kv = prefetch_b<2, C / 16>(wkv_r);
+        const BPre<1> pre_kv1 = prefetch_b<1, C / 16>(wkv1_r);
         {   // q_h : [R][64], this wave's 16 columns of its M half
             f32x4 aq[MT0][1];
 #pragma unroll
@@ -574,7 +564,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
         const float* wo_r[NTC];
         o_rows(hh, wo_r);
         const BPre<NTC> pre_o = prefetch_b<NTC, 4>(wo_r);
-        if constexpr (NSPLIT) {   // k_h, v_h : [RKV][64] each, one n-tile of the pair per wave, all m-tiles
+        {   // k_h, v_h : [RKV][64] each, one n-tile of the pair per wave, all m-tiles
             f32x4 akv1[MTKV][1];
 #pragma unroll
             for (int mt = 0; mt < MTKV; ++mt) akv1[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -584,20 +574,6 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
             for (int mt = 0; mt < MTKV; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dst[(mt * 16 + 4 * kg + r) * QS + wn * 16 + j] = akv1[mt][0][r];
-        } else {   // k_h, v_h : [RKV][64], M split
-            f32x4 akv[MK0][2];
-#pragma unroll
-            for (int mt = 0; mt < MK0; ++mt) { akv[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; akv[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-            gemm_kv(KC{}, sykv, RS, wkv_r, pre_kv, akv);
-#pragma unroll
-            for (int mt = 0; mt < MK0; ++mt)
-                if (mt < kcount) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        sk[((kbase + mt) * 16 + 4 * kg + r) * QS + wn * 16 + j] = akv[mt][0][r];
-                        sv[((kbase + mt) * 16 + 4 * kg + r) * QS + wn * 16 + j] = akv[mt][1][r];
-                    }
-                }
         }
         lds_barrier();
         stamp();
@@ -689,22 +665,22 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restri
         w2_rows(cc, w2_r);
         const BPre<NTC> pre_w2 = prefetch_b<NTC, HC / 16>(w2_r);
         {
-            f32x4 au[MTC][NTF];
+            f32x4 au[MTF][NTF];
 #pragma unroll
-            for (int mt = 0; mt < MTC; ++mt)
+            for (int mt = 0; mt < MTF; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NTF; ++nt) au[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gemm_c(INTF{}, KC{}, sy, RS, w1_r, pre_w1, au);
+            gemm_f(INTF{}, KC{}, sy, RS, w1_r, pre_w1, au);
             const int n0 = cc * HC + ftile0 * 16;
 #pragma unroll
             for (int nt = 0; nt < NTF; ++nt) {
                 const float bv = p.b1[n0 + nt * 16 + j];
 #pragma unroll
-                for (int mt = 0; mt < MTC; ++mt)
-                    if (mt < mcountC) {
+                for (int mt = 0; mt < MTF; ++mt)
+                    if (mt < mcountF) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            su[((mbaseC + mt) * 16 + 4 * kg + r) * US + (ftile0 + nt) * 16 + j] = gelu_f(au[mt][nt][r] + bv);
+                            su[((mbaseF + mt) * 16 + 4 * kg + r) * US + (ftile0 + nt) * 16 + j] = gelu_f(au[mt][nt][r] + bv);
                     }
             }
         }
