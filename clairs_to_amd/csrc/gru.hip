@@ -69,9 +69,9 @@ int launch_gru_layer2_fc1(hipStream_t s, const float* x, const float* W, const f
 }
 
 #ifdef CTO_GRU_CLOCKS
-extern "C" int cto_debug_gru_clocks(long long* out8) {
+extern "C" int cto_debug_gru_clocks(long long* out16) {
     CTO_HIP(hipDeviceSynchronize());
-    CTO_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(cto::g_gru_clk), 8 * sizeof(long long)));
+    CTO_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(cto::g_gru_clk), 16 * sizeof(long long)));
     return CTO_OK;
 }
 #endif

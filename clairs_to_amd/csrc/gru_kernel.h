@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256 * MH) void k_gru_layer(const float* __restrict_
 // Chunk sequence inside a step: h chunks NX..NC-1, then x chunks 0..NX-1 of the next step.
 // --------------------------------------------------------------------------------------------
 #ifdef CTO_GRU_CLOCKS
-__device__ long long g_gru_clk[8];
+__device__ long long g_gru_clk[16];
 #endif
 template <int KIN, int KP, int H, int MS, bool FUSE_FC1>
 __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__ x, const float* __restrict__ Wcat,
@@ -343,6 +343,10 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
     auto t_of = [&](int step) { return dir == 0 ? step : T - 1 - step; };
 #ifdef CTO_GRU_CLOCKS
     const long long c0 = clock64(), w0 = wall_clock64();
+    long long ph[4] = {0, 0, 0, 0}, tph = 0;     // barrier wait, h part, x part + gates, step tail
+#define CTO_PH(i) do { const long long n_ = clock64(); ph[i] += n_ - tph; tph = n_; } while (0)
+#else
+#define CTO_PH(i) do { } while (0)
 #endif
 
     for (int i = threadIdx.x; i < TILE * HS; i += NTHR) hbuf[i] = 0.f;       // h_{-1} = 0
@@ -542,7 +546,11 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
         const float* xnx = xbuf + ((step + 1) & 1) * (TILE * XS);   // x_{t+1}
         opq = 0;
         asm volatile("" : "+v"(opq));      // keeps the (step-invariant) weight loads inside the time loop
+#ifdef CTO_GRU_CLOCKS
+        tph = clock64();
+#endif
         __syncthreads();                   // h_{t-1} and x_{t+1} are complete
+        CTO_PH(0);
         if (step + 2 < T) x_fetch(t_of(step + 2));
         load_Ah(0, 0, hc);
 #pragma unroll
@@ -603,7 +611,9 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
             }
 #endif
             __builtin_amdgcn_sched_barrier(0);
+            if (sq == NH - 1) CTO_PH(1);
         }
+        CTO_PH(2);
         if constexpr (LAST) {
 #pragma unroll
             for (int pq = 0; pq < NP; ++pq) gate_pair(pq / NB, pq % NB, hn, t);
@@ -620,6 +630,7 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) { ar[ms][nb] = nr[ms][nb]; az[ms][nb] = nz[ms][nb]; ain[ms][nb] = nn[ms][nb]; }
         }
+        CTO_PH(3);
     };
     for (int step = 0; step + 1 < T; ++step) step_body(step, std::false_type{});
     step_body(T - 1, std::true_type{});
@@ -631,6 +642,7 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
     if (blockIdx.x == 7 && threadIdx.x == 0) {
         const int o = FUSE_FC1 ? 4 : 0;
         g_gru_clk[o] = clock64() - c0; g_gru_clk[o + 1] = wall_clock64() - w0;
+        g_gru_clk[8 + o] = ph[0]; g_gru_clk[9 + o] = ph[1]; g_gru_clk[10 + o] = ph[2]; g_gru_clk[11 + o] = ph[3];
     }
 #endif
 
