@@ -460,3 +460,22 @@ def _strip_indels(bases):
             out.append(ch)
             i += 1
     return "".join(out)
+
+
+@pytest.mark.parametrize("B", [5000, 7500])
+def test_batch_invariance_across_tile_mixes(dev, B):
+    """Batches beyond one round of workgroups: the recurrent kernels run 32-site tiles for whole rounds and 16- or 32-site
+    tiles for the remainder (csrc/gru.hip), the CvT runs 8/16-site tiles with a ragged last workgroup.  A site's logits must
+    not depend on which launch or tile it lands in: bit-equal to the same sites run in other groupings."""
+    import torch
+    from clairs_to_amd.engine import synthetic_models
+    models = synthetic_models(4)
+    rng = np.random.default_rng(B)
+    x = torch.from_numpy((rng.integers(-50, 50, size=(B, 33, 34)) * rng.random((B, 1, 1))).astype(np.float32)).to(dev)
+    for key in ("aff", "neg"):
+        m = models[key].to(dev)
+        full = m.logits(x)
+        cuts = [0, 17, 4096, 4113, B]
+        parts = torch.cat([m.logits(x[a:b].contiguous()) for a, b in zip(cuts[:-1], cuts[1:])], dim=1)
+        assert torch.equal(full, parts), key
+        assert torch.isfinite(full).all()
