@@ -241,7 +241,7 @@ def main():
                                          "achieved": round(feat_bytes / (feat_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                          "frac": round(feat_bytes / (feat_ms * 1e-3) / 1e9 / 8000.0, 4), "launch_ms": round(feat_ms, 4),
                                          "bytes_per_launch": int(feat_bytes), "traffic": pmc_traffic_featurize(args.batch),
-                                         "note": "LDS-atomic bound (about 50 read-bases of a column hit the same counter), not bandwidth bound; 5 % of the step"},
+                                         "note": "latency bound (short per-wave column runs, one binary search per site), not bandwidth bound; 2.5 % of the step"},
             "end_to_end_tflops": round(2.0 * eng.macs_per_site * sites_total / dt / 1e12, 3),
         }
         if world == 1 and not args.no_cpu_baseline:
