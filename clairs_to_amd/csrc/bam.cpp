@@ -33,6 +33,7 @@
 #include <cstdlib>
 #include <deque>
 #include <memory>
+#include <thread>
 
 #include "pack_internal.h"
 
@@ -357,14 +358,12 @@ bool in_bed(const int64_t* bed, int64_t n_bed, int64_t pos1, int64_t* cursor) {
 
 }  // namespace
 
-extern "C" int cto_pack_from_bam(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
-                                  const int64_t* bed, int64_t n_bed, const char* ref_seq, int64_t ref_start, size_t ref_len,
-                                  int excl_flags, int min_mq, int max_depth, int max_indel_length, cto_pack** out) {
-    CTO_REQUIRE(bam_path && ctg_name && ref_seq && out, CTO_EINVAL, "cto_pack_from_bam: null argument");
-    CTO_REQUIRE(start >= 1 && end >= start, CTO_EINVAL, "cto_pack_from_bam: bad region %lld-%lld", (long long)start, (long long)end);
-    CTO_REQUIRE(n_bed == 0 || bed, CTO_EINVAL, "cto_pack_from_bam: bed intervals missing");
-    for (int64_t i = 1; i < n_bed; ++i)
-        CTO_REQUIRE(bed[2 * i] >= bed[2 * i - 1], CTO_EINVAL, "cto_pack_from_bam: bed intervals must be sorted and non-overlapping");
+namespace {
+
+// One position range [start, end] on one thread: own file handle, own index query.  Errors go through set_error (thread-local).
+int pack_from_bam_range(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
+                        const int64_t* bed, int64_t n_bed, const char* ref_seq, int64_t ref_start, size_t ref_len,
+                        int excl_flags, int min_mq, int max_depth, int max_indel_length, cto_pack** out) {
     Bgzf bz;
     CTO_REQUIRE(bz.open(bam_path), CTO_EINVAL, "cto_pack_from_bam: %s", bz.err.c_str());
     // ---- header ----
@@ -538,5 +537,77 @@ extern "C" int cto_pack_from_bam(const char* bam_path, const char* bai_path, con
         fprintf(stderr, "cto_pack_from_bam: total %.1f ms: read+inflate %.1f, pileup %.1f (libdeflate %d)\n", now() - t_begin, t_read,
                 t_flush + now() - tf1, int(libdeflate().ok()));
     *out = pk.release();
+    return CTO_OK;
+}
+
+}  // namespace
+
+extern "C" int cto_pack_from_bam(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
+                                  const int64_t* bed, int64_t n_bed, const char* ref_seq, int64_t ref_start, size_t ref_len,
+                                  int excl_flags, int min_mq, int max_depth, int max_indel_length, cto_pack** out) {
+    CTO_REQUIRE(bam_path && ctg_name && ref_seq && out, CTO_EINVAL, "cto_pack_from_bam: null argument");
+    CTO_REQUIRE(start >= 1 && end >= start, CTO_EINVAL, "cto_pack_from_bam: bad region %lld-%lld", (long long)start, (long long)end);
+    CTO_REQUIRE(n_bed == 0 || bed, CTO_EINVAL, "cto_pack_from_bam: bed intervals missing");
+    for (int64_t i = 1; i < n_bed; ++i)
+        CTO_REQUIRE(bed[2 * i] >= bed[2 * i - 1], CTO_EINVAL, "cto_pack_from_bam: bed intervals must be sorted and non-overlapping");
+    // Position ranges are independent (every range re-queries the index for the reads that overlap it), so a chunk is cut into
+    // ranges of equal numbers of requested positions and piled up on several host threads, like the text tokeniser.  The
+    // max_depth cap is evaluated per range (it only bites at depths the pack does not support anyway).
+    int64_t want = 0;                                       // requested positions inside [start, end]
+    if (bed) {
+        for (int64_t i = 0; i < n_bed; ++i) {
+            const int64_t lo = std::max<int64_t>(bed[2 * i] + 1, start), hi = std::min<int64_t>(bed[2 * i + 1], end);
+            if (hi >= lo) want += hi - lo + 1;
+        }
+    } else want = end - start + 1;
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = std::max(1u, std::min(nt, 32u));
+    if (const char* e = getenv("CTO_PACK_THREADS")) nt = std::max(1u, std::min(unsigned(atoi(e)), 64u));
+    nt = unsigned(std::max<int64_t>(1, std::min<int64_t>(nt, want / 2000)));      // at least ~2000 positions per thread
+    if (nt == 1)
+        return pack_from_bam_range(bam_path, bai_path, ctg_name, start, end, bed, n_bed, ref_seq, ref_start, ref_len, excl_flags, min_mq,
+                                   max_depth, max_indel_length, out);
+    // cut points: the position at which each thread's share of the requested positions begins
+    std::vector<int64_t> cut(nt + 1, end + 1);
+    cut[0] = start;
+    {
+        int64_t seen = 0;
+        unsigned t = 1;
+        auto feed = [&](int64_t lo, int64_t hi) {           // inclusive run of requested positions
+            while (t < nt && seen + (hi - lo + 1) > want * t / nt) {
+                cut[t] = lo + (want * t / nt - seen);
+                ++t;
+            }
+            seen += hi - lo + 1;
+        };
+        if (bed) {
+            for (int64_t i = 0; i < n_bed; ++i) {
+                const int64_t lo = std::max<int64_t>(bed[2 * i] + 1, start), hi = std::min<int64_t>(bed[2 * i + 1], end);
+                if (hi >= lo) feed(lo, hi);
+            }
+        } else feed(start, end);
+    }
+    std::vector<std::unique_ptr<cto_pack>> parts(nt);
+    std::vector<int> rcs(nt, CTO_OK);
+    std::vector<std::string> errs(nt);
+    auto work = [&](unsigned t) {
+        cto_pack* p = nullptr;
+        if (cut[t + 1] - 1 < cut[t]) { parts[t].reset(new cto_pack()); pack_begin(parts[t].get(), 16, 16); return; }
+        rcs[t] = pack_from_bam_range(bam_path, bai_path, ctg_name, cut[t], cut[t + 1] - 1, bed, n_bed, ref_seq, ref_start, ref_len,
+                                     excl_flags, min_mq, max_depth, max_indel_length, &p);
+        if (rcs[t] != CTO_OK) errs[t] = cto_last_error();
+        parts[t].reset(p);
+    };
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, t);
+        for (auto& x : th) x.join();
+    }
+    for (unsigned t = 0; t < nt; ++t)
+        if (rcs[t] != CTO_OK) { set_error("%s", errs[t].c_str()); return rcs[t]; }
+    std::string merr;
+    std::unique_ptr<cto_pack> p = merge_parts(parts, &merr);
+    CTO_REQUIRE(p != nullptr, CTO_EINVAL, "cto_pack_from_bam: %s", merr.c_str());
+    *out = p.release();
     return CTO_OK;
 }

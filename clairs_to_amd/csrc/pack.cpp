@@ -128,6 +128,32 @@ int append_column(cto_pack* p, ColumnScratch& sc, int64_t pos, int64_t ri, const
     return CTO_OK;
 }
 
+// Concatenates per-thread packs of consecutive position ranges (offsets re-based); nullptr + *err when they overlap.
+std::unique_ptr<cto_pack> merge_parts(std::vector<std::unique_ptr<cto_pack>>& parts, std::string* err) {
+    std::unique_ptr<cto_pack> p(parts[0].release());
+    for (size_t t = 1; t < parts.size(); ++t) {
+        const cto_pack& q = *parts[t];
+        if (q.col_pos.empty()) continue;
+        if (!p->col_pos.empty() && q.col_pos.front() <= p->col_pos.back()) {
+            *err = "pileup rows not in increasing position order";
+            return nullptr;
+        }
+        const int64_t e0 = p->col_off.back(), s0 = p->key_str_off.back();
+        const int32_t k0 = p->key_off.back();
+        p->col_pos.insert(p->col_pos.end(), q.col_pos.begin(), q.col_pos.end());
+        p->col_ref.insert(p->col_ref.end(), q.col_ref.begin(), q.col_ref.end());
+        for (size_t i = 1; i < q.col_off.size(); ++i) p->col_off.push_back(q.col_off[i] + e0);
+        for (size_t i = 1; i < q.key_off.size(); ++i) p->key_off.push_back(q.key_off[i] + k0);
+        p->entries.insert(p->entries.end(), q.entries.begin(), q.entries.end());
+        p->key_meta.insert(p->key_meta.end(), q.key_meta.begin(), q.key_meta.end());
+        p->key_group.insert(p->key_group.end(), q.key_group.begin(), q.key_group.end());
+        for (size_t i = 1; i < q.key_str_off.size(); ++i) p->key_str_off.push_back(q.key_str_off[i] + s0);
+        p->key_str += q.key_str;
+        parts[t].reset();
+    }
+    return p;
+}
+
 }  // namespace cto
 
 using namespace cto;
@@ -253,26 +279,11 @@ extern "C" int cto_pack_from_mpileup(const char* text, size_t len, const char* r
     const auto T1 = std::chrono::steady_clock::now();
     for (unsigned t = 0; t < nt; ++t)
         if (rcs[t] != CTO_OK) { cto::set_error("%s", errs[t].c_str()); return rcs[t]; }
-    std::unique_ptr<cto_pack> p(parts[0].release());
-    for (unsigned t = 1; t < nt; ++t) {
-        const cto_pack& q = *parts[t];
-        if (q.col_pos.empty()) continue;
-        if (!p->col_pos.empty() && q.col_pos.front() <= p->col_pos.back()) {
-            cto::set_error("mpileup rows not in increasing position order");
-            return CTO_EINVAL;
-        }
-        const int64_t e0 = p->col_off.back(), s0 = p->key_str_off.back();
-        const int32_t k0 = p->key_off.back();
-        p->col_pos.insert(p->col_pos.end(), q.col_pos.begin(), q.col_pos.end());
-        p->col_ref.insert(p->col_ref.end(), q.col_ref.begin(), q.col_ref.end());
-        for (size_t i = 1; i < q.col_off.size(); ++i) p->col_off.push_back(q.col_off[i] + e0);
-        for (size_t i = 1; i < q.key_off.size(); ++i) p->key_off.push_back(q.key_off[i] + k0);
-        p->entries.insert(p->entries.end(), q.entries.begin(), q.entries.end());
-        p->key_meta.insert(p->key_meta.end(), q.key_meta.begin(), q.key_meta.end());
-        p->key_group.insert(p->key_group.end(), q.key_group.begin(), q.key_group.end());
-        for (size_t i = 1; i < q.key_str_off.size(); ++i) p->key_str_off.push_back(q.key_str_off[i] + s0);
-        p->key_str += q.key_str;
-        parts[t].reset();
+    std::unique_ptr<cto_pack> p;
+    {
+        std::string merr;
+        p = cto::merge_parts(parts, &merr);
+        if (!p) { cto::set_error("%s", merr.c_str()); return CTO_EINVAL; }
     }
     if (timing)
         fprintf(stderr, "cto_pack_from_mpileup: %u threads, parse %.1f ms, merge %.1f ms\n", nt,

@@ -2,6 +2,7 @@
 // appender that turns a column's read-bases into entries + distinct indel keys.
 #pragma once
 #include <algorithm>
+#include <memory>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -63,5 +64,7 @@ void pack_begin(cto_pack* p, size_t entries_hint, size_t cols_hint);
 // Appends one column (position `pos`, reference index ri = pos - ref_start) made of toks[0..n)
 int append_column(cto_pack* p, ColumnScratch& sc, int64_t pos, int64_t ri, const char* ref_seq, size_t ref_len,
                   int max_indel_length, const Tok* toks, int n, std::string* err);
+
+std::unique_ptr<cto_pack> merge_parts(std::vector<std::unique_ptr<cto_pack>>& parts, std::string* err);
 
 }  // namespace cto

@@ -1,5 +1,5 @@
-"""Throughput of the native BAM -> pack producer on a synthetic long-read BAM (single host thread; callers parallelise over
-chunks like the reference's `parallel -j`).  python tools/bam_bench.py [region_kb] [coverage]"""
+"""Throughput of the native BAM -> pack producer on a synthetic long-read BAM, for 1 thread and for the default thread count
+(CTO_PACK_THREADS overrides).  python tools/bam_bench.py [region_kb] [coverage]"""
 import os
 import sys
 import tempfile
@@ -66,14 +66,19 @@ def main():
     sites = list(range(1000, L - 1000, 250))
     bed = [(x - 17, x + 17) for x in sites]
     refs = ref.tobytes().decode()
-    for tag, b in (("BED windows of %d candidates" % len(sites), bed), ("every position", None)):
-        best, pack = 1e9, None
-        for _ in range(3):
-            t0 = time.perf_counter()
-            pack = ColumnPack.from_bam(bam, "chr1", 1, L, refs, 1, bed=b)
-            best = min(best, time.perf_counter() - t0)
-        print("%s: %.3f s  -> %d columns, %.2f M read-bases; %.0f candidate sites/s/thread, %.1f MB/s of BAM" % (
-            tag, best, pack.n_cols, pack.n_entries / 1e6, len(sites) / best, os.path.getsize(bam) / best / 1e6))
+    for threads in ("1", None):
+        if threads:
+            os.environ["CTO_PACK_THREADS"] = threads
+        else:
+            os.environ.pop("CTO_PACK_THREADS", None)
+        for tag, b in (("BED windows of %d candidates" % len(sites), bed), ("every position", None)):
+            best, pack = 1e9, None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                pack = ColumnPack.from_bam(bam, "chr1", 1, L, refs, 1, bed=b)
+                best = min(best, time.perf_counter() - t0)
+            print("threads %-4s %s: %.3f s  -> %d columns, %.2f M read-bases; %.0f candidate sites/s, %.1f MB/s of BAM" % (
+                threads or "auto", tag, best, pack.n_cols, pack.n_entries / 1e6, len(sites) / best, os.path.getsize(bam) / best / 1e6))
 
 
 if __name__ == "__main__":
