@@ -350,12 +350,10 @@ extern "C" int cto_pack_key_string(const cto_pack* p, int64_t k, const char** s)
 
 extern "C" void cto_pack_free(cto_pack* p) { delete p; }
 
-extern "C" int cto_alt_info(const cto_pack* p, int64_t col, int pass, const int16_t* cv, int32_t depth_aff,
-                            const int32_t* colfirst_col, const uint32_t* keycnt, const int32_t* keyfirst,
-                            char* buf, size_t cap) {
-    CTO_REQUIRE(p && cv && colfirst_col && buf && cap > 0, CTO_EINVAL, "cto_alt_info: null argument");
-    CTO_REQUIRE(col >= 0 && size_t(col) < p->col_pos.size(), CTO_EINVAL, "cto_alt_info: column out of range");
-    CTO_REQUIRE(pass == 0 || pass == 1, CTO_EINVAL, "cto_alt_info: pass must be 0 (AFF) or 1 (NEG)");
+namespace {
+// alt_info of one candidate column (create_tensor_pileup_calling.py:158-209); arguments as cto_alt_info, already validated
+std::string alt_info_string(const cto_pack* p, int64_t col, int pass, const int16_t* cv, int32_t depth_aff,
+                            const int32_t* colfirst_col, const uint32_t* keycnt, const int32_t* keyfirst) {
     cv += pass * 36;
     colfirst_col += pass * 4;
     struct Item { int64_t first; std::string key; int64_t count; };
@@ -398,7 +396,40 @@ extern "C" int cto_alt_info(const cto_pack* p, int64_t col, int pass, const int1
         s += std::string("R") + kB[ref] + " " + std::to_string(refc);
     }
     s.push_back('-');
+    return s;
+}
+}  // namespace
+
+extern "C" int cto_alt_info(const cto_pack* p, int64_t col, int pass, const int16_t* cv, int32_t depth_aff,
+                            const int32_t* colfirst_col, const uint32_t* keycnt, const int32_t* keyfirst,
+                            char* buf, size_t cap) {
+    CTO_REQUIRE(p && cv && colfirst_col && buf && cap > 0, CTO_EINVAL, "cto_alt_info: null argument");
+    CTO_REQUIRE(col >= 0 && size_t(col) < p->col_pos.size(), CTO_EINVAL, "cto_alt_info: column out of range");
+    CTO_REQUIRE(pass == 0 || pass == 1, CTO_EINVAL, "cto_alt_info: pass must be 0 (AFF) or 1 (NEG)");
+    const std::string s = alt_info_string(p, col, pass, cv, depth_aff, colfirst_col, keycnt, keyfirst);
     CTO_REQUIRE(s.size() + 1 <= cap, CTO_EINVAL, "cto_alt_info: buffer too small (%zu needed)", s.size() + 1);
     memcpy(buf, s.c_str(), s.size() + 1);
     return int(s.size());
+}
+
+extern "C" int64_t cto_alt_info_batch(const cto_pack* p, int64_t n_sites, const int32_t* site_info, int pass, const int16_t* colvec,
+                                      const int32_t* sitefirst, const uint32_t* keycnt, const int32_t* keyfirst, char* buf,
+                                      size_t cap, int64_t* offsets) {
+    CTO_REQUIRE(p && site_info && colvec && sitefirst && buf && offsets && n_sites >= 0, CTO_EINVAL, "cto_alt_info_batch: null argument");
+    CTO_REQUIRE(pass == 0 || pass == 1, CTO_EINVAL, "cto_alt_info_batch: pass must be 0 (AFF) or 1 (NEG)");
+    size_t used = 0;
+    offsets[0] = 0;
+    for (int64_t i = 0; i < n_sites; ++i) {
+        const int64_t col = site_info[i * 12];
+        if (col >= 0) {
+            CTO_REQUIRE(size_t(col) < p->col_pos.size(), CTO_EINVAL, "cto_alt_info_batch: column out of range");
+            const std::string s = alt_info_string(p, col, pass, colvec + col * CTO_COLVEC_STRIDE, site_info[i * 12 + 1 + pass],
+                                                  sitefirst + i * 8, keycnt, keyfirst);
+            CTO_REQUIRE(used + s.size() <= cap, CTO_EINVAL, "cto_alt_info_batch: buffer too small");
+            memcpy(buf + used, s.data(), s.size());
+            used += s.size();
+        }
+        offsets[i + 1] = int64_t(used);
+    }
+    return int64_t(used);
 }

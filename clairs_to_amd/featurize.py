@@ -67,14 +67,21 @@ def alt_infos(feat, host_pack, site_info_host=None, pass_idx=0):
     if keycnt.size == 0:
         keycnt = np.zeros(1, dtype=np.uint32)
         keyfirst = np.zeros((1, 2), dtype=np.int32)
-    buf = C.create_string_buffer(1 << 16)
-    out = []
-    for i in range(info.shape[0]):
-        c = int(info[i, 0])
-        if c < 0:
-            out.append("")
-            continue
-        n = check(lib.cto_alt_info(host_pack._h, c, int(pass_idx), colvec[c].ctypes.data, int(info[i, 1 + pass_idx]),
-                                   sitefirst[i].ctypes.data, keycnt.ctypes.data, keyfirst.ctypes.data, buf, len(buf)))
-        out.append(buf.raw[:n].decode())
-    return out
+    info = np.ascontiguousarray(info, dtype=np.int32)
+    n = info.shape[0]
+    if n == 0:
+        return []
+    colvec = np.ascontiguousarray(colvec)
+    cap = 256 * n + (1 << 16)
+    offsets = np.zeros(n + 1, dtype=np.int64)
+    while True:
+        buf = C.create_string_buffer(cap)
+        used = lib.cto_alt_info_batch(host_pack._h, n, info.ctypes.data, int(pass_idx), colvec.ctypes.data, sitefirst.ctypes.data,
+                                      keycnt.ctypes.data, keyfirst.ctypes.data, C.addressof(buf), cap, offsets.ctypes.data)
+        if used >= 0:
+            break
+        if "buffer too small" not in lib.cto_last_error().decode():
+            check(int(used))
+        cap *= 4
+    raw = buf.raw
+    return [raw[offsets[i]:offsets[i + 1]].decode() for i in range(n)]

@@ -159,6 +159,13 @@ int cto_extract_candidates(const cto_pack_view* dev_pack, int min_mq, int min_bq
 int cto_alt_info(const cto_pack* p, int64_t col, int pass, const int16_t* colvec_col, int32_t depth,
                  const int32_t* colfirst_col, const uint32_t* keycnt, const int32_t* keyfirst,
                  char* buf, size_t cap);
+/* The same for all sites of a chunk in one call: site_info / sitefirst as written by cto_gather_windows (host copies), colvec
+ * the whole host copy [n_cols][2][36].  Strings are packed back to back into buf; offsets[n_sites + 1] delimits them (a site
+ * without a centre column gets an empty string).  Returns the bytes used or a negative error code. */
+int64_t cto_alt_info_batch(const cto_pack* p, int64_t n_sites, const int32_t* site_info, int pass, const int16_t* colvec,
+                           const int32_t* sitefirst, const uint32_t* keycnt, const int32_t* keyfirst, char* buf, size_t cap,
+                           int64_t* offsets);
+
 
 /* ------------------------------------------------------------------------------------------------
  * Models (clairs/model.py).  Weights are handed over by state_dict name; data is host fp32.
