@@ -48,14 +48,26 @@ def call_chunks(args):
     os.makedirs(args.output_dir, exist_ok=True)
     eng = make_engine(args, device)
     n_rows = 0
-    for bed in chunks[lo:hi]:
+
+    def chunk_args(bed):
         ctg = chunk_contig(bed)
         if ctg is None:
-            continue
+            return None
         a = Namespace(**vars(args))
         a.candidates_bed_regions, a.ctg_name, a.mpileup_fn, a.predict_fn = bed, ctg, None, None
         a.call_fn = os.path.join(args.output_dir, "p_%s.vcf" % os.path.basename(bed))
-        n_rows += pileup_call(a, engine=eng)
+        return a
+    # two-stage pipeline: the pack of the next chunk is produced on a host thread (BAM decoding / samtools + tokenising run
+    # outside the GIL) while the current chunk is on the GPU and its VCF rows are written
+    from concurrent.futures import ThreadPoolExecutor
+    from .pileup_call import prepare_chunk
+    mine = [a for a in (chunk_args(b) for b in chunks[lo:hi]) if a is not None]
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        nxt = pool.submit(prepare_chunk, mine[0]) if mine else None
+        for i, a in enumerate(mine):
+            prep = nxt.result()
+            nxt = pool.submit(prepare_chunk, mine[i + 1]) if i + 1 < len(mine) else None
+            n_rows += pileup_call(a, engine=eng, prepared=prep) if prep is not None else 0
     print("[INFO] rank %d/%d: chunks %d..%d, %d VCF records" % (rank, world, lo, hi, n_rows), file=sys.stderr)
     if world > 1:
         import torch.distributed as dist

@@ -39,21 +39,30 @@ def make_engine(args, device="cuda"):
     return Engine(aff, neg, lik, edges, min_bq=min_bq, min_rescale_cov=args.min_rescale_cov, device=device)
 
 
-def pileup_call(args, device="cuda", engine=None):
-    eng = engine if engine is not None else make_engine(args, device)
-    device = eng.device
-    K = eng.K
+def prepare_chunk(args):
+    """Host-only half of a chunk: candidates, reference slice and the column pack (BAM decoding / mpileup tokenising; the C
+    calls release the GIL, so `call_chunks` runs this for chunk i+1 on a thread while chunk i is on the GPU).  None if empty."""
     centres, ctg_start, ctg_end = read_candidates(args.candidates_bed_regions, args.ctg_name)
     if not centres:
-        print("[INFO] {} total processed positions: 0".format(args.ctg_name), file=sys.stderr)
-        return 0
-    sites = sorted(centres)
+        return None
     ref_start = max(1, ctg_start - EXPAND_REF)
     ref = read_region(args.ref_fn, args.ctg_name, ref_start, ctg_end + EXPAND_REF)
     if not ref:
         sys.exit("[ERROR] Failed to load reference sequence from file ({}).".format(args.ref_fn))
     max_indel = MAX_INDEL if args.max_indel_length is None else args.max_indel_length
     pack = load_pack(args, ref, ref_start, ctg_start, ctg_end, max_indel)
+    return dict(sites=sorted(centres), ref=ref, ref_start=ref_start, pack=pack)
+
+
+def pileup_call(args, device="cuda", engine=None, prepared=None):
+    eng = engine if engine is not None else make_engine(args, device)
+    device = eng.device
+    K = eng.K
+    prep = prepared if prepared is not None else prepare_chunk(args)
+    if prep is None:
+        print("[INFO] {} total processed positions: 0".format(args.ctg_name), file=sys.stderr)
+        return 0
+    sites, ref, ref_start, pack = prep["sites"], prep["ref"], prep["ref_start"], prep["pack"]
     dp = pack.to_device(device)
     res = eng.run_device(dp, torch.tensor(sites, dtype=torch.int32, device=device))
     torch.cuda.synchronize()
