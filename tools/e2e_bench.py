@@ -69,6 +69,28 @@ def main():
     n = pileup_call(args, engine=eng)
     dt = time.perf_counter() - t0
     print("%d candidates -> %d VCF records in %.1f ms (%.0f sites/s per process), engine resident" % (len(sites), n, dt * 1e3, len(sites) / dt))
+    # a run of several chunks through call_chunks (pack production of chunk i+1 overlapped with the GPU work of chunk i)
+    from clairs_to_amd.call_chunks import call_chunks
+    n_chunks = 6
+    per = len(sites) // n_chunks
+    names = []
+    for c in range(n_chunks):
+        fn = os.path.join(d, "chr1.%d_%d_snv" % (c + 1, n_chunks))
+        open(fn, "w").write("".join("chr1\t%d\t%d\n" % (x - 17, x + 17) for x in sites[c * per:(c + 1) * per]))
+        names.append(fn)
+    open(os.path.join(d, "CANDIDATES_FILES"), "w").write("".join(n_ + "\n" for n_ in names))
+    a2 = Namespace(**vars(args))
+    a2.chunk_list, a2.output_dir = os.path.join(d, "CANDIDATES_FILES"), os.path.join(d, "vcf_output")
+    a2.merged_vcf_fn, a2.final_vcf_fn = os.path.join(d, "merged.vcf"), None
+    import clairs_to_amd.call_chunks as cc
+    orig = cc.make_engine
+    cc.make_engine = lambda *_a, **_k: eng               # keep the resident engine: measure the steady state, not model loading
+    t0 = time.perf_counter()
+    call_chunks(a2)
+    dt = time.perf_counter() - t0
+    cc.make_engine = orig
+    print("call_chunks: %d chunks x %d candidates in %.1f ms (%.0f sites/s per process, merged VCF included)" % (
+        n_chunks, per, dt * 1e3, n_chunks * per / dt))
     pr = cProfile.Profile()
     pr.enable()
     pileup_call(args, engine=eng)
