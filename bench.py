@@ -102,6 +102,21 @@ def cpu_baseline(chunks, models, lik, edges, min_bq, n_sample, budget_s=12.0):
                        "serial), %.1f s" % (total_sites, total_t)), first_probs
 
 
+def self_launch(n):
+    """Re-exec this command line under torch.distributed.run with n ranks on this node (rendezvous on 127.0.0.1, a free
+    port); the ranks' stdout is ours, so rank 0's JSON line is the only line printed.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,7 +132,12 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        # `python bench.py --gpus N` with no launcher around it: become the launcher (one rank per GPU, RCCL over xGMI)
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
@@ -196,6 +216,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- proof that the exchange step ran between `world` distinct ranks: every rank's last per-site block must sit in its
+    # rank-major slot of the gathered buffer, bit for bit, and every rank reports the device it computed on ----
+    census, gather_ok = None, None
+    if world > 1:
+        last = (args.steps - 1) & 1
+        mine = gather_buf[last][rank * args.batch:(rank + 1) * args.batch]
+        ok_local = bool(torch.equal(mine, out["probs"]))
+        sums = torch.stack([gather_buf[last][r * args.batch:(r + 1) * args.batch].double().sum() for r in range(world)])
+        own = torch.zeros(world, dtype=torch.float64, device=dev)
+        own[rank] = out["probs"].double().sum()
+        dist.all_reduce(own)                                  # own[r] = checksum rank r computed of its own block
+        flag = torch.tensor([1 if (ok_local and torch.equal(sums, own)) else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        gather_ok = bool(flag.item())
+        props = torch.cuda.get_device_properties(dev)
+        me = {"rank": rank, "device": "cuda:%d" % local_rank, "name": props.name,
+              "pci": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", ""))}
+        census = [None] * world
+        dist.all_gather_object(census, me)
+
     # ---- roofline of the dominant kernel (BiGRU layer-2 recurrent kernel), live HIP-event timing ----
     mean_ms, macs = C.c_double(0.0), C.c_int64(0)
     n_meas = check(lib.cto_model_profile_read(eng.h_neg, C.byref(mean_ms), C.byref(macs)))
@@ -243,6 +283,9 @@ def main():
                                          "bytes_per_launch": int(feat_bytes), "traffic": pmc_traffic_featurize(args.batch),
                                          "note": "latency bound (short per-wave column runs, one binary search per site), not bandwidth bound; 2.5 % of the step"},
             "end_to_end_tflops": round(2.0 * eng.macs_per_site * sites_total / dt / 1e12, 3),
+            "ranks_seen": dist.get_world_size() if world > 1 else 1,
+            "backend": (dist.get_backend() + (" (RCCL over xGMI)" if backend == "nccl" else " (test hook)")) if world > 1 else None,
+            "rank_devices": census, "gather_verified": gather_ok,
         }
         if world == 1 and not args.no_cpu_baseline:
             cb, probs_cpu = cpu_baseline(chunks, models, lik, edges, min_bq, min(args.cpu_sample, args.batch))

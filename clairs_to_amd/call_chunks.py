@@ -81,7 +81,8 @@ def call_chunks(args):
         n = sort_vcf(args.output_dir, args.merged_vcf_fn, contigs, vcf_fn_prefix="p_", ref_fn=args.ref_fn, sample_name=args.sample_name)
         print("[INFO] merged %d records into %s" % (n, args.merged_vcf_fn), file=sys.stderr)
         if args.final_vcf_fn:
-            postprocess_vcf(args.merged_vcf_fn, args.final_vcf_fn, platform=args.platform if args.platform in ("ont", "ilmn", "hifi") else "ont",
+            from .platforms import resolve_platform
+            postprocess_vcf(args.merged_vcf_fn, args.final_vcf_fn, platform=resolve_platform(args.platform)[1],
                             ref_fn=args.ref_fn, sample_name=args.sample_name)
     if world > 1:
         import torch.distributed as dist

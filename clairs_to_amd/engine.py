@@ -72,7 +72,8 @@ def synthetic_models(n_out=4, seed=0):
 class Engine:
     """One GPU's worth of the hot path.  aff/neg: nn_shims modules (or anything exposing `_handle()`)."""
 
-    def __init__(self, aff, neg, lik, edges, min_bq=20, min_rescale_cov=50, device="cuda", two_streams=False):
+    def __init__(self, aff, neg, lik, edges, min_bq=20, min_rescale_cov=50, device="cuda", two_streams=False,
+                 neg_reads_aff=False):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("clairs_to_amd.Engine needs a HIP device; there is no CPU fallback")
@@ -80,6 +81,9 @@ class Engine:
         self.K = len(aff._heads_out)
         assert len(neg._heads_out) == self.K
         self.min_bq, self.min_rescale_cov = int(min_bq), int(min_rescale_cov)
+        # Illumina: the NEG tensor files are symlinks to the AFF ones (run_clairs_to:1248-1252) - the NEG network reads the
+        # --min_bq pass, not the BQ >= 0 pass.  Identical for the platform default (min_bq 0); differs with an explicit --min_bq.
+        self.neg_reads_aff = bool(neg_reads_aff)
         with torch.cuda.device(self.device):
             self.h_aff, self.h_neg = aff._handle(), neg._handle()
             self.posterior = Posterior(lik, edges, self.device)
@@ -94,6 +98,8 @@ class Engine:
         with torch.cuda.device(self.device):
             feat = featurize(dev_pack, site_pos_dev, self.min_bq, self.min_rescale_cov, want_raw=want_raw)
             B, K = site_pos_dev.numel(), self.K
+            if self.neg_reads_aff:
+                feat.x_neg = feat.x_aff
             la = torch.empty((K, B, 2), dtype=torch.float32, device=self.device)
             ln = torch.empty((K, B, 2), dtype=torch.float32, device=self.device)
             main = torch.cuda.current_stream()

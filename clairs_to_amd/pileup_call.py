@@ -25,7 +25,7 @@ from .engine import Engine
 from .fasta import read_region
 from .featurize import alt_infos
 from .predict import load_models, str2bool
-from .synth import PLATFORMS
+from .platforms import resolve_platform
 
 
 def make_engine(args, device="cuda"):
@@ -33,10 +33,13 @@ def make_engine(args, device="cuda"):
     if not torch.cuda.is_available():
         sys.exit("[ERROR] clairs_to_amd pileup_call needs a HIP device; there is no CPU fallback")
     K = 4 if args.disable_indel_calling else 6
-    min_bq = args.min_bq if args.min_bq is not None else PLATFORMS.get(args.platform, PLATFORMS["ont"])["min_bq"]
+    _, family, default_bq = resolve_platform(args.platform)          # exits on a platform the reference does not know
+    min_bq = args.min_bq if args.min_bq is not None else default_bq
     aff, neg = load_models(args, device)
     lik, edges = load_likelihood(args.likelihood_matrix_data, K)
-    return Engine(aff, neg, lik, edges, min_bq=min_bq, min_rescale_cov=args.min_rescale_cov, device=device)
+    # ilmn: the reference's NEG tensors are a symlink to the AFF tensors (run_clairs_to:1248-1252), whatever --min_bq is
+    return Engine(aff, neg, lik, edges, min_bq=min_bq, min_rescale_cov=args.min_rescale_cov, device=device,
+                  neg_reads_aff=(family == "ilmn"))
 
 
 def prepare_chunk(args):

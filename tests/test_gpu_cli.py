@@ -136,24 +136,34 @@ def test_pileup_call_one_invocation(tmp_path, golden_region, mode, aff_cls, neg_
         assert [r[:6] for r in rows] == [r[:6] for r in ref_rows]
 
 
-def test_bench_multi_rank_code_path(tmp_path):
+@pytest.mark.parametrize("launcher", ["torchrun", "self"])
+def test_bench_multi_rank_code_path(tmp_path, launcher):
     """bench.py's N > 1 control flow (rank-sharded chunks, asynchronous double-buffered all_gather of the per-site outputs,
     barrier + max-over-ranks timing, one JSON line from rank 0), exercised with two ranks on this box's single GPU over gloo
-    (test hooks CTO_BENCH_BACKEND / CTO_BENCH_DEVICE); the driver's real runs use RCCL with one GPU per rank."""
+    (test hooks CTO_BENCH_BACKEND / CTO_BENCH_DEVICE); the driver's real runs use RCCL with one GPU per rank.
+    launcher = "self": `python bench.py --gpus 2` with no launcher and no WORLD_SIZE must start the two ranks itself."""
     import json
     import subprocess
     import sys
     from conftest import ROOT
     env = dict(os.environ, CTO_BENCH_BACKEND="gloo", CTO_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-                        "--warmup", "1", "--pool", "2"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--pool", "2"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", "29533"] + tail
+    else:
+        cmd = [sys.executable] + tail
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
     assert len(lines) == 1
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 3 and res["value"] > 0 and res["scaling"] == "weak"
     assert res["roofline"]["frac"] > 0 and "cpu_baseline" not in res
+    assert res["ranks_seen"] == 2 and res["gather_verified"] is True and res["backend"].startswith("gloo")
+    assert [d["rank"] for d in res["rank_devices"]] == [0, 1]
 
 
 def _bam_scenario(tmp_path):

@@ -114,3 +114,32 @@ def test_sort_and_postprocess_vcf_match_reference(tmp_path):
             argv += ["--ref_fn", str(tmp_path / "ref.fa")]
         postprocess_vcf_main(argv)
         assert out.read_text() == case["out"], o
+
+
+def test_bench_rejects_rank_count_mismatch():
+    """--gpus must agree with the number of ranks the launcher started (the round-1 bench silently ignored --gpus)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, cwd=ROOT, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_platform_table_matches_reference_names():
+    """Every platform name of the reference resolves to the reference's min_bq and family (shared/param.py:34,
+    run_clairs_to:590-595, 910-918, 1089-1096); unknown names are refused, never mapped to ont."""
+    import pytest
+    from clairs_to_amd.platforms import resolve_platform
+    assert resolve_platform("hifi_revio") == ("hifi_revio", "hifi", 0)
+    assert resolve_platform("ont_r10_dorado_hac_4khz") == ("ont_r10_dorado_hac_4khz", "ont", 15)
+    assert resolve_platform("ont_r10_guppy_5khz")[2] == 15 and resolve_platform("ont_r10_guppy_hac_5khz")[2] == 15
+    assert resolve_platform("r1041_e82_400bps_sup_v420") == ("ont_r10_dorado_sup_5khz", "ont", 20)
+    assert resolve_platform("ilmn_ssrs") == ("ilmn_ssrs", "ilmn", 0)
+    for name in ("ont", "ilmn", "hifi", "hifi_ss", "ont_r10_dorado_sup_5khz_ssrs"):
+        resolve_platform(name)
+    with pytest.raises(SystemExit):
+        resolve_platform("pacbio")
+    with pytest.raises(ValueError):
+        resolve_platform("", exit_on_unknown=False)
