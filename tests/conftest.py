@@ -1,4 +1,7 @@
+import base64
 import gzip
+import hashlib
+import io
 import json
 import os
 import sys
@@ -63,3 +66,29 @@ def _poisoned_lds(request):
             from clairs_to_amd._lib import lib, check, current_stream_ptr
             check(lib.cto_debug_poison_lds(current_stream_ptr()))
     yield
+
+
+@pytest.fixture(scope="session")
+def region2k():
+    """fixture + the inputs regenerated from its seed (checked against the stored SHA-256: a drifting generator must fail
+    here, not look like a parity failure)"""
+    from clairs_to_amd.synth import SynthChunk, mpileup_text
+    g = load_json_gz("region2k.json.gz")
+    kw = dict(g["params"])
+    chunk = SynthChunk(kw.pop("n_sites"), **kw)
+    ref, ref_lo = chunk.ref_window()
+    texts = {"neg": mpileup_text(chunk, min_bq=0), "aff": mpileup_text(chunk, min_bq=g["min_bq_aff"])}
+    sha = lambda t: hashlib.sha256(t.encode()).hexdigest()
+    assert sha(texts["neg"]) == g["input_sha"]["mpileup_neg"] and sha(texts["aff"]) == g["input_sha"]["mpileup_aff"]
+    assert sha(ref) == g["input_sha"]["ref"]
+    return dict(g=g, chunk=chunk, ref=ref, ref_lo=ref_lo, texts=texts, sites=chunk.site_pos.tolist())
+
+
+def load_genuine_pickle(name):
+    """torch.load of a pickle the REFERENCE's classes wrote, resolved onto the shims (clairs.model aliases)"""
+    import torch
+    from clairs_to_amd import nn_shims
+    nn_shims.install_reference_aliases()
+    g = load_json_gz("pickles.json.gz")[name]
+    raw = gzip.decompress(base64.b64decode(g["pickle_gz_b64"]))
+    return torch.load(io.BytesIO(raw), map_location="cpu", weights_only=False)[g["key"]], g

@@ -13,6 +13,11 @@ reference - they read the files this script writes next to itself:
   extract.json.gz      extract_candidates_calling through the shim: pileup text in, SNV / indel candidate positions out
   calls_<mode>.json.gz clairs_to.py predict (--predict_fn) then call_variants on those tensors: probability rows,
                        likelihood table, VCF rows                                            (H1-H6, Q1-Q6)
+  calls_branches.json.gz  hand-made probability rows through the reference's call_variants: every ALT / AF / GT / FILTER
+                       branch of output_vcf_from_probability (Q4, Q6), with and without --show_ref / --qual 20
+  region2k.json.gz     2 000 candidates through the reference's four commands; inputs regenerated from a seed and
+                       checked by SHA-256, outputs stored (tensor text as SHA-256 + per-row CRC-32)
+  pickles.json.gz      genuine torch.save'd clairs.model objects (parameter values zeroed), for the checkpoint-loading seam
 
 Usage: python tests/golden/gen_golden.py     (from the repo root)
 """
@@ -442,10 +447,239 @@ def gen_post(tmp):
     dump_json_gz("post.json.gz", fixture)
 
 
+
+# ------------------------------------------------------------------------------------------ call_variants branch coverage
+def _prob_row(ctg, pos, ref, alt_info, fwd, rev, K, winner, strong=True, aff=None, neg=None):
+    """One probability row in predict.py's format (predict.py:114-152).  `winner`: class index whose (AFF, NEG) pair says
+    "yes" (p_aff high, p_neg low); the other classes say "no".  strong=False keeps the pair near 0.5 (low QUAL)."""
+    hi, lo = (0.99999, 0.00001) if strong else (0.58, 0.42)
+    pa = [lo] * K if aff is None else list(aff)
+    pn = [hi] * K if neg is None else list(neg)
+    if aff is None:
+        pa[winner] = hi
+    if neg is None:
+        pn[winner] = lo
+    fields = [ctg, str(pos), ref, alt_info, str([float(v) for v in fwd]), str([float(v) for v in rev])]
+    fields += ["{:0.8f} {:0.8f}".format(1.0 - p, p) for p in pa] + ["{:0.8f} {:0.8f}".format(1.0 - p, p) for p in pn]
+    return "\t".join(fields) + ("\t\n" if K == 4 else "\n")
+
+
+def gen_branches(tmp):
+    """Q4 / Q6 branch coverage (call_variants.py:135-150, 306-415, 67-76): hand-made probability rows whose
+    alt_info / winner combinations drive the REFERENCE's call_variants through every ALT / AF / GT / FILTER branch - insertion
+    ALT (forward and '#'-anchored), deletion REF, 1/1, AF clamp, first-seen tie-break, SNV demotion, depth 0 and its
+    all-indel fallback, empty allele list, indel alleles in SNV mode, SNV alleles in indel mode, REF == ALT, LowQual."""
+    A, C, G, T, I, D = range(6)
+    snv = [  # (ref, alt_info, fwd, rev, winner, strong)
+        ("A", "20-XT 20-", [0, 0, 0, 11], [0, 0, 0, 9], T, True),                 # AF = 1 -> 1/1
+        ("A", "10-XT 12-", [0, 0, 0, 6], [0, 0, 0, 6], T, True),                  # count > depth: AF clamps to 1 -> 1/1
+        ("A", "40-XT 9 R 31-", [15, 0, 0, 5], [16, 0, 0, 4], T, True),            # plain 0/1
+        ("A", "40-XT 9 R 31-", [15, 0, 0, 5], [16, 0, 0, 4], C, True),            # winner C not observed -> demoted to RefCall
+        ("A", "40-XT 9 R 31-", [15, 0, 0, 5], [16, 0, 0, 4], A, True),            # reference wins
+        ("A", "40-XT 9-", [0, 0, 0, 5], [0, 0, 0, 4], A, True),                   # reference wins, no R key -> AD 0
+        ("G", "30-XC 5 XT 5 R 20-", [0, 3, 10, 2], [0, 2, 10, 3], T, True),       # tie: first-seen XC is the ALT although T won
+        ("G", "30-XT 5 XC 5 R 20-", [0, 3, 10, 2], [0, 2, 10, 3], C, True),       # same tie, other order
+        ("G", "30-XC 4 XT 6 R 20-", [0, 3, 10, 2], [0, 2, 10, 3], C, True),       # best allele is not the first key
+        ("C", "25-IAGT 14 R 11-", [0, 6, 0, 0], [0, 5, 0, 0], T, True),           # best allele is an insertion: dropped in SNV mode
+        ("C", "25-DCAG 14 XT 3 R 8-", [0, 4, 0, 2], [0, 4, 0, 1], T, True),       # best allele is a deletion: dropped in SNV mode
+        ("C", "25-XT 14 DCAG 3 R 8-", [0, 4, 0, 7], [0, 4, 0, 7], T, True),       # SNV allele ranked above an indel allele
+        ("T", "0--", [0, 0, 0, 0], [0, 0, 0, 0], A, True),                        # depth 0, variant -> "low tumor coverage"
+        ("T", "0-", [0, 0, 0, 0], [0, 0, 0, 0], A, True),                         # depth 0, no second field
+        ("T", "0-XA 3 XC 2-", [2, 1, 0, 0], [1, 1, 0, 0], A, True),               # depth 0 with two keys: no fallback
+        ("T", "0-IAC 5-", [0, 0, 0, 0], [0, 0, 0, 0], A, True),                   # depth 0, single indel key -> depth = 5, then dropped (indel)
+        ("T", "0-XA 5-", [3, 0, 0, 0], [2, 0, 0, 0], A, True),                    # depth 0, single SNV key: no fallback
+        ("T", "33-R 33-", [0, 0, 0, 17], [0, 0, 0, 16], G, True),                 # variant wins but no allele observed
+        ("T", "33-XG 0 R 33-", [0, 0, 0, 17], [0, 0, 0, 16], G, True),            # zero-count allele: AF 0 is not supported
+        ("A", "40-XT 9 R 31-", [15, 0, 0, 5], [16, 0, 0, 4], T, False),           # weak call: low QUAL (LowQual under --qual 20)
+        ("A", "40-XG 21 R 19-", [9, 0, 11, 0], [10, 0, 10, 0], G, False),
+        ("A", "57-XC 1 XG 2 XT 3 R 51-", [25, 1, 1, 1], [26, 0, 1, 2], T, True),  # three alleles, ascending counts
+        ("N", "12-XA 5 R 7-", [3, 0, 0, 0], [2, 0, 0, 0], A, True),               # reference base outside ACGT as printed by predict (never N there, kept for the parser)
+    ]
+    indel = [
+        ("A", "30-IAGT 12 R 18-", [9, 0, 0, 0], [9, 0, 0, 0], I, True),           # insertion, forward anchor: ALT = AGT
+        ("A", "30-I#GT 12 R 18-", [9, 0, 0, 0], [9, 0, 0, 0], I, True),           # '#' anchor: ALT = ref + GT
+        ("A", "30-DAC 9 R 21-", [10, 0, 0, 0], [11, 0, 0, 0], D, True),           # deletion: REF = AC, ALT = A
+        ("A", "30-DACGTT 9 R 21-", [10, 0, 0, 0], [11, 0, 0, 0], D, True),        # longer deletion
+        ("A", "30-DA 9 R 21-", [10, 0, 0, 0], [11, 0, 0, 0], D, True),            # truncated D key: REF == ALT -> dropped
+        ("A", "12-IAT 12-", [0, 0, 0, 0], [0, 0, 0, 0], I, True),                 # AF = 1 -> 1/1
+        ("A", "12-IAT 12-", [0, 0, 0, 0], [0, 0, 0, 0], D, True),                 # D wins, best allele is the insertion
+        ("A", "30-DAC 9 IAG 4 R 17-", [8, 0, 0, 0], [9, 0, 0, 0], I, True),       # I wins, best allele is the deletion
+        ("A", "30-IAG 4 DAC 4 R 22-", [11, 0, 0, 0], [11, 0, 0, 0], D, True),     # tie between I and D: first-seen
+        ("A", "30-XT 10 IAG 4 R 16-", [8, 0, 0, 5], [8, 0, 0, 5], I, True),       # I wins, best allele is an SNV: only with --show_ref
+        ("A", "30-XT 10 IAG 4 R 16-", [8, 0, 0, 5], [8, 0, 0, 5], A, True),       # reference (A) wins in indel mode
+        ("A", "30-XT 10 IAG 4 R 16-", [8, 0, 0, 5], [8, 0, 0, 5], T, True),       # a non-reference BASE wins: still "reference" in indel mode
+        ("C", "0-ICA 7-", [0, 0, 0, 0], [0, 0, 0, 0], I, True),                   # depth 0 fallback to the indel count -> 1/1
+        ("C", "0-ICA 7 DCT 2-", [0, 0, 0, 0], [0, 0, 0, 0], I, True),             # depth 0, two keys -> low tumor coverage
+        ("C", "0--", [0, 0, 0, 0], [0, 0, 0, 0], D, True),
+        ("C", "41-R 41-", [0, 20, 0, 0], [0, 21, 0, 0], I, True),                 # no allele observed
+        ("G", "30-IGAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAC 6 R 24-", [0, 0, 12, 0], [0, 0, 12, 0], I, True),
+        ("A", "30-IAGT 12 R 18-", [9, 0, 0, 0], [9, 0, 0, 0], I, False),          # weak call -> LowQual under --qual 20
+        ("A", "30-DAC 9 R 21-", [10, 0, 0, 0], [11, 0, 0, 0], D, False),
+        ("T", "48-ITC 3 ITCC 3 ITG 5 DTA 5 R 32-", [0, 0, 0, 16], [0, 0, 0, 16], I, True),   # several alleles, tie between ITG and DTA
+    ]
+    out = {}
+    for mode, K, cases in (("snv", 4, snv), ("indel", 6, indel)):
+        text = "".join(_prob_row("chr1", 1000 + 10 * i, c[0], c[1], c[2], c[3], K, c[4], c[5]) for i, c in enumerate(cases))
+        pred = os.path.join(tmp, "branch_pred_%s.gz" % mode)
+        with gzip.open(pred, "wt") as f:
+            f.write(text)
+        table = likelihood_table(K, seed=70 + K)
+        lik_fn = os.path.join(tmp, "branch_lik_%s.txt" % mode)
+        np.savetxt(lik_fn, table, fmt="%.17g")
+        runs = {}
+        for qual in (None, 20):
+            for show_ref in (False, True):
+                vcf_fn = os.path.join(tmp, "branch_%s_%s_%d.vcf" % (mode, qual, int(show_ref)))
+                cmd = [sys.executable, os.path.join(REF, "clairs_to.py"), "call_variants", "--predict_fn", pred, "--call_fn", vcf_fn,
+                       "--likelihood_matrix_data", lik_fn, "--disable_indel_calling", "True" if K == 4 else "False",
+                       "--ctg_name", "chr1", "--pileup"]
+                if qual is not None:
+                    cmd += ["--qual", str(qual)]
+                if show_ref:
+                    cmd.append("--show_ref")
+                res = subprocess.run(cmd, cwd=tmp, env=dict(os.environ, PYTHONPATH=REF), capture_output=True, text=True)
+                assert res.returncode == 0, res.stderr
+                rows = [r for r in open(vcf_fn).read().split("\n") if r and not r.startswith("#")] if os.path.exists(vcf_fn) else []
+                runs["qual%s_showref%d" % (0 if qual is None else qual, int(show_ref))] = dict(
+                    rows=rows, low_cov_messages=res.stdout.count("low tumor coverage"))
+        out[mode] = dict(n_out=K, predict_rows=text, likelihood_table=open(lik_fn).read(), runs=runs)
+        allrows = [r.split("\t") for v in runs.values() for r in v["rows"]]
+        print(mode, "branch rows:", {k: len(v["rows"]) for k, v in runs.items()},
+              "GT", sorted({r[9].split(":")[0] for r in allrows}), "FILTER", sorted({r[6] for r in allrows}),
+              "max len REF/ALT", max(len(r[3]) for r in allrows), max(len(r[4]) for r in allrows))
+    dump_json_gz("calls_branches.json.gz", out)
+
+
+# ------------------------------------------------------------------------------------------ 2 000-site region (SURVEY 8c)
+def _sha(text):
+    import hashlib
+    return hashlib.sha256(text.encode()).hexdigest()
+
+
+def _row_crcs(text):
+    import zlib
+    return [zlib.crc32(r.encode()) & 0xffffffff for r in text.split("\n") if r]
+
+
+REGION2K = dict(n_sites=2000, seed=20260928, start=5000, spacing=40, depth_mean=52.0, p_ins=0.01, p_del=0.012, n_rate=0.004)
+
+
+def gen_region2k(tmp):
+    """A 2 000-candidate ONT-like region with the mean depth sitting on the rescale threshold (AFF and NEG depths on both sides of
+    50, predict.py:181) through the reference's four commands.  The INPUTS are not stored: they are regenerated from REGION2K by the
+    same generator (clairs_to_amd/synth.py) and checked against the stored SHA-256; the OUTPUTS are stored as the reference wrote
+    them (probability rows, VCF rows) or, for the 2 x 5 MB of tensor text, as SHA-256 + per-row CRC-32 + depths + alt_info."""
+    kw = dict(REGION2K)
+    chunk = SynthChunk(kw.pop("n_sites"), **kw)
+    ref, ref_lo = chunk.ref_window()
+    full_ref = "A" * (ref_lo - 1) + ref
+    d = os.path.join(tmp, "r2k")
+    os.makedirs(d, exist_ok=True)
+    texts = {q: mpileup_text(chunk, min_bq=q) for q in (0, 20)}
+    open(os.path.join(d, "ref.fa"), "w").write(">chr1\n" + full_ref + "\n")
+    open(os.path.join(d, "ref.fa.fai"), "w").write("chr1\t%d\t6\t%d\t%d\n" % (len(full_ref), len(full_ref), len(full_ref) + 1))
+    open(os.path.join(d, "ref.txt"), "w").write(full_ref)
+    shim = os.path.join(d, "samtools")
+    open(shim, "w").write(SHIM)
+    os.chmod(shim, os.stat(shim).st_mode | stat.S_IEXEC)
+    bed = os.path.join(d, "cand.bed")
+    sites = chunk.site_pos.tolist()
+    open(bed, "w").write("".join("chr1\t%d\t%d\n" % (x - 17, x + 17) for x in sites))
+    env = dict(os.environ, PYTHONPATH=REF, FAKE_REF=os.path.join(d, "ref.txt"))
+    for q in (0, 20):
+        open(os.path.join(d, "mp_%d.txt" % q), "w").write(texts[q])
+        env["FAKE_MPILEUP_%d" % q] = os.path.join(d, "mp_%d.txt" % q)
+    tens = {}
+    for q, tag in ((20, "aff"), (0, "neg")):
+        out_fn = os.path.join(d, "tensor_%s.gz" % tag)
+        subprocess.check_call([sys.executable, os.path.join(REF, "clairs_to.py"), "create_tensor_pileup_calling", "--tumor_bam_fn", "fake.bam",
+                               "--ref_fn", os.path.join(d, "ref.fa"), "--ctg_name", "chr1", "--min_bq", str(q), "--samtools", shim,
+                               "--candidates_bed_regions", bed, "--tensor_can_fn", out_fn, "--platform", "ont"], cwd=d, env=env)
+        tens[tag] = gzip.open(out_fn, "rt").read()
+    fixture = dict(params=REGION2K, min_bq_aff=20, input_sha=dict(mpileup_neg=_sha(texts[0]), mpileup_aff=_sha(texts[20]), ref=_sha(ref)),
+                   tensor={})
+    for tag in ("aff", "neg"):
+        rows = [r.split("\t") for r in tens[tag].split("\n") if r]
+        fixture["tensor"][tag] = dict(sha=_sha(tens[tag]), row_crc=_row_crcs(tens[tag]), pos=[int(r[1]) for r in rows],
+                                      alt_info=[r[4] for r in rows])
+    da = np.array([int(a.split("-")[0]) for a in fixture["tensor"]["aff"]["alt_info"]])
+    dn = np.array([int(a.split("-")[0]) for a in fixture["tensor"]["neg"]["alt_info"]])
+    print("region2k: rows", len(da), "AFF depth <=50 / >50:", int((da <= 50).sum()), int((da > 50).sum()),
+          "NEG:", int((dn <= 50).sum()), int((dn > 50).sum()), "AFF<=50<NEG:", int(((da <= 50) & (dn > 50)).sum()))
+    fixture["calls"] = {}
+    for mode, n_out, aff_cls, neg_cls in (("snv", 4, "CvT", "BiGRU_NACGT"), ("indel", 6, "CvT_Indel", "BiGRU_NACGT_Indel")):
+        ma, _ = build_reference_model(aff_cls, n_out)
+        mn, _ = build_reference_model(neg_cls, n_out)
+        pa, pn = os.path.join(d, "aff_%s.pkl" % mode), os.path.join(d, "neg_%s.pkl" % mode)
+        torch.save({"model_acgt": ma}, pa)
+        torch.save({"model_nacgt": mn}, pn)
+        pred = os.path.join(d, "pred_%s.gz" % mode)
+        disable = "True" if mode == "snv" else "False"
+        subprocess.check_call([sys.executable, os.path.join(REF, "clairs_to.py"), "predict", "--tensor_fn_acgt", os.path.join(d, "tensor_aff.gz"),
+                               "--tensor_fn_nacgt", os.path.join(d, "tensor_neg.gz"), "--chkpnt_fn_acgt", pa, "--chkpnt_fn_nacgt", pn,
+                               "--predict_fn", pred, "--pileup", "--disable_indel_calling", disable, "--ctg_name", "chr1"], cwd=d, env=env)
+        table = likelihood_table(n_out, seed=7 + n_out)
+        lik_fn = os.path.join(d, "lik_%s.txt" % mode)
+        np.savetxt(lik_fn, table, fmt="%.17g")
+        vcf_fn = os.path.join(d, "out_%s.vcf" % mode)
+        subprocess.check_call([sys.executable, os.path.join(REF, "clairs_to.py"), "call_variants", "--predict_fn", pred, "--call_fn", vcf_fn,
+                               "--likelihood_matrix_data", lik_fn, "--disable_indel_calling", disable, "--ctg_name", "chr1", "--pileup",
+                               "--show_ref"], cwd=d, env=env)
+        rows = [r for r in open(vcf_fn).read().split("\n") if r and not r.startswith("#")]
+        prows = [r.split("\t") for r in gzip.open(pred, "rt").read().split("\n") if r]
+        # probability rows: positions + the 8-decimal p1 of every head (the other fields repeat the tensor rows)
+        fixture["calls"][mode] = dict(n_out=n_out, pos=[int(r[1]) for r in prows], ref=[r[2] for r in prows],
+                                      strand=[[r[4], r[5]] for r in prows],
+                                      p1=[[f.split()[1] for f in r[6:6 + 2 * n_out]] for r in prows],
+                                      likelihood_table=open(lik_fn).read(), vcf_show_ref=rows)
+        print("region2k", mode, "predict rows", len(prows), "vcf rows", len(rows),
+              "variants", sum(1 for r in rows if r.split("\t")[6] != "RefCall"))
+    dump_json_gz("region2k.json.gz", fixture)
+
+
+# ------------------------------------------------------------------------------------------ genuine checkpoint pickles
+def gen_pickles(tmp):
+    """`torch.save({'model_acgt': <clairs.model.CvT object>})` exactly as the reference's releases are written (predict.py:513-517,
+    555-568): the pickle stream names the reference's classes, attribute layout and sub-module nesting.  The parameter VALUES are
+    zeroed before saving (so the four files compress to a few KB); the test loads the pickle through the shims' aliases, fills in
+    weights_recipe values and compares with the logits of models_<cls>.npz.  Both CvT hyper-parameter sets are covered: the one
+    predict.py builds (16/64/128, heads 1/3/4, depth 1/2/3) and the constructor defaults (32/64/128, 1/3/6, 1/2/10)."""
+    import base64
+    out = {}
+    specs = [("CvT", "model_acgt", dict(model_type="acgt", apply_softmax=False)), ("CvT_Indel", "model_acgt", dict(model_type="acgt", apply_softmax=False)),
+             ("BiGRU_NACGT", "model_nacgt", dict(model_type="nacgt", apply_softmax=False)),
+             ("BiGRU_NACGT_Indel", "model_nacgt", dict(model_type="nacgt", apply_softmax=False)),
+             ("CvT:defaults", "model_acgt", dict(model_type="acgt"))]
+    for name, key, kw in specs:
+        cls = name.split(":")[0]
+        if name == "CvT:defaults":
+            m = rm.CvT(**kw)
+        elif cls.startswith("CvT"):
+            m, _ = build_reference_model(cls, 4 if cls == "CvT" else 6)
+        else:
+            m, _ = build_reference_model(cls, 4 if cls == "BiGRU_NACGT" else 6)
+        m.eval()
+        with torch.no_grad():
+            for t in list(m.parameters()) + list(m.buffers()):
+                t.zero_()
+        fn = os.path.join(tmp, "pk_%s.pkl" % name.replace(":", "_"))
+        torch.save({key: m}, fn)
+        raw = open(fn, "rb").read()
+        comp = gzip.compress(raw, mtime=0)
+        out[name] = dict(key=key, pickle_gz_b64=base64.b64encode(comp).decode(), n_params=int(sum(p.numel() for p in m.parameters())),
+                         state_keys=[k for k in m.state_dict().keys()], attrs={k: getattr(m, k) for k in ("model_type", "apply_softmax") if hasattr(m, k)})
+        print("pickle", name, len(raw), "->", len(comp), "bytes")
+    dump_json_gz("pickles.json.gz", out)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "post":
         with tempfile.TemporaryDirectory() as tmp:
             gen_post(tmp)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] in ("branches", "region2k", "pickles"):
+        with tempfile.TemporaryDirectory() as tmp:
+            {"branches": gen_branches, "region2k": gen_region2k, "pickles": gen_pickles}[sys.argv[1]](tmp)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "extract":
         with tempfile.TemporaryDirectory() as tmp:
@@ -458,6 +692,9 @@ def main():
         gen_calls(tmp, region)
         gen_extract(tmp)
         gen_post(tmp)
+        gen_branches(tmp)
+        gen_region2k(tmp)
+        gen_pickles(tmp)
 
 
 if __name__ == "__main__":
