@@ -61,6 +61,11 @@ SYMBOLS = {
     "cto_weights_free": (None, [c_vp]),
     "cto_cvt_create": (C.c_int, [c_vp, C.POINTER(CvtCfg), C.POINTER(c_vp)]),
     "cto_bigru_create": (C.c_int, [c_vp, C.c_int, C.POINTER(c_vp)]),
+    "cto_cvt_create_packed": (C.c_int, [c_vp, c_i64, C.POINTER(CvtCfg), C.POINTER(c_vp)]),
+    "cto_bigru_create_packed": (C.c_int, [c_vp, c_i64, C.c_int, C.POINTER(c_vp)]),
+    "cto_model_manifest": (c_i64, [C.c_int, C.POINTER(CvtCfg), C.c_int, c_vp, C.c_size_t]),
+    "cto_vcf_rows_batch": (c_i64, [C.c_char_p, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_double,
+                                   c_vp, C.c_size_t, c_vp]),
     "cto_model_forward": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "cto_model_macs_per_site": (c_i64, [c_vp]),
     "cto_model_n_out": (C.c_int, [c_vp]),
@@ -76,6 +81,23 @@ for _name, (_res, _args) in SYMBOLS.items():
     _fn = getattr(lib, _name)   # AttributeError here = the built library is stale; rebuild it
     _fn.restype = _res
     _fn.argtypes = _args
+
+
+# torch.ops.clairsto.* (csrc/torch_ops.cpp): the same entry points registered with PyTorch's dispatcher.  Loaded after the
+# C-ABI library, which it links against; missing = not built, and the custom ops (hence the nn.Module shims) fail loudly.
+TORCH_LIB_PATH = os.path.join(_HERE, "libclairsto_torch.so")
+if not os.path.exists(TORCH_LIB_PATH):
+    raise ImportError("clairs_to_amd: %s is missing - build it with `make -C clairs_to_amd/csrc` (torch custom ops)" % TORCH_LIB_PATH)
+torch.ops.load_library(TORCH_LIB_PATH)
+
+
+def model_manifest(kind, cfg=None, n_out=4):
+    """[(state_dict name, numel)] in packed-weights order (cto_model_manifest); kind 0 = CvT (cfg: CvtCfg), 1 = BiGRU."""
+    need = lib.cto_model_manifest(kind, C.byref(cfg) if cfg is not None else None, n_out, None, 0)
+    check(int(need))
+    buf = C.create_string_buffer(int(need))
+    check(int(lib.cto_model_manifest(kind, C.byref(cfg) if cfg is not None else None, n_out, C.addressof(buf), int(need))))
+    return [(ln.split("\t")[0], int(ln.split("\t")[1])) for ln in buf.value.decode().split("\n") if ln]
 
 
 class CtoError(RuntimeError):

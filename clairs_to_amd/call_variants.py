@@ -78,11 +78,38 @@ def parse_alt_info(alt_info):
     return d, depth
 
 
+def vcf_rows_batch(chrom, pos, centre, alt_buf, alt_off, site_info, decision, qual, n_out, show_ref=False, qual_pass=0):
+    """All VCF data rows of a chunk in ONE C call (cto_vcf_rows_batch, csrc/rows.cpp) - the same logic as vcf_row(), which is
+    kept as the readable one-site form and as the cross-check.  pos int32 [n], centre bytes [n] (raw reference characters),
+    alt_buf / alt_off as returned by featurize.alt_infos_packed, site_info int32 [n,12], decision int32 [n,4], qual float64 [n].
+    -> (text with one '\\n'-terminated row per record, dict(rows, sites, low_coverage, clamped))."""
+    n = len(pos)
+    pos = np.ascontiguousarray(pos, dtype=np.int32)
+    centre = np.ascontiguousarray(np.frombuffer(centre, dtype=np.uint8) if isinstance(centre, (bytes, bytearray)) else centre, dtype=np.uint8)
+    site_info = np.ascontiguousarray(site_info, dtype=np.int32)
+    decision = np.ascontiguousarray(decision, dtype=np.int32)
+    qual = np.ascontiguousarray(qual, dtype=np.float64)
+    alt_off = np.ascontiguousarray(alt_off, dtype=np.int64)
+    assert len(centre) == n and site_info.shape == (n, 12) and decision.shape == (n, 4) and len(qual) == n and len(alt_off) == n + 1
+    alt_keep = alt_buf if isinstance(alt_buf, (bytes, bytearray)) else bytes(alt_buf)
+    alt_arr = np.frombuffer(alt_keep, dtype=np.uint8) if len(alt_keep) else np.zeros(1, dtype=np.uint8)
+    cap = 512 * max(n, 1) + 2 * len(alt_keep) + 4096
+    counts = np.zeros(4, dtype=np.int64)
+    buf = C.create_string_buffer(cap)
+    used = lib.cto_vcf_rows_batch(chrom.encode(), n, pos.ctypes.data, centre.ctypes.data, alt_arr.ctypes.data, alt_off.ctypes.data,
+                                  site_info.ctypes.data, decision.ctypes.data, qual.ctypes.data, int(n_out), int(bool(show_ref)),
+                                  -1.0 if qual_pass is None else float(qual_pass), C.addressof(buf), cap, counts.ctypes.data)
+    check(int(used))
+    return buf.raw[:used].decode(), dict(rows=int(counts[0]), sites=int(counts[1]), low_coverage=int(counts[2]), clamped=int(counts[3]))
+
+
 def vcf_row(chrom, pos, ref_base, alt_info, fwd, rev, argmax, qual, n_out, show_ref=False, qual_pass=0,
             messages=None):
     """One VCF data row (without newline) or None when the reference writes nothing for the site.
     fwd/rev: the four strand counts (predict.py:626-642); argmax/qual: device epilogue outputs."""
     snv_mode = n_out == 4
+    if qual != qual:      # NaN: 0/0 posterior of a site the reference raises IndexError on (decision flag bit 1); no row
+        return None
     d, depth = parse_alt_info(alt_info)
     ref, alt = ref_base, ref_base
     if snv_mode:

@@ -33,6 +33,20 @@ __device__ inline int digitize(double x, const double* edges) {   // np.digitize
     return c - 1;
 }
 
+// Python's round(q, 4) (call_variants.py:88): the EXACT binary value of q rounded to 4 decimals, ties to even, then the
+// double nearest to that decimal.  rint(q * 1e4) alone rounds the already-rounded product and can land on the other side of
+// a ...5 boundary; the product's rounding error is recovered exactly with one fma (q * 1e4 = hi + lo as real numbers).
+__device__ __forceinline__ double round4(double q) {
+    if (!(q == q)) return q;
+    const double hi = q * 1e4, lo = fma(q, 1e4, -hi);
+    double r = rint(hi);
+    const double d = (hi - r) + lo;                 // exact: |hi - r| <= 0.5 and lo is tiny
+    const bool odd = fmod(r, 2.0) != 0.0;
+    if (d > 0.5 || (d == 0.5 && odd)) r += 1.0;
+    else if (d < -0.5 || (d == -0.5 && odd)) r -= 1.0;
+    return r / 1e4;
+}
+
 template <bool FROM_PROBS>
 __global__ __launch_bounds__(256) void k_posterior(const float* __restrict__ aff, const float* __restrict__ neg,
                                                    const double* __restrict__ p1, int K,
@@ -74,16 +88,20 @@ __global__ __launch_bounds__(256) void k_posterior(const float* __restrict__ aff
         const double num = pa * (1 - pn) * w;
         const double v = num / (num + ((1 - pa) * pn * (1 - w)));
         post[b * K + k] = v;
-        if (k == 0 || v > bestv) { bestv = v; best = k; }
+        // np.argmax (call_variants.py:213 / 292): first maximum, and a NaN (0/0: both heads saturated at 0.00000000) beats
+        // every number - the first NaN wins
+        if (k == 0 || (!(bestv != bestv) && (v > bestv || v != v))) { bestv = v; best = k; }
     }
     decision[b * 4 + 0] = best;
-    decision[b * 4 + 1] = clamped;
+    // bit 0: a bin index was clamped (the reference raises IndexError on this site); bit 1: the winning posterior is NaN
+    // (only possible together with bit 0) - the host must not format a row from it
+    decision[b * 4 + 1] = clamped | ((bestv != bestv) ? 2 : 0);
     decision[b * 4 + 2] = 0;
     decision[b * 4 + 3] = 0;
     const double phred = -10.0 * (1.0 / 2.302585092994046);   // -10 * log(e, 10)
     double q = phred * log(((1.0 - bestv) + 1e-10) / (bestv + 1e-10)) + 2.0;
     q = q > 0.0 ? q : 0.0;
-    qual[b] = rint(q * 1e4) / 1e4;
+    qual[b] = round4(q);
 }
 
 __global__ __launch_bounds__(256) void k_softmax_probs(const float* __restrict__ aff, const float* __restrict__ neg, int K,

@@ -56,9 +56,27 @@ def featurize(dev_pack, site_pos, min_bq, min_rescale_cov=50, want_raw=False, wa
     return Features(x_aff, x_neg, raw_aff, raw_neg, site_info, colvec[:nc], coldepth[:nc], sitefirst[:n], keycnt[:nk], keyfirst[:nk])
 
 
+def featurize_op(dev_pack, site_pos, min_bq, min_rescale_cov=50):
+    """The same through PyTorch's dispatcher: torch.ops.clairsto.pileup_featurize (csrc/torch_ops.cpp) on the pack's device
+    tensors.  Network inputs only (no raw int16 tensors); returns the same Features record as featurize()."""
+    t = dev_pack.t
+    site_pos = site_pos.to(device=dev_pack.device, dtype=torch.int32).contiguous()
+    x_aff, x_neg, site_info, colvec, coldepth, keycnt, sitefirst, keyfirst = torch.ops.clairsto.pileup_featurize(
+        t["entries"], t["col_off"], t["col_pos"], t["col_ref"], t["key_off"], t["key_meta"], t["key_group"], site_pos, int(min_bq),
+        int(min_rescale_cov) if min_rescale_cov else 0)
+    return Features(x_aff, x_neg, None, None, site_info, colvec, coldepth, sitefirst, keycnt, keyfirst)
+
+
 def alt_infos(feat, host_pack, site_info_host=None, pass_idx=0):
     """The reference's alt_info strings of pass `pass_idx` (0 = AFF, 1 = NEG) for every site with a centre column
     (create_tensor_pileup_calling.py:158-209); '' for sites without one.  Host work on device results."""
+    raw, offsets = alt_infos_packed(feat, host_pack, site_info_host, pass_idx)
+    return [raw[offsets[i]:offsets[i + 1]].decode() for i in range(len(offsets) - 1)]
+
+
+def alt_infos_packed(feat, host_pack, site_info_host=None, pass_idx=0):
+    """alt_infos() without the per-site Python strings: (bytes with the strings back to back, int64 offsets [n + 1]) - the form
+    cto_vcf_rows_batch consumes."""
     info = feat.site_info.cpu().numpy() if site_info_host is None else site_info_host
     colvec = feat.colvec.cpu().numpy()
     sitefirst = np.ascontiguousarray(feat.sitefirst.cpu().numpy())
@@ -70,7 +88,7 @@ def alt_infos(feat, host_pack, site_info_host=None, pass_idx=0):
     info = np.ascontiguousarray(info, dtype=np.int32)
     n = info.shape[0]
     if n == 0:
-        return []
+        return b"", np.zeros(1, dtype=np.int64)
     colvec = np.ascontiguousarray(colvec)
     cap = 256 * n + (1 << 16)
     offsets = np.zeros(n + 1, dtype=np.int64)
@@ -83,5 +101,4 @@ def alt_infos(feat, host_pack, site_info_host=None, pass_idx=0):
         if "buffer too small" not in lib.cto_last_error().decode():
             check(int(used))
         cap *= 4
-    raw = buf.raw
-    return [raw[offsets[i]:offsets[i + 1]].decode() for i in range(n)]
+    return buf.raw[:int(used)], offsets

@@ -117,6 +117,7 @@ class _HipNet(nn.Module):
     def __getstate__(self):
         d = dict(self.__dict__)
         d.pop("_cto_state", None)     # the device handle never travels in a pickle
+        d.pop("_cto_packed", None)    # ... nor does the packed copy of the weights
         return d
 
     def logits(self, x):
@@ -127,12 +128,23 @@ class _HipNet(nn.Module):
         if x.dim() != 3 or x.shape[1] != NPOS or x.shape[2] != NCHAN:
             raise ValueError("expected [B,%d,%d], got %s" % (NPOS, NCHAN, tuple(x.shape)))
         x = x.to(torch.float32).contiguous()
-        out = torch.empty((len(self._heads_out), x.shape[0], 2), dtype=torch.float32, device=x.device)
-        if x.shape[0] == 0:
-            return out
-        with torch.cuda.device(x.device):
-            check(lib.cto_model_forward(self._handle(), x.data_ptr(), x.shape[0], out.data_ptr(), current_stream_ptr()))
-        return out
+        # through PyTorch's dispatcher (csrc/torch_ops.cpp): the operator keeps a device-side handle per packed-weights tensor
+        if self._kind == "cvt":
+            cfg = self._cfg()
+            return torch.ops.clairsto.cvt_forward(x, self._packed(x.device), list(cfg.emb_dim) + list(cfg.heads) + list(cfg.depth) + [cfg.n_out])
+        return torch.ops.clairsto.bigru_forward(x, self._packed(x.device), len(self._heads_out))
+
+    def _packed(self, device):
+        """The `packed_weights` operand of the custom ops: every floating-point tensor of state_dict() flattened and
+        concatenated in state_dict order (cto_cvt_create_packed / cto_model_manifest), resident on `device`; rebuilt when a
+        parameter changes."""
+        ver = (self._weights_version(), str(device))
+        st = self.__dict__.get("_cto_packed")
+        if st is None or st[0] != ver:
+            flat = torch.cat([v.detach().reshape(-1).to("cpu", torch.float32) for v in self.state_dict().values() if v.is_floating_point()])
+            st = (ver, flat.to(device))
+            self.__dict__["_cto_packed"] = st
+        return st[1]
 
     def macs_per_site(self):
         return int(lib.cto_model_macs_per_site(self._handle()))

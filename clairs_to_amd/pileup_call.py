@@ -19,11 +19,11 @@ from argparse import ArgumentParser
 import numpy as np
 import torch
 
-from .call_variants import IUPAC_TO_ACGT, VCF_HEADER, load_likelihood, vcf_row
+from .call_variants import IUPAC_TO_ACGT, VCF_HEADER, load_likelihood, vcf_rows_batch
 from .create_tensor_pileup_calling import EXPAND_REF, MAX_INDEL, load_pack, read_candidates
 from .engine import Engine
 from .fasta import read_region
-from .featurize import alt_infos
+from .featurize import alt_infos_packed
 from .predict import load_models, str2bool
 from .platforms import resolve_platform
 
@@ -71,37 +71,38 @@ def pileup_call(args, device="cuda", engine=None, prepared=None):
     torch.cuda.synchronize()
     feat = res["features"]
     info = feat.site_info.cpu().numpy()
-    alts = alt_infos(feat, pack, info)
+    alt_buf, alt_off = alt_infos_packed(feat, pack, info)
     dec, qual = res["decision"].cpu().numpy(), res["qual"].cpu().numpy()
-    probs = res["probs"].cpu().numpy() if args.predict_fn else None
-    n_rows = n_sites = 0
-    pred = gzip.open(args.predict_fn, "wt") if args.predict_fn else None
+    sites_arr = np.asarray(sites, dtype=np.int64)
+    centre = np.frombuffer(ref.encode("latin-1"), dtype=np.uint8)[sites_arr - ref_start]
+    info = info.copy()
+    info[~np.isin(centre, np.frombuffer(b"ACGT", dtype=np.uint8)), 3] |= 1      # predict.py:219-228: centre not in ACGT -> no row
+    # every record of the chunk in one C call (cto_vcf_rows_batch): the per-site Python formatting was a third of a chunk
+    text, cnt = vcf_rows_batch(args.ctg_name, sites_arr, centre, alt_buf, alt_off, info, dec, qual, K, show_ref=args.show_ref,
+                               qual_pass=args.qual)
+    n_rows, n_sites = cnt["rows"], cnt["sites"]
+    for _ in range(cnt["low_coverage"]):
+        print("low tumor coverage")                                  # call_variants.py:328, one line per such site
+    if cnt["clamped"]:
+        for i in np.nonzero(dec[:, 1])[0]:
+            print("[WARNING] %s:%d a probability printed as 1.00000000 / 0.00000000 falls outside the likelihood bins (the "
+                  "reference raises IndexError here); %s" % (args.ctg_name, sites[i], "no posterior, site skipped" if dec[i, 1] & 2
+                                                             else "bin clamped"), file=sys.stderr)
     os.makedirs(os.path.dirname(os.path.abspath(args.call_fn)), exist_ok=True)
     with open(args.call_fn, "w") as out:
         out.write(VCF_HEADER + "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n" % args.sample_name)
-        for i, pos in enumerate(sites):
-            if info[i, 3] & 1:
-                continue
-            centre = ref[pos - ref_start]
-            if centre not in "ACGT":
-                continue
-            n_sites += 1
-            ref_base = IUPAC_TO_ACGT[centre.upper()]
-            fwd, rev = [float(v) for v in info[i, 4:8]], [float(v) for v in info[i, 8:12]]
-            if pred is not None:
-                fields = [args.ctg_name, str(pos), ref_base, alts[i], str(fwd), str(rev)]
+        out.write(text)
+    if args.predict_fn:        # debugging tap: the probability rows of the predict mirror
+        probs = res["probs"].cpu().numpy()
+        with gzip.open(args.predict_fn, "wt") as pred:
+            for i, pos in enumerate(sites):
+                c = chr(centre[i])
+                if (info[i, 3] & 1) or c not in "ACGT":
+                    continue
+                fwd, rev = [float(v) for v in info[i, 4:8]], [float(v) for v in info[i, 8:12]]
+                fields = [args.ctg_name, str(pos), IUPAC_TO_ACGT[c], alt_buf[alt_off[i]:alt_off[i + 1]].decode(), str(fwd), str(rev)]
                 fields += [" ".join("{:0.8f}".format(x) for x in probs[i, k]) for k in range(2 * K)]
                 pred.write("\t".join(fields) + ("\t\n" if K == 4 else "\n"))
-            if dec[i, 1]:
-                print("[WARNING] %s:%d probability 1.00000000 falls outside the likelihood bins (the reference raises "
-                      "IndexError here); clamped" % (args.ctg_name, pos), file=sys.stderr)
-            line = vcf_row(args.ctg_name, str(pos), ref_base, alts[i], fwd, rev, int(dec[i, 0]), float(qual[i]), K,
-                           show_ref=args.show_ref, qual_pass=args.qual)
-            if line is not None:
-                out.write(line + "\n")
-                n_rows += 1
-    if pred is not None:
-        pred.close()
     if n_rows == 0:
         os.remove(args.call_fn)            # the reference removes VCFs without records (call_variants.py:859-867)
     print("[INFO] {} total processed positions: {}".format(args.ctg_name, n_sites), file=sys.stderr)

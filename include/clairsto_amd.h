@@ -188,6 +188,17 @@ typedef struct cto_cvt_cfg {
 int cto_cvt_create(const cto_weights* w, const cto_cvt_cfg* cfg, cto_model** out);
 /* clairs.model.BiGRU_NACGT / BiGRU_NACGT_Indel (clairs/model.py:387-560); n_out = 4 or 6. */
 int cto_bigru_create(const cto_weights* w, int n_out, cto_model** out);
+/* One-blob hand-over: `packed` host fp32 = every tensor of the module's state_dict() concatenated in state_dict order
+ * (clairs/model.py:150-560 as `torch.save`d at clairs/predict.py:513-517; the integer `num_batches_tracked` entries are left
+ * out) - `torch.cat([v.flatten() for v in model.state_dict().values() if v.is_floating_point()])`.  This is the
+ * `packed_weights` argument of the torch custom ops clairsto::cvt_forward / clairsto::bigru_forward.
+ * CTO_EMISSING when numel does not match the manifest. */
+int cto_cvt_create_packed(const float* packed, int64_t numel, const cto_cvt_cfg* cfg, cto_model** out);
+int cto_bigru_create_packed(const float* packed, int64_t numel, int n_out, cto_model** out);
+/* The manifest the packed creators walk: one "name<TAB>numel<NL>" line per tensor, kind 0 = CvT (cfg, its n_out) or
+ * 1 = BiGRU (n_out; cfg ignored).  Returns the bytes needed including the terminating NUL (the text is written only when
+ * cap is large enough), or a negative error code. */
+int64_t cto_model_manifest(int kind, const cto_cvt_cfg* cfg, int n_out, char* buf, size_t cap);
 /* x dev [B][33][34] float -> logits dev [n_out][B][2] float (post-SELU, pre-softmax), exactly the tuple
  * `model(x)` returns at clairs/predict.py:646-658. */
 int cto_model_forward(cto_model* m, const float* x, int64_t B, float* logits, void* stream);
@@ -212,7 +223,10 @@ int cto_model_profile_read(cto_model* m, double* mean_ms, int64_t* macs_per_site
  *   edges dev [2K][11]   double    bin edges with 0 prepended and 1 appended, order a,na,c,nc,...
  *   probs dev [B][2K][2] float     softmax outputs, order a c g t [i d] na nc ng nt [ni nd]; may be NULL
  *   post  dev [B][K] double        posterior per base
- *   decision dev [B][4] int32      {argmax, clamped flag (an index 10 the reference would crash on), 0, 0}
+ *   decision dev [B][4] int32      {argmax (np.argmax: first maximum, a NaN first), flags, 0, 0}; flags bit 0 = a bin index
+ *                                  was clamped (the reference raises IndexError there: a probability printed as 1.00000000
+ *                                  or 0.00000000), bit 1 = the winning posterior is NaN (0/0; only together with bit 0):
+ *                                  no row can be formatted for that site
  *   qual  dev [B] double           quality_score_from(max posterior), rounded to 4 dp
  * ---------------------------------------------------------------------------------------------- */
 int cto_posterior(const float* aff_logits, const float* neg_logits, int K, int64_t B,
@@ -228,6 +242,21 @@ int cto_softmax_probs(const float* aff_logits, const float* neg_logits, int K, i
  * order a c g t [i d] na nc ng nt [ni nd], already rounded to 8 decimals by the producer. */
 int cto_posterior_from_probs(const double* p1, int K, int64_t B, const double* lik, const double* edges,
                              double* post, int32_t* decision, double* qual, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * VCF data rows of a whole chunk in one call: the string work left after the device epilogue -
+ * clairs/call_variants.py:135-150 (alt_info), 306-365 (allele ranking, ALT / REF), 367-380 (drop rules),
+ * 401-415 (AF, GT), 67-76 (FILTER), 588-618 (INFO / FORMAT) and VcfWriter.write_row (shared/vcf.py:144-185).
+ *   pos[n] 1-based; centre[n] reference base of each row (clairs/predict.py:415);
+ *   alt_buf + alt_off[n+1]: AFF alt_info strings as cto_alt_info_batch packs them; site_info[n][12] from cto_gather_windows
+ *   ([3] bit 0 = skip: site without a tensor, or dropped by the caller because its raw centre is not in "ACGT",
+ *   clairs/predict.py:219-228; [4..12) strand counts); decision[n][4] / qual[n] from cto_posterior;
+ *   K = 4 (SNV mode) or 6 (indel mode); show_ref = --show_ref; qual_pass = --qual (< 0: no threshold).
+ *   counts[4] out: rows written, sites processed, "low tumor coverage" events (call_variants.py:327-329), sites flagged clamped.
+ * Rows are '\n'-terminated in buf.  Returns the bytes used, CTO_ENOMEM when cap is too small, CTO_EINVAL on malformed input. */
+int64_t cto_vcf_rows_batch(const char* chrom, int64_t n, const int32_t* pos, const char* centre, const char* alt_buf,
+                           const int64_t* alt_off, const int32_t* site_info, const int32_t* decision, const double* qual,
+                           int K, int show_ref, double qual_pass, char* buf, size_t cap, int64_t* counts);
 
 #ifdef __cplusplus
 }
