@@ -24,6 +24,12 @@ if ROOT not in sys.path:
 BATCH = 4096
 N_OUT = 4
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+# The genuine reference cannot travel to the GPU box; tools/time_reference.py times it in the build container (8 vCPU) on the
+# same generator and writes profiles/reference_cpu_timing.json.  Quoted, not measured here.
+REFERENCE_PYTHON_NOTE = ("HKU-BAL/ClairS-TO v0.4.4 itself, build container (8 vCPU), configs[1] generator, 10 000-site chunks through its four "
+                         "commands per chunk (create_tensor x2, predict, call_variants; samtools decode excluded, CPython, torch 1 thread per "
+                         "process): 211 sites/s with 1 process, 1 297 sites/s with 8 processes (tools/time_reference.py -> "
+                         "profiles/reference_cpu_timing.json)")
 
 
 def pmc_traffic(batch):
@@ -77,15 +83,26 @@ def cpu_baseline(chunks, models, lik, edges, min_bq, n_sample, budget_s=12.0):
     cores = usable_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)
     cfg = dict(emb_dim=(16, 64, 128), heads=(1, 3, 4), depth=(1, 2, 3), n_out=N_OUT)
+    from concurrent.futures import ThreadPoolExecutor
     total_sites, total_t, first_probs = 0, 0.0, None
     for chunk in chunks:
         sites = chunk.site_pos[:n_sample]
-        last_col = int(np.searchsorted(chunk.col_pos, int(sites[-1]) + 17, side="right"))
         ref, lo = chunk.ref_window()
-        texts = {q: oracle.synth_mpileup_text(chunk, q, (0, last_col)) for q in (min_bq, 0)}      # untimed input prep
+        # tensor creation is per-site independent too: the sample is cut into one slice of sites per core, each with the
+        # mpileup rows of its own windows (untimed input prep), and the slices run on a thread pool (the C calls drop the GIL)
+        cuts = np.linspace(0, len(sites), min(cores, len(sites)) + 1).astype(int)
+        slices = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if b > a:
+                c0 = int(np.searchsorted(chunk.col_pos, int(sites[a]) - 16, side="left"))
+                c1 = int(np.searchsorted(chunk.col_pos, int(sites[b - 1]) + 17, side="right"))
+                slices.append((sites[a:b], {q: oracle.synth_mpileup_text(chunk, q, (c0, c1)) for q in (min_bq, 0)}))
         t0 = time.perf_counter()
-        ta, da, _, _ = oracle.create_tensor(texts[min_bq], ref, lo, sites)
-        tn, dn, _, _ = oracle.create_tensor(texts[0], ref, lo, sites)
+        with ThreadPoolExecutor(max_workers=cores) as ex:
+            parts = list(ex.map(lambda s: (oracle.create_tensor(s[1][min_bq], ref, lo, s[0])[:2], oracle.create_tensor(s[1][0], ref, lo, s[0])[:2]),
+                                slices))
+        ta, da = np.concatenate([p[0][0] for p in parts]), np.concatenate([p[0][1] for p in parts])
+        tn, dn = np.concatenate([p[1][0] for p in parts]), np.concatenate([p[1][1] for p in parts])
         xa, xn = oracle.rescale(ta, da), oracle.rescale(tn, dn)
         la = oracle.cvt_forward(models["aff_weights"], cfg, xa)
         ln = oracle.bigru_forward(models["neg_weights"], N_OUT, xn)
@@ -98,8 +115,8 @@ def cpu_baseline(chunks, models, lik, edges, min_bq, n_sample, budget_s=12.0):
             break
     return dict(value=round(total_sites / total_t, 2), unit="sites/s", cores=cores, kind="port",
                 sample="%d sites of the same synthetic chunks (mpileup text of both passes -> tensors -> CvT + BiGRU -> "
-                       "posterior), CPU oracle oracle/cto_oracle.c, OpenMP over sites for the networks (tensor creation "
-                       "serial), %.1f s" % (total_sites, total_t)), first_probs
+                       "posterior), CPU oracle oracle/cto_oracle.c on every usable core: tensor creation in per-core site slices, "
+                       "OpenMP over sites for the networks, %.1f s" % (total_sites, total_t)), first_probs
 
 
 def self_launch(n):
@@ -122,10 +139,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pool", type=int, default=4, help="distinct synthetic chunks resident in HBM per rank")
+    ap.add_argument("--pool", type=int, default=16,
+                    help="distinct synthetic chunks resident in HBM per rank (16 x 28.6 MB of packs = 458 MB: more than the 256 MB "
+                         "Infinity Cache, so the tensor-creation stage really reads HBM)")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=4096)
+    ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file legs (mpileup text -> VCF, BAM -> VCF)")
+    ap.add_argument("--e2e-chunks", type=int, default=12, help="chunk files of the mpileup-text leg (the BAM leg uses a third)")
     args = ap.parse_args()
 
     import numpy as np
@@ -292,6 +313,16 @@ def main():
             res["cpu_baseline"] = cb
             got = eng.run_device(packs[0], sites[0])["probs"][: probs_cpu.shape[0]].cpu().numpy()
             res["parity_max_abs_dP_vs_cpu_sample"] = float(np.abs(got - probs_cpu).max())
+        if world == 1 and not args.no_e2e:
+            # ---- file-to-file legs (never `value`): chunk files + pileup source on disk -> p_<chunk>.vcf through the call_chunks
+            # pipeline, everything a real run pays included; the rate is set by the host (cores stated), not by the GPU ----
+            from clairs_to_amd.call_chunks import usable_cores as host_cores
+            from clairs_to_amd.e2e import measure
+            e2e = {"host_cores_usable": host_cores(), "host_cores_visible": os.cpu_count(),
+                   "cpu_reference_python": REFERENCE_PYTHON_NOTE}
+            e2e["mpileup_text_to_vcf"] = measure(eng, kind="text", n_chunks=args.e2e_chunks, sites_per_chunk=args.batch)
+            e2e["bam_to_vcf"] = measure(eng, kind="bam", n_chunks=max(2, args.e2e_chunks // 3), sites_per_chunk=args.batch)
+            res["e2e"] = e2e
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -5,17 +5,30 @@ listed in CANDIDATES_FILES) to GNU parallel, four commands per chunk (run_clairs
 (`python -m torch.distributed.run --nproc-per-node N -m clairs_to_amd call_chunks ...`, or a single process) takes a
 contiguous share of the chunk list (dist.shard_range: neighbouring chunks stay on one GPU), keeps one Engine alive - the
 checkpoints are read once - and writes `p_<chunk>.vcf` per chunk exactly as `pileup_call` does; there is no data-path
-collective (sites are independent), only a barrier before rank 0 merges the chunk VCFs (`sort_vcf`) and optionally applies
-`postprocess_vcf`.
+collective (sites are independent), only a status exchange before rank 0 merges the chunk VCFs (`sort_vcf`) and optionally
+applies `postprocess_vcf`.
+
+Inside a rank the chunks flow through a three-stage pipeline, several chunks in flight:
+    producers (thread pool)   BED + reference slice + column pack (BAM decoding / samtools + tokenising; C code, GIL released)
+                              and the pack's upload on a copy stream                                   pileup_call.prepare_chunk
+    launcher (this thread)    wait for the upload event, 12 kernel launches, asynchronous copies of the per-site outputs into
+                              re-used page-locked buffers                                               pileup_call.launch_chunk
+    writers (thread pool)     alt_info strings + every VCF record in two C calls, file write            pileup_call.finish_chunk
+The GPU needs ~2 ms per 4 096-site chunk; one producer delivers a chunk in 7 ms (mpileup text) to 27 ms (BAM), so the rate is
+set by how many producers the host can run - `--producers` (default: a quarter of the usable cores, at most 16).
 """
 import os
 import sys
+import threading
 from argparse import ArgumentParser, Namespace
+from collections import deque
+from concurrent.futures import ThreadPoolExecutor
 
 import torch
 
 from .dist import shard_range
-from .pileup_call import add_common_arguments, make_engine, pileup_call
+from .pileup_call import add_common_arguments, finish_chunk, launch_chunk, make_engine, prepare_chunk
+from .platforms import resolve_platform
 from .postprocess_vcf import postprocess_vcf, sort_vcf
 
 
@@ -30,15 +43,79 @@ def chunk_contig(bed_fn):
     return None
 
 
+def usable_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def run_pipeline(eng, chunk_args, producers=4, writers=2, depth=None, stats=None):
+    """chunk_args: Namespaces as pileup_call takes them, in order.  Returns the number of VCF records written.
+    `depth` bounds the chunks prepared ahead of the launcher (packs live in host + device memory while they wait)."""
+    device = eng.device
+    depth = depth if depth is not None else producers + 2
+    n_rows = 0
+    local = threading.local()
+
+    def produce(a):
+        if getattr(local, "stream", None) is None:
+            local.stream = torch.cuda.Stream(device)            # one copy stream per producer thread
+        return prepare_chunk(a, device=device, copy_stream=local.stream)
+
+    free_pinned = deque()                                        # page-locked buffer sets, re-used chunk after chunk
+
+    def finish(a, prep, launched):
+        try:
+            return finish_chunk(a, eng.K, prep, launched)
+        finally:
+            free_pinned.append(launched["pinned"])
+
+    with ThreadPoolExecutor(max_workers=producers) as prod, ThreadPoolExecutor(max_workers=writers) as wr:
+        pending, writing = deque(), deque()
+        it = iter(chunk_args)
+
+        def feed():
+            while len(pending) < depth:
+                a = next(it, None)
+                if a is None:
+                    return
+                pending.append((a, prod.submit(produce, a)))
+        feed()
+        while pending:
+            a, fut = pending.popleft()
+            prep = fut.result()
+            feed()
+            if prep is None:
+                print("[INFO] {} total processed positions: 0".format(a.ctg_name), file=sys.stderr)
+                continue
+            launched = launch_chunk(eng, prep, want_probs=bool(getattr(a, "predict_fn", None)),
+                                    pinned=free_pinned.popleft() if free_pinned else None)
+            writing.append(wr.submit(finish, a, prep, launched))
+            if stats is not None:
+                stats["sites"] = stats.get("sites", 0) + len(prep["sites"])
+            while len(writing) > writers + 1:                    # bound the results waiting for a writer
+                n_rows += writing.popleft().result()
+        while writing:
+            n_rows += writing.popleft().result()
+    return n_rows
+
+
 def call_chunks(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # the control plane only needs a barrier: gloo keeps the GPUs' streams out of it
-        dist.init_process_group("gloo")
+        # the control plane only exchanges a status word: gloo keeps the GPUs' streams out of it; the timeout covers shards that
+        # are legitimately hours out of balance (a failed rank reports through the status exchange below, not by timing out)
+        dist.init_process_group("gloo", timeout=datetime.timedelta(hours=24))
     if not torch.cuda.is_available():
         sys.exit("[ERROR] clairs_to_amd call_chunks needs a HIP device; there is no CPU fallback")
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
@@ -46,42 +123,54 @@ def call_chunks(args):
     chunks = [r.strip() for r in open(args.chunk_list) if r.strip()]
     lo, hi = shard_range(len(chunks), world, rank)
     os.makedirs(args.output_dir, exist_ok=True)
-    eng = make_engine(args, device)
-    n_rows = 0
+    n_rows, failure = 0, None
 
     def chunk_args(bed):
         ctg = chunk_contig(bed)
         if ctg is None:
             return None
         a = Namespace(**vars(args))
-        a.candidates_bed_regions, a.ctg_name, a.mpileup_fn, a.predict_fn = bed, ctg, None, None
+        a.candidates_bed_regions, a.ctg_name, a.predict_fn = bed, ctg, None
+        mp_dir = getattr(args, "mpileup_dir", None)
+        a.mpileup_fn = os.path.join(mp_dir, os.path.basename(bed) + ".mpileup") if mp_dir else None
         a.call_fn = os.path.join(args.output_dir, "p_%s.vcf" % os.path.basename(bed))
         return a
-    # two-stage pipeline: the pack of the next chunk is produced on a host thread (BAM decoding / samtools + tokenising run
-    # outside the GIL) while the current chunk is on the GPU and its VCF rows are written
-    from concurrent.futures import ThreadPoolExecutor
-    from .pileup_call import prepare_chunk
-    mine = [a for a in (chunk_args(b) for b in chunks[lo:hi]) if a is not None]
-    with ThreadPoolExecutor(max_workers=1) as pool:
-        nxt = pool.submit(prepare_chunk, mine[0]) if mine else None
-        for i, a in enumerate(mine):
-            prep = nxt.result()
-            nxt = pool.submit(prepare_chunk, mine[i + 1]) if i + 1 < len(mine) else None
-            n_rows += pileup_call(a, engine=eng, prepared=prep) if prep is not None else 0
+    try:
+        eng = make_engine(args, device)
+        mine = [a for a in (chunk_args(b) for b in chunks[lo:hi]) if a is not None]
+        for a in mine:                       # a chunk VCF left by an earlier run must not survive into this run's merge
+            if os.path.exists(a.call_fn):
+                os.remove(a.call_fn)
+        producers = args.producers if getattr(args, "producers", None) else max(1, min(16, usable_cores() // 4))
+        n_rows = run_pipeline(eng, mine, producers=producers, writers=getattr(args, "writers", None) or 2)
+    except (Exception, SystemExit) as e:     # a bad reference, a corrupt BAM, CTO_EUNSUPPORTED ...: report, do not leave the others waiting
+        failure = "%s: %s" % (type(e).__name__, e)
+        print("[ERROR] rank %d/%d failed: %s" % (rank, world, failure), file=sys.stderr)
     print("[INFO] rank %d/%d: chunks %d..%d, %d VCF records" % (rank, world, lo, hi, n_rows), file=sys.stderr)
     if world > 1:
         import torch.distributed as dist
-        dist.barrier()
+        status = [None] * world
+        dist.all_gather_object(status, failure)       # doubles as the barrier before the merge
+        failed = [(r, s) for r, s in enumerate(status) if s]
+    else:
+        failed = [(0, failure)] if failure else []
+    if failed:
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        sys.exit("[ERROR] call_chunks: %s" % "; ".join("rank %d: %s" % f for f in failed))
     if rank == 0 and args.merged_vcf_fn:
         contigs = []
         for bed in chunks:
             c = chunk_contig(bed)
             if c is not None and c not in contigs:
                 contigs.append(c)
-        n = sort_vcf(args.output_dir, args.merged_vcf_fn, contigs, vcf_fn_prefix="p_", ref_fn=args.ref_fn, sample_name=args.sample_name)
+        # merge exactly the chunk VCFs of THIS chunk list (a stale p_*.vcf of another run in the same directory stays out)
+        names = ["p_%s.vcf" % os.path.basename(b) for b in chunks]
+        n = sort_vcf(args.output_dir, args.merged_vcf_fn, contigs, vcf_fn_prefix="p_", ref_fn=args.ref_fn, sample_name=args.sample_name,
+                     only_files=names)
         print("[INFO] merged %d records into %s" % (n, args.merged_vcf_fn), file=sys.stderr)
         if args.final_vcf_fn:
-            from .platforms import resolve_platform
             postprocess_vcf(args.merged_vcf_fn, args.final_vcf_fn, platform=resolve_platform(args.platform)[1],
                             ref_fn=args.ref_fn, sample_name=args.sample_name)
     if world > 1:
@@ -98,6 +187,10 @@ def main():
     p.add_argument("--output_dir", type=str, required=True, help="directory for the p_<chunk>.vcf files")
     p.add_argument("--merged_vcf_fn", type=str, default=None, help="rank 0: sort_vcf of all chunk VCFs")
     p.add_argument("--final_vcf_fn", type=str, default=None, help="rank 0: postprocess_vcf of the merged VCF")
+    p.add_argument("--mpileup_dir", type=str, default=None,
+                   help="read <dir>/<chunk file name>.mpileup (samtools mpileup --min-BQ 0 text of the chunk) instead of the BAM")
+    p.add_argument("--producers", type=int, default=None, help="pack-producer threads per rank (default: usable cores / 4, <= 16)")
+    p.add_argument("--writers", type=int, default=None, help="VCF-writer threads per rank (default 2)")
     call_chunks(p.parse_args())
 
 

@@ -100,7 +100,7 @@ def create_tensor(args, device="cuda"):
                 if info[i, 3] & 1:
                     continue
                 o = pos - ref_start
-                ref_seq = ref[o - FLANK: o + FLANK + 1]
+                ref_seq = ref[max(0, o - FLANK): o + FLANK + 1]      # rows with pos - 16 < 1 never get here (flag bit 0)
                 out.write("%s\t%d\t%s\t%s\t%s\t%s\t%s\n" % (
                     args.ctg_name, pos, ref_seq, " ".join("%d" % v for v in raw[i].ravel()), alts[i], centres[pos],
                     ref_seq[FLANK]))

@@ -1,0 +1,73 @@
+"""File-to-file throughput of the hot path: candidate chunk files + pileup source (mpileup text or BAM) -> p_<chunk>.vcf,
+through the same pipeline `call_chunks` runs (producers -> launcher -> writers, call_chunks.run_pipeline), with a resident
+Engine.  Everything a real run pays is inside the timed region: reading the BED / FASTA / text or BAM from disk, tokenising or
+BAM decoding, the pack upload over PCIe, the 12 kernels, the device-to-host copies, the alt_info strings, the VCF rows and the
+file writes.  Used by bench.py (`e2e` object of its JSON line; never its `value`) and tools/e2e_bench.py."""
+import os
+import shutil
+import tempfile
+import time
+from argparse import Namespace
+
+
+def chunk_namespaces(run, out_dir, bam=False):
+    """one pileup_call Namespace per chunk file of a synthetic run directory (synth_run.make_text_run / make_bam_run)"""
+    from .call_chunks import chunk_contig
+    out = []
+    for bed in run["chunks"]:
+        a = Namespace(platform="ont", ref_fn=run["ref_fn"], samtools="samtools", bam_reader="native" if bam else "samtools",
+                      tumor_bam_fn=run.get("bam_fn"), min_bq=None, max_depth=None, max_indel_length=None, min_rescale_cov=50,
+                      disable_indel_calling=True, sample_name="SAMPLE", show_ref=False, qual=0, pileup=True, predict_fn=None,
+                      output_dir=out_dir)
+        a.candidates_bed_regions, a.ctg_name = bed, chunk_contig(bed)
+        a.mpileup_fn = None if bam else os.path.join(run["mpileup_dir"], os.path.basename(bed) + ".mpileup")
+        a.call_fn = os.path.join(out_dir, "p_%s.vcf" % os.path.basename(bed))
+        out.append(a)
+    return out
+
+
+def build_run(d, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, region_kb=None):
+    """synthetic run directory under `d` (input synthesis, untimed) -> (run dict, description)"""
+    from .synth_run import make_bam_run, make_text_run
+    if kind == "text":
+        run = make_text_run(os.path.join(d, "run_text"), n_chunks=n_chunks, sites_per_chunk=sites_per_chunk, distinct=distinct)
+        mp = os.path.join(run["mpileup_dir"], os.path.basename(run["chunks"][0]) + ".mpileup")
+        return run, "samtools-mpileup text, %d chunk files x %d candidates (%d distinct pileups), %.1f MB of text per chunk" % (
+            n_chunks, sites_per_chunk, distinct, os.path.getsize(mp) / 1e6)
+    region_kb = region_kb if region_kb is not None else max(200, n_chunks * sites_per_chunk // 4)
+    run = make_bam_run(os.path.join(d, "run_bam"), region_kb=region_kb, n_chunks=n_chunks)
+    return run, "synthetic 50x long-read BAM + BAI over %d kb (%.0f MB), %d chunk files, candidates every 250 bp, native BAM reader" % (
+        region_kb, os.path.getsize(run["bam_fn"]) / 1e6, len(run["chunks"]))
+
+
+def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=2):
+    """the pipeline over a prepared run directory -> dict(sites_per_s, ...); best of `repeats` passes (the first one warms the page
+    cache, the pinned buffers and the model workspaces)"""
+    from .call_chunks import run_pipeline, usable_cores
+    producers = producers if producers else max(1, min(16, usable_cores() // 4))
+    os.makedirs(out_dir, exist_ok=True)
+    chunk_args = chunk_namespaces(run, out_dir, bam=(kind == "bam"))
+    best, rows = None, 0
+    for _ in range(max(1, repeats)):
+        t0 = time.perf_counter()
+        rows = run_pipeline(eng, chunk_args, producers=producers, writers=writers)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return dict(sites_per_s=round(run["n_sites"] / best, 1), sites=int(run["n_sites"]), chunks=len(chunk_args), seconds=round(best, 4),
+                producers=producers, writers=writers, vcf_records=int(rows),
+                includes="disk reads, tokenise / BAM decode, PCIe both ways, kernels, alt_info + VCF rows (C), file writes")
+
+
+def measure(eng, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, region_kb=None, producers=None, writers=2, workdir=None,
+            repeats=2):
+    """build_run + time_run in a temporary directory"""
+    d = tempfile.mkdtemp(prefix="cto_e2e_", dir=workdir)
+    try:
+        t0 = time.perf_counter()
+        run, source = build_run(d, kind, n_chunks, sites_per_chunk, distinct, region_kb)
+        prep_s = time.perf_counter() - t0
+        r = time_run(eng, run, kind, os.path.join(d, "vcf_output"), producers, writers, repeats)
+        r.update(source=source, input_synthesis_s=round(prep_s, 1))
+        return r
+    finally:
+        shutil.rmtree(d, ignore_errors=True)

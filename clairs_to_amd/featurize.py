@@ -78,10 +78,16 @@ def alt_infos_packed(feat, host_pack, site_info_host=None, pass_idx=0):
     """alt_infos() without the per-site Python strings: (bytes with the strings back to back, int64 offsets [n + 1]) - the form
     cto_vcf_rows_batch consumes."""
     info = feat.site_info.cpu().numpy() if site_info_host is None else site_info_host
-    colvec = feat.colvec.cpu().numpy()
-    sitefirst = np.ascontiguousarray(feat.sitefirst.cpu().numpy())
-    keycnt = np.ascontiguousarray(feat.keycnt.cpu().numpy().view(np.uint32))
-    keyfirst = np.ascontiguousarray(feat.keyfirst.cpu().numpy())
+    return alt_infos_from_host(host_pack, info, feat.colvec.cpu().numpy(), feat.sitefirst.cpu().numpy(), feat.keycnt.cpu().numpy(),
+                               feat.keyfirst.cpu().numpy(), pass_idx)
+
+
+def alt_infos_from_host(host_pack, info, colvec, sitefirst, keycnt, keyfirst, pass_idx=0):
+    """alt_infos_packed() on host copies (numpy arrays) of the featurisation outputs - what a pipelined caller has after its own
+    asynchronous device-to-host copies (call_chunks)."""
+    sitefirst = np.ascontiguousarray(sitefirst)
+    keycnt = np.ascontiguousarray(np.asarray(keycnt).view(np.uint32))
+    keyfirst = np.ascontiguousarray(keyfirst)
     if keycnt.size == 0:
         keycnt = np.zeros(1, dtype=np.uint32)
         keyfirst = np.zeros((1, 2), dtype=np.int32)

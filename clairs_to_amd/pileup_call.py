@@ -23,7 +23,7 @@ from .call_variants import IUPAC_TO_ACGT, VCF_HEADER, load_likelihood, vcf_rows_
 from .create_tensor_pileup_calling import EXPAND_REF, MAX_INDEL, load_pack, read_candidates
 from .engine import Engine
 from .fasta import read_region
-from .featurize import alt_infos_packed
+from .featurize import alt_infos_from_host
 from .predict import load_models, str2bool
 from .platforms import resolve_platform
 
@@ -42,9 +42,11 @@ def make_engine(args, device="cuda"):
                   neg_reads_aff=(family == "ilmn"))
 
 
-def prepare_chunk(args):
+def prepare_chunk(args, device=None, copy_stream=None):
     """Host-only half of a chunk: candidates, reference slice and the column pack (BAM decoding / mpileup tokenising; the C
-    calls release the GIL, so `call_chunks` runs this for chunk i+1 on a thread while chunk i is on the GPU).  None if empty."""
+    calls release the GIL, so `call_chunks` runs several of these on a thread pool while earlier chunks are on the GPU).
+    With `device` the pack is also uploaded from this (producer) thread on `copy_stream`, and `uploaded` is the event the
+    compute stream has to wait for - the PCIe transfer then never blocks the thread that launches kernels.  None if empty."""
     centres, ctg_start, ctg_end = read_candidates(args.candidates_bed_regions, args.ctg_name)
     if not centres:
         return None
@@ -54,28 +56,67 @@ def prepare_chunk(args):
         sys.exit("[ERROR] Failed to load reference sequence from file ({}).".format(args.ref_fn))
     max_indel = MAX_INDEL if args.max_indel_length is None else args.max_indel_length
     pack = load_pack(args, ref, ref_start, ctg_start, ctg_end, max_indel)
-    return dict(sites=sorted(centres), ref=ref, ref_start=ref_start, pack=pack)
+    prep = dict(sites=sorted(centres), ref=ref, ref_start=ref_start, pack=pack)
+    if device is not None:
+        with torch.cuda.device(device), torch.cuda.stream(copy_stream if copy_stream is not None else torch.cuda.current_stream(device)):
+            prep["dev_pack"] = pack.to_device(device)
+            prep["dev_sites"] = torch.tensor(prep["sites"], dtype=torch.int32).to(device)
+            prep["uploaded"] = torch.cuda.Event()
+            prep["uploaded"].record()
+    return prep
 
 
-def pileup_call(args, device="cuda", engine=None, prepared=None):
-    eng = engine if engine is not None else make_engine(args, device)
+_HOST_KEYS = ("site_info", "colvec", "sitefirst", "keycnt", "keyfirst", "decision", "qual")
+
+
+def launch_chunk(eng, prep, want_probs=False, pinned=None):
+    """Device half of a chunk, asynchronous: waits for the pack upload (if a producer thread did it), runs the hot path on the
+    current stream and queues the device-to-host copies of everything the row formatter needs into page-locked buffers
+    (`pinned`: a dict re-used from an earlier chunk, grown when too small).  Returns the host views + the event that marks
+    them valid; nothing here blocks on the GPU."""
     device = eng.device
-    K = eng.K
-    prep = prepared if prepared is not None else prepare_chunk(args)
-    if prep is None:
-        print("[INFO] {} total processed positions: 0".format(args.ctg_name), file=sys.stderr)
-        return 0
+    with torch.cuda.device(device):
+        main = torch.cuda.current_stream()
+        if "dev_pack" in prep:
+            main.wait_event(prep["uploaded"])
+            dp, sp = prep["dev_pack"], prep["dev_sites"]
+            for t in list(dp.t.values()) + [sp]:
+                t.record_stream(main)
+        else:
+            dp = prep["pack"].to_device(device)
+            sp = torch.tensor(prep["sites"], dtype=torch.int32, device=device)
+        res = eng.run_device(dp, sp)
+        feat = res["features"]
+        src = dict(site_info=feat.site_info, colvec=feat.colvec, sitefirst=feat.sitefirst, keycnt=feat.keycnt, keyfirst=feat.keyfirst,
+                   decision=res["decision"], qual=res["qual"])
+        if want_probs:
+            src["probs"] = res["probs"]
+        pinned = {} if pinned is None else pinned
+        host = {}
+        for k, t in src.items():
+            buf = pinned.get(k)
+            if buf is None or buf.dtype != t.dtype or buf.numel() < t.numel():
+                buf = torch.empty(max(t.numel(), 1) * 5 // 4, dtype=t.dtype, pin_memory=True)
+                pinned[k] = buf
+            h = buf[: t.numel()].view(t.shape)
+            h.copy_(t, non_blocking=True)
+            host[k] = h
+        done = torch.cuda.Event()
+        done.record(main)
+    return dict(host=host, done=done, pinned=pinned, keep=(res, dp, sp))
+
+
+def finish_chunk(args, K, prep, launched):
+    """Host tail of a chunk: waits for the copies, builds the alt_info strings and every VCF record in two C calls
+    (cto_alt_info_batch, cto_vcf_rows_batch) and writes `args.call_fn` (+ the probability rows when --predict_fn is given)."""
+    launched["done"].synchronize()
+    h = {k: v.numpy() for k, v in launched["host"].items()}
     sites, ref, ref_start, pack = prep["sites"], prep["ref"], prep["ref_start"], prep["pack"]
-    dp = pack.to_device(device)
-    res = eng.run_device(dp, torch.tensor(sites, dtype=torch.int32, device=device))
-    torch.cuda.synchronize()
-    feat = res["features"]
-    info = feat.site_info.cpu().numpy()
-    alt_buf, alt_off = alt_infos_packed(feat, pack, info)
-    dec, qual = res["decision"].cpu().numpy(), res["qual"].cpu().numpy()
+    info = h["site_info"].copy()
+    alt_buf, alt_off = alt_infos_from_host(pack, info, h["colvec"], h["sitefirst"], h["keycnt"], h["keyfirst"])
+    dec, qual = h["decision"], h["qual"]
     sites_arr = np.asarray(sites, dtype=np.int64)
     centre = np.frombuffer(ref.encode("latin-1"), dtype=np.uint8)[sites_arr - ref_start]
-    info = info.copy()
     info[~np.isin(centre, np.frombuffer(b"ACGT", dtype=np.uint8)), 3] |= 1      # predict.py:219-228: centre not in ACGT -> no row
     # every record of the chunk in one C call (cto_vcf_rows_batch): the per-site Python formatting was a third of a chunk
     text, cnt = vcf_rows_batch(args.ctg_name, sites_arr, centre, alt_buf, alt_off, info, dec, qual, K, show_ref=args.show_ref,
@@ -89,24 +130,36 @@ def pileup_call(args, device="cuda", engine=None, prepared=None):
                   "reference raises IndexError here); %s" % (args.ctg_name, sites[i], "no posterior, site skipped" if dec[i, 1] & 2
                                                              else "bin clamped"), file=sys.stderr)
     os.makedirs(os.path.dirname(os.path.abspath(args.call_fn)), exist_ok=True)
-    with open(args.call_fn, "w") as out:
-        out.write(VCF_HEADER + "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n" % args.sample_name)
-        out.write(text)
-    if args.predict_fn:        # debugging tap: the probability rows of the predict mirror
-        probs = res["probs"].cpu().numpy()
+    if n_rows:             # the reference removes VCFs without records (call_variants.py:859-867)
+        with open(args.call_fn, "w") as out:
+            out.write(VCF_HEADER + "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n" % args.sample_name)
+            out.write(text)
+    elif os.path.exists(args.call_fn):
+        os.remove(args.call_fn)
+    if getattr(args, "predict_fn", None):        # debugging tap: the probability rows of the predict mirror
+        probs = h["probs"]
         with gzip.open(args.predict_fn, "wt") as pred:
             for i, pos in enumerate(sites):
-                c = chr(centre[i])
-                if (info[i, 3] & 1) or c not in "ACGT":
+                if info[i, 3] & 1:
                     continue
+                c = chr(centre[i])
                 fwd, rev = [float(v) for v in info[i, 4:8]], [float(v) for v in info[i, 8:12]]
                 fields = [args.ctg_name, str(pos), IUPAC_TO_ACGT[c], alt_buf[alt_off[i]:alt_off[i + 1]].decode(), str(fwd), str(rev)]
                 fields += [" ".join("{:0.8f}".format(x) for x in probs[i, k]) for k in range(2 * K)]
                 pred.write("\t".join(fields) + ("\t\n" if K == 4 else "\n"))
-    if n_rows == 0:
-        os.remove(args.call_fn)            # the reference removes VCFs without records (call_variants.py:859-867)
     print("[INFO] {} total processed positions: {}".format(args.ctg_name, n_sites), file=sys.stderr)
     return n_rows
+
+
+def pileup_call(args, device="cuda", engine=None, prepared=None):
+    """One chunk, start to finish (the three stages above back to back)."""
+    eng = engine if engine is not None else make_engine(args, device)
+    prep = prepared if prepared is not None else prepare_chunk(args)
+    if prep is None:
+        print("[INFO] {} total processed positions: 0".format(args.ctg_name), file=sys.stderr)
+        return 0
+    launched = launch_chunk(eng, prep, want_probs=bool(getattr(args, "predict_fn", None)))
+    return finish_chunk(args, eng.K, prep, launched)
 
 
 def add_common_arguments(p):

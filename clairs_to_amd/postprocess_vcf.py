@@ -44,9 +44,15 @@ def _header_from_fai(ref_fn, sample_name, only=None):
     return out + "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s" % sample_name
 
 
-def sort_vcf(input_dir, output_fn, contigs, vcf_fn_prefix=None, vcf_fn_suffix=".vcf", ref_fn=None, sample_name="SAMPLE"):
-    """Merge chunk VCFs; returns the number of records written."""
+def sort_vcf(input_dir, output_fn, contigs, vcf_fn_prefix=None, vcf_fn_suffix=".vcf", ref_fn=None, sample_name="SAMPLE",
+             only_files=None):
+    """Merge chunk VCFs; returns the number of records written.  only_files (not in the reference, which merges whatever the
+    directory holds): restrict the merge to these file names - call_chunks passes the p_<chunk>.vcf names of its own chunk
+    list so that leftovers of an earlier run in the same directory stay out."""
     files = os.listdir(input_dir)
+    if only_files is not None:
+        keep = set(only_files)
+        files = [f for f in files if f in keep]
     if vcf_fn_prefix is not None:
         files = [f for f in files if f.startswith(vcf_fn_prefix)]
     if vcf_fn_suffix is not None:

@@ -258,6 +258,26 @@ int64_t cto_vcf_rows_batch(const char* chrom, int64_t n, const int32_t* pos, con
                            const int64_t* alt_off, const int32_t* site_info, const int32_t* decision, const double* qual,
                            int K, int show_ref, double qual_pass, char* buf, size_t cap, int64_t* counts);
 
+/* ------------------------------------------------------------------------------------------------
+ * Long-read post-calling filters (src/haplotype_filtering.py:344-707): the read-level evidence of
+ * every call of ONE mpileup job, from the nine-column text of
+ *   samtools mpileup --min-MQ q --min-BQ q --excl-flags 2316 [-l bed] -r ctg:lo-hi --output-MQ --output-QNAME --output-extra HP
+ * (haplotype_filtering.py:336-345).  Host code (no device work: thousands of calls, <= 201 columns each).
+ *   ref_seq                  upper-cased reference of [region_lo, region_lo + ref_len) (`samtools faidx ctg:lo-hi`, :1096-1101)
+ *   pos[n]                   the calls, 1-based;  fields + field_off[n+1]: per call "REF\tALT\tHETERO_INFO\tHOMO_INFO" back to
+ *                            back (HETERO / HOMO_INFO = "pos-ALT,pos-ALT,..." of the phased germline variants within
+ *                            +-flanking, :1012-1021);  af[n] (1.0 when unknown)
+ *   flanking                 --flanking (100);  max_co_exist_read_num = --min_alt_coverage (2);  disable_rse =
+ *                            --disable_read_start_end_filtering
+ *   flags[n][9] uint8        1 = True of: phaseable, pass_hetero, pass_homo, pass_read_start_end, pass_bq, pass_mq, pass_co_exist,
+ *                            pass_hetero_both_side, pass_sequence_entropy (the columns of the reference's per-call output line, :588-592)
+ *   strand[n][4] int64       a0, r0, a1, r1: the 2x2 table of Fisher's exact test (:575-582); the caller evaluates the p-value
+ *                            in exact integer arithmetic as the reference does (:60-97) and derives pass_strand_bias / pass_hap
+ * ---------------------------------------------------------------------------------------------- */
+int cto_haplotype_filter(const char* text, size_t len, const char* ref_seq, int64_t region_lo, size_t ref_len, int64_t n,
+                         const int32_t* pos, const char* fields, const int64_t* field_off, const double* af, int flanking,
+                         int max_co_exist_read_num, int disable_rse, uint8_t* flags, int64_t* strand);
+
 #ifdef __cplusplus
 }
 #endif

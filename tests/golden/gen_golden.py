@@ -672,7 +672,108 @@ def gen_pickles(tmp):
     dump_json_gz("pickles.json.gz", out)
 
 
+# ------------------------------------------------------------------------------------------ haplotype filtering (8f #4)
+SHIM_HAP = r'''#!/usr/bin/env python3
+import os, sys
+a = sys.argv[1:]
+if a[0] == "faidx":
+    seq = open(os.environ["FAKE_REF"]).read().strip()
+    ctg, rng = a[2].split(":")
+    s, e = [int(x) for x in rng.split("-")]
+    e = min(e, len(seq))
+    sys.stdout.write(">%s:%d-%d\n" % (ctg, s, e))
+    sub = seq[s - 1:e]
+    for i in range(0, len(sub), 60):
+        sys.stdout.write(sub[i:i + 60] + "\n")
+elif a[0] == "mpileup":
+    ctg, rng = a[a.index("-r") + 1].split(":")
+    lo, hi = [int(x) for x in rng.split("-")]
+    bed = None
+    if "-l" in a:
+        bed = [tuple(int(v) for v in r.split("\t")[1:3]) for r in open(a[a.index("-l") + 1]) if r.strip()]
+    for row in open(os.environ["FAKE_MPILEUP_HAP"]):
+        p = int(row.split("\t", 2)[1])
+        if lo <= p <= hi and (bed is None or any(b < p <= e for b, e in bed)):
+            sys.stdout.write(row)
+else:
+    sys.exit(1)
+'''
+
+
+def gen_hapfilter(tmp):
+    """src/haplotype_filtering.py (reference, chunk mode: one in-process mpileup per <= 200 calls) on a simulated haplotagged
+    pileup: pileup VCF of PASS calls + germline VCF + nine-column mpileup text in, filtered VCF (FILTER tags, H / SB INFO) out,
+    for the SNV pass and the indel pass (--is_indel)."""
+    import hapsim
+    sim = hapsim.simulate()
+    ref = sim["ref"]
+    d = os.path.join(tmp, "hap")
+    os.makedirs(d, exist_ok=True)
+    open(os.path.join(d, "ref.fa"), "w").write(">chr1\n" + ref + "\n")
+    open(os.path.join(d, "ref.fa.fai"), "w").write("chr1\t%d\t6\t%d\t%d\n" % (len(ref), len(ref), len(ref) + 1))
+    open(os.path.join(d, "ref.txt"), "w").write(ref)
+    shim = os.path.join(d, "samtools")
+    open(shim, "w").write(SHIM_HAP)
+    os.chmod(shim, os.stat(shim).st_mode | stat.S_IEXEC)
+    open(os.path.join(d, "fake.bam"), "w").write("")
+    head = ("##fileformat=VCFv4.2\n##FILTER=<ID=PASS,Description=\"All filters passed\">\n"
+            "##FORMAT=<ID=TU,Number=1,Type=Integer,Description=\"Count of T in the tumor BAM\">\n"
+            "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSAMPLE\n")
+    germ_vcf = os.path.join(d, "germline.vcf")
+    open(germ_vcf, "w").write(head + "".join("chr1\t%d\t.\t%s\t%s\t30.0\tPASS\t.\tGT:GQ\t%s:30\n" % g for g in sim["germline"]))
+    out = dict(ref=ref, germline_vcf=open(germ_vcf).read(), modes={})
+    flank = 100
+    for mode, calls in (("snv", sim["snv_calls"]), ("indel", sim["indel_calls"])):
+        positions = sorted({p for c in calls for p in range(max(1, c[0] - flank), c[0] + flank + 1)})
+        text = hapsim.pileup_rows(sim, positions)
+        mp = os.path.join(d, "mp_%s.txt" % mode)
+        open(mp, "w").write(text)
+        by_pos = {int(r.split("\t", 2)[1]): r.split("\t") for r in text.split("\n") if r}
+        rows = []
+        for i, (p, rb, ab) in enumerate(calls):
+            cols = by_pos[p]
+            toks = cols[7].count(",") + 1
+            if len(rb) == 1 and len(ab) == 1:
+                n_alt = sum(1 for c in cols[4].upper() if c == ab)
+            else:
+                n_alt = cols[4].count("+") + cols[4].count("-")
+            af = min(1.0, n_alt / float(toks))
+            flt = "PASS" if i % 11 != 10 else "LowQual"             # a non-PASS input record must pass through untouched
+            rows.append("chr1\t%d\t.\t%s\t%s\t%.4f\t%s\tFAU=1;FCU=2;FGU=3;FTU=4;RAU=5;RCU=6;RGU=7;RTU=8\tGT:GQ:DP:AF:AD:AU:CU:GU:TU\t0/1:%d:%d:%.4f:%d,%d:1:2:3:4\n"
+                        % (p, rb, ab, 12.5 + i, flt, 12 + i, toks, af, toks - n_alt, n_alt))
+        pile_vcf = os.path.join(d, "pileup_%s.vcf" % mode)
+        open(pile_vcf, "w").write(head + "".join(rows))
+        out_vcf = os.path.join(d, "out_%s.vcf" % mode)
+        cmd = [sys.executable, os.path.join(REF, "clairs_to.py"), "haplotype_filtering", "--tumor_bam_fn", os.path.join(d, "fake.bam"),
+               "--ref_fn", os.path.join(d, "ref.fa"), "--ctg_name", "chr1", "--pileup_vcf_fn", pile_vcf, "--germline_vcf_fn", germ_vcf,
+               "--output_vcf_fn", out_vcf, "--output_dir", os.path.join(d, "work_%s" % mode), "--samtools", shim, "--threads", "1",
+               "--haplotype_filtering_chunk_mode", "True", "--haplotype_chunk_max_sites", "7"]
+        if mode == "indel":
+            cmd.append("--is_indel")
+        results = set()
+        for hashseed in ("0", "1", "2"):       # set / dict iteration order must not matter on this fixture
+            res = subprocess.run(cmd, cwd=d, env=dict(os.environ, PYTHONPATH=REF, FAKE_REF=os.path.join(d, "ref.txt"), FAKE_MPILEUP_HAP=mp,
+                                                      PYTHONHASHSEED=hashseed), capture_output=True, text=True)
+            assert res.returncode == 0, res.stderr[-2000:]
+            results.add(open(out_vcf).read())
+        assert len(results) == 1, "reference output depends on the hash seed: pick another simulation seed"
+        got = open(out_vcf).read()
+        out["modes"][mode] = dict(pileup_vcf=open(pile_vcf).read(), mpileup=text, out_vcf=got, stdout=res.stdout)
+        tags = {}
+        for r in got.split("\n"):
+            if r and not r.startswith("#"):
+                for t in r.split("\t")[6].split(";"):
+                    tags[t] = tags.get(t, 0) + 1
+        print("hapfilter", mode, "calls", len(calls), "rows", text.count("\n"), "FILTER tags", tags,
+              "H", sum(1 for r in got.split("\n") if "\tH;" in r))
+    dump_json_gz("hapfilter.json.gz", out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "hapfilter":
+        with tempfile.TemporaryDirectory() as tmp:
+            gen_hapfilter(tmp)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "post":
         with tempfile.TemporaryDirectory() as tmp:
             gen_post(tmp)
