@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401  (must precede the dlopen, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libclairsto_amd.so")
+# CTO_LIB_PATH: A/B testing of kernel variants built next to the product library (tools/ only; never set by the product)
+LIB_PATH = os.environ.get("CTO_LIB_PATH") or os.path.join(_HERE, "libclairsto_amd.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

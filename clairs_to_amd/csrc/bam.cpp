@@ -23,8 +23,10 @@
 //   * a read is dropped when `max_depth` reads are already active at its start (htslib's per-file maxcnt);
 //   * rows exist only for positions covered by >= 1 read-base or placeholder, inside [start, end] and inside the BED
 //     intervals when given.
-// Not implemented (documented deviations): mate-overlap quality adjustment (mpileup without -x; paired-end short reads
-// only), BAQ (needs -f, which the reference does not pass), CRAM, multi-file input.
+//   * read-pair overlaps (mpileup without -x, as the reference runs it): where both mates of a pair have an aligned base at a
+//     position, the first mate's base keeps min(200, qa + qb) when they agree and the better base keeps 0.8 x its quality
+//     when they differ; the other base's quality becomes 0 (soften_overlap below).  Paired-end short reads only.
+// Not implemented (documented deviations): BAQ (needs -f, which the reference does not pass), CRAM, multi-file input.
 #include <dlfcn.h>
 #include <zlib.h>
 
@@ -201,9 +203,13 @@ bool bai_query(const char* path, int tid, int64_t beg, int64_t end, std::vector<
     FILE* f = fopen(path, "rb");
     if (!f) { *err = std::string("cannot open index ") + path; return false; }
     std::vector<uint8_t> buf;
-    fseeko(f, 0, SEEK_END);
-    const off_t sz = ftello(f);
-    fseeko(f, 0, SEEK_SET);
+    off_t sz = -1;
+    if (fseeko(f, 0, SEEK_END) == 0) sz = ftello(f);
+    if (sz < 0 || sz > (off_t(1) << 32) || fseeko(f, 0, SEEK_SET) != 0) {       // not seekable (a pipe, a directory) or absurdly large
+        fclose(f);
+        *err = std::string("cannot read index ") + path;
+        return false;
+    }
     buf.resize(size_t(sz));
     const bool ok = fread(buf.data(), 1, buf.size(), f) == buf.size();
     fclose(f);
@@ -263,14 +269,57 @@ struct Read {
                                 // BED-restricted pileup touches a small part of a long read
     int32_t l_seq = 0;
     bool no_qual = false;
+    std::string mate_key;       // QNAME of a paired read (empty otherwise): mates find each other through it
     int base4(int q) const { return (raw[size_t(q >> 1)] >> ((~q & 1) << 2)) & 15; }
     int bq(int q) const { return (no_qual || q >= l_seq) ? 0 : std::min(int(raw[size_t((l_seq + 1) / 2 + q)]), 93); }
+    uint8_t* qual_at(int q) { return &raw[size_t((l_seq + 1) / 2 + q)]; }
+    // query index of the aligned base (M / = / X) at 0-based reference position rpos, or -1 (deletion, skip, outside the read)
+    int query_at(int32_t rpos) const {
+        int32_t rp = pos, qp = 0;
+        for (uint32_t c : cigar) {
+            const int len = int(c >> 4), opc = int(c & 15);
+            const bool cons_ref = opc == 0 || opc == 2 || opc == 3 || opc == 7 || opc == 8;
+            const bool cons_q = opc == 0 || opc == 1 || opc == 4 || opc == 7 || opc == 8;
+            if (cons_ref && rpos < rp + len) return (cons_q && rpos >= rp) ? qp + (rpos - rp) : -1;
+            if (cons_ref) rp += len;
+            if (cons_q) qp += len;
+        }
+        return -1;
+    }
     // cursor: CIGAR op index, offset inside it, reference / query positions at the start of the op
     size_t op = 0;
     int32_t op_ref = 0, op_q = 0;
 };
 
 const char kNt16[] = "=ACMGRSVTWYHKDBN";
+
+// Read-pair overlap handling of `samtools mpileup` (on unless -x / --ignore-overlaps-removal; the reference never passes -x,
+// SURVEY.md App. B): where the two mates of a pair cover the same reference position with an aligned base each, one base is
+// kept and the other nullified by a base quality of 0 (samtools-mpileup(1), "--ignore-overlaps-removal"); the kept base gets
+// the sum of both qualities (capped at 200) when the mates agree, 0.8 x the larger quality when they differ (htslib's
+// tweak_overlap_quality).  `a` is the mate that entered the pileup first.  A quality-0 base still prints under --min-BQ 0 - it
+// is the AFF pass's --min_bq and the LBQ channels that see the difference.  Long reads are unpaired: nothing happens.
+void soften_overlap(Read& a, Read& b) {
+    if (a.no_qual || b.no_qual) return;
+    const int32_t lo = std::max(a.pos, b.pos), hi = std::min(a.end, b.end);
+    for (int32_t rp = lo; rp < hi; ++rp) {
+        const int qa = a.query_at(rp), qb = b.query_at(rp);
+        if (qa < 0 || qb < 0) continue;
+        uint8_t* pa = a.qual_at(qa);
+        uint8_t* pb = b.qual_at(qb);
+        if (a.base4(qa) == b.base4(qb)) {
+            const int s = int(*pa) + int(*pb);
+            *pa = uint8_t(s > 200 ? 200 : s);
+            *pb = 0;
+        } else if (*pa >= *pb) {
+            *pa = uint8_t(0.8 * *pa);
+            *pb = 0;
+        } else {
+            *pb = uint8_t(0.8 * *pb);
+            *pa = 0;
+        }
+    }
+}
 
 struct Producer {
     cto_pack* p;
@@ -405,6 +454,7 @@ int pack_from_bam_range(const char* bam_path, const char* bai_path, const char* 
     pr.max_indel = max_indel_length;
 
     std::deque<Read> active;
+    int64_t prev_start = 0;              // 0-based start of the last record that reached this point (see the flush below)
     int64_t next_col = start;            // next 1-based position to emit
     int64_t bed_cursor = 0;
     const int64_t beg0 = start - 1, end0 = end;   // 0-based half-open region
@@ -502,7 +552,7 @@ int pack_from_bam_range(const char* bam_path, const char* bai_path, const char* 
                 }
             }
             r.cigar.resize(size_t(n_ops));
-            int32_t rlen = 0, qlen = 0;
+            int64_t rlen = 0, qlen = 0;                        // 64-bit: a crafted CIGAR must not wrap the sums
             for (int i = 0; i < n_ops; ++i) {
                 const uint32_t c = uint32_t(le32(ops + i * 4));
                 r.cigar[size_t(i)] = c;
@@ -511,15 +561,20 @@ int pack_from_bam_range(const char* bam_path, const char* bai_path, const char* 
                 if (opc == 0 || opc == 1 || opc == 4 || opc == 7 || opc == 8) qlen += len;
             }
             if (qlen != l_seq || rlen == 0) continue;          // inconsistent or reference-less record
-            r.end = pos + rlen;
+            CTO_REQUIRE(int64_t(pos) + rlen <= INT32_MAX, CTO_EINVAL, "cto_pack_from_bam: alignment at %d runs past 2^31 - 1", pos);
+            r.end = int32_t(pos + rlen);
             if (r.end <= beg0) continue;
             r.op_ref = pos;
             r.l_seq = l_seq;
             r.raw.assign(sq, ql + l_seq);
             r.no_qual = ql[0] == 0xff;                                                             // QUAL absent
-            // columns strictly before this read's start are final
+            // Columns strictly before the PREVIOUS accepted read's start are emitted now; those between the two starts wait for
+            // the next record.  That is htslib's order (bam_plp_next hands out column p only once a read starting beyond p has
+            // been pushed, so a read is pushed - and its mate's qualities are edited - while the iterator stands at the
+            // previous read's start), and it shows in one place: a deletion placeholder of the first mate that lies between
+            // the two starts already prints the edited quality of the base after the deletion.
             const double tf0 = timing ? now() : 0.0;
-            const int rcf = flush_until(std::min<int64_t>(pos, end));     // columns at 1-based positions <= pos (0-based start) are final
+            const int rcf = flush_until(std::min<int64_t>(prev_start, end));     // 1-based columns <= prev_start (0-based) are final
             if (rcf != CTO_OK) return rcf;
             if (timing) t_flush += now() - tf0;
             if (max_depth > 0) {
@@ -527,6 +582,12 @@ int pack_from_bam_range(const char* bam_path, const char* bai_path, const char* 
                 for (const Read& a : active) live += a.end > pos;
                 if (live >= max_depth) continue;
             }
+            if ((flag & 1) && l_name > 1) {                    // paired: the mate may already be in the pileup
+                r.mate_key.assign(reinterpret_cast<const char*>(b + 32), size_t(l_name - 1));
+                for (Read& a : active)
+                    if (a.end > pos && a.mate_key == r.mate_key) { soften_overlap(a, r); break; }
+            }
+            prev_start = pos;
             active.push_back(std::move(r));
         }
     }
@@ -542,9 +603,29 @@ int pack_from_bam_range(const char* bam_path, const char* bai_path, const char* 
 
 }  // namespace
 
-extern "C" int cto_pack_from_bam(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
-                                  const int64_t* bed, int64_t n_bed, const char* ref_seq, int64_t ref_start, size_t ref_len,
-                                  int excl_flags, int min_mq, int max_depth, int max_indel_length, cto_pack** out) {
+namespace {
+
+// No C++ exception may cross the C ABI or leave a worker thread (std::terminate would take the host process down with it):
+// allocation failures on hostile input (a record claiming 256 MB, a 4 GB index) come back as CTO_ENOMEM.
+template <class F>
+int guarded(const char* what, F&& f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        set_error("%s: out of memory", what);
+        return CTO_ENOMEM;
+    } catch (const std::exception& e) {
+        set_error("%s: %s", what, e.what());
+        return CTO_EINVAL;
+    } catch (...) {
+        set_error("%s: unknown failure", what);
+        return CTO_EINVAL;
+    }
+}
+
+int pack_from_bam_impl(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
+                       const int64_t* bed, int64_t n_bed, const char* ref_seq, int64_t ref_start, size_t ref_len,
+                       int excl_flags, int min_mq, int max_depth, int max_indel_length, cto_pack** out) {
     CTO_REQUIRE(bam_path && ctg_name && ref_seq && out, CTO_EINVAL, "cto_pack_from_bam: null argument");
     CTO_REQUIRE(start >= 1 && end >= start, CTO_EINVAL, "cto_pack_from_bam: bad region %lld-%lld", (long long)start, (long long)end);
     CTO_REQUIRE(n_bed == 0 || bed, CTO_EINVAL, "cto_pack_from_bam: bed intervals missing");
@@ -593,8 +674,10 @@ extern "C" int cto_pack_from_bam(const char* bam_path, const char* bai_path, con
     auto work = [&](unsigned t) {
         cto_pack* p = nullptr;
         if (cut[t + 1] - 1 < cut[t]) { parts[t].reset(new cto_pack()); pack_begin(parts[t].get(), 16, 16); return; }
-        rcs[t] = pack_from_bam_range(bam_path, bai_path, ctg_name, cut[t], cut[t + 1] - 1, bed, n_bed, ref_seq, ref_start, ref_len,
-                                     excl_flags, min_mq, max_depth, max_indel_length, &p);
+        rcs[t] = guarded("cto_pack_from_bam", [&] {
+            return pack_from_bam_range(bam_path, bai_path, ctg_name, cut[t], cut[t + 1] - 1, bed, n_bed, ref_seq, ref_start, ref_len,
+                                       excl_flags, min_mq, max_depth, max_indel_length, &p);
+        });
         if (rcs[t] != CTO_OK) errs[t] = cto_last_error();
         parts[t].reset(p);
     };
@@ -610,4 +693,15 @@ extern "C" int cto_pack_from_bam(const char* bam_path, const char* bai_path, con
     CTO_REQUIRE(p != nullptr, CTO_EINVAL, "cto_pack_from_bam: %s", merr.c_str());
     *out = p.release();
     return CTO_OK;
+}
+
+}  // namespace
+
+extern "C" int cto_pack_from_bam(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
+                                  const int64_t* bed, int64_t n_bed, const char* ref_seq, int64_t ref_start, size_t ref_len,
+                                  int excl_flags, int min_mq, int max_depth, int max_indel_length, cto_pack** out) {
+    return guarded("cto_pack_from_bam", [&] {
+        return pack_from_bam_impl(bam_path, bai_path, ctg_name, start, end, bed, n_bed, ref_seq, ref_start, ref_len, excl_flags, min_mq,
+                                  max_depth, max_indel_length, out);
+    });
 }

@@ -280,9 +280,17 @@ struct CvtBlockGeom {
 // n-tile owner is wave & 3), so one wave's LDS / L2 waits and VALU phases overlap the other's MFMAs.
 constexpr int CVT_BLOCK_THREADS = 512;
 
+// Workgroups of this geometry that fit one CU's 160 KB of LDS (at most 3 are asked for): the register budget follows from
+// it through __launch_bounds__ (w = minimum waves per SIMD = 2 per resident 512-thread workgroup), otherwise a kernel that
+// fits the LDS twice still runs alone because it was given 132+ registers.
+template <int C, int W, int WKV, int TS>
+__host__ __device__ constexpr int cvt_blocks_per_cu() {
+    return CvtBlockGeom<C, W, WKV, TS>::LDS_BYTES * 3 <= 160 * 1024 ? 3 : (CvtBlockGeom<C, W, WKV, TS>::LDS_BYTES * 2 <= 160 * 1024 ? 2 : 1);
+}
+
 template <int C, int W, int WKV, int TS, int CIN, bool HEAD>
-__global__ __launch_bounds__(CVT_BLOCK_THREADS) void k_cvt_block(float* __restrict__ h, CvtBlockParams p, HeadTailParams hp,
-                                                                 int heads, int B) {
+__global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV, TS>())) void k_cvt_block(float* __restrict__ h, CvtBlockParams p,
+                                                                                                            HeadTailParams hp, int heads, int B) {
     using G = CvtBlockGeom<C, W, WKV, TS>;
     static_assert(CIN == 0 || G::emb_floats(CIN) <= G::ALIAS, "stage input tile does not fit the free LDS");
     static_assert(!HEAD || (TS == 16 && 64 + head_lds_floats(6) <= G::ALIAS), "classifier tail needs a 16-site tile");

@@ -411,11 +411,22 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
 
     float4 Bq[2][NB][3], Fq[2][2], Aq[2][MS];
     int opq = 0;
+    // K of the x part is zero-padded from KIN to KP.  When at most 4 real channels fall into the last 16-wide chunk (layer 1:
+    // channels 32, 33 of 34) that chunk is ONE k-step whose four lane groups hold k = 16 (NX - 1) + kg - scalar operand loads -
+    // instead of float4 loads of which only two of four k-steps touch a real channel: 9 k-steps for K = 34, not 10.
+#ifdef CTO_GRU_NO_TAIL1
+    constexpr bool TAIL1 = false;
+#else
+    constexpr bool TAIL1 = (KIN % 16 != 0) && (KIN - 16 * (NX - 1) <= 4);
+#endif
     auto load_B = [&](int buf, int c) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) Bq[buf][nb][q] = *reinterpret_cast<const float4*>(wrow[nb][q] + c * 16 + opq);
+            for (int q = 0; q < 3; ++q) {
+                if (TAIL1 && c == NX - 1) Bq[buf][nb][q].x = *(wrow[nb][q] - 3 * kg + c * 16 + opq);      // W[n][16 c + kg]
+                else Bq[buf][nb][q] = *reinterpret_cast<const float4*>(wrow[nb][q] + c * 16 + opq);
+            }
     };
     auto load_F = [&](int buf, int kh, int tprev) {
         if constexpr (FUSE_FC1) {
@@ -426,8 +437,10 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
     };
     auto load_Ax = [&](int buf, int c, const float* xc) {
 #pragma unroll
-        for (int ms = 0; ms < MS; ++ms)
-            Aq[buf][ms] = *reinterpret_cast<const float4*>(xc + (ms * 16 + j) * XS + c * 16 + 4 * kg);
+        for (int ms = 0; ms < MS; ++ms) {
+            if (TAIL1 && c == NX - 1) Aq[buf][ms].x = xc[(ms * 16 + j) * XS + c * 16 + kg];
+            else Aq[buf][ms] = *reinterpret_cast<const float4*>(xc + (ms * 16 + j) * XS + c * 16 + 4 * kg);
+        }
     };
     auto load_Ah = [&](int buf, int kh, const float* hc) {
 #pragma unroll
@@ -451,7 +464,7 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
     // k-steps of the last x chunk that hold real input channels: K is zero-padded from KIN to KP (layer 1: 34 -> 48) and
     // element e of lane group kg is k = 16 c + 4 kg + e, so with r = KIN - 16 (NX - 1) real channels in the last chunk only
     // the k-steps e < min(4, r) touch any of them (layer 1: r = 2, two of the four k-steps)
-    constexpr int NE_LAST = (KIN - 16 * (NX - 1)) < 4 ? (KIN - 16 * (NX - 1)) : 4;
+    constexpr int NE_LAST = TAIL1 ? 1 : ((KIN - 16 * (NX - 1)) < 4 ? (KIN - 16 * (NX - 1)) : 4);
     auto mfma_chunk = [&](int cur, f32x4 (&r_)[MS][NB], f32x4 (&z_)[MS][NB], f32x4 (&n_)[MS][NB], int ne = 4) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -589,15 +602,20 @@ __global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__
 #ifndef CTO_GRU_IL
 #define CTO_GRU_IL 5
 #endif
+#ifndef CTO_GRU_IL1
+#define CTO_GRU_IL1 3       // measured on MI355X (tools/ab.py, layer 1 + tail): 2 -> 0.302, 3 -> 0.300, 4 / 5 / 6 -> 0.306, 8 -> 0.311 ms
+#endif
 #ifndef CTO_GRU_NO_INTERLEAVE
+            // MFMAs between two operand requests: layer 2 (88-MFMA chunks, 13 requests) and layer 1 (48, 8) are tuned separately
+            constexpr int IL = FUSE_FC1 ? CTO_GRU_IL : CTO_GRU_IL1;
 #pragma unroll
-            for (int g = 0; g < NB * 3 + 2; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, CTO_GRU_IL, 0);      // MFMAs
+            for (int g = 0; g < NB * 3 + (FUSE_FC1 ? 2 : 0); ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, IL, 0);      // MFMAs
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
             }
 #pragma unroll
             for (int g = 0; g < MS; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, CTO_GRU_IL, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, IL, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
             }
             if (!FUSE_FC1 && sq == 1) {

@@ -321,9 +321,18 @@ int dispatch_block(hipStream_t s, float* h, const BlockDev& b, int heads, int64_
     return embed ? launch_cvt_block<C, W, WKV, TS, CIN, false>(s, h, b, heads, B, ex)
                  : launch_cvt_block<C, W, WKV, TS, 0, false>(s, h, b, heads, B, ex);
 }
+// Sites per workgroup of the stage-1 / stage-2 blocks.  What they trade is LDS per workgroup (q / k / v tiles dominate) against
+// workgroups resident per CU: the blocks of these stages do little matrix work per phase, so a second and third resident
+// workgroup - whose GEMM phases run under this one's LayerNorm / softmax / barrier phases - is worth more than a taller tile.
+#ifndef CTO_CVT_TS1
+#define CTO_CVT_TS1 8
+#endif
+#ifndef CTO_CVT_TS2
+#define CTO_CVT_TS2 8
+#endif
 struct FusedGeom { int c, w, wkv, ts, cin; };
 const FusedGeom* fused_geom(const StageDev& st) {
-    static const FusedGeom G[4] = {{128, 5, 3, 16, 64}, {64, 9, 5, 8, 16}, {16, 17, 9, 8, 34}, {32, 17, 9, 8, 34}};
+    static const FusedGeom G[4] = {{128, 5, 3, 16, 64}, {64, 9, 5, CTO_CVT_TS2, 16}, {16, 17, 9, CTO_CVT_TS1, 34}, {32, 17, 9, CTO_CVT_TS1, 34}};
     for (const FusedGeom& g : G)
         if (st.c == g.c && st.w == g.w && st.wkv == g.wkv) return &g;
     return nullptr;
@@ -336,9 +345,9 @@ int try_fused_block(hipStream_t s, const StageDev& st, const BlockDev& b, float*
                     bool head) {
     int rc = CTO_OK;
     if (st.c == 128 && st.w == 5 && st.wkv == 3) rc = dispatch_block<128, 5, 3, 16, 64>(s, h, b, st.heads, B, ex, embed, head);
-    else if (st.c == 64 && st.w == 9 && st.wkv == 5) rc = dispatch_block<64, 9, 5, 8, 16>(s, h, b, st.heads, B, ex, embed, head);
-    else if (st.c == 16 && st.w == 17 && st.wkv == 9) rc = dispatch_block<16, 17, 9, 8, 34>(s, h, b, st.heads, B, ex, embed, head);
-    else if (st.c == 32 && st.w == 17 && st.wkv == 9) rc = dispatch_block<32, 17, 9, 8, 34>(s, h, b, st.heads, B, ex, embed, head);
+    else if (st.c == 64 && st.w == 9 && st.wkv == 5) rc = dispatch_block<64, 9, 5, CTO_CVT_TS2, 16>(s, h, b, st.heads, B, ex, embed, head);
+    else if (st.c == 16 && st.w == 17 && st.wkv == 9) rc = dispatch_block<16, 17, 9, CTO_CVT_TS1, 34>(s, h, b, st.heads, B, ex, embed, head);
+    else if (st.c == 32 && st.w == 17 && st.wkv == 9) rc = dispatch_block<32, 17, 9, CTO_CVT_TS1, 34>(s, h, b, st.heads, B, ex, embed, head);
     else return 0;
     return rc == CTO_OK ? 1 : rc;
 }

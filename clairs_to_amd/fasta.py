@@ -30,6 +30,10 @@ def read_region(fasta_fn, ctg, start, end):
     b0 = offset + (s0 // linebases) * linewidth + s0 % linebases
     b1 = offset + ((e0 - 1) // linebases) * linewidth + (e0 - 1) % linebases + 1
     with open(fasta_fn, "rb") as f:
+        if f.read(2) == b"\x1f\x8b":
+            # `samtools faidx` also serves bgzip-compressed references through their .gzi index; byte offsets of the .fai
+            # mean nothing inside a compressed stream, so refuse loudly instead of returning garbage
+            raise ValueError("[ERROR] %s is gzip / bgzip compressed: decompress it (and re-run samtools faidx) before use" % fasta_fn)
         f.seek(b0)
         raw = f.read(b1 - b0)
     return raw.replace(b"\n", b"").replace(b"\r", b"").decode().upper()

@@ -131,11 +131,67 @@ def write_bam(path, refs, reads, block_payload=3000):
         f.write(out)
 
 
+def _aligned_positions(r):
+    """{0-based reference position: query index} of the aligned (M / = / X) bases of a read"""
+    out, rp, qp = {}, r["pos"], 0
+    for op, n in r["cigar"]:
+        if op in "M=X":
+            for k in range(n):
+                out[rp + k] = qp + k
+        if op in CONSUMES_REF:
+            rp += n
+        if op in CONSUMES_QUERY:
+            qp += n
+    return out
+
+
+def _with_overlaps_softened(reads, ref_index, start, end, excl_flags, min_mq, max_depth):
+    """mpileup's read-pair overlap handling (on by default), naive form: copies of the reads with the qualities of overlapping
+    mates adjusted.  Only reads that make it into the pileup take part (same acceptance rules and max-depth cut as below);
+    the mate that entered first keeps min(200, qa + qb) where the bases agree, the better base keeps int(0.8 * q) where they
+    differ, the other base drops to 0."""
+    out, active_ends, by_name, prev_start = [], [], {}, 0
+    for r in reads:
+        r = dict(r)
+        used = not (r["ref"] != ref_index or (r["flag"] & excl_flags) or (r["flag"] & 4) or r["mapq"] < min_mq)
+        used = used and not ((r["flag"] & 1) and not (r["flag"] & 2))
+        used = used and bool(r["cigar"]) and bool(r["seq"]) and sum(n for op, n in r["cigar"] if op in CONSUMES_QUERY) == len(r["seq"])
+        rl = ref_len_of(r["cigar"]) if r["cigar"] else 0
+        used = used and rl > 0 and not (r["pos"] >= end or r["pos"] + rl <= start - 1)
+        if used and max_depth > 0 and sum(1 for e in active_ends if e > r["pos"]) >= max_depth:
+            used = False
+        if used:
+            active_ends.append(r["pos"] + rl)
+            if (r["flag"] & 1) and r["qual"] is not None:
+                r["qual"] = list(r["qual"])
+                mate = by_name.get(r["name"])
+                if mate is not None and mate["pos"] + ref_len_of(mate["cigar"]) > r["pos"]:
+                    # htslib edits the qualities when the second mate is pushed, with the iterator standing at the start of the
+                    # read pushed before it: the first mate's columns up to there were printed with the old values (this only
+                    # shows on deletion placeholders, which print the quality of the base AFTER the deletion)
+                    mate.setdefault("qual_before", list(mate["qual"]))
+                    mate.setdefault("adjusted_from", prev_start + 1)
+                    pa, pb = _aligned_positions(mate), _aligned_positions(r)
+                    for p in sorted(set(pa) & set(pb)):
+                        qa, qb = pa[p], pb[p]
+                        if mate["seq"][qa] == r["seq"][qb]:
+                            mate["qual"][qa], r["qual"][qb] = min(200, mate["qual"][qa] + r["qual"][qb]), 0
+                        elif mate["qual"][qa] >= r["qual"][qb]:
+                            mate["qual"][qa], r["qual"][qb] = int(0.8 * mate["qual"][qa]), 0
+                        else:
+                            mate["qual"][qa], r["qual"][qb] = 0, int(0.8 * r["qual"][qb])
+                by_name.setdefault(r["name"], r)
+            prev_start = r["pos"]
+        out.append(r)
+    return out
+
+
 def mpileup_rows(reads, ref_index, ctg, start, end, bed=None, excl_flags=2316, min_mq=0, max_depth=8000, ref_seq=None,
                  ref_start=1):
     """Naive per-position pileup -> mpileup text (7 columns).  start / end 1-based inclusive; bed: 0-based [b, e) intervals."""
     cols = {}                                       # 1-based position -> list of (token, bq, mq)
     active_ends = []
+    reads = _with_overlaps_softened(reads, ref_index, start, end, excl_flags, min_mq, max_depth)
     for r in reads:
         if r["ref"] != ref_index or (r["flag"] & excl_flags) or (r["flag"] & 4) or r["mapq"] < min_mq:
             continue
@@ -178,8 +234,9 @@ def mpileup_rows(reads, ref_index, ctg, start, end, bed=None, excl_flags=2316, m
                 rp += n
                 qp += n
             elif op == "D":
-                bq = min(qual[qp], 93) if qp < len(qual) else 0
                 for k in range(n):
+                    src = r["qual_before"] if (rp + k + 1) < r.get("adjusted_from", 0) else qual
+                    bq = min(src[qp], 93) if qp < len(src) else 0
                     cols.setdefault(rp + k + 1, []).append(("#" if rev else "*", bq, mq))
                 rp += n
             elif op == "N":

@@ -57,6 +57,19 @@ def _random_reads(rng, n, ref_lens, paired_frac=0.0, weird=True):
         mapq = int(rng.choice([0, 3, 19, 20, 60, 60, 60, 120, 255]))
         reads.append(dict(name="r%d" % i, flag=flag, ref=ref, pos=pos, mapq=mapq, cigar=cigar, seq=seq, qual=qual,
                           cg_tag=bool(rng.random() < 0.1)))               # some CIGARs travel in the CG tag
+    # mates: a second read under the same name, a little downstream, same CIGAR, bases partly disagreeing - the overlap rule
+    # (agree: sum of the qualities on the first mate; differ: 0.8 x the better one; the other base -> 0) has to kick in
+    for r in [r for r in reads if (r["flag"] & 3) == 3 and not (r["flag"] & (8 | 256 | 2048))]:
+        if rng.random() < 0.6:
+            m = dict(r)
+            m["pos"] = min(r["pos"] + int(rng.integers(0, 90)), ref_lens[r["ref"]] - 450)
+            m["flag"] = (r["flag"] & ~(16 | 64)) | 128 | (16 if rng.random() < 0.5 else 0)
+            seq = list(r["seq"])
+            for k in rng.integers(0, len(seq), size=max(1, len(seq) // 6)).tolist():
+                seq[k] = str(rng.choice(list("ACGT")))
+            m["seq"] = "".join(seq)
+            m["qual"] = None if r["qual"] is None or rng.random() < 0.05 else [int(q) for q in rng.integers(0, 100, size=len(seq))]
+            reads.append(m)
     reads.sort(key=lambda r: (r["ref"], r["pos"]))
     return reads
 
@@ -169,3 +182,24 @@ def test_producers_survive_corrupt_input(tmp_path):
         except CtoError:
             outcomes["err"] += 1
     assert outcomes["ok"] + outcomes["err"] == 200 and outcomes["err"] > 20
+
+
+def test_pack_from_bam_is_invariant_to_the_thread_count(tmp_path, monkeypatch):
+    """the multi-threaded range path (CTO_PACK_THREADS > 1: position ranges piled up independently, then merged) yields the
+    pack the single-threaded path yields"""
+    from clairs_to_amd.pack import ColumnPack
+    rng = np.random.default_rng(9)
+    L = 60000
+    ref = "".join(rng.choice(list("ACGT"), size=L))
+    reads = _random_reads(rng, 1500, [L], paired_frac=0.0)
+    bam = str(tmp_path / "t.bam")
+    write_bam(bam, [("chrA", L)], reads, block_payload=4000)
+    bed = [(a, a + 40) for a in range(100, L - 100, 97)]
+    packs = {}
+    for nt in ("1", "3", "8", "13"):
+        monkeypatch.setenv("CTO_PACK_THREADS", nt)
+        packs[nt] = {bedded: _pack_arrays(ColumnPack.from_bam(bam, "chrA", 1, L, ref, 1, bed=bed if bedded else None)) for bedded in (False, True)}
+    for nt in ("3", "8", "13"):
+        for bedded in (False, True):
+            _assert_same(packs[nt][bedded], packs["1"][bedded])
+    assert len(packs["1"][False]["col_pos"]) > 40000 and len(packs["1"][True]["col_pos"]) > 15000
