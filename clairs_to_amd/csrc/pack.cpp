@@ -55,81 +55,153 @@ void pack_begin(cto_pack* p, size_t entries_hint, size_t cols_hint) {
     p->key_str_off.push_back(0);
 }
 
+// Distinct-key bookkeeping of one indel-carrying read-base: returns the entry's kind bits (1 ins, 2 del, 3 longer than
+// max_indel_length) and the id of its Counter key within the column (first-seen order); a new key also gets its key_meta,
+// its merged candidate-extraction group and its alt_info string.  `nkeys_col` counts the column's keys so far.
+static int intern_indel(cto_pack* p, ColumnScratch& sc, int* nkeys_col, int code, int tkind, const char* seq, int seqlen, int64_t ri,
+                        const char* ref_seq, size_t ref_len, int max_indel_length, uint32_t* kind_out, uint32_t* kid_out, std::string* err) {
+    std::string& keybuf = sc.keybuf;
+    std::string& groupbuf = sc.groupbuf;
+    uint32_t kind = uint32_t(tkind), kid = 0;
+    const int gate_len = (tkind == 1) ? seqlen : seqlen + 1;
+    const bool overlong = gate_len > max_indel_length;
+    if (overlong) kind = 3;
+    // distinct Counter key: base char + sign + sequence, case-sensitive
+    keybuf.clear();
+    keybuf.push_back(char('0' + code));
+    keybuf.push_back(tkind == 1 ? '+' : '-');
+    keybuf.append(seq, size_t(seqlen));
+    auto it = sc.keymap.find(keybuf);
+    if (it == sc.keymap.end()) {
+        if (*nkeys_col >= kMaxKeysPerCol) { set_err(err, "more than %d distinct indel keys in one column", kMaxKeysPerCol); return CTO_EUNSUPPORTED; }
+        kid = uint32_t((*nkeys_col)++);
+        sc.keymap.emplace(keybuf, int(kid));
+        const bool fwd = (code < 4) || code == 8 || code == 10;
+        p->key_meta.push_back(uint8_t(tkind | (fwd ? 4 : 0) | (overlong ? 8 : 0)));
+        // merged allele for candidate extraction: insertions by upper-cased anchor + sequence,
+        // deletions by length (extract_candidates_calling.py:118-126)
+        static const char kAnchor[] = "ACGTACGT*#NN";
+        groupbuf.clear();
+        if (tkind == 1) {
+            groupbuf.push_back('I');
+            groupbuf.push_back(kAnchor[code]);
+            for (int j = 0; j < seqlen; ++j) groupbuf.push_back(up(seq[j]));
+        } else {
+            groupbuf = "D" + std::to_string(seqlen);
+        }
+        auto gi = sc.groupmap.find(groupbuf);
+        if (gi == sc.groupmap.end()) gi = sc.groupmap.emplace(groupbuf, int(sc.groupmap.size())).first;
+        p->key_group.push_back(int32_t(gi->second));
+        // merged alt_info key
+        if (tkind == 1) {
+            p->key_str.push_back('I');
+            p->key_str.push_back(kAnchor[code]);
+            for (int j = 0; j < seqlen; ++j) p->key_str.push_back(up(seq[j]));
+        } else {
+            p->key_str.push_back('D');
+            // chunk_ref_seq[:len+1] with chunk_ref_seq = ref[pos : pos+max_indel_length].upper()
+            int64_t take = std::min<int64_t>(seqlen + 1, max_indel_length);
+            take = std::min<int64_t>(take, int64_t(ref_len) - ri);
+            for (int64_t j = 0; j < take; ++j) p->key_str.push_back(up(ref_seq[ri + j]));
+        }
+        p->key_str_off.push_back(int64_t(p->key_str.size()));
+    } else {
+        kid = uint32_t(it->second);
+    }
+    *kind_out = kind;
+    *kid_out = kid;
+    return CTO_OK;
+}
+
+static inline void column_scratch_reset(ColumnScratch& sc) {     // clear() walks the bucket array: skip it for the (majority of) columns without indels
+    if (!sc.keymap.empty()) sc.keymap.clear();
+    if (!sc.groupmap.empty()) sc.groupmap.clear();
+}
+
+static inline void column_end(cto_pack* p, int64_t pos, int64_t ri, const char* ref_seq) {
+    p->col_pos.push_back(int32_t(pos));
+    const char ru = up(ref_seq[ri]);
+    const bool acgt = ru == 'A' || ru == 'C' || ru == 'G' || ru == 'T';
+    p->col_ref.push_back(uint8_t(ref_code_of(ref_seq[ri]) | (acgt ? 0 : 0x80)));
+    p->col_off.push_back(int64_t(p->entries.size()));
+    p->key_off.push_back(int32_t(p->key_meta.size()));
+}
+
 int append_column(cto_pack* p, ColumnScratch& sc, int64_t pos, int64_t ri, const char* ref_seq, size_t ref_len,
                   int max_indel_length, const Tok* toks, int n, std::string* err) {
     if (n > kMaxDepth) { set_err(err, "column depth %d > %d unsupported", n, kMaxDepth); return CTO_EUNSUPPORTED; }
-    sc.keymap.clear();
-    sc.groupmap.clear();
-    std::string& keybuf = sc.keybuf;
-    std::string& groupbuf = sc.groupbuf;
+    column_scratch_reset(sc);
     int nkeys_col = 0;
     for (int i = 0; i < n; ++i) {
         const Tok& t = toks[i];
         const int bq = std::max(0, std::min(t.bq, 127));
         const int mq = std::max(0, std::min(t.mq, 255));
-        uint32_t kind = uint32_t(t.kind), kid = 0;
+        uint32_t kind = 0, kid = 0;
         if (t.kind != 0) {
-            const int gate_len = (t.kind == 1) ? t.seqlen : t.seqlen + 1;
-            const bool overlong = gate_len > max_indel_length;
-            if (overlong) kind = 3;
-            // distinct Counter key: base char + sign + sequence, case-sensitive
-            keybuf.clear();
-            keybuf.push_back(char('0' + t.code));
-            keybuf.push_back(t.kind == 1 ? '+' : '-');
-            keybuf.append(t.seq, size_t(t.seqlen));
-            auto it = sc.keymap.find(keybuf);
-            if (it == sc.keymap.end()) {
-                if (nkeys_col >= kMaxKeysPerCol) { set_err(err, "more than %d distinct indel keys in one column", kMaxKeysPerCol); return CTO_EUNSUPPORTED; }
-                kid = uint32_t(nkeys_col++);
-                sc.keymap.emplace(keybuf, int(kid));
-                const bool fwd = (t.code < 4) || t.code == 8 || t.code == 10;
-                p->key_meta.push_back(uint8_t(t.kind | (fwd ? 4 : 0) | (overlong ? 8 : 0)));
-                // merged allele for candidate extraction: insertions by upper-cased anchor + sequence,
-                // deletions by length (extract_candidates_calling.py:118-126)
-                static const char kAnchor[] = "ACGTACGT*#NN";
-                groupbuf.clear();
-                if (t.kind == 1) {
-                    groupbuf.push_back('I');
-                    groupbuf.push_back(kAnchor[t.code]);
-                    for (int j = 0; j < t.seqlen; ++j) groupbuf.push_back(up(t.seq[j]));
-                } else {
-                    groupbuf = "D" + std::to_string(t.seqlen);
-                }
-                auto gi = sc.groupmap.find(groupbuf);
-                if (gi == sc.groupmap.end()) gi = sc.groupmap.emplace(groupbuf, int(sc.groupmap.size())).first;
-                p->key_group.push_back(int32_t(gi->second));
-                // merged alt_info key
-                if (t.kind == 1) {
-                    p->key_str.push_back('I');
-                    p->key_str.push_back(kAnchor[t.code]);
-                    for (int j = 0; j < t.seqlen; ++j) p->key_str.push_back(up(t.seq[j]));
-                } else {
-                    p->key_str.push_back('D');
-                    // chunk_ref_seq[:len+1] with chunk_ref_seq = ref[pos : pos+max_indel_length].upper()
-                    int64_t take = std::min<int64_t>(t.seqlen + 1, max_indel_length);
-                    take = std::min<int64_t>(take, int64_t(ref_len) - ri);
-                    for (int64_t j = 0; j < take; ++j) p->key_str.push_back(up(ref_seq[ri + j]));
-                }
-                p->key_str_off.push_back(int64_t(p->key_str.size()));
-            } else {
-                kid = uint32_t(it->second);
-            }
+            const int rc = intern_indel(p, sc, &nkeys_col, t.code, t.kind, t.seq, t.seqlen, ri, ref_seq, ref_len, max_indel_length, &kind, &kid, err);
+            if (rc != CTO_OK) return rc;
         }
         p->entries.push_back(uint32_t(t.code) | (kind << 4) | (uint32_t(bq) << 6) | (uint32_t(mq) << 13) | (kid << 21));
     }
-    p->col_pos.push_back(int32_t(pos));
-    {
-        const char ru = up(ref_seq[ri]);
-        const bool acgt = ru == 'A' || ru == 'C' || ru == 'G' || ru == 'T';
-        p->col_ref.push_back(uint8_t(ref_code_of(ref_seq[ri]) | (acgt ? 0 : 0x80)));
-    }
-    p->col_off.push_back(int64_t(p->entries.size()));
-    p->key_off.push_back(int32_t(p->key_meta.size()));
+    column_end(p, pos, ri, ref_seq);
     return CTO_OK;
 }
 
 // Concatenates per-thread packs of consecutive position ranges (offsets re-based); nullptr + *err when they overlap.
 std::unique_ptr<cto_pack> merge_parts(std::vector<std::unique_ptr<cto_pack>>& parts, std::string* err) {
+    if (parts.size() > 2) {
+        // Parallel form: the destination arrays are sized once (the entry array without a zero fill) and every part copies
+        // itself to its offsets on its own thread - the serial concatenation below was half of a multi-threaded call's time.
+        const size_t n = parts.size();
+        std::vector<int64_t> e0(n + 1, 0), c0(n + 1, 0), k0(n + 1, 0), s0(n + 1, 0);
+        int64_t last_pos = -1;
+        for (size_t t = 0; t < n; ++t) {
+            const cto_pack& q = *parts[t];
+            if (!q.col_pos.empty()) {
+                if (q.col_pos.front() <= last_pos) { *err = "pileup rows not in increasing position order"; return nullptr; }
+                last_pos = q.col_pos.back();
+            }
+            e0[t + 1] = e0[t] + int64_t(q.entries.size());
+            c0[t + 1] = c0[t] + int64_t(q.col_pos.size());
+            k0[t + 1] = k0[t] + int64_t(q.key_meta.size());
+            s0[t + 1] = s0[t] + int64_t(q.key_str.size());
+        }
+        std::unique_ptr<cto_pack> p(new cto_pack());
+        p->entries.resize(size_t(e0[n]));
+        p->col_pos.resize(size_t(c0[n]));
+        p->col_ref.resize(size_t(c0[n]));
+        p->col_off.resize(size_t(c0[n]) + 1);
+        p->key_off.resize(size_t(c0[n]) + 1);
+        p->key_meta.resize(size_t(k0[n]));
+        p->key_group.resize(size_t(k0[n]));
+        p->key_str_off.resize(size_t(k0[n]) + 1);
+        p->key_str.resize(size_t(s0[n]));
+        p->col_off[0] = 0;
+        p->key_off[0] = 0;
+        p->key_str_off[0] = 0;
+        auto copy_part = [&](size_t t) {
+            const cto_pack& q = *parts[t];
+            if (!q.entries.empty()) memcpy(p->entries.data() + e0[t], q.entries.data(), q.entries.size() * sizeof(uint32_t));
+            if (!q.col_pos.empty()) {
+                memcpy(p->col_pos.data() + c0[t], q.col_pos.data(), q.col_pos.size() * sizeof(int32_t));
+                memcpy(p->col_ref.data() + c0[t], q.col_ref.data(), q.col_ref.size());
+            }
+            for (size_t i = 1; i < q.col_off.size(); ++i) p->col_off[size_t(c0[t]) + i] = q.col_off[i] + e0[t];
+            for (size_t i = 1; i < q.key_off.size(); ++i) p->key_off[size_t(c0[t]) + i] = q.key_off[i] + int32_t(k0[t]);
+            if (!q.key_meta.empty()) {
+                memcpy(p->key_meta.data() + k0[t], q.key_meta.data(), q.key_meta.size());
+                memcpy(p->key_group.data() + k0[t], q.key_group.data(), q.key_group.size() * sizeof(int32_t));
+            }
+            for (size_t i = 1; i < q.key_str_off.size(); ++i) p->key_str_off[size_t(k0[t]) + i] = q.key_str_off[i] + s0[t];
+            if (!q.key_str.empty()) memcpy(&p->key_str[size_t(s0[t])], q.key_str.data(), q.key_str.size());
+        };
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < n; ++t) th.emplace_back(copy_part, t);
+        copy_part(0);
+        for (auto& x : th) x.join();
+        for (auto& q : parts) q.reset();
+        return p;
+    }
     std::unique_ptr<cto_pack> p(parts[0].release());
     for (size_t t = 1; t < parts.size(); ++t) {
         const cto_pack& q = *parts[t];
@@ -160,13 +232,27 @@ using namespace cto;
 
 namespace {
 
+struct IndelTok { int idx, kind; const char* seq; int seqlen; };
+
+// character classes of the mpileup base string: 0..11 = read-base with that pack code, 12 = indel sign, 13 = '^', 14 = skipped
+struct CharClass {
+    uint8_t t[256];
+    constexpr CharClass() : t() {
+        for (int i = 0; i < 256; ++i) t[i] = 14;
+        t[int('A')] = 0; t[int('C')] = 1; t[int('G')] = 2; t[int('T')] = 3; t[int('a')] = 4; t[int('c')] = 5; t[int('g')] = 6; t[int('t')] = 7;
+        t[int('*')] = 8; t[int('#')] = 9; t[int('N')] = 10; t[int('n')] = 11; t[int('+')] = 12; t[int('-')] = 12; t[int('^')] = 13;
+    }
+};
+constexpr CharClass kCharClassTable{};
+static const uint8_t* const kCharClass = kCharClassTable.t;
+
 // Parses the rows in [text, text + len) into `p` (offsets local to p).  Thread-safe: no shared state.
 int parse_rows(const char* text, size_t len, const char* ref_seq, int64_t ref_start, size_t ref_len, int max_indel_length,
                cto_pack* p, std::string* err) {
     // one read-base is >= 3 characters of a row (base, BQ, MQ), one row >= ~40: reserve once instead of growing
     pack_begin(p, len / 3 + 16, len / 40 + 16);
-    std::vector<Tok> toks;
-    toks.reserve(1024);
+    std::vector<IndelTok> indels;
+    indels.reserve(64);
     ColumnScratch sc;
     const char* cur = text;
     const char* end = text + len;
@@ -181,8 +267,11 @@ int parse_rows(const char* text, size_t len, const char* ref_seq, int64_t ref_st
             const char* f[8];
             int nf = 0;
             f[nf++] = cur;
-            for (const char* q = cur; q < row_end && nf < 8; ++q)
-                if (*q == '\t') f[nf++] = q + 1;
+            for (const char* q = cur; nf < 8;) {                  // memchr: the base / quality fields are thousands of characters long
+                q = static_cast<const char*>(memchr(q, '\t', size_t(row_end - q)));
+                if (!q) break;
+                f[nf++] = ++q;
+            }
             if (nf < 7) {
                 set_err(err, "mpileup row has %d fields, need >= 7 (is --output-MQ on?)", nf);
                 return CTO_EINVAL;
@@ -207,36 +296,54 @@ int parse_rows(const char* text, size_t len, const char* ref_seq, int64_t ref_st
             const int nq = int(fend(5) - f[5]);
             const char* ms = f[6];
             const int nm = int(fend(6) - f[6]);
-            // ---- tokenise the base string (reference :124-144) ----
-            toks.clear();
+            // ---- tokenise the base string (reference :124-144), one pass straight into pack entries ----
+            // read-bases become entries (code only) as they are met; an indel attaches to the entry before it and is remembered
+            // in `indels`; the quality characters are merged in afterwards in one tight loop
+            const size_t e0 = p->entries.size();
+            p->entries.resize(e0 + size_t(be - bs));             // a base string never yields more read-bases than characters
+            uint32_t* ent = p->entries.data() + e0;
+            int nt = 0;
+            indels.clear();
             for (const char* q = bs; q < be;) {
-                char c = *q;
-                if (c == '+' || c == '-') {
+                const uint8_t cl = kCharClass[uint8_t(*q)];
+                if (cl < 12) {                                    // a read-base
+                    ent[nt++] = cl;
                     ++q;
-                    int adv = 0;
+                } else if (cl == 12) {                            // '+' / '-': <count><sequence>
+                    const char sign = *q++;
+                    int64_t adv = 0;
                     while (q < be && *q >= '0' && *q <= '9') { adv = adv * 10 + (*q - '0'); ++q; }
-                    if (toks.empty()) { set_err(err, "indel token before any base at pos %lld", (long long)pos); return CTO_EINVAL; }
-                    int avail = int(std::min<int64_t>(adv, be - q));
-                    toks.back().kind = (c == '+') ? 1 : 2;
-                    toks.back().seq = q;
-                    toks.back().seqlen = avail;
+                    if (nt == 0) { set_err(err, "indel token before any base at pos %lld", (long long)pos); return CTO_EINVAL; }
+                    const int avail = int(std::min<int64_t>(adv, be - q));
+                    if (!indels.empty() && indels.back().idx == nt - 1) indels.pop_back();      // a second indel on one base replaces the first
+                    indels.push_back(IndelTok{nt - 1, sign == '+' ? 1 : 2, q, avail});
                     q += adv;  // the reference advances by `adv` characters in total
-                    continue;
+                } else if (cl == 13) {                            // '^' + the mapping-quality character of a read start
+                    q += 2;
+                } else {
+                    ++q;                                          // '$' and anything else
                 }
-                int code = base_code(c);
-                if (code >= 0) {
-                    toks.push_back(Tok{code, 0, nullptr, 0, 0, 0});
-                } else if (c == '^') {
-                    ++q;  // skip the mapping-quality character of a read start
-                }
-                ++q;
             }
             // zip(base_list, mapping_quality) / zip(base_list, base_quality) truncate: entries without a
             // quality character contribute to no counter; they are dropped here (only malformed rows).
-            const int n = int(std::min<size_t>(toks.size(), size_t(std::min(nq, nm))));
-            for (int i = 0; i < n; ++i) { toks[size_t(i)].bq = qs[i] - 33; toks[size_t(i)].mq = ms[i] - 33; }
-            const int rc = append_column(p, sc, pos, ri, ref_seq, ref_len, max_indel_length, toks.data(), n, err);
-            if (rc != CTO_OK) return rc;
+            const int n = int(std::min<size_t>(size_t(nt), size_t(std::min(nq, nm))));
+            if (n > kMaxDepth) { set_err(err, "column depth %d > %d unsupported", n, kMaxDepth); return CTO_EUNSUPPORTED; }
+            for (int i = 0; i < n; ++i) {
+                const int bq = std::max(0, std::min(int(qs[i]) - 33, 127)), mq = std::max(0, std::min(int(ms[i]) - 33, 255));
+                ent[i] |= (uint32_t(bq) << 6) | (uint32_t(mq) << 13);
+            }
+            column_scratch_reset(sc);
+            int nkeys_col = 0;
+            for (const IndelTok& it : indels) {
+                if (it.idx >= n) break;
+                uint32_t kind = 0, kid = 0;
+                const int rc = intern_indel(p, sc, &nkeys_col, int(ent[it.idx] & 15u), it.kind, it.seq, it.seqlen, ri, ref_seq, ref_len,
+                                            max_indel_length, &kind, &kid, err);
+                if (rc != CTO_OK) return rc;
+                ent[it.idx] |= (kind << 4) | (kid << 21);
+            }
+            p->entries.resize(e0 + size_t(n));
+            column_end(p, pos, ri, ref_seq);
         }
         cur = eol + 1;
     }

@@ -9,12 +9,24 @@
 #include <vector>
 #include "common.h"
 
+// resize() without the zero fill: the entry array (tens of MB per chunk) is always overwritten right after it is grown - by
+// the tokeniser's single pass and by the threads of the parallel merge
+template <class T>
+struct default_init_alloc : std::allocator<T> {
+    template <class U> struct rebind { using other = default_init_alloc<U>; };
+    template <class U, class... A>
+    void construct(U* p, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new (static_cast<void*>(p)) U;
+        else ::new (static_cast<void*>(p)) U(std::forward<A>(a)...);
+    }
+};
+
 struct cto_pack {
     std::vector<int32_t> col_pos;
     std::vector<uint8_t> col_ref;
     std::vector<int64_t> col_off;   // n_cols + 1
     std::vector<int32_t> key_off;   // n_cols + 1
-    std::vector<uint32_t> entries;
+    std::vector<uint32_t, default_init_alloc<uint32_t>> entries;
     std::vector<uint8_t> key_meta;
     std::vector<int32_t> key_group;
     std::vector<int64_t> key_str_off;  // n_keys + 1
