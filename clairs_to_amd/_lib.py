@@ -65,6 +65,7 @@ SYMBOLS = {
     "cto_cvt_create_packed": (C.c_int, [c_vp, c_i64, C.POINTER(CvtCfg), C.POINTER(c_vp)]),
     "cto_bigru_create_packed": (C.c_int, [c_vp, c_i64, C.c_int, C.POINTER(c_vp)]),
     "cto_model_manifest": (c_i64, [C.c_int, C.POINTER(CvtCfg), C.c_int, c_vp, C.c_size_t]),
+    "cto_bed_centres": (c_i64, [c_vp, C.c_size_t, C.c_char_p, c_vp, c_i64, c_vp, c_vp]),
     "cto_haplotype_filter": (C.c_int, [c_vp, C.c_size_t, C.c_char_p, c_i64, C.c_size_t, c_i64, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int,
                                        C.c_int, c_vp, c_vp]),
     "cto_vcf_rows_batch": (c_i64, [C.c_char_p, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_double,

@@ -62,18 +62,30 @@ def run_pipeline(eng, chunk_args, producers=4, writers=2, depth=None, stats=None
     n_rows = 0
     local = threading.local()
 
+    import time
+
+    def clock(key, t0):
+        if stats is not None:
+            stats[key] = stats.get(key, 0.0) + time.perf_counter() - t0      # summed over threads: thread-seconds per stage
+
     def produce(a):
+        t0 = time.perf_counter()
         if getattr(local, "stream", None) is None:
             local.stream = torch.cuda.Stream(device)            # one copy stream per producer thread
-        return prepare_chunk(a, device=device, copy_stream=local.stream)
+        try:
+            return prepare_chunk(a, device=device, copy_stream=local.stream)
+        finally:
+            clock("produce_s", t0)
 
     free_pinned = deque()                                        # page-locked buffer sets, re-used chunk after chunk
 
     def finish(a, prep, launched):
+        t0 = time.perf_counter()
         try:
             return finish_chunk(a, eng.K, prep, launched)
         finally:
             free_pinned.append(launched["pinned"])
+            clock("finish_s", t0)
 
     with ThreadPoolExecutor(max_workers=producers) as prod, ThreadPoolExecutor(max_workers=writers) as wr:
         pending, writing = deque(), deque()
@@ -88,13 +100,17 @@ def run_pipeline(eng, chunk_args, producers=4, writers=2, depth=None, stats=None
         feed()
         while pending:
             a, fut = pending.popleft()
+            t0 = time.perf_counter()
             prep = fut.result()
+            clock("launcher_waits_for_producer_s", t0)
             feed()
             if prep is None:
                 print("[INFO] {} total processed positions: 0".format(a.ctg_name), file=sys.stderr)
                 continue
+            t0 = time.perf_counter()
             launched = launch_chunk(eng, prep, want_probs=bool(getattr(a, "predict_fn", None)),
                                     pinned=free_pinned.popleft() if free_pinned else None)
+            clock("launch_s", t0)
             writing.append(wr.submit(finish, a, prep, launched))
             if stats is not None:
                 stats["sites"] = stats.get("sites", 0) + len(prep["sites"])

@@ -5,7 +5,10 @@
 // VcfWriter.write_row (shared/vcf.py:144-185).  The arg-max and QUAL come from the device epilogue (posterior.hip); what is
 // left is string work, which at 16 ms per 4 000 sites in Python was a third of a chunk's wall time.
 // clairs_to_amd/call_variants.py:vcf_row is the same logic one site at a time; tests hold the two equal on every fixture.
+#include <algorithm>
+#include <climits>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -185,4 +188,56 @@ extern "C" int64_t cto_vcf_rows_batch(const char* chrom, int64_t n, const int32_
     }
     counts[0] = n_rows; counts[1] = n_sites; counts[2] = n_lowcov; counts[3] = n_clamped;
     return int64_t(used);
+}
+
+// Candidate BED chunk file -> window centres (src/create_tensor_pileup_calling.py:347-370): rows `ctg <tab> x-17 <tab> x+17
+// [<tab> type]` of contig `ctg`; position = start + 1, end = end + 1, centre = end - 18 when position < 1 (window clipped at
+// the contig start) else position + (end - position) / 2 - 1.  Writes up to `cap` centres in file order (the caller sorts and
+// de-duplicates: the reference keys a dict by them), span[0] / span[1] = min position / max end over the rows, and
+// *has_types = 1 when some row carries the optional fourth column.  Returns the number of rows of the contig, or < 0.
+extern "C" int64_t cto_bed_centres(const char* text, size_t len, const char* ctg, int32_t* out, int64_t cap, int64_t* span, int* has_types) {
+    CTO_REQUIRE(text && ctg && out && span && has_types, CTO_EINVAL, "cto_bed_centres: null argument");
+    const size_t cl = strlen(ctg);
+    int64_t n = 0, lo = INT64_MAX, hi = 0;
+    *has_types = 0;
+    for (const char* cur = text; cur < text + len;) {
+        const char* eol = static_cast<const char*>(memchr(cur, '\n', size_t(text + len - cur)));
+        if (!eol) eol = text + len;
+        const char* e = eol;
+        while (e > cur && (e[-1] == '\r' || e[-1] == ' ' || e[-1] == '\t')) --e;      // rstrip
+        const char* t1 = static_cast<const char*>(memchr(cur, '\t', size_t(e - cur)));
+        const char* t2 = t1 ? static_cast<const char*>(memchr(t1 + 1, '\t', size_t(e - t1 - 1))) : nullptr;
+        if (t2 && size_t(t1 - cur) == cl && memcmp(cur, ctg, cl) == 0) {
+            const char* t3 = static_cast<const char*>(memchr(t2 + 1, '\t', size_t(e - t2 - 1)));
+            auto to_int = [](const char* b, const char* f, int64_t* v) {
+                bool neg = false;
+                if (b < f && (*b == '-' || *b == '+')) { neg = *b == '-'; ++b; }
+                if (b >= f) return false;
+                int64_t x = 0;
+                for (; b < f; ++b) {
+                    if (*b < '0' || *b > '9') return false;
+                    x = x * 10 + (*b - '0');
+                }
+                *v = neg ? -x : x;
+                return true;
+            };
+            int64_t a = 0, b = 0;
+            CTO_REQUIRE(to_int(t1 + 1, t2, &a) && to_int(t2 + 1, t3 ? t3 : e, &b), CTO_EINVAL, "cto_bed_centres: malformed BED row '%.*s'",
+                        int(std::min<ptrdiff_t>(e - cur, 80)), cur);
+            if (t3 && !memchr(t3 + 1, '\t', size_t(e - t3 - 1))) *has_types = 1;        // exactly four columns
+            const int64_t position = a + 1, end = b + 1;
+            lo = std::min(lo, position);
+            hi = std::max(hi, end);
+            // Python's floor division for (end - position) // 2
+            const int64_t d = end - position;
+            const int64_t half = d >= 0 ? d / 2 : -((-d + 1) / 2);
+            const int64_t centre = position < 1 ? end - 16 - 2 : position + half - 1;
+            if (n < cap) out[n] = int32_t(centre);
+            ++n;
+        }
+        cur = eol + 1;
+    }
+    span[0] = lo;
+    span[1] = hi;
+    return n;
 }

@@ -2,9 +2,10 @@
 import os
 
 
-def read_region(fasta_fn, ctg, start, end):
+def read_region(fasta_fn, ctg, start, end, as_bytes=False):
     """1-based inclusive [start, end] of contig `ctg`, upper-cased like reference_sequence_from(); clipped to the
-    contig.  Needs <fasta>.fai (or <fasta without extension>.fai, as file_path_from(..., sep='.') accepts)."""
+    contig.  Needs <fasta>.fai (or <fasta without extension>.fai, as file_path_from(..., sep='.') accepts).
+    as_bytes: return `bytes` (what the C entry points and numpy take as is) instead of `str`."""
     fai = fasta_fn + ".fai"
     if not os.path.exists(fai):
         alt = ".".join(fasta_fn.split(".")[:-1]) + ".fai"
@@ -25,7 +26,7 @@ def read_region(fasta_fn, ctg, start, end):
     start = max(1, int(start))
     end = min(length, int(end))
     if end < start:
-        return ""
+        return b"" if as_bytes else ""
     s0, e0 = start - 1, end
     b0 = offset + (s0 // linebases) * linewidth + s0 % linebases
     b1 = offset + ((e0 - 1) // linebases) * linewidth + (e0 - 1) % linebases + 1
@@ -36,4 +37,5 @@ def read_region(fasta_fn, ctg, start, end):
             raise ValueError("[ERROR] %s is gzip / bgzip compressed: decompress it (and re-run samtools faidx) before use" % fasta_fn)
         f.seek(b0)
         raw = f.read(b1 - b0)
-    return raw.replace(b"\n", b"").replace(b"\r", b"").decode().upper()
+    seq = raw.replace(b"\n", b"").replace(b"\r", b"").upper()
+    return seq if as_bytes else seq.decode()

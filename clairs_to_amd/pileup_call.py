@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from .call_variants import IUPAC_TO_ACGT, VCF_HEADER, load_likelihood, vcf_rows_batch
-from .create_tensor_pileup_calling import EXPAND_REF, MAX_INDEL, load_pack, read_candidates
+from .create_tensor_pileup_calling import EXPAND_REF, MAX_INDEL, load_pack, read_candidate_positions
 from .engine import Engine
 from .fasta import read_region
 from .featurize import alt_infos_from_host
@@ -47,20 +47,20 @@ def prepare_chunk(args, device=None, copy_stream=None):
     calls release the GIL, so `call_chunks` runs several of these on a thread pool while earlier chunks are on the GPU).
     With `device` the pack is also uploaded from this (producer) thread on `copy_stream`, and `uploaded` is the event the
     compute stream has to wait for - the PCIe transfer then never blocks the thread that launches kernels.  None if empty."""
-    centres, ctg_start, ctg_end = read_candidates(args.candidates_bed_regions, args.ctg_name)
-    if not centres:
+    sites, ctg_start, ctg_end = read_candidate_positions(args.candidates_bed_regions, args.ctg_name)     # sorted, unique, int32
+    if len(sites) == 0:
         return None
     ref_start = max(1, ctg_start - EXPAND_REF)
-    ref = read_region(args.ref_fn, args.ctg_name, ref_start, ctg_end + EXPAND_REF)
+    ref = read_region(args.ref_fn, args.ctg_name, ref_start, ctg_end + EXPAND_REF, as_bytes=True)
     if not ref:
         sys.exit("[ERROR] Failed to load reference sequence from file ({}).".format(args.ref_fn))
     max_indel = MAX_INDEL if args.max_indel_length is None else args.max_indel_length
     pack = load_pack(args, ref, ref_start, ctg_start, ctg_end, max_indel)
-    prep = dict(sites=sorted(centres), ref=ref, ref_start=ref_start, pack=pack)
+    prep = dict(sites=sites, ref=ref, ref_start=ref_start, pack=pack)
     if device is not None:
         with torch.cuda.device(device), torch.cuda.stream(copy_stream if copy_stream is not None else torch.cuda.current_stream(device)):
             prep["dev_pack"] = pack.to_device(device)
-            prep["dev_sites"] = torch.tensor(prep["sites"], dtype=torch.int32).to(device)
+            prep["dev_sites"] = torch.from_numpy(sites).to(device)
             prep["uploaded"] = torch.cuda.Event()
             prep["uploaded"].record()
     return prep
@@ -84,7 +84,7 @@ def launch_chunk(eng, prep, want_probs=False, pinned=None):
                 t.record_stream(main)
         else:
             dp = prep["pack"].to_device(device)
-            sp = torch.tensor(prep["sites"], dtype=torch.int32, device=device)
+            sp = torch.from_numpy(np.ascontiguousarray(prep["sites"], dtype=np.int32)).to(device)
         res = eng.run_device(dp, sp)
         feat = res["features"]
         src = dict(site_info=feat.site_info, colvec=feat.colvec, sitefirst=feat.sitefirst, keycnt=feat.keycnt, keyfirst=feat.keyfirst,
@@ -116,7 +116,7 @@ def finish_chunk(args, K, prep, launched):
     alt_buf, alt_off = alt_infos_from_host(pack, info, h["colvec"], h["sitefirst"], h["keycnt"], h["keyfirst"])
     dec, qual = h["decision"], h["qual"]
     sites_arr = np.asarray(sites, dtype=np.int64)
-    centre = np.frombuffer(ref.encode("latin-1"), dtype=np.uint8)[sites_arr - ref_start]
+    centre = np.frombuffer(ref if isinstance(ref, bytes) else ref.encode("latin-1"), dtype=np.uint8)[sites_arr - ref_start]
     info[~np.isin(centre, np.frombuffer(b"ACGT", dtype=np.uint8)), 3] |= 1      # predict.py:219-228: centre not in ACGT -> no row
     # every record of the chunk in one C call (cto_vcf_rows_batch): the per-site Python formatting was a third of a chunk
     text, cnt = vcf_rows_batch(args.ctg_name, sites_arr, centre, alt_buf, alt_off, info, dec, qual, K, show_ref=args.show_ref,

@@ -258,6 +258,12 @@ int64_t cto_vcf_rows_batch(const char* chrom, int64_t n, const int32_t* pos, con
                            const int64_t* alt_off, const int32_t* site_info, const int32_t* decision, const double* qual,
                            int K, int show_ref, double qual_pass, char* buf, size_t cap, int64_t* counts);
 
+/* Candidate BED chunk file (text of `<ctg>.<i>_<n>_snv`, extract_candidates_calling.py:450-488) -> window centres, as
+ * create_tensor_pileup_calling.py:347-370 derives them: out[0..min(n, cap)) in file order (sort + de-duplicate to get the
+ * reference's dict keys), span[0] / span[1] = ctg_start / ctg_end of :359-360, *has_types = 1 when a row carries the
+ * optional fourth column.  Returns the number of rows of contig `ctg`, or a negative error code. */
+int64_t cto_bed_centres(const char* text, size_t len, const char* ctg, int32_t* out, int64_t cap, int64_t* span, int* has_types);
+
 /* ------------------------------------------------------------------------------------------------
  * Long-read post-calling filters (src/haplotype_filtering.py:344-707): the read-level evidence of
  * every call of ONE mpileup job, from the nine-column text of

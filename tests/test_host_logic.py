@@ -143,3 +143,26 @@ def test_platform_table_matches_reference_names():
         resolve_platform("pacbio")
     with pytest.raises(ValueError):
         resolve_platform("", exit_on_unknown=False)
+
+
+def test_c_bed_reader_equals_the_row_loop(tmp_path):
+    """cto_bed_centres (one C call per chunk file) against read_candidates, the row-by-row restatement of
+    create_tensor_pileup_calling.py:347-370: windows clipped at the contig start, other contigs, duplicates, a type column"""
+    from clairs_to_amd.create_tensor_pileup_calling import read_candidates, read_candidate_positions
+    rng = np.random.default_rng(4)
+    rows = []
+    for x in sorted(set(rng.integers(1, 5000, size=700).tolist()) | {1, 2, 17, 18, 19}):
+        rows.append("chr2\t%d\t%d" % (max(x - 17, 1) if x % 3 else x - 17, x + 17))
+    rows += ["chr20\t100\t134", "chr2\t40\t74", "chr2\t40\t74\tsnv", "", "chr2\t7"]
+    bed = tmp_path / "c.bed"
+    bed.write_text("\n".join(rows) + "\n")
+    centres, s, e = read_candidates(str(bed), "chr2")
+    pos, s2, e2 = read_candidate_positions(str(bed), "chr2")
+    assert pos.dtype == np.int32 and pos.tolist() == sorted(centres) and (s, e) == (s2, e2)
+    pos, s2, e2 = read_candidate_positions(str(bed), "chrZ")
+    assert len(pos) == 0 and e2 == 0
+    bad = tmp_path / "bad.bed"
+    bad.write_text("chr2\tx\t5\n")
+    from clairs_to_amd._lib import CtoError
+    with pytest.raises(CtoError):
+        read_candidate_positions(str(bad), "chr2")
