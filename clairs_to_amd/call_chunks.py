@@ -61,6 +61,11 @@ def run_pipeline(eng, chunk_args, producers=4, writers=2, depth=None, stats=None
     depth = depth if depth is not None else producers + 2
     n_rows = 0
     local = threading.local()
+    # The C producers split one chunk over up to 32 threads of their own (CTO_PACK_THREADS); with several producers running
+    # side by side that oversubscribes a small host (16 usable cores on the bench box: 4 producers x 8 threads measured
+    # 870-960 k sites/s from text, 4 x 32 threads 660-715 k), so the pool hands each call half of the usable cores.
+    if "CTO_PACK_THREADS" not in os.environ:
+        os.environ["CTO_PACK_THREADS"] = str(max(2, usable_cores() // 2))
 
     import time
 

@@ -75,9 +75,14 @@ def load_pack(args, ref, ref_start, ctg_start, ctg_end, max_indel):
     csrc/bam.cpp, parity unpinned) or `samtools mpileup` run exactly as the reference runs it except for `--min-BQ 0`
     (create_tensor_pileup_calling.py:426-446): one pileup serves the AFF and the NEG pass."""
     if getattr(args, "mpileup_fn", None):
-        opener = gzip.open if args.mpileup_fn.endswith(".gz") else open
-        with opener(args.mpileup_fn, "rb") as f:
-            return ColumnPack.from_mpileup(f.read(), ref, ref_start, max_indel)
+        if args.mpileup_fn.endswith(".gz"):
+            with gzip.open(args.mpileup_fn, "rb") as f:
+                return ColumnPack.from_mpileup(f.read(), ref, ref_start, max_indel)
+        import os
+        if os.path.getsize(args.mpileup_fn) == 0:
+            return ColumnPack.from_mpileup(b"", ref, ref_start, max_indel)
+        # plain text: mapped, not read - the tokeniser's threads pull the pages straight from the page cache
+        return ColumnPack.from_mpileup(np.memmap(args.mpileup_fn, dtype=np.uint8, mode="r"), ref, ref_start, max_indel)
     ext_s, ext_e = max(1, ctg_start - NPOS), ctg_end + NPOS
     if getattr(args, "bam_reader", "samtools") == "native":
         return ColumnPack.from_bam(args.tumor_bam_fn, args.ctg_name, ext_s, ext_e, ref, ref_start,

@@ -29,10 +29,17 @@ class ColumnPack:
     def from_mpileup(cls, text, ref_seq, ref_start, max_indel_length=60):
         """text: `samtools mpileup --reverse-del --output-MQ --min-BQ 0` rows of ONE contig, increasing position.
         Replaces the tokeniser of src/create_tensor_pileup_calling.py:120-144 (reference)."""
-        tb = text.encode() if isinstance(text, str) else bytes(text)
+        if isinstance(text, np.ndarray):                      # e.g. np.memmap of a text file: tokenised straight from the page cache
+            arr = text if text.dtype == np.uint8 else text.view(np.uint8)
+        else:
+            tb = text.encode() if isinstance(text, str) else bytes(text)
+            arr = np.frombuffer(tb, dtype=np.uint8)
+        n = int(arr.size)
+        if n == 0:
+            arr = np.zeros(1, dtype=np.uint8)
         rb = ref_seq.encode() if isinstance(ref_seq, str) else bytes(ref_seq)
         out = c_vp()
-        check(lib.cto_pack_from_mpileup(tb, len(tb), rb, int(ref_start), len(rb), int(max_indel_length), C.byref(out)))
+        check(lib.cto_pack_from_mpileup(arr.ctypes.data, n, rb, int(ref_start), len(rb), int(max_indel_length), C.byref(out)))
         return cls(out.value)
 
     @classmethod
