@@ -32,11 +32,18 @@ REFERENCE_PYTHON_NOTE = ("HKU-BAL/ClairS-TO v0.4.4 itself, build container (8 vC
                          "profiles/reference_cpu_timing.json)")
 
 
+def _pmc_file():
+    """newest committed rocprofv3 PMC digest (profiles/round<N>_<tag>_pmc_hbm_traffic.json, tools/collect_profiles.sh)"""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_hbm_traffic.json")))
+    return fs[-1] if fs else None
+
+
 def pmc_traffic(batch):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
-    profiles/round1_h_pmc_hbm_traffic.json, collected at batch 4096); None for any other batch."""
-    fn = os.path.join(ROOT, "profiles", "round1_h_pmc_hbm_traffic.json")
-    if batch != 4096 or not os.path.exists(fn):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate
+    passes, collected at batch 4096); None for any other batch."""
+    fn = _pmc_file()
+    if batch != 4096 or fn is None:
         return None
     k = json.load(open(fn))["kernels"]
     for name, v in k.items():
@@ -46,8 +53,8 @@ def pmc_traffic(batch):
 
 
 def pmc_traffic_featurize(batch):
-    fn = os.path.join(ROOT, "profiles", "round1_h_pmc_hbm_traffic.json")
-    if batch != 4096 or not os.path.exists(fn):
+    fn = _pmc_file()
+    if batch != 4096 or fn is None:
         return None
     tot = 0
     for name, v in json.load(open(fn))["kernels"].items():
@@ -295,7 +302,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "k_gru_layer_rot<256,256,192,2,true> (BiGRU layer 2 + fused fc1, both directions)",
                          "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(args.batch),
-                         "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/round1_h_pmc_hbm_traffic.json)",
+                         "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (%s)" % (os.path.relpath(_pmc_file(), ROOT) if _pmc_file() else "no digest committed"),
                          "launch_ms": round(mean_ms.value, 4), "launches_measured": int(n_meas),
                          "flops_per_launch": flops_per_launch},
             "roofline_tensor_creation": {"bound": "hbm", "kernel": "k_featurize_columns + k_gather_windows (both passes, rescale fused)",

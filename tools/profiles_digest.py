@@ -5,6 +5,8 @@ import json
 import os
 import sys
 
+ROUND = os.environ.get("CTO_ROUND", "round2")
+
 
 def find(d, suffix):
     fs = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
@@ -18,12 +20,12 @@ def main():
     for name in ("default", "short"):
         st = find(os.path.join(out, name), "kernel_stats.csv")
         if st:
-            open(os.path.join(dst, "round1_%s_%s_bench_kernel_stats.csv" % (tag, name)), "w").write(open(st).read())
+            open(os.path.join(dst, ROUND + "_%s_%s_bench_kernel_stats.csv" % (tag, name)), "w").write(open(st).read())
         js = os.path.join(out, name + "_bench.json")
         if os.path.exists(js):
             lines = [l for l in open(js).read().split("\n") if l.startswith("{")]
             if lines:
-                open(os.path.join(dst, "round1_%s_%s_bench.json" % (tag, name)), "w").write(lines[-1] + "\n")
+                open(os.path.join(dst, ROUND + "_%s_%s_bench.json" % (tag, name)), "w").write(lines[-1] + "\n")
     # one step's launch timeline from the short run's kernel trace
     tr = find(os.path.join(out, "short"), "kernel_trace.csv")
     if tr:
@@ -36,7 +38,7 @@ def main():
         if full:
             a, b = full[-1]
             t0 = int(rows[a]["Start_Timestamp"])
-            with open(os.path.join(dst, "round1_%s_step_timeline.txt" % tag), "w") as f:
+            with open(os.path.join(dst, ROUND + "_%s_step_timeline.txt" % tag), "w") as f:
                 f.write("# one step of bench.py (launch order): start us, duration us, kernel\n")
                 for r in rows[a:b]:
                     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
@@ -60,7 +62,7 @@ def main():
         note = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 3 "
                 "--warmup 1 --no-cpu-baseline`, batch 4096; raw counter values in KB (calibrated 1.0x on known byte counts of "
                 "these access patterns, see profiles/README.md).")
-        json.dump(dict(note=note, kernels=kern), open(os.path.join(dst, "round1_%s_pmc_hbm_traffic.json" % tag), "w"), indent=1)
+        json.dump(dict(note=note, kernels=kern), open(os.path.join(dst, ROUND + "_%s_pmc_hbm_traffic.json" % tag), "w"), indent=1)
     # matrix-pipe occupancy per kernel
     vals = {}
     for d in glob.glob(os.path.join(out, "pmc_SQ_*")) + glob.glob(os.path.join(out, "pmc_GRBM*")):
@@ -89,7 +91,7 @@ def main():
                 "SQ_WAVE_CYCLES counts quad-cycles summed over waves, so mfma_issue_cycles_over_wave_cycles = 32 N_mfma / (4 SQ_WAVE_CYCLES) "
                 "is the matrix-pipe occupancy seen by a wave (with two waves per SIMD, as in k_cvt_block, the pipe's own occupancy is "
                 "up to twice that).")
-        json.dump(dict(note=note, kernels=mf), open(os.path.join(dst, "round1_%s_pmc_mfma.json" % tag), "w"), indent=1)
+        json.dump(dict(note=note, kernels=mf), open(os.path.join(dst, ROUND + "_%s_pmc_mfma.json" % tag), "w"), indent=1)
     print("digest:", sorted(os.listdir(dst)))
 
 
