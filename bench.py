@@ -153,7 +153,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file legs (mpileup text -> VCF, BAM -> VCF)")
-    ap.add_argument("--e2e-chunks", type=int, default=12, help="chunk files of the mpileup-text leg (the BAM leg uses a third)")
+    ap.add_argument("--e2e-chunks", type=int, default=24, help="chunk files of the mpileup-text leg (the BAM leg uses a third)")
     args = ap.parse_args()
 
     import numpy as np
@@ -323,12 +323,18 @@ def main():
         if world == 1 and not args.no_e2e:
             # ---- file-to-file legs (never `value`): chunk files + pileup source on disk -> p_<chunk>.vcf through the call_chunks
             # pipeline, everything a real run pays included; the rate is set by the host (cores stated), not by the GPU ----
-            from clairs_to_amd.call_chunks import usable_cores as host_cores
-            from clairs_to_amd.e2e import measure
-            e2e = {"host_cores_usable": host_cores(), "host_cores_visible": os.cpu_count(),
-                   "cpu_reference_python": REFERENCE_PYTHON_NOTE}
-            e2e["mpileup_text_to_vcf"] = measure(eng, kind="text", n_chunks=args.e2e_chunks, sites_per_chunk=args.batch)
-            e2e["bam_to_vcf"] = measure(eng, kind="bam", n_chunks=max(2, args.e2e_chunks // 3), sites_per_chunk=args.batch)
+            # run as a child process with any attached profiler's hooks stripped from its environment: the legs launch the same
+            # kernels in a pipelined context (overlapping PCIe copies), which must not mix into this process's kernel statistics
+            import subprocess
+            env = {k: v for k, v in os.environ.items()
+                   if not (k.startswith(("ROCPROF", "ROCP_", "ROCTX", "ROCPROFILER")) or k in ("HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE"))}
+            if "LD_PRELOAD" in env:
+                env["LD_PRELOAD"] = ":".join(x for x in env["LD_PRELOAD"].split(":") if "rocprof" not in x and "roctracer" not in x)
+            child = subprocess.run([sys.executable, "-m", "clairs_to_amd.e2e", "--chunks", str(args.e2e_chunks), "--batch", str(args.batch)],
+                                   cwd=ROOT, env=env, capture_output=True, text=True)
+            lines = [ln for ln in child.stdout.split("\n") if ln.startswith("{")]
+            e2e = json.loads(lines[-1]) if child.returncode == 0 and lines else {"error": child.stderr[-500:]}
+            e2e["cpu_reference_python"] = REFERENCE_PYTHON_NOTE
             res["e2e"] = e2e
         print(json.dumps(res))
     if world > 1:
