@@ -40,7 +40,7 @@ def build_run(d, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, reg
         region_kb, os.path.getsize(run["bam_fn"]) / 1e6, len(run["chunks"]))
 
 
-def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=2):
+def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4):
     """the pipeline over a prepared run directory -> dict(sites_per_s, ...); best of `repeats` passes (the first one warms the page
     cache, the pinned buffers and the model workspaces)"""
     from .call_chunks import run_pipeline, usable_cores
@@ -62,7 +62,7 @@ def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=2):
 
 
 def measure(eng, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, region_kb=None, producers=None, writers=2, workdir=None,
-            repeats=2):
+            repeats=4):
     """build_run + time_run in a temporary directory"""
     d = tempfile.mkdtemp(prefix="cto_e2e_", dir=workdir)
     try:
