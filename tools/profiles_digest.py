@@ -60,8 +60,9 @@ def main():
             d["launches"] = len(v)
     if kern:
         note = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 3 "
-                "--warmup 1 --no-cpu-baseline`, batch 4096; raw counter values in KB (calibrated 1.0x on known byte counts of "
-                "these access patterns, see profiles/README.md).")
+                "--warmup 1 --no-cpu-baseline --no-e2e`, batch 4096; RAW counter values in KB.  WRITE_SIZE is exact on known byte counts "
+                "(GRU layer 1 writes 135 168 KB); FETCH_SIZE reports HALF the bytes of coalesced reads on gfx950 (k_featurize_columns reads "
+                "the 28.6 MB pack once and shows 14.8 MB): bench.py uses 2 x FETCH + WRITE, see profiles/README.md.")
         json.dump(dict(note=note, kernels=kern), open(os.path.join(dst, ROUND + "_%s_pmc_hbm_traffic.json" % tag), "w"), indent=1)
     # matrix-pipe occupancy per kernel
     vals = {}
