@@ -1,254 +1,29 @@
 // Fused CvT transformer block (clairs/model.py:134-147: x = attn(x) + x; x = ff(x) + x) for gfx950.
 //
-// One workgroup (8 waves, two per SIMD) owns TS sites = R = TS*W activation rows of C channels and keeps the
-// residual stream, every intermediate (LayerNorm output, depth-wise conv outputs, per-head q/k/v, attention
-// output, FFN hidden chunk) in LDS; only the weights stream in (from L2, straight into MFMA B registers) and only
-// the updated residual stream goes back to HBM.  The unfused path spends ~8 launches and ~10 HBM round trips per
-// block on the same work.
+// One workgroup (8 waves, two per SIMD) owns TS sites = R = TS*W activation rows of C channels and keeps every
+// intermediate (LayerNorm output, depth-wise conv outputs, per-head q/k/v, attention output, FFN hidden chunk) in LDS;
+// the RESIDUAL STREAM lives in the accumulator registers of the two GEMMs that update it (out-projection, second FFN GEMM),
+// only the weights stream in (from L2, straight into MFMA B registers) and only the updated residual stream goes back to HBM.
+// The unfused path spends ~8 launches and ~10 HBM round trips per block on the same work.
 //
-//   phase 0  h tile -> LDS                                  (CIN > 0, first block of a stage: the stage input tile instead,
+//   phase 0  h tile -> sy                                   (CIN > 0, first block of a stage: the stage input tile instead,
 //                                                            then the stride-2 conv embedding as an im2col GEMM + LayerNorm)
-//   phase 1  y  = LN(h; norm0)                              (model.py:57-76; 16 lanes per row, DPP row reductions)
-//   phase 2  yq = BN(DW_s1(y)) in place, ykv = BN(DW_s2(y)) (model.py:91-100, 112-113)
-//   phase 3  per head: q_h, k_h, v_h (MFMA) -> LDS; softmax(q_h k_h^T / 8) v_h per site (VALU, <= 9x5
-//            scores); out-projection accumulated over heads in registers (MFMA, K = 64 per head)
-//   phase 4  h += to_out(o) + bias
-//   phase 5  y  = LN(h; norm1)
-//   phase 6  per 128-wide chunk of the 4C hidden units: u = GELU(y W1^T + b1) -> LDS, acc += u W2^T
-//   phase 7  h += acc + b2 in LDS, then coalesced 16-byte stores to HBM
+//   phase 1  acc_o = h + bias_o (accumulator layout);  t = LN(h; norm0) -> tmp      (model.py:57-76; 16 lanes per row)
+//   phase 2  yq = BN(DW_s1(t)) -> sy, ykv = BN(DW_s2(t)) -> sykv                     (model.py:91-100, 112-113)
+//   phase 3  per head: q_h, k_h, v_h (MFMA) -> LDS; softmax(q_h k_h^T / 8) v_h per query row in ONE pass (16 lanes per
+//            row: partial dots, DPP reductions, softmax in registers, o_h over q_h in place); acc_o += o_h Wo_h^T (MFMA)
+//   phase 4  h' = acc_o -> tmp;  acc_f = h' + bias_2
+//   phase 5  y  = LN(h'; norm1) -> sy
+//   phase 6  per 128-wide chunk of the 4C hidden units: u = GELU(y W1^T + b1) -> LDS, acc_f += u W2^T
+//   phase 7  h'' = acc_f -> sy, then coalesced 16-byte stores to HBM
 //   phase 8  (HEAD, last block of the network) fc1 over the LDS image of the tile -> SELU -> K x (fc2, fc3) instead of the store
 //
-// GEMMs: fp32 MFMA 16x16x4; A fragments from LDS (ds_read_b128 = four k-steps), B fragments from global
-// (one 16-byte load per lane per n-tile per 16-wide k chunk, prefetched two chunks ahead); waves 0-3 / 4-7 split the
-// M tiles, wave & 3 owns the n-tiles, so each weight fragment is reused for 2-3 m-tiles and one wave's waits and VALU
-// epilogues overlap the other's MFMAs on the same SIMD.
+// Tile ownership of an N-wide GEMM output (ColOwn): min(8, N/16) waves own distinct 16-column tiles and the remaining
+// factor of the 8 waves splits the m-tiles, so that every wave owns MFMAs whatever N is (N = 16: eight m-tile groups).
 #pragma once
-#include <type_traits>
-#include "nn_kernels.h"
+#include "cvt_gemm.h"
 
 namespace cto {
-
-struct CvtBlockParams {
-    const float *n0g, *n0b, *dwq, *bnq, *wq, *dwkv, *bnkv, *wkv, *wo, *bo, *n1g, *n1b, *w1, *b1, *w2, *b2;
-    long long* prof;   // debug: phase time stamps (s_memtime) of workgroup 0 / thread 0 when non-null (CTO_BLOCK_PROF=1)
-    // first block of a stage (CIN > 0): the stage's conv embedding + LayerNorm run here instead of reading h
-    const float *xin, *wembp, *bemb, *lng, *lnb;   // x [B][2W-1][CIN]; wembp [C][KCHE*16] (positions padded to PS)
-    // last block of the network (HEAD): fc1 + classifier tail run here instead of writing h
-    const float *w1p, *b1h;                        // fc1 [128][KCH1*16] over the LDS image of h (rows padded to RS)
-};
-
-// The first two 16-wide k chunks of a GEMM's weights, requested early (before the barriers / VALU phases that
-// precede the GEMM) so that the matrix pipe does not start every GEMM with an exposed L2 round trip.
-template <int NTW>
-struct BPre {
-    float4 b0[NTW], b1[NTW];
-};
-template <int NTW, int KCH>
-__device__ __forceinline__ BPre<NTW> prefetch_b(const float* const (&wrow)[NTW]) {
-    BPre<NTW> p;
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-        p.b0[nt] = ldg4(wrow[nt]);
-        p.b1[nt] = KCH > 1 ? ldg4(wrow[nt] + 16) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    return p;
-}
-
-// acc[mt][nt] += A[mt*16 .. +16][0 .. KCH*16) * W[n-tile rows][same k];  wrow[nt] already points at
-// W[(n0 + nt*16 + j)][4*kg].  A rows are `lda` floats apart in LDS.  `pre` holds chunks 0 and 1.
-template <int MT, int NTW, int KCH>
-__device__ __forceinline__ void gemm_lds(const float* __restrict__ A, int lda, const float* const (&wrow)[NTW],
-                                         const BPre<NTW>& pre, f32x4 (&acc)[MT][NTW], int j, int kg) {
-    float4 Bq[3][NTW];
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) { Bq[0][nt] = pre.b0[nt]; Bq[1][nt] = pre.b1[nt]; }
-    float4 a[2][MT];     // A fragments are fetched one chunk ahead too (LDS latency is exposed with 1 wave per SIMD)
-    const float* Arow = A + j * lda + 4 * kg;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[0][mt] = *reinterpret_cast<const float4*>(Arow + mt * 16 * lda);
-#pragma unroll
-    for (int c = 0; c < KCH; ++c) {
-        if (c + 2 < KCH) {
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) Bq[(c + 2) % 3][nt] = ldg4(wrow[nt] + (c + 2) * 16);
-        }
-        if (c + 1 < KCH) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[(c + 1) & 1][mt] = *reinterpret_cast<const float4*>(Arow + mt * 16 * lda + (c + 1) * 16);
-        }
-        // Without this fence the scheduler sinks the operand requests above to the END of the chunk (nothing here needs them),
-        // i.e. right in front of the s_waitcnt of the chunk that does: the "prefetch" then exposes a full LDS / L2 round trip
-        // per chunk.  Requests first, then this chunk's MFMAs; the other wave of the SIMD covers the short issue burst.
-        __builtin_amdgcn_sched_barrier(0);
-        // k-step outermost, tiles innermost: consecutive MFMAs never hit the same accumulator (dependent latency 40 cycles
-        // vs issue interval 32 for v_mfma_f32_16x16x4_f32)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) {
-                const float4 b4 = Bq[c % 3][nt];
-                const float bv = e == 0 ? b4.x : (e == 1 ? b4.y : (e == 2 ? b4.z : b4.w));
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const float4 a4 = a[c & 1][mt];
-                    const float av = e == 0 ? a4.x : (e == 1 ? a4.y : (e == 2 ? a4.z : a4.w));
-                    acc[mt][nt] = mfma16(av, bv, acc[mt][nt]);
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// One 16-row m-tile (the classifier GEMMs: 16 sites per workgroup): weights are used once, so the loop is bound by
-// the L2 round trip, not by the matrix pipe, unless many loads are in flight - DEPTH 16-wide k chunks per n-tile are
-// requested at a time, one group ahead of the MFMAs; even / odd chunks alternate between two accumulator sets.
-template <int NTW, int DEPTH>
-struct BGroup {
-    float4 b[DEPTH][NTW];
-};
-template <int NTW, int KCH, int DEPTH>
-__device__ __forceinline__ void load_group(BGroup<NTW, DEPTH>& g, const float* const (&wrow)[NTW], int c0) {
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d)
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
-            if (c0 + d < KCH) g.b[d][nt] = ldg4(wrow[nt] + (c0 + d) * 16);
-}
-template <int NTW, int KCH, int DEPTH>
-__device__ __forceinline__ void mfma_group(const BGroup<NTW, DEPTH>& g, const float* Arow, int c0, f32x4 (&acc)[2][NTW]) {
-    float4 a[DEPTH];
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d)
-        if (c0 + d < KCH) a[d] = *reinterpret_cast<const float4*>(Arow + (c0 + d) * 16);
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-        if (c0 + d >= KCH) break;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float av = e == 0 ? a[d].x : (e == 1 ? a[d].y : (e == 2 ? a[d].z : a[d].w));
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) {
-                const float4 b4 = g.b[d][nt];
-                const float bv = e == 0 ? b4.x : (e == 1 ? b4.y : (e == 2 ? b4.z : b4.w));
-                acc[d & 1][nt] = mfma16(av, bv, acc[d & 1][nt]);
-            }
-        }
-    }
-}
-template <int NTW, int KCH, int DEPTH>
-__device__ __forceinline__ void gemm_m1(const float* __restrict__ A, int lda, const float* const (&wrow)[NTW],
-                                        const BGroup<NTW, DEPTH>& first, f32x4 (&acc)[2][NTW], int j, int kg) {
-    constexpr int NG = (KCH + DEPTH - 1) / DEPTH;
-    const float* Arow = A + j * lda + 4 * kg;
-    BGroup<NTW, DEPTH> g[2];
-    g[0] = first;
-#pragma unroll
-    for (int i = 0; i < NG; ++i) {
-        if (i + 1 < NG) load_group<NTW, KCH, DEPTH>(g[(i + 1) & 1], wrow, (i + 1) * DEPTH);
-        __builtin_amdgcn_sched_barrier(0);      // keep the next group's loads ahead of this group's MFMAs
-        mfma_group<NTW, KCH, DEPTH>(g[i & 1], Arow, i * DEPTH, acc);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// ---- classifier tail shared by both networks (clairs/model.py:245-261, 451-467): K heads of fc2 (128 -> 128) -> SELU ->
-// fc3 (128 -> 2) -> SELU on a 16-site tile whose SELU(fc1) activations sit in LDS.  8 waves; wave w owns hidden units
-// [16w, 16w+16) of every head, two heads per pass (two independent accumulators keep the matrix pipe at issue rate).
-struct HeadTailParams {
-    const float *w2, *b2;   // [K*128][128], [K*128]
-    const float *w3, *b3;   // [K][2][128], [K][2]
-    float* logits;          // [K][B][2]
-    int K;
-};
-constexpr int HEAD_T1S = 132;                       // LDS row stride of the fc1 activations [16][128]
-__host__ __device__ constexpr int head_t2s(int K) { return K * 128 + 4; }
-__host__ __device__ constexpr int head_lds_floats(int K) { return 16 * HEAD_T1S + 16 * head_t2s(K); }
-
-// t1: [16][HEAD_T1S] (in), t2: [16][head_t2s(K)] scratch.  All 512 threads call; ends without a barrier.
-template <int K>
-__device__ __forceinline__ void head_tail_k(const float* t1, float* t2, const HeadTailParams& hp, int64_t B, int64_t site0,
-                                            int nsite) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
-    constexpr int T2S = head_t2s(K);
-    static_assert(K % 2 == 0, "heads are processed in pairs");
-    const float* wr[2];
-    wr[0] = hp.w2 + int64_t(wave * 16 + j) * 128 + 4 * kg;
-    wr[1] = wr[0] + 128 * 128;
-    BGroup<2, 8> g[2];
-    load_group<2, 8, 8>(g[0], wr, 0);
-    const float* Arow = t1 + j * HEAD_T1S + 4 * kg;
-#pragma unroll
-    for (int pi = 0; pi < K / 2; ++pi) {
-        if (pi + 1 < K / 2) {        // the next pair of heads' weights fly under this pair's MFMAs
-            const float* wn[2] = {wr[0] + (pi + 1) * 2 * 128 * 128, wr[1] + (pi + 1) * 2 * 128 * 128};
-            load_group<2, 8, 8>(g[(pi + 1) & 1], wn, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        f32x4 acc[2][2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) acc[a][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        mfma_group<2, 8, 8>(g[pi & 1], Arow, 0, acc);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int col = (pi * 2 + q) * 128 + wave * 16 + j;
-            const float bv = hp.b2[col];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) t2[(4 * kg + r) * T2S + col] = selu_fast(acc[0][q][r] + acc[1][q][r] + bv);
-        }
-    }
-    __syncthreads();
-    // fc3: 16 sites x K heads x 2 outputs, four lanes per dot product of length 128
-    const int part = tid & 3;
-    for (int idx = tid >> 2; idx < 16 * K * 2; idx += blockDim.x >> 2) {
-        const int site = idx / (2 * K), rem = idx - site * 2 * K, hh = rem >> 1, o = rem & 1;
-        const float4* u = reinterpret_cast<const float4*>(t2 + site * T2S + hh * 128 + part * 32);
-        const float4* w = reinterpret_cast<const float4*>(hp.w3 + (hh * 2 + o) * 128 + part * 32);
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float4 a = u[i], b = w[i];
-            sum = fmaf(a.x, b.x, sum); sum = fmaf(a.y, b.y, sum); sum = fmaf(a.z, b.z, sum); sum = fmaf(a.w, b.w, sum);
-        }
-        sum += __shfl_xor(sum, 1, 4);
-        sum += __shfl_xor(sum, 2, 4);
-        if (part == 0 && site < nsite) hp.logits[(int64_t(hh) * B + site0 + site) * 2 + o] = selu_f(sum + hp.b3[hh * 2 + o]);
-    }
-}
-__device__ __forceinline__ void head_tail(const float* t1, float* t2, const HeadTailParams& hp, int64_t B, int64_t site0,
-                                          int nsite) {
-    if (hp.K == 4) head_tail_k<4>(t1, t2, hp, B, site0, nsite);
-    else head_tail_k<6>(t1, t2, hp, B, site0, nsite);
-}
-
-// Stand-alone classifier tail for fc1 partial sums that already sit in HBM (BiGRU: one slab per direction from the fused
-// layer-2 kernel; unfused CvT path: split-K slabs): t1 = SELU(sum_z slab_z + b1), then head_tail.
-__global__ __launch_bounds__(512) void k_head(const float* __restrict__ slabs, int S, int64_t slab_stride,
-                                              const float* __restrict__ b1, HeadTailParams hp, int64_t B) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* t1 = smem;
-    float* t2 = smem + 16 * HEAD_T1S;
-    const int64_t site0 = int64_t(blockIdx.x) * 16;
-    const int nsite = int(min(int64_t(16), B - site0));
-    {
-        const int site = threadIdx.x >> 5, c4 = (threadIdx.x & 31) * 4;     // 512 threads = 16 sites x 32 float4
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (site < nsite) {
-            for (int z = 0; z < S; ++z) {
-                const float4 a = *reinterpret_cast<const float4*>(slabs + z * slab_stride + (site0 + site) * 128 + c4);
-                v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-            }
-        }
-        const float4 bb = *reinterpret_cast<const float4*>(b1 + c4);
-        *reinterpret_cast<float4*>(t1 + site * HEAD_T1S + c4) =
-            make_float4(selu_fast(v.x + bb.x), selu_fast(v.y + bb.y), selu_fast(v.z + bb.z), selu_fast(v.w + bb.w));
-    }
-    __syncthreads();
-    head_tail(t1, t2, hp, B, site0, nsite);
-}
 
 // LDS position stride of the stage input [site][2W][PS] for the in-block conv embedding: >= CIN, multiple of 4 (float4
 // A fragments) and = 4 mod 16, so that the im2col row stride 2*PS is = 8 mod 32 banks (4-way instead of 16-way conflicts).
@@ -260,25 +35,68 @@ struct CvtBlockGeom {
     static constexpr int R = TS * W, RKV = TS * WKV;
     static constexpr int MT = (R + 15) / 16, MTKV = (RKV + 15) / 16;
     static constexpr int RS = C + 4, QS = 68, HC = (4 * C < 128 ? 4 * C : 128), US = HC + 4;
-    static constexpr int OFF_H = 0;
-    static constexpr int OFF_Y = OFF_H + MT * 16 * RS;
-    static constexpr int OFF_YKV = OFF_Y + MT * 16 * RS;
-    static constexpr int OFF_Q = OFF_YKV + MTKV * 16 * RS;
+    static constexpr int OFF_Y = 0;                            // h -> yq -> y (FFN input) -> h'' : [MT*16][RS]
+    static constexpr int OFF_YKV = OFF_Y + MT * 16 * RS;       // [MTKV*16][RS]
+    static constexpr int OFF_Q = OFF_YKV + MTKV * 16 * RS;     // q_h, then o_h : [MT*16][QS]
     static constexpr int OFF_K = OFF_Q + MT * 16 * QS;
     static constexpr int OFF_V = OFF_K + MTKV * 16 * QS;
-    static constexpr int OFF_P = OFF_V + MTKV * 16 * QS;
-    static constexpr int SCRATCH = OFF_P - OFF_YKV;            // ykv|q|k|v region, re-used for the FFN hidden chunk
+    static constexpr int OFF_END = OFF_V + MTKV * 16 * QS;
+    static constexpr int SCRATCH = OFF_END - OFF_YKV;          // ykv|q|k|v region, re-used for the FFN hidden chunk
     static constexpr int U_FLOATS = MT * 16 * US;
-    static constexpr int TOTAL = OFF_P + TS * W * WKV + (U_FLOATS > SCRATCH ? U_FLOATS - SCRATCH : 0);
+    static constexpr int TOTAL = OFF_END + (U_FLOATS > SCRATCH ? U_FLOATS - SCRATCH : 0);
     static constexpr size_t LDS_BYTES = size_t(TOTAL) * sizeof(float);
-    static constexpr int ALIAS = TOTAL - OFF_Y;                // everything but the residual stream is free in phases 0 and 8
+    static constexpr int TMP_FLOATS = OFF_END - OFF_Q;         // q|k|v region doubles as the [MT*16][RS] LayerNorm staging tile
+    static constexpr int ALIAS = TOTAL - OFF_YKV;              // everything but sy is free in phases 0 and 8
     static constexpr int KCH1 = (W * RS + 15) / 16;            // fc1 over the LDS image of one site's [W][RS] rows
     static constexpr int emb_floats(int cin) { return (MT * 32 + 4) * emb_ps(cin); }
+    static constexpr bool HEAD_OK = (TS == 16) && (64 + head_lds_floats(6) <= ALIAS);
 };
 
-// 8 waves per workgroup (two per SIMD): waves 0-3 and 4-7 split the M tiles of every GEMM between them (the
-// n-tile owner is wave & 3), so one wave's LDS / L2 waits and VALU phases overlap the other's MFMAs.
+// 8 waves per workgroup (two per SIMD), so that one wave's LDS / L2 waits and VALU epilogues overlap the other's MFMAs
 constexpr int CVT_BLOCK_THREADS = 512;
+constexpr int CVT_WAVES = CVT_BLOCK_THREADS / 64;
+
+// Who computes what of an [MTx*16] x N GEMM output.
+template <int N>
+struct ColOwn {
+    static constexpr int TILES = N / 16;
+    static constexpr int NOWN = TILES < CVT_WAVES ? TILES : CVT_WAVES;   // waves owning distinct column tiles
+    static constexpr int MSPLIT = CVT_WAVES / NOWN;                      // wave groups that split the m-tiles
+    static constexpr int NTW = TILES / NOWN;                             // column tiles per wave
+    static_assert(TILES * 16 == N && CVT_WAVES % NOWN == 0 && NTW * NOWN == TILES, "unsupported GEMM width");
+};
+template <int MTx, int MSPLIT>
+struct MSplit {
+    static constexpr int MTG = (MTx + MSPLIT - 1) / MSPLIT;    // m-tiles of a full group
+    static constexpr int FULL = MTx / MTG;                     // groups that own MTG tiles
+    static constexpr int LAST = MTx - FULL * MTG;              // tiles of the group after them (0: none); later groups own nothing
+};
+struct TileSpan { int tile0, mbase, mcount; };
+template <int N, int MTx>
+__device__ __forceinline__ TileSpan tile_span(int wave) {
+    using O = ColOwn<N>;
+    constexpr int MTG = MSplit<MTx, O::MSPLIT>::MTG;
+    const int mb = (wave / O::NOWN) * MTG;
+    const int left = MTx - mb;
+    return TileSpan{(wave % O::NOWN) * O::NTW, mb, left < 0 ? 0 : (left > MTG ? MTG : left)};
+}
+// this wave's rows of an N-wide output: a group owns MTG m-tiles, one group may own fewer (LAST), the rest none
+template <int N, int MTx, int KCH>
+__device__ __forceinline__ void gemm_span(const TileSpan& sp, const float* A, int lda, const float* const (&wrow)[ColOwn<N>::NTW],
+                                          const BPre<ColOwn<N>::NTW>& pre,
+                                          f32x4 (&acc)[MSplit<MTx, ColOwn<N>::MSPLIT>::MTG][ColOwn<N>::NTW], int j, int kg) {
+    using S = MSplit<MTx, ColOwn<N>::MSPLIT>;
+    constexpr int NTW = ColOwn<N>::NTW;
+    const float* A0 = A + sp.mbase * 16 * lda;
+    if (ColOwn<N>::MSPLIT == 1 || sp.mcount == S::MTG) {
+        gemm_lds<S::MTG, NTW, KCH>(A0, lda, wrow, pre, acc, j, kg);
+    } else if constexpr (S::LAST > 0) {
+        if (sp.mcount == S::LAST) {
+            f32x4 (&sub)[S::LAST][NTW] = reinterpret_cast<f32x4 (&)[S::LAST][NTW]>(acc);
+            gemm_lds<S::LAST, NTW, KCH>(A0, lda, wrow, pre, sub, j, kg);
+        }
+    }
+}
 
 // Workgroups of this geometry that fit one CU's 160 KB of LDS (at most 3 are asked for): the register budget follows from
 // it through __launch_bounds__ (w = minimum waves per SIMD = 2 per resident 512-thread workgroup), otherwise a kernel that
@@ -293,38 +111,29 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
                                                                                                             HeadTailParams hp, int heads, int B) {
     using G = CvtBlockGeom<C, W, WKV, TS>;
     static_assert(CIN == 0 || G::emb_floats(CIN) <= G::ALIAS, "stage input tile does not fit the free LDS");
-    static_assert(!HEAD || (TS == 16 && 64 + head_lds_floats(6) <= G::ALIAS), "classifier tail needs a 16-site tile");
-    constexpr int NT = CVT_BLOCK_THREADS, NWV = NT / 64;
-    constexpr int R = G::R, RKV = G::RKV, MT = G::MT, MTKV = G::MTKV, RS = G::RS, QS = G::QS, HC = G::HC, US = G::US;
-    constexpr int MT0 = (MT + 1) / 2, MT1 = MT - MT0;
-    // C = 128: every 128-wide output (k|v of a head, out-projection, both FFN GEMMs, the stage embedding) has exactly 8 n-tiles -
-    // one per wave, all m-tiles each.  The waves are then balanced (the M split gives waves 0-3 three m-tiles and waves 4-7 two,
-    // so half of the workgroup idled a third of every GEMM phase) and a wave requests one weight fragment per chunk, not two.
-    constexpr bool NSPLIT = (C == 128);
-    constexpr int NTC = NSPLIT ? 1 : (C >= 64 ? C / 64 : 1);   // n-tiles per wave when the output is C wide
-    constexpr bool NSPLIT_F = (HC == 128);                     // the same for a 128-wide FFN hidden chunk (any C >= 32)
-    constexpr int NTF = NSPLIT_F ? 1 : HC / 64;                // n-tiles per wave of one FFN hidden chunk
-    constexpr int MTF = NSPLIT_F ? MT : (MT + 1) / 2;
-    constexpr int MTC = NSPLIT ? MT : (MT + 1) / 2;            // m-tiles a wave holds of such an output
-    static_assert(C % 16 == 0 && HC % 64 == 0, "channel count must be a multiple of 16");
+    static_assert(!HEAD || G::HEAD_OK, "classifier tail needs a 16-site tile and room for its scratch");
+    static_assert(G::MT * 16 * G::RS <= G::TMP_FLOATS, "LayerNorm staging tile does not fit the q|k|v region");
+    constexpr int NT = CVT_BLOCK_THREADS, NWV = CVT_WAVES;
+    constexpr int R = G::R, MT = G::MT, MTKV = G::MTKV, RKV = G::RKV, RS = G::RS, QS = G::QS, HC = G::HC, US = G::US;
+    static_assert(C % 16 == 0 && C <= 128 && NT % C == 0, "channel count must be 16, 32, 64 or 128");
+    using OC = ColOwn<C>;       // C-wide outputs: embedding, out-projection, second FFN GEMM (= the residual stream's owners)
+    using OQ = ColOwn<64>;      // q of one head
+    using OKV = ColOwn<128>;    // [k_h | v_h]
+    using OF = ColOwn<HC>;      // one FFN hidden chunk
+    constexpr int MGC = MSplit<MT, OC::MSPLIT>::MTG, MGQ = MSplit<MT, OQ::MSPLIT>::MTG, MGF = MSplit<MT, OF::MSPLIT>::MTG;
+    constexpr int NTC = OC::NTW, NTF = OF::NTW;
+    static_assert(OQ::NTW == 1 && OKV::NTW == 1 && OKV::MSPLIT == 1, "q / kv tiles: one column tile per wave");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sh = smem + G::OFF_H;
     float* sy = smem + G::OFF_Y;
     float* sykv = smem + G::OFF_YKV;
     float* sq = smem + G::OFF_Q;
     float* sk = smem + G::OFF_K;
     float* sv = smem + G::OFF_V;
-    float* sp = smem + G::OFF_P;
+    float* stmp = smem + G::OFF_Q;       // alias: LayerNorm staging tile [MT*16][RS] (phases 1-2 and 4-5)
     float* su = smem + G::OFF_YKV;       // alias: FFN hidden chunk [MT*16][US]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
-    const int wn = wave & 3, mh = wave >> 2;                   // n-tile owner, M half
-    const bool own_c = NSPLIT || (wn * NTC * 16) < C;          // C < 64: only some waves own columns of a C-wide output
-    const int mbase = mh ? MT0 : 0, mcount = mh ? MT1 : MT0;   // this wave's m-tiles of [R]-row operands (M split)
-    const int ctile0 = NSPLIT ? wave : wn * NTC;               // first column tile of a C-wide output
-    const int ftile0 = NSPLIT_F ? wave : wn * NTF;             // ... of an FFN hidden chunk
-    const int mbaseF = NSPLIT_F ? 0 : mbase, mcountF = NSPLIT_F ? MT : mcount;
-    const int mbaseC = NSPLIT ? 0 : mbase, mcountC = NSPLIT ? MT : mcount;
+    const TileSpan spc = tile_span<C, MT>(wave), spq = tile_span<64, MT>(wave), spf = tile_span<HC, MT>(wave);
     const int site0 = blockIdx.x * TS;
     const int nsite = min(TS, B - site0);
     const int rows_valid = nsite * W;
@@ -334,36 +143,10 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
     auto stamp = [&]() { if (p.prof && blockIdx.x == 0 && tid == 0) p.prof[nstamp++] = clock64(); };
     stamp();
 
-    // GEMM over this wave's M half; accumulators are sized for the larger half
-    auto gemm_r = [&](auto ntw_tag, auto kch_tag, const float* A, int lda, const auto& wr, const auto& pre, auto& acc) {
-        constexpr int NTW = decltype(ntw_tag)::value, KCH = decltype(kch_tag)::value;
-        if (mh == 0) {
-            gemm_lds<MT0, NTW, KCH>(A, lda, wr, pre, acc, j, kg);
-        } else if constexpr (MT1 > 0) {
-            f32x4 (&a1)[MT1][NTW] = reinterpret_cast<f32x4 (&)[MT1][NTW]>(acc);
-            gemm_lds<MT1, NTW, KCH>(A + MT0 * 16 * lda, lda, wr, pre, a1, j, kg);
-        }
-    };
-    auto gemm_c = [&](auto ntw_tag, auto kch_tag, const float* A, int lda, const auto& wr, const auto& pre, auto& acc) {
-        constexpr int NTW = decltype(ntw_tag)::value, KCH = decltype(kch_tag)::value;
-        if constexpr (NSPLIT) gemm_lds<MT, NTW, KCH>(A, lda, wr, pre, acc, j, kg);
-        else gemm_r(ntw_tag, kch_tag, A, lda, wr, pre, acc);
-    };
-    auto gemm_f = [&](auto ntw_tag, auto kch_tag, const float* A, int lda, const auto& wr, const auto& pre, auto& acc) {
-        constexpr int NTW = decltype(ntw_tag)::value, KCH = decltype(kch_tag)::value;
-        if constexpr (NSPLIT_F) gemm_lds<MT, NTW, KCH>(A, lda, wr, pre, acc, j, kg);
-        else gemm_r(ntw_tag, kch_tag, A, lda, wr, pre, acc);
-    };
-    using I1 = std::integral_constant<int, 1>;
-    using INTC = std::integral_constant<int, NTC>;
-    using INTF = std::integral_constant<int, NTF>;
-    using KC = std::integral_constant<int, C / 16>;
-    using K4 = std::integral_constant<int, 4>;
-    using KH = std::integral_constant<int, HC / 16>;
 
-    // ---- phase 0: residual stream tile -> LDS (pad rows zero); first block of a stage: stage input -> LDS instead ----
-    if constexpr (HEAD) {   // fc1 sweeps the LDS image of h including the 4 pad columns of every row (zero weights): keep them finite
-        for (int i = tid; i < MT * 16; i += NT) *reinterpret_cast<float4*>(sh + i * RS + C) = make_float4(0.f, 0.f, 0.f, 0.f);
+    // ---- phase 0: residual stream tile -> sy (pad rows zero); first block of a stage: stage input -> LDS instead ----
+    if constexpr (HEAD) {   // fc1 sweeps the LDS image of the tile including the 4 pad columns of every row (zero weights): keep them finite
+        for (int i = tid; i < MT * 16; i += NT) *reinterpret_cast<float4*>(sy + i * RS + C) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if constexpr (CIN == 0) {
         constexpr int NIT = (MT * 16 * (C / 4) + NT - 1) / NT;
@@ -376,7 +159,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
 #pragma unroll
         for (int q = 0; q < NIT; ++q) {
             const int i = tid + q * NT, r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
-            if (i < MT * 16 * (C / 4)) *reinterpret_cast<float4*>(sh + r * RS + c4) = stage[q];
+            if (i < MT * 16 * (C / 4)) *reinterpret_cast<float4*>(sy + r * RS + c4) = stage[q];
         }
         for (int i = tid; i < (MTKV * 16 - RKV) * RS; i += NT) sykv[RKV * RS + i] = 0.f;
     } else {
@@ -384,7 +167,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
         // this site's right pad, so the im2col row of output (site, wo) is the contiguous run starting at row*2*PS
         constexpr int WIN = 2 * W - 1, PS = emb_ps(CIN), NPOS = MT * 32 + 4, VW = (CIN % 4 == 0) ? 4 : 2, SLOTS = PS / VW;
         static_assert(CIN % 2 == 0, "stage input channels must be even");
-        float* sin = smem + G::OFF_Y;
+        float* sin = smem + G::OFF_YKV;
         const float* xg = p.xin + int64_t(site0) * WIN * CIN;
         // all of a thread's pieces are requested before the first one is written to LDS: one HBM round trip, not one per piece
         constexpr int NIT = (NPOS * SLOTS + NT - 1) / NT;
@@ -415,48 +198,61 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
     }
     lds_barrier();
 
-    // Channel LayerNorm sh -> sy.  16 lanes per row (4 rows per wave at a time), each lane owning C/16 contiguous
-    // channels: the row reductions are 4 DPP steps inside a 16-lane row instead of 6 cross-lane permutes through the
-    // LDS crossbar - the wave-per-row version spent 12.5 k cycles per LayerNorm (10 % of a stage-3 block).
+    // Channel LayerNorm src -> dst (may be the same tile).  16 lanes per row (4 rows per wave and pass), each lane owning C/16
+    // contiguous channels: the row reductions are 4 DPP steps inside a 16-lane row.  All passes are in flight together - one
+    // pass is a dependent chain of an LDS read, two 4-step reductions, a square root and a division, and with two waves per
+    // SIMD nothing else hides it.
     auto layer_norm = [&](const float* src, float* dst, const float* g, const float* b) {
-        constexpr int CPL = C / 16;
+        constexpr int CPL = C / 16, NP = (MT * 16 + NWV * 4 - 1) / (NWV * 4);
         const int l16 = lane & 15, grp = lane >> 4;
         float gv[CPL], bv[CPL];
 #pragma unroll
         for (int i = 0; i < CPL; ++i) { gv[i] = g[l16 * CPL + i]; bv[i] = b[l16 * CPL + i]; }
-        for (int r = wave * 4 + grp; r < MT * 16; r += NWV * 4) {
+        float v[NP][CPL];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int r = min(q * NWV * 4 + wave * 4 + grp, MT * 16 - 1);
             const float* xr = src + r * RS + l16 * CPL;
-            float v[CPL], sum = 0.f;
             if constexpr (CPL % 4 == 0) {
 #pragma unroll
                 for (int i = 0; i < CPL; i += 4) {
-                    const float4 q = *reinterpret_cast<const float4*>(xr + i);
-                    v[i] = q.x; v[i + 1] = q.y; v[i + 2] = q.z; v[i + 3] = q.w;
+                    const float4 t = *reinterpret_cast<const float4*>(xr + i);
+                    v[q][i] = t.x; v[q][i + 1] = t.y; v[q][i + 2] = t.z; v[q][i + 3] = t.w;
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < CPL; ++i) v[i] = xr[i];
+                for (int i = 0; i < CPL; ++i) v[q][i] = xr[i];
             }
+        }
+        float inv[NP];
 #pragma unroll
-            for (int i = 0; i < CPL; ++i) sum += v[i];
+        for (int q = 0; q < NP; ++q) {
+            float sum = 0.f;
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+            for (int i = 0; i < CPL; ++i) sum += v[q][i];
+            sum = row16_sum(sum);
             const float mean = sum / float(C);
-            float sq = 0.f;
+            float sq2 = 0.f;
 #pragma unroll
-            for (int i = 0; i < CPL; ++i) { v[i] -= mean; sq += v[i] * v[i]; }
+            for (int i = 0; i < CPL; ++i) { v[q][i] -= mean; sq2 += v[q][i] * v[q][i]; }
+            sq2 = row16_sum(sq2);
+            inv[q] = 1.0f / (sqrtf(sq2 / float(C)) + 1e-5f);
+        }
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 16);
-            const float inv = 1.0f / (sqrtf(sq / float(C)) + 1e-5f);
-            float* yr = dst + r * RS + l16 * CPL;
-            if constexpr (CPL % 4 == 0) {
+        for (int q = 0; q < NP; ++q) {
+            const int r = q * NWV * 4 + wave * 4 + grp;
+            if (r < MT * 16) {
+                float* yr = dst + r * RS + l16 * CPL;
+                if constexpr (CPL % 4 == 0) {
 #pragma unroll
-                for (int i = 0; i < CPL; i += 4)
-                    *reinterpret_cast<float4*>(yr + i) = make_float4(v[i] * inv * gv[i] + bv[i], v[i + 1] * inv * gv[i + 1] + bv[i + 1],
-                                                                     v[i + 2] * inv * gv[i + 2] + bv[i + 2], v[i + 3] * inv * gv[i + 3] + bv[i + 3]);
-            } else {
+                    for (int i = 0; i < CPL; i += 4)
+                        *reinterpret_cast<float4*>(yr + i) =
+                            make_float4(v[q][i] * inv[q] * gv[i] + bv[i], v[q][i + 1] * inv[q] * gv[i + 1] + bv[i + 1],
+                                        v[q][i + 2] * inv[q] * gv[i + 2] + bv[i + 2], v[q][i + 3] * inv[q] * gv[i + 3] + bv[i + 3]);
+                } else {
 #pragma unroll
-                for (int i = 0; i < CPL; ++i) yr[i] = v[i] * inv * gv[i] + bv[i];
+                    for (int i = 0; i < CPL; ++i) yr[i] = v[q][i] * inv[q] * gv[i] + bv[i];
+                }
             }
         }
     };
@@ -466,87 +262,108 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
         constexpr int PS = emb_ps(CIN), KE = emb_kch(CIN);
         const float* we_r[NTC];
 #pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) we_r[nt] = p.wembp + int64_t(own_c ? (ctile0 + nt) * 16 + j : j) * (KE * 16) + 4 * kg;
+        for (int nt = 0; nt < NTC; ++nt) we_r[nt] = p.wembp + int64_t((spc.tile0 + nt) * 16 + j) * (KE * 16) + 4 * kg;
         const BPre<NTC> pre_e = prefetch_b<NTC, KE>(we_r);
-        f32x4 acc_e[MTC][NTC];
+        f32x4 acc_e[MGC][NTC];
 #pragma unroll
-        for (int mt = 0; mt < MTC; ++mt)
+        for (int mt = 0; mt < MGC; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTC; ++nt) acc_e[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (own_c) gemm_c(INTC{}, std::integral_constant<int, KE>{}, smem + G::OFF_Y, 2 * PS, we_r, pre_e, acc_e);
+        gemm_span<C, MT, KE>(spc, smem + G::OFF_YKV, 2 * PS, we_r, pre_e, acc_e, j, kg);
 #pragma unroll
         for (int nt = 0; nt < NTC; ++nt) {
-            if (!own_c) break;
-            const int col = (ctile0 + nt) * 16 + j;
+            const int col = (spc.tile0 + nt) * 16 + j;
             const float bv = p.bemb[col];
 #pragma unroll
-            for (int mt = 0; mt < MTC; ++mt)
-                if (mt < mcountC) {
+            for (int mt = 0; mt < MGC; ++mt)
+                if (mt < spc.mcount) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sh[((mbaseC + mt) * 16 + 4 * kg + r) * RS + col] = acc_e[mt][nt][r] + bv;
+                    for (int r = 0; r < 4; ++r) sy[((spc.mbase + mt) * 16 + 4 * kg + r) * RS + col] = acc_e[mt][nt][r] + bv;
                 }
         }
         lds_barrier();
-        for (int i = tid; i < (MTKV * 16 - RKV) * RS; i += NT) sykv[RKV * RS + i] = 0.f;
-        layer_norm(sh, sh, p.lng, p.lnb);
+        for (int i = tid; i < (MTKV * 16 - RKV) * RS; i += NT) sykv[RKV * RS + i] = 0.f;    // the input tile lay over these rows
+        layer_norm(sy, sy, p.lng, p.lnb);
         lds_barrier();
     }
 
     stamp();
-    // ---- phase 1 ----
-    layer_norm(sh, sy, p.n0g, p.n0b);
+    // ---- phase 1: the residual stream moves into the out-projection's accumulators; LayerNorm -> staging tile ----
+    f32x4 acc_o[MGC][NTC];
+#pragma unroll
+    for (int nt = 0; nt < NTC; ++nt) {
+        const int col = (spc.tile0 + nt) * 16 + j;
+        const float bv = p.bo[col];
+#pragma unroll
+        for (int mt = 0; mt < MGC; ++mt) {
+            const int row0 = (spc.mbase + (mt < spc.mcount ? mt : 0)) * 16 + 4 * kg;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc_o[mt][nt][r] = sy[(row0 + r) * RS + col] + bv;
+        }
+    }
+    layer_norm(sy, stmp, p.n0g, p.n0b);
     lds_barrier();
     stamp();
 
-    // ---- phase 2: depth-wise 3-tap conv + BatchNorm; q path in place, kv path (stride 2) to sykv ----
+    // ---- phase 2: depth-wise 3-tap conv + BatchNorm of the staging tile; q path -> sy, kv path (stride 2) -> sykv ----
     {
-        static_assert(NT % C == 0, "column mapping assumes C divides the block size");
-        const int c = tid % C;                 // every column this thread handles has the same channel
+        constexpr int NSLOT = NT / C;                                   // (site, position group) slots of one pass
+        constexpr int PG = NSLOT > TS ? NSLOT / TS : 1;                 // more slots than sites: split a site's positions
+        constexpr int SL = NSLOT / PG, NIT = (TS + SL - 1) / SL;
+        constexpr int WQ = (W + PG - 1) / PG, WK = (WKV + PG - 1) / PG;
+        static_assert(SL * PG == NSLOT, "slot split");
+        const int c = tid % C, slot = tid / C, pg = slot / SL, s0 = slot - pg * SL;
+        const int wlo = pg * WQ, whi = min(W, wlo + WQ), klo = pg * WK, khi = min(WKV, klo + WK);
         const float q0 = p.dwq[c * 3], q1 = p.dwq[c * 3 + 1], q2 = p.dwq[c * 3 + 2];
         const float k0 = p.dwkv[c * 3], k1 = p.dwkv[c * 3 + 1], k2 = p.dwkv[c * 3 + 2];
         const float qm = p.bnq[c], qi = p.bnq[C + c], qw = p.bnq[2 * C + c], qb = p.bnq[3 * C + c];
         const float km = p.bnkv[c], ki = p.bnkv[C + c], kw = p.bnkv[2 * C + c], kb = p.bnkv[3 * C + c];
-        for (int s = tid / C; s < TS; s += NT / C) {
-            float y[W];
+        float y[NIT][W];
 #pragma unroll
-            for (int w = 0; w < W; ++w) y[w] = sy[(s * W + w) * RS + c];
+        for (int it = 0; it < NIT; ++it) {
+            const int s = min(s0 + it * SL, TS - 1);
 #pragma unroll
-            for (int w = 0; w < W; ++w) {
-                const float l = w > 0 ? y[w - 1] : 0.f, r = w + 1 < W ? y[w + 1] : 0.f;
-                const float d = q0 * l + q1 * y[w] + q2 * r;
-                sy[(s * W + w) * RS + c] = (d - qm) * qi * qw + qb;
-            }
+            for (int w = 0; w < W; ++w) y[it][w] = stmp[(s * W + w) * RS + c];
+        }
 #pragma unroll
-            for (int wo = 0; wo < WKV; ++wo) {
-                const int w = 2 * wo;
-                const float l = w > 0 ? y[w - 1] : 0.f, r = w + 1 < W ? y[w + 1] : 0.f;
-                const float d = k0 * l + k1 * y[w] + k2 * r;
-                sykv[(s * WKV + wo) * RS + c] = (d - km) * ki * kw + kb;
+        for (int it = 0; it < NIT; ++it) {
+            const int s = s0 + it * SL;
+            if (s < TS) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    if (PG > 1 && (w < wlo || w >= whi)) continue;
+                    const float l = w > 0 ? y[it][w - 1] : 0.f, r = w + 1 < W ? y[it][w + 1] : 0.f;
+                    const float d = q0 * l + q1 * y[it][w] + q2 * r;
+                    sy[(s * W + w) * RS + c] = (d - qm) * qi * qw + qb;
+                }
+#pragma unroll
+                for (int wo = 0; wo < WKV; ++wo) {
+                    if (PG > 1 && (wo < klo || wo >= khi)) continue;
+                    const int w = 2 * wo;
+                    const float l = w > 0 ? y[it][w - 1] : 0.f, r = w + 1 < W ? y[it][w + 1] : 0.f;
+                    const float d = k0 * l + k1 * y[it][w] + k2 * r;
+                    sykv[(s * WKV + wo) * RS + c] = (d - km) * ki * kw + kb;
+                }
             }
         }
+        // pad rows of the q-path tile (rows R .. MT*16) keep what phase 0 left there: zeros or the embedding of zeros, finite
     }
     lds_barrier();
 
     stamp();
-    // ---- phase 3: attention, head by head; out-projection accumulates in registers ----
-    f32x4 acc_o[MTC][NTC];
-#pragma unroll
-    for (int mt = 0; mt < MTC; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) acc_o[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    auto q_rows = [&](int hh, const float* (&wr)[1]) { wr[0] = p.wq + int64_t(hh * 64 + wn * 16 + j) * C + 4 * kg; };
+    // ---- phase 3: attention, head by head; out-projection accumulates on top of the residual stream in registers ----
+    auto q_rows = [&](int hh, const float* (&wr)[1]) { wr[0] = p.wq + int64_t(hh * 64 + spq.tile0 * 16 + j) * C + 4 * kg; };
     auto o_rows = [&](int hh, const float* (&wr)[NTC]) {
 #pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) wr[nt] = p.wo + int64_t(own_c ? (ctile0 + nt) * 16 + j : j) * inner + hh * 64 + 4 * kg;
+        for (int nt = 0; nt < NTC; ++nt) wr[nt] = p.wo + int64_t((spc.tile0 + nt) * 16 + j) * inner + hh * 64 + 4 * kg;
     };
     auto w1_rows = [&](int cc, const float* (&wr)[NTF]) {
 #pragma unroll
-        for (int nt = 0; nt < NTF; ++nt) wr[nt] = p.w1 + int64_t(cc * HC + (ftile0 + nt) * 16 + j) * C + 4 * kg;
+        for (int nt = 0; nt < NTF; ++nt) wr[nt] = p.w1 + int64_t(cc * HC + (spf.tile0 + nt) * 16 + j) * C + 4 * kg;
     };
     auto w2_rows = [&](int cc, const float* (&wr)[NTC]) {
 #pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) wr[nt] = p.w2 + int64_t(own_c ? (ctile0 + nt) * 16 + j : j) * (4 * C) + cc * HC + 4 * kg;
+        for (int nt = 0; nt < NTC; ++nt) wr[nt] = p.w2 + int64_t((spc.tile0 + nt) * 16 + j) * (4 * C) + cc * HC + 4 * kg;
     };
 
     const float* wq_r[1];
@@ -555,18 +372,19 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
     for (int hh = 0; hh < heads; ++hh) {
         // [k_h | v_h] is 128 wide for every stage: wave w computes one of its 8 n-tiles (w < 4: k columns 16 w.., else v columns
         // 16 (w - 4)..) for all m-tiles
+        const int wn = wave & 3;
         const float* wkv1_r[1] = {p.wkv + int64_t((wave < 4 ? 0 : inner) + hh * 64 + wn * 16 + j) * C + 4 * kg};
         const BPre<1> pre_kv1 = prefetch_b<1, C / 16>(wkv1_r);
-        {   // q_h : [R][64], this wave's 16 columns of its M half
-            f32x4 aq[MT0][1];
+        {   // q_h : [R][64], this wave's 16 columns of its m-tile group
+            f32x4 aq[MGQ][1];
 #pragma unroll
-            for (int mt = 0; mt < MT0; ++mt) aq[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gemm_r(I1{}, KC{}, sy, RS, wq_r, pre_q, aq);
+            for (int mt = 0; mt < MGQ; ++mt) aq[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm_span<64, MT, C / 16>(spq, sy, RS, wq_r, pre_q, aq, j, kg);
 #pragma unroll
-            for (int mt = 0; mt < MT0; ++mt)
-                if (mt < mcount) {
+            for (int mt = 0; mt < MGQ; ++mt)
+                if (mt < spq.mcount) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sq[((mbase + mt) * 16 + 4 * kg + r) * QS + wn * 16 + j] = aq[mt][0][r];
+                    for (int r = 0; r < 4; ++r) sq[((spq.mbase + mt) * 16 + 4 * kg + r) * QS + spq.tile0 * 16 + j] = aq[mt][0][r];
                 }
         }
         const float* wo_r[NTC];
@@ -585,45 +403,45 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
         }
         lds_barrier();
         stamp();
-        // scores = q k^T / 8 per site (model.py:126; dim_head = 64)
-        for (int t = tid; t < TS * W * WKV; t += NT) {
-            const int s = t / (W * WKV), rem = t - s * (W * WKV), i = rem / WKV, jj = rem - i * WKV;
-            const float4* qv = reinterpret_cast<const float4*>(sq + (s * W + i) * QS);
-            const float4* kv = reinterpret_cast<const float4*>(sk + (s * WKV + jj) * QS);
-            float acc = 0.f;
+        // softmax(q k^T / 8) v of one query row per 16-lane group (model.py:126-131; dim_head = 64): lane l owns dimensions
+        // 4l .. 4l+3 of q, of every k and v row of the site and of the output, which replaces q in place.  Scores are partial
+        // dots reduced inside the 16-lane row; no score matrix in LDS, no barrier between scores, softmax and P v.
+        {
+            constexpr int NPA = (R + NT / 16 - 1) / (NT / 16); constexpr int UF = WKV <= 5 ? 2 : 1;
+            const int l4 = (lane & 15) * 4;
+#pragma unroll UF
+            for (int q = 0; q < NPA; ++q) {
+                const int row = q * (NT / 16) + (tid >> 4);
+                const int rr = row < R ? row : 0;
+                const int s = rr / W;
+                const float4 qv = *reinterpret_cast<const float4*>(sq + rr * QS + l4);
+                float4 kv[WKV], vv[WKV];
 #pragma unroll
-            for (int d = 0; d < 16; ++d) {
-                const float4 a = qv[d], b = kv[d];
-                acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+                for (int jj = 0; jj < WKV; ++jj) {
+                    kv[jj] = *reinterpret_cast<const float4*>(sk + (s * WKV + jj) * QS + l4);
+                    vv[jj] = *reinterpret_cast<const float4*>(sv + (s * WKV + jj) * QS + l4);
+                }
+                float sc[WKV];
+#pragma unroll
+                for (int jj = 0; jj < WKV; ++jj) sc[jj] = fmaf(qv.w, kv[jj].w, fmaf(qv.z, kv[jj].z, fmaf(qv.y, kv[jj].y, qv.x * kv[jj].x)));
+#pragma unroll
+                for (int jj = 0; jj < WKV; ++jj) sc[jj] = row16_sum(sc[jj]);
+                float mx = sc[0];
+#pragma unroll
+                for (int jj = 1; jj < WKV; ++jj) mx = fmaxf(mx, sc[jj]);
+                float sum = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < WKV; ++jj) { sc[jj] = exp_le0((sc[jj] - mx) * 0.125f); sum += sc[jj]; }
+                float inv = __builtin_amdgcn_rcpf(sum);
+                inv = fmaf(fmaf(-sum, inv, 1.0f), inv, inv);      // one Newton step: 0.5 ulp
+                float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int jj = 0; jj < WKV; ++jj) {
+                    const float pj = sc[jj] * inv;
+                    o4.x = fmaf(pj, vv[jj].x, o4.x); o4.y = fmaf(pj, vv[jj].y, o4.y); o4.z = fmaf(pj, vv[jj].z, o4.z); o4.w = fmaf(pj, vv[jj].w, o4.w);
+                }
+                if (row < R) *reinterpret_cast<float4*>(sq + rr * QS + l4) = o4;
             }
-            sp[t] = acc * 0.125f;
-        }
-        lds_barrier();
-        for (int t = tid; t < TS * W; t += NT) {
-            float* row = sp + t * WKV;
-            float mx = row[0];
-#pragma unroll
-            for (int jj = 1; jj < WKV; ++jj) mx = fmaxf(mx, row[jj]);
-            float e[WKV], sum = 0.f;
-#pragma unroll
-            for (int jj = 0; jj < WKV; ++jj) { e[jj] = expf(row[jj] - mx); sum += e[jj]; }
-            const float inv = 1.0f / sum;
-#pragma unroll
-            for (int jj = 0; jj < WKV; ++jj) row[jj] = e[jj] * inv;
-        }
-        lds_barrier();
-        // o_h = P v_h, overwrites q_h
-        for (int t = tid; t < R * 16; t += NT) {
-            const int row = t >> 4, d4 = (t & 15) * 4, s = row / W;
-            const float* pr = sp + row * WKV;
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int jj = 0; jj < WKV; ++jj) {
-                const float pj = pr[jj];
-                const float4 vv = *reinterpret_cast<const float4*>(sv + (s * WKV + jj) * QS + d4);
-                o.x = fmaf(pj, vv.x, o.x); o.y = fmaf(pj, vv.y, o.y); o.z = fmaf(pj, vv.z, o.z); o.w = fmaf(pj, vv.w, o.w);
-            }
-            *reinterpret_cast<float4*>(sq + row * QS + d4) = o;
         }
         if (hh + 1 < heads) {        // next head's q weights fly under the barrier and the out-projection
             q_rows(hh + 1, wq_r);
@@ -631,64 +449,63 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
         }
         lds_barrier();
         stamp();
-        if (own_c) gemm_c(INTC{}, K4{}, sq, QS, wo_r, pre_o, acc_o);   // acc_o += o_h Wo[:, hh*64 .. +64]^T
+        gemm_span<C, MT, 4>(spc, sq, QS, wo_r, pre_o, acc_o, j, kg);   // acc_o += o_h Wo[:, hh*64 .. +64]^T
         lds_barrier();   // sq / sk / sv are rewritten by the next head
         stamp();
     }
 
-    // first FFN weights are requested before the residual update and the second LayerNorm
+    // first FFN weights are requested before the residual hand-over and the second LayerNorm
     const float* w1_r[NTF];
     w1_rows(0, w1_r);
     BPre<NTF> pre_w1 = prefetch_b<NTF, C / 16>(w1_r);
 
-    // ---- phase 4: h += to_out(o) + bias ----
+    // ---- phase 4: h' = h + to_out(o) + bias sits in acc_o: a copy -> staging tile for the LayerNorm, and h' + b2 seeds the
+    //      second FFN GEMM's accumulators ----
+    f32x4 acc_f[MGC][NTC];
 #pragma unroll
     for (int nt = 0; nt < NTC; ++nt) {
-        if (!own_c) break;
-        const int col = (ctile0 + nt) * 16 + j;
-        const float bv = p.bo[col];
+        const int col = (spc.tile0 + nt) * 16 + j;
+        const float bv = p.b2[col];
 #pragma unroll
-        for (int mt = 0; mt < MTC; ++mt)
-            if (mt < mcountC) {
+        for (int mt = 0; mt < MGC; ++mt) {
+            if (mt < spc.mcount) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sh[((mbaseC + mt) * 16 + 4 * kg + r) * RS + col] += acc_o[mt][nt][r] + bv;
+                for (int r = 0; r < 4; ++r) stmp[((spc.mbase + mt) * 16 + 4 * kg + r) * RS + col] = acc_o[mt][nt][r];
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc_f[mt][nt][r] = acc_o[mt][nt][r] + bv;
+        }
     }
     lds_barrier();
 
     stamp();
     // ---- phase 5 ----
-    layer_norm(sh, sy, p.n1g, p.n1b);
+    layer_norm(stmp, sy, p.n1g, p.n1b);
     lds_barrier();
     stamp();
 
     // ---- phase 6: feed-forward, hidden units in chunks of HC ----
-    f32x4 acc_f[MTC][NTC];
-#pragma unroll
-    for (int mt = 0; mt < MTC; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) acc_f[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int cc = 0; cc < 4 * C / HC; ++cc) {
         const float* w2_r[NTC];
         w2_rows(cc, w2_r);
         const BPre<NTC> pre_w2 = prefetch_b<NTC, HC / 16>(w2_r);
         {
-            f32x4 au[MTF][NTF];
+            f32x4 au[MGF][NTF];
 #pragma unroll
-            for (int mt = 0; mt < MTF; ++mt)
+            for (int mt = 0; mt < MGF; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NTF; ++nt) au[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gemm_f(INTF{}, KC{}, sy, RS, w1_r, pre_w1, au);
-            const int n0 = cc * HC + ftile0 * 16;
+            gemm_span<HC, MT, C / 16>(spf, sy, RS, w1_r, pre_w1, au, j, kg);
+            const int n0 = cc * HC + spf.tile0 * 16;
 #pragma unroll
             for (int nt = 0; nt < NTF; ++nt) {
                 const float bv = p.b1[n0 + nt * 16 + j];
 #pragma unroll
-                for (int mt = 0; mt < MTF; ++mt)
-                    if (mt < mcountF) {
+                for (int mt = 0; mt < MGF; ++mt)
+                    if (mt < spf.mcount) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            su[((mbaseF + mt) * 16 + 4 * kg + r) * US + (ftile0 + nt) * 16 + j] = gelu_f(au[mt][nt][r] + bv);
+                            su[((spf.mbase + mt) * 16 + 4 * kg + r) * US + (spf.tile0 + nt) * 16 + j] = gelu_f(au[mt][nt][r] + bv);
                     }
             }
         }
@@ -697,39 +514,37 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
             pre_w1 = prefetch_b<NTF, C / 16>(w1_r);
         }
         lds_barrier();
-        if (own_c) gemm_c(INTC{}, KH{}, su, US, w2_r, pre_w2, acc_f);
-        lds_barrier();   // su is rewritten by the next chunk
+        gemm_span<C, MT, HC / 16>(spc, su, US, w2_r, pre_w2, acc_f, j, kg);
+        if (cc + 1 < 4 * C / HC) lds_barrier();   // su is rewritten by the next chunk
         stamp();
     }
 
-    // ---- phase 7: h += ff(y) + bias in LDS, then -> HBM (last block of the network: the classifier consumes it in LDS) ----
+    // ---- phase 7: h'' = h' + ff(y) + bias sits in acc_f -> sy (its last reader was the first GEMM of the last chunk, a barrier
+    //      ago), then -> HBM (last block of the network: the classifier consumes it in LDS) ----
 #pragma unroll
     for (int nt = 0; nt < NTC; ++nt) {
-        if (!own_c) break;
-        const int col = (ctile0 + nt) * 16 + j;
-        const float bv = p.b2[col];
+        const int col = (spc.tile0 + nt) * 16 + j;
 #pragma unroll
-        for (int mt = 0; mt < MTC; ++mt)
-            if (mt < mcountC) {
+        for (int mt = 0; mt < MGC; ++mt)
+            if (mt < spc.mcount) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = (mbaseC + mt) * 16 + 4 * kg + r;
-                    sh[row * RS + col] += acc_f[mt][nt][r] + bv;     // the tile leaves through LDS: 16-byte coalesced stores below
-                }
+                for (int r = 0; r < 4; ++r) sy[((spc.mbase + mt) * 16 + 4 * kg + r) * RS + col] = acc_f[mt][nt][r];
             }
     }
     if constexpr (!HEAD) {
         lds_barrier();
         for (int i = tid; i < rows_valid * (C / 4); i += NT) {
             const int r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
-            *reinterpret_cast<float4*>(hg + r * C + c4) = *reinterpret_cast<const float4*>(sh + r * RS + c4);
+            *reinterpret_cast<float4*>(hg + r * C + c4) = *reinterpret_cast<const float4*>(sy + r * RS + c4);
         }
     }
     if constexpr (HEAD) {
         // ---- phase 8: fc1 over the flattened [W][C] features of each site (model.py:239-247; torch's c*W + w order is folded
-        // into w1p, whose k axis follows the LDS image w*RS + c with zero weights on the pad columns), SELU, classifier tail
+        // into w1p, whose k axis follows the LDS image w*RS + c with zero weights on the pad columns), SELU, classifier tail.
+        // The scratch starts 64 floats into the free region: the last site's k run ends up to 12 floats past its rows, on
+        // floats of the last FFN hidden chunk (finite, zero weights).  The other waves may still read that chunk: barrier first.
         constexpr int K1 = G::KCH1;
-        float* t1 = smem + G::OFF_Y + 64;       // the last site's k run ends up to 12 floats past its rows
+        float* t1 = smem + G::OFF_YKV + 64;
         float* t2 = t1 + 16 * HEAD_T1S;
         const float* w1_r1[1] = {p.w1p + int64_t(wave * 16 + j) * (K1 * 16) + 4 * kg};
         BGroup<1, 7> g0;
@@ -737,7 +552,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
         lds_barrier();
         stamp();
         f32x4 a1[2][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}, {f32x4{0.f, 0.f, 0.f, 0.f}}};
-        gemm_m1<1, K1, 7>(sh, W * RS, w1_r1, g0, a1, j, kg);
+        gemm_m1<1, K1, 7>(sy, W * RS, w1_r1, g0, a1, j, kg);
         const float bv = p.b1h[wave * 16 + j];
 #pragma unroll
         for (int r = 0; r < 4; ++r) t1[(4 * kg + r) * HEAD_T1S + wave * 16 + j] = selu_fast(a1[0][0][r] + a1[1][0][r] + bv);

@@ -40,6 +40,20 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Sum over the 16 lanes of a DPP row, result in every lane: four v_add_f32 with a DPP operand (quad swaps, half-row mirror, row
+// mirror).  `__shfl_xor(v, o, 16)` compiles to ds_bpermute_b32 - a trip through the LDS crossbar and an s_waitcnt per step.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);    // row_half_mirror: the other quad of the half row
+    v += dpp_mov<0x140>(v);    // row_mirror: the other half row
+    return v;
+}
+
 // ---- activations (clairs/model.py: nn.SELU, nn.GELU() exact-erf form) ----
 __device__ __forceinline__ float selu_f(float x) {
     const float scale = 1.0507009873554804934193349852946f;
@@ -68,6 +82,16 @@ __device__ __forceinline__ float erf_as(float x) {
 }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+// exp(x) for x <= 0 (softmax numerators) on the hardware exp2: the product x * log2(e) is carried in two floats (FMA residual +
+// the constant's low part), so the result is within ~2 ulp like libm's expf, at 7 VALU instead of ~25 (no range / denormal
+// branches: below 2^-126 the hardware flushes to 0, which is what a softmax wants)
+__device__ __forceinline__ float exp_le0(float x) {
+    const float L_HI = 1.44269502162933349609375f, L_LO = 1.925963033500011e-8f;
+    const float t = x * L_HI;
+    const float e = fmaf(x, L_LO, fmaf(x, L_HI, -t));          // x * log2(e) - t
+    const float r = __builtin_amdgcn_exp2f(t);
+    return fmaf(r, e * 0.693147180559945309417f, r);            // 2^(t + e) = 2^t (1 + e ln 2 + ...)
+}
 
 
 }  // namespace cto

@@ -314,7 +314,7 @@ int launch_cvt_block(hipStream_t s, float* h, const BlockDev& b, int heads, int6
 // can run inside the stage's first block.
 template <int C, int W, int WKV, int TS, int CIN>
 int dispatch_block(hipStream_t s, float* h, const BlockDev& b, int heads, int64_t B, const BlockExtra& ex, bool embed, bool head) {
-    if constexpr (TS == 16) {
+    if constexpr (C == 128 && CvtBlockGeom<C, W, WKV, TS>::HEAD_OK) {
         if (head) return embed ? launch_cvt_block<C, W, WKV, TS, CIN, true>(s, h, b, heads, B, ex)
                                : launch_cvt_block<C, W, WKV, TS, 0, true>(s, h, b, heads, B, ex);
     }
@@ -328,7 +328,7 @@ int dispatch_block(hipStream_t s, float* h, const BlockDev& b, int heads, int64_
 #define CTO_CVT_TS1 8
 #endif
 #ifndef CTO_CVT_TS2
-#define CTO_CVT_TS2 8
+#define CTO_CVT_TS2 16
 #endif
 struct FusedGeom { int c, w, wkv, ts, cin; };
 const FusedGeom* fused_geom(const StageDev& st) {
@@ -338,7 +338,7 @@ const FusedGeom* fused_geom(const StageDev& st) {
     return nullptr;
 }
 bool can_fuse_embed(const StageDev& st) { const FusedGeom* g = fused_geom(st); return g && g->cin == st.cin && st.wembp; }
-bool can_fuse_head(const StageDev& st, const HeadDev& hd) { const FusedGeom* g = fused_geom(st); return g && g->ts == 16 && hd.w1p; }
+bool can_fuse_head(const StageDev& st, const HeadDev& hd) { const FusedGeom* g = fused_geom(st); return g && g->ts == 16 && g->c == 128 && hd.w1p; }
 
 // fused transformer block when the stage geometry has an instantiation; returns 1 if it ran, 0 if not, < 0 on error
 int try_fused_block(hipStream_t s, const StageDev& st, const BlockDev& b, float* h, int64_t B, const BlockExtra& ex, bool embed,
