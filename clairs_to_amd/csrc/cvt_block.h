@@ -309,9 +309,8 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
     {
         constexpr int NSLOT = NT / C;                                   // (site, position group) slots of one pass
         constexpr int PG = NSLOT > TS ? NSLOT / TS : 1;                 // more slots than sites: split a site's positions
-        constexpr int SL = NSLOT / PG, NIT = (TS + SL - 1) / SL;
+        constexpr int SL = PG > 1 ? TS : NSLOT, NIT = (TS + SL - 1) / SL;    // slots past SL * PG (TS does not divide NSLOT) idle
         constexpr int WQ = (W + PG - 1) / PG, WK = (WKV + PG - 1) / PG;
-        static_assert(SL * PG == NSLOT, "slot split");
         const int c = tid % C, slot = tid / C, pg = slot / SL, s0 = slot - pg * SL;
         const int wlo = pg * WQ, whi = min(W, wlo + WQ), klo = pg * WK, khi = min(WKV, klo + WK);
         const float q0 = p.dwq[c * 3], q1 = p.dwq[c * 3 + 1], q2 = p.dwq[c * 3 + 2];
@@ -328,7 +327,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int s = s0 + it * SL;
-            if (s < TS) {
+            if (s < TS && pg < PG) {
 #pragma unroll
                 for (int w = 0; w < W; ++w) {
                     if (PG > 1 && (w < wlo || w >= whi)) continue;
