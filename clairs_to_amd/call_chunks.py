@@ -15,7 +15,8 @@ Inside a rank the chunks flow through a three-stage pipeline, several chunks in 
                               re-used page-locked buffers                                               pileup_call.launch_chunk
     writers (thread pool)     alt_info strings + every VCF record in two C calls, file write            pileup_call.finish_chunk
 The GPU needs ~2 ms per 4 096-site chunk; one producer delivers a chunk in 7 ms (mpileup text) to 27 ms (BAM), so the rate is
-set by how many producers the host can run - `--producers` (default: a quarter of the usable cores, at most 16).
+set by how many producers the host can run - `--producers` (default: a quarter of the usable cores, half with the native BAM reader,
+at most 16).
 """
 import os
 import sys
@@ -52,6 +53,13 @@ def usable_cores():
     except Exception:
         pass
     return n
+
+
+def default_producers(native_bam):
+    """pack-producer threads per rank: a quarter of the usable cores for mpileup text (the tokeniser saturates memory bandwidth early),
+    half of them for the native BAM reader (inflate-bound, and its per-call serial parts - index, header, merge - want more calls in
+    flight: 8 producers x 8 threads gave 280 k sites/s on 16 cores where 4 x 8 gave 218 k)"""
+    return max(1, min(16, usable_cores() // (2 if native_bam else 4)))
 
 
 def run_pipeline(eng, chunk_args, producers=4, writers=2, depth=None, stats=None):
@@ -162,7 +170,7 @@ def call_chunks(args):
         for a in mine:                       # a chunk VCF left by an earlier run must not survive into this run's merge
             if os.path.exists(a.call_fn):
                 os.remove(a.call_fn)
-        producers = args.producers if getattr(args, "producers", None) else max(1, min(16, usable_cores() // 4))
+        producers = args.producers if getattr(args, "producers", None) else default_producers(getattr(args, "bam_reader", None) == "native")
         n_rows = run_pipeline(eng, mine, producers=producers, writers=getattr(args, "writers", None) or 2)
     except (Exception, SystemExit) as e:     # a bad reference, a corrupt BAM, CTO_EUNSUPPORTED ...: report, do not leave the others waiting
         failure = "%s: %s" % (type(e).__name__, e)
@@ -210,7 +218,7 @@ def main():
     p.add_argument("--final_vcf_fn", type=str, default=None, help="rank 0: postprocess_vcf of the merged VCF")
     p.add_argument("--mpileup_dir", type=str, default=None,
                    help="read <dir>/<chunk file name>.mpileup (samtools mpileup --min-BQ 0 text of the chunk) instead of the BAM")
-    p.add_argument("--producers", type=int, default=None, help="pack-producer threads per rank (default: usable cores / 4, <= 16)")
+    p.add_argument("--producers", type=int, default=None, help="pack-producer threads per rank (default: usable cores / 4, / 2 with --bam_reader native; <= 16)")
     p.add_argument("--writers", type=int, default=None, help="VCF-writer threads per rank (default 2)")
     call_chunks(p.parse_args())
 

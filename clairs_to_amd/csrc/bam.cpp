@@ -289,7 +289,13 @@ struct Read {
     // cursor: CIGAR op index, offset inside it, reference / query positions at the start of the op
     size_t op = 0;
     int32_t op_ref = 0, op_q = 0;
+    // reference positions op_ref <= rpos < fast_end lie inside the current op, which is an aligned run (M / = / X), and are not
+    // its last base (after which an indel may follow): the column loop packs them without looking at the CIGAR
+    int32_t fast_end = INT32_MIN;
 };
+
+// entry code of a 4-bit BAM base on the forward strand: A C G T -> 0..3, '=' -> -1 (take the reference base), IUPAC codes -> N
+const int8_t kNibCode[16] = {-1, 0, 1, 10, 2, 10, 10, 10, 3, 10, 10, 10, 10, 10, 10, 10};
 
 const char kNt16[] = "=ACMGRSVTWYHKDBN";
 
@@ -328,13 +334,57 @@ struct Producer {
     int64_t ref_start;
     size_t ref_len;
     int max_indel;
-    std::vector<Tok> toks;
-    std::deque<std::string> arena;      // inserted sequences of the current column (Tok::seq points into these)
+    // Columns are built in runs of up to RUN consecutive requested positions, read by read: a read's bases inside an aligned
+    // CIGAR run go to their columns in one tight loop (sequence, qualities and cursor stay in cache), and the order of the
+    // entries inside a column is still the order of the reads in `active` (= the order mpileup prints them in).
+    static constexpr int RUN = 64;
+    std::vector<uint32_t> ents[RUN];    // per column of the current run: packed entries, indel fields still empty
+    std::vector<IndelAt> indels[RUN];   // ... and which of them carry an indel
+    std::deque<std::string> arena;      // inserted sequences of the current run (IndelAt::seq points into these)
     std::string nbuf_up, nbuf_lo;       // runs of 'N' / 'n' for deletion keys
     std::string err;
 
-    // advances the read's cursor to reference position `rpos` (0-based) and appends its contribution to the column
-    void emit(Read& r, int32_t rpos) {
+    void begin_run(int ncol) {
+        for (int c = 0; c < ncol; ++c) { ents[c].clear(); indels[c].clear(); }
+        if (!arena.empty()) arena.clear();
+    }
+    // deletion keys are runs of 'N' / 'n' out of two shared buffers that emit_one() grows on demand
+    void seal_column(int c) {
+        for (IndelAt& it : indels[c])
+            if (it.kind == 2) {
+                const uint32_t code = ents[c][size_t(it.idx)] & 15u;
+                const bool rev = (code >= 4 && code <= 7) || code == 9 || code == 11;
+                it.seq = (rev ? nbuf_lo : nbuf_up).data();
+            }
+    }
+    // the read's contribution to the columns of reference positions lo .. hi (0-based, inside the read); run0 = position of column 0
+    void emit_run(Read& r, int32_t lo, int32_t hi, int32_t run0) {
+        const int mq = std::min(int(r.mapq), 93);              // mpileup prints min(MAPQ, 93) + 33, likewise for BQ
+        int32_t rp = lo;
+        while (rp <= hi) {
+            if (rp < r.fast_end) {                             // inside an aligned run, not its last base: no CIGAR work
+                const int32_t stop = std::min(hi + 1, r.fast_end);
+                int q = r.op_q + (rp - r.op_ref);
+                for (; rp < stop; ++rp, ++q) ents[rp - run0].push_back(pack_entry(code_at(r, q, rp), r.bq(q), mq));
+            } else {
+                emit_one(r, rp, rp - run0, mq);
+                ++rp;
+            }
+        }
+    }
+    int code_at(const Read& r, int q, int32_t rpos) const {
+        int code = kNibCode[r.base4(q)];
+        if (code < 0) {                                        // '=': the reference base (mpileup prints IUPAC codes; the decoder
+            const int64_t ri = int64_t(rpos) + 1 - ref_start;   // ignores all but ACGTN)
+            const char b = (ri >= 0 && size_t(ri) < ref_len) ? up(ref_seq[ri]) : 'N';
+            code = b == 'A' ? 0 : (b == 'C' ? 1 : (b == 'G' ? 2 : (b == 'T' ? 3 : 10)));
+        }
+        return r.rev ? code + ((code < 4) ? 4 : 1) : code;     // A..T -> a..t, N -> n
+    }
+    // advances the read's cursor to reference position `rpos` (0-based) and appends its contribution to column `col`
+    void emit_one(Read& r, int32_t rpos, int col, int mq) {
+        std::vector<uint32_t>& ents = this->ents[col];
+        std::vector<IndelAt>& indels = this->indels[col];
         while (r.op < r.cigar.size()) {
             const uint32_t c = r.cigar[r.op];
             const int len = int(c >> 4), opc = int(c & 15);
@@ -345,30 +395,20 @@ struct Producer {
             if (cons_q) r.op_q += len;
             ++r.op;
         }
+        r.fast_end = INT32_MIN;
         if (r.op >= r.cigar.size()) return;
         const uint32_t c = r.cigar[r.op];
         const int len = int(c >> 4), opc = int(c & 15);
         const int off = rpos - r.op_ref;
         if (opc == 3) return;                                  // N: reference skip, nothing in the pack
-        Tok t{0, 0, nullptr, 0, 0, std::min(int(r.mapq), 93)};      // mpileup prints min(MAPQ, 93) + 33, likewise for BQ
         if (opc == 2) {                                        // D: placeholder
-            t.code = r.rev ? 9 : 8;
-            t.bq = r.bq(r.op_q);
-            toks.push_back(t);
+            ents.push_back(pack_entry(r.rev ? 9 : 8, r.bq(r.op_q), mq));
             return;
         }
         // aligned base
+        r.fast_end = r.op_ref + len - 1;
         const int q = r.op_q + off;
-        char b = kNt16[r.base4(q)];
-        if (b == '=') {
-            const int64_t ri = int64_t(rpos) + 1 - ref_start;
-            b = (ri >= 0 && size_t(ri) < ref_len) ? up(ref_seq[ri]) : 'N';
-        }
-        if (b != 'A' && b != 'C' && b != 'G' && b != 'T') b = 'N';      // mpileup prints IUPAC codes; the decoder ignores all but ACGTN
-        int code = base_code(b);
-        if (r.rev) code += (code < 4) ? 4 : 1;                 // A..T -> a..t, N -> n
-        t.code = code;
-        t.bq = r.bq(q);
+        ents.push_back(pack_entry(code_at(r, q, rpos), r.bq(q), mq));
         if (off == len - 1) {                                  // last base of the op: does an indel follow?
             size_t nx = r.op + 1;
             while (nx < r.cigar.size() && (r.cigar[nx] & 15) == 6) ++nx;    // P
@@ -382,19 +422,14 @@ struct Producer {
                         if (ib == '=') ib = 'N';
                         s.push_back(r.rev ? char(ib | 0x20) : ib);
                     }
-                    t.kind = 1;
-                    t.seq = s.data();
-                    t.seqlen = nlen;
+                    indels.push_back(IndelAt{int(ents.size()) - 1, 1, s.data(), nlen});
                 } else if (nop == 2) {
-                    std::string& nb = r.rev ? nbuf_lo : nbuf_up;
-                    if (int(nb.size()) < nlen) nb.assign(size_t(nlen), r.rev ? 'n' : 'N');
-                    t.kind = 2;
-                    t.seq = nb.data();
-                    t.seqlen = nlen;
+                    std::string& nb = r.rev ? nbuf_lo : nbuf_up;      // may grow again within this column: the pointer is set
+                    if (int(nb.size()) < nlen) nb.assign(size_t(nlen), r.rev ? 'n' : 'N');      // by seal_column()
+                    indels.push_back(IndelAt{int(ents.size()) - 1, 2, nullptr, nlen});
                 }
             }
         }
-        toks.push_back(t);
     }
 };
 
@@ -459,29 +494,41 @@ int pack_from_bam_range(const char* bam_path, const char* bai_path, const char* 
     int64_t bed_cursor = 0;
     const int64_t beg0 = start - 1, end0 = end;   // 0-based half-open region
     auto flush_until = [&](int64_t limit1) -> int {   // emit columns next_col .. limit1 (1-based, inclusive)
-        for (; next_col <= limit1; ++next_col) {
+        while (next_col <= limit1) {
             while (!active.empty() && active.front().end <= next_col - 1) active.pop_front();
             if (active.empty()) { next_col = limit1 + 1; break; }       // nothing can cover the positions up to the limit
-            if (!in_bed(bed, n_bed, next_col, &bed_cursor)) continue;
-            pr.toks.clear();
-            pr.arena.clear();
-            const int32_t rpos = int32_t(next_col - 1);
+            int64_t last = std::min<int64_t>(limit1, next_col + Producer::RUN - 1);     // run of requested positions next_col .. last
+            if (bed) {
+                if (!in_bed(bed, n_bed, next_col, &bed_cursor)) {
+                    next_col = bed_cursor < n_bed ? std::max<int64_t>(next_col + 1, bed[2 * bed_cursor] + 1) : limit1 + 1;
+                    continue;
+                }
+                last = std::min<int64_t>(last, bed[2 * bed_cursor + 1]);      // 1-based inclusive end of the interval
+            }
+            const int ncol = int(last - next_col + 1);
+            pr.begin_run(ncol);
+            const int32_t lo0 = int32_t(next_col - 1), hi0 = int32_t(last - 1);
             size_t dead = 0;
             for (Read& r : active) {
-                if (r.pos <= rpos && rpos < r.end) pr.emit(r, rpos);
-                else dead += r.end <= rpos;
+                const int32_t lo = std::max(lo0, r.pos), hi = std::min(hi0, r.end - 1);
+                if (lo <= hi) pr.emit_run(r, lo, hi, lo0);
+                else dead += r.end <= lo0;
             }
             if (dead > 32 && dead * 2 > active.size())       // finished reads parked behind a long one: compact, keeping file order
-                active.erase(std::remove_if(active.begin(), active.end(), [&](const Read& r) { return r.end <= rpos; }), active.end());
-            if (pr.toks.empty()) continue;
-            const int64_t ri = next_col - ref_start;
-            if (ri < 0 || size_t(ri) >= ref_len) {
-                set_error("cto_pack_from_bam: position %lld outside the supplied reference", (long long)next_col);
-                return CTO_EINVAL;
+                active.erase(std::remove_if(active.begin(), active.end(), [&](const Read& r) { return r.end <= lo0; }), active.end());
+            for (int c = 0; c < ncol; ++c) {
+                if (pr.ents[c].empty()) continue;
+                pr.seal_column(c);
+                const int64_t pos1 = next_col + c, ri = pos1 - ref_start;
+                if (ri < 0 || size_t(ri) >= ref_len) {
+                    set_error("cto_pack_from_bam: position %lld outside the supplied reference", (long long)pos1);
+                    return CTO_EINVAL;
+                }
+                const int rc = append_column_packed(pr.p, pr.sc, pos1, ri, ref_seq, ref_len, max_indel_length, pr.ents[c].data(),
+                                                    int(pr.ents[c].size()), pr.indels[c].data(), int(pr.indels[c].size()), &pr.err);
+                if (rc != CTO_OK) { set_error("%s", pr.err.c_str()); return rc; }
             }
-            const int rc = append_column(pr.p, pr.sc, next_col, ri, ref_seq, ref_len, max_indel_length, pr.toks.data(),
-                                         int(pr.toks.size()), &pr.err);
-            if (rc != CTO_OK) { set_error("%s", pr.err.c_str()); return rc; }
+            next_col = last + 1;
         }
         return CTO_OK;
     };

@@ -147,6 +147,26 @@ int append_column(cto_pack* p, ColumnScratch& sc, int64_t pos, int64_t ri, const
     return CTO_OK;
 }
 
+int append_column_packed(cto_pack* p, ColumnScratch& sc, int64_t pos, int64_t ri, const char* ref_seq, size_t ref_len,
+                         int max_indel_length, const uint32_t* ents, int n, const IndelAt* indels, int n_indel, std::string* err) {
+    if (n > kMaxDepth) { set_err(err, "column depth %d > %d unsupported", n, kMaxDepth); return CTO_EUNSUPPORTED; }
+    column_scratch_reset(sc);
+    const size_t e0 = p->entries.size();
+    p->entries.resize(e0 + size_t(n));
+    memcpy(p->entries.data() + e0, ents, size_t(n) * sizeof(uint32_t));
+    int nkeys_col = 0;
+    for (int i = 0; i < n_indel; ++i) {
+        const IndelAt& it = indels[i];
+        uint32_t kind = 0, kid = 0;
+        const int rc = intern_indel(p, sc, &nkeys_col, int(ents[it.idx] & 15u), it.kind, it.seq, it.seqlen, ri, ref_seq, ref_len,
+                                    max_indel_length, &kind, &kid, err);
+        if (rc != CTO_OK) return rc;
+        p->entries[e0 + size_t(it.idx)] |= (kind << 4) | (kid << 21);
+    }
+    column_end(p, pos, ri, ref_seq);
+    return CTO_OK;
+}
+
 // Concatenates per-thread packs of consecutive position ranges (offsets re-based); nullptr + *err when they overlap.
 std::unique_ptr<cto_pack> merge_parts(std::vector<std::unique_ptr<cto_pack>>& parts, std::string* err) {
     if (parts.size() > 2) {

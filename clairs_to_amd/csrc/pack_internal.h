@@ -77,6 +77,18 @@ void pack_begin(cto_pack* p, size_t entries_hint, size_t cols_hint);
 int append_column(cto_pack* p, ColumnScratch& sc, int64_t pos, int64_t ri, const char* ref_seq, size_t ref_len,
                   int max_indel_length, const Tok* toks, int n, std::string* err);
 
+// The same for a producer that packs the plain read-bases itself: ents[0..n) are finished entries (code | bq << 6 | mq << 13)
+// except at the indices named by indels[0..n_indel), whose kind / key id are filled in here.
+struct IndelAt {
+    int idx;           // index into ents
+    int kind;          // 1 ins, 2 del
+    const char* seq;
+    int seqlen;
+};
+inline uint32_t pack_entry(int code, int bq, int mq) { return uint32_t(code) | (uint32_t(bq) << 6) | (uint32_t(mq) << 13); }
+int append_column_packed(cto_pack* p, ColumnScratch& sc, int64_t pos, int64_t ri, const char* ref_seq, size_t ref_len,
+                         int max_indel_length, const uint32_t* ents, int n, const IndelAt* indels, int n_indel, std::string* err);
+
 std::unique_ptr<cto_pack> merge_parts(std::vector<std::unique_ptr<cto_pack>>& parts, std::string* err);
 
 }  // namespace cto

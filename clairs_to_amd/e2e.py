@@ -43,8 +43,8 @@ def build_run(d, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, reg
 def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4):
     """the pipeline over a prepared run directory -> dict(sites_per_s, ...); best of `repeats` passes (the first one warms the page
     cache, the pinned buffers and the model workspaces)"""
-    from .call_chunks import run_pipeline, usable_cores
-    producers = producers if producers else max(1, min(16, usable_cores() // 4))
+    from .call_chunks import default_producers, run_pipeline
+    producers = producers if producers else default_producers(kind == "bam")
     os.makedirs(out_dir, exist_ok=True)
     chunk_args = chunk_namespaces(run, out_dir, bam=(kind == "bam"))
     best, rows, best_stats = None, 0, {}
