@@ -33,7 +33,7 @@ REFERENCE_PYTHON_NOTE = ("HKU-BAL/ClairS-TO v0.4.4 itself, build container (8 vC
 
 
 # MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE reports half the bytes of coalesced streaming reads (128-byte requests tallied
-# as 64 B).  Calibrated on this code's own access patterns (profiles/round2_b_pmc_hbm_traffic.json): k_featurize_columns reads the
+# as 64 B).  Calibrated on this code's own access patterns (profiles/round2_*_pmc_hbm_traffic.json): k_featurize_columns reads the
 # 28.6 MB pack exactly once and shows FETCH_SIZE = 14.8 MB -> x2; WRITE_SIZE is 1.0x (GRU layer 1 writes its 138.4 MB output: 138.4 MB).
 FETCH_CORRECTION = 2.0
 
