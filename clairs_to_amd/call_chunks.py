@@ -170,7 +170,7 @@ def call_chunks(args):
         for a in mine:                       # a chunk VCF left by an earlier run must not survive into this run's merge
             if os.path.exists(a.call_fn):
                 os.remove(a.call_fn)
-        producers = args.producers if getattr(args, "producers", None) else default_producers(getattr(args, "bam_reader", None) == "native")
+        producers = args.producers if getattr(args, "producers", None) else default_producers(getattr(args, "bam_reader", None) in ("native", "gpu"))
         n_rows = run_pipeline(eng, mine, producers=producers, writers=getattr(args, "writers", None) or 2)
     except (Exception, SystemExit) as e:     # a bad reference, a corrupt BAM, CTO_EUNSUPPORTED ...: report, do not leave the others waiting
         failure = "%s: %s" % (type(e).__name__, e)

@@ -70,10 +70,11 @@ def read_bed_intervals(bed_fn, ctg_name):
     return out
 
 
-def load_pack(args, ref, ref_start, ctg_start, ctg_end, max_indel):
+def load_pack(args, ref, ref_start, ctg_start, ctg_end, max_indel, device=None, stream=None):
     """The chunk's column pack from (in this order) `--mpileup_fn` text, the native BAM reader (`--bam_reader native`,
-    csrc/bam.cpp, parity unpinned) or `samtools mpileup` run exactly as the reference runs it except for `--min-BQ 0`
-    (create_tensor_pileup_calling.py:426-446): one pileup serves the AFF and the NEG pass."""
+    csrc/bam.cpp, parity unpinned; `--bam_reader gpu`: the same with the BGZF blocks inflated on `device`, csrc/inflate.hip) or
+    `samtools mpileup` run exactly as the reference runs it except for `--min-BQ 0` (create_tensor_pileup_calling.py:426-446):
+    one pileup serves the AFF and the NEG pass."""
     if getattr(args, "mpileup_fn", None):
         if args.mpileup_fn.endswith(".gz"):
             with gzip.open(args.mpileup_fn, "rb") as f:
@@ -84,10 +85,17 @@ def load_pack(args, ref, ref_start, ctg_start, ctg_end, max_indel):
         # plain text: mapped, not read - the tokeniser's threads pull the pages straight from the page cache
         return ColumnPack.from_mpileup(np.memmap(args.mpileup_fn, dtype=np.uint8, mode="r"), ref, ref_start, max_indel)
     ext_s, ext_e = max(1, ctg_start - NPOS), ctg_end + NPOS
-    if getattr(args, "bam_reader", "samtools") == "native":
+    reader = getattr(args, "bam_reader", "samtools")
+    if reader in ("native", "gpu"):
+        inflated = None
+        if reader == "gpu":
+            from .bgzf import inflate_span
+            inflated = inflate_span(args.tumor_bam_fn, None, args.ctg_name, ext_s, ext_e,
+                                    torch.device(device if device is not None else "cuda"), stream)
         return ColumnPack.from_bam(args.tumor_bam_fn, args.ctg_name, ext_s, ext_e, ref, ref_start,
                                    bed=read_bed_intervals(args.candidates_bed_regions, args.ctg_name),
-                                   max_depth=args.max_depth if args.max_depth is not None else 8000, max_indel_length=max_indel)
+                                   max_depth=args.max_depth if args.max_depth is not None else 8000, max_indel_length=max_indel,
+                                   inflated=inflated)
     cmd = "{} mpileup --reverse-del --output-MQ -r {}:{}-{} --min-MQ 0 --min-BQ 0 -l {} --excl-flags 2316".format(
         args.samtools, args.ctg_name, ext_s, ext_e, args.candidates_bed_regions)
     if args.max_depth is not None:
@@ -107,7 +115,7 @@ def create_tensor(args, device="cuda"):
     if not ref:
         sys.exit("[ERROR] Failed to load reference sequence from file ({}).".format(args.ref_fn))
     max_indel = MAX_INDEL if args.max_indel_length is None else args.max_indel_length
-    pack = load_pack(args, ref, ref_start, ctg_start, ctg_end, max_indel)
+    pack = load_pack(args, ref, ref_start, ctg_start, ctg_end, max_indel, device=device)
     dp = pack.to_device(device)
     feat = featurize(dp, torch.tensor(sites, dtype=torch.int32, device=device), args.min_bq, 0, want_raw=True, want_x=False)
     torch.cuda.synchronize()
@@ -145,7 +153,7 @@ def main():
     p.add_argument("--tensor_can_fn_neg", type=str, default=None, help="also write the --min_bq 0 (NEG) tensor")
     p.add_argument("--ctg_name", type=str, required=True)
     p.add_argument("--samtools", type=str, default="samtools")
-    p.add_argument("--bam_reader", type=str, default="samtools", choices=["samtools", "native"],
+    p.add_argument("--bam_reader", type=str, default="samtools", choices=["samtools", "native", "gpu"],
                    help="'native': built-in BAM + BAI reader instead of a samtools subprocess (parity unpinned, see csrc/bam.cpp)")
     p.add_argument("--min_bq", type=int, default=0)
     p.add_argument("--max_depth", type=int, default=None)

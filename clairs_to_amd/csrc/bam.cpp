@@ -70,9 +70,27 @@ const LibDeflate& libdeflate() {
     return ld;
 }
 
+// BGZF blocks that were inflated elsewhere (on the device: cto_bgzf_inflate), looked up by their file offset
+struct PreInflated {
+    const uint8_t* data = nullptr;
+    const cto_bgzf_block* blocks = nullptr;     // sorted by file_off
+    int64_t n = 0;
+    const cto_bgzf_block* find(int64_t coff) const {
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) / 2;
+            if (int64_t(blocks[mid].file_off) < coff) lo = mid + 1; else hi = mid;
+        }
+        return (lo < n && int64_t(blocks[lo].file_off) == coff) ? blocks + lo : nullptr;
+    }
+};
+
 struct Bgzf {
     FILE* f = nullptr;
-    std::vector<uint8_t> comp, block;   // compressed / inflated current block
+    std::vector<uint8_t> comp, block;   // compressed / inflated current block (when it was inflated here)
+    const uint8_t* bptr = nullptr;      // the current block's inflated bytes: block.data() or a slot of `pre`
+    size_t blen = 0;
+    PreInflated pre;
     int64_t block_coffset = -1;         // file offset of the current block
     int64_t next_coffset = 0;           // file offset of the block after it
     size_t upos = 0;                    // read position inside `block`
@@ -100,6 +118,14 @@ struct Bgzf {
     }
     // loads the block that starts at file offset `coff`; false at EOF (err stays empty) or on error
     bool load(int64_t coff) {
+        if (const cto_bgzf_block* pb = pre.find(coff)) {        // already inflated: a view, no file access
+            bptr = pre.data + pb->out_off;
+            blen = pb->isize;
+            block_coffset = coff;
+            next_coffset = coff + int64_t(pb->bsize);
+            upos = 0;
+            return true;
+        }
         if (coff != file_pos && fseeko(f, off_t(coff), SEEK_SET) != 0) { err = "seek failed"; return false; }   // sequential reads keep the stdio buffer
         file_pos = -1;
         uint8_t h[18];
@@ -146,6 +172,8 @@ struct Bgzf {
             const int rc = inflate(&zs, Z_FINISH);
             if (rc != Z_STREAM_END || zs.avail_out != 0) { err = "inflate failed"; return false; }
         }
+        bptr = block.data();
+        blen = block.size();
         block_coffset = coff;
         next_coffset = coff + bsize;
         file_pos = next_coffset;
@@ -156,23 +184,23 @@ struct Bgzf {
         const int64_t coff = int64_t(voff >> 16);
         if (coff != block_coffset && !load(coff)) return false;
         upos = size_t(voff & 0xffff);
-        return upos <= block.size();
+        return upos <= blen;
     }
     // virtual offset of the next byte; the end of a block is reported as the start of the next one, as index chunks do
     uint64_t tell() const {
-        if (block_coffset >= 0 && upos >= block.size()) return uint64_t(next_coffset) << 16;
+        if (block_coffset >= 0 && upos >= blen) return uint64_t(next_coffset) << 16;
         return (uint64_t(block_coffset) << 16) | uint64_t(upos);
     }
     // reads exactly n bytes across block boundaries; false at EOF / error
     bool read(void* dst, size_t n) {
         uint8_t* d = static_cast<uint8_t*>(dst);
         while (n > 0) {
-            if (block_coffset < 0 || upos >= block.size()) {
+            if (block_coffset < 0 || upos >= blen) {
                 if (!load(block_coffset < 0 ? 0 : next_coffset)) return false;
-                if (block.empty()) continue;          // empty blocks (e.g. the EOF marker) are skipped
+                if (blen == 0) continue;              // empty blocks (e.g. the EOF marker) are skipped
             }
-            const size_t take = std::min(n, block.size() - upos);
-            memcpy(d, block.data() + upos, take);
+            const size_t take = std::min(n, blen - upos);
+            memcpy(d, bptr + upos, take);
             upos += take;
             d += take;
             n -= take;
@@ -445,12 +473,8 @@ bool in_bed(const int64_t* bed, int64_t n_bed, int64_t pos1, int64_t* cursor) {
 namespace {
 
 // One position range [start, end] on one thread: own file handle, own index query.  Errors go through set_error (thread-local).
-int pack_from_bam_range(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
-                        const int64_t* bed, int64_t n_bed, const char* ref_seq, int64_t ref_start, size_t ref_len,
-                        int excl_flags, int min_mq, int max_depth, int max_indel_length, cto_pack** out) {
-    Bgzf bz;
-    CTO_REQUIRE(bz.open(bam_path), CTO_EINVAL, "cto_pack_from_bam: %s", bz.err.c_str());
-    // ---- header ----
+// tid of `ctg_name`: reads the BAM header through `bz` (positioned at the start of the file)
+int read_header_tid(Bgzf& bz, const char* bam_path, const char* ctg_name, int* tid_out) {
     uint8_t h4[4];
     CTO_REQUIRE(bz.read(h4, 4) && memcmp(h4, "BAM\1", 4) == 0, CTO_EINVAL, "cto_pack_from_bam: %s is not a BAM file%s%s", bam_path,
                 bz.err.empty() ? "" : ": ", bz.err.c_str());
@@ -473,6 +497,22 @@ int pack_from_bam_range(const char* bam_path, const char* bai_path, const char* 
         if (tid < 0 && strcmp(name.data(), ctg_name) == 0) tid = r;
     }
     CTO_REQUIRE(tid >= 0, CTO_EINVAL, "cto_pack_from_bam: contig %s not in the BAM header", ctg_name);
+    *tid_out = tid;
+    return CTO_OK;
+}
+
+int pack_from_bam_range(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
+                        const int64_t* bed, int64_t n_bed, const char* ref_seq, int64_t ref_start, size_t ref_len,
+                        int excl_flags, int min_mq, int max_depth, int max_indel_length, const PreInflated& pre, cto_pack** out) {
+    Bgzf bz;
+    CTO_REQUIRE(bz.open(bam_path), CTO_EINVAL, "cto_pack_from_bam: %s", bz.err.c_str());
+    bz.pre = pre;
+    uint8_t h4[4];
+    int tid = -1;
+    {
+        const int rch = read_header_tid(bz, bam_path, ctg_name, &tid);
+        if (rch != CTO_OK) return rch;
+    }
     // ---- index ----
     std::vector<Chunk> chunks;
     {
@@ -672,7 +712,7 @@ int guarded(const char* what, F&& f) {
 
 int pack_from_bam_impl(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
                        const int64_t* bed, int64_t n_bed, const char* ref_seq, int64_t ref_start, size_t ref_len,
-                       int excl_flags, int min_mq, int max_depth, int max_indel_length, cto_pack** out) {
+                       int excl_flags, int min_mq, int max_depth, int max_indel_length, const PreInflated& pre, cto_pack** out) {
     CTO_REQUIRE(bam_path && ctg_name && ref_seq && out, CTO_EINVAL, "cto_pack_from_bam: null argument");
     CTO_REQUIRE(start >= 1 && end >= start, CTO_EINVAL, "cto_pack_from_bam: bad region %lld-%lld", (long long)start, (long long)end);
     CTO_REQUIRE(n_bed == 0 || bed, CTO_EINVAL, "cto_pack_from_bam: bed intervals missing");
@@ -694,7 +734,7 @@ int pack_from_bam_impl(const char* bam_path, const char* bai_path, const char* c
     nt = unsigned(std::max<int64_t>(1, std::min<int64_t>(nt, want / 2000)));      // at least ~2000 positions per thread
     if (nt == 1)
         return pack_from_bam_range(bam_path, bai_path, ctg_name, start, end, bed, n_bed, ref_seq, ref_start, ref_len, excl_flags, min_mq,
-                                   max_depth, max_indel_length, out);
+                                   max_depth, max_indel_length, pre, out);
     // cut points: the position at which each thread's share of the requested positions begins
     std::vector<int64_t> cut(nt + 1, end + 1);
     cut[0] = start;
@@ -723,7 +763,7 @@ int pack_from_bam_impl(const char* bam_path, const char* bai_path, const char* c
         if (cut[t + 1] - 1 < cut[t]) { parts[t].reset(new cto_pack()); pack_begin(parts[t].get(), 16, 16); return; }
         rcs[t] = guarded("cto_pack_from_bam", [&] {
             return pack_from_bam_range(bam_path, bai_path, ctg_name, cut[t], cut[t + 1] - 1, bed, n_bed, ref_seq, ref_start, ref_len,
-                                       excl_flags, min_mq, max_depth, max_indel_length, &p);
+                                       excl_flags, min_mq, max_depth, max_indel_length, pre, &p);
         });
         if (rcs[t] != CTO_OK) errs[t] = cto_last_error();
         parts[t].reset(p);
@@ -749,6 +789,92 @@ extern "C" int cto_pack_from_bam(const char* bam_path, const char* bai_path, con
                                   int excl_flags, int min_mq, int max_depth, int max_indel_length, cto_pack** out) {
     return guarded("cto_pack_from_bam", [&] {
         return pack_from_bam_impl(bam_path, bai_path, ctg_name, start, end, bed, n_bed, ref_seq, ref_start, ref_len, excl_flags, min_mq,
-                                  max_depth, max_indel_length, out);
+                                  max_depth, max_indel_length, PreInflated{}, out);
     });
+}
+
+extern "C" int cto_pack_from_bam_inflated(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
+                                           const int64_t* bed, int64_t n_bed, const char* ref_seq, int64_t ref_start, size_t ref_len,
+                                           int excl_flags, int min_mq, int max_depth, int max_indel_length, const uint8_t* inflated,
+                                           const cto_bgzf_block* blocks, int64_t n_blocks, cto_pack** out) {
+    return guarded("cto_pack_from_bam_inflated", [&] {
+        CTO_REQUIRE(n_blocks >= 0 && (n_blocks == 0 || (inflated && blocks)), CTO_EINVAL, "cto_pack_from_bam_inflated: null argument");
+        for (int64_t i = 1; i < n_blocks; ++i)
+            CTO_REQUIRE(blocks[i].file_off > blocks[i - 1].file_off, CTO_EINVAL, "cto_pack_from_bam_inflated: block table not sorted");
+        PreInflated pre;
+        pre.data = inflated;
+        pre.blocks = blocks;
+        pre.n = n_blocks;
+        return pack_from_bam_impl(bam_path, bai_path, ctg_name, start, end, bed, n_bed, ref_seq, ref_start, ref_len, excl_flags, min_mq,
+                                  max_depth, max_indel_length, pre, out);
+    });
+}
+
+// The byte range of the BAM that holds every BGZF block the index names for ctg:start-end (the block the last chunk ends in
+// included: a BGZF block is at most 64 KiB long).
+extern "C" int cto_bam_chunk_span(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
+                                   int64_t* file_begin, int64_t* file_end) {
+    return guarded("cto_bam_chunk_span", [&] {
+        CTO_REQUIRE(bam_path && ctg_name && file_begin && file_end, CTO_EINVAL, "cto_bam_chunk_span: null argument");
+        CTO_REQUIRE(start >= 1 && end >= start, CTO_EINVAL, "cto_bam_chunk_span: bad region %lld-%lld", (long long)start, (long long)end);
+        Bgzf bz;
+        CTO_REQUIRE(bz.open(bam_path), CTO_EINVAL, "cto_bam_chunk_span: %s", bz.err.c_str());
+        int tid = -1;
+        const int rch = read_header_tid(bz, bam_path, ctg_name, &tid);
+        if (rch != CTO_OK) return rch;
+        std::vector<Chunk> chunks;
+        std::string err, idx = bai_path ? std::string(bai_path) : std::string(bam_path) + ".bai";
+        CTO_REQUIRE(bai_query(idx.c_str(), tid, start - 1, end, &chunks, &err), CTO_EINVAL, "cto_bam_chunk_span: %s", err.c_str());
+        CTO_REQUIRE(fseeko(bz.f, 0, SEEK_END) == 0, CTO_EINVAL, "cto_bam_chunk_span: seek failed");
+        const int64_t fsize = int64_t(ftello(bz.f));
+        int64_t lo = fsize, hi = 0;
+        for (const Chunk& c : chunks) {
+            lo = std::min<int64_t>(lo, int64_t(c.beg >> 16));
+            hi = std::max<int64_t>(hi, int64_t(c.end >> 16) + 65536);
+        }
+        if (chunks.empty()) { lo = 0; hi = 0; }
+        *file_begin = lo;
+        *file_end = std::min(hi, fsize);
+        return CTO_OK;
+    });
+}
+
+// Block table of a run of whole BGZF blocks (a trailing partial block is left out).
+extern "C" int64_t cto_bgzf_scan(const uint8_t* bytes, size_t len, int64_t file_begin, cto_bgzf_block* blocks, int64_t cap, int64_t* out_bytes) {
+    if (!bytes || !blocks || !out_bytes) { set_error("cto_bgzf_scan: null argument"); return CTO_EINVAL; }
+    size_t o = 0;
+    int64_t n = 0, out = 0;
+    while (o + 18 <= len) {
+        const uint8_t* h = bytes + o;
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { set_error("cto_bgzf_scan: not a BGZF block header at byte %zu", o); return CTO_EINVAL; }
+        const size_t xlen = size_t(h[10]) | (size_t(h[11]) << 8);
+        if (o + 12 + xlen > len) break;
+        int64_t bsize = -1;
+        for (size_t i = 0; i + 4 <= xlen;) {
+            const uint8_t* e = h + 12 + i;
+            const size_t slen = size_t(e[2]) | (size_t(e[3]) << 8);
+            if (e[0] == 'B' && e[1] == 'C' && slen == 2 && i + 6 <= xlen) bsize = int64_t(e[4] | (e[5] << 8)) + 1;
+            i += 4 + slen;
+        }
+        if (bsize < 0) { set_error("cto_bgzf_scan: BGZF block without BC subfield at byte %zu", o); return CTO_EINVAL; }
+        const int64_t cdata = bsize - int64_t(xlen) - 12 - 8;
+        if (cdata < 0) { set_error("cto_bgzf_scan: bad BGZF block size at byte %zu", o); return CTO_EINVAL; }
+        if (o + size_t(bsize) > len) break;                     // partial block at the end of the range
+        const uint8_t* tail = h + bsize - 8;
+        const uint32_t isize = uint32_t(tail[4]) | (uint32_t(tail[5]) << 8) | (uint32_t(tail[6]) << 16) | (uint32_t(tail[7]) << 24);
+        if (isize > 65536) { set_error("cto_bgzf_scan: BGZF block claims more than 64 KiB of data"); return CTO_EINVAL; }
+        if (n >= cap) { set_error("cto_bgzf_scan: more than %lld blocks", (long long)cap); return CTO_ENOMEM; }
+        cto_bgzf_block& b = blocks[n++];
+        b.file_off = uint64_t(file_begin) + o;
+        b.in_off = o + 12 + xlen;
+        b.out_off = uint64_t(out);
+        b.csize = uint32_t(cdata);
+        b.isize = isize;
+        b.bsize = uint32_t(bsize);
+        b.pad_ = 0;
+        out += (int64_t(isize) + 4 + 255) / 256 * 256;           // dword-granular tail stores stay inside the slot
+        o += size_t(bsize);
+    }
+    *out_bytes = out;
+    return n;
 }

@@ -1,0 +1,342 @@
+// BGZF / DEFLATE (RFC 1951) decompression on the device: one wavefront per BGZF block.
+//
+// Why: the native BAM -> pack producer (bam.cpp) is bound by inflate on the host - 80 % of the 210 core-ms
+// a 1 Mb x 50x chunk costs is file read + libdeflate + record parsing - while the device idles.  BGZF blocks
+// are independent DEFLATE streams of at most 64 KiB, so a chunk's ~750 blocks inflate side by side.
+//
+// A DEFLATE stream is decoded serially, symbol by symbol, so the wave works as ONE decoder whose 64 lanes do the wide steps:
+//   * bit reader: the compressed bytes are fetched 256 B at a time (one coalesced dword per lane, the next 256 B already in
+//     flight) and handed to a 64-bit bit buffer dword by dword with v_readlane;
+//   * Huffman decode without tables in memory: the codes are canonical, so lane L (1..15) holds first_code[L], count[L] and
+//     offset[L], bit-reverses the next L bits and tests first <= code < first + count - exactly one lane hits; a ballot names the
+//     length, a readlane fetches offset + code - first, the symbol comes out of the sorted symbol list held in 5 + 1 registers
+//     per lane;
+//   * LZ77 window: a 32 KiB ring in LDS; literals are written by lane 0, matches are copied by all lanes at once (source index
+//     (k mod distance) for overlapping copies), and every 16 KiB the finished half of the ring leaves for HBM as coalesced dwords.
+// Every loop is bounded by the block's compressed size (a symbol consumes at least one bit) or by constants; malformed input
+// ends with a status code, never with a hang or an out-of-range access (the input buffer carries CTO_BGZF_PAD bytes of padding,
+// every output slot is padded to 256 bytes).
+#include "common.h"
+
+namespace {
+
+constexpr int WIN = 32768, WMASK = WIN - 1, HALF = 16384;
+
+__constant__ uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+__device__ __forceinline__ uint32_t rl(uint32_t v, int lane) {      // value of `v` in lane `lane` (wave-uniform lane index)
+    return uint32_t(__builtin_amdgcn_readlane(int(v), __builtin_amdgcn_readfirstlane(lane)));
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+struct Bits {                     // wave-uniform bit reader over dwords of global memory
+    const uint32_t* src;          // dword-aligned base
+    uint32_t win, nxt;            // per lane: dword (wbase + lane) and dword (wbase + 64 + lane)
+    int wbase, widx;              // dword index of win's lane 0; next dword to hand out
+    uint64_t bb;                  // bit buffer, next bit = bit 0
+    int cnt;                      // valid bits in bb
+    long long used;               // bits consumed so far (relative to src + first_bit)
+};
+
+__device__ __forceinline__ void bits_init(Bits& b, const uint8_t* p, int lane) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    b.src = reinterpret_cast<const uint32_t*>(a & ~uintptr_t(3));
+    b.wbase = 0;
+    b.widx = 0;
+    b.win = b.src[lane];
+    b.nxt = b.src[64 + lane];
+    b.bb = 0;
+    b.cnt = 0;
+    b.used = 0;
+    const int skip = int(a & 3) * 8;       // bits of the first dword that precede the stream
+    // first refill, then drop the leading bits
+    b.bb = uint64_t(rl(b.win, 0)) | (uint64_t(rl(b.win, 1)) << 32);
+    b.widx = 2;
+    b.cnt = 64 - skip;
+    b.bb >>= skip;
+}
+__device__ __forceinline__ void bits_refill(Bits& b, int lane) {
+    if (b.cnt <= 32) {
+        if (b.widx - b.wbase >= 64) {
+            b.wbase += 64;
+            b.win = b.nxt;
+            b.nxt = b.src[b.wbase + 64 + lane];
+        }
+        const uint32_t d = rl(b.win, b.widx - b.wbase);
+        b.bb |= uint64_t(d) << b.cnt;
+        b.cnt += 32;
+        ++b.widx;
+    }
+}
+__device__ __forceinline__ uint32_t bits_peek(const Bits& b, int n) { return uint32_t(b.bb) & ((1u << n) - 1u); }
+__device__ __forceinline__ void bits_drop(Bits& b, int n) { b.bb >>= n; b.cnt -= n; b.used += n; }
+
+struct Huff {                     // per lane L: the codes of length L (lanes 1..15); sorted symbols: entry i in register i / 64, lane i % 64
+    uint32_t first, count, offset;
+    uint32_t sym[5];
+};
+
+// lens[0..n) (LDS) -> canonical decoder; scratch: sorted symbol list (LDS, n entries).  Returns false for an over-subscribed code.
+template <int NREG>
+__device__ bool huff_build(Huff& h, const uint8_t* lens, int n, uint16_t* sorted, int lane) {
+    uint32_t cnt = 0;
+    if (lane >= 1 && lane <= 15)
+        for (int s = 0; s < n; ++s) cnt += (lens[s] == lane);
+    h.count = cnt;
+    uint32_t first = 0, offset = 0, code = 0, off = 0;
+    int left = 1;
+    bool ok = true;
+#pragma unroll
+    for (int L = 1; L <= 15; ++L) {
+        const uint32_t c = rl(cnt, L);
+        code <<= 1;                       // first code of length L
+        left = (left << 1) - int(c);
+        ok = ok && left >= 0;
+        if (lane == L) { first = code; offset = off; }
+        code += c;
+        off += c;
+    }
+    h.first = first;
+    h.offset = offset;
+    if (lane >= 1 && lane <= 15) {        // lane L lists its symbols in increasing order behind offset[L]
+        uint32_t k = offset;
+        for (int s = 0; s < n; ++s)
+            if (lens[s] == lane) sorted[k++] = uint16_t(s);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+        const int i = r * 64 + lane;
+        h.sym[r] = i < n ? sorted[i] : 0u;
+    }
+    return ok;
+}
+
+// next symbol of the code (bits32 = the next 32 bits of the stream, bit 0 first); *len = its code length; -1: no such code
+template <int NREG>
+__device__ __forceinline__ int huff_decode(const Huff& h, uint32_t bits32, int lane, int* len) {
+    const uint32_t rev = __brev(bits32);
+    const bool live = lane >= 1 && lane <= 15;
+    const uint32_t code = live ? rev >> (32 - lane) : 0u;
+    const uint32_t rel = code - h.first;
+    const bool hit = live && rel < h.count;
+    const uint64_t m = __ballot(hit);
+    if (m == 0) return -1;
+    const int l = __ffsll((long long)m) - 1;
+    const int idx = int(rl(h.offset + rel, l));
+    *len = l;
+    const int reg = idx >> 6, ln = idx & 63;
+    uint32_t v = rl(h.sym[0], ln);
+#pragma unroll
+    for (int r = 1; r < NREG; ++r) {
+        const uint32_t w = rl(h.sym[r], ln);
+        v = reg == r ? w : v;
+    }
+    return int(v);
+}
+
+enum { ST_OK = 0, ST_BAD_BTYPE = 1, ST_BAD_STORED = 2, ST_BAD_TABLE = 3, ST_BAD_CODE = 4, ST_BAD_DIST = 5, ST_OVERRUN_OUT = 6, ST_OVERRUN_IN = 7, ST_SHORT = 8 };
+
+}  // namespace
+
+extern "C" __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* __restrict__ comp, const cto_bgzf_block* __restrict__ blocks,
+                                                                int n_blocks, uint8_t* __restrict__ out, int* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint8_t ring[WIN];
+    __shared__ uint8_t lens[320];
+    __shared__ uint16_t sorted[320];
+    const int lane = threadIdx.x;
+    const int blk = blockIdx.x;
+    if (blk >= n_blocks) return;
+    const cto_bgzf_block bd = blocks[blk];
+    const int isize = int(bd.isize);
+    const long long in_bits = (long long)bd.csize * 8;
+    uint8_t* dst = out + bd.out_off;
+    int st = ST_OK;
+    int op = 0, flushed = 0;            // bytes produced / bytes already copied to HBM (multiple of HALF)
+
+    auto flush_half = [&]() {           // ring[flushed .. flushed + HALF) -> HBM, coalesced dwords
+        const uint32_t* r32 = reinterpret_cast<const uint32_t*>(ring + (flushed & WMASK));
+        uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + flushed);
+        for (int i = lane; i < HALF / 4; i += 64) d32[i] = r32[i];
+        flushed += HALF;
+    };
+
+    if (isize > 0) {
+        Bits b;
+        bits_init(b, comp + bd.in_off, lane);
+        Huff hl, hd;
+        bool final_block = false;
+        while (!final_block && st == ST_OK) {
+            bits_refill(b, lane);
+            final_block = bits_peek(b, 1) != 0;
+            const int btype = int(bits_peek(b, 3) >> 1);
+            bits_drop(b, 3);
+            if (btype == 0) {                                    // stored
+                bits_drop(b, int((8 - (b.used & 7)) & 7));
+                bits_refill(b, lane);
+                const uint32_t len = bits_peek(b, 16);
+                bits_drop(b, 16);
+                bits_refill(b, lane);
+                const uint32_t nlen = bits_peek(b, 16);
+                bits_drop(b, 16);
+                if ((len ^ nlen) != 0xffffu) { st = ST_BAD_STORED; break; }
+                if (op + int(len) > isize) { st = ST_OVERRUN_OUT; break; }
+                for (uint32_t i = 0; i < len; ++i) {
+                    if (op - flushed > WIN - 512) { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier(); flush_half(); }
+                    bits_refill(b, lane);
+                    const uint32_t v = bits_peek(b, 8);
+                    bits_drop(b, 8);
+                    if (lane == 0) ring[op & WMASK] = uint8_t(v);
+                    ++op;
+                }
+                if (b.used > in_bits + 64) { st = ST_OVERRUN_IN; break; }
+                continue;
+            }
+            if (btype == 3) { st = ST_BAD_BTYPE; break; }
+            int nlit = 288, ndist = 30;
+            if (btype == 1) {                                    // fixed codes
+                for (int i = lane; i < 320; i += 64) lens[i] = uint8_t(i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : (i < 288 ? 8 : 5))));
+                nlit = 288;
+                ndist = 30;
+            } else {                                             // dynamic codes
+                bits_refill(b, lane);
+                nlit = int(bits_peek(b, 5)) + 257;
+                bits_drop(b, 5);
+                ndist = int(bits_peek(b, 5)) + 1;
+                bits_drop(b, 5);
+                const int ncl = int(bits_peek(b, 4)) + 4;
+                bits_drop(b, 4);
+                if (nlit > 286 || ndist > 30) { st = ST_BAD_TABLE; break; }
+                if (lane < 19) lens[lane] = 0;
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_wave_barrier();
+                for (int i = 0; i < ncl; ++i) {
+                    bits_refill(b, lane);
+                    const uint32_t v = bits_peek(b, 3);
+                    bits_drop(b, 3);
+                    if (lane == 0) lens[kClOrder[i]] = uint8_t(v);
+                }
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_wave_barrier();
+                Huff hc;
+                if (!huff_build<1>(hc, lens, 19, sorted, lane)) { st = ST_BAD_TABLE; break; }
+                // the code lengths of both alphabets, run-length coded (the decoded lengths overwrite lens[] from 0 on:
+                // hc is complete in registers by now)
+                __builtin_amdgcn_wave_barrier();
+                int i = 0, prev = 0;
+                const int total = nlit + ndist;
+                while (i < total && st == ST_OK) {
+                    bits_refill(b, lane);
+                    int l = 0;
+                    const int s = huff_decode<1>(hc, uint32_t(b.bb), lane, &l);
+                    if (s < 0) { st = ST_BAD_TABLE; break; }
+                    bits_drop(b, l);
+                    int rep = 1, val = s;
+                    if (s == 16) { if (i == 0) { st = ST_BAD_TABLE; break; } rep = 3 + int(bits_peek(b, 2)); bits_drop(b, 2); val = prev; }
+                    else if (s == 17) { rep = 3 + int(bits_peek(b, 3)); bits_drop(b, 3); val = 0; }
+                    else if (s == 18) { rep = 11 + int(bits_peek(b, 7)); bits_drop(b, 7); val = 0; }
+                    if (i + rep > total) { st = ST_BAD_TABLE; break; }
+                    if (lane < rep) lens[i + lane] = uint8_t(val);
+                    if (lane + 64 < rep) lens[i + lane + 64] = uint8_t(val);
+                    if (lane + 128 < rep) lens[i + lane + 128] = uint8_t(val);
+                    i += rep;
+                    prev = val;
+                    if (b.used > in_bits + 64) st = ST_OVERRUN_IN;
+                }
+                if (st != ST_OK) break;
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_wave_barrier();
+                // the distance lengths follow the literal / length ones: move them to lens[288..)
+                uint8_t dl = 0;
+                if (lane < ndist) dl = lens[nlit + lane];
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 32) lens[288 + lane] = lane < ndist ? dl : uint8_t(0);
+                for (int k = nlit + lane; k < 288; k += 64) lens[k] = 0;
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+            if (!huff_build<5>(hl, lens, 288, sorted, lane)) { st = ST_BAD_TABLE; break; }
+            __builtin_amdgcn_wave_barrier();
+            huff_build<1>(hd, lens + 288, 30, sorted, lane);     // an incomplete distance code is legal (one code, or none)
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- symbols ----
+            for (;;) {
+                if (op - flushed > WIN - 512) {                  // room for the longest match before the unflushed half is reached
+                    __builtin_amdgcn_s_waitcnt(0);
+                    __builtin_amdgcn_wave_barrier();
+                    flush_half();
+                }
+                bits_refill(b, lane);
+                int l = 0;
+                const int s = huff_decode<5>(hl, uint32_t(b.bb), lane, &l);
+                if (s < 0) { st = ST_BAD_CODE; break; }
+                bits_drop(b, l);
+                if (b.used > in_bits + 64) { st = ST_OVERRUN_IN; break; }
+                if (s < 256) {
+                    if (op >= isize) { st = ST_OVERRUN_OUT; break; }
+                    if (lane == 0) ring[op & WMASK] = uint8_t(s);
+                    ++op;
+                } else if (s == 256) {
+                    break;
+                } else {
+                    const int ls = s - 257;
+                    if (ls >= 29) { st = ST_BAD_CODE; break; }
+                    const int le = kLenExtra[ls];
+                    const int n = int(kLenBase[ls]) + int(bits_peek(b, le));
+                    bits_drop(b, le);
+                    bits_refill(b, lane);
+                    int dlb = 0;
+                    const int ds = huff_decode<1>(hd, uint32_t(b.bb), lane, &dlb);
+                    if (ds < 0 || ds >= 30) { st = ST_BAD_DIST; break; }
+                    bits_drop(b, dlb);
+                    const int de = kDistExtra[ds];
+                    const int d = int(kDistBase[ds]) + int(bits_peek(b, de));
+                    bits_drop(b, de);
+                    if (d > op) { st = ST_BAD_DIST; break; }
+                    if (op + n > isize) { st = ST_OVERRUN_OUT; break; }
+                    __builtin_amdgcn_s_waitcnt(0);               // lane 0's literal writes are in the ring
+                    __builtin_amdgcn_wave_barrier();
+                    const int from = op - d;
+                    for (int k = lane; k < n; k += 64) {
+                        const int sk = d >= n ? k : k % d;
+                        ring[(op + k) & WMASK] = ring[(from + sk) & WMASK];
+                    }
+                    __builtin_amdgcn_s_waitcnt(0);
+                    __builtin_amdgcn_wave_barrier();
+                    op += n;
+                }
+            }
+        }
+        if (st == ST_OK && op != isize) st = ST_SHORT;
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        // what is left in the ring (at most WIN bytes, from a multiple of HALF on): dwords, the slot is padded
+        if (st == ST_OK) {
+            while (flushed < op) {
+                const int nb = min(HALF, op - flushed);
+                const uint32_t* r32 = reinterpret_cast<const uint32_t*>(ring + (flushed & WMASK));
+                uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + flushed);
+                for (int i = lane; i < (nb + 3) / 4; i += 64) d32[i] = r32[i];
+                flushed += HALF;
+            }
+        }
+    }
+    if (lane == 0) status[blk] = st;
+}
+
+extern "C" int cto_bgzf_inflate(const void* d_comp, const cto_bgzf_block* d_blocks, int n_blocks, void* d_out, int* d_status, void* stream) {
+    using namespace cto;
+    CTO_REQUIRE(n_blocks >= 0 && (n_blocks == 0 || (d_comp && d_blocks && d_out && d_status)), CTO_EINVAL, "cto_bgzf_inflate: null argument");
+    if (n_blocks == 0) return CTO_OK;
+    hipLaunchKernelGGL(k_bgzf_inflate, dim3(unsigned(n_blocks)), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint8_t*>(d_comp), d_blocks, n_blocks, static_cast<uint8_t*>(d_out), d_status);
+    CTO_HIP(hipGetLastError());
+    return CTO_OK;
+}

@@ -10,12 +10,12 @@ import time
 from argparse import Namespace
 
 
-def chunk_namespaces(run, out_dir, bam=False):
+def chunk_namespaces(run, out_dir, bam=False, bam_reader="native"):
     """one pileup_call Namespace per chunk file of a synthetic run directory (synth_run.make_text_run / make_bam_run)"""
     from .call_chunks import chunk_contig
     out = []
     for bed in run["chunks"]:
-        a = Namespace(platform="ont", ref_fn=run["ref_fn"], samtools="samtools", bam_reader="native" if bam else "samtools",
+        a = Namespace(platform="ont", ref_fn=run["ref_fn"], samtools="samtools", bam_reader=bam_reader if bam else "samtools",
                       tumor_bam_fn=run.get("bam_fn"), min_bq=None, max_depth=None, max_indel_length=None, min_rescale_cov=50,
                       disable_indel_calling=True, sample_name="SAMPLE", show_ref=False, qual=0, pileup=True, predict_fn=None,
                       output_dir=out_dir)
@@ -40,13 +40,13 @@ def build_run(d, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, reg
         region_kb, os.path.getsize(run["bam_fn"]) / 1e6, len(run["chunks"]))
 
 
-def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4):
+def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4, bam_reader="native"):
     """the pipeline over a prepared run directory -> dict(sites_per_s, ...); best of `repeats` passes (the first one warms the page
     cache, the pinned buffers and the model workspaces)"""
     from .call_chunks import default_producers, run_pipeline
     producers = producers if producers else default_producers(kind == "bam")
     os.makedirs(out_dir, exist_ok=True)
-    chunk_args = chunk_namespaces(run, out_dir, bam=(kind == "bam"))
+    chunk_args = chunk_namespaces(run, out_dir, bam=(kind == "bam"), bam_reader=bam_reader)
     best, rows, best_stats = None, 0, {}
     for _ in range(max(1, repeats)):
         stats = {}

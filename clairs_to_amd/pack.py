@@ -44,9 +44,10 @@ class ColumnPack:
 
     @classmethod
     def from_bam(cls, bam_fn, ctg_name, start, end, ref_seq, ref_start, bed=None, bai_fn=None, excl_flags=2316, min_mq=0,
-                 max_depth=8000, max_indel_length=60):
+                 max_depth=8000, max_indel_length=60, inflated=None):
         """The pack of `samtools mpileup -r ctg:start-end --min-BQ 0 ...` on `bam_fn`, without samtools (cto_pack_from_bam;
-        PARITY UNPINNED, see csrc/bam.cpp).  bed: iterable of 0-based [begin, end) intervals restricting the positions."""
+        PARITY UNPINNED, see csrc/bam.cpp).  bed: iterable of 0-based [begin, end) intervals restricting the positions.
+        inflated = (host uint8 tensor, block table) from bgzf.inflate_span: the BGZF blocks were inflated on the device."""
         rb = ref_seq.encode() if isinstance(ref_seq, str) else bytes(ref_seq)
         iv = None
         if bed is not None:
@@ -59,6 +60,15 @@ class ColumnPack:
                     merged.append([a, b])
             iv = np.ascontiguousarray(np.array(merged, dtype=np.int64).reshape(-1, 2))
         out = c_vp()
+        if inflated is not None:
+            h_out, blocks = inflated
+            blocks = np.ascontiguousarray(blocks)
+            check(lib.cto_pack_from_bam_inflated(str(bam_fn).encode(), str(bai_fn).encode() if bai_fn else None, ctg_name.encode(),
+                                                 int(start), int(end), iv.ctypes.data if iv is not None and len(iv) else None,
+                                                 len(iv) if iv is not None else 0, rb, int(ref_start), len(rb), int(excl_flags),
+                                                 int(min_mq), int(max_depth), int(max_indel_length), h_out.data_ptr(),
+                                                 blocks.ctypes.data, len(blocks), C.byref(out)))
+            return cls(out.value)
         check(lib.cto_pack_from_bam(str(bam_fn).encode(), str(bai_fn).encode() if bai_fn else None, ctg_name.encode(), int(start),
                                     int(end), iv.ctypes.data if iv is not None and len(iv) else None, len(iv) if iv is not None else 0,
                                     rb, int(ref_start), len(rb), int(excl_flags), int(min_mq), int(max_depth), int(max_indel_length),

@@ -55,7 +55,7 @@ def prepare_chunk(args, device=None, copy_stream=None):
     if not ref:
         sys.exit("[ERROR] Failed to load reference sequence from file ({}).".format(args.ref_fn))
     max_indel = MAX_INDEL if args.max_indel_length is None else args.max_indel_length
-    pack = load_pack(args, ref, ref_start, ctg_start, ctg_end, max_indel)
+    pack = load_pack(args, ref, ref_start, ctg_start, ctg_end, max_indel, device=device, stream=copy_stream)
     prep = dict(sites=sites, ref=ref, ref_start=ref_start, pack=pack)
     if device is not None:
         with torch.cuda.device(device), torch.cuda.stream(copy_stream if copy_stream is not None else torch.cuda.current_stream(device)):
@@ -167,7 +167,7 @@ def add_common_arguments(p):
     p.add_argument("--tumor_bam_fn", type=str, default=None)
     p.add_argument("--ref_fn", type=str, required=True)
     p.add_argument("--samtools", type=str, default="samtools")
-    p.add_argument("--bam_reader", type=str, default="samtools", choices=["samtools", "native"],
+    p.add_argument("--bam_reader", type=str, default="samtools", choices=["samtools", "native", "gpu"],
                    help="'native': built-in BAM + BAI reader instead of a samtools subprocess (parity unpinned, see csrc/bam.cpp)")
     p.add_argument("--min_bq", type=int, default=None, help="AFF-pass base quality gate (default: the platform's)")
     p.add_argument("--max_depth", type=int, default=None)

@@ -96,6 +96,31 @@ int cto_pack_from_mpileup(const char* text, size_t len, const char* ref_seq, int
 int cto_pack_from_bam(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
                       const int64_t* bed, int64_t n_bed, const char* ref_seq, int64_t ref_start, size_t ref_len,
                       int excl_flags, int min_mq, int max_depth, int max_indel_length, cto_pack** out);
+/* The same with the BGZF blocks inflated on the DEVICE (csrc/inflate.hip: one wavefront per block) instead of on the host cores,
+ * which is what bounds cto_pack_from_bam.  Sequence for one chunk:
+ *   cto_bam_chunk_span   -> the byte range [*file_begin, *file_end) of the BAM that holds every BGZF block with alignments
+ *                           overlapping ctg:start-end (from the .bai; read it - plus CTO_BGZF_PAD bytes of padding - into memory)
+ *   cto_bgzf_scan        -> the block table of those bytes: payload offset / size, inflated size, output slot (256-byte aligned);
+ *                           returns the number of blocks, *out_bytes = size of the output buffer
+ *   [copy bytes + table to the device]  cto_bgzf_inflate (asynchronous on `stream`; status[b] != 0 marks a malformed block)
+ *   [copy the inflated bytes back]      cto_pack_from_bam_inflated: cto_pack_from_bam reading those blocks from memory (blocks that
+ *                           are not in the table - the header at the start of the file - are still inflated on the host). */
+#define CTO_BGZF_PAD 1024
+typedef struct cto_bgzf_block {
+    uint64_t file_off;        /* offset of the block (its gzip header) in the BAM file                      */
+    uint64_t in_off;          /* offset of its DEFLATE payload in the byte range handed to cto_bgzf_scan    */
+    uint64_t out_off;         /* offset of its inflated bytes in the output buffer (multiple of 256)        */
+    uint32_t csize, isize;    /* payload bytes, inflated bytes                                              */
+    uint32_t bsize, pad_;     /* whole block incl. header and trailer                                       */
+} cto_bgzf_block;
+int cto_bam_chunk_span(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
+                       int64_t* file_begin, int64_t* file_end);
+int64_t cto_bgzf_scan(const uint8_t* bytes, size_t len, int64_t file_begin, cto_bgzf_block* blocks, int64_t cap, int64_t* out_bytes);
+int cto_bgzf_inflate(const void* d_bytes, const cto_bgzf_block* d_blocks, int n_blocks, void* d_out, int* d_status, void* stream);
+int cto_pack_from_bam_inflated(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
+                               const int64_t* bed, int64_t n_bed, const char* ref_seq, int64_t ref_start, size_t ref_len,
+                               int excl_flags, int min_mq, int max_depth, int max_indel_length,
+                               const uint8_t* inflated, const cto_bgzf_block* blocks, int64_t n_blocks, cto_pack** out);
 /* Build a pack from caller-made arrays (synthetic generators, BAM readers); key strings are the
  * alt_info keys ("IACG", "DACGT") concatenated, key_str_off[n_keys+1]. Arrays are copied. */
 int cto_pack_from_arrays(const cto_pack_view* host_view, const int64_t* key_str_off,

@@ -226,8 +226,9 @@ def _bam_scenario(tmp_path):
 
 
 def test_pileup_call_bam_readers_agree(tmp_path):
-    """One chunk called three ways - native BAM + BAI reader, `samtools mpileup` subprocess (a shim that prints the naive
-    pileup of the same BAM, as the real tool is absent here) and pre-made mpileup text - must give the same VCF bytes."""
+    """One chunk called four ways - native BAM + BAI reader with the BGZF blocks inflated on the host and on the device,
+    `samtools mpileup` subprocess (a shim that prints the naive pileup of the same BAM, as the real tool is absent here) and
+    pre-made mpileup text - must give the same VCF bytes."""
     import numpy as np
     from argparse import Namespace
     from clairs_to_amd.pileup_call import pileup_call
@@ -239,6 +240,7 @@ def test_pileup_call_bam_readers_agree(tmp_path):
     np.savetxt(lik, likelihood_table(4, seed=11), fmt="%.17g")
     out = {}
     for tag, kw in (("native", dict(bam_reader="native", tumor_bam_fn=bam, mpileup_fn=None)),
+                    ("gpu", dict(bam_reader="gpu", tumor_bam_fn=bam, mpileup_fn=None)),        # BGZF blocks inflated on the device
                     ("shim", dict(bam_reader="samtools", tumor_bam_fn=bam, mpileup_fn=None)),
                     ("text", dict(bam_reader="samtools", tumor_bam_fn=None, mpileup_fn=mp))):
         vcf = str(tmp_path / (tag + ".vcf"))
@@ -249,7 +251,7 @@ def test_pileup_call_bam_readers_agree(tmp_path):
                                   qual=0, pileup=True, **kw))
         assert n > 50
         out[tag] = open(vcf).read()
-    assert out["native"] == out["text"] == out["shim"]
+    assert out["native"] == out["text"] == out["shim"] == out["gpu"]
 
 
 @pytest.mark.parametrize("world", [1, 2])

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--sites", type=int, default=4096)
     ap.add_argument("--producers", default="2,4,8,16")
     ap.add_argument("--writers", default="2")
+    ap.add_argument("--bam-reader", default="native", help="native (host inflate) or gpu (device inflate), comma separated")
     ap.add_argument("--pack-threads", default=None, help="CTO_PACK_THREADS values for the C producers, comma separated (default: their own, <= 32)")
     a = ap.parse_args()
     import torch
@@ -40,9 +41,10 @@ def main():
                 if pt:
                     os.environ["CTO_PACK_THREADS"] = pt
                 for w in [int(x) for x in a.writers.split(",")]:
+                  for br in (a.bam_reader.split(",") if kind == "bam" else ["-"]):
                     for p in [int(x) for x in a.producers.split(",")]:
-                        r = time_run(eng, run, kind, os.path.join(d, "vcf_%s" % kind), producers=p, writers=w)
-                        r.update(kind=kind, pack_threads=pt or "auto")
+                        r = time_run(eng, run, kind, os.path.join(d, "vcf_%s" % kind), producers=p, writers=w, bam_reader=br)
+                        r.update(kind=kind, pack_threads=pt or "auto", bam_reader=br)
                         r.pop("includes")
                         print(json.dumps(r), flush=True)
     finally:
