@@ -7,12 +7,22 @@
 // A DEFLATE stream is decoded serially, symbol by symbol, so the wave works as ONE decoder whose 64 lanes do the wide steps:
 //   * bit reader: the compressed bytes are fetched 256 B at a time (one coalesced dword per lane, the next 256 B already in
 //     flight) and handed to a 64-bit bit buffer dword by dword with v_readlane;
-//   * Huffman decode without tables in memory: the codes are canonical, so lane L (1..15) holds first_code[L], count[L] and
-//     offset[L], bit-reverses the next L bits and tests first <= code < first + count - exactly one lane hits; a ballot names the
-//     length, a readlane fetches offset + code - first, the symbol comes out of the sorted symbol list held in 5 + 1 registers
-//     per lane;
-//   * LZ77 window: a 32 KiB ring in LDS; literals are written by lane 0, matches are copied by all lanes at once (source index
-//     (k mod distance) for overlapping copies), and every 16 KiB the finished half of the ring leaves for HBM as coalesced dwords.
+//   * Huffman decode: codes of up to 10 (literal / length) and 9 (distance) bits - nearly all of them - through a lookup table in
+//     LDS indexed by the next bits of the stream, built by all lanes per DEFLATE block; longer codes without a table: the codes
+//     are canonical, so lane L (1..15) holds first_code[L], count[L] and offset[L], bit-reverses the next L bits and tests
+//     first <= code < first + count - exactly one lane hits; a ballot names the length, a readlane fetches offset + code - first,
+//     the symbol comes out of the sorted symbol list held in 5 + 1 registers per lane;
+//   * LZ77 window: the output buffer itself.  Literals are byte stores of lane 0; a match waits for the stores in flight and is
+//     copied by all lanes at once (source index (k mod distance) for overlapping copies) with loads that bypass the vector L1.
+//     A 32 KiB ring in LDS was the first version: 4 wavefronts per CU, and a single decoder wave is a chain of dependent
+//     scalar instructions, branches and one LDS round trip per symbol (500 cycles per symbol measured) - the chip inflated 36
+//     chunks a second.  With 4 KB of LDS per wave, six waves per SIMD take turns on that chain.
+// Measured on MI355X (tools/inflate_bench.py, a 1 Mb x 50x chunk: 77 MB of BAM in 1776 blocks -> 115 MB): 20 ms for one launch
+// alone (15 ms with the literal stores taken out: the decode chain, not memory, is the cost), 8 ms per chunk with 4-8 launches in
+// flight = 14 GB/s of inflated bytes, about what 20 host cores of libdeflate deliver.  That is NOT yet a gain end to end: the
+// box has 16 cores, the launches compete with the network kernels for the CUs, and the file-to-file rate through this reader is
+// 0.10-0.14 M sites/s against 0.21-0.29 M with the host reader.  The next step is decoding several symbols
+// per iteration (every lane decodes speculatively from its own bit offset, pointer jumping picks the true chain).
 // Every loop is bounded by the block's compressed size (a symbol consumes at least one bit) or by constants; malformed input
 // ends with a status code, never with a hang or an out-of-range access (the input buffer carries CTO_BGZF_PAD bytes of padding,
 // every output slot is padded to 256 bytes).
@@ -20,12 +30,20 @@
 
 namespace {
 
-constexpr int WIN = 32768, WMASK = WIN - 1, HALF = 16384;
+constexpr int TBL = 10, TBD = 9;       // index bits of the literal / length and the distance lookup tables
 
-__constant__ uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+// base value and number of extra bits of length symbol ls = sym - 257 (0..28) and of distance symbol ds (0..29), RFC 1951 3.2.5, in
+// closed form: the tables would be global-memory loads whose s_waitcnt also drains the byte stores in flight
+__device__ __forceinline__ void len_code(int ls, int* base, int* extra) {
+    const int e = ls < 8 ? 0 : (ls >> 2) - 1;
+    *extra = ls == 28 ? 0 : e;
+    *base = ls < 8 ? 3 + ls : (ls == 28 ? 258 : 3 + ((4 + (ls & 3)) << e));
+}
+__device__ __forceinline__ void dist_code(int ds, int* base, int* extra) {
+    const int e = ds < 4 ? 0 : (ds >> 1) - 1;
+    *extra = e;
+    *base = ds < 4 ? 1 + ds : 1 + ((2 + (ds & 1)) << e);
+}
 __constant__ uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) {      // value of `v` in lane `lane` (wave-uniform lane index)
@@ -33,9 +51,12 @@ __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) {      // value of 
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+typedef const __attribute__((address_space(1))) uint32_t* gdword_ptr;
 struct Bits {                     // wave-uniform bit reader over dwords of global memory
-    const uint32_t* src;          // dword-aligned base
-    uint32_t win, nxt;            // per lane: dword (wbase + lane) and dword (wbase + 64 + lane)
+    gdword_ptr src;               // dword-aligned base
+    uint32_t win;                 // per lane: dword (wbase + lane).  The next 256 bytes are NOT kept in flight: a load pending across
+                                  // loop iterations makes the compiler wait for it - and with it for every byte store in flight -
+                                  // on each iteration; one exposed load per 256 bytes of input costs ~3 cycles per symbol
     int wbase, widx;              // dword index of win's lane 0; next dword to hand out
     uint64_t bb;                  // bit buffer, next bit = bit 0
     int cnt;                      // valid bits in bb
@@ -44,11 +65,10 @@ struct Bits {                     // wave-uniform bit reader over dwords of glob
 
 __device__ __forceinline__ void bits_init(Bits& b, const uint8_t* p, int lane) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    b.src = reinterpret_cast<const uint32_t*>(a & ~uintptr_t(3));
+    b.src = reinterpret_cast<gdword_ptr>(a & ~uintptr_t(3));
     b.wbase = 0;
     b.widx = 0;
     b.win = b.src[lane];
-    b.nxt = b.src[64 + lane];
     b.bb = 0;
     b.cnt = 0;
     b.used = 0;
@@ -63,9 +83,9 @@ __device__ __forceinline__ void bits_refill(Bits& b, int lane) {
     if (b.cnt <= 32) {
         if (b.widx - b.wbase >= 64) {
             b.wbase += 64;
-            b.win = b.nxt;
-            b.nxt = b.src[b.wbase + 64 + lane];
-        }
+            b.win = b.src[b.wbase + lane];
+            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) HERE, once per 256 bytes: otherwise the compiler waits where the two
+        }                                            // paths meet, i.e. on every refill, and each wait also drains the byte stores
         const uint32_t d = rl(b.win, b.widx - b.wbase);
         b.bb |= uint64_t(d) << b.cnt;
         b.cnt += 32;
@@ -140,15 +160,46 @@ __device__ __forceinline__ int huff_decode(const Huff& h, uint32_t bits32, int l
     return int(v);
 }
 
+// Lookup table of the codes of up to TB bits: entry[next TB bits of the stream] = symbol | length << 9 (0: a longer code).
+// `fo`: scratch for first[16] | offset[16].  sorted[] / lens[] as left by huff_build.
+template <int TB>
+__device__ void huff_table(const Huff& h, const uint8_t* lens, const uint16_t* sorted, uint32_t* fo, uint16_t* table, int lane) {
+    if (lane < 16) { fo[lane] = h.first; fo[16 + lane] = h.offset; }
+    for (int i = lane; i < (1 << TB); i += 64) table[i] = 0;
+    const int total = int(rl(h.offset + h.count, 15));         // symbols that have a code
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < total; i += 64) {
+        const uint32_t sym = sorted[i];
+        const uint32_t len = lens[sym];
+        if (len <= uint32_t(TB)) {
+            const uint32_t code = fo[len] + (uint32_t(i) - fo[16 + len]);
+            const uint32_t rev = __brev(code) >> (32 - len);
+            const uint16_t e = uint16_t(sym | (len << 9));
+            for (uint32_t k = rev; k < (1u << TB); k += (1u << len)) table[k] = e;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+}
+template <int NREG, int TB>
+__device__ __forceinline__ int huff_decode_fast(const Huff& h, const uint16_t* table, uint32_t bits32, int lane, int* len) {
+    const uint32_t e = uint32_t(__builtin_amdgcn_readfirstlane(int(table[bits32 & ((1u << TB) - 1u)])));
+    if (e != 0) { *len = int(e >> 9); return int(e & 511u); }
+    return huff_decode<NREG>(h, bits32, lane, len);
+}
+
 enum { ST_OK = 0, ST_BAD_BTYPE = 1, ST_BAD_STORED = 2, ST_BAD_TABLE = 3, ST_BAD_CODE = 4, ST_BAD_DIST = 5, ST_OVERRUN_OUT = 6, ST_OVERRUN_IN = 7, ST_SHORT = 8 };
 
 }  // namespace
 
 extern "C" __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* __restrict__ comp, const cto_bgzf_block* __restrict__ blocks,
                                                                 int n_blocks, uint8_t* __restrict__ out, int* __restrict__ status) {
-    __shared__ __attribute__((aligned(16))) uint8_t ring[WIN];
     __shared__ uint8_t lens[320];
     __shared__ uint16_t sorted[320];
+    __shared__ uint32_t fo[32];
+    __shared__ uint16_t tab_l[1 << TBL];
+    __shared__ uint16_t tab_d[1 << TBD];
     const int lane = threadIdx.x;
     const int blk = blockIdx.x;
     if (blk >= n_blocks) return;
@@ -156,15 +207,10 @@ extern "C" __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* _
     const int isize = int(bd.isize);
     const long long in_bits = (long long)bd.csize * 8;
     uint8_t* dst = out + bd.out_off;
+    const uint8_t* win = dst;                // window reads are device-scope atomic loads: not through the vector L1 (it is not
+                                             // coherent with this wave's own earlier stores)
     int st = ST_OK;
-    int op = 0, flushed = 0;            // bytes produced / bytes already copied to HBM (multiple of HALF)
-
-    auto flush_half = [&]() {           // ring[flushed .. flushed + HALF) -> HBM, coalesced dwords
-        const uint32_t* r32 = reinterpret_cast<const uint32_t*>(ring + (flushed & WMASK));
-        uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + flushed);
-        for (int i = lane; i < HALF / 4; i += 64) d32[i] = r32[i];
-        flushed += HALF;
-    };
+    int op = 0;                              // bytes produced
 
     if (isize > 0) {
         Bits b;
@@ -187,11 +233,10 @@ extern "C" __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* _
                 if ((len ^ nlen) != 0xffffu) { st = ST_BAD_STORED; break; }
                 if (op + int(len) > isize) { st = ST_OVERRUN_OUT; break; }
                 for (uint32_t i = 0; i < len; ++i) {
-                    if (op - flushed > WIN - 512) { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier(); flush_half(); }
                     bits_refill(b, lane);
                     const uint32_t v = bits_peek(b, 8);
                     bits_drop(b, 8);
-                    if (lane == 0) ring[op & WMASK] = uint8_t(v);
+                    if (lane == 0) dst[op] = uint8_t(v);
                     ++op;
                 }
                 if (b.used > in_bits + 64) { st = ST_OVERRUN_IN; break; }
@@ -201,8 +246,6 @@ extern "C" __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* _
             int nlit = 288, ndist = 30;
             if (btype == 1) {                                    // fixed codes
                 for (int i = lane; i < 320; i += 64) lens[i] = uint8_t(i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : (i < 288 ? 8 : 5))));
-                nlit = 288;
-                ndist = 30;
             } else {                                             // dynamic codes
                 bits_refill(b, lane);
                 nlit = int(bits_peek(b, 5)) + 257;
@@ -262,71 +305,58 @@ extern "C" __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* _
             __builtin_amdgcn_s_waitcnt(0);
             __builtin_amdgcn_wave_barrier();
             if (!huff_build<5>(hl, lens, 288, sorted, lane)) { st = ST_BAD_TABLE; break; }
-            __builtin_amdgcn_wave_barrier();
+            huff_table<TBL>(hl, lens, sorted, fo, tab_l, lane);
             huff_build<1>(hd, lens + 288, 30, sorted, lane);     // an incomplete distance code is legal (one code, or none)
-            __builtin_amdgcn_wave_barrier();
+            huff_table<TBD>(hd, lens + 288, sorted, fo, tab_d, lane);
 
             // ---- symbols ----
             for (;;) {
-                if (op - flushed > WIN - 512) {                  // room for the longest match before the unflushed half is reached
-                    __builtin_amdgcn_s_waitcnt(0);
-                    __builtin_amdgcn_wave_barrier();
-                    flush_half();
-                }
                 bits_refill(b, lane);
                 int l = 0;
-                const int s = huff_decode<5>(hl, uint32_t(b.bb), lane, &l);
+                const int s = huff_decode_fast<5, TBL>(hl, tab_l, uint32_t(b.bb), lane, &l);
                 if (s < 0) { st = ST_BAD_CODE; break; }
                 bits_drop(b, l);
                 if (b.used > in_bits + 64) { st = ST_OVERRUN_IN; break; }
                 if (s < 256) {
                     if (op >= isize) { st = ST_OVERRUN_OUT; break; }
-                    if (lane == 0) ring[op & WMASK] = uint8_t(s);
+#ifndef CTO_INFLATE_NOSTORE
+                    if (lane == 0) dst[op] = uint8_t(s);
+#endif
                     ++op;
                 } else if (s == 256) {
                     break;
                 } else {
                     const int ls = s - 257;
                     if (ls >= 29) { st = ST_BAD_CODE; break; }
-                    const int le = kLenExtra[ls];
-                    const int n = int(kLenBase[ls]) + int(bits_peek(b, le));
+                    int lbase, le;
+                    len_code(ls, &lbase, &le);
+                    const int n = lbase + int(bits_peek(b, le));
                     bits_drop(b, le);
                     bits_refill(b, lane);
                     int dlb = 0;
-                    const int ds = huff_decode<1>(hd, uint32_t(b.bb), lane, &dlb);
+                    const int ds = huff_decode_fast<1, TBD>(hd, tab_d, uint32_t(b.bb), lane, &dlb);
                     if (ds < 0 || ds >= 30) { st = ST_BAD_DIST; break; }
                     bits_drop(b, dlb);
-                    const int de = kDistExtra[ds];
-                    const int d = int(kDistBase[ds]) + int(bits_peek(b, de));
+                    int dbase, de;
+                    dist_code(ds, &dbase, &de);
+                    const int d = dbase + int(bits_peek(b, de));
                     bits_drop(b, de);
                     if (d > op) { st = ST_BAD_DIST; break; }
                     if (op + n > isize) { st = ST_OVERRUN_OUT; break; }
-                    __builtin_amdgcn_s_waitcnt(0);               // lane 0's literal writes are in the ring
+                    __builtin_amdgcn_s_waitcnt(0);               // every earlier store of this wave has reached L2
                     __builtin_amdgcn_wave_barrier();
                     const int from = op - d;
+                    // all source bytes lie before `op`: the (k mod d) form reads the repeating pattern of an overlapping copy from
+                    // its first period, so no lane depends on a byte another lane writes in this copy
                     for (int k = lane; k < n; k += 64) {
                         const int sk = d >= n ? k : k % d;
-                        ring[(op + k) & WMASK] = ring[(from + sk) & WMASK];
+                        dst[op + k] = __hip_atomic_load(win + from + sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-                    __builtin_amdgcn_s_waitcnt(0);
-                    __builtin_amdgcn_wave_barrier();
                     op += n;
                 }
             }
         }
         if (st == ST_OK && op != isize) st = ST_SHORT;
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-        // what is left in the ring (at most WIN bytes, from a multiple of HALF on): dwords, the slot is padded
-        if (st == ST_OK) {
-            while (flushed < op) {
-                const int nb = min(HALF, op - flushed);
-                const uint32_t* r32 = reinterpret_cast<const uint32_t*>(ring + (flushed & WMASK));
-                uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + flushed);
-                for (int i = lane; i < (nb + 3) / 4; i += 64) d32[i] = r32[i];
-                flushed += HALF;
-            }
-        }
     }
     if (lane == 0) status[blk] = st;
 }
