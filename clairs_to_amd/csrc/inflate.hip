@@ -21,8 +21,13 @@
 // alone (15 ms with the literal stores taken out: the decode chain, not memory, is the cost), 8 ms per chunk with 4-8 launches in
 // flight = 14 GB/s of inflated bytes, about what 20 host cores of libdeflate deliver.  That is NOT yet a gain end to end: the
 // box has 16 cores, the launches compete with the network kernels for the CUs, and the file-to-file rate through this reader is
-// 0.10-0.14 M sites/s against 0.21-0.29 M with the host reader.  The next step is decoding several symbols
-// per iteration (every lane decodes speculatively from its own bit offset, pointer jumping picks the true chain).
+// 0.10-0.14 M sites/s against 0.21-0.29 M with the host reader.
+// Where a block's 40 M cycles go (s_memtime stamps, a 65 000-byte block of BAM records = 21.6 k literals + 12.7 k matches of 3.4
+// bytes on average): a link of the decode chain is ~80 scalar-unit and lane-0 instructions with a dozen taken branches, and a
+// single wave issues such code at 10-16 cycles per instruction - 1.3 k cycles per symbol, where a host core needs ~10.  Tried on
+// top and dropped: a 16 KiB LDS ring for near matches (the copy itself was not the cost; fewer waves per CU: 14-18 ms per chunk);
+// literal runs decoded by all lanes at once (lane i looks up the symbol at bit offset i, a scalar walk follows the chain: correct,
+// but BAM records break the run every 1.7 literals: 9.9 ms).  A device decoder that beats the host needs one block per LANE.
 // Every loop is bounded by the block's compressed size (a symbol consumes at least one bit) or by constants; malformed input
 // ends with a status code, never with a hang or an out-of-range access (the input buffer carries CTO_BGZF_PAD bytes of padding,
 // every output slot is padded to 256 bytes).
