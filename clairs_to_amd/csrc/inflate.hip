@@ -237,6 +237,7 @@ extern "C" __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* _
                 bits_drop(b, 16);
                 if ((len ^ nlen) != 0xffffu) { st = ST_BAD_STORED; break; }
                 if (op + int(len) > isize) { st = ST_OVERRUN_OUT; break; }
+                if (b.used + (long long)len * 8 > in_bits + 64) { st = ST_OVERRUN_IN; break; }     // before the copy loop reads on
                 for (uint32_t i = 0; i < len; ++i) {
                     bits_refill(b, lane);
                     const uint32_t v = bits_peek(b, 8);

@@ -104,6 +104,13 @@ def test_inflate_rejects_malformed(dev):
         except CtoError:
             n_err += 1
     assert n_err >= 5          # (the CRC is not checked, as on the host path: a flipped literal bit decodes to different bytes of the same length)
+    # a stored block that claims more bytes than the payload holds
+    payload = b"\x01" + struct.pack("<HH", 60000, 60000 ^ 0xffff) + b"x" * 100
+    bsize = len(payload) + 26
+    lying = (b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1) + payload +
+             struct.pack("<II", 0, 60000))
+    with pytest.raises(CtoError):
+        inflate_bytes(lying, dev)
     garbage = bytearray(good)
     garbage[18:len(garbage) - 8] = bytes(rng.integers(0, 256, len(garbage) - 26, dtype=np.uint8))
     with pytest.raises(CtoError):
