@@ -62,6 +62,7 @@ SYMBOLS = {
                                          C.c_int, c_vp, c_vp, c_vp]),
     "cto_alt_info": (C.c_int, [c_vp, c_i64, C.c_int, c_vp, c_i32, c_vp, c_vp, c_vp, C.c_char_p, C.c_size_t]),
     "cto_alt_info_batch": (c_i64, [c_vp, c_i64, c_vp, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_size_t, c_vp]),
+    "cto_alt_info_batch_sites": (c_i64, [c_vp, c_i64, c_vp, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_size_t, c_vp]),
     "cto_weights_new": (c_vp, []),
     "cto_weights_add": (C.c_int, [c_vp, C.c_char_p, c_vp, c_i64]),
     "cto_weights_free": (None, [c_vp]),

@@ -539,9 +539,11 @@ extern "C" int cto_alt_info(const cto_pack* p, int64_t col, int pass, const int1
     return int(s.size());
 }
 
-extern "C" int64_t cto_alt_info_batch(const cto_pack* p, int64_t n_sites, const int32_t* site_info, int pass, const int16_t* colvec,
-                                      const int32_t* sitefirst, const uint32_t* keycnt, const int32_t* keyfirst, char* buf,
-                                      size_t cap, int64_t* offsets) {
+namespace {
+// colvec: the column vectors of the whole pack (row = column index) or, with per_site, one row per candidate (row = site index)
+int64_t alt_info_batch_impl(const cto_pack* p, int64_t n_sites, const int32_t* site_info, int pass, const int16_t* colvec, bool per_site,
+                            const int32_t* sitefirst, const uint32_t* keycnt, const int32_t* keyfirst, char* buf, size_t cap,
+                            int64_t* offsets) {
     CTO_REQUIRE(p && site_info && colvec && sitefirst && buf && offsets && n_sites >= 0, CTO_EINVAL, "cto_alt_info_batch: null argument");
     CTO_REQUIRE(pass == 0 || pass == 1, CTO_EINVAL, "cto_alt_info_batch: pass must be 0 (AFF) or 1 (NEG)");
     size_t used = 0;
@@ -550,8 +552,8 @@ extern "C" int64_t cto_alt_info_batch(const cto_pack* p, int64_t n_sites, const 
         const int64_t col = site_info[i * 12];
         if (col >= 0) {
             CTO_REQUIRE(size_t(col) < p->col_pos.size(), CTO_EINVAL, "cto_alt_info_batch: column out of range");
-            const std::string s = alt_info_string(p, col, pass, colvec + col * CTO_COLVEC_STRIDE, site_info[i * 12 + 1 + pass],
-                                                  sitefirst + i * 8, keycnt, keyfirst);
+            const std::string s = alt_info_string(p, col, pass, colvec + (per_site ? i : col) * CTO_COLVEC_STRIDE,
+                                                  site_info[i * 12 + 1 + pass], sitefirst + i * 8, keycnt, keyfirst);
             CTO_REQUIRE(used + s.size() <= cap, CTO_EINVAL, "cto_alt_info_batch: buffer too small");
             memcpy(buf + used, s.data(), s.size());
             used += s.size();
@@ -559,4 +561,17 @@ extern "C" int64_t cto_alt_info_batch(const cto_pack* p, int64_t n_sites, const 
         offsets[i + 1] = int64_t(used);
     }
     return int64_t(used);
+}
+}  // namespace
+
+extern "C" int64_t cto_alt_info_batch(const cto_pack* p, int64_t n_sites, const int32_t* site_info, int pass, const int16_t* colvec,
+                                      const int32_t* sitefirst, const uint32_t* keycnt, const int32_t* keyfirst, char* buf,
+                                      size_t cap, int64_t* offsets) {
+    return alt_info_batch_impl(p, n_sites, site_info, pass, colvec, false, sitefirst, keycnt, keyfirst, buf, cap, offsets);
+}
+
+extern "C" int64_t cto_alt_info_batch_sites(const cto_pack* p, int64_t n_sites, const int32_t* site_info, int pass,
+                                            const int16_t* site_colvec, const int32_t* sitefirst, const uint32_t* keycnt,
+                                            const int32_t* keyfirst, char* buf, size_t cap, int64_t* offsets) {
+    return alt_info_batch_impl(p, n_sites, site_info, pass, site_colvec, true, sitefirst, keycnt, keyfirst, buf, cap, offsets);
 }

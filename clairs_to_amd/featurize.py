@@ -82,9 +82,10 @@ def alt_infos_packed(feat, host_pack, site_info_host=None, pass_idx=0):
                                feat.keyfirst.cpu().numpy(), pass_idx)
 
 
-def alt_infos_from_host(host_pack, info, colvec, sitefirst, keycnt, keyfirst, pass_idx=0):
+def alt_infos_from_host(host_pack, info, colvec, sitefirst, keycnt, keyfirst, pass_idx=0, per_site=False):
     """alt_infos_packed() on host copies (numpy arrays) of the featurisation outputs - what a pipelined caller has after its own
-    asynchronous device-to-host copies (call_chunks)."""
+    asynchronous device-to-host copies (call_chunks).  per_site: `colvec` holds one row per candidate (its candidate column's
+    vector, gathered on the device: 144 B per site cross PCIe instead of 144 B per pack column)."""
     sitefirst = np.ascontiguousarray(sitefirst)
     keycnt = np.ascontiguousarray(np.asarray(keycnt).view(np.uint32))
     keyfirst = np.ascontiguousarray(keyfirst)
@@ -100,8 +101,9 @@ def alt_infos_from_host(host_pack, info, colvec, sitefirst, keycnt, keyfirst, pa
     offsets = np.zeros(n + 1, dtype=np.int64)
     while True:
         buf = C.create_string_buffer(cap)
-        used = lib.cto_alt_info_batch(host_pack._h, n, info.ctypes.data, int(pass_idx), colvec.ctypes.data, sitefirst.ctypes.data,
-                                      keycnt.ctypes.data, keyfirst.ctypes.data, C.addressof(buf), cap, offsets.ctypes.data)
+        fn = lib.cto_alt_info_batch_sites if per_site else lib.cto_alt_info_batch
+        used = fn(host_pack._h, n, info.ctypes.data, int(pass_idx), colvec.ctypes.data, sitefirst.ctypes.data,
+                  keycnt.ctypes.data, keyfirst.ctypes.data, C.addressof(buf), cap, offsets.ctypes.data)
         if used >= 0:
             break
         if "buffer too small" not in lib.cto_last_error().decode():

@@ -190,6 +190,11 @@ int cto_alt_info(const cto_pack* p, int64_t col, int pass, const int16_t* colvec
 int64_t cto_alt_info_batch(const cto_pack* p, int64_t n_sites, const int32_t* site_info, int pass, const int16_t* colvec,
                            const int32_t* sitefirst, const uint32_t* keycnt, const int32_t* keyfirst, char* buf, size_t cap,
                            int64_t* offsets);
+/* The same with the candidate columns' vectors gathered on the device: site_colvec[n_sites][CTO_COLVEC_STRIDE], row i = the column
+ * vector of site i's candidate column (a per-chunk device-to-host copy of 144 B per site instead of 144 B per pack column). */
+int64_t cto_alt_info_batch_sites(const cto_pack* p, int64_t n_sites, const int32_t* site_info, int pass, const int16_t* site_colvec,
+                                 const int32_t* sitefirst, const uint32_t* keycnt, const int32_t* keyfirst, char* buf, size_t cap,
+                                 int64_t* offsets);
 
 
 /* ------------------------------------------------------------------------------------------------
