@@ -22,9 +22,6 @@
 // factor of the 8 waves splits the m-tiles, so that every wave owns MFMAs whatever N is (N = 16: eight m-tile groups).
 #pragma once
 #include "cvt_gemm.h"
-#ifndef CTO_ATT_EXP
-#define CTO_ATT_EXP exp_le0
-#endif
 
 namespace cto {
 
@@ -433,7 +430,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
                 for (int jj = 1; jj < WKV; ++jj) mx = fmaxf(mx, sc[jj]);
                 float sum = 0.f;
 #pragma unroll
-                for (int jj = 0; jj < WKV; ++jj) { sc[jj] = CTO_ATT_EXP((sc[jj] - mx) * 0.125f); sum += sc[jj]; }
+                for (int jj = 0; jj < WKV; ++jj) { sc[jj] = exp_le0((sc[jj] - mx) * 0.125f); sum += sc[jj]; }
                 float inv = __builtin_amdgcn_rcpf(sum);
                 inv = fmaf(fmaf(-sum, inv, 1.0f), inv, inv);      // one Newton step: 0.5 ulp
                 float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);

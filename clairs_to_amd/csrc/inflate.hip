@@ -325,9 +325,7 @@ extern "C" __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* _
                 if (b.used > in_bits + 64) { st = ST_OVERRUN_IN; break; }
                 if (s < 256) {
                     if (op >= isize) { st = ST_OVERRUN_OUT; break; }
-#ifndef CTO_INFLATE_NOSTORE
                     if (lane == 0) dst[op] = uint8_t(s);
-#endif
                     ++op;
                 } else if (s == 256) {
                     break;
