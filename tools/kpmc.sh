@@ -10,7 +10,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     n = r['Kernel_Name']
     if 'k_cvt_block' in n or 'k_gru' in n:
-        acc[n.split('(')[0][-48:]][r['Counter_Name']].append(float(r['Counter_Value']))
+        acc[n.replace('(anonymous namespace)::', '').split('(')[0][-48:]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in acc.items():
     print(k, '  '.join('%s=%.3g' % (c, sum(v) / len(v)) for c, v in sorted(d.items())))
 PY

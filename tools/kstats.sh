@@ -10,7 +10,7 @@ tot = 0
 for r in csv.DictReader(open(f)):
     n = r['Name']
     if 'cto::' in n or 'anonymous' in n:
-        short = n.split('(')[0][-60:]
+        short = n.replace('(anonymous namespace)::', '').split('(')[0][-60:]
         print('%-62s calls %4s  avg %9.1f us' % (short, r['Calls'], float(r['AverageNs']) / 1e3))
         if 'k_cvt_block' in n: tot += float(r['AverageNs']) / 1e3
 print('sum of k_cvt_block averages: %.1f us' % tot)
