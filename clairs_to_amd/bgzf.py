@@ -10,7 +10,7 @@ from ._lib import CtoError, check, lib
 
 BGZF_PAD = 1024            # include/clairsto_amd.h: CTO_BGZF_PAD
 BLOCK_DTYPE = np.dtype([("file_off", "<u8"), ("in_off", "<u8"), ("out_off", "<u8"), ("csize", "<u4"), ("isize", "<u4"),
-                        ("bsize", "<u4"), ("pad_", "<u4")])
+                        ("bsize", "<u4"), ("crc32", "<u4")])
 STATUS = {1: "reserved block type", 2: "stored block length check", 3: "bad code-length table", 4: "invalid literal / length code",
           5: "invalid distance", 6: "more output than ISIZE", 7: "ran past the compressed data", 8: "less output than ISIZE"}
 
@@ -76,7 +76,12 @@ def inflate_bytes(raw, device):
     torch.cuda.synchronize(device)
     check_status(d_status.cpu().numpy(), blocks)
     out = d_out.cpu().numpy()
-    return [out[int(b["out_off"]):int(b["out_off"]) + int(b["isize"])].tobytes() for b in blocks]
+    res = [out[int(b["out_off"]):int(b["out_off"]) + int(b["isize"])].tobytes() for b in blocks]
+    import zlib
+    for b, r in zip(blocks, res):          # the gzip trailer's CRC-32, as cto_pack_from_bam_inflated checks it for every block it reads
+        if zlib.crc32(r) != int(b["crc32"]):
+            raise CtoError("BGZF block at file offset %d fails its CRC-32" % int(b["file_off"]))
+    return res
 
 
 def inflate_span(bam_fn, bai_fn, ctg_name, start, end, device, stream=None):

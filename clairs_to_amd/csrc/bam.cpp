@@ -50,6 +50,7 @@ struct LibDeflate {
     void* h = nullptr;
     void* (*alloc)() = nullptr;
     int (*inflate)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+    uint32_t (*crc)(uint32_t, const void*, size_t) = nullptr;
     void (*release)(void*) = nullptr;
     LibDeflate() {
         if (getenv("CTO_NO_LIBDEFLATE")) return;
@@ -61,13 +62,23 @@ struct LibDeflate {
         alloc = reinterpret_cast<void* (*)()>(dlsym(h, "libdeflate_alloc_decompressor"));
         inflate = reinterpret_cast<int (*)(void*, const void*, size_t, void*, size_t, size_t*)>(dlsym(h, "libdeflate_deflate_decompress"));
         release = reinterpret_cast<void (*)(void*)>(dlsym(h, "libdeflate_free_decompressor"));
+        crc = reinterpret_cast<uint32_t (*)(uint32_t, const void*, size_t)>(dlsym(h, "libdeflate_crc32"));
         if (!alloc || !inflate || !release) { alloc = nullptr; inflate = nullptr; release = nullptr; }
     }
     bool ok() const { return inflate != nullptr; }
 };
+const LibDeflate& libdeflate();
+// CRC-32 of a BGZF block's inflated bytes (the gzip trailer holds the expected value; htslib checks it too)
+uint32_t block_crc(const uint8_t* p, size_t n);
+
 const LibDeflate& libdeflate() {
     static const LibDeflate ld;
     return ld;
+}
+
+uint32_t block_crc(const uint8_t* p, size_t n) {
+    if (libdeflate().crc) return libdeflate().crc(0, p, n);
+    return uint32_t(crc32(crc32(0L, Z_NULL, 0), p, uInt(n)));
 }
 
 // BGZF blocks that were inflated elsewhere (on the device: cto_bgzf_inflate), looked up by their file offset
@@ -121,6 +132,7 @@ struct Bgzf {
         if (const cto_bgzf_block* pb = pre.find(coff)) {        // already inflated: a view, no file access
             bptr = pre.data + pb->out_off;
             blen = pb->isize;
+            if (blen && block_crc(bptr, blen) != pb->crc32) { err = "BGZF block fails its CRC-32"; return false; }
             block_coffset = coff;
             next_coffset = coff + int64_t(pb->bsize);
             upos = 0;
@@ -171,6 +183,10 @@ struct Bgzf {
             zs.avail_out = uInt(isize);
             const int rc = inflate(&zs, Z_FINISH);
             if (rc != Z_STREAM_END || zs.avail_out != 0) { err = "inflate failed"; return false; }
+        }
+        if (isize) {
+            const uint32_t want = uint32_t(tail[0]) | (uint32_t(tail[1]) << 8) | (uint32_t(tail[2]) << 16) | (uint32_t(tail[3]) << 24);
+            if (block_crc(block.data(), isize) != want) { err = "BGZF block fails its CRC-32"; return false; }
         }
         bptr = block.data();
         blen = block.size();
@@ -871,7 +887,7 @@ extern "C" int64_t cto_bgzf_scan(const uint8_t* bytes, size_t len, int64_t file_
         b.csize = uint32_t(cdata);
         b.isize = isize;
         b.bsize = uint32_t(bsize);
-        b.pad_ = 0;
+        b.crc32 = uint32_t(tail[0]) | (uint32_t(tail[1]) << 8) | (uint32_t(tail[2]) << 16) | (uint32_t(tail[3]) << 24);
         out += (int64_t(isize) + 4 + 255) / 256 * 256;           // dword-granular tail stores stay inside the slot
         o += size_t(bsize);
     }

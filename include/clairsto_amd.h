@@ -111,7 +111,7 @@ typedef struct cto_bgzf_block {
     uint64_t in_off;          /* offset of its DEFLATE payload in the byte range handed to cto_bgzf_scan    */
     uint64_t out_off;         /* offset of its inflated bytes in the output buffer (multiple of 256)        */
     uint32_t csize, isize;    /* payload bytes, inflated bytes                                              */
-    uint32_t bsize, pad_;     /* whole block incl. header and trailer                                       */
+    uint32_t bsize, crc32;    /* whole block incl. header and trailer; CRC-32 of the inflated bytes (gzip trailer) */
 } cto_bgzf_block;
 int cto_bam_chunk_span(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
                        int64_t* file_begin, int64_t* file_end);

@@ -138,6 +138,35 @@ def test_pack_from_bam_errors(tmp_path):
     assert p.n_cols == 0 and p.n_entries == 0
 
 
+def test_bgzf_crc_is_checked(tmp_path):
+    """One flipped bit inside a BGZF block's payload: either the DEFLATE stream breaks or the inflated bytes fail the gzip trailer's
+    CRC-32 (htslib checks it too) - the read never succeeds with different bytes."""
+    from clairs_to_amd.pack import ColumnPack
+    from clairs_to_amd._lib import CtoError
+    rng = np.random.default_rng(5)
+    reads = _random_reads(rng, 150, [5000], weird=False)
+    bam = str(tmp_path / "ok.bam")
+    write_bam(bam, [("chrA", 5000)], reads, block_payload=4000)
+    ref = "".join(rng.choice(list("ACGT"), size=5000))
+    good = ColumnPack.from_bam(bam, "chrA", 1, 5000, ref, 1).numpy()["entries"].copy()
+    raw = open(bam, "rb").read()
+    first = 18 + 8                                  # skip the first block's header (the BAM header block may be tiny)
+    n_err = n_same = 0
+    for off in range(first + 200, len(raw) - 60, max(1, (len(raw) - 300) // 40)):
+        b = bytearray(raw)
+        b[off] ^= 0x08
+        p = tmp_path / "flip.bam"
+        p.write_bytes(bytes(b))
+        (tmp_path / "flip.bam.bai").write_bytes(open(bam + ".bai", "rb").read())
+        try:
+            got = ColumnPack.from_bam(str(p), "chrA", 1, 5000, ref, 1).numpy()["entries"]
+            assert np.array_equal(got, good)        # only a flip in bytes the reader never looks at may pass
+            n_same += 1
+        except CtoError:
+            n_err += 1
+    assert n_err >= 25 and n_same <= 10
+
+
 def test_producers_survive_corrupt_input(tmp_path):
     """Neither pack producer may crash on damaged input: every call returns a pack or raises CtoError.  200 random byte
     flips / truncations of a valid BAM, of its index and of a valid mpileup text."""

@@ -99,11 +99,10 @@ def test_inflate_rejects_malformed(dev):
         for _ in range(1 + trial % 4):
             b[int(rng.integers(lo, hi))] ^= 1 << int(rng.integers(0, 8))
         try:
-            got = inflate_bytes(bytes(b), dev)
-            assert len(got) == 1 and len(got[0]) == 40000          # a flipped bit may still decode to ISIZE bytes: that is fine
+            inflate_bytes(bytes(b), dev)
         except CtoError:
             n_err += 1
-    assert n_err >= 5          # (the CRC is not checked, as on the host path: a flipped literal bit decodes to different bytes of the same length)
+    assert n_err == 40         # a flipped bit either breaks the stream (status code) or decodes to other bytes (CRC-32)
     # a stored block that claims more bytes than the payload holds
     payload = b"\x01" + struct.pack("<HH", 60000, 60000 ^ 0xffff) + b"x" * 100
     bsize = len(payload) + 26
