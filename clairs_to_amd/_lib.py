@@ -47,7 +47,7 @@ SYMBOLS = {
     "cto_pack_from_bam": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, c_i64, c_i64, c_vp, c_i64, C.c_char_p, c_i64, C.c_size_t,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(c_vp)]),
     "cto_pack_from_bam_inflated": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, c_i64, c_i64, c_vp, c_i64, C.c_char_p, c_i64, C.c_size_t,
-                                             C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_i64, C.POINTER(c_vp)]),
+                                             C.c_int, C.c_int, C.c_int, C.c_int, c_vp, C.c_size_t, c_vp, c_i64, C.POINTER(c_vp)]),
     "cto_bam_chunk_span": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, c_i64, c_i64, C.POINTER(c_i64), C.POINTER(c_i64)]),
     "cto_bgzf_scan": (c_i64, [c_vp, C.c_size_t, c_i64, c_vp, c_i64, C.POINTER(c_i64)]),
     "cto_bgzf_inflate": (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp]),

@@ -812,11 +812,14 @@ extern "C" int cto_pack_from_bam(const char* bam_path, const char* bai_path, con
 extern "C" int cto_pack_from_bam_inflated(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
                                            const int64_t* bed, int64_t n_bed, const char* ref_seq, int64_t ref_start, size_t ref_len,
                                            int excl_flags, int min_mq, int max_depth, int max_indel_length, const uint8_t* inflated,
-                                           const cto_bgzf_block* blocks, int64_t n_blocks, cto_pack** out) {
+                                           size_t inflated_len, const cto_bgzf_block* blocks, int64_t n_blocks, cto_pack** out) {
     return guarded("cto_pack_from_bam_inflated", [&] {
         CTO_REQUIRE(n_blocks >= 0 && (n_blocks == 0 || (inflated && blocks)), CTO_EINVAL, "cto_pack_from_bam_inflated: null argument");
-        for (int64_t i = 1; i < n_blocks; ++i)
-            CTO_REQUIRE(blocks[i].file_off > blocks[i - 1].file_off, CTO_EINVAL, "cto_pack_from_bam_inflated: block table not sorted");
+        for (int64_t i = 0; i < n_blocks; ++i) {
+            CTO_REQUIRE(i == 0 || blocks[i].file_off > blocks[i - 1].file_off, CTO_EINVAL, "cto_pack_from_bam_inflated: block table not sorted");
+            CTO_REQUIRE(blocks[i].isize <= 65536 && blocks[i].out_off <= inflated_len && blocks[i].isize <= inflated_len - blocks[i].out_off,
+                        CTO_EINVAL, "cto_pack_from_bam_inflated: block %lld lies outside the inflated buffer", (long long)i);
+        }
         PreInflated pre;
         pre.data = inflated;
         pre.blocks = blocks;

@@ -67,7 +67,7 @@ class ColumnPack:
                                                  int(start), int(end), iv.ctypes.data if iv is not None and len(iv) else None,
                                                  len(iv) if iv is not None else 0, rb, int(ref_start), len(rb), int(excl_flags),
                                                  int(min_mq), int(max_depth), int(max_indel_length), h_out.data_ptr(),
-                                                 blocks.ctypes.data, len(blocks), C.byref(out)))
+                                                 int(h_out.numel()), blocks.ctypes.data, len(blocks), C.byref(out)))
             return cls(out.value)
         check(lib.cto_pack_from_bam(str(bam_fn).encode(), str(bai_fn).encode() if bai_fn else None, ctg_name.encode(), int(start),
                                     int(end), iv.ctypes.data if iv is not None and len(iv) else None, len(iv) if iv is not None else 0,

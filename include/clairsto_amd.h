@@ -120,7 +120,8 @@ int cto_bgzf_inflate(const void* d_bytes, const cto_bgzf_block* d_blocks, int n_
 int cto_pack_from_bam_inflated(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
                                const int64_t* bed, int64_t n_bed, const char* ref_seq, int64_t ref_start, size_t ref_len,
                                int excl_flags, int min_mq, int max_depth, int max_indel_length,
-                               const uint8_t* inflated, const cto_bgzf_block* blocks, int64_t n_blocks, cto_pack** out);
+                               const uint8_t* inflated, size_t inflated_len, const cto_bgzf_block* blocks, int64_t n_blocks,
+                               cto_pack** out);
 /* Build a pack from caller-made arrays (synthetic generators, BAM readers); key strings are the
  * alt_info keys ("IACG", "DACGT") concatenated, key_str_off[n_keys+1]. Arrays are copied. */
 int cto_pack_from_arrays(const cto_pack_view* host_view, const int64_t* key_str_off,
