@@ -29,6 +29,10 @@
 // Not implemented (documented deviations): BAQ (needs -f, which the reference does not pass), CRAM, multi-file input.
 #include <dlfcn.h>
 #include <zlib.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <cstdio>
@@ -97,15 +101,15 @@ struct PreInflated {
 };
 
 struct Bgzf {
-    FILE* f = nullptr;
-    std::vector<uint8_t> comp, block;   // compressed / inflated current block (when it was inflated here)
+    const uint8_t* map = nullptr;       // the BAM file, mapped: blocks are inflated straight out of the page cache
+    int64_t fsize = 0;
+    std::vector<uint8_t> block;         // inflated current block (when it was inflated here)
     const uint8_t* bptr = nullptr;      // the current block's inflated bytes: block.data() or a slot of `pre`
     size_t blen = 0;
     PreInflated pre;
     int64_t block_coffset = -1;         // file offset of the current block
     int64_t next_coffset = 0;           // file offset of the block after it
     size_t upos = 0;                    // read position inside `block`
-    int64_t file_pos = -1;              // where the FILE's cursor stands, when known
     z_stream zs;
     bool zs_init = false;
     void* ld = nullptr;                 // libdeflate decompressor when available
@@ -114,13 +118,20 @@ struct Bgzf {
     ~Bgzf() {
         if (zs_init) inflateEnd(&zs);
         if (ld) libdeflate().release(ld);
-        if (f) fclose(f);
+        if (map && fsize > 0) munmap(const_cast<uint8_t*>(map), size_t(fsize));
     }
     bool open(const char* path) {
-        f = fopen(path, "rb");
-        if (!f) { err = std::string("cannot open ") + path; return false; }
-        setvbuf(f, nullptr, _IOFBF, 1 << 20);
-        file_pos = 0;
+        const int fd = ::open(path, O_RDONLY | O_CLOEXEC);
+        if (fd < 0) { err = std::string("cannot open ") + path; return false; }
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { ::close(fd); err = std::string(path) + " is not a regular file"; return false; }
+        fsize = int64_t(st.st_size);
+        if (fsize > 0) {
+            void* m = mmap(nullptr, size_t(fsize), PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { ::close(fd); fsize = 0; err = std::string("cannot map ") + path; return false; }
+            map = static_cast<const uint8_t*>(m);
+        }
+        ::close(fd);
         memset(&zs, 0, sizeof(zs));
         if (inflateInit2(&zs, -15) != Z_OK) { err = "inflateInit2 failed"; return false; }
         zs_init = true;
@@ -138,17 +149,15 @@ struct Bgzf {
             upos = 0;
             return true;
         }
-        if (coff != file_pos && fseeko(f, off_t(coff), SEEK_SET) != 0) { err = "seek failed"; return false; }   // sequential reads keep the stdio buffer
-        file_pos = -1;
-        uint8_t h[18];
-        const size_t got = fread(h, 1, 18, f);
-        if (got == 0) return false;   // clean EOF
-        if (got != 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { err = "not a BGZF block header"; return false; }
+        if (coff < 0 || coff > fsize) { err = "seek failed"; return false; }
+        if (coff == fsize) return false;   // clean EOF
+        const uint8_t* h = map + coff;
+        const int64_t left = fsize - coff;
+        if (left < 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { err = "not a BGZF block header"; return false; }
         const int xlen = h[10] | (h[11] << 8);
+        if (left < 12 + int64_t(xlen)) { err = "truncated BGZF extra field"; return false; }
         // the BC subfield is normally first; scan the extra field in general
-        std::vector<uint8_t> extra(size_t(xlen), 0);
-        memcpy(extra.data(), h + 12, std::min<size_t>(6, size_t(xlen)));
-        if (xlen > 6 && fread(extra.data() + 6, 1, size_t(xlen - 6), f) != size_t(xlen - 6)) { err = "truncated BGZF extra field"; return false; }
+        const uint8_t* extra = h + 12;
         int bsize = -1;
         for (int i = 0; i + 4 <= xlen;) {
             const int slen = extra[size_t(i) + 2] | (extra[size_t(i) + 3] << 8);
@@ -159,25 +168,21 @@ struct Bgzf {
         if (bsize < 0) { err = "BGZF block without BC subfield"; return false; }
         const int cdata = bsize - xlen - 12 - 8;     // deflate payload; then CRC32 + ISIZE
         if (cdata < 0) { err = "bad BGZF block size"; return false; }
-        comp.resize(size_t(cdata) + 8);
-        if (xlen <= 6) {                              // part of the payload may already sit in h[]
-            const int have = 6 - xlen;                // bytes of h beyond the extra field
-            memcpy(comp.data(), h + 12 + xlen, size_t(have));
-            if (fread(comp.data() + have, 1, comp.size() - size_t(have), f) != comp.size() - size_t(have)) { err = "truncated BGZF block"; return false; }
-        } else if (fread(comp.data(), 1, comp.size(), f) != comp.size()) { err = "truncated BGZF block"; return false; }
-        const uint8_t* tail = comp.data() + cdata;
+        if (left < int64_t(bsize)) { err = "truncated BGZF block"; return false; }
+        const uint8_t* payload = h + 12 + xlen;
+        const uint8_t* tail = payload + cdata;
         const uint32_t isize = uint32_t(tail[4]) | (uint32_t(tail[5]) << 8) | (uint32_t(tail[6]) << 16) | (uint32_t(tail[7]) << 24);
         if (isize > 65536) { err = "BGZF block claims more than 64 KiB of data"; return false; }     // the format's limit
         block.resize(isize);
         if (isize && ld) {
             size_t got_out = 0;
-            if (libdeflate().inflate(ld, comp.data(), size_t(cdata), block.data(), isize, &got_out) != 0 || got_out != isize) {
+            if (libdeflate().inflate(ld, payload, size_t(cdata), block.data(), isize, &got_out) != 0 || got_out != isize) {
                 err = "inflate failed";
                 return false;
             }
         } else if (isize) {
             inflateReset(&zs);
-            zs.next_in = comp.data();
+            zs.next_in = const_cast<uint8_t*>(payload);
             zs.avail_in = uInt(cdata);
             zs.next_out = block.data();
             zs.avail_out = uInt(isize);
@@ -192,7 +197,6 @@ struct Bgzf {
         blen = block.size();
         block_coffset = coff;
         next_coffset = coff + bsize;
-        file_pos = next_coffset;
         upos = 0;
         return true;
     }
@@ -844,8 +848,7 @@ extern "C" int cto_bam_chunk_span(const char* bam_path, const char* bai_path, co
         std::vector<Chunk> chunks;
         std::string err, idx = bai_path ? std::string(bai_path) : std::string(bam_path) + ".bai";
         CTO_REQUIRE(bai_query(idx.c_str(), tid, start - 1, end, &chunks, &err), CTO_EINVAL, "cto_bam_chunk_span: %s", err.c_str());
-        CTO_REQUIRE(fseeko(bz.f, 0, SEEK_END) == 0, CTO_EINVAL, "cto_bam_chunk_span: seek failed");
-        const int64_t fsize = int64_t(ftello(bz.f));
+        const int64_t fsize = bz.fsize;
         int64_t lo = fsize, hi = 0;
         for (const Chunk& c : chunks) {
             lo = std::min<int64_t>(lo, int64_t(c.beg >> 16));
