@@ -27,6 +27,11 @@
 //     position, the first mate's base keeps min(200, qa + qb) when they agree and the better base keeps 0.8 x its quality
 //     when they differ; the other base's quality becomes 0 (soften_overlap below).  Paired-end short reads only.
 // Not implemented (documented deviations): BAQ (needs -f, which the reference does not pass), CRAM, multi-file input.
+//
+// I/O: the file is mapped; every BGZF block is inflated (libdeflate when the runtime library is present, else zlib) and checked
+// against the CRC-32 of its gzip trailer, as htslib does.  Blocks a caller inflated elsewhere (cto_pack_from_bam_inflated: on the
+// device, csrc/inflate.hip) are looked up by file offset and CRC-checked the same way.  Columns are built in runs of requested
+// positions, read by read (Producer below).
 #include <dlfcn.h>
 #include <zlib.h>
 #include <fcntl.h>
