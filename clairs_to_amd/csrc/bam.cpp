@@ -318,14 +318,15 @@ struct Read {
     uint8_t mapq = 0;
     bool rev = false;
     std::vector<uint32_t> cigar;
-    std::vector<uint8_t> raw;   // packed SEQ (4 bits per base) followed by QUAL, as in the record: decoded on demand, since a
+    std::vector<uint8_t> raw;   // the alignment record as read; packed SEQ (4 bits per base) and QUAL are decoded on demand, since a
                                 // BED-restricted pileup touches a small part of a long read
     int32_t l_seq = 0;
     bool no_qual = false;
     std::string mate_key;       // QNAME of a paired read (empty otherwise): mates find each other through it
-    int base4(int q) const { return (raw[size_t(q >> 1)] >> ((~q & 1) << 2)) & 15; }
-    int bq(int q) const { return (no_qual || q >= l_seq) ? 0 : std::min(int(raw[size_t((l_seq + 1) / 2 + q)]), 93); }
-    uint8_t* qual_at(int q) { return &raw[size_t((l_seq + 1) / 2 + q)]; }
+    size_t seq_off = 0, qual_off = 0;   // where SEQ and QUAL start in `raw` (the whole record is kept: no second copy)
+    int base4(int q) const { return (raw[seq_off + size_t(q >> 1)] >> ((~q & 1) << 2)) & 15; }
+    int bq(int q) const { return (no_qual || q >= l_seq) ? 0 : std::min(int(raw[qual_off + size_t(q)]), 93); }
+    uint8_t* qual_at(int q) { return &raw[qual_off + size_t(q)]; }
     // query index of the aligned base (M / = / X) at 0-based reference position rpos, or -1 (deletion, skip, outside the read)
     int query_at(int32_t rpos) const {
         int32_t rp = pos, qp = 0;
@@ -678,8 +679,11 @@ int pack_from_bam_range(const char* bam_path, const char* bai_path, const char* 
             if (r.end <= beg0) continue;
             r.op_ref = pos;
             r.l_seq = l_seq;
-            r.raw.assign(sq, ql + l_seq);
             r.no_qual = ql[0] == 0xff;                                                             // QUAL absent
+            r.seq_off = size_t(sq - b);
+            r.qual_off = size_t(ql - b);
+            r.raw.swap(rec);                                   // the record's buffer moves into the read (b, sq, ql stay valid: same
+                                                               // heap block); the next record gets a fresh one
             // Columns strictly before the PREVIOUS accepted read's start are emitted now; those between the two starts wait for
             // the next record.  That is htslib's order (bam_plp_next hands out column p only once a read starting beyond p has
             // been pushed, so a read is pushed - and its mate's qualities are edited - while the iterator stands at the
