@@ -37,6 +37,24 @@ class CvtCfg(C.Structure):
     _fields_ = [("emb_dim", C.c_int * 3), ("heads", C.c_int * 3), ("depth", C.c_int * 3), ("n_out", C.c_int)]
 
 
+class ChunkJob(C.Structure):
+    _fields_ = [("ctg_name", C.c_char_p), ("bed_path", C.c_char_p), ("mpileup_path", C.c_char_p), ("bam_path", C.c_char_p),
+                ("vcf_path", C.c_char_p)]
+
+
+class RunCfg(C.Structure):
+    _fields_ = [("aff", c_vp), ("neg", c_vp), ("d_lik", c_vp), ("d_edges", c_vp), ("K", C.c_int), ("min_bq", C.c_int),
+                ("min_rescale_cov", C.c_int), ("max_indel_length", C.c_int), ("max_depth", C.c_int), ("neg_reads_aff", C.c_int),
+                ("show_ref", C.c_int), ("verbose", C.c_int), ("qual_pass", C.c_double), ("ref_fa", C.c_char_p),
+                ("vcf_header", C.c_char_p), ("producers", C.c_int), ("writers", C.c_int), ("depth", C.c_int)]
+
+
+class RunStats(C.Structure):
+    _fields_ = [("candidates", c_i64), ("sites", c_i64), ("rows", c_i64), ("low_coverage", c_i64), ("clamped", c_i64), ("seconds", C.c_double),
+                ("produce_s", C.c_double), ("finish_s", C.c_double), ("launch_s", C.c_double), ("launcher_wait_s", C.c_double),
+                ("pack_s", C.c_double), ("upload_s", C.c_double), ("device_s", C.c_double)]
+
+
 # every symbol include/clairsto_amd.h declares: (restype, argtypes)
 SYMBOLS = {
     "cto_last_error": (C.c_char_p, []),
@@ -72,6 +90,8 @@ SYMBOLS = {
     "cto_bigru_create_packed": (C.c_int, [c_vp, c_i64, C.c_int, C.POINTER(c_vp)]),
     "cto_model_manifest": (c_i64, [C.c_int, C.POINTER(CvtCfg), C.c_int, c_vp, C.c_size_t]),
     "cto_bed_centres": (c_i64, [c_vp, C.c_size_t, C.c_char_p, c_vp, c_i64, c_vp, c_vp]),
+    "cto_run_chunks": (C.c_int, [C.POINTER(RunCfg), C.POINTER(ChunkJob), c_i64, c_vp, C.POINTER(RunStats)]),
+    "cto_run_release": (C.c_int, []),
     "cto_haplotype_filter": (C.c_int, [c_vp, C.c_size_t, C.c_char_p, c_i64, C.c_size_t, c_i64, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int,
                                        C.c_int, c_vp, c_vp]),
     "cto_vcf_rows_batch": (c_i64, [C.c_char_p, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_double,

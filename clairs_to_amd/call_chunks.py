@@ -134,6 +134,63 @@ def run_pipeline(eng, chunk_args, producers=4, writers=2, depth=None, stats=None
     return n_rows
 
 
+def native_eligible(chunk_args):
+    """cto_run_chunks reads plain files itself: no gzip inputs, no samtools subprocess, no device inflate, no --predict_fn tap"""
+    for a in chunk_args:
+        if getattr(a, "predict_fn", None) or a.candidates_bed_regions.endswith(".gz") or str(a.ref_fn).endswith(".gz"):
+            return False
+        mp = getattr(a, "mpileup_fn", None)
+        if mp:
+            if mp.endswith(".gz"):
+                return False
+        elif getattr(a, "bam_reader", "samtools") != "native":
+            return False
+    return True
+
+
+def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, stats=None, verbose=True):
+    """run_pipeline() as ONE C call (cto_run_chunks, csrc/pipeline.hip): the same stages on native threads - the interpreter is
+    not in the loop, which is what levels the Python pipeline off at ~290 chunks a second.  Same files, byte for byte."""
+    import ctypes as C
+    from ._lib import ChunkJob, RunCfg, RunStats, check, lib
+    from .call_variants import VCF_HEADER
+    from .create_tensor_pileup_calling import MAX_INDEL
+    chunk_args = list(chunk_args)
+    if not chunk_args:
+        return 0
+    if "CTO_PACK_THREADS" not in os.environ:
+        os.environ["CTO_PACK_THREADS"] = str(max(2, usable_cores() // 2))
+    a0 = chunk_args[0]
+    jobs = (ChunkJob * len(chunk_args))()
+    for j, a in zip(jobs, chunk_args):
+        os.makedirs(os.path.dirname(os.path.abspath(a.call_fn)), exist_ok=True)
+        mp = getattr(a, "mpileup_fn", None)
+        j.ctg_name, j.bed_path, j.vcf_path = a.ctg_name.encode(), a.candidates_bed_regions.encode(), a.call_fn.encode()
+        j.mpileup_path = mp.encode() if mp else None
+        j.bam_path = None if mp else str(a.tumor_bam_fn).encode()
+    cfg = RunCfg()
+    cfg.aff, cfg.neg = eng.h_aff, eng.h_neg
+    cfg.d_lik, cfg.d_edges = eng.posterior.lik.data_ptr(), eng.posterior.edges.data_ptr()
+    cfg.K, cfg.min_bq, cfg.min_rescale_cov = eng.K, eng.min_bq, eng.min_rescale_cov or 0
+    cfg.max_indel_length = MAX_INDEL if getattr(a0, "max_indel_length", None) is None else a0.max_indel_length
+    cfg.max_depth = 8000 if getattr(a0, "max_depth", None) is None else a0.max_depth
+    cfg.neg_reads_aff, cfg.show_ref, cfg.verbose = int(eng.neg_reads_aff), int(bool(a0.show_ref)), int(bool(verbose))
+    cfg.qual_pass = -1.0 if a0.qual is None else float(a0.qual)
+    cfg.ref_fa = str(a0.ref_fn).encode()
+    cfg.vcf_header = (VCF_HEADER + "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n" % a0.sample_name).encode()
+    cfg.producers, cfg.writers, cfg.depth = int(producers), int(writers), int(depth or 0)
+    st = RunStats()
+    with torch.cuda.device(eng.device):
+        rc = lib.cto_run_chunks(C.byref(cfg), jobs, len(chunk_args), C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(st))
+    sys.stdout.flush()
+    check(rc)
+    if stats is not None:
+        for k, v in (("sites", st.candidates), ("produce_s", st.produce_s), ("finish_s", st.finish_s), ("launch_s", st.launch_s),
+                     ("launcher_waits_for_producer_s", st.launcher_wait_s), ("pack_s", st.pack_s), ("upload_s", st.upload_s), ("device_s", st.device_s), ("low_coverage", st.low_coverage), ("clamped", st.clamped)):
+            stats[k] = stats.get(k, 0) + v
+    return int(st.rows)
+
+
 def call_chunks(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -171,7 +228,11 @@ def call_chunks(args):
             if os.path.exists(a.call_fn):
                 os.remove(a.call_fn)
         producers = args.producers if getattr(args, "producers", None) else default_producers(getattr(args, "bam_reader", None) in ("native", "gpu"))
-        n_rows = run_pipeline(eng, mine, producers=producers, writers=getattr(args, "writers", None) or 2)
+        how = getattr(args, "pipeline", None) or "auto"
+        if how == "native" and not native_eligible(mine):
+            sys.exit("[ERROR] --pipeline native reads plain files itself: needs --mpileup_dir or --bam_reader native, and no .gz inputs")
+        run = run_pipeline_native if how == "native" or (how == "auto" and native_eligible(mine)) else run_pipeline
+        n_rows = run(eng, mine, producers=producers, writers=getattr(args, "writers", None) or 2)
     except (Exception, SystemExit) as e:     # a bad reference, a corrupt BAM, CTO_EUNSUPPORTED ...: report, do not leave the others waiting
         failure = "%s: %s" % (type(e).__name__, e)
         print("[ERROR] rank %d/%d failed: %s" % (rank, world, failure), file=sys.stderr)
@@ -220,6 +281,9 @@ def main():
                    help="read <dir>/<chunk file name>.mpileup (samtools mpileup --min-BQ 0 text of the chunk) instead of the BAM")
     p.add_argument("--producers", type=int, default=None, help="pack-producer threads per rank (default: usable cores / 4, / 2 with --bam_reader native; <= 16)")
     p.add_argument("--writers", type=int, default=None, help="VCF-writer threads per rank (default 2)")
+    p.add_argument("--pipeline", type=str, default="auto", choices=["auto", "native", "python"],
+                   help="'native': the chunk loop as one C call (cto_run_chunks; plain-text inputs, --mpileup_dir or --bam_reader native); "
+                        "'python': the thread-pool pipeline of this module; 'auto': native when the inputs allow it")
     call_chunks(p.parse_args())
 
 

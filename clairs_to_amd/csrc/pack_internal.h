@@ -66,9 +66,16 @@ struct Tok {
 constexpr int kMaxDepth = 32767;
 constexpr int kMaxKeysPerCol = 2048;
 
+// Distinct indel keys of the column being built.  A column has a handful of them, so the look-up is a scan over 32-bit hashes
+// (a hit is confirmed on the characters); the sequences stay where the producer has them (mpileup text / BAM record) for the
+// duration of the column.  (std::string keys in two hash maps cost ~150 ns per indel-carrying read-base - a third of the
+// tokeniser's time on 50x long-read rows.)
 struct ColumnScratch {
-    std::unordered_map<std::string, int> keymap, groupmap;
-    std::string keybuf, groupbuf;
+    struct Key   { const char* seq; int len; uint8_t code, kind; };     // Counter key: base character + sign + sequence, case-sensitive
+    struct Group { const char* seq; int len; char anchor; uint8_t kind; };   // merged allele: anchor + upper-cased sequence / deletion length
+    std::vector<uint32_t> key_hash, group_hash;
+    std::vector<Key> keys;
+    std::vector<Group> groups;
 };
 
 void set_err(std::string* err, const char* fmt, ...);

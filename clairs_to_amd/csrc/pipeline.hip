@@ -1,0 +1,605 @@
+// Native chunk pipeline: candidate chunk files + pileup source (mpileup text or BAM) -> p_<chunk>.vcf, the whole of what
+// pileup_call.prepare_chunk / launch_chunk / finish_chunk do per chunk, without the interpreter in the loop.
+//
+//   producers (N threads)  BED -> centres, reference slice (.fai), column pack (tokeniser / BAM reader), upload on the producer's
+//                          own stream into the device buffers of a free slot
+//   launcher (the caller)  waits for the upload event; featurisation, both networks, posterior; the candidates' column vectors
+//                          gathered on the device; asynchronous copies into the slot's page-locked buffers; an event
+//   writers (M threads)    alt_info strings + every VCF record (two C calls), file write; the slot goes back to the pool
+//
+// The Python pipeline (call_chunks.run_pipeline) does the same with the same C calls, but its launcher, its BED / FASTA / file
+// handling and the glue between the calls hold the interpreter lock: it levels off at ~290 chunks a second (1.1-1.2 M sites/s
+// from text) on a GPU that needs 2 ms per chunk.  Outputs are byte-identical (tests/test_gpu_cli.py).
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+
+using namespace cto;
+
+namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct DevBuf {                          // a device allocation that only grows
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return CTO_OK;
+        if (p) CTO_HIP(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        const size_t want = n + n / 4 + 256;
+        CTO_HIP(hipMalloc(&p, want));
+        cap = want;
+        return CTO_OK;
+    }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+struct PinBuf {                          // page-locked host memory that only grows
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return CTO_OK;
+        if (p) CTO_HIP(hipHostFree(p));
+        p = nullptr;
+        cap = 0;
+        const size_t want = n + n / 4 + 256;
+        CTO_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+        return CTO_OK;
+    }
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+};
+
+struct Slot {
+    // pack on the device
+    DevBuf pack_dev;                     // the pack arrays + the candidate positions, one allocation (256-byte aligned parts)
+    PinBuf stage;                        // its page-locked source
+    const int32_t* d_site_pos = nullptr;
+    // featurisation / network / epilogue outputs
+    DevBuf colvec, coldepth, keycnt, x_aff, x_neg, site_info, sitefirst, keyfirst, la, ln, post, decision, qual, site_colvec;
+    PinBuf h_site_info, h_site_colvec, h_sitefirst, h_keycnt, h_keyfirst, h_decision, h_qual;
+    hipEvent_t uploaded = nullptr, begin = nullptr, done = nullptr;
+    // host side of the chunk
+    int64_t job = -1;
+    int device = 0;
+    cto_pack* pack = nullptr;
+    cto_pack_view hv{}, dv{};
+    std::vector<int32_t> sites;
+    std::string ref;
+    int64_t ref_start = 0;
+    std::string error;
+    ~Slot() {
+        if (pack) cto_pack_free(pack);
+        if (uploaded) (void)hipEventDestroy(uploaded);
+        if (done) (void)hipEventDestroy(done);
+        if (begin) (void)hipEventDestroy(begin);
+    }
+};
+
+template <class T>
+struct Queue {                            // unbounded MPMC queue with a closed state
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<T> q;
+    bool closed = false;
+    void push(T v) { { std::lock_guard<std::mutex> g(m); q.push_back(std::move(v)); } cv.notify_one(); }
+    void close() { { std::lock_guard<std::mutex> g(m); closed = true; } cv.notify_all(); }
+    bool pop(T* out) {
+        std::unique_lock<std::mutex> g(m);
+        cv.wait(g, [&] { return !q.empty() || closed; });
+        if (q.empty()) return false;
+        *out = std::move(q.front());
+        q.pop_front();
+        return true;
+    }
+};
+
+struct Mapped {                           // a read-only file mapping
+    const char* p = nullptr;
+    size_t n = 0;
+    bool open(const char* path, std::string* err) {
+        const int fd = ::open(path, O_RDONLY | O_CLOEXEC);
+        if (fd < 0) { *err = std::string("cannot open ") + path; return false; }
+        struct stat st;
+        if (fstat(fd, &st) != 0) { ::close(fd); *err = std::string("cannot stat ") + path; return false; }
+        n = size_t(st.st_size);
+        if (n) {
+            void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { ::close(fd); n = 0; *err = std::string("cannot map ") + path; return false; }
+            p = static_cast<const char*>(m);
+        }
+        ::close(fd);
+        return true;
+    }
+    ~Mapped() { if (p && n) munmap(const_cast<char*>(p), n); }
+};
+
+struct FaiRec { int64_t length = 0, offset = 0, linebases = 0, linewidth = 0; bool ok = false; };
+
+// <fasta>.fai (or <fasta without extension>.fai): the record of contig `ctg`  (fasta.py read_region)
+bool fai_lookup(const std::string& fasta, const std::string& ctg, FaiRec* rec, std::string* err) {
+    std::string fai = fasta + ".fai";
+    FILE* f = fopen(fai.c_str(), "r");
+    if (!f) {
+        const size_t dot = fasta.rfind('.');
+        if (dot != std::string::npos) { fai = fasta.substr(0, dot) + ".fai"; f = fopen(fai.c_str(), "r"); }
+    }
+    if (!f) { *err = "[ERROR] file " + fasta + ".fai not found"; return false; }
+    char line[4096];
+    while (fgets(line, sizeof(line), f)) {
+        char* tab = strchr(line, '\t');
+        if (!tab) continue;
+        if (size_t(tab - line) == ctg.size() && memcmp(line, ctg.data(), ctg.size()) == 0) {
+            long long a = 0, b = 0, c = 0, d = 0;
+            if (sscanf(tab + 1, "%lld\t%lld\t%lld\t%lld", &a, &b, &c, &d) == 4 && c > 0 && d > 0) {
+                rec->length = a; rec->offset = b; rec->linebases = c; rec->linewidth = d; rec->ok = true;
+            }
+            break;
+        }
+    }
+    fclose(f);
+    if (!rec->ok) { *err = "contig " + ctg + " not in " + fai; return false; }
+    return true;
+}
+
+// 1-based inclusive [start, end] of the contig, upper-cased, clipped to the contig (fasta.py read_region)
+bool read_region(const Mapped& fa, const FaiRec& r, int64_t start, int64_t end, std::string* out, std::string* err) {
+    out->clear();
+    if (fa.n >= 2 && (unsigned char)fa.p[0] == 0x1f && (unsigned char)fa.p[1] == 0x8b) {
+        *err = "[ERROR] the reference is gzip / bgzip compressed: decompress it (and re-run samtools faidx) before use";
+        return false;
+    }
+    start = std::max<int64_t>(1, start);
+    end = std::min<int64_t>(r.length, end);
+    if (end < start) return true;
+    const int64_t s0 = start - 1, e0 = end;
+    const int64_t b0 = r.offset + (s0 / r.linebases) * r.linewidth + s0 % r.linebases;
+    const int64_t b1 = r.offset + ((e0 - 1) / r.linebases) * r.linewidth + (e0 - 1) % r.linebases + 1;
+    if (b0 < 0 || b1 > int64_t(fa.n) || b1 < b0) { *err = "reference index points outside the FASTA file"; return false; }
+    out->resize(size_t(end - start + 1));
+    char* dst = &(*out)[0];
+    size_t n = 0;
+    for (const char* q = fa.p + b0; q < fa.p + b1;) {                 // line by line: memchr + one pass that folds the case
+        const char* nl = static_cast<const char*>(memchr(q, '\n', size_t(fa.p + b1 - q)));
+        const char* e = nl ? nl : fa.p + b1;
+        for (const char* c = q; c < e; ++c)
+            if (*c != '\r' && n < out->size()) dst[n++] = (*c >= 'a' && *c <= 'z') ? char(*c - 32) : *c;
+        q = e + 1;
+    }
+    out->resize(n);
+    return true;
+}
+
+// BED rows of `ctg` as 0-based [begin, end) intervals, sorted and merged (what `samtools mpileup -l` restricts positions to)
+void bed_intervals(const char* text, size_t len, const std::string& ctg, std::vector<int64_t>* out) {
+    std::vector<std::pair<int64_t, int64_t>> iv;
+    size_t i = 0;
+    while (i < len) {
+        const char* nl = static_cast<const char*>(memchr(text + i, '\n', len - i));
+        const size_t e = nl ? size_t(nl - text) : len;
+        const char* row = text + i;
+        const size_t rl = e - i;
+        const char* t1 = static_cast<const char*>(memchr(row, '\t', rl));
+        if (t1 && size_t(t1 - row) == ctg.size() && memcmp(row, ctg.data(), ctg.size()) == 0) {
+            const char* t2 = static_cast<const char*>(memchr(t1 + 1, '\t', rl - size_t(t1 + 1 - row)));
+            if (t2) {
+                const long long a = atoll(std::string(t1 + 1, size_t(t2 - t1 - 1)).c_str());
+                const char* t3 = static_cast<const char*>(memchr(t2 + 1, '\t', rl - size_t(t2 + 1 - row)));
+                const size_t l3 = t3 ? size_t(t3 - t2 - 1) : rl - size_t(t2 + 1 - row);
+                const long long b = atoll(std::string(t2 + 1, l3).c_str());
+                iv.emplace_back(std::max<long long>(0, a), b);
+            }
+        }
+        i = e + 1;
+    }
+    std::sort(iv.begin(), iv.end());
+    out->clear();
+    for (const auto& p : iv) {
+        if (!out->empty() && p.first <= (*out)[out->size() - 1]) (*out)[out->size() - 1] = std::max((*out)[out->size() - 1], p.second);
+        else { out->push_back(p.first); out->push_back(p.second); }
+    }
+}
+
+__global__ void k_gather_rows(const int16_t* __restrict__ colvec, const int32_t* __restrict__ site_info, int64_t n, int16_t* __restrict__ out) {
+    const int64_t i = blockIdx.x;
+    if (i >= n) return;
+    const int32_t c = site_info[i * 12];
+    const int64_t col = c < 0 ? 0 : c;
+    if (threadIdx.x < CTO_COLVEC_STRIDE) out[i * CTO_COLVEC_STRIDE + threadIdx.x] = colvec[col * CTO_COLVEC_STRIDE + threadIdx.x];
+}
+
+// never destroyed: at process exit the HIP runtime may already be gone when static destructors run
+std::mutex& slot_cache_m() { static std::mutex* m = new std::mutex(); return *m; }
+std::vector<std::unique_ptr<Slot>>& slot_cache() { static auto* v = new std::vector<std::unique_ptr<Slot>>(); return *v; }
+struct SlotReturn {                      // hands a finished (or failed) call's slots back to the cache
+    std::vector<std::unique_ptr<Slot>>* slots;
+    ~SlotReturn() {
+        std::lock_guard<std::mutex> g(slot_cache_m());
+        for (auto& sl : *slots) {
+            if (sl->pack) { cto_pack_free(sl->pack); sl->pack = nullptr; }
+            slot_cache().push_back(std::move(sl));
+        }
+        slots->clear();
+    }
+};
+
+constexpr int FLANK_POS = 33, EXPAND_REF = 1000;       // shared/param.py no_of_positions, expand_reference_region
+
+struct Run {
+    const cto_run_cfg* cfg;
+    const cto_chunk_job* jobs;
+    int64_t n_jobs;
+    std::atomic<int64_t> next_job{0};
+    std::vector<std::unique_ptr<Slot>> slots;
+    Queue<Slot*> free_slots, to_launch, to_write;
+    std::mutex err_m;
+    std::string first_error;
+    std::atomic<bool> failed{false};
+    std::atomic<int64_t> candidates{0}, sites{0}, rows{0}, low_cov{0}, clamped{0}, chunks_done{0};
+    std::mutex stat_m;
+    double produce_s = 0, finish_s = 0, pack_s = 0, upload_s = 0, device_s = 0;
+    Mapped fasta;
+    std::mutex fai_m;
+    std::map<std::string, FaiRec> fai;
+
+    bool fai_of(const std::string& ctg, FaiRec* rec, std::string* err) {
+        std::lock_guard<std::mutex> g(fai_m);
+        auto it = fai.find(ctg);
+        if (it != fai.end()) { *rec = it->second; return true; }
+        if (!fai_lookup(cfg->ref_fa, ctg, rec, err)) return false;
+        fai[ctg] = *rec;
+        return true;
+    }
+
+    void fail(const std::string& msg) {
+        std::lock_guard<std::mutex> g(err_m);
+        if (first_error.empty()) first_error = msg;
+        failed = true;
+    }
+
+    // host half of a chunk + the upload; false = nothing to call in this chunk (no output) or an error (failed is set)
+    bool produce(Slot* s, hipStream_t stream) {
+        const cto_chunk_job& j = jobs[s->job];
+        const std::string ctg = j.ctg_name;
+        std::string err;
+        Mapped bed;
+        if (!bed.open(j.bed_path, &err)) { fail(err); return false; }
+        std::vector<int32_t> centres(std::count(bed.p, bed.p + bed.n, '\n') + 2);
+        int64_t span[2] = {0, 0};
+        int has_types = 0;
+        const int64_t n = cto_bed_centres(bed.p ? bed.p : "", bed.n, ctg.c_str(), centres.data(), int64_t(centres.size()), span, &has_types);
+        if (n < 0) { fail(cto_last_error()); return false; }
+        centres.resize(size_t(n));
+        std::sort(centres.begin(), centres.end());
+        centres.erase(std::unique(centres.begin(), centres.end()), centres.end());
+        s->sites.swap(centres);
+        candidates += int64_t(s->sites.size());
+        if (s->sites.empty()) {
+            if (cfg->verbose) fprintf(stderr, "[INFO] %s total processed positions: 0\n", j.ctg_name);
+            return false;
+        }
+        const int64_t ctg_start = span[0], ctg_end = span[1];
+        s->ref_start = std::max<int64_t>(1, ctg_start - EXPAND_REF);
+        FaiRec fr;
+        if (!fai_of(ctg, &fr, &err) || !read_region(fasta, fr, s->ref_start, ctg_end + EXPAND_REF, &s->ref, &err)) { fail(err); return false; }
+        if (s->ref.empty()) { fail(std::string("[ERROR] Failed to load reference sequence from file (") + cfg->ref_fa + ")."); return false; }
+        if (s->pack) { cto_pack_free(s->pack); s->pack = nullptr; }
+        int rc = CTO_OK;
+        const double t_pack = now_s();
+        if (j.mpileup_path) {
+            Mapped txt;
+            if (!txt.open(j.mpileup_path, &err)) { fail(err); return false; }
+            rc = cto_pack_from_mpileup(txt.p ? txt.p : "", txt.n, s->ref.data(), s->ref_start, s->ref.size(), cfg->max_indel_length, &s->pack);
+        } else {
+            std::vector<int64_t> iv;
+            bed_intervals(bed.p ? bed.p : "", bed.n, ctg, &iv);
+            rc = cto_pack_from_bam(j.bam_path, nullptr, ctg.c_str(), std::max<int64_t>(1, ctg_start - FLANK_POS), ctg_end + FLANK_POS,
+                                   iv.empty() ? nullptr : iv.data(), int64_t(iv.size() / 2), s->ref.data(), s->ref_start, s->ref.size(), 2316, 0,
+                                   cfg->max_depth, cfg->max_indel_length, &s->pack);
+        }
+        if (rc != CTO_OK) { fail(cto_last_error()); return false; }
+        if (cto_pack_view_of(s->pack, &s->hv) != CTO_OK) { fail(cto_last_error()); return false; }
+        // ---- upload ----
+        const double t_up = now_s();
+        // One copy per chunk out of a page-locked staging buffer.  (hipMemcpyAsync from the pack's pageable arrays goes through the
+        // runtime's own staging buffer, which every producer thread shares: measured, 8 producers spent 2.4 ms per chunk in those
+        // calls, 16 producers 6.6 ms, and the whole pipeline levelled off at ~8.5 GB/s of uploads = 1.4-1.6 M sites/s.)
+        const cto_pack_view& h = s->hv;
+        const size_t nc = size_t(h.n_cols), ne = size_t(h.n_entries), nk = size_t(h.n_keys), ns = s->sites.size();
+        const void* src[8] = {h.col_pos, h.col_ref, h.col_off, h.key_off, h.entries, h.key_meta, h.key_group, s->sites.data()};
+        const size_t bytes[8] = {nc * 4, nc, (nc + 1) * 8, (nc + 1) * 4, ne * 4, nk, nk * 4, ns * 4};
+        size_t off[8], total = 0;
+        for (int i = 0; i < 8; ++i) { off[i] = total; total += (bytes[i] + 255) / 256 * 256 + 256; }
+        if (s->stage.ensure(total) != CTO_OK || s->pack_dev.ensure(total) != CTO_OK) { fail(cto_last_error()); return false; }
+        char* hs = static_cast<char*>(s->stage.p);
+        for (int i = 0; i < 8; ++i)
+            if (bytes[i]) memcpy(hs + off[i], src[i], bytes[i]);
+        if (hipMemcpyAsync(s->pack_dev.p, hs, total, hipMemcpyHostToDevice, stream) != hipSuccess) { fail("hipMemcpyAsync failed"); return false; }
+        const char* d = static_cast<const char*>(s->pack_dev.p);
+        s->dv = h;
+        s->dv.col_pos = reinterpret_cast<const int32_t*>(d + off[0]);
+        s->dv.col_ref = reinterpret_cast<const uint8_t*>(d + off[1]);
+        s->dv.col_off = reinterpret_cast<const int64_t*>(d + off[2]);
+        s->dv.key_off = reinterpret_cast<const int32_t*>(d + off[3]);
+        s->dv.entries = reinterpret_cast<const uint32_t*>(d + off[4]);
+        s->dv.key_meta = reinterpret_cast<const uint8_t*>(d + off[5]);
+        s->dv.key_group = reinterpret_cast<const int32_t*>(d + off[6]);
+        s->d_site_pos = reinterpret_cast<const int32_t*>(d + off[7]);
+        if (hipEventRecord(s->uploaded, stream) != hipSuccess) { fail("hipEventRecord failed"); return false; }
+        { std::lock_guard<std::mutex> g(stat_m); pack_s += t_up - t_pack; upload_s += now_s() - t_up; }
+        return true;
+    }
+
+    int launch(Slot* s, hipStream_t main) {
+        const int K = cfg->K;
+        const int64_t n = int64_t(s->sites.size());
+        const size_t nc = size_t(std::max<int64_t>(s->hv.n_cols, 1)), nk = size_t(std::max<int64_t>(s->hv.n_keys, 1));
+        int rc;
+        if ((rc = s->colvec.ensure(nc * CTO_COLVEC_STRIDE * 2)) || (rc = s->coldepth.ensure(nc * 8)) || (rc = s->keycnt.ensure(nk * 4)) ||
+            (rc = s->x_aff.ensure(size_t(n) * CTO_NPOS * CTO_NCHAN * 4)) || (rc = s->x_neg.ensure(size_t(n) * CTO_NPOS * CTO_NCHAN * 4)) ||
+            (rc = s->site_info.ensure(size_t(n) * 48)) || (rc = s->sitefirst.ensure(size_t(n) * 32)) || (rc = s->keyfirst.ensure(nk * 8)) ||
+            (rc = s->la.ensure(size_t(K) * n * 8)) || (rc = s->ln.ensure(size_t(K) * n * 8)) || (rc = s->post.ensure(size_t(n) * K * 8)) ||
+            (rc = s->decision.ensure(size_t(n) * 16)) || (rc = s->qual.ensure(size_t(n) * 8)) ||
+            (rc = s->site_colvec.ensure(size_t(n) * CTO_COLVEC_STRIDE * 2)) ||
+            (rc = s->h_site_info.ensure(size_t(n) * 48)) || (rc = s->h_site_colvec.ensure(size_t(n) * CTO_COLVEC_STRIDE * 2)) ||
+            (rc = s->h_sitefirst.ensure(size_t(n) * 32)) || (rc = s->h_keycnt.ensure(nk * 4)) || (rc = s->h_keyfirst.ensure(nk * 8)) ||
+            (rc = s->h_decision.ensure(size_t(n) * 16)) || (rc = s->h_qual.ensure(size_t(n) * 8)))
+            return rc;
+        CTO_HIP(hipStreamWaitEvent(main, s->uploaded, 0));
+        CTO_HIP(hipEventRecord(s->begin, main));
+        auto* colvec = static_cast<int16_t*>(s->colvec.p);
+        auto* site_info = static_cast<int32_t*>(s->site_info.p);
+        if ((rc = cto_featurize_columns(&s->dv, cfg->min_bq, colvec, static_cast<int32_t*>(s->coldepth.p), static_cast<uint32_t*>(s->keycnt.p), main)))
+            return rc;
+        if ((rc = cto_gather_windows(&s->dv, colvec, static_cast<int32_t*>(s->coldepth.p), s->d_site_pos, n, cfg->min_bq,
+                                     cfg->min_rescale_cov, static_cast<float*>(s->x_aff.p), static_cast<float*>(s->x_neg.p), nullptr, nullptr, site_info,
+                                     static_cast<int32_t*>(s->sitefirst.p), static_cast<int32_t*>(s->keyfirst.p), main)))
+            return rc;
+        const float* x_neg = cfg->neg_reads_aff ? static_cast<const float*>(s->x_aff.p) : static_cast<const float*>(s->x_neg.p);
+        if ((rc = cto_model_forward(cfg->neg, x_neg, n, static_cast<float*>(s->ln.p), main))) return rc;
+        if ((rc = cto_model_forward(cfg->aff, static_cast<const float*>(s->x_aff.p), n, static_cast<float*>(s->la.p), main))) return rc;
+        if ((rc = cto_posterior(static_cast<const float*>(s->la.p), static_cast<const float*>(s->ln.p), K, n, cfg->d_lik, cfg->d_edges, nullptr,
+                                static_cast<double*>(s->post.p), static_cast<int32_t*>(s->decision.p), static_cast<double*>(s->qual.p), main)))
+            return rc;
+        hipLaunchKernelGGL(k_gather_rows, dim3(unsigned(n)), dim3(128), 0, main, colvec, site_info, n, static_cast<int16_t*>(s->site_colvec.p));
+        CTO_HIP(hipGetLastError());
+        auto down = [&](PinBuf& h, const DevBuf& d, size_t bytes) { return bytes ? hipMemcpyAsync(h.p, d.p, bytes, hipMemcpyDeviceToHost, main) : hipSuccess; };
+        CTO_HIP(down(s->h_site_info, s->site_info, size_t(n) * 48));
+        CTO_HIP(down(s->h_site_colvec, s->site_colvec, size_t(n) * CTO_COLVEC_STRIDE * 2));
+        CTO_HIP(down(s->h_sitefirst, s->sitefirst, size_t(n) * 32));
+        CTO_HIP(down(s->h_keycnt, s->keycnt, size_t(s->hv.n_keys) * 4));
+        CTO_HIP(down(s->h_keyfirst, s->keyfirst, size_t(s->hv.n_keys) * 8));
+        CTO_HIP(down(s->h_decision, s->decision, size_t(n) * 16));
+        CTO_HIP(down(s->h_qual, s->qual, size_t(n) * 8));
+        CTO_HIP(hipEventRecord(s->done, main));
+        return CTO_OK;
+    }
+
+    // alt_info strings, VCF records, file
+    bool finish(Slot* s) {
+        const cto_chunk_job& j = jobs[s->job];
+        if (hipEventSynchronize(s->done) != hipSuccess) { fail("hipEventSynchronize failed"); return false; }
+        {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, s->begin, s->done) == hipSuccess) { std::lock_guard<std::mutex> g(stat_m); device_s += ms * 1e-3; }
+        }
+        const int64_t n = int64_t(s->sites.size());
+        auto* info = static_cast<int32_t*>(s->h_site_info.p);
+        static const uint32_t zero_k[1] = {0};
+        static const int32_t zero_kf[2] = {0, 0};
+        const uint32_t* keycnt = s->hv.n_keys ? static_cast<const uint32_t*>(s->h_keycnt.p) : zero_k;
+        const int32_t* keyfirst = s->hv.n_keys ? static_cast<const int32_t*>(s->h_keyfirst.p) : zero_kf;
+        std::vector<int64_t> alt_off(size_t(n) + 1, 0);
+        std::vector<char> alt(size_t(256 * n + (1 << 16)));
+        int64_t used = -1;
+        for (int tries = 0; tries < 8; ++tries) {
+            used = cto_alt_info_batch_sites(s->pack, n, info, 0, static_cast<const int16_t*>(s->h_site_colvec.p), static_cast<const int32_t*>(s->h_sitefirst.p),
+                                            keycnt, keyfirst, alt.data(), alt.size(), alt_off.data());
+            if (used >= 0) break;
+            if (!strstr(cto_last_error(), "buffer too small")) break;
+            alt.resize(alt.size() * 4);
+        }
+        if (used < 0) { fail(cto_last_error()); return false; }
+        std::vector<char> centre(static_cast<size_t>(n));
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t at = int64_t(s->sites[size_t(i)]) - s->ref_start;
+            const char c = at >= 0 && at < int64_t(s->ref.size()) ? s->ref[size_t(at)] : 'N';
+            centre[size_t(i)] = c;
+            if (c != 'A' && c != 'C' && c != 'G' && c != 'T') info[i * 12 + 3] |= 1;      // predict.py:219-228: centre not in ACGT -> no row
+        }
+        std::vector<char> text(size_t(512 * std::max<int64_t>(n, 1) + 2 * used + 4096));
+        int64_t counts[4] = {0, 0, 0, 0};
+        int64_t tu = -1;
+        for (int tries = 0; tries < 6; ++tries) {
+            tu = cto_vcf_rows_batch(j.ctg_name, n, s->sites.data(), centre.data(), alt.data(), alt_off.data(), info, static_cast<const int32_t*>(s->h_decision.p),
+                                    static_cast<const double*>(s->h_qual.p), cfg->K, cfg->show_ref, cfg->qual_pass, text.data(), text.size(), counts);
+            if (tu != CTO_ENOMEM) break;
+            text.resize(text.size() * 4);
+        }
+        if (tu < 0) { fail(cto_last_error()); return false; }
+        if (counts[0] > 0) {              // the reference removes VCFs without records (call_variants.py:859-867)
+            FILE* f = fopen(j.vcf_path, "w");
+            if (!f) { fail(std::string("cannot write ") + j.vcf_path); return false; }
+            const size_t hl = strlen(cfg->vcf_header);
+            const bool ok = fwrite(cfg->vcf_header, 1, hl, f) == hl && fwrite(text.data(), 1, size_t(tu), f) == size_t(tu);
+            if (fclose(f) != 0 || !ok) { fail(std::string("short write to ") + j.vcf_path); return false; }
+        } else {
+            (void)unlink(j.vcf_path);
+        }
+        if (cfg->verbose) {
+            for (int64_t i = 0; i < counts[2]; ++i) puts("low tumor coverage");             // call_variants.py:328, one line per such site
+            if (counts[3]) {
+                const int32_t* dec = static_cast<const int32_t*>(s->h_decision.p);
+                for (int64_t i = 0; i < n; ++i)
+                    if (dec[i * 4 + 1])
+                        fprintf(stderr, "[WARNING] %s:%d a probability printed as 1.00000000 / 0.00000000 falls outside the likelihood bins (the "
+                                "reference raises IndexError here); %s\n", j.ctg_name, s->sites[size_t(i)],
+                                (dec[i * 4 + 1] & 2) ? "no posterior, site skipped" : "bin clamped");
+            }
+            fprintf(stderr, "[INFO] %s total processed positions: %lld\n", j.ctg_name, (long long)counts[1]);
+        }
+        rows += counts[0];
+        sites += counts[1];
+        low_cov += counts[2];
+        clamped += counts[3];
+        return true;
+    }
+};
+
+}  // namespace
+
+extern "C" int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs, int64_t n_jobs, void* stream, cto_run_stats* stats) {
+    CTO_REQUIRE(cfg && (jobs || n_jobs == 0) && cfg->aff && cfg->neg && cfg->d_lik && cfg->d_edges && cfg->ref_fa && cfg->vcf_header, CTO_EINVAL,
+                "cto_run_chunks: null argument");
+    CTO_REQUIRE(cfg->K == 4 || cfg->K == 6, CTO_EINVAL, "cto_run_chunks: K must be 4 or 6");
+    for (int64_t i = 0; i < n_jobs; ++i)
+        CTO_REQUIRE(jobs[i].ctg_name && jobs[i].bed_path && jobs[i].vcf_path && (jobs[i].mpileup_path || jobs[i].bam_path), CTO_EINVAL,
+                    "cto_run_chunks: job %lld is incomplete", (long long)i);
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (n_jobs == 0) return CTO_OK;
+    const int producers = std::max(1, cfg->producers), writers = std::max(1, cfg->writers);
+    const int depth = cfg->depth > 0 ? cfg->depth : producers + writers + 2;
+    Run run;
+    run.cfg = cfg;
+    run.jobs = jobs;
+    run.n_jobs = n_jobs;
+    {
+        std::string err;
+        CTO_REQUIRE(run.fasta.open(cfg->ref_fa, &err), CTO_EINVAL, "cto_run_chunks: %s", err.c_str());
+    }
+    int dev = 0;
+    CTO_HIP(hipGetDevice(&dev));
+    // slots (device + page-locked buffers, events) outlive the call: allocating and freeing ~100 MB of them per slot costs tens of
+    // milliseconds, which a short chunk list would pay on every call; cto_run_release() frees them
+    SlotReturn slots_back{&run.slots};
+    {
+        std::lock_guard<std::mutex> g(slot_cache_m());
+        auto& cache = slot_cache();
+        for (size_t i = 0; i < cache.size() && int(run.slots.size()) < depth;)
+            if (cache[i]->device == dev) {
+                run.slots.push_back(std::move(cache[i]));
+                cache.erase(cache.begin() + long(i));
+            } else {
+                ++i;
+            }
+    }
+    while (int(run.slots.size()) < depth) {
+        run.slots.emplace_back(new Slot());
+        run.slots.back()->device = dev;
+        CTO_HIP(hipEventCreateWithFlags(&run.slots.back()->uploaded, hipEventDisableTiming));
+        CTO_HIP(hipEventCreate(&run.slots.back()->begin));
+        CTO_HIP(hipEventCreate(&run.slots.back()->done));
+    }
+    for (auto& sl : run.slots) run.free_slots.push(sl.get());
+    hipStream_t main = static_cast<hipStream_t>(stream);
+    const double t_begin = now_s();
+    std::atomic<int> producers_left{producers};
+
+    std::vector<std::thread> threads;
+    for (int t = 0; t < producers; ++t)
+        threads.emplace_back([&run, &producers_left, dev] {
+            hipStream_t copy = nullptr;
+            if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) != hipSuccess) run.fail("producer: no HIP stream");
+            for (;;) {
+                if (run.failed) break;
+                const int64_t j = run.next_job.fetch_add(1);
+                if (j >= run.n_jobs) break;
+                Slot* s = nullptr;
+                if (!run.free_slots.pop(&s)) break;
+                s->job = j;
+                const double t0 = now_s();
+                const bool ok = copy && run.produce(s, copy);
+                { std::lock_guard<std::mutex> g(run.stat_m); run.produce_s += now_s() - t0; }
+                if (ok) run.to_launch.push(s);
+                else { ++run.chunks_done; run.free_slots.push(s); }     // nothing to call here (or an error: `failed` is set)
+            }
+            if (copy) { (void)hipStreamSynchronize(copy); (void)hipStreamDestroy(copy); }
+            if (--producers_left == 0) run.to_launch.close();
+        });
+    for (int t = 0; t < writers; ++t)
+        threads.emplace_back([&run, dev] {
+            (void)hipSetDevice(dev);
+            Slot* s = nullptr;
+            while (run.to_write.pop(&s)) {
+                const double t0 = now_s();
+                if (!run.failed) run.finish(s);
+                { std::lock_guard<std::mutex> g(run.stat_m); run.finish_s += now_s() - t0; }
+                ++run.chunks_done;
+                run.free_slots.push(s);
+            }
+        });
+    // ---- launcher: this thread ----
+    double launch_s = 0, wait_s = 0;
+    int rc = CTO_OK;
+    for (;;) {
+        Slot* s = nullptr;
+        const double t0 = now_s();
+        if (!run.to_launch.pop(&s)) break;
+        const double t1 = now_s();
+        wait_s += t1 - t0;
+        if (!run.failed) {
+            const int r = run.launch(s, main);
+            if (r != CTO_OK) { run.fail(cto_last_error()); rc = r; }
+        }
+        launch_s += now_s() - t1;
+        if (run.failed) { ++run.chunks_done; run.free_slots.push(s); }
+        else run.to_write.push(s);
+    }
+    run.to_write.close();
+    run.free_slots.close();
+    for (auto& th : threads) th.join();
+    (void)hipStreamSynchronize(main);
+    if (stats) {
+        stats->candidates = run.candidates;
+        stats->sites = run.sites;
+        stats->rows = run.rows;
+        stats->low_coverage = run.low_cov;
+        stats->clamped = run.clamped;
+        stats->seconds = now_s() - t_begin;
+        stats->produce_s = run.produce_s;
+        stats->pack_s = run.pack_s;
+        stats->upload_s = run.upload_s;
+        stats->device_s = run.device_s;
+        stats->launch_s = launch_s;
+        stats->launcher_wait_s = wait_s;
+        stats->finish_s = run.finish_s;
+    }
+    if (run.failed) {
+        set_error("cto_run_chunks: %s", run.first_error.c_str());
+        return rc != CTO_OK ? rc : CTO_EINVAL;
+    }
+    return CTO_OK;
+}
+
+extern "C" int cto_run_release(void) {
+    std::vector<std::unique_ptr<Slot>> drop;
+    {
+        std::lock_guard<std::mutex> g(slot_cache_m());
+        drop.swap(slot_cache());
+    }
+    int cur = 0;
+    CTO_HIP(hipGetDevice(&cur));
+    for (auto& sl : drop) {
+        CTO_HIP(hipSetDevice(sl->device));
+        sl.reset();
+    }
+    CTO_HIP(hipSetDevice(cur));
+    return CTO_OK;
+}

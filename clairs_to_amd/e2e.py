@@ -4,6 +4,7 @@ Engine.  Everything a real run pays is inside the timed region: reading the BED 
 BAM decoding, the pack upload over PCIe, the 12 kernels, the device-to-host copies, the alt_info strings, the VCF rows and the
 file writes.  Used by bench.py (`e2e` object of its JSON line; never its `value`) and tools/e2e_bench.py."""
 import os
+import resource
 import shutil
 import tempfile
 import time
@@ -40,36 +41,44 @@ def build_run(d, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, reg
         region_kb, os.path.getsize(run["bam_fn"]) / 1e6, len(run["chunks"]))
 
 
-def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4, bam_reader="native"):
+def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4, bam_reader="native", pipeline="python"):
     """the pipeline over a prepared run directory -> dict(sites_per_s, ...); best of `repeats` passes (the first one warms the page
     cache, the pinned buffers and the model workspaces)"""
-    from .call_chunks import default_producers, run_pipeline
+    from .call_chunks import default_producers, run_pipeline, run_pipeline_native
     producers = producers if producers else default_producers(kind == "bam")
     os.makedirs(out_dir, exist_ok=True)
     chunk_args = chunk_namespaces(run, out_dir, bam=(kind == "bam"), bam_reader=bam_reader)
     best, rows, best_stats = None, 0, {}
     for _ in range(max(1, repeats)):
         stats = {}
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
-        rows = run_pipeline(eng, chunk_args, producers=producers, writers=writers, stats=stats)
+        if pipeline == "native":
+            rows = run_pipeline_native(eng, chunk_args, producers=producers, writers=writers, stats=stats, verbose=False)
+        else:
+            rows = run_pipeline(eng, chunk_args, producers=producers, writers=writers, stats=stats)
         dt = time.perf_counter() - t0
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
         if best is None or dt < best:
             best, best_stats = dt, stats
+            host = dict(user_cpu_ms_per_chunk=round((ru1.ru_utime - ru0.ru_utime) * 1e3 / max(1, len(chunk_args)), 2),
+                        sys_cpu_ms_per_chunk=round((ru1.ru_stime - ru0.ru_stime) * 1e3 / max(1, len(chunk_args)), 2),
+                        minor_faults_per_chunk=int((ru1.ru_minflt - ru0.ru_minflt) / max(1, len(chunk_args))))
     per_chunk = {k[:-2] + "_ms_per_chunk": round(v * 1e3 / max(1, len(chunk_args)), 3) for k, v in best_stats.items() if k.endswith("_s")}
     return dict(sites_per_s=round(run["n_sites"] / best, 1), sites=int(run["n_sites"]), chunks=len(chunk_args), seconds=round(best, 4),
-                producers=producers, writers=writers, vcf_records=int(rows), stage_thread_time=per_chunk,
+                producers=producers, writers=writers, pipeline=pipeline, vcf_records=int(rows), stage_thread_time=per_chunk, host_process=host,
                 includes="disk reads, tokenise / BAM decode, PCIe both ways, kernels, alt_info + VCF rows (C), file writes")
 
 
 def measure(eng, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, region_kb=None, producers=None, writers=2, workdir=None,
-            repeats=4):
+            repeats=4, pipeline="python"):
     """build_run + time_run in a temporary directory"""
     d = tempfile.mkdtemp(prefix="cto_e2e_", dir=workdir)
     try:
         t0 = time.perf_counter()
         run, source = build_run(d, kind, n_chunks, sites_per_chunk, distinct, region_kb)
         prep_s = time.perf_counter() - t0
-        r = time_run(eng, run, kind, os.path.join(d, "vcf_output"), producers, writers, repeats)
+        r = time_run(eng, run, kind, os.path.join(d, "vcf_output"), producers, writers, repeats, pipeline=pipeline)
         r.update(source=source, input_synthesis_s=round(prep_s, 1))
         return r
     finally:

@@ -296,6 +296,53 @@ int64_t cto_vcf_rows_batch(const char* chrom, int64_t n, const int32_t* pos, con
 int64_t cto_bed_centres(const char* text, size_t len, const char* ctg, int32_t* out, int64_t cap, int64_t* span, int* has_types);
 
 /* ------------------------------------------------------------------------------------------------
+ * All candidate chunks of a run, files in, files out: what run_clairs_to:1228-1308 / 1562-1647 does per chunk with four
+ * commands (create_tensor_pileup_calling x 2, predict --pileup, call_variants) as ONE call for the whole chunk list -
+ * producer threads (BED -> centres, reference slice, column pack, upload on their own streams), the calling thread launching
+ * featurisation + both networks + epilogue on `stream`, writer threads (alt_info strings, VCF records, p_<chunk>.vcf).
+ * Plain text inputs only (no .gz).  A chunk without records leaves no file (call_variants.py:859-867).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct cto_chunk_job {
+    const char* ctg_name;       /* --ctg_name                                                                  */
+    const char* bed_path;       /* --candidates_bed_regions: the chunk's candidate BED                          */
+    const char* mpileup_path;   /* `samtools mpileup --min-BQ 0 ...` text of the chunk, or NULL: read bam_path  */
+    const char* bam_path;       /* --tumor_bam_fn (+ .bai), through cto_pack_from_bam                           */
+    const char* vcf_path;       /* --call_fn                                                                    */
+} cto_chunk_job;
+typedef struct cto_run_cfg {
+    cto_model*    aff;          /* CvT / CvT_Indel                                                              */
+    cto_model*    neg;          /* BiGRU_NACGT / BiGRU_NACGT_Indel                                              */
+    const double* d_lik;        /* dev, as cto_posterior takes them                                             */
+    const double* d_edges;
+    int    K;                   /* 4 or 6                                                                       */
+    int    min_bq;              /* AFF pass gate (--min_bq / the platform's default)                            */
+    int    min_rescale_cov;     /* --min_rescale_cov (50); <= 0: no rescale                                     */
+    int    max_indel_length;    /* shared/param.py max_indel_length (60)                                        */
+    int    max_depth;           /* BAM input: --max-depth of the pileup (8000)                                  */
+    int    neg_reads_aff;       /* ilmn: the NEG network reads the AFF tensors (run_clairs_to:1248-1252)        */
+    int    show_ref;            /* --show_ref                                                                   */
+    int    verbose;             /* the reference's per-chunk console lines (stdout / stderr)                    */
+    double qual_pass;           /* --qual (< 0: no threshold)                                                   */
+    const char* ref_fa;         /* --ref_fn, uncompressed, with its .fai                                        */
+    const char* vcf_header;     /* everything before the first record, incl. the #CHROM line                    */
+    int    producers, writers;  /* threads (>= 1)                                                               */
+    int    depth;               /* chunks in flight (0: producers + writers + 2); each holds a pack on both sides */
+} cto_run_cfg;
+typedef struct cto_run_stats {
+    int64_t candidates;                                /* candidate positions read from the BED chunks           */
+    int64_t sites, rows, low_coverage, clamped;        /* sums of cto_vcf_rows_batch's counts                    */
+    double  seconds;                                   /* wall clock of the call                                */
+    double  produce_s, finish_s;                       /* thread-seconds summed over the producer / writer threads */
+    double  launch_s, launcher_wait_s;                 /* the calling thread: launching, waiting for a producer */
+    double  pack_s, upload_s;                          /* parts of produce_s: tokenising / BAM decoding, host-to-device copies */
+    double  device_s;                                  /* HIP-event time from a chunk's first kernel to its last copy, summed    */
+} cto_run_stats;
+int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs, int64_t n_jobs, void* stream, cto_run_stats* stats);
+/* cto_run_chunks keeps its per-chunk buffers (device, page-locked host, events) for the next call on the same device; this
+ * frees them.  Not needed before process exit. */
+int cto_run_release(void);
+
+/* ------------------------------------------------------------------------------------------------
  * Long-read post-calling filters (src/haplotype_filtering.py:344-707): the read-level evidence of
  * every call of ONE mpileup job, from the nine-column text of
  *   samtools mpileup --min-MQ q --min-BQ q --excl-flags 2316 [-l bed] -r ctg:lo-hi --output-MQ --output-QNAME --output-extra HP

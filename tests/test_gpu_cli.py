@@ -303,6 +303,98 @@ def test_call_chunks_matches_single_call(tmp_path, world):
     assert 0 < len(rec(final)) <= len(rec(merged))      # postprocess drops PASS records under the platform's AF cut-off
 
 
+@pytest.mark.parametrize("source", ["bam", "text"])
+@pytest.mark.parametrize("mode,aff_cls,neg_cls", [("snv", "CvT", "BiGRU_NACGT"), ("indel", "CvT_Indel", "BiGRU_NACGT_Indel")])
+def test_native_pipeline_writes_the_same_files(tmp_path, source, mode, aff_cls, neg_cls):
+    """cto_run_chunks (the chunk loop in C: csrc/pipeline.hip) against call_chunks.run_pipeline on the same chunk list - five
+    chunks, one of them of another contig (no candidates, no file), one whose pileup is empty: same files, byte for byte."""
+    from argparse import Namespace
+    from bamutil import mpileup_rows
+    import pickle
+    from clairs_to_amd.call_chunks import native_eligible, run_pipeline, run_pipeline_native
+    from clairs_to_amd.pileup_call import make_engine
+    from clairs_to_amd.synth import likelihood_table
+    K = 4 if mode == "snv" else 6
+    sc = _bam_scenario(tmp_path)
+    reads = pickle.load(open(tmp_path / "reads.pkl", "rb"))
+    paths = _pickle_models(tmp_path, aff_cls, neg_cls, K)
+    lik = tmp_path / "lik.txt"
+    np.savetxt(lik, likelihood_table(K, seed=11), fmt="%.17g")
+    sites = sc["sites"]
+    parts = [sites[i * len(sites) // 3:(i + 1) * len(sites) // 3] for i in range(3)]
+    parts.append([5950, 5990])               # beyond the last read's end for most reads: sparse pileup
+    beds, mps = [], []
+    for i, part in enumerate(parts):
+        fn = tmp_path / ("chr1.%d_5_snv" % (i + 1))
+        fn.write_text("".join("chr1\t%d\t%d\n" % (x - 17, x + 17) for x in part))
+        beds.append(str(fn))
+        mp = tmp_path / (fn.name + ".mpileup")
+        mp.write_text(mpileup_rows(reads, 0, "chr1", max(1, min(part) - 16 - 33), max(part) + 18 + 33, bed=[(x - 17, x + 17) for x in part]))
+        mps.append(str(mp))
+    other = tmp_path / "chr2.1_1_snv"          # a chunk of a contig the job's --ctg_name does not match: no candidates
+    other.write_text("chr2\t100\t134\n")
+    beds.append(str(other))
+    empty = tmp_path / "chr2.1_1_snv.mpileup"
+    empty.write_text("")
+    mps.append(str(empty))
+
+    def chunk_args(out_dir):
+        os.makedirs(out_dir, exist_ok=True)
+        out = []
+        for bed, mp in zip(beds, mps):
+            out.append(Namespace(platform="ont", ref_fn=sc["fa"], ctg_name="chr1", samtools="samtools", bam_reader="native",
+                                 tumor_bam_fn=sc["bam"], mpileup_fn=mp if source == "text" else None, min_bq=None, max_depth=None,
+                                 max_indel_length=None, candidates_bed_regions=bed, chkpnt_fn_acgt=paths["model_acgt"],
+                                 chkpnt_fn_nacgt=paths["model_nacgt"], min_rescale_cov=50, disable_indel_calling=(K == 4),
+                                 likelihood_matrix_data=str(lik), call_fn=os.path.join(out_dir, "p_%s.vcf" % os.path.basename(bed)),
+                                 predict_fn=None, sample_name="TUMOR", show_ref=True, qual=2, pileup=True))
+        return out
+    eng = make_engine(chunk_args(str(tmp_path / "x"))[0], "cuda:0")
+    a_py, a_nat = chunk_args(str(tmp_path / "py")), chunk_args(str(tmp_path / "nat"))
+    assert native_eligible(a_nat)
+    st_py, st_nat = {}, {}
+    n_py = run_pipeline(eng, a_py, producers=2, writers=2, stats=st_py)
+    n_nat = run_pipeline_native(eng, a_nat, producers=3, writers=2, stats=st_nat, verbose=False)
+    assert n_py == n_nat and n_py > 50
+    assert st_nat["sites"] == st_py["sites"] == sum(len(p) for p in parts)
+    names = sorted(os.listdir(tmp_path / "py"))
+    assert names == sorted(os.listdir(tmp_path / "nat")) and 3 <= len(names) <= 4
+    for fn in names:
+        assert open(tmp_path / "py" / fn, "rb").read() == open(tmp_path / "nat" / fn, "rb").read(), fn
+    # again on the same handle (slots, streams and buffers are per call), with one producer and a pipeline depth of one
+    from clairs_to_amd._lib import lib
+    assert lib.cto_run_release() == 0           # the buffers kept from the first call are dropped; the next call allocates its own
+    assert run_pipeline_native(eng, a_nat, producers=1, writers=1, depth=1, verbose=False) == n_py
+    for fn in names:
+        assert open(tmp_path / "py" / fn, "rb").read() == open(tmp_path / "nat" / fn, "rb").read(), fn
+
+
+def test_native_pipeline_reports_errors(tmp_path):
+    """a missing pileup file, a contig the reference index does not hold: CtoError naming the cause, no hang, no partial state"""
+    from argparse import Namespace
+    from clairs_to_amd._lib import CtoError
+    from clairs_to_amd.call_chunks import run_pipeline_native
+    from clairs_to_amd.pileup_call import make_engine
+    from clairs_to_amd.synth import likelihood_table
+    sc = _bam_scenario(tmp_path)
+    paths = _pickle_models(tmp_path, "CvT", "BiGRU_NACGT", 4)
+    lik = tmp_path / "lik.txt"
+    np.savetxt(lik, likelihood_table(4, seed=11), fmt="%.17g")
+    base = dict(platform="ont", ref_fn=sc["fa"], ctg_name="chr1", samtools="samtools", bam_reader="native", tumor_bam_fn=sc["bam"],
+                mpileup_fn=None, min_bq=None, max_depth=None, max_indel_length=None, candidates_bed_regions=sc["bed"],
+                chkpnt_fn_acgt=paths["model_acgt"], chkpnt_fn_nacgt=paths["model_nacgt"], min_rescale_cov=50, disable_indel_calling=True,
+                likelihood_matrix_data=str(lik), call_fn=str(tmp_path / "o" / "p.vcf"), predict_fn=None, sample_name="S", show_ref=False,
+                qual=0, pileup=True)
+    eng = make_engine(Namespace(**base), "cuda:0")
+    with pytest.raises(CtoError, match="cannot open"):
+        run_pipeline_native(eng, [Namespace(**dict(base, mpileup_fn=str(tmp_path / "absent.mpileup")))] * 6, producers=3, verbose=False)
+    bed7 = tmp_path / "chr7.bed"
+    bed7.write_text("chr7\t100\t134\n")
+    with pytest.raises(CtoError, match="chr7"):
+        run_pipeline_native(eng, [Namespace(**dict(base, ctg_name="chr7", candidates_bed_regions=str(bed7)))], producers=2, verbose=False)
+    assert run_pipeline_native(eng, [Namespace(**base)], producers=2, verbose=False) > 10      # and the engine is still usable
+
+
 def test_extract_cli_writes_reference_bed_chunks(tmp_path):
     """extract_candidates_calling at its file seam: the BED chunk files (x-17 .. x+17 windows) and the list file, from the
     golden fixture's pileup, must name exactly the candidates of the reference's own files; the native BAM reader and the

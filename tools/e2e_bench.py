@@ -1,6 +1,6 @@
 """File-to-file throughput (chunk files + mpileup text or BAM -> p_<chunk>.vcf) through the call_chunks pipeline, swept over
 the number of producer threads; one JSON line per measurement (the logs kept under profiles/ come from this).
-python tools/e2e_bench.py [--kind text,bam] [--chunks N] [--sites N] [--producers 2,4,8,16] [--writers 2] [--pack-threads T]"""
+python tools/e2e_bench.py [--kind text,bam] [--chunks N] [--sites N] [--producers 2,4,8,16] [--writers 2] [--pack-threads T] [--pipeline python,native]"""
 import argparse
 import json
 import os
@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--producers", default="2,4,8,16")
     ap.add_argument("--writers", default="2")
     ap.add_argument("--bam-reader", default="native", help="native (host inflate) or gpu (device inflate), comma separated")
+    ap.add_argument("--pipeline", default="python", help="python (call_chunks.run_pipeline) and / or native (cto_run_chunks), comma separated")
     ap.add_argument("--pack-threads", default=None, help="CTO_PACK_THREADS values for the C producers, comma separated (default: their own, <= 32)")
     a = ap.parse_args()
     import torch
@@ -42,8 +43,11 @@ def main():
                     os.environ["CTO_PACK_THREADS"] = pt
                 for w in [int(x) for x in a.writers.split(",")]:
                   for br in (a.bam_reader.split(",") if kind == "bam" else ["-"]):
+                   for pl in a.pipeline.split(","):
+                    if pl == "native" and br == "gpu":
+                        continue
                     for p in [int(x) for x in a.producers.split(",")]:
-                        r = time_run(eng, run, kind, os.path.join(d, "vcf_%s" % kind), producers=p, writers=w, bam_reader=br)
+                        r = time_run(eng, run, kind, os.path.join(d, "vcf_%s" % kind), producers=p, writers=w, bam_reader=br, pipeline=pl)
                         r.update(kind=kind, pack_threads=pt or "auto", bam_reader=br)
                         r.pop("includes")
                         print(json.dumps(r), flush=True)
