@@ -183,7 +183,8 @@ int append_column_packed(cto_pack* p, ColumnScratch& sc, int64_t pos, int64_t ri
 }
 
 // Concatenates per-thread packs of consecutive position ranges (offsets re-based); nullptr + *err when they overlap.
-std::unique_ptr<cto_pack> merge_parts(std::vector<std::unique_ptr<cto_pack>>& parts, std::string* err) {
+std::unique_ptr<cto_pack> merge_parts(std::vector<std::unique_ptr<cto_pack>>& parts, std::string* err, uint32_t* ext_entries,
+                                      size_t ext_cap) {
     if (parts.size() > 2) {
         // Parallel form: the destination arrays are sized once (the entry array without a zero fill) and every part copies
         // itself to its offsets on its own thread - the serial concatenation below was half of a multi-threaded call's time.
@@ -202,7 +203,14 @@ std::unique_ptr<cto_pack> merge_parts(std::vector<std::unique_ptr<cto_pack>>& pa
             s0[t + 1] = s0[t] + int64_t(q.key_str.size());
         }
         std::unique_ptr<cto_pack> p(new cto_pack());
-        p->entries.resize(size_t(e0[n]));
+        uint32_t* ent_dst;
+        if (ext_entries && size_t(e0[n]) <= ext_cap) {
+            p->ext_entries = ent_dst = ext_entries;
+            p->ext_n = size_t(e0[n]);
+        } else {
+            p->entries.resize(size_t(e0[n]));
+            ent_dst = p->entries.data();
+        }
         p->col_pos.resize(size_t(c0[n]));
         p->col_ref.resize(size_t(c0[n]));
         p->col_off.resize(size_t(c0[n]) + 1);
@@ -216,7 +224,7 @@ std::unique_ptr<cto_pack> merge_parts(std::vector<std::unique_ptr<cto_pack>>& pa
         p->key_str_off[0] = 0;
         auto copy_part = [&](size_t t) {
             const cto_pack& q = *parts[t];
-            if (!q.entries.empty()) memcpy(p->entries.data() + e0[t], q.entries.data(), q.entries.size() * sizeof(uint32_t));
+            if (!q.entries.empty()) memcpy(ent_dst + e0[t], q.entries.data(), q.entries.size() * sizeof(uint32_t));
             if (!q.col_pos.empty()) {
                 memcpy(p->col_pos.data() + c0[t], q.col_pos.data(), q.col_pos.size() * sizeof(int32_t));
                 memcpy(p->col_ref.data() + c0[t], q.col_ref.data(), q.col_ref.size());
@@ -257,6 +265,12 @@ std::unique_ptr<cto_pack> merge_parts(std::vector<std::unique_ptr<cto_pack>>& pa
         for (size_t i = 1; i < q.key_str_off.size(); ++i) p->key_str_off.push_back(q.key_str_off[i] + s0);
         p->key_str += q.key_str;
         parts[t].reset();
+    }
+    if (ext_entries && p->entries.size() <= ext_cap) {
+        if (!p->entries.empty()) memcpy(ext_entries, p->entries.data(), p->entries.size() * sizeof(uint32_t));
+        p->ext_entries = ext_entries;
+        p->ext_n = p->entries.size();
+        decltype(p->entries)().swap(p->entries);
     }
     return p;
 }
@@ -505,6 +519,11 @@ int parse_rows(const char* text, size_t len, const char* ref_seq, int64_t ref_st
 
 extern "C" int cto_pack_from_mpileup(const char* text, size_t len, const char* ref_seq, int64_t ref_start,
                                       size_t ref_len, int max_indel_length, cto_pack** out) {
+    return cto::pack_from_mpileup_impl(text, len, ref_seq, ref_start, ref_len, max_indel_length, nullptr, 0, out);
+}
+
+int cto::pack_from_mpileup_impl(const char* text, size_t len, const char* ref_seq, int64_t ref_start, size_t ref_len, int max_indel_length,
+                                uint32_t* ext_entries, size_t ext_cap, cto_pack** out) {
     CTO_REQUIRE(text && ref_seq && out, CTO_EINVAL, "cto_pack_from_mpileup: null argument");
     // rows are independent: split the text at line boundaries and tokenise the pieces on several host threads
     unsigned nt = std::thread::hardware_concurrency();
@@ -540,7 +559,7 @@ extern "C" int cto_pack_from_mpileup(const char* text, size_t len, const char* r
     std::unique_ptr<cto_pack> p;
     {
         std::string merr;
-        p = cto::merge_parts(parts, &merr);
+        p = cto::merge_parts(parts, &merr, ext_entries, ext_cap);
         if (!p) { cto::set_error("%s", merr.c_str()); return CTO_EINVAL; }
     }
     if (timing)
@@ -588,13 +607,13 @@ extern "C" int cto_pack_from_arrays(const cto_pack_view* v, const int64_t* key_s
 extern "C" int cto_pack_view_of(const cto_pack* p, cto_pack_view* v) {
     CTO_REQUIRE(p && v, CTO_EINVAL, "cto_pack_view_of: null argument");
     v->n_cols = int64_t(p->col_pos.size());
-    v->n_entries = int64_t(p->entries.size());
+    v->n_entries = int64_t(p->ext_entries ? p->ext_n : p->entries.size());
     v->n_keys = int64_t(p->key_meta.size());
     v->col_pos = p->col_pos.data();
     v->col_ref = p->col_ref.data();
     v->col_off = p->col_off.data();
     v->key_off = p->key_off.data();
-    v->entries = p->entries.data();
+    v->entries = p->ext_entries ? p->ext_entries : p->entries.data();
     v->key_meta = p->key_meta.data();
     v->key_group = p->key_group.data();
     return CTO_OK;

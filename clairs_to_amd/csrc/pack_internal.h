@@ -27,6 +27,10 @@ struct cto_pack {
     std::vector<int64_t> col_off;   // n_cols + 1
     std::vector<int32_t> key_off;   // n_cols + 1
     std::vector<uint32_t, default_init_alloc<uint32_t>> entries;
+    // Entry array in memory the caller owns (the chunk pipeline's page-locked staging buffer): the merge of the tokeniser's
+    // per-thread parts writes there directly and `entries` stays empty.  The caller keeps it alive as long as the pack.
+    uint32_t* ext_entries = nullptr;
+    size_t ext_n = 0;
     std::vector<uint8_t> key_meta;
     std::vector<int32_t> key_group;
     std::vector<int64_t> key_str_off;  // n_keys + 1
@@ -96,6 +100,10 @@ inline uint32_t pack_entry(int code, int bq, int mq) { return uint32_t(code) | (
 int append_column_packed(cto_pack* p, ColumnScratch& sc, int64_t pos, int64_t ri, const char* ref_seq, size_t ref_len,
                          int max_indel_length, const uint32_t* ents, int n, const IndelAt* indels, int n_indel, std::string* err);
 
-std::unique_ptr<cto_pack> merge_parts(std::vector<std::unique_ptr<cto_pack>>& parts, std::string* err);
+std::unique_ptr<cto_pack> merge_parts(std::vector<std::unique_ptr<cto_pack>>& parts, std::string* err, uint32_t* ext_entries = nullptr,
+                                      size_t ext_cap = 0);
+// cto_pack_from_mpileup with the entry array placed in ext_entries[0 .. ext_cap) when it fits (see cto_pack::ext_entries)
+int pack_from_mpileup_impl(const char* text, size_t len, const char* ref_seq, int64_t ref_start, size_t ref_len, int max_indel_length,
+                           uint32_t* ext_entries, size_t ext_cap, cto_pack** out);
 
 }  // namespace cto

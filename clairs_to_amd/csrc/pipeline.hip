@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "common.h"
+#include "pack_internal.h"
 
 using namespace cto;
 
@@ -61,6 +62,19 @@ struct PinBuf {                          // page-locked host memory that only gr
         cap = 0;
         const size_t want = n + n / 4 + 256;
         CTO_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+        return CTO_OK;
+    }
+    int grow_keeping(size_t n, size_t keep) {              // ensure(n) that carries the first `keep` bytes over
+        if (n <= cap) return CTO_OK;
+        void* q = nullptr;
+        const size_t want = n + n / 4 + 256;
+        CTO_HIP(hipHostMalloc(&q, want, hipHostMallocDefault));
+        if (p) {
+            if (keep) memcpy(q, p, keep);
+            CTO_HIP(hipHostFree(p));
+        }
+        p = q;
         cap = want;
         return CTO_OK;
     }
@@ -306,7 +320,11 @@ struct Run {
         if (j.mpileup_path) {
             Mapped txt;
             if (!txt.open(j.mpileup_path, &err)) { fail(err); return false; }
-            rc = cto_pack_from_mpileup(txt.p ? txt.p : "", txt.n, s->ref.data(), s->ref_start, s->ref.size(), cfg->max_indel_length, &s->pack);
+            // the tokeniser's threads merge their entries straight into the staging buffer (a read-base is >= 3 characters of text)
+            const size_t ecap = txt.n / 3 + 4096;
+            if (s->stage.ensure(ecap * 4 + txt.n / 4 + (size_t(1) << 20)) != CTO_OK) { fail(cto_last_error()); return false; }
+            rc = pack_from_mpileup_impl(txt.p ? txt.p : "", txt.n, s->ref.data(), s->ref_start, s->ref.size(), cfg->max_indel_length,
+                                        static_cast<uint32_t*>(s->stage.p), ecap, &s->pack);
         } else {
             std::vector<int64_t> iv;
             bed_intervals(bed.p ? bed.p : "", bed.n, ctg, &iv);
@@ -323,22 +341,23 @@ struct Run {
         // calls, 16 producers 6.6 ms, and the whole pipeline levelled off at ~8.5 GB/s of uploads = 1.4-1.6 M sites/s.)
         const cto_pack_view& h = s->hv;
         const size_t nc = size_t(h.n_cols), ne = size_t(h.n_entries), nk = size_t(h.n_keys), ns = s->sites.size();
-        const void* src[8] = {h.col_pos, h.col_ref, h.col_off, h.key_off, h.entries, h.key_meta, h.key_group, s->sites.data()};
-        const size_t bytes[8] = {nc * 4, nc, (nc + 1) * 8, (nc + 1) * 4, ne * 4, nk, nk * 4, ns * 4};
+        const void* src[8] = {h.entries, h.col_pos, h.col_ref, h.col_off, h.key_off, h.key_meta, h.key_group, s->sites.data()};
+        const size_t bytes[8] = {ne * 4, nc * 4, nc, (nc + 1) * 8, (nc + 1) * 4, nk, nk * 4, ns * 4};
         size_t off[8], total = 0;
         for (int i = 0; i < 8; ++i) { off[i] = total; total += (bytes[i] + 255) / 256 * 256 + 256; }
-        if (s->stage.ensure(total) != CTO_OK || s->pack_dev.ensure(total) != CTO_OK) { fail(cto_last_error()); return false; }
+        const bool in_place = h.entries == s->stage.p && ne > 0;          // entries first: already there for the text producer
+        if (s->stage.grow_keeping(total, in_place ? bytes[0] : 0) != CTO_OK || s->pack_dev.ensure(total) != CTO_OK) { fail(cto_last_error()); return false; }
         char* hs = static_cast<char*>(s->stage.p);
-        for (int i = 0; i < 8; ++i)
+        for (int i = in_place ? 1 : 0; i < 8; ++i)
             if (bytes[i]) memcpy(hs + off[i], src[i], bytes[i]);
         if (hipMemcpyAsync(s->pack_dev.p, hs, total, hipMemcpyHostToDevice, stream) != hipSuccess) { fail("hipMemcpyAsync failed"); return false; }
         const char* d = static_cast<const char*>(s->pack_dev.p);
         s->dv = h;
-        s->dv.col_pos = reinterpret_cast<const int32_t*>(d + off[0]);
-        s->dv.col_ref = reinterpret_cast<const uint8_t*>(d + off[1]);
-        s->dv.col_off = reinterpret_cast<const int64_t*>(d + off[2]);
-        s->dv.key_off = reinterpret_cast<const int32_t*>(d + off[3]);
-        s->dv.entries = reinterpret_cast<const uint32_t*>(d + off[4]);
+        s->dv.entries = reinterpret_cast<const uint32_t*>(d + off[0]);
+        s->dv.col_pos = reinterpret_cast<const int32_t*>(d + off[1]);
+        s->dv.col_ref = reinterpret_cast<const uint8_t*>(d + off[2]);
+        s->dv.col_off = reinterpret_cast<const int64_t*>(d + off[3]);
+        s->dv.key_off = reinterpret_cast<const int32_t*>(d + off[4]);
         s->dv.key_meta = reinterpret_cast<const uint8_t*>(d + off[5]);
         s->dv.key_group = reinterpret_cast<const int32_t*>(d + off[6]);
         s->d_site_pos = reinterpret_cast<const int32_t*>(d + off[7]);

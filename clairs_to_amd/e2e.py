@@ -1,6 +1,6 @@
 """File-to-file throughput of the hot path: candidate chunk files + pileup source (mpileup text or BAM) -> p_<chunk>.vcf,
-through the same pipeline `call_chunks` runs (producers -> launcher -> writers, call_chunks.run_pipeline), with a resident
-Engine.  Everything a real run pays is inside the timed region: reading the BED / FASTA / text or BAM from disk, tokenising or
+through the same pipeline `call_chunks` runs (producers -> launcher -> writers: cto_run_chunks in C, or call_chunks.run_pipeline
+on Python thread pools for the inputs the C loop does not read itself), with a resident Engine.  Everything a real run pays is inside the timed region: reading the BED / FASTA / text or BAM from disk, tokenising or
 BAM decoding, the pack upload over PCIe, the 12 kernels, the device-to-host copies, the alt_info strings, the VCF rows and the
 file writes.  Used by bench.py (`e2e` object of its JSON line; never its `value`) and tools/e2e_bench.py."""
 import os
@@ -98,7 +98,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--chunks", type=int, default=12)
     ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--bam-chunks", type=int, default=None, help="chunk files of the BAM leg (default: a third of --chunks)")
     ap.add_argument("--kinds", default="text,bam")
+    ap.add_argument("--pipeline", default="native", choices=["native", "python"],
+                    help="cto_run_chunks (csrc/pipeline.hip) or call_chunks.run_pipeline; same files either way")
     a = ap.parse_args()
     dev = torch.device("cuda", torch.cuda.current_device())
     models = synthetic_models(4, seed=0)
@@ -106,8 +109,9 @@ def main():
     eng = Engine(models["aff"], models["neg"], lik, edges, min_bq=20, device=dev)
     out = {"host_cores_usable": usable_cores(), "host_cores_visible": os.cpu_count()}
     for kind in a.kinds.split(","):
-        n = a.chunks if kind == "text" else max(2, a.chunks // 3)
-        out["mpileup_text_to_vcf" if kind == "text" else "bam_to_vcf"] = measure(eng, kind=kind, n_chunks=n, sites_per_chunk=a.batch)
+        n = a.chunks if kind == "text" else (a.bam_chunks or max(2, a.chunks // 3))
+        out["mpileup_text_to_vcf" if kind == "text" else "bam_to_vcf"] = measure(eng, kind=kind, n_chunks=n, sites_per_chunk=a.batch,
+                                                                                 pipeline=a.pipeline)
     print(json.dumps(out))
 
 
