@@ -55,11 +55,23 @@ def usable_cores():
     return n
 
 
-def default_producers(native_bam):
+def default_producers(native_bam, pipeline="python"):
     """pack-producer threads per rank: a quarter of the usable cores for mpileup text (the tokeniser saturates memory bandwidth early),
-    half of them for the native BAM reader (inflate-bound, and its per-call serial parts - index, header, merge - want more calls in
-    flight: 8 producers x 8 threads gave 280 k sites/s on 16 cores where 4 x 8 gave 218 k)"""
+    half of them for the native BAM reader on the Python pipeline (inflate-bound, and its per-call serial parts - index, header,
+    merge - want more calls in flight: 8 producers x 8 threads gave 280 k sites/s on 16 cores where 4 x 8 gave 218 k).  The C
+    pipeline runs one BAM producer per usable core with two decoding threads each (pack_threads()): a call split over 8 threads
+    decodes the long reads that straddle its 7 inner boundaries twice - 320 ms of CPU per 1 Mb x 50x chunk against 243 ms
+    unsplit - and 16 x 2 measured 264 k sites/s where 8 x 8 gave 205 k."""
+    if native_bam and pipeline == "native":
+        return max(1, min(32, usable_cores()))
     return max(1, min(16, usable_cores() // (2 if native_bam else 4)))
+
+
+def pack_threads(native_bam, pipeline="python"):
+    """CTO_PACK_THREADS for the C producers (they split one chunk over up to 32 threads of their own): with several producers running
+    side by side that oversubscribes a small host (16 usable cores on the bench box: 4 producers x 8 threads measured 870-960 k
+    sites/s from text, 4 x 32 threads 660-715 k), so each call gets half of the usable cores - two for BAM chunks on the C pipeline"""
+    return 2 if (native_bam and pipeline == "native") else max(2, usable_cores() // 2)
 
 
 def run_pipeline(eng, chunk_args, producers=4, writers=2, depth=None, stats=None):
@@ -69,11 +81,9 @@ def run_pipeline(eng, chunk_args, producers=4, writers=2, depth=None, stats=None
     depth = depth if depth is not None else producers + 2
     n_rows = 0
     local = threading.local()
-    # The C producers split one chunk over up to 32 threads of their own (CTO_PACK_THREADS); with several producers running
-    # side by side that oversubscribes a small host (16 usable cores on the bench box: 4 producers x 8 threads measured
-    # 870-960 k sites/s from text, 4 x 32 threads 660-715 k), so the pool hands each call half of the usable cores.
-    if "CTO_PACK_THREADS" not in os.environ:
-        os.environ["CTO_PACK_THREADS"] = str(max(2, usable_cores() // 2))
+    own_threads = "CTO_PACK_THREADS" not in os.environ
+    if own_threads:
+        os.environ["CTO_PACK_THREADS"] = str(pack_threads(False))
 
     import time
 
@@ -131,6 +141,8 @@ def run_pipeline(eng, chunk_args, producers=4, writers=2, depth=None, stats=None
                 n_rows += writing.popleft().result()
         while writing:
             n_rows += writing.popleft().result()
+    if own_threads:
+        os.environ.pop("CTO_PACK_THREADS", None)
     return n_rows
 
 
@@ -158,9 +170,10 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
     chunk_args = list(chunk_args)
     if not chunk_args:
         return 0
-    if "CTO_PACK_THREADS" not in os.environ:
-        os.environ["CTO_PACK_THREADS"] = str(max(2, usable_cores() // 2))
     a0 = chunk_args[0]
+    own_threads = "CTO_PACK_THREADS" not in os.environ
+    if own_threads:
+        os.environ["CTO_PACK_THREADS"] = str(pack_threads(not getattr(a0, "mpileup_fn", None), "native"))
     jobs = (ChunkJob * len(chunk_args))()
     for j, a in zip(jobs, chunk_args):
         os.makedirs(os.path.dirname(os.path.abspath(a.call_fn)), exist_ok=True)
@@ -182,6 +195,8 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
     st = RunStats()
     with torch.cuda.device(eng.device):
         rc = lib.cto_run_chunks(C.byref(cfg), jobs, len(chunk_args), C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(st))
+    if own_threads:
+        del os.environ["CTO_PACK_THREADS"]
     sys.stdout.flush()
     check(rc)
     if stats is not None:
@@ -227,11 +242,13 @@ def call_chunks(args):
         for a in mine:                       # a chunk VCF left by an earlier run must not survive into this run's merge
             if os.path.exists(a.call_fn):
                 os.remove(a.call_fn)
-        producers = args.producers if getattr(args, "producers", None) else default_producers(getattr(args, "bam_reader", None) in ("native", "gpu"))
         how = getattr(args, "pipeline", None) or "auto"
         if how == "native" and not native_eligible(mine):
             sys.exit("[ERROR] --pipeline native reads plain files itself: needs --mpileup_dir or --bam_reader native, and no .gz inputs")
-        run = run_pipeline_native if how == "native" or (how == "auto" and native_eligible(mine)) else run_pipeline
+        native = how == "native" or (how == "auto" and native_eligible(mine))
+        run = run_pipeline_native if native else run_pipeline
+        from_bam = not getattr(args, "mpileup_dir", None) and getattr(args, "bam_reader", None) in ("native", "gpu")
+        producers = args.producers if getattr(args, "producers", None) else default_producers(from_bam, "native" if native else "python")
         n_rows = run(eng, mine, producers=producers, writers=getattr(args, "writers", None) or 2)
     except (Exception, SystemExit) as e:     # a bad reference, a corrupt BAM, CTO_EUNSUPPORTED ...: report, do not leave the others waiting
         failure = "%s: %s" % (type(e).__name__, e)

@@ -45,7 +45,7 @@ def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4, bam_
     """the pipeline over a prepared run directory -> dict(sites_per_s, ...); best of `repeats` passes (the first one warms the page
     cache, the pinned buffers and the model workspaces)"""
     from .call_chunks import default_producers, run_pipeline, run_pipeline_native
-    producers = producers if producers else default_producers(kind == "bam")
+    producers = producers if producers else default_producers(kind == "bam", pipeline)
     os.makedirs(out_dir, exist_ok=True)
     chunk_args = chunk_namespaces(run, out_dir, bam=(kind == "bam"), bam_reader=bam_reader)
     best, rows, best_stats = None, 0, {}
