@@ -14,9 +14,13 @@ Inside a rank the chunks flow through a three-stage pipeline, several chunks in 
     launcher (this thread)    wait for the upload event, 12 kernel launches, asynchronous copies of the per-site outputs into
                               re-used page-locked buffers                                               pileup_call.launch_chunk
     writers (thread pool)     alt_info strings + every VCF record in two C calls, file write            pileup_call.finish_chunk
-The GPU needs ~2 ms per 4 096-site chunk; one producer delivers a chunk in 7 ms (mpileup text) to 27 ms (BAM), so the rate is
-set by how many producers the host can run - `--producers` (default: a quarter of the usable cores, half with the native BAM reader,
-at most 16).
+The GPU needs ~2 ms per 4 096-site chunk; one producer delivers a chunk in 5 ms (mpileup text, 8 tokeniser threads) to 100 ms
+(BAM, 2 decoding threads), so the rate is set by how many producers the host can run - `--producers` (default_producers()).
+
+The same three stages exist in C (`cto_run_chunks`, csrc/pipeline.hip: native threads, one page-locked staging copy per chunk,
+buffers kept from chunk to chunk) and are what `--pipeline auto` runs whenever the inputs are plain files - mpileup text
+(`--mpileup_dir`) or a BAM through the built-in reader (`--bam_reader native`); gzip inputs, the `samtools mpileup` subprocess, the
+device inflate and the `--predict_fn` tap stay on the thread pools of this module.  Both write the same files, byte for byte.
 """
 import os
 import sys

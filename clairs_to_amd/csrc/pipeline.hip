@@ -98,7 +98,6 @@ struct Slot {
     std::vector<int32_t> sites;
     std::string ref;
     int64_t ref_start = 0;
-    std::string error;
     ~Slot() {
         if (pack) cto_pack_free(pack);
         if (uploaded) (void)hipEventDestroy(uploaded);
@@ -266,7 +265,7 @@ struct Run {
     std::mutex err_m;
     std::string first_error;
     std::atomic<bool> failed{false};
-    std::atomic<int64_t> candidates{0}, sites{0}, rows{0}, low_cov{0}, clamped{0}, chunks_done{0};
+    std::atomic<int64_t> candidates{0}, sites{0}, rows{0}, low_cov{0}, clamped{0};
     std::mutex stat_m;
     double produce_s = 0, finish_s = 0, pack_s = 0, upload_s = 0, device_s = 0;
     Mapped fasta;
@@ -544,10 +543,15 @@ extern "C" int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs,
                 if (!run.free_slots.pop(&s)) break;
                 s->job = j;
                 const double t0 = now_s();
-                const bool ok = copy && run.produce(s, copy);
+                bool ok = false;
+                try {
+                    ok = copy && run.produce(s, copy);
+                } catch (const std::exception& e) {                  // bad_alloc on a huge chunk: an error of the run, not of the process
+                    run.fail(std::string("producer: ") + e.what());
+                }
                 { std::lock_guard<std::mutex> g(run.stat_m); run.produce_s += now_s() - t0; }
                 if (ok) run.to_launch.push(s);
-                else { ++run.chunks_done; run.free_slots.push(s); }     // nothing to call here (or an error: `failed` is set)
+                else run.free_slots.push(s);                         // nothing to call here (or an error: `failed` is set)
             }
             if (copy) { (void)hipStreamSynchronize(copy); (void)hipStreamDestroy(copy); }
             if (--producers_left == 0) run.to_launch.close();
@@ -558,9 +562,12 @@ extern "C" int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs,
             Slot* s = nullptr;
             while (run.to_write.pop(&s)) {
                 const double t0 = now_s();
-                if (!run.failed) run.finish(s);
+                try {
+                    if (!run.failed) run.finish(s);
+                } catch (const std::exception& e) {
+                    run.fail(std::string("writer: ") + e.what());
+                }
                 { std::lock_guard<std::mutex> g(run.stat_m); run.finish_s += now_s() - t0; }
-                ++run.chunks_done;
                 run.free_slots.push(s);
             }
         });
@@ -578,7 +585,7 @@ extern "C" int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs,
             if (r != CTO_OK) { run.fail(cto_last_error()); rc = r; }
         }
         launch_s += now_s() - t1;
-        if (run.failed) { ++run.chunks_done; run.free_slots.push(s); }
+        if (run.failed) run.free_slots.push(s);
         else run.to_write.push(s);
     }
     run.to_write.close();
