@@ -53,6 +53,62 @@ def test_tokeniser_rejects_malformed_rows():
     assert p.n_cols == 0 and p.n_entries == 0
 
 
+def test_tokeniser_paths_agree():
+    """cto_pack_from_mpileup parses a row samtools-style in one forward pass and hands everything unusual to the general
+    field-splitting parser (csrc/pack.cpp fast_row / parse_rows).  The same pileup written so that every row takes the general path
+    (an eighth field, or CR LF line ends) must give the same pack as the plain form, which takes the fast path; and a text cut
+    over several tokeniser threads (> 4 MB) the same pack as one thread."""
+    import os
+    from clairs_to_amd.pack import ColumnPack
+    from clairs_to_amd.synth import SynthChunk, mpileup_text
+    chunk = SynthChunk(300, seed=21, p_ins=0.05, p_del=0.05, spacing=40)
+    ref, lo = chunk.ref_window()
+    text = mpileup_text(chunk)
+    text = text if isinstance(text, str) else text.decode()
+    rows = [r for r in text.split("\n") if r]
+    forms = {"plain": "\n".join(rows) + "\n",
+             "eight_fields": "\n".join(r + "\tx" for r in rows) + "\n",
+             "crlf": "\r\n".join(rows) + "\r\n",
+             "no_final_newline": "\n".join(rows)}
+
+    def arrays(t):
+        p = ColumnPack.from_mpileup(t, ref, lo)
+        a = {k: v.copy() for k, v in p.numpy().items()}
+        a["keys"] = np.array([p.key_string(k) for k in range(p.n_keys)])
+        return a
+    want = arrays(forms["plain"])
+    assert want["entries"].size > 5000 and want["keys"].size > 50
+    for name, t in forms.items():
+        got = arrays(t)
+        for k in want:
+            np.testing.assert_array_equal(got[k], want[k], err_msg="%s: %s" % (name, k))
+    # a row whose quality string is one character short: zip() truncation of the reference (general path), not an error
+    f = rows[0].split("\t")
+    n0 = len(f[5])
+    short = "\t".join(f[:5] + [f[5][:-1], f[6]])
+    p = ColumnPack.from_mpileup(short + "\n", ref, lo)
+    assert p.n_entries == n0 - 1
+    # several tokeniser threads
+    big = SynthChunk(4096, seed=22, spacing=300)
+    bref, blo = big.ref_window()
+    btext = mpileup_text(big)
+    assert len(btext) > (1 << 22)
+    old = os.environ.get("CTO_PACK_THREADS")
+    try:
+        out = []
+        for nt in ("1", "7"):
+            os.environ["CTO_PACK_THREADS"] = nt
+            p = ColumnPack.from_mpileup(btext, bref, blo)
+            out.append({k: v.copy() for k, v in p.numpy().items()})
+    finally:
+        if old is None:
+            os.environ.pop("CTO_PACK_THREADS", None)
+        else:
+            os.environ["CTO_PACK_THREADS"] = old
+    for k in out[0]:
+        np.testing.assert_array_equal(out[0][k], out[1][k], err_msg="threads: " + k)
+
+
 def _rows(text):
     return [r.split("\t") for r in text.strip().split("\n") if r]
 
