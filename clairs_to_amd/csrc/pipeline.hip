@@ -87,9 +87,11 @@ struct Slot {
     PinBuf stage;                        // its page-locked source
     const int32_t* d_site_pos = nullptr;
     // featurisation / network / epilogue outputs
-    DevBuf colvec, coldepth, keycnt, x_aff, x_neg, site_info, sitefirst, keyfirst, la, ln, post, decision, qual, site_colvec;
-    PinBuf h_site_info, h_site_colvec, h_sitefirst, h_keycnt, h_keyfirst, h_decision, h_qual;
-    hipEvent_t uploaded = nullptr, begin = nullptr, done = nullptr;
+    DevBuf colvec, coldepth, x_aff, x_neg, la, ln, post;
+    DevBuf res_dev;                      // site_info | candidate column vectors | sitefirst | decision | qual | keycnt | keyfirst
+    PinBuf res_host;                     // the same bytes on the host, one copy per chunk
+    size_t roff[7] = {0, 0, 0, 0, 0, 0, 0};
+    hipEvent_t uploaded = nullptr, begin = nullptr, computed = nullptr, done = nullptr;
     // host side of the chunk
     int64_t job = -1;
     int device = 0;
@@ -103,6 +105,7 @@ struct Slot {
         if (uploaded) (void)hipEventDestroy(uploaded);
         if (done) (void)hipEventDestroy(done);
         if (begin) (void)hipEventDestroy(begin);
+        if (computed) (void)hipEventDestroy(computed);
     }
 };
 
@@ -365,48 +368,49 @@ struct Run {
         return true;
     }
 
-    int launch(Slot* s, hipStream_t main) {
+    int launch(Slot* s, hipStream_t main, hipStream_t copy_back) {
         const int K = cfg->K;
         const int64_t n = int64_t(s->sites.size());
         const size_t nc = size_t(std::max<int64_t>(s->hv.n_cols, 1)), nk = size_t(std::max<int64_t>(s->hv.n_keys, 1));
         int rc;
-        if ((rc = s->colvec.ensure(nc * CTO_COLVEC_STRIDE * 2)) || (rc = s->coldepth.ensure(nc * 8)) || (rc = s->keycnt.ensure(nk * 4)) ||
+        // everything the writers need goes into ONE device buffer and comes back with ONE copy on the copy-back stream: seven copies
+        // queued behind the kernels on the launch stream cost ~0.1 ms per chunk in which the next chunk's kernels could not start
+        const size_t rbytes[7] = {size_t(n) * 48, size_t(n) * CTO_COLVEC_STRIDE * 2, size_t(n) * 32, size_t(n) * 16, size_t(n) * 8, nk * 4, nk * 8};
+        size_t total = 0;
+        for (int i = 0; i < 7; ++i) { s->roff[i] = total; total += (rbytes[i] + 255) / 256 * 256; }
+        if ((rc = s->colvec.ensure(nc * CTO_COLVEC_STRIDE * 2)) || (rc = s->coldepth.ensure(nc * 8)) ||
             (rc = s->x_aff.ensure(size_t(n) * CTO_NPOS * CTO_NCHAN * 4)) || (rc = s->x_neg.ensure(size_t(n) * CTO_NPOS * CTO_NCHAN * 4)) ||
-            (rc = s->site_info.ensure(size_t(n) * 48)) || (rc = s->sitefirst.ensure(size_t(n) * 32)) || (rc = s->keyfirst.ensure(nk * 8)) ||
             (rc = s->la.ensure(size_t(K) * n * 8)) || (rc = s->ln.ensure(size_t(K) * n * 8)) || (rc = s->post.ensure(size_t(n) * K * 8)) ||
-            (rc = s->decision.ensure(size_t(n) * 16)) || (rc = s->qual.ensure(size_t(n) * 8)) ||
-            (rc = s->site_colvec.ensure(size_t(n) * CTO_COLVEC_STRIDE * 2)) ||
-            (rc = s->h_site_info.ensure(size_t(n) * 48)) || (rc = s->h_site_colvec.ensure(size_t(n) * CTO_COLVEC_STRIDE * 2)) ||
-            (rc = s->h_sitefirst.ensure(size_t(n) * 32)) || (rc = s->h_keycnt.ensure(nk * 4)) || (rc = s->h_keyfirst.ensure(nk * 8)) ||
-            (rc = s->h_decision.ensure(size_t(n) * 16)) || (rc = s->h_qual.ensure(size_t(n) * 8)))
+            (rc = s->res_dev.ensure(total)) || (rc = s->res_host.ensure(total)))
             return rc;
+        char* rd = static_cast<char*>(s->res_dev.p);
+        auto* site_info = reinterpret_cast<int32_t*>(rd + s->roff[0]);
+        auto* site_colvec = reinterpret_cast<int16_t*>(rd + s->roff[1]);
+        auto* sitefirst = reinterpret_cast<int32_t*>(rd + s->roff[2]);
+        auto* decision = reinterpret_cast<int32_t*>(rd + s->roff[3]);
+        auto* qual = reinterpret_cast<double*>(rd + s->roff[4]);
+        auto* keycnt = reinterpret_cast<uint32_t*>(rd + s->roff[5]);
+        auto* keyfirst = reinterpret_cast<int32_t*>(rd + s->roff[6]);
         CTO_HIP(hipStreamWaitEvent(main, s->uploaded, 0));
         CTO_HIP(hipEventRecord(s->begin, main));
         auto* colvec = static_cast<int16_t*>(s->colvec.p);
-        auto* site_info = static_cast<int32_t*>(s->site_info.p);
-        if ((rc = cto_featurize_columns(&s->dv, cfg->min_bq, colvec, static_cast<int32_t*>(s->coldepth.p), static_cast<uint32_t*>(s->keycnt.p), main)))
-            return rc;
+        if ((rc = cto_featurize_columns(&s->dv, cfg->min_bq, colvec, static_cast<int32_t*>(s->coldepth.p), keycnt, main))) return rc;
         if ((rc = cto_gather_windows(&s->dv, colvec, static_cast<int32_t*>(s->coldepth.p), s->d_site_pos, n, cfg->min_bq,
                                      cfg->min_rescale_cov, static_cast<float*>(s->x_aff.p), static_cast<float*>(s->x_neg.p), nullptr, nullptr, site_info,
-                                     static_cast<int32_t*>(s->sitefirst.p), static_cast<int32_t*>(s->keyfirst.p), main)))
+                                     sitefirst, keyfirst, main)))
             return rc;
         const float* x_neg = cfg->neg_reads_aff ? static_cast<const float*>(s->x_aff.p) : static_cast<const float*>(s->x_neg.p);
         if ((rc = cto_model_forward(cfg->neg, x_neg, n, static_cast<float*>(s->ln.p), main))) return rc;
         if ((rc = cto_model_forward(cfg->aff, static_cast<const float*>(s->x_aff.p), n, static_cast<float*>(s->la.p), main))) return rc;
         if ((rc = cto_posterior(static_cast<const float*>(s->la.p), static_cast<const float*>(s->ln.p), K, n, cfg->d_lik, cfg->d_edges, nullptr,
-                                static_cast<double*>(s->post.p), static_cast<int32_t*>(s->decision.p), static_cast<double*>(s->qual.p), main)))
+                                static_cast<double*>(s->post.p), decision, qual, main)))
             return rc;
-        hipLaunchKernelGGL(k_gather_rows, dim3(unsigned(n)), dim3(128), 0, main, colvec, site_info, n, static_cast<int16_t*>(s->site_colvec.p));
+        hipLaunchKernelGGL(k_gather_rows, dim3(unsigned(n)), dim3(128), 0, main, colvec, site_info, n, site_colvec);
         CTO_HIP(hipGetLastError());
-        auto down = [&](PinBuf& h, const DevBuf& d, size_t bytes) { return bytes ? hipMemcpyAsync(h.p, d.p, bytes, hipMemcpyDeviceToHost, main) : hipSuccess; };
-        CTO_HIP(down(s->h_site_info, s->site_info, size_t(n) * 48));
-        CTO_HIP(down(s->h_site_colvec, s->site_colvec, size_t(n) * CTO_COLVEC_STRIDE * 2));
-        CTO_HIP(down(s->h_sitefirst, s->sitefirst, size_t(n) * 32));
-        CTO_HIP(down(s->h_keycnt, s->keycnt, size_t(s->hv.n_keys) * 4));
-        CTO_HIP(down(s->h_keyfirst, s->keyfirst, size_t(s->hv.n_keys) * 8));
-        CTO_HIP(down(s->h_decision, s->decision, size_t(n) * 16));
-        CTO_HIP(down(s->h_qual, s->qual, size_t(n) * 8));
-        CTO_HIP(hipEventRecord(s->done, main));
+        CTO_HIP(hipEventRecord(s->computed, main));
+        CTO_HIP(hipStreamWaitEvent(copy_back, s->computed, 0));
+        CTO_HIP(hipMemcpyAsync(s->res_host.p, s->res_dev.p, total, hipMemcpyDeviceToHost, copy_back));
+        CTO_HIP(hipEventRecord(s->done, copy_back));
         return CTO_OK;
     }
 
@@ -419,16 +423,21 @@ struct Run {
             if (hipEventElapsedTime(&ms, s->begin, s->done) == hipSuccess) { std::lock_guard<std::mutex> g(stat_m); device_s += ms * 1e-3; }
         }
         const int64_t n = int64_t(s->sites.size());
-        auto* info = static_cast<int32_t*>(s->h_site_info.p);
+        char* rh = static_cast<char*>(s->res_host.p);
+        auto* info = reinterpret_cast<int32_t*>(rh + s->roff[0]);
+        const auto* h_site_colvec = reinterpret_cast<const int16_t*>(rh + s->roff[1]);
+        const auto* h_sitefirst = reinterpret_cast<const int32_t*>(rh + s->roff[2]);
+        const auto* h_decision = reinterpret_cast<const int32_t*>(rh + s->roff[3]);
+        const auto* h_qual = reinterpret_cast<const double*>(rh + s->roff[4]);
         static const uint32_t zero_k[1] = {0};
         static const int32_t zero_kf[2] = {0, 0};
-        const uint32_t* keycnt = s->hv.n_keys ? static_cast<const uint32_t*>(s->h_keycnt.p) : zero_k;
-        const int32_t* keyfirst = s->hv.n_keys ? static_cast<const int32_t*>(s->h_keyfirst.p) : zero_kf;
+        const uint32_t* keycnt = s->hv.n_keys ? reinterpret_cast<const uint32_t*>(rh + s->roff[5]) : zero_k;
+        const int32_t* keyfirst = s->hv.n_keys ? reinterpret_cast<const int32_t*>(rh + s->roff[6]) : zero_kf;
         std::vector<int64_t> alt_off(size_t(n) + 1, 0);
         std::vector<char> alt(size_t(256 * n + (1 << 16)));
         int64_t used = -1;
         for (int tries = 0; tries < 8; ++tries) {
-            used = cto_alt_info_batch_sites(s->pack, n, info, 0, static_cast<const int16_t*>(s->h_site_colvec.p), static_cast<const int32_t*>(s->h_sitefirst.p),
+            used = cto_alt_info_batch_sites(s->pack, n, info, 0, h_site_colvec, h_sitefirst,
                                             keycnt, keyfirst, alt.data(), alt.size(), alt_off.data());
             if (used >= 0) break;
             if (!strstr(cto_last_error(), "buffer too small")) break;
@@ -446,8 +455,8 @@ struct Run {
         int64_t counts[4] = {0, 0, 0, 0};
         int64_t tu = -1;
         for (int tries = 0; tries < 6; ++tries) {
-            tu = cto_vcf_rows_batch(j.ctg_name, n, s->sites.data(), centre.data(), alt.data(), alt_off.data(), info, static_cast<const int32_t*>(s->h_decision.p),
-                                    static_cast<const double*>(s->h_qual.p), cfg->K, cfg->show_ref, cfg->qual_pass, text.data(), text.size(), counts);
+            tu = cto_vcf_rows_batch(j.ctg_name, n, s->sites.data(), centre.data(), alt.data(), alt_off.data(), info, h_decision,
+                                    h_qual, cfg->K, cfg->show_ref, cfg->qual_pass, text.data(), text.size(), counts);
             if (tu != CTO_ENOMEM) break;
             text.resize(text.size() * 4);
         }
@@ -464,7 +473,7 @@ struct Run {
         if (cfg->verbose) {
             for (int64_t i = 0; i < counts[2]; ++i) puts("low tumor coverage");             // call_variants.py:328, one line per such site
             if (counts[3]) {
-                const int32_t* dec = static_cast<const int32_t*>(s->h_decision.p);
+                const int32_t* dec = h_decision;
                 for (int64_t i = 0; i < n; ++i)
                     if (dec[i * 4 + 1])
                         fprintf(stderr, "[WARNING] %s:%d a probability printed as 1.00000000 / 0.00000000 falls outside the likelihood bins (the "
@@ -523,10 +532,13 @@ extern "C" int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs,
         run.slots.back()->device = dev;
         CTO_HIP(hipEventCreateWithFlags(&run.slots.back()->uploaded, hipEventDisableTiming));
         CTO_HIP(hipEventCreate(&run.slots.back()->begin));
+        CTO_HIP(hipEventCreateWithFlags(&run.slots.back()->computed, hipEventDisableTiming));
         CTO_HIP(hipEventCreate(&run.slots.back()->done));
     }
     for (auto& sl : run.slots) run.free_slots.push(sl.get());
     hipStream_t main = static_cast<hipStream_t>(stream);
+    hipStream_t copy_back = nullptr;
+    CTO_HIP(hipStreamCreateWithFlags(&copy_back, hipStreamNonBlocking));
     const double t_begin = now_s();
     std::atomic<int> producers_left{producers};
 
@@ -581,7 +593,7 @@ extern "C" int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs,
         const double t1 = now_s();
         wait_s += t1 - t0;
         if (!run.failed) {
-            const int r = run.launch(s, main);
+            const int r = run.launch(s, main, copy_back);
             if (r != CTO_OK) { run.fail(cto_last_error()); rc = r; }
         }
         launch_s += now_s() - t1;
@@ -592,6 +604,8 @@ extern "C" int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs,
     run.free_slots.close();
     for (auto& th : threads) th.join();
     (void)hipStreamSynchronize(main);
+    (void)hipStreamSynchronize(copy_back);
+    (void)hipStreamDestroy(copy_back);
     if (stats) {
         stats->candidates = run.candidates;
         stats->sites = run.sites;
