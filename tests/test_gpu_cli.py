@@ -369,6 +369,30 @@ def test_native_pipeline_writes_the_same_files(tmp_path, source, mode, aff_cls, 
         assert open(tmp_path / "py" / fn, "rb").read() == open(tmp_path / "nat" / fn, "rb").read(), fn
 
 
+def test_native_pipeline_large_text_chunks(tmp_path):
+    """22 MB of pileup text per chunk: the tokeniser runs on several threads and merges its parts straight into the pipeline's
+    page-locked staging buffer (cto_pack::ext_entries) - same files as the Python pipeline, which uploads from the pack's own arrays."""
+    from clairs_to_amd.call_chunks import run_pipeline, run_pipeline_native
+    from clairs_to_amd.e2e import chunk_namespaces
+    from clairs_to_amd.engine import Engine, synthetic_models
+    from clairs_to_amd.synth import likelihood_table, lik_and_edges
+    from clairs_to_amd.synth_run import make_text_run
+    run = make_text_run(str(tmp_path / "run"), n_chunks=3, sites_per_chunk=4096, distinct=3)
+    models = synthetic_models(4, seed=0)
+    lik, edges = lik_and_edges(likelihood_table(4), 4)
+    eng = Engine(models["aff"], models["neg"], lik, edges, min_bq=20, device="cuda:0")
+    a_py = chunk_namespaces(run, str(tmp_path / "py"))
+    a_nat = chunk_namespaces(run, str(tmp_path / "nat"))
+    os.makedirs(tmp_path / "py"), os.makedirs(tmp_path / "nat")
+    n_py = run_pipeline(eng, a_py, producers=2, writers=2)
+    n_nat = run_pipeline_native(eng, a_nat, producers=2, writers=2, verbose=False)
+    assert n_py == n_nat and n_py > 1000
+    names = sorted(os.listdir(tmp_path / "py"))
+    assert names == sorted(os.listdir(tmp_path / "nat")) and len(names) == 3
+    for fn in names:
+        assert open(tmp_path / "py" / fn, "rb").read() == open(tmp_path / "nat" / fn, "rb").read(), fn
+
+
 def test_native_pipeline_reports_errors(tmp_path):
     """a missing pileup file, a contig the reference index does not hold: CtoError naming the cause, no hang, no partial state"""
     from argparse import Namespace

@@ -2,7 +2,8 @@
 //   g++ -O1 -g -std=c++17 -fsanitize=address,undefined -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude -Iclairs_to_amd/csrc \
 //       clairs_to_amd/csrc/bam.cpp clairs_to_amd/csrc/pack.cpp tools/fuzz_producers.cpp -o /tmp/fuzz -lz -ldl -lpthread
 //   /tmp/fuzz <dir with ok.bam, ok.bam.bai, ok.txt (tests/bamutil.py writes them)> <iterations>
-// Last runs (round 2, after the mapped-file / CRC / run-wise column loop rework): 2500 iterations + 600 with CTO_PACK_THREADS=4 under
+// Last runs (round 2, after the tokeniser's single-pass row parser and the hashed indel-key scan): 3000 iterations + 600 with
+// CTO_PACK_THREADS=4 under -fsanitize=address,undefined, no report.  Before that (mapped-file / CRC / run-wise column loop rework): 2500 iterations + 600 with CTO_PACK_THREADS=4 under
 // -fsanitize=address,undefined; earlier: 3000 + 1500 iterations and 150 under -fsanitize=thread with CTO_PACK_THREADS=4
 // (truncations, byte flips, insertions of BAM / BAI / mpileup text): no sanitizer report.
 #include <cstdio>
