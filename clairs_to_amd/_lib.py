@@ -46,13 +46,14 @@ class RunCfg(C.Structure):
     _fields_ = [("aff", c_vp), ("neg", c_vp), ("d_lik", c_vp), ("d_edges", c_vp), ("K", C.c_int), ("min_bq", C.c_int),
                 ("min_rescale_cov", C.c_int), ("max_indel_length", C.c_int), ("max_depth", C.c_int), ("neg_reads_aff", C.c_int),
                 ("show_ref", C.c_int), ("verbose", C.c_int), ("qual_pass", C.c_double), ("ref_fa", C.c_char_p),
-                ("vcf_header", C.c_char_p), ("producers", C.c_int), ("writers", C.c_int), ("depth", C.c_int)]
+                ("vcf_header", C.c_char_p), ("producers", C.c_int), ("writers", C.c_int), ("depth", C.c_int),
+                ("inflate_cus", C.c_int), ("inflate_jobs", C.c_int)]
 
 
 class RunStats(C.Structure):
     _fields_ = [("candidates", c_i64), ("sites", c_i64), ("rows", c_i64), ("low_coverage", c_i64), ("clamped", c_i64), ("seconds", C.c_double),
                 ("produce_s", C.c_double), ("finish_s", C.c_double), ("launch_s", C.c_double), ("launcher_wait_s", C.c_double),
-                ("pack_s", C.c_double), ("upload_s", C.c_double), ("device_s", C.c_double)]
+                ("pack_s", C.c_double), ("upload_s", C.c_double), ("device_s", C.c_double), ("device_inflated", c_i64)]
 
 
 # every symbol include/clairsto_amd.h declares: (restype, argtypes)

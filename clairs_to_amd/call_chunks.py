@@ -56,6 +56,10 @@ def usable_cores():
             n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
     except Exception:
         pass
+    try:                                     # one process per GPU on the node: each rank plans with its share of the cores
+        n = max(1, n // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
+    except ValueError:
+        pass
     return n
 
 
@@ -63,12 +67,20 @@ def default_producers(native_bam, pipeline="python"):
     """pack-producer threads per rank: a quarter of the usable cores for mpileup text (the tokeniser saturates memory bandwidth early),
     half of them for the native BAM reader on the Python pipeline (inflate-bound, and its per-call serial parts - index, header,
     merge - want more calls in flight: 8 producers x 8 threads gave 280 k sites/s on 16 cores where 4 x 8 gave 218 k).  The C
-    pipeline runs one BAM producer per usable core with two decoding threads each (pack_threads()): a call split over 8 threads
-    decodes the long reads that straddle its 7 inner boundaries twice - 320 ms of CPU per 1 Mb x 50x chunk against 243 ms
-    unsplit - and 16 x 2 measured 264 k sites/s where 8 x 8 gave 205 k."""
+    pipeline runs three BAM producers per two usable cores with two decoding threads each (pack_threads()): a call split over 8
+    threads decodes the long reads that straddle its 7 inner boundaries twice - 320 ms of CPU per 1 Mb x 50x chunk against 243 ms
+    unsplit - and 16 x 2 measured 264 k sites/s where 8 x 8 gave 205 k; with DEVICE_INFLATE chunks in flight through the device
+    inflate (their producers asleep meanwhile) 24 x 2 measured 350-368 k."""
     if native_bam and pipeline == "native":
-        return max(1, min(32, usable_cores()))
+        return max(1, min(48, usable_cores() * 3 // 2))     # a third of them sleep while their chunk is inflated on the device
     return max(1, min(16, usable_cores() // (2 if native_bam else 4)))
+
+
+# BAM chunks on the C pipeline: up to DEVICE_INFLATE[1] chunks at a time have their BGZF blocks inflated on the GPU, on streams confined to
+# DEVICE_INFLATE[0] of its 256 compute units (the networks keep the rest; they need a fifth of the GPU at BAM rates), the others on the
+# host cores.  Measured on 64 chunk files, 16 usable cores (sites/s): host only 240-243 k; 128 CUs x 4 / 6 / 8 chunks 337-354 k; 192 CUs x 6 / 8
+# 345-368 k; 240 CUs or 12+ chunks in flight 155-290 k (the networks starve: 8-12 ms of device time per chunk instead of 2.5).
+DEVICE_INFLATE = (160, 6)
 
 
 def pack_threads(native_bam, pipeline="python"):
@@ -164,7 +176,7 @@ def native_eligible(chunk_args):
     return True
 
 
-def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, stats=None, verbose=True):
+def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, stats=None, verbose=True, inflate_cus=None, inflate_jobs=None):
     """run_pipeline() as ONE C call (cto_run_chunks, csrc/pipeline.hip): the same stages on native threads - the interpreter is
     not in the loop, which is what levels the Python pipeline off at ~290 chunks a second.  Same files, byte for byte."""
     import ctypes as C
@@ -196,6 +208,8 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
     cfg.ref_fa = str(a0.ref_fn).encode()
     cfg.vcf_header = (VCF_HEADER + "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n" % a0.sample_name).encode()
     cfg.producers, cfg.writers, cfg.depth = int(producers), int(writers), int(depth or 0)
+    cfg.inflate_cus = DEVICE_INFLATE[0] if inflate_cus is None else int(inflate_cus)       # only BAM jobs use it
+    cfg.inflate_jobs = DEVICE_INFLATE[1] if inflate_jobs is None else int(inflate_jobs)
     st = RunStats()
     with torch.cuda.device(eng.device):
         rc = lib.cto_run_chunks(C.byref(cfg), jobs, len(chunk_args), C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(st))
@@ -205,7 +219,7 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
     check(rc)
     if stats is not None:
         for k, v in (("sites", st.candidates), ("produce_s", st.produce_s), ("finish_s", st.finish_s), ("launch_s", st.launch_s),
-                     ("launcher_waits_for_producer_s", st.launcher_wait_s), ("pack_s", st.pack_s), ("upload_s", st.upload_s), ("device_s", st.device_s), ("low_coverage", st.low_coverage), ("clamped", st.clamped)):
+                     ("launcher_waits_for_producer_s", st.launcher_wait_s), ("pack_s", st.pack_s), ("upload_s", st.upload_s), ("device_s", st.device_s), ("device_inflated", st.device_inflated), ("low_coverage", st.low_coverage), ("clamped", st.clamped)):
             stats[k] = stats.get(k, 0) + v
     return int(st.rows)
 
@@ -253,7 +267,8 @@ def call_chunks(args):
         run = run_pipeline_native if native else run_pipeline
         from_bam = not getattr(args, "mpileup_dir", None) and getattr(args, "bam_reader", None) in ("native", "gpu")
         producers = args.producers if getattr(args, "producers", None) else default_producers(from_bam, "native" if native else "python")
-        n_rows = run(eng, mine, producers=producers, writers=getattr(args, "writers", None) or 2)
+        kw = dict(inflate_cus=getattr(args, "device_inflate_cus", None)) if native else {}
+        n_rows = run(eng, mine, producers=producers, writers=getattr(args, "writers", None) or 2, **kw)
     except (Exception, SystemExit) as e:     # a bad reference, a corrupt BAM, CTO_EUNSUPPORTED ...: report, do not leave the others waiting
         failure = "%s: %s" % (type(e).__name__, e)
         print("[ERROR] rank %d/%d failed: %s" % (rank, world, failure), file=sys.stderr)
@@ -302,6 +317,8 @@ def main():
                    help="read <dir>/<chunk file name>.mpileup (samtools mpileup --min-BQ 0 text of the chunk) instead of the BAM")
     p.add_argument("--producers", type=int, default=None, help="pack-producer threads per rank (default: usable cores / 4, / 2 with --bam_reader native; <= 16)")
     p.add_argument("--writers", type=int, default=None, help="VCF-writer threads per rank (default 2)")
+    p.add_argument("--device_inflate_cus", type=int, default=None,
+                   help="C pipeline, BAM input: compute units the device BGZF inflate is confined to (default %d; 0: inflate on the host only)" % DEVICE_INFLATE[0])
     p.add_argument("--pipeline", type=str, default="auto", choices=["auto", "native", "python"],
                    help="'native': the chunk loop as one C call (cto_run_chunks; plain-text inputs, --mpileup_dir or --bam_reader native); "
                         "'python': the thread-pool pipeline of this module; 'auto': native when the inputs allow it")

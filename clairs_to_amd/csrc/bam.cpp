@@ -252,7 +252,8 @@ void reg2bins(int64_t beg, int64_t end, std::vector<uint32_t>* bins) {
 }
 
 // chunks of reference `tid` that may overlap [beg, end), merged and sorted; false on a malformed index
-bool bai_query(const char* path, int tid, int64_t beg, int64_t end, std::vector<Chunk>* out, std::string* err) {
+bool bai_query(const char* path, int tid, int64_t beg, int64_t end, std::vector<Chunk>* out, std::string* err,
+               std::vector<uint64_t>* linear = nullptr) {
     FILE* f = fopen(path, "rb");
     if (!f) { *err = std::string("cannot open index ") + path; return false; }
     std::vector<uint8_t> buf;
@@ -298,6 +299,10 @@ bool bai_query(const char* path, int tid, int64_t beg, int64_t end, std::vector<
         if (r == tid && n_intv > 0) {
             const int64_t w = std::min<int64_t>(beg >> 14, n_intv - 1);
             min_off = le64(buf.data() + o + size_t(w) * 8);
+            if (linear) {
+                linear->resize(size_t(n_intv));
+                for (int i = 0; i < n_intv; ++i) (*linear)[size_t(i)] = le64(buf.data() + o + size_t(i) * 8);
+            }
         }
         o += size_t(n_intv) * 8;
     }
@@ -855,8 +860,9 @@ extern "C" int cto_bam_chunk_span(const char* bam_path, const char* bai_path, co
         const int rch = read_header_tid(bz, bam_path, ctg_name, &tid);
         if (rch != CTO_OK) return rch;
         std::vector<Chunk> chunks;
+        std::vector<uint64_t> linear;
         std::string err, idx = bai_path ? std::string(bai_path) : std::string(bam_path) + ".bai";
-        CTO_REQUIRE(bai_query(idx.c_str(), tid, start - 1, end, &chunks, &err), CTO_EINVAL, "cto_bam_chunk_span: %s", err.c_str());
+        CTO_REQUIRE(bai_query(idx.c_str(), tid, start - 1, end, &chunks, &err, &linear), CTO_EINVAL, "cto_bam_chunk_span: %s", err.c_str());
         const int64_t fsize = bz.fsize;
         int64_t lo = fsize, hi = 0;
         for (const Chunk& c : chunks) {
@@ -864,6 +870,28 @@ extern "C" int cto_bam_chunk_span(const char* bam_path, const char* bai_path, co
             hi = std::max<int64_t>(hi, int64_t(c.end >> 16) + 65536);
         }
         if (chunks.empty()) { lo = 0; hi = 0; }
+        // The chunk lists of the coarse bins (a 512 Mb bin holds every read that straddles a finer boundary) end far behind the
+        // region - the reader stops at the first alignment that starts after it, this range has to be cut beforehand.  The file is
+        // sorted: the linear index names, per 16 kb window, the first alignment that overlaps it, and once THAT alignment starts
+        // after the region everything from its block on does.  A few one-block probes find the window.
+        if (!chunks.empty()) {
+            const int64_t w0 = ((end - 1) >> 14) + 1;
+            uint64_t last = 0;
+            int probes = 0;
+            for (int64_t w = w0; w < int64_t(linear.size()) && probes < 48; ++w) {
+                const uint64_t v = linear[size_t(w)];
+                if (v == 0 || v == last || int64_t(v >> 16) < lo) continue;
+                last = v;
+                ++probes;
+                uint8_t head[12];
+                if (!bz.seek(v) || !bz.read(head, 12)) break;         // damaged index / file: keep the wide range
+                const int32_t rid = le32(head + 4), pos0 = le32(head + 8);
+                if (rid != tid || int64_t(pos0) >= end) {             // starts after the region (1-based end = 0-based exclusive end)
+                    hi = std::min<int64_t>(hi, int64_t(v >> 16) + 65536);
+                    break;
+                }
+            }
+        }
         *file_begin = lo;
         *file_end = std::min(hi, fsize);
         return CTO_OK;

@@ -35,6 +35,17 @@ using namespace cto;
 
 namespace {
 
+// Waits for an event without occupying a core: hipEventSynchronize / hipStreamSynchronize poll the completion signal from the calling
+// thread (measured: every chunk waiting for the device inflate cost a second of CPU), and the producer and writer threads that wait
+// here share the host with the threads that tokenise and inflate.
+hipError_t wait_event(hipEvent_t ev) {
+    for (int spins = 0;; ++spins) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        if (spins >= 4) usleep(spins < 64 ? 50 : 200);
+    }
+}
+
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct DevBuf {                          // a device allocation that only grows
@@ -109,6 +120,32 @@ struct Slot {
     }
 };
 
+// One chunk's trip through the device inflate (csrc/inflate.hip): the BGZF byte range + block table in page-locked memory, their
+// device copies, the inflated blocks on both sides, and a stream CONFINED to the first `cus` compute units
+// (hipExtStreamCreateWithCUMask; tools/cumask_probe.hip: N leading bits = N / 8 CUs of every XCD).  A wave-per-block inflate launch
+// occupies its CUs for tens of milliseconds; unconfined, the networks' block kernels - which need a CU's whole register file -
+// wait for those waves to drain, confined they run on the other CUs.
+struct InflateCtx {
+    int device = 0, cus = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t landed = nullptr;         // blocking-sync: the producer thread sleeps while its chunk is on the device
+    PinBuf h_in, h_out;
+    DevBuf d_in, d_out;
+    int open(int dev, int n_cus) {
+        device = dev;
+        cus = n_cus;
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < n_cus && i < 256; ++i) mask[i / 32] |= 1u << (i % 32);
+        CTO_HIP(hipExtStreamCreateWithCUMask(&stream, 8, mask));
+        CTO_HIP(hipEventCreateWithFlags(&landed, hipEventBlockingSync | hipEventDisableTiming));
+        return CTO_OK;
+    }
+    ~InflateCtx() {
+        if (landed) (void)hipEventDestroy(landed);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
 template <class T>
 struct Queue {                            // unbounded MPMC queue with a closed state
     std::mutex m;
@@ -117,6 +154,13 @@ struct Queue {                            // unbounded MPMC queue with a closed 
     bool closed = false;
     void push(T v) { { std::lock_guard<std::mutex> g(m); q.push_back(std::move(v)); } cv.notify_one(); }
     void close() { { std::lock_guard<std::mutex> g(m); closed = true; } cv.notify_all(); }
+    bool try_pop(T* out) {
+        std::lock_guard<std::mutex> g(m);
+        if (q.empty()) return false;
+        *out = std::move(q.front());
+        q.pop_front();
+        return true;
+    }
     bool pop(T* out) {
         std::unique_lock<std::mutex> g(m);
         cv.wait(g, [&] { return !q.empty() || closed; });
@@ -244,6 +288,7 @@ __global__ void k_gather_rows(const int16_t* __restrict__ colvec, const int32_t*
 // never destroyed: at process exit the HIP runtime may already be gone when static destructors run
 std::mutex& slot_cache_m() { static std::mutex* m = new std::mutex(); return *m; }
 std::vector<std::unique_ptr<Slot>>& slot_cache() { static auto* v = new std::vector<std::unique_ptr<Slot>>(); return *v; }
+std::vector<std::unique_ptr<InflateCtx>>& inflate_cache() { static auto* v = new std::vector<std::unique_ptr<InflateCtx>>(); return *v; }
 struct SlotReturn {                      // hands a finished (or failed) call's slots back to the cache
     std::vector<std::unique_ptr<Slot>>* slots;
     ~SlotReturn() {
@@ -253,6 +298,15 @@ struct SlotReturn {                      // hands a finished (or failed) call's 
             slot_cache().push_back(std::move(sl));
         }
         slots->clear();
+    }
+};
+
+struct CtxReturn {
+    std::vector<std::unique_ptr<InflateCtx>>* ctx;
+    ~CtxReturn() {
+        std::lock_guard<std::mutex> g(slot_cache_m());
+        for (auto& c : *ctx) inflate_cache().push_back(std::move(c));
+        ctx->clear();
     }
 };
 
@@ -272,6 +326,9 @@ struct Run {
     std::mutex stat_m;
     double produce_s = 0, finish_s = 0, pack_s = 0, upload_s = 0, device_s = 0;
     Mapped fasta;
+    std::vector<std::unique_ptr<InflateCtx>> inflate_ctx;
+    Queue<InflateCtx*> free_ctx;
+    std::atomic<int64_t> device_inflated{0};
     std::mutex fai_m;
     std::map<std::string, FaiRec> fai;
 
@@ -288,6 +345,72 @@ struct Run {
         std::lock_guard<std::mutex> g(err_m);
         if (first_error.empty()) first_error = msg;
         failed = true;
+    }
+
+    // cto_pack_from_bam with the chunk's BGZF blocks inflated on the device (the sequence of include/clairsto_amd.h: chunk span ->
+    // scan -> inflate -> pile-up from memory).  *done = 0 with CTO_OK: nothing to send (no whole block in the span) - the caller reads
+    // the chunk on the host.
+    int pack_from_bam_device(const cto_chunk_job& j, const std::string& ctg, int64_t lo, int64_t hi, const std::vector<int64_t>& iv, Slot* s,
+                             InflateCtx* c, int* done) {
+        const bool timing = getenv("CTO_PIPE_TIMING") != nullptr;
+        const double T0 = now_s();
+        int64_t fb = 0, fe = 0;
+        int rc = cto_bam_chunk_span(j.bam_path, nullptr, ctg.c_str(), lo, hi, &fb, &fe);
+        if (rc != CTO_OK) return rc;
+        const size_t nbytes = fe > fb ? size_t(fe - fb) : 0;
+        if (nbytes == 0) return CTO_OK;
+        const size_t in_al = (nbytes + CTO_BGZF_PAD + 255) / 256 * 256;
+        size_t cap = nbytes / 2048 + 64;
+        if ((rc = c->h_in.ensure(in_al + cap * sizeof(cto_bgzf_block))) != CTO_OK) return rc;
+        {
+            const int fd = ::open(j.bam_path, O_RDONLY | O_CLOEXEC);
+            CTO_REQUIRE(fd >= 0, CTO_EINVAL, "cannot open %s", j.bam_path);
+            size_t got = 0;
+            while (got < nbytes) {
+                const ssize_t r = pread(fd, static_cast<char*>(c->h_in.p) + got, nbytes - got, off_t(fb) + off_t(got));
+                if (r <= 0) break;
+                got += size_t(r);
+            }
+            ::close(fd);
+            CTO_REQUIRE(got == nbytes, CTO_EINVAL, "short read from %s", j.bam_path);
+        }
+        const double T1 = now_s();
+        int64_t n = 0, out_bytes = 0;
+        for (;;) {
+            memset(static_cast<char*>(c->h_in.p) + nbytes, 0, in_al - nbytes);
+            n = cto_bgzf_scan(static_cast<const uint8_t*>(c->h_in.p), nbytes, fb, reinterpret_cast<cto_bgzf_block*>(static_cast<char*>(c->h_in.p) + in_al),
+                              int64_t(cap), &out_bytes);
+            if (n != CTO_ENOMEM || cap > (size_t(1) << 24)) break;
+            cap *= 8;                                              // many tiny blocks
+            if ((rc = c->h_in.grow_keeping(in_al + cap * sizeof(cto_bgzf_block), nbytes)) != CTO_OK) return rc;
+        }
+        if (n < 0) return int(n);
+        if (n == 0) return CTO_OK;
+        const auto* blocks = reinterpret_cast<const cto_bgzf_block*>(static_cast<char*>(c->h_in.p) + in_al);
+        const size_t tbl = size_t(n) * sizeof(cto_bgzf_block), out_al = (size_t(std::max<int64_t>(out_bytes, 256)) + 255) / 256 * 256;
+        if ((rc = c->d_in.ensure(in_al + tbl)) || (rc = c->d_out.ensure(out_al + size_t(n) * 4)) || (rc = c->h_out.ensure(out_al + size_t(n) * 4))) return rc;
+        const double T2 = now_s();
+        CTO_HIP(hipMemcpyAsync(c->d_in.p, c->h_in.p, in_al + tbl, hipMemcpyHostToDevice, c->stream));
+        if ((rc = cto_bgzf_inflate(c->d_in.p, reinterpret_cast<const cto_bgzf_block*>(static_cast<char*>(c->d_in.p) + in_al), int(n), c->d_out.p,
+                                   reinterpret_cast<int*>(static_cast<char*>(c->d_out.p) + out_al), c->stream)))
+            return rc;
+        CTO_HIP(hipMemcpyAsync(c->h_out.p, c->d_out.p, out_al + size_t(n) * 4, hipMemcpyDeviceToHost, c->stream));
+        CTO_HIP(hipEventRecord(c->landed, c->stream));
+        const double T3 = now_s();
+        CTO_HIP(wait_event(c->landed));
+        const double T4 = now_s();
+        const int* status = reinterpret_cast<const int*>(static_cast<char*>(c->h_out.p) + out_al);
+        for (int64_t b = 0; b < n; ++b)
+            CTO_REQUIRE(status[b] == 0, CTO_EINVAL, "%s: the BGZF block at file offset %llu does not inflate (status %d)", j.bam_path,
+                        (unsigned long long)blocks[b].file_off, status[b]);
+        rc = cto_pack_from_bam_inflated(j.bam_path, nullptr, ctg.c_str(), lo, hi, iv.empty() ? nullptr : iv.data(), int64_t(iv.size() / 2), s->ref.data(),
+                                        s->ref_start, s->ref.size(), 2316, 0, cfg->max_depth, cfg->max_indel_length,
+                                        static_cast<const uint8_t*>(c->h_out.p), size_t(out_bytes), blocks, n, &s->pack);
+        if (timing)
+            fprintf(stderr, "device inflate: %.1f MB in %lld blocks -> %.1f MB: read %.1f ms, scan + alloc %.1f, enqueue %.1f, on the device %.1f, pile-up %.1f\n",
+                    nbytes / 1e6, (long long)n, out_bytes / 1e6, (T1 - T0) * 1e3, (T2 - T1) * 1e3, (T3 - T2) * 1e3, (T4 - T3) * 1e3, (now_s() - T4) * 1e3);
+        if (rc == CTO_OK) { *done = 1; ++device_inflated; }
+        return rc;
     }
 
     // host half of a chunk + the upload; false = nothing to call in this chunk (no output) or an error (failed is set)
@@ -330,9 +453,16 @@ struct Run {
         } else {
             std::vector<int64_t> iv;
             bed_intervals(bed.p ? bed.p : "", bed.n, ctg, &iv);
-            rc = cto_pack_from_bam(j.bam_path, nullptr, ctg.c_str(), std::max<int64_t>(1, ctg_start - FLANK_POS), ctg_end + FLANK_POS,
-                                   iv.empty() ? nullptr : iv.data(), int64_t(iv.size() / 2), s->ref.data(), s->ref_start, s->ref.size(), 2316, 0,
-                                   cfg->max_depth, cfg->max_indel_length, &s->pack);
+            const int64_t lo = std::max<int64_t>(1, ctg_start - FLANK_POS), hi = ctg_end + FLANK_POS;
+            InflateCtx* c = nullptr;
+            int done = 0;
+            if (free_ctx.try_pop(&c)) {                            // a device-inflate context is free: this chunk's blocks go to the GPU
+                rc = pack_from_bam_device(j, ctg, lo, hi, iv, s, c, &done);
+                free_ctx.push(c);
+            }
+            if (!done && rc == CTO_OK)
+                rc = cto_pack_from_bam(j.bam_path, nullptr, ctg.c_str(), lo, hi, iv.empty() ? nullptr : iv.data(), int64_t(iv.size() / 2),
+                                       s->ref.data(), s->ref_start, s->ref.size(), 2316, 0, cfg->max_depth, cfg->max_indel_length, &s->pack);
         }
         if (rc != CTO_OK) { fail(cto_last_error()); return false; }
         if (cto_pack_view_of(s->pack, &s->hv) != CTO_OK) { fail(cto_last_error()); return false; }
@@ -417,7 +547,7 @@ struct Run {
     // alt_info strings, VCF records, file
     bool finish(Slot* s) {
         const cto_chunk_job& j = jobs[s->job];
-        if (hipEventSynchronize(s->done) != hipSuccess) { fail("hipEventSynchronize failed"); return false; }
+        if (wait_event(s->done) != hipSuccess) { fail("waiting for the chunk's results failed"); return false; }
         {
             float ms = 0;
             if (hipEventElapsedTime(&ms, s->begin, s->done) == hipSuccess) { std::lock_guard<std::mutex> g(stat_m); device_s += ms * 1e-3; }
@@ -533,9 +663,33 @@ extern "C" int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs,
         CTO_HIP(hipEventCreateWithFlags(&run.slots.back()->uploaded, hipEventDisableTiming));
         CTO_HIP(hipEventCreate(&run.slots.back()->begin));
         CTO_HIP(hipEventCreateWithFlags(&run.slots.back()->computed, hipEventDisableTiming));
-        CTO_HIP(hipEventCreate(&run.slots.back()->done));
+        CTO_HIP(hipEventCreateWithFlags(&run.slots.back()->done, hipEventBlockingSync));      // writers sleep, not spin, until their chunk is back
     }
     for (auto& sl : run.slots) run.free_slots.push(sl.get());
+    // device-inflate contexts (BAM jobs only), kept across calls like the slots
+    CtxReturn ctx_back{&run.inflate_ctx};
+    bool any_bam = false;
+    for (int64_t i = 0; i < n_jobs; ++i) any_bam = any_bam || !jobs[i].mpileup_path;
+    if (any_bam && cfg->inflate_cus > 0 && cfg->inflate_jobs > 0) {
+        const int cus = std::min(cfg->inflate_cus, 256);
+        {
+            std::lock_guard<std::mutex> g(slot_cache_m());
+            auto& cache = inflate_cache();
+            for (size_t i = 0; i < cache.size() && int(run.inflate_ctx.size()) < cfg->inflate_jobs;)
+                if (cache[i]->device == dev && cache[i]->cus == cus) {
+                    run.inflate_ctx.push_back(std::move(cache[i]));
+                    cache.erase(cache.begin() + long(i));
+                } else {
+                    ++i;
+                }
+        }
+        while (int(run.inflate_ctx.size()) < cfg->inflate_jobs) {
+            run.inflate_ctx.emplace_back(new InflateCtx());
+            const int rc0 = run.inflate_ctx.back()->open(dev, cus);
+            if (rc0 != CTO_OK) return rc0;
+        }
+        for (auto& c : run.inflate_ctx) run.free_ctx.push(c.get());
+    }
     hipStream_t main = static_cast<hipStream_t>(stream);
     hipStream_t copy_back = nullptr;
     CTO_HIP(hipStreamCreateWithFlags(&copy_back, hipStreamNonBlocking));
@@ -617,6 +771,7 @@ extern "C" int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs,
         stats->pack_s = run.pack_s;
         stats->upload_s = run.upload_s;
         stats->device_s = run.device_s;
+        stats->device_inflated = run.device_inflated;
         stats->launch_s = launch_s;
         stats->launcher_wait_s = wait_s;
         stats->finish_s = run.finish_s;
@@ -630,15 +785,21 @@ extern "C" int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs,
 
 extern "C" int cto_run_release(void) {
     std::vector<std::unique_ptr<Slot>> drop;
+    std::vector<std::unique_ptr<InflateCtx>> drop_ctx;
     {
         std::lock_guard<std::mutex> g(slot_cache_m());
         drop.swap(slot_cache());
+        drop_ctx.swap(inflate_cache());
     }
     int cur = 0;
     CTO_HIP(hipGetDevice(&cur));
     for (auto& sl : drop) {
         CTO_HIP(hipSetDevice(sl->device));
         sl.reset();
+    }
+    for (auto& c : drop_ctx) {
+        CTO_HIP(hipSetDevice(c->device));
+        c.reset();
     }
     CTO_HIP(hipSetDevice(cur));
     return CTO_OK;

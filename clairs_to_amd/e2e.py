@@ -41,7 +41,7 @@ def build_run(d, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, reg
         region_kb, os.path.getsize(run["bam_fn"]) / 1e6, len(run["chunks"]))
 
 
-def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4, bam_reader="native", pipeline="python"):
+def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4, bam_reader="native", pipeline="python", inflate_cus=None, inflate_jobs=None):
     """the pipeline over a prepared run directory -> dict(sites_per_s, ...); best of `repeats` passes (the first one warms the page
     cache, the pinned buffers and the model workspaces)"""
     from .call_chunks import default_producers, run_pipeline, run_pipeline_native
@@ -54,7 +54,8 @@ def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4, bam_
         ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         if pipeline == "native":
-            rows = run_pipeline_native(eng, chunk_args, producers=producers, writers=writers, stats=stats, verbose=False)
+            rows = run_pipeline_native(eng, chunk_args, producers=producers, writers=writers, stats=stats, verbose=False,
+                                       inflate_cus=inflate_cus, inflate_jobs=inflate_jobs)
         else:
             rows = run_pipeline(eng, chunk_args, producers=producers, writers=writers, stats=stats)
         dt = time.perf_counter() - t0
@@ -64,9 +65,10 @@ def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4, bam_
             host = dict(user_cpu_ms_per_chunk=round((ru1.ru_utime - ru0.ru_utime) * 1e3 / max(1, len(chunk_args)), 2),
                         sys_cpu_ms_per_chunk=round((ru1.ru_stime - ru0.ru_stime) * 1e3 / max(1, len(chunk_args)), 2),
                         minor_faults_per_chunk=int((ru1.ru_minflt - ru0.ru_minflt) / max(1, len(chunk_args))))
+    extra = {k: int(best_stats[k]) for k in ("device_inflated",) if k in best_stats}
     per_chunk = {k[:-2] + "_ms_per_chunk": round(v * 1e3 / max(1, len(chunk_args)), 3) for k, v in best_stats.items() if k.endswith("_s")}
     return dict(sites_per_s=round(run["n_sites"] / best, 1), sites=int(run["n_sites"]), chunks=len(chunk_args), seconds=round(best, 4),
-                producers=producers, writers=writers, pipeline=pipeline, vcf_records=int(rows), stage_thread_time=per_chunk, host_process=host,
+                producers=producers, writers=writers, pipeline=pipeline, vcf_records=int(rows), stage_thread_time=per_chunk, host_process=host, **extra,
                 includes="disk reads, tokenise / BAM decode, PCIe both ways, kernels, alt_info + VCF rows (C), file writes")
 
 

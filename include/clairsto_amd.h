@@ -327,6 +327,10 @@ typedef struct cto_run_cfg {
     const char* vcf_header;     /* everything before the first record, incl. the #CHROM line                    */
     int    producers, writers;  /* threads (>= 1)                                                               */
     int    depth;               /* chunks in flight (0: producers + writers + 2); each holds a pack on both sides */
+    int    inflate_cus;         /* BAM input: > 0 = up to inflate_jobs chunks at a time have their BGZF blocks inflated on the device
+                                   (cto_bgzf_inflate) on streams confined to the first inflate_cus compute units, the others on the
+                                   host cores as cto_pack_from_bam does; 0 = host only.  Same packs either way.               */
+    int    inflate_jobs;
 } cto_run_cfg;
 typedef struct cto_run_stats {
     int64_t candidates;                                /* candidate positions read from the BED chunks           */
@@ -336,6 +340,7 @@ typedef struct cto_run_stats {
     double  launch_s, launcher_wait_s;                 /* the calling thread: launching, waiting for a producer */
     double  pack_s, upload_s;                          /* parts of produce_s: tokenising / BAM decoding, host-to-device copies */
     double  device_s;                                  /* HIP-event time from a chunk's first kernel to its last copy, summed    */
+    int64_t device_inflated;                           /* BAM chunks whose blocks were inflated on the device                    */
 } cto_run_stats;
 int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs, int64_t n_jobs, void* stream, cto_run_stats* stats);
 /* cto_run_chunks keeps its per-chunk buffers (device, page-locked host, events) for the next call on the same device; this

@@ -362,6 +362,16 @@ def test_native_pipeline_writes_the_same_files(tmp_path, source, mode, aff_cls, 
     for fn in names:
         assert open(tmp_path / "py" / fn, "rb").read() == open(tmp_path / "nat" / fn, "rb").read(), fn
     # again on the same handle (slots, streams and buffers are per call), with one producer and a pipeline depth of one
+    if source == "bam":
+        # the default run above had some chunks' BGZF blocks inflated on the device (call_chunks.DEVICE_INFLATE); here every chunk is
+        # inflated on the host cores, then two at a time on the device with the streams confined to 64 CUs - the same files each time
+        assert st_nat["device_inflated"] >= 1
+        for kw in (dict(inflate_cus=0), dict(inflate_cus=64, inflate_jobs=2)):
+            st_dev = {}
+            assert run_pipeline_native(eng, a_nat, producers=3, writers=2, stats=st_dev, verbose=False, **kw) == n_py
+            assert (st_dev["device_inflated"] == 0) if kw["inflate_cus"] == 0 else (1 <= st_dev["device_inflated"] <= len(parts))
+            for fn in names:
+                assert open(tmp_path / "py" / fn, "rb").read() == open(tmp_path / "nat" / fn, "rb").read(), fn
     from clairs_to_amd._lib import lib
     assert lib.cto_run_release() == 0           # the buffers kept from the first call are dropped; the next call allocates its own
     assert run_pipeline_native(eng, a_nat, producers=1, writers=1, depth=1, verbose=False) == n_py

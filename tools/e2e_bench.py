@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--writers", default="2")
     ap.add_argument("--bam-reader", default="native", help="native (host inflate) or gpu (device inflate), comma separated")
     ap.add_argument("--pipeline", default="python", help="python (call_chunks.run_pipeline) and / or native (cto_run_chunks), comma separated")
+    ap.add_argument("--inflate-cus", default="160", help="BAM + native pipeline: compute units the device inflate is confined to (0 = host inflate only), comma separated")
+    ap.add_argument("--inflate-jobs", default="6", help="chunks in flight through the device inflate, comma separated")
     ap.add_argument("--pack-threads", default=None, help="CTO_PACK_THREADS values for the C producers, comma separated (default: their own, <= 32)")
     a = ap.parse_args()
     import torch
@@ -47,8 +49,12 @@ def main():
                     if pl == "native" and br == "gpu":
                         continue
                     for p in [int(x) for x in a.producers.split(",")]:
-                        r = time_run(eng, run, kind, os.path.join(d, "vcf_%s" % kind), producers=p, writers=w, bam_reader=br, pipeline=pl)
-                        r.update(kind=kind, pack_threads=pt or "auto", bam_reader=br)
+                      dev_inflate = kind == "bam" and pl == "native"
+                      for cus in ([int(x) for x in a.inflate_cus.split(",")] if dev_inflate else [0]):
+                       for ij in ([int(x) for x in a.inflate_jobs.split(",")] if (dev_inflate and cus) else [0]):
+                        r = time_run(eng, run, kind, os.path.join(d, "vcf_%s" % kind), producers=p, writers=w, bam_reader=br, pipeline=pl,
+                                     inflate_cus=cus, inflate_jobs=ij)
+                        r.update(kind=kind, pack_threads=pt or "auto", bam_reader=br, inflate_cus=cus, inflate_jobs=ij)
                         r.pop("includes")
                         print(json.dumps(r), flush=True)
     finally:
