@@ -19,9 +19,10 @@
 //     chunks a second.  With 4 KB of LDS per wave, six waves per SIMD take turns on that chain.
 // Measured on MI355X (tools/inflate_bench.py, a 1 Mb x 50x chunk: 77 MB of BAM in 1776 blocks -> 115 MB): 20 ms for one launch
 // alone (15 ms with the literal stores taken out: the decode chain, not memory, is the cost), 8 ms per chunk with 4-8 launches in
-// flight = 14 GB/s of inflated bytes, about what 20 host cores of libdeflate deliver.  That is NOT yet a gain end to end: the
-// box has 16 cores, the launches compete with the network kernels for the CUs, and the file-to-file rate through this reader is
-// 0.10-0.14 M sites/s against 0.21-0.29 M with the host reader.
+// flight = 14 GB/s of inflated bytes, about what 20 host cores of libdeflate deliver.  It pays beside the host cores, not instead
+// of them: the chunk pipeline (pipeline.hip) sends some chunks through it on streams confined to part of the CUs - unconfined, the
+// waves of a launch sit on every CU for tens of milliseconds and the networks' block kernels wait for them - and BAM -> VCF goes
+// from 240 k sites/s (16 host cores) to 337-368 k.
 // Where a block's 40 M cycles go (s_memtime stamps, a 65 000-byte block of BAM records = 21.6 k literals + 12.7 k matches of 3.4
 // bytes on average): a link of the decode chain is ~80 scalar-unit and lane-0 instructions with a dozen taken branches, and a
 // single wave issues such code at 10-16 cycles per instruction - 1.3 k cycles per symbol, where a host core needs ~10.  Tried on
