@@ -685,8 +685,11 @@ extern "C" int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs,
         }
         while (int(run.inflate_ctx.size()) < cfg->inflate_jobs) {
             run.inflate_ctx.emplace_back(new InflateCtx());
-            const int rc0 = run.inflate_ctx.back()->open(dev, cus);
-            if (rc0 != CTO_OK) return rc0;
+            if (run.inflate_ctx.back()->open(dev, cus) != CTO_OK) {           // no CU-masked streams on this runtime: host inflate only
+                if (cfg->verbose) fprintf(stderr, "[WARNING] device inflate disabled: %s\n", cto_last_error());
+                run.inflate_ctx.clear();
+                break;
+            }
         }
         for (auto& c : run.inflate_ctx) run.free_ctx.push(c.get());
     }
