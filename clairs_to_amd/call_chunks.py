@@ -67,20 +67,22 @@ def default_producers(native_bam, pipeline="python"):
     """pack-producer threads per rank: a quarter of the usable cores for mpileup text (the tokeniser saturates memory bandwidth early),
     half of them for the native BAM reader on the Python pipeline (inflate-bound, and its per-call serial parts - index, header,
     merge - want more calls in flight: 8 producers x 8 threads gave 280 k sites/s on 16 cores where 4 x 8 gave 218 k).  The C
-    pipeline runs three BAM producers per two usable cores with two decoding threads each (pack_threads()): a call split over 8
-    threads decodes the long reads that straddle its 7 inner boundaries twice - 320 ms of CPU per 1 Mb x 50x chunk against 243 ms
+    pipeline runs one BAM producer per usable core with two decoding threads each (pack_threads()): a call split over 8 threads
+    decodes the long reads that straddle its 7 inner boundaries twice - 320 ms of CPU per 1 Mb x 50x chunk against 243 ms
     unsplit - and 16 x 2 measured 264 k sites/s where 8 x 8 gave 205 k; with DEVICE_INFLATE chunks in flight through the device
-    inflate (their producers asleep meanwhile) 24 x 2 measured 350-368 k."""
+    inflate (their producers asleep meanwhile) 16 x 2 measured 348-370 k.  (24 x 2 gave 350-368 k on one box and 190-280 k on
+    another: with more runnable threads than cores the chunks that wait for the device come back to a busy host.)"""
     if native_bam and pipeline == "native":
-        return max(1, min(48, usable_cores() * 3 // 2))     # a third of them sleep while their chunk is inflated on the device
+        return max(1, min(32, usable_cores()))
     return max(1, min(16, usable_cores() // (2 if native_bam else 4)))
 
 
 # BAM chunks on the C pipeline: up to DEVICE_INFLATE[1] chunks at a time have their BGZF blocks inflated on the GPU, on streams confined to
 # DEVICE_INFLATE[0] of its 256 compute units (the networks keep the rest; they need a fifth of the GPU at BAM rates), the others on the
-# host cores.  Measured on 64 chunk files, 16 usable cores (sites/s): host only 240-243 k; 128 CUs x 4 / 6 / 8 chunks 337-354 k; 192 CUs x 6 / 8
-# 345-368 k; 240 CUs or 12+ chunks in flight 155-290 k (the networks starve: 8-12 ms of device time per chunk instead of 2.5).
-DEVICE_INFLATE = (160, 6)
+# host cores.  Measured on 64 chunk files, 16 usable cores, 16 producers (sites/s, profiles/round2_d_bam_hybrid.txt): host only 250 k;
+# 128 CUs x 4 / 6 / 8 chunks 348 / 314 / 262 k; 160 CUs 370 / 362 / 277 k; 192 CUs 158-240 k in that run (345-368 k in another);
+# 240 CUs or 12+ chunks in flight 155-290 k (the networks starve: 8-12 ms of device time per chunk instead of 2.5).
+DEVICE_INFLATE = (160, 4)
 
 
 def pack_threads(native_bam, pipeline="python"):
