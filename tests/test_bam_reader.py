@@ -232,3 +232,47 @@ def test_pack_from_bam_is_invariant_to_the_thread_count(tmp_path, monkeypatch):
         for bedded in (False, True):
             _assert_same(packs[nt][bedded], packs["1"][bedded])
     assert len(packs["1"][False]["col_pos"]) > 40000 and len(packs["1"][True]["col_pos"]) > 15000
+
+
+def test_chunk_span_is_tight_and_sufficient(tmp_path):
+    """cto_bam_chunk_span (what is sent to the device inflate for a chunk): the byte range must be cut near the first alignment that
+    starts after the region - not run to the end of the coarse bins' chunk lists - and still hold every block the pile-up needs:
+    the blocks of the span, inflated here with zlib and handed to cto_pack_from_bam_inflated, give the pack cto_pack_from_bam reads."""
+    import ctypes as C
+    import os
+    import zlib
+    from clairs_to_amd._lib import check, lib
+    from clairs_to_amd.bgzf import BGZF_PAD, scan
+    from clairs_to_amd.pack import ColumnPack
+    from clairs_to_amd.synth_run import make_bam_run
+    run = make_bam_run(str(tmp_path / "run"), region_kb=600, n_chunks=6, depth=12)
+    bam = run["bam_fn"]
+    fsize = os.path.getsize(bam)
+    ref = open(run["ref_fn"]).read().split("\n", 1)[1].replace("\n", "")
+    for lo, hi in ((100_001, 200_000), (1, 50_000), (550_001, 600_000), (299_000, 301_000)):
+        fb, fe = C.c_int64(0), C.c_int64(0)
+        check(lib.cto_bam_chunk_span(bam.encode(), None, b"chr1", lo, hi, C.byref(fb), C.byref(fe)))
+        nbytes = fe.value - fb.value
+        # reads are <= 30 kb long: the blocks needed are those of alignments starting in [lo - 30 kb, hi]; a block more on each side is allowed
+        assert 0 < nbytes <= fsize * ((hi - lo) + 80_000) / 600_000 + 3 * 65536, (lo, hi, nbytes, fsize)
+        raw = np.zeros(nbytes + BGZF_PAD, dtype=np.uint8)
+        with open(bam, "rb") as f:
+            f.seek(fb.value)
+            raw[:nbytes] = np.frombuffer(f.read(nbytes), dtype=np.uint8)
+        blocks, out_bytes = scan(raw, nbytes, fb.value)
+        inflated = np.zeros(max(out_bytes, 256), dtype=np.uint8)
+        for b in blocks:
+            data = zlib.decompress(raw[int(b["in_off"]):int(b["in_off"]) + int(b["csize"])].tobytes(), -15)
+            assert len(data) == int(b["isize"])
+            inflated[int(b["out_off"]):int(b["out_off"]) + len(data)] = np.frombuffer(data, dtype=np.uint8)
+
+        class Host:                      # what pack.from_bam expects of the page-locked tensor
+            def __init__(self, a): self.a = a
+            def data_ptr(self): return self.a.ctypes.data
+            def numel(self): return self.a.size
+        p_want = ColumnPack.from_bam(bam, "chr1", lo, hi, ref, 1)                 # numpy() gives views: the packs have to stay alive
+        p_got = ColumnPack.from_bam(bam, "chr1", lo, hi, ref, 1, inflated=(Host(inflated), blocks))
+        want, got = p_want.numpy(), p_got.numpy()
+        assert want["entries"].size > 1000
+        for k in want:
+            np.testing.assert_array_equal(got[k], want[k], err_msg="%s %d-%d" % (k, lo, hi))
