@@ -1,15 +1,18 @@
 // Native chunk pipeline: candidate chunk files + pileup source (mpileup text or BAM) -> p_<chunk>.vcf, the whole of what
-// pileup_call.prepare_chunk / launch_chunk / finish_chunk do per chunk, without the interpreter in the loop.
+// pileup_call.prepare_chunk / launch_chunk / finish_chunk do per chunk, as one C call (cto_run_chunks).
 //
-//   producers (N threads)  BED -> centres, reference slice (.fai), column pack (tokeniser / BAM reader), upload on the producer's
-//                          own stream into the device buffers of a free slot
+//   producers (N threads)  BED -> centres, reference slice (.fai), column pack (tokeniser / BAM reader; for some BAM chunks with the
+//                          BGZF blocks inflated on the device, InflateCtx), one upload out of a page-locked staging buffer on the
+//                          producer's own stream into the device buffers of a free slot
 //   launcher (the caller)  waits for the upload event; featurisation, both networks, posterior; the candidates' column vectors
-//                          gathered on the device; asynchronous copies into the slot's page-locked buffers; an event
+//                          gathered on the device; one copy of everything the writers need on the copy-back stream; an event
 //   writers (M threads)    alt_info strings + every VCF record (two C calls), file write; the slot goes back to the pool
 //
-// The Python pipeline (call_chunks.run_pipeline) does the same with the same C calls, but its launcher, its BED / FASTA / file
-// handling and the glue between the calls hold the interpreter lock: it levels off at ~290 chunks a second (1.1-1.2 M sites/s
-// from text) on a GPU that needs 2 ms per chunk.  Outputs are byte-identical (tests/test_gpu_cli.py).
+// The Python pipeline (call_chunks.run_pipeline) runs the same stages with the same C calls on thread pools.  Moving the loop here did
+// not by itself change the rate (the interpreter was not the bound); what did was what the loop can own once it is native: the
+// staging buffers the tokeniser merges into, buffers and contexts kept from chunk to chunk and from call to call, waits that sleep
+// instead of spinning, CU-masked streams for the device inflate (DESIGN.md section 6 has the sequence of measurements).
+// Outputs are byte-identical (tests/test_gpu_cli.py).
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <fcntl.h>
@@ -128,7 +131,7 @@ struct Slot {
 struct InflateCtx {
     int device = 0, cus = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t landed = nullptr;         // blocking-sync: the producer thread sleeps while its chunk is on the device
+    hipEvent_t landed = nullptr;         // recorded behind the copy back; the producer thread sleeps on it (wait_event)
     PinBuf h_in, h_out;
     DevBuf d_in, d_out;
     int open(int dev, int n_cus) {
