@@ -66,10 +66,14 @@ struct Bits {                     // wave-uniform bit reader over dwords of glob
     int wbase, widx;              // dword index of win's lane 0; next dword to hand out
     uint64_t bb;                  // bit buffer, next bit = bit 0
     int cnt;                      // valid bits in bb
-    long long used;               // bits consumed so far (relative to src + first_bit)
+    int skip;                     // bits of the first dword that precede the stream
+    int limit;                    // last dword index that may be handed out; beyond it the stream reads as zeros and `over` is set
+    int over;
 };
+// bits consumed so far: what was handed out minus what is still buffered (kept out of bits_drop: two scalar instructions per symbol)
+__device__ __forceinline__ long long bits_used(const Bits& b) { return (long long)b.widx * 32 - b.cnt - b.skip; }
 
-__device__ __forceinline__ void bits_init(Bits& b, const uint8_t* p, int lane) {
+__device__ __forceinline__ void bits_init(Bits& b, const uint8_t* p, long long in_bits, int lane) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
     b.src = reinterpret_cast<gdword_ptr>(a & ~uintptr_t(3));
     b.wbase = 0;
@@ -77,8 +81,10 @@ __device__ __forceinline__ void bits_init(Bits& b, const uint8_t* p, int lane) {
     b.win = b.src[lane];
     b.bb = 0;
     b.cnt = 0;
-    b.used = 0;
+    b.over = 0;
     const int skip = int(a & 3) * 8;       // bits of the first dword that precede the stream
+    b.skip = skip;
+    b.limit = int((skip + in_bits + 31) / 32) + 2;      // a decoder that runs ahead of a valid stream never needs more
     // first refill, then drop the leading bits
     b.bb = uint64_t(rl(b.win, 0)) | (uint64_t(rl(b.win, 1)) << 32);
     b.widx = 2;
@@ -87,19 +93,25 @@ __device__ __forceinline__ void bits_init(Bits& b, const uint8_t* p, int lane) {
 }
 __device__ __forceinline__ void bits_refill(Bits& b, int lane) {
     if (b.cnt <= 32) {
-        if (b.widx - b.wbase >= 64) {
-            b.wbase += 64;
-            b.win = b.src[b.wbase + lane];
-            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) HERE, once per 256 bytes: otherwise the compiler waits where the two
-        }                                            // paths meet, i.e. on every refill, and each wait also drains the byte stores
-        const uint32_t d = rl(b.win, b.widx - b.wbase);
+        uint32_t d = 0;
+        if (b.widx <= b.limit) {
+            if (b.widx - b.wbase >= 64) {
+                b.wbase += 64;
+                b.win = b.src[b.wbase + lane];
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) HERE, once per 256 bytes: otherwise the compiler waits where the two
+                                                     // paths meet, i.e. on every refill, and each wait also drains the byte stores
+            }
+            d = rl(b.win, b.widx - b.wbase);
+        } else {
+            b.over = 1;                              // malformed: the stream wants more than its payload holds; zeros from here on,
+        }                                            // no load past the padding - every loop ends on its output bound
         b.bb |= uint64_t(d) << b.cnt;
         b.cnt += 32;
         ++b.widx;
     }
 }
 __device__ __forceinline__ uint32_t bits_peek(const Bits& b, int n) { return uint32_t(b.bb) & ((1u << n) - 1u); }
-__device__ __forceinline__ void bits_drop(Bits& b, int n) { b.bb >>= n; b.cnt -= n; b.used += n; }
+__device__ __forceinline__ void bits_drop(Bits& b, int n) { b.bb >>= n; b.cnt -= n; }
 
 struct Huff {                     // per lane L: the codes of length L (lanes 1..15); sorted symbols: entry i in register i / 64, lane i % 64
     uint32_t first, count, offset;
@@ -166,9 +178,10 @@ __device__ __forceinline__ int huff_decode(const Huff& h, uint32_t bits32, int l
     return int(v);
 }
 
-// Lookup table of the codes of up to TB bits: entry[next TB bits of the stream] = symbol | length << 9 (0: a longer code).
+// Lookup table of the codes of up to TB bits: entry[next TB bits of the stream] = symbol | length << 9 (0: a longer code); with
+// LITFLAG bit 15 marks the symbols below 256, so that the literal loop tests one bit.
 // `fo`: scratch for first[16] | offset[16].  sorted[] / lens[] as left by huff_build.
-template <int TB>
+template <int TB, bool LITFLAG = false>
 __device__ void huff_table(const Huff& h, const uint8_t* lens, const uint16_t* sorted, uint32_t* fo, uint16_t* table, int lane) {
     if (lane < 16) { fo[lane] = h.first; fo[16 + lane] = h.offset; }
     for (int i = lane; i < (1 << TB); i += 64) table[i] = 0;
@@ -181,7 +194,7 @@ __device__ void huff_table(const Huff& h, const uint8_t* lens, const uint16_t* s
         if (len <= uint32_t(TB)) {
             const uint32_t code = fo[len] + (uint32_t(i) - fo[16 + len]);
             const uint32_t rev = __brev(code) >> (32 - len);
-            const uint16_t e = uint16_t(sym | (len << 9));
+            const uint16_t e = uint16_t(sym | (len << 9) | ((LITFLAG && sym < 256) ? 0x8000u : 0u));
             for (uint32_t k = rev; k < (1u << TB); k += (1u << len)) table[k] = e;
         }
     }
@@ -191,7 +204,7 @@ __device__ void huff_table(const Huff& h, const uint8_t* lens, const uint16_t* s
 template <int NREG, int TB>
 __device__ __forceinline__ int huff_decode_fast(const Huff& h, const uint16_t* table, uint32_t bits32, int lane, int* len) {
     const uint32_t e = uint32_t(__builtin_amdgcn_readfirstlane(int(table[bits32 & ((1u << TB) - 1u)])));
-    if (e != 0) { *len = int(e >> 9); return int(e & 511u); }
+    if (e != 0) { *len = int((e >> 9) & 15u); return int(e & 511u); }
     return huff_decode<NREG>(h, bits32, lane, len);
 }
 
@@ -220,7 +233,7 @@ extern "C" __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* _
 
     if (isize > 0) {
         Bits b;
-        bits_init(b, comp + bd.in_off, lane);
+        bits_init(b, comp + bd.in_off, in_bits, lane);
         Huff hl, hd;
         bool final_block = false;
         while (!final_block && st == ST_OK) {
@@ -229,7 +242,7 @@ extern "C" __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* _
             const int btype = int(bits_peek(b, 3) >> 1);
             bits_drop(b, 3);
             if (btype == 0) {                                    // stored
-                bits_drop(b, int((8 - (b.used & 7)) & 7));
+                bits_drop(b, int((8 - (bits_used(b) & 7)) & 7));
                 bits_refill(b, lane);
                 const uint32_t len = bits_peek(b, 16);
                 bits_drop(b, 16);
@@ -238,7 +251,7 @@ extern "C" __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* _
                 bits_drop(b, 16);
                 if ((len ^ nlen) != 0xffffu) { st = ST_BAD_STORED; break; }
                 if (op + int(len) > isize) { st = ST_OVERRUN_OUT; break; }
-                if (b.used + (long long)len * 8 > in_bits + 64) { st = ST_OVERRUN_IN; break; }     // before the copy loop reads on
+                if (bits_used(b) + (long long)len * 8 > in_bits + 64) { st = ST_OVERRUN_IN; break; }     // before the copy loop reads on
                 for (uint32_t i = 0; i < len; ++i) {
                     bits_refill(b, lane);
                     const uint32_t v = bits_peek(b, 8);
@@ -246,7 +259,7 @@ extern "C" __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* _
                     if (lane == 0) dst[op] = uint8_t(v);
                     ++op;
                 }
-                if (b.used > in_bits + 64) { st = ST_OVERRUN_IN; break; }
+                if (b.over || bits_used(b) > in_bits + 64) { st = ST_OVERRUN_IN; break; }
                 continue;
             }
             if (btype == 3) { st = ST_BAD_BTYPE; break; }
@@ -296,7 +309,7 @@ extern "C" __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* _
                     if (lane + 128 < rep) lens[i + lane + 128] = uint8_t(val);
                     i += rep;
                     prev = val;
-                    if (b.used > in_bits + 64) st = ST_OVERRUN_IN;
+                    if (b.over || bits_used(b) > in_bits + 64) st = ST_OVERRUN_IN;
                 }
                 if (st != ST_OK) break;
                 __builtin_amdgcn_s_waitcnt(0);
@@ -312,18 +325,30 @@ extern "C" __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* _
             __builtin_amdgcn_s_waitcnt(0);
             __builtin_amdgcn_wave_barrier();
             if (!huff_build<5>(hl, lens, 288, sorted, lane)) { st = ST_BAD_TABLE; break; }
-            huff_table<TBL>(hl, lens, sorted, fo, tab_l, lane);
+            huff_table<TBL, true>(hl, lens, sorted, fo, tab_l, lane);
             huff_build<1>(hd, lens + 288, 30, sorted, lane);     // an incomplete distance code is legal (one code, or none)
             huff_table<TBD>(hd, lens + 288, sorted, fo, tab_d, lane);
 
             // ---- symbols ----
             for (;;) {
+                // Literal run: a table hit with the literal flag is a byte store (all lanes store the same byte to the same address:
+                // one transaction, no exec-mask juggling) and a shift.  This loop is two thirds of all symbols of a BAM block and is
+                // kept free of everything the other symbols need (the general form below cost ~50 instructions per literal in
+                // compiler-made copies and checks; a single wave issues them one at a time).
+                for (;;) {
+                    bits_refill(b, lane);
+                    const uint32_t e = uint32_t(__builtin_amdgcn_readfirstlane(int(tab_l[uint32_t(b.bb) & ((1u << TBL) - 1u)])));
+                    if (!(e & 0x8000u) || op >= isize) break;
+                    dst[op] = uint8_t(e);
+                    ++op;
+                    bits_drop(b, int((e >> 9) & 15u));
+                }
                 bits_refill(b, lane);
                 int l = 0;
                 const int s = huff_decode_fast<5, TBL>(hl, tab_l, uint32_t(b.bb), lane, &l);
                 if (s < 0) { st = ST_BAD_CODE; break; }
                 bits_drop(b, l);
-                if (b.used > in_bits + 64) { st = ST_OVERRUN_IN; break; }
+                if (b.over || bits_used(b) > in_bits + 64) { st = ST_OVERRUN_IN; break; }
                 if (s < 256) {
                     if (op >= isize) { st = ST_OVERRUN_OUT; break; }
                     if (lane == 0) dst[op] = uint8_t(s);
@@ -348,9 +373,11 @@ extern "C" __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* _
                     bits_drop(b, de);
                     if (d > op) { st = ST_BAD_DIST; break; }
                     if (op + n > isize) { st = ST_OVERRUN_OUT; break; }
+                    const int from = op - d;
+                    // Waiting only when the source bytes can still be in flight (two thirds of a BAM block's matches reach more than
+                    // 2 KB back) was measured and bought nothing: the wait for the window load itself is a vmcnt(0), stores included.
                     __builtin_amdgcn_s_waitcnt(0);               // every earlier store of this wave has reached L2
                     __builtin_amdgcn_wave_barrier();
-                    const int from = op - d;
                     // all source bytes lie before `op`: the (k mod d) form reads the repeating pattern of an overlapping copy from
                     // its first period, so no lane depends on a byte another lane writes in this copy
                     for (int k = lane; k < n; k += 64) {
