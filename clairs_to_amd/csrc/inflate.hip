@@ -19,7 +19,8 @@
 //     chunks a second.  With 4 KB of LDS per wave, six waves per SIMD take turns on that chain.
 // Measured on MI355X (tools/inflate_bench.py, a 1 Mb x 50x chunk: 77 MB of BAM in 1776 blocks -> 115 MB): 20 ms for one launch
 // alone (15 ms with the literal stores taken out: the decode chain, not memory, is the cost), 8 ms per chunk with 4-8 launches in
-// flight = 14 GB/s of inflated bytes, about what 20 host cores of libdeflate deliver.  It pays beside the host cores, not instead
+// flight = 14 GB/s of inflated bytes (6.2 ms = 18.5 GB/s after the literal loop below), about what 20-25 host cores of libdeflate
+// deliver.  It pays beside the host cores, not instead
 // of them: the chunk pipeline (pipeline.hip) sends some chunks through it on streams confined to part of the CUs - unconfined, the
 // waves of a launch sit on every CU for tens of milliseconds and the networks' block kernels wait for them - and BAM -> VCF goes
 // from 240 k sites/s (16 host cores) to 337-368 k.
@@ -29,6 +30,14 @@
 // top and dropped: a 16 KiB LDS ring for near matches (the copy itself was not the cost; fewer waves per CU: 14-18 ms per chunk);
 // literal runs decoded by all lanes at once (lane i looks up the symbol at bit offset i, a scalar walk follows the chain: correct,
 // but BAM records break the run every 1.7 literals: 9.9 ms).  A device decoder that beats the host needs one block per LANE.
+// Later in the round, with 8 launches in flight (ms per chunk; 7.0 at that point): a literal loop of its own - table hit with a
+// literal flag, all-lanes byte store, shift; the bit count derived from the reader's position instead of updated per symbol; the
+// input bound checked where a dword is handed out - 6.2 (kept: ~27 instructions per literal instead of ~50).  8 instead of 7 waves
+// per SIMD (63 VGPRs): no change - the launches are latency-, not occupancy-bound.  Skipping the store drain for matches that
+// reach behind the last known-drained output position (two thirds reach more than 2 KB back): no change - waiting for the
+// window load is a vmcnt(0), stores included.  Matches loaded into LDS slots with global_load_lds_ubyte and stored eight
+// matches later under one wait (the window of 7 000 resident waves does not stay in the L2s; a source byte is a microsecond
+// away and nothing downstream in the stream needs it): 8.7, slower, and not pursued to correctness.
 // Every loop is bounded by the block's compressed size (a symbol consumes at least one bit) or by constants; malformed input
 // ends with a status code, never with a hang or an out-of-range access (the input buffer carries CTO_BGZF_PAD bytes of padding,
 // every output slot is padded to 256 bytes).
