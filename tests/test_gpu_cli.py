@@ -403,6 +403,33 @@ def test_native_pipeline_large_text_chunks(tmp_path):
         assert open(tmp_path / "py" / fn, "rb").read() == open(tmp_path / "nat" / fn, "rb").read(), fn
 
 
+def test_native_pipeline_illumina_min_bq(tmp_path):
+    """ilmn with an explicit --min_bq: the NEG network reads the AFF pass's tensors (run_clairs_to:1248-1252; cto_run_cfg.neg_reads_aff),
+    the AFF gate is the option's value - the C pipeline and the Python pipeline must agree on that too (indel mode, BAM input)."""
+    from argparse import Namespace
+    from clairs_to_amd.call_chunks import run_pipeline, run_pipeline_native
+    from clairs_to_amd.pileup_call import make_engine
+    from clairs_to_amd.synth import likelihood_table
+    sc = _bam_scenario(tmp_path)
+    paths = _pickle_models(tmp_path, "CvT_Indel", "BiGRU_NACGT_Indel", 6)
+    lik = tmp_path / "lik.txt"
+    np.savetxt(lik, likelihood_table(6, seed=11), fmt="%.17g")
+
+    def args(out):
+        os.makedirs(tmp_path / out, exist_ok=True)
+        return [Namespace(platform="ilmn", ref_fn=sc["fa"], ctg_name="chr1", samtools="samtools", bam_reader="native", tumor_bam_fn=sc["bam"],
+                          mpileup_fn=None, min_bq=12, max_depth=None, max_indel_length=None, candidates_bed_regions=sc["bed"],
+                          chkpnt_fn_acgt=paths["model_acgt"], chkpnt_fn_nacgt=paths["model_nacgt"], min_rescale_cov=50,
+                          disable_indel_calling=False, likelihood_matrix_data=str(lik), call_fn=str(tmp_path / out / "p.vcf"), predict_fn=None,
+                          sample_name="S", show_ref=True, qual=0, pileup=True)]
+    eng = make_engine(args("x")[0], "cuda:0")
+    assert eng.neg_reads_aff and eng.min_bq == 12
+    n_py = run_pipeline(eng, args("py"), producers=1, writers=1)
+    n_nat = run_pipeline_native(eng, args("nat"), producers=1, writers=1, verbose=False)
+    assert n_py == n_nat > 50
+    assert open(tmp_path / "py" / "p.vcf", "rb").read() == open(tmp_path / "nat" / "p.vcf", "rb").read()
+
+
 def test_native_pipeline_reports_errors(tmp_path):
     """a missing pileup file, a contig the reference index does not hold: CtoError naming the cause, no hang, no partial state"""
     from argparse import Namespace
