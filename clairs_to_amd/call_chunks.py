@@ -70,19 +70,19 @@ def default_producers(native_bam, pipeline="python"):
     pipeline runs one BAM producer per usable core with two decoding threads each (pack_threads()): a call split over 8 threads
     decodes the long reads that straddle its 7 inner boundaries twice - 320 ms of CPU per 1 Mb x 50x chunk against 243 ms
     unsplit - and 16 x 2 measured 264 k sites/s where 8 x 8 gave 205 k; with DEVICE_INFLATE chunks in flight through the device
-    inflate (their producers asleep meanwhile) 16 x 2 measured 348-370 k.  (24 x 2 gave 350-368 k on one box and 190-280 k on
-    another: with more runnable threads than cores the chunks that wait for the device come back to a busy host.)"""
+    inflate (their producers asleep meanwhile) 16 x 2 measured 390-490 k.  (20-24 producers gave 190-350 k: with more runnable
+    threads than cores the chunks that wait for the device come back to a busy host.)"""
     if native_bam and pipeline == "native":
         return max(1, min(32, usable_cores()))
     return max(1, min(16, usable_cores() // (2 if native_bam else 4)))
 
 
 # BAM chunks on the C pipeline: up to DEVICE_INFLATE[1] chunks at a time have their BGZF blocks inflated on the GPU, on streams confined to
-# DEVICE_INFLATE[0] of its 256 compute units (the networks keep the rest; they need a fifth of the GPU at BAM rates), the others on the
-# host cores.  Measured on 64 chunk files, 16 usable cores, 16 producers (sites/s, profiles/round2_d_bam_hybrid.txt): host only 250 k;
-# 128 CUs x 4 / 6 / 8 chunks 348 / 314 / 262 k; 160 CUs 370 / 362 / 277 k; 192 CUs 158-240 k in that run (345-368 k in another);
-# 240 CUs or 12+ chunks in flight 155-290 k (the networks starve: 8-12 ms of device time per chunk instead of 2.5).
-DEVICE_INFLATE = (160, 4)
+# DEVICE_INFLATE[0] of its 256 compute units (the networks keep the rest), the others on the host cores.  Measured on 64 chunk files, 16 usable
+# cores, 16 producers (sites/s; profiles/round2_d_bam_hybrid.txt, two passes per setting on one box): host only 246-250 k; 128 CUs x 8 / 10
+# chunks 347-402 / 408-429 k; 144 CUs 432-488 / 386-391 k; 160 CUs 368-396 / 323-328 k (507 k once on another box); all 64 chunks through the
+# device (16 in flight) 191-385 k; 20+ producers 263-349 k (more runnable threads than cores).
+DEVICE_INFLATE = (144, 8)
 
 
 def pack_threads(native_bam, pipeline="python"):
@@ -179,8 +179,9 @@ def native_eligible(chunk_args):
 
 
 def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, stats=None, verbose=True, inflate_cus=None, inflate_jobs=None):
-    """run_pipeline() as ONE C call (cto_run_chunks, csrc/pipeline.hip): the same stages on native threads - the interpreter is
-    not in the loop, which is what levels the Python pipeline off at ~290 chunks a second.  Same files, byte for byte."""
+    """run_pipeline() as ONE C call (cto_run_chunks, csrc/pipeline.hip): the same stages on native threads, with page-locked staging,
+    buffers kept from chunk to chunk and - for BAM input - some chunks' BGZF blocks inflated on the device.  Same files, byte for byte.
+    The kernels run on a stream of their own: the legacy default stream would synchronise with the CU-masked inflate streams."""
     import ctypes as C
     from ._lib import ChunkJob, RunCfg, RunStats, check, lib
     from .call_variants import VCF_HEADER
@@ -214,7 +215,10 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
     cfg.inflate_jobs = DEVICE_INFLATE[1] if inflate_jobs is None else int(inflate_jobs)
     st = RunStats()
     with torch.cuda.device(eng.device):
-        rc = lib.cto_run_chunks(C.byref(cfg), jobs, len(chunk_args), C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(st))
+        main = torch.cuda.Stream(eng.device)
+        main.wait_stream(torch.cuda.current_stream())
+        rc = lib.cto_run_chunks(C.byref(cfg), jobs, len(chunk_args), C.c_void_p(main.cuda_stream), C.byref(st))
+        main.synchronize()
     if own_threads:
         del os.environ["CTO_PACK_THREADS"]
     sys.stdout.flush()

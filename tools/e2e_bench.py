@@ -23,8 +23,8 @@ def main():
     ap.add_argument("--bam-reader", default="native", help="native (host inflate) or gpu (device inflate), comma separated")
     ap.add_argument("--repeats", type=int, default=4, help="passes over the chunk list per measurement (best one is reported; large values = soak test)")
     ap.add_argument("--pipeline", default="python", help="python (call_chunks.run_pipeline) and / or native (cto_run_chunks), comma separated")
-    ap.add_argument("--inflate-cus", default="160", help="BAM + native pipeline: compute units the device inflate is confined to (0 = host inflate only), comma separated")
-    ap.add_argument("--inflate-jobs", default="4", help="chunks in flight through the device inflate, comma separated")
+    ap.add_argument("--inflate-cus", default="144", help="BAM + native pipeline: compute units the device inflate is confined to (0 = host inflate only), comma separated")
+    ap.add_argument("--inflate-jobs", default="8", help="chunks in flight through the device inflate, comma separated")
     ap.add_argument("--pack-threads", default=None, help="CTO_PACK_THREADS values for the C producers, comma separated (default: their own, <= 32)")
     a = ap.parse_args()
     import torch
