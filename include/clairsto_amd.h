@@ -330,8 +330,9 @@ typedef struct cto_run_cfg {
     int    inflate_cus;         /* BAM input: > 0 = up to inflate_jobs chunks at a time have their BGZF blocks inflated on the device
                                    (cto_bgzf_inflate) on streams confined to the first inflate_cus compute units, the others on the
                                    host cores as cto_pack_from_bam does; 0 = host only.  Same packs either way.               */
-    int    inflate_jobs;        /* With device inflate, `stream` of cto_run_chunks must be a non-blocking stream: the legacy default
-                                   stream synchronises with the CU-masked (blocking) inflate streams and the two exclude each other. */
+    int    inflate_jobs;        /* `stream` of cto_run_chunks should be a non-blocking stream: the legacy default stream synchronises
+                                   with the CU-masked (blocking) inflate streams and the two exclude each other; NULL = the call
+                                   creates one of its own, ordered behind the default stream's work so far.                    */
 } cto_run_cfg;
 typedef struct cto_run_stats {
     int64_t candidates;                                /* candidate positions read from the BED chunks           */
