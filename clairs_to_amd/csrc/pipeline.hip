@@ -674,7 +674,9 @@ extern "C" int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs,
     bool any_bam = false;
     for (int64_t i = 0; i < n_jobs; ++i) any_bam = any_bam || !jobs[i].mpileup_path;
     if (any_bam && cfg->inflate_cus > 0 && cfg->inflate_jobs > 0) {
-        const int cus = std::min(cfg->inflate_cus, 256);
+        int n_cu = 256;
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        const int cus = std::max(8, std::min(cfg->inflate_cus, n_cu * 3 / 4));      // the networks keep at least a quarter of the chip
         {
             std::lock_guard<std::mutex> g(slot_cache_m());
             auto& cache = inflate_cache();
