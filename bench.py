@@ -159,7 +159,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file legs (mpileup text -> VCF, BAM -> VCF)")
-    ap.add_argument("--e2e-chunks", type=int, default=96, help="chunk files of the mpileup-text leg (the BAM leg uses a quarter as many)")
+    ap.add_argument("--e2e-chunks", type=int, default=96, help="chunk files of the mpileup-text leg (the BAM leg uses a third as many)")
     args = ap.parse_args()
 
     import numpy as np
@@ -340,7 +340,7 @@ def main():
             if "LD_PRELOAD" in env:
                 env["LD_PRELOAD"] = ":".join(x for x in env["LD_PRELOAD"].split(":") if "rocprof" not in x and "roctracer" not in x)
             child = subprocess.run([sys.executable, "-m", "clairs_to_amd.e2e", "--chunks", str(args.e2e_chunks), "--bam-chunks",
-                                    str(max(2, args.e2e_chunks // 4)), "--batch", str(args.batch)],
+                                    str(max(2, args.e2e_chunks // 3)), "--batch", str(args.batch)],
                                    cwd=ROOT, env=env, capture_output=True, text=True)
             lines = [ln for ln in child.stdout.split("\n") if ln.startswith("{")]
             e2e = json.loads(lines[-1]) if child.returncode == 0 and lines else {"error": child.stderr[-500:]}
