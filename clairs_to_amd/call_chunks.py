@@ -178,7 +178,8 @@ def native_eligible(chunk_args):
     return True
 
 
-def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, stats=None, verbose=True, inflate_cus=None, inflate_jobs=None):
+def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, stats=None, verbose=True, inflate_cus=None, inflate_jobs=None,
+                        two_streams=False):
     """run_pipeline() as ONE C call (cto_run_chunks, csrc/pipeline.hip): the same stages on native threads, with page-locked staging,
     buffers kept from chunk to chunk and - for BAM input - some chunks' BGZF blocks inflated on the device.  Same files, byte for byte.
     The kernels run on a stream of their own: the legacy default stream would synchronise with the CU-masked inflate streams."""
@@ -213,6 +214,9 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
     cfg.producers, cfg.writers, cfg.depth = int(producers), int(writers), int(depth or 0)
     cfg.inflate_cus = DEVICE_INFLATE[0] if inflate_cus is None else int(inflate_cus)       # only BAM jobs use it
     cfg.inflate_jobs = DEVICE_INFLATE[1] if inflate_jobs is None else int(inflate_jobs)
+    if two_streams:                               # consecutive chunks on two compute streams (a second pair of handles of the same weights)
+        with torch.cuda.device(eng.device):
+            cfg.aff2, cfg.neg2 = eng.aff._handle2(), eng.neg._handle2()
     st = RunStats()
     with torch.cuda.device(eng.device):
         main = torch.cuda.Stream(eng.device)

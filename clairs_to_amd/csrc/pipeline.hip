@@ -501,7 +501,7 @@ struct Run {
         return true;
     }
 
-    int launch(Slot* s, hipStream_t main, hipStream_t copy_back) {
+    int launch(Slot* s, hipStream_t main, hipStream_t copy_back, cto_model* aff, cto_model* neg) {
         const int K = cfg->K;
         const int64_t n = int64_t(s->sites.size());
         const size_t nc = size_t(std::max<int64_t>(s->hv.n_cols, 1)), nk = size_t(std::max<int64_t>(s->hv.n_keys, 1));
@@ -533,8 +533,8 @@ struct Run {
                                      sitefirst, keyfirst, main)))
             return rc;
         const float* x_neg = cfg->neg_reads_aff ? static_cast<const float*>(s->x_aff.p) : static_cast<const float*>(s->x_neg.p);
-        if ((rc = cto_model_forward(cfg->neg, x_neg, n, static_cast<float*>(s->ln.p), main))) return rc;
-        if ((rc = cto_model_forward(cfg->aff, static_cast<const float*>(s->x_aff.p), n, static_cast<float*>(s->la.p), main))) return rc;
+        if ((rc = cto_model_forward(neg, x_neg, n, static_cast<float*>(s->ln.p), main))) return rc;
+        if ((rc = cto_model_forward(aff, static_cast<const float*>(s->x_aff.p), n, static_cast<float*>(s->la.p), main))) return rc;
         if ((rc = cto_posterior(static_cast<const float*>(s->la.p), static_cast<const float*>(s->ln.p), K, n, cfg->d_lik, cfg->d_edges, nullptr,
                                 static_cast<double*>(s->post.p), decision, qual, main)))
             return rc;
@@ -713,6 +713,16 @@ extern "C" int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs,
     }
     hipStream_t copy_back = nullptr;
     CTO_HIP(hipStreamCreateWithFlags(&copy_back, hipStreamNonBlocking));
+    // a second compute stream for every other chunk, when the caller brought a second pair of handles (cto_run_cfg.aff2)
+    hipStream_t second = nullptr;
+    if (cfg->aff2 && cfg->neg2) {
+        hipEvent_t before = nullptr;
+        CTO_HIP(hipStreamCreateWithFlags(&second, hipStreamNonBlocking));
+        CTO_HIP(hipEventCreateWithFlags(&before, hipEventDisableTiming));
+        CTO_HIP(hipEventRecord(before, main));
+        CTO_HIP(hipStreamWaitEvent(second, before, 0));
+        CTO_HIP(hipEventDestroy(before));
+    }
     const double t_begin = now_s();
     std::atomic<int> producers_left{producers};
 
@@ -760,6 +770,7 @@ extern "C" int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs,
     // ---- launcher: this thread ----
     double launch_s = 0, wait_s = 0;
     int rc = CTO_OK;
+    int64_t launched = 0;
     for (;;) {
         Slot* s = nullptr;
         const double t0 = now_s();
@@ -767,7 +778,8 @@ extern "C" int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs,
         const double t1 = now_s();
         wait_s += t1 - t0;
         if (!run.failed) {
-            const int r = run.launch(s, main, copy_back);
+            const bool odd = second && (launched++ & 1);
+            const int r = run.launch(s, odd ? second : main, copy_back, odd ? cfg->aff2 : cfg->aff, odd ? cfg->neg2 : cfg->neg);
             if (r != CTO_OK) { run.fail(cto_last_error()); rc = r; }
         }
         launch_s += now_s() - t1;
@@ -778,6 +790,7 @@ extern "C" int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs,
     run.free_slots.close();
     for (auto& th : threads) th.join();
     (void)hipStreamSynchronize(main);
+    if (second) { (void)hipStreamSynchronize(second); (void)hipStreamDestroy(second); }
     (void)hipStreamSynchronize(copy_back);
     (void)hipStreamDestroy(copy_back);
     if (own_main) (void)hipStreamDestroy(own_main);

@@ -41,7 +41,7 @@ def build_run(d, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, reg
         region_kb, os.path.getsize(run["bam_fn"]) / 1e6, len(run["chunks"]))
 
 
-def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4, bam_reader="native", pipeline="python", inflate_cus=None, inflate_jobs=None):
+def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4, bam_reader="native", pipeline="python", inflate_cus=None, inflate_jobs=None, two_streams=False):
     """the pipeline over a prepared run directory -> dict(sites_per_s, ...); best of `repeats` passes (the first one warms the page
     cache, the pinned buffers and the model workspaces)"""
     from .call_chunks import default_producers, run_pipeline, run_pipeline_native
@@ -55,7 +55,7 @@ def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4, bam_
         t0 = time.perf_counter()
         if pipeline == "native":
             rows = run_pipeline_native(eng, chunk_args, producers=producers, writers=writers, stats=stats, verbose=False,
-                                       inflate_cus=inflate_cus, inflate_jobs=inflate_jobs)
+                                       inflate_cus=inflate_cus, inflate_jobs=inflate_jobs, two_streams=two_streams)
         else:
             rows = run_pipeline(eng, chunk_args, producers=producers, writers=writers, stats=stats)
         dt = time.perf_counter() - t0

@@ -83,9 +83,11 @@ class _HipNet(nn.Module):
     def _weights_version(self):
         return tuple((k, int(v._version), v.data_ptr()) for k, v in self.state_dict().items())
 
-    def _handle(self):
+    def _handle(self, slot="_cto_state"):
+        """the C-ABI model handle of this module's current weights (rebuilt when they change).  A handle's activation workspace
+        belongs to one stream at a time: `_handle2()` is a second, independent handle for a caller that runs two streams."""
         ver = self._weights_version()
-        st = self.__dict__.get("_cto_state")
+        st = self.__dict__.get(slot)
         if st is not None and st[0] == ver:
             return st[1]
         if st is not None:
@@ -105,18 +107,23 @@ class _HipNet(nn.Module):
                 check(lib.cto_bigru_create(w, len(self._heads_out), C.byref(out)))
         finally:
             lib.cto_weights_free(w)
-        self.__dict__["_cto_state"] = (ver, c_vp(out.value))
-        return self.__dict__["_cto_state"][1]
+        self.__dict__[slot] = (ver, c_vp(out.value))
+        return self.__dict__[slot][1]
+
+    def _handle2(self):
+        return self._handle("_cto_state2")
 
     def __del__(self):
-        st = self.__dict__.get("_cto_state")
-        if st is not None:
-            self.__dict__["_cto_state"] = None
-            lib.cto_model_destroy(st[1])
+        for slot in ("_cto_state", "_cto_state2"):
+            st = self.__dict__.get(slot)
+            if st is not None:
+                self.__dict__[slot] = None
+                lib.cto_model_destroy(st[1])
 
     def __getstate__(self):
         d = dict(self.__dict__)
         d.pop("_cto_state", None)     # the device handle never travels in a pickle
+        d.pop("_cto_state2", None)
         d.pop("_cto_packed", None)    # ... nor does the packed copy of the weights
         return d
 

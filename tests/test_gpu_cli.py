@@ -372,6 +372,10 @@ def test_native_pipeline_writes_the_same_files(tmp_path, source, mode, aff_cls, 
             assert (st_dev["device_inflated"] == 0) if kw["inflate_cus"] == 0 else (1 <= st_dev["device_inflated"] <= len(parts))
             for fn in names:
                 assert open(tmp_path / "py" / fn, "rb").read() == open(tmp_path / "nat" / fn, "rb").read(), fn
+    # consecutive chunks on two compute streams (a second pair of model handles): the same files
+    assert run_pipeline_native(eng, a_nat, producers=3, writers=2, verbose=False, two_streams=True) == n_py
+    for fn in names:
+        assert open(tmp_path / "py" / fn, "rb").read() == open(tmp_path / "nat" / fn, "rb").read(), fn
     from clairs_to_amd._lib import lib
     assert lib.cto_run_release() == 0           # the buffers kept from the first call are dropped; the next call allocates its own
     assert run_pipeline_native(eng, a_nat, producers=1, writers=1, depth=1, verbose=False) == n_py

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--producers", default="2,4,8,16")
     ap.add_argument("--writers", default="2")
     ap.add_argument("--bam-reader", default="native", help="native (host inflate) or gpu (device inflate), comma separated")
+    ap.add_argument("--two-streams", default="0", help="native pipeline: 1 = consecutive chunks alternate between two compute streams; comma separated")
     ap.add_argument("--repeats", type=int, default=4, help="passes over the chunk list per measurement (best one is reported; large values = soak test)")
     ap.add_argument("--pipeline", default="python", help="python (call_chunks.run_pipeline) and / or native (cto_run_chunks), comma separated")
     ap.add_argument("--inflate-cus", default="144", help="BAM + native pipeline: compute units the device inflate is confined to (0 = host inflate only), comma separated")
@@ -53,13 +54,14 @@ def main():
                       dev_inflate = kind == "bam" and pl == "native"
                       for cus in ([int(x) for x in a.inflate_cus.split(",")] if dev_inflate else [0]):
                        for ij in ([int(x) for x in a.inflate_jobs.split(",")] if (dev_inflate and cus) else [0]):
-                        r = time_run(eng, run, kind, os.path.join(d, "vcf_%s" % kind), producers=p, writers=w, bam_reader=br, pipeline=pl,
-                                     inflate_cus=cus, inflate_jobs=ij, repeats=a.repeats)
-                        import resource
-                        r.update(kind=kind, pack_threads=pt or "auto", bam_reader=br, inflate_cus=cus, inflate_jobs=ij, repeats=a.repeats,
-                                 max_rss_mb=resource.getrusage(resource.RUSAGE_SELF).ru_maxrss // 1024)
-                        r.pop("includes")
-                        print(json.dumps(r), flush=True)
+                        for ts in ([int(x) for x in a.two_streams.split(",")] if pl == "native" else [0]):
+                         r = time_run(eng, run, kind, os.path.join(d, "vcf_%s" % kind), producers=p, writers=w, bam_reader=br, pipeline=pl,
+                                     inflate_cus=cus, inflate_jobs=ij, repeats=a.repeats, two_streams=bool(ts))
+                         import resource
+                         r.update(kind=kind, pack_threads=pt or "auto", bam_reader=br, inflate_cus=cus, inflate_jobs=ij, repeats=a.repeats,
+                                  two_streams=ts, max_rss_mb=resource.getrusage(resource.RUSAGE_SELF).ru_maxrss // 1024)
+                         r.pop("includes")
+                         print(json.dumps(r), flush=True)
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
