@@ -191,9 +191,6 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
     if not chunk_args:
         return 0
     a0 = chunk_args[0]
-    own_threads = "CTO_PACK_THREADS" not in os.environ
-    if own_threads:
-        os.environ["CTO_PACK_THREADS"] = str(pack_threads(not getattr(a0, "mpileup_fn", None), "native"))
     jobs = (ChunkJob * len(chunk_args))()
     for j, a in zip(jobs, chunk_args):
         os.makedirs(os.path.dirname(os.path.abspath(a.call_fn)), exist_ok=True)
@@ -212,6 +209,8 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
     cfg.ref_fa = str(a0.ref_fn).encode()
     cfg.vcf_header = (VCF_HEADER + "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n" % a0.sample_name).encode()
     cfg.producers, cfg.writers, cfg.depth = int(producers), int(writers), int(depth or 0)
+    # threads per producer call: the environment's CTO_PACK_THREADS if the user set one, else this module's plan for the host
+    cfg.pack_threads = 0 if "CTO_PACK_THREADS" in os.environ else pack_threads(not getattr(a0, "mpileup_fn", None), "native")
     cfg.inflate_cus = DEVICE_INFLATE[0] if inflate_cus is None else int(inflate_cus)       # only BAM jobs use it
     cfg.inflate_jobs = DEVICE_INFLATE[1] if inflate_jobs is None else int(inflate_jobs)
     if two_streams:                               # consecutive chunks on two compute streams (a second pair of handles of the same weights)
@@ -223,8 +222,6 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
         main.wait_stream(torch.cuda.current_stream())
         rc = lib.cto_run_chunks(C.byref(cfg), jobs, len(chunk_args), C.c_void_p(main.cuda_stream), C.byref(st))
         main.synchronize()
-    if own_threads:
-        del os.environ["CTO_PACK_THREADS"]
     sys.stdout.flush()
     check(rc)
     if stats is not None:

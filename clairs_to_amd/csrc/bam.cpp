@@ -764,7 +764,7 @@ int pack_from_bam_impl(const char* bam_path, const char* bai_path, const char* c
     } else want = end - start + 1;
     unsigned nt = std::thread::hardware_concurrency();
     nt = std::max(1u, std::min(nt, 32u));
-    if (const char* e = getenv("CTO_PACK_THREADS")) nt = std::max(1u, std::min(unsigned(atoi(e)), 64u));
+    nt = cto::pack_threads_or(nt);
     nt = unsigned(std::max<int64_t>(1, std::min<int64_t>(nt, want / 2000)));      // at least ~2000 positions per thread
     if (nt == 1)
         return pack_from_bam_range(bam_path, bai_path, ctg_name, start, end, bed, n_bed, ref_seq, ref_start, ref_len, excl_flags, min_mq,

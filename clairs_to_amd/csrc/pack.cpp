@@ -20,6 +20,7 @@
 
 namespace cto {
 
+thread_local int tl_pack_threads = 0;
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -528,7 +529,7 @@ int cto::pack_from_mpileup_impl(const char* text, size_t len, const char* ref_se
     // rows are independent: split the text at line boundaries and tokenise the pieces on several host threads
     unsigned nt = std::thread::hardware_concurrency();
     nt = std::max(1u, std::min(nt, 32u));     // scales to ~3.9 GB/s of text at 32 threads (tools/tokenise_bench.py)
-    if (const char* e = getenv("CTO_PACK_THREADS")) nt = std::max(1u, std::min(unsigned(atoi(e)), 64u));
+    nt = cto::pack_threads_or(nt);
     if (len < (size_t(1) << 22)) nt = 1;
     std::vector<size_t> cut(nt + 1, len);
     cut[0] = 0;

@@ -3,6 +3,7 @@
 #pragma once
 #include <algorithm>
 #include <memory>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -81,6 +82,15 @@ struct ColumnScratch {
     std::vector<Key> keys;
     std::vector<Group> groups;
 };
+
+// Decoding threads of the pack producers for calls made from THIS thread (0: CTO_PACK_THREADS, else the producer's default): the chunk
+// pipeline sets it in its producer threads, so that nobody has to edit the process environment around a call.
+extern thread_local int tl_pack_threads;
+inline unsigned pack_threads_or(unsigned dflt) {
+    if (tl_pack_threads > 0) return unsigned(std::min(tl_pack_threads, 64));
+    if (const char* e = getenv("CTO_PACK_THREADS")) return std::max(1u, std::min(unsigned(atoi(e)), 64u));
+    return dflt;
+}
 
 void set_err(std::string* err, const char* fmt, ...);
 void pack_begin(cto_pack* p, size_t entries_hint, size_t cols_hint);

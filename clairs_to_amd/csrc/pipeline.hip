@@ -730,6 +730,7 @@ extern "C" int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs,
     for (int t = 0; t < producers; ++t)
         threads.emplace_back([&run, &producers_left, dev] {
             hipStream_t copy = nullptr;
+            tl_pack_threads = run.cfg->pack_threads;                 // the tokeniser's / BAM decoder's own threads per call
             if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) != hipSuccess) run.fail("producer: no HIP stream");
             for (;;) {
                 if (run.failed) break;

@@ -333,6 +333,8 @@ typedef struct cto_run_cfg {
     int    inflate_jobs;        /* `stream` of cto_run_chunks should be a non-blocking stream: the legacy default stream synchronises
                                    with the CU-masked (blocking) inflate streams and the two exclude each other; NULL = the call
                                    creates one of its own, ordered behind the default stream's work so far.                    */
+    int    pack_threads;        /* threads one producer's tokeniser / BAM decoder call may use (0: CTO_PACK_THREADS or the library's
+                                   default of up to 32): producers x pack_threads should stay near the usable cores            */
     cto_model*    aff2;         /* optional second pair of handles of the same weights (NULL: none): with them consecutive chunks  */
     cto_model*    neg2;         /* alternate between two compute streams, and the next chunk's first round of workgroups fills the
                                    CUs this chunk's last round leaves idle (chunk sizes that are not a multiple of 4096 sites:
