@@ -63,6 +63,7 @@ SYMBOLS = {
     "cto_device_count": (C.c_int, []),
     "cto_debug_poison_lds": (C.c_int, [c_vp]),
     "cto_pack_from_mpileup": (C.c_int, [c_vp, C.c_size_t, C.c_char_p, c_i64, C.c_size_t, C.c_int, C.POINTER(c_vp)]),
+    "cto_set_pack_threads": (None, [C.c_int]),
     "cto_pack_from_bam": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, c_i64, c_i64, c_vp, c_i64, C.c_char_p, c_i64, C.c_size_t,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(c_vp)]),
     "cto_pack_from_bam_inflated": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, c_i64, c_i64, c_vp, c_i64, C.c_char_p, c_i64, C.c_size_t,

@@ -99,9 +99,8 @@ def run_pipeline(eng, chunk_args, producers=4, writers=2, depth=None, stats=None
     depth = depth if depth is not None else producers + 2
     n_rows = 0
     local = threading.local()
-    own_threads = "CTO_PACK_THREADS" not in os.environ
-    if own_threads:
-        os.environ["CTO_PACK_THREADS"] = str(pack_threads(False))
+    from ._lib import lib
+    per_call = 0 if "CTO_PACK_THREADS" in os.environ else pack_threads(False)      # the user's setting wins
 
     import time
 
@@ -113,6 +112,7 @@ def run_pipeline(eng, chunk_args, producers=4, writers=2, depth=None, stats=None
         t0 = time.perf_counter()
         if getattr(local, "stream", None) is None:
             local.stream = torch.cuda.Stream(device)            # one copy stream per producer thread
+            lib.cto_set_pack_threads(per_call)                  # ... and its share of the cores for the C producers' own threads
         try:
             return prepare_chunk(a, device=device, copy_stream=local.stream)
         finally:
@@ -159,8 +159,6 @@ def run_pipeline(eng, chunk_args, producers=4, writers=2, depth=None, stats=None
                 n_rows += writing.popleft().result()
         while writing:
             n_rows += writing.popleft().result()
-    if own_threads:
-        os.environ.pop("CTO_PACK_THREADS", None)
     return n_rows
 
 

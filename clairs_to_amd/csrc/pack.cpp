@@ -32,6 +32,7 @@ void set_error(const char* fmt, ...) {
 }  // namespace cto
 
 extern "C" const char* cto_last_error(void) { return cto::g_err; }
+extern "C" void cto_set_pack_threads(int n) { cto::tl_pack_threads = n > 0 ? n : 0; }
 extern "C" int cto_version(void) { return 100; }
 
 namespace cto {

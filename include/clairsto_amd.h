@@ -87,6 +87,10 @@ typedef struct cto_pack cto_pack;   /* host-side pack incl. the key strings need
  * the row handling at :472-497.  max_indel_length: shared/param.py max_indel_length (60). */
 int cto_pack_from_mpileup(const char* text, size_t len, const char* ref_seq, int64_t ref_start,
                           size_t ref_len, int max_indel_length, cto_pack** out);
+/* The pack producers (this one and cto_pack_from_bam*) cut a call over several threads of their own: up to 32, or CTO_PACK_THREADS from
+ * the environment, or - for calls made from the CALLING thread from now on - n (0 = back to the default).  A caller that runs several
+ * producers side by side gives each its share of the cores this way. */
+void cto_set_pack_threads(int n);
 /* BAM -> pack without the mpileup text: the columns `samtools mpileup --reverse-del --output-MQ
  * -r ctg:start-end --min-MQ <min_mq> --min-BQ 0 [-l bed] --excl-flags <excl_flags> [--max-depth N]` would print
  * (create_tensor_pileup_calling.py:426-446 runs that command), tokenised as cto_pack_from_mpileup would.  Needs the
