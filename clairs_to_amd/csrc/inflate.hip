@@ -12,15 +12,15 @@
 //     are canonical, so lane L (1..15) holds first_code[L], count[L] and offset[L], bit-reverses the next L bits and tests
 //     first <= code < first + count - exactly one lane hits; a ballot names the length, a readlane fetches offset + code - first,
 //     the symbol comes out of the sorted symbol list held in 5 + 1 registers per lane;
-//   * LZ77 window: the output buffer itself.  Literals are byte stores of lane 0; a match waits for the stores in flight and is
-//     copied by all lanes at once (source index (k mod distance) for overlapping copies) with loads that bypass the vector L1.
+//   * LZ77 window: the output buffer itself.  Literals are byte stores; matches are queued and resolved 256 at a time, one match
+//     per lane, with loads that bypass the vector L1 (source index (k mod distance) for overlapping copies).
 //     A 32 KiB ring in LDS was the first version: 4 wavefronts per CU, and a single decoder wave is a chain of dependent
 //     scalar instructions, branches and one LDS round trip per symbol (500 cycles per symbol measured) - the chip inflated 36
 //     chunks a second.  With 4 KB of LDS per wave, six waves per SIMD take turns on that chain.
 // Measured on MI355X (tools/inflate_bench.py, a 1 Mb x 50x chunk: 77 MB of BAM in 1776 blocks -> 115 MB): 20 ms for one launch
 // alone (15 ms with the literal stores taken out: the decode chain, not memory, is the cost), 8 ms per chunk with 4-8 launches in
-// flight = 14 GB/s of inflated bytes (6.2 ms = 18.5 GB/s after the literal loop below), about what 20-25 host cores of libdeflate
-// deliver.  It pays beside the host cores, not instead
+// flight = 14 GB/s of inflated bytes (5.8 ms = 19.8 GB/s with the literal loop and the match queue below), about what 25 host
+// cores of libdeflate deliver.  It pays beside the host cores, not instead
 // of them: the chunk pipeline (pipeline.hip) sends some chunks through it on streams confined to part of the CUs - unconfined, the
 // waves of a launch sit on every CU for tens of milliseconds and the networks' block kernels wait for them - and BAM -> VCF goes
 // from 240 k sites/s (16 host cores) to 337-368 k.
@@ -37,7 +37,12 @@
 // reach behind the last known-drained output position (two thirds reach more than 2 KB back): no change - waiting for the
 // window load is a vmcnt(0), stores included.  Matches loaded into LDS slots with global_load_lds_ubyte and stored eight
 // matches later under one wait (the window of 7 000 resident waves does not stay in the L2s; a source byte is a microsecond
-// away and nothing downstream in the stream needs it): 8.7, slower, and not pursued to correctness.
+// away and nothing downstream in the stream needs it): 8.7, slower, and not pursued to correctness.  The same idea without the
+// LDS-DMA - matches queued in LDS (destination, source, length) and resolved 256 at a time by all lanes, one match per lane, in
+// rounds that respect the dependencies (resolve_matches) - 5.8 (kept).  That it is worth 7 % and not a factor says where the
+// bound is: the decoder is wave-uniform code, ~40 of its ~65 instructions per symbol run on the scalar unit, a CU has ONE scalar
+// unit for its four SIMDs, and 256 CUs x 2.1 GHz / 40 = 13 G symbols/s = 17 GB/s - what is measured.  Waves per SIMD, memory
+// latency and store drains are second-order once a CU holds enough waves to keep that unit busy.
 // Every loop is bounded by the block's compressed size (a symbol consumes at least one bit) or by constants; malformed input
 // ends with a status code, never with a hang or an out-of-range access (the input buffer carries CTO_BGZF_PAD bytes of padding,
 // every output slot is padded to 256 bytes).
@@ -239,6 +244,48 @@ extern "C" __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* _
                                              // coherent with this wave's own earlier stores)
     int st = ST_OK;
     int op = 0;                              // bytes produced
+    // Matches are not copied where they are decoded: a source byte is a microsecond away (the windows of thousands of resident waves
+    // do not stay in the L2s) and nothing that follows in the stream depends on it.  They are queued - destination, source, length -
+    // and resolved TOK at a time by all lanes, one match per lane, so that the trip to memory is paid once per 64 matches instead
+    // of once per match.  A match whose source ends inside the not-yet-resolved part of the queue waits for a later round
+    // (resolve_matches); literals are stored as they are decoded and have landed before a round starts.
+    constexpr int TOK = 256;
+    __shared__ uint16_t tok_dst[TOK], tok_src[TOK], tok_len[TOK];
+    int ntok = 0;
+    auto resolve_matches = [&]() {
+        if (ntok == 0) return;
+        __builtin_amdgcn_s_waitcnt(0);       // every literal (and every earlier round's copy) has reached L2; the queue is in LDS
+        __builtin_amdgcn_wave_barrier();
+        int c = 0;
+        uint64_t done = 0;                   // bit i: token c + i is resolved
+        while (c < ntok) {
+            const int t = c + lane;
+            const bool mine = t < ntok && !((done >> lane) & 1);
+            const int td = mine ? int(tok_dst[t]) : 0, ts = mine ? int(tok_src[t]) : 0, tn = mine ? int(tok_len[t]) : 0;
+            const int d = td - ts;
+            const int first = int(tok_dst[c]);                   // everything below the oldest unresolved destination is final
+            const bool ready = mine && ts + (d < tn ? d : tn) <= first;
+            if (ready) {
+                // the (k mod d) form reads the repeating pattern of an overlapping copy from its first period: no byte of this copy
+                // depends on a byte this copy writes
+                if (d >= tn) {
+                    for (int k = 0; k < tn; ++k) dst[td + k] = __hip_atomic_load(win + ts + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    for (int k = 0, j = 0; k < tn; ++k) {
+                        dst[td + k] = __hip_atomic_load(win + ts + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        j = j + 1 == d ? 0 : j + 1;
+                    }
+                }
+            }
+            done |= __ballot(ready);
+            const int adv = done == ~uint64_t(0) ? 64 : __ffsll((long long)~done) - 1;      // token c is always ready: adv >= 1
+            c += adv;
+            done = adv >= 64 ? 0 : done >> adv;
+            __builtin_amdgcn_s_waitcnt(0);   // this round's copies have reached L2 before the next round reads them
+            __builtin_amdgcn_wave_barrier();
+        }
+        ntok = 0;
+    };
 
     if (isize > 0) {
         Bits b;
@@ -382,20 +429,13 @@ extern "C" __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* _
                     bits_drop(b, de);
                     if (d > op) { st = ST_BAD_DIST; break; }
                     if (op + n > isize) { st = ST_OVERRUN_OUT; break; }
-                    const int from = op - d;
-                    // Waiting only when the source bytes can still be in flight (two thirds of a BAM block's matches reach more than
-                    // 2 KB back) was measured and bought nothing: the wait for the window load itself is a vmcnt(0), stores included.
-                    __builtin_amdgcn_s_waitcnt(0);               // every earlier store of this wave has reached L2
-                    __builtin_amdgcn_wave_barrier();
-                    // all source bytes lie before `op`: the (k mod d) form reads the repeating pattern of an overlapping copy from
-                    // its first period, so no lane depends on a byte another lane writes in this copy
-                    for (int k = lane; k < n; k += 64) {
-                        const int sk = d >= n ? k : k % d;
-                        dst[op + k] = __hip_atomic_load(win + from + sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
+                    if (lane == 0) { tok_dst[ntok] = uint16_t(op); tok_src[ntok] = uint16_t(op - d); tok_len[ntok] = uint16_t(n); }
+                    ++ntok;
                     op += n;
+                    if (ntok == TOK) resolve_matches();
                 }
             }
+            resolve_matches();                                   // end of this DEFLATE block: a stored block may follow
         }
         if (st == ST_OK && op != isize) st = ST_SHORT;
     }
