@@ -46,6 +46,7 @@
 // Every loop is bounded by the block's compressed size (a symbol consumes at least one bit) or by constants; malformed input
 // ends with a status code, never with a hang or an out-of-range access (the input buffer carries CTO_BGZF_PAD bytes of padding,
 // every output slot is padded to 256 bytes).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -442,10 +443,14 @@ extern "C" __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* _
     if (lane == 0) status[blk] = st;
 }
 
+int launch_bgzf_inflate_lanes(const void* d_comp, const cto_bgzf_block* d_blocks, int n_blocks, void* d_out, int* d_status, hipStream_t stream);
+
 extern "C" int cto_bgzf_inflate(const void* d_comp, const cto_bgzf_block* d_blocks, int n_blocks, void* d_out, int* d_status, void* stream) {
     using namespace cto;
     CTO_REQUIRE(n_blocks >= 0 && (n_blocks == 0 || (d_comp && d_blocks && d_out && d_status)), CTO_EINVAL, "cto_bgzf_inflate: null argument");
     if (n_blocks == 0) return CTO_OK;
+    const char* lanes = getenv("CTO_INFLATE_LANES");             // experimental decoder, one block per lane (inflate_lanes.hip)
+    if (lanes && lanes[0] == '1') return launch_bgzf_inflate_lanes(d_comp, d_blocks, n_blocks, d_out, d_status, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(k_bgzf_inflate, dim3(unsigned(n_blocks)), dim3(64), 0, static_cast<hipStream_t>(stream),
                        static_cast<const uint8_t*>(d_comp), d_blocks, n_blocks, static_cast<uint8_t*>(d_out), d_status);
     CTO_HIP(hipGetLastError());
