@@ -8,10 +8,12 @@
 // refreshed by the wave's stores).  Same interface and status codes as inflate.hip.
 //
 // State of the experiment (tools/inflate_bench.py concurrency, a chunk of 1 776 blocks = 28 waves): correct on the whole zlib parity
-// suite (tests/test_gpu_inflate.py runs it), and SLOW - 130 ms for one launch alone, 32 ms per chunk with 4 launches in flight and no
-// better with 8, against 23 / 5.8 ms of the wave-per-block kernel.  A symbol step of a wave costs ~8 000 cycles: the tables live in
-// private (scratch) memory, every look-up, input byte and window byte is a memory round trip of its own, and 154 VGPRs leave three
-// waves per SIMD to hide them.  What it would take: tables in LDS (512-byte tables per lane = 32 KB per wave), dword-wide input,
+// suite (tests/test_gpu_inflate.py runs it), and SLOW - 113 ms for one launch alone, 29 ms per chunk with 4 launches in flight and no
+// better with 8, against 23 / 5.8 ms of the wave-per-block kernel.  A symbol step of a wave costs ~7 000 cycles: the lanes of a wave
+// take the literal, the match and the long-code path one after the other, and each path has its own dependent memory round trips
+// (table look-ups in private memory, base / extra-bits tables in global memory, the input dword, the window bytes) with three waves
+// per SIMD (146 VGPRs) to hide them.  Dword-wide input, plain loads for the window and the code-length counts in registers were
+// each worth 0-10 %.  What it would take: tables in LDS (512-byte tables per lane = 32 KB per wave), closed-form base / extra bits,
 // batched output, and some twenty chunks in flight to fill the chip.
 #include "common.h"
 
@@ -28,12 +30,16 @@ struct Rd {
     bool over;
 };
 __device__ __forceinline__ void fill(Rd& r) {
-    while (r.cnt <= 56) {
-        uint64_t v = 0;
-        if (r.pos < r.end) v = r.p[r.pos]; else r.over = true;
-        r.bb |= v << r.cnt;
-        r.cnt += 8;
-        ++r.pos;
+    if (r.cnt <= 32) {                      // four bytes at a time (an unaligned dword load; the input carries padding behind the payload)
+        uint32_t v = 0;
+        if (r.pos < r.end) {
+            __builtin_memcpy(&v, r.p + r.pos, 4);
+        } else {
+            r.over = true;
+        }
+        r.bb |= uint64_t(v) << r.cnt;
+        r.cnt += 32;
+        r.pos += 4;
     }
 }
 __device__ __forceinline__ uint32_t take(Rd& r, int n) {
@@ -74,6 +80,34 @@ __device__ void table(const uint16_t* count, const uint16_t* sym, uint16_t* tab)
         }
         code <<= 1;
     }
+}
+// the counts of a code in registers (constant indices after unrolling): the walk below then costs arithmetic, not a memory round trip
+// per code length
+struct Counts { uint16_t c[16]; };
+__device__ __forceinline__ Counts in_registers(const uint16_t* count) {
+    Counts k;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) k.c[l] = count[l];
+    return k;
+}
+__device__ __forceinline__ int walk_reg(Rd& r, const Counts& k, const uint16_t* sym) {
+    int code = 0, first = 0, index = 0, found = -1, taken = 0;
+#pragma unroll
+    for (int l = 1; l <= 15; ++l) {
+        if (found < 0) {
+            code |= int((r.bb >> (l - 1)) & 1);
+            const int c = k.c[l];
+            if (code - c < first) { found = index + (code - first); taken = l; }
+            index += c;
+            first += c;
+            first <<= 1;
+            code <<= 1;
+        }
+    }
+    if (found < 0) return -1;
+    r.bb >>= taken;
+    r.cnt -= taken;
+    return sym[found];
 }
 // slow path: walk the code lengths (bits arrive LSB first, codes are MSB first)
 __device__ int walk(Rd& r, const uint16_t* count, const uint16_t* sym) {
@@ -176,11 +210,12 @@ extern "C" __global__ __launch_bounds__(64) void k_bgzf_inflate_lanes(const uint
             build(lens + 288, 30, dcount, dsym);             // an incomplete distance code is legal
             table<LB>(lcount, lsym, ltab);
             table<DBITS>(dcount, dsym, dtab);
+            const Counts lk = in_registers(lcount), dk = in_registers(dcount);
             for (;;) {
                 fill(r);
                 int s;
                 const uint16_t e = ltab[uint32_t(r.bb) & ((1u << LB) - 1u)];
-                if (e) { s = e & 511; r.bb >>= (e >> 9); r.cnt -= (e >> 9); } else s = walk(r, lcount, lsym);
+                if (e) { s = e & 511; r.bb >>= (e >> 9); r.cnt -= (e >> 9); } else s = walk_reg(r, lk, lsym);
                 if (s < 0) { st = ST_BAD_CODE; break; }
                 if (r.over) { st = ST_OVERRUN_IN; break; }
                 if (s < 256) {
@@ -195,13 +230,13 @@ extern "C" __global__ __launch_bounds__(64) void k_bgzf_inflate_lanes(const uint
                 fill(r);
                 int ds;
                 const uint16_t f = dtab[uint32_t(r.bb) & ((1u << DBITS) - 1u)];
-                if (f) { ds = f & 511; r.bb >>= (f >> 9); r.cnt -= (f >> 9); } else ds = walk(r, dcount, dsym);
+                if (f) { ds = f & 511; r.bb >>= (f >> 9); r.cnt -= (f >> 9); } else ds = walk_reg(r, dk, dsym);
                 if (ds < 0 || ds >= 30) { st = ST_BAD_DIST; break; }
                 const int d = int(kDistBase[ds]) + int(take(r, kDistExtra[ds]));
                 if (d > op) { st = ST_BAD_DIST; break; }
                 if (op + n > isize) { st = ST_OVERRUN_OUT; break; }
                 const uint8_t* src = dst + op - d;
-                for (int k = 0; k < n; ++k) dst[op + k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int k = 0; k < n; ++k) dst[op + k] = src[k];            // a lane reads only bytes it wrote itself
                 op += n;
             }
         }
