@@ -13,8 +13,11 @@
 // take the literal, the match and the long-code path one after the other, and each path has its own dependent memory round trips
 // (table look-ups in private memory, base / extra-bits tables in global memory, the input dword, the window bytes) with three waves
 // per SIMD (146 VGPRs) to hide them.  Dword-wide input, plain loads for the window and the code-length counts in registers were
-// each worth 0-10 %.  What it would take: tables in LDS (512-byte tables per lane = 32 KB per wave), closed-form base / extra bits,
-// batched output, and some twenty chunks in flight to fill the chip.
+// each worth 0-10 %, and so were the lookup tables in LDS (1 156 bytes per lane, two waves per CU: 112 ms): what a step waits for is
+// not the tables.  64 lanes x 1.5 bytes of input per step cross a cache line somewhere in the wave on every step, so every step
+// contains a trip to memory for input that nobody prefetched; a match's window bytes are 3 dependent byte loads; and the three code
+// paths run one after the other with one wave per SIMD to cover ~300-400 dependent instructions.  What it would take: a double-buffered dwordx4 input per lane, one wide load per match, tables in LDS with closed-form base / extra bits, no scratch
+// (launches beyond four did not overlap - the scratch pool), and some twenty chunks in flight to fill the chip.
 #include "common.h"
 
 namespace {
