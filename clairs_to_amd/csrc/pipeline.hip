@@ -625,7 +625,7 @@ struct Run {
 
 }  // namespace
 
-extern "C" int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs, int64_t n_jobs, void* stream, cto_run_stats* stats) {
+static int run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs, int64_t n_jobs, void* stream, cto_run_stats* stats) {
     CTO_REQUIRE(cfg && (jobs || n_jobs == 0) && cfg->aff && cfg->neg && cfg->d_lik && cfg->d_edges && cfg->ref_fa && cfg->vcf_header, CTO_EINVAL,
                 "cto_run_chunks: null argument");
     CTO_REQUIRE(cfg->K == 4 || cfg->K == 6, CTO_EINVAL, "cto_run_chunks: K must be 4 or 6");
@@ -727,8 +727,29 @@ extern "C" int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs,
     std::atomic<int> producers_left{producers};
 
     std::vector<std::thread> threads;
+    threads.reserve(size_t(producers + writers));
+    struct JoinAll {                         // whatever happens below, a started thread is joined (queues closed first: they all wake up)
+        Run& run;
+        std::vector<std::thread>& th;
+        ~JoinAll() {
+            run.to_launch.close();
+            run.to_write.close();
+            run.free_slots.close();
+            for (auto& t : th)
+                if (t.joinable()) t.join();
+        }
+    } join_all{run, threads};
+    auto start = [&](auto&& body) -> bool {
+        try {
+            threads.emplace_back(std::forward<decltype(body)>(body));
+            return true;
+        } catch (const std::exception& e) {      // the system is out of threads
+            run.fail(std::string("cannot start a thread: ") + e.what());
+            return false;
+        }
+    };
     for (int t = 0; t < producers; ++t)
-        threads.emplace_back([&run, &producers_left, dev] {
+        if (!start([&run, &producers_left, dev] {
             hipStream_t copy = nullptr;
             tl_pack_threads = run.cfg->pack_threads;                 // the tokeniser's / BAM decoder's own threads per call
             if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) != hipSuccess) run.fail("producer: no HIP stream");
@@ -752,9 +773,11 @@ extern "C" int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs,
             }
             if (copy) { (void)hipStreamSynchronize(copy); (void)hipStreamDestroy(copy); }
             if (--producers_left == 0) run.to_launch.close();
-        });
+        })) {
+            if (--producers_left == 0) run.to_launch.close();        // this one never ran
+        }
     for (int t = 0; t < writers; ++t)
-        threads.emplace_back([&run, dev] {
+        (void)start([&run, dev] {
             (void)hipSetDevice(dev);
             Slot* s = nullptr;
             while (run.to_write.pop(&s)) {
@@ -768,6 +791,7 @@ extern "C" int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs,
                 run.free_slots.push(s);
             }
         });
+    if (run.failed) run.free_slots.close();  // a thread did not start: nobody may wait for a slot that no writer will hand back
     // ---- launcher: this thread ----
     double launch_s = 0, wait_s = 0;
     int rc = CTO_OK;
@@ -816,6 +840,20 @@ extern "C" int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs,
         return rc != CTO_OK ? rc : CTO_EINVAL;
     }
     return CTO_OK;
+}
+
+// no C++ exception crosses the C ABI: what the set-up or the launcher thread throws (allocation failure) becomes an error code; the
+// worker threads catch their own
+extern "C" int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs, int64_t n_jobs, void* stream, cto_run_stats* stats) {
+    try {
+        return run_chunks(cfg, jobs, n_jobs, stream, stats);
+    } catch (const std::bad_alloc&) {
+        set_error("cto_run_chunks: out of memory");
+        return CTO_ENOMEM;
+    } catch (const std::exception& e) {
+        set_error("cto_run_chunks: %s", e.what());
+        return CTO_EINVAL;
+    }
 }
 
 extern "C" int cto_run_release(void) {
