@@ -728,22 +728,6 @@ namespace {
 
 // No C++ exception may cross the C ABI or leave a worker thread (std::terminate would take the host process down with it):
 // allocation failures on hostile input (a record claiming 256 MB, a 4 GB index) come back as CTO_ENOMEM.
-template <class F>
-int guarded(const char* what, F&& f) {
-    try {
-        return f();
-    } catch (const std::bad_alloc&) {
-        set_error("%s: out of memory", what);
-        return CTO_ENOMEM;
-    } catch (const std::exception& e) {
-        set_error("%s: %s", what, e.what());
-        return CTO_EINVAL;
-    } catch (...) {
-        set_error("%s: unknown failure", what);
-        return CTO_EINVAL;
-    }
-}
-
 int pack_from_bam_impl(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
                        const int64_t* bed, int64_t n_bed, const char* ref_seq, int64_t ref_start, size_t ref_len,
                        int excl_flags, int min_mq, int max_depth, int max_indel_length, const PreInflated& pre, cto_pack** out) {

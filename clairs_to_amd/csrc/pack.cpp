@@ -521,7 +521,9 @@ int parse_rows(const char* text, size_t len, const char* ref_seq, int64_t ref_st
 
 extern "C" int cto_pack_from_mpileup(const char* text, size_t len, const char* ref_seq, int64_t ref_start,
                                       size_t ref_len, int max_indel_length, cto_pack** out) {
-    return cto::pack_from_mpileup_impl(text, len, ref_seq, ref_start, ref_len, max_indel_length, nullptr, 0, out);
+    return cto::guarded("cto_pack_from_mpileup", [&] {
+        return cto::pack_from_mpileup_impl(text, len, ref_seq, ref_start, ref_len, max_indel_length, nullptr, 0, out);
+    });
 }
 
 int cto::pack_from_mpileup_impl(const char* text, size_t len, const char* ref_seq, int64_t ref_start, size_t ref_len, int max_indel_length,
@@ -543,8 +545,11 @@ int cto::pack_from_mpileup_impl(const char* text, size_t len, const char* ref_se
     std::vector<int> rcs(nt, CTO_OK);
     std::vector<std::string> errs(nt);
     auto work = [&](unsigned t) {
-        parts[t].reset(new cto_pack());
-        rcs[t] = parse_rows(text + cut[t], cut[t + 1] - cut[t], ref_seq, ref_start, ref_len, max_indel_length, parts[t].get(), &errs[t]);
+        rcs[t] = cto::guarded("cto_pack_from_mpileup", [&] {
+            parts[t].reset(new cto_pack());
+            return parse_rows(text + cut[t], cut[t + 1] - cut[t], ref_seq, ref_start, ref_len, max_indel_length, parts[t].get(), &errs[t]);
+        });
+        if (rcs[t] != CTO_OK && errs[t].empty()) errs[t] = cto_last_error();      // what guarded() caught, from this thread
     };
     const bool timing = getenv("CTO_PACK_TIMING") != nullptr;
     const auto T0 = std::chrono::steady_clock::now();

@@ -3,6 +3,8 @@
 #pragma once
 #include <algorithm>
 #include <memory>
+#include <new>
+#include <exception>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -90,6 +92,23 @@ inline unsigned pack_threads_or(unsigned dflt) {
     if (tl_pack_threads > 0) return unsigned(std::min(tl_pack_threads, 64));
     if (const char* e = getenv("CTO_PACK_THREADS")) return std::max(1u, std::min(unsigned(atoi(e)), 64u));
     return dflt;
+}
+
+// No C++ exception crosses the C ABI (or leaves a worker thread): allocation failures on hostile input come back as error codes.
+template <class F>
+int guarded(const char* what, F&& f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        set_error("%s: out of memory", what);
+        return CTO_ENOMEM;
+    } catch (const std::exception& e) {
+        set_error("%s: %s", what, e.what());
+        return CTO_EINVAL;
+    } catch (...) {
+        set_error("%s: unknown failure", what);
+        return CTO_EINVAL;
+    }
 }
 
 void set_err(std::string* err, const char* fmt, ...);
