@@ -4,6 +4,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdint>
+#include <exception>
+#include <new>
 #include "../../include/clairsto_amd.h"
 
 namespace cto {
@@ -26,6 +28,16 @@ void set_error(const char* fmt, ...);
             return (code);                          \
         }                                           \
     } while (0)
+
+// Closes a function-try-block of a C-ABI entry point: no C++ exception crosses the boundary (`extern "C" int f(...) try { ... } CTO_CATCH("f", int)`)
+#define CTO_CATCH(name, T)                                                  \
+    catch (const std::bad_alloc&) {                                         \
+        ::cto::set_error("%s: out of memory", name);                        \
+        return T(CTO_ENOMEM);                                               \
+    } catch (const std::exception& e) {                                     \
+        ::cto::set_error("%s: %s", name, e.what());                         \
+        return T(CTO_EINVAL);                                               \
+    }
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

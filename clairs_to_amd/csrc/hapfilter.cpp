@@ -244,7 +244,7 @@ enum { F_PHASEABLE = 0, F_HETERO, F_HOMO, F_RSE, F_BQ, F_MQ, F_COEXIST, F_BOTH_S
 //                       exact integer arithmetic as the reference does) - int64
 extern "C" int cto_haplotype_filter(const char* text, size_t len, const char* ref_seq, int64_t region_lo, size_t ref_len, int64_t n,
                                     const int32_t* pos, const char* fields, const int64_t* field_off, const double* af, int flanking,
-                                    int max_co_exist_read_num, int disable_rse, uint8_t* flags, int64_t* strand) {
+                                    int max_co_exist_read_num, int disable_rse, uint8_t* flags, int64_t* strand) try {
     CTO_REQUIRE(text && ref_seq && (n == 0 || (pos && fields && field_off && af && flags && strand)) && flanking > 0, CTO_EINVAL,
                 "cto_haplotype_filter: bad argument");
     if (n == 0) return CTO_OK;
@@ -525,4 +525,4 @@ extern "C" int cto_haplotype_filter(const char* text, size_t len, const char* re
         }
     }
     return CTO_OK;
-}
+} CTO_CATCH("cto_haplotype_filter", int)

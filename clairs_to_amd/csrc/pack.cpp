@@ -577,7 +577,7 @@ int cto::pack_from_mpileup_impl(const char* text, size_t len, const char* ref_se
     return CTO_OK;
 }
 
-extern "C" int cto_pack_from_arrays(const cto_pack_view* v, const int64_t* key_str_off, const char* key_str, cto_pack** out) {
+extern "C" int cto_pack_from_arrays(const cto_pack_view* v, const int64_t* key_str_off, const char* key_str, cto_pack** out) try {
     CTO_REQUIRE(v && out, CTO_EINVAL, "cto_pack_from_arrays: null argument");
     CTO_REQUIRE(v->n_cols >= 0 && v->n_entries >= 0 && v->n_keys >= 0, CTO_EINVAL, "negative sizes");
     auto* p = new cto_pack();
@@ -609,7 +609,7 @@ extern "C" int cto_pack_from_arrays(const cto_pack_view* v, const int64_t* key_s
     }
     *out = p;
     return CTO_OK;
-}
+} CTO_CATCH("cto_pack_from_arrays", int)
 
 extern "C" int cto_pack_view_of(const cto_pack* p, cto_pack_view* v) {
     CTO_REQUIRE(p && v, CTO_EINVAL, "cto_pack_view_of: null argument");
@@ -686,7 +686,7 @@ std::string alt_info_string(const cto_pack* p, int64_t col, int pass, const int1
 
 extern "C" int cto_alt_info(const cto_pack* p, int64_t col, int pass, const int16_t* cv, int32_t depth_aff,
                             const int32_t* colfirst_col, const uint32_t* keycnt, const int32_t* keyfirst,
-                            char* buf, size_t cap) {
+                            char* buf, size_t cap) try {
     CTO_REQUIRE(p && cv && colfirst_col && buf && cap > 0, CTO_EINVAL, "cto_alt_info: null argument");
     CTO_REQUIRE(col >= 0 && size_t(col) < p->col_pos.size(), CTO_EINVAL, "cto_alt_info: column out of range");
     CTO_REQUIRE(pass == 0 || pass == 1, CTO_EINVAL, "cto_alt_info: pass must be 0 (AFF) or 1 (NEG)");
@@ -694,7 +694,7 @@ extern "C" int cto_alt_info(const cto_pack* p, int64_t col, int pass, const int1
     CTO_REQUIRE(s.size() + 1 <= cap, CTO_EINVAL, "cto_alt_info: buffer too small (%zu needed)", s.size() + 1);
     memcpy(buf, s.c_str(), s.size() + 1);
     return int(s.size());
-}
+} CTO_CATCH("cto_alt_info", int)
 
 namespace {
 // colvec: the column vectors of the whole pack (row = column index) or, with per_site, one row per candidate (row = site index)
@@ -723,12 +723,12 @@ int64_t alt_info_batch_impl(const cto_pack* p, int64_t n_sites, const int32_t* s
 
 extern "C" int64_t cto_alt_info_batch(const cto_pack* p, int64_t n_sites, const int32_t* site_info, int pass, const int16_t* colvec,
                                       const int32_t* sitefirst, const uint32_t* keycnt, const int32_t* keyfirst, char* buf,
-                                      size_t cap, int64_t* offsets) {
+                                      size_t cap, int64_t* offsets) try {
     return alt_info_batch_impl(p, n_sites, site_info, pass, colvec, false, sitefirst, keycnt, keyfirst, buf, cap, offsets);
-}
+} CTO_CATCH("cto_alt_info_batch", int64_t)
 
 extern "C" int64_t cto_alt_info_batch_sites(const cto_pack* p, int64_t n_sites, const int32_t* site_info, int pass,
                                             const int16_t* site_colvec, const int32_t* sitefirst, const uint32_t* keycnt,
-                                            const int32_t* keyfirst, char* buf, size_t cap, int64_t* offsets) {
+                                            const int32_t* keyfirst, char* buf, size_t cap, int64_t* offsets) try {
     return alt_info_batch_impl(p, n_sites, site_info, pass, site_colvec, true, sitefirst, keycnt, keyfirst, buf, cap, offsets);
-}
+} CTO_CATCH("cto_alt_info_batch_sites", int64_t)

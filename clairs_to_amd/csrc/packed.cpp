@@ -112,7 +112,7 @@ int create_packed(int kind, const float* packed, int64_t numel, const cto_cvt_cf
 
 }  // namespace
 
-extern "C" int64_t cto_model_manifest(int kind, const cto_cvt_cfg* cfg, int n_out, char* buf, size_t cap) {
+extern "C" int64_t cto_model_manifest(int kind, const cto_cvt_cfg* cfg, int n_out, char* buf, size_t cap) try {
     Manifest m;
     const int rc = build(kind, cfg, n_out, m);
     if (rc != CTO_OK) return rc;
@@ -120,12 +120,12 @@ extern "C" int64_t cto_model_manifest(int kind, const cto_cvt_cfg* cfg, int n_ou
     for (const auto& e : m) s += e.first + "\t" + std::to_string(e.second) + "\n";
     if (buf && cap > s.size()) memcpy(buf, s.c_str(), s.size() + 1);
     return int64_t(s.size()) + 1;
-}
+} CTO_CATCH("cto_model_manifest", int64_t)
 
-extern "C" int cto_cvt_create_packed(const float* packed, int64_t numel, const cto_cvt_cfg* cfg, cto_model** out) {
+extern "C" int cto_cvt_create_packed(const float* packed, int64_t numel, const cto_cvt_cfg* cfg, cto_model** out) try {
     return create_packed(0, packed, numel, cfg, cfg ? cfg->n_out : 0, out);
-}
+} CTO_CATCH("cto_cvt_create_packed", int)
 
-extern "C" int cto_bigru_create_packed(const float* packed, int64_t numel, int n_out, cto_model** out) {
+extern "C" int cto_bigru_create_packed(const float* packed, int64_t numel, int n_out, cto_model** out) try {
     return create_packed(1, packed, numel, nullptr, n_out, out);
-}
+} CTO_CATCH("cto_bigru_create_packed", int)

@@ -94,7 +94,7 @@ bool parse_alt_info(const char* s, int len, std::vector<Allele>& out, long long*
 // buffer; 512 bytes per site + twice the allele strings is always enough).
 extern "C" int64_t cto_vcf_rows_batch(const char* chrom, int64_t n, const int32_t* pos, const char* centre, const char* alt_buf,
                                       const int64_t* alt_off, const int32_t* site_info, const int32_t* decision, const double* qual,
-                                      int K, int show_ref, double qual_pass, char* buf, size_t cap, int64_t* counts) {
+                                      int K, int show_ref, double qual_pass, char* buf, size_t cap, int64_t* counts) try {
     CTO_REQUIRE(chrom && (n == 0 || (pos && centre && alt_buf && alt_off && site_info && decision && qual)) && buf && counts &&
                     (K == 4 || K == 6),
                 CTO_EINVAL, "cto_vcf_rows_batch: bad argument");
@@ -188,14 +188,14 @@ extern "C" int64_t cto_vcf_rows_batch(const char* chrom, int64_t n, const int32_
     }
     counts[0] = n_rows; counts[1] = n_sites; counts[2] = n_lowcov; counts[3] = n_clamped;
     return int64_t(used);
-}
+} CTO_CATCH("cto_vcf_rows_batch", int64_t)
 
 // Candidate BED chunk file -> window centres (src/create_tensor_pileup_calling.py:347-370): rows `ctg <tab> x-17 <tab> x+17
 // [<tab> type]` of contig `ctg`; position = start + 1, end = end + 1, centre = end - 18 when position < 1 (window clipped at
 // the contig start) else position + (end - position) / 2 - 1.  Writes up to `cap` centres in file order (the caller sorts and
 // de-duplicates: the reference keys a dict by them), span[0] / span[1] = min position / max end over the rows, and
 // *has_types = 1 when some row carries the optional fourth column.  Returns the number of rows of the contig, or < 0.
-extern "C" int64_t cto_bed_centres(const char* text, size_t len, const char* ctg, int32_t* out, int64_t cap, int64_t* span, int* has_types) {
+extern "C" int64_t cto_bed_centres(const char* text, size_t len, const char* ctg, int32_t* out, int64_t cap, int64_t* span, int* has_types) try {
     CTO_REQUIRE(text && ctg && out && span && has_types, CTO_EINVAL, "cto_bed_centres: null argument");
     const size_t cl = strlen(ctg);
     int64_t n = 0, lo = INT64_MAX, hi = 0;
@@ -240,4 +240,4 @@ extern "C" int64_t cto_bed_centres(const char* text, size_t len, const char* ctg
     span[0] = lo;
     span[1] = hi;
     return n;
-}
+} CTO_CATCH("cto_bed_centres", int64_t)
