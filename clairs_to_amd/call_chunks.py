@@ -19,8 +19,8 @@ The GPU needs ~2 ms per 4 096-site chunk; one producer delivers a chunk in 5 ms 
 
 The same three stages exist in C (`cto_run_chunks`, csrc/pipeline.hip: native threads, one page-locked staging copy per chunk,
 buffers kept from chunk to chunk) and are what `--pipeline auto` runs whenever the inputs are plain files - mpileup text
-(`--mpileup_dir`) or a BAM through the built-in reader (`--bam_reader native`); gzip inputs, the `samtools mpileup` subprocess, the
-device inflate and the `--predict_fn` tap stay on the thread pools of this module.  Both write the same files, byte for byte.
+(`--mpileup_dir`, plain or .gz) or a BAM through the built-in reader (`--bam_reader native`); the `samtools mpileup` subprocess, the
+Python-side device inflate and the `--predict_fn` tap stay on the thread pools of this module.  Both write the same files, byte for byte.
 """
 import os
 import sys
@@ -163,15 +163,12 @@ def run_pipeline(eng, chunk_args, producers=4, writers=2, depth=None, stats=None
 
 
 def native_eligible(chunk_args):
-    """cto_run_chunks reads plain files itself: no gzip inputs, no samtools subprocess, no device inflate, no --predict_fn tap"""
+    """cto_run_chunks reads the files itself (BED and pileup text plain or .gz, BAM through the built-in reader): no samtools
+    subprocess, no Python-side device inflate (`--bam_reader gpu`), no --predict_fn tap"""
     for a in chunk_args:
-        if getattr(a, "predict_fn", None) or a.candidates_bed_regions.endswith(".gz") or str(a.ref_fn).endswith(".gz"):
+        if getattr(a, "predict_fn", None):
             return False
-        mp = getattr(a, "mpileup_fn", None)
-        if mp:
-            if mp.endswith(".gz"):
-                return False
-        elif getattr(a, "bam_reader", "samtools") != "native":
+        if not getattr(a, "mpileup_fn", None) and getattr(a, "bam_reader", "samtools") != "native":
             return False
     return True
 
@@ -267,7 +264,7 @@ def call_chunks(args):
                 os.remove(a.call_fn)
         how = getattr(args, "pipeline", None) or "auto"
         if how == "native" and not native_eligible(mine):
-            sys.exit("[ERROR] --pipeline native reads plain files itself: needs --mpileup_dir or --bam_reader native, and no .gz inputs")
+            sys.exit("[ERROR] --pipeline native reads the files itself: needs --mpileup_dir or --bam_reader native (and no --predict_fn)")
         native = how == "native" or (how == "auto" and native_eligible(mine))
         run = run_pipeline_native if native else run_pipeline
         from_bam = not getattr(args, "mpileup_dir", None) and getattr(args, "bam_reader", None) in ("native", "gpu")

@@ -17,6 +17,7 @@
 #include <sys/stat.h>
 #include <fcntl.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
@@ -174,10 +175,31 @@ struct Queue {                            // unbounded MPMC queue with a closed 
     }
 };
 
-struct Mapped {                           // a read-only file mapping
+struct Mapped {                           // a file's bytes: mapped read-only, or - for a *.gz path - inflated into memory (zlib)
     const char* p = nullptr;
     size_t n = 0;
+    std::vector<char> owned;
     bool open(const char* path, std::string* err) {
+        const size_t pl = strlen(path);
+        if (pl > 3 && strcmp(path + pl - 3, ".gz") == 0) {            // the reference's readers gzip.open such files
+            gzFile g = gzopen(path, "rb");
+            if (!g) { *err = std::string("cannot open ") + path; return false; }
+            (void)gzbuffer(g, 1 << 20);
+            owned.resize(size_t(1) << 22);
+            size_t got = 0;
+            for (;;) {
+                if (got == owned.size()) owned.resize(owned.size() * 2);
+                const int r = gzread(g, owned.data() + got, unsigned(std::min<size_t>(owned.size() - got, size_t(1) << 30)));
+                if (r < 0) { gzclose(g); *err = std::string("cannot inflate ") + path; return false; }
+                if (r == 0) break;
+                got += size_t(r);
+            }
+            gzclose(g);
+            owned.resize(got);
+            p = got ? owned.data() : nullptr;
+            n = got;
+            return true;
+        }
         const int fd = ::open(path, O_RDONLY | O_CLOEXEC);
         if (fd < 0) { *err = std::string("cannot open ") + path; return false; }
         struct stat st;
@@ -191,7 +213,7 @@ struct Mapped {                           // a read-only file mapping
         ::close(fd);
         return true;
     }
-    ~Mapped() { if (p && n) munmap(const_cast<char*>(p), n); }
+    ~Mapped() { if (p && n && owned.empty()) munmap(const_cast<char*>(p), n); }
 };
 
 struct FaiRec { int64_t length = 0, offset = 0, linebases = 0, linewidth = 0; bool ok = false; };

@@ -304,7 +304,8 @@ int64_t cto_bed_centres(const char* text, size_t len, const char* ctg, int32_t* 
  * commands (create_tensor_pileup_calling x 2, predict --pileup, call_variants) as ONE call for the whole chunk list -
  * producer threads (BED -> centres, reference slice, column pack, upload on their own streams), the calling thread launching
  * featurisation + both networks + epilogue on `stream`, writer threads (alt_info strings, VCF records, p_<chunk>.vcf).
- * Plain text inputs only (no .gz).  A chunk without records leaves no file (call_variants.py:859-867).
+ * BED and pileup-text paths ending in .gz are inflated (as the reference's readers gzip.open them); the reference FASTA must be plain.
+ * A chunk without records leaves no file (call_variants.py:859-867).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct cto_chunk_job {
     const char* ctg_name;       /* --ctg_name                                                                  */

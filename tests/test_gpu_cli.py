@@ -372,6 +372,21 @@ def test_native_pipeline_writes_the_same_files(tmp_path, source, mode, aff_cls, 
             assert (st_dev["device_inflated"] == 0) if kw["inflate_cus"] == 0 else (1 <= st_dev["device_inflated"] <= len(parts))
             for fn in names:
                 assert open(tmp_path / "py" / fn, "rb").read() == open(tmp_path / "nat" / fn, "rb").read(), fn
+    if source == "text":      # gzip-compressed BED and pileup text: both pipelines inflate them (gzip.open / zlib), same file again
+        import gzip
+        import shutil
+        gz_py, gz_nat = chunk_args(str(tmp_path / "gz_py"))[:1], chunk_args(str(tmp_path / "gz_nat"))[:1]
+        for a in gz_py + gz_nat:
+            for attr in ("candidates_bed_regions", "mpileup_fn"):
+                src = getattr(a, attr)
+                if not os.path.exists(src + ".gz"):
+                    with open(src, "rb") as fi, gzip.open(src + ".gz", "wb") as fo:
+                        shutil.copyfileobj(fi, fo)
+                setattr(a, attr, src + ".gz")
+        assert native_eligible(gz_nat)
+        assert run_pipeline(eng, gz_py, producers=1, writers=1) == run_pipeline_native(eng, gz_nat, producers=1, writers=1, verbose=False) > 10
+        fn = os.path.basename(gz_py[0].call_fn)
+        assert open(tmp_path / "gz_py" / fn, "rb").read() == open(tmp_path / "gz_nat" / fn, "rb").read() == open(tmp_path / "py" / names[0], "rb").read()
     # consecutive chunks on two compute streams (a second pair of model handles): the same files
     assert run_pipeline_native(eng, a_nat, producers=3, writers=2, verbose=False, two_streams=True) == n_py
     for fn in names:
