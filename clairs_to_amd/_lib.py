@@ -47,7 +47,8 @@ class RunCfg(C.Structure):
                 ("min_rescale_cov", C.c_int), ("max_indel_length", C.c_int), ("max_depth", C.c_int), ("neg_reads_aff", C.c_int),
                 ("show_ref", C.c_int), ("verbose", C.c_int), ("qual_pass", C.c_double), ("ref_fa", C.c_char_p),
                 ("vcf_header", C.c_char_p), ("producers", C.c_int), ("writers", C.c_int), ("depth", C.c_int),
-                ("inflate_cus", C.c_int), ("inflate_jobs", C.c_int), ("pack_threads", C.c_int), ("aff2", c_vp), ("neg2", c_vp)]
+                ("inflate_cus", C.c_int), ("inflate_jobs", C.c_int), ("pack_threads", C.c_int), ("samtools", C.c_char_p),
+                ("samtools_max_depth", C.c_int), ("aff2", c_vp), ("neg2", c_vp)]
 
 
 class RunStats(C.Structure):

@@ -19,8 +19,8 @@ The GPU needs ~2 ms per 4 096-site chunk; one producer delivers a chunk in 5 ms 
 
 The same three stages exist in C (`cto_run_chunks`, csrc/pipeline.hip: native threads, one page-locked staging copy per chunk,
 buffers kept from chunk to chunk) and are what `--pipeline auto` runs whenever the inputs are plain files - mpileup text
-(`--mpileup_dir`, plain or .gz) or a BAM through the built-in reader (`--bam_reader native`); the `samtools mpileup` subprocess, the
-Python-side device inflate and the `--predict_fn` tap stay on the thread pools of this module.  Both write the same files, byte for byte.
+(`--mpileup_dir`, plain or .gz), a BAM through the built-in reader (`--bam_reader native`) or through a `samtools mpileup` child per chunk;
+the Python-side device inflate (`--bam_reader gpu`) and the `--predict_fn` tap stay on the thread pools of this module.  Both write the same files, byte for byte.
 """
 import os
 import sys
@@ -163,12 +163,12 @@ def run_pipeline(eng, chunk_args, producers=4, writers=2, depth=None, stats=None
 
 
 def native_eligible(chunk_args):
-    """cto_run_chunks reads the files itself (BED and pileup text plain or .gz, BAM through the built-in reader): no samtools
-    subprocess, no Python-side device inflate (`--bam_reader gpu`), no --predict_fn tap"""
+    """cto_run_chunks reads the files itself (BED and pileup text plain or .gz, BAM through the built-in reader or a `samtools
+    mpileup` child process per chunk): not the Python-side device inflate (`--bam_reader gpu`), not the --predict_fn tap"""
     for a in chunk_args:
         if getattr(a, "predict_fn", None):
             return False
-        if not getattr(a, "mpileup_fn", None) and getattr(a, "bam_reader", "samtools") != "native":
+        if not getattr(a, "mpileup_fn", None) and getattr(a, "bam_reader", "samtools") not in ("native", "samtools"):
             return False
     return True
 
@@ -204,6 +204,9 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
     cfg.ref_fa = str(a0.ref_fn).encode()
     cfg.vcf_header = (VCF_HEADER + "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n" % a0.sample_name).encode()
     cfg.producers, cfg.writers, cfg.depth = int(producers), int(writers), int(depth or 0)
+    if not getattr(a0, "mpileup_fn", None) and getattr(a0, "bam_reader", "samtools") == "samtools":
+        cfg.samtools = str(a0.samtools).encode()                  # the reference's producer, one child process per chunk
+        cfg.samtools_max_depth = int(a0.max_depth or 0)
     # threads per producer call: the environment's CTO_PACK_THREADS if the user set one, else this module's plan for the host
     cfg.pack_threads = 0 if "CTO_PACK_THREADS" in os.environ else pack_threads(not getattr(a0, "mpileup_fn", None), "native")
     cfg.inflate_cus = DEVICE_INFLATE[0] if inflate_cus is None else int(inflate_cus)       # only BAM jobs use it
@@ -264,11 +267,16 @@ def call_chunks(args):
                 os.remove(a.call_fn)
         how = getattr(args, "pipeline", None) or "auto"
         if how == "native" and not native_eligible(mine):
-            sys.exit("[ERROR] --pipeline native reads the files itself: needs --mpileup_dir or --bam_reader native (and no --predict_fn)")
+            sys.exit("[ERROR] --pipeline native does not do --bam_reader gpu or --predict_fn")
         native = how == "native" or (how == "auto" and native_eligible(mine))
         run = run_pipeline_native if native else run_pipeline
-        from_bam = not getattr(args, "mpileup_dir", None) and getattr(args, "bam_reader", None) in ("native", "gpu")
-        producers = args.producers if getattr(args, "producers", None) else default_producers(from_bam, "native" if native else "python")
+        reader = None if getattr(args, "mpileup_dir", None) else getattr(args, "bam_reader", "samtools")
+        if getattr(args, "producers", None):
+            producers = args.producers
+        elif reader == "samtools":        # one `samtools mpileup` child per producer (a core each; the producer sleeps on its pipe)
+            producers = max(1, min(64, usable_cores()))
+        else:
+            producers = default_producers(reader in ("native", "gpu"), "native" if native else "python")
         kw = dict(inflate_cus=getattr(args, "device_inflate_cus", None)) if native else {}
         n_rows = run(eng, mine, producers=producers, writers=getattr(args, "writers", None) or 2, **kw)
     except (Exception, SystemExit) as e:     # a bad reference, a corrupt BAM, CTO_EUNSUPPORTED ...: report, do not leave the others waiting

@@ -17,6 +17,8 @@
 #include <sys/stat.h>
 #include <fcntl.h>
 #include <unistd.h>
+#include <spawn.h>
+#include <sys/wait.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -36,6 +38,8 @@
 #include "pack_internal.h"
 
 using namespace cto;
+
+extern char** environ;
 
 namespace {
 
@@ -215,6 +219,43 @@ struct Mapped {                           // a file's bytes: mapped read-only, o
     }
     ~Mapped() { if (p && n && owned.empty()) munmap(const_cast<char*>(p), n); }
 };
+
+// stdout of `argv` (a `samtools mpileup ...` command line) into `out`; false + *err when it cannot be started or exits non-zero
+// (create_tensor_pileup_calling.py:426-446 pipes the same command; subprocess.run(check=True) in the Python mirror)
+bool capture_stdout(const std::vector<std::string>& argv, std::vector<char>* out, std::string* err) {
+    int fds[2];
+    if (pipe2(fds, O_CLOEXEC) != 0) { *err = "pipe() failed"; return false; }
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_adddup2(&fa, fds[1], 1);
+    std::vector<char*> av;
+    for (const std::string& a : argv) av.push_back(const_cast<char*>(a.c_str()));
+    av.push_back(nullptr);
+    pid_t pid = 0;
+    const int rc = posix_spawnp(&pid, av[0], &fa, nullptr, av.data(), environ);
+    posix_spawn_file_actions_destroy(&fa);
+    ::close(fds[1]);
+    if (rc != 0) { ::close(fds[0]); *err = "cannot run " + argv[0] + ": " + strerror(rc); return false; }
+    out->clear();
+    out->resize(size_t(1) << 22);
+    size_t got = 0;
+    for (;;) {
+        if (got == out->size()) out->resize(out->size() * 2);
+        const ssize_t r = read(fds[0], out->data() + got, out->size() - got);
+        if (r < 0 && errno == EINTR) continue;
+        if (r <= 0) break;
+        got += size_t(r);
+    }
+    ::close(fds[0]);
+    out->resize(got);
+    int status = 0;
+    while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
+    if (!WIFEXITED(status) || WEXITSTATUS(status) != 0) {
+        *err = argv[0] + " mpileup failed (exit status " + std::to_string(WIFEXITED(status) ? WEXITSTATUS(status) : -1) + ")";
+        return false;
+    }
+    return true;
+}
 
 struct FaiRec { int64_t length = 0, offset = 0, linebases = 0, linewidth = 0; bool ok = false; };
 
@@ -479,15 +520,30 @@ struct Run {
             std::vector<int64_t> iv;
             bed_intervals(bed.p ? bed.p : "", bed.n, ctg, &iv);
             const int64_t lo = std::max<int64_t>(1, ctg_start - FLANK_POS), hi = ctg_end + FLANK_POS;
-            InflateCtx* c = nullptr;
-            int done = 0;
-            if (free_ctx.try_pop(&c)) {                            // a device-inflate context is free: this chunk's blocks go to the GPU
-                rc = pack_from_bam_device(j, ctg, lo, hi, iv, s, c, &done);
-                free_ctx.push(c);
+            if (cfg->samtools) {
+                // the reference's own producer: `samtools mpileup` with --min-BQ 0 (one pileup serves both passes), its text tokenised
+                std::vector<std::string> cmd = {cfg->samtools, "mpileup", "--reverse-del", "--output-MQ", "-r",
+                                                ctg + ":" + std::to_string(lo) + "-" + std::to_string(hi), "--min-MQ", "0", "--min-BQ", "0", "-l",
+                                                j.bed_path, "--excl-flags", "2316"};
+                if (cfg->samtools_max_depth > 0) { cmd.push_back("--max-depth"); cmd.push_back(std::to_string(cfg->samtools_max_depth)); }
+                cmd.push_back(j.bam_path);
+                std::vector<char> text;
+                if (!capture_stdout(cmd, &text, &err)) { fail(err); return false; }
+                const size_t ecap = text.size() / 3 + 4096;
+                if (s->stage.ensure(ecap * 4 + text.size() / 4 + (size_t(1) << 20)) != CTO_OK) { fail(cto_last_error()); return false; }
+                rc = pack_from_mpileup_impl(text.empty() ? "" : text.data(), text.size(), s->ref.data(), s->ref_start, s->ref.size(),
+                                            cfg->max_indel_length, static_cast<uint32_t*>(s->stage.p), ecap, &s->pack);
+            } else {
+                InflateCtx* c = nullptr;
+                int done = 0;
+                if (free_ctx.try_pop(&c)) {                        // a device-inflate context is free: this chunk's blocks go to the GPU
+                    rc = pack_from_bam_device(j, ctg, lo, hi, iv, s, c, &done);
+                    free_ctx.push(c);
+                }
+                if (!done && rc == CTO_OK)
+                    rc = cto_pack_from_bam(j.bam_path, nullptr, ctg.c_str(), lo, hi, iv.empty() ? nullptr : iv.data(), int64_t(iv.size() / 2),
+                                           s->ref.data(), s->ref_start, s->ref.size(), 2316, 0, cfg->max_depth, cfg->max_indel_length, &s->pack);
             }
-            if (!done && rc == CTO_OK)
-                rc = cto_pack_from_bam(j.bam_path, nullptr, ctg.c_str(), lo, hi, iv.empty() ? nullptr : iv.data(), int64_t(iv.size() / 2),
-                                       s->ref.data(), s->ref_start, s->ref.size(), 2316, 0, cfg->max_depth, cfg->max_indel_length, &s->pack);
         }
         if (rc != CTO_OK) { fail(cto_last_error()); return false; }
         if (cto_pack_view_of(s->pack, &s->hv) != CTO_OK) { fail(cto_last_error()); return false; }

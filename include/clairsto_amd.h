@@ -340,6 +340,11 @@ typedef struct cto_run_cfg {
                                    creates one of its own, ordered behind the default stream's work so far.                    */
     int    pack_threads;        /* threads one producer's tokeniser / BAM decoder call may use (0: CTO_PACK_THREADS or the library's
                                    default of up to 32): producers x pack_threads should stay near the usable cores            */
+    const char*   samtools;     /* BAM input: NULL = the built-in reader; else this program (PATH is searched) is run per chunk as
+                                   `samtools mpileup --reverse-del --output-MQ -r ctg:s-e --min-MQ 0 --min-BQ 0 -l <bed> --excl-flags 2316
+                                   [--max-depth samtools_max_depth] <bam>` (create_tensor_pileup_calling.py:426-446, with --min-BQ 0)
+                                   and its text tokenised                                                                      */
+    int    samtools_max_depth;  /* > 0: passed as --max-depth                                                                 */
     cto_model*    aff2;         /* optional second pair of handles of the same weights (NULL: none): with them consecutive chunks  */
     cto_model*    neg2;         /* alternate between two compute streams, and the next chunk's first round of workgroups fills the
                                    CUs this chunk's last round leaves idle (chunk sizes that are not a multiple of 4096 sites:

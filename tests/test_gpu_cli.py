@@ -449,6 +449,52 @@ def test_native_pipeline_illumina_min_bq(tmp_path):
     assert open(tmp_path / "py" / "p.vcf", "rb").read() == open(tmp_path / "nat" / "p.vcf", "rb").read()
 
 
+def test_native_pipeline_runs_samtools_per_chunk(tmp_path):
+    """--bam_reader samtools (the reference's producer, the default): cto_run_chunks starts `samtools mpileup ...` per chunk and
+    tokenises its output - same file as the Python pipeline's subprocess path and as the built-in reader; a failing samtools is an
+    error of the run.  (samtools itself is absent here: a shim that checks its arguments and prints the prepared pileup stands in.)"""
+    import stat
+    from argparse import Namespace
+    from clairs_to_amd._lib import CtoError
+    from clairs_to_amd.call_chunks import native_eligible, run_pipeline, run_pipeline_native
+    from clairs_to_amd.pileup_call import make_engine
+    from clairs_to_amd.synth import likelihood_table
+    sc = _bam_scenario(tmp_path)
+    paths = _pickle_models(tmp_path, "CvT", "BiGRU_NACGT", 4)
+    lik = tmp_path / "lik.txt"
+    np.savetxt(lik, likelihood_table(4, seed=11), fmt="%.17g")
+    shim = tmp_path / "samtools_checked"
+    shim.write_text("#!/bin/sh\n# stands in for samtools: the command line must be the reference's (with --min-BQ 0), then the prepared pileup\n"
+                    "[ \"$1\" = mpileup ] && [ \"$2\" = --reverse-del ] && [ \"$3\" = --output-MQ ] && [ \"$4\" = -r ] || exit 3\n"
+                    "case \"$*\" in *\"--min-MQ 0 --min-BQ 0 -l %s --excl-flags 2316 --max-depth 7000 %s\") ;; *) exit 4 ;; esac\n"
+                    "cat %s\n" % (sc["bed"], sc["bam"], sc["mp"]))
+    shim.chmod(shim.stat().st_mode | stat.S_IEXEC)
+    bad = tmp_path / "samtools_fails"
+    bad.write_text("#!/bin/sh\nexit 1\n")
+    bad.chmod(bad.stat().st_mode | stat.S_IEXEC)
+
+    def args(out, **kw):
+        os.makedirs(tmp_path / out, exist_ok=True)
+        base = dict(platform="ont", ref_fn=sc["fa"], ctg_name="chr1", samtools=str(shim), bam_reader="samtools", tumor_bam_fn=sc["bam"],
+                    mpileup_fn=None, min_bq=None, max_depth=7000, max_indel_length=None, candidates_bed_regions=sc["bed"],
+                    chkpnt_fn_acgt=paths["model_acgt"], chkpnt_fn_nacgt=paths["model_nacgt"], min_rescale_cov=50, disable_indel_calling=True,
+                    likelihood_matrix_data=str(lik), call_fn=str(tmp_path / out / "p.vcf"), predict_fn=None, sample_name="S", show_ref=True,
+                    qual=0, pileup=True)
+        base.update(kw)
+        return [Namespace(**base)]
+    eng = make_engine(args("x")[0], "cuda:0")
+    assert native_eligible(args("x"))
+    n_py = run_pipeline(eng, args("py"), producers=1, writers=1)
+    n_nat = run_pipeline_native(eng, args("nat"), producers=1, writers=1, verbose=False)
+    n_own = run_pipeline_native(eng, args("own", bam_reader="native", max_depth=None), producers=1, writers=1, verbose=False, inflate_cus=0)
+    assert n_py == n_nat == n_own > 50
+    assert open(tmp_path / "py" / "p.vcf", "rb").read() == open(tmp_path / "nat" / "p.vcf", "rb").read() == open(tmp_path / "own" / "p.vcf", "rb").read()
+    with pytest.raises(CtoError, match="mpileup failed"):
+        run_pipeline_native(eng, args("bad", samtools=str(bad)), producers=1, writers=1, verbose=False)
+    with pytest.raises(CtoError, match="cannot run"):
+        run_pipeline_native(eng, args("bad", samtools=str(tmp_path / "no_such_samtools")), producers=1, writers=1, verbose=False)
+
+
 def test_native_pipeline_reports_errors(tmp_path):
     """a missing pileup file, a contig the reference index does not hold: CtoError naming the cause, no hang, no partial state"""
     from argparse import Namespace
