@@ -107,6 +107,16 @@ def test_tokeniser_paths_agree():
             os.environ["CTO_PACK_THREADS"] = old
     for k in out[0]:
         np.testing.assert_array_equal(out[0][k], out[1][k], err_msg="threads: " + k)
+    # the per-thread setting (what the chunk pipelines use instead of the environment variable) wins over it, 0 hands control back
+    from clairs_to_amd._lib import lib
+    try:
+        lib.cto_set_pack_threads(5)
+        p5 = ColumnPack.from_mpileup(btext, bref, blo)
+        a5 = {k: v.copy() for k, v in p5.numpy().items()}
+    finally:
+        lib.cto_set_pack_threads(0)
+    for k in out[0]:
+        np.testing.assert_array_equal(out[0][k], a5[k], err_msg="cto_set_pack_threads: " + k)
 
 
 def _rows(text):
