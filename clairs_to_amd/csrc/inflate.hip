@@ -19,7 +19,7 @@
 //     chunks a second.  With 4 KB of LDS per wave, six waves per SIMD take turns on that chain.
 // Measured on MI355X (tools/inflate_bench.py, a 1 Mb x 50x chunk: 77 MB of BAM in 1776 blocks -> 115 MB): 20 ms for one launch
 // alone (15 ms with the literal stores taken out: the decode chain, not memory, is the cost), 8 ms per chunk with 4-8 launches in
-// flight = 14 GB/s of inflated bytes (5.8 ms = 19.8 GB/s with the literal loop and the match queue below), about what 25 host
+// flight = 14 GB/s of inflated bytes (5.5 ms = 20.9 GB/s with the literal loop and the match queue below), about what 25 host
 // cores of libdeflate deliver.  It pays beside the host cores, not instead
 // of them: the chunk pipeline (pipeline.hip) sends some chunks through it on streams confined to part of the CUs - unconfined, the
 // waves of a launch sit on every CU for tens of milliseconds and the networks' block kernels wait for them - and BAM -> VCF goes
@@ -42,7 +42,8 @@
 // rounds that respect the dependencies (resolve_matches) - 5.8 (kept).  That it is worth 7 % and not a factor says where the
 // bound is: the decoder is wave-uniform code, ~40 of its ~65 instructions per symbol run on the scalar unit, a CU has ONE scalar
 // unit for its four SIMDs, and 256 CUs x 2.1 GHz / 40 = 13 G symbols/s = 17 GB/s - what is measured.  Waves per SIMD, memory
-// latency and store drains are second-order once a CU holds enough waves to keep that unit busy.
+// latency and store drains are second-order once a CU holds enough waves to keep that unit busy.  Consequently the literal loop
+// keeps its bit buffer in vector registers (13 scalar + 11 vector instructions per literal instead of 20 + 7): 5.5.
 // Every loop is bounded by the block's compressed size (a symbol consumes at least one bit) or by constants; malformed input
 // ends with a status code, never with a hang or an out-of-range access (the input buffer carries CTO_BGZF_PAD bytes of padding,
 // every output slot is padded to 256 bytes).
@@ -392,13 +393,47 @@ extern "C" __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* _
                 // one transaction, no exec-mask juggling) and a shift.  This loop is two thirds of all symbols of a BAM block and is
                 // kept free of everything the other symbols need (the general form below cost ~50 instructions per literal in
                 // compiler-made copies and checks; a single wave issues them one at a time).
-                for (;;) {
-                    bits_refill(b, lane);
-                    const uint32_t e = uint32_t(__builtin_amdgcn_readfirstlane(int(tab_l[uint32_t(b.bb) & ((1u << TBL) - 1u)])));
-                    if (!(e & 0x8000u) || op >= isize) break;
-                    dst[op] = uint8_t(e);
-                    ++op;
-                    bits_drop(b, int((e >> 9) & 15u));
+                // The bit buffer of this loop lives in VECTOR registers (every lane holds the same value): a CU has one scalar unit for
+                // its four SIMDs and the decoder is bound by it, so the shifts, masks and the table address go to the vector ALUs and the
+                // scalar unit keeps the branches, the output position and the store address.
+                {
+                    uint32_t vlo, vhi;
+                    int vcnt;
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(vlo) : "s"(uint32_t(b.bb)));
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(vhi) : "s"(uint32_t(b.bb >> 32)));
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(vcnt) : "s"(b.cnt));
+                    uint32_t vop;                                // the output position once more, for the store's address
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(vop) : "s"(uint32_t(op)));
+                    uint64_t vbb = (uint64_t(vhi) << 32) | vlo;
+                    for (;;) {
+                        if (uni(vcnt) <= 32) {                   // bits_refill on the vector copy
+                            uint32_t d = 0;
+                            if (b.widx <= b.limit) {
+                                if (b.widx - b.wbase >= 64) {
+                                    b.wbase += 64;
+                                    b.win = b.src[b.wbase + lane];
+                                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                                }
+                                d = rl(b.win, b.widx - b.wbase);
+                            } else {
+                                b.over = 1;
+                            }
+                            vbb |= uint64_t(d) << vcnt;
+                            vcnt += 32;
+                            ++b.widx;
+                        }
+                        const uint32_t e = uint32_t(__builtin_amdgcn_readfirstlane(int(tab_l[uint32_t(vbb) & ((1u << TBL) - 1u)])));
+                        if (!(e & 0x8000u)) break;
+                        if (op >= isize) break;
+                        dst[vop] = uint8_t(e);
+                        ++vop;
+                        ++op;
+                        const int l = int((e >> 9) & 15u);
+                        vbb >>= l;
+                        vcnt -= l;
+                    }
+                    b.bb = uint64_t(uint32_t(uni(int(uint32_t(vbb))))) | (uint64_t(uint32_t(uni(int(uint32_t(vbb >> 32))))) << 32);
+                    b.cnt = uni(vcnt);
                 }
                 bits_refill(b, lane);
                 int l = 0;
