@@ -4,7 +4,7 @@ import importlib
 import sys
 
 SUBMODULES = ("extract_candidates_calling", "create_tensor_pileup_calling", "predict", "call_variants", "pileup_call", "call_chunks",
-              "sort_vcf", "postprocess_vcf", "haplotype_filtering")
+              "sort_vcf", "postprocess_vcf", "haplotype_filtering", "realign_reads", "realign_variants")
 
 
 def main():

@@ -478,14 +478,10 @@ extern "C" __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* _
     if (lane == 0) status[blk] = st;
 }
 
-int launch_bgzf_inflate_lanes(const void* d_comp, const cto_bgzf_block* d_blocks, int n_blocks, void* d_out, int* d_status, hipStream_t stream);
-
 extern "C" int cto_bgzf_inflate(const void* d_comp, const cto_bgzf_block* d_blocks, int n_blocks, void* d_out, int* d_status, void* stream) {
     using namespace cto;
     CTO_REQUIRE(n_blocks >= 0 && (n_blocks == 0 || (d_comp && d_blocks && d_out && d_status)), CTO_EINVAL, "cto_bgzf_inflate: null argument");
     if (n_blocks == 0) return CTO_OK;
-    const char* lanes = getenv("CTO_INFLATE_LANES");             // experimental decoder, one block per lane (inflate_lanes.hip)
-    if (lanes && lanes[0] == '1') return launch_bgzf_inflate_lanes(d_comp, d_blocks, n_blocks, d_out, d_status, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(k_bgzf_inflate, dim3(unsigned(n_blocks)), dim3(64), 0, static_cast<hipStream_t>(stream),
                        static_cast<const uint8_t*>(d_comp), d_blocks, n_blocks, static_cast<uint8_t*>(d_out), d_status);
     CTO_HIP(hipGetLastError());

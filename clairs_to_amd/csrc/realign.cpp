@@ -1,0 +1,585 @@
+// Illumina read realignment (SURVEY.md 8f #4b): the native half of `realign_reads`, written from scratch.
+//
+// What the reference does (src/realign/realigner.cpp, a descendant of DeepVariant's fast-pass aligner, + the SSW library):
+// the reads of one window are aligned to every candidate haplotype - first by an exact k-mer seeded "fast pass" that accepts
+// <= 2 mismatches (realigner.cpp:147-229), then, for reads no haplotype took, by Smith-Waterman (:351-384) - the haplotypes are
+// aligned to the reference by Smith-Waterman (:315-349), and every read's read->haplotype alignment is composed with its best
+// haplotype's haplotype->reference alignment into a new read->reference CIGAR and position (:386-433, :653-778).
+//
+// This file restates that contract, not its data structures: flat op arrays walked with cursors instead of std::list<CigarOp>
+// splicing and regex parsing, one integer cell model for both SSE2 kernels.  Two places have to follow the reference to the letter because their
+// *tie-breaking* decides the output bytes:
+//   (1) Smith-Waterman.  The reference's scores come from the SSE2 striped kernels of SSW (ssw.c:118-529).  Their "lazy F" loop
+//       does not feed corrected H values back into E, so whether an insertion may directly follow a deletion depends on where the
+//       stripe boundaries fall (segment length = ceil(query / 16) in 8-bit mode, ceil(query / 8) in 16-bit mode).  `striped_pass`
+//       is a scalar model of exactly that recurrence (per-stripe F chains, the two lazy-F loop shapes and their exit tests, the
+//       8-bit overflow rule that switches to 16 bit), so end points and begin points agree cell for cell.  The CIGAR comes from the
+//       banded traceback of ssw.c:531-741, whose band bookkeeping (one zeroed edge cell per row, doubled band until the score is
+//       reached, E before F before diagonal on ties) is reproduced with the same band coordinates.
+//   (2) Haplotype order.  The reference std::sort()s haplotypes by score (realigner.cpp:108) and breaks read-score ties by that
+//       order (:515-539); the same std::sort over the same keys gives the same permutation.
+// Pinned against the reference compiled here (oracle/_ref/librealigner_ref.so, `make -C oracle ref`): tests/test_realign.py and the
+// committed windows of tests/golden/realign.json.gz.
+//
+// Deviations (all unreachable from `reads_realignment`, flagged): a haplotype shorter than the k-mer makes the reference index
+// past the string (unsigned wrap at realigner.cpp:157) - here CTO_EINVAL; an alignment of score 0 makes SSW read ref[-1] - here
+// "no alignment"; bytes >= 0x80 index the reference's translation table out of bounds - here they are N.
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "common.h"
+
+namespace {
+
+// ---- scoring: realigner.cpp:63-73 (set_options) and the default SSW aligner it ends up using (ssw_cpp.cpp:230-242; `InitSswLib`
+// at realigner.cpp:121-127 builds a local object, so the member keeps its defaults - which are the same numbers)
+constexpr int kMatch = 4, kMismatch = 6, kGapOpen = 8, kGapExt = 2;
+constexpr int kKmer = 32;
+constexpr int kMaxMismatches = 2;
+constexpr int kSswThreshold = 1;      // CalculateSswAlignmentScoreThreshold (:75-85): 4*250*0.16934 - 6*250*(1-0.16934) < 0 -> 1
+
+inline int8_t base_code(char c) {      // ssw_cpp.cpp:37-50 (A C G T U, either case; everything else 4)
+    switch (c) {
+        case 'A': case 'a': case 'U': case 'u': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': return 3;
+        default: return 4;
+    }
+}
+inline int sub_score(int8_t a, int8_t b) { return (a == b && a < 4) ? kMatch : -kMismatch; }   // ssw_cpp.cpp:52-76
+
+struct Codes {
+    std::vector<int8_t> v;
+    explicit Codes(const char* s, size_t n) : v(n) { for (size_t i = 0; i < n; ++i) v[i] = base_code(s[i]); }
+};
+
+// ------------------------------------------------------------------------------------------------------------------------
+// One pass of the striped recurrence (ssw.c:118-311 for `lanes` = 16, :341-529 for 8) in scalar form.
+// ref is walked forwards (reverse = false) or backwards over [0, ref_len); the query occupies linear positions q = lane * seg + j.
+struct PassEnd { int score, ref_end, read_end; bool overflow; };
+
+PassEnd striped_pass(const int8_t* ref, int ref_len, bool reverse, const int8_t* read, int read_len, int lanes, int terminate) {
+    const int seg = (read_len + lanes - 1) / lanes, P = seg * lanes;
+    const bool byte_mode = lanes == 16;
+    const int bias = kMismatch;                       // ssw_init: |most negative matrix entry|
+    std::vector<int> prev(P, 0), cur(P, 0), E(P, 0), best_col(P, 0), F(lanes), Fl(lanes), hh(lanes);
+    int best = 0, ref_end = byte_mode ? -1 : 0;
+    bool overflow = false;
+    const int begin = reverse ? ref_len - 1 : 0, end = reverse ? -1 : ref_len, step = reverse ? -1 : 1;
+    for (int i = begin; i != end; i += step) {
+        const int8_t rc = ref[i];
+        prev.swap(cur);                               // prev = column i-1 (final), cur = scratch
+        int colmax = 0;
+        for (int lane = 0; lane < lanes; ++lane) {
+            int f = 0;
+            for (int j = 0; j < seg; ++j) {
+                const int q = lane * seg + j;
+                const int s = q < read_len ? sub_score(rc, read[q]) : 0;      // padding rows score 0 (profile = bias / 0)
+                int h = (q > 0 ? prev[q - 1] : 0) + s;
+                if (h < 0) h = 0;
+                const int e = E[q];
+                if (e > h) h = e;
+                if (f > h) h = f;
+                if (h > colmax) colmax = h;
+                cur[q] = h;
+                const int open = h > kGapOpen ? h - kGapOpen : 0;
+                E[q] = std::max(e > kGapExt ? e - kGapExt : 0, open);       // E never sees the lazy-F corrections below
+                f = std::max(f > kGapExt ? f - kGapExt : 0, open);
+            }
+            F[lane] = f;
+        }
+        // lazy F: the F chain that leaves stripe k enters stripe k+1
+        auto shift = [&](std::vector<int>& v) { for (int l = lanes - 1; l > 0; --l) v[l] = v[l - 1]; v[0] = 0; };
+        Fl = F;
+        if (byte_mode) {                              // ssw.c:207-241
+            shift(Fl);
+            int j = 0;
+            for (;;) {
+                bool settled = true;
+                for (int l = 0; l < lanes; ++l) {
+                    const int h = cur[l * seg + j];
+                    if (Fl[l] > (h > kGapOpen ? h - kGapOpen : 0)) { settled = false; break; }
+                }
+                if (settled) break;
+                for (int l = 0; l < lanes; ++l) {
+                    int& h = cur[l * seg + j];
+                    if (Fl[l] > h) h = Fl[l];
+                    if (h > colmax) colmax = h;
+                    Fl[l] = Fl[l] > kGapExt ? Fl[l] - kGapExt : 0;
+                }
+                if (++j >= seg) { j = 0; shift(Fl); }
+            }
+        } else {                                      // ssw.c:446-459
+            bool done = false;
+            for (int k = 0; k < lanes && !done; ++k) {
+                shift(Fl);
+                for (int j = 0; j < seg; ++j) {
+                    bool any = false;
+                    for (int l = 0; l < lanes; ++l) {
+                        int& h = cur[l * seg + j];
+                        if (Fl[l] > h) h = Fl[l];
+                        if (h > colmax) colmax = h;
+                        hh[l] = h > kGapOpen ? h - kGapOpen : 0;
+                        Fl[l] = Fl[l] > kGapExt ? Fl[l] - kGapExt : 0;
+                        if (Fl[l] > hh[l]) any = true;
+                    }
+                    if (!any) { done = true; break; }
+                }
+            }
+        }
+        if (colmax > best) {
+            best = colmax;
+            if (byte_mode && best + bias >= 255) { overflow = true; break; }
+            ref_end = i;
+            best_col = cur;
+        }
+        if (colmax == terminate) break;
+    }
+    int read_end = read_len - 1;
+    for (int q = 0; q < P; ++q)
+        if (best_col[q] == best) { if (q < read_end) read_end = q; break; }
+    return {overflow ? 255 : best, ref_end, read_end, overflow};
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Banded traceback (ssw.c:531-741).  Returns run-length ops over {'M','I','D'} in query order; empty = the reference would fail.
+struct Run { char op; int len; };
+
+bool banded_path(const int8_t* ref, const int8_t* read, int R, int Q, int score, int band, std::vector<Run>& out) {
+    std::vector<int> hb, eb, hc;
+    std::vector<int8_t> dir;
+    int best = 0, width_d = 0;
+    auto bu = [](int w, int i, int j) { int x = i - w; if (x < 0) x = 0; return j - x + 1; };            // set_u
+    auto bd = [](int w, int i, int j, int p) { int x = i - w; if (x < 0) x = 0; return (j - x) * 3 + p; };  // set_d
+    for (;;) {
+        const int width = band * 2 + 3;
+        width_d = band * 2 + 1;
+        if ((int)hb.size() < width + 1) { hb.resize(width + 1, 0); eb.resize(width + 1, 0); hc.resize(width + 1, 0); }
+        if ((int64_t)width_d * Q * 3 > (int64_t)1 << 30) return false;
+        dir.assign((size_t)width_d * Q * 3 + 3, 0);
+        for (int j = 1; j < width - 1; ++j) hb[j] = 0;
+        for (int i = 0; i < Q; ++i) {
+            const int beg = std::max(0, i - band), end = std::min(R - 1, i + band);
+            const int edge = std::min(end + 1, width - 1);
+            int f = 0, u = 0;
+            hb[0] = eb[0] = hb[edge] = eb[edge] = hc[0] = 0;
+            int8_t* line = dir.data() + (size_t)width_d * i * 3;
+            for (int j = beg; j <= end; ++j) {
+                u = bu(band, i, j);
+                const int up = bu(band, i - 1, j), left = bu(band, i, j - 1), diag = bu(band, i - 1, j - 1);
+                int t1 = i == 0 ? -kGapOpen : hb[up] - kGapOpen;
+                int t2 = i == 0 ? -kGapExt : eb[up] - kGapExt;
+                eb[u] = std::max(t1, t2);
+                const int8_t de = t1 > t2 ? 3 : 2;
+                line[bd(band, i, j, 0)] = de;
+                t1 = hc[left] - kGapOpen;
+                t2 = f - kGapExt;
+                f = std::max(t1, t2);
+                const int8_t df = t1 > t2 ? 5 : 4;
+                line[bd(band, i, j, 1)] = df;
+                const int e1 = std::max(eb[u], 0), f1 = std::max(f, 0);
+                t1 = std::max(e1, f1);
+                t2 = hb[diag] + sub_score(ref[j], read[i]);
+                hc[u] = std::max(t1, t2);
+                if (hc[u] > best) best = hc[u];
+                line[bd(band, i, j, 2)] = t1 <= t2 ? (int8_t)1 : (e1 > f1 ? de : df);
+            }
+            for (int j = 1; j <= u; ++j) hb[j] = hc[j];
+        }
+        if (best >= score) break;
+        band *= 2;
+    }
+    // trace back from the last cell in the H state
+    int i = Q - 1, j = R - 1, state = 2, count = 0;
+    char op = 'M', prev = 'M';
+    std::vector<Run> rev;
+    while (i > 0) {
+        const int x = i - band > 0 ? i - band : 0;
+        if (j < x || j - x >= width_d) return false;
+        const int8_t d = dir[(size_t)width_d * i * 3 + (j - x) * 3 + state];
+        switch (d) {
+            case 1: --i; --j; state = 2; op = 'M'; break;
+            case 2: --i; state = 0; op = 'I'; break;
+            case 3: --i; state = 2; op = 'I'; break;
+            case 4: --j; state = 1; op = 'D'; break;
+            case 5: --j; state = 2; op = 'D'; break;
+            default: return false;
+        }
+        if (op == prev) ++count;
+        else { rev.push_back({prev, count}); prev = op; count = 1; }
+    }
+    if (op == 'M') rev.push_back({op, count + 1});
+    else { rev.push_back({op, count}); rev.push_back({'M', 1}); }
+    out.assign(rev.rbegin(), rev.rend());
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// ssw_align (ssw.c:781-867) + Aligner::Align / ConvertAlignment / CalculateNumberMismatch (ssw_cpp.cpp:78-215, :302-337):
+// local alignment of `query` to `ref`, CIGAR over {S,=,X,I,D}.
+struct Op { char op; int len; };
+struct SwAlignment { int score = 0, ref_begin = 0; std::vector<Op> cigar; };
+
+SwAlignment sw_align(const std::vector<int8_t>& ref, const std::vector<int8_t>& query) {
+    SwAlignment al;
+    const int R = (int)ref.size(), Q = (int)query.size();
+    if (R == 0 || Q == 0) return al;
+    int lanes = 16;
+    PassEnd fw = striped_pass(ref.data(), R, false, query.data(), Q, 16, 255);
+    if (fw.overflow) { lanes = 8; fw = striped_pass(ref.data(), R, false, query.data(), Q, 8, 65535); }
+    if (fw.score <= 0) return al;
+    std::vector<int8_t> rq(query.begin(), query.begin() + fw.read_end + 1);
+    std::reverse(rq.begin(), rq.end());
+    const PassEnd bw = striped_pass(ref.data(), fw.ref_end + 1, true, rq.data(), fw.read_end + 1, lanes, fw.score);
+    const int ref_begin = bw.ref_end, read_begin = fw.read_end - bw.read_end;
+    if (ref_begin < 0 || read_begin < 0) return al;
+    const int subR = fw.ref_end - ref_begin + 1, subQ = fw.read_end - read_begin + 1;
+    if (subR > 32768 || subQ > 32768) return al;                                   // distance_filter 32767: no CIGAR
+    std::vector<Run> runs;
+    if (!banded_path(ref.data() + ref_begin, query.data() + read_begin, subR, subQ, fw.score, std::abs(subR - subQ) + 1, runs)) return al;
+    al.score = fw.score;
+    al.ref_begin = ref_begin;
+    if (read_begin > 0) al.cigar.push_back({'S', read_begin});
+    const int8_t* r = ref.data() + ref_begin;
+    const int8_t* q = query.data() + read_begin;
+    char cur = 0;
+    int len = 0;
+    auto flush = [&] { if (cur) al.cigar.push_back({cur, len}); cur = 0; len = 0; };
+    for (const Run& run : runs) {
+        if (run.op == 'M') {
+            for (int k = 0; k < run.len; ++k, ++r, ++q) {
+                const char c = *r != *q ? 'X' : '=';
+                if (c != cur) { flush(); cur = c; }
+                ++len;
+            }
+        } else {
+            flush();
+            al.cigar.push_back({run.op, run.len});
+            if (run.op == 'I') q += run.len; else r += run.len;
+        }
+    }
+    flush();
+    const int tail = Q - fw.read_end - 1;
+    if (tail > 0) al.cigar.push_back({'S', tail});
+    return al;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// CIGAR helpers.  Internal op kinds follow the reference's enum (realigner.h:48-56): only these four survive its regex.
+enum Kind : int8_t { K_MATCH = 1, K_INS = 2, K_DEL = 3, K_SOFT = 5 };
+struct Cop { int8_t kind; int len; };
+
+inline bool kind_of(char c, int8_t& k) {
+    switch (c) {
+        case '=': case 'X': case 'x': k = K_MATCH; return true;
+        case 'S': case 's': k = K_SOFT; return true;
+        case 'D': case 'd': k = K_DEL; return true;
+        case 'I': case 'i': k = K_INS; return true;
+        default: return false;
+    }
+}
+std::vector<Cop> to_cops(const std::vector<Op>& c) {
+    std::vector<Cop> v;
+    for (const Op& o : c) { int8_t k; if (kind_of(o.op, k)) v.push_back({k, o.len}); }
+    return v;
+}
+
+// MergeCigarOp (realigner.cpp:552-575)
+struct Composed {
+    std::vector<Cop> ops;
+    int aligned = 0;                   // sum of the non-deletion lengths
+    void merge(int8_t kind, int len, int read_len) {
+        int n = kind != K_DEL ? std::min(len, read_len - aligned) : len;
+        if (n <= 0 || aligned == read_len) return;
+        if (!ops.empty() && ops.back().kind == kind) ops.back().len += n;
+        else ops.push_back({kind, n});
+        if (kind != K_DEL) aligned += n;
+    }
+};
+
+inline bool is_m(int8_t k) { return k == K_MATCH || k == K_SOFT; }
+
+// CalculateReadToRefAlignment (:653-778) with LeftTrimHaplotypeToRefAlignment (:579-609): two op queues walked with cursors.
+bool compose(const std::vector<Cop>& read_to_hap_in, const std::vector<Cop>& hap_to_ref_in, int read_to_hap_pos, int read_len,
+             std::vector<Cop>& out) {
+    std::vector<Cop> a = read_to_hap_in, b = hap_to_ref_in;     // a: read -> haplotype, b: haplotype -> reference
+    size_t ia = 0, ib = 0;
+    // left trim b to the read's start on the haplotype
+    int cur = 0;
+    while (cur != read_to_hap_pos) {
+        if (ib >= b.size()) return false;                      // the reference would pop an empty list
+        Cop op = b[ib++];
+        if (op.kind == K_MATCH || op.kind == K_SOFT || op.kind == K_INS) {
+            if (op.len + cur > read_to_hap_pos) { --ib; b[ib] = {op.kind, op.len - (read_to_hap_pos - cur)}; }
+            cur = std::min(op.len + cur, read_to_hap_pos);
+        }
+    }
+    if (ib < b.size() && b[ib].kind == K_DEL) ++ib;
+    Composed c;
+    if (ia < a.size() && a[ia].kind == K_SOFT) { c.merge(K_SOFT, a[ia].len, read_len); ++ia; }
+    // put-back of a shortened head: the slot just consumed is free, so a cursor step back stands in for push_front
+    while ((ia < a.size() || ib < b.size()) && c.aligned < read_len) {
+        if (ia < a.size() && ib >= b.size()) { c.merge(a[ia].kind, a[ia].len, read_len); ++ia; continue; }
+        if (ia >= a.size()) break;
+        Cop ra = a[ia++], hb = b[ib++];
+        if (is_m(ra.kind) && is_m(hb.kind)) {
+            const int n = std::min(ra.len, hb.len);
+            c.merge(ra.kind == K_SOFT || hb.kind == K_SOFT ? K_SOFT : K_MATCH, n, read_len);
+            ra.len -= n; hb.len -= n;
+            if (ra.len > 0) a[--ia] = ra;
+            if (hb.len > 0) b[--ib] = hb;
+        } else if (ra.kind == K_DEL && is_m(hb.kind)) {
+            c.merge(K_DEL, ra.len, read_len);
+            hb.len -= ra.len;
+            if (hb.len > 0) b[--ib] = hb;
+        } else if (hb.kind == K_DEL && is_m(ra.kind)) {
+            c.merge(K_DEL, hb.len, read_len);
+            if (ra.len > 0) a[--ia] = ra;
+        } else if (ra.kind == K_DEL && hb.kind == K_DEL) {
+            c.merge(K_DEL, ra.len + hb.len, read_len);
+        } else if (ra.kind == K_INS && is_m(hb.kind)) {
+            ra.len = std::min(read_len - c.aligned, ra.len);
+            c.merge(K_INS, ra.len, read_len);
+            if (hb.len > 0) b[--ib] = hb;
+        } else if (hb.kind == K_INS && is_m(ra.kind)) {
+            hb.len = std::min(read_len - c.aligned, hb.len);
+            c.merge(K_INS, hb.len, read_len);
+            ra.len = std::max(0, ra.len - hb.len);
+            if (ra.len > 0) a[--ia] = ra;
+        } else if (ra.kind == K_INS && hb.kind == K_INS) {
+            c.merge(K_INS, ra.len + hb.len, read_len);
+        } else {
+            out.clear();
+            return true;
+        }
+    }
+    out.swap(c.ops);
+    return true;
+}
+
+// SetPositionsMap (:454-505)
+std::vector<int> positions_map(const std::vector<Op>& cigar, size_t hap_len) {
+    std::vector<int> m(hap_len, 0);
+    int shift = 0;
+    size_t p = 0;
+    auto put = [&](int v) { if (p < hap_len) m[p] = v; ++p; };
+    for (const Op& o : cigar) {
+        switch (o.op) {
+            case '=': case 'X': for (int k = 0; k < o.len; ++k) put(shift); break;
+            case 'S': shift -= o.len; for (int k = 0; k < o.len; ++k) put(shift); break;
+            case 'D': shift += o.len; break;
+            case 'I': for (int k = 0; k < o.len; ++k) { put(shift); --shift; } break;
+            default: break;
+        }
+    }
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+struct ReadHit { int position = -1, score = 0; bool exact = false; std::vector<Op> cigar; };   // ReadAlignment (realigner.h:103-127)
+struct HapState {
+    int index = 0, score = 0, ref_pos = 0;
+    bool is_reference = false;
+    std::vector<ReadHit> hits;
+    std::vector<Op> cigar;
+    std::vector<int> pos_map;
+};
+
+// k-mer index over the reads (BuildIndex, :435-452): occurrences of one k-mer keep read order, then offset order
+struct KmerIndex {
+    std::unordered_map<std::string, std::vector<std::pair<int, int>>> map;   // key = the 32 bytes
+    void add(const std::string& read, int id) {
+        if ((int)read.size() <= kKmer) return;
+        for (size_t i = 0; i + kKmer <= read.size(); ++i) map[read.substr(i, kKmer)].push_back({id, (int)i});
+    }
+};
+
+// FastAlignStrings (:231-251): N on either side is a match; the third mismatch ends the comparison with score 0
+inline int fast_score(const char* hap, const char* read, int n, int& mism) {
+    int matches = 0;
+    mism = 0;
+    for (int i = 0; i < n; ++i) {
+        const char a = hap[i], b = read[i];
+        if (a != b && a != 'N' && b != 'N') {
+            if (++mism == kMaxMismatches + 1) return 0;
+        } else ++matches;
+    }
+    return matches * kMatch - mism * kMismatch;
+}
+
+void append_cigar(std::string& s, const std::vector<Cop>& ops) {   // CigarVectorToString (:292-316): a match prints as X
+    for (const Cop& o : ops) {
+        s += std::to_string(o.len);
+        switch (o.kind) { case K_MATCH: s += 'X'; break; case K_INS: s += 'I'; break; case K_DEL: s += 'D'; break; case K_SOFT: s += 'S'; break; }
+    }
+}
+
+int realign_window(const std::vector<std::string>& reads, const int32_t* positions, const char* const* cigars,
+                   const std::string& reference, const std::vector<std::string>& haps, int ref_start, int ref_prefix, int ref_suffix,
+                   int32_t* out_pos, std::vector<std::string>& out_cigar) {
+    const int n = (int)reads.size(), H = (int)haps.size();
+    for (const std::string& h : haps)
+        CTO_REQUIRE((int)h.size() >= kKmer, CTO_EINVAL, "cto_realign_reads: a haplotype is shorter than the %d-mer seed", kKmer);
+    KmerIndex index;
+    for (int r = 0; r < n; ++r) index.add(reads[r], r);
+
+    // fast pass, haplotype by haplotype (:129-229)
+    std::vector<HapState> hs(H);
+    for (int h = 0; h < H; ++h) {
+        HapState& st = hs[h];
+        st.index = h;
+        st.hits.assign(n, ReadHit());
+        const std::string& hap = haps[h];
+        const bool is_ref = hap == reference;
+        const int L = (int)hap.size();
+        std::vector<int> coverage(L, 0);
+        int score = 0;
+        bool dropped = false;
+        for (int i = 0; i + kKmer <= L; ++i) {
+            auto it = index.map.find(hap.substr(i, kKmer));
+            if (it == index.map.end()) continue;               // ... which also skips the coverage test below (:162-165)
+            for (const auto& occ : it->second) {
+                const int r = occ.first, start = std::max(0, i - occ.second), span = (int)reads[r].size();
+                if (start + span > L) continue;
+                ReadHit& hit = st.hits[r];
+                if (hit.position == start) continue;
+                int mism;
+                const int sc = fast_score(hap.data() + start, reads[r].data(), span, mism);
+                if (mism > kMaxMismatches) continue;
+                for (int p = start; p < start + span; ++p) ++coverage[p];
+                if (hit.score < sc) {
+                    score += sc - hit.score;
+                    hit.score = sc;
+                    hit.position = start;
+                    hit.exact = true;
+                    hit.cigar.assign(1, Op{'=', span});
+                }
+            }
+            // a seeded position inside the consensus part that no read covers with <= 2 mismatches disqualifies the haplotype
+            // (the upper bound is computed in size_t by the reference: a suffix longer than the haplotype wraps instead of going negative)
+            if (coverage[i] == 0 && i >= ref_prefix && (uint64_t)i < (uint64_t)L - (uint64_t)(int64_t)ref_suffix && !is_ref) { dropped = true; break; }
+        }
+        if (dropped) score = 0;
+        if (score == 0) st.hits.assign(n, ReadHit());
+        st.score = score;
+    }
+
+    // haplotypes against the reference (:315-349), position maps (:507-512)
+    const Codes refc(reference.data(), reference.size());
+    for (HapState& st : hs) {
+        const std::string& hap = haps[st.index];
+        const SwAlignment al = sw_align(refc.v, Codes(hap.data(), hap.size()).v);
+        if (al.score > 0) {
+            st.is_reference = al.cigar.size() == 1 && al.cigar[0].op == '=' && al.cigar[0].len == (int)hap.size();
+            st.cigar = al.cigar;
+            st.ref_pos = al.ref_begin;
+        }
+        st.pos_map = positions_map(st.cigar, hap.size());
+    }
+
+    // Smith-Waterman for the reads no haplotype took (:351-384)
+    std::vector<Codes> hapc;
+    for (int r = 0; r < n; ++r) {
+        bool taken = false;
+        for (const HapState& st : hs) if (st.hits[r].score > 0) { taken = true; break; }
+        if (taken) continue;
+        if (hapc.empty()) for (const std::string& h : haps) hapc.emplace_back(h.data(), h.size());
+        const Codes rc(reads[r].data(), reads[r].size());
+        for (HapState& st : hs) {
+            if (st.score == 0) continue;
+            const SwAlignment al = sw_align(hapc[st.index].v, rc.v);
+            if (al.score > 0 && al.score >= kSswThreshold && st.hits[r].score < al.score) {
+                st.hits[r].score = al.score;
+                st.hits[r].cigar = al.cigar;
+                st.hits[r].position = al.ref_begin;
+                st.hits[r].exact = false;
+            }
+        }
+    }
+
+    // the reference's std::sort by haplotype score (:108); ties keep whatever order that algorithm leaves them in
+    std::vector<int> order(H);
+    for (int h = 0; h < H; ++h) order[h] = h;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return hs[a].score < hs[b].score; });
+
+    // every read onto the reference through its best haplotype (:386-433)
+    out_cigar.assign(n, std::string());
+    for (int r = 0; r < n; ++r) {
+        out_pos[r] = positions[r];
+        out_cigar[r] = cigars[r];
+        int best = 0, pick = -1;
+        for (int k = 0; k < H; ++k) {                          // GetBestReadAlignment (:514-538)
+            const HapState& st = hs[order[k]];
+            const int sc = st.hits[r].score;
+            if (sc > best || (best > 0 && sc == best && !st.is_reference)) { best = sc; pick = order[k]; }
+        }
+        if (pick < 0) continue;
+        const HapState& st = hs[pick];
+        const ReadHit& hit = st.hits[r];
+        CTO_REQUIRE(hit.position >= 0 && hit.position < (int)st.pos_map.size(), CTO_EINVAL, "cto_realign_reads: read %d lies outside its haplotype", r);
+        std::vector<Cop> ops;
+        if (!compose(to_cops(hit.cigar), to_cops(st.cigar), hit.position, (int)reads[r].size(), ops))
+            CTO_REQUIRE(false, CTO_EINVAL, "cto_realign_reads: the haplotype alignment ends before read %d starts", r);
+        if (!ops.empty()) {
+            out_cigar[r].clear();
+            append_cigar(out_cigar[r], ops);
+            out_pos[r] = ref_start + st.ref_pos + hit.position + st.pos_map[hit.position];
+        }
+    }
+    return CTO_OK;
+}
+
+std::vector<std::string> split_ws(const char* s) {             // `in >> t` (:786-793)
+    std::vector<std::string> v;
+    const char* p = s;
+    while (*p) {
+        while (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r' || *p == '\f' || *p == '\v') ++p;
+        const char* q = p;
+        while (*q && !(*q == ' ' || *q == '\t' || *q == '\n' || *q == '\r' || *q == '\f' || *q == '\v')) ++q;
+        if (q > p) v.emplace_back(p, q);
+        p = q;
+    }
+    return v;
+}
+
+}  // namespace
+
+extern "C" int cto_realign_reads(int n_reads, const char* const* seqs, const int32_t* positions, const char* const* cigars,
+                                 const char* reference, const char* haplotypes, int32_t ref_start, int32_t ref_prefix,
+                                 int32_t ref_suffix, int32_t* out_positions, char* cigar_buf, size_t cigar_cap, int64_t* cigar_off) try {
+    CTO_REQUIRE(n_reads >= 0 && reference && haplotypes && out_positions && cigar_off && (cigar_buf || cigar_cap == 0), CTO_EINVAL,
+                "cto_realign_reads: bad argument");
+    CTO_REQUIRE(n_reads == 0 || (seqs && positions && cigars), CTO_EINVAL, "cto_realign_reads: bad argument");
+    std::vector<std::string> reads(n_reads);
+    for (int i = 0; i < n_reads; ++i) reads[i] = seqs[i];
+    std::vector<std::string> out;
+    const int rc = realign_window(reads, positions, cigars, reference, split_ws(haplotypes), ref_start, ref_prefix, ref_suffix, out_positions, out);
+    if (rc != CTO_OK) return rc;
+    size_t used = 0;
+    for (int i = 0; i < n_reads; ++i) {
+        cigar_off[i] = (int64_t)used;
+        CTO_REQUIRE(used + out[i].size() + 1 <= cigar_cap, CTO_ENOMEM, "cto_realign_reads: cigar buffer too small");
+        memcpy(cigar_buf + used, out[i].c_str(), out[i].size() + 1);
+        used += out[i].size() + 1;
+    }
+    cigar_off[n_reads] = (int64_t)used;
+    return CTO_OK;
+}
+CTO_CATCH("cto_realign_reads", int)
+
+// Smith-Waterman alone (test hook and building block): query against ref, CIGAR text over S = X I D as SSW's C++ wrapper prints it.
+extern "C" int cto_ssw_align(const char* ref, const char* query, int32_t* score, int32_t* ref_begin, char* cigar_buf, size_t cigar_cap) try {
+    CTO_REQUIRE(ref && query && score && ref_begin && cigar_buf && cigar_cap > 0, CTO_EINVAL, "cto_ssw_align: bad argument");
+    const SwAlignment al = sw_align(Codes(ref, strlen(ref)).v, Codes(query, strlen(query)).v);
+    std::string s;
+    for (const Op& o : al.cigar) { s += std::to_string(o.len); s += o.op; }
+    CTO_REQUIRE(s.size() + 1 <= cigar_cap, CTO_ENOMEM, "cto_ssw_align: cigar buffer too small");
+    memcpy(cigar_buf, s.c_str(), s.size() + 1);
+    *score = al.score;
+    *ref_begin = al.ref_begin;
+    return CTO_OK;
+}
+CTO_CATCH("cto_ssw_align", int)

@@ -1,0 +1,341 @@
+"""Drop-in counterpart of `clairs_to.py realign_reads` (reference: src/realign_reads.py; the short-read local realignment the
+Illumina filter `realign_variants` runs per low-QUAL call, SURVEY.md 8f #4b).
+
+    samtools view -h BAM ctg:(pos-1100)-(pos+1100) -q MQ   ->   realigned SAM text on stdout (read names carry a _0 / _1 strand suffix)
+
+Same inputs, options and output text as the reference.  The two native pieces are the library's (`cto_dbg_consensus`,
+`cto_realign_reads`: csrc/debruijn.cpp, csrc/realign.cpp); this module is the bookkeeping around them, restated from the
+reference's behaviour (all line numbers into src/realign_reads.py):
+
+  * rows -> reads (:255-305): dictionary by name + "_" + strand (a later row of the same name and strand replaces the earlier
+    one but keeps its place), reads without a CIGAR or less than 55 % aligned are ignored;
+  * evidence counter (:306-352): per reference position, the reads (MQ >= 20) that mismatch it with BQ >= 20, that carry a clean
+    insertion / soft clip next to it (positions [p - len, p + len)) or delete it;
+  * per 5 000-base chunk (:441-457): positions with >= --min_coverage evidence inside the chunk (+-20) and within
+    --max_distance of --pos become windows (:463-499: runs no further than 160 apart, padded by 80); every read goes to the window
+    it overlaps most (:180-186, :502-506);
+  * per window of <= 1 000 bases (:509-615): candidate haplotypes from the de Bruijn graph of its MQ >= 14 reads (low-BQ < 15
+    positions masked), nothing to do when that is empty or just the reference; otherwise the first 1 000 reads are re-aligned
+    against reference-prefix + haplotype + reference-suffix, and a read keeps the re-alignment with the most indel bases seen so
+    far (:153-164, `>=`: the later of equals wins);
+  * output (:618-647): reads in order of their (new) start, stable; within the loop only those 1 020 bases behind the chunk.
+"""
+import ctypes as C
+import shlex
+import subprocess
+import sys
+from argparse import ArgumentParser, SUPPRESS
+
+from ._lib import lib, check
+
+CHUNK = 5000                    # realign_chunk_size (:47)
+MIN_DBG_MQ = MIN_DBG_BQ = 20    # :48
+EXPAND = 20                     # region_expansion_in_bp = expand_align_ref_region (:49)
+WINDOW_GAP = 80                 # min_windows_distance (:50)
+MAX_WINDOW = MAX_READS = 1000   # max_window_size = max_region_reads_num (:51)
+REF_EXPAND = 100000             # expandReferenceRegion (:52)
+GRAPH_MIN_MQ = 14               # graph_min_mapping_quality (:89)
+GRAPH_LOW_BQ = 15               # :526
+
+
+def dbg_consensus(ref, reads, lowbq=None):
+    """Candidate haplotypes of a window (cto_dbg_consensus; reference: dbg.get_consensus, :532-539)."""
+    n = len(reads)
+    arr = (C.c_char_p * max(n, 1))(*[r.encode() for r in reads])
+    low = off = None
+    if lowbq is not None:
+        flat = [p for one in lowbq for p in one]
+        low = (C.c_int32 * max(len(flat), 1))(*flat)
+        off = (C.c_int64 * (n + 1))()
+        for i, one in enumerate(lowbq):
+            off[i + 1] = off[i] + len(one)
+    need = C.c_size_t(0)
+    cap = 1 << 16
+    while True:
+        buf = C.create_string_buffer(cap)
+        rc = lib.cto_dbg_consensus(ref.encode(), n, arr, low, off, buf, cap, C.byref(need))
+        if rc == -3 and need.value > cap:               # CTO_ENOMEM: retry with what it asked for
+            cap = need.value
+            continue
+        check(rc)
+        return [s.decode() for s in buf.raw[:need.value].split(b"\0")[:rc]]
+
+
+def realign_window(seqs, positions, cigars, ref_seq, haplotypes, ref_start, prefix_len, suffix_len):
+    """(positions, cigars) of cto_realign_reads (reference: realigner.realign_reads, :582-595)."""
+    n = len(seqs)
+    out_pos = (C.c_int32 * n)()
+    cap = 64 * n + 8 * sum(len(s) for s in seqs) + sum(len(c) for c in cigars) + 64
+    buf = C.create_string_buffer(cap)
+    off = (C.c_int64 * (n + 1))()
+    check(lib.cto_realign_reads(n, (C.c_char_p * n)(*[s.encode() for s in seqs]), (C.c_int32 * n)(*positions),
+                                (C.c_char_p * n)(*[c.encode() for c in cigars]), ref_seq.encode(), " ".join(haplotypes).encode(),
+                                ref_start, prefix_len, suffix_len, out_pos, buf, cap, off))
+    raw = buf.raw
+    return list(out_pos), [raw[off[i]:off[i + 1] - 1].decode() for i in range(n)]
+
+
+def _cigar_ops(cigar):
+    n = 0
+    for ch in cigar:
+        if ch.isdigit():
+            n = n * 10 + int(ch)
+        else:
+            yield ch, n
+            n = 0
+
+
+def mostly_clipped(cigar):
+    """:233-248 - less than 55 % of the CIGAR's positions are not soft-clipped"""
+    soft = total = 0
+    for op, n in _cigar_ops(cigar):
+        if op == "S":
+            soft += n
+        total += n
+    return 1.0 - float(soft) / (total + 1) < 0.55
+
+
+class Read(object):
+    __slots__ = ("name", "flag", "start", "end", "mq", "cigar", "seq", "bq", "raw_bq", "rnext", "pnext", "hp", "best_cigar", "best_pos",
+                 "best_score")
+
+    def __init__(self, name, flag, start, mq, cigar, seq, raw_bq, rnext, pnext, hp):
+        self.name, self.flag, self.start, self.mq, self.cigar, self.seq, self.raw_bq = name, flag, start, mq, cigar, seq, raw_bq
+        self.rnext, self.pnext, self.hp = rnext, pnext, hp
+        self.bq = [ord(c) - 33 for c in raw_bq]
+        self.end = start + len(seq) + (sum(n for op, n in _cigar_ops(cigar) if op == "D") if "D" in cigar else 0)     # :92-98
+        self.best_cigar, self.best_pos, self.best_score = cigar, start, None
+
+    def offer(self, cigar, pos):
+        """set_realignment_info (:153-164)"""
+        cigar = cigar.replace("X", "M")
+        if cigar == self.cigar and pos == self.start:
+            return
+        if self.best_score and cigar == self.best_cigar and pos == self.best_pos:
+            return
+        score = sum(n for op, n in _cigar_ops(cigar) if op in "ID")
+        if not self.best_score or score >= self.best_score:
+            self.best_cigar, self.best_pos, self.best_score = cigar, pos, score
+
+    def sam(self, ctg):
+        # TLEN repeats PNEXT (:133), and the HP field is there even when empty (:623-629)
+        return "\t".join([self.name, self.flag, ctg, str(self.best_pos + 1), str(self.mq), self.best_cigar, self.rnext, self.pnext, self.pnext,
+                          self.seq, self.raw_bq, "HP:i:%s" % self.hp if self.hp else ""]) + "\n"
+
+
+def _hp_of(fields):
+    tags = [c for c in fields if "HP:i:" in c]
+    if not tags or len(tags[0]) < 6 or not tags[0][5].isdigit():
+        return None
+    return tags[0][5]
+
+
+class RegionRealigner(object):
+    """The state `reads_realignment` keeps while it streams the rows of one `samtools view -h` call (:427-652)."""
+
+    def __init__(self, ctg_name, reference_sequence, reference_start_0_based, pos, min_coverage=2, max_distance=50,
+                 consensus_fn=dbg_consensus, realign_fn=realign_window):
+        self.ctg, self.ref, self.ref0, self.pos = ctg_name, reference_sequence, reference_start_0_based, pos
+        self.min_coverage, self.max_distance = min_coverage, max_distance
+        self.consensus_fn, self.realign_fn = consensus_fn, realign_fn
+        self.header, self.header_out = [], False
+        self.reads = {}
+        self.evidence = {}
+        self.chunk_start = self.chunk_end = None
+
+    # ---- rows in
+    def _count(self, lo, hi):
+        ev = self.evidence
+        for p in range(lo, hi):
+            ev[p] = ev.get(p, 0) + 1
+
+    def feed(self, row, out):
+        """one row of `samtools view -h`; realigned rows that are ready go to out.write"""
+        if row[0] == "@":
+            self.header.append(row)
+            return
+        c = row.strip().split()
+        if c[2] != self.ctg:
+            return
+        flag, start, mq, cigar, seq, raw_bq = int(c[1]), int(c[3]) - 1, int(c[4]), c[5], c[9].upper(), c[10]
+        strand = int((flag & 16) == 16)
+        if self.chunk_start is None:
+            self.chunk_start, self.chunk_end = start, start + CHUNK
+        if start >= self.chunk_end + EXPAND:
+            self.flush(out)
+            self.chunk_start += CHUNK
+            self.chunk_end += CHUNK
+        read = Read(c[0] + "_" + str(strand), str(flag), start, mq, cigar, seq, raw_bq, c[6], c[7], _hp_of(c[11:]))
+        if cigar == "*" or mostly_clipped(cigar):
+            return
+        self.reads[read.name] = read
+        if mq < MIN_DBG_MQ:
+            return
+        ref, ref0, bq = self.ref, self.ref0, read.bq
+        rp, qp = start, 0
+        lo_ok, hi_ok = self.chunk_start - EXPAND, self.chunk_end + EXPAND
+        for op, n in _cigar_ops(cigar):
+            if op == "=":
+                rp += n
+                qp += n
+            elif op == "M" or op == "X":
+                for _ in range(n):
+                    if bq[qp] >= MIN_DBG_BQ:
+                        rb = ref[rp - ref0]
+                        if rb in "ACGT" and seq[qp] != rb:
+                            self.evidence[rp] = self.evidence.get(rp, 0) + 1
+                    rp += 1
+                    qp += 1
+            elif op == "I" or op == "S":
+                if lo_ok <= rp <= hi_ok and ref[rp - ref0 - 1] in "ACGT" and not any(q < MIN_DBG_BQ for q in bq[qp:qp + n]):
+                    self._count(rp - n, rp + n)
+                qp += n
+            elif op == "D":
+                if lo_ok <= rp <= hi_ok and ref[rp - ref0 - 1] in "ACGT":
+                    self._count(rp, rp + n)
+                rp += n
+            # N, H, P: the reference moves neither cursor (:309-352)
+
+    # ---- a chunk boundary (or the end of the input)
+    def flush(self, out):
+        if self.chunk_start is None:
+            return
+        if not self.header_out:
+            out.write("".join(self.header))
+            self.header_out = True
+        cs, ce = self.chunk_start, self.chunk_end
+        cand = sorted(p for p, n in self.evidence.items()
+                      if n >= self.min_coverage and cs - EXPAND - 1 <= p <= ce + EXPAND - 1
+                      and self.pos - self.max_distance <= p < self.pos + self.max_distance)
+        if not self.reads or not cand:
+            return
+        for idx in range((ce - cs) // MAX_WINDOW):
+            lo = cs + idx * MAX_WINDOW - EXPAND - 1
+            hi = lo + MAX_WINDOW + EXPAND * 2 + 1
+            self._realign_split([p for p in cand if lo <= p < hi])
+        behind = cs - EXPAND - MAX_WINDOW
+        for name, _ in sorted(((k, r.best_pos) for k, r in self.reads.items()), key=lambda kv: kv[1]):
+            if self.reads[name].best_pos < behind:
+                out.write(self.reads.pop(name).sam(self.ctg))
+        for p in [p for p in self.evidence if p < behind]:
+            del self.evidence[p]
+
+    def finish(self, out):
+        self.flush(out)
+        for name, _ in sorted(((k, r.best_pos) for k, r in self.reads.items()), key=lambda kv: kv[1]):
+            out.write(self.reads.pop(name).sam(self.ctg))
+
+    def _realign_split(self, positions):
+        windows, first, last = [], None, None
+        for p in positions:
+            if first is None:
+                first = last = p
+            elif p > last + 2 * WINDOW_GAP:
+                windows.append((first - WINDOW_GAP, last + WINDOW_GAP))
+                first = last = p
+            else:
+                last = p
+        if first is None:
+            return
+        windows.append((first - WINDOW_GAP, last + WINDOW_GAP))
+        windows.sort(key=lambda w: w[0])
+        reach = max(w[1] for w in windows)
+        members = [[] for _ in windows]
+        for name, r in self.reads.items():
+            if r.start > reach:
+                continue
+            best, best_len = None, 0
+            for i, (ws, we) in enumerate(windows):
+                ov = min(r.end, we) - max(r.start, ws)
+                if ov > best_len:
+                    best, best_len = i, ov
+            if best is not None:
+                members[best].append(name)
+        for (ws, we), names in zip(windows, members):
+            if we - ws > MAX_WINDOW:
+                continue
+            self._realign_window(ws, we, names)
+
+    def _realign_window(self, ws, we, names):
+        ref, ref0 = self.ref, self.ref0
+        centre = ref[ws - ref0:we - ref0]
+        graph_reads, graph_lowbq = [], []
+        for name in names:
+            r = self.reads[name]
+            if r.mq < GRAPH_MIN_MQ or r.start > we or r.end < ws:
+                continue
+            graph_reads.append(r.seq)
+            graph_lowbq.append([i for i, q in enumerate(r.bq) if q < GRAPH_LOW_BQ])
+        consensus = self.consensus_fn(centre, graph_reads, graph_lowbq)
+        if not consensus or (len(consensus) == 1 and consensus[0] == centre) or not names:
+            return
+        lo = max(0, min(min(self.reads[n].start for n in names), ws) - EXPAND)
+        hi = max(max(self.reads[n].end for n in names), we) + EXPAND
+        prefix, suffix = ref[lo - ref0:ws - ref0], ref[we - ref0:hi - ref0]
+        take = [self.reads[n] for n in names[:MAX_READS]]
+        new_pos, new_cigar = self.realign_fn([r.seq for r in take], [r.start for r in take], [r.cigar for r in take],
+                                             prefix + centre + suffix, [prefix + h + suffix for h in consensus], lo, len(prefix), len(suffix))
+        for r, p, cg in zip(take, new_pos, new_cigar):
+            if cg == "" or (r.cigar == cg and r.start == p):
+                continue
+            r.offer(cg, p)
+
+
+def realign_region(rows, ctg_name, reference_sequence, reference_start_0_based, pos, out, min_coverage=2, max_distance=50,
+                   consensus_fn=dbg_consensus, realign_fn=realign_window):
+    """rows of `samtools view -h` -> realigned SAM text written to out."""
+    rr = RegionRealigner(ctg_name, reference_sequence, reference_start_0_based, pos, min_coverage, max_distance, consensus_fn, realign_fn)
+    for row in rows:
+        rr.feed(row, out)
+    rr.finish(out)
+
+
+def region_of(pos, flanking):
+    """the read and reference regions `reads_realignment` fetches around --pos (:359-391): 1-based, inclusive"""
+    ctg_start, ctg_end = pos - flanking, pos + flanking
+    return (ctg_start - MAX_WINDOW, ctg_end + MAX_WINDOW), (max(1, ctg_start - REF_EXPAND), ctg_end + REF_EXPAND)
+
+
+def faidx(samtools, ref_fn, region):
+    """shared/utils.py:148-174 - the sequence of `samtools faidx`, upper-cased"""
+    p = subprocess.run(shlex.split("{} faidx {} {}".format(samtools, ref_fn, region)), stdout=subprocess.PIPE, universal_newlines=True)
+    if p.returncode != 0:
+        return None
+    return "".join(p.stdout.split("\n")[1:]).upper()
+
+
+def reads_realignment(args, out=None):
+    out = out or sys.stdout
+    (rd_lo, rd_hi), (ref_lo, ref_hi) = region_of(args.pos, args.realign_flanking_window)
+    ref = faidx(args.samtools, args.ref_fn, "{}:{}-{}".format(args.ctg_name, ref_lo, ref_hi))
+    if not ref:
+        sys.exit("[ERROR] Failed to load reference sequence from file ({}).".format(args.ref_fn))
+    cmd = "{} view -h {} {}:{}-{}".format(args.samtools, args.bam_fn, args.ctg_name, rd_lo, rd_hi) + (" -q {}".format(args.min_mq) if args.min_mq > 0 else "")
+    view = subprocess.Popen(shlex.split(cmd), stdout=subprocess.PIPE, universal_newlines=True, bufsize=8388608)
+    realign_region(view.stdout, args.ctg_name, ref, ref_lo - 1, args.pos, out, args.min_coverage, args.max_distance)
+    view.stdout.close()
+    view.wait()
+
+
+def main():
+    p = ArgumentParser(description="Reads realignment around one position (native consensus + realigner)")
+    p.add_argument("--bam_fn", type=str, default=None)
+    p.add_argument("--ref_fn", type=str, default=None)
+    p.add_argument("--read_fn", type=str, default="PIPE", help="accepted for compatibility: the realigned SAM text goes to stdout")
+    p.add_argument("--ctg_name", type=str, default=None)
+    p.add_argument("--samtools", type=str, default="samtools")
+    p.add_argument("--min_coverage", type=float, default=2)
+    p.add_argument("--min_mq", type=int, default=20)                # shared/param.py:17
+    p.add_argument("--realign_flanking_window", type=int, default=100)
+    p.add_argument("--pos", type=int, default=None)
+    p.add_argument("--max_distance", type=int, default=50, help=SUPPRESS)
+    for compat in ("--ctg_start", "--ctg_end", "--bed_fn", "--extend_bed", "--test_pos"):
+        p.add_argument(compat, default=None, help=SUPPRESS)
+    args = p.parse_args()
+    if args.pos is None or args.ctg_name is None:
+        sys.exit("[ERROR] clairs_to_amd realign_reads needs --pos and --ctg_name (the form `realign_variants` calls)")
+    reads_realignment(args)
+
+
+if __name__ == "__main__":
+    main()

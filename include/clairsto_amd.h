@@ -385,6 +385,35 @@ int cto_haplotype_filter(const char* text, size_t len, const char* ref_seq, int6
                          const int32_t* pos, const char* fields, const int64_t* field_off, const double* af, int flanking,
                          int max_co_exist_read_num, int disable_rse, uint8_t* flags, int64_t* strand);
 
+/* ------------------------------------------------------------------------------------------------
+ * Illumina realignment filter (SURVEY.md 8f #4b; src/realign_variants.py, src/realign_reads.py, the C++ under src/realign/).
+ * Host code: ~1 k low-QUAL calls per run, a window of <= 1000 reads each.
+ *
+ * cto_realign_reads replaces the reference's native entry point
+ *   struct_str_arr* realign_reads(char* seqs[], int* positions, char* cigars[], char* reference, char* haplotypes,
+ *                                 int ref_start, int ref_prefix, int ref_suffix, int read_size)   (src/realign/realigner.cpp:782-857,
+ *   bound with ctypes at src/realign_reads.py:582-591): the reads of one window are re-aligned through the candidate haplotypes
+ *   (blank-separated, each = reference prefix + consensus + reference suffix) and come back as 0-based positions and CIGAR text over
+ *   S X I D (X = aligned, as the reference prints it; the caller maps X to M).  A read nothing aligned keeps positions[i] / cigars[i].
+ *   out_positions[n]; CIGAR strings '\0'-terminated back to back in cigar_buf, cigar_off[n+1] their offsets.  CTO_ENOMEM when
+ *   cigar_cap is too small, CTO_EINVAL for a haplotype shorter than 32 bases (the reference indexes past the string there).
+ * cto_ssw_align: the Smith-Waterman the above is built on, alone - SSW's C++ `Aligner::Align(query, filter, &alignment)` with the
+ *   reference sequence `ref` (src/realign/ssw_cpp.cpp:302-337): score 4 / -6, gap 8 / 2; *score = 0 and an empty CIGAR when nothing aligns.
+ * cto_dbg_consensus replaces  get_consensus(char* reference, char* reads ","-joined, char* low-BQ positions " "/","-joined, int n)
+ *   (src/realign/debruijn_graph.cpp:432-470, bound at src/realign_reads.py:532-536): candidate haplotypes of a window, sorted,
+ *   '\0'-separated in buf; returns their number.  lowbq / lowbq_off[n+1]: per read the 0-based positions with BQ < 15 (may be NULL).
+ *   *used = bytes needed.  PARITY UNPINNED (the reference needs Boost.Graph, absent here): see csrc/debruijn.cpp.
+ * The reference's own symbol names and struct layouts are exported by two one-file shims built next to the library
+ * (clairs_to_amd/realign/realigner.so, debruijn_graph.so; csrc/ref_abi_*.cpp) for `ctypes.cdll.LoadLibrary` at
+ * src/realign_reads.py:70-71.
+ * ---------------------------------------------------------------------------------------------- */
+int cto_realign_reads(int n_reads, const char* const* seqs, const int32_t* positions, const char* const* cigars,
+                      const char* reference, const char* haplotypes, int32_t ref_start, int32_t ref_prefix, int32_t ref_suffix,
+                      int32_t* out_positions, char* cigar_buf, size_t cigar_cap, int64_t* cigar_off);
+int cto_ssw_align(const char* ref, const char* query, int32_t* score, int32_t* ref_begin, char* cigar_buf, size_t cigar_cap);
+int cto_dbg_consensus(const char* ref, int n_reads, const char* const* reads, const int32_t* lowbq, const int64_t* lowbq_off,
+                      char* buf, size_t cap, size_t* used);
+
 #ifdef __cplusplus
 }
 #endif

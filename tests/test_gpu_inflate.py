@@ -86,18 +86,6 @@ def test_inflate_many_blocks(dev):
     assert inflate_bytes(raw, dev) == data
 
 
-def test_inflate_one_block_per_lane_prototype(dev, monkeypatch):
-    """csrc/inflate_lanes.hip (CTO_INFLATE_LANES=1: every lane a decoder of its own; an experiment, slower than the wave-per-block
-    kernel) gives the same bytes on every block shape of this file."""
-    from clairs_to_amd.bgzf import inflate_bytes
-    monkeypatch.setenv("CTO_INFLATE_LANES", "1")
-    data = cases()
-    for level, strategy in ((0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY),
-                            (6, zlib.Z_FIXED), (6, zlib.Z_RLE), (6, zlib.Z_HUFFMAN_ONLY)):
-        raw = b"".join(bgzf_block(d, level, strategy) for d in data)
-        assert inflate_bytes(raw, dev) == data, (level, strategy)
-
-
 def test_inflate_rejects_malformed(dev):
     """corrupt payloads end with a status code (CtoError), never with a hang or a wrong answer"""
     from clairs_to_amd._lib import CtoError
