@@ -48,6 +48,14 @@ extern "C" cto_ref_dbg_out* get_consensus(char* reference, char* c_reads, char* 
     if (n < 0) { fprintf(stderr, "[clairs_to_amd] get_consensus: %s\n", cto_last_error()); return out; }
     const char* p = buf.data();
     for (int i = 0; i < n && i < kMaxConsensus; ++i) { out->consensus[i] = strdup(p); p += strlen(p) + 1; }
+    if (const char* log = getenv("CTO_DBG_LOG")) {       // fixture aid (tests/golden/gen_realign.py): what went in and what came out
+        if (FILE* f = fopen(log, "a")) {
+            fprintf(f, "%s\t", reference);
+            for (int i = 0; i < n && i < kMaxConsensus; ++i) fprintf(f, "%s%s", i ? "," : "", out->consensus[i]);
+            fputc('\n', f);
+            fclose(f);
+        }
+    }
     out->consensus_size = n < kMaxConsensus ? n : kMaxConsensus;
     return out;
 }

@@ -9,7 +9,21 @@ returned.  Inputs are regenerated from the seed by the test and checked by SHA-2
 
   realign.json.gz   {"seed", "n_windows", "inputs_sha256", "windows": [[[pos - ref_start, cigar], ...], ...]}
 
-Usage: make -C oracle ref && python tests/golden/gen_realign.py      (from the repo root; build container only)
+`flow` target: the reference's Python around that native code, run unmodified from /root/reference -
+  clairs_to.py realign_variants  (src/realign_variants.py: per low-QUAL PASS call `samtools mpileup`, a child `clairs_to.py
+  realign_reads --pos P` piped into `samtools mpileup -`, the demotion rule, the output VCF) and, per position,
+  clairs_to.py realign_reads --pos P  on its own (src/realign_reads.py: the realigned SAM text)
+on the simulated short-read data of realignsim.py.  `samtools` is realignsim.SHIM (neither box has samtools); the reference finds
+its two ctypes modules through its own fall-back look-up (src/realign_reads.py:56-65: <dirname(dirname(`which python`))>/bin/
+preprocess/realign/{realigner,debruijn_graph}), which a scratch directory on PATH points at oracle/_ref/librealigner_ref.so (the
+reference's realigner, compiled from its sources) and at clairs_to_amd/realign/debruijn_graph.so - the BUILD's consensus behind the
+reference's `get_consensus` ABI, because the reference's own needs Boost.Graph and cannot be built here.  So in this fixture the
+consensus strings are an INPUT (recorded per window), everything else is the reference's output.
+
+  realign_flow.json.gz  {"seed", "inputs_sha256", "vcf": output VCF text, "positions": {pos: {"sha256", "n_rows", "moved": [[name, pos,
+                         cigar], ...]}}, "consensus": [[window reference, [haplotypes]], ...] in call order}
+
+Usage: make -C oracle ref && python tests/golden/gen_realign.py [windows|flow]     (from the repo root; build container only)
 """
 import gzip
 import hashlib
@@ -52,5 +66,78 @@ def main():
     print("wrote realign.json.gz: %d windows, %d reads, %d realigned, %d bytes raw" % (N_WINDOWS, reads, moved, len(raw)))
 
 
+def flow_inputs_digest(paths):
+    h = hashlib.sha256()
+    for k in ("ref", "vcf"):
+        h.update(open(paths[k], "rb").read())
+    h.update(open(paths["bam"] + ".sam", "rb").read())
+    return h.hexdigest()
+
+
+def gen_flow():
+    import shutil
+    import subprocess
+    import tempfile
+    sys.path.insert(0, HERE)
+    import realignsim
+    REF = "/root/reference"
+    assert ru.ref_lib() is not None and os.path.isdir(REF)
+    sim = realignsim.simulate()
+    tmp = tempfile.mkdtemp(prefix="realign_flow_")
+    try:
+        paths = realignsim.write_inputs(sim, tmp)
+        mods = os.path.join(tmp, "conda", "bin", "preprocess", "realign")
+        os.makedirs(mods)
+        os.symlink(sys.executable, os.path.join(tmp, "conda", "bin", "python"))
+        shutil.copy(ru.REF_SO, os.path.join(mods, "realigner"))
+        shutil.copy(os.path.join(ROOT, "clairs_to_amd", "realign", "debruijn_graph.so"), os.path.join(mods, "debruijn_graph"))
+        env = dict(os.environ, PATH=os.path.join(tmp, "conda", "bin") + ":" + os.environ["PATH"], REALIGNSIM_TESTS=os.path.join(ROOT, "tests"),
+                   LD_LIBRARY_PATH=os.path.join(ROOT, "clairs_to_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""),
+                   CTO_DBG_LOG=os.path.join(tmp, "dbg.log"))
+        out_vcf = os.path.join(tmp, "out", "realigned.vcf")
+        subprocess.run([sys.executable, os.path.join(REF, "clairs_to.py"), "realign_variants", "--bam_fn", paths["bam"], "--ref_fn", paths["ref"],
+                        "--ctg_name", realignsim.CTG, "--pileup_vcf_fn", paths["vcf"], "--output_vcf_fn", out_vcf, "--samtools", paths["samtools"],
+                        "--python", sys.executable, "--threads", "8"], check=True, env=env, cwd=tmp)
+        vcf = open(out_vcf).read()
+        todo = []
+        for row in open(paths["vcf"]):
+            c = row.split("\t")
+            if row[0] != "#" and c[6] == "PASS" and float(c[5]) < 8 and len(c[3]) == 1 and len(c[4]) == 1:
+                todo.append(int(c[1]))
+        positions, consensus = {}, []
+        orig = {}
+        for r in realignsim.parse_sam(realignsim.sam_text(sim)):
+            orig[(r["name"] + "_" + str(int(bool(r["flag"] & 16))), r["flag"])] = (r["pos"], "".join("%d%s" % (n, o) for o, n in r["cigar"]))
+        for pos in todo:
+            log = os.path.join(tmp, "dbg_%d.log" % pos)
+            p = subprocess.run([sys.executable, os.path.join(REF, "clairs_to.py"), "realign_reads", "--pos", str(pos), "--ctg_name", realignsim.CTG,
+                                "--bam_fn", paths["bam"], "--ref_fn", paths["ref"], "--samtools", paths["samtools"]], check=True,
+                               env=dict(env, CTO_DBG_LOG=log), cwd=tmp, stdout=subprocess.PIPE, universal_newlines=True)
+            rows = [r for r in p.stdout.split("\n") if r and r[0] != "@"]
+            moved = []
+            for r in rows:
+                c = r.split("\t")
+                if orig[(c[0], int(c[1]))] != (int(c[3]) - 1, c[5]):
+                    moved.append([c[0], int(c[3]), c[5]])
+            positions[str(pos)] = {"sha256": hashlib.sha256(p.stdout.encode()).hexdigest(), "n_rows": len(rows), "moved": moved}
+            if os.path.exists(log):
+                for ln in open(log):
+                    ref_w, haps = ln.rstrip("\n").split("\t")
+                    consensus.append([pos, ref_w, [h for h in haps.split(",") if h]])
+        obj = {"seed": 20260929, "inputs_sha256": flow_inputs_digest(paths), "vcf": vcf, "positions": positions, "consensus": consensus}
+        raw = json.dumps(obj, separators=(",", ":")).encode()
+        with open(os.path.join(HERE, "realign_flow.json.gz"), "wb") as f:
+            with gzip.GzipFile(fileobj=f, mode="wb", mtime=0) as g:
+                g.write(raw)
+        print("wrote realign_flow.json.gz: %d calls re-examined, %d demoted, %d reads moved in total, %d consensus calls, %d bytes raw" % (
+            len(todo), vcf.count("LowQual;Realignment"), sum(len(v["moved"]) for v in positions.values()), len(consensus), len(raw)))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 if __name__ == "__main__":
-    main()
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "windows"):
+        main()
+    if which in ("all", "flow"):
+        gen_flow()
