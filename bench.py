@@ -156,8 +156,10 @@ def main():
                     help="distinct synthetic chunks resident in HBM per rank (16 x 28.6 MB of packs = 458 MB: more than the 256 MB "
                          "Infinity Cache, so the tensor-creation stage really reads HBM)")
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--watchdog", type=int, default=1500, help="N > 1: seconds after which a rank that is still running gives up with a message")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=4096)
+    ap.add_argument("--no-sustained", action="store_true", help="skip the 245-step run and the per-stage kernel times after the timed region")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file legs (mpileup text -> VCF, BAM -> VCF)")
     ap.add_argument("--e2e-chunks", type=int, default=96, help="chunk files of the mpileup-text leg (the BAM leg uses a third as many)")
     args = ap.parse_args()
@@ -184,7 +186,29 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend, device_id=dev) if backend == "nccl" else dist.init_process_group(backend)
+        # a rendezvous or a first collective that hangs (IPC mode, a dead peer, a GPU another rank also took) must end in a message,
+        # not in the driver's time-out: the process group times out on its own, and a watchdog thread ends the rank if the whole
+        # run overstays --watchdog seconds, naming the stage it was in
+        import datetime
+        import threading
+        stage = {"name": "init_process_group(%s)" % backend}
+
+        def _watchdog():
+            time.sleep(args.watchdog)
+            sys.stderr.write("[bench.py rank %d/%d on cuda:%d] watchdog: still in stage '%s' after %d s - giving up\n"
+                             % (rank, world, local_rank, stage["name"], args.watchdog))
+            sys.stderr.flush()
+            os._exit(3)
+        threading.Thread(target=_watchdog, daemon=True).start()
+        tmo = datetime.timedelta(seconds=min(600, args.watchdog))
+        try:
+            dist.init_process_group(backend, device_id=dev, timeout=tmo) if backend == "nccl" else dist.init_process_group(backend, timeout=tmo)
+        except Exception as e:
+            sys.exit("[bench.py rank %d/%d on cuda:%d] init_process_group(%s) failed: %r (MASTER_ADDR=%s MASTER_PORT=%s HSA_ENABLE_IPC_MODE_LEGACY=%s)"
+                     % (rank, world, local_rank, backend, e, os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"),
+                        os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")))
+    else:
+        stage = {"name": "single"}
 
     from clairs_to_amd._lib import lib, check
     from clairs_to_amd.engine import Engine, synthetic_models
@@ -197,6 +221,7 @@ def main():
     eng = Engine(models["aff"], models["neg"], lik, edges, min_bq=min_bq, device=dev)
 
     # ---- synthetic job: `pool` chunks per rank, packs resident in HBM ----
+    stage["name"] = "synthesising %d chunks" % args.pool
     chunks, packs, sites = [], [], []
     for i in range(args.pool):
         ch = SynthChunk(args.batch, seed=20260928 + 1000 * rank + i, start=100000 + (rank * args.pool + i) * 2000000)
@@ -231,10 +256,12 @@ def main():
     # set-up, not a step: the first pass sizes the per-model workspaces (hipMalloc) and the caching allocator's pools
     eng.run_device(packs[0], sites[0])
     torch.cuda.synchronize()
+    stage["name"] = "first collective (communicator set-up)"
     if world > 1:
         # communicator set-up (seconds on the first collective) never lands in the timed region, whatever --warmup is
         dist.all_gather_into_tensor(gather_buf[0], torch.zeros((args.batch, 2 * N_OUT, 2), dtype=torch.float32, device=dev))
         dist.barrier()
+    stage["name"] = "warm-up + timed steps"
     for i in range(args.warmup):
         step(i)
     sync()
@@ -275,6 +302,50 @@ def main():
     n_meas = check(lib.cto_model_profile_read(eng.h_neg, C.byref(mean_ms), C.byref(macs)))
     flops_per_launch = 2.0 * macs.value * args.batch
     achieved = flops_per_launch / (mean_ms.value * 1e-3) / 1e12 if n_meas > 0 and mean_ms.value > 0 else 0.0
+
+    # ---- after the timed region, never in `value`: (1) the whole job configs[1] names, 245 steps = 1 003 520 sites, timed in 20-step
+    # windows by events on the launch stream (no host sync inside); (2) every stage's kernel time from live HIP events ----
+    sustained, stage_fracs = None, None
+    if world == 1 and not args.no_sustained:
+        n_sus, win = 245, 20
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_sus // win + 2)]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        marks[0].record()
+        k = 1
+        for i in range(n_sus):
+            step(i)
+            if (i + 1) % win == 0:
+                marks[k].record()
+                k += 1
+        marks[k].record()
+        torch.cuda.synchronize()
+        dt_sus = time.perf_counter() - t1
+        wins = [marks[j].elapsed_time(marks[j + 1]) / win for j in range(n_sus // win)]
+        sustained = {"steps": n_sus, "sites": n_sus * args.batch, "seconds": round(dt_sus, 4), "ms_per_step": round(dt_sus / n_sus * 1e3, 4),
+                     "sites_per_s": round(n_sus * args.batch / dt_sus, 1), "window_steps": win,
+                     "ms_per_step_min_window": round(min(wins), 4), "ms_per_step_max_window": round(max(wins), 4),
+                     "note": "configs[1]'s whole job (1M sites in %d-site steps) back to back on the resident packs; windows timed by events on the launch stream" % args.batch}
+        l1_ms, l1_macs = C.c_double(0.0), C.c_int64(0)
+        check(lib.cto_model_profile_read_stage(eng.h_neg, 1, C.byref(l1_ms), C.byref(l1_macs)))       # layer-1 events of the timed region
+        check(lib.cto_model_profile(eng.h_aff, 1))
+        check(lib.cto_model_profile(eng.h_neg, 1))
+        for i in range(20):
+            step(i)
+        torch.cuda.synchronize()
+        check(lib.cto_model_profile(eng.h_aff, 0))
+        check(lib.cto_model_profile(eng.h_neg, 0))
+        cvt_ms, cvt_macs, l2_ms, l2_macs = C.c_double(0.0), C.c_int64(0), C.c_double(0.0), C.c_int64(0)
+        check(lib.cto_model_profile_read(eng.h_aff, C.byref(cvt_ms), C.byref(cvt_macs)))
+        check(lib.cto_model_profile_read(eng.h_neg, C.byref(l2_ms), C.byref(l2_macs)))
+        check(lib.cto_model_profile_read_stage(eng.h_neg, 1, C.byref(l1_ms), C.byref(l1_macs)))
+
+        def frac(ms, macs_):
+            tf = 2.0 * macs_ * args.batch / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            return {"ms": round(ms, 4), "tflops": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
+        stage_fracs = {"gru_l2": frac(l2_ms.value, l2_macs.value), "gru_l1": frac(l1_ms.value, l1_macs.value),
+                       "cvt": frac(cvt_ms.value, cvt_macs.value),
+                       "note": "mean of 20 launches each, HIP events on the launch stream (cto_model_profile); cvt = its six block launches"}
 
     # ---- secondary roofline: pileup-tensor creation (HBM-bound stage), timed on its own after the timed region ----
     from clairs_to_amd.featurize import featurize
@@ -324,6 +395,11 @@ def main():
             "backend": (dist.get_backend() + (" (RCCL over xGMI)" if backend == "nccl" else " (test hook)")) if world > 1 else None,
             "rank_devices": census, "gather_verified": gather_ok,
         }
+        if sustained is not None:
+            res["sustained"] = sustained
+            stage_fracs["tensor_creation"] = {"ms": round(feat_ms, 4), "gb_per_s": round(feat_bytes / (feat_ms * 1e-3) / 1e9, 1),
+                                              "frac_of_hbm_peak": round(feat_bytes / (feat_ms * 1e-3) / 1e9 / 8000.0, 4)}
+            res["stage_fracs"] = stage_fracs
         if world == 1 and not args.no_cpu_baseline:
             cb, probs_cpu = cpu_baseline(chunks, models, lik, edges, min_bq, min(args.cpu_sample, args.batch))
             res["cpu_baseline"] = cb
@@ -340,7 +416,7 @@ def main():
             if "LD_PRELOAD" in env:
                 env["LD_PRELOAD"] = ":".join(x for x in env["LD_PRELOAD"].split(":") if "rocprof" not in x and "roctracer" not in x)
             child = subprocess.run([sys.executable, "-m", "clairs_to_amd.e2e", "--chunks", str(args.e2e_chunks), "--bam-chunks",
-                                    str(max(2, args.e2e_chunks // 3)), "--batch", str(args.batch)],
+                                    str(max(2, args.e2e_chunks // 3)), "--batch", str(args.batch), "--reference-chunk-sites", "10000"],
                                    cwd=ROOT, env=env, capture_output=True, text=True)
             lines = [ln for ln in child.stdout.split("\n") if ln.startswith("{")]
             e2e = json.loads(lines[-1]) if child.returncode == 0 and lines else {"error": child.stderr[-500:]}

@@ -95,12 +95,14 @@ struct cto_model {
     // live kernel timing (cto_model_profile)
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev1;     // BiGRU layer 1 (cto_model_profile_read_stage, stage 1)
     int64_t prof_macs = 0;
     float *b_h = nullptr, *b_t = nullptr, *b_yq = nullptr, *b_ykv = nullptr, *b_q = nullptr, *b_kv = nullptr,
           *b_o = nullptr, *b_u = nullptr, *b_slab = nullptr, *b_h2 = nullptr;
     ~cto_model() {
         for (void* p : ws_ptrs) (void)hipFree(p);
         for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        for (auto& e : prof_ev1) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     }
 };
 
@@ -420,8 +422,13 @@ int prof_begin(cto_model* m, hipStream_t s, hipEvent_t* e0, hipEvent_t* e1) {
 
 int bigru_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStream_t s) {
     int rc;
-    if ((rc = launch_gru_layer1(s, x, m->gw1, m->gb1, m->b_h, B))) return rc;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (m->prof && (rc = prof_begin(m, s, &e0, &e1))) return rc;
+    if ((rc = launch_gru_layer1(s, x, m->gw1, m->gb1, m->b_h, B))) return rc;
+    if (m->prof) {
+        CTO_HIP(hipEventRecord(e1, s));
+        m->prof_ev1.emplace_back(e0, e1);
+    }
     if (m->prof && (rc = prof_begin(m, s, &e0, &e1))) return rc;
     // layer 2 with the head's fc1 folded in: writes one partial [B][128] slab per direction into b_slab
     if ((rc = launch_gru_layer2_fc1(s, m->b_h, m->gw2, m->gb2, m->head.w1, m->b_slab, B))) return rc;
@@ -614,11 +621,11 @@ extern "C" int cto_model_profile(cto_model* m, int enable) {
     return CTO_OK;
 }
 
-extern "C" int cto_model_profile_read(cto_model* m, double* mean_ms, int64_t* macs_per_site) {
-    CTO_REQUIRE(m && mean_ms && macs_per_site, CTO_EINVAL, "cto_model_profile_read: null argument");
+extern "C" int cto_model_profile_read(cto_model* m, double* mean_ms, int64_t* macs_per_site);
+static int profile_drain(std::vector<std::pair<hipEvent_t, hipEvent_t>>& evs, double* mean_ms) {
     double sum = 0.0;
     int n = 0;
-    for (auto& e : m->prof_ev) {
+    for (auto& e : evs) {
         CTO_HIP(hipEventSynchronize(e.second));
         float ms = 0.f;
         CTO_HIP(hipEventElapsedTime(&ms, e.first, e.second));
@@ -627,10 +634,23 @@ extern "C" int cto_model_profile_read(cto_model* m, double* mean_ms, int64_t* ma
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
-    m->prof_ev.clear();
+    evs.clear();
     *mean_ms = n ? sum / n : 0.0;
-    *macs_per_site = m->prof_macs;
     return n;
+}
+
+extern "C" int cto_model_profile_read_stage(cto_model* m, int stage, double* mean_ms, int64_t* macs_per_site) {
+    CTO_REQUIRE(m && mean_ms && macs_per_site, CTO_EINVAL, "cto_model_profile_read_stage: null argument");
+    if (stage == 0) return cto_model_profile_read(m, mean_ms, macs_per_site);
+    CTO_REQUIRE(stage == 1 && m->kind == 1, CTO_EINVAL, "cto_model_profile_read_stage: stage 1 exists for the BiGRU only");
+    *macs_per_site = int64_t(33) * 2 * 3 * 128 * (34 + 128);      // layer 1, both directions
+    return profile_drain(m->prof_ev1, mean_ms);
+}
+
+extern "C" int cto_model_profile_read(cto_model* m, double* mean_ms, int64_t* macs_per_site) {
+    CTO_REQUIRE(m && mean_ms && macs_per_site, CTO_EINVAL, "cto_model_profile_read: null argument");
+    *macs_per_site = m->prof_macs;
+    return profile_drain(m->prof_ev, mean_ms);
 }
 
 extern "C" int64_t cto_model_macs_per_site(const cto_model* m) { return m ? m->macs : 0; }

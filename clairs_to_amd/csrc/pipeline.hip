@@ -107,10 +107,12 @@ struct Slot {
     const int32_t* d_site_pos = nullptr;
     // featurisation / network / epilogue outputs
     DevBuf colvec, coldepth, x_aff, x_neg, la, ln, post;
+    DevBuf dec_l, qual_l;                // decision / QUAL of one network launch, before they are dealt out to the chunks they belong to
     DevBuf res_dev;                      // site_info | candidate column vectors | sitefirst | decision | qual | keycnt | keyfirst
     PinBuf res_host;                     // the same bytes on the host, one copy per chunk
     size_t roff[7] = {0, 0, 0, 0, 0, 0, 0};
-    hipEvent_t uploaded = nullptr, begin = nullptr, computed = nullptr, done = nullptr;
+    hipEvent_t uploaded = nullptr, begin = nullptr, computed = nullptr, done = nullptr, kernels_end = nullptr;
+    size_t res_total = 0;
     // host side of the chunk
     int64_t job = -1;
     int device = 0;
@@ -125,6 +127,7 @@ struct Slot {
         if (done) (void)hipEventDestroy(done);
         if (begin) (void)hipEventDestroy(begin);
         if (computed) (void)hipEventDestroy(computed);
+        if (kernels_end) (void)hipEventDestroy(kernels_end);
     }
 };
 
@@ -561,6 +564,10 @@ struct Run {
         const bool in_place = h.entries == s->stage.p && ne > 0;          // entries first: already there for the text producer
         if (s->stage.grow_keeping(total, in_place ? bytes[0] : 0) != CTO_OK || s->pack_dev.ensure(total) != CTO_OK) { fail(cto_last_error()); return false; }
         char* hs = static_cast<char*>(s->stage.p);
+        if (in_place) {                      // grow_keeping may have moved the staging buffer: nothing may keep pointing at the old one
+            s->pack->ext_entries = reinterpret_cast<uint32_t*>(hs);
+            s->hv.entries = reinterpret_cast<const uint32_t*>(hs);
+        }
         for (int i = in_place ? 1 : 0; i < 8; ++i)
             if (bytes[i]) memcpy(hs + off[i], src[i], bytes[i]);
         if (hipMemcpyAsync(s->pack_dev.p, hs, total, hipMemcpyHostToDevice, stream) != hipSuccess) { fail("hipMemcpyAsync failed"); return false; }
@@ -618,11 +625,134 @@ struct Run {
             return rc;
         hipLaunchKernelGGL(k_gather_rows, dim3(unsigned(n)), dim3(128), 0, main, colvec, site_info, n, site_colvec);
         CTO_HIP(hipGetLastError());
+        CTO_HIP(hipEventRecord(s->kernels_end, main));
         CTO_HIP(hipEventRecord(s->computed, main));
         CTO_HIP(hipStreamWaitEvent(copy_back, s->computed, 0));
         CTO_HIP(hipMemcpyAsync(s->res_host.p, s->res_dev.p, total, hipMemcpyDeviceToHost, copy_back));
         CTO_HIP(hipEventRecord(s->done, copy_back));
         return CTO_OK;
+    }
+
+    // ---- the networks fed by a STREAM of sites instead of by chunks --------------------------------------------------------------
+    // The recurrent kernels put 32 sites x one direction on a CU, so a launch is efficient when it is a whole number of rounds
+    // (16 x CUs sites: 4096 on MI355X) and the reference's 10 000-site chunk files (shared/param.py:21) are 2.44 rounds of work in 2.83
+    // rounds of time.  Sites are independent, so the launcher runs the networks on whole rounds only and carries the tail of a chunk
+    // into the launch of the next one: the tail's input rows are copied to the front of the next chunk's input buffers, the
+    // featurisation of that chunk appends behind them, and what the networks + the epilogue return is dealt back to the chunks it
+    // belongs to (`pending`: chunk, first row, rows, in buffer order).  A chunk goes to the writers when its last row is back; what is
+    // left at the end of the run (or when `max_pending` chunks are waiting - they hold slots the producers need) is launched as it is.
+    struct Pending { Slot* s; int64_t row0, cnt; };
+    std::vector<Pending> pending;
+    Slot* carry_home = nullptr;              // whose x buffers hold the pending rows ...
+    int64_t carry_at = 0;                    // ... starting at this row
+    int64_t round_sites = 4096;
+    size_t max_pending = 2;
+    hipEvent_t flush_begin = nullptr, flush_end = nullptr;
+    bool flush_timed = false;
+
+    int64_t pending_rows() const { int64_t c = 0; for (const Pending& q : pending) c += q.cnt; return c; }
+
+    // networks + epilogue over rows [at, at + m) of `home`'s input buffers; results dealt out to the first m pending rows
+    int run_networks(Slot* home, int64_t at, int64_t m, hipStream_t main, hipStream_t copy_back, cto_model* aff, cto_model* neg,
+                     std::vector<Slot*>* complete, hipEvent_t kernels_end) {
+        const int K = cfg->K;
+        int rc;
+        const size_t row = size_t(CTO_NPOS) * CTO_NCHAN;
+        if ((rc = home->la.ensure(size_t(K) * m * 8)) || (rc = home->ln.ensure(size_t(K) * m * 8)) || (rc = home->post.ensure(size_t(m) * K * 8)) ||
+            (rc = home->dec_l.ensure(size_t(m) * 16)) || (rc = home->qual_l.ensure(size_t(m) * 8)))
+            return rc;
+        const float* xa = static_cast<const float*>(home->x_aff.p) + size_t(at) * row;
+        const float* xn = cfg->neg_reads_aff ? xa : static_cast<const float*>(home->x_neg.p) + size_t(at) * row;
+        if ((rc = cto_model_forward(neg, xn, m, static_cast<float*>(home->ln.p), main))) return rc;
+        if ((rc = cto_model_forward(aff, xa, m, static_cast<float*>(home->la.p), main))) return rc;
+        if ((rc = cto_posterior(static_cast<const float*>(home->la.p), static_cast<const float*>(home->ln.p), K, m, cfg->d_lik, cfg->d_edges, nullptr,
+                                static_cast<double*>(home->post.p), static_cast<int32_t*>(home->dec_l.p), static_cast<double*>(home->qual_l.p), main)))
+            return rc;
+        if (kernels_end) CTO_HIP(hipEventRecord(kernels_end, main));   // before any chunk of this launch can reach a writer, which reads it
+        int64_t o = 0;
+        size_t used = 0;
+        for (Pending& q : pending) {
+            if (o >= m) break;
+            const int64_t take = std::min(q.cnt, m - o);
+            char* rd = static_cast<char*>(q.s->res_dev.p);
+            CTO_HIP(hipMemcpyAsync(rd + q.s->roff[3] + size_t(q.row0) * 16, static_cast<char*>(home->dec_l.p) + size_t(o) * 16, size_t(take) * 16,
+                                   hipMemcpyDeviceToDevice, main));
+            CTO_HIP(hipMemcpyAsync(rd + q.s->roff[4] + size_t(q.row0) * 8, static_cast<char*>(home->qual_l.p) + size_t(o) * 8, size_t(take) * 8,
+                                   hipMemcpyDeviceToDevice, main));
+            q.row0 += take;
+            q.cnt -= take;
+            o += take;
+            if (q.cnt == 0) {
+                ++used;
+                CTO_HIP(hipEventRecord(q.s->computed, main));
+                CTO_HIP(hipStreamWaitEvent(copy_back, q.s->computed, 0));
+                CTO_HIP(hipMemcpyAsync(q.s->res_host.p, q.s->res_dev.p, q.s->res_total, hipMemcpyDeviceToHost, copy_back));
+                CTO_HIP(hipEventRecord(q.s->done, copy_back));
+                complete->push_back(q.s);
+            }
+        }
+        pending.erase(pending.begin(), pending.begin() + long(used));
+        return CTO_OK;
+    }
+
+    // one chunk into the stream; chunks whose last row came back go to *complete (in chunk order)
+    int launch_stream(Slot* s, hipStream_t main, hipStream_t copy_back, cto_model* aff, cto_model* neg, std::vector<Slot*>* complete) {
+        const int64_t n = int64_t(s->sites.size()), c = pending_rows();
+        const size_t nc = size_t(std::max<int64_t>(s->hv.n_cols, 1)), nk = size_t(std::max<int64_t>(s->hv.n_keys, 1));
+        const size_t row = size_t(CTO_NPOS) * CTO_NCHAN * 4;
+        int rc;
+        const size_t rbytes[7] = {size_t(n) * 48, size_t(n) * CTO_COLVEC_STRIDE * 2, size_t(n) * 32, size_t(n) * 16, size_t(n) * 8, nk * 4, nk * 8};
+        size_t total = 0;
+        for (int i = 0; i < 7; ++i) { s->roff[i] = total; total += (rbytes[i] + 255) / 256 * 256; }
+        s->res_total = total;
+        if ((rc = s->colvec.ensure(nc * CTO_COLVEC_STRIDE * 2)) || (rc = s->coldepth.ensure(nc * 8)) ||
+            (rc = s->x_aff.ensure(size_t(c + n) * row)) || (rc = s->x_neg.ensure(size_t(c + n) * row)) ||
+            (rc = s->res_dev.ensure(total)) || (rc = s->res_host.ensure(total)))
+            return rc;
+        char* rd = static_cast<char*>(s->res_dev.p);
+        auto* site_info = reinterpret_cast<int32_t*>(rd + s->roff[0]);
+        auto* site_colvec = reinterpret_cast<int16_t*>(rd + s->roff[1]);
+        auto* sitefirst = reinterpret_cast<int32_t*>(rd + s->roff[2]);
+        auto* keycnt = reinterpret_cast<uint32_t*>(rd + s->roff[5]);
+        auto* keyfirst = reinterpret_cast<int32_t*>(rd + s->roff[6]);
+        CTO_HIP(hipStreamWaitEvent(main, s->uploaded, 0));
+        CTO_HIP(hipEventRecord(s->begin, main));
+        if (c > 0) {                         // the rows still waiting move to the front of this chunk's input buffers
+            CTO_HIP(hipMemcpyAsync(s->x_aff.p, static_cast<char*>(carry_home->x_aff.p) + size_t(carry_at) * row, size_t(c) * row, hipMemcpyDeviceToDevice, main));
+            if (!cfg->neg_reads_aff)
+                CTO_HIP(hipMemcpyAsync(s->x_neg.p, static_cast<char*>(carry_home->x_neg.p) + size_t(carry_at) * row, size_t(c) * row, hipMemcpyDeviceToDevice, main));
+        }
+        auto* colvec = static_cast<int16_t*>(s->colvec.p);
+        if ((rc = cto_featurize_columns(&s->dv, cfg->min_bq, colvec, static_cast<int32_t*>(s->coldepth.p), keycnt, main))) return rc;
+        if ((rc = cto_gather_windows(&s->dv, colvec, static_cast<int32_t*>(s->coldepth.p), s->d_site_pos, n, cfg->min_bq, cfg->min_rescale_cov,
+                                     reinterpret_cast<float*>(static_cast<char*>(s->x_aff.p) + size_t(c) * row),
+                                     reinterpret_cast<float*>(static_cast<char*>(s->x_neg.p) + size_t(c) * row), nullptr, nullptr, site_info, sitefirst,
+                                     keyfirst, main)))
+            return rc;
+        hipLaunchKernelGGL(k_gather_rows, dim3(unsigned(n)), dim3(128), 0, main, colvec, site_info, n, site_colvec);
+        CTO_HIP(hipGetLastError());
+        pending.push_back({s, 0, n});
+        carry_home = s;
+        carry_at = 0;
+        const int64_t all = c + n;
+        const int64_t m = pending.size() > max_pending ? all : all / round_sites * round_sites;
+        if (m > 0) {
+            if ((rc = run_networks(s, 0, m, main, copy_back, aff, neg, complete, s->kernels_end))) return rc;
+            carry_at = m;
+        } else {
+            CTO_HIP(hipEventRecord(s->kernels_end, main));
+        }
+        return CTO_OK;
+    }
+
+    // the end of the run: what is still waiting is launched as it is
+    int flush_stream(hipStream_t main, hipStream_t copy_back, cto_model* aff, cto_model* neg, std::vector<Slot*>* complete) {
+        const int64_t c = pending_rows();
+        if (c == 0) { for (const Pending& q : pending) complete->push_back(q.s); pending.clear(); return CTO_OK; }
+        if (flush_begin) CTO_HIP(hipEventRecord(flush_begin, main));
+        const int rc = run_networks(carry_home, carry_at, c, main, copy_back, aff, neg, complete, flush_end);
+        if (rc == CTO_OK && flush_end) flush_timed = true;
+        return rc;
     }
 
     // alt_info strings, VCF records, file
@@ -631,7 +761,8 @@ struct Run {
         if (wait_event(s->done) != hipSuccess) { fail("waiting for the chunk's results failed"); return false; }
         {
             float ms = 0;
-            if (hipEventElapsedTime(&ms, s->begin, s->done) == hipSuccess) { std::lock_guard<std::mutex> g(stat_m); device_s += ms * 1e-3; }
+            // the kernels this chunk's launch queued (with a tile stream, its own tail runs - and is counted - in the next chunk's launch)
+            if (hipEventElapsedTime(&ms, s->begin, s->kernels_end) == hipSuccess) { std::lock_guard<std::mutex> g(stat_m); device_s += ms * 1e-3; }
         }
         const int64_t n = int64_t(s->sites.size());
         char* rh = static_cast<char*>(s->res_host.p);
@@ -744,6 +875,7 @@ static int run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs, int64_t
         CTO_HIP(hipEventCreateWithFlags(&run.slots.back()->uploaded, hipEventDisableTiming));
         CTO_HIP(hipEventCreate(&run.slots.back()->begin));
         CTO_HIP(hipEventCreateWithFlags(&run.slots.back()->computed, hipEventDisableTiming));
+        CTO_HIP(hipEventCreate(&run.slots.back()->kernels_end));
         CTO_HIP(hipEventCreateWithFlags(&run.slots.back()->done, hipEventBlockingSync));      // writers sleep, not spin, until their chunk is back
     }
     for (auto& sl : run.slots) run.free_slots.push(sl.get());
@@ -837,6 +969,10 @@ static int run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs, int64_t
                 if (j >= run.n_jobs) break;
                 Slot* s = nullptr;
                 if (!run.free_slots.pop(&s)) break;
+                if (run.failed) {                                    // the run failed while this thread waited for a slot: what the slot's
+                    run.free_slots.push(s);                          // last chunk queued on the device may still be running - leave it alone
+                    break;
+                }
                 s->job = j;
                 const double t0 = now_s();
                 bool ok = false;
@@ -874,21 +1010,65 @@ static int run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs, int64_t
     double launch_s = 0, wait_s = 0;
     int rc = CTO_OK;
     int64_t launched = 0;
+    // the networks take a stream of sites, not chunks (Run::launch_stream), unless two compute streams take the chunks in turn or the
+    // caller turns it off (CTO_TILE_STREAM=0: every chunk is its own launch, as before)
+    static const bool stream_off = [] { const char* e = getenv("CTO_TILE_STREAM"); return e && e[0] == '0'; }();
+    const bool tile_stream = !second && !stream_off;
+    if (tile_stream) {
+        int n_cu = 256;
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        run.round_sites = int64_t(16) * std::max(n_cu, 1);
+        run.max_pending = size_t(std::max(1, std::min(4, depth / 3)));      // chunks that may wait for rows: each holds a slot
+        (void)hipEventCreate(&run.flush_begin);
+        (void)hipEventCreate(&run.flush_end);
+    }
+    std::vector<Slot*> complete;
+    auto hand_over = [&] {
+        for (Slot* c : complete) {
+            if (run.failed) run.free_slots.push(c); else run.to_write.push(c);
+        }
+        complete.clear();
+    };
+    auto abandon_pending = [&] {             // a failed run: the chunks still waiting for rows give their slots back
+        if (!run.pending.empty()) (void)hipStreamSynchronize(main);
+        for (const Run::Pending& q : run.pending) run.free_slots.push(q.s);
+        run.pending.clear();
+    };
     for (;;) {
         Slot* s = nullptr;
         const double t0 = now_s();
         if (!run.to_launch.pop(&s)) break;
         const double t1 = now_s();
         wait_s += t1 - t0;
+        bool queued = false;
         if (!run.failed) {
-            const bool odd = second && (launched++ & 1);
-            const int r = run.launch(s, odd ? second : main, copy_back, odd ? cfg->aff2 : cfg->aff, odd ? cfg->neg2 : cfg->neg);
+            int r;
+            if (tile_stream) {
+                r = run.launch_stream(s, main, copy_back, cfg->aff, cfg->neg, &complete);
+                queued = r == CTO_OK || std::any_of(run.pending.begin(), run.pending.end(), [s](const Run::Pending& q) { return q.s == s; });
+            } else {
+                const bool odd = second && (launched++ & 1);
+                r = run.launch(s, odd ? second : main, copy_back, odd ? cfg->aff2 : cfg->aff, odd ? cfg->neg2 : cfg->neg);
+                if (r == CTO_OK) { complete.push_back(s); queued = true; }
+            }
             if (r != CTO_OK) { run.fail(cto_last_error()); rc = r; }
         }
         launch_s += now_s() - t1;
-        if (run.failed) run.free_slots.push(s);
-        else run.to_write.push(s);
+        if (!queued) {
+            (void)hipStreamSynchronize(main);                         // its buffers may be in use by what was queued before the failure
+            run.free_slots.push(s);
+        }
+        hand_over();
+        if (run.failed) abandon_pending();
     }
+    if (tile_stream && !run.failed) {
+        const double t1 = now_s();
+        const int r = run.flush_stream(main, copy_back, cfg->aff, cfg->neg, &complete);
+        if (r != CTO_OK) { run.fail(cto_last_error()); rc = r; }
+        launch_s += now_s() - t1;
+        hand_over();
+    }
+    if (run.failed) abandon_pending();
     run.to_write.close();
     run.free_slots.close();
     for (auto& th : threads) th.join();
@@ -896,6 +1076,12 @@ static int run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs, int64_t
     if (second) { (void)hipStreamSynchronize(second); (void)hipStreamDestroy(second); }
     (void)hipStreamSynchronize(copy_back);
     (void)hipStreamDestroy(copy_back);
+    if (run.flush_timed) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, run.flush_begin, run.flush_end) == hipSuccess) run.device_s += ms * 1e-3;
+    }
+    if (run.flush_begin) (void)hipEventDestroy(run.flush_begin);
+    if (run.flush_end) (void)hipEventDestroy(run.flush_end);
     if (own_main) (void)hipStreamDestroy(own_main);
     if (stats) {
         stats->candidates = run.candidates;

@@ -248,6 +248,9 @@ void cto_model_destroy(cto_model* m);
  * in that kernel (launch MACs = per-site MACs x batch). */
 int cto_model_profile(cto_model* m, int enable);
 int cto_model_profile_read(cto_model* m, double* mean_ms, int64_t* macs_per_site);
+/* The same for one more kernel of the model: stage 0 = the above, stage 1 = BiGRU layer 1 (bracketed whenever profiling is on).
+ * Its events are kept until read; stage 1 of a CvT handle is CTO_EINVAL. */
+int cto_model_profile_read_stage(cto_model* m, int stage, double* mean_ms, int64_t* macs_per_site);
 
 /* ------------------------------------------------------------------------------------------------
  * Posterior / decision / quality (clairs/call_variants.py:154-304, 79-88), fused with the 2-way

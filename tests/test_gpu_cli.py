@@ -166,6 +166,72 @@ def test_bench_multi_rank_code_path(tmp_path, launcher):
     assert [d["rank"] for d in res["rank_devices"]] == [0, 1]
 
 
+def test_bench_two_ranks_over_rccl(tmp_path):
+    """First contact with RCCL, automatically, wherever >= 2 GPUs are visible (the build's own boxes have one: skipped there):
+    `bench.py --gpus 2` must come back with one JSON line whose exchange step ran over nccl (= RCCL) between two distinct devices.
+    A hang ends in bench.py's own watchdog message (stderr is shown), not in a silent time-out."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    from conftest import ROOT
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL over xGMI)")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CTO_BENCH_BACKEND", "CTO_BENCH_DEVICE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--pool", "2",
+                        "--watchdog", "240"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.split("\n") if l.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["ranks_seen"] == 2 and res["gather_verified"] is True
+    assert res["backend"].startswith("nccl"), res["backend"]
+    pci = [d["pci"] for d in res["rank_devices"]]
+    assert len(set(pci)) == 2 and [d["device"] for d in res["rank_devices"]] == ["cuda:0", "cuda:1"]
+
+
+def test_call_chunks_two_ranks_over_rccl(tmp_path):
+    """call_chunks on two GPUs (one rank each under torch.distributed.run; its control plane is gloo by design - chunk files shard
+    with no data-path collective): same merged records as one rank; skipped on a one-GPU box (where
+    test_call_chunks_matches_single_call[2] runs the same control flow on one device)."""
+    import subprocess
+    import sys
+    import torch
+    from conftest import ROOT
+    from clairs_to_amd.synth import likelihood_table
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL over xGMI)")
+    sc = _bam_scenario(tmp_path)
+    paths = _pickle_models(tmp_path, "CvT", "BiGRU_NACGT", 4)
+    lik = tmp_path / "lik.txt"
+    np.savetxt(lik, likelihood_table(4, seed=11), fmt="%.17g")
+    sites = sc["sites"]
+    cdir = tmp_path / "candidates"
+    cdir.mkdir()
+    names = []
+    for i in range(4):
+        part = sites[i * len(sites) // 4:(i + 1) * len(sites) // 4]
+        fn = cdir / ("chr1.%d_4_snv" % (i + 1))
+        fn.write_text("".join("chr1\t%d\t%d\n" % (x - 17, x + 17) for x in part))
+        names.append(str(fn))
+    (tmp_path / "CANDIDATES_FILES").write_text("".join(n + "\n" for n in names))
+    common = ["--platform", "ont", "--tumor_bam_fn", sc["bam"], "--ref_fn", sc["fa"], "--bam_reader", "native", "--chkpnt_fn_acgt",
+              paths["model_acgt"], "--chkpnt_fn_nacgt", paths["model_nacgt"], "--disable_indel_calling", "True",
+              "--likelihood_matrix_data", str(lik), "--show_ref"]
+    outs = {}
+    for world in (1, 2):
+        out_dir, merged = tmp_path / ("vcf_%d" % world), tmp_path / ("merged_%d.vcf" % world)
+        cmd = ["-m", "clairs_to_amd", "call_chunks", "--chunk_list", str(tmp_path / "CANDIDATES_FILES"), "--output_dir", str(out_dir),
+               "--merged_vcf_fn", str(merged)] + common
+        full = [sys.executable] + cmd if world == 1 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                                        "--master-addr", "127.0.0.1", "--master-port", "29546"] + cmd
+        env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        r = subprocess.run(full, cwd=ROOT, capture_output=True, text=True, timeout=400, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[world] = [l for l in open(merged).read().split("\n") if l and not l.startswith("#")]
+    assert outs[1] == outs[2] and len(outs[1]) > 50
+
+
 def _bam_scenario(tmp_path):
     """A 6 kb contig, 700 synthetic long reads with substitutions and indels (BAM + BAI), candidates every 37 bp, the naive
     pileup text of their windows and a `samtools` shim that prints it."""
@@ -420,6 +486,34 @@ def test_native_pipeline_large_text_chunks(tmp_path):
     assert names == sorted(os.listdir(tmp_path / "nat")) and len(names) == 3
     for fn in names:
         assert open(tmp_path / "py" / fn, "rb").read() == open(tmp_path / "nat" / fn, "rb").read(), fn
+
+
+def test_native_pipeline_tile_stream_across_chunk_seams(tmp_path):
+    """cto_run_chunks feeds the networks whole rounds of 32-site tiles and carries a chunk's tail into the next chunk's launch
+    (Run::launch_stream): 7 chunks of 2 500 sites = launches of 4096 / 4096 / 4096 / 4096 sites cut across the chunk seams + a
+    1 116-site flush.  Sites are independent and the kernels are batch-invariant, so every file must equal the Python pipeline's,
+    which launches chunk by chunk."""
+    from clairs_to_amd.call_chunks import run_pipeline, run_pipeline_native
+    from clairs_to_amd.e2e import chunk_namespaces
+    from clairs_to_amd.engine import Engine, synthetic_models
+    from clairs_to_amd.synth import likelihood_table, lik_and_edges
+    from clairs_to_amd.synth_run import make_text_run
+    run = make_text_run(str(tmp_path / "run"), n_chunks=7, sites_per_chunk=2500, distinct=7)
+    models = synthetic_models(4, seed=0)
+    lik, edges = lik_and_edges(likelihood_table(4), 4)
+    eng = Engine(models["aff"], models["neg"], lik, edges, min_bq=20, device="cuda:0")
+    a_py = chunk_namespaces(run, str(tmp_path / "py"))
+    a_nat = chunk_namespaces(run, str(tmp_path / "nat"))
+    os.makedirs(tmp_path / "py"), os.makedirs(tmp_path / "nat")
+    n_py = run_pipeline(eng, a_py, producers=2, writers=2)
+    for producers, writers, depth in ((2, 2, 0), (1, 1, 2), (4, 1, 0)):     # few slots: chunks waiting for rows must not starve the producers
+        n_nat = run_pipeline_native(eng, a_nat, producers=producers, writers=writers, depth=depth, verbose=False)
+        assert n_py == n_nat and n_py > 3000
+        names = sorted(os.listdir(tmp_path / "py"))
+        assert names == sorted(os.listdir(tmp_path / "nat")) and len(names) == 7
+        for fn in names:
+            assert open(tmp_path / "py" / fn, "rb").read() == open(tmp_path / "nat" / fn, "rb").read(), fn
+            os.remove(tmp_path / "nat" / fn)
 
 
 def test_native_pipeline_illumina_min_bq(tmp_path):
