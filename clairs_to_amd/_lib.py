@@ -48,13 +48,13 @@ class RunCfg(C.Structure):
                 ("show_ref", C.c_int), ("verbose", C.c_int), ("qual_pass", C.c_double), ("ref_fa", C.c_char_p),
                 ("vcf_header", C.c_char_p), ("producers", C.c_int), ("writers", C.c_int), ("depth", C.c_int),
                 ("inflate_cus", C.c_int), ("inflate_jobs", C.c_int), ("pack_threads", C.c_int), ("samtools", C.c_char_p),
-                ("samtools_max_depth", C.c_int), ("aff2", c_vp), ("neg2", c_vp)]
+                ("samtools_max_depth", C.c_int), ("aff2", c_vp), ("neg2", c_vp), ("device_pileup", C.c_int)]
 
 
 class RunStats(C.Structure):
     _fields_ = [("candidates", c_i64), ("sites", c_i64), ("rows", c_i64), ("low_coverage", c_i64), ("clamped", c_i64), ("seconds", C.c_double),
                 ("produce_s", C.c_double), ("finish_s", C.c_double), ("launch_s", C.c_double), ("launcher_wait_s", C.c_double),
-                ("pack_s", C.c_double), ("upload_s", C.c_double), ("device_s", C.c_double), ("device_inflated", c_i64)]
+                ("pack_s", C.c_double), ("upload_s", C.c_double), ("device_s", C.c_double), ("device_piled", c_i64), ("device_inflated", c_i64)]
 
 
 # every symbol include/clairsto_amd.h declares: (restype, argtypes)
@@ -72,6 +72,12 @@ SYMBOLS = {
     "cto_bam_chunk_span": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, c_i64, c_i64, C.POINTER(c_i64), C.POINTER(c_i64)]),
     "cto_bgzf_scan": (c_i64, [c_vp, C.c_size_t, c_i64, c_vp, c_i64, C.POINTER(c_i64)]),
     "cto_bgzf_inflate": (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp]),
+    "cto_dev_pileup_create": (C.c_int, [C.POINTER(c_vp)]),
+    "cto_dev_pileup_destroy": (None, [c_vp]),
+    "cto_bam_record_starts": (c_i64, [C.c_char_p, C.c_char_p, C.c_char_p, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, C.POINTER(c_i32)]),
+    "cto_pileup_device": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_i64, c_i64, c_vp, c_i64, C.c_char_p, c_i64, C.c_size_t,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, c_vp, C.POINTER(PackView), C.POINTER(c_vp), C.POINTER(C.c_int)]),
+    "cto_device_read": (C.c_int, [c_vp, c_vp, C.c_size_t]),
     "cto_pack_from_arrays": (C.c_int, [C.POINTER(PackView), c_vp, c_vp, C.POINTER(c_vp)]),
     "cto_pack_view_of": (C.c_int, [c_vp, C.POINTER(PackView)]),
     "cto_pack_key_string": (C.c_int, [c_vp, c_i64, C.POINTER(C.c_char_p)]),

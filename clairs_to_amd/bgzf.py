@@ -116,3 +116,67 @@ def inflate_span(bam_fn, bai_fn, ctg_name, start, end, device, stream=None):
     s.synchronize()
     check_status(h_status.numpy(), blocks)
     return h_out, blocks
+
+
+class DevicePileup(object):
+    """csrc/pileup.hip: the column pack of a chunk built on the device from the blocks inflated there (one reusable context).
+    pileup(...) -> (PackView of device arrays owned by the context - valid until the next call -, host pack handle without entries,
+    fallback flag); with fallback the chunk needs the host reader (cto_pack_from_bam)."""
+
+    def __init__(self):
+        self.h = C.c_void_p()
+        check(lib.cto_dev_pileup_create(C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.h.value:
+            lib.cto_dev_pileup_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def pileup(self, bam_fn, bai_fn, ctg_name, start, end, ref_seq, ref_start, device, bed=None, excl_flags=2316, min_mq=0, max_depth=8000,
+               max_indel_length=60, stream=None):
+        import torch
+        from ._lib import PackView
+        fb, fe = C.c_int64(0), C.c_int64(0)
+        bai = str(bai_fn).encode() if bai_fn else None
+        check(lib.cto_bam_chunk_span(str(bam_fn).encode(), bai, ctg_name.encode(), int(start), int(end), C.byref(fb), C.byref(fe)))
+        nbytes = max(0, fe.value - fb.value)
+        h_in = _pinned("h_in", nbytes + BGZF_PAD)
+        view = h_in.numpy()
+        if nbytes:
+            with open(bam_fn, "rb", buffering=0) as f:
+                f.seek(fb.value)
+                got = 0
+                while got < nbytes:
+                    more = f.readinto(memoryview(view)[got:nbytes])
+                    if not more:
+                        break
+                    got += more
+                nbytes = got
+        view[nbytes:nbytes + BGZF_PAD] = 0
+        blocks, out_bytes = scan(view, nbytes, fb.value)
+        pv, lite, fallback = PackView(), C.c_void_p(), C.c_int(0)
+        if len(blocks) == 0:
+            return None, None, True
+        cap = 4096 + int((end - start) >> 14) + 64
+        voffs = np.zeros(cap, dtype=np.uint64)
+        tid = C.c_int32(-1)
+        n_st = check(int(lib.cto_bam_record_starts(str(bam_fn).encode(), bai, ctg_name.encode(), int(start), int(end), fb.value, fe.value,
+                                                   voffs.ctypes.data, cap, C.byref(tid))))
+        if n_st == 0:
+            return None, None, True
+        s = stream if stream is not None else torch.cuda.current_stream(device)
+        with torch.cuda.stream(s):
+            d_in = h_in[:nbytes + BGZF_PAD].to(device, non_blocking=True)
+            d_out, d_status = inflate_device(d_in, blocks, out_bytes, device, s)
+            h_status = d_status.to("cpu", non_blocking=False)
+            s.synchronize()
+            check_status(h_status.numpy(), blocks)
+            bed_arr = None if bed is None else np.ascontiguousarray(np.asarray(bed, dtype=np.int64).reshape(-1))
+            hb = np.ascontiguousarray(blocks)
+            ref_b = ref_seq.encode() if isinstance(ref_seq, str) else ref_seq
+            check(lib.cto_pileup_device(self.h, d_out.data_ptr(), hb.ctypes.data, len(hb), voffs.ctypes.data, int(n_st), tid.value, int(start), int(end),
+                                        None if bed_arr is None else bed_arr.ctypes.data, 0 if bed_arr is None else len(bed_arr) // 2, ref_b,
+                                        int(ref_start), len(ref_b), int(excl_flags), int(min_mq), int(max_depth), int(max_indel_length),
+                                        C.c_void_p(s.cuda_stream), C.byref(pv), C.byref(lite), C.byref(fallback)))
+        self._keep = (d_in, d_out)
+        return pv, lite, bool(fallback.value)

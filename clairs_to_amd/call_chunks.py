@@ -211,6 +211,7 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
     cfg.pack_threads = 0 if "CTO_PACK_THREADS" in os.environ else pack_threads(not getattr(a0, "mpileup_fn", None), "native")
     cfg.inflate_cus = DEVICE_INFLATE[0] if inflate_cus is None else int(inflate_cus)       # only BAM jobs use it
     cfg.inflate_jobs = DEVICE_INFLATE[1] if inflate_jobs is None else int(inflate_jobs)
+    cfg.device_pileup = int(os.environ.get("CTO_DEVICE_PILEUP", "1") != "0")     # the device-inflated chunks are piled up on the device too
     if two_streams:                               # consecutive chunks on two compute streams (a second pair of handles of the same weights)
         with torch.cuda.device(eng.device):
             cfg.aff2, cfg.neg2 = eng.aff._handle2(), eng.neg._handle2()
@@ -224,7 +225,7 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
     check(rc)
     if stats is not None:
         for k, v in (("sites", st.candidates), ("produce_s", st.produce_s), ("finish_s", st.finish_s), ("launch_s", st.launch_s),
-                     ("launcher_waits_for_producer_s", st.launcher_wait_s), ("pack_s", st.pack_s), ("upload_s", st.upload_s), ("device_s", st.device_s), ("device_inflated", st.device_inflated), ("low_coverage", st.low_coverage), ("clamped", st.clamped)):
+                     ("launcher_waits_for_producer_s", st.launcher_wait_s), ("pack_s", st.pack_s), ("upload_s", st.upload_s), ("device_s", st.device_s), ("device_inflated", st.device_inflated), ("device_piled", st.device_piled), ("low_coverage", st.low_coverage), ("clamped", st.clamped)):
             stats[k] = stats.get(k, 0) + v
     return int(st.rows)
 

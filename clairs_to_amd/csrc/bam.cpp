@@ -882,6 +882,46 @@ extern "C" int cto_bam_chunk_span(const char* bam_path, const char* bai_path, co
     });
 }
 
+// Record boundaries the index knows inside [file_begin, file_end): the starts of the region's chunks and, per 16 kb window of the
+// region, the first alignment that overlaps it (BAI linear index) - virtual offsets, ascending, the first one being where a
+// reader of the region starts.  The device pileup (csrc/pileup.hip) walks one chain of records from each of them.
+extern "C" int64_t cto_bam_record_starts(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
+                                         int64_t file_begin, int64_t file_end, uint64_t* voffs, int64_t cap, int32_t* tid_out) {
+    int64_t n_out = 0;
+    const int rc = guarded("cto_bam_record_starts", [&] {
+        CTO_REQUIRE(bam_path && ctg_name && voffs && cap > 0 && tid_out, CTO_EINVAL, "cto_bam_record_starts: null argument");
+        CTO_REQUIRE(start >= 1 && end >= start, CTO_EINVAL, "cto_bam_record_starts: bad region");
+        Bgzf bz;
+        CTO_REQUIRE(bz.open(bam_path), CTO_EINVAL, "cto_bam_record_starts: %s", bz.err.c_str());
+        int tid = -1;
+        const int rch = read_header_tid(bz, bam_path, ctg_name, &tid);
+        if (rch != CTO_OK) return rch;
+        *tid_out = tid;
+        std::vector<Chunk> chunks;
+        std::vector<uint64_t> linear;
+        std::string err, idx = bai_path ? std::string(bai_path) : std::string(bam_path) + ".bai";
+        CTO_REQUIRE(bai_query(idx.c_str(), tid, start - 1, end, &chunks, &err, &linear), CTO_EINVAL, "cto_bam_record_starts: %s", err.c_str());
+        if (chunks.empty()) return CTO_OK;
+        const uint64_t first = chunks.front().beg;
+        std::vector<uint64_t> v;
+        for (const Chunk& c : chunks) v.push_back(c.beg);
+        const int64_t w0 = (start - 1) >> 14, w1 = std::min<int64_t>(int64_t(linear.size()) - 1, (end - 1) >> 14);
+        for (int64_t w = w0; w <= w1; ++w)
+            if (w >= 0 && linear[size_t(w)] > first) v.push_back(linear[size_t(w)]);
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+        for (uint64_t x : v) {
+            const int64_t coff = int64_t(x >> 16);
+            if (coff < file_begin || coff >= file_end) continue;
+            if (n_out < cap) voffs[n_out] = x;
+            ++n_out;
+        }
+        CTO_REQUIRE(n_out <= cap, CTO_ENOMEM, "cto_bam_record_starts: %lld offsets, room for %lld", (long long)n_out, (long long)cap);
+        return CTO_OK;
+    });
+    return rc == CTO_OK ? n_out : rc;
+}
+
 // Block table of a run of whole BGZF blocks (a trailing partial block is left out).
 extern "C" int64_t cto_bgzf_scan(const uint8_t* bytes, size_t len, int64_t file_begin, cto_bgzf_block* blocks, int64_t cap, int64_t* out_bytes) {
     if (!bytes || !blocks || !out_bytes) { set_error("cto_bgzf_scan: null argument"); return CTO_EINVAL; }

@@ -18,6 +18,10 @@
 //   phase 7  h'' = acc_f -> sy, then coalesced 16-byte stores to HBM
 //   phase 8  (HEAD, last block of the network) fc1 over the LDS image of the tile -> SELU -> K x (fc2, fc3) instead of the store
 //
+// Up to CVT_MAX_BLK consecutive blocks of a stage run in ONE launch (CvtStageParams): between two of them the tile goes from the
+// second FFN GEMM's accumulators to sy (for the next LayerNorm) and, still in registers, + bias_o into the next out-projection's
+// accumulators - no store, no load, no launch ramp, and no CU waits for the slowest one at a kernel boundary.
+//
 // Tile ownership of an N-wide GEMM output (ColOwn): min(8, N/16) waves own distinct 16-column tiles and the remaining
 // factor of the 8 waves splits the m-tiles, so that every wave owns MFMAs whatever N is (N = 16: eight m-tile groups).
 #pragma once
@@ -107,7 +111,7 @@ __host__ __device__ constexpr int cvt_blocks_per_cu() {
 }
 
 template <int C, int W, int WKV, int TS, int CIN, bool HEAD>
-__global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV, TS>())) void k_cvt_block(float* __restrict__ h, CvtBlockParams p,
+__global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV, TS>())) void k_cvt_block(float* __restrict__ h, CvtStageParams sp,
                                                                                                             HeadTailParams hp, int heads, int B) {
     using G = CvtBlockGeom<C, W, WKV, TS>;
     static_assert(CIN == 0 || G::emb_floats(CIN) <= G::ALIAS, "stage input tile does not fit the free LDS");
@@ -140,8 +144,10 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
     const int inner = heads * 64;
     float* hg = h + int64_t(site0) * W * C;
     int nstamp = 0;
-    auto stamp = [&]() { if (p.prof && blockIdx.x == 0 && tid == 0) p.prof[nstamp++] = clock64(); };
+    long long* const prof = sp.blk[0].prof;
+    auto stamp = [&]() { if (prof && blockIdx.x == 0 && tid == 0 && nstamp < 250) prof[nstamp++] = clock64(); };
     stamp();
+    const CvtBlockParams& pe = sp.blk[0];       // the stage's embedding, when this launch starts the stage
 
 
     // ---- phase 0: residual stream tile -> sy (pad rows zero); first block of a stage: stage input -> LDS instead ----
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
         constexpr int WIN = 2 * W - 1, PS = emb_ps(CIN), NPOS = MT * 32 + 4, VW = (CIN % 4 == 0) ? 4 : 2, SLOTS = PS / VW;
         static_assert(CIN % 2 == 0, "stage input channels must be even");
         float* sin = smem + G::OFF_YKV;
-        const float* xg = p.xin + int64_t(site0) * WIN * CIN;
+        const float* xg = pe.xin + int64_t(site0) * WIN * CIN;
         // all of a thread's pieces are requested before the first one is written to LDS: one HBM round trip, not one per piece
         constexpr int NIT = (NPOS * SLOTS + NT - 1) / NT;
         float4 stage[NIT];
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
         constexpr int PS = emb_ps(CIN), KE = emb_kch(CIN);
         const float* we_r[NTC];
 #pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) we_r[nt] = p.wembp + int64_t((spc.tile0 + nt) * 16 + j) * (KE * 16) + 4 * kg;
+        for (int nt = 0; nt < NTC; ++nt) we_r[nt] = pe.wembp + int64_t((spc.tile0 + nt) * 16 + j) * (KE * 16) + 4 * kg;
         const BPre<NTC> pre_e = prefetch_b<NTC, KE>(we_r);
         f32x4 acc_e[MGC][NTC];
 #pragma unroll
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
 #pragma unroll
         for (int nt = 0; nt < NTC; ++nt) {
             const int col = (spc.tile0 + nt) * 16 + j;
-            const float bv = p.bemb[col];
+            const float bv = pe.bemb[col];
 #pragma unroll
             for (int mt = 0; mt < MGC; ++mt)
                 if (mt < spc.mcount) {
@@ -283,10 +289,13 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
         }
         lds_barrier();
         for (int i = tid; i < (MTKV * 16 - RKV) * RS; i += NT) sykv[RKV * RS + i] = 0.f;    // the input tile lay over these rows
-        layer_norm(sy, sy, p.lng, p.lnb);
+        layer_norm(sy, sy, pe.lng, pe.lnb);
         lds_barrier();
     }
 
+    f32x4 acc_f[MGC][NTC];       // the residual stream at the end of a block (second FFN GEMM's accumulators)
+    for (int bi = 0; bi < sp.nblk; ++bi) {
+    const CvtBlockParams& p = sp.blk[bi];
     stamp();
     // ---- phase 1: the residual stream moves into the out-projection's accumulators; LayerNorm -> staging tile ----
     f32x4 acc_o[MGC][NTC];
@@ -297,8 +306,13 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
 #pragma unroll
         for (int mt = 0; mt < MGC; ++mt) {
             const int row0 = (spc.mbase + (mt < spc.mcount ? mt : 0)) * 16 + 4 * kg;
+            if (bi == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc_o[mt][nt][r] = sy[(row0 + r) * RS + col] + bv;
+                for (int r = 0; r < 4; ++r) acc_o[mt][nt][r] = sy[(row0 + r) * RS + col] + bv;
+            } else {             // a later block of the launch: this wave still holds its part of the tile in registers
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc_o[mt][nt][r] = acc_f[mt][nt][r] + bv;
+            }
         }
     }
     layer_norm(sy, stmp, p.n0g, p.n0b);
@@ -460,7 +474,6 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
 
     // ---- phase 4: h' = h + to_out(o) + bias sits in acc_o: a copy -> staging tile for the LayerNorm, and h' + b2 seeds the
     //      second FFN GEMM's accumulators ----
-    f32x4 acc_f[MGC][NTC];
 #pragma unroll
     for (int nt = 0; nt < NTC; ++nt) {
         const int col = (spc.tile0 + nt) * 16 + j;
@@ -530,6 +543,13 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
                 for (int r = 0; r < 4; ++r) sy[((spc.mbase + mt) * 16 + 4 * kg + r) * RS + col] = acc_f[mt][nt][r];
             }
     }
+    if (bi + 1 < sp.nblk) {
+        lds_barrier();       // the next block's LayerNorm reads whole rows of sy; every wave is past its last read of the hidden chunk
+        if constexpr (MTKV * 16 > RKV)
+            for (int i = tid; i < (MTKV * 16 - RKV) * RS; i += NT) sykv[RKV * RS + i] = 0.f;    // the hidden chunks lay over these pad rows
+    }
+    }   // blocks of this launch
+    const CvtBlockParams& p = sp.blk[sp.nblk - 1];
     if constexpr (!HEAD) {
         lds_barrier();
         for (int i = tid; i < rows_valid * (C / 4); i += NT) {

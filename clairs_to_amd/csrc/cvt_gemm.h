@@ -17,6 +17,14 @@ struct CvtBlockParams {
     const float *w1p, *b1h;                        // fc1 [128][KCH1*16] over the LDS image of h (rows padded to RS)
 };
 
+// Consecutive blocks of ONE stage run in one launch (the tile never leaves the CU between them): blk[0] may carry the stage's
+// embedding, blk[nblk - 1] the classifier.
+constexpr int CVT_MAX_BLK = 4;
+struct CvtStageParams {
+    CvtBlockParams blk[CVT_MAX_BLK];
+    int nblk;
+};
+
 // The first two 16-wide k chunks of a GEMM's weights, requested early (before the barriers / VALU phases that
 // precede the GEMM) so that the matrix pipe does not start every GEMM with an exposed L2 round trip.
 template <int NTW>

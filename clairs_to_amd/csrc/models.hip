@@ -277,7 +277,7 @@ struct BlockExtra {            // what the first / last block of the network add
 };
 
 template <int C, int W, int WKV, int TS, int CIN, bool HEAD>
-int launch_cvt_block(hipStream_t s, float* h, const BlockDev& b, int heads, int64_t B, const BlockExtra& ex) {
+int launch_cvt_block(hipStream_t s, float* h, const BlockDev* blocks, int nblk, int heads, int64_t B, const BlockExtra& ex) {
     using G = CvtBlockGeom<C, W, WKV, TS>;
     static_assert(G::LDS_BYTES <= 160 * 1024, "fused CvT block does not fit the 160 KB LDS of a gfx950 CU");
     static bool attr_set = false;
@@ -290,22 +290,31 @@ int launch_cvt_block(hipStream_t s, float* h, const BlockDev& b, int heads, int6
     static const bool prof_on = [] { const char* e = getenv("CTO_BLOCK_PROF"); return e && e[0] == '1'; }();
     if (prof_on && !prof_buf) CTO_HIP(hipMalloc(reinterpret_cast<void**>(&prof_buf), 256 * sizeof(long long)));
     if (prof_on) CTO_HIP(hipMemsetAsync(prof_buf, 0, 256 * sizeof(long long), s));
-    CvtBlockParams p{b.n0g, b.n0b, b.dwq, b.bnq, b.wq, b.dwkv, b.bnkv, b.wkv, b.wo, b.bo, b.n1g, b.n1b, b.w1, b.b1, b.w2, b.b2,
-                     prof_on ? prof_buf : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    CvtStageParams sp{};
+    sp.nblk = nblk;
+    for (int i = 0; i < nblk; ++i) {
+        const BlockDev& b = blocks[i];
+        sp.blk[i] = CvtBlockParams{b.n0g, b.n0b, b.dwq, b.bnq, b.wq, b.dwkv, b.bnkv, b.wkv, b.wo, b.bo, b.n1g, b.n1b, b.w1, b.b1, b.w2, b.b2,
+                                   prof_on ? prof_buf : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    }
     HeadTailParams hp{};
-    if (CIN > 0) { p.xin = ex.xin; p.wembp = ex.st->wembp; p.bemb = ex.st->bemb; p.lng = ex.st->lng; p.lnb = ex.st->lnb; }
+    if (CIN > 0) {
+        CvtBlockParams& p = sp.blk[0];
+        p.xin = ex.xin; p.wembp = ex.st->wembp; p.bemb = ex.st->bemb; p.lng = ex.st->lng; p.lnb = ex.st->lnb;
+    }
     if (HEAD) {
+        CvtBlockParams& p = sp.blk[nblk - 1];
         p.w1p = ex.head->w1p; p.b1h = ex.head->b1;
         hp = HeadTailParams{ex.head->w2, ex.head->b2, ex.head->w3, ex.head->b3, ex.logits, ex.n_out};
     }
     hipLaunchKernelGGL((k_cvt_block<C, W, WKV, TS, CIN, HEAD>), dim3(unsigned(cdiv(B, TS))), dim3(CVT_BLOCK_THREADS), G::LDS_BYTES,
-                       s, h, p, hp, heads, int(B));
+                       s, h, sp, hp, heads, int(B));
     CTO_HIP(hipGetLastError());
     if (prof_on) {   // debug aid: phase time stamps of workgroup 0 (cycles since the kernel's first stamp)
         long long hst[256];
         CTO_HIP(hipStreamSynchronize(s));
         CTO_HIP(hipMemcpy(hst, prof_buf, sizeof(hst), hipMemcpyDeviceToHost));
-        fprintf(stderr, "k_cvt_block<%d,%d,%d,%d,%d,%d> stamps:", C, W, WKV, TS, CIN, int(HEAD));
+        fprintf(stderr, "k_cvt_block<%d,%d,%d,%d,%d,%d> x%d stamps:", C, W, WKV, TS, CIN, int(HEAD), nblk);
         for (int i = 1; i < 256 && hst[i]; ++i) fprintf(stderr, " %lld", hst[i] - hst[i - 1]);
         fprintf(stderr, "\n");
     }
@@ -315,13 +324,13 @@ int launch_cvt_block(hipStream_t s, float* h, const BlockDev& b, int heads, int6
 // The instantiated geometries: (C, W, WKV) -> sites per workgroup and the stage-input channel count whose embedding
 // can run inside the stage's first block.
 template <int C, int W, int WKV, int TS, int CIN>
-int dispatch_block(hipStream_t s, float* h, const BlockDev& b, int heads, int64_t B, const BlockExtra& ex, bool embed, bool head) {
+int dispatch_block(hipStream_t s, float* h, const BlockDev* blocks, int nblk, int heads, int64_t B, const BlockExtra& ex, bool embed, bool head) {
     if constexpr (C == 128 && CvtBlockGeom<C, W, WKV, TS>::HEAD_OK) {
-        if (head) return embed ? launch_cvt_block<C, W, WKV, TS, CIN, true>(s, h, b, heads, B, ex)
-                               : launch_cvt_block<C, W, WKV, TS, 0, true>(s, h, b, heads, B, ex);
+        if (head) return embed ? launch_cvt_block<C, W, WKV, TS, CIN, true>(s, h, blocks, nblk, heads, B, ex)
+                               : launch_cvt_block<C, W, WKV, TS, 0, true>(s, h, blocks, nblk, heads, B, ex);
     }
-    return embed ? launch_cvt_block<C, W, WKV, TS, CIN, false>(s, h, b, heads, B, ex)
-                 : launch_cvt_block<C, W, WKV, TS, 0, false>(s, h, b, heads, B, ex);
+    return embed ? launch_cvt_block<C, W, WKV, TS, CIN, false>(s, h, blocks, nblk, heads, B, ex)
+                 : launch_cvt_block<C, W, WKV, TS, 0, false>(s, h, blocks, nblk, heads, B, ex);
 }
 // Sites per workgroup of the stage-1 / stage-2 blocks.  What they trade is LDS per workgroup (q / k / v tiles dominate) against
 // workgroups resident per CU: the blocks of these stages do little matrix work per phase, so a second and third resident
@@ -342,14 +351,15 @@ const FusedGeom* fused_geom(const StageDev& st) {
 bool can_fuse_embed(const StageDev& st) { const FusedGeom* g = fused_geom(st); return g && g->cin == st.cin && st.wembp; }
 bool can_fuse_head(const StageDev& st, const HeadDev& hd) { const FusedGeom* g = fused_geom(st); return g && g->ts == 16 && g->c == 128 && hd.w1p; }
 
-// fused transformer block when the stage geometry has an instantiation; returns 1 if it ran, 0 if not, < 0 on error
-int try_fused_block(hipStream_t s, const StageDev& st, const BlockDev& b, float* h, int64_t B, const BlockExtra& ex, bool embed,
-                    bool head) {
+// nblk consecutive fused transformer blocks of a stage in one launch, when the stage geometry has an instantiation; returns 1 if it
+// ran, 0 if not, < 0 on error
+int try_fused_blocks(hipStream_t s, const StageDev& st, const BlockDev* b, int nblk, float* h, int64_t B, const BlockExtra& ex, bool embed,
+                     bool head) {
     int rc = CTO_OK;
-    if (st.c == 128 && st.w == 5 && st.wkv == 3) rc = dispatch_block<128, 5, 3, 16, 64>(s, h, b, st.heads, B, ex, embed, head);
-    else if (st.c == 64 && st.w == 9 && st.wkv == 5) rc = dispatch_block<64, 9, 5, CTO_CVT_TS2, 16>(s, h, b, st.heads, B, ex, embed, head);
-    else if (st.c == 16 && st.w == 17 && st.wkv == 9) rc = dispatch_block<16, 17, 9, CTO_CVT_TS1, 34>(s, h, b, st.heads, B, ex, embed, head);
-    else if (st.c == 32 && st.w == 17 && st.wkv == 9) rc = dispatch_block<32, 17, 9, CTO_CVT_TS1, 34>(s, h, b, st.heads, B, ex, embed, head);
+    if (st.c == 128 && st.w == 5 && st.wkv == 3) rc = dispatch_block<128, 5, 3, 16, 64>(s, h, b, nblk, st.heads, B, ex, embed, head);
+    else if (st.c == 64 && st.w == 9 && st.wkv == 5) rc = dispatch_block<64, 9, 5, CTO_CVT_TS2, 16>(s, h, b, nblk, st.heads, B, ex, embed, head);
+    else if (st.c == 16 && st.w == 17 && st.wkv == 9) rc = dispatch_block<16, 17, 9, CTO_CVT_TS1, 34>(s, h, b, nblk, st.heads, B, ex, embed, head);
+    else if (st.c == 32 && st.w == 17 && st.wkv == 9) rc = dispatch_block<32, 17, 9, CTO_CVT_TS1, 34>(s, h, b, nblk, st.heads, B, ex, embed, head);
     else return 0;
     return rc == CTO_OK ? 1 : rc;
 }
@@ -372,17 +382,25 @@ int cvt_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStrea
             hipLaunchKernelGGL(k_layernorm, dim3(unsigned(cdiv(M, 4))), dim3(256), 0, s, m->b_t, hbuf, st.lng, st.lnb, M, C);
             CTO_HIP(hipGetLastError());
         }
+        // consecutive blocks of the stage share a launch (CTO_CVT_BLOCKS_PER_LAUNCH=1: one launch per block, as before round 3)
+        static const int group_max = [] {
+            const char* e = getenv("CTO_CVT_BLOCKS_PER_LAUNCH");
+            const int v = e ? atoi(e) : CVT_MAX_BLK;
+            return v < 1 ? 1 : (v > CVT_MAX_BLK ? CVT_MAX_BLK : v);
+        }();
         for (size_t bi = 0; bi < st.blocks.size(); ++bi) {
             const BlockDev& b = st.blocks[bi];
             if (m->fuse_blocks) {
                 BlockExtra ex;
+                const int nblk = int(std::min<size_t>(size_t(group_max), st.blocks.size() - bi));
                 const bool embed = embed_in_block && bi == 0;
-                const bool head = m->fuse_head && si == 2 && bi + 1 == st.blocks.size() && can_fuse_head(st, m->head);
+                const bool head = m->fuse_head && si == 2 && bi + size_t(nblk) == st.blocks.size() && can_fuse_head(st, m->head);
                 ex.xin = in; ex.st = &st; ex.head = &m->head; ex.logits = logits; ex.n_out = m->n_out;
-                const int fr = try_fused_block(s, st, b, hbuf, B, ex, embed, head);
+                const int fr = try_fused_blocks(s, st, &b, nblk, hbuf, B, ex, embed, head);
                 if (fr < 0) return fr;
                 if (fr == 1) {
                     if (head) return CTO_OK;
+                    bi += size_t(nblk) - 1;
                     continue;
                 }
             }

@@ -1,0 +1,764 @@
+// Reads -> columns on the device (BASELINE.json north_star: "stages per-site read pileups ... on the GPU"):
+// the column pack of cto_pack_from_bam, built in HBM from BGZF blocks that csrc/inflate.hip inflated there - the alignment
+// records never travel back to the host and no pack travels up.
+//
+// PARITY UNPINNED against samtools (absent from both boxes), like the host reader it restates (csrc/bam.cpp: the pileup rules are
+// listed in its header).  What IS held: every array of the pack equal to cto_pack_from_bam's, bit for bit, on every BAM the test
+// suite writes (tests/test_gpu_pileup.py) - the host reader is the specification of this file.
+//
+// Pipeline (one chunk = one call, all kernels on the caller's stream):
+//   k_linearise     the inflated blocks (256-byte aligned output slots) -> one contiguous record stream
+//   k_chain         record boundaries: every virtual offset the .bai names (chunk starts, the linear index's 16 kb windows) is the
+//                   head of a chain of `block_size` hops walked by one lane; counted, then written in file order
+//   k_parse         one lane per record: header filters (reference id, excluded flags, MAPQ, orphan), CIGAR lengths (CG:B,I for
+//                   > 65535 operations), the region test; the first record that ends the region's scan cuts the list
+//   k_compact       accepted reads in file order
+//   k_cover         +1 / -1 per read at the first / one-past-last REQUESTED position it covers (the BED intervals of the
+//                   candidate windows, concatenated: a read covers a contiguous run of that space)
+//   k_columns       one workgroup: running sum -> depth per requested position, rows only where depth > 0, entry offsets
+//   k_fill          one wave per read, one lane per CIGAR operation (prefix sums over 64 operations at a time give every lane
+//                   its reference / query offsets): read-bases, deletion placeholders and the indel attached to the last base
+//                   of an aligned run go to their column through an atomic cursor, tagged with the read's rank in file order
+//   k_order         one wave per column: the column's entries back into file order (rank by counting in LDS), the distinct
+//                   indel keys in first-seen order (candidates compared against the column's keys across lanes), merged
+//                   candidate-extraction groups
+//   k_keys_*        key tables and the alt_info key strings ("I<ANCHOR><SEQ>", "D<reference slice>")
+// Two round trips to the host are needed (sizes for allocation): after k_columns and after the per-column key counts.
+//
+// Not done here - the call reports `fallback` and the caller uses the host reader: paired reads (mate-overlap quality edits are
+// order dependent), reference skips (N), more reads than --max-depth in the region (the cap is order dependent too), a column
+// deeper than 2048, with more than 256 indel-carrying reads or more than 64 distinct indel keys.  The BGZF CRC-32 is not verified on this path (the host reader
+// checks it as htslib does); the inflate kernel's own checks (stream structure, ISIZE) still apply.
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+#include "common.h"
+#include "pack_internal.h"
+
+using namespace cto;
+
+namespace {
+
+struct DevRead {
+    uint32_t off;                 // of the record (its block_size field) in the linear stream
+    int32_t pos, end;             // 0-based, end exclusive
+    uint32_t ops_off;             // CIGAR operations (the field or the CG tag)
+    int32_t n_ops;
+    uint32_t seq_off, qual_off;
+    int32_t l_seq;
+    uint8_t mapq, rev, no_qual, valid;
+};
+
+struct TmpEnt { uint32_t entry, rank, ind_q, ind; };      // ind = len << 2 | kind (0 none, 1 ins, 2 del)
+struct KeyRec { uint32_t read, q, len; uint8_t code, kind, overlong, group; };
+
+struct Flags {                    // written by the kernels, read by the host after each phase
+    int stop_idx, err_idx, paired_idx, skip_idx;    // first record index with the condition (INT_MAX: none)
+    int bad_chain, deep_col, many_keys, ref_oob;
+    int n_rec, n_valid, n_cols, n_keys;
+    long long n_entries, key_str_bytes;
+};
+
+__device__ __forceinline__ uint32_t ld16(const uint8_t* p) { return uint32_t(p[0]) | (uint32_t(p[1]) << 8); }
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return uint32_t(p[0]) | (uint32_t(p[1]) << 8) | (uint32_t(p[2]) << 16) | (uint32_t(p[3]) << 24); }
+
+__global__ void k_linearise(const uint8_t* __restrict__ src, const cto_bgzf_block* __restrict__ blocks, const int64_t* __restrict__ lin_off,
+                            uint8_t* __restrict__ lin) {
+    const cto_bgzf_block b = blocks[blockIdx.x];
+    const uint8_t* s = src + b.out_off;
+    uint8_t* d = lin + lin_off[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < b.isize; i += blockDim.x) d[i] = s[i];
+}
+
+// chain k walks the records from starts[k] to starts[k + 1]; mode 0 counts, mode 1 writes their offsets at base[k]..
+__global__ void k_chain(const uint8_t* __restrict__ lin, int64_t len, const int64_t* __restrict__ starts, int n_chains, int mode,
+                        int* __restrict__ counts, const int* __restrict__ base, uint32_t* __restrict__ rec_off, Flags* fl) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_chains) return;
+    int64_t o = starts[k];
+    const int64_t limit = starts[k + 1];
+    int n = 0;
+    while (o < limit && o + 4 <= len) {
+        const int64_t bsz = int64_t(int32_t(ld32(lin + o)));
+        if (bsz < 32) { atomicExch(&fl->bad_chain, 2); break; }
+        if (o + 4 + bsz > len) break;                         // the span ends inside a record the region does not need
+        if (mode) rec_off[base[k] + n] = uint32_t(o);
+        ++n;
+        o += 4 + bsz;
+    }
+    if (o > limit) atomicExch(&fl->bad_chain, 1);              // a named offset that is not a record boundary
+    if (!mode) counts[k] = n;
+}
+
+// exclusive prefix sums of a short int array by one workgroup (chains, per-column key counts, key string lengths)
+template <typename Out>
+__global__ void k_scan_small(const int* __restrict__ in, Out* __restrict__ out, int n, Out* total) {
+    __shared__ long long part[1024];
+    const int t = threadIdx.x, per = (n + blockDim.x - 1) / blockDim.x;
+    const int lo = min(n, t * per), hi = min(n, lo + per);
+    long long s = 0;
+    for (int i = lo; i < hi; ++i) s += in[i];
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < int(blockDim.x); d <<= 1) {
+        const long long v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    long long run = part[t] - s;
+    for (int i = lo; i < hi; ++i) { out[i] = Out(run); run += in[i]; }
+    if (t == int(blockDim.x) - 1) { out[n] = Out(part[t]); if (total) *total = Out(part[t]); }
+}
+
+__global__ void k_parse(const uint8_t* __restrict__ lin, const uint32_t* __restrict__ rec_off, int n_rec, int tid, int beg0, int end0,
+                        int excl_flags, int min_mq, DevRead* __restrict__ reads, Flags* fl) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec) return;
+    DevRead r{};
+    r.off = rec_off[i];
+    const uint8_t* b = lin + r.off + 4;
+    const int64_t bsz = int64_t(int32_t(ld32(lin + r.off)));
+    const int rtid = int(ld32(b)), pos = int(ld32(b + 4));
+    const int l_name = b[8], mapq = b[9];
+    const int n_cig = int(ld16(b + 12)), flag = int(ld16(b + 14));
+    const int l_seq = int(ld32(b + 16));
+    bool stop = false, ok = false;
+    if (rtid != tid) stop = rtid > tid || rtid < 0;
+    else if (pos >= end0) stop = true;
+    else if (!((flag & excl_flags) || (flag & 4) || mapq < min_mq || n_cig == 0 || l_seq <= 0 || pos < 0 || ((flag & 1) && !(flag & 2)))) ok = true;
+    if (stop) atomicMin(&fl->stop_idx, i);
+    if (ok) {
+        const int64_t need = 32 + int64_t(l_name) + int64_t(n_cig) * 4 + int64_t((l_seq + 1) / 2) + int64_t(l_seq);
+        if (need > bsz) { atomicMin(&fl->err_idx, i); ok = false; }
+    }
+    if (ok) {
+        const uint8_t* cg = b + 32 + l_name;
+        const uint8_t* sq = cg + size_t(n_cig) * 4;
+        const uint8_t* ql = sq + (l_seq + 1) / 2;
+        int n_ops = n_cig;
+        const uint8_t* ops = cg;
+        if (n_cig == 2 && (ld32(cg) & 15) == 4 && int(ld32(cg) >> 4) == l_seq && (ld32(cg + 4) & 15) == 3) {     // CG:B,I holds the real CIGAR
+            const uint8_t* aux = ql + l_seq;
+            const uint8_t* aend = b + bsz;
+            while (aux + 3 <= aend) {
+                const char t0 = char(aux[0]), t1 = char(aux[1]), ty = char(aux[2]);
+                aux += 3;
+                size_t skip = 0;
+                if (ty == 'A' || ty == 'c' || ty == 'C') skip = 1;
+                else if (ty == 's' || ty == 'S') skip = 2;
+                else if (ty == 'i' || ty == 'I' || ty == 'f') skip = 4;
+                else if (ty == 'Z' || ty == 'H') { while (aux + skip < aend && aux[skip]) ++skip; ++skip; }
+                else if (ty == 'B') {
+                    if (aux + 5 > aend) break;
+                    const char sub = char(aux[0]);
+                    const uint32_t cnt = ld32(aux + 1);
+                    const size_t esz = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                    if (t0 == 'C' && t1 == 'G' && sub == 'I' && aux + 5 + size_t(cnt) * 4 <= aend) { n_ops = int(cnt); ops = aux + 5; break; }
+                    skip = 5 + size_t(cnt) * esz;
+                } else break;
+                aux += skip;
+            }
+        }
+        long long rlen = 0, qlen = 0;
+        bool has_skip = false;
+        for (int k = 0; k < n_ops; ++k) {
+            const uint32_t c = ld32(ops + size_t(k) * 4);
+            const int opc = int(c & 15), len = int(c >> 4);
+            if (opc == 0 || opc == 2 || opc == 3 || opc == 7 || opc == 8) rlen += len;
+            if (opc == 0 || opc == 1 || opc == 4 || opc == 7 || opc == 8) qlen += len;
+            has_skip |= opc == 3;
+        }
+        if (qlen != l_seq || rlen == 0) ok = false;
+        else if (int64_t(pos) + rlen > 0x7fffffffLL) { atomicMin(&fl->err_idx, i); ok = false; }
+        else if (pos + rlen <= beg0) ok = false;
+        if (ok) {
+            r.pos = pos;
+            r.end = int32_t(pos + rlen);
+            r.ops_off = uint32_t(ops - lin);
+            r.n_ops = n_ops;
+            r.seq_off = uint32_t(sq - lin);
+            r.qual_off = uint32_t(ql - lin);
+            r.l_seq = l_seq;
+            r.mapq = uint8_t(mapq);
+            r.rev = (flag & 16) != 0;
+            r.no_qual = ql[0] == 0xff;
+            r.valid = 1;
+            if (flag & 1) atomicMin(&fl->paired_idx, i);
+            if (has_skip) atomicMin(&fl->skip_idx, i);
+        }
+    }
+    reads[i] = r;
+}
+
+// accepted reads (in front of the record that ended the scan) in file order: rid[j] = record index
+__global__ void k_compact(const DevRead* __restrict__ reads, int n_rec, int* __restrict__ rid, Flags* fl) {
+    __shared__ int part[1024];
+    const int stop = fl->stop_idx;
+    const int n = min(n_rec, stop), t = threadIdx.x, per = (n + blockDim.x - 1) / blockDim.x;
+    const int lo = min(n, t * per), hi = min(n, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += reads[i].valid;
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < int(blockDim.x); d <<= 1) {
+        const int v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+    for (int i = lo; i < hi; ++i) if (reads[i].valid) rid[run++] = i;
+    if (t == int(blockDim.x) - 1) fl->n_valid = part[t];
+}
+
+// Requested positions: n_iv sorted, disjoint 0-based intervals [lo, hi) clipped to the region; slot space = their concatenation
+struct Ivs { const int* lo; const int* hi; const int* base; int n; int total; };
+__device__ __forceinline__ int first_slot_ge(const Ivs& v, int p) {    // slot of the first requested position >= p (total: none)
+    int a = 0, b = v.n;
+    while (a < b) { const int m = (a + b) >> 1; if (v.hi[m] > p) b = m; else a = m + 1; }
+    if (a >= v.n) return v.total;
+    return v.base[a] + (p > v.lo[a] ? p - v.lo[a] : 0);
+}
+
+__global__ void k_cover(const DevRead* __restrict__ reads, const int* __restrict__ rid, const Flags* fl, Ivs iv, int* __restrict__ diff) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= fl->n_valid) return;
+    const DevRead& r = reads[rid[j]];
+    const int a = first_slot_ge(iv, r.pos), b = first_slot_ge(iv, r.end);
+    if (b > a) { atomicAdd(&diff[a], 1); atomicAdd(&diff[b], -1); }
+}
+
+constexpr int ORD_DMAX_COLS = 2048;      // = ORD_DMAX of k_order
+// One workgroup: depth per slot (running sum of diff), rows where depth > 0 (slot_col, col_slot), col_off.
+__global__ void k_columns(const int* __restrict__ diff, int total, int* __restrict__ slot_col, int* __restrict__ col_slot,
+                          long long* __restrict__ col_off, Flags* fl) {
+    __shared__ long long pa[1024], pb[1024], pc[1024];
+    const int t = threadIdx.x, per = (total + blockDim.x - 1) / blockDim.x;
+    const int lo = min(total, t * per), hi = min(total, lo + per);
+    auto scan = [&](long long* p) {
+        __syncthreads();
+        for (int d = 1; d < int(blockDim.x); d <<= 1) {
+            const long long v = t >= d ? p[t - d] : 0;
+            __syncthreads();
+            p[t] += v;
+            __syncthreads();
+        }
+    };
+    long long s = 0;
+    for (int i = lo; i < hi; ++i) s += diff[i];
+    pa[t] = s;
+    scan(pa);
+    long long depth = pa[t] - s, nz = 0, ds = 0;
+    for (int i = lo; i < hi; ++i) { depth += diff[i]; nz += depth > 0; ds += depth; }
+    pb[t] = nz;
+    pc[t] = ds;
+    scan(pb);
+    scan(pc);
+    depth = pa[t] - s;
+    long long c = pb[t] - nz, o = pc[t] - ds;
+    bool deep = false;
+    for (int i = lo; i < hi; ++i) {
+        depth += diff[i];
+        if (depth > 0) { slot_col[i] = int(c); col_slot[c] = i; col_off[c] = o; ++c; o += depth; deep |= depth > ORD_DMAX_COLS; }
+        else slot_col[i] = -1;
+    }
+    if (deep) atomicExch(&fl->deep_col, 1);
+    if (t == int(blockDim.x) - 1) { fl->n_cols = int(pb[t]); fl->n_entries = pc[t]; col_off[pb[t]] = pc[t]; }
+}
+
+__global__ void k_col_meta(const int* __restrict__ col_slot, int n_cols, Ivs iv, const char* __restrict__ ref, long long ref_start, long long ref_len,
+                           int32_t* __restrict__ col_pos, uint8_t* __restrict__ col_ref, Flags* fl) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cols) return;
+    const int s = col_slot[c];
+    int a = 0, b = iv.n;
+    while (b - a > 1) { const int m = (a + b) >> 1; if (iv.base[m] <= s) a = m; else b = m; }
+    const long long pos1 = (long long)iv.lo[a] + (s - iv.base[a]) + 1, ri = pos1 - ref_start;
+    col_pos[c] = int32_t(pos1);
+    if (ri < 0 || ri >= ref_len) { atomicExch(&fl->ref_oob, 1); col_ref[c] = 0; return; }
+    char ch = ref[ri];
+    if (ch >= 'a' && ch <= 'z') ch = char(ch - 32);
+    const int code = ch == 'C' ? 1 : (ch == 'G' ? 2 : (ch == 'T' ? 3 : 0));
+    const bool acgt = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
+    col_ref[c] = uint8_t(code | (acgt ? 0 : 0x80));
+}
+
+__device__ __forceinline__ uint32_t dev_entry(int code, int bq, int mq) { return uint32_t(code) | (uint32_t(bq) << 6) | (uint32_t(mq) << 13); }
+__constant__ int8_t kNib[16] = {-1, 0, 1, 10, 2, 10, 10, 10, 3, 10, 10, 10, 10, 10, 10, 10};
+
+// One wave per accepted read, one lane per CIGAR operation (64 at a time).
+__global__ __launch_bounds__(256) void k_fill(const uint8_t* __restrict__ lin, const DevRead* __restrict__ reads, const int* __restrict__ rid,
+                                              const Flags* fl, Ivs iv, const int* __restrict__ slot_col, const long long* __restrict__ col_off,
+                                              int* __restrict__ cursor, TmpEnt* __restrict__ tmp, const char* __restrict__ ref, long long ref_start,
+                                              long long ref_len) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (j >= fl->n_valid) return;
+    const DevRead r = reads[rid[j]];
+    const uint8_t* ops = lin + r.ops_off;
+    const uint8_t* seq = lin + r.seq_off;
+    const uint8_t* qual = lin + r.qual_off;
+    const int mq = min(int(r.mapq), 93);
+    auto base4 = [&](int q) { return (seq[q >> 1] >> ((~q & 1) << 2)) & 15; };
+    auto bq = [&](int q) { return (r.no_qual || q >= r.l_seq) ? 0 : min(int(qual[q]), 93); };
+    int ref_carry = r.pos, q_carry = 0;
+    for (int k0 = 0; k0 < r.n_ops; k0 += 64) {
+        const int k = k0 + lane;
+        uint32_t c = 0;
+        if (k < r.n_ops) c = ld32(ops + size_t(k) * 4);
+        const int opc = int(c & 15), len = int(c >> 4);
+        const bool cons_ref = k < r.n_ops && (opc == 0 || opc == 2 || opc == 3 || opc == 7 || opc == 8);
+        const bool cons_q = k < r.n_ops && (opc == 0 || opc == 1 || opc == 4 || opc == 7 || opc == 8);
+        int rs = cons_ref ? len : 0, qs = cons_q ? len : 0;
+        const int rl = rs, ql = qs;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int a = __shfl_up(rs, d), b = __shfl_up(qs, d);
+            if (lane >= d) { rs += a; qs += b; }
+        }
+        const int op_ref = ref_carry + rs - rl, op_q = q_carry + qs - ql;
+        ref_carry += __shfl(rs, 63);
+        q_carry += __shfl(qs, 63);
+        if (k >= r.n_ops || !cons_ref || opc == 3) continue;
+        // requested positions inside [op_ref, op_ref + len)
+        int p = op_ref;
+        const int pend = op_ref + len;
+        int a = 0, b = iv.n;
+        while (a < b) { const int m = (a + b) >> 1; if (iv.hi[m] > p) b = m; else a = m + 1; }
+        int kiv = a;
+        const bool aligned = opc != 2;
+        // the indel that follows this aligned run (P operations skipped)
+        uint32_t ind = 0, ind_q = 0;
+        if (aligned) {
+            int nx = k + 1;
+            while (nx < r.n_ops && (ld32(ops + size_t(nx) * 4) & 15) == 6) ++nx;
+            if (nx < r.n_ops) {
+                const uint32_t nc = ld32(ops + size_t(nx) * 4);
+                const int nop = int(nc & 15), nlen = int(nc >> 4);
+                if (nop == 1) { ind = (uint32_t(nlen) << 2) | 1u; ind_q = uint32_t(op_q + len); }
+                else if (nop == 2) ind = (uint32_t(nlen) << 2) | 2u;
+            }
+        }
+        while (p < pend && kiv < iv.n) {
+            if (p < iv.lo[kiv]) { p = iv.lo[kiv]; continue; }
+            if (p >= iv.hi[kiv]) { ++kiv; continue; }
+            const int stop = min(pend, iv.hi[kiv]);
+            for (; p < stop; ++p) {
+                const int col = slot_col[iv.base[kiv] + (p - iv.lo[kiv])];
+                TmpEnt e;
+                e.rank = uint32_t(j);
+                e.ind = 0;
+                e.ind_q = 0;
+                if (!aligned) {
+                    e.entry = dev_entry(r.rev ? 9 : 8, bq(op_q), mq);
+                } else {
+                    const int q = op_q + (p - op_ref);
+                    int code = kNib[base4(q)];
+                    if (code < 0) {
+                        const long long ri = (long long)p + 1 - ref_start;
+                        char ch = (ri >= 0 && ri < ref_len) ? ref[ri] : 'N';
+                        if (ch >= 'a' && ch <= 'z') ch = char(ch - 32);
+                        code = ch == 'A' ? 0 : (ch == 'C' ? 1 : (ch == 'G' ? 2 : (ch == 'T' ? 3 : 10)));
+                    }
+                    if (r.rev) code += code < 4 ? 4 : 1;
+                    e.entry = dev_entry(code, bq(q), mq);
+                    if (p == pend - 1) { e.ind = ind; e.ind_q = ind_q; }
+                }
+                const long long at = col_off[col] + atomicAdd(&cursor[col], 1);
+                tmp[at] = e;
+            }
+        }
+    }
+}
+
+constexpr int ORD_DMAX = 2048, ORD_KMAX = 64, ORD_IMAX = 256;
+
+__device__ __forceinline__ int canon_nib(const uint8_t* seq, int q) {
+    const int n = (seq[q >> 1] >> ((~q & 1) << 2)) & 15;
+    return n == 0 ? 15 : n;                       // '=' prints as N, like nibble 15
+}
+
+struct IndEnt { uint32_t at, entry, rank, ind_q, ind; };     // at = the entry's place in the column once it is in file order
+
+// One wave per column (workgroup = one wave): file order, indel keys in first-seen order, merged groups.
+__global__ __launch_bounds__(64) void k_order(const uint8_t* __restrict__ lin, const DevRead* __restrict__ reads, const int* __restrict__ rid,
+                                              int n_cols, const long long* __restrict__ col_off, const TmpEnt* __restrict__ tmp,
+                                              uint32_t* __restrict__ entries, int* __restrict__ n_keys_col, KeyRec* __restrict__ keyrec, int max_indel,
+                                              Flags* fl) {
+    __shared__ uint32_t ranks[ORD_DMAX];
+    __shared__ IndEnt ind_a[ORD_IMAX], ind_b[ORD_IMAX];
+    __shared__ KeyRec keys[ORD_KMAX];
+    __shared__ int grp_key[ORD_KMAX];             // group g is represented by the key that opened it
+    __shared__ int n_ind_s;
+    const int lane = threadIdx.x;
+    for (int c = blockIdx.x; c < n_cols; c += gridDim.x) {
+        const long long o = col_off[c];
+        const int d = int(col_off[c + 1] - o);
+        if (d > ORD_DMAX) { if (lane == 0) n_keys_col[c] = 0; continue; }      // flagged by k_columns: the caller falls back
+        __syncthreads();
+        if (lane == 0) n_ind_s = 0;
+        for (int i = lane; i < d; i += 64) ranks[i] = tmp[o + i].rank;
+        __syncthreads();
+        // every entry to its place in file order (rank by counting: a read has one entry per column); indel carriers are listed
+        for (int i = lane; i < d; i += 64) {
+            const TmpEnt e = tmp[o + i];
+            int at = 0;
+            for (int t = 0; t < d; ++t) at += ranks[t] < e.rank;
+            entries[o + at] = e.entry;
+            if (e.ind & 3u) {
+                const int slot = atomicAdd(&n_ind_s, 1);
+                if (slot < ORD_IMAX) ind_a[slot] = IndEnt{uint32_t(at), e.entry, e.rank, e.ind_q, e.ind};
+            }
+        }
+        __syncthreads();
+        const int n_ind = n_ind_s;
+        if (n_ind > ORD_IMAX) { if (lane == 0) { atomicExch(&fl->many_keys, 1); n_keys_col[c] = 0; } continue; }
+        for (int i = lane; i < n_ind; i += 64) {
+            const IndEnt e = ind_a[i];
+            int at = 0;
+            for (int t = 0; t < n_ind; ++t) at += ind_a[t].at < e.at;
+            ind_b[at] = e;
+        }
+        __syncthreads();
+        int nk = 0, ng = 0;
+        bool over = false;
+        for (int x = 0; x < n_ind && !over; ++x) {
+            const IndEnt cand = ind_b[x];                                      // the same for every lane
+            const int kind = int(cand.ind & 3u), len = int(cand.ind >> 2), code = int(cand.entry & 15u);
+            const uint8_t* cseq = lin + reads[rid[cand.rank]].seq_off;
+            bool hit = false;
+            if (lane < nk) {                                                   // lane k compares the candidate with key k
+                const KeyRec kr = keys[lane];
+                if (int(kr.code) == code && int(kr.kind) == kind && int(kr.len) == len) {
+                    hit = true;
+                    if (kind == 1) {
+                        const uint8_t* kseq = lin + reads[rid[kr.read]].seq_off;
+                        for (int t = 0; t < len; ++t)
+                            if (canon_nib(kseq, int(kr.q) + t) != canon_nib(cseq, int(cand.ind_q) + t)) { hit = false; break; }
+                    }
+                }
+            }
+            const unsigned long long hm = __ballot(hit);
+            int kid;
+            if (hm) {
+                kid = __ffsll((long long)hm) - 1;
+            } else {
+                if (nk >= ORD_KMAX) { over = true; break; }
+                kid = nk;
+                // merged group for candidate extraction: insertions by upper-cased anchor + sequence, deletions by length
+                const char anchor_c = "ACGTACGT*#NN"[code];
+                bool ghit = false;
+                if (lane < ng) {
+                    const KeyRec gr = keys[grp_key[lane]];
+                    if (int(gr.kind) == kind && int(gr.len) == len) {
+                        if (kind == 2) ghit = true;
+                        else if ("ACGTACGT*#NN"[gr.code] == anchor_c) {
+                            ghit = true;
+                            const uint8_t* gseq = lin + reads[rid[gr.read]].seq_off;
+                            for (int t = 0; t < len; ++t)
+                                if (canon_nib(gseq, int(gr.q) + t) != canon_nib(cseq, int(cand.ind_q) + t)) { ghit = false; break; }
+                        }
+                    }
+                }
+                const unsigned long long gm = __ballot(ghit);
+                const int g = gm ? __ffsll((long long)gm) - 1 : ng;
+                if (lane == 0) {
+                    const int gate = kind == 1 ? len : len + 1;
+                    keys[nk] = KeyRec{cand.rank, cand.ind_q, uint32_t(len), uint8_t(code), uint8_t(kind), uint8_t(gate > max_indel), uint8_t(g)};
+                    if (!gm) grp_key[ng] = nk;
+                }
+                if (!gm) ++ng;
+                ++nk;
+                __syncthreads();
+            }
+            if (lane == 0) {
+                const int gate = kind == 1 ? len : len + 1;
+                entries[o + cand.at] = cand.entry | (uint32_t(gate > max_indel ? 3 : kind) << 4) | (uint32_t(kid) << 21);
+            }
+        }
+        if (over) { if (lane == 0) { atomicExch(&fl->many_keys, 1); n_keys_col[c] = 0; } continue; }
+        __syncthreads();
+        if (lane == 0) n_keys_col[c] = nk;
+        for (int k = lane; k < nk; k += 64) keyrec[o + k] = keys[k];          // nk <= d: the column's own slots
+    }
+}
+
+// key tables in column order + the length of every alt_info key string
+__global__ void k_keys_meta(int n_cols, const long long* __restrict__ col_off, const int* __restrict__ key_off, const KeyRec* __restrict__ keyrec,
+                            const int32_t* __restrict__ col_pos, long long ref_start, long long ref_len, int max_indel, uint8_t* __restrict__ key_meta,
+                            int32_t* __restrict__ key_group, KeyRec* __restrict__ key_final, int* __restrict__ key_col, int* __restrict__ key_len) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cols) return;
+    const int k0 = key_off[c], nk = key_off[c + 1] - k0;
+    for (int k = 0; k < nk; ++k) {
+        const KeyRec kr = keyrec[col_off[c] + k];
+        const bool fwd = kr.code < 4 || kr.code == 8 || kr.code == 10;
+        key_meta[k0 + k] = uint8_t(kr.kind | (fwd ? 4 : 0) | (kr.overlong ? 8 : 0));
+        key_group[k0 + k] = kr.group;
+        key_final[k0 + k] = kr;
+        key_col[k0 + k] = c;
+        int sl;
+        if (kr.kind == 1) sl = 2 + int(kr.len);
+        else {
+            const long long ri = (long long)col_pos[c] - ref_start;
+            long long take = min((long long)kr.len + 1, (long long)max_indel);
+            take = min(take, ref_len - ri);
+            sl = 1 + int(take > 0 ? take : 0);
+        }
+        key_len[k0 + k] = sl;
+    }
+}
+
+__global__ void k_keys_str(int n_keys, const KeyRec* __restrict__ key_final, const int* __restrict__ key_col, const long long* __restrict__ str_off,
+                           const uint8_t* __restrict__ lin, const DevRead* __restrict__ reads, const int* __restrict__ rid,
+                           const int32_t* __restrict__ col_pos, const char* __restrict__ ref, long long ref_start, char* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_keys) return;
+    const KeyRec kr = key_final[k];
+    char* o = out + str_off[k];
+    const int n = int(str_off[k + 1] - str_off[k]);
+    static const char kAnchor[] = "ACGTACGT*#NN";
+    static const char kNt16[] = "NACMGRSVTWYHKDBN";          // upper case, '=' -> N
+    if (kr.kind == 1) {
+        o[0] = 'I';
+        o[1] = kAnchor[kr.code];
+        const uint8_t* seq = lin + reads[rid[kr.read]].seq_off;
+        for (int t = 0; t + 2 < n; ++t) { const int q = int(kr.q) + t; o[2 + t] = kNt16[(seq[q >> 1] >> ((~q & 1) << 2)) & 15]; }
+    } else {
+        o[0] = 'D';
+        const long long ri = (long long)col_pos[key_col[k]] - ref_start;
+        for (int t = 0; t + 1 < n; ++t) { char ch = ref[ri + t]; if (ch >= 'a' && ch <= 'z') ch = char(ch - 32); o[1 + t] = ch; }
+    }
+}
+
+struct Buf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return CTO_OK;
+        if (p) { CTO_HIP(hipFree(p)); p = nullptr; cap = 0; }
+        const size_t want = n + n / 4 + 4096;
+        CTO_HIP(hipMalloc(&p, want));
+        cap = want;
+        return CTO_OK;
+    }
+    ~Buf() { if (p) (void)hipFree(p); }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct cto_dev_pileup {
+    Buf lin, lin_off, blocks, starts, counts, base, rec_off, reads, rid, iv, diff, slot_col, col_slot, col_off, col_pos, col_ref, cursor, tmp,
+        entries, nkc, keyrec, key_off, key_meta, key_group, key_final, key_col, key_len, str_off, key_str, ref, flags;
+    Flags* h_flags = nullptr;            // page-locked mirror
+    ~cto_dev_pileup() { if (h_flags) (void)hipHostFree(h_flags); }
+};
+
+extern "C" int cto_dev_pileup_create(cto_dev_pileup** out) try {
+    CTO_REQUIRE(out, CTO_EINVAL, "cto_dev_pileup_create: null argument");
+    std::unique_ptr<cto_dev_pileup> c(new cto_dev_pileup());
+    CTO_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_flags), sizeof(Flags), hipHostMallocDefault));
+    *out = c.release();
+    return CTO_OK;
+}
+CTO_CATCH("cto_dev_pileup_create", int)
+
+extern "C" void cto_dev_pileup_destroy(cto_dev_pileup* c) { delete c; }
+
+// Record starts the index names inside the inflated span: chunk starts of the region's bins and the linear index's windows.
+extern "C" int64_t cto_bam_record_starts(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
+                                         int64_t file_begin, int64_t file_end, uint64_t* voffs, int64_t cap, int32_t* tid_out);
+
+extern "C" int cto_pileup_device(cto_dev_pileup* cx, const void* d_inflated, const cto_bgzf_block* h_blocks, int64_t n_blocks,
+                                 const uint64_t* rec_voffs, int64_t n_starts, int32_t tid, int64_t start, int64_t end, const int64_t* bed,
+                                 int64_t n_bed, const char* ref_seq, int64_t ref_start, size_t ref_len, int excl_flags, int min_mq,
+                                 int max_depth, int max_indel_length, void* stream, cto_pack_view* dev_view, cto_pack** host_lite,
+                                 int* fallback) try {
+    CTO_REQUIRE(cx && d_inflated && h_blocks && n_blocks > 0 && rec_voffs && n_starts > 0 && ref_seq && dev_view && host_lite && fallback,
+                CTO_EINVAL, "cto_pileup_device: bad argument");
+    CTO_REQUIRE(start >= 1 && end >= start && end < (int64_t(1) << 31), CTO_EINVAL, "cto_pileup_device: bad region");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    *fallback = 0;
+    *host_lite = nullptr;
+    // ---- host-side tables: block -> linear offset, record starts as linear offsets, requested intervals ----
+    std::vector<int64_t> lin_off(size_t(n_blocks) + 1, 0);
+    for (int64_t b = 0; b < n_blocks; ++b) lin_off[size_t(b) + 1] = lin_off[size_t(b)] + h_blocks[b].isize;
+    const int64_t len = lin_off[size_t(n_blocks)];
+    CTO_REQUIRE(len < (int64_t(1) << 32) - 65536, CTO_EUNSUPPORTED, "cto_pileup_device: more than 4 GiB of alignment records in one chunk");
+    std::vector<int64_t> starts;
+    for (int64_t i = 0; i < n_starts; ++i) {
+        const int64_t coff = int64_t(rec_voffs[i] >> 16), uoff = int64_t(rec_voffs[i] & 0xffff);
+        int64_t lo = 0, hi = n_blocks;
+        while (lo < hi) { const int64_t m = (lo + hi) / 2; if (int64_t(h_blocks[m].file_off) < coff) lo = m + 1; else hi = m; }
+        if (lo >= n_blocks || int64_t(h_blocks[lo].file_off) != coff || uoff > int64_t(h_blocks[lo].isize)) continue;     // outside the span
+        starts.push_back(lin_off[size_t(lo)] + uoff);
+    }
+    CTO_REQUIRE(!starts.empty(), CTO_EINVAL, "cto_pileup_device: no record start inside the inflated span");
+    std::sort(starts.begin(), starts.end());
+    starts.erase(std::unique(starts.begin(), starts.end()), starts.end());
+    const int n_chains = int(starts.size());
+    starts.push_back(len);
+    std::vector<int> ivs;                                        // lo[], hi[], base[] back to back
+    {
+        std::vector<std::pair<int64_t, int64_t>> v;
+        if (bed) for (int64_t i = 0; i < n_bed; ++i) v.push_back({std::max<int64_t>(bed[2 * i], start - 1), std::min<int64_t>(bed[2 * i + 1], end)});
+        else v.push_back({start - 1, end});
+        std::vector<int> lo, hi, base;
+        int64_t total = 0;
+        for (auto& p : v)
+            if (p.second > p.first) { lo.push_back(int(p.first)); hi.push_back(int(p.second)); base.push_back(int(total)); total += p.second - p.first; }
+        CTO_REQUIRE(total < (int64_t(1) << 30), CTO_EUNSUPPORTED, "cto_pileup_device: too many requested positions");
+        ivs = lo;
+        ivs.insert(ivs.end(), hi.begin(), hi.end());
+        ivs.insert(ivs.end(), base.begin(), base.end());
+        ivs.push_back(int(total));
+    }
+    const int n_iv = int((ivs.size() - 1) / 3), total = ivs.back();
+    Flags* hf = cx->h_flags;
+    auto fetch_flags = [&]() -> int {
+        CTO_HIP(hipMemcpyAsync(hf, cx->flags.p, sizeof(Flags), hipMemcpyDeviceToHost, s));
+        CTO_HIP(hipStreamSynchronize(s));
+        return CTO_OK;
+    };
+    auto empty_result = [&]() -> int {
+        std::unique_ptr<cto_pack> p(new cto_pack());
+        p->col_off.push_back(0);
+        p->key_off.push_back(0);
+        p->key_str_off.push_back(0);
+        memset(dev_view, 0, sizeof(*dev_view));
+        *host_lite = p.release();
+        return CTO_OK;
+    };
+    if (total == 0) return empty_result();
+    int rc;
+    if ((rc = cx->lin.ensure(size_t(len) + 64)) || (rc = cx->lin_off.ensure(lin_off.size() * 8)) || (rc = cx->blocks.ensure(size_t(n_blocks) * sizeof(cto_bgzf_block))) ||
+        (rc = cx->starts.ensure(starts.size() * 8)) || (rc = cx->counts.ensure(size_t(n_chains + 1) * 4)) || (rc = cx->base.ensure(size_t(n_chains + 2) * 4)) ||
+        (rc = cx->iv.ensure(ivs.size() * 4)) || (rc = cx->diff.ensure(size_t(total + 1) * 4)) || (rc = cx->slot_col.ensure(size_t(total) * 4)) ||
+        (rc = cx->col_slot.ensure(size_t(total) * 4)) || (rc = cx->col_off.ensure(size_t(total + 1) * 8)) || (rc = cx->ref.ensure(ref_len + 1)) ||
+        (rc = cx->flags.ensure(sizeof(Flags))))
+        return rc;
+    Flags init{};
+    init.stop_idx = init.err_idx = init.paired_idx = init.skip_idx = 0x7fffffff;
+    *hf = init;
+    CTO_HIP(hipMemcpyAsync(cx->flags.p, hf, sizeof(Flags), hipMemcpyHostToDevice, s));
+    CTO_HIP(hipMemcpyAsync(cx->lin_off.p, lin_off.data(), lin_off.size() * 8, hipMemcpyHostToDevice, s));
+    CTO_HIP(hipMemcpyAsync(cx->blocks.p, h_blocks, size_t(n_blocks) * sizeof(cto_bgzf_block), hipMemcpyHostToDevice, s));
+    CTO_HIP(hipMemcpyAsync(cx->starts.p, starts.data(), starts.size() * 8, hipMemcpyHostToDevice, s));
+    CTO_HIP(hipMemcpyAsync(cx->iv.p, ivs.data(), ivs.size() * 4, hipMemcpyHostToDevice, s));
+    CTO_HIP(hipMemcpyAsync(cx->ref.p, ref_seq, ref_len, hipMemcpyHostToDevice, s));
+    CTO_HIP(hipMemsetAsync(cx->diff.p, 0, size_t(total + 1) * 4, s));
+    Flags* fl = cx->flags.as<Flags>();
+    const uint8_t* lin = cx->lin.as<uint8_t>();
+    hipLaunchKernelGGL(k_linearise, dim3(unsigned(n_blocks)), dim3(256), 0, s, static_cast<const uint8_t*>(d_inflated), cx->blocks.as<cto_bgzf_block>(),
+                       cx->lin_off.as<int64_t>(), cx->lin.as<uint8_t>());
+    // ---- record boundaries ----
+    const unsigned cgrid = unsigned(cdiv(n_chains, 64));
+    hipLaunchKernelGGL(k_chain, dim3(cgrid), dim3(64), 0, s, lin, len, cx->starts.as<int64_t>(), n_chains, 0, cx->counts.as<int>(), nullptr, nullptr, fl);
+    hipLaunchKernelGGL(k_scan_small<int>, dim3(1), dim3(1024), 0, s, cx->counts.as<int>(), cx->base.as<int>(), n_chains, &fl->n_rec);
+    CTO_HIP(hipGetLastError());
+    if ((rc = fetch_flags())) return rc;
+    if (hf->bad_chain) {
+        set_error(hf->bad_chain == 2 ? "cto_pileup_device: bad alignment block size" : "cto_pileup_device: an index offset is not a record boundary");
+        return CTO_EINVAL;
+    }
+    const int n_rec = hf->n_rec;
+    if (n_rec == 0) return empty_result();
+    if ((rc = cx->rec_off.ensure(size_t(n_rec) * 4)) || (rc = cx->reads.ensure(size_t(n_rec) * sizeof(DevRead))) || (rc = cx->rid.ensure(size_t(n_rec) * 4))) return rc;
+    hipLaunchKernelGGL(k_chain, dim3(cgrid), dim3(64), 0, s, lin, len, cx->starts.as<int64_t>(), n_chains, 1, cx->counts.as<int>(), cx->base.as<int>(),
+                       cx->rec_off.as<uint32_t>(), fl);
+    hipLaunchKernelGGL(k_parse, dim3(unsigned(cdiv(n_rec, 128))), dim3(128), 0, s, lin, cx->rec_off.as<uint32_t>(), n_rec, tid, int(start - 1), int(end),
+                       excl_flags, min_mq, cx->reads.as<DevRead>(), fl);
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, cx->reads.as<DevRead>(), n_rec, cx->rid.as<int>(), fl);
+    Ivs iv{cx->iv.as<int>(), cx->iv.as<int>() + n_iv, cx->iv.as<int>() + 2 * n_iv, n_iv, total};
+    hipLaunchKernelGGL(k_cover, dim3(unsigned(cdiv(n_rec, 128))), dim3(128), 0, s, cx->reads.as<DevRead>(), cx->rid.as<int>(), fl, iv, cx->diff.as<int>());
+    hipLaunchKernelGGL(k_columns, dim3(1), dim3(1024), 0, s, cx->diff.as<int>(), total, cx->slot_col.as<int>(), cx->col_slot.as<int>(),
+                       cx->col_off.as<long long>(), fl);
+    CTO_HIP(hipGetLastError());
+    if ((rc = fetch_flags())) return rc;
+    const int lim = hf->stop_idx;
+    if (hf->err_idx < lim) { set_error("cto_pileup_device: alignment record shorter than its fields, or running past 2^31 - 1"); return CTO_EINVAL; }
+    if (hf->paired_idx < lim || hf->skip_idx < lim || hf->deep_col || (max_depth > 0 && hf->n_valid >= max_depth)) { *fallback = 1; return CTO_OK; }
+    const int n_cols = hf->n_cols;
+    const long long n_entries = hf->n_entries;
+    if (n_cols == 0) return empty_result();
+    if ((rc = cx->col_pos.ensure(size_t(n_cols) * 4)) || (rc = cx->col_ref.ensure(size_t(n_cols))) || (rc = cx->cursor.ensure(size_t(n_cols) * 4)) ||
+        (rc = cx->tmp.ensure(size_t(n_entries) * sizeof(TmpEnt))) || (rc = cx->entries.ensure(size_t(n_entries) * 4)) ||
+        (rc = cx->nkc.ensure(size_t(n_cols + 1) * 4)) || (rc = cx->keyrec.ensure(size_t(n_entries) * sizeof(KeyRec))) || (rc = cx->key_off.ensure(size_t(n_cols + 1) * 4)))
+        return rc;
+    CTO_HIP(hipMemsetAsync(cx->cursor.p, 0, size_t(n_cols) * 4, s));
+    const char* d_ref = cx->ref.as<char>();
+    hipLaunchKernelGGL(k_col_meta, dim3(unsigned(cdiv(n_cols, 256))), dim3(256), 0, s, cx->col_slot.as<int>(), n_cols, iv, d_ref, (long long)ref_start,
+                       (long long)ref_len, cx->col_pos.as<int32_t>(), cx->col_ref.as<uint8_t>(), fl);
+    hipLaunchKernelGGL(k_fill, dim3(unsigned(cdiv(hf->n_valid, 4))), dim3(256), 0, s, lin, cx->reads.as<DevRead>(), cx->rid.as<int>(), fl, iv,
+                       cx->slot_col.as<int>(), cx->col_off.as<long long>(), cx->cursor.as<int>(), cx->tmp.as<TmpEnt>(), d_ref, (long long)ref_start,
+                       (long long)ref_len);
+    hipLaunchKernelGGL(k_order, dim3(unsigned(std::min(n_cols, 16384))), dim3(64), 0, s, lin, cx->reads.as<DevRead>(), cx->rid.as<int>(), n_cols,
+                       cx->col_off.as<long long>(), cx->tmp.as<TmpEnt>(), cx->entries.as<uint32_t>(), cx->nkc.as<int>(), cx->keyrec.as<KeyRec>(),
+                       max_indel_length, fl);
+    hipLaunchKernelGGL(k_scan_small<int>, dim3(1), dim3(1024), 0, s, cx->nkc.as<int>(), cx->key_off.as<int>(), n_cols, &fl->n_keys);
+    CTO_HIP(hipGetLastError());
+    if ((rc = fetch_flags())) return rc;
+    if (hf->ref_oob) { set_error("cto_pileup_device: a covered position lies outside the supplied reference"); return CTO_EINVAL; }
+    if (hf->many_keys) { *fallback = 1; return CTO_OK; }
+    const int n_keys = hf->n_keys;
+    std::unique_ptr<cto_pack> lite(new cto_pack());
+    lite->col_pos.resize(size_t(n_cols));
+    lite->col_ref.resize(size_t(n_cols));
+    lite->key_off.resize(size_t(n_cols) + 1);
+    lite->col_off.assign(1, 0);
+    lite->key_str_off.assign(size_t(n_keys) + 1, 0);
+    if ((rc = cx->key_meta.ensure(16)) || (rc = cx->key_group.ensure(16))) return rc;      // valid pointers for a pack without keys
+    if (n_keys > 0) {
+        if ((rc = cx->key_meta.ensure(size_t(n_keys))) || (rc = cx->key_group.ensure(size_t(n_keys) * 4)) || (rc = cx->key_final.ensure(size_t(n_keys) * sizeof(KeyRec))) ||
+            (rc = cx->key_col.ensure(size_t(n_keys) * 4)) || (rc = cx->key_len.ensure(size_t(n_keys + 1) * 4)) || (rc = cx->str_off.ensure(size_t(n_keys + 1) * 8)))
+            return rc;
+        hipLaunchKernelGGL(k_keys_meta, dim3(unsigned(cdiv(n_cols, 256))), dim3(256), 0, s, n_cols, cx->col_off.as<long long>(), cx->key_off.as<int>(),
+                           cx->keyrec.as<KeyRec>(), cx->col_pos.as<int32_t>(), (long long)ref_start, (long long)ref_len, max_indel_length,
+                           cx->key_meta.as<uint8_t>(), cx->key_group.as<int32_t>(), cx->key_final.as<KeyRec>(), cx->key_col.as<int>(), cx->key_len.as<int>());
+        hipLaunchKernelGGL(k_scan_small<long long>, dim3(1), dim3(1024), 0, s, cx->key_len.as<int>(), cx->str_off.as<long long>(), n_keys, &fl->key_str_bytes);
+        CTO_HIP(hipGetLastError());
+        if ((rc = fetch_flags())) return rc;
+        const long long sb = hf->key_str_bytes;
+        if ((rc = cx->key_str.ensure(size_t(sb) + 16))) return rc;
+        hipLaunchKernelGGL(k_keys_str, dim3(unsigned(cdiv(n_keys, 128))), dim3(128), 0, s, n_keys, cx->key_final.as<KeyRec>(), cx->key_col.as<int>(),
+                           cx->str_off.as<long long>(), lin, cx->reads.as<DevRead>(), cx->rid.as<int>(), cx->col_pos.as<int32_t>(), d_ref,
+                           (long long)ref_start, cx->key_str.as<char>());
+        CTO_HIP(hipGetLastError());
+        lite->key_str.resize(size_t(sb));
+        lite->key_meta.resize(size_t(n_keys));
+        lite->key_group.resize(size_t(n_keys));
+        static_assert(sizeof(long long) == sizeof(int64_t), "");
+        CTO_HIP(hipMemcpyAsync(lite->key_str_off.data(), cx->str_off.p, size_t(n_keys + 1) * 8, hipMemcpyDeviceToHost, s));
+        if (sb) CTO_HIP(hipMemcpyAsync(&lite->key_str[0], cx->key_str.p, size_t(sb), hipMemcpyDeviceToHost, s));
+        CTO_HIP(hipMemcpyAsync(lite->key_meta.data(), cx->key_meta.p, size_t(n_keys), hipMemcpyDeviceToHost, s));
+        CTO_HIP(hipMemcpyAsync(lite->key_group.data(), cx->key_group.p, size_t(n_keys) * 4, hipMemcpyDeviceToHost, s));
+    }
+    CTO_HIP(hipMemcpyAsync(lite->col_pos.data(), cx->col_pos.p, size_t(n_cols) * 4, hipMemcpyDeviceToHost, s));
+    CTO_HIP(hipMemcpyAsync(lite->col_ref.data(), cx->col_ref.p, size_t(n_cols), hipMemcpyDeviceToHost, s));
+    CTO_HIP(hipMemcpyAsync(lite->key_off.data(), cx->key_off.p, size_t(n_cols + 1) * 4, hipMemcpyDeviceToHost, s));
+    CTO_HIP(hipStreamSynchronize(s));
+    dev_view->n_cols = n_cols;
+    dev_view->n_entries = n_entries;
+    dev_view->n_keys = n_keys;
+    dev_view->col_pos = cx->col_pos.as<int32_t>();
+    dev_view->col_ref = cx->col_ref.as<uint8_t>();
+    dev_view->col_off = cx->col_off.as<int64_t>();
+    dev_view->key_off = cx->key_off.as<int32_t>();
+    dev_view->entries = cx->entries.as<uint32_t>();
+    dev_view->key_meta = cx->key_meta.as<uint8_t>();
+    dev_view->key_group = cx->key_group.as<int32_t>();
+    *host_lite = lite.release();
+    return CTO_OK;
+}
+CTO_CATCH("cto_pileup_device", int)
+
+// test / tool aid: n bytes of device memory to the host (synchronous)
+extern "C" int cto_device_read(const void* d_src, void* h_dst, size_t n) {
+    CTO_REQUIRE((d_src && h_dst) || n == 0, CTO_EINVAL, "cto_device_read: null argument");
+    if (n) CTO_HIP(hipMemcpy(h_dst, d_src, n, hipMemcpyDeviceToHost));
+    return CTO_OK;
+}

@@ -137,6 +137,7 @@ struct Slot {
 // occupies its CUs for tens of milliseconds; unconfined, the networks' block kernels - which need a CU's whole register file -
 // wait for those waves to drain, confined they run on the other CUs.
 struct InflateCtx {
+    cto_dev_pileup* pile = nullptr;      // reads -> columns on the device (csrc/pileup.hip), created on first use
     int device = 0, cus = 0;
     hipStream_t stream = nullptr;
     hipEvent_t landed = nullptr;         // recorded behind the copy back; the producer thread sleeps on it (wait_event)
@@ -152,6 +153,7 @@ struct InflateCtx {
         return CTO_OK;
     }
     ~InflateCtx() {
+        if (pile) cto_dev_pileup_destroy(pile);
         if (landed) (void)hipEventDestroy(landed);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -397,7 +399,7 @@ struct Run {
     Mapped fasta;
     std::vector<std::unique_ptr<InflateCtx>> inflate_ctx;
     Queue<InflateCtx*> free_ctx;
-    std::atomic<int64_t> device_inflated{0};
+    std::atomic<int64_t> device_inflated{0}, device_piled{0};
     std::mutex fai_m;
     std::map<std::string, FaiRec> fai;
 
@@ -463,6 +465,66 @@ struct Run {
         if ((rc = cto_bgzf_inflate(c->d_in.p, reinterpret_cast<const cto_bgzf_block*>(static_cast<char*>(c->d_in.p) + in_al), int(n), c->d_out.p,
                                    reinterpret_cast<int*>(static_cast<char*>(c->d_out.p) + out_al), c->stream)))
             return rc;
+        if (cfg->device_pileup) {
+            // reads -> columns on the device: only the blocks' status words come back before the pile-up
+            CTO_HIP(hipMemcpyAsync(static_cast<char*>(c->h_out.p) + out_al, static_cast<char*>(c->d_out.p) + out_al, size_t(n) * 4, hipMemcpyDeviceToHost, c->stream));
+            CTO_HIP(hipEventRecord(c->landed, c->stream));
+            CTO_HIP(wait_event(c->landed));
+            const int* st0 = reinterpret_cast<const int*>(static_cast<char*>(c->h_out.p) + out_al);
+            for (int64_t b = 0; b < n; ++b)
+                CTO_REQUIRE(st0[b] == 0, CTO_EINVAL, "%s: the BGZF block at file offset %llu does not inflate (status %d)", j.bam_path,
+                            (unsigned long long)blocks[b].file_off, st0[b]);
+            if (!c->pile && (rc = cto_dev_pileup_create(&c->pile))) return rc;
+            std::vector<uint64_t> voffs(size_t(4096 + ((hi - lo) >> 14) + 64));
+            int32_t tid = -1;
+            const int64_t n_st = cto_bam_record_starts(j.bam_path, nullptr, ctg.c_str(), lo, hi, fb, fe, voffs.data(), int64_t(voffs.size()), &tid);
+            if (n_st < 0) return int(n_st);
+            int fallback = n_st == 0;
+            cto_pack_view dvw{};
+            cto_pack* lite = nullptr;
+            if (!fallback) {
+                rc = cto_pileup_device(c->pile, c->d_out.p, blocks, n, voffs.data(), n_st, tid, lo, hi, iv.empty() ? nullptr : iv.data(), int64_t(iv.size() / 2),
+                                       s->ref.data(), s->ref_start, s->ref.size(), 2316, 0, cfg->max_depth, cfg->max_indel_length, c->stream, &dvw, &lite, &fallback);
+                if (rc != CTO_OK) return rc;
+            }
+            if (!fallback) {
+                // the pack's arrays move from the context (re-used by the next chunk) into the slot's one device allocation, laid out
+                // as the upload path lays it out, + the candidate positions
+                const size_t nc = size_t(dvw.n_cols), ne = size_t(dvw.n_entries), nk = size_t(dvw.n_keys), ns = s->sites.size();
+                const void* src[8] = {dvw.entries, dvw.col_pos, dvw.col_ref, dvw.col_off, dvw.key_off, dvw.key_meta, dvw.key_group, s->sites.data()};
+                const size_t bytes[8] = {ne * 4, nc * 4, nc, (nc + 1) * 8, (nc + 1) * 4, nk, nk * 4, ns * 4};
+                size_t off[8], total = 0;
+                for (int i = 0; i < 8; ++i) { off[i] = total; total += (bytes[i] + 255) / 256 * 256 + 256; }
+                if ((rc = s->pack_dev.ensure(total)) != CTO_OK) { cto_pack_free(lite); return rc; }
+                char* d = static_cast<char*>(s->pack_dev.p);
+                for (int i = 0; i < 8; ++i)
+                    if (bytes[i] && nc)
+                        CTO_HIP(hipMemcpyAsync(d + off[i], src[i], bytes[i], i == 7 ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, c->stream));
+                if (s->pack) cto_pack_free(s->pack);
+                s->pack = lite;
+                s->hv = cto_pack_view{};
+                s->hv.n_cols = dvw.n_cols; s->hv.n_entries = dvw.n_entries; s->hv.n_keys = dvw.n_keys;
+                s->dv = s->hv;
+                s->dv.entries = reinterpret_cast<const uint32_t*>(d + off[0]);
+                s->dv.col_pos = reinterpret_cast<const int32_t*>(d + off[1]);
+                s->dv.col_ref = reinterpret_cast<const uint8_t*>(d + off[2]);
+                s->dv.col_off = reinterpret_cast<const int64_t*>(d + off[3]);
+                s->dv.key_off = reinterpret_cast<const int32_t*>(d + off[4]);
+                s->dv.key_meta = reinterpret_cast<const uint8_t*>(d + off[5]);
+                s->dv.key_group = reinterpret_cast<const int32_t*>(d + off[6]);
+                s->d_site_pos = reinterpret_cast<const int32_t*>(d + off[7]);
+                CTO_HIP(hipEventRecord(s->uploaded, c->stream));
+                CTO_HIP(hipEventRecord(c->landed, c->stream));
+                CTO_HIP(wait_event(c->landed));               // the context (and s->sites' bytes) are free for the next chunk
+                if (timing)
+                    fprintf(stderr, "device pile-up: %.1f MB in %lld blocks -> %lld columns, %lld entries: read %.1f ms, inflate + pile-up %.1f\n", nbytes / 1e6,
+                            (long long)n, (long long)dvw.n_cols, (long long)dvw.n_entries, (T1 - T0) * 1e3, (now_s() - T2) * 1e3);
+                *done = 2;
+                ++device_inflated;
+                ++device_piled;
+                return CTO_OK;
+            }
+        }
         CTO_HIP(hipMemcpyAsync(c->h_out.p, c->d_out.p, out_al + size_t(n) * 4, hipMemcpyDeviceToHost, c->stream));
         CTO_HIP(hipEventRecord(c->landed, c->stream));
         const double T3 = now_s();
@@ -510,6 +572,7 @@ struct Run {
         if (s->ref.empty()) { fail(std::string("[ERROR] Failed to load reference sequence from file (") + cfg->ref_fa + ")."); return false; }
         if (s->pack) { cto_pack_free(s->pack); s->pack = nullptr; }
         int rc = CTO_OK;
+        bool piled_on_device = false;
         const double t_pack = now_s();
         if (j.mpileup_path) {
             Mapped txt;
@@ -542,6 +605,7 @@ struct Run {
                 if (free_ctx.try_pop(&c)) {                        // a device-inflate context is free: this chunk's blocks go to the GPU
                     rc = pack_from_bam_device(j, ctg, lo, hi, iv, s, c, &done);
                     free_ctx.push(c);
+                    piled_on_device = rc == CTO_OK && done == 2;
                 }
                 if (!done && rc == CTO_OK)
                     rc = cto_pack_from_bam(j.bam_path, nullptr, ctg.c_str(), lo, hi, iv.empty() ? nullptr : iv.data(), int64_t(iv.size() / 2),
@@ -549,6 +613,11 @@ struct Run {
             }
         }
         if (rc != CTO_OK) { fail(cto_last_error()); return false; }
+        if (piled_on_device) {               // the pack is in the slot's device buffers already (pack_from_bam_device), s->uploaded recorded
+            std::lock_guard<std::mutex> g(stat_m);
+            pack_s += now_s() - t_pack;
+            return true;
+        }
         if (cto_pack_view_of(s->pack, &s->hv) != CTO_OK) { fail(cto_last_error()); return false; }
         // ---- upload ----
         const double t_up = now_s();
@@ -1018,7 +1087,10 @@ static int run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs, int64_t
         int n_cu = 256;
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
         run.round_sites = int64_t(16) * std::max(n_cu, 1);
-        run.max_pending = size_t(std::max(1, std::min(4, depth / 3)));      // chunks that may wait for rows: each holds a slot
+        // chunks that may wait for rows.  Each holds a slot, and a chunk only stops waiting when a LATER chunk is launched: with every
+        // slot waiting no producer could ever deliver that chunk, so at most depth - 1 wait (the launch that would make it `depth`
+        // takes everything that is pending instead)
+        run.max_pending = size_t(std::max(0, std::min(4, depth - 1)));
         (void)hipEventCreate(&run.flush_begin);
         (void)hipEventCreate(&run.flush_end);
     }
@@ -1095,6 +1167,7 @@ static int run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs, int64_t
         stats->upload_s = run.upload_s;
         stats->device_s = run.device_s;
         stats->device_inflated = run.device_inflated;
+        stats->device_piled = run.device_piled;
         stats->launch_s = launch_s;
         stats->launcher_wait_s = wait_s;
         stats->finish_s = run.finish_s;

@@ -126,6 +126,30 @@ int cto_pack_from_bam_inflated(const char* bam_path, const char* bai_path, const
                                int excl_flags, int min_mq, int max_depth, int max_indel_length,
                                const uint8_t* inflated, size_t inflated_len, const cto_bgzf_block* blocks, int64_t n_blocks,
                                cto_pack** out);
+/* Reads -> columns on the DEVICE (csrc/pileup.hip): the pack of cto_pack_from_bam built in HBM from the blocks cto_bgzf_inflate left
+ * there - the alignment records do not come back to the host and no pack goes up (BASELINE.json north_star: the per-site read pileups
+ * are staged on the GPU).  Sequence for one chunk: cto_bam_chunk_span, cto_bgzf_scan, copy up, cto_bgzf_inflate (as above), then
+ *   cto_bam_record_starts -> the record boundaries the .bai names inside the span (virtual offsets, ascending): chunk starts and the
+ *                            linear index's 16 kb windows; *tid = the contig's reference id
+ *   cto_pileup_device     -> *dev_view: the pack's arrays in device memory owned by `ctx` (valid until its next call);
+ *                            *host_lite: a host pack WITHOUT entries (col_pos, col_ref, key_off, key tables and the alt_info key
+ *                            strings - what cto_alt_info* read); the caller frees it with cto_pack_free.
+ *                            *fallback = 1 (CTO_OK, nothing built): the chunk holds what this path does not do - paired reads, reference
+ *                            skips (N), at least max_depth accepted reads, a column deeper than 2048 or with more than 64 distinct indel
+ *                            keys - use cto_pack_from_bam[_inflated].  h_blocks: the block table on the HOST.  Synchronises `stream`
+ *                            (sizes come back twice).  The BGZF CRC-32 is not checked on this path.  PARITY UNPINNED against samtools;
+ *                            held bit-equal to cto_pack_from_bam (tests/test_gpu_pileup.py). */
+typedef struct cto_dev_pileup cto_dev_pileup;
+int  cto_dev_pileup_create(cto_dev_pileup** out);
+void cto_dev_pileup_destroy(cto_dev_pileup* ctx);
+int64_t cto_bam_record_starts(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
+                              int64_t file_begin, int64_t file_end, uint64_t* voffs, int64_t cap, int32_t* tid);
+int cto_pileup_device(cto_dev_pileup* ctx, const void* d_inflated, const cto_bgzf_block* h_blocks, int64_t n_blocks,
+                      const uint64_t* rec_voffs, int64_t n_starts, int32_t tid, int64_t start, int64_t end, const int64_t* bed,
+                      int64_t n_bed, const char* ref_seq, int64_t ref_start, size_t ref_len, int excl_flags, int min_mq,
+                      int max_depth, int max_indel_length, void* stream, cto_pack_view* dev_view, cto_pack** host_lite, int* fallback);
+/* test / tool aid: n bytes of device memory to the host (synchronous hipMemcpy); no reference counterpart */
+int cto_device_read(const void* d_src, void* h_dst, size_t n);
 /* Build a pack from caller-made arrays (synthetic generators, BAM readers); key strings are the
  * alt_info keys ("IACG", "DACGT") concatenated, key_str_off[n_keys+1]. Arrays are copied. */
 int cto_pack_from_arrays(const cto_pack_view* host_view, const int64_t* key_str_off,
@@ -352,6 +376,9 @@ typedef struct cto_run_cfg {
     cto_model*    neg2;         /* alternate between two compute streams, and the next chunk's first round of workgroups fills the
                                    CUs this chunk's last round leaves idle (chunk sizes that are not a multiple of 4096 sites:
                                    the recurrent kernels put 32 sites on a CU)                                                  */
+    int    device_pileup;       /* BAM input with inflate_cus > 0: 1 = the chunks that go through the device inflate are piled up there
+                                   too (cto_pileup_device: the records stay in HBM, the pack is built in HBM); a chunk that path does
+                                   not take (paired reads, ...) is piled up on the host from the device-inflated blocks.  Same packs.  */
 } cto_run_cfg;
 typedef struct cto_run_stats {
     int64_t candidates;                                /* candidate positions read from the BED chunks           */
@@ -361,6 +388,7 @@ typedef struct cto_run_stats {
     double  launch_s, launcher_wait_s;                 /* the calling thread: launching, waiting for a producer */
     double  pack_s, upload_s;                          /* parts of produce_s: tokenising / BAM decoding, host-to-device copies */
     double  device_s;                                  /* HIP-event time from a chunk's first kernel to its last copy, summed    */
+    int64_t device_piled;                              /* chunks whose pack was built on the device (cto_pileup_device) */
     int64_t device_inflated;                           /* BAM chunks whose blocks were inflated on the device                    */
 } cto_run_stats;
 int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs, int64_t n_jobs, void* stream, cto_run_stats* stats);

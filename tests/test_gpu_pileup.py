@@ -1,0 +1,95 @@
+"""Reads -> columns on the device (csrc/pileup.hip): the pack built in HBM from device-inflated BGZF blocks must
+equal cto_pack_from_bam's, array for array and key string for key string, on BAM + BAI files written by tests/bamutil.py.
+PARITY UNPINNED against samtools (absent from both boxes); the host reader - itself held to an independent naive pileup and to
+hand-derived SAM-specification vectors - is this path's specification."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from bamutil import write_bam
+from test_bam_reader import _random_reads, _pack_arrays
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_arrays(pv, lite):
+    from clairs_to_amd._lib import lib, check
+
+    def grab(ptr, n, dt):
+        host = np.zeros(int(n), dtype=dt)
+        if n:
+            check(lib.cto_device_read(ptr, host.ctypes.data, host.nbytes))
+        return host
+    a = dict(col_pos=grab(pv.col_pos, pv.n_cols, np.int32), col_ref=grab(pv.col_ref, pv.n_cols, np.uint8),
+             col_off=grab(pv.col_off, pv.n_cols + 1, np.int64), key_off=grab(pv.key_off, pv.n_cols + 1, np.int32),
+             entries=grab(pv.entries, pv.n_entries, np.uint32), key_meta=grab(pv.key_meta, pv.n_keys, np.uint8),
+             key_group=grab(pv.key_group, pv.n_keys, np.int32))
+    keys = []
+    for k in range(pv.n_keys):
+        s = C.c_char_p()
+        n = lib.cto_pack_key_string(lite, k, C.byref(s))
+        keys.append(C.string_at(s, n).decode())
+    a["keys"] = keys
+    return a
+
+
+def _unpaired_reads(rng, n, ref_lens, skips=False):
+    reads = _random_reads(rng, n, ref_lens, paired_frac=0.0)
+    if not skips:
+        for r in reads:
+            r["cigar"] = [(("D" if op == "N" else op), ln) for op, ln in r["cigar"]]
+    return reads
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_device_pileup_equals_the_host_reader(tmp_path, seed):
+    import torch
+    from clairs_to_amd._lib import lib
+    from clairs_to_amd.bgzf import DevicePileup
+    from clairs_to_amd.pack import ColumnPack
+    rng = np.random.default_rng(seed)
+    ref_lens = [40000, 3000]
+    refs = [("chrA", ref_lens[0]), ("chrB", ref_lens[1])]
+    ref_seqs = ["".join(rng.choice(list("ACGTN"), p=[.24, .24, .24, .24, .04], size=L)) for L in ref_lens]
+    reads = _unpaired_reads(rng, 1500, ref_lens)
+    bam = str(tmp_path / "t.bam")
+    write_bam(bam, refs, reads, block_payload=1500 if seed != 3 else 60000)
+    cases = [(0, 1, ref_lens[0], None), (0, 5000, 9000, None), (0, 16380, 16400, None), (1, 1, ref_lens[1], None),
+             (1, 700, 2400, [(650, 720), (900, 934), (2000, 2500)]), (0, 39000, 40000, [(38990, 39010)]),
+             (0, 2000, 38000, [(k, k + 33) for k in range(2100, 37000, 211)])]
+    dp = DevicePileup()
+    dev = torch.device("cuda:0")
+    done = 0
+    for ref_i, start, end, bed in cases:
+        name = refs[ref_i][0]
+        want = _pack_arrays(ColumnPack.from_bam(bam, name, start, end, ref_seqs[ref_i], 1, bed=bed))
+        pv, lite, fallback = dp.pileup(bam, None, name, start, end, ref_seqs[ref_i], 1, dev, bed=bed)
+        assert not fallback
+        got = _device_arrays(pv, lite)
+        lib.cto_pack_free(lite)
+        for k in ("col_pos", "col_ref", "col_off", "key_off", "entries", "key_meta", "key_group"):
+            np.testing.assert_array_equal(got[k], want[k], err_msg="%s %s:%d-%d" % (k, name, start, end))
+        assert got["keys"] == want["keys"]
+        done += len(want["col_pos"]) > 0
+    assert done >= 6
+
+
+def test_device_pileup_reports_what_it_leaves_to_the_host(tmp_path):
+    """paired reads, reference skips and a region with max_depth or more reads come back as `fallback`, never as a different pack"""
+    import torch
+    from clairs_to_amd.bgzf import DevicePileup
+    rng = np.random.default_rng(7)
+    refs = [("chrA", 20000)]
+    ref = "".join(rng.choice(list("ACGT"), size=20000))
+    dev = torch.device("cuda:0")
+    dp = DevicePileup()
+    for kind in ("paired", "skips", "depth"):
+        reads = _random_reads(rng, 300, [20000], paired_frac=0.6 if kind == "paired" else 0.0)
+        if kind != "skips":
+            for r in reads:
+                r["cigar"] = [(("D" if op == "N" else op), ln) for op, ln in r["cigar"]]
+        bam = str(tmp_path / (kind + ".bam"))
+        write_bam(bam, refs, reads, block_payload=3000)
+        pv, lite, fallback = dp.pileup(bam, None, "chrA", 1, 20000, ref, 1, dev, max_depth=50 if kind == "depth" else 8000)
+        assert fallback, kind
