@@ -99,3 +99,48 @@ def test_passthrough_and_disabled_stage(tmp_path):
                   output_dir=str(tmp_path / "w2"), ctg_name="chr1", flanking=100, min_alt_coverage=2)
     haplotype_filter(a)
     assert os.path.islink(tmp_path / "link.vcf")
+
+
+def test_wide_fixture_both_reference_modes(tmp_path):
+    """tests/golden/hapfilter_wide.json.gz: the reference on 16 simulated contigs (> 500 calls, SNV + indel pass) in its chunk mode
+    AND in its default per-call mode (GNU parallel, one mpileup per call; src/haplotype_filtering.py:1038, 1140-1168) - the two
+    wrote the same files, and so does this build (which always works job-wise)."""
+    import sys
+    from argparse import Namespace
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import hapsim
+    import gen_hapfilter_wide as gw
+    from clairs_to_amd.haplotype_filtering import haplotype_filter
+    g = load_json_gz("hapfilter_wide.json.gz")
+    calls = tags = 0
+    seen = set()
+    for rec in g["contigs"]:
+        ctg = rec["name"]
+        sim = hapsim.simulate(seed=rec["seed"])
+        assert gw.digest(sim, ctg) == rec["inputs_sha256"], "the simulator changed: regenerate tests/golden/hapfilter_wide.json.gz"
+        d = tmp_path / ("c%d" % rec["seed"])
+        d.mkdir()
+        ref = sim["ref"]
+        (d / "ref.fa").write_text(">%s\n%s\n" % (ctg, ref))
+        (d / "ref.fa.fai").write_text("%s\t%d\t%d\t%d\t%d\n" % (ctg, len(ref), len(ctg) + 2, len(ref), len(ref) + 1))
+        (d / "germline.vcf").write_text(gw.germline_vcf(sim, ctg))
+        for mode in ("snv", "indel"):
+            assert rec[mode]["same_in_both_modes"]
+            vcf_text, mp_text = gw.inputs_for(sim, ctg, mode)
+            (d / ("pileup_%s.vcf" % mode)).write_text(vcf_text)
+            (d / ("mp_%s.txt" % mode)).write_text(mp_text)
+            out = d / ("out_%s.vcf" % mode)
+            haplotype_filter(Namespace(
+                tumor_bam_fn="unused.bam", ref_fn=str(d / "ref.fa"), ctg_name=ctg, pileup_vcf_fn=str(d / ("pileup_%s.vcf" % mode)),
+                output_vcf_fn=str(out), germline_vcf_fn=str(d / "germline.vcf"), output_dir=str(d / ("work_" + mode)), threads=4,
+                input_filter_tag=None, show_ref=False, samtools="samtools", mpileup_fn=str(d / ("mp_%s.txt" % mode)),
+                apply_haplotype_filtering=True, min_mq=20, min_bq=0, min_alt_coverage=2, is_indel=(mode == "indel"), test_pos=None,
+                flanking=100, haplotype_chunk_max_sites=200, haplotype_chunk_max_span=5000000, disable_read_start_end_filtering=False))
+            got = out.read_text()
+            assert got == rec[mode]["out_vcf"], (ctg, mode)
+            for r in got.split("\n"):
+                if r and r[0] != "#":
+                    calls += 1
+                    seen.update(r.split("\t")[6].split(";"))
+    assert len(g["contigs"]) >= 16 and calls >= 500
+    assert {"PASS", "LowAltBQ", "LowAltMQ", "ReadStartEnd", "VariantCluster", "NoAncestry", "MultiHap", "StrandBias", "LowSeqEntropy"} <= seen
