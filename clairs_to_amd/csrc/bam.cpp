@@ -20,12 +20,16 @@
 //   * N (reference skip) contributes nothing (samtools prints '>' / '<', which the reference's decoder ignores);
 //   * S / H / P consume as the specification says and contribute nothing;
 //   * MQ and BQ are capped at 93, the largest value mpileup's phred+33 characters can carry;
-//   * a read is dropped when `max_depth` reads are already active at its start (htslib's per-file maxcnt);
+//   * a read is dropped when `max_depth` reads are already active at its start (htslib's per-file maxcnt); the outcome does
+//     not depend on the number of decoding threads (a call whose ranges hit the cap is redone unsplit);
 //   * rows exist only for positions covered by >= 1 read-base or placeholder, inside [start, end] and inside the BED
 //     intervals when given.
 //   * read-pair overlaps (mpileup without -x, as the reference runs it): where both mates of a pair have an aligned base at a
 //     position, the first mate's base keeps min(200, qa + qb) when they agree and the better base keeps 0.8 x its quality
-//     when they differ; the other base's quality becomes 0 (soften_overlap below).  Paired-end short reads only.
+//     when they differ; the other base's quality becomes 0 (soften_overlap below).  Paired-end short reads only.  WHICH mate
+//     keeps the base when they agree is a second unpinned point (advisor, round 2): recent htslib releases may pick it per read
+//     name instead of always favouring the first - with no htslib on either box this cannot be settled here, so for paired-end
+//     input `samtools` stays the reference producer and `--bam_reader native|gpu` is offered for the long-read platforms.
 // Not implemented (documented deviations): BAQ (needs -f, which the reference does not pass), CRAM, multi-file input.
 //
 // I/O: the file is mapped; every BGZF block is inflated (libdeflate when the runtime library is present, else zlib) and checked
@@ -534,7 +538,8 @@ int read_header_tid(Bgzf& bz, const char* bam_path, const char* ctg_name, int* t
 
 int pack_from_bam_range(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
                         const int64_t* bed, int64_t n_bed, const char* ref_seq, int64_t ref_start, size_t ref_len,
-                        int excl_flags, int min_mq, int max_depth, int max_indel_length, const PreInflated& pre, cto_pack** out) {
+                        int excl_flags, int min_mq, int max_depth, int max_indel_length, const PreInflated& pre, cto_pack** out,
+                        bool* cap_hit = nullptr) {
     Bgzf bz;
     CTO_REQUIRE(bz.open(bam_path), CTO_EINVAL, "cto_pack_from_bam: %s", bz.err.c_str());
     bz.pre = pre;
@@ -701,7 +706,7 @@ int pack_from_bam_range(const char* bam_path, const char* bai_path, const char* 
             if (max_depth > 0) {
                 int live = 0;
                 for (const Read& a : active) live += a.end > pos;
-                if (live >= max_depth) continue;
+                if (live >= max_depth) { if (cap_hit) *cap_hit = true; continue; }
             }
             if ((flag & 1) && l_name > 1) {                    // paired: the mate may already be in the pileup
                 r.mate_key.assign(reinterpret_cast<const char*>(b + 32), size_t(l_name - 1));
@@ -738,7 +743,10 @@ int pack_from_bam_impl(const char* bam_path, const char* bai_path, const char* c
         CTO_REQUIRE(bed[2 * i] >= bed[2 * i - 1], CTO_EINVAL, "cto_pack_from_bam: bed intervals must be sorted and non-overlapping");
     // Position ranges are independent (every range re-queries the index for the reads that overlap it), so a chunk is cut into
     // ranges of equal numbers of requested positions and piled up on several host threads, like the text tokeniser.  The
-    // max_depth cap is evaluated per range (it only bites at depths the pack does not support anyway).
+    // --max-depth cap is order dependent (a read is dropped when max_depth reads are live at its start), and a range does not see
+    // the reads that ended before it: as long as NO range drops a read, no read is dropped in the unsplit order either (at a read's
+    // start every live read reaches into the range that holds that start, so its count there is exact); as soon as one does, the
+    // call is redone unsplit, so the pack never depends on how many threads the host happens to have.
     int64_t want = 0;                                       // requested positions inside [start, end]
     if (bed) {
         for (int64_t i = 0; i < n_bed; ++i) {
@@ -776,12 +784,16 @@ int pack_from_bam_impl(const char* bam_path, const char* bai_path, const char* c
     std::vector<std::unique_ptr<cto_pack>> parts(nt);
     std::vector<int> rcs(nt, CTO_OK);
     std::vector<std::string> errs(nt);
+    std::vector<char> capped(nt, 0);
     auto work = [&](unsigned t) {
         cto_pack* p = nullptr;
         if (cut[t + 1] - 1 < cut[t]) { parts[t].reset(new cto_pack()); pack_begin(parts[t].get(), 16, 16); return; }
         rcs[t] = guarded("cto_pack_from_bam", [&] {
-            return pack_from_bam_range(bam_path, bai_path, ctg_name, cut[t], cut[t + 1] - 1, bed, n_bed, ref_seq, ref_start, ref_len,
-                                       excl_flags, min_mq, max_depth, max_indel_length, pre, &p);
+            bool hit = false;
+            const int rc = pack_from_bam_range(bam_path, bai_path, ctg_name, cut[t], cut[t + 1] - 1, bed, n_bed, ref_seq, ref_start, ref_len,
+                                               excl_flags, min_mq, max_depth, max_indel_length, pre, &p, &hit);
+            capped[t] = hit;
+            return rc;
         });
         if (rcs[t] != CTO_OK) errs[t] = cto_last_error();
         parts[t].reset(p);
@@ -791,6 +803,12 @@ int pack_from_bam_impl(const char* bam_path, const char* bai_path, const char* c
         for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, t);
         for (auto& x : th) x.join();
     }
+    for (unsigned t = 0; t < nt; ++t)
+        if (capped[t]) {                                    // the cap bit somewhere: the unsplit order decides which reads go
+            parts.clear();
+            return pack_from_bam_range(bam_path, bai_path, ctg_name, start, end, bed, n_bed, ref_seq, ref_start, ref_len, excl_flags, min_mq,
+                                       max_depth, max_indel_length, pre, out);
+        }
     for (unsigned t = 0; t < nt; ++t)
         if (rcs[t] != CTO_OK) { set_error("%s", errs[t].c_str()); return rcs[t]; }
     std::string merr;

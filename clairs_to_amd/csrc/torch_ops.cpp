@@ -16,6 +16,7 @@
 #include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
+#include <hip/hip_runtime_api.h>
 
 #include <mutex>
 #include <tuple>
@@ -43,6 +44,9 @@ void check_x(const Tensor& x, const char* op) {
 // A handle (device-resident repacked weights + workspace) is built the first time a packed_weights tensor is seen and
 // reused while that tensor is alive and unmodified: the key is its storage (held weakly), data pointer, numel, version
 // counter, device and configuration.  An in-place update of the weights bumps the version and rebuilds the handle.
+// A handle's activation workspace belongs to one stream at a time (include/clairsto_amd.h): the operator may be called with the same
+// weights from several streams or threads, so every forward records an event behind its kernels and a forward on ANOTHER stream
+// waits for it first; the look-up and the launch happen under one lock (a launch is microseconds of host time).
 struct Entry {
     c10::weak_intrusive_ptr<c10::StorageImpl> storage;
     const void* ptr;
@@ -51,6 +55,9 @@ struct Entry {
     int device, kind;
     std::vector<int64_t> cfg;
     cto_model* model;
+    hipEvent_t done;            // behind the last forward's kernels
+    void* last_stream;
+    bool used;                  // last_stream is meaningful (the default stream is a null pointer)
 };
 std::mutex g_mu;
 std::vector<Entry> g_cache;
@@ -59,24 +66,29 @@ uint32_t version_of(const Tensor& t) {
     return t.is_inference() ? 0u : uint32_t(t.unsafeGetTensorImpl()->version_counter().current_version());
 }
 
-cto_model* model_for(const Tensor& packed, int kind, const std::vector<int64_t>& cfg, const char* op) {
+void drop(Entry& e) {
+    cto_model_destroy(e.model);
+    if (e.done) (void)hipEventDestroy(e.done);
+}
+
+// g_mu held by the caller
+Entry& model_for(const Tensor& packed, int kind, const std::vector<int64_t>& cfg, const char* op) {
     TORCH_CHECK(packed.is_cuda() && packed.scalar_type() == at::kFloat && packed.dim() == 1 && packed.is_contiguous(),
                 "clairsto::", op, ": packed_weights must be a contiguous 1-D float32 tensor on the HIP device");
-    std::lock_guard<std::mutex> lock(g_mu);
     const auto* st = packed.storage().unsafeGetStorageImpl();
     const uint32_t ver = version_of(packed);
     for (size_t i = 0; i < g_cache.size();) {
         Entry& e = g_cache[i];
         auto alive = e.storage.lock();
         if (!alive) {                                       // the weights tensor is gone: so is its handle
-            cto_model_destroy(e.model);
+            drop(e);
             g_cache.erase(g_cache.begin() + i);
             continue;
         }
         if (alive.get() == st && e.ptr == packed.data_ptr() && e.numel == packed.numel() && e.device == packed.get_device() &&
             e.kind == kind && e.cfg == cfg) {
-            if (e.version == ver) return e.model;
-            cto_model_destroy(e.model);                     // same tensor, modified in place
+            if (e.version == ver) return e;
+            drop(e);                                        // same tensor, modified in place
             g_cache.erase(g_cache.begin() + i);
             continue;
         }
@@ -93,9 +105,11 @@ cto_model* model_for(const Tensor& packed, int kind, const std::vector<int64_t>&
     } else {
         check_rc(cto_bigru_create_packed(host.data_ptr<float>(), host.numel(), int(cfg[0]), &m), op);
     }
+    hipEvent_t ev = nullptr;
+    TORCH_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "clairsto::", op, ": hipEventCreate failed");
     g_cache.push_back(Entry{c10::weak_intrusive_ptr<c10::StorageImpl>(packed.storage().getWeakStorageImpl()), packed.data_ptr(),
-                            packed.numel(), ver, int(packed.get_device()), kind, cfg, m});
-    return m;
+                            packed.numel(), ver, int(packed.get_device()), kind, cfg, m, ev, nullptr, false});
+    return g_cache.back();
 }
 
 Tensor run_model(const Tensor& x, const Tensor& packed, int kind, const std::vector<int64_t>& cfg, int64_t K, const char* op) {
@@ -105,8 +119,15 @@ Tensor run_model(const Tensor& x, const Tensor& packed, int kind, const std::vec
     const Tensor xc = x.contiguous();
     Tensor out = at::empty({K, xc.size(0), 2}, xc.options());
     if (xc.size(0) == 0) return out;
-    cto_model* m = model_for(packed, kind, cfg, op);
-    check_rc(cto_model_forward(m, xc.data_ptr<float>(), xc.size(0), out.data_ptr<float>(), stream_of(xc)), op);
+    std::lock_guard<std::mutex> lock(g_mu);
+    Entry& e = model_for(packed, kind, cfg, op);
+    void* s = stream_of(xc);
+    if (e.used && e.last_stream != s)       // the workspace's previous user ran on another stream: order behind it
+        TORCH_CHECK(hipStreamWaitEvent(static_cast<hipStream_t>(s), e.done, 0) == hipSuccess, "clairsto::", op, ": hipStreamWaitEvent failed");
+    check_rc(cto_model_forward(e.model, xc.data_ptr<float>(), xc.size(0), out.data_ptr<float>(), s), op);
+    TORCH_CHECK(hipEventRecord(e.done, static_cast<hipStream_t>(s)) == hipSuccess, "clairsto::", op, ": hipEventRecord failed");
+    e.last_stream = s;
+    e.used = true;
     return out;
 }
 

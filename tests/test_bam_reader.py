@@ -276,3 +276,35 @@ def test_chunk_span_is_tight_and_sufficient(tmp_path):
         assert want["entries"].size > 1000
         for k in want:
             np.testing.assert_array_equal(got[k], want[k], err_msg="%s %d-%d" % (k, lo, hi))
+
+
+def test_max_depth_cap_does_not_depend_on_the_thread_count(tmp_path):
+    """--max-depth is order dependent; a call cut over several decoding threads must give the pack of the unsplit order
+    (advisor finding, round 2: depths in (max_depth, 32767] used to depend on the host's core count)"""
+    from clairs_to_amd._lib import lib
+    from clairs_to_amd.pack import ColumnPack
+    rng = np.random.default_rng(21)
+    L = 30000
+    ref = "".join(rng.choice(list("ACGT"), size=L))
+    reads = []
+    for i in range(2500):                                   # ~80x over the contig, capped at 25
+        pos = int(rng.integers(0, L - 1200))
+        n = int(rng.integers(300, 1100))
+        reads.append(dict(name="r%d" % i, flag=16 * int(rng.random() < 0.5), ref=0, pos=pos, mapq=60, cigar=[("M", n)],
+                          seq="".join(rng.choice(list("ACGT"), size=n)), qual=[30] * n))
+    reads.sort(key=lambda r: r["pos"])
+    bam = str(tmp_path / "deep.bam")
+    write_bam(bam, [("chrA", L)], reads, block_payload=20000)
+    packs = []
+    for threads in (1, 2, 7):
+        lib.cto_set_pack_threads(threads)
+        try:
+            packs.append(_pack_arrays(ColumnPack.from_bam(bam, "chrA", 1, L, ref, 1, max_depth=25)))
+        finally:
+            lib.cto_set_pack_threads(0)
+    _assert_same(packs[0], packs[1])
+    _assert_same(packs[0], packs[2])
+    depth = np.diff(packs[0]["col_off"])
+    assert depth.max() <= 25 + 5 and (depth >= 25).sum() > 1000       # the cap really bit
+    text = mpileup_rows(reads, 0, "chrA", 1, L, max_depth=25, ref_seq=ref, ref_start=1)
+    _assert_same(packs[0], _pack_arrays(ColumnPack.from_mpileup(text, ref, 1)))
