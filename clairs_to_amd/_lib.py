@@ -72,6 +72,7 @@ SYMBOLS = {
     "cto_bam_chunk_span": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, c_i64, c_i64, C.POINTER(c_i64), C.POINTER(c_i64)]),
     "cto_bgzf_scan": (c_i64, [c_vp, C.c_size_t, c_i64, c_vp, c_i64, C.POINTER(c_i64)]),
     "cto_bgzf_inflate": (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp]),
+    "cto_bam_view": (c_i64, [C.c_char_p, C.c_char_p, C.c_char_p, c_i64, c_i64, C.c_int, c_vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "cto_dev_pileup_create": (C.c_int, [C.POINTER(c_vp)]),
     "cto_dev_pileup_destroy": (None, [c_vp]),
     "cto_bam_record_starts": (c_i64, [C.c_char_p, C.c_char_p, C.c_char_p, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, C.POINTER(c_i32)]),

@@ -900,6 +900,127 @@ extern "C" int cto_bam_chunk_span(const char* bam_path, const char* bai_path, co
     });
 }
 
+// `samtools view BAM ctg:start-end [-q min_mq]` without samtools: the alignments overlapping the region as SAM rows (no header),
+// QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL and, when the record has one, its HP:i tag - what
+// src/realign_reads.py:255-300 reads of every row.  Returns the number of rows; *need = bytes of text (CTO_ENOMEM when cap is less).
+extern "C" int64_t cto_bam_view(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end, int min_mq,
+                                char* buf, size_t cap, size_t* need) {
+    int64_t n_rows = 0;
+    const int rc = guarded("cto_bam_view", [&] {
+        CTO_REQUIRE(bam_path && ctg_name && need && (buf || cap == 0), CTO_EINVAL, "cto_bam_view: null argument");
+        CTO_REQUIRE(start >= 1 && end >= start, CTO_EINVAL, "cto_bam_view: bad region");
+        Bgzf bz;
+        CTO_REQUIRE(bz.open(bam_path), CTO_EINVAL, "cto_bam_view: %s", bz.err.c_str());
+        // header: reference names (RNEXT of a mate on another contig)
+        uint8_t h4[4];
+        CTO_REQUIRE(bz.read(h4, 4) && memcmp(h4, "BAM\1", 4) == 0, CTO_EINVAL, "cto_bam_view: %s is not a BAM file", bam_path);
+        CTO_REQUIRE(bz.read(h4, 4) && le32(h4) >= 0 && le32(h4) <= (1 << 28), CTO_EINVAL, "cto_bam_view: bad header");
+        { std::vector<uint8_t> text(size_t(le32(h4))); CTO_REQUIRE(text.empty() || bz.read(text.data(), text.size()), CTO_EINVAL, "cto_bam_view: truncated header"); }
+        CTO_REQUIRE(bz.read(h4, 4) && le32(h4) >= 0, CTO_EINVAL, "cto_bam_view: truncated header");
+        std::vector<std::string> names(size_t(le32(h4)));
+        int tid = -1;
+        for (size_t r = 0; r < names.size(); ++r) {
+            CTO_REQUIRE(bz.read(h4, 4) && le32(h4) > 0 && le32(h4) <= 65536, CTO_EINVAL, "cto_bam_view: bad reference list");
+            std::vector<char> nm(size_t(le32(h4)));
+            CTO_REQUIRE(bz.read(nm.data(), nm.size()) && bz.read(h4, 4), CTO_EINVAL, "cto_bam_view: truncated reference list");
+            nm.back() = 0;
+            names[r] = nm.data();
+            if (tid < 0 && names[r] == ctg_name) tid = int(r);
+        }
+        CTO_REQUIRE(tid >= 0, CTO_EINVAL, "cto_bam_view: contig %s not in the BAM header", ctg_name);
+        std::vector<Chunk> chunks;
+        std::string err, idx = bai_path ? std::string(bai_path) : std::string(bam_path) + ".bai";
+        CTO_REQUIRE(bai_query(idx.c_str(), tid, start - 1, end, &chunks, &err), CTO_EINVAL, "cto_bam_view: %s", err.c_str());
+        std::string out;
+        std::vector<uint8_t> rec;
+        bool done = false;
+        const int64_t beg0 = start - 1, end0 = end;
+        for (size_t ci = 0; ci < chunks.size() && !done; ++ci) {
+            CTO_REQUIRE(bz.seek(chunks[ci].beg), CTO_EINVAL, "cto_bam_view: seek into BAM failed: %s", bz.err.c_str());
+            while (bz.tell() < chunks[ci].end) {
+                if (!bz.read(h4, 4)) { CTO_REQUIRE(bz.err.empty(), CTO_EINVAL, "cto_bam_view: %s", bz.err.c_str()); done = true; break; }
+                const int bsz = le32(h4);
+                CTO_REQUIRE(bsz >= 32 && bsz <= (1 << 28), CTO_EINVAL, "cto_bam_view: bad alignment block size %d", bsz);
+                rec.resize(size_t(bsz));
+                CTO_REQUIRE(bz.read(rec.data(), rec.size()), CTO_EINVAL, "cto_bam_view: truncated alignment record");
+                const uint8_t* b = rec.data();
+                const int rtid = le32(b), pos = le32(b + 4), l_name = b[8], mapq = b[9];
+                const int n_cig = b[12] | (b[13] << 8), flag = b[14] | (b[15] << 8), l_seq = le32(b + 16);
+                const int nref = le32(b + 20), npos = le32(b + 24), tlen = le32(b + 28);
+                if (rtid != tid) { if (rtid > tid || rtid < 0) { done = true; break; } continue; }
+                if (pos >= end0) { done = true; break; }
+                const size_t need_b = 32 + size_t(l_name) + size_t(n_cig) * 4 + size_t((std::max(l_seq, 0) + 1) / 2) + size_t(std::max(l_seq, 0));
+                CTO_REQUIRE(l_seq >= 0 && need_b <= rec.size(), CTO_EINVAL, "cto_bam_view: alignment record shorter than its fields");
+                const uint8_t* cg = b + 32 + l_name;
+                const uint8_t* sq = cg + size_t(n_cig) * 4;
+                const uint8_t* ql = sq + (l_seq + 1) / 2;
+                int64_t rlen = 0;
+                for (int i = 0; i < n_cig; ++i) {
+                    const uint32_t c = uint32_t(le32(cg + i * 4));
+                    const int opc = int(c & 15);
+                    if (opc == 0 || opc == 2 || opc == 3 || opc == 7 || opc == 8) rlen += int64_t(c >> 4);
+                }
+                if (int64_t(pos) + std::max<int64_t>(rlen, 1) <= beg0 || mapq < min_mq) continue;
+                char num[32];
+                out.append(reinterpret_cast<const char*>(b + 32), size_t(std::max(0, l_name - 1)));
+                out += '\t'; out += std::to_string(flag); out += '\t'; out += ctg_name; out += '\t'; out += std::to_string(pos + 1);
+                out += '\t'; out += std::to_string(mapq); out += '\t';
+                if (n_cig == 0) out += '*';
+                for (int i = 0; i < n_cig; ++i) {
+                    const uint32_t c = uint32_t(le32(cg + i * 4));
+                    snprintf(num, sizeof(num), "%u%c", c >> 4, "MIDNSHP=X???????"[c & 15]);
+                    out += num;
+                }
+                out += '\t';
+                out += nref < 0 ? "*" : (nref == tid ? "=" : (size_t(nref) < names.size() ? names[size_t(nref)].c_str() : "*"));
+                out += '\t'; out += std::to_string(npos + 1); out += '\t'; out += std::to_string(tlen); out += '\t';
+                if (l_seq == 0) out += '*';
+                for (int i = 0; i < l_seq; ++i) out += kNt16[(sq[i >> 1] >> ((~i & 1) << 2)) & 15];
+                out += '\t';
+                if (l_seq == 0 || ql[0] == 0xff) out += '*';
+                else for (int i = 0; i < l_seq; ++i) out += char(std::min(int(ql[i]), 93) + 33);
+                // HP:i of the auxiliary fields
+                const uint8_t* aux = ql + l_seq;
+                const uint8_t* aend = rec.data() + rec.size();
+                while (aux + 3 <= aend) {
+                    const char t0 = char(aux[0]), t1 = char(aux[1]), ty = char(aux[2]);
+                    aux += 3;
+                    size_t skip = 0;
+                    long long val = 0;
+                    bool is_int = true;
+                    if (ty == 'c' && aux + 1 <= aend) { val = int8_t(aux[0]); skip = 1; }
+                    else if (ty == 'C' && aux + 1 <= aend) { val = aux[0]; skip = 1; }
+                    else if (ty == 's' && aux + 2 <= aend) { val = int16_t(aux[0] | (aux[1] << 8)); skip = 2; }
+                    else if (ty == 'S' && aux + 2 <= aend) { val = aux[0] | (aux[1] << 8); skip = 2; }
+                    else if (ty == 'i' && aux + 4 <= aend) { val = le32(aux); skip = 4; }
+                    else if (ty == 'I' && aux + 4 <= aend) { val = uint32_t(le32(aux)); skip = 4; }
+                    else {
+                        is_int = false;
+                        if (ty == 'A') skip = 1;
+                        else if (ty == 'f') skip = 4;
+                        else if (ty == 'Z' || ty == 'H') { while (aux + skip < aend && aux[skip]) ++skip; ++skip; }
+                        else if (ty == 'B') {
+                            if (aux + 5 > aend) break;
+                            const char sub = char(aux[0]);
+                            const size_t esz = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                            skip = 5 + size_t(uint32_t(le32(aux + 1))) * esz;
+                        } else break;
+                    }
+                    if (is_int && t0 == 'H' && t1 == 'P') { out += "\tHP:i:"; out += std::to_string(val); }
+                    aux += skip;
+                }
+                out += '\n';
+                ++n_rows;
+            }
+        }
+        *need = out.size();
+        CTO_REQUIRE(out.size() <= cap, CTO_ENOMEM, "cto_bam_view: %zu bytes of text, room for %zu", out.size(), cap);
+        if (!out.empty()) memcpy(buf, out.data(), out.size());
+        return CTO_OK;
+    });
+    return rc == CTO_OK ? n_rows : rc;
+}
+
 // Record boundaries the index knows inside [file_begin, file_end): the starts of the region's chunks and, per 16 kb window of the
 // region, the first alignment that overlaps it (BAI linear index) - virtual offsets, ascending, the first one being where a
 // reader of the region starts.  The device pileup (csrc/pileup.hip) walks one chain of records from each of them.

@@ -304,9 +304,32 @@ def faidx(samtools, ref_fn, region):
     return "".join(p.stdout.split("\n")[1:]).upper()
 
 
+def bam_view(bam_fn, ctg_name, start, end, min_mq=0, bai_fn=None):
+    """rows of `samtools view bam ctg:start-end -q min_mq` from the built-in BAM reader (cto_bam_view; PARITY UNPINNED)"""
+    cap = 1 << 20
+    while True:
+        buf = C.create_string_buffer(cap)
+        need = C.c_size_t(0)
+        n = lib.cto_bam_view(str(bam_fn).encode(), str(bai_fn).encode() if bai_fn else None, ctg_name.encode(), int(start), int(end), int(min_mq),
+                             buf, cap, C.byref(need))
+        if n == -3 and need.value > cap:
+            cap = need.value + 1024
+            continue
+        check(int(n))
+        return buf.raw[:need.value].decode().splitlines(True)
+
+
 def reads_realignment(args, out=None):
     out = out or sys.stdout
     (rd_lo, rd_hi), (ref_lo, ref_hi) = region_of(args.pos, args.realign_flanking_window)
+    if getattr(args, "bam_reader", "samtools") == "native":     # no samtools: built-in BAM and FASTA readers
+        from .fasta import read_region
+        ref = read_region(args.ref_fn, args.ctg_name, ref_lo, ref_hi)
+        if not ref:
+            sys.exit("[ERROR] Failed to load reference sequence from file ({}).".format(args.ref_fn))
+        rows = bam_view(args.bam_fn, args.ctg_name, max(1, rd_lo), rd_hi, args.min_mq if args.min_mq > 0 else 0)
+        realign_region(rows, args.ctg_name, ref, ref_lo - 1, args.pos, out, args.min_coverage, args.max_distance)
+        return
     ref = faidx(args.samtools, args.ref_fn, "{}:{}-{}".format(args.ctg_name, ref_lo, ref_hi))
     if not ref:
         sys.exit("[ERROR] Failed to load reference sequence from file ({}).".format(args.ref_fn))
@@ -329,6 +352,8 @@ def main():
     p.add_argument("--realign_flanking_window", type=int, default=100)
     p.add_argument("--pos", type=int, default=None)
     p.add_argument("--max_distance", type=int, default=50, help=SUPPRESS)
+    p.add_argument("--bam_reader", type=str, default="samtools", choices=["samtools", "native"],
+                   help="samtools: `samtools view` / `faidx` as the reference runs them; native: the built-in BAM / FASTA readers (parity unpinned)")
     for compat in ("--ctg_start", "--ctg_end", "--bed_fn", "--extend_bed", "--test_pos"):
         p.add_argument(compat, default=None, help=SUPPRESS)
     args = p.parse_args()

@@ -46,11 +46,120 @@ def column_alleles(bases):
 
 
 def decide(raw_bases, realigned_bases, alt):
-    """realign_variants.py:112-123 -> (passes, (raw support, raw depth, realigned support, realigned depth))"""
-    raw, new = column_alleles(raw_bases), column_alleles(realigned_bases)
+    """realign_variants.py:112-123 -> (passes, (raw support, raw depth, realigned support, realigned depth)); the columns as
+    mpileup base strings or as allele lists"""
+    raw = column_alleles(raw_bases) if isinstance(raw_bases, str) else raw_bases
+    new = column_alleles(realigned_bases) if isinstance(realigned_bases, str) else realigned_bases
     rs, ns = Counter(raw)[alt], Counter(new)[alt]
     fails = rs / float(len(raw)) > ns / len(new) and ns < rs
     return not fails, (rs, len(raw), ns, len(new))
+
+
+# ---- the two pileup columns without samtools (--bam_reader native; PARITY UNPINNED, rules of csrc/bam.cpp's header) ----
+def bam_column_alleles(args, ctg, pos):
+    """the raw column of `samtools mpileup bam --min-MQ --min-BQ --excl-flags 2316 -r ctg:pos-pos` as upper-cased alleles"""
+    from .fasta import read_region
+    from .pack import ColumnPack
+    ref_lo = max(1, pos - 100)
+    ref = read_region(args.ref_fn, ctg, ref_lo, pos + 100)
+    pack = ColumnPack.from_bam(args.bam_fn, ctg, pos, pos, ref, ref_lo, excl_flags=EXCL_FLAGS, min_mq=args.min_mq)
+    a = pack.numpy()
+    if pack.n_cols == 0:
+        return None
+    out = []
+    k0 = int(a["key_off"][0])
+    for e in a["entries"][int(a["col_off"][0]):int(a["col_off"][1])].tolist():
+        if ((e >> 6) & 127) < args.min_bq:
+            continue
+        code, kind = e & 15, (e >> 4) & 3
+        tok = "ACGTACGT*#NN"[code]
+        if kind:                          # an indel rides on this base: the allele is never a bare letter (only that matters below)
+            key = pack.key_string(k0 + (e >> 21))
+            tok += ("+" + key[2:]) if key[0] == "I" else ("-" + "N" * (len(key) - 2))
+        out.append(tok)
+    return out
+
+
+def sam_column_alleles(sam_text, pos, min_mq, min_bq):
+    """the column at `pos` (1-based) of `samtools mpileup - --reverse-del --min-MQ --min-BQ --excl-flags 2316` over SAM rows, as
+    upper-cased alleles: excluded flags, unmapped, orphans (paired without proper-pair), MAPQ, then per read the base / deletion
+    placeholder at pos with the insertion or deletion that follows its aligned run, and the read-pair overlap rule between rows of
+    the same name (csrc/bam.cpp: soften_overlap) before the BQ gate"""
+    p0 = pos - 1
+    reads = []
+    for row in sam_text.split("\n"):
+        if not row or row[0] == "@":
+            continue
+        c = row.split("\t")
+        flag, start, mq, cigar = int(c[1]), int(c[3]) - 1, int(c[4]), c[5]
+        if (flag & EXCL_FLAGS) or (flag & 4) or mq < min_mq or cigar == "*" or c[9] == "*" or ((flag & 1) and not (flag & 2)):
+            continue
+        ops = list(rr._cigar_ops(cigar))
+        rlen = sum(n for op, n in ops if op in "MDN=X")
+        if sum(n for op, n in ops if op in "MIS=X") != len(c[9]) or rlen == 0 or not (start <= p0 < start + rlen):
+            continue
+        qual = [0] * len(c[9]) if c[10] == "*" else [min(ord(ch) - 33, 93) for ch in c[10]]
+        reads.append(dict(name=c[0], flag=flag, start=start, ops=ops, seq=c[9], qual=qual, end=start + rlen))
+    # read-pair overlaps: the mate that entered first keeps min(200, qa + qb) when the bases agree, the better base 0.8 x its quality
+    # when they differ; the other base -> 0 (only the two bases AT pos matter here)
+    def locate(r):
+        rp, qp = r["start"], 0
+        for i, (op, n) in enumerate(r["ops"]):
+            if op in "M=X":
+                if rp <= p0 < rp + n:
+                    return ("B", qp + (p0 - rp), i, p0 == rp + n - 1)
+                rp += n; qp += n
+            elif op == "D":
+                if rp <= p0 < rp + n:
+                    return ("D", qp, i, False)
+                rp += n
+            elif op == "N":
+                if rp <= p0 < rp + n:
+                    return None
+                rp += n
+            elif op in "IS":
+                qp += n
+        return None
+    first = {}
+    for r in reads:
+        r["loc"] = locate(r)
+        if (r["flag"] & 1) and r["loc"] and r["loc"][0] == "B":
+            m = first.get(r["name"])
+            if m is not None and m["loc"] and m["loc"][0] == "B":
+                qa, qb = m["loc"][1], r["loc"][1]
+                if m["seq"][qa] == r["seq"][qb]:
+                    m["qual"][qa], r["qual"][qb] = min(200, m["qual"][qa] + r["qual"][qb]), 0
+                elif m["qual"][qa] >= r["qual"][qb]:
+                    m["qual"][qa], r["qual"][qb] = int(0.8 * m["qual"][qa]), 0
+                else:
+                    m["qual"][qa], r["qual"][qb] = 0, int(0.8 * r["qual"][qb])
+        first.setdefault(r["name"], r)
+    out = []
+    for r in reads:
+        loc = r["loc"]
+        if loc is None:
+            continue
+        rev = bool(r["flag"] & 16)
+        if loc[0] == "D":
+            bq = min(r["qual"][loc[1]], 93) if loc[1] < len(r["qual"]) else 0
+            if bq >= min_bq:
+                out.append("#" if rev else "*")
+            continue
+        q, i, last = loc[1], loc[2], loc[3]
+        if min(r["qual"][q], 93) < min_bq:
+            continue
+        b = r["seq"][q].upper()
+        tok = b if b in "ACGT" else "N"
+        if last:
+            j = i + 1
+            while j < len(r["ops"]) and r["ops"][j][0] == "P":
+                j += 1
+            if j < len(r["ops"]) and r["ops"][j][0] == "I":
+                tok += "+" + r["seq"][q + 1:q + 1 + r["ops"][j][1]].upper()
+            elif j < len(r["ops"]) and r["ops"][j][0] == "D":
+                tok += "-" + "N" * r["ops"][j][1]
+        out.append(tok)
+    return out
 
 
 def _mpileup(args, source, region_or_none, stdin_text=None, reverse_del=False):
@@ -74,16 +183,29 @@ def evaluate_call(args, rec):
         qual = None
     if qual is not None and qual >= QUAL_BAR:
         return ctg, pos, True, (-1, -1, -1, -1)
-    cols = _mpileup(args, args.bam_fn, "{}:{}-{}".format(ctg, pos, pos)).rstrip().split("\t")
-    if len(cols) < 4:
-        return ctg, pos, True, (-1, -1, -1, -1)
+    native = getattr(args, "bam_reader", "samtools") == "native"
+    if native:
+        raw = bam_column_alleles(args, ctg, pos)
+        if not raw:
+            return ctg, pos, True, (-1, -1, -1, -1)
+    else:
+        cols = _mpileup(args, args.bam_fn, "{}:{}-{}".format(ctg, pos, pos)).rstrip().split("\t")
+        if len(cols) < 4:
+            return ctg, pos, True, (-1, -1, -1, -1)
     # the reference's inner command: realign_reads --pos P | samtools mpileup - --reverse-del ... | grep -w P
     sam = StringIO()
     inner = ArgumentParser()
     ns = inner.parse_args([])
     ns.pos, ns.ctg_name, ns.bam_fn, ns.ref_fn, ns.samtools = pos, ctg, args.bam_fn, args.ref_fn, args.samtools
     ns.min_mq, ns.min_coverage, ns.realign_flanking_window, ns.max_distance = 20, 2.0, 100, 50        # realign_reads' own defaults (:690-711)
+    ns.bam_reader = "native" if native else "samtools"
     rr.reads_realignment(ns, out=sam)
+    if native:
+        new = sam_column_alleles(sam.getvalue(), pos, args.min_mq, args.min_bq)
+        if not new:
+            return ctg, pos, True, (-1, -1, -1, -1)
+        ok, counts = decide(raw, new, rec["alt"])
+        return ctg, pos, ok, counts
     text = _mpileup(args, "-", None, stdin_text=sam.getvalue(), reverse_del=True)
     hits = [ln for ln in text.split("\n") if word_match(ln, str(pos))]
     new_cols = "\n".join(hits).rstrip().split("\t")
@@ -140,6 +262,9 @@ def main():
     p.add_argument("--output_dir", type=str, default=None)
     p.add_argument("--output_vcf_fn", type=str, default=None)
     p.add_argument("--samtools", type=str, default="samtools")
+    p.add_argument("--bam_reader", type=str, default="samtools", choices=["samtools", "native"],
+                   help="samtools: the reference's three samtools commands per call; native: the built-in BAM / FASTA readers and pileup "
+                        "(no samtools needed; parity against samtools unpinned)")
     p.add_argument("--threads", type=int, default=1)
     p.add_argument("--python", type=str, default="python3", help="accepted for compatibility: the realignment runs in-process")
     p.add_argument("--show_ref", action="store_true")

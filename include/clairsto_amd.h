@@ -139,6 +139,11 @@ int cto_pack_from_bam_inflated(const char* bam_path, const char* bai_path, const
  *                            keys - use cto_pack_from_bam[_inflated].  h_blocks: the block table on the HOST.  Synchronises `stream`
  *                            (sizes come back twice).  The BGZF CRC-32 is not checked on this path.  PARITY UNPINNED against samtools;
  *                            held bit-equal to cto_pack_from_bam (tests/test_gpu_pileup.py). */
+/* `samtools view BAM ctg:start-end [-q min_mq]` without samtools (src/realign_reads.py:411-416 runs that command): the alignments
+ * overlapping the region as SAM rows (no header) with the eleven mandatory fields and the HP:i tag when present.  Returns the number
+ * of rows, *need = bytes of text; CTO_ENOMEM when cap is smaller (call again).  PARITY UNPINNED against samtools. */
+int64_t cto_bam_view(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end, int min_mq,
+                     char* buf, size_t cap, size_t* need);
 typedef struct cto_dev_pileup cto_dev_pileup;
 int  cto_dev_pileup_create(cto_dev_pileup** out);
 void cto_dev_pileup_destroy(cto_dev_pileup* ctx);

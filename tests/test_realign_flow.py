@@ -123,3 +123,22 @@ def test_column_alleles_and_decision_rule():
     assert decide("AAAATTTT", "AATTTT", "T")[0] is True                          # same support, smaller depth
     assert decide("AAAATTTT", "TT", "T")[0] is True                              # fewer reads but a larger fraction
     assert decide("AAAA", "AAAA", "T")[0] is True
+
+
+def test_realign_variants_without_samtools(flow, tmp_path):
+    """--bam_reader native: the same decisions from a real BAM + BAI (tests/bamutil.write_bam) with no samtools anywhere - the
+    built-in reader serves the raw column and the region's rows (cto_pack_from_bam, cto_bam_view), the realigned column is piled up
+    in-process.  The VCF equals the one the reference wrote through the samtools shim (whose pileup is the naive restatement the
+    built-in reader is held to): PARITY UNPINNED against samtools itself."""
+    from bamutil import write_bam
+    from clairs_to_amd import realign_variants as rv
+    g, sim, paths = flow
+    bam = str(tmp_path / "sim.bam")
+    reads = [dict(r, cigar=[(o, n) for o, n in r["cigar"]]) for r in sim["reads"]]
+    write_bam(bam, [(realignsim.CTG, len(sim["ref"]))], reads, block_payload=20000)
+    out = str(tmp_path / "native.vcf")
+    failed = rv.realign_variants(Namespace(bam_fn=bam, ref_fn=paths["ref"], ctg_name=realignsim.CTG, pileup_vcf_fn=paths["vcf"], output_vcf_fn=out,
+                                           samtools="/nonexistent/samtools", threads=8, show_ref=False, min_mq=20, min_bq=0,
+                                           enable_realignment=True, is_indel=False, bam_reader="native"))
+    assert open(out).read() == g["vcf"]
+    assert len(failed) >= 8
