@@ -223,9 +223,14 @@ def main():
     # ---- synthetic job: `pool` chunks per rank, packs resident in HBM ----
     stage["name"] = "synthesising %d chunks" % args.pool
     chunks, packs, sites = [], [], []
-    for i in range(args.pool):
-        ch = SynthChunk(args.batch, seed=20260928 + 1000 * rank + i, start=100000 + (rank * args.pool + i) * 2000000)
-        chunks.append(ch)
+    # the generator is vectorised numpy whose random draws release the GIL: a few threads per rank cut the set-up (16 chunks x ~5 s
+    # of one core each) to a fraction - 8 ranks on a 16-core allotment must still start well inside the driver's patience
+    from concurrent.futures import ThreadPoolExecutor
+    gen_threads = max(1, min(8, usable_cores() // max(1, world)))
+    with ThreadPoolExecutor(max_workers=gen_threads) as ex:
+        chunks = list(ex.map(lambda i: SynthChunk(args.batch, seed=20260928 + 1000 * rank + i, start=100000 + (rank * args.pool + i) * 2000000),
+                             range(args.pool)))
+    for ch in chunks:
         packs.append(eng.upload(ch.arrays()))
         sites.append(torch.from_numpy(ch.site_pos).to(dev))
     pack_bytes = sum(p.nbytes() for p in packs) / len(packs)
@@ -345,7 +350,7 @@ def main():
             return {"ms": round(ms, 4), "tflops": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
         stage_fracs = {"gru_l2": frac(l2_ms.value, l2_macs.value), "gru_l1": frac(l1_ms.value, l1_macs.value),
                        "cvt": frac(cvt_ms.value, cvt_macs.value),
-                       "note": "mean of 20 launches each, HIP events on the launch stream (cto_model_profile); cvt = its six block launches"}
+                       "note": "mean of 20 launches each, HIP events on the launch stream (cto_model_profile); cvt = its three launches (one per stage, all blocks of the stage inside)"}
 
     # ---- secondary roofline: pileup-tensor creation (HBM-bound stage), timed on its own after the timed region ----
     from clairs_to_amd.featurize import featurize

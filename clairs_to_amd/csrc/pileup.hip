@@ -322,17 +322,11 @@ __global__ __launch_bounds__(256) void k_fill(const uint8_t* __restrict__ lin, c
         const int op_ref = ref_carry + rs - rl, op_q = q_carry + qs - ql;
         ref_carry += __shfl(rs, 63);
         q_carry += __shfl(qs, 63);
-        if (k >= r.n_ops || !cons_ref || opc == 3) continue;
-        // requested positions inside [op_ref, op_ref + len)
-        int p = op_ref;
-        const int pend = op_ref + len;
-        int a = 0, b = iv.n;
-        while (a < b) { const int m = (a + b) >> 1; if (iv.hi[m] > p) b = m; else a = m + 1; }
-        int kiv = a;
+        const bool covers = k < r.n_ops && cons_ref && opc != 3;
         const bool aligned = opc != 2;
         // the indel that follows this aligned run (P operations skipped)
         uint32_t ind = 0, ind_q = 0;
-        if (aligned) {
+        if (covers && aligned) {
             int nx = k + 1;
             while (nx < r.n_ops && (ld32(ops + size_t(nx) * 4) & 15) == 6) ++nx;
             if (nx < r.n_ops) {
@@ -342,33 +336,61 @@ __global__ __launch_bounds__(256) void k_fill(const uint8_t* __restrict__ lin, c
                 else if (nop == 2) ind = (uint32_t(nlen) << 2) | 2u;
             }
         }
-        while (p < pend && kiv < iv.n) {
-            if (p < iv.lo[kiv]) { p = iv.lo[kiv]; continue; }
-            if (p >= iv.hi[kiv]) { ++kiv; continue; }
-            const int stop = min(pend, iv.hi[kiv]);
-            for (; p < stop; ++p) {
-                const int col = slot_col[iv.base[kiv] + (p - iv.lo[kiv])];
-                TmpEnt e;
-                e.rank = uint32_t(j);
-                e.ind = 0;
-                e.ind_q = 0;
-                if (!aligned) {
-                    e.entry = dev_entry(r.rev ? 9 : 8, bq(op_q), mq);
-                } else {
-                    const int q = op_q + (p - op_ref);
-                    int code = kNib[base4(q)];
-                    if (code < 0) {
-                        const long long ri = (long long)p + 1 - ref_start;
-                        char ch = (ri >= 0 && ri < ref_len) ? ref[ri] : 'N';
-                        if (ch >= 'a' && ch <= 'z') ch = char(ch - 32);
-                        code = ch == 'A' ? 0 : (ch == 'C' ? 1 : (ch == 'G' ? 2 : (ch == 'T' ? 3 : 10)));
-                    }
-                    if (r.rev) code += code < 4 ? 4 : 1;
-                    e.entry = dev_entry(code, bq(q), mq);
-                    if (p == pend - 1) { e.ind = ind; e.ind_q = ind_q; }
+        // the read's contribution at reference position p of the operation (o_ref, o_q, o_len, ...)
+        auto emit = [&](int p, int kiv, int o_ref, int o_q, int o_len, bool o_aligned, uint32_t o_ind, uint32_t o_ind_q) {
+            const int col = slot_col[iv.base[kiv] + (p - iv.lo[kiv])];
+            TmpEnt e;
+            e.rank = uint32_t(j);
+            e.ind = 0;
+            e.ind_q = 0;
+            if (!o_aligned) {
+                e.entry = dev_entry(r.rev ? 9 : 8, bq(o_q), mq);
+            } else {
+                const int q = o_q + (p - o_ref);
+                int code = kNib[base4(q)];
+                if (code < 0) {
+                    const long long ri = (long long)p + 1 - ref_start;
+                    char ch = (ri >= 0 && ri < ref_len) ? ref[ri] : 'N';
+                    if (ch >= 'a' && ch <= 'z') ch = char(ch - 32);
+                    code = ch == 'A' ? 0 : (ch == 'C' ? 1 : (ch == 'G' ? 2 : (ch == 'T' ? 3 : 10)));
                 }
-                const long long at = col_off[col] + atomicAdd(&cursor[col], 1);
-                tmp[at] = e;
+                if (r.rev) code += code < 4 ? 4 : 1;
+                e.entry = dev_entry(code, bq(q), mq);
+                if (p == o_ref + o_len - 1) { e.ind = o_ind; e.ind_q = o_ind_q; }
+            }
+            const long long at = col_off[col] + atomicAdd(&cursor[col], 1);
+            tmp[at] = e;
+        };
+        auto first_iv = [&](int p) {
+            int a = 0, b = iv.n;
+            while (a < b) { const int m = (a + b) >> 1; if (iv.hi[m] > p) b = m; else a = m + 1; }
+            return a;
+        };
+        // short operations (real long-read CIGARs: an indel every ~10-20 bases): the lane walks its own; long aligned runs
+        // (hundreds of bases) would leave the other lanes idle, so the whole wave takes each of those in turn below
+        constexpr int LONG_OP = 48;
+        const bool is_long = covers && len > LONG_OP;
+        if (covers && !is_long) {
+            int p = op_ref, kiv = first_iv(op_ref);
+            const int pend = op_ref + len;
+            while (p < pend && kiv < iv.n) {
+                if (p < iv.lo[kiv]) { p = iv.lo[kiv]; continue; }
+                if (p >= iv.hi[kiv]) { ++kiv; continue; }
+                const int stop = min(pend, iv.hi[kiv]);
+                for (; p < stop; ++p) emit(p, kiv, op_ref, op_q, len, aligned, ind, ind_q);
+            }
+        }
+        unsigned long long lm = __ballot(is_long);
+        while (lm) {
+            const int src = __ffsll((long long)lm) - 1;
+            lm &= lm - 1;
+            const int o_ref = __shfl(op_ref, src), o_q = __shfl(op_q, src), o_len = __shfl(len, src);
+            const bool o_aligned = __shfl(int(aligned), src) != 0;
+            const uint32_t o_ind = __shfl(ind, src), o_ind_q = __shfl(ind_q, src);
+            const int pend = o_ref + o_len;
+            for (int kiv = first_iv(o_ref); kiv < iv.n && iv.lo[kiv] < pend; ++kiv) {
+                const int lo = max(o_ref, iv.lo[kiv]), hi = min(pend, iv.hi[kiv]);
+                for (int p = lo + lane; p < hi; p += 64) emit(p, kiv, o_ref, o_q, o_len, o_aligned, o_ind, o_ind_q);
             }
         }
     }

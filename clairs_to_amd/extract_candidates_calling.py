@@ -107,7 +107,8 @@ def main():
     p.add_argument("--tumor_bam_fn", type=str, default=None)
     p.add_argument("--samtools", type=str, default="samtools")
     p.add_argument("--bam_reader", type=str, default="samtools", choices=["samtools", "native"])
-    p.add_argument("--max_depth", type=int, default=None)
+    p.add_argument("--max_depth", type=int, default=None,
+                   help="EXPERIMENTAL: maximum tumor depth handed to samtools mpileup / the built-in reader (the reference's default: 8000). Engine limits, reported as an error of the chunk (CTO_EUNSUPPORTED), not silently: a pileup column may hold at most 32767 read-bases and 2048 distinct indel alleles")
     p.add_argument("--ref_fn", type=str, required=True)
     p.add_argument("--ctg_name", type=str, required=True)
     p.add_argument("--ctg_start", type=int, default=None)

@@ -174,7 +174,8 @@ def add_common_arguments(p):
     p.add_argument("--bam_reader", type=str, default="samtools", choices=["samtools", "native", "gpu"],
                    help="'native': built-in BAM + BAI reader instead of a samtools subprocess (parity unpinned, see csrc/bam.cpp)")
     p.add_argument("--min_bq", type=int, default=None, help="AFF-pass base quality gate (default: the platform's)")
-    p.add_argument("--max_depth", type=int, default=None)
+    p.add_argument("--max_depth", type=int, default=None,
+                   help="EXPERIMENTAL: maximum tumor depth handed to samtools mpileup / the built-in reader (the reference's default: 8000). Engine limits, reported as an error of the chunk (CTO_EUNSUPPORTED), not silently: a pileup column may hold at most 32767 read-bases and 2048 distinct indel alleles")
     p.add_argument("--max_indel_length", type=int, default=None)
     p.add_argument("--chkpnt_fn_acgt", type=str, required=True)
     p.add_argument("--chkpnt_fn_nacgt", type=str, required=True)

@@ -5,7 +5,7 @@ import json
 import os
 import sys
 
-ROUND = os.environ.get("CTO_ROUND", "round2")
+ROUND = os.environ.get("CTO_ROUND", "round3")
 
 
 def find(d, suffix):
