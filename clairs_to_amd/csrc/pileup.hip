@@ -92,25 +92,43 @@ __global__ void k_chain(const uint8_t* __restrict__ lin, int64_t len, const int6
     if (!mode) counts[k] = n;
 }
 
-// exclusive prefix sums of a short int array by one workgroup (chains, per-column key counts, key string lengths)
-template <typename Out>
-__global__ void k_scan_small(const int* __restrict__ in, Out* __restrict__ out, int n, Out* total) {
-    __shared__ long long part[1024];
-    const int t = threadIdx.x, per = (n + blockDim.x - 1) / blockDim.x;
-    const int lo = min(n, t * per), hi = min(n, lo + per);
-    long long s = 0;
-    for (int i = lo; i < hi; ++i) s += in[i];
-    part[t] = s;
-    __syncthreads();
-    for (int d = 1; d < int(blockDim.x); d <<= 1) {
-        const long long v = t >= d ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+// Exclusive prefix sum across the 1024 threads of the one workgroup these scan kernels run as (wave shuffles, then the 16 wave
+// totals through LDS); *total = the sum.  Two barriers.
+__device__ __forceinline__ long long block_scan_excl(long long v, long long* total, long long* wsum /* [17] shared */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long u = __shfl_up(inc, d);
+        if (lane >= d) inc += u;
     }
-    long long run = part[t] - s;
-    for (int i = lo; i < hi; ++i) { out[i] = Out(run); run += in[i]; }
-    if (t == int(blockDim.x) - 1) { out[n] = Out(part[t]); if (total) *total = Out(part[t]); }
+    __syncthreads();                                          // wsum may still be read from the previous call
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    long long before = 0, all = 0;
+    for (int w = 0; w < 16; ++w) { const long long x = wsum[w]; if (w < wave) before += x; all += x; }
+    *total = all;
+    return before + inc - v;
+}
+
+// exclusive prefix sums of an int array by one workgroup of 1024 threads, 4096 elements per pass (coalesced)
+template <typename Out>
+__global__ __launch_bounds__(1024) void k_scan_small(const int* __restrict__ in, Out* __restrict__ out, int n, Out* total) {
+    __shared__ long long wsum[17];
+    const int t = threadIdx.x;
+    long long carry = 0;
+    for (int base = 0; base < n; base += 4096) {
+        const int i0 = base + 4 * t;
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = i0 + k < n ? in[i0 + k] : 0;
+        long long tot;
+        long long ex = carry + block_scan_excl((long long)v[0] + v[1] + v[2] + v[3], &tot, wsum);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { if (i0 + k < n) out[i0 + k] = Out(ex); ex += v[k]; }
+        carry += tot;
+    }
+    if (t == 0) { out[n] = Out(carry); if (total) *total = Out(carry); }
 }
 
 __global__ void k_parse(const uint8_t* __restrict__ lin, const uint32_t* __restrict__ rec_off, int n_rec, int tid, int beg0, int end0,
@@ -232,41 +250,39 @@ __global__ void k_cover(const DevRead* __restrict__ reads, const int* __restrict
 }
 
 constexpr int ORD_DMAX_COLS = 2048;      // = ORD_DMAX of k_order
-// One workgroup: depth per slot (running sum of diff), rows where depth > 0 (slot_col, col_slot), col_off.
-__global__ void k_columns(const int* __restrict__ diff, int total, int* __restrict__ slot_col, int* __restrict__ col_slot,
-                          long long* __restrict__ col_off, Flags* fl) {
-    __shared__ long long pa[1024], pb[1024], pc[1024];
-    const int t = threadIdx.x, per = (total + blockDim.x - 1) / blockDim.x;
-    const int lo = min(total, t * per), hi = min(total, lo + per);
-    auto scan = [&](long long* p) {
-        __syncthreads();
-        for (int d = 1; d < int(blockDim.x); d <<= 1) {
-            const long long v = t >= d ? p[t - d] : 0;
-            __syncthreads();
-            p[t] += v;
-            __syncthreads();
-        }
-    };
-    long long s = 0;
-    for (int i = lo; i < hi; ++i) s += diff[i];
-    pa[t] = s;
-    scan(pa);
-    long long depth = pa[t] - s, nz = 0, ds = 0;
-    for (int i = lo; i < hi; ++i) { depth += diff[i]; nz += depth > 0; ds += depth; }
-    pb[t] = nz;
-    pc[t] = ds;
-    scan(pb);
-    scan(pc);
-    depth = pa[t] - s;
-    long long c = pb[t] - nz, o = pc[t] - ds;
+// One workgroup (1024 threads, 4096 slots per pass, coalesced): depth per slot (running sum of diff), rows where depth > 0
+// (slot_col, col_slot), col_off.
+__global__ __launch_bounds__(1024) void k_columns(const int* __restrict__ diff, int total, int* __restrict__ slot_col, int* __restrict__ col_slot,
+                                                  long long* __restrict__ col_off, Flags* fl) {
+    __shared__ long long wsum[17];
+    const int t = threadIdx.x;
+    long long c_depth = 0, c_cols = 0, c_off = 0;
     bool deep = false;
-    for (int i = lo; i < hi; ++i) {
-        depth += diff[i];
-        if (depth > 0) { slot_col[i] = int(c); col_slot[c] = i; col_off[c] = o; ++c; o += depth; deep |= depth > ORD_DMAX_COLS; }
-        else slot_col[i] = -1;
+    for (int base = 0; base < total; base += 4096) {
+        const int i0 = base + 4 * t;
+        int d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = i0 + k < total ? diff[i0 + k] : 0;
+        long long tot;
+        long long depth = c_depth + block_scan_excl((long long)d[0] + d[1] + d[2] + d[3], &tot, wsum);
+        c_depth += tot;
+        long long dep[4], nz = 0, ds = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { depth += d[k]; dep[k] = i0 + k < total ? depth : 0; nz += dep[k] > 0; ds += dep[k]; }
+        long long tot_n, tot_d;
+        long long c = c_cols + block_scan_excl(nz, &tot_n, wsum);
+        long long o = c_off + block_scan_excl(ds, &tot_d, wsum);
+        c_cols += tot_n;
+        c_off += tot_d;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k >= total) break;
+            if (dep[k] > 0) { slot_col[i0 + k] = int(c); col_slot[c] = i0 + k; col_off[c] = o; ++c; o += dep[k]; deep |= dep[k] > ORD_DMAX_COLS; }
+            else slot_col[i0 + k] = -1;
+        }
     }
     if (deep) atomicExch(&fl->deep_col, 1);
-    if (t == int(blockDim.x) - 1) { fl->n_cols = int(pb[t]); fl->n_entries = pc[t]; col_off[pb[t]] = pc[t]; }
+    if (t == 0) { fl->n_cols = int(c_cols); fl->n_entries = c_off; col_off[c_cols] = c_off; }
 }
 
 __global__ void k_col_meta(const int* __restrict__ col_slot, int n_cols, Ivs iv, const char* __restrict__ ref, long long ref_start, long long ref_len,
