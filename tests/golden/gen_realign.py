@@ -20,7 +20,7 @@ reference's realigner, compiled from its sources) and at clairs_to_amd/realign/d
 reference's `get_consensus` ABI, because the reference's own needs Boost.Graph and cannot be built here.  So in this fixture the
 consensus strings are an INPUT (recorded per window), everything else is the reference's output.
 
-  realign_flow.json.gz  {"seed", "inputs_sha256", "vcf": output VCF text, "positions": {pos: {"sha256", "n_rows", "moved": [[name, pos,
+  realign_flow.json.gz  {"seed", "inputs_sha256", "vcf": output VCF text, "vcf_indel": the same with --is_indel, "positions": {pos: {"sha256", "n_rows", "moved": [[name, pos,
                          cigar], ...]}}, "consensus": [[window reference, [haplotypes]], ...] in call order}
 
 Usage: make -C oracle ref && python tests/golden/gen_realign.py [windows|flow]     (from the repo root; build container only)
@@ -99,6 +99,13 @@ def gen_flow():
                         "--ctg_name", realignsim.CTG, "--pileup_vcf_fn", paths["vcf"], "--output_vcf_fn", out_vcf, "--samtools", paths["samtools"],
                         "--python", sys.executable, "--threads", "8"], check=True, env=env, cwd=tmp)
         vcf = open(out_vcf).read()
+        # the indel pass (--is_indel: indel records are kept; a deletion's ALT is its bare anchor base, so the reference judges such a record by
+        # how many reads show that letter at the anchor - its behaviour, reproduced as it is; an insertion's ALT never equals an allele string)
+        out_vcf_i = os.path.join(tmp, "out", "realigned_indel.vcf")
+        subprocess.run([sys.executable, os.path.join(REF, "clairs_to.py"), "realign_variants", "--bam_fn", paths["bam"], "--ref_fn", paths["ref"],
+                        "--ctg_name", realignsim.CTG, "--pileup_vcf_fn", paths["vcf"], "--output_vcf_fn", out_vcf_i, "--samtools", paths["samtools"],
+                        "--python", sys.executable, "--threads", "8", "--is_indel"], check=True, env=env, cwd=tmp)
+        vcf_indel = open(out_vcf_i).read()
         todo = []
         for row in open(paths["vcf"]):
             c = row.split("\t")
@@ -124,7 +131,7 @@ def gen_flow():
                 for ln in open(log):
                     ref_w, haps = ln.rstrip("\n").split("\t")
                     consensus.append([pos, ref_w, [h for h in haps.split(",") if h]])
-        obj = {"seed": 20260929, "inputs_sha256": flow_inputs_digest(paths), "vcf": vcf, "positions": positions, "consensus": consensus}
+        obj = {"seed": 20260929, "inputs_sha256": flow_inputs_digest(paths), "vcf": vcf, "vcf_indel": vcf_indel, "positions": positions, "consensus": consensus}
         raw = json.dumps(obj, separators=(",", ":")).encode()
         with open(os.path.join(HERE, "realign_flow.json.gz"), "wb") as f:
             with gzip.GzipFile(fileobj=f, mode="wb", mtime=0) as g:

@@ -109,6 +109,11 @@ def test_realign_variants_writes_the_reference_vcf(flow, tmp_path):
                                            enable_realignment=True, is_indel=False))
     assert open(out).read() == g["vcf"]
     assert len(failed) == g["vcf"].count("LowQual;Realignment") >= 8
+    # the indel pass: indel records stay in; a deletion's ALT is its bare anchor base, which the reference counts like an SNV allele
+    out_i = str(tmp_path / "out" / "realigned_indel.vcf")
+    rv.realign_variants(Namespace(bam_fn=paths["bam"], ref_fn=paths["ref"], ctg_name=realignsim.CTG, pileup_vcf_fn=paths["vcf"], output_vcf_fn=out_i,
+                                  samtools=paths["samtools"], threads=8, show_ref=False, min_mq=20, min_bq=0, enable_realignment=True, is_indel=True))
+    assert open(out_i).read() == g["vcf_indel"] and g["vcf_indel"].count("\n") > g["vcf"].count("\n")
     # the switch (--enable_realignment False): a link to the input, as the reference leaves it (src/realign_variants.py:134-136)
     off = str(tmp_path / "off.vcf")
     rv.realign_variants(Namespace(enable_realignment=False, pileup_vcf_fn=paths["vcf"], output_vcf_fn=off))
