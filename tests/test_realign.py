@@ -47,10 +47,11 @@ def test_realign_reads_equals_the_reference_on_the_golden_windows():
 
 @pytest.mark.skipif(ru.ref_lib() is None, reason="oracle/_ref/librealigner_ref.so not built (`make -C oracle ref`, needs /root/reference)")
 def test_realign_reads_equals_the_compiled_reference_on_fresh_windows():
-    rng = np.random.default_rng(int.from_bytes(os.urandom(4), "little"))
-    for _ in range(120):
+    seed = int.from_bytes(os.urandom(4), "little")
+    rng = np.random.default_rng(seed)
+    for i in range(120):
         w = ru.gen_window(rng)
-        assert ru.amd_realign(w) == ru.ref_realign(w)
+        assert ru.amd_realign(w) == ru.ref_realign(w), "window %d of np.random.default_rng(%d)" % (i, seed)
 
 
 @pytest.mark.skipif(ru.ref_lib() is None, reason="oracle/_ref/librealigner_ref.so not built")
