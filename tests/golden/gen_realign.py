@@ -131,7 +131,18 @@ def gen_flow():
                 for ln in open(log):
                     ref_w, haps = ln.rstrip("\n").split("\t")
                     consensus.append([pos, ref_w, [h for h in haps.split(",") if h]])
-        obj = {"seed": 20260929, "inputs_sha256": flow_inputs_digest(paths), "vcf": vcf, "vcf_indel": vcf_indel, "positions": positions, "consensus": consensus}
+        # the same entry point over a region longer than its 5 000-base chunk (--realign_flanking_window 3000: 8 200 bases of reads), which
+        # takes the chunk-boundary path of src/realign_reads.py:283-286, 618-634 that `realign_variants` (window 100) never reaches
+        wide = {}
+        inner = [q for q in todo if q > 4200]            # the read region must not start below 1
+        for pos in (inner[0], inner[len(inner) // 2], inner[-1]):
+            p = subprocess.run([sys.executable, os.path.join(REF, "clairs_to.py"), "realign_reads", "--pos", str(pos), "--ctg_name", realignsim.CTG,
+                                "--bam_fn", paths["bam"], "--ref_fn", paths["ref"], "--samtools", paths["samtools"], "--realign_flanking_window", "3000"],
+                               check=True, env=env, cwd=tmp, stdout=subprocess.PIPE, universal_newlines=True)
+            rows = [r for r in p.stdout.split("\n") if r and r[0] != "@"]
+            wide[str(pos)] = {"sha256": hashlib.sha256(p.stdout.encode()).hexdigest(), "n_rows": len(rows),
+                              "n_moved": sum(1 for r in rows if orig[(r.split("\t")[0], int(r.split("\t")[1]))] != (int(r.split("\t")[3]) - 1, r.split("\t")[5]))}
+        obj = {"seed": 20260929, "inputs_sha256": flow_inputs_digest(paths), "vcf": vcf, "wide_window": wide, "vcf_indel": vcf_indel, "positions": positions, "consensus": consensus}
         raw = json.dumps(obj, separators=(",", ":")).encode()
         with open(os.path.join(HERE, "realign_flow.json.gz"), "wb") as f:
             with gzip.GzipFile(fileobj=f, mode="wb", mtime=0) as g:

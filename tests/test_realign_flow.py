@@ -66,6 +66,22 @@ def test_realign_reads_writes_the_reference_sam_text(flow):
     assert len(g["positions"]) >= 20 and moved_total >= 200
 
 
+def test_realign_reads_across_its_chunk_boundary(flow):
+    """--realign_flanking_window 3000: 8 200 bases of reads cross the entry point's 5 000-base chunk, so rows are written and evidence
+    is dropped at the boundary (src/realign_reads.py:283-286, 618-634) - a path the filter's own window of 100 never takes"""
+    from clairs_to_amd import realign_reads as rr
+    g, sim, paths = flow
+    for pos, want in g["wide_window"].items():
+        a = _args(paths, int(pos))
+        a.realign_flanking_window = 3000
+        out = io.StringIO()
+        rr.reads_realignment(a, out=out)
+        text = out.getvalue()
+        assert len([r for r in text.split("\n") if r and r[0] != "@"]) == want["n_rows"]
+        assert hashlib.sha256(text.encode()).hexdigest() == want["sha256"], pos
+    assert len(g["wide_window"]) == 3 and sum(w["n_moved"] for w in g["wide_window"].values()) > 5
+
+
 def test_realign_reads_with_the_recorded_consensus_as_input(flow):
     """the part that is pinned without the build's de Bruijn graph: the recorded haplotypes go in, the reference's SAM text comes
     out; and the graph, asked again, returns what was recorded"""
