@@ -668,6 +668,21 @@ extern "C" int cto_pileup_device(cto_dev_pileup* cx, const void* d_inflated, con
         p->key_off.push_back(0);
         p->key_str_off.push_back(0);
         memset(dev_view, 0, sizeof(*dev_view));
+        // an empty pack still has its two one-element offset arrays (col_off = key_off = {0}) and valid pointers everywhere
+        int rc0;
+        if ((rc0 = cx->col_off.ensure(64)) || (rc0 = cx->key_off.ensure(64)) || (rc0 = cx->col_pos.ensure(64)) || (rc0 = cx->col_ref.ensure(64)) ||
+            (rc0 = cx->entries.ensure(64)) || (rc0 = cx->key_meta.ensure(64)) || (rc0 = cx->key_group.ensure(64)))
+            return rc0;
+        CTO_HIP(hipMemsetAsync(cx->col_off.p, 0, 64, s));
+        CTO_HIP(hipMemsetAsync(cx->key_off.p, 0, 64, s));
+        CTO_HIP(hipStreamSynchronize(s));
+        dev_view->col_pos = cx->col_pos.as<int32_t>();
+        dev_view->col_ref = cx->col_ref.as<uint8_t>();
+        dev_view->col_off = cx->col_off.as<int64_t>();
+        dev_view->key_off = cx->key_off.as<int32_t>();
+        dev_view->entries = cx->entries.as<uint32_t>();
+        dev_view->key_meta = cx->key_meta.as<uint8_t>();
+        dev_view->key_group = cx->key_group.as<int32_t>();
         *host_lite = p.release();
         return CTO_OK;
     };

@@ -498,7 +498,7 @@ struct Run {
                 if ((rc = s->pack_dev.ensure(total)) != CTO_OK) { cto_pack_free(lite); return rc; }
                 char* d = static_cast<char*>(s->pack_dev.p);
                 for (int i = 0; i < 8; ++i)
-                    if (bytes[i] && nc)
+                    if (bytes[i])
                         CTO_HIP(hipMemcpyAsync(d + off[i], src[i], bytes[i], i == 7 ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, c->stream));
                 if (s->pack) cto_pack_free(s->pack);
                 s->pack = lite;

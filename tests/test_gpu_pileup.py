@@ -93,3 +93,51 @@ def test_device_pileup_reports_what_it_leaves_to_the_host(tmp_path):
         write_bam(bam, refs, reads, block_payload=3000)
         pv, lite, fallback = dp.pileup(bam, None, "chrA", 1, 20000, ref, 1, dev, max_depth=50 if kind == "depth" else 8000)
         assert fallback, kind
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_device_pileup_random_regions_and_beds(tmp_path, seed):
+    """more shapes of the same comparison: random regions (contig ends, single positions, regions without reads), random BED interval
+    sets (touching, one base wide, outside the region), tiny and large BGZF blocks, reads with and without qualities / CG-tag CIGARs"""
+    import torch
+    from clairs_to_amd._lib import lib
+    from clairs_to_amd.bgzf import DevicePileup
+    from clairs_to_amd.pack import ColumnPack
+    rng = np.random.default_rng(seed)
+    L = int(rng.integers(6000, 30000))
+    refs = [("c0", 2000), ("chrQ", L), ("c2", 1500)]
+    ref_seqs = ["".join(rng.choice(list("ACGTN"), p=[.24, .24, .24, .24, .04], size=n)) for _, n in refs]
+    reads = _unpaired_reads(rng, int(rng.integers(200, 1800)), [2000, L, 1500])
+    write_bam(str(tmp_path / "t.bam"), refs, reads, block_payload=int(rng.choice([400, 2000, 9000, 60000])))
+    bam = str(tmp_path / "t.bam")
+    dp = DevicePileup()
+    dev = torch.device("cuda:0")
+    nonempty = 0
+    for case in range(10):
+        ri = int(rng.choice([0, 1, 1, 1, 2]))
+        n = refs[ri][1]
+        a = int(rng.integers(1, n + 1))
+        b = int(min(n, a + rng.choice([0, 1, 50, 700, 5000, 40000])))
+        bed = None
+        if rng.random() < 0.6:
+            k = int(rng.integers(1, 40))
+            starts = np.sort(rng.integers(max(0, a - 200), b + 200, size=k))
+            bed, last = [], -1
+            for s0 in starts.tolist():
+                s0 = max(s0, last)
+                e0 = s0 + int(rng.choice([1, 2, 33, 34, 120]))
+                bed.append((s0, e0))
+                last = e0 if rng.random() < 0.7 else e0 + int(rng.integers(0, 50))
+        want = _pack_arrays(ColumnPack.from_bam(bam, refs[ri][0], a, b, ref_seqs[ri], 1, bed=bed))
+        pv, lite, fallback = dp.pileup(bam, None, refs[ri][0], a, b, ref_seqs[ri], 1, dev, bed=bed)
+        if fallback and pv is None:                    # nothing in the index for the region: the host reader says "no columns" too
+            assert len(want["col_pos"]) == 0
+            continue
+        assert not fallback
+        got = _device_arrays(pv, lite)
+        lib.cto_pack_free(lite)
+        for key in ("col_pos", "col_ref", "col_off", "key_off", "entries", "key_meta", "key_group"):
+            np.testing.assert_array_equal(got[key], want[key], err_msg="%s seed %d case %d %s:%d-%d" % (key, seed, case, refs[ri][0], a, b))
+        assert got["keys"] == want["keys"]
+        nonempty += len(want["col_pos"]) > 0
+    assert nonempty >= 3
