@@ -27,8 +27,8 @@
 //
 // Not done here - the call reports `fallback` and the caller uses the host reader: paired reads (mate-overlap quality edits are
 // order dependent), reference skips (N), more reads than --max-depth in the region (the cap is order dependent too), a column
-// deeper than 2048, with more than 256 indel-carrying reads or more than 64 distinct indel keys.  The BGZF CRC-32 is not verified on this path (the host reader
-// checks it as htslib does); the inflate kernel's own checks (stream structure, ISIZE) still apply.
+// deeper than 2048, with more than 256 indel-carrying reads or more than 64 distinct indel keys.  The BGZF CRC-32 of every block is
+// checked on the device (k_crc32_blocks), as htslib and the host reader check it.
 #include <algorithm>
 #include <cstring>
 #include <memory>
@@ -57,6 +57,7 @@ struct KeyRec { uint32_t read, q, len; uint8_t code, kind, overlong, group; };
 struct Flags {                    // written by the kernels, read by the host after each phase
     int stop_idx, err_idx, paired_idx, skip_idx;    // first record index with the condition (INT_MAX: none)
     int bad_chain, deep_col, many_keys, ref_oob;
+    int bad_crc;                                    // 1 + index of a block whose inflated bytes fail the gzip trailer's CRC-32 (0: none)
     int n_rec, n_valid, n_cols, n_keys;
     long long n_entries, key_str_bytes;
 };
@@ -70,6 +71,49 @@ __global__ void k_linearise(const uint8_t* __restrict__ src, const cto_bgzf_bloc
     const uint8_t* s = src + b.out_off;
     uint8_t* d = lin + lin_off[blockIdx.x];
     for (uint32_t i = threadIdx.x; i < b.isize; i += blockDim.x) d[i] = s[i];
+}
+
+// CRC-32 of every inflated block against its gzip trailer, as htslib (and the host reader) checks it: one wave per block, lane k
+// runs the byte-table CRC over its own slice (the first slice is the short one, every other one 1024 bytes), lane 0 then chains the
+// 64 partial registers: state after slice k = P_k xor Z(state after slice k-1), Z = "1024 zero bytes" as a 32 x 32 bit matrix
+// (z1k[i] = image of bit i, from the host) - a CRC register is linear in its start value.
+__global__ __launch_bounds__(64) void k_crc32_blocks(const uint8_t* __restrict__ src, const cto_bgzf_block* __restrict__ blocks, int n_blocks,
+                                                     const uint32_t* __restrict__ z1k, Flags* fl) {
+    __shared__ uint32_t table[256];
+    __shared__ uint32_t part[64];
+    __shared__ uint32_t zm[32];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) {
+        uint32_t c = uint32_t(i);
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+        table[i] = c;
+    }
+    if (lane < 32) zm[lane] = z1k[lane];
+    __syncthreads();
+    for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        const cto_bgzf_block bd = blocks[b];
+        const int n = int(bd.isize);
+        if (n == 0) continue;
+        const int ns = (n + 1023) / 1024, r = n - 1024 * (ns - 1);
+        const uint8_t* p = src + bd.out_off;
+        uint32_t c = lane == 0 ? 0xFFFFFFFFu : 0u;
+        if (lane < ns) {
+            const int lo = lane == 0 ? 0 : r + 1024 * (lane - 1), len = lane == 0 ? r : 1024;
+            for (int i = 0; i < len; ++i) c = table[(c ^ p[lo + i]) & 0xFFu] ^ (c >> 8);
+        }
+        __syncthreads();
+        part[lane] = c;
+        __syncthreads();
+        if (lane == 0) {
+            uint32_t st = part[0];
+            for (int k = 1; k < ns; ++k) {
+                uint32_t z = 0;
+                for (int i = 0; i < 32; ++i) z ^= ((st >> i) & 1u) ? zm[i] : 0u;
+                st = part[k] ^ z;
+            }
+            if ((st ^ 0xFFFFFFFFu) != bd.crc32) atomicCAS(&fl->bad_crc, 0, b + 1);
+        }
+    }
 }
 
 // chain k walks the records from starts[k] to starts[k + 1]; mode 0 counts, mode 1 writes their offsets at base[k]..
@@ -591,7 +635,8 @@ struct Buf {
 
 struct cto_dev_pileup {
     Buf lin, lin_off, blocks, starts, counts, base, rec_off, reads, rid, iv, diff, slot_col, col_slot, col_off, col_pos, col_ref, cursor, tmp,
-        entries, nkc, keyrec, key_off, key_meta, key_group, key_final, key_col, key_len, str_off, key_str, ref, flags;
+        entries, nkc, keyrec, key_off, key_meta, key_group, key_final, key_col, key_len, str_off, key_str, ref, flags, z1k;
+    bool z1k_ready = false;
     Flags* h_flags = nullptr;            // page-locked mirror
     ~cto_dev_pileup() { if (h_flags) (void)hipHostFree(h_flags); }
 };
@@ -706,6 +751,16 @@ extern "C" int cto_pileup_device(cto_dev_pileup* cx, const void* d_inflated, con
     CTO_HIP(hipMemsetAsync(cx->diff.p, 0, size_t(total + 1) * 4, s));
     Flags* fl = cx->flags.as<Flags>();
     const uint8_t* lin = cx->lin.as<uint8_t>();
+    if (!cx->z1k_ready) {                                     // "1024 zero bytes" as a bit matrix, once per context
+        uint32_t tbl[256], z[32];
+        for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1; tbl[i] = c; }
+        for (int i = 0; i < 32; ++i) { uint32_t c = 1u << i; for (int k = 0; k < 1024; ++k) c = tbl[c & 0xFFu] ^ (c >> 8); z[i] = c; }
+        if ((rc = cx->z1k.ensure(sizeof(z)))) return rc;
+        CTO_HIP(hipMemcpy(cx->z1k.p, z, sizeof(z), hipMemcpyHostToDevice));
+        cx->z1k_ready = true;
+    }
+    hipLaunchKernelGGL(k_crc32_blocks, dim3(unsigned(std::min<int64_t>(n_blocks, 4096))), dim3(64), 0, s, static_cast<const uint8_t*>(d_inflated),
+                       cx->blocks.as<cto_bgzf_block>(), int(n_blocks), cx->z1k.as<uint32_t>(), fl);
     hipLaunchKernelGGL(k_linearise, dim3(unsigned(n_blocks)), dim3(256), 0, s, static_cast<const uint8_t*>(d_inflated), cx->blocks.as<cto_bgzf_block>(),
                        cx->lin_off.as<int64_t>(), cx->lin.as<uint8_t>());
     // ---- record boundaries ----
@@ -714,6 +769,10 @@ extern "C" int cto_pileup_device(cto_dev_pileup* cx, const void* d_inflated, con
     hipLaunchKernelGGL(k_scan_small<int>, dim3(1), dim3(1024), 0, s, cx->counts.as<int>(), cx->base.as<int>(), n_chains, &fl->n_rec);
     CTO_HIP(hipGetLastError());
     if ((rc = fetch_flags())) return rc;
+    if (hf->bad_crc) {
+        set_error("cto_pileup_device: the BGZF block at file offset %llu fails its CRC-32", (unsigned long long)h_blocks[hf->bad_crc - 1].file_off);
+        return CTO_EINVAL;
+    }
     if (hf->bad_chain) {
         set_error(hf->bad_chain == 2 ? "cto_pileup_device: bad alignment block size" : "cto_pileup_device: an index offset is not a record boundary");
         return CTO_EINVAL;

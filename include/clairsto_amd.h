@@ -137,7 +137,7 @@ int cto_pack_from_bam_inflated(const char* bam_path, const char* bai_path, const
  *                            *fallback = 1 (CTO_OK, nothing built): the chunk holds what this path does not do - paired reads, reference
  *                            skips (N), at least max_depth accepted reads, a column deeper than 2048 or with more than 64 distinct indel
  *                            keys - use cto_pack_from_bam[_inflated].  h_blocks: the block table on the HOST.  Synchronises `stream`
- *                            (sizes come back twice).  The BGZF CRC-32 is not checked on this path.  PARITY UNPINNED against samtools;
+ *                            (sizes come back twice).  Every block's CRC-32 is checked on the device first.  PARITY UNPINNED against samtools;
  *                            held bit-equal to cto_pack_from_bam (tests/test_gpu_pileup.py). */
 /* `samtools view BAM ctg:start-end [-q min_mq]` without samtools (src/realign_reads.py:411-416 runs that command): the alignments
  * overlapping the region as SAM rows (no header) with the eleven mandatory fields and the HP:i tag when present.  Returns the number

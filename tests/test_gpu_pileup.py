@@ -141,3 +141,38 @@ def test_device_pileup_random_regions_and_beds(tmp_path, seed):
         assert got["keys"] == want["keys"]
         nonempty += len(want["col_pos"]) > 0
     assert nonempty >= 3
+
+
+def test_device_pileup_checks_the_bgzf_crc(tmp_path):
+    """one flipped bit inside a block's payload: the DEFLATE stream breaks (inflate status) or the inflated bytes fail the gzip
+    trailer's CRC-32 (k_crc32_blocks) - the device path never succeeds with different bytes, like the host reader"""
+    import torch
+    from clairs_to_amd._lib import CtoError, lib
+    from clairs_to_amd.bgzf import DevicePileup
+    rng = np.random.default_rng(5)
+    reads = _unpaired_reads(rng, 150, [5000])
+    bam = str(tmp_path / "ok.bam")
+    write_bam(bam, [("chrA", 5000)], reads, block_payload=4000)
+    ref = "".join(rng.choice(list("ACGT"), size=5000))
+    dev = torch.device("cuda:0")
+    dp = DevicePileup()
+    pv, lite, fb = dp.pileup(bam, None, "chrA", 1, 5000, ref, 1, dev)
+    good = _device_arrays(pv, lite)["entries"]
+    lib.cto_pack_free(lite)
+    raw = open(bam, "rb").read()
+    n_err = n_same = 0
+    for off in range(18 + 8 + 200, len(raw) - 60, max(1, (len(raw) - 300) // 40)):
+        b = bytearray(raw)
+        b[off] ^= 0x08
+        p = tmp_path / "flip.bam"
+        p.write_bytes(bytes(b))
+        (tmp_path / "flip.bam.bai").write_bytes(open(bam + ".bai", "rb").read())
+        try:
+            pv, lite, fb = dp.pileup(str(p), None, "chrA", 1, 5000, ref, 1, dev)
+            if pv is not None and not fb:
+                assert np.array_equal(_device_arrays(pv, lite)["entries"], good)      # only a flip in bytes nobody reads may pass
+                lib.cto_pack_free(lite)
+            n_same += 1
+        except CtoError:
+            n_err += 1
+    assert n_err >= 25 and n_same <= 10
