@@ -64,7 +64,7 @@ def pmc_traffic_featurize(batch):
         return None
     tot = 0
     for name, v in json.load(open(fn))["kernels"].items():
-        if "k_featurize_columns" in name or "k_gather_windows" in name:
+        if "k_featurize_sites" in name:
             tot += int((FETCH_CORRECTION * v["FETCH_SIZE_KB_mean_per_launch"] + v["WRITE_SIZE_KB_mean_per_launch"]) * 1024)
     return tot or None
 
@@ -390,11 +390,11 @@ def main():
                                          % (os.path.relpath(_pmc_file(), ROOT) if _pmc_file() else "no digest committed"),
                          "launch_ms": round(mean_ms.value, 4), "launches_measured": int(n_meas),
                          "flops_per_launch": flops_per_launch},
-            "roofline_tensor_creation": {"bound": "hbm", "kernel": "k_featurize_columns + k_gather_windows (both passes, rescale fused)",
+            "roofline_tensor_creation": {"bound": "hbm", "kernel": "k_featurize_sites (one workgroup per candidate: histograms of its 33 columns in LDS, both passes, rescale fused)",
                                          "achieved": round(feat_bytes / (feat_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                          "frac": round(feat_bytes / (feat_ms * 1e-3) / 1e9 / 8000.0, 4), "launch_ms": round(feat_ms, 4),
                                          "bytes_per_launch": int(feat_bytes), "traffic": pmc_traffic_featurize(args.batch),
-                                         "note": "latency bound (short per-wave column runs, one binary search per site), not bandwidth bound; 2.5 % of the step"},
+                                         "note": "latency bound (LDS atomics on ~1650 read-bases per candidate, one binary search per site), not bandwidth bound; ~2 % of the step"},
             "end_to_end_tflops": round(2.0 * eng.macs_per_site * sites_total / dt / 1e12, 3),
             "ranks_seen": dist.get_world_size() if world > 1 else 1,
             "backend": (dist.get_backend() + (" (RCCL over xGMI)" if backend == "nccl" else " (test hook)")) if world > 1 else None,

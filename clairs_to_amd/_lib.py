@@ -86,6 +86,7 @@ SYMBOLS = {
     "cto_featurize_columns": (C.c_int, [C.POINTER(PackView), C.c_int, c_vp, c_vp, c_vp, c_vp]),
     "cto_gather_windows": (C.c_int, [C.POINTER(PackView), c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp,
                                      c_vp, c_vp, c_vp]),
+    "cto_featurize_sites": (C.c_int, [C.POINTER(PackView), c_vp, c_i64, C.c_int, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "cto_extract_candidates": (C.c_int, [C.POINTER(PackView), C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
                                          C.c_int, c_vp, c_vp, c_vp]),
     "cto_alt_info": (C.c_int, [c_vp, c_i64, C.c_int, c_vp, c_i32, c_vp, c_vp, c_vp, C.c_char_p, C.c_size_t]),

@@ -335,6 +335,298 @@ __global__ __launch_bounds__(GT) void k_gather_windows(
     }
 }
 
+// ---- both stages in one kernel, one workgroup per candidate (cto_featurize_sites) ------------------------------------------------
+// The window of a candidate is a run of consecutive pack columns (every column whose position lies in [pos - 16, pos + 16]), i.e. one
+// contiguous run of entries (~33 x 50 x 4 B): the workgroup streams it once, builds the 33 per-column histograms in LDS exactly as
+// k_featurize_columns does, finalises them there and writes the [33][34] tensors, the strand counts, the candidate column's vector
+// and its keys' counts directly - the int16 column vectors never go to HBM and back (47 MB per 4096-site chunk, 41 % of the stage's
+// traffic).  Windows that overlap (candidates closer than 33 bases) recompute the columns they share.  Same arithmetic, same results
+// as the two-kernel path, which stays for callers that want every column's vector (candidate extraction, the text seam).
+// What bounds it (rocprofv3 PMC, profiles/round3_fused_featurize.md): not HBM.  One candidate alone takes ~16 us - a chain of eight
+// dependent global accesses at ~1 us each (position, three search rounds, column probe, column tables, entries, stores) - and a CU
+// retires a candidate every ~1.4 us, with the scalar unit, the VALUs and the LDS atomics each about half busy.  So every candidate of
+// a chunk is in flight at once (128 threads and < 10 KB of LDS per workgroup = 16 workgroups per CU, 4096 on the chip), the searches
+// are 64-ary (one wave, three round trips instead of seventeen), and the per-read-base code is branch-free (one predicated LDS atomic
+// per counter family).  The histogram words (AFF count | NEG count << 16) are finalised in place to (AFF value | NEG value << 16);
+// rows are indexed by window position, not by column, so the output loop reads them as they lie.
+#ifndef CTO_FS_T
+#define CTO_FS_T 128
+#endif
+#ifndef CTO_FS_UNROLL
+#define CTO_FS_UNROLL 4
+#endif
+constexpr int FS_T = CTO_FS_T;            // threads per candidate
+constexpr int FS_W = FS_T / 64;
+constexpr int FS_KCAP = 256;              // distinct indel keys of one window counted per sweep (more: further sweeps over the entries)
+constexpr int FS_UNROLL = CTO_FS_UNROLL;  // entry loads in flight per thread
+constexpr int FS_KPT = FS_KCAP / FS_T;    // keys of a sweep per thread
+// channel of a base with MQ >= 20 and no indel, 5 bits per base code: A C G T -> 0..3, a c g t -> 9..12, '*' -> 8, '#' -> 17
+constexpr uint64_t FS_CH_LUT = 0ull | (1ull << 5) | (2ull << 10) | (3ull << 15) | (9ull << 20) | (10ull << 25) | (11ull << 30) | (12ull << 35) |
+                               (8ull << 40) | (17ull << 45);
+constexpr int FS_KMAX_WORDS = CTO_NPOS * 8;
+
+// first index in [0, n) whose col_pos is >= want (n when none), by one wave: 64 probes per round trip, three rounds for 2^18 columns
+__device__ __forceinline__ int64_t wave_lower_bound(const int32_t* __restrict__ col_pos, int64_t n, int want, int lane) {
+    int64_t lo = 0, len = n;
+    while (len > 0) {
+        const int64_t step = (len + 63) >> 6;
+        const int64_t idx = lo + int64_t(lane + 1) * step - 1;
+        const bool less = idx < lo + len && col_pos[idx] < want;
+        const int cnt = __popcll(__ballot(less));
+        const int64_t end = lo + len;
+        lo += int64_t(cnt) * step;
+        len = end - lo < step - 1 ? end - lo : step - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(FS_T) void k_featurize_sites(
+    PackDev pk, const int32_t* __restrict__ site_pos, int64_t n_sites, int min_bq, int min_rescale_cov, float* __restrict__ x_aff,
+    float* __restrict__ x_neg, int16_t* __restrict__ raw_aff, int16_t* __restrict__ raw_neg, int32_t* __restrict__ site_info,
+    int16_t* __restrict__ site_colvec, int32_t* __restrict__ sitefirst, uint32_t* __restrict__ keycnt, int32_t* __restrict__ keyfirst) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist[CTO_NPOS][HSLOTS];             // [window position][channel]
+    __shared__ __attribute__((aligned(16))) uint32_t s_kcnt[FS_KCAP];
+    // [column][strand][pass][ins, del]: largest count of one distinct key (I1 / D1 ...)
+    __shared__ __attribute__((aligned(16))) uint32_t s_kmax[CTO_NPOS][2][2][2];
+    __shared__ __attribute__((aligned(16))) int32_t s_kfirst[KFIRST_CAP][2];
+    __shared__ int32_t s_off[CTO_NPOS + 1];         // first entry of the k-th window column, relative to the window's first entry
+    __shared__ int32_t s_koff[CTO_NPOS + 1];
+    __shared__ int32_t s_slot[CTO_NPOS];            // window position (0..32) of the k-th window column
+    __shared__ int32_t s_ref[CTO_NPOS];
+    __shared__ int32_t s_depth[CTO_NPOS][2];
+    __shared__ int64_t s_clo, s_ebegin;
+    __shared__ int s_ncol, s_centre;
+    __shared__ int32_t s_first[8];
+    const int64_t site = blockIdx.x;
+    if (site >= n_sites) return;
+    const int tid = threadIdx.x;
+    const int pos = site_pos[site];
+    const int p_lo = pos - CTO_FLANK, p_hi = pos + CTO_FLANK;
+    if (tid < 64) {
+        // the window's columns: positions are strictly increasing, so they are the <= 33 columns from the lower bound of p_lo on
+        const int64_t c0 = wave_lower_bound(pk.col_pos, pk.n_cols, p_lo, tid);
+        const int64_t c = c0 + tid;
+        const int cp = (tid <= CTO_NPOS && c < pk.n_cols) ? pk.col_pos[c] : 0x7fffffff;
+        const int nc = __popcll(__ballot(cp <= p_hi));
+        const uint64_t is_centre = __ballot(cp == pos);
+        const int64_t off = (nc > 0 && tid <= nc) ? pk.col_off[c] : 0;
+        const int64_t off0 = __shfl(off, 0);
+        if (nc > 0 && tid <= nc) {
+            s_off[tid] = int32_t(off - off0);
+            s_koff[tid] = pk.key_off[c];
+            if (tid < nc) { s_slot[tid] = cp - p_lo; s_ref[tid] = pk.col_ref[c] & 3; }
+        }
+        if (tid == 0) { s_clo = c0; s_ebegin = off0; s_ncol = nc; s_centre = is_centre ? __ffsll((long long)is_centre) - 1 : -1; }
+    }
+    {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        const uint4 none = make_uint4(uint32_t(INT_NONE), uint32_t(INT_NONE), uint32_t(INT_NONE), uint32_t(INT_NONE));
+        uint4* h4 = reinterpret_cast<uint4*>(&s_hist[0][0]);
+        for (int i = tid; i < CTO_NPOS * HSLOTS / 4; i += FS_T) h4[i] = z;
+        for (int i = tid; i < FS_KCAP / 4; i += FS_T) reinterpret_cast<uint4*>(s_kcnt)[i] = z;
+        for (int i = tid; i < FS_KMAX_WORDS / 4; i += FS_T) reinterpret_cast<uint4*>(&s_kmax[0][0][0][0])[i] = z;
+        for (int i = tid; i < KFIRST_CAP * 2 / 4; i += FS_T) reinterpret_cast<uint4*>(&s_kfirst[0][0])[i] = none;
+        if (tid < 8) s_first[tid] = INT_NONE;
+    }
+    __syncthreads();
+    const int64_t c_lo = s_clo;
+    const int ncol = s_ncol;
+    const int centre = s_centre;                   // index of the candidate's own column within the window's columns, -1 without one
+    const uint32_t* __restrict__ went = pk.entries + s_ebegin;      // the window's entries
+    const int n_ent = ncol > 0 ? s_off[ncol] : 0;
+    const int kbase = ncol > 0 ? s_koff[0] : 0, nkeys = ncol > 0 ? s_koff[ncol] - kbase : 0;
+    const int ce0 = centre >= 0 ? s_off[centre] : 0;
+    const bool want_first = sitefirst != nullptr;
+    // ---- sweeps over the window's entries: the histograms in the first one, FS_KCAP distinct keys per sweep ----
+    for (int k0 = 0; k0 == 0 || k0 < nkeys; k0 += FS_KCAP) {
+        if (k0 > 0) {                               // (block-uniform) the first sweep's table was cleared above
+            for (int i = tid; i < FS_KCAP; i += FS_T) s_kcnt[i] = 0u;
+            __syncthreads();
+        }
+        uint32_t kmeta[FS_KPT];                     // this sweep's key table rows: in flight under the entries
+#pragma unroll
+        for (int j = 0; j < FS_KPT; ++j) {
+            const int k = k0 + tid + j * FS_T;
+            kmeta[j] = k < nkeys ? pk.key_meta[kbase + k] : 0u;
+        }
+        int cl = 0;
+        const bool first_sweep = k0 == 0;
+        // Entries are dealt out in 16-entry segments (one 64 B sector each), and the four 16-lane groups of a wave work in
+        // different quarters of the window: consecutive read-bases of a column mostly bump the same counter, and 64 lanes on 64
+        // consecutive entries would all queue on it.
+        const int nseg4 = (((n_ent + 15) >> 4) + 3) >> 2;                           // segments per quarter
+        const int q_base = ((tid & 63) >> 4) * nseg4 * 16 + (tid & 15);
+        for (int ib = tid >> 6; ib < nseg4; ib += FS_W * FS_UNROLL) {
+            uint32_t ents[FS_UNROLL];
+#pragma unroll
+            for (int u = 0; u < FS_UNROLL; ++u) {
+                const int i = ib + u * FS_W;
+                const int e = q_base + i * 16;
+                ents[u] = (i < nseg4 && e < n_ent) ? went[e] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < FS_UNROLL; ++u) {
+                const int i = ib + u * FS_W;
+                const int e = q_base + i * 16;
+                if (i >= nseg4 || e >= n_ent) continue;
+                while (e >= s_off[cl + 1]) ++cl;
+                // one predicated LDS atomic per counter family, the channel picked by arithmetic: the stage is bound by instruction
+                // issue, and every divergent region costs its exec-mask bookkeeping whether or not a lane enters it
+                const uint32_t ent = ents[u];
+                const uint32_t bb = ent & 15u, kind = (ent >> 4) & 3u, kid = ent >> 21;
+                const int bq = int((ent >> 6) & 127u);
+                const bool pass = bq >= min_bq, mq_ok = ((ent >> 13) & 255u) >= 20u, acgt = bb < 8u, base = kind == 0u;
+                const bool indel = (kind == 1u || kind == 2u) && mq_ok;
+                const bool fwd = (bb < 4u) || bb == 8u || bb == 10u;
+                const uint32_t inc = (pass ? 1u : 0u) | 0x10000u;
+                uint32_t* h = s_hist[s_slot[cl]];
+                // bases, '*', '#' with MQ >= 20 (`depth` sums these channels) | {ACGTacgt}LMQ | the insertion / deletion counts
+                const uint32_t ch_base = mq_ok ? uint32_t(FS_CH_LUT >> ((bb < 10u ? bb : 0u) * 5u)) & 31u : 18u + bb;
+                const uint32_t ch_indel = (kind == 1u ? 4u : 6u) + (fwd ? 0u : 9u);
+                const bool count = first_sweep && (base ? (mq_ok ? bb < 10u : acgt) : indel);
+                if (count) atomicAdd(&h[base ? ch_base : ch_indel], inc);
+                if (first_sweep && base && acgt && bq < 30) atomicAdd(&h[26u + bb], inc);       // {ACGTacgt}LBQ (threshold is always 30, F3)
+                const int kl = s_koff[cl] - kbase + int(kid) - k0;
+                if (indel && kl >= 0 && kl < FS_KCAP) atomicAdd(&s_kcnt[kl], inc);
+                // first-seen order of the alleles at the candidate column (alt_info key order, F5), as k_gather_windows
+                if (want_first && first_sweep && cl == centre && mq_ok && (base ? acgt : indel && kid < uint32_t(KFIRST_CAP))) {
+                    int32_t* const f_all = base ? &s_first[4 + (bb & 3u)] : &s_kfirst[kid][1];
+                    int32_t* const f_pass = base ? &s_first[bb & 3u] : &s_kfirst[kid][0];
+                    atomicMin(f_all, e - ce0);
+                    if (pass) atomicMin(f_pass, e - ce0);
+                }
+            }
+        }
+        __syncthreads();
+        // per column: largest count of one distinct key per strand / kind (I1, D1, i1, d1); the candidate column's counts go out
+#pragma unroll
+        for (int j = 0; j < FS_KPT; ++j) {
+            const int k = tid + j * FS_T;
+            if (k0 + k < nkeys) {
+                const int kg = kbase + k0 + k;
+                int a = 0, b = ncol;
+                while (b - a > 1) { const int m = (a + b) >> 1; if (s_koff[m] <= kg) a = m; else b = m; }
+                const uint32_t cnt = s_kcnt[k], meta = kmeta[j];
+                const int strand = (meta & 4u) ? 0 : 1, slot = ((meta & 3u) == 2u) ? 1 : 0;
+                atomicMax(&s_kmax[a][strand][0][slot], cnt & 0xffffu);
+                atomicMax(&s_kmax[a][strand][1][slot], cnt >> 16);
+                if (a == centre && keycnt) keycnt[kg] = cnt;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- finalise the columns in place: 4 lanes per column, each owns a run of channels, as k_featurize_columns ----
+    for (int c4 = tid; c4 < (ncol * 4 + FS_T - 1) / FS_T * FS_T; c4 += FS_T) {
+        const int col = c4 >> 2, part = c4 & 3;
+        const bool live = col < ncol;
+        const int ref = live ? s_ref[col] : 0;
+        const int row = live ? s_slot[col] : 0;
+        const int ch0 = part == 0 ? 0 : (part == 1 ? 9 : (part == 2 ? 18 : 26));
+        const int nch = part < 2 ? 9 : 8;
+        uint32_t hsum[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) hsum[i] = (live && i < nch) ? s_hist[row][ch0 + i] : 0u;
+        uint32_t word[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) word[i] = 0u;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            int v[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) v[i] = int(p == 0 ? (hsum[i] & 0xffffu) : (hsum[i] >> 16));
+            // depth (F4): bases, '*' / '#', insertions and deletions with MQ >= 20 = channels 0-4, 6, 8 of each strand's run
+            int dpart = part < 2 ? v[0] + v[1] + v[2] + v[3] + v[4] + v[6] + v[8] : 0;
+            dpart += __shfl_xor(dpart, 1);          // part 0 + part 1 (adjacent lanes)
+            if (live && part < 2) { v[5] = int(s_kmax[col][part][p][0]); v[7] = int(s_kmax[col][part][p][1]); }
+            // reference-channel negation of each whole 4-base group in this run (create_tensor_pileup_calling.py:223-228)
+            const int ngroups = part < 2 ? 1 : 2;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                if (g < ngroups) {
+                    const int s4 = v[g * 4] + v[g * 4 + 1] + v[g * 4 + 2] + v[g * 4 + 3];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (i == ref) v[g * 4 + i] = -s4;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) word[i] |= (uint32_t(v[i]) & 0xffffu) << (16 * p);
+            if (live && part == 0) s_depth[col][p] = dpart;
+        }
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i)
+                if (i < nch) s_hist[row][ch0 + i] = word[i];
+        }
+    }
+    __syncthreads();
+    const uint32_t (*out)[HSLOTS] = s_hist;         // [window position][channel]: AFF value | NEG value << 16
+    // ---- per-site outputs (k_gather_windows) ----
+    const bool skip = (centre < 0) || (pos - CTO_FLANK < 1);
+    const int da = centre >= 0 ? s_depth[centre][0] : 0, dn = centre >= 0 ? s_depth[centre][1] : 0;
+    if (tid < 12) {
+        int v = 0;
+        if (tid == 0) v = centre >= 0 ? int(c_lo + centre) : -1;
+        else if (tid == 1) v = da;
+        else if (tid == 2) v = dn;
+        else if (tid == 3) v = skip ? 1 : 0;
+        else if (centre >= 0) {
+            // predict.py:626-642: the negative (reference) entry becomes -(row sum) = the true ref count
+            const int st = (tid - 4) >> 2, i = (tid - 4) & 3, o = st == 0 ? 0 : 9;
+            int sum = 0, mine = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = int16_t(out[CTO_FLANK][o + j] & 0xffffu);
+                sum += c;
+                mine = j == i ? c : mine;
+            }
+            v = mine < 0 ? -sum : mine;
+        }
+        site_info[site * 12 + tid] = v;
+    }
+    if (site_colvec && tid < CTO_COLVEC_STRIDE) {
+        const int p = tid / HSLOTS, ch = tid - p * HSLOTS;
+        site_colvec[site * CTO_COLVEC_STRIDE + tid] = int16_t((out[CTO_FLANK][ch] >> (16 * p)) & 0xffffu);
+    }
+    if (want_first) {
+        const int k0 = centre >= 0 ? s_koff[centre] : 0, nk = centre >= 0 ? s_koff[centre + 1] - k0 : 0;
+        const int nk_lds = nk < KFIRST_CAP ? nk : KFIRST_CAP;
+        if (tid < 8) sitefirst[site * 8 + tid] = s_first[tid];
+        if (keyfirst) {
+            for (int k = tid; k < nk_lds; k += FS_T) { keyfirst[2 * int64_t(k0 + k)] = s_kfirst[k][0]; keyfirst[2 * int64_t(k0 + k) + 1] = s_kfirst[k][1]; }
+            if (nk > KFIRST_CAP) {
+                // block-uniform and rare: more distinct keys in the candidate column than the LDS table holds - their first-seen
+                // indices by global atomics in a pass of their own
+                const int cn = s_off[centre + 1] - ce0;
+                for (int k = KFIRST_CAP + tid; k < nk; k += FS_T) { keyfirst[2 * int64_t(k0 + k)] = INT_NONE; keyfirst[2 * int64_t(k0 + k) + 1] = INT_NONE; }
+                __threadfence();
+                __syncthreads();
+                for (int j = tid; j < cn; j += FS_T) {
+                    const uint32_t ent = went[ce0 + j];
+                    const uint32_t kind = (ent >> 4) & 3u;
+                    const int k = int(ent >> 21);
+                    if (kind == 0u || kind == 3u || k < KFIRST_CAP || int((ent >> 13) & 255u) < 20) continue;
+                    atomicMin(&keyfirst[2 * int64_t(k0 + k) + 1], j);
+                    if (int((ent >> 6) & 127u) >= min_bq) atomicMin(&keyfirst[2 * int64_t(k0 + k)], j);
+                }
+            }
+        }
+    }
+    const double sa = (min_rescale_cov > 0 && da > min_rescale_cov) ? double(min_rescale_cov) / double(da) : 1.0;
+    const double sn = (min_rescale_cov > 0 && dn > min_rescale_cov) ? double(min_rescale_cov) / double(dn) : 1.0;
+    const int64_t base = site * (CTO_NPOS * CTO_NCHAN);
+    // two channels per thread (34 per row is even; a site's tensor starts 8 B aligned): 8 B stores
+    for (int i = tid; i < CTO_NPOS * CTO_NCHAN / 2; i += FS_T) {
+        const int p = (2 * i) / CTO_NCHAN, ch = 2 * i - p * CTO_NCHAN;
+        const uint32_t w0 = skip ? 0u : out[p][ch], w1 = skip ? 0u : out[p][ch + 1];
+        const int va0 = int16_t(w0 & 0xffffu), va1 = int16_t(w1 & 0xffffu), vn0 = int16_t(w0 >> 16), vn1 = int16_t(w1 >> 16);
+        if (x_aff) *reinterpret_cast<float2*>(x_aff + base + 2 * i) = make_float2(float(double(va0) * sa), float(double(va1) * sa));
+        if (x_neg) *reinterpret_cast<float2*>(x_neg + base + 2 * i) = make_float2(float(double(vn0) * sn), float(double(vn1) * sn));
+        if (raw_aff) { raw_aff[base + 2 * i] = int16_t(va0); raw_aff[base + 2 * i + 1] = int16_t(va1); }
+        if (raw_neg) { raw_neg[base + 2 * i] = int16_t(vn0); raw_neg[base + 2 * i + 1] = int16_t(vn1); }
+    }
+}
+
 PackDev to_dev(const cto_pack_view* v) {
     PackDev d;
     d.n_cols = v->n_cols;
@@ -373,6 +665,19 @@ extern "C" int cto_gather_windows(const cto_pack_view* dp, const int16_t* colvec
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(k_gather_windows, dim3(unsigned(n_sites)), dim3(GT), 0, s, to_dev(dp), colvec, coldepth,
                        site_pos, n_sites, min_rescale_cov, x_aff, x_neg, raw_aff, raw_neg, site_info, min_bq, sitefirst,
+                       dp->n_keys > 0 ? keyfirst : nullptr);
+    CTO_HIP(hipGetLastError());
+    return CTO_OK;
+}
+
+extern "C" int cto_featurize_sites(const cto_pack_view* dp, const int32_t* site_pos, int64_t n_sites, int min_bq, int min_rescale_cov,
+                                   float* x_aff, float* x_neg, int16_t* raw_aff, int16_t* raw_neg, int32_t* site_info, int16_t* site_colvec,
+                                   int32_t* sitefirst, uint32_t* keycnt, int32_t* keyfirst, void* stream) {
+    CTO_REQUIRE(dp && site_pos && site_info, CTO_EINVAL, "cto_featurize_sites: null argument");
+    CTO_REQUIRE(dp->n_keys == 0 || !sitefirst || (keycnt && keyfirst), CTO_EINVAL, "cto_featurize_sites: key buffers missing");
+    if (n_sites == 0) return CTO_OK;
+    hipLaunchKernelGGL(k_featurize_sites, dim3(unsigned(n_sites)), dim3(FS_T), 0, static_cast<hipStream_t>(stream), to_dev(dp), site_pos, n_sites,
+                       min_bq, min_rescale_cov, x_aff, x_neg, raw_aff, raw_neg, site_info, site_colvec, sitefirst, keycnt,
                        dp->n_keys > 0 ? keyfirst : nullptr);
     CTO_HIP(hipGetLastError());
     return CTO_OK;

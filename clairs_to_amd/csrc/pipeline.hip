@@ -655,18 +655,39 @@ struct Run {
         return true;
     }
 
+    // Tensor creation of one chunk on `main`: the [33][34] inputs of both networks and what the writers need of the candidate columns.
+    // One kernel (a workgroup per candidate, the column histograms never leave LDS); CTO_FUSED_FEATURIZE=0 selects the two-stage path
+    // through the per-column vectors in HBM (kept for A/B runs - same results).
+    bool fused_featurize = true;
+    int tensors(Slot* s, int64_t n, float* x_aff, float* x_neg, int32_t* site_info, int16_t* site_colvec, int32_t* sitefirst, uint32_t* keycnt,
+                int32_t* keyfirst, hipStream_t main) {
+        int rc;
+        if (fused_featurize)
+            return cto_featurize_sites(&s->dv, s->d_site_pos, n, cfg->min_bq, cfg->min_rescale_cov, x_aff, x_neg, nullptr, nullptr, site_info, site_colvec,
+                                       sitefirst, keycnt, keyfirst, main);
+        const size_t nc = size_t(std::max<int64_t>(s->hv.n_cols, 1));
+        if ((rc = s->colvec.ensure(nc * CTO_COLVEC_STRIDE * 2)) || (rc = s->coldepth.ensure(nc * 8))) return rc;
+        auto* colvec = static_cast<int16_t*>(s->colvec.p);
+        if ((rc = cto_featurize_columns(&s->dv, cfg->min_bq, colvec, static_cast<int32_t*>(s->coldepth.p), keycnt, main))) return rc;
+        if ((rc = cto_gather_windows(&s->dv, colvec, static_cast<int32_t*>(s->coldepth.p), s->d_site_pos, n, cfg->min_bq, cfg->min_rescale_cov, x_aff,
+                                     x_neg, nullptr, nullptr, site_info, sitefirst, keyfirst, main)))
+            return rc;
+        hipLaunchKernelGGL(k_gather_rows, dim3(unsigned(n)), dim3(128), 0, main, colvec, site_info, n, site_colvec);
+        CTO_HIP(hipGetLastError());
+        return CTO_OK;
+    }
+
     int launch(Slot* s, hipStream_t main, hipStream_t copy_back, cto_model* aff, cto_model* neg) {
         const int K = cfg->K;
         const int64_t n = int64_t(s->sites.size());
-        const size_t nc = size_t(std::max<int64_t>(s->hv.n_cols, 1)), nk = size_t(std::max<int64_t>(s->hv.n_keys, 1));
+        const size_t nk = size_t(std::max<int64_t>(s->hv.n_keys, 1));
         int rc;
         // everything the writers need goes into ONE device buffer and comes back with ONE copy on the copy-back stream: seven copies
         // queued behind the kernels on the launch stream cost ~0.1 ms per chunk in which the next chunk's kernels could not start
         const size_t rbytes[7] = {size_t(n) * 48, size_t(n) * CTO_COLVEC_STRIDE * 2, size_t(n) * 32, size_t(n) * 16, size_t(n) * 8, nk * 4, nk * 8};
         size_t total = 0;
         for (int i = 0; i < 7; ++i) { s->roff[i] = total; total += (rbytes[i] + 255) / 256 * 256; }
-        if ((rc = s->colvec.ensure(nc * CTO_COLVEC_STRIDE * 2)) || (rc = s->coldepth.ensure(nc * 8)) ||
-            (rc = s->x_aff.ensure(size_t(n) * CTO_NPOS * CTO_NCHAN * 4)) || (rc = s->x_neg.ensure(size_t(n) * CTO_NPOS * CTO_NCHAN * 4)) ||
+        if ((rc = s->x_aff.ensure(size_t(n) * CTO_NPOS * CTO_NCHAN * 4)) || (rc = s->x_neg.ensure(size_t(n) * CTO_NPOS * CTO_NCHAN * 4)) ||
             (rc = s->la.ensure(size_t(K) * n * 8)) || (rc = s->ln.ensure(size_t(K) * n * 8)) || (rc = s->post.ensure(size_t(n) * K * 8)) ||
             (rc = s->res_dev.ensure(total)) || (rc = s->res_host.ensure(total)))
             return rc;
@@ -680,11 +701,8 @@ struct Run {
         auto* keyfirst = reinterpret_cast<int32_t*>(rd + s->roff[6]);
         CTO_HIP(hipStreamWaitEvent(main, s->uploaded, 0));
         CTO_HIP(hipEventRecord(s->begin, main));
-        auto* colvec = static_cast<int16_t*>(s->colvec.p);
-        if ((rc = cto_featurize_columns(&s->dv, cfg->min_bq, colvec, static_cast<int32_t*>(s->coldepth.p), keycnt, main))) return rc;
-        if ((rc = cto_gather_windows(&s->dv, colvec, static_cast<int32_t*>(s->coldepth.p), s->d_site_pos, n, cfg->min_bq,
-                                     cfg->min_rescale_cov, static_cast<float*>(s->x_aff.p), static_cast<float*>(s->x_neg.p), nullptr, nullptr, site_info,
-                                     sitefirst, keyfirst, main)))
+        if ((rc = tensors(s, n, static_cast<float*>(s->x_aff.p), static_cast<float*>(s->x_neg.p), site_info, site_colvec, sitefirst, keycnt, keyfirst,
+                          main)))
             return rc;
         const float* x_neg = cfg->neg_reads_aff ? static_cast<const float*>(s->x_aff.p) : static_cast<const float*>(s->x_neg.p);
         if ((rc = cto_model_forward(neg, x_neg, n, static_cast<float*>(s->ln.p), main))) return rc;
@@ -692,8 +710,6 @@ struct Run {
         if ((rc = cto_posterior(static_cast<const float*>(s->la.p), static_cast<const float*>(s->ln.p), K, n, cfg->d_lik, cfg->d_edges, nullptr,
                                 static_cast<double*>(s->post.p), decision, qual, main)))
             return rc;
-        hipLaunchKernelGGL(k_gather_rows, dim3(unsigned(n)), dim3(128), 0, main, colvec, site_info, n, site_colvec);
-        CTO_HIP(hipGetLastError());
         CTO_HIP(hipEventRecord(s->kernels_end, main));
         CTO_HIP(hipEventRecord(s->computed, main));
         CTO_HIP(hipStreamWaitEvent(copy_back, s->computed, 0));
@@ -767,15 +783,14 @@ struct Run {
     // one chunk into the stream; chunks whose last row came back go to *complete (in chunk order)
     int launch_stream(Slot* s, hipStream_t main, hipStream_t copy_back, cto_model* aff, cto_model* neg, std::vector<Slot*>* complete) {
         const int64_t n = int64_t(s->sites.size()), c = pending_rows();
-        const size_t nc = size_t(std::max<int64_t>(s->hv.n_cols, 1)), nk = size_t(std::max<int64_t>(s->hv.n_keys, 1));
+        const size_t nk = size_t(std::max<int64_t>(s->hv.n_keys, 1));
         const size_t row = size_t(CTO_NPOS) * CTO_NCHAN * 4;
         int rc;
         const size_t rbytes[7] = {size_t(n) * 48, size_t(n) * CTO_COLVEC_STRIDE * 2, size_t(n) * 32, size_t(n) * 16, size_t(n) * 8, nk * 4, nk * 8};
         size_t total = 0;
         for (int i = 0; i < 7; ++i) { s->roff[i] = total; total += (rbytes[i] + 255) / 256 * 256; }
         s->res_total = total;
-        if ((rc = s->colvec.ensure(nc * CTO_COLVEC_STRIDE * 2)) || (rc = s->coldepth.ensure(nc * 8)) ||
-            (rc = s->x_aff.ensure(size_t(c + n) * row)) || (rc = s->x_neg.ensure(size_t(c + n) * row)) ||
+        if ((rc = s->x_aff.ensure(size_t(c + n) * row)) || (rc = s->x_neg.ensure(size_t(c + n) * row)) ||
             (rc = s->res_dev.ensure(total)) || (rc = s->res_host.ensure(total)))
             return rc;
         char* rd = static_cast<char*>(s->res_dev.p);
@@ -791,15 +806,10 @@ struct Run {
             if (!cfg->neg_reads_aff)
                 CTO_HIP(hipMemcpyAsync(s->x_neg.p, static_cast<char*>(carry_home->x_neg.p) + size_t(carry_at) * row, size_t(c) * row, hipMemcpyDeviceToDevice, main));
         }
-        auto* colvec = static_cast<int16_t*>(s->colvec.p);
-        if ((rc = cto_featurize_columns(&s->dv, cfg->min_bq, colvec, static_cast<int32_t*>(s->coldepth.p), keycnt, main))) return rc;
-        if ((rc = cto_gather_windows(&s->dv, colvec, static_cast<int32_t*>(s->coldepth.p), s->d_site_pos, n, cfg->min_bq, cfg->min_rescale_cov,
-                                     reinterpret_cast<float*>(static_cast<char*>(s->x_aff.p) + size_t(c) * row),
-                                     reinterpret_cast<float*>(static_cast<char*>(s->x_neg.p) + size_t(c) * row), nullptr, nullptr, site_info, sitefirst,
-                                     keyfirst, main)))
+        if ((rc = tensors(s, n, reinterpret_cast<float*>(static_cast<char*>(s->x_aff.p) + size_t(c) * row),
+                          reinterpret_cast<float*>(static_cast<char*>(s->x_neg.p) + size_t(c) * row), site_info, site_colvec, sitefirst, keycnt, keyfirst,
+                          main)))
             return rc;
-        hipLaunchKernelGGL(k_gather_rows, dim3(unsigned(n)), dim3(128), 0, main, colvec, site_info, n, site_colvec);
-        CTO_HIP(hipGetLastError());
         pending.push_back({s, 0, n});
         carry_home = s;
         carry_at = 0;
@@ -1083,6 +1093,8 @@ static int run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs, int64_t
     // caller turns it off (CTO_TILE_STREAM=0: every chunk is its own launch, as before)
     static const bool stream_off = [] { const char* e = getenv("CTO_TILE_STREAM"); return e && e[0] == '0'; }();
     const bool tile_stream = !second && !stream_off;
+    static const bool fused_off = [] { const char* e = getenv("CTO_FUSED_FEATURIZE"); return e && e[0] == '0'; }();
+    run.fused_featurize = !fused_off;
     if (tile_stream) {
         int n_cu = 256;
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);

@@ -1,9 +1,11 @@
-"""Pileup-tensor creation on the GPU: host wrapper of cto_featurize_columns / cto_gather_windows.
+"""Pileup-tensor creation on the GPU: host wrapper of cto_featurize_sites (one kernel, the default) and of the two-stage path
+cto_featurize_columns / cto_gather_windows (every column's vector in HBM: candidate extraction, A/B runs).
 
 Mirrors what src/create_tensor_pileup_calling.py (reference) produces for ONE chunk of candidates, for the
 AFF pass (--min_bq <platform>) and the NEG pass (--min_bq 0) at once, plus the rescale and strand counts that
 clairs/predict.py derives from the tensor text (predict.py:172-207, 626-642)."""
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -21,21 +23,45 @@ class Features:
     raw_aff: torch.Tensor      # [n,33,34] int16 or None
     raw_neg: torch.Tensor      # [n,33,34] int16 or None
     site_info: torch.Tensor    # [n,12] int32: centre col, depth_aff, depth_neg, flags, fwd ACGT, rev ACGT
-    colvec: torch.Tensor       # [n_cols,72] int16
-    coldepth: torch.Tensor     # [n_cols,2] int32
+    colvec: torch.Tensor       # [n_cols,72] int16 (two-stage path only; None from the one-kernel path)
+    coldepth: torch.Tensor     # [n_cols,2] int32 (two-stage path only)
     sitefirst: torch.Tensor    # [n,8] int32 ([pass][A,C,G,T]) first-seen entry index within the candidate column
     keycnt: torch.Tensor       # [n_keys] int32 (uint32 bits: low16 AFF count, high16 NEG count)
     keyfirst: torch.Tensor     # [n_keys,2] int32 (per pass; defined for the keys of candidate columns only)
+    site_colvec: torch.Tensor = None   # [n,72] int16: the candidate column's own vector (one-kernel path; keycnt is then
+                                       # defined for the keys of candidate columns only, like keyfirst)
 
 
-def featurize(dev_pack, site_pos, min_bq, min_rescale_cov=50, want_raw=False, want_x=True):
-    """dev_pack: DevicePack; site_pos: int32 tensor on the same device (1-based candidate positions)."""
+def fused_default():
+    """CTO_FUSED_FEATURIZE=0 selects the two-stage path everywhere (pipeline.hip reads the same variable)."""
+    return os.environ.get("CTO_FUSED_FEATURIZE", "1") != "0"
+
+
+def featurize(dev_pack, site_pos, min_bq, min_rescale_cov=50, want_raw=False, want_x=True, fused=None):
+    """dev_pack: DevicePack; site_pos: int32 tensor on the same device (1-based candidate positions).
+    fused (default: on unless CTO_FUSED_FEATURIZE=0): one kernel, per-candidate outputs only (Features.site_colvec instead of
+    .colvec / .coldepth); the same tensors, strand counts, alt_info inputs either way."""
     dev = dev_pack.device
     if site_pos.device != dev or site_pos.dtype != torch.int32:
         site_pos = site_pos.to(device=dev, dtype=torch.int32)
     site_pos = site_pos.contiguous()
     n = site_pos.numel()
     nc, nk = dev_pack.n_cols, dev_pack.n_keys
+    if fused_default() if fused is None else fused:
+        keycnt = torch.empty((max(nk, 1),), dtype=torch.int32, device=dev)
+        keyfirst = torch.empty((max(nk, 1), 2), dtype=torch.int32, device=dev)
+        x_aff = torch.empty((n, NPOS, NCHAN), dtype=torch.float32, device=dev) if want_x else None
+        x_neg = torch.empty((n, NPOS, NCHAN), dtype=torch.float32, device=dev) if want_x else None
+        raw_aff = torch.empty((n, NPOS, NCHAN), dtype=torch.int16, device=dev) if want_raw else None
+        raw_neg = torch.empty((n, NPOS, NCHAN), dtype=torch.int16, device=dev) if want_raw else None
+        site_info = torch.empty((n, 12), dtype=torch.int32, device=dev)
+        sitefirst = torch.empty((max(n, 1), 8), dtype=torch.int32, device=dev)
+        site_colvec = torch.empty((max(n, 1), COLVEC_STRIDE), dtype=torch.int16, device=dev)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        check(lib.cto_featurize_sites(C.byref(dev_pack.view), site_pos.data_ptr(), n, int(min_bq), int(min_rescale_cov) if min_rescale_cov else 0,
+                                      ptr(x_aff), ptr(x_neg), ptr(raw_aff), ptr(raw_neg), site_info.data_ptr(), site_colvec.data_ptr(),
+                                      sitefirst.data_ptr(), keycnt.data_ptr(), keyfirst.data_ptr(), current_stream_ptr()))
+        return Features(x_aff, x_neg, raw_aff, raw_neg, site_info, None, None, sitefirst[:n], keycnt[:nk], keyfirst[:nk], site_colvec[:n])
     colvec = torch.empty((max(nc, 1), COLVEC_STRIDE), dtype=torch.int16, device=dev)   # never a null pointer
     coldepth = torch.empty((max(nc, 1), 2), dtype=torch.int32, device=dev)
     keycnt = torch.empty((max(nk, 1),), dtype=torch.int32, device=dev)
@@ -78,8 +104,10 @@ def alt_infos_packed(feat, host_pack, site_info_host=None, pass_idx=0):
     """alt_infos() without the per-site Python strings: (bytes with the strings back to back, int64 offsets [n + 1]) - the form
     cto_vcf_rows_batch consumes."""
     info = feat.site_info.cpu().numpy() if site_info_host is None else site_info_host
-    return alt_infos_from_host(host_pack, info, feat.colvec.cpu().numpy(), feat.sitefirst.cpu().numpy(), feat.keycnt.cpu().numpy(),
-                               feat.keyfirst.cpu().numpy(), pass_idx)
+    per_site = feat.site_colvec is not None
+    colvec = feat.site_colvec if per_site else feat.colvec
+    return alt_infos_from_host(host_pack, info, colvec.cpu().numpy(), feat.sitefirst.cpu().numpy(), feat.keycnt.cpu().numpy(),
+                               feat.keyfirst.cpu().numpy(), pass_idx, per_site=per_site)
 
 
 def alt_infos_from_host(host_pack, info, colvec, sitefirst, keycnt, keyfirst, pass_idx=0, per_site=False):

@@ -87,10 +87,13 @@ def launch_chunk(eng, prep, want_probs=False, pinned=None):
             sp = torch.from_numpy(np.ascontiguousarray(prep["sites"], dtype=np.int32)).to(device)
         res = eng.run_device(dp, sp)
         feat = res["features"]
-        # only the candidate columns' vectors are needed on the host (alt_info strings): gathered here, 144 B per site cross PCIe
-        # instead of 144 B per pack column (19 MB per 4096-site chunk)
-        centre = feat.site_info[:, 0].clamp(min=0).long()
-        site_colvec = feat.colvec.view(-1, feat.colvec.shape[-1]).index_select(0, centre) if feat.colvec.numel() else feat.colvec
+        # only the candidate columns' vectors are needed on the host (alt_info strings): 144 B per site cross PCIe instead of 144 B
+        # per pack column (19 MB per 4096-site chunk) - written by the one-kernel featurisation, gathered here after the two-stage one
+        if feat.site_colvec is not None:
+            site_colvec = feat.site_colvec
+        else:
+            centre = feat.site_info[:, 0].clamp(min=0).long()
+            site_colvec = feat.colvec.view(-1, feat.colvec.shape[-1]).index_select(0, centre) if feat.colvec.numel() else feat.colvec
         src = dict(site_info=feat.site_info, colvec=site_colvec, sitefirst=feat.sitefirst, keycnt=feat.keycnt, keyfirst=feat.keyfirst,
                    decision=res["decision"], qual=res["qual"])
         if want_probs:

@@ -200,6 +200,16 @@ int cto_gather_windows(const cto_pack_view* dev_pack, const int16_t* colvec, con
                        const int32_t* site_pos, int64_t n_sites, int min_bq, int min_rescale_cov,
                        float* x_aff, float* x_neg, int16_t* raw_aff, int16_t* raw_neg,
                        int32_t* site_info, int32_t* sitefirst, int32_t* keyfirst, void* stream);
+/* Both stages in ONE kernel, one workgroup per candidate: the window's entries are streamed once, the 33 column histograms live in LDS
+ * and the tensors are written directly - the int16 column vectors of Stage A never go to HBM and back.  Same results as the two calls
+ * above, for callers that need per-CANDIDATE outputs only:
+ *   site_colvec dev [n_sites][CTO_COLVEC_STRIDE] int16  the candidate column's own vector (zeros without one); may be NULL
+ *   keycnt      dev [n_keys] uint32                     written for the keys of the CANDIDATE columns only (others untouched)
+ *   everything else as cto_gather_windows.  Windows of candidates closer than 33 bases recompute the columns they share. */
+int cto_featurize_sites(const cto_pack_view* dev_pack, const int32_t* site_pos, int64_t n_sites, int min_bq, int min_rescale_cov,
+                        float* x_aff, float* x_neg, int16_t* raw_aff, int16_t* raw_neg, int32_t* site_info, int16_t* site_colvec,
+                        int32_t* sitefirst, uint32_t* keycnt, int32_t* keyfirst, void* stream);
+
 
 /* Candidate extraction (src/extract_candidates_calling.py:55-169, 322-372) on the same pack: read-bases with
  * MQ >= min_mq and BQ >= min_bq (what `samtools mpileup --min-MQ --min-BQ` would print) are counted per column,

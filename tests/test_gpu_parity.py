@@ -494,3 +494,50 @@ def test_batch_invariance_across_tile_mixes(dev, B):
         parts = torch.cat([m.logits(x[a:b].contiguous()) for a, b in zip(cuts[:-1], cuts[1:])], dim=1)
         assert torch.equal(full, parts), key
         assert torch.isfinite(full).all()
+
+
+@pytest.mark.parametrize("case", ["sparse", "dense_keys", "overlapping", "deep", "gaps"])
+def test_one_kernel_featurisation_equals_the_two_stage_path(dev, case):
+    """cto_featurize_sites (a workgroup per candidate, column histograms in LDS) against cto_featurize_columns + cto_gather_windows
+    (every column's vector through HBM): tensors, rescaled inputs, strand counts, candidate column vectors, first-seen order and
+    the key counts of the candidate columns, bit for bit.  `overlapping`: candidates 3 bases apart, so 30 of a window's 33 columns
+    are shared with its neighbours; `dense_keys`: more distinct indel keys in a window than one LDS sweep holds (several sweeps);
+    `deep`: 600x columns; `gaps`: sites at the edges of the pack and between columns (windows partly or wholly without columns)."""
+    import torch
+    from clairs_to_amd.pack import DevicePack
+    from clairs_to_amd.featurize import featurize
+    from clairs_to_amd.synth import SynthChunk
+    kw = dict(sparse=dict(n=500, spacing=40, p_ins=0.01, p_del=0.02, depth_mean=60.0),
+              dense_keys=dict(n=80, spacing=40, p_ins=0.3, p_del=0.3, depth_mean=90.0),
+              overlapping=dict(n=400, spacing=40, p_ins=0.03, p_del=0.03, depth_mean=50.0),
+              deep=dict(n=40, spacing=40, p_ins=0.02, p_del=0.02, depth_mean=600.0),
+              gaps=dict(n=200, spacing=40, p_ins=0.02, p_del=0.02, depth_mean=40.0))[case]
+    chunk = SynthChunk(kw["n"], seed=77, spacing=kw["spacing"], p_ins=kw["p_ins"], p_del=kw["p_del"], depth_mean=kw["depth_mean"])
+    dp = DevicePack(chunk.arrays(), dev)
+    sites = chunk.site_pos.astype(np.int64)
+    if case == "overlapping":
+        sites = np.unique(np.concatenate([sites + d for d in range(-15, 16, 3)]))
+    elif case == "gaps":
+        sites = np.unique(np.concatenate([sites - 30, sites + 17, sites + 20, [1, 5, 17, int(chunk.col_pos[-1]) + 1, int(chunk.col_pos[-1]) + 40]]))
+        sites = sites[sites > 0]
+    if case == "dense_keys":
+        ko = chunk.key_off
+        assert (ko[33:] - ko[:-33]).max() > 256, "a window with more keys than one sweep"
+    sp = torch.from_numpy(sites.astype(np.int32)).to(dev)
+    for min_bq, rescale in ((20, 50), (0, 0)):
+        two = featurize(dp, sp, min_bq, rescale, want_raw=True, fused=False)
+        one = featurize(dp, sp, min_bq, rescale, want_raw=True, fused=True)
+        torch.cuda.synchronize()
+        for name in ("x_aff", "x_neg", "raw_aff", "raw_neg", "site_info", "sitefirst"):
+            assert torch.equal(getattr(one, name), getattr(two, name)), name
+        info = two.site_info.cpu().numpy()
+        has = info[:, 0] >= 0
+        centre = torch.from_numpy(np.where(has, info[:, 0], 0)).long().to(dev)
+        want_cv = two.colvec.index_select(0, centre) * torch.from_numpy(has).to(dev)[:, None]
+        assert torch.equal(one.site_colvec, want_cv.to(torch.int16))
+        ko = chunk.key_off.astype(np.int64)
+        keys = np.concatenate([np.arange(ko[c], ko[c + 1]) for c in info[has, 0]] + [np.zeros(0, dtype=np.int64)]).astype(np.int64)
+        if keys.size:
+            kt = torch.from_numpy(keys).to(dev)
+            assert torch.equal(one.keycnt.index_select(0, kt), two.keycnt.index_select(0, kt))
+            assert torch.equal(one.keyfirst.index_select(0, kt), two.keyfirst.index_select(0, kt))
