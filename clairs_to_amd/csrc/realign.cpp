@@ -24,7 +24,11 @@
 // Deviations (all unreachable from `reads_realignment`, flagged): a haplotype shorter than the k-mer makes the reference index
 // past the string (unsigned wrap at realigner.cpp:157) - here CTO_EINVAL; an alignment of score 0 makes SSW read ref[-1] - here
 // "no alignment"; bytes >= 0x80 index the reference's translation table out of bounds - here they are N.
+#include <emmintrin.h>
+#include <stdlib.h>
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -57,91 +61,137 @@ struct Codes {
 };
 
 // ------------------------------------------------------------------------------------------------------------------------
-// One pass of the striped recurrence (ssw.c:118-311 for `lanes` = 16, :341-529 for 8) in scalar form.
-// ref is walked forwards (reverse = false) or backwards over [0, ref_len); the query occupies linear positions q = lane * seg + j.
+// One pass of the striped recurrence (Farrar 2007, as ssw.c:118-311 runs it on 16 unsigned bytes and :341-529 on 8 signed words):
+// the query occupies linear positions q = lane * seg + j, vector j holds the 16 (8) lanes of stripe position j.  ref is walked
+// forwards (reverse = false) or backwards over [0, ref_len).  What has to be reproduced bit for bit, because the caller's
+// CIGARs depend on it: byte arithmetic saturates and carries a bias of |mismatch|, a column whose maximum reaches 255 - bias makes the
+// caller repeat the pass on words; E never sees the corrections of the lazy-F loop; the two lazy-F loops differ (the byte one tests
+// before it corrects and wraps around the stripes, the word one corrects first and runs at most `lanes` rounds); the end position is
+// the first column that RAISES the maximum and, in that column, the smallest linear query position that holds it.
+// oracle/ssw_model.cpp states the same recurrence lane by lane in scalar code; tests hold the two and the compiled reference together.
 struct PassEnd { int score, ref_end, read_end; bool overflow; };
 
-PassEnd striped_pass(const int8_t* ref, int ref_len, bool reverse, const int8_t* read, int read_len, int lanes, int terminate) {
-    const int seg = (read_len + lanes - 1) / lanes, P = seg * lanes;
-    const bool byte_mode = lanes == 16;
-    const int bias = kMismatch;                       // ssw_init: |most negative matrix entry|
-    std::vector<int> prev(P, 0), cur(P, 0), E(P, 0), best_col(P, 0), F(lanes), Fl(lanes), hh(lanes);
-    int best = 0, ref_end = byte_mode ? -1 : 0;
+std::atomic<int> g_threads{[] { const char* e = getenv("CTO_REALIGN_THREADS"); const int n = e ? atoi(e) : 1; return n > 0 ? n : 1; }()};
+
+struct PassScratch { std::vector<__m128i> prof, h0, h1, e, hmax; };
+thread_local PassScratch t_scratch;
+
+template <bool BYTE>
+PassEnd striped_pass_t(const int8_t* ref, int ref_len, bool reverse, const int8_t* read, int read_len, int terminate) {
+    constexpr int lanes = BYTE ? 16 : 8;
+    const int seg = (read_len + lanes - 1) / lanes;
+    constexpr int bias = kMismatch;                   // ssw_init: |most negative matrix entry|
+    PassScratch& S = t_scratch;
+    const __m128i zero = _mm_setzero_si128();
+    S.prof.resize(size_t(5) * seg);
+    S.h0.assign(seg, zero);
+    S.h1.assign(seg, zero);
+    S.e.assign(seg, zero);
+    S.hmax.assign(seg, zero);
+    for (int c = 0; c < 5; ++c)                        // query profile: padding rows score 0 (profile = bias / 0)
+        for (int j = 0; j < seg; ++j) {
+            alignas(16) int8_t b8[16];
+            alignas(16) int16_t b16[8];
+            for (int l = 0; l < lanes; ++l) {
+                const int q = l * seg + j;
+                const int sc = q < read_len ? sub_score(int8_t(c), read[q]) : 0;
+                if (BYTE) b8[l] = int8_t(sc + bias); else b16[l] = int16_t(sc);
+            }
+            S.prof[size_t(c) * seg + j] = BYTE ? _mm_load_si128(reinterpret_cast<const __m128i*>(b8)) : _mm_load_si128(reinterpret_cast<const __m128i*>(b16));
+        }
+    __m128i* store = S.h0.data();
+    __m128i* load = S.h1.data();
+    __m128i* pe = S.e.data();
+    const __m128i gap_o = BYTE ? _mm_set1_epi8(kGapOpen) : _mm_set1_epi16(kGapOpen);
+    const __m128i gap_e = BYTE ? _mm_set1_epi8(kGapExt) : _mm_set1_epi16(kGapExt);
+    const __m128i vbias = _mm_set1_epi8(bias);
+    int best = 0, ref_end = BYTE ? -1 : 0;
     bool overflow = false;
     const int begin = reverse ? ref_len - 1 : 0, end = reverse ? -1 : ref_len, step = reverse ? -1 : 1;
     for (int i = begin; i != end; i += step) {
-        const int8_t rc = ref[i];
-        prev.swap(cur);                               // prev = column i-1 (final), cur = scratch
-        int colmax = 0;
-        for (int lane = 0; lane < lanes; ++lane) {
-            int f = 0;
+        const __m128i* prof = S.prof.data() + size_t(ref[i]) * seg;
+        __m128i f = zero, colmax_v = zero;
+        __m128i h = BYTE ? _mm_slli_si128(store[seg - 1], 1) : _mm_slli_si128(store[seg - 1], 2);   // H(i-1, q-1) of the stripes' first rows
+        std::swap(store, load);                       // load = column i-1 (final), store = column i
+        int colmax;
+        if (BYTE) {
             for (int j = 0; j < seg; ++j) {
-                const int q = lane * seg + j;
-                const int s = q < read_len ? sub_score(rc, read[q]) : 0;      // padding rows score 0 (profile = bias / 0)
-                int h = (q > 0 ? prev[q - 1] : 0) + s;
-                if (h < 0) h = 0;
-                const int e = E[q];
-                if (e > h) h = e;
-                if (f > h) h = f;
-                if (h > colmax) colmax = h;
-                cur[q] = h;
-                const int open = h > kGapOpen ? h - kGapOpen : 0;
-                E[q] = std::max(e > kGapExt ? e - kGapExt : 0, open);       // E never sees the lazy-F corrections below
-                f = std::max(f > kGapExt ? f - kGapExt : 0, open);
+                h = _mm_subs_epu8(_mm_adds_epu8(h, prof[j]), vbias);
+                __m128i e = pe[j];
+                h = _mm_max_epu8(_mm_max_epu8(h, e), f);
+                colmax_v = _mm_max_epu8(colmax_v, h);
+                store[j] = h;
+                h = _mm_subs_epu8(h, gap_o);
+                pe[j] = _mm_max_epu8(_mm_subs_epu8(e, gap_e), h);                   // E never sees the lazy-F corrections below
+                f = _mm_max_epu8(_mm_subs_epu8(f, gap_e), h);
+                h = load[j];
             }
-            F[lane] = f;
-        }
-        // lazy F: the F chain that leaves stripe k enters stripe k+1
-        auto shift = [&](std::vector<int>& v) { for (int l = lanes - 1; l > 0; --l) v[l] = v[l - 1]; v[0] = 0; };
-        Fl = F;
-        if (byte_mode) {                              // ssw.c:207-241
-            shift(Fl);
+            // lazy F: the F chain that leaves stripe k enters stripe k + 1 (ssw.c:207-241)
+            f = _mm_slli_si128(f, 1);
             int j = 0;
-            for (;;) {
-                bool settled = true;
-                for (int l = 0; l < lanes; ++l) {
-                    const int h = cur[l * seg + j];
-                    if (Fl[l] > (h > kGapOpen ? h - kGapOpen : 0)) { settled = false; break; }
-                }
-                if (settled) break;
-                for (int l = 0; l < lanes; ++l) {
-                    int& h = cur[l * seg + j];
-                    if (Fl[l] > h) h = Fl[l];
-                    if (h > colmax) colmax = h;
-                    Fl[l] = Fl[l] > kGapExt ? Fl[l] - kGapExt : 0;
-                }
-                if (++j >= seg) { j = 0; shift(Fl); }
+            while (_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_subs_epu8(f, _mm_subs_epu8(store[j], gap_o)), zero)) != 0xffff) {
+                h = _mm_max_epu8(store[j], f);
+                colmax_v = _mm_max_epu8(colmax_v, h);
+                store[j] = h;
+                f = _mm_subs_epu8(f, gap_e);
+                if (++j >= seg) { j = 0; f = _mm_slli_si128(f, 1); }
             }
-        } else {                                      // ssw.c:446-459
-            bool done = false;
+            __m128i m = _mm_max_epu8(colmax_v, _mm_srli_si128(colmax_v, 8));
+            m = _mm_max_epu8(m, _mm_srli_si128(m, 4));
+            m = _mm_max_epu8(m, _mm_srli_si128(m, 2));
+            m = _mm_max_epu8(m, _mm_srli_si128(m, 1));
+            colmax = _mm_cvtsi128_si32(m) & 0xff;
+        } else {
+            for (int j = 0; j < seg; ++j) {
+                h = _mm_adds_epi16(h, prof[j]);
+                __m128i e = pe[j];
+                h = _mm_max_epi16(_mm_max_epi16(h, e), f);
+                colmax_v = _mm_max_epi16(colmax_v, h);
+                store[j] = h;
+                h = _mm_subs_epu16(h, gap_o);
+                pe[j] = _mm_max_epi16(_mm_subs_epu16(e, gap_e), h);
+                f = _mm_max_epi16(_mm_subs_epu16(f, gap_e), h);
+                h = load[j];
+            }
+            bool done = false;                        // ssw.c:446-459
             for (int k = 0; k < lanes && !done; ++k) {
-                shift(Fl);
+                f = _mm_slli_si128(f, 2);
                 for (int j = 0; j < seg; ++j) {
-                    bool any = false;
-                    for (int l = 0; l < lanes; ++l) {
-                        int& h = cur[l * seg + j];
-                        if (Fl[l] > h) h = Fl[l];
-                        if (h > colmax) colmax = h;
-                        hh[l] = h > kGapOpen ? h - kGapOpen : 0;
-                        Fl[l] = Fl[l] > kGapExt ? Fl[l] - kGapExt : 0;
-                        if (Fl[l] > hh[l]) any = true;
-                    }
-                    if (!any) { done = true; break; }
+                    h = _mm_max_epi16(store[j], f);
+                    colmax_v = _mm_max_epi16(colmax_v, h);
+                    store[j] = h;
+                    h = _mm_subs_epu16(h, gap_o);
+                    f = _mm_subs_epu16(f, gap_e);
+                    if (!_mm_movemask_epi8(_mm_cmpgt_epi16(f, h))) { done = true; break; }
                 }
             }
+            __m128i m = _mm_max_epi16(colmax_v, _mm_srli_si128(colmax_v, 8));
+            m = _mm_max_epi16(m, _mm_srli_si128(m, 4));
+            m = _mm_max_epi16(m, _mm_srli_si128(m, 2));
+            colmax = int16_t(_mm_cvtsi128_si32(m) & 0xffff);
         }
         if (colmax > best) {
             best = colmax;
-            if (byte_mode && best + bias >= 255) { overflow = true; break; }
+            if (BYTE && best + bias >= 255) { overflow = true; break; }
             ref_end = i;
-            best_col = cur;
+            memcpy(S.hmax.data(), store, size_t(seg) * sizeof(__m128i));
         }
         if (colmax == terminate) break;
     }
     int read_end = read_len - 1;
-    for (int q = 0; q < P; ++q)
-        if (best_col[q] == best) { if (q < read_end) read_end = q; break; }
+    bool found = false;
+    for (int l = 0; l < lanes && !found; ++l)
+        for (int j = 0; j < seg; ++j) {
+            const int v = BYTE ? int(reinterpret_cast<const uint8_t*>(S.hmax.data())[j * 16 + l])
+                               : int(reinterpret_cast<const int16_t*>(S.hmax.data())[j * 8 + l]);
+            if (v == best) { const int q = l * seg + j; if (q < read_end) read_end = q; found = true; break; }
+        }
     return {overflow ? 255 : best, ref_end, read_end, overflow};
+}
+
+PassEnd striped_pass(const int8_t* ref, int ref_len, bool reverse, const int8_t* read, int read_len, int lanes, int terminate) {
+    return lanes == 16 ? striped_pass_t<true>(ref, ref_len, reverse, read, read_len, terminate)
+                       : striped_pass_t<false>(ref, ref_len, reverse, read, read_len, terminate);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -480,24 +530,44 @@ int realign_window(const std::vector<std::string>& reads, const int32_t* positio
         st.pos_map = positions_map(st.cigar, hap.size());
     }
 
-    // Smith-Waterman for the reads no haplotype took (:351-384)
-    std::vector<Codes> hapc;
+    // Smith-Waterman for the reads no haplotype took (:351-384).  Reads are independent (each owns its slot of every haplotype's hit
+    // list), so they are dealt to g_threads workers when the caller allows more than one (cto_set_realign_threads; default 1, as the
+    // reference's one process per chunk).
+    std::vector<int> todo;
     for (int r = 0; r < n; ++r) {
         bool taken = false;
         for (const HapState& st : hs) if (st.hits[r].score > 0) { taken = true; break; }
-        if (taken) continue;
-        if (hapc.empty()) for (const std::string& h : haps) hapc.emplace_back(h.data(), h.size());
-        const Codes rc(reads[r].data(), reads[r].size());
-        for (HapState& st : hs) {
-            if (st.score == 0) continue;
-            const SwAlignment al = sw_align(hapc[st.index].v, rc.v);
-            if (al.score > 0 && al.score >= kSswThreshold && st.hits[r].score < al.score) {
-                st.hits[r].score = al.score;
-                st.hits[r].cigar = al.cigar;
-                st.hits[r].position = al.ref_begin;
-                st.hits[r].exact = false;
-            }
-        }
+        if (!taken) todo.push_back(r);
+    }
+    if (!todo.empty()) {
+        std::vector<Codes> hapc;
+        for (const std::string& h : haps) hapc.emplace_back(h.data(), h.size());
+        std::atomic<size_t> next{0};
+        std::atomic<bool> failed{false};
+        auto work = [&]() {
+            try {
+                for (size_t k = next++; k < todo.size() && !failed; k = next++) {
+                    const int r = todo[k];
+                    const Codes rc(reads[r].data(), reads[r].size());
+                    for (HapState& st : hs) {
+                        if (st.score == 0) continue;
+                        const SwAlignment al = sw_align(hapc[st.index].v, rc.v);
+                        if (al.score > 0 && al.score >= kSswThreshold && st.hits[r].score < al.score) {
+                            st.hits[r].score = al.score;
+                            st.hits[r].cigar = al.cigar;
+                            st.hits[r].position = al.ref_begin;
+                            st.hits[r].exact = false;
+                        }
+                    }
+                }
+            } catch (...) { failed = true; }
+        };
+        const int nt = int(std::min<size_t>(size_t(std::max(1, g_threads.load())), todo.size()));
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+        work();
+        for (std::thread& t : pool) t.join();
+        CTO_REQUIRE(!failed, CTO_ENOMEM, "cto_realign_reads: a Smith-Waterman worker failed (out of memory)");
     }
 
     // the reference's std::sort by haplotype score (:108); ties keep whatever order that algorithm leaves them in
@@ -571,6 +641,22 @@ extern "C" int cto_realign_reads(int n_reads, const char* const* seqs, const int
 CTO_CATCH("cto_realign_reads", int)
 
 // Smith-Waterman alone (test hook and building block): query against ref, CIGAR text over S = X I D as SSW's C++ wrapper prints it.
+// Worker threads of the Smith-Waterman stage of cto_realign_reads (>= 1; also CTO_REALIGN_THREADS).  Results do not depend on it.
+extern "C" int cto_set_realign_threads(int n) {
+    CTO_REQUIRE(n >= 1 && n <= 1024, CTO_EINVAL, "cto_set_realign_threads: %d", n);
+    g_threads = n;
+    return CTO_OK;
+}
+
+// One striped pass alone (test hook: tests compare it with oracle/ssw_model.cpp): codes 0..4, out[4] = {score, ref_end, read_end, overflow}
+extern "C" int cto_ssw_pass(const int8_t* ref, int ref_len, int reverse, const int8_t* read, int read_len, int lanes, int terminate, int32_t* out) try {
+    CTO_REQUIRE(ref && read && out && ref_len >= 0 && read_len > 0 && (lanes == 16 || lanes == 8), CTO_EINVAL, "cto_ssw_pass: bad argument");
+    const PassEnd e = striped_pass(ref, ref_len, reverse != 0, read, read_len, lanes, terminate);
+    out[0] = e.score; out[1] = e.ref_end; out[2] = e.read_end; out[3] = e.overflow ? 1 : 0;
+    return CTO_OK;
+}
+CTO_CATCH("cto_ssw_pass", int)
+
 extern "C" int cto_ssw_align(const char* ref, const char* query, int32_t* score, int32_t* ref_begin, char* cigar_buf, size_t cigar_cap) try {
     CTO_REQUIRE(ref && query && score && ref_begin && cigar_buf && cigar_cap > 0, CTO_EINVAL, "cto_ssw_align: bad argument");
     const SwAlignment al = sw_align(Codes(ref, strlen(ref)).v, Codes(query, strlen(query)).v);

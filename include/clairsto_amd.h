@@ -457,6 +457,13 @@ int cto_realign_reads(int n_reads, const char* const* seqs, const int32_t* posit
                       const char* reference, const char* haplotypes, int32_t ref_start, int32_t ref_prefix, int32_t ref_suffix,
                       int32_t* out_positions, char* cigar_buf, size_t cigar_cap, int64_t* cigar_off);
 int cto_ssw_align(const char* ref, const char* query, int32_t* score, int32_t* ref_begin, char* cigar_buf, size_t cigar_cap);
+/* One striped Smith-Waterman pass alone (ssw.c:118-311 / :341-529 of the reference's src/realign: sw_sse2_byte / sw_sse2_word), test
+ * hook: ref / read are base codes 0..4, lanes 16 (bytes) or 8 (words), out[4] = {score (255 on 8-bit overflow), ref_end, read_end,
+ * overflow}. */
+int cto_ssw_pass(const int8_t* ref, int ref_len, int reverse, const int8_t* read, int read_len, int lanes, int terminate, int32_t* out);
+/* Worker threads of the Smith-Waterman stage inside cto_realign_reads (reads no haplotype took with <= 2 mismatches): default 1 (the
+ * reference runs one single-threaded process per chunk), environment CTO_REALIGN_THREADS; output independent of the count. */
+int cto_set_realign_threads(int n);
 int cto_dbg_consensus(const char* ref, int n_reads, const char* const* reads, const int32_t* lowbq, const int64_t* lowbq_off,
                       char* buf, size_t cap, size_t* used);
 

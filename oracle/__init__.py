@@ -13,11 +13,38 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "liboracle.so")
 
 
+_SSW_LIB = os.path.join(_HERE, "libsswmodel.so")
+
+
 def build(force=False):
-    src = os.path.join(_HERE, "cto_oracle.c")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+    stale = False
+    for lib_, src in ((_LIB, "cto_oracle.c"), (_SSW_LIB, "ssw_model.cpp")):
+        src = os.path.join(_HERE, src)
+        stale = stale or not os.path.exists(lib_) or os.path.getmtime(lib_) < os.path.getmtime(src)
+    if force or stale:
         subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
     return _LIB
+
+
+_ssw = None
+
+
+def ssw_pass(ref_codes, read_codes, lanes, reverse=False, terminate=None):
+    """Scalar model of one striped Smith-Waterman pass (oracle/ssw_model.cpp): (score, ref_end, read_end, overflow).
+    ref_codes / read_codes: int8 arrays of base codes 0..4."""
+    global _ssw
+    if _ssw is None:
+        build()
+        _ssw = C.CDLL(_SSW_LIB)
+        _ssw.orc_ssw_pass.restype = None
+    ref_codes = np.ascontiguousarray(ref_codes, dtype=np.int8)
+    read_codes = np.ascontiguousarray(read_codes, dtype=np.int8)
+    out = np.zeros(4, dtype=np.int32)
+    if terminate is None:
+        terminate = 255 if lanes == 16 else 65535
+    _ssw.orc_ssw_pass(_p(ref_codes), C.c_int(len(ref_codes)), C.c_int(int(bool(reverse))), _p(read_codes), C.c_int(len(read_codes)),
+                      C.c_int(lanes), C.c_int(int(terminate)), _p(out))
+    return int(out[0]), int(out[1]), int(out[2]), bool(out[3])
 
 
 _lib = None

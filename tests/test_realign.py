@@ -3,7 +3,8 @@
 Pins: (1) tests/golden/realign.json.gz - what the reference's `realign_reads` (src/realign/realigner.cpp:782-869, compiled here by
 `make -C oracle ref`) returned on 640 synthetic windows, regenerated inputs checked by SHA-256; (2) when oracle/_ref/ is present,
 fresh windows against the compiled reference itself; (3) the reference-ABI shim libraries (clairs_to_amd/realign/*.so), called the
-way src/realign_reads.py:532-615 calls the reference's modules.  The de Bruijn consensus has no compiled reference here (Boost):
+way src/realign_reads.py:532-615 calls the reference's modules; (4) the striped Smith-Waterman pass alone (SSE2 in the product)
+against its scalar model in oracle/ssw_model.cpp.  The de Bruijn consensus has no compiled reference here (Boost):
 hand-derived vectors and properties only - PARITY UNPINNED."""
 import ctypes as C
 import gzip
@@ -60,6 +61,79 @@ def test_realign_reads_full_window_of_a_thousand_reads():
     rng = np.random.default_rng(7)
     w = ru.gen_window(rng, n_reads=1000)
     assert ru.amd_realign(w) == ru.ref_realign(w)
+
+
+def _random_pair(rng, it):
+    R, Q = int(rng.integers(2, 400)), int(rng.integers(2, 260))
+    style = it % 4
+    if style == 0:                                   # unrelated
+        ref, read = rng.integers(0, 4, R), rng.integers(0, 4, Q)
+    elif style == 1:                                 # a piece of ref with substitutions, insertions and deletions
+        ref = rng.integers(0, 4, R)
+        a = int(rng.integers(0, R))
+        read = ref[a:min(R, a + Q)].copy()
+        for _ in range(int(rng.integers(0, 6))):
+            if len(read) < 4:
+                break
+            k, op = int(rng.integers(0, len(read))), int(rng.integers(0, 3))
+            if op == 0:
+                read[k] = (read[k] + 1) % 4
+            elif op == 1:
+                read = np.concatenate([read[:k], rng.integers(0, 4, int(rng.integers(1, 12))), read[k:]])
+            else:
+                read = np.concatenate([read[:k], read[min(len(read), k + int(rng.integers(1, 12))):]])
+        if len(read) == 0:
+            read = ref[:1].copy()
+    elif style == 2:                                 # tandem repeats and N: many equal-score cells, long F chains
+        unit = rng.integers(0, 4, int(rng.integers(1, 4)))
+        ref, read = np.tile(unit, R // len(unit) + 1)[:R].copy(), np.tile(unit, Q // len(unit) + 1)[:Q].copy()
+        if rng.random() < 0.5:
+            read[int(rng.integers(0, Q))] = 4
+        if rng.random() < 0.5:
+            ref[int(rng.integers(0, R))] = 4
+    else:                                            # a long exact match: the 8-bit pass overflows
+        ref = rng.integers(0, 4, R)
+        a = int(rng.integers(0, max(1, R - 70)))
+        read = ref[a:a + min(Q, R - a)].copy()
+    return np.ascontiguousarray(ref, dtype=np.int8), np.ascontiguousarray(read, dtype=np.int8)
+
+
+def test_striped_pass_equals_the_scalar_model():
+    """The SSE2 pass of the product (cto_ssw_pass) against oracle/ssw_model.cpp - the lane-by-lane scalar statement of the same
+    recurrence that was pinned to the compiled reference - on both widths, both directions, with and without the early stop."""
+    import oracle
+    from clairs_to_amd._lib import lib, check
+    rng = np.random.default_rng(11)
+    overflowed = stopped = 0
+    for it in range(1500):
+        ref, read = _random_pair(rng, it)
+        for lanes in (16, 8):
+            for reverse in (False, True):
+                term = 255 if lanes == 16 else 65535
+                if reverse and it % 3 == 0:
+                    term = oracle.ssw_pass(ref, read, lanes, False)[0]
+                    stopped += 1
+                want = oracle.ssw_pass(ref, read, lanes, reverse, term)
+                out = np.zeros(4, dtype=np.int32)
+                check(lib.cto_ssw_pass(ref.ctypes.data, len(ref), int(reverse), read.ctypes.data, len(read), lanes, term, out.ctypes.data))
+                assert (int(out[0]), int(out[1]), int(out[2]), bool(out[3])) == want, (it, lanes, reverse, term)
+                overflowed += int(want[3])
+    assert overflowed > 300 and stopped > 500
+
+
+def test_realign_reads_does_not_depend_on_the_thread_count():
+    from clairs_to_amd._lib import lib, check
+    rng = np.random.default_rng(21)
+    wins = [ru.gen_window(rng, n_reads=n) for n in (40, 120, 7, 300)]
+    try:
+        check(lib.cto_set_realign_threads(1))
+        want = [ru.amd_realign(w) for w in wins]
+        for nt in (2, 5, 16):
+            check(lib.cto_set_realign_threads(nt))
+            assert [ru.amd_realign(w) for w in wins] == want
+    finally:
+        check(lib.cto_set_realign_threads(1))
+    assert lib.cto_set_realign_threads(0) != 0
 
 
 def test_ssw_known_answers():
