@@ -109,6 +109,8 @@ SYMBOLS = {
     "cto_ssw_align": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(c_i32), C.POINTER(c_i32), c_vp, C.c_size_t]),
     "cto_ssw_pass": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),
     "cto_set_realign_threads": (C.c_int, [C.c_int]),
+    "cto_realign_read_evidence": (c_i64, [C.c_char_p, c_i64, C.c_char_p, c_i64, C.c_char_p, c_i64, C.c_char_p, c_i64, c_i64, c_i64, c_i64, C.c_int,
+                                          c_vp, c_i64]),
     "cto_dbg_consensus": (C.c_int, [C.c_char_p, C.c_int, c_vp, c_vp, c_vp, c_vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "cto_vcf_rows_batch": (c_i64, [C.c_char_p, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_double,
                                    c_vp, C.c_size_t, c_vp]),

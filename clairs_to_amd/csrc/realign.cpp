@@ -641,6 +641,66 @@ extern "C" int cto_realign_reads(int n_reads, const char* const* seqs, const int
 CTO_CATCH("cto_realign_reads", int)
 
 // Smith-Waterman alone (test hook and building block): query against ref, CIGAR text over S = X I D as SSW's C++ wrapper prints it.
+// The evidence a read contributes to the window search of `reads_realignment` (src/realign_reads.py:306-352; the per-base loop of
+// clairs_to_amd/realign_reads.py:RegionRealigner.feed, which is where that module's time went): every reference position the read
+// contradicts - a mismatch with BQ >= min_bq on an A/C/G/T reference base; positions [p - n, p + n) around an insertion or soft clip
+// of n bases none of which is below min_bq; the n positions of a deletion; the last two only inside [lo_ok, hi_ok] and next to an
+// A/C/G/T reference base.  One entry of `out` per increment.  `bq` is the SAM text (phred + 33).  Indexing follows the Python it
+// replaces (a negative reference index counts from the end); anything that would raise there - or more than `cap` increments -
+// returns -1 and the caller runs the Python loop, so errors stay the reference's errors.
+extern "C" int64_t cto_realign_read_evidence(const char* seq, int64_t seq_len, const char* bq, int64_t bq_len, const char* cigar, int64_t start,
+                                             const char* ref, int64_t ref_len, int64_t ref0, int64_t lo_ok, int64_t hi_ok, int min_bq,
+                                             int32_t* out, int64_t cap) {
+    if (!seq || !bq || !cigar || !ref || !out) return -1;
+    auto acgt = [](char c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; };
+    auto ref_at = [&](int64_t i, char& c) { if (i < 0) i += ref_len; if (i < 0 || i >= ref_len) return false; c = ref[i]; return true; };
+    const int thr = min_bq + 33;
+    int64_t rp = start, qp = 0, used = 0, n = 0;
+    auto range = [&](int64_t a, int64_t b) {
+        if (b - a > cap - used) return false;
+        for (int64_t p = a; p < b; ++p) out[used++] = int32_t(p);
+        return true;
+    };
+    for (const char* c = cigar; *c; ++c) {
+        if (*c >= '0' && *c <= '9') { n = n * 10 + (*c - '0'); if (n > (int64_t(1) << 40)) return -1; continue; }
+        const char op = *c;
+        if (op == '=') { rp += n; qp += n; }
+        else if (op == 'M' || op == 'X') {
+            for (int64_t k = 0; k < n; ++k, ++rp, ++qp) {
+                if (qp >= bq_len) return -1;
+                if ((unsigned char)bq[qp] - 0 >= thr) {
+                    char rb;
+                    if (!ref_at(rp - ref0, rb)) return -1;
+                    if (acgt(rb)) {
+                        if (qp >= seq_len) return -1;
+                        if (seq[qp] != rb) { if (used >= cap) return -1; out[used++] = int32_t(rp); }
+                    }
+                }
+            }
+        } else if (op == 'I' || op == 'S') {
+            if (lo_ok <= rp && rp <= hi_ok) {
+                char rb;
+                if (!ref_at(rp - ref0 - 1, rb)) return -1;
+                if (acgt(rb)) {
+                    bool low = false;
+                    for (int64_t k = qp; k < qp + n && k < bq_len && !low; ++k) low = (unsigned char)bq[k] < thr;
+                    if (!low && !range(rp - n, rp + n)) return -1;
+                }
+            }
+            qp += n;
+        } else if (op == 'D') {
+            if (lo_ok <= rp && rp <= hi_ok) {
+                char rb;
+                if (!ref_at(rp - ref0 - 1, rb)) return -1;
+                if (acgt(rb) && !range(rp, rp + n)) return -1;
+            }
+            rp += n;
+        }
+        n = 0;
+    }
+    return used;
+}
+
 // Worker threads of the Smith-Waterman stage of cto_realign_reads (>= 1; also CTO_REALIGN_THREADS).  Results do not depend on it.
 extern "C" int cto_set_realign_threads(int n) {
     CTO_REQUIRE(n >= 1 && n <= 1024, CTO_EINVAL, "cto_set_realign_threads: %d", n);

@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--kinds", default="text,bam")
     ap.add_argument("--reference-chunk-sites", type=int, default=0,
                     help="also run the text leg on chunk files of this many candidates (the reference cuts 10 000: shared/param.py:21)")
+    ap.add_argument("--producers", type=int, default=None)
+    ap.add_argument("--writers", type=int, default=2)
     ap.add_argument("--pipeline", default="native", choices=["native", "python"],
                     help="cto_run_chunks (csrc/pipeline.hip) or call_chunks.run_pipeline; same files either way")
     a = ap.parse_args()
@@ -115,10 +117,11 @@ def main():
     for kind in a.kinds.split(","):
         n = a.chunks if kind == "text" else (a.bam_chunks or max(2, a.chunks // 3))
         out["mpileup_text_to_vcf" if kind == "text" else "bam_to_vcf"] = measure(eng, kind=kind, n_chunks=n, sites_per_chunk=a.batch,
-                                                                                 pipeline=a.pipeline)
+                                                                                 producers=a.producers, writers=a.writers, pipeline=a.pipeline)
     if a.reference_chunk_sites > 0 and "text" in a.kinds.split(","):
         n = max(4, a.chunks * a.batch // a.reference_chunk_sites)
-        out["mpileup_text_to_vcf_reference_chunks"] = measure(eng, kind="text", n_chunks=n, sites_per_chunk=a.reference_chunk_sites, pipeline=a.pipeline)
+        out["mpileup_text_to_vcf_reference_chunks"] = measure(eng, kind="text", n_chunks=n, sites_per_chunk=a.reference_chunk_sites,
+                                                              producers=a.producers, writers=a.writers, pipeline=a.pipeline)
     print(json.dumps(out))
 
 

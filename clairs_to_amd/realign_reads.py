@@ -102,7 +102,7 @@ class Read(object):
     def __init__(self, name, flag, start, mq, cigar, seq, raw_bq, rnext, pnext, hp):
         self.name, self.flag, self.start, self.mq, self.cigar, self.seq, self.raw_bq = name, flag, start, mq, cigar, seq, raw_bq
         self.rnext, self.pnext, self.hp = rnext, pnext, hp
-        self.bq = [ord(c) - 33 for c in raw_bq]
+        self.bq = raw_bq.encode("latin-1")            # phred + 33 per base (compare against threshold + 33)
         self.end = start + len(seq) + (sum(n for op, n in _cigar_ops(cigar) if op == "D") if "D" in cigar else 0)     # :92-98
         self.best_cigar, self.best_pos, self.best_score = cigar, start, None
 
@@ -142,6 +142,11 @@ class RegionRealigner(object):
         self.reads = {}
         self.evidence = {}
         self.chunk_start = self.chunk_end = None
+        try:
+            self._ref_b = reference_sequence.encode("ascii")
+        except UnicodeEncodeError:
+            self._ref_b = b""                          # the C scan then declines every read and the Python loop runs
+        self._ev_buf = (C.c_int32 * 8192)()
 
     # ---- rows in
     def _count(self, lo, hi):
@@ -172,22 +177,37 @@ class RegionRealigner(object):
         if mq < MIN_DBG_MQ:
             return
         ref, ref0, bq = self.ref, self.ref0, read.bq
-        rp, qp = start, 0
         lo_ok, hi_ok = self.chunk_start - EXPAND, self.chunk_end + EXPAND
+        # the per-base scan in C (cto_realign_read_evidence); -1 = it met something the Python loop below would raise on
+        cap = len(self._ev_buf)
+        try:
+            seq_b = seq.encode("ascii")
+        except UnicodeEncodeError:
+            seq_b = None
+        k = -1 if seq_b is None else lib.cto_realign_read_evidence(seq_b, len(seq_b), bq, len(bq), cigar.encode("latin-1"), start, self._ref_b,
+                                                                   len(self._ref_b), ref0, lo_ok, hi_ok, MIN_DBG_BQ, self._ev_buf, cap)
+        if k >= 0:
+            ev, buf = self.evidence, self._ev_buf
+            for i in range(k):
+                p = buf[i]
+                ev[p] = ev.get(p, 0) + 1
+            return
+        rp, qp = start, 0
+        thr = MIN_DBG_BQ + 33
         for op, n in _cigar_ops(cigar):
             if op == "=":
                 rp += n
                 qp += n
             elif op == "M" or op == "X":
                 for _ in range(n):
-                    if bq[qp] >= MIN_DBG_BQ:
+                    if bq[qp] >= thr:
                         rb = ref[rp - ref0]
                         if rb in "ACGT" and seq[qp] != rb:
                             self.evidence[rp] = self.evidence.get(rp, 0) + 1
                     rp += 1
                     qp += 1
             elif op == "I" or op == "S":
-                if lo_ok <= rp <= hi_ok and ref[rp - ref0 - 1] in "ACGT" and not any(q < MIN_DBG_BQ for q in bq[qp:qp + n]):
+                if lo_ok <= rp <= hi_ok and ref[rp - ref0 - 1] in "ACGT" and not any(q < thr for q in bq[qp:qp + n]):
                     self._count(rp - n, rp + n)
                 qp += n
             elif op == "D":
@@ -265,7 +285,7 @@ class RegionRealigner(object):
             if r.mq < GRAPH_MIN_MQ or r.start > we or r.end < ws:
                 continue
             graph_reads.append(r.seq)
-            graph_lowbq.append([i for i, q in enumerate(r.bq) if q < GRAPH_LOW_BQ])
+            graph_lowbq.append([i for i, q in enumerate(r.bq) if q < GRAPH_LOW_BQ + 33])
         consensus = self.consensus_fn(centre, graph_reads, graph_lowbq)
         if not consensus or (len(consensus) == 1 and consensus[0] == centre) or not names:
             return

@@ -464,6 +464,13 @@ int cto_ssw_pass(const int8_t* ref, int ref_len, int reverse, const int8_t* read
 /* Worker threads of the Smith-Waterman stage inside cto_realign_reads (reads no haplotype took with <= 2 mismatches): default 1 (the
  * reference runs one single-threaded process per chunk), environment CTO_REALIGN_THREADS; output independent of the count. */
 int cto_set_realign_threads(int n);
+/* Reference positions one read contradicts (src/realign_reads.py:306-352: mismatches with BQ >= min_bq on A/C/G/T reference bases,
+ * [p - n, p + n) around clean insertions / soft clips, deleted positions; the last two only inside [lo_ok, hi_ok]): one entry of out per
+ * increment of the evidence counter.  bq = SAM quality text, positions 0-based, ref covers [ref0, ref0 + ref_len).  Returns the count,
+ * or -1 when the Python loop it replaces would raise (index out of range) or cap is too small - the caller then runs that loop. */
+int64_t cto_realign_read_evidence(const char* seq, int64_t seq_len, const char* bq, int64_t bq_len, const char* cigar, int64_t start,
+                                  const char* ref, int64_t ref_len, int64_t ref0, int64_t lo_ok, int64_t hi_ok, int min_bq,
+                                  int32_t* out, int64_t cap);
 int cto_dbg_consensus(const char* ref, int n_reads, const char* const* reads, const int32_t* lowbq, const int64_t* lowbq_off,
                       char* buf, size_t cap, size_t* used);
 

@@ -163,3 +163,48 @@ def test_realign_variants_without_samtools(flow, tmp_path):
                                            enable_realignment=True, is_indel=False, bam_reader="native"))
     assert open(out).read() == g["vcf"]
     assert len(failed) >= 8
+
+
+def test_evidence_scan_in_c_equals_the_python_loop(flow, monkeypatch):
+    """RegionRealigner.feed counts a read's evidence in C (cto_realign_read_evidence) and keeps the Python loop for whatever the C
+    side declines: the same SAM text with the C scan switched off, and the same counters on reads with every CIGAR operation."""
+    import random
+    from clairs_to_amd import realign_reads as rr
+    g, sim, paths = flow
+    pos = int(sorted(g["positions"])[0])
+    want = io.StringIO()
+    rr.reads_realignment(_args(paths, pos), out=want)
+
+    real = rr.lib
+
+    class NoScan(object):
+        def __getattr__(self, name):
+            if name == "cto_realign_read_evidence":
+                return lambda *a: -1
+            return getattr(real, name)
+    monkeypatch.setattr(rr, "lib", NoScan())
+    got = io.StringIO()
+    rr.reads_realignment(_args(paths, pos), out=got)
+    monkeypatch.setattr(rr, "lib", real)
+    assert got.getvalue() == want.getvalue() and want.getvalue().count("\n") > 100
+
+    rnd = random.Random(4)
+    ref = "".join(rnd.choice("ACGTN") for _ in range(3000))
+    for trial in range(300):
+        ops, qlen = [], 0
+        for _ in range(rnd.randint(1, 7)):
+            op, n = rnd.choice("MMM=XIDSNH"), rnd.randint(1, 30)
+            ops.append("%d%s" % (n, op))
+            qlen += n if op in "M=XIS" else 0
+        cigar = "".join(ops)
+        seq = "".join(rnd.choice("ACGT") for _ in range(max(qlen, 1)))
+        bq = "".join(chr(33 + rnd.choice((5, 19, 20, 21, 35))) for _ in seq)
+        start = rnd.randint(1100, 1500)
+        row = "r%d\t%d\t%s\t%d\t60\t%s\t=\t1\t0\t%s\t%s\n" % (trial, rnd.choice((0, 16)), realignsim.CTG, start + 1, cigar, seq, bq)
+        a = rr.RegionRealigner(realignsim.CTG, ref, 1000, 1300)
+        a.feed(row, io.StringIO())
+        monkeypatch.setattr(rr, "lib", NoScan())
+        b = rr.RegionRealigner(realignsim.CTG, ref, 1000, 1300)
+        b.feed(row, io.StringIO())
+        monkeypatch.setattr(rr, "lib", real)
+        assert a.evidence == b.evidence, cigar
