@@ -332,9 +332,8 @@ def main():
                      "ms_per_step_min_window": round(min(wins), 4), "ms_per_step_max_window": round(max(wins), 4),
                      "note": "configs[1]'s whole job (1M sites in %d-site steps) back to back on the resident packs; windows timed by events on the launch stream" % args.batch}
         l1_ms, l1_macs = C.c_double(0.0), C.c_int64(0)
-        check(lib.cto_model_profile_read_stage(eng.h_neg, 1, C.byref(l1_ms), C.byref(l1_macs)))       # layer-1 events of the timed region
         check(lib.cto_model_profile(eng.h_aff, 1))
-        check(lib.cto_model_profile(eng.h_neg, 1))
+        check(lib.cto_model_profile(eng.h_neg, 2))            # layer 1 bracketed too
         for i in range(20):
             step(i)
         torch.cuda.synchronize()
@@ -353,17 +352,28 @@ def main():
                        "note": "mean of 20 launches each, HIP events on the launch stream (cto_model_profile); cvt = its three launches (one per stage, all blocks of the stage inside)"}
 
     # ---- secondary roofline: pileup-tensor creation (HBM-bound stage), timed on its own after the timed region ----
+    # (the C entry on preallocated outputs, one event pair per launch: through featurize() the eight allocations of a call take as
+    # long as the kernel, and a slow host core would be what is measured)
     from clairs_to_amd.featurize import featurize
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    for i in range(2):
-        featurize(packs[i % args.pool], sites[i % args.pool], min_bq, 50)
-    ev[0].record()
-    n_feat = 8
-    for i in range(n_feat):
-        featurize(packs[i % args.pool], sites[i % args.pool], min_bq, 50)
-    ev[1].record()
+    from clairs_to_amd._lib import current_stream_ptr
+    f0 = featurize(packs[0], sites[0], min_bq, 50)
+    nk_max = max(max(p.n_keys for p in packs), 1)
+    kc = torch.empty((nk_max,), dtype=torch.int32, device=dev)
+    kf = torch.empty((nk_max, 2), dtype=torch.int32, device=dev)
+    n_feat = 16
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_feat)]
+    sptr = current_stream_ptr()
+    for i in range(-2, n_feat):
+        j = i % args.pool
+        if i >= 0:
+            evs[i][0].record()
+        check(lib.cto_featurize_sites(C.byref(packs[j].view), sites[j].data_ptr(), args.batch, int(min_bq), 50, f0.x_aff.data_ptr(),
+                                      f0.x_neg.data_ptr(), None, None, f0.site_info.data_ptr(), f0.site_colvec.data_ptr(),
+                                      f0.sitefirst.data_ptr(), kc.data_ptr(), kf.data_ptr(), sptr))
+        if i >= 0:
+            evs[i][1].record()
     torch.cuda.synchronize()
-    feat_ms = ev[0].elapsed_time(ev[1]) / n_feat
+    feat_ms = sum(a.elapsed_time(b) for a, b in evs) / n_feat
     # algorithmic bytes: the pack once (4 B per read-base + column tables) + two fp32 [33][34] tensors per site
     feat_bytes = pack_bytes + 2 * 33 * 34 * 4 * args.batch
 
@@ -394,7 +404,7 @@ def main():
                                          "achieved": round(feat_bytes / (feat_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                          "frac": round(feat_bytes / (feat_ms * 1e-3) / 1e9 / 8000.0, 4), "launch_ms": round(feat_ms, 4),
                                          "bytes_per_launch": int(feat_bytes), "traffic": pmc_traffic_featurize(args.batch),
-                                         "note": "latency bound (LDS atomics on ~1650 read-bases per candidate, one binary search per site), not bandwidth bound; ~2 % of the step"},
+                                         "note": "latency / issue bound, not bandwidth bound (a chain of ~8 dependent global accesses per candidate; scalar unit, VALU and LDS each about half busy: profiles/round3_fused_featurize.md); ~2 % of the step"},
             "end_to_end_tflops": round(2.0 * eng.macs_per_site * sites_total / dt / 1e12, 3),
             "ranks_seen": dist.get_world_size() if world > 1 else 1,
             "backend": (dist.get_backend() + (" (RCCL over xGMI)" if backend == "nccl" else " (test hook)")) if world > 1 else None,

@@ -93,7 +93,8 @@ struct cto_model {
     bool fuse_embed = true;    // stage embedding + LayerNorm inside the stage's first block (CTO_CVT_NO_EMBED_FUSE=1 disables)
     bool fuse_head = true;     // fc1 + classifier tail inside the network's last block (CTO_CVT_NO_HEAD_FUSE=1 disables)
     // live kernel timing (cto_model_profile)
-    bool prof = false;
+    bool prof = false;          // the dominant kernel is bracketed by events
+    bool prof_all = false;      // ... and BiGRU layer 1 too (cto_model_profile(m, 2))
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev1;     // BiGRU layer 1 (cto_model_profile_read_stage, stage 1)
     int64_t prof_macs = 0;
@@ -441,9 +442,9 @@ int prof_begin(cto_model* m, hipStream_t s, hipEvent_t* e0, hipEvent_t* e1) {
 int bigru_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStream_t s) {
     int rc;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (m->prof && (rc = prof_begin(m, s, &e0, &e1))) return rc;
+    if (m->prof_all && (rc = prof_begin(m, s, &e0, &e1))) return rc;
     if ((rc = launch_gru_layer1(s, x, m->gw1, m->gb1, m->b_h, B))) return rc;
-    if (m->prof) {
+    if (m->prof_all) {
         CTO_HIP(hipEventRecord(e1, s));
         m->prof_ev1.emplace_back(e0, e1);
     }
@@ -634,6 +635,7 @@ extern "C" int cto_model_forward(cto_model* m, const float* x, int64_t B, float*
 extern "C" int cto_model_profile(cto_model* m, int enable) {
     CTO_REQUIRE(m, CTO_EINVAL, "cto_model_profile: null model");
     m->prof = enable != 0;
+    m->prof_all = enable == 2;
     // per-site MACs of the measured kernel: BiGRU layer 2 (both directions) incl. the fused fc1, or the whole CvT
     m->prof_macs = m->kind == 1 ? int64_t(33) * 2 * 3 * 192 * (256 + 192) + int64_t(33) * 384 * 128 : m->macs;
     return CTO_OK;

@@ -280,14 +280,15 @@ int cto_model_forward(cto_model* m, const float* x, int64_t B, float* logits, vo
 int64_t cto_model_macs_per_site(const cto_model* m);
 int  cto_model_n_out(const cto_model* m);
 void cto_model_destroy(cto_model* m);
-/* Live kernel timing for roofline accounting: when enabled, the dominant kernel of the model (BiGRU: the
- * layer-2 recurrent kernel; CvT: the whole forward) is bracketed by HIP events on the launch stream.
+/* Live kernel timing for roofline accounting: when enabled (1), the dominant kernel of the model (BiGRU: the
+ * layer-2 recurrent kernel; CvT: the whole forward) is bracketed by HIP events on the launch stream; 2 brackets BiGRU layer 1 as
+ * well (an event pair costs the stream ~6 us of dispatch gap per launch, so the timed region of bench.py uses 1).
  * cto_model_profile_read waits for the recorded events, returns the number of launches measured since the
  * last read, writes their mean duration in milliseconds and the algorithmic multiply-accumulates of ONE site
  * in that kernel (launch MACs = per-site MACs x batch). */
 int cto_model_profile(cto_model* m, int enable);
 int cto_model_profile_read(cto_model* m, double* mean_ms, int64_t* macs_per_site);
-/* The same for one more kernel of the model: stage 0 = the above, stage 1 = BiGRU layer 1 (bracketed whenever profiling is on).
+/* The same for one more kernel of the model: stage 0 = the above, stage 1 = BiGRU layer 1 (bracketed in mode 2).
  * Its events are kept until read; stage 1 of a CvT handle is CTO_EINVAL. */
 int cto_model_profile_read_stage(cto_model* m, int stage, double* mean_ms, int64_t* macs_per_site);
 
