@@ -397,8 +397,11 @@ __global__ __launch_bounds__(FS_T) void k_featurize_sites(
     __shared__ int64_t s_clo, s_ebegin;
     __shared__ int s_ncol, s_centre;
     __shared__ int32_t s_first[8];
-    const int64_t site = blockIdx.x;
-    if (site >= n_sites) return;
+    // Workgroups are dealt to the 8 XCDs in turn: XCD x takes the x-th eighth of the (sorted) candidates, so that neighbouring windows -
+    // which share columns when candidates are closer than 33 bases - meet in one L2 instead of being fetched into eight
+    const int64_t per_xcd = (n_sites + 7) >> 3;
+    const int64_t site = int64_t(blockIdx.x & 7u) * per_xcd + int64_t(blockIdx.x >> 3);
+    if (int64_t(blockIdx.x >> 3) >= per_xcd || site >= n_sites) return;
     const int tid = threadIdx.x;
     const int pos = site_pos[site];
     const int p_lo = pos - CTO_FLANK, p_hi = pos + CTO_FLANK;
@@ -676,7 +679,7 @@ extern "C" int cto_featurize_sites(const cto_pack_view* dp, const int32_t* site_
     CTO_REQUIRE(dp && site_pos && site_info, CTO_EINVAL, "cto_featurize_sites: null argument");
     CTO_REQUIRE(dp->n_keys == 0 || !sitefirst || (keycnt && keyfirst), CTO_EINVAL, "cto_featurize_sites: key buffers missing");
     if (n_sites == 0) return CTO_OK;
-    hipLaunchKernelGGL(k_featurize_sites, dim3(unsigned(n_sites)), dim3(FS_T), 0, static_cast<hipStream_t>(stream), to_dev(dp), site_pos, n_sites,
+    hipLaunchKernelGGL(k_featurize_sites, dim3(unsigned(((n_sites + 7) >> 3) << 3)), dim3(FS_T), 0, static_cast<hipStream_t>(stream), to_dev(dp), site_pos, n_sites,
                        min_bq, min_rescale_cov, x_aff, x_neg, raw_aff, raw_neg, site_info, site_colvec, sitefirst, keycnt,
                        dp->n_keys > 0 ? keyfirst : nullptr);
     CTO_HIP(hipGetLastError());

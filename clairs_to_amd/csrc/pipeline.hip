@@ -662,7 +662,9 @@ struct Run {
     int tensors(Slot* s, int64_t n, float* x_aff, float* x_neg, int32_t* site_info, int16_t* site_colvec, int32_t* sitefirst, uint32_t* keycnt,
                 int32_t* keyfirst, hipStream_t main) {
         int rc;
-        if (fused_featurize)
+        // heavily overlapping windows (candidates a few bases apart) share most of their columns: the one-kernel path would histogram
+        // them once per candidate, the two-stage path once (measured equal at ~8 columns per candidate; same results either way)
+        if (fused_featurize && s->hv.n_cols >= 8 * n)
             return cto_featurize_sites(&s->dv, s->d_site_pos, n, cfg->min_bq, cfg->min_rescale_cov, x_aff, x_neg, nullptr, nullptr, site_info, site_colvec,
                                        sitefirst, keycnt, keyfirst, main);
         const size_t nc = size_t(std::max<int64_t>(s->hv.n_cols, 1));

@@ -47,7 +47,9 @@ def featurize(dev_pack, site_pos, min_bq, min_rescale_cov=50, want_raw=False, wa
     site_pos = site_pos.contiguous()
     n = site_pos.numel()
     nc, nk = dev_pack.n_cols, dev_pack.n_keys
-    if fused_default() if fused is None else fused:
+    # default: one kernel unless the windows overlap so much (< 8 pack columns per candidate) that histogramming every column once
+    # and gathering is cheaper - the same rule as csrc/pipeline.hip; results are identical
+    if (fused_default() and nc >= 8 * n) if fused is None else fused:
         keycnt = torch.empty((max(nk, 1),), dtype=torch.int32, device=dev)
         keyfirst = torch.empty((max(nk, 1), 2), dtype=torch.int32, device=dev)
         x_aff = torch.empty((n, NPOS, NCHAN), dtype=torch.float32, device=dev) if want_x else None
