@@ -356,7 +356,7 @@ def main():
     # long as the kernel, and a slow host core would be what is measured)
     from clairs_to_amd.featurize import featurize
     from clairs_to_amd._lib import current_stream_ptr
-    f0 = featurize(packs[0], sites[0], min_bq, 50)
+    f0 = featurize(packs[0], sites[0], min_bq, 50, fused=True)
     nk_max = max(max(p.n_keys for p in packs), 1)
     kc = torch.empty((nk_max,), dtype=torch.int32, device=dev)
     kf = torch.empty((nk_max, 2), dtype=torch.int32, device=dev)
