@@ -122,6 +122,7 @@ SYMBOLS = {
     "cto_model_profile_read": (C.c_int, [c_vp, C.POINTER(C.c_double), C.POINTER(c_i64)]),
     "cto_model_profile_read_stage": (C.c_int, [c_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(c_i64)]),
     "cto_posterior": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "cto_qual_finalize": (c_i64, [c_vp, c_vp, c_i64]),
     "cto_softmax_probs": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, c_vp, c_vp]),
     "cto_posterior_from_probs": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
 }

@@ -38,7 +38,8 @@ class Posterior:
 
     def __call__(self, aff_logits, neg_logits, want_probs=True):
         """aff/neg logits float32 [K,B,2] on the device -> dict(probs [B,2K,2] f32, post [B,K] f64,
-        decision [B,4] i32 (argmax, clamped, -, -), qual [B] f64)."""
+        decision [B,4] i32 (argmax, flags, posterior bits of a flagged site), qual [B] f64).  Host copies of decision / qual go
+        through finalize_qual() before QUAL is read (cto_vcf_rows_batch does it itself)."""
         K, B = aff_logits.shape[0], aff_logits.shape[1]
         assert K == self.K and neg_logits.shape == aff_logits.shape
         dev = aff_logits.device
@@ -64,6 +65,16 @@ class Posterior:
         check(lib.cto_posterior_from_probs(p1.data_ptr(), K, B, self.lik.data_ptr(), self.edges.data_ptr(),
                                            post.data_ptr(), dec.data_ptr(), qual.data_ptr(), current_stream_ptr()))
         return dict(post=post, decision=dec, qual=qual)
+
+
+def finalize_qual(decision, qual):
+    """Host half of QUAL (call_variants.py:79-88 uses the host's math.log): decision int32 [n,4] and qual float64 [n], HOST numpy
+    arrays as downloaded from the epilogue, are completed in place - the sites the device flagged as sitting on a 4-decimal
+    rounding boundary (decision[:,1] bit 2, about two in a million) are re-evaluated with the host libm, flag and posterior
+    bits cleared.  Returns the number of sites rewritten."""
+    assert decision.dtype == np.int32 and decision.flags.c_contiguous and decision.flags.writeable and decision.shape[-1] == 4
+    assert qual.dtype == np.float64 and qual.flags.c_contiguous and qual.flags.writeable and qual.size * 4 == decision.size
+    return int(check(int(lib.cto_qual_finalize(decision.ctypes.data, qual.ctypes.data, int(qual.size)))))
 
 
 def parse_alt_info(alt_info):
@@ -224,6 +235,7 @@ def call_variants_from_probability(args, device="cuda"):
             p1 = np.array([[float(f.split()[1]) for f in r[6:6 + 2 * K]] for r in rows], dtype=np.float64)
             o = post.from_probs(torch.from_numpy(p1).to(device))
             dec, qual = o["decision"].cpu().numpy(), o["qual"].cpu().numpy()
+            finalize_qual(dec, qual)
             for i, r in enumerate(rows):
                 if dec[i, 1]:
                     print("[WARNING] %s:%s probability 1.00000000 falls outside the likelihood bins (the reference "

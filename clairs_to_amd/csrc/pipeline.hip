@@ -898,7 +898,7 @@ struct Run {
             if (counts[3]) {
                 const int32_t* dec = h_decision;
                 for (int64_t i = 0; i < n; ++i)
-                    if (dec[i * 4 + 1])
+                    if (dec[i * 4 + 1] & 3)
                         fprintf(stderr, "[WARNING] %s:%d a probability printed as 1.00000000 / 0.00000000 falls outside the likelihood bins (the "
                                 "reference raises IndexError here); %s\n", j.ctg_name, s->sites[size_t(i)],
                                 (dec[i * 4 + 1] & 2) ? "no posterior, site skipped" : "bin clamped");

@@ -36,11 +36,18 @@ __device__ inline int digitize(double x, const double* edges) {   // np.digitize
 // Python's round(q, 4) (call_variants.py:88): the EXACT binary value of q rounded to 4 decimals, ties to even, then the
 // double nearest to that decimal.  rint(q * 1e4) alone rounds the already-rounded product and can land on the other side of
 // a ...5 boundary; the product's rounding error is recovered exactly with one fma (q * 1e4 = hi + lo as real numbers).
-__device__ __forceinline__ double round4(double q) {
+//
+// *near_tie: q * 1e4 lies within 1e-6 of a ...5 boundary.  The device's log() may differ from the host libm's in its last bit
+// (|dq| ~ 1e-14), which can only change round(q, 4) for such a q: those sites (about two in a million) are flagged in
+// decision[.][1] bit 2 and carry the winning posterior's bits in decision[.][2..3], and the host re-evaluates them with ITS
+// libm - the one the reference's math.log would use on this machine (cto_qual_finalize, cto_vcf_rows_batch).
+__device__ __forceinline__ double round4(double q, bool* near_tie) {
+    *near_tie = false;
     if (!(q == q)) return q;
     const double hi = q * 1e4, lo = fma(q, 1e4, -hi);
     double r = rint(hi);
     const double d = (hi - r) + lo;                 // exact: |hi - r| <= 0.5 and lo is tiny
+    *near_tie = fabs(fabs(d) - 0.5) < 1e-6;
     const bool odd = fmod(r, 2.0) != 0.0;
     if (d > 0.5 || (d == 0.5 && odd)) r += 1.0;
     else if (d < -0.5 || (d == -0.5 && odd)) r -= 1.0;
@@ -96,12 +103,15 @@ __global__ __launch_bounds__(256) void k_posterior(const float* __restrict__ aff
     // bit 0: a bin index was clamped (the reference raises IndexError on this site); bit 1: the winning posterior is NaN
     // (only possible together with bit 0) - the host must not format a row from it
     decision[b * 4 + 1] = clamped | ((bestv != bestv) ? 2 : 0);
-    decision[b * 4 + 2] = 0;
-    decision[b * 4 + 3] = 0;
     const double phred = -10.0 * (1.0 / 2.302585092994046);   // -10 * log(e, 10)
     double q = phred * log(((1.0 - bestv) + 1e-10) / (bestv + 1e-10)) + 2.0;
     q = q > 0.0 ? q : 0.0;
-    qual[b] = round4(q);
+    bool near_tie;
+    qual[b] = round4(q, &near_tie);
+    const long long bits = near_tie ? __double_as_longlong(bestv) : 0ll;
+    if (near_tie) decision[b * 4 + 1] |= 4;
+    decision[b * 4 + 2] = int32_t(bits & 0xffffffffll);
+    decision[b * 4 + 3] = int32_t((bits >> 32) & 0xffffffffll);
 }
 
 __global__ __launch_bounds__(256) void k_softmax_probs(const float* __restrict__ aff, const float* __restrict__ neg, int K,

@@ -77,6 +77,54 @@ bool parse_alt_info(const char* s, int len, std::vector<Allele>& out, long long*
 
 }  // namespace
 
+namespace {
+// QUAL of one site as the reference's quality_score_from + round(q, 4) evaluate it on THIS host (clairs/call_variants.py:79-88:
+// math.log is the C library's log).  The device epilogue flags the sites whose q * 1e4 lies within 1e-6 of a ...5 boundary
+// (decision[.][1] bit 2) and leaves the winning posterior's bits in decision[.][2..3]: for those - and only for those - a last-bit
+// difference between the device's log() and the host's could print a different 4th decimal, so they are re-evaluated here.
+double host_qual(double p) {
+#pragma clang fp contract(off)
+    const double phred = -10.0 * (1.0 / 2.302585092994046);   // -10 * log(e, 10)
+    double q = phred * std::log(((1.0 - p) + 1e-10) / (p + 1e-10)) + 2.0;
+    q = q > 0.0 ? q : 0.0;
+    if (!(q == q)) return q;
+    // Python's round(q, 4): exact value of q to 4 decimals, ties to even (q * 1e4 = hi + lo exactly, one fma)
+    const double hi = q * 1e4, lo = std::fma(q, 1e4, -hi);
+    double r = std::nearbyint(hi);
+    const double d = (hi - r) + lo;
+    const bool odd = std::fmod(r, 2.0) != 0.0;
+    if (d > 0.5 || (d == 0.5 && odd)) r += 1.0;
+    else if (d < -0.5 || (d == -0.5 && odd)) r -= 1.0;
+    return r / 1e4;
+}
+inline double flagged_posterior(const int32_t* dec) {
+    const uint64_t bits = uint64_t(uint32_t(dec[2])) | (uint64_t(uint32_t(dec[3])) << 32);
+    double p;
+    memcpy(&p, &bits, 8);
+    return p;
+}
+}  // namespace
+
+// Host half of the QUAL evaluation: rewrites qual[i] of every site the device flagged as sitting on a rounding boundary with the host
+// libm's value, clears the flag (decision[i][1] bit 2) and the posterior bits (decision[i][2..3]); afterwards decision is
+// {argmax, flags (bits 0-1), 0, 0} and qual is exactly what clairs/call_variants.py:79-88 prints on this machine.  Idempotent.
+// Returns the number of sites rewritten.  cto_vcf_rows_batch does the same on the fly, so a caller that only formats rows
+// need not call this.
+extern "C" int64_t cto_qual_finalize(int32_t* decision, double* qual, int64_t n) {
+    if (n <= 0) return 0;
+    CTO_REQUIRE(decision && qual, CTO_EINVAL, "cto_qual_finalize: null argument");
+    int64_t fixed = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        int32_t* dec = decision + i * 4;
+        if (!(dec[1] & 4)) continue;
+        qual[i] = host_qual(flagged_posterior(dec));
+        dec[1] &= ~4;
+        dec[2] = dec[3] = 0;
+        ++fixed;
+    }
+    return fixed;
+}
+
 // One chunk of sites -> VCF data rows (each terminated by '\n') in `buf`.
 //   chrom                 contig name
 //   pos[n]                1-based positions
@@ -113,8 +161,8 @@ extern "C" int64_t cto_vcf_rows_batch(const char* chrom, int64_t n, const int32_
         const int argmax = decision[i * 4];
         CTO_REQUIRE(argmax >= 0 && argmax < K, CTO_EINVAL, "cto_vcf_rows_batch: site %lld has arg-max %d outside [0, %d)", (long long)i,
                     argmax, K);
-        if (decision[i * 4 + 1]) ++n_clamped;
-        const double q = qual[i];
+        if (decision[i * 4 + 1] & 3) ++n_clamped;
+        const double q = (decision[i * 4 + 1] & 4) ? host_qual(flagged_posterior(decision + i * 4)) : qual[i];
         // 0/0 posterior (both heads of the winner printed as 0.00000000): the reference raises IndexError on this site
         // (call_variants.py:193); there is no posterior to format a row from - counted as clamped, reported by the caller
         if ((decision[i * 4 + 1] & 2) || std::isnan(q)) continue;

@@ -166,6 +166,20 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> posterior(const Tensor& aff, const Te
                                probs.data_ptr<float>(), post.data_ptr<double>(), dec.data_ptr<int32_t>(), qual.data_ptr<double>(),
                                stream_of(a)),
                  "posterior");
+    if (B > 0) {
+        // host half of QUAL (cto_qual_finalize): the op hands back final values, so it looks at the flags here - one 16 B/site
+        // copy and a stream synchronisation per call; the flagged sites (about two in a million) are re-evaluated with the host libm
+        Tensor dec_h = dec.cpu();
+        const int32_t* d = dec_h.data_ptr<int32_t>();
+        bool any = false;
+        for (int64_t i = 0; i < B && !any; ++i) any = (d[i * 4 + 1] & 4) != 0;
+        if (any) {
+            Tensor qual_h = qual.cpu();
+            check_rc(int(cto_qual_finalize(dec_h.data_ptr<int32_t>(), qual_h.data_ptr<double>(), B)) < 0 ? -1 : 0, "qual_finalize");
+            dec.copy_(dec_h);
+            qual.copy_(qual_h);
+        }
+    }
     return {probs, post, dec, qual};
 }
 std::tuple<Tensor, Tensor, Tensor, Tensor> posterior_meta(const Tensor& aff, const Tensor&, const Tensor&, const Tensor&) {

@@ -132,7 +132,7 @@ def finish_chunk(args, K, prep, launched):
     for _ in range(cnt["low_coverage"]):
         print("low tumor coverage")                                  # call_variants.py:328, one line per such site
     if cnt["clamped"]:
-        for i in np.nonzero(dec[:, 1])[0]:
+        for i in np.nonzero(dec[:, 1] & 3)[0]:
             print("[WARNING] %s:%d a probability printed as 1.00000000 / 0.00000000 falls outside the likelihood bins (the "
                   "reference raises IndexError here); %s" % (args.ctg_name, sites[i], "no posterior, site skipped" if dec[i, 1] & 2
                                                              else "bin clamped"), file=sys.stderr)

@@ -304,12 +304,21 @@ int cto_model_profile_read_stage(cto_model* m, int stage, double* mean_ms, int64
  *   decision dev [B][4] int32      {argmax (np.argmax: first maximum, a NaN first), flags, 0, 0}; flags bit 0 = a bin index
  *                                  was clamped (the reference raises IndexError there: a probability printed as 1.00000000
  *                                  or 0.00000000), bit 1 = the winning posterior is NaN (0/0; only together with bit 0):
- *                                  no row can be formatted for that site
- *   qual  dev [B] double           quality_score_from(max posterior), rounded to 4 dp
+ *                                  no row can be formatted for that site; bit 2 = QUAL sits within 1e-10 of a 4-decimal
+ *                                  rounding boundary, [2..3] then hold the bits of the winning posterior (cto_qual_finalize)
+ *   qual  dev [B] double           quality_score_from(max posterior), rounded to 4 dp (call_variants.py:79-88)
  * ---------------------------------------------------------------------------------------------- */
 int cto_posterior(const float* aff_logits, const float* neg_logits, int K, int64_t B,
                   const double* lik, const double* edges, float* probs, double* post,
                   int32_t* decision, double* qual, void* stream);
+
+/* Host half of QUAL (clairs/call_variants.py:79-88: math.log is the host C library's log).  The device's log() may differ from
+ * the host's in the last bit, which changes round(q, 4) only for a q within ~1e-14 of a ...5 boundary; cto_posterior flags
+ * every site within 1e-10 of one (about two in a million).  This call, on HOST copies of decision / qual, re-evaluates the
+ * flagged sites with the host libm, clears the flag and the posterior bits - afterwards decision[i] = {argmax, flags (bits 0-1),
+ * 0, 0} and qual[i] is bit for bit what the reference prints on this machine.  Idempotent; returns the number of sites rewritten.
+ * cto_vcf_rows_batch applies the same rule itself. */
+int64_t cto_qual_finalize(int32_t* decision, double* qual, int64_t n);
 
 /* Only the 2-way softmax of clairs/predict.py:659-684: probs dev [B][2K][2] in the order the probability text
  * rows use (a c g t [i d] na nc ng nt [ni nd]). */
