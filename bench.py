@@ -88,18 +88,22 @@ def usable_cores():
 
 
 def cpu_baseline(chunks, models, lik, edges, min_bq, n_sample, budget_s=12.0):
-    """CPU oracle (scalar C port of the reference path, OpenMP over sites) on a bounded sample of the same job:
-    the first n_sample sites of as many resident chunks as fit in ~budget_s seconds (at least one)."""
+    """CPU port of the reference path (oracle/cto_oracle.c, OpenMP over sites) on a bounded sample of the same job: the first
+    n_sample sites of as many resident chunks as fit in ~budget_s seconds (at least one).  Timed on the SPEED build of that
+    source (-O3 -march=native -ffast-math, compiled on this host: oracle.build_fast), which is first held to the -O2
+    -ffp-contract=off checker build on 64 sites (integer tensors equal, probabilities within 1e-6); the checker build's own rate
+    on a small sample is reported beside it, and so is the genuine reference's (measured in the build container, it cannot travel)."""
     import numpy as np
     import oracle
     oracle.build()
+    fast_lib = oracle.build_fast()
     cores = usable_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)
     cfg = dict(emb_dim=(16, 64, 128), heads=(1, 3, 4), depth=(1, 2, 3), n_out=N_OUT)
     from concurrent.futures import ThreadPoolExecutor
-    total_sites, total_t, first_probs = 0, 0.0, None
-    for chunk in chunks:
-        sites = chunk.site_pos[:n_sample]
+
+    def run_sample(chunk, n):
+        sites = chunk.site_pos[:n]
         ref, lo = chunk.ref_window()
         # tensor creation is per-site independent too: the sample is cut into one slice of sites per core, each with the
         # mpileup rows of its own windows (untimed input prep), and the slices run on a thread pool (the C calls drop the GIL)
@@ -120,15 +124,43 @@ def cpu_baseline(chunks, models, lik, edges, min_bq, n_sample, budget_s=12.0):
         la = oracle.cvt_forward(models["aff_weights"], cfg, xa)
         ln = oracle.bigru_forward(models["neg_weights"], N_OUT, xn)
         probs, post, dec, qual = oracle.posterior(la, ln, lik, edges)
-        total_t += time.perf_counter() - t0
-        total_sites += len(sites)
-        if first_probs is None:
-            first_probs = probs
-        if total_t >= budget_s:
-            break
+        return time.perf_counter() - t0, (ta, tn, probs)
+
+    n_chk = min(64, n_sample)
+    n_slow = min(512, n_sample)
+    t_slow, (ta0, tn0, p0) = run_sample(chunks[0], n_slow)            # checker build (-O2 -ffp-contract=off)
+    oracle.use_library(fast_lib)
+    try:
+        _, (ta1, tn1, p1) = run_sample(chunks[0], n_chk)
+        assert np.array_equal(ta0[:n_chk], ta1) and np.array_equal(tn0[:n_chk], tn1), "speed build of the CPU port: tensors differ from the checker build"
+        dev_max = float(np.abs(p0[:n_chk] - p1).max())
+        assert dev_max < 1e-6, "speed build of the CPU port differs from the checker build by %g" % dev_max
+        total_sites, total_t, first_probs = 0, 0.0, None
+        for chunk in chunks:
+            dt, (_, _, probs) = run_sample(chunk, n_sample)
+            total_t += dt
+            total_sites += min(n_sample, len(chunk.site_pos))
+            if first_probs is None:
+                first_probs = probs
+            if total_t >= budget_s:
+                break
+    finally:
+        oracle.use_library(None)
+    ref_py = None
+    try:
+        rp = json.load(open(os.path.join(ROOT, "profiles", "reference_cpu_timing.json")))
+        ref_py = {"sites_per_s_1_process": rp["runs"][0]["sites_per_s"], "sites_per_s_%d_processes" % rp["runs"][-1]["processes"]: rp["runs"][-1]["sites_per_s"],
+                  "host": "build container, %d vCPU (NOT this box: the reference cannot travel)" % rp["host_cpus"], "what": rp["note"],
+                  "source": "profiles/reference_cpu_timing.json (tools/time_reference.py)"}
+    except Exception:
+        pass
     return dict(value=round(total_sites / total_t, 2), unit="sites/s", cores=cores, kind="port",
+                build="gcc -O3 -march=native -ffast-math -fopenmp (this host); max |dP| vs the checker build on %d sites = %.2g" % (n_chk, dev_max),
+                checker_build={"value": round(n_slow / t_slow, 2), "unit": "sites/s", "cores": cores,
+                               "build": "gcc -O2 -ffp-contract=off -fopenmp (the parity checker)", "sample": "%d sites" % n_slow},
+                reference_python=ref_py,
                 sample="%d sites of the same synthetic chunks (mpileup text of both passes -> tensors -> CvT + BiGRU -> "
-                       "posterior), CPU oracle oracle/cto_oracle.c on every usable core: tensor creation in per-core site slices, "
+                       "posterior), CPU port oracle/cto_oracle.c on every usable core: tensor creation in per-core site slices, "
                        "OpenMP over sites for the networks, %.1f s" % (total_sites, total_t)), first_probs
 
 

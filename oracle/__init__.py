@@ -18,12 +18,39 @@ _SSW_LIB = os.path.join(_HERE, "libsswmodel.so")
 
 def build(force=False):
     stale = False
-    for lib_, src in ((_LIB, "cto_oracle.c"), (_SSW_LIB, "ssw_model.cpp")):
+    for lib_, src in ((os.path.join(_HERE, "liboracle.so"), "cto_oracle.c"), (_SSW_LIB, "ssw_model.cpp")):
         src = os.path.join(_HERE, src)
         stale = stale or not os.path.exists(lib_) or os.path.getmtime(lib_) < os.path.getmtime(src)
     if force or stale:
         subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
-    return _LIB
+    return os.path.join(_HERE, "liboracle.so")
+
+
+def build_fast():
+    """The same source built for speed, for bench.py's cpu_baseline leg only (never the checker): -O3 -march=native -ffast-math
+    on THIS host - the file name carries a hash of the host's CPU flags, so a library built on another machine is never loaded."""
+    import hashlib
+    flags = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("flags"):
+                flags = ln
+                break
+    except OSError:
+        pass
+    out = os.path.join(_HERE, "liboracle_fast.%s.so" % hashlib.sha1(flags.encode()).hexdigest()[:10])
+    src = os.path.join(_HERE, "cto_oracle.c")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-ffast-math", "-fPIC", "-fopenmp", "-std=c11", "-D_GNU_SOURCE", "-shared",
+                               "-o", out, src, "-lm"])
+    return out
+
+
+def use_library(path=None):
+    """Switch the module to another build of cto_oracle.c (build_fast()'s) or back to the checker (None)."""
+    global _lib, _LIB
+    _lib = None
+    _LIB = path if path else os.path.join(_HERE, "liboracle.so")
 
 
 _ssw = None
