@@ -164,6 +164,123 @@ def cpu_baseline(chunks, models, lik, edges, min_bq, n_sample, budget_s=12.0):
                        "OpenMP over sites for the networks, %.1f s" % (total_sites, total_t)), first_probs
 
 
+def config_legs(dev, batch, steps=10, warm=2, pool=4):
+    """After the timed region, never in `value`: the other single-GPU workloads BASELINE.json names, each as `steps` passes of the
+    whole hot path over `pool` resident chunks of its generator preset with its model pair - sites/s by HIP events on
+    the launch stream, per-stage kernel times from cto_model_profile - plus the clustered-candidate case of the ONT workload."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from clairs_to_amd._lib import lib, check, current_stream_ptr
+    from clairs_to_amd.engine import Engine, synthetic_models, CVT_CONSTRUCTOR_CFG
+    from clairs_to_amd.featurize import featurize
+    from clairs_to_amd.synth import SynthChunk, PLATFORMS, likelihood_table, lik_and_edges
+
+    def frac(ms, macs_):
+        tf = 2.0 * macs_ * batch / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        return {"ms": round(ms, 4), "tflops": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
+
+    def leg(platform, K, cvt_cfg=None, spacing=None, what=""):
+        models = synthetic_models(K, seed=0, cvt_cfg=cvt_cfg)
+        lik, edges = lik_and_edges(likelihood_table(K), K)
+        pf = PLATFORMS[platform]
+        # Illumina: the NEG tensor files are symlinks to the AFF ones (run_clairs_to:1248-1252)
+        eng = Engine(models["aff"], models["neg"], lik, edges, min_bq=pf["min_bq"], device=dev, neg_reads_aff=(platform == "ilmn"))
+        kw = {} if spacing is None else {"spacing": spacing}
+        with ThreadPoolExecutor(max_workers=max(1, min(pool, usable_cores()))) as ex:
+            chunks = list(ex.map(lambda i: SynthChunk.for_platform(platform, batch, seed=pf["seed"] + 7 * i, start=100000 + i * 3000000, **kw), range(pool)))
+        packs = [eng.upload(ch.arrays()) for ch in chunks]
+        sites = [torch.from_numpy(ch.site_pos).to(dev) for ch in chunks]
+        for i in range(warm):
+            eng.run_device(packs[i % pool], sites[i % pool])
+        check(lib.cto_model_profile(eng.h_aff, 1))
+        check(lib.cto_model_profile(eng.h_neg, 2))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(steps):
+            eng.run_device(packs[i % pool], sites[i % pool])
+        e1.record()
+        torch.cuda.synchronize()
+        check(lib.cto_model_profile(eng.h_aff, 0))
+        check(lib.cto_model_profile(eng.h_neg, 0))
+        ms = e0.elapsed_time(e1) / steps
+        cvt_ms, cvt_macs, l2_ms, l2_macs, l1_ms, l1_macs = C.c_double(0.0), C.c_int64(0), C.c_double(0.0), C.c_int64(0), C.c_double(0.0), C.c_int64(0)
+        check(lib.cto_model_profile_read(eng.h_aff, C.byref(cvt_ms), C.byref(cvt_macs)))
+        check(lib.cto_model_profile_read(eng.h_neg, C.byref(l2_ms), C.byref(l2_macs)))
+        check(lib.cto_model_profile_read_stage(eng.h_neg, 1, C.byref(l1_ms), C.byref(l1_macs)))
+        depth = float(np.mean([np.diff(ch.col_off).mean() for ch in chunks]))
+        out = {"workload": what, "platform": platform, "K": K, "min_bq_aff": pf["min_bq"], "neg_reads_aff": platform == "ilmn",
+               "mean_depth": round(depth, 1), "pack_bytes_per_chunk": int(sum(p_.nbytes() for p_ in packs) / pool),
+               "pack_columns_per_candidate": round(float(np.mean([ch.col_pos.size / batch for ch in chunks])), 2),
+               "sites_per_s": round(batch / (ms * 1e-3), 1), "ms_per_step": round(ms, 4), "steps": steps,
+               "mflop_per_site": round(2.0 * eng.macs_per_site / 1e6, 2),
+               "end_to_end_tflops": round(2.0 * eng.macs_per_site * batch / (ms * 1e-3) / 1e12, 2),
+               "stage_fracs": {"gru_l2": frac(l2_ms.value, l2_macs.value), "gru_l1": frac(l1_ms.value, l1_macs.value),
+                               "cvt": frac(cvt_ms.value, cvt_macs.value)}}
+        return out, eng, packs, sites
+
+    res = {}
+    plan = [("configs3_illumina_snv", "ilmn", 4, None, None, "BASELINE configs[3]: Illumina 50x, SNV model pair (K=4), NEG network reads the AFF tensor"),
+            ("configs3_illumina_indel", "ilmn", 6, None, None, "BASELINE configs[3]: Illumina 50x, indel model pair (K=6)"),
+            ("configs4_hifi_snv", "hifi", 4, None, None, "BASELINE configs[4], one GPU's share: PacBio HiFi 75x, SNV pair (no third model exists in the reference)"),
+            ("configs4_hifi_indel", "hifi", 6, None, None, "BASELINE configs[4], one GPU's share: PacBio HiFi 75x, indel pair (K=6)"),
+            ("configs1_ont_indel", "ont", 6, None, None, "ONT 50x with the indel model pair (K=6)"),
+            ("ont_snv_constructor_default_cvt", "ont", 4, CVT_CONSTRUCTOR_CFG, None,
+             "ONT 50x, SNV, AFF network with clairs/model.py:153-184's constructor defaults (emb 32/64/128, heads 1/3/6, depth 1/2/10) - "
+             "what a pickled SNV module may carry instead of the predict.py:520-553 configuration"),
+            ("ont_snv_clustered_candidates", "ont", 4, None, 3, "ONT 50x, SNV, candidates 3 bp apart on average (30 of 33 window columns shared)")]
+    for key, platform, K, cvt_cfg, spacing, what in plan:
+        out, eng, packs, sites = leg(platform, K, cvt_cfg, spacing, what)
+        if spacing is not None:
+            # tensor creation on clustered candidates, both forms, on preallocated outputs (one event pair per call): the one-kernel
+            # form re-reads shared columns once per candidate (out of L2), the two-stage form histograms every column once and gathers
+            # (what run_device picks below 8 pack columns per candidate).  Algorithmic bytes: the pack once + two fp32 tensors per site.
+            pool = len(packs)
+            f1 = featurize(packs[0], sites[0], eng.min_bq, 50, fused=True)
+            f2 = featurize(packs[0], sites[0], eng.min_bq, 50, fused=False)
+            nk = max(max(p_.n_keys for p_ in packs), 1)
+            nc = max(max(p_.n_cols for p_ in packs), 1)
+            kc = torch.empty((nk,), dtype=torch.int32, device=dev)
+            kf = torch.empty((nk, 2), dtype=torch.int32, device=dev)
+            colvec = torch.empty((nc, 72), dtype=torch.int16, device=dev)
+            coldepth = torch.empty((nc, 2), dtype=torch.int32, device=dev)
+            sp = current_stream_ptr()
+
+            def one(j):
+                check(lib.cto_featurize_sites(C.byref(packs[j].view), sites[j].data_ptr(), batch, int(eng.min_bq), 50, f1.x_aff.data_ptr(),
+                                              f1.x_neg.data_ptr(), None, None, f1.site_info.data_ptr(), f1.site_colvec.data_ptr(),
+                                              f1.sitefirst.data_ptr(), kc.data_ptr(), kf.data_ptr(), sp))
+
+            def two(j):
+                check(lib.cto_featurize_columns(C.byref(packs[j].view), int(eng.min_bq), colvec.data_ptr(), coldepth.data_ptr(), kc.data_ptr(), sp))
+                check(lib.cto_gather_windows(C.byref(packs[j].view), colvec.data_ptr(), coldepth.data_ptr(), sites[j].data_ptr(), batch,
+                                             int(eng.min_bq), 50, f2.x_aff.data_ptr(), f2.x_neg.data_ptr(), None, None, f2.site_info.data_ptr(),
+                                             f2.sitefirst.data_ptr(), kf.data_ptr(), sp))
+            tc = {}
+            nbytes = out["pack_bytes_per_chunk"] + 2 * 33 * 34 * 4 * batch
+            for name, fn in (("one_kernel", one), ("two_stage", two)):
+                evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(12)]
+                for i in range(-2, 12):
+                    if i >= 0:
+                        evs[i][0].record()
+                    fn(i % pool)
+                    if i >= 0:
+                        evs[i][1].record()
+                torch.cuda.synchronize()
+                t = sum(a.elapsed_time(b) for a, b in evs) / 12
+                tc[name] = {"ms": round(t, 4), "gb_per_s": round(nbytes / (t * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(nbytes / (t * 1e-3) / 1e9 / 8000.0, 4)}
+            tc["bytes_per_launch"] = int(nbytes)
+            tc["equal"] = bool(torch.equal(f1.x_aff, f2.x_aff) and torch.equal(f1.x_neg, f2.x_neg))
+            tc["run_device_uses"] = "two_stage" if packs[0].n_cols < 8 * batch else "one_kernel"
+            out["tensor_creation"] = tc
+        res[key] = out
+        del eng, packs, sites
+        torch.cuda.empty_cache()
+    return res
+
+
 def self_launch(n):
     """Re-exec this command line under torch.distributed.run with n ranks on this node (rendezvous on 127.0.0.1, a free
     port); the ranks' stdout is ours, so rank 0's JSON line is the only line printed.  Returns the launcher's exit code."""
@@ -192,6 +309,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-sustained", action="store_true", help="skip the 245-step run and the per-stage kernel times after the timed region")
+    ap.add_argument("--no-configs", action="store_true", help="skip the legs on the other BASELINE configs' single-GPU workloads (Illumina, HiFi, "
+                    "K = 6, the constructor-default CvT, clustered candidates)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file legs (mpileup text -> VCF, BAM -> VCF)")
     ap.add_argument("--e2e-chunks", type=int, default=96, help="chunk files of the mpileup-text leg (the BAM leg uses a third as many)")
     args = ap.parse_args()
@@ -452,6 +571,8 @@ def main():
             res["cpu_baseline"] = cb
             got = eng.run_device(packs[0], sites[0])["probs"][: probs_cpu.shape[0]].cpu().numpy()
             res["parity_max_abs_dP_vs_cpu_sample"] = float(np.abs(got - probs_cpu).max())
+        if world == 1 and not args.no_configs:
+            res["configs"] = config_legs(dev, args.batch)
         if world == 1 and not args.no_e2e:
             # ---- file-to-file legs (never `value`): chunk files + pileup source on disk -> p_<chunk>.vcf through the call_chunks
             # pipeline, everything a real run pays included; the rate is set by the host (cores stated), not by the GPU ----

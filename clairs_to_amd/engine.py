@@ -52,10 +52,14 @@ def random_state_dict(module, seed=0, head_gain=2.0):
     return out
 
 
-def synthetic_models(n_out=4, seed=0):
-    """Random-init AFF/NEG modules of the reference architecture (predict.py configuration)."""
+CVT_CONSTRUCTOR_CFG = dict(s1_emb_dim=32, s2_emb_dim=64, s3_emb_dim=128, s1_heads=1, s2_heads=3, s3_heads=6,
+                           s1_depth=1, s2_depth=2, s3_depth=10)   # clairs/model.py:153-184 (what a pickled SNV module may carry)
+
+
+def synthetic_models(n_out=4, seed=0, cvt_cfg=None):
+    """Random-init AFF/NEG modules of the reference architecture (predict.py configuration unless cvt_cfg says otherwise)."""
     aff_cls, neg_cls = (CvT, BiGRU_NACGT) if n_out == 4 else (CvT_Indel, BiGRU_NACGT_Indel)
-    aff = aff_cls(model_type="acgt", **CVT_PREDICT_CFG).eval()
+    aff = aff_cls(model_type="acgt", **(CVT_PREDICT_CFG if cvt_cfg is None else cvt_cfg)).eval()
     neg = neg_cls(model_type="nacgt").eval()
     out = {}
     for tag, m in (("aff", aff), ("neg", neg)):

@@ -166,6 +166,35 @@ def test_bench_multi_rank_code_path(tmp_path, launcher):
     assert [d["rank"] for d in res["rank_devices"]] == [0, 1]
 
 
+def test_bench_eight_rank_dry_run(tmp_path):
+    """The driver's first SCALE run must not die on set-up: `python bench.py --gpus 8` with its DEFAULT geometry (16 resident
+    4096-site chunks per rank, 20 steps, 3 warm-up) as eight ranks on this box's single GPU over gloo (test hooks) - eight times the
+    resident pool and workspaces on one device (a real rank has 288 GB to itself), the eight-way synthesis on the host's cores, the
+    rank census, the verified gather, the watchdog armed.  Start-up time is asserted: everything before the JSON line inside 10 min."""
+    import json
+    import subprocess
+    import sys
+    import time
+    from conftest import ROOT
+    env = dict(os.environ, CTO_BENCH_BACKEND="gloo", CTO_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--watchdog", "560"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    took = time.time() - t0
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and res["steps"] == 20 and res["warmup"] == 3 and res["value"] > 0 and res["scaling"] == "weak"
+    assert res["ranks_seen"] == 8 and res["gather_verified"] is True and res["backend"].startswith("gloo")
+    assert [d["rank"] for d in res["rank_devices"]] == list(range(8))
+    assert res["config"]["chunks_resident_per_gpu"] == 16 and res["config"]["batch"] == 4096
+    assert "cpu_baseline" not in res and "e2e" not in res and "configs" not in res      # N > 1: the line carries the scaling run only
+    print("8-rank dry run: %.0f s wall, %.1f sites/s aggregate on ONE device (not a scaling figure)" % (took, res["value"]))
+
+
 def test_bench_two_ranks_over_rccl(tmp_path):
     """First contact with RCCL, automatically, wherever >= 2 GPUs are visible (the build's own boxes have one: skipped there):
     `bench.py --gpus 2` must come back with one JSON line whose exchange step ran over nccl (= RCCL) between two distinct devices.
