@@ -160,8 +160,17 @@ class DevicePileup(object):
         cap = 4096 + int((end - start) >> 14) + 64
         voffs = np.zeros(cap, dtype=np.uint64)
         tid = C.c_int32(-1)
-        n_st = check(int(lib.cto_bam_record_starts(str(bam_fn).encode(), bai, ctg_name.encode(), int(start), int(end), fb.value, fe.value,
-                                                   voffs.ctypes.data, cap, C.byref(tid))))
+        n_st = -3
+        for _ in range(4):                                   # CTO_ENOMEM (-3): the index names more offsets than the table holds
+            n_st = int(lib.cto_bam_record_starts(str(bam_fn).encode(), bai, ctg_name.encode(), int(start), int(end), fb.value, fe.value,
+                                                 voffs.ctypes.data, cap, C.byref(tid)))
+            if n_st != -3:
+                break
+            cap *= 8
+            voffs = np.zeros(cap, dtype=np.uint64)
+        if n_st == -3:
+            return None, None, True                          # still too many: the host reader takes the region
+        check(n_st)
         if n_st == 0:
             return None, None, True
         s = stream if stream is not None else torch.cuda.current_stream(device)

@@ -272,6 +272,8 @@ def call_chunks(args):
         native = how == "native" or (how == "auto" and native_eligible(mine))
         run = run_pipeline_native if native else run_pipeline
         reader = None if getattr(args, "mpileup_dir", None) else getattr(args, "bam_reader", "samtools")
+        from .platforms import warn_unpinned_bam_reader
+        warn_unpinned_bam_reader(getattr(args, "platform", "ont"), reader)
         if getattr(args, "producers", None):
             producers = args.producers
         elif reader == "samtools":        # one `samtools mpileup` child per producer (a core each; the producer sleeps on its pipe)

@@ -87,6 +87,8 @@ def load_pack(args, ref, ref_start, ctg_start, ctg_end, max_indel, device=None, 
     ext_s, ext_e = max(1, ctg_start - NPOS), ctg_end + NPOS
     reader = getattr(args, "bam_reader", "samtools")
     if reader in ("native", "gpu"):
+        from .platforms import warn_unpinned_bam_reader
+        warn_unpinned_bam_reader(getattr(args, "platform", "ont"), reader)
         inflated = None
         if reader == "gpu":
             from .bgzf import inflate_span

@@ -536,6 +536,34 @@ int read_header_tid(Bgzf& bz, const char* bam_path, const char* ctg_name, int* t
     return CTO_OK;
 }
 
+// CIGARs with more than 65535 operations live in the CG:B,I tag; the CIGAR field then holds the placeholder <l_seq>S<ref_len>N
+// (SAM specification, section 4.2.2).  *ops / *n_ops are redirected to the tag's array when the record is of that form.
+static void resolve_cg_tag(const uint8_t* cg, int n_cig, int l_seq, const uint8_t* aux, const uint8_t* aend, const uint8_t** ops, int* n_ops) {
+    if (!(n_cig == 2 && (le32(cg) & 15) == 4 && int(uint32_t(le32(cg)) >> 4) == l_seq && (le32(cg + 4) & 15) == 3)) return;
+    while (aux + 3 <= aend) {
+        const char t0 = char(aux[0]), t1 = char(aux[1]), ty = char(aux[2]);
+        aux += 3;
+        size_t skip = 0;
+        if (ty == 'A' || ty == 'c' || ty == 'C') skip = 1;
+        else if (ty == 's' || ty == 'S') skip = 2;
+        else if (ty == 'i' || ty == 'I' || ty == 'f') skip = 4;
+        else if (ty == 'Z' || ty == 'H') { while (aux + skip < aend && aux[skip]) ++skip; ++skip; }
+        else if (ty == 'B') {
+            if (aux + 5 > aend) break;
+            const char sub = char(aux[0]);
+            const uint32_t cnt = uint32_t(le32(aux + 1));
+            const size_t esz = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+            if (t0 == 'C' && t1 == 'G' && sub == 'I' && aux + 5 + size_t(cnt) * 4 <= aend) {
+                *n_ops = int(cnt);
+                *ops = aux + 5;
+                return;
+            }
+            skip = 5 + size_t(cnt) * esz;
+        } else break;                                   // unknown type: stop scanning
+        aux += skip;
+    }
+}
+
 int pack_from_bam_range(const char* bam_path, const char* bai_path, const char* ctg_name, int64_t start, int64_t end,
                         const int64_t* bed, int64_t n_bed, const char* ref_seq, int64_t ref_start, size_t ref_len,
                         int excl_flags, int min_mq, int max_depth, int max_indel_length, const PreInflated& pre, cto_pack** out,
@@ -648,32 +676,7 @@ int pack_from_bam_range(const char* bam_path, const char* bai_path, const char* 
             // placeholder <l_seq>S<ref_len>N (SAM specification, section 4.2.2)
             int n_ops = n_cig;
             const uint8_t* ops = cg;
-            if (n_cig == 2 && (le32(cg) & 15) == 4 && int(uint32_t(le32(cg)) >> 4) == l_seq && (le32(cg + 4) & 15) == 3) {
-                const uint8_t* aux = ql + l_seq;
-                const uint8_t* aend = rec.data() + rec.size();
-                while (aux + 3 <= aend) {
-                    const char t0 = char(aux[0]), t1 = char(aux[1]), ty = char(aux[2]);
-                    aux += 3;
-                    size_t skip = 0;
-                    if (ty == 'A' || ty == 'c' || ty == 'C') skip = 1;
-                    else if (ty == 's' || ty == 'S') skip = 2;
-                    else if (ty == 'i' || ty == 'I' || ty == 'f') skip = 4;
-                    else if (ty == 'Z' || ty == 'H') { while (aux + skip < aend && aux[skip]) ++skip; ++skip; }
-                    else if (ty == 'B') {
-                        if (aux + 5 > aend) break;
-                        const char sub = char(aux[0]);
-                        const uint32_t cnt = uint32_t(le32(aux + 1));
-                        const size_t esz = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
-                        if (t0 == 'C' && t1 == 'G' && sub == 'I' && aux + 5 + size_t(cnt) * 4 <= aend) {
-                            n_ops = int(cnt);
-                            ops = aux + 5;
-                            break;
-                        }
-                        skip = 5 + size_t(cnt) * esz;
-                    } else break;                                   // unknown type: stop scanning
-                    aux += skip;
-                }
-            }
+            resolve_cg_tag(cg, n_cig, l_seq, ql + l_seq, rec.data() + rec.size(), &ops, &n_ops);
             r.cigar.resize(size_t(n_ops));
             int64_t rlen = 0, qlen = 0;                        // 64-bit: a crafted CIGAR must not wrap the sums
             for (int i = 0; i < n_ops; ++i) {
@@ -954,9 +957,13 @@ extern "C" int64_t cto_bam_view(const char* bam_path, const char* bai_path, cons
                 const uint8_t* cg = b + 32 + l_name;
                 const uint8_t* sq = cg + size_t(n_cig) * 4;
                 const uint8_t* ql = sq + (l_seq + 1) / 2;
+                // the real CIGAR of a read with more than 65535 operations is its CG:B,I tag (samtools view prints that one too)
+                int n_ops = n_cig;
+                const uint8_t* ops = cg;
+                resolve_cg_tag(cg, n_cig, l_seq, ql + l_seq, rec.data() + rec.size(), &ops, &n_ops);
                 int64_t rlen = 0;
-                for (int i = 0; i < n_cig; ++i) {
-                    const uint32_t c = uint32_t(le32(cg + i * 4));
+                for (int i = 0; i < n_ops; ++i) {
+                    const uint32_t c = uint32_t(le32(ops + i * 4));
                     const int opc = int(c & 15);
                     if (opc == 0 || opc == 2 || opc == 3 || opc == 7 || opc == 8) rlen += int64_t(c >> 4);
                 }
@@ -965,9 +972,9 @@ extern "C" int64_t cto_bam_view(const char* bam_path, const char* bai_path, cons
                 out.append(reinterpret_cast<const char*>(b + 32), size_t(std::max(0, l_name - 1)));
                 out += '\t'; out += std::to_string(flag); out += '\t'; out += ctg_name; out += '\t'; out += std::to_string(pos + 1);
                 out += '\t'; out += std::to_string(mapq); out += '\t';
-                if (n_cig == 0) out += '*';
-                for (int i = 0; i < n_cig; ++i) {
-                    const uint32_t c = uint32_t(le32(cg + i * 4));
+                if (n_ops == 0) out += '*';
+                for (int i = 0; i < n_ops; ++i) {
+                    const uint32_t c = uint32_t(le32(ops + i * 4));
                     snprintf(num, sizeof(num), "%u%c", c >> 4, "MIDNSHP=X???????"[c & 15]);
                     out += num;
                 }

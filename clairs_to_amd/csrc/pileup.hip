@@ -26,7 +26,7 @@
 // Two round trips to the host are needed (sizes for allocation): after k_columns and after the per-column key counts.
 //
 // Not done here - the call reports `fallback` and the caller uses the host reader: paired reads (mate-overlap quality edits are
-// order dependent), reference skips (N), more reads than --max-depth in the region (the cap is order dependent too), a column
+// order dependent), reference skips (N), --max-depth or more reads open at some read's start (the cap is order dependent; k_live_marks), a column
 // deeper than 2048, with more than 256 indel-carrying reads or more than 64 distinct indel keys.  The BGZF CRC-32 of every block is
 // checked on the device (k_crc32_blocks), as htslib and the host reader check it.
 #include <algorithm>
@@ -60,6 +60,7 @@ struct Flags {                    // written by the kernels, read by the host af
     int bad_crc;                                    // 1 + index of a block whose inflated bytes fail the gzip trailer's CRC-32 (0: none)
     int n_rec, n_valid, n_cols, n_keys;
     long long n_entries, key_str_bytes;
+    int max_live, pad_;                             // largest number of accepted reads still open at another accepted read's start
 };
 
 __device__ __forceinline__ uint32_t ld16(const uint8_t* p) { return uint32_t(p[0]) | (uint32_t(p[1]) << 8); }
@@ -274,6 +275,43 @@ __global__ void k_compact(const DevRead* __restrict__ reads, int n_rec, int* __r
     int run = part[t] - s;
     for (int i = lo; i < hi; ++i) if (reads[i].valid) rid[run++] = i;
     if (t == int(blockDim.x) - 1) fl->n_valid = part[t];
+}
+
+// The --max-depth cap (host reader, csrc/bam.cpp: a read is dropped when max_depth accepted reads are still open at its start) can
+// only bite where that many reads overlap a read's start.  Accepted reads are in file order = sorted by start, so read j is open at
+// the start of exactly the reads j+1 .. nxt(j)-1, nxt(j) = the first later read starting at or behind j's end: +1 / -1 marks over the
+// read index, a running sum, its maximum.  Below max_depth no read is dropped and the device pack is the host's; otherwise fallback.
+__global__ void k_live_marks(const DevRead* __restrict__ reads, const int* __restrict__ rid, const Flags* fl, int* __restrict__ marks) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, n = fl->n_valid;
+    if (j >= n) return;
+    const int end = reads[rid[j]].end;
+    int a = j + 1, b = n;
+    while (a < b) { const int m = (a + b) >> 1; if (reads[rid[m]].pos >= end) b = m; else a = m + 1; }
+    if (a > j + 1) { atomicAdd(&marks[j + 1], 1); atomicAdd(&marks[a], -1); }
+}
+__global__ void k_live_max(const int* __restrict__ marks, Flags* fl) {       // one workgroup
+    __shared__ int part[1024], best[1024];
+    const int n = fl->n_valid + 1, t = threadIdx.x, per = (n + blockDim.x - 1) / blockDim.x;
+    const int lo = min(n, t * per), hi = min(n, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += marks[i];
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < int(blockDim.x); d <<= 1) {
+        const int v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s, m = 0;
+    for (int i = lo; i < hi; ++i) { run += marks[i]; m = max(m, run); }
+    best[t] = m;
+    __syncthreads();
+    for (int d = int(blockDim.x) >> 1; d > 0; d >>= 1) {
+        if (t < d) best[t] = max(best[t], best[t + d]);
+        __syncthreads();
+    }
+    if (t == 0) fl->max_live = best[0];
 }
 
 // Requested positions: n_iv sorted, disjoint 0-based intervals [lo, hi) clipped to the region; slot space = their concatenation
@@ -634,7 +672,7 @@ struct Buf {
 }  // namespace
 
 struct cto_dev_pileup {
-    Buf lin, lin_off, blocks, starts, counts, base, rec_off, reads, rid, iv, diff, slot_col, col_slot, col_off, col_pos, col_ref, cursor, tmp,
+    Buf lin, lin_off, blocks, starts, counts, base, rec_off, reads, rid, live, iv, diff, slot_col, col_slot, col_off, col_pos, col_ref, cursor, tmp,
         entries, nkc, keyrec, key_off, key_meta, key_group, key_final, key_col, key_len, str_off, key_str, ref, flags, z1k;
     bool z1k_ready = false;
     Flags* h_flags = nullptr;            // page-locked mirror
@@ -779,12 +817,19 @@ extern "C" int cto_pileup_device(cto_dev_pileup* cx, const void* d_inflated, con
     }
     const int n_rec = hf->n_rec;
     if (n_rec == 0) return empty_result();
-    if ((rc = cx->rec_off.ensure(size_t(n_rec) * 4)) || (rc = cx->reads.ensure(size_t(n_rec) * sizeof(DevRead))) || (rc = cx->rid.ensure(size_t(n_rec) * 4))) return rc;
+    if ((rc = cx->rec_off.ensure(size_t(n_rec) * 4)) || (rc = cx->reads.ensure(size_t(n_rec) * sizeof(DevRead))) || (rc = cx->rid.ensure(size_t(n_rec) * 4)) ||
+        (rc = cx->live.ensure(size_t(n_rec + 1) * 4)))
+        return rc;
+    CTO_HIP(hipMemsetAsync(cx->live.p, 0, size_t(n_rec + 1) * 4, s));
     hipLaunchKernelGGL(k_chain, dim3(cgrid), dim3(64), 0, s, lin, len, cx->starts.as<int64_t>(), n_chains, 1, cx->counts.as<int>(), cx->base.as<int>(),
                        cx->rec_off.as<uint32_t>(), fl);
     hipLaunchKernelGGL(k_parse, dim3(unsigned(cdiv(n_rec, 128))), dim3(128), 0, s, lin, cx->rec_off.as<uint32_t>(), n_rec, tid, int(start - 1), int(end),
                        excl_flags, min_mq, cx->reads.as<DevRead>(), fl);
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, cx->reads.as<DevRead>(), n_rec, cx->rid.as<int>(), fl);
+    if (max_depth > 0) {
+        hipLaunchKernelGGL(k_live_marks, dim3(unsigned(cdiv(n_rec, 128))), dim3(128), 0, s, cx->reads.as<DevRead>(), cx->rid.as<int>(), fl, cx->live.as<int>());
+        hipLaunchKernelGGL(k_live_max, dim3(1), dim3(1024), 0, s, cx->live.as<int>(), fl);
+    }
     Ivs iv{cx->iv.as<int>(), cx->iv.as<int>() + n_iv, cx->iv.as<int>() + 2 * n_iv, n_iv, total};
     hipLaunchKernelGGL(k_cover, dim3(unsigned(cdiv(n_rec, 128))), dim3(128), 0, s, cx->reads.as<DevRead>(), cx->rid.as<int>(), fl, iv, cx->diff.as<int>());
     hipLaunchKernelGGL(k_columns, dim3(1), dim3(1024), 0, s, cx->diff.as<int>(), total, cx->slot_col.as<int>(), cx->col_slot.as<int>(),
@@ -793,7 +838,7 @@ extern "C" int cto_pileup_device(cto_dev_pileup* cx, const void* d_inflated, con
     if ((rc = fetch_flags())) return rc;
     const int lim = hf->stop_idx;
     if (hf->err_idx < lim) { set_error("cto_pileup_device: alignment record shorter than its fields, or running past 2^31 - 1"); return CTO_EINVAL; }
-    if (hf->paired_idx < lim || hf->skip_idx < lim || hf->deep_col || (max_depth > 0 && hf->n_valid >= max_depth)) { *fallback = 1; return CTO_OK; }
+    if (hf->paired_idx < lim || hf->skip_idx < lim || hf->deep_col || (max_depth > 0 && hf->max_live >= max_depth)) { *fallback = 1; return CTO_OK; }
     const int n_cols = hf->n_cols;
     const long long n_entries = hf->n_entries;
     if (n_cols == 0) return empty_result();

@@ -477,9 +477,13 @@ struct Run {
             if (!c->pile && (rc = cto_dev_pileup_create(&c->pile))) return rc;
             std::vector<uint64_t> voffs(size_t(4096 + ((hi - lo) >> 14) + 64));
             int32_t tid = -1;
-            const int64_t n_st = cto_bam_record_starts(j.bam_path, nullptr, ctg.c_str(), lo, hi, fb, fe, voffs.data(), int64_t(voffs.size()), &tid);
-            if (n_st < 0) return int(n_st);
-            int fallback = n_st == 0;
+            int64_t n_st = CTO_ENOMEM;
+            for (int tries = 0; tries < 4 && n_st == CTO_ENOMEM; ++tries) {       // an index naming more offsets than expected: a larger table
+                if (tries) voffs.resize(voffs.size() * 8);
+                n_st = cto_bam_record_starts(j.bam_path, nullptr, ctg.c_str(), lo, hi, fb, fe, voffs.data(), int64_t(voffs.size()), &tid);
+            }
+            if (n_st < 0 && n_st != CTO_ENOMEM) return int(n_st);
+            int fallback = n_st <= 0;                                               // still too many: the host reader takes the chunk
             cto_pack_view dvw{};
             cto_pack* lite = nullptr;
             if (!fallback) {
@@ -758,6 +762,12 @@ struct Run {
         if (kernels_end) CTO_HIP(hipEventRecord(kernels_end, main));   // before any chunk of this launch can reach a writer, which reads it
         int64_t o = 0;
         size_t used = 0;
+        // chunks handed to *complete leave `pending` on EVERY way out of the loop (a failing HIP call returns from its middle): a
+        // slot in both lists would be given back to the free list twice by the launcher's hand_over() + abandon_pending()
+        struct ErasePrefix {
+            std::vector<Pending>& v; size_t& n;
+            ~ErasePrefix() { v.erase(v.begin(), v.begin() + long(n)); }
+        } erase_prefix{pending, used};
         for (Pending& q : pending) {
             if (o >= m) break;
             const int64_t take = std::min(q.cnt, m - o);
@@ -770,15 +780,14 @@ struct Run {
             q.cnt -= take;
             o += take;
             if (q.cnt == 0) {
-                ++used;
                 CTO_HIP(hipEventRecord(q.s->computed, main));
                 CTO_HIP(hipStreamWaitEvent(copy_back, q.s->computed, 0));
                 CTO_HIP(hipMemcpyAsync(q.s->res_host.p, q.s->res_dev.p, q.s->res_total, hipMemcpyDeviceToHost, copy_back));
                 CTO_HIP(hipEventRecord(q.s->done, copy_back));
                 complete->push_back(q.s);
+                ++used;
             }
         }
-        pending.erase(pending.begin(), pending.begin() + long(used));
         return CTO_OK;
     }
 

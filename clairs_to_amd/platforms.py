@@ -41,3 +41,21 @@ def resolve_platform(platform, exit_on_unknown=True):
             sys.exit(msg)
         raise ValueError(msg)
     return name, family_of(name), MIN_BQ[name]
+
+
+_warned = set()
+
+
+def warn_unpinned_bam_reader(platform, reader):
+    """The built-in BAM readers (`--bam_reader native | gpu`) are parity-UNPINNED against samtools (absent from the build's boxes).
+    For unpaired long reads the rules that matter are the SAM specification's; for PAIRED short reads the pileup also depends on
+    htslib's mate-overlap handling (which mate keeps its base quality where the two overlap - recent htslib versions differ here),
+    which csrc/bam.cpp restates from reading, not from a run.  Short-read platforms therefore get a loud warning, once per process;
+    `samtools` stays the default producer."""
+    if reader in ("native", "gpu") and family_of(str(platform)) == "ilmn" and "ilmn" not in _warned:
+        _warned.add("ilmn")
+        sys.stderr.write("[WARNING] --bam_reader %s on a short-read platform (%s): the built-in BAM reader's mate-overlap rule is NOT pinned "
+                         "against samtools/htslib (csrc/bam.cpp); overlapping read pairs may pile up differently than `samtools mpileup` "
+                         "would print them.  Use --bam_reader samtools for paired-end data unless you have checked this reader against "
+                         "your samtools version.\n" % (reader, platform))
+        sys.stderr.flush()

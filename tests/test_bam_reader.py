@@ -308,3 +308,23 @@ def test_max_depth_cap_does_not_depend_on_the_thread_count(tmp_path):
     assert depth.max() <= 25 + 5 and (depth >= 25).sum() > 1000       # the cap really bit
     text = mpileup_rows(reads, 0, "chrA", 1, L, max_depth=25, ref_seq=ref, ref_start=1)
     _assert_same(packs[0], _pack_arrays(ColumnPack.from_mpileup(text, ref, 1)))
+
+
+def test_bam_view_prints_the_real_cigar_of_cg_tag_reads(tmp_path):
+    """cto_bam_view (the `samtools view` stand-in of realign_reads --bam_reader native): a record whose CIGAR travels in the CG:B,I
+    tag (SAM spec 4.2.2: > 65535 operations; here forced by the writer) prints that CIGAR, not the <l_seq>S<ref_len>N placeholder,
+    and is selected by its real reference span - the same row as the identical read written the ordinary way."""
+    from clairs_to_amd.realign_reads import bam_view
+    refs = [("chrA", 5000)]
+    cigar = [("S", 3), ("M", 20), ("I", 2), ("M", 10), ("D", 4), ("M", 15)]
+    seq = "ACGTTGCA" * 6 + "AC"
+    base = dict(flag=0, ref=0, pos=100, mapq=60, cigar=cigar, seq=seq, qual=[30] * len(seq))
+    rows = {}
+    for tag in (False, True):
+        bam = str(tmp_path / ("cg%d.bam" % tag))
+        write_bam(bam, refs, [dict(base, name="r", cg_tag=tag)])
+        rows[tag] = bam_view(bam, "chrA", 120, 140)
+        assert len(rows[tag]) == 1
+        assert bam_view(bam, "chrA", 160, 200) == []                  # behind the read's real end (pos 100 + 49 reference bases)
+    assert rows[True] == rows[False]
+    assert rows[True][0].split("\t")[5] == "3S20M2I10M4D15M"

@@ -75,8 +75,40 @@ def test_device_pileup_equals_the_host_reader(tmp_path, seed):
     assert done >= 6
 
 
+def test_device_pileup_depth_cap_only_where_it_can_bite(tmp_path):
+    """--max-depth is a cap on the reads OPEN at a read's start, not on the reads of the region: a region holding many times
+    max_depth reads at a depth below it stays on the device (and equals the host reader, which applies the cap itself); the same
+    region with a cap below the depth falls back."""
+    import torch
+    from clairs_to_amd._lib import lib
+    from clairs_to_amd.bgzf import DevicePileup
+    from clairs_to_amd.pack import ColumnPack
+    rng = np.random.default_rng(21)
+    L = 60000
+    ref = "".join(rng.choice(list("ACGT"), size=L))
+    reads = _unpaired_reads(rng, 2500, [L])
+    bam = str(tmp_path / "d.bam")
+    write_bam(bam, [("chrA", L)], reads, block_payload=20000)
+    dev = torch.device("cuda:0")
+    dp = DevicePileup()
+    full = _pack_arrays(ColumnPack.from_bam(bam, "chrA", 1, L, ref, 1, max_depth=0))
+    deepest = int(np.diff(full["col_off"]).max())
+    assert len(reads) > 8 * deepest                      # far more reads in the region than are ever open together
+    cap = deepest + 8
+    want = _pack_arrays(ColumnPack.from_bam(bam, "chrA", 1, L, ref, 1, max_depth=cap))
+    pv, lite, fallback = dp.pileup(bam, None, "chrA", 1, L, ref, 1, dev, max_depth=cap)
+    assert not fallback
+    got = _device_arrays(pv, lite)
+    lib.cto_pack_free(lite)
+    for k in ("col_pos", "col_ref", "col_off", "key_off", "entries", "key_meta", "key_group"):
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    assert got["keys"] == want["keys"]
+    pv, lite, fallback = dp.pileup(bam, None, "chrA", 1, L, ref, 1, dev, max_depth=max(2, deepest // 2))
+    assert fallback
+
+
 def test_device_pileup_reports_what_it_leaves_to_the_host(tmp_path):
-    """paired reads, reference skips and a region with max_depth or more reads come back as `fallback`, never as a different pack"""
+    """paired reads, reference skips and a cap that bites come back as `fallback`, never as a different pack"""
     import torch
     from clairs_to_amd.bgzf import DevicePileup
     rng = np.random.default_rng(7)
@@ -91,7 +123,7 @@ def test_device_pileup_reports_what_it_leaves_to_the_host(tmp_path):
                 r["cigar"] = [(("D" if op == "N" else op), ln) for op, ln in r["cigar"]]
         bam = str(tmp_path / (kind + ".bam"))
         write_bam(bam, refs, reads, block_payload=3000)
-        pv, lite, fallback = dp.pileup(bam, None, "chrA", 1, 20000, ref, 1, dev, max_depth=50 if kind == "depth" else 8000)
+        pv, lite, fallback = dp.pileup(bam, None, "chrA", 1, 20000, ref, 1, dev, max_depth=3 if kind == "depth" else 8000)
         assert fallback, kind
 
 

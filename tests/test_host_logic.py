@@ -232,3 +232,18 @@ def test_c_bed_reader_equals_the_row_loop(tmp_path):
     from clairs_to_amd._lib import CtoError
     with pytest.raises(CtoError):
         read_candidate_positions(str(bad), "chr2")
+
+
+def test_short_read_platforms_warn_about_the_unpinned_bam_reader(capsys):
+    """--bam_reader native | gpu on an Illumina platform: a loud warning (the mate-overlap rule of csrc/bam.cpp is not pinned against
+    samtools), once per process; long-read platforms and the samtools producer stay quiet."""
+    from clairs_to_amd import platforms
+    platforms._warned.clear()
+    platforms.warn_unpinned_bam_reader("ont_r10_dorado_sup_5khz", "native")
+    platforms.warn_unpinned_bam_reader("hifi_revio", "gpu")
+    platforms.warn_unpinned_bam_reader("ilmn", "samtools")
+    assert capsys.readouterr().err == ""
+    platforms.warn_unpinned_bam_reader("ilmn_ss", "native")
+    platforms.warn_unpinned_bam_reader("ilmn", "gpu")
+    err = capsys.readouterr().err
+    assert err.count("[WARNING]") == 1 and "mate-overlap" in err and "NOT pinned" in err
