@@ -164,7 +164,7 @@ def cpu_baseline(chunks, models, lik, edges, min_bq, n_sample, budget_s=12.0):
                        "OpenMP over sites for the networks, %.1f s" % (total_sites, total_t)), first_probs
 
 
-def config_legs(dev, batch, steps=10, warm=2, pool=4):
+def config_legs(dev, batch, steps=20, warm=40, pool=4):
     """After the timed region, never in `value`: the other single-GPU workloads BASELINE.json names, each as `steps` passes of the
     whole hot path over `pool` resident chunks of its generator preset with its model pair - sites/s by HIP events on
     the launch stream, per-stage kernel times from cto_model_profile - plus the clustered-candidate case of the ONT workload."""
@@ -192,7 +192,7 @@ def config_legs(dev, batch, steps=10, warm=2, pool=4):
             chunks = list(ex.map(lambda i: SynthChunk.for_platform(platform, batch, seed=pf["seed"] + 7 * i, start=100000 + i * 3000000, **kw), range(pool)))
         packs = [eng.upload(ch.arrays()) for ch in chunks]
         sites = [torch.from_numpy(ch.site_pos).to(dev) for ch in chunks]
-        for i in range(warm):
+        for i in range(warm):              # ~80 ms of work: the seconds of host-side synthesis before it let the shader clock drop
             eng.run_device(packs[i % pool], sites[i % pool])
         check(lib.cto_model_profile(eng.h_aff, 1))
         check(lib.cto_model_profile(eng.h_neg, 2))

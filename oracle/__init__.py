@@ -41,8 +41,12 @@ def build_fast():
     out = os.path.join(_HERE, "liboracle_fast.%s.so" % hashlib.sha1(flags.encode()).hexdigest()[:10])
     src = os.path.join(_HERE, "cto_oracle.c")
     if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
-        subprocess.check_call(["gcc", "-O3", "-march=native", "-ffast-math", "-fPIC", "-fopenmp", "-std=c11", "-D_GNU_SOURCE", "-shared",
-                               "-o", out, src, "-lm"])
+        # two steps: -ffast-math on the LINK line would pull in crtfastmath.o, whose constructor switches the whole process to
+        # flush-to-zero / denormals-are-zero the moment the library is loaded
+        obj = out[:-3] + ".o"
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-ffast-math", "-fPIC", "-fopenmp", "-std=c11", "-D_GNU_SOURCE", "-c", "-o", obj, src])
+        subprocess.check_call(["gcc", "-shared", "-fopenmp", "-o", out, obj, "-lm"])
+        os.remove(obj)
     return out
 
 
