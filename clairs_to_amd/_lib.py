@@ -39,7 +39,7 @@ class CvtCfg(C.Structure):
 
 class ChunkJob(C.Structure):
     _fields_ = [("ctg_name", C.c_char_p), ("bed_path", C.c_char_p), ("mpileup_path", C.c_char_p), ("bam_path", C.c_char_p),
-                ("vcf_path", C.c_char_p)]
+                ("vcf_path", C.c_char_p), ("region_start", c_i64), ("region_end", c_i64), ("candidates_path", C.c_char_p)]
 
 
 class RunCfg(C.Structure):
@@ -48,7 +48,9 @@ class RunCfg(C.Structure):
                 ("show_ref", C.c_int), ("verbose", C.c_int), ("qual_pass", C.c_double), ("ref_fa", C.c_char_p),
                 ("vcf_header", C.c_char_p), ("producers", C.c_int), ("writers", C.c_int), ("depth", C.c_int),
                 ("inflate_cus", C.c_int), ("inflate_jobs", C.c_int), ("pack_threads", C.c_int), ("samtools", C.c_char_p),
-                ("samtools_max_depth", C.c_int), ("aff2", c_vp), ("neg2", c_vp), ("device_pileup", C.c_int)]
+                ("samtools_max_depth", C.c_int), ("aff2", c_vp), ("neg2", c_vp), ("device_pileup", C.c_int),
+                ("extract_min_mq", C.c_int), ("extract_min_bq", C.c_int), ("alt_base_num", C.c_int), ("snv_min_af", C.c_double),
+                ("indel_min_af", C.c_double), ("min_coverage", C.c_double)]
 
 
 class RunStats(C.Structure):
@@ -123,6 +125,7 @@ SYMBOLS = {
     "cto_model_profile_read_stage": (C.c_int, [c_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(c_i64)]),
     "cto_posterior": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "cto_qual_finalize": (c_i64, [c_vp, c_vp, c_i64]),
+    "cto_candidate_positions": (C.c_int, [c_vp, c_vp, C.c_int, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "cto_softmax_probs": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, c_vp, c_vp]),
     "cto_posterior_from_probs": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
 }

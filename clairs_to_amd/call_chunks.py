@@ -190,7 +190,13 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
     for j, a in zip(jobs, chunk_args):
         os.makedirs(os.path.dirname(os.path.abspath(a.call_fn)), exist_ok=True)
         mp = getattr(a, "mpileup_fn", None)
-        j.ctg_name, j.bed_path, j.vcf_path = a.ctg_name.encode(), a.candidates_bed_regions.encode(), a.call_fn.encode()
+        j.ctg_name, j.vcf_path = a.ctg_name.encode(), a.call_fn.encode()
+        region = getattr(a, "region", None)
+        if region is not None:                 # REGION job: no candidate BED - the candidates are extracted from the same pile-up
+            j.bed_path, j.region_start, j.region_end = None, int(region[0]), int(region[1])
+            j.candidates_path = a.candidates_out_fn.encode() if getattr(a, "candidates_out_fn", None) else None
+        else:
+            j.bed_path = a.candidates_bed_regions.encode()
         j.mpileup_path = mp.encode() if mp else None
         j.bam_path = None if mp else str(a.tumor_bam_fn).encode()
     cfg = RunCfg()
@@ -212,6 +218,15 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
     cfg.inflate_cus = DEVICE_INFLATE[0] if inflate_cus is None else int(inflate_cus)       # only BAM jobs use it
     cfg.inflate_jobs = DEVICE_INFLATE[1] if inflate_jobs is None else int(inflate_jobs)
     cfg.device_pileup = int(os.environ.get("CTO_DEVICE_PILEUP", "1") != "0")     # the device-inflated chunks are piled up on the device too
+    # gates of REGION jobs = extract_candidates_calling's options as run_clairs_to:1196-1220 passes them
+    from .synth import PLATFORMS as _PF
+    fam = resolve_platform(getattr(a0, "platform", "ont"))[1]
+    cfg.extract_min_mq = int(getattr(a0, "extract_min_mq", None) or 20)
+    cfg.extract_min_bq = int(eng.min_bq if getattr(a0, "extract_min_bq", None) is None else a0.extract_min_bq)
+    cfg.alt_base_num = int(getattr(a0, "alternative_base_num", None) or 3)
+    cfg.snv_min_af = float(getattr(a0, "snv_min_af", None) or 0.05)
+    cfg.indel_min_af = float(getattr(a0, "indel_min_af", None) or _PF.get(fam, _PF["ont"])["indel_min_af"])
+    cfg.min_coverage = float(4 if getattr(a0, "min_coverage", None) is None else a0.min_coverage)
     if two_streams:                               # consecutive chunks on two compute streams (a second pair of handles of the same weights)
         with torch.cuda.device(eng.device):
             cfg.aff2, cfg.neg2 = eng.aff._handle2(), eng.neg._handle2()
@@ -245,12 +260,29 @@ def call_chunks(args):
         sys.exit("[ERROR] clairs_to_amd call_chunks needs a HIP device; there is no CPU fallback")
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
     device = torch.device("cuda", local_rank % torch.cuda.device_count())
-    chunks = [r.strip() for r in open(args.chunk_list) if r.strip()]
+    region_mode = bool(getattr(args, "region_list", None))
+    if region_mode:
+        # REGION jobs: rows `ctg start end` (1-based, inclusive: the --ctg_start / --ctg_end of extract_candidates_calling); no BED
+        chunks = [tuple(r.split()[:3]) for r in open(args.region_list) if r.strip() and not r.startswith("#")]
+    else:
+        chunks = [r.strip() for r in open(args.chunk_list) if r.strip()]
     lo, hi = shard_range(len(chunks), world, rank)
     os.makedirs(args.output_dir, exist_ok=True)
     n_rows, failure = 0, None
 
+    def region_name(r):
+        return "%s_%s_%s" % (r[0], r[1], r[2])
+
     def chunk_args(bed):
+        if region_mode:
+            a = Namespace(**vars(args))
+            a.candidates_bed_regions, a.ctg_name, a.predict_fn, a.region = None, bed[0], None, (int(bed[1]), int(bed[2]))
+            mp_dir = getattr(args, "mpileup_dir", None)
+            a.mpileup_fn = os.path.join(mp_dir, region_name(bed) + ".mpileup") if mp_dir else None
+            a.call_fn = os.path.join(args.output_dir, "p_%s.vcf" % region_name(bed))
+            cd = getattr(args, "candidates_dir", None)
+            a.candidates_out_fn = os.path.join(cd, region_name(bed) + (".snv" if args.disable_indel_calling else ".indel")) if cd else None
+            return a
         ctg = chunk_contig(bed)
         if ctg is None:
             return None
@@ -267,6 +299,12 @@ def call_chunks(args):
             if os.path.exists(a.call_fn):
                 os.remove(a.call_fn)
         how = getattr(args, "pipeline", None) or "auto"
+        if region_mode:
+            if how == "python" or not native_eligible(mine):
+                sys.exit("[ERROR] --region_list runs in the C pipeline only (cto_run_chunks): --mpileup_dir text, --bam_reader native or samtools")
+            how = "native"
+            if getattr(args, "candidates_dir", None):
+                os.makedirs(args.candidates_dir, exist_ok=True)
         if how == "native" and not native_eligible(mine):
             sys.exit("[ERROR] --pipeline native does not do --bam_reader gpu or --predict_fn")
         native = how == "native" or (how == "auto" and native_eligible(mine))
@@ -301,11 +339,11 @@ def call_chunks(args):
     if rank == 0 and args.merged_vcf_fn:
         contigs = []
         for bed in chunks:
-            c = chunk_contig(bed)
+            c = bed[0] if region_mode else chunk_contig(bed)
             if c is not None and c not in contigs:
                 contigs.append(c)
         # merge exactly the chunk VCFs of THIS chunk list (a stale p_*.vcf of another run in the same directory stays out)
-        names = ["p_%s.vcf" % os.path.basename(b) for b in chunks]
+        names = ["p_%s.vcf" % (region_name(b) if region_mode else os.path.basename(b)) for b in chunks]
         n = sort_vcf(args.output_dir, args.merged_vcf_fn, contigs, vcf_fn_prefix="p_", ref_fn=args.ref_fn, sample_name=args.sample_name,
                      only_files=names)
         print("[INFO] merged %d records into %s" % (n, args.merged_vcf_fn), file=sys.stderr)
@@ -322,7 +360,16 @@ def call_chunks(args):
 def main():
     p = ArgumentParser(description="Pileup calling of all candidate chunks of a run, one process per GPU")
     add_common_arguments(p)
-    p.add_argument("--chunk_list", type=str, required=True, help="file with one candidate BED chunk path per line (CANDIDATES_FILES)")
+    p.add_argument("--chunk_list", type=str, default=None, help="file with one candidate BED chunk path per line (CANDIDATES_FILES)")
+    p.add_argument("--region_list", type=str, default=None,
+                   help="instead of --chunk_list: rows `ctg start end` (1-based, inclusive). No candidate BEDs: every region is piled up once "
+                        "and candidate extraction (extract_candidates_calling's gates) runs on that pile-up in HBM, in front of tensor creation")
+    p.add_argument("--candidates_dir", type=str, default=None, help="--region_list: also write each region's candidates as BED window rows here")
+    p.add_argument("--snv_min_af", type=float, default=0.05, help="--region_list: extract_candidates_calling --snv_min_af")
+    p.add_argument("--indel_min_af", type=float, default=None, help="--region_list: --indel_min_af (default: the platform's)")
+    p.add_argument("--min_coverage", type=float, default=4, help="--region_list: --min_coverage")
+    p.add_argument("--alternative_base_num", type=int, default=3, help="--region_list: --alternative_base_num")
+    p.add_argument("--extract_min_mq", type=int, default=20, help="--region_list: --min_mq of extract_candidates_calling")
     p.add_argument("--output_dir", type=str, required=True, help="directory for the p_<chunk>.vcf files")
     p.add_argument("--merged_vcf_fn", type=str, default=None, help="rank 0: sort_vcf of all chunk VCFs")
     p.add_argument("--final_vcf_fn", type=str, default=None, help="rank 0: postprocess_vcf of the merged VCF")
@@ -335,7 +382,10 @@ def main():
     p.add_argument("--pipeline", type=str, default="auto", choices=["auto", "native", "python"],
                    help="'native': the chunk loop as one C call (cto_run_chunks; plain-text inputs, --mpileup_dir or --bam_reader native); "
                         "'python': the thread-pool pipeline of this module; 'auto': native when the inputs allow it")
-    call_chunks(p.parse_args())
+    args = p.parse_args()
+    if bool(args.chunk_list) == bool(args.region_list):
+        p.error("exactly one of --chunk_list / --region_list is required")
+    call_chunks(args)
 
 
 if __name__ == "__main__":

@@ -6,7 +6,9 @@
 // piled up ONCE for extraction, the AFF tensor and the NEG tensor.  HBM-bound integer work, same shape as
 // k_featurize_columns: one wave per 8 consecutive columns, counters in LDS, per-allele (merged key) counts in an
 // LDS table with a global-atomic overflow path.
+#include <mutex>
 #include "common.h"
+#include "pack_internal.h"
 
 namespace {
 
@@ -123,28 +125,102 @@ uint32_t* g_scratch = nullptr;
 int64_t g_scratch_n = 0;
 int g_scratch_dev = -1;
 
+// candidate positions, in column order: the columns whose flag has `bit` set and whose position lies in [lo, hi]
+__device__ __forceinline__ bool is_cand(const uint8_t* __restrict__ flags, const int32_t* __restrict__ col_pos, int64_t c, int64_t n, int bit,
+                                        int32_t lo, int32_t hi) {
+    if (c >= n || !(flags[c] & bit)) return false;
+    const int32_t p = col_pos[c];
+    return p >= lo && p <= hi;
+}
+__global__ __launch_bounds__(256) void k_cand_count(const uint8_t* __restrict__ flags, const int32_t* __restrict__ col_pos, int64_t n, int bit,
+                                                    int32_t lo, int32_t hi, int32_t* __restrict__ block_cnt) {
+    __shared__ int part[4];
+    const int64_t c = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const unsigned long long m = __ballot(is_cand(flags, col_pos, c, n, bit, lo, hi));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ __launch_bounds__(1024) void k_cand_scan(int32_t* __restrict__ block_cnt, int n_blocks, int32_t* __restrict__ total) {   // one workgroup
+    __shared__ int part[1024];
+    const int t = threadIdx.x, per = (n_blocks + 1023) / 1024;
+    const int lo = min(n_blocks, t * per), hi = min(n_blocks, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += block_cnt[i];
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+    for (int i = lo; i < hi; ++i) { const int v = block_cnt[i]; block_cnt[i] = run; run += v; }       // exclusive
+    if (t == 1023) *total = part[t];
+}
+__global__ __launch_bounds__(256) void k_cand_scatter(const uint8_t* __restrict__ flags, const int32_t* __restrict__ col_pos, int64_t n, int bit,
+                                                      int32_t lo, int32_t hi, const int32_t* __restrict__ block_base, int32_t* __restrict__ out,
+                                                      int64_t cap) {
+    __shared__ int part[4];
+    const int64_t c = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const bool take = is_cand(flags, col_pos, c, n, bit, lo, hi);
+    const unsigned long long m = __ballot(take);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) part[w] = __popcll(m);
+    __syncthreads();
+    int base = block_base[blockIdx.x];
+    for (int i = 0; i < w; ++i) base += part[i];
+    const int64_t at = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (take && at < cap) out[at] = col_pos[c];
+}
+
 }  // namespace
+
+int cto::extract_candidates_scratch(const cto_pack_view* dp, int min_mq, int min_bq, double snv_min_af, double indel_min_af, double min_coverage,
+                                    int alt_base_num, int select_indel, uint32_t* scratch, uint8_t* flags, int32_t* depth, void* stream) {
+    if (dp->n_cols == 0) return CTO_OK;
+    XPack pk{dp->n_cols, dp->col_ref, dp->col_off, dp->key_off, dp->entries, dp->key_meta, dp->key_group};
+    const unsigned grid = unsigned(cto::cdiv(dp->n_cols, XCOLS * XWAVES));
+    hipLaunchKernelGGL(k_extract_candidates, dim3(grid), dim3(64 * XWAVES), 0, static_cast<hipStream_t>(stream), pk, min_mq, min_bq, snv_min_af,
+                       indel_min_af, min_coverage, alt_base_num, select_indel, scratch, flags, depth);
+    CTO_HIP(hipGetLastError());
+    return CTO_OK;
+}
 
 extern "C" int cto_extract_candidates(const cto_pack_view* dp, int min_mq, int min_bq, double snv_min_af,
                                       double indel_min_af, double min_coverage, int alt_base_num, int select_indel,
                                       uint8_t* flags, int32_t* depth, void* stream) {
     CTO_REQUIRE(dp && flags && depth, CTO_EINVAL, "cto_extract_candidates: null argument");
     if (dp->n_cols == 0) return CTO_OK;
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    // merged-allele counters of the overflow path (a wave whose 8 columns hold more than 128 distinct indel alleles): one buffer per
+    // process, grown on demand - calls of this entry are serialised (cto_run_chunks brings a buffer per chunk slot instead)
+    static std::mutex m;
+    std::lock_guard<std::mutex> g(m);
     {
         int dev = -1;
         CTO_HIP(hipGetDevice(&dev));
         if (dev != g_scratch_dev) { g_scratch = nullptr; g_scratch_n = 0; g_scratch_dev = dev; }   // another device became current: start over there
     }
     if (dp->n_keys > g_scratch_n) {
-        if (g_scratch) (void)hipFree(g_scratch);
+        if (g_scratch) { CTO_HIP(hipDeviceSynchronize()); (void)hipFree(g_scratch); }
         g_scratch_n = dp->n_keys + dp->n_keys / 4 + 1024;
         CTO_HIP(hipMalloc(reinterpret_cast<void**>(&g_scratch), size_t(g_scratch_n) * 4));
     }
-    XPack pk{dp->n_cols, dp->col_ref, dp->col_off, dp->key_off, dp->entries, dp->key_meta, dp->key_group};
-    const unsigned grid = unsigned(cto::cdiv(dp->n_cols, XCOLS * XWAVES));
-    hipLaunchKernelGGL(k_extract_candidates, dim3(grid), dim3(64 * XWAVES), 0, s, pk, min_mq, min_bq, snv_min_af,
-                       indel_min_af, min_coverage, alt_base_num, select_indel, g_scratch, flags, depth);
+    return cto::extract_candidates_scratch(dp, min_mq, min_bq, snv_min_af, indel_min_af, min_coverage, alt_base_num, select_indel, g_scratch, flags,
+                                           depth, stream);
+}
+
+extern "C" int cto_candidate_positions(const cto_pack_view* dp, const uint8_t* flags, int bit, int32_t lo, int32_t hi, int32_t* out_pos,
+                                       int64_t cap, int32_t* scratch, int32_t* n_out, void* stream) {
+    CTO_REQUIRE(dp && (dp->n_cols == 0 || (flags && out_pos && scratch)) && n_out, CTO_EINVAL, "cto_candidate_positions: null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dp->n_cols == 0) { CTO_HIP(hipMemsetAsync(n_out, 0, 4, s)); return CTO_OK; }
+    const int64_t nb = cto::cdiv(dp->n_cols, 256);
+    CTO_REQUIRE(nb < (int64_t(1) << 30), CTO_EUNSUPPORTED, "cto_candidate_positions: too many columns");
+    hipLaunchKernelGGL(k_cand_count, dim3(unsigned(nb)), dim3(256), 0, s, flags, dp->col_pos, dp->n_cols, bit, lo, hi, scratch);
+    hipLaunchKernelGGL(k_cand_scan, dim3(1), dim3(1024), 0, s, scratch, int(nb), n_out);
+    hipLaunchKernelGGL(k_cand_scatter, dim3(unsigned(nb)), dim3(256), 0, s, flags, dp->col_pos, dp->n_cols, bit, lo, hi, scratch, out_pos, cap);
     CTO_HIP(hipGetLastError());
     return CTO_OK;
 }

@@ -135,4 +135,8 @@ std::unique_ptr<cto_pack> merge_parts(std::vector<std::unique_ptr<cto_pack>>& pa
 int pack_from_mpileup_impl(const char* text, size_t len, const char* ref_seq, int64_t ref_start, size_t ref_len, int max_indel_length,
                            uint32_t* ext_entries, size_t ext_cap, cto_pack** out);
 
+// cto_extract_candidates with the caller's own overflow counters (scratch dev [n_keys] uint32): what concurrent callers on different
+// streams use (csrc/pipeline.hip: one buffer per chunk slot); csrc/extract.hip
+int extract_candidates_scratch(const cto_pack_view* dp, int min_mq, int min_bq, double snv_min_af, double indel_min_af, double min_coverage,
+                               int alt_base_num, int select_indel, uint32_t* scratch, uint8_t* flags, int32_t* depth, void* stream);
 }  // namespace cto

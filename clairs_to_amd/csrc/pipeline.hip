@@ -108,6 +108,8 @@ struct Slot {
     // featurisation / network / epilogue outputs
     DevBuf colvec, coldepth, x_aff, x_neg, la, ln, post;
     DevBuf dec_l, qual_l;                // decision / QUAL of one network launch, before they are dealt out to the chunks they belong to
+    DevBuf xflags, xdepth, xscratch, cand, cand_scr;    // REGION jobs: candidate gates' outputs, overflow counters, candidate positions (+ count)
+    PinBuf cand_host;
     DevBuf res_dev;                      // site_info | candidate column vectors | sitefirst | decision | qual | keycnt | keyfirst
     PinBuf res_host;                     // the same bytes on the host, one copy per chunk
     size_t roff[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -382,6 +384,7 @@ struct CtxReturn {
 };
 
 constexpr int FLANK_POS = 33, EXPAND_REF = 1000;       // shared/param.py no_of_positions, expand_reference_region
+constexpr int REGION_FLANK = 17;                       // flankingBaseNum + 1: the window columns of a candidate at the edge of a region
 
 struct Run {
     const cto_run_cfg* cfg;
@@ -552,24 +555,37 @@ struct Run {
     bool produce(Slot* s, hipStream_t stream) {
         const cto_chunk_job& j = jobs[s->job];
         const std::string ctg = j.ctg_name;
+        const bool region_job = j.bed_path == nullptr;           // candidates are extracted from the pile-up, not read from a BED
         std::string err;
         Mapped bed;
-        if (!bed.open(j.bed_path, &err)) { fail(err); return false; }
-        std::vector<int32_t> centres(std::count(bed.p, bed.p + bed.n, '\n') + 2);
-        int64_t span[2] = {0, 0};
-        int has_types = 0;
-        const int64_t n = cto_bed_centres(bed.p ? bed.p : "", bed.n, ctg.c_str(), centres.data(), int64_t(centres.size()), span, &has_types);
-        if (n < 0) { fail(cto_last_error()); return false; }
-        centres.resize(size_t(n));
-        std::sort(centres.begin(), centres.end());
-        centres.erase(std::unique(centres.begin(), centres.end()), centres.end());
-        s->sites.swap(centres);
-        candidates += int64_t(s->sites.size());
-        if (s->sites.empty()) {
-            if (cfg->verbose) fprintf(stderr, "[INFO] %s total processed positions: 0\n", j.ctg_name);
-            return false;
+        int64_t ctg_start = 0, ctg_end = 0;
+        int64_t cand_lo = 0, cand_hi = 0;                        // REGION job: rows of this range take part in the extraction
+        if (region_job) {
+            ctg_start = std::max<int64_t>(1, j.region_start);
+            ctg_end = j.region_end;
+            // extract_candidates_calling.py:289-292: reads (and therefore rows, and candidates) of ctg_start - 33 .. ctg_end + 33
+            cand_lo = std::max<int64_t>(ctg_start - FLANK_POS, 1);
+            cand_hi = ctg_end + FLANK_POS;
+            s->sites.clear();
+        } else {
+            if (!bed.open(j.bed_path, &err)) { fail(err); return false; }
+            std::vector<int32_t> centres(std::count(bed.p, bed.p + bed.n, '\n') + 2);
+            int64_t span[2] = {0, 0};
+            int has_types = 0;
+            const int64_t n = cto_bed_centres(bed.p ? bed.p : "", bed.n, ctg.c_str(), centres.data(), int64_t(centres.size()), span, &has_types);
+            if (n < 0) { fail(cto_last_error()); return false; }
+            centres.resize(size_t(n));
+            std::sort(centres.begin(), centres.end());
+            centres.erase(std::unique(centres.begin(), centres.end()), centres.end());
+            s->sites.swap(centres);
+            candidates += int64_t(s->sites.size());
+            if (s->sites.empty()) {
+                if (cfg->verbose) fprintf(stderr, "[INFO] %s total processed positions: 0\n", j.ctg_name);
+                return false;
+            }
+            ctg_start = span[0];
+            ctg_end = span[1];
         }
-        const int64_t ctg_start = span[0], ctg_end = span[1];
         s->ref_start = std::max<int64_t>(1, ctg_start - EXPAND_REF);
         FaiRec fr;
         if (!fai_of(ctg, &fr, &err) || !read_region(fasta, fr, s->ref_start, ctg_end + EXPAND_REF, &s->ref, &err)) { fail(err); return false; }
@@ -587,14 +603,17 @@ struct Run {
             rc = pack_from_mpileup_impl(txt.p ? txt.p : "", txt.n, s->ref.data(), s->ref_start, s->ref.size(), cfg->max_indel_length,
                                         static_cast<uint32_t*>(s->stage.p), ecap, &s->pack);
         } else {
-            std::vector<int64_t> iv;
-            bed_intervals(bed.p ? bed.p : "", bed.n, ctg, &iv);
-            const int64_t lo = std::max<int64_t>(1, ctg_start - FLANK_POS), hi = ctg_end + FLANK_POS;
+            std::vector<int64_t> iv;                               // REGION job: every position of the range (no -l)
+            if (!region_job) bed_intervals(bed.p ? bed.p : "", bed.n, ctg, &iv);
+            // REGION job: the candidate range + the flanks of the windows at its edges
+            const int64_t lo = region_job ? std::max<int64_t>(1, cand_lo - REGION_FLANK) : std::max<int64_t>(1, ctg_start - FLANK_POS);
+            const int64_t hi = region_job ? cand_hi + REGION_FLANK : ctg_end + FLANK_POS;
             if (cfg->samtools) {
                 // the reference's own producer: `samtools mpileup` with --min-BQ 0 (one pileup serves both passes), its text tokenised
                 std::vector<std::string> cmd = {cfg->samtools, "mpileup", "--reverse-del", "--output-MQ", "-r",
-                                                ctg + ":" + std::to_string(lo) + "-" + std::to_string(hi), "--min-MQ", "0", "--min-BQ", "0", "-l",
-                                                j.bed_path, "--excl-flags", "2316"};
+                                                ctg + ":" + std::to_string(lo) + "-" + std::to_string(hi), "--min-MQ", "0", "--min-BQ", "0",
+                                                "--excl-flags", "2316"};
+                if (!region_job) { cmd.push_back("-l"); cmd.push_back(j.bed_path); }
                 if (cfg->samtools_max_depth > 0) { cmd.push_back("--max-depth"); cmd.push_back(std::to_string(cfg->samtools_max_depth)); }
                 cmd.push_back(j.bam_path);
                 std::vector<char> text;
@@ -618,9 +637,8 @@ struct Run {
         }
         if (rc != CTO_OK) { fail(cto_last_error()); return false; }
         if (piled_on_device) {               // the pack is in the slot's device buffers already (pack_from_bam_device), s->uploaded recorded
-            std::lock_guard<std::mutex> g(stat_m);
-            pack_s += now_s() - t_pack;
-            return true;
+            { std::lock_guard<std::mutex> g(stat_m); pack_s += now_s() - t_pack; }
+            return region_job ? extract_sites(s, j, cand_lo, cand_hi, stream) : true;
         }
         if (cto_pack_view_of(s->pack, &s->hv) != CTO_OK) { fail(cto_last_error()); return false; }
         // ---- upload ----
@@ -656,6 +674,59 @@ struct Run {
         s->d_site_pos = reinterpret_cast<const int32_t*>(d + off[7]);
         if (hipEventRecord(s->uploaded, stream) != hipSuccess) { fail("hipEventRecord failed"); return false; }
         { std::lock_guard<std::mutex> g(stat_m); pack_s += t_up - t_pack; upload_s += now_s() - t_up; }
+        return region_job ? extract_sites(s, j, cand_lo, cand_hi, stream) : true;
+    }
+
+    // REGION job: STEP 1 of the reference on the pack that is now in HBM (the gates of extract_candidates_calling.py:55-169 as
+    // cto_extract_candidates runs them, the candidate list of :433-446 compacted on the device in position order).  The positions
+    // stay in HBM as the chunk's site list and come to the host once (the writers print them); false = no candidate (no output).
+    bool extract_sites(Slot* s, const cto_chunk_job& j, int64_t cand_lo, int64_t cand_hi, hipStream_t stream) {
+        const double t0 = now_s();
+        const int64_t nc = s->hv.n_cols;
+        if (nc == 0) {
+            if (j.candidates_path) { FILE* f = fopen(j.candidates_path, "w"); if (f) fclose(f); }
+            if (cfg->verbose) fprintf(stderr, "[INFO] %s total processed positions: 0\n", j.ctg_name);
+            return false;
+        }
+        const int64_t nb = cdiv(nc, 256);
+        if (s->xflags.ensure(size_t(nc)) != CTO_OK || s->xdepth.ensure(size_t(nc) * 4) != CTO_OK ||
+            s->xscratch.ensure(size_t(std::max<int64_t>(s->hv.n_keys, 1)) * 4) != CTO_OK || s->cand.ensure(size_t(nc) * 4 + 256) != CTO_OK ||
+            s->cand_scr.ensure(size_t(nb + 2) * 4) != CTO_OK || s->cand_host.ensure(size_t(nc) * 4 + 256) != CTO_OK) {
+            fail(cto_last_error());
+            return false;
+        }
+        const bool indel = cfg->K == 6;
+        int32_t* d_n = static_cast<int32_t*>(s->cand_scr.p) + nb + 1;
+        int rc = extract_candidates_scratch(&s->dv, cfg->extract_min_mq, cfg->extract_min_bq, cfg->snv_min_af, indel ? cfg->indel_min_af : 1.0,
+                                            cfg->min_coverage, cfg->alt_base_num, indel ? 1 : 0, static_cast<uint32_t*>(s->xscratch.p),
+                                            static_cast<uint8_t*>(s->xflags.p), static_cast<int32_t*>(s->xdepth.p), stream);
+        if (rc == CTO_OK)
+            rc = cto_candidate_positions(&s->dv, static_cast<const uint8_t*>(s->xflags.p), indel ? 2 : 1, int32_t(std::min<int64_t>(cand_lo, INT32_MAX)),
+                                         int32_t(std::min<int64_t>(cand_hi, INT32_MAX)), static_cast<int32_t*>(s->cand.p), nc,
+                                         static_cast<int32_t*>(s->cand_scr.p), d_n, stream);
+        if (rc != CTO_OK) { fail(cto_last_error()); return false; }
+        auto* h = static_cast<int32_t*>(s->cand_host.p);
+        if (hipMemcpyAsync(h, d_n, 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipEventRecord(s->uploaded, stream) != hipSuccess ||
+            wait_event(s->uploaded) != hipSuccess) { fail("candidate extraction failed on the device"); return false; }
+        const int64_t n = h[0];
+        candidates += n;
+        if (n > 0) {
+            if (hipMemcpyAsync(h, s->cand.p, size_t(n) * 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipEventRecord(s->uploaded, stream) != hipSuccess ||
+                wait_event(s->uploaded) != hipSuccess) { fail("candidate extraction failed on the device"); return false; }
+            s->sites.assign(h, h + n);
+        }
+        s->d_site_pos = static_cast<const int32_t*>(s->cand.p);
+        if (j.candidates_path) {                 // the reference's BED chunk rows (extract_candidates_calling.py:450-488), one file per region
+            FILE* f = fopen(j.candidates_path, "w");
+            if (!f) { fail(std::string("cannot write ") + j.candidates_path); return false; }
+            for (int64_t i = 0; i < n; ++i) fprintf(f, "%s\t%d\t%d\n", j.ctg_name, std::max(h[i] - 17, 1), h[i] + 17);
+            if (fclose(f) != 0) { fail(std::string("short write to ") + j.candidates_path); return false; }
+        }
+        { std::lock_guard<std::mutex> g(stat_m); pack_s += now_s() - t0; }
+        if (n == 0) {
+            if (cfg->verbose) fprintf(stderr, "[INFO] %s total processed positions: 0\n", j.ctg_name);
+            return false;
+        }
         return true;
     }
 
@@ -929,8 +1000,9 @@ static int run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs, int64_t
                 "cto_run_chunks: null argument");
     CTO_REQUIRE(cfg->K == 4 || cfg->K == 6, CTO_EINVAL, "cto_run_chunks: K must be 4 or 6");
     for (int64_t i = 0; i < n_jobs; ++i)
-        CTO_REQUIRE(jobs[i].ctg_name && jobs[i].bed_path && jobs[i].vcf_path && (jobs[i].mpileup_path || jobs[i].bam_path), CTO_EINVAL,
-                    "cto_run_chunks: job %lld is incomplete", (long long)i);
+        CTO_REQUIRE(jobs[i].ctg_name && jobs[i].vcf_path && (jobs[i].mpileup_path || jobs[i].bam_path) &&
+                        (jobs[i].bed_path || (jobs[i].region_start >= 1 && jobs[i].region_end >= jobs[i].region_start)),
+                    CTO_EINVAL, "cto_run_chunks: job %lld is incomplete", (long long)i);
     if (stats) memset(stats, 0, sizeof(*stats));
     if (n_jobs == 0) return CTO_OK;
     const int producers = std::max(1, cfg->producers), writers = std::max(1, cfg->writers);

@@ -161,12 +161,16 @@ class Engine:
         while inflight:
             yield retire()
 
-    def run_region(self, dev_pack, snv_min_af=0.05, min_coverage=4, alt_base_num=3, min_mq=20):
-        """Candidates as an internal product: extract SNV candidates from the pack (STEP 1 of the reference), then run the
-        hot path on them (STEP 2) without leaving HBM.  Returns (site_pos, outputs)."""
+    def run_region(self, dev_pack, lo=1, hi=2 ** 31 - 1, snv_min_af=0.05, indel_min_af=None, min_coverage=4, alt_base_num=3, min_mq=20):
+        """Candidates as an internal product: STEP 1 of the reference (extract_candidates_calling's gates, with this engine's
+        min_bq as run_clairs_to:1201 passes it) on a pack that holds EVERY position of a region, then the hot path (STEP 2) on the
+        SNV list (K = 4) or the indel list (K = 6) of the rows in [lo, hi] - the same pack, nothing leaves HBM in between.
+        Returns (site_pos int32 device tensor, outputs of run_device)."""
         from .extract_candidates_calling import extract_candidates, candidate_positions
-        flags, _ = extract_candidates(dev_pack, self.min_bq, min_mq, snv_min_af, 1.0, min_coverage, alt_base_num, False)
-        sites = candidate_positions(dev_pack, flags, 1)
+        indel = self.K == 6
+        flags, _ = extract_candidates(dev_pack, self.min_bq, min_mq, snv_min_af, (0.05 if indel_min_af is None else indel_min_af) if indel else 1.0,
+                                      min_coverage, alt_base_num, indel)
+        sites = candidate_positions(dev_pack, flags, 2 if indel else 1, lo, hi)
         return sites, self.run_device(dev_pack, sites)
 
     def run_chunk(self, arrays, site_pos, want_raw=False):

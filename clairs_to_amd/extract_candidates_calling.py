@@ -33,10 +33,21 @@ def extract_candidates(dev_pack, min_bq, min_mq=20, snv_min_af=0.05, indel_min_a
     return flags[:dev_pack.n_cols], depth[:dev_pack.n_cols]
 
 
-def candidate_positions(dev_pack, flags, bit=1):
-    """Sorted 1-based positions of the columns whose flag has `bit` set (device tensor, int32)."""
-    idx = torch.nonzero((flags & bit) != 0).flatten()
-    return dev_pack.t["col_pos"][idx]
+def candidate_positions(dev_pack, flags, bit=1, lo=1, hi=2 ** 31 - 1):
+    """Sorted 1-based positions of the columns whose flag has `bit` set (1 = SNV list, 2 = indel list) and whose position lies in
+    [lo, hi]: device tensor, int32, compacted on the device in position order (cto_candidate_positions)."""
+    dev = dev_pack.device
+    nc = dev_pack.n_cols
+    if nc == 0:
+        return torch.empty((0,), dtype=torch.int32, device=dev)
+    flags = flags.contiguous()
+    out = torch.empty((nc,), dtype=torch.int32, device=dev)
+    scratch = torch.empty(((nc + 255) // 256 + 2,), dtype=torch.int32, device=dev)
+    n_out = torch.empty((1,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.cto_candidate_positions(C.byref(dev_pack.view), flags.data_ptr(), int(bit), int(lo), int(hi), out.data_ptr(), nc,
+                                          scratch.data_ptr(), n_out.data_ptr(), current_stream_ptr()))
+    return out[:int(n_out.item())]
 
 
 def write_bed_chunks(folder, ctg, chunk_id, positions, suffix, list_prefix):

@@ -220,6 +220,12 @@ int cto_featurize_sites(const cto_pack_view* dev_pack, const int32_t* site_pos, 
 int cto_extract_candidates(const cto_pack_view* dev_pack, int min_mq, int min_bq, double snv_min_af,
                            double indel_min_af, double min_coverage, int alt_base_num, int select_indel,
                            uint8_t* flags, int32_t* depth, void* stream);
+/* The candidate lists of extract_candidates_calling.py:433-446 from those flags, on the device and in position order: out_pos
+ * dev [cap] int32 receives the 1-based positions of the columns whose flag has `bit` set (1 = SNV list, 2 = indel list) and whose
+ * position lies in [lo, hi]; *n_out (dev int32) their number (positions beyond cap are counted, not written).  scratch: dev
+ * int32 [ceil(n_cols / 256) + 1].  Stream-ordered; three small launches. */
+int cto_candidate_positions(const cto_pack_view* dev_pack, const uint8_t* flags, int bit, int32_t lo, int32_t hi, int32_t* out_pos,
+                            int64_t cap, int32_t* scratch, int32_t* n_out, void* stream);
 
 /* Host: the reference's alt_info string "<depth>-<key count ...>-" for the column `col` of pass `pass`
  * (0 = AFF, 1 = NEG; create_tensor_pileup_calling.py:158-209), from stage-A outputs copied to the host.
@@ -365,6 +371,17 @@ typedef struct cto_chunk_job {
     const char* mpileup_path;   /* `samtools mpileup --min-BQ 0 ...` text of the chunk, or NULL: read bam_path  */
     const char* bam_path;       /* --tumor_bam_fn (+ .bai), through cto_pack_from_bam                           */
     const char* vcf_path;       /* --call_fn                                                                    */
+    /* REGION job (bed_path == NULL): candidate extraction is an internal product of the run - STEP 1 of the reference
+     * (src/extract_candidates_calling.py:172-503, run_clairs_to:1196-1220) fused in front of tensor creation.  The region
+     * [region_start, region_end] (1-based, the --ctg_start / --ctg_end of extract_candidates_calling or its chunk_id split,
+     * :252-281) is piled up ONCE (all positions of [start - 33 - 17, end + 33 + 17]: the reference's own read region :289-292 plus
+     * the flanks of the windows at its edges) from bam_path (or from mpileup_path: `samtools mpileup --reverse-del --output-MQ
+     * --min-MQ 0 --min-BQ 0 -r` text of that range); the gates of cto_run_cfg run on that pack in HBM (cto_extract_candidates; every
+     * row of [start - 33, end + 33] takes part, as in the reference), the SNV list (K = 4) or the indel list (K = 6) becomes
+     * the chunk's candidate sites, and the same pack feeds tensor creation, the networks and the epilogue. */
+    int64_t region_start, region_end;
+    const char* candidates_path; /* REGION job, optional: the candidates as the rows of the reference's `<ctg>.<chunk>_<i>_<n>_snv|_indel`
+                                    BED chunk files (`ctg \t max(x-17,1) \t x+17`, :450-488), one file for the whole region          */
 } cto_chunk_job;
 typedef struct cto_run_cfg {
     cto_model*    aff;          /* CvT / CvT_Indel                                                              */
@@ -404,9 +421,16 @@ typedef struct cto_run_cfg {
     int    device_pileup;       /* BAM input with inflate_cus > 0: 1 = the chunks that go through the device inflate are piled up there
                                    too (cto_pileup_device: the records stay in HBM, the pack is built in HBM); a chunk that path does
                                    not take (paired reads, ...) is piled up on the host from the device-inflated blocks.  Same packs.  */
+    /* gates of REGION jobs (extract_candidates_calling's options; ignored by BED jobs): */
+    int    extract_min_mq;      /* --min_mq (20)                                                                               */
+    int    extract_min_bq;      /* --min_bq of STEP 1 (the platform's min_bq, run_clairs_to:1201)                               */
+    int    alt_base_num;        /* --alternative_base_num (3)                                                                  */
+    double snv_min_af;          /* --snv_min_af (0.05)                                                                         */
+    double indel_min_af;        /* --indel_min_af (ONT 0.1, others 0.05); used when K = 6                                      */
+    double min_coverage;        /* --min_coverage (4): depth must EXCEED it                                                    */
 } cto_run_cfg;
 typedef struct cto_run_stats {
-    int64_t candidates;                                /* candidate positions read from the BED chunks           */
+    int64_t candidates;                                /* candidate positions read from the BED chunks / extracted from the regions */
     int64_t sites, rows, low_coverage, clamped;        /* sums of cto_vcf_rows_batch's counts                    */
     double  seconds;                                   /* wall clock of the call                                */
     double  produce_s, finish_s;                       /* thread-seconds summed over the producer / writer threads */

@@ -689,3 +689,141 @@ def test_extract_cli_writes_reference_bed_chunks(tmp_path):
     want = extract_to_files(Namespace(candidates_folder=str(tmp_path / "c_text"), mpileup_fn=str(txt), tumor_bam_fn=None,
                                       bam_reader="samtools", ctg_start=None, ctg_end=None, **dict(common, ref_fn=sc["fa"])))
     assert got == want and len(got[0]) > 20
+
+
+def _region_namespace(sc_fa, K, paths, lik, out_dir, name, **kw):
+    from argparse import Namespace
+    base = dict(platform="ont", ref_fn=sc_fa, ctg_name="chr1", samtools="samtools", bam_reader="native", tumor_bam_fn=None, mpileup_fn=None,
+                min_bq=None, max_depth=None, max_indel_length=None, candidates_bed_regions=None, chkpnt_fn_acgt=paths["model_acgt"],
+                chkpnt_fn_nacgt=paths["model_nacgt"], min_rescale_cov=50, disable_indel_calling=(K == 4), likelihood_matrix_data=str(lik),
+                call_fn=os.path.join(out_dir, "p_%s.vcf" % name), predict_fn=None, sample_name="TUMOR", show_ref=True, qual=2, pileup=True)
+    base.update(kw)
+    os.makedirs(out_dir, exist_ok=True)
+    return Namespace(**base)
+
+
+@pytest.mark.parametrize("mode,aff_cls,neg_cls", [("snv", "CvT", "BiGRU_NACGT"), ("indel", "CvT_Indel", "BiGRU_NACGT_Indel")])
+def test_region_job_extracts_the_references_candidates_and_calls_them(tmp_path, mode, aff_cls, neg_cls):
+    """SURVEY 8(f1) delivered inside the run: a REGION job of cto_run_chunks (no candidate BED) on the golden extraction fixture's
+    pileup.  (a) the candidates it extracts in HBM are exactly the lists the reference's extract_candidates_calling wrote for
+    that pileup (its `_snv` / `_indel` BED chunk rows); (b) its VCF is byte-identical to the BED-driven job's on those candidates."""
+    from clairs_to_amd.call_chunks import run_pipeline_native
+    from clairs_to_amd.pileup_call import make_engine
+    from clairs_to_amd.synth import likelihood_table
+    K = 4 if mode == "snv" else 6
+    g = load_json_gz("extract.json.gz")
+    pr = g["params"]
+    ref = "A" * (g["ref_start"] - 1) + g["ref"]
+    fa = tmp_path / "ref.fa"
+    fa.write_text(">chr1\n" + "\n".join(ref[i:i + 60] for i in range(0, len(ref), 60)) + "\n")
+    (tmp_path / "ref.fa.fai").write_text("chr1\t%d\t6\t60\t61\n" % len(ref))
+    mp = tmp_path / "region.mpileup"
+    mp.write_text(g["mpileup_neg"])
+    rows = [int(r.split("\t")[1]) for r in g["mpileup_neg"].split("\n") if r]
+    paths = _pickle_models(tmp_path, aff_cls, neg_cls, K)
+    lik = tmp_path / "lik.txt"
+    np.savetxt(lik, likelihood_table(K, seed=11), fmt="%.17g")
+    gates = dict(snv_min_af=pr["snv_min_af"], indel_min_af=pr["indel_min_af"], min_coverage=pr["min_coverage"], extract_min_mq=pr["min_mq"],
+                 extract_min_bq=pr["min_bq"], alternative_base_num=pr["alt_base_num"])
+    want = g["snv"] if K == 4 else g["indel"]
+    # the region whose +-33 extension (extract_candidates_calling.py:289-292) is exactly the fixture's rows
+    reg = _region_namespace(str(fa), K, paths, lik, str(tmp_path / "reg"), "region", mpileup_fn=str(mp), region=(rows[0] + 33, rows[-1] - 33),
+                            candidates_out_fn=str(tmp_path / "cand.bed"), **gates)
+    eng = make_engine(reg, "cuda:0")
+    st = {}
+    n_reg = run_pipeline_native(eng, [reg], producers=1, writers=1, stats=st, verbose=False)
+    got = [int(r.split("\t")[2]) - 17 for r in open(tmp_path / "cand.bed") if r.strip()]
+    assert got == want and st["sites"] == len(want)
+    assert all(r.split("\t")[1] == str(max(int(r.split("\t")[2]) - 34, 1)) for r in open(tmp_path / "cand.bed") if r.strip())
+    # the BED-driven job on the reference's candidate list, same pileup text
+    bed = tmp_path / "chr1.1_0_1_x"
+    bed.write_text("".join("chr1\t%d\t%d\n" % (max(x - 17, 1), x + 17) for x in want))
+    by_bed = _region_namespace(str(fa), K, paths, lik, str(tmp_path / "bed"), "region", mpileup_fn=str(mp), candidates_bed_regions=str(bed))
+    n_bed = run_pipeline_native(eng, [by_bed], producers=1, writers=1, verbose=False)
+    assert n_reg == n_bed and n_reg > 0
+    assert open(reg.call_fn, "rb").read() == open(by_bed.call_fn, "rb").read()
+    # a narrower region: only the rows of its own +-33 range are candidates
+    lo, hi = want[len(want) // 3], want[-1] - 40
+    part = _region_namespace(str(fa), K, paths, lik, str(tmp_path / "part"), "part", mpileup_fn=str(mp), region=(lo + 33, hi - 33),
+                             candidates_out_fn=str(tmp_path / "part.bed"), **gates)
+    run_pipeline_native(eng, [part], producers=1, writers=1, verbose=False)
+    assert [int(r.split("\t")[2]) - 17 for r in open(tmp_path / "part.bed") if r.strip()] == [x for x in want if lo <= x <= hi]
+
+
+@pytest.mark.parametrize("K", [4, 6])
+def test_region_jobs_from_bam_equal_the_two_step_run(tmp_path, K):
+    """BAM + regions, no BED: inflate -> pile-up of every position -> candidate gates -> tensors -> networks -> VCF in one call, on the
+    device where a context is free (device inflate + device pile-up) and through the host reader otherwise - against the two-step run
+    (extract_candidates on the same BAM's pack, then BED-driven chunks): same candidate lists, same records."""
+    import torch
+    from clairs_to_amd.call_chunks import run_pipeline_native
+    from clairs_to_amd.extract_candidates_calling import extract_candidates, candidate_positions
+    from clairs_to_amd.fasta import read_region
+    from clairs_to_amd.pack import ColumnPack
+    from clairs_to_amd.pileup_call import make_engine
+    from clairs_to_amd.synth import likelihood_table
+    sc = _bam_scenario(tmp_path)
+    cls = ("CvT", "BiGRU_NACGT") if K == 4 else ("CvT_Indel", "BiGRU_NACGT_Indel")
+    paths = _pickle_models(tmp_path, cls[0], cls[1], K)
+    lik = tmp_path / "lik.txt"
+    np.savetxt(lik, likelihood_table(K, seed=11), fmt="%.17g")
+    regions = [(300, 1900), (1901, 3500), (3501, 5600)]
+    # step 1 on its own (the Python mirror of extract_candidates_calling on the native reader's pack), per region with its +-33 rows
+    ref = read_region(sc["fa"], "chr1", 1, sc["L"])
+    want, beds = [], []
+    for i, (a, b) in enumerate(regions):
+        lo, hi = max(1, a - 33), b + 33
+        dp = ColumnPack.from_bam(sc["bam"], "chr1", lo, hi, ref, 1).to_device("cuda:0")
+        flags, _ = extract_candidates(dp, 20, 20, 0.05, 0.1, 4, 3, K == 6)
+        xs = candidate_positions(dp, flags, 1 if K == 4 else 2).cpu().tolist()
+        want.append(xs)
+        bed = tmp_path / ("chr1.%d_0_1_c" % i)
+        bed.write_text("".join("chr1\t%d\t%d\n" % (max(x - 17, 1), x + 17) for x in xs))
+        beds.append(str(bed))
+    assert sum(len(x) for x in want) > (60 if K == 4 else 10)
+    two_step = [_region_namespace(sc["fa"], K, paths, lik, str(tmp_path / "two"), "r%d" % i, tumor_bam_fn=sc["bam"], candidates_bed_regions=b)
+                for i, b in enumerate(beds) if want[i]]
+    eng = make_engine(two_step[0], "cuda:0")
+    n_two = run_pipeline_native(eng, two_step, producers=2, writers=1, verbose=False, inflate_cus=0)
+    for tag, kw in (("host", dict(inflate_cus=0)), ("device", dict(inflate_cus=64, inflate_jobs=2))):
+        out = str(tmp_path / tag)
+        jobs = [_region_namespace(sc["fa"], K, paths, lik, out, "r%d" % i, tumor_bam_fn=sc["bam"], region=r,
+                                  candidates_out_fn=os.path.join(out, "cand%d.bed" % i)) for i, r in enumerate(regions)]
+        st = {}
+        n = run_pipeline_native(eng, jobs, producers=2, writers=1, stats=st, verbose=False, **kw)
+        assert n == n_two and st["sites"] == sum(len(x) for x in want)
+        if tag == "device":
+            assert st["device_piled"] >= 1
+        for i in range(len(regions)):
+            got = [int(r.split("\t")[2]) - 17 for r in open(os.path.join(out, "cand%d.bed" % i)) if r.strip()]
+            assert got == want[i], (tag, i)
+            a, b = os.path.join(out, "p_r%d.vcf" % i), str(tmp_path / "two" / ("p_r%d.vcf" % i))
+            assert os.path.exists(a) == os.path.exists(b)
+            if os.path.exists(a):
+                assert open(a, "rb").read() == open(b, "rb").read(), (tag, i)
+    torch.cuda.synchronize()
+
+
+def test_engine_run_region_is_extraction_plus_run_device(tmp_path):
+    """Engine.run_region: candidates as an internal product on a resident pack == extract_candidates + candidate_positions + run_device"""
+    import torch
+    from clairs_to_amd.engine import Engine, synthetic_models
+    from clairs_to_amd.extract_candidates_calling import extract_candidates, candidate_positions
+    from clairs_to_amd.synth import SynthChunk, likelihood_table, lik_and_edges
+    dev = torch.device("cuda:0")
+    chunk = SynthChunk(300, seed=9, spacing=40, p_mismatch=0.03, p_ins=0.02, p_del=0.03)
+    for K in (4, 6):
+        models = synthetic_models(K)
+        lik, edges = lik_and_edges(likelihood_table(K), K)
+        eng = Engine(models["aff"], models["neg"], lik, edges, min_bq=20, device=dev)
+        dp = eng.upload(chunk.arrays())
+        lo, hi = int(chunk.col_pos[200]), int(chunk.col_pos[-200])
+        sites, out = eng.run_region(dp, lo, hi, indel_min_af=0.1)
+        flags, _ = extract_candidates(dp, 20, 20, 0.05, 0.1 if K == 6 else 1.0, 4, 3, K == 6)
+        f, pos = flags.cpu().numpy(), chunk.col_pos
+        want = pos[((f & (1 if K == 4 else 2)) != 0) & (pos >= lo) & (pos <= hi)]
+        assert sites.cpu().tolist() == want.tolist() and len(want) > 5
+        assert candidate_positions(dp, flags, 1 if K == 4 else 2).cpu().tolist() == pos[(f & (1 if K == 4 else 2)) != 0].tolist()
+        ref = eng.run_device(dp, sites)
+        for k in ("probs", "post", "decision", "qual"):
+            assert torch.equal(out[k], ref[k])
