@@ -27,6 +27,22 @@ def chunk_namespaces(run, out_dir, bam=False, bam_reader="native"):
     return out
 
 
+def region_namespaces(run, out_dir, n_regions, bam_reader="native"):
+    """REGION jobs over the BAM of a synthetic run: the contig cut into n_regions ranges, no candidate BEDs - candidate extraction is
+    an internal product of the run (cto_run_chunks REGION jobs; call_chunks --region_list)"""
+    L = run["contig_len"]
+    per = (L + n_regions - 1) // n_regions
+    out = []
+    for i in range(n_regions):
+        a = Namespace(platform="ont", ref_fn=run["ref_fn"], samtools="samtools", bam_reader=bam_reader, tumor_bam_fn=run["bam_fn"], min_bq=None,
+                      max_depth=None, max_indel_length=None, min_rescale_cov=50, disable_indel_calling=True, sample_name="SAMPLE", show_ref=False,
+                      qual=0, pileup=True, predict_fn=None, output_dir=out_dir, candidates_bed_regions=None, mpileup_fn=None, ctg_name=run["ctg"],
+                      region=(max(1, i * per + 1), min(L, (i + 1) * per)))
+        a.call_fn = os.path.join(out_dir, "p_%s_%d_%d.vcf" % (a.ctg_name, a.region[0], a.region[1]))
+        out.append(a)
+    return out
+
+
 def build_run(d, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, region_kb=None):
     """synthetic run directory under `d` (input synthesis, untimed) -> (run dict, description)"""
     from .synth_run import make_bam_run, make_text_run
@@ -41,13 +57,14 @@ def build_run(d, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, reg
         region_kb, os.path.getsize(run["bam_fn"]) / 1e6, len(run["chunks"]))
 
 
-def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4, bam_reader="native", pipeline="python", inflate_cus=None, inflate_jobs=None, two_streams=False):
+def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4, bam_reader="native", pipeline="python", inflate_cus=None, inflate_jobs=None, two_streams=False,
+             regions=0):
     """the pipeline over a prepared run directory -> dict(sites_per_s, ...); best of `repeats` passes (the first one warms the page
     cache, the pinned buffers and the model workspaces)"""
     from .call_chunks import default_producers, run_pipeline, run_pipeline_native
     producers = producers if producers else default_producers(kind == "bam", pipeline)
     os.makedirs(out_dir, exist_ok=True)
-    chunk_args = chunk_namespaces(run, out_dir, bam=(kind == "bam"), bam_reader=bam_reader)
+    chunk_args = region_namespaces(run, out_dir, regions, bam_reader) if regions else chunk_namespaces(run, out_dir, bam=(kind == "bam"), bam_reader=bam_reader)
     best, rows, best_stats = None, 0, {}
     for _ in range(max(1, repeats)):
         stats = {}
@@ -65,16 +82,23 @@ def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4, bam_
             host = dict(user_cpu_ms_per_chunk=round((ru1.ru_utime - ru0.ru_utime) * 1e3 / max(1, len(chunk_args)), 2),
                         sys_cpu_ms_per_chunk=round((ru1.ru_stime - ru0.ru_stime) * 1e3 / max(1, len(chunk_args)), 2),
                         minor_faults_per_chunk=int((ru1.ru_minflt - ru0.ru_minflt) / max(1, len(chunk_args))))
-    extra = {k: int(best_stats[k]) for k in ("device_inflated",) if k in best_stats}
+    extra = {k: int(best_stats[k]) for k in ("device_inflated", "device_piled") if k in best_stats}
+    n_sites = run["n_sites"]
+    if regions:                              # the candidates are the run's own product; every position of the contig was scanned for them
+        n_sites = int(best_stats.get("sites", 0))
+        extra["positions_scanned"] = int(run["contig_len"])
+        extra["positions_per_s"] = round(run["contig_len"] / best, 1)
+        extra["candidates_extracted"] = n_sites
     per_chunk = {k[:-2] + "_ms_per_chunk": round(v * 1e3 / max(1, len(chunk_args)), 3) for k, v in best_stats.items() if k.endswith("_s")}
-    return dict(sites_per_s=round(run["n_sites"] / best, 1), sites=int(run["n_sites"]), chunks=len(chunk_args), seconds=round(best, 4),
+    return dict(sites_per_s=round(n_sites / best, 1), sites=int(n_sites), chunks=len(chunk_args), seconds=round(best, 4),
                 producers=producers, writers=writers, pipeline=pipeline, vcf_records=int(rows), stage_thread_time=per_chunk, host_process=host, **extra,
                 includes="disk reads, tokenise / BAM decode, PCIe both ways, kernels, alt_info + VCF rows (C), file writes")
 
 
 def measure(eng, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, region_kb=None, producers=None, writers=2, workdir=None,
-            repeats=4, pipeline="python"):
-    """build_run + time_run in a temporary directory"""
+            repeats=4, pipeline="python", with_extraction=False):
+    """build_run + time_run in a temporary directory.  with_extraction (kind "bam"): -> (BED-driven leg, REGION-job leg on the same
+    BAM: no candidate BEDs, the candidates are extracted from the pile-up inside the run)"""
     d = tempfile.mkdtemp(prefix="cto_e2e_", dir=workdir)
     try:
         t0 = time.perf_counter()
@@ -82,6 +106,12 @@ def measure(eng, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, reg
         prep_s = time.perf_counter() - t0
         r = time_run(eng, run, kind, os.path.join(d, "vcf_output"), producers, writers, repeats, pipeline=pipeline)
         r.update(source=source, input_synthesis_s=round(prep_s, 1))
+        if with_extraction and kind == "bam":
+            r2 = time_run(eng, run, kind, os.path.join(d, "vcf_output_regions"), producers, writers, repeats, pipeline="native", regions=len(run["chunks"]))
+            r2.update(source=source.replace("chunk files, candidates every 250 bp", "REGION jobs (no candidate BEDs: extract_candidates_calling's gates "
+                                                                                    "run on the pile-up of every position, in HBM)"),
+                      includes=r2["includes"] + ", candidate extraction")
+            return r, r2
         return r
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -116,8 +146,12 @@ def main():
     out = {"host_cores_usable": usable_cores(), "host_cores_visible": os.cpu_count()}
     for kind in a.kinds.split(","):
         n = a.chunks if kind == "text" else (a.bam_chunks or max(2, a.chunks // 3))
-        out["mpileup_text_to_vcf" if kind == "text" else "bam_to_vcf"] = measure(eng, kind=kind, n_chunks=n, sites_per_chunk=a.batch,
-                                                                                 producers=a.producers, writers=a.writers, pipeline=a.pipeline)
+        r = measure(eng, kind=kind, n_chunks=n, sites_per_chunk=a.batch, producers=a.producers, writers=a.writers, pipeline=a.pipeline,
+                    with_extraction=(kind == "bam" and a.pipeline == "native"))
+        if isinstance(r, tuple):
+            out["bam_to_vcf"], out["bam_to_vcf_with_extraction"] = r
+        else:
+            out["mpileup_text_to_vcf" if kind == "text" else "bam_to_vcf"] = r
     if a.reference_chunk_sites > 0 and "text" in a.kinds.split(","):
         n = max(4, a.chunks * a.batch // a.reference_chunk_sites)
         out["mpileup_text_to_vcf_reference_chunks"] = measure(eng, kind="text", n_chunks=n, sites_per_chunk=a.reference_chunk_sites,

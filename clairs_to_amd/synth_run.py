@@ -201,4 +201,4 @@ def make_bam_run(d, region_kb=1000, n_chunks=4, depth=50, spacing=250, seed=1, c
     chunk_list = os.path.join(d, "CANDIDATES_FILES")
     with open(chunk_list, "w") as f:
         f.write("".join(n + "\n" for n in names))
-    return dict(ref_fn=ref_fn, bam_fn=bam_fn, chunk_list=chunk_list, chunks=names, n_sites=len(sites))
+    return dict(ref_fn=ref_fn, bam_fn=bam_fn, chunk_list=chunk_list, chunks=names, n_sites=len(sites), contig_len=L, ctg=ctg)
