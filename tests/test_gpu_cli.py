@@ -744,7 +744,9 @@ def test_region_job_extracts_the_references_candidates_and_calls_them(tmp_path, 
     assert open(reg.call_fn, "rb").read() == open(by_bed.call_fn, "rb").read()
     # a narrower region: only the rows of its own +-33 range are candidates
     lo, hi = want[len(want) // 3], want[-1] - 40
-    part = _region_namespace(str(fa), K, paths, lik, str(tmp_path / "part"), "part", mpileup_fn=str(mp), region=(lo + 33, hi - 33),
+    mp2 = tmp_path / "part.mpileup"        # `samtools mpileup -r` of that region's own read range (+ the window flanks at its edges)
+    mp2.write_text("".join(r + "\n" for r in g["mpileup_neg"].split("\n") if r and lo - 17 <= int(r.split("\t")[1]) <= hi + 17))
+    part = _region_namespace(str(fa), K, paths, lik, str(tmp_path / "part"), "part", mpileup_fn=str(mp2), region=(lo + 33, hi - 33),
                              candidates_out_fn=str(tmp_path / "part.bed"), **gates)
     run_pipeline_native(eng, [part], producers=1, writers=1, verbose=False)
     assert [int(r.split("\t")[2]) - 17 for r in open(tmp_path / "part.bed") if r.strip()] == [x for x in want if lo <= x <= hi]
