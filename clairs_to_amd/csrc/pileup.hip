@@ -15,7 +15,8 @@
 //   k_compact       accepted reads in file order
 //   k_cover         +1 / -1 per read at the first / one-past-last REQUESTED position it covers (the BED intervals of the
 //                   candidate windows, concatenated: a read covers a contiguous run of that space)
-//   k_columns       one workgroup: running sum -> depth per requested position, rows only where depth > 0, entry offsets
+//   k_columns_*     running sum -> depth per requested position, rows only where depth > 0, entry offsets (tile sums, their scan
+//                   by one workgroup, then every 4096-position tile on top of its base)
 //   k_fill          one wave per read, one lane per CIGAR operation (prefix sums over 64 operations at a time give every lane
 //                   its reference / query offsets): read-bases, deletion placeholders and the indel attached to the last base
 //                   of an aligned run go to their column through an atomic cursor, tagged with the read's rank in file order
@@ -176,6 +177,54 @@ __global__ __launch_bounds__(1024) void k_scan_small(const int* __restrict__ in,
     if (t == 0) { out[n] = Out(carry); if (total) *total = Out(carry); }
 }
 
+// The same over arrays of any length, spread over the chip: block sums of 4096-element tiles, their scan by one workgroup, then
+// every tile scans itself on top of its base (a region piled up at every position has a million columns: the one-workgroup
+// form above took 0.7 ms for them, the three launches below ~15 us).
+constexpr int SCAN_TILE = 4096;
+__global__ __launch_bounds__(1024) void k_tile_sums(const int* __restrict__ in, int n, long long* __restrict__ tsum) {
+    __shared__ long long wsum[17];
+    const int i0 = blockIdx.x * SCAN_TILE + 4 * threadIdx.x;
+    long long v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v += i0 + k < n ? in[i0 + k] : 0;
+    long long tot;
+    (void)block_scan_excl(v, &tot, wsum);
+    if (threadIdx.x == 0) tsum[blockIdx.x] = tot;
+}
+// exclusive scan in place of up to three interleaved arrays of tile sums (a[i * stride + j], j < stride) by one workgroup;
+// totals[j] receives the sums
+__global__ __launch_bounds__(1024) void k_scan_tiles(long long* __restrict__ a, int n, int stride, long long* __restrict__ totals) {
+    __shared__ long long wsum[17];
+    const int t = threadIdx.x;
+    for (int j = 0; j < stride; ++j) {
+        long long carry = 0;
+        for (int base = 0; base < n; base += 1024) {
+            const int i = base + t;
+            const long long v = i < n ? a[size_t(i) * stride + j] : 0;
+            long long tot;
+            const long long ex = carry + block_scan_excl(v, &tot, wsum);
+            if (i < n) a[size_t(i) * stride + j] = ex;
+            carry += tot;
+        }
+        if (t == 0) totals[j] = carry;
+        __syncthreads();
+    }
+}
+template <typename Out>
+__global__ __launch_bounds__(1024) void k_scan_apply(const int* __restrict__ in, Out* __restrict__ out, int n, const long long* __restrict__ tbase,
+                                                     const long long* __restrict__ totals, Out* total) {
+    __shared__ long long wsum[17];
+    const int i0 = blockIdx.x * SCAN_TILE + 4 * threadIdx.x;
+    int v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = i0 + k < n ? in[i0 + k] : 0;
+    long long tot;
+    long long ex = tbase[blockIdx.x] + block_scan_excl((long long)v[0] + v[1] + v[2] + v[3], &tot, wsum);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (i0 + k < n) out[i0 + k] = Out(ex); ex += v[k]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[n] = Out(totals[0]); if (total) *total = Out(totals[0]); }
+}
+
 __global__ void k_parse(const uint8_t* __restrict__ lin, const uint32_t* __restrict__ rec_off, int n_rec, int tid, int beg0, int end0,
                         int excl_flags, int min_mq, DevRead* __restrict__ reads, Flags* fl) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -334,37 +383,56 @@ __global__ void k_cover(const DevRead* __restrict__ reads, const int* __restrict
 constexpr int ORD_DMAX_COLS = 2048;      // = ORD_DMAX of k_order
 // One workgroup (1024 threads, 4096 slots per pass, coalesced): depth per slot (running sum of diff), rows where depth > 0
 // (slot_col, col_slot), col_off.
-__global__ __launch_bounds__(1024) void k_columns(const int* __restrict__ diff, int total, int* __restrict__ slot_col, int* __restrict__ col_slot,
-                                                  long long* __restrict__ col_off, Flags* fl) {
+// k_columns over the chip: (1) tile sums of the marks, scanned -> the depth in front of every tile; (2) per tile the number of
+// positions with depth > 0 and the sum of their depths, scanned -> the first column / entry of every tile; (3) every tile writes
+// its rows.  The one-workgroup form took 3.7 ms for the million positions of a region piled up without a BED.
+__device__ __forceinline__ void tile_depths(const int* __restrict__ diff, int total, long long before, int i0, long long* wsum, int (&d)[4],
+                                            long long (&dep)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = i0 + k < total ? diff[i0 + k] : 0;
+    long long tot;
+    long long depth = before + block_scan_excl((long long)d[0] + d[1] + d[2] + d[3], &tot, wsum);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { depth += d[k]; dep[k] = i0 + k < total ? depth : 0; }
+}
+__global__ __launch_bounds__(1024) void k_columns_count(const int* __restrict__ diff, int total, const long long* __restrict__ depth_base,
+                                                        long long* __restrict__ tcnt /* [tiles][2] */) {
     __shared__ long long wsum[17];
-    const int t = threadIdx.x;
-    long long c_depth = 0, c_cols = 0, c_off = 0;
+    const int i0 = blockIdx.x * SCAN_TILE + 4 * threadIdx.x;
+    int d[4];
+    long long dep[4];
+    tile_depths(diff, total, depth_base[blockIdx.x], i0, wsum, d, dep);
+    long long nz = 0, ds = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { nz += dep[k] > 0; ds += dep[k]; }
+    long long tn, td;
+    (void)block_scan_excl(nz, &tn, wsum);
+    (void)block_scan_excl(ds, &td, wsum);
+    if (threadIdx.x == 0) { tcnt[size_t(blockIdx.x) * 2] = tn; tcnt[size_t(blockIdx.x) * 2 + 1] = td; }
+}
+__global__ __launch_bounds__(1024) void k_columns_write(const int* __restrict__ diff, int total, const long long* __restrict__ depth_base,
+                                                        const long long* __restrict__ tcnt, const long long* __restrict__ totals,
+                                                        int* __restrict__ slot_col, int* __restrict__ col_slot, long long* __restrict__ col_off, Flags* fl) {
+    __shared__ long long wsum[17];
+    const int i0 = blockIdx.x * SCAN_TILE + 4 * threadIdx.x;
+    int d[4];
+    long long dep[4];
+    tile_depths(diff, total, depth_base[blockIdx.x], i0, wsum, d, dep);
+    long long nz = 0, ds = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { nz += dep[k] > 0; ds += dep[k]; }
+    long long tn, td;
+    long long c = tcnt[size_t(blockIdx.x) * 2] + block_scan_excl(nz, &tn, wsum);
+    long long o = tcnt[size_t(blockIdx.x) * 2 + 1] + block_scan_excl(ds, &td, wsum);
     bool deep = false;
-    for (int base = 0; base < total; base += 4096) {
-        const int i0 = base + 4 * t;
-        int d[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) d[k] = i0 + k < total ? diff[i0 + k] : 0;
-        long long tot;
-        long long depth = c_depth + block_scan_excl((long long)d[0] + d[1] + d[2] + d[3], &tot, wsum);
-        c_depth += tot;
-        long long dep[4], nz = 0, ds = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { depth += d[k]; dep[k] = i0 + k < total ? depth : 0; nz += dep[k] > 0; ds += dep[k]; }
-        long long tot_n, tot_d;
-        long long c = c_cols + block_scan_excl(nz, &tot_n, wsum);
-        long long o = c_off + block_scan_excl(ds, &tot_d, wsum);
-        c_cols += tot_n;
-        c_off += tot_d;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (i0 + k >= total) break;
-            if (dep[k] > 0) { slot_col[i0 + k] = int(c); col_slot[c] = i0 + k; col_off[c] = o; ++c; o += dep[k]; deep |= dep[k] > ORD_DMAX_COLS; }
-            else slot_col[i0 + k] = -1;
-        }
+    for (int k = 0; k < 4; ++k) {
+        if (i0 + k >= total) break;
+        if (dep[k] > 0) { slot_col[i0 + k] = int(c); col_slot[c] = i0 + k; col_off[c] = o; ++c; o += dep[k]; deep |= dep[k] > ORD_DMAX_COLS; }
+        else slot_col[i0 + k] = -1;
     }
     if (deep) atomicExch(&fl->deep_col, 1);
-    if (t == 0) { fl->n_cols = int(c_cols); fl->n_entries = c_off; col_off[c_cols] = c_off; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { fl->n_cols = int(totals[0]); fl->n_entries = totals[1]; col_off[totals[0]] = totals[1]; }
 }
 
 __global__ void k_col_meta(const int* __restrict__ col_slot, int n_cols, Ivs iv, const char* __restrict__ ref, long long ref_start, long long ref_len,
@@ -672,6 +740,7 @@ struct Buf {
 }  // namespace
 
 struct cto_dev_pileup {
+    Buf tile_a, tile_b, tile_tot;        // tile sums of the spread-out scans
     Buf lin, lin_off, blocks, starts, counts, base, rec_off, reads, rid, live, iv, diff, slot_col, col_slot, col_off, col_pos, col_ref, cursor, tmp,
         entries, nkc, keyrec, key_off, key_meta, key_group, key_final, key_col, key_len, str_off, key_str, ref, flags, z1k;
     bool z1k_ready = false;
@@ -832,8 +901,19 @@ extern "C" int cto_pileup_device(cto_dev_pileup* cx, const void* d_inflated, con
     }
     Ivs iv{cx->iv.as<int>(), cx->iv.as<int>() + n_iv, cx->iv.as<int>() + 2 * n_iv, n_iv, total};
     hipLaunchKernelGGL(k_cover, dim3(unsigned(cdiv(n_rec, 128))), dim3(128), 0, s, cx->reads.as<DevRead>(), cx->rid.as<int>(), fl, iv, cx->diff.as<int>());
-    hipLaunchKernelGGL(k_columns, dim3(1), dim3(1024), 0, s, cx->diff.as<int>(), total, cx->slot_col.as<int>(), cx->col_slot.as<int>(),
-                       cx->col_off.as<long long>(), fl);
+    {
+        const int tiles = int(cdiv(total, SCAN_TILE));
+        if ((rc = cx->tile_a.ensure(size_t(tiles + 1) * 8)) || (rc = cx->tile_b.ensure(size_t(tiles + 1) * 16)) || (rc = cx->tile_tot.ensure(64))) return rc;
+        long long* ta = cx->tile_a.as<long long>();
+        long long* tb = cx->tile_b.as<long long>();
+        long long* tt = cx->tile_tot.as<long long>();
+        hipLaunchKernelGGL(k_tile_sums, dim3(unsigned(tiles)), dim3(1024), 0, s, cx->diff.as<int>(), total, ta);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, ta, tiles, 1, tt + 2);
+        hipLaunchKernelGGL(k_columns_count, dim3(unsigned(tiles)), dim3(1024), 0, s, cx->diff.as<int>(), total, ta, tb);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tb, tiles, 2, tt);
+        hipLaunchKernelGGL(k_columns_write, dim3(unsigned(tiles)), dim3(1024), 0, s, cx->diff.as<int>(), total, ta, tb, tt, cx->slot_col.as<int>(),
+                           cx->col_slot.as<int>(), cx->col_off.as<long long>(), fl);
+    }
     CTO_HIP(hipGetLastError());
     if ((rc = fetch_flags())) return rc;
     const int lim = hf->stop_idx;
@@ -856,7 +936,16 @@ extern "C" int cto_pileup_device(cto_dev_pileup* cx, const void* d_inflated, con
     hipLaunchKernelGGL(k_order, dim3(unsigned(std::min(n_cols, 16384))), dim3(64), 0, s, lin, cx->reads.as<DevRead>(), cx->rid.as<int>(), n_cols,
                        cx->col_off.as<long long>(), cx->tmp.as<TmpEnt>(), cx->entries.as<uint32_t>(), cx->nkc.as<int>(), cx->keyrec.as<KeyRec>(),
                        max_indel_length, fl);
-    hipLaunchKernelGGL(k_scan_small<int>, dim3(1), dim3(1024), 0, s, cx->nkc.as<int>(), cx->key_off.as<int>(), n_cols, &fl->n_keys);
+    if (n_cols <= 4 * SCAN_TILE) {
+        hipLaunchKernelGGL(k_scan_small<int>, dim3(1), dim3(1024), 0, s, cx->nkc.as<int>(), cx->key_off.as<int>(), n_cols, &fl->n_keys);
+    } else {
+        const int tiles = int(cdiv(n_cols, SCAN_TILE));
+        if ((rc = cx->tile_a.ensure(size_t(tiles + 1) * 8)) || (rc = cx->tile_tot.ensure(64))) return rc;
+        hipLaunchKernelGGL(k_tile_sums, dim3(unsigned(tiles)), dim3(1024), 0, s, cx->nkc.as<int>(), n_cols, cx->tile_a.as<long long>());
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, cx->tile_a.as<long long>(), tiles, 1, cx->tile_tot.as<long long>());
+        hipLaunchKernelGGL(k_scan_apply<int>, dim3(unsigned(tiles)), dim3(1024), 0, s, cx->nkc.as<int>(), cx->key_off.as<int>(), n_cols,
+                           cx->tile_a.as<long long>(), cx->tile_tot.as<long long>(), &fl->n_keys);
+    }
     CTO_HIP(hipGetLastError());
     if ((rc = fetch_flags())) return rc;
     if (hf->ref_oob) { set_error("cto_pileup_device: a covered position lies outside the supplied reference"); return CTO_EINVAL; }

@@ -776,20 +776,20 @@ def test_region_jobs_from_bam_equal_the_two_step_run(tmp_path, K):
     for i, (a, b) in enumerate(regions):
         lo, hi = max(1, a - 33), b + 33
         dp = ColumnPack.from_bam(sc["bam"], "chr1", lo, hi, ref, 1).to_device("cuda:0")
-        flags, _ = extract_candidates(dp, 20, 20, 0.05, 0.1, 4, 3, K == 6)
+        flags, _ = extract_candidates(dp, 20, 20, 0.05, 0.03, 4, 3, K == 6)
         xs = candidate_positions(dp, flags, 1 if K == 4 else 2).cpu().tolist()
         want.append(xs)
         bed = tmp_path / ("chr1.%d_0_1_c" % i)
         bed.write_text("".join("chr1\t%d\t%d\n" % (max(x - 17, 1), x + 17) for x in xs))
         beds.append(str(bed))
-    assert sum(len(x) for x in want) > (60 if K == 4 else 10)
+    assert sum(len(x) for x in want) > (60 if K == 4 else 5)
     two_step = [_region_namespace(sc["fa"], K, paths, lik, str(tmp_path / "two"), "r%d" % i, tumor_bam_fn=sc["bam"], candidates_bed_regions=b)
                 for i, b in enumerate(beds) if want[i]]
     eng = make_engine(two_step[0], "cuda:0")
     n_two = run_pipeline_native(eng, two_step, producers=2, writers=1, verbose=False, inflate_cus=0)
     for tag, kw in (("host", dict(inflate_cus=0)), ("device", dict(inflate_cus=64, inflate_jobs=2))):
         out = str(tmp_path / tag)
-        jobs = [_region_namespace(sc["fa"], K, paths, lik, out, "r%d" % i, tumor_bam_fn=sc["bam"], region=r,
+        jobs = [_region_namespace(sc["fa"], K, paths, lik, out, "r%d" % i, tumor_bam_fn=sc["bam"], region=r, indel_min_af=0.03,
                                   candidates_out_fn=os.path.join(out, "cand%d.bed" % i)) for i, r in enumerate(regions)]
         st = {}
         n = run_pipeline_native(eng, jobs, producers=2, writers=1, stats=st, verbose=False, **kw)
