@@ -773,10 +773,11 @@ def test_region_jobs_from_bam_equal_the_two_step_run(tmp_path, K):
     # step 1 on its own (the Python mirror of extract_candidates_calling on the native reader's pack), per region with its +-33 rows
     ref = read_region(sc["fa"], "chr1", 1, sc["L"])
     want, beds = [], []
+    abn = 3 if K == 4 else 1                 # the scenario's indels are private to their reads: one supporting read makes an indel candidate
     for i, (a, b) in enumerate(regions):
         lo, hi = max(1, a - 33), b + 33
         dp = ColumnPack.from_bam(sc["bam"], "chr1", lo, hi, ref, 1).to_device("cuda:0")
-        flags, _ = extract_candidates(dp, 20, 20, 0.05, 0.03, 4, 3, K == 6)
+        flags, _ = extract_candidates(dp, 20, 20, 0.05, 0.01, 4, abn, K == 6)
         xs = candidate_positions(dp, flags, 1 if K == 4 else 2).cpu().tolist()
         want.append(xs)
         bed = tmp_path / ("chr1.%d_0_1_c" % i)
@@ -789,7 +790,7 @@ def test_region_jobs_from_bam_equal_the_two_step_run(tmp_path, K):
     n_two = run_pipeline_native(eng, two_step, producers=2, writers=1, verbose=False, inflate_cus=0)
     for tag, kw in (("host", dict(inflate_cus=0)), ("device", dict(inflate_cus=64, inflate_jobs=2))):
         out = str(tmp_path / tag)
-        jobs = [_region_namespace(sc["fa"], K, paths, lik, out, "r%d" % i, tumor_bam_fn=sc["bam"], region=r, indel_min_af=0.03,
+        jobs = [_region_namespace(sc["fa"], K, paths, lik, out, "r%d" % i, tumor_bam_fn=sc["bam"], region=r, indel_min_af=0.01, alternative_base_num=abn,
                                   candidates_out_fn=os.path.join(out, "cand%d.bed" % i)) for i, r in enumerate(regions)]
         st = {}
         n = run_pipeline_native(eng, jobs, producers=2, writers=1, stats=st, verbose=False, **kw)
