@@ -1101,7 +1101,8 @@ extern "C" int64_t cto_bgzf_scan(const uint8_t* bytes, size_t len, int64_t file_
         b.isize = isize;
         b.bsize = uint32_t(bsize);
         b.crc32 = uint32_t(tail[0]) | (uint32_t(tail[1]) << 8) | (uint32_t(tail[2]) << 16) | (uint32_t(tail[3]) << 24);
-        out += (int64_t(isize) + 4 + 255) / 256 * 256;           // dword-granular tail stores stay inside the slot
+        out += (int64_t(isize) + CTO_BGZF_SLOT_PAD + 255) / 256 * 256;   // the inflate kernel checks a literal run's output bound once
+                                                                         // per 32 input bits: a malformed block may run that far past its isize
         o += size_t(bsize);
     }
     *out_bytes = out;

@@ -110,10 +110,12 @@ int cto_pack_from_bam(const char* bam_path, const char* bai_path, const char* ct
  *   [copy the inflated bytes back]      cto_pack_from_bam_inflated: cto_pack_from_bam reading those blocks from memory (blocks that
  *                           are not in the table - the header at the start of the file - are still inflated on the host). */
 #define CTO_BGZF_PAD 1024
+#define CTO_BGZF_SLOT_PAD 64   /* bytes behind every block's inflated size in the output buffer (cto_bgzf_scan lays the slots out so) */
 typedef struct cto_bgzf_block {
     uint64_t file_off;        /* offset of the block (its gzip header) in the BAM file                      */
     uint64_t in_off;          /* offset of its DEFLATE payload in the byte range handed to cto_bgzf_scan    */
-    uint64_t out_off;         /* offset of its inflated bytes in the output buffer (multiple of 256)        */
+    uint64_t out_off;         /* offset of its inflated bytes in the output buffer (multiple of 256; the next slot
+                                 starts at least CTO_BGZF_SLOT_PAD bytes behind out_off + isize)              */
     uint32_t csize, isize;    /* payload bytes, inflated bytes                                              */
     uint32_t bsize, crc32;    /* whole block incl. header and trailer; CRC-32 of the inflated bytes (gzip trailer) */
 } cto_bgzf_block;

@@ -52,16 +52,7 @@
 
 namespace {
 
-#ifndef CTO_INF_TBL
-#define CTO_INF_TBL 9
-#endif
-#ifndef CTO_INF_TBD
-#define CTO_INF_TBD 8
-#endif
-#ifndef CTO_INF_TOK
-#define CTO_INF_TOK 128
-#endif
-constexpr int TBL = CTO_INF_TBL, TBD = CTO_INF_TBD;       // index bits of the literal / length and the distance lookup tables
+constexpr int TBL = 10, TBD = 9;       // index bits of the literal / length and the distance lookup tables
 
 // base value and number of extra bits of length symbol ls = sym - 257 (0..28) and of distance symbol ds (0..29), RFC 1951 3.2.5, in
 // closed form: the tables would be global-memory loads whose s_waitcnt also drains the byte stores in flight
@@ -233,67 +224,17 @@ __device__ __forceinline__ int huff_decode_fast(const Huff& h, const uint16_t* t
     return huff_decode<NREG>(h, bits32, lane, len);
 }
 
-// ---- lookup tables of the symbol loop: 32-bit entries that carry everything a symbol needs --------------------------------------
-// (libdeflate's idea: the loop never maps a symbol to its base value / extra-bit count - the table entry holds them)
-//   literal / length table [next TBL bits]:  literal  E_LIT | code length << 8 | byte
-//                                            end of block E_EOB | code length << 8
-//                                            length   E_VAL | (code length + extra bits) << 24 | code length << 16 | extra bits << 12 | base (3..258)
-//   distance table [next TBD bits]:          E_VAL | (code length + extra bits) << 24 | code length << 20 | extra bits << 16 | base (1..24577)
-//   0: the code is longer than the index (canonical search, huff_decode);  E_BAD: a symbol RFC 1951 reserves (286, 287; 30, 31)
-// The classes compare as unsigned numbers: literal > end of block > value > (E_BAD, 0).
-constexpr uint32_t E_LIT = 0x80000000u, E_EOB = 0x40000000u, E_VAL = 0x20000000u, E_BAD = 1u;
-__device__ __forceinline__ uint32_t litlen_entry(uint32_t sym, uint32_t len) {
-    if (sym < 256u) return E_LIT | (len << 8) | sym;
-    if (sym == 256u) return E_EOB | (len << 8);
-    const int ls = int(sym) - 257;
-    if (ls >= 29) return E_BAD;
-    int base, extra;
-    len_code(ls, &base, &extra);
-    return E_VAL | ((len + uint32_t(extra)) << 24) | (len << 16) | (uint32_t(extra) << 12) | uint32_t(base);
-}
-__device__ __forceinline__ uint32_t dist_entry(uint32_t sym, uint32_t len) {
-    if (sym >= 30u) return E_BAD;
-    int base, extra;
-    dist_code(int(sym), &base, &extra);
-    return E_VAL | ((len + uint32_t(extra)) << 24) | (len << 20) | (uint32_t(extra) << 16) | uint32_t(base);
-}
-template <int TB, bool DIST>
-__device__ void huff_table32(const Huff& h, const uint8_t* lens, const uint16_t* sorted, uint32_t* fo, uint32_t* table, int lane) {
-    if (lane < 16) { fo[lane] = h.first; fo[16 + lane] = h.offset; }
-    for (int i = lane; i < (1 << TB); i += 64) table[i] = 0;
-    const int total = int(rl(h.offset + h.count, 15));         // symbols that have a code
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < total; i += 64) {
-        const uint32_t sym = sorted[i];
-        const uint32_t len = lens[sym];
-        if (len <= uint32_t(TB)) {
-            const uint32_t code = fo[len] + (uint32_t(i) - fo[16 + len]);
-            const uint32_t rev = __brev(code) >> (32 - len);
-            const uint32_t e = DIST ? dist_entry(sym, len) : litlen_entry(sym, len);
-            for (uint32_t k = rev; k < (1u << TB); k += (1u << len)) table[k] = e;
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
-}
-
 enum { ST_OK = 0, ST_BAD_BTYPE = 1, ST_BAD_STORED = 2, ST_BAD_TABLE = 3, ST_BAD_CODE = 4, ST_BAD_DIST = 5, ST_OVERRUN_OUT = 6, ST_OVERRUN_IN = 7, ST_SHORT = 8 };
 
 }  // namespace
 
-#ifdef CTO_INF_WAVES
-#define CTO_INF_ATTR __attribute__((amdgpu_waves_per_eu(CTO_INF_WAVES, CTO_INF_WAVES)))
-#else
-#define CTO_INF_ATTR
-#endif
-extern "C" __global__ __launch_bounds__(64) CTO_INF_ATTR void k_bgzf_inflate(const uint8_t* __restrict__ comp, const cto_bgzf_block* __restrict__ blocks,
+extern "C" __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* __restrict__ comp, const cto_bgzf_block* __restrict__ blocks,
                                                                 int n_blocks, uint8_t* __restrict__ out, int* __restrict__ status) {
     __shared__ uint8_t lens[320];
     __shared__ uint16_t sorted[320];
     __shared__ uint32_t fo[32];
-    __shared__ uint32_t tab_l[1 << TBL];
-    __shared__ uint32_t tab_d[1 << TBD];
+    __shared__ uint16_t tab_l[1 << TBL];
+    __shared__ uint16_t tab_d[1 << TBD];
     const int lane = threadIdx.x;
     const int blk = blockIdx.x;
     if (blk >= n_blocks) return;
@@ -310,8 +251,8 @@ extern "C" __global__ __launch_bounds__(64) CTO_INF_ATTR void k_bgzf_inflate(con
     // and resolved TOK at a time by all lanes, one match per lane, so that the trip to memory is paid once per 64 matches instead
     // of once per match.  A match whose source ends inside the not-yet-resolved part of the queue waits for a later round
     // (resolve_matches); literals are stored as they are decoded and have landed before a round starts.
-    constexpr int TOK = CTO_INF_TOK;
-    __shared__ uint64_t tok[TOK];            // destination | source << 16 | length << 32
+    constexpr int TOK = 256;
+    __shared__ uint16_t tok_dst[TOK], tok_src[TOK], tok_len[TOK];
     int ntok = 0;
     auto resolve_matches = [&]() {
         if (ntok == 0) return;
@@ -322,10 +263,9 @@ extern "C" __global__ __launch_bounds__(64) CTO_INF_ATTR void k_bgzf_inflate(con
         while (c < ntok) {
             const int t = c + lane;
             const bool mine = t < ntok && !((done >> lane) & 1);
-            const uint64_t tk = mine ? tok[t] : 0;
-            const int td = int(tk & 0xffffu), ts = int((tk >> 16) & 0xffffu), tn = int(tk >> 32);
+            const int td = mine ? int(tok_dst[t]) : 0, ts = mine ? int(tok_src[t]) : 0, tn = mine ? int(tok_len[t]) : 0;
             const int d = td - ts;
-            const int first = int(tok[c] & 0xffffu);             // everything below the oldest unresolved destination is final
+            const int first = int(tok_dst[c]);                   // everything below the oldest unresolved destination is final
             const bool ready = mine && ts + (d < tn ? d : tn) <= first;
             if (ready) {
                 // the (k mod d) form reads the repeating pattern of an overlapping copy from its first period: no byte of this copy
@@ -443,276 +383,93 @@ extern "C" __global__ __launch_bounds__(64) CTO_INF_ATTR void k_bgzf_inflate(con
             __builtin_amdgcn_s_waitcnt(0);
             __builtin_amdgcn_wave_barrier();
             if (!huff_build<5>(hl, lens, 288, sorted, lane)) { st = ST_BAD_TABLE; break; }
-            huff_table32<TBL, false>(hl, lens, sorted, fo, tab_l, lane);
+            huff_table<TBL, true>(hl, lens, sorted, fo, tab_l, lane);
             huff_build<1>(hd, lens + 288, 30, sorted, lane);     // an incomplete distance code is legal (one code, or none)
-            huff_table32<TBD, true>(hd, lens + 288, sorted, fo, tab_d, lane);
+            huff_table<TBD>(hd, lens + 288, sorted, fo, tab_d, lane);
 
             // ---- symbols ----
-            // The decoder is wave-uniform code, and what bounds a chip full of these waves is plain instruction issue: a CU gets
-            // through about ONE instruction per cycle of whatever kind (PMC with 8 launches in flight: SALU + VALU + LDS + VMEM
-            // instructions of a launch / 256 CUs / the launch's share of the wall clock = 1.0 at 2.4 GHz - for the round-3 loop's 65
-            // instructions per symbol and for a compiler-made vector-register loop's 43 alike).  The two paths nearly every symbol
-            // takes - a literal, and a match whose two codes hit the tables - are therefore written out by hand for instruction
-            // COUNT: 16 instructions per literal, 59 per match (the compiler's best: 26 / 75).  Bit buffer (two dwords, bits above
-            // `cnt` zero) and output position in vector registers (every lane the same value), bit count and queue fill in scalar
-            // ones; 32-bit table entries that carry base value, extra-bit count and their sum; the stored byte straight out of the
-            // looked-up register; a literal run's output bound checked once per refill (<= 32 literals; the output slots carry
-            // CTO_BGZF_SLOT_PAD bytes of padding), a match's exactly.  Everything else leaves the block with a reason code and is
-            // handled in C++ below: a refill that needs the next 256 input bytes (or runs past the payload), codes longer than the
-            // tables' index, end of block, a full match queue, malformed streams.
-            {
-                uint32_t vlo, vhi, vop;
-                asm volatile("v_mov_b32 %0, %1" : "=v"(vlo) : "s"(uint32_t(b.bb)));
-                asm volatile("v_mov_b32 %0, %1" : "=v"(vhi) : "s"(uint32_t(b.bb >> 32)));
-                asm volatile("v_mov_b32 %0, %1" : "=v"(vop) : "s"(uint32_t(op)));
-                int cnt = b.cnt;
-                const uint32_t lds_tl = uint32_t(uintptr_t(tab_l)), lds_td = uint32_t(uintptr_t(tab_d)), lds_tok = uint32_t(uintptr_t(tok));
-                enum { R_REFILL = 1, R_RARE = 2, R_EOB = 3, R_RARE_DIST = 4, R_OVERRUN = 5, R_BAD_DIST = 6, R_QUEUE = 7 };
-                auto drop = [&](int nb) {
-                    uint64_t v = (uint64_t(vhi) << 32) | vlo;
-                    v >>= nb;
-                    vlo = uint32_t(v);
-                    vhi = uint32_t(v >> 32);
-                    cnt -= nb;
-                };
-                auto refill = [&]() -> bool {                    // at least 32 valid bits afterwards; false: the literal run overran the output
-                    if (cnt < 32) {
-                        uint32_t d_ = 0;
-                        if (b.widx <= b.limit) {
-                            if (b.widx - b.wbase >= 64) {
-                                b.wbase += 64;
-                                b.win = b.src[b.wbase + lane];
-                                __builtin_amdgcn_s_waitcnt(0x0F70);
+            for (;;) {
+                // Literal run: a table hit with the literal flag is a byte store (all lanes store the same byte to the same address:
+                // one transaction, no exec-mask juggling) and a shift.  This loop is two thirds of all symbols of a BAM block and is
+                // kept free of everything the other symbols need (the general form below cost ~50 instructions per literal in
+                // compiler-made copies and checks; a single wave issues them one at a time).
+                // The bit buffer of this loop lives in VECTOR registers (every lane holds the same value): a CU has one scalar unit for
+                // its four SIMDs and the decoder is bound by it, so the shifts, masks and the table address go to the vector ALUs and the
+                // scalar unit keeps the branches, the output position and the store address.
+                {
+                    uint32_t vlo, vhi;
+                    int vcnt;
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(vlo) : "s"(uint32_t(b.bb)));
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(vhi) : "s"(uint32_t(b.bb >> 32)));
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(vcnt) : "s"(b.cnt));
+                    uint32_t vop;                                // the output position once more, for the store's address
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(vop) : "s"(uint32_t(op)));
+                    uint64_t vbb = (uint64_t(vhi) << 32) | vlo;
+                    for (;;) {
+                        if (uni(vcnt) <= 32) {                   // bits_refill on the vector copy
+                            uint32_t d = 0;
+                            if (b.widx <= b.limit) {
+                                if (b.widx - b.wbase >= 64) {
+                                    b.wbase += 64;
+                                    b.win = b.src[b.wbase + lane];
+                                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                                }
+                                d = rl(b.win, b.widx - b.wbase);
+                            } else {
+                                b.over = 1;
                             }
-                            d_ = rl(b.win, b.widx - b.wbase);
-                        } else {
-                            b.over = 1;                          // zeros from here on; the loop ends on its output bound
+                            vbb |= uint64_t(d) << vcnt;
+                            vcnt += 32;
+                            ++b.widx;
                         }
-                        const uint64_t add = uint64_t(d_) << cnt;
-                        vlo |= uint32_t(add);
-                        vhi |= uint32_t(add >> 32);
-                        cnt += 32;
-                        ++b.widx;
-                        if (uni(int(vop)) > isize) return false;
+                        const uint32_t e = uint32_t(__builtin_amdgcn_readfirstlane(int(tab_l[uint32_t(vbb) & ((1u << TBL) - 1u)])));
+                        if (!(e & 0x8000u)) break;
+                        if (op >= isize) break;
+                        dst[vop] = uint8_t(e);
+                        ++vop;
+                        ++op;
+                        const int l = int((e >> 9) & 15u);
+                        vbb >>= l;
+                        vcnt -= l;
                     }
-                    return true;
-                };
-                auto queue_match = [&](uint32_t n, uint32_t d) -> bool {
-                    if (__ballot(d > vop || vop + n > uint32_t(isize))) { st = uni(int(d > vop)) ? ST_BAD_DIST : ST_OVERRUN_OUT; return false; }
-                    tok[ntok] = uint64_t(vop | ((vop - d) << 16)) | (uint64_t(n) << 32);     // every lane, the same value
-                    ++ntok;
-                    vop += n;
-                    if (ntok == TOK) resolve_matches();
-                    return true;
-                };
-                auto slow_dist = [&](uint32_t n) -> bool {       // the distance of a match of length n, tables or canonical search
-                    if (!refill()) { st = ST_OVERRUN_OUT; return false; }
-                    uint32_t ed = uint32_t(uni(int(tab_d[vlo & ((1u << TBD) - 1u)])));
-                    if (ed < E_VAL) {
-                        if (ed != 0) { st = ST_BAD_DIST; return false; }
-                        int dl0 = 0;
-                        const int ds = huff_decode<1>(hd, vlo, lane, &dl0);
-                        if (ds < 0) { st = ST_BAD_DIST; return false; }
-                        ed = dist_entry(uint32_t(ds), uint32_t(dl0));
-                        if (ed < E_VAL) { st = ST_BAD_DIST; return false; }
-                    }
-                    const int dl = int((ed >> 20) & 15u), dex = int((ed >> 16) & 15u);
-                    const uint32_t d = (ed & 0x7fffu) + ((vlo >> dl) & ((1u << dex) - 1u));
-                    drop(dl + dex);
-                    return queue_match(n, d);
-                };
-                for (bool more = true; more && st == ST_OK;) {
-                    int reason;
-                    uint32_t e, vn, t0, t2;
-                    int s0, s1, s2, s3;
-                    uint32_t vtk = lds_tok + uint32_t(ntok) * 8u;     // LDS address of the next queue entry (a vector register inside)
-                    asm volatile("v_mov_b32 %0, %0" : "+v"(vtk));
-                    asm volatile(
-                        "L_top%=:\n\t"
-                        "s_cmp_lt_i32 %[cnt], 32\n\t"
-                        "s_cbranch_scc1 L_refill%=\n"
-                        "L_look%=:\n\t"
-                        "v_and_b32 %[t0], %[mskl], %[lo]\n\t"
-                        "v_lshl_add_u32 %[t0], %[t0], 2, %[tl]\n\t"
-                        "ds_read_b32 %[t0], %[t0]\n\t"
-                        "s_waitcnt lgkmcnt(0)\n\t"
-                        "v_readfirstlane_b32 %[e], %[t0]\n\t"
-                        "s_cmp_lt_i32 %[e], 0\n\t"
-                        "s_cbranch_scc0 L_nonlit%=\n\t"
-                        // ---- literal ----
-                        "global_store_byte %[vop], %[t0], %[dst]\n\t"
-                        "s_bfe_u32 %[s0], %[e], 0x40008\n\t"
-                        "v_add_u32 %[vop], 1, %[vop]\n\t"
-                        "v_alignbit_b32 %[lo], %[hi], %[lo], %[s0]\n\t"
-                        "v_lshrrev_b32 %[hi], %[s0], %[hi]\n\t"
-                        "s_sub_i32 %[cnt], %[cnt], %[s0]\n\t"
-                        "s_branch L_top%=\n"
-                        // ---- refill in front of a literal / length code ----
-                        "L_refill%=:\n\t"
-                        "s_cmp_gt_i32 %[widx], %[limit]\n\t"
-                        "s_cbranch_scc1 L_x_refill%=\n\t"
-                        "s_sub_i32 %[s0], %[widx], %[wbase]\n\t"
-                        "s_cmp_lt_i32 %[s0], 64\n\t"
-                        "s_cbranch_scc0 L_x_refill%=\n\t"
-                        "v_readfirstlane_b32 %[s1], %[vop]\n\t"
-                        "s_cmp_gt_i32 %[s1], %[isize]\n\t"
-                        "s_cbranch_scc1 L_x_overrun%=\n\t"
-                        "v_readlane_b32 %[s1], %[win], %[s0]\n\t"
-                        "s_lshl_b32 %[s2], %[s1], %[cnt]\n\t"
-                        "s_lshr_b32 %[s1], %[s1], 1\n\t"
-                        "s_sub_i32 %[s3], 31, %[cnt]\n\t"
-                        "s_lshr_b32 %[s1], %[s1], %[s3]\n\t"
-                        "v_or_b32 %[lo], %[s2], %[lo]\n\t"
-                        "v_or_b32 %[hi], %[s1], %[hi]\n\t"
-                        "s_add_i32 %[cnt], %[cnt], 32\n\t"
-                        "s_add_i32 %[widx], %[widx], 1\n\t"
-                        "s_branch L_look%=\n"
-                        // ---- not a literal ----
-                        "L_nonlit%=:\n\t"
-                        "s_cmp_lt_u32 %[e], 0x20000000\n\t"
-                        "s_cbranch_scc1 L_x_rare%=\n\t"
-                        "s_cmp_ge_u32 %[e], 0x40000000\n\t"
-                        "s_cbranch_scc1 L_x_eob%=\n\t"
-                        // length: base + extra bits
-                        "s_bfe_u32 %[s0], %[e], 0x40010\n\t"
-                        "s_bfe_u32 %[s1], %[e], 0x3000c\n\t"
-                        "s_bfm_b32 %[s1], %[s1], 0\n\t"
-                        "s_and_b32 %[s2], %[e], 0x1ff\n\t"
-                        "v_lshrrev_b32 %[vn], %[s0], %[lo]\n\t"
-                        "v_and_b32 %[vn], %[s1], %[vn]\n\t"
-                        "v_add_u32 %[vn], %[s2], %[vn]\n\t"
-                        "s_bfe_u32 %[s0], %[e], 0x50018\n\t"
-                        "v_alignbit_b32 %[lo], %[hi], %[lo], %[s0]\n\t"
-                        "v_lshrrev_b32 %[hi], %[s0], %[hi]\n\t"
-                        "s_sub_i32 %[cnt], %[cnt], %[s0]\n\t"
-                        "s_cmp_lt_i32 %[cnt], 32\n\t"
-                        "s_cbranch_scc0 L_dist%=\n\t"
-                        // refill in front of a distance code
-                        "s_cmp_gt_i32 %[widx], %[limit]\n\t"
-                        "s_cbranch_scc1 L_x_raredist%=\n\t"
-                        "s_sub_i32 %[s0], %[widx], %[wbase]\n\t"
-                        "s_cmp_lt_i32 %[s0], 64\n\t"
-                        "s_cbranch_scc0 L_x_raredist%=\n\t"
-                        "v_readlane_b32 %[s1], %[win], %[s0]\n\t"
-                        "s_lshl_b32 %[s2], %[s1], %[cnt]\n\t"
-                        "s_lshr_b32 %[s1], %[s1], 1\n\t"
-                        "s_sub_i32 %[s3], 31, %[cnt]\n\t"
-                        "s_lshr_b32 %[s1], %[s1], %[s3]\n\t"
-                        "v_or_b32 %[lo], %[s2], %[lo]\n\t"
-                        "v_or_b32 %[hi], %[s1], %[hi]\n\t"
-                        "s_add_i32 %[cnt], %[cnt], 32\n\t"
-                        "s_add_i32 %[widx], %[widx], 1\n"
-                        "L_dist%=:\n\t"
-                        "v_and_b32 %[t0], %[mskd], %[lo]\n\t"
-                        "v_lshl_add_u32 %[t0], %[t0], 2, %[td]\n\t"
-                        "ds_read_b32 %[t0], %[t0]\n\t"
-                        "s_waitcnt lgkmcnt(0)\n\t"
-                        "v_readfirstlane_b32 %[e], %[t0]\n\t"
-                        "s_cmp_lt_u32 %[e], 0x20000000\n\t"
-                        "s_cbranch_scc1 L_x_raredist%=\n\t"
-                        "s_bfe_u32 %[s0], %[e], 0x40014\n\t"
-                        "s_bfe_u32 %[s1], %[e], 0x40010\n\t"
-                        "s_bfm_b32 %[s1], %[s1], 0\n\t"
-                        "s_and_b32 %[s2], %[e], 0x7fff\n\t"
-                        "v_lshrrev_b32 %[t0], %[s0], %[lo]\n\t"
-                        "v_and_b32 %[t0], %[s1], %[t0]\n\t"
-                        "v_add_u32 %[t0], %[s2], %[t0]\n\t"                      // t0 = distance
-                        "s_bfe_u32 %[s0], %[e], 0x50018\n\t"
-                        "v_alignbit_b32 %[lo], %[hi], %[lo], %[s0]\n\t"
-                        "v_lshrrev_b32 %[hi], %[s0], %[hi]\n\t"
-                        "s_sub_i32 %[cnt], %[cnt], %[s0]\n\t"
-                        "v_cmp_gt_u32 vcc, %[t0], %[vop]\n\t"                  // distance beyond the output so far
-                        "v_add_u32 %[t2], %[vop], %[vn]\n\t"                   // t2 = end of the match
-                        "s_cbranch_vccnz L_x_baddist%=\n\t"
-                        "v_cmp_lt_u32 vcc, %[isize], %[t2]\n\t"
-                        "s_cbranch_vccnz L_x_overrun%=\n\t"
-                        "v_sub_u32 %[t0], %[vop], %[t0]\n\t"                   // source
-                        "v_lshl_or_b32 %[t0], %[t0], 16, %[vop]\n\t"           // destination | source << 16
-                        "ds_write2_b32 %[vtk], %[t0], %[vn] offset1:1\n\t"
-                        "v_add_u32 %[vtk], 8, %[vtk]\n\t"
-                        "v_mov_b32 %[vop], %[t2]\n\t"
-                        "s_add_i32 %[ntok], %[ntok], 1\n\t"
-                        "s_cmp_eq_u32 %[ntok], %[tokcap]\n\t"
-                        "s_cbranch_scc0 L_top%=\n\t"
-                        "s_mov_b32 %[reason], 7\n\t"
-                        "s_branch L_out%=\n"
-                        "L_x_refill%=:\n\t"
-                        "s_mov_b32 %[reason], 1\n\t"
-                        "s_branch L_out%=\n"
-                        "L_x_rare%=:\n\t"
-                        "s_mov_b32 %[reason], 2\n\t"
-                        "s_branch L_out%=\n"
-                        "L_x_eob%=:\n\t"
-                        "s_mov_b32 %[reason], 3\n\t"
-                        "s_branch L_out%=\n"
-                        "L_x_raredist%=:\n\t"
-                        "s_mov_b32 %[reason], 4\n\t"
-                        "s_branch L_out%=\n"
-                        "L_x_overrun%=:\n\t"
-                        "s_mov_b32 %[reason], 5\n\t"
-                        "s_branch L_out%=\n"
-                        "L_x_baddist%=:\n\t"
-                        "s_mov_b32 %[reason], 6\n"
-                        "L_out%=:\n\t"
-                        "s_waitcnt lgkmcnt(0)\n\t"
-                        : [lo] "+v"(vlo), [hi] "+v"(vhi), [vop] "+v"(vop), [cnt] "+s"(cnt), [widx] "+s"(b.widx), [ntok] "+s"(ntok),
-                          [vtk] "+v"(vtk), [reason] "=&s"(reason), [e] "=&s"(e), [vn] "=&v"(vn), [t0] "=&v"(t0), [t2] "=&v"(t2),
-                          [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3)
-                        : [win] "v"(b.win), [wbase] "s"(b.wbase), [limit] "s"(b.limit), [isize] "s"(isize), [dst] "s"(dst), [tl] "s"(lds_tl),
-                          [td] "s"(lds_td), [mskl] "s"((1u << TBL) - 1u), [mskd] "s"((1u << TBD) - 1u), [tokcap] "s"(TOK)
-                        : "vcc", "scc", "memory");
-                    switch (reason) {
-                    case R_QUEUE:
-                        resolve_matches();
-                        break;
-                    case R_REFILL:                               // the next 256 input bytes, or the end of the payload
-                        if (!refill()) st = ST_OVERRUN_OUT;
-                        break;
-                    case R_EOB:
-                        drop(int((e >> 8) & 15u));
-                        more = false;
-                        break;
-                    case R_OVERRUN:
-                        st = ST_OVERRUN_OUT;
-                        break;
-                    case R_BAD_DIST:
-                        st = ST_BAD_DIST;
-                        break;
-                    case R_RARE_DIST:                            // the length (vn) is consumed; the distance needs a refill beyond the
-                        (void)slow_dist(vn);                     // window or a code longer than the table's index
-                        break;
-                    default: {                                   // R_RARE: a literal / length code longer than the table's index
-                        if (e != 0) { st = ST_BAD_CODE; break; }
-                        int l = 0;
-                        const int sy = huff_decode<5>(hl, vlo, lane, &l);
-                        if (sy < 0) { st = ST_BAD_CODE; break; }
-                        const uint32_t e2 = litlen_entry(uint32_t(sy), uint32_t(l));
-                        if (e2 & E_LIT) {
-                            if (uni(int(vop)) >= isize) { st = ST_OVERRUN_OUT; break; }
-                            dst[vop] = uint8_t(e2);
-                            ++vop;
-                            drop(l);
-                        } else if (e2 >= E_EOB) {
-                            drop(l);
-                            more = false;
-                        } else if (e2 >= E_VAL) {
-                            const int ex = int((e2 >> 12) & 7u);
-                            const uint32_t n = (e2 & 511u) + ((vlo >> l) & ((1u << ex) - 1u));
-                            drop(l + ex);
-                            (void)slow_dist(n);
-                        } else {
-                            st = ST_BAD_CODE;
-                        }
-                        break;
-                    }
-                    }
+                    b.bb = uint64_t(uint32_t(uni(int(uint32_t(vbb))))) | (uint64_t(uint32_t(uni(int(uint32_t(vbb >> 32))))) << 32);
+                    b.cnt = uni(vcnt);
                 }
-                b.bb = uint64_t(uint32_t(uni(int(vlo)))) | (uint64_t(uint32_t(uni(int(vhi)))) << 32);
-                b.cnt = cnt;
-                op = uni(int(vop));
-                if (st == ST_OK && op > isize) st = ST_OVERRUN_OUT;
-                if (st == ST_OK && (b.over || bits_used(b) > in_bits + 64)) st = ST_OVERRUN_IN;
-                if (st != ST_OK) break;
+                bits_refill(b, lane);
+                int l = 0;
+                const int s = huff_decode_fast<5, TBL>(hl, tab_l, uint32_t(b.bb), lane, &l);
+                if (s < 0) { st = ST_BAD_CODE; break; }
+                bits_drop(b, l);
+                if (b.over || bits_used(b) > in_bits + 64) { st = ST_OVERRUN_IN; break; }
+                if (s < 256) {
+                    if (op >= isize) { st = ST_OVERRUN_OUT; break; }
+                    if (lane == 0) dst[op] = uint8_t(s);
+                    ++op;
+                } else if (s == 256) {
+                    break;
+                } else {
+                    const int ls = s - 257;
+                    if (ls >= 29) { st = ST_BAD_CODE; break; }
+                    int lbase, le;
+                    len_code(ls, &lbase, &le);
+                    const int n = lbase + int(bits_peek(b, le));
+                    bits_drop(b, le);
+                    bits_refill(b, lane);
+                    int dlb = 0;
+                    const int ds = huff_decode_fast<1, TBD>(hd, tab_d, uint32_t(b.bb), lane, &dlb);
+                    if (ds < 0 || ds >= 30) { st = ST_BAD_DIST; break; }
+                    bits_drop(b, dlb);
+                    int dbase, de;
+                    dist_code(ds, &dbase, &de);
+                    const int d = dbase + int(bits_peek(b, de));
+                    bits_drop(b, de);
+                    if (d > op) { st = ST_BAD_DIST; break; }
+                    if (op + n > isize) { st = ST_OVERRUN_OUT; break; }
+                    if (lane == 0) { tok_dst[ntok] = uint16_t(op); tok_src[ntok] = uint16_t(op - d); tok_len[ntok] = uint16_t(n); }
+                    ++ntok;
+                    op += n;
+                    if (ntok == TOK) resolve_matches();
+                }
             }
             resolve_matches();                                   // end of this DEFLATE block: a stored block may follow
         }
