@@ -611,9 +611,10 @@ struct Run {
             if (cfg->samtools) {
                 // the reference's own producer: `samtools mpileup` with --min-BQ 0 (one pileup serves both passes), its text tokenised
                 std::vector<std::string> cmd = {cfg->samtools, "mpileup", "--reverse-del", "--output-MQ", "-r",
-                                                ctg + ":" + std::to_string(lo) + "-" + std::to_string(hi), "--min-MQ", "0", "--min-BQ", "0",
-                                                "--excl-flags", "2316"};
-                if (!region_job) { cmd.push_back("-l"); cmd.push_back(j.bed_path); }
+                                                ctg + ":" + std::to_string(lo) + "-" + std::to_string(hi), "--min-MQ", "0", "--min-BQ", "0"};
+                if (!region_job) { cmd.push_back("-l"); cmd.push_back(j.bed_path); }      // the reference's order of options
+                cmd.push_back("--excl-flags");
+                cmd.push_back("2316");
                 if (cfg->samtools_max_depth > 0) { cmd.push_back("--max-depth"); cmd.push_back(std::to_string(cfg->samtools_max_depth)); }
                 cmd.push_back(j.bam_path);
                 std::vector<char> text;
