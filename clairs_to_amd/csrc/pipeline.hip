@@ -626,7 +626,9 @@ struct Run {
             } else {
                 InflateCtx* c = nullptr;
                 int done = 0;
-                if (free_ctx.try_pop(&c)) {                        // a device-inflate context is free: this chunk's blocks go to the GPU
+                // a device-inflate context is free: this chunk's blocks go to the GPU.  A REGION job waits for one: piled up at every
+                // position it is seven times a BED chunk's work, which the host reader needs most of a second of a core for
+                if (region_job && cfg->device_pileup && !inflate_ctx.empty() ? free_ctx.pop(&c) : free_ctx.try_pop(&c)) {
                     rc = pack_from_bam_device(j, ctg, lo, hi, iv, s, c, &done);
                     free_ctx.push(c);
                     piled_on_device = rc == CTO_OK && done == 2;

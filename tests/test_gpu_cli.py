@@ -168,7 +168,7 @@ def test_bench_multi_rank_code_path(tmp_path, launcher):
 
 def test_bench_eight_rank_dry_run(tmp_path):
     """The driver's first SCALE run must not die on set-up: `python bench.py --gpus 8` with its DEFAULT geometry (16 resident
-    4096-site chunks per rank, 20 steps, 3 warm-up) as eight ranks on this box's single GPU over gloo (test hooks) - eight times the
+    4096-site chunks per rank, the default steps and warm-up) as eight ranks on this box's single GPU over gloo (test hooks) - eight times the
     resident pool and workspaces on one device (a real rank has 288 GB to itself), the eight-way synthesis on the host's cores, the
     rank census, the verified gather, the watchdog armed.  Start-up time is asserted: everything before the JSON line inside 10 min."""
     import json
@@ -187,7 +187,7 @@ def test_bench_eight_rank_dry_run(tmp_path):
     lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
     assert len(lines) == 1
     res = json.loads(lines[0])
-    assert res["n_gpus"] == 8 and res["steps"] == 20 and res["warmup"] == 3 and res["value"] > 0 and res["scaling"] == "weak"
+    assert res["n_gpus"] == 8 and res["steps"] == 100 and res["warmup"] == 100 and res["value"] > 0 and res["scaling"] == "weak"
     assert res["ranks_seen"] == 8 and res["gather_verified"] is True and res["backend"].startswith("gloo")
     assert [d["rank"] for d in res["rank_devices"]] == list(range(8))
     assert res["config"]["chunks_resident_per_gpu"] == 16 and res["config"]["batch"] == 4096
