@@ -529,6 +529,32 @@ def main():
     feat_ms = sum(a.elapsed_time(b) for a, b in evs) / n_feat
     # algorithmic bytes: the pack once (4 B per read-base + column tables) + two fp32 [33][34] tensors per site
     feat_bytes = pack_bytes + 2 * 33 * 34 * 4 * args.batch
+    # candidate extraction (the front of a REGION job of cto_run_chunks) on the same resident packs: the gates of
+    # extract_candidates_calling + the compaction of the candidate list, one event pair per call.  Algorithmic bytes: the pack once + 5 B
+    # per column (flag + depth) out.
+    nc_max = max(p.n_cols for p in packs)
+    xflags = torch.empty((nc_max,), dtype=torch.uint8, device=dev)
+    xdepth = torch.empty((nc_max,), dtype=torch.int32, device=dev)
+    xout = torch.empty((nc_max,), dtype=torch.int32, device=dev)
+    xscr = torch.empty(((nc_max + 255) // 256 + 2,), dtype=torch.int32, device=dev)
+    xn = torch.empty((1,), dtype=torch.int32, device=dev)
+    evx = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_feat)]
+    for i in range(-2, n_feat):
+        j = i % args.pool
+        if i >= 0:
+            evx[i][0].record()
+        check(lib.cto_extract_candidates(C.byref(packs[j].view), 20, int(min_bq), 0.05, 1.0, 4.0, 3, 0, xflags.data_ptr(), xdepth.data_ptr(), sptr))
+        if i >= 0:
+            evx[i][1].record()
+        check(lib.cto_candidate_positions(C.byref(packs[j].view), xflags.data_ptr(), 1, 1, 2 ** 31 - 1, xout.data_ptr(), nc_max, xscr.data_ptr(),
+                                          xn.data_ptr(), sptr))
+        if i >= 0:
+            evx[i][2].record()
+    torch.cuda.synchronize()
+    ext_ms = sum(a.elapsed_time(b) for a, b, _ in evx) / n_feat
+    cmp_ms = sum(b.elapsed_time(c) for _, b, c in evx) / n_feat
+    ext_bytes = pack_bytes + 5 * sum(p.n_cols for p in packs) / len(packs)
+    ext_cands = int(xn.item())
 
     if rank == 0:
         sites_total = world * args.steps * args.batch
@@ -558,6 +584,11 @@ def main():
                                          "frac": round(feat_bytes / (feat_ms * 1e-3) / 1e9 / 8000.0, 4), "launch_ms": round(feat_ms, 4),
                                          "bytes_per_launch": int(feat_bytes), "traffic": pmc_traffic_featurize(args.batch),
                                          "note": "latency / issue bound, not bandwidth bound (a chain of ~8 dependent global accesses per candidate; scalar unit, VALU and LDS each about half busy: profiles/round3_fused_featurize.md); ~2 % of the step"},
+            "roofline_candidate_extraction": {"bound": "hbm", "kernel": "k_extract_candidates (the gates of extract_candidates_calling on the resident pack: one wave per 8 columns, counters in LDS)",
+                                              "achieved": round(ext_bytes / (ext_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                              "frac": round(ext_bytes / (ext_ms * 1e-3) / 1e9 / 8000.0, 4), "launch_ms": round(ext_ms, 4),
+                                              "bytes_per_launch": int(ext_bytes), "compaction_ms": round(cmp_ms, 4), "candidates_last_pack": ext_cands,
+                                              "note": "same latency / LDS-atomic bound shape as the two-stage tensor creation; what a REGION job of cto_run_chunks runs between pile-up and tensor creation (e2e.bam_to_vcf_with_extraction); not part of `value`"},
             "end_to_end_tflops": round(2.0 * eng.macs_per_site * sites_total / dt / 1e12, 3),
             "ranks_seen": dist.get_world_size() if world > 1 else 1,
             "backend": (dist.get_backend() + (" (RCCL over xGMI)" if backend == "nccl" else " (test hook)")) if world > 1 else None,
