@@ -3,16 +3,22 @@
 // The reference scans `samtools mpileup --min-MQ 20 --min-BQ q` text of a 5 Mb chunk and keeps a position when
 // its depth and some non-reference allele pass the AF / read-count gates (decode_pileup_bases :55-169, the
 // candidate sets at :352-372).  Here the same gates run on the pack that tensor creation consumes, so a BAM is
-// piled up ONCE for extraction, the AFF tensor and the NEG tensor.  HBM-bound integer work, same shape as
-// k_featurize_columns: one wave per 8 consecutive columns, counters in LDS, per-allele (merged key) counts in an
-// LDS table with a global-atomic overflow path.
+// piled up ONCE for extraction, the AFF tensor and the NEG tensor.  HBM-bound integer work: one lane per column, the wave's
+// 64 columns staged through LDS with coalesced loads, counters in registers (below).
 #include <mutex>
 #include "common.h"
 #include "pack_internal.h"
 
 namespace {
 
-constexpr int XCOLS = 8, XWAVES = 4, GCAP = 128, XCOPY = 2;    // same tiling as k_featurize_columns: short waves, two counter copies
+// One LANE per column, one wave per 64 consecutive columns (round 4; the round-1 kernel - one wave per 8 columns, the ~50 read-bases of a
+// column on 50 lanes, counters in LDS - spent its time in LDS atomics on the one or two counters most of a column's read-bases hit:
+// 1.24 TB/s on the 225 MB pack of a 1 Mb region; this one 1.8 TB/s, bound by the dependent-instruction latency of seven to ten waves
+// per CU - 16 KB of LDS each - not by bandwidth).  The 64 columns' read-bases are one contiguous run of `entries`: the wave copies it into LDS with coalesced 256-byte loads
+// (the only HBM traffic), then every lane walks its own column out of LDS and counts in its own registers - four 16-bit counters to
+// a 64-bit word, no atomics, no cross-lane traffic.  Indel alleles (about one read-base in a hundred, indel mode only) are counted in a
+// lane-private LDS row, with the global-atomic overflow path of before for a column with more than XG distinct alleles.
+constexpr int XLANES = 64, XCAP = 4096, XG = 16;     // columns per wave, read-bases staged per wave (16 KB), allele groups per lane in LDS
 
 struct XPack {
     int64_t n_cols;
@@ -24,86 +30,97 @@ struct XPack {
     const int32_t* key_group;
 };
 
-__global__ __launch_bounds__(64 * XWAVES) void k_extract_candidates(
+template <bool select_indel>
+__global__ __launch_bounds__(XLANES) void k_extract_candidates(
     XPack pk, int min_mq, int min_bq, double snv_min_af, double indel_min_af, double min_coverage, int alt_base_num,
-    int select_indel, uint32_t* __restrict__ gscratch, uint8_t* __restrict__ flags, int32_t* __restrict__ depth_out) {
-    __shared__ uint32_t s_cnt[XWAVES][XCOPY][XCOLS][12];     // '*' / '#' placeholders, all-base ACGT (4), pure-base ACGT (4)
-    __shared__ int64_t s_off[XWAVES][XCOLS + 1];
-    __shared__ int32_t s_koff[XWAVES][XCOLS + 1];
-    __shared__ uint32_t s_g[XWAVES][GCAP];            // merged-allele counts, indexed like the wave's keys
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t c0 = (int64_t(blockIdx.x) * XWAVES + w) * XCOLS;
-    int ncol = 0;
-    if (c0 < pk.n_cols) ncol = int(pk.n_cols - c0 < XCOLS ? pk.n_cols - c0 : XCOLS);
-    for (int i = lane; i < XCOPY * XCOLS * 12; i += 64) (&s_cnt[w][0][0][0])[i] = 0u;
-    for (int i = lane; i < GCAP; i += 64) s_g[w][i] = 0u;
-    if (lane <= XCOLS) {
-        const int64_t ci = c0 + (lane < ncol ? lane : ncol);
-        s_off[w][lane] = ncol > 0 ? pk.col_off[ci] : 0;
-        s_koff[w][lane] = ncol > 0 ? pk.key_off[ci] : 0;
+    uint32_t* __restrict__ gscratch, uint8_t* __restrict__ flags, int32_t* __restrict__ depth_out) {
+    __shared__ uint32_t s_ent[XCAP];
+    __shared__ uint32_t s_grp[select_indel ? XLANES : 1][XG + 1];        // + 1: rows on different banks
+    const int lane = threadIdx.x;
+    const int64_t c0 = int64_t(blockIdx.x) * XLANES;
+    const int64_t c = c0 + lane;
+    const bool live = c < pk.n_cols;
+    const int64_t my_off = live ? pk.col_off[c] : 0, my_end = live ? pk.col_off[c + 1] : 0;
+    const int my_n = int(my_end - my_off);
+    const int ncol = int(pk.n_cols - c0 < XLANES ? pk.n_cols - c0 : XLANES);
+    const int64_t run0 = __shfl(my_off, 0), run1 = __shfl(my_end, ncol - 1);
+    const int64_t run = run1 - run0;
+    const bool staged = run <= XCAP;
+    if (staged) {                                    // sixteen loads in flight per lane: a load per trip would cost a memory latency per 256 bytes
+        const uint32_t* src = pk.entries + run0;
+        for (int i0 = lane; i0 < int(run); i0 += XLANES * 16) {
+            uint32_t v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int i = i0 + u * XLANES; v[u] = i < int(run) ? src[i] : 0u; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int i = i0 + u * XLANES; if (i < int(run)) s_ent[i] = v[u]; }
+        }
     }
-    __syncthreads();
-    const int kbase = s_koff[w][0];
-    const int nkeys_w = s_koff[w][ncol] - kbase;
-    const bool in_lds = nkeys_w <= GCAP;
-    if (!in_lds) {      // rare: the wave owns this slice of the global scratch exclusively and zeroes it itself
-        for (int k = lane; k < nkeys_w; k += 64) gscratch[kbase + k] = 0u;
-        __threadfence();
+    int k0 = 0, nk = 0;
+    if (select_indel && live) { k0 = pk.key_off[c]; nk = pk.key_off[c + 1] - k0; }
+    const bool grp_lds = nk <= XG;
+    if (select_indel) {
+        if (grp_lds) { for (int g = 0; g < nk; ++g) s_grp[select_indel ? lane : 0][g] = 0u; }
+        else { for (int g = 0; g < nk; ++g) gscratch[k0 + g] = 0u; }           // this column's own slice of the global counters
     }
-    if (ncol > 0) {
-        const int64_t e_end = s_off[w][ncol];
-        int cl = 0;
-        int64_t e = s_off[w][0] + lane;
-        uint32_t ent = e < e_end ? pk.entries[e] : 0u;
-        while (e < e_end) {
-            const int64_t en = e + 64;
-            const uint32_t ent_next = en < e_end ? pk.entries[en] : 0u;
-            while (e >= s_off[w][cl + 1]) ++cl;
-            const uint32_t b = ent & 15u, kind = (ent >> 4) & 3u, kid = ent >> 21;
-            const int bq = int((ent >> 6) & 127u), mq = int((ent >> 13) & 255u);
-            if (mq >= min_mq && bq >= min_bq) {       // what samtools --min-MQ / --min-BQ leaves in the column
-                uint32_t* c = s_cnt[w][lane & (XCOPY - 1)][cl];
-                if (b < 8u) {                                        // depth = bases + placeholders, summed at the end
-                    atomicAdd(&c[1 + (b & 3u)], 1u);                 // pileup_dict[base] counts indel carriers too (:111-113)
-                    if (kind == 0u) atomicAdd(&c[5 + (b & 3u)], 1u); // alt_dict single-base keys (:102)
-                } else if (b == 8u || b == 9u) {
-                    atomicAdd(&c[0], 1u);
-                }
-                if (kind != 0u) {                                    // no length gate here, unlike tensor creation
-                    const int kl = s_koff[w][cl] - kbase;            // first key of the column, wave-local
-                    const int g = kl + pk.key_group[kbase + kl + int(kid)];
-                    if (in_lds) atomicAdd(&s_g[w][g], 1u);
-                    else atomicAdd(&gscratch[kbase + g], 1u);
-                }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long all4 = 0, pure4 = 0;          // 16-bit counters: A C G T (a column holds at most 32 767 read-bases)
+    uint32_t stars = 0;
+    const int base = int(my_off - run0);
+    int max_n = my_n;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) max_n = max(max_n, __shfl_xor(max_n, d));
+    auto count = [&](uint32_t ent) {
+        const uint32_t b = ent & 15u, kind = (ent >> 4) & 3u;
+        const int bq = int((ent >> 6) & 127u), mq = int((ent >> 13) & 255u);
+        if (mq >= min_mq && bq >= min_bq) {           // what samtools --min-MQ / --min-BQ leaves in the column
+            const unsigned long long one = 1ull << (16u * (b & 3u));
+            if (b < 8u) {                              // depth = bases + placeholders, summed at the end
+                all4 += one;                           // pileup_dict[base] counts indel carriers too (:111-113)
+                if (kind == 0u) pure4 += one;          // alt_dict single-base keys (:102)
+            } else if (b == 8u || b == 9u) {
+                ++stars;
             }
-            e = en;
-            ent = ent_next;
+            if (select_indel && kind != 0u) {          // no length gate here, unlike tensor creation
+                const int g = pk.key_group[k0 + int(ent >> 21)];
+                if (grp_lds) s_grp[select_indel ? lane : 0][g] += 1u;
+                else atomicAdd(&gscratch[k0 + g], 1u);
+            }
         }
+    };
+    constexpr int XU = 4;                             // read-bases per trip: XU LDS reads in flight
+    for (int i = 0; i < max_n; i += XU) {
+        uint32_t e[XU];
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            e[u] = 0u;
+            if (i + u < my_n) e[u] = staged ? s_ent[base + i + u] : pk.entries[my_off + i + u];
+        }
+#pragma unroll
+        for (int u = 0; u < XU; ++u)
+            if (i + u < my_n) count(e[u]);
     }
-    if (!in_lds) __threadfence();
-    __syncthreads();
-    if (lane < ncol) {
-        const int64_t c = c0 + lane;
-        uint32_t cn[12];
-        for (int i = 0; i < 12; ++i) {
-            cn[i] = 0u;
-            for (int q = 0; q < XCOPY; ++q) cn[i] += s_cnt[w][q][lane][i];
-        }
+    if (live) {
+        uint32_t cn_all[4], cn_pure[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { cn_all[k] = uint32_t(all4 >> (16 * k)) & 0xffffu; cn_pure[k] = uint32_t(pure4 >> (16 * k)) & 0xffffu; }
         const int ref = pk.col_ref[c] & 3;
         const bool ref_ok = (pk.col_ref[c] & 0x80) == 0;     // rows whose reference base is not ACGT are skipped (:329-331)
-        const int depth = int(cn[0] + cn[1] + cn[2] + cn[3] + cn[4]);
+        const int depth = int(stars + cn_all[0] + cn_all[1] + cn_all[2] + cn_all[3]);
         const double den = depth > 0 ? double(depth) : 1.0;
         bool pass_snv = false, has_alt_base = false, pass_indel = false;
+#pragma unroll
         for (int b = 0; b < 4; ++b) {
             if (b == ref) continue;
-            const int cnt = int(cn[1 + b]);
+            const int cnt = int(cn_all[b]);
             pass_snv = pass_snv || (double(cnt) / den >= snv_min_af && cnt >= alt_base_num);
-            has_alt_base = has_alt_base || cn[5 + b] > 0u;
+            has_alt_base = has_alt_base || cn_pure[b] > 0u;
         }
         if (select_indel) {
-            const int k0 = s_koff[w][lane] - kbase, k1 = s_koff[w][lane + 1] - kbase;
-            for (int g = k0; g < k1; ++g) {          // groups are numbered from the column's first key; unused slots stay 0
-                const int cnt = int(in_lds ? s_g[w][g] : __hip_atomic_load(&gscratch[kbase + g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (!grp_lds) __threadfence();
+            for (int g = 0; g < nk; ++g) {           // groups are numbered from the column's first key; unused slots stay 0
+                const int cnt = int(grp_lds ? s_grp[select_indel ? lane : 0][g] : __hip_atomic_load(&gscratch[k0 + g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 pass_indel = pass_indel || (double(cnt) / den >= indel_min_af && cnt >= alt_base_num);
             }
         }
@@ -181,9 +198,13 @@ int cto::extract_candidates_scratch(const cto_pack_view* dp, int min_mq, int min
                                     int alt_base_num, int select_indel, uint32_t* scratch, uint8_t* flags, int32_t* depth, void* stream) {
     if (dp->n_cols == 0) return CTO_OK;
     XPack pk{dp->n_cols, dp->col_ref, dp->col_off, dp->key_off, dp->entries, dp->key_meta, dp->key_group};
-    const unsigned grid = unsigned(cto::cdiv(dp->n_cols, XCOLS * XWAVES));
-    hipLaunchKernelGGL(k_extract_candidates, dim3(grid), dim3(64 * XWAVES), 0, static_cast<hipStream_t>(stream), pk, min_mq, min_bq, snv_min_af,
-                       indel_min_af, min_coverage, alt_base_num, select_indel, scratch, flags, depth);
+    const unsigned grid = unsigned(cto::cdiv(dp->n_cols, XLANES));
+    if (select_indel)
+        hipLaunchKernelGGL(k_extract_candidates<true>, dim3(grid), dim3(XLANES), 0, static_cast<hipStream_t>(stream), pk, min_mq, min_bq, snv_min_af,
+                           indel_min_af, min_coverage, alt_base_num, scratch, flags, depth);
+    else
+        hipLaunchKernelGGL(k_extract_candidates<false>, dim3(grid), dim3(XLANES), 0, static_cast<hipStream_t>(stream), pk, min_mq, min_bq, snv_min_af,
+                           indel_min_af, min_coverage, alt_base_num, scratch, flags, depth);
     CTO_HIP(hipGetLastError());
     return CTO_OK;
 }
