@@ -7,13 +7,19 @@ Same inputs, options and output VCF as the reference.  What differs is how the w
 `samtools mpileup`, a second Python interpreter running `realign_reads`, and a second `samtools mpileup` fed by it, under a process
 pool; here the realignment runs in-process (realign_reads.realign_region over the library's consensus and realigner) on a thread
 pool, and only the two samtools commands remain subprocesses (the text they exchange is the reference's).
+
+Threading model: `--threads` workers (4/5 of it, as in the reference).  The samtools children and the C calls (consensus, realigner,
+read-evidence scan) run outside the GIL; the row parsing and window bookkeeping between them is Python and holds it, so a thread
+pool levels off at a few cores' worth of work.  `--pool process` runs the same calls in worker PROCESSES (spawned, one interpreter
+each - what the reference's ProcessPoolExecutor does) and scales with the cores; the output VCF is the same either way.  The
+samtools children's stderr goes to this process's stderr (the reference captures it per call).
 """
 import os
 import subprocess
 import sys
 from argparse import ArgumentParser, SUPPRESS
 from collections import Counter
-from concurrent.futures import ThreadPoolExecutor
+from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
 from io import StringIO
 
 from .haplotype_filtering import read_vcf, header_up_to_last_format, str2bool
@@ -215,6 +221,10 @@ def evaluate_call(args, rec):
     return ctg, pos, ok, counts
 
 
+def _evaluate_call_star(job):
+    return evaluate_call(*job)
+
+
 def realign_variants(args):
     if not args.enable_realignment:
         if os.path.lexists(args.output_vcf_fn):
@@ -225,8 +235,15 @@ def realign_variants(args):
     todo = [r for r in calls.values() if r["filter"] == "PASS"]
     threads = max(1, int(args.threads * 4 / 5))
     failed, done = set(), 0
-    with ThreadPoolExecutor(max_workers=threads) as ex:          # samtools children and the C calls run outside the GIL
-        for ctg, pos, ok, _ in ex.map(lambda r: evaluate_call(args, r), todo):
+    if getattr(args, "pool", "thread") == "process" and threads > 1 and len(todo) > 1:
+        import multiprocessing as mp
+        pool = ProcessPoolExecutor(max_workers=threads, mp_context=mp.get_context("spawn"))
+        results = pool.map(_evaluate_call_star, [(args, r) for r in todo], chunksize=max(1, min(64, len(todo) // (4 * threads) or 1)))
+    else:
+        pool = ThreadPoolExecutor(max_workers=threads)           # samtools children and the C calls run outside the GIL
+        results = pool.map(lambda r: evaluate_call(args, r), todo)
+    with pool as ex:
+        for ctg, pos, ok, _ in results:
             if not ok:
                 failed.add((ctg, pos))
             done += 1
@@ -266,6 +283,8 @@ def main():
                    help="samtools: the reference's three samtools commands per call; native: the built-in BAM / FASTA readers and pileup "
                         "(no samtools needed; parity against samtools unpinned)")
     p.add_argument("--threads", type=int, default=1)
+    p.add_argument("--pool", type=str, default="thread", choices=["thread", "process"],
+                   help="workers are threads (default) or spawned processes (the reference's ProcessPoolExecutor; scales with the cores)")
     p.add_argument("--python", type=str, default="python3", help="accepted for compatibility: the realignment runs in-process")
     p.add_argument("--show_ref", action="store_true")
     p.add_argument("--min_mq", type=int, default=20)             # shared/param.py:17

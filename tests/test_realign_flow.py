@@ -125,6 +125,12 @@ def test_realign_variants_writes_the_reference_vcf(flow, tmp_path):
                                            enable_realignment=True, is_indel=False))
     assert open(out).read() == g["vcf"]
     assert len(failed) == g["vcf"].count("LowQual;Realignment") >= 8
+    # the same calls in worker processes (--pool process: what the reference's ProcessPoolExecutor does): the same file
+    out_p = str(tmp_path / "out" / "realigned_processes.vcf")
+    rv.realign_variants(Namespace(bam_fn=paths["bam"], ref_fn=paths["ref"], ctg_name=realignsim.CTG, pileup_vcf_fn=paths["vcf"], output_vcf_fn=out_p,
+                                  samtools=paths["samtools"], threads=4, pool="process", show_ref=False, min_mq=20, min_bq=0,
+                                  enable_realignment=True, is_indel=False))
+    assert open(out_p).read() == g["vcf"]
     # the indel pass: indel records stay in; a deletion's ALT is its bare anchor base, which the reference counts like an SNV allele
     out_i = str(tmp_path / "out" / "realigned_indel.vcf")
     rv.realign_variants(Namespace(bam_fn=paths["bam"], ref_fn=paths["ref"], ctg_name=realignsim.CTG, pileup_vcf_fn=paths["vcf"], output_vcf_fn=out_i,
