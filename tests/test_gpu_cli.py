@@ -830,3 +830,53 @@ def test_engine_run_region_is_extraction_plus_run_device(tmp_path):
         ref = eng.run_device(dp, sites)
         for k in ("probs", "post", "decision", "qual"):
             assert torch.equal(out[k], ref[k])
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_call_chunks_region_list_equals_the_two_step_run(tmp_path, world):
+    """`call_chunks --region_list` from the command line (one process, then two ranks sharing this box's GPU): BAM + three adjacent regions, no
+    candidate BEDs.  The merged VCF equals the merged VCF of the two-step run - candidates extracted per region with the same gates
+    (written by --candidates_dir), then `call_chunks --chunk_list` over those BED files.  Adjacent regions share the candidates of their
+    +-33 overlap (extract_candidates_calling.py:289-292), as the reference's chunks do; sort_vcf keeps one record per position."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from clairs_to_amd.synth import likelihood_table
+    sc = _bam_scenario(tmp_path)
+    paths = _pickle_models(tmp_path, "CvT", "BiGRU_NACGT", 4)
+    lik = tmp_path / "lik.txt"
+    np.savetxt(lik, likelihood_table(4, seed=11), fmt="%.17g")
+    regions = [(300, 1900), (1901, 3500), (3501, 5600)]
+    (tmp_path / "REGIONS").write_text("# ctg start end\n" + "".join("chr1\t%d\t%d\n" % r for r in regions))
+    common = ["--platform", "ont", "--tumor_bam_fn", sc["bam"], "--ref_fn", sc["fa"], "--bam_reader", "native", "--chkpnt_fn_acgt",
+              paths["model_acgt"], "--chkpnt_fn_nacgt", paths["model_nacgt"], "--disable_indel_calling", "True",
+              "--likelihood_matrix_data", str(lik), "--show_ref"]
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    launcher = [sys.executable] if world == 1 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                                    "--master-addr", "127.0.0.1", "--master-port", "29546"]
+    merged_r, cand = tmp_path / "merged_regions.vcf", tmp_path / "cand"
+    r = subprocess.run(launcher + ["-m", "clairs_to_amd", "call_chunks", "--region_list", str(tmp_path / "REGIONS"), "--output_dir", str(tmp_path / "out_r"),
+                                   "--merged_vcf_fn", str(merged_r), "--candidates_dir", str(cand)] + common,
+                       cwd=ROOT, capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert sorted(os.listdir(tmp_path / "out_r")) == sorted("p_chr1_%d_%d.vcf" % rg for rg in regions)
+    beds = [str(cand / ("chr1_%d_%d.snv" % rg)) for rg in regions]
+    centres = [[int(x.split("\t")[2]) - 17 for x in open(b) if x.strip()] for b in beds]
+    assert all(len(c) > 10 for c in centres)
+    for (a, b), c in zip(regions, centres):
+        assert c == sorted(c) and a - 33 <= c[0] and c[-1] <= b + 33
+    assert set(centres[0]) & set(centres[1]) or set(centres[1]) & set(centres[2])      # the overlap zones hold candidates
+    chunk_files = []
+    for i, b in enumerate(beds):                      # the reference's chunk-file names carry the contig in front of the first dot
+        fn = tmp_path / ("chr1.%d_0_1_snv" % i)
+        fn.write_text(open(b).read())
+        chunk_files.append(str(fn))
+    (tmp_path / "CANDIDATES_FILES").write_text("".join(n + "\n" for n in chunk_files))
+    merged_b = tmp_path / "merged_beds.vcf"
+    r = subprocess.run([sys.executable, "-m", "clairs_to_amd", "call_chunks", "--chunk_list", str(tmp_path / "CANDIDATES_FILES"), "--output_dir",
+                        str(tmp_path / "out_b"), "--merged_vcf_fn", str(merged_b)] + common, cwd=ROOT, capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = lambda fn: [l for l in open(fn).read().split("\n") if l and not l.startswith("#")]
+    assert rec(merged_r) == rec(merged_b) and len(rec(merged_r)) > 50
+    pos = [int(l.split("\t")[1]) for l in rec(merged_r)]
+    assert pos == sorted(set(pos))                    # one record per position, in order
