@@ -82,7 +82,9 @@ def default_producers(native_bam, pipeline="python"):
 # cores, 16 producers (sites/s; profiles/round2_d_bam_hybrid.txt, two passes per setting on one box): host only 246-250 k; 128 CUs x 8 / 10
 # chunks 347-402 / 408-429 k; 144 CUs 432-488 / 386-391 k; 160 CUs 368-396 / 323-328 k (507 k once on another box); all 64 chunks through the
 # device (16 in flight) 191-385 k; 20+ producers 263-349 k (more runnable threads than cores).
-DEVICE_INFLATE = (144, 8)
+# Round 4, with the 2.4x faster inflate kernel (32 chunk files, one process per setting): 112 / 128 / 144 / 160 CUs x 8 chunks 584 / 696 / 696 / 708 k;
+# 144 CUs x 10 / 12 chunks 743 / 629 k; 160 x 10 739 k; 18 producers 714 k.
+DEVICE_INFLATE = (144, 10)
 
 
 def pack_threads(native_bam, pipeline="python"):
