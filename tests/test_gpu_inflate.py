@@ -92,17 +92,43 @@ def test_inflate_rejects_malformed(dev):
     from clairs_to_amd.bgzf import inflate_bytes
     rng = np.random.default_rng(3)
     good = bgzf_block(bytes(rng.integers(33, 74, 40000, dtype=np.uint8)), 6)
-    n_err = 0
-    for trial in range(40):
-        b = bytearray(good)
-        lo, hi = 18, len(b) - 8
-        for _ in range(1 + trial % 4):
-            b[int(rng.integers(lo, hi))] ^= 1 << int(rng.integers(0, 8))
-        try:
-            inflate_bytes(bytes(b), dev)
-        except CtoError:
-            n_err += 1
-    assert n_err == 40         # a flipped bit either breaks the stream (status code) or decodes to other bytes (CRC-32)
+    # literal-heavy (quality-string like), match-heavy (tab-separated records: the hand-written match path, far and near distances) and
+    # fixed-code streams, one to four flipped bits each - several damaged blocks per launch, next to intact ones that must still come out right
+    words = [bytes(rng.integers(97, 123, int(rng.integers(2, 12)), dtype=np.uint8)) for _ in range(300)]
+    texts = [bytes(rng.integers(33, 74, 40000, dtype=np.uint8)),
+             b" ".join(words[int(i)] for i in rng.integers(0, 300, 9000))[:60000],
+             (b"read%07d\t99\tchr1\t%d\t60\t100M\t=\t%d\t300\t" % (1, 2, 3)) * 800,
+             bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 30000))]
+    goods = [bgzf_block(t, lvl, strat) for t in texts for lvl, strat in ((6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED))]
+    n_err = n_trials = 0
+    for trial in range(60):
+        blocks = []
+        for g in goods:
+            b = bytearray(g)
+            lo, hi = 18, len(b) - 8
+            for _ in range(1 + trial % 4):
+                b[int(rng.integers(lo, hi))] ^= 1 << int(rng.integers(0, 8))
+            blocks.append(bytes(b))
+        for k in range(0, len(blocks), 4):            # four damaged blocks in front of an intact one per launch
+            import torch
+            from clairs_to_amd import bgzf
+            raw = b"".join(blocks[k:k + 4]) + good
+            host = np.zeros(len(raw) + bgzf.BGZF_PAD, dtype=np.uint8)
+            host[:len(raw)] = np.frombuffer(raw, dtype=np.uint8)
+            tbl, out_bytes = bgzf.scan(host, len(raw))
+            d_out, d_status = bgzf.inflate_device(torch.from_numpy(host).to(dev), tbl, out_bytes, dev)
+            torch.cuda.synchronize(dev)
+            st, out = d_status.cpu().numpy(), d_out.cpu().numpy()
+            assert len(tbl) == 5 and st[4] == 0
+            # a damaged block may run at most CTO_BGZF_SLOT_PAD bytes past its size (a literal run's bound is checked per refill):
+            # the intact block behind four damaged ones is untouched
+            assert out[int(tbl[4]["out_off"]):int(tbl[4]["out_off"]) + int(tbl[4]["isize"])].tobytes() == texts[0]
+            for j in range(4):
+                n_trials += 1
+                got = out[int(tbl[j]["out_off"]):int(tbl[j]["out_off"]) + int(tbl[j]["isize"])].tobytes()
+                n_err += int(st[j] != 0 or zlib.crc32(got) != int(tbl[j]["crc32"]))
+    assert n_err == n_trials   # a flipped bit either breaks the stream (status code) or decodes to other bytes (CRC-32)
+    assert inflate_bytes(good + goods[3], dev) == [texts[0], texts[1]]
     # a stored block that claims more bytes than the payload holds
     payload = b"\x01" + struct.pack("<HH", 60000, 60000 ^ 0xffff) + b"x" * 100
     bsize = len(payload) + 26
