@@ -91,7 +91,8 @@ def test_inflate_rejects_malformed(dev):
     from clairs_to_amd._lib import CtoError
     from clairs_to_amd.bgzf import inflate_bytes
     rng = np.random.default_rng(3)
-    good = bgzf_block(bytes(rng.integers(33, 74, 40000, dtype=np.uint8)), 6)
+    good_text = bytes(rng.integers(33, 74, 40000, dtype=np.uint8))
+    good = bgzf_block(good_text, 6)
     # literal-heavy (quality-string like), match-heavy (tab-separated records: the hand-written match path, far and near distances) and
     # fixed-code streams, one to four flipped bits each - several damaged blocks per launch, next to intact ones that must still come out right
     words = [bytes(rng.integers(97, 123, int(rng.integers(2, 12)), dtype=np.uint8)) for _ in range(300)]
@@ -122,13 +123,13 @@ def test_inflate_rejects_malformed(dev):
             assert len(tbl) == 5 and st[4] == 0
             # a damaged block may run at most CTO_BGZF_SLOT_PAD bytes past its size (a literal run's bound is checked per refill):
             # the intact block behind four damaged ones is untouched
-            assert out[int(tbl[4]["out_off"]):int(tbl[4]["out_off"]) + int(tbl[4]["isize"])].tobytes() == texts[0]
+            assert out[int(tbl[4]["out_off"]):int(tbl[4]["out_off"]) + int(tbl[4]["isize"])].tobytes() == good_text
             for j in range(4):
                 n_trials += 1
                 got = out[int(tbl[j]["out_off"]):int(tbl[j]["out_off"]) + int(tbl[j]["isize"])].tobytes()
                 n_err += int(st[j] != 0 or zlib.crc32(got) != int(tbl[j]["crc32"]))
     assert n_err == n_trials   # a flipped bit either breaks the stream (status code) or decodes to other bytes (CRC-32)
-    assert inflate_bytes(good + goods[3], dev) == [texts[0], texts[1]]
+    assert inflate_bytes(good + goods[3], dev) == [good_text, texts[1]]
     # a stored block that claims more bytes than the payload holds
     payload = b"\x01" + struct.pack("<HH", 60000, 60000 ^ 0xffff) + b"x" * 100
     bsize = len(payload) + 26
