@@ -50,7 +50,7 @@ class RunCfg(C.Structure):
                 ("inflate_cus", C.c_int), ("inflate_jobs", C.c_int), ("pack_threads", C.c_int), ("samtools", C.c_char_p),
                 ("samtools_max_depth", C.c_int), ("aff2", c_vp), ("neg2", c_vp), ("device_pileup", C.c_int),
                 ("extract_min_mq", C.c_int), ("extract_min_bq", C.c_int), ("alt_base_num", C.c_int), ("snv_min_af", C.c_double),
-                ("indel_min_af", C.c_double), ("min_coverage", C.c_double)]
+                ("indel_min_af", C.c_double), ("min_coverage", C.c_double), ("indel_regions_bed", C.c_char_p)]
 
 
 class RunStats(C.Structure):

@@ -229,6 +229,8 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
     cfg.snv_min_af = float(getattr(a0, "snv_min_af", None) or 0.05)
     cfg.indel_min_af = float(getattr(a0, "indel_min_af", None) or _PF.get(fam, _PF["ont"])["indel_min_af"])
     cfg.min_coverage = float(4 if getattr(a0, "min_coverage", None) is None else a0.min_coverage)
+    ib = getattr(a0, "call_indels_only_in_these_regions", None)
+    cfg.indel_regions_bed = str(ib).encode() if ib else None
     if two_streams:                               # consecutive chunks on two compute streams (a second pair of handles of the same weights)
         with torch.cuda.device(eng.device):
             cfg.aff2, cfg.neg2 = eng.aff._handle2(), eng.neg._handle2()
@@ -372,6 +374,8 @@ def main():
     p.add_argument("--min_coverage", type=float, default=4, help="--region_list: --min_coverage")
     p.add_argument("--alternative_base_num", type=int, default=3, help="--region_list: --alternative_base_num")
     p.add_argument("--extract_min_mq", type=int, default=20, help="--region_list: --min_mq of extract_candidates_calling")
+    p.add_argument("--call_indels_only_in_these_regions", type=str, default=None,
+                   help="--region_list, indel mode: keep an indel candidate only inside the rows of this BED (extract_candidates_calling.py:437-446)")
     p.add_argument("--output_dir", type=str, required=True, help="directory for the p_<chunk>.vcf files")
     p.add_argument("--merged_vcf_fn", type=str, default=None, help="rank 0: sort_vcf of all chunk VCFs")
     p.add_argument("--final_vcf_fn", type=str, default=None, help="rank 0: postprocess_vcf of the merged VCF")

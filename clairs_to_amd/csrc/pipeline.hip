@@ -405,6 +405,43 @@ struct Run {
     std::atomic<int64_t> device_inflated{0}, device_piled{0};
     std::mutex fai_m;
     std::map<std::string, FaiRec> fai;
+    // --call_indels_only_in_these_regions: per contig the rows as sorted, merged [begin, end) intervals (bed_tree_from of the reference)
+    std::map<std::string, std::vector<int64_t>> indel_regions;
+    bool load_indel_regions(std::string* err) {
+        if (!cfg->indel_regions_bed || !cfg->indel_regions_bed[0]) return true;
+        Mapped bed;
+        if (!bed.open(cfg->indel_regions_bed, err)) return false;
+        std::map<std::string, std::vector<std::pair<int64_t, int64_t>>> rows;
+        size_t i = 0;
+        while (i < bed.n) {
+            const char* nl = static_cast<const char*>(memchr(bed.p + i, '\n', bed.n - i));
+            const size_t e = nl ? size_t(nl - bed.p) : bed.n;
+            std::string row(bed.p + i, e - i);
+            i = e + 1;
+            if (row.empty() || row[0] == '#') continue;
+            char name[256];
+            long long a = 0, b = 0;
+            if (sscanf(row.c_str(), "%255s %lld %lld", name, &a, &b) != 3) continue;
+            if (b < a || a < 0 || b < 0) { *err = "[ERROR] Invalid bed input in " + std::string(cfg->indel_regions_bed) + ": " + row; return false; }
+            if (a == b) ++b;
+            rows[name].emplace_back(a, b);
+        }
+        for (auto& kv : rows) {
+            std::sort(kv.second.begin(), kv.second.end());
+            std::vector<int64_t>& out = indel_regions[kv.first];
+            for (const auto& p : kv.second) {
+                if (!out.empty() && p.first <= out.back()) out.back() = std::max(out.back(), p.second);
+                else { out.push_back(p.first); out.push_back(p.second); }
+            }
+        }
+        return true;
+    }
+    // is_region_in(tree, ctg, pos - 1, pos): some row with begin < pos and end > pos - 1
+    static bool in_regions(const std::vector<int64_t>& iv, int64_t pos) {
+        size_t lo = 0, hi = iv.size() / 2;
+        while (lo < hi) { const size_t m = (lo + hi) / 2; if (iv[2 * m + 1] > pos - 1) hi = m; else lo = m + 1; }
+        return lo < iv.size() / 2 && iv[2 * lo] < pos;
+    }
 
     bool fai_of(const std::string& ctg, FaiRec* rec, std::string* err) {
         std::lock_guard<std::mutex> g(fai_m);
@@ -711,11 +748,28 @@ struct Run {
         auto* h = static_cast<int32_t*>(s->cand_host.p);
         if (hipMemcpyAsync(h, d_n, 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipEventRecord(s->uploaded, stream) != hipSuccess ||
             wait_event(s->uploaded) != hipSuccess) { fail("candidate extraction failed on the device"); return false; }
-        const int64_t n = h[0];
+        int64_t n = h[0];
         candidates += n;
         if (n > 0) {
             if (hipMemcpyAsync(h, s->cand.p, size_t(n) * 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipEventRecord(s->uploaded, stream) != hipSuccess ||
                 wait_event(s->uploaded) != hipSuccess) { fail("candidate extraction failed on the device"); return false; }
+            if (indel) {                       // --call_indels_only_in_these_regions: the list shrinks on the host and goes back up
+                const auto it = indel_regions.find(j.ctg_name);
+                if (it != indel_regions.end()) {
+                    int64_t m = 0;
+                    for (int64_t i = 0; i < n; ++i)
+                        if (in_regions(it->second, h[i])) h[m++] = h[i];
+                    if (m != n) {
+                        candidates -= n - m;
+                        n = m;
+                        if (n > 0 && (hipMemcpyAsync(s->cand.p, h, size_t(n) * 4, hipMemcpyHostToDevice, stream) != hipSuccess ||
+                                      hipEventRecord(s->uploaded, stream) != hipSuccess || wait_event(s->uploaded) != hipSuccess)) {
+                            fail("candidate extraction failed on the device");
+                            return false;
+                        }
+                    }
+                }
+            }
             s->sites.assign(h, h + n);
         }
         s->d_site_pos = static_cast<const int32_t*>(s->cand.p);
@@ -1017,6 +1071,7 @@ static int run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs, int64_t
     {
         std::string err;
         CTO_REQUIRE(run.fasta.open(cfg->ref_fa, &err), CTO_EINVAL, "cto_run_chunks: %s", err.c_str());
+        CTO_REQUIRE(run.load_indel_regions(&err), CTO_EINVAL, "cto_run_chunks: %s", err.c_str());
     }
     int dev = 0;
     CTO_HIP(hipGetDevice(&dev));

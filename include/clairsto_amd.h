@@ -430,6 +430,9 @@ typedef struct cto_run_cfg {
     double snv_min_af;          /* --snv_min_af (0.05)                                                                         */
     double indel_min_af;        /* --indel_min_af (ONT 0.1, others 0.05); used when K = 6                                      */
     double min_coverage;        /* --min_coverage (4): depth must EXCEED it                                                    */
+    const char* indel_regions_bed; /* --call_indels_only_in_these_regions (NULL: none): K = 6 REGION jobs keep an indel candidate only
+                                   when [pos - 1, pos) overlaps a row of its contig (0-based half-open rows, start == end widened by
+                                   one; a BED without rows of the contig filters nothing) - extract_candidates_calling.py:437-446   */
 } cto_run_cfg;
 typedef struct cto_run_stats {
     int64_t candidates;                                /* candidate positions read from the BED chunks / extracted from the regions */

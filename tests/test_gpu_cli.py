@@ -804,6 +804,25 @@ def test_region_jobs_from_bam_equal_the_two_step_run(tmp_path, K):
             assert os.path.exists(a) == os.path.exists(b)
             if os.path.exists(a):
                 assert open(a, "rb").read() == open(b, "rb").read(), (tag, i)
+    if K == 6:
+        # --call_indels_only_in_these_regions (extract_candidates_calling.py:437-446): an indel candidate stays when [pos - 1, pos) overlaps
+        # a row of the BED; rows of other contigs, comments and a zero-length row (widened by one) as bed_tree_from reads them
+        keep_rows = [(900, 1500), (2999, 2999), (4000, 5000)]
+        bed = tmp_path / "indel_regions.bed"
+        bed.write_text("# comment\nchrX\t1\t100000\n" + "".join("chr1\t%d\t%d\n" % r for r in keep_rows))
+        out = str(tmp_path / "filtered")
+        jobs = [_region_namespace(sc["fa"], K, paths, lik, out, "r%d" % i, tumor_bam_fn=sc["bam"], region=r, indel_min_af=0.01, alternative_base_num=abn,
+                                  candidates_out_fn=os.path.join(out, "cand%d.bed" % i), call_indels_only_in_these_regions=str(bed))
+                for i, r in enumerate(regions)]
+        st = {}
+        run_pipeline_native(eng, jobs, producers=2, writers=1, stats=st, verbose=False, inflate_cus=64, inflate_jobs=2)
+        inside = lambda x: any(a < x and (b if b > a else a + 1) > x - 1 for a, b in keep_rows)
+        total = 0
+        for i in range(len(regions)):
+            got = [int(r.split("\t")[2]) - 17 for r in open(os.path.join(out, "cand%d.bed" % i)) if r.strip()]
+            assert got == [x for x in want[i] if inside(x)], i
+            total += len(got)
+        assert 0 < total < sum(len(x) for x in want) and st["sites"] == total
     torch.cuda.synchronize()
 
 
