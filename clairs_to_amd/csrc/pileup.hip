@@ -503,7 +503,8 @@ __global__ __launch_bounds__(256) void k_fill(const uint8_t* __restrict__ lin, c
             }
         }
         // the read's contribution at reference position p of the operation (o_ref, o_q, o_len, ...)
-        auto emit = [&](int p, int kiv, int o_ref, int o_q, int o_len, bool o_aligned, uint32_t o_ind, uint32_t o_ind_q) {
+        // the entry of reference position p and its column; the trip to the column's cursor is the caller's (several in flight)
+        auto make = [&](int p, int kiv, int o_ref, int o_q, int o_len, bool o_aligned, uint32_t o_ind, uint32_t o_ind_q, TmpEnt* out) -> int {
             const int col = slot_col[iv.base[kiv] + (p - iv.lo[kiv])];
             TmpEnt e;
             e.rank = uint32_t(j);
@@ -524,6 +525,12 @@ __global__ __launch_bounds__(256) void k_fill(const uint8_t* __restrict__ lin, c
                 e.entry = dev_entry(code, bq(q), mq);
                 if (p == o_ref + o_len - 1) { e.ind = o_ind; e.ind_q = o_ind_q; }
             }
+            *out = e;
+            return col;
+        };
+        auto emit = [&](int p, int kiv, int o_ref, int o_q, int o_len, bool o_aligned, uint32_t o_ind, uint32_t o_ind_q) {
+            TmpEnt e;
+            const int col = make(p, kiv, o_ref, o_q, o_len, o_aligned, o_ind, o_ind_q, &e);
             const long long at = col_off[col] + atomicAdd(&cursor[col], 1);
             tmp[at] = e;
         };
@@ -572,20 +579,33 @@ __device__ __forceinline__ int canon_nib(const uint8_t* seq, int q) {
 struct IndEnt { uint32_t at, entry, rank, ind_q, ind; };     // at = the entry's place in the column once it is in file order
 
 // One wave per column (workgroup = one wave): file order, indel keys in first-seen order, merged groups.
+// Two sizes (round 4): the kernel is bound by how many columns a CU holds in flight - a column is a chain of three dependent trips
+// to memory - and that by LDS.  The SMALL form (columns of up to 128 read-bases with up to 32 indel carriers and 16 distinct keys:
+// 2 KB of LDS, 32 waves per CU instead of 8) takes every column it can and leaves ORD_TODO in n_keys_col for the others; the LARGE
+// form (2048 / 256 / 64) then takes exactly those.  1 000 000 columns of a region: 1.35 ms with the large form alone.
+constexpr int ORD_TODO = -2;
+template <int DMAX, int IMAX, int KMAX, bool SECOND>
 __global__ __launch_bounds__(64) void k_order(const uint8_t* __restrict__ lin, const DevRead* __restrict__ reads, const int* __restrict__ rid,
                                               int n_cols, const long long* __restrict__ col_off, const TmpEnt* __restrict__ tmp,
                                               uint32_t* __restrict__ entries, int* __restrict__ n_keys_col, KeyRec* __restrict__ keyrec, int max_indel,
                                               Flags* fl) {
-    __shared__ uint32_t ranks[ORD_DMAX];
-    __shared__ IndEnt ind_a[ORD_IMAX], ind_b[ORD_IMAX];
-    __shared__ KeyRec keys[ORD_KMAX];
-    __shared__ int grp_key[ORD_KMAX];             // group g is represented by the key that opened it
+    __shared__ uint32_t ranks[DMAX];
+    __shared__ IndEnt ind_a[IMAX], ind_b[IMAX];
+    __shared__ KeyRec keys[KMAX];
+    __shared__ int grp_key[KMAX];                 // group g is represented by the key that opened it
     __shared__ int n_ind_s;
     const int lane = threadIdx.x;
-    for (int c = blockIdx.x; c < n_cols; c += gridDim.x) {
+    // the large form looks at 64 columns' marks per trip (one coalesced load) and works on the marked ones
+    for (long long base = SECOND ? blockIdx.x * 64ll : (long long)blockIdx.x; base < n_cols; base += SECOND ? gridDim.x * 64ll : (long long)gridDim.x) {
+      unsigned long long todo = 1ull;
+      if (SECOND) { const long long cc = base + lane; todo = __ballot(cc < n_cols && n_keys_col[cc] == ORD_TODO); }
+      while (todo) {
+        const int c = SECOND ? int(base) + __ffsll((long long)todo) - 1 : int(base);
+        todo &= todo - 1ull;
         const long long o = col_off[c];
         const int d = int(col_off[c + 1] - o);
         if (d > ORD_DMAX) { if (lane == 0) n_keys_col[c] = 0; continue; }      // flagged by k_columns: the caller falls back
+        if (d > DMAX) { if (lane == 0) n_keys_col[c] = ORD_TODO; continue; }
         __syncthreads();
         if (lane == 0) n_ind_s = 0;
         for (int i = lane; i < d; i += 64) ranks[i] = tmp[o + i].rank;
@@ -598,12 +618,15 @@ __global__ __launch_bounds__(64) void k_order(const uint8_t* __restrict__ lin, c
             entries[o + at] = e.entry;
             if (e.ind & 3u) {
                 const int slot = atomicAdd(&n_ind_s, 1);
-                if (slot < ORD_IMAX) ind_a[slot] = IndEnt{uint32_t(at), e.entry, e.rank, e.ind_q, e.ind};
+                if (slot < IMAX) ind_a[slot] = IndEnt{uint32_t(at), e.entry, e.rank, e.ind_q, e.ind};
             }
         }
         __syncthreads();
         const int n_ind = n_ind_s;
-        if (n_ind > ORD_IMAX) { if (lane == 0) { atomicExch(&fl->many_keys, 1); n_keys_col[c] = 0; } continue; }
+        if (n_ind > IMAX) {
+            if (lane == 0) { if (IMAX < ORD_IMAX) n_keys_col[c] = ORD_TODO; else { atomicExch(&fl->many_keys, 1); n_keys_col[c] = 0; } }
+            continue;
+        }
         for (int i = lane; i < n_ind; i += 64) {
             const IndEnt e = ind_a[i];
             int at = 0;
@@ -634,7 +657,7 @@ __global__ __launch_bounds__(64) void k_order(const uint8_t* __restrict__ lin, c
             if (hm) {
                 kid = __ffsll((long long)hm) - 1;
             } else {
-                if (nk >= ORD_KMAX) { over = true; break; }
+                if (nk >= KMAX) { over = true; break; }
                 kid = nk;
                 // merged group for candidate extraction: insertions by upper-cased anchor + sequence, deletions by length
                 const char anchor_c = "ACGTACGT*#NN"[code];
@@ -667,10 +690,14 @@ __global__ __launch_bounds__(64) void k_order(const uint8_t* __restrict__ lin, c
                 entries[o + cand.at] = cand.entry | (uint32_t(gate > max_indel ? 3 : kind) << 4) | (uint32_t(kid) << 21);
             }
         }
-        if (over) { if (lane == 0) { atomicExch(&fl->many_keys, 1); n_keys_col[c] = 0; } continue; }
+        if (over) {
+            if (lane == 0) { if (KMAX < ORD_KMAX) n_keys_col[c] = ORD_TODO; else { atomicExch(&fl->many_keys, 1); n_keys_col[c] = 0; } }
+            continue;
+        }
         __syncthreads();
         if (lane == 0) n_keys_col[c] = nk;
         for (int k = lane; k < nk; k += 64) keyrec[o + k] = keys[k];          // nk <= d: the column's own slots
+      }
     }
 }
 
@@ -933,9 +960,12 @@ extern "C" int cto_pileup_device(cto_dev_pileup* cx, const void* d_inflated, con
     hipLaunchKernelGGL(k_fill, dim3(unsigned(cdiv(hf->n_valid, 4))), dim3(256), 0, s, lin, cx->reads.as<DevRead>(), cx->rid.as<int>(), fl, iv,
                        cx->slot_col.as<int>(), cx->col_off.as<long long>(), cx->cursor.as<int>(), cx->tmp.as<TmpEnt>(), d_ref, (long long)ref_start,
                        (long long)ref_len);
-    hipLaunchKernelGGL(k_order, dim3(unsigned(std::min(n_cols, 16384))), dim3(64), 0, s, lin, cx->reads.as<DevRead>(), cx->rid.as<int>(), n_cols,
-                       cx->col_off.as<long long>(), cx->tmp.as<TmpEnt>(), cx->entries.as<uint32_t>(), cx->nkc.as<int>(), cx->keyrec.as<KeyRec>(),
+    hipLaunchKernelGGL((k_order<128, 32, 16, false>), dim3(unsigned(std::min(n_cols, 65536))), dim3(64), 0, s, lin, cx->reads.as<DevRead>(), cx->rid.as<int>(),
+                       n_cols, cx->col_off.as<long long>(), cx->tmp.as<TmpEnt>(), cx->entries.as<uint32_t>(), cx->nkc.as<int>(), cx->keyrec.as<KeyRec>(),
                        max_indel_length, fl);
+    hipLaunchKernelGGL((k_order<ORD_DMAX, ORD_IMAX, ORD_KMAX, true>), dim3(unsigned(std::min(n_cols, 16384))), dim3(64), 0, s, lin, cx->reads.as<DevRead>(),
+                       cx->rid.as<int>(), n_cols, cx->col_off.as<long long>(), cx->tmp.as<TmpEnt>(), cx->entries.as<uint32_t>(), cx->nkc.as<int>(),
+                       cx->keyrec.as<KeyRec>(), max_indel_length, fl);
     if (n_cols <= 4 * SCAN_TILE) {
         hipLaunchKernelGGL(k_scan_small<int>, dim3(1), dim3(1024), 0, s, cx->nkc.as<int>(), cx->key_off.as<int>(), n_cols, &fl->n_keys);
     } else {
