@@ -19,16 +19,16 @@
 //                   by one workgroup, then every 4096-position tile on top of its base)
 //   k_fill          one wave per read, one lane per CIGAR operation (prefix sums over 64 operations at a time give every lane
 //                   its reference / query offsets): read-bases, deletion placeholders and the indel attached to the last base
-//                   of an aligned run go to their column through an atomic cursor, tagged with the read's rank in file order
-//   k_order         one wave per column: the column's entries back into file order (rank by counting in LDS), the distinct
-//                   indel keys in first-seen order (candidates compared against the column's keys across lanes), merged
-//                   candidate-extraction groups
+//                   of an aligned run go straight to their place in their column - file order = the number of earlier reads
+//                   that cover the position, counted against the ends of the reads still open at this read's start
+//   k_order         one wave per column that holds an indel carrier: the distinct indel keys in first-seen order (candidates
+//                   compared against the column's keys across lanes), merged candidate-extraction groups
 //   k_keys_*        key tables and the alt_info key strings ("I<ANCHOR><SEQ>", "D<reference slice>")
 // Two round trips to the host are needed (sizes for allocation): after k_columns and after the per-column key counts.
 //
 // Not done here - the call reports `fallback` and the caller uses the host reader: paired reads (mate-overlap quality edits are
 // order dependent), reference skips (N), --max-depth or more reads open at some read's start (the cap is order dependent; k_live_marks), a column
-// deeper than 2048, with more than 256 indel-carrying reads or more than 64 distinct indel keys.  The BGZF CRC-32 of every block is
+// deeper than 2048, more than 1024 reads open at a read's start, or more than 64 distinct indel keys in a column.  The BGZF CRC-32 of every block is
 // checked on the device (k_crc32_blocks), as htslib and the host reader check it.
 #include <algorithm>
 #include <cstring>
@@ -61,7 +61,8 @@ struct Flags {                    // written by the kernels, read by the host af
     int bad_crc;                                    // 1 + index of a block whose inflated bytes fail the gzip trailer's CRC-32 (0: none)
     int n_rec, n_valid, n_cols, n_keys;
     long long n_entries, key_str_bytes;
-    int max_live, pad_;                             // largest number of accepted reads still open at another accepted read's start
+    int max_live, max_len;                          // largest number of accepted reads still open at another accepted read's start;
+                                                    // longest reference span of an accepted read
 };
 
 __device__ __forceinline__ uint32_t ld16(const uint8_t* p) { return uint32_t(p[0]) | (uint32_t(p[1]) << 8); }
@@ -321,8 +322,9 @@ __global__ void k_compact(const DevRead* __restrict__ reads, int n_rec, int* __r
         part[t] += v;
         __syncthreads();
     }
-    int run = part[t] - s;
-    for (int i = lo; i < hi; ++i) if (reads[i].valid) rid[run++] = i;
+    int run = part[t] - s, longest = 0;
+    for (int i = lo; i < hi; ++i) if (reads[i].valid) { rid[run++] = i; longest = max(longest, reads[i].end - reads[i].pos); }
+    if (longest > 0) atomicMax(&fl->max_len, longest);
     if (t == int(blockDim.x) - 1) fl->n_valid = part[t];
 }
 
@@ -456,14 +458,55 @@ __device__ __forceinline__ uint32_t dev_entry(int code, int bq, int mq) { return
 __constant__ int8_t kNib[16] = {-1, 0, 1, 10, 2, 10, 10, 10, 3, 10, 10, 10, 10, 10, 10, 10};
 
 // One wave per accepted read, one lane per CIGAR operation (64 at a time).
+// Where an entry goes (round 4): a column lists its reads in file order, and read j's place in the column of position p is the number
+// of EARLIER reads that cover p - all of which started at or before j's start (the file is sorted), so they are the reads still open
+// at j's start whose end lies behind p.  The wave collects the ends of those open reads once (the accepted reads in front of j, back
+// to the first one that starts more than the longest read's span before j) and counts, per position, the ends behind it: no cursor
+// atomics (device-scope atomics from eight XCDs on 51 M read-bases were most of this kernel's time), no rank to carry along, nothing
+// to put back into order afterwards - the 4-byte entry lands in its final place.  Indel carriers (one read-base in a hundred) leave
+// their details in `side` at the same index and a mark on their column for k_order.
+constexpr int FILL_LIVE = 1024;
 __global__ __launch_bounds__(256) void k_fill(const uint8_t* __restrict__ lin, const DevRead* __restrict__ reads, const int* __restrict__ rid,
-                                              const Flags* fl, Ivs iv, const int* __restrict__ slot_col, const long long* __restrict__ col_off,
-                                              int* __restrict__ cursor, TmpEnt* __restrict__ tmp, const char* __restrict__ ref, long long ref_start,
-                                              long long ref_len) {
-    const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+                                              Flags* fl, Ivs iv, const int* __restrict__ slot_col, const long long* __restrict__ col_off,
+                                              int* __restrict__ marks, uint32_t* __restrict__ entries, TmpEnt* __restrict__ side,
+                                              const char* __restrict__ ref, long long ref_start, long long ref_len) {
+    __shared__ int s_live[4][FILL_LIVE], s_sort[4][FILL_LIVE];
+    // The four waves of a workgroup share ONE read (each walks the CIGAR for itself and takes every fourth 64-position slice of a long
+    // run, every fourth short operation): the kernel lasts as long as its longest read's chain of dependent trips to memory
+    // (position -> column -> entry offset -> store, ~3 us a slice), and a 30 kb read is 470 slices.
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = blockIdx.x;
     if (j >= fl->n_valid) return;
     const DevRead r = reads[rid[j]];
+    int n_live = 0;
+    {
+        const long long reach = (long long)r.pos - fl->max_len;       // a read that starts at or before it has ended by r.pos
+        for (int i0 = j - 1; i0 >= 0; i0 -= 64) {
+            const int i = i0 - lane;
+            int ps = 0, en = 0;
+            if (i >= 0) { const int ri = rid[i]; ps = reads[ri].pos; en = reads[ri].end; }
+            const bool open = i >= 0 && en > r.pos;
+            const unsigned long long m = __ballot(open);
+            const int at = n_live + __popcll(m & ((1ull << lane) - 1ull));
+            if (open && at < FILL_LIVE) s_live[wv][at] = en;
+            n_live += __popcll(m);
+            if (__ballot(i >= 0 && (long long)ps <= reach)) break;
+        }
+        if (n_live > FILL_LIVE) { if (lane == 0) atomicExch(&fl->deep_col, 1); return; }      // the caller falls back
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        // ascending (rank by counting; n_live is about the depth): a position's count is then a binary search, not a sweep
+        for (int u0 = 0; u0 < n_live; u0 += 64) {
+            const int idx = u0 + lane;
+            const int v = idx < n_live ? s_live[wv][idx] : 0x7fffffff;
+            int rk = 0;
+            for (int k = 0; k < n_live; ++k) { const int x = s_live[wv][k]; rk += (x < v) || (x == v && k < idx); }
+            if (idx < n_live) s_sort[wv][rk] = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+    }
+    const int* const live = s_sort[wv];
     const uint8_t* ops = lin + r.ops_off;
     const uint8_t* seq = lin + r.seq_off;
     const uint8_t* qual = lin + r.qual_off;
@@ -531,8 +574,14 @@ __global__ __launch_bounds__(256) void k_fill(const uint8_t* __restrict__ lin, c
         auto emit = [&](int p, int kiv, int o_ref, int o_q, int o_len, bool o_aligned, uint32_t o_ind, uint32_t o_ind_q) {
             TmpEnt e;
             const int col = make(p, kiv, o_ref, o_q, o_len, o_aligned, o_ind, o_ind_q, &e);
-            const long long at = col_off[col] + atomicAdd(&cursor[col], 1);
-            tmp[at] = e;
+            int lo = 0, n = n_live;                                             // first end behind p: the earlier reads that cover p
+            while (n > 0) {
+                const int half = n >> 1;
+                if (live[lo + half] <= p) { lo += half + 1; n -= half + 1; } else n = half;
+            }
+            const long long at = col_off[col] + (n_live - lo);
+            entries[at] = e.entry | ((e.ind & 3u) << 4);                        // carriers: provisional kind, k_order completes it
+            if (e.ind & 3u) { side[at] = e; marks[col] = 1; }
         };
         auto first_iv = [&](int p) {
             int a = 0, b = iv.n;
@@ -543,7 +592,7 @@ __global__ __launch_bounds__(256) void k_fill(const uint8_t* __restrict__ lin, c
         // (hundreds of bases) would leave the other lanes idle, so the whole wave takes each of those in turn below
         constexpr int LONG_OP = 48;
         const bool is_long = covers && len > LONG_OP;
-        if (covers && !is_long) {
+        if (covers && !is_long && (k & 3) == wv) {
             int p = op_ref, kiv = first_iv(op_ref);
             const int pend = op_ref + len;
             while (p < pend && kiv < iv.n) {
@@ -563,13 +612,13 @@ __global__ __launch_bounds__(256) void k_fill(const uint8_t* __restrict__ lin, c
             const int pend = o_ref + o_len;
             for (int kiv = first_iv(o_ref); kiv < iv.n && iv.lo[kiv] < pend; ++kiv) {
                 const int lo = max(o_ref, iv.lo[kiv]), hi = min(pend, iv.hi[kiv]);
-                for (int p = lo + lane; p < hi; p += 64) emit(p, kiv, o_ref, o_q, o_len, o_aligned, o_ind, o_ind_q);
+                for (int p = lo + lane + 64 * wv; p < hi; p += 256) emit(p, kiv, o_ref, o_q, o_len, o_aligned, o_ind, o_ind_q);
             }
         }
     }
 }
 
-constexpr int ORD_DMAX = 2048, ORD_KMAX = 64, ORD_IMAX = 256;
+constexpr int ORD_KMAX = 64;
 
 __device__ __forceinline__ int canon_nib(const uint8_t* seq, int q) {
     const int n = (seq[q >> 1] >> ((~q & 1) << 2)) & 15;
@@ -578,126 +627,98 @@ __device__ __forceinline__ int canon_nib(const uint8_t* seq, int q) {
 
 struct IndEnt { uint32_t at, entry, rank, ind_q, ind; };     // at = the entry's place in the column once it is in file order
 
-// One wave per column (workgroup = one wave): file order, indel keys in first-seen order, merged groups.
-// Two sizes (round 4): the kernel is bound by how many columns a CU holds in flight - a column is a chain of three dependent trips
-// to memory - and that by LDS.  The SMALL form (columns of up to 128 read-bases with up to 32 indel carriers and 16 distinct keys:
-// 2 KB of LDS, 32 waves per CU instead of 8) takes every column it can and leaves ORD_TODO in n_keys_col for the others; the LARGE
-// form (2048 / 256 / 64) then takes exactly those.  1 000 000 columns of a region: 1.35 ms with the large form alone.
-constexpr int ORD_TODO = -2;
-template <int DMAX, int IMAX, int KMAX, bool SECOND>
+// The indel keys of the columns k_fill marked (round 4: the entries are in file order already): one wave per marked column walks its
+// entries 64 at a time, and every indel carrier - in file order - is compared against the column's keys across lanes: the distinct keys
+// in first-seen order, the merged candidate-extraction groups, the entry completed with kind and key id.  Columns without a carrier
+// (six in ten at 50x) cost one coalesced load of 64 marks per wave trip.
 __global__ __launch_bounds__(64) void k_order(const uint8_t* __restrict__ lin, const DevRead* __restrict__ reads, const int* __restrict__ rid,
-                                              int n_cols, const long long* __restrict__ col_off, const TmpEnt* __restrict__ tmp,
-                                              uint32_t* __restrict__ entries, int* __restrict__ n_keys_col, KeyRec* __restrict__ keyrec, int max_indel,
-                                              Flags* fl) {
-    __shared__ uint32_t ranks[DMAX];
-    __shared__ IndEnt ind_a[IMAX], ind_b[IMAX];
-    __shared__ KeyRec keys[KMAX];
-    __shared__ int grp_key[KMAX];                 // group g is represented by the key that opened it
-    __shared__ int n_ind_s;
+                                              int n_cols, const long long* __restrict__ col_off, const int* __restrict__ marks,
+                                              const TmpEnt* __restrict__ side, uint32_t* __restrict__ entries, int* __restrict__ n_keys_col,
+                                              KeyRec* __restrict__ keyrec, int max_indel, Flags* fl) {
+    __shared__ KeyRec keys[ORD_KMAX];
+    __shared__ int grp_key[ORD_KMAX];             // group g is represented by the key that opened it
     const int lane = threadIdx.x;
-    // the large form looks at 64 columns' marks per trip (one coalesced load) and works on the marked ones
-    for (long long base = SECOND ? blockIdx.x * 64ll : (long long)blockIdx.x; base < n_cols; base += SECOND ? gridDim.x * 64ll : (long long)gridDim.x) {
-      unsigned long long todo = 1ull;
-      if (SECOND) { const long long cc = base + lane; todo = __ballot(cc < n_cols && n_keys_col[cc] == ORD_TODO); }
-      while (todo) {
-        const int c = SECOND ? int(base) + __ffsll((long long)todo) - 1 : int(base);
-        todo &= todo - 1ull;
-        const long long o = col_off[c];
-        const int d = int(col_off[c + 1] - o);
-        if (d > ORD_DMAX) { if (lane == 0) n_keys_col[c] = 0; continue; }      // flagged by k_columns: the caller falls back
-        if (d > DMAX) { if (lane == 0) n_keys_col[c] = ORD_TODO; continue; }
-        __syncthreads();
-        if (lane == 0) n_ind_s = 0;
-        for (int i = lane; i < d; i += 64) ranks[i] = tmp[o + i].rank;
-        __syncthreads();
-        // every entry to its place in file order (rank by counting: a read has one entry per column); indel carriers are listed
-        for (int i = lane; i < d; i += 64) {
-            const TmpEnt e = tmp[o + i];
-            int at = 0;
-            for (int t = 0; t < d; ++t) at += ranks[t] < e.rank;
-            entries[o + at] = e.entry;
-            if (e.ind & 3u) {
-                const int slot = atomicAdd(&n_ind_s, 1);
-                if (slot < IMAX) ind_a[slot] = IndEnt{uint32_t(at), e.entry, e.rank, e.ind_q, e.ind};
-            }
-        }
-        __syncthreads();
-        const int n_ind = n_ind_s;
-        if (n_ind > IMAX) {
-            if (lane == 0) { if (IMAX < ORD_IMAX) n_keys_col[c] = ORD_TODO; else { atomicExch(&fl->many_keys, 1); n_keys_col[c] = 0; } }
-            continue;
-        }
-        for (int i = lane; i < n_ind; i += 64) {
-            const IndEnt e = ind_a[i];
-            int at = 0;
-            for (int t = 0; t < n_ind; ++t) at += ind_a[t].at < e.at;
-            ind_b[at] = e;
-        }
-        __syncthreads();
-        int nk = 0, ng = 0;
-        bool over = false;
-        for (int x = 0; x < n_ind && !over; ++x) {
-            const IndEnt cand = ind_b[x];                                      // the same for every lane
-            const int kind = int(cand.ind & 3u), len = int(cand.ind >> 2), code = int(cand.entry & 15u);
-            const uint8_t* cseq = lin + reads[rid[cand.rank]].seq_off;
-            bool hit = false;
-            if (lane < nk) {                                                   // lane k compares the candidate with key k
-                const KeyRec kr = keys[lane];
-                if (int(kr.code) == code && int(kr.kind) == kind && int(kr.len) == len) {
-                    hit = true;
-                    if (kind == 1) {
-                        const uint8_t* kseq = lin + reads[rid[kr.read]].seq_off;
-                        for (int t = 0; t < len; ++t)
-                            if (canon_nib(kseq, int(kr.q) + t) != canon_nib(cseq, int(cand.ind_q) + t)) { hit = false; break; }
-                    }
-                }
-            }
-            const unsigned long long hm = __ballot(hit);
-            int kid;
-            if (hm) {
-                kid = __ffsll((long long)hm) - 1;
-            } else {
-                if (nk >= KMAX) { over = true; break; }
-                kid = nk;
-                // merged group for candidate extraction: insertions by upper-cased anchor + sequence, deletions by length
-                const char anchor_c = "ACGTACGT*#NN"[code];
-                bool ghit = false;
-                if (lane < ng) {
-                    const KeyRec gr = keys[grp_key[lane]];
-                    if (int(gr.kind) == kind && int(gr.len) == len) {
-                        if (kind == 2) ghit = true;
-                        else if ("ACGTACGT*#NN"[gr.code] == anchor_c) {
-                            ghit = true;
-                            const uint8_t* gseq = lin + reads[rid[gr.read]].seq_off;
-                            for (int t = 0; t < len; ++t)
-                                if (canon_nib(gseq, int(gr.q) + t) != canon_nib(cseq, int(cand.ind_q) + t)) { ghit = false; break; }
+    for (long long base = blockIdx.x * 64ll; base < n_cols; base += gridDim.x * 64ll) {
+        const long long cc = base + lane;
+        const bool marked = cc < n_cols && marks[cc] != 0;
+        if (cc < n_cols && !marked) n_keys_col[cc] = 0;
+        unsigned long long todo = __ballot(marked);
+        while (todo) {
+            const int c = int(base) + __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const long long o = col_off[c];
+            const int d = int(col_off[c + 1] - o);
+            __syncthreads();
+            int nk = 0, ng = 0;
+            bool over = false;
+            for (int i0 = 0; i0 < d && !over; i0 += 64) {
+                const int i = i0 + lane;
+                const uint32_t ent = i < d ? entries[o + i] : 0u;
+                unsigned long long car = __ballot(i < d && ((ent >> 4) & 3u) != 0u);
+                while (car && !over) {
+                    const int src = __ffsll((long long)car) - 1;
+                    car &= car - 1ull;
+                    const int cat = i0 + src;
+                    const TmpEnt cand = side[o + cat];                             // the same for every lane
+                    const uint32_t centry = cand.entry;
+                    const int kind = int(cand.ind & 3u), len = int(cand.ind >> 2), code = int(centry & 15u);
+                    const uint8_t* cseq = lin + reads[rid[cand.rank]].seq_off;
+                    bool hit = false;
+                    if (lane < nk) {                                               // lane k compares the candidate with key k
+                        const KeyRec kr = keys[lane];
+                        if (int(kr.code) == code && int(kr.kind) == kind && int(kr.len) == len) {
+                            hit = true;
+                            if (kind == 1) {
+                                const uint8_t* kseq = lin + reads[rid[kr.read]].seq_off;
+                                for (int t = 0; t < len; ++t)
+                                    if (canon_nib(kseq, int(kr.q) + t) != canon_nib(cseq, int(cand.ind_q) + t)) { hit = false; break; }
+                            }
                         }
                     }
+                    const unsigned long long hm = __ballot(hit);
+                    int kid;
+                    if (hm) {
+                        kid = __ffsll((long long)hm) - 1;
+                    } else {
+                        if (nk >= ORD_KMAX) { over = true; break; }
+                        kid = nk;
+                        // merged group for candidate extraction: insertions by upper-cased anchor + sequence, deletions by length
+                        const char anchor_c = "ACGTACGT*#NN"[code];
+                        bool ghit = false;
+                        if (lane < ng) {
+                            const KeyRec gr = keys[grp_key[lane]];
+                            if (int(gr.kind) == kind && int(gr.len) == len) {
+                                if (kind == 2) ghit = true;
+                                else if ("ACGTACGT*#NN"[gr.code] == anchor_c) {
+                                    ghit = true;
+                                    const uint8_t* gseq = lin + reads[rid[gr.read]].seq_off;
+                                    for (int t = 0; t < len; ++t)
+                                        if (canon_nib(gseq, int(gr.q) + t) != canon_nib(cseq, int(cand.ind_q) + t)) { ghit = false; break; }
+                                }
+                            }
+                        }
+                        const unsigned long long gm = __ballot(ghit);
+                        const int g = gm ? __ffsll((long long)gm) - 1 : ng;
+                        if (lane == 0) {
+                            const int gate = kind == 1 ? len : len + 1;
+                            keys[nk] = KeyRec{cand.rank, cand.ind_q, uint32_t(len), uint8_t(code), uint8_t(kind), uint8_t(gate > max_indel), uint8_t(g)};
+                            if (!gm) grp_key[ng] = nk;
+                        }
+                        if (!gm) ++ng;
+                        ++nk;
+                        __syncthreads();
+                    }
+                    if (lane == 0) {
+                        const int gate = kind == 1 ? len : len + 1;
+                        entries[o + cat] = centry | (uint32_t(gate > max_indel ? 3 : kind) << 4) | (uint32_t(kid) << 21);
+                    }
                 }
-                const unsigned long long gm = __ballot(ghit);
-                const int g = gm ? __ffsll((long long)gm) - 1 : ng;
-                if (lane == 0) {
-                    const int gate = kind == 1 ? len : len + 1;
-                    keys[nk] = KeyRec{cand.rank, cand.ind_q, uint32_t(len), uint8_t(code), uint8_t(kind), uint8_t(gate > max_indel), uint8_t(g)};
-                    if (!gm) grp_key[ng] = nk;
-                }
-                if (!gm) ++ng;
-                ++nk;
-                __syncthreads();
             }
-            if (lane == 0) {
-                const int gate = kind == 1 ? len : len + 1;
-                entries[o + cand.at] = cand.entry | (uint32_t(gate > max_indel ? 3 : kind) << 4) | (uint32_t(kid) << 21);
-            }
+            if (over) { if (lane == 0) { atomicExch(&fl->many_keys, 1); n_keys_col[c] = 0; } continue; }
+            __syncthreads();
+            if (lane == 0) n_keys_col[c] = nk;
+            for (int k = lane; k < nk; k += 64) keyrec[o + k] = keys[k];          // nk <= d: the column's own slots
         }
-        if (over) {
-            if (lane == 0) { if (KMAX < ORD_KMAX) n_keys_col[c] = ORD_TODO; else { atomicExch(&fl->many_keys, 1); n_keys_col[c] = 0; } }
-            continue;
-        }
-        __syncthreads();
-        if (lane == 0) n_keys_col[c] = nk;
-        for (int k = lane; k < nk; k += 64) keyrec[o + k] = keys[k];          // nk <= d: the column's own slots
-      }
     }
 }
 
@@ -957,14 +978,11 @@ extern "C" int cto_pileup_device(cto_dev_pileup* cx, const void* d_inflated, con
     const char* d_ref = cx->ref.as<char>();
     hipLaunchKernelGGL(k_col_meta, dim3(unsigned(cdiv(n_cols, 256))), dim3(256), 0, s, cx->col_slot.as<int>(), n_cols, iv, d_ref, (long long)ref_start,
                        (long long)ref_len, cx->col_pos.as<int32_t>(), cx->col_ref.as<uint8_t>(), fl);
-    hipLaunchKernelGGL(k_fill, dim3(unsigned(cdiv(hf->n_valid, 4))), dim3(256), 0, s, lin, cx->reads.as<DevRead>(), cx->rid.as<int>(), fl, iv,
-                       cx->slot_col.as<int>(), cx->col_off.as<long long>(), cx->cursor.as<int>(), cx->tmp.as<TmpEnt>(), d_ref, (long long)ref_start,
-                       (long long)ref_len);
-    hipLaunchKernelGGL((k_order<128, 32, 16, false>), dim3(unsigned(std::min(n_cols, 65536))), dim3(64), 0, s, lin, cx->reads.as<DevRead>(), cx->rid.as<int>(),
-                       n_cols, cx->col_off.as<long long>(), cx->tmp.as<TmpEnt>(), cx->entries.as<uint32_t>(), cx->nkc.as<int>(), cx->keyrec.as<KeyRec>(),
-                       max_indel_length, fl);
-    hipLaunchKernelGGL((k_order<ORD_DMAX, ORD_IMAX, ORD_KMAX, true>), dim3(unsigned(std::min(n_cols, 16384))), dim3(64), 0, s, lin, cx->reads.as<DevRead>(),
-                       cx->rid.as<int>(), n_cols, cx->col_off.as<long long>(), cx->tmp.as<TmpEnt>(), cx->entries.as<uint32_t>(), cx->nkc.as<int>(),
+    hipLaunchKernelGGL(k_fill, dim3(unsigned(hf->n_valid)), dim3(256), 0, s, lin, cx->reads.as<DevRead>(), cx->rid.as<int>(), fl, iv,
+                       cx->slot_col.as<int>(), cx->col_off.as<long long>(), cx->cursor.as<int>(), cx->entries.as<uint32_t>(), cx->tmp.as<TmpEnt>(), d_ref,
+                       (long long)ref_start, (long long)ref_len);
+    hipLaunchKernelGGL(k_order, dim3(unsigned(std::min<long long>(cdiv(n_cols, 64), 65536))), dim3(64), 0, s, lin, cx->reads.as<DevRead>(), cx->rid.as<int>(),
+                       n_cols, cx->col_off.as<long long>(), cx->cursor.as<int>(), cx->tmp.as<TmpEnt>(), cx->entries.as<uint32_t>(), cx->nkc.as<int>(),
                        cx->keyrec.as<KeyRec>(), max_indel_length, fl);
     if (n_cols <= 4 * SCAN_TILE) {
         hipLaunchKernelGGL(k_scan_small<int>, dim3(1), dim3(1024), 0, s, cx->nkc.as<int>(), cx->key_off.as<int>(), n_cols, &fl->n_keys);
@@ -979,7 +997,7 @@ extern "C" int cto_pileup_device(cto_dev_pileup* cx, const void* d_inflated, con
     CTO_HIP(hipGetLastError());
     if ((rc = fetch_flags())) return rc;
     if (hf->ref_oob) { set_error("cto_pileup_device: a covered position lies outside the supplied reference"); return CTO_EINVAL; }
-    if (hf->many_keys) { *fallback = 1; return CTO_OK; }
+    if (hf->many_keys || hf->deep_col) { *fallback = 1; return CTO_OK; }          // deep_col here: more than FILL_LIVE reads open at a read's start
     const int n_keys = hf->n_keys;
     std::unique_ptr<cto_pack> lite(new cto_pack());
     lite->col_pos.resize(size_t(n_cols));
