@@ -612,7 +612,12 @@ __global__ __launch_bounds__(256) void k_fill(const uint8_t* __restrict__ lin, c
             const int pend = o_ref + o_len;
             for (int kiv = first_iv(o_ref); kiv < iv.n && iv.lo[kiv] < pend; ++kiv) {
                 const int lo = max(o_ref, iv.lo[kiv]), hi = min(pend, iv.hi[kiv]);
-                for (int p = lo + lane + 64 * wv; p < hi; p += 256) emit(p, kiv, o_ref, o_q, o_len, o_aligned, o_ind, o_ind_q);
+                if (hi - lo > 64) {              // a long stretch of requested positions: every wave takes each fourth 64-position slice
+                    for (int p = lo + lane + 64 * wv; p < hi; p += 256) emit(p, kiv, o_ref, o_q, o_len, o_aligned, o_ind, o_ind_q);
+                } else if ((kiv & 3) == wv) {    // candidate windows (34 positions each): every wave takes each fourth window
+                    const int p = lo + lane;
+                    if (p < hi) emit(p, kiv, o_ref, o_q, o_len, o_aligned, o_ind, o_ind_q);
+                }
             }
         }
     }
