@@ -28,7 +28,7 @@
 //
 // Not done here - the call reports `fallback` and the caller uses the host reader: paired reads (mate-overlap quality edits are
 // order dependent), reference skips (N), --max-depth or more reads open at some read's start (the cap is order dependent; k_live_marks), a column
-// deeper than 2048, more than 1024 reads open at a read's start, or more than 64 distinct indel keys in a column.  The BGZF CRC-32 of every block is
+// deeper than 2048, 2048 or more reads open at a read's start, or more than 64 distinct indel keys in a column.  The BGZF CRC-32 of every block is
 // checked on the device (k_crc32_blocks), as htslib and the host reader check it.
 #include <algorithm>
 #include <cstring>
@@ -465,18 +465,26 @@ __constant__ int8_t kNib[16] = {-1, 0, 1, 10, 2, 10, 10, 10, 3, 10, 10, 10, 10, 
 // atomics (device-scope atomics from eight XCDs on 51 M read-bases were most of this kernel's time), no rank to carry along, nothing
 // to put back into order afterwards - the 4-byte entry lands in its final place.  Indel carriers (one read-base in a hundred) leave
 // their details in `side` at the same index and a mark on their column for k_order.
-constexpr int FILL_LIVE = 1024;
-__global__ __launch_bounds__(256) void k_fill(const uint8_t* __restrict__ lin, const DevRead* __restrict__ reads, const int* __restrict__ rid,
+constexpr int FILL_LIVE_MAX = 2048;          // reads open at a read's start the kernel can hold (more: the caller falls back)
+__global__ __launch_bounds__(256) void k_fill(int live_cap, const uint8_t* __restrict__ lin, const DevRead* __restrict__ reads, const int* __restrict__ rid,
                                               Flags* fl, Ivs iv, const int* __restrict__ slot_col, const long long* __restrict__ col_off,
                                               int* __restrict__ marks, uint32_t* __restrict__ entries, TmpEnt* __restrict__ side,
                                               const char* __restrict__ ref, long long ref_start, long long ref_len) {
-    __shared__ int s_live[4][FILL_LIVE], s_sort[4][FILL_LIVE];
+    // [wave][live_cap] ends as collected, then [wave][live_cap] sorted; live_cap = the launch's bound on reads open at a read's start
+    // (k_live_max), so that ordinary depths leave the LDS - and with it the number of reads in flight per CU - alone
+    extern __shared__ int s_fill[];
+    int* const s_live_w = s_fill + (threadIdx.x >> 6) * live_cap;
+    int* const s_sort_w = s_fill + (4 + (threadIdx.x >> 6)) * live_cap;
     // The four waves of a workgroup share ONE read (each walks the CIGAR for itself and takes every fourth 64-position slice of a long
     // run, every fourth short operation): the kernel lasts as long as its longest read's chain of dependent trips to memory
     // (position -> column -> entry offset -> store, ~3 us a slice), and a 30 kb read is 470 slices.
+    // Workgroups are dealt to the 8 XCDs in turn: XCD x takes the x-th eighth of the (position-sorted) reads, so that the reads an XCD
+    // works on at one time lie next to each other on the genome and their four-byte stores - every one to another cache line of the
+    // column-major entries - meet again in that XCD's own L2 before the lines go to memory
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int j = blockIdx.x;
-    if (j >= fl->n_valid) return;
+    const int per_xcd = (fl->n_valid + 7) >> 3;
+    const int j = int(blockIdx.x & 7u) * per_xcd + int(blockIdx.x >> 3);
+    if (int(blockIdx.x >> 3) >= per_xcd || j >= fl->n_valid) return;
     const DevRead r = reads[rid[j]];
     int n_live = 0;
     {
@@ -488,25 +496,25 @@ __global__ __launch_bounds__(256) void k_fill(const uint8_t* __restrict__ lin, c
             const bool open = i >= 0 && en > r.pos;
             const unsigned long long m = __ballot(open);
             const int at = n_live + __popcll(m & ((1ull << lane) - 1ull));
-            if (open && at < FILL_LIVE) s_live[wv][at] = en;
+            if (open && at < live_cap) s_live_w[at] = en;
             n_live += __popcll(m);
             if (__ballot(i >= 0 && (long long)ps <= reach)) break;
         }
-        if (n_live > FILL_LIVE) { if (lane == 0) atomicExch(&fl->deep_col, 1); return; }      // the caller falls back
+        if (n_live > live_cap) { if (lane == 0) atomicExch(&fl->deep_col, 1); return; }      // cannot happen (live_cap > max_live); the caller falls back
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
         // ascending (rank by counting; n_live is about the depth): a position's count is then a binary search, not a sweep
         for (int u0 = 0; u0 < n_live; u0 += 64) {
             const int idx = u0 + lane;
-            const int v = idx < n_live ? s_live[wv][idx] : 0x7fffffff;
+            const int v = idx < n_live ? s_live_w[idx] : 0x7fffffff;
             int rk = 0;
-            for (int k = 0; k < n_live; ++k) { const int x = s_live[wv][k]; rk += (x < v) || (x == v && k < idx); }
-            if (idx < n_live) s_sort[wv][rk] = v;
+            for (int k = 0; k < n_live; ++k) { const int x = s_live_w[k]; rk += (x < v) || (x == v && k < idx); }
+            if (idx < n_live) s_sort_w[rk] = v;
         }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
     }
-    const int* const live = s_sort[wv];
+    const int* const live = s_sort_w;
     const uint8_t* ops = lin + r.ops_off;
     const uint8_t* seq = lin + r.seq_off;
     const uint8_t* qual = lin + r.qual_off;
@@ -948,7 +956,7 @@ extern "C" int cto_pileup_device(cto_dev_pileup* cx, const void* d_inflated, con
     hipLaunchKernelGGL(k_parse, dim3(unsigned(cdiv(n_rec, 128))), dim3(128), 0, s, lin, cx->rec_off.as<uint32_t>(), n_rec, tid, int(start - 1), int(end),
                        excl_flags, min_mq, cx->reads.as<DevRead>(), fl);
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, cx->reads.as<DevRead>(), n_rec, cx->rid.as<int>(), fl);
-    if (max_depth > 0) {
+    {
         hipLaunchKernelGGL(k_live_marks, dim3(unsigned(cdiv(n_rec, 128))), dim3(128), 0, s, cx->reads.as<DevRead>(), cx->rid.as<int>(), fl, cx->live.as<int>());
         hipLaunchKernelGGL(k_live_max, dim3(1), dim3(1024), 0, s, cx->live.as<int>(), fl);
     }
@@ -971,7 +979,10 @@ extern "C" int cto_pileup_device(cto_dev_pileup* cx, const void* d_inflated, con
     if ((rc = fetch_flags())) return rc;
     const int lim = hf->stop_idx;
     if (hf->err_idx < lim) { set_error("cto_pileup_device: alignment record shorter than its fields, or running past 2^31 - 1"); return CTO_EINVAL; }
-    if (hf->paired_idx < lim || hf->skip_idx < lim || hf->deep_col || (max_depth > 0 && hf->max_live >= max_depth)) { *fallback = 1; return CTO_OK; }
+    if (hf->paired_idx < lim || hf->skip_idx < lim || hf->deep_col || (max_depth > 0 && hf->max_live >= max_depth) || hf->max_live >= FILL_LIVE_MAX) {
+        *fallback = 1;
+        return CTO_OK;
+    }
     const int n_cols = hf->n_cols;
     const long long n_entries = hf->n_entries;
     if (n_cols == 0) return empty_result();
@@ -983,7 +994,9 @@ extern "C" int cto_pileup_device(cto_dev_pileup* cx, const void* d_inflated, con
     const char* d_ref = cx->ref.as<char>();
     hipLaunchKernelGGL(k_col_meta, dim3(unsigned(cdiv(n_cols, 256))), dim3(256), 0, s, cx->col_slot.as<int>(), n_cols, iv, d_ref, (long long)ref_start,
                        (long long)ref_len, cx->col_pos.as<int32_t>(), cx->col_ref.as<uint8_t>(), fl);
-    hipLaunchKernelGGL(k_fill, dim3(unsigned(hf->n_valid)), dim3(256), 0, s, lin, cx->reads.as<DevRead>(), cx->rid.as<int>(), fl, iv,
+    int live_cap = 64;
+    while (live_cap <= hf->max_live) live_cap <<= 1;
+    hipLaunchKernelGGL(k_fill, dim3(unsigned(((hf->n_valid + 7) >> 3) << 3)), dim3(256), size_t(live_cap) * 8 * sizeof(int), s, live_cap, lin, cx->reads.as<DevRead>(), cx->rid.as<int>(), fl, iv,
                        cx->slot_col.as<int>(), cx->col_off.as<long long>(), cx->cursor.as<int>(), cx->entries.as<uint32_t>(), cx->tmp.as<TmpEnt>(), d_ref,
                        (long long)ref_start, (long long)ref_len);
     hipLaunchKernelGGL(k_order, dim3(unsigned(std::min<long long>(cdiv(n_cols, 64), 65536))), dim3(64), 0, s, lin, cx->reads.as<DevRead>(), cx->rid.as<int>(),
