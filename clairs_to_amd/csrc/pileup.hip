@@ -30,6 +30,7 @@
 // order dependent), reference skips (N), --max-depth or more reads open at some read's start (the cap is order dependent; k_live_marks), a column
 // deeper than 2048, 2048 or more reads open at a read's start, or more than 64 distinct indel keys in a column.  The BGZF CRC-32 of every block is
 // checked on the device (k_crc32_blocks), as htslib and the host reader check it.
+#include <unistd.h>
 #include <algorithm>
 #include <cstring>
 #include <memory>
@@ -806,13 +807,37 @@ struct cto_dev_pileup {
         entries, nkc, keyrec, key_off, key_meta, key_group, key_final, key_col, key_len, str_off, key_str, ref, flags, z1k;
     bool z1k_ready = false;
     Flags* h_flags = nullptr;            // page-locked mirror
-    ~cto_dev_pileup() { if (h_flags) (void)hipHostFree(h_flags); }
+    void* h_stage = nullptr;             // page-locked landing area of the small arrays that go back to the host (a copy to pageable
+    size_t h_stage_cap = 0;              // memory blocks - and spins - until everything queued in front of it is done)
+    int stage_ensure(size_t n) {
+        if (n <= h_stage_cap) return CTO_OK;
+        if (h_stage) { CTO_HIP(hipHostFree(h_stage)); h_stage = nullptr; h_stage_cap = 0; }
+        const size_t want = n + n / 4 + 4096;
+        CTO_HIP(hipHostMalloc(&h_stage, want, hipHostMallocDefault));
+        h_stage_cap = want;
+        return CTO_OK;
+    }
+    hipEvent_t ev = nullptr;             // the driver's waits sleep on it: hipStreamSynchronize polls the completion signal from the calling
+                                         // thread, and that thread shares sixteen host cores with everything else of a run
+    ~cto_dev_pileup() { if (h_flags) (void)hipHostFree(h_flags); if (h_stage) (void)hipHostFree(h_stage); if (ev) (void)hipEventDestroy(ev); }
 };
+
+// waits for everything queued on `s` so far without occupying a core (pipeline.hip's wait_event)
+static hipError_t sleepy_sync(cto_dev_pileup* cx, hipStream_t s) {
+    hipError_t e = hipEventRecord(cx->ev, s);
+    if (e != hipSuccess) return e;
+    for (int spins = 0;; ++spins) {
+        e = hipEventQuery(cx->ev);
+        if (e != hipErrorNotReady) return e;
+        if (spins >= 4) usleep(spins < 64 ? 50 : 200);
+    }
+}
 
 extern "C" int cto_dev_pileup_create(cto_dev_pileup** out) try {
     CTO_REQUIRE(out, CTO_EINVAL, "cto_dev_pileup_create: null argument");
     std::unique_ptr<cto_dev_pileup> c(new cto_dev_pileup());
     CTO_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_flags), sizeof(Flags), hipHostMallocDefault));
+    CTO_HIP(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
     *out = c.release();
     return CTO_OK;
 }
@@ -872,7 +897,7 @@ extern "C" int cto_pileup_device(cto_dev_pileup* cx, const void* d_inflated, con
     Flags* hf = cx->h_flags;
     auto fetch_flags = [&]() -> int {
         CTO_HIP(hipMemcpyAsync(hf, cx->flags.p, sizeof(Flags), hipMemcpyDeviceToHost, s));
-        CTO_HIP(hipStreamSynchronize(s));
+        CTO_HIP(sleepy_sync(cx, s));
         return CTO_OK;
     };
     auto empty_result = [&]() -> int {
@@ -888,7 +913,7 @@ extern "C" int cto_pileup_device(cto_dev_pileup* cx, const void* d_inflated, con
             return rc0;
         CTO_HIP(hipMemsetAsync(cx->col_off.p, 0, 64, s));
         CTO_HIP(hipMemsetAsync(cx->key_off.p, 0, 64, s));
-        CTO_HIP(hipStreamSynchronize(s));
+        CTO_HIP(sleepy_sync(cx, s));
         dev_view->col_pos = cx->col_pos.as<int32_t>();
         dev_view->col_ref = cx->col_ref.as<uint8_t>();
         dev_view->col_off = cx->col_off.as<int64_t>();
@@ -1044,15 +1069,24 @@ extern "C" int cto_pileup_device(cto_dev_pileup* cx, const void* d_inflated, con
         lite->key_meta.resize(size_t(n_keys));
         lite->key_group.resize(size_t(n_keys));
         static_assert(sizeof(long long) == sizeof(int64_t), "");
-        CTO_HIP(hipMemcpyAsync(lite->key_str_off.data(), cx->str_off.p, size_t(n_keys + 1) * 8, hipMemcpyDeviceToHost, s));
-        if (sb) CTO_HIP(hipMemcpyAsync(&lite->key_str[0], cx->key_str.p, size_t(sb), hipMemcpyDeviceToHost, s));
-        CTO_HIP(hipMemcpyAsync(lite->key_meta.data(), cx->key_meta.p, size_t(n_keys), hipMemcpyDeviceToHost, s));
-        CTO_HIP(hipMemcpyAsync(lite->key_group.data(), cx->key_group.p, size_t(n_keys) * 4, hipMemcpyDeviceToHost, s));
     }
-    CTO_HIP(hipMemcpyAsync(lite->col_pos.data(), cx->col_pos.p, size_t(n_cols) * 4, hipMemcpyDeviceToHost, s));
-    CTO_HIP(hipMemcpyAsync(lite->col_ref.data(), cx->col_ref.p, size_t(n_cols), hipMemcpyDeviceToHost, s));
-    CTO_HIP(hipMemcpyAsync(lite->key_off.data(), cx->key_off.p, size_t(n_cols + 1) * 4, hipMemcpyDeviceToHost, s));
-    CTO_HIP(hipStreamSynchronize(s));
+    {
+        // everything the host keeps of the pack, through ONE page-locked landing area and one sleeping wait
+        const size_t sb = lite->key_str.size(), nk = size_t(n_keys), nc = size_t(n_cols);
+        const size_t bytes[7] = {nk ? (nk + 1) * 8 : 0, sb, nk, nk * 4, nc * 4, nc, (nc + 1) * 4};
+        const void* src[7] = {cx->str_off.p, cx->key_str.p, cx->key_meta.p, cx->key_group.p, cx->col_pos.p, cx->col_ref.p, cx->key_off.p};
+        void* dst[7] = {lite->key_str_off.data(), sb ? &lite->key_str[0] : nullptr, lite->key_meta.data(), lite->key_group.data(), lite->col_pos.data(),
+                        lite->col_ref.data(), lite->key_off.data()};
+        size_t off[7], total = 0;
+        for (int i = 0; i < 7; ++i) { off[i] = total; total += (bytes[i] + 63) / 64 * 64; }
+        if ((rc = cx->stage_ensure(total + 64))) return rc;
+        char* hs = static_cast<char*>(cx->h_stage);
+        for (int i = 0; i < 7; ++i)
+            if (bytes[i]) CTO_HIP(hipMemcpyAsync(hs + off[i], src[i], bytes[i], hipMemcpyDeviceToHost, s));
+        CTO_HIP(sleepy_sync(cx, s));
+        for (int i = 0; i < 7; ++i)
+            if (bytes[i]) memcpy(dst[i], hs + off[i], bytes[i]);
+    }
     dev_view->n_cols = n_cols;
     dev_view->n_entries = n_entries;
     dev_view->n_keys = n_keys;

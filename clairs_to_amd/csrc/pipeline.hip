@@ -55,6 +55,7 @@ hipError_t wait_event(hipEvent_t ev) {
 }
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+double cpu_s() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return double(ts.tv_sec) + double(ts.tv_nsec) * 1e-9; }   // this thread's CPU time
 
 struct DevBuf {                          // a device allocation that only grows
     void* p = nullptr;
@@ -464,12 +465,13 @@ struct Run {
     int pack_from_bam_device(const cto_chunk_job& j, const std::string& ctg, int64_t lo, int64_t hi, const std::vector<int64_t>& iv, Slot* s,
                              InflateCtx* c, int* done) {
         const bool timing = getenv("CTO_PIPE_TIMING") != nullptr;
-        const double T0 = now_s();
+        const double T0 = now_s(), C0 = cpu_s();
         int64_t fb = 0, fe = 0;
         int rc = cto_bam_chunk_span(j.bam_path, nullptr, ctg.c_str(), lo, hi, &fb, &fe);
         if (rc != CTO_OK) return rc;
         const size_t nbytes = fe > fb ? size_t(fe - fb) : 0;
         if (nbytes == 0) return CTO_OK;
+        const double Cs = cpu_s();
         const size_t in_al = (nbytes + CTO_BGZF_PAD + 255) / 256 * 256;
         size_t cap = nbytes / 2048 + 64;
         if ((rc = c->h_in.ensure(in_al + cap * sizeof(cto_bgzf_block))) != CTO_OK) return rc;
@@ -485,7 +487,7 @@ struct Run {
             ::close(fd);
             CTO_REQUIRE(got == nbytes, CTO_EINVAL, "short read from %s", j.bam_path);
         }
-        const double T1 = now_s();
+        const double T1 = now_s(), C1 = cpu_s();
         int64_t n = 0, out_bytes = 0;
         for (;;) {
             memset(static_cast<char*>(c->h_in.p) + nbytes, 0, in_al - nbytes);
@@ -500,7 +502,7 @@ struct Run {
         const auto* blocks = reinterpret_cast<const cto_bgzf_block*>(static_cast<char*>(c->h_in.p) + in_al);
         const size_t tbl = size_t(n) * sizeof(cto_bgzf_block), out_al = (size_t(std::max<int64_t>(out_bytes, 256)) + 255) / 256 * 256;
         if ((rc = c->d_in.ensure(in_al + tbl)) || (rc = c->d_out.ensure(out_al + size_t(n) * 4)) || (rc = c->h_out.ensure(out_al + size_t(n) * 4))) return rc;
-        const double T2 = now_s();
+        const double T2 = now_s(), C2 = cpu_s();
         CTO_HIP(hipMemcpyAsync(c->d_in.p, c->h_in.p, in_al + tbl, hipMemcpyHostToDevice, c->stream));
         if ((rc = cto_bgzf_inflate(c->d_in.p, reinterpret_cast<const cto_bgzf_block*>(static_cast<char*>(c->d_in.p) + in_al), int(n), c->d_out.p,
                                    reinterpret_cast<int*>(static_cast<char*>(c->d_out.p) + out_al), c->stream)))
@@ -561,8 +563,8 @@ struct Run {
                 CTO_HIP(hipEventRecord(c->landed, c->stream));
                 CTO_HIP(wait_event(c->landed));               // the context (and s->sites' bytes) are free for the next chunk
                 if (timing)
-                    fprintf(stderr, "device pile-up: %.1f MB in %lld blocks -> %lld columns, %lld entries: read %.1f ms, inflate + pile-up %.1f\n", nbytes / 1e6,
-                            (long long)n, (long long)dvw.n_cols, (long long)dvw.n_entries, (T1 - T0) * 1e3, (now_s() - T2) * 1e3);
+                    fprintf(stderr, "device pile-up: %.1f MB in %lld blocks -> %lld columns, %lld entries: read %.1f ms, inflate + pile-up %.1f; thread CPU: span %.1f ms, read %.1f, scan %.1f, rest %.1f\n", nbytes / 1e6,
+                            (long long)n, (long long)dvw.n_cols, (long long)dvw.n_entries, (T1 - T0) * 1e3, (now_s() - T2) * 1e3, (Cs - C0) * 1e3, (C1 - Cs) * 1e3, (C2 - C1) * 1e3, (cpu_s() - C2) * 1e3);
                 *done = 2;
                 ++device_inflated;
                 ++device_piled;
