@@ -136,11 +136,6 @@ __global__ __launch_bounds__(XLANES) void k_extract_candidates(
     }
 }
 
-// scratch for the overflow path lives in the library (grown on demand, per process / device)
-// merged-allele counters, grown on demand; one process drives one GPU, so one buffer per process
-uint32_t* g_scratch = nullptr;
-int64_t g_scratch_n = 0;
-int g_scratch_dev = -1;
 
 // candidate positions, in column order: the columns whose flag has `bit` set and whose position lies in [lo, hi]
 __device__ __forceinline__ bool is_cand(const uint8_t* __restrict__ flags, const int32_t* __restrict__ col_pos, int64_t c, int64_t n, int bit,
@@ -214,22 +209,33 @@ extern "C" int cto_extract_candidates(const cto_pack_view* dp, int min_mq, int m
                                       uint8_t* flags, int32_t* depth, void* stream) {
     CTO_REQUIRE(dp && flags && depth, CTO_EINVAL, "cto_extract_candidates: null argument");
     if (dp->n_cols == 0) return CTO_OK;
-    // merged-allele counters of the overflow path (a wave whose 8 columns hold more than 128 distinct indel alleles): one buffer per
-    // process, grown on demand - calls of this entry are serialised (cto_run_chunks brings a buffer per chunk slot instead)
-    static std::mutex m;
-    std::lock_guard<std::mutex> g(m);
-    {
+    // merged-allele counters of the overflow path (a column with more than XG distinct indel alleles), grown on demand.  One buffer
+    // per calling THREAD and device: two threads never share counters, and a thread that changes streams has its next launch wait for
+    // the last one (cto_run_chunks brings a buffer per chunk slot instead and needs neither)
+    struct Scratch {
+        uint32_t* p = nullptr;
+        int64_t n = 0;
         int dev = -1;
-        CTO_HIP(hipGetDevice(&dev));
-        if (dev != g_scratch_dev) { g_scratch = nullptr; g_scratch_n = 0; g_scratch_dev = dev; }   // another device became current: start over there
+        hipStream_t last = nullptr;
+        hipEvent_t done = nullptr;
+    };
+    thread_local Scratch sc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int dev = -1;
+    CTO_HIP(hipGetDevice(&dev));
+    if (dev != sc.dev) { sc = Scratch{}; sc.dev = dev; }      // another device became current: start over there (the old buffer is that device's)
+    if (!sc.done) CTO_HIP(hipEventCreateWithFlags(&sc.done, hipEventDisableTiming));
+    if (dp->n_keys > sc.n) {
+        if (sc.p) { CTO_HIP(hipEventSynchronize(sc.done)); (void)hipFree(sc.p); sc.p = nullptr; }
+        sc.n = dp->n_keys + dp->n_keys / 4 + 1024;
+        CTO_HIP(hipMalloc(reinterpret_cast<void**>(&sc.p), size_t(sc.n) * 4));
+    } else if (sc.last != st && sc.p) {
+        CTO_HIP(hipStreamWaitEvent(st, sc.done, 0));
     }
-    if (dp->n_keys > g_scratch_n) {
-        if (g_scratch) { CTO_HIP(hipDeviceSynchronize()); (void)hipFree(g_scratch); }
-        g_scratch_n = dp->n_keys + dp->n_keys / 4 + 1024;
-        CTO_HIP(hipMalloc(reinterpret_cast<void**>(&g_scratch), size_t(g_scratch_n) * 4));
-    }
-    return cto::extract_candidates_scratch(dp, min_mq, min_bq, snv_min_af, indel_min_af, min_coverage, alt_base_num, select_indel, g_scratch, flags,
-                                           depth, stream);
+    const int rc = cto::extract_candidates_scratch(dp, min_mq, min_bq, snv_min_af, indel_min_af, min_coverage, alt_base_num, select_indel, sc.p, flags,
+                                                   depth, stream);
+    if (rc == CTO_OK) { CTO_HIP(hipEventRecord(sc.done, st)); sc.last = st; }
+    return rc;
 }
 
 extern "C" int cto_candidate_positions(const cto_pack_view* dp, const uint8_t* flags, int bit, int32_t lo, int32_t hi, int32_t* out_pos,
