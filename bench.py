@@ -102,7 +102,7 @@ def cpu_baseline(chunks, models, lik, edges, min_bq, n_sample, budget_s=12.0):
     cfg = dict(emb_dim=(16, 64, 128), heads=(1, 3, 4), depth=(1, 2, 3), n_out=N_OUT)
     from concurrent.futures import ThreadPoolExecutor
 
-    def run_sample(chunk, n):
+    def run_sample(chunk, n, cores=cores):
         sites = chunk.site_pos[:n]
         ref, lo = chunk.ref_window()
         # tensor creation is per-site independent too: the sample is cut into one slice of sites per core, each with the
@@ -144,6 +144,18 @@ def cpu_baseline(chunks, models, lik, edges, min_bq, n_sample, budget_s=12.0):
                 first_probs = probs
             if total_t >= budget_s:
                 break
+        # the same build on ONE core (OpenMP team of one, one tensor-creation slice): the per-core figure next to the reference's 211 sites/s
+        single = None
+        try:
+            import ctypes
+            gomp = ctypes.CDLL("libgomp.so.1")
+            gomp.omp_set_num_threads(1)
+            n1 = min(256, n_sample)
+            t1, _ = run_sample(chunks[0], n1, cores=1)
+            gomp.omp_set_num_threads(int(cores))
+            single = {"value": round(n1 / t1, 2), "unit": "sites/s", "cores": 1, "sample": "%d sites" % n1}
+        except Exception:
+            pass
     finally:
         oracle.use_library(None)
     ref_py = None
@@ -158,7 +170,7 @@ def cpu_baseline(chunks, models, lik, edges, min_bq, n_sample, budget_s=12.0):
                 build="gcc -O3 -march=native -ffast-math -fopenmp (this host); max |dP| vs the checker build on %d sites = %.2g" % (n_chk, dev_max),
                 checker_build={"value": round(n_slow / t_slow, 2), "unit": "sites/s", "cores": cores,
                                "build": "gcc -O2 -ffp-contract=off -fopenmp (the parity checker)", "sample": "%d sites" % n_slow},
-                reference_python=ref_py,
+                single_core=single, reference_python=ref_py,
                 sample="%d sites of the same synthetic chunks (mpileup text of both passes -> tensors -> CvT + BiGRU -> "
                        "posterior), CPU port oracle/cto_oracle.c on every usable core: tensor creation in per-core site slices, "
                        "OpenMP over sites for the networks, %.1f s" % (total_sites, total_t)), first_probs
