@@ -8,24 +8,30 @@ using namespace cto;
 
 namespace {
 
+#ifndef CTO_GRU_NW1
+#define CTO_GRU_NW1 4      // waves per workgroup of layer 1.  8 (two per SIMD, half the columns each) measured slower on MI355X:
+                           // layer 1 + tail 0.301 -> 0.328 ms at 4096 sites, 1.159 -> 1.260 ms at 16384 (profiles/round4_gru_l1_eight_waves.txt)
+#endif
+
 template <int KIN, int KP, int H, int MS, bool FUSE>
 int launch_gru_range(hipStream_t s, const float* x, const float* W, const float* bias, float* out, const float* fc1w,
                      float* fc1_part, int64_t B, int64_t begin, int64_t end) {
     if (end <= begin) return CTO_OK;
     const size_t smem = size_t(2) * MS * 16 * ((H + 4) + (KP + 4)) * sizeof(float);   // h tiles + x tiles
+    constexpr int NW = FUSE ? 4 : CTO_GRU_NW1;
     // rotated schedule (gate arithmetic under the next step's x-part MFMAs); CTO_GRU_ROT=0 selects the plain one
     static const bool rot = [] { const char* e = getenv("CTO_GRU_ROT"); return !(e && e[0] == '0'); }();
     static bool attr_set = false;
     if (!attr_set) {
         CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_layer<KIN, KP, H, MS, 1, FUSE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
-        CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_layer_rot<KIN, KP, H, MS, FUSE>),
+        CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_layer_rot<KIN, KP, H, MS, FUSE, NW>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
         attr_set = true;
     }
     const unsigned grid = unsigned(cdiv(end - begin, MS * 16)) * 2;
     if (rot)
-        hipLaunchKernelGGL((k_gru_layer_rot<KIN, KP, H, MS, FUSE>), dim3(grid), dim3(256), smem, s, x, W, bias, out, fc1w, fc1_part,
+        hipLaunchKernelGGL((k_gru_layer_rot<KIN, KP, H, MS, FUSE, NW>), dim3(grid), dim3(64 * NW), smem, s, x, W, bias, out, fc1w, fc1_part,
                            int(B), int(begin), int(end));
     else
         hipLaunchKernelGGL((k_gru_layer<KIN, KP, H, MS, 1, FUSE>), dim3(grid), dim3(256), smem, s, x, W, bias, out, fc1w, fc1_part,

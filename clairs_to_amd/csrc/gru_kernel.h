@@ -318,15 +318,18 @@ __global__ __launch_bounds__(256 * MH) void k_gru_layer(const float* __restrict_
 #ifdef CTO_GRU_CLOCKS
 __device__ long long g_gru_clk[16];
 #endif
-template <int KIN, int KP, int H, int MS, bool FUSE_FC1>
-__global__ __launch_bounds__(256) void k_gru_layer_rot(const float* __restrict__ x, const float* __restrict__ Wcat,
+template <int KIN, int KP, int H, int MS, bool FUSE_FC1, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void k_gru_layer_rot(const float* __restrict__ x, const float* __restrict__ Wcat,
                                                        const float* __restrict__ bias, float* __restrict__ out,
                                                        const float* __restrict__ fc1w, float* __restrict__ fc1_part, int B, int site_begin,
                                                        int site_end) {
-    constexpr int NB = H / 64, T = 33, KT = KP + H + GRU_WPAD, HS = H + 4, NX = KP / 16, NH = H / 16, NC = NX + NH, NP = MS * NB;
+    // NW waves share the H columns of the tile: NW = 4 is one wave per SIMD, NW = 8 two (one wave's gate arithmetic then runs
+    // under the other's MFMAs as well as under its own)
+    static_assert(H % (16 * NW) == 0 && (!FUSE_FC1 || NW == 4), "the fused fc1 slab is laid out for four waves");
+    constexpr int NB = H / (16 * NW), T = 33, KT = KP + H + GRU_WPAD, HS = H + 4, NX = KP / 16, NH = H / 16, NC = NX + NH, NP = MS * NB;
     constexpr int FC1_K = T * 2 * H;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TILE = MS * 16, NTHR = 256;
+    constexpr int TILE = MS * 16, NTHR = 64 * NW;
     constexpr int XS = KP + 4;
     constexpr int XW = (KIN % 4 == 0) ? 4 : ((KIN % 2 == 0) ? 2 : 1);    // floats per staging unit (layer 1: 34 channels -> float2)
     constexpr int XQ = TILE * (KIN / XW);
