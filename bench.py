@@ -176,6 +176,55 @@ def cpu_baseline(chunks, models, lik, edges, min_bq, n_sample, budget_s=12.0):
                        "OpenMP over sites for the networks, %.1f s" % (total_sites, total_t)), first_probs
 
 
+def split_mfma_leg(dev, packs, sites, batch, lik, edges, min_bq, ref_probs, ref_dec, probs_cpu, steps=20, warm=40):
+    """EXPERIMENT, never in `value` (whose arithmetic stays f32): the step with the BiGRU layer-2 recurrence + fc1 on split 16-bit
+    operands (csrc/gru_split_kernel.h, CTO_GRU_SPLIT=f16|bf16 at model creation: a = hi + lo, three f16 / bf16 MFMA passes per
+    product, fp32 accumulation, state and gates fp32).  Per kind: the step's rate, the layer-2 kernel's time, and how far its
+    probabilities are from the f32 path's on a whole chunk and (when the cpu_baseline leg ran) from the CPU port's on its sample."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from clairs_to_amd._lib import lib, check
+    from clairs_to_amd.engine import Engine, synthetic_models
+    out = {"note": "side channel: split-operand MFMA for BiGRU layer 2 + fc1 only (60 % of the f32 step); layer 1, the CvT and everything "
+                   "else run the f32 product kernels; tests/test_gpu_split.py holds both kinds to the oracle within the 1e-4 tolerance"}
+    pool = len(packs)
+    for kind in ("f16", "bf16"):
+        models = synthetic_models(N_OUT, seed=0)          # fresh module objects: the switch is read when a module creates its handle
+        os.environ["CTO_GRU_SPLIT"] = kind
+        try:
+            eng = Engine(models["aff"], models["neg"], lik, edges, min_bq=min_bq, device=dev)
+        finally:
+            os.environ.pop("CTO_GRU_SPLIT", None)
+        for i in range(warm):
+            eng.run_device(packs[i % pool], sites[i % pool])
+        check(lib.cto_model_profile(eng.h_neg, 1))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(steps):
+            eng.run_device(packs[i % pool], sites[i % pool])
+        e1.record()
+        torch.cuda.synchronize()
+        check(lib.cto_model_profile(eng.h_neg, 0))
+        ms = e0.elapsed_time(e1) / steps
+        l2_ms, l2_macs = C.c_double(0.0), C.c_int64(0)
+        check(lib.cto_model_profile_read(eng.h_neg, C.byref(l2_ms), C.byref(l2_macs)))
+        got = eng.run_device(packs[0], sites[0])
+        probs = got["probs"].cpu().numpy()
+        dec = got["decision"].cpu().numpy()
+        tf = 2.0 * l2_macs.value * batch / (l2_ms.value * 1e-3) / 1e12
+        o = {"sites_per_s": round(batch / (ms * 1e-3), 1), "ms_per_step": round(ms, 4), "steps": steps,
+             "gru_l2_ms": round(l2_ms.value, 4), "gru_l2_algorithmic_tflops": round(tf, 1),
+             "max_abs_dP_vs_f32_path": float(np.abs(probs - ref_probs).max()), "sites_compared": int(probs.shape[0]),
+             "decisions_differing_from_f32_path": int(((dec[:, :2] & 3) != (ref_dec[:, :2] & 3)).any(axis=1).sum())}
+        if probs_cpu is not None:
+            o["max_abs_dP_vs_cpu_sample"] = float(np.abs(probs[: probs_cpu.shape[0]] - probs_cpu).max())
+        out[kind] = o
+        del eng, models
+    return out
+
+
 def config_legs(dev, batch, steps=20, warm=40, pool=4):
     """After the timed region, never in `value`: the other single-GPU workloads BASELINE.json names, each as `steps` passes of the
     whole hot path over `pool` resident chunks of its generator preset with its model pair - sites/s by HIP events on
@@ -323,6 +372,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-sustained", action="store_true", help="skip the 245-step run and the per-stage kernel times after the timed region")
+    ap.add_argument("--no-split", action="store_true", help="skip the split-operand experiment leg (`split_mfma`; never part of `value`)")
     ap.add_argument("--no-configs", action="store_true", help="skip the legs on the other BASELINE configs' single-GPU workloads (Illumina, HiFi, "
                     "K = 6, the constructor-default CvT, clustered candidates)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file legs (mpileup text -> VCF, BAM -> VCF)")
@@ -611,11 +661,16 @@ def main():
             stage_fracs["tensor_creation"] = {"ms": round(feat_ms, 4), "gb_per_s": round(feat_bytes / (feat_ms * 1e-3) / 1e9, 1),
                                               "frac_of_hbm_peak": round(feat_bytes / (feat_ms * 1e-3) / 1e9 / 8000.0, 4)}
             res["stage_fracs"] = stage_fracs
+        probs_cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cb, probs_cpu = cpu_baseline(chunks, models, lik, edges, min_bq, min(args.cpu_sample, args.batch))
             res["cpu_baseline"] = cb
             got = eng.run_device(packs[0], sites[0])["probs"][: probs_cpu.shape[0]].cpu().numpy()
             res["parity_max_abs_dP_vs_cpu_sample"] = float(np.abs(got - probs_cpu).max())
+        if world == 1 and not args.no_split:
+            ref = eng.run_device(packs[0], sites[0])
+            res["split_mfma"] = split_mfma_leg(dev, packs[:4], sites[:4], args.batch, lik, edges, min_bq, ref["probs"].cpu().numpy(),
+                                               ref["decision"].cpu().numpy(), probs_cpu)
         if world == 1 and not args.no_configs:
             res["configs"] = config_legs(dev, args.batch)
         if world == 1 and not args.no_e2e:

@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include "common.h"
 #include "gru_kernel.h"
+#include "gru_split_kernel.h"
 
 using namespace cto;
 
@@ -72,6 +73,47 @@ int launch_gru_layer1(hipStream_t s, const float* x, const float* W, const float
 int launch_gru_layer2_fc1(hipStream_t s, const float* x, const float* W, const float* bias, const float* fc1w, float* fc1_part,
                           int64_t B) {
     return launch_gru<256, 256, 192, true>(s, x, W, bias, nullptr, fc1w, fc1_part, B);
+}
+
+// layer 2 + fc1 on split 16-bit operands (experiment behind CTO_GRU_SPLIT=f16|bf16; gru_split_kernel.h): same tiling rule as above
+template <int MS, bool F16>
+static int launch_split_range(hipStream_t s, const float* x, const void* Wp, const float* bias, const void* Fp, float* fc1_part,
+                              int64_t B, int64_t begin, int64_t end) {
+    if (end <= begin) return CTO_OK;
+    constexpr int KIN = 256, H = 192;
+    const size_t smem = size_t(4) * MS * 16 * ((H + 8) + (KIN + 8)) * sizeof(unsigned short) + size_t(4) * H * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_fc1_split<KIN, H, MS, F16>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
+        attr_set = true;
+    }
+    const unsigned grid = unsigned(cdiv(end - begin, MS * 16)) * 2;
+    hipLaunchKernelGGL((k_gru_fc1_split<KIN, H, MS, F16>), dim3(grid), dim3(256), smem, s, x, static_cast<const uint4*>(Wp), bias,
+                       static_cast<const uint4*>(Fp), fc1_part, int(B), int(begin), int(end));
+    CTO_HIP(hipGetLastError());
+    return CTO_OK;
+}
+
+template <bool F16>
+static int launch_split(hipStream_t s, const float* x, const void* Wp, const float* bias, const void* Fp, float* fc1_part, int64_t B) {
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    const int64_t round32 = int64_t(16) * cus;
+    const int64_t full = (B / round32) * round32;
+    const int64_t rest = B - full;
+    int rc = launch_split_range<2, F16>(s, x, Wp, bias, Fp, fc1_part, B, 0, full);
+    if (rc != CTO_OK || rest == 0) return rc;
+    if (rest * 4 > round32 * 3) return launch_split_range<2, F16>(s, x, Wp, bias, Fp, fc1_part, B, full, B);
+    return launch_split_range<1, F16>(s, x, Wp, bias, Fp, fc1_part, B, full, B);
+}
+
+int launch_gru_layer2_fc1_split(hipStream_t s, const float* x, const void* Wp, const float* bias, const void* Fp, float* fc1_part,
+                                int64_t B, bool f16) {
+    return f16 ? launch_split<true>(s, x, Wp, bias, Fp, fc1_part, B) : launch_split<false>(s, x, Wp, bias, Fp, fc1_part, B);
 }
 
 #ifdef CTO_GRU_CLOCKS

@@ -4,6 +4,7 @@
 //   BiGRU_NACGT / .._Indel     clairs/model.py:387-560   (NEG network; the `lstm*` attributes are nn.GRU)
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <string>
@@ -17,6 +18,8 @@ using namespace cto;
 // The recurrent kernels live in their own translation unit (gru.hip): co-compiling them with the CvT kernels changed
 // their register allocation and cost up to 4 % from one unrelated edit to the next.
 int launch_gru_layer1(hipStream_t s, const float* x, const float* W, const float* bias, float* out, int64_t B);
+int launch_gru_layer2_fc1_split(hipStream_t s, const float* x, const void* Wp, const float* bias, const void* Fp, float* fc1_part,
+                                int64_t B, bool f16);
 int launch_gru_layer2_fc1(hipStream_t s, const float* x, const float* W, const float* bias, const float* fc1w, float* fc1_part,
                           int64_t B);
 
@@ -83,6 +86,8 @@ struct cto_model {
     StageDev st[3];
     // BiGRU
     float *gw1 = nullptr, *gb1 = nullptr, *gw2 = nullptr, *gb2 = nullptr;
+    float *gw2_split = nullptr, *f1_split = nullptr;     // layer 2 / fc1 as (hi, lo) 16-bit fragments: CTO_GRU_SPLIT=f16|bf16 (experiment)
+    bool split_f16 = false;
     HeadDev head;
     int64_t macs = 0;
     // workspace
@@ -450,7 +455,9 @@ int bigru_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStr
     }
     if (m->prof && (rc = prof_begin(m, s, &e0, &e1))) return rc;
     // layer 2 with the head's fc1 folded in: writes one partial [B][128] slab per direction into b_slab
-    if ((rc = launch_gru_layer2_fc1(s, m->b_h, m->gw2, m->gb2, m->head.w1, m->b_slab, B))) return rc;
+    if (m->gw2_split) rc = launch_gru_layer2_fc1_split(s, m->b_h, m->gw2_split, m->gb2, m->f1_split, m->b_slab, B, m->split_f16);
+    else rc = launch_gru_layer2_fc1(s, m->b_h, m->gw2, m->gb2, m->head.w1, m->b_slab, B);
+    if (rc) return rc;
     if (m->prof) {
         CTO_HIP(hipEventRecord(e1, s));
         m->prof_ev.emplace_back(e0, e1);
@@ -484,6 +491,87 @@ int pack_gru(const cto_weights* w, const std::string& base, int kin, int kp, int
     }
     if ((rc = a.upload(W, Wout)) != CTO_OK) return rc;
     return a.upload(bv, bout);
+}
+
+// ---- split 16-bit operands of the layer-2 recurrence (gru_split_kernel.h; experiment behind CTO_GRU_SPLIT=f16|bf16) ----
+inline uint16_t bf16_rne(float v) {
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    return uint16_t((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+inline float bf16_value(uint16_t h) {
+    const uint32_t u = uint32_t(h) << 16;
+    float v;
+    memcpy(&v, &u, 4);
+    return v;
+}
+inline uint16_t f16_rne(float v) {
+    const _Float16 h = _Float16(v);
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+inline float f16_value(uint16_t u) {
+    _Float16 h;
+    memcpy(&h, &u, 2);
+    return float(h);
+}
+// eight consecutive k of one row -> the 16 bytes a lane holds, hi then (64 lanes later) lo
+inline void put_split8(uint16_t* hi, uint16_t* lo, const float* src, bool f16) {
+    for (int e = 0; e < 8; ++e) {
+        const float v = src[e];
+        if (f16) { hi[e] = f16_rne(v); lo[e] = f16_rne(v - f16_value(hi[e])); }
+        else { hi[e] = bf16_rne(v); lo[e] = bf16_rne(v - bf16_value(hi[e])); }
+    }
+}
+int upload_halves(const std::vector<uint16_t>& v, Arena& a, float** out) {
+    std::vector<float> f(v.size() / 2);
+    memcpy(f.data(), v.data(), v.size() * 2);
+    return a.upload(f, out);
+}
+// Wp[dir][wave][chunk][nb][gate][hi,lo][lane][8], Fp[dir][t][wave][kh][nt][hi,lo][lane][8] (layouts in gru_split_kernel.h)
+int pack_gru_split(const cto_weights* w, const std::string& base, int kin, int H, const std::vector<float>& fc1, bool f16, Arena& a,
+                   float** Wout, float** Fout) {
+    const int NB = H / 64, NX = kin / 32, NH = H / 32, NC = NX + NH, T = 33;
+    int rc = CTO_OK;
+    std::vector<uint16_t> W(size_t(2) * 4 * NC * NB * 6 * 64 * 8), F(size_t(2) * T * 4 * NH * 4 * 64 * 8);
+    for (int d = 0; d < 2; ++d) {
+        const std::string sfx = d == 0 ? "" : "_reverse";
+        GETW(wih, base + ".weight_ih_l0" + sfx, int64_t(3) * H * kin);
+        GETW(whh, base + ".weight_hh_l0" + sfx, int64_t(3) * H * H);
+        if (f16) {     // hi must be finite in f16 (and is then exact to 11 bits); trained GRU weights are O(1)
+            float mx = 0.f;
+            for (float v : *wih) mx = std::max(mx, std::fabs(v));
+            for (float v : *whh) mx = std::max(mx, std::fabs(v));
+            if (d == 0) for (float v : fc1) mx = std::max(mx, std::fabs(v));
+            CTO_REQUIRE(mx < 60000.f, CTO_EUNSUPPORTED, "CTO_GRU_SPLIT=f16: a weight of %g does not fit the f16 range", double(mx));
+        }
+        for (int wv = 0; wv < 4; ++wv)
+            for (int c = 0; c < NC; ++c)
+                for (int nb = 0; nb < NB; ++nb)
+                    for (int q = 0; q < 3; ++q)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int j = lane & 15, kg = lane >> 4;
+                            const int n = q * H + (wv * NB + nb) * 16 + j;
+                            const float* src = c < NX ? wih->data() + size_t(n) * kin + c * 32 + kg * 8
+                                                      : whh->data() + size_t(n) * H + (c - NX) * 32 + kg * 8;
+                            const size_t u = ((((size_t(d) * 4 + wv) * NC + c) * NB + nb) * 6 + q * 2) * 64;
+                            put_split8(&W[(u + lane) * 8], &W[(u + 64 + lane) * 8], src, f16);
+                        }
+        for (int t = 0; t < T; ++t)
+            for (int wv = 0; wv < 4; ++wv)
+                for (int kh = 0; kh < NH; ++kh)
+                    for (int nt = 0; nt < 2; ++nt)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int j = lane & 15, kg = lane >> 4;
+                            const int n = wv * 32 + nt * 16 + j;
+                            const float* src = fc1.data() + size_t(n) * (T * 2 * H) + size_t(t) * 2 * H + d * H + kh * 32 + kg * 8;
+                            const size_t u = ((((size_t(d) * T + t) * 4 + wv) * NH + kh) * 4 + nt * 2) * 64;
+                            put_split8(&F[(u + lane) * 8], &F[(u + 64 + lane) * 8], src, f16);
+                        }
+    }
+    rc = upload_halves(W, a, Wout);
+    return rc != CTO_OK ? rc : upload_halves(F, a, Fout);
 }
 
 }  // namespace
@@ -601,6 +689,14 @@ extern "C" int cto_bigru_create(const cto_weights* w, int n_out, cto_model** out
         GETW(f1, "fc1.weight", int64_t(128) * k1);
         static const char* const names[6] = {"na", "nc", "ng", "nt", "ni", "nd"};
         if ((rc = build_head(w, names, n_out, k1, *f1, m->arena, m->head))) return fail(rc);
+        // experiment (side channel, never the default): layer 2 + fc1 on split 16-bit operands, three f16 / bf16 MFMA passes per product
+        const char* e = getenv("CTO_GRU_SPLIT");
+        if (e && e[0]) {
+            const std::string kind(e);
+            CTO_REQUIRE(kind == "f16" || kind == "bf16", CTO_EINVAL, "CTO_GRU_SPLIT must be f16 or bf16, not '%s'", e);
+            m->split_f16 = kind == "f16";
+            if ((rc = pack_gru_split(w, "lstm_2", 256, 192, *f1, m->split_f16, m->arena, &m->gw2_split, &m->f1_split))) return fail(rc);
+        }
     }
     m->macs = int64_t(33) * 2 * 3 * 128 * (34 + 128) + int64_t(33) * 2 * 3 * 192 * (256 + 192) + int64_t(k1) * 128 +
               int64_t(n_out) * (128 * 128 + 256);
