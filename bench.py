@@ -177,16 +177,16 @@ def cpu_baseline(chunks, models, lik, edges, min_bq, n_sample, budget_s=12.0):
 
 
 def split_mfma_leg(dev, packs, sites, batch, lik, edges, min_bq, ref_probs, ref_dec, probs_cpu, steps=20, warm=40):
-    """EXPERIMENT, never in `value` (whose arithmetic stays f32): the step with the BiGRU layer-2 recurrence + fc1 on split 16-bit
+    """EXPERIMENT, never in `value` (whose arithmetic stays f32): the step with both BiGRU recurrences + fc1 on split 16-bit
     operands (csrc/gru_split_kernel.h, CTO_GRU_SPLIT=f16|bf16 at model creation: a = hi + lo, three f16 / bf16 MFMA passes per
-    product, fp32 accumulation, state and gates fp32).  Per kind: the step's rate, the layer-2 kernel's time, and how far its
-    probabilities are from the f32 path's on a whole chunk and (when the cpu_baseline leg ran) from the CPU port's on its sample."""
+    product, fp32 accumulation, state and gates fp32).  Per kind: the step's rate, the two recurrent kernels' times, and how far
+    its probabilities are from the f32 path's on a whole chunk and (when the cpu_baseline leg ran) from the CPU port's on its sample."""
     import ctypes as C
     import numpy as np
     import torch
     from clairs_to_amd._lib import lib, check
     from clairs_to_amd.engine import Engine, synthetic_models
-    out = {"note": "side channel: split-operand MFMA for BiGRU layer 2 + fc1 only (60 % of the f32 step); layer 1, the CvT and everything "
+    out = {"note": "side channel: split-operand MFMA for the two BiGRU recurrences + fc1 (75 % of the f32 step); the CvT and everything "
                    "else run the f32 product kernels; tests/test_gpu_split.py holds both kinds to the oracle within the 1e-4 tolerance"}
     pool = len(packs)
     for kind in ("f16", "bf16"):
@@ -198,7 +198,7 @@ def split_mfma_leg(dev, packs, sites, batch, lik, edges, min_bq, ref_probs, ref_
             os.environ.pop("CTO_GRU_SPLIT", None)
         for i in range(warm):
             eng.run_device(packs[i % pool], sites[i % pool])
-        check(lib.cto_model_profile(eng.h_neg, 1))
+        check(lib.cto_model_profile(eng.h_neg, 2))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
@@ -208,14 +208,15 @@ def split_mfma_leg(dev, packs, sites, batch, lik, edges, min_bq, ref_probs, ref_
         torch.cuda.synchronize()
         check(lib.cto_model_profile(eng.h_neg, 0))
         ms = e0.elapsed_time(e1) / steps
-        l2_ms, l2_macs = C.c_double(0.0), C.c_int64(0)
+        l2_ms, l2_macs, l1_ms, l1_macs = C.c_double(0.0), C.c_int64(0), C.c_double(0.0), C.c_int64(0)
         check(lib.cto_model_profile_read(eng.h_neg, C.byref(l2_ms), C.byref(l2_macs)))
+        check(lib.cto_model_profile_read_stage(eng.h_neg, 1, C.byref(l1_ms), C.byref(l1_macs)))
         got = eng.run_device(packs[0], sites[0])
         probs = got["probs"].cpu().numpy()
         dec = got["decision"].cpu().numpy()
         tf = 2.0 * l2_macs.value * batch / (l2_ms.value * 1e-3) / 1e12
         o = {"sites_per_s": round(batch / (ms * 1e-3), 1), "ms_per_step": round(ms, 4), "steps": steps,
-             "gru_l2_ms": round(l2_ms.value, 4), "gru_l2_algorithmic_tflops": round(tf, 1),
+             "gru_l2_ms": round(l2_ms.value, 4), "gru_l2_algorithmic_tflops": round(tf, 1), "gru_l1_ms": round(l1_ms.value, 4),
              "max_abs_dP_vs_f32_path": float(np.abs(probs - ref_probs).max()), "sites_compared": int(probs.shape[0]),
              "decisions_differing_from_f32_path": int(((dec[:, :2] & 3) != (ref_dec[:, :2] & 3)).any(axis=1).sum())}
         if probs_cpu is not None:

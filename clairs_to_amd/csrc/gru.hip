@@ -75,28 +75,28 @@ int launch_gru_layer2_fc1(hipStream_t s, const float* x, const float* W, const f
     return launch_gru<256, 256, 192, true>(s, x, W, bias, nullptr, fc1w, fc1_part, B);
 }
 
-// layer 2 + fc1 on split 16-bit operands (experiment behind CTO_GRU_SPLIT=f16|bf16; gru_split_kernel.h): same tiling rule as above
-template <int MS, bool F16>
+// the recurrent layers on split 16-bit operands (experiment behind CTO_GRU_SPLIT=f16|bf16; gru_split_kernel.h): same tiling rule as above
+template <int KIN, int KP, int H, int MS, bool F16, bool FUSE>
 static int launch_split_range(hipStream_t s, const float* x, const void* Wp, const float* bias, const void* Fp, float* fc1_part,
-                              int64_t B, int64_t begin, int64_t end) {
+                              float* out, int64_t B, int64_t begin, int64_t end) {
     if (end <= begin) return CTO_OK;
-    constexpr int KIN = 256, H = 192;
-    const size_t smem = size_t(4) * MS * 16 * ((H + 8) + (KIN + 8)) * sizeof(unsigned short) + size_t(4) * H * sizeof(float);
+    const size_t smem = size_t(4) * MS * 16 * ((H + 8) + (KP + 8)) * sizeof(unsigned short) + size_t(4) * H * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_fc1_split<KIN, H, MS, F16>),
+        CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_split<KIN, KP, H, MS, F16, FUSE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
         attr_set = true;
     }
     const unsigned grid = unsigned(cdiv(end - begin, MS * 16)) * 2;
-    hipLaunchKernelGGL((k_gru_fc1_split<KIN, H, MS, F16>), dim3(grid), dim3(256), smem, s, x, static_cast<const uint4*>(Wp), bias,
-                       static_cast<const uint4*>(Fp), fc1_part, int(B), int(begin), int(end));
+    hipLaunchKernelGGL((k_gru_split<KIN, KP, H, MS, F16, FUSE>), dim3(grid), dim3(256), smem, s, x, static_cast<const uint4*>(Wp), bias,
+                       static_cast<const uint4*>(Fp), fc1_part, out, int(B), int(begin), int(end));
     CTO_HIP(hipGetLastError());
     return CTO_OK;
 }
 
-template <bool F16>
-static int launch_split(hipStream_t s, const float* x, const void* Wp, const float* bias, const void* Fp, float* fc1_part, int64_t B) {
+template <int KIN, int KP, int H, bool F16, bool FUSE>
+static int launch_split(hipStream_t s, const float* x, const void* Wp, const float* bias, const void* Fp, float* fc1_part, float* out,
+                        int64_t B) {
     static const int cus = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
@@ -105,15 +105,21 @@ static int launch_split(hipStream_t s, const float* x, const void* Wp, const flo
     const int64_t round32 = int64_t(16) * cus;
     const int64_t full = (B / round32) * round32;
     const int64_t rest = B - full;
-    int rc = launch_split_range<2, F16>(s, x, Wp, bias, Fp, fc1_part, B, 0, full);
+    int rc = launch_split_range<KIN, KP, H, 2, F16, FUSE>(s, x, Wp, bias, Fp, fc1_part, out, B, 0, full);
     if (rc != CTO_OK || rest == 0) return rc;
-    if (rest * 4 > round32 * 3) return launch_split_range<2, F16>(s, x, Wp, bias, Fp, fc1_part, B, full, B);
-    return launch_split_range<1, F16>(s, x, Wp, bias, Fp, fc1_part, B, full, B);
+    if (rest * 4 > round32 * 3) return launch_split_range<KIN, KP, H, 2, F16, FUSE>(s, x, Wp, bias, Fp, fc1_part, out, B, full, B);
+    return launch_split_range<KIN, KP, H, 1, F16, FUSE>(s, x, Wp, bias, Fp, fc1_part, out, B, full, B);
 }
 
 int launch_gru_layer2_fc1_split(hipStream_t s, const float* x, const void* Wp, const float* bias, const void* Fp, float* fc1_part,
                                 int64_t B, bool f16) {
-    return f16 ? launch_split<true>(s, x, Wp, bias, Fp, fc1_part, B) : launch_split<false>(s, x, Wp, bias, Fp, fc1_part, B);
+    return f16 ? launch_split<256, 256, 192, true, true>(s, x, Wp, bias, Fp, fc1_part, nullptr, B)
+               : launch_split<256, 256, 192, false, true>(s, x, Wp, bias, Fp, fc1_part, nullptr, B);
+}
+
+int launch_gru_layer1_split(hipStream_t s, const float* x, const void* Wp, const float* bias, float* out, int64_t B, bool f16) {
+    return f16 ? launch_split<34, 64, 128, true, false>(s, x, Wp, bias, nullptr, nullptr, out, B)
+               : launch_split<34, 64, 128, false, false>(s, x, Wp, bias, nullptr, nullptr, out, B);
 }
 
 #ifdef CTO_GRU_CLOCKS

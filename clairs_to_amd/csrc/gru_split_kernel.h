@@ -58,14 +58,18 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
 // Fragment-ordered operand arrays (16-byte units, index = ... * 64 + lane; lane = (kg << 4) | j holds k = 32 c + 8 kg .. + 7):
 //   Wp[dir][wave][chunk c < NX + NH][nb][gate r,z,n][hi,lo][lane] : row  gate * H + (wave * NB + nb) * 16 + j  of [W_ih | W_hh]
 //   Fp[dir][t][wave][kh < NH][nt < 2][hi,lo][lane]                : row  wave * 32 + nt * 16 + j  of fc1.weight, k = t 2H + dir H + 32 kh ..
-template <int KIN, int H, int MS, bool F16>
-__global__ __launch_bounds__(256) void k_gru_fc1_split(const float* __restrict__ x, const uint4* __restrict__ Wp,
-                                                       const float* __restrict__ bias, const uint4* __restrict__ Fp,
-                                                       float* __restrict__ fc1_part, int B, int site_begin, int site_end) {
-    constexpr int NB = H / 64, T = 33, NX = KIN / 32, NH = H / 32, NC = NX + NH, NP = MS * NB;
+// FUSE_FC1 (layer 2): the head's fc1 accumulated on the fly, one partial [B][128] slab per direction (as in k_gru_layer_rot);
+// otherwise (layer 1) h_t goes to `out` [B][33][2H] as fp32, one 16-byte store per lane, tile and block, straight from the gates.
+// KP = KIN rounded up to whole 32-wide chunks; the padding columns of the x planes stay zero.
+template <int KIN, int KP, int H, int MS, bool F16, bool FUSE_FC1>
+__global__ __launch_bounds__(256) void k_gru_split(const float* __restrict__ x, const uint4* __restrict__ Wp,
+                                                   const float* __restrict__ bias, const uint4* __restrict__ Fp,
+                                                   float* __restrict__ fc1_part, float* __restrict__ out, int B, int site_begin,
+                                                   int site_end) {
+    constexpr int NB = H / 64, T = 33, NX = KP / 32, NH = H / 32, NC = NX + NH, NP = MS * NB;
     constexpr int TILE = MS * 16, NTHR = 256;
-    constexpr int HSB = H + 8, XSB = KIN + 8;             // 16-bit elements per tile row
-    static_assert(KIN % 32 == 0 && H % 64 == 0 && (NC % 2) == 0, "chunking of the split kernel");
+    constexpr int HSB = H + 8, XSB = KP + 8;             // 16-bit elements per tile row
+    static_assert(KP % 32 == 0 && KP >= KIN && H % 64 == 0 && (NC % 2) == 0, "chunking of the split kernel");
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_s[];
     unsigned short* hbuf = smem_s;                             // [2 buffers][hi, lo][TILE][HSB]
     unsigned short* xbuf = smem_s + 4 * TILE * HSB;            // [2 buffers][hi, lo][TILE][XSB]
@@ -91,7 +95,8 @@ __global__ __launch_bounds__(256) void k_gru_fc1_split(const float* __restrict__
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint4*>(Wp) + (int64_t(dir) * 4 + wave_u) * (W_WAVE_BYTES / 16), 0, int(W_WAVE_BYTES), 0x00020000);
     const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint4*>(Fp) + (int64_t(dir) * T * 4 + wave_u) * (NH * 4 * 64), 0, int(T * F_T_BYTES), 0x00020000);
+        const_cast<uint4*>(FUSE_FC1 ? Fp : Wp) + (FUSE_FC1 ? (int64_t(dir) * T * 4 + wave_u) * (NH * 4 * 64) : 0), 0,
+        FUSE_FC1 ? int(T * F_T_BYTES) : 0, 0x00020000);
     auto buf16 = [&](const __amdgpu_buffer_rsrc_t& r, unsigned voffset, unsigned soffset) {
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, int(voffset), int(soffset), 0);
@@ -109,18 +114,21 @@ __global__ __launch_bounds__(256) void k_gru_fc1_split(const float* __restrict__
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms) { accf[ms][0] = f32x4{0.f, 0.f, 0.f, 0.f}; accf[ms][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    // ---- x staging: fp32 rows of the layer-1 output -> (hi, lo) planes ----
-    constexpr int XQ = TILE * (KIN / 4), XPER = XQ / NTHR;
-    static_assert(XQ % NTHR == 0, "x staging units per thread");
+    // ---- x staging: fp32 rows of the layer input -> (hi, lo) planes ----
+    constexpr int XW = (KIN % 4 == 0) ? 4 : 2;             // floats per staging unit (layer 1: 34 channels -> float2)
+    static_assert(KIN % XW == 0, "input rows are staged as float2 / float4");
+    constexpr int XQ = TILE * (KIN / XW), XPER = (XQ + NTHR - 1) / NTHR;
     float4 xstage[XPER];
     auto x_fetch = [&](int t) {
 #pragma unroll
         for (int q = 0; q < XPER; ++q) {
-            const int u = threadIdx.x + q * NTHR;
-            const int row = u / (KIN / 4), c = (u - row * (KIN / 4)) * 4;
+            const int u = min(int(threadIdx.x) + q * NTHR, XQ - 1);
+            const int row = u / (KIN / XW), c = (u - row * (KIN / XW)) * XW;
             // rows past the batch read the batch's last row (and are never looked at): no branch in the time loop
             const int site = min(site0 + row, site_end - 1);
-            xstage[q] = *reinterpret_cast<const float4*>(x + (int64_t(site) * T + t) * KIN + c);
+            const float* src = x + (int64_t(site) * T + t) * KIN + c;
+            if constexpr (XW == 4) xstage[q] = *reinterpret_cast<const float4*>(src);
+            else { const float2 v = *reinterpret_cast<const float2*>(src); xstage[q] = make_float4(v.x, v.y, 0.f, 0.f); }
         }
     };
     auto x_commit = [&](int buf) {
@@ -128,12 +136,19 @@ __global__ __launch_bounds__(256) void k_gru_fc1_split(const float* __restrict__
 #pragma unroll
         for (int q = 0; q < XPER; ++q) {
             const int u = threadIdx.x + q * NTHR;
-            const int row = u / (KIN / 4), c = (u - row * (KIN / 4)) * 4;
-            uint2 hi, lo;
-            split_pair<F16>(xstage[q].x, xstage[q].y, hi.x, lo.x);
-            split_pair<F16>(xstage[q].z, xstage[q].w, hi.y, lo.y);
-            *reinterpret_cast<uint2*>(xb + row * XSB + c) = hi;
-            *reinterpret_cast<uint2*>(xb + (TILE + row) * XSB + c) = lo;
+            const int row = u / (KIN / XW), c = (u - row * (KIN / XW)) * XW;
+            if (XQ % NTHR == 0 || u < XQ) {
+                uint2 hi, lo;
+                split_pair<F16>(xstage[q].x, xstage[q].y, hi.x, lo.x);
+                if constexpr (XW == 4) {
+                    split_pair<F16>(xstage[q].z, xstage[q].w, hi.y, lo.y);
+                    *reinterpret_cast<uint2*>(xb + row * XSB + c) = hi;
+                    *reinterpret_cast<uint2*>(xb + (TILE + row) * XSB + c) = lo;
+                } else {
+                    *reinterpret_cast<unsigned*>(xb + row * XSB + c) = hi.x;
+                    *reinterpret_cast<unsigned*>(xb + (TILE + row) * XSB + c) = lo.x;
+                }
+            }
         }
     };
 
@@ -159,6 +174,7 @@ __global__ __launch_bounds__(256) void k_gru_fc1_split(const float* __restrict__
                 }
     };
     auto load_F = [&](int buf, int kh, int tprev) {
+        if constexpr (!FUSE_FC1) return;
         const unsigned st = unsigned(__builtin_amdgcn_readfirstlane(tprev)) * F_T_BYTES + unsigned(kh) * 4096u;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -208,6 +224,7 @@ __global__ __launch_bounds__(256) void k_gru_fc1_split(const float* __restrict__
         }
     };
     auto fc1_chunk = [&](int cur) {
+        if constexpr (!FUSE_FC1) return;
 #pragma unroll
         for (int pass = 0; pass < 3; ++pass) {
             const int pw = pass == 2 ? 1 : 0, pa = pass == 1 ? 1 : 0;
@@ -218,7 +235,7 @@ __global__ __launch_bounds__(256) void k_gru_fc1_split(const float* __restrict__
         }
     };
     // gates + state update of one (ms, nb) pair (lane-local), publish that slice of h_t as (hi, lo)
-    auto gate_pair = [&](int ms, int nb, unsigned short* hn) {
+    auto gate_pair = [&](int ms, int nb, unsigned short* hn, int t) {
         float hv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -238,6 +255,12 @@ __global__ __launch_bounds__(256) void k_gru_fc1_split(const float* __restrict__
         const int at = (ms * 16 + j) * HSB + (wave * NB + nb) * 16 + kg * 4;
         *reinterpret_cast<uint2*>(hn + at) = hi;
         *reinterpret_cast<uint2*>(hn + TILE * HSB + at) = lo;
+        if constexpr (!FUSE_FC1) {
+            const int site = site0 + ms * 16 + j;
+            if (site < site_end)
+                *reinterpret_cast<f32x4*>(out + (int64_t(site) * T + t) * (2 * H) + dir * H + (wave * NB + nb) * 16 + kg * 4) =
+                    f32x4{hv[0], hv[1], hv[2], hv[3]};
+        }
     };
 
     // ---- prologue ----
@@ -303,7 +326,7 @@ __global__ __launch_bounds__(256) void k_gru_fc1_split(const float* __restrict__
                 // gate arithmetic of step t, spread over the x chunks of step t+1
 #pragma unroll
                 for (int pq = 0; pq < NP; ++pq)
-                    if ((pq * NX) / NP == sq - NH) gate_pair(pq / NB, pq % NB, hn);
+                    if ((pq * NX) / NP == sq - NH) gate_pair(pq / NB, pq % NB, hn, t);
             }
 #ifndef CTO_GRU_SPLIT_IL
 #define CTO_GRU_SPLIT_IL 3
@@ -311,7 +334,7 @@ __global__ __launch_bounds__(256) void k_gru_fc1_split(const float* __restrict__
 #ifndef CTO_GRU_SPLIT_NO_INTERLEAVE
             // spread the next chunk's operand requests between the MFMAs of this one
 #pragma unroll
-            for (int g = 0; g < NB * 6 + 4; ++g) {
+            for (int g = 0; g < NB * 6 + (FUSE_FC1 ? 4 : 0); ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, CTO_GRU_SPLIT_IL, 0);      // MFMAs
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     // 1 VMEM read
             }
@@ -327,7 +350,7 @@ __global__ __launch_bounds__(256) void k_gru_fc1_split(const float* __restrict__
         CTO_PH(2);
         if constexpr (LAST) {
 #pragma unroll
-            for (int pq = 0; pq < NP; ++pq) gate_pair(pq / NB, pq % NB, hn);
+            for (int pq = 0; pq < NP; ++pq) gate_pair(pq / NB, pq % NB, hn, t);
         } else {
             if (step + 2 < T) x_commit(step & 1);          // x_{t+2} replaces x_t
 #pragma unroll
@@ -341,30 +364,33 @@ __global__ __launch_bounds__(256) void k_gru_fc1_split(const float* __restrict__
     step_body(T - 1, std::true_type{});
 #ifdef CTO_GRU_CLOCKS
     if (blockIdx.x == 7 && threadIdx.x == 0) {
-        g_gru_clk[4] = clock64() - c0; g_gru_clk[5] = wall_clock64() - w0;
-        g_gru_clk[12] = ph[0]; g_gru_clk[13] = ph[1]; g_gru_clk[14] = ph[2]; g_gru_clk[15] = ph[3];
+        const int o = FUSE_FC1 ? 4 : 0;
+        g_gru_clk[o] = clock64() - c0; g_gru_clk[o + 1] = wall_clock64() - w0;
+        g_gru_clk[8 + o] = ph[0]; g_gru_clk[9 + o] = ph[1]; g_gru_clk[10 + o] = ph[2]; g_gru_clk[11 + o] = ph[3];
     }
 #endif
 
-    // fc1 contribution of the last state, then one partial slab per direction
-    __syncthreads();
-    const unsigned short* hl = hbuf + (T & 1) * (2 * TILE * HSB);
-    const int tl = t_of(T - 1);
+    if constexpr (FUSE_FC1) {
+        // fc1 contribution of the last state, then one partial slab per direction
+        __syncthreads();
+        const unsigned short* hl = hbuf + (T & 1) * (2 * TILE * HSB);
+        const int tl = t_of(T - 1);
 #pragma unroll
-    for (int kh = 0; kh < NH; ++kh) {
-        load_Ah(0, kh, hl);
-        load_F(0, kh, tl);
-        fc1_chunk(0);
-    }
-    float* part = fc1_part + int64_t(dir) * B * 128;
-#pragma unroll
-    for (int ms = 0; ms < MS; ++ms)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int site = site0 + ms * 16 + j;
-            if (site < site_end)
-                *reinterpret_cast<f32x4*>(part + int64_t(site) * 128 + wave * 32 + nt * 16 + kg * 4) = accf[ms][nt];
+        for (int kh = 0; kh < NH; ++kh) {
+            load_Ah(0, kh, hl);
+            load_F(0, kh, tl);
+            fc1_chunk(0);
         }
+        float* part = fc1_part + int64_t(dir) * B * 128;
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int site = site0 + ms * 16 + j;
+                if (site < site_end)
+                    *reinterpret_cast<f32x4*>(part + int64_t(site) * 128 + wave * 32 + nt * 16 + kg * 4) = accf[ms][nt];
+            }
+    }
 }
 
 }  // namespace cto

@@ -20,6 +20,7 @@ using namespace cto;
 int launch_gru_layer1(hipStream_t s, const float* x, const float* W, const float* bias, float* out, int64_t B);
 int launch_gru_layer2_fc1_split(hipStream_t s, const float* x, const void* Wp, const float* bias, const void* Fp, float* fc1_part,
                                 int64_t B, bool f16);
+int launch_gru_layer1_split(hipStream_t s, const float* x, const void* Wp, const float* bias, float* out, int64_t B, bool f16);
 int launch_gru_layer2_fc1(hipStream_t s, const float* x, const float* W, const float* bias, const float* fc1w, float* fc1_part,
                           int64_t B);
 
@@ -86,7 +87,7 @@ struct cto_model {
     StageDev st[3];
     // BiGRU
     float *gw1 = nullptr, *gb1 = nullptr, *gw2 = nullptr, *gb2 = nullptr;
-    float *gw2_split = nullptr, *f1_split = nullptr;     // layer 2 / fc1 as (hi, lo) 16-bit fragments: CTO_GRU_SPLIT=f16|bf16 (experiment)
+    float *gw1_split = nullptr, *gw2_split = nullptr, *f1_split = nullptr;     // layer 2 / fc1 as (hi, lo) 16-bit fragments: CTO_GRU_SPLIT=f16|bf16 (experiment)
     bool split_f16 = false;
     HeadDev head;
     int64_t macs = 0;
@@ -448,7 +449,9 @@ int bigru_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStr
     int rc;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (m->prof_all && (rc = prof_begin(m, s, &e0, &e1))) return rc;
-    if ((rc = launch_gru_layer1(s, x, m->gw1, m->gb1, m->b_h, B))) return rc;
+    if (m->gw1_split) rc = launch_gru_layer1_split(s, x, m->gw1_split, m->gb1, m->b_h, B, m->split_f16);
+    else rc = launch_gru_layer1(s, x, m->gw1, m->gb1, m->b_h, B);
+    if (rc) return rc;
     if (m->prof_all) {
         CTO_HIP(hipEventRecord(e1, s));
         m->prof_ev1.emplace_back(e0, e1);
@@ -517,9 +520,9 @@ inline float f16_value(uint16_t u) {
     return float(h);
 }
 // eight consecutive k of one row -> the 16 bytes a lane holds, hi then (64 lanes later) lo
-inline void put_split8(uint16_t* hi, uint16_t* lo, const float* src, bool f16) {
+inline void put_split8(uint16_t* hi, uint16_t* lo, const float* src, int n_valid, bool f16) {
     for (int e = 0; e < 8; ++e) {
-        const float v = src[e];
+        const float v = e < n_valid ? src[e] : 0.f;
         if (f16) { hi[e] = f16_rne(v); lo[e] = f16_rne(v - f16_value(hi[e])); }
         else { hi[e] = bf16_rne(v); lo[e] = bf16_rne(v - bf16_value(hi[e])); }
     }
@@ -530,11 +533,12 @@ int upload_halves(const std::vector<uint16_t>& v, Arena& a, float** out) {
     return a.upload(f, out);
 }
 // Wp[dir][wave][chunk][nb][gate][hi,lo][lane][8], Fp[dir][t][wave][kh][nt][hi,lo][lane][8] (layouts in gru_split_kernel.h)
-int pack_gru_split(const cto_weights* w, const std::string& base, int kin, int H, const std::vector<float>& fc1, bool f16, Arena& a,
-                   float** Wout, float** Fout) {
-    const int NB = H / 64, NX = kin / 32, NH = H / 32, NC = NX + NH, T = 33;
+// fc1 == nullptr: a layer without the fused head (layer 1); kp = kin rounded up to whole 32-wide chunks, zero weights in the padding
+int pack_gru_split(const cto_weights* w, const std::string& base, int kin, int kp, int H, const std::vector<float>* fc1, bool f16,
+                   Arena& a, float** Wout, float** Fout) {
+    const int NB = H / 64, NX = kp / 32, NH = H / 32, NC = NX + NH, T = 33;
     int rc = CTO_OK;
-    std::vector<uint16_t> W(size_t(2) * 4 * NC * NB * 6 * 64 * 8), F(size_t(2) * T * 4 * NH * 4 * 64 * 8);
+    std::vector<uint16_t> W(size_t(2) * 4 * NC * NB * 6 * 64 * 8), F(fc1 ? size_t(2) * T * 4 * NH * 4 * 64 * 8 : 0);
     for (int d = 0; d < 2; ++d) {
         const std::string sfx = d == 0 ? "" : "_reverse";
         GETW(wih, base + ".weight_ih_l0" + sfx, int64_t(3) * H * kin);
@@ -543,7 +547,7 @@ int pack_gru_split(const cto_weights* w, const std::string& base, int kin, int H
             float mx = 0.f;
             for (float v : *wih) mx = std::max(mx, std::fabs(v));
             for (float v : *whh) mx = std::max(mx, std::fabs(v));
-            if (d == 0) for (float v : fc1) mx = std::max(mx, std::fabs(v));
+            if (d == 0 && fc1) for (float v : *fc1) mx = std::max(mx, std::fabs(v));
             CTO_REQUIRE(mx < 60000.f, CTO_EUNSUPPORTED, "CTO_GRU_SPLIT=f16: a weight of %g does not fit the f16 range", double(mx));
         }
         for (int wv = 0; wv < 4; ++wv)
@@ -553,25 +557,26 @@ int pack_gru_split(const cto_weights* w, const std::string& base, int kin, int H
                         for (int lane = 0; lane < 64; ++lane) {
                             const int j = lane & 15, kg = lane >> 4;
                             const int n = q * H + (wv * NB + nb) * 16 + j;
-                            const float* src = c < NX ? wih->data() + size_t(n) * kin + c * 32 + kg * 8
-                                                      : whh->data() + size_t(n) * H + (c - NX) * 32 + kg * 8;
+                            const int k0 = (c < NX ? c : c - NX) * 32 + kg * 8;
+                            const float* src = c < NX ? wih->data() + size_t(n) * kin + k0 : whh->data() + size_t(n) * H + k0;
+                            const int n_valid = c < NX ? std::max(0, std::min(8, kin - k0)) : 8;
                             const size_t u = ((((size_t(d) * 4 + wv) * NC + c) * NB + nb) * 6 + q * 2) * 64;
-                            put_split8(&W[(u + lane) * 8], &W[(u + 64 + lane) * 8], src, f16);
+                            put_split8(&W[(u + lane) * 8], &W[(u + 64 + lane) * 8], n_valid > 0 ? src : whh->data(), n_valid, f16);
                         }
-        for (int t = 0; t < T; ++t)
+        for (int t = 0; fc1 && t < T; ++t)
             for (int wv = 0; wv < 4; ++wv)
                 for (int kh = 0; kh < NH; ++kh)
                     for (int nt = 0; nt < 2; ++nt)
                         for (int lane = 0; lane < 64; ++lane) {
                             const int j = lane & 15, kg = lane >> 4;
                             const int n = wv * 32 + nt * 16 + j;
-                            const float* src = fc1.data() + size_t(n) * (T * 2 * H) + size_t(t) * 2 * H + d * H + kh * 32 + kg * 8;
+                            const float* src = fc1->data() + size_t(n) * (T * 2 * H) + size_t(t) * 2 * H + d * H + kh * 32 + kg * 8;
                             const size_t u = ((((size_t(d) * T + t) * 4 + wv) * NH + kh) * 4 + nt * 2) * 64;
-                            put_split8(&F[(u + lane) * 8], &F[(u + 64 + lane) * 8], src, f16);
+                            put_split8(&F[(u + lane) * 8], &F[(u + 64 + lane) * 8], src, 8, f16);
                         }
     }
     rc = upload_halves(W, a, Wout);
-    return rc != CTO_OK ? rc : upload_halves(F, a, Fout);
+    return rc != CTO_OK || !fc1 ? rc : upload_halves(F, a, Fout);
 }
 
 }  // namespace
@@ -695,7 +700,11 @@ extern "C" int cto_bigru_create(const cto_weights* w, int n_out, cto_model** out
             const std::string kind(e);
             CTO_REQUIRE(kind == "f16" || kind == "bf16", CTO_EINVAL, "CTO_GRU_SPLIT must be f16 or bf16, not '%s'", e);
             m->split_f16 = kind == "f16";
-            if ((rc = pack_gru_split(w, "lstm_2", 256, 192, *f1, m->split_f16, m->arena, &m->gw2_split, &m->f1_split))) return fail(rc);
+            if ((rc = pack_gru_split(w, "lstm_2", 256, 256, 192, f1, m->split_f16, m->arena, &m->gw2_split, &m->f1_split))) return fail(rc);
+            // CTO_GRU_SPLIT_LAYERS=2 keeps layer 1 on the fp32 kernel (default: both recurrent layers on split operands)
+            const char* l = getenv("CTO_GRU_SPLIT_LAYERS");
+            if (!(l && l[0] == '2') && (rc = pack_gru_split(w, "lstm", 34, 64, 128, nullptr, m->split_f16, m->arena, &m->gw1_split, nullptr)))
+                return fail(rc);
         }
     }
     m->macs = int64_t(33) * 2 * 3 * 128 * (34 + 128) + int64_t(33) * 2 * 3 * 192 * (256 + 192) + int64_t(k1) * 128 +

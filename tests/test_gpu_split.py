@@ -1,5 +1,5 @@
-"""The split-operand experiment (csrc/gru_split_kernel.h; CTO_GRU_SPLIT=f16|bf16 at model creation): BiGRU layer 2 + fc1 with every
-operand written as hi + lo (16-bit floats) and three f16 / bf16 MFMA passes per product.  It is a side channel - the default path
+"""The split-operand experiment (csrc/gru_split_kernel.h; CTO_GRU_SPLIT=f16|bf16 at model creation): both BiGRU recurrences and the
+fused fc1 with every operand written as hi + lo (16-bit floats) and three f16 / bf16 MFMA passes per product.  It is a side channel - the default path
 and the bench's `value` stay on the fp32 kernels - but it is held to the same oracle and the same 1e-4 tolerance as they are
 (clairs/model.py:412-417, 442-448 is what all of them restate)."""
 import os

@@ -49,7 +49,7 @@ def measure(batch=4096, reps=40, oracle_sites=96, n_out=4):
         fn = lambda: check(lib.cto_model_forward(eng.h_neg, feat.x_neg.data_ptr(), batch, ln.data_ptr(), s))
         for _ in range(5):
             fn()
-        check(lib.cto_model_profile(eng.h_neg, 1))
+        check(lib.cto_model_profile(eng.h_neg, 2))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
@@ -59,6 +59,8 @@ def measure(batch=4096, reps=40, oracle_sites=96, n_out=4):
         check(lib.cto_model_profile(eng.h_neg, 0))
         ms, macs = C.c_double(0.0), C.c_int64(0)
         check(lib.cto_model_profile_read(eng.h_neg, C.byref(ms), C.byref(macs)))
+        ms1, macs1 = C.c_double(0.0), C.c_int64(0)
+        check(lib.cto_model_profile_read_stage(eng.h_neg, 1, C.byref(ms1), C.byref(macs1)))
         step = eng.run_device(dp, sp)
         e0.record()
         for _ in range(reps):
@@ -66,7 +68,7 @@ def measure(batch=4096, reps=40, oracle_sites=96, n_out=4):
         e1.record()
         torch.cuda.synchronize()
         out[name] = ln.cpu().numpy()
-        res[name] = {"gru_l2_ms": ms.value, "step_ms": e0.elapsed_time(e1) / reps,
+        res[name] = {"gru_l2_ms": ms.value, "gru_l1_ms": ms1.value, "step_ms": e0.elapsed_time(e1) / reps,
                      "sites_per_s": batch / (e0.elapsed_time(e1) / reps) * 1e3}
         del step
     for name in engs:
