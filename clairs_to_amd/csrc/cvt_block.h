@@ -56,6 +56,10 @@ struct CvtBlockGeom {
     static constexpr bool HEAD_OK = (TS == 16) && (64 + head_lds_floats(6) <= ALIAS);
 };
 
+// no pad rows in the q-path and kv-path tiles (rows of a split tile that nobody writes would be read as arbitrary 16-bit floats)
+template <int C, int W, int WKV, int TS>
+__host__ __device__ constexpr bool MT_EXACT() { return (TS * W) % 16 == 0 && (TS * WKV) % 16 == 0; }
+
 // 8 waves per workgroup (two per SIMD), so that one wave's LDS / L2 waits and VALU epilogues overlap the other's MFMAs
 constexpr int CVT_BLOCK_THREADS = 512;
 constexpr int CVT_WAVES = CVT_BLOCK_THREADS / 64;
@@ -102,6 +106,24 @@ __device__ __forceinline__ void gemm_span(const TileSpan& sp, const float* A, in
     }
 }
 
+template <int N, int MTx, int KCH, bool F16>
+__device__ __forceinline__ void gemm_span_split(const TileSpan& sp, const float* A, int lda, int klo,
+                                                const unsigned short* const (&wrow)[ColOwn<N>::NTW], int lo_off,
+                                                const BPreS<ColOwn<N>::NTW>& pre,
+                                                f32x4 (&acc)[MSplit<MTx, ColOwn<N>::MSPLIT>::MTG][ColOwn<N>::NTW], int j, int kg) {
+    using S = MSplit<MTx, ColOwn<N>::MSPLIT>;
+    constexpr int NTW = ColOwn<N>::NTW;
+    const float* A0 = A + sp.mbase * 16 * lda;
+    if (ColOwn<N>::MSPLIT == 1 || sp.mcount == S::MTG) {
+        gemm_lds_split<S::MTG, NTW, KCH, F16>(A0, lda, klo, wrow, lo_off, pre, acc, j, kg);
+    } else if constexpr (S::LAST > 0) {
+        if (sp.mcount == S::LAST) {
+            f32x4 (&sub)[S::LAST][NTW] = reinterpret_cast<f32x4 (&)[S::LAST][NTW]>(acc);
+            gemm_lds_split<S::LAST, NTW, KCH, F16>(A0, lda, klo, wrow, lo_off, pre, sub, j, kg);
+        }
+    }
+}
+
 // Workgroups of this geometry that fit one CU's 160 KB of LDS (at most 3 are asked for): the register budget follows from
 // it through __launch_bounds__ (w = minimum waves per SIMD = 2 per resident 512-thread workgroup), otherwise a kernel that
 // fits the LDS twice still runs alone because it was given 132+ registers.
@@ -110,10 +132,18 @@ __host__ __device__ constexpr int cvt_blocks_per_cu() {
     return CvtBlockGeom<C, W, WKV, TS>::LDS_BYTES * 3 <= 160 * 1024 ? 3 : (CvtBlockGeom<C, W, WKV, TS>::LDS_BYTES * 2 <= 160 * 1024 ? 2 : 1);
 }
 
-template <int C, int W, int WKV, int TS, int CIN, bool HEAD>
+// SPLIT (experiment, side channel: CTO_CVT_SPLIT=f16|bf16; 0 = the fp32 product kernel, 1 = f16, 2 = bf16): the five weight GEMMs
+// of a block (q, k|v, out-projection, both FFN GEMMs) run on split 16-bit operands (split_mfma.h) - their LDS input tiles are
+// written as [hi | lo] rows by the phase that produces them (depth-wise conv + BN, attention, second LayerNorm, GELU epilogue)
+// at the fp32 row pitch, the weights come pre-split.  The residual stream, LayerNorm, softmax, the embedding and the classifier
+// are unchanged fp32.
+template <int C, int W, int WKV, int TS, int CIN, bool HEAD, int SPLIT = 0>
 __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV, TS>())) void k_cvt_block(float* __restrict__ h, CvtStageParams sp,
                                                                                                             HeadTailParams hp, int heads, int B) {
     using G = CvtBlockGeom<C, W, WKV, TS>;
+    constexpr bool SP = SPLIT != 0, F16 = SPLIT == 1;
+    static_assert(!SP || (C % 64 == 0 && MT_EXACT<C, W, WKV, TS>()), "split GEMMs: 32-wide k chunks, 16-byte LayerNorm pieces, no pad rows");
+    using WPtr = std::conditional_t<SP, const unsigned short*, const float*>;
     static_assert(CIN == 0 || G::emb_floats(CIN) <= G::ALIAS, "stage input tile does not fit the free LDS");
     static_assert(!HEAD || G::HEAD_OK, "classifier tail needs a 16-site tile and room for its scratch");
     static_assert(G::MT * 16 * G::RS <= G::TMP_FLOATS, "LayerNorm staging tile does not fit the q|k|v region");
@@ -208,7 +238,8 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
     // contiguous channels: the row reductions are 4 DPP steps inside a 16-lane row.  All passes are in flight together - one
     // pass is a dependent chain of an LDS read, two 4-step reductions, a square root and a division, and with two waves per
     // SIMD nothing else hides it.
-    auto layer_norm = [&](const float* src, float* dst, const float* g, const float* b) {
+    auto layer_norm = [&](const float* src, float* dst, const float* g, const float* b, auto split_out) {
+        constexpr bool SPO = decltype(split_out)::value;      // dst feeds a split GEMM: rows of [hi | lo]
         constexpr int CPL = C / 16, NP = (MT * 16 + NWV * 4 - 1) / (NWV * 4);
         const int l16 = lane & 15, grp = lane >> 4;
         float gv[CPL], bv[CPL];
@@ -249,7 +280,13 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
             const int r = q * NWV * 4 + wave * 4 + grp;
             if (r < MT * 16) {
                 float* yr = dst + r * RS + l16 * CPL;
-                if constexpr (CPL % 4 == 0) {
+                if constexpr (SPO) {
+                    static_assert(!SPO || CPL % 4 == 0, "split rows are written four channels at a time");
+#pragma unroll
+                    for (int i = 0; i < CPL; i += 4)
+                        put_split4<F16>(dst + r * RS, C, l16 * CPL + i, v[q][i] * inv[q] * gv[i] + bv[i], v[q][i + 1] * inv[q] * gv[i + 1] + bv[i + 1],
+                                        v[q][i + 2] * inv[q] * gv[i + 2] + bv[i + 2], v[q][i + 3] * inv[q] * gv[i + 3] + bv[i + 3]);
+                } else if constexpr (CPL % 4 == 0) {
 #pragma unroll
                     for (int i = 0; i < CPL; i += 4)
                         *reinterpret_cast<float4*>(yr + i) =
@@ -289,7 +326,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
         }
         lds_barrier();
         for (int i = tid; i < (MTKV * 16 - RKV) * RS; i += NT) sykv[RKV * RS + i] = 0.f;    // the input tile lay over these rows
-        layer_norm(sy, sy, pe.lng, pe.lnb);
+        layer_norm(sy, sy, pe.lng, pe.lnb, std::false_type{});
         lds_barrier();
     }
 
@@ -315,7 +352,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
             }
         }
     }
-    layer_norm(sy, stmp, p.n0g, p.n0b);
+    layer_norm(sy, stmp, p.n0g, p.n0b, std::false_type{});
     lds_barrier();
     stamp();
 
@@ -347,7 +384,8 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
                     if (PG > 1 && (w < wlo || w >= whi)) continue;
                     const float l = w > 0 ? y[it][w - 1] : 0.f, r = w + 1 < W ? y[it][w + 1] : 0.f;
                     const float d = q0 * l + q1 * y[it][w] + q2 * r;
-                    sy[(s * W + w) * RS + c] = (d - qm) * qi * qw + qb;
+                    if constexpr (SP) put_split1<F16>(sy + (s * W + w) * RS, C, c, (d - qm) * qi * qw + qb);
+                    else sy[(s * W + w) * RS + c] = (d - qm) * qi * qw + qb;
                 }
 #pragma unroll
                 for (int wo = 0; wo < WKV; ++wo) {
@@ -355,7 +393,8 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
                     const int w = 2 * wo;
                     const float l = w > 0 ? y[it][w - 1] : 0.f, r = w + 1 < W ? y[it][w + 1] : 0.f;
                     const float d = k0 * l + k1 * y[it][w] + k2 * r;
-                    sykv[(s * WKV + wo) * RS + c] = (d - km) * ki * kw + kb;
+                    if constexpr (SP) put_split1<F16>(sykv + (s * WKV + wo) * RS, C, c, (d - km) * ki * kw + kb);
+                    else sykv[(s * WKV + wo) * RS + c] = (d - km) * ki * kw + kb;
                 }
             }
         }
@@ -365,34 +404,54 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
 
     stamp();
     // ---- phase 3: attention, head by head; out-projection accumulates on top of the residual stream in registers ----
-    auto q_rows = [&](int hh, const float* (&wr)[1]) { wr[0] = p.wq + int64_t(hh * 64 + spq.tile0 * 16 + j) * C + 4 * kg; };
-    auto o_rows = [&](int hh, const float* (&wr)[NTC]) {
-#pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) wr[nt] = p.wo + int64_t((spc.tile0 + nt) * 16 + j) * inner + hh * 64 + 4 * kg;
+    // weight rows of this lane: fp32 W[n][4 kg ..] or, split, the hi plane's W[n][8 kg ..] (the lo plane lo_* elements further)
+    const int lo_q = inner * C, lo_kv = 2 * inner * C, lo_o = C * inner, lo_w = 4 * C * C;
+    auto q_rows = [&](int hh, WPtr (&wr)[1]) {
+        const int64_t at = int64_t(hh * 64 + spq.tile0 * 16 + j) * C;
+        if constexpr (SP) wr[0] = p.wq_s + at + 8 * kg; else wr[0] = p.wq + at + 4 * kg;
     };
-    auto w1_rows = [&](int cc, const float* (&wr)[NTF]) {
+    auto o_rows = [&](int hh, WPtr (&wr)[NTC]) {
 #pragma unroll
-        for (int nt = 0; nt < NTF; ++nt) wr[nt] = p.w1 + int64_t(cc * HC + (spf.tile0 + nt) * 16 + j) * C + 4 * kg;
+        for (int nt = 0; nt < NTC; ++nt) {
+            const int64_t at = int64_t((spc.tile0 + nt) * 16 + j) * inner + hh * 64;
+            if constexpr (SP) wr[nt] = p.wo_s + at + 8 * kg; else wr[nt] = p.wo + at + 4 * kg;
+        }
     };
-    auto w2_rows = [&](int cc, const float* (&wr)[NTC]) {
+    auto w1_rows = [&](int cc, WPtr (&wr)[NTF]) {
 #pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) wr[nt] = p.w2 + int64_t((spc.tile0 + nt) * 16 + j) * (4 * C) + cc * HC + 4 * kg;
+        for (int nt = 0; nt < NTF; ++nt) {
+            const int64_t at = int64_t(cc * HC + (spf.tile0 + nt) * 16 + j) * C;
+            if constexpr (SP) wr[nt] = p.w1_s + at + 8 * kg; else wr[nt] = p.w1 + at + 4 * kg;
+        }
     };
+    auto w2_rows = [&](int cc, WPtr (&wr)[NTC]) {
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) {
+            const int64_t at = int64_t((spc.tile0 + nt) * 16 + j) * (4 * C) + cc * HC;
+            if constexpr (SP) wr[nt] = p.w2_s + at + 8 * kg; else wr[nt] = p.w2 + at + 4 * kg;
+        }
+    };
+    constexpr int KD = SP ? 32 : 16;            // k elements per chunk
 
-    const float* wq_r[1];
+    WPtr wq_r[1];
     q_rows(0, wq_r);
-    BPre<1> pre_q = prefetch_b<1, C / 16>(wq_r);
+    auto pre_q = prefetch_b<1, C / KD>(wq_r, lo_q);
     for (int hh = 0; hh < heads; ++hh) {
         // [k_h | v_h] is 128 wide for every stage: wave w computes one of its 8 n-tiles (w < 4: k columns 16 w.., else v columns
         // 16 (w - 4)..) for all m-tiles
         const int wn = wave & 3;
-        const float* wkv1_r[1] = {p.wkv + int64_t((wave < 4 ? 0 : inner) + hh * 64 + wn * 16 + j) * C + 4 * kg};
-        const BPre<1> pre_kv1 = prefetch_b<1, C / 16>(wkv1_r);
+        WPtr wkv1_r[1];
+        {
+            const int64_t at = int64_t((wave < 4 ? 0 : inner) + hh * 64 + wn * 16 + j) * C;
+            if constexpr (SP) wkv1_r[0] = p.wkv_s + at + 8 * kg; else wkv1_r[0] = p.wkv + at + 4 * kg;
+        }
+        const auto pre_kv1 = prefetch_b<1, C / KD>(wkv1_r, lo_kv);
         {   // q_h : [R][64], this wave's 16 columns of its m-tile group
             f32x4 aq[MGQ][1];
 #pragma unroll
             for (int mt = 0; mt < MGQ; ++mt) aq[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gemm_span<64, MT, C / 16>(spq, sy, RS, wq_r, pre_q, aq, j, kg);
+            if constexpr (SP) gemm_span_split<64, MT, C / 32, F16>(spq, sy, RS, C, wq_r, lo_q, pre_q, aq, j, kg);
+            else gemm_span<64, MT, C / 16>(spq, sy, RS, wq_r, pre_q, aq, j, kg);
 #pragma unroll
             for (int mt = 0; mt < MGQ; ++mt)
                 if (mt < spq.mcount) {
@@ -400,14 +459,15 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
                     for (int r = 0; r < 4; ++r) sq[((spq.mbase + mt) * 16 + 4 * kg + r) * QS + spq.tile0 * 16 + j] = aq[mt][0][r];
                 }
         }
-        const float* wo_r[NTC];
+        WPtr wo_r[NTC];
         o_rows(hh, wo_r);
-        const BPre<NTC> pre_o = prefetch_b<NTC, 4>(wo_r);
+        const auto pre_o = prefetch_b<NTC, 64 / KD>(wo_r, lo_o);
         {   // k_h, v_h : [RKV][64] each, one n-tile of the pair per wave, all m-tiles
             f32x4 akv1[MTKV][1];
 #pragma unroll
             for (int mt = 0; mt < MTKV; ++mt) akv1[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gemm_lds<MTKV, 1, C / 16>(sykv, RS, wkv1_r, pre_kv1, akv1, j, kg);
+            if constexpr (SP) gemm_lds_split<MTKV, 1, C / 32, F16>(sykv, RS, C, wkv1_r, lo_kv, pre_kv1, akv1, j, kg);
+            else gemm_lds<MTKV, 1, C / 16>(sykv, RS, wkv1_r, pre_kv1, akv1, j, kg);
             float* dst = wave < 4 ? sk : sv;
 #pragma unroll
             for (int mt = 0; mt < MTKV; ++mt)
@@ -453,24 +513,28 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
                     const float pj = sc[jj] * inv;
                     o4.x = fmaf(pj, vv[jj].x, o4.x); o4.y = fmaf(pj, vv[jj].y, o4.y); o4.z = fmaf(pj, vv[jj].z, o4.z); o4.w = fmaf(pj, vv[jj].w, o4.w);
                 }
-                if (row < R) *reinterpret_cast<float4*>(sq + rr * QS + l4) = o4;
+                if (row < R) {      // o_h over q_h in place (split: the row's first 256 bytes become [hi | lo])
+                    if constexpr (SP) put_split4<F16>(sq + rr * QS, 64, l4, o4.x, o4.y, o4.z, o4.w);
+                    else *reinterpret_cast<float4*>(sq + rr * QS + l4) = o4;
+                }
             }
         }
         if (hh + 1 < heads) {        // next head's q weights fly under the barrier and the out-projection
             q_rows(hh + 1, wq_r);
-            pre_q = prefetch_b<1, C / 16>(wq_r);
+            pre_q = prefetch_b<1, C / KD>(wq_r, lo_q);
         }
         lds_barrier();
         stamp();
-        gemm_span<C, MT, 4>(spc, sq, QS, wo_r, pre_o, acc_o, j, kg);   // acc_o += o_h Wo[:, hh*64 .. +64]^T
+        if constexpr (SP) gemm_span_split<C, MT, 2, F16>(spc, sq, QS, 64, wo_r, lo_o, pre_o, acc_o, j, kg);
+        else gemm_span<C, MT, 4>(spc, sq, QS, wo_r, pre_o, acc_o, j, kg);   // acc_o += o_h Wo[:, hh*64 .. +64]^T
         lds_barrier();   // sq / sk / sv are rewritten by the next head
         stamp();
     }
 
     // first FFN weights are requested before the residual hand-over and the second LayerNorm
-    const float* w1_r[NTF];
+    WPtr w1_r[NTF];
     w1_rows(0, w1_r);
-    BPre<NTF> pre_w1 = prefetch_b<NTF, C / 16>(w1_r);
+    auto pre_w1 = prefetch_b<NTF, C / KD>(w1_r, lo_w);
 
     // ---- phase 4: h' = h + to_out(o) + bias sits in acc_o: a copy -> staging tile for the LayerNorm, and h' + b2 seeds the
     //      second FFN GEMM's accumulators ----
@@ -492,22 +556,23 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
 
     stamp();
     // ---- phase 5 ----
-    layer_norm(stmp, sy, p.n1g, p.n1b);
+    layer_norm(stmp, sy, p.n1g, p.n1b, std::bool_constant<SP>{});
     lds_barrier();
     stamp();
 
     // ---- phase 6: feed-forward, hidden units in chunks of HC ----
     for (int cc = 0; cc < 4 * C / HC; ++cc) {
-        const float* w2_r[NTC];
+        WPtr w2_r[NTC];
         w2_rows(cc, w2_r);
-        const BPre<NTC> pre_w2 = prefetch_b<NTC, HC / 16>(w2_r);
+        const auto pre_w2 = prefetch_b<NTC, HC / KD>(w2_r, lo_w);
         {
             f32x4 au[MGF][NTF];
 #pragma unroll
             for (int mt = 0; mt < MGF; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NTF; ++nt) au[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gemm_span<HC, MT, C / 16>(spf, sy, RS, w1_r, pre_w1, au, j, kg);
+            if constexpr (SP) gemm_span_split<HC, MT, C / 32, F16>(spf, sy, RS, C, w1_r, lo_w, pre_w1, au, j, kg);
+            else gemm_span<HC, MT, C / 16>(spf, sy, RS, w1_r, pre_w1, au, j, kg);
             const int n0 = cc * HC + spf.tile0 * 16;
 #pragma unroll
             for (int nt = 0; nt < NTF; ++nt) {
@@ -516,17 +581,21 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
                 for (int mt = 0; mt < MGF; ++mt)
                     if (mt < spf.mcount) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            su[((spf.mbase + mt) * 16 + 4 * kg + r) * US + (spf.tile0 + nt) * 16 + j] = gelu_f(au[mt][nt][r] + bv);
+                        for (int r = 0; r < 4; ++r) {
+                            float* urow = su + ((spf.mbase + mt) * 16 + 4 * kg + r) * US;
+                            if constexpr (SP) put_split1<F16>(urow, HC, (spf.tile0 + nt) * 16 + j, gelu_f(au[mt][nt][r] + bv));
+                            else urow[(spf.tile0 + nt) * 16 + j] = gelu_f(au[mt][nt][r] + bv);
+                        }
                     }
             }
         }
         if (cc + 1 < 4 * C / HC) {
             w1_rows(cc + 1, w1_r);
-            pre_w1 = prefetch_b<NTF, C / 16>(w1_r);
+            pre_w1 = prefetch_b<NTF, C / KD>(w1_r, lo_w);
         }
         lds_barrier();
-        gemm_span<C, MT, HC / 16>(spc, su, US, w2_r, pre_w2, acc_f, j, kg);
+        if constexpr (SP) gemm_span_split<C, MT, HC / 32, F16>(spc, su, US, HC, w2_r, lo_w, pre_w2, acc_f, j, kg);
+        else gemm_span<C, MT, HC / 16>(spc, su, US, w2_r, pre_w2, acc_f, j, kg);
         if (cc + 1 < 4 * C / HC) lds_barrier();   // su is rewritten by the next chunk
         stamp();
     }

@@ -5,6 +5,7 @@
 #pragma once
 #include <type_traits>
 #include "nn_kernels.h"
+#include "split_mfma.h"
 
 namespace cto {
 
@@ -15,6 +16,8 @@ struct CvtBlockParams {
     const float *xin, *wembp, *bemb, *lng, *lnb;   // x [B][2W-1][CIN]; wembp [C][KCHE*16] (positions padded to PS)
     // last block of the network (HEAD): fc1 + classifier tail run here instead of writing h
     const float *w1p, *b1h;                        // fc1 [128][KCH1*16] over the LDS image of h (rows padded to RS)
+    // split-operand experiment (CTO_CVT_SPLIT): the five GEMM weights as [hi plane | lo plane] of 16-bit values, row-major [N][K]
+    const unsigned short *wq_s, *wkv_s, *wo_s, *w1_s, *w2_s;
 };
 
 // Consecutive blocks of ONE stage run in one launch (the tile never leaves the CU between them): blk[0] may carry the stage's
@@ -83,6 +86,75 @@ __device__ __forceinline__ void gemm_lds(const float* __restrict__ A, int lda, c
                     acc[mt][nt] = mfma16(av, bv, acc[mt][nt]);
                 }
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ---- split-operand forms of the two building blocks above (experiment, side channel: CTO_CVT_SPLIT) ----
+// A tile rows keep their fp32 pitch `lda` and hold [hi: klo 16-bit][lo: klo 16-bit] (split_mfma.h: put_split*); weights are two
+// row-major 16-bit planes [N][K], the lo plane `lo_off` elements after the hi plane; wrow[nt] points at Whi[n0 + nt*16 + j][8 kg];
+// KCH counts 32-wide k chunks.  Same output layout as gemm_lds.
+template <int NTW>
+struct BPreS {
+    uint4 b[2][NTW][2];      // chunks 0 and 1; hi, lo
+};
+template <int NTW, int KCH>
+__device__ __forceinline__ BPreS<NTW> prefetch_b(const unsigned short* const (&wrow)[NTW], int lo_off) {
+    BPreS<NTW> p;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (c < KCH) { p.b[c][nt][0] = ldg16(wrow[nt] + c * 32); p.b[c][nt][1] = ldg16(wrow[nt] + lo_off + c * 32); }
+            else { p.b[c][nt][0] = make_uint4(0u, 0u, 0u, 0u); p.b[c][nt][1] = make_uint4(0u, 0u, 0u, 0u); }
+        }
+    return p;
+}
+template <int NTW, int KCH>
+__device__ __forceinline__ BPre<NTW> prefetch_b(const float* const (&wrow)[NTW], int) { return prefetch_b<NTW, KCH>(wrow); }
+
+template <int MT, int NTW, int KCH, bool F16>
+__device__ __forceinline__ void gemm_lds_split(const float* __restrict__ A, int lda, int klo, const unsigned short* const (&wrow)[NTW],
+                                               int lo_off, const BPreS<NTW>& pre, f32x4 (&acc)[MT][NTW], int j, int kg) {
+    uint4 Bq[3][NTW][2];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { Bq[0][nt][p] = pre.b[0][nt][p]; Bq[1][nt][p] = pre.b[1][nt][p]; }
+    // A fragments one chunk ahead while they fit (MT <= 5: 80 registers); taller tiles read each chunk's fragments right before its
+    // MFMAs - the SIMD's other wave covers the LDS latency, 144 registers of fragments would spill
+    constexpr bool ADB = MT <= 5;
+    uint4 a[ADB ? 2 : 1][MT][2];
+    const unsigned short* Arow = reinterpret_cast<const unsigned short*>(A + j * lda) + 8 * kg;
+    auto load_a = [&](int buf, int c) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                a[buf][mt][p] = *reinterpret_cast<const uint4*>(Arow + mt * 16 * lda * 2 + p * klo + c * 32);
+    };
+    if (ADB) load_a(0, 0);
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) {
+        if (c + 2 < KCH) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                Bq[(c + 2) % 3][nt][0] = ldg16(wrow[nt] + (c + 2) * 32);
+                Bq[(c + 2) % 3][nt][1] = ldg16(wrow[nt] + lo_off + (c + 2) * 32);
+            }
+        }
+        if (ADB) { if (c + 1 < KCH) load_a((c + 1) & 1, c + 1); }
+        else load_a(0, c);
+        __builtin_amdgcn_sched_barrier(0);      // requests first, then this chunk's MFMAs (see gemm_lds)
+        // pass outermost: the MT * NTW accumulators between two passes over the same one keep dependent MFMAs apart
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass) {
+            const int pa = pass == 1 ? 1 : 0, pw = pass == 2 ? 1 : 0;       // (activation part, weight part)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma_split<F16>(a[ADB ? (c & 1) : 0][mt][pa], Bq[c % 3][nt][pw], acc[mt][nt]);
         }
         __builtin_amdgcn_sched_barrier(0);
     }

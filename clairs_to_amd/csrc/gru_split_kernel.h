@@ -22,38 +22,9 @@
 //   * K advances 32 per chunk: 8 x chunks + 6 h chunks per step.
 #pragma once
 #include "gru_kernel.h"
+#include "split_mfma.h"
 
 namespace cto {
-
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-
-template <bool F16>
-__device__ __forceinline__ f32x4 mfma_split(const uint4& a, const uint4& b, f32x4 c) {
-    if constexpr (F16)
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
-    else
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
-
-// (a, b) -> packed 16-bit pairs hi, lo with a ≈ hi.x + lo.x, b ≈ hi.y + lo.y
-template <bool F16>
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
-    if constexpr (F16) {
-        const auto h = __builtin_amdgcn_cvt_pkrtz(a, b);          // truncation: a - hi is exact and lo takes it up
-        hi = __builtin_bit_cast(unsigned, h);
-        const f16x2_t l = {(_Float16)(a - float(h[0])), (_Float16)(b - float(h[1]))};
-        lo = __builtin_bit_cast(unsigned, l);
-    } else {
-        const bf16x2_t h = {(__bf16)a, (__bf16)b};
-        hi = __builtin_bit_cast(unsigned, h);
-        const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
-        const bf16x2_t l = {(__bf16)ra, (__bf16)rb};
-        lo = __builtin_bit_cast(unsigned, l);
-    }
-}
 
 // Fragment-ordered operand arrays (16-byte units, index = ... * 64 + lane; lane = (kg << 4) | j holds k = 32 c + 8 kg .. + 7):
 //   Wp[dir][wave][chunk c < NX + NH][nb][gate r,z,n][hi,lo][lane] : row  gate * H + (wave * NB + nb) * 16 + j  of [W_ih | W_hh]

@@ -67,6 +67,8 @@ struct HeadDev {          // fc1 -> SELU -> K x (fc2 -> SELU -> fc3 -> SELU)
 
 struct BlockDev {
     float *n0g, *n0b, *dwq, *bnq, *wq, *dwkv, *bnkv, *wkv, *wo, *bo, *n1g, *n1b, *w1, *b1, *w2, *b2;
+    // split-operand experiment (CTO_CVT_SPLIT): [hi plane | lo plane] of 16-bit values per GEMM weight, or null
+    float *wq_s = nullptr, *wkv_s = nullptr, *wo_s = nullptr, *w1_s = nullptr, *w2_s = nullptr;
 };
 
 struct StageDev {
@@ -89,6 +91,7 @@ struct cto_model {
     float *gw1 = nullptr, *gb1 = nullptr, *gw2 = nullptr, *gb2 = nullptr;
     float *gw1_split = nullptr, *gw2_split = nullptr, *f1_split = nullptr;     // layer 2 / fc1 as (hi, lo) 16-bit fragments: CTO_GRU_SPLIT=f16|bf16 (experiment)
     bool split_f16 = false;
+    int cvt_split = 0;          // CvT block GEMMs on split operands: 0 = fp32 kernels, 1 = f16, 2 = bf16 (CTO_CVT_SPLIT, experiment)
     HeadDev head;
     int64_t macs = 0;
     // workspace
@@ -283,13 +286,13 @@ struct BlockExtra {            // what the first / last block of the network add
     int n_out = 0;
 };
 
-template <int C, int W, int WKV, int TS, int CIN, bool HEAD>
+template <int C, int W, int WKV, int TS, int CIN, bool HEAD, int SPLIT = 0>
 int launch_cvt_block(hipStream_t s, float* h, const BlockDev* blocks, int nblk, int heads, int64_t B, const BlockExtra& ex) {
     using G = CvtBlockGeom<C, W, WKV, TS>;
     static_assert(G::LDS_BYTES <= 160 * 1024, "fused CvT block does not fit the 160 KB LDS of a gfx950 CU");
     static bool attr_set = false;
     if (!attr_set) {
-        CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cvt_block<C, W, WKV, TS, CIN, HEAD>),
+        CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cvt_block<C, W, WKV, TS, CIN, HEAD, SPLIT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES)));
         attr_set = true;
     }
@@ -302,7 +305,15 @@ int launch_cvt_block(hipStream_t s, float* h, const BlockDev* blocks, int nblk, 
     for (int i = 0; i < nblk; ++i) {
         const BlockDev& b = blocks[i];
         sp.blk[i] = CvtBlockParams{b.n0g, b.n0b, b.dwq, b.bnq, b.wq, b.dwkv, b.bnkv, b.wkv, b.wo, b.bo, b.n1g, b.n1b, b.w1, b.b1, b.w2, b.b2,
-                                   prof_on ? prof_buf : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+                                   prof_on ? prof_buf : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                   nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (SPLIT != 0) {
+            CTO_REQUIRE(b.wq_s && b.wkv_s && b.wo_s && b.w1_s && b.w2_s, CTO_EINVAL, "split CvT block without split weights");
+            CvtBlockParams& p = sp.blk[i];
+            p.wq_s = reinterpret_cast<const unsigned short*>(b.wq_s); p.wkv_s = reinterpret_cast<const unsigned short*>(b.wkv_s);
+            p.wo_s = reinterpret_cast<const unsigned short*>(b.wo_s); p.w1_s = reinterpret_cast<const unsigned short*>(b.w1_s);
+            p.w2_s = reinterpret_cast<const unsigned short*>(b.w2_s);
+        }
     }
     HeadTailParams hp{};
     if (CIN > 0) {
@@ -314,7 +325,7 @@ int launch_cvt_block(hipStream_t s, float* h, const BlockDev* blocks, int nblk, 
         p.w1p = ex.head->w1p; p.b1h = ex.head->b1;
         hp = HeadTailParams{ex.head->w2, ex.head->b2, ex.head->w3, ex.head->b3, ex.logits, ex.n_out};
     }
-    hipLaunchKernelGGL((k_cvt_block<C, W, WKV, TS, CIN, HEAD>), dim3(unsigned(cdiv(B, TS))), dim3(CVT_BLOCK_THREADS), G::LDS_BYTES,
+    hipLaunchKernelGGL((k_cvt_block<C, W, WKV, TS, CIN, HEAD, SPLIT>), dim3(unsigned(cdiv(B, TS))), dim3(CVT_BLOCK_THREADS), G::LDS_BYTES,
                        s, h, sp, hp, heads, int(B));
     CTO_HIP(hipGetLastError());
     if (prof_on) {   // debug aid: phase time stamps of workgroup 0 (cycles since the kernel's first stamp)
@@ -330,14 +341,24 @@ int launch_cvt_block(hipStream_t s, float* h, const BlockDev* blocks, int nblk, 
 
 // The instantiated geometries: (C, W, WKV) -> sites per workgroup and the stage-input channel count whose embedding
 // can run inside the stage's first block.
-template <int C, int W, int WKV, int TS, int CIN>
-int dispatch_block(hipStream_t s, float* h, const BlockDev* blocks, int nblk, int heads, int64_t B, const BlockExtra& ex, bool embed, bool head) {
+template <int C, int W, int WKV, int TS, int CIN, int SPLIT>
+int dispatch_block_kind(hipStream_t s, float* h, const BlockDev* blocks, int nblk, int heads, int64_t B, const BlockExtra& ex, bool embed, bool head) {
     if constexpr (C == 128 && CvtBlockGeom<C, W, WKV, TS>::HEAD_OK) {
-        if (head) return embed ? launch_cvt_block<C, W, WKV, TS, CIN, true>(s, h, blocks, nblk, heads, B, ex)
-                               : launch_cvt_block<C, W, WKV, TS, 0, true>(s, h, blocks, nblk, heads, B, ex);
+        if (head) return embed ? launch_cvt_block<C, W, WKV, TS, CIN, true, SPLIT>(s, h, blocks, nblk, heads, B, ex)
+                               : launch_cvt_block<C, W, WKV, TS, 0, true, SPLIT>(s, h, blocks, nblk, heads, B, ex);
     }
-    return embed ? launch_cvt_block<C, W, WKV, TS, CIN, false>(s, h, blocks, nblk, heads, B, ex)
-                 : launch_cvt_block<C, W, WKV, TS, 0, false>(s, h, blocks, nblk, heads, B, ex);
+    return embed ? launch_cvt_block<C, W, WKV, TS, CIN, false, SPLIT>(s, h, blocks, nblk, heads, B, ex)
+                 : launch_cvt_block<C, W, WKV, TS, 0, false, SPLIT>(s, h, blocks, nblk, heads, B, ex);
+}
+// split (0 = fp32; 1 = f16, 2 = bf16: experiment) exists for the 64- and 128-channel stages with 16-site tiles
+template <int C, int W, int WKV, int TS, int CIN>
+int dispatch_block(hipStream_t s, float* h, const BlockDev* blocks, int nblk, int heads, int64_t B, const BlockExtra& ex, bool embed, bool head,
+                   int split) {
+    if constexpr (C % 64 == 0 && MT_EXACT<C, W, WKV, TS>()) {
+        if (split == 1) return dispatch_block_kind<C, W, WKV, TS, CIN, 1>(s, h, blocks, nblk, heads, B, ex, embed, head);
+        if (split == 2) return dispatch_block_kind<C, W, WKV, TS, CIN, 2>(s, h, blocks, nblk, heads, B, ex, embed, head);
+    }
+    return dispatch_block_kind<C, W, WKV, TS, CIN, 0>(s, h, blocks, nblk, heads, B, ex, embed, head);
 }
 // Sites per workgroup of the stage-1 / stage-2 blocks.  What they trade is LDS per workgroup (q / k / v tiles dominate) against
 // workgroups resident per CU: the blocks of these stages do little matrix work per phase, so a second and third resident
@@ -361,12 +382,13 @@ bool can_fuse_head(const StageDev& st, const HeadDev& hd) { const FusedGeom* g =
 // nblk consecutive fused transformer blocks of a stage in one launch, when the stage geometry has an instantiation; returns 1 if it
 // ran, 0 if not, < 0 on error
 int try_fused_blocks(hipStream_t s, const StageDev& st, const BlockDev* b, int nblk, float* h, int64_t B, const BlockExtra& ex, bool embed,
-                     bool head) {
+                     bool head, int split) {
     int rc = CTO_OK;
-    if (st.c == 128 && st.w == 5 && st.wkv == 3) rc = dispatch_block<128, 5, 3, 16, 64>(s, h, b, nblk, st.heads, B, ex, embed, head);
-    else if (st.c == 64 && st.w == 9 && st.wkv == 5) rc = dispatch_block<64, 9, 5, CTO_CVT_TS2, 16>(s, h, b, nblk, st.heads, B, ex, embed, head);
-    else if (st.c == 16 && st.w == 17 && st.wkv == 9) rc = dispatch_block<16, 17, 9, CTO_CVT_TS1, 34>(s, h, b, nblk, st.heads, B, ex, embed, head);
-    else if (st.c == 32 && st.w == 17 && st.wkv == 9) rc = dispatch_block<32, 17, 9, CTO_CVT_TS1, 34>(s, h, b, nblk, st.heads, B, ex, embed, head);
+    if (!b->wq_s) split = 0;
+    if (st.c == 128 && st.w == 5 && st.wkv == 3) rc = dispatch_block<128, 5, 3, 16, 64>(s, h, b, nblk, st.heads, B, ex, embed, head, split);
+    else if (st.c == 64 && st.w == 9 && st.wkv == 5) rc = dispatch_block<64, 9, 5, CTO_CVT_TS2, 16>(s, h, b, nblk, st.heads, B, ex, embed, head, split);
+    else if (st.c == 16 && st.w == 17 && st.wkv == 9) rc = dispatch_block<16, 17, 9, CTO_CVT_TS1, 34>(s, h, b, nblk, st.heads, B, ex, embed, head, split);
+    else if (st.c == 32 && st.w == 17 && st.wkv == 9) rc = dispatch_block<32, 17, 9, CTO_CVT_TS1, 34>(s, h, b, nblk, st.heads, B, ex, embed, head, split);
     else return 0;
     return rc == CTO_OK ? 1 : rc;
 }
@@ -403,7 +425,7 @@ int cvt_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStrea
                 const bool embed = embed_in_block && bi == 0;
                 const bool head = m->fuse_head && si == 2 && bi + size_t(nblk) == st.blocks.size() && can_fuse_head(st, m->head);
                 ex.xin = in; ex.st = &st; ex.head = &m->head; ex.logits = logits; ex.n_out = m->n_out;
-                const int fr = try_fused_blocks(s, st, &b, nblk, hbuf, B, ex, embed, head);
+                const int fr = try_fused_blocks(s, st, &b, nblk, hbuf, B, ex, embed, head, m->cvt_split);
                 if (fr < 0) return fr;
                 if (fr == 1) {
                     if (head) return CTO_OK;
@@ -532,6 +554,25 @@ int upload_halves(const std::vector<uint16_t>& v, Arena& a, float** out) {
     memcpy(f.data(), v.data(), v.size() * 2);
     return a.upload(f, out);
 }
+// a weight matrix [numel] as two 16-bit planes, hi then lo, in its own (row-major) order
+int upload_split_planes(const cto_weights* w, const std::string& name, int64_t numel, bool f16, Arena& a, float** out) {
+    int rc = CTO_OK;
+    GETW(v, name, numel);
+    std::vector<uint16_t> pl(size_t(2) * numel);
+    for (int64_t i = 0; i < numel; ++i) {
+        const float x = (*v)[size_t(i)];
+        if (f16) {
+            CTO_REQUIRE(std::fabs(x) < 60000.f, CTO_EUNSUPPORTED, "CTO_CVT_SPLIT=f16: weight %s holds %g, outside the f16 range", name.c_str(), double(x));
+            pl[size_t(i)] = f16_rne(x);
+            pl[size_t(numel + i)] = f16_rne(x - f16_value(pl[size_t(i)]));
+        } else {
+            pl[size_t(i)] = bf16_rne(x);
+            pl[size_t(numel + i)] = bf16_rne(x - bf16_value(pl[size_t(i)]));
+        }
+    }
+    return upload_halves(pl, a, out);
+}
+
 // Wp[dir][wave][chunk][nb][gate][hi,lo][lane][8], Fp[dir][t][wave][kh][nt][hi,lo][lane][8] (layouts in gru_split_kernel.h)
 // fc1 == nullptr: a layer without the fused head (layer 1); kp = kin rounded up to whole 32-wide chunks, zero weights in the padding
 int pack_gru_split(const cto_weights* w, const std::string& base, int kin, int kp, int H, const std::vector<float>* fc1, bool f16,
@@ -592,6 +633,14 @@ extern "C" int cto_cvt_create(const cto_weights* w, const cto_cvt_cfg* cfg, cto_
     CTO_HIP(hipGetDevice(&m->device));
     m->kind = 0;
     m->n_out = cfg->n_out;
+    {   // experiment (side channel, never the default): the block GEMMs of the 64- / 128-channel stages on split 16-bit operands
+        const char* e = getenv("CTO_CVT_SPLIT");
+        if (e && e[0]) {
+            const std::string kind(e);
+            CTO_REQUIRE(kind == "f16" || kind == "bf16", CTO_EINVAL, "CTO_CVT_SPLIT must be f16 or bf16, not '%s'", e);
+            m->cvt_split = kind == "f16" ? 1 : 2;
+        }
+    }
     Arena& a = m->arena;
     int rc = CTO_OK;
     int cin = CTO_NCHAN, win = CTO_NPOS;
@@ -641,6 +690,15 @@ extern "C" int cto_cvt_create(const cto_weights* w, const cto_cvt_cfg* cfg, cto_
                 (rc = upload_named(w, P + ".1.fn.net.3.weight", int64_t(4) * C * C, a, &b.w2)) ||
                 (rc = upload_named(w, P + ".1.fn.net.3.bias", C, a, &b.b2)))
                 return fail(rc);
+            if (m->cvt_split && C % 64 == 0) {
+                const bool f16 = m->cvt_split == 1;
+                if ((rc = upload_split_planes(w, P + ".0.fn.to_q.net.2.weight", int64_t(st.inner) * C, f16, a, &b.wq_s)) ||
+                    (rc = upload_split_planes(w, P + ".0.fn.to_kv.net.2.weight", int64_t(2) * st.inner * C, f16, a, &b.wkv_s)) ||
+                    (rc = upload_split_planes(w, P + ".0.fn.to_out.0.weight", int64_t(C) * st.inner, f16, a, &b.wo_s)) ||
+                    (rc = upload_split_planes(w, P + ".1.fn.net.0.weight", int64_t(4) * C * C, f16, a, &b.w1_s)) ||
+                    (rc = upload_split_planes(w, P + ".1.fn.net.3.weight", int64_t(4) * C * C, f16, a, &b.w2_s)))
+                    return fail(rc);
+            }
             st.blocks.push_back(b);
             macs += int64_t(st.w) * C * st.inner + int64_t(st.wkv) * C * 2 * st.inner + int64_t(st.w) * st.inner * C +
                     int64_t(st.w) * 8 * C * C + int64_t(2) * st.heads * st.w * st.wkv * 64 +

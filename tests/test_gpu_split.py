@@ -19,19 +19,31 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _engine(K, dev, split, min_bq=20):
-    """an engine over fresh module objects (a module creates its C-ABI handle once; the switch is read then)"""
+def _engine(K, dev, split, min_bq=20, cvt_split=None, cvt_cfg=None):
+    """an engine over fresh module objects (a module creates its C-ABI handle once; the switches are read then)"""
     from clairs_to_amd.engine import Engine, synthetic_models
     from clairs_to_amd.synth import likelihood_table, lik_and_edges
-    models = synthetic_models(K)
+    models = synthetic_models(K, cvt_cfg=cvt_cfg)
     lik, edges = lik_and_edges(likelihood_table(K), K)
     if split:
         os.environ["CTO_GRU_SPLIT"] = split
+    if cvt_split:
+        os.environ["CTO_CVT_SPLIT"] = cvt_split
     try:
         eng = Engine(models["aff"], models["neg"], lik, edges, min_bq=min_bq, device=dev)
     finally:
         os.environ.pop("CTO_GRU_SPLIT", None)
+        os.environ.pop("CTO_CVT_SPLIT", None)
     return eng, models, lik, edges
+
+
+def _aff_logits(eng, x_aff, B, K, dev):
+    import torch
+    from clairs_to_amd._lib import lib, check
+    out = torch.empty((K, B, 2), device=dev)
+    check(lib.cto_model_forward(eng.h_aff, x_aff.data_ptr(), B, out.data_ptr(), int(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
 
 
 def _neg_logits(eng, x_neg, B, K, dev):
@@ -86,7 +98,56 @@ def test_split_kernel_against_the_oracle_and_the_f32_kernel(dev, oracle_lib, kin
     np.testing.assert_array_equal(_neg_logits(e32, fb.x_neg, 4096, K, dev), full32)
 
 
+@pytest.mark.parametrize("kind,tol_logit", [("f16", 5e-5), ("bf16", 5e-4)])
+@pytest.mark.parametrize("K,default_cfg", [(4, False), (6, False), (4, True)])
+def test_split_cvt_blocks_against_the_oracle_and_the_f32_kernels(dev, oracle_lib, kind, tol_logit, K, default_cfg):
+    """CTO_CVT_SPLIT: the block GEMMs of the 64- and 128-channel stages on split operands (the predict.py configuration and the
+    constructor-default one, whose ten stage-3 blocks run as three launches): AFF logits against the oracle on 160 sites and
+    against the fp32 kernels on a full chunk and ragged batches; probabilities within the path's 1e-4, decisions equal.
+    The 13-block configuration gets four times the logit tolerance (measured: 1e-4 for f16 over 4096 sites - operands below
+    ~0.1 have a subnormal f16 lo half, i.e. an absolute 3e-8 instead of a relative 2^-22)."""
+    if default_cfg:
+        tol_logit *= 4
+    import torch
+    import oracle
+    from clairs_to_amd.engine import CVT_CONSTRUCTOR_CFG
+    from clairs_to_amd.featurize import featurize
+    from clairs_to_amd.synth import SynthChunk, mpileup_text
+    cfg = CVT_CONSTRUCTOR_CFG if default_cfg else None
+    ocfg = dict(emb_dim=(32, 64, 128), heads=(1, 3, 6), depth=(1, 2, 10), n_out=K) if default_cfg else dict(CVT_CFG, n_out=K)
+    e32, models, lik, edges = _engine(K, dev, None, cvt_cfg=cfg)
+    esp, _, _, _ = _engine(K, dev, kind, cvt_split=kind, cvt_cfg=cfg)
+    small = SynthChunk(160, seed=5)
+    ref, lo = small.ref_window()
+    ta, da, _, _ = oracle.create_tensor(mpileup_text(small, 20), ref, lo, small.site_pos)
+    tn, dn, _, _ = oracle.create_tensor(mpileup_text(small, 0), ref, lo, small.site_pos)
+    la = oracle.cvt_forward(models["aff_weights"], ocfg, oracle.rescale(ta, da))
+    ln = oracle.bigru_forward(models["neg_weights"], K, oracle.rescale(tn, dn))
+    probs, post, dec, qual = oracle.posterior(la, ln, lik, edges)
+    got = esp.run_chunk(small.arrays(), small.site_pos)
+    torch.cuda.synchronize()
+    assert float(np.abs(got["probs"].cpu().numpy() - probs).max()) < 1e-4
+    np.testing.assert_array_equal(got["decision"].cpu().numpy()[:, :2] & 3, np.asarray(dec)[:, :2] & 3)
+    dp = esp.upload(small.arrays())
+    feat = featurize(dp, torch.from_numpy(small.site_pos).to(dev), 20, 50)
+    lg = _aff_logits(esp, feat.x_aff, 160, K, dev)
+    assert np.isfinite(lg).all()
+    assert float(np.abs(lg - np.asarray(la).reshape(lg.shape)).max()) < tol_logit
+    big = SynthChunk(4096, seed=2)
+    dpb = e32.upload(big.arrays())
+    fb = featurize(dpb, torch.from_numpy(big.site_pos).to(dev), 20, 50)
+    full32 = _aff_logits(e32, fb.x_aff, 4096, K, dev)
+    fullsp = _aff_logits(esp, fb.x_aff, 4096, K, dev)
+    assert np.isfinite(fullsp).all()
+    assert float(np.abs(fullsp - full32).max()) < tol_logit
+    for B in (1, 15, 17, 1000):
+        np.testing.assert_array_equal(_aff_logits(esp, fb.x_aff, B, K, dev), fullsp[:, :B])
+    np.testing.assert_array_equal(_aff_logits(e32, fb.x_aff, 4096, K, dev), full32)
+
+
 def test_split_switch_rejects_unknown_kinds(dev):
     from clairs_to_amd._lib import CtoError
     with pytest.raises(CtoError):
         _engine(4, dev, "fp8")
+    with pytest.raises(CtoError):
+        _engine(4, dev, None, cvt_split="fp8")
