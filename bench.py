@@ -177,28 +177,34 @@ def cpu_baseline(chunks, models, lik, edges, min_bq, n_sample, budget_s=12.0):
 
 
 def split_mfma_leg(dev, packs, sites, batch, lik, edges, min_bq, ref_probs, ref_dec, probs_cpu, steps=20, warm=40):
-    """EXPERIMENT, never in `value` (whose arithmetic stays f32): the step with both BiGRU recurrences + fc1 on split 16-bit
-    operands (csrc/gru_split_kernel.h, CTO_GRU_SPLIT=f16|bf16 at model creation: a = hi + lo, three f16 / bf16 MFMA passes per
-    product, fp32 accumulation, state and gates fp32).  Per kind: the step's rate, the two recurrent kernels' times, and how far
-    its probabilities are from the f32 path's on a whole chunk and (when the cpu_baseline leg ran) from the CPU port's on its sample."""
+    """EXPERIMENT, never in `value` (whose arithmetic stays f32): the step with both BiGRU recurrences + fc1 and the CvT's block
+    GEMMs (64- and 128-channel stages) on split 16-bit operands (csrc/split_mfma.h, gru_split_kernel.h, cvt_gemm.h;
+    CTO_GRU_SPLIT / CTO_CVT_SPLIT = f16|bf16 at model creation: a = hi + lo, three f16 / bf16 MFMA passes per product, fp32
+    accumulation; states, gates, LayerNorm, softmax, residual stream fp32).  Per kind: the step's rate, the network kernels' times,
+    and how far its probabilities are from the f32 path's on a whole chunk and (when the cpu_baseline leg ran) from the CPU port's
+    on its sample."""
     import ctypes as C
     import numpy as np
     import torch
     from clairs_to_amd._lib import lib, check
     from clairs_to_amd.engine import Engine, synthetic_models
-    out = {"note": "side channel: split-operand MFMA for the two BiGRU recurrences + fc1 (75 % of the f32 step); the CvT and everything "
-                   "else run the f32 product kernels; tests/test_gpu_split.py holds both kinds to the oracle within the 1e-4 tolerance"}
+    out = {"note": "side channel: split-operand MFMA for the two BiGRU recurrences + fc1 and the CvT block GEMMs; embedding, classifier, "
+                   "stage-1 block and everything outside the networks run the f32 product kernels; tests/test_gpu_split.py holds both kinds "
+                   "to the oracle within the 1e-4 tolerance"}
     pool = len(packs)
     for kind in ("f16", "bf16"):
         models = synthetic_models(N_OUT, seed=0)          # fresh module objects: the switch is read when a module creates its handle
         os.environ["CTO_GRU_SPLIT"] = kind
+        os.environ["CTO_CVT_SPLIT"] = kind
         try:
             eng = Engine(models["aff"], models["neg"], lik, edges, min_bq=min_bq, device=dev)
         finally:
             os.environ.pop("CTO_GRU_SPLIT", None)
+            os.environ.pop("CTO_CVT_SPLIT", None)
         for i in range(warm):
             eng.run_device(packs[i % pool], sites[i % pool])
         check(lib.cto_model_profile(eng.h_neg, 2))
+        check(lib.cto_model_profile(eng.h_aff, 1))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
@@ -207,8 +213,11 @@ def split_mfma_leg(dev, packs, sites, batch, lik, edges, min_bq, ref_probs, ref_
         e1.record()
         torch.cuda.synchronize()
         check(lib.cto_model_profile(eng.h_neg, 0))
+        check(lib.cto_model_profile(eng.h_aff, 0))
         ms = e0.elapsed_time(e1) / steps
         l2_ms, l2_macs, l1_ms, l1_macs = C.c_double(0.0), C.c_int64(0), C.c_double(0.0), C.c_int64(0)
+        cvt_ms, cvt_macs = C.c_double(0.0), C.c_int64(0)
+        check(lib.cto_model_profile_read(eng.h_aff, C.byref(cvt_ms), C.byref(cvt_macs)))
         check(lib.cto_model_profile_read(eng.h_neg, C.byref(l2_ms), C.byref(l2_macs)))
         check(lib.cto_model_profile_read_stage(eng.h_neg, 1, C.byref(l1_ms), C.byref(l1_macs)))
         got = eng.run_device(packs[0], sites[0])
@@ -216,7 +225,7 @@ def split_mfma_leg(dev, packs, sites, batch, lik, edges, min_bq, ref_probs, ref_
         dec = got["decision"].cpu().numpy()
         tf = 2.0 * l2_macs.value * batch / (l2_ms.value * 1e-3) / 1e12
         o = {"sites_per_s": round(batch / (ms * 1e-3), 1), "ms_per_step": round(ms, 4), "steps": steps,
-             "gru_l2_ms": round(l2_ms.value, 4), "gru_l2_algorithmic_tflops": round(tf, 1), "gru_l1_ms": round(l1_ms.value, 4),
+             "gru_l2_ms": round(l2_ms.value, 4), "gru_l2_algorithmic_tflops": round(tf, 1), "gru_l1_ms": round(l1_ms.value, 4), "cvt_ms": round(cvt_ms.value, 4),
              "max_abs_dP_vs_f32_path": float(np.abs(probs - ref_probs).max()), "sites_compared": int(probs.shape[0]),
              "decisions_differing_from_f32_path": int(((dec[:, :2] & 3) != (ref_dec[:, :2] & 3)).any(axis=1).sum())}
         if probs_cpu is not None:

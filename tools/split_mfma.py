@@ -20,10 +20,12 @@ def neg_engine(n_out, lik, edges, dev, split):
     models = synthetic_models(n_out)
     if split:
         os.environ["CTO_GRU_SPLIT"] = split
+        os.environ["CTO_CVT_SPLIT"] = split
     try:
         return Engine(models["aff"], models["neg"], lik, edges, min_bq=20, device=dev)
     finally:
         os.environ.pop("CTO_GRU_SPLIT", None)
+        os.environ.pop("CTO_CVT_SPLIT", None)
 
 
 def measure(batch=4096, reps=40, oracle_sites=96, n_out=4):
@@ -43,7 +45,7 @@ def measure(batch=4096, reps=40, oracle_sites=96, n_out=4):
     sp = torch.from_numpy(ch.site_pos).to(dev)
     feat = featurize(dp, sp, 20, 50)
     s = int(torch.cuda.current_stream().cuda_stream)
-    out, res = {}, {"batch": batch, "reps": reps}
+    out, out_aff, res = {}, {}, {"batch": batch, "reps": reps}
     for name, eng in engs.items():
         ln = torch.empty((n_out, batch, 2), device=dev)
         fn = lambda: check(lib.cto_model_forward(eng.h_neg, feat.x_neg.data_ptr(), batch, ln.data_ptr(), s))
@@ -67,13 +69,26 @@ def measure(batch=4096, reps=40, oracle_sites=96, n_out=4):
             eng.run_device(dp, sp)
         e1.record()
         torch.cuda.synchronize()
+        step_ms = e0.elapsed_time(e1) / reps
         out[name] = ln.cpu().numpy()
-        res[name] = {"gru_l2_ms": ms.value, "gru_l1_ms": ms1.value, "step_ms": e0.elapsed_time(e1) / reps,
-                     "sites_per_s": batch / (e0.elapsed_time(e1) / reps) * 1e3}
+        la = torch.empty((n_out, batch, 2), device=dev)
+        fa = lambda: check(lib.cto_model_forward(eng.h_aff, feat.x_aff.data_ptr(), batch, la.data_ptr(), s))
+        for _ in range(5):
+            fa()
+        e0.record()
+        for _ in range(reps):
+            fa()
+        e1.record()
+        torch.cuda.synchronize()
+        aff_ms = e0.elapsed_time(e1) / reps
+        out_aff[name] = la.cpu().numpy()
+        res[name] = {"cvt_ms": aff_ms, "gru_l2_ms": ms.value, "gru_l1_ms": ms1.value, "step_ms": step_ms,
+                     "sites_per_s": batch / step_ms * 1e3}
         del step
     for name in engs:
         if name != "f32":
             res[name]["neg_max_abs_dlogit_vs_f32_kernel"] = float(np.abs(out[name] - out["f32"]).max())
+            res[name]["aff_max_abs_dlogit_vs_f32_kernel"] = float(np.abs(out_aff[name] - out_aff["f32"]).max())
             res[name]["l2_speedup"] = res["f32"]["gru_l2_ms"] / res[name]["gru_l2_ms"]
     if oracle_sites:
         import oracle
@@ -97,6 +112,9 @@ def measure(batch=4096, reps=40, oracle_sites=96, n_out=4):
             check(lib.cto_model_forward(eng.h_neg, sfeat.x_neg.data_ptr(), oracle_sites, lg.data_ptr(), s))
             torch.cuda.synchronize()
             res[name]["neg_max_abs_dlogit_vs_oracle"] = float(np.abs(lg.cpu().numpy() - np.asarray(ln).reshape(lg.shape)).max())
+            check(lib.cto_model_forward(eng.h_aff, sfeat.x_aff.data_ptr(), oracle_sites, lg.data_ptr(), s))
+            torch.cuda.synchronize()
+            res[name]["aff_max_abs_dlogit_vs_oracle"] = float(np.abs(lg.cpu().numpy() - np.asarray(la).reshape(lg.shape)).max())
         res["oracle_sites"] = oracle_sites
     return res
 
