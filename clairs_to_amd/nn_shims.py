@@ -10,6 +10,7 @@ the same tuple of K float32 [B,2] logit tensors that clairs/predict.py:646-658 u
 `install_reference_aliases()` registers this module as `clairs.model` so reference pickles unpickle onto it.
 """
 import ctypes as C
+import os
 import sys
 import types
 
@@ -80,8 +81,12 @@ class _HipNet(nn.Module):
     def _cfg(self):
         raise NotImplementedError
 
+    # EXPERIMENTAL, off by default: "f16" or "bf16" runs this network's GEMMs on split 16-bit operands (three MFMA passes per
+    # product, fp32 accumulation).  Set it before the first forward, or any time: the handle is rebuilt.
+    split_operands = None
+
     def _weights_version(self):
-        return tuple((k, int(v._version), v.data_ptr()) for k, v in self.state_dict().items())
+        return (self.split_operands,) + tuple((k, int(v._version), v.data_ptr()) for k, v in self.state_dict().items())
 
     def _handle(self, slot="_cto_state"):
         """the C-ABI model handle of this module's current weights (rebuilt when they change).  A handle's activation workspace
@@ -100,11 +105,23 @@ class _HipNet(nn.Module):
                 a = np.ascontiguousarray(v.detach().to("cpu", torch.float32).numpy())
                 check(lib.cto_weights_add(w, k.encode(), a.ctypes.data, a.size))
             out = c_vp()
-            if self._kind == "cvt":
-                cfg = self._cfg()
-                check(lib.cto_cvt_create(w, C.byref(cfg), C.byref(out)))
-            else:
-                check(lib.cto_bigru_create(w, len(self._heads_out), C.byref(out)))
+            # the C ABI reads the experimental switch from the environment when a handle is created
+            var = "CTO_CVT_SPLIT" if self._kind == "cvt" else "CTO_GRU_SPLIT"
+            saved = os.environ.get(var)
+            if self.split_operands:
+                os.environ[var] = str(self.split_operands)
+            try:
+                if self._kind == "cvt":
+                    cfg = self._cfg()
+                    check(lib.cto_cvt_create(w, C.byref(cfg), C.byref(out)))
+                else:
+                    check(lib.cto_bigru_create(w, len(self._heads_out), C.byref(out)))
+            finally:
+                if self.split_operands:
+                    if saved is None:
+                        os.environ.pop(var, None)
+                    else:
+                        os.environ[var] = saved
         finally:
             lib.cto_weights_free(w)
         self.__dict__[slot] = (ver, c_vp(out.value))

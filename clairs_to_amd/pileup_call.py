@@ -24,7 +24,7 @@ from .create_tensor_pileup_calling import EXPAND_REF, MAX_INDEL, load_pack, read
 from .engine import Engine
 from .fasta import read_region
 from .featurize import alt_infos_from_host
-from .predict import load_models, str2bool
+from .predict import load_models, str2bool, SPLIT_HELP
 from .platforms import resolve_platform
 
 
@@ -184,6 +184,7 @@ def add_common_arguments(p):
     p.add_argument("--chkpnt_fn_nacgt", type=str, required=True)
     p.add_argument("--min_rescale_cov", type=int, default=50)
     p.add_argument("--disable_indel_calling", type=str2bool, default=False)
+    p.add_argument("--split_operands", type=str, default=None, choices=["f16", "bf16"], help=SPLIT_HELP)
     p.add_argument("--likelihood_matrix_data", type=str, required=True)
     p.add_argument("--sample_name", type=str, default="SAMPLE")
     p.add_argument("--show_ref", action="store_true")

@@ -60,6 +60,11 @@ def strand_counts(raw):
     return out
 
 
+SPLIT_HELP = ("EXPERIMENTAL, not in the reference: run the networks' GEMMs on split 16-bit operands (hi + lo, three f16 / bf16 MFMA "
+              "passes per product, fp32 accumulation) - about twice the network throughput, probabilities within ~1e-5 (f16) of the "
+              "default fp32 kernels'; the default computes in fp32 like the reference")
+
+
 def load_models(args, device):
     nn_shims.install_reference_aliases()      # reference pickles name clairs.model.<cls>
     aff = torch.load(args.chkpnt_fn_acgt, map_location="cpu", weights_only=False)["model_acgt"]
@@ -71,6 +76,7 @@ def load_models(args, device):
     for m in (aff, neg):
         if not isinstance(m, nn_shims._HipNet):
             raise TypeError("checkpoint does not hold a clairs.model network (got %s)" % type(m).__name__)
+        m.split_operands = getattr(args, "split_operands", None)      # experimental, off by default
     return aff.eval(), neg.eval()
 
 
@@ -121,6 +127,7 @@ def main():
     p.add_argument("--disable_indel_calling", type=str2bool, default=False)
     p.add_argument("--use_gpu", type=str2bool, default=True)
     p.add_argument("--pileup", action="store_true")
+    p.add_argument("--split_operands", type=str, default=None, choices=["f16", "bf16"], help=SPLIT_HELP)
     predict(p.parse_args())
 
 

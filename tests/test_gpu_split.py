@@ -151,3 +151,34 @@ def test_split_switch_rejects_unknown_kinds(dev):
         _engine(4, dev, "fp8")
     with pytest.raises(CtoError):
         _engine(4, dev, None, cvt_split="fp8")
+
+
+def test_native_pipeline_with_split_operands_calls_the_same_variants(tmp_path):
+    """The experimental switch through the product pipeline (module.split_operands -> cto_run_chunks): same records as the fp32
+    run - position, alleles, genotype, filter - and QUAL within 0.01 (a probability moves by ~1e-5, QUAL = -10 log10(1 - p))."""
+    from clairs_to_amd.call_chunks import run_pipeline_native
+    from clairs_to_amd.e2e import chunk_namespaces
+    from clairs_to_amd.engine import Engine, synthetic_models
+    from clairs_to_amd.synth import likelihood_table, lik_and_edges
+    from clairs_to_amd.synth_run import make_text_run
+    run = make_text_run(str(tmp_path / "run"), n_chunks=2, sites_per_chunk=2048, distinct=2)
+    lik, edges = lik_and_edges(likelihood_table(4), 4)
+    rows = {}
+    for name, kind in (("f32", None), ("f16", "f16")):
+        models = synthetic_models(4, seed=0)
+        for m in (models["aff"], models["neg"]):
+            m.split_operands = kind
+        eng = Engine(models["aff"], models["neg"], lik, edges, min_bq=20, device="cuda:0")
+        os.makedirs(tmp_path / name)
+        n = run_pipeline_native(eng, chunk_namespaces(run, str(tmp_path / name)), producers=2, writers=2, verbose=False)
+        assert n > 500
+        rows[name] = []
+        for fn in sorted(os.listdir(tmp_path / name)):
+            rows[name] += [ln.rstrip("\n").split("\t") for ln in open(tmp_path / name / fn) if not ln.startswith("#")]
+    assert len(rows["f32"]) == len(rows["f16"])
+    worst = 0.0
+    for a, b in zip(rows["f32"], rows["f16"]):
+        assert a[:5] == b[:5] and a[6] == b[6], (a, b)                       # CHROM POS ID REF ALT, FILTER
+        assert a[9].split(":")[0] == b[9].split(":")[0], (a, b)              # GT
+        worst = max(worst, abs(float(a[5]) - float(b[5])))
+    assert worst < 0.01, worst
