@@ -182,3 +182,44 @@ def test_native_pipeline_with_split_operands_calls_the_same_variants(tmp_path):
         assert a[9].split(":")[0] == b[9].split(":")[0], (a, b)              # GT
         worst = max(worst, abs(float(a[5]) - float(b[5])))
     assert worst < 0.01, worst
+
+
+@pytest.mark.parametrize("default_cfg", [False, True])
+def test_split_error_report_against_the_oracle(dev, oracle_lib, default_cfg):
+    """Where each arithmetic stands against the oracle on the same 160 sites (printed with -s; profiles/round4_split_mfma_oracle.txt):
+    max |d logit| of both networks and max |dP|, for the fp32 kernels, f16 halves and bf16 halves.  Asserted: every kind inside
+    the path's 1e-4 on probabilities, and f16 no further from the oracle than twice the fp32 kernels are (plus 1e-5)."""
+    import torch
+    import oracle
+    from clairs_to_amd.engine import CVT_CONSTRUCTOR_CFG
+    from clairs_to_amd.featurize import featurize
+    from clairs_to_amd.synth import SynthChunk, mpileup_text
+    K = 4
+    cfg = CVT_CONSTRUCTOR_CFG if default_cfg else None
+    ocfg = dict(emb_dim=(32, 64, 128), heads=(1, 3, 6), depth=(1, 2, 10), n_out=K) if default_cfg else dict(CVT_CFG, n_out=K)
+    small = SynthChunk(160, seed=5)
+    ref, lo = small.ref_window()
+    ta, da, _, _ = oracle.create_tensor(mpileup_text(small, 20), ref, lo, small.site_pos)
+    tn, dn, _, _ = oracle.create_tensor(mpileup_text(small, 0), ref, lo, small.site_pos)
+    rep = {}
+    for kind in (None, "f16", "bf16"):
+        eng, models, lik, edges = _engine(K, dev, kind, cvt_split=kind, cvt_cfg=cfg)
+        if kind is None:
+            la = oracle.cvt_forward(models["aff_weights"], ocfg, oracle.rescale(ta, da))
+            ln = oracle.bigru_forward(models["neg_weights"], K, oracle.rescale(tn, dn))
+            probs, post, dec, qual = oracle.posterior(la, ln, lik, edges)
+        got = eng.run_chunk(small.arrays(), small.site_pos)
+        torch.cuda.synchronize()
+        dp = eng.upload(small.arrays())
+        feat = featurize(dp, torch.from_numpy(small.site_pos).to(dev), 20, 50)
+        ga, gn = _aff_logits(eng, feat.x_aff, 160, K, dev), _neg_logits(eng, feat.x_neg, 160, K, dev)
+        rep[kind or "f32"] = {"aff_dlogit": float(np.abs(ga - np.asarray(la).reshape(ga.shape)).max()),
+                              "neg_dlogit": float(np.abs(gn - np.asarray(ln).reshape(gn.shape)).max()),
+                              "dP": float(np.abs(got["probs"].cpu().numpy() - probs).max())}
+    print("\nvs oracle, 160 sites, %s CvT:" % ("constructor-default (13 blocks)" if default_cfg else "predict.py (6 blocks)"))
+    for k, v in rep.items():
+        print("  %-5s max|d logit| AFF %.3g  NEG %.3g   max|dP| %.3g" % (k, v["aff_dlogit"], v["neg_dlogit"], v["dP"]))
+    for k, v in rep.items():
+        assert v["dP"] < 1e-4, (k, v)
+    for net in ("aff_dlogit", "neg_dlogit"):
+        assert rep["f16"][net] <= 2 * rep["f32"][net] + 1e-5, rep
