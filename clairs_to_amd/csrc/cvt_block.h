@@ -634,19 +634,20 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
         constexpr int K1 = G::KCH1;
         float* t1 = smem + G::OFF_YKV + 64;
         float* t2 = t1 + 16 * HEAD_T1S;
-        const float* w1_r1[1] = {p.w1p + int64_t(wave * 16 + j) * (K1 * 16) + 4 * kg};
+        const float* w1_r1[1] = {p.w1p + int64_t(wave) * (K1 * 256) + 4 * lane};       // this wave's n-tile, fragment order
         BGroup<1, 7> g0;
-        load_group<1, K1, 7>(g0, w1_r1, 0);
+        load_group<1, K1, 7, 256>(g0, w1_r1, 0);
         lds_barrier();
         stamp();
         f32x4 a1[2][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}, {f32x4{0.f, 0.f, 0.f, 0.f}}};
-        gemm_m1<1, K1, 7>(sy, W * RS, w1_r1, g0, a1, j, kg);
+        HeadPre hpre;
+        gemm_m1<1, K1, 7, 256>(sy, W * RS, w1_r1, g0, a1, j, kg, [&] { head_prefetch(hpre, hp); });
         const float bv = p.b1h[wave * 16 + j];
 #pragma unroll
         for (int r = 0; r < 4; ++r) t1[(4 * kg + r) * HEAD_T1S + wave * 16 + j] = selu_fast(a1[0][0][r] + a1[1][0][r] + bv);
         lds_barrier();
         stamp();
-        head_tail(t1, t2, hp, B, site0, nsite);
+        head_tail(t1, t2, hp, B, site0, nsite, hpre);
     }
     stamp();
 }

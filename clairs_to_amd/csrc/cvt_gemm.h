@@ -15,7 +15,7 @@ struct CvtBlockParams {
     // first block of a stage (CIN > 0): the stage's conv embedding + LayerNorm run here instead of reading h
     const float *xin, *wembp, *bemb, *lng, *lnb;   // x [B][2W-1][CIN]; wembp [C][KCHE*16] (positions padded to PS)
     // last block of the network (HEAD): fc1 + classifier tail run here instead of writing h
-    const float *w1p, *b1h;                        // fc1 [128][KCH1*16] over the LDS image of h (rows padded to RS)
+    const float *w1p, *b1h;                        // fc1 over the LDS image of h (rows padded to RS), fragment order [8][KCH1][64][4]
     // split-operand experiment (CTO_CVT_SPLIT): the five GEMM weights as [hi plane | lo plane] of 16-bit values, row-major [N][K]
     const unsigned short *wq_s, *wkv_s, *wo_s, *w1_s, *w2_s;
 };
@@ -167,13 +167,18 @@ template <int NTW, int DEPTH>
 struct BGroup {
     float4 b[DEPTH][NTW];
 };
-template <int NTW, int KCH, int DEPTH>
+// CS = floats between a lane's fragments of consecutive k chunks: 16 for a row-major W[n][k] (wrow = &W[n0 + j][4 kg]); 256 for a
+// panel stored in FRAGMENT ORDER [n-tile][chunk][lane][4] (wrow = panel + tile * KCH * 256 + 4 lane), where a wave's request is one
+// contiguous 1 KB = eight whole cache lines.  Row-major requests touch sixteen half lines whose other halves the next chunk asks
+// for again after they left the 32 KB L1: a panel that is used once (the classifier's: M = 16 rows per workgroup) then crosses
+// the L2 -> CU path twice.
+template <int NTW, int KCH, int DEPTH, int CS = 16>
 __device__ __forceinline__ void load_group(BGroup<NTW, DEPTH>& g, const float* const (&wrow)[NTW], int c0) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
-            if (c0 + d < KCH) g.b[d][nt] = ldg4(wrow[nt] + (c0 + d) * 16);
+            if (c0 + d < KCH) g.b[d][nt] = ldg4(wrow[nt] + (c0 + d) * CS);
 }
 template <int NTW, int KCH, int DEPTH>
 __device__ __forceinline__ void mfma_group(const BGroup<NTW, DEPTH>& g, const float* Arow, int c0, f32x4 (&acc)[2][NTW]) {
@@ -196,27 +201,41 @@ __device__ __forceinline__ void mfma_group(const BGroup<NTW, DEPTH>& g, const fl
         }
     }
 }
+// `under_last` runs right after the last group's loads have been requested: whatever it requests (the classifier tail's fc2
+// weights) queues behind this GEMM's own stream and arrives while its last MFMA groups run.
+template <int NTW, int KCH, int DEPTH, int CS, typename F>
+__device__ __forceinline__ void gemm_m1(const float* __restrict__ A, int lda, const float* const (&wrow)[NTW],
+                                        const BGroup<NTW, DEPTH>& first, f32x4 (&acc)[2][NTW], int j, int kg, F&& under_last) {
+    constexpr int NG = (KCH + DEPTH - 1) / DEPTH;
+    const float* Arow = A + j * lda + 4 * kg;
+    // groups are requested TWO ahead of their MFMAs (every workgroup of the launch streams the same panel at the same time:
+    // an L2 round trip under that load is longer than one group's 28 MFMAs)
+    BGroup<NTW, DEPTH> g[3];
+    g[0] = first;
+    if (NG > 1) load_group<NTW, KCH, DEPTH, CS>(g[1], wrow, DEPTH);
+    if (NG <= 2) under_last();
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        if (i + 2 < NG) {
+            load_group<NTW, KCH, DEPTH, CS>(g[(i + 2) % 3], wrow, (i + 2) * DEPTH);
+            if (i + 3 == NG) under_last();
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep the requests ahead of this group's MFMAs
+        mfma_group<NTW, KCH, DEPTH>(g[i % 3], Arow, i * DEPTH, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 template <int NTW, int KCH, int DEPTH>
 __device__ __forceinline__ void gemm_m1(const float* __restrict__ A, int lda, const float* const (&wrow)[NTW],
                                         const BGroup<NTW, DEPTH>& first, f32x4 (&acc)[2][NTW], int j, int kg) {
-    constexpr int NG = (KCH + DEPTH - 1) / DEPTH;
-    const float* Arow = A + j * lda + 4 * kg;
-    BGroup<NTW, DEPTH> g[2];
-    g[0] = first;
-#pragma unroll
-    for (int i = 0; i < NG; ++i) {
-        if (i + 1 < NG) load_group<NTW, KCH, DEPTH>(g[(i + 1) & 1], wrow, (i + 1) * DEPTH);
-        __builtin_amdgcn_sched_barrier(0);      // keep the next group's loads ahead of this group's MFMAs
-        mfma_group<NTW, KCH, DEPTH>(g[i & 1], Arow, i * DEPTH, acc);
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    gemm_m1<NTW, KCH, DEPTH, 16>(A, lda, wrow, first, acc, j, kg, [] {});
 }
 
 // ---- classifier tail shared by both networks (clairs/model.py:245-261, 451-467): K heads of fc2 (128 -> 128) -> SELU ->
 // fc3 (128 -> 2) -> SELU on a 16-site tile whose SELU(fc1) activations sit in LDS.  8 waves; wave w owns hidden units
 // [16w, 16w+16) of every head, two heads per pass (two independent accumulators keep the matrix pipe at issue rate).
 struct HeadTailParams {
-    const float *w2, *b2;   // [K*128][128], [K*128]
+    const float *w2, *b2;   // fc2 in fragment order [K heads][8 n-tiles][8 chunks][64 lanes][4] (pack_fragments), [K*128]
     const float *w3, *b3;   // [K][2][128], [K][2]
     float* logits;          // [K][B][2]
     int K;
@@ -225,33 +244,45 @@ constexpr int HEAD_T1S = 132;                       // LDS row stride of the fc1
 __host__ __device__ constexpr int head_t2s(int K) { return K * 128 + 4; }
 __host__ __device__ constexpr int head_lds_floats(int K) { return 16 * HEAD_T1S + 16 * head_t2s(K); }
 
+// The fc2 weights of the first two head pairs, requested ahead of the tail (they depend on nothing the tail computes: a caller
+// asks for them under whatever precedes it - fc1's last MFMA groups, the slab sums)
+struct HeadPre {
+    BGroup<2, 8> g[2];
+};
+__device__ __forceinline__ void head_prefetch(HeadPre& hpre, const HeadTailParams& hp) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
+    const float* w0 = hp.w2 + int64_t(wave) * (8 * 256) + 4 * lane;      // this wave's n-tile of head 0
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+        const float* wr[2] = {w0 + pi * 2 * 128 * 128, w0 + (pi * 2 + 1) * 128 * 128};
+        load_group<2, 8, 8, 256>(hpre.g[pi], wr, 0);
+    }
+}
+
 // t1: [16][HEAD_T1S] (in), t2: [16][head_t2s(K)] scratch.  All 512 threads call; ends without a barrier.
 template <int K>
 __device__ __forceinline__ void head_tail_k(const float* t1, float* t2, const HeadTailParams& hp, int64_t B, int64_t site0,
-                                            int nsite) {
+                                            int nsite, HeadPre& hpre) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
     constexpr int T2S = head_t2s(K);
-    static_assert(K % 2 == 0, "heads are processed in pairs");
+    static_assert(K % 2 == 0 && K >= 4, "heads are processed in pairs; two pairs arrive prefetched");
     const float* wr[2];
-    wr[0] = hp.w2 + int64_t(wave * 16 + j) * 128 + 4 * kg;
+    wr[0] = hp.w2 + int64_t(wave) * (8 * 256) + 4 * lane;
     wr[1] = wr[0] + 128 * 128;
-    BGroup<2, 8> g[2];
-    load_group<2, 8, 8>(g[0], wr, 0);
     const float* Arow = t1 + j * HEAD_T1S + 4 * kg;
 #pragma unroll
     for (int pi = 0; pi < K / 2; ++pi) {
-        if (pi + 1 < K / 2) {        // the next pair of heads' weights fly under this pair's MFMAs
-            const float* wn[2] = {wr[0] + (pi + 1) * 2 * 128 * 128, wr[1] + (pi + 1) * 2 * 128 * 128};
-            load_group<2, 8, 8>(g[(pi + 1) & 1], wn, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
         f32x4 acc[2][2];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int q = 0; q < 2; ++q) acc[a][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        mfma_group<2, 8, 8>(g[pi & 1], Arow, 0, acc);
+        mfma_group<2, 8, 8>(hpre.g[pi & 1], Arow, 0, acc);
         __builtin_amdgcn_sched_barrier(0);
+        if (pi + 2 < K / 2) {        // a third pair (K = 6): its weights take the slot this pair just freed
+            const float* wn[2] = {wr[0] + (pi + 2) * 2 * 128 * 128, wr[1] + (pi + 2) * 2 * 128 * 128};
+            load_group<2, 8, 8, 256>(hpre.g[pi & 1], wn, 0);
+        }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int col = (pi * 2 + q) * 128 + wave * 16 + j;
@@ -279,9 +310,9 @@ __device__ __forceinline__ void head_tail_k(const float* t1, float* t2, const He
     }
 }
 __device__ __forceinline__ void head_tail(const float* t1, float* t2, const HeadTailParams& hp, int64_t B, int64_t site0,
-                                          int nsite) {
-    if (hp.K == 4) head_tail_k<4>(t1, t2, hp, B, site0, nsite);
-    else head_tail_k<6>(t1, t2, hp, B, site0, nsite);
+                                          int nsite, HeadPre& hpre) {
+    if (hp.K == 4) head_tail_k<4>(t1, t2, hp, B, site0, nsite, hpre);
+    else head_tail_k<6>(t1, t2, hp, B, site0, nsite, hpre);
 }
 
 // Stand-alone classifier tail for fc1 partial sums that already sit in HBM (BiGRU: one slab per direction from the fused
@@ -293,6 +324,8 @@ __global__ __launch_bounds__(512) void k_head(const float* __restrict__ slabs, i
     float* t2 = smem + 16 * HEAD_T1S;
     const int64_t site0 = int64_t(blockIdx.x) * 16;
     const int nsite = int(min(int64_t(16), B - site0));
+    HeadPre hpre;
+    head_prefetch(hpre, hp);       // the fc2 weights fly under the slab sums
     {
         const int site = threadIdx.x >> 5, c4 = (threadIdx.x & 31) * 4;     // 512 threads = 16 sites x 32 float4
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -306,8 +339,8 @@ __global__ __launch_bounds__(512) void k_head(const float* __restrict__ slabs, i
         *reinterpret_cast<float4*>(t1 + site * HEAD_T1S + c4) =
             make_float4(selu_fast(v.x + bb.x), selu_fast(v.y + bb.y), selu_fast(v.z + bb.z), selu_fast(v.w + bb.w));
     }
-    __syncthreads();
-    head_tail(t1, t2, hp, B, site0, nsite);
+    lds_barrier();                 // LDS hand-over only: the prefetched weights stay in flight
+    head_tail(t1, t2, hp, B, site0, nsite, hpre);
 }
 
 

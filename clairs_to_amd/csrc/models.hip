@@ -133,6 +133,20 @@ const std::vector<float>* find(const cto_weights* w, const std::string& name, in
     const std::vector<float>* var = find(w, (name), (numel), &rc); \
     if (!var) return rc;
 
+// a row-major panel W[ntiles * 16][kch * 16] in the order the MFMA lanes read it: [n-tile][16-wide k chunk][lane = (kg << 4) | j][4],
+// lane (j, kg) holding W[tile * 16 + j][16 c + 4 kg .. + 3] - a wave's request becomes one contiguous 1 KB (cvt_gemm.h: load_group)
+std::vector<float> pack_fragments(const float* W, int ntiles, int kch) {
+    std::vector<float> f(size_t(ntiles) * kch * 256);
+    for (int t = 0; t < ntiles; ++t)
+        for (int c = 0; c < kch; ++c)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int j = lane & 15, kg = lane >> 4;
+                for (int e = 0; e < 4; ++e)
+                    f[((size_t(t) * kch + c) * 64 + lane) * 4 + e] = W[size_t(t * 16 + j) * (kch * 16) + c * 16 + 4 * kg + e];
+            }
+    return f;
+}
+
 int build_head(const cto_weights* w, const char* const* names, int K, int k1, const std::vector<float>& w1perm,
                Arena& a, HeadDev& h) {
     int rc = CTO_OK;
@@ -147,7 +161,8 @@ int build_head(const cto_weights* w, const char* const* names, int K, int k1, co
         GETW(f2b, p + "_fc2.bias", 128);
         GETW(f3w, p + "_fc3.weight", 2 * 128);
         GETW(f3b, p + "_fc3.bias", 2);
-        std::copy(f2w->begin(), f2w->end(), w2.begin() + size_t(k) * 128 * 128);
+        const std::vector<float> frag = pack_fragments(f2w->data(), 8, 8);       // the classifier tail reads fc2 in fragment order
+        std::copy(frag.begin(), frag.end(), w2.begin() + size_t(k) * 128 * 128);
         std::copy(f2b->begin(), f2b->end(), b2.begin() + size_t(k) * 128);
         std::copy(f3w->begin(), f3w->end(), w3.begin() + size_t(k) * 256);
         std::copy(f3b->begin(), f3b->end(), b3.begin() + size_t(k) * 2);
@@ -724,7 +739,7 @@ extern "C" int cto_cvt_create(const cto_weights* w, const cto_cvt_cfg* cfg, cto_
             for (int n = 0; n < 128; ++n)
                 for (int ww = 0; ww < W3; ++ww)
                     for (int c = 0; c < C3; ++c) vp[size_t(n) * KP + ww * G::RS + c] = v[size_t(n) * k1 + ww * C3 + c];
-            if ((rc = a.upload(vp, &m->head.w1p))) return fail(rc);
+            if ((rc = a.upload(pack_fragments(vp.data(), 8, G::KCH1), &m->head.w1p))) return fail(rc);     // fragment order
         }
     }
     macs += int64_t(k1) * 128 + int64_t(m->n_out) * (128 * 128 + 256);
