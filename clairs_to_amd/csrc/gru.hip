@@ -14,9 +14,10 @@ namespace {
                            // layer 1 + tail 0.301 -> 0.328 ms at 4096 sites, 1.159 -> 1.260 ms at 16384 (profiles/round4_gru_l1_eight_waves.txt)
 #endif
 
+// W / fc1w: row-major (the plain schedule, CTO_GRU_ROT=0); Wf / fc1f: the same weights in fragment order (the rotated schedule)
 template <int KIN, int KP, int H, int MS, bool FUSE>
-int launch_gru_range(hipStream_t s, const float* x, const float* W, const float* bias, float* out, const float* fc1w,
-                     float* fc1_part, int64_t B, int64_t begin, int64_t end) {
+int launch_gru_range(hipStream_t s, const float* x, const float* W, const float* Wf, const float* bias, float* out, const float* fc1w,
+                     const float* fc1f, float* fc1_part, int64_t B, int64_t begin, int64_t end) {
     if (end <= begin) return CTO_OK;
     const size_t smem = size_t(2) * MS * 16 * ((H + 4) + (KP + 4)) * sizeof(float);   // h tiles + x tiles
     constexpr int NW = FUSE ? 4 : CTO_GRU_NW1;
@@ -32,7 +33,7 @@ int launch_gru_range(hipStream_t s, const float* x, const float* W, const float*
     }
     const unsigned grid = unsigned(cdiv(end - begin, MS * 16)) * 2;
     if (rot)
-        hipLaunchKernelGGL((k_gru_layer_rot<KIN, KP, H, MS, FUSE, NW>), dim3(grid), dim3(64 * NW), smem, s, x, W, bias, out, fc1w, fc1_part,
+        hipLaunchKernelGGL((k_gru_layer_rot<KIN, KP, H, MS, FUSE, NW>), dim3(grid), dim3(64 * NW), smem, s, x, Wf, bias, out, fc1f, fc1_part,
                            int(B), int(begin), int(end));
     else
         hipLaunchKernelGGL((k_gru_layer<KIN, KP, H, MS, 1, FUSE>), dim3(grid), dim3(256), smem, s, x, W, bias, out, fc1w, fc1_part,
@@ -47,8 +48,8 @@ int launch_gru_range(hipStream_t s, const float* x, const float* W, const float*
 // as 16-site tiles, whose workgroups finish in ~0.83x the time (the weight stream per workgroup is the same, the MFMA work is
 // half) and which spread a small batch over twice as many CUs: measured 1.45 -> 1.20 ms for B <= 2048, -3 % for B = 10 000.
 template <int KIN, int KP, int H, bool FUSE>
-int launch_gru(hipStream_t s, const float* x, const float* W, const float* bias, float* out, const float* fc1w, float* fc1_part,
-               int64_t B) {
+int launch_gru(hipStream_t s, const float* x, const float* W, const float* Wf, const float* bias, float* out, const float* fc1w,
+               const float* fc1f, float* fc1_part, int64_t B) {
     static const int cus = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
@@ -57,22 +58,22 @@ int launch_gru(hipStream_t s, const float* x, const float* W, const float* bias,
     const int64_t round32 = int64_t(16) * cus;                   // sites of one round of 32-site tiles (2 directions)
     const int64_t full = (B / round32) * round32;
     const int64_t rest = B - full;
-    int rc = launch_gru_range<KIN, KP, H, 2, FUSE>(s, x, W, bias, out, fc1w, fc1_part, B, 0, full);
+    int rc = launch_gru_range<KIN, KP, H, 2, FUSE>(s, x, W, Wf, bias, out, fc1w, fc1f, fc1_part, B, 0, full);
     if (rc != CTO_OK || rest == 0) return rc;
-    if (rest * 4 > round32 * 3) return launch_gru_range<KIN, KP, H, 2, FUSE>(s, x, W, bias, out, fc1w, fc1_part, B, full, B);
-    return launch_gru_range<KIN, KP, H, 1, FUSE>(s, x, W, bias, out, fc1w, fc1_part, B, full, B);
+    if (rest * 4 > round32 * 3) return launch_gru_range<KIN, KP, H, 2, FUSE>(s, x, W, Wf, bias, out, fc1w, fc1f, fc1_part, B, full, B);
+    return launch_gru_range<KIN, KP, H, 1, FUSE>(s, x, W, Wf, bias, out, fc1w, fc1f, fc1_part, B, full, B);
 }
 
 }  // namespace
 
-int launch_gru_layer1(hipStream_t s, const float* x, const float* W, const float* bias, float* out, int64_t B) {
-    return launch_gru<34, 48, 128, false>(s, x, W, bias, out, nullptr, nullptr, B);
+int launch_gru_layer1(hipStream_t s, const float* x, const float* W, const float* Wf, const float* bias, float* out, int64_t B) {
+    return launch_gru<34, 48, 128, false>(s, x, W, Wf, bias, out, nullptr, nullptr, nullptr, B);
 }
 
 // layer 2 with the head's fc1 folded in: writes one partial [B][128] slab per direction into fc1_part
-int launch_gru_layer2_fc1(hipStream_t s, const float* x, const float* W, const float* bias, const float* fc1w, float* fc1_part,
-                          int64_t B) {
-    return launch_gru<256, 256, 192, true>(s, x, W, bias, nullptr, fc1w, fc1_part, B);
+int launch_gru_layer2_fc1(hipStream_t s, const float* x, const float* W, const float* Wf, const float* bias, const float* fc1w,
+                          const float* fc1f, float* fc1_part, int64_t B) {
+    return launch_gru<256, 256, 192, true>(s, x, W, Wf, bias, nullptr, fc1w, fc1f, fc1_part, B);
 }
 
 // the recurrent layers on split 16-bit operands (experiment behind CTO_GRU_SPLIT=f16|bf16; gru_split_kernel.h): same tiling rule as above

@@ -341,7 +341,6 @@ __global__ __launch_bounds__(64 * NW) void k_gru_layer_rot(const float* __restri
     const int dir = blockIdx.x & 1;
     // the launch covers sites [site_begin, site_end) of a batch of B (sub-ranges let the host mix tile heights, see gru.hip)
     const int site0 = site_begin + (blockIdx.x >> 1) * TILE;
-    const float* Wd = Wcat + int64_t(dir) * 3 * H * KT;
     const float* bd = bias + dir * 4 * H;
     auto t_of = [&](int step) { return dir == 0 ? step : T - 1 - step; };
 #ifdef CTO_GRU_CLOCKS
@@ -355,21 +354,33 @@ __global__ __launch_bounds__(64 * NW) void k_gru_layer_rot(const float* __restri
     for (int i = threadIdx.x; i < TILE * HS; i += NTHR) hbuf[i] = 0.f;       // h_{-1} = 0
     for (int i = threadIdx.x; i < 2 * TILE * XS; i += NTHR) xbuf[i] = 0.f;   // K padding and rows past the batch stay 0
 
+    // Weights arrive in FRAGMENT ORDER (models.hip: pack_gru / pack_fc1_fragments): Wcat = [dir][wave][chunk][nb][gate][lane][4],
+    // fc1w = [dir][t][wave][kh][nt][lane][4], lane (j, kg) holding W[row .. + j][16 c + 4 kg .. + 3] - a wave's request is one
+    // contiguous 1 KB instead of sixteen half cache lines whose other halves the next chunk fetches again
+    static_assert(NW == 4, "the fragment-ordered weights are laid out for four waves");
     float bia[NB][4];
-    const float* wrow[NB][3];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int hcol = (wave * NB + nb) * 16 + j;
 #pragma unroll
         for (int q = 0; q < 4; ++q) bia[nb][q] = bd[q * H + hcol];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) wrow[nb][q] = Wd + int64_t(q * H + hcol) * KT + 4 * kg;
     }
-    const float* frow[2] = {nullptr, nullptr};
-    if constexpr (FUSE_FC1) {
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) frow[nt] = fc1w + int64_t(wave * 32 + nt * 16 + j) * FC1_K + dir * H + 4 * kg;
-    }
+    (void)KT; (void)FC1_K;
+    // requests are buffer loads: wave-uniform resource + scalar offset of the 1 KB unit + one lane offset - no per-lane 64-bit
+    // address arithmetic and no address registers in the time loop
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    constexpr unsigned W_WAVE_BYTES = unsigned(KP / 16 + H / 16) * NB * 3 * 1024u, F_T_BYTES = 4u * (H / 16) * 2 * 1024u;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(Wcat) + (int64_t(dir) * 4 + wave_u) * (W_WAVE_BYTES / 4), 0, int(W_WAVE_BYTES), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(FUSE_FC1 ? fc1w : Wcat) + (FUSE_FC1 ? (int64_t(dir) * T * 4 + wave_u) * ((H / 16) * 2 * 256) : 0), 0,
+        FUSE_FC1 ? int(T * F_T_BYTES) : 0, 0x00020000);
+    auto buf16 = [&](const __amdgpu_buffer_rsrc_t& r, unsigned voffset, unsigned soffset) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, int(voffset), int(soffset), 0);
+        return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+    };
+    unsigned voff = unsigned(lane) * 16u;
     float hprev[MS][NB][4];
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms)
@@ -427,15 +438,18 @@ __global__ __launch_bounds__(64 * NW) void k_gru_layer_rot(const float* __restri
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                if (TAIL1 && c == NX - 1) Bq[buf][nb][q].x = *(wrow[nb][q] - 3 * kg + c * 16 + opq);      // W[n][16 c + kg]
-                else Bq[buf][nb][q] = *reinterpret_cast<const float4*>(wrow[nb][q] + c * 16 + opq);
+                const unsigned unit = unsigned((c * NB + nb) * 3 + q);      // 1 KB units of this wave's stream
+                if (TAIL1 && c == NX - 1)       // W[n][16 c + kg]: the packer put it in element 0
+                    Bq[buf][nb][q].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, int(voff + (unit & 3u) * 1024u), int((unit & ~3u) * 1024u), 0));
+                else Bq[buf][nb][q] = buf16(rw, voff + (unit & 3u) * 1024u, (unit & ~3u) * 1024u);
             }
     };
     auto load_F = [&](int buf, int kh, int tprev) {
         if constexpr (FUSE_FC1) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
-                Fq[buf][nt] = *reinterpret_cast<const float4*>(frow[nt] + tprev * (2 * H) + kh * 16);
+                Fq[buf][nt] = buf16(rf, voff + unsigned((kh * 2 + nt) & 3) * 1024u,
+                                    unsigned(__builtin_amdgcn_readfirstlane(tprev)) * F_T_BYTES + unsigned((kh * 2 + nt) & ~3) * 1024u);
         }
     };
     auto load_Ax = [&](int buf, int c, const float* xc) {
@@ -562,6 +576,7 @@ __global__ __launch_bounds__(64 * NW) void k_gru_layer_rot(const float* __restri
         const float* xnx = xbuf + ((step + 1) & 1) * (TILE * XS);   // x_{t+1}
         opq = 0;
         asm volatile("" : "+v"(opq));      // keeps the (step-invariant) weight loads inside the time loop
+        voff = unsigned(lane + opq) * 16u;
 #ifdef CTO_GRU_CLOCKS
         tph = clock64();
 #endif

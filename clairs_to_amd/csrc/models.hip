@@ -17,12 +17,12 @@ using namespace cto;
 
 // The recurrent kernels live in their own translation unit (gru.hip): co-compiling them with the CvT kernels changed
 // their register allocation and cost up to 4 % from one unrelated edit to the next.
-int launch_gru_layer1(hipStream_t s, const float* x, const float* W, const float* bias, float* out, int64_t B);
+int launch_gru_layer1(hipStream_t s, const float* x, const float* W, const float* Wf, const float* bias, float* out, int64_t B);
 int launch_gru_layer2_fc1_split(hipStream_t s, const float* x, const void* Wp, const float* bias, const void* Fp, float* fc1_part,
                                 int64_t B, bool f16);
 int launch_gru_layer1_split(hipStream_t s, const float* x, const void* Wp, const float* bias, float* out, int64_t B, bool f16);
-int launch_gru_layer2_fc1(hipStream_t s, const float* x, const float* W, const float* bias, const float* fc1w, float* fc1_part,
-                          int64_t B);
+int launch_gru_layer2_fc1(hipStream_t s, const float* x, const float* W, const float* Wf, const float* bias, const float* fc1w,
+                          const float* fc1f, float* fc1_part, int64_t B);
 
 
 struct cto_weights {
@@ -89,6 +89,7 @@ struct cto_model {
     StageDev st[3];
     // BiGRU
     float *gw1 = nullptr, *gb1 = nullptr, *gw2 = nullptr, *gb2 = nullptr;
+    float *gw1f = nullptr, *gw2f = nullptr, *f1f = nullptr;     // the recurrent weights and the fused fc1 in fragment order (rotated kernels)
     float *gw1_split = nullptr, *gw2_split = nullptr, *f1_split = nullptr;     // layer 2 / fc1 as (hi, lo) 16-bit fragments: CTO_GRU_SPLIT=f16|bf16 (experiment)
     bool split_f16 = false;
     int cvt_split = 0;          // CvT block GEMMs on split operands: 0 = fp32 kernels, 1 = f16, 2 = bf16 (CTO_CVT_SPLIT, experiment)
@@ -487,7 +488,7 @@ int bigru_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStr
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (m->prof_all && (rc = prof_begin(m, s, &e0, &e1))) return rc;
     if (m->gw1_split) rc = launch_gru_layer1_split(s, x, m->gw1_split, m->gb1, m->b_h, B, m->split_f16);
-    else rc = launch_gru_layer1(s, x, m->gw1, m->gb1, m->b_h, B);
+    else rc = launch_gru_layer1(s, x, m->gw1, m->gw1f, m->gb1, m->b_h, B);
     if (rc) return rc;
     if (m->prof_all) {
         CTO_HIP(hipEventRecord(e1, s));
@@ -496,7 +497,7 @@ int bigru_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStr
     if (m->prof && (rc = prof_begin(m, s, &e0, &e1))) return rc;
     // layer 2 with the head's fc1 folded in: writes one partial [B][128] slab per direction into b_slab
     if (m->gw2_split) rc = launch_gru_layer2_fc1_split(s, m->b_h, m->gw2_split, m->gb2, m->f1_split, m->b_slab, B, m->split_f16);
-    else rc = launch_gru_layer2_fc1(s, m->b_h, m->gw2, m->gb2, m->head.w1, m->b_slab, B);
+    else rc = launch_gru_layer2_fc1(s, m->b_h, m->gw2, m->gw2f, m->gb2, m->head.w1, m->f1f, m->b_slab, B);
     if (rc) return rc;
     if (m->prof) {
         CTO_HIP(hipEventRecord(e1, s));
@@ -506,10 +507,16 @@ int bigru_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStr
 }
 
 // [W_ih | W_hh] per gate row, W_ih zero-padded to KP; bias rows: r (b_ir + b_hr), z (b_iz + b_hz), b_in, b_hn
-int pack_gru(const cto_weights* w, const std::string& base, int kin, int kp, int H, Arena& a, float** Wout, float** bout) {
+// Wfout: the same weights in the order the rotated kernel's lanes read them, [dir][wave][16-wide chunk][nb][gate][lane][4] with lane
+// (j, kg) holding row  gate * H + (wave * NB + nb) * 16 + j,  k = 16 c + 4 kg .. + 3  of [W_ih (zero-padded to kp) | W_hh]; when the
+// last x chunk holds at most four real channels (layer 1: 34 -> channels 32, 33) it is ONE k-step whose lane group kg holds
+// k = 16 c + kg in element 0 (gru_kernel.h: TAIL1)
+int pack_gru(const cto_weights* w, const std::string& base, int kin, int kp, int H, Arena& a, float** Wout, float** bout, float** Wfout) {
     int rc = CTO_OK;
     const int KT = kp + H + GRU_WPAD;
-    std::vector<float> W(size_t(2) * 3 * H * KT, 0.f), bv(size_t(2) * 4 * H);
+    const int NB = H / 64, NX = kp / 16, NC = NX + H / 16;
+    const bool tail1 = (kin % 16 != 0) && (kin - 16 * (NX - 1) <= 4);
+    std::vector<float> W(size_t(2) * 3 * H * KT, 0.f), bv(size_t(2) * 4 * H), Wf(size_t(2) * 4 * NC * NB * 3 * 256, 0.f);
     for (int d = 0; d < 2; ++d) {
         const std::string sfx = d == 0 ? "" : "_reverse";
         GETW(wih, base + ".weight_ih_l0" + sfx, int64_t(3) * H * kin);
@@ -521,6 +528,17 @@ int pack_gru(const cto_weights* w, const std::string& base, int kin, int kp, int
             for (int k = 0; k < kin; ++k) row[k] = (*wih)[size_t(n) * kin + k];
             for (int k = 0; k < H; ++k) row[kp + k] = (*whh)[size_t(n) * H + k];
         }
+        for (int wv = 0; wv < 4; ++wv)
+            for (int c = 0; c < NC; ++c)
+                for (int nb = 0; nb < NB; ++nb)
+                    for (int q = 0; q < 3; ++q)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int jj = lane & 15, kg = lane >> 4;
+                            const float* row = W.data() + (size_t(d) * 3 * H + q * H + (wv * NB + nb) * 16 + jj) * KT;
+                            float* f = &Wf[(((((size_t(d) * 4 + wv) * NC + c) * NB + nb) * 3 + q) * 64 + lane) * 4];
+                            if (tail1 && c == NX - 1) f[0] = row[16 * c + kg];
+                            else for (int e = 0; e < 4; ++e) f[e] = row[16 * c + 4 * kg + e];      // c >= NX: kp + 16 (c - NX) = 16 c
+                        }
         float* b = bv.data() + size_t(d) * 4 * H;
         for (int j = 0; j < H; ++j) {
             b[0 * H + j] = (*bih)[size_t(j)] + (*bhh)[size_t(j)];
@@ -530,7 +548,27 @@ int pack_gru(const cto_weights* w, const std::string& base, int kin, int kp, int
         }
     }
     if ((rc = a.upload(W, Wout)) != CTO_OK) return rc;
+    if ((rc = a.upload(Wf, Wfout)) != CTO_OK) return rc;
     return a.upload(bv, bout);
+}
+
+// fc1.weight [128][33 * 2H] for the fused layer-2 kernel: [dir][t][wave][kh][nt][lane][4], lane (j, kg) holding row
+// wave * 32 + nt * 16 + j,  k = t 2H + dir H + 16 kh + 4 kg .. + 3
+std::vector<float> pack_fc1_fragments(const std::vector<float>& fc1, int H) {
+    const int T = 33, NH = H / 16;
+    std::vector<float> f(size_t(2) * T * 4 * NH * 2 * 256);
+    for (int d = 0; d < 2; ++d)
+        for (int t = 0; t < T; ++t)
+            for (int wv = 0; wv < 4; ++wv)
+                for (int kh = 0; kh < NH; ++kh)
+                    for (int nt = 0; nt < 2; ++nt)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int jj = lane & 15, kg = lane >> 4;
+                            const float* src = fc1.data() + size_t(wv * 32 + nt * 16 + jj) * (T * 2 * H) + size_t(t) * 2 * H + d * H + 16 * kh + 4 * kg;
+                            float* dst = &f[((((((size_t(d) * T + t) * 4 + wv) * NH + kh) * 2 + nt) * 64) + lane) * 4];
+                            for (int e = 0; e < 4; ++e) dst[e] = src[e];
+                        }
+    return f;
 }
 
 // ---- split 16-bit operands of the layer-2 recurrence (gru_split_kernel.h; experiment behind CTO_GRU_SPLIT=f16|bf16) ----
@@ -760,13 +798,14 @@ extern "C" int cto_bigru_create(const cto_weights* w, int n_out, cto_model** out
     m->n_out = n_out;
     int rc = CTO_OK;
     auto fail = [&](int code) { return code; };
-    if ((rc = pack_gru(w, "lstm", 34, 48, 128, m->arena, &m->gw1, &m->gb1))) return fail(rc);
-    if ((rc = pack_gru(w, "lstm_2", 256, 256, 192, m->arena, &m->gw2, &m->gb2))) return fail(rc);
+    if ((rc = pack_gru(w, "lstm", 34, 48, 128, m->arena, &m->gw1, &m->gb1, &m->gw1f))) return fail(rc);
+    if ((rc = pack_gru(w, "lstm_2", 256, 256, 192, m->arena, &m->gw2, &m->gb2, &m->gw2f))) return fail(rc);
     const int k1 = 33 * 384;
     {
         GETW(f1, "fc1.weight", int64_t(128) * k1);
         static const char* const names[6] = {"na", "nc", "ng", "nt", "ni", "nd"};
         if ((rc = build_head(w, names, n_out, k1, *f1, m->arena, m->head))) return fail(rc);
+        if ((rc = m->arena.upload(pack_fc1_fragments(*f1, 192), &m->f1f))) return fail(rc);
         // experiment (side channel, never the default): layer 2 + fc1 on split 16-bit operands, three f16 / bf16 MFMA passes per product
         const char* e = getenv("CTO_GRU_SPLIT");
         if (e && e[0]) {
