@@ -108,18 +108,18 @@ __device__ __forceinline__ void gemm_span(const TileSpan& sp, const float* A, in
 
 template <int N, int MTx, int KCH, bool F16>
 __device__ __forceinline__ void gemm_span_split(const TileSpan& sp, const float* A, int lda, int klo,
-                                                const unsigned short* const (&wrow)[ColOwn<N>::NTW], int lo_off,
+                                                const unsigned short* const (&wrow)[ColOwn<N>::NTW],
                                                 const BPreS<ColOwn<N>::NTW>& pre,
                                                 f32x4 (&acc)[MSplit<MTx, ColOwn<N>::MSPLIT>::MTG][ColOwn<N>::NTW], int j, int kg) {
     using S = MSplit<MTx, ColOwn<N>::MSPLIT>;
     constexpr int NTW = ColOwn<N>::NTW;
     const float* A0 = A + sp.mbase * 16 * lda;
     if (ColOwn<N>::MSPLIT == 1 || sp.mcount == S::MTG) {
-        gemm_lds_split<S::MTG, NTW, KCH, F16>(A0, lda, klo, wrow, lo_off, pre, acc, j, kg);
+        gemm_lds_split<S::MTG, NTW, KCH, F16>(A0, lda, klo, wrow, pre, acc, j, kg);
     } else if constexpr (S::LAST > 0) {
         if (sp.mcount == S::LAST) {
             f32x4 (&sub)[S::LAST][NTW] = reinterpret_cast<f32x4 (&)[S::LAST][NTW]>(acc);
-            gemm_lds_split<S::LAST, NTW, KCH, F16>(A0, lda, klo, wrow, lo_off, pre, sub, j, kg);
+            gemm_lds_split<S::LAST, NTW, KCH, F16>(A0, lda, klo, wrow, pre, sub, j, kg);
         }
     }
 }
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
         constexpr int PS = emb_ps(CIN), KE = emb_kch(CIN);
         const float* we_r[NTC];
 #pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) we_r[nt] = pe.wembp + int64_t((spc.tile0 + nt) * 16 + j) * (KE * 16) + 4 * kg;
+        for (int nt = 0; nt < NTC; ++nt) we_r[nt] = pe.wembp + int64_t(spc.tile0 + nt) * (KE * FRAG_CS) + 4 * lane;
         const BPre<NTC> pre_e = prefetch_b<NTC, KE>(we_r);
         f32x4 acc_e[MGC][NTC];
 #pragma unroll
@@ -404,53 +404,39 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
 
     stamp();
     // ---- phase 3: attention, head by head; out-projection accumulates on top of the residual stream in registers ----
-    // weight rows of this lane: fp32 W[n][4 kg ..] or, split, the hi plane's W[n][8 kg ..] (the lo plane lo_* elements further)
-    const int lo_q = inner * C, lo_kv = 2 * inner * C, lo_o = C * inner, lo_w = 4 * C * C;
-    auto q_rows = [&](int hh, WPtr (&wr)[1]) {
-        const int64_t at = int64_t(hh * 64 + spq.tile0 * 16 + j) * C;
-        if constexpr (SP) wr[0] = p.wq_s + at + 8 * kg; else wr[0] = p.wq + at + 4 * kg;
+    // this lane's fragments (cvt_gemm.h: fragment order): n-tile `tile`, first chunk `c0` of a matrix with `kch` chunks per row
+    auto frag = [&](const float* w, const unsigned short* ws, int tile, int kch, int c0) -> WPtr {
+        if constexpr (SP) return ws + (int64_t(tile) * kch + c0) * SPLIT_CS + 8 * lane;
+        else return w + (int64_t(tile) * kch + c0) * FRAG_CS + 4 * lane;
     };
+    constexpr int KD = SP ? 32 : 16;            // k elements per chunk
+    auto q_rows = [&](int hh, WPtr (&wr)[1]) { wr[0] = frag(p.wq, p.wq_s, hh * 4 + spq.tile0, C / KD, 0); };
     auto o_rows = [&](int hh, WPtr (&wr)[NTC]) {
 #pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) {
-            const int64_t at = int64_t((spc.tile0 + nt) * 16 + j) * inner + hh * 64;
-            if constexpr (SP) wr[nt] = p.wo_s + at + 8 * kg; else wr[nt] = p.wo + at + 4 * kg;
-        }
+        for (int nt = 0; nt < NTC; ++nt) wr[nt] = frag(p.wo, p.wo_s, spc.tile0 + nt, inner / KD, hh * (64 / KD));
     };
     auto w1_rows = [&](int cc, WPtr (&wr)[NTF]) {
 #pragma unroll
-        for (int nt = 0; nt < NTF; ++nt) {
-            const int64_t at = int64_t(cc * HC + (spf.tile0 + nt) * 16 + j) * C;
-            if constexpr (SP) wr[nt] = p.w1_s + at + 8 * kg; else wr[nt] = p.w1 + at + 4 * kg;
-        }
+        for (int nt = 0; nt < NTF; ++nt) wr[nt] = frag(p.w1, p.w1_s, cc * (HC / 16) + spf.tile0 + nt, C / KD, 0);
     };
     auto w2_rows = [&](int cc, WPtr (&wr)[NTC]) {
 #pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) {
-            const int64_t at = int64_t((spc.tile0 + nt) * 16 + j) * (4 * C) + cc * HC;
-            if constexpr (SP) wr[nt] = p.w2_s + at + 8 * kg; else wr[nt] = p.w2 + at + 4 * kg;
-        }
+        for (int nt = 0; nt < NTC; ++nt) wr[nt] = frag(p.w2, p.w2_s, spc.tile0 + nt, 4 * C / KD, cc * (HC / KD));
     };
-    constexpr int KD = SP ? 32 : 16;            // k elements per chunk
-
     WPtr wq_r[1];
     q_rows(0, wq_r);
-    auto pre_q = prefetch_b<1, C / KD>(wq_r, lo_q);
+    auto pre_q = prefetch_b<1, C / KD>(wq_r);
     for (int hh = 0; hh < heads; ++hh) {
         // [k_h | v_h] is 128 wide for every stage: wave w computes one of its 8 n-tiles (w < 4: k columns 16 w.., else v columns
         // 16 (w - 4)..) for all m-tiles
         const int wn = wave & 3;
-        WPtr wkv1_r[1];
-        {
-            const int64_t at = int64_t((wave < 4 ? 0 : inner) + hh * 64 + wn * 16 + j) * C;
-            if constexpr (SP) wkv1_r[0] = p.wkv_s + at + 8 * kg; else wkv1_r[0] = p.wkv + at + 4 * kg;
-        }
-        const auto pre_kv1 = prefetch_b<1, C / KD>(wkv1_r, lo_kv);
+        WPtr wkv1_r[1] = {frag(p.wkv, p.wkv_s, (wave < 4 ? 0 : inner / 16) + hh * 4 + wn, C / KD, 0)};
+        const auto pre_kv1 = prefetch_b<1, C / KD>(wkv1_r);
         {   // q_h : [R][64], this wave's 16 columns of its m-tile group
             f32x4 aq[MGQ][1];
 #pragma unroll
             for (int mt = 0; mt < MGQ; ++mt) aq[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (SP) gemm_span_split<64, MT, C / 32, F16>(spq, sy, RS, C, wq_r, lo_q, pre_q, aq, j, kg);
+            if constexpr (SP) gemm_span_split<64, MT, C / 32, F16>(spq, sy, RS, C, wq_r, pre_q, aq, j, kg);
             else gemm_span<64, MT, C / 16>(spq, sy, RS, wq_r, pre_q, aq, j, kg);
 #pragma unroll
             for (int mt = 0; mt < MGQ; ++mt)
@@ -461,12 +447,12 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
         }
         WPtr wo_r[NTC];
         o_rows(hh, wo_r);
-        const auto pre_o = prefetch_b<NTC, 64 / KD>(wo_r, lo_o);
+        const auto pre_o = prefetch_b<NTC, 64 / KD>(wo_r);
         {   // k_h, v_h : [RKV][64] each, one n-tile of the pair per wave, all m-tiles
             f32x4 akv1[MTKV][1];
 #pragma unroll
             for (int mt = 0; mt < MTKV; ++mt) akv1[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (SP) gemm_lds_split<MTKV, 1, C / 32, F16>(sykv, RS, C, wkv1_r, lo_kv, pre_kv1, akv1, j, kg);
+            if constexpr (SP) gemm_lds_split<MTKV, 1, C / 32, F16>(sykv, RS, C, wkv1_r, pre_kv1, akv1, j, kg);
             else gemm_lds<MTKV, 1, C / 16>(sykv, RS, wkv1_r, pre_kv1, akv1, j, kg);
             float* dst = wave < 4 ? sk : sv;
 #pragma unroll
@@ -521,11 +507,11 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
         }
         if (hh + 1 < heads) {        // next head's q weights fly under the barrier and the out-projection
             q_rows(hh + 1, wq_r);
-            pre_q = prefetch_b<1, C / KD>(wq_r, lo_q);
+            pre_q = prefetch_b<1, C / KD>(wq_r);
         }
         lds_barrier();
         stamp();
-        if constexpr (SP) gemm_span_split<C, MT, 2, F16>(spc, sq, QS, 64, wo_r, lo_o, pre_o, acc_o, j, kg);
+        if constexpr (SP) gemm_span_split<C, MT, 2, F16>(spc, sq, QS, 64, wo_r, pre_o, acc_o, j, kg);
         else gemm_span<C, MT, 4>(spc, sq, QS, wo_r, pre_o, acc_o, j, kg);   // acc_o += o_h Wo[:, hh*64 .. +64]^T
         lds_barrier();   // sq / sk / sv are rewritten by the next head
         stamp();
@@ -534,7 +520,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
     // first FFN weights are requested before the residual hand-over and the second LayerNorm
     WPtr w1_r[NTF];
     w1_rows(0, w1_r);
-    auto pre_w1 = prefetch_b<NTF, C / KD>(w1_r, lo_w);
+    auto pre_w1 = prefetch_b<NTF, C / KD>(w1_r);
 
     // ---- phase 4: h' = h + to_out(o) + bias sits in acc_o: a copy -> staging tile for the LayerNorm, and h' + b2 seeds the
     //      second FFN GEMM's accumulators ----
@@ -564,14 +550,14 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
     for (int cc = 0; cc < 4 * C / HC; ++cc) {
         WPtr w2_r[NTC];
         w2_rows(cc, w2_r);
-        const auto pre_w2 = prefetch_b<NTC, HC / KD>(w2_r, lo_w);
+        const auto pre_w2 = prefetch_b<NTC, HC / KD>(w2_r);
         {
             f32x4 au[MGF][NTF];
 #pragma unroll
             for (int mt = 0; mt < MGF; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NTF; ++nt) au[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (SP) gemm_span_split<HC, MT, C / 32, F16>(spf, sy, RS, C, w1_r, lo_w, pre_w1, au, j, kg);
+            if constexpr (SP) gemm_span_split<HC, MT, C / 32, F16>(spf, sy, RS, C, w1_r, pre_w1, au, j, kg);
             else gemm_span<HC, MT, C / 16>(spf, sy, RS, w1_r, pre_w1, au, j, kg);
             const int n0 = cc * HC + spf.tile0 * 16;
 #pragma unroll
@@ -591,10 +577,10 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
         }
         if (cc + 1 < 4 * C / HC) {
             w1_rows(cc + 1, w1_r);
-            pre_w1 = prefetch_b<NTF, C / KD>(w1_r, lo_w);
+            pre_w1 = prefetch_b<NTF, C / KD>(w1_r);
         }
         lds_barrier();
-        if constexpr (SP) gemm_span_split<C, MT, HC / 32, F16>(spc, su, US, HC, w2_r, lo_w, pre_w2, acc_f, j, kg);
+        if constexpr (SP) gemm_span_split<C, MT, HC / 32, F16>(spc, su, US, HC, w2_r, pre_w2, acc_f, j, kg);
         else gemm_span<C, MT, HC / 16>(spc, su, US, w2_r, pre_w2, acc_f, j, kg);
         if (cc + 1 < 4 * C / HC) lds_barrier();   // su is rewritten by the next chunk
         stamp();

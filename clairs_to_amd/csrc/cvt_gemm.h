@@ -2,6 +2,11 @@
 //
 // GEMMs: fp32 MFMA 16x16x4; A fragments from LDS (ds_read_b128 = four k-steps), B fragments from global
 // (one 16-byte load per lane per n-tile per 16-wide k chunk, prefetched two chunks ahead).
+// Weights are stored in FRAGMENT ORDER (models.hip: pack_fragments): [n-tile][16-wide k chunk][lane = (kg << 4) | j][4] with lane
+// (j, kg) holding W[tile * 16 + j][16 c + 4 kg .. + 3], so a wave's request is one contiguous 1 KB = eight whole cache lines; a
+// row-major W[n][k] makes it sixteen half lines whose other halves the next chunk fetches again (they have left the 32 KB L1 by
+// then).  wrow[nt] = panel + (tile * chunks_per_row + first chunk) * 256 + 4 * lane; consecutive chunks are FRAG_CS floats apart.
+constexpr int FRAG_CS = 256;
 #pragma once
 #include <type_traits>
 #include "nn_kernels.h"
@@ -40,13 +45,13 @@ __device__ __forceinline__ BPre<NTW> prefetch_b(const float* const (&wrow)[NTW])
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         p.b0[nt] = ldg4(wrow[nt]);
-        p.b1[nt] = KCH > 1 ? ldg4(wrow[nt] + 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+        p.b1[nt] = KCH > 1 ? ldg4(wrow[nt] + FRAG_CS) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     return p;
 }
 
-// acc[mt][nt] += A[mt*16 .. +16][0 .. KCH*16) * W[n-tile rows][same k];  wrow[nt] already points at
-// W[(n0 + nt*16 + j)][4*kg].  A rows are `lda` floats apart in LDS.  `pre` holds chunks 0 and 1.
+// acc[mt][nt] += A[mt*16 .. +16][0 .. KCH*16) * W[n-tile rows][same k];  wrow[nt] points at this lane's fragment of the n-tile's
+// first chunk.  A rows are `lda` floats apart in LDS.  `pre` holds chunks 0 and 1.
 template <int MT, int NTW, int KCH>
 __device__ __forceinline__ void gemm_lds(const float* __restrict__ A, int lda, const float* const (&wrow)[NTW],
                                          const BPre<NTW>& pre, f32x4 (&acc)[MT][NTW], int j, int kg) {
@@ -61,7 +66,7 @@ __device__ __forceinline__ void gemm_lds(const float* __restrict__ A, int lda, c
     for (int c = 0; c < KCH; ++c) {
         if (c + 2 < KCH) {
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) Bq[(c + 2) % 3][nt] = ldg4(wrow[nt] + (c + 2) * 16);
+            for (int nt = 0; nt < NTW; ++nt) Bq[(c + 2) % 3][nt] = ldg4(wrow[nt] + (c + 2) * FRAG_CS);
         }
         if (c + 1 < KCH) {
 #pragma unroll
@@ -92,31 +97,30 @@ __device__ __forceinline__ void gemm_lds(const float* __restrict__ A, int lda, c
 }
 
 // ---- split-operand forms of the two building blocks above (experiment, side channel: CTO_CVT_SPLIT) ----
-// A tile rows keep their fp32 pitch `lda` and hold [hi: klo 16-bit][lo: klo 16-bit] (split_mfma.h: put_split*); weights are two
-// row-major 16-bit planes [N][K], the lo plane `lo_off` elements after the hi plane; wrow[nt] points at Whi[n0 + nt*16 + j][8 kg];
-// KCH counts 32-wide k chunks.  Same output layout as gemm_lds.
+// A tile rows keep their fp32 pitch `lda` and hold [hi: klo 16-bit][lo: klo 16-bit] (split_mfma.h: put_split*); weights are in
+// fragment order too - [n-tile][32-wide k chunk][hi, lo][lane][8 x 16-bit], lane (j, kg) holding W[tile * 16 + j][32 c + 8 kg .. + 7]
+// (models.hip: upload_split_fragments) - wrow[nt] points at the lane's hi fragment of the first chunk, the lo fragment is
+// SPLIT_LO elements further, the next chunk SPLIT_CS.  KCH counts 32-wide k chunks.  Same output layout as gemm_lds.
+constexpr int SPLIT_LO = 512, SPLIT_CS = 1024;
 template <int NTW>
 struct BPreS {
     uint4 b[2][NTW][2];      // chunks 0 and 1; hi, lo
 };
 template <int NTW, int KCH>
-__device__ __forceinline__ BPreS<NTW> prefetch_b(const unsigned short* const (&wrow)[NTW], int lo_off) {
+__device__ __forceinline__ BPreS<NTW> prefetch_b(const unsigned short* const (&wrow)[NTW]) {
     BPreS<NTW> p;
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            if (c < KCH) { p.b[c][nt][0] = ldg16(wrow[nt] + c * 32); p.b[c][nt][1] = ldg16(wrow[nt] + lo_off + c * 32); }
+            if (c < KCH) { p.b[c][nt][0] = ldg16(wrow[nt] + c * SPLIT_CS); p.b[c][nt][1] = ldg16(wrow[nt] + SPLIT_LO + c * SPLIT_CS); }
             else { p.b[c][nt][0] = make_uint4(0u, 0u, 0u, 0u); p.b[c][nt][1] = make_uint4(0u, 0u, 0u, 0u); }
         }
     return p;
 }
-template <int NTW, int KCH>
-__device__ __forceinline__ BPre<NTW> prefetch_b(const float* const (&wrow)[NTW], int) { return prefetch_b<NTW, KCH>(wrow); }
-
 template <int MT, int NTW, int KCH, bool F16>
 __device__ __forceinline__ void gemm_lds_split(const float* __restrict__ A, int lda, int klo, const unsigned short* const (&wrow)[NTW],
-                                               int lo_off, const BPreS<NTW>& pre, f32x4 (&acc)[MT][NTW], int j, int kg) {
+                                               const BPreS<NTW>& pre, f32x4 (&acc)[MT][NTW], int j, int kg) {
     uint4 Bq[3][NTW][2];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
@@ -140,8 +144,8 @@ __device__ __forceinline__ void gemm_lds_split(const float* __restrict__ A, int 
         if (c + 2 < KCH) {
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
-                Bq[(c + 2) % 3][nt][0] = ldg16(wrow[nt] + (c + 2) * 32);
-                Bq[(c + 2) % 3][nt][1] = ldg16(wrow[nt] + lo_off + (c + 2) * 32);
+                Bq[(c + 2) % 3][nt][0] = ldg16(wrow[nt] + (c + 2) * SPLIT_CS);
+                Bq[(c + 2) % 3][nt][1] = ldg16(wrow[nt] + SPLIT_LO + (c + 2) * SPLIT_CS);
             }
         }
         if (ADB) { if (c + 1 < KCH) load_a((c + 1) & 1, c + 1); }

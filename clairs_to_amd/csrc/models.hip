@@ -67,7 +67,9 @@ struct HeadDev {          // fc1 -> SELU -> K x (fc2 -> SELU -> fc3 -> SELU)
 
 struct BlockDev {
     float *n0g, *n0b, *dwq, *bnq, *wq, *dwkv, *bnkv, *wkv, *wo, *bo, *n1g, *n1b, *w1, *b1, *w2, *b2;
-    // split-operand experiment (CTO_CVT_SPLIT): [hi plane | lo plane] of 16-bit values per GEMM weight, or null
+    // the five GEMM weights in fragment order for the fused block kernel (cvt_gemm.h); the row-major ones serve the unfused path
+    float *wq_f = nullptr, *wkv_f = nullptr, *wo_f = nullptr, *w1_f = nullptr, *w2_f = nullptr;
+    // split-operand experiment (CTO_CVT_SPLIT): (hi, lo) 16-bit fragments per GEMM weight, or null
     float *wq_s = nullptr, *wkv_s = nullptr, *wo_s = nullptr, *w1_s = nullptr, *w2_s = nullptr;
 };
 
@@ -320,7 +322,7 @@ int launch_cvt_block(hipStream_t s, float* h, const BlockDev* blocks, int nblk, 
     sp.nblk = nblk;
     for (int i = 0; i < nblk; ++i) {
         const BlockDev& b = blocks[i];
-        sp.blk[i] = CvtBlockParams{b.n0g, b.n0b, b.dwq, b.bnq, b.wq, b.dwkv, b.bnkv, b.wkv, b.wo, b.bo, b.n1g, b.n1b, b.w1, b.b1, b.w2, b.b2,
+        sp.blk[i] = CvtBlockParams{b.n0g, b.n0b, b.dwq, b.bnq, b.wq_f, b.dwkv, b.bnkv, b.wkv_f, b.wo_f, b.bo, b.n1g, b.n1b, b.w1_f, b.b1, b.w2_f, b.b2,
                                    prof_on ? prof_buf : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                                    nullptr, nullptr, nullptr, nullptr, nullptr};
         if (SPLIT != 0) {
@@ -607,23 +609,31 @@ int upload_halves(const std::vector<uint16_t>& v, Arena& a, float** out) {
     memcpy(f.data(), v.data(), v.size() * 2);
     return a.upload(f, out);
 }
-// a weight matrix [numel] as two 16-bit planes, hi then lo, in its own (row-major) order
-int upload_split_planes(const cto_weights* w, const std::string& name, int64_t numel, bool f16, Arena& a, float** out) {
+// a row-major weight matrix W[ntiles * 16][kch32 * 32] as (hi, lo) 16-bit fragments: [n-tile][32-wide k chunk][hi, lo][lane][8],
+// lane (j, kg) holding W[tile * 16 + j][32 c + 8 kg .. + 7] (cvt_gemm.h: gemm_lds_split)
+int upload_split_fragments(const cto_weights* w, const std::string& name, int ntiles, int kch32, bool f16, Arena& a, float** out) {
     int rc = CTO_OK;
-    GETW(v, name, numel);
-    std::vector<uint16_t> pl(size_t(2) * numel);
-    for (int64_t i = 0; i < numel; ++i) {
-        const float x = (*v)[size_t(i)];
-        if (f16) {
-            CTO_REQUIRE(std::fabs(x) < 60000.f, CTO_EUNSUPPORTED, "CTO_CVT_SPLIT=f16: weight %s holds %g, outside the f16 range", name.c_str(), double(x));
-            pl[size_t(i)] = f16_rne(x);
-            pl[size_t(numel + i)] = f16_rne(x - f16_value(pl[size_t(i)]));
-        } else {
-            pl[size_t(i)] = bf16_rne(x);
-            pl[size_t(numel + i)] = bf16_rne(x - bf16_value(pl[size_t(i)]));
-        }
-    }
-    return upload_halves(pl, a, out);
+    const int K = kch32 * 32;
+    GETW(v, name, int64_t(ntiles) * 16 * K);
+    std::vector<uint16_t> fr(size_t(ntiles) * kch32 * 2 * 64 * 8);
+    for (int t = 0; t < ntiles; ++t)
+        for (int c = 0; c < kch32; ++c)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int j = lane & 15, kg = lane >> 4;
+                const float* src = v->data() + size_t(t * 16 + j) * K + c * 32 + kg * 8;
+                if (f16)
+                    for (int e = 0; e < 8; ++e)
+                        CTO_REQUIRE(std::fabs(src[e]) < 60000.f, CTO_EUNSUPPORTED, "CTO_CVT_SPLIT=f16: weight %s holds %g, outside the f16 range",
+                                    name.c_str(), double(src[e]));
+                const size_t u = ((size_t(t) * kch32 + c) * 2) * 64;
+                put_split8(&fr[(u + lane) * 8], &fr[(u + 64 + lane) * 8], src, 8, f16);
+            }
+    return upload_halves(fr, a, out);
+}
+int upload_fragments(const cto_weights* w, const std::string& name, int ntiles, int kch, Arena& a, float** out) {
+    int rc = CTO_OK;
+    GETW(v, name, int64_t(ntiles) * 16 * kch * 16);
+    return a.upload(pack_fragments(v->data(), ntiles, kch), out);
 }
 
 // Wp[dir][wave][chunk][nb][gate][hi,lo][lane][8], Fp[dir][t][wave][kh][nt][hi,lo][lane][8] (layouts in gru_split_kernel.h)
@@ -719,7 +729,7 @@ extern "C" int cto_cvt_create(const cto_weights* w, const cto_cvt_cfg* cfg, cto_
             for (int n = 0; n < C; ++n)
                 for (int t = 0; t < 3; ++t)
                     for (int ci = 0; ci < cin; ++ci) vp[size_t(n) * KP + t * PS + ci] = v[(size_t(n) * 3 + t) * cin + ci];
-            if ((rc = a.upload(vp, &st.wembp))) return fail(rc);
+            if (C % 16 == 0) { if ((rc = a.upload(pack_fragments(vp.data(), C / 16, KP / 16), &st.wembp))) return fail(rc); }   // fragment order
         }
         if ((rc = upload_named(w, L + ".0.bias", C, a, &st.bemb))) return fail(rc);
         if ((rc = upload_named(w, L + ".1.g", C, a, &st.lng))) return fail(rc);
@@ -743,13 +753,21 @@ extern "C" int cto_cvt_create(const cto_weights* w, const cto_cvt_cfg* cfg, cto_
                 (rc = upload_named(w, P + ".1.fn.net.3.weight", int64_t(4) * C * C, a, &b.w2)) ||
                 (rc = upload_named(w, P + ".1.fn.net.3.bias", C, a, &b.b2)))
                 return fail(rc);
+            const int NI = st.inner / 16, NC16 = C / 16;
+            if (C % 16 == 0 &&      // the fused block kernel exists for 16 / 32 / 64 / 128 channels; other widths run the unfused path
+                ((rc = upload_fragments(w, P + ".0.fn.to_q.net.2.weight", NI, NC16, a, &b.wq_f)) ||
+                (rc = upload_fragments(w, P + ".0.fn.to_kv.net.2.weight", 2 * NI, NC16, a, &b.wkv_f)) ||
+                (rc = upload_fragments(w, P + ".0.fn.to_out.0.weight", NC16, NI, a, &b.wo_f)) ||
+                (rc = upload_fragments(w, P + ".1.fn.net.0.weight", 4 * NC16, NC16, a, &b.w1_f)) ||
+                 (rc = upload_fragments(w, P + ".1.fn.net.3.weight", NC16, 4 * NC16, a, &b.w2_f))))
+                return fail(rc);
             if (m->cvt_split && C % 64 == 0) {
                 const bool f16 = m->cvt_split == 1;
-                if ((rc = upload_split_planes(w, P + ".0.fn.to_q.net.2.weight", int64_t(st.inner) * C, f16, a, &b.wq_s)) ||
-                    (rc = upload_split_planes(w, P + ".0.fn.to_kv.net.2.weight", int64_t(2) * st.inner * C, f16, a, &b.wkv_s)) ||
-                    (rc = upload_split_planes(w, P + ".0.fn.to_out.0.weight", int64_t(C) * st.inner, f16, a, &b.wo_s)) ||
-                    (rc = upload_split_planes(w, P + ".1.fn.net.0.weight", int64_t(4) * C * C, f16, a, &b.w1_s)) ||
-                    (rc = upload_split_planes(w, P + ".1.fn.net.3.weight", int64_t(4) * C * C, f16, a, &b.w2_s)))
+                if ((rc = upload_split_fragments(w, P + ".0.fn.to_q.net.2.weight", NI, C / 32, f16, a, &b.wq_s)) ||
+                    (rc = upload_split_fragments(w, P + ".0.fn.to_kv.net.2.weight", 2 * NI, C / 32, f16, a, &b.wkv_s)) ||
+                    (rc = upload_split_fragments(w, P + ".0.fn.to_out.0.weight", NC16, st.inner / 32, f16, a, &b.wo_s)) ||
+                    (rc = upload_split_fragments(w, P + ".1.fn.net.0.weight", 4 * NC16, C / 32, f16, a, &b.w1_s)) ||
+                    (rc = upload_split_fragments(w, P + ".1.fn.net.3.weight", NC16, 4 * C / 32, f16, a, &b.w2_s)))
                     return fail(rc);
             }
             st.blocks.push_back(b);
