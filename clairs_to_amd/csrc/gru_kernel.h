@@ -19,7 +19,8 @@ namespace cto {
 //             of step t for step t+1, written to LDS just before the barrier of step t: the HBM latency of the
 //             activations - which every one of the 4 waves needs in full - is paid once per step, off the MFMA path),
 //             h_{t-1} from a double-buffered LDS tile [MS*16][H] that all waves rewrite each step.
-// B operands (weights) stream from L2 as one 16-byte load per lane per (gate, 16-wide k chunk); they
+// B operands (weights) stream from L2 as one 16-byte load per lane per (gate, 16-wide k chunk) - in the rotated kernel out of a
+//             fragment-ordered copy (one contiguous 1 KB per wave request, buffer loads with scalar offsets); they
 //             are shared by the MS row-subtiles.  One barrier per time step.
 // The K loop is fully unrolled and software-pipelined by hand: the operands of chunk c+1 (and, at the
 // end of a step, of chunk 0 of the next step) are requested before the MFMAs of chunk c, so the matrix
