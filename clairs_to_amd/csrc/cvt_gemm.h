@@ -254,7 +254,7 @@ struct HeadPre {
     BGroup<2, 8> g[2];
 };
 __device__ __forceinline__ void head_prefetch(HeadPre& hpre, const HeadTailParams& hp) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kg = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* w0 = hp.w2 + int64_t(wave) * (8 * 256) + 4 * lane;      // this wave's n-tile of head 0
 #pragma unroll
     for (int pi = 0; pi < 2; ++pi) {
