@@ -803,12 +803,26 @@ struct Buf {
 
 struct cto_dev_pileup {
     Buf tile_a, tile_b, tile_tot;        // tile sums of the spread-out scans
-    Buf lin, lin_off, blocks, starts, counts, base, rec_off, reads, rid, live, iv, diff, slot_col, col_slot, col_off, col_pos, col_ref, cursor, tmp,
-        entries, nkc, keyrec, key_off, key_meta, key_group, key_final, key_col, key_len, str_off, key_str, ref, flags, z1k;
+    Buf lin, counts, base, rec_off, reads, rid, live, diff, slot_col, col_slot, col_off, col_pos, col_ref, cursor, tmp,
+        entries, nkc, keyrec, key_off, key_meta, key_group, key_final, key_col, key_len, str_off, key_str, z1k;
     bool z1k_ready = false;
     Flags* h_flags = nullptr;            // page-locked mirror
     void* h_stage = nullptr;             // page-locked landing area of the small arrays that go back to the host (a copy to pageable
     size_t h_stage_cap = 0;              // memory blocks - and spins - until everything queued in front of it is done)
+    // The chunk's small inputs (flags, block table, linear offsets, record starts, intervals, reference window) go up as ONE copy out
+    // of page-locked memory: six hipMemcpyAsync calls from pageable vectors each pin their source on the fly, under a lock every
+    // producer thread of the run shares.
+    Buf up;
+    void* h_up = nullptr;
+    size_t h_up_cap = 0;
+    int up_ensure(size_t n) {
+        if (n <= h_up_cap) return CTO_OK;
+        if (h_up) { CTO_HIP(hipHostFree(h_up)); h_up = nullptr; h_up_cap = 0; }
+        const size_t want = n + n / 4 + 4096;
+        CTO_HIP(hipHostMalloc(&h_up, want, hipHostMallocDefault));
+        h_up_cap = want;
+        return CTO_OK;
+    }
     int stage_ensure(size_t n) {
         if (n <= h_stage_cap) return CTO_OK;
         if (h_stage) { CTO_HIP(hipHostFree(h_stage)); h_stage = nullptr; h_stage_cap = 0; }
@@ -819,7 +833,7 @@ struct cto_dev_pileup {
     }
     hipEvent_t ev = nullptr;             // the driver's waits sleep on it: hipStreamSynchronize polls the completion signal from the calling
                                          // thread, and that thread shares sixteen host cores with everything else of a run
-    ~cto_dev_pileup() { if (h_flags) (void)hipHostFree(h_flags); if (h_stage) (void)hipHostFree(h_stage); if (ev) (void)hipEventDestroy(ev); }
+    ~cto_dev_pileup() { if (h_flags) (void)hipHostFree(h_flags); if (h_stage) (void)hipHostFree(h_stage); if (h_up) (void)hipHostFree(h_up); if (ev) (void)hipEventDestroy(ev); }
 };
 
 // waits for everything queued on `s` so far without occupying a core (pipeline.hip's wait_event)
@@ -895,8 +909,9 @@ extern "C" int cto_pileup_device(cto_dev_pileup* cx, const void* d_inflated, con
     }
     const int n_iv = int((ivs.size() - 1) / 3), total = ivs.back();
     Flags* hf = cx->h_flags;
+    Flags* fl = nullptr;                 // the flags on the device (first part of the upload block, set below)
     auto fetch_flags = [&]() -> int {
-        CTO_HIP(hipMemcpyAsync(hf, cx->flags.p, sizeof(Flags), hipMemcpyDeviceToHost, s));
+        CTO_HIP(hipMemcpyAsync(hf, fl, sizeof(Flags), hipMemcpyDeviceToHost, s));
         CTO_HIP(sleepy_sync(cx, s));
         return CTO_OK;
     };
@@ -926,23 +941,28 @@ extern "C" int cto_pileup_device(cto_dev_pileup* cx, const void* d_inflated, con
     };
     if (total == 0) return empty_result();
     int rc;
-    if ((rc = cx->lin.ensure(size_t(len) + 64)) || (rc = cx->lin_off.ensure(lin_off.size() * 8)) || (rc = cx->blocks.ensure(size_t(n_blocks) * sizeof(cto_bgzf_block))) ||
-        (rc = cx->starts.ensure(starts.size() * 8)) || (rc = cx->counts.ensure(size_t(n_chains + 1) * 4)) || (rc = cx->base.ensure(size_t(n_chains + 2) * 4)) ||
-        (rc = cx->iv.ensure(ivs.size() * 4)) || (rc = cx->diff.ensure(size_t(total + 1) * 4)) || (rc = cx->slot_col.ensure(size_t(total) * 4)) ||
-        (rc = cx->col_slot.ensure(size_t(total) * 4)) || (rc = cx->col_off.ensure(size_t(total + 1) * 8)) || (rc = cx->ref.ensure(ref_len + 1)) ||
-        (rc = cx->flags.ensure(sizeof(Flags))))
+    if ((rc = cx->lin.ensure(size_t(len) + 64)) || (rc = cx->counts.ensure(size_t(n_chains + 1) * 4)) || (rc = cx->base.ensure(size_t(n_chains + 2) * 4)) ||
+        (rc = cx->diff.ensure(size_t(total + 1) * 4)) || (rc = cx->slot_col.ensure(size_t(total) * 4)) ||
+        (rc = cx->col_slot.ensure(size_t(total) * 4)) || (rc = cx->col_off.ensure(size_t(total + 1) * 8)))
         return rc;
     Flags init{};
     init.stop_idx = init.err_idx = init.paired_idx = init.skip_idx = 0x7fffffff;
     *hf = init;
-    CTO_HIP(hipMemcpyAsync(cx->flags.p, hf, sizeof(Flags), hipMemcpyHostToDevice, s));
-    CTO_HIP(hipMemcpyAsync(cx->lin_off.p, lin_off.data(), lin_off.size() * 8, hipMemcpyHostToDevice, s));
-    CTO_HIP(hipMemcpyAsync(cx->blocks.p, h_blocks, size_t(n_blocks) * sizeof(cto_bgzf_block), hipMemcpyHostToDevice, s));
-    CTO_HIP(hipMemcpyAsync(cx->starts.p, starts.data(), starts.size() * 8, hipMemcpyHostToDevice, s));
-    CTO_HIP(hipMemcpyAsync(cx->iv.p, ivs.data(), ivs.size() * 4, hipMemcpyHostToDevice, s));
-    CTO_HIP(hipMemcpyAsync(cx->ref.p, ref_seq, ref_len, hipMemcpyHostToDevice, s));
+    // ---- one upload: flags | linear offsets | block table | record starts | intervals | reference window (256-byte aligned parts) ----
+    const void* up_src[6] = {&init, lin_off.data(), h_blocks, starts.data(), ivs.data(), ref_seq};
+    const size_t up_bytes[6] = {sizeof(Flags), lin_off.size() * 8, size_t(n_blocks) * sizeof(cto_bgzf_block), starts.size() * 8, ivs.size() * 4, ref_len};
+    size_t up_off[6], up_total = 0;
+    for (int i = 0; i < 6; ++i) { up_off[i] = up_total; up_total += (up_bytes[i] + 255) / 256 * 256 + 256; }
+    if ((rc = cx->up.ensure(up_total)) || (rc = cx->up_ensure(up_total))) return rc;
+    for (int i = 0; i < 6; ++i) memcpy(static_cast<char*>(cx->h_up) + up_off[i], up_src[i], up_bytes[i]);
+    CTO_HIP(hipMemcpyAsync(cx->up.p, cx->h_up, up_total, hipMemcpyHostToDevice, s));
+    char* const d_up = static_cast<char*>(cx->up.p);
+    fl = reinterpret_cast<Flags*>(d_up + up_off[0]);
+    const int64_t* d_lin_off = reinterpret_cast<const int64_t*>(d_up + up_off[1]);
+    const cto_bgzf_block* d_blocks = reinterpret_cast<const cto_bgzf_block*>(d_up + up_off[2]);
+    const int64_t* d_starts = reinterpret_cast<const int64_t*>(d_up + up_off[3]);
+    int* d_ivs = reinterpret_cast<int*>(d_up + up_off[4]);
     CTO_HIP(hipMemsetAsync(cx->diff.p, 0, size_t(total + 1) * 4, s));
-    Flags* fl = cx->flags.as<Flags>();
     const uint8_t* lin = cx->lin.as<uint8_t>();
     if (!cx->z1k_ready) {                                     // "1024 zero bytes" as a bit matrix, once per context
         uint32_t tbl[256], z[32];
@@ -953,12 +973,12 @@ extern "C" int cto_pileup_device(cto_dev_pileup* cx, const void* d_inflated, con
         cx->z1k_ready = true;
     }
     hipLaunchKernelGGL(k_crc32_blocks, dim3(unsigned(std::min<int64_t>(n_blocks, 4096))), dim3(64), 0, s, static_cast<const uint8_t*>(d_inflated),
-                       cx->blocks.as<cto_bgzf_block>(), int(n_blocks), cx->z1k.as<uint32_t>(), fl);
-    hipLaunchKernelGGL(k_linearise, dim3(unsigned(n_blocks)), dim3(256), 0, s, static_cast<const uint8_t*>(d_inflated), cx->blocks.as<cto_bgzf_block>(),
-                       cx->lin_off.as<int64_t>(), cx->lin.as<uint8_t>());
+                       d_blocks, int(n_blocks), cx->z1k.as<uint32_t>(), fl);
+    hipLaunchKernelGGL(k_linearise, dim3(unsigned(n_blocks)), dim3(256), 0, s, static_cast<const uint8_t*>(d_inflated), d_blocks,
+                       d_lin_off, cx->lin.as<uint8_t>());
     // ---- record boundaries ----
     const unsigned cgrid = unsigned(cdiv(n_chains, 64));
-    hipLaunchKernelGGL(k_chain, dim3(cgrid), dim3(64), 0, s, lin, len, cx->starts.as<int64_t>(), n_chains, 0, cx->counts.as<int>(), nullptr, nullptr, fl);
+    hipLaunchKernelGGL(k_chain, dim3(cgrid), dim3(64), 0, s, lin, len, d_starts, n_chains, 0, cx->counts.as<int>(), nullptr, nullptr, fl);
     hipLaunchKernelGGL(k_scan_small<int>, dim3(1), dim3(1024), 0, s, cx->counts.as<int>(), cx->base.as<int>(), n_chains, &fl->n_rec);
     CTO_HIP(hipGetLastError());
     if ((rc = fetch_flags())) return rc;
@@ -976,7 +996,7 @@ extern "C" int cto_pileup_device(cto_dev_pileup* cx, const void* d_inflated, con
         (rc = cx->live.ensure(size_t(n_rec + 1) * 4)))
         return rc;
     CTO_HIP(hipMemsetAsync(cx->live.p, 0, size_t(n_rec + 1) * 4, s));
-    hipLaunchKernelGGL(k_chain, dim3(cgrid), dim3(64), 0, s, lin, len, cx->starts.as<int64_t>(), n_chains, 1, cx->counts.as<int>(), cx->base.as<int>(),
+    hipLaunchKernelGGL(k_chain, dim3(cgrid), dim3(64), 0, s, lin, len, d_starts, n_chains, 1, cx->counts.as<int>(), cx->base.as<int>(),
                        cx->rec_off.as<uint32_t>(), fl);
     hipLaunchKernelGGL(k_parse, dim3(unsigned(cdiv(n_rec, 128))), dim3(128), 0, s, lin, cx->rec_off.as<uint32_t>(), n_rec, tid, int(start - 1), int(end),
                        excl_flags, min_mq, cx->reads.as<DevRead>(), fl);
@@ -985,7 +1005,7 @@ extern "C" int cto_pileup_device(cto_dev_pileup* cx, const void* d_inflated, con
         hipLaunchKernelGGL(k_live_marks, dim3(unsigned(cdiv(n_rec, 128))), dim3(128), 0, s, cx->reads.as<DevRead>(), cx->rid.as<int>(), fl, cx->live.as<int>());
         hipLaunchKernelGGL(k_live_max, dim3(1), dim3(1024), 0, s, cx->live.as<int>(), fl);
     }
-    Ivs iv{cx->iv.as<int>(), cx->iv.as<int>() + n_iv, cx->iv.as<int>() + 2 * n_iv, n_iv, total};
+    Ivs iv{d_ivs, d_ivs + n_iv, d_ivs + 2 * n_iv, n_iv, total};
     hipLaunchKernelGGL(k_cover, dim3(unsigned(cdiv(n_rec, 128))), dim3(128), 0, s, cx->reads.as<DevRead>(), cx->rid.as<int>(), fl, iv, cx->diff.as<int>());
     {
         const int tiles = int(cdiv(total, SCAN_TILE));
@@ -1016,7 +1036,7 @@ extern "C" int cto_pileup_device(cto_dev_pileup* cx, const void* d_inflated, con
         (rc = cx->nkc.ensure(size_t(n_cols + 1) * 4)) || (rc = cx->keyrec.ensure(size_t(n_entries) * sizeof(KeyRec))) || (rc = cx->key_off.ensure(size_t(n_cols + 1) * 4)))
         return rc;
     CTO_HIP(hipMemsetAsync(cx->cursor.p, 0, size_t(n_cols) * 4, s));
-    const char* d_ref = cx->ref.as<char>();
+    const char* d_ref = d_up + up_off[5];
     hipLaunchKernelGGL(k_col_meta, dim3(unsigned(cdiv(n_cols, 256))), dim3(256), 0, s, cx->col_slot.as<int>(), n_cols, iv, d_ref, (long long)ref_start,
                        (long long)ref_len, cx->col_pos.as<int32_t>(), cx->col_ref.as<uint8_t>(), fl);
     int live_cap = 64;

@@ -144,7 +144,7 @@ struct InflateCtx {
     int device = 0, cus = 0;
     hipStream_t stream = nullptr;
     hipEvent_t landed = nullptr;         // recorded behind the copy back; the producer thread sleeps on it (wait_event)
-    PinBuf h_in, h_out;
+    PinBuf h_in, h_out, h_sites;         // h_sites: the chunk's candidate positions on their way up (page-locked like every copy source)
     DevBuf d_in, d_out;
     int open(int dev, int n_cus) {
         device = dev;
@@ -545,7 +545,9 @@ struct Run {
                 // the pack's arrays move from the context (re-used by the next chunk) into the slot's one device allocation, laid out
                 // as the upload path lays it out, + the candidate positions
                 const size_t nc = size_t(dvw.n_cols), ne = size_t(dvw.n_entries), nk = size_t(dvw.n_keys), ns = s->sites.size();
-                const void* src[8] = {dvw.entries, dvw.col_pos, dvw.col_ref, dvw.col_off, dvw.key_off, dvw.key_meta, dvw.key_group, s->sites.data()};
+                if ((rc = c->h_sites.ensure(s->sites.size() * 4 + 4)) != CTO_OK) { cto_pack_free(lite); return rc; }
+                memcpy(c->h_sites.p, s->sites.data(), s->sites.size() * 4);
+                const void* src[8] = {dvw.entries, dvw.col_pos, dvw.col_ref, dvw.col_off, dvw.key_off, dvw.key_meta, dvw.key_group, c->h_sites.p};
                 const size_t bytes[8] = {ne * 4, nc * 4, nc, (nc + 1) * 8, (nc + 1) * 4, nk, nk * 4, ns * 4};
                 size_t off[8], total = 0;
                 for (int i = 0; i < 8; ++i) { off[i] = total; total += (bytes[i] + 255) / 256 * 256 + 256; }
