@@ -13,7 +13,7 @@ if not fs:
     print('no counter file'); raise SystemExit
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(fs[0])):
-    if 'k_gru_fc1_split' in r['Kernel_Name']:
+    if 'k_gru_split<256' in r['Kernel_Name']:
         acc[r['Counter_Name']].append(float(r['Counter_Value']))
 print('  '.join('%s=%.5g (n=%d)' % (c, sum(v) / len(v), len(v)) for c, v in sorted(acc.items())))
 PY
