@@ -429,11 +429,8 @@ __global__ __launch_bounds__(64 * NW) void k_gru_layer_rot(const float* __restri
     // K of the x part is zero-padded from KIN to KP.  When at most 4 real channels fall into the last 16-wide chunk (layer 1:
     // channels 32, 33 of 34) that chunk is ONE k-step whose four lane groups hold k = 16 (NX - 1) + kg - scalar operand loads -
     // instead of float4 loads of which only two of four k-steps touch a real channel: 9 k-steps for K = 34, not 10.
-#ifdef CTO_GRU_NO_TAIL1
-    constexpr bool TAIL1 = false;
-#else
+    // (models.hip: pack_gru lays the last x chunk's fragments out for exactly this rule)
     constexpr bool TAIL1 = (KIN % 16 != 0) && (KIN - 16 * (NX - 1) <= 4);
-#endif
     auto load_B = [&](int buf, int c) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
