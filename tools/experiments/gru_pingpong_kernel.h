@@ -3,7 +3,8 @@
 // to k_gru_layer_rot.  Measured on MI355X (tools/ab.py, 4096 sites): layer 2 1.101 vs 1.089 ms, layer 1 + tail 0.306 vs 0.287 ms.
 // Phase stamps (-DCTO_GRU_CLOCKS): the same number of shader cycles as the rotated kernel (layer 2: 2.529 M vs 2.536 M per
 // workgroup) - the gate arithmetic is hidden, the chunk loop is less efficient (twice the operand requests per MFMA) - at a
-// LOWER average shader clock (2.05 vs 2.15 GHz in the instrumented build): the denser stream is paid for in frequency.
+// lower ratio of s_memtime ticks to wall time (2.05 vs 2.15 G/s in the instrumented builds; rocm-smi reads 2.39 GHz during the
+// default bench, so not a power limit of the default path - not separated further).
 // DESIGN.md section 6, round 4.
 // --------------------------------------------------------------------------------------------
 // Ping-pong schedule of the same recurrence (32-site tiles): the two 16-site sub-tiles of a workgroup are independent recurrences
