@@ -247,3 +247,27 @@ def test_short_read_platforms_warn_about_the_unpinned_bam_reader(capsys):
     platforms.warn_unpinned_bam_reader("ilmn", "gpu")
     err = capsys.readouterr().err
     assert err.count("[WARNING]") == 1 and "mate-overlap" in err and "NOT pinned" in err
+
+
+def test_split_operands_is_an_opt_in_of_the_drivers_and_of_a_module():
+    """The experimental split-operand kernels are never the default: the drivers take --split_operands f16|bf16 (nothing else), a
+    module carries the choice as an attribute, and changing it changes the key under which its C-ABI handle is cached (a handle
+    is rebuilt, not reused, when the arithmetic changes)."""
+    from argparse import ArgumentParser
+    from clairs_to_amd import nn_shims
+    from clairs_to_amd.pileup_call import add_common_arguments
+    p = ArgumentParser()
+    add_common_arguments(p)
+    base = ["--tumor_bam_fn", "t.bam", "--ref_fn", "r.fa", "--ctg_name", "c", "--chkpnt_fn_acgt", "a", "--chkpnt_fn_nacgt", "n",
+            "--likelihood_matrix_data", "l", "--platform", "ont_r10_dorado_sup_5khz"]
+    known = {a.dest for a in p._actions}
+    argv = [x for i, x in enumerate(base) if (x.startswith("--") and x[2:] in known) or (i and base[i - 1].startswith("--") and base[i - 1][2:] in known and not x.startswith("--"))]
+    assert p.parse_args(argv).split_operands is None
+    assert p.parse_args(argv + ["--split_operands", "f16"]).split_operands == "f16"
+    with pytest.raises(SystemExit):
+        p.parse_args(argv + ["--split_operands", "fp8"])
+    m = nn_shims.BiGRU_NACGT()
+    assert m.split_operands is None
+    v0 = m._weights_version()
+    m.split_operands = "f16"
+    assert m._weights_version() != v0 and m._weights_version()[0] == "f16"
