@@ -180,6 +180,15 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
     const CvtBlockParams& pe = sp.blk[0];       // the stage's embedding, when this launch starts the stage
 
 
+    // the embedding GEMM's first weight chunks are requested before the stage input is: their L2 round trip runs under the HBM one
+    constexpr int KE_ = CIN > 0 ? emb_kch(CIN) : 1;
+    const float* we_r[NTC];
+    BPre<NTC> pre_e;
+    if constexpr (CIN > 0) {
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) we_r[nt] = pe.wembp + int64_t(spc.tile0 + nt) * (KE_ * FRAG_CS) + 4 * lane;
+        pre_e = prefetch_b<NTC, KE_>(we_r);
+    }
     // ---- phase 0: residual stream tile -> sy (pad rows zero); first block of a stage: stage input -> LDS instead ----
     if constexpr (HEAD) {   // fc1 sweeps the LDS image of the tile including the 4 pad columns of every row (zero weights): keep them finite
         for (int i = tid; i < MT * 16; i += NT) *reinterpret_cast<float4*>(sy + i * RS + C) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -303,10 +312,6 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
     if constexpr (CIN > 0) {
         // conv embedding (model.py:195, only the middle kernel row is live) + bias, then the stage's channel LayerNorm
         constexpr int PS = emb_ps(CIN), KE = emb_kch(CIN);
-        const float* we_r[NTC];
-#pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) we_r[nt] = pe.wembp + int64_t(spc.tile0 + nt) * (KE * FRAG_CS) + 4 * lane;
-        const BPre<NTC> pre_e = prefetch_b<NTC, KE>(we_r);
         f32x4 acc_e[MGC][NTC];
 #pragma unroll
         for (int mt = 0; mt < MGC; ++mt)
