@@ -99,6 +99,8 @@ SYMBOLS = {
     "cto_weights_free": (None, [c_vp]),
     "cto_cvt_create": (C.c_int, [c_vp, C.POINTER(CvtCfg), C.POINTER(c_vp)]),
     "cto_bigru_create": (C.c_int, [c_vp, C.c_int, C.POINTER(c_vp)]),
+    "cto_cvt_create_ex": (C.c_int, [c_vp, C.POINTER(CvtCfg), C.c_int, C.POINTER(c_vp)]),
+    "cto_bigru_create_ex": (C.c_int, [c_vp, C.c_int, C.c_int, C.POINTER(c_vp)]),
     "cto_cvt_create_packed": (C.c_int, [c_vp, c_i64, C.POINTER(CvtCfg), C.POINTER(c_vp)]),
     "cto_bigru_create_packed": (C.c_int, [c_vp, c_i64, C.c_int, C.POINTER(c_vp)]),
     "cto_model_manifest": (c_i64, [C.c_int, C.POINTER(CvtCfg), C.c_int, c_vp, C.c_size_t]),

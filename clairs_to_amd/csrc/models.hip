@@ -686,7 +686,12 @@ int pack_gru_split(const cto_weights* w, const std::string& base, int kin, int k
 }  // namespace
 
 extern "C" int cto_cvt_create(const cto_weights* w, const cto_cvt_cfg* cfg, cto_model** out) {
+    return cto_cvt_create_ex(w, cfg, CTO_SPLIT_ENV, out);
+}
+
+extern "C" int cto_cvt_create_ex(const cto_weights* w, const cto_cvt_cfg* cfg, int split_mode, cto_model** out) {
     CTO_REQUIRE(w && cfg && out, CTO_EINVAL, "cto_cvt_create: null argument");
+    CTO_REQUIRE(split_mode >= CTO_SPLIT_ENV && split_mode <= CTO_SPLIT_BF16, CTO_EINVAL, "cto_cvt_create_ex: split_mode %d", split_mode);
     CTO_REQUIRE(cfg->n_out == 4 || cfg->n_out == 6, CTO_EINVAL, "n_out must be 4 or 6");
     for (int i = 0; i < 3; ++i)
         CTO_REQUIRE(cfg->emb_dim[i] >= 4 && cfg->emb_dim[i] <= 128 && cfg->emb_dim[i] % 4 == 0 && cfg->heads[i] >= 1 &&
@@ -697,12 +702,13 @@ extern "C" int cto_cvt_create(const cto_weights* w, const cto_cvt_cfg* cfg, cto_
     m->kind = 0;
     m->n_out = cfg->n_out;
     {   // experiment (side channel, never the default): the block GEMMs of the 64- / 128-channel stages on split 16-bit operands
-        const char* e = getenv("CTO_CVT_SPLIT");
+        const char* e = split_mode == CTO_SPLIT_ENV ? getenv("CTO_CVT_SPLIT") : nullptr;
         if (e && e[0]) {
             const std::string kind(e);
             CTO_REQUIRE(kind == "f16" || kind == "bf16", CTO_EINVAL, "CTO_CVT_SPLIT must be f16 or bf16, not '%s'", e);
             m->cvt_split = kind == "f16" ? 1 : 2;
         }
+        if (split_mode > 0) m->cvt_split = split_mode;
     }
     Arena& a = m->arena;
     int rc = CTO_OK;
@@ -808,7 +814,12 @@ extern "C" int cto_cvt_create(const cto_weights* w, const cto_cvt_cfg* cfg, cto_
 }
 
 extern "C" int cto_bigru_create(const cto_weights* w, int n_out, cto_model** out) {
+    return cto_bigru_create_ex(w, n_out, CTO_SPLIT_ENV, out);
+}
+
+extern "C" int cto_bigru_create_ex(const cto_weights* w, int n_out, int split_mode, cto_model** out) {
     CTO_REQUIRE(w && out, CTO_EINVAL, "cto_bigru_create: null argument");
+    CTO_REQUIRE(split_mode >= CTO_SPLIT_ENV && split_mode <= CTO_SPLIT_BF16, CTO_EINVAL, "cto_bigru_create_ex: split_mode %d", split_mode);
     CTO_REQUIRE(n_out == 4 || n_out == 6, CTO_EINVAL, "n_out must be 4 or 6");
     std::unique_ptr<cto_model> m(new cto_model());
     CTO_HIP(hipGetDevice(&m->device));
@@ -825,7 +836,7 @@ extern "C" int cto_bigru_create(const cto_weights* w, int n_out, cto_model** out
         if ((rc = build_head(w, names, n_out, k1, *f1, m->arena, m->head))) return fail(rc);
         if ((rc = m->arena.upload(pack_fc1_fragments(*f1, 192), &m->f1f))) return fail(rc);
         // experiment (side channel, never the default): layer 2 + fc1 on split 16-bit operands, three f16 / bf16 MFMA passes per product
-        const char* e = getenv("CTO_GRU_SPLIT");
+        const char* e = split_mode == CTO_SPLIT_ENV ? getenv("CTO_GRU_SPLIT") : split_mode == CTO_SPLIT_F16 ? "f16" : split_mode == CTO_SPLIT_BF16 ? "bf16" : nullptr;
         if (e && e[0]) {
             const std::string kind(e);
             CTO_REQUIRE(kind == "f16" || kind == "bf16", CTO_EINVAL, "CTO_GRU_SPLIT must be f16 or bf16, not '%s'", e);

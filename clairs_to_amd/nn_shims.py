@@ -105,23 +105,18 @@ class _HipNet(nn.Module):
                 a = np.ascontiguousarray(v.detach().to("cpu", torch.float32).numpy())
                 check(lib.cto_weights_add(w, k.encode(), a.ctypes.data, a.size))
             out = c_vp()
-            # the C ABI reads the experimental switch from the environment when a handle is created
-            var = "CTO_CVT_SPLIT" if self._kind == "cvt" else "CTO_GRU_SPLIT"
-            saved = os.environ.get(var)
-            if self.split_operands:
-                os.environ[var] = str(self.split_operands)
-            try:
-                if self._kind == "cvt":
-                    cfg = self._cfg()
-                    check(lib.cto_cvt_create(w, C.byref(cfg), C.byref(out)))
-                else:
-                    check(lib.cto_bigru_create(w, len(self._heads_out), C.byref(out)))
-            finally:
-                if self.split_operands:
-                    if saved is None:
-                        os.environ.pop(var, None)
-                    else:
-                        os.environ[var] = saved
+            # the arithmetic travels as an argument (cto_*_create_ex), never through os.environ: a handle built at the same
+            # moment on another thread must not see this module's choice.  None = the documented process-wide default
+            # (CTO_CVT_SPLIT / CTO_GRU_SPLIT), "f32" pins fp32 whatever the environment says.
+            modes = {None: -1, "f32": 0, "f16": 1, "bf16": 2}
+            if self.split_operands not in modes:
+                raise ValueError("split_operands must be None, 'f32', 'f16' or 'bf16', not %r" % (self.split_operands,))
+            mode = modes[self.split_operands]
+            if self._kind == "cvt":
+                cfg = self._cfg()
+                check(lib.cto_cvt_create_ex(w, C.byref(cfg), mode, C.byref(out)))
+            else:
+                check(lib.cto_bigru_create_ex(w, len(self._heads_out), mode, C.byref(out)))
         finally:
             lib.cto_weights_free(w)
         self.__dict__[slot] = (ver, c_vp(out.value))

@@ -270,6 +270,17 @@ typedef struct cto_cvt_cfg {
 int cto_cvt_create(const cto_weights* w, const cto_cvt_cfg* cfg, cto_model** out);
 /* clairs.model.BiGRU_NACGT / BiGRU_NACGT_Indel (clairs/model.py:387-560); n_out = 4 or 6. */
 int cto_bigru_create(const cto_weights* w, int n_out, cto_model** out);
+/* The same with the arithmetic of the GEMM operands chosen by the caller instead of by the process environment
+ * (the reference has one arithmetic, fp32: clairs/predict.py:512-568 builds the modules and never casts them).
+ * CTO_SPLIT_ENV = what cto_*_create do: fp32 unless CTO_CVT_SPLIT / CTO_GRU_SPLIT name "f16" or "bf16";
+ * CTO_SPLIT_F32 = fp32 MFMA whatever the environment says; CTO_SPLIT_F16 / _BF16 = every GEMM operand written as
+ * hi + lo 16-bit halves, three MFMA passes per product, fp32 accumulation (the opt-in side channel of DESIGN.md 6). */
+#define CTO_SPLIT_ENV  (-1)
+#define CTO_SPLIT_F32  0
+#define CTO_SPLIT_F16  1
+#define CTO_SPLIT_BF16 2
+int cto_cvt_create_ex(const cto_weights* w, const cto_cvt_cfg* cfg, int split_mode, cto_model** out);
+int cto_bigru_create_ex(const cto_weights* w, int n_out, int split_mode, cto_model** out);
 /* One-blob hand-over: `packed` host fp32 = every tensor of the module's state_dict() concatenated in state_dict order
  * (clairs/model.py:150-560 as `torch.save`d at clairs/predict.py:513-517; the integer `num_batches_tracked` entries are left
  * out) - `torch.cat([v.flatten() for v in model.state_dict().values() if v.is_floating_point()])`.  This is the

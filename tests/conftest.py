@@ -92,3 +92,26 @@ def load_genuine_pickle(name):
     g = load_json_gz("pickles.json.gz")[name]
     raw = gzip.decompress(base64.b64decode(g["pickle_gz_b64"]))
     return torch.load(io.BytesIO(raw), map_location="cpu", weights_only=False)[g["key"]], g
+
+
+def load_range_npz(cls):
+    """models_<cls>_range.npz (tests/golden/gen_range.py): the reference modules outside the O(1) regime, fp32 and fp64."""
+    z = np.load(os.path.join(GOLDEN, "models_%s_range.npz" % cls))
+    manifest = [(k, tuple(s)) for k, s in json.loads(str(z["manifest"]))]
+    sets = [(n, float(s), float(g)) for n, s, g in json.loads(str(z["sets"]))]
+    return dict(x=z["x"], manifest=manifest, n_out=int(z["n_out"]), sets=sets, z=z)
+
+
+def range_errors(logits, z, name):
+    """(max |dP| vs the reference's fp64 run, vs its fp32 run, relative logit error vs fp64, the fp32 reference's own
+    |dP| vs fp64, its own relative logit error) for one range set."""
+    l64 = z["logits64_" + name]
+    p64, p32 = z["probs64_" + name], z["probs32_" + name]
+    lg = np.asarray(logits, dtype=np.float64)
+    e = np.exp(lg - lg.max(-1, keepdims=True))
+    p = e / e.sum(-1, keepdims=True)
+    scale = max(1.0, float(np.abs(l64).max()))
+    return dict(dp64=float(np.abs(p - p64).max()), dp32=float(np.abs(p - p32.astype(np.float64)).max()),
+                rel=float(np.abs(lg - l64).max() / scale),
+                ref_dp=float(np.abs(p32.astype(np.float64) - p64).max()),
+                ref_rel=float(np.abs(z["logits32_" + name].astype(np.float64) - l64).max() / scale))

@@ -18,8 +18,12 @@ def _rng(name, seed):
     return np.random.default_rng([zlib.crc32(name.encode()) & 0xffffffff, seed])
 
 
-def make_weights(manifest, seed=0, head_gain=2.0):
+def make_weights(manifest, seed=0, head_gain=2.0, scale=1.0):
     """manifest: list of (name, shape). Returns dict name -> float32 array.
+
+    `scale` multiplies every weight MATRIX (not biases, norm gains or BN statistics): the range fixtures
+    (gen_range.py) use 1.5 / 2 / 3 to leave the O(1)-activation regime the defaults were tuned for, and a
+    larger `head_gain` to saturate the two-way softmax.
 
     Scales are chosen so activations stay O(1) through the depth of both networks and the final logits
     spread enough to exercise every decision branch of call_variants."""
@@ -50,6 +54,6 @@ def make_weights(manifest, seed=0, head_gain=2.0):
                 bound *= 0.05
             if name.startswith("lstm.weight_ih"):
                 bound *= 0.05
-            a = r.uniform(-bound, bound, size=shape)
+            a = r.uniform(-bound, bound, size=shape) * scale
         out[name] = a.astype(np.float32)
     return out
