@@ -53,6 +53,18 @@ class RunCfg(C.Structure):
                 ("indel_min_af", C.c_double), ("min_coverage", C.c_double), ("indel_regions_bed", C.c_char_p)]
 
 
+class RealignJob(C.Structure):
+    _fields_ = [("n_reads", c_i32), ("seqs", c_vp), ("positions", c_vp), ("cigars", c_vp), ("reference", C.c_char_p),
+                ("haplotypes", C.c_char_p), ("ref_start", c_i32), ("ref_prefix", c_i32), ("ref_suffix", c_i32),
+                ("out_positions", c_vp), ("cigar_buf", c_vp), ("cigar_cap", C.c_size_t), ("cigar_off", c_vp), ("status", c_i32)]
+
+
+class RealignStats(C.Structure):
+    _fields_ = [("windows", c_i64), ("host_windows", c_i64), ("reads", c_i64), ("haplotypes", c_i64), ("fast_pairs", c_i64),
+                ("sw_pairs", c_i64), ("sw_cells", c_i64), ("fast_pass_ms", C.c_double), ("sw_ms", C.c_double),
+                ("device_stage_ms", C.c_double), ("host_ms", C.c_double)]
+
+
 class RunStats(C.Structure):
     _fields_ = [("candidates", c_i64), ("sites", c_i64), ("rows", c_i64), ("low_coverage", c_i64), ("clamped", c_i64), ("seconds", C.c_double),
                 ("produce_s", C.c_double), ("finish_s", C.c_double), ("launch_s", C.c_double), ("launcher_wait_s", C.c_double),
@@ -110,6 +122,7 @@ SYMBOLS = {
     "cto_haplotype_filter": (C.c_int, [c_vp, C.c_size_t, C.c_char_p, c_i64, C.c_size_t, c_i64, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int,
                                        C.c_int, c_vp, c_vp]),
     "cto_realign_reads": (C.c_int, [C.c_int, c_vp, c_vp, c_vp, C.c_char_p, C.c_char_p, c_i32, c_i32, c_i32, c_vp, c_vp, C.c_size_t, c_vp]),
+    "cto_realign_windows": (C.c_int, [C.c_int, C.POINTER(RealignJob), C.c_int, C.c_int, c_vp, C.POINTER(RealignStats)]),
     "cto_ssw_align": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(c_i32), C.POINTER(c_i32), c_vp, C.c_size_t]),
     "cto_ssw_pass": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),
     "cto_set_realign_threads": (C.c_int, [C.c_int]),

@@ -496,7 +496,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
                 float sum = 0.f;
 #pragma unroll
                 for (int jj = 0; jj < WKV; ++jj) { sc[jj] = exp_le0((sc[jj] - mx) * 0.125f); sum += sc[jj]; }
-                float inv = __builtin_amdgcn_rcpf(sum);
+                float inv = rcp_fast(sum);
                 inv = fmaf(fmaf(-sum, inv, 1.0f), inv, inv);      // one Newton step: 0.5 ulp
                 float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll

@@ -79,7 +79,7 @@ int launch_gru_layer2_fc1(hipStream_t s, const float* x, const float* W, const f
 // the recurrent layers on split 16-bit operands (experiment behind CTO_GRU_SPLIT=f16|bf16; gru_split_kernel.h): same tiling rule as above
 template <int KIN, int KP, int H, int MS, bool F16, bool FUSE>
 static int launch_split_range(hipStream_t s, const float* x, const void* Wp, const float* bias, const void* Fp, float* fc1_part,
-                              float* out, int64_t B, int64_t begin, int64_t end) {
+                              float* out, int64_t B, int64_t begin, int64_t end, const GruSplitScale& sc) {
     if (end <= begin) return CTO_OK;
     const size_t smem = size_t(4) * MS * 16 * ((H + 8) + (KP + 8)) * sizeof(unsigned short) + size_t(4) * H * sizeof(float);
     static bool attr_set = false;
@@ -90,14 +90,14 @@ static int launch_split_range(hipStream_t s, const float* x, const void* Wp, con
     }
     const unsigned grid = unsigned(cdiv(end - begin, MS * 16)) * 2;
     hipLaunchKernelGGL((k_gru_split<KIN, KP, H, MS, F16, FUSE>), dim3(grid), dim3(256), smem, s, x, static_cast<const uint4*>(Wp), bias,
-                       static_cast<const uint4*>(Fp), fc1_part, out, int(B), int(begin), int(end));
+                       static_cast<const uint4*>(Fp), fc1_part, out, int(B), int(begin), int(end), sc);
     CTO_HIP(hipGetLastError());
     return CTO_OK;
 }
 
 template <int KIN, int KP, int H, bool F16, bool FUSE>
 static int launch_split(hipStream_t s, const float* x, const void* Wp, const float* bias, const void* Fp, float* fc1_part, float* out,
-                        int64_t B) {
+                        int64_t B, const GruSplitScale& sc) {
     static const int cus = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
@@ -106,21 +106,25 @@ static int launch_split(hipStream_t s, const float* x, const void* Wp, const flo
     const int64_t round32 = int64_t(16) * cus;
     const int64_t full = (B / round32) * round32;
     const int64_t rest = B - full;
-    int rc = launch_split_range<KIN, KP, H, 2, F16, FUSE>(s, x, Wp, bias, Fp, fc1_part, out, B, 0, full);
+    int rc = launch_split_range<KIN, KP, H, 2, F16, FUSE>(s, x, Wp, bias, Fp, fc1_part, out, B, 0, full, sc);
     if (rc != CTO_OK || rest == 0) return rc;
-    if (rest * 4 > round32 * 3) return launch_split_range<KIN, KP, H, 2, F16, FUSE>(s, x, Wp, bias, Fp, fc1_part, out, B, full, B);
-    return launch_split_range<KIN, KP, H, 1, F16, FUSE>(s, x, Wp, bias, Fp, fc1_part, out, B, full, B);
+    if (rest * 4 > round32 * 3) return launch_split_range<KIN, KP, H, 2, F16, FUSE>(s, x, Wp, bias, Fp, fc1_part, out, B, full, B, sc);
+    return launch_split_range<KIN, KP, H, 1, F16, FUSE>(s, x, Wp, bias, Fp, fc1_part, out, B, full, B, sc);
 }
 
+// scale5 = {sx, sh, s_total, inv_s, inv_f} (GruSplitScale; chosen by pack_gru_split)
 int launch_gru_layer2_fc1_split(hipStream_t s, const float* x, const void* Wp, const float* bias, const void* Fp, float* fc1_part,
-                                int64_t B, bool f16) {
-    return f16 ? launch_split<256, 256, 192, true, true>(s, x, Wp, bias, Fp, fc1_part, nullptr, B)
-               : launch_split<256, 256, 192, false, true>(s, x, Wp, bias, Fp, fc1_part, nullptr, B);
+                                int64_t B, bool f16, const float* scale5) {
+    const GruSplitScale sc{scale5[0], scale5[1], scale5[2], scale5[3], scale5[4]};
+    return f16 ? launch_split<256, 256, 192, true, true>(s, x, Wp, bias, Fp, fc1_part, nullptr, B, sc)
+               : launch_split<256, 256, 192, false, true>(s, x, Wp, bias, Fp, fc1_part, nullptr, B, sc);
 }
 
-int launch_gru_layer1_split(hipStream_t s, const float* x, const void* Wp, const float* bias, float* out, int64_t B, bool f16) {
-    return f16 ? launch_split<34, 64, 128, true, false>(s, x, Wp, bias, nullptr, nullptr, out, B)
-               : launch_split<34, 64, 128, false, false>(s, x, Wp, bias, nullptr, nullptr, out, B);
+int launch_gru_layer1_split(hipStream_t s, const float* x, const void* Wp, const float* bias, float* out, int64_t B, bool f16,
+                            const float* scale5) {
+    const GruSplitScale sc{scale5[0], scale5[1], scale5[2], scale5[3], scale5[4]};
+    return f16 ? launch_split<34, 64, 128, true, false>(s, x, Wp, bias, nullptr, nullptr, out, B, sc)
+               : launch_split<34, 64, 128, false, false>(s, x, Wp, bias, nullptr, nullptr, out, B, sc);
 }
 
 #ifdef CTO_GRU_CLOCKS

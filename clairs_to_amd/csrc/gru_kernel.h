@@ -32,8 +32,13 @@ namespace cto {
 // --------------------------------------------------------------------------------------------
 // v_exp_f32 / v_rcp_f32 (1 ulp each): `__fdividef` expands to the full IEEE division sequence (div_scale, fma chain,
 // div_fmas, div_fixup: ~10 VALU) - three of those per state element were 40 % of the kernel's non-MFMA instructions.
+#ifdef CTO_PRECISE_MATH
+__device__ __forceinline__ float fast_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return tanhf(x); }
+#else
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+#endif
 
 // MS = 16-row sub-tiles per wave, MH = wave groups along M: the block has 4*MH waves and owns MH*MS*16 sites.
 // With MH = 2 every SIMD hosts two waves of the same workgroup, so one wave's gate arithmetic / barrier wait

@@ -26,6 +26,14 @@
 
 namespace cto {
 
+// Power-of-two scales of the f16 form (models.hip: pack_gru_split chooses them; all 1 for bf16, whose exponent range is fp32's).
+// An f16 half below 2^-14 is sub-normal: a weight of 0.015 then keeps an ABSOLUTE error of 2^-25, which an unrescaled count of 8 000
+// multiplies into 2e-4 of a pre-activation (tests/golden/gen_range.py found it; tools/experiments/split_model.py reproduces it on
+// the CPU).  So every operand class is lifted towards the top of the f16 range before it is split - x by sx, h by sh (|h| <= 1:
+// 2^14), [W_ih | W_hh] by s_total / sx and s_total / sh, fc1.weight by 1 / (inv_f sh) - the accumulators and the bias they start
+// from are in units of s_total, and the gates fold 1 / s_total into the constant their exp2 argument is multiplied with anyway.
+struct GruSplitScale { float sx, sh, s_total, inv_s, inv_f; };
+
 // Fragment-ordered operand arrays (16-byte units, index = ... * 64 + lane; lane = (kg << 4) | j holds k = 32 c + 8 kg .. + 7):
 //   Wp[dir][wave][chunk c < NX + NH][nb][gate r,z,n][hi,lo][lane] : row  gate * H + (wave * NB + nb) * 16 + j  of [W_ih | W_hh]
 //   Fp[dir][t][wave][kh < NH][nt < 2][hi,lo][lane]                : row  wave * 32 + nt * 16 + j  of fc1.weight, k = t 2H + dir H + 32 kh ..
@@ -36,7 +44,7 @@ template <int KIN, int KP, int H, int MS, bool F16, bool FUSE_FC1>
 __global__ __launch_bounds__(256) void k_gru_split(const float* __restrict__ x, const uint4* __restrict__ Wp,
                                                    const float* __restrict__ bias, const uint4* __restrict__ Fp,
                                                    float* __restrict__ fc1_part, float* __restrict__ out, int B, int site_begin,
-                                                   int site_end) {
+                                                   int site_end, GruSplitScale sc) {
     constexpr int NB = H / 64, T = 33, NX = KP / 32, NH = H / 32, NC = NX + NH, NP = MS * NB;
     constexpr int TILE = MS * 16, NTHR = 256;
     constexpr int HSB = H + 8, XSB = KP + 8;             // 16-bit elements per tile row
@@ -57,7 +65,7 @@ __global__ __launch_bounds__(256) void k_gru_split(const float* __restrict__ x, 
 
     for (int i = threadIdx.x; i < 4 * TILE * HSB / 2; i += NTHR) reinterpret_cast<unsigned*>(hbuf)[i] = 0u;   // h_{-1} = 0
     for (int i = threadIdx.x; i < 4 * TILE * XSB / 2; i += NTHR) reinterpret_cast<unsigned*>(xbuf)[i] = 0u;   // rows past the batch
-    for (int i = threadIdx.x; i < 4 * H; i += NTHR) blds[i] = bias[dir * 4 * H + i];
+    for (int i = threadIdx.x; i < 4 * H; i += NTHR) blds[i] = bias[dir * 4 * H + i] * sc.s_total;
 
     // Operand requests are buffer loads: a wave-uniform resource + scalar offset for the (chunk, block) and one lane offset
     // (16 bytes per lane inside a 1 KB unit) - no per-lane 64-bit address arithmetic in the time loop.
@@ -110,9 +118,9 @@ __global__ __launch_bounds__(256) void k_gru_split(const float* __restrict__ x, 
             const int row = u / (KIN / XW), c = (u - row * (KIN / XW)) * XW;
             if (XQ % NTHR == 0 || u < XQ) {
                 uint2 hi, lo;
-                split_pair<F16>(xstage[q].x, xstage[q].y, hi.x, lo.x);
+                split_pair<F16>(xstage[q].x * sc.sx, xstage[q].y * sc.sx, hi.x, lo.x);
                 if constexpr (XW == 4) {
-                    split_pair<F16>(xstage[q].z, xstage[q].w, hi.y, lo.y);
+                    split_pair<F16>(xstage[q].z * sc.sx, xstage[q].w * sc.sx, hi.y, lo.y);
                     *reinterpret_cast<uint2*>(xb + row * XSB + c) = hi;
                     *reinterpret_cast<uint2*>(xb + (TILE + row) * XSB + c) = lo;
                 } else {
@@ -206,6 +214,7 @@ __global__ __launch_bounds__(256) void k_gru_split(const float* __restrict__ x, 
         }
     };
     // gates + state update of one (ms, nb) pair (lane-local), publish that slice of h_t as (hi, lo)
+    const float c_sig = -1.44269504088896340736f * sc.inv_s, c_tanh = 2.88539008177792681472f * sc.inv_s;
     auto gate_pair = [&](int ms, int nb, unsigned short* hn, int t) {
         float hv[4];
 #pragma unroll
@@ -213,16 +222,17 @@ __global__ __launch_bounds__(256) void k_gru_split(const float* __restrict__ x, 
 #if defined(CTO_SPLIT_DBG) && CTO_SPLIT_DBG == 2     // timing probe: no transcendentals (wrong results)
             const float rg = ar[ms][nb][r], zg = az[ms][nb][r], ng = ain[ms][nb][r] + rg * ahn[ms][nb][r];
 #else
-            const float rg = fast_sigmoid(ar[ms][nb][r]);
-            const float zg = fast_sigmoid(az[ms][nb][r]);
-            const float ng = fast_tanh(ain[ms][nb][r] + rg * ahn[ms][nb][r]);
+            // fast_sigmoid / fast_tanh of gru_kernel.h on accumulators in units of s_total (the unit rides on the exp2 constant)
+            const float rg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ar[ms][nb][r] * c_sig));
+            const float zg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(az[ms][nb][r] * c_sig));
+            const float ng = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((ain[ms][nb][r] + rg * ahn[ms][nb][r]) * c_tanh));
 #endif
             hv[r] = ng + zg * (hprev[ms][nb][r] - ng);      // (1 - z) * n + z * h
             hprev[ms][nb][r] = hv[r];
         }
         uint2 hi, lo;
-        split_pair<F16>(hv[0], hv[1], hi.x, lo.x);
-        split_pair<F16>(hv[2], hv[3], hi.y, lo.y);
+        split_pair<F16>(hv[0] * sc.sh, hv[1] * sc.sh, hi.x, lo.x);
+        split_pair<F16>(hv[2] * sc.sh, hv[3] * sc.sh, hi.y, lo.y);
         const int at = (ms * 16 + j) * HSB + (wave * NB + nb) * 16 + kg * 4;
         *reinterpret_cast<uint2*>(hn + at) = hi;
         *reinterpret_cast<uint2*>(hn + TILE * HSB + at) = lo;
@@ -359,7 +369,7 @@ __global__ __launch_bounds__(256) void k_gru_split(const float* __restrict__ x, 
             for (int nt = 0; nt < 2; ++nt) {
                 const int site = site0 + ms * 16 + j;
                 if (site < site_end)
-                    *reinterpret_cast<f32x4*>(part + int64_t(site) * 128 + wave * 32 + nt * 16 + kg * 4) = accf[ms][nt];
+                    *reinterpret_cast<f32x4*>(part + int64_t(site) * 128 + wave * 32 + nt * 16 + kg * 4) = accf[ms][nt] * sc.inv_f;
             }
     }
 }

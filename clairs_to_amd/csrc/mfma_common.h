@@ -63,6 +63,9 @@ __device__ __forceinline__ float selu_f(float x) {
 // branch-free SELU for MFMA epilogues: exp(x) - 1 by the hardware exponential; the cancellation near 0 costs at most one
 // ulp of 1.0 (6e-8 absolute), far inside the 1e-4 parity bar, and there is no libm expm1f call (branches, ~50 VALU) per element
 __device__ __forceinline__ float selu_fast(float x) {
+#ifdef CTO_PRECISE_MATH     // tools/ab builds only: libm everywhere, to price what the fast forms cost in accuracy (range sweep)
+    return selu_f(x);
+#endif
     const float scale = 1.0507009873554804934193349852946f;
     const float alpha = 1.6732632423543772848170429916717f;
     const float neg = scale * alpha * (__expf(fminf(x, 0.f)) - 1.0f);
@@ -71,6 +74,9 @@ __device__ __forceinline__ float selu_fast(float x) {
 // exact-erf GELU (nn.GELU() default).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 round-off class):
 // libm's erff costs ~45 VALU per call and the FFN epilogues evaluate it 160 times per lane per transformer block.
 __device__ __forceinline__ float erf_as(float x) {
+#ifdef CTO_PRECISE_MATH
+    return erff(x);
+#endif
     const float ax = fabsf(x);
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
     float p = fmaf(1.061405429f, t, -1.453152027f);
@@ -81,11 +87,22 @@ __device__ __forceinline__ float erf_as(float x) {
     return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
+// 1 / x where the kernels accept the hardware reciprocal (1 ulp)
+__device__ __forceinline__ float rcp_fast(float x) {
+#ifdef CTO_PRECISE_MATH
+    return 1.0f / x;
+#else
+    return __builtin_amdgcn_rcpf(x);
+#endif
+}
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 // exp(x) for x <= 0 (softmax numerators) on the hardware exp2: the product x * log2(e) is carried in two floats (FMA residual +
 // the constant's low part), so the result is within ~2 ulp like libm's expf, at 7 VALU instead of ~25 (no range / denormal
 // branches: below 2^-126 the hardware flushes to 0, which is what a softmax wants)
 __device__ __forceinline__ float exp_le0(float x) {
+#ifdef CTO_PRECISE_MATH
+    return expf(x);
+#endif
     const float L_HI = 1.44269502162933349609375f, L_LO = 1.925963033500011e-8f;
     const float t = x * L_HI;
     const float e = fmaf(x, L_LO, fmaf(x, L_HI, -t));          // x * log2(e) - t

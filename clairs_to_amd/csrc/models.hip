@@ -19,8 +19,9 @@ using namespace cto;
 // their register allocation and cost up to 4 % from one unrelated edit to the next.
 int launch_gru_layer1(hipStream_t s, const float* x, const float* W, const float* Wf, const float* bias, float* out, int64_t B);
 int launch_gru_layer2_fc1_split(hipStream_t s, const float* x, const void* Wp, const float* bias, const void* Fp, float* fc1_part,
-                                int64_t B, bool f16);
-int launch_gru_layer1_split(hipStream_t s, const float* x, const void* Wp, const float* bias, float* out, int64_t B, bool f16);
+                                int64_t B, bool f16, const float* scale5);
+int launch_gru_layer1_split(hipStream_t s, const float* x, const void* Wp, const float* bias, float* out, int64_t B, bool f16,
+                            const float* scale5);
 int launch_gru_layer2_fc1(hipStream_t s, const float* x, const float* W, const float* Wf, const float* bias, const float* fc1w,
                           const float* fc1f, float* fc1_part, int64_t B);
 
@@ -94,6 +95,7 @@ struct cto_model {
     float *gw1f = nullptr, *gw2f = nullptr, *f1f = nullptr;     // the recurrent weights and the fused fc1 in fragment order (rotated kernels)
     float *gw1_split = nullptr, *gw2_split = nullptr, *f1_split = nullptr;     // layer 2 / fc1 as (hi, lo) 16-bit fragments: CTO_GRU_SPLIT=f16|bf16 (experiment)
     bool split_f16 = false;
+    float split_sc1[5] = {1.f, 1.f, 1.f, 1.f, 1.f}, split_sc2[5] = {1.f, 1.f, 1.f, 1.f, 1.f};   // GruSplitScale of layer 1 / layer 2 (gru_split_kernel.h)
     int cvt_split = 0;          // CvT block GEMMs on split operands: 0 = fp32 kernels, 1 = f16, 2 = bf16 (CTO_CVT_SPLIT, experiment)
     HeadDev head;
     int64_t macs = 0;
@@ -489,7 +491,7 @@ int bigru_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStr
     int rc;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (m->prof_all && (rc = prof_begin(m, s, &e0, &e1))) return rc;
-    if (m->gw1_split) rc = launch_gru_layer1_split(s, x, m->gw1_split, m->gb1, m->b_h, B, m->split_f16);
+    if (m->gw1_split) rc = launch_gru_layer1_split(s, x, m->gw1_split, m->gb1, m->b_h, B, m->split_f16, m->split_sc1);
     else rc = launch_gru_layer1(s, x, m->gw1, m->gw1f, m->gb1, m->b_h, B);
     if (rc) return rc;
     if (m->prof_all) {
@@ -498,7 +500,7 @@ int bigru_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStr
     }
     if (m->prof && (rc = prof_begin(m, s, &e0, &e1))) return rc;
     // layer 2 with the head's fc1 folded in: writes one partial [B][128] slab per direction into b_slab
-    if (m->gw2_split) rc = launch_gru_layer2_fc1_split(s, m->b_h, m->gw2_split, m->gb2, m->f1_split, m->b_slab, B, m->split_f16);
+    if (m->gw2_split) rc = launch_gru_layer2_fc1_split(s, m->b_h, m->gw2_split, m->gb2, m->f1_split, m->b_slab, B, m->split_f16, m->split_sc2);
     else rc = launch_gru_layer2_fc1(s, m->b_h, m->gw2, m->gw2f, m->gb2, m->head.w1, m->f1f, m->b_slab, B);
     if (rc) return rc;
     if (m->prof) {
@@ -597,9 +599,9 @@ inline float f16_value(uint16_t u) {
     return float(h);
 }
 // eight consecutive k of one row -> the 16 bytes a lane holds, hi then (64 lanes later) lo
-inline void put_split8(uint16_t* hi, uint16_t* lo, const float* src, int n_valid, bool f16) {
+inline void put_split8(uint16_t* hi, uint16_t* lo, const float* src, int n_valid, bool f16, float scale = 1.f) {
     for (int e = 0; e < 8; ++e) {
-        const float v = e < n_valid ? src[e] : 0.f;
+        const float v = e < n_valid ? src[e] * scale : 0.f;
         if (f16) { hi[e] = f16_rne(v); lo[e] = f16_rne(v - f16_value(hi[e])); }
         else { hi[e] = bf16_rne(v); lo[e] = bf16_rne(v - bf16_value(hi[e])); }
     }
@@ -638,22 +640,43 @@ int upload_fragments(const cto_weights* w, const std::string& name, int ntiles, 
 
 // Wp[dir][wave][chunk][nb][gate][hi,lo][lane][8], Fp[dir][t][wave][kh][nt][hi,lo][lane][8] (layouts in gru_split_kernel.h)
 // fc1 == nullptr: a layer without the fused head (layer 1); kp = kin rounded up to whole 32-wide chunks, zero weights in the padding
+// The f16 form lifts every operand class towards the top of the f16 range by a power of two (GruSplitScale in gru_split_kernel.h):
+// log2_sx is the scale of the layer's input as the kernel stages it (0 for layer 1, whose input are counts up to 32 767; 14 for
+// layer 2, whose input is layer 1's |h| <= 1), h is staged times 2^14; the weights take what is left of a common accumulator unit
+// 2^S = min over the two parts of (activation scale x the largest power of two that keeps the part's largest weight below 32 768).
 int pack_gru_split(const cto_weights* w, const std::string& base, int kin, int kp, int H, const std::vector<float>* fc1, bool f16,
-                   Arena& a, float** Wout, float** Fout) {
+                   int log2_sx, Arena& a, float** Wout, float** Fout, float* scale5) {
     const int NB = H / 64, NX = kp / 32, NH = H / 32, NC = NX + NH, T = 33;
     int rc = CTO_OK;
     std::vector<uint16_t> W(size_t(2) * 4 * NC * NB * 6 * 64 * 8), F(fc1 ? size_t(2) * T * 4 * NH * 4 * 64 * 8 : 0);
+    float w_ih_scale = 1.f, w_hh_scale = 1.f, f_scale = 1.f;
+    scale5[0] = scale5[1] = scale5[2] = scale5[3] = scale5[4] = 1.f;
+    if (f16) {
+        float mx_ih = 0.f, mx_hh = 0.f, mx_f = 0.f;
+        for (int d = 0; d < 2; ++d) {
+            const std::string sfx = d == 0 ? "" : "_reverse";
+            GETW(wih, base + ".weight_ih_l0" + sfx, int64_t(3) * H * kin);
+            GETW(whh, base + ".weight_hh_l0" + sfx, int64_t(3) * H * H);
+            for (float v : *wih) mx_ih = std::max(mx_ih, std::fabs(v));
+            for (float v : *whh) mx_hh = std::max(mx_hh, std::fabs(v));
+        }
+        if (fc1) for (float v : *fc1) mx_f = std::max(mx_f, std::fabs(v));
+        CTO_REQUIRE(std::isfinite(mx_ih) && std::isfinite(mx_hh) && std::isfinite(mx_f), CTO_EUNSUPPORTED,
+                    "split f16: %s holds a non-finite weight", base.c_str());
+        auto room = [](float mx) { return mx > 0.f ? std::max(-60, std::min(60, int(std::floor(std::log2(32768.0 / double(mx)))))) : 60; };
+        const int log2_sh = 14;
+        const int S = std::min(log2_sx + room(mx_ih), log2_sh + room(mx_hh));
+        w_ih_scale = std::ldexp(1.f, S - log2_sx);
+        w_hh_scale = std::ldexp(1.f, S - log2_sh);
+        const int Sf = room(mx_f);
+        f_scale = std::ldexp(1.f, Sf);
+        scale5[0] = std::ldexp(1.f, log2_sx); scale5[1] = std::ldexp(1.f, log2_sh); scale5[2] = std::ldexp(1.f, S);
+        scale5[3] = std::ldexp(1.f, -S); scale5[4] = std::ldexp(1.f, -(log2_sh + Sf));
+    }
     for (int d = 0; d < 2; ++d) {
         const std::string sfx = d == 0 ? "" : "_reverse";
         GETW(wih, base + ".weight_ih_l0" + sfx, int64_t(3) * H * kin);
         GETW(whh, base + ".weight_hh_l0" + sfx, int64_t(3) * H * H);
-        if (f16) {     // hi must be finite in f16 (and is then exact to 11 bits); trained GRU weights are O(1)
-            float mx = 0.f;
-            for (float v : *wih) mx = std::max(mx, std::fabs(v));
-            for (float v : *whh) mx = std::max(mx, std::fabs(v));
-            if (d == 0 && fc1) for (float v : *fc1) mx = std::max(mx, std::fabs(v));
-            CTO_REQUIRE(mx < 60000.f, CTO_EUNSUPPORTED, "CTO_GRU_SPLIT=f16: a weight of %g does not fit the f16 range", double(mx));
-        }
         for (int wv = 0; wv < 4; ++wv)
             for (int c = 0; c < NC; ++c)
                 for (int nb = 0; nb < NB; ++nb)
@@ -665,7 +688,8 @@ int pack_gru_split(const cto_weights* w, const std::string& base, int kin, int k
                             const float* src = c < NX ? wih->data() + size_t(n) * kin + k0 : whh->data() + size_t(n) * H + k0;
                             const int n_valid = c < NX ? std::max(0, std::min(8, kin - k0)) : 8;
                             const size_t u = ((((size_t(d) * 4 + wv) * NC + c) * NB + nb) * 6 + q * 2) * 64;
-                            put_split8(&W[(u + lane) * 8], &W[(u + 64 + lane) * 8], n_valid > 0 ? src : whh->data(), n_valid, f16);
+                            put_split8(&W[(u + lane) * 8], &W[(u + 64 + lane) * 8], n_valid > 0 ? src : whh->data(), n_valid, f16,
+                                       c < NX ? w_ih_scale : w_hh_scale);
                         }
         for (int t = 0; fc1 && t < T; ++t)
             for (int wv = 0; wv < 4; ++wv)
@@ -676,7 +700,7 @@ int pack_gru_split(const cto_weights* w, const std::string& base, int kin, int k
                             const int n = wv * 32 + nt * 16 + j;
                             const float* src = fc1->data() + size_t(n) * (T * 2 * H) + size_t(t) * 2 * H + d * H + kh * 32 + kg * 8;
                             const size_t u = ((((size_t(d) * T + t) * 4 + wv) * NH + kh) * 4 + nt * 2) * 64;
-                            put_split8(&F[(u + lane) * 8], &F[(u + 64 + lane) * 8], src, 8, f16);
+                            put_split8(&F[(u + lane) * 8], &F[(u + 64 + lane) * 8], src, 8, f16, f_scale);
                         }
     }
     rc = upload_halves(W, a, Wout);
@@ -841,10 +865,10 @@ extern "C" int cto_bigru_create_ex(const cto_weights* w, int n_out, int split_mo
             const std::string kind(e);
             CTO_REQUIRE(kind == "f16" || kind == "bf16", CTO_EINVAL, "CTO_GRU_SPLIT must be f16 or bf16, not '%s'", e);
             m->split_f16 = kind == "f16";
-            if ((rc = pack_gru_split(w, "lstm_2", 256, 256, 192, f1, m->split_f16, m->arena, &m->gw2_split, &m->f1_split))) return fail(rc);
+            if ((rc = pack_gru_split(w, "lstm_2", 256, 256, 192, f1, m->split_f16, 14, m->arena, &m->gw2_split, &m->f1_split, m->split_sc2))) return fail(rc);
             // CTO_GRU_SPLIT_LAYERS=2 keeps layer 1 on the fp32 kernel (default: both recurrent layers on split operands)
             const char* l = getenv("CTO_GRU_SPLIT_LAYERS");
-            if (!(l && l[0] == '2') && (rc = pack_gru_split(w, "lstm", 34, 64, 128, nullptr, m->split_f16, m->arena, &m->gw1_split, nullptr)))
+            if (!(l && l[0] == '2') && (rc = pack_gru_split(w, "lstm", 34, 64, 128, nullptr, m->split_f16, 0, m->arena, &m->gw1_split, nullptr, m->split_sc1)))
                 return fail(rc);
         }
     }

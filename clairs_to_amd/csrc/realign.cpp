@@ -34,8 +34,14 @@
 #include <unordered_map>
 #include <vector>
 #include "common.h"
+#include "realign_internal.h"
 
 namespace {
+using cto_realign::Ends;
+using cto_realign::Op;
+using cto_realign::ReadHit;
+using cto_realign::HapState;
+using cto_realign::SwPair;
 
 // ---- scoring: realigner.cpp:63-73 (set_options) and the default SSW aligner it ends up using (ssw_cpp.cpp:230-242; `InitSswLib`
 // at realigner.cpp:121-127 builds a local object, so the member keeps its defaults - which are the same numbers)
@@ -270,31 +276,37 @@ bool banded_path(const int8_t* ref, const int8_t* read, int R, int Q, int score,
 // ------------------------------------------------------------------------------------------------------------------------
 // ssw_align (ssw.c:781-867) + Aligner::Align / ConvertAlignment / CalculateNumberMismatch (ssw_cpp.cpp:78-215, :302-337):
 // local alignment of `query` to `ref`, CIGAR over {S,=,X,I,D}.
-struct Op { char op; int len; };
 struct SwAlignment { int score = 0, ref_begin = 0; std::vector<Op> cigar; };
 
-SwAlignment sw_align(const std::vector<int8_t>& ref, const std::vector<int8_t>& query) {
-    SwAlignment al;
-    const int R = (int)ref.size(), Q = (int)query.size();
-    if (R == 0 || Q == 0) return al;
+// the two striped passes (ssw.c:781-830): where the best local alignment ends and begins
+Ends sw_ends(const int8_t* ref, int R, const int8_t* query, int Q) {
+    Ends z{0, 0, 0, 0, 0, 16};
+    if (R == 0 || Q == 0) return z;
     int lanes = 16;
-    PassEnd fw = striped_pass(ref.data(), R, false, query.data(), Q, 16, 255);
-    if (fw.overflow) { lanes = 8; fw = striped_pass(ref.data(), R, false, query.data(), Q, 8, 65535); }
-    if (fw.score <= 0) return al;
-    std::vector<int8_t> rq(query.begin(), query.begin() + fw.read_end + 1);
+    PassEnd fw = striped_pass(ref, R, false, query, Q, 16, 255);
+    if (fw.overflow) { lanes = 8; fw = striped_pass(ref, R, false, query, Q, 8, 65535); }
+    if (fw.score <= 0) return z;
+    std::vector<int8_t> rq(query, query + fw.read_end + 1);
     std::reverse(rq.begin(), rq.end());
-    const PassEnd bw = striped_pass(ref.data(), fw.ref_end + 1, true, rq.data(), fw.read_end + 1, lanes, fw.score);
-    const int ref_begin = bw.ref_end, read_begin = fw.read_end - bw.read_end;
+    const PassEnd bw = striped_pass(ref, fw.ref_end + 1, true, rq.data(), fw.read_end + 1, lanes, fw.score);
+    return Ends{fw.score, fw.ref_end, fw.read_end, bw.ref_end, bw.read_end, lanes};
+}
+
+// banded traceback between those points and the CIGAR SSW's C++ wrapper prints (ssw.c:831-867, ssw_cpp.cpp:78-215)
+SwAlignment sw_finish(const int8_t* ref, int R, const int8_t* query, int Q, const Ends& e) {
+    SwAlignment al;
+    if (R == 0 || Q == 0 || e.score <= 0) return al;
+    const int ref_begin = e.ref_begin, read_begin = e.read_end - e.bw_read_end;
     if (ref_begin < 0 || read_begin < 0) return al;
-    const int subR = fw.ref_end - ref_begin + 1, subQ = fw.read_end - read_begin + 1;
+    const int subR = e.ref_end - ref_begin + 1, subQ = e.read_end - read_begin + 1;
     if (subR > 32768 || subQ > 32768) return al;                                   // distance_filter 32767: no CIGAR
     std::vector<Run> runs;
-    if (!banded_path(ref.data() + ref_begin, query.data() + read_begin, subR, subQ, fw.score, std::abs(subR - subQ) + 1, runs)) return al;
-    al.score = fw.score;
+    if (!banded_path(ref + ref_begin, query + read_begin, subR, subQ, e.score, std::abs(subR - subQ) + 1, runs)) return al;
+    al.score = e.score;
     al.ref_begin = ref_begin;
     if (read_begin > 0) al.cigar.push_back({'S', read_begin});
-    const int8_t* r = ref.data() + ref_begin;
-    const int8_t* q = query.data() + read_begin;
+    const int8_t* r = ref + ref_begin;
+    const int8_t* q = query + read_begin;
     char cur = 0;
     int len = 0;
     auto flush = [&] { if (cur) al.cigar.push_back({cur, len}); cur = 0; len = 0; };
@@ -312,9 +324,14 @@ SwAlignment sw_align(const std::vector<int8_t>& ref, const std::vector<int8_t>& 
         }
     }
     flush();
-    const int tail = Q - fw.read_end - 1;
+    const int tail = Q - e.read_end - 1;
     if (tail > 0) al.cigar.push_back({'S', tail});
     return al;
+}
+
+SwAlignment sw_align(const std::vector<int8_t>& ref, const std::vector<int8_t>& query) {
+    const int R = (int)ref.size(), Q = (int)query.size();
+    return sw_finish(ref.data(), R, query.data(), Q, sw_ends(ref.data(), R, query.data(), Q));
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -429,14 +446,6 @@ std::vector<int> positions_map(const std::vector<Op>& cigar, size_t hap_len) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-struct ReadHit { int position = -1, score = 0; bool exact = false; std::vector<Op> cigar; };   // ReadAlignment (realigner.h:103-127)
-struct HapState {
-    int index = 0, score = 0, ref_pos = 0;
-    bool is_reference = false;
-    std::vector<ReadHit> hits;
-    std::vector<Op> cigar;
-    std::vector<int> pos_map;
-};
 
 // k-mer index over the reads (BuildIndex, :435-452): occurrences of one k-mer keep read order, then offset order
 struct KmerIndex {
@@ -467,21 +476,64 @@ void append_cigar(std::string& s, const std::vector<Cop>& ops) {   // CigarVecto
     }
 }
 
-int realign_window(const std::vector<std::string>& reads, const int32_t* positions, const char* const* cigars,
-                   const std::string& reference, const std::vector<std::string>& haps, int ref_start, int ref_prefix, int ref_suffix,
-                   int32_t* out_pos, std::vector<std::string>& out_cigar) {
-    const int n = (int)reads.size(), H = (int)haps.size();
+}  // namespace
+
+int cto_realign_write_cigars(const std::vector<std::string>& out, char* cigar_buf, size_t cigar_cap, int64_t* cigar_off) {
+    size_t used = 0;
+    const int n = (int)out.size();
+    for (int i = 0; i < n; ++i) {
+        cigar_off[i] = (int64_t)used;
+        CTO_REQUIRE(used + out[i].size() + 1 <= cigar_cap, CTO_ENOMEM, "cto_realign_reads: cigar buffer too small");
+        memcpy(cigar_buf + used, out[i].c_str(), out[i].size() + 1);
+        used += out[i].size() + 1;
+    }
+    cigar_off[n] = (int64_t)used;
+    return CTO_OK;
+}
+
+namespace cto_realign {
+
+int get_threads() { return std::max(1, g_threads.load()); }
+
+static std::vector<std::string> split_ws(const char* s) {             // `in >> t` (:786-793)
+    std::vector<std::string> v;
+    const char* p = s;
+    while (*p) {
+        while (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r' || *p == '\f' || *p == '\v') ++p;
+        const char* q = p;
+        while (*q && !(*q == ' ' || *q == '\t' || *q == '\n' || *q == '\r' || *q == '\f' || *q == '\v')) ++q;
+        if (q > p) v.emplace_back(p, q);
+        p = q;
+    }
+    return v;
+}
+
+int Window::init(int n_reads, const char* const* seqs, const int32_t* pos, const char* const* cig, const char* ref,
+                 const char* haplotypes, int ref_start_, int ref_prefix_, int ref_suffix_) {
+    CTO_REQUIRE(n_reads >= 0 && ref && haplotypes, CTO_EINVAL, "cto_realign_reads: bad argument");
+    CTO_REQUIRE(n_reads == 0 || (seqs && pos && cig), CTO_EINVAL, "cto_realign_reads: bad argument");
+    reads.resize(n_reads);
+    cigars.resize(n_reads);
+    positions.assign(pos, pos + n_reads);
+    for (int i = 0; i < n_reads; ++i) { reads[i] = seqs[i]; cigars[i] = cig[i]; }
+    reference = ref;
+    haps = split_ws(haplotypes);
+    ref_start = ref_start_; ref_prefix = ref_prefix_; ref_suffix = ref_suffix_;
     for (const std::string& h : haps)
         CTO_REQUIRE((int)h.size() >= kKmer, CTO_EINVAL, "cto_realign_reads: a haplotype is shorter than the %d-mer seed", kKmer);
+    const int n = n_reads, H = (int)haps.size();
+    hs.assign(H, HapState());
+    for (int h = 0; h < H; ++h) { hs[h].index = h; hs[h].hits.assign(n, ReadHit()); }
+    return CTO_OK;
+}
+
+// fast pass, haplotype by haplotype (:129-229)
+void Window::fast_pass_host() {
+    const int n = (int)reads.size(), H = (int)haps.size();
     KmerIndex index;
     for (int r = 0; r < n; ++r) index.add(reads[r], r);
-
-    // fast pass, haplotype by haplotype (:129-229)
-    std::vector<HapState> hs(H);
     for (int h = 0; h < H; ++h) {
         HapState& st = hs[h];
-        st.index = h;
-        st.hits.assign(n, ReadHit());
         const std::string& hap = haps[h];
         const bool is_ref = hap == reference;
         const int L = (int)hap.size();
@@ -516,59 +568,100 @@ int realign_window(const std::vector<std::string>& reads, const int32_t* positio
         if (score == 0) st.hits.assign(n, ReadHit());
         st.score = score;
     }
+}
 
-    // haplotypes against the reference (:315-349), position maps (:507-512)
-    const Codes refc(reference.data(), reference.size());
-    for (HapState& st : hs) {
-        const std::string& hap = haps[st.index];
-        const SwAlignment al = sw_align(refc.v, Codes(hap.data(), hap.size()).v);
-        if (al.score > 0) {
-            st.is_reference = al.cigar.size() == 1 && al.cigar[0].op == '=' && al.cigar[0].len == (int)hap.size();
-            st.cigar = al.cigar;
-            st.ref_pos = al.ref_begin;
+// The same state from the device's fast pass (csrc/realign_batch.hip: k_fast_pass)
+void Window::set_fast_pass(const int32_t* hit_score, const int32_t* hit_pos, const int32_t* hap_score) {
+    const int n = (int)reads.size(), H = (int)haps.size();
+    for (int h = 0; h < H; ++h) {
+        HapState& st = hs[h];
+        st.score = hap_score[h];
+        st.hits.assign(n, ReadHit());
+        if (st.score == 0) continue;
+        for (int r = 0; r < n; ++r) {
+            const int sc = hit_score[size_t(h) * n + r];
+            if (sc <= 0) continue;
+            ReadHit& hit = st.hits[r];
+            hit.score = sc;
+            hit.position = hit_pos[size_t(h) * n + r];
+            hit.exact = true;
+            hit.cigar.assign(1, Op{'=', (int)reads[r].size()});
         }
-        st.pos_map = positions_map(st.cigar, hap.size());
     }
+}
 
-    // Smith-Waterman for the reads no haplotype took (:351-384).  Reads are independent (each owns its slot of every haplotype's hit
-    // list), so they are dealt to g_threads workers when the caller allows more than one (cto_set_realign_threads; default 1, as the
-    // reference's one process per chunk).
-    std::vector<int> todo;
+// haplotypes against the reference (:315-349) and Smith-Waterman for the reads no haplotype took (:351-384): the list of alignments
+void Window::collect_pairs() {
+    const int n = (int)reads.size(), H = (int)haps.size();
+    refc = Codes(reference.data(), reference.size()).v;
+    hapc.clear();
+    for (const std::string& h : haps) hapc.push_back(Codes(h.data(), h.size()).v);
+    todo.clear();
     for (int r = 0; r < n; ++r) {
         bool taken = false;
         for (const HapState& st : hs) if (st.hits[r].score > 0) { taken = true; break; }
         if (!taken) todo.push_back(r);
     }
-    if (!todo.empty()) {
-        std::vector<Codes> hapc;
-        for (const std::string& h : haps) hapc.emplace_back(h.data(), h.size());
-        std::atomic<size_t> next{0};
-        std::atomic<bool> failed{false};
-        auto work = [&]() {
-            try {
-                for (size_t k = next++; k < todo.size() && !failed; k = next++) {
-                    const int r = todo[k];
-                    const Codes rc(reads[r].data(), reads[r].size());
-                    for (HapState& st : hs) {
-                        if (st.score == 0) continue;
-                        const SwAlignment al = sw_align(hapc[st.index].v, rc.v);
-                        if (al.score > 0 && al.score >= kSswThreshold && st.hits[r].score < al.score) {
-                            st.hits[r].score = al.score;
-                            st.hits[r].cigar = al.cigar;
-                            st.hits[r].position = al.ref_begin;
-                            st.hits[r].exact = false;
-                        }
-                    }
-                }
-            } catch (...) { failed = true; }
-        };
-        const int nt = int(std::min<size_t>(size_t(std::max(1, g_threads.load())), todo.size()));
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nt; ++t) pool.emplace_back(work);
-        work();
-        for (std::thread& t : pool) t.join();
-        CTO_REQUIRE(!failed, CTO_ENOMEM, "cto_realign_reads: a Smith-Waterman worker failed (out of memory)");
+    readc.assign(n, std::vector<int8_t>());
+    for (int r : todo) readc[r] = Codes(reads[r].data(), reads[r].size()).v;
+    pairs.clear();
+    for (int h = 0; h < H; ++h) pairs.push_back({refc.data(), (int)refc.size(), hapc[h].data(), (int)hapc[h].size()});
+    for (int r : todo)
+        for (const HapState& st : hs) {
+            if (st.score == 0) continue;
+            pairs.push_back({hapc[st.index].data(), (int)hapc[st.index].size(), readc[r].data(), (int)readc[r].size()});
+        }
+    ends.clear();
+}
+
+// Reads are independent, so the pairs are dealt to g_threads workers when the caller allows more than one
+// (cto_set_realign_threads; default 1, as the reference's one process per chunk).
+void Window::ends_host() {
+    ends.assign(pairs.size(), Ends{0, 0, 0, 0, 0, 16});
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (size_t k = next++; k < pairs.size(); k = next++) {
+            const SwPair& p = pairs[k];
+            ends[k] = sw_ends(p.ref, p.R, p.query, p.Q);
+        }
+    };
+    const int nt = int(std::min<size_t>(size_t(get_threads()), pairs.size() > (size_t)haps.size() ? pairs.size() - haps.size() : 1));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (std::thread& t : pool) t.join();
+}
+
+int Window::finish(int32_t* out_pos, std::vector<std::string>& out_cigar) {
+    const int n = (int)reads.size(), H = (int)haps.size();
+    CTO_REQUIRE(ends.size() == pairs.size(), CTO_EINVAL, "cto_realign_reads: stage 2 did not run");
+    size_t k = 0;
+    // haplotypes against the reference (:315-349), position maps (:507-512)
+    for (HapState& st : hs) {
+        const SwPair& p = pairs[k];
+        const SwAlignment al = sw_finish(p.ref, p.R, p.query, p.Q, ends[k]);
+        ++k;
+        if (al.score > 0) {
+            st.is_reference = al.cigar.size() == 1 && al.cigar[0].op == '=' && al.cigar[0].len == (int)haps[st.index].size();
+            st.cigar = al.cigar;
+            st.ref_pos = al.ref_begin;
+        }
+        st.pos_map = positions_map(st.cigar, haps[st.index].size());
     }
+    // Smith-Waterman for the reads no haplotype took (:351-384)
+    for (int r : todo)
+        for (HapState& st : hs) {
+            if (st.score == 0) continue;
+            const SwPair& p = pairs[k];
+            const SwAlignment al = sw_finish(p.ref, p.R, p.query, p.Q, ends[k]);
+            ++k;
+            if (al.score > 0 && al.score >= kSswThreshold && st.hits[r].score < al.score) {
+                st.hits[r].score = al.score;
+                st.hits[r].cigar = al.cigar;
+                st.hits[r].position = al.ref_begin;
+                st.hits[r].exact = false;
+            }
+        }
 
     // the reference's std::sort by haplotype score (:108); ties keep whatever order that algorithm leaves them in
     std::vector<int> order(H);
@@ -581,10 +674,10 @@ int realign_window(const std::vector<std::string>& reads, const int32_t* positio
         out_pos[r] = positions[r];
         out_cigar[r] = cigars[r];
         int best = 0, pick = -1;
-        for (int k = 0; k < H; ++k) {                          // GetBestReadAlignment (:514-538)
-            const HapState& st = hs[order[k]];
+        for (int kk = 0; kk < H; ++kk) {                          // GetBestReadAlignment (:514-538)
+            const HapState& st = hs[order[kk]];
             const int sc = st.hits[r].score;
-            if (sc > best || (best > 0 && sc == best && !st.is_reference)) { best = sc; pick = order[k]; }
+            if (sc > best || (best > 0 && sc == best && !st.is_reference)) { best = sc; pick = order[kk]; }
         }
         if (pick < 0) continue;
         const HapState& st = hs[pick];
@@ -602,18 +695,9 @@ int realign_window(const std::vector<std::string>& reads, const int32_t* positio
     return CTO_OK;
 }
 
-std::vector<std::string> split_ws(const char* s) {             // `in >> t` (:786-793)
-    std::vector<std::string> v;
-    const char* p = s;
-    while (*p) {
-        while (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r' || *p == '\f' || *p == '\v') ++p;
-        const char* q = p;
-        while (*q && !(*q == ' ' || *q == '\t' || *q == '\n' || *q == '\r' || *q == '\f' || *q == '\v')) ++q;
-        if (q > p) v.emplace_back(p, q);
-        p = q;
-    }
-    return v;
-}
+}  // namespace cto_realign
+
+namespace {
 
 }  // namespace
 
@@ -622,21 +706,16 @@ extern "C" int cto_realign_reads(int n_reads, const char* const* seqs, const int
                                  int32_t ref_suffix, int32_t* out_positions, char* cigar_buf, size_t cigar_cap, int64_t* cigar_off) try {
     CTO_REQUIRE(n_reads >= 0 && reference && haplotypes && out_positions && cigar_off && (cigar_buf || cigar_cap == 0), CTO_EINVAL,
                 "cto_realign_reads: bad argument");
-    CTO_REQUIRE(n_reads == 0 || (seqs && positions && cigars), CTO_EINVAL, "cto_realign_reads: bad argument");
-    std::vector<std::string> reads(n_reads);
-    for (int i = 0; i < n_reads; ++i) reads[i] = seqs[i];
-    std::vector<std::string> out;
-    const int rc = realign_window(reads, positions, cigars, reference, split_ws(haplotypes), ref_start, ref_prefix, ref_suffix, out_positions, out);
+    cto_realign::Window w;
+    int rc = w.init(n_reads, seqs, positions, cigars, reference, haplotypes, ref_start, ref_prefix, ref_suffix);
     if (rc != CTO_OK) return rc;
-    size_t used = 0;
-    for (int i = 0; i < n_reads; ++i) {
-        cigar_off[i] = (int64_t)used;
-        CTO_REQUIRE(used + out[i].size() + 1 <= cigar_cap, CTO_ENOMEM, "cto_realign_reads: cigar buffer too small");
-        memcpy(cigar_buf + used, out[i].c_str(), out[i].size() + 1);
-        used += out[i].size() + 1;
-    }
-    cigar_off[n_reads] = (int64_t)used;
-    return CTO_OK;
+    w.fast_pass_host();
+    w.collect_pairs();
+    w.ends_host();
+    std::vector<std::string> out;
+    rc = w.finish(out_positions, out);
+    if (rc != CTO_OK) return rc;
+    return cto_realign_write_cigars(out, cigar_buf, cigar_cap, cigar_off);
 }
 CTO_CATCH("cto_realign_reads", int)
 

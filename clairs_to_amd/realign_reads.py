@@ -75,6 +75,45 @@ def realign_window(seqs, positions, cigars, ref_seq, haplotypes, ref_start, pref
     return list(out_pos), [raw[off[i]:off[i + 1] - 1].decode() for i in range(n)]
 
 
+def realign_windows(windows, where="device", threads=0, stats=None):
+    """Many windows in one call (cto_realign_windows, csrc/realign_batch.hip): `windows` = list of the argument tuples of
+    realign_window (seqs, positions, cigars, ref_seq, haplotypes, ref_start, prefix_len, suffix_len); returns the list of
+    (positions, cigars).  where = "device": the k-mer fast pass and the striped Smith-Waterman passes of every window run as two
+    HIP launches (a HIP device must be current); "host": the same windows on `threads` host workers.  Outputs are identical."""
+    from ._lib import RealignJob, RealignStats
+    n = len(windows)
+    jobs = (RealignJob * max(n, 1))()
+    keep = []
+    for j, (seqs, positions, cigars, ref_seq, haplotypes, ref_start, prefix_len, suffix_len) in zip(jobs, windows):
+        m = len(seqs)
+        a_seq = (C.c_char_p * max(m, 1))(*[s.encode() for s in seqs])
+        a_pos = (C.c_int32 * max(m, 1))(*positions)
+        a_cig = (C.c_char_p * max(m, 1))(*[c.encode() for c in cigars])
+        out_pos = (C.c_int32 * max(m, 1))()
+        cap = 64 * m + 8 * sum(len(s) for s in seqs) + sum(len(c) for c in cigars) + 64
+        buf = C.create_string_buffer(cap)
+        off = (C.c_int64 * (m + 1))()
+        j.n_reads = m
+        j.seqs, j.positions, j.cigars = C.cast(a_seq, C.c_void_p), C.cast(a_pos, C.c_void_p), C.cast(a_cig, C.c_void_p)
+        j.reference, j.haplotypes = ref_seq.encode(), " ".join(haplotypes).encode()
+        j.ref_start, j.ref_prefix, j.ref_suffix = ref_start, prefix_len, suffix_len
+        j.out_positions, j.cigar_buf, j.cigar_cap, j.cigar_off = C.cast(out_pos, C.c_void_p), C.cast(buf, C.c_void_p), cap, C.cast(off, C.c_void_p)
+        keep.append((a_seq, a_pos, a_cig, out_pos, buf, off, m))
+    st = RealignStats()
+    stream = None
+    if where == "device":
+        from ._lib import current_stream_ptr
+        stream = current_stream_ptr()
+    check(lib.cto_realign_windows(n, jobs, 1 if where == "device" else 0, int(threads), stream, C.byref(st)))
+    if stats is not None:
+        stats.update({k: getattr(st, k) for k, _ in RealignStats._fields_})
+    out = []
+    for (_, _, _, out_pos, buf, off, m) in keep:
+        raw = buf.raw
+        out.append((list(out_pos[:m]), [raw[off[i]:off[i + 1] - 1].decode() for i in range(m)]))
+    return out
+
+
 def _cigar_ops(cigar):
     n = 0
     for ch in cigar:

@@ -507,6 +507,40 @@ int cto_realign_reads(int n_reads, const char* const* seqs, const int32_t* posit
                       const char* reference, const char* haplotypes, int32_t ref_start, int32_t ref_prefix, int32_t ref_suffix,
                       int32_t* out_positions, char* cigar_buf, size_t cigar_cap, int64_t* cigar_off);
 int cto_ssw_align(const char* ref, const char* query, int32_t* score, int32_t* ref_begin, char* cigar_buf, size_t cigar_cap);
+/* Every window of a run in one call (csrc/realign_batch.hip).  The reference calls realign_reads(...) (src/realign/realigner.cpp:782-857,
+ * bound at src/realign_reads.py:582-591) once per window from one Python process per low-QUAL call (src/realign_variants.py:73-110);
+ * a job is the argument list of one such call plus the caller's output buffers (as cto_realign_reads: out_positions[n_reads],
+ * cigar_off[n_reads + 1], the CIGARs NUL-terminated in cigar_buf).  where = CTO_REALIGN_HOST: the windows are dealt to host_threads
+ * workers (<= 0: cto_set_realign_threads' value), each running what cto_realign_reads runs.  where = CTO_REALIGN_DEVICE: the k-mer
+ * fast pass (realigner.cpp:129-229) of every (window, haplotype) and both striped Smith-Waterman passes (ssw.c:118-529 as
+ * ssw_align drives them, :781-830) of every haplotype / reference and unplaced-read / haplotype pair run as two launches on `stream`
+ * (HIP device current to the caller); the banded traceback and the CIGAR composition stay on the host (host_threads workers).
+ * Windows the device form does not take (a haplotype or the reference longer than 2 048 bases, a read longer than 512) run on the
+ * host inside the same call.  Outputs are the reference's byte for byte either way (tests/test_gpu_realign.py holds both to
+ * oracle/_ref).  jobs[i].status is that window's code; the return value is the first failing window's code. */
+typedef struct cto_realign_job {
+    int32_t n_reads;
+    const char* const* seqs;           /* [n_reads] NUL-terminated read bases                                   */
+    const int32_t* positions;          /* [n_reads] current 0-based alignment starts                            */
+    const char* const* cigars;         /* [n_reads] current CIGARs                                              */
+    const char* reference;             /* prefix + window + suffix                                              */
+    const char* haplotypes;            /* candidate haplotypes, white-space separated (get_consensus' output)  */
+    int32_t ref_start, ref_prefix, ref_suffix;
+    int32_t* out_positions;            /* [n_reads]                                                             */
+    char* cigar_buf; size_t cigar_cap; /* CIGAR text, NUL-terminated one after the other                        */
+    int64_t* cigar_off;                /* [n_reads + 1] offsets into cigar_buf                                  */
+    int32_t status;                    /* out                                                                   */
+} cto_realign_job;
+typedef struct cto_realign_stats {
+    int64_t windows, host_windows, reads, haplotypes;
+    int64_t fast_pairs;                /* (haplotype, read) pairs of the device fast pass                       */
+    int64_t sw_pairs, sw_cells;        /* device Smith-Waterman alignments and their ref x query cells          */
+    double fast_pass_ms, sw_ms;        /* HIP-event time of the two launches                                    */
+    double device_stage_ms, host_ms;   /* wall time up to / after the device stages (packing and copies included) */
+} cto_realign_stats;
+#define CTO_REALIGN_HOST   0
+#define CTO_REALIGN_DEVICE 1
+int cto_realign_windows(int n_jobs, cto_realign_job* jobs, int where, int host_threads, void* stream, cto_realign_stats* stats);
 /* One striped Smith-Waterman pass alone (ssw.c:118-311 / :341-529 of the reference's src/realign: sw_sse2_byte / sw_sse2_word), test
  * hook: ref / read are base codes 0..4, lanes 16 (bytes) or 8 (words), out[4] = {score (255 on 8-bit overflow), ref_end, read_end,
  * overflow}. */

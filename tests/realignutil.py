@@ -162,3 +162,13 @@ def gen_window(rng, n_reads=None):
         cigars.append("%dM" % len(s) if rng.random() < 0.8 else "%dS%dM" % (3, len(s) - 3) if len(s) > 3 else "%dM" % len(s))
     return dict(seqs=seqs, positions=positions, cigars=cigars, reference=ref.decode(), haplotypes=[h.decode() for h in haps],
                 ref_start=ref_start, ref_prefix=prefix, ref_suffix=suffix)
+
+
+def window_args(w):
+    """the argument tuple of clairs_to_amd.realign_reads.realign_window / realign_windows for window dict w"""
+    return (w["seqs"], w["positions"], w["cigars"], w["reference"], w["haplotypes"], w["ref_start"], w["ref_prefix"], w["ref_suffix"])
+
+
+def amd_realign_batch(ws, where, threads=0, stats=None):
+    from clairs_to_amd.realign_reads import realign_windows
+    return [(p, c) for p, c in realign_windows([window_args(w) for w in ws], where=where, threads=threads, stats=stats)]

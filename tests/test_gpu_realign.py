@@ -1,0 +1,102 @@
+"""The device form of the Illumina realigner (csrc/realign_batch.hip; SURVEY.md 8f #4b, the `realign_reads` leg of BASELINE
+configs[3]): k_fast_pass (src/realign/realigner.cpp:129-229) and k_sw_ends (src/realign/ssw.c:118-529 as ssw_align drives them,
+:781-830) for every window of a batch, traceback and CIGAR composition on the host - POS and CIGAR of every read byte for byte
+what the reference's own realigner.cpp + SSW return (oracle/_ref/librealigner_ref.so, compiled from /root/reference by
+`make -C oracle ref`; it travels to the GPU box as a built file) and what the committed golden windows hold."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+import realignutil as ru
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    torch.cuda.set_device(0)
+    return torch.device("cuda:0")
+
+
+def test_device_realigner_on_the_golden_windows(dev):
+    with gzip.open(os.path.join(HERE, "golden", "realign.json.gz"), "rb") as f:
+        g = json.loads(f.read())
+    rng = np.random.default_rng(g["seed"])
+    ws = [ru.gen_window(rng) for _ in g["windows"]]
+    st = {}
+    got = ru.amd_realign_batch(ws, "device", threads=8, stats=st)
+    bad = [i for i, (w, (pos, cig), want) in enumerate(zip(ws, got, g["windows"]))
+           if [[p - w["ref_start"], c] for p, c in zip(pos, cig)] != want]
+    assert not bad, "windows %s differ from the reference's output" % bad[:10]
+    assert st["host_windows"] == 0 and st["fast_pairs"] > 10000 and st["sw_pairs"] > 2000
+    print("golden windows: %d windows, %d reads, fast pass %.3f ms (%d pairs), Smith-Waterman %.3f ms (%d alignments, %.2e cells)" % (
+        st["windows"], st["reads"], st["fast_pass_ms"], st["fast_pairs"], st["sw_ms"], st["sw_pairs"], st["sw_cells"]))
+
+
+@pytest.mark.skipif(ru.ref_lib() is None, reason="oracle/_ref/librealigner_ref.so not built (`make -C oracle ref`, needs /root/reference)")
+def test_device_realigner_equals_the_compiled_reference_on_fresh_windows(dev):
+    seed = int.from_bytes(os.urandom(4), "little")
+    rng = np.random.default_rng(seed)
+    ws = [ru.gen_window(rng) for _ in range(400)] + [ru.gen_window(rng, n_reads=n) for n in (300, 1000)]
+    got = ru.amd_realign_batch(ws, "device", threads=8)
+    for i, (w, g) in enumerate(zip(ws, got)):
+        assert g == ru.ref_realign(w), "window %d of np.random.default_rng(%d)" % (i, seed)
+
+
+def test_device_and_host_forms_agree_and_long_windows_fall_back(dev):
+    rng = np.random.default_rng(77)
+    ws = [ru.gen_window(rng) for _ in range(60)]
+    # a window too long for the device form (haplotypes of 2 500 bases) and one with a 600-base read: host stages inside the same call
+    long_ref = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 2500))
+    hap = long_ref[:1200] + "T" + long_ref[1200:]
+    reads = [hap[a:a + 150] for a in (100, 1100, 1150, 2000)]
+    ws.append(dict(seqs=reads, positions=[100, 1100, 1150, 2000], cigars=["150M"] * 4, reference=long_ref, haplotypes=[long_ref, hap],
+                   ref_start=5000, ref_prefix=100, ref_suffix=100))
+    r2 = ru.gen_window(rng, n_reads=6)
+    r2["seqs"][0] = (r2["reference"] * 3)[:600]
+    r2["cigars"][0] = "600M"
+    ws.append(r2)
+    st = {}
+    got = ru.amd_realign_batch(ws, "device", threads=4, stats=st)
+    assert st["host_windows"] >= 1
+    assert got == ru.amd_realign_batch(ws, "host", threads=4)
+    assert got[-2][1][1] != "150M"                                 # the insertion haplotype re-aligned a read of the long window
+    # a batch is independent of how it is cut
+    assert got[:10] == ru.amd_realign_batch(ws[:10], "device") and got[10:] == ru.amd_realign_batch(ws[10:], "device")
+    assert ru.amd_realign_batch([], "device") == []
+
+
+def test_device_realigner_word_mode_and_ties(dev):
+    """long exact matches (the 8-bit pass overflows at score 249: 63 matching bases) and tandem repeats (equal-score cells:
+    the lazy-F corrections and the first-visited rule of the fast pass decide)"""
+    rng = np.random.default_rng(5)
+    ws = []
+    for it in range(80):
+        unit = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, int(rng.integers(1, 5))))
+        core = (unit * 200)[:int(rng.integers(150, 400))]
+        flank = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 120))
+        ref = flank + core + flank[::-1]
+        hap = flank + core[:len(core) // 2] + unit * int(rng.integers(1, 4)) + core[len(core) // 2:] + flank[::-1]
+        src = [ref, hap]
+        seqs, pos = [], []
+        for _ in range(12):
+            s = src[int(rng.integers(0, 2))]
+            a = int(rng.integers(0, len(s) - 151))
+            r = list(s[a:a + 150])
+            for _ in range(int(rng.integers(0, 6))):
+                r[int(rng.integers(0, 150))] = "ACGT"[int(rng.integers(0, 4))]
+            seqs.append("".join(r))
+            pos.append(1000 + a)
+        ws.append(dict(seqs=seqs, positions=pos, cigars=["150M"] * 12, reference=ref, haplotypes=sorted({ref, hap}), ref_start=1000,
+                       ref_prefix=100, ref_suffix=100))
+    got = ru.amd_realign_batch(ws, "device", threads=4)
+    assert got == ru.amd_realign_batch(ws, "host", threads=4)
+    if ru.ref_lib() is not None:
+        for w, g in zip(ws, got):
+            assert g == ru.ref_realign(w)
