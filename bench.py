@@ -352,6 +352,104 @@ def config_legs(dev, batch, steps=20, warm=40, pool=4):
     return res
 
 
+def realign_leg(dev, n_windows=1500, seed=20260930):
+    """configs[3]'s `realign_reads` leg (SURVEY.md 8f #4b), after the timed region and never in `value`: the native half of the
+    Illumina realignment filter (reference: realign_reads(...) of src/realign/realigner.cpp:782-857, one call per window from one
+    process per low-QUAL call) on synthetic windows (clairs_to_amd/synth_realign.py: 1-60 reads of 20-250 bases, 1-18 haplotypes),
+    the whole set handed to cto_realign_windows in ONE call: host SSE2 on 1 thread and on every usable core, and the device form
+    (k_fast_pass + k_sw_ends, traceback / composition on the cores).  The three outputs are compared for equality here; the tests hold
+    them to the reference compiled into oracle/_ref."""
+    import numpy as np
+    from clairs_to_amd.synth_realign import gen_window
+    from clairs_to_amd.realign_reads import realign_windows
+    rng = np.random.default_rng(seed)
+    ws = [gen_window(rng) for _ in range(n_windows)]
+    args = [(w["seqs"], w["positions"], w["cigars"], w["reference"], w["haplotypes"], w["ref_start"], w["ref_prefix"], w["ref_suffix"]) for w in ws]
+    reads = sum(len(w["seqs"]) for w in ws)
+    cores = usable_cores()
+    out, legs = {}, {}
+
+    def run(name, where, threads, reps):
+        best, got, st = None, None, {}
+        for _ in range(reps):
+            st = {}
+            t = time.perf_counter()
+            got = realign_windows(args, where=where, threads=threads, stats=st)
+            dt = time.perf_counter() - t
+            best = dt if best is None or dt < best else best
+        legs[name] = {"seconds": round(best, 4), "windows_per_s": round(n_windows / best, 1), "reads_per_s": round(reads / best, 1), "host_threads": threads}
+        return got, st
+    sub = 300
+    t = time.perf_counter()
+    one = realign_windows(args[:sub], where="host", threads=1)
+    dt1 = time.perf_counter() - t
+    r1 = sum(len(w["seqs"]) for w in ws[:sub])
+    legs["host_sse2_1_thread"] = {"seconds": round(dt1, 4), "windows_per_s": round(sub / dt1, 1), "reads_per_s": round(r1 / dt1, 1),
+                                  "host_threads": 1, "sample": "first %d windows" % sub}
+    host, _ = run("host_sse2_all_cores", "host", cores, 2)
+    devo, st = run("device", "device", cores, 3)
+    legs["device"].update({
+        "kernel_fast_pass_ms": round(st["fast_pass_ms"], 3), "kernel_sw_ms": round(st["sw_ms"], 3),
+        "fast_pass_pairs": int(st["fast_pairs"]), "sw_alignments": int(st["sw_pairs"]), "sw_cells": int(st["sw_cells"]),
+        "sw_gcups": round(st["sw_cells"] / (st["sw_ms"] * 1e-3) / 1e9, 2) if st["sw_ms"] > 0 else None,
+        "device_stage_wall_ms": round(st["device_stage_ms"], 2), "host_stage_wall_ms": round(st["host_ms"], 2),
+        "windows_on_host": int(st["host_windows"])})
+    out = {"workload": "%d synthetic Illumina realignment windows, %d reads (BASELINE configs[3]: realign_reads path)" % (n_windows, reads),
+           "cores": cores, "outputs_equal": bool(host == devo and host[:sub] == one), **legs,
+           "note": "one cto_realign_windows call per figure, Python list packing included; the reference's own library on one core runs "
+                   "this generator's windows at ~3.8 k reads/s (tools/realign_bench.py, build container); kernel times are HIP events, "
+                   "sw_gcups = reference x query cells of every alignment / k_sw_ends time (both passes of an alignment counted once)"}
+    return out
+
+
+def hapfilter_leg(repeats=8):
+    """the long-read post-calling filter (src/haplotype_filtering.py:882; SURVEY.md 8f #4a) on the committed reference-generated
+    fixture (tests/golden/hapfilter.json.gz: SNV and indel pass of a simulated haplotagged BAM), file to file through
+    clairs_to_amd.haplotype_filtering.haplotype_filter (C evaluation of every read-level rule of a job in one call) - calls/s on the
+    host cores; host code by nature (strings and per-read sets), no device form."""
+    import contextlib
+    import gzip
+    import io
+    import tempfile
+    from argparse import Namespace
+    from clairs_to_amd.haplotype_filtering import haplotype_filter
+    fx = os.path.join(ROOT, "tests", "golden", "hapfilter.json.gz")
+    if not os.path.exists(fx):
+        return {"error": "tests/golden/hapfilter.json.gz not present"}
+    with gzip.open(fx, "rt") as f:
+        g = json.load(f)
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        ref = g["ref"]
+        open(os.path.join(tmp, "ref.fa"), "w").write(">chr1\n" + ref + "\n")
+        open(os.path.join(tmp, "ref.fa.fai"), "w").write("chr1\t%d\t6\t%d\t%d\n" % (len(ref), len(ref), len(ref) + 1))
+        open(os.path.join(tmp, "germline.vcf"), "w").write(g["germline_vcf"])
+        for mode in ("snv", "indel"):
+            m = g["modes"][mode]
+            open(os.path.join(tmp, "pileup_%s.vcf" % mode), "w").write(m["pileup_vcf"])
+            open(os.path.join(tmp, "mp_%s.txt" % mode), "w").write(m["mpileup"])
+            a = Namespace(tumor_bam_fn="unused.bam", ref_fn=os.path.join(tmp, "ref.fa"), ctg_name="chr1",
+                          pileup_vcf_fn=os.path.join(tmp, "pileup_%s.vcf" % mode), output_vcf_fn=os.path.join(tmp, "out_%s.vcf" % mode),
+                          germline_vcf_fn=os.path.join(tmp, "germline.vcf"), output_dir=os.path.join(tmp, "work_" + mode), threads=usable_cores(),
+                          input_filter_tag=None, show_ref=False, samtools="samtools", mpileup_fn=os.path.join(tmp, "mp_%s.txt" % mode),
+                          apply_haplotype_filtering=True, min_mq=20, min_bq=0, min_alt_coverage=2, is_indel=(mode == "indel"), test_pos=None,
+                          flanking=100, haplotype_chunk_max_sites=7, haplotype_chunk_max_span=5000000, disable_read_start_end_filtering=False)
+            best, n_calls = None, 0
+            for _ in range(repeats):
+                t = time.perf_counter()
+                with contextlib.redirect_stdout(io.StringIO()):        # the stage prints its tallies; the bench prints ONE line
+                    r = haplotype_filter(a)
+                dt = time.perf_counter() - t
+                n_calls = len(r)
+                best = dt if best is None or dt < best else best
+            same = open(a.output_vcf_fn).read() == m["out_vcf"]
+            res[mode] = {"calls": n_calls, "seconds": round(best, 4), "calls_per_s": round(n_calls / best, 1), "vcf_equals_reference": bool(same),
+                         "mpileup_bytes": len(m["mpileup"])}
+    res["cores"] = usable_cores()
+    res["note"] = "pileup VCF + germline VCF + nine-column mpileup text in, tagged VCF out (best of %d passes); the reference starts one `samtools mpileup` per call" % repeats
+    return res
+
+
 def self_launch(n):
     """Re-exec this command line under torch.distributed.run with n ranks on this node (rendezvous on 127.0.0.1, a free
     port); the ranks' stdout is ours, so rank 0's JSON line is the only line printed.  Returns the launcher's exit code."""
@@ -385,6 +483,8 @@ def main():
     ap.add_argument("--no-split", action="store_true", help="skip the split-operand experiment leg (`split_mfma`; never part of `value`)")
     ap.add_argument("--no-configs", action="store_true", help="skip the legs on the other BASELINE configs' single-GPU workloads (Illumina, HiFi, "
                     "K = 6, the constructor-default CvT, clustered candidates)")
+    ap.add_argument("--no-postfilters", action="store_true", help="skip the post-calling filter legs (`configs3_realign`: the Illumina realigner, host and "
+                    "device form; `hapfilter`: the long-read haplotype filter) - after the timed region, never part of `value`")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file legs (mpileup text -> VCF, BAM -> VCF)")
     ap.add_argument("--e2e-chunks", type=int, default=96, help="chunk files of the mpileup-text leg (the BAM leg uses a third as many)")
     args = ap.parse_args()
@@ -656,11 +756,11 @@ def main():
                                          "frac": round(feat_bytes / (feat_ms * 1e-3) / 1e9 / 8000.0, 4), "launch_ms": round(feat_ms, 4),
                                          "bytes_per_launch": int(feat_bytes), "traffic": pmc_traffic_featurize(args.batch),
                                          "note": "latency / issue bound, not bandwidth bound (a chain of ~8 dependent global accesses per candidate; scalar unit, VALU and LDS each about half busy: profiles/round3_fused_featurize.md); ~2 % of the step"},
-            "roofline_candidate_extraction": {"bound": "hbm", "kernel": "k_extract_candidates (the gates of extract_candidates_calling on the resident pack: one wave per 8 columns, counters in LDS)",
+            "roofline_candidate_extraction": {"bound": "hbm", "kernel": "k_extract_candidates (the gates of extract_candidates_calling on the resident pack: one lane per column, the 64 columns of a wave staged in LDS, counters in registers - no atomics)",
                                               "achieved": round(ext_bytes / (ext_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                               "frac": round(ext_bytes / (ext_ms * 1e-3) / 1e9 / 8000.0, 4), "launch_ms": round(ext_ms, 4),
                                               "bytes_per_launch": int(ext_bytes), "compaction_ms": round(cmp_ms, 4), "candidates_last_pack": ext_cands,
-                                              "note": "same latency / LDS-atomic bound shape as the two-stage tensor creation; what a REGION job of cto_run_chunks runs between pile-up and tensor creation (e2e.bam_to_vcf_with_extraction); not part of `value`"},
+                                              "note": "bound by dependent-instruction latency at 7-10 waves per CU (16 KB of LDS each), not by bandwidth (0.25 of the HBM peak on a region's 225 MB pack); what a REGION job of cto_run_chunks runs between pile-up and tensor creation (e2e.bam_to_vcf_with_extraction); not part of `value`"},
             "end_to_end_tflops": round(2.0 * eng.macs_per_site * sites_total / dt / 1e12, 3),
             "ranks_seen": dist.get_world_size() if world > 1 else 1,
             "backend": (dist.get_backend() + (" (RCCL over xGMI)" if backend == "nccl" else " (test hook)")) if world > 1 else None,
@@ -683,6 +783,9 @@ def main():
                                                ref["decision"].cpu().numpy(), probs_cpu)
         if world == 1 and not args.no_configs:
             res["configs"] = config_legs(dev, args.batch)
+        if world == 1 and not args.no_postfilters:
+            res.setdefault("configs", {})["configs3_realign"] = realign_leg(dev)
+            res["hapfilter"] = hapfilter_leg()
         if world == 1 and not args.no_e2e:
             # ---- file-to-file legs (never `value`): chunk files + pileup source on disk -> p_<chunk>.vcf through the call_chunks
             # pipeline, everything a real run pays included; the rate is set by the host (cores stated), not by the GPU ----
