@@ -10,12 +10,12 @@
 //                 brute force is O(L * span) byte compares per pair, a few microseconds of a CU - and reproduces the order-
 //                 dependent parts of the original (which start a read keeps on a score tie, when a haplotype position counts as
 //                 covered) from the time (haplotype position, read offset) each candidate would have been visited first.
-//   k_sw_ends     ssw.c:118-529 (sw_sse2_byte / sw_sse2_word) as ssw_align runs them (:781-830): forward pass, word-mode rerun
-//                 on overflow, backward pass.  One 16-lane DPP row is one SSE2 register: lane l holds the stripe positions
-//                 q = l * seg + j of the query exactly as the striped layout of Farrar's kernel does, the byte shift
-//                 _mm_slli_si128 is row_shr:1, the lazy-F loops and their exit tests are kept operation for operation because
-//                 their corrections are not fed back into E - output CIGARs depend on it (csrc/realign.cpp header).  Four
-//                 alignments per wavefront; H / E columns live in LDS.
+//   k_sw<byte>,   ssw.c:118-529 (sw_sse2_byte / sw_sse2_word) as ssw_align runs them (:781-830): forward pass, word-mode rerun
+//   k_sw<word>    on overflow, backward pass.  One DPP row is one SSE2 register - 16 lanes in the 8-bit kernel (four alignments per
+//                 wavefront), 8 lanes in the 16-bit kernel (eight per wavefront): lane l holds the stripe positions q = l * seg + j
+//                 of the query exactly as the striped layout of Farrar's kernel does, the byte shift _mm_slli_si128 is row_shr:1,
+//                 the lazy-F loops and their exit tests are kept operation for operation because their corrections are not fed
+//                 back into E - output CIGARs depend on it (csrc/realign.cpp header).  H / E columns live in LDS.
 // Everything after that - banded traceback between the end points, haplotype order, CIGAR composition - is strings and a few
 // hundred cells per read and stays on the host (csrc/realign.cpp: Window::finish), so device results and host results meet in the
 // same code and are held byte-equal by tests/test_gpu_realign.py against oracle/_ref (the reference's own realigner.cpp + SSW).
@@ -40,16 +40,34 @@ constexpr int FP_NT = 256;
 
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
-__device__ __forceinline__ int row_max16(int v) {
-    v = max(v, dpp_i<0xB1>(v));      // quad_perm [1,0,3,2]
-    v = max(v, dpp_i<0x4E>(v));      // quad_perm [2,3,0,1]
-    v = max(v, dpp_i<0x141>(v));     // row_half_mirror
-    v = max(v, dpp_i<0x140>(v));     // row_mirror
+// A "row" is one SSE2 register of the reference's kernels: LW = 16 lanes (sw_sse2_byte) or 8 lanes (sw_sse2_word) of a wavefront.
+template <int LW>
+__device__ __forceinline__ int row_max(int v) {
+    v = max(v, dpp_i<0xB1>(v));                      // quad_perm [1,0,3,2]
+    v = max(v, dpp_i<0x4E>(v));                      // quad_perm [2,3,0,1]
+    v = max(v, dpp_i<0x141>(v));                     // row_half_mirror: the other quad of the 8 lanes
+    if (LW == 16) v = max(v, dpp_i<0x140>(v));       // row_mirror: the other 8 lanes
     return v;
 }
-__device__ __forceinline__ int row_min16(int v) { return -row_max16(-v); }
-// _mm_slli_si128(x, one element): lane l takes lane l - 1 of its row, lane 0 takes 0
-__device__ __forceinline__ int row_shl1(int v) { return dpp_i<0x111>(v); }
+template <int LW>
+__device__ __forceinline__ int row_min(int v) { return -row_max<LW>(-v); }
+template <int LW>
+__device__ __forceinline__ unsigned row_or(unsigned u) {
+    int v = int(u);
+    v |= dpp_i<0xB1>(v);
+    v |= dpp_i<0x4E>(v);
+    v |= dpp_i<0x141>(v);
+    if (LW == 16) v |= dpp_i<0x140>(v);
+    return unsigned(v);
+}
+// _mm_slli_si128(x, one element): lane l takes lane l - 1 of its row, lane 0 takes 0 (row_shr:1 works on 16 lanes: the first lane
+// of an 8-lane row in the upper half must not see its neighbour row's last lane)
+template <int LW>
+__device__ __forceinline__ int row_shl1(int v, int l) {
+    v = dpp_i<0x111>(v);
+    if (LW == 8 && l == 0) v = 0;
+    return v;
+}
 
 // ------------------------------------------------------------------------------------------------------------------------
 // Fast pass.  One workgroup per haplotype.  Notation of realigner.cpp:147-229: i = haplotype position of a k-mer, o = its offset in
@@ -152,90 +170,162 @@ __global__ __launch_bounds__(FP_NT) void k_fast_pass(FpArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// Striped Smith-Waterman end points.  ROWS alignments per workgroup of 16 * ROWS lanes.
+// Striped Smith-Waterman end points.  k_sw_byte: the 8-bit passes, four 16-lane rows per wavefront (forward; backward when the
+// forward pass did not overflow).  k_sw_word: the 16-bit passes of the alignments whose 8-bit pass overflowed (score >= 249: any
+// read with 63 matching bases in a row, every haplotype against its reference), eight 8-lane rows per wavefront.  The H columns of
+// the previous and the current reference position and the E column live in LDS, [stripe position j][lane]; every lane reads and
+// writes only its own entries, so there is no barrier inside a pass - lanes meet in DPP shifts, ballots and row reductions only.
 struct SwDesc { int ref_off, R, q_off, Q; };
 struct RowPass { int score, ref_end, read_end; bool overflow; };
+#ifdef CTO_SW_PROF      // tools/ builds only: cycles of wave 0 of the launch per phase {main loop, lazy F, best scan, columns, lazy chunks}
+__device__ long long g_sw_prof[8];
+#define SW_T(x) const long long x = clock64()
+#define SW_ADD(i, a, b) if (blockIdx.x == 0 && threadIdx.x == 0) g_sw_prof[i] += (b) - (a)
+#define SW_INC(i) if (blockIdx.x == 0 && threadIdx.x == 0) g_sw_prof[i] += 1
+#else
+#define SW_T(x)
+#define SW_ADD(i, a, b)
+#define SW_INC(i)
+#endif
 
 constexpr int kBias = 6, kGapO = 8, kGapE = 2;
 
 // query profile in striped order: entry (j, l) = code of query position l * seg + j, 7 = padding (scores 0 against everything).
 // `rev_from` >= 0: the query is qraw[rev_from], qraw[rev_from - 1], ... (the reversed prefix of the backward pass)
-__device__ __forceinline__ void build_profile(unsigned char* qprof, const signed char* qraw, int Q, int seg, int lanes, int l, int rev_from) {
+template <int LW>
+__device__ __forceinline__ void build_profile(unsigned char* qprof, const signed char* qraw, int Q, int seg, int l, int rev_from) {
     for (int j = 0; j < seg; ++j) {
         const int q = l * seg + j;
         unsigned char c = 7;
-        if (l < lanes && q < Q) c = static_cast<unsigned char>(rev_from >= 0 ? qraw[rev_from - q] : qraw[q]);
-        qprof[j * 16 + l] = c;
+        if (q < Q) c = static_cast<unsigned char>(rev_from >= 0 ? qraw[rev_from - q] : qraw[q]);
+        qprof[j * LW + l] = c;
     }
 }
 
+// One column of LDS traffic at a time would leave a wavefront waiting out an LDS round trip per stripe position (and, in the lazy-F
+// loops, per exit test): every loop below works in chunks of CH stripe positions - CH reads in flight, the dependent arithmetic on
+// registers, the writes behind it.  The lazy-F loops evaluate a chunk's exit tests speculatively (ballots are cheap) and apply the
+// corrections up to the first test that ends the loop, which is exactly the set the one-at-a-time loop would have applied.
 template <bool BYTE>
 __device__ RowPass row_pass(const signed char* refc, int r_begin, int r_end, int r_step, const unsigned char* qprof, int Q, int seg,
-                            short* H0, short* H1, short* E, int terminate, int l, int rowshift) {
-    constexpr int LANES = BYTE ? 16 : 8;
-    const bool act = l < LANES;
-    for (int j = 0; j < seg; ++j) { H0[j * 16 + l] = 0; H1[j * 16 + l] = 0; E[j * 16 + l] = 0; }
+                            short* H0, short* H1, short* E, int terminate, int l, int rowbase) {
+    constexpr int LW = BYTE ? 16 : 8, CH = 8;
+    for (int j = 0; j < seg; ++j) { H0[j * LW + l] = 0; H1[j * LW + l] = 0; E[j * LW + l] = 0; }
     short* store = H0;
     short* load = H1;
     int best = 0, ref_end = BYTE ? -1 : 0, best_q = 0x7fffffff;
     bool overflow = false;
-    auto row_any = [&](bool p) { return ((__ballot(p) >> rowshift) & 0xffffull) != 0ull; };
+    auto row_any = [&](bool p) { return ((__ballot(p) >> rowbase) & ((1ull << LW) - 1ull)) != 0ull; };
+    int rc = r_begin != r_end ? refc[r_begin] : 0;
     for (int i = r_begin; i != r_end; i += r_step) {
-        const int rc = refc[i];
+        const int rc_next = i + r_step != r_end ? refc[i + r_step] : 0;       // one column ahead of its use
         int f = 0, colmax = 0;
-        int h = row_shl1(int(store[(seg - 1) * 16 + l]));
+        SW_T(t0); SW_INC(3);
+        int h = row_shl1<LW>(int(store[(seg - 1) * LW + l]), l);
         { short* t = store; store = load; load = t; }          // load = column i - 1 (final), store = column i
-        for (int j = 0; j < seg; ++j) {
-            const int qc = qprof[j * 16 + l];
-            const int sc = qc == 7 ? 0 : ((qc == rc && rc < 4) ? 4 : -6);
-            if (BYTE) h = max(min(h + sc + kBias, 255) - kBias, 0);
-            else h = min(h + sc, 32767);
-            const int e = E[j * 16 + l];
-            h = max(h, max(e, f));
-            if (!act) h = 0;
-            colmax = max(colmax, h);
-            store[j * 16 + l] = short(h);
-            const int h2 = max(h - kGapO, 0);
-            E[j * 16 + l] = short(max(max(e - kGapE, 0), h2));            // E never sees the lazy-F corrections below
-            f = max(max(f - kGapE, 0), h2);
-            h = load[j * 16 + l];
-        }
-        if (BYTE) {               // ssw.c:207-241: test, then correct; the chain wraps around the stripes
-            f = row_shl1(f);
-            int j = 0;
-            while (row_any(f > max(int(store[j * 16 + l]) - kGapO, 0))) {
-                const int hh = max(int(store[j * 16 + l]), f);
-                colmax = max(colmax, hh);
-                store[j * 16 + l] = short(hh);
-                f = max(f - kGapE, 0);
-                if (++j >= seg) { j = 0; f = row_shl1(f); }
+        for (int j0 = 0; j0 < seg; j0 += CH) {
+            int ev[CH], hv[CH], qv[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int j = min(j0 + c, seg - 1);
+                ev[c] = E[j * LW + l]; hv[c] = load[j * LW + l]; qv[c] = qprof[j * LW + l];
             }
-        } else {                  // ssw.c:446-459: correct, then test; at most `lanes` rounds
-            bool done = false;
-            for (int k = 0; k < LANES && !done; ++k) {
-                f = row_shl1(f);
-                if (!act) f = 0;
-                for (int j = 0; j < seg; ++j) {
-                    const int hh = max(int(store[j * 16 + l]), f);
-                    colmax = max(colmax, hh);
-                    store[j * 16 + l] = short(hh);
-                    const int h2 = max(hh - kGapO, 0);
-                    f = max(f - kGapE, 0);
-                    if (!row_any(f > h2)) { done = true; break; }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (j0 + c < seg) {
+                    const int j = j0 + c, e = ev[c], qc = qv[c];
+                    const int sc = qc == 7 ? 0 : ((qc == rc && rc < 4) ? 4 : -6);
+                    if (BYTE) h = max(min(h + sc + kBias, 255) - kBias, 0);
+                    else h = min(h + sc, 32767);
+                    h = max(h, max(e, f));
+                    colmax = max(colmax, h);
+                    store[j * LW + l] = short(h);
+                    const int h2 = max(h - kGapO, 0);
+                    E[j * LW + l] = short(max(max(e - kGapE, 0), h2));            // E never sees the lazy-F corrections below
+                    f = max(max(f - kGapE, 0), h2);
+                    h = hv[c];
                 }
             }
         }
-        colmax = row_max16(colmax);
+        SW_T(t1); SW_ADD(0, t0, t1);
+        // The lazy-F loops, a chunk of CH stripe positions per trip.  Inside a chunk the carried F only decays (f - 2c, clamped at 0)
+        // and a position's corrected value depends on nothing but that and what is stored there, so every position's exit test can be
+        // evaluated at once: bit c of `want` = "this lane's test at position c says go on", OR-ed over the row; the loop ends at the
+        // first position whose bit is clear - the corrections up to there are exactly those of the one-position-at-a-time loop.
+        if (BYTE) {               // ssw.c:207-241: test, then correct; the chain wraps around the stripes
+            f = row_shl1<LW>(f, l);
+            int j0 = 0;
+            for (bool go = true; go;) {
+                const int nv = min(CH, seg - j0);
+                int sv[CH];
+#pragma unroll
+                for (int c = 0; c < CH; ++c) sv[c] = store[min(j0 + c, seg - 1) * LW + l];
+                unsigned want = 0;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) want |= (max(f - kGapE * c, 0) > max(sv[c] - kGapO, 0) ? 1u : 0u) << c;
+                want = row_or<LW>(want);
+                const unsigned ends = ~want & ((1u << nv) - 1u);
+                const int ncorr = ends ? __ffs(int(ends)) - 1 : nv;      // positions [0, ncorr) are corrected
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int hh = c < ncorr ? max(sv[c], max(f - kGapE * c, 0)) : sv[c];
+                    colmax = max(colmax, hh);
+                    if (c < nv) store[(j0 + c) * LW + l] = short(hh);
+                }
+                f = max(f - kGapE * ncorr, 0);
+                if (ends) go = false;
+                else { j0 += nv; if (j0 >= seg) { j0 = 0; f = row_shl1<LW>(f, l); } }
+            }
+        } else {                  // ssw.c:446-459: correct, then test; at most `lanes` rounds
+            bool done = false;
+            for (int k = 0; k < LW && !done; ++k) {
+                f = row_shl1<LW>(f, l);
+                for (int j0 = 0; j0 < seg && !done; j0 += CH) {
+                    SW_INC(4);
+                    const int nv = min(CH, seg - j0);
+                    int sv[CH];
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) sv[c] = store[min(j0 + c, seg - 1) * LW + l];
+                    unsigned want = 0;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const int hh = max(sv[c], max(f - kGapE * c, 0));
+                        want |= (max(f - kGapE * (c + 1), 0) > max(hh - kGapO, 0) ? 1u : 0u) << c;
+                    }
+                    want = row_or<LW>(want);
+                    const unsigned ends = ~want & ((1u << nv) - 1u);
+                    const int ncorr = ends ? __ffs(int(ends)) : nv;       // positions [0, ncorr) are corrected (the ending one included)
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const int hh = c < ncorr ? max(sv[c], max(f - kGapE * c, 0)) : sv[c];
+                        colmax = max(colmax, hh);
+                        if (c < nv) store[(j0 + c) * LW + l] = short(hh);
+                    }
+                    f = max(f - kGapE * ncorr, 0);
+                    if (ends) done = true;
+                }
+            }
+        }
+        SW_T(t2); SW_ADD(1, t1, t2);
+        colmax = row_max<LW>(colmax);
         if (colmax > best) {
             best = colmax;
             if (BYTE && best + kBias >= 255) { overflow = true; break; }
             ref_end = i;
             int mq = 0x7fffffff;            // smallest linear query position that holds the new maximum
-            for (int j = 0; j < seg; ++j)
-                if (int(store[j * 16 + l]) == best) { mq = l * seg + j; break; }
-            best_q = row_min16(mq);
+            for (int j0 = 0; j0 < seg && mq == 0x7fffffff; j0 += CH) {
+                int sv[CH];
+#pragma unroll
+                for (int c = 0; c < CH; ++c) sv[c] = store[min(j0 + c, seg - 1) * LW + l];
+#pragma unroll
+                for (int c = CH - 1; c >= 0; --c)
+                    if (j0 + c < seg && sv[c] == best) mq = l * seg + j0 + c;
+            }
+            best_q = row_min<LW>(mq);
         }
+        SW_T(t3); SW_ADD(2, t2, t3);
         if (colmax == terminate) break;
+        rc = rc_next;
     }
     int read_end = Q - 1;
     if (best == 0) read_end = min(read_end, 0);          // the zeroed hmax matches a maximum of 0 at position 0
@@ -243,47 +333,52 @@ __device__ RowPass row_pass(const signed char* refc, int r_begin, int r_end, int
     return RowPass{overflow ? 255 : best, ref_end, read_end, overflow};
 }
 
-template <int ROWS>
-__global__ __launch_bounds__(16 * ROWS) void k_sw_ends(const signed char* pool, const SwDesc* desc, const int* order, int n, Ends* out,
-                                                         int Rcap, int Qcap, int segcap) {
+// LDS of one row: reference codes, query codes, striped profile, H (two columns) and E
+__host__ __device__ inline size_t sw_row_bytes(int Rcap, int Qcap, int segcap, int LW) {
+    return size_t(Rcap) + Qcap + size_t(segcap) * LW + size_t(3) * segcap * LW * sizeof(short);
+}
+
+template <bool BYTE>
+__global__ __launch_bounds__(64) void k_sw(const signed char* pool, const SwDesc* desc, const int* order, int n, Ends* out,
+                                             unsigned char* overflowed, int Rcap, int Qcap, int segcap) {
+    constexpr int LW = BYTE ? 16 : 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int row = threadIdx.x >> 4, l = threadIdx.x & 15;
-    const int slot = blockIdx.x * ROWS + row;
-    const bool live = slot < n;
+    const int row = threadIdx.x / LW, l = threadIdx.x % LW;
+    const int slot = blockIdx.x * (blockDim.x / LW) + row;         // 1, 2, 4 (, 8) rows per wavefront: launch_sw decides
+    bool live = slot < n;
     const int k = live ? order[slot] : 0;
-    const size_t row_bytes = size_t(Rcap) + Qcap + size_t(segcap) * 16 + size_t(3) * segcap * 16 * sizeof(short);
-    unsigned char* base = lds + size_t(row) * row_bytes;
+    if (!BYTE && live && !overflowed[k]) live = false;        // the 16-bit kernel takes only what the 8-bit pass gave up on
+    unsigned char* base = lds + size_t(row) * sw_row_bytes(Rcap, Qcap, segcap, LW);
     signed char* refc = reinterpret_cast<signed char*>(base);
     signed char* qraw = refc + Rcap;
     unsigned char* qprof = reinterpret_cast<unsigned char*>(qraw + Qcap);
-    short* H0 = reinterpret_cast<short*>(qprof + size_t(segcap) * 16);
-    short* H1 = H0 + size_t(segcap) * 16;
-    short* E = H1 + size_t(segcap) * 16;
+    short* H0 = reinterpret_cast<short*>(qprof + size_t(segcap) * LW);
+    short* H1 = H0 + size_t(segcap) * LW;
+    short* E = H1 + size_t(segcap) * LW;
     const SwDesc d = live ? desc[k] : SwDesc{0, 0, 0, 0};
-    for (int i = l; i < d.R; i += 16) refc[i] = pool[d.ref_off + i];
-    for (int i = l; i < d.Q; i += 16) qraw[i] = pool[d.q_off + i];
+    for (int i = l; i < d.R; i += LW) refc[i] = pool[d.ref_off + i];
+    for (int i = l; i < d.Q; i += LW) qraw[i] = pool[d.q_off + i];
     __syncthreads();
     if (!live) return;
     Ends e{0, 0, 0, 0, 0, 16};
+    bool ovf = false;
     if (d.R > 0 && d.Q > 0) {
-        const int rowshift = (threadIdx.x & 63) & ~15;
-        int lanes = 16, seg = (d.Q + 15) / 16;
-        build_profile(qprof, qraw, d.Q, seg, 16, l, -1);
-        RowPass fw = row_pass<true>(refc, 0, d.R, 1, qprof, d.Q, seg, H0, H1, E, 255, l, rowshift);
-        if (fw.overflow) {
-            lanes = 8; seg = (d.Q + 7) / 8;
-            build_profile(qprof, qraw, d.Q, seg, 8, l, -1);
-            fw = row_pass<false>(refc, 0, d.R, 1, qprof, d.Q, seg, H0, H1, E, 65535, l, rowshift);
-        }
-        if (fw.score > 0) {
-            const int Q2 = fw.read_end + 1, seg2 = (Q2 + lanes - 1) / lanes;
-            build_profile(qprof, qraw, Q2, seg2, lanes, l, fw.read_end);
-            const RowPass bw = lanes == 16 ? row_pass<true>(refc, fw.ref_end, -1, -1, qprof, Q2, seg2, H0, H1, E, fw.score, l, rowshift)
-                                           : row_pass<false>(refc, fw.ref_end, -1, -1, qprof, Q2, seg2, H0, H1, E, fw.score, l, rowshift);
-            e = Ends{fw.score, fw.ref_end, fw.read_end, bw.ref_end, bw.read_end, lanes};
+        const int rowbase = threadIdx.x - l;
+        const int seg = (d.Q + LW - 1) / LW;
+        build_profile<LW>(qprof, qraw, d.Q, seg, l, -1);
+        const RowPass fw = row_pass<BYTE>(refc, 0, d.R, 1, qprof, d.Q, seg, H0, H1, E, BYTE ? 255 : 65535, l, rowbase);
+        if (BYTE && fw.overflow) ovf = true;
+        else if (fw.score > 0) {
+            const int Q2 = fw.read_end + 1, seg2 = (Q2 + LW - 1) / LW;
+            build_profile<LW>(qprof, qraw, Q2, seg2, l, fw.read_end);
+            const RowPass bw = row_pass<BYTE>(refc, fw.ref_end, -1, -1, qprof, Q2, seg2, H0, H1, E, fw.score, l, rowbase);
+            e = Ends{fw.score, fw.ref_end, fw.read_end, bw.ref_end, bw.read_end, LW};
         }
     }
-    if (l == 0) out[k] = e;
+    if (l == 0) {
+        if (BYTE) overflowed[k] = ovf ? 1 : 0;
+        if (!ovf) out[k] = e;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -381,16 +476,21 @@ int fast_pass_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats*
     return CTO_OK;
 }
 
-template <int ROWS>
-int launch_sw(hipStream_t s, const signed char* pool, const SwDesc* desc, const int* order, int n, Ends* out, int Rcap, int Qcap) {
+template <bool BYTE>
+int launch_sw(hipStream_t s, const signed char* pool, const SwDesc* desc, const int* order, int n, Ends* out, unsigned char* overflowed,
+              int Rcap, int Qcap) {
     if (n == 0) return CTO_OK;
+    constexpr int LW = BYTE ? 16 : 8;
+    // A pass is a chain of dependent steps: a wavefront runs it at the pace of ONE row whatever the number of rows it holds
+    // (measured: one row per wavefront is no faster than eight - 56 against 45 ms for the 2 560 haplotype-length alignments of the
+    // bench's batch: the time IS the chain of the longest alignment, ~1.4 M dependent stripe positions at ~90 cycles each)
+    const int ROWS = 64 / LW;
     Rcap = (Rcap + 15) & ~15; Qcap = (Qcap + 15) & ~15;
-    const int segcap = (Qcap + 7) / 8;
-    const size_t row_bytes = size_t(Rcap) + Qcap + size_t(segcap) * 16 + size_t(3) * segcap * 16 * sizeof(short);
-    const size_t smem = row_bytes * ROWS;
+    const int segcap = (Qcap + LW - 1) / LW;
+    const size_t smem = sw_row_bytes(Rcap, Qcap, segcap, LW) * ROWS;
     CTO_REQUIRE(smem <= size_t(160) * 1024, CTO_EUNSUPPORTED, "cto_realign_windows: an alignment of %d x %d does not fit the LDS", Rcap, Qcap);
-    CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sw_ends<ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
-    hipLaunchKernelGGL((k_sw_ends<ROWS>), dim3(unsigned((n + ROWS - 1) / ROWS)), dim3(16 * ROWS), smem, s, pool, desc, order, n, out, Rcap, Qcap, segcap);
+    CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sw<BYTE>), hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
+    hipLaunchKernelGGL((k_sw<BYTE>), dim3(unsigned((n + ROWS - 1) / ROWS)), dim3(unsigned(LW * ROWS)), smem, s, pool, desc, order, n, out, overflowed, Rcap, Qcap, segcap);
     CTO_HIP(hipGetLastError());
     return CTO_OK;
 }
@@ -423,7 +523,7 @@ int ends_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats* st) 
     first[ws.size()] = desc.size();
     const int n = int(desc.size());
     if (n == 0) return CTO_OK;
-    // two classes: queries of read length (4 per wavefront) and haplotype-length queries (1 per wavefront); inside a class
+    // two classes (their LDS footprints differ): queries of read length and haplotype-length queries; inside a class
     // by descending query length, so that the rows of a wavefront - and the waves of a round - run for about as long
     std::vector<int> small, large;
     int Rs = 0, Qs = 0, Rl = 0, Ql = 0;
@@ -442,26 +542,54 @@ int ends_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats* st) 
     DevBuf<SwDesc> d_desc;
     DevBuf<int> d_order;
     DevBuf<Ends> d_out;
+    DevBuf<unsigned char> d_ovf;
     int rc;
-    if ((rc = d_pool.put(pool, s)) || (rc = d_desc.put(desc, s)) || (rc = d_order.put(order, s)) || (rc = d_out.alloc(size_t(n)))) return rc;
-    hipEvent_t e0, e1;
+    if ((rc = d_pool.put(pool, s)) || (rc = d_desc.put(desc, s)) || (rc = d_order.put(order, s)) || (rc = d_out.alloc(size_t(n))) ||
+        (rc = d_ovf.alloc(size_t(n))))
+        return rc;
+    // 8-bit passes, then the 16-bit passes of what overflowed (same slots, same order: a row without overflow leaves at once).  The two
+    // classes are independent chains of two launches each and both end in a long tail (the longest alignment of the class), so the
+    // haplotype-length class runs on a stream of its own beside the read-length class.
+    hipEvent_t e0, e1, fork, join;
+    hipStream_t s2;
     CTO_HIP(hipEventCreate(&e0)); CTO_HIP(hipEventCreate(&e1));
+    CTO_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming)); CTO_HIP(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+    CTO_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
     CTO_HIP(hipEventRecord(e0, s));
-    if ((rc = launch_sw<4>(s, d_pool.p, d_desc.p, d_order.p, int(small.size()), d_out.p, Rs, Qs))) return rc;
-    if ((rc = launch_sw<1>(s, d_pool.p, d_desc.p, d_order.p + small.size(), int(large.size()), d_out.p, Rl, Ql))) return rc;
+    CTO_HIP(hipEventRecord(fork, s));
+    CTO_HIP(hipStreamWaitEvent(s2, fork, 0));
+    if ((rc = launch_sw<true>(s2, d_pool.p, d_desc.p, d_order.p + small.size(), int(large.size()), d_out.p, d_ovf.p, Rl, Ql)) ||
+        (rc = launch_sw<false>(s2, d_pool.p, d_desc.p, d_order.p + small.size(), int(large.size()), d_out.p, d_ovf.p, Rl, Ql)) ||
+        (rc = launch_sw<true>(s, d_pool.p, d_desc.p, d_order.p, int(small.size()), d_out.p, d_ovf.p, Rs, Qs)) ||
+        (rc = launch_sw<false>(s, d_pool.p, d_desc.p, d_order.p, int(small.size()), d_out.p, d_ovf.p, Rs, Qs))) {
+        (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2);
+        return rc;
+    }
+    CTO_HIP(hipEventRecord(join, s2));
+    CTO_HIP(hipStreamWaitEvent(s, join, 0));
     CTO_HIP(hipEventRecord(e1, s));
     std::vector<Ends> ends(static_cast<size_t>(n), Ends{0, 0, 0, 0, 0, 16});
     CTO_HIP(hipMemcpyAsync(ends.data(), d_out.p, size_t(n) * sizeof(Ends), hipMemcpyDeviceToHost, s));
     CTO_HIP(hipStreamSynchronize(s));
     float ms = 0.f;
     CTO_HIP(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(fork); (void)hipEventDestroy(join);
+    (void)hipStreamDestroy(s2);
     if (st) { st->sw_ms += ms; st->sw_pairs += n; st->sw_cells += cells; }
     for (size_t wi = 0; wi < ws.size(); ++wi) ws[wi]->set_ends(ends.data() + first[wi]);
     return CTO_OK;
 }
 
 }  // namespace
+
+#ifdef CTO_SW_PROF
+extern "C" int cto_debug_sw_prof(long long* out8, int reset) {
+    CTO_HIP(hipDeviceSynchronize());
+    CTO_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_sw_prof), 8 * sizeof(long long)));
+    if (reset) { long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; CTO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sw_prof), z, sizeof(z))); }
+    return CTO_OK;
+}
+#endif
 
 extern "C" int cto_realign_windows(int n_jobs, cto_realign_job* jobs, int where, int host_threads, void* stream, cto_realign_stats* stats) try {
     CTO_REQUIRE(n_jobs >= 0 && (jobs || n_jobs == 0) && (where == CTO_REALIGN_HOST || where == CTO_REALIGN_DEVICE), CTO_EINVAL,
