@@ -75,7 +75,7 @@ def realign_window(seqs, positions, cigars, ref_seq, haplotypes, ref_start, pref
     return list(out_pos), [raw[off[i]:off[i + 1] - 1].decode() for i in range(n)]
 
 
-def realign_windows(windows, where="device", threads=0, stats=None):
+def realign_windows(windows, where="device", threads=0, stats=None, statuses=None):
     """Many windows in one call (cto_realign_windows, csrc/realign_batch.hip): `windows` = list of the argument tuples of
     realign_window (seqs, positions, cigars, ref_seq, haplotypes, ref_start, prefix_len, suffix_len); returns the list of
     (positions, cigars).  where = "device": the k-mer fast pass and the striped Smith-Waterman passes of every window run as two
@@ -104,7 +104,13 @@ def realign_windows(windows, where="device", threads=0, stats=None):
     if where == "device":
         from ._lib import current_stream_ptr
         stream = current_stream_ptr()
-    check(lib.cto_realign_windows(n, jobs, 1 if where == "device" else 0, int(threads), stream, C.byref(st)))
+    rc = lib.cto_realign_windows(n, jobs, 1 if where == "device" else 0, int(threads), stream, C.byref(st))
+    if statuses is not None:          # the caller sorts the failures out window by window (a list of codes, then the first error's text)
+        statuses[:] = [int(j.status) for j in jobs[:n]] + [lib.cto_last_error().decode("utf-8", "replace") if rc != 0 else ""]
+        if rc != 0 and not any(statuses[:n]):
+            check(rc)
+    else:
+        check(rc)
     if stats is not None:
         stats.update({k: getattr(st, k) for k, _ in RealignStats._fields_})
     out = []
@@ -112,6 +118,104 @@ def realign_windows(windows, where="device", threads=0, stats=None):
         raw = buf.raw
         out.append((list(out_pos[:m]), [raw[off[i]:off[i + 1] - 1].decode() for i in range(m)]))
     return out
+
+
+class WindowBatcher(object):
+    """realign_fn of many calls at once.  The reference starts one `realign_reads` process per low-QUAL call and each hands its
+    windows to the native realigner one by one (src/realign_variants.py:73-110, src/realign_reads.py:582-595).  Here the calls of
+    a run are worker THREADS; a worker that needs a window realigned parks it here and sleeps, and when every live worker is
+    parked (or `max_batch` windows wait) one cto_realign_windows call does them all - on the device two launches per batch.
+    What a call sees is what realign_window returns, so its SAM text does not depend on who shared the batch.
+        with WindowBatcher("device", threads=8) as b:      # b.worker() brackets a worker thread's life
+            ...
+    """
+
+    def __init__(self, where="device", threads=0, max_batch=8192, device=None):
+        import threading
+        self.where, self.threads, self.max_batch = where, int(threads), int(max_batch)
+        self.cv = threading.Condition()
+        self.queue, self.live, self.parked, self.closed = [], 0, 0, False
+        self.batches, self.windows, self.stats = 0, 0, {}
+        self.device = device
+        self.thread = threading.Thread(target=self._run, name="cto-window-batcher", daemon=True)
+        self.thread.start()
+
+    # -- worker side
+    def worker(self):
+        b = self
+
+        class _W(object):
+            def __enter__(self_):
+                with b.cv:
+                    b.live += 1
+
+            def __exit__(self_, *exc):
+                with b.cv:
+                    b.live -= 1
+                    b.cv.notify_all()
+        return _W()
+
+    def __call__(self, seqs, positions, cigars, ref_seq, haplotypes, ref_start, prefix_len, suffix_len):
+        slot = {"args": (seqs, positions, cigars, ref_seq, haplotypes, ref_start, prefix_len, suffix_len), "done": False, "out": None, "err": None}
+        with self.cv:
+            if self.closed:
+                raise RuntimeError("WindowBatcher is closed")
+            self.queue.append(slot)
+            self.parked += 1
+            self.cv.notify_all()
+            while not slot["done"]:
+                self.cv.wait()
+            self.parked -= 1
+        if slot["err"] is not None:
+            raise RuntimeError(slot["err"])
+        return slot["out"]
+
+    # -- dispatcher
+    def _run(self):
+        if self.where == "device":
+            import torch
+            if self.device is not None:
+                torch.cuda.set_device(self.device)
+        while True:
+            with self.cv:
+                # dispatch when nobody is left to add to the batch: every live worker is parked (a caller outside worker() counts
+                # as one that is), or the batch is full
+                while not self.closed and not (self.queue and (self.parked >= max(self.live, 1) or len(self.queue) >= self.max_batch)):
+                    self.cv.wait(0.05 if self.queue else None)
+                if self.closed and not self.queue:
+                    return
+                batch, self.queue = self.queue, []
+            st, codes = {}, []
+            try:
+                outs = realign_windows([b["args"] for b in batch], where=self.where, threads=self.threads, stats=st, statuses=codes)
+                for b, o, code in zip(batch, outs, codes):
+                    if code == 0:
+                        b["out"] = o
+                    else:
+                        b["err"] = "cto_realign_windows: status %d (%s)" % (code, codes[-1])
+            except Exception as e:          # the whole batch failed (out of device memory, ...): every caller hears of it
+                for b in batch:
+                    b["err"] = str(e)
+            with self.cv:
+                self.batches += 1
+                self.windows += len(batch)
+                for k, v in st.items():
+                    self.stats[k] = self.stats.get(k, 0) + v
+                for b in batch:
+                    b["done"] = True
+                self.cv.notify_all()
+
+    def close(self):
+        with self.cv:
+            self.closed = True
+            self.cv.notify_all()
+        self.thread.join()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def _cigar_ops(cigar):
@@ -387,14 +491,16 @@ def reads_realignment(args, out=None):
         if not ref:
             sys.exit("[ERROR] Failed to load reference sequence from file ({}).".format(args.ref_fn))
         rows = bam_view(args.bam_fn, args.ctg_name, max(1, rd_lo), rd_hi, args.min_mq if args.min_mq > 0 else 0)
-        realign_region(rows, args.ctg_name, ref, ref_lo - 1, args.pos, out, args.min_coverage, args.max_distance)
+        realign_region(rows, args.ctg_name, ref, ref_lo - 1, args.pos, out, args.min_coverage, args.max_distance,
+                       realign_fn=getattr(args, "realign_fn", None) or realign_window)
         return
     ref = faidx(args.samtools, args.ref_fn, "{}:{}-{}".format(args.ctg_name, ref_lo, ref_hi))
     if not ref:
         sys.exit("[ERROR] Failed to load reference sequence from file ({}).".format(args.ref_fn))
     cmd = "{} view -h {} {}:{}-{}".format(args.samtools, args.bam_fn, args.ctg_name, rd_lo, rd_hi) + (" -q {}".format(args.min_mq) if args.min_mq > 0 else "")
     view = subprocess.Popen(shlex.split(cmd), stdout=subprocess.PIPE, universal_newlines=True, bufsize=8388608)
-    realign_region(view.stdout, args.ctg_name, ref, ref_lo - 1, args.pos, out, args.min_coverage, args.max_distance)
+    realign_region(view.stdout, args.ctg_name, ref, ref_lo - 1, args.pos, out, args.min_coverage, args.max_distance,
+                   realign_fn=getattr(args, "realign_fn", None) or realign_window)
     view.stdout.close()
     view.wait()
 

@@ -180,7 +180,7 @@ def word_match(line, word):
     return re.search(r"(?<![A-Za-z0-9_])%s(?![A-Za-z0-9_])" % re.escape(word), line) is not None
 
 
-def evaluate_call(args, rec):
+def evaluate_call(args, rec, realign_fn=None):
     """extract_base (realign_variants.py:59-123) for one call -> (ctg, pos, passes, counts)"""
     ctg, pos = (args.ctg_name if args.ctg_name is not None else rec["ctg"]), rec["pos"]
     try:
@@ -205,6 +205,7 @@ def evaluate_call(args, rec):
     ns.pos, ns.ctg_name, ns.bam_fn, ns.ref_fn, ns.samtools = pos, ctg, args.bam_fn, args.ref_fn, args.samtools
     ns.min_mq, ns.min_coverage, ns.realign_flanking_window, ns.max_distance = 20, 2.0, 100, 50        # realign_reads' own defaults (:690-711)
     ns.bam_reader = "native" if native else "samtools"
+    ns.realign_fn = realign_fn                # None: one cto_realign_reads per window; a WindowBatcher: windows of many calls per launch
     rr.reads_realignment(ns, out=sam)
     if native:
         new = sam_column_alleles(sam.getvalue(), pos, args.min_mq, args.min_bq)
@@ -235,7 +236,20 @@ def realign_variants(args):
     todo = [r for r in calls.values() if r["filter"] == "PASS"]
     threads = max(1, int(args.threads * 4 / 5))
     failed, done = set(), 0
-    if getattr(args, "pool", "thread") == "process" and threads > 1 and len(todo) > 1:
+    batcher = None
+    if getattr(args, "realigner", "host") == "device" and todo:
+        # the calls are worker threads that park their windows at a WindowBatcher (realign_reads.py): when all of them wait, one
+        # cto_realign_windows call - k_fast_pass + k_sw on the current HIP device - serves the lot.  More threads than cores on
+        # purpose: they sleep while the batch runs, and a batch is only as large as the number of calls in flight.
+        batcher = rr.WindowBatcher("device", threads=threads)
+        workers = max(threads, min(256, len(todo)))
+        pool = ThreadPoolExecutor(max_workers=workers)
+
+        def one(r):
+            with batcher.worker():
+                return evaluate_call(args, r, realign_fn=batcher)
+        results = pool.map(one, todo)
+    elif getattr(args, "pool", "thread") == "process" and threads > 1 and len(todo) > 1:
         import multiprocessing as mp
         pool = ProcessPoolExecutor(max_workers=threads, mp_context=mp.get_context("spawn"))
         results = pool.map(_evaluate_call_star, [(args, r) for r in todo], chunksize=max(1, min(64, len(todo) // (4 * threads) or 1)))
@@ -249,6 +263,9 @@ def realign_variants(args):
             done += 1
             if done % 1000 == 0:
                 print("[INFO] Processing in {}, total processed positions: {}".format(ctg, done), flush=True)
+    if batcher is not None:
+        batcher.close()
+        print("[INFO] Realigner on the device: {} windows in {} batches".format(batcher.windows, batcher.batches), flush=True)
     out_header = header_up_to_last_format(header)
     fai = args.ref_fn + ".fai" if os.path.exists(args.ref_fn + ".fai") else ".".join(args.ref_fn.split(".")[:-1]) + ".fai"
     names = None if args.ctg_name is None else args.ctg_name.split(",")
@@ -285,6 +302,10 @@ def main():
     p.add_argument("--threads", type=int, default=1)
     p.add_argument("--pool", type=str, default="thread", choices=["thread", "process"],
                    help="workers are threads (default) or spawned processes (the reference's ProcessPoolExecutor; scales with the cores)")
+    p.add_argument("--realigner", type=str, default="host", choices=["host", "device"],
+                   help="host: every window through cto_realign_reads on the worker that needs it (SSE2); device: the windows of all calls "
+                        "in flight are batched into cto_realign_windows calls on the current HIP device (k-mer fast pass and both striped "
+                        "Smith-Waterman passes as kernels; same output)")
     p.add_argument("--python", type=str, default="python3", help="accepted for compatibility: the realignment runs in-process")
     p.add_argument("--show_ref", action="store_true")
     p.add_argument("--min_mq", type=int, default=20)             # shared/param.py:17

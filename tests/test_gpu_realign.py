@@ -100,3 +100,35 @@ def test_device_realigner_word_mode_and_ties(dev):
     if ru.ref_lib() is not None:
         for w, g in zip(ws, got):
             assert g == ru.ref_realign(w)
+
+
+from test_realign_flow import flow  # noqa: E402,F401  (the simulated paired-end run the reference's Python was recorded on)
+
+
+def test_realign_variants_with_the_device_realigner_writes_the_reference_vcf(dev, flow, tmp_path):
+    """`realign_variants --realigner device`: the calls of the run are worker threads whose windows meet in WindowBatcher and go to the
+    device in batches - the output VCF is the one the unmodified reference wrote (tests/golden/realign_flow.json.gz), SNV and indel
+    pass, and `realign_reads` SAM text through the batcher equals the one-window-at-a-time text."""
+    import io
+    from argparse import Namespace
+    import realignsim
+    from clairs_to_amd import realign_variants as rv
+    from clairs_to_amd import realign_reads as rr
+    g, sim, paths = flow
+    for is_indel, key in ((False, "vcf"), (True, "vcf_indel")):
+        out = str(tmp_path / ("device_%s.vcf" % key))
+        failed = rv.realign_variants(Namespace(bam_fn=paths["bam"], ref_fn=paths["ref"], ctg_name=realignsim.CTG, pileup_vcf_fn=paths["vcf"],
+                                               output_vcf_fn=out, samtools=paths["samtools"], threads=8, show_ref=False, min_mq=20, min_bq=0,
+                                               enable_realignment=True, is_indel=is_indel, realigner="device"))
+        assert open(out).read() == g[key]
+        assert len(failed) >= 8
+    pos = int(sorted(g["positions"])[0])
+    a = Namespace(pos=pos, ctg_name=realignsim.CTG, bam_fn=paths["bam"], ref_fn=paths["ref"], samtools=paths["samtools"], min_mq=20,
+                  min_coverage=2.0, realign_flanking_window=100, max_distance=50)
+    want = io.StringIO()
+    rr.reads_realignment(a, out=want)
+    with rr.WindowBatcher("device", threads=2) as b:
+        a.realign_fn = b
+        got = io.StringIO()
+        rr.reads_realignment(a, out=got)
+    assert got.getvalue() == want.getvalue() and b.windows >= 1

@@ -37,3 +37,28 @@ def test_batch_reports_the_failing_window_and_finishes_the_others():
     st = {}
     ru.amd_realign_batch(ws[:2], "host", stats=st)
     assert st["windows"] == 2 and st["host_windows"] == 2 and st["reads"] == 10 and st["sw_pairs"] == 0
+
+
+def test_window_batcher_serves_many_callers_with_what_one_call_returns():
+    """WindowBatcher (clairs_to_amd/realign_reads.py): worker threads park windows, one cto_realign_windows call per batch - every
+    caller gets what realign_window gives, a failing window raises in its own caller only."""
+    from concurrent.futures import ThreadPoolExecutor
+    from clairs_to_amd.realign_reads import WindowBatcher, realign_window
+    rng = np.random.default_rng(9)
+    ws = [ru.gen_window(rng, n_reads=6) for _ in range(80)]
+    want = [realign_window(*ru.window_args(w)) for w in ws]
+    bad = dict(ws[5], haplotypes=["ACGT"])
+    with WindowBatcher("host", threads=2, max_batch=16) as b:
+        def one(w):
+            with b.worker():
+                try:
+                    return b(*ru.window_args(w))
+                except RuntimeError as e:
+                    return str(e)
+        with ThreadPoolExecutor(24) as ex:
+            got = list(ex.map(one, ws + [bad]))
+        assert b.windows == 81 and 1 < b.batches < 81
+    assert got[:80] == [(p, c) for p, c in want]
+    assert "shorter" in got[80]
+    with pytest.raises(RuntimeError):
+        b(*ru.window_args(ws[0]))
