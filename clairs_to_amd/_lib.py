@@ -122,6 +122,8 @@ SYMBOLS = {
     "cto_haplotype_filter": (C.c_int, [c_vp, C.c_size_t, C.c_char_p, c_i64, C.c_size_t, c_i64, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int,
                                        C.c_int, c_vp, c_vp]),
     "cto_realign_reads": (C.c_int, [C.c_int, c_vp, c_vp, c_vp, C.c_char_p, C.c_char_p, c_i32, c_i32, c_i32, c_vp, c_vp, C.c_size_t, c_vp]),
+    "cto_softmax_pairs": (C.c_int, [c_vp, c_i64, c_vp, c_vp]),
+    "cto_qual_pending": (C.c_int, [c_vp, c_i64, c_vp, c_vp]),
     "cto_realign_windows": (C.c_int, [C.c_int, C.POINTER(RealignJob), C.c_int, C.c_int, c_vp, C.POINTER(RealignStats)]),
     "cto_ssw_align": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(c_i32), C.POINTER(c_i32), c_vp, C.c_size_t]),
     "cto_ssw_pass": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),

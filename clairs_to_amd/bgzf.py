@@ -12,7 +12,8 @@ BGZF_PAD = 1024            # include/clairsto_amd.h: CTO_BGZF_PAD
 BLOCK_DTYPE = np.dtype([("file_off", "<u8"), ("in_off", "<u8"), ("out_off", "<u8"), ("csize", "<u4"), ("isize", "<u4"),
                         ("bsize", "<u4"), ("crc32", "<u4")])
 STATUS = {1: "reserved block type", 2: "stored block length check", 3: "bad code-length table", 4: "invalid literal / length code",
-          5: "invalid distance", 6: "more output than ISIZE", 7: "ran past the compressed data", 8: "less output than ISIZE"}
+          5: "invalid distance", 6: "more output than ISIZE", 7: "ran past the compressed data", 8: "less output than ISIZE",
+          9: "output slot closer than CTO_BGZF_SLOT_PAD to the next one (block table not laid out by cto_bgzf_scan)"}
 
 _tls = threading.local()
 

@@ -278,7 +278,7 @@ __device__ void huff_table32(const Huff& h, const uint8_t* lens, const uint16_t*
     __builtin_amdgcn_wave_barrier();
 }
 
-enum { ST_OK = 0, ST_BAD_BTYPE = 1, ST_BAD_STORED = 2, ST_BAD_TABLE = 3, ST_BAD_CODE = 4, ST_BAD_DIST = 5, ST_OVERRUN_OUT = 6, ST_OVERRUN_IN = 7, ST_SHORT = 8 };
+enum { ST_OK = 0, ST_BAD_BTYPE = 1, ST_BAD_STORED = 2, ST_BAD_TABLE = 3, ST_BAD_CODE = 4, ST_BAD_DIST = 5, ST_OVERRUN_OUT = 6, ST_OVERRUN_IN = 7, ST_SHORT = 8, ST_BAD_SLOT = 9 };
 
 }  // namespace
 
@@ -299,6 +299,14 @@ extern "C" __global__ __launch_bounds__(64) CTO_INF_ATTR void k_bgzf_inflate(con
     if (blk >= n_blocks) return;
     const cto_bgzf_block bd = blocks[blk];
     const int isize = int(bd.isize);
+    // the literal path checks its output bound once per refill and may store up to 32 bytes behind isize: every slot must be followed by
+    // CTO_BGZF_SLOT_PAD bytes that belong to nobody (cto_bgzf_scan lays them out so).  A table laid out by an older rule (isize + 4) is
+    // refused here, block by block, instead of corrupting its neighbour's output; the pad behind the LAST slot is the caller's to provide
+    // (cto_bgzf_scan's *out_bytes includes it).
+    if (blk + 1 < n_blocks && blocks[blk + 1].out_off < bd.out_off + uint64_t(isize) + CTO_BGZF_SLOT_PAD && blocks[blk + 1].out_off >= bd.out_off) {
+        if (threadIdx.x == 0) status[blk] = ST_BAD_SLOT;
+        return;
+    }
     const long long in_bits = (long long)bd.csize * 8;
     uint8_t* dst = out + bd.out_off;
     const uint8_t* win = dst;                // window reads are device-scope atomic loads: not through the vector L1 (it is not

@@ -199,9 +199,20 @@ struct Mapped {                           // a file's bytes: mapped read-only, o
     const char* p = nullptr;
     size_t n = 0;
     std::vector<char> owned;
-    bool open(const char* path, std::string* err) {
+    // sniff = true: look at the first two bytes instead of the name (`gzip -fdc`, which the reference's bed_tree_from pipes every BED
+    // through, shared/interval_tree.py:43, inflates what is gzip and passes on what is not)
+    bool open(const char* path, std::string* err, bool sniff = false) {
         const size_t pl = strlen(path);
-        if (pl > 3 && strcmp(path + pl - 3, ".gz") == 0) {            // the reference's readers gzip.open such files
+        bool gz = pl > 3 && strcmp(path + pl - 3, ".gz") == 0;        // the reference's readers gzip.open such files
+        if (sniff && !gz) {
+            const int fd0 = ::open(path, O_RDONLY | O_CLOEXEC);
+            if (fd0 < 0) { *err = std::string("cannot open ") + path; return false; }
+            unsigned char magic[2] = {0, 0};
+            const ssize_t got = ::read(fd0, magic, 2);
+            ::close(fd0);
+            gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        }
+        if (gz) {
             gzFile g = gzopen(path, "rb");
             if (!g) { *err = std::string("cannot open ") + path; return false; }
             (void)gzbuffer(g, 1 << 20);
@@ -419,10 +430,12 @@ struct Run {
     bool load_indel_regions(std::string* err) {
         if (!cfg->indel_regions_bed || !cfg->indel_regions_bed[0]) return true;
         Mapped bed;
-        if (!bed.open(cfg->indel_regions_bed, err)) return false;
+        if (!bed.open(cfg->indel_regions_bed, err, /*sniff=*/true)) return false;
         std::map<std::string, std::vector<std::pair<int64_t, int64_t>>> rows;
         size_t i = 0;
+        int64_t row_id = 0;
         while (i < bed.n) {
+            ++row_id;
             const char* nl = static_cast<const char*>(memchr(bed.p + i, '\n', bed.n - i));
             const size_t e = nl ? size_t(nl - bed.p) : bed.n;
             std::string row(bed.p + i, e - i);
@@ -430,7 +443,13 @@ struct Run {
             if (row.empty() || row[0] == '#') continue;
             char name[256];
             long long a = 0, b = 0;
-            if (sscanf(row.c_str(), "%255s %lld %lld", name, &a, &b) != 3) continue;
+            if (row.find_first_not_of(" \t\r") == std::string::npos) continue;
+            // a row the reference cannot split into name, start, end ends its run with an exception (interval_tree.py:47-55): an
+            // unreadable BED must not turn into "no regions", which would let every indel candidate through
+            if (sscanf(row.c_str(), "%255s %lld %lld", name, &a, &b) != 3) {
+                *err = "[ERROR] Invalid bed input in " + std::to_string(row_id) + "-th row of " + std::string(cfg->indel_regions_bed) + ": " + row.substr(0, 80);
+                return false;
+            }
             if (b < a || a < 0 || b < 0) { *err = "[ERROR] Invalid bed input in " + std::string(cfg->indel_regions_bed) + ": " + row; return false; }
             if (a == b) ++b;
             rows[name].emplace_back(a, b);

@@ -125,7 +125,41 @@ __global__ __launch_bounds__(256) void k_softmax_probs(const float* __restrict__
     probs[i * 2 + 1] = softmax_p1(o);
 }
 
+// 2-way softmax of n rows [n][2] (the modules' own `apply_softmax`, clairs/model.py:255-259 / 461-465): the arithmetic of k_softmax_probs
+__global__ void k_softmax_pairs(const float* __restrict__ logits, int64_t n, float* __restrict__ out) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float o[2] = {logits[i * 2], logits[i * 2 + 1]};
+    out[i * 2 + 0] = softmax_p0(o);
+    out[i * 2 + 1] = softmax_p1(o);
+}
+
+// number of sites whose QUAL waits for the host half (decision[.][1] bit 2), added to *count
+__global__ void k_qual_pending(const int32_t* __restrict__ decision, int64_t B, int32_t* __restrict__ count) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const bool flagged = i < B && (decision[i * 4 + 1] & 4) != 0;
+    const unsigned long long m = __ballot(flagged);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, int32_t(__popcll(m)));
+}
+
 }  // namespace
+
+extern "C" int cto_softmax_pairs(const float* logits, int64_t n, float* out, void* stream) {
+    CTO_REQUIRE(n >= 0 && (n == 0 || (logits && out)), CTO_EINVAL, "cto_softmax_pairs: bad argument");
+    if (n == 0) return CTO_OK;
+    hipLaunchKernelGGL(k_softmax_pairs, dim3(unsigned(cto::cdiv(n, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), logits, n, out);
+    CTO_HIP(hipGetLastError());
+    return CTO_OK;
+}
+
+extern "C" int cto_qual_pending(const int32_t* decision, int64_t B, int32_t* count, void* stream) {
+    CTO_REQUIRE(decision && count && B >= 0, CTO_EINVAL, "cto_qual_pending: bad argument");
+    CTO_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), static_cast<hipStream_t>(stream)));
+    if (B == 0) return CTO_OK;
+    hipLaunchKernelGGL(k_qual_pending, dim3(unsigned(cto::cdiv(B, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), decision, B, count);
+    CTO_HIP(hipGetLastError());
+    return CTO_OK;
+}
 
 extern "C" int cto_softmax_probs(const float* aff_logits, const float* neg_logits, int K, int64_t B, float* probs, void* stream) {
     CTO_REQUIRE(aff_logits && neg_logits && probs, CTO_EINVAL, "cto_softmax_probs: null argument");

@@ -215,7 +215,7 @@ __device__ RowPass row_pass(const signed char* refc, int r_begin, int r_end, int
     short* load = H1;
     int best = 0, ref_end = BYTE ? -1 : 0, best_q = 0x7fffffff;
     bool overflow = false;
-    auto row_any = [&](bool p) { return ((__ballot(p) >> rowbase) & ((1ull << LW) - 1ull)) != 0ull; };
+    (void)rowbase;
     int rc = r_begin != r_end ? refc[r_begin] : 0;
     for (int i = r_begin; i != r_end; i += r_step) {
         const int rc_next = i + r_step != r_end ? refc[i + r_step] : 0;       // one column ahead of its use

@@ -167,13 +167,17 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> posterior(const Tensor& aff, const Te
                                stream_of(a)),
                  "posterior");
     if (B > 0) {
-        // host half of QUAL (cto_qual_finalize): the op hands back final values, so it looks at the flags here - one 16 B/site
-        // copy and a stream synchronisation per call; the flagged sites (about two in a million) are re-evaluated with the host libm
-        Tensor dec_h = dec.cpu();
-        const int32_t* d = dec_h.data_ptr<int32_t>();
-        bool any = false;
-        for (int64_t i = 0; i < B && !any; ++i) any = (d[i * 4 + 1] & 4) != 0;
-        if (any) {
+        // host half of QUAL (cto_qual_finalize): the op hands back final values.  The flags are counted on the device
+        // (cto_qual_pending) and only those four bytes cross PCIe per call; the 16 B/site download and the host pass happen on the
+        // ~1 call in a hundred that holds a site on a rounding boundary
+        Tensor pending = at::empty({1}, a.options().dtype(at::kInt));
+        check_rc(cto_qual_pending(dec.data_ptr<int32_t>(), B, pending.data_ptr<int32_t>(), stream_of(a)), "qual_pending");
+        int32_t n_pending = 0;
+        C10_HIP_CHECK(hipMemcpyAsync(&n_pending, pending.data_ptr<int32_t>(), sizeof(int32_t), hipMemcpyDeviceToHost,
+                                     static_cast<hipStream_t>(stream_of(a))));
+        C10_HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream_of(a))));
+        if (n_pending > 0) {
+            Tensor dec_h = dec.cpu();
             Tensor qual_h = qual.cpu();
             check_rc(int(cto_qual_finalize(dec_h.data_ptr<int32_t>(), qual_h.data_ptr<double>(), B)) < 0 ? -1 : 0, "qual_finalize");
             dec.copy_(dec_h);
@@ -187,6 +191,18 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> posterior_meta(const Tensor& aff, con
     return {at::empty({B, 2 * K, 2}, aff.options()), at::empty({B, K}, aff.options().dtype(at::kDouble)),
             at::empty({B, 4}, aff.options().dtype(at::kInt)), at::empty({B}, aff.options().dtype(at::kDouble))};
 }
+
+// ---- the modules' own Softmax(dim=1) (apply_softmax=True) ---------------------------------------------------------------
+Tensor softmax2(const Tensor& logits) {
+    TORCH_CHECK(logits.is_cuda() && logits.scalar_type() == at::kFloat && logits.dim() >= 1 && logits.size(-1) == 2,
+                "clairsto::softmax2: float32 [..., 2] on the HIP device");
+    const c10::hip::HIPGuard guard(logits.get_device());
+    const Tensor a = logits.contiguous();
+    Tensor out = at::empty_like(a);
+    check_rc(cto_softmax_pairs(a.data_ptr<float>(), a.numel() / 2, out.data_ptr<float>(), stream_of(a)), "softmax2");
+    return out;
+}
+Tensor softmax2_meta(const Tensor& logits) { return at::empty_like(logits); }
 
 // ---- pileup featurisation ----------------------------------------------------------------------------------------------
 using Feat = std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor>;
@@ -245,6 +261,7 @@ Feat pileup_featurize_meta(const Tensor&, const Tensor&, const Tensor& col_pos, 
 TORCH_LIBRARY(clairsto, m) {
     m.def("cvt_forward(Tensor x, Tensor packed_weights, int[] cfg) -> Tensor");
     m.def("bigru_forward(Tensor x, Tensor packed_weights, int n_out) -> Tensor");
+    m.def("softmax2(Tensor logits) -> Tensor");
     m.def("posterior(Tensor aff_logits, Tensor neg_logits, Tensor lik, Tensor edges) -> (Tensor probs, Tensor post, Tensor decision, Tensor qual)");
     m.def("pileup_featurize(Tensor entries, Tensor col_off, Tensor col_pos, Tensor col_ref, Tensor key_off, Tensor key_meta, "
           "Tensor key_group, Tensor site_pos, int min_bq, int min_rescale_cov) -> (Tensor x_aff, Tensor x_neg, Tensor site_info, "
@@ -254,6 +271,7 @@ TORCH_LIBRARY(clairsto, m) {
 TORCH_LIBRARY_IMPL(clairsto, CUDA, m) {      // "CUDA" is the dispatch key of HIP devices in PyTorch-ROCm
     m.impl("cvt_forward", &cvt_forward);
     m.impl("bigru_forward", &bigru_forward);
+    m.impl("softmax2", &softmax2);
     m.impl("posterior", &posterior);
     m.impl("pileup_featurize", &pileup_featurize);
 }
@@ -261,6 +279,7 @@ TORCH_LIBRARY_IMPL(clairsto, CUDA, m) {      // "CUDA" is the dispatch key of HI
 TORCH_LIBRARY_IMPL(clairsto, Meta, m) {
     m.impl("cvt_forward", &cvt_forward_meta);
     m.impl("bigru_forward", &bigru_forward_meta);
+    m.impl("softmax2", &softmax2_meta);
     m.impl("posterior", &posterior_meta);
     m.impl("pileup_featurize", &pileup_featurize_meta);
 }

@@ -170,8 +170,8 @@ class _HipNet(nn.Module):
 
     def _tuple(self, x):
         out = self.logits(x)
-        if getattr(self, "apply_softmax", False):        # clairs/model.py:255-259 / 461-465
-            out = torch.softmax(out, dim=-1)
+        if getattr(self, "apply_softmax", False):        # clairs/model.py:255-259 / 461-465: nn.Softmax(dim=1) per head, on the device
+            out = torch.ops.clairsto.softmax2(out)       # (cto_softmax_pairs: no torch operator computes on the path)
         return tuple(out[k] for k in range(out.shape[0]))
 
 

@@ -338,10 +338,17 @@ int cto_posterior(const float* aff_logits, const float* neg_logits, int K, int64
  * 0, 0} and qual[i] is bit for bit what the reference prints on this machine.  Idempotent; returns the number of sites rewritten.
  * cto_vcf_rows_batch applies the same rule itself. */
 int64_t cto_qual_finalize(int32_t* decision, double* qual, int64_t n);
+/* How many of the B sites of a DEVICE decision array wait for that host half (flag bit 2): *count (device int32) is zeroed and
+ * filled on `stream`.  A caller that wants final values without downloading 16 B per site every time (the torch operator) reads
+ * these four bytes and runs cto_qual_finalize on host copies only when they are non-zero - about one 4096-site call in a hundred. */
+int cto_qual_pending(const int32_t* decision, int64_t B, int32_t* count, void* stream);
 
 /* Only the 2-way softmax of clairs/predict.py:659-684: probs dev [B][2K][2] in the order the probability text
  * rows use (a c g t [i d] na nc ng nt [ni nd]). */
 int cto_softmax_probs(const float* aff_logits, const float* neg_logits, int K, int64_t B, float* probs, void* stream);
+/* nn.Softmax(dim=1) over n rows of two logits (dev [n][2] -> dev [n][2]): what a module built with apply_softmax=True applies to each
+ * head before returning (clairs/model.py:255-259, :461-465).  Same arithmetic as cto_softmax_probs. */
+int cto_softmax_pairs(const float* logits, int64_t n, float* out, void* stream);
 
 /* Same epilogue entered at the probability text seam (clairs/call_variants.py:798-829 parses the rows that
  * clairs/predict.py:114-152 wrote): p1 dev [B][2K] double = the second number of each "p0 p1" field, in the

@@ -823,6 +823,27 @@ def test_region_jobs_from_bam_equal_the_two_step_run(tmp_path, K):
             assert got == [x for x in want[i] if inside(x)], i
             total += len(got)
         assert 0 < total < sum(len(x) for x in want) and st["sites"] == total
+        # the same BED gzipped, with and without a .gz name (bed_tree_from reads every BED through `gzip -fdc`, shared/interval_tree.py:43):
+        # the same candidates - not "no regions, everything passes"
+        import gzip as _gz
+        for name in ("indel_regions.bed.gz", "indel_regions_gz_without_suffix.bed"):
+            zb = tmp_path / name
+            zb.write_bytes(_gz.compress(bed.read_bytes()))
+            outz = str(tmp_path / ("filtered_" + name))
+            jobs = [_region_namespace(sc["fa"], K, paths, lik, outz, "r%d" % i, tumor_bam_fn=sc["bam"], region=r, indel_min_af=0.01, alternative_base_num=abn,
+                                      candidates_out_fn=os.path.join(outz, "cand%d.bed" % i), call_indels_only_in_these_regions=str(zb))
+                    for i, r in enumerate(regions)]
+            run_pipeline_native(eng, jobs, producers=2, writers=1, verbose=False, inflate_cus=64, inflate_jobs=2)
+            for i in range(len(regions)):
+                assert open(os.path.join(outz, "cand%d.bed" % i)).read() == open(os.path.join(out, "cand%d.bed" % i)).read(), (name, i)
+        # a row that is not "name start end" ends the run (the reference's int() raises): it is not skipped
+        badbed = tmp_path / "bad.bed"
+        badbed.write_text("chr1\t900\t1500\nchr1 this-is-not-a-number 7\n")
+        jobs = [_region_namespace(sc["fa"], K, paths, lik, str(tmp_path / "bad"), "r0", tumor_bam_fn=sc["bam"], region=regions[0], indel_min_af=0.01,
+                                  alternative_base_num=abn, call_indels_only_in_these_regions=str(badbed))]
+        with pytest.raises(RuntimeError) as ei:
+            run_pipeline_native(eng, jobs, producers=1, writers=1, verbose=False, inflate_cus=64, inflate_jobs=2)
+        assert "Invalid bed input in 2-th row" in str(ei.value)
     torch.cuda.synchronize()
 
 

@@ -143,6 +143,32 @@ def test_inflate_rejects_malformed(dev):
         inflate_bytes(bytes(garbage), dev)
 
 
+def test_inflate_refuses_a_slot_table_without_the_pad(dev):
+    """the literal path may store up to 32 bytes behind a block's size (its bound is checked once per refill): a table whose slots
+    lie closer than CTO_BGZF_SLOT_PAD to each other - the `isize + 4` rule of an older layout - is refused block by block (status 9)
+    instead of letting a block write into its neighbour's output"""
+    import torch
+    from clairs_to_amd import bgzf
+    rng = np.random.default_rng(5)
+    datas = [bytes(rng.integers(33, 74, 30000, dtype=np.uint8)) for _ in range(3)]
+    raw = b"".join(bgzf_block(d, 6) for d in datas)
+    host = np.zeros(len(raw) + bgzf.BGZF_PAD, dtype=np.uint8)
+    host[:len(raw)] = np.frombuffer(raw, dtype=np.uint8)
+    tbl, out_bytes = bgzf.scan(host, len(raw))
+    assert all(int(tbl[i + 1]["out_off"]) >= int(tbl[i]["out_off"]) + int(tbl[i]["isize"]) + 64 for i in range(2))   # CTO_BGZF_SLOT_PAD
+    tight = tbl.copy()
+    off = 0
+    for i in range(3):
+        tight[i]["out_off"] = off
+        off += int(tight[i]["isize"]) + 4
+    d_out, d_status = bgzf.inflate_device(torch.from_numpy(host).to(dev), tight, out_bytes, dev)
+    torch.cuda.synchronize(dev)
+    st = d_status.cpu().numpy()
+    assert st[0] == 9 and st[1] == 9 and st[2] == 0        # the last slot's pad is the caller's buffer size
+    out = d_out.cpu().numpy()
+    assert out[int(tight[2]["out_off"]):int(tight[2]["out_off"]) + 30000].tobytes() == datas[2]
+
+
 def test_bam_pack_device_inflate_equals_host_inflate(dev, tmp_path):
     """the pack of a multi-megabyte BAM region: BGZF blocks inflated on the device (bgzf.inflate_span) vs on the host, every array"""
     from clairs_to_amd.bgzf import inflate_span

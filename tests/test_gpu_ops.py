@@ -110,6 +110,7 @@ def test_opcheck():
     ln = torch.randn(4, 64, 2, device=dev)
     opcheck(torch.ops.clairsto.posterior.default, (la, ln, torch.from_numpy(lik).to(dev), torch.from_numpy(edges).to(dev)),
             test_utils=OPCHECKS)
+    opcheck(torch.ops.clairsto.softmax2.default, (la,), test_utils=OPCHECKS)
     chunk = SynthChunk(40, seed=8)
     dp = DevicePack(chunk.arrays(), dev)
     t = dp.t
@@ -131,3 +132,26 @@ def test_ops_trace_under_fake_tensors():
         p, post, dec, q = torch.ops.clairsto.posterior(lo, lo, torch.empty(4, 10, 10, device="cuda", dtype=torch.float64),
                                                        torch.empty(8, 11, device="cuda", dtype=torch.float64))
         assert p.shape == (17, 8, 2) and post.shape == (17, 4) and dec.dtype == torch.int32 and q.dtype == torch.float64
+
+
+def test_apply_softmax_modules_return_probabilities_from_the_device_op():
+    """a module built with apply_softmax=True (clairs/model.py:255-259, :461-465) returns Softmax(dim=1) of every head: computed by
+    clairsto::softmax2 (cto_softmax_pairs), the arithmetic of the epilogue's own softmax, incl. saturated and equal logits"""
+    from clairs_to_amd.nn_shims import from_state_dict
+    dev = torch.device("cuda:0")
+    lg = torch.tensor([[[-30.0, 30.0], [30.0, -30.0], [0.0, 0.0], [1e-3, -1e-3], [-1.7, 20.0]]], device=dev)
+    got = torch.ops.clairsto.softmax2(lg).cpu().numpy()
+    want = torch.softmax(lg.cpu().double(), dim=-1).numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-7)
+    assert got[0, 0, 1] == 1.0 and got[0, 1, 1] == 0.0 and got[0, 2, 0] == 0.5
+    assert torch.ops.clairsto.softmax2(torch.empty((4, 0, 2), device=dev)).shape == (4, 0, 2)
+    for cls in ("CvT", "BiGRU_NACGT_Indel"):
+        g = load_models_npz(cls)
+        m = from_state_dict(cls, make_weights(g["manifest"], seed=g["n_out"]))
+        x = torch.from_numpy(g["x"][:40]).to(dev)
+        plain = torch.stack(m(x))
+        m.apply_softmax = True
+        probs = torch.stack(m(x))
+        np.testing.assert_array_equal(probs.cpu().numpy(), torch.ops.clairsto.softmax2(plain).cpu().numpy())
+        p_ref = torch.softmax(torch.from_numpy(g["logits"][:, :40]), dim=-1).numpy()
+        assert np.abs(probs.cpu().numpy() - p_ref).max() < 1e-4
