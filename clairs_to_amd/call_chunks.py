@@ -154,7 +154,7 @@ def run_pipeline(eng, chunk_args, producers=4, writers=2, depth=None, stats=None
                 print("[INFO] {} total processed positions: 0".format(a.ctg_name), file=sys.stderr)
                 continue
             t0 = time.perf_counter()
-            launched = launch_chunk(eng, prep, want_probs=bool(getattr(a, "predict_fn", None)),
+            launched = launch_chunk(eng, prep, want_probs=bool(getattr(a, "predict_fn", None)) or getattr(a, "site_sink", None) is not None,
                                     pinned=free_pinned.popleft() if free_pinned else None)
             clock("launch_s", t0)
             writing.append(wr.submit(finish, a, prep, launched))
@@ -262,7 +262,10 @@ def call_chunks(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # the control plane only exchanges a status word: gloo keeps the GPUs' streams out of it; the timeout covers shards that
         # are legitimately hours out of balance (a failed rank reports through the status exchange below, not by timing out)
-        dist.init_process_group("gloo", timeout=datetime.timedelta(hours=24))
+        # --gather_outputs adds the data-path exchange of the per-site outputs: device tensors over nccl (= RCCL over xGMI), the status
+        # objects stay on gloo.  CTO_GATHER_BACKEND=gloo (tests on a one-GPU box) sends the rows through host memory instead.
+        gather_backend = os.environ.get("CTO_GATHER_BACKEND", "nccl") if getattr(args, "gather_outputs", False) else None
+        dist.init_process_group("cpu:gloo,cuda:nccl" if gather_backend == "nccl" else "gloo", timeout=datetime.timedelta(hours=24))
     if not torch.cuda.is_available():
         sys.exit("[ERROR] clairs_to_amd call_chunks needs a HIP device; there is no CPU fallback")
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
@@ -276,6 +279,8 @@ def call_chunks(args):
     lo, hi = shard_range(len(chunks), world, rank)
     os.makedirs(args.output_dir, exist_ok=True)
     n_rows, failure = 0, None
+    gathering = bool(getattr(args, "gather_outputs", False))
+    collected = {}                       # chunk index -> the chunk's per-site outputs (finish_chunk's site_sink)
 
     def region_name(r):
         return "%s_%s_%s" % (r[0], r[1], r[2])
@@ -301,11 +306,23 @@ def call_chunks(args):
         return a
     try:
         eng = make_engine(args, device)
-        mine = [a for a in (chunk_args(b) for b in chunks[lo:hi]) if a is not None]
+        mine = []
+        for ci, b in enumerate(chunks[lo:hi]):
+            a = chunk_args(b)
+            if a is None:
+                continue
+            if gathering:
+                a.site_sink = (lambda rec, ci=lo + ci, ctg=a.ctg_name: collected.__setitem__(ci, dict(rec, ctg=ctg)))
+            mine.append(a)
         for a in mine:                       # a chunk VCF left by an earlier run must not survive into this run's merge
             if os.path.exists(a.call_fn):
                 os.remove(a.call_fn)
         how = getattr(args, "pipeline", None) or "auto"
+        if gathering:
+            if region_mode or how == "native":
+                sys.exit("[ERROR] --gather_outputs runs on the thread-pool pipeline of this module (--pipeline python, --chunk_list): "
+                         "cto_run_chunks keeps the per-site outputs to itself")
+            how = "python"
         if region_mode:
             if how == "python" or not native_eligible(mine):
                 sys.exit("[ERROR] --region_list runs in the C pipeline only (cto_run_chunks): --mpileup_dir text, --bam_reader native or samtools")
@@ -343,7 +360,14 @@ def call_chunks(args):
             import torch.distributed as dist
             dist.destroy_process_group()
         sys.exit("[ERROR] call_chunks: %s" % "; ".join("rank %d: %s" % f for f in failed))
-    if rank == 0 and args.merged_vcf_fn:
+    if gathering:
+        n_g = gather_and_write(args, collected, chunks, world, rank, device)
+        if rank == 0:
+            print("[INFO] gathered the outputs of %d sites from %d rank(s); %d records in %s" % (n_g[0], world, n_g[1], args.merged_vcf_fn), file=sys.stderr)
+        if rank == 0 and args.final_vcf_fn:
+            postprocess_vcf(args.merged_vcf_fn, args.final_vcf_fn, platform=resolve_platform(args.platform)[1],
+                            ref_fn=args.ref_fn, sample_name=args.sample_name)
+    elif rank == 0 and args.merged_vcf_fn:
         contigs = []
         for bed in chunks:
             c = bed[0] if region_mode else chunk_contig(bed)
@@ -364,6 +388,91 @@ def call_chunks(args):
     return n_rows
 
 
+def gather_and_write(args, collected, chunks, world, rank, device):
+    """--gather_outputs: the exchange step north_star names, in a real run.  Every rank's per-site outputs - probabilities [2K][2],
+    decision, QUAL, strand / depth words, the candidate's position and reference base, its alt_info string - are all_gathered in
+    rank-major order (= the chunk list's order: ranks hold contiguous runs of it) and rank 0 formats the merged VCF from the
+    gathered buffer with the same C call that formats a chunk's (cto_vcf_rows_batch), in sort_vcf's order.  The reference's
+    equivalent is files: p_<chunk>.vcf per GNU-parallel job, then sort_vcf over the directory (run_clairs_to:1293-1317).
+    Returns (sites gathered, records written)."""
+    import numpy as np
+    import torch.distributed as dist
+    from .call_variants import vcf_rows_batch
+    from .dist import gather_site_rows
+    from .pileup_call import VCF_HEADER
+    from .postprocess_vcf import contig_order, _header_from_fai
+    K = 4 if args.disable_indel_calling else 6
+    recs = [collected[i] for i in sorted(collected)]
+    names = sorted({c for c in (chunk_contig(b) for b in chunks) if c is not None})        # the same on every rank
+    on_gpu = world > 1 and os.environ.get("CTO_GATHER_BACKEND", "nccl") == "nccl"
+    dev = device if on_gpu else torch.device("cpu")
+
+    def cat(key, dtype, tail):
+        parts = [np.asarray(r[key]).reshape((-1,) + tail) for r in recs]
+        a = np.concatenate(parts) if parts else np.zeros((0,) + tail, dtype=dtype)
+        return torch.from_numpy(np.ascontiguousarray(a.astype(dtype, copy=False))).to(dev)
+    n_local = sum(len(r["pos"]) for r in recs)
+    ctg_idx = np.concatenate([np.full(len(r["pos"]), names.index(r["ctg"]), dtype=np.int64) for r in recs]) if recs else np.zeros(0, dtype=np.int64)
+    alt_max = max([int(r["alt_len"].max()) if len(r["alt_len"]) else 0 for r in recs] + [1])
+    if world > 1:
+        m = torch.tensor([alt_max], dtype=torch.int64, device=dev)
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        alt_max = int(m.item())
+    alt = np.zeros((n_local, alt_max), dtype=np.uint8)
+    row = 0
+    for r in recs:
+        off = np.concatenate([[0], np.cumsum(r["alt_len"])])
+        buf = np.frombuffer(r["alt_buf"], dtype=np.uint8)
+        for i in range(len(r["pos"])):
+            alt[row, : r["alt_len"][i]] = buf[off[i]:off[i + 1]]
+            row += 1
+    local = {"key": torch.from_numpy(np.stack([ctg_idx, np.concatenate([r["pos"] for r in recs]) if recs else np.zeros(0, dtype=np.int64)], axis=1)).to(dev),
+             "centre": cat("centre", np.uint8, ()), "info": cat("info", np.int32, (12,)), "decision": cat("decision", np.int32, (4,)),
+             "qual": cat("qual", np.float64, ()), "probs": cat("probs", np.float32, (2 * K, 2)), "alt_len": cat("alt_len", np.int32, ()),
+             "alt": torch.from_numpy(alt).to(dev)}
+    if world > 1:
+        got = {k: gather_site_rows(v)[0] for k, v in local.items()}
+        # the exchange is checked where it is cheap: this rank's block sits bit for bit at its offset of the gathered probabilities
+        counts = gather_site_rows(local["qual"])[1]
+        base = sum(counts[:rank])
+        ok = torch.tensor([int(torch.equal(got["probs"][base:base + n_local], local["probs"]))], dtype=torch.int64, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) != 1:
+            sys.exit("[ERROR] call_chunks --gather_outputs: a rank's block is not where the gathered buffer should hold it")
+    else:
+        got = local
+    n_sites, n_records = int(got["qual"].shape[0]), 0
+    if rank == 0:
+        g = {k: v.cpu().numpy() for k, v in got.items()}
+        if getattr(args, "gathered_probs_fn", None):
+            np.save(args.gathered_probs_fn, g["probs"])
+        body = []
+        for ctg in contig_order(list(names)):
+            sel = np.nonzero(g["key"][:, 0] == names.index(ctg))[0]
+            if not len(sel):
+                continue
+            al = g["alt_len"][sel].astype(np.int64)
+            off = np.concatenate([[0], np.cumsum(al)]).astype(np.int64)
+            buf = b"".join(g["alt"][i, : g["alt_len"][i]].tobytes() for i in sel)
+            text, cnt = vcf_rows_batch(ctg, np.ascontiguousarray(g["key"][sel, 1]), np.ascontiguousarray(g["centre"][sel]), buf, off,
+                                       np.ascontiguousarray(g["info"][sel]), np.ascontiguousarray(g["decision"][sel]),
+                                       np.ascontiguousarray(g["qual"][sel]), K, show_ref=args.show_ref, qual_pass=args.qual)
+            at = {}
+            for r in text.split("\n"):
+                if r:
+                    at[int(r.split("\t", 2)[1])] = r + "\n"
+            body.extend(at[p] for p in sorted(at))
+            n_records += len(at)
+        os.makedirs(os.path.dirname(os.path.abspath(args.merged_vcf_fn)), exist_ok=True)
+        with open(args.merged_vcf_fn, "w") as out:
+            if n_records == 0:
+                out.write(_header_from_fai(args.ref_fn, args.sample_name))
+            else:
+                out.write(VCF_HEADER + "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n" % args.sample_name)
+                out.write("".join(body))
+    return n_sites, n_records
+
+
 def main():
     p = ArgumentParser(description="Pileup calling of all candidate chunks of a run, one process per GPU")
     add_common_arguments(p)
@@ -382,6 +491,11 @@ def main():
     p.add_argument("--output_dir", type=str, required=True, help="directory for the p_<chunk>.vcf files")
     p.add_argument("--merged_vcf_fn", type=str, default=None, help="rank 0: sort_vcf of all chunk VCFs")
     p.add_argument("--final_vcf_fn", type=str, default=None, help="rank 0: postprocess_vcf of the merged VCF")
+    p.add_argument("--gather_outputs", action="store_true",
+                   help="exchange step in the data path: every rank's per-site outputs (probabilities, decision, QUAL, counts, alt_info) are "
+                        "all_gathered in rank-major = chunk-list order (RCCL over xGMI) and rank 0 writes --merged_vcf_fn from the gathered "
+                        "buffer instead of merging the p_<chunk>.vcf files (which are still written); same file either way")
+    p.add_argument("--gathered_probs_fn", type=str, default=None, help="--gather_outputs: rank 0 also saves the gathered probabilities [sites][2K][2] (.npy)")
     p.add_argument("--mpileup_dir", type=str, default=None,
                    help="read <dir>/<chunk file name>.mpileup (samtools mpileup --min-BQ 0 text of the chunk) instead of the BAM")
     p.add_argument("--producers", type=int, default=None, help="pack-producer threads per rank (default: usable cores / 4, / 2 with --bam_reader native; <= 16)")
@@ -394,6 +508,8 @@ def main():
     args = p.parse_args()
     if bool(args.chunk_list) == bool(args.region_list):
         p.error("exactly one of --chunk_list / --region_list is required")
+    if args.gather_outputs and not args.merged_vcf_fn:
+        p.error("--gather_outputs writes --merged_vcf_fn from the gathered outputs: name it")
     call_chunks(args)
 
 

@@ -28,3 +28,21 @@ def gather_site_outputs(local, n_total, group=None):
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad, group=group)
     return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
+
+
+def gather_site_rows(local, group=None):
+    """The exchange step of a real run (call_chunks --gather_outputs): local [n_r, ...] per-site rows of this rank's chunks (ranks hold
+    contiguous runs of the chunk list, so rank-major order is the run's order), any n_r.  Returns ([sum n_r, ...] on every rank, the
+    list of n_r).  One all_gather of the row counts, one of the rows padded to the largest count (nccl = RCCL over xGMI for device
+    tensors, gloo for host tensors) - no reduction."""
+    world = dist.get_world_size(group)
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    counts = [torch.empty_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    cap = max(max(counts), 1)
+    pad = torch.zeros((cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    return torch.cat([bufs[r][: counts[r]] for r in range(world)], dim=0), counts

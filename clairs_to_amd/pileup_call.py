@@ -129,6 +129,11 @@ def finish_chunk(args, K, prep, launched):
     text, cnt = vcf_rows_batch(args.ctg_name, sites_arr, centre, alt_buf, alt_off, info, dec, qual, K, show_ref=args.show_ref,
                                qual_pass=args.qual)
     n_rows, n_sites = cnt["rows"], cnt["sites"]
+    sink = getattr(args, "site_sink", None)
+    if sink is not None:       # call_chunks --gather_outputs: this chunk's per-site outputs, for the exchange step (dist.gather_site_rows)
+        alt_len = np.diff(np.asarray(alt_off, dtype=np.int64)).astype(np.int32)
+        sink(dict(pos=sites_arr.copy(), centre=np.ascontiguousarray(centre), info=info, decision=dec.copy(), qual=qual.copy(),
+                  probs=h["probs"].copy(), alt_buf=bytes(alt_buf), alt_len=alt_len))
     for _ in range(cnt["low_coverage"]):
         print("low tumor coverage")                                  # call_variants.py:328, one line per such site
     if cnt["clamped"]:

@@ -22,6 +22,15 @@ WORKER = textwrap.dedent('''
     assert out.shape == full.shape and torch.equal(out, full), "gather is not bit-identical to the single-rank result"
     cover = [shard_range(n, world, r) for r in range(world)]
     assert cover[0][0] == 0 and cover[-1][1] == n and all(cover[i][1] == cover[i + 1][0] for i in range(world - 1))
+    # the ragged form a real run uses (call_chunks --gather_outputs: ranks hold whole chunks, so their site counts differ freely)
+    from clairs_to_amd.dist import gather_site_rows
+    cut = [0, 700, n] if world == 2 else [0] + [n * (r + 1) // world for r in range(world)]
+    for dtype in (torch.float32, torch.uint8, torch.int64, torch.float64):
+        fullt = (full * 0 + torch.arange(n).reshape(n, 1, 1)).to(dtype)
+        got, counts = gather_site_rows(fullt[cut[rank]:cut[rank + 1]].clone())
+        assert counts == [cut[r + 1] - cut[r] for r in range(world)] and torch.equal(got, fullt)
+    got, counts = gather_site_rows(torch.zeros((0, 3), dtype=torch.int32) if rank == 0 else torch.ones((5, 3), dtype=torch.int32))
+    assert counts[0] == 0 and got.shape == (5 * (world - 1), 3)
     dist.destroy_process_group()
     print("rank", rank, "ok")
 ''') % ROOT

@@ -259,6 +259,18 @@ def test_call_chunks_two_ranks_over_rccl(tmp_path):
         assert r.returncode == 0, r.stderr[-3000:]
         outs[world] = [l for l in open(merged).read().split("\n") if l and not l.startswith("#")]
     assert outs[1] == outs[2] and len(outs[1]) > 50
+    # the exchange step in the data path: --gather_outputs all_gathers every rank's per-site outputs as DEVICE tensors - the process
+    # group is "cpu:gloo,cuda:nccl", i.e. this is RCCL over xGMI - and rank 0 writes the merged VCF from the gathered buffer
+    out_dir, merged = tmp_path / "vcf_gather", tmp_path / "merged_gather.vcf"
+    cmd = ["-m", "clairs_to_amd", "call_chunks", "--chunk_list", str(tmp_path / "CANDIDATES_FILES"), "--output_dir", str(out_dir),
+           "--merged_vcf_fn", str(merged), "--gather_outputs"] + common
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.pop("CTO_GATHER_BACKEND", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29547"] + cmd, cwd=ROOT, capture_output=True, text=True, timeout=400, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert [l for l in open(merged).read().split("\n") if l and not l.startswith("#")] == outs[1]
+    assert "from 2 rank(s)" in r.stderr
 
 
 def _bam_scenario(tmp_path):
@@ -396,6 +408,58 @@ def test_call_chunks_matches_single_call(tmp_path, world):
     assert rec(merged) == rec(one) and len(rec(one)) > 50
     assert sorted(os.listdir(out_dir)) == ["p_chr1.%d_3_snv.vcf" % (i + 1) for i in range(3)]
     assert 0 < len(rec(final)) <= len(rec(merged))      # postprocess drops PASS records under the platform's AF cut-off
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_call_chunks_gather_outputs_writes_the_merged_vcf_of_the_file_merge(tmp_path, world):
+    """call_chunks --gather_outputs: the per-site outputs of every rank all_gathered rank-major (dist.gather_site_rows) and the merged
+    VCF written by rank 0 from the gathered buffer - byte-identical to the merge of the p_<chunk>.vcf files (the reference's way,
+    run_clairs_to:1293-1317, and this driver's default).  Two ranks share this box's GPU and exchange over gloo (CTO_GATHER_BACKEND:
+    on a multi-GPU box the same call goes over RCCL, test_call_chunks_two_ranks_over_rccl)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from clairs_to_amd.synth import likelihood_table
+    sc = _bam_scenario(tmp_path)
+    paths = _pickle_models(tmp_path, "CvT_Indel", "BiGRU_NACGT_Indel", 6)
+    lik = tmp_path / "lik.txt"
+    np.savetxt(lik, likelihood_table(6, seed=11), fmt="%.17g")
+    sites = sc["sites"]
+    cdir = tmp_path / "candidates"
+    cdir.mkdir()
+    names = []
+    cuts = [0, len(sites) // 7, len(sites) // 2, len(sites) // 2, len(sites)]             # uneven chunks, one of them empty
+    for i in range(4):
+        fn = cdir / ("chr1.%d_4_indel" % (i + 1))
+        fn.write_text("".join("chr1\t%d\t%d\n" % (x - 17, x + 17) for x in sites[cuts[i]:cuts[i + 1]]))
+        names.append(str(fn))
+    (tmp_path / "CANDIDATES_FILES").write_text("".join(n + "\n" for n in names))
+    common = ["--platform", "ont", "--tumor_bam_fn", sc["bam"], "--ref_fn", sc["fa"], "--bam_reader", "native", "--chkpnt_fn_acgt",
+              paths["model_acgt"], "--chkpnt_fn_nacgt", paths["model_nacgt"], "--disable_indel_calling", "False",
+              "--likelihood_matrix_data", str(lik), "--show_ref"]
+
+    def run(tag, extra):
+        out_dir, merged = tmp_path / ("vcf_" + tag), tmp_path / ("merged_%s.vcf" % tag)
+        cmd = ["-m", "clairs_to_amd", "call_chunks", "--chunk_list", str(tmp_path / "CANDIDATES_FILES"), "--output_dir", str(out_dir),
+               "--merged_vcf_fn", str(merged)] + common + extra
+        full = [sys.executable] + cmd if world == 1 else \
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+             "--master-port", "29546"] + cmd
+        r = subprocess.run(full, cwd=ROOT, capture_output=True, text=True, timeout=280, env=dict(os.environ, PYTHONPATH=ROOT, CTO_GATHER_BACKEND="gloo"))
+        assert r.returncode == 0, r.stderr[-3000:]
+        return open(merged).read(), r.stderr
+    files, _ = run("files", ["--pipeline", "python"])
+    probs_fn = tmp_path / "gathered_probs.npy"
+    gathered, err = run("gather", ["--gather_outputs", "--gathered_probs_fn", str(probs_fn)])
+    assert gathered == files and gathered.count("\n") > 60
+    assert "gathered the outputs of %d sites from %d rank(s)" % (len(sites), world) in err
+    p = np.load(probs_fn)
+    assert p.shape == (len(sites), 12, 2) and np.allclose(p.sum(axis=2), 1.0, atol=1e-6)
+    # the C pipeline keeps the per-site outputs to itself: asking for both is an error, not a silent fallback
+    r = subprocess.run([sys.executable, "-m", "clairs_to_amd", "call_chunks", "--chunk_list", str(tmp_path / "CANDIDATES_FILES"), "--output_dir",
+                        str(tmp_path / "x"), "--merged_vcf_fn", str(tmp_path / "x.vcf"), "--gather_outputs", "--pipeline", "native"] + common,
+                       cwd=ROOT, capture_output=True, text=True, timeout=120, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode != 0 and "--gather_outputs runs on the thread-pool pipeline" in r.stderr
 
 
 @pytest.mark.parametrize("source", ["bam", "text"])

@@ -143,7 +143,7 @@ def test_apply_softmax_modules_return_probabilities_from_the_device_op():
     got = torch.ops.clairsto.softmax2(lg).cpu().numpy()
     want = torch.softmax(lg.cpu().double(), dim=-1).numpy()
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-7)
-    assert got[0, 0, 1] == 1.0 and got[0, 1, 1] == 0.0 and got[0, 2, 0] == 0.5
+    assert got[0, 0, 1] == 1.0 and 0.0 < got[0, 1, 1] < 1e-25 and got[0, 2, 0] == 0.5
     assert torch.ops.clairsto.softmax2(torch.empty((4, 0, 2), device=dev)).shape == (4, 0, 2)
     for cls in ("CvT", "BiGRU_NACGT_Indel"):
         g = load_models_npz(cls)
