@@ -36,6 +36,7 @@ REFERENCE_PYTHON_NOTE = ("HKU-BAL/ClairS-TO v0.4.4 itself, build container (8 vC
 # as 64 B).  Calibrated on this code's own access patterns (profiles/round2_*_pmc_hbm_traffic.json): k_featurize_columns reads the
 # 28.6 MB pack exactly once and shows FETCH_SIZE = 14.8 MB -> x2; WRITE_SIZE is 1.0x (GRU layer 1 writes its 138.4 MB output: 138.4 MB).
 FETCH_CORRECTION = 2.0
+PEAK_16BIT_MFMA_TFLOPS = 2500.0     # dense bf16 / f16 MFMA (MI355X_MICROARCH.md:42), the yardstick of the split-operand side channel only
 
 
 def _pmc_file():
@@ -56,6 +57,50 @@ def pmc_traffic(batch):
         if "k_gru_layer" in name and "<256" in name:
             return int((FETCH_CORRECTION * v["FETCH_SIZE_KB_mean_per_launch"] + v["WRITE_SIZE_KB_mean_per_launch"]) * 1024)
     return None
+
+
+def live_pmc_traffic(batch, timeout_s=240):
+    """HBM / fabric bytes per launch MEASURED in this run: two child runs of this file under `rocprofv3 --kernel-trace --pmc`
+    (FETCH_SIZE, then WRITE_SIZE: separate passes, no other trace domain - MI355X_MICROARCH.md's recipe), three timed steps each on
+    two resident chunks, legs off.  Returns {"gru_l2": bytes, "featurize": bytes} (FETCH x FETCH_CORRECTION + WRITE, mean per launch)
+    or None when rocprofv3 is not on the box / a pass fails - the caller then falls back to the committed digest and says so."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None or batch != 4096:
+        return None
+    env = {k: v for k, v in os.environ.items() if not (k.startswith(("ROCPROF", "ROCP_", "ROCTX")) or k == "HSA_TOOLS_LIB")}
+    env["TMPDIR"] = "/tmp"
+    sums = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                   "--steps", "3", "--warmup", "1", "--pool", "2", "--no-cpu-baseline", "--no-e2e", "--no-sustained", "--no-split", "--no-configs",
+                   "--no-postfilters", "--no-live-traffic"]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            except Exception:
+                return None
+            fs = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not fs:
+                return None
+            acc = {}
+            for row in csv.DictReader(open(fs[0])):
+                if row["Counter_Name"] == ctr:
+                    acc.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+            for name, v in acc.items():
+                key = "gru_l2" if ("k_gru_layer" in name and "<256" in name) else "featurize" if "k_featurize_sites" in name else None
+                if key:
+                    sums.setdefault(key, {})[ctr] = sum(v) / len(v) * 1024.0          # the counters are in KB
+    out = {}
+    for key, d in sums.items():
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            out[key] = int(FETCH_CORRECTION * d["FETCH_SIZE"] + d["WRITE_SIZE"])
+    return out or None
 
 
 def pmc_traffic_featurize(batch):
@@ -193,14 +238,10 @@ def split_mfma_leg(dev, packs, sites, batch, lik, edges, min_bq, ref_probs, ref_
                    "to the oracle within the 1e-4 tolerance"}
     pool = len(packs)
     for kind in ("f16", "bf16"):
-        models = synthetic_models(N_OUT, seed=0)          # fresh module objects: the switch is read when a module creates its handle
-        os.environ["CTO_GRU_SPLIT"] = kind
-        os.environ["CTO_CVT_SPLIT"] = kind
-        try:
-            eng = Engine(models["aff"], models["neg"], lik, edges, min_bq=min_bq, device=dev)
-        finally:
-            os.environ.pop("CTO_GRU_SPLIT", None)
-            os.environ.pop("CTO_CVT_SPLIT", None)
+        models = synthetic_models(N_OUT, seed=0)          # fresh module objects: the arithmetic is chosen when a module creates its handle
+        models["aff"].split_operands = kind               # (cto_*_create_ex: an argument, not the process environment)
+        models["neg"].split_operands = kind
+        eng = Engine(models["aff"], models["neg"], lik, edges, min_bq=min_bq, device=dev)
         for i in range(warm):
             eng.run_device(packs[i % pool], sites[i % pool])
         check(lib.cto_model_profile(eng.h_neg, 2))
@@ -230,6 +271,12 @@ def split_mfma_leg(dev, packs, sites, batch, lik, edges, min_bq, ref_probs, ref_
              "decisions_differing_from_f32_path": int(((dec[:, 0] != ref_dec[:, 0]) | ((dec[:, 1] & 3) != (ref_dec[:, 1] & 3))).sum())}
         if probs_cpu is not None:
             o["max_abs_dP_vs_cpu_sample"] = float(np.abs(probs[: probs_cpu.shape[0]] - probs_cpu).max())
+        # its own roofline, against the 16-bit dense MFMA peak: three MFMA passes execute per algorithmic product
+        exe_tf = 3.0 * tf
+        o["roofline"] = {"bound": "mfma", "kernel": "k_gru_split<256,256,192,2,%s,true> (BiGRU layer 2 + fused fc1 on hi+lo %s operands)" % ("true" if kind == "f16" else "false", kind),
+                         "achieved": round(exe_tf, 1), "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(exe_tf / PEAK_16BIT_MFMA_TFLOPS, 4),
+                         "algorithmic_tflops": round(tf, 1), "launch_ms": round(l2_ms.value, 4), "traffic": None,
+                         "note": "achieved = 3 x algorithmic FLOPs / launch time (hi.hi + hi.lo + lo.hi); peak = dense bf16 / f16 MFMA (MI355X_MICROARCH.md:42)"}
         out[kind] = o
         del eng, models
     return out
@@ -483,6 +530,8 @@ def main():
     ap.add_argument("--no-split", action="store_true", help="skip the split-operand experiment leg (`split_mfma`; never part of `value`)")
     ap.add_argument("--no-configs", action="store_true", help="skip the legs on the other BASELINE configs' single-GPU workloads (Illumina, HiFi, "
                     "K = 6, the constructor-default CvT, clustered candidates)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="`roofline.traffic` from the newest committed PMC digest instead of two "
+                    "rocprofv3 --pmc child runs of this file (FETCH_SIZE, WRITE_SIZE) after the timed region")
     ap.add_argument("--no-postfilters", action="store_true", help="skip the post-calling filter legs (`configs3_realign`: the Illumina realigner, host and "
                     "device form; `hapfilter`: the long-read haplotype filter) - after the timed region, never part of `value`")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file legs (mpileup text -> VCF, BAM -> VCF)")
@@ -728,6 +777,9 @@ def main():
     ext_bytes = pack_bytes + 5 * sum(p.n_cols for p in packs) / len(packs)
     ext_cands = int(xn.item())
 
+    live_traffic = None
+    if rank == 0 and world == 1 and not args.no_live_traffic:
+        live_traffic = live_pmc_traffic(args.batch)
     if rank == 0:
         sites_total = world * args.steps * args.batch
         res = {
@@ -744,7 +796,10 @@ def main():
                        "weights": "seeded random init (no pretrained weights offline)"},
             "roofline": {"bound": "mfma", "kernel": "k_gru_layer_rot<256,256,192,2,true> (BiGRU layer 2 + fused fc1, both directions)",
                          "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(args.batch),
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "traffic": (live_traffic or {}).get("gru_l2") or pmc_traffic(args.batch),
+                         "traffic_source": "measured in this run (two rocprofv3 --pmc child passes of this file after the timed region)" if (live_traffic or {}).get("gru_l2")
+                                           else "from_digest (%s)" % (os.path.relpath(_pmc_file(), ROOT) if _pmc_file() else "none committed"),
                          "traffic_note": "fabric (HBM + Infinity Cache) bytes per launch = 2 x FETCH_SIZE (gfx950 halves coalesced reads; calibrated on the pack read of "
                                          "k_featurize_columns) + WRITE_SIZE, separate rocprofv3 --pmc passes (%s); algorithmic 151 MB: the 138 MB layer-1 output is "
                                          "fetched once per DIRECTION (two workgroups per site tile, on different XCDs), the second time from the Infinity Cache"
@@ -754,7 +809,8 @@ def main():
             "roofline_tensor_creation": {"bound": "hbm", "kernel": "k_featurize_sites (one workgroup per candidate: histograms of its 33 columns in LDS, both passes, rescale fused)",
                                          "achieved": round(feat_bytes / (feat_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                          "frac": round(feat_bytes / (feat_ms * 1e-3) / 1e9 / 8000.0, 4), "launch_ms": round(feat_ms, 4),
-                                         "bytes_per_launch": int(feat_bytes), "traffic": pmc_traffic_featurize(args.batch),
+                                         "bytes_per_launch": int(feat_bytes), "traffic": (live_traffic or {}).get("featurize") or pmc_traffic_featurize(args.batch),
+                                         "traffic_source": "measured in this run" if (live_traffic or {}).get("featurize") else "from_digest",
                                          "note": "latency / issue bound, not bandwidth bound (a chain of ~8 dependent global accesses per candidate; scalar unit, VALU and LDS each about half busy: profiles/round3_fused_featurize.md); ~2 % of the step"},
             "roofline_candidate_extraction": {"bound": "hbm", "kernel": "k_extract_candidates (the gates of extract_candidates_calling on the resident pack: one lane per column, the 64 columns of a wave staged in LDS, counters in registers - no atomics)",
                                               "achieved": round(ext_bytes / (ext_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",

@@ -225,3 +225,55 @@ def test_split_error_report_against_the_oracle(dev, oracle_lib, default_cfg):
         assert v["dP"] < 1e-4, (k, v)
     for net in ("aff_dlogit", "neg_dlogit"):
         assert rep["f16"][net] <= 2 * rep["f32"][net] + 1e-5, rep
+
+
+@pytest.mark.parametrize("platform", ["ont", "ilmn", "hifi"])
+@pytest.mark.parametrize("K", [4, 6])
+def test_split_f16_at_full_size_on_every_config_leg(dev, oracle_lib, platform, K):
+    """The f16 side channel (the validated one: power-of-two operand scales, tests/test_gpu_range.py) on every single-GPU workload the
+    bench line carries as a config leg - ONT 50x, Illumina 50x, HiFi 75x with the SNV (K = 4) and indel (K = 6) model pairs - at the
+    full 4096-site chunk: probabilities within 1e-4 of the fp32 kernels' on all sites and of the oracle's on a 256-site sample, every
+    decision and every 4-decimal QUAL that is not on a rounding boundary equal, batch invariance."""
+    import torch
+    import oracle
+    from clairs_to_amd.engine import Engine, synthetic_models
+    from clairs_to_amd.synth import SynthChunk, PLATFORMS, likelihood_table, lik_and_edges
+    min_bq = PLATFORMS[platform]["min_bq"]
+    chunk = SynthChunk.for_platform(platform, 4096)
+    lik, edges = lik_and_edges(likelihood_table(K), K)
+    engs = {}
+    for kind in ("f32", "f16"):
+        models = synthetic_models(K)
+        models["aff"].split_operands = kind
+        models["neg"].split_operands = kind
+        engs[kind] = Engine(models["aff"], models["neg"], lik, edges, min_bq=min_bq, device=dev, neg_reads_aff=(platform == "ilmn"))
+    dp = engs["f32"].upload(chunk.arrays())
+    sp = torch.from_numpy(chunk.site_pos).to(dev)
+    r32 = engs["f32"].run_device(dp, sp)
+    r16 = engs["f16"].run_device(dp, sp)
+    torch.cuda.synchronize()
+    p32, p16 = r32["probs"].cpu().numpy(), r16["probs"].cpu().numpy()
+    assert np.isfinite(p16).all()
+    d = float(np.abs(p16 - p32).max())
+    print("split f16 %s K=%d: max |dP| vs fp32 kernels %.2e over 4096 sites" % (platform, K, d))
+    assert d < 1e-4
+    d32, d16 = r32["decision"].cpu().numpy(), r16["decision"].cpu().numpy()
+    same = (d32[:, 0] == d16[:, 0]) & ((d32[:, 1] & 3) == (d16[:, 1] & 3))
+    # a decision may only differ where the two winning posteriors are within the probabilities' own distance of each other
+    post = np.sort(r32["post"].cpu().numpy(), axis=1)
+    assert (same | (post[:, -1] - post[:, -2] < 1e-3)).all() and same.mean() > 0.999
+    # oracle on a sample
+    n_s = 256
+    ref, lo = chunk.ref_window()
+    sites = chunk.site_pos[:n_s]
+    c1 = int(np.searchsorted(chunk.col_pos, int(sites[-1]) + 17, side="right"))
+    ta, da, _, _ = oracle.create_tensor(oracle.synth_mpileup_text(chunk, min_bq, (0, c1)), ref, lo, sites)
+    tn, dn, _, _ = oracle.create_tensor(oracle.synth_mpileup_text(chunk, 0, (0, c1)), ref, lo, sites)
+    models = synthetic_models(K)
+    la = oracle.cvt_forward(models["aff_weights"], dict(CVT_CFG, n_out=K), oracle.rescale(ta, da))
+    ln = oracle.bigru_forward(models["neg_weights"], K, oracle.rescale(ta if platform == "ilmn" else tn, da if platform == "ilmn" else dn))
+    probs, _, _, _ = oracle.posterior(la, ln, lik, edges)
+    assert float(np.abs(p16[:n_s] - probs).max()) < 1e-4
+    for a, b in ((0, 17), (17, 1000), (1000, 4096)):
+        part = engs["f16"].run_device(dp, sp[a:b])
+        assert torch.equal(part["probs"], r16["probs"][a:b])
