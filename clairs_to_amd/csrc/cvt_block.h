@@ -248,6 +248,9 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
     // pass is a dependent chain of an LDS read, two 4-step reductions, a square root and a division, and with two waves per
     // SIMD nothing else hides it.
     auto layer_norm = [&](const float* src, float* dst, const float* g, const float* b, auto split_out) {
+#if CTO_CVT_ABL == 2
+        return;
+#endif
         constexpr bool SPO = decltype(split_out)::value;      // dst feeds a split GEMM: rows of [hi | lo]
         constexpr int CPL = C / 16, NP = (MT * 16 + NWV * 4 - 1) / (NWV * 4);
         const int l16 = lane & 15, grp = lane >> 4;
@@ -362,6 +365,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
     stamp();
 
     // ---- phase 2: depth-wise 3-tap conv + BatchNorm of the staging tile; q path -> sy, kv path (stride 2) -> sykv ----
+#if CTO_CVT_ABL != 2
     {
         constexpr int NSLOT = NT / C;                                   // (site, position group) slots of one pass
         constexpr int PG = NSLOT > TS ? NSLOT / TS : 1;                 // more slots than sites: split a site's positions
@@ -405,6 +409,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
         }
         // pad rows of the q-path tile (rows R .. MT*16) keep what phase 0 left there: zeros or the embedding of zeros, finite
     }
+#endif
     lds_barrier();
 
     stamp();
@@ -470,6 +475,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
         // softmax(q k^T / 8) v of one query row per 16-lane group (model.py:126-131; dim_head = 64): lane l owns dimensions
         // 4l .. 4l+3 of q, of every k and v row of the site and of the output, which replaces q in place.  Scores are partial
         // dots reduced inside the 16-lane row; no score matrix in LDS, no barrier between scores, softmax and P v.
+#if CTO_CVT_ABL != 2
         {
             constexpr int NPA = (R + NT / 16 - 1) / (NT / 16); constexpr int UF = WKV <= 5 ? 2 : 1;
             const int l4 = (lane & 15) * 4;
@@ -510,6 +516,7 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
                 }
             }
         }
+#endif
         if (hh + 1 < heads) {        // next head's q weights fly under the barrier and the out-projection
             q_rows(hh + 1, wq_r);
             pre_q = prefetch_b<1, C / KD>(wq_r);
@@ -575,7 +582,11 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
                         for (int r = 0; r < 4; ++r) {
                             float* urow = su + ((spf.mbase + mt) * 16 + 4 * kg + r) * US;
                             if constexpr (SP) put_split1<F16>(urow, HC, (spf.tile0 + nt) * 16 + j, gelu_f(au[mt][nt][r] + bv));
+#if CTO_CVT_ABL == 2
+                            else urow[(spf.tile0 + nt) * 16 + j] = au[mt][nt][r] + bv;
+#else
                             else urow[(spf.tile0 + nt) * 16 + j] = gelu_f(au[mt][nt][r] + bv);
+#endif
                         }
                     }
             }

@@ -8,6 +8,13 @@
 // then).  wrow[nt] = panel + (tile * chunks_per_row + first chunk) * 256 + 4 * lane; consecutive chunks are FRAG_CS floats apart.
 constexpr int FRAG_CS = 256;
 #pragma once
+// CTO_CVT_ABL (tools/ builds only, wrong results by design - DESIGN.md 7.1): 1 = every GEMM of the fused CvT kernel returns at once
+// (what is left is LayerNorm, depth-wise conv, softmax, epilogues, barriers); 2 = those phases do nothing (what is left is the GEMMs, their
+// operand traffic, their epilogue stores and the barriers).  Timing the two beside the product kernel bounds what ANY schedule that overlaps the
+// two kinds of work inside a workgroup can reach.
+#ifndef CTO_CVT_ABL
+#define CTO_CVT_ABL 0
+#endif
 #include <type_traits>
 #include "nn_kernels.h"
 #include "split_mfma.h"
@@ -55,6 +62,9 @@ __device__ __forceinline__ BPre<NTW> prefetch_b(const float* const (&wrow)[NTW])
 template <int MT, int NTW, int KCH>
 __device__ __forceinline__ void gemm_lds(const float* __restrict__ A, int lda, const float* const (&wrow)[NTW],
                                          const BPre<NTW>& pre, f32x4 (&acc)[MT][NTW], int j, int kg) {
+#if CTO_CVT_ABL == 1
+    return;
+#endif
     float4 Bq[3][NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) { Bq[0][nt] = pre.b0[nt]; Bq[1][nt] = pre.b1[nt]; }

@@ -389,9 +389,12 @@ int dispatch_block(hipStream_t s, float* h, const BlockDev* blocks, int nblk, in
 #ifndef CTO_CVT_TS2
 #define CTO_CVT_TS2 16
 #endif
+#ifndef CTO_CVT_TS3
+#define CTO_CVT_TS3 16      // stage 3; 8 (tools/ builds, with CTO_CVT_NO_HEAD_FUSE=1: the classifier needs the 16-site tile) prices half-height tiles
+#endif
 struct FusedGeom { int c, w, wkv, ts, cin; };
 const FusedGeom* fused_geom(const StageDev& st) {
-    static const FusedGeom G[4] = {{128, 5, 3, 16, 64}, {64, 9, 5, CTO_CVT_TS2, 16}, {16, 17, 9, CTO_CVT_TS1, 34}, {32, 17, 9, CTO_CVT_TS1, 34}};
+    static const FusedGeom G[4] = {{128, 5, 3, CTO_CVT_TS3, 64}, {64, 9, 5, CTO_CVT_TS2, 16}, {16, 17, 9, CTO_CVT_TS1, 34}, {32, 17, 9, CTO_CVT_TS1, 34}};
     for (const FusedGeom& g : G)
         if (st.c == g.c && st.w == g.w && st.wkv == g.wkv) return &g;
     return nullptr;
@@ -405,7 +408,7 @@ int try_fused_blocks(hipStream_t s, const StageDev& st, const BlockDev* b, int n
                      bool head, int split) {
     int rc = CTO_OK;
     if (!b->wq_s) split = 0;
-    if (st.c == 128 && st.w == 5 && st.wkv == 3) rc = dispatch_block<128, 5, 3, 16, 64>(s, h, b, nblk, st.heads, B, ex, embed, head, split);
+    if (st.c == 128 && st.w == 5 && st.wkv == 3) rc = dispatch_block<128, 5, 3, CTO_CVT_TS3, 64>(s, h, b, nblk, st.heads, B, ex, embed, head, split);
     else if (st.c == 64 && st.w == 9 && st.wkv == 5) rc = dispatch_block<64, 9, 5, CTO_CVT_TS2, 16>(s, h, b, nblk, st.heads, B, ex, embed, head, split);
     else if (st.c == 16 && st.w == 17 && st.wkv == 9) rc = dispatch_block<16, 17, 9, CTO_CVT_TS1, 34>(s, h, b, nblk, st.heads, B, ex, embed, head, split);
     else if (st.c == 32 && st.w == 17 && st.wkv == 9) rc = dispatch_block<32, 17, 9, CTO_CVT_TS1, 34>(s, h, b, nblk, st.heads, B, ex, embed, head, split);
