@@ -122,6 +122,11 @@ SYMBOLS = {
     "cto_haplotype_filter": (C.c_int, [c_vp, C.c_size_t, C.c_char_p, c_i64, C.c_size_t, c_i64, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int,
                                        C.c_int, c_vp, c_vp]),
     "cto_realign_reads": (C.c_int, [C.c_int, c_vp, c_vp, c_vp, C.c_char_p, C.c_char_p, c_i32, c_i32, c_i32, c_vp, c_vp, C.c_size_t, c_vp]),
+    "cto_dev_tokeniser_create": (C.c_int, [C.POINTER(c_vp)]),
+    "cto_dev_tokeniser_destroy": (None, [c_vp]),
+    "cto_dev_tokeniser_buffer": (c_vp, [c_vp, C.c_size_t]),
+    "cto_tokenise_device": (C.c_int, [c_vp, c_vp, C.c_size_t, C.c_char_p, c_i64, C.c_size_t, C.c_int, c_vp, C.POINTER(PackView), C.POINTER(c_vp),
+                                      C.POINTER(C.c_int)]),
     "cto_softmax_pairs": (C.c_int, [c_vp, c_i64, c_vp, c_vp]),
     "cto_qual_pending": (C.c_int, [c_vp, c_i64, c_vp, c_vp]),
     "cto_realign_windows": (C.c_int, [C.c_int, C.POINTER(RealignJob), C.c_int, C.c_int, c_vp, C.POINTER(RealignStats)]),

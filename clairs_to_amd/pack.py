@@ -121,6 +121,48 @@ class ColumnPack:
         return DevicePack(self.numpy(), device, host=self)
 
 
+class DeviceTokeniser:
+    """mpileup text -> pack in HBM (cto_tokenise_device, csrc/tokenise.hip).  One context per thread / stream; the arrays of a result
+    live in the context until its next call."""
+
+    def __init__(self):
+        h = c_vp()
+        check(lib.cto_dev_tokeniser_create(C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.cto_dev_tokeniser_destroy(h)
+
+    def __call__(self, text, ref_seq, ref_start, max_indel_length=60):
+        """-> (PackView of device pointers, ColumnPack `lite` without entries) or None when the text has to go through
+        ColumnPack.from_mpileup (fallback)."""
+        from ._lib import current_stream_ptr
+        tb = text.encode() if isinstance(text, str) else bytes(text)
+        rb = ref_seq.encode() if isinstance(ref_seq, str) else bytes(ref_seq)
+        arr = np.frombuffer(tb, dtype=np.uint8) if tb else np.zeros(1, dtype=np.uint8)
+        v, lite, fb = PackView(), c_vp(), C.c_int(0)
+        check(lib.cto_tokenise_device(self._h, arr.ctypes.data, len(tb), rb, int(ref_start), len(rb), int(max_indel_length),
+                                      current_stream_ptr(), C.byref(v), C.byref(lite), C.byref(fb)))
+        if fb.value:
+            return None
+        return v, ColumnPack(lite.value)
+
+    @staticmethod
+    def download(view):
+        """the device arrays of a PackView as numpy arrays (tests)"""
+        n = dict(col_pos=view.n_cols, col_ref=view.n_cols, col_off=view.n_cols + 1, key_off=view.n_cols + 1, entries=view.n_entries,
+                 key_meta=view.n_keys, key_group=view.n_keys)
+        out = {}
+        for k, dt in _FIELDS:
+            a = np.zeros(int(n[k]), dtype=dt)
+            if a.size:
+                check(lib.cto_device_read(getattr(view, k), a.ctypes.data, a.nbytes))
+            out[k] = a
+        return out
+
+
 def pin_arrays(arrays):
     """Copies of the pack arrays in page-locked host memory (torch tensors), for asynchronous uploads.  A producer that
     fills such buffers directly (instead of copying into them) gets the PCIe transfer fully off the critical path."""

@@ -155,6 +155,22 @@ int cto_pileup_device(cto_dev_pileup* ctx, const void* d_inflated, const cto_bgz
                       const uint64_t* rec_voffs, int64_t n_starts, int32_t tid, int64_t start, int64_t end, const int64_t* bed,
                       int64_t n_bed, const char* ref_seq, int64_t ref_start, size_t ref_len, int excl_flags, int min_mq,
                       int max_depth, int max_indel_length, void* stream, cto_pack_view* dev_view, cto_pack** host_lite, int* fallback);
+/* mpileup TEXT -> pack on the DEVICE (csrc/tokenise.hip): what cto_pack_from_mpileup builds - the tokeniser of decode_pileup_bases
+ * (src/create_tensor_pileup_calling.py:120-144) and the row handling of :465-532 - born in HBM from the text as `samtools mpileup --output-MQ`
+ * prints it: one lane per row, the single forward pass of the host tokeniser.  `text` is HOST memory (copied through the context's page-locked
+ * buffer unless it IS that buffer: cto_dev_tokeniser_buffer(ctx, len) hands out room to read a file into).  *dev_view: the pack's arrays in device
+ * memory owned by `ctx` (valid until its next call); *host_lite: a host pack WITHOUT entries (col_pos, col_ref, key_off, key tables, alt_info key
+ * strings), freed with cto_pack_free.  *fallback = 1 (CTO_OK, nothing built): the text holds what the single pass declines (another field
+ * count, a short quality string, '\r', a non-printable byte, an indel or '^' running into the field's end, more than 32 indel-carrying read-bases
+ * in one row, an empty row, no final '\n', rows out of position order, a position outside [ref_start, ref_start + ref_len)) - the caller runs
+ * cto_pack_from_mpileup, which defines the behaviour and words the errors.  Synchronises `stream` (sizes come back three times).  Bit-equal to
+ * cto_pack_from_mpileup, array for array and key string for key string (tests/test_gpu_tokenise.py). */
+typedef struct cto_dev_tokeniser cto_dev_tokeniser;
+int   cto_dev_tokeniser_create(cto_dev_tokeniser** out);
+void  cto_dev_tokeniser_destroy(cto_dev_tokeniser* ctx);
+char* cto_dev_tokeniser_buffer(cto_dev_tokeniser* ctx, size_t len);
+int   cto_tokenise_device(cto_dev_tokeniser* ctx, const char* text, size_t len, const char* ref_seq, int64_t ref_start, size_t ref_len,
+                          int max_indel_length, void* stream, cto_pack_view* dev_view, cto_pack** host_lite, int* fallback);
 /* test / tool aid: n bytes of device memory to the host (synchronous hipMemcpy); no reference counterpart */
 int cto_device_read(const void* d_src, void* h_dst, size_t n);
 /* Build a pack from caller-made arrays (synthetic generators, BAM readers); key strings are the
