@@ -50,7 +50,7 @@ class RunCfg(C.Structure):
                 ("inflate_cus", C.c_int), ("inflate_jobs", C.c_int), ("pack_threads", C.c_int), ("samtools", C.c_char_p),
                 ("samtools_max_depth", C.c_int), ("aff2", c_vp), ("neg2", c_vp), ("device_pileup", C.c_int),
                 ("extract_min_mq", C.c_int), ("extract_min_bq", C.c_int), ("alt_base_num", C.c_int), ("snv_min_af", C.c_double),
-                ("indel_min_af", C.c_double), ("min_coverage", C.c_double), ("indel_regions_bed", C.c_char_p)]
+                ("indel_min_af", C.c_double), ("min_coverage", C.c_double), ("indel_regions_bed", C.c_char_p), ("device_tokenise", C.c_int)]
 
 
 class RealignJob(C.Structure):
@@ -68,7 +68,7 @@ class RealignStats(C.Structure):
 class RunStats(C.Structure):
     _fields_ = [("candidates", c_i64), ("sites", c_i64), ("rows", c_i64), ("low_coverage", c_i64), ("clamped", c_i64), ("seconds", C.c_double),
                 ("produce_s", C.c_double), ("finish_s", C.c_double), ("launch_s", C.c_double), ("launcher_wait_s", C.c_double),
-                ("pack_s", C.c_double), ("upload_s", C.c_double), ("device_s", C.c_double), ("device_piled", c_i64), ("device_inflated", c_i64)]
+                ("pack_s", C.c_double), ("upload_s", C.c_double), ("device_s", C.c_double), ("device_piled", c_i64), ("device_inflated", c_i64), ("device_tokenised", c_i64)]
 
 
 # every symbol include/clairsto_amd.h declares: (restype, argtypes)

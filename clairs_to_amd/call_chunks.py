@@ -179,7 +179,7 @@ def native_eligible(chunk_args):
 
 
 def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, stats=None, verbose=True, inflate_cus=None, inflate_jobs=None,
-                        two_streams=False):
+                        two_streams=False, device_tokenise=None):
     """run_pipeline() as ONE C call (cto_run_chunks, csrc/pipeline.hip): the same stages on native threads, with page-locked staging,
     buffers kept from chunk to chunk and - for BAM input - some chunks' BGZF blocks inflated on the device.  Same files, byte for byte.
     The kernels run on a stream of their own: the legacy default stream would synchronise with the CU-masked inflate streams."""
@@ -223,6 +223,9 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
     cfg.inflate_cus = DEVICE_INFLATE[0] if inflate_cus is None else int(inflate_cus)       # only BAM jobs use it
     cfg.inflate_jobs = DEVICE_INFLATE[1] if inflate_jobs is None else int(inflate_jobs)
     cfg.device_pileup = int(os.environ.get("CTO_DEVICE_PILEUP", "1") != "0")     # the device-inflated chunks are piled up on the device too
+    # mpileup text (files or the samtools child's output) goes up as it is and is tokenised on the device (csrc/tokenise.hip); texts its single
+    # pass declines are tokenised on the host.  CTO_DEVICE_TOKENISE=0 / device_tokenise=False: host tokeniser only (same packs)
+    cfg.device_tokenise = int(os.environ.get("CTO_DEVICE_TOKENISE", "1") != "0") if device_tokenise is None else int(bool(device_tokenise))
     # gates of REGION jobs = extract_candidates_calling's options as run_clairs_to:1196-1220 passes them
     from .synth import PLATFORMS as _PF
     fam = resolve_platform(getattr(a0, "platform", "ont"))[1]
@@ -247,7 +250,7 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
     check(rc)
     if stats is not None:
         for k, v in (("sites", st.candidates), ("produce_s", st.produce_s), ("finish_s", st.finish_s), ("launch_s", st.launch_s),
-                     ("launcher_waits_for_producer_s", st.launcher_wait_s), ("pack_s", st.pack_s), ("upload_s", st.upload_s), ("device_s", st.device_s), ("device_inflated", st.device_inflated), ("device_piled", st.device_piled), ("low_coverage", st.low_coverage), ("clamped", st.clamped)):
+                     ("launcher_waits_for_producer_s", st.launcher_wait_s), ("pack_s", st.pack_s), ("upload_s", st.upload_s), ("device_s", st.device_s), ("device_inflated", st.device_inflated), ("device_piled", st.device_piled), ("device_tokenised", st.device_tokenised), ("low_coverage", st.low_coverage), ("clamped", st.clamped)):
             stats[k] = stats.get(k, 0) + v
     return int(st.rows)
 

@@ -124,7 +124,9 @@ struct Slot {
     std::vector<int32_t> sites;
     std::string ref;
     int64_t ref_start = 0;
+    cto_dev_tokeniser* tok = nullptr;    // text input with cfg.device_tokenise: the slot's tokeniser context (text staging + row tables)
     ~Slot() {
+        if (tok) cto_dev_tokeniser_destroy(tok);
         if (pack) cto_pack_free(pack);
         if (uploaded) (void)hipEventDestroy(uploaded);
         if (done) (void)hipEventDestroy(done);
@@ -422,7 +424,7 @@ struct Run {
     Mapped fasta;
     std::vector<std::unique_ptr<InflateCtx>> inflate_ctx;
     Queue<InflateCtx*> free_ctx;
-    std::atomic<int64_t> device_inflated{0}, device_piled{0};
+    std::atomic<int64_t> device_inflated{0}, device_piled{0}, device_tokenised{0};
     std::mutex fai_m;
     std::map<std::string, FaiRec> fai;
     // --call_indels_only_in_these_regions: per contig the rows as sorted, merged [begin, end) intervals (bed_tree_from of the reference)
@@ -619,6 +621,50 @@ struct Run {
         return rc;
     }
 
+    // mpileup text -> pack on the device (cto_tokenise_device): `text` is host memory (the slot's tokeniser buffer when the file was read
+    // straight into it).  *done = 1: the pack sits in the slot's device buffers in the layout of the upload path, s->pack is the host's
+    // lite part, s->uploaded is recorded; *done = 0: the text is one the single pass declines - the caller tokenises it on the host.
+    int pack_from_text_device(Slot* s, const char* text, size_t len, hipStream_t stream, int* done) {
+        *done = 0;
+        int rc;
+        if (!s->tok && (rc = cto_dev_tokeniser_create(&s->tok))) return rc;
+        cto_pack_view dvw{};
+        cto_pack* lite = nullptr;
+        int fallback = 0;
+        if ((rc = cto_tokenise_device(s->tok, text, len, s->ref.data(), s->ref_start, s->ref.size(), cfg->max_indel_length, stream, &dvw, &lite, &fallback)))
+            return rc;
+        if (fallback) return CTO_OK;
+        const size_t nc = size_t(dvw.n_cols), ne = size_t(dvw.n_entries), nk = size_t(dvw.n_keys), ns = s->sites.size();
+        if ((rc = s->stage.ensure(ns * 4 + 256)) != CTO_OK) { cto_pack_free(lite); return rc; }
+        memcpy(s->stage.p, s->sites.data(), ns * 4);
+        const void* src[8] = {dvw.entries, dvw.col_pos, dvw.col_ref, dvw.col_off, dvw.key_off, dvw.key_meta, dvw.key_group, s->stage.p};
+        const size_t bytes[8] = {ne * 4, nc * 4, nc, (nc + 1) * 8, (nc + 1) * 4, nk, nk * 4, ns * 4};
+        size_t off[8], total = 0;
+        for (int i = 0; i < 8; ++i) { off[i] = total; total += (bytes[i] + 255) / 256 * 256 + 256; }
+        if ((rc = s->pack_dev.ensure(total)) != CTO_OK) { cto_pack_free(lite); return rc; }
+        char* d = static_cast<char*>(s->pack_dev.p);
+        for (int i = 0; i < 8; ++i)
+            if (bytes[i]) CTO_HIP(hipMemcpyAsync(d + off[i], src[i], bytes[i], i == 7 ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, stream));
+        if (s->pack) cto_pack_free(s->pack);
+        s->pack = lite;
+        s->hv = cto_pack_view{};
+        s->hv.n_cols = dvw.n_cols; s->hv.n_entries = dvw.n_entries; s->hv.n_keys = dvw.n_keys;
+        s->dv = s->hv;
+        s->dv.entries = reinterpret_cast<const uint32_t*>(d + off[0]);
+        s->dv.col_pos = reinterpret_cast<const int32_t*>(d + off[1]);
+        s->dv.col_ref = reinterpret_cast<const uint8_t*>(d + off[2]);
+        s->dv.col_off = reinterpret_cast<const int64_t*>(d + off[3]);
+        s->dv.key_off = reinterpret_cast<const int32_t*>(d + off[4]);
+        s->dv.key_meta = reinterpret_cast<const uint8_t*>(d + off[5]);
+        s->dv.key_group = reinterpret_cast<const int32_t*>(d + off[6]);
+        s->d_site_pos = reinterpret_cast<const int32_t*>(d + off[7]);
+        CTO_HIP(hipEventRecord(s->uploaded, stream));
+        CTO_HIP(wait_event(s->uploaded));              // the site list left the staging buffer; the tokeniser's arrays are free for the next chunk
+        *done = 1;
+        ++device_tokenised;
+        return CTO_OK;
+    }
+
     // host half of a chunk + the upload; false = nothing to call in this chunk (no output) or an error (failed is set)
     bool produce(Slot* s, hipStream_t stream) {
         const cto_chunk_job& j = jobs[s->job];
@@ -663,13 +709,46 @@ struct Run {
         bool piled_on_device = false;
         const double t_pack = now_s();
         if (j.mpileup_path) {
+            const size_t pl = strlen(j.mpileup_path);
+            const bool gz = pl > 3 && strcmp(j.mpileup_path + pl - 3, ".gz") == 0;
+            int on_dev = 0;
+            const char* tp = nullptr;
+            size_t tn = 0;
             Mapped txt;
-            if (!txt.open(j.mpileup_path, &err)) { fail(err); return false; }
-            // the tokeniser's threads merge their entries straight into the staging buffer (a read-base is >= 3 characters of text)
-            const size_t ecap = txt.n / 3 + 4096;
-            if (s->stage.ensure(ecap * 4 + txt.n / 4 + (size_t(1) << 20)) != CTO_OK) { fail(cto_last_error()); return false; }
-            rc = pack_from_mpileup_impl(txt.p ? txt.p : "", txt.n, s->ref.data(), s->ref_start, s->ref.size(), cfg->max_indel_length,
-                                        static_cast<uint32_t*>(s->stage.p), ecap, &s->pack);
+            if (cfg->device_tokenise && !gz) {
+                // the file is read straight into the tokeniser's page-locked buffer: no mapping, no staging copy
+                if (!s->tok && (rc = cto_dev_tokeniser_create(&s->tok)) != CTO_OK) { fail(cto_last_error()); return false; }
+                const int fd = ::open(j.mpileup_path, O_RDONLY | O_CLOEXEC);
+                if (fd < 0) { fail(std::string("cannot open ") + j.mpileup_path); return false; }
+                struct stat st;
+                if (fstat(fd, &st) != 0) { ::close(fd); fail(std::string("cannot stat ") + j.mpileup_path); return false; }
+                tn = size_t(st.st_size);
+                char* buf = cto_dev_tokeniser_buffer(s->tok, tn + 1);
+                if (!buf) { ::close(fd); fail(cto_last_error()); return false; }
+                size_t got = 0;
+                while (got < tn) {
+                    const ssize_t r = ::pread(fd, buf + got, tn - got, off_t(got));
+                    if (r <= 0) break;
+                    got += size_t(r);
+                }
+                ::close(fd);
+                if (got != tn) { fail(std::string("short read of ") + j.mpileup_path); return false; }
+                tp = buf;
+                rc = pack_from_text_device(s, tp, tn, stream, &on_dev);
+            } else {
+                if (!txt.open(j.mpileup_path, &err)) { fail(err); return false; }
+                tp = txt.p ? txt.p : "";
+                tn = txt.n;
+                if (cfg->device_tokenise) rc = pack_from_text_device(s, tp, tn, stream, &on_dev);
+            }
+            if (rc == CTO_OK && on_dev) piled_on_device = true;
+            else if (rc == CTO_OK) {
+                // the tokeniser's threads merge their entries straight into the staging buffer (a read-base is >= 3 characters of text)
+                const size_t ecap = tn / 3 + 4096;
+                if (s->stage.ensure(ecap * 4 + tn / 4 + (size_t(1) << 20)) != CTO_OK) { fail(cto_last_error()); return false; }
+                rc = pack_from_mpileup_impl(tp, tn, s->ref.data(), s->ref_start, s->ref.size(), cfg->max_indel_length,
+                                            static_cast<uint32_t*>(s->stage.p), ecap, &s->pack);
+            }
         } else {
             std::vector<int64_t> iv;                               // REGION job: every position of the range (no -l)
             if (!region_job) bed_intervals(bed.p ? bed.p : "", bed.n, ctg, &iv);
@@ -687,10 +766,15 @@ struct Run {
                 cmd.push_back(j.bam_path);
                 std::vector<char> text;
                 if (!capture_stdout(cmd, &text, &err)) { fail(err); return false; }
-                const size_t ecap = text.size() / 3 + 4096;
-                if (s->stage.ensure(ecap * 4 + text.size() / 4 + (size_t(1) << 20)) != CTO_OK) { fail(cto_last_error()); return false; }
-                rc = pack_from_mpileup_impl(text.empty() ? "" : text.data(), text.size(), s->ref.data(), s->ref_start, s->ref.size(),
-                                            cfg->max_indel_length, static_cast<uint32_t*>(s->stage.p), ecap, &s->pack);
+                int on_dev = 0;
+                if (cfg->device_tokenise && !text.empty()) rc = pack_from_text_device(s, text.data(), text.size(), stream, &on_dev);
+                if (rc == CTO_OK && on_dev) piled_on_device = true;
+                else if (rc == CTO_OK) {
+                    const size_t ecap = text.size() / 3 + 4096;
+                    if (s->stage.ensure(ecap * 4 + text.size() / 4 + (size_t(1) << 20)) != CTO_OK) { fail(cto_last_error()); return false; }
+                    rc = pack_from_mpileup_impl(text.empty() ? "" : text.data(), text.size(), s->ref.data(), s->ref_start, s->ref.size(),
+                                                cfg->max_indel_length, static_cast<uint32_t*>(s->stage.p), ecap, &s->pack);
+                }
             } else {
                 InflateCtx* c = nullptr;
                 int done = 0;
@@ -1357,6 +1441,7 @@ static int run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs, int64_t
         stats->device_s = run.device_s;
         stats->device_inflated = run.device_inflated;
         stats->device_piled = run.device_piled;
+        stats->device_tokenised = run.device_tokenised;
         stats->launch_s = launch_s;
         stats->launcher_wait_s = wait_s;
         stats->finish_s = run.finish_s;

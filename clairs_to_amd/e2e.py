@@ -58,7 +58,7 @@ def build_run(d, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, reg
 
 
 def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4, bam_reader="native", pipeline="python", inflate_cus=None, inflate_jobs=None, two_streams=False,
-             regions=0, times=1):
+             regions=0, times=1, device_tokenise=None):
     """the pipeline over a prepared run directory -> dict(sites_per_s, ...); best of `repeats` passes (the first one warms the page
     cache, the pinned buffers and the model workspaces)"""
     from .call_chunks import default_producers, run_pipeline, run_pipeline_native
@@ -82,7 +82,7 @@ def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4, bam_
         t0 = time.perf_counter()
         if pipeline == "native":
             rows = run_pipeline_native(eng, chunk_args, producers=producers, writers=writers, stats=stats, verbose=False,
-                                       inflate_cus=inflate_cus, inflate_jobs=inflate_jobs, two_streams=two_streams)
+                                       inflate_cus=inflate_cus, inflate_jobs=inflate_jobs, two_streams=two_streams, device_tokenise=device_tokenise)
         else:
             rows = run_pipeline(eng, chunk_args, producers=producers, writers=writers, stats=stats)
         dt = time.perf_counter() - t0
@@ -92,7 +92,7 @@ def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4, bam_
             host = dict(user_cpu_ms_per_chunk=round((ru1.ru_utime - ru0.ru_utime) * 1e3 / max(1, len(chunk_args)), 2),
                         sys_cpu_ms_per_chunk=round((ru1.ru_stime - ru0.ru_stime) * 1e3 / max(1, len(chunk_args)), 2),
                         minor_faults_per_chunk=int((ru1.ru_minflt - ru0.ru_minflt) / max(1, len(chunk_args))))
-    extra = {k: int(best_stats[k]) for k in ("device_inflated", "device_piled") if k in best_stats}
+    extra = {k: int(best_stats[k]) for k in ("device_inflated", "device_piled", "device_tokenised") if k in best_stats}
     n_sites = run["n_sites"] * times
     if regions:                              # the candidates are the run's own product; every position of the contig was scanned for them
         n_sites = int(best_stats.get("sites", 0))
@@ -106,7 +106,7 @@ def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4, bam_
 
 
 def measure(eng, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, region_kb=None, producers=None, writers=2, workdir=None,
-            repeats=4, pipeline="python", with_extraction=False):
+            repeats=4, pipeline="python", with_extraction=False, host_tokeniser_too=False):
     """build_run + time_run in a temporary directory.  with_extraction (kind "bam"): -> (BED-driven leg, REGION-job leg on the same
     BAM: no candidate BEDs, the candidates are extracted from the pile-up inside the run)"""
     d = tempfile.mkdtemp(prefix="cto_e2e_", dir=workdir)
@@ -119,6 +119,11 @@ def measure(eng, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, reg
         if times > 1:
             source += "; every chunk %d times per pass (%d jobs)" % (times, times * len(run["chunks"]))
         r.update(source=source, input_synthesis_s=round(prep_s, 1))
+        if host_tokeniser_too and kind == "text" and pipeline == "native":
+            # the same files with the host tokeniser (cto_pack_from_mpileup on the producer threads) instead of cto_tokenise_device
+            h = time_run(eng, run, kind, os.path.join(d, "vcf_output_host_tok"), producers, writers, repeats, pipeline=pipeline, times=times,
+                         device_tokenise=False)
+            r["host_tokeniser"] = {k: h[k] for k in ("sites_per_s", "seconds", "producers", "stage_thread_time", "host_process")}
         if with_extraction and kind == "bam":
             r2 = time_run(eng, run, kind, os.path.join(d, "vcf_output_regions"), producers, writers, repeats, pipeline="native", regions=len(run["chunks"]),
                           times=times)
@@ -161,7 +166,7 @@ def main():
     for kind in a.kinds.split(","):
         n = a.chunks if kind == "text" else (a.bam_chunks or max(2, a.chunks // 3))
         r = measure(eng, kind=kind, n_chunks=n, sites_per_chunk=a.batch, producers=a.producers, writers=a.writers, pipeline=a.pipeline,
-                    with_extraction=(kind == "bam" and a.pipeline == "native"))
+                    with_extraction=(kind == "bam" and a.pipeline == "native"), host_tokeniser_too=True)
         if isinstance(r, tuple):
             out["bam_to_vcf"], out["bam_to_vcf_with_extraction"] = r
         else:
@@ -169,7 +174,7 @@ def main():
     if a.reference_chunk_sites > 0 and "text" in a.kinds.split(","):
         n = max(4, a.chunks * a.batch // a.reference_chunk_sites)
         out["mpileup_text_to_vcf_reference_chunks"] = measure(eng, kind="text", n_chunks=n, sites_per_chunk=a.reference_chunk_sites,
-                                                              producers=a.producers, writers=a.writers, pipeline=a.pipeline)
+                                                              producers=a.producers, writers=a.writers, pipeline=a.pipeline, host_tokeniser_too=True)
     print(json.dumps(out))
 
 

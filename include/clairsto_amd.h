@@ -467,6 +467,9 @@ typedef struct cto_run_cfg {
     const char* indel_regions_bed; /* --call_indels_only_in_these_regions (NULL: none): K = 6 REGION jobs keep an indel candidate only
                                    when [pos - 1, pos) overlaps a row of its contig (0-based half-open rows, start == end widened by
                                    one; a BED without rows of the contig filters nothing) - extract_candidates_calling.py:437-446   */
+    int    device_tokenise;     /* mpileup-text input (mpileup_path, or the samtools child's output): 1 = the text goes up as it is and the
+                                   pack is built in HBM (cto_tokenise_device); a text that path declines is tokenised on the host
+                                   (cto_pack_from_mpileup).  Same packs.                                                         */
 } cto_run_cfg;
 typedef struct cto_run_stats {
     int64_t candidates;                                /* candidate positions read from the BED chunks / extracted from the regions */
@@ -478,6 +481,7 @@ typedef struct cto_run_stats {
     double  device_s;                                  /* HIP-event time from a chunk's first kernel to its last copy, summed    */
     int64_t device_piled;                              /* chunks whose pack was built on the device (cto_pileup_device) */
     int64_t device_inflated;                           /* BAM chunks whose blocks were inflated on the device                    */
+    int64_t device_tokenised;                          /* text chunks whose pack was built on the device (cto_tokenise_device)   */
 } cto_run_stats;
 int cto_run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs, int64_t n_jobs, void* stream, cto_run_stats* stats);
 /* cto_run_chunks keeps its per-chunk buffers (device, page-locked host, events) for the next call on the same device; this
