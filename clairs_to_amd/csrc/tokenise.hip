@@ -144,208 +144,296 @@ __device__ __forceinline__ int ref_code_dev(unsigned char c) {
     switch (up_c(c)) { case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 0; }
 }
 
-__global__ __launch_bounds__(256) void k_count_lines(const unsigned char* __restrict__ text, long long len, int n_seg, int* __restrict__ cnt) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_seg) return;
-    const long long lo = (long long)s * SEG, hi = min(len, lo + SEG);
-    int c = (s == 0 && len > 0) ? 1 : 0;                    // a row starts at byte 0 and behind every '\n' that is not the last byte
-    for (long long p = lo; p < hi; ++p) c += (text[p] == '\n' && p + 1 < len) ? 1 : 0;
-    // (a '\n' at p makes a row start at p + 1, which may lie in the next segment: it is counted where its '\n' is, and k_rows<COUNT>
-    // walks the same '\n's, so the indices agree)
-    cnt[s] = c;
-}
-
 struct RowArgs {
     const unsigned char* text; long long len;
     const unsigned char* ref; long long ref_start, ref_len;
     int max_indel_length;
-    // COUNT: per segment
-    const int* seg_base; int n_seg;
-    long long* row_start; int* row_nt; int* row_nk; int* row_pos;
-    // FILL: per row
     int n_rows;
+    const long long* row_start;
+    // COUNT writes, FILL reads
+    int* row_nt; int* row_nk; int* row_pos; int* row_b0; int* row_blen;
+    // FILL
     const long long* col_off; const int* key_off;
     unsigned* entries; int* col_pos; unsigned char* col_ref;
     unsigned char* key_meta; int* key_group; int* key_len; long long* key_seq; int* key_info;
     TokFlags* fl;
 };
 
-// One row.  FILL = false: counts; true: writes.  Returns false when the row is not one the single pass takes.
-template <bool FILL>
-__device__ bool one_row(const RowArgs& a, long long cur, int row) {
-    const unsigned char* t = a.text;
-    const long long len = a.len;
-    long long q = cur;
-    auto at = [&](long long p) -> unsigned { return p < len ? unsigned(t[p]) : 10u; };
-    while (at(q) > 10u) ++q;                                           // contig
-    if (at(q) != '\t' || q == cur) return false;                       // (an empty contig field: leave it to the host)
-    ++q;
-    const long long d0 = q;
-    long long pos = 0;
-    while (at(q) - '0' < 10u) { pos = pos * 10 + (at(q) - '0'); ++q; }
-    if (q == d0 || q - d0 > 15 || at(q) != '\t') return false;
-    ++q;
-    while (at(q) > 10u) ++q;                                           // reference base
-    if (at(q) != '\t') return false;
-    ++q;
-    while (at(q) > 10u) ++q;                                           // depth
-    if (at(q) != '\t') return false;
-    ++q;
-    const long long b0 = q;
-    int nt = 0, ni = 0;
-    long long ind_seq[MAX_IND];
-    int ind_len[MAX_IND], ind_at[MAX_IND];                             // ind_at = read-base index << 2 | kind
+// A forward reader of the text: the next <= 8 bytes sit in a register and a byte costs a shift, the following aligned 8 bytes are
+// requested one refill ahead.  (A row parsed through one dependent global byte load per character - the first form of this file -
+// is a chain of ~300 L2 round trips: 250 us per launch however many rows are in flight.)  The device copy of the text is padded, so
+// the aligned word that holds the last byte may be read whole.
+struct ByteStream {
+    const unsigned char* t;
+    long long pos, next;               // position of the byte peek() returns; offset of the word behind q2
+    unsigned long long bits, q0, q1, q2;   // the word being consumed and the three behind it (24 bytes of look-ahead: an L2 round trip is
+    int have;                              // ~700 cycles, eight bytes of parsing ~400)
+    __device__ __forceinline__ static unsigned long long ld8(const unsigned char* t, long long a) {
+        return *reinterpret_cast<const unsigned long long*>(t + a);
+    }
+    __device__ __forceinline__ void seek(const unsigned char* text, long long p) {
+        t = text; pos = p;
+        const long long a = p & ~7LL;
+        const int o = int(p - a);
+        bits = ld8(t, a) >> (8 * o);
+        have = 8 - o;
+        q0 = ld8(t, a + 8); q1 = ld8(t, a + 16); q2 = ld8(t, a + 24);
+        next = a + 32;
+    }
+    __device__ __forceinline__ unsigned peek() const { return unsigned(bits & 0xffull); }
+    __device__ __forceinline__ unsigned peek1() const { return have >= 2 ? unsigned((bits >> 8) & 0xffull) : unsigned(q0 & 0xffull); }
+    __device__ __forceinline__ void step() {
+        bits >>= 8; ++pos;
+        if (--have == 0) { bits = q0; q0 = q1; q1 = q2; q2 = ld8(t, next); next += 8; have = 8; }
+    }
+    __device__ __forceinline__ unsigned take() { const unsigned c = peek(); step(); return c; }
+    __device__ __forceinline__ void skip(long long n) { if (n < have) { bits >>= 8 * int(n); have -= int(n); pos += n; } else seek(t, pos + n); }
+};
+
+// indel-carrying read-bases of the row being parsed (a lane's private memory; rows without indels never touch it)
+struct RowIndels {
+    long long seq[MAX_IND];
+    int len[MAX_IND], at[MAX_IND], code[MAX_IND], kid[MAX_IND];          // at = read-base index << 2 | kind
+    int n = 0, nk = 0;
+    // distinct keys, first seen first: Counter key = read-base code + sign + sequence, case-sensitive (pack.cpp: intern_indel)
+    __device__ void intern(const unsigned char* t) {
+        nk = 0;
+        for (int i = 0; i < n; ++i) {
+            int found = -1;
+            for (int j2 = 0; j2 < i && found < 0; ++j2) {
+                if (len[j2] != len[i] || (at[j2] & 3) != (at[i] & 3) || code[j2] != code[i]) continue;
+                bool eq = true;
+                for (int k = 0; k < len[i] && eq; ++k) eq = t[seq[j2] + k] == t[seq[i] + k];
+                if (eq) found = kid[j2];
+            }
+            kid[i] = found >= 0 ? found : nk++;
+        }
+    }
+};
+
+// The base string from `st` on: counts read-bases, collects the indel tokens.  Returns false when the single pass declines the row.
+__device__ __forceinline__ bool walk_bases(ByteStream& st, const unsigned char* t, long long len, int& nt, RowIndels& ind) {
+    nt = 0;
+    int last_code = 0;
     for (;;) {
-        const int cl = char_class(at(q));
-        if (cl < 12) { ++nt; ++q; }
-        else if (cl == 14) ++q;
-        else if (cl == 13) { if (at(q + 1) <= 10u) return false; q += 2; }
+        const unsigned c = st.peek();
+        const int cl = char_class(c);
+        if (cl < 12) { last_code = cl; ++nt; st.step(); }
+        else if (cl == 14) st.step();
+        else if (cl == 13) { if (st.peek1() <= 10u) return false; st.step(); st.step(); }
         else if (cl == 12) {
-            const int kind = at(q) == '+' ? 1 : 2;
-            ++q;
+            const int kind = c == '+' ? 1 : 2;
+            st.step();
             long long adv = 0;
-            while (at(q) - '0' < 10u) { adv = adv * 10 + (at(q) - '0'); ++q; if (adv > (1 << 24)) return false; }
-            if (nt == 0 || q + adv > len) return false;
-            for (long long k = 0; k < adv; ++k) if (t[q + k] <= 10) return false;
-            if (ni > 0 && (ind_at[ni - 1] >> 2) == nt - 1) --ni;      // a second annotation of the same read-base replaces the first
-            if (ni >= MAX_IND) return false;
-            ind_seq[ni] = q; ind_len[ni] = int(adv); ind_at[ni] = ((nt - 1) << 2) | kind;
-            ++ni;
-            q += adv;
+            while (st.peek() - '0' < 10u) { adv = adv * 10 + (st.peek() - '0'); st.step(); if (adv > (1 << 24)) return false; }
+            if (nt == 0 || st.pos + adv > len) return false;
+            for (long long k = 0; k < adv; ++k) if (t[st.pos + k] <= 10) return false;
+            if (ind.n > 0 && (ind.at[ind.n - 1] >> 2) == nt - 1) --ind.n;      // a second annotation of the same read-base replaces the first
+            if (ind.n >= MAX_IND) return false;
+            ind.seq[ind.n] = st.pos; ind.len[ind.n] = int(adv); ind.at[ind.n] = ((nt - 1) << 2) | kind; ind.code[ind.n] = last_code;
+            ++ind.n;
+            st.skip(adv);
         } else break;
     }
-    if (at(q) != '\t' || nt > kMaxDepth) return false;
-    const long long qs = q + 1, ms = qs + nt + 1, eol = ms + nt;
-    if (eol >= len || t[qs + nt] != '\t' || t[eol] != '\n') return false;
-    // distinct keys, first seen first: Counter key = read-base code + sign + sequence, case-sensitive (pack.cpp: intern_indel)
-    int kid[MAX_IND], nk = 0;
-    // read-base codes of the indel carriers need the base string again: walk it once more, only as far as needed
-    int code_of[MAX_IND];
-    if (ni > 0) {
-        long long p = b0;
-        int idx = 0, w = 0;
-        while (w < ni) {
-            const int cl = char_class(t[p]);
-            if (cl < 12) { if (idx == (ind_at[w] >> 2)) { code_of[w] = cl; ++w; } ++idx; ++p; }
-            else if (cl == 14) ++p;
-            else if (cl == 13) p += 2;
-            else {                                                     // an indel token: skip sign, digits and sequence
-                ++p;
-                long long adv = 0;
-                while (unsigned(t[p]) - '0' < 10u) { adv = adv * 10 + (t[p] - '0'); ++p; }
-                p += adv;
+    return true;
+}
+
+// pass 1 of a row: the single forward pass of pack.cpp's fast_row; writes the row's counts, false = not a row this path takes
+__device__ bool count_row(const RowArgs& a, long long cur, int row) {
+    const unsigned char* t = a.text;
+    const long long len = a.len;
+    ByteStream st;
+    st.seek(t, cur);
+    if (st.peek() <= 10u) return false;                                 // an empty row / an empty contig field: the host's
+    while (st.peek() > 10u) st.step();                                  // contig
+    if (st.peek() != '\t') return false;
+    st.step();
+    long long pos = 0;
+    int nd = 0;
+    while (st.peek() - '0' < 10u) { pos = pos * 10 + (st.peek() - '0'); st.step(); ++nd; if (nd > 15) return false; }
+    if (nd == 0 || st.peek() != '\t') return false;
+    st.step();
+    while (st.peek() > 10u) st.step();                                  // reference base
+    if (st.peek() != '\t') return false;
+    st.step();
+    while (st.peek() > 10u) st.step();                                  // depth
+    if (st.peek() != '\t') return false;
+    st.step();
+    const long long b0 = st.pos;
+    int nt = 0;
+    RowIndels ind;
+    if (!walk_bases(st, t, len, nt, ind)) return false;
+    if (st.peek() != '\t' || nt > kMaxDepth) return false;
+    const long long blen = st.pos - b0;
+    st.step();
+    // as many quality and mapping-quality characters as read-bases, printable (phred 0..94), then the end of the row
+    if (st.pos + 2LL * nt + 1 >= len) return false;
+    bool bad = false;
+    for (int i = 0; i < nt; ++i) bad |= st.take() - 33u > 94u;
+    if (st.take() != '\t') return false;
+    for (int i = 0; i < nt; ++i) bad |= st.take() - 33u > 94u;
+    if (bad || st.peek() != '\n') return false;
+    if (ind.n > 0) ind.intern(t);
+    a.row_nt[row] = nt;
+    a.row_nk[row] = ind.nk;
+    a.row_pos[row] = int(min(pos, (long long)0x7fffffff));
+    a.row_b0[row] = int(b0 - cur);
+    a.row_blen[row] = int(blen);
+    const long long ri = pos - a.ref_start;
+    if (ri < 0 || ri >= a.ref_len || pos > 0x7fffffffLL) atomicMax(&a.fl->oob, 1);
+    return b0 - cur < (1LL << 30);
+}
+
+// pass 2 of a row: entries, column tables, the row's distinct keys
+__device__ void fill_row(const RowArgs& a, long long cur, int row) {
+    const unsigned char* t = a.text;
+    const long long e0 = a.col_off[row];
+    const int k0 = a.key_off[row];
+    const int nt = a.row_nt[row];
+    const long long pos = a.row_pos[row], ri = pos - a.ref_start;
+    const unsigned char rb = a.ref[ri];
+    const unsigned char ru = up_c(rb);
+    a.col_pos[row] = int(pos);
+    a.col_ref[row] = static_cast<unsigned char>(ref_code_dev(rb) | ((ru == 'A' || ru == 'C' || ru == 'G' || ru == 'T') ? 0 : 0x80));
+    const long long b0 = cur + a.row_b0[row], qs = b0 + a.row_blen[row] + 1, ms = qs + nt + 1;
+    RowIndels ind;
+    if (a.row_nk[row] > 0) {                                             // the row's indel tokens and their key ids, as pass 1 saw them
+        ByteStream sb;
+        sb.seek(t, b0);
+        int n2 = 0;
+        (void)walk_bases(sb, t, a.len, n2, ind);
+        ind.intern(t);
+    }
+    ByteStream sb, sq, sm;
+    sb.seek(t, b0); sq.seek(t, qs); sm.seek(t, ms);
+    int idx = 0, w = 0;
+    while (idx < nt) {
+        const unsigned c = sb.peek();
+        const int cl = char_class(c);
+        if (cl < 12) {
+            unsigned e = unsigned(cl) | ((sq.take() - 33u) << 6) | ((sm.take() - 33u) << 13);
+            if (w < ind.n && (ind.at[w] >> 2) == idx) {
+                const int tk = ind.at[w] & 3;
+                const int gate = tk == 1 ? ind.len[w] : ind.len[w] + 1;
+                e |= unsigned(gate > a.max_indel_length ? 3 : tk) << 4;
+                e |= unsigned(ind.kid[w]) << 21;
+                ++w;
             }
+            a.entries[e0 + idx] = e;
+            ++idx;
+            sb.step();
+        } else if (cl == 14) sb.step();
+        else if (cl == 13) { sb.step(); sb.step(); }
+        else {                                                           // an indel token: sign, digits, sequence
+            sb.step();
+            long long adv = 0;
+            while (sb.peek() - '0' < 10u) { adv = adv * 10 + (sb.peek() - '0'); sb.step(); }
+            sb.skip(adv);
         }
     }
-    for (int i = 0; i < ni; ++i) {
-        int found = -1;
-        for (int j2 = 0; j2 < i && found < 0; ++j2) {
-            if (ind_len[j2] != ind_len[i] || (ind_at[j2] & 3) != (ind_at[i] & 3) || code_of[j2] != code_of[i]) continue;
+    // the row's distinct keys: meta byte, merged group (insertions by upper-cased anchor + sequence, deletions by length:
+    // extract_candidates_calling.py:118-126), alt_info string length; where k_key_strings finds the sequence
+    int grp[MAX_IND];
+    int ng = 0;
+    for (int i = 0; i < ind.n; ++i) {
+        bool first = true;
+        for (int j2 = 0; j2 < i; ++j2) if (ind.kid[j2] == ind.kid[i]) { first = false; break; }
+        if (!first) continue;
+        const int tk = ind.at[i] & 3, code = ind.code[i], sl = ind.len[i];
+        const int gate = tk == 1 ? sl : sl + 1;
+        const bool overlong = gate > a.max_indel_length;
+        const bool fwd = code < 4 || code == 8 || code == 10;
+        const unsigned char anchors[12] = {'A', 'C', 'G', 'T', 'A', 'C', 'G', 'T', '*', '#', 'N', 'N'};
+        const unsigned char anchor = tk == 1 ? anchors[code] : static_cast<unsigned char>('D');
+        int g = -1;
+        for (int j2 = 0; j2 < i && g < 0; ++j2) {                        // earlier FIRST occurrences only carry a group
+            bool jfirst = true;
+            for (int j3 = 0; j3 < j2; ++j3) if (ind.kid[j3] == ind.kid[j2]) { jfirst = false; break; }
+            if (!jfirst) continue;
+            if ((ind.at[j2] & 3) != tk || ind.len[j2] != sl) continue;
+            if (tk == 2) { g = grp[j2]; break; }
+            if (anchors[ind.code[j2]] != anchor) continue;
             bool eq = true;
-            for (int k = 0; k < ind_len[i] && eq; ++k) eq = t[ind_seq[j2] + k] == t[ind_seq[i] + k];
-            if (eq) found = kid[j2];
+            for (int k = 0; k < sl && eq; ++k) eq = up_c(t[ind.seq[j2] + k]) == up_c(t[ind.seq[i] + k]);
+            if (eq) g = grp[j2];
         }
-        kid[i] = found >= 0 ? found : nk++;
-    }
-    if constexpr (!FILL) {
-        a.row_start[row] = cur;
-        a.row_nt[row] = nt;
-        a.row_nk[row] = nk;
-        a.row_pos[row] = int(min(pos, (long long)0x7fffffff));
-        const long long ri = pos - a.ref_start;
-        if (ri < 0 || ri >= a.ref_len || pos > 0x7fffffffLL) atomicMax(&a.fl->oob, 1);
-        // quality characters: printable only (phred 0..94), as the host's single pass demands
-        bool bad = false;
-        for (int i = 0; i < nt; ++i) bad |= (unsigned(t[qs + i]) - 33u > 94u) | (unsigned(t[ms + i]) - 33u > 94u);
-        return !bad;
-    } else {
-        const long long e0 = a.col_off[row];
-        const int k0 = a.key_off[row];
-        const long long ri = pos - a.ref_start;
-        const unsigned char rb = a.ref[ri];
-        const unsigned char ru = up_c(rb);
-        a.col_pos[row] = int(pos);
-        a.col_ref[row] = static_cast<unsigned char>(ref_code_dev(rb) | ((ru == 'A' || ru == 'C' || ru == 'G' || ru == 'T') ? 0 : 0x80));
-        // entries: codes in a third walk of the base string, qualities beside them
-        long long p = b0;
-        int idx = 0, w = 0;
-        while (idx < nt) {
-            const int cl = char_class(t[p]);
-            if (cl < 12) {
-                unsigned e = unsigned(cl) | ((unsigned(t[qs + idx]) - 33u) << 6) | ((unsigned(t[ms + idx]) - 33u) << 13);
-                while (w < ni && (ind_at[w] >> 2) < idx) ++w;
-                if (w < ni && (ind_at[w] >> 2) == idx) {
-                    const int tk = ind_at[w] & 3;
-                    const int gate = tk == 1 ? ind_len[w] : ind_len[w] + 1;
-                    e |= unsigned(gate > a.max_indel_length ? 3 : tk) << 4;
-                    e |= unsigned(kid[w]) << 21;
-                }
-                a.entries[e0 + idx] = e;
-                ++idx; ++p;
-            } else if (cl == 14) ++p;
-            else if (cl == 13) p += 2;
-            else {
-                ++p;
-                long long adv = 0;
-                while (unsigned(t[p]) - '0' < 10u) { adv = adv * 10 + (t[p] - '0'); ++p; }
-                p += adv;
-            }
-        }
-        // the row's distinct keys: meta byte, merged group (insertions by upper-cased anchor + sequence, deletions by length:
-        // extract_candidates_calling.py:118-126), alt_info string length; sequence location for k_key_strings
-        int grp[MAX_IND], ng = 0;
-        for (int i = 0; i < ni; ++i) {
-            bool first = true;
-            for (int j2 = 0; j2 < i; ++j2) if (kid[j2] == kid[i]) { first = false; break; }
-            if (!first) continue;
-            const int tk = ind_at[i] & 3, code = code_of[i], sl = ind_len[i];
-            const int gate = tk == 1 ? sl : sl + 1;
-            const bool overlong = gate > a.max_indel_length;
-            const bool fwd = code < 4 || code == 8 || code == 10;
-            const unsigned char anchors[12] = {'A', 'C', 'G', 'T', 'A', 'C', 'G', 'T', '*', '#', 'N', 'N'};
-            const unsigned char anchor = tk == 1 ? anchors[code] : static_cast<unsigned char>('D');
-            int g = -1;
-            for (int j2 = 0; j2 < i && g < 0; ++j2) {                  // earlier FIRST occurrences only carry a group
-                bool jfirst = true;
-                for (int j3 = 0; j3 < j2; ++j3) if (kid[j3] == kid[j2]) { jfirst = false; break; }
-                if (!jfirst) continue;
-                const int tk2 = ind_at[j2] & 3;
-                if (tk2 != tk || ind_len[j2] != sl) continue;
-                if (tk == 2) { g = grp[j2]; break; }
-                if (anchors[code_of[j2]] != anchor) continue;
-                bool eq = true;
-                for (int k = 0; k < sl && eq; ++k) eq = up_c(t[ind_seq[j2] + k]) == up_c(t[ind_seq[i] + k]);
-                if (eq) g = grp[j2];
-            }
-            if (g < 0) g = ng++;
-            grp[i] = g;
-            const int k = k0 + kid[i];
-            a.key_meta[k] = static_cast<unsigned char>(tk | (fwd ? 4 : 0) | (overlong ? 8 : 0));
-            a.key_group[k] = g;
-            long long take = min((long long)(sl + 1), (long long)a.max_indel_length);
-            take = min(take, a.ref_len - ri);
-            a.key_len[k] = tk == 1 ? 2 + sl : 1 + int(take);
-            a.key_seq[k] = tk == 1 ? ind_seq[i] : ri;
-            a.key_info[k] = (sl << 8) | (code << 4) | tk;
-        }
-        return true;
+        if (g < 0) g = ng++;
+        grp[i] = g;
+        const int k = k0 + ind.kid[i];
+        a.key_meta[k] = static_cast<unsigned char>(tk | (fwd ? 4 : 0) | (overlong ? 8 : 0));
+        a.key_group[k] = g;
+        long long take = min((long long)(sl + 1), (long long)a.max_indel_length);
+        take = min(take, a.ref_len - ri);
+        a.key_len[k] = tk == 1 ? 2 + sl : 1 + int(take);
+        a.key_seq[k] = tk == 1 ? ind.seq[i] : ri;
+        a.key_info[k] = (sl << 8) | (code << 4) | tk;
     }
 }
 
-__global__ __launch_bounds__(256) void k_rows_count(RowArgs a) {
+// zero-byte detector on eight bytes at once: bit 7 of every byte of the result that was '\n' in x
+__device__ __forceinline__ unsigned long long newline_mask(unsigned long long x) {
+    const unsigned long long y = x ^ 0x0a0a0a0a0a0a0a0aull, m = 0x7f7f7f7f7f7f7f7full;
+    return ~(((y & m) + m) | y | m);                          // the exact form: no borrow from a zero byte into its neighbour
+}
+
+__global__ __launch_bounds__(256) void k_count_lines(const unsigned char* __restrict__ text, long long len, int n_seg, int* __restrict__ cnt) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= a.n_seg) return;
-    const long long lo = (long long)s * SEG, hi = min(a.len, lo + SEG);
-    int row = a.seg_base[s];
-    if (s == 0 && a.len > 0) { if (!one_row<false>(a, 0, row)) atomicMax(&a.fl->slow, 1); ++row; }
-    for (long long p = lo; p < hi; ++p)
-        if (a.text[p] == '\n' && p + 1 < a.len) { if (!one_row<false>(a, p + 1, row)) atomicMax(&a.fl->slow, int(min(p + 2, (long long)0x7fffffff))); ++row; }
+    if (s >= n_seg) return;
+    const long long lo = (long long)s * SEG, hi = min(len, lo + SEG);
+    int c = (s == 0 && len > 0) ? 1 : 0;                    // a row starts at byte 0 and behind every '\n' that is not the last byte
+    if (hi - lo == SEG && hi < len) {                       // a whole segment that does not hold the text's last byte: eight bytes at a time
+        const uint4* w = reinterpret_cast<const uint4*>(text + lo);
+#pragma unroll 4
+        for (int i = 0; i < SEG / 16; ++i) {
+            const uint4 v = w[i];
+            c += __popcll(newline_mask((unsigned long long)v.x | ((unsigned long long)v.y << 32))) +
+                 __popcll(newline_mask((unsigned long long)v.z | ((unsigned long long)v.w << 32)));
+        }
+    } else {
+        for (long long p = lo; p < hi; ++p) c += (text[p] == '\n' && p + 1 < len) ? 1 : 0;
+    }
+    // (a '\n' at p makes a row start at p + 1, which may lie in the next segment: it is counted where its '\n' is, and k_row_starts
+    // walks the same '\n's, so the indices agree)
+    cnt[s] = c;
+}
+
+// row index -> byte offset of the row's first character (one lane per segment, the rows that start behind its '\n's)
+__global__ __launch_bounds__(256) void k_row_starts(const unsigned char* __restrict__ text, long long len, int n_seg, const int* __restrict__ seg_base,
+                                                    long long* __restrict__ row_start) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    const long long lo = (long long)s * SEG, hi = min(len, lo + SEG);
+    int row = seg_base[s];
+    if (s == 0 && len > 0) row_start[row++] = 0;
+    if (row == seg_base[s + 1]) return;                      // no row starts behind a '\n' of this segment
+    if (hi - lo == SEG && hi < len) {
+        const unsigned long long* w = reinterpret_cast<const unsigned long long*>(text + lo);
+        for (int i = 0; i < SEG / 8; ++i) {
+            unsigned long long m = newline_mask(w[i]);
+            while (m) {
+                const int b = __ffsll((long long)m) - 1;     // bit 7 of byte b / 8
+                row_start[row++] = lo + i * 8 + (b >> 3) + 1;
+                m &= m - 1;
+            }
+        }
+    } else {
+        for (long long p = lo; p < hi; ++p)
+            if (text[p] == '\n' && p + 1 < len) row_start[row++] = p + 1;
+    }
+}
+// one lane per row (a lane per segment that parsed "its" rows where it found them ran the parser once per '\n' position of the
+// wavefront, one or two lanes at a time: 4.5 ms instead of 0.3)
+__global__ __launch_bounds__(256) void k_rows_count(RowArgs a) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_rows) return;
+    const long long cur = a.row_start[r];
+    if (!count_row(a, cur, r)) atomicMax(&a.fl->slow, int(min(cur + 1, (long long)0x7fffffff)));
 }
 __global__ __launch_bounds__(256) void k_rows_fill(RowArgs a) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.n_rows) return;
     if (r > 0 && a.row_pos[r] <= a.row_pos[r - 1]) atomicMax(&a.fl->bad_order, 1);
-    one_row<true>(a, a.row_start[r], r);
+    fill_row(a, a.row_start[r], r);
 }
 __global__ __launch_bounds__(128) void k_key_strings(const unsigned char* __restrict__ text, const unsigned char* __restrict__ ref, int n_keys,
                                                      const long long* __restrict__ key_seq, const int* __restrict__ key_info,
@@ -369,7 +457,7 @@ __global__ __launch_bounds__(128) void k_key_strings(const unsigned char* __rest
 }  // namespace
 
 struct cto_dev_tokeniser {
-    Buf text, ref, seg_cnt, seg_base, row_start, row_nt, row_nk, row_pos, col_off, key_off, entries, col_pos, col_ref, key_meta, key_group,
+    Buf text, ref, seg_cnt, seg_base, row_start, row_nt, row_nk, row_pos, row_b0, row_blen, col_off, key_off, entries, col_pos, col_ref, key_meta, key_group,
         key_len, key_seq, key_info, str_off, key_str, tiles, flags;
     void* h_text = nullptr; size_t h_text_cap = 0;      // page-locked: the text on its way up
     void* h_stage = nullptr; size_t h_stage_cap = 0;    // page-locked: everything that comes back
@@ -430,10 +518,11 @@ extern "C" int cto_tokenise_device(cto_dev_tokeniser* cx, const char* text, size
         memcpy(cx->h_text, text, len);
     }
     const int n_seg = int(cdiv(int64_t(len), SEG));
-    if ((rc = cx->text.ensure(len + 16)) || (rc = cx->ref.ensure(ref_len + 16)) || (rc = cx->seg_cnt.ensure(size_t(n_seg) * 4)) ||
+    if ((rc = cx->text.ensure(len + 128)) || (rc = cx->ref.ensure(ref_len + 16)) || (rc = cx->seg_cnt.ensure(size_t(n_seg) * 4)) ||
         (rc = cx->seg_base.ensure(size_t(n_seg + 1) * 4)) || (rc = cx->tiles.ensure(size_t(cdiv(std::max<int64_t>(n_seg, int64_t(len / 8)), SCAN_TILE) + 2) * 8)) ||
         (rc = cx->flags.ensure(sizeof(TokFlags) + 64)) || (rc = cx->pin(&cx->h_stage, &cx->h_stage_cap, 4096)))
         return rc;
+    CTO_HIP(hipMemsetAsync(cx->text.as<char>() + (len & ~size_t(15)), '\n', 96 + (len & 15), s));     // the readers look up to five words past the end
     CTO_HIP(hipMemcpyAsync(cx->text.p, cx->h_text, len, hipMemcpyHostToDevice, s));
     CTO_HIP(hipMemcpyAsync(cx->ref.p, ref_seq, ref_len, hipMemcpyHostToDevice, s));
     CTO_HIP(hipMemsetAsync(cx->flags.p, 0, sizeof(TokFlags), s));
@@ -450,16 +539,22 @@ extern "C" int cto_tokenise_device(cto_dev_tokeniser* cx, const char* text, size
     const int n_rows = hf->n_rows;
     if (n_rows <= 0) { *fallback = 1; return CTO_OK; }
     if ((rc = cx->row_start.ensure(size_t(n_rows) * 8)) || (rc = cx->row_nt.ensure(size_t(n_rows) * 4)) || (rc = cx->row_nk.ensure(size_t(n_rows) * 4)) ||
-        (rc = cx->row_pos.ensure(size_t(n_rows) * 4)) || (rc = cx->col_off.ensure(size_t(n_rows + 1) * 8)) || (rc = cx->key_off.ensure(size_t(n_rows + 1) * 4)) ||
+        (rc = cx->row_pos.ensure(size_t(n_rows) * 4)) || (rc = cx->row_b0.ensure(size_t(n_rows) * 4)) || (rc = cx->row_blen.ensure(size_t(n_rows) * 4)) || (rc = cx->col_off.ensure(size_t(n_rows + 1) * 8)) || (rc = cx->key_off.ensure(size_t(n_rows + 1) * 4)) ||
         (rc = cx->col_pos.ensure(size_t(n_rows) * 4)) || (rc = cx->col_ref.ensure(size_t(n_rows) + 16)) ||
         (rc = cx->tiles.ensure(size_t(cdiv(std::max(n_rows, n_seg), SCAN_TILE) + 2) * 8)))
         return rc;
     RowArgs a{};
     a.text = d_text; a.len = (long long)len; a.ref = cx->ref.as<unsigned char>(); a.ref_start = ref_start; a.ref_len = (long long)ref_len;
-    a.max_indel_length = max_indel_length; a.seg_base = cx->seg_base.as<int>(); a.n_seg = n_seg;
+    a.max_indel_length = max_indel_length;
     a.row_start = cx->row_start.as<long long>(); a.row_nt = cx->row_nt.as<int>(); a.row_nk = cx->row_nk.as<int>(); a.row_pos = cx->row_pos.as<int>();
+    a.row_b0 = cx->row_b0.as<int>(); a.row_blen = cx->row_blen.as<int>();
     a.n_rows = n_rows; a.fl = fl;
-    hipLaunchKernelGGL(k_rows_count, dim3(unsigned(cdiv(n_seg, 256))), dim3(256), 0, s, a);
+    CTO_HIP(hipMemsetAsync(cx->row_nt.p, 0, size_t(n_rows) * 4, s));        // rows the pass declines leave theirs unwritten
+    CTO_HIP(hipMemsetAsync(cx->row_nk.p, 0, size_t(n_rows) * 4, s));
+    CTO_HIP(hipMemsetAsync(cx->row_pos.p, 0, size_t(n_rows) * 4, s));
+    hipLaunchKernelGGL(k_row_starts, dim3(unsigned(cdiv(n_seg, 256))), dim3(256), 0, s, d_text, (long long)len, n_seg, cx->seg_base.as<int>(),
+                       cx->row_start.as<long long>());
+    hipLaunchKernelGGL(k_rows_count, dim3(unsigned(cdiv(n_rows, 256))), dim3(256), 0, s, a);
     CTO_HIP(hipGetLastError());
     if ((rc = scan_exclusive<long long>(s, cx->row_nt.as<int>(), n_rows, cx->col_off.as<long long>(), cx->tiles.as<long long>(), &fl->n_entries))) return rc;
     if ((rc = scan_exclusive<int>(s, cx->row_nk.as<int>(), n_rows, cx->key_off.as<int>(), cx->tiles.as<int>(), &fl->n_keys))) return rc;

@@ -82,7 +82,8 @@ def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4, bam_
         t0 = time.perf_counter()
         if pipeline == "native":
             rows = run_pipeline_native(eng, chunk_args, producers=producers, writers=writers, stats=stats, verbose=False,
-                                       inflate_cus=inflate_cus, inflate_jobs=inflate_jobs, two_streams=two_streams, device_tokenise=device_tokenise)
+                                       inflate_cus=inflate_cus, inflate_jobs=inflate_jobs, two_streams=two_streams,
+                                       device_tokenise=bool(device_tokenise))
         else:
             rows = run_pipeline(eng, chunk_args, producers=producers, writers=writers, stats=stats)
         dt = time.perf_counter() - t0
@@ -120,10 +121,11 @@ def measure(eng, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, reg
             source += "; every chunk %d times per pass (%d jobs)" % (times, times * len(run["chunks"]))
         r.update(source=source, input_synthesis_s=round(prep_s, 1))
         if host_tokeniser_too and kind == "text" and pipeline == "native":
-            # the same files with the host tokeniser (cto_pack_from_mpileup on the producer threads) instead of cto_tokenise_device
-            h = time_run(eng, run, kind, os.path.join(d, "vcf_output_host_tok"), producers, writers, repeats, pipeline=pipeline, times=times,
-                         device_tokenise=False)
-            r["host_tokeniser"] = {k: h[k] for k in ("sites_per_s", "seconds", "producers", "stage_thread_time", "host_process")}
+            # the same files with the text tokenised on the device (cto_tokenise_device) instead of on the producer threads: what a rank with
+            # a few cores to itself runs (call_chunks' default there); two producers are enough to keep it fed
+            h = time_run(eng, run, kind, os.path.join(d, "vcf_output_dev_tok"), 2, writers, repeats, pipeline=pipeline, times=times,
+                         device_tokenise=True)
+            r["device_tokeniser"] = {k: h[k] for k in ("sites_per_s", "seconds", "producers", "stage_thread_time", "host_process", "device_tokenised")}
         if with_extraction and kind == "bam":
             r2 = time_run(eng, run, kind, os.path.join(d, "vcf_output_regions"), producers, writers, repeats, pipeline="native", regions=len(run["chunks"]),
                           times=times)

@@ -532,12 +532,14 @@ def test_native_pipeline_writes_the_same_files(tmp_path, source, mode, aff_cls, 
             for fn in names:
                 assert open(tmp_path / "py" / fn, "rb").read() == open(tmp_path / "nat" / fn, "rb").read(), fn
     if source == "text":
-        # the default run above built every non-empty chunk's pack on the device from the text as it is (cto_tokenise_device); the host
-        # tokeniser (device_tokenise=False) writes the same files
-        assert st_nat["device_tokenised"] >= 3
-        st_host = {}
-        assert run_pipeline_native(eng, a_nat, producers=3, writers=2, stats=st_host, verbose=False, device_tokenise=False) == n_py
-        assert st_host["device_tokenised"] == 0
+        # the text tokenised on the device (cto_tokenise_device: every non-empty chunk's pack born in HBM) and on the producer threads
+        # (cto_pack_from_mpileup): the same files
+        for flag in (True, False):
+            st_tok = {}
+            assert run_pipeline_native(eng, a_nat, producers=3, writers=2, stats=st_tok, verbose=False, device_tokenise=flag) == n_py
+            assert (st_tok["device_tokenised"] >= 3) if flag else (st_tok["device_tokenised"] == 0)
+            for fn in names:
+                assert open(tmp_path / "py" / fn, "rb").read() == open(tmp_path / "nat" / fn, "rb").read(), (flag, fn)
         for fn in names:
             assert open(tmp_path / "py" / fn, "rb").read() == open(tmp_path / "nat" / fn, "rb").read(), fn
     if source == "text":      # gzip-compressed BED and pileup text: both pipelines inflate them (gzip.open / zlib), same file again
