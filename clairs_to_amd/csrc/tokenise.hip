@@ -20,6 +20,7 @@
 // end in '\n', rows out of position order, a position outside the reference slice - sets a flag, the call returns *fallback = 1 and
 // the caller runs cto_pack_from_mpileup, which defines the behaviour (and words the errors).  Held bit-equal to it, array for array and
 // key string for key string, by tests/test_gpu_tokenise.py.
+#include <stdlib.h>
 #include <unistd.h>
 #include <algorithm>
 #include <cstring>
@@ -370,6 +371,251 @@ __device__ void fill_row(const RowArgs& a, long long cur, int row) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// A WAVEFRONT per row (CTO_TOK_WAVES=1; the lane-per-row kernels above are the default).  A row's ~250 bytes are classified 64 at a time
+// with ballots instead of one after the other:
+//   * tabs, control bytes                    -> field boundaries (exactly six tabs), declines
+//   * '^x' pairs                             -> which bytes a live '^' consumes: runs of '^' alternate live / consumed; the carry-add trick
+//                                               of simdjson's escaped-character scan resolves all runs of a 64-byte word at once
+//   * '+n<seq>' / '-n<seq>' tokens           -> every sign that is not consumed is a token (a sequence holds no sign and no '^' in samtools'
+//                                               output; a row where one does is declined): digits, n bytes masked
+//   * read-bases                             -> class < 12, not consumed, not masked: their count is a popcount, their index a prefix popcount
+// so the serial part of a row is its handful of indel tokens.  Rows longer than TOKW_CAP bytes are declined (the host's).
+// Measured on MI355X (22 MB, 140 000 rows): count 0.27 ms, fill 0.39 ms against 0.21 / 0.32 ms lane per row.  It is not the idea that is slow
+// but its granularity: a 170-byte row is 2.7 ballots' worth of bytes and every one of the ~15 ballot steps of a row is a dependent
+// LDS-read -> compare -> scalar-mask chain, ~800 wave instructions per row, where 64 rows sharing a wavefront spend ~190 each.  The form
+// that would win runs these masks over the TEXT (64 bytes of whatever rows they belong to, row boundaries as one more mask) - not built.
+constexpr int TOKW_CAP = 4096, TOKW_WAVES = 4, TOKW_TOK = 32;
+constexpr unsigned char F_CONS = 1, F_SKIP = 2;
+
+struct WaveRow {                 // what one pass over a row's base string leaves behind (wave-uniform)
+    int nt, ntok, nk;
+    long long pos;
+    int b0, b1, qs, ms, L;
+};
+
+template <bool FILL>
+__global__ __launch_bounds__(64 * TOKW_WAVES) void k_rows_wave(RowArgs a) {
+    __shared__ unsigned char s_buf[TOKW_WAVES][TOKW_CAP + 64];
+    __shared__ unsigned char s_flg[TOKW_WAVES][TOKW_CAP + 64];
+    __shared__ int s_tok[TOKW_WAVES][TOKW_TOK][6];        // sign position (relative to b0), sequence start (row offset), length, kind, carrier index, carrier code
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * TOKW_WAVES + wv;
+    if (r >= a.n_rows) return;
+    unsigned char* buf = s_buf[wv];
+    unsigned char* flg = s_flg[wv];
+    int (*tok)[6] = s_tok[wv];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const long long cur = a.row_start[r], nxt = r + 1 < a.n_rows ? a.row_start[r + 1] : a.len;
+    const int L = int(min(nxt - cur - 1, (long long)TOKW_CAP + 1));           // without the '\n'
+    auto decline = [&]() { if (lane == 0) atomicMax(&a.fl->slow, int(min(cur + 1, (long long)0x7fffffff))); };
+    if (L <= 0 || L > TOKW_CAP) { decline(); return; }
+    for (int i = lane; i < L; i += 64) buf[i] = a.text[cur + i];
+    __builtin_amdgcn_wave_barrier();
+    // ---- fields: exactly six tabs, no other byte <= 10 ----
+    int tp[6] = {0, 0, 0, 0, 0, 0}, ntab = 0;
+    bool ctrl = false;
+    for (int base = 0; base < L; base += 64) {
+        const unsigned c = base + lane < L ? buf[base + lane] : 'x';
+        unsigned long long mt = __ballot(c == '\t');
+        ctrl |= __ballot(c <= 10u && c != '\t') != 0ull;
+        while (mt) {
+            const int b = __ffsll((long long)mt) - 1;
+            if (ntab < 6) tp[ntab] = base + b;
+            ++ntab;
+            mt &= mt - 1;
+        }
+    }
+    if (ctrl || ntab != 6 || tp[0] == 0) { decline(); return; }
+    long long pos = 0;
+    {
+        const int d0 = tp[0] + 1, d1 = tp[1];
+        if (d1 == d0 || d1 - d0 > 15) { decline(); return; }
+        bool okd = true;
+        for (int i = d0; i < d1; ++i) { const unsigned d = unsigned(buf[i]) - '0'; okd &= d < 10u; pos = pos * 10 + (long long)d; }
+        if (!okd) { decline(); return; }
+    }
+    const int b0 = tp[3] + 1, b1 = tp[4], qs = b1 + 1, t6 = tp[5], ms = t6 + 1, blen = b1 - b0;
+    for (int i = lane; i < blen + 1; i += 64) flg[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    // ---- bytes consumed by a live '^' ----
+    {
+        unsigned long long prev = 0ull;
+        bool tail = false;                                     // the field's last byte is a live '^': it would consume the tab
+        for (int base = 0; base < blen; base += 64) {
+            const unsigned c = base + lane < blen ? buf[b0 + base + lane] : 0u;
+            unsigned long long bs = __ballot(c == '^');
+            bs &= ~prev;
+            const unsigned long long follows = (bs << 1) | prev, even = 0x5555555555555555ull;
+            const unsigned long long odd_starts = bs & ~even & ~follows;
+            const unsigned long long seq_even = odd_starts + bs;
+            prev = seq_even < odd_starts ? 1ull : 0ull;
+            const unsigned long long escaped = (even ^ (seq_even << 1)) & follows;
+            if ((escaped >> lane) & 1ull) flg[base + lane] |= F_CONS;
+            if (blen - base < 64) tail = ((escaped >> (blen - base)) & 1ull) != 0ull;
+            else if (base + 64 >= blen) tail = prev != 0ull;
+        }
+        if (tail) { decline(); return; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- indel tokens ----
+    int ntok = 0;
+    for (int base = 0; base < blen; base += 64) {
+        const bool in = base + lane < blen;
+        const unsigned c = in ? buf[b0 + base + lane] : 0u;
+        unsigned long long m = __ballot(in && (c == '+' || c == '-') && !(flg[base + lane] & (F_CONS | F_SKIP)));
+        while (m) {
+            const int p = base + __ffsll((long long)m) - 1;
+            m &= m - 1;
+            long long adv = 0;
+            int nd = 0;
+            while (p + 1 + nd < blen && unsigned(buf[b0 + p + 1 + nd]) - '0' < 10u && nd < 9) { adv = adv * 10 + (buf[b0 + p + 1 + nd] - '0'); ++nd; }
+            const int seq0 = p + 1 + nd;
+            if (nd == 0 || nd >= 9 || adv == 0 || seq0 + adv > blen || ntok >= TOKW_TOK) { decline(); return; }
+            bool bad = false;
+            for (int i = lane; i < int(adv); i += 64) {
+                const unsigned ch = buf[b0 + seq0 + i];
+                bad |= ch == '+' || ch == '-' || ch == '^';
+            }
+            if (__ballot(bad)) { decline(); return; }
+            for (int i = lane; i < nd + 1 + int(adv); i += 64) flg[p + i] |= F_SKIP;
+            if (lane == 0) { tok[ntok][0] = p; tok[ntok][1] = b0 + seq0; tok[ntok][2] = int(adv); tok[ntok][3] = buf[b0 + p] == '+' ? 1 : 2; }
+            ++ntok;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- read-bases: count, and the carrier of every token ----
+    int nt = 0, last_code = -1, tnext = 0;
+    for (int base = 0; base < blen; base += 64) {
+        const bool in = base + lane < blen;
+        const unsigned c = in ? buf[b0 + base + lane] : 0u;
+        const int cl = char_class(c);
+        const unsigned long long mb = __ballot(in && cl < 12 && !(flg[base + lane] & (F_CONS | F_SKIP)));
+        while (tnext < ntok && tok[tnext][0] < base + 64) {
+            const int off = tok[tnext][0] - base;
+            const unsigned long long mlow = off > 0 ? mb & ((off >= 64 ? ~0ull : (1ull << off)) - 1ull) : 0ull;
+            const int idx = nt + __popcll(mlow) - 1;
+            const int code = mlow ? char_class(buf[b0 + base + 63 - __clzll((long long)mlow)]) : last_code;
+            if (lane == 0) { tok[tnext][4] = idx; tok[tnext][5] = code; }
+            ++tnext;
+        }
+        if (mb) last_code = char_class(buf[b0 + base + 63 - __clzll((long long)mb)]);
+        nt += __popcll(mb);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (nt > kMaxDepth || t6 != qs + nt || L != ms + nt) { decline(); return; }
+    {   // quality characters: printable (phred 0 .. 94)
+        bool bad = false;
+        for (int i = lane; i < nt; i += 64) bad |= (unsigned(buf[qs + i]) - 33u > 94u) | (unsigned(buf[ms + i]) - 33u > 94u);
+        if (__ballot(bad)) { decline(); return; }
+    }
+    // a read-base annotated twice keeps its last annotation; a token in front of the first read-base is not this path's
+    int kept[TOKW_TOK], nkept = 0;
+    for (int t = 0; t < ntok; ++t) {
+        if (tok[t][4] < 0) { decline(); return; }
+        if (t + 1 < ntok && tok[t + 1][4] == tok[t][4]) continue;
+        kept[nkept++] = t;
+    }
+    // distinct keys, first seen first (wave-uniform work on a handful of tokens)
+    int kid[TOKW_TOK], nk = 0;
+    for (int x = 0; x < nkept; ++x) {
+        const int t = kept[x];
+        int found = -1;
+        for (int y = 0; y < x && found < 0; ++y) {
+            const int u = kept[y];
+            if (tok[u][2] != tok[t][2] || tok[u][3] != tok[t][3] || tok[u][5] != tok[t][5]) continue;
+            bool eq = true;
+            for (int k = 0; k < tok[t][2] && eq; ++k) eq = buf[tok[u][1] + k] == buf[tok[t][1] + k];
+            if (eq) found = kid[y];
+        }
+        kid[x] = found >= 0 ? found : nk++;
+    }
+    const long long ri = pos - a.ref_start;
+    if constexpr (!FILL) {
+        if (lane == 0) {
+            a.row_nt[r] = nt;
+            a.row_nk[r] = nk;
+            a.row_pos[r] = int(min(pos, (long long)0x7fffffff));
+            if (ri < 0 || ri >= a.ref_len || pos > 0x7fffffffLL) atomicMax(&a.fl->oob, 1);
+        }
+        return;
+    } else {
+        const long long e0 = a.col_off[r];
+        const int k0 = a.key_off[r];
+        if (lane == 0) {
+            if (r > 0 && a.row_pos[r] <= a.row_pos[r - 1]) atomicMax(&a.fl->bad_order, 1);
+            const unsigned char rb = a.ref[ri];
+            const unsigned char ru = up_c(rb);
+            a.col_pos[r] = int(pos);
+            a.col_ref[r] = static_cast<unsigned char>(ref_code_dev(rb) | ((ru == 'A' || ru == 'C' || ru == 'G' || ru == 'T') ? 0 : 0x80));
+        }
+        // entries: every read-base lane writes its own (index = prefix popcount), indel bits looked up in the kept tokens
+        int n0 = 0;
+        for (int base = 0; base < blen; base += 64) {
+            const bool in = base + lane < blen;
+            const unsigned c = in ? buf[b0 + base + lane] : 0u;
+            const int cl = char_class(c);
+            const bool isb = in && cl < 12 && !(flg[base + lane] & (F_CONS | F_SKIP));
+            const unsigned long long mb = __ballot(isb);
+            if (isb) {
+                const int idx = n0 + __popcll(mb & below);
+                unsigned e = unsigned(cl) | ((unsigned(buf[qs + idx]) - 33u) << 6) | ((unsigned(buf[ms + idx]) - 33u) << 13);
+                for (int x = 0; x < nkept; ++x) {
+                    const int t = kept[x];
+                    if (tok[t][4] == idx) {
+                        const int tk = tok[t][3];
+                        const int gate = tk == 1 ? tok[t][2] : tok[t][2] + 1;
+                        e |= unsigned(gate > a.max_indel_length ? 3 : tk) << 4;
+                        e |= unsigned(kid[x]) << 21;
+                    }
+                }
+                a.entries[e0 + idx] = e;
+            }
+            n0 += __popcll(mb);
+        }
+        // the row's distinct keys (first occurrences): meta, merged group, string length, where k_key_strings finds the sequence
+        int grp[TOKW_TOK], ng = 0;
+        for (int x = 0; x < nkept; ++x) {
+            bool first = true;
+            for (int y = 0; y < x; ++y) if (kid[y] == kid[x]) { first = false; break; }
+            if (!first) continue;
+            const int t = kept[x];
+            const int tk = tok[t][3], code = tok[t][5], sl = tok[t][2];
+            const int gate = tk == 1 ? sl : sl + 1;
+            const bool overlong = gate > a.max_indel_length;
+            const bool fwd = code < 4 || code == 8 || code == 10;
+            const unsigned char anchors[12] = {'A', 'C', 'G', 'T', 'A', 'C', 'G', 'T', '*', '#', 'N', 'N'};
+            const unsigned char anchor = tk == 1 ? anchors[code] : static_cast<unsigned char>('D');
+            int g = -1;
+            for (int y = 0; y < x && g < 0; ++y) {
+                bool yfirst = true;
+                for (int z = 0; z < y; ++z) if (kid[z] == kid[y]) { yfirst = false; break; }
+                if (!yfirst) continue;
+                const int u = kept[y];
+                if (tok[u][3] != tk || tok[u][2] != sl) continue;
+                if (tk == 2) { g = grp[y]; break; }
+                if (anchors[tok[u][5]] != anchor) continue;
+                bool eq = true;
+                for (int k = 0; k < sl && eq; ++k) eq = up_c(buf[tok[u][1] + k]) == up_c(buf[tok[t][1] + k]);
+                if (eq) g = grp[y];
+            }
+            if (g < 0) g = ng++;
+            grp[x] = g;
+            if (lane == 0) {
+                const int k = k0 + kid[x];
+                a.key_meta[k] = static_cast<unsigned char>(tk | (fwd ? 4 : 0) | (overlong ? 8 : 0));
+                a.key_group[k] = g;
+                long long take = min((long long)(sl + 1), (long long)a.max_indel_length);
+                take = min(take, a.ref_len - ri);
+                a.key_len[k] = tk == 1 ? 2 + sl : 1 + int(take);
+                a.key_seq[k] = tk == 1 ? cur + tok[t][1] : ri;
+                a.key_info[k] = (sl << 8) | (code << 4) | tk;
+            }
+        }
+    }
+}
+
 // zero-byte detector on eight bytes at once: bit 7 of every byte of the result that was '\n' in x
 __device__ __forceinline__ unsigned long long newline_mask(unsigned long long x) {
     const unsigned long long y = x ^ 0x0a0a0a0a0a0a0a0aull, m = 0x7f7f7f7f7f7f7f7full;
@@ -554,7 +800,13 @@ extern "C" int cto_tokenise_device(cto_dev_tokeniser* cx, const char* text, size
     CTO_HIP(hipMemsetAsync(cx->row_pos.p, 0, size_t(n_rows) * 4, s));
     hipLaunchKernelGGL(k_row_starts, dim3(unsigned(cdiv(n_seg, 256))), dim3(256), 0, s, d_text, (long long)len, n_seg, cx->seg_base.as<int>(),
                        cx->row_start.as<long long>());
-    hipLaunchKernelGGL(k_rows_count, dim3(unsigned(cdiv(n_rows, 256))), dim3(256), 0, s, a);
+    // a lane per row (the default: 64 rows share a wavefront's instruction stream, ~190 instructions per row); CTO_TOK_WAVES=1: a wavefront
+    // per row (ballots over 64 bytes at a time: ~800 instructions per row - measured slower, 0.67 against 0.52 ms for the two passes - kept as the
+    // second statement of the pass the tests hold the first one to)
+    const char* tw = getenv("CTO_TOK_WAVES");
+    const bool by_lanes = !(tw && tw[0] == '1');
+    if (by_lanes) hipLaunchKernelGGL(k_rows_count, dim3(unsigned(cdiv(n_rows, 256))), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_rows_wave<false>, dim3(unsigned(cdiv(n_rows, TOKW_WAVES))), dim3(64 * TOKW_WAVES), 0, s, a);
     CTO_HIP(hipGetLastError());
     if ((rc = scan_exclusive<long long>(s, cx->row_nt.as<int>(), n_rows, cx->col_off.as<long long>(), cx->tiles.as<long long>(), &fl->n_entries))) return rc;
     if ((rc = scan_exclusive<int>(s, cx->row_nk.as<int>(), n_rows, cx->key_off.as<int>(), cx->tiles.as<int>(), &fl->n_keys))) return rc;
@@ -570,7 +822,8 @@ extern "C" int cto_tokenise_device(cto_dev_tokeniser* cx, const char* text, size
     a.col_off = cx->col_off.as<long long>(); a.key_off = cx->key_off.as<int>(); a.entries = cx->entries.as<unsigned>(); a.col_pos = cx->col_pos.as<int>();
     a.col_ref = cx->col_ref.as<unsigned char>(); a.key_meta = cx->key_meta.as<unsigned char>(); a.key_group = cx->key_group.as<int>();
     a.key_len = cx->key_len.as<int>(); a.key_seq = cx->key_seq.as<long long>(); a.key_info = cx->key_info.as<int>();
-    hipLaunchKernelGGL(k_rows_fill, dim3(unsigned(cdiv(n_rows, 256))), dim3(256), 0, s, a);
+    if (by_lanes) hipLaunchKernelGGL(k_rows_fill, dim3(unsigned(cdiv(n_rows, 256))), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_rows_wave<true>, dim3(unsigned(cdiv(n_rows, TOKW_WAVES))), dim3(64 * TOKW_WAVES), 0, s, a);
     CTO_HIP(hipGetLastError());
     if ((rc = scan_exclusive<long long>(s, cx->key_len.as<int>(), n_keys, cx->str_off.as<long long>(), cx->tiles.as<long long>(), &fl->key_str_bytes))) return rc;
     if ((rc = fetch_flags())) return rc;

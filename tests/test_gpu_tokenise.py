@@ -10,6 +10,16 @@ from conftest import load_json_gz
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["lanes", "waves"])
+def tokeniser_form(request, monkeypatch):
+    """every test runs on both forms of the row kernels: a lane per row (default) and a wavefront per row (CTO_TOK_WAVES=1)"""
+    if request.param == "waves":
+        monkeypatch.setenv("CTO_TOK_WAVES", "1")
+    else:
+        monkeypatch.delenv("CTO_TOK_WAVES", raising=False)
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def dev():
     import torch
