@@ -190,140 +190,170 @@ __device__ long long g_sw_prof[8];
 
 constexpr int kBias = 6, kGapO = 8, kGapE = 2;
 
-// query profile in striped order: entry (j, l) = code of query position l * seg + j, 7 = padding (scores 0 against everything).
+// LDS of a row, lane-private and contiguous: lane l owns stripe positions j = 0 .. seg-1 at [l * SP + j] of every array (SP = the
+// launch's largest seg rounded up to 16 positions, an odd multiple of 8 so that the lanes' 16-byte reads fall on different banks):
+//   prof [5][LW][SP] signed bytes   the query profile of SSW (ssw.c:64-116): score of reference code c against the lane's positions
+//                                   (4 / -6, 0 on padding), so a column reads 8 scores with one ds_read_b64 and compares nothing
+//   H0, H1, E [LW][SP] shorts       the two H columns and E; 8 positions = one ds_read_b128
+// A lane never touches another lane's entries: lanes meet in DPP shifts and row reductions only, and there is no barrier inside a pass.
+__host__ __device__ inline int sw_sp(int segcap) { int sp = (segcap + 15) / 16 * 16; if (((sp / 8) & 1) == 0) sp += 8; return sp; }
+__host__ __device__ inline size_t sw_row_bytes(int Rcap, int Qcap, int segcap, int LW) {
+    return size_t(Rcap) + Qcap + size_t(sw_sp(segcap)) * LW * (5 + 3 * sizeof(short));
+}
+
 // `rev_from` >= 0: the query is qraw[rev_from], qraw[rev_from - 1], ... (the reversed prefix of the backward pass)
 template <int LW>
-__device__ __forceinline__ void build_profile(unsigned char* qprof, const signed char* qraw, int Q, int seg, int l, int rev_from) {
-    for (int j = 0; j < seg; ++j) {
+__device__ __forceinline__ void build_profile(signed char* prof, const signed char* qraw, int Q, int seg, int SP, int l, int rev_from) {
+    for (int j = 0; j < SP; ++j) {
         const int q = l * seg + j;
-        unsigned char c = 7;
-        if (q < Q) c = static_cast<unsigned char>(rev_from >= 0 ? qraw[rev_from - q] : qraw[q]);
-        qprof[j * LW + l] = c;
+        const int c = (j < seg && q < Q) ? int(rev_from >= 0 ? qraw[rev_from - q] : qraw[q]) : 7;
+#pragma unroll
+        for (int rc = 0; rc < 5; ++rc) prof[(rc * LW + l) * SP + j] = static_cast<signed char>(c == 7 ? 0 : ((c == rc && rc < 4) ? 4 : -6));
     }
 }
 
-// One column of LDS traffic at a time would leave a wavefront waiting out an LDS round trip per stripe position (and, in the lazy-F
-// loops, per exit test): every loop below works in chunks of CH stripe positions - CH reads in flight, the dependent arithmetic on
-// registers, the writes behind it.  The lazy-F loops evaluate a chunk's exit tests speculatively (ballots are cheap) and apply the
-// corrections up to the first test that ends the loop, which is exactly the set the one-at-a-time loop would have applied.
+// packed pairs of 16-bit values (all values here are 0 .. 32767, so signed and unsigned order agree): SSE2's own operations
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_subs(unsigned a, unsigned b) {      // _mm_subs_epu16
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, a), __builtin_bit_cast(i16x2, b)));
+}
+__device__ __forceinline__ unsigned pk_min(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ unsigned pk_neg(unsigned a) {                    // 0 - a per half, wrapping: 1 -> 0xffff
+    return __builtin_bit_cast(unsigned, u16x2{0, 0} - __builtin_bit_cast(u16x2, a));
+}
+__device__ __forceinline__ unsigned pk2(int lo, int hi) { return (unsigned(lo) & 0xffffu) | (unsigned(hi) << 16); }
+// the two halves of a pair as bits 0 and 1: non-zero -> 1
+__device__ __forceinline__ unsigned pk_nz_bits(unsigned w) { const unsigned t = pk_min(w, 0x00010001u); return (t | (t >> 15)) & 3u; }
+
+// A pass works in trips: 8 stripe positions of the main loop (the F chain is serial: h and f of a position need those of the one before),
+// 16 of the lazy-F loops - whose carried F only decays inside a trip (f - 2c, clamped), so a position's corrected value depends on
+// nothing but that and what is stored there: all sixteen exit tests are evaluated at once on pairs (v_pk_*), OR-ed over the row, and the
+// loop ends at the first position whose bit is clear - the corrections up to there are exactly those of the one-at-a-time loop.
 template <bool BYTE>
-__device__ RowPass row_pass(const signed char* refc, int r_begin, int r_end, int r_step, const unsigned char* qprof, int Q, int seg,
-                            short* H0, short* H1, short* E, int terminate, int l, int rowbase) {
-    constexpr int LW = BYTE ? 16 : 8, CH = 8;
-    for (int j = 0; j < seg; ++j) { H0[j * LW + l] = 0; H1[j * LW + l] = 0; E[j * LW + l] = 0; }
+__device__ RowPass row_pass(const signed char* refc, int r_begin, int r_end, int r_step, const signed char* prof, int Q, int seg, int SP,
+                            short* H0, short* H1, short* E, int terminate, int l) {
+    constexpr int LW = BYTE ? 16 : 8;
+    const int lb = l * SP;
+    {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        for (int j = 0; j < SP; j += 8) {
+            *reinterpret_cast<uint4*>(H0 + lb + j) = z; *reinterpret_cast<uint4*>(H1 + lb + j) = z; *reinterpret_cast<uint4*>(E + lb + j) = z;
+        }
+    }
     short* store = H0;
     short* load = H1;
     int best = 0, ref_end = BYTE ? -1 : 0, best_q = 0x7fffffff;
     bool overflow = false;
-    (void)rowbase;
     int rc = r_begin != r_end ? refc[r_begin] : 0;
     for (int i = r_begin; i != r_end; i += r_step) {
         const int rc_next = i + r_step != r_end ? refc[i + r_step] : 0;       // one column ahead of its use
         int f = 0, colmax = 0;
-        SW_T(t0); SW_INC(3);
-        int h = row_shl1<LW>(int(store[(seg - 1) * LW + l]), l);
+        int h = row_shl1<LW>(int(store[lb + seg - 1]), l);
         { short* t = store; store = load; load = t; }          // load = column i - 1 (final), store = column i
-        for (int j0 = 0; j0 < seg; j0 += CH) {
-            int ev[CH], hv[CH], qv[CH];
+        const signed char* pr = prof + ((unsigned(rc) < 4u ? rc : 4) * LW + l) * SP;      // plane 4: matches nothing
+        for (int j0 = 0; j0 < seg; j0 += 8) {
+            const uint4 e8 = *reinterpret_cast<const uint4*>(E + lb + j0);
+            const uint4 h8 = *reinterpret_cast<const uint4*>(load + lb + j0);
+            const uint2 p8 = *reinterpret_cast<const uint2*>(pr + j0);
+            const unsigned ew[4] = {e8.x, e8.y, e8.z, e8.w}, hw[4] = {h8.x, h8.y, h8.z, h8.w}, pw[2] = {p8.x, p8.y};
+            unsigned sw[4] = {0u, 0u, 0u, 0u}, nw[4] = {ew[0], ew[1], ew[2], ew[3]};
 #pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                const int j = min(j0 + c, seg - 1);
-                ev[c] = E[j * LW + l]; hv[c] = load[j * LW + l]; qv[c] = qprof[j * LW + l];
-            }
-#pragma unroll
-            for (int c = 0; c < CH; ++c) {
+            for (int c = 0; c < 8; ++c) {
                 if (j0 + c < seg) {
-                    const int j = j0 + c, e = ev[c], qc = qv[c];
-                    const int sc = qc == 7 ? 0 : ((qc == rc && rc < 4) ? 4 : -6);
+                    const int e = int((ew[c >> 1] >> (16 * (c & 1))) & 0xffffu);
+                    const int sc = int(pw[c >> 2] << (24 - 8 * (c & 3))) >> 24;      // signed byte c
                     if (BYTE) h = max(min(h + sc + kBias, 255) - kBias, 0);
                     else h = min(h + sc, 32767);
                     h = max(h, max(e, f));
                     colmax = max(colmax, h);
-                    store[j * LW + l] = short(h);
                     const int h2 = max(h - kGapO, 0);
-                    E[j * LW + l] = short(max(max(e - kGapE, 0), h2));            // E never sees the lazy-F corrections below
+                    const int en = max(max(e - kGapE, 0), h2);            // E never sees the lazy-F corrections below
                     f = max(max(f - kGapE, 0), h2);
-                    h = hv[c];
+                    if (c & 1) { sw[c >> 1] |= unsigned(h) << 16; nw[c >> 1] = (nw[c >> 1] & 0xffffu) | (unsigned(en) << 16); }
+                    else { sw[c >> 1] = unsigned(h) & 0xffffu; nw[c >> 1] = (nw[c >> 1] & 0xffff0000u) | unsigned(en); }
+                    h = int((hw[c >> 1] >> (16 * (c & 1))) & 0xffffu);
                 }
             }
+            *reinterpret_cast<uint4*>(store + lb + j0) = make_uint4(sw[0], sw[1], sw[2], sw[3]);
+            *reinterpret_cast<uint4*>(E + lb + j0) = make_uint4(nw[0], nw[1], nw[2], nw[3]);
         }
-        SW_T(t1); SW_ADD(0, t0, t1);
-        // The lazy-F loops, a chunk of CH stripe positions per trip.  Inside a chunk the carried F only decays (f - 2c, clamped at 0)
-        // and a position's corrected value depends on nothing but that and what is stored there, so every position's exit test can be
-        // evaluated at once: bit c of `want` = "this lane's test at position c says go on", OR-ed over the row; the loop ends at the
-        // first position whose bit is clear - the corrections up to there are exactly those of the one-position-at-a-time loop.
+        unsigned cm2 = 0u;                                     // column maximum of the corrections, as a pair
+        // one trip of 16 positions from j0: TEST_FIRST (8-bit loop: a position is corrected when its own test says go on) or
+        // correct-then-test (16-bit loop: the position whose test ends the loop is still corrected).  Returns false when the loop ends.
+        auto trip = [&](int j0, auto test_first) -> bool {
+            constexpr bool TF = decltype(test_first)::value;
+            const int nv = min(16, seg - j0);
+            const uint4 a8 = *reinterpret_cast<const uint4*>(store + lb + j0);
+            const uint4 b8 = *reinterpret_cast<const uint4*>(store + lb + j0 + 8);
+            const unsigned sv[8] = {a8.x, a8.y, a8.z, a8.w, b8.x, b8.y, b8.z, b8.w};
+            const unsigned ff = pk2(f, f);
+            unsigned hh[8], want = 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned fc = pk_subs(ff, pk2(kGapE * 2 * k, kGapE * (2 * k + 1)));
+                hh[k] = pk_max(sv[k], fc);
+                unsigned w;
+                if (TF) w = pk_subs(fc, pk_subs(sv[k], pk2(kGapO, kGapO)));                              // f > max(stored - gap_o, 0)
+                else w = pk_subs(pk_subs(fc, pk2(kGapE, kGapE)), pk_subs(hh[k], pk2(kGapO, kGapO)));     // f - gap_e > max(corrected - gap_o, 0)
+                want |= pk_nz_bits(w) << (2 * k);
+            }
+            want = row_or<LW>(want);
+            const unsigned ends = ~want & ((1u << nv) - 1u);
+            const int stop = ends ? __ffs(int(ends)) - 1 : nv;
+            const int ncorr = TF ? stop : (ends ? stop + 1 : nv);           // positions [0, ncorr) are corrected
+            const unsigned nn = pk2(ncorr, ncorr);
+            unsigned out[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned m = pk_neg(pk_min(pk_subs(nn, pk2(2 * k, 2 * k + 1)), 0x00010001u));      // 0xffff where position < ncorr
+                out[k] = (hh[k] & m) | (sv[k] & ~m);
+                cm2 = pk_max(cm2, out[k] & m);
+            }
+            *reinterpret_cast<uint4*>(store + lb + j0) = make_uint4(out[0], out[1], out[2], out[3]);
+            if (nv > 8) *reinterpret_cast<uint4*>(store + lb + j0 + 8) = make_uint4(out[4], out[5], out[6], out[7]);
+            f = max(f - kGapE * ncorr, 0);
+            return ends == 0u;
+        };
         if (BYTE) {               // ssw.c:207-241: test, then correct; the chain wraps around the stripes
             f = row_shl1<LW>(f, l);
             int j0 = 0;
-            for (bool go = true; go;) {
-                const int nv = min(CH, seg - j0);
-                int sv[CH];
-#pragma unroll
-                for (int c = 0; c < CH; ++c) sv[c] = store[min(j0 + c, seg - 1) * LW + l];
-                unsigned want = 0;
-#pragma unroll
-                for (int c = 0; c < CH; ++c) want |= (max(f - kGapE * c, 0) > max(sv[c] - kGapO, 0) ? 1u : 0u) << c;
-                want = row_or<LW>(want);
-                const unsigned ends = ~want & ((1u << nv) - 1u);
-                const int ncorr = ends ? __ffs(int(ends)) - 1 : nv;      // positions [0, ncorr) are corrected
-#pragma unroll
-                for (int c = 0; c < CH; ++c) {
-                    const int hh = c < ncorr ? max(sv[c], max(f - kGapE * c, 0)) : sv[c];
-                    colmax = max(colmax, hh);
-                    if (c < nv) store[(j0 + c) * LW + l] = short(hh);
-                }
-                f = max(f - kGapE * ncorr, 0);
-                if (ends) go = false;
-                else { j0 += nv; if (j0 >= seg) { j0 = 0; f = row_shl1<LW>(f, l); } }
+            while (trip(j0, std::true_type{})) {
+                j0 += 16;
+                if (j0 >= seg) { j0 = 0; f = row_shl1<LW>(f, l); }
             }
         } else {                  // ssw.c:446-459: correct, then test; at most `lanes` rounds
-            bool done = false;
-            for (int k = 0; k < LW && !done; ++k) {
+            bool go = true;
+            for (int k = 0; k < LW && go; ++k) {
                 f = row_shl1<LW>(f, l);
-                for (int j0 = 0; j0 < seg && !done; j0 += CH) {
-                    SW_INC(4);
-                    const int nv = min(CH, seg - j0);
-                    int sv[CH];
-#pragma unroll
-                    for (int c = 0; c < CH; ++c) sv[c] = store[min(j0 + c, seg - 1) * LW + l];
-                    unsigned want = 0;
-#pragma unroll
-                    for (int c = 0; c < CH; ++c) {
-                        const int hh = max(sv[c], max(f - kGapE * c, 0));
-                        want |= (max(f - kGapE * (c + 1), 0) > max(hh - kGapO, 0) ? 1u : 0u) << c;
-                    }
-                    want = row_or<LW>(want);
-                    const unsigned ends = ~want & ((1u << nv) - 1u);
-                    const int ncorr = ends ? __ffs(int(ends)) : nv;       // positions [0, ncorr) are corrected (the ending one included)
-#pragma unroll
-                    for (int c = 0; c < CH; ++c) {
-                        const int hh = c < ncorr ? max(sv[c], max(f - kGapE * c, 0)) : sv[c];
-                        colmax = max(colmax, hh);
-                        if (c < nv) store[(j0 + c) * LW + l] = short(hh);
-                    }
-                    f = max(f - kGapE * ncorr, 0);
-                    if (ends) done = true;
-                }
+                for (int j0 = 0; j0 < seg && go; j0 += 16) go = trip(j0, std::false_type{});
             }
         }
-        SW_T(t2); SW_ADD(1, t1, t2);
+        colmax = max(colmax, max(int(cm2 & 0xffffu), int(cm2 >> 16)));
         colmax = row_max<LW>(colmax);
         if (colmax > best) {
             best = colmax;
             if (BYTE && best + kBias >= 255) { overflow = true; break; }
             ref_end = i;
             int mq = 0x7fffffff;            // smallest linear query position that holds the new maximum
-            for (int j0 = 0; j0 < seg && mq == 0x7fffffff; j0 += CH) {
-                int sv[CH];
+            const unsigned bb = pk2(best, best);
+            for (int j0 = 0; j0 < seg && mq == 0x7fffffff; j0 += 8) {
+                const uint4 a8 = *reinterpret_cast<const uint4*>(store + lb + j0);
+                const unsigned sv[4] = {a8.x, a8.y, a8.z, a8.w};
 #pragma unroll
-                for (int c = 0; c < CH; ++c) sv[c] = store[min(j0 + c, seg - 1) * LW + l];
-#pragma unroll
-                for (int c = CH - 1; c >= 0; --c)
-                    if (j0 + c < seg && sv[c] == best) mq = l * seg + j0 + c;
+                for (int k = 3; k >= 0; --k) {
+                    const unsigned x = sv[k] ^ bb;
+                    if (j0 + 2 * k + 1 < seg && (x >> 16) == 0u) mq = l * seg + j0 + 2 * k + 1;
+                    if (j0 + 2 * k < seg && (x & 0xffffu) == 0u) mq = l * seg + j0 + 2 * k;
+                }
             }
             best_q = row_min<LW>(mq);
         }
-        SW_T(t3); SW_ADD(2, t2, t3);
         if (colmax == terminate) break;
         rc = rc_next;
     }
@@ -333,28 +363,24 @@ __device__ RowPass row_pass(const signed char* refc, int r_begin, int r_end, int
     return RowPass{overflow ? 255 : best, ref_end, read_end, overflow};
 }
 
-// LDS of one row: reference codes, query codes, striped profile, H (two columns) and E
-__host__ __device__ inline size_t sw_row_bytes(int Rcap, int Qcap, int segcap, int LW) {
-    return size_t(Rcap) + Qcap + size_t(segcap) * LW + size_t(3) * segcap * LW * sizeof(short);
-}
-
 template <bool BYTE>
 __global__ __launch_bounds__(64) void k_sw(const signed char* pool, const SwDesc* desc, const int* order, int n, Ends* out,
                                              unsigned char* overflowed, int Rcap, int Qcap, int segcap) {
     constexpr int LW = BYTE ? 16 : 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int row = threadIdx.x / LW, l = threadIdx.x % LW;
-    const int slot = blockIdx.x * (blockDim.x / LW) + row;         // 1, 2, 4 (, 8) rows per wavefront: launch_sw decides
+    const int slot = blockIdx.x * (blockDim.x / LW) + row;
     bool live = slot < n;
     const int k = live ? order[slot] : 0;
     if (!BYTE && live && !overflowed[k]) live = false;        // the 16-bit kernel takes only what the 8-bit pass gave up on
-    unsigned char* base = lds + size_t(row) * sw_row_bytes(Rcap, Qcap, segcap, LW);
-    signed char* refc = reinterpret_cast<signed char*>(base);
+    const int SP = sw_sp(segcap);
+    unsigned char* base = lds + size_t(row) * ((sw_row_bytes(Rcap, Qcap, segcap, LW) + 15) / 16 * 16);
+    short* H0 = reinterpret_cast<short*>(base);
+    short* H1 = H0 + size_t(SP) * LW;
+    short* E = H1 + size_t(SP) * LW;
+    signed char* prof = reinterpret_cast<signed char*>(E + size_t(SP) * LW);
+    signed char* refc = prof + size_t(5) * SP * LW;
     signed char* qraw = refc + Rcap;
-    unsigned char* qprof = reinterpret_cast<unsigned char*>(qraw + Qcap);
-    short* H0 = reinterpret_cast<short*>(qprof + size_t(segcap) * LW);
-    short* H1 = H0 + size_t(segcap) * LW;
-    short* E = H1 + size_t(segcap) * LW;
     const SwDesc d = live ? desc[k] : SwDesc{0, 0, 0, 0};
     for (int i = l; i < d.R; i += LW) refc[i] = pool[d.ref_off + i];
     for (int i = l; i < d.Q; i += LW) qraw[i] = pool[d.q_off + i];
@@ -363,15 +389,14 @@ __global__ __launch_bounds__(64) void k_sw(const signed char* pool, const SwDesc
     Ends e{0, 0, 0, 0, 0, 16};
     bool ovf = false;
     if (d.R > 0 && d.Q > 0) {
-        const int rowbase = threadIdx.x - l;
         const int seg = (d.Q + LW - 1) / LW;
-        build_profile<LW>(qprof, qraw, d.Q, seg, l, -1);
-        const RowPass fw = row_pass<BYTE>(refc, 0, d.R, 1, qprof, d.Q, seg, H0, H1, E, BYTE ? 255 : 65535, l, rowbase);
+        build_profile<LW>(prof, qraw, d.Q, seg, SP, l, -1);
+        const RowPass fw = row_pass<BYTE>(refc, 0, d.R, 1, prof, d.Q, seg, SP, H0, H1, E, BYTE ? 255 : 65535, l);
         if (BYTE && fw.overflow) ovf = true;
         else if (fw.score > 0) {
             const int Q2 = fw.read_end + 1, seg2 = (Q2 + LW - 1) / LW;
-            build_profile<LW>(qprof, qraw, Q2, seg2, l, fw.read_end);
-            const RowPass bw = row_pass<BYTE>(refc, fw.ref_end, -1, -1, qprof, Q2, seg2, H0, H1, E, fw.score, l, rowbase);
+            build_profile<LW>(prof, qraw, Q2, seg2, SP, l, fw.read_end);
+            const RowPass bw = row_pass<BYTE>(refc, fw.ref_end, -1, -1, prof, Q2, seg2, SP, H0, H1, E, fw.score, l);
             e = Ends{fw.score, fw.ref_end, fw.read_end, bw.ref_end, bw.read_end, LW};
         }
     }
@@ -487,7 +512,7 @@ int launch_sw(hipStream_t s, const signed char* pool, const SwDesc* desc, const 
     const int ROWS = 64 / LW;
     Rcap = (Rcap + 15) & ~15; Qcap = (Qcap + 15) & ~15;
     const int segcap = (Qcap + LW - 1) / LW;
-    const size_t smem = sw_row_bytes(Rcap, Qcap, segcap, LW) * ROWS;
+    const size_t smem = ((sw_row_bytes(Rcap, Qcap, segcap, LW) + 15) / 16 * 16) * ROWS;
     CTO_REQUIRE(smem <= size_t(160) * 1024, CTO_EUNSUPPORTED, "cto_realign_windows: an alignment of %d x %d does not fit the LDS", Rcap, Qcap);
     CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sw<BYTE>), hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
     hipLaunchKernelGGL((k_sw<BYTE>), dim3(unsigned((n + ROWS - 1) / ROWS)), dim3(unsigned(LW * ROWS)), smem, s, pool, desc, order, n, out, overflowed, Rcap, Qcap, segcap);
