@@ -231,10 +231,26 @@ __device__ __forceinline__ unsigned pk2(int lo, int hi) { return (unsigned(lo) &
 // the two halves of a pair as bits 0 and 1: non-zero -> 1
 __device__ __forceinline__ unsigned pk_nz_bits(unsigned w) { const unsigned t = pk_min(w, 0x00010001u); return (t | (t >> 15)) & 3u; }
 
-// A pass works in trips: 8 stripe positions of the main loop (the F chain is serial: h and f of a position need those of the one before),
-// 16 of the lazy-F loops - whose carried F only decays inside a trip (f - 2c, clamped), so a position's corrected value depends on
-// nothing but that and what is stored there: all sixteen exit tests are evaluated at once on pairs (v_pk_*), OR-ed over the row, and the
-// loop ends at the first position whose bit is clear - the corrections up to there are exactly those of the one-at-a-time loop.
+// lane l takes lane l - S of its row, the first S lanes take 0
+template <int LW, int S>
+__device__ __forceinline__ int row_shl(int v, int l) {
+    v = dpp_i<0x110 + S>(v);                         // row_shr:S, out-of-row lanes read 0
+    if (LW == 8 && l < S) v = 0;
+    return v;
+}
+
+// The lazy-F step of a column.  The reference's two loops (ssw.c:207-241 for bytes: test, then correct, wrapping around the stripes;
+// :446-459 for words: correct, then test, at most `lanes` rounds) carry the F that leaves lane l - 1's stripe into lane l's, sweep
+// after sweep, and stop at the first position where no lane's carried F can matter any more.  Run to the end they compute
+//     Fin[l]  = max over k >= 1 of ( F_out[l - k] - ext * seg * (k - 1) )          (a max-plus scan over the lanes, saturating at 0)
+//     H[l][j] = max( H[l][j], Fin[l] - ext * j )
+// and their exits are pure shortcuts: when a loop stops, every lane's carried F is 0 or lies gap_open below an H that a stronger
+// chain (the main pass, or an earlier sweep - already applied) put there, so everything not yet applied changes nothing
+// (oracle/ssw_model.cpp states both forms; tests/test_realign.py::test_lazy_f_closed_form_equals_the_loops holds them equal column by
+// column).  So a column costs ONE pass over the stripe: the scan is log2(lanes) DPP steps on the outgoing F, and the sweep is not done
+// at all - the column stays in LDS as the main loop wrote it and its Fin stays in a register: the next column corrects H as it loads
+// it (two packed instructions per pair of positions), the column maximum is max(main-loop maximum, Fin) since the correction is
+// largest at j = 0, and the search for the best cell corrects on the fly as well.  E never sees the corrections, as in the reference.
 template <bool BYTE>
 __device__ RowPass row_pass(const signed char* refc, int r_begin, int r_end, int r_step, const signed char* prof, int Q, int seg, int SP,
                             short* H0, short* H1, short* E, int terminate, int l) {
@@ -250,22 +266,31 @@ __device__ RowPass row_pass(const signed char* refc, int r_begin, int r_end, int
     short* load = H1;
     int best = 0, ref_end = BYTE ? -1 : 0, best_q = 0x7fffffff;
     bool overflow = false;
+    int fin = 0;                                     // Fin of the column in `store` (the last one written)
+    const int D = kGapE * seg;
     int rc = r_begin != r_end ? refc[r_begin] : 0;
     for (int i = r_begin; i != r_end; i += r_step) {
         const int rc_next = i + r_step != r_end ? refc[i + r_step] : 0;       // one column ahead of its use
         int f = 0, colmax = 0;
-        int h = row_shl1<LW>(int(store[lb + seg - 1]), l);
-        { short* t = store; store = load; load = t; }          // load = column i - 1 (final), store = column i
+        int h = row_shl1<LW>(max(int(store[lb + seg - 1]), max(fin - kGapE * (seg - 1), 0)), l);
+        { short* t = store; store = load; load = t; }          // load = column i - 1 (as its main loop left it; `fin` completes it), store = column i
         const signed char* pr = prof + ((unsigned(rc) < 4u ? rc : 4) * LW + l) * SP;      // plane 4: matches nothing
-        for (int j0 = 0; j0 < seg; j0 += 8) {
+        int fg = fin;                                          // Fin - ext * j0
+        auto group = [&](int j0, auto is_tail) {
+            constexpr bool TAIL = decltype(is_tail)::value;
             const uint4 e8 = *reinterpret_cast<const uint4*>(E + lb + j0);
             const uint4 h8 = *reinterpret_cast<const uint4*>(load + lb + j0);
             const uint2 p8 = *reinterpret_cast<const uint2*>(pr + j0);
-            const unsigned ew[4] = {e8.x, e8.y, e8.z, e8.w}, hw[4] = {h8.x, h8.y, h8.z, h8.w}, pw[2] = {p8.x, p8.y};
+            const unsigned ew[4] = {e8.x, e8.y, e8.z, e8.w}, pw[2] = {p8.x, p8.y};
+            const unsigned fg2 = pk2(fg, fg);
+            unsigned hw[4] = {h8.x, h8.y, h8.z, h8.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hw[k] = pk_max(hw[k], pk_subs(fg2, pk2(kGapE * 2 * k, kGapE * (2 * k + 1))));
+            fg = max(fg - kGapE * 8, 0);
             unsigned sw[4] = {0u, 0u, 0u, 0u}, nw[4] = {ew[0], ew[1], ew[2], ew[3]};
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                if (j0 + c < seg) {
+                if (!TAIL || j0 + c < seg) {
                     const int e = int((ew[c >> 1] >> (16 * (c & 1))) & 0xffffu);
                     const int sc = int(pw[c >> 2] << (24 - 8 * (c & 3))) >> 24;      // signed byte c
                     if (BYTE) h = max(min(h + sc + kBias, 255) - kBias, 0);
@@ -273,8 +298,8 @@ __device__ RowPass row_pass(const signed char* refc, int r_begin, int r_end, int
                     h = max(h, max(e, f));
                     colmax = max(colmax, h);
                     const int h2 = max(h - kGapO, 0);
-                    const int en = max(max(e - kGapE, 0), h2);            // E never sees the lazy-F corrections below
-                    f = max(max(f - kGapE, 0), h2);
+                    const int en = max(max(e - kGapE, 0), h2);            // E never sees the lazy-F corrections
+                    f = max(f - kGapE, h2);
                     if (c & 1) { sw[c >> 1] |= unsigned(h) << 16; nw[c >> 1] = (nw[c >> 1] & 0xffffu) | (unsigned(en) << 16); }
                     else { sw[c >> 1] = unsigned(h) & 0xffffu; nw[c >> 1] = (nw[c >> 1] & 0xffff0000u) | unsigned(en); }
                     h = int((hw[c >> 1] >> (16 * (c & 1))) & 0xffffu);
@@ -282,74 +307,34 @@ __device__ RowPass row_pass(const signed char* refc, int r_begin, int r_end, int
             }
             *reinterpret_cast<uint4*>(store + lb + j0) = make_uint4(sw[0], sw[1], sw[2], sw[3]);
             *reinterpret_cast<uint4*>(E + lb + j0) = make_uint4(nw[0], nw[1], nw[2], nw[3]);
-        }
-        unsigned cm2 = 0u;                                     // column maximum of the corrections, as a pair
-        // one trip of 16 positions from j0: TEST_FIRST (8-bit loop: a position is corrected when its own test says go on) or
-        // correct-then-test (16-bit loop: the position whose test ends the loop is still corrected).  Returns false when the loop ends.
-        auto trip = [&](int j0, auto test_first) -> bool {
-            constexpr bool TF = decltype(test_first)::value;
-            const int nv = min(16, seg - j0);
-            const uint4 a8 = *reinterpret_cast<const uint4*>(store + lb + j0);
-            const uint4 b8 = *reinterpret_cast<const uint4*>(store + lb + j0 + 8);
-            const unsigned sv[8] = {a8.x, a8.y, a8.z, a8.w, b8.x, b8.y, b8.z, b8.w};
-            const unsigned ff = pk2(f, f);
-            unsigned hh[8], want = 0u;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const unsigned fc = pk_subs(ff, pk2(kGapE * 2 * k, kGapE * (2 * k + 1)));
-                hh[k] = pk_max(sv[k], fc);
-                unsigned w;
-                if (TF) w = pk_subs(fc, pk_subs(sv[k], pk2(kGapO, kGapO)));                              // f > max(stored - gap_o, 0)
-                else w = pk_subs(pk_subs(fc, pk2(kGapE, kGapE)), pk_subs(hh[k], pk2(kGapO, kGapO)));     // f - gap_e > max(corrected - gap_o, 0)
-                want |= pk_nz_bits(w) << (2 * k);
-            }
-            want = row_or<LW>(want);
-            const unsigned ends = ~want & ((1u << nv) - 1u);
-            const int stop = ends ? __ffs(int(ends)) - 1 : nv;
-            const int ncorr = TF ? stop : (ends ? stop + 1 : nv);           // positions [0, ncorr) are corrected
-            const unsigned nn = pk2(ncorr, ncorr);
-            unsigned out[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const unsigned m = pk_neg(pk_min(pk_subs(nn, pk2(2 * k, 2 * k + 1)), 0x00010001u));      // 0xffff where position < ncorr
-                out[k] = (hh[k] & m) | (sv[k] & ~m);
-                cm2 = pk_max(cm2, out[k] & m);
-            }
-            *reinterpret_cast<uint4*>(store + lb + j0) = make_uint4(out[0], out[1], out[2], out[3]);
-            if (nv > 8) *reinterpret_cast<uint4*>(store + lb + j0 + 8) = make_uint4(out[4], out[5], out[6], out[7]);
-            f = max(f - kGapE * ncorr, 0);
-            return ends == 0u;
         };
-        if (BYTE) {               // ssw.c:207-241: test, then correct; the chain wraps around the stripes
-            f = row_shl1<LW>(f, l);
-            int j0 = 0;
-            while (trip(j0, std::true_type{})) {
-                j0 += 16;
-                if (j0 >= seg) { j0 = 0; f = row_shl1<LW>(f, l); }
-            }
-        } else {                  // ssw.c:446-459: correct, then test; at most `lanes` rounds
-            bool go = true;
-            for (int k = 0; k < LW && go; ++k) {
-                f = row_shl1<LW>(f, l);
-                for (int j0 = 0; j0 < seg && go; j0 += 16) go = trip(j0, std::false_type{});
-            }
-        }
-        colmax = max(colmax, max(int(cm2 & 0xffffu), int(cm2 >> 16)));
-        colmax = row_max<LW>(colmax);
+        int j0 = 0;
+        for (; j0 + 8 <= seg; j0 += 8) group(j0, std::false_type{});
+        if (j0 < seg) group(j0, std::true_type{});
+        // Fin of this column: lane l - 1's outgoing F, or an earlier lane's after whole stripes of decay
+        fin = row_shl1<LW>(f, l);
+        fin = max(fin, max(row_shl<LW, 1>(fin, l) - D, 0));
+        fin = max(fin, max(row_shl<LW, 2>(fin, l) - 2 * D, 0));
+        fin = max(fin, max(row_shl<LW, 4>(fin, l) - 4 * D, 0));
+        if (LW == 16) fin = max(fin, max(row_shl<LW, 8>(fin, l) - 8 * D, 0));
+        colmax = row_max<LW>(max(colmax, fin));
         if (colmax > best) {
             best = colmax;
             if (BYTE && best + kBias >= 255) { overflow = true; break; }
             ref_end = i;
             int mq = 0x7fffffff;            // smallest linear query position that holds the new maximum
             const unsigned bb = pk2(best, best);
-            for (int j0 = 0; j0 < seg && mq == 0x7fffffff; j0 += 8) {
-                const uint4 a8 = *reinterpret_cast<const uint4*>(store + lb + j0);
+            int fs = fin;
+            for (int s0 = 0; s0 < seg && mq == 0x7fffffff; s0 += 8) {
+                const uint4 a8 = *reinterpret_cast<const uint4*>(store + lb + s0);
                 const unsigned sv[4] = {a8.x, a8.y, a8.z, a8.w};
+                const unsigned fs2 = pk2(fs, fs);
+                fs = max(fs - kGapE * 8, 0);
 #pragma unroll
                 for (int k = 3; k >= 0; --k) {
-                    const unsigned x = sv[k] ^ bb;
-                    if (j0 + 2 * k + 1 < seg && (x >> 16) == 0u) mq = l * seg + j0 + 2 * k + 1;
-                    if (j0 + 2 * k < seg && (x & 0xffffu) == 0u) mq = l * seg + j0 + 2 * k;
+                    const unsigned x = pk_max(sv[k], pk_subs(fs2, pk2(kGapE * 2 * k, kGapE * (2 * k + 1)))) ^ bb;
+                    if (s0 + 2 * k + 1 < seg && (x >> 16) == 0u) mq = l * seg + s0 + 2 * k + 1;
+                    if (s0 + 2 * k < seg && (x & 0xffffu) == 0u) mq = l * seg + s0 + 2 * k;
                 }
             }
             best_q = row_min<LW>(mq);
@@ -506,10 +491,11 @@ int launch_sw(hipStream_t s, const signed char* pool, const SwDesc* desc, const 
               int Rcap, int Qcap) {
     if (n == 0) return CTO_OK;
     constexpr int LW = BYTE ? 16 : 8;
-    // A pass is a chain of dependent steps: a wavefront runs it at the pace of ONE row whatever the number of rows it holds
-    // (measured: one row per wavefront is no faster than eight - 56 against 45 ms for the 2 560 haplotype-length alignments of the
-    // bench's batch: the time IS the chain of the longest alignment, ~1.4 M dependent stripe positions at ~90 cycles each)
-    const int ROWS = 64 / LW;
+    // A pass is a chain of dependent steps: a wavefront runs it at the pace of ONE row whatever the number of rows it holds, so a
+    // class with few alignments (the haplotype-length one: ~2 500 of the bench's batch) spreads them over more wavefronts - rows per
+    // wavefront halve until the class has a wavefront for every SIMD of the chip (1 024) or one row per wavefront is reached
+    int ROWS = 64 / LW;
+    while (ROWS > 1 && (n + ROWS - 1) / ROWS < 1024) ROWS /= 2;
     Rcap = (Rcap + 15) & ~15; Qcap = (Qcap + 15) & ~15;
     const int segcap = (Qcap + LW - 1) / LW;
     const size_t smem = ((sw_row_bytes(Rcap, Qcap, segcap, LW) + 15) / 16 * 16) * ROWS;
@@ -548,21 +534,41 @@ int ends_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats* st) 
     first[ws.size()] = desc.size();
     const int n = int(desc.size());
     if (n == 0) return CTO_OK;
-    // two classes (their LDS footprints differ): queries of read length and haplotype-length queries; inside a class
-    // by descending query length, so that the rows of a wavefront - and the waves of a round - run for about as long
-    std::vector<int> small, large;
-    int Rs = 0, Qs = 0, Rl = 0, Ql = 0;
+    // Classes by query length: a launch's LDS footprint is sized by its longest query (H, E and the profile are per stripe position),
+    // and the footprint is what bounds the wavefronts a CU holds - one class for everything would run the 100-base reads at the
+    // occupancy of the haplotype-length queries.  Inside a class by descending work, so that the rows of a wavefront - and the
+    // waves of a round - run for about as long.
+    constexpr int kClasses = 5;
+    const int qcap[kClasses] = {64, 128, 256, FP_RMAX, 0x7fffffff};
+    std::vector<int> cls[kClasses];
+    int Rc[kClasses] = {0, 0, 0, 0, 0}, Qc[kClasses] = {0, 0, 0, 0, 0};
     long long cells = 0;
     for (int k = 0; k < n; ++k) {
         cells += (long long)desc[k].R * desc[k].Q;
-        if (desc[k].Q <= FP_RMAX) { small.push_back(k); Rs = std::max(Rs, desc[k].R); Qs = std::max(Qs, desc[k].Q); }
-        else { large.push_back(k); Rl = std::max(Rl, desc[k].R); Ql = std::max(Ql, desc[k].Q); }
+        int c = 0;
+        while (desc[k].Q > qcap[c]) ++c;
+        cls[c].push_back(k); Rc[c] = std::max(Rc[c], desc[k].R); Qc[c] = std::max(Qc[c], desc[k].Q);
     }
     auto by_work = [&](int x, int y) { const long long a = (long long)desc[x].Q * desc[x].R, b = (long long)desc[y].Q * desc[y].R; return a != b ? a > b : x < y; };
-    std::sort(small.begin(), small.end(), by_work);
-    std::sort(large.begin(), large.end(), by_work);
-    std::vector<int> order(small);
-    order.insert(order.end(), large.begin(), large.end());
+    std::vector<int> order;
+    size_t at[kClasses + 1] = {0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < kClasses; ++c) {
+        std::sort(cls[c].begin(), cls[c].end(), by_work);
+        at[c] = order.size();
+        order.insert(order.end(), cls[c].begin(), cls[c].end());
+    }
+    at[kClasses] = order.size();
+    if (std::getenv("CTO_SW_CLASSES")) {
+        for (int c = 0; c < kClasses; ++c) {
+            const std::vector<int>& v = cls[c];
+            if (v.empty()) continue;
+            long long w = 0, sr = 0, sq = 0;
+            for (int k : v) { w += (long long)desc[k].R * desc[k].Q; sr += desc[k].R; sq += desc[k].Q; }
+            std::fprintf(stderr, "[sw class %d] n %zu cells %lld mean R %lld Q %lld; largest %d x %d, median %d x %d, smallest %d x %d\n", c, v.size(), w,
+                         sr / (long long)v.size(), sq / (long long)v.size(), desc[v[0]].R, desc[v[0]].Q, desc[v[v.size() / 2]].R, desc[v[v.size() / 2]].Q,
+                         desc[v.back()].R, desc[v.back()].Q);
+        }
+    }
     DevBuf<signed char> d_pool;
     DevBuf<SwDesc> d_desc;
     DevBuf<int> d_order;
@@ -572,34 +578,42 @@ int ends_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats* st) 
     if ((rc = d_pool.put(pool, s)) || (rc = d_desc.put(desc, s)) || (rc = d_order.put(order, s)) || (rc = d_out.alloc(size_t(n))) ||
         (rc = d_ovf.alloc(size_t(n))))
         return rc;
-    // 8-bit passes, then the 16-bit passes of what overflowed (same slots, same order: a row without overflow leaves at once).  The two
-    // classes are independent chains of two launches each and both end in a long tail (the longest alignment of the class), so the
-    // haplotype-length class runs on a stream of its own beside the read-length class.
-    hipEvent_t e0, e1, fork, join;
-    hipStream_t s2;
+    // 8-bit passes, then the 16-bit passes of what overflowed (same slots, same order: a row without overflow leaves at once).  The
+    // classes are independent chains of two launches each and every one ends in a tail (the longest alignment of the class), so each
+    // runs on a stream of its own, longest queries first.
+    hipEvent_t e0, e1, fork, join[kClasses];
+    hipStream_t sx[kClasses];
     CTO_HIP(hipEventCreate(&e0)); CTO_HIP(hipEventCreate(&e1));
-    CTO_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming)); CTO_HIP(hipEventCreateWithFlags(&join, hipEventDisableTiming));
-    CTO_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    CTO_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
     CTO_HIP(hipEventRecord(e0, s));
     CTO_HIP(hipEventRecord(fork, s));
-    CTO_HIP(hipStreamWaitEvent(s2, fork, 0));
-    if ((rc = launch_sw<true>(s2, d_pool.p, d_desc.p, d_order.p + small.size(), int(large.size()), d_out.p, d_ovf.p, Rl, Ql)) ||
-        (rc = launch_sw<false>(s2, d_pool.p, d_desc.p, d_order.p + small.size(), int(large.size()), d_out.p, d_ovf.p, Rl, Ql)) ||
-        (rc = launch_sw<true>(s, d_pool.p, d_desc.p, d_order.p, int(small.size()), d_out.p, d_ovf.p, Rs, Qs)) ||
-        (rc = launch_sw<false>(s, d_pool.p, d_desc.p, d_order.p, int(small.size()), d_out.p, d_ovf.p, Rs, Qs))) {
-        (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2);
-        return rc;
+    int made = 0;
+    rc = CTO_OK;
+    for (int c = kClasses - 1; c >= 0 && rc == CTO_OK; --c) {
+        if (cls[c].empty()) continue;
+        if (hipStreamCreateWithFlags(&sx[made], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&join[made], hipEventDisableTiming) != hipSuccess) { rc = CTO_EHIP; break; }
+        hipStream_t t = sx[made];
+        ++made;
+        if (hipStreamWaitEvent(t, fork, 0) != hipSuccess) { rc = CTO_EHIP; break; }
+        const int m = int(cls[c].size());
+        if ((rc = launch_sw<true>(t, d_pool.p, d_desc.p, d_order.p + at[c], m, d_out.p, d_ovf.p, Rc[c], Qc[c])) ||
+            (rc = launch_sw<false>(t, d_pool.p, d_desc.p, d_order.p + at[c], m, d_out.p, d_ovf.p, Rc[c], Qc[c])))
+            break;
+        if (hipEventRecord(join[made - 1], t) != hipSuccess || hipStreamWaitEvent(s, join[made - 1], 0) != hipSuccess) rc = CTO_EHIP;
     }
-    CTO_HIP(hipEventRecord(join, s2));
-    CTO_HIP(hipStreamWaitEvent(s, join, 0));
+    auto drop = [&]() {
+        for (int i = 0; i < made; ++i) { (void)hipStreamSynchronize(sx[i]); (void)hipStreamDestroy(sx[i]); (void)hipEventDestroy(join[i]); }
+        (void)hipEventDestroy(fork);
+    };
+    if (rc != CTO_OK) { drop(); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
     CTO_HIP(hipEventRecord(e1, s));
     std::vector<Ends> ends(static_cast<size_t>(n), Ends{0, 0, 0, 0, 0, 16});
     CTO_HIP(hipMemcpyAsync(ends.data(), d_out.p, size_t(n) * sizeof(Ends), hipMemcpyDeviceToHost, s));
     CTO_HIP(hipStreamSynchronize(s));
     float ms = 0.f;
     CTO_HIP(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(fork); (void)hipEventDestroy(join);
-    (void)hipStreamDestroy(s2);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    drop();
     if (st) { st->sw_ms += ms; st->sw_pairs += n; st->sw_cells += cells; }
     for (size_t wi = 0; wi < ws.size(); ++wi) ws[wi]->set_ends(ends.data() + first[wi]);
     return CTO_OK;

@@ -78,6 +78,26 @@ def ssw_pass(ref_codes, read_codes, lanes, reverse=False, terminate=None):
     return int(out[0]), int(out[1]), int(out[2]), bool(out[3])
 
 
+def ssw_pass_ex(ref_codes, read_codes, lanes, reverse=False, terminate=None, closed_form=False):
+    """ssw_pass with the lazy-F loops as the reference has them or as their closed form; returns ((score, ref_end, read_end, overflow),
+    hash of every H column after its lazy-F step)."""
+    global _ssw
+    if _ssw is None:
+        build()
+        _ssw = C.CDLL(_SSW_LIB)
+        _ssw.orc_ssw_pass.restype = None
+    ref_codes = np.ascontiguousarray(ref_codes, dtype=np.int8)
+    read_codes = np.ascontiguousarray(read_codes, dtype=np.int8)
+    out = np.zeros(4, dtype=np.int32)
+    h = C.c_uint64(0)
+    if terminate is None:
+        terminate = 255 if lanes == 16 else 65535
+    _ssw.orc_ssw_pass_ex.restype = None
+    _ssw.orc_ssw_pass_ex(_p(ref_codes), C.c_int(len(ref_codes)), C.c_int(int(bool(reverse))), _p(read_codes), C.c_int(len(read_codes)),
+                         C.c_int(lanes), C.c_int(int(terminate)), C.c_int(int(bool(closed_form))), _p(out), C.byref(h))
+    return (int(out[0]), int(out[1]), int(out[2]), bool(out[3])), int(h.value)
+
+
 _lib = None
 
 

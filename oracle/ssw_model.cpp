@@ -18,7 +18,14 @@ inline int sub_score(int8_t a, int8_t b) { return (a == b && a < 4) ? kMatch : -
 
 struct PassEnd { int score, ref_end, read_end; bool overflow; };
 
-PassEnd striped_pass(const int8_t* ref, int ref_len, bool reverse, const int8_t* read, int read_len, int lanes, int terminate) {
+// `closed_form`: the two lazy-F loops replaced by what they compute when they run to the end - a max-plus scan of the stripes' outgoing
+// F over the lanes, Fin[l] = max(F[l-1], Fin[l-1] - ext * seg), and ONE sweep H[l][j] = max(H[l][j], Fin[l] - ext * j) (all
+// saturating at 0).  The loops' early exits are pure shortcuts (at an exit every lane's carried F is 0 or is at least gap_open below
+// an H that a stronger chain - the main pass or an earlier round, already applied - put there), which is what
+// tests/test_realign.py::test_lazy_f_closed_form_equals_the_loops pins column by column through `column_hash`; the device kernel
+// (clairs_to_amd/csrc/realign_batch.hip) is built on the closed form.
+PassEnd striped_pass(const int8_t* ref, int ref_len, bool reverse, const int8_t* read, int read_len, int lanes, int terminate,
+                     bool closed_form = false, uint64_t* column_hash = nullptr) {
     const int seg = (read_len + lanes - 1) / lanes, P = seg * lanes;
     const bool byte_mode = lanes == 16;
     const int bias = kMismatch;                       // ssw_init: |most negative matrix entry|
@@ -51,7 +58,17 @@ PassEnd striped_pass(const int8_t* ref, int ref_len, bool reverse, const int8_t*
         // lazy F: the F chain that leaves stripe k enters stripe k+1
         auto shift = [&](std::vector<int>& v) { for (int l = lanes - 1; l > 0; --l) v[l] = v[l - 1]; v[0] = 0; };
         Fl = F;
-        if (byte_mode) {                              // ssw.c:207-241
+        if (closed_form) {
+            int fin = 0;
+            for (int l = 1; l < lanes; ++l) {
+                fin = std::max(F[l - 1], fin > kGapExt * seg ? fin - kGapExt * seg : 0);
+                for (int j = 0; j < seg && fin > kGapExt * j; ++j) {
+                    int& h = cur[l * seg + j];
+                    if (fin - kGapExt * j > h) h = fin - kGapExt * j;
+                    if (h > colmax) colmax = h;
+                }
+            }
+        } else if (byte_mode) {                       // ssw.c:207-241
             shift(Fl);
             int j = 0;
             for (;;) {
@@ -87,6 +104,8 @@ PassEnd striped_pass(const int8_t* ref, int ref_len, bool reverse, const int8_t*
                 }
             }
         }
+        if (column_hash)
+            for (int q = 0; q < P; ++q) *column_hash = (*column_hash ^ uint64_t(cur[q])) * 1099511628211ull;
         if (colmax > best) {
             best = colmax;
             if (byte_mode && best + bias >= 255) { overflow = true; break; }
@@ -109,5 +128,15 @@ extern "C" void orc_ssw_pass(const int8_t* ref, int ref_len, int reverse, const 
     out[0] = out[1] = out[2] = out[3] = 0;
     if (!ref || !read || ref_len < 0 || read_len <= 0 || (lanes != 16 && lanes != 8)) return;
     const PassEnd e = striped_pass(ref, ref_len, reverse != 0, read, read_len, lanes, terminate);
+    out[0] = e.score; out[1] = e.ref_end; out[2] = e.read_end; out[3] = e.overflow ? 1 : 0;
+}
+
+// the same pass with the lazy-F loops (closed_form = 0) or their closed form (1); *column_hash = FNV-1a over every H column after its lazy-F step
+extern "C" void orc_ssw_pass_ex(const int8_t* ref, int ref_len, int reverse, const int8_t* read, int read_len, int lanes, int terminate,
+                                int closed_form, int* out, uint64_t* column_hash) {
+    out[0] = out[1] = out[2] = out[3] = 0;
+    *column_hash = 1469598103934665603ull;
+    if (!ref || !read || ref_len < 0 || read_len <= 0 || (lanes != 16 && lanes != 8)) return;
+    const PassEnd e = striped_pass(ref, ref_len, reverse != 0, read, read_len, lanes, terminate, closed_form != 0, column_hash);
     out[0] = e.score; out[1] = e.ref_end; out[2] = e.read_end; out[3] = e.overflow ? 1 : 0;
 }

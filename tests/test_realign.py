@@ -121,6 +121,40 @@ def test_striped_pass_equals_the_scalar_model():
     assert overflowed > 300 and stopped > 500
 
 
+def test_lazy_f_closed_form_equals_the_loops():
+    """What the device kernel rests on (realign_batch.hip): the two lazy-F loops of the striped pass (ssw.c:207-241, :446-459) compute,
+    exits and all, the max-plus scan of the stripes' outgoing F over the lanes followed by one sweep.  Pinned here on the scalar model
+    (itself pinned to the compiled reference): every H column after its lazy-F step (hashed), and the pass's result, on both widths and
+    directions - random pairs of every style of this file, queries shorter than the lane count, two-letter alphabets (ties everywhere),
+    and hundreds of bases of exact match with one long gap (F chains that cross every stripe)."""
+    import oracle
+    rng = np.random.default_rng(5)
+    cases = [_random_pair(rng, it) for it in range(1200)]
+    for it in range(600):                           # short queries, tiny alphabets
+        R, Q = int(rng.integers(1, 90)), int(rng.integers(1, 40))
+        k = int(rng.integers(1, 3))
+        cases.append((rng.integers(0, k + 1, R).astype(np.int8), rng.integers(0, k + 1, Q).astype(np.int8)))
+    for it in range(150):                           # long matches around one deletion / insertion of 1..60 bases
+        R = int(rng.integers(150, 700))
+        ref = rng.integers(0, 4, R).astype(np.int8)
+        cut, g = int(rng.integers(20, R - 20)), int(rng.integers(1, 60))
+        read = np.concatenate([ref[:cut], ref[min(R, cut + g):]]) if it % 2 else np.concatenate([ref[:cut], rng.integers(0, 4, g).astype(np.int8), ref[cut:]])
+        cases.append((ref, read.astype(np.int8)) if it % 4 < 2 else (read.astype(np.int8), ref))
+    crossings = 0
+    for it, (ref, read) in enumerate(cases):
+        for lanes in (16, 8):
+            for reverse in (False, True):
+                term = None
+                if reverse and it % 3 == 0:
+                    term = oracle.ssw_pass(ref, read, lanes, False)[0]
+                a = oracle.ssw_pass_ex(ref, read, lanes, reverse, term, closed_form=False)
+                b = oracle.ssw_pass_ex(ref, read, lanes, reverse, term, closed_form=True)
+                assert a == b, (it, lanes, reverse, term, len(ref), len(read))
+                assert a[0] == oracle.ssw_pass(ref, read, lanes, reverse, term)
+                crossings += int(a[0][0] > 100)
+    assert crossings > 1500
+
+
 def test_realign_reads_does_not_depend_on_the_thread_count():
     from clairs_to_amd._lib import lib, check
     rng = np.random.default_rng(21)

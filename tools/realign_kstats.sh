@@ -8,7 +8,11 @@ python - <<'PY'
 import csv, glob
 f = glob.glob('/tmp/prof_rl/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
-for r in rows[-6:]:
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+last = [i for i, r in enumerate(rows) if 'k_fast_pass' in r['Kernel_Name']][-1]          # the last call's launches, on one time axis
+t0 = int(rows[last]['Start_Timestamp'])
+for r in rows[last:]:
     n = r['Kernel_Name'].replace('(anonymous namespace)::', '')
-    print('%-40s grid %7s wg %4s lds %6s  %9.3f ms' % (n[:40], r['Grid_Size_X'], r['Workgroup_Size_X'], r['LDS_Block_Size'], (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6))
+    print('%-34s grid %7s wg %4s lds %6s  start %8.3f  end %8.3f ms' % (n[:34], r['Grid_Size_X'], r['Workgroup_Size_X'], r['LDS_Block_Size'],
+          (int(r['Start_Timestamp']) - t0) / 1e6, (int(r['End_Timestamp']) - t0) / 1e6))
 PY
