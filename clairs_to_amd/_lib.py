@@ -56,7 +56,8 @@ class RunCfg(C.Structure):
 class RealignJob(C.Structure):
     _fields_ = [("n_reads", c_i32), ("seqs", c_vp), ("positions", c_vp), ("cigars", c_vp), ("reference", C.c_char_p),
                 ("haplotypes", C.c_char_p), ("ref_start", c_i32), ("ref_prefix", c_i32), ("ref_suffix", c_i32),
-                ("out_positions", c_vp), ("cigar_buf", c_vp), ("cigar_cap", C.c_size_t), ("cigar_off", c_vp), ("status", c_i32)]
+                ("out_positions", c_vp), ("cigar_buf", c_vp), ("cigar_cap", C.c_size_t), ("cigar_off", c_vp), ("status", c_i32),
+                ("seqs_joined", c_vp), ("cigars_joined", c_vp)]
 
 
 class RealignStats(C.Structure):

@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <cstring>
 #include <string>
@@ -205,8 +206,9 @@ PassEnd striped_pass(const int8_t* ref, int ref_len, bool reverse, const int8_t*
 struct Run { char op; int len; };
 
 bool banded_path(const int8_t* ref, const int8_t* read, int R, int Q, int score, int band, std::vector<Run>& out) {
-    std::vector<int> hb, eb, hc;
-    std::vector<int8_t> dir;
+    static thread_local std::vector<int> hb, eb, hc;            // scratch of the calling worker: no allocation per alignment
+    static thread_local std::vector<int8_t> dir;
+    hb.clear(); eb.clear(); hc.clear();                         // contents as of fresh vectors, the storage kept
     int best = 0, width_d = 0;
     auto bu = [](int w, int i, int j) { int x = i - w; if (x < 0) x = 0; return j - x + 1; };            // set_u
     auto bd = [](int w, int i, int j, int p) { int x = i - w; if (x < 0) x = 0; return (j - x) * 3 + p; };  // set_d
@@ -557,7 +559,6 @@ void Window::fast_pass_host() {
                     hit.score = sc;
                     hit.position = start;
                     hit.exact = true;
-                    hit.cigar.assign(1, Op{'=', span});
                 }
             }
             // a seeded position inside the consensus part that no read covers with <= 2 mismatches disqualifies the haplotype
@@ -585,7 +586,6 @@ void Window::set_fast_pass(const int32_t* hit_score, const int32_t* hit_pos, con
             hit.score = sc;
             hit.position = hit_pos[size_t(h) * n + r];
             hit.exact = true;
-            hit.cigar.assign(1, Op{'=', (int)reads[r].size()});
         }
     }
 }
@@ -648,19 +648,18 @@ int Window::finish(int32_t* out_pos, std::vector<std::string>& out_cigar) {
         }
         st.pos_map = positions_map(st.cigar, haps[st.index].size());
     }
-    // Smith-Waterman for the reads no haplotype took (:351-384)
+    // Smith-Waterman for the reads no haplotype took (:351-384).  The reference runs the banded traceback of every (read, haplotype)
+    // pair and then uses one of them per read; here a pair whose score would replace the read's hit on that haplotype is only NOTED,
+    // with the score the striped passes found - the traceback either confirms exactly that score or fails (then the hit stays as it
+    // was) - and the traceback runs for the pair a read ends up picking (below).
+    std::vector<int> noted(todo.empty() ? 0 : size_t(H) * size_t(n), -1);            // [haplotype][read] -> pair
     for (int r : todo)
-        for (HapState& st : hs) {
+        for (int hi = 0; hi < H; ++hi) {
+            HapState& st = hs[size_t(hi)];
             if (st.score == 0) continue;
-            const SwPair& p = pairs[k];
-            const SwAlignment al = sw_finish(p.ref, p.R, p.query, p.Q, ends[k]);
+            const Ends& e = ends[k];
+            if (e.score > 0 && e.score >= kSswThreshold && st.hits[r].score < e.score) noted[size_t(hi) * n + r] = int(k);
             ++k;
-            if (al.score > 0 && al.score >= kSswThreshold && st.hits[r].score < al.score) {
-                st.hits[r].score = al.score;
-                st.hits[r].cigar = al.cigar;
-                st.hits[r].position = al.ref_begin;
-                st.hits[r].exact = false;
-            }
         }
 
     // the reference's std::sort by haplotype score (:108); ties keep whatever order that algorithm leaves them in
@@ -673,18 +672,40 @@ int Window::finish(int32_t* out_pos, std::vector<std::string>& out_cigar) {
     for (int r = 0; r < n; ++r) {
         out_pos[r] = positions[r];
         out_cigar[r] = cigars[r];
-        int best = 0, pick = -1;
-        for (int kk = 0; kk < H; ++kk) {                          // GetBestReadAlignment (:514-538)
-            const HapState& st = hs[order[kk]];
-            const int sc = st.hits[r].score;
-            if (sc > best || (best > 0 && sc == best && !st.is_reference)) { best = sc; pick = order[kk]; }
+        int pick = -1;
+        for (;;) {
+            int best = 0;
+            pick = -1;
+            for (int kk = 0; kk < H; ++kk) {                      // GetBestReadAlignment (:514-538)
+                const HapState& st = hs[order[kk]];
+                const int at = noted.empty() ? -1 : noted[size_t(order[kk]) * n + r];
+                const int sc = at >= 0 ? ends[size_t(at)].score : st.hits[r].score;
+                if (sc > best || (best > 0 && sc == best && !st.is_reference)) { best = sc; pick = order[kk]; }
+            }
+            if (pick < 0 || noted.empty() || noted[size_t(pick) * n + r] < 0) break;
+            // The pick is a noted pair: its traceback now.  Success installs the hit with the score it was noted with (the pick
+            // stands); a failure leaves the read's hit on that haplotype as it was, which can only lower that entry - and lowering an
+            // entry that was not picked never changes the pick, so the pairs not traced leave no trace - and the choice is made again.
+            const size_t at = size_t(noted[size_t(pick) * n + r]);
+            noted[size_t(pick) * n + r] = -1;
+            const SwPair& p = pairs[at];
+            const SwAlignment al = sw_finish(p.ref, p.R, p.query, p.Q, ends[at]);
+            ReadHit& hit = hs[size_t(pick)].hits[r];
+            if (al.score > 0 && al.score >= kSswThreshold && hit.score < al.score) {
+                hit.score = al.score;
+                hit.cigar = al.cigar;
+                hit.position = al.ref_begin;
+                hit.exact = false;
+            }
         }
         if (pick < 0) continue;
         const HapState& st = hs[pick];
         const ReadHit& hit = st.hits[r];
         CTO_REQUIRE(hit.position >= 0 && hit.position < (int)st.pos_map.size(), CTO_EINVAL, "cto_realign_reads: read %d lies outside its haplotype", r);
         std::vector<Cop> ops;
-        if (!compose(to_cops(hit.cigar), to_cops(st.cigar), hit.position, (int)reads[r].size(), ops))
+        // an exact hit (fast pass) is the whole read in one '=' run; it is spelled out here, not stored per (haplotype, read)
+        const std::vector<Cop> read_ops = hit.exact ? to_cops(std::vector<Op>{Op{'=', (int)reads[r].size()}}) : to_cops(hit.cigar);
+        if (!compose(read_ops, to_cops(st.cigar), hit.position, (int)reads[r].size(), ops))
             CTO_REQUIRE(false, CTO_EINVAL, "cto_realign_reads: the haplotype alignment ends before read %d starts", r);
         if (!ops.empty()) {
             out_cigar[r].clear();

@@ -425,7 +425,15 @@ bool device_eligible(const Window& w) {
     return true;
 }
 
+// CTO_REALIGN_TRACE=1: the classes of the Smith-Waterman stage and the wall time of every stage of a call, on stderr
+bool trace_on() { static const bool on = std::getenv("CTO_REALIGN_TRACE") != nullptr; return on; }
+struct StageClock {
+    double t = now_ms();
+    void lap(const char* what) { if (trace_on()) { const double n = now_ms(); std::fprintf(stderr, "[realign] %-28s %8.3f ms\n", what, n - t); t = n; } }
+};
+
 int fast_pass_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats* st) {
+    StageClock clk;
     std::vector<unsigned char> hap_bytes, read_bytes, hap_isref;
     std::vector<int> hap_off{0}, hap_win, read_off{0}, win_read0{0}, win_prefix, win_suffix;
     std::vector<long long> hit_off;
@@ -447,6 +455,7 @@ int fast_pass_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats*
     }
     const int nh = int(hap_win.size());
     if (nh == 0) return CTO_OK;
+    clk.lap("  fast pass: pack");
     CTO_REQUIRE(hap_bytes.size() < (size_t(1) << 31) && read_bytes.size() < (size_t(1) << 31), CTO_EUNSUPPORTED,
                 "cto_realign_windows: more than 2 GiB of sequence in one call; split it");
     DevBuf<unsigned char> d_hap, d_read, d_isref;
@@ -458,6 +467,7 @@ int fast_pass_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats*
         (rc = d_prefix.put(win_prefix, s)) || (rc = d_suffix.put(win_suffix, s)) || (rc = d_hit_off.put(hit_off, s)) ||
         (rc = d_hit_score.alloc(size_t(hits))) || (rc = d_hit_pos.alloc(size_t(hits))) || (rc = d_hap_score.alloc(size_t(nh))))
         return rc;
+    clk.lap("  fast pass: alloc + H2D");
     FpArgs a{d_hap.p, d_hap_off.p, d_hap_win.p, d_isref.p, d_hit_off.p, d_read.p, d_read_off.p, d_win_read0.p, d_prefix.p, d_suffix.p,
              d_hit_score.p, d_hit_pos.p, d_hap_score.p};
     hipEvent_t e0, e1;
@@ -477,6 +487,7 @@ int fast_pass_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats*
     CTO_HIP(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (st) { st->fast_pass_ms += ms; st->fast_pairs += hits; }
+    clk.lap("  fast pass: kernel + D2H");
     size_t hcur = 0;
     for (Window* w : ws) {
         const size_t H = size_t(w->n_haps());
@@ -507,6 +518,7 @@ int launch_sw(hipStream_t s, const signed char* pool, const SwDesc* desc, const 
 }
 
 int ends_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats* st) {
+    StageClock clk;
     // code pool: per window the reference, its haplotypes, the reads that need Smith-Waterman - each once
     std::vector<signed char> pool;
     std::vector<SwDesc> desc;
@@ -534,6 +546,7 @@ int ends_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats* st) 
     first[ws.size()] = desc.size();
     const int n = int(desc.size());
     if (n == 0) return CTO_OK;
+    clk.lap("  SW: pool + descriptors");
     // Classes by query length: a launch's LDS footprint is sized by its longest query (H, E and the profile are per stripe position),
     // and the footprint is what bounds the wavefronts a CU holds - one class for everything would run the 100-base reads at the
     // occupancy of the haplotype-length queries.  Inside a class by descending work, so that the rows of a wavefront - and the
@@ -558,7 +571,7 @@ int ends_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats* st) 
         order.insert(order.end(), cls[c].begin(), cls[c].end());
     }
     at[kClasses] = order.size();
-    if (std::getenv("CTO_SW_CLASSES")) {
+    if (trace_on()) {
         for (int c = 0; c < kClasses; ++c) {
             const std::vector<int>& v = cls[c];
             if (v.empty()) continue;
@@ -578,6 +591,7 @@ int ends_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats* st) 
     if ((rc = d_pool.put(pool, s)) || (rc = d_desc.put(desc, s)) || (rc = d_order.put(order, s)) || (rc = d_out.alloc(size_t(n))) ||
         (rc = d_ovf.alloc(size_t(n))))
         return rc;
+    clk.lap("  SW: classes, alloc + H2D");
     // 8-bit passes, then the 16-bit passes of what overflowed (same slots, same order: a row without overflow leaves at once).  The
     // classes are independent chains of two launches each and every one ends in a tail (the longest alignment of the class), so each
     // runs on a stream of its own, longest queries first.
@@ -615,6 +629,7 @@ int ends_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats* st) 
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     drop();
     if (st) { st->sw_ms += ms; st->sw_pairs += n; st->sw_cells += cells; }
+    clk.lap("  SW: launches + D2H");
     for (size_t wi = 0; wi < ws.size(); ++wi) ws[wi]->set_ends(ends.data() + first[wi]);
     return CTO_OK;
 }
@@ -642,9 +657,20 @@ extern "C" int cto_realign_windows(int n_jobs, cto_realign_job* jobs, int where,
     parallel_for(size_t(n_jobs), threads, [&](size_t i) {
         cto_realign_job& j = jobs[i];
         if (!(j.out_positions && j.cigar_off && (j.cigar_buf || j.cigar_cap == 0))) { status[i] = CTO_EINVAL; errors[i] = "cto_realign_windows: a job without output buffers"; return; }
-        status[i] = ws[i].init(j.n_reads, j.seqs, j.positions, j.cigars, j.reference, j.haplotypes, j.ref_start, j.ref_prefix, j.ref_suffix);
+        std::vector<const char*> ps, pc;         // the joined forms: n_reads strings back to back
+        auto split = [&](const char* joined, std::vector<const char*>& v) {
+            v.resize(static_cast<size_t>(std::max(j.n_reads, 0)));
+            for (int r = 0; r < j.n_reads; ++r) { v[size_t(r)] = joined; joined += strlen(joined) + 1; }
+            return v.data();
+        };
+        const char* const* seqs = j.seqs ? j.seqs : (j.seqs_joined ? split(j.seqs_joined, ps) : nullptr);
+        const char* const* cigars = j.cigars ? j.cigars : (j.cigars_joined ? split(j.cigars_joined, pc) : nullptr);
+        status[i] = ws[i].init(j.n_reads, seqs, j.positions, cigars, j.reference, j.haplotypes, j.ref_start, j.ref_prefix, j.ref_suffix);
         if (status[i] != CTO_OK) errors[i] = cto_last_error();
     });
+    StageClock clk;
+    clk.t = t0;
+    clk.lap("windows: parse, de Bruijn");
     std::vector<Window*> dev, host;
     for (size_t i = 0; i < ws.size(); ++i) {
         if (status[i] != CTO_OK) continue;
@@ -655,9 +681,12 @@ extern "C" int cto_realign_windows(int n_jobs, cto_realign_job* jobs, int where,
     if (!dev.empty()) {
         int rc = fast_pass_device(dev, s, stats);
         if (rc != CTO_OK) return rc;
+        clk.lap("fast pass (device, copies)");
         parallel_for(dev.size(), threads, [&](size_t i) { dev[i]->collect_pairs(); });
+        clk.lap("collect pairs");
         rc = ends_device(dev, s, stats);
         if (rc != CTO_OK) return rc;
+        clk.lap("SW ends (device, copies)");
     }
     const double t1 = now_ms();
     parallel_for(host.size(), threads, [&](size_t i) { host[i]->fast_pass_host(); host[i]->collect_pairs(); host[i]->ends_host(); });
@@ -669,6 +698,7 @@ extern "C" int cto_realign_windows(int n_jobs, cto_realign_job* jobs, int where,
         if (rc == CTO_OK) rc = cto_realign_write_cigars(out, j.cigar_buf, j.cigar_cap, j.cigar_off);
         if (rc != CTO_OK) { status[i] = rc; errors[i] = cto_last_error(); }
     });
+    clk.lap("host windows, traceback, CIGARs");
     int first_bad = -1;
     for (size_t i = 0; i < ws.size(); ++i) {
         jobs[i].status = status[i];
@@ -679,8 +709,10 @@ extern "C" int cto_realign_windows(int n_jobs, cto_realign_job* jobs, int where,
         stats->host_windows = (long long)host.size();
         for (const Window& w : ws) { stats->reads += w.n_reads(); stats->haplotypes += w.n_haps(); }
         stats->device_stage_ms = t1 - t0;
-        stats->host_ms = now_ms() - t1;
     }
+    // a window owns thousands of small vectors (a hit per read and haplotype): given back by the workers, not by the caller alone
+    parallel_for(ws.size(), threads, [&](size_t i) { ws[i] = Window(); });
+    if (stats) stats->host_ms = now_ms() - t1;
     if (first_bad >= 0) { cto::set_error("window %d: %s", first_bad, errors[size_t(first_bad)].c_str()); return status[size_t(first_bad)]; }
     return CTO_OK;
 }

@@ -16,7 +16,7 @@ namespace cto_realign {
 struct Ends { int32_t score, ref_end, read_end, ref_begin, bw_read_end, lanes; };
 
 struct Op { char op; int len; };
-struct ReadHit { int position = -1, score = 0; bool exact = false; std::vector<Op> cigar; };   // ReadAlignment (realigner.h:103-127)
+struct ReadHit { int position = -1, score = 0; bool exact = false; std::vector<Op> cigar; };   // ReadAlignment (realigner.h:103-127); exact: the fast pass's hit, CIGAR '=' x read length (not stored)
 struct HapState {
     int index = 0, score = 0, ref_pos = 0;
     bool is_reference = false;

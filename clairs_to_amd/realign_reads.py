@@ -21,6 +21,7 @@ reference's behaviour (all line numbers into src/realign_reads.py):
   * output (:618-647): reads in order of their (new) start, stable; within the loop only those 1 020 bases behind the chunk.
 """
 import ctypes as C
+import numpy as np
 import shlex
 import subprocess
 import sys
@@ -81,24 +82,53 @@ def realign_windows(windows, where="device", threads=0, stats=None, statuses=Non
     (positions, cigars).  where = "device": the k-mer fast pass and the striped Smith-Waterman passes of every window run as two
     HIP launches (a HIP device must be current); "host": the same windows on `threads` host workers.  Outputs are identical."""
     from ._lib import RealignJob, RealignStats
+    from itertools import chain
     n = len(windows)
     jobs = (RealignJob * max(n, 1))()
-    keep = []
-    for j, (seqs, positions, cigars, ref_seq, haplotypes, ref_start, prefix_len, suffix_len) in zip(jobs, windows):
-        m = len(seqs)
-        a_seq = (C.c_char_p * max(m, 1))(*[s.encode() for s in seqs])
-        a_pos = (C.c_int32 * max(m, 1))(*positions)
-        a_cig = (C.c_char_p * max(m, 1))(*[c.encode() for c in cigars])
-        out_pos = (C.c_int32 * max(m, 1))()
-        cap = 64 * m + 8 * sum(len(s) for s in seqs) + sum(len(c) for c in cigars) + 64
-        buf = C.create_string_buffer(cap)
-        off = (C.c_int64 * (m + 1))()
-        j.n_reads = m
-        j.seqs, j.positions, j.cigars = C.cast(a_seq, C.c_void_p), C.cast(a_pos, C.c_void_p), C.cast(a_cig, C.c_void_p)
-        j.reference, j.haplotypes = ref_seq.encode(), " ".join(haplotypes).encode()
-        j.ref_start, j.ref_prefix, j.ref_suffix = ref_start, prefix_len, suffix_len
-        j.out_positions, j.cigar_buf, j.cigar_cap, j.cigar_off = C.cast(out_pos, C.c_void_p), C.cast(buf, C.c_void_p), cap, C.cast(off, C.c_void_p)
-        keep.append((a_seq, a_pos, a_cig, out_pos, buf, off, m))
+    # Marshalling for the whole list at once (a run has tens of reads per window and thousands of windows: per-read ctypes objects
+    # would cost more than the call): every read of every window in ONE NUL-separated buffer, the same for the CIGARs, one array of
+    # positions; a job points into them (seqs_joined / cigars_joined of cto_realign_job).
+    counts = np.fromiter((len(w[0]) for w in windows), dtype=np.int64, count=n)
+    if n and (np.any(counts != np.fromiter((len(w[1]) for w in windows), dtype=np.int64, count=n)) or
+              np.any(counts != np.fromiter((len(w[2]) for w in windows), dtype=np.int64, count=n))):
+        raise ValueError("realign_windows: reads, positions and CIGARs of a window must be equally many")
+    total = int(counts.sum())
+    first = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(counts, out=first[1:])
+
+    def blob(column):
+        strings = list(chain.from_iterable(w[column] for w in windows))
+        data = ("\0".join(strings) + "\0").encode() if strings else b"\0"
+        ends = np.zeros(total + 1, dtype=np.int64)
+        np.cumsum(np.fromiter(map(len, strings), dtype=np.int64, count=total) + 1, out=ends[1:])
+        if total and (int(ends[-1]) != len(data) or data.count(b"\0") != total):
+            raise ValueError("realign_windows: a read or CIGAR string with NUL or non-ASCII characters")
+        return data, ends[first]                           # the buffer, byte offset of every window's first string (and the end)
+
+    seq_blob, seq_at = blob(0)
+    cig_blob, cig_at = blob(2)
+    seq_base = C.cast(C.c_char_p(seq_blob), C.c_void_p).value
+    cig_base = C.cast(C.c_char_p(cig_blob), C.c_void_p).value
+    pos_all = np.fromiter(chain.from_iterable(w[1] for w in windows), dtype=np.int32, count=total)
+    out_pos_all = np.empty(max(total, 1), dtype=np.int32)
+    off_all = np.zeros(total + n + 1, dtype=np.int64)      # window i: m + 1 offsets from first[i] + i
+    caps = 64 * counts + 8 * np.diff(seq_at) + np.diff(cig_at) + 64 if n else np.zeros(0, dtype=np.int64)
+    buf_at = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(caps, out=buf_at[1:])
+    buf_all = np.empty(max(int(buf_at[-1]), 1), dtype=np.uint8)      # not zeroed: the call writes what off[] then delimits
+    p_pos, p_out, p_off, p_buf = pos_all.ctypes.data, out_pos_all.ctypes.data, off_all.ctypes.data, buf_all.ctypes.data
+    keep = [seq_blob, cig_blob, pos_all, out_pos_all, off_all, buf_all]
+    for i, (j, w) in enumerate(zip(jobs, windows)):
+        f = int(first[i])
+        j.n_reads = int(counts[i])
+        j.seqs, j.cigars = None, None
+        j.seqs_joined, j.cigars_joined = seq_base + int(seq_at[i]), cig_base + int(cig_at[i])
+        j.positions = p_pos + 4 * f
+        ref, haps = w[3].encode(), " ".join(w[4]).encode()
+        keep.append((ref, haps))
+        j.reference, j.haplotypes = ref, haps
+        j.ref_start, j.ref_prefix, j.ref_suffix = w[5], w[6], w[7]
+        j.out_positions, j.cigar_buf, j.cigar_cap, j.cigar_off = p_out + 4 * f, p_buf + int(buf_at[i]), int(caps[i]), p_off + 8 * (f + i)
     st = RealignStats()
     stream = None
     if where == "device":
@@ -114,9 +144,11 @@ def realign_windows(windows, where="device", threads=0, stats=None, statuses=Non
     if stats is not None:
         stats.update({k: getattr(st, k) for k, _ in RealignStats._fields_})
     out = []
-    for (_, _, _, out_pos, buf, off, m) in keep:
-        raw = buf.raw
-        out.append((list(out_pos[:m]), [raw[off[i]:off[i + 1] - 1].decode() for i in range(m)]))
+    for i in range(n):
+        f, m = int(first[i]), int(counts[i])
+        at = int(buf_at[i])
+        text = buf_all[at:at + int(off_all[f + i + m])].tobytes().decode() if m else ""
+        out.append((out_pos_all[f:f + m].tolist(), text[:-1].split("\0") if m else []))
     return out
 
 

@@ -557,6 +557,8 @@ typedef struct cto_realign_job {
     char* cigar_buf; size_t cigar_cap; /* CIGAR text, NUL-terminated one after the other                        */
     int64_t* cigar_off;                /* [n_reads + 1] offsets into cigar_buf                                  */
     int32_t status;                    /* out                                                                   */
+    const char* seqs_joined;           /* read when seqs == NULL: the n_reads strings back to back, each NUL-terminated - a host  */
+    const char* cigars_joined;         /* language that holds them as one buffer need not build pointer arrays; same for cigars   */
 } cto_realign_job;
 typedef struct cto_realign_stats {
     int64_t windows, host_windows, reads, haplotypes;

@@ -62,3 +62,29 @@ def test_window_batcher_serves_many_callers_with_what_one_call_returns():
     assert "shorter" in got[80]
     with pytest.raises(RuntimeError):
         b(*ru.window_args(ws[0]))
+
+
+def test_a_job_takes_pointer_arrays_or_joined_buffers():
+    """cto_realign_job: seqs / cigars as [n_reads] pointers (what the reference's binding builds, realign_reads.py:582-591) or, when
+    those are NULL, as seqs_joined / cigars_joined - the same bytes out"""
+    import ctypes as C
+    from clairs_to_amd._lib import lib, check, RealignJob
+    rng = np.random.default_rng(8)
+    w = ru.gen_window(rng, n_reads=25)
+    want = ru.amd_realign_batch([w], "host", threads=1)[0]
+    m = len(w["seqs"])
+    jobs = (RealignJob * 1)()
+    j = jobs[0]
+    a_seq = (C.c_char_p * m)(*[s.encode() for s in w["seqs"]])
+    a_cig = (C.c_char_p * m)(*[c.encode() for c in w["cigars"]])
+    a_pos = (C.c_int32 * m)(*w["positions"])
+    out_pos, off, buf = (C.c_int32 * m)(), (C.c_int64 * (m + 1))(), C.create_string_buffer(1 << 16)
+    j.n_reads, j.seqs, j.cigars, j.positions = m, C.cast(a_seq, C.c_void_p), C.cast(a_cig, C.c_void_p), C.cast(a_pos, C.c_void_p)
+    j.reference, j.haplotypes = w["reference"].encode(), " ".join(w["haplotypes"]).encode()
+    j.ref_start, j.ref_prefix, j.ref_suffix = w["ref_start"], w["ref_prefix"], w["ref_suffix"]
+    j.out_positions, j.cigar_buf, j.cigar_cap, j.cigar_off = C.cast(out_pos, C.c_void_p), C.cast(buf, C.c_void_p), 1 << 16, C.cast(off, C.c_void_p)
+    check(lib.cto_realign_windows(1, jobs, 0, 1, None, None))
+    got = (list(out_pos), [buf.raw[off[i]:off[i + 1] - 1].decode() for i in range(m)])
+    assert got == want
+    j.seqs, j.cigars = None, None                      # neither form: refused, not read
+    assert lib.cto_realign_windows(1, jobs, 0, 1, None, None) != 0
