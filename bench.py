@@ -445,7 +445,7 @@ def realign_leg(dev, n_windows=1500, seed=20260930):
         "windows_on_host": int(st["host_windows"])})
     out = {"workload": "%d synthetic Illumina realignment windows, %d reads (BASELINE configs[3]: realign_reads path)" % (n_windows, reads),
            "cores": cores, "outputs_equal": bool(host == devo and host[:sub] == one), **legs,
-           "note": "one cto_realign_windows call per figure; seconds / reads_per_s include the Python side's packing of 33 k strings into ctypes arrays (~60 ms), c_call_seconds / reads_per_s_c_call are the C call alone (what a C or C++ orchestrator pays); the reference's own library on one core runs "
+           "note": "one cto_realign_windows call per figure; seconds / reads_per_s include the Python side (every read and CIGAR of the list joined into one buffer each, the outputs split again: seconds - c_call_seconds), c_call_seconds / reads_per_s_c_call are the C call alone (what a C or C++ orchestrator pays); the reference's own library on one core runs "
                    "this generator's windows at ~3.8 k reads/s (tools/realign_bench.py, build container); kernel times are HIP events, "
                    "sw_gcups = reference x query cells of every alignment / k_sw_ends time (both passes of an alignment counted once)"}
     return out
