@@ -632,6 +632,8 @@ void Window::ends_host() {
     for (std::thread& t : pool) t.join();
 }
 
+Ends ends_of_pair(const int8_t* ref, int R, const int8_t* query, int Q) { return sw_ends(ref, R, query, Q); }
+
 int Window::finish(int32_t* out_pos, std::vector<std::string>& out_cigar) {
     const int n = (int)reads.size(), H = (int)haps.size();
     CTO_REQUIRE(ends.size() == pairs.size(), CTO_EINVAL, "cto_realign_reads: stage 2 did not run");

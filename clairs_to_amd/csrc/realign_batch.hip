@@ -51,15 +51,6 @@ __device__ __forceinline__ int row_max(int v) {
 }
 template <int LW>
 __device__ __forceinline__ int row_min(int v) { return -row_max<LW>(-v); }
-template <int LW>
-__device__ __forceinline__ unsigned row_or(unsigned u) {
-    int v = int(u);
-    v |= dpp_i<0xB1>(v);
-    v |= dpp_i<0x4E>(v);
-    v |= dpp_i<0x141>(v);
-    if (LW == 16) v |= dpp_i<0x140>(v);
-    return unsigned(v);
-}
 // _mm_slli_si128(x, one element): lane l takes lane l - 1 of its row, lane 0 takes 0 (row_shr:1 works on 16 lanes: the first lane
 // of an 8-lane row in the upper half must not see its neighbour row's last lane)
 template <int LW>
@@ -170,23 +161,12 @@ __global__ __launch_bounds__(FP_NT) void k_fast_pass(FpArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// Striped Smith-Waterman end points.  k_sw_byte: the 8-bit passes, four 16-lane rows per wavefront (forward; backward when the
-// forward pass did not overflow).  k_sw_word: the 16-bit passes of the alignments whose 8-bit pass overflowed (score >= 249: any
-// read with 63 matching bases in a row, every haplotype against its reference), eight 8-lane rows per wavefront.  The H columns of
-// the previous and the current reference position and the E column live in LDS, [stripe position j][lane]; every lane reads and
-// writes only its own entries, so there is no barrier inside a pass - lanes meet in DPP shifts, ballots and row reductions only.
+// Striped Smith-Waterman end points.  k_sw<true>: the 8-bit passes, 16-lane rows (forward; backward when the forward pass did not
+// overflow).  k_sw<false>: the 16-bit passes of the alignments whose 8-bit pass overflowed (score >= 249: any read with 63 matching
+// bases in a row, every haplotype against its reference), 8-lane rows.  Every lane reads and writes only its own LDS entries (layout
+// at sw_sp below), so there is no barrier inside a pass - lanes meet in DPP shifts and row reductions only.
 struct SwDesc { int ref_off, R, q_off, Q; };
 struct RowPass { int score, ref_end, read_end; bool overflow; };
-#ifdef CTO_SW_PROF      // tools/ builds only: cycles of wave 0 of the launch per phase {main loop, lazy F, best scan, columns, lazy chunks}
-__device__ long long g_sw_prof[8];
-#define SW_T(x) const long long x = clock64()
-#define SW_ADD(i, a, b) if (blockIdx.x == 0 && threadIdx.x == 0) g_sw_prof[i] += (b) - (a)
-#define SW_INC(i) if (blockIdx.x == 0 && threadIdx.x == 0) g_sw_prof[i] += 1
-#else
-#define SW_T(x)
-#define SW_ADD(i, a, b)
-#define SW_INC(i)
-#endif
 
 constexpr int kBias = 6, kGapO = 8, kGapE = 2;
 
@@ -221,15 +201,7 @@ __device__ __forceinline__ unsigned pk_subs(unsigned a, unsigned b) {      // _m
 __device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b) {
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, a), __builtin_bit_cast(i16x2, b)));
 }
-__device__ __forceinline__ unsigned pk_min(unsigned a, unsigned b) {
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
-}
-__device__ __forceinline__ unsigned pk_neg(unsigned a) {                    // 0 - a per half, wrapping: 1 -> 0xffff
-    return __builtin_bit_cast(unsigned, u16x2{0, 0} - __builtin_bit_cast(u16x2, a));
-}
 __device__ __forceinline__ unsigned pk2(int lo, int hi) { return (unsigned(lo) & 0xffffu) | (unsigned(hi) << 16); }
-// the two halves of a pair as bits 0 and 1: non-zero -> 1
-__device__ __forceinline__ unsigned pk_nz_bits(unsigned w) { const unsigned t = pk_min(w, 0x00010001u); return (t | (t >> 15)) & 3u; }
 
 // lane l takes lane l - S of its row, the first S lanes take 0
 template <int LW, int S>
@@ -517,36 +489,12 @@ int launch_sw(hipStream_t s, const signed char* pool, const SwDesc* desc, const 
     return CTO_OK;
 }
 
-int ends_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats* st) {
+// Both passes of every alignment of `desc` (operands = base codes in `pool`): the end points, in desc order
+int sw_ends_pool(const std::vector<signed char>& pool, const std::vector<SwDesc>& desc, hipStream_t s, cto_realign_stats* st, std::vector<Ends>& ends) {
     StageClock clk;
-    // code pool: per window the reference, its haplotypes, the reads that need Smith-Waterman - each once
-    std::vector<signed char> pool;
-    std::vector<SwDesc> desc;
-    std::vector<size_t> first(ws.size() + 1, 0);
-    for (size_t wi = 0; wi < ws.size(); ++wi) {
-        Window& w = *ws[wi];
-        first[wi] = desc.size();
-        auto put = [&](const std::vector<int8_t>& v) { const int off = int(pool.size()); pool.insert(pool.end(), v.begin(), v.end()); return off; };
-        const int ref_off = put(w.refc);
-        std::vector<int> hap_at(w.hapc.size()), read_at(w.readc.size(), -1);
-        for (size_t h = 0; h < w.hapc.size(); ++h) hap_at[h] = put(w.hapc[h]);
-        for (int r : w.todo) read_at[r] = put(w.readc[r]);
-        for (const cto_realign::SwPair& p : w.sw_pairs()) {
-            // identify the operands by address (the pairs point into refc / hapc / readc)
-            int roff = -1, qoff = -1;
-            if (p.ref == w.refc.data()) roff = ref_off;
-            else for (size_t h = 0; h < w.hapc.size(); ++h) if (p.ref == w.hapc[h].data()) { roff = hap_at[h]; break; }
-            for (size_t h = 0; h < w.hapc.size() && qoff < 0; ++h) if (p.query == w.hapc[h].data()) qoff = hap_at[h];
-            if (qoff < 0) for (int r : w.todo) if (p.query == w.readc[r].data()) { qoff = read_at[r]; break; }
-            CTO_REQUIRE(roff >= 0 && qoff >= 0, CTO_EINVAL, "cto_realign_windows: internal: unknown operand");
-            desc.push_back(SwDesc{roff, p.R, qoff, p.Q});
-        }
-        CTO_REQUIRE(pool.size() < (size_t(1) << 31), CTO_EUNSUPPORTED, "cto_realign_windows: more than 2 GiB of sequence in one call; split it");
-    }
-    first[ws.size()] = desc.size();
     const int n = int(desc.size());
+    ends.assign(static_cast<size_t>(n), Ends{0, 0, 0, 0, 0, 16});
     if (n == 0) return CTO_OK;
-    clk.lap("  SW: pool + descriptors");
     // Classes by query length: a launch's LDS footprint is sized by its longest query (H, E and the profile are per stripe position),
     // and the footprint is what bounds the wavefronts a CU holds - one class for everything would run the 100-base reads at the
     // occupancy of the haplotype-length queries.  Inside a class by descending work, so that the rows of a wavefront - and the
@@ -621,7 +569,6 @@ int ends_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats* st) 
     };
     if (rc != CTO_OK) { drop(); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
     CTO_HIP(hipEventRecord(e1, s));
-    std::vector<Ends> ends(static_cast<size_t>(n), Ends{0, 0, 0, 0, 0, 16});
     CTO_HIP(hipMemcpyAsync(ends.data(), d_out.p, size_t(n) * sizeof(Ends), hipMemcpyDeviceToHost, s));
     CTO_HIP(hipStreamSynchronize(s));
     float ms = 0.f;
@@ -630,20 +577,76 @@ int ends_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats* st) 
     drop();
     if (st) { st->sw_ms += ms; st->sw_pairs += n; st->sw_cells += cells; }
     clk.lap("  SW: launches + D2H");
+    return CTO_OK;
+}
+
+int ends_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats* st) {
+    StageClock clk;
+    // code pool: per window the reference, its haplotypes, the reads that need Smith-Waterman - each once
+    std::vector<signed char> pool;
+    std::vector<SwDesc> desc;
+    std::vector<size_t> first(ws.size() + 1, 0);
+    for (size_t wi = 0; wi < ws.size(); ++wi) {
+        Window& w = *ws[wi];
+        first[wi] = desc.size();
+        auto put = [&](const std::vector<int8_t>& v) { const int off = int(pool.size()); pool.insert(pool.end(), v.begin(), v.end()); return off; };
+        const int ref_off = put(w.refc);
+        std::vector<int> hap_at(w.hapc.size()), read_at(w.readc.size(), -1);
+        for (size_t h = 0; h < w.hapc.size(); ++h) hap_at[h] = put(w.hapc[h]);
+        for (int r : w.todo) read_at[r] = put(w.readc[r]);
+        for (const cto_realign::SwPair& p : w.sw_pairs()) {
+            // identify the operands by address (the pairs point into refc / hapc / readc)
+            int roff = -1, qoff = -1;
+            if (p.ref == w.refc.data()) roff = ref_off;
+            else for (size_t h = 0; h < w.hapc.size(); ++h) if (p.ref == w.hapc[h].data()) { roff = hap_at[h]; break; }
+            for (size_t h = 0; h < w.hapc.size() && qoff < 0; ++h) if (p.query == w.hapc[h].data()) qoff = hap_at[h];
+            if (qoff < 0) for (int r : w.todo) if (p.query == w.readc[r].data()) { qoff = read_at[r]; break; }
+            CTO_REQUIRE(roff >= 0 && qoff >= 0, CTO_EINVAL, "cto_realign_windows: internal: unknown operand");
+            desc.push_back(SwDesc{roff, p.R, qoff, p.Q});
+        }
+        CTO_REQUIRE(pool.size() < (size_t(1) << 31), CTO_EUNSUPPORTED, "cto_realign_windows: more than 2 GiB of sequence in one call; split it");
+    }
+    first[ws.size()] = desc.size();
+    if (desc.empty()) return CTO_OK;
+    clk.lap("  SW: pool + descriptors");
+    std::vector<Ends> ends;
+    const int rc = sw_ends_pool(pool, desc, s, st, ends);
+    if (rc != CTO_OK) return rc;
     for (size_t wi = 0; wi < ws.size(); ++wi) ws[wi]->set_ends(ends.data() + first[wi]);
     return CTO_OK;
 }
 
 }  // namespace
 
-#ifdef CTO_SW_PROF
-extern "C" int cto_debug_sw_prof(long long* out8, int reset) {
-    CTO_HIP(hipDeviceSynchronize());
-    CTO_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_sw_prof), 8 * sizeof(long long)));
-    if (reset) { long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; CTO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sw_prof), z, sizeof(z))); }
+extern "C" int cto_sw_ends_batch(int n, const int8_t* codes, size_t n_codes, const int32_t* desc, int where, int host_threads, void* stream,
+                                 int32_t* out) try {
+    CTO_REQUIRE(n >= 0 && (n == 0 || (codes && desc && out)) && (where == CTO_REALIGN_HOST || where == CTO_REALIGN_DEVICE), CTO_EINVAL,
+                "cto_sw_ends_batch: bad argument");
+    CTO_REQUIRE(n_codes < (size_t(1) << 31), CTO_EUNSUPPORTED, "cto_sw_ends_batch: more than 2 GiB of sequence in one call; split it");
+    std::vector<SwDesc> d(static_cast<size_t>(n));
+    for (int k = 0; k < n; ++k) {
+        d[size_t(k)] = SwDesc{desc[4 * k], desc[4 * k + 1], desc[4 * k + 2], desc[4 * k + 3]};
+        const SwDesc& x = d[size_t(k)];
+        CTO_REQUIRE(x.R >= 0 && x.Q >= 0 && x.ref_off >= 0 && x.q_off >= 0 && size_t(x.ref_off) + size_t(x.R) <= n_codes &&
+                    size_t(x.q_off) + size_t(x.Q) <= n_codes, CTO_EINVAL, "cto_sw_ends_batch: alignment %d reaches outside the codes", k);
+    }
+    std::vector<Ends> ends(static_cast<size_t>(n), Ends{0, 0, 0, 0, 0, 16});
+    if (where == CTO_REALIGN_DEVICE) {
+        const std::vector<signed char> pool(reinterpret_cast<const signed char*>(codes), reinterpret_cast<const signed char*>(codes) + n_codes);
+        const int rc = sw_ends_pool(pool, d, static_cast<hipStream_t>(stream), nullptr, ends);
+        if (rc != CTO_OK) return rc;
+    } else {
+        const int threads = host_threads > 0 ? host_threads : cto_realign::get_threads();
+        parallel_for(size_t(n), threads, [&](size_t k) { ends[k] = cto_realign::ends_of_pair(codes + d[k].ref_off, d[k].R, codes + d[k].q_off, d[k].Q); });
+    }
+    for (int k = 0; k < n; ++k) {
+        const Ends& e = ends[size_t(k)];
+        int32_t* o = out + 6 * size_t(k);
+        o[0] = e.score; o[1] = e.ref_end; o[2] = e.read_end; o[3] = e.ref_begin; o[4] = e.bw_read_end; o[5] = e.lanes;
+    }
     return CTO_OK;
 }
-#endif
+CTO_CATCH("cto_sw_ends_batch", int)
 
 extern "C" int cto_realign_windows(int n_jobs, cto_realign_job* jobs, int where, int host_threads, void* stream, cto_realign_stats* stats) try {
     CTO_REQUIRE(n_jobs >= 0 && (jobs || n_jobs == 0) && (where == CTO_REALIGN_HOST || where == CTO_REALIGN_DEVICE), CTO_EINVAL,

@@ -60,6 +60,8 @@ public:
 };
 
 int get_threads();
+// the two striped passes of one alignment on the host (ssw.c:781-830): what Window::ends_host runs per pair
+Ends ends_of_pair(const int8_t* ref, int R, const int8_t* query, int Q);
 
 }  // namespace cto_realign
 

@@ -152,6 +152,27 @@ def realign_windows(windows, where="device", threads=0, stats=None, statuses=Non
     return out
 
 
+def sw_ends_batch(pairs, where="device", threads=0):
+    """The striped Smith-Waterman passes of many (reference, query) pairs in one call (cto_sw_ends_batch; ssw.c:781-830): pairs = list of
+    (ref_codes, query_codes) int8 arrays of base codes 0..4; returns an [n, 6] int32 array {score, ref_end, read_end, ref_begin,
+    read_end - read_begin, lanes}."""
+    n = len(pairs)
+    flat = [np.ascontiguousarray(x, dtype=np.int8) for p in pairs for x in p]
+    codes = np.concatenate(flat) if flat else np.zeros(0, dtype=np.int8)
+    lens = np.fromiter((len(x) for x in flat), dtype=np.int64, count=len(flat))
+    offs = np.zeros(len(flat) + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    desc = np.stack([offs[0:-1:2], lens[0::2], offs[1::2], lens[1::2]], axis=1).astype(np.int32) if n else np.zeros((0, 4), dtype=np.int32)
+    desc = np.ascontiguousarray(desc)
+    out = np.zeros((n, 6), dtype=np.int32)
+    stream = None
+    if where == "device":
+        from ._lib import current_stream_ptr
+        stream = current_stream_ptr()
+    check(lib.cto_sw_ends_batch(n, codes.ctypes.data, codes.size, desc.ctypes.data, 1 if where == "device" else 0, int(threads), stream, out.ctypes.data))
+    return out
+
+
 class WindowBatcher(object):
     """realign_fn of many calls at once.  The reference starts one `realign_reads` process per low-QUAL call and each hands its
     windows to the native realigner one by one (src/realign_variants.py:73-110, src/realign_reads.py:582-595).  Here the calls of

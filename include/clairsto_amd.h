@@ -570,6 +570,12 @@ typedef struct cto_realign_stats {
 #define CTO_REALIGN_HOST   0
 #define CTO_REALIGN_DEVICE 1
 int cto_realign_windows(int n_jobs, cto_realign_job* jobs, int where, int host_threads, void* stream, cto_realign_stats* stats);
+/* The Smith-Waterman stage of cto_realign_windows on its own: the two striped passes ssw_align runs per alignment (ssw.c:781-830: 8-bit
+ * forward pass, 16-bit passes instead when it overflows at 249, backward pass over the reversed prefixes) for n independent alignments.
+ * codes = base codes 0..4 (A C G T other; n_codes bytes), desc[k] = {ref_off, ref_len, query_off, query_len} into codes, out[k] = {score,
+ * ref_end, read_end, ref_begin, read_end - read_begin, lanes used (16 / 8)} - all zero (lanes 16) for an empty operand or score 0.
+ * where = CTO_REALIGN_DEVICE: the k_sw launches on `stream`; CTO_REALIGN_HOST: the SSE2 passes on host_threads workers.  Same numbers. */
+int cto_sw_ends_batch(int n, const int8_t* codes, size_t n_codes, const int32_t* desc, int where, int host_threads, void* stream, int32_t* out);
 /* One striped Smith-Waterman pass alone (ssw.c:118-311 / :341-529 of the reference's src/realign: sw_sse2_byte / sw_sse2_word), test
  * hook: ref / read are base codes 0..4, lanes 16 (bytes) or 8 (words), out[4] = {score (255 on 8-bit overflow), ref_end, read_end,
  * overflow}. */

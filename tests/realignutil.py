@@ -82,3 +82,64 @@ def window_args(w):
 def amd_realign_batch(ws, where, threads=0, stats=None):
     from clairs_to_amd.realign_reads import realign_windows
     return [(p, c) for p, c in realign_windows([window_args(w) for w in ws], where=where, threads=threads, stats=stats)]
+
+
+def model_ends(ref, q):
+    """ssw_align's two passes (ssw.c:781-830) composed from the scalar model of one pass (oracle/ssw_model.cpp): the row
+    cto_sw_ends_batch writes for this pair"""
+    import oracle
+    if len(ref) == 0 or len(q) == 0:
+        return [0, 0, 0, 0, 0, 16]
+    fw, lanes = oracle.ssw_pass(ref, q, 16), 16
+    if fw[3]:
+        fw, lanes = oracle.ssw_pass(ref, q, 8), 8
+    if fw[0] <= 0:
+        return [0, 0, 0, 0, 0, 16]
+    bw = oracle.ssw_pass(ref[:fw[1] + 1], q[:fw[2] + 1][::-1], lanes, True, fw[0])
+    return [fw[0], fw[1], fw[2], bw[1], bw[2], lanes]
+
+
+def adversarial_pairs(rng, n, max_len=700):
+    """(reference, query) code pairs that stress the lazy-F step: long matches around one or several long gaps (F chains that cross
+    every stripe), tandem repeats and two-letter alphabets (ties), queries shorter than the lane count, N bases, unrelated pairs"""
+    pairs = []
+    for it in range(n):
+        style = it % 6
+        R = int(rng.integers(1, max_len))
+        ref = rng.integers(0, 4, R).astype(np.int8)
+        if style == 0:                                   # a copy with 0..4 gaps of 1..80 bases and a few substitutions
+            q = ref.copy()
+            for _ in range(int(rng.integers(0, 5))):
+                k, g = int(rng.integers(0, max(1, len(q)))), int(rng.integers(1, 80))
+                q = np.concatenate([q[:k], q[k + g:]]) if rng.random() < 0.5 else np.concatenate([q[:k], rng.integers(0, 4, g).astype(np.int8), q[k:]])
+            for _ in range(int(rng.integers(0, 4))):
+                if len(q):
+                    k = int(rng.integers(0, len(q)))
+                    q[k] = (q[k] + 1) % 4
+            if len(q) == 0:
+                q = ref[:1].copy()
+            if rng.random() < 0.5:
+                ref, q = q, ref
+        elif style == 1:                                 # tandem repeats
+            unit = rng.integers(0, 4, int(rng.integers(1, 5))).astype(np.int8)
+            Q = int(rng.integers(1, max_len))
+            ref, q = np.tile(unit, R // len(unit) + 1)[:R].copy(), np.tile(unit, Q // len(unit) + 1)[:Q].copy()
+            if rng.random() < 0.5:
+                q[int(rng.integers(0, Q))] = 4
+        elif style == 2:                                 # tiny alphabet
+            k = int(rng.integers(1, 3))
+            ref = rng.integers(0, k + 1, R).astype(np.int8)
+            q = rng.integers(0, k + 1, int(rng.integers(1, max_len))).astype(np.int8)
+        elif style == 3:                                 # a query shorter than the lanes
+            a = int(rng.integers(0, R))
+            q = ref[a:a + int(rng.integers(1, 17))].copy()
+        elif style == 4:                                 # a read-length window of the reference
+            a = int(rng.integers(0, R))
+            q = ref[a:a + int(rng.integers(20, 300))].copy()
+            if len(q) > 4 and rng.random() < 0.7:
+                k = int(rng.integers(1, len(q) - 1))
+                q = np.concatenate([q[:k], q[k + int(rng.integers(1, 30)):]])
+        else:                                            # unrelated
+            q = rng.integers(0, 4, int(rng.integers(1, max_len))).astype(np.int8)
+        pairs.append((np.ascontiguousarray(ref, dtype=np.int8), np.ascontiguousarray(q, dtype=np.int8)))
+    return pairs

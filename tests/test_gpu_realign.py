@@ -132,3 +132,23 @@ def test_realign_variants_with_the_device_realigner_writes_the_reference_vcf(dev
         got = io.StringIO()
         rr.reads_realignment(a, out=got)
     assert got.getvalue() == want.getvalue() and b.windows >= 1
+
+
+def test_device_sw_passes_on_adversarial_pairs(dev):
+    """cto_sw_ends_batch on the device - the kernel whose lazy-F step is the closed form (csrc/realign_batch.hip) - on pairs built to
+    stress exactly that step (long matches around long gaps in both orientations, tandem repeats, tiny alphabets, queries shorter than
+    the lane count), operands up to 2 000 bases: every end point equal to the scalar model's (oracle/ssw_model.cpp, the loops as the
+    reference has them) on 3 000 pairs and to the SSE2 host form on 20 000 more, fresh pairs every run."""
+    from clairs_to_amd.realign_reads import sw_ends_batch
+    seed = int.from_bytes(os.urandom(4), "little")
+    rng = np.random.default_rng(seed)
+    small = ru.adversarial_pairs(rng, 3000, max_len=500)
+    small += [(np.zeros(0, dtype=np.int8), small[0][1]), (small[0][0], np.zeros(0, dtype=np.int8))]
+    got = sw_ends_batch(small, "device")
+    for i, ((ref, q), o) in enumerate(zip(small, got)):
+        assert o.tolist() == ru.model_ends(ref, q), "pair %d of np.random.default_rng(%d)" % (i, seed)
+    big = ru.adversarial_pairs(rng, 20000, max_len=700) + ru.adversarial_pairs(rng, 600, max_len=2000)
+    d, h = sw_ends_batch(big, "device"), sw_ends_batch(big, "host", threads=16)
+    bad = np.nonzero((d != h).any(axis=1))[0]
+    assert bad.size == 0, "pair %d of np.random.default_rng(%d): device %s host %s" % (bad[0], seed, d[bad[0]], h[bad[0]])
+    assert int((d[:, 5] == 8).sum()) > 2000 and int((d[:, 0] > 1000).sum()) > 500

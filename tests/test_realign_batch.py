@@ -88,3 +88,19 @@ def test_a_job_takes_pointer_arrays_or_joined_buffers():
     assert got == want
     j.seqs, j.cigars = None, None                      # neither form: refused, not read
     assert lib.cto_realign_windows(1, jobs, 0, 1, None, None) != 0
+
+
+def test_sw_ends_batch_host_equals_the_scalar_model():
+    """cto_sw_ends_batch, host form: the two striped passes per alignment as ssw_align composes them (ssw.c:781-830), against the same
+    composition of the scalar model's passes - incl. empty operands"""
+    from clairs_to_amd.realign_reads import sw_ends_batch
+    rng = np.random.default_rng(17)
+    pairs = ru.adversarial_pairs(rng, 900, max_len=400)
+    pairs += [(np.zeros(0, dtype=np.int8), pairs[0][1]), (pairs[0][0], np.zeros(0, dtype=np.int8))]
+    got = sw_ends_batch(pairs, "host", threads=4)
+    word = 0
+    for (ref, q), o in zip(pairs, got):
+        assert o.tolist() == ru.model_ends(ref, q), (len(ref), len(q))
+        word += int(o[5] == 8)
+    assert word > 100
+    assert sw_ends_batch([], "host").shape == (0, 6)
