@@ -239,10 +239,14 @@ __device__ __forceinline__ bool walk_bases(ByteStream& st, const unsigned char* 
     return true;
 }
 
+// Where a row's bytes are read: the text in HBM (base 0), or a wavefront's staged copy of its rows in LDS (t[0] = text[base]; offsets
+// below are relative to t, `len` = the bytes that belong to rows - what lies behind is look-ahead padding)
+struct TextRef { const unsigned char* t; long long base, len; };
+
 // pass 1 of a row: the single forward pass of pack.cpp's fast_row; writes the row's counts, false = not a row this path takes
-__device__ bool count_row(const RowArgs& a, long long cur, int row) {
-    const unsigned char* t = a.text;
-    const long long len = a.len;
+__device__ bool count_row(const RowArgs& a, const TextRef& T, long long cur, int row) {
+    const unsigned char* t = T.t;
+    const long long len = T.len;
     ByteStream st;
     st.seek(t, cur);
     if (st.peek() <= 10u) return false;                                 // an empty row / an empty contig field: the host's
@@ -286,8 +290,8 @@ __device__ bool count_row(const RowArgs& a, long long cur, int row) {
 }
 
 // pass 2 of a row: entries, column tables, the row's distinct keys
-__device__ void fill_row(const RowArgs& a, long long cur, int row) {
-    const unsigned char* t = a.text;
+__device__ void fill_row(const RowArgs& a, const TextRef& T, long long cur, int row) {
+    const unsigned char* t = T.t;
     const long long e0 = a.col_off[row];
     const int k0 = a.key_off[row];
     const int nt = a.row_nt[row];
@@ -302,7 +306,7 @@ __device__ void fill_row(const RowArgs& a, long long cur, int row) {
         ByteStream sb;
         sb.seek(t, b0);
         int n2 = 0;
-        (void)walk_bases(sb, t, a.len, n2, ind);
+        (void)walk_bases(sb, t, T.len, n2, ind);
         ind.intern(t);
     }
     ByteStream sb, sq, sm;
@@ -366,7 +370,7 @@ __device__ void fill_row(const RowArgs& a, long long cur, int row) {
         long long take = min((long long)(sl + 1), (long long)a.max_indel_length);
         take = min(take, a.ref_len - ri);
         a.key_len[k] = tk == 1 ? 2 + sl : 1 + int(take);
-        a.key_seq[k] = tk == 1 ? ind.seq[i] : ri;
+        a.key_seq[k] = tk == 1 ? ind.seq[i] + T.base : ri;
         a.key_info[k] = (sl << 8) | (code << 4) | tk;
     }
 }
@@ -667,19 +671,35 @@ __global__ __launch_bounds__(256) void k_row_starts(const unsigned char* __restr
             if (text[p] == '\n' && p + 1 < len) row_start[row++] = p + 1;
     }
 }
-// one lane per row (a lane per segment that parsed "its" rows where it found them ran the parser once per '\n' position of the
-// wavefront, one or two lanes at a time: 4.5 ms instead of 0.3)
-__global__ __launch_bounds__(256) void k_rows_count(RowArgs a) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+// One lane per row (a lane per segment that parsed "its" rows where it found them ran the parser once per '\n' position of the
+// wavefront, one or two lanes at a time: 4.5 ms instead of 0.3).  The 64 rows of a wavefront are consecutive lines, i.e. ONE contiguous
+// span of the text (~11 KB at 50x): the wave copies it into LDS with coalesced 16-byte loads and the lanes parse from there - a lane's
+// byte stream then refills from LDS instead of waiting out an L2 round trip per 8 bytes, three streams at a time in the fill pass.
+// Spans that do not fit (deep columns) are parsed from HBM as before; the decision is the wavefront's.
+constexpr int TOKL_CAP = 16384;
+template <bool FILL>
+__global__ __launch_bounds__(64) void k_rows_lanes(RowArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_text[TOKL_CAP];
+    const int lane = threadIdx.x;
+    const int r0 = blockIdx.x * 64, r = r0 + lane;
+    const int r1 = min(r0 + 64, a.n_rows);
+    const long long span0 = a.row_start[r0], span1 = r1 < a.n_rows ? a.row_start[r1] : a.len;
+    const long long a0 = span0 & ~15LL;
+    const long long need = span1 - a0 + 48;                 // a stream looks 40 bytes past the byte it stands on
+    TextRef T{a.text, 0, a.len};
+    if (need <= TOKL_CAP) {
+        for (long long i = lane * 16LL; i < need; i += 64 * 16) *reinterpret_cast<uint4*>(s_text + i) = *reinterpret_cast<const uint4*>(a.text + a0 + i);
+        __syncthreads();
+        T = TextRef{s_text, a0, span1 - a0};
+    }
     if (r >= a.n_rows) return;
     const long long cur = a.row_start[r];
-    if (!count_row(a, cur, r)) atomicMax(&a.fl->slow, int(min(cur + 1, (long long)0x7fffffff)));
-}
-__global__ __launch_bounds__(256) void k_rows_fill(RowArgs a) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.n_rows) return;
-    if (r > 0 && a.row_pos[r] <= a.row_pos[r - 1]) atomicMax(&a.fl->bad_order, 1);
-    fill_row(a, a.row_start[r], r);
+    if (FILL) {
+        if (r > 0 && a.row_pos[r] <= a.row_pos[r - 1]) atomicMax(&a.fl->bad_order, 1);
+        fill_row(a, T, cur - T.base, r);
+    } else if (!count_row(a, T, cur - T.base, r)) {
+        atomicMax(&a.fl->slow, int(min(cur + 1, (long long)0x7fffffff)));
+    }
 }
 __global__ __launch_bounds__(128) void k_key_strings(const unsigned char* __restrict__ text, const unsigned char* __restrict__ ref, int n_keys,
                                                      const long long* __restrict__ key_seq, const int* __restrict__ key_info,
@@ -805,7 +825,7 @@ extern "C" int cto_tokenise_device(cto_dev_tokeniser* cx, const char* text, size
     // second statement of the pass the tests hold the first one to)
     const char* tw = getenv("CTO_TOK_WAVES");
     const bool by_lanes = !(tw && tw[0] == '1');
-    if (by_lanes) hipLaunchKernelGGL(k_rows_count, dim3(unsigned(cdiv(n_rows, 256))), dim3(256), 0, s, a);
+    if (by_lanes) hipLaunchKernelGGL(k_rows_lanes<false>, dim3(unsigned(cdiv(n_rows, 64))), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(k_rows_wave<false>, dim3(unsigned(cdiv(n_rows, TOKW_WAVES))), dim3(64 * TOKW_WAVES), 0, s, a);
     CTO_HIP(hipGetLastError());
     if ((rc = scan_exclusive<long long>(s, cx->row_nt.as<int>(), n_rows, cx->col_off.as<long long>(), cx->tiles.as<long long>(), &fl->n_entries))) return rc;
@@ -822,7 +842,7 @@ extern "C" int cto_tokenise_device(cto_dev_tokeniser* cx, const char* text, size
     a.col_off = cx->col_off.as<long long>(); a.key_off = cx->key_off.as<int>(); a.entries = cx->entries.as<unsigned>(); a.col_pos = cx->col_pos.as<int>();
     a.col_ref = cx->col_ref.as<unsigned char>(); a.key_meta = cx->key_meta.as<unsigned char>(); a.key_group = cx->key_group.as<int>();
     a.key_len = cx->key_len.as<int>(); a.key_seq = cx->key_seq.as<long long>(); a.key_info = cx->key_info.as<int>();
-    if (by_lanes) hipLaunchKernelGGL(k_rows_fill, dim3(unsigned(cdiv(n_rows, 256))), dim3(256), 0, s, a);
+    if (by_lanes) hipLaunchKernelGGL(k_rows_lanes<true>, dim3(unsigned(cdiv(n_rows, 64))), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(k_rows_wave<true>, dim3(unsigned(cdiv(n_rows, TOKW_WAVES))), dim3(64 * TOKW_WAVES), 0, s, a);
     CTO_HIP(hipGetLastError());
     if ((rc = scan_exclusive<long long>(s, cx->key_len.as<int>(), n_keys, cx->str_off.as<long long>(), cx->tiles.as<long long>(), &fl->key_str_bytes))) return rc;
