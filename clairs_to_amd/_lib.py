@@ -63,7 +63,8 @@ class RealignJob(C.Structure):
 class RealignStats(C.Structure):
     _fields_ = [("windows", c_i64), ("host_windows", c_i64), ("reads", c_i64), ("haplotypes", c_i64), ("fast_pairs", c_i64),
                 ("sw_pairs", c_i64), ("sw_cells", c_i64), ("fast_pass_ms", C.c_double), ("sw_ms", C.c_double),
-                ("device_stage_ms", C.c_double), ("host_ms", C.c_double)]
+                ("device_stage_ms", C.c_double), ("host_ms", C.c_double),
+                ("tracebacks", c_i64), ("tracebacks_declined", c_i64), ("traceback_ms", C.c_double)]
 
 
 class RunStats(C.Structure):

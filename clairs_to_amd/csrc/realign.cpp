@@ -43,6 +43,8 @@ using cto_realign::Op;
 using cto_realign::ReadHit;
 using cto_realign::HapState;
 using cto_realign::SwPair;
+using cto_realign::SwAlignment;
+using cto_realign::TraceJob;
 
 // ---- scoring: realigner.cpp:63-73 (set_options) and the default SSW aligner it ends up using (ssw_cpp.cpp:230-242; `InitSswLib`
 // at realigner.cpp:121-127 builds a local object, so the member keeps its defaults - which are the same numbers)
@@ -278,7 +280,6 @@ bool banded_path(const int8_t* ref, const int8_t* read, int R, int Q, int score,
 // ------------------------------------------------------------------------------------------------------------------------
 // ssw_align (ssw.c:781-867) + Aligner::Align / ConvertAlignment / CalculateNumberMismatch (ssw_cpp.cpp:78-215, :302-337):
 // local alignment of `query` to `ref`, CIGAR over {S,=,X,I,D}.
-struct SwAlignment { int score = 0, ref_begin = 0; std::vector<Op> cigar; };
 
 // the two striped passes (ssw.c:781-830): where the best local alignment ends and begins
 Ends sw_ends(const int8_t* ref, int R, const int8_t* query, int Q) {
@@ -295,20 +296,26 @@ Ends sw_ends(const int8_t* ref, int R, const int8_t* query, int Q) {
 }
 
 // banded traceback between those points and the CIGAR SSW's C++ wrapper prints (ssw.c:831-867, ssw_cpp.cpp:78-215)
-SwAlignment sw_finish(const int8_t* ref, int R, const int8_t* query, int Q, const Ends& e) {
+// the sub-problem of the traceback; false = the reference returns no alignment before it gets there
+bool trace_job(int R, int Q, const Ends& e, TraceJob& j) {
+    if (R == 0 || Q == 0 || e.score <= 0) return false;
+    j.ref_begin = e.ref_begin; j.read_begin = e.read_end - e.bw_read_end;
+    if (j.ref_begin < 0 || j.read_begin < 0) return false;
+    j.subR = e.ref_end - j.ref_begin + 1; j.subQ = e.read_end - j.read_begin + 1;
+    if (j.subR > 32768 || j.subQ > 32768) return false;                             // distance_filter 32767: no CIGAR
+    j.score = e.score;
+    j.band = std::abs(j.subR - j.subQ) + 1;
+    return true;
+}
+
+// the runs of the banded walk ({'M','I','D'} in query order) as Align prints them: soft clips, '=' / 'X' runs
+SwAlignment alignment_from_runs(const int8_t* ref, const int8_t* query, int Q, const Ends& e, const TraceJob& j, const std::vector<Run>& runs) {
     SwAlignment al;
-    if (R == 0 || Q == 0 || e.score <= 0) return al;
-    const int ref_begin = e.ref_begin, read_begin = e.read_end - e.bw_read_end;
-    if (ref_begin < 0 || read_begin < 0) return al;
-    const int subR = e.ref_end - ref_begin + 1, subQ = e.read_end - read_begin + 1;
-    if (subR > 32768 || subQ > 32768) return al;                                   // distance_filter 32767: no CIGAR
-    std::vector<Run> runs;
-    if (!banded_path(ref + ref_begin, query + read_begin, subR, subQ, e.score, std::abs(subR - subQ) + 1, runs)) return al;
     al.score = e.score;
-    al.ref_begin = ref_begin;
-    if (read_begin > 0) al.cigar.push_back({'S', read_begin});
-    const int8_t* r = ref + ref_begin;
-    const int8_t* q = query + read_begin;
+    al.ref_begin = j.ref_begin;
+    if (j.read_begin > 0) al.cigar.push_back({'S', j.read_begin});
+    const int8_t* r = ref + j.ref_begin;
+    const int8_t* q = query + j.read_begin;
     char cur = 0;
     int len = 0;
     auto flush = [&] { if (cur) al.cigar.push_back({cur, len}); cur = 0; len = 0; };
@@ -329,6 +336,14 @@ SwAlignment sw_finish(const int8_t* ref, int R, const int8_t* query, int Q, cons
     const int tail = Q - e.read_end - 1;
     if (tail > 0) al.cigar.push_back({'S', tail});
     return al;
+}
+
+SwAlignment sw_finish(const int8_t* ref, int R, const int8_t* query, int Q, const Ends& e) {
+    TraceJob j{};
+    if (!trace_job(R, Q, e, j)) return SwAlignment();
+    std::vector<Run> runs;
+    if (!banded_path(ref + j.ref_begin, query + j.read_begin, j.subR, j.subQ, j.score, j.band, runs)) return SwAlignment();
+    return alignment_from_runs(ref, query, Q, e, j, runs);
 }
 
 SwAlignment sw_align(const std::vector<int8_t>& ref, const std::vector<int8_t>& query) {
@@ -612,6 +627,8 @@ void Window::collect_pairs() {
             pairs.push_back({hapc[st.index].data(), (int)hapc[st.index].size(), readc[r].data(), (int)readc[r].size()});
         }
     ends.clear();
+    traced_at.clear();
+    traced.clear();
 }
 
 // Reads are independent, so the pairs are dealt to g_threads workers when the caller allows more than one
@@ -634,14 +651,93 @@ void Window::ends_host() {
 
 Ends ends_of_pair(const int8_t* ref, int R, const int8_t* query, int Q) { return sw_ends(ref, R, query, Q); }
 
+bool trace_runs_host(const Window& w, const TraceJob& job, std::vector<int32_t>& runs) {
+    const SwPair& p = w.sw_pairs()[size_t(job.pair)];
+    std::vector<Run> rr;
+    runs.clear();
+    if (!banded_path(p.ref + job.ref_begin, p.query + job.read_begin, job.subR, job.subQ, job.score, job.band, rr)) return false;
+    for (const Run& r : rr) runs.push_back((r.len << 2) | (r.op == 'M' ? kTraceM : (r.op == 'I' ? kTraceI : kTraceD)));
+    return true;
+}
+
+// the rule of GetBestReadAlignment (:514-538) over the haplotypes in their sorted order; score(h) = the read's score on haplotype h
+template <class Score, class IsRef>
+int pick_haplotype(const std::vector<int>& order, Score&& score, IsRef&& is_reference) {
+    int best = 0, pick = -1;
+    for (int h : order) {
+        const int sc = score(h);
+        if (sc > best || (best > 0 && sc == best && !is_reference(h))) { best = sc; pick = h; }
+    }
+    return pick;
+}
+
+// the reference's std::sort by haplotype score (:108); ties keep whatever order that algorithm leaves them in
+std::vector<int> haplotype_order(const std::vector<HapState>& hs) {
+    std::vector<int> order(hs.size());
+    for (size_t h = 0; h < hs.size(); ++h) order[h] = int(h);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return hs[a].score < hs[b].score; });
+    return order;
+}
+
+void Window::plan_tracebacks(std::vector<TraceJob>& jobs) const {
+    const int n = (int)reads.size(), H = (int)haps.size();
+    if (ends.size() != pairs.size()) return;
+    std::vector<char> is_ref(size_t(H), 0);
+    for (int h = 0; h < H; ++h) {
+        TraceJob j{};
+        j.pair = h;
+        if (!trace_job(pairs[h].R, pairs[h].Q, ends[h], j)) continue;
+        jobs.push_back(j);
+        is_ref[size_t(h)] = ends[h].score == kMatch * pairs[h].Q;      // every base of the haplotype matched: one '=' run of its length
+    }
+    if (todo.empty()) return;
+    std::vector<int> noted(size_t(H) * size_t(n), -1);
+    size_t k = size_t(H);
+    for (int r : todo)
+        for (int hi = 0; hi < H; ++hi) {
+            const HapState& st = hs[size_t(hi)];
+            if (st.score == 0) continue;
+            const Ends& e = ends[k];
+            if (e.score > 0 && e.score >= kSswThreshold && st.hits[r].score < e.score) noted[size_t(hi) * n + r] = int(k);
+            ++k;
+        }
+    const std::vector<int> order = haplotype_order(hs);
+    for (int r : todo) {
+        const int pick = pick_haplotype(order, [&](int h) { const int at = noted[size_t(h) * n + r]; return at >= 0 ? ends[size_t(at)].score : hs[size_t(h)].hits[r].score; },
+                                        [&](int h) { return is_ref[size_t(h)] != 0; });
+        if (pick < 0 || noted[size_t(pick) * n + r] < 0) continue;
+        TraceJob j{};
+        j.pair = noted[size_t(pick) * n + r];
+        if (trace_job(pairs[size_t(j.pair)].R, pairs[size_t(j.pair)].Q, ends[size_t(j.pair)], j)) jobs.push_back(j);
+    }
+}
+
+void Window::set_traced(const TraceJob& job, bool ok, const int32_t* runs, int n_runs) {
+    if (traced_at.empty()) traced_at.assign(pairs.size(), -1);
+    SwAlignment al;
+    if (ok) {
+        std::vector<Run> rr(static_cast<size_t>(n_runs));
+        for (int i = 0; i < n_runs; ++i) rr[size_t(i)] = Run{"MID"[runs[i] & 3], int(runs[i] >> 2)};
+        const SwPair& p = pairs[size_t(job.pair)];
+        al = alignment_from_runs(p.ref, p.query, p.Q, ends[size_t(job.pair)], job, rr);
+    }
+    traced_at[size_t(job.pair)] = int(traced.size());
+    traced.push_back(std::move(al));
+}
+
 int Window::finish(int32_t* out_pos, std::vector<std::string>& out_cigar) {
     const int n = (int)reads.size(), H = (int)haps.size();
     CTO_REQUIRE(ends.size() == pairs.size(), CTO_EINVAL, "cto_realign_reads: stage 2 did not run");
+    // the traceback of pair k: taken from set_traced when it was done elsewhere, run here otherwise
+    auto finish_pair = [&](size_t k) -> SwAlignment {
+        if (!traced_at.empty() && traced_at[k] >= 0) return traced[size_t(traced_at[k])];
+        const SwPair& p = pairs[k];
+        return sw_finish(p.ref, p.R, p.query, p.Q, ends[k]);
+    };
     size_t k = 0;
     // haplotypes against the reference (:315-349), position maps (:507-512)
     for (HapState& st : hs) {
-        const SwPair& p = pairs[k];
-        const SwAlignment al = sw_finish(p.ref, p.R, p.query, p.Q, ends[k]);
+        const SwAlignment al = finish_pair(k);
         ++k;
         if (al.score > 0) {
             st.is_reference = al.cigar.size() == 1 && al.cigar[0].op == '=' && al.cigar[0].len == (int)haps[st.index].size();
@@ -664,10 +760,7 @@ int Window::finish(int32_t* out_pos, std::vector<std::string>& out_cigar) {
             ++k;
         }
 
-    // the reference's std::sort by haplotype score (:108); ties keep whatever order that algorithm leaves them in
-    std::vector<int> order(H);
-    for (int h = 0; h < H; ++h) order[h] = h;
-    std::sort(order.begin(), order.end(), [&](int a, int b) { return hs[a].score < hs[b].score; });
+    const std::vector<int> order = haplotype_order(hs);
 
     // every read onto the reference through its best haplotype (:386-433)
     out_cigar.assign(n, std::string());
@@ -676,22 +769,16 @@ int Window::finish(int32_t* out_pos, std::vector<std::string>& out_cigar) {
         out_cigar[r] = cigars[r];
         int pick = -1;
         for (;;) {
-            int best = 0;
-            pick = -1;
-            for (int kk = 0; kk < H; ++kk) {                      // GetBestReadAlignment (:514-538)
-                const HapState& st = hs[order[kk]];
-                const int at = noted.empty() ? -1 : noted[size_t(order[kk]) * n + r];
-                const int sc = at >= 0 ? ends[size_t(at)].score : st.hits[r].score;
-                if (sc > best || (best > 0 && sc == best && !st.is_reference)) { best = sc; pick = order[kk]; }
-            }
+            pick = pick_haplotype(order, [&](int h) { const int at = noted.empty() ? -1 : noted[size_t(h) * n + r];
+                                                      return at >= 0 ? ends[size_t(at)].score : hs[size_t(h)].hits[r].score; },
+                                  [&](int h) { return hs[size_t(h)].is_reference; });
             if (pick < 0 || noted.empty() || noted[size_t(pick) * n + r] < 0) break;
             // The pick is a noted pair: its traceback now.  Success installs the hit with the score it was noted with (the pick
             // stands); a failure leaves the read's hit on that haplotype as it was, which can only lower that entry - and lowering an
             // entry that was not picked never changes the pick, so the pairs not traced leave no trace - and the choice is made again.
             const size_t at = size_t(noted[size_t(pick) * n + r]);
             noted[size_t(pick) * n + r] = -1;
-            const SwPair& p = pairs[at];
-            const SwAlignment al = sw_finish(p.ref, p.R, p.query, p.Q, ends[at]);
+            const SwAlignment al = finish_pair(at);
             ReadHit& hit = hs[size_t(pick)].hits[r];
             if (al.score > 0 && al.score >= kSswThreshold && hit.score < al.score) {
                 hit.score = al.score;

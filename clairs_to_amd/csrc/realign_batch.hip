@@ -490,7 +490,8 @@ int launch_sw(hipStream_t s, const signed char* pool, const SwDesc* desc, const 
 }
 
 // Both passes of every alignment of `desc` (operands = base codes in `pool`): the end points, in desc order
-int sw_ends_pool(const std::vector<signed char>& pool, const std::vector<SwDesc>& desc, hipStream_t s, cto_realign_stats* st, std::vector<Ends>& ends) {
+int sw_ends_pool(const std::vector<signed char>& pool, const std::vector<SwDesc>& desc, hipStream_t s, cto_realign_stats* st, std::vector<Ends>& ends,
+                 DevBuf<signed char>* keep_pool = nullptr) {
     StageClock clk;
     const int n = int(desc.size());
     ends.assign(static_cast<size_t>(n), Ends{0, 0, 0, 0, 0, 16});
@@ -576,16 +577,21 @@ int sw_ends_pool(const std::vector<signed char>& pool, const std::vector<SwDesc>
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     drop();
     if (st) { st->sw_ms += ms; st->sw_pairs += n; st->sw_cells += cells; }
+    if (keep_pool) std::swap(keep_pool->p, d_pool.p);
     clk.lap("  SW: launches + D2H");
     return CTO_OK;
 }
 
-int ends_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats* st) {
+struct SwStage { std::vector<SwDesc> desc; std::vector<size_t> first; DevBuf<signed char> d_pool; };     // what the traceback stage re-uses
+
+int ends_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats* st, SwStage& stage) {
     StageClock clk;
     // code pool: per window the reference, its haplotypes, the reads that need Smith-Waterman - each once
     std::vector<signed char> pool;
-    std::vector<SwDesc> desc;
-    std::vector<size_t> first(ws.size() + 1, 0);
+    std::vector<SwDesc>& desc = stage.desc;
+    std::vector<size_t>& first = stage.first;
+    desc.clear();
+    first.assign(ws.size() + 1, 0);
     for (size_t wi = 0; wi < ws.size(); ++wi) {
         Window& w = *ws[wi];
         first[wi] = desc.size();
@@ -610,9 +616,210 @@ int ends_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats* st) 
     if (desc.empty()) return CTO_OK;
     clk.lap("  SW: pool + descriptors");
     std::vector<Ends> ends;
-    const int rc = sw_ends_pool(pool, desc, s, st, ends);
+    const int rc = sw_ends_pool(pool, desc, s, st, ends, &stage.d_pool);
     if (rc != CTO_OK) return rc;
     for (size_t wi = 0; wi < ws.size(); ++wi) ws[wi]->set_ends(ends.data() + first[wi]);
+    return CTO_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Banded traceback (ssw.c:531-741 as restated in realign.cpp's banded_path, which is what the reference's compiled code is held to):
+// one wavefront per alignment.  A row of the band is computed by the lanes side by side - E and the diagonal term of a cell depend on
+// the previous row only, and the F chain along the row, f[j] = max(h[j-1] - open, f[j-1] - ext), is a max-plus scan because an h that
+// owes its value to f cannot win that max (f - open < f - ext): f[j] = max over k < j of (h'[k] - open - ext * (j-1-k)) with h' = the cell
+// without its F term.  The three rolling arrays (previous H, E, current H) live in LDS with the reference's own indices, zeroed edge cells
+// included; direction choices (one byte per cell: E's, F's, H's) go to a scratch region in HBM, rows the band does not reach written
+// as 0 = "not a cell" as the host's zero-filled array has them.  The band doubles until the best cell reaches the score the striped passes
+// found; lane 0 then walks back from the last cell.  Runs leave in walk order (the host reverses them).
+constexpr int TB_RUNS = 61;
+struct TbDesc { int ref_off, q_off, R, Q, score, band, band_cap, pad; long long dir_off; };
+struct TbOut { int status, n_runs, band; int runs[TB_RUNS]; };          // status 1 = done, 0 = the reference's traceback fails, 2 = not done here
+constexpr int TB_NEG = -(1 << 28);
+
+__global__ __launch_bounds__(64) void k_banded(const signed char* __restrict__ pool, const TbDesc* __restrict__ desc, const int* __restrict__ order,
+                                                int n, unsigned char* dirbuf, TbOut* __restrict__ out, int W) {
+    extern __shared__ int tb_lds[];
+    if (int(blockIdx.x) >= n) return;
+    const int k = order[blockIdx.x];
+    const int lane = threadIdx.x;
+    const TbDesc d = desc[k];
+    const signed char* ref = pool + d.ref_off;
+    const signed char* read = pool + d.q_off;
+    unsigned char* dir = dirbuf + d.dir_off;
+    int* hb = tb_lds;
+    int* eb = tb_lds + W;
+    int* hc = tb_lds + 2 * W;
+    const int R = d.R, Q = d.Q;
+    for (int i = lane; i < 3 * W; i += 64) tb_lds[i] = 0;
+    int band = d.band, best = 0, status = 1, width_d = 0;
+    for (;;) {
+        const int width = band * 2 + 3;
+        width_d = band * 2 + 1;
+        __syncthreads();
+        for (int j = 1 + lane; j < width - 1; j += 64) hb[j] = 0;
+        for (int i = 0; i < Q; ++i) {
+            const int x = max(0, i - band), dx = x - max(0, i - 1 - band);
+            const int end = min(R - 1, i + band), nc = end - x + 1;             // cells of this row: j = x .. end
+            const int edge = min(end + 1, width - 1);
+            __syncthreads();
+            if (lane == 0) { hb[0] = 0; eb[0] = 0; hb[edge] = 0; eb[edge] = 0; hc[0] = 0; }
+            __syncthreads();
+            const int ri = read[i];
+            int carry = kGapE * x - 4;                       // the F chain that enters the row: f = 0 before the first cell, h[-1] = 0
+            int g_prev = -kGapO, f_prev = 0;
+            unsigned char* line = dir + size_t(i) * size_t(width_d);
+            for (int c0 = 0; c0 < width_d; c0 += 64) {
+                const int jj = c0 + lane;
+                const bool valid = jj < nc;
+                const int j = x + jj, u = jj + 1, up = u + dx;
+                const int hbu = valid ? hb[up] : 0, ebu = valid ? eb[up] : 0, hbd = valid ? hb[up - 1] : 0;
+                const int t1 = i == 0 ? -kGapO : hbu - kGapO, t2 = i == 0 ? -kGapE : ebu - kGapE;
+                const int e = max(t1, t2);
+                const bool de3 = t1 > t2;
+                const int rj = valid ? ref[j] : 0;
+                const int sc = (rj == ri && rj < 4) ? 4 : -6;
+                const int t2h = hbd + sc, e1 = max(e, 0), hp = max(e1, t2h), g = hp - kGapO;
+                int incl = valid ? g + kGapE * j : TB_NEG;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl = max(incl, t); }
+                int excl = __shfl_up(incl, 1);
+                if (lane == 0) excl = TB_NEG;
+                const int f = max(carry, excl) - kGapE * (j - 1);
+                int gp = __shfl_up(g, 1), fp = __shfl_up(f, 1);
+                if (lane == 0) { gp = g_prev; fp = f_prev; }
+                const bool df5 = gp > fp - kGapE;
+                const int f1 = max(f, 0), tt1 = max(e1, f1), h = max(tt1, t2h);
+                const int dh = tt1 <= t2h ? 1 : (e1 > f1 ? (de3 ? 3 : 2) : (df5 ? 5 : 4));
+                if (valid) { eb[u] = e; hc[u] = h; best = max(best, h); }
+                if (jj < width_d) line[jj] = valid ? static_cast<unsigned char>(int(de3) | (int(df5) << 1) | (dh << 2)) : static_cast<unsigned char>(0);
+                carry = max(carry, __shfl(incl, 63));
+                g_prev = __shfl(g, 63); f_prev = __shfl(f, 63);
+            }
+            __syncthreads();
+            for (int u = 1 + lane; u <= nc; u += 64) hb[u] = hc[u];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
+        if (best >= d.score) break;
+        band *= 2;
+        if (band > d.band_cap) { status = 2; break; }
+    }
+    __threadfence();
+    __syncthreads();
+    if (lane != 0) return;
+    TbOut& o = out[k];
+    int nr = 0;
+    if (status == 1) {
+        int i = Q - 1, j = R - 1, state = 2, count = 0, op = cto_realign::kTraceM, prev = cto_realign::kTraceM;
+        const volatile unsigned char* vdir = dir;
+        while (i > 0) {
+            const int x = i - band > 0 ? i - band : 0;
+            if (j < x || j - x >= width_d) { status = 0; break; }
+            const int b = vdir[size_t(i) * size_t(width_d) + size_t(j - x)];
+            if (b == 0) { status = 0; break; }
+            const int dd = state == 0 ? 2 + (b & 1) : (state == 1 ? 4 + ((b >> 1) & 1) : (b >> 2));
+            if (dd == 1) { --i; --j; state = 2; op = cto_realign::kTraceM; }
+            else if (dd == 2) { --i; state = 0; op = cto_realign::kTraceI; }
+            else if (dd == 3) { --i; state = 2; op = cto_realign::kTraceI; }
+            else if (dd == 4) { --j; state = 1; op = cto_realign::kTraceD; }
+            else { --j; state = 2; op = cto_realign::kTraceD; }
+            if (op == prev) ++count;
+            else {
+                if (nr >= TB_RUNS) { status = 2; break; }
+                o.runs[nr++] = (count << 2) | prev;
+                prev = op; count = 1;
+            }
+        }
+        if (status == 1) {
+            if (nr + 2 > TB_RUNS) status = 2;
+            else if (op == cto_realign::kTraceM) o.runs[nr++] = ((count + 1) << 2) | op;
+            else { o.runs[nr++] = (count << 2) | op; o.runs[nr++] = (1 << 2) | cto_realign::kTraceM; }
+        }
+    }
+    o.status = status; o.n_runs = nr; o.band = band;
+}
+
+// the tracebacks the windows are going to ask for (Window::plan_tracebacks), on the device; what the device declines stays for finish()
+int traceback_device(std::vector<Window*>& ws, const SwStage& stage, hipStream_t s, int threads, cto_realign_stats* st) {
+    StageClock clk;
+    std::vector<std::vector<cto_realign::TraceJob>> jobs(ws.size());
+    parallel_for(ws.size(), threads, [&](size_t i) { ws[i]->plan_tracebacks(jobs[i]); });
+    std::vector<TbDesc> desc;
+    std::vector<std::pair<int, int>> who;                   // (window, job)
+    size_t dir_bytes = 0;
+    constexpr int kBandMax = 1024;
+    constexpr size_t kDirMax = size_t(6) << 30;
+    for (size_t wi = 0; wi < ws.size(); ++wi)
+        for (size_t ji = 0; ji < jobs[wi].size(); ++ji) {
+            const cto_realign::TraceJob& j = jobs[wi][ji];
+            if (j.band > kBandMax) continue;                // finish() runs it on the host
+            const int cap = std::min(kBandMax, j.band * 4);
+            const size_t need = (size_t(j.subQ) * size_t(2 * cap + 1) + 63) & ~size_t(63);
+            if (dir_bytes + need > kDirMax) continue;
+            const SwDesc& p = stage.desc[stage.first[wi] + size_t(j.pair)];
+            desc.push_back(TbDesc{p.ref_off + j.ref_begin, p.q_off + j.read_begin, j.subR, j.subQ, j.score, j.band, cap, 0, (long long)dir_bytes});
+            who.emplace_back(int(wi), int(ji));
+            dir_bytes += need;
+        }
+    const int n = int(desc.size());
+    if (n == 0) return CTO_OK;
+    // two classes by the widest band an alignment may reach (the LDS footprint), longest first inside a class
+    std::vector<int> order(static_cast<size_t>(n));
+    for (int k = 0; k < n; ++k) order[size_t(k)] = k;
+    auto wide = [&](int k) { return desc[size_t(k)].band_cap > 62; };
+    std::sort(order.begin(), order.end(), [&](int a, int b) {
+        if (wide(a) != wide(b)) return wide(a);
+        const long long wa = (long long)desc[size_t(a)].Q * desc[size_t(a)].band, wb = (long long)desc[size_t(b)].Q * desc[size_t(b)].band;
+        return wa != wb ? wa > wb : a < b;
+    });
+    int n_wide = 0, cap_wide = 0;
+    for (int k = 0; k < n; ++k) if (wide(k)) { ++n_wide; cap_wide = std::max(cap_wide, desc[size_t(k)].band_cap); }
+    clk.lap("  traceback: plan + descriptors");
+    DevBuf<TbDesc> d_desc;
+    DevBuf<int> d_order;
+    DevBuf<TbOut> d_out;
+    DevBuf<unsigned char> d_dir;
+    int rc;
+    if ((rc = d_desc.put(desc, s)) || (rc = d_order.put(order, s)) || (rc = d_out.alloc(size_t(n))) || (rc = d_dir.alloc(dir_bytes))) return rc;
+    hipEvent_t e0, e1;
+    CTO_HIP(hipEventCreate(&e0)); CTO_HIP(hipEventCreate(&e1));
+    CTO_HIP(hipEventRecord(e0, s));
+    auto launch = [&](int first, int count, int cap) -> int {
+        if (count == 0) return CTO_OK;
+        const int W = 2 * cap + 4;
+        hipLaunchKernelGGL(k_banded, dim3(unsigned(count)), dim3(64), size_t(3) * W * sizeof(int), s, stage.d_pool.p, d_desc.p, d_order.p + first, count,
+                           d_dir.p, d_out.p, W);
+        CTO_HIP(hipGetLastError());
+        return CTO_OK;
+    };
+    if ((rc = launch(0, n_wide, cap_wide)) || (rc = launch(n_wide, n - n_wide, 62))) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
+    CTO_HIP(hipEventRecord(e1, s));
+    std::vector<TbOut> out(static_cast<size_t>(n));
+    CTO_HIP(hipMemcpyAsync(out.data(), d_out.p, size_t(n) * sizeof(TbOut), hipMemcpyDeviceToHost, s));
+    CTO_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    CTO_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (st) { st->traceback_ms += ms; st->tracebacks += n; }
+    clk.lap("  traceback: launches + D2H");
+    // a window's results are installed by one worker (set_traced appends to the window's own vectors)
+    std::vector<size_t> wfirst(ws.size() + 1, size_t(n));
+    for (int k = n - 1; k >= 0; --k) wfirst[size_t(who[size_t(k)].first)] = size_t(k);
+    for (size_t wi = ws.size(); wi-- > 0;) if (wfirst[wi] == size_t(n)) wfirst[wi] = wfirst[wi + 1];
+    long long declined = 0;
+    for (int k = 0; k < n; ++k) declined += out[size_t(k)].status == 2;
+    if (st) st->tracebacks_declined += declined;
+    parallel_for(ws.size(), threads, [&](size_t wi) {
+        for (size_t k = wfirst[wi]; k < wfirst[wi + 1]; ++k) {
+            const TbOut& o = out[k];
+            if (o.status == 2) continue;
+            int32_t runs[TB_RUNS];
+            for (int i = 0; i < o.n_runs; ++i) runs[i] = o.runs[o.n_runs - 1 - i];
+            ws[wi]->set_traced(jobs[wi][size_t(who[k].second)], o.status == 1, runs, o.n_runs);
+        }
+    });
+    clk.lap("  traceback: CIGARs");
     return CTO_OK;
 }
 
@@ -687,12 +894,31 @@ extern "C" int cto_realign_windows(int n_jobs, cto_realign_job* jobs, int where,
         clk.lap("fast pass (device, copies)");
         parallel_for(dev.size(), threads, [&](size_t i) { dev[i]->collect_pairs(); });
         clk.lap("collect pairs");
-        rc = ends_device(dev, s, stats);
+        SwStage stage;
+        rc = ends_device(dev, s, stats, stage);
         if (rc != CTO_OK) return rc;
         clk.lap("SW ends (device, copies)");
+        static const bool host_traceback = std::getenv("CTO_REALIGN_HOST_TRACEBACK") != nullptr;      // A/B switch: every traceback in finish()
+        if (!host_traceback) {
+            rc = traceback_device(dev, stage, s, threads, stats);
+            if (rc != CTO_OK) return rc;
+            clk.lap("tracebacks (device, copies)");
+        }
     }
     const double t1 = now_ms();
-    parallel_for(host.size(), threads, [&](size_t i) { host[i]->fast_pass_host(); host[i]->collect_pairs(); host[i]->ends_host(); });
+    // CTO_REALIGN_PLAN_HOST=1 (tests): the host windows' tracebacks go the way the device stage's do - planned, run, installed - before finish()
+    const bool plan_host = std::getenv("CTO_REALIGN_PLAN_HOST") != nullptr;
+    parallel_for(host.size(), threads, [&](size_t i) {
+        host[i]->fast_pass_host(); host[i]->collect_pairs(); host[i]->ends_host();
+        if (!plan_host) return;
+        std::vector<cto_realign::TraceJob> jobs;
+        host[i]->plan_tracebacks(jobs);
+        std::vector<int32_t> runs;
+        for (const cto_realign::TraceJob& j : jobs) {
+            const bool ok = cto_realign::trace_runs_host(*host[i], j, runs);
+            host[i]->set_traced(j, ok, runs.data(), int(runs.size()));
+        }
+    });
     parallel_for(ws.size(), threads, [&](size_t i) {
         if (status[i] != CTO_OK) return;
         cto_realign_job& j = jobs[i];

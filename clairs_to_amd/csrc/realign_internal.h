@@ -26,6 +26,11 @@ struct HapState {
 };
 
 struct SwPair { const int8_t* ref; int R; const int8_t* query; int Q; };
+struct SwAlignment { int score = 0, ref_begin = 0; std::vector<Op> cigar; };     // what ssw's Align returns of an alignment (ssw_cpp.cpp:78-215)
+// The banded traceback of pair `pair` (ssw.c:531-741, as ssw_align calls it, :831-867): the sub-problem between the end points the
+// striped passes found - ref[ref_begin .. +subR), query[read_begin .. +subQ), the score to reach, the first band.
+struct TraceJob { int pair, ref_begin, read_begin, subR, subQ, score, band; };
+constexpr int kTraceM = 0, kTraceI = 1, kTraceD = 2;                               // a run = len << 2 | op, in query order
 
 class Window {
 public:
@@ -44,6 +49,11 @@ public:
     void ends_host();
     void set_ends(const Ends* e) { ends.assign(e, e + pairs.size()); }
     // ---- stage 3
+    // the tracebacks finish() is going to ask for if every one of them confirms its score (a prediction: finish() computes what it
+    // finds missing itself): every haplotype against the reference, and per unplaced read the pair it would pick
+    void plan_tracebacks(std::vector<TraceJob>& jobs) const;
+    // a traceback done elsewhere (the device): ok = the banded pass reached the score and the walk stayed inside the band
+    void set_traced(const TraceJob& job, bool ok, const int32_t* runs, int n_runs);
     int finish(int32_t* out_pos, std::vector<std::string>& out_cigar);
 
     std::vector<std::string> reads, haps;
@@ -57,11 +67,15 @@ public:
     std::vector<int> todo;
     std::vector<SwPair> pairs;
     std::vector<Ends> ends;
+    std::vector<int> traced_at;                        // pair -> index into traced, -1 = not done elsewhere
+    std::vector<SwAlignment> traced;
 };
 
 int get_threads();
 // the two striped passes of one alignment on the host (ssw.c:781-830): what Window::ends_host runs per pair
 Ends ends_of_pair(const int8_t* ref, int R, const int8_t* query, int Q);
+// a planned traceback on the host, in set_traced's format (what the device stage delivers); false = the banded pass fails
+bool trace_runs_host(const Window& w, const TraceJob& job, std::vector<int32_t>& runs);
 
 }  // namespace cto_realign
 

@@ -566,6 +566,8 @@ typedef struct cto_realign_stats {
     int64_t sw_pairs, sw_cells;        /* device Smith-Waterman alignments and their ref x query cells          */
     double fast_pass_ms, sw_ms;        /* HIP-event time of the two launches                                    */
     double device_stage_ms, host_ms;   /* wall time up to / after the device stages (packing and copies included) */
+    int64_t tracebacks, tracebacks_declined;   /* banded tracebacks sent to the device; those it left to the host     */
+    double traceback_ms;               /* HIP-event time of their launches                                      */
 } cto_realign_stats;
 #define CTO_REALIGN_HOST   0
 #define CTO_REALIGN_DEVICE 1

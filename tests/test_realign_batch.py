@@ -104,3 +104,17 @@ def test_sw_ends_batch_host_equals_the_scalar_model():
         word += int(o[5] == 8)
     assert word > 100
     assert sw_ends_batch([], "host").shape == (0, 6)
+
+
+def test_planned_tracebacks_give_the_same_windows(monkeypatch):
+    """The device stage's plumbing on the host (CTO_REALIGN_PLAN_HOST=1): the tracebacks finish() will ask for are planned from the end
+    points (every haplotype against the reference, per unplaced read the pair it would pick), run, and installed as runs - the windows
+    come out as without the plan (golden POS + CIGAR), and nearly every traceback finish() needs was planned."""
+    with gzip.open(os.path.join(HERE, "golden", "realign.json.gz"), "rb") as f:
+        g = json.loads(f.read())
+    rng = np.random.default_rng(g["seed"])
+    ws = [ru.gen_window(rng) for _ in g["windows"][:250]]
+    monkeypatch.setenv("CTO_REALIGN_PLAN_HOST", "1")
+    got = ru.amd_realign_batch(ws, "host", threads=3)
+    for w, (pos, cig), want in zip(ws, got, g["windows"]):
+        assert [[p - w["ref_start"], c] for p, c in zip(pos, cig)] == want
