@@ -23,6 +23,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <thread>
 #include "common.h"
@@ -390,6 +391,20 @@ void parallel_for(size_t n, int threads, F&& f) {
     for (std::thread& t : pool) t.join();
 }
 
+struct Reaper {
+    std::mutex m;
+    std::thread t;
+    void wait() { if (t.joinable()) t.join(); }
+    ~Reaper() { wait(); }
+};
+Reaper g_reaper;
+void reap(std::vector<Window>&& ws) {
+    std::lock_guard<std::mutex> lock(g_reaper.m);
+    g_reaper.wait();
+    auto* gone = new std::vector<Window>(std::move(ws));
+    g_reaper.t = std::thread([gone]() { delete gone; });
+}
+
 bool device_eligible(const Window& w) {
     if (w.reference.size() > size_t(FP_LMAX) || w.haps.empty()) return false;
     for (const std::string& h : w.haps) if (h.size() > size_t(FP_LMAX)) return false;
@@ -476,9 +491,12 @@ int launch_sw(hipStream_t s, const signed char* pool, const SwDesc* desc, const 
     constexpr int LW = BYTE ? 16 : 8;
     // A pass is a chain of dependent steps: a wavefront runs it at the pace of ONE row whatever the number of rows it holds, so a
     // class with few alignments (the haplotype-length one: ~2 500 of the bench's batch) spreads them over more wavefronts - rows per
-    // wavefront halve until the class has a wavefront for every SIMD of the chip (1 024) or one row per wavefront is reached
+    // wavefront halve until the class has 512 wavefronts (CTO_SW_MIN_WAVES) or one row per wavefront.  Not further: the classes run
+    // side by side and together keep every SIMD busy, where a wavefront with idle lanes costs the others its issue slots (measured
+    // on the bench batch: 0 -> 17.4 ms, 256 / 512 -> 15.5, 1 024 -> 17.3, 2 048 -> 24.5)
     int ROWS = 64 / LW;
-    while (ROWS > 1 && (n + ROWS - 1) / ROWS < 1024) ROWS /= 2;
+    static const int min_waves = std::getenv("CTO_SW_MIN_WAVES") ? atoi(std::getenv("CTO_SW_MIN_WAVES")) : 512;
+    while (ROWS > 1 && (n + ROWS - 1) / ROWS < min_waves) ROWS /= 2;
     Rcap = (Rcap + 15) & ~15; Qcap = (Qcap + 15) & ~15;
     const int segcap = (Qcap + LW - 1) / LW;
     const size_t smem = ((sw_row_bytes(Rcap, Qcap, segcap, LW) + 15) / 16 * 16) * ROWS;
@@ -785,15 +803,33 @@ int traceback_device(std::vector<Window*>& ws, const SwStage& stage, hipStream_t
     hipEvent_t e0, e1;
     CTO_HIP(hipEventCreate(&e0)); CTO_HIP(hipEventCreate(&e1));
     CTO_HIP(hipEventRecord(e0, s));
-    auto launch = [&](int first, int count, int cap) -> int {
+    // the few wide-band alignments are a tail of their own: on a second stream beside the many narrow ones
+    hipStream_t s2 = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    if (n_wide > 0 && n_wide < n) {
+        CTO_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        CTO_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming)); CTO_HIP(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+        CTO_HIP(hipEventRecord(fork, s)); CTO_HIP(hipStreamWaitEvent(s2, fork, 0));
+    }
+    hipStream_t s_wide = s2 ? s2 : s;
+    auto launch_on = [&](hipStream_t t, int first, int count, int cap) -> int {
         if (count == 0) return CTO_OK;
         const int W = 2 * cap + 4;
-        hipLaunchKernelGGL(k_banded, dim3(unsigned(count)), dim3(64), size_t(3) * W * sizeof(int), s, stage.d_pool.p, d_desc.p, d_order.p + first, count,
+        hipLaunchKernelGGL(k_banded, dim3(unsigned(count)), dim3(64), size_t(3) * W * sizeof(int), t, stage.d_pool.p, d_desc.p, d_order.p + first, count,
                            d_dir.p, d_out.p, W);
         CTO_HIP(hipGetLastError());
         return CTO_OK;
     };
-    if ((rc = launch(0, n_wide, cap_wide)) || (rc = launch(n_wide, n - n_wide, 62))) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
+    rc = launch_on(s_wide, 0, n_wide, cap_wide);
+    if (rc == CTO_OK) rc = launch_on(s, n_wide, n - n_wide, 62);
+    if (s2) {
+        if (rc == CTO_OK && (hipEventRecord(join, s2) != hipSuccess || hipStreamWaitEvent(s, join, 0) != hipSuccess)) rc = CTO_EHIP;
+        if (rc != CTO_OK) (void)hipStreamSynchronize(s2);
+    }
+    auto drop = [&]() {
+        if (s2) { (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2); (void)hipEventDestroy(fork); (void)hipEventDestroy(join); s2 = nullptr; }
+    };
+    if (rc != CTO_OK) { drop(); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
     CTO_HIP(hipEventRecord(e1, s));
     std::vector<TbOut> out(static_cast<size_t>(n));
     CTO_HIP(hipMemcpyAsync(out.data(), d_out.p, size_t(n) * sizeof(TbOut), hipMemcpyDeviceToHost, s));
@@ -801,6 +837,7 @@ int traceback_device(std::vector<Window*>& ws, const SwStage& stage, hipStream_t
     float ms = 0.f;
     CTO_HIP(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    drop();
     if (st) { st->traceback_ms += ms; st->tracebacks += n; }
     clk.lap("  traceback: launches + D2H");
     // a window's results are installed by one worker (set_traced appends to the window's own vectors)
@@ -939,9 +976,11 @@ extern "C" int cto_realign_windows(int n_jobs, cto_realign_job* jobs, int where,
         for (const Window& w : ws) { stats->reads += w.n_reads(); stats->haplotypes += w.n_haps(); }
         stats->device_stage_ms = t1 - t0;
     }
-    // a window owns thousands of small vectors (a hit per read and haplotype): given back by the workers, not by the caller alone
-    parallel_for(ws.size(), threads, [&](size_t i) { ws[i] = Window(); });
+    // A window owns thousands of small vectors (a hit per read and haplotype) and giving ~100 k of them back costs as much as the
+    // traceback stage (and more when many threads free into each other's arenas): the windows are handed to a thread that does it
+    // behind the caller's back; the next call (or the library's unloading) waits for it.
     if (stats) stats->host_ms = now_ms() - t1;
+    reap(std::move(ws));
     if (first_bad >= 0) { cto::set_error("window %d: %s", first_bad, errors[size_t(first_bad)].c_str()); return status[size_t(first_bad)]; }
     return CTO_OK;
 }
