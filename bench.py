@@ -442,12 +442,13 @@ def realign_leg(dev, n_windows=1500, seed=20260930):
         "fast_pass_pairs": int(st["fast_pairs"]), "sw_alignments": int(st["sw_pairs"]), "sw_cells": int(st["sw_cells"]),
         "sw_gcups": round(st["sw_cells"] / (st["sw_ms"] * 1e-3) / 1e9, 2) if st["sw_ms"] > 0 else None,
         "device_stage_wall_ms": round(st["device_stage_ms"], 2), "host_stage_wall_ms": round(st["host_ms"], 2),
+        "kernel_traceback_ms": round(st["traceback_ms"], 3), "tracebacks": int(st["tracebacks"]), "tracebacks_left_to_host": int(st["tracebacks_declined"]),
         "windows_on_host": int(st["host_windows"])})
     out = {"workload": "%d synthetic Illumina realignment windows, %d reads (BASELINE configs[3]: realign_reads path)" % (n_windows, reads),
            "cores": cores, "outputs_equal": bool(host == devo and host[:sub] == one), **legs,
            "note": "one cto_realign_windows call per figure; seconds / reads_per_s include the Python side (every read and CIGAR of the list joined into one buffer each, the outputs split again: seconds - c_call_seconds), c_call_seconds / reads_per_s_c_call are the C call alone (what a C or C++ orchestrator pays); the reference's own library on one core runs "
                    "this generator's windows at ~3.8 k reads/s (tools/realign_bench.py, build container); kernel times are HIP events, "
-                   "sw_gcups = reference x query cells of every alignment / k_sw_ends time (both passes of an alignment counted once)"}
+                   "sw_gcups = reference x query cells of every alignment / k_sw time (both passes of an alignment counted once); tracebacks = banded tracebacks run by k_banded (every haplotype against the reference + the pair each unplaced read picks)"}
     return out
 
 

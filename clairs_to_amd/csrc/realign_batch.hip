@@ -419,7 +419,7 @@ struct StageClock {
     void lap(const char* what) { if (trace_on()) { const double n = now_ms(); std::fprintf(stderr, "[realign] %-28s %8.3f ms\n", what, n - t); t = n; } }
 };
 
-int fast_pass_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats* st) {
+int fast_pass_device(std::vector<Window*>& ws, hipStream_t s, int threads, cto_realign_stats* st) {
     StageClock clk;
     std::vector<unsigned char> hap_bytes, read_bytes, hap_isref;
     std::vector<int> hap_off{0}, hap_win, read_off{0}, win_read0{0}, win_prefix, win_suffix;
@@ -475,12 +475,12 @@ int fast_pass_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats*
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (st) { st->fast_pass_ms += ms; st->fast_pairs += hits; }
     clk.lap("  fast pass: kernel + D2H");
-    size_t hcur = 0;
-    for (Window* w : ws) {
-        const size_t H = size_t(w->n_haps());
-        w->set_fast_pass(hit_score.data() + hit_off[hcur], hit_pos.data() + hit_off[hcur], hap_score.data() + hcur);
-        hcur += H;
-    }
+    std::vector<size_t> hfirst(ws.size() + 1, 0);
+    for (size_t wi = 0; wi < ws.size(); ++wi) hfirst[wi + 1] = hfirst[wi] + size_t(ws[wi]->n_haps());
+    parallel_for(ws.size(), threads, [&](size_t wi) {
+        const size_t hcur = hfirst[wi];
+        if (ws[wi]->n_haps() > 0) ws[wi]->set_fast_pass(hit_score.data() + hit_off[hcur], hit_pos.data() + hit_off[hcur], hap_score.data() + hcur);
+    });
     return CTO_OK;
 }
 
@@ -602,7 +602,7 @@ int sw_ends_pool(const std::vector<signed char>& pool, const std::vector<SwDesc>
 
 struct SwStage { std::vector<SwDesc> desc; std::vector<size_t> first; DevBuf<signed char> d_pool; };     // what the traceback stage re-uses
 
-int ends_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats* st, SwStage& stage) {
+int ends_device(std::vector<Window*>& ws, hipStream_t s, int threads, cto_realign_stats* st, SwStage& stage) {
     StageClock clk;
     // code pool: per window the reference, its haplotypes, the reads that need Smith-Waterman - each once
     std::vector<signed char> pool;
@@ -636,7 +636,7 @@ int ends_device(std::vector<Window*>& ws, hipStream_t s, cto_realign_stats* st, 
     std::vector<Ends> ends;
     const int rc = sw_ends_pool(pool, desc, s, st, ends, &stage.d_pool);
     if (rc != CTO_OK) return rc;
-    for (size_t wi = 0; wi < ws.size(); ++wi) ws[wi]->set_ends(ends.data() + first[wi]);
+    parallel_for(ws.size(), threads, [&](size_t wi) { ws[wi]->set_ends(ends.data() + first[wi]); });
     return CTO_OK;
 }
 
@@ -926,13 +926,13 @@ extern "C" int cto_realign_windows(int n_jobs, cto_realign_job* jobs, int where,
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!dev.empty()) {
-        int rc = fast_pass_device(dev, s, stats);
+        int rc = fast_pass_device(dev, s, threads, stats);
         if (rc != CTO_OK) return rc;
         clk.lap("fast pass (device, copies)");
         parallel_for(dev.size(), threads, [&](size_t i) { dev[i]->collect_pairs(); });
         clk.lap("collect pairs");
         SwStage stage;
-        rc = ends_device(dev, s, stats, stage);
+        rc = ends_device(dev, s, threads, stats, stage);
         if (rc != CTO_OK) return rc;
         clk.lap("SW ends (device, copies)");
         static const bool host_traceback = std::getenv("CTO_REALIGN_HOST_TRACEBACK") != nullptr;      // A/B switch: every traceback in finish()

@@ -541,7 +541,8 @@ int cto_ssw_align(const char* ref, const char* query, int32_t* score, int32_t* r
  * workers (<= 0: cto_set_realign_threads' value), each running what cto_realign_reads runs.  where = CTO_REALIGN_DEVICE: the k-mer
  * fast pass (realigner.cpp:129-229) of every (window, haplotype) and both striped Smith-Waterman passes (ssw.c:118-529 as
  * ssw_align drives them, :781-830) of every haplotype / reference and unplaced-read / haplotype pair run as two launches on `stream`
- * (HIP device current to the caller); the banded traceback and the CIGAR composition stay on the host (host_threads workers).
+ * (HIP device current to the caller), the banded tracebacks (ssw.c:531-741) the windows will need - every haplotype against the reference,
+ * per unplaced read the pair it picks - as a third stage (k_banded); CIGAR composition stays on the host (host_threads workers).
  * Windows the device form does not take (a haplotype or the reference longer than 2 048 bases, a read longer than 512) run on the
  * host inside the same call.  Outputs are the reference's byte for byte either way (tests/test_gpu_realign.py holds both to
  * oracle/_ref).  jobs[i].status is that window's code; the return value is the first failing window's code. */
