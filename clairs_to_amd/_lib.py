@@ -133,6 +133,7 @@ SYMBOLS = {
     "cto_qual_pending": (C.c_int, [c_vp, c_i64, c_vp, c_vp]),
     "cto_realign_windows": (C.c_int, [C.c_int, C.POINTER(RealignJob), C.c_int, C.c_int, c_vp, C.POINTER(RealignStats)]),
     "cto_sw_ends_batch": (C.c_int, [C.c_int, c_vp, C.c_size_t, c_vp, C.c_int, C.c_int, c_vp, c_vp]),
+    "cto_ssw_align_batch": (C.c_int, [C.c_int, c_vp, C.c_size_t, c_vp, C.c_int, C.c_int, c_vp, c_vp, c_vp, c_vp, C.c_size_t, c_vp]),
     "cto_ssw_align": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(c_i32), C.POINTER(c_i32), c_vp, C.c_size_t]),
     "cto_ssw_pass": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),
     "cto_set_realign_threads": (C.c_int, [C.c_int]),

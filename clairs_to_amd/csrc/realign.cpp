@@ -651,6 +651,14 @@ void Window::ends_host() {
 
 Ends ends_of_pair(const int8_t* ref, int R, const int8_t* query, int Q) { return sw_ends(ref, R, query, Q); }
 
+bool plan_pair(int R, int Q, const Ends& e, TraceJob& j) { return trace_job(R, Q, e, j); }
+SwAlignment alignment_of_pair(const int8_t* ref, int R, const int8_t* query, int Q, const Ends& e) { return sw_finish(ref, R, query, Q, e); }
+SwAlignment alignment_from_device_runs(const int8_t* ref, const int8_t* query, int Q, const Ends& e, const TraceJob& j, const int32_t* runs, int n_runs) {
+    std::vector<Run> rr(static_cast<size_t>(n_runs));
+    for (int i = 0; i < n_runs; ++i) rr[size_t(i)] = Run{"MID"[runs[i] & 3], int(runs[i] >> 2)};
+    return alignment_from_runs(ref, query, Q, e, j, rr);
+}
+
 bool trace_runs_host(const Window& w, const TraceJob& job, std::vector<int32_t>& runs) {
     const SwPair& p = w.sw_pairs()[size_t(job.pair)];
     std::vector<Run> rr;
@@ -716,10 +724,8 @@ void Window::set_traced(const TraceJob& job, bool ok, const int32_t* runs, int n
     if (traced_at.empty()) traced_at.assign(pairs.size(), -1);
     SwAlignment al;
     if (ok) {
-        std::vector<Run> rr(static_cast<size_t>(n_runs));
-        for (int i = 0; i < n_runs; ++i) rr[size_t(i)] = Run{"MID"[runs[i] & 3], int(runs[i] >> 2)};
         const SwPair& p = pairs[size_t(job.pair)];
-        al = alignment_from_runs(p.ref, p.query, p.Q, ends[size_t(job.pair)], job, rr);
+        al = alignment_from_device_runs(p.ref, p.query, p.Q, ends[size_t(job.pair)], job, runs, n_runs);
     }
     traced_at[size_t(job.pair)] = int(traced.size());
     traced.push_back(std::move(al));

@@ -25,6 +25,7 @@
 #include <cstring>
 #include <mutex>
 #include <numeric>
+#include <string>
 #include <thread>
 #include "common.h"
 #include "realign_internal.h"
@@ -758,29 +759,24 @@ __global__ __launch_bounds__(64) void k_banded(const signed char* __restrict__ p
     o.status = status; o.n_runs = nr; o.band = band;
 }
 
-// the tracebacks the windows are going to ask for (Window::plan_tracebacks), on the device; what the device declines stays for finish()
-int traceback_device(std::vector<Window*>& ws, const SwStage& stage, hipStream_t s, int threads, cto_realign_stats* st) {
-    StageClock clk;
-    std::vector<std::vector<cto_realign::TraceJob>> jobs(ws.size());
-    parallel_for(ws.size(), threads, [&](size_t i) { ws[i]->plan_tracebacks(jobs[i]); });
-    std::vector<TbDesc> desc;
-    std::vector<std::pair<int, int>> who;                   // (window, job)
-    size_t dir_bytes = 0;
-    constexpr int kBandMax = 1024;
-    constexpr size_t kDirMax = size_t(6) << 30;
-    for (size_t wi = 0; wi < ws.size(); ++wi)
-        for (size_t ji = 0; ji < jobs[wi].size(); ++ji) {
-            const cto_realign::TraceJob& j = jobs[wi][ji];
-            if (j.band > kBandMax) continue;                // finish() runs it on the host
-            const int cap = std::min(kBandMax, j.band * 4);
-            const size_t need = (size_t(j.subQ) * size_t(2 * cap + 1) + 63) & ~size_t(63);
-            if (dir_bytes + need > kDirMax) continue;
-            const SwDesc& p = stage.desc[stage.first[wi] + size_t(j.pair)];
-            desc.push_back(TbDesc{p.ref_off + j.ref_begin, p.q_off + j.read_begin, j.subR, j.subQ, j.score, j.band, cap, 0, (long long)dir_bytes});
-            who.emplace_back(int(wi), int(ji));
-            dir_bytes += need;
-        }
+constexpr int kBandMax = 1024;                          // bands beyond are the host's
+constexpr size_t kDirMax = size_t(6) << 30;             // direction scratch of one call
+
+// band cap and scratch offset of a traceback; false = not taken (the caller leaves it to the host)
+bool tb_place(const cto_realign::TraceJob& j, int ref_off, int q_off, size_t& dir_bytes, TbDesc& d) {
+    if (j.band > kBandMax) return false;
+    const int cap = std::min(kBandMax, j.band * 4);
+    const size_t need = (size_t(j.subQ) * size_t(2 * cap + 1) + 63) & ~size_t(63);
+    if (dir_bytes + need > kDirMax) return false;
+    d = TbDesc{ref_off + j.ref_begin, q_off + j.read_begin, j.subR, j.subQ, j.score, j.band, cap, 0, (long long)dir_bytes};
+    dir_bytes += need;
+    return true;
+}
+
+// the tracebacks of `desc` (operands = base codes in the device pool): out[k] in desc order
+int traceback_pool(const signed char* d_pool, const std::vector<TbDesc>& desc, size_t dir_bytes, hipStream_t s, cto_realign_stats* st, std::vector<TbOut>& out) {
     const int n = int(desc.size());
+    out.clear();
     if (n == 0) return CTO_OK;
     // two classes by the widest band an alignment may reach (the LDS footprint), longest first inside a class
     std::vector<int> order(static_cast<size_t>(n));
@@ -793,7 +789,6 @@ int traceback_device(std::vector<Window*>& ws, const SwStage& stage, hipStream_t
     });
     int n_wide = 0, cap_wide = 0;
     for (int k = 0; k < n; ++k) if (wide(k)) { ++n_wide; cap_wide = std::max(cap_wide, desc[size_t(k)].band_cap); }
-    clk.lap("  traceback: plan + descriptors");
     DevBuf<TbDesc> d_desc;
     DevBuf<int> d_order;
     DevBuf<TbOut> d_out;
@@ -815,7 +810,7 @@ int traceback_device(std::vector<Window*>& ws, const SwStage& stage, hipStream_t
     auto launch_on = [&](hipStream_t t, int first, int count, int cap) -> int {
         if (count == 0) return CTO_OK;
         const int W = 2 * cap + 4;
-        hipLaunchKernelGGL(k_banded, dim3(unsigned(count)), dim3(64), size_t(3) * W * sizeof(int), t, stage.d_pool.p, d_desc.p, d_order.p + first, count,
+        hipLaunchKernelGGL(k_banded, dim3(unsigned(count)), dim3(64), size_t(3) * W * sizeof(int), t, d_pool, d_desc.p, d_order.p + first, count,
                            d_dir.p, d_out.p, W);
         CTO_HIP(hipGetLastError());
         return CTO_OK;
@@ -831,7 +826,7 @@ int traceback_device(std::vector<Window*>& ws, const SwStage& stage, hipStream_t
     };
     if (rc != CTO_OK) { drop(); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
     CTO_HIP(hipEventRecord(e1, s));
-    std::vector<TbOut> out(static_cast<size_t>(n));
+    out.resize(static_cast<size_t>(n));
     CTO_HIP(hipMemcpyAsync(out.data(), d_out.p, size_t(n) * sizeof(TbOut), hipMemcpyDeviceToHost, s));
     CTO_HIP(hipStreamSynchronize(s));
     float ms = 0.f;
@@ -839,6 +834,32 @@ int traceback_device(std::vector<Window*>& ws, const SwStage& stage, hipStream_t
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     drop();
     if (st) { st->traceback_ms += ms; st->tracebacks += n; }
+    return CTO_OK;
+}
+
+// the tracebacks the windows are going to ask for (Window::plan_tracebacks), on the device; what the device declines stays for finish()
+int traceback_device(std::vector<Window*>& ws, const SwStage& stage, hipStream_t s, int threads, cto_realign_stats* st) {
+    StageClock clk;
+    std::vector<std::vector<cto_realign::TraceJob>> jobs(ws.size());
+    parallel_for(ws.size(), threads, [&](size_t i) { ws[i]->plan_tracebacks(jobs[i]); });
+    std::vector<TbDesc> desc;
+    std::vector<std::pair<int, int>> who;                   // (window, job)
+    size_t dir_bytes = 0;
+    for (size_t wi = 0; wi < ws.size(); ++wi)
+        for (size_t ji = 0; ji < jobs[wi].size(); ++ji) {
+            const cto_realign::TraceJob& j = jobs[wi][ji];
+            const SwDesc& p = stage.desc[stage.first[wi] + size_t(j.pair)];
+            TbDesc d;
+            if (!tb_place(j, p.ref_off, p.q_off, dir_bytes, d)) continue;       // finish() runs it on the host
+            desc.push_back(d);
+            who.emplace_back(int(wi), int(ji));
+        }
+    const int n = int(desc.size());
+    if (n == 0) return CTO_OK;
+    clk.lap("  traceback: plan + descriptors");
+    std::vector<TbOut> out;
+    const int rc = traceback_pool(stage.d_pool.p, desc, dir_bytes, s, st, out);
+    if (rc != CTO_OK) return rc;
     clk.lap("  traceback: launches + D2H");
     // a window's results are installed by one worker (set_traced appends to the window's own vectors)
     std::vector<size_t> wfirst(ws.size() + 1, size_t(n));
@@ -891,6 +912,64 @@ extern "C" int cto_sw_ends_batch(int n, const int8_t* codes, size_t n_codes, con
     return CTO_OK;
 }
 CTO_CATCH("cto_sw_ends_batch", int)
+
+extern "C" int cto_ssw_align_batch(int n, const int8_t* codes, size_t n_codes, const int32_t* desc, int where, int host_threads, void* stream,
+                                  int32_t* score, int32_t* ref_begin, char* cigar_buf, size_t cigar_cap, int64_t* cigar_off) try {
+    CTO_REQUIRE(n >= 0 && (n == 0 || (codes && desc && score && ref_begin)) && cigar_off && (cigar_buf || cigar_cap == 0) &&
+                (where == CTO_REALIGN_HOST || where == CTO_REALIGN_DEVICE), CTO_EINVAL, "cto_ssw_align_batch: bad argument");
+    CTO_REQUIRE(n_codes < (size_t(1) << 31), CTO_EUNSUPPORTED, "cto_ssw_align_batch: more than 2 GiB of sequence in one call; split it");
+    std::vector<SwDesc> d(static_cast<size_t>(n));
+    for (int k = 0; k < n; ++k) {
+        d[size_t(k)] = SwDesc{desc[4 * k], desc[4 * k + 1], desc[4 * k + 2], desc[4 * k + 3]};
+        const SwDesc& x = d[size_t(k)];
+        CTO_REQUIRE(x.R >= 0 && x.Q >= 0 && x.ref_off >= 0 && x.q_off >= 0 && size_t(x.ref_off) + size_t(x.R) <= n_codes &&
+                    size_t(x.q_off) + size_t(x.Q) <= n_codes, CTO_EINVAL, "cto_ssw_align_batch: alignment %d reaches outside the codes", k);
+    }
+    const int threads = host_threads > 0 ? host_threads : cto_realign::get_threads();
+    std::vector<cto_realign::SwAlignment> al(static_cast<size_t>(n));
+    auto on_host = [&](size_t k, const Ends& e) { al[k] = cto_realign::alignment_of_pair(codes + d[k].ref_off, d[k].R, codes + d[k].q_off, d[k].Q, e); };
+    if (where == CTO_REALIGN_DEVICE && n > 0) {
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        const std::vector<signed char> pool(reinterpret_cast<const signed char*>(codes), reinterpret_cast<const signed char*>(codes) + n_codes);
+        std::vector<Ends> ends;
+        DevBuf<signed char> d_pool;
+        int rc = sw_ends_pool(pool, d, s, nullptr, ends, &d_pool);
+        if (rc != CTO_OK) return rc;
+        std::vector<cto_realign::TraceJob> jobs(static_cast<size_t>(n));
+        std::vector<int> at(static_cast<size_t>(n), -1);                  // alignment -> traceback, -1 = none on the device
+        std::vector<char> planned(static_cast<size_t>(n), 0);
+        std::vector<TbDesc> tb;
+        size_t dir_bytes = 0;
+        for (int k = 0; k < n; ++k) {
+            jobs[size_t(k)].pair = k;
+            planned[size_t(k)] = cto_realign::plan_pair(d[size_t(k)].R, d[size_t(k)].Q, ends[size_t(k)], jobs[size_t(k)]) ? 1 : 0;
+            TbDesc t;
+            if (planned[size_t(k)] && tb_place(jobs[size_t(k)], d[size_t(k)].ref_off, d[size_t(k)].q_off, dir_bytes, t)) { at[size_t(k)] = int(tb.size()); tb.push_back(t); }
+        }
+        std::vector<TbOut> out;
+        rc = traceback_pool(d_pool.p, tb, dir_bytes, s, nullptr, out);
+        if (rc != CTO_OK) return rc;
+        parallel_for(size_t(n), threads, [&](size_t k) {
+            if (!planned[k]) return;                                     // no alignment: score 0, empty CIGAR
+            if (at[k] < 0 || out[size_t(at[k])].status == 2) { on_host(k, ends[k]); return; }
+            const TbOut& o = out[size_t(at[k])];
+            if (o.status != 1) return;                                   // the reference's traceback fails
+            int32_t runs[TB_RUNS];
+            for (int i = 0; i < o.n_runs; ++i) runs[i] = o.runs[o.n_runs - 1 - i];
+            al[k] = cto_realign::alignment_from_device_runs(codes + d[k].ref_off, codes + d[k].q_off, d[k].Q, ends[k], jobs[k], runs, o.n_runs);
+        });
+    } else {
+        parallel_for(size_t(n), threads, [&](size_t k) { on_host(k, cto_realign::ends_of_pair(codes + d[k].ref_off, d[k].R, codes + d[k].q_off, d[k].Q)); });
+    }
+    std::vector<std::string> text(static_cast<size_t>(n));
+    for (int k = 0; k < n; ++k) {
+        score[k] = al[size_t(k)].score;
+        ref_begin[k] = al[size_t(k)].ref_begin;
+        for (const cto_realign::Op& o : al[size_t(k)].cigar) { text[size_t(k)] += std::to_string(o.len); text[size_t(k)] += o.op; }
+    }
+    return cto_realign_write_cigars(text, cigar_buf, cigar_cap, cigar_off);
+}
+CTO_CATCH("cto_ssw_align_batch", int)
 
 extern "C" int cto_realign_windows(int n_jobs, cto_realign_job* jobs, int where, int host_threads, void* stream, cto_realign_stats* stats) try {
     CTO_REQUIRE(n_jobs >= 0 && (jobs || n_jobs == 0) && (where == CTO_REALIGN_HOST || where == CTO_REALIGN_DEVICE), CTO_EINVAL,

@@ -74,6 +74,11 @@ public:
 int get_threads();
 // the two striped passes of one alignment on the host (ssw.c:781-830): what Window::ends_host runs per pair
 Ends ends_of_pair(const int8_t* ref, int R, const int8_t* query, int Q);
+// one alignment outside a window (cto_ssw_align_batch): the traceback's sub-problem (false: the reference returns no alignment), the
+// alignment with the traceback run here, and the alignment from runs delivered in set_traced's format
+bool plan_pair(int R, int Q, const Ends& e, TraceJob& j);
+SwAlignment alignment_of_pair(const int8_t* ref, int R, const int8_t* query, int Q, const Ends& e);
+SwAlignment alignment_from_device_runs(const int8_t* ref, const int8_t* query, int Q, const Ends& e, const TraceJob& j, const int32_t* runs, int n_runs);
 // a planned traceback on the host, in set_traced's format (what the device stage delivers); false = the banded pass fails
 bool trace_runs_host(const Window& w, const TraceJob& job, std::vector<int32_t>& runs);
 

@@ -152,6 +152,34 @@ def realign_windows(windows, where="device", threads=0, stats=None, statuses=Non
     return out
 
 
+def _pair_codes(pairs):
+    flat = [np.ascontiguousarray(x, dtype=np.int8) for p in pairs for x in p]
+    codes = np.concatenate(flat) if flat else np.zeros(0, dtype=np.int8)
+    lens = np.fromiter((len(x) for x in flat), dtype=np.int64, count=len(flat))
+    offs = np.zeros(len(flat) + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    desc = np.stack([offs[0:-1:2], lens[0::2], offs[1::2], lens[1::2]], axis=1).astype(np.int32) if pairs else np.zeros((0, 4), dtype=np.int32)
+    return codes, np.ascontiguousarray(desc)
+
+
+def ssw_align_batch(pairs, where="device", threads=0):
+    """Aligner::Align for many (reference, query) pairs of base codes in one call (cto_ssw_align_batch): returns (scores, ref_begins,
+    list of CIGAR strings)."""
+    n = len(pairs)
+    codes, desc = _pair_codes(pairs)
+    score, begin = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+    cap = int(16 * n + 12 * codes.size + 64)
+    buf, off = np.empty(cap, dtype=np.uint8), np.zeros(n + 1, dtype=np.int64)
+    stream = None
+    if where == "device":
+        from ._lib import current_stream_ptr
+        stream = current_stream_ptr()
+    check(lib.cto_ssw_align_batch(n, codes.ctypes.data, codes.size, desc.ctypes.data, 1 if where == "device" else 0, int(threads), stream,
+                                  score.ctypes.data, begin.ctypes.data, buf.ctypes.data, cap, off.ctypes.data))
+    text = buf[:int(off[n])].tobytes().decode()
+    return score, begin, (text[:-1].split("\0") if n else [])
+
+
 def sw_ends_batch(pairs, where="device", threads=0):
     """The striped Smith-Waterman passes of many (reference, query) pairs in one call (cto_sw_ends_batch; ssw.c:781-830): pairs = list of
     (ref_codes, query_codes) int8 arrays of base codes 0..4; returns an [n, 6] int32 array {score, ref_end, read_end, ref_begin,

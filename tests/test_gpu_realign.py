@@ -152,3 +152,21 @@ def test_device_sw_passes_on_adversarial_pairs(dev):
     bad = np.nonzero((d != h).any(axis=1))[0]
     assert bad.size == 0, "pair %d of np.random.default_rng(%d): device %s host %s" % (bad[0], seed, d[bad[0]], h[bad[0]])
     assert int((d[:, 5] == 8).sum()) > 2000 and int((d[:, 0] > 1000).sum()) > 500
+
+
+def test_device_alignments_on_adversarial_pairs(dev):
+    """cto_ssw_align_batch on the device (k_sw for the end points, k_banded for the traceback) against the host form - score, reference
+    start and CIGAR - on pairs built to stress the band: long matches around gaps of up to 80 bases in both orientations (the band
+    starts at the length difference and doubles), several gaps (the walk changes state often), tandem repeats (ties in every cell),
+    unrelated pairs (short local alignments), operands up to 2 000 bases; fresh pairs every run."""
+    from clairs_to_amd.realign_reads import ssw_align_batch
+    seed = int.from_bytes(os.urandom(4), "little")
+    rng = np.random.default_rng(seed)
+    pairs = ru.adversarial_pairs(rng, 12000, max_len=700) + ru.adversarial_pairs(rng, 400, max_len=2000)
+    pairs += [(np.zeros(5, dtype=np.int8), np.ones(7, dtype=np.int8)), (np.zeros(0, dtype=np.int8), np.ones(7, dtype=np.int8))]
+    ds, db, dc = ssw_align_batch(pairs, "device", threads=16)
+    hs, hb, hc = ssw_align_batch(pairs, "host", threads=16)
+    for i in range(len(pairs)):
+        assert (int(ds[i]), int(db[i]), dc[i]) == (int(hs[i]), int(hb[i]), hc[i]), "pair %d of np.random.default_rng(%d)" % (i, seed)
+    gapped = sum(1 for c in dc if "D" in c or "I" in c)
+    assert gapped > 3000 and sum(1 for c in dc if c == "") >= 2

@@ -118,3 +118,23 @@ def test_planned_tracebacks_give_the_same_windows(monkeypatch):
     got = ru.amd_realign_batch(ws, "host", threads=3)
     for w, (pos, cig), want in zip(ws, got, g["windows"]):
         assert [[p - w["ref_start"], c] for p, c in zip(pos, cig)] == want
+
+
+def test_ssw_align_batch_host_equals_the_one_pair_call():
+    """cto_ssw_align_batch, host form, against cto_ssw_align pair by pair: score, reference start, CIGAR - incl. pairs without an
+    alignment (nothing matches) and empty operands"""
+    import ctypes as C
+    from clairs_to_amd.realign_reads import ssw_align_batch
+    from clairs_to_amd._lib import lib, check
+    rng = np.random.default_rng(41)
+    pairs = ru.adversarial_pairs(rng, 500, max_len=300)
+    pairs += [(np.zeros(5, dtype=np.int8), np.ones(7, dtype=np.int8)), (np.zeros(0, dtype=np.int8), np.ones(7, dtype=np.int8))]
+    sc, rb, cg = ssw_align_batch(pairs, "host", threads=3)
+    letters = "ACGTN"
+    buf = C.create_string_buffer(1 << 16)
+    for (r, q), s, b, c in zip(pairs, sc, rb, cg):
+        score, beg = C.c_int32(), C.c_int32()
+        check(lib.cto_ssw_align("".join(letters[x] for x in r).encode(), "".join(letters[x] for x in q).encode(), C.byref(score), C.byref(beg), buf, 1 << 16))
+        assert (score.value, beg.value, buf.value.decode()) == (int(s), int(b), c)
+    assert cg[-1] == "" and cg[-2] == "" and int(sc[-1]) == 0
+    assert ssw_align_batch([], "host")[2] == []
