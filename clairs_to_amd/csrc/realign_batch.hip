@@ -794,7 +794,16 @@ int traceback_pool(const signed char* d_pool, const std::vector<TbDesc>& desc, s
     DevBuf<TbOut> d_out;
     DevBuf<unsigned char> d_dir;
     int rc;
-    if ((rc = d_desc.put(desc, s)) || (rc = d_order.put(order, s)) || (rc = d_out.alloc(size_t(n))) || (rc = d_dir.alloc(dir_bytes))) return rc;
+    // the direction scratch is the one large allocation of a call (~40 KB per haplotype traceback): without it every traceback is the host's
+    if (hipMalloc(reinterpret_cast<void**>(&d_dir.p), std::max<size_t>(dir_bytes, 1)) != hipSuccess) {
+        (void)hipGetLastError();
+        d_dir.p = nullptr;
+        out.assign(static_cast<size_t>(n), TbOut{});
+        for (TbOut& o : out) o.status = 2;
+        return CTO_OK;
+    }
+    if (trace_on()) std::fprintf(stderr, "[realign]   traceback: %d alignments, %.1f MB of direction scratch\n", n, double(dir_bytes) / 1e6);
+    if ((rc = d_desc.put(desc, s)) || (rc = d_order.put(order, s)) || (rc = d_out.alloc(size_t(n)))) return rc;
     hipEvent_t e0, e1;
     CTO_HIP(hipEventCreate(&e0)); CTO_HIP(hipEventCreate(&e1));
     CTO_HIP(hipEventRecord(e0, s));
