@@ -530,11 +530,17 @@ int sw_ends_pool(const std::vector<signed char>& pool, const std::vector<SwDesc>
         while (desc[k].Q > qcap[c]) ++c;
         cls[c].push_back(k); Rc[c] = std::max(Rc[c], desc[k].R); Qc[c] = std::max(Qc[c], desc[k].Q);
     }
-    auto by_work = [&](int x, int y) { const long long a = (long long)desc[x].Q * desc[x].R, b = (long long)desc[y].Q * desc[y].R; return a != b ? a > b : x < y; };
+    // inside a class by descending work: one 64-bit key per alignment ((2^40 - 1 - work) << 24 | index), sorted as numbers
     std::vector<int> order;
+    order.reserve(static_cast<size_t>(n));
     size_t at[kClasses + 1] = {0, 0, 0, 0, 0, 0};
+    std::vector<unsigned long long> keys;
     for (int c = 0; c < kClasses; ++c) {
-        std::sort(cls[c].begin(), cls[c].end(), by_work);
+        CTO_REQUIRE(n < (1 << 24), CTO_EUNSUPPORTED, "cto_realign_windows: more than 16 M alignments in one call; split it");
+        keys.clear();
+        for (int k : cls[c]) keys.push_back(((((1ull << 40) - 1ull) - (unsigned long long)desc[k].Q * (unsigned long long)desc[k].R) << 24) | (unsigned long long)k);
+        std::sort(keys.begin(), keys.end());
+        for (size_t i = 0; i < keys.size(); ++i) cls[c][i] = int(keys[i] & 0xffffffull);
         at[c] = order.size();
         order.insert(order.end(), cls[c].begin(), cls[c].end());
     }
@@ -611,27 +617,41 @@ int ends_device(std::vector<Window*>& ws, hipStream_t s, int threads, cto_realig
     std::vector<size_t>& first = stage.first;
     desc.clear();
     first.assign(ws.size() + 1, 0);
+    // sizes first, so that every window fills its own slice of the pool and of the descriptors (on the workers)
+    std::vector<size_t> pool_at(ws.size() + 1, 0);
     for (size_t wi = 0; wi < ws.size(); ++wi) {
-        Window& w = *ws[wi];
-        first[wi] = desc.size();
-        auto put = [&](const std::vector<int8_t>& v) { const int off = int(pool.size()); pool.insert(pool.end(), v.begin(), v.end()); return off; };
+        const Window& w = *ws[wi];
+        size_t bytes = w.refc.size();
+        for (const std::vector<int8_t>& h : w.hapc) bytes += h.size();
+        for (int r : w.todo) bytes += w.readc[size_t(r)].size();
+        pool_at[wi + 1] = pool_at[wi] + bytes;
+        first[wi + 1] = first[wi] + w.sw_pairs().size();
+    }
+    CTO_REQUIRE(pool_at[ws.size()] < (size_t(1) << 31), CTO_EUNSUPPORTED, "cto_realign_windows: more than 2 GiB of sequence in one call; split it");
+    pool.resize(pool_at[ws.size()]);
+    desc.resize(first[ws.size()]);
+    std::atomic<int> unknown{0};
+    parallel_for(ws.size(), threads, [&](size_t wi) {
+        const Window& w = *ws[wi];
+        size_t at = pool_at[wi];
+        auto put = [&](const std::vector<int8_t>& v) { const int off = int(at); if (!v.empty()) memcpy(pool.data() + at, v.data(), v.size()); at += v.size(); return off; };
         const int ref_off = put(w.refc);
         std::vector<int> hap_at(w.hapc.size()), read_at(w.readc.size(), -1);
         for (size_t h = 0; h < w.hapc.size(); ++h) hap_at[h] = put(w.hapc[h]);
-        for (int r : w.todo) read_at[r] = put(w.readc[r]);
+        for (int r : w.todo) read_at[size_t(r)] = put(w.readc[size_t(r)]);
+        size_t k = first[wi];
         for (const cto_realign::SwPair& p : w.sw_pairs()) {
             // identify the operands by address (the pairs point into refc / hapc / readc)
             int roff = -1, qoff = -1;
             if (p.ref == w.refc.data()) roff = ref_off;
             else for (size_t h = 0; h < w.hapc.size(); ++h) if (p.ref == w.hapc[h].data()) { roff = hap_at[h]; break; }
             for (size_t h = 0; h < w.hapc.size() && qoff < 0; ++h) if (p.query == w.hapc[h].data()) qoff = hap_at[h];
-            if (qoff < 0) for (int r : w.todo) if (p.query == w.readc[r].data()) { qoff = read_at[r]; break; }
-            CTO_REQUIRE(roff >= 0 && qoff >= 0, CTO_EINVAL, "cto_realign_windows: internal: unknown operand");
-            desc.push_back(SwDesc{roff, p.R, qoff, p.Q});
+            if (qoff < 0) for (int r : w.todo) if (p.query == w.readc[size_t(r)].data()) { qoff = read_at[size_t(r)]; break; }
+            if (roff < 0 || qoff < 0) { unknown = 1; roff = qoff = 0; }
+            desc[k++] = SwDesc{roff, p.R, qoff, p.Q};
         }
-        CTO_REQUIRE(pool.size() < (size_t(1) << 31), CTO_EUNSUPPORTED, "cto_realign_windows: more than 2 GiB of sequence in one call; split it");
-    }
-    first[ws.size()] = desc.size();
+    });
+    CTO_REQUIRE(unknown == 0, CTO_EINVAL, "cto_realign_windows: internal: unknown operand");
     if (desc.empty()) return CTO_OK;
     clk.lap("  SW: pool + descriptors");
     std::vector<Ends> ends;
@@ -651,7 +671,7 @@ int ends_device(std::vector<Window*>& ws, hipStream_t s, int threads, cto_realig
 // included; direction choices (one byte per cell: E's, F's, H's) go to a scratch region in HBM, rows the band does not reach written
 // as 0 = "not a cell" as the host's zero-filled array has them.  The band doubles until the best cell reaches the score the striped passes
 // found; lane 0 then walks back from the last cell.  Runs leave in walk order (the host reverses them).
-constexpr int TB_RUNS = 61;
+constexpr int TB_RUNS = 29;          // runs an alignment may have here (2 x gaps + 1): 128 bytes of result per alignment; more: the host's
 struct TbDesc { int ref_off, q_off, R, Q, score, band, band_cap, pad; long long dir_off; };
 struct TbOut { int status, n_runs, band; int runs[TB_RUNS]; };          // status 1 = done, 0 = the reference's traceback fails, 2 = not done here
 constexpr int TB_NEG = -(1 << 28);
@@ -759,6 +779,38 @@ __global__ __launch_bounds__(64) void k_banded(const signed char* __restrict__ p
     o.status = status; o.n_runs = nr; o.band = band;
 }
 
+// grow-only direction scratch kept by the library between calls
+struct DirScratch {
+    static std::mutex& lock() { static std::mutex m; return m; }
+    static unsigned char*& kept() { static unsigned char* p = nullptr; return p; }
+    static size_t& kept_cap() { static size_t c = 0; return c; }
+    static bool& busy() { static bool b = false; return b; }
+    unsigned char* p = nullptr;
+    bool from_kept = false;
+    bool get(size_t bytes) {
+        bytes = std::max<size_t>(bytes, 1);
+        {
+            std::lock_guard<std::mutex> g(lock());
+            if (!busy()) {
+                if (kept_cap() < bytes) {
+                    if (kept()) (void)hipFree(kept());
+                    kept() = nullptr; kept_cap() = 0;
+                    const size_t want = bytes + bytes / 4;
+                    if (hipMalloc(reinterpret_cast<void**>(&kept()), want) == hipSuccess) kept_cap() = want;
+                    else { (void)hipGetLastError(); kept() = nullptr; }
+                }
+                if (kept()) { busy() = true; from_kept = true; p = kept(); return true; }
+            }
+        }
+        if (hipMalloc(reinterpret_cast<void**>(&p), bytes) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return false; }
+        return true;
+    }
+    ~DirScratch() {
+        if (from_kept) { std::lock_guard<std::mutex> g(lock()); busy() = false; }
+        else if (p) (void)hipFree(p);
+    }
+};
+
 constexpr int kBandMax = 1024;                          // bands beyond are the host's
 constexpr size_t kDirMax = size_t(6) << 30;             // direction scratch of one call
 
@@ -792,16 +844,16 @@ int traceback_pool(const signed char* d_pool, const std::vector<TbDesc>& desc, s
     DevBuf<TbDesc> d_desc;
     DevBuf<int> d_order;
     DevBuf<TbOut> d_out;
-    DevBuf<unsigned char> d_dir;
     int rc;
-    // the direction scratch is the one large allocation of a call (~40 KB per haplotype traceback): without it every traceback is the host's
-    if (hipMalloc(reinterpret_cast<void**>(&d_dir.p), std::max<size_t>(dir_bytes, 1)) != hipSuccess) {
-        (void)hipGetLastError();
-        d_dir.p = nullptr;
+    // the direction scratch is the one large allocation of a call (~40 KB per haplotype traceback): kept between calls (one call at a
+    // time uses the kept one, a concurrent call allocates its own); without it every traceback is the host's
+    DirScratch dir_scratch;
+    if (!dir_scratch.get(dir_bytes)) {
         out.assign(static_cast<size_t>(n), TbOut{});
         for (TbOut& o : out) o.status = 2;
         return CTO_OK;
     }
+    struct { unsigned char* p; } d_dir{dir_scratch.p};
     if (trace_on()) std::fprintf(stderr, "[realign]   traceback: %d alignments, %.1f MB of direction scratch\n", n, double(dir_bytes) / 1e6);
     if ((rc = d_desc.put(desc, s)) || (rc = d_order.put(order, s)) || (rc = d_out.alloc(size_t(n)))) return rc;
     hipEvent_t e0, e1;
@@ -1067,8 +1119,10 @@ extern "C" int cto_realign_windows(int n_jobs, cto_realign_job* jobs, int where,
     // A window owns thousands of small vectors (a hit per read and haplotype) and giving ~100 k of them back costs as much as the
     // traceback stage (and more when many threads free into each other's arenas): the windows are handed to a thread that does it
     // behind the caller's back; the next call (or the library's unloading) waits for it.
+    static const bool inline_teardown = std::getenv("CTO_REALIGN_INLINE_TEARDOWN") != nullptr;      // A/B switch
+    if (inline_teardown) parallel_for(ws.size(), threads, [&](size_t i) { ws[i] = Window(); });
     if (stats) stats->host_ms = now_ms() - t1;
-    reap(std::move(ws));
+    if (!inline_teardown) reap(std::move(ws));
     if (first_bad >= 0) { cto::set_error("window %d: %s", first_bad, errors[size_t(first_bad)].c_str()); return status[size_t(first_bad)]; }
     return CTO_OK;
 }

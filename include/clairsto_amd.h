@@ -583,7 +583,7 @@ int cto_sw_ends_batch(int n, const int8_t* codes, size_t n_codes, const int32_t*
  * banded traceback (ssw.c:531-741) and the CIGAR over {S = X I D}.  codes / desc as for cto_sw_ends_batch; score[k] = 0 and an empty
  * CIGAR where the reference returns no alignment.  CIGAR text as cto_realign_reads writes it: NUL-terminated one after the other in
  * cigar_buf, cigar_off[n + 1] offsets.  where = CTO_REALIGN_DEVICE: k_sw + k_banded on `stream` (tracebacks with a first band over
- * 1 024 or more than 61 runs are done on the host inside the call); CTO_REALIGN_HOST: host_threads workers.  Same bytes. */
+ * 1 024 or more than 29 runs are done on the host inside the call); CTO_REALIGN_HOST: host_threads workers.  Same bytes. */
 int cto_ssw_align_batch(int n, const int8_t* codes, size_t n_codes, const int32_t* desc, int where, int host_threads, void* stream,
                         int32_t* score, int32_t* ref_begin, char* cigar_buf, size_t cigar_cap, int64_t* cigar_off);
 /* One striped Smith-Waterman pass alone (ssw.c:118-311 / :341-529 of the reference's src/realign: sw_sse2_byte / sw_sse2_word), test
