@@ -179,9 +179,9 @@ constexpr int kBias = 6, kGapO = 8, kGapE = 2;
 //   H0, H1, E [LW][SP] shorts       the two H columns and E; 8 positions = one ds_read_b128
 // A lane never touches another lane's entries: lanes meet in DPP shifts and row reductions only, and there is no barrier inside a pass.
 __host__ __device__ inline int sw_sp(int segcap) { int sp = (segcap + 15) / 16 * 16; if (((sp / 8) & 1) == 0) sp += 8; return sp; }
-__host__ __device__ inline size_t sw_row_bytes(int Rcap, int Qcap, int segcap, int LW) {
-    return size_t(Rcap) + Qcap + size_t(sw_sp(segcap)) * LW * (5 + 3 * sizeof(short));
-}
+// (the operands themselves stay in HBM: a pass reads one reference code per column, two columns ahead of its use, and the query once,
+// when the profile is built)
+__host__ __device__ inline size_t sw_row_bytes(int segcap, int LW) { return size_t(sw_sp(segcap)) * LW * (5 + 3 * sizeof(short)); }
 
 // `rev_from` >= 0: the query is qraw[rev_from], qraw[rev_from - 1], ... (the reversed prefix of the backward pass)
 template <int LW>
@@ -242,9 +242,11 @@ __device__ RowPass row_pass(const signed char* refc, int r_begin, int r_end, int
     bool overflow = false;
     int fin = 0;                                     // Fin of the column in `store` (the last one written)
     const int D = kGapE * seg;
-    int rc = r_begin != r_end ? refc[r_begin] : 0;
-    for (int i = r_begin; i != r_end; i += r_step) {
-        const int rc_next = i + r_step != r_end ? refc[i + r_step] : 0;       // one column ahead of its use
+    const int n_col = (r_end - r_begin) * r_step;
+    int rc = n_col > 0 ? refc[r_begin] : 0, rc_next = n_col > 1 ? refc[r_begin + r_step] : 0;
+    int col = 0;
+    for (int i = r_begin; i != r_end; i += r_step, ++col) {
+        const int rc_next2 = col + 2 < n_col ? refc[i + 2 * r_step] : 0;       // from HBM, two columns ahead of its use
         int f = 0, colmax = 0;
         int h = row_shl1<LW>(max(int(store[lb + seg - 1]), max(fin - kGapE * (seg - 1), 0)), l);
         { short* t = store; store = load; load = t; }          // load = column i - 1 (as its main loop left it; `fin` completes it), store = column i
@@ -262,21 +264,37 @@ __device__ RowPass row_pass(const signed char* refc, int r_begin, int r_end, int
             for (int k = 0; k < 4; ++k) hw[k] = pk_max(hw[k], pk_subs(fg2, pk2(kGapE * 2 * k, kGapE * (2 * k + 1))));
             fg = max(fg - kGapE * 8, 0);
             unsigned sw[4] = {0u, 0u, 0u, 0u}, nw[4] = {ew[0], ew[1], ew[2], ew[3]};
+            // Three sweeps over the eight positions instead of one chain through all of them.  With t = max(diagonal + score, e) - which
+            // does not depend on F - the recurrence of a position is h = max(t, f), f' = max(f - ext, max(h - open, 0)) =
+            // max(f - ext, max(t - open, 0)) (f - open < f - ext): only TWO dependent operations per position carry F along; t before
+            // and h, E, the column maximum after are independent across the eight positions.  (Measured: 15.1-15.4 ms for the bench batch
+            // against 15.5 with one chain through all eight - the stage is not bound by dependent-issue latency; PMC: ~7 clocks per VALU
+            // instruction of a wavefront, the time of a class is its longest alignment's chain next to the other classes' waves.)
+            int t[8], u[8], ev[8], fv[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                ev[c] = int((ew[c >> 1] >> (16 * (c & 1))) & 0xffffu);
+                const int sc = int(pw[c >> 2] << (24 - 8 * (c & 3))) >> 24;      // signed byte c
+                int x;
+                if (BYTE) x = max(min(h + sc + kBias, 255) - kBias, 0);
+                else x = min(h + sc, 32767);
+                t[c] = max(x, ev[c]);
+                u[c] = max(t[c] - kGapO, 0);
+                h = int((hw[c >> 1] >> (16 * (c & 1))) & 0xffffu);            // the diagonal of the next position
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                fv[c] = f;
+                if (!TAIL || j0 + c < seg) f = max(f - kGapE, u[c]);
+            }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 if (!TAIL || j0 + c < seg) {
-                    const int e = int((ew[c >> 1] >> (16 * (c & 1))) & 0xffffu);
-                    const int sc = int(pw[c >> 2] << (24 - 8 * (c & 3))) >> 24;      // signed byte c
-                    if (BYTE) h = max(min(h + sc + kBias, 255) - kBias, 0);
-                    else h = min(h + sc, 32767);
-                    h = max(h, max(e, f));
-                    colmax = max(colmax, h);
-                    const int h2 = max(h - kGapO, 0);
-                    const int en = max(max(e - kGapE, 0), h2);            // E never sees the lazy-F corrections
-                    f = max(f - kGapE, h2);
-                    if (c & 1) { sw[c >> 1] |= unsigned(h) << 16; nw[c >> 1] = (nw[c >> 1] & 0xffffu) | (unsigned(en) << 16); }
-                    else { sw[c >> 1] = unsigned(h) & 0xffffu; nw[c >> 1] = (nw[c >> 1] & 0xffff0000u) | unsigned(en); }
-                    h = int((hw[c >> 1] >> (16 * (c & 1))) & 0xffffu);
+                    const int hh = max(t[c], fv[c]);
+                    colmax = max(colmax, hh);
+                    const int en = max(max(ev[c] - kGapE, 0), max(hh - kGapO, 0));            // E never sees the lazy-F corrections
+                    if (c & 1) { sw[c >> 1] |= unsigned(hh) << 16; nw[c >> 1] = (nw[c >> 1] & 0xffffu) | (unsigned(en) << 16); }
+                    else { sw[c >> 1] = unsigned(hh) & 0xffffu; nw[c >> 1] = (nw[c >> 1] & 0xffff0000u) | unsigned(en); }
                 }
             }
             *reinterpret_cast<uint4*>(store + lb + j0) = make_uint4(sw[0], sw[1], sw[2], sw[3]);
@@ -314,7 +332,7 @@ __device__ RowPass row_pass(const signed char* refc, int r_begin, int r_end, int
             best_q = row_min<LW>(mq);
         }
         if (colmax == terminate) break;
-        rc = rc_next;
+        rc = rc_next; rc_next = rc_next2;
     }
     int read_end = Q - 1;
     if (best == 0) read_end = min(read_end, 0);          // the zeroed hmax matches a maximum of 0 at position 0
@@ -324,7 +342,7 @@ __device__ RowPass row_pass(const signed char* refc, int r_begin, int r_end, int
 
 template <bool BYTE>
 __global__ __launch_bounds__(64) void k_sw(const signed char* pool, const SwDesc* desc, const int* order, int n, Ends* out,
-                                             unsigned char* overflowed, int Rcap, int Qcap, int segcap) {
+                                             unsigned char* overflowed, int segcap) {
     constexpr int LW = BYTE ? 16 : 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int row = threadIdx.x / LW, l = threadIdx.x % LW;
@@ -333,18 +351,15 @@ __global__ __launch_bounds__(64) void k_sw(const signed char* pool, const SwDesc
     const int k = live ? order[slot] : 0;
     if (!BYTE && live && !overflowed[k]) live = false;        // the 16-bit kernel takes only what the 8-bit pass gave up on
     const int SP = sw_sp(segcap);
-    unsigned char* base = lds + size_t(row) * ((sw_row_bytes(Rcap, Qcap, segcap, LW) + 15) / 16 * 16);
+    unsigned char* base = lds + size_t(row) * ((sw_row_bytes(segcap, LW) + 15) / 16 * 16);
     short* H0 = reinterpret_cast<short*>(base);
     short* H1 = H0 + size_t(SP) * LW;
     short* E = H1 + size_t(SP) * LW;
     signed char* prof = reinterpret_cast<signed char*>(E + size_t(SP) * LW);
-    signed char* refc = prof + size_t(5) * SP * LW;
-    signed char* qraw = refc + Rcap;
-    const SwDesc d = live ? desc[k] : SwDesc{0, 0, 0, 0};
-    for (int i = l; i < d.R; i += LW) refc[i] = pool[d.ref_off + i];
-    for (int i = l; i < d.Q; i += LW) qraw[i] = pool[d.q_off + i];
-    __syncthreads();
     if (!live) return;
+    const SwDesc d = desc[k];
+    const signed char* refc = pool + d.ref_off;
+    const signed char* qraw = pool + d.q_off;
     Ends e{0, 0, 0, 0, 0, 16};
     bool ovf = false;
     if (d.R > 0 && d.Q > 0) {
@@ -498,12 +513,13 @@ int launch_sw(hipStream_t s, const signed char* pool, const SwDesc* desc, const 
     int ROWS = 64 / LW;
     static const int min_waves = std::getenv("CTO_SW_MIN_WAVES") ? atoi(std::getenv("CTO_SW_MIN_WAVES")) : 512;
     while (ROWS > 1 && (n + ROWS - 1) / ROWS < min_waves) ROWS /= 2;
-    Rcap = (Rcap + 15) & ~15; Qcap = (Qcap + 15) & ~15;
+    (void)Rcap;
+    Qcap = (Qcap + 15) & ~15;
     const int segcap = (Qcap + LW - 1) / LW;
-    const size_t smem = ((sw_row_bytes(Rcap, Qcap, segcap, LW) + 15) / 16 * 16) * ROWS;
+    const size_t smem = ((sw_row_bytes(segcap, LW) + 15) / 16 * 16) * ROWS;
     CTO_REQUIRE(smem <= size_t(160) * 1024, CTO_EUNSUPPORTED, "cto_realign_windows: an alignment of %d x %d does not fit the LDS", Rcap, Qcap);
     CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sw<BYTE>), hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
-    hipLaunchKernelGGL((k_sw<BYTE>), dim3(unsigned((n + ROWS - 1) / ROWS)), dim3(unsigned(LW * ROWS)), smem, s, pool, desc, order, n, out, overflowed, Rcap, Qcap, segcap);
+    hipLaunchKernelGGL((k_sw<BYTE>), dim3(unsigned((n + ROWS - 1) / ROWS)), dim3(unsigned(LW * ROWS)), smem, s, pool, desc, order, n, out, overflowed, segcap);
     CTO_HIP(hipGetLastError());
     return CTO_OK;
 }
@@ -519,10 +535,14 @@ int sw_ends_pool(const std::vector<signed char>& pool, const std::vector<SwDesc>
     // and the footprint is what bounds the wavefronts a CU holds - one class for everything would run the 100-base reads at the
     // occupancy of the haplotype-length queries.  Inside a class by descending work, so that the rows of a wavefront - and the
     // waves of a round - run for about as long.
-    constexpr int kClasses = 5;
-    const int qcap[kClasses] = {64, 128, 256, FP_RMAX, 0x7fffffff};
+    constexpr int kClasses = 11;
+    // (CTO_SW_FINE_CLASSES: eleven classes in steps of 1.5 - smaller LDS footprints, more launches: measured slower, 17-19.5 ms against 15.3)
+    static const bool fine = std::getenv("CTO_SW_FINE_CLASSES") != nullptr;
+    const int qcap_fine[kClasses] = {64, 96, 128, 192, 256, 384, FP_RMAX, 768, 1024, 1536, 0x7fffffff};
+    const int qcap_coarse[kClasses] = {64, 128, 256, FP_RMAX, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    const int* qcap = fine ? qcap_fine : qcap_coarse;
     std::vector<int> cls[kClasses];
-    int Rc[kClasses] = {0, 0, 0, 0, 0}, Qc[kClasses] = {0, 0, 0, 0, 0};
+    int Rc[kClasses] = {}, Qc[kClasses] = {};
     long long cells = 0;
     for (int k = 0; k < n; ++k) {
         cells += (long long)desc[k].R * desc[k].Q;
@@ -533,7 +553,7 @@ int sw_ends_pool(const std::vector<signed char>& pool, const std::vector<SwDesc>
     // inside a class by descending work: one 64-bit key per alignment ((2^40 - 1 - work) << 24 | index), sorted as numbers
     std::vector<int> order;
     order.reserve(static_cast<size_t>(n));
-    size_t at[kClasses + 1] = {0, 0, 0, 0, 0, 0};
+    size_t at[kClasses + 1] = {};
     std::vector<unsigned long long> keys;
     for (int c = 0; c < kClasses; ++c) {
         CTO_REQUIRE(n < (1 << 24), CTO_EUNSUPPORTED, "cto_realign_windows: more than 16 M alignments in one call; split it");
