@@ -516,7 +516,9 @@ int launch_sw(hipStream_t s, const signed char* pool, const SwDesc* desc, const 
     (void)Rcap;
     Qcap = (Qcap + 15) & ~15;
     const int segcap = (Qcap + LW - 1) / LW;
-    const size_t smem = ((sw_row_bytes(segcap, LW) + 15) / 16 * 16) * ROWS;
+    const size_t row_bytes = (sw_row_bytes(segcap, LW) + 15) / 16 * 16;
+    while (ROWS > 1 && row_bytes * ROWS > size_t(160) * 1024) ROWS /= 2;          // queries near 2 048 bases: fewer rows share the LDS
+    const size_t smem = row_bytes * ROWS;
     CTO_REQUIRE(smem <= size_t(160) * 1024, CTO_EUNSUPPORTED, "cto_realign_windows: an alignment of %d x %d does not fit the LDS", Rcap, Qcap);
     CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sw<BYTE>), hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
     hipLaunchKernelGGL((k_sw<BYTE>), dim3(unsigned((n + ROWS - 1) / ROWS)), dim3(unsigned(LW * ROWS)), smem, s, pool, desc, order, n, out, overflowed, segcap);

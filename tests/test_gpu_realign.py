@@ -170,3 +170,22 @@ def test_device_alignments_on_adversarial_pairs(dev):
         assert (int(ds[i]), int(db[i]), dc[i]) == (int(hs[i]), int(hb[i]), hc[i]), "pair %d of np.random.default_rng(%d)" % (i, seed)
     gapped = sum(1 for c in dc if "D" in c or "I" in c)
     assert gapped > 3000 and sum(1 for c in dc if c == "") >= 2
+
+
+def test_device_sw_on_thousands_of_longest_queries(dev):
+    """a class of more than 4 096 alignments whose queries are as long as the device form takes (2 048 bases): eight 8-lane rows of
+    them do not fit the LDS of a workgroup - the launch must share it among fewer rows, not refuse the call"""
+    from clairs_to_amd.realign_reads import sw_ends_batch
+    rng = np.random.default_rng(12)
+    ref = rng.integers(0, 4, 2048).astype(np.int8)
+    pairs = []
+    for i in range(4300):
+        q = ref.copy()
+        k = int(rng.integers(100, 1900))
+        q[k] = (q[k] + 1) % 4
+        if i % 3 == 0:
+            q = np.concatenate([q[:k], q[k + int(rng.integers(1, 40)):]])
+        pairs.append((ref, q))
+    d = sw_ends_batch(pairs, "device")
+    h = sw_ends_batch(pairs[:600], "host", threads=16)
+    assert (d[:600] == h).all() and int((d[:, 5] == 8).sum()) == len(pairs)
