@@ -237,7 +237,14 @@ def realign_variants(args):
     threads = max(1, int(args.threads * 4 / 5))
     failed, done = set(), 0
     batcher = None
-    if getattr(args, "realigner", "host") == "device" and todo:
+    realigner = getattr(args, "realigner", "host")
+    if realigner == "auto":                       # the device form where a HIP device is visible to this process
+        try:
+            import torch
+            realigner = "device" if torch.cuda.is_available() else "host"
+        except ImportError:
+            realigner = "host"
+    if realigner == "device" and todo:
         # the calls are worker threads that park their windows at a WindowBatcher (realign_reads.py): when all of them wait, one
         # cto_realign_windows call - k_fast_pass + k_sw on the current HIP device - serves the lot.  More threads than cores on
         # purpose: they sleep while the batch runs, and a batch is only as large as the number of calls in flight.
@@ -302,8 +309,8 @@ def main():
     p.add_argument("--threads", type=int, default=1)
     p.add_argument("--pool", type=str, default="thread", choices=["thread", "process"],
                    help="workers are threads (default) or spawned processes (the reference's ProcessPoolExecutor; scales with the cores)")
-    p.add_argument("--realigner", type=str, default="host", choices=["host", "device"],
-                   help="host: every window through cto_realign_reads on the worker that needs it (SSE2); device: the windows of all calls "
+    p.add_argument("--realigner", type=str, default="auto", choices=["auto", "host", "device"],
+                   help="auto (default): device where a HIP device is visible, host otherwise; host: every window through cto_realign_reads on the worker that needs it (SSE2); device: the windows of all calls "
                         "in flight are batched into cto_realign_windows calls on the current HIP device (k-mer fast pass and both striped "
                         "Smith-Waterman passes as kernels; same output)")
     p.add_argument("--python", type=str, default="python3", help="accepted for compatibility: the realignment runs in-process")
