@@ -143,6 +143,7 @@ SYMBOLS = {
     "cto_vcf_rows_batch": (c_i64, [C.c_char_p, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_double,
                                    c_vp, C.c_size_t, c_vp]),
     "cto_model_forward": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "cto_model_forward_raw": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, c_i64, c_vp, c_vp]),
     "cto_model_macs_per_site": (c_i64, [c_vp]),
     "cto_model_n_out": (C.c_int, [c_vp]),
     "cto_model_destroy": (None, [c_vp]),

@@ -225,9 +225,23 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
             const bool ok = i < NPOS * SLOTS && pos >= 0 && s < nsite && c < CIN;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ok) {
-                const float* src = xg + (s * WIN + pos) * CIN + c;
-                if constexpr (VW == 4) v = *reinterpret_cast<const float4*>(src);
-                else { const float2 w2 = *reinterpret_cast<const float2*>(src); v.x = w2.x; v.y = w2.y; }
+                if (pe.xraw) {              // (workgroup-uniform) int16 tensor: converted with the site's coverage scale, in double
+                    const short* src = pe.xraw + (int64_t(site0 + s) * WIN + pos) * CIN + c;
+                    const int depth = pe.xinfo[int64_t(site0 + s) * 12 + 1 + pe.xwhich];
+                    const double sc = (pe.xcov > 0 && depth > pe.xcov) ? double(pe.xcov) / double(depth) : 1.0;
+                    if constexpr (VW == 4) {
+                        const uint2 w = *reinterpret_cast<const uint2*>(src);
+                        v = make_float4(float(double(int(short(w.x & 0xffffu))) * sc), float(double(int(short(w.x >> 16))) * sc),
+                                        float(double(int(short(w.y & 0xffffu))) * sc), float(double(int(short(w.y >> 16))) * sc));
+                    } else {
+                        const unsigned w = *reinterpret_cast<const unsigned*>(src);
+                        v.x = float(double(int(short(w & 0xffffu))) * sc); v.y = float(double(int(short(w >> 16))) * sc);
+                    }
+                } else {
+                    const float* src = xg + (s * WIN + pos) * CIN + c;
+                    if constexpr (VW == 4) v = *reinterpret_cast<const float4*>(src);
+                    else { const float2 w2 = *reinterpret_cast<const float2*>(src); v.x = w2.x; v.y = w2.y; }
+                }
             }
             stage[q] = v;
         }

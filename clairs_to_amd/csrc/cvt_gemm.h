@@ -30,6 +30,11 @@ struct CvtBlockParams {
     const float *w1p, *b1h;                        // fc1 over the LDS image of h (rows padded to RS), fragment order [8][KCH1][64][4]
     // split-operand experiment (CTO_CVT_SPLIT): the five GEMM weights as [hi plane | lo plane] of 16-bit values, row-major [N][K]
     const unsigned short *wq_s, *wkv_s, *wo_s, *w1_s, *w2_s;
+    // stage input as the un-rescaled int16 tensor (xraw != null replaces xin): the rescale of predict.py:172-207 happens at the load,
+    // float(double(v) * min_rescale_cov / depth) with the site's depth = xinfo[site][1 + xwhich], exactly the tensor kernel's expression
+    const short* xraw;
+    const int* xinfo;
+    int xwhich, xcov;
 };
 
 // Consecutive blocks of ONE stage run in one launch (the tile never leaves the CU between them): blk[0] may carry the stage's

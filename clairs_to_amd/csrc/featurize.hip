@@ -625,8 +625,9 @@ __global__ __launch_bounds__(FS_T) void k_featurize_sites(
         const int va0 = int16_t(w0 & 0xffffu), va1 = int16_t(w1 & 0xffffu), vn0 = int16_t(w0 >> 16), vn1 = int16_t(w1 >> 16);
         if (x_aff) *reinterpret_cast<float2*>(x_aff + base + 2 * i) = make_float2(float(double(va0) * sa), float(double(va1) * sa));
         if (x_neg) *reinterpret_cast<float2*>(x_neg + base + 2 * i) = make_float2(float(double(vn0) * sn), float(double(vn1) * sn));
-        if (raw_aff) { raw_aff[base + 2 * i] = int16_t(va0); raw_aff[base + 2 * i + 1] = int16_t(va1); }
-        if (raw_neg) { raw_neg[base + 2 * i] = int16_t(vn0); raw_neg[base + 2 * i + 1] = int16_t(vn1); }
+        // (a site's int16 tensor starts 4 B aligned: 33 * 34 * 2 B per site) one 4-byte store per pair
+        if (raw_aff) *reinterpret_cast<uint32_t*>(raw_aff + base + 2 * i) = (w0 & 0xffffu) | (w1 << 16);
+        if (raw_neg) *reinterpret_cast<uint32_t*>(raw_neg + base + 2 * i) = (w0 >> 16) | (w1 & 0xffff0000u);
     }
 }
 

@@ -17,7 +17,7 @@ namespace {
 // W / fc1w: row-major (the plain schedule, CTO_GRU_ROT=0); Wf / fc1f: the same weights in fragment order (the rotated schedule)
 template <int KIN, int KP, int H, int MS, bool FUSE>
 int launch_gru_range(hipStream_t s, const float* x, const float* W, const float* Wf, const float* bias, float* out, const float* fc1w,
-                     const float* fc1f, float* fc1_part, int64_t B, int64_t begin, int64_t end) {
+                     const float* fc1f, float* fc1_part, int64_t B, int64_t begin, int64_t end, const XRawArgs* raw = nullptr) {
     if (end <= begin) return CTO_OK;
     const size_t smem = size_t(2) * MS * 16 * ((H + 4) + (KP + 4)) * sizeof(float);   // h tiles + x tiles
     constexpr int NW = FUSE ? 4 : CTO_GRU_NW1;
@@ -32,9 +32,23 @@ int launch_gru_range(hipStream_t s, const float* x, const float* W, const float*
         attr_set = true;
     }
     const unsigned grid = unsigned(cdiv(end - begin, MS * 16)) * 2;
+    if constexpr (!FUSE && KIN == 34) {
+        if (raw) {       // layer 1 on the int16 tensor (x = its address): the rotated schedule only - the caller expands for the plain one
+            static bool raw_attr_set = false;
+            if (!raw_attr_set) {
+                CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_layer_rot<KIN, KP, H, MS, FUSE, NW, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
+                raw_attr_set = true;
+            }
+            hipLaunchKernelGGL((k_gru_layer_rot<KIN, KP, H, MS, FUSE, NW, true>), dim3(grid), dim3(64 * NW), smem, s, x, Wf, bias, out, fc1f, fc1_part,
+                               int(B), int(begin), int(end), *raw);
+            CTO_HIP(hipGetLastError());
+            return CTO_OK;
+        }
+    }
     if (rot)
         hipLaunchKernelGGL((k_gru_layer_rot<KIN, KP, H, MS, FUSE, NW>), dim3(grid), dim3(64 * NW), smem, s, x, Wf, bias, out, fc1f, fc1_part,
-                           int(B), int(begin), int(end));
+                           int(B), int(begin), int(end), XRawArgs{nullptr, 0, 0});
     else
         hipLaunchKernelGGL((k_gru_layer<KIN, KP, H, MS, 1, FUSE>), dim3(grid), dim3(256), smem, s, x, W, bias, out, fc1w, fc1_part,
                            int(B), int(begin), int(end));
@@ -49,7 +63,7 @@ int launch_gru_range(hipStream_t s, const float* x, const float* W, const float*
 // half) and which spread a small batch over twice as many CUs: measured 1.45 -> 1.20 ms for B <= 2048, -3 % for B = 10 000.
 template <int KIN, int KP, int H, bool FUSE>
 int launch_gru(hipStream_t s, const float* x, const float* W, const float* Wf, const float* bias, float* out, const float* fc1w,
-               const float* fc1f, float* fc1_part, int64_t B) {
+               const float* fc1f, float* fc1_part, int64_t B, const XRawArgs* raw = nullptr) {
     static const int cus = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
@@ -58,14 +72,24 @@ int launch_gru(hipStream_t s, const float* x, const float* W, const float* Wf, c
     const int64_t round32 = int64_t(16) * cus;                   // sites of one round of 32-site tiles (2 directions)
     const int64_t full = (B / round32) * round32;
     const int64_t rest = B - full;
-    int rc = launch_gru_range<KIN, KP, H, 2, FUSE>(s, x, W, Wf, bias, out, fc1w, fc1f, fc1_part, B, 0, full);
+    int rc = launch_gru_range<KIN, KP, H, 2, FUSE>(s, x, W, Wf, bias, out, fc1w, fc1f, fc1_part, B, 0, full, raw);
     if (rc != CTO_OK || rest == 0) return rc;
-    if (rest * 4 > round32 * 3) return launch_gru_range<KIN, KP, H, 2, FUSE>(s, x, W, Wf, bias, out, fc1w, fc1f, fc1_part, B, full, B);
-    return launch_gru_range<KIN, KP, H, 1, FUSE>(s, x, W, Wf, bias, out, fc1w, fc1f, fc1_part, B, full, B);
+    if (rest * 4 > round32 * 3) return launch_gru_range<KIN, KP, H, 2, FUSE>(s, x, W, Wf, bias, out, fc1w, fc1f, fc1_part, B, full, B, raw);
+    return launch_gru_range<KIN, KP, H, 1, FUSE>(s, x, W, Wf, bias, out, fc1w, fc1f, fc1_part, B, full, B, raw);
 }
 
 }  // namespace
 
+// true when launch_gru_layer1_raw runs natively (the rotated schedule); otherwise the caller expands the tensor first
+bool gru_layer1_takes_raw() {
+    static const bool rot = [] { const char* e = getenv("CTO_GRU_ROT"); return !(e && e[0] == '0'); }();
+    return rot;
+}
+int launch_gru_layer1_raw(hipStream_t s, const int16_t* x_raw, const int32_t* site_info, int which, int min_rescale_cov, const float* Wf,
+                          const float* bias, float* out, int64_t B) {
+    const XRawArgs raw{site_info, which, min_rescale_cov};
+    return launch_gru<34, 48, 128, false>(s, reinterpret_cast<const float*>(x_raw), nullptr, Wf, bias, out, nullptr, nullptr, nullptr, B, &raw);
+}
 int launch_gru_layer1(hipStream_t s, const float* x, const float* W, const float* Wf, const float* bias, float* out, int64_t B) {
     return launch_gru<34, 48, 128, false>(s, x, W, Wf, bias, out, nullptr, nullptr, nullptr, B);
 }

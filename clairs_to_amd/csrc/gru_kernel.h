@@ -324,11 +324,17 @@ __global__ __launch_bounds__(256 * MH) void k_gru_layer(const float* __restrict_
 #ifdef CTO_GRU_CLOCKS
 __device__ long long g_gru_clk[16];
 #endif
-template <int KIN, int KP, int H, int MS, bool FUSE_FC1, int NW = 4>
+// XRAW (layer 1 only): x is the un-rescaled int16 tensor cto_featurize_sites writes (raw_aff / raw_neg) and the coverage rescale of
+// clairs/predict.py:172-207 happens where the tile is staged: float(double(v) * scale), scale = min_rescale_cov / depth in double when
+// the site's depth (site_info[site][1 + which]) exceeds min_rescale_cov - the expression the tensor kernel itself uses for its fp32
+// outputs, so the values that reach the LDS tile are the same bits; the fp32 tensors are then never written or read (18 MB per network
+// and 4096-site step).
+struct XRawArgs { const int* site_info; int which, min_rescale_cov; };
+template <int KIN, int KP, int H, int MS, bool FUSE_FC1, int NW = 4, bool XRAW = false>
 __global__ __launch_bounds__(64 * NW) void k_gru_layer_rot(const float* __restrict__ x, const float* __restrict__ Wcat,
                                                        const float* __restrict__ bias, float* __restrict__ out,
                                                        const float* __restrict__ fc1w, float* __restrict__ fc1_part, int B, int site_begin,
-                                                       int site_end) {
+                                                       int site_end, XRawArgs xr = XRawArgs{nullptr, 0, 0}) {
     // NW waves share the H columns of the tile: NW = 4 is one wave per SIMD, NW = 8 two (one wave's gate arithmetic then runs
     // under the other's MFMAs as well as under its own)
     static_assert(H % (16 * NW) == 0 && (!FUSE_FC1 || NW == 4), "the fused fc1 slab is laid out for four waves");
@@ -399,6 +405,21 @@ __global__ __launch_bounds__(64 * NW) void k_gru_layer_rot(const float* __restri
     for (int ms = 0; ms < MS; ++ms) { accf[ms][0] = f32x4{0.f, 0.f, 0.f, 0.f}; accf[ms][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     float4 xstage[XPER];
+    double xscale[XRAW ? XPER : 1];
+    if constexpr (XRAW) {
+        static_assert(!XRAW || XW == 2, "the int16 loader is written for layer 1 (34 channels, two per staging unit)");
+#pragma unroll
+        for (int q = 0; q < XPER; ++q) {
+            const int u = threadIdx.x + q * NTHR;
+            const int row = u / (KIN / XW);
+            double sc = 1.0;
+            if (u < XQ && site0 + row < site_end) {
+                const int depth = xr.site_info[int64_t(site0 + row) * 12 + 1 + xr.which];
+                if (xr.min_rescale_cov > 0 && depth > xr.min_rescale_cov) sc = double(xr.min_rescale_cov) / double(depth);
+            }
+            xscale[q] = sc;
+        }
+    }
     auto x_fetch = [&](int t) {
 #pragma unroll
         for (int q = 0; q < XPER; ++q) {
@@ -406,10 +427,15 @@ __global__ __launch_bounds__(64 * NW) void k_gru_layer_rot(const float* __restri
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const int row = u / (KIN / XW), c = (u - row * (KIN / XW)) * XW;
             if (u < XQ && site0 + row < site_end) {
-                const float* src = x + (int64_t(site0 + row) * T + t) * KIN + c;     // (site, t) rows are KIN floats: XW-aligned
-                if constexpr (XW == 4) v = *reinterpret_cast<const float4*>(src);
-                else if constexpr (XW == 2) { const float2 w2 = *reinterpret_cast<const float2*>(src); v.x = w2.x; v.y = w2.y; }
-                else v.x = *src;
+                if constexpr (XRAW) {          // two int16 channels in one 4-byte load, kept as bits until the tile is committed
+                    const short* src = reinterpret_cast<const short*>(x) + (int64_t(site0 + row) * T + t) * KIN + c;
+                    v.x = __uint_as_float(*reinterpret_cast<const unsigned*>(src));
+                } else {
+                    const float* src = x + (int64_t(site0 + row) * T + t) * KIN + c;     // (site, t) rows are KIN floats: XW-aligned
+                    if constexpr (XW == 4) v = *reinterpret_cast<const float4*>(src);
+                    else if constexpr (XW == 2) { const float2 w2 = *reinterpret_cast<const float2*>(src); v.x = w2.x; v.y = w2.y; }
+                    else v.x = *src;
+                }
             }
             xstage[q] = v;
         }
@@ -422,7 +448,11 @@ __global__ __launch_bounds__(64 * NW) void k_gru_layer_rot(const float* __restri
             const int row = u / (KIN / XW), c = (u - row * (KIN / XW)) * XW;
             if (u < XQ) {
                 float* dst = xb + row * XS + c;
-                if constexpr (XW == 4) *reinterpret_cast<float4*>(dst) = xstage[q];
+                if constexpr (XRAW) {
+                    const unsigned w = __float_as_uint(xstage[q].x);
+                    const int v0 = int(short(w & 0xffffu)), v1 = int(short(w >> 16));
+                    *reinterpret_cast<float2*>(dst) = make_float2(float(double(v0) * xscale[q]), float(double(v1) * xscale[q]));
+                } else if constexpr (XW == 4) *reinterpret_cast<float4*>(dst) = xstage[q];
                 else if constexpr (XW == 2) *reinterpret_cast<float2*>(dst) = make_float2(xstage[q].x, xstage[q].y);
                 else *dst = xstage[q].x;
             }

@@ -18,6 +18,9 @@ using namespace cto;
 // The recurrent kernels live in their own translation unit (gru.hip): co-compiling them with the CvT kernels changed
 // their register allocation and cost up to 4 % from one unrelated edit to the next.
 int launch_gru_layer1(hipStream_t s, const float* x, const float* W, const float* Wf, const float* bias, float* out, int64_t B);
+bool gru_layer1_takes_raw();
+int launch_gru_layer1_raw(hipStream_t s, const int16_t* x_raw, const int32_t* site_info, int which, int min_rescale_cov, const float* Wf,
+                          const float* bias, float* out, int64_t B);
 int launch_gru_layer2_fc1_split(hipStream_t s, const float* x, const void* Wp, const float* bias, const void* Fp, float* fc1_part,
                                 int64_t B, bool f16, const float* scale5);
 int launch_gru_layer1_split(hipStream_t s, const float* x, const void* Wp, const float* bias, float* out, int64_t B, bool f16,
@@ -102,6 +105,8 @@ struct cto_model {
     // workspace
     int64_t ws_B = 0;
     std::vector<void*> ws_ptrs;
+    float* b_xexp = nullptr;          // cto_model_forward_raw's fp32 copy of the int16 tensor where the first layer cannot read it
+    int64_t xexp_B = 0;
     // CvT fusion levels, read from the environment when the model is created (debugging / A-B testing):
     bool fuse_blocks = true;   // fused transformer-block kernel where the stage geometry allows (CTO_CVT_UNFUSED=1 disables)
     bool fuse_embed = true;    // stage embedding + LayerNorm inside the stage's first block (CTO_CVT_NO_EMBED_FUSE=1 disables)
@@ -115,6 +120,7 @@ struct cto_model {
     float *b_h = nullptr, *b_t = nullptr, *b_yq = nullptr, *b_ykv = nullptr, *b_q = nullptr, *b_kv = nullptr,
           *b_o = nullptr, *b_u = nullptr, *b_slab = nullptr, *b_h2 = nullptr;
     ~cto_model() {
+        if (b_xexp) (void)hipFree(b_xexp);
         for (void* p : ws_ptrs) (void)hipFree(p);
         for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (auto& e : prof_ev1) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -298,8 +304,11 @@ int run_head(cto_model* m, hipStream_t s, const float* feat, int64_t B, float* l
     return launch_head(m, s, m->b_slab, S, B, logits);
 }
 
+struct RawIn { const int16_t* x; const int32_t* site_info; int which, min_rescale_cov; };     // the int16 tensor + what rescales it
+
 struct BlockExtra {            // what the first / last block of the network additionally needs
     const float* xin = nullptr;          // stage input when the embedding runs in the block
+    const RawIn* raw = nullptr;          // ... as the int16 tensor instead
     const StageDev* st = nullptr;
     const HeadDev* head = nullptr;       // classifier when the tail runs in the block
     float* logits = nullptr;
@@ -339,6 +348,7 @@ int launch_cvt_block(hipStream_t s, float* h, const BlockDev* blocks, int nblk, 
     if (CIN > 0) {
         CvtBlockParams& p = sp.blk[0];
         p.xin = ex.xin; p.wembp = ex.st->wembp; p.bemb = ex.st->bemb; p.lng = ex.st->lng; p.lnb = ex.st->lnb;
+        if (ex.raw) { p.xraw = reinterpret_cast<const short*>(ex.raw->x); p.xinfo = ex.raw->site_info; p.xwhich = ex.raw->which; p.xcov = ex.raw->min_rescale_cov; }
     }
     if (HEAD) {
         CvtBlockParams& p = sp.blk[nblk - 1];
@@ -416,7 +426,7 @@ int try_fused_blocks(hipStream_t s, const StageDev& st, const BlockDev* b, int n
     return rc == CTO_OK ? 1 : rc;
 }
 
-int cvt_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStream_t s) {
+int cvt_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStream_t s, const RawIn* raw = nullptr) {
     int rc;
     const float* in = x;
     for (int si = 0; si < 3; ++si) {
@@ -448,6 +458,7 @@ int cvt_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStrea
                 const bool embed = embed_in_block && bi == 0;
                 const bool head = m->fuse_head && si == 2 && bi + size_t(nblk) == st.blocks.size() && can_fuse_head(st, m->head);
                 ex.xin = in; ex.st = &st; ex.head = &m->head; ex.logits = logits; ex.n_out = m->n_out;
+                ex.raw = (si == 0 && embed) ? raw : nullptr;
                 const int fr = try_fused_blocks(s, st, &b, nblk, hbuf, B, ex, embed, head, m->cvt_split);
                 if (fr < 0) return fr;
                 if (fr == 1) {
@@ -490,11 +501,12 @@ int prof_begin(cto_model* m, hipStream_t s, hipEvent_t* e0, hipEvent_t* e1) {
     return CTO_OK;
 }
 
-int bigru_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStream_t s) {
+int bigru_forward(cto_model* m, const float* x, int64_t B, float* logits, hipStream_t s, const RawIn* raw = nullptr) {
     int rc;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (m->prof_all && (rc = prof_begin(m, s, &e0, &e1))) return rc;
-    if (m->gw1_split) rc = launch_gru_layer1_split(s, x, m->gw1_split, m->gb1, m->b_h, B, m->split_f16, m->split_sc1);
+    if (raw) rc = launch_gru_layer1_raw(s, raw->x, raw->site_info, raw->which, raw->min_rescale_cov, m->gw1f, m->gb1, m->b_h, B);
+    else if (m->gw1_split) rc = launch_gru_layer1_split(s, x, m->gw1_split, m->gb1, m->b_h, B, m->split_f16, m->split_sc1);
     else rc = launch_gru_layer1(s, x, m->gw1, m->gw1f, m->gb1, m->b_h, B);
     if (rc) return rc;
     if (m->prof_all) {
@@ -898,6 +910,59 @@ extern "C" int cto_model_forward(cto_model* m, const float* x, int64_t B, float*
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (m->prof && (rc = prof_begin(m, s, &e0, &e1))) return rc;
     rc = cvt_forward(m, x, B, logits, s);
+    if (m->prof && rc == CTO_OK) {
+        CTO_HIP(hipEventRecord(e1, s));
+        m->prof_ev.emplace_back(e0, e1);
+    }
+    return rc;
+}
+
+namespace {
+// the fp32 tensor of the int16 one, for handles whose first layer has no int16 loader (split operands, the plain GRU schedule, an
+// embedding outside the block): float(double(v) * scale), the tensor kernel's own expression
+__global__ __launch_bounds__(256) void k_expand_raw(const int16_t* __restrict__ raw, const int32_t* __restrict__ site_info, int which, int cov,
+                                                    int64_t n, float* __restrict__ out) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int depth = site_info[(i / (33 * 34)) * 12 + 1 + which];
+    const double sc = (cov > 0 && depth > cov) ? double(cov) / double(depth) : 1.0;
+    out[i] = float(double(int(raw[i])) * sc);
+}
+}  // namespace
+
+extern "C" int cto_model_forward_raw(cto_model* m, const int16_t* x_raw, const int32_t* site_info, int which, int min_rescale_cov, int64_t B,
+                                     float* logits, void* stream) {
+    CTO_REQUIRE(m && x_raw && site_info && logits && B >= 0 && (which == 0 || which == 1), CTO_EINVAL, "cto_model_forward_raw: bad argument");
+    CTO_REQUIRE(B * 33 < (int64_t(1) << 31) / 640, CTO_EUNSUPPORTED, "batch too large for 32-bit row indices; split it");
+    if (B == 0) return CTO_OK;
+    {
+        int dev = -1;
+        CTO_HIP(hipGetDevice(&dev));
+        CTO_REQUIRE(dev == m->device, CTO_EINVAL, "cto_model_forward_raw: model lives on device %d but device %d is current (one process per GPU)",
+                    m->device, dev);
+    }
+    int rc = ensure_ws(m, B);
+    if (rc != CTO_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool native = m->kind == 1 ? (!m->gw1_split && gru_layer1_takes_raw())
+                                     : (m->fuse_blocks && m->fuse_embed && can_fuse_embed(m->st[0]));
+    if (!native) {
+        if (m->xexp_B < B) {
+            if (m->b_xexp) (void)hipFree(m->b_xexp);
+            m->b_xexp = nullptr; m->xexp_B = 0;
+            CTO_HIP(hipMalloc(reinterpret_cast<void**>(&m->b_xexp), size_t(B) * 33 * 34 * sizeof(float)));
+            m->xexp_B = B;
+        }
+        const int64_t n = B * 33 * 34;
+        hipLaunchKernelGGL(k_expand_raw, dim3(unsigned(cdiv(n, 256))), dim3(256), 0, s, x_raw, site_info, which, min_rescale_cov, n, m->b_xexp);
+        CTO_HIP(hipGetLastError());
+        return cto_model_forward(m, m->b_xexp, B, logits, stream);
+    }
+    const RawIn raw{x_raw, site_info, which, min_rescale_cov};
+    if (m->kind == 1) return bigru_forward(m, nullptr, B, logits, s, &raw);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (m->prof && (rc = prof_begin(m, s, &e0, &e1))) return rc;
+    rc = cvt_forward(m, nullptr, B, logits, s, &raw);
     if (m->prof && rc == CTO_OK) {
         CTO_HIP(hipEventRecord(e1, s));
         m->prof_ev.emplace_back(e0, e1);

@@ -6,6 +6,8 @@ no text tensors, no gzip pipes, no host round trips.  The AFF and NEG networks a
 tensors, so they run on two HIP streams.
 """
 import numpy as np
+import os
+
 import torch
 
 from ._lib import lib, check, c_vp
@@ -77,7 +79,7 @@ class Engine:
     """One GPU's worth of the hot path.  aff/neg: nn_shims modules (or anything exposing `_handle()`)."""
 
     def __init__(self, aff, neg, lik, edges, min_bq=20, min_rescale_cov=50, device="cuda", two_streams=False,
-                 neg_reads_aff=False):
+                 neg_reads_aff=False, raw_inputs=None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("clairs_to_amd.Engine needs a HIP device; there is no CPU fallback")
@@ -88,6 +90,11 @@ class Engine:
         # Illumina: the NEG tensor files are symlinks to the AFF ones (run_clairs_to:1248-1252) - the NEG network reads the
         # --min_bq pass, not the BQ >= 0 pass.  Identical for the platform default (min_bq 0); differs with an explicit --min_bq.
         self.neg_reads_aff = bool(neg_reads_aff)
+        # raw_inputs: the networks read the int16 tensors and rescale where they load them (cto_model_forward_raw) - the fp32 tensors, 18 MB
+        # per network and 4096-site step, are then never written.  Same logits bit for bit, but measured SLOWER on MI355X (the f64
+        # conversion sits in the first layers' staging path: BiGRU layer 1 0.278 -> 0.293 ms, CvT 0.438 -> 0.446, a step 1.866 -> 1.885 ms),
+        # so the fp32 hand-over stays the default; CTO_RAW_INPUTS=1 / raw_inputs=True select the int16 one.
+        self.raw_inputs = (os.environ.get("CTO_RAW_INPUTS", "0") == "1") if raw_inputs is None else bool(raw_inputs)
         with torch.cuda.device(self.device):
             self.h_aff, self.h_neg = aff._handle(), neg._handle()
             self.posterior = Posterior(lik, edges, self.device)
@@ -100,23 +107,36 @@ class Engine:
     def run_device(self, dev_pack, site_pos_dev, want_raw=False):
         """All inputs already resident in HBM. Returns device tensors."""
         with torch.cuda.device(self.device):
-            feat = featurize(dev_pack, site_pos_dev, self.min_bq, self.min_rescale_cov, want_raw=want_raw)
+            raw = self.raw_inputs
+            feat = featurize(dev_pack, site_pos_dev, self.min_bq, self.min_rescale_cov, want_raw=want_raw or raw, want_x=not raw)
             B, K = site_pos_dev.numel(), self.K
-            if self.neg_reads_aff:
-                feat.x_neg = feat.x_aff
             la = torch.empty((K, B, 2), dtype=torch.float32, device=self.device)
             ln = torch.empty((K, B, 2), dtype=torch.float32, device=self.device)
             main = torch.cuda.current_stream()
+            cov = int(self.min_rescale_cov) if self.min_rescale_cov else 0
+            neg_pass = 0 if self.neg_reads_aff else 1
+            if not raw and self.neg_reads_aff:
+                feat.x_neg = feat.x_aff
+
+            def forward(handle, which, logits, stream):
+                if raw:
+                    x = feat.raw_aff if which == 0 else feat.raw_neg
+                    check(lib.cto_model_forward_raw(handle, x.data_ptr(), feat.site_info.data_ptr(), which, cov, B, logits.data_ptr(), int(stream.cuda_stream)))
+                else:
+                    x = feat.x_aff if which == 0 else feat.x_neg
+                    check(lib.cto_model_forward(handle, x.data_ptr(), B, logits.data_ptr(), int(stream.cuda_stream)))
+                return x
+
             if self.s_neg is not None:
                 self.s_neg.wait_stream(main)
-                check(lib.cto_model_forward(self.h_neg, feat.x_neg.data_ptr(), B, ln.data_ptr(), int(self.s_neg.cuda_stream)))
-                check(lib.cto_model_forward(self.h_aff, feat.x_aff.data_ptr(), B, la.data_ptr(), int(main.cuda_stream)))
+                xn = forward(self.h_neg, neg_pass, ln, self.s_neg)
+                forward(self.h_aff, 0, la, main)
                 main.wait_stream(self.s_neg)
-                feat.x_neg.record_stream(self.s_neg)
+                xn.record_stream(self.s_neg)
                 ln.record_stream(self.s_neg)
             else:
-                check(lib.cto_model_forward(self.h_neg, feat.x_neg.data_ptr(), B, ln.data_ptr(), int(main.cuda_stream)))
-                check(lib.cto_model_forward(self.h_aff, feat.x_aff.data_ptr(), B, la.data_ptr(), int(main.cuda_stream)))
+                forward(self.h_neg, neg_pass, ln, main)
+                forward(self.h_aff, 0, la, main)
             out = self.posterior(la, ln)
         out.update(aff_logits=la, neg_logits=ln, site_info=feat.site_info, features=feat)
         return out

@@ -6,7 +6,6 @@ AFF pass (--min_bq <platform>) and the NEG pass (--min_bq 0) at once, plus the r
 clairs/predict.py derives from the tensor text (predict.py:172-207, 626-642)."""
 import ctypes as C
 import os
-from dataclasses import dataclass
 
 import numpy as np
 import torch
@@ -16,20 +15,39 @@ from ._lib import lib, check, current_stream_ptr
 NPOS, NCHAN, COLVEC_STRIDE = 33, 34, 72
 
 
-@dataclass
 class Features:
-    x_aff: torch.Tensor        # [n,33,34] float32, rescaled AFF tensor (network input)
-    x_neg: torch.Tensor        # [n,33,34] float32, rescaled NEG tensor
-    raw_aff: torch.Tensor      # [n,33,34] int16 or None
-    raw_neg: torch.Tensor      # [n,33,34] int16 or None
-    site_info: torch.Tensor    # [n,12] int32: centre col, depth_aff, depth_neg, flags, fwd ACGT, rev ACGT
-    colvec: torch.Tensor       # [n_cols,72] int16 (two-stage path only; None from the one-kernel path)
-    coldepth: torch.Tensor     # [n_cols,2] int32 (two-stage path only)
-    sitefirst: torch.Tensor    # [n,8] int32 ([pass][A,C,G,T]) first-seen entry index within the candidate column
-    keycnt: torch.Tensor       # [n_keys] int32 (uint32 bits: low16 AFF count, high16 NEG count)
-    keyfirst: torch.Tensor     # [n_keys,2] int32 (per pass; defined for the keys of candidate columns only)
-    site_colvec: torch.Tensor = None   # [n,72] int16: the candidate column's own vector (one-kernel path; keycnt is then
-                                       # defined for the keys of candidate columns only, like keyfirst)
+    """What tensor creation leaves in HBM for one batch of candidates.  The network inputs exist as the un-rescaled int16 tensors
+    (raw_aff / raw_neg - the reference's own tensor text, create_tensor_pileup_calling.py) and / or as the rescaled fp32 tensors
+    (x_aff / x_neg - what clairs/predict.py:172-207 makes of that text); a record that was made without the fp32 form derives it on
+    first use from the int16 one: float(double(v) * min_rescale_cov / depth), the tensor kernel's own expression, same bits."""
+
+    def __init__(self, x_aff, x_neg, raw_aff, raw_neg, site_info, colvec, coldepth, sitefirst, keycnt, keyfirst, site_colvec=None,
+                 min_rescale_cov=0):
+        self._x = [x_aff, x_neg]           # [n,33,34] float32, rescaled AFF / NEG tensors (network inputs) or None
+        self.raw_aff = raw_aff             # [n,33,34] int16 or None
+        self.raw_neg = raw_neg
+        self.site_info = site_info         # [n,12] int32: centre col, depth_aff, depth_neg, flags, fwd ACGT, rev ACGT
+        self.colvec = colvec               # [n_cols,72] int16 (two-stage path only; None from the one-kernel path)
+        self.coldepth = coldepth           # [n_cols,2] int32 (two-stage path only)
+        self.sitefirst = sitefirst         # [n,8] int32 ([pass][A,C,G,T]) first-seen entry index within the candidate column
+        self.keycnt = keycnt               # [n_keys] int32 (uint32 bits: low16 AFF count, high16 NEG count)
+        self.keyfirst = keyfirst           # [n_keys,2] int32 (per pass; defined for the keys of candidate columns only)
+        self.site_colvec = site_colvec     # [n,72] int16: the candidate column's own vector (one-kernel path; keycnt is then
+        self.min_rescale_cov = int(min_rescale_cov or 0)      # defined for the keys of candidate columns only, like keyfirst)
+
+    def _expanded(self, which):
+        if self._x[which] is None:
+            raw = self.raw_aff if which == 0 else self.raw_neg
+            if raw is None:
+                return None
+            depth = self.site_info[:, 1 + which].to(torch.float64)
+            cov = float(self.min_rescale_cov)
+            scale = torch.where(depth > cov, cov / depth, torch.ones_like(depth)) if cov > 0 else torch.ones_like(depth)
+            self._x[which] = (raw.to(torch.float64) * scale.view(-1, 1, 1)).to(torch.float32)
+        return self._x[which]
+
+    x_aff = property(lambda self: self._expanded(0), lambda self, v: self._x.__setitem__(0, v))
+    x_neg = property(lambda self: self._expanded(1), lambda self, v: self._x.__setitem__(1, v))
 
 
 def fused_default():
@@ -63,7 +81,8 @@ def featurize(dev_pack, site_pos, min_bq, min_rescale_cov=50, want_raw=False, wa
         check(lib.cto_featurize_sites(C.byref(dev_pack.view), site_pos.data_ptr(), n, int(min_bq), int(min_rescale_cov) if min_rescale_cov else 0,
                                       ptr(x_aff), ptr(x_neg), ptr(raw_aff), ptr(raw_neg), site_info.data_ptr(), site_colvec.data_ptr(),
                                       sitefirst.data_ptr(), keycnt.data_ptr(), keyfirst.data_ptr(), current_stream_ptr()))
-        return Features(x_aff, x_neg, raw_aff, raw_neg, site_info, None, None, sitefirst[:n], keycnt[:nk], keyfirst[:nk], site_colvec[:n])
+        return Features(x_aff, x_neg, raw_aff, raw_neg, site_info, None, None, sitefirst[:n], keycnt[:nk], keyfirst[:nk], site_colvec[:n],
+                        min_rescale_cov=min_rescale_cov)
     colvec = torch.empty((max(nc, 1), COLVEC_STRIDE), dtype=torch.int16, device=dev)   # never a null pointer
     coldepth = torch.empty((max(nc, 1), 2), dtype=torch.int32, device=dev)
     keycnt = torch.empty((max(nk, 1),), dtype=torch.int32, device=dev)
@@ -81,7 +100,8 @@ def featurize(dev_pack, site_pos, min_bq, min_rescale_cov=50, want_raw=False, wa
     check(lib.cto_gather_windows(C.byref(dev_pack.view), colvec.data_ptr(), coldepth.data_ptr(), site_pos.data_ptr(), n,
                                  int(min_bq), int(min_rescale_cov) if min_rescale_cov else 0, ptr(x_aff), ptr(x_neg), ptr(raw_aff),
                                  ptr(raw_neg), site_info.data_ptr(), sitefirst.data_ptr(), keyfirst.data_ptr(), s))
-    return Features(x_aff, x_neg, raw_aff, raw_neg, site_info, colvec[:nc], coldepth[:nc], sitefirst[:n], keycnt[:nk], keyfirst[:nk])
+    return Features(x_aff, x_neg, raw_aff, raw_neg, site_info, colvec[:nc], coldepth[:nc], sitefirst[:n], keycnt[:nk], keyfirst[:nk],
+                    min_rescale_cov=min_rescale_cov)
 
 
 def featurize_op(dev_pack, site_pos, min_bq, min_rescale_cov=50):
@@ -92,7 +112,7 @@ def featurize_op(dev_pack, site_pos, min_bq, min_rescale_cov=50):
     x_aff, x_neg, site_info, colvec, coldepth, keycnt, sitefirst, keyfirst = torch.ops.clairsto.pileup_featurize(
         t["entries"], t["col_off"], t["col_pos"], t["col_ref"], t["key_off"], t["key_meta"], t["key_group"], site_pos, int(min_bq),
         int(min_rescale_cov) if min_rescale_cov else 0)
-    return Features(x_aff, x_neg, None, None, site_info, colvec, coldepth, sitefirst, keycnt, keyfirst)
+    return Features(x_aff, x_neg, None, None, site_info, colvec, coldepth, sitefirst, keycnt, keyfirst, min_rescale_cov=min_rescale_cov)
 
 
 def alt_infos(feat, host_pack, site_info_host=None, pass_idx=0):

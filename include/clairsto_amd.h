@@ -311,6 +311,14 @@ int64_t cto_model_manifest(int kind, const cto_cvt_cfg* cfg, int n_out, char* bu
 /* x dev [B][33][34] float -> logits dev [n_out][B][2] float (post-SELU, pre-softmax), exactly the tuple
  * `model(x)` returns at clairs/predict.py:646-658. */
 int cto_model_forward(cto_model* m, const float* x, int64_t B, float* logits, void* stream);
+/* The same from the un-rescaled int16 tensor (raw_aff / raw_neg of cto_featurize_sites) - the form the reference keeps its tensors in
+ * (create_tensor_pileup_calling.py writes integer text; clairs/predict.py:172-207 rescales on load): x_raw dev [B][33][34] int16,
+ * site_info dev [B][12] as cto_featurize_sites writes it (the depth of pass `which` = 0 AFF / 1 NEG at [1 + which]), min_rescale_cov as
+ * given to the tensor kernel (<= 0: no rescale).  The first layer's loader converts - float(double(v) * min_rescale_cov / depth), the
+ * tensor kernel's own expression, so the logits equal cto_model_forward's on the fp32 tensor bit for bit - and the fp32 tensor is
+ * never written or read.  Handles whose first layer has no int16 loader (split operands, CTO_GRU_ROT=0) expand it once inside the call. */
+int cto_model_forward_raw(cto_model* m, const int16_t* x_raw, const int32_t* site_info, int which, int min_rescale_cov, int64_t B,
+                          float* logits, void* stream);
 /* algorithmic multiply-accumulate count per site of this model (for roofline accounting). */
 int64_t cto_model_macs_per_site(const cto_model* m);
 int  cto_model_n_out(const cto_model* m);
