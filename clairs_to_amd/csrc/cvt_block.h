@@ -225,18 +225,10 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
             const bool ok = i < NPOS * SLOTS && pos >= 0 && s < nsite && c < CIN;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ok) {
-                if (pe.xraw) {              // (workgroup-uniform) int16 tensor: converted with the site's coverage scale, in double
+                if (pe.xraw) {              // (workgroup-uniform) int16 tensor: the bits now, the conversion when all pieces are in flight
                     const short* src = pe.xraw + (int64_t(site0 + s) * WIN + pos) * CIN + c;
-                    const int depth = pe.xinfo[int64_t(site0 + s) * 12 + 1 + pe.xwhich];
-                    const double sc = (pe.xcov > 0 && depth > pe.xcov) ? double(pe.xcov) / double(depth) : 1.0;
-                    if constexpr (VW == 4) {
-                        const uint2 w = *reinterpret_cast<const uint2*>(src);
-                        v = make_float4(float(double(int(short(w.x & 0xffffu))) * sc), float(double(int(short(w.x >> 16))) * sc),
-                                        float(double(int(short(w.y & 0xffffu))) * sc), float(double(int(short(w.y >> 16))) * sc));
-                    } else {
-                        const unsigned w = *reinterpret_cast<const unsigned*>(src);
-                        v.x = float(double(int(short(w & 0xffffu))) * sc); v.y = float(double(int(short(w >> 16))) * sc);
-                    }
+                    if constexpr (VW == 4) { const uint2 w = *reinterpret_cast<const uint2*>(src); v.x = __uint_as_float(w.x); v.y = __uint_as_float(w.y); }
+                    else v.x = __uint_as_float(*reinterpret_cast<const unsigned*>(src));
                 } else {
                     const float* src = xg + (s * WIN + pos) * CIN + c;
                     if constexpr (VW == 4) v = *reinterpret_cast<const float4*>(src);
@@ -244,6 +236,30 @@ __global__ __launch_bounds__(CVT_BLOCK_THREADS, (2 * cvt_blocks_per_cu<C, W, WKV
                 }
             }
             stage[q] = v;
+        }
+        if (pe.xraw) {
+            // the coverage scale of a site, in double as clairs/predict.py:172-207 computes it: one division per site (lane l of every wave
+            // holds site l's), not one per piece
+            static_assert(TS <= 64, "one lane per site of the tile");
+            double sc_lane = 1.0;
+            if (lane < nsite) {
+                const int depth = pe.xinfo[int64_t(site0 + lane) * 12 + 1 + pe.xwhich];
+                if (pe.xcov > 0 && depth > pe.xcov) sc_lane = double(pe.xcov) / double(depth);
+            }
+            const int sc_lo = __double2loint(sc_lane), sc_hi = __double2hiint(sc_lane);
+#pragma unroll
+            for (int q = 0; q < NIT; ++q) {
+                const int i = tid + q * NT;
+                const int pp = i / SLOTS, sx = pp / (2 * W), pos = pp - sx * 2 * W - 1;
+                const int from = sx < TS ? sx : 0;         // every lane takes part in the exchange: a lane that sits out may be another's source
+                const double sc = __hiloint2double(__shfl(sc_hi, from), __shfl(sc_lo, from));
+                if (i < NPOS * SLOTS && pos >= 0 && sx < nsite) {
+                    const unsigned w0 = __float_as_uint(stage[q].x), w1 = __float_as_uint(stage[q].y);
+                    stage[q].x = float(double(int(short(w0 & 0xffffu))) * sc);
+                    stage[q].y = float(double(int(short(w0 >> 16))) * sc);
+                    if constexpr (VW == 4) { stage[q].z = float(double(int(short(w1 & 0xffffu))) * sc); stage[q].w = float(double(int(short(w1 >> 16))) * sc); }
+                }
+            }
         }
 #pragma unroll
         for (int q = 0; q < NIT; ++q) {

@@ -448,17 +448,27 @@ __global__ __launch_bounds__(64 * NW) void k_gru_layer_rot(const float* __restri
             const int row = u / (KIN / XW), c = (u - row * (KIN / XW)) * XW;
             if (u < XQ) {
                 float* dst = xb + row * XS + c;
-                if constexpr (XRAW) {
-                    const unsigned w = __float_as_uint(xstage[q].x);
-                    const int v0 = int(short(w & 0xffffu)), v1 = int(short(w >> 16));
-                    *reinterpret_cast<float2*>(dst) = make_float2(float(double(v0) * xscale[q]), float(double(v1) * xscale[q]));
-                } else if constexpr (XW == 4) *reinterpret_cast<float4*>(dst) = xstage[q];
+                if constexpr (XRAW) *reinterpret_cast<float2*>(dst) = make_float2(xstage[q].x, xstage[q].y);       // converted by x_convert
+                else if constexpr (XW == 4) *reinterpret_cast<float4*>(dst) = xstage[q];
                 else if constexpr (XW == 2) *reinterpret_cast<float2*>(dst) = make_float2(xstage[q].x, xstage[q].y);
                 else *dst = xstage[q].x;
             }
         }
     };
 
+    // XRAW: the int16 pairs a step fetched become floats in the middle of the NEXT step's h part - the loads have long landed and the
+    // vector unit has nothing else to do under those MFMAs - instead of at the commit, which sits on the step's critical tail
+    auto x_convert = [&]() {
+        if constexpr (XRAW) {
+#pragma unroll
+            for (int q = 0; q < XPER; ++q) {
+                const unsigned w = __float_as_uint(xstage[q].x);
+                const int v0 = int(short(w & 0xffffu)), v1 = int(short(w >> 16));
+                xstage[q].x = float(double(v0) * xscale[q]);
+                xstage[q].y = float(double(v1) * xscale[q]);
+            }
+        }
+    };
     float4 Bq[2][NB][3], Fq[2][2], Aq[2][MS];
     int opq = 0;
     // K of the x part is zero-padded from KIN to KP.  When at most 4 real channels fall into the last 16-wide chunk (layer 1:
@@ -582,8 +592,10 @@ __global__ __launch_bounds__(64 * NW) void k_gru_layer_rot(const float* __restri
     constexpr int P0 = NX & 1;          // buffer parity such that the weights of the first h chunk land in buffer 0
     x_fetch(t_of(0));
     __syncthreads();                    // zero fill complete
+    x_convert();
     x_commit(0);
     x_fetch(t_of(1));
+    x_convert();
     x_commit(1);
     load_B(P0, 0);
     __syncthreads();
@@ -637,6 +649,9 @@ __global__ __launch_bounds__(64 * NW) void k_gru_layer_rot(const float* __restri
             if (sq < NH) {
                 if constexpr (!FUSE_FC1) {
                     if (sq == 1 && step > 0) store_tile(hc, tprev);
+                }
+                if constexpr (XRAW) {
+                    if (sq == NH - 1 && step + 2 < T) x_convert();        // x_{t+2}, fetched at the top of this step
                 }
                 mfma_chunk(cur, ar, az, ahn);
                 fc1_chunk(cur);
