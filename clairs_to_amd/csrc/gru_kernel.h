@@ -405,19 +405,18 @@ __global__ __launch_bounds__(64 * NW) void k_gru_layer_rot(const float* __restri
     for (int ms = 0; ms < MS; ++ms) { accf[ms][0] = f32x4{0.f, 0.f, 0.f, 0.f}; accf[ms][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     float4 xstage[XPER];
-    double xscale[XRAW ? XPER : 1];
+    // XRAW: the coverage scale of a tile row, in double as clairs/predict.py:172-207 computes it; kept in LDS (registers are what this
+    // kernel has none to spare of)
+    __shared__ double xscale_row[XRAW ? TILE : 1];
     if constexpr (XRAW) {
         static_assert(!XRAW || XW == 2, "the int16 loader is written for layer 1 (34 channels, two per staging unit)");
-#pragma unroll
-        for (int q = 0; q < XPER; ++q) {
-            const int u = threadIdx.x + q * NTHR;
-            const int row = u / (KIN / XW);
+        for (int row = threadIdx.x; row < TILE; row += NTHR) {
             double sc = 1.0;
-            if (u < XQ && site0 + row < site_end) {
+            if (site0 + row < site_end) {
                 const int depth = xr.site_info[int64_t(site0 + row) * 12 + 1 + xr.which];
                 if (xr.min_rescale_cov > 0 && depth > xr.min_rescale_cov) sc = double(xr.min_rescale_cov) / double(depth);
             }
-            xscale[q] = sc;
+            xscale_row[row] = sc;
         }
     }
     auto x_fetch = [&](int t) {
@@ -458,16 +457,21 @@ __global__ __launch_bounds__(64 * NW) void k_gru_layer_rot(const float* __restri
 
     // XRAW: the int16 pairs a step fetched become floats in the middle of the NEXT step's h part - the loads have long landed and the
     // vector unit has nothing else to do under those MFMAs - instead of at the commit, which sits on the step's critical tail
-    auto x_convert = [&]() {
+    auto x_convert_one = [&](int q) {
         if constexpr (XRAW) {
-#pragma unroll
-            for (int q = 0; q < XPER; ++q) {
-                const unsigned w = __float_as_uint(xstage[q].x);
-                const int v0 = int(short(w & 0xffffu)), v1 = int(short(w >> 16));
-                xstage[q].x = float(double(v0) * xscale[q]);
-                xstage[q].y = float(double(v1) * xscale[q]);
-            }
+            const unsigned w = __float_as_uint(xstage[q].x);
+            const int v0 = int(short(w & 0xffffu)), v1 = int(short(w >> 16));
+            const int u = threadIdx.x + q * NTHR;
+            const double xsc = xscale_row[u < XQ ? u / (KIN / XW) : 0];
+            // (not the f64 arithmetic is what this costs - an fp32 stand-in measures the same - but the registers: with the scales in
+            // registers layer 1 took 0.292 ms, with them in LDS 0.284, on the fp32 tensor 0.278)
+            xstage[q].x = float(double(v0) * xsc);
+            xstage[q].y = float(double(v1) * xsc);
         }
+    };
+    auto x_convert = [&]() {
+#pragma unroll
+        for (int q = 0; q < XPER; ++q) x_convert_one(q);
     };
     float4 Bq[2][NB][3], Fq[2][2], Aq[2][MS];
     int opq = 0;
@@ -650,8 +654,9 @@ __global__ __launch_bounds__(64 * NW) void k_gru_layer_rot(const float* __restri
                 if constexpr (!FUSE_FC1) {
                     if (sq == 1 && step > 0) store_tile(hc, tprev);
                 }
-                if constexpr (XRAW) {
-                    if (sq == NH - 1 && step + 2 < T) x_convert();        // x_{t+2}, fetched at the top of this step
+                if constexpr (XRAW) {        // x_{t+2}, fetched at the top of this step: one staging unit per chunk, the last chunks of the h part
+                    static_assert(!XRAW || XPER <= NH, "one h chunk per staging unit");
+                    if (sq >= NH - XPER && step + 2 < T) x_convert_one(sq - (NH - XPER));
                 }
                 mfma_chunk(cur, ar, az, ahn);
                 fc1_chunk(cur);

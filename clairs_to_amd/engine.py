@@ -91,9 +91,8 @@ class Engine:
         # --min_bq pass, not the BQ >= 0 pass.  Identical for the platform default (min_bq 0); differs with an explicit --min_bq.
         self.neg_reads_aff = bool(neg_reads_aff)
         # raw_inputs: the networks read the int16 tensors and rescale where they load them (cto_model_forward_raw) - the fp32 tensors, 18 MB
-        # per network and 4096-site step, are then never written.  Same logits bit for bit, but measured slightly SLOWER on MI355X (BiGRU
-        # layer 1 0.278 -> 0.291 ms with the f64 conversion under its h-part MFMAs, the CvT unchanged, a step 1.868 -> 1.875 ms: three
-        # A/B pairs), so the fp32 hand-over stays the default; CTO_RAW_INPUTS=1 / raw_inputs=True select the int16 one.
+        # per network and 4096-site step, are then never written.  Same logits bit for bit, but measured no faster on MI355X (BiGRU layer
+        # 1 0.278 -> 0.284 ms - its register budget, not the f64 arithmetic -, the CvT unchanged, a step 1.874 -> 1.879 ms: A/B pairs), so the fp32 hand-over stays the default; CTO_RAW_INPUTS=1 / raw_inputs=True select the int16 one.
         self.raw_inputs = (os.environ.get("CTO_RAW_INPUTS", "0") == "1") if raw_inputs is None else bool(raw_inputs)
         with torch.cuda.device(self.device):
             self.h_aff, self.h_neg = aff._handle(), neg._handle()
