@@ -205,7 +205,7 @@ class WindowBatcher(object):
     """realign_fn of many calls at once.  The reference starts one `realign_reads` process per low-QUAL call and each hands its
     windows to the native realigner one by one (src/realign_variants.py:73-110, src/realign_reads.py:582-595).  Here the calls of
     a run are worker THREADS; a worker that needs a window realigned parks it here and sleeps, and when every live worker is
-    parked (or `max_batch` windows wait) one cto_realign_windows call does them all - on the device two launches per batch.
+    parked (or `max_batch` windows wait) one cto_realign_windows call does them all - on the device three stages of launches per batch.
     What a call sees is what realign_window returns, so its SAM text does not depend on who shared the batch.
         with WindowBatcher("device", threads=8) as b:      # b.worker() brackets a worker thread's life
             ...

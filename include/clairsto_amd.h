@@ -548,7 +548,7 @@ int cto_ssw_align(const char* ref, const char* query, int32_t* score, int32_t* r
  * cigar_off[n_reads + 1], the CIGARs NUL-terminated in cigar_buf).  where = CTO_REALIGN_HOST: the windows are dealt to host_threads
  * workers (<= 0: cto_set_realign_threads' value), each running what cto_realign_reads runs.  where = CTO_REALIGN_DEVICE: the k-mer
  * fast pass (realigner.cpp:129-229) of every (window, haplotype) and both striped Smith-Waterman passes (ssw.c:118-529 as
- * ssw_align drives them, :781-830) of every haplotype / reference and unplaced-read / haplotype pair run as two launches on `stream`
+ * ssw_align drives them, :781-830) of every haplotype / reference and unplaced-read / haplotype pair run as kernels on `stream` (and streams forked from it)
  * (HIP device current to the caller), the banded tracebacks (ssw.c:531-741) the windows will need - every haplotype against the reference,
  * per unplaced read the pair it picks - as a third stage (k_banded); CIGAR composition stays on the host (host_threads workers).
  * Windows the device form does not take (a haplotype or the reference longer than 2 048 bases, a read longer than 512) run on the
@@ -573,7 +573,7 @@ typedef struct cto_realign_stats {
     int64_t windows, host_windows, reads, haplotypes;
     int64_t fast_pairs;                /* (haplotype, read) pairs of the device fast pass                       */
     int64_t sw_pairs, sw_cells;        /* device Smith-Waterman alignments and their ref x query cells          */
-    double fast_pass_ms, sw_ms;        /* HIP-event time of the two launches                                    */
+    double fast_pass_ms, sw_ms;        /* HIP-event time of the two stages' launches                            */
     double device_stage_ms, host_ms;   /* wall time up to / after the device stages (packing and copies included) */
     int64_t tracebacks, tracebacks_declined;   /* banded tracebacks sent to the device; those it left to the host     */
     double traceback_ms;               /* HIP-event time of their launches                                      */
