@@ -115,6 +115,16 @@ __global__ __launch_bounds__(FP_NT) void k_fast_pass(FpArgs a) {
             const int q_lo = d < 0 ? -d : 0, q_hi = min(span, L - d);
             const bool full = d >= 0 && d + span <= L;
             int run = 0, first = -1, mism = 0;
+            // A run of >= 32 equal bytes contains a whole 16-aligned block of the read, so a diagonal on which no such block matches
+            // has no k-mer hit: nothing to mark, nothing to emit - and only diagonal 0 needs its mismatch count without a hit of its
+            // own (the clipped diagonals may supply one).  A block of unrelated sequence fails after 1.3 compares on average.
+            bool maybe = d == 0;
+            for (int qb = (q_lo + 15) & ~15; qb + 16 <= q_hi && !maybe; qb += 16) {
+                int k = 0;
+                while (k < 16 && s_hap[qb + k + d] == s_read[qb + k]) ++k;
+                maybe = k == 16;
+            }
+            if (!maybe) continue;
             for (int q = q_lo; q < q_hi; ++q) {
                 const unsigned char x = s_hap[q + d], y = s_read[q];
                 const bool eq = x == y;
