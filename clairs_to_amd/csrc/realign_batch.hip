@@ -1,24 +1,26 @@
 // Illumina read realignment, every window of a run at once (SURVEY.md 8f #4b; the `realign_reads` leg of BASELINE configs[3]).
 //
 // The reference hands its native realigner ONE window per call (src/realign_reads.py:582-595 -> realign_reads(...),
-// src/realign/realigner.cpp:782-857) from one Python process per low-QUAL call.  Two of that call's stages are data-parallel over
-// (haplotype, read) pairs and carry nearly all of its arithmetic; cto_realign_windows runs them for ALL windows handed over in
-// one launch each:
+// src/realign/realigner.cpp:782-857) from one Python process per low-QUAL call.  Three of that call's stages are data-parallel over
+// (haplotype, read) pairs and carry nearly all of its arithmetic; cto_realign_windows runs them for ALL windows handed over at once:
 //   k_fast_pass   realigner.cpp:129-229 (FastPassAligner): a read is placed on a haplotype where one of its 32-mers matches
 //                 exactly and the whole read has <= 2 mismatches.  The reference walks a hash index of the reads' k-mers; here
-//                 one workgroup per (window, haplotype) tries every diagonal of every read against the haplotype held in LDS -
-//                 brute force is O(L * span) byte compares per pair, a few microseconds of a CU - and reproduces the order-
-//                 dependent parts of the original (which start a read keeps on a score tie, when a haplotype position counts as
-//                 covered) from the time (haplotype position, read offset) each candidate would have been visited first.
+//                 one workgroup per (window, haplotype) tries the diagonals of every read against the haplotype held in LDS (a
+//                 diagonal is walked when one 16-aligned block of the read matches on it: a run of 32 contains one) and reproduces
+//                 the order-dependent parts of the original (which start a read keeps on a score tie, when a haplotype position
+//                 counts as covered) from the time (haplotype position, read offset) each candidate would have been visited first.
 //   k_sw<byte>,   ssw.c:118-529 (sw_sse2_byte / sw_sse2_word) as ssw_align runs them (:781-830): forward pass, word-mode rerun
 //   k_sw<word>    on overflow, backward pass.  One DPP row is one SSE2 register - 16 lanes in the 8-bit kernel (four alignments per
 //                 wavefront), 8 lanes in the 16-bit kernel (eight per wavefront): lane l holds the stripe positions q = l * seg + j
-//                 of the query exactly as the striped layout of Farrar's kernel does, the byte shift _mm_slli_si128 is row_shr:1,
-//                 the lazy-F loops and their exit tests are kept operation for operation because their corrections are not fed
-//                 back into E - output CIGARs depend on it (csrc/realign.cpp header).  H / E columns live in LDS.
-// Everything after that - banded traceback between the end points, haplotype order, CIGAR composition - is strings and a few
-// hundred cells per read and stays on the host (csrc/realign.cpp: Window::finish), so device results and host results meet in the
-// same code and are held byte-equal by tests/test_gpu_realign.py against oracle/_ref (the reference's own realigner.cpp + SSW).
+//                 of the query exactly as the striped layout of Farrar's kernel does, the byte shift _mm_slli_si128 is row_shr:1.
+//                 The lazy-F loops are computed as what they amount to (a scan over the lanes, one correction applied where the
+//                 next column loads H: row_pass) - their corrections are not fed back into E, and output CIGARs depend on that
+//                 (csrc/realign.cpp header), which the closed form keeps.  H / E columns and the score profile live in LDS.
+//   k_banded      ssw.c:531-741 (banded_sw): the traceback between the end points, one wavefront per alignment, for the pairs the
+//                 windows predict they will need (every haplotype against the reference, the pair each unplaced read picks).
+// What is left - haplotype order, the picks, CIGAR composition - is strings and stays on the host (csrc/realign.cpp:
+// Window::finish, which also runs any traceback it finds missing), so device results and host results meet in the same code and
+// are held byte-equal by tests/test_gpu_realign.py against oracle/_ref (the reference's own realigner.cpp + SSW).
 #include <algorithm>
 #include <atomic>
 #include <chrono>

@@ -1,9 +1,10 @@
-// Stages of one realignment window (csrc/realign.cpp), so that the batch driver (csrc/realign_batch.hip) can run the two
+// Stages of one realignment window (csrc/realign.cpp), so that the batch driver (csrc/realign_batch.hip) can run the
 // data-parallel ones on the device for every window of a run at once and leave the rest where it is:
 //   1. fast pass       k-mer seeded, <= 2 mismatches            host: Window::fast_pass_host   device: k_fast_pass -> set_fast_pass
-//   2. striped passes  forward + backward Smith-Waterman ends   host: Window::ends_host        device: k_sw_ends   -> set_ends
+//   2. striped passes  forward + backward Smith-Waterman ends   host: Window::ends_host        device: k_sw        -> set_ends
 //      for every haplotype against the reference and every read no haplotype took against every live haplotype
-//   3. finish          banded traceback, haplotype order, read -> reference composition (host; strings)
+//   3. tracebacks      banded, between those ends               host: inside finish            device: plan_tracebacks -> k_banded -> set_traced
+//   4. finish          haplotype order, picks, read -> reference composition (host; strings); runs the tracebacks it finds missing
 // The reference runs all of it per window inside realign_reads(...) (src/realign/realigner.cpp:782-857).
 #pragma once
 #include <cstdint>
