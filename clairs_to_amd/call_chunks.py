@@ -214,7 +214,7 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
     cfg.qual_pass = -1.0 if a0.qual is None else float(a0.qual)
     cfg.ref_fa = str(a0.ref_fn).encode()
     cfg.vcf_header = (VCF_HEADER + "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n" % a0.sample_name).encode()
-    cfg.producers, cfg.writers, cfg.depth = int(producers), int(writers), int(depth or 0)
+    cfg.producers, cfg.writers, cfg.depth = int(producers), int(writers), int(depth or os.environ.get("CTO_PIPELINE_DEPTH", 0))
     if not getattr(a0, "mpileup_fn", None) and getattr(a0, "bam_reader", "samtools") == "samtools":
         cfg.samtools = str(a0.samtools).encode()                  # the reference's producer, one child process per chunk
         cfg.samtools_max_depth = int(a0.max_depth or 0)

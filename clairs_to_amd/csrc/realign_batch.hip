@@ -532,7 +532,9 @@ int launch_sw(hipStream_t s, const signed char* pool, const SwDesc* desc, const 
     while (ROWS > 1 && row_bytes * ROWS > size_t(160) * 1024) ROWS /= 2;          // queries near 2 048 bases: fewer rows share the LDS
     const size_t smem = row_bytes * ROWS;
     CTO_REQUIRE(smem <= size_t(160) * 1024, CTO_EUNSUPPORTED, "cto_realign_windows: an alignment of %d x %d does not fit the LDS", Rcap, Qcap);
-    CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sw<BYTE>), hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
+    // once per kernel and for the whole LDS: launches of different classes (and of concurrent calls) must not lower each other's limit
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sw<BYTE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    CTO_HIP(attr);
     hipLaunchKernelGGL((k_sw<BYTE>), dim3(unsigned((n + ROWS - 1) / ROWS)), dim3(unsigned(LW * ROWS)), smem, s, pool, desc, order, n, out, overflowed, segcap);
     CTO_HIP(hipGetLastError());
     return CTO_OK;

@@ -189,3 +189,25 @@ def test_device_sw_on_thousands_of_longest_queries(dev):
     d = sw_ends_batch(pairs, "device")
     h = sw_ends_batch(pairs[:600], "host", threads=16)
     assert (d[:600] == h).all() and int((d[:, 5] == 8).sum()) == len(pairs)
+
+
+def test_concurrent_device_calls_give_what_serial_calls_give(dev):
+    """two host threads inside cto_realign_windows at once (what two dispatchers of one process would do): the kept direction
+    scratch serves one of them, the other allocates its own; launch attributes are set once, not per call"""
+    import threading
+    rng = np.random.default_rng(9)
+    batches = [[ru.gen_window(rng) for _ in range(120)] for _ in range(4)]
+    want = [ru.amd_realign_batch(b, "device", threads=4) for b in batches]
+    got = [None] * len(batches)
+
+    def work(i):
+        import torch
+        torch.cuda.set_device(0)
+        for _ in range(3):
+            got[i] = ru.amd_realign_batch(batches[i], "device", threads=4)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(batches))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert got == want
