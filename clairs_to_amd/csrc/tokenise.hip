@@ -191,6 +191,27 @@ struct ByteStream {
     __device__ __forceinline__ void skip(long long n) { if (n < have) { bits >>= 8 * int(n); have -= int(n); pos += n; } else seek(t, pos + n); }
 };
 
+// The same reader over a wavefront's staged copy of its rows: a byte is one ds_read_u8 at a 32-bit index - no shift register, no
+// refill branch, no 64-bit position.  PMC (tools/tokenise_pmc.sh), count pass, per wavefront of 64 rows: the register reader on the LDS
+// copy 9.1 k vector + 17.8 k scalar + 3.4 k branch instructions, this reader 5.1 k + 16.7 k + 2.8 k (170 -> 156 us; fill 283 -> 265).
+// A CU issues one instruction per cycle whatever its kind, and two thirds of them are SCALAR: the exec-mask bookkeeping of divergent
+// loops and branches (8-13 s_* per trip: s_and_saveexec, s_or / s_andn2 on exec, s_cbranch) - 64 rows that sit at different places of
+// their grammar.  The next form would have to be branch-free (selects on a mode, tokens stored through a selected address), not leaner.
+typedef const __attribute__((address_space(3))) unsigned char* lds_bytes;
+struct LdsStream {
+    lds_bytes t;
+    int pos;
+    __device__ __forceinline__ void seek(const unsigned char* text, long long p) {
+        t = (lds_bytes)text;           // `text` is the LDS copy (TextRef::t of a staged span)
+        pos = int(p);
+    }
+    __device__ __forceinline__ unsigned peek() const { return t[pos]; }
+    __device__ __forceinline__ unsigned peek1() const { return t[pos + 1]; }
+    __device__ __forceinline__ void step() { ++pos; }
+    __device__ __forceinline__ unsigned take() { return t[pos++]; }
+    __device__ __forceinline__ void skip(long long n) { pos += int(n); }
+};
+
 // indel-carrying read-bases of the row being parsed (a lane's private memory; rows without indels never touch it)
 struct RowIndels {
     long long seq[MAX_IND];
@@ -213,7 +234,8 @@ struct RowIndels {
 };
 
 // The base string from `st` on: counts read-bases, collects the indel tokens.  Returns false when the single pass declines the row.
-__device__ __forceinline__ bool walk_bases(ByteStream& st, const unsigned char* t, long long len, int& nt, RowIndels& ind) {
+template <class Stream>
+__device__ __forceinline__ bool walk_bases(Stream& st, const unsigned char* t, long long len, int& nt, RowIndels& ind) {
     nt = 0;
     int last_code = 0;
     for (;;) {
@@ -244,10 +266,11 @@ __device__ __forceinline__ bool walk_bases(ByteStream& st, const unsigned char* 
 struct TextRef { const unsigned char* t; long long base, len; };
 
 // pass 1 of a row: the single forward pass of pack.cpp's fast_row; writes the row's counts, false = not a row this path takes
+template <class Stream>
 __device__ bool count_row(const RowArgs& a, const TextRef& T, long long cur, int row) {
     const unsigned char* t = T.t;
     const long long len = T.len;
-    ByteStream st;
+    Stream st;
     st.seek(t, cur);
     if (st.peek() <= 10u) return false;                                 // an empty row / an empty contig field: the host's
     while (st.peek() > 10u) st.step();                                  // contig
@@ -290,6 +313,7 @@ __device__ bool count_row(const RowArgs& a, const TextRef& T, long long cur, int
 }
 
 // pass 2 of a row: entries, column tables, the row's distinct keys
+template <class Stream>
 __device__ void fill_row(const RowArgs& a, const TextRef& T, long long cur, int row) {
     const unsigned char* t = T.t;
     const long long e0 = a.col_off[row];
@@ -303,13 +327,13 @@ __device__ void fill_row(const RowArgs& a, const TextRef& T, long long cur, int 
     const long long b0 = cur + a.row_b0[row], qs = b0 + a.row_blen[row] + 1, ms = qs + nt + 1;
     RowIndels ind;
     if (a.row_nk[row] > 0) {                                             // the row's indel tokens and their key ids, as pass 1 saw them
-        ByteStream sb;
+        Stream sb;
         sb.seek(t, b0);
         int n2 = 0;
         (void)walk_bases(sb, t, T.len, n2, ind);
         ind.intern(t);
     }
-    ByteStream sb, sq, sm;
+    Stream sb, sq, sm;
     sb.seek(t, b0); sq.seek(t, qs); sm.seek(t, ms);
     int idx = 0, w = 0;
     while (idx < nt) {
@@ -694,11 +718,14 @@ __global__ __launch_bounds__(64) void k_rows_lanes(RowArgs a) {
     }
     if (r >= a.n_rows) return;
     const long long cur = a.row_start[r];
+    const bool staged = T.t != a.text;                       // (the wavefront's decision)
     if (FILL) {
         if (r > 0 && a.row_pos[r] <= a.row_pos[r - 1]) atomicMax(&a.fl->bad_order, 1);
-        fill_row(a, T, cur - T.base, r);
-    } else if (!count_row(a, T, cur - T.base, r)) {
-        atomicMax(&a.fl->slow, int(min(cur + 1, (long long)0x7fffffff)));
+        if (staged) fill_row<LdsStream>(a, T, cur - T.base, r);
+        else fill_row<ByteStream>(a, T, cur - T.base, r);
+    } else {
+        const bool ok = staged ? count_row<LdsStream>(a, T, cur - T.base, r) : count_row<ByteStream>(a, T, cur - T.base, r);
+        if (!ok) atomicMax(&a.fl->slow, int(min(cur + 1, (long long)0x7fffffff)));
     }
 }
 __global__ __launch_bounds__(128) void k_key_strings(const unsigned char* __restrict__ text, const unsigned char* __restrict__ ref, int n_keys,
