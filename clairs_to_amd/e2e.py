@@ -115,7 +115,9 @@ def measure(eng, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, reg
         t0 = time.perf_counter()
         run, source = build_run(d, kind, n_chunks, sites_per_chunk, distinct, region_kb)
         prep_s = time.perf_counter() - t0
-        times = 3 if kind == "bam" else 1
+        # a pass over the prepared files runs them several times over: its fill and drain (~12 ms: the first chunk's tokenising, the last one's
+        # records) are a fixed cost that a run of 96 chunks (0.2 s) would carry as 6 % of its rate, a genome's run not at all
+        times = 3 if kind == "bam" else 2
         r = time_run(eng, run, kind, os.path.join(d, "vcf_output"), producers, writers, repeats, pipeline=pipeline, times=times)
         if times > 1:
             source += "; every chunk %d times per pass (%d jobs)" % (times, times * len(run["chunks"]))
