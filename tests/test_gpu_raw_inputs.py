@@ -69,8 +69,9 @@ def test_engine_on_raw_inputs_equals_the_fp32_engine(dev):
     import torch
     from clairs_to_amd.synth import SynthChunk
     chunk = SynthChunk(1500, seed=7)
-    e_raw, e_f32 = _engine(4, dev, raw_inputs=True), _engine(4, dev)
-    assert e_raw.raw_inputs and not e_f32.raw_inputs          # the fp32 hand-over is the default (measured faster: engine.py)
+    e_raw, e_f32 = _engine(4, dev, raw_inputs=True), _engine(4, dev, raw_inputs=False)
+    assert e_raw.raw_inputs and not e_f32.raw_inputs
+    assert _engine(4, dev).raw_inputs == (os.environ.get("CTO_RAW_INPUTS", "0") == "1")      # the fp32 hand-over is the default (engine.py)
     a = e_raw.run_chunk(chunk.arrays(), chunk.site_pos)
     b = e_f32.run_chunk(chunk.arrays(), chunk.site_pos)
     torch.cuda.synchronize()
@@ -79,7 +80,7 @@ def test_engine_on_raw_inputs_equals_the_fp32_engine(dev):
     assert a["features"]._x == [None, None] and a["features"].raw_aff is not None          # no fp32 tensor was written
     assert torch.equal(a["features"].x_aff, b["features"].x_aff)
     # Illumina: the NEG network reads the AFF pass
-    e1, e2 = _engine(4, dev, neg_reads_aff=True, raw_inputs=True), _engine(4, dev, neg_reads_aff=True)
+    e1, e2 = _engine(4, dev, neg_reads_aff=True, raw_inputs=True), _engine(4, dev, neg_reads_aff=True, raw_inputs=False)
     a, b = e1.run_chunk(chunk.arrays(), chunk.site_pos), e2.run_chunk(chunk.arrays(), chunk.site_pos)
     torch.cuda.synchronize()
     assert torch.equal(a["neg_logits"], b["neg_logits"]) and torch.equal(a["probs"], b["probs"])
