@@ -129,17 +129,17 @@ int scan_exclusive(hipStream_t s, const int* in, int n, T* out /* n + 1 */, T* t
 }
 
 // ---- character classes of pack.cpp: 0..11 read-base code, 12 indel sign, 13 '^', 14 skipped, 15 ends a field (byte <= 10) ----
-__device__ __forceinline__ int char_class(unsigned c) {
-    if (c <= 10u) return 15;
-    switch (c) {
-        case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3;
-        case 'a': return 4; case 'c': return 5; case 'g': return 6; case 't': return 7;
-        case '*': return 8; case '#': return 9; case 'N': return 10; case 'n': return 11;
-        case '+': case '-': return 12;
-        case '^': return 13;
-        default: return 14;
-    }
-}
+// as a table: a `switch` over the byte is a dozen compare-and-branch steps, each with its exec-mask bookkeeping, per byte and wavefront
+__device__ const unsigned char kCharClass[256] = {
+    15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14,
+    14, 14, 14, 9, 14, 14, 14, 14, 14, 14, 8, 12, 14, 12, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14,
+    14, 0, 14, 1, 14, 14, 14, 2, 14, 14, 14, 14, 14, 14, 10, 14, 14, 14, 14, 14, 3, 14, 14, 14, 14, 14, 14, 14, 14, 14, 13, 14,
+    14, 4, 14, 5, 14, 14, 14, 6, 14, 14, 14, 14, 14, 14, 11, 14, 14, 14, 14, 14, 7, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14,
+    14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14,
+    14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14,
+    14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14,
+    14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14};
+__device__ __forceinline__ int char_class(unsigned c) { return kCharClass[c & 255u]; }
 __device__ __forceinline__ unsigned char up_c(unsigned char c) { return (c >= 'a' && c <= 'z') ? static_cast<unsigned char>(c - 32) : c; }
 __device__ __forceinline__ int ref_code_dev(unsigned char c) {
     switch (up_c(c)) { case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 0; }
