@@ -140,6 +140,9 @@ __device__ const unsigned char kCharClass[256] = {
     14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14,
     14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14};
 __device__ __forceinline__ int char_class(unsigned c) { return kCharClass[c & 255u]; }
+// the same from a workgroup's LDS copy of the table (k_rows_lanes: a byte's class is on the byte walk's dependent chain)
+typedef const __attribute__((address_space(3))) unsigned char* lds_table;
+__device__ __forceinline__ int char_class(lds_table cls, unsigned c) { return cls ? int(cls[c & 255u]) : int(kCharClass[c & 255u]); }
 __device__ __forceinline__ unsigned char up_c(unsigned char c) { return (c >= 'a' && c <= 'z') ? static_cast<unsigned char>(c - 32) : c; }
 __device__ __forceinline__ int ref_code_dev(unsigned char c) {
     switch (up_c(c)) { case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 0; }
@@ -235,12 +238,13 @@ struct RowIndels {
 
 // The base string from `st` on: counts read-bases, collects the indel tokens.  Returns false when the single pass declines the row.
 template <class Stream>
-__device__ __forceinline__ bool walk_bases(Stream& st, const unsigned char* t, long long len, int& nt, RowIndels& ind) {
+__device__ __forceinline__ bool walk_bases(Stream& st, const unsigned char* t, long long len, int& nt, RowIndels& ind, const unsigned char* cls_g = nullptr) {
+    lds_table cls = (lds_table)cls_g;
     nt = 0;
     int last_code = 0;
     for (;;) {
         const unsigned c = st.peek();
-        const int cl = char_class(c);
+        const int cl = char_class(cls, c);
         if (cl < 12) { last_code = cl; ++nt; st.step(); }
         else if (cl == 14) st.step();
         else if (cl == 13) { if (st.peek1() <= 10u) return false; st.step(); st.step(); }
@@ -263,7 +267,7 @@ __device__ __forceinline__ bool walk_bases(Stream& st, const unsigned char* t, l
 
 // Where a row's bytes are read: the text in HBM (base 0), or a wavefront's staged copy of its rows in LDS (t[0] = text[base]; offsets
 // below are relative to t, `len` = the bytes that belong to rows - what lies behind is look-ahead padding)
-struct TextRef { const unsigned char* t; long long base, len; };
+struct TextRef { const unsigned char* t; long long base, len; const unsigned char* cls; };      // cls: the class table in LDS (or null)
 
 // pass 1 of a row: the single forward pass of pack.cpp's fast_row; writes the row's counts, false = not a row this path takes
 template <class Stream>
@@ -290,7 +294,7 @@ __device__ bool count_row(const RowArgs& a, const TextRef& T, long long cur, int
     const long long b0 = st.pos;
     int nt = 0;
     RowIndels ind;
-    if (!walk_bases(st, t, len, nt, ind)) return false;
+    if (!walk_bases(st, t, len, nt, ind, T.cls)) return false;
     if (st.peek() != '\t' || nt > kMaxDepth) return false;
     const long long blen = st.pos - b0;
     st.step();
@@ -330,15 +334,16 @@ __device__ void fill_row(const RowArgs& a, const TextRef& T, long long cur, int 
         Stream sb;
         sb.seek(t, b0);
         int n2 = 0;
-        (void)walk_bases(sb, t, T.len, n2, ind);
+        (void)walk_bases(sb, t, T.len, n2, ind, T.cls);
         ind.intern(t);
     }
     Stream sb, sq, sm;
     sb.seek(t, b0); sq.seek(t, qs); sm.seek(t, ms);
     int idx = 0, w = 0;
+    lds_table cls = (lds_table)T.cls;
     while (idx < nt) {
         const unsigned c = sb.peek();
-        const int cl = char_class(c);
+        const int cl = char_class(cls, c);
         if (cl < 12) {
             unsigned e = unsigned(cl) | ((sq.take() - 33u) << 6) | ((sm.take() - 33u) << 13);
             if (w < ind.n && (ind.at[w] >> 2) == idx) {
@@ -710,11 +715,14 @@ __global__ __launch_bounds__(64) void k_rows_lanes(RowArgs a) {
     const long long span0 = a.row_start[r0], span1 = r1 < a.n_rows ? a.row_start[r1] : a.len;
     const long long a0 = span0 & ~15LL;
     const long long need = span1 - a0 + 48;                 // a stream looks 40 bytes past the byte it stands on
-    TextRef T{a.text, 0, a.len};
+    __shared__ unsigned char s_cls[256];
+    for (int i = lane; i < 256; i += 64) s_cls[i] = kCharClass[i];
+    __syncthreads();
+    TextRef T{a.text, 0, a.len, s_cls};
     if (need <= TOKL_CAP) {
         for (long long i = lane * 16LL; i < need; i += 64 * 16) *reinterpret_cast<uint4*>(s_text + i) = *reinterpret_cast<const uint4*>(a.text + a0 + i);
         __syncthreads();
-        T = TextRef{s_text, a0, span1 - a0};
+        T = TextRef{s_text, a0, span1 - a0, s_cls};
     }
     if (r >= a.n_rows) return;
     const long long cur = a.row_start[r];
