@@ -756,8 +756,10 @@ __global__ __launch_bounds__(64) void k_banded(const signed char* __restrict__ p
                 const int sc = (rj == ri && rj < 4) ? 4 : -6;
                 const int t2h = hbd + sc, e1 = max(e, 0), hp = max(e1, t2h), g = hp - kGapO;
                 int incl = valid ? g + kGapE * j : TB_NEG;
+                const int span = min(64, width_d - c0);            // lanes of this chunk that can hold a cell: most bands are a few cells wide
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl = max(incl, t); }
+                for (int o = 1; o < 64; o <<= 1)
+                    if (o < span) { const int t = __shfl_up(incl, o); if (lane >= o) incl = max(incl, t); }
                 int excl = __shfl_up(incl, 1);
                 if (lane == 0) excl = TB_NEG;
                 const int f = max(carry, excl) - kGapE * (j - 1);
@@ -768,7 +770,7 @@ __global__ __launch_bounds__(64) void k_banded(const signed char* __restrict__ p
                 const int dh = tt1 <= t2h ? 1 : (e1 > f1 ? (de3 ? 3 : 2) : (df5 ? 5 : 4));
                 if (valid) { eb[u] = e; hc[u] = h; best = max(best, h); }
                 if (jj < width_d) line[jj] = valid ? static_cast<unsigned char>(int(de3) | (int(df5) << 1) | (dh << 2)) : static_cast<unsigned char>(0);
-                carry = max(carry, __shfl(incl, 63));
+                carry = max(carry, __shfl(incl, span - 1));
                 g_prev = __shfl(g, 63); f_prev = __shfl(f, 63);
             }
             __syncthreads();
