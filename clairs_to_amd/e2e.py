@@ -124,8 +124,9 @@ def measure(eng, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, reg
         r.update(source=source, input_synthesis_s=round(prep_s, 1))
         if host_tokeniser_too and kind == "text" and pipeline == "native":
             # the same files with the text tokenised on the device (cto_tokenise_device) instead of on the producer threads: what a rank with
-            # a few cores to itself runs (call_chunks' default there); two producers are enough to keep it fed
-            h = time_run(eng, run, kind, os.path.join(d, "vcf_output_dev_tok"), 2, writers, repeats, pipeline=pipeline, times=times,
+            # a few cores to itself runs (call_chunks' default there); four producer threads (they mostly wait for the device: ~5 ms of CPU
+            # per chunk all threads together; measured 1.42 / 1.59 / 1.66 M sites/s with 2 / 3 / 4)
+            h = time_run(eng, run, kind, os.path.join(d, "vcf_output_dev_tok"), 4, writers, repeats, pipeline=pipeline, times=times,
                          device_tokenise=True)
             r["device_tokeniser"] = {k: h[k] for k in ("sites_per_s", "seconds", "producers", "stage_thread_time", "host_process", "device_tokenised")}
         if with_extraction and kind == "bam":
