@@ -94,9 +94,24 @@ __global__ __launch_bounds__(1024) void k_tile_scan(T* __restrict__ tile_sum, in
     }
     if (threadIdx.x == 0) *total = carry;
 }
-template <class T>
-__global__ __launch_bounds__(256) void k_tile_apply(const int* __restrict__ in, int n, const T* __restrict__ tile_base, T* __restrict__ out) {
+// SUMS: tile_base holds the tiles' SUMS (k_tile_sum's output, no k_tile_scan in between) and every workgroup adds up those in front of
+// its own - for the few dozen tiles of a chunk's rows and keys that is cheaper than a launch; `total` is then written here
+template <class T, bool SUMS>
+__global__ __launch_bounds__(256) void k_tile_apply(const int* __restrict__ in, int n, const T* __restrict__ tile_base, T* __restrict__ out,
+                                                    T* __restrict__ total) {
     __shared__ T part[256];
+    __shared__ T s_base;
+    if (SUMS) {
+        T b = 0;
+        for (int i = threadIdx.x; i < int(blockIdx.x); i += 256) b += tile_base[i];
+        part[threadIdx.x] = b;
+        __syncthreads();
+        for (int d = 128; d > 0; d >>= 1) { if (int(threadIdx.x) < d) part[threadIdx.x] += part[threadIdx.x + d]; __syncthreads(); }
+        if (threadIdx.x == 0) s_base = part[0];
+        __syncthreads();
+    }
+    const T tile0 = SUMS ? s_base : tile_base[blockIdx.x];
+    __syncthreads();
     const int t0 = blockIdx.x * SCAN_TILE;
     constexpr int PER = SCAN_TILE / 256;
     const int i0 = t0 + threadIdx.x * PER;
@@ -112,18 +127,25 @@ __global__ __launch_bounds__(256) void k_tile_apply(const int* __restrict__ in, 
         part[threadIdx.x] += a;
         __syncthreads();
     }
-    const T base = tile_base[blockIdx.x] + part[threadIdx.x] - s;
+    const T base = tile0 + part[threadIdx.x] - s;
 #pragma unroll
     for (int k = 0; k < PER; ++k) if (i0 + k < n) out[i0 + k] = base + loc[k];
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) out[n] = tile_base[blockIdx.x] + part[255];      // out has n + 1 elements
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
+        out[n] = tile0 + part[255];      // out has n + 1 elements
+        if (SUMS) *total = tile0 + part[255];
+    }
 }
 template <class T>
 int scan_exclusive(hipStream_t s, const int* in, int n, T* out /* n + 1 */, T* tile_tmp, T* total) {
     if (n <= 0) { CTO_HIP(hipMemsetAsync(out, 0, sizeof(T), s)); CTO_HIP(hipMemsetAsync(total, 0, sizeof(T), s)); return CTO_OK; }
     const int tiles = int(cdiv(n, SCAN_TILE));
     hipLaunchKernelGGL(k_tile_sum<T>, dim3(unsigned(tiles)), dim3(256), 0, s, in, n, tile_tmp);
-    hipLaunchKernelGGL(k_tile_scan<T>, dim3(1), dim3(1024), 0, s, tile_tmp, tiles, total);
-    hipLaunchKernelGGL(k_tile_apply<T>, dim3(unsigned(tiles)), dim3(256), 0, s, in, n, tile_tmp, out);
+    if (tiles <= 256) {                 // a chunk's rows / keys: two launches instead of three
+        hipLaunchKernelGGL((k_tile_apply<T, true>), dim3(unsigned(tiles)), dim3(256), 0, s, in, n, tile_tmp, out, total);
+    } else {
+        hipLaunchKernelGGL(k_tile_scan<T>, dim3(1), dim3(1024), 0, s, tile_tmp, tiles, total);
+        hipLaunchKernelGGL((k_tile_apply<T, false>), dim3(unsigned(tiles)), dim3(256), 0, s, in, n, tile_tmp, out, total);
+    }
     CTO_HIP(hipGetLastError());
     return CTO_OK;
 }
