@@ -224,7 +224,7 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
     cfg.inflate_jobs = DEVICE_INFLATE[1] if inflate_jobs is None else int(inflate_jobs)
     cfg.device_pileup = int(os.environ.get("CTO_DEVICE_PILEUP", "1") != "0")     # the device-inflated chunks are piled up on the device too
     # mpileup text (files or the samtools child's output) can go up as it is and be tokenised on the device (csrc/tokenise.hip; texts its
-    # single pass declines are tokenised on the host; same packs).  It trades GPU time for host cores - ~0.33 ms of kernels per 22 MB chunk
+    # single pass declines are tokenised on the host; same packs).  It trades GPU time for host cores - ~0.27 ms of kernels per 22 MB chunk
     # beside the networks' 1.9 ms, against 28 ms of host CPU - so the default follows the cores this rank has: with 16 cores to one GPU the
     # host tokeniser keeps the GPU for the networks (measured 1.9 M sites/s against 1.6-1.74 M); the host form is bound by cores / 28 ms
     # per chunk (12 cores: 1.7 M sites/s, 4 cores: 0.58 M), so up to 12 cores per rank - an 8-GPU node's share - the device form is used.
