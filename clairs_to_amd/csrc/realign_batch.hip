@@ -393,17 +393,91 @@ __global__ __launch_bounds__(64) void k_sw(const signed char* pool, const SwDesc
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// Device memory of one call: a bump allocator over a block the library keeps between calls (grow-only; one call at a time has the kept
+// one, a concurrent call - or one on another device - a block of its own that it frees).  A call makes ~25 small allocations; as
+// hipMalloc / hipFree pairs they cost it ~3 ms (hipFree waits for the device each time).
+struct DeviceArena {
+    struct Block { char* p; size_t cap, used; };
+    std::vector<Block> blocks;
+    size_t asked = 0;                  // bytes taken since the last reset
+    int device = -1;
+    void* take(size_t bytes) {
+        bytes = (std::max<size_t>(bytes, 1) + 255) & ~size_t(255);
+        asked += bytes;
+        if (!blocks.empty() && blocks.back().used + bytes <= blocks.back().cap) {
+            void* r = blocks.back().p + blocks.back().used;
+            blocks.back().used += bytes;
+            return r;
+        }
+        const size_t cap = std::max<size_t>(bytes, std::max<size_t>(size_t(32) << 20, blocks.empty() ? 0 : 2 * blocks.back().cap));
+        char* p = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&p), cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        blocks.push_back(Block{p, cap, bytes});
+        return p;
+    }
+    void free_all() { for (Block& b : blocks) (void)hipFree(b.p); blocks.clear(); asked = 0; }
+    // end of a call: one block large enough for what this call took, so that the next one of its size allocates nothing
+    void reset() {
+        if (blocks.size() > 1) {
+            const size_t want = asked + asked / 4;
+            free_all();
+            char* p = nullptr;
+            if (hipMalloc(reinterpret_cast<void**>(&p), want) == hipSuccess) blocks.push_back(Block{p, want, 0});
+            else (void)hipGetLastError();
+        } else if (!blocks.empty()) {
+            blocks.back().used = 0;
+        }
+        asked = 0;
+    }
+};
+thread_local DeviceArena* t_arena = nullptr;
+struct ArenaLease {
+    static std::mutex& lock() { static std::mutex m; return m; }
+    static DeviceArena& kept() { static DeviceArena a; return a; }
+    static bool& busy() { static bool b = false; return b; }
+    DeviceArena* a = nullptr;
+    DeviceArena* prev = nullptr;
+    bool from_kept = false;
+    ArenaLease() {
+        int dev = -1;
+        (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> g(lock());
+            if (!busy() && (kept().device < 0 || kept().device == dev)) { busy() = true; kept().device = dev; a = &kept(); from_kept = true; }
+        }
+        if (!a) a = new DeviceArena();
+        prev = t_arena;
+        t_arena = a;
+    }
+    ~ArenaLease() {
+        t_arena = prev;
+        if (from_kept) { a->reset(); std::lock_guard<std::mutex> g(lock()); busy() = false; }
+        else { a->free_all(); delete a; }
+    }
+};
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t n) { CTO_HIP(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T))); return CTO_OK; }
+    bool owned = true;                 // false: the call's arena owns the bytes
+    ~DevBuf() { if (p && owned) (void)hipFree(p); }
+    int alloc(size_t n) {
+        if (t_arena) {
+            p = static_cast<T*>(t_arena->take(std::max<size_t>(n, 1) * sizeof(T)));
+            owned = false;
+            CTO_REQUIRE(p != nullptr, CTO_EHIP, "cto_realign_windows: out of device memory");
+            return CTO_OK;
+        }
+        CTO_HIP(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T)));
+        return CTO_OK;
+    }
     int put(const std::vector<T>& v, hipStream_t s) {
         int rc = alloc(v.size());
         if (rc != CTO_OK) return rc;
         if (!v.empty()) CTO_HIP(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
         return CTO_OK;
     }
+    void swap(DevBuf& o) { std::swap(p, o.p); std::swap(owned, o.owned); }
 };
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -638,7 +712,7 @@ int sw_ends_pool(const std::vector<signed char>& pool, const std::vector<SwDesc>
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     drop();
     if (st) { st->sw_ms += ms; st->sw_pairs += n; st->sw_cells += cells; }
-    if (keep_pool) std::swap(keep_pool->p, d_pool.p);
+    if (keep_pool) keep_pool->swap(d_pool);
     clk.lap("  SW: launches + D2H");
     return CTO_OK;
 }
@@ -996,6 +1070,7 @@ extern "C" int cto_sw_ends_batch(int n, const int8_t* codes, size_t n_codes, con
     }
     std::vector<Ends> ends(static_cast<size_t>(n), Ends{0, 0, 0, 0, 0, 16});
     if (where == CTO_REALIGN_DEVICE) {
+        ArenaLease lease;
         const std::vector<signed char> pool(reinterpret_cast<const signed char*>(codes), reinterpret_cast<const signed char*>(codes) + n_codes);
         const int rc = sw_ends_pool(pool, d, static_cast<hipStream_t>(stream), nullptr, ends);
         if (rc != CTO_OK) return rc;
@@ -1028,6 +1103,7 @@ extern "C" int cto_ssw_align_batch(int n, const int8_t* codes, size_t n_codes, c
     std::vector<cto_realign::SwAlignment> al(static_cast<size_t>(n));
     auto on_host = [&](size_t k, const Ends& e) { al[k] = cto_realign::alignment_of_pair(codes + d[k].ref_off, d[k].R, codes + d[k].q_off, d[k].Q, e); };
     if (where == CTO_REALIGN_DEVICE && n > 0) {
+        ArenaLease lease;
         hipStream_t s = static_cast<hipStream_t>(stream);
         const std::vector<signed char> pool(reinterpret_cast<const signed char*>(codes), reinterpret_cast<const signed char*>(codes) + n_codes);
         std::vector<Ends> ends;
@@ -1104,6 +1180,7 @@ extern "C" int cto_realign_windows(int n_jobs, cto_realign_job* jobs, int where,
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!dev.empty()) {
+        ArenaLease lease;                                    // (declared before the stage objects: they go first)
         int rc = fast_pass_device(dev, s, threads, stats);
         if (rc != CTO_OK) return rc;
         clk.lap("fast pass (device, copies)");
