@@ -523,30 +523,51 @@ struct StageClock {
 
 int fast_pass_device(std::vector<Window*>& ws, hipStream_t s, int threads, cto_realign_stats* st) {
     StageClock clk;
-    std::vector<unsigned char> hap_bytes, read_bytes, hap_isref;
-    std::vector<int> hap_off{0}, hap_win, read_off{0}, win_read0{0}, win_prefix, win_suffix;
-    std::vector<long long> hit_off;
-    long long hits = 0;
-    for (size_t wi = 0; wi < ws.size(); ++wi) {
+    // sizes first, then every window fills its own slices (on the workers)
+    const size_t nw = ws.size();
+    std::vector<size_t> r0(nw + 1, 0), h0(nw + 1, 0), rb0(nw + 1, 0), hb0(nw + 1, 0);
+    std::vector<long long> hits0(nw + 1, 0);
+    for (size_t wi = 0; wi < nw; ++wi) {
         const Window& w = *ws[wi];
-        for (const std::string& r : w.reads) { read_bytes.insert(read_bytes.end(), r.begin(), r.end()); read_off.push_back(int(read_bytes.size())); }
-        win_read0.push_back(int(read_off.size()) - 1);
-        win_prefix.push_back(w.ref_prefix);
-        win_suffix.push_back(w.ref_suffix);
-        for (const std::string& h : w.haps) {
-            hap_bytes.insert(hap_bytes.end(), h.begin(), h.end());
-            hap_off.push_back(int(hap_bytes.size()));
-            hap_win.push_back(int(wi));
-            hap_isref.push_back(h == w.reference ? 1 : 0);
-            hit_off.push_back(hits);
-            hits += w.n_reads();
-        }
+        size_t rb = 0, hb = 0;
+        for (const std::string& r : w.reads) rb += r.size();
+        for (const std::string& h : w.haps) hb += h.size();
+        r0[wi + 1] = r0[wi] + w.reads.size(); h0[wi + 1] = h0[wi] + w.haps.size();
+        rb0[wi + 1] = rb0[wi] + rb; hb0[wi + 1] = hb0[wi] + hb;
+        hits0[wi + 1] = hits0[wi] + (long long)w.haps.size() * w.n_reads();
     }
+    const long long hits = hits0[nw];
+    std::vector<unsigned char> hap_bytes(hb0[nw]), read_bytes(rb0[nw]), hap_isref(h0[nw]);
+    std::vector<int> hap_off(h0[nw] + 1, 0), hap_win(h0[nw]), read_off(r0[nw] + 1, 0), win_read0(nw + 1, 0), win_prefix(nw), win_suffix(nw);
+    std::vector<long long> hit_off(h0[nw]);
+    CTO_REQUIRE(hb0[nw] < (size_t(1) << 31) && rb0[nw] < (size_t(1) << 31), CTO_EUNSUPPORTED,
+                "cto_realign_windows: more than 2 GiB of sequence in one call; split it");
+    parallel_for(nw, threads, [&](size_t wi) {
+        const Window& w = *ws[wi];
+        size_t at = rb0[wi];
+        for (size_t r = 0; r < w.reads.size(); ++r) {
+            if (!w.reads[r].empty()) memcpy(read_bytes.data() + at, w.reads[r].data(), w.reads[r].size());
+            at += w.reads[r].size();
+            read_off[r0[wi] + r + 1] = int(at);
+        }
+        win_read0[wi + 1] = int(r0[wi + 1]);
+        win_prefix[wi] = w.ref_prefix;
+        win_suffix[wi] = w.ref_suffix;
+        at = hb0[wi];
+        long long hit = hits0[wi];
+        for (size_t h = 0; h < w.haps.size(); ++h) {
+            if (!w.haps[h].empty()) memcpy(hap_bytes.data() + at, w.haps[h].data(), w.haps[h].size());
+            at += w.haps[h].size();
+            hap_off[h0[wi] + h + 1] = int(at);
+            hap_win[h0[wi] + h] = int(wi);
+            hap_isref[h0[wi] + h] = w.haps[h] == w.reference ? 1 : 0;
+            hit_off[h0[wi] + h] = hit;
+            hit += w.n_reads();
+        }
+    });
     const int nh = int(hap_win.size());
     if (nh == 0) return CTO_OK;
     clk.lap("  fast pass: pack");
-    CTO_REQUIRE(hap_bytes.size() < (size_t(1) << 31) && read_bytes.size() < (size_t(1) << 31), CTO_EUNSUPPORTED,
-                "cto_realign_windows: more than 2 GiB of sequence in one call; split it");
     DevBuf<unsigned char> d_hap, d_read, d_isref;
     DevBuf<int> d_hap_off, d_hap_win, d_read_off, d_win_read0, d_prefix, d_suffix, d_hit_score, d_hit_pos, d_hap_score;
     DevBuf<long long> d_hit_off;
