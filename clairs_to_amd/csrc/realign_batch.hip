@@ -430,13 +430,71 @@ struct DeviceArena {
         asked = 0;
     }
 };
+// the same for page-locked host memory: what a call copies up and down (operand bytes, descriptors, results) is built in and landed on
+// pinned blocks, so that hipMemcpyAsync is a DMA and not a staged copy through the runtime's bounce buffers
+struct HostArena {
+    struct Block { char* p; size_t cap, used; };
+    std::vector<Block> blocks;
+    size_t asked = 0;
+    void* take(size_t bytes) {
+        bytes = (std::max<size_t>(bytes, 1) + 255) & ~size_t(255);
+        asked += bytes;
+        if (!blocks.empty() && blocks.back().used + bytes <= blocks.back().cap) {
+            void* r = blocks.back().p + blocks.back().used;
+            blocks.back().used += bytes;
+            return r;
+        }
+        const size_t cap = std::max<size_t>(bytes, std::max<size_t>(size_t(16) << 20, blocks.empty() ? 0 : 2 * blocks.back().cap));
+        char* p = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void**>(&p), cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        blocks.push_back(Block{p, cap, bytes});
+        return p;
+    }
+    bool owns(const void* q) const {
+        for (const Block& b : blocks) if (q >= b.p && q < b.p + b.cap) return true;
+        return false;
+    }
+    void free_all() { for (Block& b : blocks) (void)hipHostFree(b.p); blocks.clear(); asked = 0; }
+    void reset() {
+        if (blocks.size() > 1) {
+            const size_t want = asked + asked / 4;
+            free_all();
+            char* p = nullptr;
+            if (hipHostMalloc(reinterpret_cast<void**>(&p), want, hipHostMallocDefault) == hipSuccess) blocks.push_back(Block{p, want, 0});
+            else (void)hipGetLastError();
+        } else if (!blocks.empty()) {
+            blocks.back().used = 0;
+        }
+        asked = 0;
+    }
+};
+thread_local HostArena* t_harena = nullptr;
+// std::vector over the call's pinned arena (plain heap outside a call or when the arena cannot grow)
+template <class T>
+struct PinnedAlloc {
+    typedef T value_type;
+    PinnedAlloc() = default;
+    template <class U> PinnedAlloc(const PinnedAlloc<U>&) {}
+    T* allocate(size_t n) {
+        if (t_harena) { void* p = t_harena->take(n * sizeof(T)); if (p) return static_cast<T*>(p); }
+        return static_cast<T*>(::operator new(n * sizeof(T)));
+    }
+    void deallocate(T* p, size_t) { if (!(t_harena && t_harena->owns(p))) ::operator delete(p); }
+    template <class U> bool operator==(const PinnedAlloc<U>&) const { return true; }
+    template <class U> bool operator!=(const PinnedAlloc<U>&) const { return false; }
+};
+template <class T> using pinned_vector = std::vector<T, PinnedAlloc<T>>;
+
 thread_local DeviceArena* t_arena = nullptr;
 struct ArenaLease {
     static std::mutex& lock() { static std::mutex m; return m; }
     static DeviceArena& kept() { static DeviceArena a; return a; }
+    static HostArena& kept_host() { static HostArena a; return a; }
     static bool& busy() { static bool b = false; return b; }
     DeviceArena* a = nullptr;
     DeviceArena* prev = nullptr;
+    HostArena* h = nullptr;
+    HostArena* hprev = nullptr;
     bool from_kept = false;
     ArenaLease() {
         int dev = -1;
@@ -446,13 +504,14 @@ struct ArenaLease {
             if (!busy() && (kept().device < 0 || kept().device == dev)) { busy() = true; kept().device = dev; a = &kept(); from_kept = true; }
         }
         if (!a) a = new DeviceArena();
-        prev = t_arena;
-        t_arena = a;
+        h = from_kept ? &kept_host() : new HostArena();
+        prev = t_arena; hprev = t_harena;
+        t_arena = a; t_harena = h;
     }
     ~ArenaLease() {
-        t_arena = prev;
-        if (from_kept) { a->reset(); std::lock_guard<std::mutex> g(lock()); busy() = false; }
-        else { a->free_all(); delete a; }
+        t_arena = prev; t_harena = hprev;
+        if (from_kept) { a->reset(); h->reset(); std::lock_guard<std::mutex> g(lock()); busy() = false; }
+        else { a->free_all(); delete a; h->free_all(); delete h; }
     }
 };
 
@@ -471,7 +530,8 @@ struct DevBuf {
         CTO_HIP(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T)));
         return CTO_OK;
     }
-    int put(const std::vector<T>& v, hipStream_t s) {
+    template <class A>
+    int put(const std::vector<T, A>& v, hipStream_t s) {
         int rc = alloc(v.size());
         if (rc != CTO_OK) return rc;
         if (!v.empty()) CTO_HIP(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
@@ -537,7 +597,8 @@ int fast_pass_device(std::vector<Window*>& ws, hipStream_t s, int threads, cto_r
         hits0[wi + 1] = hits0[wi] + (long long)w.haps.size() * w.n_reads();
     }
     const long long hits = hits0[nw];
-    std::vector<unsigned char> hap_bytes(hb0[nw]), read_bytes(rb0[nw]), hap_isref(h0[nw]);
+    pinned_vector<unsigned char> hap_bytes(hb0[nw]), read_bytes(rb0[nw]);            // (page-locked: the two large uploads of the stage)
+    std::vector<unsigned char> hap_isref(h0[nw]);
     std::vector<int> hap_off(h0[nw] + 1, 0), hap_win(h0[nw]), read_off(r0[nw] + 1, 0), win_read0(nw + 1, 0), win_prefix(nw), win_suffix(nw);
     std::vector<long long> hit_off(h0[nw]);
     CTO_REQUIRE(hb0[nw] < (size_t(1) << 31) && rb0[nw] < (size_t(1) << 31), CTO_EUNSUPPORTED,
@@ -586,7 +647,8 @@ int fast_pass_device(std::vector<Window*>& ws, hipStream_t s, int threads, cto_r
     hipLaunchKernelGGL(k_fast_pass, dim3(unsigned(nh)), dim3(FP_NT), 0, s, a);
     CTO_HIP(hipGetLastError());
     CTO_HIP(hipEventRecord(e1, s));
-    std::vector<int> hit_score(static_cast<size_t>(hits), 0), hit_pos(static_cast<size_t>(hits), 0), hap_score(static_cast<size_t>(nh), 0);
+    pinned_vector<int> hit_score(static_cast<size_t>(hits), 0), hit_pos(static_cast<size_t>(hits), 0);
+    std::vector<int> hap_score(static_cast<size_t>(nh), 0);
     if (hits) {
         CTO_HIP(hipMemcpyAsync(hit_score.data(), d_hit_score.p, size_t(hits) * sizeof(int), hipMemcpyDeviceToHost, s));
         CTO_HIP(hipMemcpyAsync(hit_pos.data(), d_hit_pos.p, size_t(hits) * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -636,7 +698,8 @@ int launch_sw(hipStream_t s, const signed char* pool, const SwDesc* desc, const 
 }
 
 // Both passes of every alignment of `desc` (operands = base codes in `pool`): the end points, in desc order
-int sw_ends_pool(const std::vector<signed char>& pool, const std::vector<SwDesc>& desc, hipStream_t s, cto_realign_stats* st, std::vector<Ends>& ends,
+template <class PoolVec>
+int sw_ends_pool(const PoolVec& pool, const std::vector<SwDesc>& desc, hipStream_t s, cto_realign_stats* st, std::vector<Ends>& ends,
                  DevBuf<signed char>* keep_pool = nullptr) {
     StageClock clk;
     const int n = int(desc.size());
@@ -726,8 +789,10 @@ int sw_ends_pool(const std::vector<signed char>& pool, const std::vector<SwDesc>
     };
     if (rc != CTO_OK) { drop(); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
     CTO_HIP(hipEventRecord(e1, s));
-    CTO_HIP(hipMemcpyAsync(ends.data(), d_out.p, size_t(n) * sizeof(Ends), hipMemcpyDeviceToHost, s));
+    pinned_vector<Ends> landed(static_cast<size_t>(n));
+    CTO_HIP(hipMemcpyAsync(landed.data(), d_out.p, size_t(n) * sizeof(Ends), hipMemcpyDeviceToHost, s));
     CTO_HIP(hipStreamSynchronize(s));
+    memcpy(ends.data(), landed.data(), size_t(n) * sizeof(Ends));
     float ms = 0.f;
     CTO_HIP(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
@@ -743,7 +808,7 @@ struct SwStage { std::vector<SwDesc> desc; std::vector<size_t> first; DevBuf<sig
 int ends_device(std::vector<Window*>& ws, hipStream_t s, int threads, cto_realign_stats* st, SwStage& stage) {
     StageClock clk;
     // code pool: per window the reference, its haplotypes, the reads that need Smith-Waterman - each once
-    std::vector<signed char> pool;
+    pinned_vector<signed char> pool;
     std::vector<SwDesc>& desc = stage.desc;
     std::vector<size_t>& first = stage.first;
     desc.clear();
@@ -959,7 +1024,7 @@ bool tb_place(const cto_realign::TraceJob& j, int ref_off, int q_off, size_t& di
 }
 
 // the tracebacks of `desc` (operands = base codes in the device pool): out[k] in desc order
-int traceback_pool(const signed char* d_pool, const std::vector<TbDesc>& desc, size_t dir_bytes, hipStream_t s, cto_realign_stats* st, std::vector<TbOut>& out) {
+int traceback_pool(const signed char* d_pool, const std::vector<TbDesc>& desc, size_t dir_bytes, hipStream_t s, cto_realign_stats* st, pinned_vector<TbOut>& out) {
     const int n = int(desc.size());
     out.clear();
     if (n == 0) return CTO_OK;
@@ -1051,7 +1116,7 @@ int traceback_device(std::vector<Window*>& ws, const SwStage& stage, hipStream_t
     const int n = int(desc.size());
     if (n == 0) return CTO_OK;
     clk.lap("  traceback: plan + descriptors");
-    std::vector<TbOut> out;
+    pinned_vector<TbOut> out;
     const int rc = traceback_pool(stage.d_pool.p, desc, dir_bytes, s, st, out);
     if (rc != CTO_OK) return rc;
     clk.lap("  traceback: launches + D2H");
@@ -1142,7 +1207,7 @@ extern "C" int cto_ssw_align_batch(int n, const int8_t* codes, size_t n_codes, c
             TbDesc t;
             if (planned[size_t(k)] && tb_place(jobs[size_t(k)], d[size_t(k)].ref_off, d[size_t(k)].q_off, dir_bytes, t)) { at[size_t(k)] = int(tb.size()); tb.push_back(t); }
         }
-        std::vector<TbOut> out;
+        pinned_vector<TbOut> out;
         rc = traceback_pool(d_pool.p, tb, dir_bytes, s, nullptr, out);
         if (rc != CTO_OK) return rc;
         parallel_for(size_t(n), threads, [&](size_t k) {
