@@ -105,6 +105,10 @@ SYMBOLS = {
     "cto_featurize_sites": (C.c_int, [C.POINTER(PackView), c_vp, c_i64, C.c_int, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "cto_extract_candidates": (C.c_int, [C.POINTER(PackView), C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
                                          C.c_int, c_vp, c_vp, c_vp]),
+    "cto_extract_restrict": (C.c_int, [C.POINTER(PackView), c_vp, c_vp, c_vp, C.c_int, C.c_int, c_vp]),
+    "cto_extract_mark": (C.c_int, [C.POINTER(PackView), c_vp, c_vp, C.c_int, C.c_int, c_vp]),
+    "cto_hybrid_info": (C.c_int, [C.POINTER(PackView), c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_vp, c_vp]),
+    "cto_hybrid_info_rows": (c_i64, [c_vp, C.c_char_p, c_i64, c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp, C.c_size_t]),
     "cto_alt_info": (C.c_int, [c_vp, c_i64, C.c_int, c_vp, c_i32, c_vp, c_vp, c_vp, C.c_char_p, C.c_size_t]),
     "cto_alt_info_batch": (c_i64, [c_vp, c_i64, c_vp, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_size_t, c_vp]),
     "cto_alt_info_batch_sites": (c_i64, [c_vp, c_i64, c_vp, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_size_t, c_vp]),

@@ -185,7 +185,7 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
     The kernels run on a stream of their own: the legacy default stream would synchronise with the CU-masked inflate streams."""
     import ctypes as C
     from ._lib import ChunkJob, RunCfg, RunStats, check, lib
-    from .call_variants import VCF_HEADER
+    from .call_variants import chunk_vcf_header
     from .create_tensor_pileup_calling import MAX_INDEL
     chunk_args = list(chunk_args)
     if not chunk_args:
@@ -213,7 +213,7 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
     cfg.neg_reads_aff, cfg.show_ref, cfg.verbose = int(eng.neg_reads_aff), int(bool(a0.show_ref)), int(bool(verbose))
     cfg.qual_pass = -1.0 if a0.qual is None else float(a0.qual)
     cfg.ref_fa = str(a0.ref_fn).encode()
-    cfg.vcf_header = (VCF_HEADER + "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n" % a0.sample_name).encode()
+    cfg.vcf_header = chunk_vcf_header(str(a0.ref_fn), eng.K, a0.sample_name).encode()
     cfg.producers, cfg.writers, cfg.depth = int(producers), int(writers), int(depth or os.environ.get("CTO_PIPELINE_DEPTH", 0))
     if not getattr(a0, "mpileup_fn", None) and getattr(a0, "bam_reader", "samtools") == "samtools":
         cfg.samtools = str(a0.samtools).encode()                  # the reference's producer, one child process per chunk
@@ -409,7 +409,7 @@ def gather_and_write(args, collected, chunks, world, rank, device):
     import torch.distributed as dist
     from .call_variants import vcf_rows_batch
     from .dist import gather_site_rows
-    from .pileup_call import VCF_HEADER
+    from .call_variants import chunk_vcf_header
     from .postprocess_vcf import contig_order, _header_from_fai
     K = 4 if args.disable_indel_calling else 6
     recs = [collected[i] for i in sorted(collected)]
@@ -478,12 +478,12 @@ def gather_and_write(args, collected, chunks, world, rank, device):
             if n_records == 0:
                 out.write(_header_from_fai(args.ref_fn, args.sample_name))
             else:
-                out.write(VCF_HEADER + "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n" % args.sample_name)
+                out.write(chunk_vcf_header(args.ref_fn, K, args.sample_name))
                 out.write("".join(body))
     return n_sites, n_records
 
 
-def main():
+def main(argv=None):
     p = ArgumentParser(description="Pileup calling of all candidate chunks of a run, one process per GPU")
     add_common_arguments(p)
     p.add_argument("--chunk_list", type=str, default=None, help="file with one candidate BED chunk path per line (CANDIDATES_FILES)")
@@ -515,7 +515,7 @@ def main():
     p.add_argument("--pipeline", type=str, default="auto", choices=["auto", "native", "python"],
                    help="'native': the chunk loop as one C call (cto_run_chunks; plain-text inputs, --mpileup_dir or --bam_reader native); "
                         "'python': the thread-pool pipeline of this module; 'auto': native when the inputs allow it")
-    args = p.parse_args()
+    args = p.parse_args(argv)
     if bool(args.chunk_list) == bool(args.region_list):
         p.error("exactly one of --chunk_list / --region_list is required")
     if args.gather_outputs and not args.merged_vcf_fn:

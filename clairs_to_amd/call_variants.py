@@ -179,33 +179,62 @@ def vcf_row(chrom, pos, ref_base, alt_info, fwd, rev, argmax, qual, n_out, show_
         f[0] + r[0], f[1] + r[1], f[2] + r[2], f[3] + r[3])
 
 
-VCF_HEADER = """##fileformat=VCFv4.2
-##source=clairs_to_amd
-##FILTER=<ID=PASS,Description="All filters passed">
-##FILTER=<ID=LowQual,Description="Low quality variant">
-##FILTER=<ID=NonSomatic,Description="Tagged as non-somatic by a panel of normals (set downstream, kept by postprocess_vcf)">
-##FILTER=<ID=RefCall,Description="Reference call">
-##INFO=<ID=H,Number=0,Type=Flag,Description="Phaseable: variant seen on one haplotype only (set downstream, read by postprocess_vcf)">
-##INFO=<ID=FAU,Number=1,Type=Integer,Description="Forward-strand A count in the tumor BAM">
-##INFO=<ID=FCU,Number=1,Type=Integer,Description="Forward-strand C count in the tumor BAM">
-##INFO=<ID=FGU,Number=1,Type=Integer,Description="Forward-strand G count in the tumor BAM">
-##INFO=<ID=FTU,Number=1,Type=Integer,Description="Forward-strand T count in the tumor BAM">
-##INFO=<ID=RAU,Number=1,Type=Integer,Description="Reverse-strand A count in the tumor BAM">
-##INFO=<ID=RCU,Number=1,Type=Integer,Description="Reverse-strand C count in the tumor BAM">
-##INFO=<ID=RGU,Number=1,Type=Integer,Description="Reverse-strand G count in the tumor BAM">
-##INFO=<ID=RTU,Number=1,Type=Integer,Description="Reverse-strand T count in the tumor BAM">
-##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">
-##FORMAT=<ID=GQ,Number=1,Type=Integer,Description="Genotype quality">
-##FORMAT=<ID=DP,Number=1,Type=Integer,Description="Read depth">
-##FORMAT=<ID=AF,Number=1,Type=Float,Description="Estimated allele frequency">
-##FORMAT=<ID=AD,Number=R,Type=Integer,Description="Allelic depths (ref, alt)">
-##FORMAT=<ID=AU,Number=1,Type=Integer,Description="A count in the tumor BAM">
-##FORMAT=<ID=CU,Number=1,Type=Integer,Description="C count in the tumor BAM">
-##FORMAT=<ID=GU,Number=1,Type=Integer,Description="G count in the tumor BAM">
-##FORMAT=<ID=TU,Number=1,Type=Integer,Description="Count of T in the tumor BAM">
-"""
-# The TU line is byte-identical to the reference's (shared/vcf.py): its postprocess_vcf cuts the header after exactly this
-# line (src/postprocess_vcf.py:165-166), so a VCF written here stays a valid input of the reference's own tail.
+# The meta-information lines of every VCF of a run, byte for byte the reference's (shared/vcf.py:14-55: `vcf_header`): its own tools read
+# them back - postprocess_vcf cuts the header after the `##FORMAT=<ID=TU` line (src/postprocess_vcf.py:165-166) - and a file written here
+# must be indistinguishable from one its call_variants wrote.  Kept as tables (ID, Number, Type, Description) and rendered once.
+CALLER_NAME, CALLER_VERSION = "clairs_to", "0.4.4"            # shared/param.py caller_name, version: the `##clairs_to_version=` line
+_FILTERS = (
+    ("PASS", "All filters passed"), ("NonSomatic", "Non-somatic variant tagged by panel of normals"), ("LowQual", "Low-quality variant"),
+    ("LowAltBQ", "Average alt allele base quality <20"), ("LowAltMQ", "Average alt allele read mapping quality <20"),
+    ("ReadStartEnd", ">30% of the supporting alt alleles are within 100bp of the start or end of a read"),
+    ("VariantCluster", "Three or more variants clustered within 200bp"), ("NoAncestry", "Variant without an ancestral haplotype support"),
+    ("MultiHap", "Alt alleles existed in multiple haplotypes"), ("StrandBias", "Strand bias p-value <0.001"),
+    ("LowSeqEntropy", "Sequence entropy <0.9"),
+    ("Realignment", "For short-read, both the count of supporting alt alleles and AF decreased after realignment"), ("RefCall", "Reference call"))
+_INFOS = tuple(("Verdict_" + k, "0", "Flag", "Variant tagged by verdict as " + v)
+               for k, v in (("Germline", "Germline"), ("Somatic", "Somatic"), ("SubclonalSomatic", "Subclonal Somatic"))) + \
+    (("H", "0", "Flag", "Variant found only in one haplotype in the phased reads"),) + \
+    tuple((s[0].upper() + b + "U", "1", "Integer", "Count of %s in %s strand in the tumor BAM" % (b, s)) for s in ("forward", "reverse") for b in "ACGT") + \
+    (("SB", "1", "Float", "The p-value of Fisher\u2019s exact test on strand bias"),)
+_FORMATS = (("GT", "1", "String", "Genotype"), ("GQ", "1", "Integer", "Genotype quality"), ("DP", "1", "Integer", "Read depth"),
+            ("AF", "1", "Float", "Estimated allele frequency"),
+            ("AD", "R", "Integer", "Allelic depths for the ref and alt alleles in the order listed in the ALT column")) + \
+    tuple((b + "U", "1", "Integer", "Count of %s in the tumor BAM" % b) for b in "ACGT")
+VCF_HEADER = "##fileformat=VCFv4.2\n##source=ClairS-TO\n##%s_version=%s\n" % (CALLER_NAME, CALLER_VERSION) + \
+    "".join('##FILTER=<ID=%s,Description="%s">\n' % f for f in _FILTERS) + \
+    "".join('##INFO=<ID=%s,Number=%s,Type=%s,Description="%s">\n' % i for i in _INFOS) + \
+    "".join('##FORMAT=<ID=%s,Number=%s,Type=%s,Description="%s">\n' % f for f in _FORMATS)
+
+
+def vcf_header(ref_fn=None, ctg_name=None, sample_name="SAMPLE", cmdline=None):
+    """VcfWriter.write_header (shared/vcf.py:100-121): the meta lines, `##cmdline=` as the fourth line when given, a `##contig` line per
+    row of <ref_fn>.fai (all of them, or those named in the comma-separated ctg_name), the column line."""
+    import os
+    out = VCF_HEADER
+    if cmdline is not None and cmdline != "":
+        rows = out.rstrip("\n").split("\n")
+        rows.insert(3 if len(rows) >= 3 else len(rows) - 1, "##cmdline={}".format(cmdline))
+        out = "\n".join(rows) + "\n"
+    if ref_fn is not None:
+        fai = ref_fn + ".fai"
+        if not os.path.exists(fai):                       # file_path_from(..., sep='.'): ref.fa -> ref.fai
+            fai = ".".join(ref_fn.split(".")[:-1]) + ".fai"
+        if not os.path.exists(fai):
+            raise SystemExit("[ERROR] file %s not found" % (ref_fn + ".fai"))
+        names = None if ctg_name is None else (ctg_name.split(",") if "," in ctg_name else [ctg_name])
+        with open(fai) as f:
+            for row in f:
+                c = row.strip().split("\t")
+                if names is not None and c[0] not in names:
+                    continue
+                out += "##contig=<ID=%s,length=%s>\n" % (c[0], c[1])
+    return out + "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n" % sample_name
+
+
+def chunk_vcf_header(ref_fn, K, sample_name="SAMPLE"):
+    """The header of a p_<chunk>.vcf as a run of run_clairs_to leaves it: its SNV call_variants command carries --ref_fn (the ##contig lines
+    of the whole .fai, run_clairs_to:1300), its indel one does not (:1631-1645); neither carries --ctg_name."""
+    return vcf_header(ref_fn if K == 4 else None, None, sample_name)
 
 
 def call_variants_from_probability(args, device="cuda"):
@@ -230,7 +259,7 @@ def call_variants_from_probability(args, device="cuda"):
     n_rows = 0
     os.makedirs(os.path.dirname(os.path.abspath(args.call_fn)), exist_ok=True)
     with open(args.call_fn, "w") as out:
-        out.write(VCF_HEADER + "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n" % args.sample_name)
+        out.write(vcf_header(getattr(args, "ref_fn", None), args.ctg_name, args.sample_name))
         if rows:
             p1 = np.array([[float(f.split()[1]) for f in r[6:6 + 2 * K]] for r in rows], dtype=np.float64)
             o = post.from_probs(torch.from_numpy(p1).to(device))
@@ -250,20 +279,27 @@ def call_variants_from_probability(args, device="cuda"):
     return n_rows
 
 
-def main():
+def build_parser():
     from argparse import ArgumentParser
+    from ._cli import add_ignored, str2bool
     p = ArgumentParser(description="Call variants from probability rows (GPU posterior)")
     p.add_argument("--platform", type=str, default="ont")
     p.add_argument("--call_fn", type=str, required=True)
     p.add_argument("--predict_fn", type=str, required=True)
     p.add_argument("--likelihood_matrix_data", type=str, required=True)
+    p.add_argument("--ref_fn", type=str, default=None, help="with its .fai: the ##contig lines of the header (shared/vcf.py:109-117)")
     p.add_argument("--ctg_name", type=str, default=None)
     p.add_argument("--sample_name", type=str, default="SAMPLE")
     p.add_argument("--qual", type=int, default=0)
     p.add_argument("--show_ref", action="store_true")
-    p.add_argument("--disable_indel_calling", type=lambda v: str(v).lower() in ("yes", "true", "t", "y", "1"), default=False)
+    p.add_argument("--disable_indel_calling", type=str2bool, default=False)
     p.add_argument("--pileup", action="store_true")
-    call_variants_from_probability(p.parse_args())
+    add_ignored(p, samtools="str")                  # clairs/call_variants.py:890: declared, never read
+    return p
+
+
+def main(argv=None):
+    call_variants_from_probability(build_parser().parse_args(argv))
 
 
 if __name__ == "__main__":

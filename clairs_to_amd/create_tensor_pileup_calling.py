@@ -14,6 +14,7 @@ from argparse import ArgumentParser
 import numpy as np
 import torch
 
+from ._cli import add_ignored, add_unsupported, check_unsupported
 from .fasta import read_region
 from .featurize import featurize, alt_infos
 from .pack import ColumnPack
@@ -145,7 +146,7 @@ def create_tensor(args, device="cuda"):
     return n_written
 
 
-def main():
+def build_parser():
     p = ArgumentParser(description="Generate tumor pileup tensors for calling (GPU featurisation)")
     p.add_argument("--platform", type=str, default="ont")
     p.add_argument("--tumor_bam_fn", type=str, default=None)
@@ -162,7 +163,22 @@ def main():
                    help="EXPERIMENTAL: maximum tumor depth handed to samtools mpileup / the built-in reader (the reference's default: 8000). Engine limits, reported as an error of the chunk (CTO_EUNSUPPORTED), not silently: a pileup column may hold at most 32767 read-bases and 2048 distinct indel alleles")
     p.add_argument("--max_indel_length", type=int, default=None)
     p.add_argument("--candidates_bed_regions", type=str, required=True)
-    create_tensor(p.parse_args())
+    # the rest of the reference's parser (src/create_tensor_pileup_calling.py:582-661).  With --candidates_bed_regions - the only form
+    # run_clairs_to uses (:1228-1271) - the reference itself reads none of the `ignored` ones: the gates below are decode_pileup_bases
+    # arguments that calling never consults (has_pileup_candidates, :238-242), --min_mq is overridden by a literal 0 (:421), --zstd
+    # names the compressor of the tensor text (gzip here), --bed_fn is read into a variable nothing uses (:322).
+    add_ignored(p, snv_min_af="float", indel_min_af="float", min_coverage="float", min_mq="int", zstd="str", bed_fn="str", ctg_start="int",
+                ctg_end="int")
+    add_unsupported(p, vcf_fn=("str", None), extend_bed=("str?", None), alt_fn=("str", None), truth_vcf_fn=("str", None), chunk_num=("int", None),
+                    chunk_id=("int", None), phase_tumor=("bool", False), flanking=("int", None))
+    return p
+
+
+def main(argv=None):
+    p = build_parser()
+    a = p.parse_args(argv)
+    check_unsupported(p, a)
+    create_tensor(a)
 
 
 if __name__ == "__main__":

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(XLANES) void k_extract_candidates(
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     unsigned long long all4 = 0, pure4 = 0;          // 16-bit counters: A C G T (a column holds at most 32 767 read-bases)
-    uint32_t stars = 0;
+    uint32_t stars = 0, n_row = 0, n_ind = 0;        // reads that pass --min-MQ (the row is printed at all); read-bases carrying an indel
     const int base = int(my_off - run0);
     int max_n = my_n;
 #pragma unroll
@@ -74,6 +74,7 @@ __global__ __launch_bounds__(XLANES) void k_extract_candidates(
     auto count = [&](uint32_t ent) {
         const uint32_t b = ent & 15u, kind = (ent >> 4) & 3u;
         const int bq = int((ent >> 6) & 127u), mq = int((ent >> 13) & 255u);
+        n_row += mq >= min_mq ? 1u : 0u;
         if (mq >= min_mq && bq >= min_bq) {           // what samtools --min-MQ / --min-BQ leaves in the column
             const unsigned long long one = 1ull << (16u * (b & 3u));
             if (b < 8u) {                              // depth = bases + placeholders, summed at the end
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(XLANES) void k_extract_candidates(
                 ++stars;
             }
             if (select_indel && kind != 0u) {          // no length gate here, unlike tensor creation
+                ++n_ind;
                 const int g = pk.key_group[k0 + int(ent >> 21)];
                 if (grp_lds) s_grp[select_indel ? lane : 0][g] += 1u;
                 else atomicAdd(&gscratch[k0 + g], 1u);
@@ -131,18 +133,95 @@ __global__ __launch_bounds__(XLANES) void k_extract_candidates(
             if (pass_snv && has_alt_base) f |= 1;
             if (select_indel && pass_indel) f |= 2;
         }
+        if (ref_ok && n_row > 0u) {                 // what a hybrid / genotyping position needs to know of a row that fails the gates (:374-383)
+            f |= 32;
+            if (has_alt_base) f |= 8;
+            if (select_indel && n_ind > 0u) f |= 16;
+        }
         flags[c] = f;
         depth_out[c] = ref_ok ? depth : 0;   // skipped rows (reference base not ACGT) report nothing
     }
 }
 
 
-// candidate positions, in column order: the columns whose flag has `bit` set and whose position lies in [lo, hi]
+// candidate positions, in column order: the columns whose flag has `bit` set and whose position lies in [lo, hi] - and, for the
+// SNV (bit 1) and indel (bit 2) lists, the marked columns (bit 6: a position of --hybrid_mode_vcf_fn / --genotyping_mode_vcf_fn) that
+// fail the AF gates but show an alternative base / an indel at all (extract_candidates_calling.py:374-383)
 __device__ __forceinline__ bool is_cand(const uint8_t* __restrict__ flags, const int32_t* __restrict__ col_pos, int64_t c, int64_t n, int bit,
                                         int32_t lo, int32_t hi) {
-    if (c >= n || !(flags[c] & bit)) return false;
+    if (c >= n) return false;
+    const unsigned f = flags[c];
+    const unsigned inject = bit == 1 ? 8u : bit == 2 ? 16u : 0u;
+    if (!(f & unsigned(bit)) && !((f & 64u) && !(f & 4u) && (f & inject))) return false;
     const int32_t p = col_pos[c];
     return p >= lo && p <= hi;
+}
+
+// rows outside a BED: `samtools mpileup -l` prints a position p only inside a row  begin < p <= end  (0-based half-open rows; the
+// intervals arrive sorted and merged).  clear = 0xff: the row does not exist (confident BED, :302); clear = 2 | 16: the position
+// cannot be an indel candidate (--call_indels_only_in_these_regions, :437-446).
+__global__ __launch_bounds__(256) void k_restrict(const int32_t* __restrict__ col_pos, int64_t n, const int32_t* __restrict__ iv, int n_iv,
+                                                  unsigned clear, uint8_t* __restrict__ flags, int32_t* __restrict__ depth) {
+    const int64_t c = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (c >= n) return;
+    const int32_t q = col_pos[c] - 1;                 // 0-based
+    int lo = 0, hi = n_iv;                            // first interval whose begin is beyond q
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (iv[2 * mid] <= q) lo = mid + 1; else hi = mid; }
+    const bool inside = lo > 0 && q < iv[2 * lo - 1];
+    if (!inside) {
+        flags[c] = uint8_t(flags[c] & ~clear);
+        if (clear == 0xffu && depth) depth[c] = 0;
+    }
+}
+__global__ __launch_bounds__(256) void k_mark(const int32_t* __restrict__ col_pos, int64_t n, const int32_t* __restrict__ pos, int n_pos,
+                                              unsigned set, uint8_t* __restrict__ flags) {
+    const int64_t c = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (c >= n) return;
+    const int32_t p = col_pos[c];
+    int lo = 0, hi = n_pos;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (pos[mid] < p) lo = mid + 1; else hi = mid; }
+    if (lo < n_pos && pos[lo] == p) flags[c] = uint8_t(flags[c] | set);
+}
+
+// The `tumor_alt_info` of a hybrid / genotyping position (extract_candidates_calling.py:352-354: depth + pileup_list, the allele counts
+// of pileup_dict in decreasing order, ties in the order the dictionary met them): one LANE per listed position (a run has a few
+// thousand of them at most) walks its column once and leaves counts and first-seen read indices; the host orders and prints them.
+// rec[16]: column (-1: no row), depth, count A C G T I D, first-seen A C G T I D, the column's first key, the column's flags.
+__global__ __launch_bounds__(64) void k_hybrid_info(XPack pk, const int32_t* __restrict__ col_pos, const int32_t* __restrict__ pos, int n_pos,
+                                                    const uint8_t* __restrict__ flags, int min_mq, int min_bq, int select_indel,
+                                                    int32_t* __restrict__ rec, uint32_t* __restrict__ gcnt, int32_t* __restrict__ gfirst) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_pos) return;
+    int32_t* r = rec + int64_t(i) * 16;
+    for (int k = 0; k < 16; ++k) r[k] = k >= 8 && k < 14 ? INT32_MAX : 0;
+    r[0] = -1;
+    const int32_t p = pos[i];
+    int64_t lo = 0, hi = pk.n_cols;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (col_pos[mid] < p) lo = mid + 1; else hi = mid; }
+    if (lo >= pk.n_cols || col_pos[lo] != p || !(flags[lo] & 32u)) return;
+    const int64_t c = lo;
+    const int k0 = pk.key_off[c], nk = pk.key_off[c + 1] - k0;
+    if (select_indel)
+        for (int g = 0; g < nk; ++g) { gcnt[k0 + g] = 0u; gfirst[k0 + g] = INT32_MAX; }
+    int cnt[6] = {0, 0, 0, 0, 0, 0}, first[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX}, depth = 0;
+    const int64_t e0 = pk.col_off[c], e1 = pk.col_off[c + 1];
+    for (int64_t e = e0; e < e1; ++e) {
+        const uint32_t ent = pk.entries[e];
+        const uint32_t b = ent & 15u, kind = (ent >> 4) & 3u;
+        const int bq = int((ent >> 6) & 127u), mq = int((ent >> 13) & 255u);
+        if (mq < min_mq || bq < min_bq) continue;
+        const int at = int(e - e0);
+        if (b < 8u) { ++depth; ++cnt[b & 3u]; first[b & 3u] = min(first[b & 3u], at); }
+        else if (b == 8u || b == 9u) ++depth;
+        if (kind != 0u) {
+            const int k = k0 + int(ent >> 21);
+            if (select_indel) { const int g = k0 + pk.key_group[k]; ++gcnt[g]; gfirst[g] = min(gfirst[g], at); }
+            else { const int w = (pk.key_meta[k] & 3u) == 1u ? 4 : 5; ++cnt[w]; first[w] = min(first[w], at); }
+        }
+    }
+    r[0] = int32_t(c); r[1] = depth;
+    for (int k = 0; k < 6; ++k) { r[2 + k] = cnt[k]; r[8 + k] = first[k]; }
+    r[14] = k0; r[15] = int32_t(flags[c]);
 }
 __global__ __launch_bounds__(256) void k_cand_count(const uint8_t* __restrict__ flags, const int32_t* __restrict__ col_pos, int64_t n, int bit,
                                                     int32_t lo, int32_t hi, int32_t* __restrict__ block_cnt) {
@@ -248,6 +327,37 @@ extern "C" int cto_candidate_positions(const cto_pack_view* dp, const uint8_t* f
     hipLaunchKernelGGL(k_cand_count, dim3(unsigned(nb)), dim3(256), 0, s, flags, dp->col_pos, dp->n_cols, bit, lo, hi, scratch);
     hipLaunchKernelGGL(k_cand_scan, dim3(1), dim3(1024), 0, s, scratch, int(nb), n_out);
     hipLaunchKernelGGL(k_cand_scatter, dim3(unsigned(nb)), dim3(256), 0, s, flags, dp->col_pos, dp->n_cols, bit, lo, hi, scratch, out_pos, cap);
+    CTO_HIP(hipGetLastError());
+    return CTO_OK;
+}
+
+extern "C" int cto_extract_restrict(const cto_pack_view* dp, uint8_t* flags, int32_t* depth, const int32_t* d_intervals, int n_intervals, int clear,
+                                    void* stream) {
+    CTO_REQUIRE(dp && (dp->n_cols == 0 || flags) && (n_intervals == 0 || d_intervals) && n_intervals >= 0, CTO_EINVAL, "cto_extract_restrict: bad argument");
+    if (dp->n_cols == 0) return CTO_OK;
+    hipLaunchKernelGGL(k_restrict, dim3(unsigned(cto::cdiv(dp->n_cols, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), dp->col_pos, dp->n_cols,
+                       d_intervals, n_intervals, unsigned(clear) & 0xffu, flags, depth);
+    CTO_HIP(hipGetLastError());
+    return CTO_OK;
+}
+
+extern "C" int cto_extract_mark(const cto_pack_view* dp, uint8_t* flags, const int32_t* d_pos, int n_pos, int set, void* stream) {
+    CTO_REQUIRE(dp && (dp->n_cols == 0 || flags) && (n_pos == 0 || d_pos) && n_pos >= 0, CTO_EINVAL, "cto_extract_mark: bad argument");
+    if (dp->n_cols == 0 || n_pos == 0) return CTO_OK;
+    hipLaunchKernelGGL(k_mark, dim3(unsigned(cto::cdiv(dp->n_cols, 256))), dim3(256), 0, static_cast<hipStream_t>(stream), dp->col_pos, dp->n_cols, d_pos,
+                       n_pos, unsigned(set) & 0xffu, flags);
+    CTO_HIP(hipGetLastError());
+    return CTO_OK;
+}
+
+extern "C" int cto_hybrid_info(const cto_pack_view* dp, const uint8_t* flags, const int32_t* d_pos, int n_pos, int min_mq, int min_bq, int select_indel,
+                               int32_t* rec, uint32_t* gcnt, int32_t* gfirst, void* stream) {
+    CTO_REQUIRE(dp && n_pos >= 0 && (n_pos == 0 || (d_pos && rec && (dp->n_cols == 0 || flags))) && (!select_indel || dp->n_keys == 0 || (gcnt && gfirst)),
+                CTO_EINVAL, "cto_hybrid_info: bad argument");
+    if (n_pos == 0) return CTO_OK;
+    XPack pk{dp->n_cols, dp->col_ref, dp->col_off, dp->key_off, dp->entries, dp->key_meta, dp->key_group};
+    hipLaunchKernelGGL(k_hybrid_info, dim3(unsigned(cto::cdiv(n_pos, 64))), dim3(64), 0, static_cast<hipStream_t>(stream), pk, dp->col_pos, d_pos, n_pos,
+                       flags, min_mq, min_bq, select_indel ? 1 : 0, rec, gcnt, gfirst);
     CTO_HIP(hipGetLastError());
     return CTO_OK;
 }

@@ -696,6 +696,67 @@ extern "C" int cto_alt_info(const cto_pack* p, int64_t col, int pass, const int1
     return int(s.size());
 } CTO_CATCH("cto_alt_info", int)
 
+// The rows of `<ctg>.<chunk>_hybrid_info` (extract_candidates_calling.py:352-354, 490-497) from cto_hybrid_info's records: per listed
+// position with a row,  ctg \t pos \t REF \t <depth>-<allele count allele count ...>  - the alleles of pileup_dict (:108-126: a base counts
+// its indel carriers too; insertions `I<ANCHOR><SEQ>` and deletions `D` + one N per deleted base when indel candidates are selected, bare
+// `I` / `D` otherwise) in decreasing count, ties in the order the dictionary met them (a read's base before its indel).  For a row that
+// passes the AF gates the reference prints, in place of each count, str(round(count / depth, 3)) - decode_pileup_bases returns its
+// pileup_list re-made as fractions on that path (:149-153) and :353 prints whatever came back; reproduced: a correctly rounded "%.3f"
+// without its trailing zeros is Python's str() of the rounded float.
+extern "C" int64_t cto_hybrid_info_rows(const cto_pack* p, const char* ctg, int64_t n_pos, const int32_t* pos, const int32_t* rec, int select_indel,
+                                        const uint32_t* gcnt, const int32_t* gfirst, char* buf, size_t cap) try {
+    CTO_REQUIRE(p && ctg && n_pos >= 0 && (n_pos == 0 || (pos && rec)) && (buf || cap == 0), CTO_EINVAL, "cto_hybrid_info_rows: null argument");
+    struct Item { int64_t count, when; std::string key; };
+    std::string out;
+    static const char kB[] = "ACGT";
+    for (int64_t i = 0; i < n_pos; ++i) {
+        const int32_t* r = rec + i * 16;
+        const int64_t col = r[0];
+        if (col < 0) continue;
+        CTO_REQUIRE(size_t(col) < p->col_pos.size(), CTO_EINVAL, "cto_hybrid_info_rows: column out of range");
+        std::vector<Item> items;
+        for (int b = 0; b < 4; ++b)
+            if (r[2 + b] > 0) items.push_back(Item{r[2 + b], int64_t(r[8 + b]) * 2, std::string(1, kB[b])});
+        if (!select_indel) {
+            if (r[6] > 0) items.push_back(Item{r[6], int64_t(r[12]) * 2 + 1, "I"});
+            if (r[7] > 0) items.push_back(Item{r[7], int64_t(r[13]) * 2 + 1, "D"});
+        } else {
+            CTO_REQUIRE(gcnt && gfirst, CTO_EINVAL, "cto_hybrid_info_rows: the per-allele counts are missing");
+            const int32_t k0 = p->key_off[size_t(col)], k1 = p->key_off[size_t(col) + 1];
+            for (int32_t g = 0; g < k1 - k0; ++g) {
+                if (gcnt[k0 + g] == 0) continue;
+                int32_t k = k0;
+                while (k < k1 && p->key_group[size_t(k)] != g) ++k;            // any key of the merged allele spells it
+                CTO_REQUIRE(k < k1, CTO_EINVAL, "cto_hybrid_info_rows: allele group without a key");
+                const char* ks = p->key_str.data() + p->key_str_off[size_t(k)];
+                const size_t kl = size_t(p->key_str_off[size_t(k) + 1] - p->key_str_off[size_t(k)]);
+                std::string key;
+                if ((p->key_meta[size_t(k)] & 3) == 1) { key.assign(ks, kl); for (auto& ch : key) ch = cto::up(ch); }
+                else key = "D" + std::string(kl > 0 ? kl - 1 : 0, 'N');
+                items.push_back(Item{int64_t(gcnt[k0 + g]), int64_t(gfirst[k0 + g]) * 2 + 1, key});
+            }
+        }
+        std::sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.count != b.count ? a.count > b.count : a.when < b.when; });
+        out += ctg; out.push_back('\t'); out += std::to_string(pos[i]); out.push_back('\t');
+        out.push_back(kB[p->col_ref[size_t(col)] & 3]); out.push_back('\t');
+        out += std::to_string(r[1]); out.push_back('-');
+        const bool as_fraction = (r[15] & 4) != 0;
+        const double den = r[1] > 0 ? double(r[1]) : 1.0;
+        for (size_t j = 0; j < items.size(); ++j) {
+            if (j) out.push_back(' ');
+            out += items[j].key; out.push_back(' ');
+            if (!as_fraction) { out += std::to_string(items[j].count); continue; }
+            char num[64];
+            int n = snprintf(num, sizeof num, "%.3f", double(items[j].count) / den);
+            while (n > 0 && num[n - 1] == '0' && num[n - 2] != '.') --n;
+            out.append(num, size_t(n));
+        }
+        out.push_back('\n');
+    }
+    if (out.size() <= cap && !out.empty()) memcpy(buf, out.data(), out.size());
+    return int64_t(out.size());            // larger than cap: nothing was written, call again with that much room
+} CTO_CATCH("cto_hybrid_info_rows", int64_t)
+
 namespace {
 // colvec: the column vectors of the whole pack (row = column index) or, with per_site, one row per candidate (row = site index)
 int64_t alt_info_batch_impl(const cto_pack* p, int64_t n_sites, const int32_t* site_info, int pass, const int16_t* colvec, bool per_site,

@@ -23,16 +23,13 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
+from ._cli import add_ignored, add_unsupported, check_unsupported, str2bool, str_none
 from ._lib import lib, check
 from .fasta import read_region
 
 LAST_FORMAT_LINE = '##FORMAT=<ID=TU,Number=1,Type=Integer,Description="Count of T in the tumor BAM">'
 FLAG_NAMES = ("phaseable", "hetero", "homo", "read_start_end", "bq", "mq", "co_exist", "hetero_both_side", "sequence_entropy")
 MAX_SITES_PER_JOB, MAX_SPAN_PER_JOB = 200, 5000000          # haplotype_filtering.py:190-191
-
-
-def str2bool(v):
-    return v if isinstance(v, bool) else str(v).lower() in ("yes", "true", "t", "y", "1")
 
 
 # ------------------------------------------------------------------------------------------ Fisher's exact test
@@ -182,8 +179,10 @@ def mpileup_text(args, contig, lo, hi, positions, flanking):
     try:
         with os.fdopen(fd, "w") as f:
             f.write("".join("%s\t%d\t%d\n" % (contig, s, e) for s, e in flank_bed(positions, flanking)))
-        cmd = "{} mpileup --min-MQ {} --min-BQ {} --excl-flags 2316 -l {} -r {} --output-MQ --output-QNAME --output-extra HP {}".format(
-            shlex.quote(args.samtools), args.min_mq, args.min_bq, shlex.quote(bed), shlex.quote("%s:%d-%d" % (contig, lo, hi)), shlex.quote(bam))
+        # --haplotype_chunk_mpileup_bed False: the job's whole span without -l (:1085-1093) - more rows, the same evidence
+        bed_opt = "-l {} ".format(shlex.quote(bed)) if getattr(args, "haplotype_chunk_mpileup_bed", True) else ""
+        cmd = "{} mpileup --min-MQ {} --min-BQ {} --excl-flags 2316 {}-r {} --output-MQ --output-QNAME --output-extra HP {}".format(
+            shlex.quote(args.samtools), args.min_mq, args.min_bq, bed_opt, shlex.quote("%s:%d-%d" % (contig, lo, hi)), shlex.quote(bam))
         res = subprocess.run(shlex.split(cmd), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         if res.returncode != 0:
             print("[ERROR] samtools mpileup failed (exit {}). Command (trunc): {} stderr: {}".format(
@@ -321,7 +320,7 @@ def haplotype_filter(args):
     return results
 
 
-def main():
+def build_parser():
     p = ArgumentParser(description="Haplotype filtering for long-read data (C evaluation of the read-level rules)")
     p.add_argument("--tumor_bam_fn", type=str, default=None)
     p.add_argument("--ref_fn", type=str, default=None)
@@ -331,7 +330,7 @@ def main():
     p.add_argument("--germline_vcf_fn", type=str, default=None)
     p.add_argument("--output_dir", type=str, default=None)
     p.add_argument("--threads", type=int, default=4)
-    p.add_argument("--input_filter_tag", type=lambda v: None if v in (None, "None") else v, default=None)
+    p.add_argument("--input_filter_tag", type=str_none, default=None)
     p.add_argument("--show_ref", action="store_true")
     p.add_argument("--samtools", type=str, default="samtools")
     p.add_argument("--mpileup_fn", type=str, default=None, help="prepared nine-column mpileup text instead of running samtools")
@@ -342,13 +341,28 @@ def main():
     p.add_argument("--is_indel", action="store_true")
     p.add_argument("--test_pos", type=int, default=None)
     p.add_argument("--flanking", type=int, default=100)
-    p.add_argument("--haplotype_filtering_chunk_mode", type=str2bool, default=True, help="accepted for compatibility: always chunked here")
+    p.add_argument("--haplotype_filtering_chunk_mode", type=str2bool, default=True,
+                   help="the reference's default is False (one pypy3 process per call under GNU parallel, :800-880); both of its modes evaluate the "
+                        "same rules on the same rows, and here every call is evaluated in mpileup jobs either way")
     p.add_argument("--haplotype_chunk_max_sites", type=int, default=MAX_SITES_PER_JOB)
     p.add_argument("--haplotype_chunk_max_span", type=int, default=MAX_SPAN_PER_JOB)
+    p.add_argument("--haplotype_chunk_mpileup_bed", type=str2bool, default=True)
     p.add_argument("--disable_read_start_end_filtering", type=str2bool, default=False)
-    for compat in ("--python", "--pypy3", "--parallel", "--hap_info_fn"):
-        p.add_argument(compat, type=str, default=None, help="accepted for compatibility, unused")
-    haplotype_filter(p.parse_args())
+    # src/haplotype_filtering.py:1213-1312.  --python / --pypy3 / --parallel name the interpreters of its per-call worker processes;
+    # --debug, --add_phasing_info, --is_happy_format, --max_overlap_distance, --hap_info_fn are declared there and read nowhere.
+    add_ignored(p, python="str", pypy3="str", parallel="str", hap_info_fn="str", debug="flag", add_phasing_info="bool", is_happy_format="bool",
+                max_overlap_distance="int")
+    # its worker mode: ONE call per process, described on the command line (:708-740) - only the reference's own driver starts those
+    add_unsupported(p, pos=("int", None), ref_base=("str", None), alt_base=("str", None), af=("float", None), qual=("float", None),
+                    hetero_info=("str", None), homo_info=("str", None))
+    return p
+
+
+def main(argv=None):
+    p = build_parser()
+    a = p.parse_args(argv)
+    check_unsupported(p, a)
+    haplotype_filter(a)
 
 
 if __name__ == "__main__":

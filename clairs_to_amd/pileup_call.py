@@ -19,7 +19,7 @@ from argparse import ArgumentParser
 import numpy as np
 import torch
 
-from .call_variants import IUPAC_TO_ACGT, VCF_HEADER, load_likelihood, vcf_rows_batch
+from .call_variants import IUPAC_TO_ACGT, VCF_HEADER, chunk_vcf_header, load_likelihood, vcf_rows_batch
 from .create_tensor_pileup_calling import EXPAND_REF, MAX_INDEL, load_pack, read_candidate_positions
 from .engine import Engine
 from .fasta import read_region
@@ -144,7 +144,7 @@ def finish_chunk(args, K, prep, launched):
     os.makedirs(os.path.dirname(os.path.abspath(args.call_fn)), exist_ok=True)
     if n_rows:             # the reference removes VCFs without records (call_variants.py:859-867)
         with open(args.call_fn, "w") as out:
-            out.write(VCF_HEADER + "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n" % args.sample_name)
+            out.write(chunk_vcf_header(args.ref_fn, K, args.sample_name))
             out.write(text)
     elif os.path.exists(args.call_fn):
         os.remove(args.call_fn)
@@ -197,7 +197,7 @@ def add_common_arguments(p):
     p.add_argument("--pileup", action="store_true")
 
 
-def main():
+def main(argv=None):
     p = ArgumentParser(description="Pileup calling of one candidate chunk on the GPU: BED + BAM/mpileup -> VCF")
     add_common_arguments(p)
     p.add_argument("--mpileup_fn", type=str, default=None, help="samtools mpileup text (--min-BQ 0) instead of a BAM")
@@ -205,7 +205,7 @@ def main():
     p.add_argument("--candidates_bed_regions", type=str, required=True)
     p.add_argument("--call_fn", type=str, required=True)
     p.add_argument("--predict_fn", type=str, default=None, help="also write the probability rows (debugging tap)")
-    pileup_call(p.parse_args())
+    pileup_call(p.parse_args(argv))
 
 
 if __name__ == "__main__":

@@ -189,7 +189,16 @@ def _none_or_float(v):
     return None if v is None or str(v) == "None" else float(v)
 
 
-def sort_vcf_main(argv=None):
+def compress_index_vcf(vcf_fn):
+    """src/postprocess_vcf.py:54-59: `bgzip -f` then `tabix -f -p vcf`, run the same way - through the shell, outcome not checked, so
+    a host without the two tools keeps the plain .vcf exactly as the reference would leave it"""
+    import subprocess
+    subprocess.run("bgzip -f {}".format(vcf_fn), shell=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    subprocess.run("tabix -f -p vcf {}.gz".format(vcf_fn), shell=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+
+
+def build_sort_vcf_parser():
+    from ._cli import str2bool
     ap = ArgumentParser(description="merge and sort chunk VCFs (mirror of src/sort_vcf.py)")
     ap.add_argument("--output_fn", required=True)
     ap.add_argument("--input_dir", required=True)
@@ -198,28 +207,47 @@ def sort_vcf_main(argv=None):
     ap.add_argument("--ref_fn", default=None)
     ap.add_argument("--sample_name", default="SAMPLE")
     ap.add_argument("--contigs_fn", required=True)
-    a = ap.parse_args(argv)
+    ap.add_argument("--compress_vcf", type=str2bool, default=False)          # src/sort_vcf.py:248
+    return ap
+
+
+def sort_vcf_main(argv=None):
+    a = build_sort_vcf_parser().parse_args(argv)
     contigs = [r.rstrip() for r in open(a.contigs_fn)]
-    return sort_vcf(a.input_dir, a.output_fn, contigs, a.vcf_fn_prefix, a.vcf_fn_suffix, a.ref_fn, a.sample_name)
+    n = sort_vcf(a.input_dir, a.output_fn, contigs, a.vcf_fn_prefix, a.vcf_fn_suffix, a.ref_fn, a.sample_name)
+    if a.compress_vcf:
+        compress_index_vcf(a.output_fn)
+    return n
 
 
-def postprocess_vcf_main(argv=None):
+def build_postprocess_vcf_parser():
+    from ._cli import add_ignored, add_unsupported, str2bool, str_none
     ap = ArgumentParser(description="QUAL / AF gates on the merged pileup VCF (mirror of src/postprocess_vcf.py)")
     ap.add_argument("--platform", default="ont")
     ap.add_argument("--output_fn", required=True)
     ap.add_argument("--pileup_vcf_fn", required=True)
     ap.add_argument("--ref_fn", default=None)
     ap.add_argument("--sample_name", default="SAMPLE")
-    ap.add_argument("--cmdline", default=None)
+    ap.add_argument("--cmdline", type=str_none, default=None)
     ap.add_argument("--qual", default=None)
     ap.add_argument("--qual_cutoff_phaseable_region", default=None)
     ap.add_argument("--qual_cutoff_unphaseable_region", default=None)
     ap.add_argument("--af", default=None)
     ap.add_argument("--max_qual_filter_pileup_calls", default=None)
-    a = ap.parse_args(argv)
+    ap.add_argument("--compress_vcf", type=str2bool, default=True)           # src/postprocess_vcf.py:223: bgzip + tabix when they exist
+    # src/postprocess_vcf.py:239-256: declared there, read nowhere (run_clairs_to:1527, 1783-1784 passes the first two on every run)
+    add_ignored(ap, disable_indel_calling="bool", indel_calling="flag", bed_format="flag", prefer_recall="bool")
+    return ap
+
+
+def postprocess_vcf_main(argv=None):
+    a = build_postprocess_vcf_parser().parse_args(argv)
     cmd = None
-    if a.cmdline not in (None, "None") and os.path.exists(a.cmdline):
+    if a.cmdline is not None and os.path.exists(a.cmdline):
         cmd = open(a.cmdline).read().rstrip()
-    return postprocess_vcf(a.pileup_vcf_fn, a.output_fn, a.platform, _none_or_float(a.qual),
-                           _none_or_float(a.qual_cutoff_phaseable_region), _none_or_float(a.qual_cutoff_unphaseable_region),
-                           _none_or_float(a.af), _none_or_float(a.max_qual_filter_pileup_calls), a.ref_fn, a.sample_name, cmd)
+    n = postprocess_vcf(a.pileup_vcf_fn, a.output_fn, a.platform, _none_or_float(a.qual),
+                        _none_or_float(a.qual_cutoff_phaseable_region), _none_or_float(a.qual_cutoff_unphaseable_region),
+                        _none_or_float(a.af), _none_or_float(a.max_qual_filter_pileup_calls), a.ref_fn, a.sample_name, cmd)
+    if a.compress_vcf:
+        compress_index_vcf(a.output_fn)
+    return n

@@ -11,6 +11,7 @@ from argparse import ArgumentParser
 import numpy as np
 import torch
 
+from ._cli import add_ignored, add_unsupported, check_unsupported, str2bool
 from ._lib import lib, check, current_stream_ptr
 from .call_variants import IUPAC_TO_ACGT
 from . import nn_shims
@@ -110,11 +111,7 @@ def predict(args, device="cuda"):
     return B
 
 
-def str2bool(v):
-    return v if isinstance(v, bool) else str(v).lower() in ("yes", "true", "t", "y", "1")
-
-
-def main():
+def build_parser():
     p = ArgumentParser(description="Candidate variants probability prediction (HIP networks)")
     p.add_argument("--platform", type=str, default="ont")
     p.add_argument("--tensor_fn_acgt", type=str, required=True)
@@ -125,10 +122,22 @@ def main():
     p.add_argument("--ctg_name", type=str, default=None)
     p.add_argument("--min_rescale_cov", type=int, default=50)
     p.add_argument("--disable_indel_calling", type=str2bool, default=False)
-    p.add_argument("--use_gpu", type=str2bool, default=True)
+    p.add_argument("--use_gpu", type=str2bool, default=True, help="accepted as the reference accepts it: the networks always run on the HIP device")
     p.add_argument("--pileup", action="store_true")
     p.add_argument("--split_operands", type=str, default=None, choices=["f16", "bf16"], help=SPLIT_HELP)
-    predict(p.parse_args())
+    # clairs/predict.py:736-812.  --show_ref / --qual / --sample_name / --ref_fn / --samtools only configure the VCF writer of its
+    # --call_fn mode (:454-499); run_clairs_to passes --show_ref with --print_ref_calls all the same (:1287).  The one-invocation form
+    # of that mode here is `pileup_call`.
+    add_ignored(p, show_ref="flag", qual="int", sample_name="str", ref_fn="str", samtools="str")
+    add_unsupported(p, call_fn=("str", None), is_from_tables=("bool", False), flanking=("int", None))
+    return p
+
+
+def main(argv=None):
+    p = build_parser()
+    a = p.parse_args(argv)
+    check_unsupported(p, a)
+    predict(a)
 
 
 if __name__ == "__main__":

@@ -586,7 +586,7 @@ def reads_realignment(args, out=None):
     view.wait()
 
 
-def main():
+def build_parser():
     p = ArgumentParser(description="Reads realignment around one position (native consensus + realigner)")
     p.add_argument("--bam_fn", type=str, default=None)
     p.add_argument("--ref_fn", type=str, default=None)
@@ -602,7 +602,11 @@ def main():
                    help="samtools: `samtools view` / `faidx` as the reference runs them; native: the built-in BAM / FASTA readers (parity unpinned)")
     for compat in ("--ctg_start", "--ctg_end", "--bed_fn", "--extend_bed", "--test_pos"):
         p.add_argument(compat, default=None, help=SUPPRESS)
-    args = p.parse_args()
+    return p
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
     if args.pos is None or args.ctg_name is None:
         sys.exit("[ERROR] clairs_to_amd realign_reads needs --pos and --ctg_name (the form `realign_variants` calls)")
     reads_realignment(args)

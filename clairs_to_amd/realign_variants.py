@@ -294,7 +294,7 @@ def realign_variants(args):
     return failed
 
 
-def main():
+def build_parser():
     p = ArgumentParser(description="Reads realignment workflow for all input variants")
     p.add_argument("--bam_fn", type=str, default=None)
     p.add_argument("--ref_fn", type=str, default="ref.fa")
@@ -321,10 +321,15 @@ def main():
     p.add_argument("--qual", type=float, default=None, help="accepted for compatibility (unused by the reference too)")
     p.add_argument("--pos", type=int, default=None, help=SUPPRESS)
     p.add_argument("--is_indel", action="store_true", help=SUPPRESS)
-    if len(sys.argv[1:]) == 0:
+    return p
+
+
+def main(argv=None):
+    p = build_parser()
+    if len(sys.argv[1:] if argv is None else argv) == 0:
         p.print_help()
         sys.exit(1)
-    realign_variants(p.parse_args())
+    realign_variants(p.parse_args(argv))
 
 
 if __name__ == "__main__":

@@ -234,7 +234,8 @@ int cto_featurize_sites(const cto_pack_view* dev_pack, const int32_t* site_pos, 
  *   depth = bases in ACGTacgt*#;  pass_depth = depth > min_coverage;
  *   pass_snv   = some non-reference base with count / depth >= snv_min_af and count >= alt_base_num;
  *   pass_indel = (select_indel) some merged indel allele with count / depth >= indel_min_af and count >= alt_base_num;
- * flags dev [n_cols] uint8: bit0 SNV candidate, bit1 indel candidate, bit2 pass_af; depth dev [n_cols] int32. */
+ * flags dev [n_cols] uint8: bit0 SNV candidate, bit1 indel candidate, bit2 pass_af (bits 3-5: see cto_extract_mark below); depth dev
+ * [n_cols] int32. */
 int cto_extract_candidates(const cto_pack_view* dev_pack, int min_mq, int min_bq, double snv_min_af,
                            double indel_min_af, double min_coverage, int alt_base_num, int select_indel,
                            uint8_t* flags, int32_t* depth, void* stream);
@@ -244,6 +245,29 @@ int cto_extract_candidates(const cto_pack_view* dev_pack, int min_mq, int min_bq
  * int32 [ceil(n_cols / 256) + 1].  Stream-ordered; three small launches. */
 int cto_candidate_positions(const cto_pack_view* dev_pack, const uint8_t* flags, int bit, int32_t lo, int32_t hi, int32_t* out_pos,
                             int64_t cap, int32_t* scratch, int32_t* n_out, void* stream);
+
+/* The rest of extract_candidates_calling's modes, on the same flags (src/extract_candidates_calling.py:225-238, 249-260, 302, 347-383, 437-446,
+ * 490-497).  cto_extract_candidates also sets, for a row that exists (some read passes min_mq and the reference base is A/C/G/T: bit5, 32),
+ * bit3 (8) = some non-reference A/C/G/T read-base without an indel and bit4 (16, select_indel only) = some read-base carrying an indel.
+ *   cto_extract_restrict  rows outside a BED: d_intervals = n_intervals sorted, merged, 0-based half-open [begin, end) pairs (dev int32);
+ *                         a position p is inside when begin < p <= end - what `samtools mpileup -l` prints (:302) and what
+ *                         is_region_in(tree, ctg, p - 1, p) accepts (:437-446).  Columns outside lose the bits of `clear`: 0xff = the row
+ *                         does not exist (confident BED; depth, if not NULL, becomes 0), 2|16 = no indel candidate there.
+ *   cto_extract_mark      sets the bits of `set` on the columns whose position is in d_pos (dev int32 [n_pos], sorted): bit6 (64) = a position of
+ *                         --hybrid_mode_vcf_fn / --genotyping_mode_vcf_fn.  cto_candidate_positions then also lists a marked column that
+ *                         fails the AF gates (no bit2) when it shows an alternative base (SNV list) / an indel (indel list), :374-383.
+ *   cto_hybrid_info       per position of d_pos (sorted) a record rec[16] (dev int32): column index (-1: no row), depth, count A C G T I D,
+ *                         first-seen read index A C G T I D, first key of the column, the column's flags; with select_indel the merged
+ *                         indel alleles are counted per group instead: gcnt / gfirst (dev [n_keys]) at [first key + group].
+ *   cto_hybrid_info_rows  host: the rows of `<ctg>.<chunk>_hybrid_info` (:352-354, 490-497) from those records (copied to the host) and the
+ *                         pack's key strings; returns the text length (when > cap nothing was written). */
+int cto_extract_restrict(const cto_pack_view* dev_pack, uint8_t* flags, int32_t* depth, const int32_t* d_intervals, int n_intervals, int clear,
+                         void* stream);
+int cto_extract_mark(const cto_pack_view* dev_pack, uint8_t* flags, const int32_t* d_pos, int n_pos, int set, void* stream);
+int cto_hybrid_info(const cto_pack_view* dev_pack, const uint8_t* flags, const int32_t* d_pos, int n_pos, int min_mq, int min_bq, int select_indel,
+                    int32_t* rec, uint32_t* gcnt, int32_t* gfirst, void* stream);
+int64_t cto_hybrid_info_rows(const cto_pack* p, const char* ctg, int64_t n_pos, const int32_t* pos, const int32_t* rec, int select_indel,
+                             const uint32_t* gcnt, const int32_t* gfirst, char* buf, size_t cap);
 
 /* Host: the reference's alt_info string "<depth>-<key count ...>-" for the column `col` of pass `pass`
  * (0 = AFF, 1 = NEG; create_tensor_pileup_calling.py:158-209), from stage-A outputs copied to the host.

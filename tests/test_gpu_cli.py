@@ -733,7 +733,7 @@ def test_extract_cli_writes_reference_bed_chunks(tmp_path):
     (tmp_path / "ref.fa.fai").write_text("chr1\t%d\t6\t60\t61\n" % len(ref))
     mp = tmp_path / "mp.txt"
     mp.write_text(g["mpileup_neg"])
-    common = dict(platform="ont", ref_fn=str(fa), ctg_name="chr1", chunk_id=1, snv_min_af=pr["snv_min_af"],
+    common = dict(platform="ont", ref_fn=str(fa), ctg_name="chr1", chunk_id=None, snv_min_af=pr["snv_min_af"],
                   indel_min_af=pr["indel_min_af"], min_coverage=pr["min_coverage"], min_mq=pr["min_mq"], min_bq=pr["min_bq"],
                   alternative_base_num=pr["alt_base_num"], select_indel_candidates=True, samtools="samtools", max_depth=None)
     out = tmp_path / "cand"
@@ -750,7 +750,8 @@ def test_extract_cli_writes_reference_bed_chunks(tmp_path):
                     xs.append(int(c[2]) - 17)
         return xs
     assert centres("_snv") == g["snv"] and centres("_indel") == g["indel"]
-    assert open(out / "SNV_CANDIDATES_FILE_chr1_1").read().split() == [str(out / "chr1.1_0_1_snv")]
+    # without --chunk_id the reference's file names carry `None` (extract_candidates_calling.py:182, 457, 467)
+    assert open(out / "SNV_CANDIDATES_FILE_chr1_None").read().split() == [str(out / "chr1.None_0_1_snv")]
     # BAM path: native reader vs the text of the naive pileup of the same BAM
     from bamutil import mpileup_rows
     sc = _bam_scenario(tmp_path)
@@ -760,7 +761,7 @@ def test_extract_cli_writes_reference_bed_chunks(tmp_path):
     import pickle
     reads = pickle.load(open(tmp_path / "reads.pkl", "rb"))
     txt = tmp_path / "region.txt"
-    txt.write_text(mpileup_rows(reads, 0, "chr1", 200, L - 200))
+    txt.write_text(mpileup_rows(reads, 0, "chr1", 200 - 33, L - 200 + 33))       # --ctg_start / --ctg_end: the rows of start - 33 .. end + 33 (:289-292)
     want = extract_to_files(Namespace(candidates_folder=str(tmp_path / "c_text"), mpileup_fn=str(txt), tumor_bam_fn=None,
                                       bam_reader="samtools", ctg_start=None, ctg_end=None, **dict(common, ref_fn=sc["fa"])))
     assert got == want and len(got[0]) > 20

@@ -1,0 +1,188 @@
+"""The reference's command lines, run: `python -m clairs_to_amd <sub-module> <the argv run_clairs_to built>` against what the reference's own
+sub-modules wrote with the same argv on the same inputs (tests/golden/cli_run.json.gz, made by gen_cli.py in the build container).
+
+STEP 1 (extract_candidates_calling + concat_files) in five set-ups - default, --bed_fn, --call_indels_only_in_these_regions,
+--hybrid_mode_vcf_fn, --genotyping_mode_vcf_fn - must leave the candidates folder the reference left, file for file and byte for byte: the BED
+chunk files, the list files, bed/<ctg>_<chunk>.bed, <ctg>.<chunk>_hybrid_info.  STEP 2 / STEP 6 (create_tensor_pileup_calling x 2, predict,
+call_variants per chunk file) must write the reference's tensor text (SHA-256), its probability rows (non-probability fields equal,
+probabilities within 1e-4: north_star's tolerance) and its p_<chunk>.vcf: header byte for byte, records field for field with QUAL / GQ free to
+move in the last digit - and, from the reference's OWN probability files, the whole VCF byte for byte.
+
+`samtools` is clisim.py's stand-in on both sides (neither box has samtools)."""
+import gzip
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_json_gz
+import clisim
+from test_gpu_cli import _pickle_models
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def golden():
+    g = load_json_gz("cli_run.json.gz")
+    assert g["chunk_kw"] == clisim.CHUNK_KW
+    from clairs_to_amd.synth import mpileup_text
+    assert hashlib.sha256(mpileup_text(clisim.chunk(), 0, ctg=clisim.CTG).encode()).hexdigest() == g["pileup_sha256"]
+    return g
+
+
+class Work:
+    """the scratch tree of one run: <t>/in (inputs), <t>/runs/<name> = @W@, the stand-in `samtools` first on PATH"""
+
+    def __init__(self, tmp_path, name, rec, g):
+        self.t = str(tmp_path)
+        self.w = os.path.join(self.t, "runs", name)
+        self.inputs = clisim.write_inputs(os.path.join(self.t, "in"))
+        for k, text in g["inputs"].items():
+            assert open(self.inputs[k]).read() == text, k               # the generator's inputs, regenerated
+        clisim.write_shims(os.path.join(self.t, "bin"))
+        self.old_path = os.environ["PATH"]
+        for sub in ("tmp/candidates", "tmp/predict", "tmp/vcf_output", "tmp/pileup_tensor_can_affirmative", "tmp/pileup_tensor_can_negational",
+                    "tmp/split_beds", "tmp/split_indel_beds"):
+            os.makedirs(os.path.join(self.w, sub), exist_ok=True)
+        for k, text in rec["work_files"].items():
+            open(os.path.join(self.w, "tmp", k), "w").write(self.real(text))
+        for d in ("split_beds", "split_indel_beds"):
+            for f, text in rec.get(d, {}).items():
+                open(os.path.join(self.w, "tmp", d, f), "w").write(text)
+
+    def __enter__(self):
+        os.environ["PATH"] = os.path.join(self.t, "bin") + ":" + self.old_path
+        return self
+
+    def __exit__(self, *a):
+        os.environ["PATH"] = self.old_path
+
+    def real(self, s):
+        return s.replace("@W@", self.w).replace("@T@", self.t)
+
+    def run(self, sub, argv):
+        from clairs_to_amd.__main__ import dispatch
+        dispatch(sub, [self.real(t) for t in argv])
+
+    def files(self, sub):
+        out = {}
+        d = os.path.join(self.w, "tmp", sub)
+        for base, _, names in os.walk(d):
+            for f in names:
+                out[os.path.relpath(os.path.join(base, f), d)] = open(os.path.join(base, f)).read().replace(self.w, "@W@").replace(self.t, "@T@")
+        return out
+
+
+def same_candidates(got, want):
+    assert sorted(got) == sorted(want)
+    for f in want:
+        if f in ("SNV_CANDIDATES_FILES", "INDEL_CANDIDATES_FILES"):           # concat_files lists in directory order
+            assert sorted(got[f].split("\n")) == sorted(want[f].split("\n")), f
+        else:
+            assert got[f] == want[f], f
+
+
+@pytest.mark.parametrize("name", ["ont", "ont_bed", "ont_indel_bed", "ont_hybrid", "ont_genotyping", "ont_hybrid_indel"])
+def test_step1_writes_the_references_candidates_folder(tmp_path, golden, name):
+    rec = golden["executed"][name]
+    with Work(tmp_path, name, rec, golden) as wk:
+        for sub, argv in rec["step1_argv"]:
+            wk.run(sub, argv)
+        got = wk.files("candidates")
+    same_candidates(got, rec["candidates"])
+    if "hybrid" in name or "genotyping" in name:
+        info = [f for f in got if f.endswith("_hybrid_info")]
+        assert len(info) == 3 and sum(len(got[f].split("\n")) for f in info) > 40
+
+
+def test_python_m_entry_point_takes_the_argv(tmp_path, golden):
+    """the same through the real entry point, one invocation: `python -m clairs_to_amd extract_candidates_calling <argv>`"""
+    rec = golden["executed"]["ont_hybrid"]
+    with Work(tmp_path, "ont_hybrid", rec, golden) as wk:
+        sub, argv = rec["step1_argv"][0]
+        p = subprocess.run([sys.executable, "-m", "clairs_to_amd", sub] + [wk.real(t) for t in argv], cwd=ROOT,
+                           env=dict(os.environ, PYTHONPATH=ROOT), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert p.returncode == 0, p.stdout.decode()[-2000:]
+        got = wk.files("candidates")
+    chunk = argv[argv.index("--chunk_id") + 1]
+    mine = {f: t for f, t in rec["candidates"].items() if (".%d_" % (int(chunk) - 1)) in f or f.endswith("_%d" % (int(chunk) - 1)) or
+            f == "bed/chr20_%d.bed" % (int(chunk) - 1)}
+    assert len(mine) >= 4
+    for f, text in mine.items():
+        assert got[f] == text, f
+
+
+def vcf_parts(text):
+    rows = text.split("\n")
+    return "".join(r + "\n" for r in rows if r.startswith("#")), [r for r in rows if r and not r.startswith("#")]
+
+
+def test_step2_and_step6_with_the_references_argv(tmp_path, golden):
+    rec = golden["executed"]["ont"]
+    with Work(tmp_path, "ont", rec, golden) as wk:
+        for sub, argv in rec["step1_argv"]:
+            wk.run(sub, argv)
+        same_candidates(wk.files("candidates"), rec["candidates"])
+        models = os.path.join(wk.t, "models")
+        os.makedirs(models, exist_ok=True)
+        for mode, K, aff_cls, neg_cls in (("snv", 4, "CvT", "BiGRU_NACGT"), ("indel", 6, "CvT_Indel", "BiGRU_NACGT_Indel")):
+            d = tmp_path / ("pk_" + mode)
+            d.mkdir()
+            paths = _pickle_models(d, aff_cls, neg_cls, K)
+            os.replace(paths["model_acgt"], os.path.join(models, "aff_%s.pkl" % mode))
+            os.replace(paths["model_nacgt"], os.path.join(models, "neg_%s.pkl" % mode))
+            from clairs_to_amd.synth import likelihood_table
+            np.savetxt(os.path.join(models, "lik_%s.txt" % mode), likelihood_table(K, seed=7 + K), fmt="%.17g")
+        n = {}
+        for sub, argv in rec["step2_argv"]:
+            wk.run(sub, argv)
+            n[sub] = n.get(sub, 0) + 1
+        assert n == {"concat_files": 1, "create_tensor_pileup_calling": 12, "predict": 6, "call_variants": 6}
+        # tensor text: byte-identical (the reference's gzip stream is not reproducible; its content is)
+        for f, sha in rec["tensor_sha256"].items():
+            assert hashlib.sha256(gzip.open(os.path.join(wk.w, "tmp", f), "rb").read()).hexdigest() == sha, f
+        # probability rows
+        for f, text in rec["predict"].items():
+            K = 4 if f.endswith("_snv") else 6
+            got = [r.split("\t") for r in gzip.open(os.path.join(wk.w, "tmp", "predict", f), "rt").read().split("\n") if r]
+            want = [r.split("\t") for r in text.split("\n") if r]
+            assert len(got) == len(want) > 10
+            worst = 0.0
+            for a, b in zip(got, want):
+                assert a[:6] == b[:6] and len(a) == len(b)
+                pa = np.array([[float(v) for v in x.split()] for x in a[6:6 + 2 * K]])
+                pb = np.array([[float(v) for v in x.split()] for x in b[6:6 + 2 * K]])
+                worst = max(worst, float(np.abs(pa - pb).max()))
+            assert worst < 1e-4, (f, worst)                                  # north_star's tolerance, fp32 probabilities
+        # p_<chunk>.vcf through the whole chain
+        got = wk.files("vcf_output")
+        assert sorted(got) == sorted(rec["vcf_output"])
+        for f, text in rec["vcf_output"].items():
+            head, rows = vcf_parts(text)
+            ghead, grows = vcf_parts(got[f])
+            assert ghead == head, f
+            assert len(grows) == len(rows) > 0
+            for a, b in zip(grows, rows):
+                a, b = a.split("\t"), b.split("\t")
+                assert a[:5] == b[:5] and a[6:9] == b[6:9]
+                assert abs(float(a[5]) - float(b[5])) < 0.02                 # QUAL moves with the 8th decimal of the probabilities
+                fa_, fb_ = a[9].split(":"), b[9].split(":")
+                assert fa_[0] == fb_[0] and fa_[2:] == fb_[2:] and abs(int(fa_[1]) - int(fb_[1])) <= 1
+        # call_variants on the reference's own probability files: the whole VCF, byte for byte, with and without --show_ref
+        for f, text in rec["predict"].items():
+            with gzip.open(os.path.join(wk.w, "tmp", "predict", f), "wt") as out:
+                out.write(text)
+        for sub, argv in rec["step2_argv"]:
+            if sub != "call_variants":
+                continue
+            wk.run(sub, argv)
+            a2 = list(argv)
+            i = a2.index("--call_fn") + 1
+            a2[i] = a2[i].replace("vcf_output", "vcf_output_show_ref")
+            wk.run(sub, a2 + ["--show_ref"])
+        assert wk.files("vcf_output") == rec["vcf_output"]
+        assert wk.files("vcf_output_show_ref") == rec["vcf_output_show_ref"]
