@@ -732,7 +732,14 @@ extern "C" int64_t cto_hybrid_info_rows(const cto_pack* p, const char* ctg, int6
                 const size_t kl = size_t(p->key_str_off[size_t(k) + 1] - p->key_str_off[size_t(k)]);
                 std::string key;
                 if ((p->key_meta[size_t(k)] & 3) == 1) { key.assign(ks, kl); for (auto& ch : key) ch = cto::up(ch); }
-                else key = "D" + std::string(kl > 0 ? kl - 1 : 0, 'N');
+                else {
+                    // a deletion's key string is 'D' + the reference slice anchor .. last deleted base, cut at max_indel_length: its length
+                    // gives the deleted length unless the deletion is over-long (key_meta bit 3) - then the pack does not say how long
+                    CTO_REQUIRE(!(p->key_meta[size_t(k)] & 8), CTO_EUNSUPPORTED,
+                                "cto_hybrid_info_rows: %s:%d carries a deletion longer than max_indel_length; its per-allele row cannot be printed",
+                                ctg, int(pos[i]));
+                    key = "D" + std::string(kl >= 2 ? kl - 2 : 0, 'N');
+                }
                 items.push_back(Item{int64_t(gcnt[k0 + g]), int64_t(gfirst[k0 + g]) * 2 + 1, key});
             }
         }

@@ -265,3 +265,27 @@ def extract_candidates(text, ref, ref_start, snv_min_af=0.05, indel_min_af=0.05,
           C.c_double(snv_min_af), C.c_double(indel_min_af), int(alt_base_num), int(bool(select_indel)), _p(pos), _p(flags),
           _p(depth), C.c_int64(cap))
     return pos[:n], flags[:n], depth[:n]
+
+
+def hybrid_info_rows(text, ref, ref_start, positions, ctg, snv_min_af=0.05, indel_min_af=0.05, min_coverage=4, alt_base_num=3,
+                     select_indel=False):
+    """The rows of `<ctg>.<chunk>_hybrid_info` (extract_candidates_calling.py:352-354, 490-497) for the listed positions that have a row in
+    the extraction pileup `text` (6 columns) and an A/C/G/T reference base."""
+    pos, flags, _ = extract_candidates(text, ref, ref_start, snv_min_af, indel_min_af, min_coverage, alt_base_num, select_indel)
+    at = {int(p): i for i, p in enumerate(pos)}
+    wanted = set(int(p) for p in positions)
+    f = lib().orc_hybrid_alt_info
+    out = []
+    buf = C.create_string_buffer(1 << 20)
+    tb = text.encode() if isinstance(text, str) else text
+    for row in tb.split(b"\n"):
+        c = row.split(b"\t")
+        if len(c) < 5 or int(c[1]) not in wanted:
+            continue
+        p = int(c[1])
+        if not flags[at[p]] & 32:
+            continue
+        n = f(c[4], len(c[4]), int(bool(select_indel)), int(bool(flags[at[p]] & 4)), buf, len(buf))
+        assert n >= 0
+        out.append("%s\t%d\t%s\t%s\n" % (ctg, p, ref[p - ref_start].upper(), buf.raw[:n].decode()))
+    return "".join(out)

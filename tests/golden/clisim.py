@@ -127,7 +127,10 @@ def write_inputs(w):
         f.write("%s\t100\t2000\n%s\t3900\t5200\n" % (CTG, CTG))
     rng = np.random.default_rng(77)
     pos = ch.col_pos.astype(np.int64)
-    picks = sorted(set(int(v) for v in rng.choice(pos[(pos > 60)], size=60, replace=False)) | {int(pos[-1]) + 40, 48, 20})
+    # 60 random columns (most fail the AF gates), every 10th planted site (most pass them: their rows are printed as fractions), and three
+    # positions without a pileup row
+    picks = sorted(set(int(v) for v in rng.choice(pos[(pos > 60)], size=60, replace=False)) | set(int(v) for v in ch.site_pos[::10]) |
+                   {int(pos[-1]) + 40, 48, 20})
     with open(p["vcf"], "w") as f:
         f.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSAMPLE\n")
         for i, x in enumerate(picks):

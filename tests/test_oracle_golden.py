@@ -99,3 +99,46 @@ def test_extract_candidates_match_reference(oracle_lib):
     assert pos[(flags & 1) != 0].tolist() == g["snv"] and len(g["snv"]) > 10
     assert pos[(flags & 2) != 0].tolist() == g["indel"] and len(g["indel"]) > 0
     assert ((flags & 4) != 0).sum() >= len(g["snv"])
+
+
+@pytest.mark.parametrize("name", ["ont_hybrid", "ont_genotyping", "ont_hybrid_indel"])
+def test_hybrid_rows_match_reference(oracle_lib, name):
+    """cli_run.json.gz: the `<ctg>.<chunk>_hybrid_info` files and the candidate lists the reference's extract_candidates_calling wrote for
+    run_clairs_to's hybrid / genotyping command lines (and the same with indel candidates selected) vs the restatement - the injected
+    candidates of :374-383, the count form and the fraction form (a row that passes the gates) of the rows of :352-354."""
+    import clisim
+    from clairs_to_amd.synth import mpileup_text
+    g = load_json_gz("cli_run.json.gz")
+    rec = g["executed"][name]
+    ch = clisim.chunk()
+    seq, L = clisim.contig(ch)
+    select_indel = name.endswith("_indel")
+    known = sorted({int(r.split("\t")[1]) for r in g["inputs"]["vcf"].split("\n") if r and r[0] != "#" and r.split("\t")[0] == clisim.CTG})
+    text = mpileup_text(ch, 20, ctg=clisim.CTG, min_mq=20, with_mq=False)
+    n_rows = n_frac = 0
+    for chunk_id in range(3):
+        size = L // 3 + 1 if L % 3 else L // 3
+        if name == "ont_genotyping":                    # the region comes from the span of split_beds/<ctg> (:249-260), the rows from its intervals
+            iv = [tuple(int(v) for v in r.split()[1:3]) for r in rec["split_beds"][clisim.CTG].split("\n") if r]
+            b0, b1 = min(a for a, _ in iv), max(b for _, b in iv)
+            size = (b1 - b0) // 3 + 1 if (b1 - b0) % 3 else (b1 - b0) // 3
+            start = b0 + 1 + size * chunk_id
+        else:
+            iv = None
+            start = size * chunk_id
+        lo, hi = max(start - 33, 1), start + size + 33
+        rows = [r for r in text.split("\n") if r and lo <= int(r.split("\t")[1]) <= hi and
+                (iv is None or any(a < int(r.split("\t")[1]) <= b for a, b in iv))]
+        sub = "\n".join(rows) + "\n"
+        want = rec["candidates"]["%s.%d_hybrid_info" % (clisim.CTG, chunk_id)]
+        got = oracle_lib.hybrid_info_rows(sub, seq, 1, known, clisim.CTG, 0.05, 0.1, 4, 3, select_indel)
+        assert got == want
+        n_rows += want.count("\n")
+        n_frac += sum("." in r.split("\t")[3] for r in want.split("\n") if r)
+        # the SNV list with the injected positions
+        pos, flags, _ = oracle_lib.extract_candidates(sub, seq, 1, 0.05, 0.1, 4, 3, select_indel)
+        hyb = np.isin(pos, known)
+        snv = pos[((flags & 1) != 0) | (hyb & ((flags & 4) == 0) & ((flags & 8) != 0))]
+        bed = rec["candidates"].get("%s.%d_0_1_snv" % (clisim.CTG, chunk_id), "")
+        assert [int(r.split("\t")[2]) - 17 for r in bed.split("\n") if r] == snv.tolist()
+    assert n_rows > 50 and n_frac >= 6
