@@ -211,6 +211,11 @@ bool banded_path(const int8_t* ref, const int8_t* read, int R, int Q, int score,
     static thread_local std::vector<int> hb, eb, hc;            // scratch of the calling worker: no allocation per alignment
     static thread_local std::vector<int8_t> dir;
     hb.clear(); eb.clear(); hc.clear();                         // contents as of fresh vectors, the storage kept
+    // ... up to a bound: one wide-band traceback (dir may reach 1 GiB under the guard below) must not stay pinned to this worker thread
+    struct Shrink {
+        std::vector<int8_t>& d;
+        ~Shrink() { if (d.capacity() > (size_t(64) << 20)) std::vector<int8_t>().swap(d); }
+    } shrink{dir};
     int best = 0, width_d = 0;
     auto bu = [](int w, int i, int j) { int x = i - w; if (x < 0) x = 0; return j - x + 1; };            // set_u
     auto bd = [](int w, int i, int j, int p) { int x = i - w; if (x < 0) x = 0; return (j - x) * 3 + p; };  // set_d

@@ -25,6 +25,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstring>
+#include <exception>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -544,13 +545,30 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 
 template <class F>
 void parallel_for(size_t n, int threads, F&& f) {
+    // an exception on a worker (std::bad_alloc in a window's vectors) must not reach std::terminate: the first one is kept, every
+    // worker stops taking items, and the caller rethrows it after the join - where the C boundary's CTO_CATCH turns it into an error code
     std::atomic<size_t> next{0};
-    auto work = [&]() { for (size_t i = next++; i < n; i = next++) f(i); };
+    std::atomic<bool> failed{false};
+    std::exception_ptr first;
+    std::mutex first_lock;
+    auto work = [&]() {
+        try {
+            for (size_t i = next++; i < n && !failed.load(std::memory_order_relaxed); i = next++) f(i);
+        } catch (...) {
+            std::lock_guard<std::mutex> g(first_lock);
+            if (!first) first = std::current_exception();
+            failed.store(true);
+        }
+    };
     const int nt = int(std::min<size_t>(size_t(std::max(1, threads)), n));
     std::vector<std::thread> pool;
-    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    try {
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    } catch (...) {                                   // no more threads to be had: the ones that started and this one do the work
+    }
     work();
     for (std::thread& t : pool) t.join();
+    if (first) std::rethrow_exception(first);
 }
 
 struct Reaper {
@@ -690,8 +708,16 @@ int launch_sw(hipStream_t s, const signed char* pool, const SwDesc* desc, const 
     const size_t smem = row_bytes * ROWS;
     CTO_REQUIRE(smem <= size_t(160) * 1024, CTO_EUNSUPPORTED, "cto_realign_windows: an alignment of %d x %d does not fit the LDS", Rcap, Qcap);
     // once per kernel and for the whole LDS: launches of different classes (and of concurrent calls) must not lower each other's limit
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sw<BYTE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    CTO_HIP(attr);
+    // (a function attribute belongs to the device it was set on: once per kernel AND device)
+    {
+        static std::atomic<unsigned char> done[64];
+        int dev = 0;
+        CTO_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !done[dev].load(std::memory_order_acquire)) {
+            CTO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sw<BYTE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            if (dev >= 0 && dev < 64) done[dev].store(1, std::memory_order_release);
+        }
+    }
     hipLaunchKernelGGL((k_sw<BYTE>), dim3(unsigned((n + ROWS - 1) / ROWS)), dim3(unsigned(LW * ROWS)), smem, s, pool, desc, order, n, out, overflowed, segcap);
     CTO_HIP(hipGetLastError());
     return CTO_OK;
@@ -983,13 +1009,18 @@ struct DirScratch {
     static unsigned char*& kept() { static unsigned char* p = nullptr; return p; }
     static size_t& kept_cap() { static size_t c = 0; return c; }
     static bool& busy() { static bool b = false; return b; }
+    static int& kept_device() { static int d = -1; return d; }
     unsigned char* p = nullptr;
     bool from_kept = false;
     bool get(size_t bytes) {
         bytes = std::max<size_t>(bytes, 1);
+        int dev = -1;
+        (void)hipGetDevice(&dev);
         {
+            // the kept buffer belongs to the device of the first call (as the kept arena does): a call on another device allocates its own
             std::lock_guard<std::mutex> g(lock());
-            if (!busy()) {
+            if (!busy() && (kept_device() < 0 || kept_device() == dev)) {
+                kept_device() = dev;
                 if (kept_cap() < bytes) {
                     if (kept()) (void)hipFree(kept());
                     kept() = nullptr; kept_cap() = 0;

@@ -211,9 +211,12 @@ class WindowBatcher(object):
             ...
     """
 
-    def __init__(self, where="device", threads=0, max_batch=8192, device=None):
+    def __init__(self, where="device", threads=0, max_batch=8192, device=None, host_fallback=False):
         import threading
         self.where, self.threads, self.max_batch = where, int(threads), int(max_batch)
+        # host_fallback (--realigner auto): windows a device batch gives back with an error are done again by the host form - the same
+        # output - and the run goes on, with one line on stderr; an explicit `--realigner device` fails loudly instead
+        self.host_fallback, self.fell_back = bool(host_fallback), 0
         self.cv = threading.Condition()
         self.queue, self.live, self.parked, self.closed = [], 0, 0, False
         self.batches, self.windows, self.stats = 0, 0, {}
@@ -245,8 +248,7 @@ class WindowBatcher(object):
             self.parked += 1
             self.cv.notify_all()
             while not slot["done"]:
-                self.cv.wait()
-            self.parked -= 1
+                self.cv.wait()                                   # (the dispatcher took this slot out of `parked` when it marked it done)
         if slot["err"] is not None:
             raise RuntimeError(slot["err"])
         return slot["out"]
@@ -266,25 +268,41 @@ class WindowBatcher(object):
                 if self.closed and not self.queue:
                     return
                 batch, self.queue = self.queue, []
-            st, codes = {}, []
-            try:
-                outs = realign_windows([b["args"] for b in batch], where=self.where, threads=self.threads, stats=st, statuses=codes)
-                for b, o, code in zip(batch, outs, codes):
-                    if code == 0:
-                        b["out"] = o
-                    else:
-                        b["err"] = "cto_realign_windows: status %d (%s)" % (code, codes[-1])
-            except Exception as e:          # the whole batch failed (out of device memory, ...): every caller hears of it
-                for b in batch:
-                    b["err"] = str(e)
+            st = {}
+            self._realign(batch, self.where, st)
+            failed = [b for b in batch if b["err"] is not None]
+            if failed and self.host_fallback and self.where == "device":
+                import sys
+                if not self.fell_back:
+                    sys.stderr.write("[WARNING] realigner: the device form gave up on %d window(s) (%s); the host form does them (--realigner auto)\n"
+                                     % (len(failed), failed[0]["err"]))
+                self.fell_back += len(failed)
+                for b in failed:
+                    b["err"] = None
+                self._realign(failed, "host", {})
             with self.cv:
                 self.batches += 1
                 self.windows += len(batch)
+                self.parked -= len(batch)                         # under the lock, together with `done`: a worker that wakes and re-queues
+                                                                  # at once must not be counted twice while the others are still waking
                 for k, v in st.items():
                     self.stats[k] = self.stats.get(k, 0) + v
                 for b in batch:
                     b["done"] = True
                 self.cv.notify_all()
+
+    def _realign(self, batch, where, st):
+        codes = []
+        try:
+            outs = realign_windows([b["args"] for b in batch], where=where, threads=self.threads, stats=st, statuses=codes)
+            for b, o, code in zip(batch, outs, codes):
+                if code == 0:
+                    b["out"] = o
+                else:
+                    b["err"] = "cto_realign_windows: status %d (%s)" % (code, codes[-1])
+        except Exception as e:          # the whole batch failed (out of device memory, ...): every caller hears of it
+            for b in batch:
+                b["err"] = str(e)
 
     def close(self):
         with self.cv:

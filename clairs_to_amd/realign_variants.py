@@ -238,6 +238,10 @@ def realign_variants(args):
     failed, done = set(), 0
     batcher = None
     realigner = getattr(args, "realigner", "host")
+    chose_auto = realigner == "auto"
+    explicit_process_pool = getattr(args, "pool", "thread") == "process" and getattr(args, "pool_given", False)
+    if realigner == "auto" and explicit_process_pool:
+        realigner = "host"                        # a --pool process that was asked for is honoured: the batcher needs threads
     if realigner == "auto":                       # the device form where a HIP device is visible to this process
         try:
             import torch
@@ -248,7 +252,7 @@ def realign_variants(args):
         # the calls are worker threads that park their windows at a WindowBatcher (realign_reads.py): when all of them wait, one
         # cto_realign_windows call - k_fast_pass + k_sw on the current HIP device - serves the lot.  More threads than cores on
         # purpose: they sleep while the batch runs, and a batch is only as large as the number of calls in flight.
-        batcher = rr.WindowBatcher("device", threads=threads)
+        batcher = rr.WindowBatcher("device", threads=threads, host_fallback=chose_auto)
         workers = max(threads, min(256, len(todo)))
         pool = ThreadPoolExecutor(max_workers=workers)
 
@@ -272,7 +276,8 @@ def realign_variants(args):
                 print("[INFO] Processing in {}, total processed positions: {}".format(ctg, done), flush=True)
     if batcher is not None:
         batcher.close()
-        print("[INFO] Realigner on the device: {} windows in {} batches".format(batcher.windows, batcher.batches), flush=True)
+        print("[INFO] Realigner on the device: {} windows in {} batches{}".format(
+            batcher.windows, batcher.batches, ", {} of them redone by the host form".format(batcher.fell_back) if batcher.fell_back else ""), flush=True)
     out_header = header_up_to_last_format(header)
     fai = args.ref_fn + ".fai" if os.path.exists(args.ref_fn + ".fai") else ".".join(args.ref_fn.split(".")[:-1]) + ".fai"
     names = None if args.ctg_name is None else args.ctg_name.split(",")
@@ -310,7 +315,7 @@ def build_parser():
     p.add_argument("--pool", type=str, default="thread", choices=["thread", "process"],
                    help="workers are threads (default) or spawned processes (the reference's ProcessPoolExecutor; scales with the cores)")
     p.add_argument("--realigner", type=str, default="auto", choices=["auto", "host", "device"],
-                   help="auto (default): device where a HIP device is visible, host otherwise; host: every window through cto_realign_reads on the worker that needs it (SSE2); device: the windows of all calls "
+                   help="auto (default): device where a HIP device is visible (windows the device form gives back with an error are redone by the host form, same output; an explicit --pool process selects the host form), host otherwise; host: every window through cto_realign_reads on the worker that needs it (SSE2); device: the windows of all calls "
                         "in flight are batched into cto_realign_windows calls on the current HIP device (k-mer fast pass and both striped "
                         "Smith-Waterman passes as kernels; same output)")
     p.add_argument("--python", type=str, default="python3", help="accepted for compatibility: the realignment runs in-process")
@@ -329,7 +334,9 @@ def main(argv=None):
     if len(sys.argv[1:] if argv is None else argv) == 0:
         p.print_help()
         sys.exit(1)
-    realign_variants(p.parse_args(argv))
+    a = p.parse_args(argv)
+    a.pool_given = any(t == "--pool" or t.startswith("--pool=") for t in (sys.argv[1:] if argv is None else argv))
+    realign_variants(a)
 
 
 if __name__ == "__main__":

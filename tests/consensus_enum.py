@@ -106,3 +106,39 @@ def enumerate_consensus(ref, reads, lowbq=None, limit_margin=40):
             return None
         return sorted(out)
     return []
+
+
+def consensus_windows(seed, count):
+    """The generated windows of tests/test_realign.py::test_debruijn_against_an_independent_enumerator and of tools/pin_dbg.sh: (reference,
+    reads, low-quality positions per read) with SNVs, insertions, deletions, N bases, a repeated reference stretch every seventh window
+    and reads that carry a tandem duplication (a cycle at small k)."""
+    import numpy as np
+    BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+    rng = np.random.default_rng(seed)
+    for it in range(count):
+        n = int(rng.integers(60, 260))
+        ref = bytes(rng.choice(BASES, n)).decode()
+        if it % 7 == 0:                                             # a repeated stretch: the smallest k is not 10
+            a = int(rng.integers(0, n - 40)); ref = ref[:a + 30] + ref[a:a + 25] + ref[a + 30:]
+        haps = [ref]
+        for _ in range(int(rng.integers(0, 4))):
+            p = int(rng.integers(15, len(ref) - 15)); kind = int(rng.integers(0, 3))
+            base = haps[int(rng.integers(0, len(haps)))]
+            if kind == 0:
+                haps.append(base[:p] + "ACGT"[("ACGT".index(base[p]) + 1) % 4] + base[p + 1:])
+            elif kind == 1:
+                haps.append(base[:p] + bytes(rng.choice(BASES, int(rng.integers(1, 9)))).decode() + base[p:])
+            else:
+                haps.append(base[:p] + base[p + int(rng.integers(1, 9)):])
+        reads, lowbq = [], []
+        for _ in range(int(rng.integers(6, 40))):
+            h = haps[int(rng.integers(0, len(haps)))]
+            a = int(rng.integers(0, max(1, len(h) - 40)))
+            r = h[a:a + int(rng.integers(30, 151))]
+            if rng.random() < 0.15:
+                q = int(rng.integers(0, len(r))); r = r[:q] + "N" + r[q + 1:]
+            if rng.random() < 0.1 and len(r) > 70:                 # a tandem duplication inside a read: a cycle at small k
+                q = int(rng.integers(10, len(r) - 50)); r = r[:q + 30] + r[q:q + 30] + r[q + 30:]
+            reads.append(r)
+            lowbq.append(sorted({int(x) for x in rng.integers(0, len(r), int(rng.integers(0, 3)))}) if rng.random() < 0.3 else [])
+        yield ref, reads, lowbq

@@ -150,7 +150,7 @@ def test_step2_and_step6_with_the_references_argv(tmp_path, golden):
             K = 4 if f.endswith("_snv") else 6
             got = [r.split("\t") for r in gzip.open(os.path.join(wk.w, "tmp", "predict", f), "rt").read().split("\n") if r]
             want = [r.split("\t") for r in text.split("\n") if r]
-            assert len(got) == len(want) > 10
+            assert len(got) == len(want) > (10 if K == 4 else 2)
             worst = 0.0
             for a, b in zip(got, want):
                 assert a[:6] == b[:6] and len(a) == len(b)

@@ -298,38 +298,12 @@ def test_debruijn_path_limit():
 
 
 def test_debruijn_against_an_independent_enumerator():
-    """tests/dbg_enum.py - the reference's contract restated a second time with other means (recursion instead of the queue, dictionaries
+    """tests/consensus_enum.py - the reference's contract restated a second time with other means (recursion instead of the queue, dictionaries
     instead of vertex arrays) - agrees with cto_dbg_consensus on windows with SNVs, indels, low-quality positions, N bases, repeated
     reference k-mers and reads that close cycles.  PARITY STAYS UNPINNED: neither side is the compiled reference (Boost.Graph)."""
-    from dbg_enum import enumerate_consensus
-    rng = np.random.default_rng(2026)
+    from consensus_enum import enumerate_consensus, consensus_windows
     checked = multi = 0
-    for it in range(250):
-        n = int(rng.integers(60, 260))
-        ref = bytes(rng.choice(ru.BASES, n)).decode()
-        if it % 7 == 0:                                             # a repeated stretch: the smallest k is not 10
-            a = int(rng.integers(0, n - 40)); ref = ref[:a + 30] + ref[a:a + 25] + ref[a + 30:]
-        haps = [ref]
-        for _ in range(int(rng.integers(0, 4))):
-            p = int(rng.integers(15, len(ref) - 15)); kind = int(rng.integers(0, 3))
-            base = haps[int(rng.integers(0, len(haps)))]
-            if kind == 0:
-                haps.append(base[:p] + "ACGT"[("ACGT".index(base[p]) + 1) % 4] + base[p + 1:])
-            elif kind == 1:
-                haps.append(base[:p] + bytes(rng.choice(ru.BASES, int(rng.integers(1, 9)))).decode() + base[p:])
-            else:
-                haps.append(base[:p] + base[p + int(rng.integers(1, 9)):])
-        reads, lowbq = [], []
-        for _ in range(int(rng.integers(6, 40))):
-            h = haps[int(rng.integers(0, len(haps)))]
-            a = int(rng.integers(0, max(1, len(h) - 40)))
-            r = h[a:a + int(rng.integers(30, 151))]
-            if rng.random() < 0.15:
-                q = int(rng.integers(0, len(r))); r = r[:q] + "N" + r[q + 1:]
-            if rng.random() < 0.1 and len(r) > 70:                 # a tandem duplication inside a read: a cycle at small k
-                q = int(rng.integers(10, len(r) - 50)); r = r[:q + 30] + r[q:q + 30] + r[q + 30:]
-            reads.append(r)
-            lowbq.append(sorted({int(x) for x in rng.integers(0, len(r), int(rng.integers(0, 3)))}) if rng.random() < 0.3 else [])
+    for it, (ref, reads, lowbq) in enumerate(consensus_windows(2026, 250)):
         want = enumerate_consensus(ref, reads, lowbq)
         if want is None:                                            # near the 256-path cut-off: order dependent in the reference
             continue
