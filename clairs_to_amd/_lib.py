@@ -39,7 +39,9 @@ class CvtCfg(C.Structure):
 
 class ChunkJob(C.Structure):
     _fields_ = [("ctg_name", C.c_char_p), ("bed_path", C.c_char_p), ("mpileup_path", C.c_char_p), ("bam_path", C.c_char_p),
-                ("vcf_path", C.c_char_p), ("region_start", c_i64), ("region_end", c_i64), ("candidates_path", C.c_char_p)]
+                ("vcf_path", C.c_char_p), ("region_start", c_i64), ("region_end", c_i64), ("candidates_path", C.c_char_p),
+                ("confident_intervals", C.c_void_p), ("n_confident_intervals", c_i64), ("restrict_to_confident", C.c_int),
+                ("known_pos", C.c_void_p), ("n_known_pos", c_i64), ("hybrid_info_path", C.c_char_p)]
 
 
 class RunCfg(C.Structure):
@@ -50,7 +52,8 @@ class RunCfg(C.Structure):
                 ("inflate_cus", C.c_int), ("inflate_jobs", C.c_int), ("pack_threads", C.c_int), ("samtools", C.c_char_p),
                 ("samtools_max_depth", C.c_int), ("aff2", c_vp), ("neg2", c_vp), ("device_pileup", C.c_int),
                 ("extract_min_mq", C.c_int), ("extract_min_bq", C.c_int), ("alt_base_num", C.c_int), ("snv_min_af", C.c_double),
-                ("indel_min_af", C.c_double), ("min_coverage", C.c_double), ("indel_regions_bed", C.c_char_p), ("device_tokenise", C.c_int)]
+                ("indel_min_af", C.c_double), ("min_coverage", C.c_double), ("indel_regions_bed", C.c_char_p), ("device_tokenise", C.c_int),
+                ("indel_bed_superseded", C.c_int)]
 
 
 class RealignJob(C.Structure):

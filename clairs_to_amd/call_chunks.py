@@ -29,6 +29,7 @@ from argparse import ArgumentParser, Namespace
 from collections import deque
 from concurrent.futures import ThreadPoolExecutor
 
+import numpy as np
 import torch
 
 from .dist import shard_range
@@ -178,6 +179,65 @@ def native_eligible(chunk_args):
     return True
 
 
+class RegionModes(object):
+    """What REGION jobs take from extract_candidates_calling's optional inputs, per contig and read once: the confident BED's rows
+    (--bed_fn; a path that does not exist is no BED, as for the reference, :205-210) as sorted merged int32 pairs, and the positions of
+    the --hybrid_mode_vcf_fn / --genotyping_mode_vcf_fn records (read_known_vcf = VcfReader as :225-238 uses it)."""
+
+    def __init__(self, args):
+        from .extract_candidates_calling import merged_intervals, read_bed_rows, read_known_vcf
+        self._rows, self._merged, self._known_of = read_bed_rows, merged_intervals, read_known_vcf
+        bed = getattr(args, "bed_fn", None)
+        self.bed_fn = bed if bed and os.path.exists(bed) else None
+        self.known_fn = getattr(args, "hybrid_mode_vcf_fn", None) or getattr(args, "genotyping_mode_vcf_fn", None)
+        self.select_indel = not args.disable_indel_calling
+        self._conf, self._known, self.rows = {}, {}, {}
+
+    def confident_rows(self, ctg):
+        if self.bed_fn is None:
+            return None
+        if ctg not in self.rows:
+            self.rows[ctg] = self._rows(self.bed_fn, ctg)
+        return self.rows[ctg]
+
+    def confident(self, ctg):
+        rows = self.confident_rows(ctg)
+        if rows is None:
+            return None
+        if ctg not in self._conf:
+            self._conf[ctg] = np.ascontiguousarray(np.asarray(self._merged(rows, widen_empty=False), dtype=np.int32).reshape(-1))
+        return self._conf[ctg]
+
+    def known(self, ctg):
+        if not self.known_fn:
+            return None
+        if ctg not in self._known:
+            self._known[ctg] = np.ascontiguousarray(np.asarray(self._known_of(self.known_fn, ctg, self.select_indel)[0], dtype=np.int32))
+        return self._known[ctg]
+
+
+def region_rows(args):
+    """--region_list rows -> (ctg, start, end) strings.  `ctg start end` as given; `ctg i/n` = --chunk_id i --chunk_num n of
+    extract_candidates_calling (chunk_region: the .fai's length or, with --bed_fn, the span of the confident rows)."""
+    from .extract_candidates_calling import chunk_region
+    modes = RegionModes(args)
+    out = []
+    for r in open(args.region_list):
+        c = r.split()
+        if not c or r.startswith("#"):
+            continue
+        if len(c) >= 3:
+            out.append((c[0], c[1], c[2]))
+            continue
+        if len(c) != 2 or "/" not in c[1]:
+            sys.exit("[ERROR] --region_list: a row is `ctg start end` or `ctg i/n`: " + r.strip())
+        i, n = (int(x) for x in c[1].split("/"))
+        a = Namespace(chunk_id=i, chunk_num=n, ctg_name=c[0], ref_fn=args.ref_fn, bed_fn=modes.bed_fn, ctg_start=None, ctg_end=None)
+        s, e, _ = chunk_region(a, modes.confident_rows(c[0]))
+        out.append((c[0], str(s), str(e)))
+    return out
+
+
 def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, stats=None, verbose=True, inflate_cus=None, inflate_jobs=None,
                         two_streams=False, device_tokenise=None):
     """run_pipeline() as ONE C call (cto_run_chunks, csrc/pipeline.hip): the same stages on native threads, with page-locked staging,
@@ -192,6 +252,7 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
         return 0
     a0 = chunk_args[0]
     jobs = (ChunkJob * len(chunk_args))()
+    keep = []                                  # the arrays the jobs point into, alive until the call returns
     for j, a in zip(jobs, chunk_args):
         os.makedirs(os.path.dirname(os.path.abspath(a.call_fn)), exist_ok=True)
         mp = getattr(a, "mpileup_fn", None)
@@ -200,6 +261,15 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
         if region is not None:                 # REGION job: no candidate BED - the candidates are extracted from the same pile-up
             j.bed_path, j.region_start, j.region_end = None, int(region[0]), int(region[1])
             j.candidates_path = a.candidates_out_fn.encode() if getattr(a, "candidates_out_fn", None) else None
+            # the other modes of extract_candidates_calling: the job carries its contig's confident rows and hybrid / genotyping positions
+            conf, known = getattr(a, "confident_intervals", None), getattr(a, "known_pos", None)
+            if conf is not None:
+                keep.append(conf)
+                j.confident_intervals, j.n_confident_intervals, j.restrict_to_confident = conf.ctypes.data, len(conf) // 2, 1
+            if known is not None and len(known):
+                keep.append(known)
+                j.known_pos, j.n_known_pos = known.ctypes.data, len(known)
+            j.hybrid_info_path = a.hybrid_info_fn.encode() if getattr(a, "hybrid_info_fn", None) else None
         else:
             j.bed_path = a.candidates_bed_regions.encode()
         j.mpileup_path = mp.encode() if mp else None
@@ -243,7 +313,8 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
     cfg.indel_min_af = float(getattr(a0, "indel_min_af", None) or _PF.get(fam, _PF["ont"])["indel_min_af"])
     cfg.min_coverage = float(4 if getattr(a0, "min_coverage", None) is None else a0.min_coverage)
     ib = getattr(a0, "call_indels_only_in_these_regions", None)
-    cfg.indel_regions_bed = str(ib).encode() if ib else None
+    cfg.indel_regions_bed = str(ib).encode() if ib and os.path.exists(str(ib)) else None       # a path that does not exist is no BED (:205-210)
+    cfg.indel_bed_superseded = int(bool(getattr(a0, "bed_fn_source", None)))
     if two_streams:                               # consecutive chunks on two compute streams (a second pair of handles of the same weights)
         with torch.cuda.device(eng.device):
             cfg.aff2, cfg.neg2 = eng.aff._handle2(), eng.neg._handle2()
@@ -283,7 +354,9 @@ def call_chunks(args):
     region_mode = bool(getattr(args, "region_list", None))
     if region_mode:
         # REGION jobs: rows `ctg start end` (1-based, inclusive: the --ctg_start / --ctg_end of extract_candidates_calling); no BED
-        chunks = [tuple(r.split()[:3]) for r in open(args.region_list) if r.strip() and not r.startswith("#")]
+        # or rows `ctg i/n`: part i (1-based) of n equal parts of the contig's length from the .fai - with --bed_fn, of the span of its rows
+        # (--chunk_id / --chunk_num, extract_candidates_calling.py:240-270)
+        chunks = region_rows(args)
     else:
         chunks = [r.strip() for r in open(args.chunk_list) if r.strip()]
     lo, hi = shard_range(len(chunks), world, rank)
@@ -294,6 +367,7 @@ def call_chunks(args):
 
     def region_name(r):
         return "%s_%s_%s" % (r[0], r[1], r[2])
+    modes = RegionModes(args) if region_mode else None
 
     def chunk_args(bed):
         if region_mode:
@@ -304,6 +378,8 @@ def call_chunks(args):
             a.call_fn = os.path.join(args.output_dir, "p_%s.vcf" % region_name(bed))
             cd = getattr(args, "candidates_dir", None)
             a.candidates_out_fn = os.path.join(cd, region_name(bed) + (".snv" if args.disable_indel_calling else ".indel")) if cd else None
+            a.confident_intervals, a.known_pos = modes.confident(bed[0]), modes.known(bed[0])
+            a.hybrid_info_fn = os.path.join(cd, region_name(bed) + "_hybrid_info") if cd and modes.known_fn else None
             return a
         ctg = chunk_contig(bed)
         if ctg is None:
@@ -496,6 +572,13 @@ def main(argv=None):
     p.add_argument("--min_coverage", type=float, default=4, help="--region_list: --min_coverage")
     p.add_argument("--alternative_base_num", type=int, default=3, help="--region_list: --alternative_base_num")
     p.add_argument("--extract_min_mq", type=int, default=20, help="--region_list: --min_mq of extract_candidates_calling")
+    p.add_argument("--bed_fn", type=str, default=None,
+                   help="--region_list: confident regions (extract_candidates_calling --bed_fn, :249-260, 302): positions outside its rows have no pileup row - "
+                        "no candidate there, and `ctg i/n` rows of --region_list cut the span of its rows; a missing file is no BED")
+    p.add_argument("--bed_fn_source", type=str, default=None, help="--region_list: the user's own --bed_fn, if any: it supersedes --call_indels_only_in_these_regions (:438)")
+    p.add_argument("--hybrid_mode_vcf_fn", type=str, default=None,
+                   help="--region_list: positions of this VCF's records are candidates whenever they show an alternative base / an indel, AF gates or not (:347-349, 370-383)")
+    p.add_argument("--genotyping_mode_vcf_fn", type=str, default=None, help="--region_list: the same list under the reference's other name (:225-238)")
     p.add_argument("--call_indels_only_in_these_regions", type=str, default=None,
                    help="--region_list, indel mode: keep an indel candidate only inside the rows of this BED (extract_candidates_calling.py:437-446)")
     p.add_argument("--output_dir", type=str, required=True, help="directory for the p_<chunk>.vcf files")

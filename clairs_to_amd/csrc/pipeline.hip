@@ -111,6 +111,8 @@ struct Slot {
     DevBuf dec_l, qual_l;                // decision / QUAL of one network launch, before they are dealt out to the chunks they belong to
     DevBuf xflags, xdepth, xscratch, cand, cand_scr;    // REGION jobs: candidate gates' outputs, overflow counters, candidate positions (+ count)
     PinBuf cand_host;
+    DevBuf xmode;                        // REGION jobs with a confident BED / an indel BED / a hybrid list: intervals, positions, hybrid_info records
+    PinBuf xmode_host;
     DevBuf res_dev;                      // site_info | candidate column vectors | sitefirst | decision | qual | keycnt | keyfirst
     PinBuf res_host;                     // the same bytes on the host, one copy per chunk
     size_t roff[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -466,13 +468,6 @@ struct Run {
         }
         return true;
     }
-    // is_region_in(tree, ctg, pos - 1, pos): some row with begin < pos and end > pos - 1
-    static bool in_regions(const std::vector<int64_t>& iv, int64_t pos) {
-        size_t lo = 0, hi = iv.size() / 2;
-        while (lo < hi) { const size_t m = (lo + hi) / 2; if (iv[2 * m + 1] > pos - 1) hi = m; else lo = m + 1; }
-        return lo < iv.size() / 2 && iv[2 * lo] < pos;
-    }
-
     bool fai_of(const std::string& ctg, FaiRec* rec, std::string* err) {
         std::lock_guard<std::mutex> g(fai_m);
         auto it = fai.find(ctg);
@@ -845,6 +840,7 @@ struct Run {
         const int64_t nc = s->hv.n_cols;
         if (nc == 0) {
             if (j.candidates_path) { FILE* f = fopen(j.candidates_path, "w"); if (f) fclose(f); }
+            if (j.hybrid_info_path) { FILE* f = fopen(j.hybrid_info_path, "w"); if (f) fclose(f); }
             if (cfg->verbose) fprintf(stderr, "[INFO] %s total processed positions: 0\n", j.ctg_name);
             return false;
         }
@@ -860,6 +856,54 @@ struct Run {
         int rc = extract_candidates_scratch(&s->dv, cfg->extract_min_mq, cfg->extract_min_bq, cfg->snv_min_af, indel ? cfg->indel_min_af : 1.0,
                                             cfg->min_coverage, cfg->alt_base_num, indel ? 1 : 0, static_cast<uint32_t*>(s->xscratch.p),
                                             static_cast<uint8_t*>(s->xflags.p), static_cast<int32_t*>(s->xdepth.p), stream);
+        // the other modes of extract_candidates_calling, each on the flags in HBM and in the reference's order: rows outside the confident
+        // BED do not exist (`samtools mpileup -l`, :302); indel candidates only inside --call_indels_only_in_these_regions (:437-446; the
+        // user's own --bed_fn supersedes it, :438); positions of the hybrid / genotyping VCF are marked (:347-349, 370-383)
+        const std::vector<int64_t>* indel_iv = nullptr;
+        if (indel && !cfg->indel_bed_superseded) {
+            const auto it = indel_regions.find(j.ctg_name);
+            if (it != indel_regions.end()) indel_iv = &it->second;
+        }
+        const int64_t n_conf = j.restrict_to_confident ? std::max<int64_t>(j.n_confident_intervals, 0) : 0;
+        const int64_t n_indel_iv = indel_iv ? int64_t(indel_iv->size() / 2) : 0;
+        int64_t k_lo = 0, k_hi = 0;                    // the known positions inside the rows that take part
+        if (j.known_pos && j.n_known_pos > 0) {
+            k_lo = std::lower_bound(j.known_pos, j.known_pos + j.n_known_pos, int32_t(std::min<int64_t>(cand_lo, INT32_MAX))) - j.known_pos;
+            k_hi = std::upper_bound(j.known_pos, j.known_pos + j.n_known_pos, int32_t(std::min<int64_t>(cand_hi, INT32_MAX))) - j.known_pos;
+        }
+        const int64_t n_known = k_hi - k_lo;
+        const bool want_info = j.hybrid_info_path != nullptr;
+        const size_t nk_pack = size_t(std::max<int64_t>(s->hv.n_keys, 1));
+        // layout of xmode (int32 words): confident pairs | indel pairs | known positions | records [n_known][16] | gcnt [n_keys] | gfirst [n_keys]
+        const size_t w_conf = 0, w_indel = w_conf + size_t(2 * n_conf), w_known = w_indel + size_t(2 * n_indel_iv), w_rec = w_known + size_t(n_known),
+                     w_gcnt = w_rec + (want_info ? size_t(n_known) * 16 : 0), w_gfirst = w_gcnt + (want_info && indel ? nk_pack : 0),
+                     w_end = w_gfirst + (want_info && indel ? nk_pack : 0);
+        int32_t* xm = nullptr;
+        int32_t* xh = nullptr;
+        if (rc == CTO_OK && (j.restrict_to_confident || n_indel_iv > 0 || n_known > 0)) {
+            if (s->xmode.ensure(w_end * 4 + 256) != CTO_OK || s->xmode_host.ensure(w_end * 4 + 256) != CTO_OK) { fail(cto_last_error()); return false; }
+            xm = static_cast<int32_t*>(s->xmode.p);
+            xh = static_cast<int32_t*>(s->xmode_host.p);
+            if (n_conf > 0) memcpy(xh + w_conf, j.confident_intervals, size_t(2 * n_conf) * 4);
+            for (int64_t i = 0; i < 2 * n_indel_iv; ++i) xh[w_indel + size_t(i)] = int32_t(std::min<int64_t>((*indel_iv)[size_t(i)], INT32_MAX));
+            if (n_known > 0) memcpy(xh + w_known, j.known_pos + k_lo, size_t(n_known) * 4);
+            if (w_rec > 0 && hipMemcpyAsync(xm, xh, w_rec * 4, hipMemcpyHostToDevice, stream) != hipSuccess) { fail("hipMemcpyAsync failed"); return false; }
+            if (j.restrict_to_confident)
+                rc = cto_extract_restrict(&s->dv, static_cast<uint8_t*>(s->xflags.p), static_cast<int32_t*>(s->xdepth.p), xm + w_conf, int(n_conf), 0xff, stream);
+            if (rc == CTO_OK && n_indel_iv > 0)
+                rc = cto_extract_restrict(&s->dv, static_cast<uint8_t*>(s->xflags.p), nullptr, xm + w_indel, int(n_indel_iv), 2 | 16, stream);
+            if (rc == CTO_OK && n_known > 0)
+                rc = cto_extract_mark(&s->dv, static_cast<uint8_t*>(s->xflags.p), xm + w_known, int(n_known), 64, stream);
+            if (rc == CTO_OK && want_info && n_known > 0) {
+                if (indel && hipMemsetAsync(xm + w_gcnt, 0, 2 * nk_pack * 4, stream) != hipSuccess) { fail("hipMemsetAsync failed"); return false; }
+                rc = cto_hybrid_info(&s->dv, static_cast<const uint8_t*>(s->xflags.p), xm + w_known, int(n_known), cfg->extract_min_mq, cfg->extract_min_bq,
+                                     indel ? 1 : 0, xm + w_rec, indel ? reinterpret_cast<uint32_t*>(xm + w_gcnt) : nullptr, indel ? xm + w_gfirst : nullptr, stream);
+                if (rc == CTO_OK && hipMemcpyAsync(xh + w_rec, xm + w_rec, (w_end - w_rec) * 4, hipMemcpyDeviceToHost, stream) != hipSuccess) {
+                    fail("hipMemcpyAsync failed");
+                    return false;
+                }
+            }
+        }
         if (rc == CTO_OK)
             rc = cto_candidate_positions(&s->dv, static_cast<const uint8_t*>(s->xflags.p), indel ? 2 : 1, int32_t(std::min<int64_t>(cand_lo, INT32_MAX)),
                                          int32_t(std::min<int64_t>(cand_hi, INT32_MAX)), static_cast<int32_t*>(s->cand.p), nc,
@@ -873,24 +917,23 @@ struct Run {
         if (n > 0) {
             if (hipMemcpyAsync(h, s->cand.p, size_t(n) * 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipEventRecord(s->uploaded, stream) != hipSuccess ||
                 wait_event(s->uploaded) != hipSuccess) { fail("candidate extraction failed on the device"); return false; }
-            if (indel) {                       // --call_indels_only_in_these_regions: the list shrinks on the host and goes back up
-                const auto it = indel_regions.find(j.ctg_name);
-                if (it != indel_regions.end()) {
-                    int64_t m = 0;
-                    for (int64_t i = 0; i < n; ++i)
-                        if (in_regions(it->second, h[i])) h[m++] = h[i];
-                    if (m != n) {
-                        candidates -= n - m;
-                        n = m;
-                        if (n > 0 && (hipMemcpyAsync(s->cand.p, h, size_t(n) * 4, hipMemcpyHostToDevice, stream) != hipSuccess ||
-                                      hipEventRecord(s->uploaded, stream) != hipSuccess || wait_event(s->uploaded) != hipSuccess)) {
-                            fail("candidate extraction failed on the device");
-                            return false;
-                        }
-                    }
-                }
-            }
             s->sites.assign(h, h + n);
+        }
+        if (want_info) {                         // `<ctg>.<chunk>_hybrid_info` (:352-354, 490-497): counts from the device, strings here
+            FILE* f = fopen(j.hybrid_info_path, "w");
+            if (!f) { fail(std::string("cannot write ") + j.hybrid_info_path); return false; }
+            if (n_known > 0) {
+                const uint32_t* gc = indel ? reinterpret_cast<const uint32_t*>(xh + w_gcnt) : nullptr;
+                const int32_t* gf = indel ? xh + w_gfirst : nullptr;
+                const int64_t need = cto_hybrid_info_rows(s->pack, j.ctg_name, n_known, xh + w_known, xh + w_rec, indel ? 1 : 0, gc, gf, nullptr, 0);
+                if (need < 0) { fclose(f); fail(cto_last_error()); return false; }
+                std::vector<char> text(size_t(need) + 1);
+                if (need > 0 && cto_hybrid_info_rows(s->pack, j.ctg_name, n_known, xh + w_known, xh + w_rec, indel ? 1 : 0, gc, gf, text.data(), size_t(need)) != need) {
+                    fclose(f); fail(cto_last_error()); return false;
+                }
+                if (need > 0) fwrite(text.data(), 1, size_t(need), f);
+            }
+            if (fclose(f) != 0) { fail(std::string("short write to ") + j.hybrid_info_path); return false; }
         }
         s->d_site_pos = static_cast<const int32_t*>(s->cand.p);
         if (j.candidates_path) {                 // the reference's BED chunk rows (extract_candidates_calling.py:450-488), one file per region

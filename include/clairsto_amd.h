@@ -450,6 +450,19 @@ typedef struct cto_chunk_job {
     int64_t region_start, region_end;
     const char* candidates_path; /* REGION job, optional: the candidates as the rows of the reference's `<ctg>.<chunk>_<i>_<n>_snv|_indel`
                                     BED chunk files (`ctg \t max(x-17,1) \t x+17`, :450-488), one file for the whole region          */
+    /* REGION job, the other modes of extract_candidates_calling - each an interval test or a marker on the flags in HBM (cto_extract_restrict /
+     * cto_extract_mark / cto_hybrid_info), between the gates and the compaction of the candidate list: */
+    const int32_t* confident_intervals; /* --bed_fn (:249-260, 302: `samtools mpileup -l`): host int32 [2 n], sorted, merged, 0-based half-open
+                                    [begin, end) rows of the job's contig; a position p exists when begin < p <= end.  Read when
+                                    restrict_to_confident != 0 (n = 0 then means: no row of the region exists, no candidate)          */
+    int64_t n_confident_intervals;
+    int restrict_to_confident;
+    const int32_t* known_pos;     /* --hybrid_mode_vcf_fn / --genotyping_mode_vcf_fn (:225-238, 347-349, 370-383): host int32 [n], sorted
+                                    positions of the VCF's records of this contig; one that has a row and shows an alternative base
+                                    (K = 4) / an indel (K = 6) is a candidate whether or not it passes the AF gates                    */
+    int64_t n_known_pos;
+    const char* hybrid_info_path; /* optional: the rows of `<ctg>.<chunk>_hybrid_info` (:352-354, 490-497) of the known positions inside
+                                    [region_start - 33, region_end + 33], written here (an empty file when there are none)           */
 } cto_chunk_job;
 typedef struct cto_run_cfg {
     cto_model*    aff;          /* CvT / CvT_Indel                                                              */
@@ -502,6 +515,8 @@ typedef struct cto_run_cfg {
     int    device_tokenise;     /* mpileup-text input (mpileup_path, or the samtools child's output): 1 = the text goes up as it is and the
                                    pack is built in HBM (cto_tokenise_device); a text that path declines is tokenised on the host
                                    (cto_pack_from_mpileup).  Same packs.                                                         */
+    int    indel_bed_superseded; /* the user gave --bed_fn (run_clairs_to's --bed_fn_source): indel_regions_bed filters nothing then
+                                   (extract_candidates_calling.py:438)                                                            */
 } cto_run_cfg;
 typedef struct cto_run_stats {
     int64_t candidates;                                /* candidate positions read from the BED chunks / extracted from the regions */
