@@ -221,6 +221,94 @@ def cpu_baseline(chunks, models, lik, edges, min_bq, n_sample, budget_s=12.0):
                        "OpenMP over sites for the networks, %.1f s" % (total_sites, total_t)), first_probs
 
 
+def sustained_distinct_leg(eng, base_chunks, models, lik, edges, min_bq, batch, n_chunks=245, n_oracle=512, stream_too=True):
+    """configs[1]'s 1M-site job with EVERY chunk different (after the timed region, never in `value`): the timed region and `sustained`
+    cycle `--pool` resident chunks; here n_chunks distinct packs (the pool's chunks x SynthChunk.variant: other BQ / MQ of every read-base,
+    other positions - other tensors, other outputs) go through ONE engine, (1) all resident in HBM, one run_device per chunk back to back,
+    (2) from page-locked host arrays through Engine.run_stream (uploads behind compute, results back in pinned buffers), results of (2)
+    compared bit for bit with (1)'s, and the oracle (oracle/cto_oracle.c from the chunks' mpileup text) on a sample of n_oracle sites spread
+    over ALL chunks (two or three per chunk).  Also what tests/test_gpu_distinct.py asserts on."""
+    import numpy as np
+    import torch
+    import oracle
+    from concurrent.futures import ThreadPoolExecutor
+    from clairs_to_amd.pack import pin_arrays
+    oracle.build()
+    dev, nb = eng.device, len(base_chunks)
+    cores = usable_cores()
+
+    def make(i):
+        return base_chunks[i % nb].variant(i // nb, shift=(i // nb) * 40000000)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=max(1, min(8, cores))) as ex:
+        var = list(ex.map(make, range(n_chunks)))
+    assert len({int(v.site_pos[0]) for v in var}) == n_chunks
+    packs = [eng.upload(v.arrays()) for v in var]
+    sites = [torch.from_numpy(v.site_pos).to(dev) for v in var]
+    prep_s = time.perf_counter() - t0
+    keys = ("probs", "decision", "qual")
+    for i in range(8):                                       # workspaces and the allocator's pools for these shapes
+        eng.run_device(packs[i], sites[i])
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    res = []
+    for p, sp in zip(packs, sites):
+        o = eng.run_device(p, sp)
+        res.append({k: o[k] for k in keys})
+    torch.cuda.synchronize()
+    dt_res = time.perf_counter() - t1
+    n_sites = sum(int(sp.numel()) for sp in sites)
+    out = {"chunks": n_chunks, "distinct_sites": n_sites, "pack_bytes_resident": int(sum(p.nbytes() for p in packs)),
+           "resident": {"seconds": round(dt_res, 4), "sites_per_s": round(n_sites / dt_res, 1), "ms_per_chunk": round(dt_res / n_chunks * 1e3, 4)},
+           "input_prep_s": round(prep_s, 1),
+           "how_distinct": "%d generated chunks x %d variants each (SynthChunk.variant: every read-base's BQ moved by -6..+6, every fourth MQ lowered by 45, "
+                           "positions shifted by 40 Mb per variant): no two chunks share a tensor" % (nb, -(-n_chunks // nb))}
+    # ---- the oracle on a sample spread over every chunk ----
+    per = max(1, n_oracle // n_chunks)
+    picks = []                                               # (chunk, site index)
+    for i in range(n_chunks):
+        for j in range(per + (1 if i < n_oracle - per * n_chunks else 0)):
+            picks.append((i, (i * 131 + j * 1777 + 7) % int(sites[i].numel())))
+    cfg = dict(emb_dim=(16, 64, 128), heads=(1, 3, 4), depth=(1, 2, 3), n_out=N_OUT)
+    ta, da, tn, dn = [], [], [], []
+    win_of = {}
+    for i, j in picks:
+        v = var[i]
+        if win_of.get("i") != i:                              # picks are grouped by chunk: one reference window at a time
+            win_of = {"i": i, "w": v.ref_window()}
+        ref, lo = win_of["w"]
+        x = int(v.site_pos[j])
+        c0 = int(np.searchsorted(v.col_pos, x - 16, side="left"))
+        c1 = int(np.searchsorted(v.col_pos, x + 17, side="right"))
+        for q, (tt, dd) in ((min_bq, (ta, da)), (0, (tn, dn))):
+            t_, d_ = oracle.create_tensor(oracle.synth_mpileup_text(v, q, (c0, c1)), ref, lo, v.site_pos[j:j + 1])[:2]
+            tt.append(t_)
+            dd.append(d_)
+    xa, xn = oracle.rescale(np.concatenate(ta), np.concatenate(da)), oracle.rescale(np.concatenate(tn), np.concatenate(dn))
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    la = oracle.cvt_forward(models["aff_weights"], cfg, xa)
+    ln = oracle.bigru_forward(models["neg_weights"], N_OUT, xn)
+    probs_o, _, dec_o, qual_o = oracle.posterior(la, ln, lik, edges)
+    got_p = np.stack([res[i]["probs"][j].cpu().numpy() for i, j in picks])
+    got_d = np.stack([res[i]["decision"][j].cpu().numpy() for i, j in picks])
+    out["oracle"] = {"sites": len(picks), "chunks_sampled": len({i for i, _ in picks}), "max_abs_dP": float(np.abs(got_p - probs_o).max()),
+                     "decisions_equal_frac": float((got_d == np.asarray(dec_o).reshape(got_d.shape)).all(axis=1).mean())}
+    # ---- the same chunks from the host through Engine.run_stream ----
+    if stream_too:
+        with ThreadPoolExecutor(max_workers=max(1, min(8, cores))) as ex:
+            pinned = list(ex.map(lambda v: pin_arrays(v.arrays()), var))
+        host_sites = [v.site_pos for v in var]
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        got = list(eng.run_stream(zip(pinned, host_sites), depth=2))
+        dt_st = time.perf_counter() - t2
+        same = all(np.array_equal(g[k], r[k].cpu().numpy()) for g, r in zip(got, res) for k in keys)
+        out["run_stream"] = {"seconds": round(dt_st, 4), "sites_per_s": round(n_sites / dt_st, 1), "ms_per_chunk": round(dt_st / n_chunks * 1e3, 4),
+                             "bit_equal_to_resident_pass": bool(same),
+                             "includes": "PCIe both ways (28.6 MB of pack up, 140 B per site down per chunk), uploads on a copy stream behind the previous chunk's kernels"}
+    return out
+
+
 def split_mfma_leg(dev, packs, sites, batch, lik, edges, min_bq, ref_probs, ref_dec, probs_cpu, steps=20, warm=40):
     """EXPERIMENT, never in `value` (whose arithmetic stays f32): the step with both BiGRU recurrences + fc1 and the CvT's block
     GEMMs (64- and 128-channel stages) on split 16-bit operands (csrc/split_mfma.h, gru_split_kernel.h, cvt_gemm.h;
@@ -497,7 +585,89 @@ def hapfilter_leg(repeats=8):
                          "mpileup_bytes": len(m["mpileup"])}
     res["cores"] = usable_cores()
     res["note"] = "pileup VCF + germline VCF + nine-column mpileup text in, tagged VCF out (best of %d passes); the reference starts one `samtools mpileup` per call" % repeats
+    try:
+        res["many_calls"] = hapfilter_many_calls()
+    except Exception as e:                                    # a leg after the timed region must not cost the line
+        res["many_calls"] = {"error": repr(e)[:300]}
     return res
+
+
+def _hapsim_job(job):
+    """worker of hapfilter_many_calls (spawned process: input synthesis only): one simulated contig's inputs written under d"""
+    seed, ctg, d, modes = job
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import gen_hapfilter_wide as gw
+    import hapsim
+    sim = hapsim.simulate(seed=seed)
+    os.makedirs(d, exist_ok=True)
+    ref = sim["ref"]
+    open(os.path.join(d, "ref.fa"), "w").write(">%s\n%s\n" % (ctg, ref))
+    open(os.path.join(d, "ref.fa.fai"), "w").write("%s\t%d\t%d\t%d\t%d\n" % (ctg, len(ref), len(ctg) + 2, len(ref), len(ref) + 1))
+    open(os.path.join(d, "germline.vcf"), "w").write(gw.germline_vcf(sim, ctg))
+    n = {}
+    for mode in modes:
+        v, t = gw.inputs_for(sim, ctg, mode)
+        open(os.path.join(d, "pileup_%s.vcf" % mode), "w").write(v)
+        open(os.path.join(d, "mp_%s.txt" % mode), "w").write(t)
+        n[mode] = (sum(1 for r in v.split("\n") if r and r[0] != "#" and "\tPASS\t" in r), len(t))
+    return ctg, d, n
+
+
+def hapfilter_many_calls(n_contigs=216, indel_every=4):
+    """a throughput figure for the long-read filter: n_contigs simulated contigs (tests/golden/hapsim.py, one seed each: the generator of the
+    reference-made fixtures), >= 5 000 PASS calls in the SNV pass, every contig one haplotype_filter job as a real run has one per contig,
+    all usable cores inside each job; beside it the reference's own cost per call (profiles/reference_hapfilter_timing.json, build container)."""
+    import contextlib
+    import io
+    import multiprocessing as mp
+    import shutil
+    import tempfile
+    from argparse import Namespace
+    from concurrent.futures import ProcessPoolExecutor
+    from clairs_to_amd.haplotype_filtering import haplotype_filter
+    cores = usable_cores()
+    tmp = tempfile.mkdtemp(prefix="cto_hapfilter_")
+    try:
+        t0 = time.perf_counter()
+        jobs = [(5000 + k, "ctg%d" % (k + 1), os.path.join(tmp, "c%d" % k), ("snv", "indel") if k % indel_every == 0 else ("snv",)) for k in range(n_contigs)]
+        with ProcessPoolExecutor(max_workers=max(1, cores), mp_context=mp.get_context("spawn")) as ex:
+            made = list(ex.map(_hapsim_job, jobs, chunksize=2))
+        prep_s = time.perf_counter() - t0
+        out = {}
+        for mode in ("snv", "indel"):
+            sel = made if mode == "snv" else made[::indel_every]
+            calls = sum(n[mode][0] for _, _, n in sel)
+            text_bytes = sum(n[mode][1] for _, _, n in sel)
+            best = None
+            for _ in range(2):
+                t1 = time.perf_counter()
+                evaluated = 0
+                for ctg, d, n in sel:
+                    a = Namespace(tumor_bam_fn="unused.bam", ref_fn=os.path.join(d, "ref.fa"), ctg_name=ctg, pileup_vcf_fn=os.path.join(d, "pileup_%s.vcf" % mode),
+                                  output_vcf_fn=os.path.join(d, "out_%s.vcf" % mode), germline_vcf_fn=os.path.join(d, "germline.vcf"),
+                                  output_dir=os.path.join(d, "work_" + mode), threads=cores, input_filter_tag=None, show_ref=False, samtools="samtools",
+                                  mpileup_fn=os.path.join(d, "mp_%s.txt" % mode), apply_haplotype_filtering=True, min_mq=20, min_bq=0, min_alt_coverage=2,
+                                  is_indel=(mode == "indel"), test_pos=None, flanking=100, haplotype_chunk_max_sites=200, haplotype_chunk_max_span=5000000,
+                                  disable_read_start_end_filtering=False)
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        evaluated += len(haplotype_filter(a))
+                dt = time.perf_counter() - t1
+                best = dt if best is None or dt < best else best
+            out[mode] = {"contig_jobs": len(sel), "pass_calls": calls, "calls_evaluated": evaluated, "seconds": round(best, 4), "calls_per_s": round(evaluated / best, 1),
+                         "mpileup_text_mb": round(text_bytes / 1e6, 1), "text_mb_per_s": round(text_bytes / 1e6 / best, 1)}
+        out["cores"] = cores
+        out["input_synthesis_s"] = round(prep_s, 1)
+        try:
+            rp = json.load(open(os.path.join(ROOT, "profiles", "reference_hapfilter_timing.json")))
+            r1 = rp["runs"]["chunk_mode_threads_1"]
+            out["reference_python"] = {"calls_per_s_chunk_mode": {m: r1[m]["calls_per_s"] for m in r1}, "calls_per_s_per_call_mode": {m: v["calls_per_s"] for m, v in rp["runs"]["percall_mode_threads_1"].items()},
+                                       "host": "build container, %d vCPU (NOT this box)" % rp["host_cpus"], "what": rp["what"], "source": "profiles/reference_hapfilter_timing.json (tools/time_reference_hapfilter.py)"}
+        except Exception:
+            pass
+        out["note"] = "one haplotype_filter job per contig, one after the other, all cores inside a job (best of 2 passes over all contigs); host code by nature - no device form; mpileup text pre-made on both sides (BAM decoding excluded)"
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def self_launch(n):
@@ -688,10 +858,13 @@ def main():
     # ---- after the timed region, never in `value`: (1) the whole job configs[1] names, 245 steps = 1 003 520 sites, timed in 20-step
     # windows by events on the launch stream (no host sync inside); (2) every stage's kernel time from live HIP events ----
     sustained, stage_fracs = None, None
-    if world == 1 and not args.no_sustained:
+    if not args.no_sustained:
+        # every rank runs the whole job on its shard (weak scaling: 245 steps each), the exchange step included when there are several;
+        # bracketed like the timed region (barrier + synchronize on both sides, MAX over ranks)
+        stage["name"] = "sustained run"
         n_sus, win = 245, 20
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_sus // win + 2)]
-        torch.cuda.synchronize()
+        sync()
         t1 = time.perf_counter()
         marks[0].record()
         k = 1
@@ -701,13 +874,20 @@ def main():
                 marks[k].record()
                 k += 1
         marks[k].record()
-        torch.cuda.synchronize()
+        sync()
         dt_sus = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt_sus], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_sus = float(t.item())
         wins = [marks[j].elapsed_time(marks[j + 1]) / win for j in range(n_sus // win)]
-        sustained = {"steps": n_sus, "sites": n_sus * args.batch, "seconds": round(dt_sus, 4), "ms_per_step": round(dt_sus / n_sus * 1e3, 4),
-                     "sites_per_s": round(n_sus * args.batch / dt_sus, 1), "window_steps": win,
+        sustained = {"steps": n_sus, "sites": world * n_sus * args.batch, "seconds": round(dt_sus, 4), "ms_per_step": round(dt_sus / n_sus * 1e3, 4),
+                     "sites_per_s": round(world * n_sus * args.batch / dt_sus, 1), "window_steps": win,
                      "ms_per_step_min_window": round(min(wins), 4), "ms_per_step_max_window": round(max(wins), 4),
-                     "note": "configs[1]'s whole job (1M sites in %d-site steps) back to back on the resident packs; windows timed by events on the launch stream" % args.batch}
+                     "note": ("configs[1]'s whole job (1M sites in %d-site steps) back to back on the resident packs" % args.batch) +
+                             (" of every rank, the all_gather of each step included; seconds = MAX over ranks, windows = rank 0's" if world > 1 else "") +
+                             "; windows timed by events on the launch stream"}
+    if world == 1 and not args.no_sustained:
         l1_ms, l1_macs = C.c_double(0.0), C.c_int64(0)
         check(lib.cto_model_profile(eng.h_aff, 1))
         check(lib.cto_model_profile(eng.h_neg, 2))            # layer 1 bracketed too
@@ -827,6 +1007,7 @@ def main():
         }
         if sustained is not None:
             res["sustained"] = sustained
+        if stage_fracs is not None:
             stage_fracs["tensor_creation"] = {"ms": round(feat_ms, 4), "gb_per_s": round(feat_bytes / (feat_ms * 1e-3) / 1e9, 1),
                                               "frac_of_hbm_peak": round(feat_bytes / (feat_ms * 1e-3) / 1e9 / 8000.0, 4)}
             res["stage_fracs"] = stage_fracs
@@ -836,6 +1017,8 @@ def main():
             res["cpu_baseline"] = cb
             got = eng.run_device(packs[0], sites[0])["probs"][: probs_cpu.shape[0]].cpu().numpy()
             res["parity_max_abs_dP_vs_cpu_sample"] = float(np.abs(got - probs_cpu).max())
+        if world == 1 and not args.no_sustained and not args.no_cpu_baseline:
+            res["sustained_distinct"] = sustained_distinct_leg(eng, chunks, models, lik, edges, min_bq, args.batch)
         if world == 1 and not args.no_split:
             ref = eng.run_device(packs[0], sites[0])
             res["split_mfma"] = split_mfma_leg(dev, packs[:4], sites[:4], args.batch, lik, edges, min_bq, ref["probs"].cpu().numpy(),

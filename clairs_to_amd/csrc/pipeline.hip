@@ -1221,7 +1221,7 @@ static int run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs, int64_t
     CTO_REQUIRE(cfg->K == 4 || cfg->K == 6, CTO_EINVAL, "cto_run_chunks: K must be 4 or 6");
     for (int64_t i = 0; i < n_jobs; ++i)
         CTO_REQUIRE(jobs[i].ctg_name && jobs[i].vcf_path && (jobs[i].mpileup_path || jobs[i].bam_path) &&
-                        (jobs[i].bed_path || (jobs[i].region_start >= 1 && jobs[i].region_end >= jobs[i].region_start)),
+                        (jobs[i].bed_path || (jobs[i].region_start >= 0 && jobs[i].region_end >= std::max<int64_t>(jobs[i].region_start, 1))),   // a first chunk of --chunk_id starts at 0 (:262)
                     CTO_EINVAL, "cto_run_chunks: job %lld is incomplete", (long long)i);
     if (stats) memset(stats, 0, sizeof(*stats));
     if (n_jobs == 0) return CTO_OK;

@@ -106,8 +106,46 @@ def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4, bam_
                 includes="disk reads, tokenise / BAM decode, PCIe both ways, kernels, alt_info + VCF rows (C), file writes")
 
 
+class confined(object):
+    """the calling thread - and every thread it starts from here on: the producers and writers of cto_run_chunks - on the first `n` of the
+    cores it may use now (sched_setaffinity); usable_cores() then plans with n, as a rank of a node with that share of the cores would"""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        self.old = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, set(sorted(self.old)[:max(1, self.n)]))
+        return self
+
+    def __exit__(self, *exc):
+        os.sched_setaffinity(0, self.old)
+
+
+def rank_share_legs(eng, run, kind, d, writers, pipeline, times, share):
+    """What ONE rank of a node with `share` GPUs gets from this host: the same files with the process confined to usable_cores / share
+    cores (an 8-GPU node leaves a rank an eighth of the cores; bench.py has one GPU, so this is the per-rank budget of the file -> VCF path,
+    not a scaling curve).  Text: the host tokeniser and the device tokeniser (call_chunks' choice at <= 12 cores); BAM: the device inflate +
+    pile-up path with that many cores behind it."""
+    from .call_chunks import default_producers, usable_cores
+    n = max(1, usable_cores() // max(1, share))
+    out = {"cores": n, "of_usable": usable_cores(), "share": "1/%d" % share}
+    pick = lambda h: {k: h[k] for k in ("sites_per_s", "seconds", "producers", "stage_thread_time", "host_process") if k in h} | \
+        {k: h[k] for k in ("device_inflated", "device_piled", "device_tokenised") if k in h}
+    with confined(n):
+        if kind == "text":
+            out["host_tokeniser"] = pick(time_run(eng, run, kind, os.path.join(d, "vcf_rank_host"), max(1, n), writers, 2, pipeline=pipeline, times=times,
+                                                  device_tokenise=False))
+            out["device_tokeniser"] = pick(time_run(eng, run, kind, os.path.join(d, "vcf_rank_dev"), max(2, n), writers, 2, pipeline=pipeline, times=times,
+                                                    device_tokenise=True))
+        else:
+            out["device_inflate_pileup"] = pick(time_run(eng, run, kind, os.path.join(d, "vcf_rank_bam"), default_producers(True, pipeline), writers, 2,
+                                                         pipeline=pipeline, times=times))
+    return out
+
+
 def measure(eng, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, region_kb=None, producers=None, writers=2, workdir=None,
-            repeats=4, pipeline="python", with_extraction=False, host_tokeniser_too=False):
+            repeats=4, pipeline="python", with_extraction=False, host_tokeniser_too=False, rank_share=0):
     """build_run + time_run in a temporary directory.  with_extraction (kind "bam"): -> (BED-driven leg, REGION-job leg on the same
     BAM: no candidate BEDs, the candidates are extracted from the pile-up inside the run)"""
     d = tempfile.mkdtemp(prefix="cto_e2e_", dir=workdir)
@@ -129,6 +167,8 @@ def measure(eng, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, reg
             h = time_run(eng, run, kind, os.path.join(d, "vcf_output_dev_tok"), 4, writers, repeats, pipeline=pipeline, times=times,
                          device_tokenise=True)
             r["device_tokeniser"] = {k: h[k] for k in ("sites_per_s", "seconds", "producers", "stage_thread_time", "host_process", "device_tokenised")}
+        if rank_share and pipeline == "native" and hasattr(os, "sched_setaffinity"):
+            r["rank_of_%d" % rank_share] = rank_share_legs(eng, run, kind, d, writers, pipeline, times, rank_share)
         if with_extraction and kind == "bam":
             r2 = time_run(eng, run, kind, os.path.join(d, "vcf_output_regions"), producers, writers, repeats, pipeline="native", regions=len(run["chunks"]),
                           times=times)
@@ -160,6 +200,7 @@ def main():
                     help="also run the text leg on chunk files of this many candidates (the reference cuts 10 000: shared/param.py:21)")
     ap.add_argument("--producers", type=int, default=None)
     ap.add_argument("--writers", type=int, default=2)
+    ap.add_argument("--rank-share", type=int, default=8, help="also run each kind confined to usable_cores / N cores: one rank's share of an N-GPU node (0: skip)")
     ap.add_argument("--pipeline", default="native", choices=["native", "python"],
                     help="cto_run_chunks (csrc/pipeline.hip) or call_chunks.run_pipeline; same files either way")
     a = ap.parse_args()
@@ -171,7 +212,7 @@ def main():
     for kind in a.kinds.split(","):
         n = a.chunks if kind == "text" else (a.bam_chunks or max(2, a.chunks // 3))
         r = measure(eng, kind=kind, n_chunks=n, sites_per_chunk=a.batch, producers=a.producers, writers=a.writers, pipeline=a.pipeline,
-                    with_extraction=(kind == "bam" and a.pipeline == "native"), host_tokeniser_too=True)
+                    with_extraction=(kind == "bam" and a.pipeline == "native"), host_tokeniser_too=True, rank_share=a.rank_share)
         if isinstance(r, tuple):
             out["bam_to_vcf"], out["bam_to_vcf_with_extraction"] = r
         else:

@@ -142,6 +142,28 @@ class SynthChunk:
         return dict(col_pos=self.col_pos, col_ref=self.col_ref, col_off=self.col_off, key_off=self.key_off,
                     entries=self.entries, key_meta=self.key_meta, key_group=self.key_group)
 
+    def variant(self, k, shift=0):
+        """A DIFFERENT chunk of the same shape for a fraction of the generator's cost (5 s of a core per 4096-site chunk): every read-base's
+        BQ moves by a per-read-base amount in -6 .. +6 (clipped to the generator's 1 .. 50: the AFF pass's --min-BQ gate and the low-BQ
+        channels see other reads), every fourth one's MQ drops by 45 (the low-MQ channels, candidate extraction's --min-MQ gate), both from
+        a hash of (read-base index, k), and all positions move by `shift`.  k = 0 with shift = 0 is NOT the chunk itself (its BQs move too).
+        The text writers and arrays() read the same fields, so a variant is as self-consistent as a generated chunk."""
+        import copy
+        v = copy.copy(self)
+        idx = np.arange(self.entries.size, dtype=np.uint64)
+        h = (idx * np.uint64(2654435761 + 2 * int(k)) + np.uint64(40503 * int(k) + 977)) >> np.uint64(7)
+        e = self.entries.astype(np.uint32)
+        bq = ((e >> np.uint32(6)) & np.uint32(127)).astype(np.int64)
+        mq = ((e >> np.uint32(13)) & np.uint32(255)).astype(np.int64)
+        bq = np.clip(bq + (h % np.uint64(13)).astype(np.int64) - 6, 1, 50)
+        mq = np.where(((h >> np.uint64(5)) & np.uint64(3)) == 3, np.maximum(mq - 45, 0), mq)
+        v.entries = ((e & np.uint32(~((127 << 6) | (255 << 13)) & 0xffffffff)) | (bq.astype(np.uint32) << np.uint32(6)) |
+                     (mq.astype(np.uint32) << np.uint32(13))).astype(self.entries.dtype)
+        if shift:
+            v.site_pos = (self.site_pos.astype(np.int64) + int(shift)).astype(self.site_pos.dtype)
+            v.col_pos = (self.col_pos.astype(np.int64) + int(shift)).astype(self.col_pos.dtype)
+        return v
+
     def ref_window(self):
         """(ref_seq, ref_start): a reference string covering every column +- 100 bp; gaps are 'A'."""
         lo = int(self.col_pos[0]) - 100
