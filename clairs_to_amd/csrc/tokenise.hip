@@ -4,19 +4,18 @@
 // :120-144 walks the base string character by character); csrc/pack.cpp does the same on host threads (one forward pass per row,
 // 1.5 GB/s per thread) and was what a text-fed run waited for: 28 ms of CPU per 22 MB chunk against 1.9 ms of device time.  Here
 // the text goes up as it is and the pack is born in HBM, as it is for BAM input (csrc/pileup.hip):
-//   k_count_lines   one lane per 256-byte segment: rows that start in it                     -> scan -> row index of every segment
-//   k_rows<COUNT>   one lane per segment, for each of its rows: the single forward pass of pack.cpp's fast_row (contig, position,
-//                   reference base, depth, base string with ^x / $ / +n.. / -n.. , as many quality and mapping-quality characters
-//                   as read-bases, '\n') - counts read-bases and DISTINCT indel keys (first-seen order, compared on the characters)
-//                   -> scans -> col_off, key_off
-//   k_rows<FILL>    one lane per row: the same pass again, now writing entries (code | kind << 4 | BQ << 6 | MQ << 13 | key id << 21),
-//                   col_pos, col_ref, and per distinct key its meta byte, its merged candidate-extraction group and its alt_info
-//                   string length                                                           -> scan -> key_str_off
-//   k_key_strings   one lane per key: "I<ANCHOR><SEQ>" upper-cased / "D<reference slice>"
+//   k_count_lines   a thread per 16-byte piece: rows that start in each 256-byte segment         -> one scan launch -> k_row_starts
+//   k_rows_walk     one lane per row, ONE forward pass (pack.cpp's fast_row: contig, position, reference base, depth, base string with
+//                   ^x / $ / +n.. / -n..): the read-bases' codes (a byte each, in the text's own layout), the indel tokens as a chain of
+//                   records in HBM, DISTINCT indel keys per row (first-seen order, compared on the characters), counts
+//                   -> one scan launch (k_apply3: col_off, key_off, key-string offsets)
+//   k_expand        a thread per read-base: entries (code | kind << 4 | BQ << 6 | MQ << 13 | key id << 21) from three coalesced byte runs,
+//                   col_pos, col_ref; checks the quality strings and their separators
+//   k_row_keys      one lane per row with keys: meta byte, merged candidate-extraction group, "I<ANCHOR><SEQ>" / "D<reference slice>"
 // A row is a chain of dependent byte reads, so a lane is slow - but there are 140 000 rows in a 4096-site chunk, and a wavefront's
 // 64 rows are ~10 KB of consecutive text that stay in the vector L1 while its lanes walk them.
 // Anything the single pass does not take - another field count, a short quality string, '\r', a byte outside the printable range,
-// an indel or '^' running into the field's end, more than 32 indel-carrying read-bases in a row, an empty row, text that does not
+// an indel or '^' running into the field's end, more than 256 indel-carrying read-bases in a row, an empty row, text that does not
 // end in '\n', rows out of position order, a position outside the reference slice - sets a flag, the call returns *fallback = 1 and
 // the caller runs cto_pack_from_mpileup, which defines the behaviour (and words the errors).  Held bit-equal to it, array for array and
 // key string for key string, by tests/test_gpu_tokenise.py.
@@ -35,7 +34,7 @@ using namespace cto;
 namespace {
 
 constexpr int SEG = 256;            // bytes of text per lane in the row-start search
-constexpr int MAX_IND = 32;         // indel-carrying read-bases of one row this path interns in a lane's private memory
+constexpr int MAX_IND = 256;        // indel-carrying read-bases of one row this path takes (interning compares every pair)
 
 struct TokFlags {
     int slow;                       // a row (1 + its byte offset, clamped) the single pass declined
@@ -102,8 +101,25 @@ __global__ __launch_bounds__(256) void k_tile_apply(const int* __restrict__ in, 
     __shared__ T part[256];
     __shared__ T s_base;
     if (SUMS) {
+        // tile_base == nullptr: no tile sums at all - the workgroup adds up the ELEMENTS in front of its tile (a chunk's 86 000 segment counts:
+        // the last of 21 workgroups reads 340 KB out of the L2; tile sums by atomics from the counting kernel cost it 0.8 ms - 5 400 atomics
+        // on 21 addresses)
         T b = 0;
-        for (int i = threadIdx.x; i < int(blockIdx.x); i += 256) b += tile_base[i];
+        if (tile_base == nullptr) {
+            // 16-byte loads, eight in flight per thread (one element per trip waited out an L2 round trip per element: 45 us)
+            const int4* in4 = reinterpret_cast<const int4*>(in);
+            const int n4 = int(blockIdx.x) * (SCAN_TILE / 4);
+            int i = threadIdx.x;
+            for (; i + 7 * 256 < n4; i += 8 * 256) {
+                int4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = in4[i + k * 256];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) b += T(v[k].x) + T(v[k].y) + T(v[k].z) + T(v[k].w);
+            }
+            for (; i < n4; i += 256) { const int4 v = in4[i]; b += T(v.x) + T(v.y) + T(v.z) + T(v.w); }
+        }
+        else for (int i = threadIdx.x; i < int(blockIdx.x); i += 256) b += tile_base[i];
         part[threadIdx.x] = b;
         __syncthreads();
         for (int d = 128; d > 0; d >>= 1) { if (int(threadIdx.x) < d) part[threadIdx.x] += part[threadIdx.x + d]; __syncthreads(); }
@@ -170,27 +186,46 @@ __device__ __forceinline__ int ref_code_dev(unsigned char c) {
     switch (up_c(c)) { case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 0; }
 }
 
+// An indel-carrying read-base of a row, in HBM: the records of a row form a chain in the order of the row's read-bases.  A record's slot is
+// its sign's byte offset in the text / 4 - two tokens lie at least four bytes apart ("+1A" and the next read-base), so slots never collide,
+// no allocation and no counter is needed, and a row may carry any number of them (the lane keeps the first / last slot in registers; the
+// private arrays of the first form of this file - 784-928 bytes of scratch per lane - are gone).
+struct TokRec {
+    int len;        // bases inserted / deleted
+    int info;       // read-base index << 2 | kind (1 insertion, 2 deletion) - 17 bits; code << 17 (4); sign offset & 3 << 21; digits << 23 (4)
+    int next;       // slot of the row's next record, -1 at the end
+    int kg;         // key id within the row (first seen first) | merged candidate-extraction group << 16 (k_row_keys)
+};
+__device__ __forceinline__ int tok_idx(int info) { return (info >> 2) & 0x7fff; }
+__device__ __forceinline__ int tok_kind(int info) { return info & 3; }
+__device__ __forceinline__ int tok_code(int info) { return (info >> 17) & 15; }
+__device__ __forceinline__ long long tok_seq(int slot, int info) { return ((long long)slot << 2) + ((info >> 21) & 3) + 1 + ((info >> 23) & 15); }
+
 struct RowArgs {
     const unsigned char* text; long long len;
     const unsigned char* ref; long long ref_start, ref_len;
     int max_indel_length;
     int n_rows;
     const long long* row_start;
-    // COUNT writes, FILL reads
-    int* row_nt; int* row_nk; int* row_pos; int* row_b0; int* row_blen;
-    // FILL
-    const long long* col_off; const int* key_off;
+    // the walk (k_rows_walk) writes, the later kernels read
+    int* row_nt; int* row_nk; int* row_pos; int* row_b0; int* row_blen; int* row_tok; int* row_str;
+    unsigned char* codes;            // the read-base codes of a row at [row start + b0 + i]: the walk's product, the text's own layout
+    TokRec* tok;
+    long long* tile_nt; int* tile_nk; long long* tile_str;      // sums per SCAN_TILE rows (atomics of the walk's wavefronts)
+    // after the scans
+    const long long* col_off; const int* key_off; const long long* row_str_off;
     unsigned* entries; int* col_pos; unsigned char* col_ref;
-    unsigned char* key_meta; int* key_group; int* key_len; long long* key_seq; int* key_info;
+    unsigned char* key_meta; int* key_group; long long* str_off; char* key_str;
     TokFlags* fl;
 };
 
 // A forward reader of the text: the next <= 8 bytes sit in a register and a byte costs a shift, the following aligned 8 bytes are
 // requested one refill ahead.  (A row parsed through one dependent global byte load per character - the first form of this file -
 // is a chain of ~300 L2 round trips: 250 us per launch however many rows are in flight.)  The device copy of the text is padded, so
-// the aligned word that holds the last byte may be read whole.
+// the aligned word that holds the last byte may be read whole.  Used for the spans that do not fit the LDS (deep columns).
 struct ByteStream {
     const unsigned char* t;
+    unsigned char* codes;              // where put() stores: the codes buffer at this row's text offsets
     long long pos, next;               // position of the byte peek() returns; offset of the word behind q2
     unsigned long long bits, q0, q1, q2;   // the word being consumed and the three behind it (24 bytes of look-ahead: an L2 round trip is
     int have;                              // ~700 cycles, eight bytes of parsing ~400)
@@ -212,8 +247,9 @@ struct ByteStream {
         bits >>= 8; ++pos;
         if (--have == 0) { bits = q0; q0 = q1; q1 = q2; q2 = ld8(t, next); next += 8; have = 8; }
     }
-    __device__ __forceinline__ unsigned take() { const unsigned c = peek(); step(); return c; }
     __device__ __forceinline__ void skip(long long n) { if (n < have) { bits >>= 8 * int(n); have -= int(n); pos += n; } else seek(t, pos + n); }
+    __device__ __forceinline__ unsigned at(long long p) const { return t[p]; }
+    __device__ __forceinline__ void put(long long p, int code) { codes[p] = static_cast<unsigned char>(code); }
 };
 
 // The same reader over a wavefront's staged copy of its rows: a byte is one ds_read_u8 at a 32-bit index - no shift register, no
@@ -223,7 +259,9 @@ struct ByteStream {
 // loops and branches (8-13 s_* per trip: s_and_saveexec, s_or / s_andn2 on exec, s_cbranch) - 64 rows that sit at different places of
 // their grammar.  (Most of those scalar instructions turned out to be char_class's `switch`: as a table, 33.8 M -> 9.1 M per launch and
 // 156 -> 82 us.  A branch-free pass - one wave-uniform loop, states moved by selects - was written and measured before that: 209 us.)
-typedef const __attribute__((address_space(3))) unsigned char* lds_bytes;
+// put(): the code of a row's i-th read-base goes IN PLACE over the row's own base string - byte b0 + i lies at or before the byte being
+// read, every read-base costs at least one byte - and the wavefront copies its span out to the codes buffer when its lanes are done.
+typedef __attribute__((address_space(3))) unsigned char* lds_bytes;
 struct LdsStream {
     lds_bytes t;
     int pos;
@@ -234,71 +272,100 @@ struct LdsStream {
     __device__ __forceinline__ unsigned peek() const { return t[pos]; }
     __device__ __forceinline__ unsigned peek1() const { return t[pos + 1]; }
     __device__ __forceinline__ void step() { ++pos; }
-    __device__ __forceinline__ unsigned take() { return t[pos++]; }
     __device__ __forceinline__ void skip(long long n) { pos += int(n); }
+    __device__ __forceinline__ unsigned at(long long p) const { return t[int(p)]; }
+    __device__ __forceinline__ void put(long long p, int code) { t[int(p)] = static_cast<unsigned char>(code); }
 };
 
-// indel-carrying read-bases of the row being parsed (a lane's private memory; rows without indels never touch it)
-struct RowIndels {
-    long long seq[MAX_IND];
-    int len[MAX_IND], at[MAX_IND], code[MAX_IND], kid[MAX_IND];          // at = read-base index << 2 | kind
-    int n = 0, nk = 0;
-    // distinct keys, first seen first: Counter key = read-base code + sign + sequence, case-sensitive (pack.cpp: intern_indel)
-    __device__ void intern(const unsigned char* t) {
-        nk = 0;
-        for (int i = 0; i < n; ++i) {
-            int found = -1;
-            for (int j2 = 0; j2 < i && found < 0; ++j2) {
-                if (len[j2] != len[i] || (at[j2] & 3) != (at[i] & 3) || code[j2] != code[i]) continue;
-                bool eq = true;
-                for (int k = 0; k < len[i] && eq; ++k) eq = t[seq[j2] + k] == t[seq[i] + k];
-                if (eq) found = kid[j2];
-            }
-            kid[i] = found >= 0 ? found : nk++;
-        }
-    }
-};
+// Where a row's bytes are read: the text in HBM (base 0), or a wavefront's staged copy of its rows in LDS (t[0] = text[base]; offsets
+// below are relative to t, `len` = the bytes that belong to rows - what lies behind is look-ahead padding)
+struct TextRef { const unsigned char* t; long long base, len; const unsigned char* cls; };      // cls: the class table in LDS (or null)
 
-// The base string from `st` on: counts read-bases, collects the indel tokens.  Returns false when the single pass declines the row.
+struct RowToks { int n, first, last, before_last, last_idx; };
+
+// The base string from `st` on: counts read-bases, stores their codes, chains the indel tokens.  Returns false when the single pass declines the row.
 template <class Stream>
-__device__ __forceinline__ bool walk_bases(Stream& st, const unsigned char* t, long long len, int& nt, RowIndels& ind, const unsigned char* cls_g = nullptr) {
-    lds_table cls = (lds_table)cls_g;
+__device__ __forceinline__ bool walk_bases(const RowArgs& a, Stream& st, const TextRef& T, int& nt, RowToks& tk) {
+    lds_table cls = (lds_table)T.cls;
     nt = 0;
+    tk.n = 0; tk.first = tk.last = tk.before_last = -1; tk.last_idx = -1;
     int last_code = 0;
+    const long long b0 = st.pos;
     for (;;) {
         const unsigned c = st.peek();
         const int cl = char_class(cls, c);
-        if (cl < 12) { last_code = cl; ++nt; st.step(); }
+        if (cl < 12) { last_code = cl; st.put(b0 + nt, cl); ++nt; st.step(); }
         else if (cl == 14) st.step();
         else if (cl == 13) { if (st.peek1() <= 10u) return false; st.step(); st.step(); }
         else if (cl == 12) {
             const int kind = c == '+' ? 1 : 2;
+            const long long sign_abs = T.base + st.pos;
             st.step();
             long long adv = 0;
-            while (st.peek() - '0' < 10u) { adv = adv * 10 + (st.peek() - '0'); st.step(); if (adv > (1 << 24)) return false; }
-            if (nt == 0 || st.pos + adv > len) return false;
-            for (long long k = 0; k < adv; ++k) if (t[st.pos + k] <= 10) return false;
-            if (ind.n > 0 && (ind.at[ind.n - 1] >> 2) == nt - 1) --ind.n;      // a second annotation of the same read-base replaces the first
-            if (ind.n >= MAX_IND) return false;
-            ind.seq[ind.n] = st.pos; ind.len[ind.n] = int(adv); ind.at[ind.n] = ((nt - 1) << 2) | kind; ind.code[ind.n] = last_code;
-            ++ind.n;
+            int nd = 0;
+            while (st.peek() - '0' < 10u) { adv = adv * 10 + (st.peek() - '0'); st.step(); ++nd; if (adv > (1 << 24) || nd > 15) return false; }
+            if (nt == 0 || nt > kMaxDepth || st.pos + adv > T.len) return false;
+            for (long long k = 0; k < adv; ++k) if (st.at(st.pos + k) <= 10u) return false;
+            const int slot = int(sign_abs >> 2);
+            const bool replace = tk.n > 0 && tk.last_idx == nt - 1;       // a second annotation of the same read-base replaces the first
+            if (!replace && tk.n >= MAX_IND) return false;
+            a.tok[slot] = TokRec{int(adv), ((nt - 1) << 2) | kind | (last_code << 17) | (int(sign_abs & 3) << 21) | (nd << 23), -1, 0};
+            if (replace) {
+                if (tk.n == 1) tk.first = slot; else a.tok[tk.before_last].next = slot;
+            } else {
+                if (tk.n == 0) tk.first = slot; else a.tok[tk.last].next = slot;
+                tk.before_last = tk.last;
+                ++tk.n;
+            }
+            tk.last = slot;
+            tk.last_idx = nt - 1;
             st.skip(adv);
         } else break;
     }
     return true;
 }
 
-// Where a row's bytes are read: the text in HBM (base 0), or a wavefront's staged copy of its rows in LDS (t[0] = text[base]; offsets
-// below are relative to t, `len` = the bytes that belong to rows - what lies behind is look-ahead padding)
-struct TextRef { const unsigned char* t; long long base, len; const unsigned char* cls; };      // cls: the class table in LDS (or null)
+// distinct keys of a row, first seen first: Counter key = read-base code + sign + sequence, case-sensitive (pack.cpp: intern_indel); the
+// sequences are compared on the text in HBM (the LDS copy's base strings are being overwritten with codes).  Returns the number of distinct
+// keys; *str_bytes = the bytes of their alt_info strings
+__device__ int intern_row(const RowArgs& a, const RowToks& tk, long long ri, int* str_bytes) {
+    int nk = 0, sb = 0;
+    int si = tk.first;
+    for (int i = 0; i < tk.n; ++i) {
+        const TokRec ri_ = a.tok[si];
+        int found = -1;
+        int sj = tk.first;
+        for (int j = 0; j < i && found < 0; ++j) {
+            const TokRec rj = a.tok[sj];
+            if (rj.len == ri_.len && tok_kind(rj.info) == tok_kind(ri_.info) && tok_code(rj.info) == tok_code(ri_.info)) {
+                const unsigned char* x = a.text + tok_seq(sj, rj.info);
+                const unsigned char* y = a.text + tok_seq(si, ri_.info);
+                bool eq = true;
+                for (int k = 0; k < ri_.len && eq; ++k) eq = x[k] == y[k];
+                if (eq) found = rj.kg & 0xffff;
+            }
+            sj = rj.next;
+        }
+        if (found < 0) {
+            found = nk++;
+            long long take = min((long long)(ri_.len + 1), (long long)a.max_indel_length);
+            take = min(take, a.ref_len - ri);
+            sb += tok_kind(ri_.info) == 1 ? 2 + ri_.len : 1 + int(take);
+        }
+        a.tok[si].kg = found;
+        si = ri_.next;
+    }
+    *str_bytes = sb;
+    return nk;
+}
 
-// pass 1 of a row: the single forward pass of pack.cpp's fast_row; writes the row's counts, false = not a row this path takes
+// pass 1 of a row: the single forward pass of pack.cpp's fast_row up to the end of the base string; writes the row's counts, the codes of
+// its read-bases and its token chain; false = not a row this path takes.  (The quality and mapping-quality strings are not walked here:
+// k_expand reads them, coalesced, and checks them and their separators on the text in HBM.)
 template <class Stream>
-__device__ bool count_row(const RowArgs& a, const TextRef& T, long long cur, int row) {
-    const unsigned char* t = T.t;
+__device__ bool walk_row(const RowArgs& a, const TextRef& T, Stream& st, long long cur, int row, int& nt_out, int& nk_out, int& sb_out) {
     const long long len = T.len;
-    Stream st;
-    st.seek(t, cur);
+    st.seek(T.t, cur);
     if (st.peek() <= 10u) return false;                                 // an empty row / an empty contig field: the host's
     while (st.peek() > 10u) st.step();                                  // contig
     if (st.peek() != '\t') return false;
@@ -316,360 +383,26 @@ __device__ bool count_row(const RowArgs& a, const TextRef& T, long long cur, int
     st.step();
     const long long b0 = st.pos;
     int nt = 0;
-    RowIndels ind;
-    if (!walk_bases(st, t, len, nt, ind, T.cls)) return false;
+    RowToks tk;
+    if (!walk_bases(a, st, T, nt, tk)) return false;
     if (st.peek() != '\t' || nt > kMaxDepth) return false;
     const long long blen = st.pos - b0;
-    st.step();
-    // as many quality and mapping-quality characters as read-bases, printable (phred 0..94), then the end of the row
-    if (st.pos + 2LL * nt + 1 >= len) return false;
-    bool bad = false;
-    for (int i = 0; i < nt; ++i) bad |= st.take() - 33u > 94u;
-    if (st.take() != '\t') return false;
-    for (int i = 0; i < nt; ++i) bad |= st.take() - 33u > 94u;
-    if (bad || st.peek() != '\n') return false;
-    if (ind.n > 0) ind.intern(t);
+    // as many quality and mapping-quality characters as read-bases and the end of the row must lie inside the text (k_expand looks at them)
+    if (st.pos + 1 + 2LL * nt + 1 >= len) return false;
+    const long long ri = pos - a.ref_start;
+    const bool oob = ri < 0 || ri >= a.ref_len || pos > 0x7fffffffLL;
+    if (oob) atomicMax(&a.fl->oob, 1);
+    int sb = 0;
+    const int nk = (tk.n > 0 && !oob) ? intern_row(a, tk, ri, &sb) : 0;
     a.row_nt[row] = nt;
-    a.row_nk[row] = ind.nk;
+    a.row_nk[row] = nk;
+    a.row_str[row] = sb;
+    a.row_tok[row] = tk.first;
     a.row_pos[row] = int(min(pos, (long long)0x7fffffff));
     a.row_b0[row] = int(b0 - cur);
     a.row_blen[row] = int(blen);
-    const long long ri = pos - a.ref_start;
-    if (ri < 0 || ri >= a.ref_len || pos > 0x7fffffffLL) atomicMax(&a.fl->oob, 1);
+    nt_out = nt; nk_out = nk; sb_out = sb;
     return b0 - cur < (1LL << 30);
-}
-
-// pass 2 of a row: entries, column tables, the row's distinct keys
-template <class Stream>
-__device__ void fill_row(const RowArgs& a, const TextRef& T, long long cur, int row) {
-    const unsigned char* t = T.t;
-    const long long e0 = a.col_off[row];
-    const int k0 = a.key_off[row];
-    const int nt = a.row_nt[row];
-    const long long pos = a.row_pos[row], ri = pos - a.ref_start;
-    const unsigned char rb = a.ref[ri];
-    const unsigned char ru = up_c(rb);
-    a.col_pos[row] = int(pos);
-    a.col_ref[row] = static_cast<unsigned char>(ref_code_dev(rb) | ((ru == 'A' || ru == 'C' || ru == 'G' || ru == 'T') ? 0 : 0x80));
-    const long long b0 = cur + a.row_b0[row], qs = b0 + a.row_blen[row] + 1, ms = qs + nt + 1;
-    RowIndels ind;
-    if (a.row_nk[row] > 0) {                                             // the row's indel tokens and their key ids, as pass 1 saw them
-        Stream sb;
-        sb.seek(t, b0);
-        int n2 = 0;
-        (void)walk_bases(sb, t, T.len, n2, ind, T.cls);
-        ind.intern(t);
-    }
-    Stream sb, sq, sm;
-    sb.seek(t, b0); sq.seek(t, qs); sm.seek(t, ms);
-    int idx = 0, w = 0;
-    lds_table cls = (lds_table)T.cls;
-    while (idx < nt) {
-        const unsigned c = sb.peek();
-        const int cl = char_class(cls, c);
-        if (cl < 12) {
-            unsigned e = unsigned(cl) | ((sq.take() - 33u) << 6) | ((sm.take() - 33u) << 13);
-            if (w < ind.n && (ind.at[w] >> 2) == idx) {
-                const int tk = ind.at[w] & 3;
-                const int gate = tk == 1 ? ind.len[w] : ind.len[w] + 1;
-                e |= unsigned(gate > a.max_indel_length ? 3 : tk) << 4;
-                e |= unsigned(ind.kid[w]) << 21;
-                ++w;
-            }
-            a.entries[e0 + idx] = e;
-            ++idx;
-            sb.step();
-        } else if (cl == 14) sb.step();
-        else if (cl == 13) { sb.step(); sb.step(); }
-        else {                                                           // an indel token: sign, digits, sequence
-            sb.step();
-            long long adv = 0;
-            while (sb.peek() - '0' < 10u) { adv = adv * 10 + (sb.peek() - '0'); sb.step(); }
-            sb.skip(adv);
-        }
-    }
-    // the row's distinct keys: meta byte, merged group (insertions by upper-cased anchor + sequence, deletions by length:
-    // extract_candidates_calling.py:118-126), alt_info string length; where k_key_strings finds the sequence
-    int grp[MAX_IND];
-    int ng = 0;
-    for (int i = 0; i < ind.n; ++i) {
-        bool first = true;
-        for (int j2 = 0; j2 < i; ++j2) if (ind.kid[j2] == ind.kid[i]) { first = false; break; }
-        if (!first) continue;
-        const int tk = ind.at[i] & 3, code = ind.code[i], sl = ind.len[i];
-        const int gate = tk == 1 ? sl : sl + 1;
-        const bool overlong = gate > a.max_indel_length;
-        const bool fwd = code < 4 || code == 8 || code == 10;
-        const unsigned char anchors[12] = {'A', 'C', 'G', 'T', 'A', 'C', 'G', 'T', '*', '#', 'N', 'N'};
-        const unsigned char anchor = tk == 1 ? anchors[code] : static_cast<unsigned char>('D');
-        int g = -1;
-        for (int j2 = 0; j2 < i && g < 0; ++j2) {                        // earlier FIRST occurrences only carry a group
-            bool jfirst = true;
-            for (int j3 = 0; j3 < j2; ++j3) if (ind.kid[j3] == ind.kid[j2]) { jfirst = false; break; }
-            if (!jfirst) continue;
-            if ((ind.at[j2] & 3) != tk || ind.len[j2] != sl) continue;
-            if (tk == 2) { g = grp[j2]; break; }
-            if (anchors[ind.code[j2]] != anchor) continue;
-            bool eq = true;
-            for (int k = 0; k < sl && eq; ++k) eq = up_c(t[ind.seq[j2] + k]) == up_c(t[ind.seq[i] + k]);
-            if (eq) g = grp[j2];
-        }
-        if (g < 0) g = ng++;
-        grp[i] = g;
-        const int k = k0 + ind.kid[i];
-        a.key_meta[k] = static_cast<unsigned char>(tk | (fwd ? 4 : 0) | (overlong ? 8 : 0));
-        a.key_group[k] = g;
-        long long take = min((long long)(sl + 1), (long long)a.max_indel_length);
-        take = min(take, a.ref_len - ri);
-        a.key_len[k] = tk == 1 ? 2 + sl : 1 + int(take);
-        a.key_seq[k] = tk == 1 ? ind.seq[i] + T.base : ri;
-        a.key_info[k] = (sl << 8) | (code << 4) | tk;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------------
-// A WAVEFRONT per row (CTO_TOK_WAVES=1; the lane-per-row kernels above are the default).  A row's ~250 bytes are classified 64 at a time
-// with ballots instead of one after the other:
-//   * tabs, control bytes                    -> field boundaries (exactly six tabs), declines
-//   * '^x' pairs                             -> which bytes a live '^' consumes: runs of '^' alternate live / consumed; the carry-add trick
-//                                               of simdjson's escaped-character scan resolves all runs of a 64-byte word at once
-//   * '+n<seq>' / '-n<seq>' tokens           -> every sign that is not consumed is a token (a sequence holds no sign and no '^' in samtools'
-//                                               output; a row where one does is declined): digits, n bytes masked
-//   * read-bases                             -> class < 12, not consumed, not masked: their count is a popcount, their index a prefix popcount
-// so the serial part of a row is its handful of indel tokens.  Rows longer than TOKW_CAP bytes are declined (the host's).
-// Measured on MI355X (22 MB, 140 000 rows): count 0.27 ms, fill 0.39 ms against 0.21 / 0.32 ms lane per row.  It is not the idea that is slow
-// but its granularity: a 170-byte row is 2.7 ballots' worth of bytes and every one of the ~15 ballot steps of a row is a dependent
-// LDS-read -> compare -> scalar-mask chain, ~800 wave instructions per row, where 64 rows sharing a wavefront spend ~190 each.  The form
-// that would win runs these masks over the TEXT (64 bytes of whatever rows they belong to, row boundaries as one more mask) - not built.
-constexpr int TOKW_CAP = 4096, TOKW_WAVES = 4, TOKW_TOK = 32;
-constexpr unsigned char F_CONS = 1, F_SKIP = 2;
-
-struct WaveRow {                 // what one pass over a row's base string leaves behind (wave-uniform)
-    int nt, ntok, nk;
-    long long pos;
-    int b0, b1, qs, ms, L;
-};
-
-template <bool FILL>
-__global__ __launch_bounds__(64 * TOKW_WAVES) void k_rows_wave(RowArgs a) {
-    __shared__ unsigned char s_buf[TOKW_WAVES][TOKW_CAP + 64];
-    __shared__ unsigned char s_flg[TOKW_WAVES][TOKW_CAP + 64];
-    __shared__ int s_tok[TOKW_WAVES][TOKW_TOK][6];        // sign position (relative to b0), sequence start (row offset), length, kind, carrier index, carrier code
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int r = blockIdx.x * TOKW_WAVES + wv;
-    if (r >= a.n_rows) return;
-    unsigned char* buf = s_buf[wv];
-    unsigned char* flg = s_flg[wv];
-    int (*tok)[6] = s_tok[wv];
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const long long cur = a.row_start[r], nxt = r + 1 < a.n_rows ? a.row_start[r + 1] : a.len;
-    const int L = int(min(nxt - cur - 1, (long long)TOKW_CAP + 1));           // without the '\n'
-    auto decline = [&]() { if (lane == 0) atomicMax(&a.fl->slow, int(min(cur + 1, (long long)0x7fffffff))); };
-    if (L <= 0 || L > TOKW_CAP) { decline(); return; }
-    for (int i = lane; i < L; i += 64) buf[i] = a.text[cur + i];
-    __builtin_amdgcn_wave_barrier();
-    // ---- fields: exactly six tabs, no other byte <= 10 ----
-    int tp[6] = {0, 0, 0, 0, 0, 0}, ntab = 0;
-    bool ctrl = false;
-    for (int base = 0; base < L; base += 64) {
-        const unsigned c = base + lane < L ? buf[base + lane] : 'x';
-        unsigned long long mt = __ballot(c == '\t');
-        ctrl |= __ballot(c <= 10u && c != '\t') != 0ull;
-        while (mt) {
-            const int b = __ffsll((long long)mt) - 1;
-            if (ntab < 6) tp[ntab] = base + b;
-            ++ntab;
-            mt &= mt - 1;
-        }
-    }
-    if (ctrl || ntab != 6 || tp[0] == 0) { decline(); return; }
-    long long pos = 0;
-    {
-        const int d0 = tp[0] + 1, d1 = tp[1];
-        if (d1 == d0 || d1 - d0 > 15) { decline(); return; }
-        bool okd = true;
-        for (int i = d0; i < d1; ++i) { const unsigned d = unsigned(buf[i]) - '0'; okd &= d < 10u; pos = pos * 10 + (long long)d; }
-        if (!okd) { decline(); return; }
-    }
-    const int b0 = tp[3] + 1, b1 = tp[4], qs = b1 + 1, t6 = tp[5], ms = t6 + 1, blen = b1 - b0;
-    for (int i = lane; i < blen + 1; i += 64) flg[i] = 0;
-    __builtin_amdgcn_wave_barrier();
-    // ---- bytes consumed by a live '^' ----
-    {
-        unsigned long long prev = 0ull;
-        bool tail = false;                                     // the field's last byte is a live '^': it would consume the tab
-        for (int base = 0; base < blen; base += 64) {
-            const unsigned c = base + lane < blen ? buf[b0 + base + lane] : 0u;
-            unsigned long long bs = __ballot(c == '^');
-            bs &= ~prev;
-            const unsigned long long follows = (bs << 1) | prev, even = 0x5555555555555555ull;
-            const unsigned long long odd_starts = bs & ~even & ~follows;
-            const unsigned long long seq_even = odd_starts + bs;
-            prev = seq_even < odd_starts ? 1ull : 0ull;
-            const unsigned long long escaped = (even ^ (seq_even << 1)) & follows;
-            if ((escaped >> lane) & 1ull) flg[base + lane] |= F_CONS;
-            if (blen - base < 64) tail = ((escaped >> (blen - base)) & 1ull) != 0ull;
-            else if (base + 64 >= blen) tail = prev != 0ull;
-        }
-        if (tail) { decline(); return; }
-    }
-    __builtin_amdgcn_wave_barrier();
-    // ---- indel tokens ----
-    int ntok = 0;
-    for (int base = 0; base < blen; base += 64) {
-        const bool in = base + lane < blen;
-        const unsigned c = in ? buf[b0 + base + lane] : 0u;
-        unsigned long long m = __ballot(in && (c == '+' || c == '-') && !(flg[base + lane] & (F_CONS | F_SKIP)));
-        while (m) {
-            const int p = base + __ffsll((long long)m) - 1;
-            m &= m - 1;
-            long long adv = 0;
-            int nd = 0;
-            while (p + 1 + nd < blen && unsigned(buf[b0 + p + 1 + nd]) - '0' < 10u && nd < 9) { adv = adv * 10 + (buf[b0 + p + 1 + nd] - '0'); ++nd; }
-            const int seq0 = p + 1 + nd;
-            if (nd == 0 || nd >= 9 || adv == 0 || seq0 + adv > blen || ntok >= TOKW_TOK) { decline(); return; }
-            bool bad = false;
-            for (int i = lane; i < int(adv); i += 64) {
-                const unsigned ch = buf[b0 + seq0 + i];
-                bad |= ch == '+' || ch == '-' || ch == '^';
-            }
-            if (__ballot(bad)) { decline(); return; }
-            for (int i = lane; i < nd + 1 + int(adv); i += 64) flg[p + i] |= F_SKIP;
-            if (lane == 0) { tok[ntok][0] = p; tok[ntok][1] = b0 + seq0; tok[ntok][2] = int(adv); tok[ntok][3] = buf[b0 + p] == '+' ? 1 : 2; }
-            ++ntok;
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    // ---- read-bases: count, and the carrier of every token ----
-    int nt = 0, last_code = -1, tnext = 0;
-    for (int base = 0; base < blen; base += 64) {
-        const bool in = base + lane < blen;
-        const unsigned c = in ? buf[b0 + base + lane] : 0u;
-        const int cl = char_class(c);
-        const unsigned long long mb = __ballot(in && cl < 12 && !(flg[base + lane] & (F_CONS | F_SKIP)));
-        while (tnext < ntok && tok[tnext][0] < base + 64) {
-            const int off = tok[tnext][0] - base;
-            const unsigned long long mlow = off > 0 ? mb & ((off >= 64 ? ~0ull : (1ull << off)) - 1ull) : 0ull;
-            const int idx = nt + __popcll(mlow) - 1;
-            const int code = mlow ? char_class(buf[b0 + base + 63 - __clzll((long long)mlow)]) : last_code;
-            if (lane == 0) { tok[tnext][4] = idx; tok[tnext][5] = code; }
-            ++tnext;
-        }
-        if (mb) last_code = char_class(buf[b0 + base + 63 - __clzll((long long)mb)]);
-        nt += __popcll(mb);
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (nt > kMaxDepth || t6 != qs + nt || L != ms + nt) { decline(); return; }
-    {   // quality characters: printable (phred 0 .. 94)
-        bool bad = false;
-        for (int i = lane; i < nt; i += 64) bad |= (unsigned(buf[qs + i]) - 33u > 94u) | (unsigned(buf[ms + i]) - 33u > 94u);
-        if (__ballot(bad)) { decline(); return; }
-    }
-    // a read-base annotated twice keeps its last annotation; a token in front of the first read-base is not this path's
-    int kept[TOKW_TOK], nkept = 0;
-    for (int t = 0; t < ntok; ++t) {
-        if (tok[t][4] < 0) { decline(); return; }
-        if (t + 1 < ntok && tok[t + 1][4] == tok[t][4]) continue;
-        kept[nkept++] = t;
-    }
-    // distinct keys, first seen first (wave-uniform work on a handful of tokens)
-    int kid[TOKW_TOK], nk = 0;
-    for (int x = 0; x < nkept; ++x) {
-        const int t = kept[x];
-        int found = -1;
-        for (int y = 0; y < x && found < 0; ++y) {
-            const int u = kept[y];
-            if (tok[u][2] != tok[t][2] || tok[u][3] != tok[t][3] || tok[u][5] != tok[t][5]) continue;
-            bool eq = true;
-            for (int k = 0; k < tok[t][2] && eq; ++k) eq = buf[tok[u][1] + k] == buf[tok[t][1] + k];
-            if (eq) found = kid[y];
-        }
-        kid[x] = found >= 0 ? found : nk++;
-    }
-    const long long ri = pos - a.ref_start;
-    if constexpr (!FILL) {
-        if (lane == 0) {
-            a.row_nt[r] = nt;
-            a.row_nk[r] = nk;
-            a.row_pos[r] = int(min(pos, (long long)0x7fffffff));
-            if (ri < 0 || ri >= a.ref_len || pos > 0x7fffffffLL) atomicMax(&a.fl->oob, 1);
-        }
-        return;
-    } else {
-        const long long e0 = a.col_off[r];
-        const int k0 = a.key_off[r];
-        if (lane == 0) {
-            if (r > 0 && a.row_pos[r] <= a.row_pos[r - 1]) atomicMax(&a.fl->bad_order, 1);
-            const unsigned char rb = a.ref[ri];
-            const unsigned char ru = up_c(rb);
-            a.col_pos[r] = int(pos);
-            a.col_ref[r] = static_cast<unsigned char>(ref_code_dev(rb) | ((ru == 'A' || ru == 'C' || ru == 'G' || ru == 'T') ? 0 : 0x80));
-        }
-        // entries: every read-base lane writes its own (index = prefix popcount), indel bits looked up in the kept tokens
-        int n0 = 0;
-        for (int base = 0; base < blen; base += 64) {
-            const bool in = base + lane < blen;
-            const unsigned c = in ? buf[b0 + base + lane] : 0u;
-            const int cl = char_class(c);
-            const bool isb = in && cl < 12 && !(flg[base + lane] & (F_CONS | F_SKIP));
-            const unsigned long long mb = __ballot(isb);
-            if (isb) {
-                const int idx = n0 + __popcll(mb & below);
-                unsigned e = unsigned(cl) | ((unsigned(buf[qs + idx]) - 33u) << 6) | ((unsigned(buf[ms + idx]) - 33u) << 13);
-                for (int x = 0; x < nkept; ++x) {
-                    const int t = kept[x];
-                    if (tok[t][4] == idx) {
-                        const int tk = tok[t][3];
-                        const int gate = tk == 1 ? tok[t][2] : tok[t][2] + 1;
-                        e |= unsigned(gate > a.max_indel_length ? 3 : tk) << 4;
-                        e |= unsigned(kid[x]) << 21;
-                    }
-                }
-                a.entries[e0 + idx] = e;
-            }
-            n0 += __popcll(mb);
-        }
-        // the row's distinct keys (first occurrences): meta, merged group, string length, where k_key_strings finds the sequence
-        int grp[TOKW_TOK], ng = 0;
-        for (int x = 0; x < nkept; ++x) {
-            bool first = true;
-            for (int y = 0; y < x; ++y) if (kid[y] == kid[x]) { first = false; break; }
-            if (!first) continue;
-            const int t = kept[x];
-            const int tk = tok[t][3], code = tok[t][5], sl = tok[t][2];
-            const int gate = tk == 1 ? sl : sl + 1;
-            const bool overlong = gate > a.max_indel_length;
-            const bool fwd = code < 4 || code == 8 || code == 10;
-            const unsigned char anchors[12] = {'A', 'C', 'G', 'T', 'A', 'C', 'G', 'T', '*', '#', 'N', 'N'};
-            const unsigned char anchor = tk == 1 ? anchors[code] : static_cast<unsigned char>('D');
-            int g = -1;
-            for (int y = 0; y < x && g < 0; ++y) {
-                bool yfirst = true;
-                for (int z = 0; z < y; ++z) if (kid[z] == kid[y]) { yfirst = false; break; }
-                if (!yfirst) continue;
-                const int u = kept[y];
-                if (tok[u][3] != tk || tok[u][2] != sl) continue;
-                if (tk == 2) { g = grp[y]; break; }
-                if (anchors[tok[u][5]] != anchor) continue;
-                bool eq = true;
-                for (int k = 0; k < sl && eq; ++k) eq = up_c(buf[tok[u][1] + k]) == up_c(buf[tok[t][1] + k]);
-                if (eq) g = grp[y];
-            }
-            if (g < 0) g = ng++;
-            grp[x] = g;
-            if (lane == 0) {
-                const int k = k0 + kid[x];
-                a.key_meta[k] = static_cast<unsigned char>(tk | (fwd ? 4 : 0) | (overlong ? 8 : 0));
-                a.key_group[k] = g;
-                long long take = min((long long)(sl + 1), (long long)a.max_indel_length);
-                take = min(take, a.ref_len - ri);
-                a.key_len[k] = tk == 1 ? 2 + sl : 1 + int(take);
-                a.key_seq[k] = tk == 1 ? cur + tok[t][1] : ri;
-                a.key_info[k] = (sl << 8) | (code << 4) | tk;
-            }
-        }
-    }
 }
 
 // zero-byte detector on eight bytes at once: bit 7 of every byte of the result that was '\n' in x
@@ -730,63 +463,237 @@ __global__ __launch_bounds__(256) void k_row_starts(const unsigned char* __restr
 // One lane per row (a lane per segment that parsed "its" rows where it found them ran the parser once per '\n' position of the
 // wavefront, one or two lanes at a time: 4.5 ms instead of 0.3).  The 64 rows of a wavefront are consecutive lines, i.e. ONE contiguous
 // span of the text (~11 KB at 50x): the wave copies it into LDS with coalesced 16-byte loads and the lanes parse from there - a lane's
-// byte stream then refills from LDS instead of waiting out an L2 round trip per 8 bytes, three streams at a time in the fill pass.
-// Spans that do not fit (deep columns) are parsed from HBM as before; the decision is the wavefront's.
+// byte stream then reads LDS instead of waiting out an L2 round trip per 8 bytes.  Spans that do not fit (deep columns) are parsed from
+// HBM; the decision is the wavefront's.  Round 6: ONE walk per row.  The walk leaves the read-bases' codes (a byte each, in the text's own
+// layout), the row's token chain and its counts; entries are then written by k_expand - a thread per read-base, coalesced - and the key tables
+// by k_row_keys.  (Rounds 4-5 walked every base string twice - counts first, entries after the scans - with the tokens of a row in a lane's
+// private memory: 0.07 + 0.12 ms and 784-928 bytes of scratch per lane.)
 constexpr int TOKL_CAP = 16384;
-template <bool FILL>
-__global__ __launch_bounds__(64) void k_rows_lanes(RowArgs a) {
+__global__ __launch_bounds__(64) void k_rows_walk(RowArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char s_text[TOKL_CAP];
+    __shared__ unsigned char s_cls[256];
     const int lane = threadIdx.x;
     const int r0 = blockIdx.x * 64, r = r0 + lane;
     const int r1 = min(r0 + 64, a.n_rows);
     const long long span0 = a.row_start[r0], span1 = r1 < a.n_rows ? a.row_start[r1] : a.len;
     const long long a0 = span0 & ~15LL;
-    const long long need = span1 - a0 + 48;                 // a stream looks 40 bytes past the byte it stands on
-    __shared__ unsigned char s_cls[256];
+    const long long need = span1 - a0 + 48;                 // a reader looks a few bytes past the byte it stands on
     for (int i = lane; i < 256; i += 64) s_cls[i] = kCharClass[i];
-    __syncthreads();
-    TextRef T{a.text, 0, a.len, s_cls};
-    if (need <= TOKL_CAP) {
+    const bool staged = need <= TOKL_CAP;                    // (the wavefront's decision)
+    if (staged)
         for (long long i = lane * 16LL; i < need; i += 64 * 16) *reinterpret_cast<uint4*>(s_text + i) = *reinterpret_cast<const uint4*>(a.text + a0 + i);
-        __syncthreads();
-        T = TextRef{s_text, a0, span1 - a0, s_cls};
+    __syncthreads();
+    int nt = 0, nk = 0, sb = 0;
+    if (r < a.n_rows) {
+        const long long cur = a.row_start[r];
+        bool ok;
+        if (staged) {
+            const TextRef T{s_text, a0, span1 - a0, s_cls};
+            LdsStream st;
+            ok = walk_row<LdsStream>(a, T, st, cur - a0, r, nt, nk, sb);
+        } else {
+            const TextRef T{a.text, 0, a.len, s_cls};
+            ByteStream st;
+            st.codes = a.codes;
+            ok = walk_row<ByteStream>(a, T, st, cur, r, nt, nk, sb);
+        }
+        if (!ok) { nt = nk = sb = 0; atomicMax(&a.fl->slow, int(min(cur + 1, (long long)0x7fffffff))); }
     }
-    if (r >= a.n_rows) return;
-    const long long cur = a.row_start[r];
-    const bool staged = T.t != a.text;                       // (the wavefront's decision)
-    if (FILL) {
-        if (r > 0 && a.row_pos[r] <= a.row_pos[r - 1]) atomicMax(&a.fl->bad_order, 1);
-        if (staged) fill_row<LdsStream>(a, T, cur - T.base, r);
-        else fill_row<ByteStream>(a, T, cur - T.base, r);
-    } else {
-        const bool ok = staged ? count_row<LdsStream>(a, T, cur - T.base, r) : count_row<ByteStream>(a, T, cur - T.base, r);
-        if (!ok) atomicMax(&a.fl->slow, int(min(cur + 1, (long long)0x7fffffff)));
+    __syncthreads();
+    if (staged) {
+        // the span's bytes - base strings now hold the codes - out to the codes buffer: exactly [span0, span1), the rows of this wavefront
+        const long long lo = span0 - a0, hi = span1 - a0;
+        for (long long i = lane * 16LL; i < hi; i += 64 * 16) {
+            if (i >= lo && i + 16 <= hi) *reinterpret_cast<uint4*>(a.codes + a0 + i) = *reinterpret_cast<const uint4*>(s_text + i);
+            else for (int k = 0; k < 16; ++k) if (i + k >= lo && i + k < hi) a.codes[a0 + i + k] = s_text[i + k];
+        }
+    }
+    // the wavefront's sums into its tile's (SCAN_TILE is a multiple of 64: a wavefront's rows share a tile)
+    long long snt = nt, ssb = sb;
+    int snk = nk;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { snt += __shfl_xor(snt, o); ssb += __shfl_xor(ssb, o); snk += __shfl_xor(snk, o); }
+    if (lane == 0) {
+        const int tile = r0 / SCAN_TILE;
+        if (snt) atomicAdd(reinterpret_cast<unsigned long long*>(a.tile_nt + tile), (unsigned long long)snt);
+        if (snk) atomicAdd(a.tile_nk + tile, snk);
+        if (ssb) atomicAdd(reinterpret_cast<unsigned long long*>(a.tile_str + tile), (unsigned long long)ssb);
     }
 }
-__global__ __launch_bounds__(128) void k_key_strings(const unsigned char* __restrict__ text, const unsigned char* __restrict__ ref, int n_keys,
-                                                     const long long* __restrict__ key_seq, const int* __restrict__ key_info,
-                                                     const long long* __restrict__ str_off, char* __restrict__ out) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_keys) return;
-    const int info = key_info[k], tk = info & 3, code = (info >> 4) & 15, sl = info >> 8;
-    const long long o = str_off[k], n = str_off[k + 1] - o;
-    char* dst = out + o;
-    if (tk == 1) {
-        const char anchors[12] = {'A', 'C', 'G', 'T', 'A', 'C', 'G', 'T', '*', '#', 'N', 'N'};
-        dst[0] = 'I';
-        dst[1] = anchors[code];
-        for (int i = 0; i < sl; ++i) dst[2 + i] = char(up_c(text[key_seq[k] + i]));
-    } else {
-        dst[0] = 'D';
-        for (long long i = 0; i + 1 < n; ++i) dst[1 + i] = char(up_c(ref[key_seq[k] + i]));
+
+// The three exclusive scans a chunk needs after the walk, in ONE launch: read-bases -> col_off, distinct keys -> key_off, key-string bytes ->
+// row_str_off.  A workgroup per SCAN_TILE rows; the tiles' sums came from the walk's atomics, every workgroup adds up those in front of its own.
+__global__ __launch_bounds__(256) void k_apply3(const int* __restrict__ row_nt, const int* __restrict__ row_nk, const int* __restrict__ row_str, int n,
+                                                const long long* __restrict__ tile_nt, const int* __restrict__ tile_nk, const long long* __restrict__ tile_str,
+                                                long long* __restrict__ col_off, int* __restrict__ key_off, long long* __restrict__ str_off, TokFlags* __restrict__ fl) {
+    __shared__ long long p_nt[256], p_sb[256];
+    __shared__ int p_nk[256];
+    long long b_nt = 0, b_sb = 0;
+    int b_nk = 0;
+    for (int i = threadIdx.x; i < int(blockIdx.x); i += 256) { b_nt += tile_nt[i]; b_nk += tile_nk[i]; b_sb += tile_str[i]; }
+    p_nt[threadIdx.x] = b_nt; p_nk[threadIdx.x] = b_nk; p_sb[threadIdx.x] = b_sb;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (int(threadIdx.x) < d) { p_nt[threadIdx.x] += p_nt[threadIdx.x + d]; p_nk[threadIdx.x] += p_nk[threadIdx.x + d]; p_sb[threadIdx.x] += p_sb[threadIdx.x + d]; }
+        __syncthreads();
+    }
+    const long long t_nt = p_nt[0], t_sb = p_sb[0];
+    const int t_nk = p_nk[0];
+    __syncthreads();
+    constexpr int PER = SCAN_TILE / 256;
+    const int i0 = blockIdx.x * SCAN_TILE + threadIdx.x * PER;
+    long long l_nt[PER], l_sb[PER], s_nt = 0, s_sb = 0;
+    int l_nk[PER], s_nk = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        l_nt[k] = s_nt; l_nk[k] = s_nk; l_sb[k] = s_sb;
+        if (i0 + k < n) { s_nt += row_nt[i0 + k]; s_nk += row_nk[i0 + k]; s_sb += row_str[i0 + k]; }
+    }
+    p_nt[threadIdx.x] = s_nt; p_nk[threadIdx.x] = s_nk; p_sb[threadIdx.x] = s_sb;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const bool up = int(threadIdx.x) >= d;
+        const long long x = up ? p_nt[threadIdx.x - d] : 0, z = up ? p_sb[threadIdx.x - d] : 0;
+        const int y = up ? p_nk[threadIdx.x - d] : 0;
+        __syncthreads();
+        p_nt[threadIdx.x] += x; p_nk[threadIdx.x] += y; p_sb[threadIdx.x] += z;
+        __syncthreads();
+    }
+    const long long o_nt = t_nt + p_nt[threadIdx.x] - s_nt, o_sb = t_sb + p_sb[threadIdx.x] - s_sb;
+    const int o_nk = t_nk + p_nk[threadIdx.x] - s_nk;
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (i0 + k < n) { col_off[i0 + k] = o_nt + l_nt[k]; key_off[i0 + k] = o_nk + l_nk[k]; str_off[i0 + k] = o_sb + l_sb[k]; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
+        col_off[n] = t_nt + p_nt[255]; key_off[n] = t_nk + p_nk[255]; str_off[n] = t_sb + p_sb[255];
+        fl->n_entries = t_nt + p_nt[255]; fl->n_keys = t_nk + p_nk[255]; fl->key_str_bytes = t_sb + p_sb[255];
+    }
+}
+
+// entries (code | kind << 4 | BQ << 6 | MQ << 13 | key id << 21), col_pos, col_ref: a workgroup per 64 rows, a thread per read-base - the codes,
+// the quality and the mapping-quality characters of a row are three runs of consecutive bytes, the entries one run of words.  Also what the
+// walk left unchecked: the two strings' separators and their characters' range (phred 0 .. 94), on the text in HBM; rows in position order.
+__global__ __launch_bounds__(256) void k_expand(RowArgs a) {
+    __shared__ long long s_off[65], s_b0[64];
+    __shared__ int s_nt[64];
+    const int r0 = blockIdx.x * 64, nr = min(64, a.n_rows - r0);
+    const int t = threadIdx.x;
+    if (t <= nr) s_off[t] = a.col_off[r0 + t];
+    bool bad = false;
+    if (t < nr) {
+        const int r = r0 + t, nt = a.row_nt[r];
+        const long long cur = a.row_start[r], b0 = cur + a.row_b0[r];
+        s_b0[t] = b0;
+        s_nt[t] = nt;
+        const long long pos = a.row_pos[r], ri = pos - a.ref_start;
+        if (a.row_b0[r] > 0) {                                 // a row the walk took (a declined one has set `slow` already)
+            const long long qs = b0 + a.row_blen[r] + 1;
+            bad = a.text[qs + nt] != '\t' || a.text[qs + nt + 1 + nt] != '\n';
+            if (ri >= 0 && ri < a.ref_len) {
+                const unsigned char rb = a.ref[ri];
+                const unsigned char ru = up_c(rb);
+                a.col_pos[r] = int(pos);
+                a.col_ref[r] = static_cast<unsigned char>(ref_code_dev(rb) | ((ru == 'A' || ru == 'C' || ru == 'G' || ru == 'T') ? 0 : 0x80));
+            }
+            if (r > 0 && a.row_pos[r] <= a.row_pos[r - 1]) atomicMax(&a.fl->bad_order, 1);
+        }
+    }
+    __syncthreads();
+    const long long e0 = s_off[0], e1 = s_off[nr];
+    for (long long e = e0 + t; e < e1; e += 256) {
+        int lo = 0, hi = nr;                                   // the row of entry e: the last one whose offset is <= e
+        while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (s_off[m] <= e) lo = m; else hi = m; }
+        const int i = int(e - s_off[lo]), nt = s_nt[lo];
+        const long long b0 = s_b0[lo], qs = b0 + a.row_blen[r0 + lo] + 1;
+        const unsigned q = unsigned(a.text[qs + i]) - 33u, m = unsigned(a.text[qs + nt + 1 + i]) - 33u;
+        bad |= q > 94u || m > 94u;
+        a.entries[e] = unsigned(a.codes[b0 + i]) | ((q & 127u) << 6) | ((m & 255u) << 13);
+    }
+    if (bad) atomicMax(&a.fl->slow, 1);
+    __syncthreads();                                           // the entries of this workgroup's rows are written: the indel bits go on top
+    if (t < nr) {
+        int slot = a.row_tok[r0 + t];
+        if (a.row_nk[r0 + t] > 0)
+            while (slot >= 0) {
+                const TokRec rec = a.tok[slot];
+                const int tk = tok_kind(rec.info);
+                const int gate = tk == 1 ? rec.len : rec.len + 1;
+                a.entries[s_off[t] + tok_idx(rec.info)] |= (unsigned(gate > a.max_indel_length ? 3 : tk) << 4) | (unsigned(rec.kg & 0xffff) << 21);
+                slot = rec.next;
+            }
+    }
+}
+
+// the distinct keys of every row that has some: meta byte, merged group (insertions by upper-cased anchor + sequence, deletions by length:
+// extract_candidates_calling.py:118-126), the alt_info key string ("I<ANCHOR><SEQ>" upper-cased / "D<reference slice>") and its offset.
+// A lane per row; a row's first occurrences are the records whose key id equals the number of distinct ids seen before them.
+__global__ __launch_bounds__(64) void k_row_keys(RowArgs a) {
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= a.n_rows) return;
+    if (r == a.n_rows - 1) a.str_off[a.key_off[a.n_rows]] = a.row_str_off[a.n_rows];
+    if (a.row_nk[r] <= 0) return;
+    const int k0 = a.key_off[r], first = a.row_tok[r];
+    const long long ri = (long long)a.row_pos[r] - a.ref_start;
+    const unsigned char anchors[12] = {'A', 'C', 'G', 'T', 'A', 'C', 'G', 'T', '*', '#', 'N', 'N'};
+    long long so = a.row_str_off[r];
+    int seen = 0, ng = 0;
+    for (int si = first; si >= 0;) {
+        const TokRec x = a.tok[si];
+        const int kid = x.kg & 0xffff;
+        if (kid == seen) {
+            ++seen;
+            const int tk = tok_kind(x.info), code = tok_code(x.info), sl = x.len;
+            const unsigned char anchor = tk == 1 ? anchors[code] : static_cast<unsigned char>('D');
+            int g = -1, seen_j = 0;
+            for (int sj = first; sj != si && g < 0;) {              // earlier FIRST occurrences only carry a group
+                const TokRec y = a.tok[sj];
+                if ((y.kg & 0xffff) == seen_j) {
+                    ++seen_j;
+                    if (tok_kind(y.info) == tk && y.len == sl) {
+                        if (tk == 2) g = (y.kg >> 16) & 0xffff;
+                        else if (anchors[tok_code(y.info)] == anchor) {
+                            const unsigned char* u = a.text + tok_seq(sj, y.info);
+                            const unsigned char* v = a.text + tok_seq(si, x.info);
+                            bool eq = true;
+                            for (int k = 0; k < sl && eq; ++k) eq = up_c(u[k]) == up_c(v[k]);
+                            if (eq) g = (y.kg >> 16) & 0xffff;
+                        }
+                    }
+                }
+                sj = y.next;
+            }
+            if (g < 0) g = ng++;
+            a.tok[si].kg = kid | (g << 16);
+            const int gate = tk == 1 ? sl : sl + 1;
+            const bool fwd = code < 4 || code == 8 || code == 10;
+            const int k = k0 + kid;
+            a.key_meta[k] = static_cast<unsigned char>(tk | (fwd ? 4 : 0) | (gate > a.max_indel_length ? 8 : 0));
+            a.key_group[k] = g;
+            a.str_off[k] = so;
+            char* dst = a.key_str + so;
+            if (tk == 1) {
+                const unsigned char* v = a.text + tok_seq(si, x.info);
+                dst[0] = 'I';
+                dst[1] = char(anchor);
+                for (int i = 0; i < sl; ++i) dst[2 + i] = char(up_c(v[i]));
+                so += 2 + sl;
+            } else {
+                long long take = min((long long)(sl + 1), (long long)a.max_indel_length);
+                take = min(take, a.ref_len - ri);
+                dst[0] = 'D';
+                for (long long i = 0; i < take; ++i) dst[1 + i] = char(up_c(a.ref[ri + i]));
+                so += 1 + take;
+            }
+        }
+        si = x.next;
     }
 }
 
 }  // namespace
 
 struct cto_dev_tokeniser {
-    Buf text, ref, seg_cnt, seg_base, row_start, row_nt, row_nk, row_pos, row_b0, row_blen, col_off, key_off, entries, col_pos, col_ref, key_meta, key_group,
-        key_len, key_seq, key_info, str_off, key_str, tiles, flags;
+    Buf text, ref, seg_cnt, seg_base, row_start, row_nt, row_nk, row_pos, row_b0, row_blen, row_tok, row_str, row_str_off, col_off, key_off, entries, col_pos, col_ref,
+        key_meta, key_group, str_off, key_str, tiles, row_tiles, codes, tok, flags;
     void* h_text = nullptr; size_t h_text_cap = 0;      // page-locked: the text on its way up
     void* h_stage = nullptr; size_t h_stage_cap = 0;    // page-locked: everything that comes back
     hipEvent_t ev = nullptr;
@@ -861,62 +768,61 @@ extern "C" int cto_tokenise_device(cto_dev_tokeniser* cx, const char* text, size
         return cx->wait(s);
     };
     const unsigned char* d_text = cx->text.as<unsigned char>();
+    // rows: newline counts per 256-byte segment, one launch for their scan, the row starts
+    const int seg_tiles = int(cdiv(n_seg, SCAN_TILE));
+    if ((rc = cx->tiles.ensure(size_t(seg_tiles + 2) * 8))) return rc;
     hipLaunchKernelGGL(k_count_lines, dim3(unsigned(cdiv(int64_t(n_seg) * PIECES, 256))), dim3(256), 0, s, d_text, (long long)len, n_seg, cx->seg_cnt.as<int>());
-    if ((rc = scan_exclusive<int>(s, cx->seg_cnt.as<int>(), n_seg, cx->seg_base.as<int>(), cx->tiles.as<int>(), &fl->n_rows))) return rc;
+    hipLaunchKernelGGL((k_tile_apply<int, true>), dim3(unsigned(seg_tiles)), dim3(256), 0, s, cx->seg_cnt.as<int>(), n_seg, static_cast<const int*>(nullptr),
+                       cx->seg_base.as<int>(), &fl->n_rows);
+    CTO_HIP(hipGetLastError());
     if ((rc = fetch_flags())) return rc;
     const int n_rows = hf->n_rows;
     if (n_rows <= 0) { *fallback = 1; return CTO_OK; }
-    if ((rc = cx->row_start.ensure(size_t(n_rows) * 8)) || (rc = cx->row_nt.ensure(size_t(n_rows) * 4)) || (rc = cx->row_nk.ensure(size_t(n_rows) * 4)) ||
-        (rc = cx->row_pos.ensure(size_t(n_rows) * 4)) || (rc = cx->row_b0.ensure(size_t(n_rows) * 4)) || (rc = cx->row_blen.ensure(size_t(n_rows) * 4)) || (rc = cx->col_off.ensure(size_t(n_rows + 1) * 8)) || (rc = cx->key_off.ensure(size_t(n_rows + 1) * 4)) ||
-        (rc = cx->col_pos.ensure(size_t(n_rows) * 4)) || (rc = cx->col_ref.ensure(size_t(n_rows) + 16)) ||
-        (rc = cx->tiles.ensure(size_t(cdiv(std::max(n_rows, n_seg), SCAN_TILE) + 2) * 8)))
+    const int row_tiles = int(cdiv(n_rows, SCAN_TILE));
+    const size_t nr = size_t(n_rows);
+    if ((rc = cx->row_start.ensure(nr * 8)) || (rc = cx->row_nt.ensure(nr * 4)) || (rc = cx->row_nk.ensure(nr * 4)) || (rc = cx->row_pos.ensure(nr * 4)) ||
+        (rc = cx->row_b0.ensure(nr * 4)) || (rc = cx->row_blen.ensure(nr * 4)) || (rc = cx->row_tok.ensure(nr * 4)) || (rc = cx->row_str.ensure(nr * 4)) ||
+        (rc = cx->col_off.ensure((nr + 1) * 8)) || (rc = cx->key_off.ensure((nr + 1) * 4)) || (rc = cx->row_str_off.ensure((nr + 1) * 8)) ||
+        (rc = cx->col_pos.ensure(nr * 4)) || (rc = cx->col_ref.ensure(nr + 16)) || (rc = cx->codes.ensure(len + 128)) ||
+        (rc = cx->tok.ensure((len / 4 + 64) * sizeof(TokRec))) || (rc = cx->row_tiles.ensure(size_t(row_tiles + 1) * 24)))
         return rc;
     RowArgs a{};
     a.text = d_text; a.len = (long long)len; a.ref = cx->ref.as<unsigned char>(); a.ref_start = ref_start; a.ref_len = (long long)ref_len;
     a.max_indel_length = max_indel_length;
     a.row_start = cx->row_start.as<long long>(); a.row_nt = cx->row_nt.as<int>(); a.row_nk = cx->row_nk.as<int>(); a.row_pos = cx->row_pos.as<int>();
-    a.row_b0 = cx->row_b0.as<int>(); a.row_blen = cx->row_blen.as<int>();
+    a.row_b0 = cx->row_b0.as<int>(); a.row_blen = cx->row_blen.as<int>(); a.row_tok = cx->row_tok.as<int>(); a.row_str = cx->row_str.as<int>();
+    a.codes = cx->codes.as<unsigned char>(); a.tok = cx->tok.as<TokRec>();
+    a.tile_nt = cx->row_tiles.as<long long>(); a.tile_str = a.tile_nt + (row_tiles + 1); a.tile_nk = reinterpret_cast<int*>(a.tile_str + (row_tiles + 1));
     a.n_rows = n_rows; a.fl = fl;
-    CTO_HIP(hipMemsetAsync(cx->row_nt.p, 0, size_t(n_rows) * 4, s));        // rows the pass declines leave theirs unwritten
-    CTO_HIP(hipMemsetAsync(cx->row_nk.p, 0, size_t(n_rows) * 4, s));
-    CTO_HIP(hipMemsetAsync(cx->row_pos.p, 0, size_t(n_rows) * 4, s));
+    CTO_HIP(hipMemsetAsync(cx->row_tiles.p, 0, size_t(row_tiles + 1) * 24, s));
+    // rows the walk declines leave theirs unwritten (one memset over the six adjacent-in-meaning arrays would need one allocation: they are small)
+    CTO_HIP(hipMemsetAsync(cx->row_nt.p, 0, nr * 4, s));
+    CTO_HIP(hipMemsetAsync(cx->row_nk.p, 0, nr * 4, s));
+    CTO_HIP(hipMemsetAsync(cx->row_pos.p, 0, nr * 4, s));
+    CTO_HIP(hipMemsetAsync(cx->row_blen.p, 0, nr * 4, s));
+    CTO_HIP(hipMemsetAsync(cx->row_b0.p, 0, nr * 4, s));
+    CTO_HIP(hipMemsetAsync(cx->row_str.p, 0, nr * 4, s));
+    CTO_HIP(hipMemsetAsync(cx->row_tok.p, 0xff, nr * 4, s));
     hipLaunchKernelGGL(k_row_starts, dim3(unsigned(cdiv(int64_t(n_seg) * PIECES, 256))), dim3(256), 0, s, d_text, (long long)len, n_seg, cx->seg_base.as<int>(),
                        cx->row_start.as<long long>());
-    // a lane per row (the default: 64 rows share a wavefront's instruction stream, ~190 instructions per row); CTO_TOK_WAVES=1: a wavefront
-    // per row (ballots over 64 bytes at a time: ~800 instructions per row - measured slower, 0.67 against 0.52 ms for the two passes - kept as the
-    // second statement of the pass the tests hold the first one to)
-    const char* tw = getenv("CTO_TOK_WAVES");
-    const bool by_lanes = !(tw && tw[0] == '1');
-    if (by_lanes) hipLaunchKernelGGL(k_rows_lanes<false>, dim3(unsigned(cdiv(n_rows, 64))), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(k_rows_wave<false>, dim3(unsigned(cdiv(n_rows, TOKW_WAVES))), dim3(64 * TOKW_WAVES), 0, s, a);
+    hipLaunchKernelGGL(k_rows_walk, dim3(unsigned(cdiv(n_rows, 64))), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_apply3, dim3(unsigned(row_tiles)), dim3(256), 0, s, a.row_nt, a.row_nk, a.row_str, n_rows, a.tile_nt, a.tile_nk, a.tile_str,
+                       cx->col_off.as<long long>(), cx->key_off.as<int>(), cx->row_str_off.as<long long>(), fl);
     CTO_HIP(hipGetLastError());
-    if ((rc = scan_exclusive<long long>(s, cx->row_nt.as<int>(), n_rows, cx->col_off.as<long long>(), cx->tiles.as<long long>(), &fl->n_entries))) return rc;
-    if ((rc = scan_exclusive<int>(s, cx->row_nk.as<int>(), n_rows, cx->key_off.as<int>(), cx->tiles.as<int>(), &fl->n_keys))) return rc;
     if ((rc = fetch_flags())) return rc;
     if (hf->slow || hf->oob) { *fallback = 1; return CTO_OK; }
     const long long n_entries = hf->n_entries;
     const int n_keys = hf->n_keys;
-    if ((rc = cx->entries.ensure(size_t(std::max<long long>(n_entries, 1)) * 4)) || (rc = cx->key_meta.ensure(size_t(n_keys) + 16)) ||
-        (rc = cx->key_group.ensure(size_t(n_keys + 1) * 4)) || (rc = cx->key_len.ensure(size_t(n_keys + 1) * 4)) ||
-        (rc = cx->key_seq.ensure(size_t(n_keys + 1) * 8)) || (rc = cx->key_info.ensure(size_t(n_keys + 1) * 4)) ||
-        (rc = cx->str_off.ensure(size_t(n_keys + 2) * 8)) || (rc = cx->tiles.ensure(size_t(cdiv(std::max(n_rows, n_keys), SCAN_TILE) + 2) * 8)))
-        return rc;
-    a.col_off = cx->col_off.as<long long>(); a.key_off = cx->key_off.as<int>(); a.entries = cx->entries.as<unsigned>(); a.col_pos = cx->col_pos.as<int>();
-    a.col_ref = cx->col_ref.as<unsigned char>(); a.key_meta = cx->key_meta.as<unsigned char>(); a.key_group = cx->key_group.as<int>();
-    a.key_len = cx->key_len.as<int>(); a.key_seq = cx->key_seq.as<long long>(); a.key_info = cx->key_info.as<int>();
-    if (by_lanes) hipLaunchKernelGGL(k_rows_lanes<true>, dim3(unsigned(cdiv(n_rows, 64))), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(k_rows_wave<true>, dim3(unsigned(cdiv(n_rows, TOKW_WAVES))), dim3(64 * TOKW_WAVES), 0, s, a);
-    CTO_HIP(hipGetLastError());
-    if ((rc = scan_exclusive<long long>(s, cx->key_len.as<int>(), n_keys, cx->str_off.as<long long>(), cx->tiles.as<long long>(), &fl->key_str_bytes))) return rc;
-    if ((rc = fetch_flags())) return rc;
-    if (hf->bad_order) { *fallback = 1; return CTO_OK; }
     const long long sb = hf->key_str_bytes;
-    if ((rc = cx->key_str.ensure(size_t(sb) + 16))) return rc;
-    if (n_keys > 0) {
-        hipLaunchKernelGGL(k_key_strings, dim3(unsigned(cdiv(n_keys, 128))), dim3(128), 0, s, d_text, cx->ref.as<unsigned char>(), n_keys,
-                           cx->key_seq.as<long long>(), cx->key_info.as<int>(), cx->str_off.as<long long>(), cx->key_str.as<char>());
-        CTO_HIP(hipGetLastError());
-    }
+    if ((rc = cx->entries.ensure(size_t(std::max<long long>(n_entries, 1)) * 4)) || (rc = cx->key_meta.ensure(size_t(n_keys) + 16)) ||
+        (rc = cx->key_group.ensure(size_t(n_keys + 1) * 4)) || (rc = cx->str_off.ensure(size_t(n_keys + 2) * 8)) || (rc = cx->key_str.ensure(size_t(sb) + 16)))
+        return rc;
+    a.col_off = cx->col_off.as<long long>(); a.key_off = cx->key_off.as<int>(); a.row_str_off = cx->row_str_off.as<long long>();
+    a.entries = cx->entries.as<unsigned>(); a.col_pos = cx->col_pos.as<int>(); a.col_ref = cx->col_ref.as<unsigned char>();
+    a.key_meta = cx->key_meta.as<unsigned char>(); a.key_group = cx->key_group.as<int>(); a.str_off = cx->str_off.as<long long>(); a.key_str = cx->key_str.as<char>();
+    hipLaunchKernelGGL(k_expand, dim3(unsigned(cdiv(n_rows, 64))), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_row_keys, dim3(unsigned(cdiv(n_rows, 64))), dim3(64), 0, s, a);
+    CTO_HIP(hipGetLastError());
     // the host's part of the pack (what cto_alt_info* read): positions, reference codes, key tables and strings - no entries
     std::unique_ptr<cto_pack> lite(new cto_pack());
     const size_t nc = size_t(n_rows), nk = size_t(n_keys);
@@ -933,13 +839,17 @@ extern "C" int cto_tokenise_device(cto_dev_tokeniser* cx, const char* text, size
         const void* src[7] = {cx->str_off.p, cx->key_str.p, cx->key_meta.p, cx->key_group.p, cx->col_pos.p, cx->col_ref.p, cx->key_off.p};
         void* dst[7] = {lite->key_str_off.data(), sb ? &lite->key_str[0] : nullptr, lite->key_meta.data(), lite->key_group.data(), lite->col_pos.data(),
                         lite->col_ref.data(), lite->key_off.data()};
-        size_t off[7], total = 0;
+        size_t off[7], total = 256;                            // (the flags came down into the first bytes of the same buffer)
         for (int i = 0; i < 7; ++i) { off[i] = total; total += (bytes[i] + 63) / 64 * 64; }
-        if ((rc = cx->pin(&cx->h_stage, &cx->h_stage_cap, total + 64))) return rc;
+        if ((rc = cx->pin(&cx->h_stage, &cx->h_stage_cap, total + 64))) return rc;         // (may move the buffer: nothing is in flight into it)
         char* hs = static_cast<char*>(cx->h_stage);
+        const TokFlags* hf2 = reinterpret_cast<const TokFlags*>(hs);
+        // slow (a quality character out of range, a separator out of place) and bad_order come down with the tables
+        CTO_HIP(hipMemcpyAsync(hs, fl, sizeof(TokFlags), hipMemcpyDeviceToHost, s));
         for (int i = 0; i < 7; ++i)
             if (bytes[i]) CTO_HIP(hipMemcpyAsync(hs + off[i], src[i], bytes[i], hipMemcpyDeviceToHost, s));
         if ((rc = cx->wait(s))) return rc;
+        if (hf2->slow || hf2->bad_order) { *fallback = 1; return CTO_OK; }
         for (int i = 0; i < 7; ++i)
             if (bytes[i]) memcpy(dst[i], hs + off[i], bytes[i]);
     }

@@ -10,16 +10,6 @@ from conftest import load_json_gz
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["lanes", "waves"])
-def tokeniser_form(request, monkeypatch):
-    """every test runs on both forms of the row kernels: a lane per row (default) and a wavefront per row (CTO_TOK_WAVES=1)"""
-    if request.param == "waves":
-        monkeypatch.setenv("CTO_TOK_WAVES", "1")
-    else:
-        monkeypatch.delenv("CTO_TOK_WAVES", raising=False)
-    return request.param
-
-
 @pytest.fixture(scope="module")
 def dev():
     import torch
@@ -112,11 +102,28 @@ def test_what_the_single_pass_declines_falls_back(dev):
                 ok + "\n",                                           # an empty row
                 "chr1\t10\tN\t1\tA\tI\t]\nchr1\t9\tN\t1\tA\tI\t]\n",   # rows out of order
                 "chr1\t5000\tN\t1\tA\tI\t]\n",                      # outside the reference slice
-                "chr1\t10\tN\t40\t" + "A+1c" * 40 + "\t" + "I" * 40 + "\t" + "]" * 40 + "\n",     # 40 indel carriers in a row
+                "chr1\t10\tN\t300\t" + "A+1c" * 300 + "\t" + "I" * 300 + "\t" + "]" * 300 + "\n",     # 300 indel carriers in a row (the limit is 256)
                 ""):
         assert tok(bad, ref, 1) is None, repr(bad[:60])
     # ... and the context is still good afterwards
     assert tok(ok, ref, 1) is not None
+
+
+def test_rows_with_many_indel_carriers(dev):
+    """round 6: a row's indel tokens are a chain of records in HBM, not a lane's private array - 40 carriers in a row (the old form declined
+    more than 32), 200 carriers with a dozen distinct keys in both cases and on both strands, doubled annotations, over-long ones"""
+    ref = "ACGT" * 200
+    rng = np.random.default_rng(11)
+    rows = []
+    for pos, n in ((10, 40), (11, 200), (12, 3), (13, 256)):
+        toks = []
+        for i in range(n):
+            b = "ACGTacgt*#"[int(rng.integers(0, 10))]
+            k = int(rng.integers(0, 6))
+            t = b + ("", "+1c", "-2at", "+3GGT", "+1c-1g", "+61" + "a" * 61)[k] if b not in "*#" or k in (0, 1, 3) else b
+            toks.append(t)
+        rows.append("chr1\t%d\tN\t%d\t%s\t%s\t%s\n" % (pos, n, "".join(toks), "I" * n, "]" * n))
+    _same_pack("".join(rows), ref, 1)
 
 
 def test_tensors_from_a_device_tokenised_pack(dev, golden_region):
