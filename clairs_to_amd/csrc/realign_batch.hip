@@ -187,23 +187,50 @@ constexpr int kBias = 6, kGapO = 8, kGapE = 2;
 
 // LDS of a row, lane-private and contiguous: lane l owns stripe positions j = 0 .. seg-1 at [l * SP + j] of every array (SP = the
 // launch's largest seg rounded up to 16 positions, an odd multiple of 8 so that the lanes' 16-byte reads fall on different banks):
-//   prof [5][LW][SP] signed bytes   the query profile of SSW (ssw.c:64-116): score of reference code c against the lane's positions
-//                                   (4 / -6, 0 on padding), so a column reads 8 scores with one ds_read_b64 and compares nothing
-//   H0, H1, E [LW][SP] shorts       the two H columns and E; 8 positions = one ds_read_b128
+//   P [LW][SP] shorts    the query profile of SSW (ssw.c:64-116) as one 16-bit word per position: five 3-bit fields f, one per
+//                        reference code (field 4: a reference base that matches nothing), score = 2 f - 6, i.e. f = 5 match (4), 0
+//                        mismatch (-6), 3 padding (0) - a column picks its field with one bit-field extract per position
+//   H, E [LW][SP] shorts the H column - ONE array, updated in place: the old value of a position is the next position's diagonal and is
+//                        read before the new one is written - and E; 8 positions = one ds_read_b128
+// 6 bytes per stripe position.  Round 5 kept five signed-byte profile planes and two H columns, 11 bytes: the LDS footprint is what
+// bounds the number of resident wavefronts of the long classes (a 590-base haplotype against its reference, four to a wavefront: 31 KB,
+// five wavefronts per CU - one per SIMD, which then runs a dependent chain at 7-9 clocks per instruction with nothing to overlap it).
 // A lane never touches another lane's entries: lanes meet in DPP shifts and row reductions only, and there is no barrier inside a pass.
 __host__ __device__ inline int sw_sp(int segcap) { int sp = (segcap + 15) / 16 * 16; if (((sp / 8) & 1) == 0) sp += 8; return sp; }
 // (the operands themselves stay in HBM: a pass reads one reference code per column, two columns ahead of its use, and the query once,
 // when the profile is built)
-__host__ __device__ inline size_t sw_row_bytes(int segcap, int LW) { return size_t(sw_sp(segcap)) * LW * (5 + 3 * sizeof(short)); }
+__host__ __device__ inline size_t sw_row_bytes(int segcap, int LW) { return size_t(sw_sp(segcap)) * LW * (3 * sizeof(short)); }
+
+// The rows' arrays are addressed as LDS explicitly (address space 3): row_pass is a function of its own, and through generic pointers its
+// reads and writes were FLAT instructions - an address-space check and the global path's latency in front of every LDS access, on the
+// critical path of every group of positions (round 5's kernels: 13 clocks per instruction for a wavefront alone on its SIMD).
+typedef __attribute__((address_space(3))) short* lds_i16;
+typedef __attribute__((address_space(3))) unsigned short* lds_u16;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <class P> __device__ __forceinline__ u32x4 lds_ld16(P p) { return *(const __attribute__((address_space(3))) u32x4*)p; }
+template <class P> __device__ __forceinline__ u32x2 lds_ld8(P p) { return *(const __attribute__((address_space(3))) u32x2*)p; }
+template <class P> __device__ __forceinline__ unsigned lds_ld4(P p) { return *(const __attribute__((address_space(3))) unsigned*)p; }
+template <class P> __device__ __forceinline__ void lds_st16(P p, unsigned a, unsigned b, unsigned c, unsigned d) {
+    u32x4 v; v.x = a; v.y = b; v.z = c; v.w = d;
+    *(__attribute__((address_space(3))) u32x4*)p = v;
+}
+template <class P> __device__ __forceinline__ void lds_st8(P p, unsigned a, unsigned b) {
+    u32x2 v; v.x = a; v.y = b;
+    *(__attribute__((address_space(3))) u32x2*)p = v;
+}
+template <class P> __device__ __forceinline__ void lds_st4(P p, unsigned a) { *(__attribute__((address_space(3))) unsigned*)p = a; }
 
 // `rev_from` >= 0: the query is qraw[rev_from], qraw[rev_from - 1], ... (the reversed prefix of the backward pass)
 template <int LW>
-__device__ __forceinline__ void build_profile(signed char* prof, const signed char* qraw, int Q, int seg, int SP, int l, int rev_from) {
+__device__ __forceinline__ void build_profile(lds_u16 prof, const signed char* qraw, int Q, int seg, int SP, int l, int rev_from) {
     for (int j = 0; j < SP; ++j) {
         const int q = l * seg + j;
         const int c = (j < seg && q < Q) ? int(rev_from >= 0 ? qraw[rev_from - q] : qraw[q]) : 7;
+        unsigned w = 0u;
 #pragma unroll
-        for (int rc = 0; rc < 5; ++rc) prof[(rc * LW + l) * SP + j] = static_cast<signed char>(c == 7 ? 0 : ((c == rc && rc < 4) ? 4 : -6));
+        for (int rc = 0; rc < 5; ++rc) w |= (c == 7 ? 3u : ((c == rc && rc < 4) ? 5u : 0u)) << (3 * rc);
+        prof[l * SP + j] = static_cast<unsigned short>(w);
     }
 }
 
@@ -239,18 +266,15 @@ __device__ __forceinline__ int row_shl(int v, int l) {
 // it (two packed instructions per pair of positions), the column maximum is max(main-loop maximum, Fin) since the correction is
 // largest at j = 0, and the search for the best cell corrects on the fly as well.  E never sees the corrections, as in the reference.
 template <bool BYTE>
-__device__ RowPass row_pass(const signed char* refc, int r_begin, int r_end, int r_step, const signed char* prof, int Q, int seg, int SP,
-                            short* H0, short* H1, short* E, int terminate, int l) {
+__device__ RowPass row_pass(const signed char* refc, int r_begin, int r_end, int r_step, lds_u16 prof, int Q, int seg, int SP,
+                            lds_i16 Hc, lds_i16 E, int terminate, int l) {
     constexpr int LW = BYTE ? 16 : 8;
     const int lb = l * SP;
     {
-        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-        for (int j = 0; j < SP; j += 8) {
-            *reinterpret_cast<uint4*>(H0 + lb + j) = z; *reinterpret_cast<uint4*>(H1 + lb + j) = z; *reinterpret_cast<uint4*>(E + lb + j) = z;
-        }
+        for (int j = 0; j < SP; j += 8) { lds_st16(Hc + lb + j, 0u, 0u, 0u, 0u); lds_st16(E + lb + j, 0u, 0u, 0u, 0u); }
     }
-    short* store = H0;
-    short* load = H1;
+    const lds_i16 store = Hc;           // the column being written ...
+    const lds_i16 load = Hc;            // ... over the one before it (read first, position by position)
     int best = 0, ref_end = BYTE ? -1 : 0, best_q = 0x7fffffff;
     bool overflow = false;
     int fin = 0;                                     // Fin of the column in `store` (the last one written)
@@ -260,84 +284,118 @@ __device__ RowPass row_pass(const signed char* refc, int r_begin, int r_end, int
     int col = 0;
     for (int i = r_begin; i != r_end; i += r_step, ++col) {
         const int rc_next2 = col + 2 < n_col ? refc[i + 2 * r_step] : 0;       // from HBM, two columns ahead of its use
-        int f = 0, colmax = 0;
+        int f = 0, colmax = 0, garg = 0;                       // garg: the first group of eight whose maximum is the lane's
         int h = row_shl1<LW>(max(int(store[lb + seg - 1]), max(fin - kGapE * (seg - 1), 0)), l);
-        { short* t = store; store = load; load = t; }          // load = column i - 1 (as its main loop left it; `fin` completes it), store = column i
-        const signed char* pr = prof + ((unsigned(rc) < 4u ? rc : 4) * LW + l) * SP;      // plane 4: matches nothing
+        // (the array holds column i - 1 as its main loop left it - `fin` completes it - and becomes column i group by group)
+        const lds_u16 pr = prof + lb;
+        const int sh0 = 3 * (unsigned(rc) < 4u ? rc : 4), sh1 = sh0 + 16;                // field 4: matches nothing
         int fg = fin;                                          // Fin - ext * j0
-        auto group = [&](int j0, auto is_tail) {
+        // G = positions a call handles: 8, or - for what is left of a stripe behind its last full eight, which for a short query is the
+        // whole stripe - 4 or 2.  (A 30-base read on 16 lanes is 2 positions per lane: as a predicated group of eight, three quarters of the
+        // column's instructions computed nothing, and half of the batch's alignments are such reads - the stage is bound by instruction issue.)
+        auto group = [&](int j0, auto g_const, auto is_tail) {
+            constexpr int G = decltype(g_const)::value;
             constexpr bool TAIL = decltype(is_tail)::value;
-            const uint4 e8 = *reinterpret_cast<const uint4*>(E + lb + j0);
-            const uint4 h8 = *reinterpret_cast<const uint4*>(load + lb + j0);
-            const uint2 p8 = *reinterpret_cast<const uint2*>(pr + j0);
-            const unsigned ew[4] = {e8.x, e8.y, e8.z, e8.w}, pw[2] = {p8.x, p8.y};
+            unsigned ew[4] = {0u, 0u, 0u, 0u}, hw[4] = {0u, 0u, 0u, 0u}, pw[4] = {0u, 0u, 0u, 0u};
+            if (G == 8) {
+                const u32x4 e8 = lds_ld16(E + lb + j0), h8 = lds_ld16(load + lb + j0), p8 = lds_ld16(pr + j0);
+                ew[0] = e8.x; ew[1] = e8.y; ew[2] = e8.z; ew[3] = e8.w;
+                hw[0] = h8.x; hw[1] = h8.y; hw[2] = h8.z; hw[3] = h8.w;
+                pw[0] = p8.x; pw[1] = p8.y; pw[2] = p8.z; pw[3] = p8.w;
+            } else if (G == 4) {
+                const u32x2 e4 = lds_ld8(E + lb + j0), h4 = lds_ld8(load + lb + j0), p4 = lds_ld8(pr + j0);
+                ew[0] = e4.x; ew[1] = e4.y; hw[0] = h4.x; hw[1] = h4.y; pw[0] = p4.x; pw[1] = p4.y;
+            } else {
+                ew[0] = lds_ld4(E + lb + j0);
+                hw[0] = lds_ld4(load + lb + j0);
+                pw[0] = lds_ld4(pr + j0);
+            }
             const unsigned fg2 = pk2(fg, fg);
-            unsigned hw[4] = {h8.x, h8.y, h8.z, h8.w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) hw[k] = pk_max(hw[k], pk_subs(fg2, pk2(kGapE * 2 * k, kGapE * (2 * k + 1))));
-            fg = max(fg - kGapE * 8, 0);
+            for (int k = 0; k < G / 2; ++k) hw[k] = pk_max(hw[k], pk_subs(fg2, pk2(kGapE * 2 * k, kGapE * (2 * k + 1))));
+            fg = max(fg - kGapE * G, 0);
             unsigned sw[4] = {0u, 0u, 0u, 0u}, nw[4] = {ew[0], ew[1], ew[2], ew[3]};
-            // Three sweeps over the eight positions instead of one chain through all of them.  With t = max(diagonal + score, e) - which
+            // Three sweeps over the positions instead of one chain through all of them.  With t = max(diagonal + score, e) - which
             // does not depend on F - the recurrence of a position is h = max(t, f), f' = max(f - ext, max(h - open, 0)) =
             // max(f - ext, max(t - open, 0)) (f - open < f - ext): only TWO dependent operations per position carry F along; t before
-            // and h, E, the column maximum after are independent across the eight positions.  (Measured: 15.1-15.4 ms for the bench batch
-            // against 15.5 with one chain through all eight - the stage is not bound by dependent-issue latency; PMC: ~7 clocks per VALU
-            // instruction of a wavefront, the time of a class is its longest alignment's chain next to the other classes' waves.)
-            int t[8], u[8], ev[8], fv[8];
+            // and h, E, the column maximum after are independent across the positions.  (Measured: 15.1-15.4 ms for the bench batch
+            // against 15.5 with one chain through all eight.)
+            int t[G], u[G], ev[G], fv[G];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
+            for (int c = 0; c < G; ++c) {
                 ev[c] = int((ew[c >> 1] >> (16 * (c & 1))) & 0xffffu);
-                const int sc = int(pw[c >> 2] << (24 - 8 * (c & 3))) >> 24;      // signed byte c
+                const int f2 = int(__builtin_amdgcn_ubfe(pw[c >> 1], unsigned((c & 1) ? sh1 : sh0), 3u)) * 2;      // score + 6 (= score + bias)
                 int x;
-                if (BYTE) x = max(min(h + sc + kBias, 255) - kBias, 0);
-                else x = min(h + sc, 32767);
+                static_assert(kBias == 6, "the profile's fields hold (score + 6) / 2");
+                if (BYTE) x = max(min(h + f2, 255) - kBias, 0);
+                else x = min(h + f2 - 6, 32767);
                 t[c] = max(x, ev[c]);
                 u[c] = max(t[c] - kGapO, 0);
                 h = int((hw[c >> 1] >> (16 * (c & 1))) & 0xffffu);            // the diagonal of the next position
             }
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
+            for (int c = 0; c < G; ++c) {
                 fv[c] = f;
                 if (!TAIL || j0 + c < seg) f = max(f - kGapE, u[c]);
             }
+            int gm = 0;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
+            for (int c = 0; c < G; ++c) {
                 if (!TAIL || j0 + c < seg) {
                     const int hh = max(t[c], fv[c]);
-                    colmax = max(colmax, hh);
+                    gm = max(gm, hh);
                     const int en = max(max(ev[c] - kGapE, 0), max(hh - kGapO, 0));            // E never sees the lazy-F corrections
                     if (c & 1) { sw[c >> 1] |= unsigned(hh) << 16; nw[c >> 1] = (nw[c >> 1] & 0xffffu) | (unsigned(en) << 16); }
                     else { sw[c >> 1] = unsigned(hh) & 0xffffu; nw[c >> 1] = (nw[c >> 1] & 0xffff0000u) | unsigned(en); }
                 }
             }
-            *reinterpret_cast<uint4*>(store + lb + j0) = make_uint4(sw[0], sw[1], sw[2], sw[3]);
-            *reinterpret_cast<uint4*>(E + lb + j0) = make_uint4(nw[0], nw[1], nw[2], nw[3]);
+            if (gm > colmax) { colmax = gm; garg = j0; }
+            if (G == 8) {
+                lds_st16(store + lb + j0, sw[0], sw[1], sw[2], sw[3]);
+                lds_st16(E + lb + j0, nw[0], nw[1], nw[2], nw[3]);
+            } else if (G == 4) {
+                lds_st8(store + lb + j0, sw[0], sw[1]);
+                lds_st8(E + lb + j0, nw[0], nw[1]);
+            } else {
+                lds_st4(store + lb + j0, sw[0]);
+                lds_st4(E + lb + j0, nw[0]);
+            }
         };
         int j0 = 0;
-        for (; j0 + 8 <= seg; j0 += 8) group(j0, std::false_type{});
-        if (j0 < seg) group(j0, std::true_type{});
+        for (; j0 + 8 <= seg; j0 += 8) group(j0, std::integral_constant<int, 8>{}, std::false_type{});
+        {
+            const int left = seg - j0;                         // 0 .. 7 (wave-uniform per row only through seg: lanes of a wavefront's rows may differ)
+            if (left > 4) group(j0, std::integral_constant<int, 8>{}, std::true_type{});
+            else if (left > 2) group(j0, std::integral_constant<int, 4>{}, std::true_type{});
+            else if (left > 0) group(j0, std::integral_constant<int, 2>{}, std::true_type{});
+        }
         // Fin of this column: lane l - 1's outgoing F, or an earlier lane's after whole stripes of decay
         fin = row_shl1<LW>(f, l);
         fin = max(fin, max(row_shl<LW, 1>(fin, l) - D, 0));
         fin = max(fin, max(row_shl<LW, 2>(fin, l) - 2 * D, 0));
         fin = max(fin, max(row_shl<LW, 4>(fin, l) - 4 * D, 0));
         if (LW == 16) fin = max(fin, max(row_shl<LW, 8>(fin, l) - 8 * D, 0));
+        const int lane_max = colmax;                       // of the main loop's values of this lane's stripe
         colmax = row_max<LW>(max(colmax, fin));
         if (colmax > best) {
             best = colmax;
             if (BYTE && best + kBias >= 255) { overflow = true; break; }
             ref_end = i;
-            int mq = 0x7fffffff;            // smallest linear query position that holds the new maximum
-            const unsigned bb = pk2(best, best);
-            int fs = fin;
-            for (int s0 = 0; s0 < seg && mq == 0x7fffffff; s0 += 8) {
-                const uint4 a8 = *reinterpret_cast<const uint4*>(store + lb + s0);
+            // the smallest linear query position that holds the new maximum.  In a lane that is position 0 when its Fin is the maximum (the
+            // correction Fin - ext * j is largest there and cannot reach the maximum anywhere else), otherwise a position of the FIRST group
+            // of eight whose main-loop maximum is the lane's - the groups before it stay below it - and of no group when the lane's maximum
+            // is not the row's.  One group per lane: a haplotype against its reference sets a new maximum in nearly every column, and a
+            // search through the whole stripe was a third of the pass's instructions.
+            int mq = 0x7fffffff;
+            if (fin == best) mq = l * seg;
+            else if (lane_max == best) {
+                const unsigned bb = pk2(best, best);
+                const int s0 = garg;
+                const u32x4 a8 = lds_ld16(store + lb + s0);
                 const unsigned sv[4] = {a8.x, a8.y, a8.z, a8.w};
-                const unsigned fs2 = pk2(fs, fs);
-                fs = max(fs - kGapE * 8, 0);
 #pragma unroll
                 for (int k = 3; k >= 0; --k) {
-                    const unsigned x = pk_max(sv[k], pk_subs(fs2, pk2(kGapE * 2 * k, kGapE * (2 * k + 1)))) ^ bb;
+                    const unsigned x = sv[k] ^ bb;
                     if (s0 + 2 * k + 1 < seg && (x >> 16) == 0u) mq = l * seg + s0 + 2 * k + 1;
                     if (s0 + 2 * k < seg && (x & 0xffffu) == 0u) mq = l * seg + s0 + 2 * k;
                 }
@@ -362,13 +420,16 @@ __global__ __launch_bounds__(64) void k_sw(const signed char* pool, const SwDesc
     const int slot = blockIdx.x * (blockDim.x / LW) + row;
     bool live = slot < n;
     const int k = live ? order[slot] : 0;
-    if (!BYTE && live && !overflowed[k]) live = false;        // the 16-bit kernel takes only what the 8-bit pass gave up on
+    // the 16-bit kernel takes only what the 8-bit pass gave up on.  (Round 6 tried the dense form - the 8-bit launch appends the alignments
+    // that overflow to a list, the 16-bit launch runs full wavefronts over it: 10.3 -> 12.0 ms.  A wavefront lasts as long as its longest row
+    // whether four or eight of its rows are live, so the list halves the number of wavefronts that share the work and loses the
+    // longest-first order on top.)
+    if (!BYTE && live && !overflowed[k]) live = false;
     const int SP = sw_sp(segcap);
     unsigned char* base = lds + size_t(row) * ((sw_row_bytes(segcap, LW) + 15) / 16 * 16);
-    short* H0 = reinterpret_cast<short*>(base);
-    short* H1 = H0 + size_t(SP) * LW;
-    short* E = H1 + size_t(SP) * LW;
-    signed char* prof = reinterpret_cast<signed char*>(E + size_t(SP) * LW);
+    const lds_i16 Hc = (lds_i16)base;
+    const lds_i16 E = Hc + SP * LW;
+    const lds_u16 prof = (lds_u16)(E + SP * LW);
     if (!live) return;
     const SwDesc d = desc[k];
     const signed char* refc = pool + d.ref_off;
@@ -378,12 +439,12 @@ __global__ __launch_bounds__(64) void k_sw(const signed char* pool, const SwDesc
     if (d.R > 0 && d.Q > 0) {
         const int seg = (d.Q + LW - 1) / LW;
         build_profile<LW>(prof, qraw, d.Q, seg, SP, l, -1);
-        const RowPass fw = row_pass<BYTE>(refc, 0, d.R, 1, prof, d.Q, seg, SP, H0, H1, E, BYTE ? 255 : 65535, l);
+        const RowPass fw = row_pass<BYTE>(refc, 0, d.R, 1, prof, d.Q, seg, SP, Hc, E, BYTE ? 255 : 65535, l);
         if (BYTE && fw.overflow) ovf = true;
         else if (fw.score > 0) {
             const int Q2 = fw.read_end + 1, seg2 = (Q2 + LW - 1) / LW;
             build_profile<LW>(prof, qraw, Q2, seg2, SP, l, fw.read_end);
-            const RowPass bw = row_pass<BYTE>(refc, fw.ref_end, -1, -1, prof, Q2, seg2, SP, H0, H1, E, fw.score, l);
+            const RowPass bw = row_pass<BYTE>(refc, fw.ref_end, -1, -1, prof, Q2, seg2, SP, Hc, E, fw.score, l);
             e = Ends{fw.score, fw.ref_end, fw.read_end, bw.ref_end, bw.read_end, LW};
         }
     }
@@ -693,12 +754,13 @@ int launch_sw(hipStream_t s, const signed char* pool, const SwDesc* desc, const 
     if (n == 0) return CTO_OK;
     constexpr int LW = BYTE ? 16 : 8;
     // A pass is a chain of dependent steps: a wavefront runs it at the pace of ONE row whatever the number of rows it holds, so a
-    // class with few alignments (the haplotype-length one: ~2 500 of the bench's batch) spreads them over more wavefronts - rows per
-    // wavefront halve until the class has 512 wavefronts (CTO_SW_MIN_WAVES) or one row per wavefront.  Not further: the classes run
-    // side by side and together keep every SIMD busy, where a wavefront with idle lanes costs the others its issue slots (measured
-    // on the bench batch: 0 -> 17.4 ms, 256 / 512 -> 15.5, 1 024 -> 17.3, 2 048 -> 24.5)
+    // class with few alignments (the haplotype-length one: ~2 500 of the bench's batch) can spread them over more wavefronts - rows per
+    // wavefront halve until the class has CTO_SW_MIN_WAVES wavefronts or one row per wavefront.  Round 5 measured 0 -> 17.4 ms, 256 / 512
+    // -> 15.5, 1 024 -> 17.3, 2 048 -> 24.5 and used 512.  Round 6, after the best-cell search stopped re-reading the whole stripe in
+    // every column of a matching pair (the longest class's 16-bit launch: 10.6 -> 7.0 ms), the stage is bound by instruction issue and a
+    // wavefront with idle lanes costs the others its slots: 0 -> 10.1-10.3 ms, 256 -> 10.9, 512 -> 11.2 - full wavefronts are the default
     int ROWS = 64 / LW;
-    static const int min_waves = std::getenv("CTO_SW_MIN_WAVES") ? atoi(std::getenv("CTO_SW_MIN_WAVES")) : 512;
+    static const int min_waves = std::getenv("CTO_SW_MIN_WAVES") ? atoi(std::getenv("CTO_SW_MIN_WAVES")) : 0;
     while (ROWS > 1 && (n + ROWS - 1) / ROWS < min_waves) ROWS /= 2;
     (void)Rcap;
     Qcap = (Qcap + 15) & ~15;
