@@ -288,7 +288,7 @@ __device__ RowPass row_pass(const signed char* refc, int r_begin, int r_end, int
         int h = row_shl1<LW>(max(int(store[lb + seg - 1]), max(fin - kGapE * (seg - 1), 0)), l);
         // (the array holds column i - 1 as its main loop left it - `fin` completes it - and becomes column i group by group)
         const lds_u16 pr = prof + lb;
-        const int sh0 = 3 * (unsigned(rc) < 4u ? rc : 4), sh1 = sh0 + 16;                // field 4: matches nothing
+        const int sh0 = 3 * (unsigned(rc) < 4u ? rc : 4);                                // field 4: matches nothing
         int fg = fin;                                          // Fin - ext * j0
         // G = positions a call handles: 8, or - for what is left of a stripe behind its last full eight, which for a short query is the
         // whole stripe - 4 or 2.  (A 30-base read on 16 lanes is 2 positions per lane: as a predicated group of eight, three quarters of the
@@ -314,41 +314,54 @@ __device__ RowPass row_pass(const signed char* refc, int r_begin, int r_end, int
 #pragma unroll
             for (int k = 0; k < G / 2; ++k) hw[k] = pk_max(hw[k], pk_subs(fg2, pk2(kGapE * 2 * k, kGapE * (2 * k + 1))));
             fg = max(fg - kGapE * G, 0);
+            // Two positions to an instruction wherever the recurrence allows it.  With t = max(diagonal + score, e) - which does not depend on
+            // F - a position is h = max(t, f), f' = max(f - ext, max(h - open, 0)) = max(f - ext, max(t - open, 0)) (f - open < f - ext): only
+            // the two operations that carry F from position to position are a chain; the diagonal, the score, t, u = max(t - open, 0) before it
+            // and h, the new E, the group's maximum after it work on the PAIRS of 16-bit values the arrays hold anyway (v_pk_*: SSE2's own
+            // operations - all values here are 0 .. 32 767, saturating adds and subtractions as in ssw.c).  Round 5 unpacked every position into
+            // a 32-bit register: ~17 vector instructions per position, ~10 now.
             unsigned sw[4] = {0u, 0u, 0u, 0u}, nw[4] = {ew[0], ew[1], ew[2], ew[3]};
-            // Three sweeps over the positions instead of one chain through all of them.  With t = max(diagonal + score, e) - which
-            // does not depend on F - the recurrence of a position is h = max(t, f), f' = max(f - ext, max(h - open, 0)) =
-            // max(f - ext, max(t - open, 0)) (f - open < f - ext): only TWO dependent operations per position carry F along; t before
-            // and h, E, the column maximum after are independent across the positions.  (Measured: 15.1-15.4 ms for the bench batch
-            // against 15.5 with one chain through all eight.)
-            int t[G], u[G], ev[G], fv[G];
+            unsigned tp[G / 2], up[G / 2];
+            const unsigned shv = unsigned(sh0);
 #pragma unroll
-            for (int c = 0; c < G; ++c) {
-                ev[c] = int((ew[c >> 1] >> (16 * (c & 1))) & 0xffffu);
-                const int f2 = int(__builtin_amdgcn_ubfe(pw[c >> 1], unsigned((c & 1) ? sh1 : sh0), 3u)) * 2;      // score + 6 (= score + bias)
-                int x;
-                static_assert(kBias == 6, "the profile's fields hold (score + 6) / 2");
-                if (BYTE) x = max(min(h + f2, 255) - kBias, 0);
-                else x = min(h + f2 - 6, 32767);
-                t[c] = max(x, ev[c]);
-                u[c] = max(t[c] - kGapO, 0);
-                h = int((hw[c >> 1] >> (16 * (c & 1))) & 0xffffu);            // the diagonal of the next position
-            }
-#pragma unroll
-            for (int c = 0; c < G; ++c) {
-                fv[c] = f;
-                if (!TAIL || j0 + c < seg) f = max(f - kGapE, u[c]);
-            }
-            int gm = 0;
-#pragma unroll
-            for (int c = 0; c < G; ++c) {
-                if (!TAIL || j0 + c < seg) {
-                    const int hh = max(t[c], fv[c]);
-                    gm = max(gm, hh);
-                    const int en = max(max(ev[c] - kGapE, 0), max(hh - kGapO, 0));            // E never sees the lazy-F corrections
-                    if (c & 1) { sw[c >> 1] |= unsigned(hh) << 16; nw[c >> 1] = (nw[c >> 1] & 0xffffu) | (unsigned(en) << 16); }
-                    else { sw[c >> 1] = unsigned(hh) & 0xffffu; nw[c >> 1] = (nw[c >> 1] & 0xffff0000u) | unsigned(en); }
+            for (int k = 0; k < G / 2; ++k) {
+                // the diagonals of positions 2k, 2k + 1: the old (corrected) H of 2k - 1 and 2k
+                const unsigned dg = k == 0 ? ((unsigned(h) & 0xffffu) | (hw[0] << 16)) : __builtin_amdgcn_alignbit(hw[k], hw[k - 1], 16);
+                const unsigned fld = (pw[k] >> shv) & 0x00070007u;                 // (score + 6) / 2 of both
+                unsigned x;
+                static_assert(kBias == 6, "the profile's fields hold (score + bias) / 2");
+                if (BYTE) {
+                    const u16x2 s2 = __builtin_bit_cast(u16x2, dg) + __builtin_bit_cast(u16x2, fld) * (unsigned short)2;       // h + score + bias
+                    x = pk_subs(__builtin_bit_cast(unsigned, __builtin_elementwise_min(s2, (u16x2){255, 255})), pk2(kBias, kBias));
+                } else {
+                    const i16x2 sc = __builtin_bit_cast(i16x2, fld) * (short)2 - (short)6;
+                    x = __builtin_bit_cast(unsigned, __builtin_elementwise_add_sat(__builtin_bit_cast(i16x2, dg), sc));
                 }
+                tp[k] = pk_max(x, ew[k]);
+                up[k] = pk_subs(tp[k], pk2(kGapO, kGapO));
             }
+            h = int(hw[G / 2 - 1] >> 16);                                          // the diagonal of the next group's first position
+            int gm = 0;
+            unsigned gm2 = 0u;
+#pragma unroll
+            for (int k = 0; k < G / 2; ++k) {
+                const bool v0 = !TAIL || j0 + 2 * k < seg, v1 = !TAIL || j0 + 2 * k + 1 < seg;
+                const int f0 = f;
+                if (v0) f = max(f - kGapE, int(up[k] & 0xffffu));
+                const int f1 = f;
+                if (v1) f = max(f - kGapE, int(up[k] >> 16));
+                unsigned hh = pk_max(tp[k], pk2(f0, f1));
+                unsigned en = pk_max(pk_subs(ew[k], pk2(kGapE, kGapE)), pk_subs(hh, pk2(kGapO, kGapO)));            // E never sees the lazy-F corrections
+                if (TAIL) {
+                    const unsigned m = (v0 ? 0xffffu : 0u) | (v1 ? 0xffff0000u : 0u);
+                    hh &= m;
+                    en = (en & m) | (ew[k] & ~m);
+                }
+                gm2 = pk_max(gm2, hh);
+                sw[k] = hh;
+                nw[k] = en;
+            }
+            gm = max(int(gm2 & 0xffffu), int(gm2 >> 16));
             if (gm > colmax) { colmax = gm; garg = j0; }
             if (G == 8) {
                 lds_st16(store + lb + j0, sw[0], sw[1], sw[2], sw[3]);
@@ -857,14 +870,22 @@ int sw_ends_pool(const PoolVec& pool, const std::vector<SwDesc>& desc, hipStream
     CTO_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
     CTO_HIP(hipEventRecord(e0, s));
     CTO_HIP(hipEventRecord(fork, s));
-    int made = 0;
+    int made = 0, used = 0;
     rc = CTO_OK;
+    // at most FOUR streams: the runtime has four hardware queues for a process's streams, and a fifth stream shares one - its launches then
+    // wait behind another class's two launches instead of running beside them (measured: the two shortest classes started when the longest
+    // one's 16-bit launch ended, 3 ms of the stage's 8.5).  The three longest classes get a stream each, the others follow one another on the fourth.
+    constexpr int kStreams = 4;
     for (int c = kClasses - 1; c >= 0 && rc == CTO_OK; --c) {
         if (cls[c].empty()) continue;
-        if (hipStreamCreateWithFlags(&sx[made], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&join[made], hipEventDisableTiming) != hipSuccess) { rc = CTO_EHIP; break; }
-        hipStream_t t = sx[made];
-        ++made;
-        if (hipStreamWaitEvent(t, fork, 0) != hipSuccess) { rc = CTO_EHIP; break; }
+        const bool own = used < kStreams;
+        if (own) {
+            if (hipStreamCreateWithFlags(&sx[made], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&join[made], hipEventDisableTiming) != hipSuccess) { rc = CTO_EHIP; break; }
+            ++made;
+            if (hipStreamWaitEvent(sx[made - 1], fork, 0) != hipSuccess) { rc = CTO_EHIP; break; }
+        }
+        ++used;
+        hipStream_t t = sx[made - 1];
         const int m = int(cls[c].size());
         if ((rc = launch_sw<true>(t, d_pool.p, d_desc.p, d_order.p + at[c], m, d_out.p, d_ovf.p, Rc[c], Qc[c])) ||
             (rc = launch_sw<false>(t, d_pool.p, d_desc.p, d_order.p + at[c], m, d_out.p, d_ovf.p, Rc[c], Qc[c])))
