@@ -24,8 +24,11 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <pthread.h>
+#include <condition_variable>
 #include <cstring>
 #include <exception>
+#include <functional>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -617,6 +620,62 @@ struct DevBuf {
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// Worker threads that outlive a call.  A call runs a dozen parallel loops over its windows (packing, collecting pairs, filing results,
+// planning and composing tracebacks) of a millisecond or less each; as std::threads created and joined per loop, sixteen at a time, the
+// creation alone was a third of a millisecond per loop.  The pool is made once (grown on demand, never destroyed: its threads sleep on a
+// condition variable and end with the process); one call at a time uses it, a concurrent one falls back to threads of its own.
+class WorkerPool {
+    std::mutex m;
+    std::condition_variable cv_start, cv_done;
+    std::vector<std::thread> th;
+    const std::function<void()>* job = nullptr;
+    unsigned long long gen = 0;
+    int want = 0, pending = 0;
+    void worker(int id) {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void()>* mine = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_start.wait(lk, [&] { return gen != seen; });
+                seen = gen;
+                if (id < want) mine = job;
+            }
+            if (!mine) continue;
+            (*mine)();
+            std::lock_guard<std::mutex> lk(m);
+            if (--pending == 0) cv_done.notify_all();
+        }
+    }
+public:
+    std::mutex use;                                    // held by the call that runs loops on the pool
+    bool run(int helpers, const std::function<void()>& f) {
+        try {
+            std::lock_guard<std::mutex> lk(m);
+            while (int(th.size()) < helpers) { th.emplace_back(&WorkerPool::worker, this, int(th.size())); th.back().detach(); }
+        } catch (...) {
+            return false;                              // no more threads to be had
+        }
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = &f; want = helpers; pending = helpers; ++gen;
+        }
+        cv_start.notify_all();
+        f();
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return pending == 0; });
+        job = nullptr;
+        return true;
+    }
+    // (a child of fork() has none of the parent's threads: it starts with a pool of its own; the parent's object is left as it is)
+    static WorkerPool*& slot() { static WorkerPool* p = nullptr; return p; }
+    static WorkerPool& get() {
+        static std::once_flag once;
+        std::call_once(once, [] { (void)pthread_atfork(nullptr, nullptr, [] { slot() = new WorkerPool(); }); slot() = new WorkerPool(); });
+        return *slot();
+    }
+};
+
 template <class F>
 void parallel_for(size_t n, int threads, F&& f) {
     // an exception on a worker (std::bad_alloc in a window's vectors) must not reach std::terminate: the first one is kept, every
@@ -625,7 +684,7 @@ void parallel_for(size_t n, int threads, F&& f) {
     std::atomic<bool> failed{false};
     std::exception_ptr first;
     std::mutex first_lock;
-    auto work = [&]() {
+    const std::function<void()> work = [&]() {
         try {
             for (size_t i = next++; i < n && !failed.load(std::memory_order_relaxed); i = next++) f(i);
         } catch (...) {
@@ -635,13 +694,21 @@ void parallel_for(size_t n, int threads, F&& f) {
         }
     };
     const int nt = int(std::min<size_t>(size_t(std::max(1, threads)), n));
-    std::vector<std::thread> pool;
-    try {
-        for (int t = 1; t < nt; ++t) pool.emplace_back(work);
-    } catch (...) {                                   // no more threads to be had: the ones that started and this one do the work
+    bool done = false;
+    if (nt > 1) {
+        WorkerPool& pool = WorkerPool::get();
+        std::unique_lock<std::mutex> mine(pool.use, std::try_to_lock);
+        if (mine.owns_lock()) done = pool.run(nt - 1, work);
     }
-    work();
-    for (std::thread& t : pool) t.join();
+    if (!done) {
+        std::vector<std::thread> own;
+        try {
+            for (int t = 1; t < nt; ++t) own.emplace_back(work);
+        } catch (...) {                               // no more threads to be had: the ones that started and this one do the work
+        }
+        work();
+        for (std::thread& t : own) t.join();
+    }
     if (first) std::rethrow_exception(first);
 }
 
@@ -829,13 +896,15 @@ int sw_ends_pool(const PoolVec& pool, const std::vector<SwDesc>& desc, hipStream
     std::vector<int> order;
     order.reserve(static_cast<size_t>(n));
     size_t at[kClasses + 1] = {};
-    std::vector<unsigned long long> keys;
-    for (int c = 0; c < kClasses; ++c) {
-        CTO_REQUIRE(n < (1 << 24), CTO_EUNSUPPORTED, "cto_realign_windows: more than 16 M alignments in one call; split it");
-        keys.clear();
+    CTO_REQUIRE(n < (1 << 24), CTO_EUNSUPPORTED, "cto_realign_windows: more than 16 M alignments in one call; split it");
+    parallel_for(size_t(kClasses), kClasses, [&](size_t c) {           // the classes' sorts side by side
+        std::vector<unsigned long long> keys;
+        keys.reserve(cls[c].size());
         for (int k : cls[c]) keys.push_back(((((1ull << 40) - 1ull) - (unsigned long long)desc[k].Q * (unsigned long long)desc[k].R) << 24) | (unsigned long long)k);
         std::sort(keys.begin(), keys.end());
         for (size_t i = 0; i < keys.size(); ++i) cls[c][i] = int(keys[i] & 0xffffffull);
+    });
+    for (int c = 0; c < kClasses; ++c) {
         at[c] = order.size();
         order.insert(order.end(), cls[c].begin(), cls[c].end());
     }
@@ -1143,14 +1212,18 @@ int traceback_pool(const signed char* d_pool, const std::vector<TbDesc>& desc, s
     out.clear();
     if (n == 0) return CTO_OK;
     // two classes by the widest band an alignment may reach (the LDS footprint), longest first inside a class
-    std::vector<int> order(static_cast<size_t>(n));
-    for (int k = 0; k < n; ++k) order[size_t(k)] = k;
+    // (one 64-bit key per alignment, sorted as numbers: class bit | (2^38 - 1 - work) << 24 | index - a comparator that looks both
+    // descriptors up took 2 ms for the bench batch's 23 000)
+    CTO_REQUIRE(n < (1 << 24), CTO_EUNSUPPORTED, "cto_realign_windows: more than 16 M tracebacks in one call; split it");
     auto wide = [&](int k) { return desc[size_t(k)].band_cap > 62; };
-    std::sort(order.begin(), order.end(), [&](int a, int b) {
-        if (wide(a) != wide(b)) return wide(a);
-        const long long wa = (long long)desc[size_t(a)].Q * desc[size_t(a)].band, wb = (long long)desc[size_t(b)].Q * desc[size_t(b)].band;
-        return wa != wb ? wa > wb : a < b;
-    });
+    std::vector<unsigned long long> keys(static_cast<size_t>(n));
+    for (int k = 0; k < n; ++k) {
+        const unsigned long long work = std::min<unsigned long long>((unsigned long long)desc[size_t(k)].Q * (unsigned long long)desc[size_t(k)].band, (1ull << 38) - 1ull);
+        keys[size_t(k)] = (wide(k) ? 0ull : 1ull << 63) | ((((1ull << 38) - 1ull) - work) << 24) | (unsigned long long)k;
+    }
+    std::sort(keys.begin(), keys.end());
+    std::vector<int> order(static_cast<size_t>(n));
+    for (int k = 0; k < n; ++k) order[size_t(k)] = int(keys[size_t(k)] & 0xffffffull);
     int n_wide = 0, cap_wide = 0;
     for (int k = 0; k < n; ++k) if (wide(k)) { ++n_wide; cap_wide = std::max(cap_wide, desc[size_t(k)].band_cap); }
     DevBuf<TbDesc> d_desc;
