@@ -865,6 +865,53 @@ int launch_sw(hipStream_t s, const signed char* pool, const SwDesc* desc, const 
     return CTO_OK;
 }
 
+// Side streams kept between calls (per device; one call at a time holds them, a concurrent call makes and destroys its own): creating and
+// destroying four streams and their events cost a call ~1 ms.
+struct SideStreams {
+    static constexpr int kMax = 5;
+    hipStream_t sx[kMax] = {};
+    hipEvent_t join[kMax] = {};
+    int n = 0;
+    bool cached = false;
+    static std::mutex& lock() { static std::mutex m; return m; }
+    struct Kept { hipStream_t sx[kMax]; hipEvent_t join[kMax]; int n = 0; int device = -1; bool busy = false; };
+    static Kept& kept() { static Kept k; return k; }
+    // stream i (made on first use)
+    int get(int i, hipStream_t* out) {
+        if (i >= kMax) return CTO_EINVAL;
+        while (n <= i) {
+            if (hipStreamCreateWithFlags(&sx[n], hipStreamNonBlocking) != hipSuccess) return CTO_EHIP;
+            if (hipEventCreateWithFlags(&join[n], hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(sx[n]); return CTO_EHIP; }
+            ++n;
+        }
+        *out = sx[i];
+        return CTO_OK;
+    }
+    SideStreams() {
+        int dev = -1;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> g(lock());
+        Kept& k = kept();
+        if (!k.busy && (k.device < 0 || k.device == dev)) {
+            k.busy = true; k.device = dev; cached = true;
+            n = k.n;
+            for (int i = 0; i < n; ++i) { sx[i] = k.sx[i]; join[i] = k.join[i]; }
+        }
+    }
+    ~SideStreams() {
+        for (int i = 0; i < n; ++i) (void)hipStreamSynchronize(sx[i]);
+        if (cached) {
+            std::lock_guard<std::mutex> g(lock());
+            Kept& k = kept();
+            k.n = n;
+            for (int i = 0; i < n; ++i) { k.sx[i] = sx[i]; k.join[i] = join[i]; }
+            k.busy = false;
+        } else {
+            for (int i = 0; i < n; ++i) { (void)hipStreamDestroy(sx[i]); (void)hipEventDestroy(join[i]); }
+        }
+    }
+};
+
 // Both passes of every alignment of `desc` (operands = base codes in `pool`): the end points, in desc order
 template <class PoolVec>
 int sw_ends_pool(const PoolVec& pool, const std::vector<SwDesc>& desc, hipStream_t s, cto_realign_stats* st, std::vector<Ends>& ends,
@@ -933,8 +980,8 @@ int sw_ends_pool(const PoolVec& pool, const std::vector<SwDesc>& desc, hipStream
     // 8-bit passes, then the 16-bit passes of what overflowed (same slots, same order: a row without overflow leaves at once).  The
     // classes are independent chains of two launches each and every one ends in a tail (the longest alignment of the class), so each
     // runs on a stream of its own, longest queries first.
-    hipEvent_t e0, e1, fork, join[kClasses];
-    hipStream_t sx[kClasses];
+    hipEvent_t e0, e1, fork;
+    SideStreams side;
     CTO_HIP(hipEventCreate(&e0)); CTO_HIP(hipEventCreate(&e1));
     CTO_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
     CTO_HIP(hipEventRecord(e0, s));
@@ -948,21 +995,21 @@ int sw_ends_pool(const PoolVec& pool, const std::vector<SwDesc>& desc, hipStream
     for (int c = kClasses - 1; c >= 0 && rc == CTO_OK; --c) {
         if (cls[c].empty()) continue;
         const bool own = used < kStreams;
+        hipStream_t t = nullptr;
         if (own) {
-            if (hipStreamCreateWithFlags(&sx[made], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&join[made], hipEventDisableTiming) != hipSuccess) { rc = CTO_EHIP; break; }
+            if ((rc = side.get(made, &t)) != CTO_OK) break;
             ++made;
-            if (hipStreamWaitEvent(sx[made - 1], fork, 0) != hipSuccess) { rc = CTO_EHIP; break; }
-        }
+            if (hipStreamWaitEvent(t, fork, 0) != hipSuccess) { rc = CTO_EHIP; break; }
+        } else if ((rc = side.get(made - 1, &t)) != CTO_OK) break;
         ++used;
-        hipStream_t t = sx[made - 1];
         const int m = int(cls[c].size());
         if ((rc = launch_sw<true>(t, d_pool.p, d_desc.p, d_order.p + at[c], m, d_out.p, d_ovf.p, Rc[c], Qc[c])) ||
             (rc = launch_sw<false>(t, d_pool.p, d_desc.p, d_order.p + at[c], m, d_out.p, d_ovf.p, Rc[c], Qc[c])))
             break;
-        if (hipEventRecord(join[made - 1], t) != hipSuccess || hipStreamWaitEvent(s, join[made - 1], 0) != hipSuccess) rc = CTO_EHIP;
+        if (hipEventRecord(side.join[made - 1], t) != hipSuccess || hipStreamWaitEvent(s, side.join[made - 1], 0) != hipSuccess) rc = CTO_EHIP;
     }
     auto drop = [&]() {
-        for (int i = 0; i < made; ++i) { (void)hipStreamSynchronize(sx[i]); (void)hipStreamDestroy(sx[i]); (void)hipEventDestroy(join[i]); }
+        for (int i = 0; i < made; ++i) (void)hipStreamSynchronize(side.sx[i]);      // (the streams themselves go back to the cache with `side`)
         (void)hipEventDestroy(fork);
     };
     if (rc != CTO_OK) { drop(); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
@@ -1247,9 +1294,11 @@ int traceback_pool(const signed char* d_pool, const std::vector<TbDesc>& desc, s
     // the few wide-band alignments are a tail of their own: on a second stream beside the many narrow ones
     hipStream_t s2 = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
+    SideStreams side;                                  // (declared before the launches: its destructor waits for the side stream)
     if (n_wide > 0 && n_wide < n) {
-        CTO_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
-        CTO_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming)); CTO_HIP(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+        if ((rc = side.get(0, &s2)) != CTO_OK) return rc;
+        join = side.join[0];
+        CTO_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
         CTO_HIP(hipEventRecord(fork, s)); CTO_HIP(hipStreamWaitEvent(s2, fork, 0));
     }
     hipStream_t s_wide = s2 ? s2 : s;
@@ -1268,7 +1317,7 @@ int traceback_pool(const signed char* d_pool, const std::vector<TbDesc>& desc, s
         if (rc != CTO_OK) (void)hipStreamSynchronize(s2);
     }
     auto drop = [&]() {
-        if (s2) { (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2); (void)hipEventDestroy(fork); (void)hipEventDestroy(join); s2 = nullptr; }
+        if (s2) { (void)hipStreamSynchronize(s2); (void)hipEventDestroy(fork); s2 = nullptr; }
     };
     if (rc != CTO_OK) { drop(); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
     CTO_HIP(hipEventRecord(e1, s));
