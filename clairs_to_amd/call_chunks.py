@@ -78,7 +78,17 @@ def default_producers(native_bam, pipeline="python"):
         # per chunk instead of 74), so a quarter more producers than cores keeps the cores busy: 16 / 20 / 24 producers on 16 cores
         # 664-708 / 736 / 576 k sites/s
         return max(1, min(40, usable_cores() + usable_cores() // 4))
+    if pipeline == "native" and not native_bam:
+        # mpileup text on the C pipeline: round 6's sweep on 16 cores (tools/experiments/writers_sweep.py, 4096-site chunks, M sites/s;
+        # producers x writers): 4 x 2 1.91, 4 x 3 1.94, 4 x 6 1.97, 6 x 2 1.95, 6 x 3 1.99, 6 x 6 2.01 - of the networks' 2.16.  A chunk holds its
+        # slot from tokenising to the written VCF, and with two writers the writers' 4.2 ms per chunk was the period
+        return max(1, min(16, usable_cores() * 3 // 8))
     return max(1, min(16, usable_cores() // (2 if native_bam else 4)))
+
+
+def default_writers():
+    """VCF-writer threads per rank: a quarter of the usable cores, at least two (see default_producers)"""
+    return max(2, min(8, usable_cores() // 4))
 
 
 # BAM chunks on the C pipeline: up to DEVICE_INFLATE[1] chunks at a time have their BGZF blocks inflated on the GPU, on streams confined to
@@ -429,7 +439,7 @@ def call_chunks(args):
         else:
             producers = default_producers(reader in ("native", "gpu"), "native" if native else "python")
         kw = dict(inflate_cus=getattr(args, "device_inflate_cus", None)) if native else {}
-        n_rows = run(eng, mine, producers=producers, writers=getattr(args, "writers", None) or 2, **kw)
+        n_rows = run(eng, mine, producers=producers, writers=getattr(args, "writers", None) or default_writers(), **kw)
     except (Exception, SystemExit) as e:     # a bad reference, a corrupt BAM, CTO_EUNSUPPORTED ...: report, do not leave the others waiting
         failure = "%s: %s" % (type(e).__name__, e)
         print("[ERROR] rank %d/%d failed: %s" % (rank, world, failure), file=sys.stderr)
@@ -592,7 +602,7 @@ def main(argv=None):
     p.add_argument("--mpileup_dir", type=str, default=None,
                    help="read <dir>/<chunk file name>.mpileup (samtools mpileup --min-BQ 0 text of the chunk) instead of the BAM")
     p.add_argument("--producers", type=int, default=None, help="pack-producer threads per rank (default: usable cores / 4, / 2 with --bam_reader native; <= 16)")
-    p.add_argument("--writers", type=int, default=None, help="VCF-writer threads per rank (default 2)")
+    p.add_argument("--writers", type=int, default=None, help="VCF-writer threads per rank (default: a quarter of the usable cores, at least 2)")
     p.add_argument("--device_inflate_cus", type=int, default=None,
                    help="C pipeline, BAM input: compute units the device BGZF inflate is confined to (default %d; 0: inflate on the host only)" % DEVICE_INFLATE[0])
     p.add_argument("--pipeline", type=str, default="auto", choices=["auto", "native", "python"],

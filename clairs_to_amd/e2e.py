@@ -61,8 +61,9 @@ def time_run(eng, run, kind, out_dir, producers=None, writers=2, repeats=4, bam_
              regions=0, times=1, device_tokenise=None):
     """the pipeline over a prepared run directory -> dict(sites_per_s, ...); best of `repeats` passes (the first one warms the page
     cache, the pinned buffers and the model workspaces)"""
-    from .call_chunks import default_producers, run_pipeline, run_pipeline_native
+    from .call_chunks import default_producers, default_writers, run_pipeline, run_pipeline_native
     producers = producers if producers else default_producers(kind == "bam", pipeline)
+    writers = writers if writers else default_writers()
     os.makedirs(out_dir, exist_ok=True)
     chunk_args = region_namespaces(run, out_dir, regions, bam_reader) if regions else chunk_namespaces(run, out_dir, bam=(kind == "bam"), bam_reader=bam_reader)
     if times > 1:
@@ -144,7 +145,7 @@ def rank_share_legs(eng, run, kind, d, writers, pipeline, times, share):
     return out
 
 
-def measure(eng, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, region_kb=None, producers=None, writers=2, workdir=None,
+def measure(eng, kind="text", n_chunks=16, sites_per_chunk=4096, distinct=3, region_kb=None, producers=None, writers=None, workdir=None,
             repeats=4, pipeline="python", with_extraction=False, host_tokeniser_too=False, rank_share=0):
     """build_run + time_run in a temporary directory.  with_extraction (kind "bam"): -> (BED-driven leg, REGION-job leg on the same
     BAM: no candidate BEDs, the candidates are extracted from the pile-up inside the run)"""
@@ -199,7 +200,7 @@ def main():
     ap.add_argument("--reference-chunk-sites", type=int, default=0,
                     help="also run the text leg on chunk files of this many candidates (the reference cuts 10 000: shared/param.py:21)")
     ap.add_argument("--producers", type=int, default=None)
-    ap.add_argument("--writers", type=int, default=2)
+    ap.add_argument("--writers", type=int, default=None, help="default: call_chunks.default_writers()")
     ap.add_argument("--rank-share", type=int, default=8, help="also run each kind confined to usable_cores / N cores: one rank's share of an N-GPU node (0: skip)")
     ap.add_argument("--pipeline", default="native", choices=["native", "python"],
                     help="cto_run_chunks (csrc/pipeline.hip) or call_chunks.run_pipeline; same files either way")
