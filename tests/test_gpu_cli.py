@@ -164,6 +164,8 @@ def test_bench_multi_rank_code_path(tmp_path, launcher):
     assert res["roofline"]["frac"] > 0 and "cpu_baseline" not in res
     assert res["ranks_seen"] == 2 and res["gather_verified"] is True and res["backend"].startswith("gloo")
     assert [d["rank"] for d in res["rank_devices"]] == [0, 1]
+    # round 6: every N's line carries the 245-step job of every rank, the gather of each step included
+    assert res["sustained"]["steps"] == 245 and res["sustained"]["sites"] == 2 * 245 * res["config"]["batch"] and res["sustained"]["sites_per_s"] > 0
 
 
 def test_bench_eight_rank_dry_run(tmp_path):
