@@ -126,6 +126,28 @@ def test_rows_with_many_indel_carriers(dev):
     _same_pack("".join(rows), ref, 1)
 
 
+def test_deep_columns_take_the_unstaged_path(dev):
+    """a wavefront's 64 rows are staged in LDS when they fit 16 KB; deeper columns (the generator caps a column at 200 reads: ~600 bytes per row, 38 KB per wavefront) are walked from
+    HBM with the register byte stream and write their codes straight to the codes buffer - same pack; mixed with shallow rows in one text"""
+    import oracle
+    from clairs_to_amd.synth import SynthChunk
+    rows = []
+    ref_parts = {}
+    for k, (depth, n) in enumerate(((400.0, 96), (30.0, 200), (2000.0, 24))):
+        ch = SynthChunk(n, seed=40 + k, depth_mean=depth, start=1000 + k * 200000, spacing=3, p_ins=0.01, p_del=0.01)
+        text = oracle.synth_mpileup_text(ch, 0)
+        rows.append(text if isinstance(text, str) else text.decode())
+        r, lo = ch.ref_window()
+        ref_parts[lo] = r
+    lo0 = min(ref_parts)
+    hi0 = max(lo + len(r) for lo, r in ref_parts.items())
+    ref = bytearray(b"A" * (hi0 - lo0))
+    for lo, r in ref_parts.items():
+        ref[lo - lo0:lo - lo0 + len(r)] = r.encode()
+    h = _same_pack("".join(rows), ref.decode(), lo0)
+    assert h.n_entries > 90000 and h.n_keys > 200
+
+
 def test_tensors_from_a_device_tokenised_pack(dev, golden_region):
     """featurisation fed from the device-born pack = featurisation fed from the uploaded host pack (bit for bit)"""
     import ctypes as C
