@@ -32,9 +32,17 @@ def main():
         rows = list(csv.DictReader(open(tr)))
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
         names = [r["Kernel_Name"] for r in rows]
-        # last occurrence of the first kernel of a step (featurize) marks the last step
-        starts = [i for i, n in enumerate(names) if "k_featurize_columns" in n]
-        full = [(a, b) for a, b in zip(starts[:-1], starts[1:]) if b - a >= 10]    # whole steps, not the featurize-only tail
+        # a step = k_featurize_sites (tensor creation, one kernel since round 3) ... k_posterior with both networks in between; the last
+        # such run of launches of the trace's timed region (the legs after it launch featurize / extraction kernels on their own)
+        full = []
+        for b in [i for i, n in enumerate(names) if "k_posterior" in n]:
+            a = b
+            while a > 0 and b - a < 16 and "k_featurize_sites" not in names[a]:
+                a -= 1
+            span = names[a:b + 1]
+            if "k_featurize_sites" in names[a] and any("k_gru_layer" in n for n in span) and any("k_cvt_block" in n for n in span):
+                full.append((a, b + 1))
+        full = full[:max(1, len(full) // 2)]                 # the first half of them: warm-up + timed steps of the default model pair
         if full:
             a, b = full[-1]
             t0 = int(rows[a]["Start_Timestamp"])
