@@ -574,7 +574,8 @@ def main(argv=None):
     add_common_arguments(p)
     p.add_argument("--chunk_list", type=str, default=None, help="file with one candidate BED chunk path per line (CANDIDATES_FILES)")
     p.add_argument("--region_list", type=str, default=None,
-                   help="instead of --chunk_list: rows `ctg start end` (1-based, inclusive). No candidate BEDs: every region is piled up once "
+                   help="instead of --chunk_list: rows `ctg start end` (1-based, inclusive) or `ctg i/n` (part i of n of the contig: extract_candidates_calling's "
+                        "--chunk_id i --chunk_num n, from the .fai or - with --bed_fn - from the span of its rows). No candidate BEDs: every region is piled up once "
                         "and candidate extraction (extract_candidates_calling's gates) runs on that pile-up in HBM, in front of tensor creation")
     p.add_argument("--candidates_dir", type=str, default=None, help="--region_list: also write each region's candidates as BED window rows here")
     p.add_argument("--snv_min_af", type=float, default=0.05, help="--region_list: extract_candidates_calling --snv_min_af")
