@@ -77,7 +77,10 @@ def default_producers(native_bam, pipeline="python"):
         # round 4: the device chunks' producers sleep while the device works (no spinning waits left in the pile-up driver: 55 ms of CPU
         # per chunk instead of 74), so a quarter more producers than cores keeps the cores busy: 16 / 20 / 24 producers on 16 cores
         # 664-708 / 736 / 576 k sites/s
-        return max(1, min(40, usable_cores() + usable_cores() // 4))
+        # round 6: never fewer than 8 - a device chunk costs its producer 14 ms of CPU and 25 ms of waiting (file read, inflate, pile-up), so a
+        # rank with two cores to itself (an 8-GPU node's share) keeps the device busy with eight chunks in flight, not with two; eight stay
+        # below the inflate contexts (DEVICE_INFLATE[1]), so none of them falls back to decoding on the host
+        return max(1, min(40, max(usable_cores() + usable_cores() // 4, 8)))
     if pipeline == "native" and not native_bam:
         # mpileup text on the C pipeline: round 6's sweep on 16 cores (tools/experiments/writers_sweep.py, 4096-site chunks, M sites/s;
         # producers x writers): 4 x 2 1.91, 4 x 3 1.94, 4 x 6 1.97, 6 x 2 1.95, 6 x 3 1.99, 6 x 6 2.01 - of the networks' 2.16.  A chunk holds its
