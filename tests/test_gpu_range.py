@@ -48,13 +48,17 @@ def _forward(cls, w, x, dev, split=None):
 # (DESIGN.md section 6, round 5): the fp32 kernels 0.3-3.2 x (the same with libm in place of every fast form: -DCTO_PRECISE_MATH,
 # 0.8-2.6 x - the fast forms are not what the distance is made of), f16 halves 0.3-5 x; each figure is the MAXIMUM over 52 windows x
 # 2K probabilities of a chaotic amplification of rounding noise, so the bound leaves room.
+# Round 6: the product's fp32 kernels are held to 4 x (their measured worst is 3.3 x: CvT_Indel x2, 1.1e-3 against the fp32 reference's own
+# 3.3e-4), the opt-in f16 side channel keeps 6 x.
 NOISE = 6.0
+NOISE_FP32 = 4.0
 
 
 def _check(cls, name, e, fp32_path, bad):
-    if not e["dp64"] <= max(1e-4, NOISE * e["ref_dp"]):
+    noise = NOISE_FP32 if fp32_path else NOISE
+    if not e["dp64"] <= max(1e-4, noise * e["ref_dp"]):
         bad.append((cls, name, "dP vs ref64", e["dp64"], e["ref_dp"]))
-    if not e["rel"] <= max(1e-5 if fp32_path else 3e-5, NOISE * e["ref_rel"]):
+    if not e["rel"] <= max(1e-5 if fp32_path else 3e-5, noise * e["ref_rel"]):
         bad.append((cls, name, "rel logit", e["rel"], e["ref_rel"]))
     if e["ref_dp"] < 2e-5 and not e["dp32"] < 1e-4:
         bad.append((cls, name, "dP vs ref32", e["dp32"], e["ref_dp"]))
