@@ -30,6 +30,8 @@
 // top and dropped: a 16 KiB LDS ring for near matches (the copy itself was not the cost; fewer waves per CU: 14-18 ms per chunk);
 // literal runs decoded by all lanes at once (lane i looks up the symbol at bit offset i, a scalar walk follows the chain: correct,
 // but BAM records break the run every 1.7 literals: 9.9 ms).  A device decoder that beats the host needs one block per LANE.
+// (Round 6 built that form in two phases - tools/experiments/inflate_lanes_two_phase.hip - and measured it: correct, 7 x slower than this kernel;
+// a wavefront whose lanes decode 64 different streams executes the union of their code paths at every step.)
 // Later in the round, with 8 launches in flight (ms per chunk; 7.0 at that point): a literal loop of its own - table hit with a
 // literal flag, all-lanes byte store, shift; the bit count derived from the reader's position instead of updated per symbol; the
 // input bound checked where a dword is handed out - 6.2 (kept: ~27 instructions per literal instead of ~50).  8 instead of 7 waves
