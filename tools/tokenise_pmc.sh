@@ -13,7 +13,7 @@ if not fs:
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(fs[0])):
     n = r['Kernel_Name']
-    if 'k_rows' in n:
+    if 'k_rows' in n or 'k_expand' in n or 'k_row_keys' in n or 'k_apply3' in n:
         acc[n.replace('(anonymous namespace)::', '').split('(')[0][:28]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in acc.items():
     print(k.ljust(30), ' '.join('%s=%.4g' % (c.replace('SQ_', ''), sum(v) / len(v)) for c, v in sorted(d.items())))
