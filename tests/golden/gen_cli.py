@@ -237,7 +237,9 @@ DRY_MATRIX = [
     ("hifi_use_gpu", "hifi_revio", ["--use_gpu", "--region", "chr20:400-3000"]),
 ]
 EXEC = {"ont": ("extract_candidates_calling", "concat_files"), "ont_bed": ("extract_candidates_calling",), "ont_indel_bed": ("extract_candidates_calling",),
-        "ont_hybrid": ("extract_candidates_calling",), "ont_genotyping": ("extract_candidates_calling",)}
+        "ont_hybrid": ("extract_candidates_calling",), "ont_genotyping": ("extract_candidates_calling",),
+        # STEP 1 under the other platforms' gates (--min_bq, --indel_min_af of run_clairs_to's platform tables) on the same simulated pileup
+        "ilmn": ("extract_candidates_calling",), "hifi": ("extract_candidates_calling",)}
 
 
 def main():

@@ -1,8 +1,9 @@
 """The reference's command lines, run: `python -m clairs_to_amd <sub-module> <the argv run_clairs_to built>` against what the reference's own
 sub-modules wrote with the same argv on the same inputs (tests/golden/cli_run.json.gz, made by gen_cli.py in the build container).
 
-STEP 1 (extract_candidates_calling + concat_files) in five set-ups - default, --bed_fn, --call_indels_only_in_these_regions,
---hybrid_mode_vcf_fn, --genotyping_mode_vcf_fn - must leave the candidates folder the reference left, file for file and byte for byte: the BED
+STEP 1 (extract_candidates_calling + concat_files) in eight set-ups - default, --bed_fn, --call_indels_only_in_these_regions,
+--hybrid_mode_vcf_fn, --genotyping_mode_vcf_fn, the hybrid list with indel candidates, and the Illumina and HiFi platforms' gates (--min_bq 0,
+--indel_min_af 0.05) - must leave the candidates folder the reference left, file for file and byte for byte: the BED
 chunk files, the list files, bed/<ctg>_<chunk>.bed, <ctg>.<chunk>_hybrid_info.  STEP 2 / STEP 6 (create_tensor_pileup_calling x 2, predict,
 call_variants per chunk file) must write the reference's tensor text (SHA-256), its probability rows (non-probability fields equal,
 probabilities within 1e-4: north_star's tolerance) and its p_<chunk>.vcf: header byte for byte, records field for field with QUAL / GQ free to
@@ -86,7 +87,7 @@ def same_candidates(got, want):
             assert got[f] == want[f], f
 
 
-@pytest.mark.parametrize("name", ["ont", "ont_bed", "ont_indel_bed", "ont_hybrid", "ont_genotyping", "ont_hybrid_indel"])
+@pytest.mark.parametrize("name", ["ont", "ont_bed", "ont_indel_bed", "ont_hybrid", "ont_genotyping", "ont_hybrid_indel", "ilmn", "hifi"])
 def test_step1_writes_the_references_candidates_folder(tmp_path, golden, name):
     rec = golden["executed"][name]
     with Work(tmp_path, name, rec, golden) as wk:

@@ -16,7 +16,8 @@ from test_gpu_cli_argv import Work, golden  # noqa: F401  (fixture)
 
 pytestmark = pytest.mark.gpu
 
-SETUPS = [("ont", 4), ("ont", 6), ("ont_bed", 4), ("ont_bed", 6), ("ont_indel_bed", 6), ("ont_hybrid", 4), ("ont_genotyping", 4), ("ont_hybrid_indel", 6)]
+SETUPS = [("ont", 4), ("ont", 6), ("ont_bed", 4), ("ont_bed", 6), ("ont_indel_bed", 6), ("ont_hybrid", 4), ("ont_genotyping", 4), ("ont_hybrid_indel", 6),
+          ("ilmn", 4), ("ilmn", 6), ("hifi", 4), ("hifi", 6)]
 
 
 def _opt(argv, k):
@@ -40,7 +41,7 @@ def test_region_jobs_extract_the_references_candidates_in_every_mode(tmp_path, g
         lik = tmp_path / "lik.txt"
         np.savetxt(lik, likelihood_table(K, seed=11), fmt="%.17g")
         (tmp_path / "REGIONS").write_text("".join("%s %d/%d\n" % (clisim.CTG, i + 1, n_chunks) for i in range(n_chunks)))
-        common = ["--platform", "ont", "--tumor_bam_fn", wk.inputs["bam"], "--ref_fn", wk.inputs["ref"], "--bam_reader", "samtools", "--samtools", "samtools",
+        common = ["--platform", _opt(argv0, "--platform") or "ont", "--tumor_bam_fn", wk.inputs["bam"], "--ref_fn", wk.inputs["ref"], "--bam_reader", "samtools", "--samtools", "samtools",
                   "--chkpnt_fn_acgt", paths["model_acgt"], "--chkpnt_fn_nacgt", paths["model_nacgt"], "--disable_indel_calling", str(K == 4),
                   "--likelihood_matrix_data", str(lik), "--show_ref"]
         modes = ["--snv_min_af", _opt(argv0, "--snv_min_af"), "--indel_min_af", _opt(argv0, "--indel_min_af"), "--min_coverage", _opt(argv0, "--min_coverage")]
