@@ -239,7 +239,7 @@ DRY_MATRIX = [
 EXEC = {"ont": ("extract_candidates_calling", "concat_files"), "ont_bed": ("extract_candidates_calling",), "ont_indel_bed": ("extract_candidates_calling",),
         "ont_hybrid": ("extract_candidates_calling",), "ont_genotyping": ("extract_candidates_calling",),
         # STEP 1 under the other platforms' gates (--min_bq, --indel_min_af of run_clairs_to's platform tables) on the same simulated pileup
-        "ilmn": ("extract_candidates_calling",), "hifi": ("extract_candidates_calling",)}
+        "ilmn": ("extract_candidates_calling", "concat_files"), "hifi": ("extract_candidates_calling", "concat_files")}
 
 
 def main():
@@ -272,11 +272,18 @@ def main():
             rec["step1_argv"] = [[s, [norm(t, tmp, w) for t in a]] for s, a in ran]
             rec["candidates"] = folder_files(os.path.join(wt, "candidates"), w, tmp)
             print("  step 1:", len(ran), "invocations,", len(rec["candidates"]), "files")
-            if name == "ont":
-                # STEP 2 (commands 1..4: create_tensor x2, predict, call_variants) and STEP 6 (the concat + 4 commands after the SNV tail)
-                step2 = [c for c in commands if "SNV_CANDIDATES_FILES" in c and "extract_candidates_calling" not in c]
-                step6 = [c for c in commands if "INDEL_CANDIDATES_FILES" in c]
-                ran2 = run_step(step2 + step6, ("concat_files", "create_tensor_pileup_calling", "predict", "call_variants"), w, env)
+            if name in ("ont", "ilmn", "hifi"):
+                # STEP 2 (create_tensor x2 - Illumina: once, then `ln -sf` of the affirmative tensors into the negational folder,
+                # run_clairs_to:1248-1252 - predict, call_variants) and STEP 6 (the concat + the same commands on the indel lists)
+                sel = [c for c in commands if "extract_candidates_calling" not in c and
+                       ("SNV_CANDIDATES_FILES" in c or "INDEL_CANDIDATES_FILES" in c or (c.startswith("ln -sf") and "pileup_tensor_can" in c))]
+                ran2 = []
+                for c in sel:
+                    if c.startswith("ln -sf"):
+                        subprocess.run(c, shell=True, check=True)              # a plain shell command of the orchestrator: the glob is the shell's
+                        ran2.append(("sh", [c]))
+                    else:
+                        ran2 += run_step([c], ("concat_files", "create_tensor_pileup_calling", "predict", "call_variants"), w, env)
                 rec["step2_argv"] = [[s, [norm(t, tmp, w) for t in a]] for s, a in ran2]
                 rec["predict"] = {f: gzip.open(os.path.join(wt, "predict", f), "rt").read() for f in sorted(os.listdir(os.path.join(wt, "predict")))}
                 rec["vcf_output"] = folder_files(os.path.join(wt, "vcf_output"), w, tmp)
@@ -289,12 +296,15 @@ def main():
                 # the same call_variants commands with --print_ref_calls's --show_ref, on the same probability files
                 rec["vcf_output_show_ref"] = {}
                 for s, a in ran2:
-                    if s == "call_variants":
+                    if s == "call_variants" and name == "ont":
                         a2 = list(a)
                         out = a2[a2.index("--call_fn") + 1]
                         a2[a2.index("--call_fn") + 1] = out.replace("vcf_output", "vcf_output_show_ref")
                         run_ref(s, a2 + ["--show_ref"], env, w)
-                rec["vcf_output_show_ref"] = folder_files(os.path.join(wt, "vcf_output_show_ref"), w, tmp)
+                if name == "ont":
+                    rec["vcf_output_show_ref"] = folder_files(os.path.join(wt, "vcf_output_show_ref"), w, tmp)
+                else:
+                    del rec["vcf_output_show_ref"]
             executed[name] = rec
             if name == "ont_hybrid":
                 # not a run_clairs_to set-up (hybrid mode switches indel calling off there): the same command lines with indel candidates selected
