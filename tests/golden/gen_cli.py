@@ -8,9 +8,11 @@
                      `clairs_to.py <sub-module> ...` invocations as argv lists, GNU parallel's replacement strings ({1} {2} {3} {1/} {1/.}) still in
                      place, scratch paths replaced by @W@ (the work directory) / @REF@ (the reference checkout).
   cli_run.json.gz  those command lines EXECUTED with the reference's sub-modules on the simulated run of clisim.py (GNU parallel emulated: one
-                   invocation per row of the `::::` file): STEP 1 in five set-ups (default, --bed_fn, --call_indels_only_in_these_regions,
-                   --hybrid_mode_vcf_fn, --genotyping_mode_vcf_fn) -> every file of the candidates folder; for the default set-up STEP 2 (SNV)
-                   and STEP 6 (indel): the probability files and the whole p_<chunk>.vcf files, header included, also with --print_ref_calls.
+                   invocation per row of the `::::` file): STEP 1 in eight set-ups (default, --bed_fn, --call_indels_only_in_these_regions,
+                   --hybrid_mode_vcf_fn, --genotyping_mode_vcf_fn, hybrid + indel candidates; the Illumina and HiFi gates) -> every file of the
+                   candidates folder; for ont / ilmn / hifi STEP 2 (SNV) and STEP 6 (indel): the probability files and the whole p_<chunk>.vcf
+                   files, header included, for ont also with --print_ref_calls; `ont_whole` (--disable_intermediate_phasing
+                   --disable_nonsomatic_tagging): all fifteen commands of the run, in order, down to the final snv.vcf / indel.vcf.
 
 Only data is stored (argv lists, option tables, file contents the reference wrote).  Usage: python tests/golden/gen_cli.py"""
 import argparse
@@ -235,11 +237,15 @@ DRY_MATRIX = [
     ("ilmn_ref_calls_norealign", "ilmn", ["--print_ref_calls", "--enable_realignment", "False", "--enable_postfilter", "False"]),
     ("hifi", "hifi_revio", []),
     ("hifi_use_gpu", "hifi_revio", ["--use_gpu", "--region", "chr20:400-3000"]),
+    # every command of this one is a sub-module of the hot path or its tail (no phasing, no tagging database): executed from end to end
+    ("ont_whole", "ont_r10_dorado_sup_5khz", ["--disable_intermediate_phasing", "--disable_nonsomatic_tagging"]),
 ]
 EXEC = {"ont": ("extract_candidates_calling", "concat_files"), "ont_bed": ("extract_candidates_calling",), "ont_indel_bed": ("extract_candidates_calling",),
         "ont_hybrid": ("extract_candidates_calling",), "ont_genotyping": ("extract_candidates_calling",),
         # STEP 1 under the other platforms' gates (--min_bq, --indel_min_af of run_clairs_to's platform tables) on the same simulated pileup
-        "ilmn": ("extract_candidates_calling", "concat_files"), "hifi": ("extract_candidates_calling", "concat_files")}
+        "ilmn": ("extract_candidates_calling", "concat_files"), "hifi": ("extract_candidates_calling", "concat_files"),
+        "ont_whole": ("extract_candidates_calling", "concat_files")}
+TAIL = ("concat_files", "create_tensor_pileup_calling", "predict", "call_variants", "sort_vcf", "postprocess_vcf")
 
 
 def main():
@@ -305,6 +311,25 @@ def main():
                     rec["vcf_output_show_ref"] = folder_files(os.path.join(wt, "vcf_output_show_ref"), w, tmp)
                 else:
                     del rec["vcf_output_show_ref"]
+            if name == "ont_whole":
+                # the whole run: the dry run's commands 1.. in order - STEP 2, sort_vcf, `ln -sf` (STEP 3 without the databases,
+                # run_clairs_to:1356-1360), postprocess_vcf, STEP 6, sort_vcf, `ln -sf`, postprocess_vcf - down to <output>/snv.vcf and indel.vcf
+                if os.path.exists(os.path.join(wt, "CMD")):
+                    rec["work_files"]["CMD"] = norm(open(os.path.join(wt, "CMD")).read(), tmp, w)
+                ran2 = []
+                for c in commands[1:]:
+                    if "clairs_to.py" not in c:
+                        subprocess.run(c, shell=True, check=True)
+                        ran2.append(("sh", [c]))
+                    else:
+                        got = run_step([c], TAIL, w, env)
+                        assert got and len(got) >= len(invocations(c)), c
+                        ran2 += got
+                rec["whole_argv"] = [[s, [norm(t, tmp, w) for t in a]] for s, a in ran2]
+                rec["predict"] = {f: gzip.open(os.path.join(wt, "predict", f), "rt").read() for f in sorted(os.listdir(os.path.join(wt, "predict")))}
+                rec["vcf_output"] = folder_files(os.path.join(wt, "vcf_output"), w, tmp)
+                rec["final"] = {f: norm(open(os.path.join(w, f)).read(), tmp, w) for f in sorted(os.listdir(w)) if f.endswith(".vcf")}
+                print("  whole run:", len(ran2), "commands,", {f: t.count("\n") for f, t in rec["final"].items()})
             executed[name] = rec
             if name == "ont_hybrid":
                 # not a run_clairs_to set-up (hybrid mode switches indel calling off there): the same command lines with indel candidates selected

@@ -7,7 +7,8 @@ STEP 1 (extract_candidates_calling + concat_files) in eight set-ups - default, -
 chunk files, the list files, bed/<ctg>_<chunk>.bed, <ctg>.<chunk>_hybrid_info.  STEP 2 / STEP 6 (create_tensor_pileup_calling x 2, predict,
 call_variants per chunk file) must write the reference's tensor text (SHA-256), its probability rows (non-probability fields equal,
 probabilities within 1e-4: north_star's tolerance) and its p_<chunk>.vcf: header byte for byte, records field for field with QUAL / GQ free to
-move in the last digit - and, from the reference's OWN probability files, the whole VCF byte for byte.
+move in the last digit - and, from the reference's OWN probability files, the whole VCF byte for byte.  One whole run (no phasing, no tagging
+database: fifteen commands, all of them sub-modules mirrored here) goes down to the final snv.vcf / indel.vcf.
 
 `samtools` is clisim.py's stand-in on both sides (neither box has samtools)."""
 import gzip
@@ -122,6 +123,35 @@ def vcf_parts(text):
     return "".join(r + "\n" for r in rows if r.startswith("#")), [r for r in rows if r and not r.startswith("#")]
 
 
+def write_models(wk, tmp_path):
+    """<t>/models: the weights recipe pickled as the reference's releases are, and the likelihood tables gen_cli.make_models wrote"""
+    models = os.path.join(wk.t, "models")
+    os.makedirs(models, exist_ok=True)
+    for mode, K, aff_cls, neg_cls in (("snv", 4, "CvT", "BiGRU_NACGT"), ("indel", 6, "CvT_Indel", "BiGRU_NACGT_Indel")):
+        d = tmp_path / ("pk_" + mode)
+        d.mkdir()
+        paths = _pickle_models(d, aff_cls, neg_cls, K)
+        os.replace(paths["model_acgt"], os.path.join(models, "aff_%s.pkl" % mode))
+        os.replace(paths["model_nacgt"], os.path.join(models, "neg_%s.pkl" % mode))
+        from clairs_to_amd.synth import likelihood_table
+        np.savetxt(os.path.join(models, "lik_%s.txt" % mode), likelihood_table(K, seed=7 + K), fmt="%.17g")
+
+
+def same_vcf_but_the_last_digit(got, want, f):
+    """header byte for byte; records field for field with QUAL / GQ free to move with the 8th decimal of the fp32 probabilities"""
+    head, rows = vcf_parts(want)
+    ghead, grows = vcf_parts(got)
+    assert ghead == head, f
+    assert len(grows) == len(rows), f
+    for a, b in zip(grows, rows):
+        a, b = a.split("\t"), b.split("\t")
+        assert a[:5] == b[:5] and a[6:9] == b[6:9], (f, a, b)
+        assert abs(float(a[5]) - float(b[5])) < 0.02, (f, a, b)
+        fa_, fb_ = a[9].split(":"), b[9].split(":")
+        assert fa_[0] == fb_[0] and fa_[2:] == fb_[2:] and abs(int(fa_[1]) - int(fb_[1])) <= 1, (f, a, b)
+    return len(rows)
+
+
 @pytest.mark.parametrize("name", ["ont", "ilmn", "hifi"])
 def test_step2_and_step6_with_the_references_argv(tmp_path, golden, name):
     """ont, and the Illumina and HiFi platforms: Illumina creates the affirmative tensors only and `ln -sf`s them into the negational folder
@@ -133,16 +163,7 @@ def test_step2_and_step6_with_the_references_argv(tmp_path, golden, name):
         for sub, argv in rec["step1_argv"]:
             wk.run(sub, argv)
         same_candidates(wk.files("candidates"), rec["candidates"])
-        models = os.path.join(wk.t, "models")
-        os.makedirs(models, exist_ok=True)
-        for mode, K, aff_cls, neg_cls in (("snv", 4, "CvT", "BiGRU_NACGT"), ("indel", 6, "CvT_Indel", "BiGRU_NACGT_Indel")):
-            d = tmp_path / ("pk_" + mode)
-            d.mkdir()
-            paths = _pickle_models(d, aff_cls, neg_cls, K)
-            os.replace(paths["model_acgt"], os.path.join(models, "aff_%s.pkl" % mode))
-            os.replace(paths["model_nacgt"], os.path.join(models, "neg_%s.pkl" % mode))
-            from clairs_to_amd.synth import likelihood_table
-            np.savetxt(os.path.join(models, "lik_%s.txt" % mode), likelihood_table(K, seed=7 + K), fmt="%.17g")
+        write_models(wk, tmp_path)
         n = {}
         for sub, argv in rec["step2_argv"]:
             if sub == "sh":
@@ -174,16 +195,7 @@ def test_step2_and_step6_with_the_references_argv(tmp_path, golden, name):
         got = wk.files("vcf_output")
         assert sorted(got) == sorted(rec["vcf_output"])
         for f, text in rec["vcf_output"].items():
-            head, rows = vcf_parts(text)
-            ghead, grows = vcf_parts(got[f])
-            assert ghead == head, f
-            assert len(grows) == len(rows) > 0
-            for a, b in zip(grows, rows):
-                a, b = a.split("\t"), b.split("\t")
-                assert a[:5] == b[:5] and a[6:9] == b[6:9]
-                assert abs(float(a[5]) - float(b[5])) < 0.02                 # QUAL moves with the 8th decimal of the probabilities
-                fa_, fb_ = a[9].split(":"), b[9].split(":")
-                assert fa_[0] == fb_[0] and fa_[2:] == fb_[2:] and abs(int(fa_[1]) - int(fb_[1])) <= 1
+            assert same_vcf_but_the_last_digit(got[f], text, f) > 0
         # call_variants on the reference's own probability files: the whole VCF, byte for byte, with and without --show_ref
         for f, text in rec["predict"].items():
             with gzip.open(os.path.join(wk.w, "tmp", "predict", f), "wt") as out:
@@ -200,3 +212,50 @@ def test_step2_and_step6_with_the_references_argv(tmp_path, golden, name):
         assert wk.files("vcf_output") == rec["vcf_output"]
         if "vcf_output_show_ref" in rec:
             assert wk.files("vcf_output_show_ref") == rec["vcf_output_show_ref"]
+
+
+def test_the_whole_run_without_phasing(tmp_path, golden):
+    """`run_clairs_to --disable_intermediate_phasing --disable_nonsomatic_tagging`: every command of that run is a sub-module of the hot path
+    or of its tail, so the reference executed all fifteen on the simulated pileup (gen_cli.py: STEP 1, STEP 2, sort_vcf, `ln -sf`,
+    postprocess_vcf, STEP 6, sort_vcf, `ln -sf`, postprocess_vcf) - the same command lines through `python -m clairs_to_amd`'s dispatcher
+    must leave <output>/snv.vcf and <output>/indel.vcf as the reference left them."""
+    rec = golden["executed"]["ont_whole"]
+    with Work(tmp_path, "ont_whole", rec, golden) as wk:
+        for sub, argv in rec["step1_argv"]:
+            wk.run(sub, argv)
+        same_candidates(wk.files("candidates"), rec["candidates"])
+        write_models(wk, tmp_path)
+
+        def tail(after_predict=None):
+            n = {}
+            for sub, argv in rec["whole_argv"]:
+                if sub == "sh":
+                    subprocess.run(wk.real(argv[0]), shell=True, check=True)
+                else:
+                    wk.run(sub, argv)
+                    if sub == "predict" and after_predict:
+                        after_predict(wk.real(argv[argv.index("--predict_fn") + 1]))
+                n[sub] = n.get(sub, 0) + 1
+            final = {f: open(os.path.join(wk.w, f)).read().replace(wk.w, "@W@").replace(wk.t, "@T@") for f in sorted(os.listdir(wk.w))
+                     if f.endswith(".vcf")}
+            return n, final
+
+        n, final = tail()
+        assert n == {"concat_files": 1, "create_tensor_pileup_calling": 12, "predict": 6, "call_variants": 6, "sort_vcf": 2, "sh": 2,
+                     "postprocess_vcf": 2}
+        assert sorted(final) == sorted(rec["final"]) == ["indel.vcf", "snv.vcf"]
+        got = wk.files("vcf_output")
+        assert sorted(got) == sorted(rec["vcf_output"])
+        for f, text in rec["vcf_output"].items():
+            same_vcf_but_the_last_digit(got[f], text, f)
+        for f, text in rec["final"].items():
+            assert same_vcf_but_the_last_digit(final[f], text, f) > (10 if f == "snv.vcf" else 1)
+        assert "PASS" in rec["final"]["snv.vcf"]
+
+        # the same tail on the reference's own probability files: every file of the run, byte for byte
+        def swap(path):
+            with gzip.open(path, "wt") as out:
+                out.write(rec["predict"][os.path.basename(path)])
+        _, final = tail(after_predict=swap)
+        assert wk.files("vcf_output") == rec["vcf_output"]
+        assert final == rec["final"]
