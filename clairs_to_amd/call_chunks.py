@@ -464,8 +464,7 @@ def call_chunks(args):
         if rank == 0:
             print("[INFO] gathered the outputs of %d sites from %d rank(s); %d records in %s" % (n_g[0], world, n_g[1], args.merged_vcf_fn), file=sys.stderr)
         if rank == 0 and args.final_vcf_fn:
-            postprocess_vcf(args.merged_vcf_fn, args.final_vcf_fn, platform=resolve_platform(args.platform)[1],
-                            ref_fn=args.ref_fn, sample_name=args.sample_name)
+            final_vcf(args)
     elif rank == 0 and args.merged_vcf_fn:
         contigs = []
         for bed in chunks:
@@ -478,13 +477,24 @@ def call_chunks(args):
                      only_files=names)
         print("[INFO] merged %d records into %s" % (n, args.merged_vcf_fn), file=sys.stderr)
         if args.final_vcf_fn:
-            postprocess_vcf(args.merged_vcf_fn, args.final_vcf_fn, platform=resolve_platform(args.platform)[1],
-                            ref_fn=args.ref_fn, sample_name=args.sample_name)
+            final_vcf(args)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
     return n_rows
+
+
+def final_vcf(args):
+    """--final_vcf_fn: postprocess_vcf of the merged VCF with run_clairs_to's gates (:1519-1529: --qual, the two region cut-offs, --af,
+    --cmdline = the file holding the command line for the header); a gate left out is the platform's default, as in the reference."""
+    cmd = None
+    if args.cmdline is not None and os.path.exists(args.cmdline):
+        cmd = open(args.cmdline).read().rstrip()
+    return postprocess_vcf(args.merged_vcf_fn, args.final_vcf_fn, platform=resolve_platform(args.platform)[1], qual=args.postprocess_qual,
+                           qual_cutoff_phaseable_region=args.postprocess_qual_cutoff_phaseable_region,
+                           qual_cutoff_unphaseable_region=args.postprocess_qual_cutoff_unphaseable_region, af=args.postprocess_af, ref_fn=args.ref_fn,
+                           sample_name=args.sample_name, cmdline=cmd)
 
 
 def gather_and_write(args, collected, chunks, world, rank, device):
@@ -598,6 +608,12 @@ def main(argv=None):
     p.add_argument("--output_dir", type=str, required=True, help="directory for the p_<chunk>.vcf files")
     p.add_argument("--merged_vcf_fn", type=str, default=None, help="rank 0: sort_vcf of all chunk VCFs")
     p.add_argument("--final_vcf_fn", type=str, default=None, help="rank 0: postprocess_vcf of the merged VCF")
+    # (--qual is call_variants' option here, as in pileup_call: the gates of the final step carry postprocess_vcf's names behind a prefix)
+    p.add_argument("--postprocess_qual", type=float, default=None, help="--final_vcf_fn: postprocess_vcf --qual (default: the platform's)")
+    p.add_argument("--postprocess_qual_cutoff_phaseable_region", type=float, default=None, help="--final_vcf_fn: postprocess_vcf --qual_cutoff_phaseable_region")
+    p.add_argument("--postprocess_qual_cutoff_unphaseable_region", type=float, default=None, help="--final_vcf_fn: postprocess_vcf --qual_cutoff_unphaseable_region")
+    p.add_argument("--postprocess_af", type=float, default=None, help="--final_vcf_fn: postprocess_vcf --af (default: the platform's)")
+    p.add_argument("--cmdline", type=str, default=None, help="--final_vcf_fn: file holding the command line for the ##cmdline header row (tmp/CMD)")
     p.add_argument("--gather_outputs", action="store_true",
                    help="exchange step in the data path: every rank's per-site outputs (probabilities, decision, QUAL, counts, alt_info) are "
                         "all_gathered in rank-major = chunk-list order (RCCL over xGMI) and rank 0 writes --merged_vcf_fn from the gathered "

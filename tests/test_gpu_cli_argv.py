@@ -259,3 +259,41 @@ def test_the_whole_run_without_phasing(tmp_path, golden):
         _, final = tail(after_predict=swap)
         assert wk.files("vcf_output") == rec["vcf_output"]
         assert final == rec["final"]
+
+
+def test_the_whole_run_as_one_invocation_per_model(tmp_path, golden):
+    """The same run the way this package is meant to be driven: `call_chunks --region_list` (rows `ctg i/n`), once for the SNV models and
+    once for the indel models - extraction, tensor creation, both networks, the epilogue, the chunk VCFs, sort_vcf and postprocess_vcf in
+    one process each, no candidates folder, no tensor or probability files - must leave the final snv.vcf / indel.vcf the REFERENCE left
+    after its fifteen commands (records with QUAL / GQ free in the last digit: these probabilities never pass through the 6-decimal
+    text of the probability files)."""
+    from clairs_to_amd.call_chunks import main as call_chunks
+    rec = golden["executed"]["ont_whole"]
+    opt = lambda argv, k: argv[argv.index(k) + 1]
+    a1 = rec["step1_argv"][0][1]
+    n_chunks = int(opt(a1, "--chunk_num"))
+    post = {("snv" if "True" == opt(a, "--disable_indel_calling") else "indel"): a for s, a in rec["whole_argv"] if s == "postprocess_vcf"}
+    with Work(tmp_path, "ont_whole", rec, golden) as wk:
+        write_models(wk, tmp_path)
+        regions = tmp_path / "REGIONS"
+        regions.write_text("".join("%s %d/%d\n" % (clisim.CTG, i + 1, n_chunks) for i in range(n_chunks)))
+        for mode in ("snv", "indel"):
+            pa = post[mode]
+            out = tmp_path / ("chunks_" + mode)
+            call_chunks(["--region_list", str(regions), "--output_dir", str(out), "--platform", opt(a1, "--platform"),
+                         "--tumor_bam_fn", wk.inputs["bam"], "--ref_fn", wk.inputs["ref"], "--bam_reader", "samtools", "--samtools", "samtools",
+                         "--chkpnt_fn_acgt", os.path.join(wk.t, "models", "aff_%s.pkl" % mode),
+                         "--chkpnt_fn_nacgt", os.path.join(wk.t, "models", "neg_%s.pkl" % mode),
+                         "--likelihood_matrix_data", os.path.join(wk.t, "models", "lik_%s.txt" % mode),
+                         "--disable_indel_calling", str(mode == "snv"),
+                         "--snv_min_af", opt(a1, "--snv_min_af"), "--indel_min_af", opt(a1, "--indel_min_af"), "--min_coverage", opt(a1, "--min_coverage"),
+                         "--merged_vcf_fn", os.path.join(wk.w, "tmp", "vcf_output", mode + "_pileup.vcf"), "--final_vcf_fn", wk.real(opt(pa, "--output_fn")),
+                         "--postprocess_qual", opt(pa, "--qual"), "--postprocess_qual_cutoff_phaseable_region", opt(pa, "--qual_cutoff_phaseable_region"),
+                         "--postprocess_qual_cutoff_unphaseable_region", opt(pa, "--qual_cutoff_unphaseable_region"), "--postprocess_af", opt(pa, "--af"),
+                         "--sample_name", opt(pa, "--sample_name"), "--cmdline", wk.real(opt(pa, "--cmdline"))])
+        merged = wk.files("vcf_output")
+        for mode in ("snv", "indel"):
+            same_vcf_but_the_last_digit(merged[mode + "_pileup.vcf"], rec["vcf_output"][mode + "_pileup.vcf"], mode)
+            got = open(os.path.join(wk.w, mode + ".vcf")).read().replace(wk.w, "@W@").replace(wk.t, "@T@")
+            assert same_vcf_but_the_last_digit(got, rec["final"][mode + ".vcf"], mode) > (10 if mode == "snv" else 1)
+        assert not os.listdir(os.path.join(wk.w, "tmp", "candidates")) and not os.listdir(os.path.join(wk.w, "tmp", "predict"))
