@@ -239,12 +239,16 @@ DRY_MATRIX = [
     ("hifi_use_gpu", "hifi_revio", ["--use_gpu", "--region", "chr20:400-3000"]),
     # every command of this one is a sub-module of the hot path or its tail (no phasing, no tagging database): executed from end to end
     ("ont_whole", "ont_r10_dorado_sup_5khz", ["--disable_intermediate_phasing", "--disable_nonsomatic_tagging"]),
+    # the same with the knobs turned: RefCall rows through sort_vcf / postprocess_vcf, a confident BED, other gates, a sample name (-> tmp_T1, snv_T1.vcf)
+    ("ont_whole_knobs", "ont_r10_dorado_sup_5khz", ["--disable_intermediate_phasing", "--disable_nonsomatic_tagging", "--print_ref_calls", "--bed_fn", "@bed@",
+                                                    "--qual", "12", "--snv_min_af", "0.08", "--indel_min_af", "0.12", "--min_coverage", "6", "--sample_name", "T1",
+                                                    "--max_indel_length", "50"]),
 ]
 EXEC = {"ont": ("extract_candidates_calling", "concat_files"), "ont_bed": ("extract_candidates_calling",), "ont_indel_bed": ("extract_candidates_calling",),
         "ont_hybrid": ("extract_candidates_calling",), "ont_genotyping": ("extract_candidates_calling",),
         # STEP 1 under the other platforms' gates (--min_bq, --indel_min_af of run_clairs_to's platform tables) on the same simulated pileup
         "ilmn": ("extract_candidates_calling", "concat_files"), "hifi": ("extract_candidates_calling", "concat_files"),
-        "ont_whole": ("extract_candidates_calling", "concat_files")}
+        "ont_whole": ("extract_candidates_calling", "concat_files"), "ont_whole_knobs": ("extract_candidates_calling", "concat_files")}
 TAIL = ("concat_files", "create_tensor_pileup_calling", "predict", "call_variants", "sort_vcf", "postprocess_vcf")
 
 
@@ -269,7 +273,8 @@ def main():
             print("dry run", name, len(commands), "commands,", len(inv), "sub-module invocations")
             if name not in EXEC:
                 continue
-            wt = os.path.join(w, "tmp")
+            tmp_name = "tmp" if os.path.isdir(os.path.join(w, "tmp")) else [d for d in sorted(os.listdir(w)) if d.startswith("tmp")][0]
+            wt = os.path.join(w, tmp_name)                                      # tmp_<sample name> when one is given
             rec = dict(work_files={k: norm(open(os.path.join(wt, k)).read(), tmp, w) for k in ("CHUNK_LIST", "CONTIGS")})
             for sd in ("split_beds", "split_indel_beds"):
                 if os.path.isdir(os.path.join(wt, sd)):
@@ -311,7 +316,9 @@ def main():
                     rec["vcf_output_show_ref"] = folder_files(os.path.join(wt, "vcf_output_show_ref"), w, tmp)
                 else:
                     del rec["vcf_output_show_ref"]
-            if name == "ont_whole":
+            if tmp_name != "tmp":
+                rec["tmp"] = tmp_name
+            if name.startswith("ont_whole"):
                 # the whole run: the dry run's commands 1.. in order - STEP 2, sort_vcf, `ln -sf` (STEP 3 without the databases,
                 # run_clairs_to:1356-1360), postprocess_vcf, STEP 6, sort_vcf, `ln -sf`, postprocess_vcf - down to <output>/snv.vcf and indel.vcf
                 if os.path.exists(os.path.join(wt, "CMD")):

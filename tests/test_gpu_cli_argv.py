@@ -42,19 +42,19 @@ class Work:
     def __init__(self, tmp_path, name, rec, g):
         self.t = str(tmp_path)
         self.w = os.path.join(self.t, "runs", name)
+        self.tmp = rec.get("tmp", "tmp")                                 # tmp_<sample name> when the run names one
         self.inputs = clisim.write_inputs(os.path.join(self.t, "in"))
         for k, text in g["inputs"].items():
             assert open(self.inputs[k]).read() == text, k               # the generator's inputs, regenerated
         clisim.write_shims(os.path.join(self.t, "bin"))
         self.old_path = os.environ["PATH"]
-        for sub in ("tmp/candidates", "tmp/predict", "tmp/vcf_output", "tmp/pileup_tensor_can_affirmative", "tmp/pileup_tensor_can_negational",
-                    "tmp/split_beds", "tmp/split_indel_beds"):
-            os.makedirs(os.path.join(self.w, sub), exist_ok=True)
+        for sub in ("candidates", "predict", "vcf_output", "pileup_tensor_can_affirmative", "pileup_tensor_can_negational", "split_beds", "split_indel_beds"):
+            os.makedirs(os.path.join(self.w, self.tmp, sub), exist_ok=True)
         for k, text in rec["work_files"].items():
-            open(os.path.join(self.w, "tmp", k), "w").write(self.real(text))
+            open(os.path.join(self.w, self.tmp, k), "w").write(self.real(text))
         for d in ("split_beds", "split_indel_beds"):
             for f, text in rec.get(d, {}).items():
-                open(os.path.join(self.w, "tmp", d, f), "w").write(text)
+                open(os.path.join(self.w, self.tmp, d, f), "w").write(text)
 
     def __enter__(self):
         os.environ["PATH"] = os.path.join(self.t, "bin") + ":" + self.old_path
@@ -72,7 +72,7 @@ class Work:
 
     def files(self, sub):
         out = {}
-        d = os.path.join(self.w, "tmp", sub)
+        d = os.path.join(self.w, self.tmp, sub)
         for base, _, names in os.walk(d):
             for f in names:
                 out[os.path.relpath(os.path.join(base, f), d)] = open(os.path.join(base, f)).read().replace(self.w, "@W@").replace(self.t, "@T@")
@@ -177,11 +177,11 @@ def test_step2_and_step6_with_the_references_argv(tmp_path, golden, name):
             assert n == {"concat_files": 1, "create_tensor_pileup_calling": 12, "predict": 6, "call_variants": 6}
         # tensor text: byte-identical (the reference's gzip stream is not reproducible; its content is)
         for f, sha in rec["tensor_sha256"].items():
-            assert hashlib.sha256(gzip.open(os.path.join(wk.w, "tmp", f), "rb").read()).hexdigest() == sha, f
+            assert hashlib.sha256(gzip.open(os.path.join(wk.w, wk.tmp, f), "rb").read()).hexdigest() == sha, f
         # probability rows
         for f, text in rec["predict"].items():
             K = 4 if f.endswith("_snv") else 6
-            got = [r.split("\t") for r in gzip.open(os.path.join(wk.w, "tmp", "predict", f), "rt").read().split("\n") if r]
+            got = [r.split("\t") for r in gzip.open(os.path.join(wk.w, wk.tmp, "predict", f), "rt").read().split("\n") if r]
             want = [r.split("\t") for r in text.split("\n") if r]
             assert len(got) == len(want) > (10 if K == 4 else 2)
             worst = 0.0
@@ -198,7 +198,7 @@ def test_step2_and_step6_with_the_references_argv(tmp_path, golden, name):
             assert same_vcf_but_the_last_digit(got[f], text, f) > 0
         # call_variants on the reference's own probability files: the whole VCF, byte for byte, with and without --show_ref
         for f, text in rec["predict"].items():
-            with gzip.open(os.path.join(wk.w, "tmp", "predict", f), "wt") as out:
+            with gzip.open(os.path.join(wk.w, wk.tmp, "predict", f), "wt") as out:
                 out.write(text)
         for sub, argv in rec["step2_argv"]:
             if sub != "call_variants":
@@ -214,13 +214,19 @@ def test_step2_and_step6_with_the_references_argv(tmp_path, golden, name):
             assert wk.files("vcf_output_show_ref") == rec["vcf_output_show_ref"]
 
 
-def test_the_whole_run_without_phasing(tmp_path, golden):
+WHOLE = ["ont_whole", "ont_whole_knobs"]
+
+
+@pytest.mark.parametrize("name", WHOLE)
+def test_the_whole_run_without_phasing(tmp_path, golden, name):
     """`run_clairs_to --disable_intermediate_phasing --disable_nonsomatic_tagging`: every command of that run is a sub-module of the hot path
     or of its tail, so the reference executed all fifteen on the simulated pileup (gen_cli.py: STEP 1, STEP 2, sort_vcf, `ln -sf`,
     postprocess_vcf, STEP 6, sort_vcf, `ln -sf`, postprocess_vcf) - the same command lines through `python -m clairs_to_amd`'s dispatcher
-    must leave <output>/snv.vcf and <output>/indel.vcf as the reference left them."""
-    rec = golden["executed"]["ont_whole"]
-    with Work(tmp_path, "ont_whole", rec, golden) as wk:
+    must leave <output>/snv.vcf and <output>/indel.vcf as the reference left them.  `ont_whole_knobs`: the same run with --print_ref_calls
+    (RefCall rows through sort_vcf and postprocess_vcf), a confident BED, --qual 12, other AF / coverage gates, --max_indel_length 50 and a
+    sample name (work folder tmp_T1, outputs snv_T1.vcf / indel_T1.vcf; the merged VCFs keep SAMPLE: sort_vcf is not told the name)."""
+    rec = golden["executed"][name]
+    with Work(tmp_path, name, rec, golden) as wk:
         for sub, argv in rec["step1_argv"]:
             wk.run(sub, argv)
         same_candidates(wk.files("candidates"), rec["candidates"])
@@ -243,14 +249,14 @@ def test_the_whole_run_without_phasing(tmp_path, golden):
         n, final = tail()
         assert n == {"concat_files": 1, "create_tensor_pileup_calling": 12, "predict": 6, "call_variants": 6, "sort_vcf": 2, "sh": 2,
                      "postprocess_vcf": 2}
-        assert sorted(final) == sorted(rec["final"]) == ["indel.vcf", "snv.vcf"]
+        assert sorted(final) == sorted(rec["final"]) == (["indel.vcf", "snv.vcf"] if name == "ont_whole" else ["indel_T1.vcf", "snv_T1.vcf"])
         got = wk.files("vcf_output")
         assert sorted(got) == sorted(rec["vcf_output"])
         for f, text in rec["vcf_output"].items():
             same_vcf_but_the_last_digit(got[f], text, f)
         for f, text in rec["final"].items():
-            assert same_vcf_but_the_last_digit(final[f], text, f) > (10 if f == "snv.vcf" else 1)
-        assert "PASS" in rec["final"]["snv.vcf"]
+            assert same_vcf_but_the_last_digit(final[f], text, f) > (10 if f.startswith("snv") else 1)
+            assert "\tPASS\t" in text and ("\tRefCall\t" in text) == (name == "ont_whole_knobs" and f.startswith("snv"))
 
         # the same tail on the reference's own probability files: every file of the run, byte for byte
         def swap(path):
@@ -261,22 +267,33 @@ def test_the_whole_run_without_phasing(tmp_path, golden):
         assert final == rec["final"]
 
 
-def test_the_whole_run_as_one_invocation_per_model(tmp_path, golden):
-    """The same run the way this package is meant to be driven: `call_chunks --region_list` (rows `ctg i/n`), once for the SNV models and
+@pytest.mark.parametrize("name", WHOLE)
+def test_the_whole_run_as_one_invocation_per_model(tmp_path, golden, name):
+    """The same runs the way this package is meant to be driven: `call_chunks --region_list` (rows `ctg i/n`), once for the SNV models and
     once for the indel models - extraction, tensor creation, both networks, the epilogue, the chunk VCFs, sort_vcf and postprocess_vcf in
     one process each, no candidates folder, no tensor or probability files - must leave the final snv.vcf / indel.vcf the REFERENCE left
     after its fifteen commands (records with QUAL / GQ free in the last digit: these probabilities never pass through the 6-decimal
     text of the probability files)."""
     from clairs_to_amd.call_chunks import main as call_chunks
-    rec = golden["executed"]["ont_whole"]
+    rec = golden["executed"][name]
     opt = lambda argv, k: argv[argv.index(k) + 1]
     a1 = rec["step1_argv"][0][1]
     n_chunks = int(opt(a1, "--chunk_num"))
+    first = lambda sub: [a for s, a in rec["whole_argv"] if s == sub][0]
     post = {("snv" if "True" == opt(a, "--disable_indel_calling") else "indel"): a for s, a in rec["whole_argv"] if s == "postprocess_vcf"}
-    with Work(tmp_path, "ont_whole", rec, golden) as wk:
+    with Work(tmp_path, name, rec, golden) as wk:
         write_models(wk, tmp_path)
         regions = tmp_path / "REGIONS"
         regions.write_text("".join("%s %d/%d\n" % (clisim.CTG, i + 1, n_chunks) for i in range(n_chunks)))
+        modes = ["--snv_min_af", opt(a1, "--snv_min_af"), "--indel_min_af", opt(a1, "--indel_min_af"), "--min_coverage", opt(a1, "--min_coverage")]
+        for k in ("--bed_fn", "--bed_fn_source", "--call_indels_only_in_these_regions"):
+            if k in a1 and opt(a1, k) != "None":
+                modes += [k, wk.real(opt(a1, k))]
+        if "--show_ref" in first("call_variants"):
+            modes += ["--show_ref"]
+        if "--max_indel_length" in first("create_tensor_pileup_calling"):
+            modes += ["--max_indel_length", opt(first("create_tensor_pileup_calling"), "--max_indel_length")]
+        sample = opt(post["snv"], "--sample_name")
         for mode in ("snv", "indel"):
             pa = post[mode]
             out = tmp_path / ("chunks_" + mode)
@@ -285,15 +302,17 @@ def test_the_whole_run_as_one_invocation_per_model(tmp_path, golden):
                          "--chkpnt_fn_acgt", os.path.join(wk.t, "models", "aff_%s.pkl" % mode),
                          "--chkpnt_fn_nacgt", os.path.join(wk.t, "models", "neg_%s.pkl" % mode),
                          "--likelihood_matrix_data", os.path.join(wk.t, "models", "lik_%s.txt" % mode),
-                         "--disable_indel_calling", str(mode == "snv"),
-                         "--snv_min_af", opt(a1, "--snv_min_af"), "--indel_min_af", opt(a1, "--indel_min_af"), "--min_coverage", opt(a1, "--min_coverage"),
-                         "--merged_vcf_fn", os.path.join(wk.w, "tmp", "vcf_output", mode + "_pileup.vcf"), "--final_vcf_fn", wk.real(opt(pa, "--output_fn")),
+                         "--disable_indel_calling", str(mode == "snv")] + modes +
+                        ["--merged_vcf_fn", os.path.join(wk.w, wk.tmp, "vcf_output", mode + "_pileup.vcf"), "--final_vcf_fn", wk.real(opt(pa, "--output_fn")),
                          "--postprocess_qual", opt(pa, "--qual"), "--postprocess_qual_cutoff_phaseable_region", opt(pa, "--qual_cutoff_phaseable_region"),
                          "--postprocess_qual_cutoff_unphaseable_region", opt(pa, "--qual_cutoff_unphaseable_region"), "--postprocess_af", opt(pa, "--af"),
-                         "--sample_name", opt(pa, "--sample_name"), "--cmdline", wk.real(opt(pa, "--cmdline"))])
+                         "--sample_name", sample, "--cmdline", wk.real(opt(pa, "--cmdline"))])
         merged = wk.files("vcf_output")
         for mode in ("snv", "indel"):
-            same_vcf_but_the_last_digit(merged[mode + "_pileup.vcf"], rec["vcf_output"][mode + "_pileup.vcf"], mode)
-            got = open(os.path.join(wk.w, mode + ".vcf")).read().replace(wk.w, "@W@").replace(wk.t, "@T@")
-            assert same_vcf_but_the_last_digit(got, rec["final"][mode + ".vcf"], mode) > (10 if mode == "snv" else 1)
-        assert not os.listdir(os.path.join(wk.w, "tmp", "candidates")) and not os.listdir(os.path.join(wk.w, "tmp", "predict"))
+            # the reference's sort_vcf is not told the sample name (run_clairs_to:1309-1315): its merged VCF says SAMPLE, this one the name given
+            want = rec["vcf_output"][mode + "_pileup.vcf"].replace("\tFORMAT\tSAMPLE\n", "\tFORMAT\t%s\n" % sample)
+            same_vcf_but_the_last_digit(merged[mode + "_pileup.vcf"], want, mode)
+            fn = opt(post[mode], "--output_fn")
+            got = open(wk.real(fn)).read().replace(wk.w, "@W@").replace(wk.t, "@T@")
+            assert same_vcf_but_the_last_digit(got, rec["final"][os.path.basename(fn)], mode) > (10 if mode == "snv" else 1)
+        assert not os.listdir(os.path.join(wk.w, wk.tmp, "candidates")) and not os.listdir(os.path.join(wk.w, wk.tmp, "predict"))
