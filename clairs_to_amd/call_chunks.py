@@ -596,6 +596,7 @@ def main(argv=None):
     p.add_argument("--min_coverage", type=float, default=4, help="--region_list: --min_coverage")
     p.add_argument("--alternative_base_num", type=int, default=3, help="--region_list: --alternative_base_num")
     p.add_argument("--extract_min_mq", type=int, default=20, help="--region_list: --min_mq of extract_candidates_calling")
+    p.add_argument("--extract_min_bq", type=int, default=None, help="--region_list: --min_bq of extract_candidates_calling (default: --min_bq, as run_clairs_to passes the same value to both)")
     p.add_argument("--bed_fn", type=str, default=None,
                    help="--region_list: confident regions (extract_candidates_calling --bed_fn, :249-260, 302): positions outside its rows have no pileup row - "
                         "no candidate there, and `ctg i/n` rows of --region_list cut the span of its rows; a missing file is no BED")

@@ -243,12 +243,16 @@ DRY_MATRIX = [
     ("ont_whole_knobs", "ont_r10_dorado_sup_5khz", ["--disable_intermediate_phasing", "--disable_nonsomatic_tagging", "--print_ref_calls", "--bed_fn", "@bed@",
                                                     "--qual", "12", "--snv_min_af", "0.08", "--indel_min_af", "0.12", "--min_coverage", "6", "--sample_name", "T1",
                                                     "--max_indel_length", "50"]),
+    # and under two other platform tables: --min_bq 15 (the 4 kHz HAC model's gate, in extraction and in the affirmative tensors), HiFi's gates
+    ("ont_hac_whole", "ont_r10_dorado_hac_4khz", ["--disable_intermediate_phasing", "--disable_nonsomatic_tagging"]),
+    ("hifi_whole", "hifi_revio", ["--disable_intermediate_phasing", "--disable_nonsomatic_tagging"]),
 ]
 EXEC = {"ont": ("extract_candidates_calling", "concat_files"), "ont_bed": ("extract_candidates_calling",), "ont_indel_bed": ("extract_candidates_calling",),
         "ont_hybrid": ("extract_candidates_calling",), "ont_genotyping": ("extract_candidates_calling",),
         # STEP 1 under the other platforms' gates (--min_bq, --indel_min_af of run_clairs_to's platform tables) on the same simulated pileup
         "ilmn": ("extract_candidates_calling", "concat_files"), "hifi": ("extract_candidates_calling", "concat_files"),
-        "ont_whole": ("extract_candidates_calling", "concat_files"), "ont_whole_knobs": ("extract_candidates_calling", "concat_files")}
+        "ont_whole": ("extract_candidates_calling", "concat_files"), "ont_whole_knobs": ("extract_candidates_calling", "concat_files"),
+        "ont_hac_whole": ("extract_candidates_calling", "concat_files"), "hifi_whole": ("extract_candidates_calling", "concat_files")}
 TAIL = ("concat_files", "create_tensor_pileup_calling", "predict", "call_variants", "sort_vcf", "postprocess_vcf")
 
 
@@ -318,7 +322,7 @@ def main():
                     del rec["vcf_output_show_ref"]
             if tmp_name != "tmp":
                 rec["tmp"] = tmp_name
-            if name.startswith("ont_whole"):
+            if "whole" in name:
                 # the whole run: the dry run's commands 1.. in order - STEP 2, sort_vcf, `ln -sf` (STEP 3 without the databases,
                 # run_clairs_to:1356-1360), postprocess_vcf, STEP 6, sort_vcf, `ln -sf`, postprocess_vcf - down to <output>/snv.vcf and indel.vcf
                 if os.path.exists(os.path.join(wt, "CMD")):

@@ -214,7 +214,7 @@ def test_step2_and_step6_with_the_references_argv(tmp_path, golden, name):
             assert wk.files("vcf_output_show_ref") == rec["vcf_output_show_ref"]
 
 
-WHOLE = ["ont_whole", "ont_whole_knobs"]
+WHOLE = ["ont_whole", "ont_whole_knobs", "ont_hac_whole", "hifi_whole"]
 
 
 @pytest.mark.parametrize("name", WHOLE)
@@ -224,7 +224,8 @@ def test_the_whole_run_without_phasing(tmp_path, golden, name):
     postprocess_vcf, STEP 6, sort_vcf, `ln -sf`, postprocess_vcf) - the same command lines through `python -m clairs_to_amd`'s dispatcher
     must leave <output>/snv.vcf and <output>/indel.vcf as the reference left them.  `ont_whole_knobs`: the same run with --print_ref_calls
     (RefCall rows through sort_vcf and postprocess_vcf), a confident BED, --qual 12, other AF / coverage gates, --max_indel_length 50 and a
-    sample name (work folder tmp_T1, outputs snv_T1.vcf / indel_T1.vcf; the merged VCFs keep SAMPLE: sort_vcf is not told the name)."""
+    sample name (work folder tmp_T1, outputs snv_T1.vcf / indel_T1.vcf; the merged VCFs keep SAMPLE: sort_vcf is not told the name).
+    `ont_hac_whole` / `hifi_whole`: the run under two other platform tables (--min_bq 15 in extraction and in the affirmative tensors; HiFi's gates)."""
     rec = golden["executed"][name]
     with Work(tmp_path, name, rec, golden) as wk:
         for sub, argv in rec["step1_argv"]:
@@ -249,7 +250,7 @@ def test_the_whole_run_without_phasing(tmp_path, golden, name):
         n, final = tail()
         assert n == {"concat_files": 1, "create_tensor_pileup_calling": 12, "predict": 6, "call_variants": 6, "sort_vcf": 2, "sh": 2,
                      "postprocess_vcf": 2}
-        assert sorted(final) == sorted(rec["final"]) == (["indel.vcf", "snv.vcf"] if name == "ont_whole" else ["indel_T1.vcf", "snv_T1.vcf"])
+        assert sorted(final) == sorted(rec["final"]) == (["indel_T1.vcf", "snv_T1.vcf"] if name == "ont_whole_knobs" else ["indel.vcf", "snv.vcf"])
         got = wk.files("vcf_output")
         assert sorted(got) == sorted(rec["vcf_output"])
         for f, text in rec["vcf_output"].items():
@@ -291,6 +292,7 @@ def test_the_whole_run_as_one_invocation_per_model(tmp_path, golden, name):
                 modes += [k, wk.real(opt(a1, k))]
         if "--show_ref" in first("call_variants"):
             modes += ["--show_ref"]
+        modes += ["--min_bq", opt(first("create_tensor_pileup_calling"), "--min_bq"), "--extract_min_bq", opt(a1, "--min_bq")]      # 20 / 15 (HAC) / HiFi's
         if "--max_indel_length" in first("create_tensor_pileup_calling"):
             modes += ["--max_indel_length", opt(first("create_tensor_pileup_calling"), "--max_indel_length")]
         sample = opt(post["snv"], "--sample_name")
