@@ -225,7 +225,8 @@ template <class P> __device__ __forceinline__ void lds_st8(P p, unsigned a, unsi
 template <class P> __device__ __forceinline__ void lds_st4(P p, unsigned a) { *(__attribute__((address_space(3))) unsigned*)p = a; }
 
 // `rev_from` >= 0: the query is qraw[rev_from], qraw[rev_from - 1], ... (the reversed prefix of the backward pass)
-template <int LW>
+// BEHIND_NEG: the entries j >= seg score -6 against every reference base (row_pass_regs computes those positions) instead of padding's 0
+template <int LW, bool BEHIND_NEG = false>
 __device__ __forceinline__ void build_profile(lds_u16 prof, const signed char* qraw, int Q, int seg, int SP, int l, int rev_from) {
     for (int j = 0; j < SP; ++j) {
         const int q = l * seg + j;
@@ -233,6 +234,7 @@ __device__ __forceinline__ void build_profile(lds_u16 prof, const signed char* q
         unsigned w = 0u;
 #pragma unroll
         for (int rc = 0; rc < 5; ++rc) w |= (c == 7 ? 3u : ((c == rc && rc < 4) ? 5u : 0u)) << (3 * rc);
+        if (BEHIND_NEG && j >= seg) w = 0u;
         prof[l * SP + j] = static_cast<unsigned short>(w);
     }
 }
@@ -427,6 +429,191 @@ __device__ RowPass row_pass(const signed char* refc, int r_begin, int r_end, int
     return RowPass{overflow ? 255 : best, ref_end, read_end, overflow};
 }
 
+// A run of 63 matching bases on one diagonal carries H to 249 - the 8-bit pass's overflow threshold (ssw.c:165, 243-247: max + bias >= 255)
+// - whatever else the matrix holds: a column computes H = max(diagonal + score, E, F) with saturating bytes, so H never falls below the
+// diagonal's chain.  A haplotype begins and ends like its window's reference, so for the haplotype-length classes the 8-bit pass is
+// known to give up before it starts: the row says so and leaves (the 16-bit pass computes the alignment either way).
+__device__ __forceinline__ bool sure_overflow16(const signed char* refc, int R, const signed char* qraw, int Q, int l) {
+    if (R < 64 || Q < 64) return false;
+    int okp = 1, oks = 1;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int i = 4 * l + t;
+        const int a = refc[i], b = qraw[i], c = refc[R - 64 + i], d = qraw[Q - 64 + i];
+        okp &= int(a == b && unsigned(a) < 4u);
+        oks &= int(c == d && unsigned(c) < 4u);
+    }
+    return row_min<16>(okp) != 0 || row_min<16>(oks) != 0;
+}
+
+// The same pass with the H column and E in REGISTERS (round 6, late): NG groups of eight stripe positions per lane, the loop over a
+// stripe unrolled so that every group has registers of its own; the LDS holds the profile only (2 bytes per position instead of 6).  Why:
+// the three long classes' 16-bit launches are the stage (5-6 ms of its 8.5), their LDS footprint (31 KB a wavefront at 590 bases) leaves a
+// CU five wavefronts - one to a SIMD, which then issues a chain of dependent instructions at 5-6 clocks each with nothing beside it -
+// and while they hold the LDS the short classes' launches wait.  The arithmetic is row_pass's, position for position.  What differs is
+// the end of a stripe: row_pass masks the positions j >= seg of the last group (TAIL); here they are computed like any other, against a
+// profile entry that scores -6 for every reference base (build_profile<.., true>), and are inert -
+//   * their H never exceeds the best score seen before this column (diagonal: an H of the previous column - 6; E: an earlier H - 8) or lies
+//     below an H of the same lane and column (F), so they neither set a maximum nor equal a new one;
+//   * they feed positions j >= seg only (diagonal and F run towards higher j), except through the two values a lane hands on: its outgoing
+//     F and the H of its last position - both are taken where position seg - 1 is computed (`fout`, `hlast`), not at the end of the loop.
+template <bool BYTE, int NG>
+__device__ RowPass row_pass_regs(const signed char* refc, int r_begin, int r_end, int r_step, lds_u16 prof, int Q, int seg, int SP, int terminate, int l) {
+    constexpr int LW = BYTE ? 16 : 8;
+    const int lb = l * SP;
+    unsigned Hr[NG][4], Er[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { Hr[g][k] = 0u; Er[g][k] = 0u; }
+    int best = 0, ref_end = BYTE ? -1 : 0, best_q = 0x7fffffff;
+    bool overflow = false;
+    int fin = 0, hlast = 0;
+    const int D = kGapE * seg;
+    const int gl = (seg - 1) >> 3, rl_ = (seg - 1) & 7;          // the group and the place in it of the stripe's last position
+    const int n_col = (r_end - r_begin) * r_step;
+    int rc = n_col > 0 ? refc[r_begin] : 0, rc_next = n_col > 1 ? refc[r_begin + r_step] : 0;
+    int col = 0;
+    const lds_u16 pr = prof + lb;
+    for (int i = r_begin; i != r_end; i += r_step, ++col) {
+        const int rc_next2 = col + 2 < n_col ? refc[i + 2 * r_step] : 0;
+        int f = 0, colmax = 0, garg = 0, fout = 0;
+        int h = row_shl1<LW>(max(hlast, max(fin - kGapE * (seg - 1), 0)), l);
+        const unsigned shv = unsigned(3 * (unsigned(rc) < 4u ? rc : 4));
+        int fg = fin;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (8 * g < seg) {
+                const int j0 = 8 * g;
+                const u32x4 p8 = lds_ld16(pr + j0);
+                const unsigned pw[4] = {p8.x, p8.y, p8.z, p8.w};
+                unsigned hw[4] = {Hr[g][0], Hr[g][1], Hr[g][2], Hr[g][3]};
+                const unsigned ew[4] = {Er[g][0], Er[g][1], Er[g][2], Er[g][3]};
+                const unsigned fg2 = pk2(fg, fg);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) hw[k] = pk_max(hw[k], pk_subs(fg2, pk2(kGapE * 2 * k, kGapE * (2 * k + 1))));
+                fg = max(fg - kGapE * 8, 0);
+                unsigned tp[4], up[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned dg = k == 0 ? ((unsigned(h) & 0xffffu) | (hw[0] << 16)) : __builtin_amdgcn_alignbit(hw[k], hw[k - 1], 16);
+                    const unsigned fld = (pw[k] >> shv) & 0x00070007u;
+                    unsigned x;
+                    if (BYTE) {
+                        const u16x2 s2 = __builtin_bit_cast(u16x2, dg) + __builtin_bit_cast(u16x2, fld) * (unsigned short)2;
+                        x = pk_subs(__builtin_bit_cast(unsigned, __builtin_elementwise_min(s2, (u16x2){255, 255})), pk2(kBias, kBias));
+                    } else {
+                        const i16x2 sc = __builtin_bit_cast(i16x2, fld) * (short)2 - (short)6;
+                        x = __builtin_bit_cast(unsigned, __builtin_elementwise_add_sat(__builtin_bit_cast(i16x2, dg), sc));
+                    }
+                    tp[k] = pk_max(x, ew[k]);
+                    up[k] = pk_subs(tp[k], pk2(kGapO, kGapO));
+                }
+                h = int(hw[3] >> 16);
+                unsigned gm2 = 0u;
+                int fb[9];                                     // F in front of position j0 + t (fb[8]: behind the group)
+                fb[0] = f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    fb[2 * k + 1] = max(fb[2 * k] - kGapE, int(up[k] & 0xffffu));
+                    fb[2 * k + 2] = max(fb[2 * k + 1] - kGapE, int(up[k] >> 16));
+                    const unsigned hh = pk_max(tp[k], pk2(fb[2 * k], fb[2 * k + 1]));
+                    Er[g][k] = pk_max(pk_subs(ew[k], pk2(kGapE, kGapE)), pk_subs(hh, pk2(kGapO, kGapO)));
+                    Hr[g][k] = hh;
+                    gm2 = pk_max(gm2, hh);
+                }
+                f = fb[8];
+                const int gm = max(int(gm2 & 0xffffu), int(gm2 >> 16));
+                if (gm > colmax) { colmax = gm; garg = j0; }
+                if (g == gl) {                                 // the stripe ends in this group: what the lane hands on
+                    int fo = fb[1];
+                    unsigned w = Hr[g][0];
+#pragma unroll
+                    for (int t = 1; t < 8; ++t) if (rl_ == t) { fo = fb[t + 1]; w = Hr[g][t >> 1]; }
+                    fout = fo;
+                    hlast = int((rl_ & 1) ? (w >> 16) : (w & 0xffffu));
+                }
+            }
+        }
+        fin = row_shl1<LW>(fout, l);
+        fin = max(fin, max(row_shl<LW, 1>(fin, l) - D, 0));
+        fin = max(fin, max(row_shl<LW, 2>(fin, l) - 2 * D, 0));
+        fin = max(fin, max(row_shl<LW, 4>(fin, l) - 4 * D, 0));
+        if (LW == 16) fin = max(fin, max(row_shl<LW, 8>(fin, l) - 8 * D, 0));
+        const int lane_max = colmax;
+        colmax = row_max<LW>(max(colmax, fin));
+        if (colmax > best) {
+            best = colmax;
+            if (BYTE && best + kBias >= 255) { overflow = true; break; }
+            ref_end = i;
+            int mq = 0x7fffffff;
+            if (fin == best) mq = l * seg;
+            else if (lane_max == best) {
+                const unsigned bb = pk2(best, best);
+                const int s0 = garg;
+                unsigned sv[4] = {Hr[0][0], Hr[0][1], Hr[0][2], Hr[0][3]};
+#pragma unroll
+                for (int g = 1; g < NG; ++g) if (s0 == 8 * g) { sv[0] = Hr[g][0]; sv[1] = Hr[g][1]; sv[2] = Hr[g][2]; sv[3] = Hr[g][3]; }
+#pragma unroll
+                for (int k = 3; k >= 0; --k) {
+                    const unsigned x = sv[k] ^ bb;
+                    if (s0 + 2 * k + 1 < seg && (x >> 16) == 0u) mq = l * seg + s0 + 2 * k + 1;
+                    if (s0 + 2 * k < seg && (x & 0xffffu) == 0u) mq = l * seg + s0 + 2 * k;
+                }
+            }
+            best_q = row_min<LW>(mq);
+        }
+        if (colmax == terminate) break;
+        rc = rc_next; rc_next = rc_next2;
+    }
+    int read_end = Q - 1;
+    if (best == 0) read_end = min(read_end, 0);
+    else if (best_q < read_end) read_end = best_q;
+    return RowPass{overflow ? 255 : best, ref_end, read_end, overflow};
+}
+
+template <bool BYTE, int NG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NG <= 4 ? 4 : (NG <= 12 ? 3 : 2)))) void k_sw_regs(const signed char* pool, const SwDesc* desc, const int* order, int n, Ends* out,
+                                                  unsigned char* overflowed, int segcap) {
+    constexpr int LW = BYTE ? 16 : 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int row = threadIdx.x / LW, l = threadIdx.x % LW;
+    const int slot = blockIdx.x * (blockDim.x / LW) + row;
+    bool live = slot < n;
+    const int k = live ? order[slot] : 0;
+    if (!BYTE && live && !overflowed[k]) live = false;
+    const int SP = sw_sp(segcap);
+    const lds_u16 prof = (lds_u16)(lds + size_t(row) * (size_t(SP) * LW * sizeof(short)));
+    if (!live) return;
+    // the longest alignments are the end of the stage: their wavefronts go first where a SIMD's wavefronts compete for issue slots
+    __builtin_amdgcn_s_setprio(NG >= 12 ? 3 : (NG >= 8 ? 2 : 1));
+    const SwDesc d = desc[k];
+    const signed char* refc = pool + d.ref_off;
+    const signed char* qraw = pool + d.q_off;
+    Ends e{0, 0, 0, 0, 0, 16};
+    bool ovf = false;
+    if (BYTE && sure_overflow16(refc, d.R, qraw, d.Q, l)) {
+        if (l == 0) overflowed[k] = 1;
+        return;
+    }
+    if (d.R > 0 && d.Q > 0) {
+        const int seg = (d.Q + LW - 1) / LW;
+        build_profile<LW, true>(prof, qraw, d.Q, seg, SP, l, -1);
+        const RowPass fw = row_pass_regs<BYTE, NG>(refc, 0, d.R, 1, prof, d.Q, seg, SP, BYTE ? 255 : 65535, l);
+        if (BYTE && fw.overflow) ovf = true;
+        else if (fw.score > 0) {
+            const int Q2 = fw.read_end + 1, seg2 = (Q2 + LW - 1) / LW;
+            build_profile<LW, true>(prof, qraw, Q2, seg2, SP, l, fw.read_end);
+            const RowPass bw = row_pass_regs<BYTE, NG>(refc, fw.ref_end, -1, -1, prof, Q2, seg2, SP, fw.score, l);
+            e = Ends{fw.score, fw.ref_end, fw.read_end, bw.ref_end, bw.read_end, LW};
+        }
+    }
+    if (l == 0) {
+        if (BYTE) overflowed[k] = ovf ? 1 : 0;
+        if (!ovf) out[k] = e;
+    }
+}
+
 template <bool BYTE>
 __global__ __launch_bounds__(64) void k_sw(const signed char* pool, const SwDesc* desc, const int* order, int n, Ends* out,
                                              unsigned char* overflowed, int segcap) {
@@ -452,6 +639,10 @@ __global__ __launch_bounds__(64) void k_sw(const signed char* pool, const SwDesc
     const signed char* qraw = pool + d.q_off;
     Ends e{0, 0, 0, 0, 0, 16};
     bool ovf = false;
+    if (BYTE && sure_overflow16(refc, d.R, qraw, d.Q, l)) {
+        if (l == 0) overflowed[k] = 1;
+        return;
+    }
     if (d.R > 0 && d.Q > 0) {
         const int seg = (d.Q + LW - 1) / LW;
         build_profile<LW>(prof, qraw, d.Q, seg, SP, l, -1);
@@ -860,6 +1051,18 @@ int launch_sw(hipStream_t s, const signed char* pool, const SwDesc* desc, const 
             if (dev >= 0 && dev < 64) done[dev].store(1, std::memory_order_release);
         }
     }
+    // stripes of 17 .. 128 positions: the register form (row_pass_regs) - the LDS holds the profile only
+    static const bool regs_on = !(std::getenv("CTO_SW_REGS") && atoi(std::getenv("CTO_SW_REGS")) == 0);
+    if (regs_on && segcap > 16 && segcap <= 128 && ROWS == 64 / LW) {
+        const size_t pm = size_t(sw_sp(segcap)) * LW * sizeof(short) * ROWS;
+        const dim3 grid(unsigned((n + ROWS - 1) / ROWS)), block(unsigned(LW * ROWS));
+        if (segcap <= 32) hipLaunchKernelGGL((k_sw_regs<BYTE, 4>), grid, block, pm, s, pool, desc, order, n, out, overflowed, segcap);
+        else if (segcap <= 64) hipLaunchKernelGGL((k_sw_regs<BYTE, 8>), grid, block, pm, s, pool, desc, order, n, out, overflowed, segcap);
+        else if (segcap <= 96) hipLaunchKernelGGL((k_sw_regs<BYTE, 12>), grid, block, pm, s, pool, desc, order, n, out, overflowed, segcap);
+        else hipLaunchKernelGGL((k_sw_regs<BYTE, 16>), grid, block, pm, s, pool, desc, order, n, out, overflowed, segcap);
+        CTO_HIP(hipGetLastError());
+        return CTO_OK;
+    }
     hipLaunchKernelGGL((k_sw<BYTE>), dim3(unsigned((n + ROWS - 1) / ROWS)), dim3(unsigned(LW * ROWS)), smem, s, pool, desc, order, n, out, overflowed, segcap);
     CTO_HIP(hipGetLastError());
     return CTO_OK;
@@ -988,26 +1191,30 @@ int sw_ends_pool(const PoolVec& pool, const std::vector<SwDesc>& desc, hipStream
     CTO_HIP(hipEventRecord(fork, s));
     int made = 0, used = 0;
     rc = CTO_OK;
-    // at most FOUR streams: the runtime has four hardware queues for a process's streams, and a fifth stream shares one - its launches then
-    // wait behind another class's two launches instead of running beside them (measured: the two shortest classes started when the longest
-    // one's 16-bit launch ended, 3 ms of the stage's 8.5).  The three longest classes get a stream each, the others follow one another on the fourth.
-    constexpr int kStreams = 4;
+    // at most FOUR streams, the caller's included: the runtime has four hardware queues for a process's streams, and one more stream shares
+    // one - its launches then wait behind another class's two launches instead of running beside them (measured: the two shortest classes
+    // started when the longest one's 16-bit launch ended, 3 ms of the stage's 8.5 - and again, late in round 6, with four side streams beside
+    // the caller's idle one).  The three longest classes get a side stream each, the others follow one another on the caller's stream, which
+    // waits for the side streams after its own launches.
+    constexpr int kSide = 3;
     for (int c = kClasses - 1; c >= 0 && rc == CTO_OK; --c) {
         if (cls[c].empty()) continue;
-        const bool own = used < kStreams;
-        hipStream_t t = nullptr;
+        const bool own = used < kSide;
+        hipStream_t t = s;
         if (own) {
             if ((rc = side.get(made, &t)) != CTO_OK) break;
             ++made;
             if (hipStreamWaitEvent(t, fork, 0) != hipSuccess) { rc = CTO_EHIP; break; }
-        } else if ((rc = side.get(made - 1, &t)) != CTO_OK) break;
+        }
         ++used;
         const int m = int(cls[c].size());
         if ((rc = launch_sw<true>(t, d_pool.p, d_desc.p, d_order.p + at[c], m, d_out.p, d_ovf.p, Rc[c], Qc[c])) ||
             (rc = launch_sw<false>(t, d_pool.p, d_desc.p, d_order.p + at[c], m, d_out.p, d_ovf.p, Rc[c], Qc[c])))
             break;
-        if (hipEventRecord(side.join[made - 1], t) != hipSuccess || hipStreamWaitEvent(s, side.join[made - 1], 0) != hipSuccess) rc = CTO_EHIP;
+        if (own && hipEventRecord(side.join[made - 1], t) != hipSuccess) rc = CTO_EHIP;
     }
+    for (int i = 0; i < made && rc == CTO_OK; ++i)
+        if (hipStreamWaitEvent(s, side.join[i], 0) != hipSuccess) rc = CTO_EHIP;
     auto drop = [&]() {
         for (int i = 0; i < made; ++i) (void)hipStreamSynchronize(side.sx[i]);      // (the streams themselves go back to the cache with `side`)
         (void)hipEventDestroy(fork);
