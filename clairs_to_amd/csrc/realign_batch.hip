@@ -9,13 +9,14 @@
 //                 diagonal is walked when one 16-aligned block of the read matches on it: a run of 32 contains one) and reproduces
 //                 the order-dependent parts of the original (which start a read keeps on a score tie, when a haplotype position
 //                 counts as covered) from the time (haplotype position, read offset) each candidate would have been visited first.
-//   k_sw<byte>,   ssw.c:118-529 (sw_sse2_byte / sw_sse2_word) as ssw_align runs them (:781-830): forward pass, word-mode rerun
-//   k_sw<word>    on overflow, backward pass.  One DPP row is one SSE2 register - 16 lanes in the 8-bit kernel (four alignments per
+//   k_sw*<byte>,  ssw.c:118-529 (sw_sse2_byte / sw_sse2_word) as ssw_align runs them (:781-830): forward pass, word-mode rerun
+//   k_sw*<word>   on overflow, backward pass.  One DPP row is one SSE2 register - 16 lanes in the 8-bit kernel (four alignments per
 //                 wavefront), 8 lanes in the 16-bit kernel (eight per wavefront): lane l holds the stripe positions q = l * seg + j
 //                 of the query exactly as the striped layout of Farrar's kernel does, the byte shift _mm_slli_si128 is row_shr:1.
 //                 The lazy-F loops are computed as what they amount to (a scan over the lanes, one correction applied where the
 //                 next column loads H: row_pass) - their corrections are not fed back into E, and output CIGARs depend on that
-//                 (csrc/realign.cpp header), which the closed form keeps.  H / E columns and the score profile live in LDS.
+//                 (csrc/realign.cpp header), which the closed form keeps.  Stripes of up to 128 positions keep their H / E columns
+//                 in registers and the score profile in LDS (k_sw_regs / row_pass_regs); longer ones all three in LDS (k_sw).
 //   k_banded      ssw.c:531-741 (banded_sw): the traceback between the end points, one wavefront per alignment, for the pairs the
 //                 windows predict they will need (every haplotype against the reference, the pair each unplaced read picks).
 // What is left - haplotype order, the picks, CIGAR composition - is strings and stays on the host (csrc/realign.cpp:
@@ -191,8 +192,8 @@ constexpr int kBias = 6, kGapO = 8, kGapE = 2;
 // LDS of a row, lane-private and contiguous: lane l owns stripe positions j = 0 .. seg-1 at [l * SP + j] of every array (SP = the
 // launch's largest seg rounded up to 16 positions, an odd multiple of 8 so that the lanes' 16-byte reads fall on different banks):
 //   P [LW][SP] shorts    the query profile of SSW (ssw.c:64-116) as one 16-bit word per position: five 3-bit fields f, one per
-//                        reference code (field 4: a reference base that matches nothing), score = 2 f - 6, i.e. f = 5 match (4), 0
-//                        mismatch (-6), 3 padding (0) - a column picks its field with one bit-field extract per position
+//                        reference code (field 4: a reference base that matches nothing) from bit 1 up, score = 2 f - 6, i.e. f = 5
+//                        match (4), 0 mismatch (-6), 3 padding (0) - a column shifts its field down and reads 2 f = score + bias for a pair of positions
 //   H, E [LW][SP] shorts the H column - ONE array, updated in place: the old value of a position is the next position's diagonal and is
 //                        read before the new one is written - and E; 8 positions = one ds_read_b128
 // 6 bytes per stripe position.  Round 5 kept five signed-byte profile planes and two H columns, 11 bytes: the LDS footprint is what
@@ -233,7 +234,7 @@ __device__ __forceinline__ void build_profile(lds_u16 prof, const signed char* q
         const int c = (j < seg && q < Q) ? int(rev_from >= 0 ? qraw[rev_from - q] : qraw[q]) : 7;
         unsigned w = 0u;
 #pragma unroll
-        for (int rc = 0; rc < 5; ++rc) w |= (c == 7 ? 3u : ((c == rc && rc < 4) ? 5u : 0u)) << (3 * rc);
+        for (int rc = 0; rc < 5; ++rc) w |= (c == 7 ? 3u : ((c == rc && rc < 4) ? 5u : 0u)) << (3 * rc + 1);      // bits 1 .. 15: a field reads as 2 f
         if (BEHIND_NEG && j >= seg) w = 0u;
         prof[l * SP + j] = static_cast<unsigned short>(w);
     }
@@ -332,16 +333,14 @@ __device__ RowPass row_pass(const signed char* refc, int r_begin, int r_end, int
             for (int k = 0; k < G / 2; ++k) {
                 // the diagonals of positions 2k, 2k + 1: the old (corrected) H of 2k - 1 and 2k
                 const unsigned dg = k == 0 ? ((unsigned(h) & 0xffffu) | (hw[0] << 16)) : __builtin_amdgcn_alignbit(hw[k], hw[k - 1], 16);
-                const unsigned fld = (pw[k] >> shv) & 0x00070007u;                 // (score + 6) / 2 of both
+                const unsigned fld = (pw[k] >> shv) & 0x000e000eu;                 // score + 6 of both
                 unsigned x;
                 static_assert(kBias == 6, "the profile's fields hold (score + bias) / 2");
-                if (BYTE) {
-                    const u16x2 s2 = __builtin_bit_cast(u16x2, dg) + __builtin_bit_cast(u16x2, fld) * (unsigned short)2;       // h + score + bias
-                    x = pk_subs(__builtin_bit_cast(unsigned, __builtin_elementwise_min(s2, (u16x2){255, 255})), pk2(kBias, kBias));
-                } else {
-                    const i16x2 sc = __builtin_bit_cast(i16x2, fld) * (short)2 - (short)6;
-                    x = __builtin_bit_cast(unsigned, __builtin_elementwise_add_sat(__builtin_bit_cast(i16x2, dg), sc));
-                }
+                const u16x2 s2 = __builtin_bit_cast(u16x2, dg) + __builtin_bit_cast(u16x2, fld);                               // h + score + bias
+                // (16 bits: the reference adds with signed saturation at 32 767 and takes the maximum with E >= 0 next - scores here stay
+                // below 4 x 2 048, and a sum below the bias ends at 0 either way)
+                if (BYTE) x = pk_subs(__builtin_bit_cast(unsigned, __builtin_elementwise_min(s2, (u16x2){255, 255})), pk2(kBias, kBias));
+                else x = pk_subs(__builtin_bit_cast(unsigned, s2), pk2(kBias, kBias));
                 tp[k] = pk_max(x, ew[k]);
                 up[k] = pk_subs(tp[k], pk2(kGapO, kGapO));
             }
@@ -450,27 +449,30 @@ __device__ __forceinline__ bool sure_overflow16(const signed char* refc, int R, 
 // stripe unrolled so that every group has registers of its own; the LDS holds the profile only (2 bytes per position instead of 6).  Why:
 // the three long classes' 16-bit launches are the stage (5-6 ms of its 8.5), their LDS footprint (31 KB a wavefront at 590 bases) leaves a
 // CU five wavefronts - one to a SIMD, which then issues a chain of dependent instructions at 5-6 clocks each with nothing beside it -
-// and while they hold the LDS the short classes' launches wait.  The arithmetic is row_pass's, position for position.  What differs is
+// and while they hold the LDS the short classes' launches wait.  The arithmetic is row_pass's, position for position.  (Stage: 8.5 -> 5.6 ms
+// together with the stream layout of sw_ends_pool and sure_overflow16)  What differs is
 // the end of a stripe: row_pass masks the positions j >= seg of the last group (TAIL); here they are computed like any other, against a
 // profile entry that scores -6 for every reference base (build_profile<.., true>), and are inert -
 //   * their H never exceeds the best score seen before this column (diagonal: an H of the previous column - 6; E: an earlier H - 8) or lies
 //     below an H of the same lane and column (F), so they neither set a maximum nor equal a new one;
 //   * they feed positions j >= seg only (diagonal and F run towards higher j), except through the two values a lane hands on: its outgoing
 //     F and the H of its last position - both are taken where position seg - 1 is computed (`fout`, `hlast`), not at the end of the loop.
-template <bool BYTE, int NG>
+template <bool BYTE, int NG, int GW>
 __device__ RowPass row_pass_regs(const signed char* refc, int r_begin, int r_end, int r_step, lds_u16 prof, int Q, int seg, int SP, int terminate, int l) {
     constexpr int LW = BYTE ? 16 : 8;
     const int lb = l * SP;
-    unsigned Hr[NG][4], Er[NG][4];
+    static_assert(GW == 8 || GW == 4, "a group is eight positions, or four for the shortest queries");
+    constexpr int GP = GW / 2;                                   // packed pairs of a group
+    unsigned Hr[NG][GP], Er[NG][GP];
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { Hr[g][k] = 0u; Er[g][k] = 0u; }
+        for (int k = 0; k < GP; ++k) { Hr[g][k] = 0u; Er[g][k] = 0u; }
     int best = 0, ref_end = BYTE ? -1 : 0, best_q = 0x7fffffff;
     bool overflow = false;
     int fin = 0, hlast = 0;
     const int D = kGapE * seg;
-    const int gl = (seg - 1) >> 3, rl_ = (seg - 1) & 7;          // the group and the place in it of the stripe's last position
+    const int gl = (seg - 1) / GW, rl_ = (seg - 1) % GW;          // the group and the place in it of the stripe's last position
     const int n_col = (r_end - r_begin) * r_step;
     int rc = n_col > 0 ? refc[r_begin] : 0, rc_next = n_col > 1 ? refc[r_begin + r_step] : 0;
     int col = 0;
@@ -483,38 +485,40 @@ __device__ RowPass row_pass_regs(const signed char* refc, int r_begin, int r_end
         int fg = fin;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            if (8 * g < seg) {
-                const int j0 = 8 * g;
-                const u32x4 p8 = lds_ld16(pr + j0);
-                const unsigned pw[4] = {p8.x, p8.y, p8.z, p8.w};
-                unsigned hw[4] = {Hr[g][0], Hr[g][1], Hr[g][2], Hr[g][3]};
-                const unsigned ew[4] = {Er[g][0], Er[g][1], Er[g][2], Er[g][3]};
+            if (GW * g < seg) {
+                const int j0 = GW * g;
+                unsigned pw[GP], hw[GP], ew[GP];
+                if (GW == 8) {
+                    const u32x4 p8 = lds_ld16(pr + j0);
+                    pw[0] = p8.x; pw[1] = p8.y; pw[GP - 2] = p8.z; pw[GP - 1] = p8.w;
+                } else {
+                    const u32x2 p4 = lds_ld8(pr + j0);
+                    pw[0] = p4.x; pw[1] = p4.y;
+                }
+#pragma unroll
+                for (int k = 0; k < GP; ++k) { hw[k] = Hr[g][k]; ew[k] = Er[g][k]; }
                 const unsigned fg2 = pk2(fg, fg);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) hw[k] = pk_max(hw[k], pk_subs(fg2, pk2(kGapE * 2 * k, kGapE * (2 * k + 1))));
-                fg = max(fg - kGapE * 8, 0);
-                unsigned tp[4], up[4];
+                for (int k = 0; k < GP; ++k) hw[k] = pk_max(hw[k], pk_subs(fg2, pk2(kGapE * 2 * k, kGapE * (2 * k + 1))));
+                fg = max(fg - kGapE * GW, 0);
+                unsigned tp[GP], up[GP];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < GP; ++k) {
                     const unsigned dg = k == 0 ? ((unsigned(h) & 0xffffu) | (hw[0] << 16)) : __builtin_amdgcn_alignbit(hw[k], hw[k - 1], 16);
-                    const unsigned fld = (pw[k] >> shv) & 0x00070007u;
+                    const unsigned fld = (pw[k] >> shv) & 0x000e000eu;
                     unsigned x;
-                    if (BYTE) {
-                        const u16x2 s2 = __builtin_bit_cast(u16x2, dg) + __builtin_bit_cast(u16x2, fld) * (unsigned short)2;
-                        x = pk_subs(__builtin_bit_cast(unsigned, __builtin_elementwise_min(s2, (u16x2){255, 255})), pk2(kBias, kBias));
-                    } else {
-                        const i16x2 sc = __builtin_bit_cast(i16x2, fld) * (short)2 - (short)6;
-                        x = __builtin_bit_cast(unsigned, __builtin_elementwise_add_sat(__builtin_bit_cast(i16x2, dg), sc));
-                    }
+                    const u16x2 s2 = __builtin_bit_cast(u16x2, dg) + __builtin_bit_cast(u16x2, fld);
+                    if (BYTE) x = pk_subs(__builtin_bit_cast(unsigned, __builtin_elementwise_min(s2, (u16x2){255, 255})), pk2(kBias, kBias));
+                    else x = pk_subs(__builtin_bit_cast(unsigned, s2), pk2(kBias, kBias));
                     tp[k] = pk_max(x, ew[k]);
                     up[k] = pk_subs(tp[k], pk2(kGapO, kGapO));
                 }
-                h = int(hw[3] >> 16);
+                h = int(hw[GP - 1] >> 16);
                 unsigned gm2 = 0u;
-                int fb[9];                                     // F in front of position j0 + t (fb[8]: behind the group)
+                int fb[GW + 1];                                // F in front of position j0 + t (fb[GW]: behind the group)
                 fb[0] = f;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < GP; ++k) {
                     fb[2 * k + 1] = max(fb[2 * k] - kGapE, int(up[k] & 0xffffu));
                     fb[2 * k + 2] = max(fb[2 * k + 1] - kGapE, int(up[k] >> 16));
                     const unsigned hh = pk_max(tp[k], pk2(fb[2 * k], fb[2 * k + 1]));
@@ -522,14 +526,14 @@ __device__ RowPass row_pass_regs(const signed char* refc, int r_begin, int r_end
                     Hr[g][k] = hh;
                     gm2 = pk_max(gm2, hh);
                 }
-                f = fb[8];
+                f = fb[GW];
                 const int gm = max(int(gm2 & 0xffffu), int(gm2 >> 16));
                 if (gm > colmax) { colmax = gm; garg = j0; }
                 if (g == gl) {                                 // the stripe ends in this group: what the lane hands on
                     int fo = fb[1];
                     unsigned w = Hr[g][0];
 #pragma unroll
-                    for (int t = 1; t < 8; ++t) if (rl_ == t) { fo = fb[t + 1]; w = Hr[g][t >> 1]; }
+                    for (int t = 1; t < GW; ++t) if (rl_ == t) { fo = fb[t + 1]; w = Hr[g][t >> 1]; }
                     fout = fo;
                     hlast = int((rl_ & 1) ? (w >> 16) : (w & 0xffffu));
                 }
@@ -551,11 +555,17 @@ __device__ RowPass row_pass_regs(const signed char* refc, int r_begin, int r_end
             else if (lane_max == best) {
                 const unsigned bb = pk2(best, best);
                 const int s0 = garg;
-                unsigned sv[4] = {Hr[0][0], Hr[0][1], Hr[0][2], Hr[0][3]};
+                unsigned sv[GP];
 #pragma unroll
-                for (int g = 1; g < NG; ++g) if (s0 == 8 * g) { sv[0] = Hr[g][0]; sv[1] = Hr[g][1]; sv[2] = Hr[g][2]; sv[3] = Hr[g][3]; }
+                for (int k = 0; k < GP; ++k) sv[k] = Hr[0][k];
 #pragma unroll
-                for (int k = 3; k >= 0; --k) {
+                for (int g = 1; g < NG; ++g)
+                    if (s0 == GW * g) {
+#pragma unroll
+                        for (int k = 0; k < GP; ++k) sv[k] = Hr[g][k];
+                    }
+#pragma unroll
+                for (int k = GP - 1; k >= 0; --k) {
                     const unsigned x = sv[k] ^ bb;
                     if (s0 + 2 * k + 1 < seg && (x >> 16) == 0u) mq = l * seg + s0 + 2 * k + 1;
                     if (s0 + 2 * k < seg && (x & 0xffffu) == 0u) mq = l * seg + s0 + 2 * k;
@@ -572,7 +582,7 @@ __device__ RowPass row_pass_regs(const signed char* refc, int r_begin, int r_end
     return RowPass{overflow ? 255 : best, ref_end, read_end, overflow};
 }
 
-template <bool BYTE, int NG>
+template <bool BYTE, int NG, int GW = 8>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NG <= 4 ? 4 : (NG <= 12 ? 3 : 2)))) void k_sw_regs(const signed char* pool, const SwDesc* desc, const int* order, int n, Ends* out,
                                                   unsigned char* overflowed, int segcap) {
     constexpr int LW = BYTE ? 16 : 8;
@@ -586,7 +596,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NG <= 4 ? 4 
     const lds_u16 prof = (lds_u16)(lds + size_t(row) * (size_t(SP) * LW * sizeof(short)));
     if (!live) return;
     // the longest alignments are the end of the stage: their wavefronts go first where a SIMD's wavefronts compete for issue slots
-    __builtin_amdgcn_s_setprio(NG >= 12 ? 3 : (NG >= 8 ? 2 : 1));
+    __builtin_amdgcn_s_setprio(NG >= 12 ? 3 : (NG >= 8 ? 2 : (NG >= 4 ? 1 : 0)));
     const SwDesc d = desc[k];
     const signed char* refc = pool + d.ref_off;
     const signed char* qraw = pool + d.q_off;
@@ -599,12 +609,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NG <= 4 ? 4 
     if (d.R > 0 && d.Q > 0) {
         const int seg = (d.Q + LW - 1) / LW;
         build_profile<LW, true>(prof, qraw, d.Q, seg, SP, l, -1);
-        const RowPass fw = row_pass_regs<BYTE, NG>(refc, 0, d.R, 1, prof, d.Q, seg, SP, BYTE ? 255 : 65535, l);
+        const RowPass fw = row_pass_regs<BYTE, NG, GW>(refc, 0, d.R, 1, prof, d.Q, seg, SP, BYTE ? 255 : 65535, l);
         if (BYTE && fw.overflow) ovf = true;
         else if (fw.score > 0) {
             const int Q2 = fw.read_end + 1, seg2 = (Q2 + LW - 1) / LW;
             build_profile<LW, true>(prof, qraw, Q2, seg2, SP, l, fw.read_end);
-            const RowPass bw = row_pass_regs<BYTE, NG>(refc, fw.ref_end, -1, -1, prof, Q2, seg2, SP, fw.score, l);
+            const RowPass bw = row_pass_regs<BYTE, NG, GW>(refc, fw.ref_end, -1, -1, prof, Q2, seg2, SP, fw.score, l);
             e = Ends{fw.score, fw.ref_end, fw.read_end, bw.ref_end, bw.read_end, LW};
         }
     }
@@ -1053,10 +1063,14 @@ int launch_sw(hipStream_t s, const signed char* pool, const SwDesc* desc, const 
     }
     // stripes of 17 .. 128 positions: the register form (row_pass_regs) - the LDS holds the profile only
     static const bool regs_on = !(std::getenv("CTO_SW_REGS") && atoi(std::getenv("CTO_SW_REGS")) == 0);
-    if (regs_on && segcap > 16 && segcap <= 128 && ROWS == 64 / LW) {
+    static const int regs_min = std::getenv("CTO_SW_REGS_MIN") ? atoi(std::getenv("CTO_SW_REGS_MIN")) : 0;
+    if (regs_on && segcap > regs_min && segcap <= 128 && ROWS == 64 / LW) {
         const size_t pm = size_t(sw_sp(segcap)) * LW * sizeof(short) * ROWS;
         const dim3 grid(unsigned((n + ROWS - 1) / ROWS)), block(unsigned(LW * ROWS));
-        if (segcap <= 32) hipLaunchKernelGGL((k_sw_regs<BYTE, 4>), grid, block, pm, s, pool, desc, order, n, out, overflowed, segcap);
+        if (segcap <= 4) hipLaunchKernelGGL((k_sw_regs<BYTE, 1, 4>), grid, block, pm, s, pool, desc, order, n, out, overflowed, segcap);
+        else if (segcap <= 8) hipLaunchKernelGGL((k_sw_regs<BYTE, 1>), grid, block, pm, s, pool, desc, order, n, out, overflowed, segcap);
+        else if (segcap <= 16) hipLaunchKernelGGL((k_sw_regs<BYTE, 2>), grid, block, pm, s, pool, desc, order, n, out, overflowed, segcap);
+        else if (segcap <= 32) hipLaunchKernelGGL((k_sw_regs<BYTE, 4>), grid, block, pm, s, pool, desc, order, n, out, overflowed, segcap);
         else if (segcap <= 64) hipLaunchKernelGGL((k_sw_regs<BYTE, 8>), grid, block, pm, s, pool, desc, order, n, out, overflowed, segcap);
         else if (segcap <= 96) hipLaunchKernelGGL((k_sw_regs<BYTE, 12>), grid, block, pm, s, pool, desc, order, n, out, overflowed, segcap);
         else hipLaunchKernelGGL((k_sw_regs<BYTE, 16>), grid, block, pm, s, pool, desc, order, n, out, overflowed, segcap);
