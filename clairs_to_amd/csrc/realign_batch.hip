@@ -1097,7 +1097,13 @@ struct SideStreams {
     int get(int i, hipStream_t* out) {
         if (i >= kMax) return CTO_EINVAL;
         while (n <= i) {
-            if (hipStreamCreateWithFlags(&sx[n], hipStreamNonBlocking) != hipSuccess) return CTO_EHIP;
+            // at the device's highest priority: the runtime keeps a pool of hardware queues PER PRIORITY and hands a new stream the least used
+            // queue of its pool - beside a process's ordinary streams (torch's, the pipeline's) two of these could land on one queue and their
+            // classes would run one after the other (bench.py's process: 7.2 ms for the stage the stand-alone tool runs in 5.6); a pool of their own
+            // gives the four of them a queue each
+            int lo = 0, hi = 0;
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+            if (hipStreamCreateWithPriority(&sx[n], hipStreamNonBlocking, hi) != hipSuccess) return CTO_EHIP;
             if (hipEventCreateWithFlags(&join[n], hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(sx[n]); return CTO_EHIP; }
             ++n;
         }
