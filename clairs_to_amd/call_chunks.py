@@ -333,7 +333,12 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
             cfg.aff2, cfg.neg2 = eng.aff._handle2(), eng.neg._handle2()
     st = RunStats()
     with torch.cuda.device(eng.device):
-        main = torch.cuda.Stream(eng.device)
+        # BAM input: the compute stream at high priority - the networks' launches then go ahead of the inflate / pile-up kernels that share
+        # the chip with them (BAM -> VCF 0.72-0.73 -> 0.74-0.76 M sites/s, with extraction 0.57 -> 0.61; text input: no inflate kernels to
+        # overtake, 1.99-2.02 -> 1.91-1.97 M, so text keeps an ordinary stream).  CTO_MAIN_PRIORITY=0|1 decides by hand.
+        from_bam = any(getattr(a, "mpileup_fn", None) is None for a in chunk_args)
+        want = os.environ.get("CTO_MAIN_PRIORITY")
+        main = torch.cuda.Stream(eng.device, priority=-1 if (want == "1" or (want is None and from_bam)) else 0)
         main.wait_stream(torch.cuda.current_stream())
         rc = lib.cto_run_chunks(C.byref(cfg), jobs, len(chunk_args), C.c_void_p(main.cuda_stream), C.byref(st))
         main.synchronize()
