@@ -172,6 +172,41 @@ def test_device_alignments_on_adversarial_pairs(dev):
     assert gapped > 3000 and sum(1 for c in dc if c == "") >= 2
 
 
+def test_device_sw_register_form_at_its_boundaries_and_known_overflows(dev):
+    """The register form of the passes (csrc/realign_batch.hip: row_pass_regs - NG groups of eight stripe positions per lane, the
+    positions behind a stripe's end computed and inert) at every boundary it has: query lengths around 8 / 16 lanes x 4, 8, 16, 32, 64,
+    96 and 128 positions (one below, at, one above: the last group exactly full, one position in the next group, the class changes),
+    long and short references; and the 8-bit pass's early exit (sure_overflow16): operands that share their first or their last 64
+    bases and nothing else, 62 / 63 shared bases (no exit: the pass itself decides), an N among the 64 - against the SSE2 host form."""
+    from clairs_to_amd.realign_reads import sw_ends_batch
+    rng = np.random.default_rng(int.from_bytes(os.urandom(4), "little"))
+    pairs = []
+    for lanes in (8, 16):
+        for seg in (4, 8, 16, 32, 64, 96, 128):
+            for dq in (-1, 0, 1, 7):
+                Q = lanes * seg + dq
+                if Q > 2040:
+                    continue
+                for R in (Q // 2 + 3, Q + 40):
+                    ref = rng.integers(0, 4, R).astype(np.int8)
+                    q = np.concatenate([ref[: min(R, Q) // 2], rng.integers(0, 4, Q - min(R, Q) // 2).astype(np.int8)])       # half a match, half noise
+                    pairs.append((ref, q))
+                    q2 = np.tile(np.array([0, 1], dtype=np.int8), Q // 2 + 1)[:Q].copy()                                     # ties in every cell
+                    pairs.append((np.tile(np.array([0, 1], dtype=np.int8), R // 2 + 1)[:R].copy(), q2))
+    for n_same in (62, 63, 64, 65, 200):
+        for at_end in (False, True):
+            for with_n in (False, True):
+                a = rng.integers(0, 4, n_same).astype(np.int8)
+                if with_n:
+                    a[n_same // 2] = 4
+                x, y = rng.integers(0, 4, int(rng.integers(80, 400))).astype(np.int8), rng.integers(0, 4, int(rng.integers(80, 400))).astype(np.int8)
+                pairs.append((np.concatenate([x, a]), np.concatenate([y, a])) if at_end else (np.concatenate([a, x]), np.concatenate([a, y])))
+    d, h = sw_ends_batch(pairs, "device"), sw_ends_batch(pairs, "host", threads=16)
+    bad = np.nonzero((d != h).any(axis=1))[0]
+    assert bad.size == 0, "pair %d: device %s host %s" % (bad[0], d[bad[0]], h[bad[0]])
+    assert int((d[:, 5] == 8).sum()) > 40 and int((d[:, 5] == 16).sum()) > 40          # both the 16-bit and the 8-bit results are in the set
+
+
 def test_device_sw_on_thousands_of_longest_queries(dev):
     """a class of more than 4 096 alignments whose queries are as long as the device form takes (2 048 bases): eight 8-lane rows of
     them do not fit the LDS of a workgroup - the launch must share it among fewer rows, not refuse the call"""
