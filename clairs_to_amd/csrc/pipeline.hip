@@ -1319,6 +1319,21 @@ static int run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs, int64_t
     const double t_begin = now_s();
     std::atomic<int> producers_left{producers};
 
+    // CTO_COPY_STREAMS=n: the producers share n copy streams instead of owning one each (default 0: one each).  Measured at the end of
+    // round 6 with n = 2: text -> VCF of 4 096-site chunks 2.01 -> 2.09 M sites/s (the copies of six producers arrive one after the other
+    // instead of all late), but 10 000-site chunks 1.93 -> 1.32 M, BAM with every chunk on the device 0.57 -> 0.48 M and REGION jobs 0.56 ->
+    // 0.50 M (a producer's kernels and waits queue behind another producer's): not the default.
+    static const int shared_n = [] { const char* e = getenv("CTO_COPY_STREAMS"); return e ? atoi(e) : 0; }();
+    struct CopyStreams {                     // (declared before the threads: destroyed after they are joined)
+        std::vector<hipStream_t> v;
+        ~CopyStreams() { for (hipStream_t c : v) { (void)hipStreamSynchronize(c); (void)hipStreamDestroy(c); } }
+    } copy_streams;
+    for (int i = 0; i < shared_n; ++i) {
+        hipStream_t c = nullptr;
+        CTO_HIP(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+        copy_streams.v.push_back(c);
+    }
+    const std::vector<hipStream_t>& shared_copy = copy_streams.v;
     std::vector<std::thread> threads;
     threads.reserve(size_t(producers + writers));
     struct JoinAll {                         // whatever happens below, a started thread is joined (queues closed first: they all wake up)
@@ -1342,10 +1357,12 @@ static int run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs, int64_t
         }
     };
     for (int t = 0; t < producers; ++t)
-        if (!start([&run, &producers_left, dev] {
+        if (!start([&run, &producers_left, dev, t, &shared_copy] {
             hipStream_t copy = nullptr;
+            const bool shared = !shared_copy.empty();
             tl_pack_threads = run.cfg->pack_threads;                 // the tokeniser's / BAM decoder's own threads per call
-            if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) != hipSuccess) run.fail("producer: no HIP stream");
+            if (shared) { (void)hipSetDevice(dev); copy = shared_copy[size_t(t) % shared_copy.size()]; }
+            else if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) != hipSuccess) run.fail("producer: no HIP stream");
             for (;;) {
                 if (run.failed) break;
                 const int64_t j = run.next_job.fetch_add(1);
@@ -1368,7 +1385,7 @@ static int run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs, int64_t
                 if (ok) run.to_launch.push(s);
                 else run.free_slots.push(s);                         // nothing to call here (or an error: `failed` is set)
             }
-            if (copy) { (void)hipStreamSynchronize(copy); (void)hipStreamDestroy(copy); }
+            if (copy) { (void)hipStreamSynchronize(copy); if (!shared) (void)hipStreamDestroy(copy); }
             if (--producers_left == 0) run.to_launch.close();
         })) {
             if (--producers_left == 0) run.to_launch.close();        // this one never ran
