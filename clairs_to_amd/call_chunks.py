@@ -333,12 +333,12 @@ def run_pipeline_native(eng, chunk_args, producers=4, writers=2, depth=None, sta
             cfg.aff2, cfg.neg2 = eng.aff._handle2(), eng.neg._handle2()
     st = RunStats()
     with torch.cuda.device(eng.device):
-        # BAM input: the compute stream at high priority - the networks' launches then go ahead of the inflate / pile-up kernels that share
-        # the chip with them (BAM -> VCF 0.72-0.73 -> 0.74-0.76 M sites/s, with extraction 0.57 -> 0.61; text input: no inflate kernels to
-        # overtake, 1.99-2.02 -> 1.91-1.97 M, so text keeps an ordinary stream).  CTO_MAIN_PRIORITY=0|1 decides by hand.
-        from_bam = any(getattr(a, "mpileup_fn", None) is None for a in chunk_args)
-        want = os.environ.get("CTO_MAIN_PRIORITY")
-        main = torch.cuda.Stream(eng.device, priority=-1 if (want == "1" or (want is None and from_bam)) else 0)
+        # CTO_MAIN_PRIORITY=1: the compute stream at high priority.  Measured at the end of round 6: with BAM input the networks' launches then
+        # go ahead of the inflate / pile-up kernels they share the chip with (BAM -> VCF 0.72-0.73 -> 0.74-0.78 M sites/s, REGION jobs 0.57 ->
+        # 0.61 M) - but torch creates its whole pool of high-priority streams with the first one, their hardware queues stay for the life of
+        # the process, and beside the CU-masked inflate streams' queues that is more queues than the chip keeps resident: runs that follow in
+        # the same process lose (10 000-site text chunks 1.95 -> 1.31 M, all-device BAM on two cores 0.55 -> 0.48 M).  Not the default.
+        main = torch.cuda.Stream(eng.device, priority=-1 if os.environ.get("CTO_MAIN_PRIORITY") == "1" else 0)
         main.wait_stream(torch.cuda.current_stream())
         rc = lib.cto_run_chunks(C.byref(cfg), jobs, len(chunk_args), C.c_void_p(main.cuda_stream), C.byref(st))
         main.synchronize()
