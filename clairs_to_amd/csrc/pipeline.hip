@@ -1319,11 +1319,13 @@ static int run_chunks(const cto_run_cfg* cfg, const cto_chunk_job* jobs, int64_t
     const double t_begin = now_s();
     std::atomic<int> producers_left{producers};
 
-    // CTO_COPY_STREAMS=n: the producers share n copy streams instead of owning one each (default 0: one each).  Measured at the end of
-    // round 6 with n = 2: text -> VCF of 4 096-site chunks 2.01 -> 2.09 M sites/s (the copies of six producers arrive one after the other
-    // instead of all late), but 10 000-site chunks 1.93 -> 1.32 M, BAM with every chunk on the device 0.57 -> 0.48 M and REGION jobs 0.56 ->
-    // 0.50 M (a producer's kernels and waits queue behind another producer's): not the default.
-    static const int shared_n = [] { const char* e = getenv("CTO_COPY_STREAMS"); return e ? atoi(e) : 0; }();
+    // The producers share TWO copy streams (CTO_COPY_STREAMS=n; 0: a stream each, as until the end of round 6).  The runtime maps a process's
+    // streams onto four hardware queues; with a stream per producer the stream the networks run on shares its queue with one or two copy
+    // streams, whose waits (a copy's completion) then stand in front of the networks' launches.  Two interleaved A/B runs of every file-to-file
+    // leg: text -> VCF 1.97-1.98 -> 2.04-2.06 M sites/s, with the device tokeniser 1.85 -> 1.93-1.96 M, all-device BAM on two cores 0.56-0.58
+    // -> 0.59-0.60 M, BAM -> VCF, REGION jobs and 10 000-site chunks unchanged.  A producer only queues on its stream and waits on its own
+    // events, so what another producer queues in between costs it little.
+    static const int shared_n = [] { const char* e = getenv("CTO_COPY_STREAMS"); return e ? atoi(e) : 2; }();
     struct CopyStreams {                     // (declared before the threads: destroyed after they are joined)
         std::vector<hipStream_t> v;
         ~CopyStreams() { for (hipStream_t c : v) { (void)hipStreamSynchronize(c); (void)hipStreamDestroy(c); } }
