@@ -1324,6 +1324,23 @@ struct TbDesc { int ref_off, q_off, R, Q, score, band, band_cap, pad; long long 
 struct TbOut { int status, n_runs, band; int runs[TB_RUNS]; };          // status 1 = done, 0 = the reference's traceback fails, 2 = not done here
 constexpr int TB_NEG = -(1 << 28);
 
+// wavefront-wide steps of a traceback row as DPP operations (a few clocks each; as ds_bpermute shuffles they were a chain of ~100-clock LDS
+// crossbar trips, and a row of k_banded is nothing but that chain: 2.8 of the stage's 3.2 ms)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_keep(int identity, int v) { return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false); }
+// inclusive max-scan over the 64 lanes: row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast:15 / :31 carry a row's total into the rows above
+__device__ __forceinline__ int wave_scan_max(int v, int identity) {
+    v = max(v, dpp_keep<0x111, 0xf>(identity, v));
+    v = max(v, dpp_keep<0x112, 0xf>(identity, v));
+    v = max(v, dpp_keep<0x114, 0xf>(identity, v));
+    v = max(v, dpp_keep<0x118, 0xf>(identity, v));
+    v = max(v, dpp_keep<0x142, 0xa>(identity, v));          // row_bcast:15 into rows 1 and 3
+    v = max(v, dpp_keep<0x143, 0xc>(identity, v));          // row_bcast:31 into rows 2 and 3
+    return v;
+}
+// lane l takes lane l - 1, lane 0 takes `fill` (wave_shr:1)
+__device__ __forceinline__ int wave_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+
 __global__ __launch_bounds__(64) void k_banded(const signed char* __restrict__ pool, const TbDesc* __restrict__ desc, const int* __restrict__ order,
                                                 int n, unsigned char* dirbuf, TbOut* __restrict__ out, int W) {
     extern __shared__ int tb_lds[];
@@ -1339,20 +1356,33 @@ __global__ __launch_bounds__(64) void k_banded(const signed char* __restrict__ p
     int* hc = tb_lds + 2 * W;
     const int R = d.R, Q = d.Q;
     for (int i = lane; i < 3 * W; i += 64) tb_lds[i] = 0;
+    // The workgroup is ONE wavefront: its LDS operations execute in order, so a row's steps need no s_barrier - and must not have
+    // __syncthreads()'s fence, which also drains the row's direction bytes on their way to HBM (a microsecond per row, twice).
+    auto lds_sync = [] { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
     int band = d.band, best = 0, status = 1, width_d = 0;
     for (;;) {
         const int width = band * 2 + 3;
         width_d = band * 2 + 1;
-        __syncthreads();
+        lds_sync();
         for (int j = 1 + lane; j < width - 1; j += 64) hb[j] = 0;
+        // operands one step ahead of their use: the read's base of the next row, the reference bases of the next row's first 64 cells
+        // and of the next chunk of this row - a row is a chain of LDS steps, and a load from HBM in it costs more than the rest
+        int ri_next = Q > 0 ? read[0] : 0;
+        int rj_row = (lane <= min(R - 1, band)) ? ref[lane] : 0;          // row 0: x = 0, cells 0 .. min(R - 1, band)
         for (int i = 0; i < Q; ++i) {
             const int x = max(0, i - band), dx = x - max(0, i - 1 - band);
             const int end = min(R - 1, i + band), nc = end - x + 1;             // cells of this row: j = x .. end
             const int edge = min(end + 1, width - 1);
-            __syncthreads();
+            lds_sync();
             if (lane == 0) { hb[0] = 0; eb[0] = 0; hb[edge] = 0; eb[edge] = 0; hc[0] = 0; }
-            __syncthreads();
-            const int ri = read[i];
+            lds_sync();
+            const int ri = ri_next;
+            int rj_cur = rj_row;
+            if (i + 1 < Q) {
+                ri_next = read[i + 1];
+                const int xn = max(0, i + 1 - band), endn = min(R - 1, i + 1 + band);
+                rj_row = (xn + lane <= endn) ? ref[xn + lane] : 0;
+            }
             int carry = kGapE * x - 4;                       // the F chain that enters the row: f = 0 before the first cell, h[-1] = 0
             int g_prev = -kGapO, f_prev = 0;
             unsigned char* line = dir + size_t(i) * size_t(width_d);
@@ -1364,29 +1394,26 @@ __global__ __launch_bounds__(64) void k_banded(const signed char* __restrict__ p
                 const int t1 = i == 0 ? -kGapO : hbu - kGapO, t2 = i == 0 ? -kGapE : ebu - kGapE;
                 const int e = max(t1, t2);
                 const bool de3 = t1 > t2;
-                const int rj = valid ? ref[j] : 0;
+                const int rj = valid ? rj_cur : 0;
+                if (c0 + 64 < width_d) rj_cur = (jj + 64 < nc) ? ref[j + 64] : 0;          // the next chunk's
                 const int sc = (rj == ri && rj < 4) ? 4 : -6;
                 const int t2h = hbd + sc, e1 = max(e, 0), hp = max(e1, t2h), g = hp - kGapO;
                 int incl = valid ? g + kGapE * j : TB_NEG;
                 const int span = min(64, width_d - c0);            // lanes of this chunk that can hold a cell: most bands are a few cells wide
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1)
-                    if (o < span) { const int t = __shfl_up(incl, o); if (lane >= o) incl = max(incl, t); }
-                int excl = __shfl_up(incl, 1);
-                if (lane == 0) excl = TB_NEG;
+                incl = wave_scan_max(incl, TB_NEG);                // (lanes behind the row's cells hold TB_NEG: the scan may run over all 64)
+                const int excl = wave_shr1(incl, TB_NEG);
                 const int f = max(carry, excl) - kGapE * (j - 1);
-                int gp = __shfl_up(g, 1), fp = __shfl_up(f, 1);
-                if (lane == 0) { gp = g_prev; fp = f_prev; }
+                const int gp = wave_shr1(g, g_prev), fp = wave_shr1(f, f_prev);
                 const bool df5 = gp > fp - kGapE;
                 const int f1 = max(f, 0), tt1 = max(e1, f1), h = max(tt1, t2h);
                 const int dh = tt1 <= t2h ? 1 : (e1 > f1 ? (de3 ? 3 : 2) : (df5 ? 5 : 4));
                 if (valid) { eb[u] = e; hc[u] = h; best = max(best, h); }
                 if (jj < width_d) line[jj] = valid ? static_cast<unsigned char>(int(de3) | (int(df5) << 1) | (dh << 2)) : static_cast<unsigned char>(0);
-                carry = max(carry, __shfl(incl, span - 1));
-                g_prev = __shfl(g, 63); f_prev = __shfl(f, 63);
+                carry = max(carry, __builtin_amdgcn_readlane(incl, __builtin_amdgcn_readfirstlane(span - 1)));
+                g_prev = __builtin_amdgcn_readlane(g, 63); f_prev = __builtin_amdgcn_readlane(f, 63);
             }
-            __syncthreads();
-            for (int u = 1 + lane; u <= nc; u += 64) hb[u] = hc[u];
+            { int* t = hb; hb = hc; hc = t; }              // the row just written is the next row's "row above" (no copy: the two cells
+                                                           // a row reads outside what the last one wrote - [0] and [edge] - it zeroes first)
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
