@@ -88,11 +88,16 @@ struct FpArgs {
 };
 
 __global__ __launch_bounds__(FP_NT) void k_fast_pass(FpArgs a) {
-    __shared__ unsigned char s_hap[FP_LMAX], s_seed[FP_LMAX], s_read[FP_RMAX];
+    __shared__ __attribute__((aligned(16))) unsigned char s_hap[FP_LMAX + 16], s_read[FP_RMAX];      // (+16: the block test reads whole dwords)
+    __shared__ unsigned char s_seed[FP_LMAX];
     __shared__ int s_cov[FP_LMAX];
     __shared__ unsigned long long s_best;
     __shared__ unsigned s_neg, s_d0_visit;
     __shared__ int s_d0_mism, s_dropped;
+    // diagonals with a k-mer hit in sight are not walked by the thread that found them - one thread walking 150 positions and marking
+    // 150 covered positions while 255 wait - but listed, and every listed diagonal is walked by a wavefront
+    constexpr int FP_CAND = 64;
+    __shared__ int s_cand[FP_CAND], s_ncand;
     const int h = blockIdx.x, tid = threadIdx.x;
     const int h0 = a.hap_off[h], L = a.hap_off[h + 1] - h0, w = a.hap_win[h];
     const int r0 = a.win_read0[w], n = a.win_read0[w + 1] - r0;
@@ -107,6 +112,13 @@ __global__ __launch_bounds__(FP_NT) void k_fast_pass(FpArgs a) {
         atomicMax(&s_best, key);
         for (int p = start; p < start + span; ++p) atomicMin(&s_cov[p], t);
     };
+    auto emit_all = [&](int start, int span, int mism, int t, int o) {            // the same, called by every thread of the workgroup
+        const int sc = (span - mism) * 4 - mism * 6;
+        const unsigned long long key = (static_cast<unsigned long long>(sc) << 32) | (static_cast<unsigned long long>(0xffff - t) << 16) |
+                                       static_cast<unsigned long long>(0xffff - o);
+        if (tid == 0) atomicMax(&s_best, key);
+        for (int p = start + tid; p < start + span; p += FP_NT) atomicMin(&s_cov[p], t);
+    };
     for (int r = 0; r < n; ++r) {
         const int q0 = a.read_off[r0 + r], span = a.read_off[r0 + r + 1] - q0;
         __syncthreads();                  // the previous read's result has been taken
@@ -115,7 +127,7 @@ __global__ __launch_bounds__(FP_NT) void k_fast_pass(FpArgs a) {
             continue;
         }
         for (int i = tid; i < span; i += FP_NT) s_read[i] = a.read_bytes[q0 + i];
-        if (tid == 0) { s_best = 0ull; s_neg = 0xffffffffu; s_d0_visit = 0xffffffffu; s_d0_mism = 99; }
+        if (tid == 0) { s_best = 0ull; s_neg = 0xffffffffu; s_d0_visit = 0xffffffffu; s_d0_mism = 99; s_ncand = 0; }
         __syncthreads();
         const int dmin = -(span - kKmer), dmax = L - kKmer;
         for (int d = dmin + tid; d <= dmax; d += FP_NT) {
@@ -126,12 +138,23 @@ __global__ __launch_bounds__(FP_NT) void k_fast_pass(FpArgs a) {
             // has no k-mer hit: nothing to mark, nothing to emit - and only diagonal 0 needs its mismatch count without a hit of its
             // own (the clipped diagonals may supply one).  A block of unrelated sequence fails after 1.3 compares on average.
             bool maybe = d == 0;
+            // (sixteen bytes a side in one LDS round trip: the read's block is one aligned 16-byte read - the same address in every lane -,
+            // the haplotype's the five dwords around it shifted into place; byte by byte a block cost ~3.5 dependent round trips, the
+            // longest lane's)
             for (int qb = (q_lo + 15) & ~15; qb + 16 <= q_hi && !maybe; qb += 16) {
-                int k = 0;
-                while (k < 16 && s_hap[qb + k + d] == s_read[qb + k]) ++k;
-                maybe = k == 16;
+                const int at = qb + d, sh = at & 3;
+                const unsigned* hp = reinterpret_cast<const unsigned*>(s_hap + (at & ~3));
+                const unsigned w0 = hp[0], w1 = hp[1], w2 = hp[2], w3 = hp[3], w4 = hp[4];
+                const uint4 rb = *reinterpret_cast<const uint4*>(s_read + qb);
+                const unsigned diff = (__builtin_amdgcn_alignbyte(w1, w0, sh) ^ rb.x) | (__builtin_amdgcn_alignbyte(w2, w1, sh) ^ rb.y) |
+                                      (__builtin_amdgcn_alignbyte(w3, w2, sh) ^ rb.z) | (__builtin_amdgcn_alignbyte(w4, w3, sh) ^ rb.w);
+                maybe = diff == 0u;
             }
             if (!maybe) continue;
+            {
+                const int slot = atomicAdd(&s_ncand, 1);
+                if (slot < FP_CAND) { s_cand[slot] = d; continue; }               // (a full list: this thread walks its diagonal itself)
+            }
             for (int q = q_lo; q < q_hi; ++q) {
                 const unsigned char x = s_hap[q + d], y = s_read[q];
                 const bool eq = x == y;
@@ -148,9 +171,62 @@ __global__ __launch_bounds__(FP_NT) void k_fast_pass(FpArgs a) {
             else if (first >= 0) atomicMin(&s_neg, visit);
         }
         __syncthreads();
-        if (tid == 0) {                   // start 0: k-mer hits of diagonal 0 and of every clipped diagonal
+        const int n_cand = min(s_ncand, FP_CAND);
+        // a wavefront per listed diagonal (no workgroup barrier inside: everything a diagonal contributes goes through atomics that
+        // commute - s_best, s_cov, s_neg - or belongs to diagonal 0 alone).  64 positions a step: the equality bits are a ballot, a
+        // run of 32 that starts at bit p is p of M & M>>1 & ... folded five times over two steps' masks - scalar arithmetic.
+        for (int c = tid >> 6; c < n_cand; c += FP_NT / 64) {
+            const int lane = tid & 63;
+            const int d = s_cand[c];
+            const int q_lo = d < 0 ? -d : 0, q_hi = min(span, L - d);
+            const bool full = d >= 0 && d + span <= L;
+            int first = -1, mism = 0;
+            unsigned long long cur = 0ull;                      // equality bits of positions [qs, qs + 64)
+            {
+                const int q = lane;
+                const bool in = q >= q_lo && q < q_hi;
+                const unsigned char x = in ? s_hap[q + d] : 0, y = in ? s_read[q] : 1;
+                cur = __ballot(in && x == y);
+                mism += __popcll(__ballot(in && x != y && x != 'N' && y != 'N'));
+            }
+            for (int qs = 0; qs < q_hi; qs += 64) {
+                unsigned long long nxt = 0ull;
+                {
+                    const int q = qs + 64 + lane;
+                    const bool in = q >= q_lo && q < q_hi;
+                    const unsigned char x = in ? s_hap[q + d] : 0, y = in ? s_read[q] : 1;
+                    nxt = __ballot(in && x == y);
+                    mism += __popcll(__ballot(in && x != y && x != 'N' && y != 'N'));
+                }
+                // starts p in [0, 64) of a run of 32 set bits in the 128 bits (nxt : cur)
+                unsigned long long lo = cur, hi = nxt;
+#pragma unroll
+                for (int k = 1; k < 32; k <<= 1) {
+                    const unsigned long long slo = (lo >> k) | (hi << (64 - k)), shi = hi >> k;
+                    lo &= slo; hi &= shi;
+                }
+                if (lo) {
+                    if (first < 0) first = qs + __builtin_ctzll(lo);
+                    if ((lo >> lane) & 1ull) s_seed[qs + lane + d] = 1;
+                }
+                cur = nxt;
+            }
+            const unsigned visit = first >= 0 ? (static_cast<unsigned>(first + d) << 16) | static_cast<unsigned>(first) : 0xffffffffu;
+            auto emit_wave = [&](int start, int t, int o) {
+                const int sc = (span - mism) * 4 - mism * 6;
+                const unsigned long long key = (static_cast<unsigned long long>(sc) << 32) | (static_cast<unsigned long long>(0xffff - t) << 16) |
+                                               static_cast<unsigned long long>(0xffff - o);
+                if (lane == 0) atomicMax(&s_best, key);
+                for (int p = start + lane; p < start + span; p += 64) atomicMin(&s_cov[p], t);
+            };
+            if (d == 0) { if (lane == 0) { s_d0_mism = full ? mism : 99; s_d0_visit = visit; } }
+            else if (d > 0) { if (first >= 0 && full && mism <= kMaxMism) emit_wave(d, first + d, first); }
+            else if (first >= 0 && lane == 0) atomicMin(&s_neg, visit);
+        }
+        __syncthreads();
+        {                                 // start 0: k-mer hits of diagonal 0 and of every clipped diagonal
             const unsigned visit = min(s_d0_visit, s_neg);
-            if (visit != 0xffffffffu && s_d0_mism <= kMaxMism) emit(0, span, s_d0_mism, int(visit >> 16), int(visit & 0xffffu));
+            if (visit != 0xffffffffu && s_d0_mism <= kMaxMism) emit_all(0, span, s_d0_mism, int(visit >> 16), int(visit & 0xffffu));
         }
         __syncthreads();
         if (tid == 0) {
